@@ -1,0 +1,609 @@
+"""ctypes front-end of the CPU ORACLE (test infrastructure -- see the header of elag_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+PARITY UNPINNED at kernel granularity (hypre/MFEM absent; see elag_oracle.c header and DESIGN.md).
+
+The ParCSR-level routines compose the C kernels exactly where the reference places the halo
+exchange (src/hypreExtension/hypre_ParCSRMatrixMatvecBoolInt.c:148-201, :212-345); the exchange
+itself is a pluggable object so the same code runs serially, with all ranks in one process, or
+across processes (torch.distributed/gloo in tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import scipy.sparse as sp
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_c_int_p = C.POINTER(C.c_int)
+_c_dbl_p = C.POINTER(C.c_double)
+
+
+def build(native: bool = False) -> str:
+    out = "libelag_oracle_native.so" if native else "libelag_oracle.so"
+    path = os.path.join(_DIR, out)
+    src = os.path.join(_DIR, "elag_oracle.c")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        args = ["make", "-C", _DIR, f"OUT={out}"]
+        if native:
+            args.append("ARCH=-march=native")
+        subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return path
+
+
+_libs = {}
+
+
+def lib(native: bool = False):
+    if native not in _libs:
+        L = C.CDLL(build(native))
+        L.orc_csr_max_norm.restype = C.c_double
+        L.orc_csr_frobenius_norm.restype = C.c_double
+        L.orc_hier_create.restype = C.c_void_p
+        _libs[native] = L
+    return _libs[native]
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(_c_int_p)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(_c_dbl_p)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def csr(A) -> sp.csr_matrix:
+    """Canonical oracle CSR: int32 indices, fp64 values, storage order preserved."""
+    A = sp.csr_matrix(A)
+    A.indptr = _i32(A.indptr); A.indices = _i32(A.indices); A.data = _f64(A.data)
+    return A
+
+
+def raw_csr(n_rows, n_cols, I, J, a) -> sp.csr_matrix:
+    M = sp.csr_matrix((n_rows, n_cols))
+    M.indptr, M.indices, M.data = _i32(I), _i32(J), _f64(a)
+    return M
+
+
+def diag_first(A: sp.csr_matrix) -> sp.csr_matrix:
+    """Reorder each row of a square CSR so that the diagonal entry is stored first (hypre / MFEM
+    convention for square ParCSR diag blocks)."""
+    A = csr(A).copy()
+    I, J, a = A.indptr, A.indices, A.data
+    for i in range(A.shape[0]):
+        s, e = I[i], I[i + 1]
+        k = np.nonzero(J[s:e] == i)[0]
+        if len(k) and k[0] != 0:
+            k = s + k[0]
+            J[s + 1:k + 1], J[s] = J[s:k].copy(), i
+            v = a[k]
+            a[s + 1:k + 1] = a[s:k].copy(); a[s] = v
+    return A
+
+
+# ---- CSR kernels --------------------------------------------------------------------------------
+
+def csr_matvec(A, alpha, x, beta, y):
+    lib().orc_csr_matvec(C.c_int(A.shape[0]), _ip(A.indptr), _ip(A.indices), _dp(A.data),
+                         C.c_double(alpha), _dp(x), C.c_double(beta), _dp(y))
+
+
+def csr_matvecT(A, alpha, x, beta, y):
+    lib().orc_csr_matvecT(C.c_int(A.shape[0]), C.c_int(A.shape[1]), _ip(A.indptr), _ip(A.indices),
+                          _dp(A.data), C.c_double(alpha), _dp(x), C.c_double(beta), _dp(y))
+
+
+def csr_matvec_boolint(A, alpha, x, beta, y):
+    lib().orc_csr_matvec_boolint(C.c_int(A.shape[0]), _ip(A.indptr), _ip(A.indices), C.c_int(alpha),
+                                 _ip(x), C.c_int(beta), _ip(y))
+
+
+def transpose(A) -> sp.csr_matrix:
+    A = csr(A)
+    n, m = A.shape
+    TI = np.empty(m + 1, np.int32); TJ = np.empty(A.nnz, np.int32); Ta = np.empty(A.nnz)
+    lib().orc_csr_transpose(C.c_int(n), C.c_int(m), _ip(A.indptr), _ip(A.indices), _dp(A.data),
+                            _ip(TI), _ip(TJ), _dp(Ta))
+    return raw_csr(m, n, TI, TJ, Ta)
+
+
+def matmul(A, B) -> sp.csr_matrix:
+    A, B = csr(A), csr(B)
+    n = A.shape[0]
+    CI = np.empty(n + 1, np.int32)
+    nnz = lib().orc_csr_matmul_count(C.c_int(n), C.c_int(B.shape[1]), _ip(A.indptr), _ip(A.indices),
+                                     _ip(B.indptr), _ip(B.indices), _ip(CI))
+    CJ = np.empty(nnz, np.int32); Ca = np.empty(nnz)
+    lib().orc_csr_matmul_fill(C.c_int(n), C.c_int(B.shape[1]), _ip(A.indptr), _ip(A.indices), _dp(A.data),
+                              _ip(B.indptr), _ip(B.indices), _dp(B.data), _ip(CI), _ip(CJ), _dp(Ca))
+    return raw_csr(n, B.shape[1], CI, CJ, Ca)
+
+
+def rap(RT, A, P) -> sp.csr_matrix:
+    """hypre_BoomerAMGBuildCoarseOperator(RT, A, P) on one rank (diag blocks)."""
+    RT, A, P = csr(RT), csr(A), csr(P)
+    R = transpose(RT)
+    ncr, ncc, nf = RT.shape[1], P.shape[1], A.shape[0]
+    sq = int(ncr == ncc)
+    CI = np.empty(ncr + 1, np.int32)
+    args = (C.c_int(ncr), C.c_int(nf), C.c_int(ncc), C.c_int(sq), _ip(R.indptr), _ip(R.indices), _dp(R.data),
+            _ip(A.indptr), _ip(A.indices), _dp(A.data), _ip(P.indptr), _ip(P.indices), _dp(P.data))
+    nnz = lib().orc_rap(*args, _ip(CI), None, None)
+    CJ = np.empty(nnz, np.int32); Ca = np.empty(nnz)
+    lib().orc_rap(*args, _ip(CI), _ip(CJ), _dp(Ca))
+    return raw_csr(ncr, ncc, CI, CJ, Ca)
+
+
+def mfem_rap(Rt, A, P) -> sp.csr_matrix:
+    """mfem::RAP(Rt, A, P) on serial SparseMatrix: Transpose(Rt), R*A, then (RA)*P."""
+    return matmul(matmul(transpose(Rt), A), P)
+
+
+def add(a, A, b, B) -> sp.csr_matrix:
+    A, B = csr(A), csr(B)
+    n, m = A.shape
+    CI = np.empty(n + 1, np.int32)
+    nnz = lib().orc_csr_add_count(C.c_int(n), C.c_int(m), _ip(A.indptr), _ip(A.indices), _ip(B.indptr),
+                                  _ip(B.indices), _ip(CI))
+    CJ = np.empty(nnz, np.int32); Ca = np.empty(nnz)
+    lib().orc_csr_add_fill(C.c_int(n), C.c_int(m), C.c_double(a), _ip(A.indptr), _ip(A.indices), _dp(A.data),
+                           C.c_double(b), _ip(B.indptr), _ip(B.indices), _dp(B.data), _ip(CI), _ip(CJ), _dp(Ca))
+    return raw_csr(n, m, CI, CJ, Ca)
+
+
+def delete_zeros(A, tol) -> sp.csr_matrix:
+    A = csr(A)
+    OI = np.empty(A.shape[0] + 1, np.int32); OJ = np.empty(A.nnz, np.int32); Oa = np.empty(A.nnz)
+    nnz = lib().orc_csr_delete_zeros(C.c_int(A.shape[0]), _ip(A.indptr), _ip(A.indices), _dp(A.data),
+                                     C.c_double(tol), _ip(OI), _ip(OJ), _dp(Oa))
+    return raw_csr(A.shape[0], A.shape[1], OI, OJ[:nnz].copy(), Oa[:nnz].copy())
+
+
+def sign_transform(A) -> sp.csr_matrix:
+    A = csr(A).copy()
+    lib().orc_sign_transform(C.c_int(A.nnz), _dp(A.data))
+    return A
+
+
+def max_norm(A):
+    return lib().orc_csr_max_norm(C.c_int(A.nnz), _dp(_f64(A.data)))
+
+
+def frobenius_norm(A):
+    return lib().orc_csr_frobenius_norm(C.c_int(A.nnz), _dp(_f64(A.data)))
+
+
+def fix_zero_rows(diag, offd=None) -> int:
+    return lib().orc_fix_zero_rows(C.c_int(diag.shape[0]), _ip(diag.indptr), _ip(diag.indices), _dp(diag.data),
+                                   _ip(offd.indptr) if offd is not None else None,
+                                   _dp(offd.data) if offd is not None else None)
+
+
+def l1_norms(diag, offd=None, option=1) -> np.ndarray:
+    l1 = np.empty(diag.shape[0])
+    bad = lib().orc_l1_norms(C.c_int(diag.shape[0]), _ip(diag.indptr), _ip(diag.indices), _dp(diag.data),
+                             _ip(offd.indptr) if offd is not None else None,
+                             _dp(offd.data) if offd is not None else None, C.c_int(option), _dp(l1))
+    if bad:
+        raise RuntimeError(f"hypre_ParCSRComputeL1Norms: {bad} zero l1 norms")
+    return l1
+
+
+def cheby_coefs(max_eig, min_eig, fraction, order):
+    c = np.zeros(5)
+    co = lib().orc_cheby_coefs(C.c_double(max_eig), C.c_double(min_eig), C.c_double(fraction), C.c_int(order), _dp(c))
+    return co, c
+
+
+def hypre_random(n, seed=1):
+    v = np.empty(n)
+    lib().orc_hypre_random(C.c_int(n), C.c_int(seed), _dp(v))
+    return v
+
+
+def tql1(d, e):
+    d = _f64(d).copy(); e = _f64(e).copy()
+    err = lib().orc_tql1(C.c_int(len(d)), _dp(d), _dp(e))
+    if err:
+        raise RuntimeError("tql1 failed")
+    return d
+
+
+# ---- index maps ---------------------------------------------------------------------------------
+
+def partition_refined(n_elements, n_parts):
+    p = np.empty(n_elements, np.int32)
+    lib().orc_partition_refined(C.c_int(n_elements), C.c_int(n_parts), _ip(p))
+    return p
+
+
+def partition_refined_legacy(n_elements, n_parts, ndim=3):
+    p = np.empty(n_elements, np.int32)
+    lib().orc_partition_refined_legacy(C.c_int(n_elements), C.c_int(n_parts), C.c_int(ndim), _ip(p))
+    return p
+
+
+def connected_components(partitioning, conn):
+    conn = csr(conn)
+    p = _i32(partitioning).copy()
+    n = lib().orc_connected_components(C.c_int(len(p)), _ip(p), _ip(conn.indptr), _ip(conn.indices))
+    return n, p
+
+
+def transpose_partitioning(partitioning, nparts):
+    p = _i32(partitioning)
+    I = np.empty(nparts + 1, np.int32); J = np.empty(int((p > -1).sum()), np.int32)
+    lib().orc_transpose_partitioning(C.c_int(len(p)), _ip(p), C.c_int(nparts), _ip(I), _ip(J))
+    return I, J
+
+
+# ---- ParCSR with a pluggable halo exchange --------------------------------------------------------
+
+class SerialExchange:
+    """One rank: there are no neighbours (hypre's comm handle with num_sends = num_recvs = 0)."""
+    rank, size = 0, 1
+
+    def forward(self, pkg, send_buf):
+        return np.empty(0)
+
+    def reverse(self, pkg, ghost_buf):
+        return np.empty(0)
+
+    def allreduce_sum(self, v):
+        return v
+
+    def allreduce_max(self, v):
+        return v
+
+
+class OParCSR:
+    """Oracle-side ParCSR: diag + offd CSR, col_map_offd, comm package lists."""
+
+    def __init__(self, diag, offd=None, col_map_offd=None, pkg=None, exch=None,
+                 first_row=0, first_col=0, global_shape=None):
+        self.diag = csr(diag)
+        n = self.diag.shape[0]
+        self.offd = csr(offd) if offd is not None else csr(sp.csr_matrix((n, 0)))
+        self.col_map_offd = np.asarray(col_map_offd if col_map_offd is not None else [], dtype=np.int64)
+        self.pkg = pkg   # dict(send_procs, send_starts, send_elmts, recv_procs, recv_starts)
+        self.exch = exch or SerialExchange()
+        self.first_row, self.first_col = first_row, first_col
+        self.global_shape = global_shape or self.diag.shape
+
+    @property
+    def shape(self):
+        return self.diag.shape
+
+    def _send_buf(self, x):
+        if self.pkg is None or len(self.pkg["send_elmts"]) == 0:
+            return np.empty(0)
+        el = _i32(self.pkg["send_elmts"])
+        buf = np.empty(len(el))
+        lib().orc_gather(C.c_int(len(el)), _ip(el), _dp(x), _dp(buf))
+        return buf
+
+    def matvec(self, alpha, x, beta, y):
+        """hypre_ParCSRMatrixMatvec: pack, start exchange, diag product, wait, offd product (beta=1)."""
+        x = _f64(x)
+        ghost = self.exch.forward(self.pkg, self._send_buf(x))
+        csr_matvec(self.diag, alpha, x, beta, y)
+        if self.offd.shape[1]:
+            csr_matvec(self.offd, alpha, _f64(ghost), 1.0, y)
+
+    def matvecT(self, alpha, x, beta, y):
+        """hypre_ParCSRMatrixMatvecT: offd^T x -> y_tmp, reverse exchange, diag^T x, scatter-add."""
+        x = _f64(x)
+        ytmp = np.zeros(self.offd.shape[1])
+        if self.offd.shape[1]:
+            csr_matvecT(self.offd, alpha, x, 0.0, ytmp)
+        ybuf = self.exch.reverse(self.pkg, ytmp)
+        csr_matvecT(self.diag, alpha, x, beta, y)
+        if self.pkg is not None and len(self.pkg["send_elmts"]):
+            el = _i32(self.pkg["send_elmts"])
+            lib().orc_scatter_add(C.c_int(len(el)), _ip(el), _dp(_f64(ybuf)), _dp(y))
+
+    def ghost(self, x):
+        return _f64(self.exch.forward(self.pkg, self._send_buf(_f64(x))))
+
+    def norm_linf(self):
+        """hypre_ParCSRMatrixNormlinf (hypre_ParCSRMatrixNorms.c:74-127)."""
+        Aabs = OParCSR(abs(self.diag), abs(self.offd), self.col_map_offd, self.pkg, self.exch)
+        y = np.zeros(self.shape[0])
+        Aabs.matvec(1.0, np.ones(self.shape[1]), 0.0, y)
+        return self.exch.allreduce_max(max(0.0, y.max(initial=0.0)))
+
+    def norm_l1(self):
+        """hypre_ParCSRMatrixNorml1 (:18-72): max entry of |A|^T 1."""
+        Aabs = OParCSR(abs(self.diag), abs(self.offd), self.col_map_offd, self.pkg, self.exch)
+        y = np.zeros(self.shape[1])
+        Aabs.matvecT(1.0, np.ones(self.shape[0]), 0.0, y)
+        return self.exch.allreduce_max(max(0.0, y.max(initial=0.0)))
+
+    def norm_max(self):
+        return self.exch.allreduce_max(max(max_norm(self.diag), max_norm(self.offd)))
+
+    def norm_frobenius(self):
+        return float(np.sqrt(self.exch.allreduce_sum(frobenius_norm(self.diag) ** 2 + frobenius_norm(self.offd) ** 2)))
+
+
+def compare(A: OParCSR, B: OParCSR, tol: float) -> int:
+    """hypre_ParCSRMatrixCompare (hypre_ParCSRMatrixCompare.c:125-195): bit mask of mismatches."""
+    cmp = 0
+    if A.global_shape[0] != B.global_shape[0]: cmp |= 1
+    if A.global_shape[1] != B.global_shape[1]: cmp |= 2
+    if A.first_row != B.first_row: cmp |= 4
+    if A.first_row + A.shape[0] != B.first_row + B.shape[0]: cmp |= 8
+    if A.first_col != B.first_col: cmp |= 16
+    if A.first_col + A.shape[1] != B.first_col + B.shape[1]: cmp |= 32
+
+    def merged(M):
+        ncol = M.global_shape[1]
+        d = sp.csr_matrix((M.diag.data, M.diag.indices + M.first_col, M.diag.indptr), shape=(M.shape[0], ncol))
+        if M.offd.shape[1]:
+            o = sp.csr_matrix((M.offd.data, M.col_map_offd[M.offd.indices], M.offd.indptr), shape=(M.shape[0], ncol))
+            return add(1.0, d, 1.0, o)
+        return csr(d)
+    if cmp & 3 == 0 and A.shape[0] == B.shape[0]:
+        c = add(1.0, merged(A), -1.0, merged(B))
+        diff = A.exch.allreduce_sum(max_norm(c))
+        if diff > tol: cmp |= 64
+    else:
+        cmp |= 64
+    return cmp
+
+
+# ---- smoothers ------------------------------------------------------------------------------------
+
+class OSmoother:
+    """mfem::HypreSmoother as driven by HypreSmootherWrapper (ParELAG_HypreSmootherWrapper.cpp:28-34):
+    types 1 (l1-Jacobi), 2 (l1-GS), 16 (Chebyshev).  ``iterative_mode`` as in mfem::Solver."""
+
+    def __init__(self, A: OParCSR, type=1, sweeps=1, weight=1.0, omega=1.0, order=2, fraction=0.3,
+                 eig=None):
+        self.A, self.type, self.sweeps, self.weight, self.omega = A, type, sweeps, weight, omega
+        self.order, self.fraction = order, fraction
+        self.iterative_mode = True
+        n = A.shape[0]
+        if type in (1, 2, 3, 4):
+            self.l1 = l1_norms(A.diag, A.offd, option=type)
+        if type == 16:
+            self.max_eig, self.min_eig = eig if eig is not None else max_eig_estimate_cg(A, 1, 10)
+            self.co, self.coefs = cheby_coefs(self.max_eig, self.min_eig, fraction, order)
+            self.ds = np.empty(n)
+            lib().orc_inv_sqrt_diag(C.c_int(n), _ip(A.diag.indptr), _dp(A.diag.data), _dp(self.ds))
+
+    def Mult(self, f, u):
+        A, n = self.A, self.A.shape[0]
+        f = _f64(f)
+        if not self.iterative_mode:
+            u[:] = 0.0
+        L = lib()
+        for _ in range(self.sweeps):
+            if self.type == 1:
+                v = f.copy()
+                A.matvec(-self.weight, u, self.weight, v)
+                L.orc_jacobi_update(C.c_int(n), _dp(v), _dp(self.l1), _dp(u))
+            elif self.type == 2:
+                ue = A.ghost(u)
+                has = A.offd.shape[1] > 0
+                L.orc_l1gs_sweep(C.c_int(n), _ip(A.diag.indptr), _ip(A.diag.indices), _dp(A.diag.data),
+                                 _ip(A.offd.indptr) if has else None, _ip(A.offd.indices) if has else None,
+                                 _dp(A.offd.data) if has else None, _dp(f), _dp(self.l1), _dp(ue), _dp(u))
+            elif self.type == 16:
+                tmp = np.zeros(n); r = np.empty(n); orig = np.empty(n); v = np.zeros(n)
+                A.matvec(-1.0, u, 0.0, tmp)
+                L.orc_cheby_r(C.c_int(n), _dp(self.ds), _dp(f), _dp(tmp), _dp(r))
+                L.orc_cheby_start(C.c_int(n), C.c_double(self.coefs[self.co]), _dp(r), _dp(u), _dp(orig))
+                for i in range(self.co - 1, -1, -1):
+                    L.orc_vec_mul(C.c_int(n), _dp(self.ds), _dp(u), _dp(tmp))
+                    A.matvec(1.0, tmp, 0.0, v)
+                    L.orc_cheby_step(C.c_int(n), C.c_double(self.coefs[i]), _dp(r), _dp(self.ds), _dp(v), _dp(u))
+                L.orc_cheby_finish(C.c_int(n), _dp(orig), _dp(self.ds), _dp(u))
+            else:
+                raise NotImplementedError(self.type)
+
+
+def max_eig_estimate_cg(A: OParCSR, scale=1, max_iter=10, seed=1):
+    """hypre_ParCSRMaxEigEstimateCG [3P par_relax_more.c]: ``max_iter`` CG/Lanczos steps on
+    D^-1/2 A D^-1/2 from a hypre-RNG start vector; eigenvalues of the tridiagonal via tql1."""
+    n = A.shape[0]
+    ex = A.exch
+    size = int(A.global_shape[0])
+    max_iter = min(max_iter, size)
+    r = hypre_random(n, seed * (ex.rank + 1))
+    ds = np.ones(n)
+    if scale:
+        lib().orc_inv_sqrt_diag(C.c_int(n), _ip(A.diag.indptr), _dp(A.diag.data), _dp(ds))
+    tridiag = np.zeros(max_iter + 1); trioffd = np.zeros(max_iter + 1)
+    p = np.zeros(n); s = np.zeros(n); u = np.zeros(n)
+    gamma = 1.0
+    i = 0
+    while i < max_iter:
+        s[:] = r
+        gamma_old = gamma
+        gamma = ex.allreduce_sum(float(r @ s))
+        if i == 0:
+            beta = 1.0
+            p[:] = s
+        else:
+            beta = gamma / gamma_old
+            p[:] = s + beta * p
+        if scale:
+            u[:] = ds * p
+            A.matvec(1.0, u, 0.0, s)
+            s *= ds
+        else:
+            A.matvec(1.0, p, 0.0, s)
+        sdotp = ex.allreduce_sum(float(s @ p))
+        alpha = gamma / sdotp
+        alphainv = 1.0 / alpha
+        tridiag[i + 1] = alphainv
+        tridiag[i] *= beta
+        tridiag[i] += alphainv
+        trioffd[i + 1] = alphainv
+        trioffd[i] *= np.sqrt(beta)
+        r -= alpha * s
+        i += 1
+    ev = tql1(tridiag[:i], trioffd[:i])
+    return float(ev[i - 1]), float(ev[0])
+
+
+class OHiptmair:
+    """HiptmairSmoother::Mult / MultTranspose (ParELAG_HiptmairSmoother.cpp:48-109)."""
+
+    def __init__(self, A: OParCSR, D: OParCSR, primary: OSmoother, aux: OSmoother):
+        self.A, self.D, self.primary, self.aux = A, D, primary, aux
+        self.iterative_mode = True
+        self.primary.iterative_mode = True
+        self.aux.iterative_mode = False
+
+    def _residual(self, X, B):
+        tmp = np.zeros(self.A.shape[0])
+        self.A.matvec(1.0, X, 0.0, tmp)
+        tmp -= B
+        tmp *= -1
+        return tmp
+
+    def _aux_correct(self, R, X):
+        auxb = np.zeros(self.D.shape[1]); auxx = np.zeros(self.D.shape[1])
+        self.D.matvecT(1.0, R, 0.0, auxb)
+        self.aux.Mult(auxb, auxx)
+        pv = np.zeros(self.A.shape[0])
+        self.D.matvec(1.0, auxx, 0.0, pv)
+        X += pv
+
+    def Mult(self, B, X):
+        if not self.iterative_mode:
+            X[:] = 0.0
+        self.primary.Mult(B, X)
+        self._aux_correct(self._residual(X, B), X)
+
+    def MultTranspose(self, B, X):
+        if not self.iterative_mode:
+            X[:] = 0.0
+            self._aux_correct(_f64(B), X)
+        else:
+            self._aux_correct(self._residual(X, B), X)
+        self.primary.Mult(B, X)
+
+
+class OHierarchy:
+    """Hierarchy::Mult/Iterate (ParELAG_Hierarchy.cpp:109-253), composed from ParCSR pieces so it works
+    with any exchange.  levels[l] = dict(A=OParCSR, P=OParCSR (l+1 -> l) or None, pre=..., post=...,
+    coarse=callable(rhs, sol) or None)."""
+
+    def __init__(self, levels, preconditioner=True):
+        self.levels, self.preconditioner = levels, preconditioner
+
+    def Mult(self, rhs, sol):
+        A0 = self.levels[0]["A"]
+        if self.preconditioner:
+            r = _f64(rhs)
+            s = sol
+        else:
+            r = np.zeros(len(rhs))
+            A0.matvec(1.0, sol, 0.0, r)
+            r *= -1.0
+            r += rhs
+            s = np.empty(len(sol))
+        s[:] = 0.0
+        self._iterate(r, s, 0)
+        if not self.preconditioner:
+            sol += s
+
+    def _iterate(self, RHS, SOL, l):
+        L = self.levels[l]
+        if l == len(self.levels) - 1:
+            if L.get("coarse") is not None:
+                L["coarse"](RHS, SOL)
+            else:
+                if L.get("pre") is not None: L["pre"].Mult(RHS, SOL)
+                if L.get("post") is not None: L["post"].Mult(RHS, SOL)
+            return
+        Cl = self.levels[l + 1]
+        if L.get("pre") is not None:
+            L["pre"].Mult(RHS, SOL)
+        n = L["A"].shape[0]
+        tmp_correct = np.zeros(n)
+        L["A"].matvec(1.0, SOL, 0.0, tmp_correct)
+        tmp_resid = RHS + (-1.0) * tmp_correct
+        P = Cl["P"]
+        cres = np.zeros(P.shape[1])
+        P.matvecT(1.0, tmp_resid, 0.0, cres)
+        csol = np.zeros(P.shape[1])
+        self._iterate(cres, csol, l + 1)
+        P.matvec(1.0, csol, 0.0, tmp_correct)
+        SOL += tmp_correct
+        if L.get("post") is not None:
+            post = L["post"]
+            if L.get("post_transpose"):
+                post.MultTranspose(RHS, SOL)
+            else:
+                post.Mult(RHS, SOL)
+
+
+# ---- dense coarse solve and the all-C serial hierarchy ---------------------------------------------
+
+def chol_factor(A_dense):
+    Lf = _f64(np.array(A_dense, dtype=np.float64, copy=True))
+    err = lib().orc_chol_factor(C.c_int(Lf.shape[0]), _dp(Lf))
+    if err:
+        raise RuntimeError(f"Cholesky failed at pivot {err - 1}")
+    return Lf
+
+
+def chol_solve(Lf, b, x):
+    lib().orc_chol_solve(C.c_int(Lf.shape[0]), _dp(Lf), _dp(_f64(b)), _dp(x))
+
+
+class CHierarchy:
+    """All-C serial V-cycle (orc_hier_*), used for CPU-baseline timing and as a second statement of the
+    cycle to cross-check OHierarchy."""
+
+    def __init__(self, As, Ps, smoothers, coarse_chol=None, native=False, hipt=None):
+        """As: list of csr (diag-first for Chebyshev); Ps: list of csr; smoothers: list of dict(type,sweeps,
+        weight,l1,order,max_eig,min_eig,fraction,ds) per level; hipt: optional list of dict(D, Aaux, sm)."""
+        self.L = lib(native)
+        self.keep = [As, Ps, smoothers, coarse_chol, hipt]
+        nl = len(As)
+        self.n = As[0].shape[0]
+        self.h = C.c_void_p(self.L.orc_hier_create(C.c_int(nl)))
+
+        def sm_args(s):
+            return (C.c_int(s["type"]), C.c_int(s.get("sweeps", 1)), C.c_double(s.get("weight", 1.0)),
+                    _dp(s.get("l1")), C.c_int(s.get("order", 2)), C.c_double(s.get("max_eig", 0.0)),
+                    C.c_double(s.get("min_eig", 0.0)), C.c_double(s.get("fraction", 0.3)), _dp(s.get("ds")))
+        for l in range(nl):
+            A = As[l]; P = Ps[l] if l < nl - 1 else None
+            s = smoothers[l]
+            self.L.orc_hier_set_level(self.h, C.c_int(l), C.c_int(A.shape[0]), _ip(A.indptr), _ip(A.indices),
+                                      _dp(A.data), C.c_int(P.shape[1] if P is not None else 0),
+                                      _ip(P.indptr) if P is not None else None,
+                                      _ip(P.indices) if P is not None else None,
+                                      _dp(P.data) if P is not None else None, *sm_args(s))
+            if hipt is not None and hipt[l] is not None:
+                D, X, sa = hipt[l]["D"], hipt[l]["Aaux"], hipt[l]["sm"]
+                self.L.orc_hier_set_hiptmair(self.h, C.c_int(l), C.c_int(D.shape[1]), _ip(D.indptr), _ip(D.indices),
+                                             _dp(D.data), _ip(X.indptr), _ip(X.indices), _dp(X.data), *sm_args(sa))
+        if coarse_chol is not None:
+            self.L.orc_hier_set_coarse_chol(self.h, C.c_int(coarse_chol.shape[0]), _dp(coarse_chol))
+
+    def apply(self, rhs, sol, symmetric_post=False):
+        self.L.orc_hier_apply(self.h, _dp(_f64(rhs)), _dp(sol), C.c_int(int(symmetric_post)))
+
+    def __del__(self):
+        try:
+            self.L.orc_hier_destroy(self.h)
+        except Exception:
+            pass

@@ -1,0 +1,65 @@
+"""The oracle V-cycle: two independent statements agree, and it behaves like a multigrid cycle."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import oracle as orc
+from parelag_amd import meshgen
+from tests.helpers import oracle_h1_hierarchy, oracle_py_hierarchy, pcg
+
+
+def test_galerkin_equals_geometric_coarse_operator(h1_k2):
+    """Invariant M_c = P^T M_f P (DeRhamSequence.cpp:802-848) for nested spaces: RAP + FixZeroRows reproduces the
+    coarse-mesh stiffness with eliminated boundary rows."""
+    A, Ps, seq = h1_k2
+    h = oracle_h1_hierarchy(A, Ps)
+    for l in (1, 2):
+        m = seq.meshes[l]
+        ref = meshgen.eliminate_rowcol(m.M0_P1_stiffness(), m.boundary_marker(0))
+        assert abs(h["As"][l] - ref).max() < 1e-13
+        assert orc.compare(orc.OParCSR(h["As"][l]), orc.OParCSR(orc.csr(ref)), 1e-12) == 0
+
+
+@pytest.mark.parametrize("smoother", [1, 2, 16])
+def test_c_and_python_hierarchies_agree(h1_k2, smoother):
+    A, Ps, _ = h1_k2
+    h = oracle_h1_hierarchy(A, Ps, smoother=smoother, order=3)
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"])
+    Hp = oracle_py_hierarchy(h)
+    rng = np.random.default_rng(7)
+    b = rng.uniform(-1, 1, A.shape[0])
+    x1 = np.empty_like(b); x2 = np.full_like(b, 3.0)
+    Hc.apply(b, x1)
+    Hp.Mult(b, x2)
+    assert np.allclose(x1, x2, rtol=1e-13, atol=1e-15)
+
+
+def test_vcycle_symmetric_and_pcg_converges(h1_k2):
+    """mg_utils::CheckSymmetric (ParELAG_MG_Utils.cpp:59-89, tol 1e-10) holds for Jacobi pre/post + SPD coarse."""
+    A, Ps, _ = h1_k2
+    h = oracle_h1_hierarchy(A, Ps, smoother=1)
+    H = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"])
+    rng = np.random.default_rng(13)
+    v, w = rng.uniform(0, 1, A.shape[0]), rng.uniform(0, 1, A.shape[0])
+    Mv, Mw = np.empty_like(v), np.empty_like(w)
+    H.apply(v, Mv); H.apply(w, Mw)
+    assert abs(w @ Mv - v @ Mw) < 1e-10
+    b = np.full(A.shape[0], 2.0)
+    x, its, hist = pcg(A, H.apply, b, rtol=1e-10)
+    assert its <= 25
+    assert np.linalg.norm(b - A @ x) <= 1e-9 * np.linalg.norm(b)
+
+
+def test_solver_mode_matches_preconditioner_mode(h1_k1):
+    """Hierarchy::Mult with IsPreconditioner()==false: r = rhs - A sol; sol += cycle(r) (Hierarchy.cpp:119-135)."""
+    A, Ps, _ = h1_k1
+    h = oracle_h1_hierarchy(A, Ps)
+    Hp = oracle_py_hierarchy(h)
+    rng = np.random.default_rng(3)
+    b, x0 = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+    e = np.empty_like(b)
+    Hp.Mult(b - A @ x0, e)
+    Hp.preconditioner = False
+    x = x0.copy()
+    Hp.Mult(b, x)
+    assert np.allclose(x, x0 + e, rtol=1e-12, atol=1e-13)
