@@ -1,0 +1,244 @@
+/*
+ * elag_hip.h -- C ABI of the MI355X-native AMGe V-cycle hot path (libelag_hip.so).
+ *
+ * This is the drop-in boundary for ParElag's solver plug-in API: a host-side SolverFactory registered
+ * with SolverLibrary::AddNewSolverFactory (src/linalg/solver_core/ParELAG_SolverLibrary.hpp:199-203)
+ * pulls the hypre_ParCSRMatrix pieces out of mfem::HypreParMatrix and hands them to the functions
+ * below; the returned opaque handles stand behind mfem::Operator::Mult.  See INTEGRATION.md for the
+ * reference-side binding.  Every entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - every function returns an int status (0 = ELAG_HIP_OK); never throws across the ABI.
+ *     elag_hip_last_error() returns the message of the last failure on the calling thread
+ *     (the C++ shim rethrows it like PARELAG_ASSERT_HYPRE_ERROR_FLAG, src/utilities/elagError.hpp:83-110).
+ *   - indices are 32-bit (HYPRE_Int), global ids 64-bit (HYPRE_BigInt), values fp64.
+ *   - *_create functions COPY the caller's host arrays to the device; the caller keeps ownership of its
+ *     arrays (SURVEY 8b "Ownership").  Handles are destroyed with the matching *_destroy.
+ *   - vector arguments carry a location flag `loc`: ELAG_HIP_HOST pointers are staged through device
+ *     buffers (synchronous on return), ELAG_HIP_DEVICE pointers are used in place and the call is
+ *     asynchronous on the library's compute stream (elag_hip_synchronize() to wait).
+ *   - one calling host thread per process and one device per process (ParElag runs one thread per MPI
+ *     rank: INSTALL:44-48); Hierarchy/HiptmairSmoother hold scratch exactly as the reference's mutable
+ *     members do (ParELAG_Hierarchy.hpp:296-298), so apply calls on one handle are not re-entrant.
+ */
+#ifndef ELAG_HIP_H
+#define ELAG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ELAG_HIP_API __attribute__((visibility("default")))
+
+typedef struct elag_hip_parcsr_s *elag_hip_parcsr_t;       /* mfem::HypreParMatrix / hypre_ParCSRMatrix   */
+typedef struct elag_hip_smoother_s *elag_hip_smoother_t;   /* HypreSmootherWrapper / HiptmairSmoother     */
+typedef struct elag_hip_coarse_s *elag_hip_coarse_t;       /* the Level's "CoarseSolver"                  */
+typedef struct elag_hip_hierarchy_s *elag_hip_hierarchy_t; /* parelag::Hierarchy                          */
+
+enum { ELAG_HIP_HOST = 0, ELAG_HIP_DEVICE = 1 };
+
+enum {
+    ELAG_HIP_OK = 0,
+    ELAG_HIP_ERR_ARG = 1,      /* bad argument / shape mismatch (Hierarchy.cpp:344-352 throws for these) */
+    ELAG_HIP_ERR_HIP = 2,      /* a HIP runtime call failed                                            */
+    ELAG_HIP_ERR_COMM = 3,     /* RCCL failure / communicator not initialised                          */
+    ELAG_HIP_ERR_STATE = 4,    /* library not initialised, hierarchy not finalised, ...                */
+    ELAG_HIP_ERR_NUMERIC = 5,  /* zero l1 norm, non-SPD coarse matrix, ...                             */
+    ELAG_HIP_ERR_NODEVICE = 6  /* no usable GPU                                                        */
+};
+
+/* hypre relax types accepted by elag_hip_smoother_create -- the string->type table of
+ * src/linalg/factories/ParELAG_HypreSmootherFactory.cpp:92-109.  Types that are sequential per rank
+ * (l1-GS = 2, GS = 6, ...) are rejected with ELAG_HIP_ERR_ARG: GPU configurations select 1 or 16. */
+enum { ELAG_HIP_SMOOTHER_JACOBI = 0, ELAG_HIP_SMOOTHER_L1_JACOBI = 1, ELAG_HIP_SMOOTHER_CHEBYSHEV = 16 };
+
+/* --------------------------------------------------------------------------------------------------
+ * Library / device / communicator
+ * ------------------------------------------------------------------------------------------------ */
+ELAG_HIP_API int elag_hip_init(int device);                 /* hipSetDevice + private streams          */
+ELAG_HIP_API int elag_hip_finalize(void);
+ELAG_HIP_API int elag_hip_synchronize(void);                /* wait for the compute stream             */
+ELAG_HIP_API const char *elag_hip_last_error(void);
+ELAG_HIP_API int elag_hip_device_name(char *buf, int len);
+
+/* One MPI rank <-> one GPU.  Replaces hypre's MPI communicator inside hypre_ParCSRCommHandleCreate
+ * (call site src/hypreExtension/hypre_ParCSRMatrixMatvecBoolInt.c:189) by an RCCL communicator over xGMI.
+ * Rank 0 calls elag_hip_comm_unique_id, the host broadcasts the 128 bytes (MPI_Bcast / torch.distributed),
+ * every rank calls elag_hip_comm_init.  With nranks == 1 no communicator is created. */
+ELAG_HIP_API int elag_hip_comm_unique_id(void *id128);
+ELAG_HIP_API int elag_hip_comm_init(int rank, int nranks, const void *id128);
+ELAG_HIP_API int elag_hip_comm_rank(int *rank, int *nranks);
+/* 8-byte reductions that end the norm / dot routines (MPI_Allreduce in hypre_ParCSRMatrixNorms.c:60) */
+ELAG_HIP_API int elag_hip_comm_allreduce(double *value, int op /*0 sum, 1 max*/);
+
+/* Device memory for hosts that do not bring their own allocator (the bench harness uses torch). */
+ELAG_HIP_API int elag_hip_malloc(void **dptr, size_t bytes);
+ELAG_HIP_API int elag_hip_free(void *dptr);
+ELAG_HIP_API int elag_hip_memcpy(void *dst, const void *src, size_t bytes, int kind /*0 H2D,1 D2H,2 D2D*/);
+ELAG_HIP_API int elag_hip_memset(void *dptr, int value, size_t bytes);
+
+/* --------------------------------------------------------------------------------------------------
+ * ParCSR matrix  (hypre_ParCSRMatrix as accessed in hypre_ParCSRMatrixMatvecBoolInt.c:149-185 and
+ * src/linalg/factories/ParELAG_SchurComplementFactory.cpp:74-98)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    /* diag block: local rows x local columns */
+    int num_rows, num_cols_diag;
+    const int *diag_i, *diag_j;
+    const double *diag_a;
+    /* offd block: local rows x compressed ghost columns; all NULL / 0 on a single rank */
+    int num_cols_offd;
+    const int *offd_i, *offd_j;
+    const double *offd_a;
+    const int64_t *col_map_offd;           /* ascending global column ids of the ghost columns */
+    /* global layout (assumed partition: src/structures/SharingMap.cpp:103-108) */
+    int64_t first_row, first_col_diag, global_num_rows, global_num_cols;
+    /* comm package (hypre_ParCSRCommPkg): may be all 0/NULL when num_cols_offd == 0 */
+    int num_sends;
+    const int *send_procs, *send_map_starts, *send_map_elmts;
+    int num_recvs;
+    const int *recv_procs, *recv_vec_starts;
+} elag_hip_parcsr_desc;
+
+ELAG_HIP_API int elag_hip_parcsr_create(elag_hip_parcsr_t *out, const elag_hip_parcsr_desc *desc);
+ELAG_HIP_API int elag_hip_parcsr_destroy(elag_hip_parcsr_t A);
+
+typedef struct {
+    int num_rows, num_cols_diag, num_cols_offd;
+    int64_t nnz_diag, nnz_offd, first_row, first_col_diag, global_num_rows, global_num_cols;
+    int num_sends, num_recvs, send_total;
+} elag_hip_parcsr_info;
+ELAG_HIP_API int elag_hip_parcsr_get_info(elag_hip_parcsr_t A, elag_hip_parcsr_info *info);
+
+/* Copy a (device-built) matrix back to caller-allocated host arrays sized from get_info, e.g. to hand a
+ * coarse operator to a hypre coarse solver.  diag_first != 0 stores the diagonal entry first in each
+ * row of a square diag block (hypre / MFEM convention); otherwise columns ascend. */
+ELAG_HIP_API int elag_hip_parcsr_export(elag_hip_parcsr_t A, int diag_first,
+                                        int *diag_i, int *diag_j, double *diag_a,
+                                        int *offd_i, int *offd_j, double *offd_a, int64_t *col_map_offd);
+
+/* y = alpha*op(A)*x + beta*y.  trans=0: hypre_ParCSRMatrixMatvec (A->Mult, Hierarchy.cpp:124-125,193;
+ * P->Mult :231-234); trans=1: hypre_ParCSRMatrixMatvecT (P->MultTranspose :199-203, D^T in
+ * HiptmairSmoother.cpp:62-63).  Halo pattern of hypre_ParCSRMatrixMatvecBoolInt.c:148-201 / :212-345. */
+ELAG_HIP_API int elag_hip_parcsr_spmv(elag_hip_parcsr_t A, int trans, double alpha, const double *x,
+                                      double beta, double *y, int loc);
+/* r = b - A*x   (mg_utils::ComputeResidual, src/linalg/utilities/ParELAG_MG_Utils.hpp:405-426; the
+ * A->Mult + add() pair of Hierarchy.cpp:191-194), fused into the SpMV epilogue. */
+ELAG_HIP_API int elag_hip_parcsr_residual(elag_hip_parcsr_t A, const double *b, const double *x, double *r, int loc);
+
+/* Setup-side sparse algebra ------------------------------------------------------------------ */
+/* hypre_ParCSRMatrixTranspose2 (src/hypreExtension/par_Tmatmul.c:41-79) */
+ELAG_HIP_API int elag_hip_parcsr_transpose(elag_hip_parcsr_t A, elag_hip_parcsr_t *At);
+/* hypre_ParMatmul / mfem::ParMult (MG_Utils_impl.hpp:27-88, MatrixUtils.cpp:1053-1063): C = A*B */
+ELAG_HIP_API int elag_hip_parcsr_matmul(elag_hip_parcsr_t A, elag_hip_parcsr_t B, elag_hip_parcsr_t *C);
+/* hypre_BoomerAMGBuildCoarseOperator(RT,A,P) = RT^T A P: mfem::RAP(A,P) at Hierarchy.cpp:365,511-513;
+ * RAP(A,D) at HiptmairSmootherFactory.cpp:160-161; generic RAP/PtAP at MatrixUtils.cpp:919-948. */
+ELAG_HIP_API int elag_hip_parcsr_rap(elag_hip_parcsr_t RT, elag_hip_parcsr_t A, elag_hip_parcsr_t P,
+                                     elag_hip_parcsr_t *RAP);
+/* hypre_ParCSRMatrixAdd2: C = a*A + b*B (src/hypreExtension/parcsr-add.c:199-245; :27-78 is a=b=1) */
+ELAG_HIP_API int elag_hip_parcsr_add(double a, elag_hip_parcsr_t A, double b, elag_hip_parcsr_t B,
+                                     elag_hip_parcsr_t *C);
+/* hypre_RDP: RT^T diag(d) P (par_Tmatmul.c:17-39); d is a host or device vector of local fine rows */
+ELAG_HIP_API int elag_hip_parcsr_rdp(elag_hip_parcsr_t RT, const double *d, int loc, elag_hip_parcsr_t P,
+                                     elag_hip_parcsr_t *RDP);
+/* hypre_ParCSRMatrixFixZeroRows (Hierarchy.cpp:366-371,515-519; HiptmairSmootherFactory.cpp:162) */
+ELAG_HIP_API int elag_hip_parcsr_fix_zero_rows(elag_hip_parcsr_t A, int *num_fixed);
+/* hypre_ParCSRMatrixDeleteZeros (src/hypreExtension/deleteZeros.c:16-47): drop |a| <= tol */
+ELAG_HIP_API int elag_hip_parcsr_delete_zeros(elag_hip_parcsr_t A, double tol);
+/* hypre_ParCSRDataTransformationSign (hypre_ParCSRDataTransformationSign.c:29-33) */
+ELAG_HIP_API int elag_hip_parcsr_sign_transform(elag_hip_parcsr_t A);
+/* hypre_IdentityParCSRMatrix / hypre_DiagonalParCSRMatrix (hypre_CSRFactory.c:16-250); d may be NULL (=1) */
+ELAG_HIP_API int elag_hip_parcsr_diagonal(elag_hip_parcsr_t *out, int num_rows, int64_t first_row,
+                                          int64_t global_num_rows, const double *d_host);
+/* Norms (hypre_ParCSRMatrixNorms.c:18-160): kind 0 = l1 (max col sum), 1 = linf (max row sum),
+ * 2 = max |a_ij|, 3 = Frobenius.  Ends in the communicator's 8-byte all-reduce. */
+ELAG_HIP_API int elag_hip_parcsr_norm(elag_hip_parcsr_t A, int kind, double *value);
+/* hypre_ParCSRMatrixCompare (hypre_ParCSRMatrixCompare.c:125-195): bit mask 1..32 shape, 64 = |A-B|max>tol */
+ELAG_HIP_API int elag_hip_parcsr_compare(elag_hip_parcsr_t A, elag_hip_parcsr_t B, double tol, int *mask);
+/* a_ii of every local row -> d (device or host vector of num_rows) */
+ELAG_HIP_API int elag_hip_parcsr_get_diagonal(elag_hip_parcsr_t A, double *d, int loc);
+
+/* --------------------------------------------------------------------------------------------------
+ * Smoothers  (HypreSmootherWrapper -> mfem::HypreSmoother -> hypre_ParCSRRelax;
+ * src/linalg/solver_ops/ParELAG_HypreSmootherWrapper.cpp:20-35, .hpp:69-83)
+ * Parameters are the ParameterList keys "Sweeps", "Damping Factor", "Omega", "Cheby Poly Order",
+ * "Cheby Poly Fraction" (HypreSmootherWrapper.cpp:28-33) with the same defaults 1, 1.0, 1.0, 2, 0.3.
+ * ------------------------------------------------------------------------------------------------ */
+ELAG_HIP_API int elag_hip_smoother_create(elag_hip_smoother_t *out, elag_hip_parcsr_t A, int relax_type,
+                                          int sweeps, double damping, double omega,
+                                          int cheby_order, double cheby_fraction);
+/* Chebyshev: eigenvalue bounds of D^-1/2 A D^-1/2.  create() runs hypre_ParCSRMaxEigEstimateCG's
+ * algorithm (10 CG-Lanczos steps, hypre RNG seed 1); set() injects bounds (parity of the sweep). */
+ELAG_HIP_API int elag_hip_smoother_get_eig_estimate(elag_hip_smoother_t S, double *max_eig, double *min_eig);
+ELAG_HIP_API int elag_hip_smoother_set_eig_estimate(elag_hip_smoother_t S, double max_eig, double min_eig);
+/* HiptmairSmoother(A, D, primary, auxiliary) (ParELAG_HiptmairSmoother.cpp:22-46); A_aux = D^T A D is owned
+ * by `auxiliary`.  The result is an elag_hip_smoother_t and can be used wherever a smoother can. */
+ELAG_HIP_API int elag_hip_hiptmair_create(elag_hip_smoother_t *out, elag_hip_parcsr_t A, elag_hip_parcsr_t D,
+                                          elag_hip_smoother_t primary, elag_hip_smoother_t auxiliary);
+/* sol <- smoother(rhs, sol).  zero_initial_guess != 0 is mfem::Solver::iterative_mode == false
+ * (sol is ignored on entry).  transpose != 0 calls MultTranspose (HiptmairSmoother.cpp:79-109; the hypre
+ * relaxations handled here are symmetric, so it equals Mult for them). */
+ELAG_HIP_API int elag_hip_smoother_apply(elag_hip_smoother_t S, const double *rhs, double *sol,
+                                         int zero_initial_guess, int transpose, int loc);
+ELAG_HIP_API int elag_hip_smoother_destroy(elag_hip_smoother_t S);
+
+/* --------------------------------------------------------------------------------------------------
+ * Coarse solver.  The reference puts any SolverFactory product here (AMGeSolverFactory.cpp:144-163;
+ * shipped lists use PCG+BoomerAMG, Create0FormParameterList.hpp:87-136).  kind 0: dense Cholesky of the
+ * (<= 4096 dof, SPD) coarsest operator, applied on device as a dense inverse; kind 1: `iters` steps of
+ * Jacobi-preconditioned CG on device.  A host that wants hypre there exports the operator instead.
+ * ------------------------------------------------------------------------------------------------ */
+ELAG_HIP_API int elag_hip_coarse_create(elag_hip_coarse_t *out, elag_hip_parcsr_t A, int kind, int iters);
+ELAG_HIP_API int elag_hip_coarse_apply(elag_hip_coarse_t C, const double *rhs, double *sol, int loc);
+ELAG_HIP_API int elag_hip_coarse_destroy(elag_hip_coarse_t C);
+
+/* --------------------------------------------------------------------------------------------------
+ * Hierarchy  (parelag::Hierarchy, src/linalg/solver_ops/ParELAG_Hierarchy.cpp:109-267)
+ * Level keys follow Level::Set in the reference: level l holds "A", "PreSmoother", "PostSmoother";
+ * level l >= 1 holds "P" (maps level l to level l-1); the last level holds "CoarseSolver".
+ * Handles are shared, not owned (ParELAG_Level.hpp:155-176).
+ * ------------------------------------------------------------------------------------------------ */
+ELAG_HIP_API int elag_hip_hierarchy_create(elag_hip_hierarchy_t *out, int num_levels);
+ELAG_HIP_API int elag_hip_hierarchy_set_operator(elag_hip_hierarchy_t H, int level, elag_hip_parcsr_t A);
+ELAG_HIP_API int elag_hip_hierarchy_set_prolongator(elag_hip_hierarchy_t H, int coarse_level, elag_hip_parcsr_t P);
+ELAG_HIP_API int elag_hip_hierarchy_set_smoothers(elag_hip_hierarchy_t H, int level,
+                                                  elag_hip_smoother_t pre, elag_hip_smoother_t post);
+ELAG_HIP_API int elag_hip_hierarchy_set_coarse_solver(elag_hip_hierarchy_t H, elag_hip_coarse_t C);
+/* Hierarchy::Finalize (:255-267): size the per-level vectors; also builds explicit P^T and, when
+ * use_graph != 0, arms hipGraph capture of the whole cycle (launch-bound small levels). */
+ELAG_HIP_API int elag_hip_hierarchy_finalize(elag_hip_hierarchy_t H, int use_graph);
+/* Hierarchy::Mult (:109-136): is_preconditioner != 0 -> sol = cycle(rhs); else r = rhs - A sol,
+ * sol += cycle(r).  mu = 0 (V-cycle) only, as in the reference. */
+ELAG_HIP_API int elag_hip_hierarchy_apply(elag_hip_hierarchy_t H, const double *rhs, double *sol,
+                                          int is_preconditioner, int loc);
+ELAG_HIP_API int elag_hip_hierarchy_destroy(elag_hip_hierarchy_t H);
+
+/* buildHierarchyFromDeRhamSequence + AMGeSolverFactory::_do_build_solver in one call
+ * (Hierarchy.cpp:282-383, AMGeSolverFactory.cpp:26-169): A_{l+1} = P_l^T A_l P_l, optional FixZeroRows
+ * (essential BCs), a smoother of `relax_type` on every non-coarsest level (pre = post), dense coarse solve.
+ * P[l] maps level l+1 -> l.  The hierarchy owns everything it builds; level operators are retrievable. */
+ELAG_HIP_API int elag_hip_hierarchy_build(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P,
+                                          const elag_hip_parcsr_t *P, int fix_zero_rows,
+                                          int relax_type, int sweeps, double damping, int cheby_order,
+                                          double cheby_fraction, int coarse_kind, int coarse_iters, int use_graph);
+ELAG_HIP_API int elag_hip_hierarchy_get_operator(elag_hip_hierarchy_t H, int level, elag_hip_parcsr_t *A);
+ELAG_HIP_API int elag_hip_hierarchy_get_smoother(elag_hip_hierarchy_t H, int level, elag_hip_smoother_t *S);
+
+/* --------------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py): run `reps` launches of one fine-level kernel on the compute stream
+ * bracketed by HIP events created on that stream and return the mean milliseconds per launch.
+ * kernel: 0 = SpMV y=Ax, 1 = residual, 2 = l1-Jacobi sweep.
+ * ------------------------------------------------------------------------------------------------ */
+ELAG_HIP_API int elag_hip_time_kernel(elag_hip_parcsr_t A, elag_hip_smoother_t S, int kernel, int reps,
+                                      const double *x_dev, double *y_dev, double *ms_per_launch);
+/* Time `reps` applications of the hierarchy (preconditioner mode, device vectors) with HIP events. */
+ELAG_HIP_API int elag_hip_time_hierarchy(elag_hip_hierarchy_t H, const double *rhs_dev, double *sol_dev,
+                                         int reps, double *ms_per_apply);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ELAG_HIP_H */

@@ -1,0 +1,159 @@
+"""ctypes binding of libelag_hip.so (the C ABI declared in include/elag_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or the device cannot be initialised
+the import / init raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libelag_hip.so")
+
+HOST, DEVICE = 0, 1
+SMOOTHER_JACOBI, SMOOTHER_L1_JACOBI, SMOOTHER_CHEBYSHEV = 0, 1, 16
+
+_i = C.c_int
+_d = C.c_double
+_p = C.c_void_p
+_i64 = C.c_int64
+_ip = C.POINTER(C.c_int)
+_dp = C.POINTER(C.c_double)
+_lp = C.POINTER(C.c_int64)
+
+
+class ParCSRDesc(C.Structure):
+    _fields_ = [
+        ("num_rows", _i), ("num_cols_diag", _i),
+        ("diag_i", _p), ("diag_j", _p), ("diag_a", _p),
+        ("num_cols_offd", _i),
+        ("offd_i", _p), ("offd_j", _p), ("offd_a", _p),
+        ("col_map_offd", _p),
+        ("first_row", _i64), ("first_col_diag", _i64), ("global_num_rows", _i64), ("global_num_cols", _i64),
+        ("num_sends", _i),
+        ("send_procs", _p), ("send_map_starts", _p), ("send_map_elmts", _p),
+        ("num_recvs", _i),
+        ("recv_procs", _p), ("recv_vec_starts", _p),
+    ]
+
+
+class ParCSRInfo(C.Structure):
+    _fields_ = [
+        ("num_rows", _i), ("num_cols_diag", _i), ("num_cols_offd", _i),
+        ("nnz_diag", _i64), ("nnz_offd", _i64), ("first_row", _i64), ("first_col_diag", _i64),
+        ("global_num_rows", _i64), ("global_num_cols", _i64),
+        ("num_sends", _i), ("num_recvs", _i), ("send_total", _i),
+    ]
+
+
+# name -> argtypes (restype is int status unless listed in _RESTYPES)
+_SIGNATURES = {
+    "elag_hip_init": [_i],
+    "elag_hip_finalize": [],
+    "elag_hip_synchronize": [],
+    "elag_hip_last_error": [],
+    "elag_hip_device_name": [C.c_char_p, _i],
+    "elag_hip_comm_unique_id": [_p],
+    "elag_hip_comm_init": [_i, _i, _p],
+    "elag_hip_comm_rank": [_ip, _ip],
+    "elag_hip_comm_allreduce": [_dp, _i],
+    "elag_hip_malloc": [C.POINTER(_p), C.c_size_t],
+    "elag_hip_free": [_p],
+    "elag_hip_memcpy": [_p, _p, C.c_size_t, _i],
+    "elag_hip_memset": [_p, _i, C.c_size_t],
+    "elag_hip_parcsr_create": [C.POINTER(_p), C.POINTER(ParCSRDesc)],
+    "elag_hip_parcsr_destroy": [_p],
+    "elag_hip_parcsr_get_info": [_p, C.POINTER(ParCSRInfo)],
+    "elag_hip_parcsr_export": [_p, _i, _p, _p, _p, _p, _p, _p, _p],
+    "elag_hip_parcsr_spmv": [_p, _i, _d, _p, _d, _p, _i],
+    "elag_hip_parcsr_residual": [_p, _p, _p, _p, _i],
+    "elag_hip_parcsr_transpose": [_p, C.POINTER(_p)],
+    "elag_hip_parcsr_matmul": [_p, _p, C.POINTER(_p)],
+    "elag_hip_parcsr_rap": [_p, _p, _p, C.POINTER(_p)],
+    "elag_hip_parcsr_add": [_d, _p, _d, _p, C.POINTER(_p)],
+    "elag_hip_parcsr_rdp": [_p, _p, _i, _p, C.POINTER(_p)],
+    "elag_hip_parcsr_fix_zero_rows": [_p, _ip],
+    "elag_hip_parcsr_delete_zeros": [_p, _d],
+    "elag_hip_parcsr_sign_transform": [_p],
+    "elag_hip_parcsr_diagonal": [C.POINTER(_p), _i, _i64, _i64, _p],
+    "elag_hip_parcsr_norm": [_p, _i, _dp],
+    "elag_hip_parcsr_compare": [_p, _p, _d, _ip],
+    "elag_hip_parcsr_get_diagonal": [_p, _p, _i],
+    "elag_hip_smoother_create": [C.POINTER(_p), _p, _i, _i, _d, _d, _i, _d],
+    "elag_hip_smoother_get_eig_estimate": [_p, _dp, _dp],
+    "elag_hip_smoother_set_eig_estimate": [_p, _d, _d],
+    "elag_hip_hiptmair_create": [C.POINTER(_p), _p, _p, _p, _p],
+    "elag_hip_smoother_apply": [_p, _p, _p, _i, _i, _i],
+    "elag_hip_smoother_destroy": [_p],
+    "elag_hip_coarse_create": [C.POINTER(_p), _p, _i, _i],
+    "elag_hip_coarse_apply": [_p, _p, _p, _i],
+    "elag_hip_coarse_destroy": [_p],
+    "elag_hip_hierarchy_create": [C.POINTER(_p), _i],
+    "elag_hip_hierarchy_set_operator": [_p, _i, _p],
+    "elag_hip_hierarchy_set_prolongator": [_p, _i, _p],
+    "elag_hip_hierarchy_set_smoothers": [_p, _i, _p, _p],
+    "elag_hip_hierarchy_set_coarse_solver": [_p, _p],
+    "elag_hip_hierarchy_finalize": [_p, _i],
+    "elag_hip_hierarchy_apply": [_p, _p, _p, _i, _i],
+    "elag_hip_hierarchy_destroy": [_p],
+    "elag_hip_hierarchy_build": [C.POINTER(_p), _p, _i, C.POINTER(_p), _i, _i, _i, _d, _i, _d, _i, _i, _i],
+    "elag_hip_hierarchy_get_operator": [_p, _i, C.POINTER(_p)],
+    "elag_hip_hierarchy_get_smoother": [_p, _i, C.POINTER(_p)],
+    "elag_hip_time_kernel": [_p, _p, _i, _i, _p, _p, _dp],
+    "elag_hip_time_hierarchy": [_p, _p, _p, _i, _dp],
+}
+_RESTYPES = {"elag_hip_last_error": C.c_char_p}
+
+ABI_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+_initialised = False
+
+
+class ElagHipError(RuntimeError):
+    """Raised for any non-zero status of the C ABI (like PARELAG_ASSERT_HYPRE_ERROR_FLAG -> exception)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"elag_hip error {code}: {msg}")
+        self.code = code
+
+
+def load(path: str = LIB_PATH):
+    """dlopen the HIP library and declare prototypes.  No GPU is touched."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -m parelag_amd.build` (hipcc, gfx950). "
+                          "There is no CPU fallback for the product path.")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and the header drift apart
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def check(status: int):
+    if status != 0:
+        raise ElagHipError(status, (load().elag_hip_last_error() or b"").decode())
+
+
+def init(device: int | None = None):
+    """elag_hip_init on LOCAL_RANK's device (one process per GPU)."""
+    global _initialised
+    lib = load()
+    if not _initialised:
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        check(lib.elag_hip_init(device))
+        _initialised = True
+    return lib
+
+
+def device_name() -> str:
+    buf = C.create_string_buffer(256)
+    check(init().elag_hip_device_name(buf, 256))
+    return buf.value.decode()

@@ -1,0 +1,163 @@
+#include "comm.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace elag {
+
+struct Comm {
+    void *lib = nullptr;
+    ncclComm_t comm = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static Comm *load_rccl()
+{
+    static Comm c;
+    if (c.lib) return &c;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char *n : names) {
+        c.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (c.lib) break;
+    }
+    if (!c.lib) fail(ELAG_HIP_ERR_COMM, "cannot load librccl: %s", dlerror());
+#define ELAG_SYM(field, name)                                                      \
+    c.field = reinterpret_cast<decltype(c.field)>(dlsym(c.lib, name));             \
+    if (!c.field) fail(ELAG_HIP_ERR_COMM, "librccl lacks symbol %s", name)
+    ELAG_SYM(GetUniqueId, "ncclGetUniqueId");
+    ELAG_SYM(CommInitRank, "ncclCommInitRank");
+    ELAG_SYM(CommDestroy, "ncclCommDestroy");
+    ELAG_SYM(GroupStart, "ncclGroupStart");
+    ELAG_SYM(GroupEnd, "ncclGroupEnd");
+    ELAG_SYM(Send, "ncclSend");
+    ELAG_SYM(Recv, "ncclRecv");
+    ELAG_SYM(AllReduce, "ncclAllReduce");
+    ELAG_SYM(GetErrorString, "ncclGetErrorString");
+#undef ELAG_SYM
+    return &c;
+}
+
+#define ELAG_NCCL_CHECK(c, expr)                                                                               \
+    do {                                                                                                       \
+        ncclResult_t r_ = (expr);                                                                              \
+        if (r_ != ncclSuccess) fail(ELAG_HIP_ERR_COMM, "%s failed: %s", #expr, (c)->GetErrorString(r_));       \
+    } while (0)
+
+bool comm_active() { return ctx().nranks > 1 && ctx().comm && ctx().comm->comm; }
+
+void comm_destroy()
+{
+    Context &c = ctx();
+    if (c.comm && c.comm->comm) {
+        c.comm->CommDestroy(c.comm->comm);
+        c.comm->comm = nullptr;
+    }
+    c.comm = nullptr;
+    c.rank = 0;
+    c.nranks = 1;
+}
+
+void comm_unique_id(void *id128)
+{
+    Comm *c = load_rccl();
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+    ncclUniqueId id;
+    ELAG_NCCL_CHECK(c, c->GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+}
+
+void comm_init(int rank, int nranks, const void *id128)
+{
+    Context &x = ctx();
+    ELAG_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d of %d", rank, nranks);
+    if (nranks == 1) { x.rank = 0; x.nranks = 1; return; }
+    ELAG_REQUIRE(id128 != nullptr, "null unique id");
+    Comm *c = load_rccl();
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ELAG_NCCL_CHECK(c, c->CommInitRank(&c->comm, nranks, id, rank));
+    x.comm = c;
+    x.rank = rank;
+    x.nranks = nranks;
+}
+
+void comm_neighbor_exchange(const void *sendbuf, int nsend, const int *send_procs, const int *send_starts,
+                            void *recvbuf, int nrecv, const int *recv_procs, const int *recv_starts,
+                            size_t elem_bytes, hipStream_t st)
+{
+    if (nsend == 0 && nrecv == 0) return;
+    if (!comm_active()) fail(ELAG_HIP_ERR_COMM, "matrix has off-rank columns but no communicator was initialised");
+    Comm *c = ctx().comm;
+    ELAG_NCCL_CHECK(c, c->GroupStart());
+    for (int i = 0; i < nrecv; i++) {
+        const size_t n = (size_t)(recv_starts[i + 1] - recv_starts[i]) * elem_bytes;
+        if (n) ELAG_NCCL_CHECK(c, c->Recv(static_cast<char *>(recvbuf) + (size_t)recv_starts[i] * elem_bytes, n, ncclInt8, recv_procs[i], c->comm, st));
+    }
+    for (int i = 0; i < nsend; i++) {
+        const size_t n = (size_t)(send_starts[i + 1] - send_starts[i]) * elem_bytes;
+        if (n) ELAG_NCCL_CHECK(c, c->Send(static_cast<const char *>(sendbuf) + (size_t)send_starts[i] * elem_bytes, n, ncclInt8, send_procs[i], c->comm, st));
+    }
+    ELAG_NCCL_CHECK(c, c->GroupEnd());
+}
+
+void comm_allreduce_device(double *d_values, int n, int op, hipStream_t st)
+{
+    if (!comm_active() || n == 0) return;
+    Comm *c = ctx().comm;
+    ELAG_NCCL_CHECK(c, c->AllReduce(d_values, d_values, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, c->comm, st));
+}
+
+void comm_allreduce_scalar(double *value, int op)
+{
+    if (!comm_active()) return;
+    Context &x = ctx();
+    x.h_scalar[8] = *value;
+    ELAG_HIP_CHECK(hipMemcpyAsync(x.d_scalar + 8, x.h_scalar + 8, sizeof(double), hipMemcpyHostToDevice, x.stream));
+    comm_allreduce_device(x.d_scalar + 8, 1, op, x.stream);
+    ELAG_HIP_CHECK(hipMemcpyAsync(x.h_scalar + 8, x.d_scalar + 8, sizeof(double), hipMemcpyDeviceToHost, x.stream));
+    ELAG_HIP_CHECK(hipStreamSynchronize(x.stream));
+    *value = x.h_scalar[8];
+}
+
+}  // namespace elag
+
+using namespace elag;
+
+extern "C" {
+
+int elag_hip_comm_unique_id(void *id128)
+{
+    return guarded([&] { ELAG_REQUIRE(id128 != nullptr, "null id buffer"); comm_unique_id(id128); });
+}
+
+int elag_hip_comm_init(int rank, int nranks, const void *id128)
+{
+    return guarded([&] { require_init(); comm_init(rank, nranks, id128); });
+}
+
+int elag_hip_comm_rank(int *rank, int *nranks)
+{
+    return guarded([&] {
+        if (rank) *rank = ctx().rank;
+        if (nranks) *nranks = ctx().nranks;
+    });
+}
+
+int elag_hip_comm_allreduce(double *value, int op)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(value != nullptr && (op == 0 || op == 1), "bad all-reduce arguments");
+        comm_allreduce_scalar(value, op);
+    });
+}
+
+}  // extern "C"

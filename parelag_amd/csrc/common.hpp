@@ -1,0 +1,167 @@
+// Shared declarations of libelag_hip.so: context, error plumbing, device containers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/elag_hip.h"
+
+namespace elag {
+
+// ---- error plumbing: C++ exceptions inside, int status + message at the ABI --------------------
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+void set_last_error(const std::string &msg);
+[[noreturn]] void fail(int code, const char *fmt, ...);
+
+#define ELAG_HIP_CHECK(expr)                                                                      \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            ::elag::fail(ELAG_HIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                         __FILE__, __LINE__);                                                     \
+    } while (0)
+
+#define ELAG_REQUIRE(cond, ...)                                  \
+    do {                                                         \
+        if (!(cond)) ::elag::fail(ELAG_HIP_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+// Wrap an ABI body: translate exceptions to status codes.
+template <class F>
+int guarded(F &&f) noexcept
+{
+    try {
+        f();
+        return ELAG_HIP_OK;
+    } catch (const Error &e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        return ELAG_HIP_ERR_STATE;
+    } catch (...) {
+        set_last_error("unknown exception");
+        return ELAG_HIP_ERR_STATE;
+    }
+}
+
+// ---- context -----------------------------------------------------------------------------------
+struct Comm;  // RCCL wrapper (comm.hip)
+
+struct Context {
+    bool initialised = false;
+    int device = -1;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;       // compute stream
+    hipStream_t comm_stream = nullptr;  // halo exchange stream
+    hipEvent_t ev_pack = nullptr;       // send buffer packed   (compute -> comm)
+    hipEvent_t ev_halo = nullptr;       // ghost values arrived (comm -> compute)
+    int rank = 0, nranks = 1;
+    Comm *comm = nullptr;
+    double *d_scalar = nullptr;         // device scratch for reductions (16 doubles)
+    double *h_scalar = nullptr;         // pinned mirror
+};
+Context &ctx();
+void require_init();
+
+// ---- device memory helpers ---------------------------------------------------------------------
+template <class T>
+T *dev_alloc(size_t n)
+{
+    T *p = nullptr;
+    if (n == 0) n = 1;
+    ELAG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)));
+    return p;
+}
+template <class T>
+void dev_free(T *&p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+template <class T>
+T *dev_from_host(const T *h, size_t n)
+{
+    T *p = dev_alloc<T>(n);
+    if (n) ELAG_HIP_CHECK(hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, ctx().stream));
+    return p;
+}
+template <class T>
+std::vector<T> host_from_dev(const T *d, size_t n)
+{
+    std::vector<T> v(n);
+    if (n) {
+        ELAG_HIP_CHECK(hipMemcpyAsync(v.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, ctx().stream));
+        ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    }
+    return v;
+}
+
+// Stream-ordered temporary (setup-time scratch).
+template <class T>
+struct Temp {
+    T *p = nullptr;
+    explicit Temp(size_t n)
+    {
+        if (n == 0) n = 1;
+        ELAG_HIP_CHECK(hipMallocAsync(reinterpret_cast<void **>(&p), n * sizeof(T), ctx().stream));
+    }
+    ~Temp()
+    {
+        if (p) (void)hipFreeAsync(p, ctx().stream);
+    }
+    Temp(const Temp &) = delete;
+    Temp &operator=(const Temp &) = delete;
+    operator T *() const { return p; }
+};
+
+// ---- device CSR --------------------------------------------------------------------------------
+struct DevCSR {
+    int nrows = 0, ncols = 0;
+    int64_t nnz = 0;
+    int *I = nullptr, *J = nullptr;
+    double *a = nullptr;
+    int lanes_per_row = 8;  // SpMV row-group width chosen from nnz/nrows
+
+    DevCSR() = default;
+    DevCSR(const DevCSR &) = delete;
+    DevCSR &operator=(const DevCSR &) = delete;
+    DevCSR(DevCSR &&o) noexcept { *this = std::move(o); }
+    DevCSR &operator=(DevCSR &&o) noexcept
+    {
+        if (this != &o) {
+            release();
+            nrows = o.nrows; ncols = o.ncols; nnz = o.nnz; I = o.I; J = o.J; a = o.a;
+            lanes_per_row = o.lanes_per_row;
+            o.I = o.J = nullptr; o.a = nullptr; o.nnz = 0; o.nrows = o.ncols = 0;
+        }
+        return *this;
+    }
+    ~DevCSR() { release(); }
+    void release() { dev_free(I); dev_free(J); dev_free(a); }
+    void alloc(int nr, int nc, int64_t nz)
+    {
+        release();
+        nrows = nr; ncols = nc; nnz = nz;
+        I = dev_alloc<int>((size_t)nr + 1);
+        J = dev_alloc<int>((size_t)nz);
+        a = dev_alloc<double>((size_t)nz);
+    }
+    void upload(int nr, int nc, const int *hi, const int *hj, const double *ha);
+    void set_empty(int nr, int nc);
+    void choose_spmv_shape();
+};
+
+}  // namespace elag

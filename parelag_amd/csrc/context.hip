@@ -1,0 +1,184 @@
+// Library context, error plumbing, memory entry points and DevCSR helpers.
+#include "kernels.hpp"
+#include "comm.hpp"
+
+namespace elag {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+
+void fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    throw Error(code, buf);
+}
+
+Context &ctx()
+{
+    static Context c;
+    return c;
+}
+
+void require_init()
+{
+    if (!ctx().initialised) fail(ELAG_HIP_ERR_STATE, "elag_hip_init() has not been called");
+}
+
+void DevCSR::upload(int nr, int nc, const int *hi, const int *hj, const double *ha)
+{
+    ELAG_REQUIRE(nr >= 0 && nc >= 0, "negative matrix dimension");
+    ELAG_REQUIRE(nr == 0 || hi != nullptr, "null row pointer array");
+    const int64_t nz = nr ? hi[nr] : 0;
+    ELAG_REQUIRE(nz >= 0 && (nr == 0 || hi[0] == 0), "malformed CSR row pointers");
+    ELAG_REQUIRE(nz == 0 || (hj && ha), "null column/value array");
+    for (int i = 0; i < nr; i++) ELAG_REQUIRE(hi[i + 1] >= hi[i], "CSR row pointers decrease at row %d", i);
+    for (int64_t k = 0; k < nz; k++)
+        ELAG_REQUIRE(hj[k] >= 0 && hj[k] < nc, "column index %d out of range [0,%d) at entry %lld", hj[k], nc, (long long)k);
+    alloc(nr, nc, nz);
+    hipStream_t st = ctx().stream;
+    if (nr) ELAG_HIP_CHECK(hipMemcpyAsync(I, hi, sizeof(int) * ((size_t)nr + 1), hipMemcpyHostToDevice, st));
+    else ELAG_HIP_CHECK(hipMemsetAsync(I, 0, sizeof(int), st));
+    if (nz) {
+        ELAG_HIP_CHECK(hipMemcpyAsync(J, hj, sizeof(int) * (size_t)nz, hipMemcpyHostToDevice, st));
+        ELAG_HIP_CHECK(hipMemcpyAsync(a, ha, sizeof(double) * (size_t)nz, hipMemcpyHostToDevice, st));
+    }
+    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    choose_spmv_shape();
+}
+
+void DevCSR::set_empty(int nr, int nc)
+{
+    alloc(nr, nc, 0);
+    ELAG_HIP_CHECK(hipMemsetAsync(I, 0, sizeof(int) * ((size_t)nr + 1), ctx().stream));
+    lanes_per_row = 1;
+}
+
+void DevCSR::choose_spmv_shape()
+{
+    // lanes per row: smallest power of two >= (nnz/row)/2, so a row takes ~2 strided iterations
+    static int forced = -1;
+    if (forced < 0) {
+        const char *e = getenv("ELAG_HIP_LPR");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced > 0) { lanes_per_row = forced; return; }
+    const double avg = nrows ? (double)nnz / nrows : 0.0;
+    int l = 1;
+    while (l < 64 && 2.0 * l < avg) l <<= 1;
+    lanes_per_row = l;
+}
+
+}  // namespace elag
+
+using namespace elag;
+
+extern "C" {
+
+int elag_hip_init(int device)
+{
+    return guarded([&] {
+        Context &c = ctx();
+        if (c.initialised) {
+            ELAG_REQUIRE(device == c.device, "elag_hip_init: already initialised on device %d", c.device);
+            return;
+        }
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0) fail(ELAG_HIP_ERR_NODEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+        ELAG_REQUIRE(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
+        ELAG_HIP_CHECK(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        ELAG_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        c.num_cus = prop.multiProcessorCount;
+        ELAG_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        ELAG_HIP_CHECK(hipStreamCreateWithFlags(&c.comm_stream, hipStreamNonBlocking));
+        ELAG_HIP_CHECK(hipEventCreateWithFlags(&c.ev_pack, hipEventDisableTiming));
+        ELAG_HIP_CHECK(hipEventCreateWithFlags(&c.ev_halo, hipEventDisableTiming));
+        ELAG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&c.d_scalar), 16 * sizeof(double)));
+        ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c.h_scalar), 16 * sizeof(double), hipHostMallocDefault));
+        c.device = device;
+        c.initialised = true;
+    });
+}
+
+int elag_hip_finalize(void)
+{
+    return guarded([&] {
+        Context &c = ctx();
+        if (!c.initialised) return;
+        (void)hipStreamSynchronize(c.stream);
+        (void)hipStreamSynchronize(c.comm_stream);
+        comm_destroy();
+        (void)hipFree(c.d_scalar);
+        (void)hipHostFree(c.h_scalar);
+        (void)hipEventDestroy(c.ev_pack);
+        (void)hipEventDestroy(c.ev_halo);
+        (void)hipStreamDestroy(c.stream);
+        (void)hipStreamDestroy(c.comm_stream);
+        c = Context();
+    });
+}
+
+int elag_hip_synchronize(void)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    });
+}
+
+const char *elag_hip_last_error(void) { return g_last_error.c_str(); }
+
+int elag_hip_device_name(char *buf, int len)
+{
+    return guarded([&] {
+        require_init();
+        hipDeviceProp_t prop;
+        ELAG_HIP_CHECK(hipGetDeviceProperties(&prop, ctx().device));
+        snprintf(buf, (size_t)len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    });
+}
+
+int elag_hip_malloc(void **dptr, size_t bytes)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(dptr != nullptr, "null output pointer");
+        ELAG_HIP_CHECK(hipMalloc(dptr, bytes ? bytes : 8));
+    });
+}
+
+int elag_hip_free(void *dptr)
+{
+    return guarded([&] {
+        if (dptr) ELAG_HIP_CHECK(hipFree(dptr));
+    });
+}
+
+int elag_hip_memcpy(void *dst, const void *src, size_t bytes, int kind)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(kind >= 0 && kind <= 2, "bad memcpy kind %d", kind);
+        const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : (kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+        if (bytes) {
+            ELAG_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, k, ctx().stream));
+            if (kind != 2) ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+        }
+    });
+}
+
+int elag_hip_memset(void *dptr, int value, size_t bytes)
+{
+    return guarded([&] {
+        require_init();
+        if (bytes) ELAG_HIP_CHECK(hipMemsetAsync(dptr, value, bytes, ctx().stream));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,378 @@
+// parelag::Hierarchy on the device (src/linalg/solver_ops/ParELAG_Hierarchy.cpp:109-267) plus the
+// hierarchy builder (buildHierarchyFromDeRhamSequence :282-383 + AMGeSolverFactory.cpp:26-169) and the
+// measurement hooks used by bench.py.
+#include <algorithm>
+
+#include "comm.hpp"
+#include "smoother.hpp"
+#include "staging.hpp"
+
+using namespace elag;
+
+namespace {
+
+struct Level {
+    ParCSR *A = nullptr;
+    ParCSR *P = nullptr;  // maps this level to the next finer one (null on level 0)
+    elag_hip_smoother_s *pre = nullptr, *post = nullptr;
+    double *resid = nullptr, *sol = nullptr, *alt = nullptr, *tmp_resid = nullptr;
+};
+
+struct GraphEntry {
+    const double *rhs;
+    double *sol;
+    int mode;
+    hipGraphExec_t exec;
+};
+
+}  // namespace
+
+struct elag_hip_hierarchy_s {
+    std::vector<Level> lev;
+    elag_hip_coarse_s *coarse = nullptr;
+    bool finalized = false;
+    bool use_graph = false;
+    std::vector<GraphEntry> graphs;
+    // objects created by elag_hip_hierarchy_build (owned)
+    std::vector<ParCSR *> owned_mats;
+    std::vector<elag_hip_smoother_s *> owned_smoothers;
+    elag_hip_coarse_s *owned_coarse = nullptr;
+    double *r0 = nullptr, *e0 = nullptr;  // solver-mode residual / correction on level 0
+
+    ~elag_hip_hierarchy_s()
+    {
+        for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);
+        for (auto &l : lev) { dev_free(l.resid); dev_free(l.sol); dev_free(l.alt); dev_free(l.tmp_resid); }
+        dev_free(r0); dev_free(e0);
+        for (auto *s : owned_smoothers) delete s;
+        delete owned_coarse;
+        for (auto *m : owned_mats) delete m;
+    }
+
+    void finalize(bool graph)
+    {
+        const int nl = (int)lev.size();
+        for (int l = 0; l < nl; l++) {
+            Level &L = lev[(size_t)l];
+            ELAG_REQUIRE(L.A, "Hierarchy::Finalize: level %d has no operator \"A\"", l);
+            ELAG_REQUIRE(L.A->nrows() == L.A->ncols(), "level %d operator is not square", l);
+            if (l > 0) {
+                ELAG_REQUIRE(L.P, "Hierarchy::Finalize: level %d has no prolongator \"P\"", l);
+                ELAG_REQUIRE(L.P->nrows() == lev[(size_t)l - 1].A->nrows() && L.P->ncols() == L.A->nrows(),
+                             "P on level %d is %dx%d but fine/coarse sizes are %d/%d", l, L.P->nrows(), L.P->ncols(),
+                             lev[(size_t)l - 1].A->nrows(), L.A->nrows());
+                L.P->ensure_transpose();
+            }
+            const size_t n = (size_t)L.A->nrows();
+            dev_free(L.resid); dev_free(L.sol); dev_free(L.alt); dev_free(L.tmp_resid);
+            L.resid = dev_alloc<double>(n); L.sol = dev_alloc<double>(n); L.alt = dev_alloc<double>(n);
+            L.tmp_resid = dev_alloc<double>(n);
+        }
+        dev_free(r0); dev_free(e0);
+        r0 = dev_alloc<double>((size_t)lev[0].A->nrows());
+        e0 = dev_alloc<double>((size_t)lev[0].A->nrows());
+        for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);
+        graphs.clear();
+        use_graph = graph && ctx().nranks == 1;
+        finalized = true;
+        ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    }
+
+    // Hierarchy::Iterate(RHS, SOL, l) with mu = 0; SOL is zero on entry by construction (:130, :212), which
+    // the pre-smoother exploits (zero_guess).  The result is left in `sol`.
+    void iterate(int l, const double *rhs, double *sol, double *alt)
+    {
+        Level &F = lev[(size_t)l];
+        const int nl = (int)lev.size();
+        if (l == nl - 1) {
+            if (coarse) { coarse->apply(rhs, sol); return; }
+            // no coarse solver: pre- then post-smoother (:160-172)
+            int nf = (F.pre ? F.pre->flips(true) : 0) + (F.post ? F.post->flips(F.pre == nullptr) : 0);
+            double *cur = (nf & 1) ? alt : sol, *oth = (nf & 1) ? sol : alt;
+            if (!F.pre && !F.post) { k::vec_fill(F.A->nrows(), 0.0, sol); return; }
+            if (F.pre) F.pre->apply(rhs, cur, oth, true, false);
+            if (F.post) F.post->apply(rhs, cur, oth, F.pre == nullptr, false);
+            return;
+        }
+        Level &C = lev[(size_t)l + 1];
+        const int n = F.A->nrows();
+        const int nf = (F.pre ? F.pre->flips(true) : 0) + (F.post ? F.post->flips(false) : 0);
+        double *cur = (nf & 1) ? alt : sol, *oth = (nf & 1) ? sol : alt;
+        // pre-smoothing (:180-184)
+        if (F.pre) F.pre->apply(rhs, cur, oth, true, false);
+        else k::vec_fill(n, 0.0, cur);
+        // residual (:191-194), fused A*SOL and RHS - tmp
+        {
+            k::SpmvArgs a;
+            a.x = cur; a.alpha = -1.0; a.f = rhs; a.gamma = 1.0; a.out = F.tmp_resid;
+            par_spmv(*F.A, a);
+        }
+        // restriction P^T r (:199-203)
+        par_spmvT(*C.P, 1.0, F.tmp_resid, 0.0, C.resid);
+        // coarse-grid correction (:212-227)
+        iterate(l + 1, C.resid, C.sol, C.alt);
+        // SOL += P * coarse_sol (:231-238), fused
+        {
+            k::SpmvArgs a;
+            a.x = C.sol; a.alpha = 1.0; a.yin = cur; a.beta = 1.0; a.out = cur;
+            par_spmv(*C.P, a);
+        }
+        // post-smoothing (:244-249)
+        if (F.post) F.post->apply(rhs, cur, oth, false, false);
+        if (cur != sol) fail(ELAG_HIP_ERR_STATE, "internal: ping-pong parity mismatch on level %d", l);
+    }
+
+    void run(const double *rhs, double *sol, bool precond)
+    {
+        Level &L0 = lev[0];
+        const int n = L0.A->nrows();
+        if (precond) {
+            iterate(0, rhs, sol, L0.alt);
+        } else {
+            k::SpmvArgs a;  // r = rhs - A sol (:119-128)
+            a.x = sol; a.alpha = -1.0; a.f = rhs; a.gamma = 1.0; a.out = r0;
+            par_spmv(*L0.A, a);
+            iterate(0, r0, e0, L0.alt);
+            k::vec_axpby(n, 1.0, sol, 1.0, e0, sol);  // sol += correction (:134-135)
+        }
+    }
+
+    void apply_device(const double *rhs, double *sol, bool precond)
+    {
+        if (!use_graph) { run(rhs, sol, precond); return; }
+        hipStream_t st = ctx().stream;
+        for (auto &g : graphs)
+            if (g.rhs == rhs && g.sol == sol && g.mode == (int)precond) {
+                ELAG_HIP_CHECK(hipGraphLaunch(g.exec, st));
+                return;
+            }
+        // capture the whole cycle once per (rhs, sol) pair: the small levels are launch-bound
+        hipGraph_t graph = nullptr;
+        ELAG_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        try {
+            run(rhs, sol, precond);
+        } catch (...) {
+            (void)hipStreamEndCapture(st, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            throw;
+        }
+        ELAG_HIP_CHECK(hipStreamEndCapture(st, &graph));
+        hipGraphExec_t exec = nullptr;
+        ELAG_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        if (graphs.size() >= 8) { (void)hipGraphExecDestroy(graphs.front().exec); graphs.erase(graphs.begin()); }
+        graphs.push_back(GraphEntry{rhs, sol, (int)precond, exec});
+        ELAG_HIP_CHECK(hipGraphLaunch(exec, st));
+    }
+};
+
+extern "C" {
+
+int elag_hip_hierarchy_create(elag_hip_hierarchy_t *out, int num_levels)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(out && num_levels > 0, "Hierarchy needs at least one level");
+        auto *H = new elag_hip_hierarchy_s();
+        H->lev.resize((size_t)num_levels);
+        *out = H;
+    });
+}
+
+static Level &level_of(elag_hip_hierarchy_t H, int l)
+{
+    ELAG_REQUIRE(H, "null hierarchy");
+    ELAG_REQUIRE(l >= 0 && l < (int)H->lev.size(), "Hierarchy::GetLevel(): Level = %d is out of range (%d levels)", l, (int)H->lev.size());
+    return H->lev[(size_t)l];
+}
+
+int elag_hip_hierarchy_set_operator(elag_hip_hierarchy_t H, int level, elag_hip_parcsr_t A)
+{
+    return guarded([&] { ELAG_REQUIRE(A, "null operator"); level_of(H, level).A = A; H->finalized = false; });
+}
+
+int elag_hip_hierarchy_set_prolongator(elag_hip_hierarchy_t H, int coarse_level, elag_hip_parcsr_t P)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(P, "null prolongator");
+        ELAG_REQUIRE(coarse_level >= 1, "\"P\" lives on levels >= 1");
+        level_of(H, coarse_level).P = P;
+        H->finalized = false;
+    });
+}
+
+int elag_hip_hierarchy_set_smoothers(elag_hip_hierarchy_t H, int level, elag_hip_smoother_t pre, elag_hip_smoother_t post)
+{
+    return guarded([&] {
+        Level &L = level_of(H, level);
+        L.pre = pre; L.post = post;
+        H->finalized = false;
+    });
+}
+
+int elag_hip_hierarchy_set_coarse_solver(elag_hip_hierarchy_t H, elag_hip_coarse_t C)
+{
+    return guarded([&] { ELAG_REQUIRE(H, "null hierarchy"); H->coarse = C; H->finalized = false; });
+}
+
+int elag_hip_hierarchy_finalize(elag_hip_hierarchy_t H, int use_graph)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(H, "null hierarchy");
+        for (size_t l = 0; l < H->lev.size(); l++) {
+            Level &L = H->lev[l];
+            if (L.pre) ELAG_REQUIRE(L.A && L.pre->n() == L.A->nrows(), "PreSmoother size mismatch on level %d", (int)l);
+            if (L.post) ELAG_REQUIRE(L.A && L.post->n() == L.A->nrows(), "PostSmoother size mismatch on level %d", (int)l);
+        }
+        if (H->coarse) ELAG_REQUIRE(H->lev.back().A && H->coarse->n == H->lev.back().A->nrows(), "CoarseSolver size mismatch");
+        H->finalize(use_graph != 0);
+    });
+}
+
+int elag_hip_hierarchy_apply(elag_hip_hierarchy_t H, const double *rhs, double *sol, int is_preconditioner, int loc)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(H && rhs && sol, "null argument");
+        ELAG_REQUIRE(H->finalized, "Hierarchy::Mult before Finalize()");
+        ELAG_REQUIRE(rhs != sol, "rhs and sol must not alias");
+        check_loc(loc);
+        const size_t n = (size_t)H->lev[0].A->nrows();
+        if (loc == ELAG_HIP_DEVICE) {
+            H->apply_device(rhs, sol, is_preconditioner != 0);
+        } else {
+            // host vectors are staged through the level-0 scratch (stable addresses keep the graph cache warm)
+            hipStream_t st = ctx().stream;
+            double *drhs = H->lev[0].resid, *dsol = H->lev[0].sol;
+            ELAG_HIP_CHECK(hipMemcpyAsync(drhs, rhs, n * sizeof(double), hipMemcpyHostToDevice, st));
+            if (!is_preconditioner) ELAG_HIP_CHECK(hipMemcpyAsync(dsol, sol, n * sizeof(double), hipMemcpyHostToDevice, st));
+            H->apply_device(drhs, dsol, is_preconditioner != 0);
+            ELAG_HIP_CHECK(hipMemcpyAsync(sol, dsol, n * sizeof(double), hipMemcpyDeviceToHost, st));
+            ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        }
+    });
+}
+
+int elag_hip_hierarchy_destroy(elag_hip_hierarchy_t H)
+{
+    return guarded([&] {
+        if (H) { (void)hipStreamSynchronize(ctx().stream); delete H; }
+    });
+}
+
+int elag_hip_hierarchy_build(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P, const elag_hip_parcsr_t *P,
+                             int fix_zero_rows, int relax_type, int sweeps, double damping, int cheby_order,
+                             double cheby_fraction, int coarse_kind, int coarse_iters, int use_graph)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(out && A && num_P >= 0 && (num_P == 0 || P), "bad argument");
+        std::unique_ptr<elag_hip_hierarchy_s> H(new elag_hip_hierarchy_s());
+        H->lev.resize((size_t)num_P + 1);
+        H->lev[0].A = A;
+        for (int l = 0; l < num_P; l++) {
+            ParCSR *Af = H->lev[(size_t)l].A;
+            ParCSR *Pl = P[l];
+            ELAG_REQUIRE(Pl, "null P on level %d", l);
+            // "Number of rows in P does not match A" check of Hierarchy.cpp:344-352
+            ELAG_REQUIRE(Pl->nrows() == Af->nrows(), "buildHierarchy: P[%d] has %d rows but A has %d", l, Pl->nrows(), Af->nrows());
+            elag_hip_parcsr_t Ac = nullptr;
+            int rc = elag_hip_parcsr_rap(Pl, Af, Pl, &Ac);
+            if (rc) fail(rc, "%s", elag_hip_last_error());
+            H->owned_mats.push_back(Ac);
+            if (fix_zero_rows) k::fix_zero_rows(Ac->diag, &Ac->offd);
+            H->lev[(size_t)l + 1].A = Ac;
+            H->lev[(size_t)l + 1].P = Pl;
+        }
+        for (int l = 0; l < num_P; l++) {
+            elag_hip_smoother_t S = nullptr;
+            int rc = elag_hip_smoother_create(&S, H->lev[(size_t)l].A, relax_type, sweeps, damping, 1.0, cheby_order, cheby_fraction);
+            if (rc) fail(rc, "%s", elag_hip_last_error());
+            H->owned_smoothers.push_back(S);
+            H->lev[(size_t)l].pre = S;
+            H->lev[(size_t)l].post = S;  // same parameters => same operator; scratch is not shared across calls
+        }
+        elag_hip_coarse_t C = nullptr;
+        int rc = elag_hip_coarse_create(&C, H->lev.back().A, coarse_kind, coarse_iters);
+        if (rc) fail(rc, "%s", elag_hip_last_error());
+        H->owned_coarse = C;
+        H->coarse = C;
+        H->finalize(use_graph != 0);
+        *out = H.release();
+    });
+}
+
+int elag_hip_hierarchy_get_operator(elag_hip_hierarchy_t H, int level, elag_hip_parcsr_t *A)
+{
+    return guarded([&] { ELAG_REQUIRE(A, "null output"); *A = level_of(H, level).A; });
+}
+
+int elag_hip_hierarchy_get_smoother(elag_hip_hierarchy_t H, int level, elag_hip_smoother_t *S)
+{
+    return guarded([&] { ELAG_REQUIRE(S, "null output"); *S = level_of(H, level).pre; });
+}
+
+int elag_hip_time_kernel(elag_hip_parcsr_t A, elag_hip_smoother_t S, int kernel, int reps, const double *x_dev,
+                         double *y_dev, double *ms_per_launch)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(A && x_dev && y_dev && ms_per_launch && reps > 0, "bad argument");
+        ELAG_REQUIRE(kernel >= 0 && kernel <= 2, "unknown kernel id %d", kernel);
+        const RelaxSmoother *R = nullptr;
+        if (kernel == 2) {
+            R = dynamic_cast<RelaxSmoother *>(S);
+            ELAG_REQUIRE(R && R->dinv, "kernel 2 needs a (l1-)Jacobi smoother");
+        }
+        hipStream_t st = ctx().stream;
+        hipEvent_t e0, e1;
+        ELAG_HIP_CHECK(hipEventCreate(&e0));
+        ELAG_HIP_CHECK(hipEventCreate(&e1));
+        Temp<double> f((size_t)A->nrows());
+        k::vec_fill(A->nrows(), 1.0, f);
+        auto launch = [&] {
+            k::SpmvArgs a;
+            a.x = x_dev; a.out = y_dev;
+            if (kernel == 0) { a.alpha = 1.0; }
+            else if (kernel == 1) { a.alpha = -1.0; a.f = f; a.gamma = 1.0; }
+            else { a.alpha = -1.0; a.f = f; a.gamma = 1.0; a.s = R->dinv; a.yin = x_dev; a.beta = 1.0; }
+            par_spmv(*A, a);
+        };
+        launch();  // warm
+        ELAG_HIP_CHECK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; i++) launch();
+        ELAG_HIP_CHECK(hipEventRecord(e1, st));
+        ELAG_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        ELAG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *ms_per_launch = (double)ms / reps;
+    });
+}
+
+int elag_hip_time_hierarchy(elag_hip_hierarchy_t H, const double *rhs_dev, double *sol_dev, int reps, double *ms_per_apply)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(H && rhs_dev && sol_dev && ms_per_apply && reps > 0, "bad argument");
+        ELAG_REQUIRE(H->finalized, "hierarchy not finalised");
+        hipStream_t st = ctx().stream;
+        hipEvent_t e0, e1;
+        ELAG_HIP_CHECK(hipEventCreate(&e0));
+        ELAG_HIP_CHECK(hipEventCreate(&e1));
+        H->apply_device(rhs_dev, sol_dev, true);
+        ELAG_HIP_CHECK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; i++) H->apply_device(rhs_dev, sol_dev, true);
+        ELAG_HIP_CHECK(hipEventRecord(e1, st));
+        ELAG_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        ELAG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *ms_per_apply = (double)ms / reps;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// Host-callable launchers of the hand-written gfx950 kernels (defined in kernels_*.hip).
+// Everything is enqueued on ctx().stream unless a stream is passed explicitly.
+#pragma once
+#include "common.hpp"
+
+namespace elag {
+namespace k {
+
+// -------------------------------------------------------------------------------------------------
+// Fused CSR SpMV family.  One kernel computes, per local row i,
+//     sum  = sum_j A_ij * x_j * (cs ? cs_j : 1)  [+ sum_j Offd_ij * xg_j * (csg ? csg_j : 1)]
+//     out_i = beta * yin_i + (s ? s_i : 1) * (gamma * f_i + alpha * (s2 ? s2_i : 1) * sum)
+//     out2_i = x_i * (cs ? cs_i : 1)                      (optional; square matrices only)
+// which covers y = alpha A x + beta y, r = b - A x, the l1-Jacobi sweep, the zero-guess pre-smooth
+// fused with the residual, and every Chebyshev step (see smoother.cpp).  Null pointers mean 0 / 1.
+// -------------------------------------------------------------------------------------------------
+struct SpmvArgs {
+    const double *x = nullptr, *cs = nullptr;
+    const double *xg = nullptr, *csg = nullptr;
+    const double *yin = nullptr;
+    double beta = 0.0;
+    const double *f = nullptr;
+    double gamma = 0.0;
+    const double *s = nullptr, *s2 = nullptr;
+    double alpha = 1.0;
+    double *out = nullptr, *out2 = nullptr;
+    // row subset (multi-GPU overlap): rows == nullptr -> all rows [0,nrows)
+    const int *rows = nullptr;
+    int nrows_sel = 0;
+    int skip_rows_with_offd = 0;  // interior pass: rows whose offd row is non-empty are left untouched
+};
+void spmv_fused(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, hipStream_t st = nullptr);
+
+// ---- vector kernels ----------------------------------------------------------------------------
+void vec_axpby(int n, double a, const double *x, double b, const double *y, double *out);  // out = a x + b y
+void vec_scale_mul(int n, double a, const double *x, const double *d, double *out);        // out = a x .* d
+void vec_add_scaled_mul(int n, const double *y, const double *d, const double *z, double c, const double *r,
+                        double *out);  // out = y + d .* (c r + z)   (z or r may be null)
+void vec_fill(int n, double v, double *x);
+void vec_dot(int n, const double *x, const double *y, double *d_result);  // deterministic 2-stage
+void vec_gather(int n, const int *idx, const double *x, double *buf, hipStream_t st = nullptr);
+void vec_hypre_random(int n, int seed, double *out);  // Lehmer 16807 stream, 2 r - 1 (host generated)
+
+// ---- row statistics ----------------------------------------------------------------------------
+// option as hypre_ParCSRComputeL1Norms (1,2,3,4) incl. the negative-diagonal sign flip.  d_bad counts zero norms.
+void l1_norms(const DevCSR &diag, const DevCSR *offd, int option, double *l1, int *d_bad);
+void extract_diagonal(const DevCSR &diag, double *d);  // 0 where the row stores no diagonal entry
+void vec_rsqrt(int n, const double *d, double *out, int *d_bad);            // 1/sqrt(d), counts d <= 0
+void vec_reciprocal_scale(int n, double w, const double *d, double *out);   // w / d
+int fix_zero_rows(DevCSR &diag, DevCSR *offd);
+void values_abs(int64_t n, const double *a, double *out);
+void values_sign(int64_t n, double *a);
+double reduce_max_abs(int64_t n, const double *a);
+double reduce_sum_sq(int64_t n, const double *a);
+double reduce_max(int64_t n, const double *a);
+
+// ---- sparse setup (two-pass, wave-level) -------------------------------------------------------
+void exclusive_scan(const int *in, int *out, int n);  // out has n+1 entries, out[n] = total
+void csr_transpose(const DevCSR &A, DevCSR &AT);
+void csr_sort_rows(DevCSR &A);
+void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C);  // C = A*B, columns ascending
+void csr_add(double a, const DevCSR &A, double b, const DevCSR &B, DevCSR &C);
+void csr_delete_zeros(const DevCSR &A, double tol, DevCSR &out);
+void csr_scale_rows(DevCSR &A, const double *d);
+void csr_copy(const DevCSR &A, DevCSR &out);
+
+// ---- dense coarse solve ------------------------------------------------------------------------
+void dense_gemv(int n, const double *Minv, const double *x, double *y);
+
+}  // namespace k
+}  // namespace elag

@@ -1,0 +1,525 @@
+// Setup-side sparse kernels for gfx950: scan, row sort, transpose, two-pass SpGEMM, sparse add.
+//
+// SpGEMM / add / row-sort share one "expand - sort - compress" (ESC) engine that is deterministic
+// (results do not depend on scheduling): a 256-thread workgroup owns a run of consecutive rows whose
+// expanded products fit in LDS, wavefronts expand rows (a wave-level exclusive scan over the B-row
+// lengths places every product), the workgroup sorts (row,col) keys with an in-LDS bitonic network,
+// and run heads sum their equal-key segment.  Pass 1 (symbolic) counts the distinct columns per row;
+// a device scan turns counts into row offsets; pass 2 (numeric) repeats the expansion with values and
+// writes C.  This is the two-pass structure of hypre's RAP / mfem::Mult mapped onto
+// wave64 + LDS instead of a per-thread marker array.
+#include "kernels.hpp"
+
+namespace elag {
+namespace k {
+
+namespace {
+
+constexpr int kBlock = 256;
+typedef unsigned long long u64;
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan of ints (n up to 2^31), 1024 items per block, recursive on the block sums
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread across the block; returns exclusive prefix, total in *total
+__device__ __forceinline__ int block_excl_scan(int v, int *sh /*>= 5 ints*/, int *total)
+{
+    const int incl = wave_incl_scan(v);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 63) sh[w] = incl;
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) {
+        const int s = sh[i];
+        if (i < w) off += s;
+        tot += s;
+    }
+    *total = tot;
+    return off + incl - v;
+}
+
+__global__ __launch_bounds__(kBlock) void scan_block_sums(const int *__restrict__ in, int n, int *__restrict__ bsum)
+{
+    __shared__ int sh[8];
+    const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+    int s = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (base + q < n) s += in[base + q];
+    int tot;
+    block_excl_scan(s, sh, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kBlock) void scan_block_final(const int *__restrict__ in, int n, const int *__restrict__ boff,
+                                                           int *__restrict__ out, int write_total)
+{
+    __shared__ int sh[8];
+    const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+    int v[4], s = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { v[q] = (base + q < n) ? in[base + q] : 0; s += v[q]; }
+    int tot;
+    int off = block_excl_scan(s, sh, &tot) + (boff ? boff[blockIdx.x] : 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (base + q < n) out[base + q] = off;
+        off += v[q];
+    }
+    if (write_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) out[n] = off;
+}
+
+}  // namespace
+
+void exclusive_scan(const int *in, int *out, int n)
+{
+    hipStream_t st = ctx().stream;
+    if (n == 0) { ELAG_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(int), st)); return; }
+    const int nb = (n + 1023) / 1024;
+    if (nb == 1) {
+        hipLaunchKernelGGL(scan_block_final, dim3(1), dim3(kBlock), 0, st, in, n, (const int *)nullptr, out, 1);
+    } else {
+        Temp<int> bsum((size_t)nb), boff((size_t)nb + 1);
+        hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(kBlock), 0, st, in, n, bsum.p);
+        exclusive_scan(bsum, boff, nb);
+        hipLaunchKernelGGL(scan_block_final, dim3(nb), dim3(kBlock), 0, st, in, n, (const int *)boff.p, out, 1);
+    }
+    ELAG_HIP_CHECK(hipGetLastError());
+}
+
+// ================================================================================================
+// ESC engine
+// ================================================================================================
+namespace {
+
+constexpr int kCap = 2048;    // products per chunk (by start offset); LDS holds 2*kCap
+constexpr int kBigCap = 8192; // single-row workgroups for rows with more products than kCap
+
+struct CsrView {
+    const int *I, *J;
+    const double *a;
+};
+
+// Expanders: ub(row) = number of expanded entries, expand(row) writes them at lds offset `off`.
+struct MatmulExpander {
+    CsrView A, B;
+    __device__ int ub_entry(int k) const { const int j = A.J[k]; return B.I[j + 1] - B.I[j]; }
+    // wave-cooperative expansion of one row
+    template <bool NUMERIC>
+    __device__ void expand(int row, unsigned rl, int off, u64 *key, double *val) const
+    {
+        const int lane = threadIdx.x & 63;
+        for (int k0 = A.I[row]; k0 < A.I[row + 1]; k0 += 64) {
+            const int k = k0 + lane;
+            int len = 0, j = 0;
+            if (k < A.I[row + 1]) { j = A.J[k]; len = B.I[j + 1] - B.I[j]; }
+            const int incl = wave_incl_scan(len);
+            int pos = off + incl - len;
+            if (len) {
+                const double av = NUMERIC ? A.a[k] : 0.0;
+                const int bs = B.I[j];
+                for (int q = 0; q < len; q++) {
+                    key[pos + q] = ((u64)rl << 32) | (unsigned)B.J[bs + q];
+                    if (NUMERIC) val[pos + q] = av * B.a[bs + q];
+                }
+            }
+            off += __shfl(incl, 63, 64);
+        }
+    }
+};
+
+struct AddExpander {
+    CsrView A, B;
+    double ca, cb;
+    template <bool NUMERIC>
+    __device__ void expand(int row, unsigned rl, int off, u64 *key, double *val) const
+    {
+        const int lane = threadIdx.x & 63;
+        const int as = A.I[row], na = A.I[row + 1] - as;
+        const int bs = B.I[row], nb = B.I[row + 1] - bs;
+        for (int q = lane; q < na; q += 64) {
+            key[off + q] = ((u64)rl << 32) | (unsigned)A.J[as + q];
+            if (NUMERIC) val[off + q] = ca * A.a[as + q];
+        }
+        for (int q = lane; q < nb; q += 64) {
+            key[off + na + q] = ((u64)rl << 32) | (unsigned)B.J[bs + q];
+            if (NUMERIC) val[off + na + q] = cb * B.a[bs + q];
+        }
+    }
+};
+
+struct SortExpander {  // identity: re-emit the row (used to sort columns inside rows)
+    CsrView A;
+    template <bool NUMERIC>
+    __device__ void expand(int row, unsigned rl, int off, u64 *key, double *val) const
+    {
+        const int lane = threadIdx.x & 63;
+        const int as = A.I[row], na = A.I[row + 1] - as;
+        for (int q = lane; q < na; q += 64) {
+            key[off + q] = ((u64)rl << 32) | (unsigned)A.J[as + q];
+            if (NUMERIC) val[off + q] = A.a[as + q];
+        }
+    }
+};
+
+template <bool HAS_VAL>
+__device__ void bitonic_sort_lds(u64 *key, double *val, int n2)
+{
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (n2 >> 1); t += kBlock) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int p = i | j;
+                const bool up = ((i & k) == 0);
+                const u64 ki = key[i], kp = key[p];
+                if ((ki > kp) == up) {
+                    key[i] = kp; key[p] = ki;
+                    if (HAS_VAL) { const double t2 = val[i]; val[i] = val[p]; val[p] = t2; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ int lower_bound_dev(const int *a, int n, int v)
+{
+    int lo = 0, hi = n;  // first index in [0,n] with a[idx] >= v
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// NMAX: LDS capacity in entries.  BIG: one listed row per workgroup; otherwise chunks by start offset.
+template <int NMAX, bool BIG, bool NUMERIC, class Expander>
+__global__ __launch_bounds__(kBlock) void esc_kernel(int nrows, const int *__restrict__ ubscan /*nrows+1*/,
+                                                     const int *__restrict__ ub, const int *__restrict__ biglist,
+                                                     Expander ex, int *__restrict__ rownnz,
+                                                     const int *__restrict__ CI, int *__restrict__ CJ, double *__restrict__ Ca)
+{
+    __shared__ u64 key[NMAX];
+    __shared__ double val[NUMERIC ? NMAX : 1];
+    __shared__ int sh[8];
+    __shared__ int s_r0, s_r1;
+    int r0, r1, base, count;
+    if (BIG) {
+        r0 = biglist[blockIdx.x]; r1 = r0 + 1; base = 0; count = ub[r0];
+    } else {
+        if (threadIdx.x == 0) {
+            s_r0 = lower_bound_dev(ubscan, nrows, (int)blockIdx.x * kCap);
+            s_r1 = lower_bound_dev(ubscan, nrows, ((int)blockIdx.x + 1) * kCap);
+        }
+        __syncthreads();
+        r0 = s_r0; r1 = s_r1;
+        if (r0 >= r1) return;
+        base = ubscan[r0]; count = ubscan[r1] - base;
+    }
+    if (count == 0) return;
+    int n2 = 64;
+    while (n2 < count) n2 <<= 1;
+    // expand: one wavefront per row, round-robin
+    const int w = threadIdx.x >> 6;
+    for (int row = r0 + w; row < r1; row += kBlock / 64) {
+        const int off = BIG ? 0 : (ubscan[row] - base);
+        if (BIG || ub[row] > 0) ex.template expand<NUMERIC>(row, (unsigned)(row - r0), off, key, val);
+    }
+    for (int i = count + threadIdx.x; i < n2; i += kBlock) key[i] = ~0ull;
+    __syncthreads();
+    bitonic_sort_lds<NUMERIC>(key, val, n2);
+    // heads of equal-key runs; each thread owns a contiguous slice
+    const int per = n2 / kBlock > 0 ? n2 / kBlock : 1;
+    const int beg = threadIdx.x * per;
+    int nheads = 0;
+    if (beg < n2)
+        for (int i = beg; i < beg + per; i++) {
+            const u64 kk = key[i];
+            if (kk != ~0ull && (i == 0 || key[i - 1] != kk)) nheads++;
+        }
+    if (!NUMERIC) {
+        // symbolic: distinct columns per row
+        if (beg < n2)
+            for (int i = beg; i < beg + per; i++) {
+                const u64 kk = key[i];
+                if (kk != ~0ull && (i == 0 || key[i - 1] != kk)) atomicAdd(&rownnz[r0 + (int)(kk >> 32)], 1);
+            }
+        return;
+    }
+    int tot;
+    int hidx = block_excl_scan(nheads, sh, &tot);
+    const int cbase = CI[r0];
+    if (beg < n2)
+        for (int i = beg; i < beg + per; i++) {
+            const u64 kk = key[i];
+            if (kk != ~0ull && (i == 0 || key[i - 1] != kk)) {
+                double s = val[i];
+                for (int q = i + 1; q < n2 && key[q] == kk; q++) s += val[q];
+                CJ[cbase + hidx] = (int)(kk & 0xffffffffu);
+                Ca[cbase + hidx] = s;
+                hidx++;
+            }
+        }
+}
+
+__global__ void matmul_ub_kernel(int nrows, CsrView A, CsrView B, int *__restrict__ ub)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nrows) return;
+    int s = 0;
+    for (int k = A.I[row]; k < A.I[row + 1]; k++) { const int j = A.J[k]; s += B.I[j + 1] - B.I[j]; }
+    ub[row] = s;
+}
+
+__global__ void add_ub_kernel(int nrows, CsrView A, CsrView B, int *__restrict__ ub)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nrows) return;
+    ub[row] = (A.I[row + 1] - A.I[row]) + (B.I[row + 1] - B.I[row]);
+}
+
+__global__ void rowlen_kernel(int nrows, const int *__restrict__ I, int *__restrict__ ub)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < nrows) ub[row] = I[row + 1] - I[row];
+}
+
+// split ub into chunkable part (ub <= kCap) and a list of big rows
+__global__ void split_big_kernel(int nrows, const int *__restrict__ ub, int *__restrict__ ub_small, int *__restrict__ biglist,
+                                 int *__restrict__ nbig, int *__restrict__ too_big)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nrows) return;
+    const int u = ub[row];
+    if (u > kCap) {
+        ub_small[row] = 0;
+        if (u > kBigCap) atomicAdd(too_big, 1);
+        else biglist[atomicAdd(nbig, 1)] = row;
+    } else ub_small[row] = u;
+}
+
+inline unsigned grid1(long long n, int b = kBlock) { return (unsigned)((n + b - 1) / b < 1 ? 1 : (n + b - 1) / b); }
+
+struct EscPlan {
+    int nrows;
+    Temp<int> ub, ub_small, ubscan, biglist, counters;
+    int total_small = 0, nbig = 0;
+    explicit EscPlan(int n) : nrows(n), ub((size_t)n), ub_small((size_t)n), ubscan((size_t)n + 1), biglist((size_t)n), counters(2) {}
+    void finish()
+    {
+        hipStream_t st = ctx().stream;
+        ELAG_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * sizeof(int), st));
+        hipLaunchKernelGGL(split_big_kernel, dim3(grid1(nrows)), dim3(kBlock), 0, st, nrows, ub.p, ub_small.p, biglist.p,
+                           counters.p, counters.p + 1);
+        exclusive_scan(ub_small, ubscan, nrows);
+        int h[2], tot;
+        ELAG_HIP_CHECK(hipMemcpyAsync(h, counters.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        ELAG_HIP_CHECK(hipMemcpyAsync(&tot, ubscan.p + nrows, sizeof(int), hipMemcpyDeviceToHost, st));
+        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        if (h[1] > 0)
+            fail(ELAG_HIP_ERR_ARG, "sparse product: %d rows expand to more than %d intermediate products (unsupported)", h[1], kBigCap);
+        nbig = h[0];
+        total_small = tot;
+    }
+    int nchunks() const { return (total_small + kCap - 1) / kCap; }
+};
+
+template <class Expander>
+void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C)
+{
+    hipStream_t st = ctx().stream;
+    const int n = plan.nrows;
+    Temp<int> rownnz((size_t)n);
+    ELAG_HIP_CHECK(hipMemsetAsync(rownnz, 0, sizeof(int) * (size_t)n, st));
+    const int nch = plan.nchunks();
+    if (nch)
+        hipLaunchKernelGGL((esc_kernel<2 * kCap, false, false, Expander>), dim3(nch), dim3(kBlock), 0, st, n, plan.ubscan.p,
+                           plan.ub_small.p, (const int *)nullptr, ex, rownnz.p, (const int *)nullptr, (int *)nullptr, (double *)nullptr);
+    if (plan.nbig)
+        hipLaunchKernelGGL((esc_kernel<kBigCap, true, false, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
+                           plan.ub.p, plan.biglist.p, ex, rownnz.p, (const int *)nullptr, (int *)nullptr, (double *)nullptr);
+    ELAG_HIP_CHECK(hipGetLastError());
+    int *CI = dev_alloc<int>((size_t)n + 1);
+    exclusive_scan(rownnz, CI, n);
+    int nnz = 0;
+    ELAG_HIP_CHECK(hipMemcpyAsync(&nnz, CI + n, sizeof(int), hipMemcpyDeviceToHost, st));
+    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    C.release();
+    C.nrows = n; C.ncols = ncols; C.nnz = nnz; C.I = CI;
+    C.J = dev_alloc<int>((size_t)nnz);
+    C.a = dev_alloc<double>((size_t)nnz);
+    if (nch)
+        hipLaunchKernelGGL((esc_kernel<2 * kCap, false, true, Expander>), dim3(nch), dim3(kBlock), 0, st, n, plan.ubscan.p,
+                           plan.ub_small.p, (const int *)nullptr, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
+    if (plan.nbig)
+        hipLaunchKernelGGL((esc_kernel<kBigCap, true, true, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
+                           plan.ub.p, plan.biglist.p, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
+    ELAG_HIP_CHECK(hipGetLastError());
+    C.choose_spmv_shape();
+}
+
+}  // namespace
+
+void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C)
+{
+    ELAG_REQUIRE(A.ncols == B.nrows, "spgemm: inner dimensions differ (%d vs %d)", A.ncols, B.nrows);
+    if (A.nrows == 0) { C.set_empty(0, B.ncols); return; }
+    EscPlan plan(A.nrows);
+    CsrView a{A.I, A.J, A.a}, b{B.I, B.J, B.a};
+    hipLaunchKernelGGL(matmul_ub_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, ctx().stream, A.nrows, a, b, plan.ub.p);
+    plan.finish();
+    MatmulExpander ex{a, b};
+    esc_run(plan, ex, B.ncols, C);
+}
+
+void csr_add(double ca, const DevCSR &A, double cb, const DevCSR &B, DevCSR &C)
+{
+    ELAG_REQUIRE(A.nrows == B.nrows && A.ncols == B.ncols, "add: incompatible matrix dimensions");
+    if (A.nrows == 0) { C.set_empty(0, A.ncols); return; }
+    EscPlan plan(A.nrows);
+    CsrView a{A.I, A.J, A.a}, b{B.I, B.J, B.a};
+    hipLaunchKernelGGL(add_ub_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, ctx().stream, A.nrows, a, b, plan.ub.p);
+    plan.finish();
+    AddExpander ex{a, b, ca, cb};
+    esc_run(plan, ex, A.ncols, C);
+}
+
+void csr_sort_rows(DevCSR &A)
+{
+    if (A.nrows == 0 || A.nnz == 0) return;
+    EscPlan plan(A.nrows);
+    hipLaunchKernelGGL(rowlen_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, ctx().stream, A.nrows, (const int *)A.I, plan.ub.p);
+    plan.finish();
+    SortExpander ex{CsrView{A.I, A.J, A.a}};
+    DevCSR out;
+    esc_run(plan, ex, A.ncols, out);  // duplicates (none expected) would be summed
+    out.lanes_per_row = A.lanes_per_row;
+    A = std::move(out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// transpose: column histogram -> scan -> atomic fill -> per-row sort (deterministic result)
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void col_hist_kernel(long long nnz, const int *__restrict__ J, int *__restrict__ cnt)
+{
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x)
+        atomicAdd(&cnt[J[k]], 1);
+}
+__global__ void transpose_fill_kernel(int nrows, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
+                                      int *__restrict__ cursor, int *__restrict__ TJ, double *__restrict__ Ta)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nrows) return;
+    for (int k = I[row]; k < I[row + 1]; k++) {
+        const int p = atomicAdd(&cursor[J[k]], 1);
+        TJ[p] = row;
+        Ta[p] = a[k];
+    }
+}
+}  // namespace
+
+void csr_transpose(const DevCSR &A, DevCSR &AT)
+{
+    hipStream_t st = ctx().stream;
+    AT.alloc(A.ncols, A.nrows, A.nnz);
+    Temp<int> cnt((size_t)A.ncols);
+    ELAG_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(A.ncols > 0 ? A.ncols : 1), st));
+    if (A.nnz) {
+        long long g = (A.nnz + kBlock - 1) / kBlock; if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(col_hist_kernel, dim3((unsigned)g), dim3(kBlock), 0, st, (long long)A.nnz, (const int *)A.J, cnt.p);
+    }
+    exclusive_scan(cnt, AT.I, A.ncols);
+    if (A.nnz) {
+        Temp<int> cursor((size_t)A.ncols);
+        ELAG_HIP_CHECK(hipMemcpyAsync(cursor, AT.I, sizeof(int) * (size_t)A.ncols, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(transpose_fill_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, st, A.nrows, (const int *)A.I,
+                           (const int *)A.J, (const double *)A.a, cursor.p, AT.J, AT.a);
+        ELAG_HIP_CHECK(hipGetLastError());
+        AT.choose_spmv_shape();
+        csr_sort_rows(AT);
+    }
+    AT.choose_spmv_shape();
+}
+
+// ------------------------------------------------------------------------------------------------
+// delete zeros / scale rows / copy
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void count_keep_kernel(int nrows, const int *__restrict__ I, const double *__restrict__ a, double tol, int *__restrict__ cnt)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nrows) return;
+    int c = 0;
+    for (int k = I[row]; k < I[row + 1]; k++) c += (fabs(a[k]) > tol);
+    cnt[row] = c;
+}
+__global__ void fill_keep_kernel(int nrows, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a, double tol,
+                                 const int *__restrict__ OI, int *__restrict__ OJ, double *__restrict__ Oa)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nrows) return;
+    int p = OI[row];
+    for (int k = I[row]; k < I[row + 1]; k++)
+        if (fabs(a[k]) > tol) { OJ[p] = J[k]; Oa[p] = a[k]; p++; }
+}
+__global__ void scale_rows_kernel(int nrows, const int *__restrict__ I, double *__restrict__ a, const double *__restrict__ d)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nrows) return;
+    const double s = d[row];
+    for (int k = I[row]; k < I[row + 1]; k++) a[k] *= s;
+}
+}  // namespace
+
+void csr_delete_zeros(const DevCSR &A, double tol, DevCSR &out)
+{
+    hipStream_t st = ctx().stream;
+    const int n = A.nrows;
+    Temp<int> cnt((size_t)n);
+    int *OI = dev_alloc<int>((size_t)n + 1);
+    if (n) hipLaunchKernelGGL(count_keep_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, (const int *)A.I, (const double *)A.a, tol, cnt.p);
+    exclusive_scan(cnt, OI, n);
+    int nnz = 0;
+    ELAG_HIP_CHECK(hipMemcpyAsync(&nnz, OI + n, sizeof(int), hipMemcpyDeviceToHost, st));
+    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    out.release();
+    out.nrows = n; out.ncols = A.ncols; out.nnz = nnz; out.I = OI;
+    out.J = dev_alloc<int>((size_t)nnz);
+    out.a = dev_alloc<double>((size_t)nnz);
+    if (n) hipLaunchKernelGGL(fill_keep_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, (const int *)A.I, (const int *)A.J,
+                              (const double *)A.a, tol, (const int *)OI, out.J, out.a);
+    ELAG_HIP_CHECK(hipGetLastError());
+    out.choose_spmv_shape();
+}
+
+void csr_scale_rows(DevCSR &A, const double *d)
+{
+    if (A.nrows == 0) return;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, ctx().stream, A.nrows, (const int *)A.I, A.a, d);
+    ELAG_HIP_CHECK(hipGetLastError());
+}
+
+void csr_copy(const DevCSR &A, DevCSR &out)
+{
+    hipStream_t st = ctx().stream;
+    out.alloc(A.nrows, A.ncols, A.nnz);
+    ELAG_HIP_CHECK(hipMemcpyAsync(out.I, A.I, sizeof(int) * ((size_t)A.nrows + 1), hipMemcpyDeviceToDevice, st));
+    if (A.nnz) {
+        ELAG_HIP_CHECK(hipMemcpyAsync(out.J, A.J, sizeof(int) * (size_t)A.nnz, hipMemcpyDeviceToDevice, st));
+        ELAG_HIP_CHECK(hipMemcpyAsync(out.a, A.a, sizeof(double) * (size_t)A.nnz, hipMemcpyDeviceToDevice, st));
+    }
+    out.lanes_per_row = A.lanes_per_row;
+}
+
+}  // namespace k
+}  // namespace elag

@@ -1,0 +1,516 @@
+// CSR SpMV family, vector kernels and row statistics for gfx950 (wave64).
+//
+// SpMV design (HBM-bound, no MFMA): a group of LPR lanes (power of two, 1..64, chosen from nnz/row)
+// owns one row, so a 64-lane wavefront covers 64/LPR consecutive rows and its loads of J/a sweep one
+// contiguous span of the CSR arrays (coalesced 4-/8-byte accesses); partial sums are combined with
+// cross-lane shuffles inside the group and lane 0 applies the fused epilogue.  The x gathers are served
+// from L2 / Infinity Cache.  Algorithmic bytes per launch: 12 nnz + 4 (n+1) + 8 ncols + 8 n (+8 n per extra
+// epilogue vector), see DESIGN.md.
+#include "kernels.hpp"
+
+namespace elag {
+namespace k {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+template <int LPR>
+__device__ __forceinline__ double group_reduce(double v)
+{
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int LPR, bool HAS_OFFD, bool HAS_CS>
+__global__ __launch_bounds__(kBlock) void spmv_fused_kernel(
+    int nrows, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
+    const int *__restrict__ oI, const int *__restrict__ oJ, const double *__restrict__ oa, SpmvArgs p)
+{
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int grp = gid / LPR;
+    const int lane = threadIdx.x & (LPR - 1);
+    const int nsel = p.rows ? p.nrows_sel : nrows;
+    if (grp >= nsel) return;
+    const int row = p.rows ? p.rows[grp] : grp;
+
+    int os = 0, oe = 0;
+    if (HAS_OFFD || p.skip_rows_with_offd) {
+        if (oI) { os = oI[row]; oe = oI[row + 1]; }
+        if (p.skip_rows_with_offd && oe > os) return;
+    }
+
+    const int s = I[row], e = I[row + 1];
+    double sum = 0.0;
+    const double *__restrict__ x = p.x;
+    if (HAS_CS) {
+        const double *__restrict__ cs = p.cs;
+        for (int k = s + lane; k < e; k += LPR) {
+            const int j = J[k];
+            sum += a[k] * (x[j] * cs[j]);
+        }
+    } else {
+        int k = s + lane;
+        // two independent loads in flight per lane
+        for (; k + LPR < e; k += 2 * LPR) {
+            const int j0 = J[k], j1 = J[k + LPR];
+            const double a0 = a[k], a1 = a[k + LPR];
+            sum += a0 * x[j0];
+            sum += a1 * x[j1];
+        }
+        if (k < e) sum += a[k] * x[J[k]];
+    }
+    if (HAS_OFFD) {
+        const double *__restrict__ xg = p.xg;
+        if (HAS_CS && p.csg) {
+            for (int k = os + lane; k < oe; k += LPR) { const int j = oJ[k]; sum += oa[k] * (xg[j] * p.csg[j]); }
+        } else {
+            for (int k = os + lane; k < oe; k += LPR) sum += oa[k] * xg[oJ[k]];
+        }
+    }
+    sum = group_reduce<LPR>(sum);
+    if (lane == 0) {
+        double t = p.alpha * sum;
+        if (p.s2) t *= p.s2[row];
+        if (p.f) t += p.gamma * p.f[row];
+        if (p.s) t *= p.s[row];
+        if (p.yin) t += p.beta * p.yin[row];
+        p.out[row] = t;
+        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
+    }
+}
+
+template <int LPR>
+void launch_lpr(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hipStream_t st)
+{
+    const int nsel = p.rows ? p.nrows_sel : A.nrows;
+    if (nsel == 0) return;
+    const long long threads = (long long)nsel * LPR;
+    const unsigned grid = (unsigned)((threads + kBlock - 1) / kBlock);
+    const bool has_offd = offd && offd->nnz > 0 && !p.skip_rows_with_offd;
+    const bool has_cs = p.cs != nullptr;
+    const int *oI = offd ? offd->I : nullptr;
+    const int *oJ = offd ? offd->J : nullptr;
+    const double *oa = offd ? offd->a : nullptr;
+    if (has_offd) {
+        if (has_cs)
+            hipLaunchKernelGGL((spmv_fused_kernel<LPR, true, true>), dim3(grid), dim3(kBlock), 0, st, A.nrows, A.I, A.J, A.a, oI, oJ, oa, p);
+        else
+            hipLaunchKernelGGL((spmv_fused_kernel<LPR, true, false>), dim3(grid), dim3(kBlock), 0, st, A.nrows, A.I, A.J, A.a, oI, oJ, oa, p);
+    } else {
+        if (has_cs)
+            hipLaunchKernelGGL((spmv_fused_kernel<LPR, false, true>), dim3(grid), dim3(kBlock), 0, st, A.nrows, A.I, A.J, A.a, oI, oJ, oa, p);
+        else
+            hipLaunchKernelGGL((spmv_fused_kernel<LPR, false, false>), dim3(grid), dim3(kBlock), 0, st, A.nrows, A.I, A.J, A.a, oI, oJ, oa, p);
+    }
+    ELAG_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+
+void spmv_fused(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, hipStream_t st)
+{
+    if (!st) st = ctx().stream;
+    switch (A.lanes_per_row) {
+    case 1: launch_lpr<1>(A, offd, args, st); break;
+    case 2: launch_lpr<2>(A, offd, args, st); break;
+    case 4: launch_lpr<4>(A, offd, args, st); break;
+    case 8: launch_lpr<8>(A, offd, args, st); break;
+    case 16: launch_lpr<16>(A, offd, args, st); break;
+    case 32: launch_lpr<32>(A, offd, args, st); break;
+    default: launch_lpr<64>(A, offd, args, st); break;
+    }
+}
+
+// ================================================================================================
+// vector kernels: grid-stride, 2 doubles per lane per access where alignment allows
+// ================================================================================================
+namespace {
+
+inline unsigned vec_grid(long long n)
+{
+    long long g = (n + kBlock - 1) / kBlock;
+    const long long cap = 2048;  // ~8 blocks per CU, grid-stride beyond
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+__global__ void axpby_kernel(int n, double a, const double *__restrict__ x, double b, const double *__restrict__ y,
+                             double *__restrict__ out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double t = 0.0;
+        if (x) t = a * x[i];
+        if (y) t += b * y[i];
+        out[i] = t;
+    }
+}
+
+__global__ void scale_mul_kernel(int n, double a, const double *__restrict__ x, const double *__restrict__ d,
+                                 double *__restrict__ out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = a * x[i] * (d ? d[i] : 1.0);
+}
+
+__global__ void add_scaled_mul_kernel(int n, const double *__restrict__ y, const double *__restrict__ d,
+                                      const double *__restrict__ z, double c, const double *__restrict__ r,
+                                      double *__restrict__ out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double t = z ? z[i] : 0.0;
+        if (r) t += c * r[i];
+        out[i] = (y ? y[i] : 0.0) + d[i] * t;
+    }
+}
+
+__global__ void fill_kernel(int n, double v, double *__restrict__ x)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] = v;
+}
+
+__global__ void gather_kernel(int n, const int *__restrict__ idx, const double *__restrict__ x, double *__restrict__ buf)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) buf[i] = x[idx[i]];
+}
+
+__device__ __forceinline__ double block_reduce_sum(double v, double *sh)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) r += sh[i];
+    return r;  // valid on thread 0
+}
+
+__device__ __forceinline__ double block_reduce_max(double v, double *sh)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    double r = v;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) r = fmax(r, sh[i]);
+    return r;
+}
+
+constexpr int kRedBlocks = 512;
+
+// mode 0: sum x*y ; 1: sum x*x ; 2: max |x| ; 3: max x
+__global__ __launch_bounds__(kBlock) void reduce_stage1(long long n, const double *__restrict__ x,
+                                                        const double *__restrict__ y, int mode, double *__restrict__ part)
+{
+    __shared__ double sh[kBlock / 64];
+    double acc = (mode == 3) ? -1.0e308 : 0.0;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+        const double v = x[i];
+        if (mode == 0) acc += v * y[i];
+        else if (mode == 1) acc += v * v;
+        else if (mode == 2) acc = fmax(acc, fabs(v));
+        else acc = fmax(acc, v);
+    }
+    const double r = (mode >= 2) ? block_reduce_max(acc, sh) : block_reduce_sum(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(kBlock) void reduce_stage2(int nparts, const double *__restrict__ part, int mode,
+                                                        double *__restrict__ result)
+{
+    __shared__ double sh[kBlock / 64];
+    double acc = (mode == 3) ? -1.0e308 : 0.0;
+    for (int i = threadIdx.x; i < nparts; i += kBlock) acc = (mode >= 2) ? fmax(acc, part[i]) : acc + part[i];
+    const double r = (mode >= 2) ? block_reduce_max(acc, sh) : block_reduce_sum(acc, sh);
+    if (threadIdx.x == 0) result[0] = r;
+}
+
+double *reduce_scratch()
+{
+    static double *p = nullptr;
+    if (!p) p = dev_alloc<double>(kRedBlocks);
+    return p;
+}
+
+void reduce_launch(long long n, const double *x, const double *y, int mode, double *d_result)
+{
+    hipStream_t st = ctx().stream;
+    long long g = (n + kBlock - 1) / kBlock;
+    const int grid = (int)(g < 1 ? 1 : (g > kRedBlocks ? kRedBlocks : g));
+    double *part = reduce_scratch();
+    hipLaunchKernelGGL(reduce_stage1, dim3(grid), dim3(kBlock), 0, st, n, x, y, mode, part);
+    hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(kBlock), 0, st, grid, part, mode, d_result);
+    ELAG_HIP_CHECK(hipGetLastError());
+}
+
+double reduce_to_host(long long n, const double *x, int mode)
+{
+    if (n == 0) return 0.0;
+    Context &c = ctx();
+    reduce_launch(n, x, nullptr, mode, c.d_scalar);
+    ELAG_HIP_CHECK(hipMemcpyAsync(c.h_scalar, c.d_scalar, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    ELAG_HIP_CHECK(hipStreamSynchronize(c.stream));
+    return c.h_scalar[0];
+}
+
+}  // namespace
+
+void vec_axpby(int n, double a, const double *x, double b, const double *y, double *out)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(axpby_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, n, a, x, b, y, out);
+    ELAG_HIP_CHECK(hipGetLastError());
+}
+void vec_scale_mul(int n, double a, const double *x, const double *d, double *out)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(scale_mul_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, n, a, x, d, out);
+    ELAG_HIP_CHECK(hipGetLastError());
+}
+void vec_add_scaled_mul(int n, const double *y, const double *d, const double *z, double c, const double *r, double *out)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(add_scaled_mul_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, n, y, d, z, c, r, out);
+    ELAG_HIP_CHECK(hipGetLastError());
+}
+void vec_fill(int n, double v, double *x)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(fill_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, n, v, x);
+    ELAG_HIP_CHECK(hipGetLastError());
+}
+void vec_gather(int n, const int *idx, const double *x, double *buf, hipStream_t st)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(gather_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, st ? st : ctx().stream, n, idx, x, buf);
+    ELAG_HIP_CHECK(hipGetLastError());
+}
+void vec_dot(int n, const double *x, const double *y, double *d_result)
+{
+    if (n == 0) { ELAG_HIP_CHECK(hipMemsetAsync(d_result, 0, sizeof(double), ctx().stream)); return; }
+    reduce_launch(n, x, y, 0, d_result);
+}
+
+void vec_hypre_random(int n, int seed, double *out)
+{
+    // hypre_SeqVectorSetRandomValues: sequential Lehmer stream (a = 16807, m = 2^31 - 1), value 2 r - 1.
+    // Generated on the host: the recurrence is inherently serial and runs once per Chebyshev setup.
+    std::vector<double> h((size_t)n);
+    const long long a = 16807, m = 2147483647;
+    long long s = seed;
+    for (int i = 0; i < n; i++) { s = (a * s) % m; h[(size_t)i] = 2.0 * ((double)s / (double)m) - 1.0; }
+    if (n) {
+        ELAG_HIP_CHECK(hipMemcpyAsync(out, h.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx().stream));
+        ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    }
+}
+
+double reduce_max_abs(int64_t n, const double *a) { return reduce_to_host(n, a, 2); }
+double reduce_sum_sq(int64_t n, const double *a) { return reduce_to_host(n, a, 1); }
+double reduce_max(int64_t n, const double *a) { return reduce_to_host(n, a, 3); }
+
+// ================================================================================================
+// row statistics
+// ================================================================================================
+namespace {
+
+// one 8-lane group per row
+__global__ __launch_bounds__(kBlock) void l1_norms_kernel(int n, const int *__restrict__ I, const int *__restrict__ J,
+                                                          const double *__restrict__ a, const int *__restrict__ oI,
+                                                          const double *__restrict__ oa, int option,
+                                                          double *__restrict__ l1, int *__restrict__ bad)
+{
+    constexpr int LPR = 8;
+    const int row = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int lane = threadIdx.x & (LPR - 1);
+    if (row >= n) return;
+    double sd = 0.0, so = 0.0, dneg = 0.0;
+    for (int k = I[row] + lane; k < I[row + 1]; k += LPR) {
+        const double v = a[k];
+        const bool isd = (J[k] == row);
+        if (isd && v < 0.0) dneg = 1.0;
+        if (option == 1) sd += fabs(v);
+        else if (option == 3) sd += v * v;
+        else if (isd) sd += fabs(v);  // options 2, 4
+    }
+    if (oI)
+        for (int k = oI[row] + lane; k < oI[row + 1]; k += LPR) {
+            const double v = oa[k];
+            so += (option == 3) ? v * v : fabs(v);
+        }
+    sd = group_reduce<LPR>(sd);
+    so = group_reduce<LPR>(so);
+    dneg = group_reduce<LPR>(dneg);
+    if (lane == 0) {
+        double r;
+        if (option == 4) { r = sd + 0.5 * so; if (r <= 4.0 / 3.0 * sd) r = sd; }
+        else r = sd + so;
+        if (dneg > 0.0) r = -r;
+        if (fabs(r) < 2.220446049250313e-16) atomicAdd(bad, 1);
+        l1[row] = r;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void extract_diag_kernel(int n, const int *__restrict__ I, const int *__restrict__ J,
+                                                              const double *__restrict__ a, double *__restrict__ d)
+{
+    constexpr int LPR = 8;
+    const int row = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int lane = threadIdx.x & (LPR - 1);
+    if (row >= n) return;
+    double v = 0.0;
+    for (int k = I[row] + lane; k < I[row + 1]; k += LPR)
+        if (J[k] == row) v += a[k];
+    v = group_reduce<LPR>(v);
+    if (lane == 0) d[row] = v;
+}
+
+__global__ void rsqrt_kernel(int n, const double *__restrict__ d, double *__restrict__ out, int *__restrict__ bad)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double v = d[i];
+        if (!(v > 0.0)) atomicAdd(bad, 1);
+        out[i] = 1.0 / sqrt(v);
+    }
+}
+
+__global__ void recip_scale_kernel(int n, double w, const double *__restrict__ d, double *__restrict__ out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = w / d[i];
+}
+
+__global__ __launch_bounds__(kBlock) void fix_zero_rows_kernel(int n, const int *__restrict__ I, const int *__restrict__ J,
+                                                               double *__restrict__ a, const int *__restrict__ oI,
+                                                               double *__restrict__ oa, int *__restrict__ nfixed)
+{
+    constexpr int LPR = 8;
+    const int row = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int lane = threadIdx.x & (LPR - 1);
+    if (row >= n) return;
+    double l1 = 0.0;
+    for (int k = I[row] + lane; k < I[row + 1]; k += LPR) l1 += fabs(a[k]);
+    if (oI)
+        for (int k = oI[row] + lane; k < oI[row + 1]; k += LPR) l1 += fabs(oa[k]);
+    l1 = group_reduce<LPR>(l1);
+    if (l1 <= 0.0) {
+        for (int k = I[row] + lane; k < I[row + 1]; k += LPR) a[k] = (J[k] == row) ? 1.0 : 0.0;
+        if (oI)
+            for (int k = oI[row] + lane; k < oI[row + 1]; k += LPR) oa[k] = 0.0;
+        if (lane == 0) atomicAdd(nfixed, 1);
+    }
+}
+
+__global__ void abs_kernel(long long n, const double *__restrict__ a, double *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = fabs(a[i]);
+}
+
+__global__ void sign_kernel(long long n, double *__restrict__ a)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double v = a[i];
+        a[i] = (fabs(v) > 1e-9) ? ((v > 0.) ? 1.0 : -1.0) : 0.0;
+    }
+}
+
+inline unsigned row_grid(int n, int lpr) { return (unsigned)(((long long)n * lpr + kBlock - 1) / kBlock); }
+
+int read_counter(int *d_cnt)
+{
+    int h = 0;
+    ELAG_HIP_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+    ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    return h;
+}
+
+}  // namespace
+
+void l1_norms(const DevCSR &diag, const DevCSR *offd, int option, double *l1, int *d_bad)
+{
+    if (diag.nrows == 0) return;
+    const bool ho = offd && offd->nnz > 0;
+    hipLaunchKernelGGL(l1_norms_kernel, dim3(row_grid(diag.nrows, 8)), dim3(kBlock), 0, ctx().stream, diag.nrows,
+                       diag.I, diag.J, diag.a, ho ? offd->I : nullptr, ho ? offd->a : nullptr, option, l1, d_bad);
+    ELAG_HIP_CHECK(hipGetLastError());
+}
+
+void extract_diagonal(const DevCSR &diag, double *d)
+{
+    if (diag.nrows == 0) return;
+    hipLaunchKernelGGL(extract_diag_kernel, dim3(row_grid(diag.nrows, 8)), dim3(kBlock), 0, ctx().stream, diag.nrows,
+                       diag.I, diag.J, diag.a, d);
+    ELAG_HIP_CHECK(hipGetLastError());
+}
+
+void vec_rsqrt(int n, const double *d, double *out, int *d_bad)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(rsqrt_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, n, d, out, d_bad);
+    ELAG_HIP_CHECK(hipGetLastError());
+}
+
+void vec_reciprocal_scale(int n, double w, const double *d, double *out)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(recip_scale_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, n, w, d, out);
+    ELAG_HIP_CHECK(hipGetLastError());
+}
+
+int fix_zero_rows(DevCSR &diag, DevCSR *offd)
+{
+    if (diag.nrows == 0) return 0;
+    Temp<int> cnt(1);
+    ELAG_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int), ctx().stream));
+    const bool ho = offd && offd->nnz > 0;
+    hipLaunchKernelGGL(fix_zero_rows_kernel, dim3(row_grid(diag.nrows, 8)), dim3(kBlock), 0, ctx().stream, diag.nrows,
+                       diag.I, diag.J, diag.a, ho ? offd->I : nullptr, ho ? offd->a : nullptr, cnt.p);
+    ELAG_HIP_CHECK(hipGetLastError());
+    return read_counter(cnt);
+}
+
+void values_abs(int64_t n, const double *a, double *out)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(abs_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, (long long)n, a, out);
+    ELAG_HIP_CHECK(hipGetLastError());
+}
+
+void values_sign(int64_t n, double *a)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(sign_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, (long long)n, a);
+    ELAG_HIP_CHECK(hipGetLastError());
+}
+
+// ================================================================================================
+// dense coarse apply: y = Minv x, one wavefront per row (n <= 4096; Minv stays in L2)
+// ================================================================================================
+namespace {
+__global__ __launch_bounds__(kBlock) void dense_gemv_kernel(int n, const double *__restrict__ M, const double *__restrict__ x,
+                                                            double *__restrict__ y)
+{
+    const int row = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const double *__restrict__ m = M + (size_t)row * n;
+    double s = 0.0;
+    for (int j = lane; j < n; j += 64) s += m[j] * x[j];
+    s = group_reduce<64>(s);
+    if (lane == 0) y[row] = s;
+}
+}  // namespace
+
+void dense_gemv(int n, const double *Minv, const double *x, double *y)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(dense_gemv_kernel, dim3(row_grid(n, 64)), dim3(kBlock), 0, ctx().stream, n, Minv, x, y);
+    ELAG_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace k
+}  // namespace elag

@@ -1,0 +1,51 @@
+// Device-resident ParCSR matrix (hypre_ParCSRMatrix equivalent) and its halo-exchanging products.
+#pragma once
+#include "kernels.hpp"
+
+struct elag_hip_parcsr_s {
+    elag::DevCSR diag, offd;
+    std::vector<int64_t> col_map_offd;
+    int64_t first_row = 0, first_col = 0, global_rows = 0, global_cols = 0;
+
+    // comm package (hypre_ParCSRCommPkg) -- host copies drive the RCCL calls
+    std::vector<int> send_procs, send_starts, send_elmts, recv_procs, recv_starts;
+    int *d_send_elmts = nullptr;
+    double *d_send_buf = nullptr;  // send_total
+    double *d_ghost = nullptr;     // num_cols_offd
+    // rows whose offd part is non-empty (boundary rows): processed after the halo has arrived
+    int *d_boundary_rows = nullptr;
+    int n_boundary = 0;
+
+    // explicit transposes, built on first MatvecT (deterministic gather form instead of scatter-add)
+    std::unique_ptr<elag::DevCSR> diagT, offdT;
+    std::unique_ptr<elag::DevCSR> scatT;  // num_cols_diag x send_total, unit entries: y[send_elmts[k]] += buf[k]
+    double *d_rev_send = nullptr;         // num_cols_offd  (offd^T x)
+    double *d_rev_recv = nullptr;         // send_total
+
+    elag_hip_parcsr_s() = default;
+    ~elag_hip_parcsr_s();
+    elag_hip_parcsr_s(const elag_hip_parcsr_s &) = delete;
+    elag_hip_parcsr_s &operator=(const elag_hip_parcsr_s &) = delete;
+
+    int nrows() const { return diag.nrows; }
+    int ncols() const { return diag.ncols; }
+    int ncols_offd() const { return offd.ncols; }
+    int send_total() const { return send_starts.empty() ? 0 : send_starts.back(); }
+    bool has_halo() const { return offd.ncols > 0 && offd.nnz > 0; }
+
+    void finish_setup();      // device copies of the comm lists, boundary row list, buffers
+    void ensure_transpose();  // diagT / offdT / scatT
+};
+
+namespace elag {
+typedef elag_hip_parcsr_s ParCSR;
+
+// out_i = beta*yin_i + s_i*(gamma*f_i + alpha*s2_i*(A x)_i) with the halo exchange overlapped with the
+// interior rows.  `a.x` is the local vector (length ncols of diag); a.xg / a.csg are filled in here.
+void par_spmv(ParCSR &A, k::SpmvArgs a);
+// y = alpha*A^T x + beta*y  (x: local rows, y: local columns of diag)
+void par_spmvT(ParCSR &A, double alpha, const double *x, double beta, double *y);
+
+// Build a single-rank ParCSR from a device CSR (takes ownership of `d`).
+ParCSR *parcsr_from_diag(DevCSR &&d, int64_t first_row, int64_t first_col, int64_t grows, int64_t gcols);
+}  // namespace elag

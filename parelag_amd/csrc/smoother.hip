@@ -1,0 +1,450 @@
+// Smoother implementations + ABI.  Algorithms: SURVEY App. A.2/A.3 (hypre_ParCSRRelax types 0/1/16,
+// hypre_ParCSRComputeL1Norms, hypre_ParCSRMaxEigEstimateCG), HiptmairSmoother.cpp:48-109.
+#include "smoother.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+#include "comm.hpp"
+#include "staging.hpp"
+
+namespace elag {
+
+RelaxSmoother::~RelaxSmoother() { dev_free(dinv); dev_free(ds); dev_free(r); dev_free(za); dev_free(zb); }
+
+static int read_int(int *d)
+{
+    int h = 0;
+    ELAG_HIP_CHECK(hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+    ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    return h;
+}
+
+static double read_scalar(const double *d)
+{
+    Context &c = ctx();
+    ELAG_HIP_CHECK(hipMemcpyAsync(c.h_scalar, d, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    ELAG_HIP_CHECK(hipStreamSynchronize(c.stream));
+    return c.h_scalar[0];
+}
+
+void RelaxSmoother::setup()
+{
+    const int nn = n();
+    Temp<int> bad(1);
+    ELAG_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), ctx().stream));
+    if (type == ELAG_HIP_SMOOTHER_L1_JACOBI || type == ELAG_HIP_SMOOTHER_JACOBI) {
+        Temp<double> l1((size_t)nn);
+        if (type == ELAG_HIP_SMOOTHER_L1_JACOBI) {
+            // mfem::HypreSmoother::SetOperator: l1_norms = hypre_ParCSRComputeL1Norms(A, 1)
+            k::l1_norms(A->diag, &A->offd, 1, l1, bad);
+            if (read_int(bad)) fail(ELAG_HIP_ERR_NUMERIC, "l1-Jacobi: matrix has a zero l1 row norm");
+        } else {
+            k::extract_diagonal(A->diag, l1);
+        }
+        dinv = dev_alloc<double>((size_t)nn);
+        k::vec_reciprocal_scale(nn, weight, l1, dinv);
+        if (sweeps > 1 || true) { /* nothing else: the alt vector is supplied by the caller */ }
+    } else if (type == ELAG_HIP_SMOOTHER_CHEBYSHEV) {
+        Temp<double> d((size_t)nn);
+        k::extract_diagonal(A->diag, d);
+        ds = dev_alloc<double>((size_t)nn);
+        k::vec_rsqrt(nn, d, ds, bad);
+        if (read_int(bad)) fail(ELAG_HIP_ERR_NUMERIC, "Chebyshev: matrix has a non-positive diagonal entry");
+        r = dev_alloc<double>((size_t)nn);
+        za = dev_alloc<double>((size_t)nn);
+        zb = dev_alloc<double>((size_t)nn);
+        estimate_eigs();
+        compute_coefs();
+    } else {
+        fail(ELAG_HIP_ERR_ARG,
+             "relax type %d is not available on the device (sequential per rank); GPU configurations select "
+             "\"L1 Jacobi\" (1), \"Jacobi\" (0) or \"Chebyshev\" (16)", type);
+    }
+    ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+}
+
+void RelaxSmoother::compute_coefs()
+{
+    int ord = std::min(std::max(order, 1), 4);
+    cheby_order = ord - 1;
+    const double ub = max_eig * 1.1;
+    const double lb = (ub - min_eig) * fraction + min_eig;
+    const double th = (ub + lb) / 2, de = (ub - lb) / 2;
+    double den;
+    switch (cheby_order) {
+    case 0: coefs[0] = 1.0 / th; break;
+    case 1: den = de * de - 2 * th * th; coefs[0] = -4 * th / den; coefs[1] = 2 / den; break;
+    case 2: den = 3 * (de * de) * th - 4 * (th * th * th);
+            coefs[0] = (3 * de * de - 12 * th * th) / den; coefs[1] = 12 * th / den; coefs[2] = -4 / den; break;
+    default: den = std::pow(de, 4) - 8 * de * de * th * th + 8 * std::pow(th, 4);
+             coefs[0] = (32 * std::pow(th, 3) - 16 * de * de * th) / den;
+             coefs[1] = (8 * de * de - 48 * th * th) / den; coefs[2] = 32 * th / den; coefs[3] = -8 / den; break;
+    }
+}
+
+// symmetric tridiagonal eigenvalues (implicit QL with Wilkinson shift); d[0..n-1], e[1..n-1]
+static void tridiag_eigs(int n, std::vector<double> &d, std::vector<double> &e)
+{
+    for (int i = 1; i < n; i++) e[(size_t)i - 1] = e[(size_t)i];
+    e[(size_t)n - 1] = 0.0;
+    for (int l = 0; l < n; l++) {
+        int iter = 0, m;
+        do {
+            for (m = l; m < n - 1; m++) {
+                const double dd = std::fabs(d[(size_t)m]) + std::fabs(d[(size_t)m + 1]);
+                if (std::fabs(e[(size_t)m]) <= 2.3e-16 * dd) break;
+            }
+            if (m != l) {
+                if (iter++ == 60) fail(ELAG_HIP_ERR_NUMERIC, "tridiagonal eigen-solve did not converge");
+                double g = (d[(size_t)l + 1] - d[(size_t)l]) / (2.0 * e[(size_t)l]);
+                double rr = std::hypot(g, 1.0);
+                g = d[(size_t)m] - d[(size_t)l] + e[(size_t)l] / (g + std::copysign(rr, g));
+                double s = 1.0, c = 1.0, p = 0.0;
+                int i;
+                for (i = m - 1; i >= l; i--) {
+                    double f = s * e[(size_t)i], b = c * e[(size_t)i];
+                    rr = std::hypot(f, g);
+                    e[(size_t)i + 1] = rr;
+                    if (rr == 0.0) { d[(size_t)i + 1] -= p; e[(size_t)m] = 0.0; break; }
+                    s = f / rr; c = g / rr;
+                    g = d[(size_t)i + 1] - p;
+                    rr = (d[(size_t)i] - g) * s + 2.0 * c * b;
+                    p = s * rr;
+                    d[(size_t)i + 1] = g + p;
+                    g = c * rr - b;
+                }
+                if (rr == 0.0 && i >= l) continue;
+                d[(size_t)l] -= p; e[(size_t)l] = g; e[(size_t)m] = 0.0;
+            }
+        } while (m != l);
+    }
+    std::sort(d.begin(), d.begin() + n);
+}
+
+void RelaxSmoother::estimate_eigs()
+{
+    // hypre_ParCSRMaxEigEstimateCG(A, scale = 1, max_iter = 10): CG-Lanczos on D^-1/2 A D^-1/2 from
+    // hypre_ParVectorSetRandomValues(r, 1) (local seed = 1 * (rank + 1)).
+    Context &c = ctx();
+    const int nn = n();
+    int max_iter = 10;
+    if (A->global_rows < max_iter) max_iter = (int)A->global_rows;
+    if (max_iter == 0) { max_eig = min_eig = 0.0; return; }
+    Temp<double> rv((size_t)nn), p((size_t)nn), s((size_t)nn);
+    k::vec_hypre_random(nn, 1 * (c.rank + 1), rv);
+    std::vector<double> tri((size_t)max_iter + 1, 0.0), off((size_t)max_iter + 1, 0.0);
+    double gamma = 1.0, beta = 1.0;
+    int i = 0;
+    while (i < max_iter) {
+        const double gamma_old = gamma;
+        k::vec_dot(nn, rv, rv, c.d_scalar);
+        gamma = read_scalar(c.d_scalar);
+        comm_allreduce_scalar(&gamma, 0);
+        if (i == 0) {
+            beta = 1.0;
+            ELAG_HIP_CHECK(hipMemcpyAsync(p, rv, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, c.stream));
+        } else {
+            beta = gamma / gamma_old;
+            k::vec_axpby(nn, 1.0, rv, beta, p, p);
+        }
+        k::SpmvArgs a;  // s = ds .* A (ds .* p)
+        a.x = p; a.cs = ds; a.alpha = 1.0; a.s = ds; a.out = s;
+        par_spmv(*A, a);
+        k::vec_dot(nn, s, p, c.d_scalar);
+        double sdotp = read_scalar(c.d_scalar);
+        comm_allreduce_scalar(&sdotp, 0);
+        const double alpha = gamma / sdotp;
+        const double alphainv = 1.0 / alpha;
+        tri[(size_t)i + 1] = alphainv;
+        tri[(size_t)i] *= beta;
+        tri[(size_t)i] += alphainv;
+        off[(size_t)i + 1] = alphainv;
+        off[(size_t)i] *= std::sqrt(beta);
+        k::vec_axpby(nn, -alpha, s, 1.0, rv, rv);
+        i++;
+    }
+    tridiag_eigs(i, tri, off);
+    max_eig = tri[(size_t)i - 1];
+    min_eig = tri[0];
+}
+
+int RelaxSmoother::flips(bool zero_guess) const
+{
+    if (type == ELAG_HIP_SMOOTHER_CHEBYSHEV) return 0;
+    return zero_guess ? sweeps - 1 : sweeps;
+}
+
+void RelaxSmoother::apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool /*transpose*/)
+{
+    const int nn = n();
+    if (type != ELAG_HIP_SMOOTHER_CHEBYSHEV) {
+        for (int sw = 0; sw < sweeps; sw++) {
+            if (zero_guess && sw == 0) {
+                // u = 0 + w (f - A 0) / l1
+                k::vec_scale_mul(nn, 1.0, f, dinv, cur);
+            } else {
+                // hypre_ParCSRRelax type 1: v = w (f - A u); u += v / l1   -- one fused pass, out of place
+                k::SpmvArgs a;
+                a.x = cur; a.alpha = -1.0; a.f = f; a.gamma = 1.0; a.s = dinv; a.yin = cur; a.beta = 1.0; a.out = alt;
+                par_spmv(*A, a);
+                std::swap(cur, alt);
+            }
+        }
+        return;
+    }
+    // hypre_ParCSRRelax_Cheby(scale = 1, variant = 0)
+    const int co = cheby_order;
+    for (int sw = 0; sw < sweeps; sw++) {
+        const bool zero = zero_guess && sw == 0;
+        if (zero) {
+            k::vec_scale_mul(nn, 1.0, f, ds, r);  // r = ds .* f
+        } else {
+            k::SpmvArgs a;  // r = ds .* (f - A u)
+            a.x = cur; a.alpha = -1.0; a.f = f; a.gamma = 1.0; a.s = ds; a.out = r;
+            par_spmv(*A, a);
+        }
+        if (co == 0) {
+            k::vec_add_scaled_mul(nn, zero ? nullptr : cur, ds, nullptr, coefs[0], r, cur);
+            continue;
+        }
+        // z = c_{co-1} r + ds .* A (ds .* (c_co r))
+        double *z = za, *zo = zb;
+        {
+            k::SpmvArgs a;
+            a.x = r; a.cs = ds; a.alpha = coefs[co]; a.s = ds; a.yin = r; a.beta = coefs[co - 1]; a.out = z;
+            par_spmv(*A, a);
+        }
+        for (int i = co - 2; i >= 0; i--) {
+            k::SpmvArgs a;  // z' = c_i r + ds .* A (ds .* z)
+            a.x = z; a.cs = ds; a.alpha = 1.0; a.s = ds; a.yin = r; a.beta = coefs[i]; a.out = zo;
+            par_spmv(*A, a);
+            std::swap(z, zo);
+        }
+        k::vec_add_scaled_mul(nn, zero ? nullptr : cur, ds, z, 0.0, nullptr, cur);  // u = orig_u + ds .* z
+    }
+}
+
+// ---- Hiptmair -----------------------------------------------------------------------------------
+HiptmairSmoother::~HiptmairSmoother() { dev_free(pv); dev_free(auxb); dev_free(auxx); dev_free(auxalt); }
+
+void HiptmairSmoother::setup()
+{
+    ELAG_REQUIRE(D->nrows() == A->nrows(), "Hiptmair: D has %d rows, A has %d", D->nrows(), A->nrows());
+    ELAG_REQUIRE(aux->n() == D->ncols(), "Hiptmair: auxiliary operator size %d != columns of D %d", aux->n(), D->ncols());
+    pv = dev_alloc<double>((size_t)A->nrows());
+    auxb = dev_alloc<double>((size_t)D->ncols());
+    auxx = dev_alloc<double>((size_t)D->ncols());
+    auxalt = dev_alloc<double>((size_t)D->ncols());
+    D->ensure_transpose();
+}
+
+void HiptmairSmoother::aux_correct(const double *resid, double *x)
+{
+    // cB = D^T defect ; relax on A_aux (iterative_mode == false) ; X += D * correction   (HiptmairSmoother.cpp:61-75)
+    par_spmvT(*D, 1.0, resid, 0.0, auxb);
+    double *cx = auxx, *ca = auxalt;
+    if (aux->flips(true) & 1) std::swap(cx, ca);
+    aux->apply(auxb, cx, ca, true, false);
+    k::SpmvArgs a;
+    a.x = cx; a.alpha = 1.0; a.yin = x; a.beta = 1.0; a.out = x;
+    par_spmv(*D, a);
+}
+
+void HiptmairSmoother::apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose)
+{
+    if (!transpose) {
+        primary->apply(f, cur, alt, zero_guess, false);
+        k::SpmvArgs a;  // R = B - A X
+        a.x = cur; a.alpha = -1.0; a.f = f; a.gamma = 1.0; a.out = pv;
+        par_spmv(*A, a);
+        aux_correct(pv, cur);
+    } else {
+        // MultTranspose (:79-109): auxiliary correction first, then the primary sweep in iterative mode
+        if (zero_guess) {
+            k::vec_fill(n(), 0.0, cur);
+            aux_correct(f, cur);
+        } else {
+            k::SpmvArgs a;
+            a.x = cur; a.alpha = -1.0; a.f = f; a.gamma = 1.0; a.out = pv;
+            par_spmv(*A, a);
+            aux_correct(pv, cur);
+        }
+        primary->apply(f, cur, alt, false, true);
+    }
+}
+
+}  // namespace elag
+
+// ---- dense coarse solver --------------------------------------------------------------------------
+void elag_hip_coarse_s::setup()
+{
+    using namespace elag;
+    ELAG_REQUIRE(kind == 0, "coarse solver kind %d is not implemented (0 = dense Cholesky)", kind);
+    ELAG_REQUIRE(A->offd.ncols == 0 && ctx().nranks == 1, "dense coarse solve expects a rank-local operator");
+    n = A->nrows();
+    ELAG_REQUIRE(n == A->ncols(), "coarse operator must be square");
+    ELAG_REQUIRE(n <= 4096, "dense coarse solve limited to 4096 dofs (got %d)", n);
+    std::vector<int> I = host_from_dev(A->diag.I, (size_t)n + 1);
+    std::vector<int> J = host_from_dev(A->diag.J, (size_t)A->diag.nnz);
+    std::vector<double> a = host_from_dev(A->diag.a, (size_t)A->diag.nnz);
+    std::vector<double> L((size_t)n * n, 0.0);
+    for (int i = 0; i < n; i++)
+        for (int k = I[(size_t)i]; k < I[(size_t)i + 1]; k++) L[(size_t)i * n + J[(size_t)k]] += a[(size_t)k];
+    // symmetrise the (numerically symmetric) input, then Cholesky L L^T in place (lower)
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++) {
+            const double v = 0.5 * (L[(size_t)i * n + j] + L[(size_t)j * n + i]);
+            L[(size_t)i * n + j] = v; L[(size_t)j * n + i] = v;
+        }
+    for (int j = 0; j < n; j++) {
+        double d = L[(size_t)j * n + j];
+        for (int k = 0; k < j; k++) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+        if (!(d > 0.0)) fail(ELAG_HIP_ERR_NUMERIC, "coarse operator is not positive definite (pivot %d = %g)", j, d);
+        d = std::sqrt(d);
+        L[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double s = L[(size_t)i * n + j];
+            for (int k = 0; k < j; k++) s -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+            L[(size_t)i * n + j] = s / d;
+        }
+    }
+    // inverse: solve L L^T X = I column by column
+    std::vector<double> Minv_h((size_t)n * n), x((size_t)n);
+    for (int c = 0; c < n; c++) {
+        for (int i = 0; i < n; i++) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int k = (c < i ? c : i); k < i; k++) s -= L[(size_t)i * n + k] * x[(size_t)k];
+            x[(size_t)i] = (i < c) ? 0.0 : s / L[(size_t)i * n + i];
+        }
+        for (int i = n - 1; i >= 0; i--) {
+            double s = x[(size_t)i];
+            for (int k = i + 1; k < n; k++) s -= L[(size_t)k * n + i] * x[(size_t)k];
+            x[(size_t)i] = s / L[(size_t)i * n + i];
+        }
+        for (int i = 0; i < n; i++) Minv_h[(size_t)i * n + c] = x[(size_t)i];
+    }
+    // exact symmetry of the stored inverse keeps the cycle symmetric to rounding
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++) {
+            const double v = 0.5 * (Minv_h[(size_t)i * n + j] + Minv_h[(size_t)j * n + i]);
+            Minv_h[(size_t)i * n + j] = v; Minv_h[(size_t)j * n + i] = v;
+        }
+    Minv = dev_from_host(Minv_h.data(), Minv_h.size());
+    ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+}
+
+void elag_hip_coarse_s::apply(const double *rhs, double *sol) { elag::k::dense_gemv(n, Minv, rhs, sol); }
+
+using namespace elag;
+
+extern "C" {
+
+int elag_hip_smoother_create(elag_hip_smoother_t *out, elag_hip_parcsr_t A, int relax_type, int sweeps, double damping,
+                             double omega, int cheby_order, double cheby_fraction)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(out && A, "null argument");
+        ELAG_REQUIRE(A->nrows() == A->ncols(), "smoother needs a square operator (%d x %d)", A->nrows(), A->ncols());
+        ELAG_REQUIRE(sweeps >= 1, "Sweeps must be >= 1");
+        std::unique_ptr<RelaxSmoother> S(new RelaxSmoother());
+        S->A = A; S->type = relax_type; S->sweeps = sweeps; S->weight = damping; S->omega = omega;
+        S->order = cheby_order; S->fraction = cheby_fraction;
+        S->setup();
+        *out = S.release();
+    });
+}
+
+int elag_hip_smoother_get_eig_estimate(elag_hip_smoother_t S, double *max_eig, double *min_eig)
+{
+    return guarded([&] {
+        auto *R = dynamic_cast<RelaxSmoother *>(S);
+        ELAG_REQUIRE(R && R->type == ELAG_HIP_SMOOTHER_CHEBYSHEV, "not a Chebyshev smoother");
+        if (max_eig) *max_eig = R->max_eig;
+        if (min_eig) *min_eig = R->min_eig;
+    });
+}
+
+int elag_hip_smoother_set_eig_estimate(elag_hip_smoother_t S, double max_eig, double min_eig)
+{
+    return guarded([&] {
+        auto *R = dynamic_cast<RelaxSmoother *>(S);
+        ELAG_REQUIRE(R && R->type == ELAG_HIP_SMOOTHER_CHEBYSHEV, "not a Chebyshev smoother");
+        R->max_eig = max_eig; R->min_eig = min_eig;
+        R->compute_coefs();
+    });
+}
+
+int elag_hip_hiptmair_create(elag_hip_smoother_t *out, elag_hip_parcsr_t A, elag_hip_parcsr_t D,
+                             elag_hip_smoother_t primary, elag_hip_smoother_t auxiliary)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(out && A && D && primary && auxiliary, "null argument");
+        std::unique_ptr<HiptmairSmoother> S(new HiptmairSmoother());
+        S->A = A; S->D = D; S->primary = primary; S->aux = auxiliary;
+        S->setup();
+        *out = S.release();
+    });
+}
+
+int elag_hip_smoother_apply(elag_hip_smoother_t S, const double *rhs, double *sol, int zero_initial_guess, int transpose, int loc)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(S && rhs && sol, "null argument");
+        check_loc(loc);
+        const size_t n = (size_t)S->n();
+        VecIn f(rhs, n, loc);
+        VecInOut u(sol, n, loc, !zero_initial_guess);
+        Temp<double> altbuf(n);
+        double *cur = u.d, *alt = altbuf;
+        S->apply(f.d, cur, alt, zero_initial_guess != 0, transpose != 0);
+        if (cur != u.d)
+            ELAG_HIP_CHECK(hipMemcpyAsync(u.d, cur, n * sizeof(double), hipMemcpyDeviceToDevice, ctx().stream));
+        u.finish();
+    });
+}
+
+int elag_hip_smoother_destroy(elag_hip_smoother_t S)
+{
+    return guarded([&] {
+        if (S) { (void)hipStreamSynchronize(ctx().stream); delete S; }
+    });
+}
+
+int elag_hip_coarse_create(elag_hip_coarse_t *out, elag_hip_parcsr_t A, int kind, int iters)
+{
+    return guarded([&] {
+        require_init();
+        (void)iters;
+        ELAG_REQUIRE(out && A, "null argument");
+        std::unique_ptr<elag_hip_coarse_s> C(new elag_hip_coarse_s());
+        C->A = A; C->kind = kind;
+        C->setup();
+        *out = C.release();
+    });
+}
+
+int elag_hip_coarse_apply(elag_hip_coarse_t C, const double *rhs, double *sol, int loc)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(C && rhs && sol, "null argument");
+        check_loc(loc);
+        VecIn f(rhs, (size_t)C->n, loc);
+        VecInOut u(sol, (size_t)C->n, loc, false);
+        C->apply(f.d, u.d);
+        u.finish();
+    });
+}
+
+int elag_hip_coarse_destroy(elag_hip_coarse_t C)
+{
+    return guarded([&] {
+        if (C) { (void)hipStreamSynchronize(ctx().stream); delete C; }
+    });
+}
+
+}  // extern "C"

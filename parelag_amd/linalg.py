@@ -1,0 +1,482 @@
+"""Host-side mirror of the reference's operator interface for the V-cycle path, over the C ABI.
+
+Class / method names follow the reference so that tests read like its own code:
+
+* ``ParallelCSRMatrix``      <- mfem::HypreParMatrix as used by ParElag (``Mult``, ``MultTranspose``)
+* ``HypreSmootherWrapper``   <- src/linalg/solver_ops/ParELAG_HypreSmootherWrapper.{hpp,cpp}
+* ``HiptmairSmoother``       <- src/linalg/solver_ops/ParELAG_HiptmairSmoother.{hpp,cpp}
+* ``Hierarchy``              <- src/linalg/solver_ops/ParELAG_Hierarchy.{hpp,cpp}
+* ``SolverLibrary`` / factories selected by the ``"Type"`` string <- src/linalg/solver_core, src/linalg/factories
+
+Vectors may be numpy arrays (host; staged by the library), ``DeviceVector`` objects, or anything exposing
+``data_ptr()`` on the GPU (a ``torch.Tensor`` on ``cuda``).  Everything executes in libelag_hip.so; there is no
+CPU path in this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from ._lib import DEVICE, HOST, ParCSRDesc, ParCSRInfo, check
+
+_vp = C.c_void_p
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+class DeviceVector:
+    """A length-n fp64 vector in HBM owned through elag_hip_malloc."""
+
+    def __init__(self, n: int, fill: float | None = None):
+        self.n = int(n)
+        self._lib = _lib.init()
+        p = _vp()
+        check(self._lib.elag_hip_malloc(C.byref(p), self.n * 8))
+        self.ptr = p
+        if fill is not None:
+            self.copy_from(np.full(self.n, float(fill)))
+
+    @classmethod
+    def from_numpy(cls, a):
+        v = cls(len(a))
+        v.copy_from(a)
+        return v
+
+    def copy_from(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.size == self.n
+        check(self._lib.elag_hip_memcpy(self.ptr, _np_ptr(a), self.n * 8, 0))
+
+    def to_numpy(self):
+        out = np.empty(self.n)
+        check(self._lib.elag_hip_memcpy(_np_ptr(out), self.ptr, self.n * 8, 1))
+        return out
+
+    def data_ptr(self):
+        return self.ptr.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._lib.elag_hip_free(self.ptr)
+        except Exception:
+            pass
+
+
+def _vec(v, n=None, writable=False):
+    """-> (pointer, loc, keepalive)"""
+    if isinstance(v, DeviceVector):
+        return v.ptr, DEVICE, v
+    if isinstance(v, np.ndarray):
+        if v.dtype != np.float64 or not v.flags.c_contiguous:
+            if writable:
+                raise TypeError("output vectors must be C-contiguous float64 numpy arrays")
+            v = np.ascontiguousarray(v, dtype=np.float64)
+        if n is not None and v.size != n:
+            raise ValueError(f"vector has size {v.size}, expected {n}")
+        return _np_ptr(v), HOST, v
+    if hasattr(v, "data_ptr"):  # torch tensor on the GPU
+        if getattr(v, "is_cuda", True) is False:
+            raise TypeError("torch tensors must live on the GPU (use numpy arrays for host vectors)")
+        return _vp(v.data_ptr()), DEVICE, v
+    raise TypeError(f"unsupported vector type {type(v)}")
+
+
+def _same_loc(*locs):
+    if len(set(locs)) != 1:
+        raise TypeError("all vectors of one call must live in the same memory space")
+    return locs[0]
+
+
+def synchronize():
+    check(_lib.init().elag_hip_synchronize())
+
+
+class ParallelCSRMatrix:
+    """Device-resident ParCSR matrix (one rank's rows)."""
+
+    def __init__(self, handle, owner=True):
+        self._lib = _lib.init()
+        self.h = handle
+        self._owner = owner
+        info = ParCSRInfo()
+        check(self._lib.elag_hip_parcsr_get_info(self.h, C.byref(info)))
+        self.info = info
+
+    # ---- construction --------------------------------------------------------------------------
+    @classmethod
+    def from_scipy(cls, A):
+        """Single-rank matrix from a scipy CSR (storage order is preserved on upload)."""
+        A = sp.csr_matrix(A)
+        I = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        J = np.ascontiguousarray(A.indices, dtype=np.int32)
+        a = np.ascontiguousarray(A.data, dtype=np.float64)
+        d = ParCSRDesc()
+        d.num_rows, d.num_cols_diag = A.shape
+        d.diag_i, d.diag_j, d.diag_a = _np_ptr(I), _np_ptr(J), _np_ptr(a)
+        d.global_num_rows, d.global_num_cols = A.shape
+        return cls._create(d)
+
+    @classmethod
+    def from_parts(cls, part):
+        """From one rank's pieces as produced by ``parelag_amd.partition.split_rows`` (dict)."""
+        keep = []
+
+        def arr(x, dt):
+            x = np.ascontiguousarray(x, dtype=dt)
+            keep.append(x)
+            return _np_ptr(x)
+        dg, od = sp.csr_matrix(part["diag"]), sp.csr_matrix(part["offd"])
+        d = ParCSRDesc()
+        d.num_rows, d.num_cols_diag = dg.shape
+        d.diag_i, d.diag_j, d.diag_a = arr(dg.indptr, np.int32), arr(dg.indices, np.int32), arr(dg.data, np.float64)
+        d.num_cols_offd = od.shape[1]
+        if od.shape[1]:
+            d.offd_i, d.offd_j, d.offd_a = arr(od.indptr, np.int32), arr(od.indices, np.int32), arr(od.data, np.float64)
+            d.col_map_offd = arr(part["col_map_offd"], np.int64)
+        d.first_row, d.first_col_diag = int(part["first_row"]), int(part["first_col"])
+        d.global_num_rows, d.global_num_cols = (int(x) for x in part["global_shape"])
+        d.num_sends = len(part["send_procs"])
+        d.send_procs = arr(part["send_procs"], np.int32)
+        d.send_map_starts = arr(part["send_starts"], np.int32)
+        d.send_map_elmts = arr(part["send_elmts"], np.int32)
+        d.num_recvs = len(part["recv_procs"])
+        d.recv_procs = arr(part["recv_procs"], np.int32)
+        d.recv_vec_starts = arr(part["recv_starts"], np.int32)
+        return cls._create(d)
+
+    @classmethod
+    def _create(cls, desc):
+        lib = _lib.init()
+        h = _vp()
+        check(lib.elag_hip_parcsr_create(C.byref(h), C.byref(desc)))
+        return cls(h)
+
+    @classmethod
+    def diagonal(cls, d):
+        lib = _lib.init()
+        d = np.ascontiguousarray(d, dtype=np.float64)
+        h = _vp()
+        check(lib.elag_hip_parcsr_diagonal(C.byref(h), len(d), 0, len(d), _np_ptr(d)))
+        return cls(h)
+
+    def __del__(self):
+        try:
+            if self._owner and self.h:
+                self._lib.elag_hip_parcsr_destroy(self.h)
+        except Exception:
+            pass
+
+    # ---- shape ---------------------------------------------------------------------------------
+    @property
+    def shape(self):
+        return (self.info.num_rows, self.info.num_cols_diag)
+
+    def Height(self):
+        return self.info.num_rows
+
+    def Width(self):
+        return self.info.num_cols_diag
+
+    @property
+    def nnz(self):
+        return self.info.nnz_diag + self.info.nnz_offd
+
+    # ---- operator application (mfem::Operator contract) --------------------------------------------
+    def Mult(self, x, y, alpha=1.0, beta=0.0):
+        px, lx, _k1 = _vec(x, self.Width())
+        py, ly, _k2 = _vec(y, self.Height(), writable=True)
+        check(self._lib.elag_hip_parcsr_spmv(self.h, 0, alpha, px, beta, py, _same_loc(lx, ly)))
+
+    def MultTranspose(self, x, y, alpha=1.0, beta=0.0):
+        px, lx, _k1 = _vec(x, self.Height())
+        py, ly, _k2 = _vec(y, self.Width(), writable=True)
+        check(self._lib.elag_hip_parcsr_spmv(self.h, 1, alpha, px, beta, py, _same_loc(lx, ly)))
+
+    def residual(self, b, x, r):
+        """r = b - A x  (mg_utils::ComputeResidual)."""
+        pb, lb, _k1 = _vec(b, self.Height())
+        px, lx, _k2 = _vec(x, self.Width())
+        pr, lr, _k3 = _vec(r, self.Height(), writable=True)
+        check(self._lib.elag_hip_parcsr_residual(self.h, pb, px, pr, _same_loc(lb, lx, lr)))
+
+    # ---- setup-side algebra ----------------------------------------------------------------------
+    def _new(self, fn, *args):
+        h = _vp()
+        check(fn(*args, C.byref(h)))
+        return ParallelCSRMatrix(h)
+
+    def Transpose(self):
+        return self._new(self._lib.elag_hip_parcsr_transpose, self.h)
+
+    def matmul(self, B):
+        return self._new(self._lib.elag_hip_parcsr_matmul, self.h, B.h)
+
+    def fix_zero_rows(self) -> int:
+        n = C.c_int(0)
+        check(self._lib.elag_hip_parcsr_fix_zero_rows(self.h, C.byref(n)))
+        return n.value
+
+    def delete_zeros(self, tol):
+        check(self._lib.elag_hip_parcsr_delete_zeros(self.h, tol))
+        check(self._lib.elag_hip_parcsr_get_info(self.h, C.byref(self.info)))
+
+    def sign_transform(self):
+        check(self._lib.elag_hip_parcsr_sign_transform(self.h))
+
+    def norm(self, kind: str) -> float:
+        k = {"l1": 0, "linf": 1, "max": 2, "frobenius": 3}[kind]
+        v = C.c_double(0)
+        check(self._lib.elag_hip_parcsr_norm(self.h, k, C.byref(v)))
+        return v.value
+
+    def get_diagonal(self):
+        d = np.empty(self.Height())
+        check(self._lib.elag_hip_parcsr_get_diagonal(self.h, _np_ptr(d), HOST))
+        return d
+
+    def to_scipy(self, diag_first=False):
+        """Export the diag block (and offd mapped to global columns when present)."""
+        i = self.info
+        I = np.empty(i.num_rows + 1, np.int32); J = np.empty(i.nnz_diag, np.int32); a = np.empty(i.nnz_diag)
+        oI = np.empty(i.num_rows + 1, np.int32); oJ = np.empty(i.nnz_offd, np.int32); oa = np.empty(i.nnz_offd)
+        cm = np.empty(i.num_cols_offd, np.int64)
+        check(self._lib.elag_hip_parcsr_export(self.h, int(diag_first), _np_ptr(I), _np_ptr(J), _np_ptr(a),
+                                               _np_ptr(oI), _np_ptr(oJ), _np_ptr(oa), _np_ptr(cm)))
+        D = sp.csr_matrix((i.num_rows, i.num_cols_diag))
+        D.indptr, D.indices, D.data = I, J, a
+        if i.num_cols_offd == 0:
+            return D
+        O = sp.csr_matrix((i.num_rows, i.num_cols_offd))
+        O.indptr, O.indices, O.data = oI, oJ, oa
+        return D, O, cm
+
+
+def RAP(a: ParallelCSRMatrix, b: ParallelCSRMatrix, c: ParallelCSRMatrix | None = None):
+    """mfem::RAP(A, P) = P^T A P, or mfem::RAP(Rt, A, P) = Rt^T A P -> hypre_BoomerAMGBuildCoarseOperator
+    (call sites Hierarchy.cpp:365,511-513; HiptmairSmootherFactory.cpp:160-161)."""
+    Rt, A, P = (b, a, b) if c is None else (a, b, c)
+    h = _vp()
+    check(_lib.init().elag_hip_parcsr_rap(Rt.h, A.h, P.h, C.byref(h)))
+    return ParallelCSRMatrix(h)
+
+
+def Add(a, A: ParallelCSRMatrix, b, B: ParallelCSRMatrix):
+    """hypre_ParCSRMatrixAdd2 (src/hypreExtension/parcsr-add.c:199-245)."""
+    h = _vp()
+    check(_lib.init().elag_hip_parcsr_add(a, A.h, b, B.h, C.byref(h)))
+    return ParallelCSRMatrix(h)
+
+
+def RDP(Rt: ParallelCSRMatrix, d, P: ParallelCSRMatrix):
+    """hypre_RDP (src/hypreExtension/par_Tmatmul.c:17-39)."""
+    pd, ld, _k = _vec(d, Rt.Height())
+    h = _vp()
+    check(_lib.init().elag_hip_parcsr_rdp(Rt.h, pd, ld, P.h, C.byref(h)))
+    return ParallelCSRMatrix(h)
+
+
+def Compare(A: ParallelCSRMatrix, B: ParallelCSRMatrix, tol: float) -> int:
+    """hypre_ParCSRMatrixCompare bit mask."""
+    m = C.c_int(0)
+    check(_lib.init().elag_hip_parcsr_compare(A.h, B.h, tol, C.byref(m)))
+    return m.value
+
+
+# ---- smoothers ------------------------------------------------------------------------------------
+
+# string -> hypre relax type, the table of src/linalg/factories/ParELAG_HypreSmootherFactory.cpp:92-109
+HYPRE_SMOOTHER_TYPES = {
+    "Jacobi": 0, "L1 Jacobi": 1, "L1 Gauss-Seidel": 2, "Kaczmarz": 3, "L1 Gauss-Seidel Truncated": 4,
+    "Lumped Jacobi": 5, "Gauss-Seidel": 6, "Chebyshev": 16, "Taubin": 1001, "FIR": 1002,
+}
+
+
+class _SolverBase:
+    iterative_mode = True
+
+    def IsPreconditioner(self):
+        return not self.iterative_mode
+
+
+class HypreSmootherWrapper(_SolverBase):
+    """HypreSmootherWrapper(A, type, params): params uses the reference's ParameterList keys
+    ("Sweeps", "Damping Factor", "Omega", "Cheby Poly Order", "Cheby Poly Fraction")."""
+
+    def __init__(self, A: ParallelCSRMatrix, type: int = 1, params: dict | None = None, handle=None, owner=True):
+        params = params or {}
+        self._lib = _lib.init()
+        self.A = A
+        self.type = type
+        self._owner = owner
+        if handle is None:
+            handle = _vp()
+            check(self._lib.elag_hip_smoother_create(
+                C.byref(handle), A.h, int(type), int(params.get("Sweeps", 1)), float(params.get("Damping Factor", 1.0)),
+                float(params.get("Omega", 1.0)), int(params.get("Cheby Poly Order", 2)),
+                float(params.get("Cheby Poly Fraction", 0.3))))
+        self.h = handle
+        self.iterative_mode = True
+
+    def eig_estimate(self):
+        mx, mn = C.c_double(), C.c_double()
+        check(self._lib.elag_hip_smoother_get_eig_estimate(self.h, C.byref(mx), C.byref(mn)))
+        return mx.value, mn.value
+
+    def set_eig_estimate(self, max_eig, min_eig):
+        check(self._lib.elag_hip_smoother_set_eig_estimate(self.h, max_eig, min_eig))
+
+    def _apply(self, rhs, sol, transpose):
+        n = self.A.Height()
+        pr, lr, _k1 = _vec(rhs, n)
+        ps, ls, _k2 = _vec(sol, n, writable=True)
+        check(self._lib.elag_hip_smoother_apply(self.h, pr, ps, int(not self.iterative_mode), int(transpose), _same_loc(lr, ls)))
+
+    def Mult(self, rhs, sol):
+        self._apply(rhs, sol, False)
+
+    def MultTranspose(self, rhs, sol):
+        self._apply(rhs, sol, True)
+
+    def __del__(self):
+        try:
+            if self._owner and self.h:
+                self._lib.elag_hip_smoother_destroy(self.h)
+        except Exception:
+            pass
+
+
+class HiptmairSmoother(HypreSmootherWrapper):
+    """HiptmairSmoother(A, A_aux, D, primary, auxiliary) (ParELAG_HiptmairSmoother.cpp:22-46)."""
+
+    def __init__(self, A, D, primary: HypreSmootherWrapper, auxiliary: HypreSmootherWrapper):
+        self._lib = _lib.init()
+        self.A, self.D, self.primary, self.auxiliary = A, D, primary, auxiliary
+        self._owner = True
+        h = _vp()
+        check(self._lib.elag_hip_hiptmair_create(C.byref(h), A.h, D.h, primary.h, auxiliary.h))
+        self.h = h
+        self.iterative_mode = True
+
+
+class CoarseSolver(_SolverBase):
+    def __init__(self, A: ParallelCSRMatrix, kind: int = 0, iters: int = 0):
+        self._lib = _lib.init()
+        self.A = A
+        h = _vp()
+        check(self._lib.elag_hip_coarse_create(C.byref(h), A.h, kind, iters))
+        self.h = h
+        self.iterative_mode = False
+
+    def Mult(self, rhs, sol):
+        pr, lr, _k1 = _vec(rhs, self.A.Height())
+        ps, ls, _k2 = _vec(sol, self.A.Height(), writable=True)
+        check(self._lib.elag_hip_coarse_apply(self.h, pr, ps, _same_loc(lr, ls)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._lib.elag_hip_coarse_destroy(self.h)
+        except Exception:
+            pass
+
+
+# ---- hierarchy --------------------------------------------------------------------------------------
+
+class Hierarchy(_SolverBase):
+    """parelag::Hierarchy.  ``iterative_mode`` False <=> IsPreconditioner() (Solver.hpp:57-103)."""
+
+    def __init__(self, num_levels: int | None = None, handle=None):
+        self._lib = _lib.init()
+        self._keep = []
+        if handle is None:
+            handle = _vp()
+            check(self._lib.elag_hip_hierarchy_create(C.byref(handle), int(num_levels)))
+        self.h = handle
+        self.iterative_mode = False
+
+    def SetOperator(self, level, A):
+        self._keep.append(A)
+        check(self._lib.elag_hip_hierarchy_set_operator(self.h, level, A.h))
+
+    def SetProlongator(self, coarse_level, P):
+        self._keep.append(P)
+        check(self._lib.elag_hip_hierarchy_set_prolongator(self.h, coarse_level, P.h))
+
+    def SetSmoothers(self, level, pre, post):
+        self._keep += [pre, post]
+        check(self._lib.elag_hip_hierarchy_set_smoothers(self.h, level, pre.h if pre else None, post.h if post else None))
+
+    def SetCoarseSolver(self, solver):
+        self._keep.append(solver)
+        check(self._lib.elag_hip_hierarchy_set_coarse_solver(self.h, solver.h))
+
+    def Finalize(self, use_graph=True):
+        check(self._lib.elag_hip_hierarchy_finalize(self.h, int(use_graph)))
+
+    def Mult(self, rhs, sol):
+        pr, lr, _k1 = _vec(rhs)
+        ps, ls, _k2 = _vec(sol, writable=True)
+        check(self._lib.elag_hip_hierarchy_apply(self.h, pr, ps, int(self.IsPreconditioner()), _same_loc(lr, ls)))
+
+    def GetOperator(self, level) -> ParallelCSRMatrix:
+        h = _vp()
+        check(self._lib.elag_hip_hierarchy_get_operator(self.h, level, C.byref(h)))
+        return ParallelCSRMatrix(h, owner=False)
+
+    def GetSmoother(self, level) -> HypreSmootherWrapper:
+        h = _vp()
+        check(self._lib.elag_hip_hierarchy_get_smoother(self.h, level, C.byref(h)))
+        return HypreSmootherWrapper(self.GetOperator(level), handle=h, owner=False)
+
+    def time_apply(self, rhs, sol, reps) -> float:
+        """mean milliseconds per V-cycle, measured with HIP events on the library's compute stream"""
+        pr, lr, _k1 = _vec(rhs)
+        ps, ls, _k2 = _vec(sol, writable=True)
+        if _same_loc(lr, ls) != DEVICE:
+            raise TypeError("time_apply needs device vectors")
+        ms = C.c_double(0)
+        check(self._lib.elag_hip_time_hierarchy(self.h, pr, ps, int(reps), C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._lib.elag_hip_hierarchy_destroy(self.h)
+        except Exception:
+            pass
+
+
+def buildHierarchyFromDeRhamSequence(A: ParallelCSRMatrix, Ps, smoother="L1 Jacobi", params: dict | None = None,
+                                     fix_zero_rows=True, coarse_kind=0, use_graph=True) -> Hierarchy:
+    """RAP chain + smoothers + coarse solve in one ABI call (Hierarchy.cpp:282-383, AMGeSolverFactory.cpp:26-169).
+    ``Ps[l]`` is the true interpolator from level l+1 to level l (DeRhamSequence::ComputeTrueP)."""
+    params = params or {}
+    t = HYPRE_SMOOTHER_TYPES[smoother] if isinstance(smoother, str) else int(smoother)
+    lib = _lib.init()
+    arr = (_vp * max(len(Ps), 1))(*[P.h for P in Ps])
+    h = _vp()
+    check(lib.elag_hip_hierarchy_build(C.byref(h), A.h, len(Ps), arr, int(fix_zero_rows), t,
+                                       int(params.get("Sweeps", 1)), float(params.get("Damping Factor", 1.0)),
+                                       int(params.get("Cheby Poly Order", 2)), float(params.get("Cheby Poly Fraction", 0.3)),
+                                       int(coarse_kind), 0, int(use_graph)))
+    H = Hierarchy(handle=h)
+    H._keep += [A, *Ps]
+    return H
+
+
+def time_kernel(A: ParallelCSRMatrix, kernel: str, x, y, reps=20, smoother: HypreSmootherWrapper | None = None) -> float:
+    """mean ms per launch of a fine-level kernel ('spmv' | 'residual' | 'jacobi') by HIP events."""
+    kid = {"spmv": 0, "residual": 1, "jacobi": 2}[kernel]
+    px, lx, _k1 = _vec(x)
+    py, ly, _k2 = _vec(y, writable=True)
+    if _same_loc(lx, ly) != DEVICE:
+        raise TypeError("time_kernel needs device vectors")
+    ms = C.c_double(0)
+    check(_lib.init().elag_hip_time_kernel(A.h, smoother.h if smoother else None, kid, int(reps), px, py, C.byref(ms)))
+    return ms.value

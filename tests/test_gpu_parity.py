@@ -1,0 +1,337 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances: indices / patterns / integer maps bit-exact; fp64 values within 1e-12 relative to the
+magnitude of the terms being summed (the device sums a row with a lane-strided tree instead of hypre's
+storage order, so the last bits differ) -- two orders tighter than the 1e-10 the north star asks for.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import oracle as orc
+from tests.helpers import oracle_h1_hierarchy, oracle_py_hierarchy, pcg
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def la():
+    from parelag_amd import linalg
+    return linalg
+
+
+def rand_csr(n, m, density, seed, empty_rows=False):
+    rng = np.random.default_rng(seed)
+    A = sp.random(n, m, density=density, random_state=rng, format="csr")
+    A.data = rng.uniform(-1, 1, A.nnz)
+    if empty_rows and n > 4:
+        A = A.tolil(); A[1, :] = 0; A[n - 2, :] = 0; A = A.tocsr(); A.eliminate_zeros()
+    return orc.csr(A)
+
+
+def close(x, ref, scale=None, tol=RTOL):
+    scale = np.max(np.abs(ref)) if scale is None else scale
+    return np.max(np.abs(np.asarray(x) - np.asarray(ref))) <= tol * max(scale, 1e-300)
+
+
+# ---- SpMV ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape,density", [((1, 1), 1.0), ((7, 5), 0.5), ((300, 200), 0.01), ((257, 257), 0.06),
+                                           ((1000, 1000), 0.02), ((64, 4096), 0.2), ((2000, 3), 0.7)])
+@pytest.mark.parametrize("alpha,beta", [(1.0, 0.0), (-1.0, 1.0), (0.5, -2.0)])
+def test_spmv_and_transpose(la, shape, density, alpha, beta):
+    A = rand_csr(*shape, density, 1, empty_rows=True)
+    M = la.ParallelCSRMatrix.from_scipy(A)
+    rng = np.random.default_rng(2)
+    x, y0 = rng.standard_normal(shape[1]), rng.standard_normal(shape[0])
+    y, yr = y0.copy(), y0.copy()
+    M.Mult(x, y, alpha, beta)
+    orc.csr_matvec(A, alpha, x, beta, yr)
+    assert close(y, yr, scale=np.max(np.abs(A) @ np.abs(x)) + np.max(np.abs(y0)) if shape[0] else 1)
+    xt, z0 = rng.standard_normal(shape[0]), rng.standard_normal(shape[1])
+    z, zr = z0.copy(), z0.copy()
+    M.MultTranspose(xt, z, alpha, beta)
+    orc.csr_matvecT(A, alpha, xt, beta, zr)
+    assert close(z, zr, scale=np.max(np.abs(A).T @ np.abs(xt)) + np.max(np.abs(z0)))
+
+
+def test_spmv_empty_matrix_and_zero_rows(la):
+    A = orc.csr(sp.csr_matrix((5, 4)))
+    M = la.ParallelCSRMatrix.from_scipy(A)
+    y = np.ones(5)
+    M.Mult(np.ones(4), y)
+    assert np.array_equal(y, np.zeros(5))
+    y = np.ones(5)
+    M.Mult(np.ones(4), y, 1.0, 2.0)
+    assert np.array_equal(y, 2 * np.ones(5))
+
+
+def test_spmv_device_vectors_and_residual(la, h1_k2):
+    A, _, _ = h1_k2
+    M = la.ParallelCSRMatrix.from_scipy(A)
+    rng = np.random.default_rng(5)
+    x, b = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+    dx, db, dr = la.DeviceVector.from_numpy(x), la.DeviceVector.from_numpy(b), la.DeviceVector(A.shape[0])
+    M.residual(db, dx, dr)
+    la.synchronize()
+    ref = np.zeros_like(b)
+    orc.csr_matvec(orc.csr(A), 1.0, x, 0.0, ref)
+    ref = b - ref
+    assert close(dr.to_numpy(), ref, scale=np.max(np.abs(A) @ np.abs(x)))
+
+
+def test_bad_arguments_raise(la):
+    from parelag_amd._lib import ElagHipError
+    A = la.ParallelCSRMatrix.from_scipy(sp.eye(4, format="csr"))
+    with pytest.raises(ValueError):
+        A.Mult(np.ones(3), np.ones(4))
+    bad = sp.csr_matrix((np.ones(2), np.array([0, 7]), np.array([0, 1, 2])), shape=(2, 3))
+    with pytest.raises(ElagHipError):
+        la.ParallelCSRMatrix.from_scipy(bad)
+    with pytest.raises(ElagHipError):   # sequential smoother types are CPU-only in the reference's sense
+        la.HypreSmootherWrapper(A, la.HYPRE_SMOOTHER_TYPES["L1 Gauss-Seidel"])
+    B = la.ParallelCSRMatrix.from_scipy(sp.eye(5, format="csr"))
+    with pytest.raises(ElagHipError):
+        A.matmul(B)
+
+
+# ---- setup-side sparse algebra ---------------------------------------------------------------------------
+
+def same_matrix(dev: sp.csr_matrix, ref: sp.csr_matrix, tol=RTOL):
+    """pattern bit-exact after column sort; values to tolerance"""
+    ref = sp.csr_matrix(ref).copy(); ref.sort_indices()
+    dev = sp.csr_matrix(dev).copy()
+    assert dev.has_sorted_indices or True
+    d2 = dev.copy(); d2.sort_indices()
+    assert np.array_equal(d2.indptr, ref.indptr)
+    assert np.array_equal(d2.indices, ref.indices)
+    assert np.array_equal(dev.indices, d2.indices), "device rows must come back column-sorted"
+    scale = np.max(np.abs(ref.data)) if ref.nnz else 1.0
+    assert np.max(np.abs(d2.data - ref.data), initial=0.0) <= tol * scale
+
+
+@pytest.mark.parametrize("n,m,density", [(40, 15, 0.2), (500, 300, 0.02), (1200, 1200, 0.004), (3, 2000, 0.5)])
+def test_transpose(la, n, m, density):
+    A = rand_csr(n, m, density, 3, empty_rows=True)
+    T = la.ParallelCSRMatrix.from_scipy(A).Transpose().to_scipy()
+    ref = orc.transpose(A)
+    same_matrix(T, ref, tol=0.0)   # pure data movement: bit-exact
+
+
+def test_matmul_rap_add_small(la):
+    R = rand_csr(60, 25, 0.2, 4); A = rand_csr(60, 60, 0.15, 5); P = rand_csr(60, 25, 0.2, 6)
+    dR, dA, dP = (la.ParallelCSRMatrix.from_scipy(X) for X in (R, A, P))
+    same_matrix(dA.matmul(dP).to_scipy(), orc.matmul(A, P))
+    same_matrix(la.RAP(dR, dA, dP).to_scipy(), orc.rap(R, A, P))
+    same_matrix(la.RAP(dA, dP).to_scipy(), orc.rap(P, A, P))
+    B = rand_csr(60, 60, 0.1, 7)
+    same_matrix(la.Add(2.0, dA, -3.0, la.ParallelCSRMatrix.from_scipy(B)).to_scipy(), orc.add(2.0, A, -3.0, B))
+    d = np.random.default_rng(1).uniform(0.5, 2, 60)
+    same_matrix(la.RDP(dR, d, dP).to_scipy(), orc.matmul(orc.transpose(R), orc.csr(sp.diags(d) @ P)))
+
+
+def test_matmul_with_wide_rows_uses_big_row_path(la):
+    """rows whose expansion exceeds one LDS chunk (2048 products) go through the single-row workgroups"""
+    A = rand_csr(20, 400, 0.5, 8)       # ~200 entries per row
+    B = rand_csr(400, 300, 0.08, 9)     # ~24 per row -> ~4800 products per row of A*B
+    C = la.ParallelCSRMatrix.from_scipy(A).matmul(la.ParallelCSRMatrix.from_scipy(B)).to_scipy()
+    same_matrix(C, orc.matmul(A, B), tol=1e-12)
+
+
+def test_rap_chain_on_mesh_hierarchy_matches_oracle(la, h1_k2):
+    A, Ps, _ = h1_k2
+    h = oracle_h1_hierarchy(A, Ps)
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    for l, P in enumerate(Ps):
+        dP = la.ParallelCSRMatrix.from_scipy(P)
+        dAc = la.RAP(dA, dP)
+        nfixed = dAc.fix_zero_rows()
+        ref = h["As"][l + 1]
+        assert nfixed == int((np.abs(orc.rap(orc.csr(P), h["As"][l], orc.csr(P))).sum(axis=1) == 0).sum())
+        same_matrix(dAc.to_scipy(), ref)
+        # export with the diagonal first reproduces hypre's convention exactly
+        df = dAc.to_scipy(diag_first=True)
+        assert all(df.indices[df.indptr[i]] == i for i in range(df.shape[0]))
+        assert la.Compare(dAc, la.ParallelCSRMatrix.from_scipy(ref), 1e-12) == 0
+        dA = dAc
+
+
+def test_fix_zero_rows_delete_zeros_sign_norms_compare(la):
+    A = orc.csr(sp.csr_matrix((np.array([2.0, -1.0, 0.0, 0.0, -1.0, 2.0]), np.array([0, 1, 1, 0, 1, 2]),
+                               np.array([0, 2, 4, 6])), shape=(3, 3)))
+    M = la.ParallelCSRMatrix.from_scipy(A)
+    assert M.fix_zero_rows() == 1
+    assert np.allclose(M.to_scipy().toarray(), [[2, -1, 0], [0, 1, 0], [0, -1, 2]])
+    B = orc.csr(sp.csr_matrix(np.array([[1.0, 1e-12, 0.0], [-3.0, 0.0, 2.0], [0.0, 0.0, -1e-13]])))
+    N = la.ParallelCSRMatrix.from_scipy(B)
+    O = orc.OParCSR(B)
+    for kind, ref in (("linf", O.norm_linf()), ("l1", O.norm_l1()), ("max", O.norm_max()), ("frobenius", O.norm_frobenius())):
+        assert N.norm(kind) == pytest.approx(ref, rel=1e-14)
+    S = la.ParallelCSRMatrix.from_scipy(B); S.sign_transform()
+    assert np.array_equal(np.sort(S.to_scipy().data), np.sort(orc.sign_transform(B).data))
+    N.delete_zeros(1e-9)
+    same_matrix(N.to_scipy(), orc.delete_zeros(B, 1e-9), tol=0.0)
+    assert la.Compare(N, la.ParallelCSRMatrix.from_scipy(orc.delete_zeros(B, 1e-9)), 0.0) == 0
+    B2 = B.copy(); B2.data[0] += 1e-3
+    assert la.Compare(la.ParallelCSRMatrix.from_scipy(B), la.ParallelCSRMatrix.from_scipy(B2), 1e-6) == 64
+    assert la.Compare(M, la.ParallelCSRMatrix.from_scipy(sp.eye(4, format="csr")), 1e-6) & 3 == 3
+
+
+def test_norms_on_mesh_operator(la, h1_k2):
+    A, Ps, _ = h1_k2
+    for X in (A, Ps[0]):
+        M = la.ParallelCSRMatrix.from_scipy(X)
+        O = orc.OParCSR(orc.csr(X))
+        for kind, ref in (("linf", O.norm_linf()), ("l1", O.norm_l1()), ("max", O.norm_max()), ("frobenius", O.norm_frobenius())):
+            assert M.norm(kind) == pytest.approx(ref, rel=1e-13)
+
+
+# ---- smoothers ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("sweeps,weight", [(1, 1.0), (2, 0.8), (3, 0.6)])
+@pytest.mark.parametrize("iterative", [True, False])
+def test_l1_jacobi_matches_oracle(la, h1_k2, sweeps, weight, iterative):
+    A, _, _ = h1_k2
+    Ad = orc.diag_first(A)
+    ref_s = orc.OSmoother(orc.OParCSR(Ad), type=1, sweeps=sweeps, weight=weight)
+    dev_s = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), 1, {"Sweeps": sweeps, "Damping Factor": weight})
+    ref_s.iterative_mode = dev_s.iterative_mode = iterative
+    rng = np.random.default_rng(11)
+    f, u0 = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+    u, ur = u0.copy(), u0.copy()
+    dev_s.Mult(f, u); ref_s.Mult(f, ur)
+    assert close(u, ur)
+
+
+def test_plain_jacobi_uses_the_diagonal(la, h1_k1):
+    A, _, _ = h1_k1
+    s = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), la.HYPRE_SMOOTHER_TYPES["Jacobi"], {"Damping Factor": 0.7})
+    rng = np.random.default_rng(2)
+    f, u0 = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+    u = u0.copy(); s.Mult(f, u)
+    assert close(u, u0 + 0.7 * (f - A @ u0) / A.diagonal())
+
+
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
+@pytest.mark.parametrize("iterative", [True, False])
+def test_chebyshev_sweep_matches_oracle_with_injected_eigs(la, h1_k2, order, iterative):
+    A, _, _ = h1_k2
+    Ad = orc.diag_first(A)
+    eig = (1.83, 0.07)
+    ref_s = orc.OSmoother(orc.OParCSR(Ad), type=16, sweeps=2, order=order, fraction=0.3, eig=eig)
+    dev_s = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), 16,
+                                    {"Sweeps": 2, "Cheby Poly Order": order, "Cheby Poly Fraction": 0.3})
+    dev_s.set_eig_estimate(*eig)
+    ref_s.iterative_mode = dev_s.iterative_mode = iterative
+    rng = np.random.default_rng(12)
+    f, u0 = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+    u, ur = u0.copy(), u0.copy()
+    dev_s.Mult(f, u); ref_s.Mult(f, ur)
+    assert close(u, ur, tol=1e-11)
+
+
+def test_chebyshev_eig_estimate_matches_oracle(la, h1_k2):
+    """hypre_ParCSRMaxEigEstimateCG with the hypre RNG start vector: same 10-step Lanczos on both sides."""
+    A, _, _ = h1_k2
+    mx_ref, mn_ref = orc.max_eig_estimate_cg(orc.OParCSR(orc.diag_first(A)), 1, 10)
+    s = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), 16, {})
+    mx, mn = s.eig_estimate()
+    assert mx == pytest.approx(mx_ref, rel=1e-10)
+    assert mn == pytest.approx(mn_ref, rel=1e-8)
+
+
+# ---- the V-cycle -----------------------------------------------------------------------------------------
+
+def device_hierarchy(la, A, Ps, smoother, params=None, use_graph=True):
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    return la.buildHierarchyFromDeRhamSequence(dA, dPs, smoother, params or {}, use_graph=use_graph)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("smoother,params", [("L1 Jacobi", {}), ("L1 Jacobi", {"Sweeps": 2, "Damping Factor": 0.9}),
+                                             ("Chebyshev", {"Cheby Poly Order": 3})])
+def test_vcycle_matches_oracle(la, h1_k2, smoother, params, use_graph):
+    A, Ps, _ = h1_k2
+    H = device_hierarchy(la, A, Ps, smoother, params, use_graph)
+    stype = la.HYPRE_SMOOTHER_TYPES[smoother]
+    eigs = None
+    if stype == 16:
+        eigs = [H.GetSmoother(l).eig_estimate() for l in range(len(Ps))] + [(1.0, 0.1)]
+    h = oracle_h1_hierarchy(A, Ps, smoother=stype, sweeps=params.get("Sweeps", 1), weight=params.get("Damping Factor", 1.0),
+                            order=params.get("Cheby Poly Order", 2), eigs=eigs)
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"])
+    rng = np.random.default_rng(21)
+    for trial in range(3):      # repeated applies exercise graph replay
+        b = rng.uniform(-1, 1, A.shape[0])
+        x, xr = np.full_like(b, 7.0), np.empty_like(b)
+        H.Mult(b, x)
+        Hc.apply(b, xr)
+        assert close(x, xr, tol=1e-11)
+
+
+def test_vcycle_device_vectors_solver_mode_and_symmetry(la, h1_k2):
+    A, Ps, _ = h1_k2
+    H = device_hierarchy(la, A, Ps, "L1 Jacobi")
+    h = oracle_h1_hierarchy(A, Ps)
+    Hp = oracle_py_hierarchy(h)
+    n = A.shape[0]
+    rng = np.random.default_rng(13)
+    # device vectors, timing vectors b = 2 (KrylovSolverFactory.cpp:59-73)
+    db, dx = la.DeviceVector(n, 2.0), la.DeviceVector(n, 1.0)
+    H.Mult(db, dx); H.Mult(db, dx)
+    la.synchronize()
+    xr = np.empty(n); Hp.Mult(np.full(n, 2.0), xr)
+    assert close(dx.to_numpy(), xr, tol=1e-11)
+    # solver mode: sol += cycle(rhs - A sol)
+    b, x0 = rng.standard_normal(n), rng.standard_normal(n)
+    H.iterative_mode = True; Hp.preconditioner = False
+    x, xr = x0.copy(), x0.copy()
+    H.Mult(b, x); Hp.Mult(b, xr)
+    assert close(x, xr, tol=1e-11)
+    H.iterative_mode = False
+    # mg_utils::CheckSymmetric (MG_Utils.cpp:59-89, tol 1e-10)
+    v, w = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+    Mv, Mw = np.empty(n), np.empty(n)
+    H.Mult(v, Mv); H.Mult(w, Mw)
+    assert abs(w @ Mv - v @ Mw) < 1e-10
+
+
+def test_pcg_with_device_vcycle_converges_like_the_oracle(la, h1_k2):
+    """final residual of a fixed PCG solve within 1e-10 (relative) of the CPU path"""
+    A, Ps, _ = h1_k2
+    H = device_hierarchy(la, A, Ps, "L1 Jacobi")
+    h = oracle_h1_hierarchy(A, Ps)
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"])
+    b = np.full(A.shape[0], 2.0)
+    x_dev, it_dev, hist_dev = pcg(A, H.Mult, b, rtol=1e-8)
+    x_ref, it_ref, hist_ref = pcg(A, Hc.apply, b, rtol=1e-8)
+    assert it_dev == it_ref
+    assert abs(hist_dev[-1] - hist_ref[-1]) <= 1e-10 * hist_ref[0]
+    assert np.linalg.norm(b - A @ x_dev) <= 1e-7 * np.linalg.norm(b)
+
+
+def test_manual_hierarchy_assembly_equals_builder(la, h1_k2):
+    """Level-by-level construction through Set*/Finalize (the Level keys of the reference) == one-call builder."""
+    A, Ps, _ = h1_k2
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    H = la.Hierarchy(len(Ps) + 1)
+    ops = [dA]
+    for P in dPs:
+        Ac = la.RAP(ops[-1], P); Ac.fix_zero_rows(); ops.append(Ac)
+    for l, op in enumerate(ops):
+        H.SetOperator(l, op)
+        if l > 0:
+            H.SetProlongator(l, dPs[l - 1])
+        if l < len(ops) - 1:
+            H.SetSmoothers(l, la.HypreSmootherWrapper(op, 1), la.HypreSmootherWrapper(op, 1))
+    H.SetCoarseSolver(la.CoarseSolver(ops[-1]))
+    H.Finalize(use_graph=False)
+    H2 = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi", use_graph=False)
+    b = np.random.default_rng(4).standard_normal(A.shape[0])
+    x1, x2 = np.empty_like(b), np.empty_like(b)
+    H.Mult(b, x1); H2.Mult(b, x2)
+    assert np.array_equal(x1, x2)
