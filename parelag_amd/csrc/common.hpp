@@ -23,6 +23,7 @@ struct Error : std::runtime_error {
 };
 
 void set_last_error(const std::string &msg);
+bool debug_sync();
 [[noreturn]] void fail(int code, const char *fmt, ...);
 
 #define ELAG_HIP_CHECK(expr)                                                                      \
@@ -31,6 +32,13 @@ void set_last_error(const std::string &msg);
         if (e_ != hipSuccess)                                                                     \
             ::elag::fail(ELAG_HIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
                          __FILE__, __LINE__);                                                     \
+    } while (0)
+
+// after every kernel launch; ELAG_HIP_DEBUG_SYNC=1 turns each launch into a synchronous, checked one
+#define ELAG_LAUNCH_CHECK()                                             \
+    do {                                                                \
+        ELAG_HIP_CHECK(hipGetLastError());                              \
+        if (::elag::debug_sync()) ELAG_HIP_CHECK(hipDeviceSynchronize()); \
     } while (0)
 
 #define ELAG_REQUIRE(cond, ...)                                  \
@@ -77,12 +85,16 @@ Context &ctx();
 void require_init();
 
 // ---- device memory helpers ---------------------------------------------------------------------
+bool debug_sync();     // ELAG_HIP_DEBUG_SYNC=1
+int debug_poison();  // ELAG_HIP_DEBUG_POISON=<byte>: fill every fresh allocation (debug aid), -1 = off
+
 template <class T>
 T *dev_alloc(size_t n)
 {
     T *p = nullptr;
     if (n == 0) n = 1;
     ELAG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)));
+    if (debug_poison() >= 0) ELAG_HIP_CHECK(hipMemset(p, debug_poison(), n * sizeof(T)));
     return p;
 }
 template <class T>
@@ -109,19 +121,26 @@ std::vector<T> host_from_dev(const T *d, size_t n)
     return v;
 }
 
-// Stream-ordered temporary (setup-time scratch).
+// Setup-time scratch: a LIFO stack of device slabs owned by the context.  Temps are automatic variables, so
+// they are released in reverse order of creation; memory is recycled in stream order (all work runs on
+// ctx().stream), which makes reuse safe without any synchronisation.  (hipMallocAsync's pool was measured to
+// hand out blocks that corrupted in-flight setup data on ROCm 7.2 / gfx950, so it is not used.)
+void *scratch_push(size_t bytes, int *slab, size_t *prev_top);
+void scratch_pop(int slab, size_t prev_top);
+void scratch_release_all();
+
 template <class T>
 struct Temp {
     T *p = nullptr;
+    int slab = -1;
+    size_t prev_top = 0;
     explicit Temp(size_t n)
     {
         if (n == 0) n = 1;
-        ELAG_HIP_CHECK(hipMallocAsync(reinterpret_cast<void **>(&p), n * sizeof(T), ctx().stream));
+        p = static_cast<T *>(scratch_push(n * sizeof(T), &slab, &prev_top));
+        if (debug_poison() >= 0) ELAG_HIP_CHECK(hipMemsetAsync(p, debug_poison(), n * sizeof(T), ctx().stream));
     }
-    ~Temp()
-    {
-        if (p) (void)hipFreeAsync(p, ctx().stream);
-    }
+    ~Temp() { if (p) scratch_pop(slab, prev_top); }
     Temp(const Temp &) = delete;
     Temp &operator=(const Temp &) = delete;
     operator T *() const { return p; }

@@ -2,6 +2,8 @@
 #include "kernels.hpp"
 #include "comm.hpp"
 
+#include <algorithm>
+
 namespace elag {
 
 static thread_local std::string g_last_error;
@@ -22,6 +24,72 @@ Context &ctx()
 {
     static Context c;
     return c;
+}
+
+bool debug_sync()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ELAG_HIP_DEBUG_SYNC"); v = (e && atoi(e)) ? 1 : 0; }
+    return v == 1;
+}
+
+// ---- scratch stack ------------------------------------------------------------------------------
+namespace {
+struct Slab { char *p; size_t cap, top; };
+std::vector<Slab> g_slabs;
+int g_cur = -1;
+}  // namespace
+
+void *scratch_push(size_t bytes, int *slab, size_t *prev_top)
+{
+    bytes = (bytes + 255) & ~size_t(255);
+    // find room in the current slab, else move to / create the next one
+    while (true) {
+        if (g_cur >= 0 && g_slabs[(size_t)g_cur].top + bytes <= g_slabs[(size_t)g_cur].cap) break;
+        if (g_cur + 1 < (int)g_slabs.size() && g_slabs[(size_t)g_cur + 1].cap >= bytes) { g_cur++; continue; }
+        // new slab (inserted right after the current one); later, smaller slabs are dropped
+        for (size_t i = (size_t)g_cur + 1; i < g_slabs.size(); i++) (void)hipFree(g_slabs[i].p);
+        g_slabs.resize((size_t)g_cur + 1);
+        size_t cap = size_t(64) << 20;
+        if (!g_slabs.empty()) cap = std::max(cap, 2 * g_slabs.back().cap);
+        cap = std::max(cap, bytes);
+        Slab s{nullptr, cap, 0};
+        ELAG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s.p), cap));
+        g_slabs.push_back(s);
+        g_cur++;
+    }
+    Slab &s = g_slabs[(size_t)g_cur];
+    *slab = g_cur;
+    *prev_top = s.top;
+    void *p = s.p + s.top;
+    s.top += bytes;
+    return p;
+}
+
+void scratch_pop(int slab, size_t prev_top)
+{
+    // LIFO: everything pushed after this allocation has already been popped
+    for (int i = slab + 1; i <= g_cur; i++) g_slabs[(size_t)i].top = 0;
+    g_cur = slab;
+    g_slabs[(size_t)slab].top = prev_top;
+    if (slab > 0 && prev_top == 0) g_cur = slab - 1;
+}
+
+void scratch_release_all()
+{
+    for (auto &s : g_slabs) (void)hipFree(s.p);
+    g_slabs.clear();
+    g_cur = -1;
+}
+
+int debug_poison()
+{
+    static int v = -2;
+    if (v == -2) {
+        const char *e = getenv("ELAG_HIP_DEBUG_POISON");
+        v = e ? (atoi(e) & 0xff) : -1;
+    }
+    return v;
 }
 
 void require_init()
@@ -114,6 +182,7 @@ int elag_hip_finalize(void)
         (void)hipStreamSynchronize(c.stream);
         (void)hipStreamSynchronize(c.comm_stream);
         comm_destroy();
+        scratch_release_all();
         (void)hipFree(c.d_scalar);
         (void)hipHostFree(c.h_scalar);
         (void)hipEventDestroy(c.ev_pack);

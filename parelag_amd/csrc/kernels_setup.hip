@@ -96,7 +96,7 @@ void exclusive_scan(const int *in, int *out, int n)
         exclusive_scan(bsum, boff, nb);
         hipLaunchKernelGGL(scan_block_final, dim3(nb), dim3(kBlock), 0, st, in, n, (const int *)boff.p, out, 1);
     }
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
 }
 
 // ================================================================================================
@@ -347,7 +347,7 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C)
     if (plan.nbig)
         hipLaunchKernelGGL((esc_kernel<kBigCap, true, false, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
                            plan.ub.p, plan.biglist.p, ex, rownnz.p, (const int *)nullptr, (int *)nullptr, (double *)nullptr);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
     int *CI = dev_alloc<int>((size_t)n + 1);
     exclusive_scan(rownnz, CI, n);
     int nnz = 0;
@@ -363,7 +363,7 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C)
     if (plan.nbig)
         hipLaunchKernelGGL((esc_kernel<kBigCap, true, true, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
                            plan.ub.p, plan.biglist.p, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
     C.choose_spmv_shape();
 }
 
@@ -444,7 +444,7 @@ void csr_transpose(const DevCSR &A, DevCSR &AT)
         ELAG_HIP_CHECK(hipMemcpyAsync(cursor, AT.I, sizeof(int) * (size_t)A.ncols, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(transpose_fill_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, st, A.nrows, (const int *)A.I,
                            (const int *)A.J, (const double *)A.a, cursor.p, AT.J, AT.a);
-        ELAG_HIP_CHECK(hipGetLastError());
+        ELAG_LAUNCH_CHECK();
         AT.choose_spmv_shape();
         csr_sort_rows(AT);
     }
@@ -498,7 +498,7 @@ void csr_delete_zeros(const DevCSR &A, double tol, DevCSR &out)
     out.a = dev_alloc<double>((size_t)nnz);
     if (n) hipLaunchKernelGGL(fill_keep_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, (const int *)A.I, (const int *)A.J,
                               (const double *)A.a, tol, (const int *)OI, out.J, out.a);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
     out.choose_spmv_shape();
 }
 
@@ -506,7 +506,7 @@ void csr_scale_rows(DevCSR &A, const double *d)
 {
     if (A.nrows == 0) return;
     hipLaunchKernelGGL(scale_rows_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, ctx().stream, A.nrows, (const int *)A.I, A.a, d);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
 }
 
 void csr_copy(const DevCSR &A, DevCSR &out)

@@ -104,7 +104,7 @@ void launch_lpr(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hipStrea
         else
             hipLaunchKernelGGL((spmv_fused_kernel<LPR, false, false>), dim3(grid), dim3(kBlock), 0, st, A.nrows, A.I, A.J, A.a, oI, oJ, oa, p);
     }
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
 }
 
 }  // namespace
@@ -244,7 +244,7 @@ void reduce_launch(long long n, const double *x, const double *y, int mode, doub
     double *part = reduce_scratch();
     hipLaunchKernelGGL(reduce_stage1, dim3(grid), dim3(kBlock), 0, st, n, x, y, mode, part);
     hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(kBlock), 0, st, grid, part, mode, d_result);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
 }
 
 double reduce_to_host(long long n, const double *x, int mode)
@@ -263,31 +263,31 @@ void vec_axpby(int n, double a, const double *x, double b, const double *y, doub
 {
     if (n == 0) return;
     hipLaunchKernelGGL(axpby_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, n, a, x, b, y, out);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
 }
 void vec_scale_mul(int n, double a, const double *x, const double *d, double *out)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(scale_mul_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, n, a, x, d, out);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
 }
 void vec_add_scaled_mul(int n, const double *y, const double *d, const double *z, double c, const double *r, double *out)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(add_scaled_mul_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, n, y, d, z, c, r, out);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
 }
 void vec_fill(int n, double v, double *x)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(fill_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, n, v, x);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
 }
 void vec_gather(int n, const int *idx, const double *x, double *buf, hipStream_t st)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(gather_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, st ? st : ctx().stream, n, idx, x, buf);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
 }
 void vec_dot(int n, const double *x, const double *y, double *d_result)
 {
@@ -436,7 +436,7 @@ void l1_norms(const DevCSR &diag, const DevCSR *offd, int option, double *l1, in
     const bool ho = offd && offd->nnz > 0;
     hipLaunchKernelGGL(l1_norms_kernel, dim3(row_grid(diag.nrows, 8)), dim3(kBlock), 0, ctx().stream, diag.nrows,
                        diag.I, diag.J, diag.a, ho ? offd->I : nullptr, ho ? offd->a : nullptr, option, l1, d_bad);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
 }
 
 void extract_diagonal(const DevCSR &diag, double *d)
@@ -444,21 +444,21 @@ void extract_diagonal(const DevCSR &diag, double *d)
     if (diag.nrows == 0) return;
     hipLaunchKernelGGL(extract_diag_kernel, dim3(row_grid(diag.nrows, 8)), dim3(kBlock), 0, ctx().stream, diag.nrows,
                        diag.I, diag.J, diag.a, d);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
 }
 
 void vec_rsqrt(int n, const double *d, double *out, int *d_bad)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(rsqrt_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, n, d, out, d_bad);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
 }
 
 void vec_reciprocal_scale(int n, double w, const double *d, double *out)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(recip_scale_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, n, w, d, out);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
 }
 
 int fix_zero_rows(DevCSR &diag, DevCSR *offd)
@@ -469,7 +469,7 @@ int fix_zero_rows(DevCSR &diag, DevCSR *offd)
     const bool ho = offd && offd->nnz > 0;
     hipLaunchKernelGGL(fix_zero_rows_kernel, dim3(row_grid(diag.nrows, 8)), dim3(kBlock), 0, ctx().stream, diag.nrows,
                        diag.I, diag.J, diag.a, ho ? offd->I : nullptr, ho ? offd->a : nullptr, cnt.p);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
     return read_counter(cnt);
 }
 
@@ -477,14 +477,14 @@ void values_abs(int64_t n, const double *a, double *out)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(abs_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, (long long)n, a, out);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
 }
 
 void values_sign(int64_t n, double *a)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(sign_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, (long long)n, a);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
 }
 
 // ================================================================================================
@@ -509,7 +509,7 @@ void dense_gemv(int n, const double *Minv, const double *x, double *y)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(dense_gemv_kernel, dim3(row_grid(n, 64)), dim3(kBlock), 0, ctx().stream, n, Minv, x, y);
-    ELAG_HIP_CHECK(hipGetLastError());
+    ELAG_LAUNCH_CHECK();
 }
 
 }  // namespace k

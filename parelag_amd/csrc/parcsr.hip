@@ -89,7 +89,7 @@ void par_spmv(ParCSR &A, k::SpmvArgs a)
     if (st) {
         const unsigned g = (unsigned)std::min<long long>(((long long)st + 255) / 256, 1024);
         hipLaunchKernelGGL(gather_scaled_kernel, dim3(g), dim3(256), 0, c.stream, st, (const int *)A.d_send_elmts, a.x, a.cs, A.d_send_buf);
-        ELAG_HIP_CHECK(hipGetLastError());
+        ELAG_LAUNCH_CHECK();
     }
     ELAG_HIP_CHECK(hipEventRecord(c.ev_pack, c.stream));
     ELAG_HIP_CHECK(hipStreamWaitEvent(c.comm_stream, c.ev_pack, 0));
