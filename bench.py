@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Benchmark of the AMGe V-cycle hot path on MI355X (contract: see the task's bench.py section).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[1]): MultigridTest0Form on cube456 refined x3, 4 levels by derefinement, L1-Jacobi
+(1 sweep) pre/post smoothing, dense coarse solve; one *step* = one V-cycle = one Hierarchy::Mult in preconditioner
+mode on the timing vector b = 2 (src/linalg/factories/ParELAG_KrylovSolverFactory.cpp:59-73), vectors resident in HBM.
+
+Besides the V-cycle rate the line carries
+  roofline     -- the fine-level CSR SpMV kernel at the HBM-bound size (cube456 x5 by default; x3 is cache
+                  resident), algorithmic bytes / mean launch time from HIP events on the library stream;
+  cpu_baseline -- the CPU oracle's all-C V-cycle (a *port*; hypre/MFEM cannot be built here) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy peak 6290 GB/s
+
+
+def spmv_bytes(n_rows, n_cols, nnz):
+    """12 nnz + 4 (n+1) + 8 n_cols (x once) + 8 n (y write)."""
+    return 12 * nnz + 4 * (n_rows + 1) + 8 * n_cols + 8 * n_rows
+
+
+def vcycle_bytes(shapes):
+    """Algorithmic bytes of one V-cycle with 1-sweep l1-Jacobi: per non-coarsest level a zero-guess pre-smooth
+    (24 n), residual (SpMV + 8 n), restriction (SpMV of P^T), prolongation+add (SpMV of P + 8 n), post-smooth
+    (SpMV + 24 n); dense coarse solve 8 nc^2."""
+    total = 0
+    for (n, nnzA, nc, nnzP) in shapes[:-1]:
+        total += 24 * n + (spmv_bytes(n, n, nnzA) + 8 * n) + spmv_bytes(nc, n, nnzP) + (spmv_bytes(n, nc, nnzP) + 8 * n) \
+            + (spmv_bytes(n, n, nnzA) + 24 * n)
+    nc = shapes[-1][0]
+    total += 8 * nc * nc + 16 * nc
+    return total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--refines", type=int, default=3, help="uniform refinements of cube456 for the V-cycle workload")
+    ap.add_argument("--roofline-refines", type=int, default=5, help="refinements for the HBM-bound SpMV measurement")
+    ap.add_argument("--roofline-reps", type=int, default=50)
+    ap.add_argument("--roofline-only", action="store_true", help="only run the fine-level SpMV launches (for rocprofv3)")
+    ap.add_argument("--smoother", default="L1 Jacobi")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    from parelag_amd import _lib, linalg as la, meshgen
+
+    dist = None
+    if world > 1:
+        from parelag_amd import distributed
+        dist = distributed.init(rank, world)
+    else:
+        _lib.init()
+
+    out = {}
+    # ---------------------------------------------------------------- roofline leg (rank 0 of N=1 runs only)
+    roof = None
+    if world == 1 and not args.no_roofline:
+        k = args.roofline_refines
+        t0 = time.time()
+        Ar, _, _ = meshgen.h1_problem(k, nlevels=1)
+        gen_s = time.time() - t0
+        dAr = la.ParallelCSRMatrix.from_scipy(Ar)
+        n, nnz = Ar.shape[0], Ar.nnz
+        x = la.DeviceVector.from_numpy(np.random.default_rng(12345).uniform(-1, 1, n))
+        y = la.DeviceVector(n)
+        ms = la.time_kernel(dAr, "spmv", x, y, reps=args.roofline_reps)
+        S = la.HypreSmootherWrapper(dAr, 1)
+        ms_j = la.time_kernel(dAr, "jacobi", x, y, reps=args.roofline_reps, smoother=S)
+        b = spmv_bytes(n, n, nnz)
+        roof = {"bound": "hbm", "kernel": "spmv_fused_kernel (fine-level y = A x)", "workload": f"cube456 x{k} refines, H1 A: n={n}, nnz={nnz}",
+                "achieved": round(b / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch": b, "ms_per_launch": round(ms, 5), "frac_of_measured_copy_peak_6290": round(b / (ms * 1e-3) / 1e9 / 6290.0, 4),
+                "jacobi_sweep_GBs": round((b + 16 * n) / (ms_j * 1e-3) / 1e9, 1), "generate_s": round(gen_s, 1)}
+        del dAr, x, y, S
+        if args.roofline_only:
+            print(json.dumps({"roofline": roof}))
+            return
+
+    # ---------------------------------------------------------------- V-cycle workload
+    A, Ps, seq = meshgen.h1_problem(args.refines)
+    if world == 1:
+        dA = la.ParallelCSRMatrix.from_scipy(A)
+        dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+        t0 = time.time()
+        H = la.buildHierarchyFromDeRhamSequence(dA, dPs, args.smoother, use_graph=not args.no_graph)
+        la.synchronize()
+        setup_s = time.time() - t0
+        n_local = A.shape[0]
+        level_shapes = []
+        for l in range(len(Ps) + 1):
+            op = H.GetOperator(l)
+            level_shapes.append((op.Height(), op.nnz, Ps[l].shape[1] if l < len(Ps) else 0, Ps[l].nnz if l < len(Ps) else 0))
+    else:
+        from parelag_amd import distributed
+        H, n_local, level_shapes, setup_s = distributed.build_hierarchy(dist, A, Ps, seq, args.smoother)
+
+    rhs = la.DeviceVector(n_local, 2.0)
+    sol = la.DeviceVector(n_local, 1.0)
+
+    def barrier():
+        la.synchronize()
+        if dist is not None:
+            dist.barrier()
+        la.synchronize()
+
+    for _ in range(args.warmup):
+        H.Mult(rhs, sol)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        H.Mult(rhs, sol)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        elapsed = dist.allreduce_max(elapsed)
+    # device-side time of the same loop by HIP events (no host launch overhead in between)
+    ms_dev = H.time_apply(rhs, sol, min(args.steps, 500))
+    if dist is not None:
+        ms_dev = dist.allreduce_max(ms_dev)
+
+    vbytes = vcycle_bytes(level_shapes)
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # fine-level kernel at the benchmark size (cache-resident at x3)
+    fine = None
+    if world == 1:
+        A0 = H.GetOperator(0)
+        n0, nnz0 = A0.Height(), A0.nnz
+        x = la.DeviceVector.from_numpy(np.random.default_rng(1).uniform(-1, 1, n0))
+        y = la.DeviceVector(n0)
+        ms0 = la.time_kernel(A0, "spmv", x, y, reps=200)
+        b0 = spmv_bytes(n0, n0, nnz0)
+        fine = {"n": n0, "nnz": nnz0, "bytes_per_launch": b0, "us_per_launch": round(ms0 * 1e3, 2),
+                "achieved_GBs": round(b0 / (ms0 * 1e-3) / 1e9, 1), "note": "operator is cache resident (L2/Infinity Cache), not an HBM figure"}
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline and rank == 0:
+        from oracle import oracle as orc
+        from tests.helpers import oracle_h1_hierarchy
+        h = oracle_h1_hierarchy(A, Ps, smoother=la.HYPRE_SMOOTHER_TYPES[args.smoother])
+        Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], native=True)
+        b = np.full(A.shape[0], 2.0); xs = np.empty_like(b)
+        Hc.apply(b, xs)
+        cnt, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(10):
+                Hc.apply(b, xs)
+            cnt += 10
+            if time.perf_counter() - t0 >= args.cpu_seconds:
+                break
+        cpu_rate = cnt / (time.perf_counter() - t0)
+        cpu = {"value": round(cpu_rate, 2), "unit": "V-cycles/s", "cores": 1, "kind": "port",
+               "sample": f"{cnt} V-cycles of the same cube456 x{args.refines} hierarchy on one host core "
+                         f"(oracle/elag_oracle.c, -O3 -march=native; hypre/MFEM unavailable, so this is a restatement)"}
+        # parity spot check of the timed operator against the baseline operator
+        xd = sol.to_numpy()
+        out["parity_rel_err_vs_oracle"] = float(np.max(np.abs(xd - xs)) / np.max(np.abs(xs)))
+
+    if rank == 0:
+        out.update({
+            "metric": "V-cycles/sec (MultigridTest0Form cube456, Hierarchy::Mult in preconditioner mode)",
+            "value": round(args.steps / elapsed, 2),
+            "unit": "V-cycles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"MultigridTest0Form cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
+                                   f"{args.smoother} 1 sweep pre/post, dense coarse solve, b=2",
+                       "levels": [{"n": s[0], "nnz": s[1]} for s in level_shapes],
+                       "hipgraph": not args.no_graph and world == 1, "parallelism": f"row-block domain decomposition x{world}"},
+            "device_ms_per_step": round(ms_dev, 5),
+            "vcycle_algorithmic_bytes": vbytes,
+            "vcycle_achieved_GBs": round(vbytes / (ms_dev * 1e-3) / 1e9, 1),
+            "setup_s": round(setup_s, 3),
+            "fine_level_spmv": fine,
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        })
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

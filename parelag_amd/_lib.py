@@ -80,6 +80,7 @@ _SIGNATURES = {
     "elag_hip_parcsr_norm": [_p, _i, _dp],
     "elag_hip_parcsr_compare": [_p, _p, _d, _ip],
     "elag_hip_parcsr_get_diagonal": [_p, _p, _i],
+    "elag_hip_parcsr_set_spmv_lanes": [_p, _i],
     "elag_hip_smoother_create": [C.POINTER(_p), _p, _i, _i, _d, _d, _i, _d],
     "elag_hip_smoother_get_eig_estimate": [_p, _dp, _dp],
     "elag_hip_smoother_set_eig_estimate": [_p, _d, _d],

@@ -517,6 +517,16 @@ int elag_hip_parcsr_compare(elag_hip_parcsr_t A, elag_hip_parcsr_t B, double tol
     });
 }
 
+int elag_hip_parcsr_set_spmv_lanes(elag_hip_parcsr_t A, int lanes)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(A, "null matrix");
+        ELAG_REQUIRE(lanes >= 0 && lanes <= 64 && (lanes & (lanes - 1)) == 0, "lanes must be 0 or a power of two <= 64");
+        if (lanes == 0) { A->diag.choose_spmv_shape(); A->offd.choose_spmv_shape(); }
+        else A->diag.lanes_per_row = lanes;
+    });
+}
+
 int elag_hip_parcsr_get_diagonal(elag_hip_parcsr_t A, double *d, int loc)
 {
     return guarded([&] {

@@ -235,6 +235,9 @@ class ParallelCSRMatrix:
         check(self._lib.elag_hip_parcsr_norm(self.h, k, C.byref(v)))
         return v.value
 
+    def set_spmv_lanes(self, lanes: int):
+        check(self._lib.elag_hip_parcsr_set_spmv_lanes(self.h, int(lanes)))
+
     def get_diagonal(self):
         d = np.empty(self.Height())
         check(self._lib.elag_hip_parcsr_get_diagonal(self.h, _np_ptr(d), HOST))
