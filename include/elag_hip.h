@@ -221,12 +221,30 @@ ELAG_HIP_API int elag_hip_hierarchy_destroy(elag_hip_hierarchy_t H);
 
 /* buildHierarchyFromDeRhamSequence + AMGeSolverFactory::_do_build_solver in one call
  * (Hierarchy.cpp:282-383, AMGeSolverFactory.cpp:26-169): A_{l+1} = P_l^T A_l P_l, optional FixZeroRows
- * (essential BCs), a smoother of `relax_type` on every non-coarsest level (pre = post), dense coarse solve.
- * P[l] maps level l+1 -> l.  The hierarchy owns everything it builds; level operators are retrievable. */
+ * (essential BCs), a smoother of `relax_type` on every non-coarsest level (pre = post), coarse solve.
+ * P[l] maps level l+1 -> l.  The hierarchy owns everything it builds; level operators are retrievable.
+ * The option fields are the AMGe / smoother ParameterList entries of the reference plus two device knobs. */
+typedef struct {
+    int fix_zero_rows;      /* hypre_ParCSRMatrixFixZeroRows on every coarse operator (Hierarchy.cpp:366-371)     */
+    int relax_type;         /* "Smoother" type (HypreSmootherFactory.cpp:92-109): 0, 1 or 16                      */
+    int sweeps;             /* "Sweeps"                                                                            */
+    double damping;         /* "Damping Factor"                                                                    */
+    int cheby_order;        /* "Cheby Poly Order"                                                                  */
+    double cheby_fraction;  /* "Cheby Poly Fraction"                                                               */
+    int coarse_kind;        /* "Coarse solver": 0 = dense Cholesky                                                 */
+    int coarse_iters;
+    int use_graph;          /* capture the cycle in a hipGraph (single rank)                                       */
+    int reorder;            /* renumber the dofs of every level for cache locality of the x gathers: children are
+                               numbered contiguously under their strongest coarse parent (from P), the coarsest
+                               level by Cuthill-McKee.  -1 = automatic (on when level 0 has >= 2^18 rows), 0 = off,
+                               1 = on.  Purely internal: vectors cross the ABI in the caller's numbering; operators
+                               returned by elag_hip_hierarchy_get_operator are in the internal numbering.        */
+} elag_hip_amge_options;
+ELAG_HIP_API int elag_hip_amge_default_options(elag_hip_amge_options *opt);
 ELAG_HIP_API int elag_hip_hierarchy_build(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P,
-                                          const elag_hip_parcsr_t *P, int fix_zero_rows,
-                                          int relax_type, int sweeps, double damping, int cheby_order,
-                                          double cheby_fraction, int coarse_kind, int coarse_iters, int use_graph);
+                                          const elag_hip_parcsr_t *P, const elag_hip_amge_options *opt);
+/* new -> old row map of a level (identity when the hierarchy was not reordered); `order` has num_rows entries */
+ELAG_HIP_API int elag_hip_hierarchy_get_ordering(elag_hip_hierarchy_t H, int level, int *order);
 ELAG_HIP_API int elag_hip_hierarchy_get_operator(elag_hip_hierarchy_t H, int level, elag_hip_parcsr_t *A);
 ELAG_HIP_API int elag_hip_hierarchy_get_smoother(elag_hip_hierarchy_t H, int level, elag_hip_smoother_t *S);
 

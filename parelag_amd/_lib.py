@@ -47,6 +47,11 @@ class ParCSRInfo(C.Structure):
     ]
 
 
+class AMGeOptions(C.Structure):
+    _fields_ = [("fix_zero_rows", _i), ("relax_type", _i), ("sweeps", _i), ("damping", _d), ("cheby_order", _i),
+                ("cheby_fraction", _d), ("coarse_kind", _i), ("coarse_iters", _i), ("use_graph", _i), ("reorder", _i)]
+
+
 # name -> argtypes (restype is int status unless listed in _RESTYPES)
 _SIGNATURES = {
     "elag_hip_init": [_i],
@@ -98,7 +103,9 @@ _SIGNATURES = {
     "elag_hip_hierarchy_finalize": [_p, _i],
     "elag_hip_hierarchy_apply": [_p, _p, _p, _i, _i],
     "elag_hip_hierarchy_destroy": [_p],
-    "elag_hip_hierarchy_build": [C.POINTER(_p), _p, _i, C.POINTER(_p), _i, _i, _i, _d, _i, _d, _i, _i, _i],
+    "elag_hip_amge_default_options": [C.POINTER(AMGeOptions)],
+    "elag_hip_hierarchy_build": [C.POINTER(_p), _p, _i, C.POINTER(_p), C.POINTER(AMGeOptions)],
+    "elag_hip_hierarchy_get_ordering": [_p, _i, _p],
     "elag_hip_hierarchy_get_operator": [_p, _i, C.POINTER(_p)],
     "elag_hip_hierarchy_get_smoother": [_p, _i, C.POINTER(_p)],
     "elag_hip_time_kernel": [_p, _p, _i, _i, _p, _p, _dp],

@@ -150,9 +150,16 @@ struct Temp {
 struct DevCSR {
     int nrows = 0, ncols = 0;
     int64_t nnz = 0;
-    int *I = nullptr, *J = nullptr;
+    int *I = nullptr, *J = nullptr;   // J and a carry 4 zero-filled pad entries past nnz (16-byte vector loads)
     double *a = nullptr;
-    int lanes_per_row = 8;  // SpMV row-group width chosen from nnz/nrows
+    // SpMV dispatch: lanes_per_row > 0 -> wave-group-per-row kernel with that many lanes;
+    //                lanes_per_row == 0 -> LDS-staged stream kernel over the row blocks below.
+    int lanes_per_row = 8;
+    int *block_row = nullptr;  // nblocks+1 row offsets: block c owns rows whose first entry lies in [c*kStreamNnz, (c+1)*kStreamNnz)
+    int nblocks = 0, max_row_nnz = 0;
+
+    static constexpr int kStreamNnz = 2048;     // entries per 256-thread workgroup
+    static constexpr int kStreamMaxRow = 4096;  // longer rows fall back to the row-group kernel
 
     DevCSR() = default;
     DevCSR(const DevCSR &) = delete;
@@ -163,24 +170,18 @@ struct DevCSR {
         if (this != &o) {
             release();
             nrows = o.nrows; ncols = o.ncols; nnz = o.nnz; I = o.I; J = o.J; a = o.a;
-            lanes_per_row = o.lanes_per_row;
-            o.I = o.J = nullptr; o.a = nullptr; o.nnz = 0; o.nrows = o.ncols = 0;
+            lanes_per_row = o.lanes_per_row; block_row = o.block_row; nblocks = o.nblocks; max_row_nnz = o.max_row_nnz;
+            o.I = o.J = nullptr; o.a = nullptr; o.block_row = nullptr; o.nnz = 0; o.nrows = o.ncols = 0; o.nblocks = 0;
         }
         return *this;
     }
     ~DevCSR() { release(); }
-    void release() { dev_free(I); dev_free(J); dev_free(a); }
-    void alloc(int nr, int nc, int64_t nz)
-    {
-        release();
-        nrows = nr; ncols = nc; nnz = nz;
-        I = dev_alloc<int>((size_t)nr + 1);
-        J = dev_alloc<int>((size_t)nz);
-        a = dev_alloc<double>((size_t)nz);
-    }
+    void release() { dev_free(I); dev_free(J); dev_free(a); dev_free(block_row); nblocks = 0; }
+    void alloc(int nr, int nc, int64_t nz);
+    void alloc_entries(int64_t nz);   // J / a (+pad) for a matrix whose I is already in place
     void upload(int nr, int nc, const int *hi, const int *hj, const double *ha);
     void set_empty(int nr, int nc);
-    void choose_spmv_shape();
+    void choose_spmv_shape();   // call after I/J/a are final: picks the kernel and builds the row-block plan
 };
 
 }  // namespace elag

@@ -119,22 +119,48 @@ void DevCSR::upload(int nr, int nc, const int *hi, const int *hj, const double *
     choose_spmv_shape();
 }
 
+void DevCSR::alloc(int nr, int nc, int64_t nz)
+{
+    release();
+    nrows = nr; ncols = nc;
+    I = dev_alloc<int>((size_t)nr + 1);
+    alloc_entries(nz);
+}
+
+void DevCSR::alloc_entries(int64_t nz)
+{
+    dev_free(J); dev_free(a);
+    nnz = nz;
+    J = dev_alloc<int>((size_t)nz + 4);
+    a = dev_alloc<double>((size_t)nz + 4);
+    // zero pad: the stream kernel's 16-byte loads may run up to 3 entries past nnz
+    ELAG_HIP_CHECK(hipMemsetAsync(J + nz, 0, 4 * sizeof(int), ctx().stream));
+    ELAG_HIP_CHECK(hipMemsetAsync(a + nz, 0, 4 * sizeof(double), ctx().stream));
+}
+
 void DevCSR::set_empty(int nr, int nc)
 {
     alloc(nr, nc, 0);
     ELAG_HIP_CHECK(hipMemsetAsync(I, 0, sizeof(int) * ((size_t)nr + 1), ctx().stream));
-    lanes_per_row = 1;
+    choose_spmv_shape();
 }
 
 void DevCSR::choose_spmv_shape()
 {
-    // lanes per row: smallest power of two >= (nnz/row)/2, so a row takes ~2 strided iterations
+    // ELAG_HIP_LPR=<n> forces the row-group kernel with n lanes (tuning / A-B runs)
     static int forced = -1;
     if (forced < 0) {
         const char *e = getenv("ELAG_HIP_LPR");
         forced = e ? atoi(e) : 0;
     }
+    dev_free(block_row);
+    nblocks = 0;
+    k::build_stream_plan(*this);
     if (forced > 0) { lanes_per_row = forced; return; }
+    // the stream kernel wins once the matrix outgrows the caches' latency regime; small (coarse-level) operators
+    // are launch/latency-bound and do better with one dependent phase less
+    if (max_row_nnz <= kStreamMaxRow && nnz >= (int64_t(1) << 20)) { lanes_per_row = 0; return; }
+    // lanes per row = smallest power of two >= (nnz/row)/2
     const double avg = nrows ? (double)nnz / nrows : 0.0;
     int l = 1;
     while (l < 64 && 2.0 * l < avg) l <<= 1;

@@ -2,6 +2,7 @@
 // hierarchy builder (buildHierarchyFromDeRhamSequence :282-383 + AMGeSolverFactory.cpp:26-169) and the
 // measurement hooks used by bench.py.
 #include <algorithm>
+#include <cmath>
 
 #include "comm.hpp"
 #include "smoother.hpp"
@@ -38,12 +39,18 @@ struct elag_hip_hierarchy_s {
     std::vector<elag_hip_smoother_s *> owned_smoothers;
     elag_hip_coarse_s *owned_coarse = nullptr;
     double *r0 = nullptr, *e0 = nullptr;  // solver-mode residual / correction on level 0
+    // internal renumbering (elag_hip_amge_options::reorder): order[l][new] = old
+    bool reordered = false;
+    ParCSR *A_user = nullptr;             // level-0 operator in the caller's numbering (solver-mode residual)
+    std::vector<std::vector<int>> order;  // host copies, one per level
+    int *d_order0 = nullptr;
+    double *p_rhs = nullptr, *p_sol = nullptr;
 
     ~elag_hip_hierarchy_s()
     {
         for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);
         for (auto &l : lev) { dev_free(l.resid); dev_free(l.sol); dev_free(l.alt); dev_free(l.tmp_resid); }
-        dev_free(r0); dev_free(e0);
+        dev_free(r0); dev_free(e0); dev_free(d_order0); dev_free(p_rhs); dev_free(p_sol);
         for (auto *s : owned_smoothers) delete s;
         delete owned_coarse;
         for (auto *m : owned_mats) delete m;
@@ -71,6 +78,11 @@ struct elag_hip_hierarchy_s {
         dev_free(r0); dev_free(e0);
         r0 = dev_alloc<double>((size_t)lev[0].A->nrows());
         e0 = dev_alloc<double>((size_t)lev[0].A->nrows());
+        if (reordered) {
+            dev_free(p_rhs); dev_free(p_sol);
+            p_rhs = dev_alloc<double>((size_t)lev[0].A->nrows());
+            p_sol = dev_alloc<double>((size_t)lev[0].A->nrows());
+        }
         for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);
         graphs.clear();
         use_graph = graph && ctx().nranks == 1;
@@ -126,15 +138,29 @@ struct elag_hip_hierarchy_s {
     {
         Level &L0 = lev[0];
         const int n = L0.A->nrows();
-        if (precond) {
-            iterate(0, rhs, sol, L0.alt);
-        } else {
-            k::SpmvArgs a;  // r = rhs - A sol (:119-128)
-            a.x = sol; a.alpha = -1.0; a.f = rhs; a.gamma = 1.0; a.out = r0;
-            par_spmv(*L0.A, a);
-            iterate(0, r0, e0, L0.alt);
-            k::vec_axpby(n, 1.0, sol, 1.0, e0, sol);  // sol += correction (:134-135)
+        if (!reordered) {
+            if (precond) {
+                iterate(0, rhs, sol, L0.alt);
+            } else {
+                k::SpmvArgs a;  // r = rhs - A sol (:119-128)
+                a.x = sol; a.alpha = -1.0; a.f = rhs; a.gamma = 1.0; a.out = r0;
+                par_spmv(*L0.A, a);
+                iterate(0, r0, e0, L0.alt);
+                k::vec_axpby(n, 1.0, sol, 1.0, e0, sol);  // sol += correction (:134-135)
+            }
+            return;
         }
+        // internal numbering: permute on the way in and out
+        const double *src = rhs;
+        if (!precond) {
+            k::SpmvArgs a;
+            a.x = sol; a.alpha = -1.0; a.f = rhs; a.gamma = 1.0; a.out = r0;
+            par_spmv(*A_user, a);
+            src = r0;
+        }
+        k::vec_gather(n, d_order0, src, p_rhs);
+        iterate(0, p_rhs, p_sol, L0.alt);
+        k::vec_scatter(n, d_order0, p_sol, sol, precond ? 0 : 1);
     }
 
     void apply_device(const double *rhs, double *sol, bool precond)
@@ -261,13 +287,93 @@ int elag_hip_hierarchy_destroy(elag_hip_hierarchy_t H)
     });
 }
 
+int elag_hip_amge_default_options(elag_hip_amge_options *opt)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(opt, "null options");
+        opt->fix_zero_rows = 1; opt->relax_type = ELAG_HIP_SMOOTHER_L1_JACOBI; opt->sweeps = 1; opt->damping = 1.0;
+        opt->cheby_order = 2; opt->cheby_fraction = 0.3; opt->coarse_kind = 0; opt->coarse_iters = 0; opt->use_graph = 1;
+        opt->reorder = -1;
+    });
+}
+
+}  // extern "C"
+
+namespace {
+
+// Cuthill-McKee order (new -> old) of a symmetric pattern, components in index order
+std::vector<int> cm_order(int n, const std::vector<int> &I, const std::vector<int> &J)
+{
+    std::vector<int> order; order.reserve((size_t)n);
+    std::vector<char> seen((size_t)n, 0);
+    std::vector<int> nb;
+    for (int start = 0; start < n; start++) {
+        if (seen[(size_t)start]) continue;
+        // lowest-degree unvisited vertex of this component would be the textbook choice; the first one is enough here
+        seen[(size_t)start] = 1;
+        size_t head = order.size();
+        order.push_back(start);
+        while (head < order.size()) {
+            const int v = order[head++];
+            nb.clear();
+            for (int k = I[(size_t)v]; k < I[(size_t)v + 1]; k++) {
+                const int w = J[(size_t)k];
+                if (w >= 0 && w < n && !seen[(size_t)w]) { seen[(size_t)w] = 1; nb.push_back(w); }
+            }
+            std::sort(nb.begin(), nb.end(), [&](int x, int y) {
+                const int dx = I[(size_t)x + 1] - I[(size_t)x], dy = I[(size_t)y + 1] - I[(size_t)y];
+                return dx != dy ? dx < dy : x < y;
+            });
+            order.insert(order.end(), nb.begin(), nb.end());
+        }
+    }
+    return order;
+}
+
+// children under their strongest coarse parent: stable counting sort of the fine dofs by rank_c[parent]
+std::vector<int> child_order(const ParCSR &P, const std::vector<int> &coarse_order)
+{
+    const int nf = P.nrows(), nc = P.ncols();
+    std::vector<int> I = host_from_dev(P.diag.I, (size_t)nf + 1);
+    std::vector<int> J = host_from_dev(P.diag.J, (size_t)P.diag.nnz);
+    std::vector<double> a = host_from_dev(P.diag.a, (size_t)P.diag.nnz);
+    std::vector<int> rank_c((size_t)nc);
+    for (int r = 0; r < nc; r++) rank_c[(size_t)coarse_order[(size_t)r]] = r;
+    std::vector<int> key((size_t)nf), cnt((size_t)nc + 2, 0);
+    for (int i = 0; i < nf; i++) {
+        int best = -1; double bv = -1.0;
+        for (int k = I[(size_t)i]; k < I[(size_t)i + 1]; k++) {
+            const double v = std::fabs(a[(size_t)k]);
+            if (v > bv) { bv = v; best = J[(size_t)k]; }
+        }
+        key[(size_t)i] = best < 0 ? nc : rank_c[(size_t)best];   // rows without entries go last
+        cnt[(size_t)key[(size_t)i] + 1]++;
+    }
+    for (int c = 0; c <= nc; c++) cnt[(size_t)c + 1] += cnt[(size_t)c];
+    std::vector<int> order((size_t)nf);
+    for (int i = 0; i < nf; i++) order[(size_t)cnt[(size_t)key[(size_t)i]]++] = i;
+    return order;
+}
+
+std::vector<int> inverse_perm(const std::vector<int> &order)
+{
+    std::vector<int> rank(order.size());
+    for (size_t r = 0; r < order.size(); r++) rank[(size_t)order[r]] = (int)r;
+    return rank;
+}
+
+}  // namespace
+
+extern "C" {
+
 int elag_hip_hierarchy_build(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P, const elag_hip_parcsr_t *P,
-                             int fix_zero_rows, int relax_type, int sweeps, double damping, int cheby_order,
-                             double cheby_fraction, int coarse_kind, int coarse_iters, int use_graph)
+                             const elag_hip_amge_options *opt_in)
 {
     return guarded([&] {
         require_init();
         ELAG_REQUIRE(out && A && num_P >= 0 && (num_P == 0 || P), "bad argument");
+        elag_hip_amge_options opt;
+        if (opt_in) opt = *opt_in; else elag_hip_amge_default_options(&opt);
         std::unique_ptr<elag_hip_hierarchy_s> H(new elag_hip_hierarchy_s());
         H->lev.resize((size_t)num_P + 1);
         H->lev[0].A = A;
@@ -281,25 +387,86 @@ int elag_hip_hierarchy_build(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int
             int rc = elag_hip_parcsr_rap(Pl, Af, Pl, &Ac);
             if (rc) fail(rc, "%s", elag_hip_last_error());
             H->owned_mats.push_back(Ac);
-            if (fix_zero_rows) k::fix_zero_rows(Ac->diag, &Ac->offd);
+            if (opt.fix_zero_rows) k::fix_zero_rows(Ac->diag, &Ac->offd);
             H->lev[(size_t)l + 1].A = Ac;
             H->lev[(size_t)l + 1].P = Pl;
         }
+
+        // ---- optional internal renumbering for gather locality -------------------------------------
+        const bool reorder = ctx().nranks == 1 && A->offd.ncols == 0 &&
+                             (opt.reorder > 0 || (opt.reorder < 0 && A->nrows() >= (1 << 18)));
+        if (reorder) {
+            const int nl = num_P + 1;
+            H->order.resize((size_t)nl);
+            {
+                ParCSR *Ac = H->lev[(size_t)nl - 1].A;
+                std::vector<int> I = host_from_dev(Ac->diag.I, (size_t)Ac->nrows() + 1);
+                std::vector<int> J = host_from_dev(Ac->diag.J, (size_t)Ac->diag.nnz);
+                H->order[(size_t)nl - 1] = cm_order(Ac->nrows(), I, J);
+            }
+            for (int l = nl - 2; l >= 0; l--) H->order[(size_t)l] = child_order(*H->lev[(size_t)l + 1].P, H->order[(size_t)l + 1]);
+            std::vector<int *> d_order((size_t)nl), d_rank((size_t)nl);
+            for (int l = 0; l < nl; l++) {
+                std::vector<int> rank = inverse_perm(H->order[(size_t)l]);
+                d_order[(size_t)l] = dev_from_host(H->order[(size_t)l].data(), H->order[(size_t)l].size());
+                d_rank[(size_t)l] = dev_from_host(rank.data(), rank.size());
+            }
+            ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+            std::vector<ParCSR *> newA((size_t)nl), newP((size_t)nl, nullptr);
+            for (int l = 0; l < nl; l++) {
+                ParCSR *Al = H->lev[(size_t)l].A;
+                DevCSR Ap;
+                k::csr_permute(Al->diag, d_order[(size_t)l], d_rank[(size_t)l], Al->ncols(), Ap);
+                newA[(size_t)l] = parcsr_from_diag(std::move(Ap), 0, 0, Al->global_rows, Al->global_cols);
+                if (l > 0) {
+                    ParCSR *Pl = H->lev[(size_t)l].P;
+                    DevCSR Pp;
+                    k::csr_permute(Pl->diag, d_order[(size_t)l - 1], d_rank[(size_t)l], Pl->ncols(), Pp);
+                    newP[(size_t)l] = parcsr_from_diag(std::move(Pp), 0, 0, Pl->global_rows, Pl->global_cols);
+                }
+            }
+            ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+            for (auto *m : H->owned_mats) delete m;   // the natural-order coarse operators
+            H->owned_mats.clear();
+            for (int l = 0; l < nl; l++) {
+                H->lev[(size_t)l].A = newA[(size_t)l];
+                H->owned_mats.push_back(newA[(size_t)l]);
+                if (l > 0) { H->lev[(size_t)l].P = newP[(size_t)l]; H->owned_mats.push_back(newP[(size_t)l]); }
+            }
+            H->d_order0 = d_order[0];
+            for (int l = 1; l < nl; l++) dev_free(d_order[(size_t)l]);
+            for (int l = 0; l < nl; l++) dev_free(d_rank[(size_t)l]);
+            H->A_user = A;
+            H->reordered = true;
+        }
+
         for (int l = 0; l < num_P; l++) {
             elag_hip_smoother_t S = nullptr;
-            int rc = elag_hip_smoother_create(&S, H->lev[(size_t)l].A, relax_type, sweeps, damping, 1.0, cheby_order, cheby_fraction);
+            int rc = elag_hip_smoother_create(&S, H->lev[(size_t)l].A, opt.relax_type, opt.sweeps, opt.damping, 1.0, opt.cheby_order,
+                                              opt.cheby_fraction);
             if (rc) fail(rc, "%s", elag_hip_last_error());
             H->owned_smoothers.push_back(S);
             H->lev[(size_t)l].pre = S;
             H->lev[(size_t)l].post = S;  // same parameters => same operator; scratch is not shared across calls
         }
         elag_hip_coarse_t C = nullptr;
-        int rc = elag_hip_coarse_create(&C, H->lev.back().A, coarse_kind, coarse_iters);
+        int rc = elag_hip_coarse_create(&C, H->lev.back().A, opt.coarse_kind, opt.coarse_iters);
         if (rc) fail(rc, "%s", elag_hip_last_error());
         H->owned_coarse = C;
         H->coarse = C;
-        H->finalize(use_graph != 0);
+        H->finalize(opt.use_graph != 0);
         *out = H.release();
+    });
+}
+
+int elag_hip_hierarchy_get_ordering(elag_hip_hierarchy_t H, int level, int *order)
+{
+    return guarded([&] {
+        Level &L = level_of(H, level);
+        ELAG_REQUIRE(order && L.A, "bad argument");
+        const int n = L.A->nrows();
+        if (H->reordered) memcpy(order, H->order[(size_t)level].data(), sizeof(int) * (size_t)n);
+        else for (int i = 0; i < n; i++) order[i] = i;
     });
 }
 

@@ -30,6 +30,8 @@ struct SpmvArgs {
     int skip_rows_with_offd = 0;  // interior pass: rows whose offd row is non-empty are left untouched
 };
 void spmv_fused(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, hipStream_t st = nullptr);
+// row-block plan of the LDS-staged stream kernel (block_row, nblocks, max_row_nnz); synchronous, setup time
+void build_stream_plan(DevCSR &A);
 
 // ---- vector kernels ----------------------------------------------------------------------------
 void vec_axpby(int n, double a, const double *x, double b, const double *y, double *out);  // out = a x + b y
@@ -39,6 +41,7 @@ void vec_add_scaled_mul(int n, const double *y, const double *d, const double *z
 void vec_fill(int n, double v, double *x);
 void vec_dot(int n, const double *x, const double *y, double *d_result);  // deterministic 2-stage
 void vec_gather(int n, const int *idx, const double *x, double *buf, hipStream_t st = nullptr);
+void vec_scatter(int n, const int *idx, const double *src, double *dst, int add);  // dst[idx[i]] (+)= src[i], idx a permutation
 void vec_hypre_random(int n, int seed, double *out);  // Lehmer 16807 stream, 2 r - 1 (host generated)
 
 // ---- row statistics ----------------------------------------------------------------------------
@@ -63,6 +66,8 @@ void csr_add(double a, const DevCSR &A, double b, const DevCSR &B, DevCSR &C);
 void csr_delete_zeros(const DevCSR &A, double tol, DevCSR &out);
 void csr_scale_rows(DevCSR &A, const double *d);
 void csr_copy(const DevCSR &A, DevCSR &out);
+// out = A(order_rows, :) with columns renumbered by rank_cols (old -> new); rows come back column-sorted
+void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_cols, int ncols_out, DevCSR &out);
 
 // ---- dense coarse solve ------------------------------------------------------------------------
 void dense_gemv(int n, const double *Minv, const double *x, double *y);

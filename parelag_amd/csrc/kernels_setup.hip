@@ -354,9 +354,8 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C)
     ELAG_HIP_CHECK(hipMemcpyAsync(&nnz, CI + n, sizeof(int), hipMemcpyDeviceToHost, st));
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
     C.release();
-    C.nrows = n; C.ncols = ncols; C.nnz = nnz; C.I = CI;
-    C.J = dev_alloc<int>((size_t)nnz);
-    C.a = dev_alloc<double>((size_t)nnz);
+    C.nrows = n; C.ncols = ncols; C.I = CI;
+    C.alloc_entries(nnz);
     if (nch)
         hipLaunchKernelGGL((esc_kernel<2 * kCap, false, true, Expander>), dim3(nch), dim3(kBlock), 0, st, n, plan.ubscan.p,
                            plan.ub_small.p, (const int *)nullptr, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
@@ -402,7 +401,6 @@ void csr_sort_rows(DevCSR &A)
     SortExpander ex{CsrView{A.I, A.J, A.a}};
     DevCSR out;
     esc_run(plan, ex, A.ncols, out);  // duplicates (none expected) would be summed
-    out.lanes_per_row = A.lanes_per_row;
     A = std::move(out);
 }
 
@@ -445,10 +443,10 @@ void csr_transpose(const DevCSR &A, DevCSR &AT)
         hipLaunchKernelGGL(transpose_fill_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, st, A.nrows, (const int *)A.I,
                            (const int *)A.J, (const double *)A.a, cursor.p, AT.J, AT.a);
         ELAG_LAUNCH_CHECK();
-        AT.choose_spmv_shape();
         csr_sort_rows(AT);
+    } else {
+        AT.choose_spmv_shape();
     }
-    AT.choose_spmv_shape();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -493,9 +491,8 @@ void csr_delete_zeros(const DevCSR &A, double tol, DevCSR &out)
     ELAG_HIP_CHECK(hipMemcpyAsync(&nnz, OI + n, sizeof(int), hipMemcpyDeviceToHost, st));
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
     out.release();
-    out.nrows = n; out.ncols = A.ncols; out.nnz = nnz; out.I = OI;
-    out.J = dev_alloc<int>((size_t)nnz);
-    out.a = dev_alloc<double>((size_t)nnz);
+    out.nrows = n; out.ncols = A.ncols; out.I = OI;
+    out.alloc_entries(nnz);
     if (n) hipLaunchKernelGGL(fill_keep_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, (const int *)A.I, (const int *)A.J,
                               (const double *)A.a, tol, (const int *)OI, out.J, out.a);
     ELAG_LAUNCH_CHECK();
@@ -509,6 +506,47 @@ void csr_scale_rows(DevCSR &A, const double *d)
     ELAG_LAUNCH_CHECK();
 }
 
+namespace {
+__global__ void perm_len_kernel(int n, const int *__restrict__ I, const int *__restrict__ order, int *__restrict__ len)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) { const int o = order[r]; len[r] = I[o + 1] - I[o]; }
+}
+__global__ void perm_fill_kernel(int n, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
+                                 const int *__restrict__ order, const int *__restrict__ rank, const int *__restrict__ OI,
+                                 int *__restrict__ OJ, double *__restrict__ Oa)
+{
+    // 8 lanes per output row
+    const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int lane = threadIdx.x & 7;
+    if (r >= n) return;
+    const int o = order[r];
+    const int s = I[o], len = I[o + 1] - s, d = OI[r];
+    for (int q = lane; q < len; q += 8) { OJ[d + q] = rank ? rank[J[s + q]] : J[s + q]; Oa[d + q] = a[s + q]; }
+}
+}  // namespace
+
+void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_cols, int ncols_out, DevCSR &out)
+{
+    hipStream_t st = ctx().stream;
+    const int n = A.nrows;
+    out.release();
+    out.nrows = n; out.ncols = ncols_out;
+    out.I = dev_alloc<int>((size_t)n + 1);
+    {
+        Temp<int> len((size_t)n);
+        if (n) hipLaunchKernelGGL(perm_len_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, (const int *)A.I, d_order_rows, len.p);
+        exclusive_scan(len, out.I, n);
+    }
+    out.alloc_entries(A.nnz);
+    if (n && A.nnz)
+        hipLaunchKernelGGL(perm_fill_kernel, dim3(grid1((long long)n * 8)), dim3(kBlock), 0, st, n, (const int *)A.I, (const int *)A.J,
+                           (const double *)A.a, d_order_rows, d_rank_cols, (const int *)out.I, out.J, out.a);
+    ELAG_LAUNCH_CHECK();
+    if (A.nnz) csr_sort_rows(out);
+    else out.choose_spmv_shape();
+}
+
 void csr_copy(const DevCSR &A, DevCSR &out)
 {
     hipStream_t st = ctx().stream;
@@ -518,7 +556,7 @@ void csr_copy(const DevCSR &A, DevCSR &out)
         ELAG_HIP_CHECK(hipMemcpyAsync(out.J, A.J, sizeof(int) * (size_t)A.nnz, hipMemcpyDeviceToDevice, st));
         ELAG_HIP_CHECK(hipMemcpyAsync(out.a, A.a, sizeof(double) * (size_t)A.nnz, hipMemcpyDeviceToDevice, st));
     }
-    out.lanes_per_row = A.lanes_per_row;
+    out.choose_spmv_shape();
 }
 
 }  // namespace k

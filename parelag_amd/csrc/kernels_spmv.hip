@@ -8,6 +8,8 @@
 // epilogue vector), see DESIGN.md.
 #include "kernels.hpp"
 
+#include <algorithm>
+
 namespace elag {
 namespace k {
 
@@ -107,12 +109,235 @@ void launch_lpr(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hipStrea
     ELAG_LAUNCH_CHECK();
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-staged stream kernel (default).  A 256-thread workgroup owns the rows whose first entry lies in one
+// 2048-entry window of the CSR arrays.  Phase 1 streams that window with 16-byte loads (int4 of J, 2 x double2
+// of a per lane: up to 160 B in flight per lane), gathers x and parks the products in LDS; phase 2 gives each
+// row to one lane, which sums its products in storage order (hypre's order, so the sum is bit-identical to the
+// CPU loop) and applies the fused epilogue with coalesced vector accesses.
+// ------------------------------------------------------------------------------------------------
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef double double2v __attribute__((ext_vector_type(2)));
+
+template <bool HAS_CS, int VARIANT>
+__global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
+    int nrows, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
+    const int *__restrict__ block_row, const int *__restrict__ oI, SpmvArgs p)
+{
+    extern __shared__ double prod[];
+    // one 16-byte scalar load: (first row, first entry) of this block and of the next one
+    const int4v br = *reinterpret_cast<const int4v *>(block_row + 2 * blockIdx.x);
+    const int r0 = br.x, kbeg = br.y, r1 = br.z, kend = br.w;
+    if (r0 >= r1) return;
+    const int kal = kbeg & ~3;
+    const double *__restrict__ x = p.x;
+    const double *__restrict__ cs = p.cs;
+
+    // Issue everything that depends only on (r0, kbeg) before waiting on anything: the row extents and the
+    // epilogue operands of this lane's first row travel together with the matrix stream, which takes three
+    // dependent memory round trips out of the wave's critical path.
+    const int row0 = r0 + (int)threadIdx.x;
+    const bool has0 = row0 < r1;
+    int s0 = 0, e0 = 0;
+    double f0 = 0.0, y0 = 0.0, sc0 = 1.0, sc20 = 1.0;
+    if (has0) {
+        s0 = I[row0]; e0 = I[row0 + 1];
+        if (p.f) f0 = p.f[row0];
+        if (p.yin) y0 = p.yin[row0];
+        if (p.s) sc0 = p.s[row0];
+        if (p.s2) sc20 = p.s2[row0];
+    }
+
+    auto quad = [&](int k) {
+        int4v j4; double2v a01, a23;
+        if (VARIANT & 1) {
+            j4 = __builtin_nontemporal_load(reinterpret_cast<const int4v *>(J + k));
+            a01 = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(a + k));
+            a23 = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(a + k + 2));
+        } else {
+            j4 = *reinterpret_cast<const int4v *>(J + k);
+            a01 = *reinterpret_cast<const double2v *>(a + k);
+            a23 = *reinterpret_cast<const double2v *>(a + k + 2);
+        }
+        if (VARIANT & 4) {  // DIAGNOSTIC ONLY (wrong results): coalesced x reads instead of the gather
+            const int b = (k - kal) + r0;
+            j4.x = min(b, nrows - 1) + 0 * j4.x; j4.y = min(b + 1, nrows - 1) + 0 * j4.y; j4.z = min(b + 2, nrows - 1) + 0 * j4.z; j4.w = min(b + 3, nrows - 1) + 0 * j4.w;
+        }
+        double x0 = x[j4.x], x1 = x[j4.y], x2 = x[j4.z], x3 = x[j4.w];
+        if (HAS_CS) { x0 *= cs[j4.x]; x1 *= cs[j4.y]; x2 *= cs[j4.z]; x3 *= cs[j4.w]; }
+        double2v p01, p23;
+        p01.x = a01.x * x0; p01.y = a01.y * x1; p23.x = a23.x * x2; p23.y = a23.y * x3;
+        *reinterpret_cast<double2v *>(prod + (k - kal)) = p01;
+        *reinterpret_cast<double2v *>(prod + (k - kal) + 2) = p23;
+    };
+
+    if (VARIANT & 8) {
+        // lane-consecutive mapping: one gather instruction covers 64 consecutive entries (~4 rows), which touch
+        // ~1/3 fewer distinct cache lines than the stride-4 mapping of the 16-byte loads
+        constexpr int U = 8;
+        int jj[U]; double aa[U];
+        const int kb = kbeg + (int)threadIdx.x;
+#pragma unroll
+        for (int q = 0; q < U; q++) {
+            const int k = kb + q * kBlock;
+            const bool ok = k < kend;
+            jj[q] = ok ? J[k] : 0;
+            aa[q] = ok ? a[k] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < U; q++) {
+            const int k = kb + q * kBlock;
+            double xv = x[jj[q]];
+            if (HAS_CS) xv *= cs[jj[q]];
+            if (k < kend) prod[k - kal] = aa[q] * xv;
+        }
+        for (int k = kb + U * kBlock; k < kend; k += kBlock) {
+            double xv = x[J[k]];
+            if (HAS_CS) xv *= cs[J[k]];
+            prod[k - kal] = a[k] * xv;
+        }
+    } else if (VARIANT & 2) {
+        // first pass: two quads per lane with all six vector loads issued before the gathers
+        const int k0 = kal + (int)threadIdx.x * 4, k1 = k0 + kBlock * 4;
+        if (k1 < kend) {
+            const int4v ja = *reinterpret_cast<const int4v *>(J + k0), jb = *reinterpret_cast<const int4v *>(J + k1);
+            const double2v a0 = *reinterpret_cast<const double2v *>(a + k0), a1 = *reinterpret_cast<const double2v *>(a + k0 + 2);
+            const double2v b0 = *reinterpret_cast<const double2v *>(a + k1), b1 = *reinterpret_cast<const double2v *>(a + k1 + 2);
+            double xa0 = x[ja.x], xa1 = x[ja.y], xa2 = x[ja.z], xa3 = x[ja.w];
+            double xb0 = x[jb.x], xb1 = x[jb.y], xb2 = x[jb.z], xb3 = x[jb.w];
+            if (HAS_CS) {
+                xa0 *= cs[ja.x]; xa1 *= cs[ja.y]; xa2 *= cs[ja.z]; xa3 *= cs[ja.w];
+                xb0 *= cs[jb.x]; xb1 *= cs[jb.y]; xb2 *= cs[jb.z]; xb3 *= cs[jb.w];
+            }
+            double2v q;
+            q.x = a0.x * xa0; q.y = a0.y * xa1; *reinterpret_cast<double2v *>(prod + (k0 - kal)) = q;
+            q.x = a1.x * xa2; q.y = a1.y * xa3; *reinterpret_cast<double2v *>(prod + (k0 - kal) + 2) = q;
+            q.x = b0.x * xb0; q.y = b0.y * xb1; *reinterpret_cast<double2v *>(prod + (k1 - kal)) = q;
+            q.x = b1.x * xb2; q.y = b1.y * xb3; *reinterpret_cast<double2v *>(prod + (k1 - kal) + 2) = q;
+        } else if (k0 < kend) {
+            quad(k0);
+        }
+        for (int k = k0 + 2 * kBlock * 4; k < kend; k += kBlock * 4) quad(k);
+    } else {
+        for (int k = kal + (int)threadIdx.x * 4; k < kend; k += kBlock * 4) quad(k);
+    }
+    __syncthreads();
+    if (has0 && !(p.skip_rows_with_offd && oI && oI[row0 + 1] > oI[row0])) {
+        double sum = 0.0;
+        for (int k = s0 - kal; k < e0 - kal; k++) sum += prod[k];
+        double t = p.alpha * sum;
+        t *= sc20;
+        t += p.gamma * f0;
+        t *= sc0;
+        t += p.beta * y0;
+        p.out[row0] = t;
+        if (p.out2) p.out2[row0] = HAS_CS ? x[row0] * p.cs[row0] : x[row0];
+    }
+    // blocks of short rows hold more than 256 rows: remaining rows the plain way
+    for (int row = row0 + kBlock; row < r1; row += kBlock) {
+        if (p.skip_rows_with_offd && oI && oI[row + 1] > oI[row]) continue;
+        const int s = I[row] - kal, e = I[row + 1] - kal;
+        double sum = 0.0;
+        for (int k = s; k < e; k++) sum += prod[k];
+        double t = p.alpha * sum;
+        if (p.s2) t *= p.s2[row];
+        if (p.f) t += p.gamma * p.f[row];
+        if (p.s) t *= p.s[row];
+        if (p.yin) t += p.beta * p.yin[row];
+        p.out[row] = t;
+        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
+    }
+}
+
+__global__ void stream_plan_kernel(int nrows, const int *__restrict__ I, int nblocks, int window, int *__restrict__ block_row)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > nblocks) return;
+    if (c == nblocks) { block_row[2 * c] = nrows; block_row[2 * c + 1] = I[nrows]; return; }
+    const long long v = (long long)c * window;
+    int lo = 0, hi = nrows;  // first row with I[row] >= v
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (I[mid] < v) lo = mid + 1; else hi = mid; }
+    block_row[2 * c] = lo;
+    block_row[2 * c + 1] = I[lo];
+}
+
+__global__ void max_row_kernel(int nrows, const int *__restrict__ I, int *__restrict__ result)
+{
+    int m = 0;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) m = max(m, I[r + 1] - I[r]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(result, m);
+}
+
+int stream_variant()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ELAG_HIP_STREAM_VARIANT"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+template <int VARIANT>
+void launch_stream_v(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hipStream_t st)
+{
+    const size_t lds = sizeof(double) * (size_t)(DevCSR::kStreamNnz + A.max_row_nnz + 8);
+    const int *oI = (p.skip_rows_with_offd && offd) ? offd->I : nullptr;
+    if (p.cs)
+        hipLaunchKernelGGL((spmv_stream_kernel<true, VARIANT>), dim3((unsigned)A.nblocks), dim3(kBlock), lds, st, A.nrows, A.I, A.J, A.a, A.block_row, oI, p);
+    else
+        hipLaunchKernelGGL((spmv_stream_kernel<false, VARIANT>), dim3((unsigned)A.nblocks), dim3(kBlock), lds, st, A.nrows, A.I, A.J, A.a, A.block_row, oI, p);
+    ELAG_LAUNCH_CHECK();
+}
+
+void launch_stream(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hipStream_t st)
+{
+    switch (stream_variant()) {
+    case 1: launch_stream_v<1>(A, offd, p, st); break;
+    case 2: launch_stream_v<2>(A, offd, p, st); break;
+    case 3: launch_stream_v<3>(A, offd, p, st); break;
+    case 4: launch_stream_v<4>(A, offd, p, st); break;
+    case 8: launch_stream_v<8>(A, offd, p, st); break;
+    default: launch_stream_v<0>(A, offd, p, st); break;
+    }
+}
+
 }  // namespace
+
+void build_stream_plan(DevCSR &A)
+{
+    hipStream_t st = ctx().stream;
+    A.nblocks = (int)((A.nnz + DevCSR::kStreamNnz - 1) / DevCSR::kStreamNnz);
+    if (A.nblocks < 1) A.nblocks = 1;
+    A.block_row = dev_alloc<int>(2 * ((size_t)A.nblocks + 1) + 2);
+    hipLaunchKernelGGL(stream_plan_kernel, dim3((unsigned)((A.nblocks + 1 + 255) / 256)), dim3(256), 0, st, A.nrows, (const int *)A.I,
+                       A.nblocks, DevCSR::kStreamNnz, A.block_row);
+    Temp<int> m(1);
+    ELAG_HIP_CHECK(hipMemsetAsync(m, 0, sizeof(int), st));
+    if (A.nrows) {
+        const unsigned g = (unsigned)std::min<long long>(((long long)A.nrows + 255) / 256, 1024);
+        hipLaunchKernelGGL(max_row_kernel, dim3(g), dim3(256), 0, st, A.nrows, (const int *)A.I, m.p);
+    }
+    ELAG_LAUNCH_CHECK();
+    ELAG_HIP_CHECK(hipMemcpyAsync(&A.max_row_nnz, m.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+}
 
 void spmv_fused(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, hipStream_t st)
 {
     if (!st) st = ctx().stream;
-    switch (A.lanes_per_row) {
+    const bool rowlist = args.rows != nullptr;
+    const bool offd_terms = offd && offd->nnz > 0 && !args.skip_rows_with_offd;
+    if (A.lanes_per_row == 0 && !rowlist && !offd_terms && A.block_row) {
+        if (A.nrows) launch_stream(A, offd, args, st);
+        return;
+    }
+    int lanes = A.lanes_per_row;
+    if (lanes == 0) {  // row subsets / offd terms use the row-group kernel
+        const double avg = A.nrows ? (double)(A.nnz + (offd ? offd->nnz : 0)) / A.nrows : 0.0;
+        lanes = 1;
+        while (lanes < 64 && 2.0 * lanes < avg) lanes <<= 1;
+    }
+    switch (lanes) {
     case 1: launch_lpr<1>(A, offd, args, st); break;
     case 2: launch_lpr<2>(A, offd, args, st); break;
     case 4: launch_lpr<4>(A, offd, args, st); break;
@@ -172,6 +397,14 @@ __global__ void fill_kernel(int n, double v, double *__restrict__ x)
 __global__ void gather_kernel(int n, const int *__restrict__ idx, const double *__restrict__ x, double *__restrict__ buf)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) buf[i] = x[idx[i]];
+}
+
+__global__ void scatter_kernel(int n, const int *__restrict__ idx, const double *__restrict__ src, double *__restrict__ dst, int add)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int j = idx[i];
+        dst[j] = add ? dst[j] + src[i] : src[i];
+    }
 }
 
 __device__ __forceinline__ double block_reduce_sum(double v, double *sh)
@@ -287,6 +520,12 @@ void vec_gather(int n, const int *idx, const double *x, double *buf, hipStream_t
 {
     if (n == 0) return;
     hipLaunchKernelGGL(gather_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, st ? st : ctx().stream, n, idx, x, buf);
+    ELAG_LAUNCH_CHECK();
+}
+void vec_scatter(int n, const int *idx, const double *src, double *dst, int add)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(scatter_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, n, idx, src, dst, add);
     ELAG_LAUNCH_CHECK();
 }
 void vec_dot(int n, const double *x, const double *y, double *d_result)

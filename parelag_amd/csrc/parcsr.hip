@@ -58,7 +58,6 @@ void elag_hip_parcsr_s::ensure_transpose()
         for (int k = 0; k < st; k++) J[(size_t)pos[(size_t)send_elmts[(size_t)k]]++] = k;
         scatT.reset(new DevCSR());
         scatT->upload(diag.ncols, st, I.data(), J.data(), a.data());
-        scatT->lanes_per_row = 1;
         d_rev_recv = dev_alloc<double>((size_t)st);
     }
 }

@@ -437,6 +437,13 @@ class Hierarchy(_SolverBase):
         check(self._lib.elag_hip_hierarchy_get_smoother(self.h, level, C.byref(h)))
         return HypreSmootherWrapper(self.GetOperator(level), handle=h, owner=False)
 
+    def GetOrdering(self, level):
+        """new -> old row map of a level (identity unless the hierarchy was built with reordering)."""
+        n = self.GetOperator(level).Height()
+        o = np.empty(n, np.int32)
+        check(self._lib.elag_hip_hierarchy_get_ordering(self.h, level, _np_ptr(o)))
+        return o
+
     def time_apply(self, rhs, sol, reps) -> float:
         """mean milliseconds per V-cycle, measured with HIP events on the library's compute stream"""
         pr, lr, _k1 = _vec(rhs)
@@ -456,18 +463,26 @@ class Hierarchy(_SolverBase):
 
 
 def buildHierarchyFromDeRhamSequence(A: ParallelCSRMatrix, Ps, smoother="L1 Jacobi", params: dict | None = None,
-                                     fix_zero_rows=True, coarse_kind=0, use_graph=True) -> Hierarchy:
+                                     fix_zero_rows=True, coarse_kind=0, use_graph=True, reorder=-1) -> Hierarchy:
     """RAP chain + smoothers + coarse solve in one ABI call (Hierarchy.cpp:282-383, AMGeSolverFactory.cpp:26-169).
     ``Ps[l]`` is the true interpolator from level l+1 to level l (DeRhamSequence::ComputeTrueP)."""
     params = params or {}
     t = HYPRE_SMOOTHER_TYPES[smoother] if isinstance(smoother, str) else int(smoother)
     lib = _lib.init()
     arr = (_vp * max(len(Ps), 1))(*[P.h for P in Ps])
+    opt = _lib.AMGeOptions()
+    check(lib.elag_hip_amge_default_options(C.byref(opt)))
+    opt.fix_zero_rows = int(fix_zero_rows)
+    opt.relax_type = t
+    opt.sweeps = int(params.get("Sweeps", 1))
+    opt.damping = float(params.get("Damping Factor", 1.0))
+    opt.cheby_order = int(params.get("Cheby Poly Order", 2))
+    opt.cheby_fraction = float(params.get("Cheby Poly Fraction", 0.3))
+    opt.coarse_kind = int(coarse_kind)
+    opt.use_graph = int(use_graph)
+    opt.reorder = int(reorder)
     h = _vp()
-    check(lib.elag_hip_hierarchy_build(C.byref(h), A.h, len(Ps), arr, int(fix_zero_rows), t,
-                                       int(params.get("Sweeps", 1)), float(params.get("Damping Factor", 1.0)),
-                                       int(params.get("Cheby Poly Order", 2)), float(params.get("Cheby Poly Fraction", 0.3)),
-                                       int(coarse_kind), 0, int(use_graph)))
+    check(lib.elag_hip_hierarchy_build(C.byref(h), A.h, len(Ps), arr, C.byref(opt)))
     H = Hierarchy(handle=h)
     H._keep += [A, *Ps]
     return H

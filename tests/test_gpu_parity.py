@@ -335,3 +335,39 @@ def test_manual_hierarchy_assembly_equals_builder(la, h1_k2):
     x1, x2 = np.empty_like(b), np.empty_like(b)
     H.Mult(b, x1); H2.Mult(b, x2)
     assert np.array_equal(x1, x2)
+
+
+@pytest.mark.parametrize("smoother,params", [("L1 Jacobi", {}), ("Chebyshev", {"Cheby Poly Order": 2})])
+def test_vcycle_with_internal_reordering_matches_oracle(la, h1_k2, smoother, params):
+    """reorder=1 renumbers every level internally; the result in the caller's numbering is unchanged (to rounding)."""
+    A, Ps, _ = h1_k2
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    H = la.buildHierarchyFromDeRhamSequence(dA, dPs, smoother, params, reorder=1)
+    order = H.GetOrdering(0)
+    assert np.array_equal(np.sort(order), np.arange(A.shape[0]))          # a permutation ...
+    assert not np.array_equal(order, np.arange(A.shape[0]))               # ... and not the identity
+    # level operators are the permuted Galerkin operators (pattern bit-exact after un-permuting)
+    h = oracle_h1_hierarchy(A, Ps)
+    for l in range(len(Ps) + 1):
+        o = H.GetOrdering(l)
+        Ap = H.GetOperator(l).to_scipy()
+        ref = sp.csr_matrix(h["As"][l])[o][:, o].tocsr()
+        same_matrix(Ap, ref)
+    stype = la.HYPRE_SMOOTHER_TYPES[smoother]
+    eigs = None
+    if stype == 16:
+        eigs = [H.GetSmoother(l).eig_estimate() for l in range(len(Ps))] + [(1.0, 0.1)]
+    h = oracle_h1_hierarchy(A, Ps, smoother=stype, order=params.get("Cheby Poly Order", 2), eigs=eigs)
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"])
+    rng = np.random.default_rng(5)
+    b = rng.uniform(-1, 1, A.shape[0])
+    x, xr = np.empty_like(b), np.empty_like(b)
+    H.Mult(b, x); Hc.apply(b, xr)
+    assert close(x, xr, tol=1e-11)
+    # solver mode through the permutation
+    H.iterative_mode = True
+    x0 = rng.standard_normal(A.shape[0]); x = x0.copy()
+    H.Mult(b, x)
+    e = np.empty_like(b); Hc.apply(b - A @ x0, e)
+    assert close(x, x0 + e, tol=1e-11)

@@ -22,7 +22,7 @@ for f in sorted(glob.glob(out + "/kt/**/*kernel_stats.csv", recursive=True)):
 for f in sorted(glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
-        if "spmv_fused" in r["Kernel_Name"]:
+        if "spmv_" in r["Kernel_Name"]:
             a = acc[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
     for k, (s, n) in acc.items():
         print("pmc", k, "mean per dispatch", s / max(n, 1), "dispatches", n)
