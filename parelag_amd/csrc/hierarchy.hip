@@ -110,12 +110,19 @@ struct elag_hip_hierarchy_s {
         const int n = F.A->nrows();
         const int nf = (F.pre ? F.pre->flips(true) : 0) + (F.post ? F.post->flips(false) : 0);
         double *cur = (nf & 1) ? alt : sol, *oth = (nf & 1) ? sol : alt;
-        // pre-smoothing (:180-184)
-        if (F.pre) F.pre->apply(rhs, cur, oth, true, false);
-        else k::vec_fill(n, 0.0, cur);
-        // residual (:191-194), fused A*SOL and RHS - tmp
-        {
+        // pre-smoothing (:180-184) and residual (:191-194)
+        const RelaxSmoother *jac = dynamic_cast<const RelaxSmoother *>(F.pre);
+        // (worth it only while the level is launch-bound: the fused form gathers two vectors per entry)
+        if (jac && jac->dinv && jac->sweeps == 1 && jac->A == F.A && F.A->diag.nnz < (int64_t(1) << 20)) {
+            // one kernel: SOL = dinv .* RHS (Jacobi sweep from the zero guess) gathered on the fly as the SpMV
+            // operand, tmp_resid = RHS - A SOL
             k::SpmvArgs a;
+            a.x = rhs; a.cs = jac->dinv; a.alpha = -1.0; a.f = rhs; a.gamma = 1.0; a.out = F.tmp_resid; a.out2 = cur;
+            par_spmv(*F.A, a);
+        } else {
+            if (F.pre) F.pre->apply(rhs, cur, oth, true, false);
+            else k::vec_fill(n, 0.0, cur);
+            k::SpmvArgs a;  // fused A*SOL and RHS - tmp
             a.x = cur; a.alpha = -1.0; a.f = rhs; a.gamma = 1.0; a.out = F.tmp_resid;
             par_spmv(*F.A, a);
         }
