@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even with one rank (testing)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -69,7 +70,7 @@ def main():
     from parelag_amd import _lib, linalg as la, meshgen
 
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         from parelag_amd import distributed
         dist = distributed.init(rank, world)
     else:
@@ -78,7 +79,8 @@ def main():
     out = {}
     # ---------------------------------------------------------------- roofline leg (rank 0 of N=1 runs only)
     roof = None
-    if world == 1 and not args.no_roofline:
+    single = world == 1 and not args.force_dist
+    if single and not args.no_roofline:
         k = args.roofline_refines
         t0 = time.time()
         Ar, Pr, _ = meshgen.h1_problem(k)
@@ -122,7 +124,7 @@ def main():
 
     # ---------------------------------------------------------------- V-cycle workload
     A, Ps, seq = meshgen.h1_problem(args.refines)
-    if world == 1:
+    if single:
         dA = la.ParallelCSRMatrix.from_scipy(A)
         dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
         t0 = time.time()
@@ -167,7 +169,7 @@ def main():
 
     # fine-level kernel at the benchmark size (cache-resident at x3)
     fine = None
-    if world == 1:
+    if single:
         A0 = H.GetOperator(0)
         n0, nnz0 = A0.Height(), A0.nnz
         x = la.DeviceVector.from_numpy(np.random.default_rng(1).uniform(-1, 1, n0))
@@ -179,7 +181,7 @@ def main():
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
     cpu = None
-    if world == 1 and not args.no_cpu_baseline and rank == 0:
+    if single and not args.no_cpu_baseline and rank == 0:
         from oracle import oracle as orc
         from tests.helpers import oracle_h1_hierarchy
         h = oracle_h1_hierarchy(A, Ps, smoother=la.HYPRE_SMOOTHER_TYPES[args.smoother])
@@ -218,7 +220,7 @@ def main():
             "config": {"workload": f"MultigridTest0Form cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
                                    f"{args.smoother} 1 sweep pre/post, dense coarse solve, b=2",
                        "levels": [{"n": s[0], "nnz": s[1]} for s in level_shapes],
-                       "hipgraph": not args.no_graph and world == 1, "parallelism": f"row-block domain decomposition x{world}"},
+                       "hipgraph": not args.no_graph and single, "parallelism": f"row-block domain decomposition x{world}"},
             "device_ms_per_step": round(ms_dev, 5),
             "vcycle_algorithmic_bytes": vbytes,
             "vcycle_achieved_GBs": round(vbytes / (ms_dev * 1e-3) / 1e9, 1),

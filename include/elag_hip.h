@@ -195,6 +195,11 @@ ELAG_HIP_API int elag_hip_smoother_destroy(elag_hip_smoother_t S);
  * Jacobi-preconditioned CG on device.  A host that wants hypre there exports the operator instead.
  * ------------------------------------------------------------------------------------------------ */
 ELAG_HIP_API int elag_hip_coarse_create(elag_hip_coarse_t *out, elag_hip_parcsr_t A, int kind, int iters);
+/* Multi-rank coarse solve: every rank holds the whole (tiny) coarsest operator `A_global` as a single-rank matrix,
+ * the distributed right-hand side is all-gathered over RCCL and each rank applies its own rows of the dense
+ * inverse (SURVEY 8e "gather the coarsest levels onto every GPU").  row_starts has nranks+1 entries. */
+ELAG_HIP_API int elag_hip_coarse_create_replicated(elag_hip_coarse_t *out, elag_hip_parcsr_t A_global,
+                                                   const int64_t *row_starts);
 ELAG_HIP_API int elag_hip_coarse_apply(elag_hip_coarse_t C, const double *rhs, double *sol, int loc);
 ELAG_HIP_API int elag_hip_coarse_destroy(elag_hip_coarse_t C);
 

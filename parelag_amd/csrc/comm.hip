@@ -94,16 +94,52 @@ void comm_neighbor_exchange(const void *sendbuf, int nsend, const int *send_proc
                             size_t elem_bytes, hipStream_t st)
 {
     if (nsend == 0 && nrecv == 0) return;
+    const int me = ctx().rank;
+    // a rank may list itself as a neighbour (periodic coupling; also how the halo path is exercised on one GPU):
+    // that segment is a device-to-device copy on the same stream
+    int self_s = -1, self_r = -1, remote = 0;
+    for (int i = 0; i < nsend; i++) { if (send_procs[i] == me) self_s = i; else remote++; }
+    for (int i = 0; i < nrecv; i++) { if (recv_procs[i] == me) self_r = i; else remote++; }
+    if ((self_s >= 0) != (self_r >= 0)) fail(ELAG_HIP_ERR_COMM, "self neighbour listed on one side of the comm package only");
+    if (self_s >= 0) {
+        const size_t ns = (size_t)(send_starts[self_s + 1] - send_starts[self_s]), nr = (size_t)(recv_starts[self_r + 1] - recv_starts[self_r]);
+        if (ns != nr) fail(ELAG_HIP_ERR_COMM, "self neighbour: send and receive lengths differ (%zu vs %zu)", ns, nr);
+        if (ns)
+            ELAG_HIP_CHECK(hipMemcpyAsync(static_cast<char *>(recvbuf) + (size_t)recv_starts[self_r] * elem_bytes,
+                                          static_cast<const char *>(sendbuf) + (size_t)send_starts[self_s] * elem_bytes, ns * elem_bytes,
+                                          hipMemcpyDeviceToDevice, st));
+    }
+    if (!remote) return;
     if (!comm_active()) fail(ELAG_HIP_ERR_COMM, "matrix has off-rank columns but no communicator was initialised");
     Comm *c = ctx().comm;
     ELAG_NCCL_CHECK(c, c->GroupStart());
     for (int i = 0; i < nrecv; i++) {
+        if (i == self_r) continue;
         const size_t n = (size_t)(recv_starts[i + 1] - recv_starts[i]) * elem_bytes;
         if (n) ELAG_NCCL_CHECK(c, c->Recv(static_cast<char *>(recvbuf) + (size_t)recv_starts[i] * elem_bytes, n, ncclInt8, recv_procs[i], c->comm, st));
     }
     for (int i = 0; i < nsend; i++) {
+        if (i == self_s) continue;
         const size_t n = (size_t)(send_starts[i + 1] - send_starts[i]) * elem_bytes;
         if (n) ELAG_NCCL_CHECK(c, c->Send(static_cast<const char *>(sendbuf) + (size_t)send_starts[i] * elem_bytes, n, ncclInt8, send_procs[i], c->comm, st));
+    }
+    ELAG_NCCL_CHECK(c, c->GroupEnd());
+}
+
+void comm_allgatherv(const double *send, double *recv, const int *counts, const int *displs, hipStream_t st)
+{
+    Context &x = ctx();
+    const int me = x.rank, n = x.nranks;
+    if (counts[me])
+        ELAG_HIP_CHECK(hipMemcpyAsync(recv + displs[me], send, sizeof(double) * (size_t)counts[me], hipMemcpyDeviceToDevice, st));
+    if (n == 1) return;
+    if (!comm_active()) fail(ELAG_HIP_ERR_COMM, "all-gather without a communicator");
+    Comm *c = x.comm;
+    ELAG_NCCL_CHECK(c, c->GroupStart());
+    for (int r = 0; r < n; r++) {
+        if (r == me) continue;
+        if (counts[r]) ELAG_NCCL_CHECK(c, c->Recv(recv + displs[r], (size_t)counts[r], ncclDouble, r, c->comm, st));
+        if (counts[me]) ELAG_NCCL_CHECK(c, c->Send(send, (size_t)counts[me], ncclDouble, r, c->comm, st));
     }
     ELAG_NCCL_CHECK(c, c->GroupEnd());
 }

@@ -17,6 +17,8 @@ void comm_init(int rank, int nranks, const void *id128);
 void comm_neighbor_exchange(const void *sendbuf, int nsend, const int *send_procs, const int *send_starts,
                             void *recvbuf, int nrecv, const int *recv_procs, const int *recv_starts,
                             size_t elem_bytes, hipStream_t st);
+// all-gather of variable-size double segments: recv[displs[r] .. +counts[r]) <- rank r's `send` (counts[rank] doubles)
+void comm_allgatherv(const double *send, double *recv, const int *counts, const int *displs, hipStream_t st);
 // 8-byte all-reduce of a host scalar (op 0 = sum, 1 = max); identity when nranks == 1.
 void comm_allreduce_scalar(double *value, int op);
 // all-reduce of a small device array in place on the compute stream

@@ -258,7 +258,9 @@ int elag_hip_hierarchy_finalize(elag_hip_hierarchy_t H, int use_graph)
             if (L.pre) ELAG_REQUIRE(L.A && L.pre->n() == L.A->nrows(), "PreSmoother size mismatch on level %d", (int)l);
             if (L.post) ELAG_REQUIRE(L.A && L.post->n() == L.A->nrows(), "PostSmoother size mismatch on level %d", (int)l);
         }
-        if (H->coarse) ELAG_REQUIRE(H->lev.back().A && H->coarse->n == H->lev.back().A->nrows(), "CoarseSolver size mismatch");
+        if (H->coarse)
+            ELAG_REQUIRE(H->lev.back().A && (H->coarse->replicated ? H->coarse->nloc : H->coarse->n) == H->lev.back().A->nrows(),
+                         "CoarseSolver size mismatch");
         H->finalize(use_graph != 0);
     });
 }

@@ -70,7 +70,7 @@ void csr_copy(const DevCSR &A, DevCSR &out);
 void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_cols, int ncols_out, DevCSR &out);
 
 // ---- dense coarse solve ------------------------------------------------------------------------
-void dense_gemv(int n, const double *Minv, const double *x, double *y);
+void dense_gemv(int nrows, int ncols, const double *M, const double *x, double *y);  // y = M x, M row-major
 
 }  // namespace k
 }  // namespace elag

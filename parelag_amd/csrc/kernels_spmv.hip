@@ -730,12 +730,12 @@ void values_sign(int64_t n, double *a)
 // dense coarse apply: y = Minv x, one wavefront per row (n <= 4096; Minv stays in L2)
 // ================================================================================================
 namespace {
-__global__ __launch_bounds__(kBlock) void dense_gemv_kernel(int n, const double *__restrict__ M, const double *__restrict__ x,
+__global__ __launch_bounds__(kBlock) void dense_gemv_kernel(int nrows, int n, const double *__restrict__ M, const double *__restrict__ x,
                                                             double *__restrict__ y)
 {
     const int row = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (row >= n) return;
+    if (row >= nrows) return;
     const double *__restrict__ m = M + (size_t)row * n;
     double s = 0.0;
     for (int j = lane; j < n; j += 64) s += m[j] * x[j];
@@ -744,10 +744,10 @@ __global__ __launch_bounds__(kBlock) void dense_gemv_kernel(int n, const double 
 }
 }  // namespace
 
-void dense_gemv(int n, const double *Minv, const double *x, double *y)
+void dense_gemv(int nrows, int ncols, const double *M, const double *x, double *y)
 {
-    if (n == 0) return;
-    hipLaunchKernelGGL(dense_gemv_kernel, dim3(row_grid(n, 64)), dim3(kBlock), 0, ctx().stream, n, Minv, x, y);
+    if (nrows == 0) return;
+    hipLaunchKernelGGL(dense_gemv_kernel, dim3(row_grid(nrows, 64)), dim3(kBlock), 0, ctx().stream, nrows, ncols, M, x, y);
     ELAG_LAUNCH_CHECK();
 }
 

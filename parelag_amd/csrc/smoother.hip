@@ -281,7 +281,8 @@ void elag_hip_coarse_s::setup()
 {
     using namespace elag;
     ELAG_REQUIRE(kind == 0, "coarse solver kind %d is not implemented (0 = dense Cholesky)", kind);
-    ELAG_REQUIRE(A->offd.ncols == 0 && ctx().nranks == 1, "dense coarse solve expects a rank-local operator");
+    ELAG_REQUIRE(A->offd.ncols == 0 && (ctx().nranks == 1 || replicated),
+                 "dense coarse solve expects a rank-local operator (use elag_hip_coarse_create_replicated across ranks)");
     n = A->nrows();
     ELAG_REQUIRE(n == A->ncols(), "coarse operator must be square");
     ELAG_REQUIRE(n <= 4096, "dense coarse solve limited to 4096 dofs (got %d)", n);
@@ -334,7 +335,13 @@ void elag_hip_coarse_s::setup()
     ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
 }
 
-void elag_hip_coarse_s::apply(const double *rhs, double *sol) { elag::k::dense_gemv(n, Minv, rhs, sol); }
+void elag_hip_coarse_s::apply(const double *rhs, double *sol)
+{
+    using namespace elag;
+    if (!replicated) { k::dense_gemv(n, n, Minv, rhs, sol); return; }
+    comm_allgatherv(rhs, full_rhs, counts.data(), displs.data(), ctx().stream);
+    k::dense_gemv(nloc, n, Minv + (size_t)my0 * n, full_rhs, sol);
+}
 
 using namespace elag;
 
@@ -427,14 +434,37 @@ int elag_hip_coarse_create(elag_hip_coarse_t *out, elag_hip_parcsr_t A, int kind
     });
 }
 
+int elag_hip_coarse_create_replicated(elag_hip_coarse_t *out, elag_hip_parcsr_t A_global, const int64_t *row_starts)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(out && A_global && row_starts, "null argument");
+        const int nr = ctx().nranks, me = ctx().rank;
+        ELAG_REQUIRE(row_starts[0] == 0 && row_starts[nr] == A_global->nrows(), "row_starts must cover the %d coarse rows", A_global->nrows());
+        std::unique_ptr<elag_hip_coarse_s> C(new elag_hip_coarse_s());
+        C->A = A_global; C->kind = 0; C->replicated = true;
+        C->counts.resize((size_t)nr); C->displs.resize((size_t)nr);
+        for (int r = 0; r < nr; r++) {
+            ELAG_REQUIRE(row_starts[r + 1] >= row_starts[r], "row_starts must not decrease");
+            C->counts[(size_t)r] = (int)(row_starts[r + 1] - row_starts[r]);
+            C->displs[(size_t)r] = (int)row_starts[r];
+        }
+        C->setup();
+        C->nloc = C->counts[(size_t)me]; C->my0 = C->displs[(size_t)me];
+        C->full_rhs = dev_alloc<double>((size_t)C->n);
+        *out = C.release();
+    });
+}
+
 int elag_hip_coarse_apply(elag_hip_coarse_t C, const double *rhs, double *sol, int loc)
 {
     return guarded([&] {
         require_init();
         ELAG_REQUIRE(C && rhs && sol, "null argument");
         check_loc(loc);
-        VecIn f(rhs, (size_t)C->n, loc);
-        VecInOut u(sol, (size_t)C->n, loc, false);
+        const size_t nv = (size_t)(C->replicated ? C->nloc : C->n);
+        VecIn f(rhs, nv, loc);
+        VecInOut u(sol, nv, loc, false);
         C->apply(f.d, u.d);
         u.finish();
     });

@@ -50,7 +50,12 @@ struct elag_hip_coarse_s {
     elag::ParCSR *A = nullptr;
     int kind = 0, n = 0;
     double *Minv = nullptr;  // dense inverse, row-major n x n (device)
-    ~elag_hip_coarse_s() { elag::dev_free(Minv); }
+    // replicated mode: n = global size, this rank applies rows [my0, my0 + nloc)
+    bool replicated = false;
+    int nloc = 0, my0 = 0;
+    std::vector<int> counts, displs;
+    double *full_rhs = nullptr;
+    ~elag_hip_coarse_s() { elag::dev_free(Minv); elag::dev_free(full_rhs); }
     void setup();
     void apply(const double *rhs, double *sol);
 };

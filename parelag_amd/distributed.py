@@ -1,0 +1,104 @@
+"""One process per GPU: control plane on torch.distributed (gloo), data plane on RCCL inside libelag_hip.so.
+
+The reference runs one MPI rank per sub-domain and exchanges halos inside hypre.  Here ``init`` creates
+the RCCL communicator the library uses for the neighbour exchange (rank 0 makes the unique id, the host broadcasts
+it), and ``build_hierarchy`` hands every rank its rows of every level's operators.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+from . import _lib, linalg as la, partition
+
+
+class Dist:
+    def __init__(self, rank, world, td):
+        self.rank, self.world, self._td = rank, world, td
+
+    def barrier(self):
+        self._td.barrier()
+
+    def allreduce_max(self, v: float) -> float:
+        import torch
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        self._td.all_reduce(t, op=self._td.ReduceOp.MAX)
+        return float(t[0])
+
+    def allreduce_sum(self, v: float) -> float:
+        import torch
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        self._td.all_reduce(t, op=self._td.ReduceOp.SUM)
+        return float(t[0])
+
+
+def init(rank: int, world: int) -> Dist:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # Load the HIP library (and, across ranks, the system RCCL) BEFORE torch: the dynamic loader then binds
+    # everything in this process to the one ROCm runtime the kernels were built with; torch is used on the CPU
+    # only (gloo rendezvous / barriers), so its bundled copies of the same sonames are never needed.
+    lib = _lib.init(int(os.environ.get("LOCAL_RANK", rank)))
+    if world > 1:
+        for name in ("/opt/rocm/lib/librccl.so.1", "librccl.so.1"):
+            try:
+                C.CDLL(name, mode=C.RTLD_GLOBAL)
+                break
+            except OSError:
+                continue
+    import torch
+    import torch.distributed as td
+    if not td.is_initialized():
+        td.init_process_group("gloo", rank=rank, world_size=world)
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        buf = (C.c_ubyte * 128)()
+        _lib.check(lib.elag_hip_comm_unique_id(buf))
+        uid = torch.tensor(list(buf), dtype=torch.uint8)
+    td.broadcast(uid, src=0)
+    buf = (C.c_ubyte * 128)(*uid.tolist())
+    _lib.check(lib.elag_hip_comm_init(rank, world, buf))
+    return Dist(rank, world, td)
+
+
+def build_hierarchy(dist: Dist, A, Ps, seq, smoother="L1 Jacobi", params=None):
+    """Distributed 0-form hierarchy: every level row-partitioned over the ranks (halo exchange per operator apply),
+    coarsest level solved redundantly on every GPU after an all-gather.  Returns (H, n_local, global level shapes,
+    setup seconds)."""
+    t0 = time.time()
+    d = partition.distributed_h1_hierarchy(A, Ps, seq, dist.world)
+    nl = len(d["levels"])
+    t = la.HYPRE_SMOOTHER_TYPES[smoother] if isinstance(smoother, str) else int(smoother)
+    H = la.Hierarchy(nl)
+    ops = []
+    for l, lev in enumerate(d["levels"]):
+        Al = la.ParallelCSRMatrix.from_parts(lev["A_parts"][dist.rank])
+        ops.append(Al)
+        H.SetOperator(l, Al)
+        if l > 0:
+            H.SetProlongator(l, la.ParallelCSRMatrix.from_parts(lev["P_parts"][dist.rank]))
+        if l < nl - 1:
+            S = la.HypreSmootherWrapper(Al, t, params or {})
+            H.SetSmoothers(l, S, S)
+    Ac = la.ParallelCSRMatrix.from_scipy(d["A_global"][-1])
+    starts = np.ascontiguousarray(d["levels"][-1]["starts"], dtype=np.int64)
+    lib = _lib.init()
+    h = C.c_void_p()
+    _lib.check(lib.elag_hip_coarse_create_replicated(C.byref(h), Ac.h, starts.ctypes.data_as(C.c_void_p)))
+    cs = la.CoarseSolver.__new__(la.CoarseSolver)
+    cs._lib, cs.A, cs.h, cs.iterative_mode = lib, Ac, h, False
+    H.SetCoarseSolver(cs)
+    H.Finalize(use_graph=False)
+    la.synchronize()
+    shapes = []
+    for l in range(nl):
+        Ag = d["A_global"][l]
+        Pg = d["P_global"][l] if l < nl - 1 else None
+        shapes.append((Ag.shape[0], Ag.nnz, Pg.shape[1] if Pg is not None else 0, Pg.nnz if Pg is not None else 0))
+    n_local = ops[0].Height()
+    H._dist_info = d
+    return H, n_local, shapes, time.time() - t0

@@ -1,0 +1,144 @@
+"""Row-block domain decomposition of the benchmark operators into per-rank ParCSR pieces (host logic).
+
+In ParElag the pieces come from ``mfem::ParMesh`` + ``SharingMap`` (``src/structures/SharingMap.cpp:975-1011``) and the
+comm package from ``hypre_MatvecCommPkgCreate`` (call sites ``src/hypreExtension/hypre_ParCSRMatrixMatvecBoolInt.c:
+168-172``, ``SharingMap.cpp:110-111``).  Here every rank can see the whole synthetic problem, so the same lists are
+computed directly: ``diag`` / ``offd`` split by the owner's column range, ``col_map_offd`` ascending, ghosts grouped by
+owner (``recv_procs`` / ``recv_vec_starts``) and, symmetrically, the local indices each neighbour asked for
+(``send_procs`` / ``send_map_starts`` / ``send_map_elmts``).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+
+def rcb_partition(points: np.ndarray, nparts: int) -> np.ndarray:
+    """Recursive coordinate bisection of a point cloud into ``nparts`` (any integer >= 1) balanced parts."""
+    part = np.zeros(len(points), dtype=np.int32)
+
+    def rec(idx, first, count):
+        if count == 1:
+            part[idx] = first
+            return
+        left = count // 2
+        p = points[idx]
+        axis = int(np.argmax(p.max(axis=0) - p.min(axis=0)))
+        order = np.argsort(p[:, axis], kind="stable")
+        cut = int(round(len(idx) * left / count))
+        rec(idx[order[:cut]], first, left)
+        rec(idx[order[cut:]], first + left, count - left)
+    rec(np.arange(len(points)), 0, nparts)
+    return part
+
+
+def element_partitions(seq, nparts: int):
+    """Partition the coarsest (base) tets by RCB of their centroids; children inherit their parent's rank, so every
+    derefinement agglomerate stays rank-local as ParElag requires (``CoarsenLocalPartitioning`` is per rank:
+    ``src/topology/Topology.cpp:686-740``).  Returns one element->rank array per level (finest first)."""
+    base = seq.meshes[-1]
+    cent = base.vertices[base.tets].mean(axis=1)
+    p = rcb_partition(cent, nparts)
+    out = [p]
+    for _ in range(len(seq.meshes) - 1):
+        out.append(np.repeat(out[-1], 8))
+    return out[::-1]
+
+
+def vertex_owners(mesh, elem_part: np.ndarray) -> np.ndarray:
+    """A vertex belongs to the lowest rank among the elements that contain it (the SharingMap master rule)."""
+    owner = np.full(mesh.nv, np.iinfo(np.int32).max, dtype=np.int32)
+    np.minimum.at(owner, mesh.tets.reshape(-1), np.repeat(elem_part, 4))
+    return owner
+
+
+def block_numbering(owner: np.ndarray, nparts: int):
+    """Renumber dofs so that each rank owns a contiguous block (hypre's row partition).
+    Returns (order: new->old, rank_of_old: old->new, starts: nparts+1)."""
+    order = np.argsort(owner, kind="stable")
+    new_of_old = np.empty(len(owner), dtype=np.int64)
+    new_of_old[order] = np.arange(len(owner))
+    starts = np.concatenate([[0], np.cumsum(np.bincount(owner, minlength=nparts))]).astype(np.int64)
+    return order, new_of_old, starts
+
+
+def split_rows(A, row_starts, col_starts):
+    """Split a global CSR (already in block numbering) into one ParCSR piece per rank, with comm packages.
+    Returns a list of dicts understood by ``ParallelCSRMatrix.from_parts`` and by the oracle's ``OParCSR``."""
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    nparts = len(row_starts) - 1
+    col_starts = np.asarray(col_starts, dtype=np.int64)
+    parts = []
+    for r in range(nparts):
+        r0, r1 = int(row_starts[r]), int(row_starts[r + 1])
+        c0, c1 = int(col_starts[r]), int(col_starts[r + 1])
+        loc = A[r0:r1].tocsr()
+        loc.sort_indices()
+        cols = loc.indices
+        is_diag = (cols >= c0) & (cols < c1)
+        rows = np.repeat(np.arange(r1 - r0), np.diff(loc.indptr))
+        diag = sp.csr_matrix((loc.data[is_diag], (rows[is_diag], cols[is_diag] - c0)), shape=(r1 - r0, c1 - c0))
+        gcols = cols[~is_diag]
+        col_map = np.unique(gcols)
+        offd = sp.csr_matrix((loc.data[~is_diag], (rows[~is_diag], np.searchsorted(col_map, gcols))),
+                             shape=(r1 - r0, len(col_map)))
+        diag.sort_indices(); offd.sort_indices()
+        # ghosts grouped by owner, ascending (col_map is ascending and owners own contiguous ranges)
+        owner = np.searchsorted(col_starts, col_map, side="right") - 1
+        recv_procs = np.unique(owner)
+        recv_starts = np.concatenate([[0], np.cumsum([(owner == q).sum() for q in recv_procs])]).astype(np.int32)
+        parts.append(dict(diag=diag, offd=offd, col_map_offd=col_map.astype(np.int64), first_row=r0, first_col=c0,
+                          global_shape=A.shape, recv_procs=recv_procs.astype(np.int32), recv_starts=recv_starts,
+                          _ghost_owner=owner))
+    # send lists: what every neighbour asked for, in the neighbour's ghost order
+    for r in range(nparts):
+        c0 = int(col_starts[r])
+        procs, starts, elmts = [], [0], []
+        for q in range(nparts):
+            if q == r:
+                continue
+            pq = parts[q]
+            want = pq["col_map_offd"][pq["_ghost_owner"] == r]
+            if len(want):
+                procs.append(q)
+                elmts.append(want - c0)
+                starts.append(starts[-1] + len(want))
+        parts[r]["send_procs"] = np.asarray(procs, dtype=np.int32)
+        parts[r]["send_starts"] = np.asarray(starts, dtype=np.int32)
+        parts[r]["send_elmts"] = (np.concatenate(elmts) if elmts else np.empty(0)).astype(np.int32)
+    for p in parts:
+        del p["_ghost_owner"]
+    return parts
+
+
+def distributed_h1_hierarchy(A, Ps, seq, nparts: int):
+    """Block-number every level of the 0-form hierarchy for ``nparts`` ranks and split all operators.
+
+    Coarse operators are the Galerkin products in the new numbering (computed here with scipy: the distributed
+    device RAP is a later row of the scope table).  Returns dict(levels=[dict(A_parts, P_parts, starts, order)],
+    A_global=[...]) with P_parts[l] mapping level l+1 -> l."""
+    eparts = element_partitions(seq, nparts)
+    nl = len(Ps) + 1
+    orders, news, starts = [], [], []
+    for l in range(nl):
+        own = vertex_owners(seq.meshes[l], eparts[l])
+        o, n, s = block_numbering(own, nparts)
+        orders.append(o); news.append(n); starts.append(s)
+    A_glob = [sp.csr_matrix(A)[orders[0]][:, orders[0]].tocsr()]
+    P_glob = []
+    for l, P in enumerate(Ps):
+        Pp = sp.csr_matrix(P)[orders[l]][:, orders[l + 1]].tocsr()
+        P_glob.append(Pp)
+        Ac = (Pp.T @ A_glob[-1] @ Pp).tocsr()
+        # hypre_ParCSRMatrixFixZeroRows: essential-BC rows of the Galerkin operator are empty -> unit diagonal
+        zero = np.asarray(abs(Ac).sum(axis=1)).ravel() == 0
+        Ac = (Ac + sp.diags(zero.astype(float))).tocsr()
+        A_glob.append(Ac)
+    levels = []
+    for l in range(nl):
+        lev = dict(A_parts=split_rows(A_glob[l], starts[l], starts[l]), starts=starts[l], order=orders[l])
+        if l > 0:
+            lev["P_parts"] = split_rows(P_glob[l - 1], starts[l - 1], starts[l])
+        levels.append(lev)
+    return dict(levels=levels, A_global=A_glob, P_global=P_glob)

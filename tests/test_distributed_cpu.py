@@ -1,0 +1,68 @@
+"""N > 1 path on CPU: partition / comm-package logic in one process, and a world_size-2 gloo run of the worker."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import oracle as orc
+from parelag_amd import meshgen, partition
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("nparts", [1, 2, 3, 8])
+def test_split_rows_reassembles_products(h1_k2, nparts):
+    A, Ps, seq = h1_k2
+    d = partition.distributed_h1_hierarchy(A, Ps, seq, nparts)
+    rng = np.random.default_rng(0)
+    for l, lev in enumerate(d["levels"]):
+        Ag = d["A_global"][l]
+        W = orc.InProcessWorld(lev["A_parts"])
+        x = rng.standard_normal(Ag.shape[1])
+        assert np.allclose(W.matvec(x), Ag @ x, rtol=1e-12, atol=1e-13)
+        assert np.allclose(W.matvec(x, trans=True), Ag.T @ x, rtol=1e-12, atol=1e-13)
+        # block numbering is a permutation of the natural one and keeps the operator
+        o = lev["order"]
+        assert np.array_equal(np.sort(o), np.arange(Ag.shape[0]))
+        if l == 0:
+            assert abs(Ag - sp.csr_matrix(A)[o][:, o]).max() == 0
+        if l > 0:
+            Pg = d["P_global"][l - 1]
+            Wp = orc.InProcessWorld(lev["P_parts"])
+            xc, xf = rng.standard_normal(Pg.shape[1]), rng.standard_normal(Pg.shape[0])
+            assert np.allclose(Wp.matvec(xc), Pg @ xc, rtol=1e-12, atol=1e-13)
+            assert np.allclose(Wp.matvec(xf, trans=True), Pg.T @ xf, rtol=1e-12, atol=1e-13)
+        for p in lev["A_parts"]:
+            # comm package invariants of hypre_MatvecCommPkgCreate
+            assert np.all(np.diff(p["col_map_offd"]) > 0)
+            assert p["recv_starts"][-1] == p["offd"].shape[1]
+            assert len(p["send_elmts"]) == p["send_starts"][-1]
+            assert np.all(p["send_elmts"] < p["diag"].shape[1])
+
+
+def test_elements_stay_rank_local_under_derefinement(h1_k2):
+    _, _, seq = h1_k2
+    parts = partition.element_partitions(seq, 4)
+    for l in range(len(parts) - 1):
+        fine, coarse = parts[l], parts[l + 1]
+        assert np.array_equal(fine, np.repeat(coarse, 8))          # p[j] = j/8 agglomerates never straddle ranks
+    assert set(np.unique(parts[0])) == {0, 1, 2, 3}
+
+
+def test_rcb_is_balanced():
+    pts = np.random.default_rng(1).uniform(size=(456, 3))
+    for n in (2, 3, 8):
+        c = np.bincount(partition.rcb_partition(pts, n), minlength=n)
+        assert c.max() - c.min() <= 2
+
+
+def test_world_size_2_gloo():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29613", os.path.join(ROOT, "tests", "dist_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "DIST_WORKER_OK 2" in r.stdout

@@ -371,3 +371,63 @@ def test_vcycle_with_internal_reordering_matches_oracle(la, h1_k2, smoother, par
     H.Mult(b, x)
     e = np.empty_like(b); Hc.apply(b - A @ x0, e)
     assert close(x, x0 + e, tol=1e-11)
+
+
+# ---- halo path on one GPU: a rank that is its own neighbour ---------------------------------------------------
+
+def self_coupled_part(n, g, seed):
+    """diag (n x n) + offd (n x g) whose ghost column c is owned by this very rank as local column send_elmts[c]."""
+    rng = np.random.default_rng(seed)
+    diag = rand_csr(n, n, 8.0 / n, seed)
+    offd = sp.random(n, g, density=0.02, random_state=rng, format="csr"); offd.data = rng.uniform(-1, 1, offd.nnz)
+    elm = rng.integers(0, n, g).astype(np.int32)
+    part = dict(diag=diag, offd=orc.csr(offd), col_map_offd=n + np.arange(g, dtype=np.int64), first_row=0, first_col=0,
+                global_shape=(n, n + g), send_procs=np.array([0], np.int32), send_starts=np.array([0, g], np.int32),
+                send_elmts=elm, recv_procs=np.array([0], np.int32), recv_starts=np.array([0, g], np.int32))
+    return part, elm
+
+
+@pytest.mark.parametrize("n,g", [(300, 40), (5000, 700), (150000, 9000)])
+def test_halo_exchange_overlap_path(la, n, g):
+    """pack -> exchange (self copy) -> interior rows -> boundary rows (+offd), and the reverse path of MatvecT."""
+    part, elm = self_coupled_part(n, g, 7)
+    M = la.ParallelCSRMatrix.from_parts(part)
+    D, O = part["diag"], part["offd"]
+    rng = np.random.default_rng(8)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(n)
+    y = y0.copy()
+    M.Mult(x, y, 0.7, -1.3)
+    ref = 0.7 * (D @ x + O @ x[elm]) - 1.3 * y0
+    assert close(y, ref, scale=np.max(np.abs(D) @ np.abs(x)) + np.max(np.abs(y0)))
+    # residual epilogue through both passes
+    b, r = rng.standard_normal(n), np.empty(n)
+    M.residual(b, x, r)
+    assert close(r, b - (D @ x + O @ x[elm]), scale=np.max(np.abs(D) @ np.abs(x)) + 1)
+    # MatvecT: y = diag^T x + scatter-add of (offd^T x) at send_map_elmts (duplicates included)
+    z = np.zeros(n)
+    M.MultTranspose(x, z)
+    refT = D.T @ x
+    np.add.at(refT, elm, O.T @ x)
+    assert close(z, refT, scale=np.max(np.abs(D).T @ np.abs(x)) + 1)
+    # norms see both blocks
+    absrow = np.asarray(abs(D).sum(axis=1)).ravel() + np.asarray(abs(O).sum(axis=1)).ravel()
+    assert M.norm("linf") == pytest.approx(absrow.max(), rel=1e-13)
+    colsum = np.asarray(abs(D).sum(axis=0)).ravel(); np.add.at(colsum, elm, np.asarray(abs(O).sum(axis=0)).ravel())
+    assert M.norm("l1") == pytest.approx(colsum.max(), rel=1e-13)
+
+
+def test_l1_jacobi_with_offd_block(la):
+    n, g = 4000, 500
+    part, elm = self_coupled_part(n, g, 9)
+    part["diag"] = orc.csr(part["diag"] + sp.diags(np.full(n, 6.0)))
+    M = la.ParallelCSRMatrix.from_parts(part)
+    S = la.HypreSmootherWrapper(M, 1, {"Sweeps": 2, "Damping Factor": 0.9})
+    D, O = part["diag"], part["offd"]
+    l1 = np.asarray(abs(D).sum(axis=1)).ravel() + np.asarray(abs(O).sum(axis=1)).ravel()
+    rng = np.random.default_rng(10)
+    f, u0 = rng.standard_normal(n), rng.standard_normal(n)
+    u = u0.copy(); S.Mult(f, u)
+    ref = u0.copy()
+    for _ in range(2):
+        ref = ref + 0.9 * (f - (D @ ref + O @ ref[elm])) / l1
+    assert close(u, ref)
