@@ -248,6 +248,14 @@ typedef struct {
 ELAG_HIP_API int elag_hip_amge_default_options(elag_hip_amge_options *opt);
 ELAG_HIP_API int elag_hip_hierarchy_build(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P,
                                           const elag_hip_parcsr_t *P, const elag_hip_amge_options *opt);
+/* Same, with a HiptmairSmoother on every non-coarsest level ("PreSmoother"/"PostSmoother" = a "Hiptmair" entry:
+ * examples/testing_helpers/Create2FormParameterList.hpp:78-133).  D[l] is the true exterior derivative into the
+ * form of level l (HiptmairSmootherFactory.cpp:84-103); A_aux = D^T A D + FixZeroRows is formed on the device
+ * (:143-165); `opt` configures the hierarchy and the primary smoother, `aux_opt` (relax_type, sweeps, damping,
+ * Chebyshev fields) the auxiliary one.  Reordering is not applied to Hiptmair hierarchies. */
+ELAG_HIP_API int elag_hip_hierarchy_build_hiptmair(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P,
+                                                   const elag_hip_parcsr_t *P, const elag_hip_parcsr_t *D,
+                                                   const elag_hip_amge_options *opt, const elag_hip_amge_options *aux_opt);
 /* new -> old row map of a level (identity when the hierarchy was not reordered); `order` has num_rows entries */
 ELAG_HIP_API int elag_hip_hierarchy_get_ordering(elag_hip_hierarchy_t H, int level, int *order);
 ELAG_HIP_API int elag_hip_hierarchy_get_operator(elag_hip_hierarchy_t H, int level, elag_hip_parcsr_t *A);

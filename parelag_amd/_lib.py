@@ -106,6 +106,8 @@ _SIGNATURES = {
     "elag_hip_hierarchy_destroy": [_p],
     "elag_hip_amge_default_options": [C.POINTER(AMGeOptions)],
     "elag_hip_hierarchy_build": [C.POINTER(_p), _p, _i, C.POINTER(_p), C.POINTER(AMGeOptions)],
+    "elag_hip_hierarchy_build_hiptmair": [C.POINTER(_p), _p, _i, C.POINTER(_p), C.POINTER(_p), C.POINTER(AMGeOptions),
+                                          C.POINTER(AMGeOptions)],
     "elag_hip_hierarchy_get_ordering": [_p, _i, _p],
     "elag_hip_hierarchy_get_operator": [_p, _i, C.POINTER(_p)],
     "elag_hip_hierarchy_get_smoother": [_p, _i, C.POINTER(_p)],

@@ -375,14 +375,15 @@ std::vector<int> inverse_perm(const std::vector<int> &order)
 
 extern "C" {
 
-int elag_hip_hierarchy_build(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P, const elag_hip_parcsr_t *P,
-                             const elag_hip_amge_options *opt_in)
+static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P, const elag_hip_parcsr_t *P,
+                       const elag_hip_parcsr_t *D, const elag_hip_amge_options *opt_in, const elag_hip_amge_options *aux_in)
 {
-    return guarded([&] {
+    {
         require_init();
         ELAG_REQUIRE(out && A && num_P >= 0 && (num_P == 0 || P), "bad argument");
-        elag_hip_amge_options opt;
+        elag_hip_amge_options opt, aux;
         if (opt_in) opt = *opt_in; else elag_hip_amge_default_options(&opt);
+        if (aux_in) aux = *aux_in; else elag_hip_amge_default_options(&aux);
         std::unique_ptr<elag_hip_hierarchy_s> H(new elag_hip_hierarchy_s());
         H->lev.resize((size_t)num_P + 1);
         H->lev[0].A = A;
@@ -402,7 +403,7 @@ int elag_hip_hierarchy_build(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int
         }
 
         // ---- optional internal renumbering for gather locality -------------------------------------
-        const bool reorder = ctx().nranks == 1 && A->offd.ncols == 0 &&
+        const bool reorder = ctx().nranks == 1 && A->offd.ncols == 0 && D == nullptr &&
                              (opt.reorder > 0 || (opt.reorder < 0 && A->nrows() >= (1 << 18)));
         if (reorder) {
             const int nl = num_P + 1;
@@ -455,6 +456,28 @@ int elag_hip_hierarchy_build(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int
                                               opt.cheby_fraction);
             if (rc) fail(rc, "%s", elag_hip_last_error());
             H->owned_smoothers.push_back(S);
+            if (D) {
+                // HiptmairSmootherFactory::_do_build_solver: A_aux = RAP(A, D) + FixZeroRows (:143-165), auxiliary smoother
+                // with iterative_mode = false (:134), primary with iterative_mode = true (:113)
+                ParCSR *Dl = D[l];
+                ELAG_REQUIRE(Dl, "null D on level %d", l);
+                ELAG_REQUIRE(H->lev[(size_t)l].A->ncols() == Dl->nrows(),
+                             "A and D do not have compatible sizes to compute D^T*A*D on level %d (A %dx%d, D %dx%d)", l,
+                             H->lev[(size_t)l].A->nrows(), H->lev[(size_t)l].A->ncols(), Dl->nrows(), Dl->ncols());
+                elag_hip_parcsr_t Aaux = nullptr;
+                rc = elag_hip_parcsr_rap(Dl, H->lev[(size_t)l].A, Dl, &Aaux);
+                if (rc) fail(rc, "%s", elag_hip_last_error());
+                H->owned_mats.push_back(Aaux);
+                k::fix_zero_rows(Aaux->diag, &Aaux->offd);
+                elag_hip_smoother_t Sa = nullptr, Sh = nullptr;
+                rc = elag_hip_smoother_create(&Sa, Aaux, aux.relax_type, aux.sweeps, aux.damping, 1.0, aux.cheby_order, aux.cheby_fraction);
+                if (rc) fail(rc, "%s", elag_hip_last_error());
+                H->owned_smoothers.push_back(Sa);
+                rc = elag_hip_hiptmair_create(&Sh, H->lev[(size_t)l].A, Dl, S, Sa);
+                if (rc) fail(rc, "%s", elag_hip_last_error());
+                H->owned_smoothers.push_back(Sh);
+                S = Sh;
+            }
             H->lev[(size_t)l].pre = S;
             H->lev[(size_t)l].post = S;  // same parameters => same operator; scratch is not shared across calls
         }
@@ -465,6 +488,21 @@ int elag_hip_hierarchy_build(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int
         H->coarse = C;
         H->finalize(opt.use_graph != 0);
         *out = H.release();
+    }
+}
+
+int elag_hip_hierarchy_build(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P, const elag_hip_parcsr_t *P,
+                             const elag_hip_amge_options *opt)
+{
+    return guarded([&] { build_impl(out, A, num_P, P, nullptr, opt, nullptr); });
+}
+
+int elag_hip_hierarchy_build_hiptmair(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P, const elag_hip_parcsr_t *P,
+                                      const elag_hip_parcsr_t *D, const elag_hip_amge_options *opt, const elag_hip_amge_options *aux_opt)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(D != nullptr || num_P == 0, "null D array");
+        build_impl(out, A, num_P, P, D, opt, aux_opt);
     });
 }
 

@@ -462,18 +462,12 @@ class Hierarchy(_SolverBase):
             pass
 
 
-def buildHierarchyFromDeRhamSequence(A: ParallelCSRMatrix, Ps, smoother="L1 Jacobi", params: dict | None = None,
-                                     fix_zero_rows=True, coarse_kind=0, use_graph=True, reorder=-1) -> Hierarchy:
-    """RAP chain + smoothers + coarse solve in one ABI call (Hierarchy.cpp:282-383, AMGeSolverFactory.cpp:26-169).
-    ``Ps[l]`` is the true interpolator from level l+1 to level l (DeRhamSequence::ComputeTrueP)."""
+def _amge_options(lib, smoother, params, fix_zero_rows=True, coarse_kind=0, use_graph=True, reorder=-1):
     params = params or {}
-    t = HYPRE_SMOOTHER_TYPES[smoother] if isinstance(smoother, str) else int(smoother)
-    lib = _lib.init()
-    arr = (_vp * max(len(Ps), 1))(*[P.h for P in Ps])
     opt = _lib.AMGeOptions()
     check(lib.elag_hip_amge_default_options(C.byref(opt)))
     opt.fix_zero_rows = int(fix_zero_rows)
-    opt.relax_type = t
+    opt.relax_type = HYPRE_SMOOTHER_TYPES[smoother] if isinstance(smoother, str) else int(smoother)
     opt.sweeps = int(params.get("Sweeps", 1))
     opt.damping = float(params.get("Damping Factor", 1.0))
     opt.cheby_order = int(params.get("Cheby Poly Order", 2))
@@ -481,10 +475,30 @@ def buildHierarchyFromDeRhamSequence(A: ParallelCSRMatrix, Ps, smoother="L1 Jaco
     opt.coarse_kind = int(coarse_kind)
     opt.use_graph = int(use_graph)
     opt.reorder = int(reorder)
+    return opt
+
+
+def buildHierarchyFromDeRhamSequence(A: ParallelCSRMatrix, Ps, smoother="L1 Jacobi", params: dict | None = None,
+                                     fix_zero_rows=True, coarse_kind=0, use_graph=True, reorder=-1,
+                                     Ds=None, aux_smoother="L1 Jacobi", aux_params: dict | None = None) -> Hierarchy:
+    """RAP chain + smoothers + coarse solve in one ABI call (Hierarchy.cpp:282-383, AMGeSolverFactory.cpp:26-169).
+    ``Ps[l]`` is the true interpolator from level l+1 to level l (DeRhamSequence::ComputeTrueP).  With ``Ds`` (the true
+    exterior derivative into the form, one per non-coarsest level) every level gets a HiptmairSmoother whose primary /
+    auxiliary relaxations are ``smoother`` / ``aux_smoother`` ("Primary Smoother" / "Auxiliary Smoother")."""
+    lib = _lib.init()
+    arr = (_vp * max(len(Ps), 1))(*[P.h for P in Ps])
+    opt = _amge_options(lib, smoother, params, fix_zero_rows, coarse_kind, use_graph, reorder)
     h = _vp()
-    check(lib.elag_hip_hierarchy_build(C.byref(h), A.h, len(Ps), arr, C.byref(opt)))
+    if Ds is None:
+        check(lib.elag_hip_hierarchy_build(C.byref(h), A.h, len(Ps), arr, C.byref(opt)))
+    else:
+        if len(Ds) < len(Ps):
+            raise ValueError("need one D per non-coarsest level")
+        darr = (_vp * max(len(Ps), 1))(*[D.h for D in Ds[:len(Ps)]])
+        aux = _amge_options(lib, aux_smoother, aux_params)
+        check(lib.elag_hip_hierarchy_build_hiptmair(C.byref(h), A.h, len(Ps), arr, darr, C.byref(opt), C.byref(aux)))
     H = Hierarchy(handle=h)
-    H._keep += [A, *Ps]
+    H._keep += [A, *Ps, *(Ds or [])]
     return H
 
 

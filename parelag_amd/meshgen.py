@@ -444,3 +444,25 @@ def h1_problem(nref: int, nlevels: int | None = None):
         f, c = seq.meshes[l], seq.meshes[l + 1]
         Ps.append(eliminate_cols(interp_P0(c, f), c.boundary_marker_unit_cube()))
     return A, Ps, seq
+
+
+def hdiv_problem(nref: int, nlevels: int | None = None, alpha: float = 1.0, beta: float = 1.0):
+    """2-form problem of MultigridTest2Form: A = alpha M2 + beta D2^T M3 D2 (``examples/MultigridTest2Form.cpp:541-559``)
+    with every boundary face essential, the true interpolators P2 with essential columns zeroed and, for the Hiptmair
+    smoother, the true curl D1 of every level with essential (boundary-edge) columns zeroed
+    (``HiptmairSmootherFactory.cpp:84-103`` -> ``DeRhamSequence::ComputeTrueD(form-1, ess)``).
+
+    Returns (A_fine, [P_l], [D_l], seq); P_l maps level l+1 -> l, D_l is faces x edges on level l."""
+    seq = Sequence.cube456(nref, nlevels)
+    fine = seq.meshes[0]
+    D2 = fine.D2()
+    A = (alpha * fine.M2() + beta * (D2.T @ fine.M3() @ D2)).tocsr()
+    A.sort_indices()
+    A = eliminate_rowcol(A, fine.boundary_marker(2))
+    Ps, Ds = [], []
+    for l, m in enumerate(seq.meshes):
+        Ds.append(eliminate_cols(m.D1(), m.boundary_marker(1)))
+        if l < len(seq.meshes) - 1:
+            c = seq.meshes[l + 1]
+            Ps.append(eliminate_cols(interp_P2(c, m), c.boundary_marker(2)))
+    return A, Ps, Ds, seq

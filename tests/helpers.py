@@ -71,3 +71,27 @@ def pcg(A, M_apply, b, rtol=1e-10, maxit=200):
         p = z + (rz_new / rz) * p
         rz = rz_new
     return x, maxit, hist
+
+
+def oracle_hdiv_hierarchy(A, Ps, Ds, primary=1, aux=1):
+    """2-form hierarchy with HiptmairSmoother(primary, auxiliary) on every non-coarsest level
+    (Create2FormParameterList.hpp:78-133 with the relaxation types swapped for GPU-capable ones):
+    A_aux = RAP(A, D) + FixZeroRows per HiptmairSmootherFactory.cpp:143-165."""
+    As = [orc.diag_first(A)]
+    Pl = [orc.csr(P) for P in Ps]
+    for P in Pl:
+        Ac = orc.rap(P, As[-1], P)
+        orc.fix_zero_rows(Ac)
+        As.append(Ac)
+    sms, hipt = [], []
+    for l, Al in enumerate(As):
+        sms.append(dict(type=primary, l1=orc.l1_norms(Al, None, option=primary)))
+        if l < len(As) - 1:
+            D = orc.csr(Ds[l])
+            X = orc.rap(D, Al, D)
+            orc.fix_zero_rows(X)
+            hipt.append(dict(D=D, Aaux=X, sm=dict(type=aux, l1=orc.l1_norms(X, None, option=aux))))
+        else:
+            hipt.append(None)
+    chol = orc.chol_factor(As[-1].toarray())
+    return dict(As=As, Ps=Pl, sms=sms, hipt=hipt, chol=chol)

@@ -431,3 +431,54 @@ def test_l1_jacobi_with_offd_block(la):
     for _ in range(2):
         ref = ref + 0.9 * (f - (D @ ref + O @ ref[elm])) / l1
     assert close(u, ref)
+
+
+# ---- config 3: H(div) + Hiptmair ------------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def hdiv_k2():
+    from parelag_amd import meshgen
+    return meshgen.hdiv_problem(2)
+
+
+def test_hiptmair_smoother_matches_oracle(la, hdiv_k2):
+    """HiptmairSmoother::Mult and MultTranspose, iterative and preconditioner mode (HiptmairSmoother.cpp:48-109)."""
+    A, Ps, Ds, _ = hdiv_k2
+    from tests.helpers import oracle_hdiv_hierarchy
+    h = oracle_hdiv_hierarchy(A, Ps, Ds)
+    A0, D0, X0 = orc.OParCSR(h["As"][0]), orc.OParCSR(h["hipt"][0]["D"]), orc.OParCSR(h["hipt"][0]["Aaux"])
+    ref = orc.OHiptmair(A0, D0, orc.OSmoother(A0, 1), orc.OSmoother(X0, 1))
+    dA, dD = la.ParallelCSRMatrix.from_scipy(A), la.ParallelCSRMatrix.from_scipy(Ds[0])
+    dX = la.RAP(dA, dD); dX.fix_zero_rows()
+    same_matrix(dX.to_scipy(), h["hipt"][0]["Aaux"])
+    dev = la.HiptmairSmoother(dA, dD, la.HypreSmootherWrapper(dA, 1), la.HypreSmootherWrapper(dX, 1))
+    rng = np.random.default_rng(31)
+    f, u0 = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+    for iterative in (True, False):
+        ref.iterative_mode = dev.iterative_mode = iterative
+        for tr in (False, True):
+            u, ur = u0.copy(), u0.copy()
+            (dev.MultTranspose if tr else dev.Mult)(f, u)
+            (ref.MultTranspose if tr else ref.Mult)(f, ur)
+            assert close(u, ur, tol=1e-11), (iterative, tr)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_hdiv_hiptmair_vcycle_matches_oracle(la, hdiv_k2, use_graph):
+    A, Ps, Ds, _ = hdiv_k2
+    from tests.helpers import oracle_hdiv_hierarchy
+    h = oracle_hdiv_hierarchy(A, Ps, Ds)
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], hipt=h["hipt"])
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    dDs = [la.ParallelCSRMatrix.from_scipy(D) for D in Ds]
+    H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi", Ds=dDs, aux_smoother="L1 Jacobi", use_graph=use_graph)
+    rng = np.random.default_rng(32)
+    for _ in range(2):
+        b = rng.uniform(-1, 1, A.shape[0])
+        x, xr = np.empty_like(b), np.empty_like(b)
+        H.Mult(b, x); Hc.apply(b, xr)
+        assert close(x, xr, tol=1e-10)
+    xd, it_d, hist_d = pcg(A, H.Mult, np.full(A.shape[0], 2.0), rtol=1e-8)
+    xo, it_o, hist_o = pcg(A, Hc.apply, np.full(A.shape[0], 2.0), rtol=1e-8)
+    assert it_d == it_o and abs(hist_d[-1] - hist_o[-1]) <= 1e-10 * hist_o[0]
