@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--roofline-reps", type=int, default=50)
     ap.add_argument("--roofline-only", action="store_true", help="only run the fine-level SpMV launches (for rocprofv3)")
     ap.add_argument("--smoother", default="L1 Jacobi")
+    ap.add_argument("--form", type=int, default=0, choices=[0, 2],
+                    help="0: MultigridTest0Form (H1, the BASELINE metric); 2: MultigridTest2Form (H(div), Hiptmair smoother)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -133,12 +135,20 @@ def main():
         del Hr, A0, dAr, dPr, x, y, rhs_r, sol_r
 
     # ---------------------------------------------------------------- V-cycle workload
-    A, Ps, seq = meshgen.h1_problem(args.refines)
+    Ds = None
+    if args.form == 2:
+        if not single:
+            raise SystemExit("--form 2 is a single-GPU configuration (BASELINE configs[2])")
+        A, Ps, Ds, seq = meshgen.hdiv_problem(args.refines)
+    else:
+        A, Ps, seq = meshgen.h1_problem(args.refines)
     if single:
         dA = la.ParallelCSRMatrix.from_scipy(A)
         dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+        dDs = [la.ParallelCSRMatrix.from_scipy(D) for D in Ds[:len(Ps)]] if Ds is not None else None
         t0 = time.time()
-        H = la.buildHierarchyFromDeRhamSequence(dA, dPs, args.smoother, use_graph=not args.no_graph)
+        H = la.buildHierarchyFromDeRhamSequence(dA, dPs, args.smoother, use_graph=not args.no_graph, Ds=dDs,
+                                                aux_smoother=args.smoother)
         la.synchronize()
         setup_s = time.time() - t0
         n_local = A.shape[0]
@@ -193,9 +203,13 @@ def main():
     cpu = None
     if single and not args.no_cpu_baseline and rank == 0:
         from oracle import oracle as orc
-        from tests.helpers import oracle_h1_hierarchy
-        h = oracle_h1_hierarchy(A, Ps, smoother=la.HYPRE_SMOOTHER_TYPES[args.smoother])
-        Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], native=True)
+        from tests.helpers import oracle_h1_hierarchy, oracle_hdiv_hierarchy
+        if args.form == 2:
+            h = oracle_hdiv_hierarchy(A, Ps, Ds)
+            Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], native=True, hipt=h["hipt"])
+        else:
+            h = oracle_h1_hierarchy(A, Ps, smoother=la.HYPRE_SMOOTHER_TYPES[args.smoother])
+            Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], native=True)
         b = np.full(A.shape[0], 2.0); xs = np.empty_like(b)
         Hc.apply(b, xs)
         cnt, t0 = 0, time.perf_counter()
@@ -215,7 +229,7 @@ def main():
 
     if rank == 0:
         out.update({
-            "metric": "V-cycles/sec (MultigridTest0Form cube456, Hierarchy::Mult in preconditioner mode)",
+            "metric": f"V-cycles/sec (MultigridTest{args.form}Form cube456, Hierarchy::Mult in preconditioner mode)",
             "value": round(args.steps / elapsed, 2),
             "unit": "V-cycles/s",
             "n_gpus": world,
@@ -227,8 +241,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"MultigridTest0Form cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
-                                   f"{args.smoother} 1 sweep pre/post, dense coarse solve, b=2",
+            "config": {"workload": (f"MultigridTest0Form cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
+                                    f"{args.smoother} 1 sweep pre/post, dense coarse solve, b=2") if args.form == 0 else
+                                   (f"MultigridTest2Form (H(div)) cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
+                                    f"Hiptmair({args.smoother}, {args.smoother}) pre/post, dense coarse solve, b=2"),
                        "levels": [{"n": s[0], "nnz": s[1]} for s in level_shapes],
                        "hipgraph": not args.no_graph and single, "parallelism": f"row-block domain decomposition x{world}"},
             "device_ms_per_step": round(ms_dev, 5),
