@@ -17,6 +17,12 @@ struct Level {
     ParCSR *P = nullptr;  // maps this level to the next finer one (null on level 0)
     elag_hip_smoother_s *pre = nullptr, *post = nullptr;
     double *resid = nullptr, *sol = nullptr, *alt = nullptr, *tmp_resid = nullptr;
+    // launch-bound levels with one l1-Jacobi sweep before and after (see plan_fused): the level costs two launches
+    //   down:  r_c  = G f,                      G  = P^T (I - A W),     W = diag(weight / l1)
+    //   up:    x    = W (2 f - (A W f + S e)),  S  = A P - W^-1 P
+    // which is algebraically the reference's  x = W f; r = f - A x; r_c = P^T r; x += P e; x += W (f - A x).
+    std::shared_ptr<DevCSR> G, S;
+    const double *fused_dinv = nullptr;
 };
 
 struct GraphEntry {
@@ -86,7 +92,51 @@ struct elag_hip_hierarchy_s {
         for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);
         graphs.clear();
         use_graph = graph && ctx().nranks == 1;
+        plan_fused();
         finalized = true;
+        ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    }
+
+    void plan_fused()
+    {
+        static int disabled = -1;
+        static long long max_nnz = 0;
+        if (disabled < 0) {
+            const char *e = getenv("ELAG_HIP_NO_LEVEL_FUSION"); disabled = (e && atoi(e)) ? 1 : 0;
+            const char *m = getenv("ELAG_HIP_FUSE_NNZ"); max_nnz = m ? atoll(m) : (1ll << 20);
+        }
+        const int nl = (int)lev.size();
+        for (int l = 0; l + 1 < nl; l++) {
+            Level &F = lev[(size_t)l];
+            Level &C = lev[(size_t)l + 1];
+            F.G.reset(); F.S.reset(); F.fused_dinv = nullptr;
+            const RelaxSmoother *j = dynamic_cast<const RelaxSmoother *>(F.pre);
+            const RelaxSmoother *jp = dynamic_cast<const RelaxSmoother *>(F.post);
+            if (disabled || ctx().nranks != 1 || !j || !jp || !j->dinv || j->sweeps != 1 || jp->sweeps != 1 || j->A != F.A || jp->A != F.A ||
+                j->type != jp->type || j->weight != jp->weight)
+                continue;
+            if (F.A->offd.ncols > 0 || C.P->offd.ncols > 0 || F.A->diag.nnz >= max_nnz) continue;
+            const int n = F.A->nrows();
+            C.P->ensure_transpose();
+            // G = R - (R A) W
+            DevCSR RA;
+            k::csr_spgemm(*C.P->diagT, F.A->diag, RA);
+            k::csr_scale_cols(RA, j->dinv);
+            F.G.reset(new DevCSR());
+            k::csr_add(1.0, *C.P->diagT, -1.0, RA, *F.G);
+            // S = A P - W^-1 P
+            DevCSR AP, WP;
+            k::csr_spgemm(F.A->diag, C.P->diag, AP);
+            k::csr_copy(C.P->diag, WP);
+            {
+                Temp<double> winv((size_t)n);
+                k::vec_reciprocal_scale(n, 1.0, j->dinv, winv);
+                k::csr_scale_rows(WP, winv);
+                F.S.reset(new DevCSR());
+                k::csr_add(1.0, AP, -1.0, WP, *F.S);
+            }
+            F.fused_dinv = j->dinv;
+        }
         ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
     }
 
@@ -108,6 +158,16 @@ struct elag_hip_hierarchy_s {
         }
         Level &C = lev[(size_t)l + 1];
         const int n = F.A->nrows();
+        if (F.G) {
+            k::SpmvArgs d;  // restricted residual of the zero-guess Jacobi sweep in one product
+            d.x = rhs; d.alpha = 1.0; d.out = C.resid;
+            k::spmv_fused(*F.G, nullptr, d);
+            iterate(l + 1, C.resid, C.sol, C.alt);
+            k::SpmvArgs u;  // coarse correction and post-smoothing in one product pair
+            u.x = rhs; u.cs = F.fused_dinv; u.xg = C.sol; u.alpha = -1.0; u.f = rhs; u.gamma = 2.0; u.s = F.fused_dinv; u.out = sol;
+            k::spmv_fused(F.A->diag, F.S.get(), u);
+            return;
+        }
         const int nf = (F.pre ? F.pre->flips(true) : 0) + (F.post ? F.post->flips(false) : 0);
         double *cur = (nf & 1) ? alt : sol, *oth = (nf & 1) ? sol : alt;
         // pre-smoothing (:180-184) and residual (:191-194)

@@ -65,6 +65,7 @@ void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C);  // C = A*B, colum
 void csr_add(double a, const DevCSR &A, double b, const DevCSR &B, DevCSR &C);
 void csr_delete_zeros(const DevCSR &A, double tol, DevCSR &out);
 void csr_scale_rows(DevCSR &A, const double *d);
+void csr_scale_cols(DevCSR &A, const double *d);  // a_ij *= d_j
 void csr_copy(const DevCSR &A, DevCSR &out);
 // out = A(order_rows, :) with columns renumbered by rank_cols (old -> new); rows come back column-sorted
 void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_cols, int ncols_out, DevCSR &out);

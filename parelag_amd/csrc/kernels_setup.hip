@@ -499,6 +499,21 @@ void csr_delete_zeros(const DevCSR &A, double tol, DevCSR &out)
     out.choose_spmv_shape();
 }
 
+namespace {
+__global__ void scale_cols_kernel(long long nnz, const int *__restrict__ J, double *__restrict__ a, const double *__restrict__ d)
+{
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x) a[k] *= d[J[k]];
+}
+}  // namespace
+
+void csr_scale_cols(DevCSR &A, const double *d)
+{
+    if (A.nnz == 0) return;
+    long long g = (A.nnz + kBlock - 1) / kBlock; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)g), dim3(kBlock), 0, ctx().stream, (long long)A.nnz, (const int *)A.J, A.a, d);
+    ELAG_LAUNCH_CHECK();
+}
+
 void csr_scale_rows(DevCSR &A, const double *d)
 {
     if (A.nrows == 0) return;
