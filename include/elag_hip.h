@@ -164,6 +164,31 @@ ELAG_HIP_API int elag_hip_parcsr_set_spmv_lanes(elag_hip_parcsr_t A, int lanes);
 /* a_ii of every local row -> d (device or host vector of num_rows) */
 ELAG_HIP_API int elag_hip_parcsr_get_diagonal(elag_hip_parcsr_t A, double *d, int loc);
 
+/* hypre_ParCSRMatrixMatvecBoolInt (src/hypreExtension/hypre_ParCSRMatrixMatvecBoolInt.c:140-202): integer
+ * y = alpha*|A|_bool*x + beta*y, values of A ignored (pattern = 1), same halo exchange with comm job 11. */
+ELAG_HIP_API int elag_hip_parcsr_spmv_boolint(elag_hip_parcsr_t A, int alpha, const int *x, int beta, int *y, int loc);
+/* hypre_ParCSRMatrixKeepEqualEntries (src/hypreExtension/deleteZeros.c:113-200): A and B share a pattern; entries
+ * of A equal to B's (|a-b| < 1e-9) become 1, the others are dropped.  Overwrites A. */
+ELAG_HIP_API int elag_hip_parcsr_keep_equal_entries(elag_hip_parcsr_t A, elag_hip_parcsr_t B);
+
+/* --------------------------------------------------------------------------------------------------
+ * Agglomerate index maps.  Integer setup logic that stays on the host side of the boundary
+ * (north star: "host code stays C++"); results are bit-exact with the reference's routines.  No GPU needed.
+ * ------------------------------------------------------------------------------------------------ */
+/* MFEMRefinedMeshPartitioner::Partition (src/partitioning/MFEMRefinedMeshPartitioner.cpp:50-95).
+ * legacy_numbering = 0: MFEM >= 4.1 branch (:64-70); != 0: parent-then-children numbering (:71-91). */
+ELAG_HIP_API int elag_hip_partition_refined(int num_elements, int num_parts, int num_dimensions, int legacy_numbering,
+                                            int *partitioning);
+/* connectedComponents (src/structures/connectedComponents.cpp:23-85): splits every part into its connected
+ * components of the graph (conn_i, conn_j); new ids = offset[part] + component, components numbered by their first
+ * node.  All part ids must be >= 0. */
+ELAG_HIP_API int elag_hip_connected_components(int num_nodes, int *partitioning, const int *conn_i, const int *conn_j,
+                                               int *num_components);
+/* transposePartitioning (src/structures/transpose.cpp:27-55): element->part array to part->elements CSR
+ * (i_out: num_parts+1 entries, j_out: number of entries with part >= 0; elements ascending inside a part). */
+ELAG_HIP_API int elag_hip_transpose_partitioning(int num_elements, const int *partitioning, int num_parts, int *i_out,
+                                                 int *j_out);
+
 /* --------------------------------------------------------------------------------------------------
  * Smoothers  (HypreSmootherWrapper -> mfem::HypreSmoother -> hypre_ParCSRRelax;
  * src/linalg/solver_ops/ParELAG_HypreSmootherWrapper.cpp:20-35, .hpp:69-83)

@@ -86,6 +86,11 @@ _SIGNATURES = {
     "elag_hip_parcsr_compare": [_p, _p, _d, _ip],
     "elag_hip_parcsr_get_diagonal": [_p, _p, _i],
     "elag_hip_parcsr_set_spmv_lanes": [_p, _i],
+    "elag_hip_parcsr_spmv_boolint": [_p, _i, _p, _i, _p, _i],
+    "elag_hip_parcsr_keep_equal_entries": [_p, _p],
+    "elag_hip_partition_refined": [_i, _i, _i, _i, _p],
+    "elag_hip_connected_components": [_i, _p, _p, _p, _ip],
+    "elag_hip_transpose_partitioning": [_i, _p, _i, _p, _p],
     "elag_hip_smoother_create": [C.POINTER(_p), _p, _i, _i, _d, _d, _i, _d],
     "elag_hip_smoother_get_eig_estimate": [_p, _dp, _dp],
     "elag_hip_smoother_set_eig_estimate": [_p, _d, _d],

@@ -198,6 +198,18 @@ class ParallelCSRMatrix:
         py, ly, _k2 = _vec(y, self.Width(), writable=True)
         check(self._lib.elag_hip_parcsr_spmv(self.h, 1, alpha, px, beta, py, _same_loc(lx, ly)))
 
+    def MultBoolInt(self, x, y, alpha=1, beta=0):
+        """hypre_ParCSRMatrixMatvecBoolInt: integer y = alpha*pattern(A)*x + beta*y (host int32 arrays)."""
+        x = np.ascontiguousarray(x, dtype=np.int32)
+        if y.dtype != np.int32 or not y.flags.c_contiguous:
+            raise TypeError("y must be a contiguous int32 array")
+        check(self._lib.elag_hip_parcsr_spmv_boolint(self.h, int(alpha), _np_ptr(x), int(beta), _np_ptr(y), HOST))
+
+    def keep_equal_entries(self, B):
+        """hypre_ParCSRMatrixKeepEqualEntries(A, B): overwrites this matrix."""
+        check(self._lib.elag_hip_parcsr_keep_equal_entries(self.h, B.h))
+        check(self._lib.elag_hip_parcsr_get_info(self.h, C.byref(self.info)))
+
     def residual(self, b, x, r):
         """r = b - A x  (mg_utils::ComputeResidual)."""
         pb, lb, _k1 = _vec(b, self.Height())
@@ -512,3 +524,30 @@ def time_kernel(A: ParallelCSRMatrix, kernel: str, x, y, reps=20, smoother: Hypr
     ms = C.c_double(0)
     check(_lib.init().elag_hip_time_kernel(A.h, smoother.h if smoother else None, kid, int(reps), px, py, C.byref(ms)))
     return ms.value
+
+
+# ---- agglomerate index maps (host-side integer logic of the library; no GPU needed) ------------------------------
+
+def partition_refined(n_elements: int, n_parts: int, ndim: int = 3, legacy_numbering: bool = False):
+    """MFEMRefinedMeshPartitioner::Partition (src/partitioning/MFEMRefinedMeshPartitioner.cpp:50-95)."""
+    p = np.empty(n_elements, np.int32)
+    check(_lib.load().elag_hip_partition_refined(n_elements, n_parts, ndim, int(legacy_numbering), _np_ptr(p)))
+    return p
+
+
+def connected_components(partitioning, conn):
+    """connectedComponents (src/structures/connectedComponents.cpp:23-85) -> (number of components, new partitioning)."""
+    conn = sp.csr_matrix(conn)
+    p = np.ascontiguousarray(partitioning, dtype=np.int32).copy()
+    I = np.ascontiguousarray(conn.indptr, dtype=np.int32); J = np.ascontiguousarray(conn.indices, dtype=np.int32)
+    n = C.c_int(0)
+    check(_lib.load().elag_hip_connected_components(len(p), _np_ptr(p), _np_ptr(I), _np_ptr(J), C.byref(n)))
+    return n.value, p
+
+
+def transpose_partitioning(partitioning, n_parts: int):
+    """transposePartitioning (src/structures/transpose.cpp:27-55) -> (i, j) of the part -> elements table."""
+    p = np.ascontiguousarray(partitioning, dtype=np.int32)
+    I = np.empty(n_parts + 1, np.int32); J = np.empty(int((p >= 0).sum()), np.int32)
+    check(_lib.load().elag_hip_transpose_partitioning(len(p), _np_ptr(p), n_parts, _np_ptr(I), _np_ptr(J)))
+    return I, J

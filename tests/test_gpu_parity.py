@@ -482,3 +482,65 @@ def test_hdiv_hiptmair_vcycle_matches_oracle(la, hdiv_k2, use_graph):
     xd, it_d, hist_d = pcg(A, H.Mult, np.full(A.shape[0], 2.0), rtol=1e-8)
     xo, it_o, hist_o = pcg(A, Hc.apply, np.full(A.shape[0], 2.0), rtol=1e-8)
     assert it_d == it_o and abs(hist_d[-1] - hist_o[-1]) <= 1e-10 * hist_o[0]
+
+
+# ---- operator hand-off from amge -----------------------------------------------------------------
+
+def test_operator_handoff_triple_products(la, h1_k1):
+    """spA = mfem::RAP(D, M, D) (examples/MultigridTest0Form.cpp:450-454) and the mass operator R^T M_e R are sparse
+    triple products with +-1 matrices: the device RAP reproduces them and the P1 stiffness they define."""
+    _, _, seq = h1_k1
+    m = seq.meshes[0]
+    D0, M1 = orc.csr(m.D0()), orc.csr(m.M1())
+    dD0, dM1 = la.ParallelCSRMatrix.from_scipy(D0), la.ParallelCSRMatrix.from_scipy(M1)
+    spA = la.RAP(dD0, dM1, dD0).to_scipy()
+    same_matrix(spA, orc.mfem_rap(D0, M1, D0), tol=1e-12)
+    K = m.M0_P1_stiffness()
+    assert abs(spA - K).max() < 1e-13
+    # D_{j+1} D_j = 0 with the four hypreExtension norms < 1e-12 (testsuite/topology.cpp:109-116)
+    dD1 = la.ParallelCSRMatrix.from_scipy(orc.csr(m.D1()))
+    Z = dD1.matmul(dD0)
+    for kind in ("l1", "linf", "max", "frobenius"):
+        assert Z.norm(kind) < 1e-12
+    # D_f P_j = P_{j+1} D_c (DeRhamSequence.cpp:753-800) through device products and Compare
+    from parelag_amd import meshgen as mg
+    c = seq.meshes[1]
+    P0, P1 = (la.ParallelCSRMatrix.from_scipy(orc.csr(X)) for X in (mg.interp_P0(c, m), mg.interp_P1(c, m)))
+    lhs = dD0.matmul(P0)
+    rhs = P1.matmul(la.ParallelCSRMatrix.from_scipy(orc.csr(c.D0())))
+    diff = la.Add(1.0, lhs, -1.0, rhs)
+    assert diff.norm("max") < 1e-12
+
+
+# ---- integer / pattern helpers of src/hypreExtension ---------------------------------------------------------------
+
+def test_boolint_matvec_and_keep_equal_entries(la):
+    A = rand_csr(500, 400, 0.03, 41, empty_rows=True)
+    M = la.ParallelCSRMatrix.from_scipy(A)
+    rng = np.random.default_rng(42)
+    x = rng.integers(-5, 6, 400).astype(np.int32)
+    for alpha, beta in ((1, 0), (2, 4), (-1, 1), (0, 3)):
+        y0 = rng.integers(-9, 10, 500).astype(np.int32)
+        y, yr = y0.copy(), y0.copy()
+        M.MultBoolInt(x, y, alpha, beta)
+        orc.csr_matvec_boolint(A, alpha, x, beta, yr)
+        assert np.array_equal(y, yr)                          # integer work: bit-exact
+    # through the halo path (self-neighbour): pattern(diag) x + pattern(offd) x[send_elmts]
+    part, elm = self_coupled_part(300, 40, 5)
+    P = la.ParallelCSRMatrix.from_parts(part)
+    xi = rng.integers(-3, 4, 300).astype(np.int32)
+    y = np.zeros(300, np.int32)
+    P.MultBoolInt(xi, y)
+    Db, Ob = part["diag"].copy(), part["offd"].copy(); Db.data[:] = 1; Ob.data[:] = 1
+    assert np.array_equal(y, (Db @ xi + Ob @ xi[elm]).astype(np.int32))
+    # KeepEqualEntries: equal entries -> 1, different ones dropped
+    B = A.copy()
+    flip = rng.random(B.nnz) < 0.3
+    B.data[flip] += 0.5
+    dA, dB = la.ParallelCSRMatrix.from_scipy(A), la.ParallelCSRMatrix.from_scipy(B)
+    dA.keep_equal_entries(dB)
+    ref = A.copy(); ref.data = np.where(flip, 0.0, 1.0); ref = orc.delete_zeros(ref, 1e-9)
+    same_matrix(dA.to_scipy(), ref, tol=0.0)
+    from parelag_amd._lib import ElagHipError
+    with pytest.raises(ElagHipError):
+        dA.keep_equal_entries(dB)                             # patterns differ now

@@ -1,0 +1,76 @@
+"""Agglomerate index maps of the product (host-side C++ in libelag_hip.so) against the oracle's restatement of the
+reference routines: BIT-EXACT.  Runs on CPU."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import oracle as orc
+from parelag_amd import linalg as la, meshgen
+
+
+@pytest.mark.parametrize("n,parts,dim", [(64, 8, 3), (4096, 8, 3), (233472, 29184, 3), (256, 16, 2), (1024, 64, 1)])
+def test_partition_refined_both_numberings(n, parts, dim):
+    assert np.array_equal(la.partition_refined(n, parts, dim), orc.partition_refined(n, parts))
+    if (n // parts) % (1 << dim) == 0:
+        a, b = la.partition_refined(n, parts, dim, legacy_numbering=True), orc.partition_refined_legacy(n, parts, dim)
+        assert np.array_equal(a, b)
+        assert np.array_equal(np.bincount(a), np.full(parts, n // parts))
+
+
+def test_partition_matches_the_refinement_numbering():
+    """children of tet i are 8i..8i+7 in the generator, so p[j] = j/8 is the parent map of every level"""
+    seq = meshgen.Sequence.cube456(2)
+    for l in range(2):
+        fine, coarse = seq.meshes[l], seq.meshes[l + 1]
+        p = la.partition_refined(fine.nt, coarse.nt)
+        assert np.array_equal(p, seq.partition(l))
+        # every child lies inside its parent: child vertices are parent vertices or midpoints of parent edges
+        pv = set(map(int, coarse.tets[p[123]]))
+        cv = [int(v) for v in fine.tets[123] if v < coarse.nv]
+        assert set(cv) <= pv
+
+
+def tet_adjacency(mesh):
+    mesh.build_faces()
+    T = mesh.nt
+    ef = sp.csr_matrix((np.ones(4 * T), (np.repeat(np.arange(T), 4), mesh.tet_faces.reshape(-1))), shape=(T, mesh.nf))
+    A = (ef @ ef.T).tocsr()
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_connected_components_bit_exact(seed):
+    seq = meshgen.Sequence.cube456(1)
+    conn = tet_adjacency(seq.meshes[0])
+    rng = np.random.default_rng(seed)
+    # random partition with many disconnected pieces, plus the derefinement partition (connected agglomerates)
+    for part in (rng.integers(0, 40, conn.shape[0]).astype(np.int32), la.partition_refined(conn.shape[0], conn.shape[0] // 8)):
+        n_ref, p_ref = orc.connected_components(part, conn)
+        n_dev, p_dev = la.connected_components(part, conn)
+        assert n_dev == n_ref
+        assert np.array_equal(p_dev, p_ref)
+    # the derefinement agglomerates are connected: nothing changes
+    part = la.partition_refined(conn.shape[0], conn.shape[0] // 8)
+    n, p = la.connected_components(part, conn)
+    assert n == conn.shape[0] // 8 and np.array_equal(p, part)
+
+
+def test_transpose_partitioning_bit_exact():
+    rng = np.random.default_rng(3)
+    part = rng.integers(-1, 17, 5000).astype(np.int32)
+    I, J = la.transpose_partitioning(part, 17)
+    Ir, Jr = orc.transpose_partitioning(part, 17)
+    assert np.array_equal(I, Ir) and np.array_equal(J, Jr)
+    # AEntity_entity of the derefinement partition: agglomerate i holds elements 8i..8i+7 (Topology.cpp:693-725)
+    p = la.partition_refined(3648, 456)
+    I, J = la.transpose_partitioning(p, 456)
+    assert np.array_equal(I, 8 * np.arange(457)) and np.array_equal(J, np.arange(3648))
+
+
+def test_bad_arguments():
+    from parelag_amd._lib import ElagHipError
+    with pytest.raises(ElagHipError):
+        la.partition_refined(10, 3)
+    with pytest.raises(ElagHipError):
+        la.connected_components(np.array([0, -1], np.int32), sp.eye(2, format="csr"))
