@@ -155,11 +155,13 @@ void comm_allreduce_scalar(double *value, int op)
 {
     if (!comm_active()) return;
     Context &x = ctx();
-    x.h_scalar[8] = *value;
-    ELAG_HIP_CHECK(hipMemcpyAsync(x.d_scalar + 8, x.h_scalar + 8, sizeof(double), hipMemcpyHostToDevice, x.stream));
-    comm_allreduce_device(x.d_scalar + 8, 1, op, x.stream);
-    ELAG_HIP_CHECK(hipMemcpyAsync(x.h_scalar + 8, x.d_scalar + 8, sizeof(double), hipMemcpyDeviceToHost, x.stream));
+    // setup-time scalar: drain the compute stream, then run on the comm stream like every other RCCL call
     ELAG_HIP_CHECK(hipStreamSynchronize(x.stream));
+    x.h_scalar[8] = *value;
+    ELAG_HIP_CHECK(hipMemcpyAsync(x.d_scalar + 8, x.h_scalar + 8, sizeof(double), hipMemcpyHostToDevice, x.comm_stream));
+    comm_allreduce_device(x.d_scalar + 8, 1, op, x.comm_stream);
+    ELAG_HIP_CHECK(hipMemcpyAsync(x.h_scalar + 8, x.d_scalar + 8, sizeof(double), hipMemcpyDeviceToHost, x.comm_stream));
+    ELAG_HIP_CHECK(hipStreamSynchronize(x.comm_stream));
     *value = x.h_scalar[8];
 }
 

@@ -179,19 +179,24 @@ int elag_hip_parcsr_spmv_boolint(elag_hip_parcsr_t A, int alpha, const int *x, i
             dx = tx; dy = ty;
         }
         int *ghost = nullptr, *sbuf = nullptr;
-        const bool halo = A->offd.ncols > 0;
+        const bool halo = A->needs_exchange();
         if (halo) {
             ghost = dev_alloc<int>((size_t)A->offd.ncols);
             const int stn = A->send_total();
             sbuf = dev_alloc<int>((size_t)stn);
             if (stn) hipLaunchKernelGGL(gather_int_kernel, dim3((unsigned)std::min((stn + 255) / 256, 1024)), dim3(256), 0, st, stn,
                                         (const int *)A->d_send_elmts, dx, sbuf);
+            Context &c = ctx();
+            ELAG_HIP_CHECK(hipEventRecord(c.ev_pack, st));
+            ELAG_HIP_CHECK(hipStreamWaitEvent(c.comm_stream, c.ev_pack, 0));
             comm_neighbor_exchange(sbuf, (int)A->send_procs.size(), A->send_procs.data(), A->send_starts.data(), ghost,
-                                   (int)A->recv_procs.size(), A->recv_procs.data(), A->recv_starts.data(), sizeof(int), st);
+                                   (int)A->recv_procs.size(), A->recv_procs.data(), A->recv_starts.data(), sizeof(int), c.comm_stream);
+            ELAG_HIP_CHECK(hipEventRecord(c.ev_halo, c.comm_stream));
+            ELAG_HIP_CHECK(hipStreamWaitEvent(st, c.ev_halo, 0));
         }
         if (n)
             hipLaunchKernelGGL(boolint_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (const int *)A->diag.I,
-                               (const int *)A->diag.J, halo ? (const int *)A->offd.I : nullptr, halo ? (const int *)A->offd.J : nullptr, dx,
+                               (const int *)A->diag.J, A->offd.ncols > 0 ? (const int *)A->offd.I : nullptr, A->offd.ncols > 0 ? (const int *)A->offd.J : nullptr, dx,
                                (const int *)ghost, alpha, beta, dy);
         ELAG_LAUNCH_CHECK();
         if (loc == ELAG_HIP_HOST && n) ELAG_HIP_CHECK(hipMemcpyAsync(y, ty, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));

@@ -78,7 +78,7 @@ __global__ void gather_scaled_kernel(int n, const int *__restrict__ idx, const d
 void par_spmv(ParCSR &A, k::SpmvArgs a)
 {
     Context &c = ctx();
-    if (!A.has_halo()) {
+    if (!A.needs_exchange()) {
         a.xg = nullptr; a.csg = nullptr; a.rows = nullptr; a.skip_rows_with_offd = 0;
         k::spmv_fused(A.diag, nullptr, a, c.stream);
         return;
@@ -142,12 +142,14 @@ void par_spmvT(ParCSR &A, double alpha, const double *x, double beta, double *y)
 {
     Context &c = ctx();
     A.ensure_transpose();
-    const bool halo = A.offd.ncols > 0;
+    const bool halo = A.needs_exchange();
     if (halo) {
         // y_ghost = offd^T x, then the reverse exchange (roles of the send/recv lists swapped)
-        k::SpmvArgs g;
-        g.x = x; g.alpha = 1.0; g.out = A.d_rev_send;
-        k::spmv_fused(*A.offdT, nullptr, g, c.stream);
+        if (A.offd.ncols > 0) {
+            k::SpmvArgs g;
+            g.x = x; g.alpha = 1.0; g.out = A.d_rev_send;
+            k::spmv_fused(*A.offdT, nullptr, g, c.stream);
+        }
         reverse_halo_start(A);
     }
     k::SpmvArgs d;

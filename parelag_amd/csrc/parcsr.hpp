@@ -31,7 +31,9 @@ struct elag_hip_parcsr_s {
     int ncols() const { return diag.ncols; }
     int ncols_offd() const { return offd.ncols; }
     int send_total() const { return send_starts.empty() ? 0 : send_starts.back(); }
-    bool has_halo() const { return offd.ncols > 0 && offd.nnz > 0; }
+    // a rank takes part in the exchange if it has ghosts OR a neighbour needs its values (the two can differ for
+    // rectangular operators such as P)
+    bool needs_exchange() const { return offd.ncols > 0 || send_total() > 0; }
 
     void finish_setup();      // device copies of the comm lists, boundary row list, buffers
     void ensure_transpose();  // diagT / offdT / scatT

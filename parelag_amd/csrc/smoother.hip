@@ -339,7 +339,13 @@ void elag_hip_coarse_s::apply(const double *rhs, double *sol)
 {
     using namespace elag;
     if (!replicated) { k::dense_gemv(n, n, Minv, rhs, sol); return; }
-    comm_allgatherv(rhs, full_rhs, counts.data(), displs.data(), ctx().stream);
+    // RCCL traffic always goes through the comm stream (one communicator, one stream): fork/join with events
+    Context &c = ctx();
+    ELAG_HIP_CHECK(hipEventRecord(c.ev_pack, c.stream));
+    ELAG_HIP_CHECK(hipStreamWaitEvent(c.comm_stream, c.ev_pack, 0));
+    comm_allgatherv(rhs, full_rhs, counts.data(), displs.data(), c.comm_stream);
+    ELAG_HIP_CHECK(hipEventRecord(c.ev_halo, c.comm_stream));
+    ELAG_HIP_CHECK(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
     k::dense_gemv(nloc, n, Minv + (size_t)my0 * n, full_rhs, sol);
 }
 
