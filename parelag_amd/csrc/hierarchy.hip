@@ -45,6 +45,10 @@ struct elag_hip_hierarchy_s {
     std::vector<elag_hip_smoother_s *> owned_smoothers;
     elag_hip_coarse_s *owned_coarse = nullptr;
     double *r0 = nullptr, *e0 = nullptr;  // solver-mode residual / correction on level 0
+    // dense coarse-cycle operator: every level from dense_level down is replaced by ONE dense matrix B (the sub-cycle
+    // is a linear map; B's columns are its images of the unit vectors, computed once in finalize), applied as a GEMV
+    int dense_level = -1;
+    double *Bdense = nullptr;
     // internal renumbering (elag_hip_amge_options::reorder): order[l][new] = old
     bool reordered = false;
     ParCSR *A_user = nullptr;             // level-0 operator in the caller's numbering (solver-mode residual)
@@ -56,7 +60,7 @@ struct elag_hip_hierarchy_s {
     {
         for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);
         for (auto &l : lev) { dev_free(l.resid); dev_free(l.sol); dev_free(l.alt); dev_free(l.tmp_resid); }
-        dev_free(r0); dev_free(e0); dev_free(d_order0); dev_free(p_rhs); dev_free(p_sol);
+        dev_free(r0); dev_free(e0); dev_free(d_order0); dev_free(p_rhs); dev_free(p_sol); dev_free(Bdense);
         for (auto *s : owned_smoothers) delete s;
         delete owned_coarse;
         for (auto *m : owned_mats) delete m;
@@ -93,8 +97,41 @@ struct elag_hip_hierarchy_s {
         graphs.clear();
         use_graph = graph && ctx().nranks == 1;
         plan_fused();
+        plan_dense_tail();
         finalized = true;
         ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    }
+
+    void plan_dense_tail()
+    {
+        dense_level = -1;
+        dev_free(Bdense);
+        static int max_n = -1;
+        if (max_n < 0) { const char *e = getenv("ELAG_HIP_DENSE_TAIL_N"); max_n = e ? atoi(e) : 1024; }
+        const int nl = (int)lev.size();
+        if (ctx().nranks != 1 || nl < 3 || max_n <= 0) return;
+        int L = -1;
+        for (int l = 1; l < nl - 1; l++)   // the coarsest level alone is already a single dense product
+            if (lev[(size_t)l].A->nrows() <= max_n && lev[(size_t)l].A->offd.ncols == 0) { L = l; break; }
+        if (L < 0) return;
+        const int n = lev[(size_t)L].A->nrows();
+        if (n == 0) return;
+        hipStream_t st = ctx().stream;
+        // column j of B = sub-cycle applied to e_j; stored transposed first (one contiguous row per application)
+        double *Bt = dev_alloc<double>((size_t)n * n);
+        Temp<double> ej((size_t)n);
+        ELAG_HIP_CHECK(hipMemsetAsync(ej, 0, sizeof(double) * (size_t)n, st));
+        const double one = 1.0, zero = 0.0;
+        for (int j = 0; j < n; j++) {
+            ELAG_HIP_CHECK(hipMemcpyAsync(ej.p + j, &one, sizeof(double), hipMemcpyHostToDevice, st));
+            iterate(L, ej, Bt + (size_t)j * n, lev[(size_t)L].alt);
+            ELAG_HIP_CHECK(hipMemcpyAsync(ej.p + j, &zero, sizeof(double), hipMemcpyHostToDevice, st));
+        }
+        Bdense = dev_alloc<double>((size_t)n * n);
+        k::dense_transpose(n, Bt, Bdense);
+        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        dev_free(Bt);
+        dense_level = L;
     }
 
     void plan_fused()
@@ -146,6 +183,7 @@ struct elag_hip_hierarchy_s {
     {
         Level &F = lev[(size_t)l];
         const int nl = (int)lev.size();
+        if (l == dense_level) { k::dense_gemv(F.A->nrows(), F.A->nrows(), Bdense, rhs, sol); return; }
         if (l == nl - 1) {
             if (coarse) { coarse->apply(rhs, sol); return; }
             // no coarse solver: pre- then post-smoother (:160-172)

@@ -72,6 +72,7 @@ void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_col
 
 // ---- dense coarse solve ------------------------------------------------------------------------
 void dense_gemv(int nrows, int ncols, const double *M, const double *x, double *y);  // y = M x, M row-major
+void dense_transpose(int n, const double *in, double *out);                           // out = in^T (n x n)
 
 }  // namespace k
 }  // namespace elag

@@ -744,6 +744,31 @@ __global__ __launch_bounds__(kBlock) void dense_gemv_kernel(int nrows, int n, co
 }
 }  // namespace
 
+namespace {
+__global__ void dense_transpose_kernel(int n, const double *__restrict__ in, double *__restrict__ out)
+{
+    __shared__ double tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int i = by + r, j = bx + threadIdx.x;
+        if (i < n && j < n) tile[r][threadIdx.x] = in[(size_t)i * n + j];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int i = bx + r, j = by + threadIdx.x;
+        if (i < n && j < n) out[(size_t)i * n + j] = tile[threadIdx.x][r];
+    }
+}
+}  // namespace
+
+void dense_transpose(int n, const double *in, double *out)
+{
+    if (n == 0) return;
+    const unsigned g = (unsigned)((n + 31) / 32);
+    hipLaunchKernelGGL(dense_transpose_kernel, dim3(g, g), dim3(32, 8), 0, ctx().stream, n, in, out);
+    ELAG_LAUNCH_CHECK();
+}
+
 void dense_gemv(int nrows, int ncols, const double *M, const double *x, double *y)
 {
     if (nrows == 0) return;
