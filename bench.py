@@ -227,6 +227,19 @@ def main():
         xd = sol.to_numpy()
         out["parity_rel_err_vs_oracle"] = float(np.max(np.abs(xd - xs)) / np.max(np.abs(xs)))
 
+    if not single:
+        # parity of the distributed cycle against the serial CPU oracle (every rank checks its own rows)
+        from oracle import oracle as orc
+        from tests.helpers import oracle_h1_hierarchy
+        h = oracle_h1_hierarchy(A, Ps, smoother=la.HYPRE_SMOOTHER_TYPES[args.smoother])
+        xs = np.empty(A.shape[0])
+        orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"]).apply(np.full(A.shape[0], 2.0), xs)
+        info = H._dist_info["levels"][0]
+        lo, hi = int(info["starts"][dist.rank]), int(info["starts"][dist.rank + 1])
+        ref = xs[info["order"]][lo:hi]
+        err = float(np.max(np.abs(sol.to_numpy() - ref)) / np.max(np.abs(xs)))
+        out["parity_rel_err_vs_oracle"] = dist.allreduce_max(err)
+
     if rank == 0:
         out.update({
             "metric": f"V-cycles/sec (MultigridTest{args.form}Form cube456, Hierarchy::Mult in preconditioner mode)",

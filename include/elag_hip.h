@@ -225,6 +225,13 @@ ELAG_HIP_API int elag_hip_coarse_create(elag_hip_coarse_t *out, elag_hip_parcsr_
  * inverse (SURVEY 8e "gather the coarsest levels onto every GPU").  row_starts has nranks+1 entries. */
 ELAG_HIP_API int elag_hip_coarse_create_replicated(elag_hip_coarse_t *out, elag_hip_parcsr_t A_global,
                                                    const int64_t *row_starts);
+/* A whole (rank-replicated) hierarchy as the coarse solver of a distributed one: every rank holds the same
+ * sub-hierarchy of the levels that are too small to be worth a halo exchange (SURVEY 8e "gather the coarsest levels onto
+ * every GPU").  With allreduce_rhs != 0 the right-hand side handed to apply() is this rank's partial sum of the
+ * restricted residual (P stored with global coarse columns) and is summed over the ranks with one RCCL all-reduce
+ * before the replicated cycle; the solution is complete on every rank, so the prolongation needs no exchange.
+ * A distributed V-cycle then costs three RCCL rounds (two halos on the fine level + this all-reduce). */
+ELAG_HIP_API int elag_hip_coarse_create_from_hierarchy(elag_hip_coarse_t *out, elag_hip_hierarchy_t sub, int allreduce_rhs);
 ELAG_HIP_API int elag_hip_coarse_apply(elag_hip_coarse_t C, const double *rhs, double *sol, int loc);
 ELAG_HIP_API int elag_hip_coarse_destroy(elag_hip_coarse_t C);
 

@@ -99,6 +99,7 @@ _SIGNATURES = {
     "elag_hip_smoother_destroy": [_p],
     "elag_hip_coarse_create": [C.POINTER(_p), _p, _i, _i],
     "elag_hip_coarse_create_replicated": [C.POINTER(_p), _p, _p],
+    "elag_hip_coarse_create_from_hierarchy": [C.POINTER(_p), _p, _i],
     "elag_hip_coarse_apply": [_p, _p, _p, _i],
     "elag_hip_coarse_destroy": [_p],
     "elag_hip_hierarchy_create": [C.POINTER(_p), _i],

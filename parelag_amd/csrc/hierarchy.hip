@@ -39,6 +39,7 @@ struct elag_hip_hierarchy_s {
     elag_hip_coarse_s *coarse = nullptr;
     bool finalized = false;
     bool use_graph = false;
+    bool all_local = true;
     std::vector<GraphEntry> graphs;
     // objects created by elag_hip_hierarchy_build (owned)
     std::vector<ParCSR *> owned_mats;
@@ -95,7 +96,14 @@ struct elag_hip_hierarchy_s {
         }
         for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);
         graphs.clear();
-        use_graph = graph && ctx().nranks == 1;
+        bool local_only = true;   // every operator rank-local (no halo): graphs / fusion are safe even across ranks
+        for (auto &L : lev) {
+            if (L.A && L.A->needs_exchange()) local_only = false;
+            if (L.P && L.P->needs_exchange()) local_only = false;
+        }
+        if (coarse && (coarse->replicated || coarse->custom_apply)) local_only = false;
+        all_local = local_only;
+        use_graph = graph && local_only;
         plan_fused();
         plan_dense_tail();
         finalized = true;
@@ -109,7 +117,7 @@ struct elag_hip_hierarchy_s {
         static int max_n = -1;
         if (max_n < 0) { const char *e = getenv("ELAG_HIP_DENSE_TAIL_N"); max_n = e ? atoi(e) : 1024; }
         const int nl = (int)lev.size();
-        if (ctx().nranks != 1 || nl < 3 || max_n <= 0) return;
+        if (!all_local || nl < 3 || max_n <= 0) return;
         int L = -1;
         for (int l = 1; l < nl - 1; l++)   // the coarsest level alone is already a single dense product
             if (lev[(size_t)l].A->nrows() <= max_n && lev[(size_t)l].A->offd.ncols == 0) { L = l; break; }
@@ -149,7 +157,7 @@ struct elag_hip_hierarchy_s {
             F.G.reset(); F.S.reset(); F.fused_dinv = nullptr;
             const RelaxSmoother *j = dynamic_cast<const RelaxSmoother *>(F.pre);
             const RelaxSmoother *jp = dynamic_cast<const RelaxSmoother *>(F.post);
-            if (disabled || ctx().nranks != 1 || !j || !jp || !j->dinv || j->sweeps != 1 || jp->sweeps != 1 || j->A != F.A || jp->A != F.A ||
+            if (disabled || !all_local || !j || !jp || !j->dinv || j->sweeps != 1 || jp->sweeps != 1 || j->A != F.A || jp->A != F.A ||
                 j->type != jp->type || j->weight != jp->weight)
                 continue;
             if (F.A->offd.ncols > 0 || C.P->offd.ncols > 0 || F.A->diag.nnz >= max_nnz) continue;
@@ -387,6 +395,38 @@ int elag_hip_hierarchy_apply(elag_hip_hierarchy_t H, const double *rhs, double *
     });
 }
 
+int elag_hip_coarse_create_from_hierarchy(elag_hip_coarse_t *out, elag_hip_hierarchy_t sub, int allreduce_rhs)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(out && sub, "null argument");
+        ELAG_REQUIRE(sub->finalized, "the sub-hierarchy must be finalised first");
+        std::unique_ptr<elag_hip_coarse_s> C(new elag_hip_coarse_s());
+        C->A = sub->reordered ? sub->A_user : sub->lev[0].A;
+        C->n = C->A->nrows();
+        C->kind = 2;
+        const int n = C->n;
+        double *buf = dev_alloc<double>((size_t)n);   // owned through full_rhs
+        C->full_rhs = buf;
+        C->custom_apply = [sub, buf, n, allreduce_rhs](const double *rhs, double *sol) {
+            Context &c = ctx();
+            const double *src = rhs;
+            if (allreduce_rhs && comm_active()) {
+                // sum the ranks' partial restricted residuals: one collective on the comm stream, fork/join by events
+                ELAG_HIP_CHECK(hipMemcpyAsync(buf, rhs, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, c.stream));
+                ELAG_HIP_CHECK(hipEventRecord(c.ev_pack, c.stream));
+                ELAG_HIP_CHECK(hipStreamWaitEvent(c.comm_stream, c.ev_pack, 0));
+                comm_allreduce_device(buf, n, 0, c.comm_stream);
+                ELAG_HIP_CHECK(hipEventRecord(c.ev_halo, c.comm_stream));
+                ELAG_HIP_CHECK(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
+                src = buf;
+            }
+            sub->apply_device(src, sol, true);
+        };
+        *out = C.release();
+    });
+}
+
 int elag_hip_hierarchy_destroy(elag_hip_hierarchy_t H)
 {
     return guarded([&] {
@@ -501,7 +541,7 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
         }
 
         // ---- optional internal renumbering for gather locality -------------------------------------
-        const bool reorder = ctx().nranks == 1 && A->offd.ncols == 0 && D == nullptr &&
+        const bool reorder = !A->needs_exchange() && A->global_rows == A->nrows() && D == nullptr &&
                              (opt.reorder > 0 || (opt.reorder < 0 && A->nrows() >= (1 << 18)));
         if (reorder) {
             const int nl = num_P + 1;

@@ -131,8 +131,11 @@ void RelaxSmoother::estimate_eigs()
     int max_iter = 10;
     if (A->global_rows < max_iter) max_iter = (int)A->global_rows;
     if (max_iter == 0) { max_eig = min_eig = 0.0; return; }
+    // a matrix whose local rows are all its rows is serial (or replicated on every rank): serial semantics, so that
+    // replicated smoothers are identical on all ranks
+    const bool distributed = A->needs_exchange() || A->global_rows != A->nrows();
     Temp<double> rv((size_t)nn), p((size_t)nn), s((size_t)nn);
-    k::vec_hypre_random(nn, 1 * (c.rank + 1), rv);
+    k::vec_hypre_random(nn, distributed ? 1 * (c.rank + 1) : 1, rv);
     std::vector<double> tri((size_t)max_iter + 1, 0.0), off((size_t)max_iter + 1, 0.0);
     double gamma = 1.0, beta = 1.0;
     int i = 0;
@@ -140,7 +143,7 @@ void RelaxSmoother::estimate_eigs()
         const double gamma_old = gamma;
         k::vec_dot(nn, rv, rv, c.d_scalar);
         gamma = read_scalar(c.d_scalar);
-        comm_allreduce_scalar(&gamma, 0);
+        if (distributed) comm_allreduce_scalar(&gamma, 0);
         if (i == 0) {
             beta = 1.0;
             ELAG_HIP_CHECK(hipMemcpyAsync(p, rv, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, c.stream));
@@ -153,7 +156,7 @@ void RelaxSmoother::estimate_eigs()
         par_spmv(*A, a);
         k::vec_dot(nn, s, p, c.d_scalar);
         double sdotp = read_scalar(c.d_scalar);
-        comm_allreduce_scalar(&sdotp, 0);
+        if (distributed) comm_allreduce_scalar(&sdotp, 0);
         const double alpha = gamma / sdotp;
         const double alphainv = 1.0 / alpha;
         tri[(size_t)i + 1] = alphainv;
@@ -281,7 +284,7 @@ void elag_hip_coarse_s::setup()
 {
     using namespace elag;
     ELAG_REQUIRE(kind == 0, "coarse solver kind %d is not implemented (0 = dense Cholesky)", kind);
-    ELAG_REQUIRE(A->offd.ncols == 0 && (ctx().nranks == 1 || replicated),
+    ELAG_REQUIRE(!A->needs_exchange() && (A->global_rows == A->nrows() || replicated),
                  "dense coarse solve expects a rank-local operator (use elag_hip_coarse_create_replicated across ranks)");
     n = A->nrows();
     ELAG_REQUIRE(n == A->ncols(), "coarse operator must be square");
@@ -338,6 +341,7 @@ void elag_hip_coarse_s::setup()
 void elag_hip_coarse_s::apply(const double *rhs, double *sol)
 {
     using namespace elag;
+    if (custom_apply) { custom_apply(rhs, sol); return; }
     if (!replicated) { k::dense_gemv(n, n, Minv, rhs, sol); return; }
     // RCCL traffic always goes through the comm stream (one communicator, one stream): fork/join with events
     Context &c = ctx();
@@ -469,6 +473,7 @@ int elag_hip_coarse_apply(elag_hip_coarse_t C, const double *rhs, double *sol, i
         ELAG_REQUIRE(C && rhs && sol, "null argument");
         check_loc(loc);
         const size_t nv = (size_t)(C->replicated ? C->nloc : C->n);
+        ELAG_REQUIRE(!C->custom_apply || loc == ELAG_HIP_DEVICE, "a hierarchy-backed coarse solver takes device vectors");
         VecIn f(rhs, nv, loc);
         VecInOut u(sol, nv, loc, false);
         C->apply(f.d, u.d);

@@ -2,6 +2,8 @@
 // dense coarse solver.  Internally smoothers work on a ping-pong pair of device vectors so that the
 // Jacobi update never needs an extra copy pass.
 #pragma once
+#include <functional>
+
 #include "parcsr.hpp"
 
 struct elag_hip_smoother_s {
@@ -55,6 +57,8 @@ struct elag_hip_coarse_s {
     int nloc = 0, my0 = 0;
     std::vector<int> counts, displs;
     double *full_rhs = nullptr;
+    // sub-hierarchy mode (elag_hip_coarse_create_from_hierarchy): apply() = [all-reduce rhs] + replicated cycle
+    std::function<void(const double *, double *)> custom_apply;
     ~elag_hip_coarse_s() { elag::dev_free(Minv); elag::dev_free(full_rhs); }
     void setup();
     void apply(const double *rhs, double *sol);

@@ -65,34 +65,48 @@ def init(rank: int, world: int) -> Dist:
     return Dist(rank, world, td)
 
 
-def build_hierarchy(dist: Dist, A, Ps, seq, smoother="L1 Jacobi", params=None):
-    """Distributed 0-form hierarchy: every level row-partitioned over the ranks (halo exchange per operator apply),
-    coarsest level solved redundantly on every GPU after an all-gather.  Returns (H, n_local, global level shapes,
-    setup seconds)."""
+def build_hierarchy(dist: Dist, A, Ps, seq, smoother="L1 Jacobi", params=None, replicate_from=1):
+    """Distributed 0-form hierarchy.  Levels < ``replicate_from`` are row-partitioned over the ranks (halo exchange per
+    operator apply, hypre's ParCSR model); the levels from ``replicate_from`` down are far too small to be worth a halo
+    exchange and live, complete, on every GPU as an ordinary single-GPU hierarchy (fused levels, dense tail, hipGraph).
+    The restriction into the first replicated level produces per-rank partial sums (its P is stored with global coarse
+    columns) that one RCCL all-reduce completes, and the prolongation back needs no exchange at all -- with
+    ``replicate_from = 1`` a V-cycle costs three RCCL rounds.  Returns (H, n_local, global level shapes, setup s)."""
+    import scipy.sparse as sp
     t0 = time.time()
     d = partition.distributed_h1_hierarchy(A, Ps, seq, dist.world)
     nl = len(d["levels"])
+    R = max(1, min(int(replicate_from), nl - 1))
     t = la.HYPRE_SMOOTHER_TYPES[smoother] if isinstance(smoother, str) else int(smoother)
-    H = la.Hierarchy(nl)
+    lib = _lib.init()
+    # replicated tail: levels R..nl-1 in block numbering, built redundantly on every GPU (device RAP, FixZeroRows)
+    subA = la.ParallelCSRMatrix.from_scipy(d["A_global"][R])
+    subP = [la.ParallelCSRMatrix.from_scipy(P) for P in d["P_global"][R:]]
+    Hsub = la.buildHierarchyFromDeRhamSequence(subA, subP, smoother, params or {}, reorder=0)
+    hc = C.c_void_p()
+    _lib.check(lib.elag_hip_coarse_create_from_hierarchy(C.byref(hc), Hsub.h, 1))
+    cs = la.CoarseSolver.__new__(la.CoarseSolver)
+    cs._lib, cs.A, cs.h, cs.iterative_mode = lib, subA, hc, False
+    # distributed head: levels 0..R-1 plus level R as the "coarsest" level of the outer hierarchy
+    H = la.Hierarchy(R + 1)
     ops = []
-    for l, lev in enumerate(d["levels"]):
+    for l in range(R):
+        lev = d["levels"][l]
         Al = la.ParallelCSRMatrix.from_parts(lev["A_parts"][dist.rank])
         ops.append(Al)
         H.SetOperator(l, Al)
         if l > 0:
             H.SetProlongator(l, la.ParallelCSRMatrix.from_parts(lev["P_parts"][dist.rank]))
-        if l < nl - 1:
-            S = la.HypreSmootherWrapper(Al, t, params or {})
-            H.SetSmoothers(l, S, S)
-    Ac = la.ParallelCSRMatrix.from_scipy(d["A_global"][-1])
-    starts = np.ascontiguousarray(d["levels"][-1]["starts"], dtype=np.int64)
-    lib = _lib.init()
-    h = C.c_void_p()
-    _lib.check(lib.elag_hip_coarse_create_replicated(C.byref(h), Ac.h, starts.ctypes.data_as(C.c_void_p)))
-    cs = la.CoarseSolver.__new__(la.CoarseSolver)
-    cs._lib, cs.A, cs.h, cs.iterative_mode = lib, Ac, h, False
+        S = la.HypreSmootherWrapper(Al, t, params or {})
+        H.SetSmoothers(l, S, S)
+    H.SetOperator(R, subA)
+    # P from the first replicated level: this rank's rows, GLOBAL coarse columns, no comm package
+    s = d["levels"][R - 1]["starts"]
+    Ploc = sp.csr_matrix(d["P_global"][R - 1])[int(s[dist.rank]):int(s[dist.rank + 1])].tocsr()
+    H.SetProlongator(R, la.ParallelCSRMatrix.from_scipy(Ploc))
     H.SetCoarseSolver(cs)
     H.Finalize(use_graph=False)
+    H._keep += [Hsub, subA, *subP]
     la.synchronize()
     shapes = []
     for l in range(nl):

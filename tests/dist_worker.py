@@ -80,6 +80,29 @@ def main():
     err = np.max(np.abs(x_loc - ref)) / np.max(np.abs(xs))
     assert err < 1e-11, f"distributed V-cycle differs from the serial one: {err}"
 
+    # --- the layout bench.py uses across GPUs: level 0 distributed, levels >= 1 replicated on every rank; the restriction
+    #     produces per-rank partial sums (P with global coarse columns) completed by ONE all-reduce, the prolongation
+    #     needs no exchange
+    import scipy.sparse as sp
+    import torch
+    Pg0 = sp.csr_matrix(d["P_global"][0])
+    Ploc = orc.csr(Pg0[s0[rank]:s0[rank + 1]])
+    hsub = oracle_h1_hierarchy(d["A_global"][1], d["P_global"][1:])
+    Hsub = orc.CHierarchy(hsub["As"], hsub["Ps"], hsub["sms"], hsub["chol"])
+
+    def replicated_coarse(rhs_partial, sol):
+        t = torch.from_numpy(np.ascontiguousarray(rhs_partial).copy())
+        td.all_reduce(t)                       # sum of the ranks' partial restricted residuals
+        Hsub.apply(t.numpy(), sol)
+    A0 = levels[0]["A"]
+    lev2 = [dict(A=A0, P=None, pre=orc.OSmoother(A0, type=1), post=orc.OSmoother(A0, type=1)),
+            dict(A=orc.OParCSR(orc.csr(sp.csr_matrix((Pg0.shape[1], Pg0.shape[1])))), P=orc.OParCSR(Ploc), coarse=replicated_coarse)]
+    H2 = orc.OHierarchy(lev2)
+    x2 = np.empty_like(x_loc)
+    H2.Mult(b[s0[rank]:s0[rank + 1]], x2)
+    err2 = np.max(np.abs(x2 - ref)) / np.max(np.abs(xs))
+    assert err2 < 1e-11, f"replicated-coarse layout differs from the serial cycle: {err2}"
+
     # Chebyshev eigen-estimate runs through the distributed dot products
     M0 = levels[0]["A"]
     mx, mn = orc.max_eig_estimate_cg(M0, 1, 10)
