@@ -149,16 +149,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
     }
 
     auto quad = [&](int k) {
-        int4v j4; double2v a01, a23;
-        if (VARIANT & 1) {
-            j4 = __builtin_nontemporal_load(reinterpret_cast<const int4v *>(J + k));
-            a01 = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(a + k));
-            a23 = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(a + k + 2));
-        } else {
-            j4 = *reinterpret_cast<const int4v *>(J + k);
-            a01 = *reinterpret_cast<const double2v *>(a + k);
-            a23 = *reinterpret_cast<const double2v *>(a + k + 2);
-        }
+        int4v j4 = *reinterpret_cast<const int4v *>(J + k);
+        const double2v a01 = *reinterpret_cast<const double2v *>(a + k);
+        const double2v a23 = *reinterpret_cast<const double2v *>(a + k + 2);
         if (VARIANT & 4) {  // DIAGNOSTIC ONLY (wrong results): coalesced x reads instead of the gather
             const int b = (k - kal) + r0;
             j4.x = min(b, nrows - 1) + 0 * j4.x; j4.y = min(b + 1, nrows - 1) + 0 * j4.y; j4.z = min(b + 2, nrows - 1) + 0 * j4.z; j4.w = min(b + 3, nrows - 1) + 0 * j4.w;
@@ -171,56 +164,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
         *reinterpret_cast<double2v *>(prod + (k - kal) + 2) = p23;
     };
 
-    if (VARIANT & 8) {
-        // lane-consecutive mapping: one gather instruction covers 64 consecutive entries (~4 rows), which touch
-        // ~1/3 fewer distinct cache lines than the stride-4 mapping of the 16-byte loads
-        constexpr int U = 8;
-        int jj[U]; double aa[U];
-        const int kb = kbeg + (int)threadIdx.x;
-#pragma unroll
-        for (int q = 0; q < U; q++) {
-            const int k = kb + q * kBlock;
-            const bool ok = k < kend;
-            jj[q] = ok ? J[k] : 0;
-            aa[q] = ok ? a[k] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < U; q++) {
-            const int k = kb + q * kBlock;
-            double xv = x[jj[q]];
-            if (HAS_CS) xv *= cs[jj[q]];
-            if (k < kend) prod[k - kal] = aa[q] * xv;
-        }
-        for (int k = kb + U * kBlock; k < kend; k += kBlock) {
-            double xv = x[J[k]];
-            if (HAS_CS) xv *= cs[J[k]];
-            prod[k - kal] = a[k] * xv;
-        }
-    } else if (VARIANT & 2) {
-        // first pass: two quads per lane with all six vector loads issued before the gathers
-        const int k0 = kal + (int)threadIdx.x * 4, k1 = k0 + kBlock * 4;
-        if (k1 < kend) {
-            const int4v ja = *reinterpret_cast<const int4v *>(J + k0), jb = *reinterpret_cast<const int4v *>(J + k1);
-            const double2v a0 = *reinterpret_cast<const double2v *>(a + k0), a1 = *reinterpret_cast<const double2v *>(a + k0 + 2);
-            const double2v b0 = *reinterpret_cast<const double2v *>(a + k1), b1 = *reinterpret_cast<const double2v *>(a + k1 + 2);
-            double xa0 = x[ja.x], xa1 = x[ja.y], xa2 = x[ja.z], xa3 = x[ja.w];
-            double xb0 = x[jb.x], xb1 = x[jb.y], xb2 = x[jb.z], xb3 = x[jb.w];
-            if (HAS_CS) {
-                xa0 *= cs[ja.x]; xa1 *= cs[ja.y]; xa2 *= cs[ja.z]; xa3 *= cs[ja.w];
-                xb0 *= cs[jb.x]; xb1 *= cs[jb.y]; xb2 *= cs[jb.z]; xb3 *= cs[jb.w];
-            }
-            double2v q;
-            q.x = a0.x * xa0; q.y = a0.y * xa1; *reinterpret_cast<double2v *>(prod + (k0 - kal)) = q;
-            q.x = a1.x * xa2; q.y = a1.y * xa3; *reinterpret_cast<double2v *>(prod + (k0 - kal) + 2) = q;
-            q.x = b0.x * xb0; q.y = b0.y * xb1; *reinterpret_cast<double2v *>(prod + (k1 - kal)) = q;
-            q.x = b1.x * xb2; q.y = b1.y * xb3; *reinterpret_cast<double2v *>(prod + (k1 - kal) + 2) = q;
-        } else if (k0 < kend) {
-            quad(k0);
-        }
-        for (int k = k0 + 2 * kBlock * 4; k < kend; k += kBlock * 4) quad(k);
-    } else {
-        for (int k = kal + (int)threadIdx.x * 4; k < kend; k += kBlock * 4) quad(k);
-    }
+    for (int k = kal + (int)threadIdx.x * 4; k < kend; k += kBlock * 4) quad(k);
     __syncthreads();
     if (has0 && !(p.skip_rows_with_offd && oI && oI[row0 + 1] > oI[row0])) {
         double sum = 0.0;
@@ -291,14 +235,10 @@ void launch_stream_v(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hip
 
 void launch_stream(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hipStream_t st)
 {
-    switch (stream_variant()) {
-    case 1: launch_stream_v<1>(A, offd, p, st); break;
-    case 2: launch_stream_v<2>(A, offd, p, st); break;
-    case 3: launch_stream_v<3>(A, offd, p, st); break;
-    case 4: launch_stream_v<4>(A, offd, p, st); break;
-    case 8: launch_stream_v<8>(A, offd, p, st); break;
-    default: launch_stream_v<0>(A, offd, p, st); break;
-    }
+    // ELAG_HIP_STREAM_VARIANT=4 selects a DIAGNOSTIC build of the kernel (coalesced x reads, wrong results) that
+    // prices the gather: 7.2 TB/s against 5.1-5.4 TB/s for the real kernel
+    if (stream_variant() == 4) launch_stream_v<4>(A, offd, p, st);
+    else launch_stream_v<0>(A, offd, p, st);
 }
 
 }  // namespace

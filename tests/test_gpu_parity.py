@@ -544,3 +544,85 @@ def test_boolint_matvec_and_keep_equal_entries(la):
     from parelag_amd._lib import ElagHipError
     with pytest.raises(ElagHipError):
         dA.keep_equal_entries(dB)                             # patterns differ now
+
+
+# ---- BASELINE.json full sizes (cube456 x3) -------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def h1_k3():
+    from parelag_amd import meshgen
+    return meshgen.h1_problem(3)
+
+
+def test_full_size_h1_hierarchy_operators_and_cycle(la, h1_k3):
+    """configs[1]: every Galerkin operator of the 42 309 -> 5 739 -> 840 -> 141 hierarchy against the oracle (pattern
+    bit-exact, values 1e-12), then the cycle itself, its symmetry (mg_utils::CheckSymmetric) and PCG parity."""
+    A, Ps, _ = h1_k3
+    assert A.shape[0] == 42309 and A.nnz == 607053
+    h = oracle_h1_hierarchy(A, Ps)
+    H = device_hierarchy(la, A, Ps, "L1 Jacobi", use_graph=True)
+    for l, n in enumerate((42309, 5739, 840, 141)):
+        op = H.GetOperator(l)
+        assert op.Height() == n
+        same_matrix(op.to_scipy(), h["As"][l])
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"])
+    n = A.shape[0]
+    b = np.full(n, 2.0)
+    x, xr = np.empty(n), np.empty(n)
+    H.Mult(b, x); Hc.apply(b, xr)
+    assert close(x, xr, tol=1e-11)
+    rng = np.random.default_rng(13)
+    v, w = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+    Mv, Mw = np.empty(n), np.empty(n)
+    H.Mult(v, Mv); H.Mult(w, Mw)
+    # the reference's absolute 1e-10 (MG_Utils.cpp:59-89) is meant for its small test operators; here w'Mv ~ 1e7
+    assert abs(w @ Mv - v @ Mw) < 1e-13 * abs(w @ Mv)
+    _, it_d, hist_d = pcg(A, H.Mult, b, rtol=1e-8)
+    _, it_o, hist_o = pcg(A, Hc.apply, b, rtol=1e-8)
+    assert it_d == it_o and abs(hist_d[-1] - hist_o[-1]) <= 1e-10 * hist_o[0]
+    # idempotence-type property at full size: the cycle is linear, M(a v + w) = a M v + M w
+    z = np.empty(n); H.Mult(3.0 * v + w, z)
+    assert close(z, 3.0 * Mv + Mw, tol=1e-11)
+
+
+def test_full_size_hdiv_hiptmair_cycle(la):
+    """configs[2]: H(div) 473 536 dofs / 3 275 200 nnz, Hiptmair(L1-Jacobi, L1-Jacobi), against the oracle."""
+    from parelag_amd import meshgen
+    from tests.helpers import oracle_hdiv_hierarchy
+    A, Ps, Ds, _ = meshgen.hdiv_problem(3)
+    assert A.shape[0] == 473536 and A.nnz == 3275200
+    h = oracle_hdiv_hierarchy(A, Ps, Ds)
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], hipt=h["hipt"])
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    H = la.buildHierarchyFromDeRhamSequence(dA, [la.ParallelCSRMatrix.from_scipy(P) for P in Ps], "L1 Jacobi",
+                                            Ds=[la.ParallelCSRMatrix.from_scipy(D) for D in Ds])
+    for l in range(len(Ps) + 1):
+        same_matrix(H.GetOperator(l).to_scipy(), h["As"][l])
+    b = np.full(A.shape[0], 2.0)
+    x, xr = np.empty_like(b), np.empty_like(b)
+    H.Mult(b, x); Hc.apply(b, xr)
+    assert close(x, xr, tol=1e-10)
+
+
+def test_degenerate_hierarchies(la, h1_k1):
+    """one level (coarse solve only), two levels, and a hierarchy without coarse solver (pre+post smoothing there)."""
+    A, Ps, _ = h1_k1
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    b = np.random.default_rng(0).standard_normal(A.shape[0])
+    H1 = la.buildHierarchyFromDeRhamSequence(dA, [], "L1 Jacobi")
+    x = np.empty_like(b); H1.Mult(b, x)
+    assert close(A @ x, b, tol=1e-9)                              # exact solve
+    H = la.Hierarchy(1)
+    H.SetOperator(0, dA)
+    S = la.HypreSmootherWrapper(dA, 1)
+    H.SetSmoothers(0, S, S)
+    H.Finalize()
+    x2 = np.empty_like(b); H.Mult(b, x2)
+    ref = orc.OSmoother(orc.OParCSR(orc.diag_first(A)), type=1, sweeps=2); ref.iterative_mode = False
+    xr = np.empty_like(b); ref.Mult(b, xr)
+    assert close(x2, xr)
+    from parelag_amd._lib import ElagHipError
+    Hbad = la.Hierarchy(2)
+    Hbad.SetOperator(0, dA)
+    with pytest.raises(ElagHipError):
+        Hbad.Finalize()                                           # level 1 has no operator
