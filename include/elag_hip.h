@@ -70,6 +70,10 @@ ELAG_HIP_API int elag_hip_device_name(char *buf, int len);
  * every rank calls elag_hip_comm_init.  With nranks == 1 no communicator is created. */
 ELAG_HIP_API int elag_hip_comm_unique_id(void *id128);
 ELAG_HIP_API int elag_hip_comm_init(int rank, int nranks, const void *id128);
+/* In-process communicator: `nranks` host threads of one process, each with its own library context on the same
+ * device, exchange through a mailbox and device-to-device copies (same `group` id on all of them).  It lets the whole
+ * multi-rank path run on a single-GPU box (tests); a production run uses elag_hip_comm_init. */
+ELAG_HIP_API int elag_hip_comm_init_inprocess(int rank, int nranks, int group);
 ELAG_HIP_API int elag_hip_comm_rank(int *rank, int *nranks);
 /* 8-byte reductions that end the norm / dot routines (MPI_Allreduce in hypre_ParCSRMatrixNorms.c:60) */
 ELAG_HIP_API int elag_hip_comm_allreduce(double *value, int op /*0 sum, 1 max*/);

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "elag_hip_device_name": [C.c_char_p, _i],
     "elag_hip_comm_unique_id": [_p],
     "elag_hip_comm_init": [_i, _i, _p],
+    "elag_hip_comm_init_inprocess": [_i, _i, _i],
     "elag_hip_comm_rank": [_ip, _ip],
     "elag_hip_comm_allreduce": [_dp, _i],
     "elag_hip_malloc": [C.POINTER(_p), C.c_size_t],
@@ -125,7 +126,7 @@ _RESTYPES = {"elag_hip_last_error": C.c_char_p}
 ABI_SYMBOLS = tuple(_SIGNATURES)
 
 _lib = None
-_initialised = False
+_tls = __import__("threading").local()
 
 
 class ElagHipError(RuntimeError):
@@ -160,13 +161,12 @@ def check(status: int):
 
 def init(device: int | None = None):
     """elag_hip_init on LOCAL_RANK's device (one process per GPU)."""
-    global _initialised
     lib = load()
-    if not _initialised:
+    if not getattr(_tls, "initialised", False):   # the library context is per host thread (one thread per rank)
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
         check(lib.elag_hip_init(device))
-        _initialised = True
+        _tls.initialised = True
     return lib
 
 

@@ -3,6 +3,12 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <algorithm>
+
 namespace elag {
 
 struct Comm {
@@ -45,22 +51,117 @@ static Comm *load_rccl()
     return &c;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// In-process communicator ("hub"): several ranks run as host threads of ONE process on ONE device, each with its own
+// thread-local context and streams.  Messages are matched through a mailbox keyed by (source, destination, sequence)
+// and delivered by device-to-device copies.  It exists so that the whole multi-rank code path (halo exchange with
+// interior/boundary overlap, reverse halo, all-gather, all-reduce, distributed hierarchies) is exercised on a
+// single-GPU box; only the thin RCCL wrappers above differ on a real multi-GPU node.  Host-synchronous by design.
+// ------------------------------------------------------------------------------------------------------------------
+struct HubMsg { const void *ptr; size_t bytes; };
+struct Hub {
+    std::mutex m;
+    std::condition_variable cv;
+    int nranks = 0, attached = 0;
+    std::map<std::tuple<int, int, unsigned long long>, HubMsg> box;
+};
+struct HubEndpoint {                      // per rank (lives in the thread's context)
+    std::shared_ptr<Hub> hub;
+    std::map<int, unsigned long long> send_seq, recv_seq;
+};
+
+static std::mutex g_hubs_m;
+static std::map<int, std::shared_ptr<Hub>> g_hubs;
+
+static HubEndpoint *hub_ep() { return static_cast<HubEndpoint *>(ctx().hub); }
+
+static void hub_exchange(const void *sendbuf, int nsend, const int *send_procs, const int *send_starts, void *recvbuf, int nrecv,
+                         const int *recv_procs, const int *recv_starts, size_t elem_bytes, hipStream_t st, int skip_s, int skip_r)
+{
+    HubEndpoint *ep = hub_ep();
+    Hub &H = *ep->hub;
+    const int me = ctx().rank;
+    ELAG_HIP_CHECK(hipStreamSynchronize(st));   // the data to send is final
+    std::vector<std::tuple<int, int, unsigned long long>> mine;
+    {
+        std::unique_lock<std::mutex> lk(H.m);
+        for (int i = 0; i < nsend; i++) {
+            if (i == skip_s) continue;
+            const size_t n = (size_t)(send_starts[i + 1] - send_starts[i]) * elem_bytes;
+            if (!n) continue;
+            auto key = std::make_tuple(me, send_procs[i], ep->send_seq[send_procs[i]]++);
+            H.box[key] = HubMsg{static_cast<const char *>(sendbuf) + (size_t)send_starts[i] * elem_bytes, n};
+            mine.push_back(key);
+        }
+    }
+    H.cv.notify_all();
+    for (int i = 0; i < nrecv; i++) {
+        if (i == skip_r) continue;
+        const size_t n = (size_t)(recv_starts[i + 1] - recv_starts[i]) * elem_bytes;
+        if (!n) continue;
+        auto key = std::make_tuple(recv_procs[i], me, ep->recv_seq[recv_procs[i]]++);
+        HubMsg msg;
+        {
+            std::unique_lock<std::mutex> lk(H.m);
+            H.cv.wait(lk, [&] { return H.box.count(key) > 0; });
+            msg = H.box[key];
+        }
+        if (msg.bytes != n) fail(ELAG_HIP_ERR_COMM, "hub: rank %d expected %zu bytes from %d, got %zu", me, n, recv_procs[i], msg.bytes);
+        ELAG_HIP_CHECK(hipMemcpyAsync(static_cast<char *>(recvbuf) + (size_t)recv_starts[i] * elem_bytes, msg.ptr, n, hipMemcpyDeviceToDevice, st));
+        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        {
+            std::unique_lock<std::mutex> lk(H.m);
+            H.box.erase(key);
+        }
+        H.cv.notify_all();
+    }
+    // my send buffers may be reused only after every receiver has copied them
+    std::unique_lock<std::mutex> lk(H.m);
+    H.cv.wait(lk, [&] {
+        for (auto &k : mine) if (H.box.count(k)) return false;
+        return true;
+    });
+}
+
+static void hub_init(int rank, int nranks, int group)
+{
+    Context &x = ctx();
+    std::shared_ptr<Hub> h;
+    {
+        std::lock_guard<std::mutex> lk(g_hubs_m);
+        auto &slot = g_hubs[group];
+        if (!slot || slot->attached >= slot->nranks) { slot = std::make_shared<Hub>(); slot->nranks = nranks; }
+        if (slot->nranks != nranks) fail(ELAG_HIP_ERR_COMM, "hub group %d was opened for %d ranks, not %d", group, slot->nranks, nranks);
+        slot->attached++;
+        h = slot;
+    }
+    auto *ep = new HubEndpoint();
+    ep->hub = h;
+    x.hub = ep;
+    x.comm_kind = 2;
+    x.rank = rank;
+    x.nranks = nranks;
+}
+
 #define ELAG_NCCL_CHECK(c, expr)                                                                               \
     do {                                                                                                       \
         ncclResult_t r_ = (expr);                                                                              \
         if (r_ != ncclSuccess) fail(ELAG_HIP_ERR_COMM, "%s failed: %s", #expr, (c)->GetErrorString(r_));       \
     } while (0)
 
-bool comm_active() { return ctx().nranks > 1 && ctx().comm && ctx().comm->comm; }
+bool comm_active() { return ctx().nranks > 1 && ((ctx().comm_kind == 1 && ctx().comm && ctx().comm->comm) || (ctx().comm_kind == 2 && ctx().hub)); }
 
 void comm_destroy()
 {
     Context &c = ctx();
-    if (c.comm && c.comm->comm) {
+    if (c.comm_kind == 1 && c.comm && c.comm->comm) {
         c.comm->CommDestroy(c.comm->comm);
         c.comm->comm = nullptr;
     }
+    if (c.hub) { delete static_cast<HubEndpoint *>(c.hub); c.hub = nullptr; }
     c.comm = nullptr;
+    c.comm_kind = 0;
     c.rank = 0;
     c.nranks = 1;
 }
@@ -85,6 +186,7 @@ void comm_init(int rank, int nranks, const void *id128)
     memcpy(&id, id128, sizeof(id));
     ELAG_NCCL_CHECK(c, c->CommInitRank(&c->comm, nranks, id, rank));
     x.comm = c;
+    x.comm_kind = 1;
     x.rank = rank;
     x.nranks = nranks;
 }
@@ -111,6 +213,10 @@ void comm_neighbor_exchange(const void *sendbuf, int nsend, const int *send_proc
     }
     if (!remote) return;
     if (!comm_active()) fail(ELAG_HIP_ERR_COMM, "matrix has off-rank columns but no communicator was initialised");
+    if (ctx().comm_kind == 2) {
+        hub_exchange(sendbuf, nsend, send_procs, send_starts, recvbuf, nrecv, recv_procs, recv_starts, elem_bytes, st, self_s, self_r);
+        return;
+    }
     Comm *c = ctx().comm;
     ELAG_NCCL_CHECK(c, c->GroupStart());
     for (int i = 0; i < nrecv; i++) {
@@ -134,6 +240,16 @@ void comm_allgatherv(const double *send, double *recv, const int *counts, const 
         ELAG_HIP_CHECK(hipMemcpyAsync(recv + displs[me], send, sizeof(double) * (size_t)counts[me], hipMemcpyDeviceToDevice, st));
     if (n == 1) return;
     if (!comm_active()) fail(ELAG_HIP_ERR_COMM, "all-gather without a communicator");
+    if (x.comm_kind == 2) {
+        // every rank exchanges its piece with every other rank through the mailbox, peers in ascending order
+        for (int peer = 0; peer < n; peer++) {
+            if (peer == me) continue;
+            const int one_s[2] = {0, counts[me]};
+            const int one_r[2] = {0, counts[peer]};
+            hub_exchange(send, 1, &peer, one_s, recv + displs[peer], 1, &peer, one_r, sizeof(double), st, -1, -1);
+        }
+        return;
+    }
     Comm *c = x.comm;
     ELAG_NCCL_CHECK(c, c->GroupStart());
     for (int r = 0; r < n; r++) {
@@ -147,6 +263,27 @@ void comm_allgatherv(const double *send, double *recv, const int *counts, const 
 void comm_allreduce_device(double *d_values, int n, int op, hipStream_t st)
 {
     if (!comm_active() || n == 0) return;
+    if (ctx().comm_kind == 2) {
+        // gather every rank's vector (rank order), reduce on the host in that order, write back: deterministic
+        const int nr = ctx().nranks, me = ctx().rank;
+        double *all = dev_alloc<double>((size_t)n * nr);
+        std::vector<int> counts((size_t)nr, n), displs((size_t)nr);
+        for (int r = 0; r < nr; r++) displs[(size_t)r] = r * n;
+        comm_allgatherv(d_values, all, counts.data(), displs.data(), st);
+        std::vector<double> h((size_t)n * nr), out((size_t)n);
+        ELAG_HIP_CHECK(hipMemcpyAsync(h.data(), all, sizeof(double) * h.size(), hipMemcpyDeviceToHost, st));
+        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        for (int i = 0; i < n; i++) {
+            double acc = h[(size_t)i];
+            for (int r = 1; r < nr; r++) acc = (op == 0) ? acc + h[(size_t)r * n + i] : std::max(acc, h[(size_t)r * n + i]);
+            out[(size_t)i] = acc;
+        }
+        ELAG_HIP_CHECK(hipMemcpyAsync(d_values, out.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        (void)me;
+        dev_free(all);
+        return;
+    }
     Comm *c = ctx().comm;
     ELAG_NCCL_CHECK(c, c->AllReduce(d_values, d_values, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, c->comm, st));
 }
@@ -179,6 +316,16 @@ int elag_hip_comm_unique_id(void *id128)
 int elag_hip_comm_init(int rank, int nranks, const void *id128)
 {
     return guarded([&] { require_init(); comm_init(rank, nranks, id128); });
+}
+
+int elag_hip_comm_init_inprocess(int rank, int nranks, int group)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d of %d", rank, nranks);
+        if (nranks == 1) { ctx().rank = 0; ctx().nranks = 1; return; }
+        hub_init(rank, nranks, group);
+    });
 }
 
 int elag_hip_comm_rank(int *rank, int *nranks)

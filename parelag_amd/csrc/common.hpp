@@ -68,6 +68,10 @@ int guarded(F &&f) noexcept
 // ---- context -----------------------------------------------------------------------------------
 struct Comm;  // RCCL wrapper (comm.hip)
 
+struct ScratchSlab { char *p; size_t cap, top; };
+
+// One context per calling host thread: ParElag runs one thread per rank (SURVEY 8b "Threading"); the in-process
+// communicator used by the tests runs several ranks as threads of one process on one device.
 struct Context {
     bool initialised = false;
     int device = -1;
@@ -77,7 +81,12 @@ struct Context {
     hipEvent_t ev_pack = nullptr;       // send buffer packed   (compute -> comm)
     hipEvent_t ev_halo = nullptr;       // ghost values arrived (comm -> compute)
     int rank = 0, nranks = 1;
-    Comm *comm = nullptr;
+    int comm_kind = 0;                  // 0 none, 1 RCCL, 2 in-process hub
+    Comm *comm = nullptr;               // RCCL
+    void *hub = nullptr;                // in-process hub (comm.hip)
+    std::vector<ScratchSlab> slabs;     // setup scratch arena (LIFO)
+    int cur_slab = -1;
+    double *reduce_part = nullptr;      // partial sums of the two-stage reductions
     double *d_scalar = nullptr;         // device scratch for reductions (16 doubles)
     double *h_scalar = nullptr;         // pinned mirror
 };

@@ -22,7 +22,7 @@ void fail(int code, const char *fmt, ...)
 
 Context &ctx()
 {
-    static Context c;
+    static thread_local Context c;
     return c;
 }
 
@@ -33,33 +33,30 @@ bool debug_sync()
     return v == 1;
 }
 
-// ---- scratch stack ------------------------------------------------------------------------------
-namespace {
-struct Slab { char *p; size_t cap, top; };
-std::vector<Slab> g_slabs;
-int g_cur = -1;
-}  // namespace
-
+// ---- scratch stack (per context) ------------------------------------------------------------------
 void *scratch_push(size_t bytes, int *slab, size_t *prev_top)
 {
+    Context &c = ctx();
+    std::vector<ScratchSlab> &slabs = c.slabs;
+    int &cur = c.cur_slab;
     bytes = (bytes + 255) & ~size_t(255);
     // find room in the current slab, else move to / create the next one
     while (true) {
-        if (g_cur >= 0 && g_slabs[(size_t)g_cur].top + bytes <= g_slabs[(size_t)g_cur].cap) break;
-        if (g_cur + 1 < (int)g_slabs.size() && g_slabs[(size_t)g_cur + 1].cap >= bytes) { g_cur++; continue; }
+        if (cur >= 0 && slabs[(size_t)cur].top + bytes <= slabs[(size_t)cur].cap) break;
+        if (cur + 1 < (int)slabs.size() && slabs[(size_t)cur + 1].cap >= bytes) { cur++; continue; }
         // new slab (inserted right after the current one); later, smaller slabs are dropped
-        for (size_t i = (size_t)g_cur + 1; i < g_slabs.size(); i++) (void)hipFree(g_slabs[i].p);
-        g_slabs.resize((size_t)g_cur + 1);
+        for (size_t i = (size_t)cur + 1; i < slabs.size(); i++) (void)hipFree(slabs[i].p);
+        slabs.resize((size_t)cur + 1);
         size_t cap = size_t(64) << 20;
-        if (!g_slabs.empty()) cap = std::max(cap, 2 * g_slabs.back().cap);
+        if (!slabs.empty()) cap = std::max(cap, 2 * slabs.back().cap);
         cap = std::max(cap, bytes);
-        Slab s{nullptr, cap, 0};
+        ScratchSlab s{nullptr, cap, 0};
         ELAG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s.p), cap));
-        g_slabs.push_back(s);
-        g_cur++;
+        slabs.push_back(s);
+        cur++;
     }
-    Slab &s = g_slabs[(size_t)g_cur];
-    *slab = g_cur;
+    ScratchSlab &s = slabs[(size_t)cur];
+    *slab = cur;
     *prev_top = s.top;
     void *p = s.p + s.top;
     s.top += bytes;
@@ -68,18 +65,20 @@ void *scratch_push(size_t bytes, int *slab, size_t *prev_top)
 
 void scratch_pop(int slab, size_t prev_top)
 {
+    Context &c = ctx();
     // LIFO: everything pushed after this allocation has already been popped
-    for (int i = slab + 1; i <= g_cur; i++) g_slabs[(size_t)i].top = 0;
-    g_cur = slab;
-    g_slabs[(size_t)slab].top = prev_top;
-    if (slab > 0 && prev_top == 0) g_cur = slab - 1;
+    for (int i = slab + 1; i <= c.cur_slab; i++) c.slabs[(size_t)i].top = 0;
+    c.cur_slab = slab;
+    c.slabs[(size_t)slab].top = prev_top;
+    if (slab > 0 && prev_top == 0) c.cur_slab = slab - 1;
 }
 
 void scratch_release_all()
 {
-    for (auto &s : g_slabs) (void)hipFree(s.p);
-    g_slabs.clear();
-    g_cur = -1;
+    Context &c = ctx();
+    for (auto &s : c.slabs) (void)hipFree(s.p);
+    c.slabs.clear();
+    c.cur_slab = -1;
 }
 
 int debug_poison()
@@ -210,6 +209,7 @@ int elag_hip_finalize(void)
         comm_destroy();
         scratch_release_all();
         (void)hipFree(c.d_scalar);
+        if (c.reduce_part) (void)hipFree(c.reduce_part);
         (void)hipHostFree(c.h_scalar);
         (void)hipEventDestroy(c.ev_pack);
         (void)hipEventDestroy(c.ev_halo);

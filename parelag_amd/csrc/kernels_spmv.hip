@@ -404,9 +404,9 @@ __global__ __launch_bounds__(kBlock) void reduce_stage2(int nparts, const double
 
 double *reduce_scratch()
 {
-    static double *p = nullptr;
-    if (!p) p = dev_alloc<double>(kRedBlocks);
-    return p;
+    Context &c = ctx();
+    if (!c.reduce_part) c.reduce_part = dev_alloc<double>(kRedBlocks);
+    return c.reduce_part;
 }
 
 void reduce_launch(long long n, const double *x, const double *y, int mode, double *d_result)

@@ -90,6 +90,7 @@ def build_hierarchy(dist: Dist, A, Ps, seq, smoother="L1 Jacobi", params=None, r
     # distributed head: levels 0..R-1 plus level R as the "coarsest" level of the outer hierarchy
     H = la.Hierarchy(R + 1)
     ops = []
+    H._keep_smoothers = []
     for l in range(R):
         lev = d["levels"][l]
         Al = la.ParallelCSRMatrix.from_parts(lev["A_parts"][dist.rank])
@@ -99,6 +100,7 @@ def build_hierarchy(dist: Dist, A, Ps, seq, smoother="L1 Jacobi", params=None, r
             H.SetProlongator(l, la.ParallelCSRMatrix.from_parts(lev["P_parts"][dist.rank]))
         S = la.HypreSmootherWrapper(Al, t, params or {})
         H.SetSmoothers(l, S, S)
+        H._keep_smoothers.append(S)
     H.SetOperator(R, subA)
     # P from the first replicated level: this rank's rows, GLOBAL coarse columns, no comm package
     s = d["levels"][R - 1]["starts"]
