@@ -139,9 +139,14 @@ ELAG_HIP_API int elag_hip_parcsr_transpose(elag_hip_parcsr_t A, elag_hip_parcsr_
 /* hypre_ParMatmul / mfem::ParMult (MG_Utils_impl.hpp:27-88, MatrixUtils.cpp:1053-1063): C = A*B */
 ELAG_HIP_API int elag_hip_parcsr_matmul(elag_hip_parcsr_t A, elag_hip_parcsr_t B, elag_hip_parcsr_t *C);
 /* hypre_BoomerAMGBuildCoarseOperator(RT,A,P) = RT^T A P: mfem::RAP(A,P) at Hierarchy.cpp:365,511-513;
- * RAP(A,D) at HiptmairSmootherFactory.cpp:160-161; generic RAP/PtAP at MatrixUtils.cpp:919-948. */
+ * RAP(A,D) at HiptmairSmootherFactory.cpp:160-161; generic RAP/PtAP at MatrixUtils.cpp:919-948.
+ * Distributed operands are supported (collective call): external rows of P are fetched along A's comm package,
+ * off-rank contributions travel back along RT's, and the result carries its own negotiated comm package. */
 ELAG_HIP_API int elag_hip_parcsr_rap(elag_hip_parcsr_t RT, elag_hip_parcsr_t A, elag_hip_parcsr_t P,
                                      elag_hip_parcsr_t *RAP);
+/* Gather a distributed matrix onto every rank (rank-local, replicated copy; row_starts: nranks+1 entries or NULL).
+ * Collective.  Used for the coarsest operators of a distributed hierarchy. */
+ELAG_HIP_API int elag_hip_parcsr_replicate(elag_hip_parcsr_t A, elag_hip_parcsr_t *A_replicated, int64_t *row_starts);
 /* hypre_ParCSRMatrixAdd2: C = a*A + b*B (src/hypreExtension/parcsr-add.c:199-245; :27-78 is a=b=1) */
 ELAG_HIP_API int elag_hip_parcsr_add(double a, elag_hip_parcsr_t A, double b, elag_hip_parcsr_t B,
                                      elag_hip_parcsr_t *C);

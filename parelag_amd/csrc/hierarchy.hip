@@ -620,7 +620,16 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
             H->lev[(size_t)l].post = S;  // same parameters => same operator; scratch is not shared across calls
         }
         elag_hip_coarse_t C = nullptr;
-        int rc = elag_hip_coarse_create(&C, H->lev.back().A, opt.coarse_kind, opt.coarse_iters);
+        int rc;
+        if (is_distributed(*H->lev.back().A)) {
+            // coarsest operator gathered onto every rank, right-hand side all-gathered at apply time
+            std::vector<int64_t> starts;
+            ParCSR *Arep = replicate_matrix(*H->lev.back().A, &starts);
+            H->owned_mats.push_back(Arep);
+            rc = elag_hip_coarse_create_replicated(&C, Arep, starts.data());
+        } else {
+            rc = elag_hip_coarse_create(&C, H->lev.back().A, opt.coarse_kind, opt.coarse_iters);
+        }
         if (rc) fail(rc, "%s", elag_hip_last_error());
         H->owned_coarse = C;
         H->coarse = C;

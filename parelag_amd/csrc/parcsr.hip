@@ -355,7 +355,12 @@ int elag_hip_parcsr_rap(elag_hip_parcsr_t RT, elag_hip_parcsr_t A, elag_hip_parc
     return guarded([&] {
         require_init();
         ELAG_REQUIRE(RT && A && P && RAP, "null argument");
-        require_single_rank(RT, "rap"); require_single_rank(A, "rap"); require_single_rank(P, "rap");
+        if (is_distributed(*RT) || is_distributed(*A) || is_distributed(*P)) {
+            ELAG_REQUIRE(RT->nrows() == A->nrows() && A->ncols() == P->nrows() && RT->global_rows == A->global_rows &&
+                         A->global_cols == P->global_rows, "rap: distributed shapes do not chain");
+            *RAP = distributed_rap(*RT, *A, *P);
+            return;
+        }
         ELAG_REQUIRE(RT->nrows() == A->nrows() && A->ncols() == P->nrows(),
                      "rap: shapes RT %dx%d, A %dx%d, P %dx%d do not chain", RT->nrows(), RT->ncols(), A->nrows(), A->ncols(),
                      P->nrows(), P->ncols());
@@ -364,6 +369,17 @@ int elag_hip_parcsr_rap(elag_hip_parcsr_t RT, elag_hip_parcsr_t A, elag_hip_parc
         RT->ensure_transpose();
         k::csr_spgemm(*RT->diagT, AP, out);
         *RAP = parcsr_from_diag(std::move(out), RT->first_col, P->first_col, RT->global_cols, P->global_cols);
+    });
+}
+
+int elag_hip_parcsr_replicate(elag_hip_parcsr_t A, elag_hip_parcsr_t *Arep, int64_t *row_starts)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(A && Arep, "null argument");
+        std::vector<int64_t> st;
+        *Arep = replicate_matrix(*A, &st);
+        if (row_starts) std::copy(st.begin(), st.end(), row_starts);
     });
 }
 

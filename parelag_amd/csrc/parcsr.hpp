@@ -48,6 +48,11 @@ void par_spmv(ParCSR &A, k::SpmvArgs a);
 // y = alpha*A^T x + beta*y  (x: local rows, y: local columns of diag)
 void par_spmvT(ParCSR &A, double alpha, const double *x, double beta, double *y);
 
+// dist_rap.hip
+ParCSR *distributed_rap(ParCSR &RT, ParCSR &A, ParCSR &P);
+ParCSR *replicate_matrix(ParCSR &A, std::vector<int64_t> *row_starts_out);
+inline bool is_distributed(const ParCSR &M) { return M.needs_exchange() || M.global_rows != M.nrows() || M.global_cols != M.ncols(); }
+
 // Build a single-rank ParCSR from a device CSR (takes ownership of `d`).
 ParCSR *parcsr_from_diag(DevCSR &&d, int64_t first_row, int64_t first_col, int64_t grows, int64_t gcols);
 }  // namespace elag

@@ -79,28 +79,31 @@ def build_hierarchy(dist: Dist, A, Ps, seq, smoother="L1 Jacobi", params=None, r
     R = max(1, min(int(replicate_from), nl - 1))
     t = la.HYPRE_SMOOTHER_TYPES[smoother] if isinstance(smoother, str) else int(smoother)
     lib = _lib.init()
-    # replicated tail: levels R..nl-1 in block numbering, built redundantly on every GPU (device RAP, FixZeroRows)
-    subA = la.ParallelCSRMatrix.from_scipy(d["A_global"][R])
+    # distributed head: levels 0..R-1; their Galerkin operators are formed on the device across the ranks
+    # (elag_hip_parcsr_rap with distributed operands + FixZeroRows), inputs are the fine operator and the true P's
+    H = la.Hierarchy(R + 1)
+    ops = [la.ParallelCSRMatrix.from_parts(d["levels"][0]["A_parts"][dist.rank])]
+    Pd = [la.ParallelCSRMatrix.from_parts(d["levels"][l]["P_parts"][dist.rank]) for l in range(1, R + 1)]
+    for l in range(1, R + 1):
+        Ac = la.RAP(ops[-1], Pd[l - 1])
+        Ac.fix_zero_rows()
+        ops.append(Ac)
+    H._keep_smoothers = []
+    for l in range(R):
+        H.SetOperator(l, ops[l])
+        if l > 0:
+            H.SetProlongator(l, Pd[l - 1])
+        S = la.HypreSmootherWrapper(ops[l], t, params or {})
+        H.SetSmoothers(l, S, S)
+        H._keep_smoothers.append(S)
+    # replicated tail: level R gathered onto every GPU, the levels below built there redundantly (device RAP)
+    subA, _starts = ops[R].Replicate()
     subP = [la.ParallelCSRMatrix.from_scipy(P) for P in d["P_global"][R:]]
     Hsub = la.buildHierarchyFromDeRhamSequence(subA, subP, smoother, params or {}, reorder=0)
     hc = C.c_void_p()
     _lib.check(lib.elag_hip_coarse_create_from_hierarchy(C.byref(hc), Hsub.h, 1))
     cs = la.CoarseSolver.__new__(la.CoarseSolver)
     cs._lib, cs.A, cs.h, cs.iterative_mode = lib, subA, hc, False
-    # distributed head: levels 0..R-1 plus level R as the "coarsest" level of the outer hierarchy
-    H = la.Hierarchy(R + 1)
-    ops = []
-    H._keep_smoothers = []
-    for l in range(R):
-        lev = d["levels"][l]
-        Al = la.ParallelCSRMatrix.from_parts(lev["A_parts"][dist.rank])
-        ops.append(Al)
-        H.SetOperator(l, Al)
-        if l > 0:
-            H.SetProlongator(l, la.ParallelCSRMatrix.from_parts(lev["P_parts"][dist.rank]))
-        S = la.HypreSmootherWrapper(Al, t, params or {})
-        H.SetSmoothers(l, S, S)
-        H._keep_smoothers.append(S)
     H.SetOperator(R, subA)
     # P from the first replicated level: this rank's rows, GLOBAL coarse columns, no comm package
     s = d["levels"][R - 1]["starts"]
@@ -108,7 +111,7 @@ def build_hierarchy(dist: Dist, A, Ps, seq, smoother="L1 Jacobi", params=None, r
     H.SetProlongator(R, la.ParallelCSRMatrix.from_scipy(Ploc))
     H.SetCoarseSolver(cs)
     H.Finalize(use_graph=False)
-    H._keep += [Hsub, subA, *subP]
+    H._keep += [Hsub, subA, *subP, *ops, *Pd]
     la.synchronize()
     shapes = []
     for l in range(nl):

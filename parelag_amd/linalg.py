@@ -229,6 +229,15 @@ class ParallelCSRMatrix:
     def matmul(self, B):
         return self._new(self._lib.elag_hip_parcsr_matmul, self.h, B.h)
 
+    def Replicate(self):
+        """collective: the whole matrix on every rank -> (rank-local ParallelCSRMatrix, row_starts)"""
+        nr = C.c_int(0)
+        check(self._lib.elag_hip_comm_rank(None, C.byref(nr)))
+        starts = np.zeros(nr.value + 1, np.int64)
+        h = _vp()
+        check(self._lib.elag_hip_parcsr_replicate(self.h, C.byref(h), _np_ptr(starts)))
+        return ParallelCSRMatrix(h), starts
+
     def fix_zero_rows(self) -> int:
         n = C.c_int(0)
         check(self._lib.elag_hip_parcsr_fix_zero_rows(self.h, C.byref(n)))

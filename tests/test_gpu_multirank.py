@@ -140,3 +140,67 @@ def test_distributed_vcycle_matches_serial_oracle(problem, world, replicate_from
         xfull[order] = xb
         r0, r1 = np.linalg.norm(b_nat), np.linalg.norm(b_nat - A @ xfull)
         assert r1 < 0.6 * r0
+
+
+def _local_global_csr(M, shape):
+    """device ParCSR (this rank's rows) -> scipy CSR with global column ids"""
+    out = M.to_scipy()
+    if isinstance(out, tuple):
+        D, O, cm = out
+        Dg = sp.csr_matrix((D.data, D.indices + M.info.first_col_diag, D.indptr), shape=(D.shape[0], shape[1]))
+        Og = sp.csr_matrix((O.data, cm[O.indices], O.indptr), shape=(D.shape[0], shape[1]))
+        return (Dg + Og).tocsr()
+    return sp.csr_matrix((out.data, out.indices + M.info.first_col_diag, out.indptr), shape=(out.shape[0], shape[1]))
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_distributed_rap_replicate_and_device_built_hierarchy(problem, world):
+    """hypre_BoomerAMGBuildCoarseOperator across ranks: external rows of P fetched along A's comm package, off-rank
+    contributions sent home along RT's, comm package of the product negotiated; then the whole hierarchy is built on
+    the device from the distributed fine operator and interpolators."""
+    from parelag_amd import linalg as la, partition
+    A, Ps, seq = problem
+    d = partition.distributed_h1_hierarchy(A, Ps, seq, world)
+    Ag, Pg = d["A_global"][0], d["P_global"][0]
+    ref1 = (Pg.T @ Ag @ Pg).tocsr()
+    rng = np.random.default_rng(9)
+    xc = rng.standard_normal(ref1.shape[0])
+    b_nat = rng.uniform(-1, 1, A.shape[0])
+
+    def body(dist):
+        r = dist.rank
+        s0, s1 = d["levels"][0]["starts"], d["levels"][1]["starts"]
+        dA = la.ParallelCSRMatrix.from_parts(d["levels"][0]["A_parts"][r])
+        dPs = [la.ParallelCSRMatrix.from_parts(d["levels"][l]["P_parts"][r]) for l in range(1, len(d["levels"]))]
+        C = la.RAP(dA, dPs[0])
+        assert C.info.global_num_rows == ref1.shape[0] and C.info.first_row == s1[r] and C.Height() == s1[r + 1] - s1[r]
+        loc = _local_global_csr(C, ref1.shape)
+        refl = ref1[s1[r]:s1[r + 1]]
+        assert abs(loc - refl).max() <= 1e-12 * abs(ref1).max()
+        # the negotiated comm package works: y = C x
+        y = np.zeros(C.Height())
+        C.Mult(xc[s1[r]:s1[r + 1]], y)
+        assert np.max(np.abs(y - (ref1 @ xc)[s1[r]:s1[r + 1]])) <= 1e-12 * np.max(np.abs(ref1) @ np.abs(xc))
+        # FixZeroRows + replicate == the global coarse operator on every rank
+        C.fix_zero_rows()
+        Crep, starts = C.Replicate()
+        assert np.array_equal(starts, s1)
+        full = Crep.to_scipy()
+        assert abs(full - d["A_global"][1]).max() <= 1e-12 * abs(d["A_global"][1]).max()
+        # whole distributed hierarchy built on the device (RAP chain across ranks, replicated coarsest solve)
+        H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi", use_graph=False, reorder=0)
+        lo, hi = int(s0[r]), int(s0[r + 1])
+        order = d["levels"][0]["order"]
+        rhs = la.DeviceVector.from_numpy(b_nat[order][lo:hi]); sol = la.DeviceVector(hi - lo)
+        H.Mult(rhs, sol)
+        la.synchronize()
+        x = sol.to_numpy()
+        del H, C, Crep, dA, dPs, rhs, sol
+        return x, (lo, hi)
+    res = run_ranks(world, body)
+    h = oracle_h1_hierarchy(A, Ps)
+    xs = np.empty_like(b_nat)
+    orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"]).apply(b_nat, xs)
+    order = d["levels"][0]["order"]
+    for x, (lo, hi) in res:
+        assert np.max(np.abs(x - xs[order][lo:hi])) <= 1e-11 * np.max(np.abs(xs))
