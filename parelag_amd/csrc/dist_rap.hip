@@ -316,6 +316,88 @@ ParCSR *parcsr_from_global_columns(const DevCSR &Cg, int64_t first_row, int64_t 
     return M.release();
 }
 
+// this rank's rows with GLOBAL column ids (hypre_MergeDiagAndOffd), columns ascending
+static void to_global(ParCSR &M, DevCSR &out)
+{
+    hipStream_t st = ctx().stream;
+    ELAG_REQUIRE(M.global_cols < (int64_t(1) << 31), "global sizes beyond 2^31 are not supported");
+    std::vector<int> cm(M.col_map_offd.begin(), M.col_map_offd.end());
+    Temp<int> dcm(cm.size());
+    if (!cm.empty()) ELAG_HIP_CHECK(hipMemcpyAsync(dcm.p, cm.data(), sizeof(int) * cm.size(), hipMemcpyHostToDevice, st));
+    concat_rows(M.diag, nullptr, (int)M.first_col, M.offd.ncols ? &M.offd : nullptr, dcm.p, 0, (int)M.global_cols, true, out);
+    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+}
+
+// hypre_ParCSRMatrixAdd2 across ranks (parcsr-add.c:199-245: merge diag+offd, add, GenerateDiagAndOffd)
+ParCSR *distributed_add(double a, ParCSR &A, double b, ParCSR &B)
+{
+    DevCSR Ag, Bg, Cg;
+    to_global(A, Ag);
+    to_global(B, Bg);
+    k::csr_add(a, Ag, b, Bg, Cg);
+    return parcsr_from_global_columns(Cg, A.first_row, A.global_rows, A.first_col, A.ncols(), A.global_cols);
+}
+
+// hypre_ParMatmul: C = A*B, rows of B for A's ghost columns fetched along A's comm package
+ParCSR *distributed_matmul(ParCSR &A, ParCSR &B)
+{
+    const int g = A.offd.ncols;
+    DevCSR Bg, Bext, Bst, Aloc, Cg;
+    to_global(B, Bg);
+    exchange_rows(Bg, A.d_send_elmts, A.send_procs, A.send_starts, A.recv_procs, A.recv_starts, Bext);
+    vstack(Bg, Bext, Bst);
+    concat_rows(A.diag, nullptr, 0, g ? &A.offd : nullptr, nullptr, A.ncols(), A.ncols() + g, false, Aloc);
+    k::csr_spgemm(Aloc, Bst, Cg);
+    return parcsr_from_global_columns(Cg, A.first_row, A.global_rows, B.first_col, B.ncols(), B.global_cols);
+}
+
+// hypre_ParCSRMatrixTranspose2 (par_Tmatmul.c:41-79): rows of A^T for this rank's columns; the transposed ghost
+// columns are rows owned elsewhere and travel home along the reverse comm package
+ParCSR *distributed_transpose(ParCSR &A)
+{
+    hipStream_t st = ctx().stream;
+    ELAG_REQUIRE(A.global_rows < (int64_t(1) << 31), "global sizes beyond 2^31 are not supported");
+    const int nc = A.ncols(), g = A.offd.ncols;
+    DevCSR Aloc, Tall, Tg;
+    concat_rows(A.diag, nullptr, 0, g ? &A.offd : nullptr, nullptr, nc, nc + g, false, Aloc);
+    k::csr_transpose(Aloc, Tall);                       // (nc + g) x n, columns = local row ids
+    // local row ids -> global row ids
+    {
+        DevCSR shifted;
+        DevCSR *none = nullptr;
+        concat_rows(Tall, nullptr, (int)A.first_row, none, nullptr, 0, (int)A.global_rows, false, shifted);
+        Tall = std::move(shifted);
+    }
+    if (A.needs_exchange()) {
+        DevCSR Town, Text, Trecv;
+        slice_rows(Tall, 0, nc, Town);
+        slice_rows(Tall, nc, nc + g, Text);
+        exchange_rows(Text, nullptr, A.recv_procs, A.recv_starts, A.send_procs, A.send_starts, Trecv);
+        if (A.send_total()) {
+            A.ensure_transpose();
+            DevCSR E;
+            k::csr_spgemm(*A.scatT, Trecv, E);
+            k::csr_add(1.0, Town, 1.0, E, Tg);
+        } else {
+            Tg = std::move(Town);
+        }
+    } else {
+        Tg = std::move(Tall);
+    }
+    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    return parcsr_from_global_columns(Tg, A.first_col, A.global_cols, A.first_row, A.nrows(), A.global_rows);
+}
+
+// local part of || A - B ||_max for hypre_ParCSRMatrixCompare (merge, subtract, max)
+double distributed_max_abs_diff(ParCSR &A, ParCSR &B)
+{
+    DevCSR Ag, Bg, Dg;
+    to_global(A, Ag);
+    to_global(B, Bg);
+    k::csr_add(1.0, Ag, -1.0, Bg, Dg);
+    return k::reduce_max_abs(Dg.nnz, Dg.a);
+}
+
 // Every rank receives every other rank's rows (global columns): the whole matrix as a rank-local, replicated ParCSR.
 // Used for the coarsest operator(s) of a distributed hierarchy ("gather the coarsest 1-2 levels onto every GPU").
 ParCSR *replicate_matrix(ParCSR &A, std::vector<int64_t> *row_starts_out)
@@ -379,7 +461,7 @@ ParCSR *distributed_rap(ParCSR &RT, ParCSR &A, ParCSR &P)
     Context &c = ctx();
     hipStream_t st = c.stream;
     ELAG_REQUIRE(P.global_cols < (int64_t(1) << 31) && A.global_cols < (int64_t(1) << 31), "global sizes beyond 2^31 are not supported");
-    const int n = A.nrows(), g = A.offd.ncols;
+    const int g = A.offd.ncols;
     const int ncR = RT.ncols(), gR = RT.offd.ncols;
     // 1. P with global columns, external rows
     DevCSR Pg;
@@ -397,7 +479,7 @@ ParCSR *distributed_rap(ParCSR &RT, ParCSR &A, ParCSR &P)
     {
         DevCSR B, Aloc;
         vstack(Pg, Pext, B);
-        concat_rows(A.diag, nullptr, 0, g ? &A.offd : nullptr, nullptr, n, n + g, false, Aloc);
+        concat_rows(A.diag, nullptr, 0, g ? &A.offd : nullptr, nullptr, A.ncols(), A.ncols() + g, false, Aloc);
         k::csr_spgemm(Aloc, B, AP);
     }
     // 3. C_all = [RT_diag | RT_offd]^T * AP

@@ -330,7 +330,7 @@ int elag_hip_parcsr_transpose(elag_hip_parcsr_t A, elag_hip_parcsr_t *At)
     return guarded([&] {
         require_init();
         ELAG_REQUIRE(A && At, "null argument");
-        require_single_rank(A, "transpose");
+        if (is_distributed(*A)) { *At = distributed_transpose(*A); return; }
         DevCSR T;
         k::csr_transpose(A->diag, T);
         *At = parcsr_from_diag(std::move(T), A->first_col, A->first_row, A->global_cols, A->global_rows);
@@ -342,8 +342,12 @@ int elag_hip_parcsr_matmul(elag_hip_parcsr_t A, elag_hip_parcsr_t B, elag_hip_pa
     return guarded([&] {
         require_init();
         ELAG_REQUIRE(A && B && C, "null argument");
-        require_single_rank(A, "matmul"); require_single_rank(B, "matmul");
         ELAG_REQUIRE(A->ncols() == B->nrows(), "matmul: A has %d columns, B has %d rows", A->ncols(), B->nrows());
+        if (is_distributed(*A) || is_distributed(*B)) {
+            ELAG_REQUIRE(A->global_cols == B->global_rows && A->first_col == B->first_row, "matmul: distributed shapes do not chain");
+            *C = distributed_matmul(*A, *B);
+            return;
+        }
         DevCSR out;
         k::csr_spgemm(A->diag, B->diag, out);
         *C = parcsr_from_diag(std::move(out), A->first_row, B->first_col, A->global_rows, B->global_cols);
@@ -388,7 +392,13 @@ int elag_hip_parcsr_add(double a, elag_hip_parcsr_t A, double b, elag_hip_parcsr
     return guarded([&] {
         require_init();
         ELAG_REQUIRE(A && B && C, "null argument");
-        require_single_rank(A, "add"); require_single_rank(B, "add");
+        if (is_distributed(*A) || is_distributed(*B)) {
+            ELAG_REQUIRE(A->nrows() == B->nrows() && A->ncols() == B->ncols() && A->global_rows == B->global_rows &&
+                         A->global_cols == B->global_cols && A->first_row == B->first_row && A->first_col == B->first_col,
+                         "add: incompatible matrix dimensions");
+            *C = distributed_add(a, *A, b, *B);
+            return;
+        }
         DevCSR out;
         k::csr_add(a, A->diag, b, B->diag, out);
         *C = parcsr_from_diag(std::move(out), A->first_row, A->first_col, A->global_rows, A->global_cols);
@@ -429,11 +439,18 @@ int elag_hip_parcsr_delete_zeros(elag_hip_parcsr_t A, double tol)
     return guarded([&] {
         require_init();
         ELAG_REQUIRE(A, "null matrix");
-        require_single_rank(A, "delete_zeros");
         DevCSR out;
         k::csr_delete_zeros(A->diag, tol, out);
         A->diag = std::move(out);
-        A->diagT.reset();
+        if (A->offd.nnz) {   // the ghost column set (and the comm package built on it) is kept, as the reference rebuilds it on the same col_map
+            DevCSR o;
+            k::csr_delete_zeros(A->offd, tol, o);
+            const int nco = A->offd.ncols;
+            A->offd = std::move(o);
+            A->offd.ncols = nco;
+        }
+        A->diagT.reset(); A->offdT.reset();
+        A->finish_setup();
     });
 }
 
@@ -522,10 +539,14 @@ int elag_hip_parcsr_compare(elag_hip_parcsr_t A, elag_hip_parcsr_t B, double tol
         if (A->first_col != B->first_col) cmp |= 16;
         if (A->first_col + A->ncols() != B->first_col + B->ncols()) cmp |= 32;
         if (cmp == 0) {
-            require_single_rank(A, "compare"); require_single_rank(B, "compare");
-            DevCSR D;
-            k::csr_add(1.0, A->diag, -1.0, B->diag, D);
-            double diff = k::reduce_max_abs(D.nnz, D.a);
+            double diff;
+            if (is_distributed(*A) || is_distributed(*B)) {
+                diff = distributed_max_abs_diff(*A, *B);
+            } else {
+                DevCSR D;
+                k::csr_add(1.0, A->diag, -1.0, B->diag, D);
+                diff = k::reduce_max_abs(D.nnz, D.a);
+            }
             comm_allreduce_scalar(&diff, 0);
             if (diff > tol) cmp |= 64;
         } else {

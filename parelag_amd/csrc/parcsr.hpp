@@ -51,6 +51,12 @@ void par_spmvT(ParCSR &A, double alpha, const double *x, double beta, double *y)
 // dist_rap.hip
 ParCSR *distributed_rap(ParCSR &RT, ParCSR &A, ParCSR &P);
 ParCSR *replicate_matrix(ParCSR &A, std::vector<int64_t> *row_starts_out);
+ParCSR *distributed_add(double a, ParCSR &A, double b, ParCSR &B);
+ParCSR *distributed_matmul(ParCSR &A, ParCSR &B);
+ParCSR *distributed_transpose(ParCSR &A);
+double distributed_max_abs_diff(ParCSR &A, ParCSR &B);
+ParCSR *parcsr_from_global_columns(const DevCSR &Cg, int64_t first_row, int64_t global_rows, int64_t first_col, int ncols_local,
+                                   int64_t global_cols);
 inline bool is_distributed(const ParCSR &M) { return M.needs_exchange() || M.global_rows != M.nrows() || M.global_cols != M.ncols(); }
 
 // Build a single-rank ParCSR from a device CSR (takes ownership of `d`).

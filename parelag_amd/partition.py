@@ -13,6 +13,15 @@ import numpy as np
 import scipy.sparse as sp
 
 
+def canon(M) -> sp.csr_matrix:
+    """CSR with truly ascending column indices and no duplicates (do not trust cached flags after fancy indexing)."""
+    M = sp.csr_matrix(M)
+    M.has_sorted_indices = False
+    M.sort_indices()
+    M.sum_duplicates()
+    return M
+
+
 def rcb_partition(points: np.ndarray, nparts: int) -> np.ndarray:
     """Recursive coordinate bisection of a point cloud into ``nparts`` (any integer >= 1) balanced parts."""
     part = np.zeros(len(points), dtype=np.int32)
@@ -125,15 +134,15 @@ def distributed_h1_hierarchy(A, Ps, seq, nparts: int):
         own = vertex_owners(seq.meshes[l], eparts[l])
         o, n, s = block_numbering(own, nparts)
         orders.append(o); news.append(n); starts.append(s)
-    A_glob = [sp.csr_matrix(A)[orders[0]][:, orders[0]].tocsr()]
+    A_glob = [canon(sp.csr_matrix(A)[orders[0]][:, orders[0]])]
     P_glob = []
     for l, P in enumerate(Ps):
-        Pp = sp.csr_matrix(P)[orders[l]][:, orders[l + 1]].tocsr()
+        Pp = canon(sp.csr_matrix(P)[orders[l]][:, orders[l + 1]])
         P_glob.append(Pp)
-        Ac = (Pp.T @ A_glob[-1] @ Pp).tocsr()
+        Ac = canon(Pp.T @ A_glob[-1] @ Pp)
         # hypre_ParCSRMatrixFixZeroRows: essential-BC rows of the Galerkin operator are empty -> unit diagonal
         zero = np.asarray(abs(Ac).sum(axis=1)).ravel() == 0
-        Ac = (Ac + sp.diags(zero.astype(float))).tocsr()
+        Ac = canon(Ac + sp.diags(zero.astype(float)))
         A_glob.append(Ac)
     levels = []
     for l in range(nl):

@@ -162,7 +162,7 @@ def test_distributed_rap_replicate_and_device_built_hierarchy(problem, world):
     A, Ps, seq = problem
     d = partition.distributed_h1_hierarchy(A, Ps, seq, world)
     Ag, Pg = d["A_global"][0], d["P_global"][0]
-    ref1 = (Pg.T @ Ag @ Pg).tocsr()
+    ref1 = partition.canon(Pg.T @ Ag @ Pg)
     rng = np.random.default_rng(9)
     xc = rng.standard_normal(ref1.shape[0])
     b_nat = rng.uniform(-1, 1, A.shape[0])
@@ -204,3 +204,48 @@ def test_distributed_rap_replicate_and_device_built_hierarchy(problem, world):
     order = d["levels"][0]["order"]
     for x, (lo, hi) in res:
         assert np.max(np.abs(x - xs[order][lo:hi])) <= 1e-11 * np.max(np.abs(xs))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_hypre_extension_set(problem, world):
+    """src/hypreExtension across ranks: ParMatmul, Transpose2, Add2, Compare, DeleteZeros on distributed operands."""
+    from parelag_amd import linalg as la, partition
+    A, Ps, seq = problem
+    d = partition.distributed_h1_hierarchy(A, Ps, seq, world)
+    Ag, Pg = d["A_global"][0], d["P_global"][0]
+    APref = partition.canon(Ag @ Pg)
+    PTref = partition.canon(Pg.T)
+    Sref = partition.canon(2.0 * Ag - 0.5 * partition.canon(Ag @ Ag))
+    xchk = np.random.default_rng(77).standard_normal(Ag.shape[0])     # the reference itself is self-consistent
+    assert np.allclose(Sref @ xchk, 2 * (Ag @ xchk) - 0.5 * (Ag @ (Ag @ xchk)))
+
+    def body(dist):
+        r = dist.rank
+        s0, s1 = d["levels"][0]["starts"], d["levels"][1]["starts"]
+        dA = la.ParallelCSRMatrix.from_parts(d["levels"][0]["A_parts"][r])
+        dP = la.ParallelCSRMatrix.from_parts(d["levels"][1]["P_parts"][r])
+        AP = dA.matmul(dP)                                     # hypre_ParMatmul
+        assert abs(_local_global_csr(AP, APref.shape) - APref[s0[r]:s0[r + 1]]).max() <= 1e-12 * abs(APref).max()
+        PT = dP.Transpose()                                    # hypre_ParCSRMatrixTranspose2
+        assert PT.info.first_row == s1[r] and PT.Height() == s1[r + 1] - s1[r] and PT.info.global_num_cols == Ag.shape[0]
+        assert abs(_local_global_csr(PT, PTref.shape) - PTref[s1[r]:s1[r + 1]]).max() == 0.0
+        # (P^T)(A P) through the distributed products == the RAP routine
+        C1 = PT.matmul(AP)
+        C2 = la.RAP(dA, dP)
+        assert la.Compare(C1, C2, 1e-12 * abs(APref).max()) == 0
+        AA = dA.matmul(dA)
+        S = la.Add(2.0, dA, -0.5, AA)                          # hypre_ParCSRMatrixAdd2, different patterns
+        assert abs(_local_global_csr(S, Sref.shape) - Sref[s0[r]:s0[r + 1]]).max() <= 1e-12 * abs(Sref).max()
+        x = np.random.default_rng(3).standard_normal(Ag.shape[0])
+        y = np.zeros(S.Height()); S.Mult(x[s0[r]:s0[r + 1]], y)
+        assert np.max(np.abs(y - (Sref @ x)[s0[r]:s0[r + 1]])) <= 1e-11 * np.max(np.abs(Sref) @ np.abs(x))
+        assert la.Compare(S, dA, 1e-9) == 64                   # same shape, different values
+        # DeleteZeros keeps the halo machinery usable
+        nnz0 = dA.nnz
+        dA.delete_zeros(1e-300)
+        assert dA.nnz <= nnz0
+        y2 = np.zeros(dA.Height()); dA.Mult(x[s0[r]:s0[r + 1]], y2)
+        assert np.max(np.abs(y2 - (Ag @ x)[s0[r]:s0[r + 1]])) <= 1e-12 * np.max(np.abs(Ag) @ np.abs(x))
+        del AP, PT, C1, C2, AA, S, dA, dP
+        return True
+    run_ranks(world, body)
