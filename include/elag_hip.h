@@ -147,6 +147,18 @@ ELAG_HIP_API int elag_hip_parcsr_rap(elag_hip_parcsr_t RT, elag_hip_parcsr_t A, 
 /* Gather a distributed matrix onto every rank (rank-local, replicated copy; row_starts: nranks+1 entries or NULL).
  * Collective.  Used for the coarsest operators of a distributed hierarchy. */
 ELAG_HIP_API int elag_hip_parcsr_replicate(elag_hip_parcsr_t A, elag_hip_parcsr_t *A_replicated, int64_t *row_starts);
+/* IgnoreNonLocalRange(RT, A, P) (src/linalg/utilities/ParELAG_MatrixUtils.cpp:878-916): the same triple product
+ * with RT's offd block (and comm package) set aside, i.e. contributions to rows owned by other ranks are dropped.
+ * DeRhamSequence::ComputeTrueP / ComputeTrueD go through it (src/amge/DeRhamSequence.cpp:1118-1153).
+ * Together with elag_hip_parcsr_rap this also is Assemble(SharingMap, SparseMatrix, SharingMap)
+ * (src/structures/SharingMap.cpp:975-1011): RT = range.entity_trueEntity, A = the rank-local matrix wrapped as a
+ * block-diagonal ParCSR (elag_hip_parcsr_create with num_cols_offd = 0), P = domain.entity_trueEntity. */
+ELAG_HIP_API int elag_hip_parcsr_rap_ignore_nonlocal_range(elag_hip_parcsr_t RT, elag_hip_parcsr_t A, elag_hip_parcsr_t P,
+                                                           elag_hip_parcsr_t *out);
+/* SharingMap::IgnoreNonLocal(data, trueData) (SharingMap.cpp:726-742): y = diag(A)^T x, no exchange.  The other two
+ * vector forms are plain products with entity_trueEntity: Assemble = elag_hip_parcsr_spmv(trans = 1) (:768-780),
+ * Distribute = elag_hip_parcsr_spmv(trans = 0) (:664-677). */
+ELAG_HIP_API int elag_hip_parcsr_spmvT_ignore_nonlocal(elag_hip_parcsr_t A, const double *x, double *y, int loc);
 /* hypre_ParCSRMatrixAdd2: C = a*A + b*B (src/hypreExtension/parcsr-add.c:199-245; :27-78 is a=b=1) */
 ELAG_HIP_API int elag_hip_parcsr_add(double a, elag_hip_parcsr_t A, double b, elag_hip_parcsr_t B,
                                      elag_hip_parcsr_t *C);

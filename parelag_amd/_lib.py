@@ -78,6 +78,8 @@ _SIGNATURES = {
     "elag_hip_parcsr_matmul": [_p, _p, C.POINTER(_p)],
     "elag_hip_parcsr_rap": [_p, _p, _p, C.POINTER(_p)],
     "elag_hip_parcsr_replicate": [_p, C.POINTER(_p), _p],
+    "elag_hip_parcsr_rap_ignore_nonlocal_range": [_p, _p, _p, C.POINTER(_p)],
+    "elag_hip_parcsr_spmvT_ignore_nonlocal": [_p, _p, _p, _i],
     "elag_hip_parcsr_add": [_d, _p, _d, _p, C.POINTER(_p)],
     "elag_hip_parcsr_rdp": [_p, _p, _i, _p, C.POINTER(_p)],
     "elag_hip_parcsr_fix_zero_rows": [_p, _ip],

@@ -456,13 +456,13 @@ ParCSR *replicate_matrix(ParCSR &A, std::vector<int64_t> *row_starts_out)
     return M.release();
 }
 
-ParCSR *distributed_rap(ParCSR &RT, ParCSR &A, ParCSR &P)
+ParCSR *distributed_rap(ParCSR &RT, ParCSR &A, ParCSR &P, bool ignore_nonlocal_range)
 {
     Context &c = ctx();
     hipStream_t st = c.stream;
     ELAG_REQUIRE(P.global_cols < (int64_t(1) << 31) && A.global_cols < (int64_t(1) << 31), "global sizes beyond 2^31 are not supported");
     const int g = A.offd.ncols;
-    const int ncR = RT.ncols(), gR = RT.offd.ncols;
+    const int ncR = RT.ncols(), gR = ignore_nonlocal_range ? 0 : RT.offd.ncols;
     // 1. P with global columns, external rows
     DevCSR Pg;
     {
@@ -492,7 +492,7 @@ ParCSR *distributed_rap(ParCSR &RT, ParCSR &A, ParCSR &P)
     }
     // 4. contributions to remote coarse rows go home (reverse direction of RT's comm package)
     DevCSR Cg;
-    if (RT.needs_exchange()) {
+    if (RT.needs_exchange() && !ignore_nonlocal_range) {
         DevCSR Cown, Cext, Crecv;
         slice_rows(Call, 0, ncR, Cown);
         slice_rows(Call, ncR, ncR + gR, Cext);

@@ -376,6 +376,32 @@ int elag_hip_parcsr_rap(elag_hip_parcsr_t RT, elag_hip_parcsr_t A, elag_hip_parc
     });
 }
 
+int elag_hip_parcsr_rap_ignore_nonlocal_range(elag_hip_parcsr_t RT, elag_hip_parcsr_t A, elag_hip_parcsr_t P, elag_hip_parcsr_t *out)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(RT && A && P && out, "null argument");
+        ELAG_REQUIRE(RT->nrows() == A->nrows() && A->ncols() == P->nrows(), "IgnoreNonLocalRange: shapes do not chain");
+        *out = distributed_rap(*RT, *A, *P, true);
+    });
+}
+
+int elag_hip_parcsr_spmvT_ignore_nonlocal(elag_hip_parcsr_t A, const double *x, double *y, int loc)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(A && x && y && x != y, "bad argument");
+        check_loc(loc);
+        VecIn xin(x, (size_t)A->nrows(), loc);
+        VecInOut yio(y, (size_t)A->ncols(), loc, false);
+        A->ensure_transpose();
+        k::SpmvArgs d;
+        d.x = xin.d; d.alpha = 1.0; d.out = yio.d;
+        k::spmv_fused(*A->diagT, nullptr, d);
+        yio.finish();
+    });
+}
+
 int elag_hip_parcsr_replicate(elag_hip_parcsr_t A, elag_hip_parcsr_t *Arep, int64_t *row_starts)
 {
     return guarded([&] {

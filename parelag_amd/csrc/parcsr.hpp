@@ -49,7 +49,7 @@ void par_spmv(ParCSR &A, k::SpmvArgs a);
 void par_spmvT(ParCSR &A, double alpha, const double *x, double beta, double *y);
 
 // dist_rap.hip
-ParCSR *distributed_rap(ParCSR &RT, ParCSR &A, ParCSR &P);
+ParCSR *distributed_rap(ParCSR &RT, ParCSR &A, ParCSR &P, bool ignore_nonlocal_range = false);
 ParCSR *replicate_matrix(ParCSR &A, std::vector<int64_t> *row_starts_out);
 ParCSR *distributed_add(double a, ParCSR &A, double b, ParCSR &B);
 ParCSR *distributed_matmul(ParCSR &A, ParCSR &B);

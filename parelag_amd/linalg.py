@@ -210,6 +210,12 @@ class ParallelCSRMatrix:
         check(self._lib.elag_hip_parcsr_keep_equal_entries(self.h, B.h))
         check(self._lib.elag_hip_parcsr_get_info(self.h, C.byref(self.info)))
 
+    def MultTransposeIgnoreNonLocal(self, x, y):
+        """SharingMap::IgnoreNonLocal: y = diag^T x (no exchange)."""
+        px, lx, _k1 = _vec(x, self.Height())
+        py, ly, _k2 = _vec(y, self.Width(), writable=True)
+        check(self._lib.elag_hip_parcsr_spmvT_ignore_nonlocal(self.h, px, py, _same_loc(lx, ly)))
+
     def residual(self, b, x, r):
         """r = b - A x  (mg_utils::ComputeResidual)."""
         pb, lb, _k1 = _vec(b, self.Height())
@@ -288,6 +294,18 @@ def RAP(a: ParallelCSRMatrix, b: ParallelCSRMatrix, c: ParallelCSRMatrix | None 
     h = _vp()
     check(_lib.init().elag_hip_parcsr_rap(Rt.h, A.h, P.h, C.byref(h)))
     return ParallelCSRMatrix(h)
+
+
+def IgnoreNonLocalRange(Rt: ParallelCSRMatrix, A: ParallelCSRMatrix, P: ParallelCSRMatrix):
+    """IgnoreNonLocalRange(RT, A, P) (MatrixUtils.cpp:878-916): RAP with RT's off-rank columns set aside."""
+    h = _vp()
+    check(_lib.init().elag_hip_parcsr_rap_ignore_nonlocal_range(Rt.h, A.h, P.h, C.byref(h)))
+    return ParallelCSRMatrix(h)
+
+
+def Assemble(range_e_tE: ParallelCSRMatrix, A_blockdiag: ParallelCSRMatrix, domain_e_tE: ParallelCSRMatrix):
+    """Assemble(SharingMap, SparseMatrix, SharingMap) (SharingMap.cpp:975-1011): e_tE^T blockdiag(A) e_tE."""
+    return RAP(range_e_tE, A_blockdiag, domain_e_tE)
 
 
 def Add(a, A: ParallelCSRMatrix, b, B: ParallelCSRMatrix):

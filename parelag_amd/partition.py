@@ -151,3 +151,38 @@ def distributed_h1_hierarchy(A, Ps, seq, nparts: int):
             lev["P_parts"] = split_rows(P_glob[l - 1], starts[l - 1], starts[l])
         levels.append(lev)
     return dict(levels=levels, A_global=A_glob, P_global=P_glob)
+
+
+def sharing_map_h1(mesh, elem_part: np.ndarray, nparts: int):
+    """dof -> trueDof map of the 0-form dofs (``SharingMap::entity_trueEntity``, src/structures/SharingMap.hpp:266-287)
+    for an element partition: rank r's *local* dofs are the vertices of its elements (shared vertices appear on every
+    adjacent rank), its *true* dofs the vertices it owns (lowest adjacent rank).  Returns dict with
+    ``parts`` (e_tE as per-rank ParCSR pieces: local dofs x true dofs, entries 1), ``local_vertices[r]`` (natural ids of
+    rank r's local dofs), ``entity_starts``, ``true_starts``, ``order`` (true-dof block numbering, new -> natural) and
+    the stacked selection matrix ``E`` (all local dofs x true dofs)."""
+    own = vertex_owners(mesh, elem_part)
+    order, new_of_old, true_starts = block_numbering(own, nparts)
+    loc, rows, cols = [], [], []
+    off = 0
+    entity_starts = [0]
+    for r in range(nparts):
+        verts = np.unique(mesh.tets[elem_part == r].reshape(-1))
+        verts = verts[np.argsort(new_of_old[verts], kind="stable")]      # local dofs in ascending true-dof order
+        loc.append(verts)
+        rows.append(off + np.arange(len(verts)))
+        cols.append(new_of_old[verts])
+        off += len(verts)
+        entity_starts.append(off)
+    E = sp.csr_matrix((np.ones(off), (np.concatenate(rows), np.concatenate(cols))), shape=(off, mesh.nv))
+    entity_starts = np.asarray(entity_starts, dtype=np.int64)
+    return dict(parts=split_rows(E, entity_starts, true_starts), local_vertices=loc, entity_starts=entity_starts,
+                true_starts=true_starts, order=order, E=canon(E))
+
+
+def local_stiffness(mesh, elem_part: np.ndarray, rank: int, local_vertices: np.ndarray) -> sp.csr_matrix:
+    """P1 stiffness sub-assembled over rank ``rank``'s elements only, in its local dof numbering (the SerialCSRMatrix a
+    ParElag rank holds before ``Assemble``)."""
+    from .meshgen import TetMesh
+    sub = TetMesh(mesh.vertices, mesh.tets[elem_part == rank])
+    S = sub.M0_P1_stiffness()
+    return canon(S[local_vertices][:, local_vertices])

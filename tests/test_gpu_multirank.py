@@ -249,3 +249,55 @@ def test_distributed_hypre_extension_set(problem, world):
         del AP, PT, C1, C2, AA, S, dA, dP
         return True
     run_ranks(world, body)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_sharingmap_assemble_on_device(problem, world):
+    """SURVEY 8f-1, the step right before the path: Assemble(SharingMap, SparseMatrix, SharingMap) =
+    e_tE^T blockdiag(A_local) e_tE (src/structures/SharingMap.cpp:975-1011), IgnoreNonLocalRange
+    (MatrixUtils.cpp:878-916) and the vector forms Assemble / Distribute / IgnoreNonLocal (SharingMap.cpp:664-780)."""
+    from parelag_amd import linalg as la, partition
+    A, Ps, seq = problem
+    mesh = seq.meshes[0]
+    epart = partition.element_partitions(seq, world)[0]
+    sm = partition.sharing_map_h1(mesh, epart, world)
+    E = sm["E"]
+    K = partition.canon(mesh.M0_P1_stiffness()[sm["order"]][:, sm["order"]])          # true-dof (block) numbering
+    Aloc = [partition.local_stiffness(mesh, epart, r, sm["local_vertices"][r]) for r in range(world)]
+    es, ts = sm["entity_starts"], sm["true_starts"]
+    assert abs(partition.canon(E.T @ sp.block_diag(Aloc, format="csr") @ E) - K).max() < 1e-12     # the reference identity
+    rng = np.random.default_rng(6)
+    vloc = rng.standard_normal(E.shape[0]); vtrue = rng.standard_normal(E.shape[1])
+
+    def body(dist):
+        r = dist.rank
+        e_tE = la.ParallelCSRMatrix.from_parts(sm["parts"][r])
+        blk = dict(diag=Aloc[r], offd=sp.csr_matrix((Aloc[r].shape[0], 0)), col_map_offd=np.empty(0, np.int64),
+                   first_row=int(es[r]), first_col=int(es[r]), global_shape=(int(es[-1]), int(es[-1])),
+                   send_procs=[], send_starts=[0], send_elmts=[], recv_procs=[], recv_starts=[0])
+        Bdiag = la.ParallelCSRMatrix.from_parts(blk)
+        At = la.Assemble(e_tE, Bdiag, e_tE)
+        assert At.info.global_num_rows == K.shape[0] and At.info.first_row == ts[r]
+        loc = _local_global_csr(At, K.shape)
+        assert abs(loc - K[ts[r]:ts[r + 1]]).max() <= 1e-12 * abs(K).max()
+        # IgnoreNonLocalRange: only this rank's own sub-assembled contributions to the rows it owns
+        Er = E[es[r]:es[r + 1]]
+        own = sp.csr_matrix((Er.data, Er.indices, Er.indptr), shape=Er.shape).tocsc()
+        mask = np.zeros(E.shape[1], bool); mask[ts[r]:ts[r + 1]] = True
+        Ediag = sp.csr_matrix(Er.multiply(mask[None, :]))
+        ref_ign = partition.canon(Ediag.T @ Aloc[r] @ Er)[ts[r]:ts[r + 1]]
+        Ig = la.IgnoreNonLocalRange(e_tE, Bdiag, e_tE)
+        assert abs(_local_global_csr(Ig, K.shape) - ref_ign).max() <= 1e-12 * abs(K).max()
+        # vector forms
+        t = np.zeros(e_tE.Width())
+        e_tE.MultTranspose(vloc[es[r]:es[r + 1]], t)                                  # Assemble
+        assert np.allclose(t, (E.T @ vloc)[ts[r]:ts[r + 1]], rtol=1e-13, atol=1e-13)
+        dloc = np.zeros(e_tE.Height())
+        e_tE.Mult(vtrue[ts[r]:ts[r + 1]], dloc)                                       # Distribute
+        assert np.array_equal(dloc, (E @ vtrue)[es[r]:es[r + 1]])
+        t2 = np.zeros(e_tE.Width())
+        e_tE.MultTransposeIgnoreNonLocal(vloc[es[r]:es[r + 1]], t2)                   # IgnoreNonLocal
+        assert np.allclose(t2, (Ediag.T @ vloc[es[r]:es[r + 1]])[ts[r]:ts[r + 1]], rtol=1e-13, atol=1e-13)
+        del own, At, Ig, Bdiag, e_tE
+        return True
+    run_ranks(world, body)
