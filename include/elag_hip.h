@@ -37,6 +37,7 @@ typedef struct elag_hip_parcsr_s *elag_hip_parcsr_t;       /* mfem::HypreParMatr
 typedef struct elag_hip_smoother_s *elag_hip_smoother_t;   /* HypreSmootherWrapper / HiptmairSmoother     */
 typedef struct elag_hip_coarse_s *elag_hip_coarse_t;       /* the Level's "CoarseSolver"                  */
 typedef struct elag_hip_hierarchy_s *elag_hip_hierarchy_t; /* parelag::Hierarchy                          */
+typedef struct elag_hip_blockop_s *elag_hip_blockop_t;     /* parelag::MfemBlockOperator                  */
 
 enum { ELAG_HIP_HOST = 0, ELAG_HIP_DEVICE = 1 };
 
@@ -237,15 +238,17 @@ ELAG_HIP_API int elag_hip_smoother_destroy(elag_hip_smoother_t S);
 /* --------------------------------------------------------------------------------------------------
  * Coarse solver.  The reference puts any SolverFactory product here (AMGeSolverFactory.cpp:144-163;
  * shipped lists use PCG+BoomerAMG, Create0FormParameterList.hpp:87-136).  kind 0: dense Cholesky of the
- * (<= 4096 dof, SPD) coarsest operator, applied on device as a dense inverse; kind 1: `iters` steps of
- * Jacobi-preconditioned CG on device.  A host that wants hypre there exports the operator instead.
+ * (<= 4096 dof, SPD) coarsest operator, applied on device as a dense inverse; kind 1: dense LU with partial
+ * pivoting (Gauss-Jordan on the device) for indefinite operators such as the blocked saddle-point systems, where the
+ * reference's lists name a "Direct" solver (ParELAG_DirectSolverFactory.cpp) or a short GMRES; `iters` is unused.
+ * A host that wants hypre there exports the operator instead.
  * ------------------------------------------------------------------------------------------------ */
 ELAG_HIP_API int elag_hip_coarse_create(elag_hip_coarse_t *out, elag_hip_parcsr_t A, int kind, int iters);
 /* Multi-rank coarse solve: every rank holds the whole (tiny) coarsest operator `A_global` as a single-rank matrix,
  * the distributed right-hand side is all-gathered over RCCL and each rank applies its own rows of the dense
  * inverse (SURVEY 8e "gather the coarsest levels onto every GPU").  row_starts has nranks+1 entries. */
 ELAG_HIP_API int elag_hip_coarse_create_replicated(elag_hip_coarse_t *out, elag_hip_parcsr_t A_global,
-                                                   const int64_t *row_starts);
+                                                   const int64_t *row_starts, int kind);
 /* A whole (rank-replicated) hierarchy as the coarse solver of a distributed one: every rank holds the same
  * sub-hierarchy of the levels that are too small to be worth a halo exchange (SURVEY 8e "gather the coarsest levels onto
  * every GPU").  With allreduce_rhs != 0 the right-hand side handed to apply() is this rank's partial sum of the
@@ -313,6 +316,72 @@ ELAG_HIP_API int elag_hip_hierarchy_build_hiptmair(elag_hip_hierarchy_t *out, el
 ELAG_HIP_API int elag_hip_hierarchy_get_ordering(elag_hip_hierarchy_t H, int level, int *order);
 ELAG_HIP_API int elag_hip_hierarchy_get_operator(elag_hip_hierarchy_t H, int level, elag_hip_parcsr_t *A);
 ELAG_HIP_API int elag_hip_hierarchy_get_smoother(elag_hip_hierarchy_t H, int level, elag_hip_smoother_t *S);
+
+/* --------------------------------------------------------------------------------------------------
+ * Blocked (saddle-point) layer -- SURVEY 8f-2: MultigridTestDarcy / SPE10 monolithic AMGe.
+ *
+ * elag_hip_blockop_t mirrors parelag::MfemBlockOperator (src/linalg/utilities/ParELAG_MfemBlockOperator.hpp:30-135,
+ * .cpp:93-130): a num_block_rows x num_block_cols array of ParCSR blocks (NULL = zero block) over contiguous block
+ * vectors with the given LOCAL offsets (mfem::BlockVector).  On the device the blocks are additionally merged into one
+ * "monolithic" ParCSR (block row i / column j at local offsets row_offsets[i] / col_offsets[j]; across ranks, rank r
+ * owns the contiguous global range made of its share of every block, in block order), so that Mult / MultTranspose and
+ * every V-cycle product with the operator are ONE fused SpMV launch and ONE halo exchange.  Blocks are borrowed.
+ * ------------------------------------------------------------------------------------------------ */
+ELAG_HIP_API int elag_hip_blockop_create(elag_hip_blockop_t *out, int num_block_rows, int num_block_cols,
+                                         const int *row_offsets, const int *col_offsets);
+/* MfemBlockOperator::SetBlock (.cpp:107-128): size-checked against the offsets */
+ELAG_HIP_API int elag_hip_blockop_set_block(elag_hip_blockop_t B, int block_row, int block_col, elag_hip_parcsr_t A);
+/* GetBlock / IsZeroBlock: *A = NULL for a zero block */
+ELAG_HIP_API int elag_hip_blockop_get_block(elag_hip_blockop_t B, int block_row, int block_col, elag_hip_parcsr_t *A);
+/* the merged operator (owned by B, rebuilt after SetBlock); usable wherever a ParCSR handle is (hierarchy levels ...) */
+ELAG_HIP_API int elag_hip_blockop_monolithic(elag_hip_blockop_t B, elag_hip_parcsr_t *A);
+/* y = alpha*op(A)*x + beta*y on block vectors (MfemBlockOperator::Mult / MultTranspose, .cpp:93-103) */
+ELAG_HIP_API int elag_hip_blockop_mult(elag_hip_blockop_t B, int trans, double alpha, const double *x, double beta,
+                                       double *y, int loc);
+ELAG_HIP_API int elag_hip_blockop_destroy(elag_hip_blockop_t B);
+
+/* SchurComplementFactory::BuildOperator (src/linalg/factories/ParELAG_SchurComplementFactory.cpp:36-181):
+ *   S = A11 - alpha * A10 * D^-1 * A01,  D = diag(A00) ("DIAGONAL") or the absolute row sums of A00 ("ABSROWSUM");
+ * negate != 0 returns -S ("Use Negative S", Block2x2JacobiSolverFactory.cpp:83-88).  "MASS" needs the DeRhamSequence
+ * and stays on the host side (the caller passes ComputeTrueM(form) as A11 instead).  The caller owns *S. */
+enum { ELAG_HIP_SCHUR_NONE = 0, ELAG_HIP_SCHUR_DIAGONAL = 1, ELAG_HIP_SCHUR_ABSROWSUM = 2 };
+ELAG_HIP_API int elag_hip_schur_complement(elag_hip_blockop_t B, int s_type, double alpha, int negate,
+                                           elag_hip_parcsr_t *S);
+
+/* Block smoothers (all are elag_hip_smoother_t: apply / destroy / hierarchy_set_smoothers work on them):
+ *   ELAG_HIP_BLOCK_JACOBI    BlockDiagonalSolver::Mult        (solver_ops/ParELAG_BlockDiagonalSolver.cpp:67-112)
+ *   ELAG_HIP_BLOCK_GS_LOWER / _UPPER  BlockTriangularSolver   (solver_ops/ParELAG_BlockTriangularSolver.cpp:73-300)
+ *       -- `inverses` holds one smoother per diagonal block (built on A_ii, or on S for the last block);
+ *   ELAG_HIP_BLOCK_LDU       Block2x2LDUInverseOperator::Mult (solver_ops/ParELAG_Block2x2LDUInverseOperator.cpp:73-137)
+ *       -- `inverses` = {A00_1, A00_2, A00_3, S} and `damping` is its "Damping Factor".
+ * The inner smoothers run from the zero guess (iterative_mode == false, as the factories set them); the block smoother
+ * itself honours zero_initial_guess like every other smoother.  Inverses are borrowed. */
+enum { ELAG_HIP_BLOCK_JACOBI = 0, ELAG_HIP_BLOCK_GS_LOWER = 1, ELAG_HIP_BLOCK_GS_UPPER = 2, ELAG_HIP_BLOCK_LDU = 3 };
+ELAG_HIP_API int elag_hip_block_smoother_create(elag_hip_smoother_t *out, elag_hip_blockop_t B, int kind,
+                                                int num_inverses, const elag_hip_smoother_t *inverses, double damping);
+
+/* buildBlockedHierarchyFromDeRhamSequence (src/linalg/solver_ops/ParELAG_Hierarchy.cpp:400-541) + the block-smoother
+ * factories (factories/ParELAG_Block2x2{Jacobi,GaussSeidel,LDU}SolverFactory.cpp) on the device: per block
+ * A_c[i][j] = P_i^T A[i][j] P_j for the stored blocks, FixZeroRows on the diagonal blocks flagged in fix_zero_rows
+ * (NULL = none; the "label_ess[row].size() > 0" test of :515), P = blockdiag(P_i); on every level but the coarsest
+ * the block smoother named in the options (A00 inverse on A00, A11 inverse on S or A11), on the coarsest a dense
+ * direct solve of the merged operator.  P holds num_P * num_blocks handles, P[l*num_blocks + i] = block i of the
+ * interpolator from level l+1 to level l.  The hierarchy borrows A and P and owns everything it builds. */
+typedef struct {
+    int block_smoother;             /* ELAG_HIP_BLOCK_*                                            */
+    elag_hip_amge_options inv_a00;  /* "A00 Inverse": relax_type / sweeps / damping / cheby_* used */
+    elag_hip_amge_options inv_a11;  /* "A11 Inverse" (applied to S when s_type != NONE)            */
+    int s_type;                     /* "S Type": ELAG_HIP_SCHUR_*                                  */
+    double alpha;                   /* "Alpha"                                                     */
+    int use_negative_s;             /* "Use Negative S"                                            */
+    double damping;                 /* "Damping Factor" (LDU)                                      */
+    int coarse_kind;                /* 1 = dense LU (saddle point), 0 = Cholesky                   */
+    int use_graph;
+} elag_hip_blocked_options;
+ELAG_HIP_API int elag_hip_blocked_default_options(elag_hip_blocked_options *opt);
+ELAG_HIP_API int elag_hip_hierarchy_build_blocked(elag_hip_hierarchy_t *out, elag_hip_blockop_t A, int num_P,
+                                                  const elag_hip_parcsr_t *P, const int *fix_zero_rows,
+                                                  const elag_hip_blocked_options *opt);
 
 /* --------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): run `reps` launches of one fine-level kernel on the compute stream

@@ -375,7 +375,9 @@ ORC_API void orc_csr_matmul_fill(int nrowsA, int ncolsB, const int *AI, const in
  * mfem::RAP(A,P) at Hierarchy.cpp:365 and through IgnoreNonLocalRange (MatrixUtils.cpp:878-916), which
  * empties RT's offd so that exactly this loop remains.  R must be the transpose of RT
  * (orc_csr_transpose).  For a square result the diagonal entry is emitted first; other columns are in
- * first-touch order.  Two passes: count (RJ/Ra NULL) then fill.
+ * first-touch order.  Two passes: count (RJ/Ra NULL) then fill.  `nfine` is the number of COLUMNS of A
+ * (hypre sizes A_marker by num_cols_diag_A + num_cols_offd_A), so rectangular A -- the off-diagonal blocks of the
+ * blocked hierarchy, Hierarchy.cpp:511-513 -- are covered.
  * ---------------------------------------------------------------------------------------------- */
 ORC_API int orc_rap(int nc_rows, int nfine, int nc_cols, int square,
                     const int *RI, const int *RJ, const double *Ra,

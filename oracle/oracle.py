@@ -134,7 +134,7 @@ def rap(RT, A, P) -> sp.csr_matrix:
     """hypre_BoomerAMGBuildCoarseOperator(RT, A, P) on one rank (diag blocks)."""
     RT, A, P = csr(RT), csr(A), csr(P)
     R = transpose(RT)
-    ncr, ncc, nf = RT.shape[1], P.shape[1], A.shape[0]
+    ncr, ncc, nf = RT.shape[1], P.shape[1], A.shape[1]   # A_marker spans A's columns (rectangular blocks: B = W D)
     sq = int(ncr == ncc)
     CI = np.empty(ncr + 1, np.int32)
     args = (C.c_int(ncr), C.c_int(nf), C.c_int(ncc), C.c_int(sq), _ip(R.indptr), _ip(R.indices), _dp(R.data),
@@ -551,6 +551,182 @@ class OHierarchy:
                 post.MultTranspose(RHS, SOL)
             else:
                 post.Mult(RHS, SOL)
+
+
+# ---- blocked (saddle-point) layer -------------------------------------------------------------------
+
+class OBlockOperator:
+    """MfemBlockOperator::Mult / MultTranspose (ParELAG_MfemBlockOperator.cpp:93-103), i.e. mfem::BlockOperator:
+    y_i = sum_j A_ij x_j accumulated block by block, j ascending.  ``blocks`` maps (i, j) -> OParCSR."""
+
+    def __init__(self, row_off, col_off, blocks):
+        self.row_off, self.col_off, self.blocks = list(row_off), list(col_off), dict(blocks)
+        self.nbr, self.nbc = len(self.row_off) - 1, len(self.col_off) - 1
+
+    @property
+    def shape(self):
+        return (self.row_off[-1], self.col_off[-1])
+
+    def GetBlock(self, i, j):
+        return self.blocks.get((i, j))
+
+    def _apply(self, x, trans):
+        x = _f64(x)
+        ro, co = (self.col_off, self.row_off) if trans else (self.row_off, self.col_off)
+        out = np.zeros(ro[-1])
+        for i in range(len(ro) - 1):
+            for j in range(len(co) - 1):
+                blk = self.blocks.get((j, i) if trans else (i, j))
+                if blk is None:
+                    continue
+                tmp = np.zeros(ro[i + 1] - ro[i])
+                xs = np.ascontiguousarray(x[co[j]:co[j + 1]])
+                (blk.matvecT if trans else blk.matvec)(1.0, xs, 0.0, tmp)
+                out[ro[i]:ro[i + 1]] += tmp
+        return out
+
+    def matvec(self, alpha, x, beta, y):
+        y *= beta
+        y += alpha * self._apply(x, False)
+
+    def matvecT(self, alpha, x, beta, y):
+        y *= beta
+        y += alpha * self._apply(x, True)
+
+
+def schur_complement(A00, A01, A10, A11=None, s_type="DIAGONAL", alpha=1.0):
+    """SchurComplementFactory::BuildOperator (ParELAG_SchurComplementFactory.cpp:52-170) on serial CSR blocks:
+    A11 - alpha * A10 * D^-1 * A01 with D = diag(A00) or its absolute row sums."""
+    A00, A01, A10 = csr(A00), csr(A01), csr(A10)
+    if s_type.upper() == "DIAGONAL":
+        d = A00.diagonal()
+    elif s_type.upper() == "ABSROWSUM":
+        d = np.asarray(abs(A00).sum(axis=1)).ravel()
+    else:
+        raise ValueError(f'Schur complement type = "{s_type}" is invalid.')
+    tmp = csr(A01.copy())
+    tmp.data = tmp.data / np.repeat(d, np.diff(tmp.indptr))        # InvScaleRows
+    prod = matmul(A10, tmp)
+    if A11 is not None:
+        return add(1.0, csr(A11), -1.0 * alpha, prod)
+    prod = csr(prod)
+    prod.data = prod.data * (-1.0 * alpha)
+    return prod
+
+
+class _OBlockSolverBase:
+    def __init__(self, A: OBlockOperator, inv_ops):
+        self.A, self.inv_ops = A, list(inv_ops)
+        self.iterative_mode = True
+        for s in self.inv_ops:
+            s.iterative_mode = False                               # Block2x2*SolverFactory: inv_ops[i]->iterative_mode = false
+
+    def _residual(self, rhs, sol):
+        r = np.zeros(len(rhs))
+        self.A.matvec(1.0, sol, 0.0, r)
+        r *= -1.0
+        r += rhs
+        return r
+
+    def _run(self, rhs, sol, solve):
+        rhs = _f64(rhs)
+        if self.iterative_mode:                                    # not IsPreconditioner(): Resid = rhs - A sol
+            r = self._residual(rhs, sol)
+            corr = np.zeros(len(sol))
+            solve(r, corr)
+            sol += corr
+        else:
+            sol[:] = 0.0
+            solve(rhs, sol)
+
+    def _blk(self, v, i):
+        o = self.A.row_off
+        return v[o[i]:o[i + 1]]
+
+
+class OBlockDiagonalSolver(_OBlockSolverBase):
+    """BlockDiagonalSolver::Mult (ParELAG_BlockDiagonalSolver.cpp:67-112)."""
+
+    def Mult(self, rhs, sol, transpose=False):
+        def solve(r, x):
+            for i, inv in enumerate(self.inv_ops):
+                xi = np.zeros(len(self._blk(x, i)))
+                (inv.MultTranspose if transpose and hasattr(inv, "MultTranspose") else inv.Mult)(np.ascontiguousarray(self._blk(r, i)), xi)
+                self._blk(x, i)[:] = xi
+        self._run(rhs, sol, solve)
+
+    def MultTranspose(self, rhs, sol):
+        self.Mult(rhs, sol, transpose=True)
+
+
+class OBlockTriangularSolver(_OBlockSolverBase):
+    """BlockTriangularSolver (ParELAG_BlockTriangularSolver.cpp:73-300): lower counts up, upper counts down; the
+    transposes swap the direction and use A_ji^T."""
+
+    def __init__(self, A, inv_ops, lower=True):
+        super().__init__(A, inv_ops)
+        self.lower = lower
+
+    def _sweep(self, r, x, transpose):
+        nb = len(self.inv_ops)
+        ascending = (self.lower != transpose)
+        order = range(nb) if ascending else range(nb - 1, -1, -1)
+        for i in order:
+            ri = np.array(self._blk(r, i), dtype=np.float64)
+            others = range(0, i) if ascending else range(i + 1, nb)
+            for j in others:
+                blk = self.A.GetBlock(j, i) if transpose else self.A.GetBlock(i, j)
+                if blk is None:
+                    continue
+                tmp = np.zeros(len(ri))
+                (blk.matvecT if transpose else blk.matvec)(1.0, np.ascontiguousarray(self._blk(x, j)), 0.0, tmp)
+                ri -= tmp
+            xi = np.zeros(len(ri))
+            inv = self.inv_ops[i]
+            (inv.MultTranspose if transpose and hasattr(inv, "MultTranspose") else inv.Mult)(ri, xi)
+            self._blk(x, i)[:] = xi
+
+    def Mult(self, rhs, sol):
+        self._run(rhs, sol, lambda r, x: self._sweep(r, x, False))
+
+    def MultTranspose(self, rhs, sol):
+        self._run(rhs, sol, lambda r, x: self._sweep(r, x, True))
+
+
+class OBlock2x2LDU(_OBlockSolverBase):
+    """Block2x2LDUInverseOperator::Mult (ParELAG_Block2x2LDUInverseOperator.cpp:73-137)."""
+
+    def __init__(self, A, invA00_1, invA00_2, invA00_3, invS, damping=1.0):
+        super().__init__(A, [invA00_1, invA00_2, invA00_3, invS])
+        self.damping = damping
+        self.iterative_mode = False                                # constructed as a preconditioner (:31)
+
+    def Mult(self, rhs, sol):
+        i1, i2, i3, iS = self.inv_ops
+
+        def solve(r, c):
+            r = np.array(r, dtype=np.float64)
+            r0, r1 = self._blk(r, 0), self._blk(r, 1)
+            n0, n1 = len(r0), len(r1)
+            t0 = np.zeros(n0)
+            i2.Mult(np.ascontiguousarray(r0), t0)                  # du~ = A_2^-1 r_f
+            t1 = np.zeros(n1)
+            self.A.GetBlock(1, 0).matvec(1.0, t0, 0.0, t1)
+            r1 -= t1                                               # r_g - A10 du~
+            c1 = np.zeros(n1)
+            iS.Mult(np.ascontiguousarray(r1), c1)                  # dp
+            c0 = np.zeros(n0)
+            self.A.GetBlock(0, 1).matvec(1.0, c1, 0.0, c0)         # A01 dp
+            t0 = np.zeros(n0)
+            i3.Mult(c0, t0)                                        # A_3^-1 A01 dp
+            c0 = np.zeros(n0)
+            i1.Mult(np.ascontiguousarray(r0), c0)                  # du^
+            c0 -= t0
+            self._blk(c, 0)[:] = c0
+            self._blk(c, 1)[:] = c1
+            if self.damping != 1.0:
+                c *= self.damping
+        self._run(rhs, sol, solve)
 
 
 # ---- dense coarse solve and the all-C serial hierarchy ---------------------------------------------

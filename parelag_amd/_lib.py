@@ -52,6 +52,11 @@ class AMGeOptions(C.Structure):
                 ("cheby_fraction", _d), ("coarse_kind", _i), ("coarse_iters", _i), ("use_graph", _i), ("reorder", _i)]
 
 
+class BlockedOptions(C.Structure):
+    _fields_ = [("block_smoother", _i), ("inv_a00", AMGeOptions), ("inv_a11", AMGeOptions), ("s_type", _i), ("alpha", _d),
+                ("use_negative_s", _i), ("damping", _d), ("coarse_kind", _i), ("use_graph", _i)]
+
+
 # name -> argtypes (restype is int status unless listed in _RESTYPES)
 _SIGNATURES = {
     "elag_hip_init": [_i],
@@ -102,7 +107,7 @@ _SIGNATURES = {
     "elag_hip_smoother_apply": [_p, _p, _p, _i, _i, _i],
     "elag_hip_smoother_destroy": [_p],
     "elag_hip_coarse_create": [C.POINTER(_p), _p, _i, _i],
-    "elag_hip_coarse_create_replicated": [C.POINTER(_p), _p, _p],
+    "elag_hip_coarse_create_replicated": [C.POINTER(_p), _p, _p, C.c_int],
     "elag_hip_coarse_create_from_hierarchy": [C.POINTER(_p), _p, _i],
     "elag_hip_coarse_apply": [_p, _p, _p, _i],
     "elag_hip_coarse_destroy": [_p],
@@ -121,6 +126,16 @@ _SIGNATURES = {
     "elag_hip_hierarchy_get_ordering": [_p, _i, _p],
     "elag_hip_hierarchy_get_operator": [_p, _i, C.POINTER(_p)],
     "elag_hip_hierarchy_get_smoother": [_p, _i, C.POINTER(_p)],
+    "elag_hip_blockop_create": [C.POINTER(_p), _i, _i, _p, _p],
+    "elag_hip_blockop_set_block": [_p, _i, _i, _p],
+    "elag_hip_blockop_get_block": [_p, _i, _i, C.POINTER(_p)],
+    "elag_hip_blockop_monolithic": [_p, C.POINTER(_p)],
+    "elag_hip_blockop_mult": [_p, _i, _d, _p, _d, _p, _i],
+    "elag_hip_blockop_destroy": [_p],
+    "elag_hip_schur_complement": [_p, _i, _d, _i, C.POINTER(_p)],
+    "elag_hip_block_smoother_create": [C.POINTER(_p), _p, _i, _i, C.POINTER(_p), _d],
+    "elag_hip_blocked_default_options": [C.POINTER(BlockedOptions)],
+    "elag_hip_hierarchy_build_blocked": [C.POINTER(_p), _p, _i, C.POINTER(_p), _p, C.POINTER(BlockedOptions)],
     "elag_hip_time_kernel": [_p, _p, _i, _i, _p, _p, _dp],
     "elag_hip_time_hierarchy": [_p, _p, _p, _i, _dp],
 }

@@ -1,0 +1,136 @@
+// Dense inverse of a small general (indefinite) operator on the device: Gauss-Jordan with partial pivoting on the
+// augmented matrix [A | I].  Used for the coarsest saddle-point operator of the blocked (Darcy) hierarchy, where the
+// reference's XML names a "Direct" solver (SuperLU; src/linalg/factories/ParELAG_DirectSolverFactory.cpp) or a short
+// GMRES; the SPD single-form hierarchies keep the Cholesky path of smoother.hip.
+//
+// One elimination step = 4 small launches (pivot search, row swap + scale, column save, rank-1 update); n steps.  The
+// work is n * (n x 2n) updates, i.e. ~13 GFLOP at n = 1500: tens of milliseconds, once per hierarchy.
+#include "kernels.hpp"
+
+namespace elag {
+namespace k {
+
+namespace {
+
+constexpr int kB = 256;
+
+__global__ void dense_scatter_kernel(int n, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
+                                     double *__restrict__ M, int ld)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    for (int k = I[r]; k < I[r + 1]; k++) M[(size_t)r * ld + J[k]] += a[k];   // duplicates (if any) add up, one thread per row
+    M[(size_t)r * ld + n + r] = 1.0;
+}
+
+// argmax_i>=k |M[i][k]|, lowest index on ties (deterministic)
+__global__ void __launch_bounds__(1024) gj_pivot_kernel(int n, int k, const double *__restrict__ M, int ld, int *__restrict__ piv,
+                                                        double *__restrict__ pivval)
+{
+    __shared__ double sv[1024];
+    __shared__ int si[1024];
+    double best = -1.0;
+    int bi = n;
+    for (int i = k + (int)threadIdx.x; i < n; i += 1024) {
+        const double v = fabs(M[(size_t)i * ld + k]);
+        if (v > best) { best = v; bi = i; }
+    }
+    sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            const double ov = sv[threadIdx.x + s];
+            const int oi = si[threadIdx.x + s];
+            if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int p = si[0] < n ? si[0] : k;
+        piv[0] = p;
+        pivval[0] = M[(size_t)p * ld + k];
+    }
+}
+
+__global__ void gj_swap_scale_kernel(int k, double *__restrict__ M, int ld, const int *__restrict__ piv, const double *__restrict__ pivval,
+                                     int *__restrict__ singular)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ld) return;
+    const int p = piv[0];
+    const double pv = pivval[0];
+    if (pv == 0.0 || pv != pv) { if (c == 0) atomicAdd(singular, 1); return; }
+    const double tk = M[(size_t)k * ld + c], tp = M[(size_t)p * ld + c];
+    if (p != k) M[(size_t)p * ld + c] = tk;
+    M[(size_t)k * ld + c] = tp / pv;
+}
+
+__global__ void gj_savecol_kernel(int n, int k, const double *__restrict__ M, int ld, double *__restrict__ colk)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) colk[i] = (i == k) ? 0.0 : M[(size_t)i * ld + k];
+}
+
+// M[i][c] -= colk[i] * M[k][c] for every row i != k (colk[k] == 0 makes row k a no-op)
+__global__ void gj_eliminate_kernel(int n, int k, double *__restrict__ M, int ld, const double *__restrict__ colk)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i0 = blockIdx.y * 8;
+    if (c >= ld) return;
+    const double mk = M[(size_t)k * ld + c];
+    if (mk == 0.0) return;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int i = i0 + q;
+        if (i < n) {
+            const double f = colk[i];
+            if (f != 0.0) M[(size_t)i * ld + c] -= f * mk;
+        }
+    }
+}
+
+__global__ void gj_extract_kernel(int n, const double *__restrict__ M, int ld, double *__restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c < n) out[(size_t)r * n + c] = M[(size_t)r * ld + n + c];
+}
+
+}  // namespace
+
+void dense_inverse_general(const DevCSR &A, double *Minv)
+{
+    hipStream_t st = ctx().stream;
+    const int n = A.nrows, ld = 2 * n;
+    ELAG_REQUIRE(n == A.ncols, "dense inverse needs a square matrix");
+    if (n == 0) return;
+    double *M = dev_alloc<double>((size_t)n * ld);
+    try {
+        Temp<int> piv(1), singular(1);
+        Temp<double> pivval(1), colk((size_t)n);
+        ELAG_HIP_CHECK(hipMemsetAsync(M, 0, sizeof(double) * (size_t)n * ld, st));
+        ELAG_HIP_CHECK(hipMemsetAsync(singular.p, 0, sizeof(int), st));
+        hipLaunchKernelGGL(dense_scatter_kernel, dim3((n + kB - 1) / kB), dim3(kB), 0, st, n, (const int *)A.I, (const int *)A.J,
+                           (const double *)A.a, M, ld);
+        const dim3 gcol((ld + kB - 1) / kB), grow((n + kB - 1) / kB), gel((ld + kB - 1) / kB, (n + 7) / 8);
+        for (int k = 0; k < n; k++) {
+            hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(1024), 0, st, n, k, (const double *)M, ld, piv.p, pivval.p);
+            hipLaunchKernelGGL(gj_swap_scale_kernel, gcol, dim3(kB), 0, st, k, M, ld, (const int *)piv.p, (const double *)pivval.p, singular.p);
+            hipLaunchKernelGGL(gj_savecol_kernel, grow, dim3(kB), 0, st, n, k, (const double *)M, ld, colk.p);
+            hipLaunchKernelGGL(gj_eliminate_kernel, gel, dim3(kB), 0, st, n, k, M, ld, (const double *)colk.p);
+        }
+        hipLaunchKernelGGL(gj_extract_kernel, dim3((n + kB - 1) / kB, n), dim3(kB), 0, st, n, (const double *)M, ld, Minv);
+        ELAG_LAUNCH_CHECK();
+        int bad = 0;
+        ELAG_HIP_CHECK(hipMemcpyAsync(&bad, singular.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        if (bad) fail(ELAG_HIP_ERR_NUMERIC, "coarse operator is singular (%d zero pivots in the dense LU)", bad);
+    } catch (...) {
+        dev_free(M);
+        throw;
+    }
+    dev_free(M);
+}
+
+}  // namespace k
+}  // namespace elag

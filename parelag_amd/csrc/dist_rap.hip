@@ -328,6 +328,28 @@ static void to_global(ParCSR &M, DevCSR &out)
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
 }
 
+void parcsr_to_global(ParCSR &M, DevCSR &out) { to_global(M, out); }
+void csr_hstack(const DevCSR &X, const int *mapX, int offX, const DevCSR *Y, const int *mapY, int offY, int ncols_out, bool sort, DevCSR &out)
+{
+    concat_rows(X, mapX, offX, Y, mapY, offY, ncols_out, sort, out);
+}
+void csr_vstack(const DevCSR &X, const DevCSR &Y, DevCSR &out) { vstack(X, Y, out); }
+std::vector<double> comm_allgather_scalar(double v) { return allgather_scalar(v); }
+
+ParCSR *parcsr_clone(ParCSR &M)
+{
+    std::unique_ptr<ParCSR> C(new ParCSR());
+    k::csr_copy(M.diag, C->diag);
+    if (M.offd.nnz) k::csr_copy(M.offd, C->offd);
+    else C->offd.set_empty(M.nrows(), M.offd.ncols);
+    C->col_map_offd = M.col_map_offd;
+    C->first_row = M.first_row; C->first_col = M.first_col; C->global_rows = M.global_rows; C->global_cols = M.global_cols;
+    C->send_procs = M.send_procs; C->send_starts = M.send_starts; C->send_elmts = M.send_elmts;
+    C->recv_procs = M.recv_procs; C->recv_starts = M.recv_starts;
+    C->finish_setup();
+    return C.release();
+}
+
 // hypre_ParCSRMatrixAdd2 across ranks (parcsr-add.c:199-245: merge diag+offd, add, GenerateDiagAndOffd)
 ParCSR *distributed_add(double a, ParCSR &A, double b, ParCSR &B)
 {

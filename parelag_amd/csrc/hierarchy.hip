@@ -45,6 +45,7 @@ struct elag_hip_hierarchy_s {
     std::vector<ParCSR *> owned_mats;
     std::vector<elag_hip_smoother_s *> owned_smoothers;
     elag_hip_coarse_s *owned_coarse = nullptr;
+    std::vector<std::function<void()>> adopted;   // destructors of objects built for this hierarchy elsewhere (blocked.hip)
     double *r0 = nullptr, *e0 = nullptr;  // solver-mode residual / correction on level 0
     // dense coarse-cycle operator: every level from dense_level down is replaced by ONE dense matrix B (the sub-cycle
     // is a linear map; B's columns are its images of the unit vectors, computed once in finalize), applied as a GEMV
@@ -60,6 +61,7 @@ struct elag_hip_hierarchy_s {
     ~elag_hip_hierarchy_s()
     {
         for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);
+        for (auto it = adopted.rbegin(); it != adopted.rend(); ++it) (*it)();
         for (auto &l : lev) { dev_free(l.resid); dev_free(l.sol); dev_free(l.alt); dev_free(l.tmp_resid); }
         dev_free(r0); dev_free(e0); dev_free(d_order0); dev_free(p_rhs); dev_free(p_sol); dev_free(Bdense);
         for (auto *s : owned_smoothers) delete s;
@@ -155,10 +157,9 @@ struct elag_hip_hierarchy_s {
             Level &F = lev[(size_t)l];
             Level &C = lev[(size_t)l + 1];
             F.G.reset(); F.S.reset(); F.fused_dinv = nullptr;
-            const RelaxSmoother *j = dynamic_cast<const RelaxSmoother *>(F.pre);
-            const RelaxSmoother *jp = dynamic_cast<const RelaxSmoother *>(F.post);
-            if (disabled || !all_local || !j || !jp || !j->dinv || j->sweeps != 1 || jp->sweeps != 1 || j->A != F.A || jp->A != F.A ||
-                j->type != jp->type || j->weight != jp->weight)
+            const double *dinv = F.pre ? F.pre->diag_scaling() : nullptr;
+            if (disabled || !all_local || !dinv || !F.post || !F.post->diag_scaling() || F.pre->A != F.A || F.post->A != F.A ||
+                !F.pre->same_scaling_as(F.post))
                 continue;
             if (F.A->offd.ncols > 0 || C.P->offd.ncols > 0 || F.A->diag.nnz >= max_nnz) continue;
             const int n = F.A->nrows();
@@ -166,7 +167,7 @@ struct elag_hip_hierarchy_s {
             // G = R - (R A) W
             DevCSR RA;
             k::csr_spgemm(*C.P->diagT, F.A->diag, RA);
-            k::csr_scale_cols(RA, j->dinv);
+            k::csr_scale_cols(RA, dinv);
             F.G.reset(new DevCSR());
             k::csr_add(1.0, *C.P->diagT, -1.0, RA, *F.G);
             // S = A P - W^-1 P
@@ -175,12 +176,12 @@ struct elag_hip_hierarchy_s {
             k::csr_copy(C.P->diag, WP);
             {
                 Temp<double> winv((size_t)n);
-                k::vec_reciprocal_scale(n, 1.0, j->dinv, winv);
+                k::vec_reciprocal_scale(n, 1.0, dinv, winv);
                 k::csr_scale_rows(WP, winv);
                 F.S.reset(new DevCSR());
                 k::csr_add(1.0, AP, -1.0, WP, *F.S);
             }
-            F.fused_dinv = j->dinv;
+            F.fused_dinv = dinv;
         }
         ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
     }
@@ -217,13 +218,13 @@ struct elag_hip_hierarchy_s {
         const int nf = (F.pre ? F.pre->flips(true) : 0) + (F.post ? F.post->flips(false) : 0);
         double *cur = (nf & 1) ? alt : sol, *oth = (nf & 1) ? sol : alt;
         // pre-smoothing (:180-184) and residual (:191-194)
-        const RelaxSmoother *jac = dynamic_cast<const RelaxSmoother *>(F.pre);
+        const double *pre_dinv = (F.pre && F.pre->A == F.A) ? F.pre->diag_scaling() : nullptr;
         // (worth it only while the level is launch-bound: the fused form gathers two vectors per entry)
-        if (jac && jac->dinv && jac->sweeps == 1 && jac->A == F.A && F.A->diag.nnz < (int64_t(1) << 20)) {
+        if (pre_dinv && F.A->diag.nnz < (int64_t(1) << 20)) {
             // one kernel: SOL = dinv .* RHS (Jacobi sweep from the zero guess) gathered on the fly as the SpMV
             // operand, tmp_resid = RHS - A SOL
             k::SpmvArgs a;
-            a.x = rhs; a.cs = jac->dinv; a.alpha = -1.0; a.f = rhs; a.gamma = 1.0; a.out = F.tmp_resid; a.out2 = cur;
+            a.x = rhs; a.cs = pre_dinv; a.alpha = -1.0; a.f = rhs; a.gamma = 1.0; a.out = F.tmp_resid; a.out2 = cur;
             par_spmv(*F.A, a);
         } else {
             if (F.pre) F.pre->apply(rhs, cur, oth, true, false);
@@ -304,6 +305,10 @@ struct elag_hip_hierarchy_s {
         ELAG_HIP_CHECK(hipGraphLaunch(exec, st));
     }
 };
+
+namespace elag {
+void hierarchy_adopt(elag_hip_hierarchy_s *H, std::function<void()> destroy) { H->adopted.push_back(std::move(destroy)); }
+}  // namespace elag
 
 extern "C" {
 
@@ -626,7 +631,7 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
             std::vector<int64_t> starts;
             ParCSR *Arep = replicate_matrix(*H->lev.back().A, &starts);
             H->owned_mats.push_back(Arep);
-            rc = elag_hip_coarse_create_replicated(&C, Arep, starts.data());
+            rc = elag_hip_coarse_create_replicated(&C, Arep, starts.data(), opt.coarse_kind);
         } else {
             rc = elag_hip_coarse_create(&C, H->lev.back().A, opt.coarse_kind, opt.coarse_iters);
         }

@@ -73,6 +73,8 @@ void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_col
 // ---- dense coarse solve ------------------------------------------------------------------------
 void dense_gemv(int nrows, int ncols, const double *M, const double *x, double *y);  // y = M x, M row-major
 void dense_transpose(int n, const double *in, double *out);                           // out = in^T (n x n)
+// Minv (n x n row-major, device) = A^-1 for a general square CSR (Gauss-Jordan, partial pivoting); throws when singular
+void dense_inverse_general(const DevCSR &A, double *Minv);
 
 }  // namespace k
 }  // namespace elag

@@ -57,6 +57,15 @@ ParCSR *distributed_transpose(ParCSR &A);
 double distributed_max_abs_diff(ParCSR &A, ParCSR &B);
 ParCSR *parcsr_from_global_columns(const DevCSR &Cg, int64_t first_row, int64_t global_rows, int64_t first_col, int ncols_local,
                                    int64_t global_cols);
+// this rank's rows with GLOBAL column ids (hypre_MergeDiagAndOffd), columns ascending
+void parcsr_to_global(ParCSR &M, DevCSR &out);
+// [X | Y] row by row; column ids: map ? map[j] : j + off; optional per-row sort
+void csr_hstack(const DevCSR &X, const int *mapX, int offX, const DevCSR *Y, const int *mapY, int offY, int ncols_out, bool sort, DevCSR &out);
+void csr_vstack(const DevCSR &X, const DevCSR &Y, DevCSR &out);
+// one double from every rank, in rank order
+std::vector<double> comm_allgather_scalar(double v);
+// deep copy (matrix, comm package, buffers)
+ParCSR *parcsr_clone(ParCSR &M);
 inline bool is_distributed(const ParCSR &M) { return M.needs_exchange() || M.global_rows != M.nrows() || M.global_cols != M.ncols(); }
 
 // Build a single-rank ParCSR from a device CSR (takes ownership of `d`).

@@ -283,12 +283,18 @@ void HiptmairSmoother::apply(const double *f, double *&cur, double *&alt, bool z
 void elag_hip_coarse_s::setup()
 {
     using namespace elag;
-    ELAG_REQUIRE(kind == 0, "coarse solver kind %d is not implemented (0 = dense Cholesky)", kind);
+    ELAG_REQUIRE(kind == 0 || kind == 1, "coarse solver kind %d is not implemented (0 = dense Cholesky, 1 = dense LU)", kind);
     ELAG_REQUIRE(!A->needs_exchange() && (A->global_rows == A->nrows() || replicated),
                  "dense coarse solve expects a rank-local operator (use elag_hip_coarse_create_replicated across ranks)");
     n = A->nrows();
     ELAG_REQUIRE(n == A->ncols(), "coarse operator must be square");
     ELAG_REQUIRE(n <= 4096, "dense coarse solve limited to 4096 dofs (got %d)", n);
+    if (kind == 1) {
+        // general (indefinite) operator: Gauss-Jordan with partial pivoting on the device (dense.hip)
+        Minv = dev_alloc<double>((size_t)n * n);
+        k::dense_inverse_general(A->diag, Minv);
+        return;
+    }
     std::vector<int> I = host_from_dev(A->diag.I, (size_t)n + 1);
     std::vector<int> J = host_from_dev(A->diag.J, (size_t)A->diag.nnz);
     std::vector<double> a = host_from_dev(A->diag.a, (size_t)A->diag.nnz);
@@ -444,7 +450,7 @@ int elag_hip_coarse_create(elag_hip_coarse_t *out, elag_hip_parcsr_t A, int kind
     });
 }
 
-int elag_hip_coarse_create_replicated(elag_hip_coarse_t *out, elag_hip_parcsr_t A_global, const int64_t *row_starts)
+int elag_hip_coarse_create_replicated(elag_hip_coarse_t *out, elag_hip_parcsr_t A_global, const int64_t *row_starts, int kind)
 {
     return guarded([&] {
         require_init();
@@ -452,7 +458,7 @@ int elag_hip_coarse_create_replicated(elag_hip_coarse_t *out, elag_hip_parcsr_t 
         const int nr = ctx().nranks, me = ctx().rank;
         ELAG_REQUIRE(row_starts[0] == 0 && row_starts[nr] == A_global->nrows(), "row_starts must cover the %d coarse rows", A_global->nrows());
         std::unique_ptr<elag_hip_coarse_s> C(new elag_hip_coarse_s());
-        C->A = A_global; C->kind = 0; C->replicated = true;
+        C->A = A_global; C->kind = kind; C->replicated = true;
         C->counts.resize((size_t)nr); C->displs.resize((size_t)nr);
         for (int r = 0; r < nr; r++) {
             ELAG_REQUIRE(row_starts[r + 1] >= row_starts[r], "row_starts must not decrease");

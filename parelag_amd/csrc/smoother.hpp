@@ -14,6 +14,11 @@ struct elag_hip_smoother_s {
     virtual void apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose) = 0;
     // number of cur/alt swaps apply() performs (lets the caller choose where the result ends up)
     virtual int flips(bool zero_guess) const = 0;
+    // non-null iff apply() is exactly  sol <- sol + W (rhs - A sol)  with W = diag(returned vector), one sweep: lets the
+    // hierarchy fold the sweep into its fused level kernels
+    virtual const double *diag_scaling() const { return nullptr; }
+    // identifies smoothers that are the same operator (same W): type/weight for the relaxations
+    virtual bool same_scaling_as(const elag_hip_smoother_s *o) const { return o == this; }
     int n() const { return A->nrows(); }
 };
 
@@ -33,6 +38,12 @@ struct RelaxSmoother : elag_hip_smoother_s {
     void compute_coefs();
     void apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose) override;
     int flips(bool zero_guess) const override;
+    const double *diag_scaling() const override { return (dinv && sweeps == 1) ? dinv : nullptr; }
+    bool same_scaling_as(const elag_hip_smoother_s *o) const override
+    {
+        const RelaxSmoother *r = dynamic_cast<const RelaxSmoother *>(o);
+        return r && r->A == A && r->type == type && r->weight == weight && r->sweeps == sweeps;
+    }
 };
 
 struct HiptmairSmoother : elag_hip_smoother_s {
@@ -48,9 +59,15 @@ struct HiptmairSmoother : elag_hip_smoother_s {
 
 }  // namespace elag
 
+struct elag_hip_hierarchy_s;
+namespace elag {
+// hands an object's destructor to the hierarchy (run, in reverse order, when the hierarchy is destroyed)
+void hierarchy_adopt(elag_hip_hierarchy_s *H, std::function<void()> destroy);
+}  // namespace elag
+
 struct elag_hip_coarse_s {
     elag::ParCSR *A = nullptr;
-    int kind = 0, n = 0;
+    int kind = 0, n = 0;   // kind 0: Cholesky (SPD), 1: LU with partial pivoting (indefinite, e.g. saddle point)
     double *Minv = nullptr;  // dense inverse, row-major n x n (device)
     // replicated mode: n = global size, this rank applies rows [my0, my0 + nloc)
     bool replicated = false;

@@ -541,6 +541,142 @@ def buildHierarchyFromDeRhamSequence(A: ParallelCSRMatrix, Ps, smoother="L1 Jaco
     return H
 
 
+# ---- blocked (saddle-point) layer ---------------------------------------------------------------------------------
+
+class MfemBlockOperator:
+    """parelag::MfemBlockOperator (src/linalg/utilities/ParELAG_MfemBlockOperator.hpp:30-135): blocks are
+    ParallelCSRMatrix handles over contiguous block vectors with the given local offsets.  On the device the blocks are
+    also merged into one ParCSR (``Monolithic()``) so that Mult is a single fused SpMV."""
+
+    def __init__(self, row_offsets, col_offsets=None):
+        self._lib = _lib.init()
+        self.row_offsets = np.ascontiguousarray(row_offsets, dtype=np.int32)
+        self.col_offsets = self.row_offsets if col_offsets is None else np.ascontiguousarray(col_offsets, dtype=np.int32)
+        h = _vp()
+        check(self._lib.elag_hip_blockop_create(C.byref(h), len(self.row_offsets) - 1, len(self.col_offsets) - 1,
+                                                _np_ptr(self.row_offsets), _np_ptr(self.col_offsets)))
+        self.h = h
+        self._blocks = {}
+
+    def GetNumBlockRows(self):
+        return len(self.row_offsets) - 1
+
+    def GetNumBlockCols(self):
+        return len(self.col_offsets) - 1
+
+    def Height(self):
+        return int(self.row_offsets[-1])
+
+    def Width(self):
+        return int(self.col_offsets[-1])
+
+    def SetBlock(self, i, j, op: ParallelCSRMatrix):
+        check(self._lib.elag_hip_blockop_set_block(self.h, int(i), int(j), op.h))
+        self._blocks[(i, j)] = op
+
+    def IsZeroBlock(self, i, j):
+        h = _vp()
+        check(self._lib.elag_hip_blockop_get_block(self.h, int(i), int(j), C.byref(h)))
+        return not h
+
+    def GetBlock(self, i, j) -> ParallelCSRMatrix:
+        return self._blocks[(i, j)]
+
+    def Monolithic(self) -> ParallelCSRMatrix:
+        h = _vp()
+        check(self._lib.elag_hip_blockop_monolithic(self.h, C.byref(h)))
+        M = ParallelCSRMatrix(h, owner=False)
+        M._keep = self
+        return M
+
+    def _mult(self, trans, x, y, alpha, beta):
+        px, lx, _k1 = _vec(x, self.Height() if trans else self.Width())
+        py, ly, _k2 = _vec(y, self.Width() if trans else self.Height(), writable=True)
+        check(self._lib.elag_hip_blockop_mult(self.h, int(trans), alpha, px, beta, py, _same_loc(lx, ly)))
+
+    def Mult(self, x, y, alpha=1.0, beta=0.0):
+        self._mult(False, x, y, alpha, beta)
+
+    def MultTranspose(self, x, y, alpha=1.0, beta=0.0):
+        self._mult(True, x, y, alpha, beta)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._lib.elag_hip_blockop_destroy(self.h)
+        except Exception:
+            pass
+
+
+SCHUR_TYPES = {"NONE": 0, "DIAGONAL": 1, "ABSROWSUM": 2}
+BLOCK_SMOOTHERS = {"Block Jacobi": 0, "Block GS": 1, "Block GS Lower": 1, "Block GS Upper": 2, "Block LDU": 3}
+
+
+def SchurComplement(op: MfemBlockOperator, s_type="DIAGONAL", alpha=1.0, negate=False) -> ParallelCSRMatrix:
+    """SchurComplementFactory::BuildOperator (ParELAG_SchurComplementFactory.cpp:36-181): A11 - alpha A10 D^-1 A01."""
+    h = _vp()
+    check(_lib.init().elag_hip_schur_complement(op.h, SCHUR_TYPES[s_type.upper()], float(alpha), int(negate), C.byref(h)))
+    return ParallelCSRMatrix(h)
+
+
+class BlockSolver(HypreSmootherWrapper):
+    """BlockDiagonalSolver / BlockTriangularSolver / Block2x2LDUInverseOperator over device smoothers.
+    ``inv_ops`` are smoother objects (HypreSmootherWrapper, HiptmairSmoother ...): one per block, or the four LDU inverses
+    {A00_1, A00_2, A00_3, S}."""
+
+    def __init__(self, op: MfemBlockOperator, inv_ops, kind="Block Jacobi", damping=1.0):
+        self._lib = _lib.init()
+        self.op, self.inv_ops = op, list(inv_ops)
+        self.A = op                       # Height() for the vector checks
+        self._owner = True
+        arr = (_vp * len(self.inv_ops))(*[s.h for s in self.inv_ops])
+        h = _vp()
+        check(self._lib.elag_hip_block_smoother_create(C.byref(h), op.h, BLOCK_SMOOTHERS[kind] if isinstance(kind, str) else int(kind),
+                                                       len(self.inv_ops), arr, float(damping)))
+        self.h = h
+        self.iterative_mode = True
+
+
+def BlockDiagonalSolver(op, inv_ops):
+    return BlockSolver(op, inv_ops, "Block Jacobi")
+
+
+def BlockTriangularSolver(op, inv_ops, triangle="Lower"):
+    return BlockSolver(op, inv_ops, "Block GS Lower" if triangle.lower().startswith("l") else "Block GS Upper")
+
+
+def Block2x2LDUInverseOperator(op, invA00_1, invA00_2, invA00_3, invS, damping=1.0):
+    return BlockSolver(op, [invA00_1, invA00_2, invA00_3, invS], "Block LDU", damping)
+
+
+def buildBlockedHierarchyFromDeRhamSequence(A: MfemBlockOperator, Ps, block_smoother="Block Jacobi",
+                                            a00_inverse="L1 Jacobi", a00_params=None, a11_inverse="L1 Jacobi", a11_params=None,
+                                            s_type="DIAGONAL", alpha=1.0, use_negative_s=True, damping=1.0,
+                                            fix_zero_rows=None, coarse_kind=1, use_graph=True) -> Hierarchy:
+    """buildBlockedHierarchyFromDeRhamSequence (Hierarchy.cpp:400-541) with the block smoother of the
+    Block2x2{Jacobi,GaussSeidel,LDU}SolverFactory on every level.  ``Ps[l][i]`` = block i of the interpolator level l+1 -> l."""
+    lib = _lib.init()
+    nb = A.GetNumBlockRows()
+    flat = [P.h for Pl in Ps for P in Pl]
+    if any(len(Pl) != nb for Pl in Ps):
+        raise ValueError("every level needs one interpolator per block")
+    arr = (_vp * max(len(flat), 1))(*flat)
+    opt = _lib.BlockedOptions()
+    check(lib.elag_hip_blocked_default_options(C.byref(opt)))
+    opt.block_smoother = BLOCK_SMOOTHERS[block_smoother]
+    opt.inv_a00 = _amge_options(lib, a00_inverse, a00_params)
+    opt.inv_a11 = _amge_options(lib, a11_inverse, a11_params)
+    opt.s_type = SCHUR_TYPES[s_type.upper()]
+    opt.alpha, opt.use_negative_s, opt.damping = float(alpha), int(use_negative_s), float(damping)
+    opt.coarse_kind, opt.use_graph = int(coarse_kind), int(use_graph)
+    fz = None if fix_zero_rows is None else np.ascontiguousarray(fix_zero_rows, dtype=np.int32)
+    h = _vp()
+    check(lib.elag_hip_hierarchy_build_blocked(C.byref(h), A.h, len(Ps), arr, _np_ptr(fz), C.byref(opt)))
+    H = Hierarchy(handle=h)
+    H._keep += [A, *[P for Pl in Ps for P in Pl]]
+    return H
+
+
 def time_kernel(A: ParallelCSRMatrix, kernel: str, x, y, reps=20, smoother: HypreSmootherWrapper | None = None) -> float:
     """mean ms per launch of a fine-level kernel ('spmv' | 'residual' | 'jacobi') by HIP events."""
     kid = {"spmv": 0, "residual": 1, "jacobi": 2}[kernel]

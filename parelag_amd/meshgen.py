@@ -426,6 +426,34 @@ class Sequence:
             ms = ms[:nlevels]
         return cls(ms)
 
+    @classmethod
+    def kuhn_cube(cls, n: int, nref: int, nlevels: int | None = None) -> "Sequence":
+        """A small synthetic base mesh for unit tests: the unit cube cut into n^3 cells of 6 Kuhn tets each (conforming),
+        refined ``nref`` times like cube456."""
+        g = np.arange(n + 1)
+        X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+        verts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1).astype(np.float64) / n
+        vid = lambda i, j, k: (i * (n + 1) + j) * (n + 1) + k
+        perms = [(0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)]
+        tets = []
+        for i in range(n):
+            for j in range(n):
+                for k in range(n):
+                    for pm in perms:
+                        c = [i, j, k]
+                        path = [vid(*c)]
+                        for ax in pm:
+                            c[ax] += 1
+                            path.append(vid(*c))
+                        tets.append(path)
+        ms = [TetMesh(verts, np.asarray(tets, dtype=np.int64))]
+        for _ in range(nref):
+            ms.append(ms[-1].refine())
+        ms = ms[::-1]
+        if nlevels is not None:
+            ms = ms[:nlevels]
+        return cls(ms)
+
     def partition(self, level: int) -> np.ndarray:
         """Element -> agglomerate map of level ``level`` (``MFEMRefinedMeshPartitioner::Partition``)."""
         return np.arange(self.meshes[level].nt, dtype=np.int32) // 8
@@ -466,3 +494,26 @@ def hdiv_problem(nref: int, nlevels: int | None = None, alpha: float = 1.0, beta
             c = seq.meshes[l + 1]
             Ps.append(eliminate_cols(interp_P2(c, m), c.boundary_marker(2)))
     return A, Ps, Ds, seq
+
+
+def darcy_problem(nref: int, nlevels: int | None = None, seq: "Sequence | None" = None):
+    """Mixed Darcy system of MultigridTestDarcy (``examples/MultigridTestDarcy.cpp:417-441``): blocks ``M`` (2-form mass),
+    ``B = W D`` (``W`` the 3-form mass, ``D`` the divergence) and ``Bt = B^T`` of ``[[M, Bt], [B, 0]]``; no essential
+    boundary labels on either form (``:479-480`` passes two empty label lists), so the true interpolators are the plain
+    ``P2`` / ``P3`` of every level.
+
+    Returns dict(M, B, Bt, Ps=[(P2_l, P3_l)], seq); P*_l maps level l+1 -> l."""
+    if seq is None:
+        seq = Sequence.cube456(nref, nlevels)
+    fine = seq.meshes[0]
+    M = fine.M2().tocsr()
+    B = (fine.M3() @ fine.D2()).tocsr()
+    for X in (M, B):
+        X.sort_indices()
+    Bt = B.T.tocsr()
+    Bt.sort_indices()
+    Ps = []
+    for l in range(len(seq.meshes) - 1):
+        f, c = seq.meshes[l], seq.meshes[l + 1]
+        Ps.append((interp_P2(c, f), interp_P3(c, f)))
+    return dict(M=M, B=B, Bt=Bt, Ps=Ps, seq=seq)

@@ -1,0 +1,303 @@
+"""Parity of the device's blocked (saddle-point) layer -- SURVEY 8f-2 -- against the oracle: MfemBlockOperator,
+SchurComplementFactory, Block Jacobi / Gauss-Seidel / LDU smoothers, the dense LU coarse solve and the blocked AMGe
+V-cycle of MultigridTestDarcy (examples/MultigridTestDarcy.cpp:417-441, darcy_example_parameters.xml)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import oracle as orc
+from tests.helpers import BLOCK2X2_FIXTURE as FX, gmres, oracle_block_solver, oracle_blocked_hierarchy
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def la():
+    from parelag_amd import linalg
+    return linalg
+
+
+def close(x, ref, tol=TOL):
+    return np.max(np.abs(np.asarray(x) - np.asarray(ref))) <= tol * max(np.max(np.abs(ref)), 1e-300)
+
+
+def device_blockop(la, blocks, offsets):
+    op = la.MfemBlockOperator(offsets)
+    for (i, j), M in blocks.items():
+        op.SetBlock(i, j, la.ParallelCSRMatrix.from_scipy(orc.csr(M)))
+    return op
+
+
+def fixture_blocks():
+    return {(0, 0): FX["M"], (0, 1): FX["Bt"], (1, 0): FX["B"], (1, 1): FX["C"]}
+
+
+@pytest.fixture(scope="module")
+def darcy_small():
+    """kuhn_cube(2) refined twice: 3 levels, 9984+4608 -> 1248+576 -> 156+72... fine enough for every code path"""
+    from parelag_amd import meshgen
+    d = meshgen.darcy_problem(0, seq=meshgen.Sequence.kuhn_cube(2, 2))
+    d["blocks"] = {(0, 0): d["M"], (0, 1): d["Bt"], (1, 0): d["B"]}
+    n0, n1 = d["M"].shape[0], d["B"].shape[0]
+    d["off"] = [0, n0, n0 + n1]
+    return d
+
+
+# ---- block operator -------------------------------------------------------------------------------------------------
+
+def test_block_operator_on_the_block2x2_fixture(la):
+    op = device_blockop(la, fixture_blocks(), [0, 4, 6])
+    assert op.GetNumBlockRows() == 2 and op.Height() == 6 and not op.IsZeroBlock(1, 1)
+    r = FX["b"].copy()
+    op.Mult(FX["x0"], r, alpha=-1.0, beta=1.0)
+    assert np.array_equal(r, FX["residual"])          # small integers: exact
+    dense = sp.bmat([[FX["M"], FX["Bt"]], [FX["B"], FX["C"]]]).toarray()
+    y = np.zeros(6)
+    op.MultTranspose(FX["x0"], y)
+    assert close(y, dense.T @ FX["x0"])
+    mono = op.Monolithic().to_scipy()
+    assert np.array_equal(mono.toarray(), dense)
+
+
+def test_block_operator_zero_block_rectangular_and_errors(la, darcy_small):
+    d = darcy_small
+    op = device_blockop(la, d["blocks"], d["off"])
+    assert op.IsZeroBlock(1, 1)
+    ref = sp.bmat([[d["M"], d["Bt"]], [d["B"], None]]).tocsr()
+    mono = op.Monolithic().to_scipy()
+    mono.sort_indices(); ref.sort_indices()
+    assert np.array_equal(mono.indptr, ref.indptr) and np.array_equal(mono.indices, ref.indices)
+    assert np.array_equal(mono.data, ref.data)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, ref.shape[1]); y = rng.uniform(-1, 1, ref.shape[0]); y0 = y.copy()
+    oop = orc.OBlockOperator(d["off"], d["off"], {k: orc.OParCSR(orc.csr(v)) for k, v in d["blocks"].items()})
+    yr = y0.copy()
+    op.Mult(x, y, alpha=0.5, beta=-2.0)
+    oop.matvec(0.5, x, -2.0, yr)
+    assert close(y, yr, 1e-12)
+    # rectangular block operator: P = blockdiag(P2, P3)
+    P2, P3 = d["Ps"][0]
+    coff = [0, P2.shape[1], P2.shape[1] + P3.shape[1]]
+    Pop = la.MfemBlockOperator(d["off"], coff)
+    Pop.SetBlock(0, 0, la.ParallelCSRMatrix.from_scipy(orc.csr(P2)))
+    Pop.SetBlock(1, 1, la.ParallelCSRMatrix.from_scipy(orc.csr(P3)))
+    xc = rng.uniform(-1, 1, coff[-1]); yf = np.zeros(d["off"][-1])
+    Pop.Mult(xc, yf)
+    assert close(yf, sp.block_diag([P2, P3]) @ xc, 1e-13)
+    yc = np.zeros(coff[-1])
+    Pop.MultTranspose(x, yc)
+    assert close(yc, sp.block_diag([P2, P3]).T @ x, 1e-13)
+    # SetBlock size check (MfemBlockOperator.cpp:107-118)
+    with pytest.raises(la._lib.ElagHipError, match="wrong size"):
+        op.SetBlock(1, 1, la.ParallelCSRMatrix.from_scipy(orc.csr(d["M"])))
+    with pytest.raises(la._lib.ElagHipError, match="out of range"):
+        op.SetBlock(2, 0, la.ParallelCSRMatrix.from_scipy(orc.csr(d["M"])))
+
+
+# ---- Schur complement -----------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("s_type", ["DIAGONAL", "ABSROWSUM"])
+@pytest.mark.parametrize("negate", [False, True])
+def test_schur_complement_matches_oracle(la, darcy_small, s_type, negate):
+    d = darcy_small
+    for blocks, off in ((fixture_blocks(), [0, 4, 6]), (d["blocks"], d["off"])):
+        op = device_blockop(la, blocks, off)
+        S = la.SchurComplement(op, s_type, alpha=0.8, negate=negate).to_scipy()
+        ref = orc.schur_complement(blocks[(0, 0)], blocks[(0, 1)], blocks[(1, 0)], blocks.get((1, 1)), s_type, 0.8)
+        ref = orc.csr(ref * (-1.0 if negate else 1.0))
+        S.sort_indices(); ref.sort_indices()
+        assert np.array_equal(S.indptr, ref.indptr) and np.array_equal(S.indices, ref.indices)
+        assert close(S.data, ref.data, 1e-13)
+    with pytest.raises(la._lib.ElagHipError, match="invalid"):
+        import ctypes
+        out = ctypes.c_void_p()
+        la._lib.check(la._lib.init().elag_hip_schur_complement(op.h, 7, 1.0, 0, ctypes.byref(out)))
+
+
+# ---- block smoothers --------------------------------------------------------------------------------------------------
+
+INNER = {
+    "l1": (dict(type=1), ("L1 Jacobi", {})),
+    "l1x2": (dict(type=1, sweeps=2, weight=0.8), ("L1 Jacobi", {"Sweeps": 2, "Damping Factor": 0.8})),
+    "cheby": (dict(type=16, order=2), ("Chebyshev", {"Cheby Poly Order": 2})),
+}
+
+
+def device_block_solver(la, blocks, off, kind, inner, s_type="DIAGONAL", alpha=1.0, use_negative_s=True, damping=1.0):
+    op = device_blockop(la, blocks, off)
+    S = la.SchurComplement(op, s_type, alpha, use_negative_s) if s_type != "NONE" else op.GetBlock(1, 1)
+    name, params = INNER[inner][1]
+    t = la.HYPRE_SMOOTHER_TYPES[name]
+    mk = lambda M: la.HypreSmootherWrapper(M, t, params)
+    if kind == "Block LDU":
+        i0 = mk(op.GetBlock(0, 0))
+        invs = [i0, i0, i0, mk(S)]
+    else:
+        invs = [mk(op.GetBlock(0, 0)), mk(S)]
+    sol = la.BlockSolver(op, invs, kind, damping)
+    sol._keep_S = S
+    eigs = None
+    if t == 16:
+        eigs = (invs[0].eig_estimate(), invs[-1].eig_estimate())
+    return sol, eigs
+
+
+@pytest.mark.parametrize("kind", ["Block Jacobi", "Block GS Lower", "Block GS Upper", "Block LDU"])
+@pytest.mark.parametrize("inner", ["l1", "l1x2", "cheby"])
+@pytest.mark.parametrize("iterative", [True, False])
+def test_block_smoothers_match_oracle(la, darcy_small, kind, inner, iterative):
+    d = darcy_small
+    sol, eigs = device_block_solver(la, d["blocks"], d["off"], kind, inner, damping=0.9 if kind == "Block LDU" else 1.0)
+    spec = INNER[inner][0]
+    osol, _op, _S = oracle_block_solver(d["blocks"], d["off"], kind=kind, a00=spec, a11=spec, eigs=eigs,
+                                       damping=0.9 if kind == "Block LDU" else 1.0)
+    sol.iterative_mode = osol.iterative_mode = iterative
+    rng = np.random.default_rng(11)
+    n = d["off"][-1]
+    b = rng.uniform(-1, 1, n); x0 = rng.uniform(-1, 1, n)
+    x, xr = x0.copy(), x0.copy()
+    sol.Mult(b, x)
+    osol.Mult(b, xr)
+    assert close(x, xr)
+    if kind.startswith("Block GS"):
+        x, xr = x0.copy(), x0.copy()
+        sol.MultTranspose(b, x)
+        osol.MultTranspose(b, xr)
+        assert close(x, xr)
+
+
+def test_block_gs_on_the_fixture_with_a11_and_positive_s(la):
+    """the 4 stored blocks of block2x2_test.cpp, "Use Negative S" = false (negative l1 norms flip the sweep's sign)"""
+    for neg in (True, False):
+        sol, _ = device_block_solver(la, fixture_blocks(), [0, 4, 6], "Block GS Lower", "l1", use_negative_s=neg)
+        osol, _o, _s = oracle_block_solver(fixture_blocks(), [0, 4, 6], kind="Block GS Lower", use_negative_s=neg)
+        x, xr = FX["x0"].copy(), FX["x0"].copy()
+        sol.Mult(FX["b"], x); osol.Mult(FX["b"], xr)
+        assert close(x, xr, 1e-13)
+
+
+def test_block_smoother_argument_checks(la, darcy_small):
+    d = darcy_small
+    op = device_blockop(la, d["blocks"], d["off"])
+    s0 = la.HypreSmootherWrapper(op.GetBlock(0, 0), 1)
+    with pytest.raises(la._lib.ElagHipError, match="one inverse per block"):
+        la.BlockSolver(op, [s0], "Block Jacobi")
+    with pytest.raises(la._lib.ElagHipError, match="wrong size"):
+        la.BlockSolver(op, [s0, s0], "Block Jacobi")
+
+
+# ---- coarse solve ---------------------------------------------------------------------------------------------------
+
+def test_dense_lu_coarse_solver(la, darcy_small):
+    d = darcy_small
+    _H, lev = oracle_blocked_hierarchy(d["blocks"], d["Ps"], kind="Block Jacobi")
+    blk = lev[-1]
+    A = sp.bmat([[blk[(0, 0)], blk[(0, 1)]], [blk[(1, 0)], None]]).tocsr()
+    Ad = la.ParallelCSRMatrix.from_scipy(orc.csr(A))
+    C = la.CoarseSolver(Ad, kind=1)
+    rng = np.random.default_rng(2)
+    b = rng.uniform(-1, 1, A.shape[0]); x = np.zeros_like(b)
+    C.Mult(b, x)
+    ref = np.linalg.solve(A.toarray(), b)
+    assert close(x, ref, 1e-10)
+    assert np.max(np.abs(A @ x - b)) <= 1e-11 * np.max(np.abs(b)) * np.linalg.cond(A.toarray()) ** 0.5
+    # needs pivoting: leading zero, and a singular matrix is reported
+    Z = sp.csr_matrix(np.array([[0., 2, 0], [1, 0, 0], [0, 0, 4]]))
+    Cz = la.CoarseSolver(la.ParallelCSRMatrix.from_scipy(orc.csr(Z)), kind=1)
+    xz = np.zeros(3); Cz.Mult(np.array([2., 3, 4]), xz)
+    assert np.allclose(xz, [3, 1, 1], atol=1e-15)
+    with pytest.raises(la._lib.ElagHipError, match="singular"):
+        la.CoarseSolver(la.ParallelCSRMatrix.from_scipy(orc.csr(sp.csr_matrix(np.array([[1., 2], [2, 4]])))), kind=1)
+    with pytest.raises(la._lib.ElagHipError, match="positive definite"):
+        la.CoarseSolver(Ad, kind=0)                  # the saddle-point operator is not SPD
+
+
+# ---- blocked hierarchy ------------------------------------------------------------------------------------------------
+
+def device_blocked_hierarchy(la, d, use_graph=True, **kw):
+    op = device_blockop(la, d["blocks"], d["off"])
+    Ps = [[la.ParallelCSRMatrix.from_scipy(orc.csr(P)) for P in Pl] for Pl in d["Ps"]]
+    return la.buildBlockedHierarchyFromDeRhamSequence(op, Ps, use_graph=use_graph, **kw), op
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("kind,inner", [("Block Jacobi", "l1"), ("Block Jacobi", "l1x2"), ("Block Jacobi", "cheby"),
+                                        ("Block GS", "l1"), ("Block GS Upper", "cheby"), ("Block LDU", "l1")])
+def test_blocked_vcycle_matches_oracle(la, darcy_small, kind, inner, use_graph):
+    d = darcy_small
+    name, params = INNER[inner][1]
+    H, _op = device_blocked_hierarchy(la, d, use_graph, block_smoother=kind, a00_inverse=name, a00_params=params,
+                                      a11_inverse=name, a11_params=params)
+    eigs = None
+    if inner == "cheby":   # inject the device's eigenvalue estimates (their own parity is tested separately)
+        eigs = []
+        for l in range(len(d["Ps"])):
+            ob = {k: orc.csr(v) for k, v in _level_blocks(d, l).items()}
+            opl = device_blockop(la, ob, [0, ob[(0, 0)].shape[0], ob[(0, 0)].shape[0] + ob[(1, 0)].shape[0]])
+            S = la.SchurComplement(opl, "DIAGONAL", 1.0, True)
+            e0 = la.HypreSmootherWrapper(opl.GetBlock(0, 0), 16, params).eig_estimate()
+            e1 = la.HypreSmootherWrapper(S, 16, params).eig_estimate()
+            eigs.append((e0, e1))
+    spec = INNER[inner][0]
+    Ho, _lev = oracle_blocked_hierarchy(d["blocks"], d["Ps"], eigs=eigs, kind="Block GS Lower" if kind == "Block GS" else kind,
+                                        a00=spec, a11=spec)
+    rng = np.random.default_rng(7)
+    n = d["off"][-1]
+    for trial in range(3):
+        b = rng.uniform(-1, 1, n)
+        x, xr = np.full(n, 3.0), np.zeros(n)
+        H.Mult(b, x)
+        Ho.Mult(b, xr)
+        assert close(x, xr, 1e-10)
+    # solver mode (iterative_mode): sol += cycle(rhs - A sol)
+    H.iterative_mode = True; Ho.preconditioner = False
+    x0 = rng.uniform(-1, 1, n); x, xr = x0.copy(), x0.copy()
+    H.Mult(b, x); Ho.Mult(b, xr)
+    assert close(x, xr, 1e-10)
+
+
+def _level_blocks(d, l):
+    blk = {k: orc.csr(v) for k, v in d["blocks"].items()}
+    for Pl in d["Ps"][:l]:
+        Pc = [orc.csr(P) for P in Pl]
+        blk = {(i, j): orc.rap(Pc[i], A, Pc[j]) for (i, j), A in blk.items()}
+    return blk
+
+
+def test_blocked_hierarchy_coarse_operators_are_the_blockwise_galerkin_products(la, darcy_small):
+    d = darcy_small
+    H, _op = device_blocked_hierarchy(la, d)
+    for l in range(len(d["Ps"]) + 1):
+        blk = _level_blocks(d, l)
+        ref = sp.bmat([[blk[(0, 0)], blk[(0, 1)]], [blk[(1, 0)], None]]).tocsr()
+        ref.sort_indices()
+        A = H.GetOperator(l).to_scipy(); A.sort_indices()
+        assert A.shape == ref.shape and np.array_equal(A.indptr, ref.indptr) and np.array_equal(A.indices, ref.indices)
+        assert close(A.data, ref.data, 1e-12)
+
+
+def test_gmres_with_the_blocked_vcycle_converges_like_the_oracle(la, darcy_small):
+    """MultigridTestDarcy's solve: GMRES preconditioned by the blocked AMGe cycle (darcy_example_parameters.xml).
+    "Use Negative S" = false keeps the Schur block's sign (S = -B D^-1 B^T is negative definite), which makes the block
+    Gauss-Seidel sweep a convergent smoother; with the factories' default (true) both the oracle and the device need
+    > 100 iterations -- the XML's own comment says as much ("This won't work super well")."""
+    d = darcy_small
+    H, op = device_blocked_hierarchy(la, d, block_smoother="Block GS", use_negative_s=False)
+    Ho, _ = oracle_blocked_hierarchy(d["blocks"], d["Ps"], kind="Block GS Lower", use_negative_s=False)
+    A = sp.bmat([[d["M"], d["Bt"]], [d["B"], None]]).tocsr()
+    n = A.shape[0]
+    b = np.concatenate([np.zeros(d["off"][1]), d["seq"].meshes[0].M3() @ np.ones(d["off"][2] - d["off"][1])])
+
+    def dev(r, z):
+        H.Mult(r, z)
+
+    def ora(r, z):
+        z[:] = 0.0
+        Ho.Mult(r, z)
+    x, it = gmres(lambda v: A @ v, dev, b, rtol=1e-8)
+    xo, ito = gmres(lambda v: A @ v, ora, b, rtol=1e-8)
+    assert abs(it - ito) <= 1 and it < 60      # (the oracle stops at 9.998e-9 on iteration 43: a threshold crossing)
+    assert np.linalg.norm(A @ x - b) <= 1e-7 * np.linalg.norm(b)
+    assert close(x, xo, 1e-6)
