@@ -54,14 +54,19 @@ def main():
     ap.add_argument("--roofline-reps", type=int, default=50)
     ap.add_argument("--roofline-only", action="store_true", help="only run the fine-level SpMV launches (for rocprofv3)")
     ap.add_argument("--smoother", default="L1 Jacobi")
-    ap.add_argument("--form", type=int, default=0, choices=[0, 2],
-                    help="0: MultigridTest0Form (H1, the BASELINE metric); 2: MultigridTest2Form (H(div), Hiptmair smoother)")
+    ap.add_argument("--form", default="0", choices=["0", "2", "darcy"],
+                    help="0: MultigridTest0Form (H1, the BASELINE metric); 2: MultigridTest2Form (H(div), Hiptmair smoother); "
+                         "darcy: MultigridTestDarcy (blocked AMGe, Block Jacobi smoother, BASELINE configs[3] on one GPU)")
+    ap.add_argument("--block-smoother", default="Block Jacobi", help="darcy: Block Jacobi | Block GS | Block GS Upper | Block LDU")
+    ap.add_argument("--positive-s", action="store_true", help='darcy: "Use Negative S" = false (sign-correct Schur block)')
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even with one rank (testing)")
     args = ap.parse_args()
+    darcy = args.form == "darcy"
+    args.form = 3 if darcy else int(args.form)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -69,6 +74,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import numpy as np
+    import scipy.sparse as sp
     from parelag_amd import _lib, linalg as la, meshgen
 
     dist = None
@@ -136,13 +142,38 @@ def main():
 
     # ---------------------------------------------------------------- V-cycle workload
     Ds = None
-    if args.form == 2:
+    if darcy:
+        if not single:
+            raise SystemExit("--form darcy is benchmarked on one GPU here (the multi-rank blocked path is covered by the tests)")
+        dar = meshgen.darcy_problem(args.refines)
+        Ps = dar["Ps"]
+        A = sp.bmat([[dar["M"], dar["Bt"]], [dar["B"], None]]).tocsr()
+    elif args.form == 2:
         if not single:
             raise SystemExit("--form 2 is a single-GPU configuration (BASELINE configs[2])")
         A, Ps, Ds, seq = meshgen.hdiv_problem(args.refines)
     else:
         A, Ps, seq = meshgen.h1_problem(args.refines)
-    if single:
+    if darcy:
+        n0, n1 = dar["M"].shape[0], dar["B"].shape[0]
+        bop = la.MfemBlockOperator([0, n0, n0 + n1])
+        for (i, j), M in {(0, 0): dar["M"], (0, 1): dar["Bt"], (1, 0): dar["B"]}.items():
+            bop.SetBlock(i, j, la.ParallelCSRMatrix.from_scipy(M))
+        dPs = [[la.ParallelCSRMatrix.from_scipy(P) for P in Pl] for Pl in Ps]
+        t0 = time.time()
+        H = la.buildBlockedHierarchyFromDeRhamSequence(bop, dPs, block_smoother=args.block_smoother, a00_inverse=args.smoother,
+                                                       a11_inverse=args.smoother, use_negative_s=not args.positive_s,
+                                                       use_graph=not args.no_graph)
+        la.synchronize()
+        setup_s = time.time() - t0
+        n_local = A.shape[0]
+        level_shapes = []
+        for l in range(len(Ps) + 1):
+            op = H.GetOperator(l)
+            pn = sum(P.shape[1] for P in Ps[l]) if l < len(Ps) else 0
+            pz = sum(P.nnz for P in Ps[l]) if l < len(Ps) else 0
+            level_shapes.append((op.Height(), op.nnz, pn, pz))
+    elif single:
         dA = la.ParallelCSRMatrix.from_scipy(A)
         dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
         dDs = [la.ParallelCSRMatrix.from_scipy(D) for D in Ds[:len(Ps)]] if Ds is not None else None
@@ -204,7 +235,20 @@ def main():
     if single and not args.no_cpu_baseline and rank == 0:
         from oracle import oracle as orc
         from tests.helpers import oracle_h1_hierarchy, oracle_hdiv_hierarchy
-        if args.form == 2:
+        if darcy:
+            from tests.helpers import oracle_blocked_hierarchy
+            kind = {"Block GS": "Block GS Lower"}.get(args.block_smoother, args.block_smoother)
+            spec = dict(type=la.HYPRE_SMOOTHER_TYPES[args.smoother])
+            Ho, _lev = oracle_blocked_hierarchy({(0, 0): dar["M"], (0, 1): dar["Bt"], (1, 0): dar["B"]}, Ps, kind=kind, a00=spec, a11=spec,
+                                                use_negative_s=not args.positive_s)
+
+            class _Hc:
+                @staticmethod
+                def apply(b, x):
+                    x[:] = 0.0
+                    Ho.Mult(b, x)
+            Hc = _Hc
+        elif args.form == 2:
             h = oracle_hdiv_hierarchy(A, Ps, Ds)
             Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], native=True, hipt=h["hipt"])
         else:
@@ -213,16 +257,19 @@ def main():
         b = np.full(A.shape[0], 2.0); xs = np.empty_like(b)
         Hc.apply(b, xs)
         cnt, t0 = 0, time.perf_counter()
+        batch = 1 if darcy else 10
         while True:
-            for _ in range(10):
+            for _ in range(batch):
                 Hc.apply(b, xs)
-            cnt += 10
+            cnt += batch
             if time.perf_counter() - t0 >= args.cpu_seconds:
                 break
         cpu_rate = cnt / (time.perf_counter() - t0)
         cpu = {"value": round(cpu_rate, 2), "unit": "V-cycles/s", "cores": 1, "kind": "port",
                "sample": f"{cnt} V-cycles of the same cube456 x{args.refines} hierarchy on one host core "
-                         f"(oracle/elag_oracle.c, -O3 -march=native; hypre/MFEM unavailable, so this is a restatement)"}
+                         + ("(oracle.OHierarchy over OBlockOperator: C kernels composed in numpy; hypre/MFEM unavailable, so this is a restatement)"
+                            if darcy else
+                            "(oracle/elag_oracle.c, -O3 -march=native; hypre/MFEM unavailable, so this is a restatement)")}
         # parity spot check of the timed operator against the baseline operator
         xd = sol.to_numpy()
         out["parity_rel_err_vs_oracle"] = float(np.max(np.abs(xd - xs)) / np.max(np.abs(xs)))
@@ -242,7 +289,8 @@ def main():
 
     if rank == 0:
         out.update({
-            "metric": f"V-cycles/sec (MultigridTest{args.form}Form cube456, Hierarchy::Mult in preconditioner mode)",
+            "metric": ("V-cycles/sec (MultigridTestDarcy cube456, blocked Hierarchy::Mult in preconditioner mode)" if darcy else
+                       f"V-cycles/sec (MultigridTest{args.form}Form cube456, Hierarchy::Mult in preconditioner mode)"),
             "value": round(args.steps / elapsed, 2),
             "unit": "V-cycles/s",
             "n_gpus": world,
@@ -256,6 +304,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": (f"MultigridTest0Form cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
                                     f"{args.smoother} 1 sweep pre/post, dense coarse solve, b=2") if args.form == 0 else
+                                   (f"MultigridTestDarcy [[M,Bt],[B,0]] (forms 2,3) cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
+                                    f"{args.block_smoother} (A00: {args.smoother}, A11: {args.smoother} on "
+                                    f"{'S' if args.positive_s else '-S'} = -+B diag(M)^-1 Bt) pre/post, dense LU coarse solve, b=2") if darcy else
                                    (f"MultigridTest2Form (H(div)) cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
                                     f"Hiptmair({args.smoother}, {args.smoother}) pre/post, dense coarse solve, b=2"),
                        "levels": [{"n": s[0], "nnz": s[1]} for s in level_shapes],
