@@ -201,10 +201,84 @@ public:
         return H;
     }
 
+    void Keep(const std::shared_ptr<void> &p) { keep_.push_back(p); }
+    void SetHeight(int n) { n0_ = n; }
+
 private:
     elag_hip_hierarchy_t h_ = nullptr;
     std::vector<std::shared_ptr<void>> keep_;
     int n0_ = 0;
 };
+
+// ---- blocked (saddle-point) layer: MfemBlockOperator, SchurComplementFactory, Block2x2 smoothers -----------------------
+class MfemBlockOperator {
+public:
+    // MfemBlockOperator(row_offsets, col_offsets) (ParELAG_MfemBlockOperator.hpp:45-66); offsets are local dof offsets
+    MfemBlockOperator(const std::vector<int> &row_offsets, const std::vector<int> &col_offsets)
+        : row_offsets_(row_offsets), col_offsets_(col_offsets), ops_((row_offsets.size() - 1) * (col_offsets.size() - 1))
+    { check(elag_hip_blockop_create(&h_, GetNumBlockRows(), GetNumBlockCols(), row_offsets_.data(), col_offsets_.data())); }
+    explicit MfemBlockOperator(const std::vector<int> &offsets) : MfemBlockOperator(offsets, offsets) {}
+    ~MfemBlockOperator() { if (h_) elag_hip_blockop_destroy(h_); }
+    MfemBlockOperator(const MfemBlockOperator &) = delete;
+    MfemBlockOperator &operator=(const MfemBlockOperator &) = delete;
+
+    int GetNumBlockRows() const { return (int)row_offsets_.size() - 1; }
+    int GetNumBlockCols() const { return (int)col_offsets_.size() - 1; }
+    int Height() const { return row_offsets_.back(); }
+    int Width() const { return col_offsets_.back(); }
+    const std::vector<int> &ViewRowOffsets() const { return row_offsets_; }
+    const std::vector<int> &ViewColumnOffsets() const { return col_offsets_; }
+    void SetBlock(int i, int j, const std::shared_ptr<ParallelCSRMatrix> &op)
+    { check(elag_hip_blockop_set_block(h_, i, j, op->Handle())); ops_[(size_t)i * GetNumBlockCols() + j] = op; }
+    bool IsZeroBlock(int i, int j) const { elag_hip_parcsr_t a = nullptr; check(elag_hip_blockop_get_block(h_, i, j, &a)); return a == nullptr; }
+    std::shared_ptr<ParallelCSRMatrix> GetBlockPtr(int i, int j) const { return ops_[(size_t)i * GetNumBlockCols() + j]; }
+    void Mult(const double *x, double *y, int loc = ELAG_HIP_HOST) const { check(elag_hip_blockop_mult(h_, 0, 1.0, x, 0.0, y, loc)); }
+    void MultTranspose(const double *x, double *y, int loc = ELAG_HIP_HOST) const { check(elag_hip_blockop_mult(h_, 1, 1.0, x, 0.0, y, loc)); }
+    elag_hip_blockop_t Handle() const { return h_; }
+
+private:
+    std::vector<int> row_offsets_, col_offsets_;
+    std::vector<std::shared_ptr<ParallelCSRMatrix>> ops_;
+    elag_hip_blockop_t h_ = nullptr;
+};
+
+// SchurComplementFactory(type, alpha).BuildOperator(op, state) (ParELAG_SchurComplementFactory.cpp:36-181)
+inline std::shared_ptr<ParallelCSRMatrix> SchurComplement(const MfemBlockOperator &op, int s_type, double alpha = 1.0, bool negate = false)
+{ elag_hip_parcsr_t s; check(elag_hip_schur_complement(op.Handle(), s_type, alpha, negate ? 1 : 0, &s)); return std::make_shared<ParallelCSRMatrix>(s); }
+
+// BlockDiagonalSolver / BlockTriangularSolver / Block2x2LDUInverseOperator (kind = ELAG_HIP_BLOCK_*)
+class BlockSolver : public HypreSmootherWrapper {
+public:
+    BlockSolver(const std::shared_ptr<MfemBlockOperator> &op, const std::vector<std::shared_ptr<HypreSmootherWrapper>> &inv_ops, int kind,
+                double damping = 1.0)
+        : op_(op), inv_(inv_ops)
+    {
+        std::vector<elag_hip_smoother_t> hs;
+        for (auto &s : inv_) hs.push_back(s->Handle());
+        check(elag_hip_block_smoother_create(&h_, op->Handle(), kind, (int)hs.size(), hs.data(), damping));
+        iterative_mode = true;   // Solver{..., IsPreconditioner = false} of the block solvers
+    }
+    int Height() const override { return op_->Height(); }
+
+private:
+    std::shared_ptr<MfemBlockOperator> op_;
+    std::vector<std::shared_ptr<HypreSmootherWrapper>> inv_;
+};
+
+// buildBlockedHierarchyFromDeRhamSequence (Hierarchy.cpp:400-541) + block smoothers + dense LU coarse solve
+inline std::unique_ptr<Hierarchy> BuildBlockedHierarchy(const std::shared_ptr<MfemBlockOperator> &A,
+                                                        const std::vector<std::vector<std::shared_ptr<ParallelCSRMatrix>>> &P,
+                                                        const elag_hip_blocked_options *opt = nullptr, const int *fix_zero_rows = nullptr)
+{
+    std::vector<elag_hip_parcsr_t> ph;
+    for (auto &lvl : P) for (auto &p : lvl) ph.push_back(p->Handle());
+    elag_hip_hierarchy_t h;
+    check(elag_hip_hierarchy_build_blocked(&h, A->Handle(), (int)P.size(), ph.data(), fix_zero_rows, opt));
+    auto H = std::make_unique<Hierarchy>(h);
+    H->Keep(A);
+    for (auto &lvl : P) for (auto &p : lvl) H->Keep(p);
+    H->SetHeight(A->Height());
+    return H;
+}
 
 }  // namespace elag_hip

@@ -186,3 +186,44 @@ def local_stiffness(mesh, elem_part: np.ndarray, rank: int, local_vertices: np.n
     sub = TetMesh(mesh.vertices, mesh.tets[elem_part == rank])
     S = sub.M0_P1_stiffness()
     return canon(S[local_vertices][:, local_vertices])
+
+
+def entity_owners(mesh, elem_part: np.ndarray, form: int) -> np.ndarray:
+    """Owner rank of every dof of a lowest-order form (0 vertices, 1 edges, 2 faces, 3 elements): the lowest rank among
+    the elements that contain the entity (the SharingMap master rule)."""
+    if form == 3:
+        return np.asarray(elem_part, dtype=np.int32).copy()
+    if form == 0:
+        return vertex_owners(mesh, elem_part)
+    mesh.build_faces()
+    conn = mesh.tet_edges if form == 1 else mesh.tet_faces
+    n = mesh.ne if form == 1 else mesh.nf
+    owner = np.full(n, np.iinfo(np.int32).max, dtype=np.int32)
+    np.minimum.at(owner, conn.reshape(-1), np.repeat(elem_part, conn.shape[1]))
+    return owner
+
+
+def distributed_darcy(dar, nparts: int):
+    """Row-block decomposition of the mixed Darcy system of ``meshgen.darcy_problem`` for ``nparts`` ranks: faces (2-form)
+    and elements (3-form) are block-numbered per level, every block and every interpolator block is split into ParCSR
+    pieces.  Returns dict(blocks={(i, j): parts}, P=[[parts of P2_l, parts of P3_l]], order=[(faces, tets) per level],
+    starts=[(faces, tets) per level])."""
+    seq = dar["seq"]
+    eparts = element_partitions(seq, nparts)
+    order, starts = [], []
+    for l, mesh in enumerate(seq.meshes):
+        o2, _n2, s2 = block_numbering(entity_owners(mesh, eparts[l], 2), nparts)
+        o3, _n3, s3 = block_numbering(entity_owners(mesh, eparts[l], 3), nparts)
+        order.append((o2, o3)); starts.append((s2, s3))
+    o2, o3 = order[0]
+    s2, s3 = starts[0]
+    glob = {(0, 0): canon(sp.csr_matrix(dar["M"])[o2][:, o2]), (0, 1): canon(sp.csr_matrix(dar["Bt"])[o2][:, o3]),
+            (1, 0): canon(sp.csr_matrix(dar["B"])[o3][:, o2])}
+    blocks = {(0, 0): split_rows(glob[(0, 0)], s2, s2), (0, 1): split_rows(glob[(0, 1)], s2, s3),
+              (1, 0): split_rows(glob[(1, 0)], s3, s2)}
+    P = []
+    for l, (P2, P3) in enumerate(dar["Ps"]):
+        (f2, f3), (c2, c3) = order[l], order[l + 1]
+        P.append([split_rows(canon(sp.csr_matrix(P2)[f2][:, c2]), starts[l][0], starts[l + 1][0]),
+                  split_rows(canon(sp.csr_matrix(P3)[f3][:, c3]), starts[l][1], starts[l + 1][1])])
+    return dict(blocks=blocks, P=P, order=order, starts=starts, global_blocks=glob)

@@ -114,6 +114,40 @@ int main()
     threw = false;
     try { HypreSmootherWrapper gs(A, 2); } catch (const std::runtime_error &) { threw = true; }  // l1-GS is CPU-only
     REQUIRE(threw);
+
+    // ---- blocked layer on the explicit 6x6 system of src/linalg/unit_test/block2x2_test.cpp:14-34 ----------------------
+    {
+        HostCSR M{4, 4, {0, 2, 5, 8, 10}, {0, 1, 0, 1, 2, 1, 2, 3, 2, 3}, {2., 1., 3., 4., 3., 3., 4., 3., 1., 2.}};
+        HostCSR Bt{4, 2, {0, 1, 3, 5, 6}, {0, 0, 1, 0, 1, 1}, {1., 1., 1., 1., 1., 1.}};
+        HostCSR B{2, 4, {0, 3, 6}, {0, 1, 2, 1, 2, 3}, {2., 1., 2., 2., 1., 2.}};
+        HostCSR C{2, 2, {0, 1, 3}, {0, 0, 1}, {3., 1., 3.}};
+        auto op = std::make_shared<MfemBlockOperator>(std::vector<int>{0, 4, 6});
+        op->SetBlock(0, 0, upload(M)); op->SetBlock(0, 1, upload(Bt)); op->SetBlock(1, 0, upload(B)); op->SetBlock(1, 1, upload(C));
+        REQUIRE(!op->IsZeroBlock(1, 1) && op->Height() == 6);
+        const double bb[6] = {2., 1., 3., 1., 4., 1.}, x0[6] = {1., 2., 3., 4., 5., 6.};
+        const double resid[6] = {-7., -30., -38., -16., -21., -37.};   // b - A x0, what the reference test prints first
+        double y[6];
+        op->Mult(x0, y);
+        for (int i = 0; i < 6; i++) REQUIRE(bb[i] - y[i] == resid[i]);
+        // Block GS (lower) with one l1-Jacobi sweep per block and S = -(C - B diag(M)^-1 Bt): closed form
+        auto S = SchurComplement(*op, ELAG_HIP_SCHUR_DIAGONAL, 1.0, true);
+        auto i0 = std::make_shared<HypreSmootherWrapper>(op->GetBlockPtr(0, 0), ELAG_HIP_SMOOTHER_L1_JACOBI);
+        auto i1 = std::make_shared<HypreSmootherWrapper>(S, ELAG_HIP_SMOOTHER_L1_JACOBI);
+        BlockSolver gs(op, {i0, i1}, ELAG_HIP_BLOCK_GS_LOWER);
+        double xs[6]; for (int i = 0; i < 6; i++) xs[i] = x0[i];
+        gs.Mult(bb, xs);
+        const double l1M[4] = {3., 10., 10., 3.};
+        double c0[4]; for (int i = 0; i < 4; i++) c0[i] = resid[i] / l1M[i];
+        // S rows: -(C - B D^-1 Bt) = [[-3 + 2/2 + 1/4 + 2/4, 1/4 + 2/4], [-1 + 2/4 + 1/4, -3 + 2/4 + 1/4 + 2/2]]
+        const double s00 = -3. + 1. + .25 + .5, s01 = .25 + .5, s10 = -1. + .5 + .25, s11 = -3. + .5 + .25 + 1.;
+        const double l1S[2] = {-(std::fabs(s00) + std::fabs(s01)), -(std::fabs(s10) + std::fabs(s11))};   // negative diagonal: sign flip
+        const double r1[2] = {resid[4] - (2. * c0[0] + c0[1] + 2. * c0[2]), resid[5] - (2. * c0[1] + c0[2] + 2. * c0[3])};
+        for (int i = 0; i < 4; i++) REQUIRE(std::fabs(xs[i] - (x0[i] + c0[i])) < 1e-13);
+        for (int i = 0; i < 2; i++) REQUIRE(std::fabs(xs[4 + i] - (x0[4 + i] + r1[i] / l1S[i])) < 1e-13);
+        threw = false;
+        try { op->SetBlock(1, 1, upload(M)); } catch (const std::runtime_error &) { threw = true; }   // size check of SetBlock
+        REQUIRE(threw);
+    }
     std::printf("HOST_MIRROR_OK\n");
     return 0;
 }
