@@ -38,6 +38,7 @@ typedef struct elag_hip_smoother_s *elag_hip_smoother_t;   /* HypreSmootherWrapp
 typedef struct elag_hip_coarse_s *elag_hip_coarse_t;       /* the Level's "CoarseSolver"                  */
 typedef struct elag_hip_hierarchy_s *elag_hip_hierarchy_t; /* parelag::Hierarchy                          */
 typedef struct elag_hip_blockop_s *elag_hip_blockop_t;     /* parelag::MfemBlockOperator                  */
+typedef struct elag_hip_krylov_s *elag_hip_krylov_t;       /* parelag::KrylovSolver / StationarySolver    */
 
 enum { ELAG_HIP_HOST = 0, ELAG_HIP_DEVICE = 1 };
 
@@ -382,6 +383,41 @@ ELAG_HIP_API int elag_hip_blocked_default_options(elag_hip_blocked_options *opt)
 ELAG_HIP_API int elag_hip_hierarchy_build_blocked(elag_hip_hierarchy_t *out, elag_hip_blockop_t A, int num_P,
                                                   const elag_hip_parcsr_t *P, const int *fix_zero_rows,
                                                   const elag_hip_blocked_options *opt);
+
+/* --------------------------------------------------------------------------------------------------
+ * Krylov shells around the V-cycle -- SURVEY 8f-4.
+ *
+ * parelag::KrylovSolver (src/linalg/solver_ops/ParELAG_KrylovSolver.cpp:23-96) wraps mfem::CGSolver / GMRESSolver /
+ * FGMRESSolver chosen by "Solver name" with "Relative tolerance", "Absolute tolerance", "Maximum iterations",
+ * "Restart size"; parelag::StationarySolver (solver_ops/ParELAG_StationarySolver.cpp:41-130) is the preconditioned
+ * Richardson loop with "Relative Tolerance" / "Absolute Tolerance" / "Maximum Iterations".  The device versions follow
+ * the MFEM 4.x iterations statement by statement (same convergence tests, final_iter / final_norm / converged), with
+ * every scalar of the recurrence kept on the device: the host enqueues iterations without reading anything back and
+ * polls a `done` flag every `check_every` iterations; kernels after convergence are predicated off, so iterate and
+ * iteration count equal the sequential algorithm's.  The preconditioner is any object of this library and is applied
+ * from the zero guess (KrylovSolver.cpp:79-83 sets iterative_mode = false on it).  A and the preconditioner are
+ * borrowed.  For a blocked system pass elag_hip_blockop_monolithic(B) as A.
+ * ------------------------------------------------------------------------------------------------ */
+enum { ELAG_HIP_KRYLOV_CG = 0, ELAG_HIP_KRYLOV_GMRES = 1, ELAG_HIP_KRYLOV_FGMRES = 2, ELAG_HIP_KRYLOV_STATIONARY = 3 };
+enum { ELAG_HIP_PREC_NONE = 0, ELAG_HIP_PREC_SMOOTHER = 1, ELAG_HIP_PREC_HIERARCHY = 2, ELAG_HIP_PREC_COARSE = 3 };
+typedef struct {
+    int solver;        /* ELAG_HIP_KRYLOV_*  ("Solver name")                       */
+    int max_iter;      /* "Maximum iterations" (default 10, KrylovSolver.cpp:92-93) */
+    double rel_tol;    /* "Relative tolerance"                                      */
+    double abs_tol;    /* "Absolute tolerance"                                      */
+    int restart;       /* "Restart size" (GMRES / FGMRES, default 50)               */
+    int check_every;   /* iterations enqueued between two reads of the done flag    */
+    int use_graph;     /* CG: replay one captured hipGraph per iteration            */
+} elag_hip_krylov_options;
+ELAG_HIP_API int elag_hip_krylov_default_options(elag_hip_krylov_options *opt);
+/* prec: elag_hip_smoother_t / elag_hip_hierarchy_t / elag_hip_coarse_t according to prec_kind, or NULL */
+ELAG_HIP_API int elag_hip_krylov_create(elag_hip_krylov_t *out, elag_hip_parcsr_t A, int prec_kind, void *prec,
+                                        const elag_hip_krylov_options *opt);
+/* mfem::IterativeSolver::Mult(b, x): iterative_mode != 0 starts from x, otherwise from zero */
+ELAG_HIP_API int elag_hip_krylov_mult(elag_hip_krylov_t K, const double *b, double *x, int iterative_mode, int loc);
+/* GetConverged / GetNumIterations / GetFinalNorm of the last Mult */
+ELAG_HIP_API int elag_hip_krylov_get_stats(elag_hip_krylov_t K, int *converged, int *final_iter, double *final_norm);
+ELAG_HIP_API int elag_hip_krylov_destroy(elag_hip_krylov_t K);
 
 /* --------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): run `reps` launches of one fine-level kernel on the compute stream

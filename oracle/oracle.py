@@ -729,6 +729,179 @@ class OBlock2x2LDU(_OBlockSolverBase):
         self._run(rhs, sol, solve)
 
 
+# ---- Krylov shells (mfem::CGSolver / GMRESSolver / FGMRESSolver, parelag::StationarySolver) -------------------------
+
+class KrylovResult:
+    def __init__(self, converged, final_iter, final_norm):
+        self.converged, self.final_iter, self.final_norm = int(converged), int(final_iter), float(final_norm)
+
+
+def mfem_cg(A_mul, prec, b, x, iterative_mode=False, rel_tol=0.0, abs_tol=0.0, max_iter=10, dot=np.dot):
+    """mfem::CGSolver::Mult (MFEM 4.x linalg/solvers.cpp [3P]; selected by KrylovSolver.cpp:44-45).  ``A_mul(v)`` returns
+    A v, ``prec(r, z)`` writes z = B r (or None)."""
+    b = _f64(b)
+    if iterative_mode:
+        r = b - A_mul(x)
+    else:
+        r = b.copy(); x[:] = 0.0
+    z = np.zeros_like(r)
+    if prec is not None:
+        prec(r, z); d = z.copy()
+    else:
+        d = r.copy()
+    nom = dot(d, r)
+    if nom < 0.0:
+        return KrylovResult(0, 0, nom)
+    r0 = max(nom * rel_tol * rel_tol, abs_tol * abs_tol)
+    if nom <= r0:
+        return KrylovResult(1, 0, np.sqrt(nom))
+    z = A_mul(d)
+    den = dot(z, d)
+    if den == 0.0:
+        return KrylovResult(0, 0, np.sqrt(nom))
+    converged, final_iter = 0, max_iter
+    i = 1
+    while True:
+        alpha = nom / den
+        x += alpha * d
+        r += (-alpha) * z
+        if prec is not None:
+            z = np.zeros_like(r); prec(r, z)
+            betanom = dot(r, z)
+        else:
+            betanom = dot(r, r)
+        if betanom < 0.0:
+            converged, final_iter = 0, i
+            break
+        if betanom <= r0:
+            converged, final_iter = 1, i
+            break
+        i += 1
+        if i > max_iter:
+            break
+        beta = betanom / nom
+        d = (z if prec is not None else r) + beta * d
+        z = A_mul(d)
+        den = dot(d, z)
+        if den == 0.0:
+            final_iter = i
+            break
+        nom = betanom
+    return KrylovResult(converged, final_iter, np.sqrt(betanom) if betanom >= 0 else float("nan"))
+
+
+def _gen_rot(dx, dy):
+    if dy == 0.0:
+        return 1.0, 0.0
+    if abs(dy) > abs(dx):
+        t = dx / dy; sn = 1.0 / np.sqrt(1.0 + t * t); return t * sn, sn
+    t = dy / dx; cs = 1.0 / np.sqrt(1.0 + t * t); return cs, t * cs
+
+
+def _app_rot(dx, dy, cs, sn):
+    return cs * dx + sn * dy, -sn * dx + cs * dy
+
+
+def _gmres_update(x, k, H, s, V):
+    y = s.copy()
+    for i in range(k, -1, -1):
+        y[i] /= H[i, i]
+        for j in range(i - 1, -1, -1):
+            y[j] -= H[j, i] * y[i]
+    for j in range(k + 1):
+        x += y[j] * V[j]
+
+
+def mfem_gmres(A_mul, prec, b, x, iterative_mode=False, rel_tol=0.0, abs_tol=0.0, max_iter=10, m=50, flexible=False, dot=np.dot):
+    """mfem::GMRESSolver::Mult (left-preconditioned) and, with ``flexible``, mfem::FGMRESSolver::Mult (right, flexible):
+    modified Gram-Schmidt Arnoldi, Givens rotations, restart every ``m`` (MFEM 4.x linalg/solvers.cpp [3P];
+    KrylovSolver.cpp:46-59)."""
+    b = _f64(b)
+    n = len(b)
+    norm = lambda v: np.sqrt(dot(v, v))
+
+    def pz(v):
+        z = np.zeros(n); prec(v, z); return z
+    if flexible or prec is None:
+        if iterative_mode:
+            r = b - A_mul(x)
+        else:
+            x[:] = 0.0; r = b.copy()
+    else:
+        if iterative_mode:
+            r = pz(b - A_mul(x))
+        else:
+            x[:] = 0.0; r = pz(b)
+    beta = norm(r)
+    final_norm = max(rel_tol * beta, abs_tol)
+    if beta <= final_norm:
+        return KrylovResult(1, 0, beta)
+    H = np.zeros((m + 1, m)); s = np.zeros(m + 1); cs = np.zeros(m + 1); sn = np.zeros(m + 1)
+    V = [None] * (m + 1); Z = [None] * (m + 1)
+    j = 1
+    while j <= max_iter:
+        V[0] = (1.0 / beta) * r
+        s[:] = 0.0; s[0] = beta
+        i = 0
+        while i < m and j <= max_iter:
+            if flexible:
+                Z[i] = pz(V[i]) if prec is not None else V[i].copy()
+                w = A_mul(Z[i])
+            elif prec is not None:
+                w = pz(A_mul(V[i]))
+            else:
+                w = A_mul(V[i])
+            for k in range(i + 1):
+                H[k, i] = dot(w, V[k])
+                w = w + (-H[k, i]) * V[k]
+            H[i + 1, i] = norm(w)
+            V[i + 1] = (1.0 / H[i + 1, i]) * w
+            for k in range(i):
+                H[k, i], H[k + 1, i] = _app_rot(H[k, i], H[k + 1, i], cs[k], sn[k])
+            cs[i], sn[i] = _gen_rot(H[i, i], H[i + 1, i])
+            H[i, i], H[i + 1, i] = _app_rot(H[i, i], H[i + 1, i], cs[i], sn[i])
+            s[i], s[i + 1] = _app_rot(s[i], s[i + 1], cs[i], sn[i])
+            resid = abs(s[i + 1])
+            if resid <= final_norm:
+                _gmres_update(x, i, H, s, Z if flexible else V)
+                return KrylovResult(1, j, resid)
+            i += 1; j += 1
+        _gmres_update(x, i - 1, H, s, Z if flexible else V)
+        r = b - A_mul(x)
+        if not flexible and prec is not None:
+            r = pz(r)
+        beta = norm(r)
+        if beta <= final_norm:
+            return KrylovResult(1, j, beta)
+    return KrylovResult(0, max_iter, beta)
+
+
+def stationary_solver(A_mul, solver, b, x, iterative_mode=False, rel_tol=0.0, abs_tol=0.0, max_iter=1, dot=np.dot):
+    """StationarySolver::Mult (src/linalg/solver_ops/ParELAG_StationarySolver.cpp:41-130)."""
+    b = _f64(b)
+    if iterative_mode:
+        r = b - A_mul(x)
+    else:
+        r = b.copy(); x[:] = 0.0
+    norm_k_1 = np.sqrt(dot(r, r))
+    its, ratio, converged, norm_k = 0, 1.0, False, norm_k_1
+    while its < max_iter:
+        its += 1
+        c = np.zeros_like(r)
+        solver(r, c)
+        x += c
+        r -= A_mul(c)
+        norm_k = np.sqrt(dot(r, r))
+        ratio *= norm_k / norm_k_1
+        if norm_k < abs_tol or ratio < rel_tol:
+            converged = True
+            break
+        if norm_k / norm_k_1 == 1.0:
+            break
+        norm_k_1 = norm_k
+    return KrylovResult(converged, its, norm_k)
+
+
 # ---- dense coarse solve and the all-C serial hierarchy ---------------------------------------------
 
 def chol_factor(A_dense):

@@ -57,6 +57,11 @@ class BlockedOptions(C.Structure):
                 ("use_negative_s", _i), ("damping", _d), ("coarse_kind", _i), ("use_graph", _i)]
 
 
+class KrylovOptions(C.Structure):
+    _fields_ = [("solver", _i), ("max_iter", _i), ("rel_tol", _d), ("abs_tol", _d), ("restart", _i), ("check_every", _i),
+                ("use_graph", _i)]
+
+
 # name -> argtypes (restype is int status unless listed in _RESTYPES)
 _SIGNATURES = {
     "elag_hip_init": [_i],
@@ -136,6 +141,11 @@ _SIGNATURES = {
     "elag_hip_block_smoother_create": [C.POINTER(_p), _p, _i, _i, C.POINTER(_p), _d],
     "elag_hip_blocked_default_options": [C.POINTER(BlockedOptions)],
     "elag_hip_hierarchy_build_blocked": [C.POINTER(_p), _p, _i, C.POINTER(_p), _p, C.POINTER(BlockedOptions)],
+    "elag_hip_krylov_default_options": [C.POINTER(KrylovOptions)],
+    "elag_hip_krylov_create": [C.POINTER(_p), _p, _i, _p, C.POINTER(KrylovOptions)],
+    "elag_hip_krylov_mult": [_p, _p, _p, _i, _i],
+    "elag_hip_krylov_get_stats": [_p, _ip, _ip, _dp],
+    "elag_hip_krylov_destroy": [_p],
     "elag_hip_time_kernel": [_p, _p, _i, _i, _p, _p, _dp],
     "elag_hip_time_hierarchy": [_p, _p, _p, _i, _dp],
 }

@@ -308,6 +308,13 @@ struct elag_hip_hierarchy_s {
 
 namespace elag {
 void hierarchy_adopt(elag_hip_hierarchy_s *H, std::function<void()> destroy) { H->adopted.push_back(std::move(destroy)); }
+void hierarchy_apply_raw(elag_hip_hierarchy_s *H, const double *rhs, double *sol, bool precond)
+{
+    ELAG_REQUIRE(H->finalized, "Hierarchy::Mult before Finalize()");
+    H->run(rhs, sol, precond);
+}
+bool hierarchy_is_local(const elag_hip_hierarchy_s *H) { return H->all_local; }
+int hierarchy_height(const elag_hip_hierarchy_s *H) { return (H->reordered ? H->A_user : H->lev[0].A)->nrows(); }
 }  // namespace elag
 
 extern "C" {

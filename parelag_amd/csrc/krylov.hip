@@ -1,0 +1,628 @@
+// Krylov shells around the V-cycle, resident on the device.
+//
+// Reference: parelag::KrylovSolver (src/linalg/solver_ops/ParELAG_KrylovSolver.cpp:23-96) is a thin wrapper that picks
+// mfem::CGSolver / GMRESSolver / FGMRESSolver by "Solver name", sets iterative_mode = false on solver and
+// preconditioner and forwards "Relative tolerance" / "Absolute tolerance" / "Maximum iterations" / "Restart size";
+// parelag::StationarySolver::Mult (solver_ops/ParELAG_StationarySolver.cpp:41-130) is the preconditioned Richardson loop.
+// The iterations themselves live in MFEM (linalg/solvers.cpp, third party, not in the reference tree); they are restated
+// here from the published MFEM 4.x algorithms, statement by statement (same order of operations, same tests, same
+// final_iter / final_norm / converged bookkeeping).
+//
+// GPU design: nothing in the loop goes back to the host.  Every scalar of the recurrences (nom, den, alpha, beta, the
+// Hessenberg matrix, the Givens rotations) lives in a small device state block; one-thread "scalar" kernels advance the
+// recurrences and take the reference's branches, vector kernels read their coefficients from that block and are
+// predicated on its `done` flag.  The host enqueues iterations blindly (CG: one captured hipGraph per iteration) and
+// only polls the flag every `check_every` iterations; once `done` is set the remaining enqueued kernels are no-ops, so
+// the iterate and the iteration count are exactly those of the reference's sequential loop.
+#include <cmath>
+
+#include "comm.hpp"
+#include "smoother.hpp"
+#include "staging.hpp"
+
+using namespace elag;
+
+namespace {
+
+constexpr int kB = 256;
+inline unsigned g1(long long n) { return (unsigned)std::max<long long>(1, (n + kB - 1) / kB); }
+
+enum { S_NOM, S_DEN, S_BETANOM, S_R0, S_ALPHA, S_BETA, S_TMP, S_FINAL_NORM, S_GBETA, S_THRESH, S_NORMK1, S_RATIO, S_COUNT = 16 };
+enum { F_DONE, F_CONVERGED, F_FINAL_ITER, F_ITER, F_PENDING, F_COUNT = 8 };
+
+struct KState {
+    double sc[S_COUNT];
+    int fl[F_COUNT];
+};
+
+// ---- CG scalar kernels (mfem::CGSolver::Mult) --------------------------------------------------------------------------
+__global__ void cg_init1_kernel(KState *st, double rel_tol, double abs_tol, int max_iter)
+{
+    const double nom = st->sc[S_TMP];
+    st->sc[S_NOM] = nom;
+    st->sc[S_BETANOM] = nom;
+    st->fl[F_DONE] = 0; st->fl[F_CONVERGED] = 0; st->fl[F_FINAL_ITER] = max_iter; st->fl[F_ITER] = 1;
+    if (nom < 0.0) {   // "PCG: The preconditioner is not positive definite."
+        st->fl[F_DONE] = 1; st->fl[F_FINAL_ITER] = 0; st->sc[S_FINAL_NORM] = nom;
+        return;
+    }
+    const double r0 = fmax(nom * rel_tol * rel_tol, abs_tol * abs_tol);
+    st->sc[S_R0] = r0;
+    if (nom <= r0) { st->fl[F_DONE] = 1; st->fl[F_CONVERGED] = 1; st->fl[F_FINAL_ITER] = 0; st->sc[S_FINAL_NORM] = sqrt(nom); }
+}
+
+__global__ void cg_init2_kernel(KState *st)
+{
+    if (st->fl[F_DONE]) return;
+    const double den = st->sc[S_TMP];
+    st->sc[S_DEN] = den;
+    if (den == 0.0) { st->fl[F_DONE] = 1; st->fl[F_FINAL_ITER] = 0; st->sc[S_FINAL_NORM] = sqrt(st->sc[S_NOM]); return; }
+    st->sc[S_ALPHA] = st->sc[S_NOM] / den;
+}
+
+__global__ void cg_step1_kernel(KState *st, int max_iter)
+{
+    if (st->fl[F_DONE]) return;
+    const double betanom = st->sc[S_TMP];
+    st->sc[S_BETANOM] = betanom;
+    st->sc[S_FINAL_NORM] = sqrt(betanom);
+    int i = st->fl[F_ITER];
+    if (betanom < 0.0) { st->fl[F_DONE] = 1; st->fl[F_FINAL_ITER] = i; return; }
+    if (betanom <= st->sc[S_R0]) { st->fl[F_DONE] = 1; st->fl[F_CONVERGED] = 1; st->fl[F_FINAL_ITER] = i; return; }
+    if (++i > max_iter) { st->fl[F_DONE] = 1; st->fl[F_ITER] = i; return; }   // final_iter stays max_iter
+    st->fl[F_ITER] = i;
+    st->sc[S_BETA] = betanom / st->sc[S_NOM];
+}
+
+__global__ void cg_step2_kernel(KState *st)
+{
+    if (st->fl[F_DONE]) return;
+    const double den = st->sc[S_TMP];
+    st->sc[S_DEN] = den;
+    if (den == 0.0) { st->fl[F_DONE] = 1; st->fl[F_FINAL_ITER] = st->fl[F_ITER]; return; }
+    st->sc[S_NOM] = st->sc[S_BETANOM];
+    st->sc[S_ALPHA] = st->sc[S_NOM] / den;
+}
+
+// x += alpha d ; r -= alpha z
+__global__ void cg_update_kernel(int n, const KState *__restrict__ st, double *__restrict__ x, const double *__restrict__ d,
+                                 double *__restrict__ r, const double *__restrict__ z)
+{
+    if (st->fl[F_DONE]) return;
+    const double alpha = st->sc[S_ALPHA];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { x[i] = x[i] + alpha * d[i]; r[i] = r[i] + (-alpha) * z[i]; }
+}
+
+// d = src + beta d
+__global__ void cg_dir_kernel(int n, const KState *__restrict__ st, const double *__restrict__ src, double *__restrict__ d)
+{
+    if (st->fl[F_DONE]) return;
+    const double beta = st->sc[S_BETA];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = src[i] + beta * d[i];
+}
+
+// ---- GMRES / FGMRES (mfem::GMRESSolver::Mult, FGMRESSolver::Mult) -------------------------------------------------------
+// hs layout: H column-major (m+1) x m, then s, cs, sn, y (m+1 each)
+__device__ inline double &Hm(double *hs, int m, int k, int i) { return hs[(size_t)i * (m + 1) + k]; }
+
+__global__ void gmres_init_kernel(KState *st, double rel_tol, double abs_tol, int max_iter)
+{
+    const double beta = sqrt(st->sc[S_TMP]);
+    st->sc[S_GBETA] = beta;
+    st->fl[F_DONE] = 0; st->fl[F_CONVERGED] = 0; st->fl[F_FINAL_ITER] = max_iter; st->fl[F_PENDING] = -1;
+    const double thr = fmax(rel_tol * beta, abs_tol);
+    st->sc[S_THRESH] = thr;
+    st->sc[S_FINAL_NORM] = beta;
+    if (beta <= thr) { st->fl[F_DONE] = 1; st->fl[F_CONVERGED] = 1; st->fl[F_FINAL_ITER] = 0; }
+}
+
+__global__ void gmres_start_cycle_kernel(KState *st, double *hs, int m)
+{
+    if (st->fl[F_DONE]) return;
+    double *s = hs + (size_t)m * (m + 1);
+    for (int k = 0; k <= m; k++) s[k] = 0.0;
+    s[0] = st->sc[S_GBETA];
+}
+
+// dst = src / sc[idx]
+__global__ void scale_inv_kernel(int n, const KState *__restrict__ st, int idx, const double *__restrict__ src, double *__restrict__ dst)
+{
+    if (st->fl[F_DONE]) return;
+    const double f = 1.0 / st->sc[idx];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = f * src[i];
+}
+
+// H(k,i) = tmp ; w -= tmp v_k
+__global__ void gmres_orth_kernel(int n, const KState *__restrict__ st, double *__restrict__ hs, int m, int k, int i, double *__restrict__ w,
+                                  const double *__restrict__ v)
+{
+    if (st->fl[F_DONE]) return;
+    const double h = st->sc[S_TMP];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) Hm(hs, m, k, i) = h;
+    if (t < n) w[t] = w[t] + (-h) * v[t];
+}
+
+__global__ void gmres_norm_kernel(KState *st, double *hs, int m, int i)
+{
+    if (st->fl[F_DONE]) return;
+    const double nw = sqrt(st->sc[S_TMP]);
+    Hm(hs, m, i + 1, i) = nw;
+    st->sc[S_BETA] = nw;   // divisor of the next basis vector
+}
+
+__device__ inline void gen_rot(double dx, double dy, double &cs, double &sn)
+{
+    if (dy == 0.0) { cs = 1.0; sn = 0.0; }
+    else if (fabs(dy) > fabs(dx)) { const double t = dx / dy; sn = 1.0 / sqrt(1.0 + t * t); cs = t * sn; }
+    else { const double t = dy / dx; cs = 1.0 / sqrt(1.0 + t * t); sn = t * cs; }
+}
+__device__ inline void app_rot(double &dx, double &dy, double cs, double sn)
+{
+    const double t = cs * dx + sn * dy;
+    dy = -sn * dx + cs * dy;
+    dx = t;
+}
+__device__ inline void backsolve(double *hs, int m, int k)   // Update(): y = s; back substitution with H(0..k, 0..k)
+{
+    double *s = hs + (size_t)m * (m + 1), *y = s + 3 * (m + 1);
+    for (int q = 0; q <= m; q++) y[q] = s[q];
+    for (int i = k; i >= 0; i--) {
+        y[i] /= Hm(hs, m, i, i);
+        for (int j = i - 1; j >= 0; j--) y[j] -= Hm(hs, m, j, i) * y[i];
+    }
+}
+
+__global__ void gmres_givens_kernel(KState *st, double *hs, int m, int i, int j, int step_id)
+{
+    if (st->fl[F_DONE]) return;
+    double *s = hs + (size_t)m * (m + 1), *cs = s + (m + 1), *sn = cs + (m + 1);
+    for (int k = 0; k < i; k++) app_rot(Hm(hs, m, k, i), Hm(hs, m, k + 1, i), cs[k], sn[k]);
+    gen_rot(Hm(hs, m, i, i), Hm(hs, m, i + 1, i), cs[i], sn[i]);
+    app_rot(Hm(hs, m, i, i), Hm(hs, m, i + 1, i), cs[i], sn[i]);
+    app_rot(s[i], s[i + 1], cs[i], sn[i]);
+    const double resid = fabs(s[i + 1]);
+    if (resid <= st->sc[S_THRESH]) {
+        backsolve(hs, m, i);
+        st->fl[F_PENDING] = step_id;   // the update kernel of this step applies x += sum_{q<=i} y_q v_q
+        st->sc[S_FINAL_NORM] = resid; st->fl[F_FINAL_ITER] = j; st->fl[F_CONVERGED] = 1; st->fl[F_DONE] = 1;
+    }
+}
+
+__global__ void gmres_restart_backsolve_kernel(KState *st, double *hs, int m, int k, int step_id)
+{
+    if (st->fl[F_DONE]) return;
+    backsolve(hs, m, k);
+    st->fl[F_PENDING] = step_id;
+}
+
+// x += sum_{q < count} y_q V_q    (runs only for the step that set F_PENDING; `done` may already be set by that step)
+__global__ void gmres_update_kernel(int n, const KState *__restrict__ st, int step_id, const double *__restrict__ hs, int m, int count,
+                                    const double *__restrict__ V, double *__restrict__ x)
+{
+    if (st->fl[F_PENDING] != step_id) return;
+    const double *y = hs + (size_t)m * (m + 1) + 3 * (m + 1);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double acc = x[t];
+    for (int q = 0; q < count; q++) acc = acc + y[q] * V[(size_t)q * n + t];
+    x[t] = acc;
+}
+
+__global__ void gmres_restart_norm_kernel(KState *st, int j)
+{
+    if (st->fl[F_DONE]) return;
+    const double beta = sqrt(st->sc[S_TMP]);
+    st->sc[S_GBETA] = beta;
+    st->sc[S_FINAL_NORM] = beta;
+    if (beta <= st->sc[S_THRESH]) { st->fl[F_FINAL_ITER] = j; st->fl[F_CONVERGED] = 1; st->fl[F_DONE] = 1; }
+}
+
+// ---- stationary (StationarySolver::Mult) --------------------------------------------------------------------------------
+__global__ void stat_init_kernel(KState *st, int max_iter)
+{
+    st->sc[S_NORMK1] = sqrt(st->sc[S_TMP]);
+    st->sc[S_RATIO] = 1.0;
+    st->sc[S_FINAL_NORM] = st->sc[S_NORMK1];
+    st->fl[F_DONE] = 0; st->fl[F_CONVERGED] = 0; st->fl[F_FINAL_ITER] = 0; st->fl[F_ITER] = 0;
+    (void)max_iter;
+}
+
+__global__ void stat_step_kernel(KState *st, double rel_tol, double abs_tol)
+{
+    if (st->fl[F_DONE]) return;
+    const double nk = sqrt(st->sc[S_TMP]), nk1 = st->sc[S_NORMK1];
+    st->fl[F_ITER] += 1;
+    st->fl[F_FINAL_ITER] = st->fl[F_ITER];
+    st->sc[S_RATIO] *= nk / nk1;
+    st->sc[S_FINAL_NORM] = nk;
+    if (nk < abs_tol || st->sc[S_RATIO] < rel_tol) { st->fl[F_CONVERGED] = 1; st->fl[F_DONE] = 1; return; }
+    if (nk / nk1 == 1.0) { st->fl[F_DONE] = 1; return; }   // "Computed a zero correction! Stopping..."
+    st->sc[S_NORMK1] = nk;
+}
+
+// sol += c ; (pred)
+__global__ void add_pred_kernel(int n, const KState *__restrict__ st, double *__restrict__ x, const double *__restrict__ c)
+{
+    if (st->fl[F_DONE]) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = x[i] + c[i];
+}
+__global__ void sub_pred_kernel(int n, const KState *__restrict__ st, double *__restrict__ r, const double *__restrict__ t)
+{
+    if (st->fl[F_DONE]) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) r[i] = r[i] - t[i];
+}
+
+}  // namespace
+
+struct elag_hip_krylov_s {
+    ParCSR *A = nullptr;
+    int solver = ELAG_HIP_KRYLOV_CG;
+    int max_iter = 10, restart = 50, check_every = 8;
+    double rel_tol = 0.0, abs_tol = 0.0;
+    bool use_graph = true;
+    // preconditioner
+    int prec_kind = ELAG_HIP_PREC_NONE;
+    elag_hip_smoother_s *psm = nullptr;
+    elag_hip_hierarchy_s *phier = nullptr;
+    elag_hip_coarse_s *pcoarse = nullptr;
+    // device state
+    KState *st = nullptr;
+    int *h_flags = nullptr;       // pinned mirror of st->fl
+    double *h_sc = nullptr;       // pinned mirror of st->sc
+    double *x = nullptr, *r = nullptr, *z = nullptr, *d = nullptr, *w = nullptr, *scr = nullptr;
+    double *V = nullptr, *Z = nullptr, *hs = nullptr;
+    hipGraphExec_t cg_iter = nullptr;
+    // results of the last Mult
+    int converged = 0, final_iter = 0;
+    double final_norm = 0.0;
+
+    int n() const { return A->nrows(); }
+    bool distributed() const { return is_distributed(*A); }
+    bool has_prec() const { return prec_kind != ELAG_HIP_PREC_NONE; }
+
+    ~elag_hip_krylov_s()
+    {
+        if (cg_iter) (void)hipGraphExecDestroy(cg_iter);
+        dev_free(x); dev_free(r); dev_free(z); dev_free(d); dev_free(w); dev_free(scr); dev_free(V); dev_free(Z); dev_free(hs);
+        if (st) (void)hipFree(st);
+        if (h_flags) (void)hipHostFree(h_flags);
+        if (h_sc) (void)hipHostFree(h_sc);
+    }
+
+    void setup()
+    {
+        const size_t nn = (size_t)n();
+        ELAG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&st), sizeof(KState)));
+        ELAG_HIP_CHECK(hipMemset(st, 0, sizeof(KState)));
+        ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_flags), sizeof(int) * F_COUNT));
+        ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_sc), sizeof(double) * S_COUNT));
+        x = dev_alloc<double>(nn); r = dev_alloc<double>(nn); z = dev_alloc<double>(nn); scr = dev_alloc<double>(nn);
+        if (solver == ELAG_HIP_KRYLOV_CG) d = dev_alloc<double>(nn);
+        if (solver == ELAG_HIP_KRYLOV_STATIONARY) { d = dev_alloc<double>(nn); }
+        if (solver == ELAG_HIP_KRYLOV_GMRES || solver == ELAG_HIP_KRYLOV_FGMRES) {
+            ELAG_REQUIRE(restart >= 1, "\"Restart size\" must be >= 1");
+            const size_t m = (size_t)restart;
+            w = dev_alloc<double>(nn);
+            V = dev_alloc<double>((m + 1) * nn);
+            if (solver == ELAG_HIP_KRYLOV_FGMRES) Z = dev_alloc<double>(m * nn);
+            hs = dev_alloc<double>(m * (m + 1) + 4 * (m + 1));
+        }
+    }
+
+    // z_out = B r_in from the zero guess (the reference sets iterative_mode = false on the preconditioner: KrylovSolver.cpp:79-83)
+    void prec(const double *rin, double *zout)
+    {
+        if (prec_kind == ELAG_HIP_PREC_SMOOTHER) {
+            const int nf = psm->flips(true);
+            double *c = (nf & 1) ? scr : zout, *a = (nf & 1) ? zout : scr;
+            psm->apply(rin, c, a, true, false);
+            if (c != zout) fail(ELAG_HIP_ERR_STATE, "internal: smoother result in scratch");
+        } else if (prec_kind == ELAG_HIP_PREC_HIERARCHY) {
+            hierarchy_apply_raw(phier, rin, zout, true);
+        } else if (prec_kind == ELAG_HIP_PREC_COARSE) {
+            pcoarse->apply(rin, zout);
+        } else {
+            ELAG_HIP_CHECK(hipMemcpyAsync(zout, rin, sizeof(double) * (size_t)n(), hipMemcpyDeviceToDevice, ctx().stream));
+        }
+    }
+
+    void amul(const double *in, double *out)
+    {
+        k::SpmvArgs a;
+        a.x = in; a.alpha = 1.0; a.out = out;
+        par_spmv(*A, a);
+    }
+    void residual(const double *b, const double *xin, double *out)   // out = b - A x
+    {
+        k::SpmvArgs a;
+        a.x = xin; a.alpha = -1.0; a.f = b; a.gamma = 1.0; a.out = out;
+        par_spmv(*A, a);
+    }
+
+    // (u, v) summed over the ranks, left in st->sc[S_TMP]
+    void dot(const double *u, const double *v)
+    {
+        Context &c = ctx();
+        k::vec_dot(n(), u, v, &st->sc[S_TMP]);
+        if (distributed() && comm_active()) {
+            ELAG_HIP_CHECK(hipEventRecord(c.ev_pack, c.stream));
+            ELAG_HIP_CHECK(hipStreamWaitEvent(c.comm_stream, c.ev_pack, 0));
+            comm_allreduce_device(&st->sc[S_TMP], 1, 0, c.comm_stream);
+            ELAG_HIP_CHECK(hipEventRecord(c.ev_halo, c.comm_stream));
+            ELAG_HIP_CHECK(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
+        }
+    }
+
+    bool poll()
+    {
+        hipStream_t s = ctx().stream;
+        ELAG_HIP_CHECK(hipMemcpyAsync(h_flags, st->fl, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, s));
+        ELAG_HIP_CHECK(hipStreamSynchronize(s));
+        return h_flags[F_DONE] != 0;
+    }
+
+    void fetch_results()
+    {
+        hipStream_t s = ctx().stream;
+        ELAG_HIP_CHECK(hipMemcpyAsync(h_flags, st->fl, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, s));
+        ELAG_HIP_CHECK(hipMemcpyAsync(h_sc, st->sc, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, s));
+        ELAG_HIP_CHECK(hipStreamSynchronize(s));
+        converged = h_flags[F_CONVERGED]; final_iter = h_flags[F_FINAL_ITER]; final_norm = h_sc[S_FINAL_NORM];
+    }
+
+    bool capturable() const
+    {
+        if (!use_graph || distributed() || A->needs_exchange()) return false;
+        if (prec_kind == ELAG_HIP_PREC_HIERARCHY) return hierarchy_is_local(phier);
+        if (prec_kind == ELAG_HIP_PREC_SMOOTHER) return !psm->A->needs_exchange() && !is_distributed(*psm->A);
+        if (prec_kind == ELAG_HIP_PREC_COARSE) return !pcoarse->replicated && !pcoarse->custom_apply;
+        return true;
+    }
+
+    void cg_iteration()
+    {
+        hipStream_t s = ctx().stream;
+        const int nn = n();
+        hipLaunchKernelGGL(cg_update_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, x, (const double *)d, r, (const double *)z);
+        if (has_prec()) { prec(r, z); dot(r, z); } else dot(r, r);
+        hipLaunchKernelGGL(cg_step1_kernel, dim3(1), dim3(1), 0, s, st, max_iter);
+        hipLaunchKernelGGL(cg_dir_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, (const double *)(has_prec() ? z : r), d);
+        amul(d, z);
+        dot(d, z);
+        hipLaunchKernelGGL(cg_step2_kernel, dim3(1), dim3(1), 0, s, st);
+        ELAG_LAUNCH_CHECK();
+    }
+
+    void run_cg(const double *b, bool iterative)
+    {
+        hipStream_t s = ctx().stream;
+        const int nn = n();
+        if (iterative) residual(b, x, r);
+        else {
+            ELAG_HIP_CHECK(hipMemcpyAsync(r, b, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s));
+            k::vec_fill(nn, 0.0, x);
+        }
+        if (has_prec()) { prec(r, z); ELAG_HIP_CHECK(hipMemcpyAsync(d, z, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s)); }
+        else ELAG_HIP_CHECK(hipMemcpyAsync(d, r, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s));
+        dot(d, r);
+        hipLaunchKernelGGL(cg_init1_kernel, dim3(1), dim3(1), 0, s, st, rel_tol, abs_tol, max_iter);
+        amul(d, z);
+        dot(z, d);
+        hipLaunchKernelGGL(cg_init2_kernel, dim3(1), dim3(1), 0, s, st);
+        ELAG_LAUNCH_CHECK();
+        if (poll()) return;
+        const bool graph = capturable();
+        if (graph && !cg_iter) {
+            hipGraph_t g = nullptr;
+            ELAG_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            try { cg_iteration(); } catch (...) { (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); throw; }
+            ELAG_HIP_CHECK(hipStreamEndCapture(s, &g));
+            ELAG_HIP_CHECK(hipGraphInstantiate(&cg_iter, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+        }
+        const int total = std::max(1, max_iter);   // mfem's loop body runs once even with max_iter == 0
+        for (int it = 0; it < total;) {
+            const int batch = std::min(check_every, total - it);
+            for (int q = 0; q < batch; q++) {
+                if (graph) ELAG_HIP_CHECK(hipGraphLaunch(cg_iter, s));
+                else cg_iteration();
+            }
+            it += batch;
+            if (poll()) break;
+        }
+    }
+
+    void run_gmres(const double *b, bool iterative, bool flexible)
+    {
+        hipStream_t s = ctx().stream;
+        const int nn = n(), m = restart;
+        auto Vq = [&](int q) { return V + (size_t)q * nn; };
+        auto Zq = [&](int q) { return Z + (size_t)q * nn; };
+        // initial (preconditioned) residual
+        if (flexible) {
+            if (iterative) residual(b, x, r);
+            else { k::vec_fill(nn, 0.0, x); ELAG_HIP_CHECK(hipMemcpyAsync(r, b, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s)); }
+        } else if (has_prec()) {
+            if (iterative) { residual(b, x, w); prec(w, r); }
+            else { k::vec_fill(nn, 0.0, x); prec(b, r); }
+        } else {
+            if (iterative) residual(b, x, r);
+            else { k::vec_fill(nn, 0.0, x); ELAG_HIP_CHECK(hipMemcpyAsync(r, b, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s)); }
+        }
+        dot(r, r);
+        hipLaunchKernelGGL(gmres_init_kernel, dim3(1), dim3(1), 0, s, st, rel_tol, abs_tol, max_iter);
+        ELAG_LAUNCH_CHECK();
+        if (poll()) return;
+        int step_id = 0, since_poll = 0;
+        bool finished = false;
+        for (int j = 1; j <= max_iter && !finished;) {
+            hipLaunchKernelGGL(scale_inv_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, (int)S_GBETA, (const double *)r, Vq(0));
+            hipLaunchKernelGGL(gmres_start_cycle_kernel, dim3(1), dim3(1), 0, s, st, hs, m);
+            int i = 0;
+            for (; i < m && j <= max_iter; i++, j++) {
+                double *target = flexible ? r : w;   // the vector that is orthogonalised
+                if (flexible) {
+                    if (has_prec()) prec(Vq(i), Zq(i));
+                    else ELAG_HIP_CHECK(hipMemcpyAsync(Zq(i), Vq(i), sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s));
+                    amul(Zq(i), r);
+                } else if (has_prec()) {
+                    amul(Vq(i), r);
+                    prec(r, w);
+                } else {
+                    amul(Vq(i), w);
+                }
+                for (int k = 0; k <= i; k++) {
+                    dot(target, Vq(k));
+                    hipLaunchKernelGGL(gmres_orth_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, hs, m, k, i, target, (const double *)Vq(k));
+                }
+                dot(target, target);
+                hipLaunchKernelGGL(gmres_norm_kernel, dim3(1), dim3(1), 0, s, st, hs, m, i);
+                hipLaunchKernelGGL(scale_inv_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, (int)S_BETA, (const double *)target, Vq(i + 1));
+                ++step_id;
+                hipLaunchKernelGGL(gmres_givens_kernel, dim3(1), dim3(1), 0, s, st, hs, m, i, j, step_id);
+                hipLaunchKernelGGL(gmres_update_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, step_id, (const double *)hs, m, i + 1,
+                                   (const double *)(flexible ? Z : V), x);
+                ELAG_LAUNCH_CHECK();
+                if (++since_poll >= check_every) { since_poll = 0; if (poll()) { finished = true; i++; j++; break; } }
+            }
+            if (finished) break;
+            // restart: Update(x, i-1, ...), true residual, convergence test on its norm
+            ++step_id;
+            hipLaunchKernelGGL(gmres_restart_backsolve_kernel, dim3(1), dim3(1), 0, s, st, hs, m, i - 1, step_id);
+            hipLaunchKernelGGL(gmres_update_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, step_id, (const double *)hs, m, i,
+                               (const double *)(flexible ? Z : V), x);
+            if (!flexible && has_prec()) { residual(b, x, w); prec(w, r); }
+            else residual(b, x, r);
+            dot(r, r);
+            hipLaunchKernelGGL(gmres_restart_norm_kernel, dim3(1), dim3(1), 0, s, st, j);
+            ELAG_LAUNCH_CHECK();
+            if (poll()) break;
+        }
+    }
+
+    void run_stationary(const double *b, bool iterative)
+    {
+        hipStream_t s = ctx().stream;
+        const int nn = n();
+        if (iterative) residual(b, x, r);
+        else { ELAG_HIP_CHECK(hipMemcpyAsync(r, b, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s)); k::vec_fill(nn, 0.0, x); }
+        dot(r, r);
+        hipLaunchKernelGGL(stat_init_kernel, dim3(1), dim3(1), 0, s, st, max_iter);
+        for (int it = 0; it < max_iter;) {
+            const int batch = std::min(check_every, max_iter - it);
+            for (int q = 0; q < batch; q++) {
+                prec(r, d);                                                                                       // Correction = Solver(Residual)
+                hipLaunchKernelGGL(add_pred_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, x, (const double *)d);   // sol += Correction
+                amul(d, z);                                                                                       // Tmp = A Correction
+                hipLaunchKernelGGL(sub_pred_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, r, (const double *)z);   // Residual -= Tmp
+                dot(r, r);
+                hipLaunchKernelGGL(stat_step_kernel, dim3(1), dim3(1), 0, s, st, rel_tol, abs_tol);
+            }
+            ELAG_LAUNCH_CHECK();
+            it += batch;
+            if (poll()) break;
+        }
+    }
+
+    void mult(const double *b, double *xio, bool iterative)
+    {
+        hipStream_t s = ctx().stream;
+        const size_t nn = (size_t)n();
+        if (iterative) ELAG_HIP_CHECK(hipMemcpyAsync(x, xio, sizeof(double) * nn, hipMemcpyDeviceToDevice, s));
+        switch (solver) {
+        case ELAG_HIP_KRYLOV_CG: run_cg(b, iterative); break;
+        case ELAG_HIP_KRYLOV_GMRES: run_gmres(b, iterative, false); break;
+        case ELAG_HIP_KRYLOV_FGMRES: run_gmres(b, iterative, true); break;
+        default: run_stationary(b, iterative); break;
+        }
+        fetch_results();
+        ELAG_HIP_CHECK(hipMemcpyAsync(xio, x, sizeof(double) * nn, hipMemcpyDeviceToDevice, s));
+    }
+};
+
+extern "C" {
+
+int elag_hip_krylov_default_options(elag_hip_krylov_options *opt)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(opt, "null options");
+        // the defaults KrylovSolver falls back to (KrylovSolver.cpp:86-94) and "Restart size" 50 (:47-49)
+        opt->solver = ELAG_HIP_KRYLOV_CG; opt->max_iter = 10; opt->rel_tol = 0.0; opt->abs_tol = 0.0; opt->restart = 50;
+        opt->check_every = 8; opt->use_graph = 1;
+    });
+}
+
+int elag_hip_krylov_create(elag_hip_krylov_t *out, elag_hip_parcsr_t A, int prec_kind, void *prec, const elag_hip_krylov_options *opt_in)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(out && A, "null argument");
+        ELAG_REQUIRE(A->nrows() == A->ncols(), "Krylov solvers need a square operator");
+        elag_hip_krylov_options opt;
+        if (opt_in) opt = *opt_in; else { int rc = elag_hip_krylov_default_options(&opt); if (rc) fail(rc, "%s", elag_hip_last_error()); }
+        ELAG_REQUIRE(opt.solver >= ELAG_HIP_KRYLOV_CG && opt.solver <= ELAG_HIP_KRYLOV_STATIONARY,
+                     "KrylovSolver::KrylovSolver(...): Bad solver type (%d). Device choices are CG, GMRES, FGMRES and the stationary iteration",
+                     opt.solver);
+        ELAG_REQUIRE(opt.max_iter >= 0, "\"Maximum iterations\" must be >= 0");
+        ELAG_REQUIRE(prec_kind >= ELAG_HIP_PREC_NONE && prec_kind <= ELAG_HIP_PREC_COARSE, "unknown preconditioner kind %d", prec_kind);
+        ELAG_REQUIRE(prec_kind == ELAG_HIP_PREC_NONE || prec, "null preconditioner");
+        ELAG_REQUIRE(opt.solver != ELAG_HIP_KRYLOV_STATIONARY || prec_kind != ELAG_HIP_PREC_NONE, "the stationary iteration needs a solver to apply");
+        std::unique_ptr<elag_hip_krylov_s> K(new elag_hip_krylov_s());
+        K->A = A; K->solver = opt.solver; K->max_iter = opt.max_iter; K->rel_tol = opt.rel_tol; K->abs_tol = opt.abs_tol;
+        K->restart = opt.restart; K->check_every = std::max(1, opt.check_every); K->use_graph = opt.use_graph != 0;
+        K->prec_kind = prec_kind;
+        if (prec_kind == ELAG_HIP_PREC_SMOOTHER) {
+            K->psm = static_cast<elag_hip_smoother_s *>(prec);
+            ELAG_REQUIRE(K->psm->n() == A->nrows(), "preconditioner size %d does not match the operator (%d)", K->psm->n(), A->nrows());
+        } else if (prec_kind == ELAG_HIP_PREC_HIERARCHY) {
+            K->phier = static_cast<elag_hip_hierarchy_s *>(prec);
+            ELAG_REQUIRE(hierarchy_height(K->phier) == A->nrows(), "hierarchy size %d does not match the operator (%d)", hierarchy_height(K->phier), A->nrows());
+        } else if (prec_kind == ELAG_HIP_PREC_COARSE) {
+            K->pcoarse = static_cast<elag_hip_coarse_s *>(prec);
+            ELAG_REQUIRE((K->pcoarse->replicated ? K->pcoarse->nloc : K->pcoarse->n) == A->nrows(), "coarse solver size does not match the operator");
+        }
+        K->setup();
+        *out = K.release();
+    });
+}
+
+int elag_hip_krylov_mult(elag_hip_krylov_t K, const double *b, double *x, int iterative_mode, int loc)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(K && b && x, "null argument");
+        ELAG_REQUIRE(b != x, "rhs and sol must not alias");
+        check_loc(loc);
+        const size_t n = (size_t)K->n();
+        VecIn bb(b, n, loc);
+        VecInOut xx(x, n, loc, iterative_mode != 0);
+        K->mult(bb.d, xx.d, iterative_mode != 0);
+        xx.finish();
+        ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    });
+}
+
+int elag_hip_krylov_get_stats(elag_hip_krylov_t K, int *converged, int *final_iter, double *final_norm)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(K, "null solver");
+        if (converged) *converged = K->converged;
+        if (final_iter) *final_iter = K->final_iter;
+        if (final_norm) *final_norm = K->final_norm;
+    });
+}
+
+int elag_hip_krylov_destroy(elag_hip_krylov_t K)
+{
+    return guarded([&] {
+        if (K) { (void)hipStreamSynchronize(ctx().stream); delete K; }
+    });
+}
+
+}  // extern "C"

@@ -63,6 +63,10 @@ struct elag_hip_hierarchy_s;
 namespace elag {
 // hands an object's destructor to the hierarchy (run, in reverse order, when the hierarchy is destroyed)
 void hierarchy_adopt(elag_hip_hierarchy_s *H, std::function<void()> destroy);
+// Hierarchy::Mult on device vectors without the hierarchy's own graph replay (callers that capture their own graph)
+void hierarchy_apply_raw(elag_hip_hierarchy_s *H, const double *rhs, double *sol, bool precond);
+bool hierarchy_is_local(const elag_hip_hierarchy_s *H);   // no halo exchange / collective anywhere in the cycle
+int hierarchy_height(const elag_hip_hierarchy_s *H);
 }  // namespace elag
 
 struct elag_hip_coarse_s {

@@ -677,6 +677,84 @@ def buildBlockedHierarchyFromDeRhamSequence(A: MfemBlockOperator, Ps, block_smoo
     return H
 
 
+# ---- Krylov shells ----------------------------------------------------------------------------------------------------
+
+KRYLOV_SOLVERS = {"CG": 0, "PCG": 0, "GMRES": 1, "FGMRES": 2, "STATIONARY": 3}
+
+
+class KrylovSolver(_SolverBase):
+    """parelag::KrylovSolver(A, Prec, params) (src/linalg/solver_ops/ParELAG_KrylovSolver.cpp:23-96) on the device.
+    ``params`` uses the reference's keys: "Solver name" (CG | PCG | GMRES | FGMRES; "Stationary" selects
+    parelag::StationarySolver), "Relative tolerance", "Absolute tolerance", "Maximum iterations", "Restart size".
+    ``Prec`` is any solver object of this module (smoother, block solver, Hierarchy, CoarseSolver) or None."""
+
+    def __init__(self, A, Prec=None, params: dict | None = None):
+        params = params or {}
+        self._lib = _lib.init()
+        self.A_user = A
+        self.A = A.Monolithic() if isinstance(A, MfemBlockOperator) else A
+        self.Prec = Prec
+        name = str(params.get("Solver name", "CG")).upper()
+        if name not in KRYLOV_SOLVERS:
+            raise ValueError(f'KrylovSolver::KrylovSolver(...): Bad solver type ("{name}"). Device choices are "CG", "GMRES", '
+                             f'"FGMRES" (and "Stationary"); "BiCGSTAB" and "MINRES" stay on the host')
+        opt = _lib.KrylovOptions()
+        check(self._lib.elag_hip_krylov_default_options(C.byref(opt)))
+        opt.solver = KRYLOV_SOLVERS[name]
+        opt.max_iter = int(params.get("Maximum iterations", params.get("Maximum Iterations", 1 if name == "STATIONARY" else 10)))
+        opt.rel_tol = float(params.get("Relative tolerance", params.get("Relative Tolerance", 0.0)))
+        opt.abs_tol = float(params.get("Absolute tolerance", params.get("Absolute Tolerance", 0.0)))
+        opt.restart = int(params.get("Restart size", 50))
+        opt.check_every = int(params.get("Check every", 8))
+        opt.use_graph = int(params.get("Use graph", True))
+        if Prec is None:
+            kind, ph = 0, None
+        elif isinstance(Prec, Hierarchy):
+            kind, ph = 2, Prec.h
+        elif isinstance(Prec, CoarseSolver):
+            kind, ph = 3, Prec.h
+        else:
+            kind, ph = 1, Prec.h
+        h = _vp()
+        check(self._lib.elag_hip_krylov_create(C.byref(h), self.A.h, kind, ph, C.byref(opt)))
+        self.h = h
+        self.iterative_mode = False      # KrylovSolver.cpp:77
+
+    def Mult(self, rhs, sol):
+        n = self.A.Height()
+        pr, lr, _k1 = _vec(rhs, n)
+        ps, ls, _k2 = _vec(sol, n, writable=True)
+        check(self._lib.elag_hip_krylov_mult(self.h, pr, ps, int(self.iterative_mode), _same_loc(lr, ls)))
+
+    def _stats(self):
+        c, it, nrm = C.c_int(), C.c_int(), C.c_double()
+        check(self._lib.elag_hip_krylov_get_stats(self.h, C.byref(c), C.byref(it), C.byref(nrm)))
+        return c.value, it.value, nrm.value
+
+    def GetConverged(self):
+        return bool(self._stats()[0])
+
+    def GetNumIterations(self):
+        return self._stats()[1]
+
+    def GetFinalNorm(self):
+        return self._stats()[2]
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._lib.elag_hip_krylov_destroy(self.h)
+        except Exception:
+            pass
+
+
+def StationarySolver(A, solver, rel_tol=0.0, abs_tol=0.0, max_its=1):
+    """parelag::StationarySolver(op, solver, rel_tol, abs_tol, max_its) (ParELAG_StationarySolver.cpp:23-39); it is
+    constructed as a preconditioner (IsPreconditioner() == true), i.e. iterative_mode False."""
+    return KrylovSolver(A, solver, {"Solver name": "Stationary", "Relative Tolerance": rel_tol, "Absolute Tolerance": abs_tol,
+                                    "Maximum Iterations": max_its})
+
+
 def time_kernel(A: ParallelCSRMatrix, kernel: str, x, y, reps=20, smoother: HypreSmootherWrapper | None = None) -> float:
     """mean ms per launch of a fine-level kernel ('spmv' | 'residual' | 'jacobi') by HIP events."""
     kid = {"spmv": 0, "residual": 1, "jacobi": 2}[kernel]

@@ -1,0 +1,159 @@
+"""Device Krylov shells against the oracle's restatement of mfem::CGSolver / GMRESSolver / FGMRESSolver and
+parelag::StationarySolver: same iteration counts, same convergence flags, iterates within rounding."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import oracle as orc
+from tests.helpers import oracle_h1_hierarchy, oracle_blocked_hierarchy
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def la():
+    from parelag_amd import linalg
+    return linalg
+
+
+def close(x, ref, tol):
+    return np.max(np.abs(np.asarray(x) - np.asarray(ref))) <= tol * max(np.max(np.abs(ref)), 1e-300)
+
+
+def h1_setup(la, prob, smoother="L1 Jacobi"):
+    A, Ps, _ = prob
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    H = la.buildHierarchyFromDeRhamSequence(dA, dPs, smoother)
+    h = oracle_h1_hierarchy(A, Ps, smoother=la.HYPRE_SMOOTHER_TYPES[smoother])
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"])
+
+    def oprec(r, z):
+        Hc.apply(r, z)
+    return dA, H, oprec
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+@pytest.mark.parametrize("check_every", [1, 8])
+def test_pcg_with_vcycle_matches_mfem_cg(la, h1_k2, use_graph, check_every):
+    """MultigridTest0Form's solve: PCG preconditioned by the AMGe cycle (examples/MultigridTest0Form.cpp:513-600)."""
+    A = h1_k2[0]
+    dA, H, oprec = h1_setup(la, h1_k2)
+    b = np.random.default_rng(1).uniform(-1, 1, A.shape[0])
+    params = {"Solver name": "PCG", "Relative tolerance": 1e-10, "Absolute tolerance": 1e-14, "Maximum iterations": 100,
+              "Use graph": use_graph, "Check every": check_every}
+    K = la.KrylovSolver(dA, H, params)
+    x = np.full(A.shape[0], 5.0)
+    K.Mult(b, x)
+    xr = np.zeros_like(b)
+    ref = orc.mfem_cg(lambda v: A @ v, oprec, b, xr, rel_tol=1e-10, abs_tol=1e-14, max_iter=100)
+    assert K.GetConverged() and ref.converged
+    assert K.GetNumIterations() == ref.final_iter and 3 < ref.final_iter < 40
+    assert np.isclose(K.GetFinalNorm(), ref.final_norm, rtol=1e-5)
+    assert close(x, xr, 1e-9)
+    assert np.linalg.norm(A @ x - b) <= 1e-8 * np.linalg.norm(b)
+    # device vectors, second solve on the same object, iterative_mode from the previous solution
+    db, dx = la.DeviceVector.from_numpy(b), la.DeviceVector.from_numpy(x)
+    K.iterative_mode = True
+    K.Mult(db, dx)
+    xr2 = x.copy()    # (the relative test restarts from the new, tiny initial residual)
+    ref2 = orc.mfem_cg(lambda v: A @ v, oprec, b, xr2, iterative_mode=True, rel_tol=1e-10, abs_tol=1e-14, max_iter=100)
+    assert K.GetConverged() == bool(ref2.converged) and abs(K.GetNumIterations() - ref2.final_iter) <= 1
+    assert close(dx.to_numpy(), xr2, 1e-9)
+
+
+def test_cg_stops_at_maximum_iterations_and_unpreconditioned(la, h1_k1):
+    A = h1_k1[0]
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    b = np.random.default_rng(2).uniform(-1, 1, A.shape[0])
+    for maxit in (0, 1, 7):
+        K = la.KrylovSolver(dA, None, {"Solver name": "CG", "Relative tolerance": 1e-12, "Maximum iterations": maxit})
+        x = np.zeros_like(b); xr = np.zeros_like(b)
+        K.Mult(b, x)
+        ref = orc.mfem_cg(lambda v: A @ v, None, b, xr, rel_tol=1e-12, max_iter=maxit)
+        assert (K.GetConverged(), K.GetNumIterations()) == (bool(ref.converged), ref.final_iter)
+        assert close(x, xr, 1e-11) and np.isclose(K.GetFinalNorm(), ref.final_norm, rtol=1e-9)
+    # zero right-hand side: converged at iteration 0
+    K = la.KrylovSolver(dA, None, {"Solver name": "CG", "Relative tolerance": 1e-12, "Maximum iterations": 5})
+    x = np.ones_like(b)
+    K.Mult(np.zeros_like(b), x)
+    assert K.GetConverged() and K.GetNumIterations() == 0 and not x.any()
+    # a smoother as preconditioner
+    S = la.HypreSmootherWrapper(dA, 1)
+    K = la.KrylovSolver(dA, S, {"Solver name": "PCG", "Relative tolerance": 1e-8, "Maximum iterations": 500})
+    x = np.zeros_like(b); xr = np.zeros_like(b)
+    K.Mult(b, x)
+    l1 = orc.l1_norms(orc.diag_first(A), None, 1)
+    ref = orc.mfem_cg(lambda v: A @ v, lambda r, z: z.__setitem__(slice(None), r / l1), b, xr, rel_tol=1e-8, max_iter=500)
+    assert K.GetNumIterations() == ref.final_iter and close(x, xr, 1e-8)
+    with pytest.raises(ValueError, match="Bad solver type"):
+        la.KrylovSolver(dA, None, {"Solver name": "MINRES"})
+
+
+@pytest.mark.parametrize("name", ["GMRES", "FGMRES"])
+@pytest.mark.parametrize("restart", [50, 7])
+def test_gmres_on_the_darcy_system_matches_mfem(la, name, restart):
+    """MultigridTestDarcy's solve: (F)GMRES preconditioned by the blocked AMGe cycle (darcy_example_parameters.xml)."""
+    from parelag_amd import meshgen
+    d = meshgen.darcy_problem(0, seq=meshgen.Sequence.kuhn_cube(2, 2))
+    blocks = {(0, 0): d["M"], (0, 1): d["Bt"], (1, 0): d["B"]}
+    n0, n1 = d["M"].shape[0], d["B"].shape[0]
+    op = la.MfemBlockOperator([0, n0, n0 + n1])
+    for (i, j), M in blocks.items():
+        op.SetBlock(i, j, la.ParallelCSRMatrix.from_scipy(orc.csr(M)))
+    Ps = [[la.ParallelCSRMatrix.from_scipy(orc.csr(P)) for P in Pl] for Pl in d["Ps"]]
+    H = la.buildBlockedHierarchyFromDeRhamSequence(op, Ps, block_smoother="Block GS", use_negative_s=False)
+    Ho, _ = oracle_blocked_hierarchy(blocks, d["Ps"], kind="Block GS Lower", use_negative_s=False)
+    A = sp.bmat([[d["M"], d["Bt"]], [d["B"], None]]).tocsr()
+    b = np.concatenate([np.zeros(n0), d["seq"].meshes[0].M3() @ np.ones(n1)])
+
+    def oprec(r, z):
+        z[:] = 0.0
+        Ho.Mult(r, z)
+    params = {"Solver name": name, "Relative tolerance": 1e-6, "Absolute tolerance": 1e-12, "Maximum iterations": 300, "Restart size": restart}
+    K = la.KrylovSolver(op, H, params)
+    x = np.full(n0 + n1, 2.0)
+    K.Mult(b, x)
+    xr = np.zeros_like(b)
+    ref = orc.mfem_gmres(lambda v: A @ v, oprec, b, xr, rel_tol=1e-6, abs_tol=1e-12, max_iter=300, m=restart, flexible=(name == "FGMRES"))
+    assert K.GetConverged() and ref.converged
+    assert abs(K.GetNumIterations() - ref.final_iter) <= 1 and ref.final_iter < 120
+    if K.GetNumIterations() == ref.final_iter:
+        assert np.isclose(K.GetFinalNorm(), ref.final_norm, rtol=1e-3)
+        assert close(x, xr, 1e-6)
+    assert np.linalg.norm(A @ x - b) <= 1e-4 * np.linalg.norm(b)
+
+
+def test_gmres_unpreconditioned_small_steps_and_max_iter(la):
+    rng = np.random.default_rng(3)
+    n = 300
+    A = orc.csr(sp.random(n, n, density=0.03, random_state=rng) + sp.diags(np.full(n, 3.0)))
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    b = rng.uniform(-1, 1, n)
+    for name, maxit, m in (("GMRES", 5, 50), ("GMRES", 12, 5), ("FGMRES", 9, 4), ("GMRES", 0, 10)):
+        K = la.KrylovSolver(dA, None, {"Solver name": name, "Maximum iterations": maxit, "Restart size": m, "Check every": 3})
+        x = np.zeros(n); xr = np.zeros(n)
+        K.Mult(b, x)
+        ref = orc.mfem_gmres(lambda v: A @ v, None, b, xr, max_iter=maxit, m=m, flexible=(name == "FGMRES"))
+        assert (K.GetConverged(), K.GetNumIterations()) == (bool(ref.converged), ref.final_iter)
+        assert close(x, xr, 1e-11) if maxit else not x.any()
+        assert np.isclose(K.GetFinalNorm(), ref.final_norm, rtol=1e-9)
+    # converges in the middle of a cycle; iterative_mode restart from the solution converges at once
+    K = la.KrylovSolver(dA, None, {"Solver name": "GMRES", "Relative tolerance": 1e-10, "Maximum iterations": 200, "Restart size": 20})
+    x = np.zeros(n); xr = np.zeros(n)
+    K.Mult(b, x)
+    ref = orc.mfem_gmres(lambda v: A @ v, None, b, xr, rel_tol=1e-10, max_iter=200, m=20)
+    assert K.GetConverged() and K.GetNumIterations() == ref.final_iter and close(x, xr, 1e-9)
+
+
+def test_stationary_solver_matches_reference_loop(la, h1_k1):
+    A = h1_k1[0]
+    dA, H, oprec = h1_setup(la, h1_k1)
+    b = np.random.default_rng(4).uniform(-1, 1, A.shape[0])
+    for kw in (dict(max_its=1), dict(max_its=4), dict(rel_tol=1e-6, max_its=100)):
+        S = la.StationarySolver(dA, H, **kw)
+        x = np.full_like(b, 3.0); xr = np.zeros_like(b)
+        S.Mult(b, x)
+        ref = orc.stationary_solver(lambda v: A @ v, oprec, b, xr, rel_tol=kw.get("rel_tol", 0.0), max_iter=kw["max_its"])
+        assert (S.GetConverged(), S.GetNumIterations()) == (bool(ref.converged), ref.final_iter)
+        assert close(x, xr, 1e-10) and np.isclose(S.GetFinalNorm(), ref.final_norm, rtol=1e-6)
