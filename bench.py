@@ -44,6 +44,11 @@ def vcycle_bytes(shapes):
     return total
 
 
+def seq_fine_M3_one(dar):
+    """(1, q) for the piecewise-constant pressure space: element volumes (rhs_p of MultigridTestDarcy with f = 1)"""
+    return dar["seq"].meshes[0].M3() @ __import__("numpy").ones(dar["B"].shape[0])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,6 +68,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--solve", action="store_true", help="also time the Krylov solve of the example (PCG / GMRES with the cycle as "
+                                                        "preconditioner, device-resident) and report it under \"solve\"")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even with one rank (testing)")
     args = ap.parse_args()
     darcy = args.form == "darcy"
@@ -230,6 +237,37 @@ def main():
         fine = {"n": n0, "nnz": nnz0, "bytes_per_launch": b0, "us_per_launch": round(ms0 * 1e3, 2),
                 "achieved_GBs": round(b0 / (ms0 * 1e-3) / 1e9, 1), "note": "operator is cache resident (L2/Infinity Cache), not an HBM figure"}
 
+    # ---------------------------------------------------------------- optional: the example's Krylov solve on the device
+    solve = None
+    if args.solve and single:
+        if darcy:
+            kparams = {"Solver name": "GMRES", "Relative tolerance": 1e-6, "Absolute tolerance": 1e-6, "Maximum iterations": 300,
+                       "Restart size": 50}                                  # darcy_example_parameters.xml:66-79
+            b_solve = np.concatenate([np.zeros(dar["M"].shape[0]), seq_fine_M3_one(dar)])
+            Kop = bop
+        else:
+            kparams = {"Solver name": "PCG", "Relative tolerance": 1e-6, "Absolute tolerance": 1e-6, "Maximum iterations": 100}
+            fine_mesh = seq.meshes[0]                                       # Create0FormParameterList.hpp:78-83
+            if args.form == 0:
+                b_solve = meshgen.load_vector_P1(fine_mesh, fine_mesh.boundary_marker_unit_cube())
+            else:
+                b_solve = np.where(fine_mesh.boundary_marker(2), 0.0, 1.0)
+            Kop = dA
+        K = la.KrylovSolver(Kop, H, kparams)
+        db, dx = la.DeviceVector.from_numpy(b_solve), la.DeviceVector(n_local, 0.0)
+        K.Mult(db, dx)
+        la.synchronize()
+        t0 = time.perf_counter()
+        nsolve = 20
+        for _ in range(nsolve):
+            K.Mult(db, dx)
+        la.synchronize()
+        solve_ms = (time.perf_counter() - t0) / nsolve * 1e3
+        xs_dev = dx.to_numpy()
+        solve = {"solver": kparams["Solver name"], "rel_tol": 1e-6, "iterations": K.GetNumIterations(), "converged": K.GetConverged(),
+                 "final_norm": K.GetFinalNorm(), "ms_per_solve": round(solve_ms, 4),
+                 "true_rel_residual": float(np.linalg.norm(A @ xs_dev - b_solve) / np.linalg.norm(b_solve))}
+
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
     cpu = None
     if single and not args.no_cpu_baseline and rank == 0:
@@ -273,6 +311,16 @@ def main():
         # parity spot check of the timed operator against the baseline operator
         xd = sol.to_numpy()
         out["parity_rel_err_vs_oracle"] = float(np.max(np.abs(xd - xs)) / np.max(np.abs(xs)))
+        if solve is not None:
+            xo = np.zeros_like(b_solve)
+            t0 = time.perf_counter()
+            if darcy:
+                ref = orc.mfem_gmres(lambda v: A @ v, lambda r, z: Hc.apply(r, z), b_solve, xo, rel_tol=1e-6, abs_tol=1e-6, max_iter=300, m=50)
+            else:
+                ref = orc.mfem_cg(lambda v: A @ v, lambda r, z: Hc.apply(r, z), b_solve, xo, rel_tol=1e-6, abs_tol=1e-6, max_iter=100)
+            solve["cpu_port_ms_per_solve"] = round((time.perf_counter() - t0) * 1e3, 2)
+            solve["cpu_port_iterations"] = ref.final_iter
+            solve["solution_rel_diff_vs_cpu_port"] = float(np.max(np.abs(xs_dev - xo)) / np.max(np.abs(xo)))
 
     if not single:
         # parity of the distributed cycle against the serial CPU oracle (every rank checks its own rows)
@@ -319,6 +367,8 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         })
+        if solve is not None:
+            out["solve"] = solve
         print(json.dumps(out))
 
 

@@ -459,6 +459,17 @@ class Sequence:
         return np.arange(self.meshes[level].nt, dtype=np.int32) // 8
 
 
+def load_vector_P1(mesh: TetMesh, marker: np.ndarray | None = None) -> np.ndarray:
+    """(f, phi_i) for f = 1 and P1 basis functions: |T|/4 per vertex of every tet (the DomainLFIntegrator of
+    ``examples/MultigridTest0Form.cpp:455-466``), essential entries zeroed (homogeneous Dirichlet data)."""
+    _g, vol, _s = mesh._grads()
+    b = np.zeros(mesh.nv)
+    np.add.at(b, mesh._sorted_tets().reshape(-1), np.repeat(vol / 4.0, 4))
+    if marker is not None:
+        b[marker] = 0.0
+    return b
+
+
 def h1_problem(nref: int, nlevels: int | None = None):
     """0-form problem of MultigridTest0Form: A = D0^T M1 D0 with all boundary dofs essential, and the
     true interpolators with essential columns zeroed (ComputeTrueP(jform, ess)).

@@ -392,3 +392,38 @@ def test_distributed_blocked_vcycle_matches_serial_oracle(darcy, world, kind):
     for r in range(world):
         ref = _local_block_vector(dd, 0, r, xr[:n0], xr[n0:])
         assert np.max(np.abs(xs[r] - ref)) <= 1e-10 * np.max(np.abs(xr))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name", ["PCG", "GMRES"])
+def test_distributed_krylov_matches_serial_oracle(problem, world, name):
+    """dots are all-reduced on the device scalars; iteration counts and iterates equal the serial algorithm's"""
+    from parelag_amd import distributed, linalg as la
+    A, Ps, seq = problem
+    b_nat = np.random.default_rng(14).uniform(-1, 1, A.shape[0])
+    params = {"Solver name": name, "Relative tolerance": 1e-8, "Maximum iterations": 60, "Restart size": 10, "Check every": 4}
+
+    def body(dist):
+        H, n_local, shapes, _ = distributed.build_hierarchy(dist, A, Ps, seq, "L1 Jacobi", replicate_from=2)
+        info = H._dist_info["levels"][0]
+        lo, hi = int(info["starts"][dist.rank]), int(info["starts"][dist.rank + 1])
+        K = la.KrylovSolver(H.GetOperator(0), H, params)
+        rhs = la.DeviceVector.from_numpy(b_nat[info["order"]][lo:hi])
+        sol = la.DeviceVector(n_local, 7.0)
+        K.Mult(rhs, sol)
+        la.synchronize()
+        out = (sol.to_numpy(), info["order"], (lo, hi), K.GetConverged(), K.GetNumIterations(), K.GetFinalNorm())
+        del K, H, rhs, sol
+        return out
+    res = run_ranks(world, body)
+    h = oracle_h1_hierarchy(A, Ps, smoother=1)
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"])
+    xr = np.zeros(A.shape[0])
+    if name == "PCG":
+        ref = orc.mfem_cg(lambda v: A @ v, lambda r, z: Hc.apply(r, z), b_nat, xr, rel_tol=1e-8, max_iter=60)
+    else:
+        ref = orc.mfem_gmres(lambda v: A @ v, lambda r, z: Hc.apply(r, z), b_nat, xr, rel_tol=1e-8, max_iter=60, m=10)
+    for x, order, (lo, hi), conv, its, nrm in res:
+        assert conv == bool(ref.converged) and its == ref.final_iter
+        assert np.isclose(nrm, ref.final_norm, rtol=1e-4)
+        assert np.max(np.abs(x - xr[order][lo:hi])) <= 1e-9 * np.max(np.abs(xr))
