@@ -59,9 +59,11 @@ def main():
     ap.add_argument("--roofline-reps", type=int, default=50)
     ap.add_argument("--roofline-only", action="store_true", help="only run the fine-level SpMV launches (for rocprofv3)")
     ap.add_argument("--smoother", default="L1 Jacobi")
-    ap.add_argument("--form", default="0", choices=["0", "2", "darcy"],
+    ap.add_argument("--form", default="0", choices=["0", "2", "darcy", "spe10"],
                     help="0: MultigridTest0Form (H1, the BASELINE metric); 2: MultigridTest2Form (H(div), Hiptmair smoother); "
-                         "darcy: MultigridTestDarcy (blocked AMGe, Block Jacobi smoother, BASELINE configs[3] on one GPU)")
+                         "darcy: MultigridTestDarcy (blocked AMGe, Block Jacobi smoother, BASELINE configs[3]); "
+                         "spe10: the same with a synthetic log-normal permeability (BASELINE configs[4]; the SPE10 data file is not shipped)")
+    ap.add_argument("--perm-sigma", type=float, default=2.0, help="spe10: std-dev of log-permeability")
     ap.add_argument("--block-smoother", default="Block Jacobi", help="darcy: Block Jacobi | Block GS | Block GS Upper | Block LDU")
     ap.add_argument("--positive-s", action="store_true", help='darcy: "Use Negative S" = false (sign-correct Schur block)')
     ap.add_argument("--no-graph", action="store_true")
@@ -72,7 +74,8 @@ def main():
                                                         "preconditioner, device-resident) and report it under \"solve\"")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even with one rank (testing)")
     args = ap.parse_args()
-    darcy = args.form == "darcy"
+    spe10 = args.form == "spe10"
+    darcy = args.form in ("darcy", "spe10")
     args.form = 3 if darcy else int(args.form)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -150,9 +153,11 @@ def main():
     # ---------------------------------------------------------------- V-cycle workload
     Ds = None
     if darcy:
-        if not single:
-            raise SystemExit("--form darcy is benchmarked on one GPU here (the multi-rank blocked path is covered by the tests)")
-        dar = meshgen.darcy_problem(args.refines)
+        kinv = None
+        if spe10:
+            kinv = meshgen.lognormal_inverse_permeability(meshgen.Sequence.cube456(args.refines), args.perm_sigma)
+        dar = meshgen.darcy_problem(args.refines, kinv=kinv)
+        seq = dar["seq"]
         Ps = dar["Ps"]
         A = sp.bmat([[dar["M"], dar["Bt"]], [dar["B"], None]]).tocsr()
     elif args.form == 2:
@@ -161,7 +166,11 @@ def main():
         A, Ps, Ds, seq = meshgen.hdiv_problem(args.refines)
     else:
         A, Ps, seq = meshgen.h1_problem(args.refines)
-    if darcy:
+    if darcy and not single:
+        from parelag_amd import distributed
+        H, n_local, level_shapes, setup_s = distributed.build_darcy_hierarchy(dist, dar, args.block_smoother, args.smoother,
+                                                                              use_negative_s=not args.positive_s)
+    elif darcy:
         n0, n1 = dar["M"].shape[0], dar["B"].shape[0]
         bop = la.MfemBlockOperator([0, n0, n0 + n1])
         for (i, j), M in {(0, 0): dar["M"], (0, 1): dar["Bt"], (1, 0): dar["B"]}.items():
@@ -322,7 +331,21 @@ def main():
             solve["cpu_port_iterations"] = ref.final_iter
             solve["solution_rel_diff_vs_cpu_port"] = float(np.max(np.abs(xs_dev - xo)) / np.max(np.abs(xo)))
 
-    if not single:
+    if not single and darcy:
+        from tests.helpers import oracle_blocked_hierarchy
+        kind = {"Block GS": "Block GS Lower"}.get(args.block_smoother, args.block_smoother)
+        spec = dict(type=la.HYPRE_SMOOTHER_TYPES[args.smoother])
+        Ho, _lev = oracle_blocked_hierarchy({(0, 0): dar["M"], (0, 1): dar["Bt"], (1, 0): dar["B"]}, Ps, kind=kind, a00=spec, a11=spec,
+                                            use_negative_s=not args.positive_s)
+        xs = np.zeros(A.shape[0])
+        Ho.Mult(np.full(A.shape[0], 2.0), xs)
+        dd = H._dist_info
+        (o2, o3), (s2, s3) = dd["order"][0], dd["starts"][0]
+        n0 = dar["M"].shape[0]
+        ref = np.concatenate([xs[:n0][o2][int(s2[dist.rank]):int(s2[dist.rank + 1])], xs[n0:][o3][int(s3[dist.rank]):int(s3[dist.rank + 1])]])
+        err = float(np.max(np.abs(sol.to_numpy() - ref)) / np.max(np.abs(xs)))
+        out["parity_rel_err_vs_oracle"] = dist.allreduce_max(err)
+    elif not single:
         # parity of the distributed cycle against the serial CPU oracle (every rank checks its own rows)
         from oracle import oracle as orc
         from tests.helpers import oracle_h1_hierarchy
@@ -352,7 +375,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": (f"MultigridTest0Form cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
                                     f"{args.smoother} 1 sweep pre/post, dense coarse solve, b=2") if args.form == 0 else
-                                   (f"MultigridTestDarcy [[M,Bt],[B,0]] (forms 2,3) cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
+                                   (("MultigridTestSPE10-like (synthetic log-normal k, sigma=%g, contrast %.1e) " % (args.perm_sigma, float(kinv.max() / kinv.min())) if spe10 else "") +
+                                    f"MultigridTestDarcy [[M,Bt],[B,0]] (forms 2,3) cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
                                     f"{args.block_smoother} (A00: {args.smoother}, A11: {args.smoother} on "
                                     f"{'S' if args.positive_s else '-S'} = -+B diag(M)^-1 Bt) pre/post, dense LU coarse solve, b=2") if darcy else
                                    (f"MultigridTest2Form (H(div)) cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "

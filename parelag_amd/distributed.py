@@ -121,3 +121,78 @@ def build_hierarchy(dist: Dist, A, Ps, seq, smoother="L1 Jacobi", params=None, r
     n_local = ops[0].Height()
     H._dist_info = d
     return H, n_local, shapes, time.time() - t0
+
+
+def build_darcy_hierarchy(dist: Dist, dar, block_smoother="Block Jacobi", smoother="L1 Jacobi", params=None, use_negative_s=True):
+    """Distributed blocked (Darcy) hierarchy in the same layout as ``build_hierarchy``: the fine level is row-partitioned
+    (faces and elements owned per rank, one merged operator = one halo exchange per product, block smoother on this
+    rank's sub-vectors); the levels below are complete on every GPU as an ordinary single-GPU blocked hierarchy behind
+    one all-reduce of the restricted residual.  Returns (H, n_local, global level shapes, setup s); ``H._dist_info``
+    carries the numbering (``order`` / ``starts`` per space)."""
+    import scipy.sparse as sp
+    t0 = time.time()
+    lib = _lib.init()
+    r = dist.rank
+    dd = partition.distributed_darcy(dar, dist.world)
+    (s2, s3) = dd["starts"][0]
+    off = [0, int(s2[r + 1] - s2[r]), int(s2[r + 1] - s2[r] + s3[r + 1] - s3[r])]
+    op = la.MfemBlockOperator(off)
+    for k, parts in dd["blocks"].items():
+        op.SetBlock(*k, la.ParallelCSRMatrix.from_parts(parts[r]))
+    t = la.HYPRE_SMOOTHER_TYPES[smoother] if isinstance(smoother, str) else int(smoother)
+    # fine-level block smoother on the distributed blocks
+    S = la.SchurComplement(op, "DIAGONAL", 1.0, use_negative_s)
+    i0, i1 = la.HypreSmootherWrapper(op.GetBlock(0, 0), t, params or {}), la.HypreSmootherWrapper(S, t, params or {})
+    inv = [i0, i0, i0, i1] if block_smoother == "Block LDU" else [i0, i1]
+    bs = la.BlockSolver(op, inv, block_smoother)
+    # level-1 blocks: distributed Galerkin products, gathered onto every rank (each space keeps its block numbering)
+    P0 = [la.ParallelCSRMatrix.from_parts(p[r]) for p in dd["P"][0]]
+    rep = {}
+    for (i, j), _parts in dd["blocks"].items():
+        C_ij = la.RAP(P0[i], op.GetBlock(i, j), P0[j])
+        rep[(i, j)], _st = C_ij.Replicate()
+        del C_ij
+    n0c, n1c = rep[(0, 0)].Height(), rep[(1, 0)].Height()
+    sub_op = la.MfemBlockOperator([0, n0c, n0c + n1c])
+    for k, M in rep.items():
+        sub_op.SetBlock(*k, M)
+    (o2c, o3c) = dd["order"][1]
+    sub_Ps = []
+    for l, (P2, P3) in enumerate(dar["Ps"][1:], start=1):
+        if l == 1:
+            P2, P3 = sp.csr_matrix(P2)[o2c], sp.csr_matrix(P3)[o3c]      # rows in level-1 block numbering, natural columns
+        sub_Ps.append([la.ParallelCSRMatrix.from_scipy(partition.canon(P2)), la.ParallelCSRMatrix.from_scipy(partition.canon(P3))])
+    Hsub = la.buildBlockedHierarchyFromDeRhamSequence(sub_op, sub_Ps, block_smoother=block_smoother, a00_inverse=smoother,
+                                                     a00_params=params, a11_inverse=smoother, a11_params=params,
+                                                     use_negative_s=use_negative_s)
+    hc = C.c_void_p()
+    _lib.check(lib.elag_hip_coarse_create_from_hierarchy(C.byref(hc), Hsub.h, 1))
+    cs = la.CoarseSolver.__new__(la.CoarseSolver)
+    subA = sub_op.Monolithic()
+    cs._lib, cs.A, cs.h, cs.iterative_mode = lib, subA, hc, False
+    # P from level 1: this rank's rows [faces; elements], GLOBAL level-1 columns [faces; elements], no comm package
+    (o2, o3) = dd["order"][0]
+    P2g = sp.csr_matrix(dar["Ps"][0][0])[o2[int(s2[r]):int(s2[r + 1])]][:, o2c]
+    P3g = sp.csr_matrix(dar["Ps"][0][1])[o3[int(s3[r]):int(s3[r + 1])]][:, o3c]
+    Ploc = la.ParallelCSRMatrix.from_scipy(partition.canon(sp.block_diag([P2g, P3g]).tocsr()))
+    H = la.Hierarchy(2)
+    A0 = op.Monolithic()
+    H.SetOperator(0, A0)
+    H.SetSmoothers(0, bs, bs)
+    H.SetOperator(1, subA)
+    H.SetProlongator(1, Ploc)
+    H.SetCoarseSolver(cs)
+    H.Finalize(use_graph=False)
+    H._keep += [Hsub, sub_op, subA, rep, sub_Ps, op, S, i0, i1, bs, P0, Ploc, A0, cs]
+    la.synchronize()
+    shapes = []
+    shapes.append((dar["M"].shape[0] + dar["B"].shape[0], dar["M"].nnz + 2 * dar["B"].nnz,
+                   sum(P.shape[1] for P in dar["Ps"][0]), sum(P.nnz for P in dar["Ps"][0])))
+    for l in range(len(dar["Ps"])):
+        opl = Hsub.GetOperator(l)
+        pn = sum(P.shape[1] for P in dar["Ps"][l + 1]) if l + 1 < len(dar["Ps"]) else 0
+        pz = sum(P.nnz for P in dar["Ps"][l + 1]) if l + 1 < len(dar["Ps"]) else 0
+        shapes.append((opl.Height(), opl.nnz, pn, pz))
+    H._dist_info = dd
+    H._block_op = op
+    return H, off[-1], shapes, time.time() - t0

@@ -247,8 +247,9 @@ class TetMesh:
             sig[:, k] = np.sign(np.einsum("td,td->t", nrm, a - x[:, k]))
         return sig
 
-    def M2(self, chunk=1 << 18) -> sp.csr_matrix:
-        """Lowest-order Raviart-Thomas (Whitney 2-form) mass matrix, unit coefficient."""
+    def M2(self, chunk=1 << 18, weight: np.ndarray | None = None) -> sp.csr_matrix:
+        """Lowest-order Raviart-Thomas (Whitney 2-form) mass matrix; ``weight`` is an optional per-element scalar
+        coefficient (e.g. the inverse permeability of ``VectorFEMassIntegrator(kinv)``, MultigridTestSPE10.cpp:377-395)."""
         self.build_faces()
         acc = None
         I = (np.ones((4, 4)) + np.eye(4)) / 20.0
@@ -262,6 +263,8 @@ class TetMesh:
             # loc[k,l] = sum_ij I_ij (x_i-x_k).(x_j-x_l) * vol / (9 vol^2)
             loc = np.einsum("ij,tkid,tljd->tkl", I, d, d) / (9.0 * vol)[:, None, None]
             loc *= sig[:, :, None] * sig[:, None, :]
+            if weight is not None:
+                loc *= np.asarray(weight, dtype=np.float64)[sl][:, None, None]
             m = self._assemble(self.tet_faces[sl], loc, self.nf, chunk)
             acc = m if acc is None else acc + m
         acc.sum_duplicates(); acc.sort_indices()
@@ -507,17 +510,31 @@ def hdiv_problem(nref: int, nlevels: int | None = None, alpha: float = 1.0, beta
     return A, Ps, Ds, seq
 
 
-def darcy_problem(nref: int, nlevels: int | None = None, seq: "Sequence | None" = None):
+def lognormal_inverse_permeability(seq: "Sequence", sigma: float = 2.0, seed: int = 2025) -> np.ndarray:
+    """Synthetic stand-in for the SPE10 data set (``data/spe_perm.dat`` is not shipped with the reference,
+    ``examples/MultigridTestSPE10.cpp:85``): one log-normal value ``exp(sigma * N(0,1))`` per element of the COARSEST mesh
+    (piecewise constant on the agglomerates, so contrast survives every level), inherited by the children.
+    Returns the per-element inverse permeability on the finest mesh."""
+    rng = np.random.default_rng(seed)
+    k = np.exp(sigma * rng.standard_normal(seq.meshes[-1].nt))
+    for _ in range(len(seq.meshes) - 1):
+        k = np.repeat(k, 8)
+    return 1.0 / k
+
+
+def darcy_problem(nref: int, nlevels: int | None = None, seq: "Sequence | None" = None, kinv: np.ndarray | None = None):
     """Mixed Darcy system of MultigridTestDarcy (``examples/MultigridTestDarcy.cpp:417-441``): blocks ``M`` (2-form mass),
     ``B = W D`` (``W`` the 3-form mass, ``D`` the divergence) and ``Bt = B^T`` of ``[[M, Bt], [B, 0]]``; no essential
     boundary labels on either form (``:479-480`` passes two empty label lists), so the true interpolators are the plain
     ``P2`` / ``P3`` of every level.
 
+    ``kinv``: optional per-element inverse permeability (heterogeneous-coefficient Darcy, BASELINE configs[4]).
+
     Returns dict(M, B, Bt, Ps=[(P2_l, P3_l)], seq); P*_l maps level l+1 -> l."""
     if seq is None:
         seq = Sequence.cube456(nref, nlevels)
     fine = seq.meshes[0]
-    M = fine.M2().tocsr()
+    M = fine.M2(weight=kinv).tocsr()
     B = (fine.M3() @ fine.D2()).tocsr()
     for X in (M, B):
         X.sort_indices()

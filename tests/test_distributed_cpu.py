@@ -66,3 +66,30 @@ def test_world_size_2_gloo():
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "DIST_WORKER_OK 2" in r.stdout
+
+
+@pytest.mark.parametrize("nparts", [2, 3, 5])
+def test_distributed_darcy_blocks_reassemble(nparts):
+    """faces / elements are owned per rank, rectangular blocks (B: elements x faces) carry separate row / column
+    partitions; every block and interpolator piece reproduces the global product through the oracle's exchange"""
+    from parelag_amd import meshgen
+    dar = meshgen.darcy_problem(0, seq=meshgen.Sequence.kuhn_cube(2, 1))
+    dd = partition.distributed_darcy(dar, nparts)
+    rng = np.random.default_rng(1)
+    for k, parts in dd["blocks"].items():
+        G = dd["global_blocks"][k]
+        W = orc.InProcessWorld(parts)
+        x = rng.standard_normal(G.shape[1]); y = rng.standard_normal(G.shape[0])
+        assert np.allclose(W.matvec(x), G @ x, rtol=1e-12, atol=1e-13)
+        assert np.allclose(W.matvec(y, trans=True), G.T @ y, rtol=1e-12, atol=1e-13)
+    (o2, o3), (c2, c3) = dd["order"][0], dd["order"][1]
+    for parts, P, fo, co in ((dd["P"][0][0], dar["Ps"][0][0], o2, c2), (dd["P"][0][1], dar["Ps"][0][1], o3, c3)):
+        Pg = sp.csr_matrix(P)[fo][:, co]
+        xc = rng.standard_normal(Pg.shape[1])
+        assert np.allclose(orc.InProcessWorld(parts).matvec(xc), Pg @ xc, rtol=1e-12, atol=1e-13)
+    # ownership: an element's rank owns it; a face belongs to the lowest rank among its elements
+    ep = partition.element_partitions(dar["seq"], nparts)[0]
+    own2 = partition.entity_owners(dar["seq"].meshes[0], ep, 2)
+    mesh = dar["seq"].meshes[0]
+    assert np.all(own2[mesh.tet_faces] <= ep[:, None])
+    assert np.array_equal(partition.entity_owners(mesh, ep, 3), ep)

@@ -301,3 +301,22 @@ def test_gmres_with_the_blocked_vcycle_converges_like_the_oracle(la, darcy_small
     assert abs(it - ito) <= 1 and it < 60      # (the oracle stops at 9.998e-9 on iteration 43: a threshold crossing)
     assert np.linalg.norm(A @ x - b) <= 1e-7 * np.linalg.norm(b)
     assert close(x, xo, 1e-6)
+
+
+def test_heterogeneous_coefficient_darcy_cycle_matches_oracle(la):
+    """BASELINE configs[4] (MultigridTestSPE10): the same blocked path with a strongly heterogeneous inverse permeability
+    in the velocity mass matrix (synthetic log-normal field, contrast ~1e5; the SPE10 data file is not in the reference)."""
+    from parelag_amd import meshgen
+    seq = meshgen.Sequence.kuhn_cube(2, 2)
+    kinv = meshgen.lognormal_inverse_permeability(seq, 2.0)
+    assert kinv.max() / kinv.min() > 1e4
+    d = meshgen.darcy_problem(0, seq=seq, kinv=kinv)
+    d["blocks"] = {(0, 0): d["M"], (0, 1): d["Bt"], (1, 0): d["B"]}
+    d["off"] = [0, d["M"].shape[0], d["M"].shape[0] + d["B"].shape[0]]
+    for kind in ("Block Jacobi", "Block LDU"):
+        H, _op = device_blocked_hierarchy(la, d, block_smoother=kind, use_negative_s=False)
+        Ho, _ = oracle_blocked_hierarchy(d["blocks"], d["Ps"], kind=kind, use_negative_s=False)
+        b = np.random.default_rng(31).uniform(-1, 1, d["off"][-1])
+        x, xr = np.zeros_like(b), np.zeros_like(b)
+        H.Mult(b, x); Ho.Mult(b, xr)
+        assert close(x, xr, 1e-10)

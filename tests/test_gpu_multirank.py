@@ -427,3 +427,35 @@ def test_distributed_krylov_matches_serial_oracle(problem, world, name):
         assert conv == bool(ref.converged) and its == ref.final_iter
         assert np.isclose(nrm, ref.final_norm, rtol=1e-4)
         assert np.max(np.abs(x - xr[order][lo:hi])) <= 1e-9 * np.max(np.abs(xr))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("kind", ["Block Jacobi", "Block GS"])
+def test_bench_layout_of_the_distributed_darcy_hierarchy(darcy, world, kind):
+    """bench.py --form darcy --gpus N: fine level distributed (merged operator + block smoother), blocked sub-hierarchy
+    replicated behind one all-reduce"""
+    from parelag_amd import distributed, linalg as la
+    from tests.helpers import oracle_blocked_hierarchy
+    n0, n1 = darcy["M"].shape[0], darcy["B"].shape[0]
+    rng = np.random.default_rng(19)
+    b0, b1 = rng.uniform(-1, 1, n0), rng.uniform(-1, 1, n1)
+
+    def body(dist):
+        H, n_local, shapes, _ = distributed.build_darcy_hierarchy(dist, darcy, kind, "L1 Jacobi")
+        dd = H._dist_info
+        rhs = la.DeviceVector.from_numpy(_local_block_vector(dd, 0, dist.rank, b0, b1))
+        sol = la.DeviceVector(n_local, 7.0)
+        H.Mult(rhs, sol); H.Mult(rhs, sol)
+        la.synchronize()
+        x = sol.to_numpy()
+        assert shapes[0][0] == n0 + n1 and len(shapes) == len(darcy["Ps"]) + 1
+        del H, rhs, sol
+        return x, dd
+    res = run_ranks(world, body)
+    Ho, _ = oracle_blocked_hierarchy({(0, 0): darcy["M"], (0, 1): darcy["Bt"], (1, 0): darcy["B"]}, darcy["Ps"],
+                                     kind="Block GS Lower" if kind == "Block GS" else kind)
+    xr = np.zeros(n0 + n1)
+    Ho.Mult(np.concatenate([b0, b1]), xr)
+    for r, (x, dd) in enumerate(res):
+        ref = _local_block_vector(dd, 0, r, xr[:n0], xr[n0:])
+        assert np.max(np.abs(x - ref)) <= 1e-10 * np.max(np.abs(xr))
