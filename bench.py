@@ -118,7 +118,7 @@ def main():
         if args.roofline_only:
             # only the launches of the one kernel, so a rocprofv3 --stats / --pmc pass of this command sees nothing else
             # under that kernel's name
-            print(json.dumps({"roofline": {"kernel": "spmv_stream_kernel", "n": n, "nnz": nnz, "bytes_per_launch": b,
+            print(json.dumps({"roofline": {"kernel": "spmv_xc_kernel", "n": n, "nnz": nnz, "bytes_per_launch": b,
                                            "ms_per_launch": round(ms, 5), "achieved_GBs": round(b / ms / 1e6, 1)}}))
             return
         ms_j = la.time_kernel(A0, "jacobi", x, y, reps=args.roofline_reps, smoother=Hr.GetSmoother(0))
@@ -130,7 +130,7 @@ def main():
             op = Hr.GetOperator(l)
             shapes_r.append((op.Height(), op.nnz, Pr[l].shape[1] if l < len(Pr) else 0, Pr[l].nnz if l < len(Pr) else 0))
         vb = vcycle_bytes(shapes_r)
-        roof = {"bound": "hbm", "kernel": "spmv_stream_kernel (fine-level y = A x, level-0 operator of the hierarchy)",
+        roof = {"bound": "hbm", "kernel": "spmv_xc_kernel (windowed x-cache form of the stream SpMV; fine-level y = A x, level-0 operator of the hierarchy)",
                 "workload": f"cube456 x{k} refines, H1 A: n={n}, nnz={nnz}",
                 "achieved": round(b / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,

@@ -182,7 +182,8 @@ ELAG_HIP_API int elag_hip_parcsr_norm(elag_hip_parcsr_t A, int kind, double *val
 /* hypre_ParCSRMatrixCompare (hypre_ParCSRMatrixCompare.c:125-195): bit mask 1..32 shape, 64 = |A-B|max>tol */
 ELAG_HIP_API int elag_hip_parcsr_compare(elag_hip_parcsr_t A, elag_hip_parcsr_t B, double tol, int *mask);
 /* Tuning knob: lanes of a wavefront that cooperate on one row in the SpMV kernels (power of two 1..64;
- * 0 restores the nnz/row heuristic).  No reference counterpart. */
+ * 0 restores the size heuristic; -2 forces the LDS-staged stream kernel, -1 its windowed x-cache form).
+ * No reference counterpart. */
 ELAG_HIP_API int elag_hip_parcsr_set_spmv_lanes(elag_hip_parcsr_t A, int lanes);
 /* a_ii of every local row -> d (device or host vector of num_rows) */
 ELAG_HIP_API int elag_hip_parcsr_get_diagonal(elag_hip_parcsr_t A, double *d, int loc);

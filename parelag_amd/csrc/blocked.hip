@@ -216,6 +216,9 @@ void BlockSmoother::setup()
         for (int i = 0; i < nb; i++)
             ELAG_REQUIRE(inv[(size_t)i] && inv[(size_t)i]->n() == B->row_off[(size_t)i + 1] - B->row_off[(size_t)i], "inverse of block %d has the wrong size", i);
     }
+    for (ParCSR *blk : B->blk)
+        if (blk) k::prepare_spmv(blk->diag);
+    for (auto *s : inv) if (s->A) k::prepare_spmv(s->A->diag);
     const size_t n = (size_t)A->nrows();
     resid = dev_alloc<double>(n); corr = dev_alloc<double>(n); tmp = dev_alloc<double>(n); spare = dev_alloc<double>(n);
     if (kind == ELAG_HIP_BLOCK_JACOBI) {

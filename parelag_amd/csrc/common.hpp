@@ -166,6 +166,13 @@ struct DevCSR {
     int lanes_per_row = 8;
     int *block_row = nullptr;  // nblocks+1 row offsets: block c owns rows whose first entry lies in [c*kStreamNnz, (c+1)*kStreamNnz)
     int nblocks = 0, max_row_nnz = 0;
+    // "x-cache" form of the stream kernel (built on first use for matrices whose windows reuse their columns): per
+    // window the sorted unique columns (ucols[uoff[c] .. uoff[c+1])) and, per entry, the 16-bit position of its column
+    // in that list.  The kernel gathers x once per unique column into LDS and streams 10 bytes per entry.
+    mutable unsigned short *lidx = nullptr;
+    mutable int *uoff = nullptr, *ucols = nullptr;
+    mutable int xc_state = 0;   // 0 = not examined, 1 = built, -1 = not worthwhile / not applicable
+    mutable int xc_max_unique = 0;
 
     static constexpr int kStreamNnz = 2048;     // entries per 256-thread workgroup
     static constexpr int kStreamMaxRow = 4096;  // longer rows fall back to the row-group kernel
@@ -180,12 +187,15 @@ struct DevCSR {
             release();
             nrows = o.nrows; ncols = o.ncols; nnz = o.nnz; I = o.I; J = o.J; a = o.a;
             lanes_per_row = o.lanes_per_row; block_row = o.block_row; nblocks = o.nblocks; max_row_nnz = o.max_row_nnz;
+            lidx = o.lidx; uoff = o.uoff; ucols = o.ucols; xc_state = o.xc_state; xc_max_unique = o.xc_max_unique;
+            o.lidx = nullptr; o.uoff = nullptr; o.ucols = nullptr; o.xc_state = 0;
             o.I = o.J = nullptr; o.a = nullptr; o.block_row = nullptr; o.nnz = 0; o.nrows = o.ncols = 0; o.nblocks = 0;
         }
         return *this;
     }
     ~DevCSR() { release(); }
-    void release() { dev_free(I); dev_free(J); dev_free(a); dev_free(block_row); nblocks = 0; }
+    void release_xc() const { dev_free(lidx); dev_free(uoff); dev_free(ucols); xc_state = 0; }
+    void release() { dev_free(I); dev_free(J); dev_free(a); dev_free(block_row); nblocks = 0; release_xc(); }
     void alloc(int nr, int nc, int64_t nz);
     void alloc_entries(int64_t nz);   // J / a (+pad) for a matrix whose I is already in place
     void upload(int nr, int nc, const int *hi, const int *hj, const double *ha);

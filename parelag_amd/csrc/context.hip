@@ -154,6 +154,7 @@ void DevCSR::choose_spmv_shape()
     }
     dev_free(block_row);
     nblocks = 0;
+    release_xc();
     k::build_stream_plan(*this);
     if (forced > 0) { lanes_per_row = forced; return; }
     // the stream kernel wins once the matrix outgrows the caches' latency regime; small (coarse-level) operators

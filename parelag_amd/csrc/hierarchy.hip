@@ -107,6 +107,14 @@ struct elag_hip_hierarchy_s {
         all_local = local_only;
         use_graph = graph && local_only;
         plan_fused();
+        // SpMV forms that are built on first use must exist before the cycle is captured into a graph
+        for (auto &L : lev) {
+            k::prepare_spmv(L.A->diag);
+            if (L.P) { k::prepare_spmv(L.P->diag); if (L.P->diagT) k::prepare_spmv(*L.P->diagT); }
+            if (L.G) k::prepare_spmv(*L.G);
+            if (L.S) k::prepare_spmv(*L.S);
+        }
+        if (A_user) k::prepare_spmv(A_user->diag);
         plan_dense_tail();
         finalized = true;
         ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));

@@ -32,6 +32,9 @@ struct SpmvArgs {
 void spmv_fused(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, hipStream_t st = nullptr);
 // row-block plan of the LDS-staged stream kernel (block_row, nblocks, max_row_nnz); synchronous, setup time
 void build_stream_plan(DevCSR &A);
+// builds the x-cache form of a stream-kernel matrix if it pays (synchronous, allocates: never call while capturing);
+// spmv_fused does this lazily on the first uncaptured launch, hierarchies do it for their operators at Finalize
+void prepare_spmv(const DevCSR &A, bool force = false);
 
 // ---- vector kernels ----------------------------------------------------------------------------
 void vec_axpby(int n, double a, const double *x, double b, const double *y, double *out);  // out = a x + b y

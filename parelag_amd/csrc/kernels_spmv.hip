@@ -193,6 +193,165 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
     }
 }
 
+// ---- x-cache variant -------------------------------------------------------------------------------------------------
+// Same window decomposition and storage-order row sums as spmv_stream_kernel, but the gather is done once per DISTINCT
+// column of the window: phase 1 loads x (times cs) for the window's sorted unique columns into LDS (ascending addresses,
+// long contiguous runs after the hierarchy renumbering), phase 2 streams the values with a 16-bit LDS index per entry
+// (10 bytes per entry from HBM instead of 12, and no global gather in the inner loop).
+typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
+
+template <bool HAS_CS>
+__global__ __launch_bounds__(kBlock) void spmv_xc_kernel(
+    int nrows, const int *__restrict__ I, const double *__restrict__ a, const unsigned short *__restrict__ lidx,
+    const int *__restrict__ block_row, const int *__restrict__ uoff, const int *__restrict__ ucols, const int *__restrict__ oI,
+    int cap, SpmvArgs p)
+{
+    extern __shared__ double sh[];
+    double *prod = sh, *xs = sh + cap;
+    const int win = blockIdx.x;
+    const int4v br = *reinterpret_cast<const int4v *>(block_row + 2 * win);
+    const int r0 = br.x, kbeg = br.y, r1 = br.z, kend = br.w;
+    if (r0 >= r1) return;
+    const int kal = kbeg & ~3;
+    const double *__restrict__ x = p.x;
+    const double *__restrict__ cs = p.cs;
+    const int u0 = uoff[win], nu = uoff[win + 1] - u0;
+
+    const int row0 = r0 + (int)threadIdx.x;
+    const bool has0 = row0 < r1;
+    int s0 = 0, e0 = 0;
+    double f0 = 0.0, y0 = 0.0, sc0 = 1.0, sc20 = 1.0;
+    if (has0) {
+        s0 = I[row0]; e0 = I[row0 + 1];
+        if (p.f) f0 = p.f[row0];
+        if (p.yin) y0 = p.yin[row0];
+        if (p.s) sc0 = p.s[row0];
+        if (p.s2) sc20 = p.s2[row0];
+    }
+    // the value / position stream of this lane's first two quads is requested before the gather phase, so both
+    // memory streams are in flight together
+    const int k0 = kal + (int)threadIdx.x * 4, k1 = k0 + kBlock * 4;
+    ushort4v l0 = {0, 0, 0, 0}, l1 = {0, 0, 0, 0};
+    double2v a0a = {0, 0}, a0b = {0, 0}, a1a = {0, 0}, a1b = {0, 0};
+    if (k0 < kend) { l0 = *reinterpret_cast<const ushort4v *>(lidx + k0); a0a = *reinterpret_cast<const double2v *>(a + k0); a0b = *reinterpret_cast<const double2v *>(a + k0 + 2); }
+    if (k1 < kend) { l1 = *reinterpret_cast<const ushort4v *>(lidx + k1); a1a = *reinterpret_cast<const double2v *>(a + k1); a1b = *reinterpret_cast<const double2v *>(a + k1 + 2); }
+    for (int u = (int)threadIdx.x; u < nu; u += kBlock) {
+        const int c = ucols[u0 + u];
+        double v = x[c];
+        if (HAS_CS) v *= cs[c];
+        xs[u] = v;
+    }
+    __syncthreads();
+    if (k0 < kend) {
+        double2v p01, p23;
+        p01.x = a0a.x * xs[l0.x]; p01.y = a0a.y * xs[l0.y]; p23.x = a0b.x * xs[l0.z]; p23.y = a0b.y * xs[l0.w];
+        *reinterpret_cast<double2v *>(prod + (k0 - kal)) = p01;
+        *reinterpret_cast<double2v *>(prod + (k0 - kal) + 2) = p23;
+    }
+    if (k1 < kend) {
+        double2v p01, p23;
+        p01.x = a1a.x * xs[l1.x]; p01.y = a1a.y * xs[l1.y]; p23.x = a1b.x * xs[l1.z]; p23.y = a1b.y * xs[l1.w];
+        *reinterpret_cast<double2v *>(prod + (k1 - kal)) = p01;
+        *reinterpret_cast<double2v *>(prod + (k1 - kal) + 2) = p23;
+    }
+    for (int k = k1 + kBlock * 4; k < kend; k += kBlock * 4) {
+        const ushort4v l4 = *reinterpret_cast<const ushort4v *>(lidx + k);
+        const double2v a01 = *reinterpret_cast<const double2v *>(a + k);
+        const double2v a23 = *reinterpret_cast<const double2v *>(a + k + 2);
+        // (entries of the neighbouring windows inside the first / last quad carry their own window's positions; they
+        //  stay below the xs capacity, and their products are never summed)
+        double2v p01, p23;
+        p01.x = a01.x * xs[l4.x]; p01.y = a01.y * xs[l4.y]; p23.x = a23.x * xs[l4.z]; p23.y = a23.y * xs[l4.w];
+        *reinterpret_cast<double2v *>(prod + (k - kal)) = p01;
+        *reinterpret_cast<double2v *>(prod + (k - kal) + 2) = p23;
+    }
+    __syncthreads();
+    if (has0 && !(p.skip_rows_with_offd && oI && oI[row0 + 1] > oI[row0])) {
+        double sum = 0.0;
+        for (int k = s0 - kal; k < e0 - kal; k++) sum += prod[k];
+        double t = p.alpha * sum;
+        t *= sc20;
+        t += p.gamma * f0;
+        t *= sc0;
+        t += p.beta * y0;
+        p.out[row0] = t;
+        if (p.out2) p.out2[row0] = HAS_CS ? x[row0] * p.cs[row0] : x[row0];
+    }
+    for (int row = row0 + kBlock; row < r1; row += kBlock) {
+        if (p.skip_rows_with_offd && oI && oI[row + 1] > oI[row]) continue;
+        const int s = I[row] - kal, e = I[row + 1] - kal;
+        double sum = 0.0;
+        for (int k = s; k < e; k++) sum += prod[k];
+        double t = p.alpha * sum;
+        if (p.s2) t *= p.s2[row];
+        if (p.f) t += p.gamma * p.f[row];
+        if (p.s) t *= p.s[row];
+        if (p.yin) t += p.beta * p.yin[row];
+        p.out[row] = t;
+        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
+    }
+}
+
+// One workgroup per window: sort the window's columns in LDS (bitonic), mark the first element of every run, scan.
+// fill == 0: ucount[c] = number of distinct columns.  fill == 1: ucols / lidx are written.
+constexpr int kXcCap = 4096;   // entries per window the builder handles (kStreamNnz + max_row <= kXcCap)
+
+__global__ __launch_bounds__(kBlock) void xc_build_kernel(const int *__restrict__ block_row, const int *__restrict__ J, int *__restrict__ ucount,
+                                                          const int *__restrict__ uoff, int *__restrict__ ucols,
+                                                          unsigned short *__restrict__ lidx, int fill)
+{
+    __shared__ int keys[kXcCap];
+    __shared__ unsigned short pos[kXcCap];
+    __shared__ int part[kBlock];
+    const int c = blockIdx.x;
+    const int kbeg = block_row[2 * c + 1], kend = block_row[2 * c + 3];
+    const int len = kend - kbeg;
+    int npow = 256;
+    while (npow < len) npow <<= 1;
+    for (int i = threadIdx.x; i < npow; i += kBlock) keys[i] = i < len ? J[kbeg + i] : 0x7fffffff;
+    __syncthreads();
+    for (int size = 2; size <= npow; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < (npow >> 1); t += kBlock) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const int a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    // run starts among the first `len` sorted keys; each thread owns a contiguous chunk
+    const int per = npow / kBlock;
+    const int b0 = threadIdx.x * per;
+    int cnt = 0;
+    for (int i = b0; i < b0 + per; i++)
+        if (i < len && (i == 0 || keys[i] != keys[i - 1])) cnt++;
+    part[threadIdx.x] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int t = 0; t < kBlock; t++) { const int v = part[t]; part[t] = acc; acc += v; }
+        if (!fill) ucount[c] = acc;
+    }
+    __syncthreads();
+    if (!fill) return;
+    int run = part[threadIdx.x];   // distinct columns before this chunk
+    const int u0 = uoff[c];
+    for (int i = b0; i < b0 + per; i++) {
+        if (i >= len) break;
+        if (i == 0 || keys[i] != keys[i - 1]) { ucols[u0 + run] = keys[i]; run++; }
+        pos[i] = (unsigned short)(run - 1);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < len; e += kBlock) {
+        const int col = J[kbeg + e];
+        int lo = 0, hi = len;   // first sorted position holding col
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < col) lo = mid + 1; else hi = mid; }
+        lidx[kbeg + e] = pos[lo];
+    }
+}
+
 __global__ void stream_plan_kernel(int nrows, const int *__restrict__ I, int nblocks, int window, int *__restrict__ block_row)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -233,8 +392,33 @@ void launch_stream_v(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hip
     ELAG_LAUNCH_CHECK();
 }
 
+int xc_mode()
+{
+    static int v = -2;
+    if (v == -2) { const char *e = getenv("ELAG_HIP_XC"); v = e ? atoi(e) : -1; }   // 0 = off, 1 = always when applicable, -1 = heuristic
+    return v;
+}
+
+void launch_xc(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hipStream_t st)
+{
+    const int cap = DevCSR::kStreamNnz + A.max_row_nnz + 8;
+    const size_t lds = sizeof(double) * ((size_t)cap + (size_t)A.xc_max_unique);
+    const int *oI = (p.skip_rows_with_offd && offd) ? offd->I : nullptr;
+    if (p.cs)
+        hipLaunchKernelGGL((spmv_xc_kernel<true>), dim3((unsigned)A.nblocks), dim3(kBlock), lds, st, A.nrows, A.I, A.a, A.lidx, A.block_row, A.uoff, A.ucols, oI, cap, p);
+    else
+        hipLaunchKernelGGL((spmv_xc_kernel<false>), dim3((unsigned)A.nblocks), dim3(kBlock), lds, st, A.nrows, A.I, A.a, A.lidx, A.block_row, A.uoff, A.ucols, oI, cap, p);
+    ELAG_LAUNCH_CHECK();
+}
+
 void launch_stream(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hipStream_t st)
 {
+    if (A.xc_state == 0 && xc_mode() != 0) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cs);
+        if (cs == hipStreamCaptureStatusNone) prepare_spmv(A);
+    }
+    if (A.xc_state == 1 && stream_variant() != 4) { launch_xc(A, offd, p, st); return; }
     // ELAG_HIP_STREAM_VARIANT=4 selects a DIAGNOSTIC build of the kernel (coalesced x reads, wrong results) that
     // prices the gather: 7.2 TB/s against 5.1-5.4 TB/s for the real kernel
     if (stream_variant() == 4) launch_stream_v<4>(A, offd, p, st);
@@ -260,6 +444,52 @@ void build_stream_plan(DevCSR &A)
     ELAG_LAUNCH_CHECK();
     ELAG_HIP_CHECK(hipMemcpyAsync(&A.max_row_nnz, m.p, sizeof(int), hipMemcpyDeviceToHost, st));
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
+}
+
+void prepare_spmv(const DevCSR &A, bool force)
+{
+    if (A.xc_state != 0 || (xc_mode() == 0 && !force)) return;
+    A.xc_state = -1;
+    if (A.lanes_per_row != 0 || !A.block_row || A.nnz == 0 || A.nblocks == 0) return;
+    // Measured: the form pays only for operators streamed from HBM (cube456 x5, 37.7 M entries: +6 % SpMV, +12 % Jacobi
+    // sweep); operators that stay resident in the 256 MB Infinity Cache (x3 / x4 sizes) run 2-5 % faster with the plain
+    // stream kernel, whose single phase hides the cache latency better.
+    if (!force && xc_mode() < 0 && A.nnz < (int64_t(1) << 24)) return;
+    if (DevCSR::kStreamNnz + A.max_row_nnz + 8 > kXcCap) return;   // window must fit the builder and two LDS arrays (<= 64 KB)
+    hipStream_t st = ctx().stream;
+    const int nb = A.nblocks;
+    int *uoff = dev_alloc<int>((size_t)nb + 1);
+    int total = 0;
+    {
+        Temp<int> ucount((size_t)nb);
+        hipLaunchKernelGGL(xc_build_kernel, dim3((unsigned)nb), dim3(kBlock), 0, st, (const int *)A.block_row, (const int *)A.J, ucount.p,
+                           (const int *)nullptr, (int *)nullptr, (unsigned short *)nullptr, 0);
+        ELAG_LAUNCH_CHECK();
+        exclusive_scan(ucount, uoff, nb);
+        ELAG_HIP_CHECK(hipMemcpyAsync(&total, uoff + nb, sizeof(int), hipMemcpyDeviceToHost, st));
+        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    // worthwhile when a column is used by >= 2 entries of its window on average (otherwise the plain gather is as good)
+    const double reuse = total ? (double)A.nnz / total : 0.0;
+    {
+        std::vector<int> ho = host_from_dev((const int *)uoff, (size_t)nb + 1);
+        int mx = 0;
+        for (int c = 0; c < nb; c++) mx = std::max(mx, ho[(size_t)c + 1] - ho[(size_t)c]);
+        A.xc_max_unique = (mx + 7) & ~7;
+        if (getenv("ELAG_HIP_XC_VERBOSE"))
+            fprintf(stderr, "[elag_hip] x-cache: n=%d nnz=%lld windows=%d unique/window avg %.1f max %d reuse %.2f\n", A.nrows, (long long)A.nnz, nb,
+                    (double)total / nb, mx, reuse);
+    }
+    if (!force && xc_mode() < 0 && reuse < 2.0) { dev_free(uoff); return; }
+    A.uoff = uoff;
+    A.ucols = dev_alloc<int>((size_t)total);
+    A.lidx = dev_alloc<unsigned short>((size_t)A.nnz + 8);
+    ELAG_HIP_CHECK(hipMemsetAsync(A.lidx + A.nnz, 0, 8 * sizeof(unsigned short), st));
+    hipLaunchKernelGGL(xc_build_kernel, dim3((unsigned)nb), dim3(kBlock), 0, st, (const int *)A.block_row, (const int *)A.J, (int *)nullptr,
+                       (const int *)A.uoff, A.ucols, A.lidx, 1);
+    ELAG_LAUNCH_CHECK();
+    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    A.xc_state = 1;
 }
 
 void spmv_fused(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, hipStream_t st)

@@ -302,6 +302,7 @@ struct elag_hip_krylov_s {
         ELAG_HIP_CHECK(hipMemset(st, 0, sizeof(KState)));
         ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_flags), sizeof(int) * F_COUNT));
         ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_sc), sizeof(double) * S_COUNT));
+        k::prepare_spmv(A->diag);
         x = dev_alloc<double>(nn); r = dev_alloc<double>(nn); z = dev_alloc<double>(nn); scr = dev_alloc<double>(nn);
         if (solver == ELAG_HIP_KRYLOV_CG) d = dev_alloc<double>(nn);
         if (solver == ELAG_HIP_KRYLOV_STATIONARY) { d = dev_alloc<double>(nn); }

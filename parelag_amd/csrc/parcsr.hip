@@ -586,7 +586,16 @@ int elag_hip_parcsr_set_spmv_lanes(elag_hip_parcsr_t A, int lanes)
 {
     return guarded([&] {
         ELAG_REQUIRE(A, "null matrix");
-        ELAG_REQUIRE(lanes >= 0 && lanes <= 64 && (lanes & (lanes - 1)) == 0, "lanes must be 0 or a power of two <= 64");
+        if (lanes == -1 || lanes == -2) {
+            // the LDS-staged stream kernel regardless of size; -1 additionally forces its windowed x-cache form
+            ELAG_REQUIRE(A->diag.block_row && A->diag.max_row_nnz <= DevCSR::kStreamMaxRow, "rows too long for the stream kernel");
+            A->diag.lanes_per_row = 0;
+            A->diag.release_xc();
+            if (lanes == -1) k::prepare_spmv(A->diag, true);
+            else A->diag.xc_state = -1;
+            return;
+        }
+        ELAG_REQUIRE(lanes >= 0 && lanes <= 64 && (lanes & (lanes - 1)) == 0, "lanes must be -2, -1, 0 or a power of two <= 64");
         if (lanes == 0) { A->diag.choose_spmv_shape(); A->offd.choose_spmv_shape(); }
         else A->diag.lanes_per_row = lanes;
     });

@@ -240,6 +240,9 @@ void HiptmairSmoother::setup()
     auxx = dev_alloc<double>((size_t)D->ncols());
     auxalt = dev_alloc<double>((size_t)D->ncols());
     D->ensure_transpose();
+    k::prepare_spmv(A->diag); k::prepare_spmv(D->diag);
+    if (D->diagT) k::prepare_spmv(*D->diagT);
+    if (aux->A) k::prepare_spmv(aux->A->diag);
 }
 
 void HiptmairSmoother::aux_correct(const double *resid, double *x)

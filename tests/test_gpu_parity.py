@@ -626,3 +626,66 @@ def test_degenerate_hierarchies(la, h1_k1):
     Hbad.SetOperator(0, dA)
     with pytest.raises(ElagHipError):
         Hbad.Finalize()                                           # level 1 has no operator
+
+
+# ---- large-operator SpMV forms (stream / x-cache kernels: nnz >= 2^20) ----------------------------------------------------
+
+def _banded(n, m, per_row, band, seed):
+    """n x m matrix with `per_row` entries per row inside a sliding band (columns reused by neighbouring rows)"""
+    rng = np.random.default_rng(seed)
+    centre = (np.arange(n) * (m / n)).astype(np.int64)
+    cols = (centre[:, None] + rng.integers(-band, band + 1, size=(n, per_row))) % m
+    rows = np.repeat(np.arange(n), per_row)
+    A = sp.csr_matrix((rng.uniform(-1, 1, n * per_row), (rows, cols.ravel())), shape=(n, m))
+    A.sum_duplicates(); A.sort_indices()
+    return orc.csr(A)
+
+
+@pytest.mark.parametrize("n,m,per_row,band", [(140000, 140000, 12, 40), (60000, 300000, 24, 300), (400000, 50000, 4, 6),
+                                              (100001, 100001, 16, 20000)])
+def test_large_operator_spmv_forms_match_scipy(la, n, m, per_row, band):
+    """every epilogue the V-cycle uses, on operators big enough for the LDS-staged kernels (incl. the windowed x-cache
+    form when the band makes columns reusable, and its fall-back when it does not)"""
+    A = _banded(n, m, per_row, band, 42)
+    assert A.nnz >= (1 << 20)
+    M = la.ParallelCSRMatrix.from_scipy(A)
+    rng = np.random.default_rng(43)
+    x = rng.uniform(-1, 1, m); y0 = rng.uniform(-1, 1, n)
+    scale = np.max(np.abs(A) @ np.abs(x)) + 1.0
+    for form in (0, -2, -1):      # heuristic choice, plain stream kernel, windowed x-cache form
+        M.set_spmv_lanes(form)
+        for alpha, beta in ((1.0, 0.0), (-0.5, 2.0)):
+            y = y0.copy()
+            M.Mult(x, y, alpha, beta)
+            assert close(y, alpha * (A @ x) + beta * y0, scale=scale)
+    xt = rng.uniform(-1, 1, n); z = np.zeros(m)
+    M.MultTranspose(xt, z)
+    assert close(z, A.T @ xt, scale=np.max(np.abs(A).T @ np.abs(xt)) + 1.0)
+    if n == m:
+        b, r = rng.uniform(-1, 1, n), np.empty(n)
+        M.residual(b, x, r)
+        assert close(r, b - A @ x, scale=scale)
+
+
+def test_large_operator_smoother_and_cycle_forms(la):
+    """l1-Jacobi (s, yin epilogue), Chebyshev (cs / s / beta forms) and the zero-guess + residual fusion on a big SPD band"""
+    n = 150000
+    B = _banded(n, n, 10, 30, 5)
+    A = orc.csr(B + B.T + sp.diags(np.asarray(abs(B).sum(axis=1)).ravel() + np.asarray(abs(B).sum(axis=0)).ravel() + 1.0))
+    assert A.nnz >= (1 << 20)
+    M = la.ParallelCSRMatrix.from_scipy(A)
+    M.set_spmv_lanes(-1)          # x-cache form (the default only selects it for operators streamed from HBM)
+    rng = np.random.default_rng(6)
+    b, x0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    for sweeps in (1, 2):
+        S = la.HypreSmootherWrapper(M, 1, {"Sweeps": sweeps, "Damping Factor": 0.9})
+        x = x0.copy()
+        S.Mult(b, x)
+        So = orc.OSmoother(orc.OParCSR(orc.diag_first(A)), type=1, sweeps=sweeps, weight=0.9)
+        xr = x0.copy(); So.Mult(b, xr)
+        assert close(x, xr)
+    C = la.HypreSmootherWrapper(M, 16, {"Cheby Poly Order": 3})
+    x = x0.copy(); C.Mult(b, x)
+    Co = orc.OSmoother(orc.OParCSR(orc.diag_first(A)), type=16, order=3, eig=C.eig_estimate())
+    xr = x0.copy(); Co.Mult(b, xr)
+    assert close(x, xr, tol=1e-11)

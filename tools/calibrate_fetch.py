@@ -12,6 +12,7 @@ A, _, _ = meshgen.h1_problem(k, nlevels=1)
 n, nnz = A.shape[0], A.nnz
 B = sp.csr_matrix((A.data, np.zeros(nnz, np.int32), A.indptr), shape=A.shape)
 dB = la.ParallelCSRMatrix.from_scipy(B)
+dB.set_spmv_lanes(-2)     # the plain stream kernel: its HBM read bytes are exactly the J / a / I streams counted below
 x = la.DeviceVector.from_numpy(np.ones(n)); y = la.DeviceVector(n)
 ms = la.time_kernel(dB, "spmv", x, y, reps=50)
 print(json.dumps({"calibration": True, "n": n, "nnz": nnz, "known_read_bytes": 12 * nnz + 4 * (n + 1), "ms_per_launch": ms}))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence for bench.py's roofline object (run on the GPU box from the repo root):
-#   1. --kernel-trace --stats of bench.py --roofline-only    -> mean duration of spmv_stream_kernel
+#   1. --kernel-trace --stats of bench.py --roofline-only    -> mean duration of spmv_xc_kernel
 #   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE of the same command (separate passes)
 #   3. --pmc FETCH_SIZE of tools/calibrate_fetch.py              -> gfx950 FETCH_SIZE correction for this access pattern
 # usage: tools/roofline_profile.sh <tag>      (writes gpurun_out/<tag>/summary.txt and roofline_traffic.json)
@@ -16,13 +16,15 @@ python3 - <<PY
 import csv, glob, json, collections
 out = "$OUT"
 L = []
+KERN = "spmv_xc_kernel"        # the kernel bench.py --roofline-only launches (windowed x-cache form of the stream SpMV)
 def stats():
     for f in sorted(glob.glob(out + "/kt/**/*kernel_stats.csv", recursive=True)):
         for r in csv.DictReader(open(f)):
-            if "spmv_stream_kernel" in r["Name"]:
+            if KERN in r["Name"]:
                 return int(r["Calls"]), float(r["AverageNs"])
     return 0, 0.0
-def pmc(d, counter, kern="spmv_stream_kernel"):
+def pmc(d, counter, kern=None):
+    kern = kern or KERN
     s = n = 0
     for f in glob.glob(out + f"/{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -33,18 +35,18 @@ calls, avg_ns = stats()
 bench = json.loads([l for l in open(out + "/kt.log") if l.startswith("{")][-1])["roofline"]
 fetch_kb, nf = pmc("fetch", "FETCH_SIZE")
 write_kb, nw = pmc("write", "WRITE_SIZE")
-cal_kb, nc = pmc("calib", "FETCH_SIZE")
+cal_kb, nc = pmc("calib", "FETCH_SIZE", "spmv_stream_kernel")
 cal = json.loads([l for l in open(out + "/calib.log") if l.startswith("{")][-1])
 factor = cal["known_read_bytes"] / (cal_kb * 1024.0)
 traffic = factor * fetch_kb * 1024.0 + write_kb * 1024.0
 L.append("# rocprofv3 evidence for bench.py's roofline object -- command: python3 bench.py --roofline-only")
-L.append(f"kernel: spmv_stream_kernel<false, 0>  (level-0 operator of the cube456 x5 hierarchy, n={bench['n']}, nnz={bench['nnz']})")
+L.append(f"kernel: {KERN}<false>  (level-0 operator of the cube456 x5 hierarchy, n={bench['n']}, nnz={bench['nnz']})")
 L.append(f"rocprofv3 --kernel-trace --stats: calls={calls}  AverageNs={avg_ns:.1f}  ({avg_ns/1e3:.2f} us)")
 L.append(f"bench.py HIP events (same run):  ms_per_launch={bench['ms_per_launch']}  ({bench['ms_per_launch']*1e3:.2f} us), algorithmic bytes/launch={bench['bytes_per_launch']}")
 L.append(f"achieved = {bench['bytes_per_launch']/avg_ns:.1f} GB/s by rocprof mean, {bench['achieved_GBs']} GB/s by HIP events; peak 8000 GB/s (HBM3E spec), 6290 GB/s measured copy")
 L.append(f"--pmc FETCH_SIZE (own pass): mean {fetch_kb:.1f} KB per launch over {nf} launches")
 L.append(f"--pmc WRITE_SIZE (own pass): mean {write_kb:.1f} KB per launch over {nw} launches")
-L.append(f"calibration (tools/calibrate_fetch.py: same stream, all column indices 0 => HBM reads are exactly {cal['known_read_bytes']} B): FETCH_SIZE {cal_kb:.1f} KB over {nc} launches -> correction factor {factor:.4f}")
+L.append(f"calibration (tools/calibrate_fetch.py: plain stream kernel on the same operator, all column indices 0 => HBM reads are exactly {cal['known_read_bytes']} B): FETCH_SIZE {cal_kb:.1f} KB over {nc} launches -> correction factor {factor:.4f}")
 L.append(f"traffic per launch = factor * FETCH_SIZE + WRITE_SIZE = {traffic:.0f} B = {traffic/bench['bytes_per_launch']:.3f} x algorithmic")
 open(out + "/summary.txt", "w").write("\n".join(L) + "\n")
 json.dump({"n": bench["n"], "nnz": bench["nnz"], "traffic_bytes_per_launch": int(traffic), "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
