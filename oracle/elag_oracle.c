@@ -26,6 +26,34 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+/* The same source builds the multi-core timing baseline (oracle/Makefile target libelag_oracle_omp.so, -fopenmp): the
+ * row loops of the V-cycle are split statically over the cores, which is the work split of the reference's
+ * one-MPI-rank-per-core runs without their message passing (so it flatters the CPU).  Row sums keep their storage
+ * order; only P^T r is formed from an explicit transpose (as newer hypre does) instead of the serial scatter-add, so
+ * that result differs from the serial oracle in the last bits.  The parity checks always use the serial build. */
+#ifdef _OPENMP
+#include <omp.h>
+#define ORC_PFOR _Pragma("omp parallel for schedule(static)")
+#else
+#define ORC_PFOR
+#endif
+ORC_API int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+ORC_API void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* ------------------------------------------------------------------------------------------------
  * CSR matvec  y = alpha*A*x + beta*y
  * Follows the double-precision twin of hypre_CSRMatrixMatvecBoolInt
@@ -36,19 +64,20 @@
 ORC_API void orc_csr_matvec(int n, const int *I, const int *J, const double *a,
                             double alpha, const double *x, double beta, double *y)
 {
-    int i, jj;
+    int i;
     if (alpha == 0.0) { for (i = 0; i < n; i++) y[i] *= beta; return; }
     double temp = beta / alpha;
     if (temp != 1.0) {
-        if (temp == 0.0) for (i = 0; i < n; i++) y[i] = 0.0;
-        else             for (i = 0; i < n; i++) y[i] *= temp;
+        if (temp == 0.0) { ORC_PFOR for (i = 0; i < n; i++) y[i] = 0.0; }
+        else             { ORC_PFOR for (i = 0; i < n; i++) y[i] *= temp; }
     }
+    ORC_PFOR
     for (i = 0; i < n; i++) {
         double t = 0.0;
-        for (jj = I[i]; jj < I[i + 1]; jj++) t += a[jj] * x[J[jj]];
+        for (int jj = I[i]; jj < I[i + 1]; jj++) t += a[jj] * x[J[jj]];
         y[i] += t;
     }
-    if (alpha != 1.0) for (i = 0; i < n; i++) y[i] *= alpha;
+    if (alpha != 1.0) { ORC_PFOR for (i = 0; i < n; i++) y[i] *= alpha; }
 }
 
 /* y = alpha*A^T*x + beta*y ; scatter-add form of hypre_CSRMatrixMatvecT, the kernel behind
@@ -137,7 +166,7 @@ ORC_API int orc_l1_norms(int n, const int *dI, const int *dJ, const double *da,
 /* u[i] += v[i]/l1[i] -- tail of hypre_ParCSRRelax relax_type 1 (l1-Jacobi) [3P par_relax_more.c];
  * the preceding step v = -w*A*u + w*f is a ParCSR matvec done by the caller. */
 ORC_API void orc_jacobi_update(int n, const double *v, const double *l1, double *u)
-{ for (int i = 0; i < n; i++) u[i] += v[i] / l1[i]; }
+{ ORC_PFOR for (int i = 0; i < n; i++) u[i] += v[i] / l1[i]; }
 
 /* hypre_ParCSRRelax relax_type 2/4 (l1 Gauss-Seidel, the reference's shipped default smoother:
  * examples/testing_helpers/Create0FormParameterList.hpp:103-116), relax_weight = omega = 1 branch:
@@ -199,15 +228,15 @@ ORC_API void orc_inv_sqrt_diag(int n, const int *dI, const double *da, double *d
 
 /* vector pieces of the scaled Chebyshev sweep (the matvecs in between are done by the caller) */
 ORC_API void orc_cheby_r(int n, const double *ds, const double *f, const double *tmp, double *r)
-{ for (int j = 0; j < n; j++) r[j] = ds[j] * (f[j] + tmp[j]); }
+{ ORC_PFOR for (int j = 0; j < n; j++) r[j] = ds[j] * (f[j] + tmp[j]); }
 ORC_API void orc_cheby_start(int n, double c, const double *r, double *u, double *orig)
-{ for (int j = 0; j < n; j++) { orig[j] = u[j]; u[j] = r[j] * c; } }
+{ ORC_PFOR for (int j = 0; j < n; j++) { orig[j] = u[j]; u[j] = r[j] * c; } }
 ORC_API void orc_vec_mul(int n, const double *a, const double *b, double *out)
-{ for (int j = 0; j < n; j++) out[j] = a[j] * b[j]; }
+{ ORC_PFOR for (int j = 0; j < n; j++) out[j] = a[j] * b[j]; }
 ORC_API void orc_cheby_step(int n, double c, const double *r, const double *ds, const double *v, double *u)
-{ for (int j = 0; j < n; j++) { double t = ds[j] * v[j]; u[j] = c * r[j] + t; } }
+{ ORC_PFOR for (int j = 0; j < n; j++) { double t = ds[j] * v[j]; u[j] = c * r[j] + t; } }
 ORC_API void orc_cheby_finish(int n, const double *orig, const double *ds, double *u)
-{ for (int j = 0; j < n; j++) u[j] = orig[j] + ds[j] * u[j]; }
+{ ORC_PFOR for (int j = 0; j < n; j++) u[j] = orig[j] + ds[j] * u[j]; }
 
 /* hypre_Rand / hypre_SeqVectorSetRandomValues [3P utilities/random.c]: Lehmer LCG a=16807,
  * m=2^31-1 via Schrage (q=127773, r=2836); value = 2*rand-1.  Used for the CG eigen-estimate start. */
@@ -602,6 +631,8 @@ typedef struct {
     int hiptmair;
     orc_csr D;  int naux;  orc_csr Aaux;  orc_smoother sm_aux;
     double *tmp_resid, *tmp_correct, *resid, *sol, *v, *z, *r, *auxb, *auxx, *pv, *auxv, *auxz, *auxr;
+    /* multi-core build only: explicit transposes so that P^T r / D^T r are row-parallel gathers */
+    int *PTI, *PTJ, *DTI, *DTJ; double *PTa, *DTa;
 } orc_level;
 
 typedef struct {
@@ -632,11 +663,11 @@ static void smoother_apply(const orc_csr *A, const orc_smoother *s, const double
                    vector; here row i of w is consumed as soon as it is formed (same arithmetic:
                    matvec(1.0, A, tmp, 0.0, w) gives w_i = 0 + sum in storage order). */
                 double *tmp = z;
-                int row, jj;
                 orc_vec_mul(n, s->ds, u, tmp);
-                for (row = 0; row < n; row++) {
+                ORC_PFOR
+                for (int row = 0; row < n; row++) {
                     double t = 0.0;
-                    for (jj = A->I[row]; jj < A->I[row + 1]; jj++) t += A->a[jj] * tmp[A->J[jj]];
+                    for (int jj = A->I[row]; jj < A->I[row + 1]; jj++) t += A->a[jj] * tmp[A->J[jj]];
                     double td = s->ds[row] * (0.0 + t);
                     u[row] = s->coefs[i] * r[row] + td;
                 }
@@ -644,6 +675,14 @@ static void smoother_apply(const orc_csr *A, const orc_smoother *s, const double
             orc_cheby_finish(n, v, s->ds, u);
         }
     }
+}
+
+/* y = B^T x: serial build = hypre's scatter-add MatvecT; multi-core build = gather product with the stored transpose */
+static void level_matvecT(int nrows, int ncols, const orc_csr *B, const int *TI, const int *TJ, const double *Ta,
+                          const double *x, double *y)
+{
+    if (TI) { orc_csr_matvec(ncols, TI, TJ, Ta, 1.0, x, 0.0, y); return; }
+    orc_csr_matvecT(nrows, ncols, B->I, B->J, B->a, 1.0, x, 0.0, y);
 }
 
 static void level_smooth(orc_level *L, const double *f, double *u, int zero_guess)
@@ -654,12 +693,12 @@ static void level_smooth(orc_level *L, const double *f, double *u, int zero_gues
         /* R = B - A X  (mg_utils::ComputeResidual, MG_Utils.hpp:405-426: tmp=0; tmp=A x; tmp-=B; tmp*=-1) */
         memset(L->pv, 0, sizeof(double) * (size_t)n);
         orc_csr_matvec(n, L->A.I, L->A.J, L->A.a, 1.0, u, 0.0, L->pv);
-        for (i = 0; i < n; i++) { L->pv[i] -= f[i]; L->pv[i] *= -1; }
+        ORC_PFOR for (i = 0; i < n; i++) { L->pv[i] -= f[i]; L->pv[i] *= -1; }
         memset(L->auxb, 0, sizeof(double) * (size_t)L->naux);
-        orc_csr_matvecT(n, L->naux, L->D.I, L->D.J, L->D.a, 1.0, L->pv, 0.0, L->auxb);
+        level_matvecT(n, L->naux, &L->D, L->DTI, L->DTJ, L->DTa, L->pv, L->auxb);
         smoother_apply(&L->Aaux, &L->sm_aux, L->auxb, L->auxx, L->auxv, L->auxz, L->auxr, 1);
         orc_csr_matvec(n, L->D.I, L->D.J, L->D.a, 1.0, L->auxx, 0.0, L->pv);
-        for (i = 0; i < n; i++) u[i] += L->pv[i];
+        ORC_PFOR for (i = 0; i < n; i++) u[i] += L->pv[i];
     }
 }
 
@@ -671,12 +710,12 @@ static void level_smooth_T(orc_level *L, const double *f, double *u)
         int n = L->A.n, i;
         memset(L->pv, 0, sizeof(double) * (size_t)n);
         orc_csr_matvec(n, L->A.I, L->A.J, L->A.a, 1.0, u, 0.0, L->pv);
-        for (i = 0; i < n; i++) { L->pv[i] -= f[i]; L->pv[i] *= -1; }
+        ORC_PFOR for (i = 0; i < n; i++) { L->pv[i] -= f[i]; L->pv[i] *= -1; }
         memset(L->auxb, 0, sizeof(double) * (size_t)L->naux);
-        orc_csr_matvecT(n, L->naux, L->D.I, L->D.J, L->D.a, 1.0, L->pv, 0.0, L->auxb);
+        level_matvecT(n, L->naux, &L->D, L->DTI, L->DTJ, L->DTa, L->pv, L->auxb);
         smoother_apply(&L->Aaux, &L->sm_aux, L->auxb, L->auxx, L->auxv, L->auxz, L->auxr, 1);
         orc_csr_matvec(n, L->D.I, L->D.J, L->D.a, 1.0, L->auxx, 0.0, L->pv);
-        for (i = 0; i < n; i++) u[i] += L->pv[i];
+        ORC_PFOR for (i = 0; i < n; i++) u[i] += L->pv[i];
     }
     smoother_apply(&L->A, &L->sm, f, u, L->v, L->z, L->r, 0);
 }
@@ -727,13 +766,13 @@ static void iterate(orc_hier *H, const double *RHS, double *SOL, int l, int symm
     level_smooth(F, RHS, SOL, 0);                                   /* :180-184 */
     memset(F->tmp_correct, 0, sizeof(double) * (size_t)n);          /* :191-194 */
     orc_csr_matvec(n, F->A.I, F->A.J, F->A.a, 1.0, SOL, 0.0, F->tmp_correct);
-    for (i = 0; i < n; i++) F->tmp_resid[i] = RHS[i] + (-1.0) * F->tmp_correct[i];
+    ORC_PFOR for (i = 0; i < n; i++) F->tmp_resid[i] = RHS[i] + (-1.0) * F->tmp_correct[i];
     double *cr = H->lev[l + 1].resid, *cs = H->lev[l + 1].sol;
-    orc_csr_matvecT(n, nc, F->P.I, F->P.J, F->P.a, 1.0, F->tmp_resid, 0.0, cr);   /* :199-203 */
+    level_matvecT(n, nc, &F->P, F->PTI, F->PTJ, F->PTa, F->tmp_resid, cr);        /* :199-203 */
     memset(cs, 0, sizeof(double) * (size_t)nc);                     /* :212 */
     iterate(H, cr, cs, l + 1, symmetric_post);                      /* :222-227, mu = 0 */
     orc_csr_matvec(n, F->P.I, F->P.J, F->P.a, 1.0, cs, 0.0, F->tmp_correct);       /* :231-234 */
-    for (i = 0; i < n; i++) SOL[i] += F->tmp_correct[i];            /* :238 */
+    ORC_PFOR for (i = 0; i < n; i++) SOL[i] += F->tmp_correct[i];   /* :238 */
     if (symmetric_post) level_smooth_T(F, RHS, SOL); else level_smooth(F, RHS, SOL, 0);  /* :244-249 */
 }
 
@@ -759,6 +798,14 @@ ORC_API void orc_hier_set_level(orc_hier *H, int l, int n, const int *AI, const 
     if (type == 16) L->sm.cheby_order = orc_cheby_coefs(max_eig, min_eig, fraction, order, L->sm.coefs);
     L->tmp_resid = dalloc(n); L->tmp_correct = dalloc(n); L->resid = dalloc(n); L->sol = dalloc(n);
     L->v = dalloc(n); L->z = dalloc(n); L->r = dalloc(n);
+#ifdef _OPENMP
+    if (PI && ncoarse > 0) {
+        const int nnz = PI[n];
+        L->PTI = (int *)malloc(sizeof(int) * ((size_t)ncoarse + 1)); L->PTJ = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+        L->PTa = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+        orc_csr_transpose(n, ncoarse, PI, PJ, Pa, L->PTI, L->PTJ, L->PTa);
+    }
+#endif
 }
 
 ORC_API void orc_hier_set_hiptmair(orc_hier *H, int l, int naux, const int *DI, const int *DJ, const double *Da,
@@ -774,6 +821,14 @@ ORC_API void orc_hier_set_hiptmair(orc_hier *H, int l, int naux, const int *DI, 
     if (type == 16) L->sm_aux.cheby_order = orc_cheby_coefs(max_eig, min_eig, fraction, order, L->sm_aux.coefs);
     L->auxb = dalloc(naux); L->auxx = dalloc(naux); L->pv = dalloc(L->A.n);
     L->auxv = dalloc(naux); L->auxz = dalloc(naux); L->auxr = dalloc(naux);
+#ifdef _OPENMP
+    {
+        const int nnz = DI[L->A.n];
+        L->DTI = (int *)malloc(sizeof(int) * ((size_t)naux + 1)); L->DTJ = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+        L->DTa = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+        orc_csr_transpose(L->A.n, naux, DI, DJ, Da, L->DTI, L->DTJ, L->DTa);
+    }
+#endif
 }
 
 ORC_API void orc_hier_set_coarse_chol(orc_hier *H, int n, const double *Lfactor)
@@ -792,6 +847,7 @@ ORC_API void orc_hier_destroy(orc_hier *H)
         orc_level *L = &H->lev[l];
         free(L->tmp_resid); free(L->tmp_correct); free(L->resid); free(L->sol); free(L->v); free(L->z); free(L->r);
         free(L->auxb); free(L->auxx); free(L->pv); free(L->auxv); free(L->auxz); free(L->auxr);
+        free(L->PTI); free(L->PTJ); free(L->PTa); free(L->DTI); free(L->DTJ); free(L->DTa);
     }
     free(H->lev); free(H);
 }

@@ -22,13 +22,18 @@ _c_int_p = C.POINTER(C.c_int)
 _c_dbl_p = C.POINTER(C.c_double)
 
 
-def build(native: bool = False) -> str:
-    out = "libelag_oracle_native.so" if native else "libelag_oracle.so"
+def build(native: bool = False, omp: bool = False) -> str:
+    """native: -march=native (timing); omp: the multi-core timing build (-fopenmp, see the header of elag_oracle.c).
+    The parity checks use the default serial, generic build."""
+    if omp:
+        out, target = "libelag_oracle_native_omp.so", "OMPOUT"
+    else:
+        out, target = ("libelag_oracle_native.so" if native else "libelag_oracle.so"), "OUT"
     path = os.path.join(_DIR, out)
     src = os.path.join(_DIR, "elag_oracle.c")
     if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-        args = ["make", "-C", _DIR, f"OUT={out}"]
-        if native:
+        args = ["make", "-C", _DIR, f"{target}={out}", out]
+        if native or omp:
             args.append("ARCH=-march=native")
         subprocess.check_call(args, stdout=subprocess.DEVNULL)
     return path
@@ -37,14 +42,15 @@ def build(native: bool = False) -> str:
 _libs = {}
 
 
-def lib(native: bool = False):
-    if native not in _libs:
-        L = C.CDLL(build(native))
+def lib(native: bool = False, omp: bool = False):
+    key = (native, omp)
+    if key not in _libs:
+        L = C.CDLL(build(native, omp))
         L.orc_csr_max_norm.restype = C.c_double
         L.orc_csr_frobenius_norm.restype = C.c_double
         L.orc_hier_create.restype = C.c_void_p
-        _libs[native] = L
-    return _libs[native]
+        _libs[key] = L
+    return _libs[key]
 
 
 def _ip(a):
@@ -920,10 +926,10 @@ class CHierarchy:
     """All-C serial V-cycle (orc_hier_*), used for CPU-baseline timing and as a second statement of the
     cycle to cross-check OHierarchy."""
 
-    def __init__(self, As, Ps, smoothers, coarse_chol=None, native=False, hipt=None):
+    def __init__(self, As, Ps, smoothers, coarse_chol=None, native=False, hipt=None, omp=False):
         """As: list of csr (diag-first for Chebyshev); Ps: list of csr; smoothers: list of dict(type,sweeps,
         weight,l1,order,max_eig,min_eig,fraction,ds) per level; hipt: optional list of dict(D, Aaux, sm)."""
-        self.L = lib(native)
+        self.L = lib(native, omp)
         self.keep = [As, Ps, smoothers, coarse_chol, hipt]
         nl = len(As)
         self.n = As[0].shape[0]
