@@ -208,8 +208,10 @@ ELAG_HIP_API int elag_hip_partition_refined(int num_elements, int num_parts, int
  * node.  All part ids must be >= 0. */
 ELAG_HIP_API int elag_hip_connected_components(int num_nodes, int *partitioning, const int *conn_i, const int *conn_j,
                                                int *num_components);
-/* transposePartitioning (src/structures/transpose.cpp:27-55): element->part array to part->elements CSR
- * (i_out: num_parts+1 entries, j_out: number of entries with part >= 0; elements ascending inside a part). */
+/* transposePartitioning (src/structures/transpose.cpp:27-55) and TransposeOrientation
+ * (src/topology/TopologyTable.cpp:218-254; same table, entries -1 skipped, unit data): element->part array to
+ * part->elements CSR (i_out: num_parts+1 entries, j_out: number of entries with part >= 0; elements ascending inside a
+ * part). */
 ELAG_HIP_API int elag_hip_transpose_partitioning(int num_elements, const int *partitioning, int num_parts, int *i_out,
                                                  int *j_out);
 
