@@ -76,6 +76,10 @@ ELAG_HIP_API int elag_hip_comm_init(int rank, int nranks, const void *id128);
  * device, exchange through a mailbox and device-to-device copies (same `group` id on all of them).  It lets the whole
  * multi-rank path run on a single-GPU box (tests); a production run uses elag_hip_comm_init. */
 ELAG_HIP_API int elag_hip_comm_init_inprocess(int rank, int nranks, int group);
+/* Diagnostic for single-GPU boxes: runs the RCCL wrappers for real on a communicator of size one (dlopen, unique id,
+ * ncclCommInitRank, ncclAllReduce sum / max of {1.5,-2} / {3.25,8}, a grouped ncclSend/ncclRecv of the four values to
+ * this rank, ncclCommDestroy).  Both outputs have 4 entries and must come back equal to the inputs. */
+ELAG_HIP_API int elag_hip_comm_selftest(double *allreduce_out, double *sendrecv_out);
 ELAG_HIP_API int elag_hip_comm_rank(int *rank, int *nranks);
 /* 8-byte reductions that end the norm / dot routines (MPI_Allreduce in hypre_ParCSRMatrixNorms.c:60) */
 ELAG_HIP_API int elag_hip_comm_allreduce(double *value, int op /*0 sum, 1 max*/);

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "elag_hip_comm_unique_id": [_p],
     "elag_hip_comm_init": [_i, _i, _p],
     "elag_hip_comm_init_inprocess": [_i, _i, _i],
+    "elag_hip_comm_selftest": [_dp, _dp],
     "elag_hip_comm_rank": [_ip, _ip],
     "elag_hip_comm_allreduce": [_dp, _i],
     "elag_hip_malloc": [C.POINTER(_p), C.c_size_t],

@@ -313,6 +313,38 @@ int elag_hip_comm_unique_id(void *id128)
     return guarded([&] { ELAG_REQUIRE(id128 != nullptr, "null id buffer"); comm_unique_id(id128); });
 }
 
+int elag_hip_comm_selftest(double *allreduce_out, double *sendrecv_out)
+{
+    // Diagnostic for single-GPU boxes: the multi-rank data path is tested through the in-process communicator, which
+    // leaves only the thin RCCL wrappers unexercised.  This runs them for real on a communicator of size one:
+    // dlopen + symbol lookup, ncclGetUniqueId, ncclCommInitRank, ncclAllReduce (sum and max) on the comm stream and a
+    // grouped ncclSend/ncclRecv pair addressed to this rank, then ncclCommDestroy.
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(allreduce_out && sendrecv_out, "null argument");
+        Context &x = ctx();
+        Comm *c = load_rccl();
+        ncclUniqueId id;
+        ELAG_NCCL_CHECK(c, c->GetUniqueId(&id));
+        ncclComm_t comm = nullptr;
+        ELAG_NCCL_CHECK(c, c->CommInitRank(&comm, 1, id, 0));
+        double h[4] = {1.5, -2.0, 3.25, 8.0}, *d = dev_alloc<double>(8);
+        ELAG_HIP_CHECK(hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, x.comm_stream));
+        ELAG_NCCL_CHECK(c, c->AllReduce(d, d, 2, ncclDouble, ncclSum, comm, x.comm_stream));
+        ELAG_NCCL_CHECK(c, c->AllReduce(d + 2, d + 2, 2, ncclDouble, ncclMax, comm, x.comm_stream));
+        ELAG_NCCL_CHECK(c, c->GroupStart());
+        ELAG_NCCL_CHECK(c, c->Send(d, 4, ncclDouble, 0, comm, x.comm_stream));
+        ELAG_NCCL_CHECK(c, c->Recv(d + 4, 4, ncclDouble, 0, comm, x.comm_stream));
+        ELAG_NCCL_CHECK(c, c->GroupEnd());
+        double out[8];
+        ELAG_HIP_CHECK(hipMemcpyAsync(out, d, sizeof(out), hipMemcpyDeviceToHost, x.comm_stream));
+        ELAG_HIP_CHECK(hipStreamSynchronize(x.comm_stream));
+        ELAG_NCCL_CHECK(c, c->CommDestroy(comm));
+        dev_free(d);
+        for (int i = 0; i < 4; i++) { allreduce_out[i] = out[i]; sendrecv_out[i] = out[4 + i]; }
+    });
+}
+
 int elag_hip_comm_init(int rank, int nranks, const void *id128)
 {
     return guarded([&] { require_init(); comm_init(rank, nranks, id128); });

@@ -459,3 +459,23 @@ def test_bench_layout_of_the_distributed_darcy_hierarchy(darcy, world, kind):
     for r, (x, dd) in enumerate(res):
         ref = _local_block_vector(dd, 0, r, xr[:n0], xr[n0:])
         assert np.max(np.abs(x - ref)) <= 1e-10 * np.max(np.abs(xr))
+
+
+def test_rccl_wrappers_on_a_single_rank_communicator():
+    """the only multi-rank code the in-process communicator cannot reach: run it for real on a size-1 RCCL communicator
+    (in a child process with a time limit: a stuck bootstrap must not take the test session with it)"""
+    import subprocess, sys, textwrap, os
+    code = textwrap.dedent("""
+        import ctypes as C, os
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        from parelag_amd import _lib
+        lib = _lib.init(0)
+        a = (C.c_double * 4)(); b = (C.c_double * 4)()
+        _lib.check(lib.elag_hip_comm_selftest(a, b))
+        print("RCCL_SELFTEST", list(a), list(b))
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RCCL_SELFTEST [1.5, -2.0, 3.25, 8.0] [1.5, -2.0, 3.25, 8.0]" in r.stdout, r.stdout + r.stderr
