@@ -146,6 +146,72 @@ __global__ void gmres_orth_kernel(int n, const KState *__restrict__ st, double *
     if (t < n) w[t] = w[t] + (-h) * v[t];
 }
 
+// ---- fused modified Gram-Schmidt (single rank) ---------------------------------------------------------------------------
+// MGS is a chain h_k = <w, v_k>; w -= h_k v_k.  One kernel per k does both halves of two neighbouring links: it finishes
+// the dot whose per-block partial sums the previous kernel left in part_in (every block adds them up in the same fixed
+// order), applies w -= h_k v_k, and while the updated w is in registers accumulates the partial sums of the NEXT dot
+// (<w, v_{k+1}>, or <w, w> after the last vector).  i+2 launches and 4 vector passes per link instead of 3(i+1) and 5.
+constexpr int kPart = 512;   // partial sums per dot (= blocks of the fused kernels)
+
+__device__ inline double block_sum_256(double v, double *sh)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return r;   // same value on every thread
+}
+
+__device__ inline double sum_partials(const double *__restrict__ part, double *sh)
+{
+    double v = 0.0;
+    for (int q = threadIdx.x; q < kPart; q += kB) v += part[q];
+    return block_sum_256(v, sh);
+}
+
+// part_out[b] = partial sums of <w, v> (no update): first link of a step
+__global__ void __launch_bounds__(kB) gmres_dot0_kernel(int n, const KState *__restrict__ st, const double *__restrict__ w,
+                                                        const double *__restrict__ v, double *__restrict__ part_out)
+{
+    __shared__ double sh[4];
+    if (st->fl[F_DONE]) return;
+    double acc = 0.0;
+    for (int t = blockIdx.x * kB + threadIdx.x; t < n; t += kPart * kB) acc += w[t] * v[t];
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) part_out[blockIdx.x] = acc;
+}
+
+// h = sum(part_in); H(k,i) = h; w -= h v_k; part_out = partial sums of <w, vnext> (vnext == nullptr: <w, w>)
+__global__ void __launch_bounds__(kB) gmres_orth_fused_kernel(int n, const KState *__restrict__ st, double *__restrict__ hs, int m, int k, int i,
+                                                              double *__restrict__ w, const double *__restrict__ vk,
+                                                              const double *__restrict__ vnext, const double *__restrict__ part_in,
+                                                              double *__restrict__ part_out)
+{
+    __shared__ double sh[4];
+    if (st->fl[F_DONE]) return;
+    const double h = sum_partials(part_in, sh);
+    if (blockIdx.x == 0 && threadIdx.x == 0) Hm(hs, m, k, i) = h;
+    double acc = 0.0;
+    for (int t = blockIdx.x * kB + threadIdx.x; t < n; t += kPart * kB) {
+        const double wn = w[t] + (-h) * vk[t];
+        w[t] = wn;
+        acc += wn * (vnext ? vnext[t] : wn);
+    }
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) part_out[blockIdx.x] = acc;
+}
+
+// H(i+1,i) = sqrt(sum(part_in))
+__global__ void __launch_bounds__(kB) gmres_norm_fused_kernel(KState *st, double *hs, int m, int i, const double *__restrict__ part_in)
+{
+    __shared__ double sh[4];
+    if (st->fl[F_DONE]) return;
+    const double nw = sqrt(sum_partials(part_in, sh));
+    if (threadIdx.x == 0) { Hm(hs, m, i + 1, i) = nw; st->sc[S_BETA] = nw; }
+}
+
 __global__ void gmres_norm_kernel(KState *st, double *hs, int m, int i)
 {
     if (st->fl[F_DONE]) return;
@@ -276,7 +342,7 @@ struct elag_hip_krylov_s {
     int *h_flags = nullptr;       // pinned mirror of st->fl
     double *h_sc = nullptr;       // pinned mirror of st->sc
     double *x = nullptr, *r = nullptr, *z = nullptr, *d = nullptr, *w = nullptr, *scr = nullptr;
-    double *V = nullptr, *Z = nullptr, *hs = nullptr;
+    double *V = nullptr, *Z = nullptr, *hs = nullptr, *part = nullptr;
     hipGraphExec_t cg_iter = nullptr;
     // results of the last Mult
     int converged = 0, final_iter = 0;
@@ -289,7 +355,7 @@ struct elag_hip_krylov_s {
     ~elag_hip_krylov_s()
     {
         if (cg_iter) (void)hipGraphExecDestroy(cg_iter);
-        dev_free(x); dev_free(r); dev_free(z); dev_free(d); dev_free(w); dev_free(scr); dev_free(V); dev_free(Z); dev_free(hs);
+        dev_free(x); dev_free(r); dev_free(z); dev_free(d); dev_free(w); dev_free(scr); dev_free(V); dev_free(Z); dev_free(hs); dev_free(part);
         if (st) (void)hipFree(st);
         if (h_flags) (void)hipHostFree(h_flags);
         if (h_sc) (void)hipHostFree(h_sc);
@@ -313,6 +379,7 @@ struct elag_hip_krylov_s {
             V = dev_alloc<double>((m + 1) * nn);
             if (solver == ELAG_HIP_KRYLOV_FGMRES) Z = dev_alloc<double>(m * nn);
             hs = dev_alloc<double>(m * (m + 1) + 4 * (m + 1));
+            part = dev_alloc<double>(2 * (size_t)kPart);
         }
     }
 
@@ -478,12 +545,24 @@ struct elag_hip_krylov_s {
                 } else {
                     amul(Vq(i), w);
                 }
-                for (int k = 0; k <= i; k++) {
-                    dot(target, Vq(k));
-                    hipLaunchKernelGGL(gmres_orth_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, hs, m, k, i, target, (const double *)Vq(k));
+                if (!distributed()) {
+                    // fused modified Gram-Schmidt: see gmres_orth_fused_kernel
+                    double *pin = part, *pout = part + kPart;
+                    hipLaunchKernelGGL(gmres_dot0_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, (const double *)target, (const double *)Vq(0), pin);
+                    for (int k = 0; k <= i; k++) {
+                        hipLaunchKernelGGL(gmres_orth_fused_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, hs, m, k, i, target,
+                                           (const double *)Vq(k), (const double *)(k < i ? Vq(k + 1) : nullptr), (const double *)pin, pout);
+                        std::swap(pin, pout);
+                    }
+                    hipLaunchKernelGGL(gmres_norm_fused_kernel, dim3(1), dim3(kB), 0, s, st, hs, m, i, (const double *)pin);
+                } else {
+                    for (int k = 0; k <= i; k++) {
+                        dot(target, Vq(k));
+                        hipLaunchKernelGGL(gmres_orth_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, hs, m, k, i, target, (const double *)Vq(k));
+                    }
+                    dot(target, target);
+                    hipLaunchKernelGGL(gmres_norm_kernel, dim3(1), dim3(1), 0, s, st, hs, m, i);
                 }
-                dot(target, target);
-                hipLaunchKernelGGL(gmres_norm_kernel, dim3(1), dim3(1), 0, s, st, hs, m, i);
                 hipLaunchKernelGGL(scale_inv_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, (int)S_BETA, (const double *)target, Vq(i + 1));
                 ++step_id;
                 hipLaunchKernelGGL(gmres_givens_kernel, dim3(1), dim3(1), 0, s, st, hs, m, i, j, step_id);
