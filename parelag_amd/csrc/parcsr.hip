@@ -437,8 +437,20 @@ int elag_hip_parcsr_rdp(elag_hip_parcsr_t RT, const double *d, int loc, elag_hip
         require_init();
         ELAG_REQUIRE(RT && d && P && RDP, "null argument");
         check_loc(loc);
-        require_single_rank(RT, "rdp"); require_single_rank(P, "rdp");
         ELAG_REQUIRE(RT->nrows() == P->nrows(), "rdp: RT and P must have the same number of rows");
+        if (is_distributed(*RT) || is_distributed(*P)) {
+            // across ranks: the triple product with the diagonal operator diag(d) in the middle
+            ELAG_REQUIRE(RT->first_row == P->first_row && RT->global_rows == P->global_rows, "rdp: RT and P must share the row partition");
+            std::vector<double> dh((size_t)P->nrows());
+            if (loc == ELAG_HIP_DEVICE) dh = host_from_dev(d, (size_t)P->nrows());
+            else std::copy(d, d + P->nrows(), dh.begin());
+            elag_hip_parcsr_t D = nullptr;
+            int rc = elag_hip_parcsr_diagonal(&D, P->nrows(), P->first_row, P->global_rows, dh.data());
+            if (rc) fail(rc, "%s", elag_hip_last_error());
+            std::unique_ptr<ParCSR> Dg(D);
+            *RDP = distributed_rap(*RT, *Dg, *P);
+            return;
+        }
         VecIn din(d, (size_t)P->nrows(), loc);
         DevCSR DP, out;
         k::csr_copy(P->diag, DP);

@@ -240,6 +240,12 @@ def test_distributed_hypre_extension_set(problem, world):
         y = np.zeros(S.Height()); S.Mult(x[s0[r]:s0[r + 1]], y)
         assert np.max(np.abs(y - (Sref @ x)[s0[r]:s0[r + 1]])) <= 1e-11 * np.max(np.abs(Sref) @ np.abs(x))
         assert la.Compare(S, dA, 1e-9) == 64                   # same shape, different values
+        # hypre_RDP across ranks: P^T diag(w) P with this rank's slice of a global weight vector
+        wg = np.random.default_rng(5).uniform(0.5, 2.0, Ag.shape[0])
+        RDP = la.RDP(dP, wg[s0[r]:s0[r + 1]], dP)
+        RDPref = partition.canon(Pg.T @ sp.diags(wg) @ Pg)
+        assert abs(_local_global_csr(RDP, RDPref.shape) - RDPref[s1[r]:s1[r + 1]]).max() <= 1e-12 * abs(RDPref).max()
+        del RDP
         # DeleteZeros keeps the halo machinery usable
         nnz0 = dA.nnz
         dA.delete_zeros(1e-300)
