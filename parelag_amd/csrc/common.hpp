@@ -34,11 +34,12 @@ bool debug_sync();
                          __FILE__, __LINE__);                                                     \
     } while (0)
 
-// after every kernel launch; ELAG_HIP_DEBUG_SYNC=1 turns each launch into a synchronous, checked one
+// after every kernel launch; ELAG_HIP_DEBUG_SYNC=1 turns each launch into a synchronous, checked one (launches that are
+// being captured into a graph cannot be synchronised: they are checked when the graph runs)
 #define ELAG_LAUNCH_CHECK()                                             \
     do {                                                                \
         ELAG_HIP_CHECK(hipGetLastError());                              \
-        if (::elag::debug_sync()) ELAG_HIP_CHECK(hipDeviceSynchronize()); \
+        if (::elag::debug_sync() && !::elag::stream_is_capturing()) ELAG_HIP_CHECK(hipDeviceSynchronize()); \
     } while (0)
 
 #define ELAG_REQUIRE(cond, ...)                                  \
@@ -95,6 +96,7 @@ void require_init();
 
 // ---- device memory helpers ---------------------------------------------------------------------
 bool debug_sync();     // ELAG_HIP_DEBUG_SYNC=1
+bool stream_is_capturing();   // the context's compute stream is inside hipStreamBeginCapture ... EndCapture
 int debug_poison();  // ELAG_HIP_DEBUG_POISON=<byte>: fill every fresh allocation (debug aid), -1 = off
 
 template <class T>
@@ -103,7 +105,13 @@ T *dev_alloc(size_t n)
     T *p = nullptr;
     if (n == 0) n = 1;
     ELAG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)));
-    if (debug_poison() >= 0) ELAG_HIP_CHECK(hipMemset(p, debug_poison(), n * sizeof(T)));
+    if (debug_poison() >= 0) {
+        // on the compute stream, so that the fill is ordered before whatever the caller enqueues next (a null-stream
+        // memset is not ordered with the library's non-blocking streams and could land after a later copy)
+        // (and completed before returning: the buffer may first be written from the comm stream)
+        if (ctx().stream) { ELAG_HIP_CHECK(hipMemsetAsync(p, debug_poison(), n * sizeof(T), ctx().stream)); ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream)); }
+        else { ELAG_HIP_CHECK(hipMemset(p, debug_poison(), n * sizeof(T))); ELAG_HIP_CHECK(hipDeviceSynchronize()); }
+    }
     return p;
 }
 template <class T>

@@ -26,6 +26,14 @@ Context &ctx()
     return c;
 }
 
+bool stream_is_capturing()
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (!ctx().stream) return false;
+    (void)hipStreamIsCapturing(ctx().stream, &cs);
+    return cs != hipStreamCaptureStatusNone;
+}
+
 bool debug_sync()
 {
     static int v = -1;
