@@ -44,16 +44,37 @@ __global__ __launch_bounds__(kBlock) void spmv_fused_kernel(
     }
 
     const int s = I[row], e = I[row + 1];
-    double sum = 0.0;
+    // These kernels serve the launch/latency-bound levels, where the time is the length of the dependent chain of memory
+    // round trips, not the bytes: the epilogue operands are requested up front (they only need `row`), and the first
+    // entry of the diag and of the offd stream travel together, as do their two gathers.
+    double f0 = 0.0, y0 = 0.0, sc0 = 1.0, sc20 = 1.0;
+    if (lane == 0) {
+        if (p.s2) sc20 = p.s2[row];
+        if (p.f) f0 = p.f[row];
+        if (p.s) sc0 = p.s[row];
+        if (p.yin) y0 = p.yin[row];
+    }
     const double *__restrict__ x = p.x;
+    const double *__restrict__ cs = p.cs;
+    const double *__restrict__ xg = p.xg;
+    int k = s + lane, ko = os + lane;
+    const bool hd = k < e, ho = HAS_OFFD && ko < oe;
+    int jd = 0, jo = 0;
+    double ad = 0.0, ao = 0.0;
+    if (hd) { jd = J[k]; ad = a[k]; }
+    if (ho) { jo = oJ[ko]; ao = oa[ko]; }
+    double xd = 0.0, xo = 0.0;
+    if (hd) { xd = x[jd]; if (HAS_CS) xd *= cs[jd]; }
+    if (ho) { xo = xg[jo]; if (HAS_CS && p.csg) xo *= p.csg[jo]; }
+    double sum = 0.0;
+    if (hd) sum += ad * xd;
+    k += LPR;
     if (HAS_CS) {
-        const double *__restrict__ cs = p.cs;
-        for (int k = s + lane; k < e; k += LPR) {
+        for (; k < e; k += LPR) {
             const int j = J[k];
             sum += a[k] * (x[j] * cs[j]);
         }
     } else {
-        int k = s + lane;
         // two independent loads in flight per lane
         for (; k + LPR < e; k += 2 * LPR) {
             const int j0 = J[k], j1 = J[k + LPR];
@@ -64,20 +85,21 @@ __global__ __launch_bounds__(kBlock) void spmv_fused_kernel(
         if (k < e) sum += a[k] * x[J[k]];
     }
     if (HAS_OFFD) {
-        const double *__restrict__ xg = p.xg;
+        if (ho) sum += ao * xo;
+        ko += LPR;
         if (HAS_CS && p.csg) {
-            for (int k = os + lane; k < oe; k += LPR) { const int j = oJ[k]; sum += oa[k] * (xg[j] * p.csg[j]); }
+            for (; ko < oe; ko += LPR) { const int j = oJ[ko]; sum += oa[ko] * (xg[j] * p.csg[j]); }
         } else {
-            for (int k = os + lane; k < oe; k += LPR) sum += oa[k] * xg[oJ[k]];
+            for (; ko < oe; ko += LPR) sum += oa[ko] * xg[oJ[ko]];
         }
     }
     sum = group_reduce<LPR>(sum);
     if (lane == 0) {
         double t = p.alpha * sum;
-        if (p.s2) t *= p.s2[row];
-        if (p.f) t += p.gamma * p.f[row];
-        if (p.s) t *= p.s[row];
-        if (p.yin) t += p.beta * p.yin[row];
+        t *= sc20;
+        t += p.gamma * f0;
+        t *= sc0;
+        t += p.beta * y0;
         p.out[row] = t;
         if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
     }
@@ -912,6 +934,29 @@ __global__ __launch_bounds__(kBlock) void dense_gemv_kernel(int nrows, int n, co
     s = group_reduce<64>(s);
     if (lane == 0) y[row] = s;
 }
+
+// One workgroup per row: every lane requests its (up to 4 per pass) matrix and vector entries before the first use, so
+// a row of <= 1024 entries costs one memory round trip instead of n/64 dependent ones (the coarse solve sits on the
+// critical path of every V-cycle: 5.0 -> ~2 us at n = 840).
+__global__ __launch_bounds__(kBlock) void dense_gemv_row_kernel(int n, const double *__restrict__ M, const double *__restrict__ x,
+                                                                double *__restrict__ y)
+{
+    __shared__ double sh[kBlock / 64];
+    const double *__restrict__ m = M + (size_t)blockIdx.x * n;
+    double s = 0.0;
+    for (int j0 = threadIdx.x; j0 < n; j0 += 4 * kBlock) {
+        const int j1 = j0 + kBlock, j2 = j0 + 2 * kBlock, j3 = j0 + 3 * kBlock;
+        const double a0 = m[j0], b0 = x[j0];
+        const double a1 = j1 < n ? m[j1] : 0.0, b1 = j1 < n ? x[j1] : 0.0;
+        const double a2 = j2 < n ? m[j2] : 0.0, b2 = j2 < n ? x[j2] : 0.0;
+        const double a3 = j3 < n ? m[j3] : 0.0, b3 = j3 < n ? x[j3] : 0.0;
+        s += a0 * b0; s += a1 * b1; s += a2 * b2; s += a3 * b3;
+    }
+    s = group_reduce<64>(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) y[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
 }  // namespace
 
 namespace {
@@ -942,7 +987,8 @@ void dense_transpose(int n, const double *in, double *out)
 void dense_gemv(int nrows, int ncols, const double *M, const double *x, double *y)
 {
     if (nrows == 0) return;
-    hipLaunchKernelGGL(dense_gemv_kernel, dim3(row_grid(nrows, 64)), dim3(kBlock), 0, ctx().stream, nrows, ncols, M, x, y);
+    if (ncols >= 256) hipLaunchKernelGGL(dense_gemv_row_kernel, dim3((unsigned)nrows), dim3(kBlock), 0, ctx().stream, ncols, M, x, y);
+    else hipLaunchKernelGGL(dense_gemv_kernel, dim3(row_grid(nrows, 64)), dim3(kBlock), 0, ctx().stream, nrows, ncols, M, x, y);
     ELAG_LAUNCH_CHECK();
 }
 
