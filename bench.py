@@ -161,8 +161,6 @@ def main():
         Ps = dar["Ps"]
         A = sp.bmat([[dar["M"], dar["Bt"]], [dar["B"], None]]).tocsr()
     elif args.form == 2:
-        if not single:
-            raise SystemExit("--form 2 is a single-GPU configuration (BASELINE configs[2])")
         A, Ps, Ds, seq = meshgen.hdiv_problem(args.refines)
     else:
         A, Ps, seq = meshgen.h1_problem(args.refines)
@@ -203,6 +201,20 @@ def main():
         for l in range(len(Ps) + 1):
             op = H.GetOperator(l)
             level_shapes.append((op.Height(), op.nnz, Ps[l].shape[1] if l < len(Ps) else 0, Ps[l].nnz if l < len(Ps) else 0))
+    elif args.form == 2:
+        # every level row-partitioned (faces / edges owned by the lowest adjacent rank), coarsest operator replicated
+        from parelag_amd import partition
+        t0 = time.time()
+        hd = partition.distributed_hdiv(A, Ps, Ds, seq, world)
+        dA = la.ParallelCSRMatrix.from_parts(hd["A"][rank])
+        dPs = [la.ParallelCSRMatrix.from_parts(p[rank]) for p in hd["P"]]
+        dDs = [la.ParallelCSRMatrix.from_parts(p[rank]) for p in hd["D"]]
+        H = la.buildHierarchyFromDeRhamSequence(dA, dPs, args.smoother, Ds=dDs, aux_smoother=args.smoother, use_graph=False)
+        la.synchronize()
+        setup_s = time.time() - t0
+        n_local = dA.Height()
+        H._dist_info = {"levels": [{"starts": hd["starts2"][0], "order": hd["order2"][0]}]}
+        level_shapes = [(A.shape[0], A.nnz, Ps[0].shape[1], Ps[0].nnz)]
     else:
         from parelag_amd import distributed
         H, n_local, level_shapes, setup_s = distributed.build_hierarchy(dist, A, Ps, seq, args.smoother)
@@ -389,10 +401,14 @@ def main():
     elif not single:
         # parity of the distributed cycle against the serial CPU oracle (every rank checks its own rows)
         from oracle import oracle as orc
-        from tests.helpers import oracle_h1_hierarchy
-        h = oracle_h1_hierarchy(A, Ps, smoother=la.HYPRE_SMOOTHER_TYPES[args.smoother])
+        from tests.helpers import oracle_h1_hierarchy, oracle_hdiv_hierarchy
         xs = np.empty(A.shape[0])
-        orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"]).apply(np.full(A.shape[0], 2.0), xs)
+        if args.form == 2:
+            h = oracle_hdiv_hierarchy(A, Ps, Ds)
+            orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], hipt=h["hipt"]).apply(np.full(A.shape[0], 2.0), xs)
+        else:
+            h = oracle_h1_hierarchy(A, Ps, smoother=la.HYPRE_SMOOTHER_TYPES[args.smoother])
+            orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"]).apply(np.full(A.shape[0], 2.0), xs)
         info = H._dist_info["levels"][0]
         lo, hi = int(info["starts"][dist.rank]), int(info["starts"][dist.rank + 1])
         ref = xs[info["order"]][lo:hi]

@@ -227,3 +227,23 @@ def distributed_darcy(dar, nparts: int):
         P.append([split_rows(canon(sp.csr_matrix(P2)[f2][:, c2]), starts[l][0], starts[l + 1][0]),
                   split_rows(canon(sp.csr_matrix(P3)[f3][:, c3]), starts[l][1], starts[l + 1][1])])
     return dict(blocks=blocks, P=P, order=order, starts=starts, global_blocks=glob)
+
+
+def distributed_hdiv(A, Ps, Ds, seq, nparts: int):
+    """Row-block decomposition of the 2-form problem of ``meshgen.hdiv_problem`` (faces owned by the lowest adjacent
+    rank, edges likewise for the auxiliary space of the Hiptmair smoother): A (faces x faces), every P_l and every
+    D_l (faces x edges) as per-rank ParCSR pieces.  Returns dict(A=parts, P=[parts], D=[parts], order2=[...], starts2=[...])."""
+    eparts = element_partitions(seq, nparts)
+    o2, s2, o1, s1 = [], [], [], []
+    for l, mesh in enumerate(seq.meshes):
+        a, _n, b = block_numbering(entity_owners(mesh, eparts[l], 2), nparts)
+        o2.append(a); s2.append(b)
+        a, _n, b = block_numbering(entity_owners(mesh, eparts[l], 1), nparts)
+        o1.append(a); s1.append(b)
+    Ag = canon(sp.csr_matrix(A)[o2[0]][:, o2[0]])
+    out = dict(A=split_rows(Ag, s2[0], s2[0]), P=[], D=[], order2=o2, starts2=s2, A_global=Ag)
+    for l, P in enumerate(Ps):
+        out["P"].append(split_rows(canon(sp.csr_matrix(P)[o2[l]][:, o2[l + 1]]), s2[l], s2[l + 1]))
+    for l, D in enumerate(Ds[:len(Ps)]):
+        out["D"].append(split_rows(canon(sp.csr_matrix(D)[o2[l]][:, o1[l]]), s2[l], s1[l]))
+    return out
