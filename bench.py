@@ -121,6 +121,16 @@ def main():
             print(json.dumps({"roofline": {"kernel": "spmv_xc_kernel", "n": n, "nnz": nnz, "bytes_per_launch": b,
                                            "ms_per_launch": round(ms, 5), "achieved_GBs": round(b / ms / 1e6, 1)}}))
             return
+        # the fine-level Galerkin product of the same problem (SURVEY 8d "RAP": bytes(A) + 2 bytes(P) + bytes(AP) written and
+        # read + bytes(A_c)), caller's numbering, wall time around a synchronised call
+        csr_bytes = lambda rows, nz: 12 * nz + 4 * (rows + 1)
+        la.RAP(dAr, dPr[0]); la.synchronize()
+        t0 = time.perf_counter(); Ac_r = la.RAP(dAr, dPr[0]); la.synchronize(); rap_s = time.perf_counter() - t0
+        AP_r = dAr.matmul(dPr[0])
+        rap_bytes = (csr_bytes(n, nnz) + 2 * csr_bytes(n, dPr[0].nnz) + 2 * csr_bytes(n, AP_r.nnz) + csr_bytes(Ac_r.Height(), Ac_r.nnz))
+        rap = {"what": f"A_c = P^T A P on the cube456 x{k} fine level (A nnz {nnz}, P nnz {dPr[0].nnz}, AP nnz {AP_r.nnz}, A_c nnz {Ac_r.nnz})",
+               "ms": round(rap_s * 1e3, 3), "algorithmic_bytes": rap_bytes, "GBs": round(rap_bytes / rap_s / 1e9, 1)}
+        del Ac_r, AP_r
         ms_j = la.time_kernel(A0, "jacobi", x, y, reps=args.roofline_reps, smoother=Hr.GetSmoother(0))
         ms_nat = la.time_kernel(dAr, "spmv", x, y, reps=args.roofline_reps)   # same matrix in the caller's numbering
         rhs_r, sol_r = la.DeviceVector(n, 2.0), la.DeviceVector(n, 1.0)
@@ -138,6 +148,8 @@ def main():
                 "frac_of_measured_copy_peak_6290": round(b / (ms * 1e-3) / 1e9 / 6290.0, 4),
                 "jacobi_sweep_GBs": round((b + 16 * n) / (ms_j * 1e-3) / 1e9, 1),
                 "callers_numbering_GBs": round(b / (ms_nat * 1e-3) / 1e9, 1),
+                "rap": rap,
+                "rap": rap,
                 "vcycle_ms": round(ms_v, 4), "vcycles_per_s": round(1e3 / ms_v, 1),
                 "vcycle_GBs": round(vb / (ms_v * 1e-3) / 1e9, 1), "vcycle_frac": round(vb / (ms_v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "hierarchy_setup_s": round(setup_r, 3), "generate_s": round(gen_s, 1)}

@@ -257,15 +257,31 @@ __global__ __launch_bounds__(kBlock) void esc_kernel(int nrows, const int *__res
     }
     int tot;
     int hidx = block_excl_scan(nheads, sh, &tot);
-    const int cbase = CI[r0];
+    // Output position of a head = CI[its row] + its rank among the heads of that row.  (The rows of a chunk need not be
+    // adjacent in C: rows handled by the wave-per-row kernel may lie between them.)  rank = hidx - (heads before the
+    // row's first sorted entry); the latter from the per-thread head offsets.
+    __shared__ int hstart[kBlock];
+    hstart[threadIdx.x] = hidx;
+    __syncthreads();
     if (beg < n2)
         for (int i = beg; i < beg + per; i++) {
             const u64 kk = key[i];
             if (kk != ~0ull && (i == 0 || key[i - 1] != kk)) {
                 double s = val[i];
                 for (int q = i + 1; q < n2 && key[q] == kk; q++) s += val[q];
-                CJ[cbase + hidx] = (int)(kk & 0xffffffffu);
-                Ca[cbase + hidx] = s;
+                const unsigned rl = (unsigned)(kk >> 32);
+                int lo = 0, hi = i;   // first sorted index of row rl (<= i)
+                const u64 rowkey = (u64)rl << 32;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (key[mid] < rowkey) lo = mid + 1; else hi = mid; }
+                const int t0 = lo / per;
+                int h0 = hstart[t0];
+                for (int q = t0 * per; q < lo; q++) {
+                    const u64 kq = key[q];
+                    if (kq != ~0ull && (q == 0 || key[q - 1] != kq)) h0++;
+                }
+                const int pos = CI[r0 + (int)rl] + (hidx - h0);
+                CJ[pos] = (int)(kk & 0xffffffffu);
+                Ca[pos] = s;
                 hidx++;
             }
         }
@@ -294,8 +310,10 @@ __global__ void rowlen_kernel(int nrows, const int *__restrict__ I, int *__restr
 }
 
 // split ub into chunkable part (ub <= kCap) and a list of big rows
+constexpr int kWaveCap = 256;   // rows expanding to at most this many products are handled by one wavefront in registers
+
 __global__ void split_big_kernel(int nrows, const int *__restrict__ ub, int *__restrict__ ub_small, int *__restrict__ biglist,
-                                 int *__restrict__ nbig, int *__restrict__ too_big)
+                                 int *__restrict__ nbig, int *__restrict__ too_big, int wave_cap)
 {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= nrows) return;
@@ -304,7 +322,78 @@ __global__ void split_big_kernel(int nrows, const int *__restrict__ ub, int *__r
         ub_small[row] = 0;
         if (u > kBigCap) atomicAdd(too_big, 1);
         else biglist[atomicAdd(nbig, 1)] = row;
-    } else ub_small[row] = u;
+    } else ub_small[row] = (u <= wave_cap) ? 0 : u;   // wave rows are not part of the chunked LDS path
+}
+
+// ---- wave-per-row path ------------------------------------------------------------------------------------------------
+// Most rows of the products on the V-cycle path are short (A P: ~28 products per row, P^T(AP): ~120, fused level
+// operators alike).  Sorting them -- in LDS with barriers, or in registers with shuffles -- is what the time goes to
+// (measured: both ~10 ms per product at cube456 x5).  Here ONE wavefront handles a row without sorting the products:
+//   1. expand the row's products into the wave's LDS slice (storage order = hypre's accumulation order),
+//   2. mark first occurrences of every column: all lanes walk the product list together (LDS broadcast reads),
+//   3. compact the distinct columns; rank each among them (<= 64R, again broadcast reads) => sorted output position,
+//   4. the lane owning an output entry walks the product list once more and adds the matching products in storage
+//      order -- deterministic, no atomics, and the same summation order as the reference's marker loop.
+// O(products) broadcast steps per row instead of O(products log^2) exchanges.
+template <int R, bool NUMERIC, class Expander>
+__global__ __launch_bounds__(kBlock) void esc_wave_kernel(int nrows, const int *__restrict__ ub, int lo, int hi, Expander ex,
+                                                          int *__restrict__ rownnz, const int *__restrict__ CI, int *__restrict__ CJ,
+                                                          double *__restrict__ Ca)
+{
+    constexpr int N = 64 * R;
+    __shared__ u64 key[(kBlock / 64) * N];
+    __shared__ double val[NUMERIC ? (kBlock / 64) * N : 1];
+    __shared__ int ucol[(kBlock / 64) * N];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (kBlock / 64) + w;
+    const int u = row < nrows ? ub[row] : 0;
+    const bool active = u > lo && u <= hi;          // (lo, hi]: this launch's class of rows
+    u64 *kw = key + w * N;
+    double *vw = NUMERIC ? val + w * N : val;
+    int *uc = ucol + w * N;
+    if (active) ex.template expand<NUMERIC>(row, 0u, 0, kw, vw);
+    __syncthreads();
+    int E = 0;
+    if (active) {
+        int ck[R];
+        bool first[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) { const int e = r * 64 + lane; ck[r] = e < u ? (int)(kw[e] & 0xffffffffu) : -1; first[r] = e < u; }
+        for (int q = 0; q < u; q++) {
+            const int cq = (int)(kw[q] & 0xffffffffu);
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (q < r * 64 + lane && cq == ck[r]) first[r] = false;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const unsigned long long m = __ballot(first[r]);
+            if (first[r]) uc[E + __popcll(m & ((1ull << lane) - 1ull))] = ck[r];
+            E += __popcll(m);
+        }
+        if (!NUMERIC && lane == 0) rownnz[row] = E;
+    }
+    if (!NUMERIC) return;
+    __syncthreads();                                 // the distinct-column lists are complete
+    if (!active) return;
+    const int base = CI[row];
+    for (int eo = lane; eo < E; eo += 64) {          // (wave-uniform trip count is not needed: no collectives below)
+        const int c = uc[eo];
+        int rank = 0;
+        for (int t = 0; t < E; t++) rank += (uc[t] < c) ? 1 : 0;
+        double sum = 0.0;
+        for (int q = 0; q < u; q++)
+            if ((int)(kw[q] & 0xffffffffu) == c) sum += vw[q];
+        CJ[base + rank] = c;
+        Ca[base + rank] = sum;
+    }
+}
+
+inline bool wave_path_enabled()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ELAG_HIP_ESC_WAVE"); v = e ? atoi(e) : 1; }   // 0 = chunked LDS path only (A/B runs)
+    return v != 0;
 }
 
 inline unsigned grid1(long long n, int b = kBlock) { return (unsigned)((n + b - 1) / b < 1 ? 1 : (n + b - 1) / b); }
@@ -313,13 +402,14 @@ struct EscPlan {
     int nrows;
     Temp<int> ub, ub_small, ubscan, biglist, counters;
     int total_small = 0, nbig = 0;
+    int wave_cap = 0;   // > 0: rows with at most this many products go to esc_wave_kernel
     explicit EscPlan(int n) : nrows(n), ub((size_t)n), ub_small((size_t)n), ubscan((size_t)n + 1), biglist((size_t)n), counters(2) {}
     void finish()
     {
         hipStream_t st = ctx().stream;
         ELAG_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * sizeof(int), st));
         hipLaunchKernelGGL(split_big_kernel, dim3(grid1(nrows)), dim3(kBlock), 0, st, nrows, ub.p, ub_small.p, biglist.p,
-                           counters.p, counters.p + 1);
+                           counters.p, counters.p + 1, wave_cap);
         exclusive_scan(ub_small, ubscan, nrows);
         int h[2], tot;
         ELAG_HIP_CHECK(hipMemcpyAsync(h, counters.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -347,6 +437,13 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C)
     if (plan.nbig)
         hipLaunchKernelGGL((esc_kernel<kBigCap, true, false, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
                            plan.ub.p, plan.biglist.p, ex, rownnz.p, (const int *)nullptr, (int *)nullptr, (double *)nullptr);
+    const unsigned wgrid = grid1((long long)n * 64);
+    if (plan.wave_cap > 0) {
+        hipLaunchKernelGGL((esc_wave_kernel<1, false, Expander>), dim3(wgrid), dim3(kBlock), 0, st, n, (const int *)plan.ub.p, 0, 64, ex, rownnz.p,
+                           (const int *)nullptr, (int *)nullptr, (double *)nullptr);
+        hipLaunchKernelGGL((esc_wave_kernel<4, false, Expander>), dim3(wgrid), dim3(kBlock), 0, st, n, (const int *)plan.ub.p, 64, kWaveCap, ex, rownnz.p,
+                           (const int *)nullptr, (int *)nullptr, (double *)nullptr);
+    }
     ELAG_LAUNCH_CHECK();
     int *CI = dev_alloc<int>((size_t)n + 1);
     exclusive_scan(rownnz, CI, n);
@@ -362,6 +459,12 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C)
     if (plan.nbig)
         hipLaunchKernelGGL((esc_kernel<kBigCap, true, true, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
                            plan.ub.p, plan.biglist.p, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
+    if (plan.wave_cap > 0) {
+        hipLaunchKernelGGL((esc_wave_kernel<1, true, Expander>), dim3(wgrid), dim3(kBlock), 0, st, n, (const int *)plan.ub.p, 0, 64, ex, (int *)nullptr,
+                           (const int *)C.I, C.J, C.a);
+        hipLaunchKernelGGL((esc_wave_kernel<4, true, Expander>), dim3(wgrid), dim3(kBlock), 0, st, n, (const int *)plan.ub.p, 64, kWaveCap, ex, (int *)nullptr,
+                           (const int *)C.I, C.J, C.a);
+    }
     ELAG_LAUNCH_CHECK();
     C.choose_spmv_shape();
 }
@@ -375,6 +478,7 @@ void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C)
     EscPlan plan(A.nrows);
     CsrView a{A.I, A.J, A.a}, b{B.I, B.J, B.a};
     hipLaunchKernelGGL(matmul_ub_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, ctx().stream, A.nrows, a, b, plan.ub.p);
+    plan.wave_cap = wave_path_enabled() ? kWaveCap : 0;
     plan.finish();
     MatmulExpander ex{a, b};
     esc_run(plan, ex, B.ncols, C);
@@ -387,14 +491,57 @@ void csr_add(double ca, const DevCSR &A, double cb, const DevCSR &B, DevCSR &C)
     EscPlan plan(A.nrows);
     CsrView a{A.I, A.J, A.a}, b{B.I, B.J, B.a};
     hipLaunchKernelGGL(add_ub_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, ctx().stream, A.nrows, a, b, plan.ub.p);
+    plan.wave_cap = wave_path_enabled() ? kWaveCap : 0;
     plan.finish();
     AddExpander ex{a, b, ca, cb};
     esc_run(plan, ex, A.ncols, C);
 }
 
+namespace {
+// Rows of at most G entries: one G-lane group per row sorts (column, value) pairs in registers with a shuffle bitonic
+// network -- no LDS, no barriers, in place (row lengths do not change, so no count / scan / fill passes either).
+template <int G>
+__global__ __launch_bounds__(kBlock) void sort_rows_group_kernel(int nrows, const int *__restrict__ I, int *__restrict__ J, double *__restrict__ a)
+{
+    const int row = (blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    if (row >= nrows) return;
+    const int s = I[row], len = I[row + 1] - s;
+    if (len < 2) return;
+    int key = 0x7fffffff;
+    double v = 0.0;
+    if (lane < len) { key = J[s + lane]; v = a[s + lane]; }
+#pragma unroll
+    for (int k = 2; k <= G; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int pk = __shfl_xor(key, j, 64);
+            const double pv = __shfl_xor(v, j, 64);
+            const bool up = ((lane & k) == 0);
+            const bool lower = ((lane & j) == 0);
+            // the lower lane of an ascending pair keeps the smaller key (ties: everybody keeps its own)
+            const bool take = (lower == up) ? (pk < key) : (pk > key);
+            if (take) { key = pk; v = pv; }
+        }
+    }
+    if (lane < len) { J[s + lane] = key; a[s + lane] = v; }
+}
+}  // namespace
+
 void csr_sort_rows(DevCSR &A)
 {
     if (A.nrows == 0 || A.nnz == 0) return;
+    if (A.block_row == nullptr || A.max_row_nnz <= 0) build_stream_plan(A);   // max_row_nnz
+    if (A.max_row_nnz <= 64) {
+        hipStream_t st = ctx().stream;
+        const int *I = A.I;
+        if (A.max_row_nnz <= 16) hipLaunchKernelGGL((sort_rows_group_kernel<16>), dim3(grid1((long long)A.nrows * 16)), dim3(kBlock), 0, st, A.nrows, I, A.J, A.a);
+        else if (A.max_row_nnz <= 32) hipLaunchKernelGGL((sort_rows_group_kernel<32>), dim3(grid1((long long)A.nrows * 32)), dim3(kBlock), 0, st, A.nrows, I, A.J, A.a);
+        else hipLaunchKernelGGL((sort_rows_group_kernel<64>), dim3(grid1((long long)A.nrows * 64)), dim3(kBlock), 0, st, A.nrows, I, A.J, A.a);
+        ELAG_LAUNCH_CHECK();
+        A.choose_spmv_shape();
+        return;
+    }
     EscPlan plan(A.nrows);
     hipLaunchKernelGGL(rowlen_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, ctx().stream, A.nrows, (const int *)A.I, plan.ub.p);
     plan.finish();
