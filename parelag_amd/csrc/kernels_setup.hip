@@ -32,6 +32,18 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     return v;
 }
 
+template <int G>
+__device__ __forceinline__ int group_incl_scan(int v)   // inclusive scan inside aligned groups of G lanes
+{
+    const int lane = threadIdx.x & (G - 1);
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) {
+        const int t = __shfl_up(v, o, G);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
 // exclusive scan of one value per thread across the block; returns exclusive prefix, total in *total
 __device__ __forceinline__ int block_excl_scan(int v, int *sh /*>= 5 ints*/, int *total)
 {
@@ -116,16 +128,16 @@ struct CsrView {
 struct MatmulExpander {
     CsrView A, B;
     __device__ int ub_entry(int k) const { const int j = A.J[k]; return B.I[j + 1] - B.I[j]; }
-    // wave-cooperative expansion of one row
-    template <bool NUMERIC>
+    // cooperative expansion of one row by a group of G lanes (G = 64: a wavefront)
+    template <bool NUMERIC, int G = 64>
     __device__ void expand(int row, unsigned rl, int off, u64 *key, double *val) const
     {
-        const int lane = threadIdx.x & 63;
-        for (int k0 = A.I[row]; k0 < A.I[row + 1]; k0 += 64) {
+        const int lane = threadIdx.x & (G - 1);
+        for (int k0 = A.I[row]; k0 < A.I[row + 1]; k0 += G) {
             const int k = k0 + lane;
             int len = 0, j = 0;
             if (k < A.I[row + 1]) { j = A.J[k]; len = B.I[j + 1] - B.I[j]; }
-            const int incl = wave_incl_scan(len);
+            const int incl = group_incl_scan<G>(len);
             int pos = off + incl - len;
             if (len) {
                 const double av = NUMERIC ? A.a[k] : 0.0;
@@ -135,7 +147,7 @@ struct MatmulExpander {
                     if (NUMERIC) val[pos + q] = av * B.a[bs + q];
                 }
             }
-            off += __shfl(incl, 63, 64);
+            off += __shfl(incl, G - 1, G);
         }
     }
 };
@@ -143,17 +155,17 @@ struct MatmulExpander {
 struct AddExpander {
     CsrView A, B;
     double ca, cb;
-    template <bool NUMERIC>
+    template <bool NUMERIC, int G = 64>
     __device__ void expand(int row, unsigned rl, int off, u64 *key, double *val) const
     {
-        const int lane = threadIdx.x & 63;
+        const int lane = threadIdx.x & (G - 1);
         const int as = A.I[row], na = A.I[row + 1] - as;
         const int bs = B.I[row], nb = B.I[row + 1] - bs;
-        for (int q = lane; q < na; q += 64) {
+        for (int q = lane; q < na; q += G) {
             key[off + q] = ((u64)rl << 32) | (unsigned)A.J[as + q];
             if (NUMERIC) val[off + q] = ca * A.a[as + q];
         }
-        for (int q = lane; q < nb; q += 64) {
+        for (int q = lane; q < nb; q += G) {
             key[off + na + q] = ((u64)rl << 32) | (unsigned)B.J[bs + q];
             if (NUMERIC) val[off + na + q] = cb * B.a[bs + q];
         }
@@ -162,12 +174,12 @@ struct AddExpander {
 
 struct SortExpander {  // identity: re-emit the row (used to sort columns inside rows)
     CsrView A;
-    template <bool NUMERIC>
+    template <bool NUMERIC, int G = 64>
     __device__ void expand(int row, unsigned rl, int off, u64 *key, double *val) const
     {
-        const int lane = threadIdx.x & 63;
+        const int lane = threadIdx.x & (G - 1);
         const int as = A.I[row], na = A.I[row + 1] - as;
-        for (int q = lane; q < na; q += 64) {
+        for (int q = lane; q < na; q += G) {
             key[off + q] = ((u64)rl << 32) | (unsigned)A.J[as + q];
             if (NUMERIC) val[off + q] = A.a[as + q];
         }
@@ -335,39 +347,44 @@ __global__ void split_big_kernel(int nrows, const int *__restrict__ ub, int *__r
 //   4. the lane owning an output entry walks the product list once more and adds the matching products in storage
 //      order -- deterministic, no atomics, and the same summation order as the reference's marker loop.
 // O(products) broadcast steps per row instead of O(products log^2) exchanges.
-template <int R, bool NUMERIC, class Expander>
+template <int G, int R, bool NUMERIC, class Expander>
 __global__ __launch_bounds__(kBlock) void esc_wave_kernel(int nrows, const int *__restrict__ ub, int lo, int hi, Expander ex,
                                                           int *__restrict__ rownnz, const int *__restrict__ CI, int *__restrict__ CJ,
                                                           double *__restrict__ Ca)
 {
-    constexpr int N = 64 * R;
-    __shared__ u64 key[(kBlock / 64) * N];
-    __shared__ double val[NUMERIC ? (kBlock / 64) * N : 1];
-    __shared__ int ucol[(kBlock / 64) * N];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (kBlock / 64) + w;
+    // a group of G lanes per row (G = 16 / 32: several rows per wavefront; G = 64: one row, R products per lane)
+    static_assert(G == 64 || R == 1, "several products per lane only with whole-wave groups");
+    constexpr int N = G * R;
+    constexpr int NG = kBlock / G;
+    __shared__ u64 key[NG * N];
+    __shared__ double val[NUMERIC ? NG * N : 1];
+    __shared__ int ucol[NG * N];
+    const int g = threadIdx.x / G, lane = threadIdx.x & (G - 1);
+    const int row = blockIdx.x * NG + g;
     const int u = row < nrows ? ub[row] : 0;
     const bool active = u > lo && u <= hi;          // (lo, hi]: this launch's class of rows
-    u64 *kw = key + w * N;
-    double *vw = NUMERIC ? val + w * N : val;
-    int *uc = ucol + w * N;
-    if (active) ex.template expand<NUMERIC>(row, 0u, 0, kw, vw);
+    u64 *kw = key + g * N;
+    double *vw = NUMERIC ? val + g * N : val;
+    int *uc = ucol + g * N;
+    if (active) ex.template expand<NUMERIC, G>(row, 0u, 0, kw, vw);
     __syncthreads();
     int E = 0;
     if (active) {
         int ck[R];
         bool first[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) { const int e = r * 64 + lane; ck[r] = e < u ? (int)(kw[e] & 0xffffffffu) : -1; first[r] = e < u; }
+        for (int r = 0; r < R; r++) { const int e = r * G + lane; ck[r] = e < u ? (int)(kw[e] & 0xffffffffu) : -1; first[r] = e < u; }
         for (int q = 0; q < u; q++) {
             const int cq = (int)(kw[q] & 0xffffffffu);
 #pragma unroll
             for (int r = 0; r < R; r++)
-                if (q < r * 64 + lane && cq == ck[r]) first[r] = false;
+                if (q < r * G + lane && cq == ck[r]) first[r] = false;
         }
+        const int gshift = (int)(threadIdx.x & 63) & ~(G - 1);   // first lane of this group inside its wavefront
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const unsigned long long m = __ballot(first[r]);
+            unsigned long long m = __ballot(first[r]);
+            if (G < 64) m = (m >> gshift) & ((1ull << (G & 63)) - 1ull);
             if (first[r]) uc[E + __popcll(m & ((1ull << lane) - 1ull))] = ck[r];
             E += __popcll(m);
         }
@@ -377,7 +394,7 @@ __global__ __launch_bounds__(kBlock) void esc_wave_kernel(int nrows, const int *
     __syncthreads();                                 // the distinct-column lists are complete
     if (!active) return;
     const int base = CI[row];
-    for (int eo = lane; eo < E; eo += 64) {          // (wave-uniform trip count is not needed: no collectives below)
+    for (int eo = lane; eo < E; eo += G) {
         const int c = uc[eo];
         int rank = 0;
         for (int t = 0; t < E; t++) rank += (uc[t] < c) ? 1 : 0;
@@ -437,11 +454,16 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C)
     if (plan.nbig)
         hipLaunchKernelGGL((esc_kernel<kBigCap, true, false, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
                            plan.ub.p, plan.biglist.p, ex, rownnz.p, (const int *)nullptr, (int *)nullptr, (double *)nullptr);
-    const unsigned wgrid = grid1((long long)n * 64);
+    // row classes by number of products: (0,16] 16 lanes per row, (16,32] 32, (32,64] a wavefront, (64,256] 4 per lane
     if (plan.wave_cap > 0) {
-        hipLaunchKernelGGL((esc_wave_kernel<1, false, Expander>), dim3(wgrid), dim3(kBlock), 0, st, n, (const int *)plan.ub.p, 0, 64, ex, rownnz.p,
+        const int *ubp = plan.ub.p;
+        hipLaunchKernelGGL((esc_wave_kernel<16, 1, false, Expander>), dim3(grid1((long long)n * 16)), dim3(kBlock), 0, st, n, ubp, 0, 16, ex, rownnz.p,
                            (const int *)nullptr, (int *)nullptr, (double *)nullptr);
-        hipLaunchKernelGGL((esc_wave_kernel<4, false, Expander>), dim3(wgrid), dim3(kBlock), 0, st, n, (const int *)plan.ub.p, 64, kWaveCap, ex, rownnz.p,
+        hipLaunchKernelGGL((esc_wave_kernel<32, 1, false, Expander>), dim3(grid1((long long)n * 32)), dim3(kBlock), 0, st, n, ubp, 16, 32, ex, rownnz.p,
+                           (const int *)nullptr, (int *)nullptr, (double *)nullptr);
+        hipLaunchKernelGGL((esc_wave_kernel<64, 1, false, Expander>), dim3(grid1((long long)n * 64)), dim3(kBlock), 0, st, n, ubp, 32, 64, ex, rownnz.p,
+                           (const int *)nullptr, (int *)nullptr, (double *)nullptr);
+        hipLaunchKernelGGL((esc_wave_kernel<64, 4, false, Expander>), dim3(grid1((long long)n * 64)), dim3(kBlock), 0, st, n, ubp, 64, kWaveCap, ex, rownnz.p,
                            (const int *)nullptr, (int *)nullptr, (double *)nullptr);
     }
     ELAG_LAUNCH_CHECK();
@@ -460,9 +482,14 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C)
         hipLaunchKernelGGL((esc_kernel<kBigCap, true, true, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
                            plan.ub.p, plan.biglist.p, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
     if (plan.wave_cap > 0) {
-        hipLaunchKernelGGL((esc_wave_kernel<1, true, Expander>), dim3(wgrid), dim3(kBlock), 0, st, n, (const int *)plan.ub.p, 0, 64, ex, (int *)nullptr,
+        const int *ubp = plan.ub.p;
+        hipLaunchKernelGGL((esc_wave_kernel<16, 1, true, Expander>), dim3(grid1((long long)n * 16)), dim3(kBlock), 0, st, n, ubp, 0, 16, ex, (int *)nullptr,
                            (const int *)C.I, C.J, C.a);
-        hipLaunchKernelGGL((esc_wave_kernel<4, true, Expander>), dim3(wgrid), dim3(kBlock), 0, st, n, (const int *)plan.ub.p, 64, kWaveCap, ex, (int *)nullptr,
+        hipLaunchKernelGGL((esc_wave_kernel<32, 1, true, Expander>), dim3(grid1((long long)n * 32)), dim3(kBlock), 0, st, n, ubp, 16, 32, ex, (int *)nullptr,
+                           (const int *)C.I, C.J, C.a);
+        hipLaunchKernelGGL((esc_wave_kernel<64, 1, true, Expander>), dim3(grid1((long long)n * 64)), dim3(kBlock), 0, st, n, ubp, 32, 64, ex, (int *)nullptr,
+                           (const int *)C.I, C.J, C.a);
+        hipLaunchKernelGGL((esc_wave_kernel<64, 4, true, Expander>), dim3(grid1((long long)n * 64)), dim3(kBlock), 0, st, n, ubp, 64, kWaveCap, ex, (int *)nullptr,
                            (const int *)C.I, C.J, C.a);
     }
     ELAG_LAUNCH_CHECK();
