@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Golden vectors of the V-cycle path on cube456 refined once (840 -> 141 dofs), generated with the CPU oracle
+(nothing can be captured from the reference itself -- hypre/MFEM are absent -- so these pin the ORACLE against
+accidental change and give the device tests a fixed target).  Inputs are reproducible from tests/golden/cube456.npz and
+the seeds below; outputs are stored.
+
+    python tools/make_oracle_golden.py          # writes tests/golden/oracle_h1_k1.npz
+"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import oracle as orc
+from parelag_amd import meshgen
+from tests.helpers import oracle_h1_hierarchy
+
+A, Ps, seq = meshgen.h1_problem(1)
+n = A.shape[0]
+rng = np.random.default_rng(20240607)
+f, u0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+Ao = orc.OParCSR(orc.diag_first(A))
+out = dict(seed=20240607, n=n, nnz=A.nnz, f=f, u0=u0)
+out["l1"] = orc.l1_norms(orc.diag_first(A), None, 1)
+y = np.zeros(n); Ao.matvec(1.0, u0, 0.0, y); out["spmv"] = y
+s = orc.OSmoother(Ao, type=1, sweeps=2, weight=0.9); u = u0.copy(); s.Mult(f, u); out["l1_jacobi_2sweeps_w09"] = u
+mx, mn = orc.max_eig_estimate_cg(Ao, 1, 10); out["eig_estimate"] = np.array([mx, mn])
+c = orc.OSmoother(Ao, type=16, order=3, eig=(mx, mn)); u = u0.copy(); c.Mult(f, u); out["cheby_order3"] = u
+Ac = orc.rap(orc.csr(Ps[0]), orc.diag_first(A), orc.csr(Ps[0])); orc.fix_zero_rows(Ac)
+Acs = Ac.copy(); Acs.sort_indices()
+out["rap_indptr"], out["rap_indices"], out["rap_data"] = Acs.indptr, Acs.indices, Acs.data
+h = oracle_h1_hierarchy(A, Ps, smoother=1)
+x = np.empty(n); orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"]).apply(np.full(n, 2.0), x); out["vcycle_b2"] = x
+xr = np.zeros(n)
+res = orc.mfem_cg(lambda v: A @ v, lambda r, z: orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"]).apply(r, z), f, xr, rel_tol=1e-10, max_iter=50)
+out["pcg_solution"], out["pcg_iterations"], out["pcg_final_norm"] = xr, res.final_iter, res.final_norm
+part = orc.partition_refined(seq.meshes[0].nt, seq.meshes[1].nt)
+out["partition"] = part
+np.savez_compressed(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "oracle_h1_k1.npz"), **out)
+print("written", {k: (np.asarray(v).shape if hasattr(v, "shape") else v) for k, v in out.items()})
