@@ -138,11 +138,12 @@ void reverse_halo_add(ParCSR &A, double alpha, double *y)
     reverse_halo_finish(A, alpha, y);
 }
 
-void par_spmvT(ParCSR &A, double alpha, const double *x, double beta, double *y)
+void par_spmvT(ParCSR &A, double alpha, const double *x, double beta, double *y, const double *row_scale)
 {
     Context &c = ctx();
     A.ensure_transpose();
     const bool halo = A.needs_exchange();
+    ELAG_REQUIRE(!(halo && row_scale), "internal: scaled transposed product needs a rank-local operator");
     if (halo) {
         // y_ghost = offd^T x, then the reverse exchange (roles of the send/recv lists swapped)
         if (A.offd.ncols > 0) {
@@ -153,7 +154,7 @@ void par_spmvT(ParCSR &A, double alpha, const double *x, double beta, double *y)
         reverse_halo_start(A);
     }
     k::SpmvArgs d;
-    d.x = x; d.alpha = alpha; d.yin = (beta != 0.0) ? y : nullptr; d.beta = beta; d.out = y;
+    d.x = x; d.alpha = alpha; d.yin = (beta != 0.0) ? y : nullptr; d.beta = beta; d.out = y; d.s = row_scale;
     k::spmv_fused(*A.diagT, nullptr, d, c.stream);
     if (halo) reverse_halo_finish(A, alpha, y);
 }

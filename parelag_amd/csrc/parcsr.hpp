@@ -46,7 +46,8 @@ typedef elag_hip_parcsr_s ParCSR;
 // interior rows.  `a.x` is the local vector (length ncols of diag); a.xg / a.csg are filled in here.
 void par_spmv(ParCSR &A, k::SpmvArgs a);
 // y = alpha*A^T x + beta*y  (x: local rows, y: local columns of diag)
-void par_spmvT(ParCSR &A, double alpha, const double *x, double beta, double *y);
+// `row_scale` (optional, rank-local operators only): y_i = row_scale_i * (alpha*(A^T x)_i) + beta*y_i
+void par_spmvT(ParCSR &A, double alpha, const double *x, double beta, double *y, const double *row_scale = nullptr);
 
 // dist_rap.hip
 ParCSR *distributed_rap(ParCSR &RT, ParCSR &A, ParCSR &P, bool ignore_nonlocal_range = false);

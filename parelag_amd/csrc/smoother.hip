@@ -248,10 +248,16 @@ void HiptmairSmoother::setup()
 void HiptmairSmoother::aux_correct(const double *resid, double *x)
 {
     // cB = D^T defect ; relax on A_aux (iterative_mode == false) ; X += D * correction   (HiptmairSmoother.cpp:61-75)
-    par_spmvT(*D, 1.0, resid, 0.0, auxb);
     double *cx = auxx, *ca = auxalt;
-    if (aux->flips(true) & 1) std::swap(cx, ca);
-    aux->apply(auxb, cx, ca, true, false);
+    const double *aux_w = (aux->A && aux->n() == D->ncols()) ? aux->diag_scaling() : nullptr;
+    if (aux_w && !D->needs_exchange()) {
+        // one diagonal sweep from the zero guess is a row scaling: folded into the epilogue of the D^T product
+        par_spmvT(*D, 1.0, resid, 0.0, cx, aux_w);
+    } else {
+        par_spmvT(*D, 1.0, resid, 0.0, auxb);
+        if (aux->flips(true) & 1) std::swap(cx, ca);
+        aux->apply(auxb, cx, ca, true, false);
+    }
     k::SpmvArgs a;
     a.x = cx; a.alpha = 1.0; a.yin = x; a.beta = 1.0; a.out = x;
     par_spmv(*D, a);
@@ -260,10 +266,18 @@ void HiptmairSmoother::aux_correct(const double *resid, double *x)
 void HiptmairSmoother::apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose)
 {
     if (!transpose) {
-        primary->apply(f, cur, alt, zero_guess, false);
-        k::SpmvArgs a;  // R = B - A X
-        a.x = cur; a.alpha = -1.0; a.f = f; a.gamma = 1.0; a.out = pv;
-        par_spmv(*A, a);
+        const double *w = (primary->A == A) ? primary->diag_scaling() : nullptr;
+        if (zero_guess && w) {
+            // X = W B and R = B - A X in one product: the sweep's result is the (column-scaled) operand of the SpMV
+            k::SpmvArgs a;
+            a.x = f; a.cs = w; a.alpha = -1.0; a.f = f; a.gamma = 1.0; a.out = pv; a.out2 = cur;
+            par_spmv(*A, a);
+        } else {
+            primary->apply(f, cur, alt, zero_guess, false);
+            k::SpmvArgs a;  // R = B - A X
+            a.x = cur; a.alpha = -1.0; a.f = f; a.gamma = 1.0; a.out = pv;
+            par_spmv(*A, a);
+        }
         aux_correct(pv, cur);
     } else {
         // MultTranspose (:79-109): auxiliary correction first, then the primary sweep in iterative mode
