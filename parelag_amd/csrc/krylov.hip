@@ -28,7 +28,7 @@ constexpr int kB = 256;
 inline unsigned g1(long long n) { return (unsigned)std::max<long long>(1, (n + kB - 1) / kB); }
 
 enum { S_NOM, S_DEN, S_BETANOM, S_R0, S_ALPHA, S_BETA, S_TMP, S_FINAL_NORM, S_GBETA, S_THRESH, S_NORMK1, S_RATIO, S_COUNT = 16 };
-enum { F_DONE, F_CONVERGED, F_FINAL_ITER, F_ITER, F_PENDING, F_COUNT = 8 };
+enum { F_DONE, F_CONVERGED, F_FINAL_ITER, F_ITER, F_PENDING, F_ITER2, F_COUNT = 8 };
 
 struct KState {
     double sc[S_COUNT];
@@ -212,6 +212,49 @@ __global__ void __launch_bounds__(kB) gmres_norm_fused_kernel(KState *st, double
     if (threadIdx.x == 0) { Hm(hs, m, i + 1, i) = nw; st->sc[S_BETA] = nw; }
 }
 
+// ---- CG with the reductions finished inside their consumers (single rank) ------------------------------------------------
+// betanom = sum(part) is re-summed by every block of the direction update (same fixed order everywhere); block 0 takes
+// cg_step1's branches and writes the state.  The iteration counter is double-buffered (read F_ITER, write F_ITER2;
+// cg_step2 copies it back) so that no block reads a value another block of the same launch is writing; a block that
+// observes the freshly written `done` flag returns, which is exactly what the others decide from `stop`.
+__global__ void __launch_bounds__(kB) cg_fused_dir_kernel(int n, KState *__restrict__ st, int max_iter, const double *__restrict__ part,
+                                                          const double *__restrict__ src, double *__restrict__ d)
+{
+    __shared__ double sh[4];
+    if (st->fl[F_DONE]) return;
+    const double betanom = sum_partials(part, sh);
+    const int i = st->fl[F_ITER];
+    const double r0 = st->sc[S_R0], nom = st->sc[S_NOM];
+    const bool stop = (betanom < 0.0) || (betanom <= r0) || (i + 1 > max_iter);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->sc[S_BETANOM] = betanom;
+        st->sc[S_FINAL_NORM] = sqrt(betanom);
+        st->fl[F_ITER2] = i;
+        if (betanom < 0.0) { st->fl[F_FINAL_ITER] = i; st->fl[F_DONE] = 1; }
+        else if (betanom <= r0) { st->fl[F_CONVERGED] = 1; st->fl[F_FINAL_ITER] = i; st->fl[F_DONE] = 1; }
+        else if (i + 1 > max_iter) { st->fl[F_ITER2] = i + 1; st->fl[F_DONE] = 1; }   // final_iter stays max_iter
+        else { st->fl[F_ITER2] = i + 1; st->sc[S_BETA] = betanom / nom; }
+    }
+    if (stop) return;
+    const double beta = betanom / nom;
+    for (int t = blockIdx.x * kB + threadIdx.x; t < n; t += kPart * kB) d[t] = src[t] + beta * d[t];
+}
+
+// cg_step2 with the dot finished in-kernel (one block)
+__global__ void __launch_bounds__(kB) cg_fused_step2_kernel(KState *st, const double *__restrict__ part)
+{
+    __shared__ double sh[4];
+    if (st->fl[F_DONE]) return;
+    const double den = sum_partials(part, sh);
+    if (threadIdx.x == 0) {
+        st->fl[F_ITER] = st->fl[F_ITER2];
+        st->sc[S_DEN] = den;
+        if (den == 0.0) { st->fl[F_FINAL_ITER] = st->fl[F_ITER]; st->fl[F_DONE] = 1; return; }
+        st->sc[S_NOM] = st->sc[S_BETANOM];
+        st->sc[S_ALPHA] = st->sc[S_NOM] / den;
+    }
+}
+
 __global__ void gmres_norm_kernel(KState *st, double *hs, int m, int i)
 {
     if (st->fl[F_DONE]) return;
@@ -370,7 +413,7 @@ struct elag_hip_krylov_s {
         ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_sc), sizeof(double) * S_COUNT));
         k::prepare_spmv(A->diag);
         x = dev_alloc<double>(nn); r = dev_alloc<double>(nn); z = dev_alloc<double>(nn); scr = dev_alloc<double>(nn);
-        if (solver == ELAG_HIP_KRYLOV_CG) d = dev_alloc<double>(nn);
+        if (solver == ELAG_HIP_KRYLOV_CG) { d = dev_alloc<double>(nn); part = dev_alloc<double>(2 * (size_t)kPart); }
         if (solver == ELAG_HIP_KRYLOV_STATIONARY) { d = dev_alloc<double>(nn); }
         if (solver == ELAG_HIP_KRYLOV_GMRES || solver == ELAG_HIP_KRYLOV_FGMRES) {
             ELAG_REQUIRE(restart >= 1, "\"Restart size\" must be >= 1");
@@ -431,6 +474,7 @@ struct elag_hip_krylov_s {
     {
         hipStream_t s = ctx().stream;
         ELAG_HIP_CHECK(hipMemcpyAsync(h_flags, st->fl, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, s));
+        ELAG_HIP_CHECK(hipMemcpyAsync(h_sc, st->sc, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, s));
         ELAG_HIP_CHECK(hipStreamSynchronize(s));
         return h_flags[F_DONE] != 0;
     }
@@ -458,6 +502,18 @@ struct elag_hip_krylov_s {
         hipStream_t s = ctx().stream;
         const int nn = n();
         hipLaunchKernelGGL(cg_update_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, x, (const double *)d, r, (const double *)z);
+        if (!distributed()) {
+            // single rank: each dot is one partial-sum kernel, finished inside the kernel that consumes it
+            const double *src = has_prec() ? z : r;
+            if (has_prec()) prec(r, z);
+            hipLaunchKernelGGL(gmres_dot0_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, (const double *)r, src, part);
+            hipLaunchKernelGGL(cg_fused_dir_kernel, dim3(kPart), dim3(kB), 0, s, nn, st, max_iter, (const double *)part, src, d);
+            amul(d, z);
+            hipLaunchKernelGGL(gmres_dot0_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, (const double *)d, (const double *)z, part + kPart);
+            hipLaunchKernelGGL(cg_fused_step2_kernel, dim3(1), dim3(kB), 0, s, st, (const double *)(part + kPart));
+            ELAG_LAUNCH_CHECK();
+            return;
+        }
         if (has_prec()) { prec(r, z); dot(r, z); } else dot(r, r);
         hipLaunchKernelGGL(cg_step1_kernel, dim3(1), dim3(1), 0, s, st, max_iter);
         hipLaunchKernelGGL(cg_dir_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, (const double *)(has_prec() ? z : r), d);
@@ -495,14 +551,29 @@ struct elag_hip_krylov_s {
             (void)hipGraphDestroy(g);
         }
         const int total = std::max(1, max_iter);   // mfem's loop body runs once even with max_iter == 0
+        // Iterations enqueued past convergence are no-ops for the iterate but still run the (unpredicated) preconditioner,
+        // so the batch between two reads of the state is sized from the observed convergence rate: the host reads
+        // (B r, r) with the flag and enqueues about as many iterations as the rate predicts are still needed.
+        double prev = 0.0;
+        int batch = std::min(check_every, std::max(1, std::min(total, 4)));
         for (int it = 0; it < total;) {
-            const int batch = std::min(check_every, total - it);
+            batch = std::min(batch, total - it);
             for (int q = 0; q < batch; q++) {
                 if (graph) ELAG_HIP_CHECK(hipGraphLaunch(cg_iter, s));
                 else cg_iteration();
             }
             it += batch;
             if (poll()) break;
+            const double cur = h_sc[S_BETANOM], r0v = h_sc[S_R0];
+            int next = check_every;
+            if (prev > 0.0 && cur > 0.0 && cur < prev && r0v > 0.0 && cur > r0v) {
+                const double rate = std::log(prev / cur) / batch;          // decrease of log (Br,r) per iteration
+                next = (int)std::ceil(std::log(cur / r0v) / rate);
+            } else if (prev == 0.0) {
+                next = batch;                                               // no rate yet: same size once more
+            }
+            prev = cur;
+            batch = std::max(1, std::min(check_every, next));
         }
     }
 
