@@ -427,6 +427,82 @@ ELAG_HIP_API int elag_hip_krylov_get_stats(elag_hip_krylov_t K, int *converged, 
 ELAG_HIP_API int elag_hip_krylov_destroy(elag_hip_krylov_t K);
 
 /* --------------------------------------------------------------------------------------------------
+ * AMGe coarse-space construction: the per-agglomerate dense work of DeRhamSequence::Coarsen
+ * (src/amge/DeRhamSequence.cpp:572-692) for the (H(div), L2) pair, i.e. the path taken with jformStart_ = nDim-1
+ * (examples/MultigridTestSPE10.cpp:441).  The host keeps the integer tables the reference builds in
+ * AgglomeratedTopology::CoarsenLocalPartitioning and DofAgglomeration (which entity lies in which agglomerate, local
+ * dof numbering with interior dofs first); the device does every flop, one workgroup per agglomerated entity:
+ *   elag_hip_coarsen_traces      loop body of ComputeCoarseTracesWithTargets (DeRhamSequence.cpp:1818-1926) --
+ *                                local mass assembly (AssembleAgglomerateMatrix, DOFAgglomeration.cpp:533-546), PV
+ *                                deflation (InnerProduct.cpp:157-169), SVD_Calculator::ComputeON in the mass inner
+ *                                product (ParELAG_SVDCalculator.cpp:192-284), coarse mass, CochainProjector::
+ *                                CreateDofFunctional (CochainProjector.cpp:53-137);
+ *   elag_hip_coarsen_extension   loop body of hFacetExtension (DeRhamSequence.cpp:2364-2556) -- FacetSaddlePoint
+ *                                (ParELAG_SaddlePointSolver.cpp:70-130) factorised once per agglomerate and solved for
+ *                                the trace extensions, the RangeT bubbles and the target extensions; coarse derivative
+ *                                row, null-space dofs by SVD, dof functional, coarse element mass.
+ * All arrays are HOST pointers (copied in / out); dense blocks are packed one after the other.  "col-major n x m" =
+ * m columns of length n.  Per-entity output slots have the maximal size (1 + nT trace dofs, nT null dofs); the int
+ * outputs say how much of a slot is used.  Status ELAG_HIP_ERR_NUMERIC when a local system is singular ("bad topology,
+ * such as a torus-shaped agglomerate", ParELAG_SaddlePointSolver.cpp:117-126).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    /* entity e owns items asm_ptr[e] .. asm_ptr[e+1]-1; item t adds the row-major block of order blk_n[t] stored at
+     * blocks + blk_off[t] into the entity's matrix at the local indices loc_idx[loc_off[t] .. loc_off[t] + blk_n[t]) */
+    const int64_t *asm_ptr;
+    const int64_t *blk_off;
+    const int *blk_n;
+    const int64_t *loc_off;
+    const int *loc_idx;
+    const double *blocks;
+    int64_t n_items, n_loc, n_block_values;
+} elag_hip_dense_assembly;
+
+typedef struct {
+    int n_ent, nT;
+    double svd_tol;               /* SVD_Tolerance_ (relative to (pv, pv)_M)                    */
+    const int *ndof;              /* local dofs per entity                                       */
+    elag_hip_dense_assembly mass; /* entity mass matrix                                          */
+    const double *pv;             /* packed, ndof[e] values per entity                           */
+    const double *T;              /* packed, col-major ndof[e] x nT per entity                   */
+} elag_hip_coarsen_traces_in;
+typedef struct {
+    int *ncoarse;                 /* n_ent: 1 + kept target directions                           */
+    double *p_loc;                /* col-major ndof[e] x (1+nT) per entity                       */
+    double *cmass;                /* row-major (1+nT) x (1+nT) per entity, leading ncoarse used  */
+    double *functional;           /* row-major (1+nT) x ndof[e] per entity, first ncoarse rows   */
+} elag_hip_coarsen_traces_out;
+ELAG_HIP_API int elag_hip_coarsen_traces(const elag_hip_coarsen_traces_in *in, const elag_hip_coarsen_traces_out *out,
+                                         double *kernel_ms /* may be NULL: device time of the batch */);
+
+typedef struct {
+    int n_ent, nT;
+    double svd_tol;               /* absolute (DeRhamSequence.cpp:2498)                          */
+    double smallest_entry;        /* SmallestEntry_ (:2403)                                      */
+    const int *nu, *ni, *np;      /* u dofs (interior first), interior u dofs, p dofs per entity */
+    const int *next, *nrt;        /* coarse dofs on the boundary, RangeT bubbles per entity      */
+    elag_hip_dense_assembly mass_u, mass_p;
+    const int64_t *d_ptr;         /* local derivative D (np x nu) as triplets d_ptr[e]..         */
+    const int *d_row, *d_col;
+    const double *d_val;
+    const double *pv_p;           /* packed np[e]: P_3(fine p dofs, PV dof of the agglomerate)   */
+    const double *R_b;            /* packed col-major (nu-ni) x next: traces on the boundary     */
+    const double *cP;             /* packed col-major np x nrt: non-PV coarse form-3 functions   */
+    const double *T;              /* packed col-major nu x nT: targets                           */
+} elag_hip_coarsen_extension_in;
+typedef struct {
+    int *n_null;                  /* n_ent                                                       */
+    double *ext;                  /* col-major ni x next                                         */
+    double *dc;                   /* next: entries of the coarse derivative row of the PV dof    */
+    double *rt;                   /* col-major ni x nrt                                          */
+    double *nul;                  /* col-major ni x nT, first n_null columns used                */
+    double *functional;           /* row-major (nrt+nT) x ni, first nrt+n_null rows used         */
+    double *cmass;                /* row-major of order next+nrt+n_null, stored with ld next+nrt+nT */
+} elag_hip_coarsen_extension_out;
+ELAG_HIP_API int elag_hip_coarsen_extension(const elag_hip_coarsen_extension_in *in, const elag_hip_coarsen_extension_out *out,
+                                            double *kernel_ms);
+
+/* --------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): run `reps` launches of one fine-level kernel on the compute stream
  * bracketed by HIP events created on that stream and return the mean milliseconds per launch.
  * kernel: 0 = SpMV y=Ax, 1 = residual, 2 = l1-Jacobi sweep.
