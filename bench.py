@@ -46,7 +46,62 @@ def vcycle_bytes(shapes):
 
 def seq_fine_M3_one(dar):
     """(1, q) for the piecewise-constant pressure space: element volumes (rhs_p of MultigridTestDarcy with f = 1)"""
+    if "rhs_p" in dar:
+        return dar["rhs_p"]
     return dar["seq"].meshes[0].M3() @ __import__("numpy").ones(dar["B"].shape[0])
+
+
+def amge_darcy_problem(args, spe10, np):
+    """Darcy / SPE10 system whose interpolators come from the device AMGe coarsening.  Returns the ``dar``
+    dict of meshgen.darcy_problem plus an ``amge`` record (what was coarsened, wall and kernel times)."""
+    from parelag_amd import amge, meshgen
+    from parelag_amd.amge_level import box_partition, level_from_hex, level_from_tets
+    t0 = time.time()
+    if args.hex:
+        n = tuple(args.hex)
+        ne = n[0] * n[1] * n[2]
+        kinv = np.exp(args.perm_sigma * np.random.default_rng(2025).standard_normal(ne)) if spe10 else None
+        lv = level_from_hex(n, h=(20.0, 10.0, 2.0), kinv=kinv)          # SPE10 cell size in feet (MultigridTestSPE10.cpp:194-208)
+        parts, m = [], n
+        while (args.amge_levels is None and m[0] * m[1] * m[2] > 2000) or (args.amge_levels is not None and len(parts) < args.amge_levels):
+            parts.append(box_partition(m, (2, 2, 2)))
+            m = tuple(-(-v // 2) for v in m)
+        seq, what = None, "hex %dx%dx%d, 2x2x2 box agglomerates" % n
+    else:
+        seq = meshgen.Sequence.cube456(args.refines)
+        kinv = meshgen.lognormal_inverse_permeability(seq, args.perm_sigma) if spe10 else None
+        lv = level_from_tets(seq.meshes[0], kinv=kinv)
+        parts = [seq.partition(l) for l in range(len(seq.meshes) - 1)]
+        what = "cube456 x%d tets, derefinement agglomerates" % args.refines
+    gen_s = time.time() - t0
+    amge.coarsen(level_from_hex((2, 2, 2)), np.zeros(8, np.int32))         # library / device warm-up
+    recs, Ps, cur = [], [], lv
+    t0 = time.time()
+    for part in parts:
+        tm = {}
+        t1 = time.time()
+        res = amge.coarsen(cur, part, timings=tm)
+        c = res["coarse"]
+        recs.append({"agglomerates": c.nE, "agglomerated_facets": c.nF, "dofs2": [cur.ndof2, c.ndof2], "dofs3": [cur.ndof3, c.ndof3],
+                     "null_dofs": int(res["n_null"].sum()), "wall_s": round(time.time() - t1, 4),
+                     "kernel_ms": {k: round(v, 4) for k, v in tm.items()}})
+        Ps.append((res["P2"], res["P3"]))
+        cur = c
+    total_s = time.time() - t0
+    note("AMGe coarsening: %d levels in %.3f s" % (len(parts), total_s))
+    M, B, Bt = lv.darcy_blocks()
+    dar = dict(M=M, B=B, Bt=Bt, Ps=Ps, seq=seq, rhs_p=lv.mass3() @ lv.const3, kinv=kinv,
+               amge={"what": "DeRhamSequence::Coarsen (jformStart=2) on the device: " + what, "levels": recs,
+                     "coarsen_total_s": round(total_s, 3), "generate_s": round(gen_s, 2), "level0": lv, "parts": parts})
+    return dar
+
+
+def note(msg):
+    """progress line on stderr (stdout carries exactly one JSON line)"""
+    print("[bench %7.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.time()
 
 
 def main():
@@ -64,6 +119,11 @@ def main():
                          "darcy: MultigridTestDarcy (blocked AMGe, Block Jacobi smoother, BASELINE configs[3]); "
                          "spe10: the same with a synthetic log-normal permeability (BASELINE configs[4]; the SPE10 data file is not shipped)")
     ap.add_argument("--perm-sigma", type=float, default=2.0, help="spe10: std-dev of log-permeability")
+    ap.add_argument("--amge", action="store_true", help="darcy/spe10: interpolators from the device AMGe coarsening "
+                    "(DeRhamSequence::Coarsen, jformStart=2) instead of the nested geometric ones")
+    ap.add_argument("--hex", type=int, nargs=3, default=None, metavar=("NX", "NY", "NZ"),
+                    help="darcy/spe10 with --amge: Cartesian hex grid (MultigridTestSPE10 uses 60 220 85) agglomerated in 2x2x2 boxes")
+    ap.add_argument("--amge-levels", type=int, default=None, help="--hex: number of coarsenings (default: until < 2000 elements)")
     ap.add_argument("--block-smoother", default="Block Jacobi", help="darcy: Block Jacobi | Block GS | Block GS Upper | Block LDU")
     ap.add_argument("--positive-s", action="store_true", help='darcy: "Use Negative S" = false (sign-correct Schur block)')
     ap.add_argument("--no-graph", action="store_true")
@@ -72,6 +132,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--solve", action="store_true", help="also time the Krylov solve of the example (PCG / GMRES with the cycle as "
                                                         "preconditioner, device-resident) and report it under \"solve\"")
+    ap.add_argument("--no-cpu-solve", action="store_true", help="--solve: skip the CPU port of the Krylov solve (minutes at SPE10 size)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even with one rank (testing)")
     args = ap.parse_args()
     spe10 = args.form == "spe10"
@@ -166,9 +227,15 @@ def main():
     Ds = None
     if darcy:
         kinv = None
-        if spe10:
-            kinv = meshgen.lognormal_inverse_permeability(meshgen.Sequence.cube456(args.refines), args.perm_sigma)
-        dar = meshgen.darcy_problem(args.refines, kinv=kinv)
+        if args.amge or args.hex:
+            if not single:
+                raise SystemExit("--amge / --hex: single-GPU only in this round (the coarsening runs per rank, shared agglomerated facets are not exchanged yet)")
+            dar = amge_darcy_problem(args, spe10, np)
+            kinv = dar["kinv"]
+        else:
+            if spe10:
+                kinv = meshgen.lognormal_inverse_permeability(meshgen.Sequence.cube456(args.refines), args.perm_sigma)
+            dar = meshgen.darcy_problem(args.refines, kinv=kinv)
         seq = dar["seq"]
         Ps = dar["Ps"]
         A = sp.bmat([[dar["M"], dar["Bt"]], [dar["B"], None]]).tocsr()
@@ -231,6 +298,7 @@ def main():
         from parelag_amd import distributed
         H, n_local, level_shapes, setup_s = distributed.build_hierarchy(dist, A, Ps, seq, args.smoother)
 
+    note("hierarchy built (%d levels, setup %.3f s)" % (len(level_shapes), setup_s))
     rhs = la.DeviceVector(n_local, 2.0)
     sol = la.DeviceVector(n_local, 1.0)
 
@@ -301,6 +369,7 @@ def main():
                  "final_norm": K.GetFinalNorm(), "ms_per_solve": round(solve_ms, 4),
                  "true_rel_residual": float(np.linalg.norm(A @ xs_dev - b_solve) / np.linalg.norm(b_solve))}
 
+    note("device timing done")
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
     cpu = None
     if single and not args.no_cpu_baseline and rank == 0:
@@ -385,7 +454,7 @@ def main():
         # parity spot check of the timed operator against the baseline operator
         xd = sol.to_numpy()
         out["parity_rel_err_vs_oracle"] = float(np.max(np.abs(xd - xs)) / np.max(np.abs(xs)))
-        if solve is not None:
+        if solve is not None and not args.no_cpu_solve:
             xo = np.zeros_like(b_solve)
             t0 = time.perf_counter()
             if darcy:
@@ -450,6 +519,7 @@ def main():
                                     f"{'S' if args.positive_s else '-S'} = -+B diag(M)^-1 Bt) pre/post, dense LU coarse solve, b=2") if darcy else
                                    (f"MultigridTest2Form (H(div)) cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
                                     f"Hiptmair({args.smoother}, {args.smoother}) pre/post, dense coarse solve, b=2"),
+                       "interpolators": (dar["amge"]["what"] if darcy and "amge" in dar else "nested geometric (generator)"),
                        "levels": [{"n": s[0], "nnz": s[1]} for s in level_shapes],
                        "hipgraph": not args.no_graph and single, "parallelism": f"row-block domain decomposition x{world}"},
             "device_ms_per_step": round(ms_dev, 5),
@@ -462,6 +532,33 @@ def main():
         })
         if solve is not None:
             out["solve"] = solve
+        if darcy and "amge" in dar:
+            rec = dar["amge"]
+            lv0, parts = rec.pop("level0"), rec.pop("parts")
+            n_ae = sum(l["agglomerates"] for l in rec["levels"])
+            rec["agglomerates_per_s"] = round(n_ae / rec["coarsen_total_s"], 1)
+            rec["kernel_ms_total"] = round(sum(sum(l["kernel_ms"].values()) for l in rec["levels"]), 3)
+            if not args.no_cpu_baseline:
+                # CPU port of the same coarsening (oracle/amge.py: numpy, entity by entity) on a bounded sample: the levels
+                # with at most 4000 agglomerates, reached with the oracle's own coarse levels being skipped -- the device's
+                # levels are equal to 1e-10 (tests/test_gpu_amge.py), so the sample starts from them
+                from oracle import amge as oa
+                from parelag_amd import amge as pa
+                cur, done, t_cpu = lv0, 0, 0.0
+                for part in parts:
+                    n_here = int(part.max()) + 1
+                    if n_here <= 4000 and t_cpu < 3 * args.cpu_seconds:
+                        t1 = time.perf_counter()
+                        res = oa.coarsen(cur, part)
+                        t_cpu += time.perf_counter() - t1
+                        done += n_here
+                    else:
+                        res = pa.coarsen(cur, part)
+                    cur = res["coarse"]
+                if done:
+                    rec["cpu_port"] = {"agglomerates_per_s": round(done / t_cpu, 1), "cores": 1, "kind": "port",
+                                       "sample": f"{done} agglomerates (the levels with <= 4000 of them) in {t_cpu:.2f} s, oracle/amge.py"}
+            out["amge"] = rec
         print(json.dumps(out))
 
 
