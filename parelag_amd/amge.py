@@ -81,11 +81,11 @@ def coarsen_topology(lv: AmgeLevel, part: np.ndarray) -> dict:
     k3 = np.where(is_bdr, attr, 0)
     k4 = np.where(is_bdr & (attr > 0) & have_attr, (s_lo > 0).astype(np.int64), 0)
     k2 = np.where(is_bdr, -1, a_hi)
-    keys = np.stack([a_lo, k2, k3, k4], axis=1)
-    uk, inv = np.unique(keys, axis=0, return_inverse=True)
+    nattr = int(lv.facet_attr.max()) + 1
+    keys = ((a_lo * (nAE + 1) + (k2 + 1)) * nattr + k3) * 2 + k4          # one scalar per facet (< 2^63 for any realistic size)
+    uk, first, inv = np.unique(keys, return_index=True, return_inverse=True)
     inv = inv.reshape(-1)
-    lowest = np.full(uk.shape[0], np.iinfo(np.int64).max)
-    np.minimum.at(lowest, inv, fid)
+    lowest = fid[first]                                                    # fid ascends, so the first occurrence is the lowest facet
     rank = np.empty(uk.shape[0], dtype=np.int64)
     rank[np.argsort(lowest)] = np.arange(uk.shape[0])
     mis_of = np.full(lv.nF, -1, dtype=np.int64)

@@ -1,7 +1,8 @@
 """Where the time of one AMGe coarsening goes (host tables vs device kernels).  python tools/amge_time.py tet 3 | hex 60 220 85"""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from parelag_amd import amge, meshgen
 from parelag_amd.amge_level import level_from_tets, level_from_hex, box_partition
 
