@@ -228,8 +228,11 @@ def main():
     if darcy:
         kinv = None
         if args.amge or args.hex:
-            if not single:
-                raise SystemExit("--amge / --hex: single-GPU only in this round (the coarsening runs per rank, shared agglomerated facets are not exchanged yet)")
+            if not single and args.hex:
+                raise SystemExit("--hex: single-GPU only in this round (the row-block partitioner works on the cube456 meshes)")
+            # with several ranks every rank runs the (cheap) coarsening of the whole mesh on its own GPU and the distributed
+            # builder partitions the result like the generator's interpolators; a per-rank coarsening with shared
+            # agglomerated facets (AE_TrueAE.IsShared, DeRhamSequence.cpp:1820) is not built yet
             dar = amge_darcy_problem(args, spe10, np)
             kinv = dar["kinv"]
         else:

@@ -2,7 +2,7 @@
 """Golden vectors of the AMGe coarsening generated with the CPU oracle (nothing can be captured from the
 reference: MFEM/LAPACK wrappers are absent).  Case: 5 x 4 x 3 hex grid, cells 20 x 10 x 2, log-normal coefficient (seed
 below), boxes of 3 x 2 x 2 cells, then one more coarsening to 1 x 2 x 2 boxes.  Columns that come out of an SVD are stored
-with the sign that makes their largest entry positive.
+with the sign that makes their first significant entry positive.
 
     python tools/make_amge_golden.py            # writes tests/golden/oracle_amge_hex.npz
 """
@@ -17,13 +17,15 @@ SEED = 20240611
 
 
 def canonical_signs(P):
-    """+-1 per column: sign of the entry of largest magnitude (first one on ties)."""
+    """+-1 per column: sign of the first entry (in row order) whose magnitude is at least half the column's largest -- robust
+    against rounding when two entries have (nearly) equal magnitude."""
     P = sp.csc_matrix(P)
     s = np.ones(P.shape[1])
     for j in range(P.shape[1]):
         col = P.data[P.indptr[j]:P.indptr[j + 1]]
         if col.size:
-            s[j] = 1.0 if col[np.argmax(np.abs(col))] >= 0 else -1.0
+            big = np.nonzero(np.abs(col) >= 0.5 * np.max(np.abs(col)))[0][0]
+            s[j] = 1.0 if col[big] >= 0 else -1.0
     return s
 
 
