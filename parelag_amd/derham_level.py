@@ -1,0 +1,207 @@
+"""Level data of a whole 3-D de Rham sequence (forms ``jstart .. 3``) as ``DeRhamSequence::Coarsen`` consumes and produces
+it (``src/amge/DeRhamSequence.hpp:655-727``): the agglomerated topology's boundary operators ``B_[0..2]``
+(``src/topology/Topology.hpp``), one dof handler per form (interior dofs per entity, numbered peak dofs first, then ridge,
+facet and element dofs: ``DofHandlerALG::computeOffset``, ``src/amge/DofHandler.cpp:1058-1186``), the mass matrices
+``M_(form, codim)`` entity by entity in repeated-dof space, the derivatives ``D_[j]``, targets and PV base vectors.
+
+``AmgeLevel`` (``amge_level.py``) is the two-form special case the device path consumes today; ``SeqLevel`` is the general
+container used by the oracle of the full ``Coarsen`` (``oracle/derham.py``).  The builder at the bottom manufactures the
+lowest-order finest level on the generator's tets (MFEM is not available: it replaces ``DeRhamSequence3D_FE``,
+``src/amge/DeRhamSequenceFE.cpp:633-722``) with the conventions of ``amge_level.level_from_tets`` (Whitney forms: a dof is the
+integral of the form over its entity; boundary facets oriented outward).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import scipy.sparse as sp
+
+from .amge_level import _unit_cube_attr, ptr_from_counts
+
+NFORMS = 4
+
+
+def bool_mult(a_ptr, a_idx, b_ptr, b_idx):
+    """``BoolMult`` / ``mfem::Mult`` pattern product with the columns of a row in first-touch order."""
+    out_ptr, out_idx = [0], []
+    for r in range(len(a_ptr) - 1):
+        seen = {}
+        for k in a_idx[a_ptr[r]:a_ptr[r + 1]]:
+            for c in b_idx[b_ptr[k]:b_ptr[k + 1]]:
+                seen.setdefault(int(c), None)
+        out_idx.extend(seen.keys())
+        out_ptr.append(len(out_idx))
+    return np.array(out_ptr, dtype=np.int64), np.array(out_idx, dtype=np.int64)
+
+
+@dataclass
+class SeqLevel:
+    n: list                      # entity counts by codimension: elements, facets, ridges, peaks
+    B: list                      # B[c] = (ptr, idx, sgn): codim c -> c+1, c = 0, 1, 2 (row order is meaningful)
+    facet_attr: np.ndarray
+    jstart: int
+    idof: list                   # idof[j][c] = (n[c]+1,) offsets of the interior dofs of form j on codim-c entities (c <= 3-j)
+    M: list                      # M[j][c] = (ptr, vals): packed row-major blocks over entity_dof(j, c, e)
+    D: list                      # D[j]: csr ndof[j+1] x ndof[j], j = jstart .. 2
+    T: list                      # T[j]: (ndof[j], nT_j)
+    pv: list                     # pv[j]: (ndof[j],) PV base values (times the entity's orientation in its agglomerate)
+    const3: np.ndarray
+    meta: dict = field(default_factory=dict)
+    _conn: dict = field(default_factory=dict)
+    _edof: dict = field(default_factory=dict)
+
+    def cb(self, j):
+        return 3 - j
+
+    def base(self, j, c):
+        """First dof of form j living on codim-c entities (higher codimensions are numbered first)."""
+        return int(sum(self.idof[j][c2][-1] for c2 in range(self.cb(j), c, -1)))
+
+    def ndof(self, j):
+        return int(sum(self.idof[j][c][-1] for c in range(self.cb(j) + 1)))
+
+    def conn(self, c, c2):
+        """``GetConnectivity(c, c2)`` (``src/topology/Topology.cpp:240-268``)."""
+        key = (c, c2)
+        if key not in self._conn:
+            if c2 == c + 1:
+                self._conn[key] = (self.B[c][0], self.B[c][1])
+            elif (c, c2) == (0, 3):
+                p, i = self.conn(0, 2)
+                self._conn[key] = bool_mult(p, i, self.B[2][0], self.B[2][1])
+            else:
+                self._conn[key] = bool_mult(self.B[c][0], self.B[c][1], self.B[c + 1][0], self.B[c + 1][1])
+        return self._conn[key]
+
+    def interior_dofs(self, j, c, e):
+        return self.base(j, c) + np.arange(self.idof[j][c][e], self.idof[j][c][e + 1])
+
+    def entity_dof(self, j, c):
+        """``entity_dof[c]`` of form j as a list of arrays: dofs of the entity's peaks, ridges, facets (connectivity order),
+        then its interior dofs (``DofHandlerALG::build*DofTable``, ``src/amge/DofHandler.cpp:1188-1461``)."""
+        key = (j, c)
+        if key not in self._edof:
+            rows = []
+            cb = self.cb(j)
+            subs = [(c2, self.conn(c, c2)) for c2 in range(3, c, -1) if c2 <= cb]
+            bases = {c2: self.base(j, c2) for c2 in range(cb + 1)}
+            for e in range(self.n[c]):
+                parts = []
+                for c2, (p, i) in subs:
+                    ip = self.idof[j][c2]
+                    for s in i[p[e]:p[e + 1]]:
+                        parts.append(bases[c2] + np.arange(ip[s], ip[s + 1]))
+                parts.append(bases[c] + np.arange(self.idof[j][c][e], self.idof[j][c][e + 1]))
+                rows.append(np.concatenate(parts).astype(np.int64))
+            self._edof[key] = rows
+        return self._edof[key]
+
+    def block(self, j, c, e):
+        ptr, val = self.M[j][c]
+        v = val[ptr[e]:ptr[e + 1]]
+        k = int(round(np.sqrt(v.size)))
+        return v.reshape(k, k)
+
+    def mass(self, j, c=0):
+        """Assembled mass of form j from the codim-c blocks (``ComputeMassOperator`` for c = 0)."""
+        ed = self.entity_dof(j, c)
+        r, cc, v = [], [], []
+        for e in range(self.n[c]):
+            d = ed[e]
+            r.append(np.repeat(d, d.size)); cc.append(np.tile(d, d.size)); v.append(self.block(j, c, e).reshape(-1))
+        M = sp.csr_matrix((np.concatenate(v), (np.concatenate(r), np.concatenate(cc))), shape=(self.ndof(j), self.ndof(j)))
+        M.sum_duplicates(); M.sort_indices()
+        return M
+
+
+# ---- finest level on tets --------------------------------------------------------------------------------------------------
+
+def _reorder_blocks(loc, have, want):
+    """``loc`` (E,k,k) is indexed like the id lists ``have`` (E,k); return it indexed like ``want`` (E,k) (same ids per row)."""
+    oh = np.argsort(have, axis=1); ow = np.argsort(want, axis=1)
+    perm = np.empty_like(oh)
+    np.put_along_axis(perm, ow, oh, axis=1)          # want[:, q] == have[:, perm[:, q]]
+    assert np.array_equal(np.take_along_axis(have, perm, axis=1), want)
+    return loc[np.arange(loc.shape[0])[:, None, None], perm[:, :, None], perm[:, None, :]]
+
+
+def seq_level_from_tets(mesh, jstart: int = 0, kinv: np.ndarray | None = None, bdr_attr: bool = True) -> SeqLevel:
+    from .meshgen import _LE
+    mesh.build_faces()
+    T, F, E, V = mesh.nt, mesh.nf, mesh.ne, mesh.nv
+    x = mesh.vertices[mesh.stets]
+    g, vol, _sg = mesh._grads()
+    sig = mesh._face_sign()
+    tf = mesh.tet_faces
+    is_bdr = np.bincount(tf.reshape(-1), minlength=F) == 1
+    o = np.ones(F)
+    bslot = is_bdr[tf]
+    o[tf[bslot]] = sig[bslot]
+    s = sig * o[tf]
+    S3 = (sig * np.array([1.0, -1.0, 1.0, -1.0])[None, :])[:, 0].copy()
+    # topology
+    B0 = (4 * np.arange(T + 1, dtype=np.int64), tf.reshape(-1).astype(np.int64), s.reshape(-1).copy())
+    f = mesh.faces
+    e_bc, e_ac, e_ab = mesh._edge_ids(f[:, [1, 2]]), mesh._edge_ids(f[:, [0, 2]]), mesh._edge_ids(f[:, [0, 1]])
+    fe = np.stack([e_bc, e_ac, e_ab], 1).astype(np.int64)
+    B1 = (3 * np.arange(F + 1, dtype=np.int64), fe.reshape(-1), (np.array([1.0, -1.0, 1.0])[None, :] * o[:, None]).reshape(-1))
+    B2 = (2 * np.arange(E + 1, dtype=np.int64), mesh.edges.reshape(-1).astype(np.int64), np.tile(np.array([-1.0, 1.0]), E))
+    fv = mesh.vertices[f]
+    nrm = 0.5 * np.cross(fv[:, 1] - fv[:, 0], fv[:, 2] - fv[:, 0])
+    area = np.linalg.norm(nrm, axis=1)
+    ev = mesh.vertices[mesh.edges[:, 1]] - mesh.vertices[mesh.edges[:, 0]]
+    elen = np.linalg.norm(ev, axis=1)
+    attr = _unit_cube_attr(fv.mean(axis=1), is_bdr) if bdr_attr else np.zeros(F, np.int32)
+    ones = lambda k: np.arange(k + 1, dtype=np.int64)
+    zeros = lambda k: np.zeros(k + 1, dtype=np.int64)
+    n = [T, F, E, V]
+    idof = [[zeros(T), zeros(F), zeros(E), ones(V)], [zeros(T), zeros(F), ones(E)], [zeros(T), ones(F)], [ones(T)]]
+    lv = SeqLevel(n=n, B=[B0, B1, B2], facet_attr=attr, jstart=jstart, idof=idof, M=[None] * 4, D=[None] * 3, T=[None] * 4, pv=[None] * 4,
+                  const3=vol.copy(), meta=dict(S2=o, S3=S3, kind="tet"))
+    I4 = (np.ones((4, 4)) + np.eye(4)) / 20.0
+    # ---- form 3 / 2 (as amge_level.level_from_tets)
+    d = x[:, None, :, :] - x[:, :, None, :]
+    loc2 = np.einsum("ij,tkid,tljd->tkl", I4, d, d) / (9.0 * vol)[:, None, None] * (s[:, :, None] * s[:, None, :])
+    if kinv is not None:
+        loc2 = loc2 * np.asarray(kinv, dtype=np.float64)[:, None, None]
+    lv.M[3] = [(ones(T), 1.0 / vol)]
+    lv.M[2] = [(16 * ones(T), np.ascontiguousarray(loc2).reshape(-1)), (ones(F), 1.0 / area)]
+    lv.D[2] = sp.csr_matrix((s.reshape(-1), tf.reshape(-1).astype(np.int64), B0[0]), shape=(T, F))
+    lv.T[3] = vol[:, None].copy(); lv.pv[3] = vol.copy()
+    lv.T[2] = nrm * o[:, None]; lv.pv[2] = area.copy()
+    if jstart <= 1:
+        # ---- form 1: Whitney 1-forms, dof = tangential integral along the edge (low -> high vertex)
+        G = np.einsum("tid,tjd->tij", g, g)
+        i_, j_ = _LE[:, 0], _LE[:, 1]
+        ik = I4[np.ix_(i_, i_)]; il = I4[np.ix_(i_, j_)]; jk = I4[np.ix_(j_, i_)]; jl = I4[np.ix_(j_, j_)]
+        loc1 = (ik[None] * G[:, j_][:, :, j_] - il[None] * G[:, j_][:, :, i_] - jk[None] * G[:, i_][:, :, j_] + jl[None] * G[:, i_][:, :, i_]) * vol[:, None, None]
+        p02, i02 = lv.conn(0, 2)
+        assert np.all(np.diff(p02) == 6)
+        loc1 = _reorder_blocks(loc1, mesh.tet_edges, i02.reshape(T, 6))
+        # facet mass of the tangential trace: 2-D Whitney 1-forms on the triangle (ND_3D_FacetMassIntegrator)
+        a, b, c = fv[:, 0], fv[:, 1], fv[:, 2]
+        nn = np.cross(b - a, c - a); n2 = np.einsum("fd,fd->f", nn, nn)
+        gl = np.stack([np.cross(nn, c - b), np.cross(nn, a - c), np.cross(nn, b - a)], axis=1) / n2[:, None, None]   # surface grad lambda_i
+        Gf = np.einsum("fid,fjd->fij", gl, gl)
+        I3 = (np.ones((3, 3)) + np.eye(3)) / 12.0
+        le = np.array([[1, 2], [0, 2], [0, 1]])          # local edges in B1 row order: bc, ac, ab
+        fi, fj = le[:, 0], le[:, 1]
+        ik = I3[np.ix_(fi, fi)]; il = I3[np.ix_(fi, fj)]; jk = I3[np.ix_(fj, fi)]; jl = I3[np.ix_(fj, fj)]
+        loc1f = (ik[None] * Gf[:, fj][:, :, fj] - il[None] * Gf[:, fj][:, :, fi] - jk[None] * Gf[:, fi][:, :, fj] + jl[None] * Gf[:, fi][:, :, fi]) * area[:, None, None]
+        lv.M[1] = [(36 * ones(T), np.ascontiguousarray(loc1).reshape(-1)), (9 * ones(F), np.ascontiguousarray(loc1f).reshape(-1)), (ones(E), 1.0 / elen)]
+        lv.D[1] = sp.csr_matrix((B1[2], B1[1], B1[0]), shape=(F, E))
+        lv.T[1] = ev.copy(); lv.pv[1] = elen.copy()
+    if jstart <= 0:
+        p03, i03 = lv.conn(0, 3)
+        assert np.all(np.diff(p03) == 4)
+        loc0 = np.broadcast_to(I4[None], (T, 4, 4)) * vol[:, None, None]
+        loc0 = _reorder_blocks(loc0, mesh.stets, i03.reshape(T, 4))      # (symmetric under permutation, kept for clarity)
+        I3 = (np.ones((3, 3)) + np.eye(3)) / 12.0
+        loc0f = np.broadcast_to(I3[None], (F, 3, 3)) * area[:, None, None]
+        loc0r = np.broadcast_to(np.array([[2.0, 1.0], [1.0, 2.0]])[None] / 6.0, (E, 2, 2)) * elen[:, None, None]
+        lv.M[0] = [(16 * ones(T), np.ascontiguousarray(loc0).reshape(-1)), (9 * ones(F), np.ascontiguousarray(loc0f).reshape(-1)),
+                   (4 * ones(E), np.ascontiguousarray(loc0r).reshape(-1)), (ones(V), np.ones(V))]
+        lv.D[0] = sp.csr_matrix((B2[2], B2[1], B2[0]), shape=(E, V))
+        lv.T[0] = np.concatenate([np.ones((V, 1)), mesh.vertices], axis=1); lv.pv[0] = np.ones(V)
+    return lv
