@@ -477,18 +477,28 @@ ELAG_HIP_API int elag_hip_coarsen_traces(const elag_hip_coarsen_traces_in *in, c
 
 typedef struct {
     int n_ent, nT;
+    int mode;                     /* 0: hFacetExtension (FacetSaddlePoint, PV multiplier row);
+                                     1: hRidgePeakExtension (:2629-3055; RidgePeakSaddlePoint [M B^T; B -C],
+                                        ParELAG_SaddlePointSolver.cpp:150-189, -C = -(D^T W D) of the next form, GetMinusC) */
+    int null_dofs;                /* build null-space dofs from the targets (0 for the "peak" stage, :2924) */
     double svd_tol;               /* absolute (DeRhamSequence.cpp:2498)                          */
     double smallest_entry;        /* SmallestEntry_ (:2403)                                      */
     const int *nu, *ni, *np;      /* u dofs (interior first), interior u dofs, p dofs per entity */
+    const int *npi, *nq;          /* mode 1: interior p dofs (first in the p numbering), dofs of form j+2 */
     const int *next, *nrt;        /* coarse dofs on the boundary, RangeT bubbles per entity      */
     elag_hip_dense_assembly mass_u, mass_p;
+    elag_hip_dense_assembly mass_q; /* mode 1: mass of form j+2 on the entity                    */
     const int64_t *d_ptr;         /* local derivative D (np x nu) as triplets d_ptr[e]..         */
     const int *d_row, *d_col;
     const double *d_val;
+    const int64_t *d2_ptr;        /* mode 1: local derivative of form j+1 (nq x np)              */
+    const int *d2_row, *d2_col;
+    const double *d2_val;
     const double *pv_p;           /* packed np[e]: P_3(fine p dofs, PV dof of the agglomerate)   */
     const double *R_b;            /* packed col-major (nu-ni) x next: traces on the boundary     */
-    const double *cP;             /* packed col-major np x nrt: non-PV coarse form-3 functions   */
+    const double *cP;             /* packed col-major npi x nrt: null-space coarse functions of form j+1 interior to the entity */
     const double *T;              /* packed col-major nu x nT: targets                           */
+    const double *PDc;            /* mode 1: packed col-major np x next: (P_{j+1} D_c)(p dofs, coarse boundary dofs), :2696-2697 */
 } elag_hip_coarsen_extension_in;
 typedef struct {
     int *n_null;                  /* n_ent                                                       */

@@ -127,11 +127,13 @@ class _TracesOut(C.Structure):
 
 
 class _ExtIn(C.Structure):
-    _fields_ = [("n_ent", C.c_int), ("nT", C.c_int), ("svd_tol", C.c_double), ("smallest_entry", C.c_double),
-                ("nu", C.c_void_p), ("ni", C.c_void_p), ("np", C.c_void_p), ("next", C.c_void_p), ("nrt", C.c_void_p),
-                ("mass_u", _Assembly), ("mass_p", _Assembly),
+    _fields_ = [("n_ent", C.c_int), ("nT", C.c_int), ("mode", C.c_int), ("null_dofs", C.c_int), ("svd_tol", C.c_double), ("smallest_entry", C.c_double),
+                ("nu", C.c_void_p), ("ni", C.c_void_p), ("np", C.c_void_p), ("npi", C.c_void_p), ("nq", C.c_void_p),
+                ("next", C.c_void_p), ("nrt", C.c_void_p),
+                ("mass_u", _Assembly), ("mass_p", _Assembly), ("mass_q", _Assembly),
                 ("d_ptr", C.c_void_p), ("d_row", C.c_void_p), ("d_col", C.c_void_p), ("d_val", C.c_void_p),
-                ("pv_p", C.c_void_p), ("R_b", C.c_void_p), ("cP", C.c_void_p), ("T", C.c_void_p)]
+                ("d2_ptr", C.c_void_p), ("d2_row", C.c_void_p), ("d2_col", C.c_void_p), ("d2_val", C.c_void_p),
+                ("pv_p", C.c_void_p), ("R_b", C.c_void_p), ("cP", C.c_void_p), ("T", C.c_void_p), ("PDc", C.c_void_p)]
 
 
 class _ExtOut(C.Structure):
@@ -326,11 +328,11 @@ def coarsen(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_ent
     csrc, owncp = expand_ranges(ae_d3_ptr[:-1] * k3 + np_, np_ * nrt)
     cP = o_p3[csrc]
     keep3 = _Keep()
-    ein = _ExtIn(nAE, nT2, svd_tol, smallest_entry, keep3.i32(nu), keep3.i32(ni), keep3.i32(np_), keep3.i32(nxt), keep3.i32(nrt),
+    ein = _ExtIn(nAE, nT2, 0, 1, svd_tol, smallest_entry, keep3.i32(nu), keep3.i32(ni), keep3.i32(np_), None, None, keep3.i32(nxt), keep3.i32(nrt),
                  _assembly(keep3, ae_of_item, nAE, lv.M2e_ptr[els], n2e[els], loc2, lv.M2e),
-                 _assembly(keep3, ae_of_item, nAE, lv.M3e_ptr[els], n3e[els], loc3, lv.M3e),
-                 keep3.i64(d_ptr), keep3.i32(d_row), keep3.i32(d_col), keep3.f64(D.data[dq]),
-                 keep3.f64(pv_p), keep3.f64(R_b), keep3.f64(cP), keep3.f64(_pack_cols(lv.T2, ae_dofs2, ae_d2_ptr)))
+                 _assembly(keep3, ae_of_item, nAE, lv.M3e_ptr[els], n3e[els], loc3, lv.M3e), _Assembly(),
+                 keep3.i64(d_ptr), keep3.i32(d_row), keep3.i32(d_col), keep3.f64(D.data[dq]), None, None, None, None,
+                 keep3.f64(pv_p), keep3.f64(R_b), keep3.f64(cP), keep3.f64(_pack_cols(lv.T2, ae_dofs2, ae_d2_ptr)), None)
     kf = nrt + nT2
     ncm = nxt + nrt + nT2
     o_nn = np.zeros(nAE, np.int32)
@@ -464,6 +466,8 @@ def _first_dof_indicator(ptr, n):
 
 
 def _spmm_device(A: sp.csr_matrix, X: np.ndarray) -> np.ndarray:
+    if A.nnz == 0 or X.shape[1] == 0:
+        return np.zeros((A.shape[0], X.shape[1]))
     from . import linalg as la
     dA = la.ParallelCSRMatrix.from_scipy(A.tocsr())
     out = np.empty((A.shape[0], X.shape[1]))

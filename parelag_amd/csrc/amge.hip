@@ -320,16 +320,20 @@ __global__ void coarsen_traces_kernel(TracesArgs a)
 }
 
 struct ExtArgs {
-    int n_ent, nT;
+    int n_ent, nT, mode;          // mode 0: FacetSaddlePoint (PV multiplier row), 1: RidgePeakSaddlePoint ([M B^T; B -C])
+    int null_dofs;                // 0: no null-space dofs are built (the "peak" stage of the 0-forms)
     double svd_tol, smallest_entry;
-    const int *nu, *ni, *np, *next, *nrt;
-    AsmDev mass_u, mass_p;
+    const int *nu, *ni, *np, *npi, *nq, *next, *nrt;
+    AsmDev mass_u, mass_p, mass_q;
     const int64_t *d_ptr;
     const int *d_row, *d_col;
     const double *d_val;
-    const double *pv_p, *R_b, *cP, *T;
+    const int64_t *d2_ptr;
+    const int *d2_row, *d2_col;
+    const double *d2_val;
+    const double *pv_p, *R_b, *cP, *T, *PDc;
     // packed input / output offsets per entity
-    const int64_t *off_p, *off_Rb, *off_cP, *off_T, *off_ext, *off_dc, *off_rt, *off_nul, *off_fun, *off_cm;
+    const int64_t *off_p, *off_Rb, *off_cP, *off_T, *off_PDc, *off_ext, *off_dc, *off_rt, *off_nul, *off_fun, *off_cm;
     int *n_null;
     double *ext, *dc, *rt, *nul, *functional, *cmass;
     const int64_t *ws_off;
@@ -342,74 +346,105 @@ __global__ void coarsen_extension_kernel(ExtArgs a)
     extern __shared__ double dyn[];
     __shared__ Shared sh;
     const int e = blockIdx.x;
-    const int nu = a.nu[e], ni = a.ni[e], np = a.np[e], next = a.next[e], nrt = a.nrt[e];
+    const int nu = a.nu[e], ni = a.ni[e], np = a.np[e], npi = a.npi[e], next = a.next[e], nrt = a.nrt[e];
+    const int nq = a.mode ? a.nq[e] : 0;
     const int nb = nu - ni;
-    const int nTe = (ni > nrt && a.nT > 0) ? a.nT : 0;          // :2451
-    const int n = ni + np + 1, nrhs = next + nrt + nTe, m = n + nrhs;
+    const int nTe = (a.null_dofs && ni > nrt && a.nT > 0) ? a.nT : 0;          // :2451, :2930
+    const int n = ni + npi + (a.mode ? 0 : 1), nrhs = next + nrt + nTe, m = n + nrhs;
     const int ncolmax = next + nrt + a.nT, kfmax = nrt + a.nT;
+    const bool solve = a.mode == 0 || ni > 0;                                   // :2778 guards the ridge / peak solves only
     double *ws = a.ws_off[e] >= 0 ? a.gws + a.ws_off[e] : dyn;
     double *Maa = ws;                               // nu x nu
     double *W = Maa + (size_t)nu * nu;              // np x np
     double *Dl = W + (size_t)np * np;               // np x nu
-    double *B = Dl + (size_t)np * nu;               // np x nu
-    double *tloc = B + (size_t)np * nu;             // np
-    double *K = tloc + np;                          // n x m
-    double *ti = K + (size_t)n * m;                 // ni x nT
+    double *B = Dl + (size_t)np * nu;               // npi x nu
+    double *tloc = B + (size_t)npi * nu;            // np
+    double *K = tloc + np;                          // n x (n + next + nrt + nT)
+    double *ti = K + (size_t)n * (n + next + nrt + a.nT);   // ni x nT
     double *basis = ti + (size_t)ni * a.nT;         // nu x ncolmax
     double *MB = basis + (size_t)nu * ncolmax;      // nu x ncolmax
     double *aug = MB + (size_t)nu * ncolmax;        // kfmax x (kfmax + ni)
     double *Pi = aug + (size_t)kfmax * (kfmax + ni); // 2 x (ni x kfmax): interior bubbles and M_ii times them
+    double *W2 = Pi + 2 * (size_t)ni * kfmax;       // nq x nq        (mode 1)
+    double *D2l = W2 + (size_t)nq * nq;             // nq x np
+    double *WD2 = D2l + (size_t)nq * np;            // nq x np
 
     const double *pv_p = a.pv_p + a.off_p[e];
     const double *R_b = a.R_b + a.off_Rb[e];
     const double *cP = a.cP + a.off_cP[e];
     const double *T = a.T + a.off_T[e];
+    const double *PDc = a.mode ? a.PDc + a.off_PDc[e] : nullptr;
 
     assemble_blocks(Maa, nu, a.mass_u, e);
     assemble_blocks(W, np, a.mass_p, e);
     zero_fill(Dl, np * nu);
+    if (a.mode) {
+        assemble_blocks(W2, nq, a.mass_q, e);
+        zero_fill(D2l, nq * np);
+    }
     __syncthreads();
     for (int64_t t = a.d_ptr[e] + threadIdx.x; t < a.d_ptr[e + 1]; t += blockDim.x) Dl[a.d_row[t] * nu + a.d_col[t]] = a.d_val[t];
+    if (a.mode)
+        for (int64_t t = a.d2_ptr[e] + threadIdx.x; t < a.d2_ptr[e + 1]; t += blockDim.x) D2l[a.d2_row[t] * np + a.d2_col[t]] = a.d2_val[t];
     __syncthreads();
-    // B_d = W_d D_d (:2258), tloc = W pv (SaddlePointSolver.cpp:104-108)
-    for (int t = threadIdx.x; t < np * nu; t += blockDim.x) {
+    // B_d = W_d D_d (:2258, :2690), rows of the interior p dofs; tloc = W pv (SaddlePointSolver.cpp:104-108)
+    for (int t = threadIdx.x; t < npi * nu; t += blockDim.x) {
         const int p = t / nu, j = t - p * nu;
         double s = 0.0;
         for (int q = 0; q < np; q++) s += W[p * np + q] * Dl[q * nu + j];
         B[t] = s;
     }
-    for (int p = threadIdx.x; p < np; p += blockDim.x) {
-        double s = 0.0;
-        for (int q = 0; q < np; q++) s += W[p * np + q] * pv_p[q];
-        tloc[p] = s;
-    }
+    if (a.mode == 0)
+        for (int p = threadIdx.x; p < np; p += blockDim.x) {
+            double s = 0.0;
+            for (int q = 0; q < np; q++) s += W[p * np + q] * pv_p[q];
+            tloc[p] = s;
+        }
+    else
+        for (int t = threadIdx.x; t < nq * np; t += blockDim.x) {             // W2 D2 (GetMinusC, :2583-2606)
+            const int q = t / np, p = t - q * np;
+            double s = 0.0;
+            for (int r = 0; r < nq; r++) s += W2[q * nq + r] * D2l[r * np + p];
+            WD2[t] = s;
+        }
     zero_fill(K, n * m);
     __syncthreads();
-    // [ M_ii  B_i^T  0 ; B_i  0  t ; 0  t^T  0 ]
     for (int t = threadIdx.x; t < ni * ni; t += blockDim.x) { const int i = t / ni, j = t - i * ni; K[i * m + j] = Maa[i * nu + j]; }
-    for (int t = threadIdx.x; t < np * ni; t += blockDim.x) {
+    for (int t = threadIdx.x; t < npi * ni; t += blockDim.x) {
         const int p = t / ni, j = t - p * ni;
         const double v = B[p * nu + j];
         K[(ni + p) * m + j] = v;
         K[j * m + ni + p] = v;
     }
-    for (int p = threadIdx.x; p < np; p += blockDim.x) { K[(n - 1) * m + ni + p] = tloc[p]; K[(ni + p) * m + n - 1] = tloc[p]; }
-    // right-hand sides: trace extensions (:2386-2390), RangeT bubbles (:2428-2431), target extensions (:2469-2476)
-    for (int t = threadIdx.x; t < (ni + np) * next; t += blockDim.x) {
-        const int c = t / (ni + np), r = t - c * (ni + np);
+    if (a.mode == 0) {
+        for (int p = threadIdx.x; p < np; p += blockDim.x) { K[(n - 1) * m + ni + p] = tloc[p]; K[(ni + p) * m + n - 1] = tloc[p]; }
+    } else {
+        for (int t = threadIdx.x; t < npi * npi; t += blockDim.x) {           // -C = -(D2^T W2 D2), interior block
+            const int p = t / npi, p2 = t - p * npi;
+            double s = 0.0;
+            for (int q = 0; q < nq; q++) s += D2l[q * np + p] * WD2[q * np + p2];
+            K[(ni + p) * m + ni + p2] = -s;
+        }
+    }
+    // right-hand sides: trace extensions (:2386-2390, :2812-2823), RangeT bubbles (:2428-2431), target extensions (:2469-2476)
+    for (int t = threadIdx.x; t < (ni + npi) * next; t += blockDim.x) {
+        const int c = t / (ni + npi), r = t - c * (ni + npi);
         const double *row = r < ni ? Maa + (size_t)r * nu + ni : B + (size_t)(r - ni) * nu + ni;
         double s = 0.0;
         for (int b = 0; b < nb; b++) s += row[b] * R_b[c * nb + b];
-        K[r * m + n + c] = -s;
+        s = -s;
+        if (a.mode && r >= ni)
+            for (int q = 0; q < np; q++) s += W[(r - ni) * np + q] * PDc[c * np + q];
+        K[r * m + n + c] = s;
     }
-    for (int t = threadIdx.x; t < np * nrt; t += blockDim.x) {
-        const int c = t / np, p = t - c * np;
+    for (int t = threadIdx.x; t < npi * nrt; t += blockDim.x) {
+        const int c = t / npi, p = t - c * npi;
         double s = 0.0;
-        for (int q = 0; q < np; q++) s += W[p * np + q] * cP[c * np + q];
+        for (int q = 0; q < npi; q++) s += W[p * np + q] * cP[c * npi + q];
         K[(ni + p) * m + n + next + c] = s;
     }
-    for (int t = threadIdx.x; t < (ni + np) * nTe; t += blockDim.x) {
-        const int c = t / (ni + np), r = t - c * (ni + np);
+    for (int t = threadIdx.x; t < (ni + npi) * nTe; t += blockDim.x) {
+        const int c = t / (ni + npi), r = t - c * (ni + npi);
         double s = 0.0;
         if (r < ni) {
             for (int b = 0; b < nb; b++) s -= Maa[r * nu + ni + b] * T[c * nu + ni + b];
@@ -419,7 +454,7 @@ __global__ void coarsen_extension_kernel(ExtArgs a)
         K[r * m + n + next + nrt + c] = s;
     }
     __syncthreads();
-    int bad = gauss_solve(K, n, m, sh.piv);
+    int bad = solve ? gauss_solve(K, n, m, sh.piv) : 0;
     if (bad) {
         if (threadIdx.x == 0) { atomicAdd(a.singular, 1); a.n_null[e] = 0; }
         return;
@@ -428,8 +463,12 @@ __global__ void coarsen_extension_kernel(ExtArgs a)
     double *oext = a.ext + a.off_ext[e];
     for (int t = threadIdx.x; t < ni * next; t += blockDim.x) { const int c = t / ni, i = t - c * ni; oext[t] = K[i * m + n + c]; }
     for (int c = threadIdx.x; c < next; c += blockDim.x) {
-        const double l = K[(n - 1) * m + n + c];
-        a.dc[a.off_dc[e] + c] = fabs(l) > a.smallest_entry ? -l : 0.0;
+        double v = 0.0;
+        if (a.mode == 0) {
+            const double l = K[(n - 1) * m + n + c];
+            v = fabs(l) > a.smallest_entry ? -l : 0.0;
+        }
+        a.dc[a.off_dc[e] + c] = v;
     }
     // (4) RangeT bubbles
     double *ort = a.rt + a.off_rt[e];
@@ -484,8 +523,7 @@ __global__ void coarsen_extension_kernel(ExtArgs a)
     double *ofun = a.functional + a.off_fun[e];
     for (int t = threadIdx.x; t < kfmax * ni; t += blockDim.x) ofun[t] = 0.0;
     const int kf = nrt + knull;
-    if (kf > 0) {
-        // interior part of the bubble columns, contiguous with leading dimension ni
+    if (kf > 0 && ni > 0) {
         double *PMi = Pi + (size_t)ni * kf;
         for (int t = threadIdx.x; t < ni * kf; t += blockDim.x) { const int c = t / ni, i = t - c * ni; Pi[t] = basis[(next + c) * nu + i]; }
         __syncthreads();
@@ -644,30 +682,45 @@ ELAG_HIP_API int elag_hip_coarsen_extension(const elag_hip_coarsen_extension_in 
         ELAG_REQUIRE(ne >= 0 && nT >= 0 && nT < kMaxCols, "at most %d target vectors are supported (got %d)", kMaxCols - 1, nT);
         if (kernel_ms) *kernel_ms = 0.0;
         if (ne == 0) return;
+        const int mode = in->mode;
+        ELAG_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (facet) or 1 (ridge / peak)");
         check_assembly(in->mass_u, ne, in->nu, "coarsen_extension mass_u");
         check_assembly(in->mass_p, ne, in->np, "coarsen_extension mass_p");
+        if (mode) check_assembly(in->mass_q, ne, in->nq, "coarsen_extension mass_q");
         hipStream_t st = ctx().stream;
-        std::vector<int64_t> c_p(ne), c_Rb(ne), c_cP(ne), c_T(ne), c_ext(ne), c_dc(ne), c_rt(ne), c_nul(ne), c_fun(ne), c_cm(ne), need(ne);
+        std::vector<int64_t> c_p(ne), c_Rb(ne), c_cP(ne), c_T(ne), c_PDc(ne), c_ext(ne), c_dc(ne), c_rt(ne), c_nul(ne), c_fun(ne), c_cm(ne), need(ne);
         for (int e = 0; e < ne; e++) {
             const int64_t nu = in->nu[e], ni = in->ni[e], np = in->np[e], nx = in->next[e], nrt = in->nrt[e];
-            ELAG_REQUIRE(nu > 0 && ni >= 0 && ni <= nu && np > 0 && nx >= 0 && nrt >= 0, "bad dimensions of entity %d", e);
+            const int64_t npi = mode ? in->npi[e] : np, nq = mode ? in->nq[e] : 0;
+            ELAG_REQUIRE(nu > 0 && ni >= 0 && ni <= nu && np >= 0 && npi >= 0 && npi <= np && nq >= 0 && nx >= 0 && nrt >= 0 && (mode || np > 0),
+                         "bad dimensions of entity %d", e);
+            if (mode)
+                for (int64_t t = in->d2_ptr[e]; t < in->d2_ptr[e + 1]; t++)
+                    ELAG_REQUIRE(in->d2_row[t] >= 0 && in->d2_row[t] < nq && in->d2_col[t] >= 0 && in->d2_col[t] < np, "second derivative triplet outside entity %d", e);
             for (int64_t t = in->d_ptr[e]; t < in->d_ptr[e + 1]; t++)
                 ELAG_REQUIRE(in->d_row[t] >= 0 && in->d_row[t] < np && in->d_col[t] >= 0 && in->d_col[t] < nu, "derivative triplet outside entity %d", e);
-            c_p[e] = np; c_Rb[e] = (nu - ni) * nx; c_cP[e] = np * nrt; c_T[e] = nu * nT;
+            c_p[e] = np; c_Rb[e] = (nu - ni) * nx; c_cP[e] = npi * nrt; c_T[e] = nu * nT; c_PDc[e] = mode ? np * nx : 0;
             c_ext[e] = ni * nx; c_dc[e] = nx; c_rt[e] = ni * nrt; c_nul[e] = ni * nT; c_fun[e] = (nrt + nT) * ni;
             const int64_t ncm = nx + nrt + nT;
             c_cm[e] = ncm * ncm;
-            const int64_t n = ni + np + 1, m = n + nx + nrt + nT, kf = nrt + nT;
-            need[e] = nu * nu + np * np + 2 * np * nu + np + n * m + ni * nT + 2 * nu * ncm + kf * (kf + ni) + 2 * ni * kf;
+            const int64_t n = ni + npi + (mode ? 0 : 1), m = n + nx + nrt + nT, kf = nrt + nT;
+            need[e] = nu * nu + np * np + np * nu + npi * nu + np + n * m + ni * nT + 2 * nu * ncm + kf * (kf + ni) + 2 * ni * kf + nq * nq + 2 * nq * np;
         }
-        const auto o_p = prefix(c_p), o_Rb = prefix(c_Rb), o_cP = prefix(c_cP), o_T = prefix(c_T), o_ext = prefix(c_ext), o_dc = prefix(c_dc),
+        const auto o_p = prefix(c_p), o_Rb = prefix(c_Rb), o_cP = prefix(c_cP), o_T = prefix(c_T), o_PDc = prefix(c_PDc), o_ext = prefix(c_ext), o_dc = prefix(c_dc),
                    o_rt = prefix(c_rt), o_nul = prefix(c_nul), o_fun = prefix(c_fun), o_cm = prefix(c_cm);
         Placement pl;
         pl.finish(need);
-        AsmUpload mu, mp;
+        AsmUpload mu, mp, mq;
         mu.upload(in->mass_u, ne);
         mp.upload(in->mass_p, ne);
-        const int64_t nd = in->d_ptr[ne];
+        if (mode) mq.upload(in->mass_q, ne);
+        const int64_t nd = in->d_ptr[ne], nd2 = mode ? in->d2_ptr[ne] : 0;
+        std::vector<int> np_copy(in->np, in->np + ne);
+        DevBuf<int> d_npi(mode ? in->npi : np_copy.data(), ne), d_nq(mode ? in->nq : np_copy.data(), ne), d_d2row(mode ? in->d2_row : nullptr, (size_t)nd2),
+            d_d2col(mode ? in->d2_col : nullptr, (size_t)nd2);
+        std::vector<int64_t> zero_ptr((size_t)ne + 1, 0);
+        DevBuf<int64_t> d_d2ptr(mode ? in->d2_ptr : zero_ptr.data(), (size_t)ne + 1), f_PDc(o_PDc.data(), ne);
+        DevBuf<double> d_d2val(mode ? in->d2_val : nullptr, (size_t)nd2), d_PDc(mode ? in->PDc : nullptr, (size_t)o_PDc[ne]);
         DevBuf<int> d_nu(in->nu, ne), d_ni(in->ni, ne), d_np(in->np, ne), d_nx(in->next, ne), d_nrt(in->nrt, ne), d_drow(in->d_row, (size_t)nd),
             d_dcol(in->d_col, (size_t)nd), d_nnull((size_t)ne), d_sing(1);
         DevBuf<int64_t> d_dptr(in->d_ptr, (size_t)ne + 1), d_wsoff(pl.ws_off.data(), (size_t)ne);
@@ -679,8 +732,9 @@ ELAG_HIP_API int elag_hip_coarsen_extension(const elag_hip_coarsen_extension_in 
             d_cm((size_t)o_cm[ne]), d_gws((size_t)pl.gws_total);
         ELAG_HIP_CHECK(hipMemsetAsync(d_sing.p, 0, sizeof(int), st));
         ExtArgs a{};
-        a.n_ent = ne; a.nT = nT; a.svd_tol = in->svd_tol; a.smallest_entry = in->smallest_entry;
-        a.nu = d_nu; a.ni = d_ni; a.np = d_np; a.next = d_nx; a.nrt = d_nrt; a.mass_u = mu.dev; a.mass_p = mp.dev;
+        a.n_ent = ne; a.nT = nT; a.mode = mode; a.null_dofs = in->null_dofs; a.svd_tol = in->svd_tol; a.smallest_entry = in->smallest_entry;
+        a.nu = d_nu; a.ni = d_ni; a.np = d_np; a.npi = d_npi; a.nq = d_nq; a.next = d_nx; a.nrt = d_nrt; a.mass_u = mu.dev; a.mass_p = mp.dev; a.mass_q = mq.dev;
+        a.d2_ptr = d_d2ptr; a.d2_row = d_d2row; a.d2_col = d_d2col; a.d2_val = d_d2val; a.PDc = d_PDc; a.off_PDc = f_PDc;
         a.d_ptr = d_dptr; a.d_row = d_drow; a.d_col = d_dcol; a.d_val = d_dval;
         a.pv_p = d_pvp; a.R_b = d_Rb; a.cP = d_cP; a.T = d_T;
         a.off_p = f_p; a.off_Rb = f_Rb; a.off_cP = f_cP; a.off_T = f_T; a.off_ext = f_ext; a.off_dc = f_dc; a.off_rt = f_rt; a.off_nul = f_nul;

@@ -1,0 +1,487 @@
+"""Host side of the full AMGe coarse-space construction: ``DeRhamSequence::Coarsen`` (``src/amge/DeRhamSequence.cpp:572-692``)
+for all forms ``jformStart_ .. 3`` of a 3-D sequence.
+
+Same split as ``amge.py`` (the two-form special case): the *integer tables* -- agglomerated topology of every codimension
+(``AgglomeratedTopology::CoarsenLocalPartitioning``, ``src/topology/Topology.cpp:686-828``), dof agglomeration
+(``src/amge/DOFAgglomeration.cpp:33-314``), coarse dof numbering (``DofHandlerALG``) -- are built here with vectorised numpy;
+every floating-point operation of the per-agglomerate loops runs on the device: ``ComputeCoarseTracesWithTargets``
+(``:1818-1926``) through ``elag_hip_coarsen_traces``; ``hFacetExtension`` (``:2364-2556``) and ``hRidgePeakExtension``
+(``:2762-3033``) through ``elag_hip_coarsen_extension`` in mode 0 / 1; the product ``P_{j+1} D_c`` (``:2696``) and the
+projection of the targets through the device SpGEMM / SpMV.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+from scipy.sparse.csgraph import connected_components
+
+from . import _lib
+from .amge import (EPS, _Assembly, _ExtIn, _ExtOut, _Keep, _TracesIn, _TracesOut, _assembly, _blocks_to_csr, _first_touch_groups,
+                   _join_cols, _pack_cols, _ptr, _spmm_device, _take_leading, _take_leading_rows, expand_ranges)
+from .amge_level import ptr_from_counts
+from .derham_level import SeqLevel
+
+
+# ---- ragged-row primitives ------------------------------------------------------------------------------------------------
+
+def _product(a_ptr, a_idx, b_ptr, b_idx, a_sgn=None, b_sgn=None):
+    """Row-by-row product of two ragged tables, columns in first-touch order (``mfem::Mult``).  With signs: the signed sum
+    per column, cancelled entries dropped, reduced to the sign (``MultOrientation``, ``TopologyTable.cpp:130-139``)."""
+    nrow = len(a_ptr) - 1
+    cnt = np.diff(b_ptr)[a_idx]
+    q, own = expand_ranges(b_ptr[a_idx], cnt)
+    row = np.repeat(np.arange(nrow, dtype=np.int64), np.diff(a_ptr))[own]
+    val = np.ones(q.size) if a_sgn is None else a_sgn[own] * b_sgn[q]
+    r, c, s = _first_touch_groups(row, b_idx[q].astype(np.int64), val)
+    if a_sgn is not None:
+        keep = np.abs(s) > 1e-10
+        r, c, s = r[keep], c[keep], np.sign(s[keep])
+    return ptr_from_counts(np.bincount(r, minlength=nrow)), c, s
+
+
+def _concat_rows(tables, nrow):
+    """Row-wise concatenation of ragged tables [(ptr, idx), ...] in the given order."""
+    cnts = [np.diff(p) for p, _ in tables]
+    ptr = ptr_from_counts(sum(cnts))
+    out = np.empty(int(ptr[-1]), dtype=np.int64)
+    off = ptr[:-1].copy()
+    for (p, i), cn in zip(tables, cnts):
+        pos, own = expand_ranges(off, cn)
+        out[pos] = i
+        off = off + cn
+    return ptr, out
+
+
+class _Lookup:
+    """position of (row, id) pairs inside ragged rows"""
+
+    def __init__(self, ptr, idx, nid):
+        self.ptr, self.nid = ptr, int(nid) + 1
+        row = np.repeat(np.arange(len(ptr) - 1, dtype=np.int64), np.diff(ptr))
+        key = row * self.nid + idx
+        o = np.argsort(key, kind="stable")
+        self.key = key[o]
+        self.pos = (np.arange(idx.size, dtype=np.int64) - ptr[row])[o]
+
+    def find(self, row, ids):
+        k = row * self.nid + ids
+        if self.key.size == 0:
+            return np.full(k.size, -1, dtype=np.int64)
+        p = np.minimum(np.searchsorted(self.key, k), self.key.size - 1)
+        return np.where(self.key[p] == k, self.pos[p], -1)
+
+
+def _gather_dense(M: sp.csr_matrix, row_ptr, rows, col_lookup: _Lookup, ncol):
+    """Per entity the dense sub-block M[rows of the entity, columns of the entity] packed col-major (nrows_e x ncol_e)."""
+    nr = np.diff(row_ptr)
+    out_ptr = ptr_from_counts(nr * ncol)
+    out = np.zeros(int(out_ptr[-1]))
+    ent = np.repeat(np.arange(nr.size, dtype=np.int64), nr)
+    lr = np.arange(rows.size, dtype=np.int64) - row_ptr[ent]
+    q, own = expand_ranges(M.indptr[rows], np.diff(M.indptr)[rows])
+    lc = col_lookup.find(ent[own], M.indices[q].astype(np.int64))
+    ok = lc >= 0
+    e = ent[own][ok]
+    out[out_ptr[e] + lc[ok] * nr[e] + lr[own][ok]] = M.data[q][ok]
+    return out
+
+
+# ---- topology ----------------------------------------------------------------------------------------------------------------
+
+def coarsen_topology(lv: SeqLevel, part: np.ndarray) -> dict:
+    """``CoarsenLocalPartitioning`` for all codimensions.  The minimal intersection sets
+    (``src/structures/minimalIntersectionSet.cpp:43-132``) are the connected components of the relation
+    ``Z_ii = Z_jj = |Z_ij|`` (an equivalence relation on a sane topology), numbered by their lowest member and oriented
+    like it."""
+    part = np.asarray(part, dtype=np.int64)
+    nA = int(part.max()) + 1
+    order = np.argsort(part, kind="stable")
+    A = [(ptr_from_counts(np.bincount(part, minlength=nA)), order.astype(np.int64), np.ones(order.size))]
+    Bc, attr_c = [], None
+    for c in range(3):
+        ap, ai, asg = A[c]
+        fp, fi, fs = _product(ap, ai, lv.B[c][0], lv.B[c][1], asg, lv.B[c][2])          # AE_fc
+        nsub = lv.n[c + 1]
+        row = np.repeat(np.arange(len(fp) - 1, dtype=np.int64), np.diff(fp))
+        Am = sp.csr_matrix((fs, (row, fi)), shape=(len(fp) - 1, nsub))
+        Z = (Am.T @ Am).tocsr()
+        if c == 0 and np.any(lv.facet_attr > 0):
+            bf = np.nonzero(lv.facet_attr > 0)[0]
+            Bat = sp.csr_matrix((np.ones(bf.size), (bf, lv.facet_attr[bf] - 1)), shape=(nsub, int(lv.facet_attr.max())))
+            Z = (Z + Bat @ Bat.T).tocsr()
+        Z = Z.tocoo()
+        dZ = np.zeros(nsub)
+        dg = Z.row == Z.col
+        dZ[Z.row[dg]] = Z.data[dg]
+        rel = (dZ[Z.row] > 0.5 - 1e-10) & (np.abs(dZ[Z.row] - dZ[Z.col]) < 1e-10) & (np.abs(np.abs(Z.data) - dZ[Z.row]) < 1e-10)
+        G = sp.csr_matrix((Z.data[rel], (Z.row[rel], Z.col[rel])), shape=(nsub, nsub))
+        member = dZ > 0.5 - 1e-10
+        _, lab = connected_components(G, directed=False)
+        mem = np.nonzero(member)[0]
+        ulab, first, inv = np.unique(lab[mem], return_index=True, return_inverse=True)
+        lowest = mem[first]                                                   # mem ascends: first occurrence = lowest member
+        rank = np.empty(ulab.size, dtype=np.int64)
+        rank[np.argsort(lowest)] = np.arange(ulab.size)
+        mis = np.full(nsub, -1, dtype=np.int64)
+        mis[mem] = rank[inv.reshape(-1)]
+        low_of_set = np.empty(ulab.size, dtype=np.int64)
+        low_of_set[rank] = lowest
+        ori = np.zeros(nsub)
+        # orientation relative to the lowest member: Z(low, j) / Z(low, low)
+        Gc = G.tocsr()
+        ori[mem] = np.asarray(Gc[low_of_set[mis[mem]], mem]).ravel() / dZ[mem]
+        nmis = ulab.size
+        o2 = np.argsort(mis[mem], kind="stable")
+        A.append((ptr_from_counts(np.bincount(mis[mem], minlength=nmis)), mem[o2].astype(np.int64), ori[mem[o2]]))
+        sub_ptr = ptr_from_counts(member.astype(np.int64))                   # fc_AF: one entry per member row
+        bp, bi, bs = _product(fp, fi, sub_ptr, mis[mem], fs, ori[mem])
+        Bc.append((bp, bi.astype(np.int64), bs))
+        if c == 0:
+            attr_c = lv.facet_attr[A[1][1][A[1][0][:-1]]].astype(np.int32)
+    return dict(A=A, B=Bc, facet_attr=attr_c, n=[len(a[0]) - 1 for a in A])
+
+
+# ---- dof tables ---------------------------------------------------------------------------------------------------------------
+
+class _Tables:
+    """Vectorised ``entity_dof`` tables of a level and the agglomerated rows built from them."""
+
+    def __init__(self, lv: SeqLevel):
+        self.lv = lv
+        self._conn, self._edof = {}, {}
+
+    def conn(self, c, c2):
+        if (c, c2) not in self._conn:
+            B = self.lv.B
+            if c2 == c + 1:
+                self._conn[(c, c2)] = (B[c][0], B[c][1])
+            elif (c, c2) == (0, 3):
+                p, i = self.conn(0, 2)
+                self._conn[(c, c2)] = _product(p, i, B[2][0], B[2][1])[:2]
+            else:
+                self._conn[(c, c2)] = _product(B[c][0], B[c][1], B[c + 1][0], B[c + 1][1])[:2]
+        return self._conn[(c, c2)]
+
+    def edof(self, j, c):
+        """(ptr, idx) of ``entity_dof[c]`` of form j: peaks', ridges', facets' dofs in connectivity order, then interior."""
+        if (j, c) not in self._edof:
+            lv = self.lv
+            cb = lv.cb(j)
+            tabs = []
+            for c2 in range(3, c, -1):
+                if c2 > cb:
+                    continue
+                p, i = self.conn(c, c2)
+                ip = lv.idof[j][c2]
+                d, own = expand_ranges(lv.base(j, c2) + ip[i], np.diff(ip)[i])
+                cnt = np.bincount(np.repeat(np.arange(len(p) - 1, dtype=np.int64), np.diff(p))[own], minlength=len(p) - 1)
+                tabs.append((ptr_from_counts(cnt), d))
+            ip = lv.idof[j][c]
+            d, _ = expand_ranges(lv.base(j, c) + ip[:-1], np.diff(ip))
+            tabs.append((ip.astype(np.int64), d))
+            self._edof[(j, c)] = _concat_rows(tabs, lv.n[c])
+        return self._edof[(j, c)]
+
+
+def agglomerate_dofs(lv: SeqLevel, tb: _Tables, topo: dict, j: int) -> dict:
+    """``DofAgglomeration`` of form j for every codimension: rows (ptr, dofs), interior counts, separator types."""
+    cb = lv.cb(j)
+    nd = lv.ndof(j)
+    rows = {}
+    for c in range(cb + 1):
+        ep, ei = tb.edof(j, c)
+        p, d, _ = _product(topo["A"][c][0], topo["A"][c][1], ep, ei)
+        rows[c] = (p, d)
+    sep = np.zeros(nd, dtype=np.int64)
+    for c in range(1, cb + 1):
+        sep[rows[c][1]] = c
+    nint = {}
+    for c in range(cb + 1):
+        p, d = rows[c]
+        a = np.repeat(np.arange(len(p) - 1, dtype=np.int64), np.diff(p))
+        if cb > c:
+            o = np.lexsort((d, sep[d], a))
+            d = d[o]
+            rows[c] = (p, d)
+            nint[c] = np.bincount(a, weights=(sep[d] == c), minlength=len(p) - 1).astype(np.int64)
+        else:
+            nint[c] = np.diff(p)
+    return dict(rows=rows, nint=nint, sep=sep, look={c: _Lookup(rows[c][0], rows[c][1], nd) for c in range(cb + 1)})
+
+
+class _CoarseDofs:
+    def __init__(self, lv, topo, j):
+        self.cb = lv.cb(j)
+        self.cnt = {c: np.zeros(topo["n"][c], dtype=np.int64) for c in range(self.cb + 1)}
+        self.n_rt = {c: np.zeros(topo["n"][c], dtype=np.int64) for c in range(self.cb + 1)}
+        self.ptr, self.base = {}, {}
+
+    def freeze(self, c):
+        self.ptr[c] = ptr_from_counts(self.cnt[c])
+        self.base[c] = int(sum(self.cnt[c2].sum() for c2 in range(self.cb, c, -1)))
+
+    def ndof_upto(self, c):
+        return int(sum(self.cnt[c2].sum() for c2 in range(self.cb, c - 1, -1)))
+
+
+def _asm(keep, lv, tb, j, c, topo, look):
+    """Assembly list of the codim-c mass of form j over the agglomerated entities of that codimension."""
+    ap, ai, _ = topo["A"][c]
+    nA = len(ap) - 1
+    ent_of_item = np.repeat(np.arange(nA, dtype=np.int64), np.diff(ap))
+    ep, ei = tb.edof(j, c)
+    n_e = np.diff(ep)[ai]
+    q, own = expand_ranges(ep[ai], n_e)
+    loc = look.find(ent_of_item[own], ei[q])
+    assert np.all(loc >= 0)
+    ptr, vals = lv.M[j][c]
+    return _assembly(keep, ent_of_item, nA, ptr[ai], n_e, loc, vals)
+
+
+def _triplets(D: sp.csr_matrix, rows_ptr, rows, look_cols: _Lookup):
+    """Local triplets of D restricted to (rows of the entity) x (its columns)."""
+    ent = np.repeat(np.arange(len(rows_ptr) - 1, dtype=np.int64), np.diff(rows_ptr))
+    lr = np.arange(rows.size, dtype=np.int64) - rows_ptr[ent]
+    q, own = expand_ranges(D.indptr[rows], np.diff(D.indptr)[rows])
+    lc = look_cols.find(ent[own], D.indices[q].astype(np.int64))
+    assert np.all(lc >= 0), "a derivative couples an agglomerate with a dof outside it"
+    e = ent[own]
+    return ptr_from_counts(np.bincount(e, minlength=len(rows_ptr) - 1)), lr[own], lc, D.data[q]
+
+
+# ---- Coarsen ------------------------------------------------------------------------------------------------------------------
+
+def coarsen(lv: SeqLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entry: float = EPS, timings: dict | None = None) -> dict:
+    """``DeRhamSequence::Coarsen`` for forms ``lv.jstart .. 3``.  Returns dict(P, hat, coarse, topo, n_null)."""
+    L = _lib.init()
+    tb = _Tables(lv)
+    topo = coarsen_topology(lv, part)
+    js = lv.jstart
+    agg = {j: agglomerate_dofs(lv, tb, topo, j) for j in range(js, 4)}
+    cd = {j: _CoarseDofs(lv, topo, j) for j in range(js, 4)}
+    D = {j: lv.D[j].tocsr() for j in range(js, 3)}
+    Ppieces = {j: [] for j in range(js, 4)}
+    hat = {j: {} for j in range(js, 4)}
+    Mc = {j: {} for j in range(js, 4)}
+    Dc_e = {j: ([], [], []) for j in range(js, 3)}
+    P, Dc = {}, {}
+    n_null = {j: 0 for j in range(js, 4)}
+    tms = {} if timings is None else timings
+    ms = C.c_double(0.0)
+
+    for codim in range(4):
+        j = 3 - codim
+        if j < js:
+            break
+        ctr = codim
+        nAt = topo["n"][ctr]
+        rp, rd = agg[j]["rows"][ctr]
+        nT = lv.T[j].shape[1]
+        kmax = 1 + nT
+        # ======== coarse traces ========
+        if j == 0:                                                   # Compute0formCoarseTraces
+            assert np.all(np.diff(rp) == 1), "likely topology error, possibly disconnected edge"
+            ncoarse = np.ones(nAt, dtype=np.int64)
+            o_p = np.ones(nAt); o_cm = np.ones(nAt); o_f = np.ones(nAt)
+            kmax = 1
+        else:
+            keep = _Keep()
+            ap, ai, asg = topo["A"][ctr]
+            # PV vector: base value of the dof times the orientation of its entity in the agglomerate
+            ent_of_dof_sgn = np.zeros(lv.ndof(j))
+            ip = lv.idof[j][ctr]
+            dd, own = expand_ranges(lv.base(j, ctr) + ip[ai], np.diff(ip)[ai])
+            ent_of_dof_sgn[dd] = asg[own]
+            tin = _TracesIn(nAt, nT, svd_tol, keep.i32(np.diff(rp)), _asm(keep, lv, tb, j, ctr, topo, agg[j]["look"][ctr]),
+                            keep.f64(lv.pv[j][rd] * ent_of_dof_sgn[rd]), keep.f64(_pack_cols(lv.T[j], rd, rp)))
+            o_nc = np.zeros(nAt, np.int32); o_p = np.zeros(rd.size * kmax); o_cm = np.zeros(nAt * kmax * kmax); o_f = np.zeros(rd.size * kmax)
+            _lib.check(L.elag_hip_coarsen_traces(C.byref(tin), C.byref(_TracesOut(_ptr(o_nc), _ptr(o_p), _ptr(o_cm), _ptr(o_f))), C.byref(ms)))
+            tms[f"traces{j}_ms"] = ms.value
+            ncoarse = o_nc.astype(np.int64)
+        cd[j].cnt[ctr][:] = ncoarse
+        cd[j].freeze(ctr)
+        n_null[j] += int((ncoarse - 1).sum())
+        cptr = cd[j].ptr[ctr]
+        cidx = cd[j].base[ctr] + np.arange(int(cptr[-1]), dtype=np.int64)
+        Ppieces[j].append(("tr", rp, rd, cptr, cidx, o_p, np.full(nAt, kmax)))
+        hat[j][ctr] = (cptr, cidx, rp, rd, o_f, np.diff(rp), np.full(nAt, kmax))
+        Mc[j][ctr] = (_take_leading(o_cm, np.full(nAt, kmax), ncoarse), ncoarse)
+
+        # ======== extensions ========
+        for step, cdom in enumerate(range(ctr - 1, -1, -1)):
+            mode = 0 if step == 0 else 1
+            null_dofs = 1 if step <= 1 else 0
+            nA = topo["n"][cdom]
+            ncols_sofar = cd[j].ndof_upto(cdom + 1)
+            Pj = _assemble_P(Ppieces[j], lv.ndof(j), ncols_sofar, keep_zeros=True)
+            Pp = P[j + 1]
+            cdp = cd[j + 1]
+            up, ud = agg[j]["rows"][cdom]; ni = agg[j]["nint"][cdom]; nu = np.diff(up)
+            pp, pd = agg[j + 1]["rows"][cdom]; npi = agg[j + 1]["nint"][cdom]; np_ = np.diff(pp)
+            # coarse dofs on the boundary (GetDofsOnBdr / hAE_AFCD): sub-entities from the highest codimension down
+            tabs = []
+            tbc = _CoarseConn(topo)
+            for c2 in range(cd[j].cb, cdom, -1):
+                sp_, si = tbc.conn(cdom, c2)
+                cp2 = cd[j].ptr[c2]
+                dcol, own = expand_ranges(cd[j].base[c2] + cp2[si], np.diff(cp2)[si])
+                cnt = np.bincount(np.repeat(np.arange(nA, dtype=np.int64), np.diff(sp_))[own], minlength=nA)
+                tabs.append((ptr_from_counts(cnt), dcol))
+            cbp, cbd = _concat_rows(tabs, nA)
+            nxt = np.diff(cbp)
+            look_cbd = _Lookup(cbp, cbd, ncols_sofar)
+            # boundary rows of every agglomerate
+            bq, ownb = expand_ranges(up[:-1] + ni, nu - ni)
+            b_ptr = ptr_from_counts(nu - ni)
+            R_b = _gather_dense(Pj, b_ptr, ud[bq], look_cbd, nxt)
+            keep = _Keep()
+            d_ptr, d_row, d_col, d_val = _triplets(D[j], pp, pd, agg[j]["look"][cdom])
+            pint_ptr = cdp.ptr[cdom]; pint_base = cdp.base[cdom]
+            iq, owni = expand_ranges(pp[:-1], npi)                     # interior p dofs
+            ip_ptr = ptr_from_counts(npi)
+            if mode == 0:
+                assert np.array_equal(npi, np_)
+                nrt = cdp.cnt[cdom] - 1
+                pv_cols = (ptr_from_counts(np.ones(nA, dtype=np.int64)), pint_base + pint_ptr[:-1])
+                pv_p = _gather_dense(Pp, pp, pd, _Lookup(pv_cols[0], pv_cols[1], Pp.shape[1]), np.ones(nA, dtype=np.int64))
+                null_start = pint_ptr[:-1] + 1
+            else:
+                nrt = cdp.cnt[cdom] - cdp.n_rt[cdom]
+                pv_p = np.zeros(int(np_.sum()))
+                null_start = pint_ptr[:-1] + cdp.n_rt[cdom]
+            ncol_, own_n = expand_ranges(pint_base + null_start, nrt)
+            nl_ptr = ptr_from_counts(nrt)
+            cP = _gather_dense(Pp, ip_ptr, pd[iq], _Lookup(nl_ptr, ncol_, Pp.shape[1]), nrt)
+            args = dict(mass_q=_Assembly(), d2=(None, None, None, None), PDc=None, npi=None, nq=None)
+            if mode == 1:
+                qp, qd = agg[j + 2]["rows"][cdom]
+                d2_ptr, d2_row, d2_col, d2_val = _triplets(D[j + 1], qp, qd, agg[j + 1]["look"][cdom])
+                r_, c_, v_ = Dc_e[j]
+                Dc_now = sp.csr_matrix((np.concatenate(v_) if v_ else np.zeros(0), (np.concatenate(r_) if r_ else np.zeros(0, np.int64),
+                                                                                     np.concatenate(c_) if c_ else np.zeros(0, np.int64))),
+                                       shape=(Pp.shape[1], ncols_sofar))
+                PDc = _spgemm_device(Pp, Dc_now)                                    # :2696-2697
+                args = dict(mass_q=_asm(keep, lv, tb, j + 2, cdom, topo, agg[j + 2]["look"][cdom]),
+                            d2=(keep.i64(d2_ptr), keep.i32(d2_row), keep.i32(d2_col), keep.f64(d2_val)),
+                            PDc=keep.f64(_gather_dense(PDc, pp, pd, look_cbd, nxt)), npi=keep.i32(npi), nq=keep.i32(np.diff(qp)))
+            ein = _ExtIn(nA, nT, mode, null_dofs, svd_tol, smallest_entry, keep.i32(nu), keep.i32(ni), keep.i32(np_), args["npi"], args["nq"],
+                         keep.i32(nxt), keep.i32(nrt),
+                         _asm(keep, lv, tb, j, cdom, topo, agg[j]["look"][cdom]), _asm(keep, lv, tb, j + 1, cdom, topo, agg[j + 1]["look"][cdom]),
+                         args["mass_q"], keep.i64(d_ptr), keep.i32(d_row), keep.i32(d_col), keep.f64(d_val), *args["d2"],
+                         keep.f64(pv_p), keep.f64(R_b), keep.f64(cP), keep.f64(_pack_cols(lv.T[j], ud, up)), args["PDc"])
+            kf = nrt + nT
+            ncm = nxt + nrt + nT
+            o_nn = np.zeros(nA, np.int32)
+            o_ext = np.zeros(int((ni * nxt).sum())); o_dc = np.zeros(int(nxt.sum())); o_rt = np.zeros(int((ni * nrt).sum()))
+            o_nul = np.zeros(int((ni * nT).sum())); o_fun = np.zeros(int((kf * ni).sum())); o_cme = np.zeros(int((ncm * ncm).sum()))
+            eout = _ExtOut(_ptr(o_nn), _ptr(o_ext), _ptr(o_dc), _ptr(o_rt), _ptr(o_nul), _ptr(o_fun), _ptr(o_cme))
+            _lib.check(L.elag_hip_coarsen_extension(C.byref(ein), C.byref(eout), C.byref(ms)))
+            tms[f"extension{j}_{cdom}_ms"] = ms.value
+            nn = o_nn.astype(np.int64)
+            nint_c = nrt + nn
+            cd[j].cnt[cdom][:] = nint_c
+            cd[j].n_rt[cdom][:] = nrt
+            cd[j].freeze(cdom)
+            n_null[j] += int(nn.sum())
+            ci_ptr = cd[j].ptr[cdom]
+            ci_idx = cd[j].base[cdom] + np.arange(int(ci_ptr[-1]), dtype=np.int64)
+            i_ptr = ptr_from_counts(ni)
+            iu, _o = expand_ranges(up[:-1], ni)
+            int_dofs = ud[iu]
+            Ppieces[j].append(("ext", i_ptr, int_dofs, cbp, cbd, o_ext, nxt))
+            Ppieces[j].append(("bub", i_ptr, int_dofs, ci_ptr, ci_idx, _join_cols(o_rt, ni, nrt, o_nul, nT, nn), nint_c))
+            hat[j][cdom] = (ci_ptr, ci_idx, i_ptr, int_dofs, _take_leading_rows(o_fun, kf, ni, nint_c), ni, nint_c)
+            Mc[j][cdom] = (_take_leading(o_cme, ncm, nxt + nint_c), nxt + nint_c)
+            r_, c_, v_ = Dc_e[j]
+            if mode == 0:
+                sel = o_dc != 0.0
+                pv_row = pint_base + pint_ptr[:-1]
+                r_.append(np.repeat(pv_row, nxt)[sel]); c_.append(cbd[sel]); v_.append(o_dc[sel])
+            rt_rows, _o = expand_ranges(pint_base + null_start, nrt)
+            rt_cols, _o = expand_ranges(cd[j].base[cdom] + ci_ptr[:-1], nrt)
+            r_.append(rt_rows); c_.append(rt_cols); v_.append(np.ones(rt_rows.size))
+        # ======== finalise form j ========
+        ndc = cd[j].ndof_upto(0)
+        P[j] = _assemble_P(Ppieces[j], lv.ndof(j), ndc, keep_zeros=False)
+        if j < 3:
+            r_, c_, v_ = Dc_e[j]
+            Dc[j] = sp.csr_matrix((np.concatenate(v_), (np.concatenate(r_), np.concatenate(c_))), shape=(P[j + 1].shape[1], ndc))
+            Dc[j].sort_indices()
+
+    # ---- projector pieces and the projected targets (CochainProjector::Project, CochainProjector.cpp:158-216) ----
+    hats, Tc = {}, [None] * 4
+    for j in range(js, 4):
+        ndc = P[j].shape[1]
+        hats[j] = {}
+        for c, h in hat[j].items():
+            cptr, cidx, rp, rd, vals, ld, slot_rows = h
+            hats[j][c] = _blocks_to_csr(cptr, cidx, rp, rd, vals, ld, (ndc, lv.ndof(j)), col_major=False, slot_rows=slot_rows)
+        v = np.zeros((ndc, lv.T[j].shape[1]))
+        res = lv.T[j]
+        for c in range(lv.cb(j), -1, -1):
+            v = v + _spmm_device(hats[j][c], res)
+            if c > 0:
+                res = lv.T[j] - _spmm_device(P[j], v)
+        Tc[j] = v
+    const3 = _spmm_device(hats[3][0], lv.const3[:, None])[:, 0]
+
+    idof_c, M_c = [None] * 4, [None] * 4
+    for j in range(js, 4):
+        idof_c[j] = [cd[j].ptr[c] for c in range(lv.cb(j) + 1)]
+        M_c[j] = [(ptr_from_counts(Mc[j][c][1] * Mc[j][c][1]), Mc[j][c][0]) for c in range(lv.cb(j) + 1)]
+    coarse = SeqLevel(n=topo["n"], B=topo["B"], facet_attr=topo["facet_attr"], jstart=js, idof=idof_c, M=M_c,
+                      D=[Dc.get(j) for j in range(3)], T=Tc, pv=[None] * 4, const3=const3, meta=dict(kind="alg"))
+    for j in range(js, 4):
+        vv = np.zeros(coarse.ndof(j)); ctr = coarse.cb(j)
+        p = coarse.idof[j][ctr]
+        vv[coarse.base(j, ctr) + p[:-1][np.diff(p) > 0]] = 1.0
+        coarse.pv[j] = vv
+    return dict(P=P, hat=hats, coarse=coarse, topo=topo, n_null=n_null, dofs=cd)
+
+
+def projector(res: dict, j: int) -> sp.csr_matrix:
+    """``CochainProjector::ComputeProjector``: ``Pi_{c-1} = Pi_c + hat_{c-1} (I - P Pi_c)`` (test helper: host sparse algebra)."""
+    cur = None
+    for c in sorted(res["hat"][j].keys(), reverse=True):
+        h = res["hat"][j][c]
+        cur = h if cur is None else (cur + h - h @ (res["P"][j] @ cur))
+    cur = cur.tocsr(); cur.sort_indices()
+    return cur
+
+
+class _CoarseConn:
+    def __init__(self, topo):
+        self.B = topo["B"]
+        self._c = {}
+
+    def conn(self, c, c2):
+        if (c, c2) not in self._c:
+            B = self.B
+            if c2 == c + 1:
+                self._c[(c, c2)] = (B[c][0], B[c][1])
+            elif (c, c2) == (0, 3):
+                p, i = self.conn(0, 2)
+                self._c[(c, c2)] = _product(p, i, B[2][0], B[2][1])[:2]
+            else:
+                self._c[(c, c2)] = _product(B[c][0], B[c][1], B[c + 1][0], B[c + 1][1])[:2]
+        return self._c[(c, c2)]
+
+
+def _assemble_P(pieces, nrows, ncols, keep_zeros):
+    out = None
+    for _tag, rptr, ridx, cptr, cidx, vals, ld in pieces:
+        M = _blocks_to_csr(rptr, ridx, cptr, cidx, vals, ld, (nrows, ncols), col_major=True)
+        out = M if out is None else out + M
+    out = out.tocsr()
+    out.sort_indices()
+    return out
+
+
+def _spgemm_device(A: sp.csr_matrix, B: sp.csr_matrix) -> sp.csr_matrix:
+    if A.nnz == 0 or B.nnz == 0:
+        return sp.csr_matrix((A.shape[0], B.shape[1]))
+    from . import linalg as la
+    out = la.ParallelCSRMatrix.from_scipy(A.tocsr()).matmul(la.ParallelCSRMatrix.from_scipy(B.tocsr())).to_scipy()
+    return out.tocsr()

@@ -1,0 +1,109 @@
+"""CPU suite for the oracle of the whole ``DeRhamSequence::Coarsen`` (``oracle/derham.py``, forms jformStart..3): the
+reference cannot run here, so the restatement is pinned by the reference's invariants (``DeRhamSequence::CheckInvariants``,
+``src/amge/DeRhamSequence.cpp:694-970``): ``D_f P_j = P_{j+1} D_c`` (CheckDP), ``D_c D_c = 0`` (CheckD), ``M_c = P^T M_f P``
+(CheckCoarseMassMatrix), ``Pi P = I`` (CheckPi) and the targets lying in the coarse spaces; the product's integer tables
+(``parelag_amd/derham.py``) are checked bit-exact against the oracle's entity-by-entity loops."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import amge as oa, derham as od
+from parelag_amd import derham, meshgen
+from parelag_amd.amge_level import level_from_tets
+from parelag_amd.derham_level import seq_level_from_tets
+
+
+def invariants(lv, res, Pi=None):
+    c, P = res["coarse"], res["P"]
+    Pi = res["Pi"] if Pi is None else Pi
+    out = {}
+    for j in range(lv.jstart, 4):
+        M, Mc = lv.mass(j), c.mass(j)
+        out[f"mass{j}"] = abs(P[j].T @ M @ P[j] - Mc).max() / abs(Mc).max()
+        out[f"pip{j}"] = abs(Pi[j] @ P[j] - sp.identity(P[j].shape[1])).max()
+        out[f"targets{j}"] = np.abs(P[j] @ c.T[j] - lv.T[j]).max() / np.abs(lv.T[j]).max()
+        if j < 3:
+            out[f"commute{j}"] = abs(lv.D[j] @ P[j] - P[j + 1] @ c.D[j]).max() / max(abs(lv.D[j] @ P[j]).max(), 1e-300)
+        if j < 2:
+            out[f"exact{j}"] = abs(c.D[j + 1] @ c.D[j]).max()
+    return out
+
+
+@pytest.fixture(scope="module")
+def seq():
+    return meshgen.Sequence.kuhn_cube(1, 2)
+
+
+def test_finest_level_is_a_complex_and_matches_the_generator(seq):
+    m = seq.meshes[0]
+    lv = seq_level_from_tets(m, jstart=0)
+    assert abs(lv.D[1] @ lv.D[0]).max() == 0.0 and abs(lv.D[2] @ lv.D[1]).max() == 0.0
+    S2 = sp.diags(lv.meta["S2"])
+    assert abs(m.M1() - lv.mass(1)).max() < 1e-15                          # edges keep the generator's orientation
+    assert abs(S2 @ m.M2() @ S2 - lv.mass(2)).max() < 1e-15
+    assert abs(S2 @ m.D1() - lv.D[1]).max() == 0.0 and abs(m.D0() - lv.D[0]).max() == 0.0
+    assert abs(m.M0_P1_stiffness() - lv.D[0].T @ lv.mass(1) @ lv.D[0]).max() < 1e-12
+    # gradients of the linears are the constant fields, curls of constants vanish
+    assert np.abs(lv.D[0] @ lv.T[0][:, 1:] - lv.T[1]).max() < 1e-15 and np.abs(lv.D[1] @ lv.T[1]).max() < 1e-15
+    # lower-dimensional masses: tangential trace on a face (partition of unity of the Whitney forms' traces), edge, vertex
+    one_t = lv.T[1]                                                         # constant fields
+    ed = lv.entity_dof(1, 1)
+    f = 5
+    t = one_t[ed[f]]
+    assert np.allclose(t.T @ lv.block(1, 1, f) @ t, (np.eye(3) - np.outer(lv.T[2][f], lv.T[2][f]) / lv.pv[2][f] ** 2) * lv.pv[2][f], atol=1e-13)
+
+
+@pytest.mark.parametrize("jstart", [2, 1, 0])
+def test_reference_invariants_two_levels(seq, jstart):
+    lv = seq_level_from_tets(seq.meshes[0], jstart=jstart)
+    r0 = od.coarsen(lv, seq.partition(0))
+    r1 = od.coarsen(r0["coarse"], seq.partition(1))
+    for l, r in ((lv, r0), (r0["coarse"], r1)):
+        inv = invariants(l, r)
+        assert max(inv.values()) < 1e-12, inv
+    for m in seq.meshes:
+        m.build_faces()
+    # derefined tets with lowest-order targets: one coarse dof per coarse vertex / edge / face / element
+    want = lambda m: [m.nv, m.ne, m.nf, m.nt][jstart:]
+    assert [r0["coarse"].ndof(j) for j in range(jstart, 4)] == want(seq.meshes[1])
+    assert [r1["coarse"].ndof(j) for j in range(jstart, 4)] == want(seq.meshes[2])
+
+
+def test_general_oracle_equals_the_two_form_oracle(seq):
+    lv = seq_level_from_tets(seq.meshes[0], jstart=2)
+    r = od.coarsen(lv, seq.partition(0))
+    r2 = oa.coarsen(level_from_tets(seq.meshes[0]), seq.partition(0))
+    assert abs(r["P"][2] - r2["P2"]).max() == 0.0 and abs(r["P"][3] - r2["P3"]).max() == 0.0
+    assert abs(r["coarse"].D[2] - r2["coarse"].D2).max() == 0.0 and abs(r["Pi"][2] - r2["Pi2"]).max() < 1e-15
+
+
+def test_heterogeneous_coefficient_gives_null_space_dofs(seq):
+    rng = np.random.default_rng(3)
+    lv = seq_level_from_tets(seq.meshes[0], jstart=1, kinv=np.exp(2 * rng.standard_normal(seq.meshes[0].nt)))
+    r0 = od.coarsen(lv, seq.partition(0))
+    assert r0["n_null"][2] > 0
+    inv = invariants(lv, r0)
+    assert max(inv.values()) < 1e-10, inv
+    r1 = od.coarsen(r0["coarse"], seq.partition(1))
+    inv = invariants(r0["coarse"], r1)
+    assert max(inv.values()) < 1e-10, inv
+
+
+@pytest.mark.parametrize("jstart", [1, 0])
+def test_product_topology_and_dof_tables_are_bit_exact(seq, jstart):
+    lv = seq_level_from_tets(seq.meshes[0], jstart=jstart)
+    a, b = od.coarsen_topology(lv, seq.partition(0)), derham.coarsen_topology(lv, seq.partition(0))
+    assert a["n"] == b["n"]
+    for c in range(4):
+        for k in range(3):
+            assert np.array_equal(a["A"][c][k], b["A"][c][k]), ("A", c, k)
+            if c < 3:
+                assert np.array_equal(a["B"][c][k], b["B"][c][k]), ("B", c, k)
+    tb = derham._Tables(lv)
+    for j in range(jstart, 4):
+        ao, ap = od.agglomerate_dofs(lv, a, j), derham.agglomerate_dofs(lv, tb, b, j)
+        for c in range(lv.cb(j) + 1):
+            assert np.array_equal(np.concatenate(ao["rows"][c]), ap["rows"][c][1]), (j, c)
+            assert np.array_equal(np.array(ao["nint"][c]), ap["nint"][c]), (j, c)
+        ep, ei = tb.edof(j, 0)
+        assert np.array_equal(np.concatenate(lv.entity_dof(j, 0)), ei)

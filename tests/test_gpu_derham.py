@@ -1,0 +1,125 @@
+"""GPU parity of the full AMGe coarsening (``parelag_amd/derham.py``: all forms jformStart..3, ``hFacetExtension`` and
+``hRidgePeakExtension`` on the device) against the CPU oracle of ``DeRhamSequence::Coarsen`` (``oracle/derham.py``) on
+identical inputs: integer tables bit-exact, fp64 operators 1e-10 relative after aligning the sign of SVD columns (as in
+``tests/test_gpu_amge.py``); the device's spaces satisfy the reference's invariants themselves."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import derham as od
+from parelag_amd import meshgen
+from parelag_amd.derham_level import seq_level_from_tets
+from tests.test_derham_oracle import invariants
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def derham():
+    from parelag_amd import derham as m
+    return m
+
+
+def rel(x, ref):
+    den = max(abs(ref).max(), 1e-300)
+    return abs(x - ref).max() / den if x.shape == ref.shape else np.inf
+
+
+def signs(P_dev, P_ref):
+    d = np.asarray(P_dev.multiply(P_ref).sum(axis=0)).ravel()
+    return np.where(d < 0, -1.0, 1.0)
+
+
+def compare(derham, lv, part):
+    ro = od.coarsen(lv, part)
+    tm = {}
+    rd = derham.coarsen(lv, part, timings=tm)
+    for c in range(4):
+        for k in range(3):
+            assert np.array_equal(ro["topo"]["A"][c][k], rd["topo"]["A"][c][k])
+            if c < 3:
+                assert np.array_equal(ro["topo"]["B"][c][k], rd["topo"]["B"][c][k])
+    co, cd = ro["coarse"], rd["coarse"]
+    assert ro["n_null"] == rd["n_null"]
+    S = {j: sp.diags(signs(rd["P"][j], ro["P"][j])) for j in range(lv.jstart, 4)}
+    Pi = {j: derham.projector(rd, j) for j in range(lv.jstart, 4)}
+    errs = {}
+    for j in range(lv.jstart, 4):
+        for c in range(lv.cb(j) + 1):
+            assert np.array_equal(co.idof[j][c], cd.idof[j][c]), (j, c)
+        errs[f"P{j}"] = rel(rd["P"][j] @ S[j], ro["P"][j])
+        errs[f"Pi{j}"] = rel(S[j] @ Pi[j], ro["Pi"][j])
+        errs[f"M{j}"] = rel(S[j] @ cd.mass(j) @ S[j], co.mass(j))
+        errs[f"T{j}"] = rel(S[j] @ cd.T[j], co.T[j])
+        if j < 3:
+            errs[f"D{j}"] = rel(S[j + 1] @ cd.D[j] @ S[j], co.D[j])
+    assert max(errs.values()) < TOL, errs
+    inv = invariants(lv, rd, Pi=Pi)
+    assert max(inv.values()) < 1e-9, inv
+    return ro, rd, tm
+
+
+@pytest.mark.parametrize("jstart", [2, 1, 0])
+def test_two_tet_levels(derham, jstart):
+    seq = meshgen.Sequence.kuhn_cube(1, 2)
+    lv = seq_level_from_tets(seq.meshes[0], jstart=jstart)
+    _ro, rd, tm = compare(derham, lv, seq.partition(0))
+    if jstart < 2:
+        assert tm[f"extension{jstart}_0_ms"] > 0.0                       # the ridge / peak stage ran on the device
+    compare(derham, rd["coarse"], seq.partition(1))
+
+
+def test_heterogeneous_coefficient_null_dofs(derham):
+    seq = meshgen.Sequence.kuhn_cube(1, 2)
+    rng = np.random.default_rng(3)
+    lv = seq_level_from_tets(seq.meshes[0], jstart=1, kinv=np.exp(2 * rng.standard_normal(seq.meshes[0].nt)))
+    ro, rd, _tm = compare(derham, lv, seq.partition(0))
+    assert ro["n_null"][2] > 0
+    compare(derham, rd["coarse"], seq.partition(1))
+
+
+def test_invariants_on_a_larger_mesh(derham):
+    """kuhn_cube(2) refined twice (3072 elements, 384 agglomerates), all four forms: the device result is checked through
+    the reference's invariants alone (the numpy oracle would take a minute here)."""
+    seq = meshgen.Sequence.kuhn_cube(2, 2)
+    lv = seq_level_from_tets(seq.meshes[0], jstart=0)
+    rd = derham.coarsen(lv, seq.partition(0))
+    inv = invariants(lv, rd, Pi={j: derham.projector(rd, j) for j in range(4)})
+    assert max(inv.values()) < 1e-9, inv
+    for m in seq.meshes:
+        m.build_faces()
+    c = seq.meshes[1]
+    assert [rd["coarse"].ndof(j) for j in range(4)] == [c.nv, c.ne, c.nf, c.nt]
+
+
+def test_amge_h1_spaces_in_the_pcg_solve(derham):
+    """BASELINE configs[1]: the 0-form problem ``A = D0^T M1 D0`` with essential boundary, hierarchy built from the device's
+    AMGe interpolators P_0 (essential columns eliminated as ``ComputeTrueP(jform, ess)`` does): PCG converges like with the
+    nested geometric interpolators."""
+    from parelag_amd import linalg as la
+    seq = meshgen.Sequence.kuhn_cube(2, 2)
+    lv = seq_level_from_tets(seq.meshes[0], jstart=0)
+    Ps, cur = [], lv
+    for l in range(2):
+        r = derham.coarsen(cur, seq.partition(l))
+        Ps.append(r["P"][0])
+        cur = r["coarse"]
+    m = seq.meshes[0]
+    A = meshgen.eliminate_rowcol((lv.D[0].T @ lv.mass(1) @ lv.D[0]).tocsr(), m.boundary_marker_unit_cube())
+    marks = [mm.boundary_marker_unit_cube() for mm in seq.meshes]
+    # coarse vertices are the agglomerated peaks, numbered like the coarse mesh's vertices on derefined tets
+    Pe = [meshgen.eliminate_cols(P, marks[l + 1]) for l, P in enumerate(Ps)]
+    Pg = [meshgen.eliminate_cols(meshgen.interp_P0(seq.meshes[l + 1], seq.meshes[l]), marks[l + 1]) for l in range(2)]
+    b = meshgen.load_vector_P1(m, marks[0])
+    its = []
+    for P_list in (Pe, Pg):
+        dA = la.ParallelCSRMatrix.from_scipy(A)
+        H = la.buildHierarchyFromDeRhamSequence(dA, [la.ParallelCSRMatrix.from_scipy(P) for P in P_list], "L1 Jacobi")
+        K = la.KrylovSolver(dA, H, {"Solver name": "PCG", "Relative tolerance": 1e-8, "Maximum iterations": 100})
+        x = np.zeros_like(b)
+        K.Mult(b, x)
+        assert K.GetConverged()
+        assert np.linalg.norm(A @ x - b) < 1e-6 * np.linalg.norm(b)
+        its.append(K.GetNumIterations())
+    assert abs(its[0] - its[1]) <= 2, its
