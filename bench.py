@@ -242,6 +242,13 @@ def main():
         seq = dar["seq"]
         Ps = dar["Ps"]
         A = sp.bmat([[dar["M"], dar["Bt"]], [dar["B"], None]]).tocsr()
+    elif args.amge:
+        # forms 0 / 2 on AMGe spaces: the whole sequence is coarsened on the device (every rank does the whole mesh; the
+        # distributed builders partition the result like the generator's interpolators)
+        from parelag_amd import derham
+        seq = meshgen.Sequence.cube456(args.refines)
+        A, Ps, Ds, _levels, amge_rec = derham.amge_problem(args.form, seq)
+        note("AMGe coarsening (forms %d..3): %d levels in %.3f s" % (0 if args.form == 0 else 1, len(Ps), amge_rec["coarsen_total_s"]))
     elif args.form == 2:
         A, Ps, Ds, seq = meshgen.hdiv_problem(args.refines)
     else:
@@ -535,6 +542,9 @@ def main():
         })
         if solve is not None:
             out["solve"] = solve
+        if not darcy and args.amge:
+            out["amge"] = amge_rec
+            out["config"]["interpolators"] = amge_rec["what"]
         if darcy and "amge" in dar:
             rec = dar["amge"]
             lv0, parts = rec.pop("level0"), rec.pop("parts")

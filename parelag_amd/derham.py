@@ -485,3 +485,57 @@ def _spgemm_device(A: sp.csr_matrix, B: sp.csr_matrix) -> sp.csr_matrix:
     from . import linalg as la
     out = la.ParallelCSRMatrix.from_scipy(A.tocsr()).matmul(la.ParallelCSRMatrix.from_scipy(B.tocsr())).to_scipy()
     return out.tocsr()
+
+
+# ---- the examples' problems on AMGe spaces --------------------------------------------------------------------------------
+
+def boundary_dofs(lv: SeqLevel, j: int) -> np.ndarray:
+    """Marker of the dofs of form j lying on boundary facets with an attribute (``DofHandler::MarkDofsOnSelectedBndr`` with
+    every attribute selected, ``src/amge/DofHandler.cpp:105-137,812-852``)."""
+    mk = np.zeros(lv.ndof(j), dtype=bool)
+    if lv.cb(j) < 1:
+        return mk
+    ep, ei = _Tables(lv).edof(j, 1)
+    bf = np.nonzero(lv.facet_attr > 0)[0]
+    q, _ = expand_ranges(ep[bf], np.diff(ep)[bf])
+    mk[ei[q]] = True
+    return mk
+
+
+def amge_problem(form: int, seq, timings: dict | None = None):
+    """The operators of MultigridTest0Form / MultigridTest2Form on AMGe spaces built by the device coarsening: fine operator
+    (``D0^T M1 D0`` resp. ``M2 + D2^T M3 D2``) with all boundary attributes essential, the interpolators ``P_form`` of every
+    level with essential columns eliminated (``ComputeTrueP(jform, ess)``, ``src/amge/DeRhamSequence.cpp:1118-1153,1230-1253``)
+    and, for the Hiptmair smoother of the 2-form, the derivative ``D_1`` of every level with essential columns eliminated
+    (``HiptmairSmootherFactory.cpp:84-103``).  Returns (A, Ps, Ds or None, levels, record)."""
+    import time
+    from . import meshgen
+    from .derham_level import seq_level_from_tets
+    t0 = time.time()
+    lv = seq_level_from_tets(seq.meshes[0], jstart=0 if form == 0 else 1)
+    gen_s = time.time() - t0
+    levels, Ps, recs = [lv], [], []
+    t0 = time.time()
+    for l in range(len(seq.meshes) - 1):
+        tm = {}
+        t1 = time.time()
+        res = coarsen(levels[-1], seq.partition(l), timings=tm)
+        c = res["coarse"]
+        recs.append({"agglomerates": c.n[0], "entities": c.n, "dofs": [c.ndof(j) for j in range(c.jstart, 4)],
+                     "wall_s": round(time.time() - t1, 4), "kernel_ms": round(sum(tm.values()), 4)})
+        Ps.append(res["P"][form])
+        levels.append(c)
+    total_s = time.time() - t0
+    marks = [boundary_dofs(L_, form) for L_ in levels]
+    if form == 0:
+        A = (lv.D[0].T @ lv.mass(1) @ lv.D[0]).tocsr()
+        Ds = None
+    else:
+        A = (lv.mass(2) + lv.D[2].T @ lv.mass(3) @ lv.D[2]).tocsr()
+        Ds = [meshgen.eliminate_cols(L_.D[1].tocsr(), boundary_dofs(L_, 1)) for L_ in levels]
+    A.sort_indices()
+    A = meshgen.eliminate_rowcol(A, marks[0])
+    Ps = [meshgen.eliminate_cols(P.tocsr(), marks[l + 1]) for l, P in enumerate(Ps)]
+    rec = {"what": "DeRhamSequence::Coarsen (jformStart=%d) on the device: cube456 x%d tets, derefinement agglomerates" % (lv.jstart, len(seq.meshes) - 1),
+           "levels": recs, "coarsen_total_s": round(total_s, 3), "generate_s": round(gen_s, 2)}
+    return A, Ps, Ds, levels, rec

@@ -8,6 +8,27 @@ from parelag_amd.amge_level import level_from_tets, level_from_hex, box_partitio
 
 kind = sys.argv[1]
 t0 = time.time()
+if kind == "seq":
+    # whole sequence (forms jstart..3) on cube456 x k:  python tools/amge_time.py seq 3 0
+    from parelag_amd import derham
+    from parelag_amd.derham_level import seq_level_from_tets
+    k, js = int(sys.argv[2]), int(sys.argv[3])
+    seq = meshgen.Sequence.cube456(k)
+    lv = seq_level_from_tets(seq.meshes[0], jstart=js)
+    print("generate %.2fs  n=%s dofs=%s" % (time.time() - t0, lv.n, [lv.ndof(j) for j in range(js, 4)]), flush=True)
+    amge.coarsen(level_from_hex((2, 2, 2)), np.zeros(8, np.int32))
+    for rep in range(2):
+        cur = lv
+        for l in range(k):
+            tm = {}
+            t0 = time.time()
+            res = derham.coarsen(cur, seq.partition(l), timings=tm)
+            wall = time.time() - t0
+            c = res["coarse"]
+            print("rep %d level %d: n %s -> %s dofs -> %s  wall %.3fs  kernel ms total %.3f  %s" %
+                  (rep, l, cur.n, c.n, [c.ndof(j) for j in range(js, 4)], wall, sum(tm.values()), {a: round(b, 3) for a, b in tm.items()}), flush=True)
+            cur = c
+    sys.exit(0)
 if kind == "tet":
     k = int(sys.argv[2])
     seq = meshgen.Sequence.cube456(k)
