@@ -380,12 +380,10 @@ def coarsen(lv: SeqLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entr
     return dict(P=P, Pi=Pi, coarse=coarse, topo=topo, n_null=n_null_tot, dofs=cd_)
 
 
-_conn_cache = {}
-
-
 def _coarse_conn(topo, c, c2):
     """Connectivity codim c -> c2 of the coarse topology (``BuildConnectivity``), rows as lists."""
-    key = (id(topo), c, c2)
+    _conn_cache = topo.setdefault("_conn", {})
+    key = (c, c2)
     if key not in _conn_cache:
         from parelag_amd.derham_level import bool_mult
         B = topo["B"]
