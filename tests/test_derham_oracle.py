@@ -107,3 +107,27 @@ def test_product_topology_and_dof_tables_are_bit_exact(seq, jstart):
             assert np.array_equal(np.array(ao["nint"][c]), ap["nint"][c]), (j, c)
         ep, ei = tb.edof(j, 0)
         assert np.array_equal(np.concatenate(lv.entity_dof(j, 0)), ei)
+
+
+def kuhn_boxes(n=4, hetero=True, jstart=0):
+    """n^3 Kuhn cells (6 tets each), agglomerated in 2 x 2 x 2 boxes of cells: 48 tets per agglomerate, not a derefinement --
+    agglomerated facets of 8 triangles, ridges of 2 edges, balls / discs / paths as the lower forms need them."""
+    seq = meshgen.Sequence.kuhn_cube(n, 0)
+    m = seq.meshes[0]
+    cell = np.minimum((m.vertices[m.tets].mean(1) * n).astype(int), n - 1)
+    part = ((cell[:, 0] // 2) * (n // 2) + cell[:, 1] // 2) * (n // 2) + cell[:, 2] // 2
+    kinv = np.exp(np.random.default_rng(5).standard_normal(m.nt)) if hetero else None
+    return seq_level_from_tets(m, jstart=jstart, kinv=kinv), part.astype(np.int64)
+
+
+def test_box_agglomerates_with_heterogeneous_coefficient():
+    lv, part = kuhn_boxes()
+    r0 = od.coarsen(lv, part)
+    assert r0["coarse"].n == [8, 36, 54, 27]
+    assert r0["n_null"][2] == 24 and r0["coarse"].ndof(1) == 54 + 24          # null dofs of form 2 <-> RangeT bubbles of form 1
+    inv = invariants(lv, r0)
+    assert max(inv.values()) < 1e-11, inv
+    r1 = od.coarsen(r0["coarse"], np.zeros(8, dtype=np.int64))                # one agglomerate: the whole cube
+    assert r1["coarse"].n == [1, 6, 12, 8]
+    inv = invariants(r0["coarse"], r1)
+    assert max(inv.values()) < 1e-11, inv

@@ -9,7 +9,7 @@ import scipy.sparse as sp
 from oracle import derham as od
 from parelag_amd import meshgen
 from parelag_amd.derham_level import seq_level_from_tets
-from tests.test_derham_oracle import invariants
+from tests.test_derham_oracle import invariants, kuhn_boxes
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -123,3 +123,13 @@ def test_amge_h1_spaces_in_the_pcg_solve(derham):
         assert np.linalg.norm(A @ x - b) < 1e-6 * np.linalg.norm(b)
         its.append(K.GetNumIterations())
     assert abs(its[0] - its[1]) <= 2, its
+
+
+def test_box_agglomerates_of_48_tets(derham):
+    """Non-nested agglomerates (2 x 2 x 2 Kuhn cells), heterogeneous coefficient: null-space dofs, RangeT bubbles of the
+    1-forms, local systems beyond the LDS budget (global scratch) in both extension modes; then the whole cube as one
+    agglomerate."""
+    lv, part = kuhn_boxes()
+    ro, rd, _tm = compare(derham, lv, part)
+    assert ro["n_null"][2] == 24
+    compare(derham, rd["coarse"], np.zeros(8, dtype=np.int64))
