@@ -16,6 +16,7 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <functional>
 
 namespace elag {
@@ -43,12 +44,60 @@ __device__ inline void zero_fill(double *p, int n)
     for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.0;
 }
 
-// M (n x n row-major) = sum of the entity's blocks, added block after block (deterministic order)
+// M (n x n row-major) = sum of the entity's blocks, added block after block (deterministic order).
+// Fast path (one wave per workgroup, blocks of at most 64 entries -- every finest level and most coarse ones): the
+// descriptors of eight blocks are fetched by eight lanes and broadcast, the eight blocks' values and index pairs are
+// requested together, then added in block order by plain LDS read-modify-writes (a single wave executes its LDS operations
+// in order, so no barrier is needed and the summation order stays the sequential one).  The general path pays one global
+// round trip and one barrier per block.
 __device__ void assemble_blocks(double *M, int n, const AsmDev &A, int e)
 {
     zero_fill(M, n * n);
     __syncthreads();
-    for (int64_t t = A.asm_ptr[e]; t < A.asm_ptr[e + 1]; t++) {
+    const int64_t t0 = A.asm_ptr[e], t1 = A.asm_ptr[e + 1];
+    if (blockDim.x == 64) {
+        const int lane = threadIdx.x;
+        for (int64_t tb = t0; tb < t1; tb += 8) {
+            int my_m = 0;
+            int64_t my_bo = 0, my_lo = 0;
+            if (lane < 8 && tb + lane < t1) { my_m = A.blk_n[tb + lane]; my_bo = A.blk_off[tb + lane]; my_lo = A.loc_off[tb + lane]; }
+            // all blocks of this chunk small?  (uniform decision)
+            const int big = __any(my_m * my_m > 64);
+            if (!big) {
+                double v[8];
+                int pos[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int m = __shfl(my_m, u, 64);
+                    const int64_t bo = __shfl(my_bo, u, 64);
+                    const int64_t lo = __shfl(my_lo, u, 64);
+                    pos[u] = -1;
+                    v[u] = 0.0;
+                    if (lane < m * m) {
+                        const int r = lane / m, c = lane - r * m;
+                        v[u] = A.blocks[bo + lane];
+                        pos[u] = A.loc_idx[lo + r] * n + A.loc_idx[lo + c];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (pos[u] >= 0) M[pos[u]] += v[u];
+            } else {
+                for (int u = 0; u < 8 && tb + u < t1; u++) {
+                    const int m = __shfl(my_m, u, 64);
+                    const double *b = A.blocks + __shfl(my_bo, u, 64);
+                    const int *li = A.loc_idx + __shfl(my_lo, u, 64);
+                    for (int i = lane; i < m * m; i += 64) {
+                        const int r = i / m, c = i - r * m;
+                        M[li[r] * n + li[c]] += b[i];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    for (int64_t t = t0; t < t1; t++) {
         const int m = A.blk_n[t];
         const double *b = A.blocks + A.blk_off[t];
         const int *li = A.loc_idx + A.loc_off[t];
@@ -241,12 +290,6 @@ struct TracesArgs {
     int *singular;
 };
 
-__device__ inline int64_t traces_ws_need(int n, int k0)
-{
-    const int kc = 1 + k0;
-    return (int64_t)n * n + 2 * (int64_t)n * k0 + 2 * n + 2 * (int64_t)n * kc + (int64_t)kc * (kc + n);
-}
-
 __global__ void coarsen_traces_kernel(TracesArgs a)
 {
     extern __shared__ double dyn[];
@@ -322,6 +365,7 @@ __global__ void coarsen_traces_kernel(TracesArgs a)
 struct ExtArgs {
     int n_ent, nT, mode;          // mode 0: FacetSaddlePoint (PV multiplier row), 1: RidgePeakSaddlePoint ([M B^T; B -C])
     int null_dofs;                // 0: no null-space dofs are built (the "peak" stage of the 0-forms)
+    int debug_stop;               // diagnostic: leave the kernel after phase k (ELAG_HIP_AMGE_STOP), 0 = run everything
     double svd_tol, smallest_entry;
     const int *nu, *ni, *np, *npi, *nq, *next, *nrt;
     AsmDev mass_u, mass_p, mass_q;
@@ -383,6 +427,7 @@ __global__ void coarsen_extension_kernel(ExtArgs a)
         zero_fill(D2l, nq * np);
     }
     __syncthreads();
+    if (a.debug_stop == 1) return;
     for (int64_t t = a.d_ptr[e] + threadIdx.x; t < a.d_ptr[e + 1]; t += blockDim.x) Dl[a.d_row[t] * nu + a.d_col[t]] = a.d_val[t];
     if (a.mode)
         for (int64_t t = a.d2_ptr[e] + threadIdx.x; t < a.d2_ptr[e + 1]; t += blockDim.x) D2l[a.d2_row[t] * np + a.d2_col[t]] = a.d2_val[t];
@@ -454,7 +499,9 @@ __global__ void coarsen_extension_kernel(ExtArgs a)
         K[r * m + n + next + nrt + c] = s;
     }
     __syncthreads();
+    if (a.debug_stop == 2) return;
     int bad = solve ? gauss_solve(K, n, m, sh.piv) : 0;
+    if (a.debug_stop == 3) return;
     if (bad) {
         if (threadIdx.x == 0) { atomicAdd(a.singular, 1); a.n_null[e] = 0; }
         return;
@@ -488,6 +535,7 @@ __global__ void coarsen_extension_kernel(ExtArgs a)
         __syncthreads();
         knull = sh.cnt;
     }
+    if (a.debug_stop == 4) return;
     double *onul = a.nul + a.off_nul[e];
     for (int t = threadIdx.x; t < ni * a.nT; t += blockDim.x) {
         const int c = t / ni, i = t - c * ni;
@@ -519,6 +567,7 @@ __global__ void coarsen_extension_kernel(ExtArgs a)
         ocm[r * ncolmax + c] = v;
         ocm[c * ncolmax + r] = v;
     }
+    if (a.debug_stop == 5) return;
     // cochain projector functional of the interior dofs: [RangeT | null] in the M_ii inner product (:2530-2538)
     double *ofun = a.functional + a.off_fun[e];
     for (int t = threadIdx.x; t < kfmax * ni; t += blockDim.x) ofun[t] = 0.0;
@@ -732,7 +781,7 @@ ELAG_HIP_API int elag_hip_coarsen_extension(const elag_hip_coarsen_extension_in 
             d_cm((size_t)o_cm[ne]), d_gws((size_t)pl.gws_total);
         ELAG_HIP_CHECK(hipMemsetAsync(d_sing.p, 0, sizeof(int), st));
         ExtArgs a{};
-        a.n_ent = ne; a.nT = nT; a.mode = mode; a.null_dofs = in->null_dofs; a.svd_tol = in->svd_tol; a.smallest_entry = in->smallest_entry;
+        a.n_ent = ne; a.nT = nT; a.mode = mode; a.null_dofs = in->null_dofs; a.debug_stop = getenv("ELAG_HIP_AMGE_STOP") ? atoi(getenv("ELAG_HIP_AMGE_STOP")) : 0; a.svd_tol = in->svd_tol; a.smallest_entry = in->smallest_entry;
         a.nu = d_nu; a.ni = d_ni; a.np = d_np; a.npi = d_npi; a.nq = d_nq; a.next = d_nx; a.nrt = d_nrt; a.mass_u = mu.dev; a.mass_p = mp.dev; a.mass_q = mq.dev;
         a.d2_ptr = d_d2ptr; a.d2_row = d_d2row; a.d2_col = d_d2col; a.d2_val = d_d2val; a.PDc = d_PDc; a.off_PDc = f_PDc;
         a.d_ptr = d_dptr; a.d_row = d_drow; a.d_col = d_dcol; a.d_val = d_dval;
