@@ -21,37 +21,7 @@ from . import _lib
 from .amge import (EPS, _Assembly, _ExtIn, _ExtOut, _Keep, _TracesIn, _TracesOut, _assembly, _blocks_to_csr, _first_touch_groups,
                    _join_cols, _pack_cols, _ptr, _spmm_device, _take_leading, _take_leading_rows, expand_ranges)
 from .amge_level import ptr_from_counts
-from .derham_level import SeqLevel
-
-
-# ---- ragged-row primitives ------------------------------------------------------------------------------------------------
-
-def _product(a_ptr, a_idx, b_ptr, b_idx, a_sgn=None, b_sgn=None):
-    """Row-by-row product of two ragged tables, columns in first-touch order (``mfem::Mult``).  With signs: the signed sum
-    per column, cancelled entries dropped, reduced to the sign (``MultOrientation``, ``TopologyTable.cpp:130-139``)."""
-    nrow = len(a_ptr) - 1
-    cnt = np.diff(b_ptr)[a_idx]
-    q, own = expand_ranges(b_ptr[a_idx], cnt)
-    row = np.repeat(np.arange(nrow, dtype=np.int64), np.diff(a_ptr))[own]
-    val = np.ones(q.size) if a_sgn is None else a_sgn[own] * b_sgn[q]
-    r, c, s = _first_touch_groups(row, b_idx[q].astype(np.int64), val)
-    if a_sgn is not None:
-        keep = np.abs(s) > 1e-10
-        r, c, s = r[keep], c[keep], np.sign(s[keep])
-    return ptr_from_counts(np.bincount(r, minlength=nrow)), c, s
-
-
-def _concat_rows(tables, nrow):
-    """Row-wise concatenation of ragged tables [(ptr, idx), ...] in the given order."""
-    cnts = [np.diff(p) for p, _ in tables]
-    ptr = ptr_from_counts(sum(cnts))
-    out = np.empty(int(ptr[-1]), dtype=np.int64)
-    off = ptr[:-1].copy()
-    for (p, i), cn in zip(tables, cnts):
-        pos, own = expand_ranges(off, cn)
-        out[pos] = i
-        off = off + cn
-    return ptr, out
+from .derham_level import SeqLevel, _Tables, _concat_rows, _product
 
 
 class _Lookup:
@@ -144,46 +114,6 @@ def coarsen_topology(lv: SeqLevel, part: np.ndarray) -> dict:
 
 
 # ---- dof tables ---------------------------------------------------------------------------------------------------------------
-
-class _Tables:
-    """Vectorised ``entity_dof`` tables of a level and the agglomerated rows built from them."""
-
-    def __init__(self, lv: SeqLevel):
-        self.lv = lv
-        self._conn, self._edof = {}, {}
-
-    def conn(self, c, c2):
-        if (c, c2) not in self._conn:
-            B = self.lv.B
-            if c2 == c + 1:
-                self._conn[(c, c2)] = (B[c][0], B[c][1])
-            elif (c, c2) == (0, 3):
-                p, i = self.conn(0, 2)
-                self._conn[(c, c2)] = _product(p, i, B[2][0], B[2][1])[:2]
-            else:
-                self._conn[(c, c2)] = _product(B[c][0], B[c][1], B[c + 1][0], B[c + 1][1])[:2]
-        return self._conn[(c, c2)]
-
-    def edof(self, j, c):
-        """(ptr, idx) of ``entity_dof[c]`` of form j: peaks', ridges', facets' dofs in connectivity order, then interior."""
-        if (j, c) not in self._edof:
-            lv = self.lv
-            cb = lv.cb(j)
-            tabs = []
-            for c2 in range(3, c, -1):
-                if c2 > cb:
-                    continue
-                p, i = self.conn(c, c2)
-                ip = lv.idof[j][c2]
-                d, own = expand_ranges(lv.base(j, c2) + ip[i], np.diff(ip)[i])
-                cnt = np.bincount(np.repeat(np.arange(len(p) - 1, dtype=np.int64), np.diff(p))[own], minlength=len(p) - 1)
-                tabs.append((ptr_from_counts(cnt), d))
-            ip = lv.idof[j][c]
-            d, _ = expand_ranges(lv.base(j, c) + ip[:-1], np.diff(ip))
-            tabs.append((ip.astype(np.int64), d))
-            self._edof[(j, c)] = _concat_rows(tabs, lv.n[c])
-        return self._edof[(j, c)]
-
 
 def agglomerate_dofs(lv: SeqLevel, tb: _Tables, topo: dict, j: int) -> dict:
     """``DofAgglomeration`` of form j for every codimension: rows (ptr, dofs), interior counts, separator types."""

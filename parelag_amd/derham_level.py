@@ -17,7 +17,7 @@ from dataclasses import dataclass, field
 import numpy as np
 import scipy.sparse as sp
 
-from .amge_level import _unit_cube_attr, ptr_from_counts
+from .amge_level import _block_rc, _unit_cube_attr, ptr_from_counts
 
 NFORMS = 4
 
@@ -33,6 +33,82 @@ def bool_mult(a_ptr, a_idx, b_ptr, b_idx):
         out_idx.extend(seen.keys())
         out_ptr.append(len(out_idx))
     return np.array(out_ptr, dtype=np.int64), np.array(out_idx, dtype=np.int64)
+
+
+def _amge_helpers():
+    from . import amge
+    return amge.expand_ranges, amge._first_touch_groups
+
+
+def _product(a_ptr, a_idx, b_ptr, b_idx, a_sgn=None, b_sgn=None):
+    """Row-by-row product of two ragged tables, columns in first-touch order (``mfem::Mult``).  With signs: the signed sum
+    per column, cancelled entries dropped, reduced to the sign (``MultOrientation``, ``TopologyTable.cpp:130-139``)."""
+    expand_ranges, _first_touch_groups = _amge_helpers()
+    nrow = len(a_ptr) - 1
+    cnt = np.diff(b_ptr)[a_idx]
+    q, own = expand_ranges(b_ptr[a_idx], cnt)
+    row = np.repeat(np.arange(nrow, dtype=np.int64), np.diff(a_ptr))[own]
+    val = np.ones(q.size) if a_sgn is None else a_sgn[own] * b_sgn[q]
+    r, c, s = _first_touch_groups(row, b_idx[q].astype(np.int64), val)
+    if a_sgn is not None:
+        keep = np.abs(s) > 1e-10
+        r, c, s = r[keep], c[keep], np.sign(s[keep])
+    return ptr_from_counts(np.bincount(r, minlength=nrow)), c, s
+
+
+def _concat_rows(tables, nrow):
+    """Row-wise concatenation of ragged tables [(ptr, idx), ...] in the given order."""
+    expand_ranges, _ = _amge_helpers()
+    cnts = [np.diff(p) for p, _ in tables]
+    ptr = ptr_from_counts(sum(cnts))
+    out = np.empty(int(ptr[-1]), dtype=np.int64)
+    off = ptr[:-1].copy()
+    for (p, i), cn in zip(tables, cnts):
+        pos, own = expand_ranges(off, cn)
+        out[pos] = i
+        off = off + cn
+    return ptr, out
+
+
+class _Tables:
+    """Vectorised ``entity_dof`` tables of a level and the agglomerated rows built from them."""
+
+    def __init__(self, lv: SeqLevel):
+        self.lv = lv
+        self._conn, self._edof = {}, {}
+
+    def conn(self, c, c2):
+        if (c, c2) not in self._conn:
+            B = self.lv.B
+            if c2 == c + 1:
+                self._conn[(c, c2)] = (B[c][0], B[c][1])
+            elif (c, c2) == (0, 3):
+                p, i = self.conn(0, 2)
+                self._conn[(c, c2)] = _product(p, i, B[2][0], B[2][1])[:2]
+            else:
+                self._conn[(c, c2)] = _product(B[c][0], B[c][1], B[c + 1][0], B[c + 1][1])[:2]
+        return self._conn[(c, c2)]
+
+    def edof(self, j, c):
+        """(ptr, idx) of ``entity_dof[c]`` of form j: peaks', ridges', facets' dofs in connectivity order, then interior."""
+        if (j, c) not in self._edof:
+            expand_ranges, _ = _amge_helpers()
+            lv = self.lv
+            cb = lv.cb(j)
+            tabs = []
+            for c2 in range(3, c, -1):
+                if c2 > cb:
+                    continue
+                p, i = self.conn(c, c2)
+                ip = lv.idof[j][c2]
+                d, own = expand_ranges(lv.base(j, c2) + ip[i], np.diff(ip)[i])
+                cnt = np.bincount(np.repeat(np.arange(len(p) - 1, dtype=np.int64), np.diff(p))[own], minlength=len(p) - 1)
+                tabs.append((ptr_from_counts(cnt), d))
+            ip = lv.idof[j][c]
+            d, _ = expand_ranges(lv.base(j, c) + ip[:-1], np.diff(ip))
+            tabs.append((ip.astype(np.int64), d))
+            self._edof[(j, c)] = _concat_rows(tabs, lv.n[c])
+        return self._edof[(j, c)]
 
 
 @dataclass
@@ -105,12 +181,9 @@ class SeqLevel:
 
     def mass(self, j, c=0):
         """Assembled mass of form j from the codim-c blocks (``ComputeMassOperator`` for c = 0)."""
-        ed = self.entity_dof(j, c)
-        r, cc, v = [], [], []
-        for e in range(self.n[c]):
-            d = ed[e]
-            r.append(np.repeat(d, d.size)); cc.append(np.tile(d, d.size)); v.append(self.block(j, c, e).reshape(-1))
-        M = sp.csr_matrix((np.concatenate(v), (np.concatenate(r), np.concatenate(cc))), shape=(self.ndof(j), self.ndof(j)))
+        ep, ei = _Tables(self).edof(j, c)
+        lr, lc = _block_rc(ep[:-1], np.diff(ep))
+        M = sp.csr_matrix((self.M[j][c][1], (ei[lr], ei[lc])), shape=(self.ndof(j), self.ndof(j)))
         M.sum_duplicates(); M.sort_indices()
         return M
 
@@ -176,7 +249,7 @@ def seq_level_from_tets(mesh, jstart: int = 0, kinv: np.ndarray | None = None, b
         i_, j_ = _LE[:, 0], _LE[:, 1]
         ik = I4[np.ix_(i_, i_)]; il = I4[np.ix_(i_, j_)]; jk = I4[np.ix_(j_, i_)]; jl = I4[np.ix_(j_, j_)]
         loc1 = (ik[None] * G[:, j_][:, :, j_] - il[None] * G[:, j_][:, :, i_] - jk[None] * G[:, i_][:, :, j_] + jl[None] * G[:, i_][:, :, i_]) * vol[:, None, None]
-        p02, i02 = lv.conn(0, 2)
+        p02, i02 = _Tables(lv).conn(0, 2)
         assert np.all(np.diff(p02) == 6)
         loc1 = _reorder_blocks(loc1, mesh.tet_edges, i02.reshape(T, 6))
         # facet mass of the tangential trace: 2-D Whitney 1-forms on the triangle (ND_3D_FacetMassIntegrator)
@@ -193,7 +266,7 @@ def seq_level_from_tets(mesh, jstart: int = 0, kinv: np.ndarray | None = None, b
         lv.D[1] = sp.csr_matrix((B1[2], B1[1], B1[0]), shape=(F, E))
         lv.T[1] = ev.copy(); lv.pv[1] = elen.copy()
     if jstart <= 0:
-        p03, i03 = lv.conn(0, 3)
+        p03, i03 = _Tables(lv).conn(0, 3)
         assert np.all(np.diff(p03) == 4)
         loc0 = np.broadcast_to(I4[None], (T, 4, 4)) * vol[:, None, None]
         loc0 = _reorder_blocks(loc0, mesh.stets, i03.reshape(T, 4))      # (symmetric under permutation, kept for clarity)

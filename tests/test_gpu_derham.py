@@ -133,3 +133,16 @@ def test_box_agglomerates_of_48_tets(derham):
     ro, rd, _tm = compare(derham, lv, part)
     assert ro["n_null"][2] == 24
     compare(derham, rd["coarse"], np.zeros(8, dtype=np.int64))
+
+
+def test_full_size_cube456_x3_all_forms(derham):
+    """BASELINE's size (cube456 refined three times: 233 472 elements, 29 184 agglomerates on level 0), all four forms, checked
+    through the size-independent properties the reference itself checks (``CheckInvariants``): commutation, exactness of the
+    coarse complex, Galerkin masses, ``Pi P = I``, targets in the coarse spaces."""
+    seq = meshgen.Sequence.cube456(3)
+    lv = seq_level_from_tets(seq.meshes[0], jstart=0)
+    rd = derham.coarsen(lv, seq.partition(0))
+    c = rd["coarse"]
+    assert c.n == [29184, 60016, 36570, 5739] and [c.ndof(j) for j in range(4)] == [5739, 36570, 60016, 29184]
+    inv = invariants(lv, rd, Pi={j: derham.projector(rd, j) for j in range(4)})
+    assert max(inv.values()) < 1e-9, inv
