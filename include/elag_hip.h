@@ -405,7 +405,8 @@ ELAG_HIP_API int elag_hip_hierarchy_build_blocked(elag_hip_hierarchy_t *out, ela
  * from the zero guess (KrylovSolver.cpp:79-83 sets iterative_mode = false on it).  A and the preconditioner are
  * borrowed.  For a blocked system pass elag_hip_blockop_monolithic(B) as A.
  * ------------------------------------------------------------------------------------------------ */
-enum { ELAG_HIP_KRYLOV_CG = 0, ELAG_HIP_KRYLOV_GMRES = 1, ELAG_HIP_KRYLOV_FGMRES = 2, ELAG_HIP_KRYLOV_STATIONARY = 3 };
+enum { ELAG_HIP_KRYLOV_CG = 0, ELAG_HIP_KRYLOV_GMRES = 1, ELAG_HIP_KRYLOV_FGMRES = 2, ELAG_HIP_KRYLOV_STATIONARY = 3,
+       ELAG_HIP_KRYLOV_BICGSTAB = 4, ELAG_HIP_KRYLOV_MINRES = 5 };   /* "BICGSTAB", "MINRES": KrylovSolver.cpp:39-42 */
 enum { ELAG_HIP_PREC_NONE = 0, ELAG_HIP_PREC_SMOOTHER = 1, ELAG_HIP_PREC_HIERARCHY = 2, ELAG_HIP_PREC_COARSE = 3 };
 typedef struct {
     int solver;        /* ELAG_HIP_KRYLOV_*  ("Solver name")                       */

@@ -882,6 +882,120 @@ def mfem_gmres(A_mul, prec, b, x, iterative_mode=False, rel_tol=0.0, abs_tol=0.0
     return KrylovResult(0, max_iter, beta)
 
 
+def mfem_bicgstab(A_mul, prec, b, x, iterative_mode=False, rel_tol=0.0, abs_tol=0.0, max_iter=10, dot=np.dot):
+    """mfem::BiCGSTABSolver::Mult (MFEM 4.x linalg/solvers.cpp [3P], "p. 27 of the SIAM Templates book"; selected by
+    ``KrylovSolver.cpp:39-40``), statement by statement."""
+    b = _f64(b)
+    if iterative_mode:
+        r = b - A_mul(x)
+    else:
+        x[:] = 0.0; r = b.copy()
+    rtilde = r.copy()
+    resid = np.sqrt(dot(r, r))
+    tol_goal = max(resid * rel_tol, abs_tol)
+    if resid <= tol_goal:
+        return KrylovResult(1, 0, resid)
+    rho_2 = alpha = omega = 1.0
+    p = v = None
+    for i in range(1, max_iter + 1):
+        rho_1 = dot(rtilde, r)
+        if rho_1 == 0.0:
+            return KrylovResult(0, i, resid)
+        if i == 1:
+            p = r.copy()
+        else:
+            beta = (rho_1 / rho_2) * (alpha / omega)
+            p = p + (-omega) * v
+            p = r + beta * p
+        if prec is not None:
+            phat = np.zeros_like(p); prec(p, phat)
+        else:
+            phat = p.copy()
+        v = A_mul(phat)
+        alpha = rho_1 / dot(rtilde, v)
+        s = r + (-alpha) * v
+        resid = np.sqrt(dot(s, s))
+        if resid < tol_goal:
+            x += alpha * phat
+            return KrylovResult(1, i, resid)
+        if prec is not None:
+            shat = np.zeros_like(s); prec(s, shat)
+        else:
+            shat = s.copy()
+        t = A_mul(shat)
+        omega = dot(t, s) / dot(t, t)
+        x += alpha * phat
+        x += omega * shat
+        r = s + (-omega) * t
+        rho_2 = rho_1
+        resid = np.sqrt(dot(r, r))
+        if resid < tol_goal:
+            return KrylovResult(1, i, resid)
+        if omega == 0.0:
+            return KrylovResult(0, i, resid)
+    return KrylovResult(0, max_iter, resid)
+
+
+def mfem_minres(A_mul, prec, b, x, iterative_mode=False, rel_tol=0.0, abs_tol=0.0, max_iter=10, dot=np.dot):
+    """mfem::MINRESSolver::Mult (MFEM 4.x linalg/solvers.cpp [3P]: van der Vorst, "Iterative Krylov Methods for Large Linear
+    Systems", Fig. 6.9, extended to an SPD preconditioner; selected by ``KrylovSolver.cpp:41-42``), statement by statement."""
+    b = _f64(b)
+    if not iterative_mode:
+        v1 = b.copy(); x[:] = 0.0
+    else:
+        v1 = b - A_mul(x)
+    u1 = None
+    if prec is not None:
+        u1 = np.zeros_like(v1); prec(v1, u1)
+    z = lambda: u1 if prec is not None else v1
+    eta = beta = np.sqrt(dot(z(), v1))
+    gamma0 = gamma1 = 1.0
+    sigma0 = sigma1 = 0.0
+    norm_goal = max(rel_tol * eta, abs_tol)
+    if eta <= norm_goal:
+        return KrylovResult(1, 0, abs(eta))
+    v0 = np.zeros_like(v1); w0 = np.zeros_like(v1); w1 = np.zeros_like(v1)
+    for it in range(1, max_iter + 1):
+        m = 1.0 / beta
+        v1 = v1 * m
+        if prec is not None:
+            u1 = u1 * m
+        q = A_mul(z())
+        alpha = dot(z(), q)
+        if it > 1:
+            q = q + (-beta) * v0
+        v0 = q + (-alpha) * v1
+        delta = gamma1 * alpha - gamma0 * sigma1 * beta
+        rho3 = sigma0 * beta
+        rho2 = sigma1 * alpha + gamma0 * gamma1 * beta
+        if prec is None:
+            beta = np.sqrt(dot(v0, v0))
+        else:
+            q = np.zeros_like(v0); prec(v0, q)
+            beta = np.sqrt(dot(v0, q))
+        rho1 = np.hypot(delta, beta)
+        if it == 1:
+            w0 = (1.0 / rho1) * z()
+        elif it == 2:
+            w0 = (1.0 / rho1) * z() + (-rho2 / rho1) * w1
+        else:
+            w0 = (-rho3 / rho1) * w0 + (-rho2 / rho1) * w1
+            w0 = w0 + (1.0 / rho1) * z()
+        gamma0 = gamma1
+        gamma1 = delta / rho1
+        x += (gamma1 * eta) * w0
+        sigma0 = sigma1
+        sigma1 = beta / rho1
+        eta = -sigma1 * eta
+        if abs(eta) <= norm_goal:
+            return KrylovResult(1, it, abs(eta))
+        if prec is not None:
+            u1, q = q, u1
+        v0, v1 = v1, v0
+        w0, w1 = w1, w0
+    return KrylovResult(0, max_iter, abs(eta))
+
+
 def stationary_solver(A_mul, solver, b, x, iterative_mode=False, rel_tol=0.0, abs_tol=0.0, max_iter=1, dot=np.dot):
     """StationarySolver::Mult (src/linalg/solver_ops/ParELAG_StationarySolver.cpp:41-130)."""
     b = _f64(b)

@@ -27,7 +27,10 @@ namespace {
 constexpr int kB = 256;
 inline unsigned g1(long long n) { return (unsigned)std::max<long long>(1, (n + kB - 1) / kB); }
 
-enum { S_NOM, S_DEN, S_BETANOM, S_R0, S_ALPHA, S_BETA, S_TMP, S_FINAL_NORM, S_GBETA, S_THRESH, S_NORMK1, S_RATIO, S_COUNT = 16 };
+enum { S_NOM, S_DEN, S_BETANOM, S_R0, S_ALPHA, S_BETA, S_TMP, S_FINAL_NORM, S_GBETA, S_THRESH, S_NORMK1, S_RATIO,
+       // BiCGSTAB / MINRES recurrences
+       S_RHO1, S_RHO2, S_OMEGA, S_RESID, S_GOAL, S_TS, S_ETA, S_GAMMA0, S_GAMMA1, S_SIGMA0, S_SIGMA1, S_DELTA, S_MRHO1, S_MRHO2, S_MRHO3,
+       S_C0, S_C1, S_C2, S_COUNT = 40 };
 enum { F_DONE, F_CONVERGED, F_FINAL_ITER, F_ITER, F_PENDING, F_ITER2, F_COUNT = 8 };
 
 struct KState {
@@ -330,6 +333,144 @@ __global__ void gmres_restart_norm_kernel(KState *st, int j)
     if (beta <= st->sc[S_THRESH]) { st->fl[F_FINAL_ITER] = j; st->fl[F_CONVERGED] = 1; st->fl[F_DONE] = 1; }
 }
 
+// ---- generic predicated vector kernels for the two solvers below ---------------------------------------------------------
+// coefficient: slot < 0 -> 1.0, otherwise sign * st->sc[slot]
+__device__ inline double kcoef(const KState *st, int slot, double sign) { return slot < 0 ? sign : sign * st->sc[slot]; }
+// out = ca * x + cb * y   (out may alias x or y); pending_id > 0: also runs for the step that set F_PENDING to it
+__global__ void lin2_kernel(int n, const KState *__restrict__ st, int pending_id, int sa, double sga, const double *x, int sb, double sgb, const double *y,
+                            double *out)
+{
+    if (st->fl[F_DONE] && !(pending_id > 0 && st->fl[F_PENDING] == pending_id)) return;
+    const double ca = kcoef(st, sa, sga), cb = kcoef(st, sb, sgb);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (x ? ca * x[i] : 0.0) + cb * y[i];
+}
+// out = x + ca * y  (exactly mfem's add(x, a, y, out) / Vector::Add: no product on the first operand)
+__global__ void axpy_kernel(int n, const KState *__restrict__ st, int pending_id, const double *x, int sa, double sga, const double *y, double *out)
+{
+    if (st->fl[F_DONE] && !(pending_id > 0 && st->fl[F_PENDING] == pending_id)) return;
+    const double ca = kcoef(st, sa, sga);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[i] + ca * y[i];
+}
+// p = r + beta (p - omega v)   (BiCGSTAB: add(p, -omega, v, p); add(r, beta, p, p))
+__global__ void bicg_p_kernel(int n, const KState *__restrict__ st, const double *__restrict__ r, const double *__restrict__ v, double *__restrict__ p)
+{
+    if (st->fl[F_DONE]) return;
+    const double beta = st->sc[S_BETA], momega = -st->sc[S_OMEGA];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const double t = p[i] + momega * v[i]; p[i] = r[i] + beta * t; }
+}
+// dst = src * (1 / sc[slot])     (mfem Vector::operator/=)
+__global__ void scale_recip_kernel(int n, const KState *__restrict__ st, int slot, double *__restrict__ v)
+{
+    if (st->fl[F_DONE]) return;
+    const double m = 1.0 / st->sc[slot];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = v[i] * m;
+}
+__global__ void copy_pred_kernel(int n, const KState *__restrict__ st, const double *__restrict__ src, double *__restrict__ dst)
+{
+    if (st->fl[F_DONE]) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// ---- BiCGSTAB scalar kernels (mfem::BiCGSTABSolver::Mult) ------------------------------------------------------------------
+__global__ void bicg_init_kernel(KState *st, double rel_tol, double abs_tol, int max_iter)
+{
+    const double resid = sqrt(st->sc[S_TMP]);
+    st->sc[S_RESID] = resid; st->sc[S_FINAL_NORM] = resid;
+    st->sc[S_GOAL] = fmax(resid * rel_tol, abs_tol);
+    st->sc[S_RHO2] = 1.0; st->sc[S_ALPHA] = 1.0; st->sc[S_OMEGA] = 1.0;
+    st->fl[F_DONE] = 0; st->fl[F_CONVERGED] = 0; st->fl[F_FINAL_ITER] = max_iter; st->fl[F_PENDING] = 0;
+    if (resid <= st->sc[S_GOAL]) { st->fl[F_DONE] = 1; st->fl[F_CONVERGED] = 1; st->fl[F_FINAL_ITER] = 0; }
+}
+__global__ void bicg_rho_kernel(KState *st, int i)
+{
+    if (st->fl[F_DONE]) return;
+    const double rho1 = st->sc[S_TMP];
+    st->sc[S_RHO1] = rho1;
+    if (rho1 == 0.0) { st->fl[F_DONE] = 1; st->fl[F_CONVERGED] = 0; st->fl[F_FINAL_ITER] = i; return; }
+    if (i > 1) st->sc[S_BETA] = (rho1 / st->sc[S_RHO2]) * (st->sc[S_ALPHA] / st->sc[S_OMEGA]);
+}
+__global__ void bicg_alpha_kernel(KState *st)
+{
+    if (st->fl[F_DONE]) return;
+    st->sc[S_ALPHA] = st->sc[S_RHO1] / st->sc[S_TMP];
+}
+// resid = |s|; converged in the middle of the step: x += alpha phat still has to run (F_PENDING = id)
+__global__ void bicg_mid_kernel(KState *st, int i, int id)
+{
+    if (st->fl[F_DONE]) return;
+    const double resid = sqrt(st->sc[S_TMP]);
+    st->sc[S_RESID] = resid; st->sc[S_FINAL_NORM] = resid;
+    if (resid < st->sc[S_GOAL]) { st->fl[F_DONE] = 1; st->fl[F_CONVERGED] = 1; st->fl[F_FINAL_ITER] = i; st->fl[F_PENDING] = id; }
+}
+__global__ void bicg_ts_kernel(KState *st)
+{
+    if (st->fl[F_DONE]) return;
+    st->sc[S_TS] = st->sc[S_TMP];
+}
+__global__ void bicg_omega_kernel(KState *st)
+{
+    if (st->fl[F_DONE]) return;
+    st->sc[S_OMEGA] = st->sc[S_TS] / st->sc[S_TMP];
+}
+__global__ void bicg_end_kernel(KState *st, int i)
+{
+    if (st->fl[F_DONE]) return;
+    st->sc[S_RHO2] = st->sc[S_RHO1];
+    const double resid = sqrt(st->sc[S_TMP]);
+    st->sc[S_RESID] = resid; st->sc[S_FINAL_NORM] = resid;
+    if (resid < st->sc[S_GOAL]) { st->fl[F_DONE] = 1; st->fl[F_CONVERGED] = 1; st->fl[F_FINAL_ITER] = i; return; }
+    if (st->sc[S_OMEGA] == 0.0) { st->fl[F_DONE] = 1; st->fl[F_CONVERGED] = 0; st->fl[F_FINAL_ITER] = i; }
+}
+
+// ---- MINRES scalar kernels (mfem::MINRESSolver::Mult) ----------------------------------------------------------------------
+__global__ void minres_init_kernel(KState *st, double rel_tol, double abs_tol, int max_iter)
+{
+    const double eta = sqrt(st->sc[S_TMP]);
+    st->sc[S_ETA] = eta; st->sc[S_BETA] = eta;
+    st->sc[S_GAMMA0] = 1.0; st->sc[S_GAMMA1] = 1.0; st->sc[S_SIGMA0] = 0.0; st->sc[S_SIGMA1] = 0.0;
+    st->sc[S_GOAL] = fmax(rel_tol * eta, abs_tol);
+    st->sc[S_FINAL_NORM] = fabs(eta);
+    st->fl[F_DONE] = 0; st->fl[F_CONVERGED] = 0; st->fl[F_FINAL_ITER] = max_iter; st->fl[F_PENDING] = 0;
+    if (eta <= st->sc[S_GOAL]) { st->fl[F_DONE] = 1; st->fl[F_CONVERGED] = 1; st->fl[F_FINAL_ITER] = 0; }
+}
+__global__ void minres_alpha_kernel(KState *st)
+{
+    if (st->fl[F_DONE]) return;
+    st->sc[S_ALPHA] = st->sc[S_TMP];
+}
+// delta, rho3, rho2 from the OLD beta; then beta = sqrt(TMP), rho1, the w-update coefficients, gamma, x-update coefficient
+__global__ void minres_beta_kernel(KState *st)
+{
+    if (st->fl[F_DONE]) return;
+    const double alpha = st->sc[S_ALPHA], beta_old = st->sc[S_BETA];
+    const double gamma0 = st->sc[S_GAMMA0], gamma1 = st->sc[S_GAMMA1], sigma0 = st->sc[S_SIGMA0], sigma1 = st->sc[S_SIGMA1];
+    const double delta = gamma1 * alpha - gamma0 * sigma1 * beta_old;
+    const double rho3 = sigma0 * beta_old;
+    const double rho2 = sigma1 * alpha + gamma0 * gamma1 * beta_old;
+    const double beta = sqrt(st->sc[S_TMP]);
+    const double rho1 = hypot(delta, beta);
+    st->sc[S_BETA] = beta; st->sc[S_DELTA] = delta; st->sc[S_MRHO1] = rho1; st->sc[S_MRHO2] = rho2; st->sc[S_MRHO3] = rho3;
+    st->sc[S_C0] = 1.0 / rho1; st->sc[S_C1] = -rho2 / rho1; st->sc[S_C2] = -rho3 / rho1;
+    st->sc[S_GAMMA0] = gamma1;
+    st->sc[S_GAMMA1] = delta / rho1;
+    st->sc[S_TS] = st->sc[S_GAMMA1] * st->sc[S_ETA];          // coefficient of x.Add(gamma1*eta, w0)
+}
+__global__ void minres_eta_kernel(KState *st, int it)
+{
+    if (st->fl[F_DONE]) return;
+    st->sc[S_SIGMA0] = st->sc[S_SIGMA1];
+    st->sc[S_SIGMA1] = st->sc[S_BETA] / st->sc[S_MRHO1];
+    const double eta = -st->sc[S_SIGMA1] * st->sc[S_ETA];
+    st->sc[S_ETA] = eta;
+    st->sc[S_FINAL_NORM] = fabs(eta);
+    if (fabs(eta) <= st->sc[S_GOAL]) { st->fl[F_DONE] = 1; st->fl[F_CONVERGED] = 1; st->fl[F_FINAL_ITER] = it; }
+}
+
 // ---- stationary (StationarySolver::Mult) --------------------------------------------------------------------------------
 __global__ void stat_init_kernel(KState *st, int max_iter)
 {
@@ -386,6 +527,7 @@ struct elag_hip_krylov_s {
     double *h_sc = nullptr;       // pinned mirror of st->sc
     double *x = nullptr, *r = nullptr, *z = nullptr, *d = nullptr, *w = nullptr, *scr = nullptr;
     double *V = nullptr, *Z = nullptr, *hs = nullptr, *part = nullptr;
+    double *e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // BiCGSTAB / MINRES work vectors
     hipGraphExec_t cg_iter = nullptr;
     // results of the last Mult
     int converged = 0, final_iter = 0;
@@ -399,6 +541,7 @@ struct elag_hip_krylov_s {
     {
         if (cg_iter) (void)hipGraphExecDestroy(cg_iter);
         dev_free(x); dev_free(r); dev_free(z); dev_free(d); dev_free(w); dev_free(scr); dev_free(V); dev_free(Z); dev_free(hs); dev_free(part);
+        for (auto &p : e) dev_free(p);
         if (st) (void)hipFree(st);
         if (h_flags) (void)hipHostFree(h_flags);
         if (h_sc) (void)hipHostFree(h_sc);
@@ -415,6 +558,8 @@ struct elag_hip_krylov_s {
         x = dev_alloc<double>(nn); r = dev_alloc<double>(nn); z = dev_alloc<double>(nn); scr = dev_alloc<double>(nn);
         if (solver == ELAG_HIP_KRYLOV_CG) { d = dev_alloc<double>(nn); part = dev_alloc<double>(2 * (size_t)kPart); }
         if (solver == ELAG_HIP_KRYLOV_STATIONARY) { d = dev_alloc<double>(nn); }
+        if (solver == ELAG_HIP_KRYLOV_BICGSTAB || solver == ELAG_HIP_KRYLOV_MINRES)
+            for (auto &p : e) p = dev_alloc<double>(nn);
         if (solver == ELAG_HIP_KRYLOV_GMRES || solver == ELAG_HIP_KRYLOV_FGMRES) {
             ELAG_REQUIRE(restart >= 1, "\"Restart size\" must be >= 1");
             const size_t m = (size_t)restart;
@@ -657,6 +802,96 @@ struct elag_hip_krylov_s {
         }
     }
 
+    // mfem::BiCGSTABSolver::Mult: r, rtilde = z, p = e[0], phat = e[1], v = e[2], s = e[3], shat = e[4], t = e[5]
+    void run_bicgstab(const double *b, bool iterative)
+    {
+        hipStream_t s = ctx().stream;
+        const int nn = n();
+        const dim3 g(g1(nn)), blk(kB);
+        double *rt = z, *p = e[0], *phat = e[1], *v = e[2], *sv = e[3], *shat = e[4], *t = e[5];
+        if (iterative) residual(b, x, r);
+        else { k::vec_fill(nn, 0.0, x); ELAG_HIP_CHECK(hipMemcpyAsync(r, b, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s)); }
+        ELAG_HIP_CHECK(hipMemcpyAsync(rt, r, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s));
+        dot(r, r);
+        hipLaunchKernelGGL(bicg_init_kernel, dim3(1), dim3(1), 0, s, st, rel_tol, abs_tol, max_iter);
+        ELAG_LAUNCH_CHECK();
+        if (poll()) return;
+        int since_poll = 0;
+        for (int i = 1; i <= max_iter; i++) {
+            dot(rt, r);
+            hipLaunchKernelGGL(bicg_rho_kernel, dim3(1), dim3(1), 0, s, st, i);
+            if (i == 1) hipLaunchKernelGGL(copy_pred_kernel, g, blk, 0, s, nn, (const KState *)st, (const double *)r, p);
+            else hipLaunchKernelGGL(bicg_p_kernel, g, blk, 0, s, nn, (const KState *)st, (const double *)r, (const double *)v, p);
+            if (has_prec()) prec(p, phat);
+            else hipLaunchKernelGGL(copy_pred_kernel, g, blk, 0, s, nn, (const KState *)st, (const double *)p, phat);
+            amul(phat, v);
+            dot(rt, v);
+            hipLaunchKernelGGL(bicg_alpha_kernel, dim3(1), dim3(1), 0, s, st);
+            hipLaunchKernelGGL(axpy_kernel, g, blk, 0, s, nn, (const KState *)st, 0, (const double *)r, (int)S_ALPHA, -1.0, (const double *)v, sv);   // s = r - alpha v
+            dot(sv, sv);
+            hipLaunchKernelGGL(bicg_mid_kernel, dim3(1), dim3(1), 0, s, st, i, i);
+            hipLaunchKernelGGL(axpy_kernel, g, blk, 0, s, nn, (const KState *)st, i, (const double *)x, (int)S_ALPHA, 1.0, (const double *)phat, x);   // x += alpha phat
+            if (has_prec()) prec(sv, shat);
+            else hipLaunchKernelGGL(copy_pred_kernel, g, blk, 0, s, nn, (const KState *)st, (const double *)sv, shat);
+            amul(shat, t);
+            dot(t, sv);
+            hipLaunchKernelGGL(bicg_ts_kernel, dim3(1), dim3(1), 0, s, st);
+            dot(t, t);
+            hipLaunchKernelGGL(bicg_omega_kernel, dim3(1), dim3(1), 0, s, st);
+            hipLaunchKernelGGL(axpy_kernel, g, blk, 0, s, nn, (const KState *)st, 0, (const double *)x, (int)S_OMEGA, 1.0, (const double *)shat, x);   // x += omega shat
+            hipLaunchKernelGGL(axpy_kernel, g, blk, 0, s, nn, (const KState *)st, 0, (const double *)sv, (int)S_OMEGA, -1.0, (const double *)t, r);   // r = s - omega t
+            dot(r, r);
+            hipLaunchKernelGGL(bicg_end_kernel, dim3(1), dim3(1), 0, s, st, i);
+            ELAG_LAUNCH_CHECK();
+            if (++since_poll >= check_every) { since_poll = 0; if (poll()) break; }
+        }
+    }
+
+    // mfem::MINRESSolver::Mult: v0 = e[0], v1 = e[1], w0 = e[2], w1 = e[3], q = e[4], u1 = e[5]
+    void run_minres(const double *b, bool iterative)
+    {
+        hipStream_t s = ctx().stream;
+        const int nn = n();
+        const dim3 g(g1(nn)), blk(kB);
+        double *v0 = e[0], *v1 = e[1], *w0 = e[2], *w1 = e[3], *q = e[4], *u1 = e[5];
+        if (iterative) residual(b, x, v1);
+        else { ELAG_HIP_CHECK(hipMemcpyAsync(v1, b, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s)); k::vec_fill(nn, 0.0, x); }
+        if (has_prec()) prec(v1, u1);
+        dot(has_prec() ? u1 : v1, v1);
+        hipLaunchKernelGGL(minres_init_kernel, dim3(1), dim3(1), 0, s, st, rel_tol, abs_tol, max_iter);
+        ELAG_LAUNCH_CHECK();
+        if (poll()) return;
+        int since_poll = 0;
+        for (int it = 1; it <= max_iter; it++) {
+            double *zz = has_prec() ? u1 : v1;
+            hipLaunchKernelGGL(scale_recip_kernel, g, blk, 0, s, nn, (const KState *)st, (int)S_BETA, v1);
+            if (has_prec()) hipLaunchKernelGGL(scale_recip_kernel, g, blk, 0, s, nn, (const KState *)st, (int)S_BETA, u1);
+            amul(zz, q);
+            dot(zz, q);
+            hipLaunchKernelGGL(minres_alpha_kernel, dim3(1), dim3(1), 0, s, st);
+            if (it > 1) hipLaunchKernelGGL(axpy_kernel, g, blk, 0, s, nn, (const KState *)st, 0, (const double *)q, (int)S_BETA, -1.0, (const double *)v0, q);   // q -= beta v0
+            hipLaunchKernelGGL(axpy_kernel, g, blk, 0, s, nn, (const KState *)st, 0, (const double *)q, (int)S_ALPHA, -1.0, (const double *)v1, v0);         // v0 = q - alpha v1
+            if (!has_prec()) dot(v0, v0);
+            else { prec(v0, q); dot(v0, q); }
+            hipLaunchKernelGGL(minres_beta_kernel, dim3(1), dim3(1), 0, s, st);
+            if (it == 1)
+                hipLaunchKernelGGL(lin2_kernel, g, blk, 0, s, nn, (const KState *)st, 0, -1, 0.0, (const double *)nullptr, (int)S_C0, 1.0, (const double *)zz, w0);
+            else if (it == 2)
+                hipLaunchKernelGGL(lin2_kernel, g, blk, 0, s, nn, (const KState *)st, 0, (int)S_C0, 1.0, (const double *)zz, (int)S_C1, 1.0, (const double *)w1, w0);
+            else {
+                hipLaunchKernelGGL(lin2_kernel, g, blk, 0, s, nn, (const KState *)st, 0, (int)S_C2, 1.0, (const double *)w0, (int)S_C1, 1.0, (const double *)w1, w0);
+                hipLaunchKernelGGL(axpy_kernel, g, blk, 0, s, nn, (const KState *)st, 0, (const double *)w0, (int)S_C0, 1.0, (const double *)zz, w0);
+            }
+            hipLaunchKernelGGL(axpy_kernel, g, blk, 0, s, nn, (const KState *)st, 0, (const double *)x, (int)S_TS, 1.0, (const double *)w0, x);              // x += gamma1 eta w0
+            hipLaunchKernelGGL(minres_eta_kernel, dim3(1), dim3(1), 0, s, st, it);
+            ELAG_LAUNCH_CHECK();
+            if (has_prec()) std::swap(u1, q);
+            std::swap(v0, v1);
+            std::swap(w0, w1);
+            if (++since_poll >= check_every) { since_poll = 0; if (poll()) break; }
+        }
+    }
+
     void run_stationary(const double *b, bool iterative)
     {
         hipStream_t s = ctx().stream;
@@ -690,6 +925,8 @@ struct elag_hip_krylov_s {
         case ELAG_HIP_KRYLOV_CG: run_cg(b, iterative); break;
         case ELAG_HIP_KRYLOV_GMRES: run_gmres(b, iterative, false); break;
         case ELAG_HIP_KRYLOV_FGMRES: run_gmres(b, iterative, true); break;
+        case ELAG_HIP_KRYLOV_BICGSTAB: run_bicgstab(b, iterative); break;
+        case ELAG_HIP_KRYLOV_MINRES: run_minres(b, iterative); break;
         default: run_stationary(b, iterative); break;
         }
         fetch_results();
@@ -717,7 +954,7 @@ int elag_hip_krylov_create(elag_hip_krylov_t *out, elag_hip_parcsr_t A, int prec
         ELAG_REQUIRE(A->nrows() == A->ncols(), "Krylov solvers need a square operator");
         elag_hip_krylov_options opt;
         if (opt_in) opt = *opt_in; else { int rc = elag_hip_krylov_default_options(&opt); if (rc) fail(rc, "%s", elag_hip_last_error()); }
-        ELAG_REQUIRE(opt.solver >= ELAG_HIP_KRYLOV_CG && opt.solver <= ELAG_HIP_KRYLOV_STATIONARY,
+        ELAG_REQUIRE(opt.solver >= ELAG_HIP_KRYLOV_CG && opt.solver <= ELAG_HIP_KRYLOV_MINRES,
                      "KrylovSolver::KrylovSolver(...): Bad solver type (%d). Device choices are CG, GMRES, FGMRES and the stationary iteration",
                      opt.solver);
         ELAG_REQUIRE(opt.max_iter >= 0, "\"Maximum iterations\" must be >= 0");

@@ -679,7 +679,7 @@ def buildBlockedHierarchyFromDeRhamSequence(A: MfemBlockOperator, Ps, block_smoo
 
 # ---- Krylov shells ----------------------------------------------------------------------------------------------------
 
-KRYLOV_SOLVERS = {"CG": 0, "PCG": 0, "GMRES": 1, "FGMRES": 2, "STATIONARY": 3}
+KRYLOV_SOLVERS = {"CG": 0, "PCG": 0, "GMRES": 1, "FGMRES": 2, "STATIONARY": 3, "BICGSTAB": 4, "MINRES": 5}
 
 
 class KrylovSolver(_SolverBase):
@@ -696,8 +696,8 @@ class KrylovSolver(_SolverBase):
         self.Prec = Prec
         name = str(params.get("Solver name", "CG")).upper()
         if name not in KRYLOV_SOLVERS:
-            raise ValueError(f'KrylovSolver::KrylovSolver(...): Bad solver type ("{name}"). Device choices are "CG", "GMRES", '
-                             f'"FGMRES" (and "Stationary"); "BiCGSTAB" and "MINRES" stay on the host')
+            raise ValueError(f'KrylovSolver::KrylovSolver(...): Bad solver type ("{name}"). Valid choices are "CG", "PCG", "GMRES", '
+                             f'"FGMRES", "BiCGSTAB", "MINRES" (KrylovSolver.cpp:44-51) and "Stationary"')
         opt = _lib.KrylovOptions()
         check(self._lib.elag_hip_krylov_default_options(C.byref(opt)))
         opt.solver = KRYLOV_SOLVERS[name]

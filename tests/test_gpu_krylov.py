@@ -157,3 +157,88 @@ def test_stationary_solver_matches_reference_loop(la, h1_k1):
         ref = orc.stationary_solver(lambda v: A @ v, oprec, b, xr, rel_tol=kw.get("rel_tol", 0.0), max_iter=kw["max_its"])
         assert (S.GetConverged(), S.GetNumIterations()) == (bool(ref.converged), ref.final_iter)
         assert close(x, xr, 1e-10) and np.isclose(S.GetFinalNorm(), ref.final_norm, rtol=1e-6)
+
+
+# ---- BiCGSTAB / MINRES (KrylovSolver.cpp:39-42) ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("prec", ["none", "vcycle"])
+@pytest.mark.parametrize("check_every", [1, 8])
+def test_bicgstab_matches_mfem(la, h1_k2, prec, check_every):
+    A = h1_k2[0]
+    dA, H, oprec = h1_setup(la, h1_k2)
+    b = np.random.default_rng(4).uniform(-1, 1, A.shape[0])
+    params = {"Solver name": "BiCGSTAB", "Relative tolerance": 1e-9, "Maximum iterations": 400, "Check every": check_every}
+    K = la.KrylovSolver(dA, H if prec == "vcycle" else None, params)
+    x = np.full(A.shape[0], -2.0)
+    K.Mult(b, x)
+    xr = np.zeros_like(b)
+    ref = orc.mfem_bicgstab(lambda v: A @ v, oprec if prec == "vcycle" else None, b, xr, rel_tol=1e-9, max_iter=400)
+    assert K.GetConverged() and ref.converged
+    # the recurrences are run in the same order: same count up to one step of rounding-induced drift on long runs
+    assert abs(K.GetNumIterations() - ref.final_iter) <= (0 if prec == "vcycle" else 2)
+    assert np.linalg.norm(A @ x - b) <= 1e-8 * np.linalg.norm(b)
+    if prec == "vcycle":
+        assert close(x, xr, 1e-8) and np.isclose(K.GetFinalNorm(), ref.final_norm, rtol=1e-4)
+    # maximum iterations: not converged, final_iter = max_iter, same iterate
+    K2 = la.KrylovSolver(dA, H if prec == "vcycle" else None, dict(params, **{"Maximum iterations": 3, "Relative tolerance": 1e-14}))
+    x3, xr3 = np.zeros_like(b), np.zeros_like(b)
+    K2.Mult(b, x3)
+    ref3 = orc.mfem_bicgstab(lambda v: A @ v, oprec if prec == "vcycle" else None, b, xr3, rel_tol=1e-14, max_iter=3)
+    assert not K2.GetConverged() and K2.GetNumIterations() == ref3.final_iter == 3
+    assert close(x3, xr3, 1e-10) and np.isclose(K2.GetFinalNorm(), ref3.final_norm, rtol=1e-8)
+
+
+@pytest.mark.parametrize("prec", ["none", "l1-jacobi"])
+def test_minres_on_the_darcy_system_matches_mfem(la, prec):
+    """The symmetric indefinite system [[M, Bt], [B, 0]] of MultigridTestDarcy; the preconditioner must be SPD for MINRES:
+    one l1-Jacobi sweep on the block-diagonal operator blockdiag(M, B diag(M)^-1 Bt)."""
+    from parelag_amd import meshgen
+    d = meshgen.darcy_problem(0, seq=meshgen.Sequence.kuhn_cube(2, 1))
+    M, B, Bt = d["M"], d["B"], d["Bt"]
+    A = sp.bmat([[M, Bt], [B, None]]).tocsr()
+    n = A.shape[0]
+    b = np.random.default_rng(6).uniform(-1, 1, n)
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    S = (B @ sp.diags(1.0 / M.diagonal()) @ Bt).tocsr()
+    Pd = sp.block_diag([M, S]).tocsr()
+    if prec == "none":
+        sm, oprec = None, None
+    else:
+        dP = la.ParallelCSRMatrix.from_scipy(Pd)
+        sm = la.HypreSmootherWrapper(dP, 1, {"Sweeps": 1})
+        osm = orc.OSmoother(orc.OParCSR(orc.diag_first(Pd)), type=1, sweeps=1)
+
+        def oprec(r, z):
+            z[:] = 0.0
+            osm.Mult(r, z)
+    params = {"Solver name": "MINRES", "Relative tolerance": 1e-8, "Maximum iterations": 2000, "Check every": 8}
+    K = la.KrylovSolver(dA, sm, params)
+    x = np.zeros(n)
+    K.Mult(b, x)
+    xr = np.zeros(n)
+    ref = orc.mfem_minres(lambda v: A @ v, oprec, b, xr, rel_tol=1e-8, max_iter=2000)
+    assert K.GetConverged() and ref.converged
+    assert abs(K.GetNumIterations() - ref.final_iter) <= 2 and ref.final_iter < 2000
+    assert np.isclose(K.GetFinalNorm(), ref.final_norm, rtol=1e-3)
+    assert close(x, xr, 1e-6)
+    # a few steps only: identical recurrences, identical iterates
+    K5 = la.KrylovSolver(dA, sm, dict(params, **{"Maximum iterations": 5, "Relative tolerance": 1e-14}))
+    x5, xr5 = np.zeros(n), np.zeros(n)
+    K5.Mult(b, x5)
+    ref5 = orc.mfem_minres(lambda v: A @ v, oprec, b, xr5, rel_tol=1e-14, max_iter=5)
+    assert not K5.GetConverged() and K5.GetNumIterations() == ref5.final_iter == 5
+    assert close(x5, xr5, 1e-11) and np.isclose(K5.GetFinalNorm(), ref5.final_norm, rtol=1e-10)
+    # iterative_mode: continue from the five-step iterate
+    K.iterative_mode = True
+    x6 = x5.copy(); xr6 = xr5.copy()
+    K.Mult(b, x6)
+    orc.mfem_minres(lambda v: A @ v, oprec, b, xr6, iterative_mode=True, rel_tol=1e-8, max_iter=2000)
+    assert close(x6, xr6, 1e-6)
+
+
+def test_krylov_solver_names(la, h1_k1):
+    dA = la.ParallelCSRMatrix.from_scipy(h1_k1[0])
+    for name in ("CG", "PCG", "GMRES", "FGMRES", "BiCGSTAB", "MINRES"):
+        la.KrylovSolver(dA, None, {"Solver name": name})
+    with pytest.raises(ValueError, match="Bad solver type"):
+        la.KrylovSolver(dA, None, {"Solver name": "QMR"})
