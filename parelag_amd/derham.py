@@ -99,9 +99,10 @@ def coarsen_topology(lv: SeqLevel, part: np.ndarray) -> dict:
         low_of_set = np.empty(ulab.size, dtype=np.int64)
         low_of_set[rank] = lowest
         ori = np.zeros(nsub)
-        # orientation relative to the lowest member: Z(low, j) / Z(low, low)
-        Gc = G.tocsr()
-        ori[mem] = np.asarray(Gc[low_of_set[mis[mem]], mem]).ravel() / dZ[mem]
+        # orientation relative to the lowest member: Z(low, j) / Z(low, low) -- the relation's entries in the rows of the lowest members
+        gr, gc, gv = Z.row[rel], Z.col[rel], Z.data[rel]
+        from_low = gr == low_of_set[np.maximum(mis[gc], 0)]
+        ori[gc[from_low]] = gv[from_low] / dZ[gc[from_low]]
         nmis = ulab.size
         o2 = np.argsort(mis[mem], kind="stable")
         A.append((ptr_from_counts(np.bincount(mis[mem], minlength=nmis)), mem[o2].astype(np.int64), ori[mem[o2]]))
