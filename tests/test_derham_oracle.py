@@ -131,3 +131,32 @@ def test_box_agglomerates_with_heterogeneous_coefficient():
     assert r1["coarse"].n == [1, 6, 12, 8]
     inv = invariants(r0["coarse"], r1)
     assert max(inv.values()) < 1e-11, inv
+
+
+def rich_targets_level(seq, jstart=0):
+    """"Upscaling order" 1: linears for the 3-forms, linear vector fields for the 2- and 1-forms (midpoint rule), quadratics
+    for the 0-forms -- null-space dofs on every codimension, RangeT bubbles in every extension stage."""
+    m = seq.meshes[0]
+    lv = seq_level_from_tets(m, jstart=jstart)
+    xv = m.vertices
+    xe = 0.5 * (xv[m.edges[:, 0]] + xv[m.edges[:, 1]]); xf = xv[m.faces].mean(1); xt = xv[m.tets].mean(1)
+    lin = lambda T, xc: np.concatenate([T] + [T[:, [d]] * xc[:, [c]] for d in range(3) for c in range(3)], axis=1)
+    lv.T[3] = np.concatenate([lv.T[3], lv.T[3] * xt], axis=1)
+    lv.T[2] = lin(lv.T[2], xf)
+    if jstart <= 1:
+        lv.T[1] = lin(lv.T[1], xe)
+    if jstart <= 0:
+        x, y, z = xv.T
+        lv.T[0] = np.stack([np.ones_like(x), x, y, z, x * x, y * y, z * z, x * y, y * z, x * z], axis=1)
+    return lv
+
+
+def test_richer_targets_on_every_form(seq):
+    lv = rich_targets_level(seq)
+    r0 = od.coarsen(lv, seq.partition(0))
+    assert r0["n_null"][3] == 48 * 3 and r0["n_null"][2] > 0 and r0["n_null"][1] > 0
+    inv = invariants(lv, r0)
+    assert max(inv.values()) < 1e-11, inv
+    r1 = od.coarsen(r0["coarse"], seq.partition(1))
+    inv = invariants(r0["coarse"], r1)
+    assert max(inv.values()) < 1e-11, inv
