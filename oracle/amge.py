@@ -205,7 +205,6 @@ def coarsen(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_ent
     topo = coarsen_topology(lv, part)
     agg = agglomerate_dofs(lv, topo)
     nAE, nAF = topo["nAE"], topo["nAF"]
-    M3_dof_of = None
 
     # ===== codim 0, jform 3: ComputeCoarseTracesWithTargets(3) (:1723-2085); PV vector = constant 1 (computePVTraces) =====
     p3_blocks, m3c_blocks, fun3 = [], [], []

@@ -18,8 +18,8 @@ import scipy.sparse as sp
 from scipy.sparse.csgraph import connected_components
 
 from . import _lib
-from .amge import (EPS, _Assembly, _ExtIn, _ExtOut, _Keep, _TracesIn, _TracesOut, _assembly, _blocks_to_csr, _first_touch_groups,
-                   _join_cols, _pack_cols, _ptr, _spmm_device, _take_leading, _take_leading_rows, expand_ranges)
+from .amge import (EPS, _Assembly, _ExtIn, _ExtOut, _Keep, _TracesIn, _TracesOut, _assembly, _blocks_to_csr, _join_cols,
+                   _pack_cols, _ptr, _spmm_device, _take_leading, _take_leading_rows, expand_ranges)
 from .amge_level import ptr_from_counts
 from .derham_level import SeqLevel, _Tables, _concat_rows, _product
 
