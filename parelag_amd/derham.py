@@ -470,3 +470,139 @@ def amge_problem(form: int, seq, timings: dict | None = None):
     rec = {"what": "DeRhamSequence::Coarsen (jformStart=%d) on the device: cube456 x%d tets, derefinement agglomerates" % (lv.jstart, len(seq.meshes) - 1),
            "levels": recs, "coarsen_total_s": round(total_s, 3), "generate_s": round(gen_s, 2)}
     return A, Ps, Ds, levels, rec
+
+
+# ---- the reference's class interface ------------------------------------------------------------------------------------------
+
+class DeRhamSequence:
+    """Mirror of ``parelag::DeRhamSequence`` (``src/amge/DeRhamSequence.hpp:64-330``) over the device coarsening: the same
+    member names and argument meaning, so that a driver written against the reference
+    (``examples/MultigridTest0Form.cpp:214-300``: ``SetjformStart`` / ``SetTargets`` / ``SetSVDTol`` / ``Coarsen`` /
+    ``ComputeTrueP`` / ``ComputeMassOperator`` / ``GetDerivativeOperator``) reads the same here.  Matrices are scipy CSR on the
+    host (the reference returns ``mfem::SparseMatrix``); one rank, so "true" dofs are the dofs."""
+
+    def __init__(self, level: SeqLevel, finer: "DeRhamSequence | None" = None):
+        self.level = level
+        self.FinerSequence = finer
+        self.CoarserSequence = None
+        self.SVD_Tolerance = 1e-9                       # DeRhamSequence.cpp:56
+        self.SmallestEntry = EPS                        # :57
+        self._res = None
+
+    # -- getters ------------------------------------------------------------------------------------------------------------
+    def GetNumberOfForms(self):
+        return 4
+
+    def GetNumberOfDofs(self, jform):
+        return self.level.ndof(jform)
+
+    GetNumberOfTrueDofs = GetNumberOfDofs
+
+    def GetD(self, jform):
+        return self.level.D[jform]
+
+    GetDerivativeOperator = GetD
+
+    def GetP(self, jform):
+        self._need_coarse("GetP")
+        return self._res["P"][jform]
+
+    def GetPi(self, jform):
+        """The cochain projector as a matrix (``CochainProjector::GetProjectorMatrix``)."""
+        self._need_coarse("GetPi")
+        return projector(self._res, jform)
+
+    def GetM(self, etype, jform):
+        """Entity mass matrices of codimension ``etype`` as one "DG-like" block-diagonal matrix (``:207-213``)."""
+        ptr, vals = self.level.M[jform][etype]
+        sizes = np.sqrt(np.diff(ptr)).round().astype(np.int64)
+        return sp.block_diag([vals[ptr[e]:ptr[e + 1]].reshape(sizes[e], sizes[e]) for e in range(sizes.size)], format="csr")
+
+    def ComputeMassOperator(self, jform):
+        return self.level.mass(jform)
+
+    def ComputeTrueMassOperator(self, jform):
+        return self.level.mass(jform)
+
+    def ComputeTrueDerivativeOperator(self, jform):
+        return self.level.D[jform]
+
+    def ComputeTrueD(self, jform, ess_label=None):
+        """``ComputeTrueD(jform, ess_label)`` (``:1230-1253``): columns of the essential dofs eliminated."""
+        from . import meshgen
+        D = self.level.D[jform].tocsr()
+        return D if ess_label is None else meshgen.eliminate_cols(D, self._marker(jform, ess_label))
+
+    def ComputeTrueP(self, jform, ess_label=None):
+        """``ComputeTrueP(jform, ess_label)`` (``:1118-1153,1230-1253``): essential coarse columns eliminated."""
+        from . import meshgen
+        self._need_coarse("ComputeTrueP")
+        P = self._res["P"][jform].tocsr()
+        return P if ess_label is None else meshgen.eliminate_cols(P, self.CoarserSequence._marker(jform, ess_label))
+
+    def _marker(self, jform, ess_label):
+        """Dofs on boundary facets whose attribute is selected (``ess_label[attr-1] != 0``; ``MarkDofsOnSelectedBndr``)."""
+        lab = np.asarray(ess_label)
+        mk = np.zeros(self.level.ndof(jform), dtype=bool)
+        if self.level.cb(jform) < 1:
+            return mk
+        ep, ei = _Tables(self.level).edof(jform, 1)
+        attr = self.level.facet_attr
+        sel = np.nonzero((attr > 0) & (lab[np.maximum(attr, 1) - 1] != 0))[0]
+        q, _ = expand_ranges(ep[sel], np.diff(ep)[sel])
+        mk[ei[q]] = True
+        return mk
+
+    # -- setters ------------------------------------------------------------------------------------------------------------
+    def SetjformStart(self, start):
+        if not 0 <= start <= 3:
+            raise ValueError("SetjformStart: start must be one of the forms 0 .. 3")
+        for j in range(start, 4):
+            if self.level.M[j] is None:
+                raise ValueError(f"SetjformStart({start}): this sequence was built without form {j}")
+        self.level.jstart = int(start)
+
+    def SetTargets(self, targets):
+        """``SetTargets`` (``:63-96``): one (ndof x nTargets) array per form (deep copy); forms below ``jformStart`` may be None."""
+        for j in range(self.level.jstart, 4):
+            T = np.array(targets[j], dtype=np.float64, copy=True)
+            if T.ndim != 2 or T.shape[0] != self.level.ndof(j):
+                raise ValueError(f"SetTargets: targets of form {j} must have {self.level.ndof(j)} rows")
+            self.level.T[j] = T
+
+    def SetSVDTol(self, tol):
+        self.SVD_Tolerance = float(tol)
+
+    # -- math ---------------------------------------------------------------------------------------------------------------
+    def Coarsen(self, partitioning, timings: dict | None = None) -> "DeRhamSequence":
+        """``Coarsen()`` (``:572-692``).  The element partitioning is an argument here because this mirror has no separate
+        ``AgglomeratedTopology`` object: the reference reads it from ``Topo_->CoarserTopology()``, which
+        ``CoarsenLocalPartitioning(partitioning, ...)`` built from the same array."""
+        self._res = coarsen(self.level, partitioning, svd_tol=self.SVD_Tolerance, smallest_entry=self.SmallestEntry, timings=timings)
+        self.CoarserSequence = DeRhamSequence(self._res["coarse"], finer=self)
+        self.CoarserSequence.SVD_Tolerance = self.SVD_Tolerance
+        return self.CoarserSequence
+
+    def CheckInvariants(self, tol=1e-9, loose_tol=1e-6):
+        """``CheckInvariants`` (``:694-970``): CheckD (``D_{j+1} D_j = 0``), CheckDP (``D_f P_j = P_{j+1} D_c``),
+        CheckCoarseMassMatrix (``M_c = P^T M P``), CheckPi (``Pi P = I``).  Raises like the reference's
+        ``PARELAG_TEST_FOR_EXCEPTION``; returns the measured defects."""
+        self._need_coarse("CheckInvariants")
+        lv, c, P = self.level, self._res["coarse"], self._res["P"]
+        out = {}
+        for j in range(lv.jstart, 4):
+            M, Mc = lv.mass(j), c.mass(j)
+            out[f"CheckCoarseMassMatrix[{j}]"] = abs(P[j].T @ M @ P[j] - Mc).max() / max(abs(Mc).max(), 1e-300)
+            out[f"CheckPi[{j}]"] = abs(projector(self._res, j) @ P[j] - sp.identity(P[j].shape[1])).max()
+            if j < 3:
+                out[f"CheckDP[{j}]"] = abs(lv.D[j] @ P[j] - P[j + 1] @ c.D[j]).max() / max(abs(lv.D[j]).max(), 1e-300)
+            if j < 2:
+                out[f"CheckD[{j}]"] = abs(lv.D[j + 1] @ lv.D[j]).max()
+        bad = {k: v for k, v in out.items() if v > (loose_tol if k.startswith("CheckCoarseMass") else tol)}
+        if bad:
+            raise RuntimeError(f"DeRhamSequence::CheckInvariants(): {bad}")
+        return out
+
+    def _need_coarse(self, what):
+        if self._res is None:
+            raise RuntimeError(f"DeRhamSequence::{what}(): call Coarsen() first")

@@ -167,3 +167,42 @@ def test_richer_targets_on_every_form(derham):
     rd1 = derham.coarsen(rd["coarse"], seq.partition(1))
     inv = invariants(rd["coarse"], rd1, Pi={j: derham.projector(rd1, j) for j in range(4)})
     assert max(inv.values()) < 1e-9, inv
+
+
+def test_derham_sequence_class_reads_like_the_reference_driver(derham):
+    """The flow of ``examples/MultigridTest0Form.cpp:214-300`` against the class mirror: SetjformStart / SetTargets /
+    SetSVDTol / Coarsen level by level / CheckInvariants / ComputeTrueP with essential labels."""
+    from parelag_amd import linalg as la
+    seq = meshgen.Sequence.kuhn_cube(2, 2)
+    sequence = [derham.DeRhamSequence(seq_level_from_tets(seq.meshes[0], jstart=0))]
+    sequence[0].SetjformStart(0)
+    sequence[0].SetTargets(sequence[0].level.T)
+    for i in range(2):
+        sequence[i].SetSVDTol(1e-9)
+        sequence.append(sequence[i].Coarsen(seq.partition(i)))
+        defects = sequence[i].CheckInvariants()
+        assert max(defects.values()) < 1e-9
+    for m in seq.meshes:
+        m.build_faces()
+    assert [sequence[2].GetNumberOfDofs(j) for j in range(4)] == [seq.meshes[2].nv, seq.meshes[2].ne, seq.meshes[2].nf, seq.meshes[2].nt]
+    ess = np.ones(6, dtype=int)                              # every boundary attribute essential (MultigridTest0Form.cpp:194-196)
+    A = sequence[0].ComputeTrueDerivativeOperator(0).T @ sequence[0].ComputeTrueMassOperator(1) @ sequence[0].ComputeTrueDerivativeOperator(0)
+    A = meshgen.eliminate_rowcol(A.tocsr(), sequence[0]._marker(0, ess))
+    Ps = [sequence[i].ComputeTrueP(0, ess) for i in range(2)]
+    assert abs(Ps[0] - meshgen.eliminate_cols(sequence[0].GetP(0), seq.meshes[1].boundary_marker_unit_cube())).max() == 0.0
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    H = la.buildHierarchyFromDeRhamSequence(dA, [la.ParallelCSRMatrix.from_scipy(P) for P in Ps], "L1 Jacobi")
+    K = la.KrylovSolver(dA, H, {"Solver name": "PCG", "Relative tolerance": 1e-8, "Maximum iterations": 60})
+    b = meshgen.load_vector_P1(seq.meshes[0], seq.meshes[0].boundary_marker_unit_cube())
+    x = np.zeros_like(b)
+    K.Mult(b, x)
+    assert K.GetConverged() and K.GetNumIterations() < 25
+    # selective labels: only the x = 0 side essential
+    only_x0 = np.array([1, 0, 0, 0, 0, 0])
+    mk = sequence[1]._marker(0, only_x0)
+    assert 0 < mk.sum() < sequence[1]._marker(0, ess).sum()
+    assert sequence[0].GetM(2, 1).shape == (seq.meshes[0].ne, seq.meshes[0].ne)      # ridge mass of the 1-forms: one dof per edge
+    with pytest.raises(RuntimeError, match="Coarsen"):
+        sequence[2].GetP(0)
+    with pytest.raises(ValueError):
+        derham.DeRhamSequence(seq_level_from_tets(seq.meshes[2], jstart=2)).SetjformStart(0)
