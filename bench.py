@@ -114,8 +114,9 @@ def main():
     ap.add_argument("--roofline-reps", type=int, default=50)
     ap.add_argument("--roofline-only", action="store_true", help="only run the fine-level SpMV launches (for rocprofv3)")
     ap.add_argument("--smoother", default="L1 Jacobi")
-    ap.add_argument("--form", default="0", choices=["0", "2", "darcy", "spe10"],
-                    help="0: MultigridTest0Form (H1, the BASELINE metric); 2: MultigridTest2Form (H(div), Hiptmair smoother); "
+    ap.add_argument("--form", default="0", choices=["0", "1", "2", "darcy", "spe10"],
+                    help="0: MultigridTest0Form (H1, the BASELINE metric); 1: MultigridTest1Form (H(curl), Hiptmair through the gradient); "
+                         "2: MultigridTest2Form (H(div), Hiptmair smoother); "
                          "darcy: MultigridTestDarcy (blocked AMGe, Block Jacobi smoother, BASELINE configs[3]); "
                          "spe10: the same with a synthetic log-normal permeability (BASELINE configs[4]; the SPE10 data file is not shipped)")
     ap.add_argument("--perm-sigma", type=float, default=2.0, help="spe10: std-dev of log-permeability")
@@ -248,9 +249,11 @@ def main():
         from parelag_amd import derham
         seq = meshgen.Sequence.cube456(args.refines)
         A, Ps, Ds, _levels, amge_rec = derham.amge_problem(args.form, seq)
-        note("AMGe coarsening (forms %d..3): %d levels in %.3f s" % (0 if args.form == 0 else 1, len(Ps), amge_rec["coarsen_total_s"]))
+        note("AMGe coarsening (forms %d..3): %d levels in %.3f s" % (0 if args.form <= 1 else 1, len(Ps), amge_rec["coarsen_total_s"]))
     elif args.form == 2:
         A, Ps, Ds, seq = meshgen.hdiv_problem(args.refines)
+    elif args.form == 1:
+        A, Ps, Ds, seq = meshgen.hcurl_problem(args.refines)
     else:
         A, Ps, seq = meshgen.h1_problem(args.refines)
     if darcy and not single:
@@ -290,6 +293,8 @@ def main():
         for l in range(len(Ps) + 1):
             op = H.GetOperator(l)
             level_shapes.append((op.Height(), op.nnz, Ps[l].shape[1] if l < len(Ps) else 0, Ps[l].nnz if l < len(Ps) else 0))
+    elif args.form == 1:
+        raise SystemExit("--form 1 --gpus N: the row-block partitioner of the Hiptmair hierarchies handles the 2-form (faces / edges) only")
     elif args.form == 2:
         # every level row-partitioned (faces / edges owned by the lowest adjacent rank), coarsest operator replicated
         from parelag_amd import partition
@@ -362,7 +367,7 @@ def main():
             if args.form == 0:
                 b_solve = meshgen.load_vector_P1(fine_mesh, fine_mesh.boundary_marker_unit_cube())
             else:
-                b_solve = np.where(fine_mesh.boundary_marker(2), 0.0, 1.0)
+                b_solve = np.where(fine_mesh.boundary_marker(args.form), 0.0, 1.0)
             Kop = dA
         K = la.KrylovSolver(Kop, H, kparams)
         db, dx = la.DeviceVector.from_numpy(b_solve), la.DeviceVector(n_local, 0.0)
@@ -398,7 +403,7 @@ def main():
                     x[:] = 0.0
                     Ho.Mult(b, x)
             Hc = _Hc
-        elif args.form == 2:
+        elif args.form in (1, 2):
             h = oracle_hdiv_hierarchy(A, Ps, Ds)
             Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], native=True, hipt=h["hipt"])
             Hmc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], hipt=h["hipt"], omp=True)
@@ -527,7 +532,7 @@ def main():
                                     f"MultigridTestDarcy [[M,Bt],[B,0]] (forms 2,3) cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
                                     f"{args.block_smoother} (A00: {args.smoother}, A11: {args.smoother} on "
                                     f"{'S' if args.positive_s else '-S'} = -+B diag(M)^-1 Bt) pre/post, dense LU coarse solve, b=2") if darcy else
-                                   (f"MultigridTest2Form (H(div)) cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
+                                   (f"MultigridTest{args.form}Form ({'H(div)' if args.form == 2 else 'H(curl)'}) cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
                                     f"Hiptmair({args.smoother}, {args.smoother}) pre/post, dense coarse solve, b=2"),
                        "interpolators": (dar["amge"]["what"] if darcy and "amge" in dar else "nested geometric (generator)"),
                        "levels": [{"n": s[0], "nnz": s[1]} for s in level_shapes],

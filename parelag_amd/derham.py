@@ -434,7 +434,7 @@ def boundary_dofs(lv: SeqLevel, j: int) -> np.ndarray:
 
 
 def amge_problem(form: int, seq, timings: dict | None = None):
-    """The operators of MultigridTest0Form / MultigridTest2Form on AMGe spaces built by the device coarsening: fine operator
+    """The operators of MultigridTest0Form / 1Form / 2Form on AMGe spaces built by the device coarsening: fine operator
     (``D0^T M1 D0`` resp. ``M2 + D2^T M3 D2``) with all boundary attributes essential, the interpolators ``P_form`` of every
     level with essential columns eliminated (``ComputeTrueP(jform, ess)``, ``src/amge/DeRhamSequence.cpp:1118-1153,1230-1253``)
     and, for the Hiptmair smoother of the 2-form, the derivative ``D_1`` of every level with essential columns eliminated
@@ -443,7 +443,7 @@ def amge_problem(form: int, seq, timings: dict | None = None):
     from . import meshgen
     from .derham_level import seq_level_from_tets
     t0 = time.time()
-    lv = seq_level_from_tets(seq.meshes[0], jstart=0 if form == 0 else 1)
+    lv = seq_level_from_tets(seq.meshes[0], jstart=0 if form <= 1 else 1)
     gen_s = time.time() - t0
     levels, Ps, recs = [lv], [], []
     t0 = time.time()
@@ -461,9 +461,9 @@ def amge_problem(form: int, seq, timings: dict | None = None):
     if form == 0:
         A = (lv.D[0].T @ lv.mass(1) @ lv.D[0]).tocsr()
         Ds = None
-    else:
-        A = (lv.mass(2) + lv.D[2].T @ lv.mass(3) @ lv.D[2]).tocsr()
-        Ds = [meshgen.eliminate_cols(L_.D[1].tocsr(), boundary_dofs(L_, 1)) for L_ in levels]
+    else:                                               # MultigridTest1Form / 2Form: M_j + D_j^T M_{j+1} D_j, Hiptmair through D_{j-1}
+        A = (lv.mass(form) + lv.D[form].T @ lv.mass(form + 1) @ lv.D[form]).tocsr()
+        Ds = [meshgen.eliminate_cols(L_.D[form - 1].tocsr(), boundary_dofs(L_, form - 1)) for L_ in levels]
     A.sort_indices()
     A = meshgen.eliminate_rowcol(A, marks[0])
     Ps = [meshgen.eliminate_cols(P.tocsr(), marks[l + 1]) for l, P in enumerate(Ps)]

@@ -510,6 +510,26 @@ def hdiv_problem(nref: int, nlevels: int | None = None, alpha: float = 1.0, beta
     return A, Ps, Ds, seq
 
 
+def hcurl_problem(nref: int, nlevels: int | None = None, alpha: float = 1.0, beta: float = 1.0):
+    """1-form problem of MultigridTest1Form: A = beta M1 + alpha D1^T M2 D1 (``examples/MultigridTest1Form.cpp:262-263,487-492``)
+    with every boundary edge essential, the true interpolators P1 with essential columns zeroed and, for the Hiptmair
+    smoother, the true gradient D0 of every level with essential (boundary-vertex) columns zeroed
+    (``HiptmairSmootherFactory.cpp:84-103``).  Returns (A_fine, [P_l], [D_l], seq)."""
+    seq = Sequence.cube456(nref, nlevels)
+    fine = seq.meshes[0]
+    D1 = fine.D1()
+    A = (beta * fine.M1() + alpha * (D1.T @ fine.M2() @ D1)).tocsr()
+    A.sort_indices()
+    A = eliminate_rowcol(A, fine.boundary_marker(1))
+    Ps, Ds = [], []
+    for l, m in enumerate(seq.meshes):
+        Ds.append(eliminate_cols(m.D0(), m.boundary_marker(0)))
+        if l < len(seq.meshes) - 1:
+            c = seq.meshes[l + 1]
+            Ps.append(eliminate_cols(interp_P1(c, m), c.boundary_marker(1)))
+    return A, Ps, Ds, seq
+
+
 def lognormal_inverse_permeability(seq: "Sequence", sigma: float = 2.0, seed: int = 2025) -> np.ndarray:
     """Synthetic stand-in for the SPE10 data set (``data/spe_perm.dat`` is not shipped with the reference,
     ``examples/MultigridTestSPE10.cpp:85``): one log-normal value ``exp(sigma * N(0,1))`` per element of the COARSEST mesh

@@ -689,3 +689,34 @@ def test_large_operator_smoother_and_cycle_forms(la):
     Co = orc.OSmoother(orc.OParCSR(orc.diag_first(A)), type=16, order=3, eig=C.eig_estimate())
     xr = x0.copy(); Co.Mult(b, xr)
     assert close(x, xr, tol=1e-11)
+
+
+# ---- MultigridTest1Form: H(curl) with the Hiptmair smoother through the gradient ----------------------------------------------
+
+def test_hcurl_hiptmair_vcycle_and_pcg_match_the_oracle():
+    """``examples/MultigridTest1Form.cpp``: A = M1 + D1^T M2 D1, Hiptmair(l1-Jacobi, l1-Jacobi) with the auxiliary space H1
+    through the true gradient D0 (``HiptmairSmootherFactory.cpp:75-103``); same machinery as the 2-form, one form lower."""
+    from parelag_amd import linalg as la, meshgen
+    from tests.helpers import oracle_hdiv_hierarchy
+    A, Ps, Ds, _seq = meshgen.hcurl_problem(2)
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    dDs = [la.ParallelCSRMatrix.from_scipy(D) for D in Ds[:len(Ps)]]
+    H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi", Ds=dDs, aux_smoother="L1 Jacobi")
+    h = oracle_hdiv_hierarchy(A, Ps, Ds)
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], hipt=h["hipt"])
+    rng = np.random.default_rng(21)
+    n = A.shape[0]
+    for _ in range(2):
+        b = rng.uniform(-1, 1, n)
+        x, xr = np.full(n, 7.0), np.empty(n)
+        H.Mult(b, x)
+        Hc.apply(b, xr)
+        assert np.max(np.abs(x - xr)) <= 1e-11 * np.max(np.abs(xr))
+    K = la.KrylovSolver(dA, H, {"Solver name": "PCG", "Relative tolerance": 1e-8, "Maximum iterations": 100})
+    rhs = np.where(_seq.meshes[0].boundary_marker(1), 0.0, 1.0)
+    xs, xo = np.zeros(n), np.zeros(n)
+    K.Mult(rhs, xs)
+    ref = orc.mfem_cg(lambda v: A @ v, lambda r, z: Hc.apply(r, z), rhs, xo, rel_tol=1e-8, max_iter=100)
+    assert K.GetConverged() and K.GetNumIterations() == ref.final_iter and ref.final_iter < 40
+    assert np.max(np.abs(xs - xo)) <= 1e-8 * np.max(np.abs(xo))
