@@ -316,7 +316,8 @@ def coarsen(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_ent
     dcol_glob = D.indices[dq].astype(np.int64)
     dkey = d_ae * big + sep[dcol_glob] * lv.ndof2 + dcol_glob
     pos = np.searchsorted(ukey, dkey)
-    assert np.array_equal(ukey[pos], dkey), "D_2 couples an agglomerate with a dof outside it"
+    if not np.array_equal(ukey[np.minimum(pos, ukey.size - 1)], dkey):
+        raise ValueError("DistributeAgglomerateMatrix: D_2 couples an agglomerate with a dof outside it")
     d_col = pos - ae_d2_ptr[d_ae]
     d_ptr = ptr_from_counts(np.bincount(d_ae, minlength=nAE))
     # pv_p and cP from P_3 (packed p_loc of the element kernel: col-major np x k3 per agglomerate)

@@ -166,7 +166,8 @@ def _asm(keep, lv, tb, j, c, topo, look):
     n_e = np.diff(ep)[ai]
     q, own = expand_ranges(ep[ai], n_e)
     loc = look.find(ent_of_item[own], ei[q])
-    assert np.all(loc >= 0)
+    if not np.all(loc >= 0):
+        raise ValueError("DofAgglomeration: an entity dof is missing from its agglomerate's dof list (inconsistent level tables)")
     ptr, vals = lv.M[j][c]
     return _assembly(keep, ent_of_item, nA, ptr[ai], n_e, loc, vals)
 
@@ -177,7 +178,8 @@ def _triplets(D: sp.csr_matrix, rows_ptr, rows, look_cols: _Lookup):
     lr = np.arange(rows.size, dtype=np.int64) - rows_ptr[ent]
     q, own = expand_ranges(D.indptr[rows], np.diff(D.indptr)[rows])
     lc = look_cols.find(ent[own], D.indices[q].astype(np.int64))
-    assert np.all(lc >= 0), "a derivative couples an agglomerate with a dof outside it"
+    if not np.all(lc >= 0):
+        raise ValueError("DistributeAgglomerateMatrix: a derivative couples an agglomerate with a dof outside it")
     e = ent[own]
     return ptr_from_counts(np.bincount(e, minlength=len(rows_ptr) - 1)), lr[own], lc, D.data[q]
 
@@ -213,7 +215,8 @@ def coarsen(lv: SeqLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entr
         kmax = 1 + nT
         # ======== coarse traces ========
         if j == 0:                                                   # Compute0formCoarseTraces
-            assert np.all(np.diff(rp) == 1), "likely topology error, possibly disconnected edge"
+            if not np.all(np.diff(rp) == 1):                            # the reference's message (DeRhamSequence.cpp:1553-1556)
+                raise ValueError("DeRhamSequence::compute0formCoarseTraces: likely topology error, possibly disconnected edge.")
             ncoarse = np.ones(nAt, dtype=np.int64)
             o_p = np.ones(nAt); o_cm = np.ones(nAt); o_f = np.ones(nAt)
             kmax = 1
@@ -273,7 +276,8 @@ def coarsen(lv: SeqLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entr
             iq, owni = expand_ranges(pp[:-1], npi)                     # interior p dofs
             ip_ptr = ptr_from_counts(npi)
             if mode == 0:
-                assert np.array_equal(npi, np_)
+                if not np.array_equal(npi, np_):
+                    raise ValueError("hFacetExtension: form j+1 has dofs on entities of higher codimension than its trace entities")
                 nrt = cdp.cnt[cdom] - 1
                 pv_cols = (ptr_from_counts(np.ones(nA, dtype=np.int64)), pint_base + pint_ptr[:-1])
                 pv_p = _gather_dense(Pp, pp, pd, _Lookup(pv_cols[0], pv_cols[1], Pp.shape[1]), np.ones(nA, dtype=np.int64))
