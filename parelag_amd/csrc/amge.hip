@@ -180,8 +180,9 @@ __device__ int gauss_solve(double *A, int n, int m, int *piv)
 
 // One-sided Jacobi: rotates the k columns (length n, col-major) of A until they are orthogonal in the inner product whose
 // Gram data is carried by Y = W A (pass Y == A for the Euclidean product; Y is rotated along).  Afterwards sh.sv[j] is
-// the norm of column j and sh.perm the column order by descending norm.
-__device__ void jacobi_orthogonalise(double *A, double *Y, int n, int k, Shared &sh)
+// the norm of column j and sh.perm the column order by descending norm.  floor2: squared norm below which a column is noise
+// (a small fraction of the caller's cut-off).
+__device__ void jacobi_orthogonalise(double *A, double *Y, int n, int k, Shared &sh, double floor2)
 {
     const bool same = (A == Y);
     for (int sweep = 0; sweep < 40; sweep++) {
@@ -195,7 +196,9 @@ __device__ void jacobi_orthogonalise(double *A, double *Y, int n, int k, Shared 
                     g += A[p * n + i] * Y[q * n + i];
                 }
                 block_sum3(a, b, g, sh.red);
-                if (a > 0.0 && b > 0.0 && fabs(g) > 1e-15 * sqrt(a * b)) {
+                // (two columns whose norms are both far below the cut-off are rounding noise that will be dropped: rotating
+                // them against each other would only keep the sweeps going)
+                if (a > 0.0 && b > 0.0 && (a > floor2 || b > floor2) && fabs(g) > 1e-15 * sqrt(a * b)) {
                     rotated = 1;
                     const double zeta = (b - a) / (2.0 * g);
                     const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -328,7 +331,7 @@ __global__ void coarsen_traces_kernel(TracesArgs a)
     __syncthreads();
     mat_times_cols(M, n, Tm, Y, n, k0);
     __syncthreads();
-    jacobi_orthogonalise(Tm, Y, n, k0, sh);
+    { const double cut = pvpv * a.svd_tol * 1e-3; jacobi_orthogonalise(Tm, Y, n, k0, sh, cut * cut); }
     // keep the directions whose singular value is not below (pv,pv)_M * tol (:1875-1882)
     if (threadIdx.x == 0) {
         const double tol = pvpv * a.svd_tol;
@@ -365,7 +368,7 @@ __global__ void coarsen_traces_kernel(TracesArgs a)
 struct ExtArgs {
     int n_ent, nT, mode;          // mode 0: FacetSaddlePoint (PV multiplier row), 1: RidgePeakSaddlePoint ([M B^T; B -C])
     int null_dofs;                // 0: no null-space dofs are built (the "peak" stage of the 0-forms)
-    int debug_stop;               // diagnostic: leave the kernel after phase k (ELAG_HIP_AMGE_STOP), 0 = run everything
+    int debug_stop;               // diagnostic builds (-DELAG_AMGE_PHASE_STOP): leave the kernel after phase k (ELAG_HIP_AMGE_STOP)
     double svd_tol, smallest_entry;
     const int *nu, *ni, *np, *npi, *nq, *next, *nrt;
     AsmDev mass_u, mass_p, mass_q;
@@ -427,7 +430,9 @@ __global__ void coarsen_extension_kernel(ExtArgs a)
         zero_fill(D2l, nq * np);
     }
     __syncthreads();
+#ifdef ELAG_AMGE_PHASE_STOP
     if (a.debug_stop == 1) return;
+#endif
     for (int64_t t = a.d_ptr[e] + threadIdx.x; t < a.d_ptr[e + 1]; t += blockDim.x) Dl[a.d_row[t] * nu + a.d_col[t]] = a.d_val[t];
     if (a.mode)
         for (int64_t t = a.d2_ptr[e] + threadIdx.x; t < a.d2_ptr[e + 1]; t += blockDim.x) D2l[a.d2_row[t] * np + a.d2_col[t]] = a.d2_val[t];
@@ -499,9 +504,13 @@ __global__ void coarsen_extension_kernel(ExtArgs a)
         K[r * m + n + next + nrt + c] = s;
     }
     __syncthreads();
+#ifdef ELAG_AMGE_PHASE_STOP
     if (a.debug_stop == 2) return;
+#endif
     int bad = solve ? gauss_solve(K, n, m, sh.piv) : 0;
+#ifdef ELAG_AMGE_PHASE_STOP
     if (a.debug_stop == 3) return;
+#endif
     if (bad) {
         if (threadIdx.x == 0) { atomicAdd(a.singular, 1); a.n_null[e] = 0; }
         return;
@@ -525,7 +534,7 @@ __global__ void coarsen_extension_kernel(ExtArgs a)
     __syncthreads();
     int knull = 0;
     if (nTe > 0) {
-        jacobi_orthogonalise(ti, ti, ni, nTe, sh);
+        { const double cut = a.svd_tol * 1e-3; jacobi_orthogonalise(ti, ti, ni, nTe, sh, cut * cut); }
         if (threadIdx.x == 0) {
             int k = 0;
             const int kcap = nTe < ni ? nTe : ni;
@@ -535,7 +544,9 @@ __global__ void coarsen_extension_kernel(ExtArgs a)
         __syncthreads();
         knull = sh.cnt;
     }
+#ifdef ELAG_AMGE_PHASE_STOP
     if (a.debug_stop == 4) return;
+#endif
     double *onul = a.nul + a.off_nul[e];
     for (int t = threadIdx.x; t < ni * a.nT; t += blockDim.x) {
         const int c = t / ni, i = t - c * ni;
@@ -567,7 +578,9 @@ __global__ void coarsen_extension_kernel(ExtArgs a)
         ocm[r * ncolmax + c] = v;
         ocm[c * ncolmax + r] = v;
     }
+#ifdef ELAG_AMGE_PHASE_STOP
     if (a.debug_stop == 5) return;
+#endif
     // cochain projector functional of the interior dofs: [RangeT | null] in the M_ii inner product (:2530-2538)
     double *ofun = a.functional + a.off_fun[e];
     for (int t = threadIdx.x; t < kfmax * ni; t += blockDim.x) ofun[t] = 0.0;
