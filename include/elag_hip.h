@@ -323,6 +323,13 @@ ELAG_HIP_API int elag_hip_hierarchy_build_hiptmair(elag_hip_hierarchy_t *out, el
 /* new -> old row map of a level (identity when the hierarchy was not reordered); `order` has num_rows entries */
 ELAG_HIP_API int elag_hip_hierarchy_get_ordering(elag_hip_hierarchy_t H, int level, int *order);
 ELAG_HIP_API int elag_hip_hierarchy_get_operator(elag_hip_hierarchy_t H, int level, elag_hip_parcsr_t *A);
+/* A finalized hierarchy wrapped as a solver object, for the places where a parameter list names an AMGe hierarchy as an
+ * inner inverse: "A00_1 Inverse" = "AMGe-GS" of the Block LDU list (example_parameterlists/spe10_example_parameters.xml:114-127,
+ * src/linalg/factories/ParELAG_Block2x2LDUSolverFactory.cpp).  Pass the handle as an entry of `inverses` to
+ * elag_hip_block_smoother_create or as a ELAG_HIP_PREC_SMOOTHER preconditioner.  scale multiplies the result (-1: a hierarchy
+ * built on  B D^-1 B^T  applied as the inverse of the saddle point's Schur complement  -B D^-1 B^T).  The hierarchy is
+ * borrowed; destroy the wrapper with elag_hip_smoother_destroy. */
+ELAG_HIP_API int elag_hip_smoother_from_hierarchy(elag_hip_smoother_t *out, elag_hip_hierarchy_t H, double scale);
 ELAG_HIP_API int elag_hip_hierarchy_get_smoother(elag_hip_hierarchy_t H, int level, elag_hip_smoother_t *S);
 
 /* --------------------------------------------------------------------------------------------------

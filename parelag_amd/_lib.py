@@ -131,6 +131,7 @@ _SIGNATURES = {
                                           C.POINTER(AMGeOptions)],
     "elag_hip_hierarchy_get_ordering": [_p, _i, _p],
     "elag_hip_hierarchy_get_operator": [_p, _i, C.POINTER(_p)],
+    "elag_hip_smoother_from_hierarchy": [C.POINTER(_p), _p, _d],
     "elag_hip_hierarchy_get_smoother": [_p, _i, C.POINTER(_p)],
     "elag_hip_blockop_create": [C.POINTER(_p), _i, _i, _p, _p],
     "elag_hip_blockop_set_block": [_p, _i, _i, _p],

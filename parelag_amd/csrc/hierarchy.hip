@@ -322,6 +322,24 @@ void hierarchy_apply_raw(elag_hip_hierarchy_s *H, const double *rhs, double *sol
     H->run(rhs, sol, precond);
 }
 bool hierarchy_is_local(const elag_hip_hierarchy_s *H) { return H->all_local; }
+
+// A hierarchy standing where the reference puts any mfem::Solver: the "A00 Inverse" / "S Inverse" entries of the
+// Block2x2*SolverFactory lists name AMGe hierarchies (example_parameterlists/spe10_example_parameters.xml:114-127,
+// "A00_1 Inverse" = "AMGe-GS").  scale multiplies the result: -1 applies  -(B D^-1 B^T)^-1  with a hierarchy built on the
+// positive matrix  B D^-1 B^T  (the Schur complement of the saddle point is its negative).
+struct HierarchySolver : elag_hip_smoother_s {
+    elag_hip_hierarchy_s *H = nullptr;
+    double scale = 1.0;
+    void apply(const double *f, double *&cur, double *&, bool zero_guess, bool) override
+    {
+        // the V-cycle with its symmetric smoothers is its own transpose (Hierarchy::MultTranspose is not implemented in the
+        // reference either: ParELAG_Hierarchy.hpp:125-129)
+        ELAG_REQUIRE(scale == 1.0 || zero_guess, "a scaled hierarchy can only be applied as a preconditioner (iterative_mode == false)");
+        hierarchy_apply_raw(H, f, cur, zero_guess);
+        if (scale != 1.0) k::vec_axpby(n(), scale, cur, 0.0, cur, cur);
+    }
+    int flips(bool) const override { return 0; }
+};
 int hierarchy_height(const elag_hip_hierarchy_s *H) { return (H->reordered ? H->A_user : H->lev[0].A)->nrows(); }
 }  // namespace elag
 
@@ -687,6 +705,20 @@ int elag_hip_hierarchy_get_ordering(elag_hip_hierarchy_t H, int level, int *orde
 int elag_hip_hierarchy_get_operator(elag_hip_hierarchy_t H, int level, elag_hip_parcsr_t *A)
 {
     return guarded([&] { ELAG_REQUIRE(A, "null output"); *A = level_of(H, level).A; });
+}
+
+int elag_hip_smoother_from_hierarchy(elag_hip_smoother_t *out, elag_hip_hierarchy_t H, double scale)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(out && H, "null argument");
+        ELAG_REQUIRE(H->finalized, "the hierarchy must be finalized before it is used as a solver");
+        auto *S = new elag::HierarchySolver();
+        S->H = H;
+        S->scale = scale;
+        S->A = H->reordered ? H->A_user : H->lev[0].A;
+        *out = S;
+    });
 }
 
 int elag_hip_hierarchy_get_smoother(elag_hip_hierarchy_t H, int level, elag_hip_smoother_t *S)

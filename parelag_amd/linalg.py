@@ -393,6 +393,21 @@ class HypreSmootherWrapper(_SolverBase):
             pass
 
 
+class HierarchySolver(HypreSmootherWrapper):
+    """A finalized ``Hierarchy`` as an inner solver object -- what the parameter lists call an AMGe solver in an
+    "A00 Inverse" / "S Inverse" entry (``example_parameterlists/spe10_example_parameters.xml:114-127``).  ``scale = -1``
+    applies the negative of the cycle (hierarchy built on ``B D^-1 B^T``, used as the inverse of ``-B D^-1 B^T``)."""
+
+    def __init__(self, H: "Hierarchy", scale: float = 1.0):
+        lib = _lib.init()
+        handle = _vp()
+        check(lib.elag_hip_smoother_from_hierarchy(C.byref(handle), H.h, float(scale)))
+        A0 = H.GetOperator(0)
+        super().__init__(A0, type=-1, handle=handle, owner=True)
+        self._keep = [H, A0]
+        self.iterative_mode = False
+
+
 class HiptmairSmoother(HypreSmootherWrapper):
     """HiptmairSmoother(A, A_aux, D, primary, auxiliary) (ParELAG_HiptmairSmoother.cpp:22-46)."""
 

@@ -320,3 +320,78 @@ def test_heterogeneous_coefficient_darcy_cycle_matches_oracle(la):
         x, xr = np.zeros_like(b), np.zeros_like(b)
         H.Mult(b, x); Ho.Mult(b, xr)
         assert close(x, xr, 1e-10)
+
+
+# ---- AMGe hierarchies as the inner inverses of the block solvers ("A00_1 Inverse" = "AMGe-GS", spe10_example_parameters.xml:114-127)
+
+def test_block_ldu_with_inner_amge_hierarchies(la, darcy_small):
+    """GMRES preconditioned by Block2x2LDUInverseOperator whose four inverses are AMGe V-cycles: three on A00 = M (2-form
+    hierarchy) and one on the Schur complement, applied as -(B diag(M)^-1 Bt)^-1 by a hierarchy built on the positive matrix
+    with the 3-form interpolators -- the solver graph of the reference's SPE10 list with the BoomerAMG entry replaced by an
+    AMGe cycle.  Far fewer iterations than with Jacobi-class inner inverses, same counts as the oracle composition."""
+    from tests.helpers import oracle_h1_hierarchy, oracle_py_hierarchy, oracle_inner_smoother
+    d = darcy_small
+    M, B, Bt = orc.csr(d["M"]), orc.csr(d["B"]), orc.csr(d["Bt"])
+    n0, n1 = M.shape[0], B.shape[0]
+    A = sp.bmat([[M, Bt], [B, None]]).tocsr()
+    Spos = orc.csr(B @ sp.diags(1.0 / M.diagonal()) @ Bt)
+    P2s, P3s = [orc.csr(p[0]) for p in d["Ps"]], [orc.csr(p[1]) for p in d["Ps"]]
+    op = device_blockop(la, d["blocks"], d["off"])
+
+    def dev_h(Aop, Pl):
+        dA = la.ParallelCSRMatrix.from_scipy(Aop)
+        return la.buildHierarchyFromDeRhamSequence(dA, [la.ParallelCSRMatrix.from_scipy(P) for P in Pl], "L1 Jacobi")
+    HM, HS = dev_h(M, P2s), dev_h(Spos, P3s)
+    iM, iS = la.HierarchySolver(HM), la.HierarchySolver(HS, scale=-1.0)
+    ldu = la.Block2x2LDUInverseOperator(op, iM, iM, iM, iS)
+    ldu.iterative_mode = False
+
+    class OH:
+        iterative_mode = False
+
+        def __init__(self, Aop, Pl, scale):
+            self.H = oracle_py_hierarchy(oracle_h1_hierarchy(Aop, Pl, smoother=1))
+            self.scale = scale
+
+        def Mult(self, r, z):
+            z[:] = 0.0
+            self.H.Mult(r, z)
+            z *= self.scale
+    oM, oS = OH(M, P2s, 1.0), OH(Spos, P3s, -1.0)
+    oop = orc.OBlockOperator(d["off"], d["off"], {k: orc.OParCSR(orc.csr(v)) for k, v in d["blocks"].items()})
+    oldu = orc.OBlock2x2LDU(oop, oM, oM, oM, oS)
+    rng = np.random.default_rng(31)
+    r = rng.uniform(-1, 1, n0 + n1)
+    z, zr = np.full(n0 + n1, 9.0), np.zeros(n0 + n1)
+    ldu.Mult(r, z)
+    oldu.Mult(r, zr)
+    assert close(z, zr, 1e-10)
+    # the inner solver alone, and its sign
+    y, yr = np.zeros(n1), np.zeros(n1)
+    iS.Mult(r[n0:], y)
+    oS.Mult(r[n0:], yr)
+    assert close(y, yr, 1e-11) and (r[n0:] @ y) < 0.0
+    rhs = np.concatenate([np.zeros(n0), d["seq"].meshes[0].M3() @ np.ones(n1)])
+    K = la.KrylovSolver(op, ldu, {"Solver name": "GMRES", "Relative tolerance": 1e-8, "Maximum iterations": 200, "Restart size": 50})
+    x = np.zeros(n0 + n1)
+    K.Mult(rhs, x)
+    xo = np.zeros(n0 + n1)
+
+    def oprec(rr, zz):
+        zz[:] = 0.0
+        oldu.Mult(rr, zz)
+    ref = orc.mfem_gmres(lambda v: A @ v, oprec, rhs, xo, rel_tol=1e-8, max_iter=200, m=50)
+    assert K.GetConverged() and ref.converged and abs(K.GetNumIterations() - ref.final_iter) <= 1 and ref.final_iter < 60
+    assert close(x, xo, 1e-6)
+    # against Jacobi-class inner inverses
+    jM = la.HypreSmootherWrapper(op.GetBlock(0, 0), 1)
+    jS = la.HypreSmootherWrapper(la.SchurComplement(op, "DIAGONAL", 1.0, False), 1)
+    lduj = la.Block2x2LDUInverseOperator(op, jM, jM, jM, jS)
+    lduj.iterative_mode = False
+    Kj = la.KrylovSolver(op, lduj, {"Solver name": "GMRES", "Relative tolerance": 1e-8, "Maximum iterations": 400, "Restart size": 50})
+    xj = np.zeros(n0 + n1)
+    Kj.Mult(rhs, xj)
+    assert Kj.GetNumIterations() > 2 * K.GetNumIterations()
+    with pytest.raises(la._lib.ElagHipError, match="preconditioner"):
+        iS.iterative_mode = True
+        iS.Mult(r[n0:], y)
