@@ -203,11 +203,53 @@ public:
 
     void Keep(const std::shared_ptr<void> &p) { keep_.push_back(p); }
     void SetHeight(int n) { n0_ = n; }
+    elag_hip_hierarchy_t Handle() const { return h_; }
 
 private:
     elag_hip_hierarchy_t h_ = nullptr;
     std::vector<std::shared_ptr<void>> keep_;
     int n0_ = 0;
+};
+
+// A finalized hierarchy as an inner solver object: what a parameter list means by an AMGe solver in an "A00_1 Inverse" /
+// "S Inverse" entry (example_parameterlists/spe10_example_parameters.xml:114-127).  scale = -1: a hierarchy built on
+// B diag(M)^-1 B^T applied as the inverse of the saddle point's Schur complement.
+class HierarchySolver : public HypreSmootherWrapper {
+public:
+    explicit HierarchySolver(const std::shared_ptr<Hierarchy> &H, double scale = 1.0) : H_(H)
+    {
+        check(elag_hip_smoother_from_hierarchy(&h_, H->Handle(), scale));
+        iterative_mode = false;
+    }
+    int Height() const override { return H_->Height(); }
+
+private:
+    std::shared_ptr<Hierarchy> H_;
+};
+
+// parelag::KrylovSolver(A, Prec, params) (src/linalg/solver_ops/ParELAG_KrylovSolver.cpp:23-96): "Solver name" CG/PCG, GMRES,
+// FGMRES, BiCGSTAB, MINRES with the iteration resident on the device.
+class KrylovSolver : public Solver {
+public:
+    KrylovSolver(const std::shared_ptr<ParallelCSRMatrix> &A, const std::shared_ptr<Hierarchy> &prec, const elag_hip_krylov_options &opt)
+        : A_(A), keep_(prec)
+    { check(elag_hip_krylov_create(&h_, A->Handle(), ELAG_HIP_PREC_HIERARCHY, prec->Handle(), &opt)); iterative_mode = false; }
+    KrylovSolver(const std::shared_ptr<ParallelCSRMatrix> &A, const std::shared_ptr<HypreSmootherWrapper> &prec, const elag_hip_krylov_options &opt)
+        : A_(A), keep_(prec)
+    { check(elag_hip_krylov_create(&h_, A->Handle(), prec ? ELAG_HIP_PREC_SMOOTHER : ELAG_HIP_PREC_NONE, prec ? prec->Handle() : nullptr, &opt)); iterative_mode = false; }
+    ~KrylovSolver() override { if (h_) elag_hip_krylov_destroy(h_); }
+    static elag_hip_krylov_options DefaultOptions() { elag_hip_krylov_options o; check(elag_hip_krylov_default_options(&o)); return o; }
+    void Mult(const double *rhs, double *sol, int loc = ELAG_HIP_HOST) const override
+    { check(elag_hip_krylov_mult(h_, rhs, sol, iterative_mode ? 1 : 0, loc)); }
+    int Height() const override { return A_->Height(); }
+    int GetNumIterations() const { int c, it; double nrm; check(elag_hip_krylov_get_stats(h_, &c, &it, &nrm)); return it; }
+    bool GetConverged() const { int c, it; double nrm; check(elag_hip_krylov_get_stats(h_, &c, &it, &nrm)); return c != 0; }
+    double GetFinalNorm() const { int c, it; double nrm; check(elag_hip_krylov_get_stats(h_, &c, &it, &nrm)); return nrm; }
+
+private:
+    std::shared_ptr<ParallelCSRMatrix> A_;
+    std::shared_ptr<void> keep_;
+    elag_hip_krylov_t h_ = nullptr;
 };
 
 // ---- blocked (saddle-point) layer: MfemBlockOperator, SchurComplementFactory, Block2x2 smoothers -----------------------

@@ -87,6 +87,28 @@ int main()
     double err = 0; for (int i = 0; i < n0; i++) err = std::fmax(err, std::fabs(x[i] - 0.5 * (i + 1.0) * (n0 - i)));
     REQUIRE(err < 1e-6 * 0.125 * n0 * (double)n0);
 
+    // the same solve through the device-resident Krylov shell (KrylovSolver.cpp:23-96): every "Solver name" of the reference
+    {
+        std::shared_ptr<Hierarchy> Hs = Hierarchy::Build(A, P, &opt);
+        for (int name : {ELAG_HIP_KRYLOV_CG, ELAG_HIP_KRYLOV_GMRES, ELAG_HIP_KRYLOV_FGMRES, ELAG_HIP_KRYLOV_BICGSTAB, ELAG_HIP_KRYLOV_MINRES}) {
+            elag_hip_krylov_options ko = KrylovSolver::DefaultOptions();
+            ko.solver = name; ko.rel_tol = 1e-10; ko.max_iter = 60;
+            KrylovSolver K(A, Hs, ko);
+            std::vector<double> xk(n0, 3.0);
+            K.Mult(b.data(), xk.data());
+            REQUIRE(K.GetConverged() && K.GetNumIterations() <= 20);
+            double e2 = 0; for (int i = 0; i < n0; i++) e2 = std::fmax(e2, std::fabs(xk[i] - 0.5 * (i + 1.0) * (n0 - i)));
+            REQUIRE(e2 < 1e-6 * 0.125 * n0 * (double)n0);
+        }
+        // a hierarchy as an inner solver object equals the hierarchy applied as a preconditioner; scale = -1 negates it
+        HierarchySolver inner(Hs), neg(Hs, -1.0);
+        std::vector<double> z1(n0), z2(n0, 7.0), z3(n0, 7.0);
+        Hs->Mult(b.data(), z1.data());
+        inner.Mult(b.data(), z2.data());
+        neg.Mult(b.data(), z3.data());
+        for (int i = 0; i < n0; i++) { REQUIRE(z1[i] == z2[i]); REQUIRE(z3[i] == -z1[i]); }
+    }
+
     // level-by-level assembly through the Level keys gives the same operator
     Hierarchy H2(levels);
     std::vector<std::shared_ptr<ParallelCSRMatrix>> ops{A};
