@@ -126,3 +126,38 @@ def test_second_level_topology_tables_are_bit_exact(kuhn):
     a, b = oa.coarsen_topology(r0["coarse"], seq.partition(1)), amge.coarsen_topology(r0["coarse"], seq.partition(1))
     for k in TOPO_KEYS:
         assert np.array_equal(a[k], b[k]), k
+
+
+def upscaling_errors(coarsen_sequence):
+    """Numerical upscaling (what ParElag is for, ``examples/Upscaling*.cpp``): the mixed Darcy problem with a smooth source is
+    solved on every level of the AMGe sequence (Galerkin operators ``P^T A P``) and the prolongated coarse solutions are
+    compared with the fine one in the mass norms.  Returns [(u error, p error) per coarse level]."""
+    import scipy.sparse.linalg as spl
+    seq = meshgen.Sequence.kuhn_cube(2, 2)
+    lv = level_from_tets(seq.meshes[0])
+    res = coarsen_sequence(lv, [seq.partition(0), seq.partition(1)])
+    M, B, Bt = lv.darcy_blocks()
+    W = lv.mass3()
+    n0, n1 = M.shape[0], B.shape[0]
+    A = sp.bmat([[M, Bt], [B, None]]).tocsc()
+    xc = seq.meshes[0].vertices[seq.meshes[0].tets].mean(1)
+    f = np.prod(np.sin(np.pi * xc), axis=1)
+    rhs = np.concatenate([np.zeros(n0), -(W @ (f * lv.const3))])
+    xf = spl.spsolve(A, rhs)
+    uf, pf = xf[:n0], xf[n0:]
+    out = []
+    P2, P3 = sp.identity(n0), sp.identity(n1)
+    for r in res:
+        P2, P3 = P2 @ r["P2"], P3 @ r["P3"]
+        P = sp.block_diag([P2, P3]).tocsc()
+        xu = P @ spl.spsolve((P.T @ A @ P).tocsc(), P.T @ rhs)
+        eu, ep = xu[:n0] - uf, xu[n0:] - pf
+        out.append((np.sqrt((eu @ (M @ eu)) / (uf @ (M @ uf))), np.sqrt((ep @ (W @ ep)) / (pf @ (W @ pf)))))
+    return out
+
+
+def test_upscaling_error_decreases_like_h():
+    (u1, p1), (u2, p2) = upscaling_errors(oa.coarsen_sequence)
+    # lowest-order spaces: O(h) in both variables -- the error roughly doubles with every coarsening
+    assert 0.15 < u1 < 0.30 and 0.15 < p1 < 0.30
+    assert 1.7 < u2 / u1 < 2.6 and 1.7 < p2 / p1 < 2.6

@@ -13,7 +13,7 @@ import scipy.sparse as sp
 from oracle import amge as oa
 from parelag_amd import meshgen
 from parelag_amd.amge_level import box_partition, level_from_hex, level_from_tets
-from tests.test_amge_oracle import TOPO_KEYS, invariants
+from tests.test_amge_oracle import TOPO_KEYS, invariants, upscaling_errors
 
 pytestmark = pytest.mark.gpu
 
@@ -183,3 +183,11 @@ def test_amge_spaces_in_the_blocked_darcy_cycle(amge):
     xr, ito = gmres(lambda v: A @ v, ora, rhs, rtol=1e-8)
     assert it == ito and it < 100
     assert np.max(np.abs(x - xr)) < 1e-7 * np.max(np.abs(xr))
+
+
+def test_upscaling_errors_equal_the_oracle_s(amge):
+    """The device-built sequence upscales the Darcy problem exactly like the oracle's (``examples/Upscaling*.cpp``)."""
+    dev = upscaling_errors(amge.coarsen_sequence)
+    ref = upscaling_errors(oa.coarsen_sequence)
+    assert np.allclose(dev, ref, rtol=1e-8)
+    assert dev[1][0] > 1.7 * dev[0][0]
