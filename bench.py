@@ -245,12 +245,27 @@ def main():
         seq = dar["seq"]
         Ps = dar["Ps"]
         A = sp.bmat([[dar["M"], dar["Bt"]], [dar["B"], None]]).tocsr()
-    elif args.amge:
-        # forms 0 / 2 on AMGe spaces: the whole sequence is coarsened on the device (every rank does the whole mesh; the
+    elif args.amge or args.hex:
+        # forms 0 / 1 / 2 on AMGe spaces: the whole sequence is coarsened on the device (every rank does the whole mesh; the
         # distributed builders partition the result like the generator's interpolators)
         from parelag_amd import derham
-        seq = meshgen.Sequence.cube456(args.refines)
-        A, Ps, Ds, _levels, amge_rec = derham.amge_problem(args.form, seq)
+        if args.hex:
+            # the SPE10 grid in its "derefinement" flavour (MultigridTestSPE10.cpp:441: jformStart = 0): 2 x 2 x 2 boxes of cells
+            if not single:
+                raise SystemExit("--hex: single-GPU only in this round (the row-block partitioner works on the cube456 meshes)")
+            from parelag_amd.amge_level import box_partition
+            from parelag_amd.derham_level import seq_level_from_hex
+            nh = tuple(args.hex)
+            lvh = seq_level_from_hex(nh, h=(20.0, 10.0, 2.0), jstart=0 if args.form <= 1 else 1)
+            parts_h, mh = [], nh
+            while (args.amge_levels is None and mh[0] * mh[1] * mh[2] > 2000) or (args.amge_levels is not None and len(parts_h) < args.amge_levels):
+                parts_h.append(box_partition(mh, (2, 2, 2)))
+                mh = tuple(-(-v // 2) for v in mh)
+            seq = None
+            A, Ps, Ds, _levels, amge_rec = derham.amge_problem(args.form, level=lvh, parts=parts_h, what="hex %dx%dx%d, 2x2x2 box agglomerates" % nh)
+        else:
+            seq = meshgen.Sequence.cube456(args.refines)
+            A, Ps, Ds, _levels, amge_rec = derham.amge_problem(args.form, seq)
         note("AMGe coarsening (forms %d..3): %d levels in %.3f s" % (0 if args.form <= 1 else 1, len(Ps), amge_rec["coarsen_total_s"]))
     elif args.form == 2:
         A, Ps, Ds, seq = meshgen.hdiv_problem(args.refines)
@@ -365,8 +380,11 @@ def main():
             Kop = bop
         else:
             kparams = {"Solver name": "PCG", "Relative tolerance": 1e-6, "Absolute tolerance": 1e-6, "Maximum iterations": 100}
-            fine_mesh = seq.meshes[0]                                       # Create0FormParameterList.hpp:78-83
-            if args.form == 0:
+            fine_mesh = seq.meshes[0] if seq is not None else None          # Create0FormParameterList.hpp:78-83
+            if seq is None:                                                 # hex grid: unit load, zero on the essential (eliminated) rows
+                offdiag = np.asarray(abs(A - sp.diags(A.diagonal())).sum(axis=1)).ravel()
+                b_solve = np.where(offdiag == 0.0, 0.0, 1.0)
+            elif args.form == 0:
                 b_solve = meshgen.load_vector_P1(fine_mesh, fine_mesh.boundary_marker_unit_cube())
             else:
                 b_solve = np.where(fine_mesh.boundary_marker(args.form), 0.0, 1.0)
@@ -576,7 +594,7 @@ def main():
         })
         if solve is not None:
             out["solve"] = solve
-        if not darcy and args.amge:
+        if not darcy and (args.amge or args.hex):
             out["amge"] = amge_rec
             out["config"]["interpolators"] = amge_rec["what"]
         if darcy and "amge" in dar:

@@ -437,26 +437,33 @@ def boundary_dofs(lv: SeqLevel, j: int) -> np.ndarray:
     return mk
 
 
-def amge_problem(form: int, seq, timings: dict | None = None):
+def amge_problem(form: int, seq=None, level: SeqLevel | None = None, parts: list | None = None, what: str | None = None):
     """The operators of MultigridTest0Form / 1Form / 2Form on AMGe spaces built by the device coarsening: fine operator
-    (``D0^T M1 D0`` resp. ``M2 + D2^T M3 D2``) with all boundary attributes essential, the interpolators ``P_form`` of every
-    level with essential columns eliminated (``ComputeTrueP(jform, ess)``, ``src/amge/DeRhamSequence.cpp:1118-1153,1230-1253``)
-    and, for the Hiptmair smoother of the 2-form, the derivative ``D_1`` of every level with essential columns eliminated
-    (``HiptmairSmootherFactory.cpp:84-103``).  Returns (A, Ps, Ds or None, levels, record)."""
+    (``D0^T M1 D0`` resp. ``M_j + D_j^T M_{j+1} D_j``) with all boundary attributes essential, the interpolators ``P_form`` of
+    every level with essential columns eliminated (``ComputeTrueP(jform, ess)``, ``src/amge/DeRhamSequence.cpp:1118-1153,1230-1253``)
+    and, for the Hiptmair smoother, the derivative ``D_{form-1}`` of every level with essential columns eliminated
+    (``HiptmairSmootherFactory.cpp:84-103``).  Either ``seq`` (the generator's refined cube456: derefinement agglomerates)
+    or a finest ``level`` with its list of element partitionings.  Returns (A, Ps, Ds or None, levels, record)."""
     import time
     from . import meshgen
     from .derham_level import seq_level_from_tets
     t0 = time.time()
-    lv = seq_level_from_tets(seq.meshes[0], jstart=0 if form <= 1 else 1)
+    if level is None:
+        lv = seq_level_from_tets(seq.meshes[0], jstart=0 if form <= 1 else 1)
+        parts = [seq.partition(l) for l in range(len(seq.meshes) - 1)]
+        what = "cube456 x%d tets, derefinement agglomerates" % (len(seq.meshes) - 1)
+    else:
+        lv = level
     gen_s = time.time() - t0
     levels, Ps, recs = [lv], [], []
     t0 = time.time()
-    for l in range(len(seq.meshes) - 1):
+    for part in parts:
         tm = {}
         t1 = time.time()
-        res = coarsen(levels[-1], seq.partition(l), timings=tm)
+        res = coarsen(levels[-1], part, timings=tm)
         c = res["coarse"]
         recs.append({"agglomerates": c.n[0], "entities": c.n, "dofs": [c.ndof(j) for j in range(c.jstart, 4)],
+                     "null_dofs": {str(j): v for j, v in res["n_null"].items()},
                      "wall_s": round(time.time() - t1, 4), "kernel_ms": round(sum(tm.values()), 4)})
         Ps.append(res["P"][form])
         levels.append(c)
@@ -471,7 +478,7 @@ def amge_problem(form: int, seq, timings: dict | None = None):
     A.sort_indices()
     A = meshgen.eliminate_rowcol(A, marks[0])
     Ps = [meshgen.eliminate_cols(P.tocsr(), marks[l + 1]) for l, P in enumerate(Ps)]
-    rec = {"what": "DeRhamSequence::Coarsen (jformStart=%d) on the device: cube456 x%d tets, derefinement agglomerates" % (lv.jstart, len(seq.meshes) - 1),
+    rec = {"what": "DeRhamSequence::Coarsen (jformStart=%d) on the device: %s" % (lv.jstart, what),
            "levels": recs, "coarsen_total_s": round(total_s, 3), "generate_s": round(gen_s, 2)}
     return A, Ps, Ds, levels, rec
 

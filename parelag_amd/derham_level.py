@@ -278,3 +278,106 @@ def seq_level_from_tets(mesh, jstart: int = 0, kinv: np.ndarray | None = None, b
         lv.D[0] = sp.csr_matrix((B2[2], B2[1], B2[0]), shape=(E, V))
         lv.T[0] = np.concatenate([np.ones((V, 1)), mesh.vertices], axis=1); lv.pv[0] = np.ones(V)
     return lv
+
+
+# ---- finest level on a Cartesian hex grid -----------------------------------------------------------------------------------
+
+def seq_level_from_hex(n, h=(1.0, 1.0, 1.0), jstart: int = 0, kinv: np.ndarray | None = None, bdr_attr: bool = True) -> SeqLevel:
+    """Lowest-order sequence (Q1, Nedelec, Raviart-Thomas, Q0 on boxes; dofs = integrals of the forms over vertices / edges /
+    faces / cells) on an ``n[0] x n[1] x n[2]`` Cartesian grid: the element type of ``examples/MultigridTestSPE10.cpp:194-208``
+    for every form (``amge_level.level_from_hex`` holds forms 2 and 3).  Edges point along their axis, faces along theirs
+    except the low-side boundary faces (outward), the face -> edge table carries the right-hand circulation."""
+    from .amge_level import level_from_hex
+    nx, ny, nz = (int(v) for v in n)
+    hx, hy, hz = (float(v) for v in h)
+    l2 = level_from_hex(n, h, kinv=kinv, bdr_attr=bdr_attr)
+    o = l2.meta["S2"]
+    nE, nF = l2.nE, l2.nF
+    I, J, K = (g.ravel() for g in np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij"))
+    vid = lambda i, j, k: (i * (ny + 1) + j) * (nz + 1) + k
+    nV = (nx + 1) * (ny + 1) * (nz + 1)
+    nEx, nEy, nEz = nx * (ny + 1) * (nz + 1), (nx + 1) * ny * (nz + 1), (nx + 1) * (ny + 1) * nz
+    ex = lambda i, j, k: (i * (ny + 1) + j) * (nz + 1) + k
+    ey = lambda i, j, k: nEx + (i * ny + j) * (nz + 1) + k
+    ez = lambda i, j, k: nEx + nEy + (i * (ny + 1) + j) * nz + k
+    nR = nEx + nEy + nEz
+    # edges -> vertices (tail, head)
+    def grid(a, b, c):
+        g = np.meshgrid(np.arange(a), np.arange(b), np.arange(c), indexing="ij")
+        return tuple(q.ravel() for q in g)
+    xi, xj, xk = grid(nx, ny + 1, nz + 1); yi, yj, yk = grid(nx + 1, ny, nz + 1); zi, zj, zk = grid(nx + 1, ny + 1, nz)
+    ev = np.concatenate([np.stack([vid(xi, xj, xk), vid(xi + 1, xj, xk)], 1), np.stack([vid(yi, yj, yk), vid(yi, yj + 1, yk)], 1),
+                         np.stack([vid(zi, zj, zk), vid(zi, zj, zk + 1)], 1)]).astype(np.int64)
+    elen = np.concatenate([np.full(nEx, hx), np.full(nEy, hy), np.full(nEz, hz)])
+    B2 = (2 * np.arange(nR + 1, dtype=np.int64), ev.reshape(-1), np.tile(np.array([-1.0, 1.0]), nR))
+    # faces -> edges with the right-hand circulation (numbering of the faces as in level_from_hex: x-, y-, z-faces)
+    fi, fj, fk = grid(nx + 1, ny, nz)
+    fe_x = np.stack([ey(fi, fj, fk), ez(fi, fj + 1, fk), ey(fi, fj, fk + 1), ez(fi, fj, fk)], 1)
+    gi, gj, gk = grid(nx, ny + 1, nz)
+    fe_y = np.stack([ez(gi, gj, gk), ex(gi, gj, gk + 1), ez(gi + 1, gj, gk), ex(gi, gj, gk)], 1)
+    hi, hj, hk = grid(nx, ny, nz + 1)
+    fe_z = np.stack([ex(hi, hj, hk), ey(hi + 1, hj, hk), ex(hi, hj + 1, hk), ey(hi, hj, hk)], 1)
+    fe = np.concatenate([fe_x, fe_y, fe_z]).astype(np.int64)
+    assert fe.shape[0] == nF
+    B1 = (4 * np.arange(nF + 1, dtype=np.int64), fe.reshape(-1), (np.array([1.0, 1.0, -1.0, -1.0])[None, :] * o[:, None]).reshape(-1))
+    B0 = (l2.ef_ptr, l2.ef_idx, l2.ef_sgn)
+    ones = lambda k: np.arange(k + 1, dtype=np.int64)
+    zeros = lambda k: np.zeros(k + 1, dtype=np.int64)
+    nn = [nE, nF, nR, nV]
+    idof = [[zeros(nE), zeros(nF), zeros(nR), ones(nV)], [zeros(nE), zeros(nF), ones(nR)], [zeros(nE), ones(nF)], [ones(nE)]]
+    lv = SeqLevel(n=nn, B=[B0, B1, B2], facet_attr=l2.facet_attr, jstart=jstart, idof=idof, M=[None] * 4, D=[None] * 3, T=[None] * 4,
+                  pv=[None] * 4, const3=l2.const3.copy(), meta=dict(S2=o, kind="hex", n=(nx, ny, nz), h=(hx, hy, hz)))
+    lv.M[3] = [(l2.M3e_ptr, l2.M3e)]
+    lv.M[2] = [(l2.M2e_ptr, l2.M2e), (l2.M2f_ptr, l2.M2f)]
+    lv.D[2] = l2.D2
+    lv.T[3], lv.pv[3], lv.T[2], lv.pv[2] = l2.T3, l2.pv3, l2.T2, l2.pv2
+    m2 = np.array([[1.0 / 3, 1.0 / 6], [1.0 / 6, 1.0 / 3]])
+    mm = np.kron(m2, m2)                                            # index (a, b) -> 2 a + b
+    tb = _Tables(lv)
+    if jstart <= 1:
+        # cell mass of the edge elements: per direction the four parallel edges, (h_b h_c / h_a) m (x) m
+        have = np.stack([ex(I, J, K), ex(I, J, K + 1), ex(I, J + 1, K), ex(I, J + 1, K + 1),          # (j', k') -> 2 j' + k'
+                         ey(I, J, K), ey(I, J, K + 1), ey(I + 1, J, K), ey(I + 1, J, K + 1),          # (i', k')
+                         ez(I, J, K), ez(I, J + 1, K), ez(I + 1, J, K), ez(I + 1, J + 1, K)], 1)      # (i', j')
+        loc = np.zeros((12, 12))
+        loc[0:4, 0:4] = mm * (hy * hz / hx); loc[4:8, 4:8] = mm * (hx * hz / hy); loc[8:12, 8:12] = mm * (hx * hy / hz)
+        p02, i02 = tb.conn(0, 2)
+        assert np.all(np.diff(p02) == 12)
+        loc1 = _reorder_blocks(np.broadcast_to(loc[None], (nE, 12, 12)).copy(), have, i02.reshape(nE, 12))
+        # face mass of the tangential trace, rows in the B1 row order (e0, e1, e2, e3): pairs (e0, e2) and (e1, e3) are parallel
+        def face_block(ha, hb):                                     # e0/e2 along a (spaced by hb), e1/e3 along b (spaced by ha)
+            blk = np.zeros((4, 4))
+            blk[np.ix_([0, 2], [0, 2])] = m2 * (hb / ha)
+            blk[np.ix_([3, 1], [3, 1])] = m2 * (ha / hb)
+            return blk
+        loc1f = np.concatenate([np.broadcast_to(face_block(hy, hz)[None], (fe_x.shape[0], 4, 4)),     # x-face: e0 = y-edge, e1 = z-edge
+                                np.broadcast_to(face_block(hz, hx)[None], (fe_y.shape[0], 4, 4)),     # y-face: e0 = z-edge, e1 = x-edge
+                                np.broadcast_to(face_block(hx, hy)[None], (fe_z.shape[0], 4, 4))])    # z-face: e0 = x-edge, e1 = y-edge
+        lv.M[1] = [(144 * ones(nE), np.ascontiguousarray(loc1).reshape(-1)), (16 * ones(nF), np.ascontiguousarray(loc1f).reshape(-1)),
+                   (ones(nR), 1.0 / elen)]
+        lv.D[1] = sp.csr_matrix((B1[2], B1[1], B1[0]), shape=(nF, nR))
+        T1 = np.zeros((nR, 3))
+        T1[:nEx, 0] = hx; T1[nEx:nEx + nEy, 1] = hy; T1[nEx + nEy:, 2] = hz
+        lv.T[1] = T1; lv.pv[1] = elen.copy()
+    if jstart <= 0:
+        have = np.stack([vid(I + a, J + b, K + c) for a in (0, 1) for b in (0, 1) for c in (0, 1)], 1)
+        loc = np.kron(m2, np.kron(m2, m2)) * (hx * hy * hz)
+        p03, i03 = tb.conn(0, 3)
+        assert np.all(np.diff(p03) == 8)
+        loc0 = _reorder_blocks(np.broadcast_to(loc[None], (nE, 8, 8)).copy(), have, i03.reshape(nE, 8))
+        # face mass: vertices of the face in its two in-plane directions
+        hv_x = np.stack([vid(fi, fj + b, fk + c) for b in (0, 1) for c in (0, 1)], 1)
+        hv_y = np.stack([vid(gi + a, gj, gk + c) for a in (0, 1) for c in (0, 1)], 1)
+        hv_z = np.stack([vid(hi + a, hj + b, hk) for a in (0, 1) for b in (0, 1)], 1)
+        have_f = np.concatenate([hv_x, hv_y, hv_z])
+        area = l2.pv2
+        p13, i13 = tb.conn(1, 3)
+        assert np.all(np.diff(p13) == 4)
+        loc0f = _reorder_blocks(mm[None] * area[:, None, None], have_f, i13.reshape(nF, 4))
+        loc0r = m2[None] * elen[:, None, None]
+        lv.M[0] = [(64 * ones(nE), np.ascontiguousarray(loc0).reshape(-1)), (16 * ones(nF), np.ascontiguousarray(loc0f).reshape(-1)),
+                   (4 * ones(nR), np.ascontiguousarray(loc0r).reshape(-1)), (ones(nV), np.ones(nV))]
+        lv.D[0] = sp.csr_matrix((B2[2], B2[1], B2[0]), shape=(nR, nV))
+        Vi, Vj, Vk = grid(nx + 1, ny + 1, nz + 1)
+        lv.T[0] = np.stack([np.ones(nV), Vi * hx, Vj * hy, Vk * hz], 1); lv.pv[0] = np.ones(nV)
+    return lv

@@ -10,7 +10,8 @@ import scipy.sparse as sp
 from oracle import amge as oa, derham as od
 from parelag_amd import derham, meshgen
 from parelag_amd.amge_level import level_from_tets
-from parelag_amd.derham_level import seq_level_from_tets
+from parelag_amd.amge_level import box_partition
+from parelag_amd.derham_level import seq_level_from_hex, seq_level_from_tets
 
 
 def invariants(lv, res, Pi=None):
@@ -160,3 +161,31 @@ def test_richer_targets_on_every_form(seq):
     r1 = od.coarsen(r0["coarse"], seq.partition(1))
     inv = invariants(r0["coarse"], r1)
     assert max(inv.values()) < 1e-11, inv
+
+
+def test_hex_sequence_is_exact_and_coarsens(seq):
+    """The Cartesian hex builder for all forms (the element type of MultigridTestSPE10): exact complex, constants' energy =
+    volume in every mass matrix, gradients of linears = constants; two coarsenings with 2 x 2 x 2 (then 2 x 2 x 1) boxes keep the
+    reference's invariants, with and without a heterogeneous coefficient."""
+    n, h = (4, 4, 2), (2.0, 1.0, 0.5)
+    vol = float(np.prod(n) * np.prod(h))
+    for kinv in (None, np.exp(np.random.default_rng(0).standard_normal(32))):
+        lv = seq_level_from_hex(n, h, jstart=0, kinv=kinv)
+        assert abs(lv.D[1] @ lv.D[0]).max() == 0.0 and abs(lv.D[2] @ lv.D[1]).max() == 0.0
+        assert np.abs(lv.D[0] @ lv.T[0][:, 1:] - lv.T[1]).max() == 0.0
+        assert np.abs(lv.D[1] @ lv.T[1]).max() == 0.0 and np.abs(lv.D[2] @ lv.T[2]).max() == 0.0
+        assert np.allclose((lv.T[1].T @ lv.mass(1) @ lv.T[1]), vol * np.eye(3), rtol=1e-13, atol=1e-13)
+        if kinv is None:
+            assert np.allclose((lv.T[2].T @ lv.mass(2) @ lv.T[2]), vol * np.eye(3), rtol=1e-13, atol=1e-13)
+        one = np.ones(lv.ndof(0))
+        assert np.isclose(one @ lv.mass(0) @ one, vol, rtol=1e-13)
+        r0 = od.coarsen(lv, box_partition(n, (2, 2, 2)))
+        assert r0["coarse"].n == [4, 20, 33, 18]
+        inv = invariants(lv, r0)
+        assert max(inv.values()) < 1e-11, inv
+        r1 = od.coarsen(r0["coarse"], box_partition((2, 2, 1), (2, 2, 1)))
+        assert r1["coarse"].n == [1, 6, 12, 8]
+        inv = invariants(r0["coarse"], r1)
+        assert max(inv.values()) < 1e-11, inv
+        if kinv is not None:
+            assert r0["n_null"][2] > 0

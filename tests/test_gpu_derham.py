@@ -8,7 +8,8 @@ import scipy.sparse as sp
 
 from oracle import derham as od
 from parelag_amd import meshgen
-from parelag_amd.derham_level import seq_level_from_tets
+from parelag_amd.amge_level import box_partition
+from parelag_amd.derham_level import seq_level_from_hex, seq_level_from_tets
 from tests.test_derham_oracle import invariants, kuhn_boxes, rich_targets_level
 
 pytestmark = pytest.mark.gpu
@@ -206,3 +207,11 @@ def test_derham_sequence_class_reads_like_the_reference_driver(derham):
         sequence[2].GetP(0)
     with pytest.raises(ValueError):
         derham.DeRhamSequence(seq_level_from_tets(seq.meshes[2], jstart=2)).SetjformStart(0)
+
+
+def test_hex_grid_all_forms(derham):
+    """Cartesian hex cells (MultigridTestSPE10's element type), all four forms, heterogeneous coefficient, ragged boxes."""
+    n, h = (5, 4, 3), (2.0, 1.0, 0.5)
+    lv = seq_level_from_hex(n, h, jstart=0, kinv=np.exp(np.random.default_rng(4).standard_normal(60)))
+    _ro, rd, _tm = compare(derham, lv, box_partition(n, (2, 2, 2)))
+    compare(derham, rd["coarse"], box_partition((3, 2, 2), (3, 2, 2)))
