@@ -22,7 +22,7 @@
 namespace elag {
 namespace {
 
-constexpr int kMaxCols = 16;   // 1 PV + up to 15 targets
+constexpr int kMaxCols = 40;   // 1 PV + up to 39 targets (order-2 targets of the vector-valued forms: 3 x 10 = 30)
 constexpr int kLdsDoubles = 7936;   // 62 KiB of dynamic LDS per workgroup
 
 struct AsmDev {

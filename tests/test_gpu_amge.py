@@ -191,3 +191,23 @@ def test_upscaling_errors_equal_the_oracle_s(amge):
     ref = upscaling_errors(oa.coarsen_sequence)
     assert np.allclose(dev, ref, rtol=1e-8)
     assert dev[1][0] > 1.7 * dev[0][0]
+
+
+def test_many_targets(amge):
+    """30 target vectors on the 2-forms (the count of "Upscaling order" 2): more targets than an agglomerated facet has dofs,
+    so the SVD keeps at most (dofs - 1) directions next to the PV vector; subspaces compared through the projectors."""
+    rng = np.random.default_rng(12)
+    hx = level_from_hex((4, 4, 2), h=(1.0, 2.0, 0.5), kinv=np.exp(rng.standard_normal(32)))
+    hx.T2 = np.concatenate([hx.T2, rng.standard_normal((hx.ndof2, 27))], axis=1)
+    # the targets of the next form must contain the derivatives of these (``targetDerivativesInForm``, DeRhamSequence.cpp:475-570),
+    # otherwise the coarse spaces cannot hold them: 28 targets on the 3-forms, RangeT bubbles for their non-constant part
+    hx.T3 = np.concatenate([hx.T3, hx.D2 @ hx.T2[:, 3:]], axis=1)
+    part = box_partition((4, 4, 2), (2, 2, 2))
+    ro, rd = oa.coarsen(hx, part), amge.coarsen(hx, part)
+    assert np.array_equal(ro["n_null"], rd["n_null"]) and np.array_equal(ro["n_rt"], rd["n_rt"]) and ro["n_rt"].sum() > 0
+    for k in ("f_dof2_ptr", "e_idof2_ptr", "e_dof3_ptr"):
+        assert np.array_equal(getattr(ro["coarse"], k), getattr(rd["coarse"], k)), k
+    Pi2 = (rd["hat1"] + rd["hat0"] - rd["hat0"] @ (rd["P2"] @ rd["hat1"])).tocsr()
+    assert rel((rd["P2"] @ Pi2).toarray(), (ro["P2"] @ ro["Pi2"]).toarray()) < 1e-8
+    inv = invariants(hx, dict(rd, Pi2=Pi2))
+    assert max(inv.values()) < 1e-9, inv
