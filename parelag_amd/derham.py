@@ -219,6 +219,19 @@ def coarsen(lv: SeqLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entr
     D = {j: lv.D[j].tocsr() for j in range(js, 3)}
     Ppieces = {j: [] for j in range(js, 4)}
     Pcache = {j: [0, None] for j in range(js, 4)}
+    keep_all = _Keep()                                   # arrays behind the cached assembly lists / triplets stay alive for the whole call
+    asm_cache, trip_cache = {}, {}
+
+    def asm(jj, cc):                                     # the (form, codim) mass of the agglomerated entities: used by up to three stages
+        if (jj, cc) not in asm_cache:
+            asm_cache[(jj, cc)] = _asm(keep_all, lv, tb, jj, cc, topo, agg[jj]["look"][cc])
+        return asm_cache[(jj, cc)]
+
+    def trip(jj, cc):                                    # local triplets of D_jj on the codim-cc agglomerated entities (as D and as D2)
+        if (jj, cc) not in trip_cache:
+            rp_, rd_ = agg[jj + 1]["rows"][cc]
+            trip_cache[(jj, cc)] = _triplets(D[jj], rp_, rd_, agg[jj]["look"][cc])
+        return trip_cache[(jj, cc)]
     hat = {j: {} for j in range(js, 4)}
     Mc = {j: {} for j in range(js, 4)}
     Dc_e = {j: ([], [], []) for j in range(js, 3)}
@@ -251,7 +264,7 @@ def coarsen(lv: SeqLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entr
             ip = lv.idof[j][ctr]
             dd, own = expand_ranges(lv.base(j, ctr) + ip[ai], np.diff(ip)[ai])
             ent_of_dof_sgn[dd] = asg[own]
-            tin = _TracesIn(nAt, nT, svd_tol, keep.i32(np.diff(rp)), _asm(keep, lv, tb, j, ctr, topo, agg[j]["look"][ctr]),
+            tin = _TracesIn(nAt, nT, svd_tol, keep.i32(np.diff(rp)), asm(j, ctr),
                             keep.f64(lv.pv[j][rd] * ent_of_dof_sgn[rd]), keep.f64(_pack_cols(lv.T[j], rd, rp)))
             o_nc = np.zeros(nAt, np.int32); o_p = np.zeros(rd.size * kmax); o_cm = np.zeros(nAt * kmax * kmax); o_f = np.zeros(rd.size * kmax)
             _lib.check(L.elag_hip_coarsen_traces(C.byref(tin), C.byref(_TracesOut(_ptr(o_nc), _ptr(o_p), _ptr(o_cm), _ptr(o_f))), C.byref(ms)))
@@ -294,7 +307,7 @@ def coarsen(lv: SeqLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entr
             b_ptr = ptr_from_counts(nu - ni)
             R_b = _gather_dense(Pj, b_ptr, ud[bq], look_cbd, nxt)
             keep = _Keep()
-            d_ptr, d_row, d_col, d_val = _triplets(D[j], pp, pd, agg[j]["look"][cdom])
+            d_ptr, d_row, d_col, d_val = trip(j, cdom)
             pint_ptr = cdp.ptr[cdom]; pint_base = cdp.base[cdom]
             iq, owni = expand_ranges(pp[:-1], npi)                     # interior p dofs
             ip_ptr = ptr_from_counts(npi)
@@ -315,18 +328,18 @@ def coarsen(lv: SeqLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entr
             args = dict(mass_q=_Assembly(), d2=(None, None, None, None), PDc=None, npi=None, nq=None)
             if mode == 1:
                 qp, qd = agg[j + 2]["rows"][cdom]
-                d2_ptr, d2_row, d2_col, d2_val = _triplets(D[j + 1], qp, qd, agg[j + 1]["look"][cdom])
+                d2_ptr, d2_row, d2_col, d2_val = trip(j + 1, cdom)
                 r_, c_, v_ = Dc_e[j]
                 Dc_now = sp.csr_matrix((np.concatenate(v_) if v_ else np.zeros(0), (np.concatenate(r_) if r_ else np.zeros(0, np.int64),
                                                                                      np.concatenate(c_) if c_ else np.zeros(0, np.int64))),
                                        shape=(Pp.shape[1], ncols_sofar))
                 PDc = _spgemm_device(Pp, Dc_now)                                    # :2696-2697
-                args = dict(mass_q=_asm(keep, lv, tb, j + 2, cdom, topo, agg[j + 2]["look"][cdom]),
+                args = dict(mass_q=asm(j + 2, cdom),
                             d2=(keep.i64(d2_ptr), keep.i32(d2_row), keep.i32(d2_col), keep.f64(d2_val)),
                             PDc=keep.f64(_gather_dense(PDc, pp, pd, look_cbd, nxt)), npi=keep.i32(npi), nq=keep.i32(np.diff(qp)))
             ein = _ExtIn(nA, nT, mode, null_dofs, svd_tol, smallest_entry, keep.i32(nu), keep.i32(ni), keep.i32(np_), args["npi"], args["nq"],
                          keep.i32(nxt), keep.i32(nrt),
-                         _asm(keep, lv, tb, j, cdom, topo, agg[j]["look"][cdom]), _asm(keep, lv, tb, j + 1, cdom, topo, agg[j + 1]["look"][cdom]),
+                         asm(j, cdom), asm(j + 1, cdom),
                          args["mass_q"], keep.i64(d_ptr), keep.i32(d_row), keep.i32(d_col), keep.f64(d_val), *args["d2"],
                          keep.f64(pv_p), keep.f64(R_b), keep.f64(cP), keep.f64(_pack_cols(lv.T[j], ud, up)), args["PDc"])
             kf = nrt + nT
