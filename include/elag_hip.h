@@ -520,6 +520,13 @@ typedef struct {
 ELAG_HIP_API int elag_hip_coarsen_extension(const elag_hip_coarsen_extension_in *in, const elag_hip_coarsen_extension_out *out,
                                             double *kernel_ms);
 
+/* Ranks of a batch of small matrices given as triplets (matrix e: nrows[e] x ncols[e], triplets t_ptr[e] .. t_ptr[e+1]-1): the
+ * DenseMatrix::Rank(1e-9) calls of AgglomeratedTopologyCheck::computeBettiNumbersAgglomeratedEntities
+ * (src/topology/AgglomeratedTopologyCheck.cpp:241-318: local boundary operators of every agglomerated entity), one workgroup
+ * per matrix, Gaussian elimination with row pivoting; pivots <= tol end a column.  Host arrays in, host ranks out. */
+ELAG_HIP_API int elag_hip_batched_rank(int n_mat, const int *nrows, const int *ncols, const int64_t *t_ptr, const int *t_row, const int *t_col,
+                                       const double *t_val, double tol, int *rank);
+
 /* --------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): run `reps` launches of one fine-level kernel on the compute stream
  * bracketed by HIP events created on that stream and return the mean milliseconds per launch.

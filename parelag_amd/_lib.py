@@ -148,6 +148,7 @@ _SIGNATURES = {
     "elag_hip_krylov_mult": [_p, _p, _p, _i, _i],
     "elag_hip_krylov_get_stats": [_p, _ip, _ip, _dp],
     "elag_hip_krylov_destroy": [_p],
+    "elag_hip_batched_rank": [_i, _p, _p, _p, _p, _p, _p, _d, _p],
     "elag_hip_coarsen_traces": [_p, _p, _dp],
     "elag_hip_coarsen_extension": [_p, _p, _dp],
     "elag_hip_time_kernel": [_p, _p, _i, _i, _p, _p, _dp],

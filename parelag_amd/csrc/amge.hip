@@ -596,6 +596,73 @@ __global__ void coarsen_extension_kernel(ExtArgs a)
     }
 }
 
+// ---- ranks of small matrices (Betti numbers of agglomerated entities) ------------------------------------------------------
+// AgglomeratedTopologyCheck::computeBettiNumbersAgglomeratedEntities (src/topology/AgglomeratedTopologyCheck.cpp:241-318) takes
+// DenseMatrix::Rank(1e-9) of the local boundary operators (entries 0, +-1): here by Gaussian elimination with row pivoting per
+// column; a column whose remaining entries are all below the tolerance adds nothing to the rank.
+struct RankArgs {
+    int n_mat;
+    double tol;
+    const int *nr, *nc;
+    const int64_t *t_ptr;
+    const int *t_row, *t_col;
+    const double *t_val;
+    int *rank;
+    const int64_t *ws_off;
+    double *gws;
+};
+
+__global__ void batched_rank_kernel(RankArgs a)
+{
+    extern __shared__ double dyn[];
+    __shared__ int piv[2];
+    const int e = blockIdx.x;
+    const int nr = a.nr[e], nc = a.nc[e];
+    double *A = a.ws_off[e] >= 0 ? a.gws + a.ws_off[e] : dyn;
+    zero_fill(A, nr * nc);
+    __syncthreads();
+    for (int64_t t = a.t_ptr[e] + threadIdx.x; t < a.t_ptr[e + 1]; t += blockDim.x) A[a.t_row[t] * nc + a.t_col[t]] = a.t_val[t];
+    __syncthreads();
+    int r = 0;                                            // rows 0 .. r-1 hold the pivots found so far
+    for (int c = 0; c < nc && r < nr; c++) {
+        if (threadIdx.x < 64) {
+            double best = -1.0;
+            int bi = r;
+            for (int i = r + threadIdx.x; i < nr; i += 64) {
+                const double v = fabs(A[i * nc + c]);
+                if (v > best) { best = v; bi = i; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ov = __shfl_down(best, o, 64);
+                const int oi = __shfl_down(bi, o, 64);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            if (threadIdx.x == 0) { piv[0] = bi; piv[1] = best > a.tol ? 1 : 0; }
+        }
+        __syncthreads();
+        const int p = piv[0], ok = piv[1];
+        if (ok) {
+            if (p != r)
+                for (int j = c + threadIdx.x; j < nc; j += blockDim.x) {
+                    const double t = A[r * nc + j];
+                    A[r * nc + j] = A[p * nc + j];
+                    A[p * nc + j] = t;
+                }
+            __syncthreads();
+            const double inv = 1.0 / A[r * nc + c];
+            const int w = nc - c - 1, h = nr - r - 1;
+            for (int t = threadIdx.x; t < w * h; t += blockDim.x) {
+                const int i = r + 1 + t / w, j = c + 1 + t % w;
+                A[i * nc + j] -= (A[i * nc + c] * inv) * A[r * nc + j];
+            }
+            r++;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.rank[e] = r;
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------------
 
 struct AsmUpload {
@@ -817,6 +884,35 @@ ELAG_HIP_API int elag_hip_coarsen_extension(const elag_hip_coarsen_extension_in 
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
         if (bad)
             fail(ELAG_HIP_ERR_NUMERIC, "coarsen_extension: %d singular local systems (bad topology, e.g. a torus-shaped or disconnected agglomerate?)", bad);
+    });
+}
+
+ELAG_HIP_API int elag_hip_batched_rank(int n_mat, const int *nrows, const int *ncols, const int64_t *t_ptr, const int *t_row, const int *t_col,
+                                       const double *t_val, double tol, int *rank)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(n_mat >= 0 && (n_mat == 0 || (nrows && ncols && t_ptr && rank)), "null argument");
+        if (n_mat == 0) return;
+        hipStream_t st = ctx().stream;
+        std::vector<int64_t> need((size_t)n_mat);
+        for (int e = 0; e < n_mat; e++) {
+            ELAG_REQUIRE(nrows[e] >= 0 && ncols[e] >= 0, "negative matrix size");
+            for (int64_t t = t_ptr[e]; t < t_ptr[e + 1]; t++)
+                ELAG_REQUIRE(t_row[t] >= 0 && t_row[t] < nrows[e] && t_col[t] >= 0 && t_col[t] < ncols[e], "triplet outside matrix %d", e);
+            need[(size_t)e] = (int64_t)nrows[e] * ncols[e];
+        }
+        Placement pl;
+        pl.finish(need);
+        const int64_t nt = t_ptr[n_mat];
+        DevBuf<int> d_nr(nrows, n_mat), d_nc(ncols, n_mat), d_row(t_row, (size_t)nt), d_col(t_col, (size_t)nt), d_rank((size_t)n_mat);
+        DevBuf<int64_t> d_ptr(t_ptr, (size_t)n_mat + 1), d_ws(pl.ws_off.data(), (size_t)n_mat);
+        DevBuf<double> d_val(t_val, (size_t)nt), d_gws((size_t)pl.gws_total);
+        RankArgs a{n_mat, tol, d_nr, d_nc, d_ptr, d_row, d_col, d_val, d_rank, d_ws, d_gws};
+        hipLaunchKernelGGL(batched_rank_kernel, dim3(n_mat), dim3(pl.threads), (size_t)pl.lds_doubles * sizeof(double), st, a);
+        ELAG_LAUNCH_CHECK();
+        ELAG_HIP_CHECK(hipMemcpyAsync(rank, d_rank.p, sizeof(int) * n_mat, hipMemcpyDeviceToHost, st));
+        ELAG_HIP_CHECK(hipStreamSynchronize(st));
     });
 }
 

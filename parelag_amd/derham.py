@@ -59,14 +59,37 @@ def _gather_dense(M: sp.csr_matrix, row_ptr, rows, col_lookup: _Lookup, ncol):
 
 # ---- topology ----------------------------------------------------------------------------------------------------------------
 
-def coarsen_topology(lv: SeqLevel, part: np.ndarray) -> dict:
+def _deagglomerate(A, bad):
+    """``DeAgglomerateBadAgglomeratedEntities`` (``Topology.cpp:1151-1214``): every member of a bad agglomerated entity becomes
+    an agglomerated entity of its own, in place (the later ones move up), orientations kept."""
+    ptr, idx, sgn = A
+    first = np.zeros(idx.size + 1, dtype=bool)
+    first[ptr] = True
+    row = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+    first[:-1] |= bad[row]
+    return np.nonzero(first)[0].astype(np.int64), idx, sgn
+
+
+def coarsen_topology(lv: SeqLevel, part: np.ndarray, check: bool = False) -> dict:
     """``CoarsenLocalPartitioning`` for all codimensions.  The minimal intersection sets
     (``src/structures/minimalIntersectionSet.cpp:43-132``) are the classes of the relation ``Z_ii = Z_jj = |Z_ij|``, i.e. of equal
-    adjacency signatures (see below), numbered by their lowest member and oriented like it."""
+    adjacency signatures (see below), numbered by their lowest member and oriented like it.  With ``check`` (the reference's
+    ``check_topology`` argument, ``Topology.cpp:727-738, 778, 803``) the agglomerated entities of every codimension are tested as
+    soon as they exist (``check_topology`` below) and the bad ones are de-agglomerated before the next codimension is built;
+    the diagnostics are returned under ``"messages"``."""
     part = np.asarray(part, dtype=np.int64)
     nA = int(part.max()) + 1
     order = np.argsort(part, kind="stable")
     A = [(ptr_from_counts(np.bincount(part, minlength=nA)), order.astype(np.int64), np.ones(order.size))]
+    messages, nfixed = [], [0, 0, 0]
+
+    def fix(Ac, c):
+        _b, bad, msg = _check_codim(lv, Ac, c)
+        messages.extend(msg)
+        nfixed[c] = int(bad.sum())
+        return _deagglomerate(Ac, bad) if bad.any() else Ac
+    if check:
+        A[0] = fix(A[0], 0)
     Bc, attr_c = [], None
     for c in range(3):
         ap, ai, asg = A[c]
@@ -127,13 +150,22 @@ def coarsen_topology(lv: SeqLevel, part: np.ndarray) -> dict:
         ulab = lowest                                                           # (only its size is used below)
         nmis = ulab.size
         o2 = np.argsort(mis[mem], kind="stable")
-        A.append((ptr_from_counts(np.bincount(mis[mem], minlength=nmis)), mem[o2].astype(np.int64), ori[mem[o2]]))
+        Anew = (ptr_from_counts(np.bincount(mis[mem], minlength=nmis)), mem[o2].astype(np.int64), ori[mem[o2]])
+        if check and c + 1 <= 2:
+            Afix = fix(Anew, c + 1)
+            if Afix is not Anew:
+                Anew = Afix
+                mis[Anew[1]] = np.repeat(np.arange(len(Anew[0]) - 1, dtype=np.int64), np.diff(Anew[0]))
+        A.append(Anew)
         sub_ptr = ptr_from_counts(member.astype(np.int64))                   # fc_AF: one entry per member row
         bp, bi, bs = _product(fp, fi, sub_ptr, mis[mem], fs, ori[mem])
         Bc.append((bp, bi.astype(np.int64), bs))
         if c == 0:
             attr_c = lv.facet_attr[A[1][1][A[1][0][:-1]]].astype(np.int32)
-    return dict(A=A, B=Bc, facet_attr=attr_c, n=[len(a[0]) - 1 for a in A])
+    out = dict(A=A, B=Bc, facet_attr=attr_c, n=[len(a[0]) - 1 for a in A])
+    if check:
+        out["messages"], out["n_deagglomerated"] = messages, nfixed
+    return out
 
 
 # ---- dof tables ---------------------------------------------------------------------------------------------------------------
@@ -208,11 +240,13 @@ def _triplets(D: sp.csr_matrix, rows_ptr, rows, look_cols: _Lookup):
 
 # ---- Coarsen ------------------------------------------------------------------------------------------------------------------
 
-def coarsen(lv: SeqLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entry: float = EPS, timings: dict | None = None) -> dict:
-    """``DeRhamSequence::Coarsen`` for forms ``lv.jstart .. 3``.  Returns dict(P, hat, coarse, topo, n_null)."""
+def coarsen(lv: SeqLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entry: float = EPS, timings: dict | None = None,
+            check_topology: bool = False) -> dict:
+    """``DeRhamSequence::Coarsen`` for forms ``lv.jstart .. 3``.  Returns dict(P, hat, coarse, topo, n_null).  ``check_topology``:
+    build the agglomerated topology with the checks and repairs of ``CoarsenLocalPartitioning(..., check_topology = true)``."""
     L = _lib.init()
     tb = _Tables(lv)
-    topo = coarsen_topology(lv, part)
+    topo = coarsen_topology(lv, part, check=check_topology)
     js = lv.jstart
     agg = {j: agglomerate_dofs(lv, tb, topo, j) for j in range(js, 4)}
     cd = {j: _CoarseDofs(lv, topo, j) for j in range(js, 4)}
@@ -632,11 +666,14 @@ class DeRhamSequence:
         self.SVD_Tolerance = float(tol)
 
     # -- math ---------------------------------------------------------------------------------------------------------------
-    def Coarsen(self, partitioning, timings: dict | None = None) -> "DeRhamSequence":
+    def Coarsen(self, partitioning, timings: dict | None = None, check_topology: bool = False) -> "DeRhamSequence":
         """``Coarsen()`` (``:572-692``).  The element partitioning is an argument here because this mirror has no separate
         ``AgglomeratedTopology`` object: the reference reads it from ``Topo_->CoarserTopology()``, which
-        ``CoarsenLocalPartitioning(partitioning, ...)`` built from the same array."""
-        self._res = coarsen(self.level, partitioning, svd_tol=self.SVD_Tolerance, smallest_entry=self.SmallestEntry, timings=timings)
+        ``CoarsenLocalPartitioning(partitioning, check_topology, ...)`` built from the same array; the diagnostics of a checked
+        coarsening are kept in ``self.TopologyMessages``."""
+        self._res = coarsen(self.level, partitioning, svd_tol=self.SVD_Tolerance, smallest_entry=self.SmallestEntry, timings=timings,
+                            check_topology=check_topology)
+        self.TopologyMessages = self._res["topo"].get("messages", [])
         self.CoarserSequence = DeRhamSequence(self._res["coarse"], finer=self)
         self.CoarserSequence.SVD_Tolerance = self.SVD_Tolerance
         return self.CoarserSequence
@@ -664,3 +701,82 @@ class DeRhamSequence:
     def _need_coarse(self, what):
         if self._res is None:
             raise RuntimeError(f"DeRhamSequence::{what}(): call Coarsen() first")
+
+
+# ---- topology checks ------------------------------------------------------------------------------------------------------------
+
+def _B_csr(lv: SeqLevel, c: int) -> sp.csr_matrix:
+    return sp.csr_matrix((lv.B[c][2], lv.B[c][1], lv.B[c][0]), shape=(lv.n[c], lv.n[c + 1]))
+
+
+def betti_numbers(lv: SeqLevel, topo, codim: int) -> np.ndarray:
+    """``AgglomeratedTopologyCheck::computeBettiNumbersAgglomeratedEntities`` (``src/topology/AgglomeratedTopologyCheck.cpp:241-318``):
+    for every agglomerated entity of codimension ``codim`` the Betti numbers of the sub-complex of the fine entities it is
+    made of -- column 0 connected components, then (elements) tunnels and holes, (facets) holes.  The ranks of the local
+    boundary operators come from the device (``elag_hip_batched_rank``)."""
+    Ac = topo["A"][codim] if isinstance(topo, dict) else topo
+    nlow = 3 - codim
+    nA = len(Ac[0]) - 1
+    if nlow == 0:
+        return np.zeros((nA, 0), dtype=np.int64)
+    rows = [(Ac[0], Ac[1])]
+    for i in range(nlow):                                   # MultBoolean chain: all sub-entities, interior ones included
+        rows.append(_product(rows[i][0], rows[i][1], lv.B[codim + i][0], lv.B[codim + i][1])[:2])
+    dims = [np.diff(r[0]) for r in rows]
+    ranks = []
+    for i in range(nlow):
+        look = _Lookup(rows[i + 1][0], rows[i + 1][1], lv.n[codim + i + 1])
+        t_ptr, t_row, t_col, t_val = _triplets(_B_csr(lv, codim + i), rows[i][0], rows[i][1], look)
+        L = _lib.init()
+        keep = _Keep()
+        out = np.zeros(nA, dtype=np.int32)
+        _lib.check(L.elag_hip_batched_rank(nA, keep.i32(dims[i]), keep.i32(dims[i + 1]), keep.i64(t_ptr), keep.i32(t_row), keep.i32(t_col),
+                                           keep.f64(t_val), 1e-9, _ptr(out)))
+        ranks.append(out.astype(np.int64))
+    ranks.append(np.zeros(nA, dtype=np.int64))
+    betti = np.zeros((nA, nlow), dtype=np.int64)
+    for i in range(nlow):
+        betti[:, nlow - i - 1] = dims[i + 1] - ranks[i] - ranks[i + 1]
+    return betti
+
+
+def _bad_connectivity(lv: SeqLevel, topo: dict, codim: int) -> np.ndarray:
+    """``additionalTopologyCheck`` (``:25-83``): on the boundary of an agglomerated element (facet) every boundary ridge (peak)
+    must lie on exactly two boundary facets (ridges) -- the reference compares the sums only."""
+    ap, ai, asg = topo["A"][codim] if isinstance(topo, dict) else topo
+    fp, fi, _fs = _product(ap, ai, lv.B[codim][0], lv.B[codim][1], asg, lv.B[codim][2])      # boundary facets (interior ones cancel)
+    ep, _ei, _ = _product(fp, fi, lv.B[codim + 1][0], lv.B[codim + 1][1])                      # boundary ridges
+    per_facet = np.diff(lv.B[codim + 1][0])[fi]
+    nnz = np.bincount(np.repeat(np.arange(len(fp) - 1), np.diff(fp)), weights=per_facet, minlength=len(fp) - 1)
+    return np.abs(nnz - 2 * np.diff(ep)) > 1e-10
+
+
+_ENTITY_NAMES = {0: "Element", 1: "Facet", 2: "Ridge"}
+
+
+def _check_codim(lv: SeqLevel, topo, codim: int):
+    """Betti numbers, bad flags and the reference's diagnostic lines for the agglomerated entities of one codimension
+    (``topo``: the coarsened topology, or the (ptr, idx, sgn) table of that codimension while it is being built)."""
+    b = betti_numbers(lv, topo, codim)
+    bad = b[:, 0] != 1
+    msg = [f"    {_ENTITY_NAMES[codim]} {a} is disconnected. The number of connected components is {b[a, 0]}" for a in np.nonzero(bad)[0]]
+    for i in range(1, b.shape[1]):
+        bad |= b[:, i] != 0
+        what = "holes" if (codim == 1 or i == 2) else "tunnels"
+        msg += [f"    {_ENTITY_NAMES[codim]} {a} has {b[a, i]} {what}." for a in np.nonzero(b[:, i] != 0)[0]]
+    if codim <= 1:
+        bc = _bad_connectivity(lv, topo, codim)
+        bad |= bc
+        msg += [f"    codim {codim} iAE {a} has bad connectivity (eg boundary edge adjacent to >2 boundary faces)." for a in np.nonzero(bc)[0]]
+    return b, bad, msg
+
+
+def check_topology(lv: SeqLevel, topo: dict) -> dict:
+    """``MarkBadAgglomeratedEntities`` / ``ShowBadAgglomeratedEntities`` (``:85-240``) for agglomerated elements, facets and
+    ridges: Betti numbers, the extra boundary-connectivity test for codimensions 0 and 1, the reference's diagnostic lines.
+    Returns dict(betti={codim: array}, isbad={codim: bool array}, messages=[...])."""
+    out = dict(betti={}, isbad={}, messages=[])
+    for codim in range(3):
+        out["betti"][codim], out["isbad"][codim], msg = _check_codim(lv, topo, codim)
+        out["messages"] += msg
+    return out
