@@ -1,9 +1,10 @@
 """CPU restatement of ``DeRhamSequence::Coarsen`` for the (H(div), L2) pair -- TEST INFRASTRUCTURE ONLY.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module; the product
-(``parelag_amd/amge.py`` + ``csrc/amge.hip``) never does.  **Parity unpinned**: the reference cannot be built here (MFEM,
-hypre, METIS, SuiteSparse, LAPACK wrappers absent) and holds no golden vectors for this path; the restatement is pinned
-by the reference's own invariants (``DeRhamSequence::CheckInvariants``, ``src/amge/DeRhamSequence.cpp:694-970``):
+(``parelag_amd/amge.py`` + ``csrc/amge.hip``) never does.  The reference cannot be built here (MFEM, hypre, METIS,
+SuiteSparse, LAPACK wrappers absent).  Pinned indirectly: the general oracle ``oracle/derham.py`` reproduces the reference's
+printed upscaling errors (``tests/test_upscaling_golden.py``) and equals this module bit for bit on forms 2-3
+(``test_general_oracle_equals_the_two_form_oracle``); directly by the reference's own invariants (``DeRhamSequence::CheckInvariants``, ``src/amge/DeRhamSequence.cpp:694-970``):
 ``D_f P_2 = P_3 D_c``, ``M_c = P^T M_f P``, ``Pi P = I``, targets reproduced -- see ``tests/test_amge_oracle.py``.
 
 What is restated (reference file:line in every function): the path ``Coarsen()`` takes with ``jformStart_ = nDim-1 = 2``
