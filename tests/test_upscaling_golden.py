@@ -130,3 +130,72 @@ def test_geometric_box_partitioner_known_answers():
     ref = box_partition(N, (2, 2, 2))
     pairs = np.unique(np.stack([part, ref], 1), axis=0)
     assert pairs.shape[0] == 8                                                     # the same agglomerates, numbered differently
+
+
+# ---- examples/Upscaling2FormAMGe.cpp: three levels of the (H(div), L2) pair ----------------------------------------------------
+
+GOLDEN_2FORM = (("1.9010e-02", "3.9570e-03"), ("1.2883e-01", "5.7793e-02"))       # examples/CMakeLists.txt:50-55 (coarsest level first)
+N3, H3 = (8, 8, 8), 0.125
+
+
+def three_level_errors(M, W, D, Ps, ess, b0):
+    """``Upscaling2FormAMGe.cpp:222-235, 282-345, 372-410``: ``A = M + D^T W D`` per level, every side essential (zero normal
+    flux), coarse right-hand sides ``P^T b``; errors of the interpolated coarse solutions against the fine one."""
+    b, sol = [b0], []
+    for P in Ps:
+        b.append(P.T @ b[-1])
+    for k in range(3):
+        A = (M[k] + D[k].T @ W[k] @ D[k]).tocsr()
+        free = np.nonzero(~ess[k])[0]
+        u = np.zeros(A.shape[0])
+        u[free] = spl.spsolve(A[free][:, free].tocsc(), b[k][free])
+        sol.append(u)
+    out = []
+    for k in (2, 1):
+        u = sol[k]
+        for j in range(k, 0, -1):
+            u = Ps[j - 1] @ u
+        e = u - sol[0]
+        de = D[0] @ e
+        out.append(("%.4e" % np.sqrt(e @ (M[0] @ e)), "%.4e" % np.sqrt(de @ (W[0] @ de))))
+    return tuple(zip(*out))
+
+
+def three_levels_general(coarsen_fn, jstart):
+    """Unit cube, 2 x 2 x 2 hexahedra refined twice (512 cells); derefinement agglomerates: 64 boxes of 2 x 2 x 2 cells, then
+    8 boxes of 2 x 2 x 2 of those; right-hand side the domain integral of (0,0,1) . phi = M x (interpolant of the constant field)."""
+    lv = seq_level_from_hex(N3, h=(H3, H3, H3), jstart=jstart)
+    r0 = coarsen_fn(lv, box_partition(N3, (2, 2, 2)).astype(np.int64))
+    r1 = coarsen_fn(r0["coarse"], box_partition((4, 4, 4), (2, 2, 2)).astype(np.int64))
+    levels = [lv, r0["coarse"], r1["coarse"]]
+    ess = [derham.DeRhamSequence(L)._marker(2, np.ones(6, dtype=np.int64)) for L in levels]
+    return three_level_errors([L.mass(2).tocsr() for L in levels], [L.mass(3).tocsr() for L in levels], [L.D[2].tocsr() for L in levels],
+                              [r0["P"][2].tocsr(), r1["P"][2].tocsr()], ess, lv.mass(2) @ lv.T[2][:, 2])
+
+
+def test_oracle_reproduces_the_reference_three_level_hdiv_errors():
+    assert three_levels_general(od.coarsen, jstart=2) == GOLDEN_2FORM
+
+
+@pytest.mark.gpu
+def test_device_coarsening_reproduces_the_reference_three_level_hdiv_errors():
+    assert three_levels_general(derham.coarsen, jstart=0) == GOLDEN_2FORM          # jFormStart = 0 as the example sets it
+
+
+@pytest.mark.gpu
+def test_two_form_fast_path_reproduces_the_reference_three_level_hdiv_errors():
+    """The same numbers through ``parelag_amd/amge.py`` (``jformStart_ = 2``, vectorised tables) on ``AmgeLevel``."""
+    from parelag_amd import amge
+    from parelag_amd.amge_level import level_from_hex
+    lv = level_from_hex(N3, h=(H3, H3, H3))
+    rs = amge.coarsen_sequence(lv, [box_partition(N3, (2, 2, 2)), box_partition((4, 4, 4), (2, 2, 2))])
+    levels = [lv, rs[0]["coarse"], rs[1]["coarse"]]
+    ess = []
+    for L in levels:
+        mk = np.zeros(L.ndof2, dtype=bool)
+        for f in np.nonzero(L.facet_attr > 0)[0]:
+            mk[L.f_dof2_ptr[f]:L.f_dof2_ptr[f + 1]] = True
+        ess.append(mk)
+    got = three_level_errors([L.mass2() for L in levels], [L.mass3() for L in levels], [L.D2.tocsr() for L in levels],
+                             [rs[0]["P2"].tocsr(), rs[1]["P2"].tocsr()], ess, lv.mass2() @ lv.T2[:, 2])
+    assert got == GOLDEN_2FORM
