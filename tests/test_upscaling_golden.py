@@ -199,3 +199,53 @@ def test_two_form_fast_path_reproduces_the_reference_three_level_hdiv_errors():
     got = three_level_errors([L.mass2() for L in levels], [L.mass3() for L in levels], [L.D2.tocsr() for L in levels],
                              [rs[0]["P2"].tocsr(), rs[1]["P2"].tocsr()], ess, lv.mass2() @ lv.T2[:, 2])
     assert got == GOLDEN_2FORM
+
+
+@pytest.mark.gpu
+def test_three_level_hdiv_errors_through_the_device_solver_stack():
+    """End to end as ``Upscaling2FormAMGe.cpp:305-410`` runs it: on every level k the system ``M + D^T W D`` (essential rows
+    and columns eliminated) is solved by PCG preconditioned with the multilevel Hiptmair hierarchy of the levels k .. 2
+    (``MLHiptmairSolver<HdivProblem3D>(seqs, ess_attr)``) -- here ``KrylovSolver`` over ``buildHierarchyFromDeRhamSequence``
+    with the device's AMGe interpolators ``ComputeTrueP(2, ess)`` and true curls ``ComputeTrueD(1, ess)`` -- and the printed errors
+    come out of the device solutions."""
+    from parelag_amd import linalg as la, meshgen
+    lv = seq_level_from_hex(N3, h=(H3, H3, H3), jstart=0)
+    seqs = [derham.DeRhamSequence(lv)]
+    seqs[0].SetTargets(lv.T)
+    for part in (box_partition(N3, (2, 2, 2)), box_partition((4, 4, 4), (2, 2, 2))):
+        seqs[-1].SetSVDTol(1e-9)
+        seqs.append(seqs[-1].Coarsen(part.astype(np.int64)))
+    ess_attr = np.ones(6, dtype=np.int64)
+    P = [seqs[k].GetP(2).tocsr() for k in range(2)]
+    Pe = [seqs[k].ComputeTrueP(2, ess_attr) for k in range(2)]
+    Ce = [seqs[k].ComputeTrueD(1, ess_attr) for k in range(3)]
+    M = [s.ComputeMassOperator(2).tocsr() for s in seqs]
+    W = [s.ComputeMassOperator(3).tocsr() for s in seqs]
+    D = [s.GetD(2).tocsr() for s in seqs]
+    b = [M[0] @ lv.T[2][:, 2]]
+    for k in range(2):
+        b.append(P[k].T @ b[k])
+    sol, its = [], []
+    for k in range(3):
+        ess = seqs[k]._marker(2, ess_attr)
+        A = meshgen.eliminate_rowcol((M[k] + D[k].T @ W[k] @ D[k]).tocsr(), ess)
+        rhs = np.where(ess, 0.0, b[k])
+        dA = la.ParallelCSRMatrix.from_scipy(A)
+        H = la.buildHierarchyFromDeRhamSequence(dA, [la.ParallelCSRMatrix.from_scipy(p) for p in Pe[k:]], "L1 Jacobi",
+                                                Ds=[la.ParallelCSRMatrix.from_scipy(c) for c in Ce[k:]] if k < 2 else None)
+        K = la.KrylovSolver(dA, H, {"Solver name": "PCG", "Relative tolerance": 1e-12, "Absolute tolerance": 0.0, "Maximum iterations": 500})
+        x = np.zeros_like(rhs)
+        K.Mult(rhs, x)
+        assert K.GetConverged()
+        sol.append(x)
+        its.append(K.GetNumIterations())
+    assert its[0] < 40 and its[2] <= 2, its                  # multilevel Hiptmair on 512 cells; the coarsest level is solved directly
+    out = []
+    for k in (2, 1):
+        u = sol[k]
+        for j in range(k, 0, -1):
+            u = P[j - 1] @ u
+        e = u - sol[0]
+        de = D[0] @ e
+        out.append(("%.4e" % np.sqrt(e @ (M[0] @ e)), "%.4e" % np.sqrt(de @ (W[0] @ de))))
+    assert tuple(zip(*out)) == GOLDEN_2FORM
