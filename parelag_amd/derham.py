@@ -610,11 +610,30 @@ class DeRhamSequence:
         sizes = np.sqrt(np.diff(ptr)).round().astype(np.int64)
         return sp.block_diag([vals[ptr[e]:ptr[e + 1]].reshape(sizes[e], sizes[e]) for e in range(sizes.size)], format="csr")
 
-    def ComputeMassOperator(self, jform):
-        return self.level.mass(jform)
+    def ComputeMassOperator(self, jform, elemMatrixScaling=None):
+        """``ComputeMassOperator(jform[, elemMatrixScaling])`` (``DeRhamSequence.hpp:407-425``): the element blocks, each scaled
+        by its entry of ``elemMatrixScaling`` when given, assembled over the dofs."""
+        return self.level.mass(jform, scaling=elemMatrixScaling)
 
-    def ComputeTrueMassOperator(self, jform):
-        return self.level.mass(jform)
+    def ComputeTrueMassOperator(self, jform, elemMatrixScaling=None):
+        return self.level.mass(jform, scaling=elemMatrixScaling)
+
+    ComputeTrueM = ComputeTrueMassOperator
+
+    def GetNumTrueDofs(self, jform):
+        return self.GetNumberOfDofs(jform)                       # one rank: every dof is a true dof
+
+    GetNumberOfTrueDofs = GetNumTrueDofs
+
+    def GetDerivativeOperator(self, jform):
+        return self.GetD(jform)
+
+    def ComputeTruePi(self, jform):
+        return self.GetPi(jform)
+
+    def GetL2ConstRepresentation(self):
+        """Coefficients of the constant function in the last form (``L2_const_rep_``, ``:452-453``)."""
+        return self.level.const3
 
     def ComputeTrueDerivativeOperator(self, jform):
         return self.level.D[jform]
@@ -696,6 +715,42 @@ class DeRhamSequence:
         bad = {k: v for k, v in out.items() if v > (loose_tol if k.startswith("CheckCoarseMass") else tol)}
         if bad:
             raise RuntimeError(f"DeRhamSequence::CheckInvariants(): {bad}")
+        return out
+
+    def ComputeSpaceInterpolationError(self, jform, fineVector, out: list | None = None):
+        """``ComputeSpaceInterpolationError`` (``:972-1080``): for this sequence (when it has a finer one) and every coarser one,
+        project the finest-level vectors down with the cochain projectors, interpolate back, and measure per vector
+        ``|| v - P Pi v ||_M / || v ||_M`` and the graph-norm version with ``D``.  The reference prints one row per level
+        (number of coarse dofs, then the ratios); the rows are returned here as (ndofs, l2_ratios, graph_ratios or None)."""
+        out = [] if out is None else out
+        V0 = np.asarray(fineVector, dtype=np.float64)
+        if self.FinerSequence is not None:
+            chain = [self]
+            while chain[-1].FinerSequence is not None:
+                chain.append(chain[-1].FinerSequence)
+            finest = chain[-1]
+            if V0.ndim != 2 or V0.shape[0] != finest.level.ndof(jform):
+                raise ValueError("DeRhamSequence::ComputeSpaceInterpolationError(): fineVector size is wrong.")
+            v = V0
+            for seq in reversed(chain[1:]):                       # finest ... the sequence just above this one
+                v = seq.GetPi(jform) @ v
+            for seq in chain[1:]:
+                v = seq.GetP(jform) @ v
+            diff = V0 - v
+            M = finest.level.mass(jform)
+            l2d = np.einsum("ij,ij->j", diff, M @ diff)
+            l2v = np.einsum("ij,ij->j", V0, M @ V0)
+            graph = None
+            if jform < 3:
+                W, D = finest.level.mass(jform + 1), finest.level.D[jform]
+                dd, dv = D @ diff, D @ V0
+                l2dd = np.einsum("ij,ij->j", dd, W @ dd)
+                l2dv = np.einsum("ij,ij->j", dv, W @ dv)
+                l2dv = np.where(np.abs(l2v + l2dv) < 1e-9, 1.0, l2dv)          # DEFAULT_EQUALITY_TOL
+                graph = np.sqrt((l2d + l2dd) / (l2v + l2dv))
+            out.append((self.level.ndof(jform), np.sqrt(l2d / l2v), graph))
+        if self.CoarserSequence is not None:
+            self.CoarserSequence.ComputeSpaceInterpolationError(jform, V0, out)
         return out
 
     def _need_coarse(self, what):

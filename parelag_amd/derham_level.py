@@ -179,11 +179,18 @@ class SeqLevel:
         k = int(round(np.sqrt(v.size)))
         return v.reshape(k, k)
 
-    def mass(self, j, c=0):
-        """Assembled mass of form j from the codim-c blocks (``ComputeMassOperator`` for c = 0)."""
+    def mass(self, j, c=0, scaling=None):
+        """Assembled mass of form j from the codim-c blocks (``ComputeMassOperator`` for c = 0); ``scaling``: one factor per
+        entity applied to its block first (``ComputeMassOperator(jform, elemMatrixScaling)``, ``DeRhamSequence.cpp:1325-1370``)."""
         ep, ei = _Tables(self).edof(j, c)
         lr, lc = _block_rc(ep[:-1], np.diff(ep))
-        M = sp.csr_matrix((self.M[j][c][1], (ei[lr], ei[lc])), shape=(self.ndof(j), self.ndof(j)))
+        vals = self.M[j][c][1]
+        if scaling is not None:
+            scaling = np.asarray(scaling, dtype=np.float64)
+            if scaling.shape != (self.n[c],):
+                raise ValueError(f"elemMatrixScaling has the wrong size. Size is {scaling.size}. Should be {self.n[c]}.")
+            vals = vals * np.repeat(scaling, np.diff(self.M[j][c][0]))
+        M = sp.csr_matrix((vals, (ei[lr], ei[lc])), shape=(self.ndof(j), self.ndof(j)))
         M.sum_duplicates(); M.sort_indices()
         return M
 

@@ -189,3 +189,21 @@ def test_hex_sequence_is_exact_and_coarsens(seq):
         assert max(inv.values()) < 1e-11, inv
         if kinv is not None:
             assert r0["n_null"][2] > 0
+
+
+def test_element_scaled_mass_operator():
+    """``ComputeMassOperator(jform, elemMatrixScaling)`` (``DeRhamSequence.cpp:1325-1370``): every element block scaled by its
+    factor before the assembly; a vector of the wrong length is refused like in the reference."""
+    from parelag_amd import derham
+    from parelag_amd.derham_level import seq_level_from_hex
+    seq = derham.DeRhamSequence(seq_level_from_hex((2, 3, 2), jstart=0))
+    ne = seq.level.n[0]
+    s = np.linspace(0.5, 3.0, ne)
+    for j in range(4):
+        M = seq.ComputeMassOperator(j, s)
+        ref = sum(seq.ComputeMassOperator(j, (np.arange(ne) == e) * s[e]) for e in range(ne))
+        assert abs(M - ref).max() < 1e-15
+        assert abs(seq.ComputeMassOperator(j, np.ones(ne)) - seq.ComputeMassOperator(j)).max() == 0.0
+    with pytest.raises(ValueError, match="elemMatrixScaling has the wrong size"):
+        seq.ComputeMassOperator(2, np.ones(ne + 1))
+    assert seq.GetNumTrueDofs(1) == seq.GetNumberOfDofs(1) and seq.GetL2ConstRepresentation().shape == (ne,)

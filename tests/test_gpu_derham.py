@@ -203,6 +203,14 @@ def test_derham_sequence_class_reads_like_the_reference_driver(derham):
     mk = sequence[1]._marker(0, only_x0)
     assert 0 < mk.sum() < sequence[1]._marker(0, ess).sum()
     assert sequence[0].GetM(2, 1).shape == (seq.meshes[0].ne, seq.meshes[0].ne)      # ridge mass of the 1-forms: one dof per edge
+    # testsuite/coarseSpaces.cpp:193-198: the targets are interpolated without error on every level, a rough field is not
+    for jf in range(4):
+        rows = sequence[0].ComputeSpaceInterpolationError(jf, sequence[0].level.T[jf])
+        assert [r[0] for r in rows] == [sequence[1].GetNumberOfDofs(jf), sequence[2].GetNumberOfDofs(jf)]
+        assert all(r[1].max() < 1e-9 and (r[2] is None or r[2].max() < 1e-9) for r in rows), (jf, rows)
+    rough = np.random.default_rng(5).standard_normal((sequence[0].GetNumberOfDofs(0), 2))
+    rows = sequence[0].ComputeSpaceInterpolationError(0, rough)
+    assert 0.1 < rows[0][1].min() and np.all(rows[1][1] >= rows[0][1] - 1e-12)
     with pytest.raises(RuntimeError, match="Coarsen"):
         sequence[2].GetP(0)
     with pytest.raises(ValueError):
