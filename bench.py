@@ -246,8 +246,7 @@ def main():
         Ps = dar["Ps"]
         A = sp.bmat([[dar["M"], dar["Bt"]], [dar["B"], None]]).tocsr()
     elif args.amge or args.hex:
-        # forms 0 / 1 / 2 on AMGe spaces: the whole sequence is coarsened on the device (every rank does the whole mesh; the
-        # distributed builders partition the result like the generator's interpolators)
+        # forms 0 / 1 / 2 on AMGe spaces: the whole sequence is coarsened on the device
         from parelag_amd import derham
         if args.hex:
             # the SPE10 grid in its "derefinement" flavour (MultigridTestSPE10.cpp:441: jformStart = 0): 2 x 2 x 2 boxes of cells
@@ -265,7 +264,20 @@ def main():
             A, Ps, Ds, _levels, amge_rec = derham.amge_problem(args.form, level=lvh, parts=parts_h, what="hex %dx%dx%d, 2x2x2 box agglomerates" % nh)
         else:
             seq = meshgen.Sequence.cube456(args.refines)
-            A, Ps, Ds, _levels, amge_rec = derham.amge_problem(args.form, seq)
+            coarsen_fn = None
+            if not single:
+                # several ranks: the numeric stages are sharded by agglomerate ownership (the derefinement agglomerates follow
+                # the row-block partition of the elements), the pieces are all-gathered for the row-block builders
+                from parelag_amd import derham_dist, partition as _partition
+                eparts = _partition.element_partitions(seq, world)
+
+                def coarsen_fn(level, part, l):
+                    owner = np.zeros(int(part.max()) + 1, dtype=np.int64)
+                    owner[part] = eparts[l]
+                    return derham_dist.coarsen_allgather(level, part, rank, world, owner=owner)
+            A, Ps, Ds, _levels, amge_rec = derham.amge_problem(args.form, seq, coarsen_fn=coarsen_fn)
+            if not single:
+                amge_rec["what"] += "; sharded over %d rank(s) by agglomerate ownership (derham_dist)" % world
         note("AMGe coarsening (forms %d..3): %d levels in %.3f s" % (0 if args.form <= 1 else 1, len(Ps), amge_rec["coarsen_total_s"]))
     elif args.form == 2:
         A, Ps, Ds, seq = meshgen.hdiv_problem(args.refines)

@@ -194,9 +194,10 @@ class _CoarseDofs:
         return int(sum(self.cnt[c2].sum() for c2 in range(self.cb, c - 1, -1)))
 
 
-def coarsen(lv: SeqLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entry: float = EPS) -> dict:
-    """``DeRhamSequence::Coarsen`` (``src/amge/DeRhamSequence.cpp:572-692``) for forms ``lv.jstart .. 3``."""
-    topo = coarsen_topology(lv, part)
+def coarsen(lv: SeqLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entry: float = EPS, topo: dict | None = None) -> dict:
+    """``DeRhamSequence::Coarsen`` (``src/amge/DeRhamSequence.cpp:572-692``) for forms ``lv.jstart .. 3``.  ``topo``: an
+    agglomerated topology made elsewhere (the restriction of the global one to a rank's part) instead of ``coarsen_topology``."""
+    topo = coarsen_topology(lv, part) if topo is None else topo
     js = lv.jstart
     agg = {j: agglomerate_dofs(lv, topo, j) for j in range(js, 4)}
     cd_ = {j: _CoarseDofs(lv, topo, j) for j in range(js, 4)}

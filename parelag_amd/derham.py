@@ -241,12 +241,13 @@ def _triplets(D: sp.csr_matrix, rows_ptr, rows, look_cols: _Lookup):
 # ---- Coarsen ------------------------------------------------------------------------------------------------------------------
 
 def coarsen(lv: SeqLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entry: float = EPS, timings: dict | None = None,
-            check_topology: bool = False) -> dict:
+            check_topology: bool = False, topo: dict | None = None) -> dict:
     """``DeRhamSequence::Coarsen`` for forms ``lv.jstart .. 3``.  Returns dict(P, hat, coarse, topo, n_null).  ``check_topology``:
-    build the agglomerated topology with the checks and repairs of ``CoarsenLocalPartitioning(..., check_topology = true)``."""
+    build the agglomerated topology with the checks and repairs of ``CoarsenLocalPartitioning(..., check_topology = true)``.
+    ``topo``: an agglomerated topology made elsewhere (``derham_dist``: the global one restricted to a rank's part)."""
     L = _lib.init()
     tb = _Tables(lv)
-    topo = coarsen_topology(lv, part, check=check_topology)
+    topo = coarsen_topology(lv, part, check=check_topology) if topo is None else topo
     js = lv.jstart
     agg = {j: agglomerate_dofs(lv, tb, topo, j) for j in range(js, 4)}
     cd = {j: _CoarseDofs(lv, topo, j) for j in range(js, 4)}
@@ -518,13 +519,14 @@ def boundary_dofs(lv: SeqLevel, j: int) -> np.ndarray:
     return mk
 
 
-def amge_problem(form: int, seq=None, level: SeqLevel | None = None, parts: list | None = None, what: str | None = None):
+def amge_problem(form: int, seq=None, level: SeqLevel | None = None, parts: list | None = None, what: str | None = None, coarsen_fn=None):
     """The operators of MultigridTest0Form / 1Form / 2Form on AMGe spaces built by the device coarsening: fine operator
     (``D0^T M1 D0`` resp. ``M_j + D_j^T M_{j+1} D_j``) with all boundary attributes essential, the interpolators ``P_form`` of
     every level with essential columns eliminated (``ComputeTrueP(jform, ess)``, ``src/amge/DeRhamSequence.cpp:1118-1153,1230-1253``)
     and, for the Hiptmair smoother, the derivative ``D_{form-1}`` of every level with essential columns eliminated
     (``HiptmairSmootherFactory.cpp:84-103``).  Either ``seq`` (the generator's refined cube456: derefinement agglomerates)
-    or a finest ``level`` with its list of element partitionings.  Returns (A, Ps, Ds or None, levels, record)."""
+    or a finest ``level`` with its list of element partitionings.  ``coarsen_fn(level, part, l)`` replaces the single-rank
+    ``coarsen`` (``derham_dist.coarsen_allgather`` on several ranks).  Returns (A, Ps, Ds or None, levels, record)."""
     import time
     from . import meshgen
     from .derham_level import seq_level_from_tets
@@ -541,7 +543,7 @@ def amge_problem(form: int, seq=None, level: SeqLevel | None = None, parts: list
     for part in parts:
         tm = {}
         t1 = time.time()
-        res = coarsen(levels[-1], part, timings=tm)
+        res = coarsen(levels[-1], part, timings=tm) if coarsen_fn is None else coarsen_fn(levels[-1], part, len(Ps))
         c = res["coarse"]
         recs.append({"agglomerates": c.n[0], "entities": c.n, "dofs": [c.ndof(j) for j in range(c.jstart, 4)],
                      "null_dofs": {str(j): v for j, v in res["n_null"].items()},

@@ -1,0 +1,152 @@
+"""``DeRhamSequence::Coarsen`` on several ranks (``parelag_amd/derham_dist.py``): replicated integer topology, numeric stages
+sharded by agglomerate ownership with the interface entities computed redundantly, one integer exchange for the coarse dof
+numbering.  The reference's counterpart is its shared-entity handling (``src/amge/DeRhamSequence.cpp:1820, 1930, 1971, 2024``);
+the property tested is the one its parallel ctest runs rely on (``par_form1_np2`` expects the serial numbers,
+``testsuite/CMakeLists.txt:127-133``): the ranks' pieces put together are the single-rank result.
+
+CPU half: the oracle's numeric path under the product's restriction / renumbering (in-process ranks), and the count
+exchange over a real two-process gloo group.  GPU half: the device path per rank."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import derham as od
+from parelag_amd import derham, derham_dist as dd
+from parelag_amd.amge_level import box_partition
+from parelag_amd.derham_level import seq_level_from_hex
+
+from tests.test_derham_oracle import kuhn_boxes
+
+
+def in_process(lv, part, nranks, owner, coarsen_fn):
+    """All ranks one after the other in this process; the all-reduce is replaced by a two-pass stand-in: every rank first
+    reports its counts (``probe``), then runs again against the elementwise maximum."""
+    topo = derham.coarsen_topology(lv, part)
+    reported = []
+
+    def probe(local):
+        reported.append(local.copy())
+        return local
+    for r in range(nranks):
+        dd.coarsen_rank(lv, part, r, nranks, owner=owner, topo=topo, exchange=probe, coarsen_fn=coarsen_fn)
+    glob = np.max(np.stack(reported), axis=0)
+    for a in reported:
+        assert np.all((a == 0) | (a == glob))                      # ranks sharing an entity agree on its coarse dofs
+    pieces = [dd.coarsen_rank(lv, part, r, nranks, owner=owner, topo=topo, exchange=lambda local: glob, coarsen_fn=coarsen_fn)
+              for r in range(nranks)]
+    return topo, pieces
+
+
+def same_as_single_rank(lv, merged, single, tol):
+    c, cs = merged["coarse"], single["coarse"]
+    for j in range(lv.jstart, 4):
+        assert [np.array_equal(a, b) for a, b in zip(c.idof[j], cs.idof[j])] == [True] * (lv.cb(j) + 1)
+        d = abs(merged["P"][j] - single["P"][j])
+        assert (d.max() if d.nnz else 0.0) <= tol * abs(single["P"][j]).max(), j
+        assert np.abs(c.T[j] - cs.T[j]).max() <= tol * max(np.abs(cs.T[j]).max(), 1e-300)
+        for k in range(lv.cb(j) + 1):
+            assert np.array_equal(c.M[j][k][0], cs.M[j][k][0])
+            assert np.abs(c.M[j][k][1] - cs.M[j][k][1]).max() <= tol * np.abs(cs.M[j][k][1]).max()
+        if j < 3:
+            d = abs(c.D[j] - cs.D[j])
+            assert (d.max() if d.nnz else 0.0) <= tol * abs(cs.D[j]).max()
+        assert np.array_equal(c.pv[j], cs.pv[j])
+    assert np.abs(c.const3 - cs.const3).max() <= tol * np.abs(cs.const3).max()
+
+
+CASES = {"hex_blocks_2": ("hex", 2, None), "hex_blocks_3": ("hex", 3, None), "hex_checkerboard": ("hex", 2, "checker"),
+         "tets_hetero_3": ("tet", 3, None)}
+
+
+def make(case):
+    kind, nranks, own = CASES[case]
+    if kind == "hex":
+        n = (4, 4, 4)
+        lv, part = seq_level_from_hex(n, h=(0.25, 0.5, 1.0), jstart=0), box_partition(n, (2, 2, 2)).astype(np.int64)
+    else:
+        lv, part = kuhn_boxes()
+    owner = None if own is None else (np.arange(int(part.max()) + 1) * 7 // 3) % nranks
+    return lv, part, nranks, owner
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_rank_pieces_reproduce_the_single_rank_coarsening_oracle_numerics(case):
+    lv, part, nranks, owner = make(case)
+    topo, pieces = in_process(lv, part, nranks, owner, od.coarsen)
+    assert sum(p.agglomerates.size for p in pieces) == topo["n"][0]
+    shared = sum(p.csel[1].size for p in pieces) - topo["n"][1]
+    assert shared > 0                                                   # some agglomerated facets are held by two ranks
+    merged = dd.merge_pieces(lv, topo, pieces, atol=1e-14)
+    same_as_single_rank(lv, merged, od.coarsen(lv, part), tol=1e-14)
+
+
+def test_restriction_keeps_the_sequence_exact():
+    lv, part, _n, _o = make("tets_hetero_3")
+    topo = derham.coarsen_topology(lv, part)
+    R = dd.restrict_level(lv, topo, np.array([1, 6]))
+    s = R.level
+    assert s.n[0] == 96 and all(abs(s.D[j + 1] @ s.D[j]).max() == 0.0 for j in range(2))
+    for c in range(2):
+        Bc = [sp.csr_matrix((s.B[k][2], s.B[k][1], s.B[k][0]), shape=(s.n[k], s.n[k + 1])) for k in (c, c + 1)]
+        assert abs(Bc[0] @ Bc[1]).max() == 0.0
+    for j in range(4):
+        full = lv.mass(j, 0, scaling=np.isin(np.arange(lv.n[0]), R.sel[0]) * 1.0)       # mass of the kept elements only
+        assert abs(s.mass(j) - full[R.dofs[j]][:, R.dofs[j]]).max() < 1e-15
+    with pytest.raises(ValueError):
+        dd._restrict_rows(*lv.B[0][:2], R.sel[0], np.full(lv.n[1], -1))
+
+
+def _gloo_worker(rank, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        lv, part, _n, _o = make("hex_blocks_2")
+        piece = dd.coarsen_rank(lv, part, rank, 2, coarsen_fn=od.coarsen)              # the real all-reduce of the counts
+        full = dd.coarsen_allgather(lv, part, rank, 2, coarsen_fn=od.coarsen)          # + the all-gather of the pieces
+        single = od.coarsen(lv, part)
+        same_as_single_rank(lv, full, single, tol=1e-14)
+        q.put((rank, {k: v.tolist() for k, v in piece.counts.items()}, [p.shape for p in piece.P], piece.coarse_dofs[2].tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_count_exchange_over_gloo_world_size_2():
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lv, part, _n, _o = make("hex_blocks_2")
+    single = od.coarsen(lv, part)
+    assert got[0][1] == got[1][1]                                                       # both ranks hold the global counts
+    for (j, c), cnt in got[0][1].items():
+        assert cnt == np.diff(single["coarse"].idof[j][c]).tolist()
+    assert got[0][2] == got[1][2] and [s[1] for s in got[0][2]] == [single["coarse"].ndof(j) for j in range(4)]
+    assert set(got[0][3]) | set(got[1][3]) == set(range(single["coarse"].ndof(2)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_rank_pieces_reproduce_the_single_rank_coarsening_on_device(case):
+    lv, part, nranks, owner = make(case)
+    topo, pieces = in_process(lv, part, nranks, owner, derham.coarsen)
+    merged = dd.merge_pieces(lv, topo, pieces, atol=1e-11)
+    single = derham.coarsen(lv, part)
+    same_as_single_rank(lv, merged, single, tol=1e-10)
+    # the merged result is a valid coarsening on its own: the reference's invariants
+    from tests.test_derham_oracle import invariants
+    merged["Pi"] = {j: derham.projector(single, j) for j in range(4)}
+    inv = invariants(lv, merged, Pi=merged["Pi"])
+    assert max(inv.values()) < 1e-9, inv
