@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <functional>
+#include <memory>
 
 namespace elag {
 namespace {
@@ -280,6 +281,7 @@ __device__ int dof_functional(const double *P, const double *MP, int n, int kc, 
 }
 
 struct TracesArgs {
+    const int *ent_list;          // entities of this launch (nullptr: all of them, blockIdx.x is the entity)
     int n_ent, nT;
     double svd_tol;
     const int *ndof;
@@ -297,7 +299,7 @@ __global__ void coarsen_traces_kernel(TracesArgs a)
 {
     extern __shared__ double dyn[];
     __shared__ Shared sh;
-    const int e = blockIdx.x;
+    const int e = a.ent_list ? a.ent_list[blockIdx.x] : (int)blockIdx.x;
     const int n = a.ndof[e], k0 = a.nT, kmax = 1 + k0;
     const int64_t doff = a.dof_off[e];
     double *ws = a.ws_off[e] >= 0 ? a.gws + a.ws_off[e] : dyn;
@@ -366,6 +368,7 @@ __global__ void coarsen_traces_kernel(TracesArgs a)
 }
 
 struct ExtArgs {
+    const int *ent_list;          // entities of this launch (nullptr: all of them)
     int n_ent, nT, mode;          // mode 0: FacetSaddlePoint (PV multiplier row), 1: RidgePeakSaddlePoint ([M B^T; B -C])
     int null_dofs;                // 0: no null-space dofs are built (the "peak" stage of the 0-forms)
     int debug_stop;               // diagnostic builds (-DELAG_AMGE_PHASE_STOP): leave the kernel after phase k (ELAG_HIP_AMGE_STOP)
@@ -392,7 +395,7 @@ __global__ void coarsen_extension_kernel(ExtArgs a)
 {
     extern __shared__ double dyn[];
     __shared__ Shared sh;
-    const int e = blockIdx.x;
+    const int e = a.ent_list ? a.ent_list[blockIdx.x] : (int)blockIdx.x;
     const int nu = a.nu[e], ni = a.ni[e], np = a.np[e], npi = a.npi[e], next = a.next[e], nrt = a.nrt[e];
     const int nq = a.mode ? a.nq[e] : 0;
     const int nb = nu - ni;
@@ -601,6 +604,7 @@ __global__ void coarsen_extension_kernel(ExtArgs a)
 // DenseMatrix::Rank(1e-9) of the local boundary operators (entries 0, +-1): here by Gaussian elimination with row pivoting per
 // column; a column whose remaining entries are all below the tolerance adds nothing to the rank.
 struct RankArgs {
+    const int *ent_list;
     int n_mat;
     double tol;
     const int *nr, *nc;
@@ -616,7 +620,7 @@ __global__ void batched_rank_kernel(RankArgs a)
 {
     extern __shared__ double dyn[];
     __shared__ int piv[2];
-    const int e = blockIdx.x;
+    const int e = a.ent_list ? a.ent_list[blockIdx.x] : (int)blockIdx.x;
     const int nr = a.nr[e], nc = a.nc[e];
     double *A = a.ws_off[e] >= 0 ? a.gws + a.ws_off[e] : dyn;
     zero_fill(A, nr * nc);
@@ -706,21 +710,42 @@ struct DevBuf {
     operator T *() const { return p; }
 };
 
-// scratch placement: entities that fit into the dynamic LDS budget run there, the others get a slice of global scratch
+// Scratch placement: entities that fit into the dynamic LDS budget run there, the others get a slice of global scratch.
+// Where an entity's workspace lives (LDS or a slot of the global scratch) and how many threads work on it.  Both depend on
+// the entity alone, never on what else is in the launch: an entity computed by two ranks (an agglomerated facet on their
+// interface, derham_dist.py) or in two differently composed batches goes through the same reductions in the same order and
+// comes out bit-identical.  Entities of the two workgroup sizes are launched separately.
 struct Placement {
+    static constexpr int64_t kWideNeed = 3000;               // more doubles than this: 256 threads instead of one wave
     std::vector<int64_t> ws_off;
-    int64_t gws_total = 0, max_need = 0;
-    int lds_doubles = 0, threads = 64;
+    int64_t gws_total = 0;
+    std::vector<int> group[2];                               // entities per workgroup size (64, 256)
+    int lds_doubles[2] = {0, 0};
     void finish(const std::vector<int64_t> &need)
     {
         ws_off.resize(need.size());
         for (size_t e = 0; e < need.size(); e++) {
-            max_need = std::max(max_need, need[e]);
-            if (need[e] <= kLdsDoubles) { ws_off[e] = -1; lds_doubles = std::max<int>(lds_doubles, (int)need[e]); }
+            const int g = need[e] > kWideNeed ? 1 : 0;
+            group[g].push_back((int)e);
+            if (need[e] <= kLdsDoubles) { ws_off[e] = -1; lds_doubles[g] = std::max<int>(lds_doubles[g], (int)need[e]); }
             else { ws_off[e] = gws_total; gws_total += need[e]; }
         }
-        threads = max_need > 3000 ? 256 : 64;
     }
+    // launch(list or nullptr, number of workgroups, threads, dynamic LDS bytes) once per non-empty group
+    template <class F> void for_each_group(F &&launch) const
+    {
+        static const int threads[2] = {64, 256};
+        if (group[0].empty() || group[1].empty()) {
+            const int g = group[0].empty() ? 1 : 0;
+            if (!group[g].empty()) launch((const int *)nullptr, (int)group[g].size(), threads[g], (size_t)lds_doubles[g] * sizeof(double));
+            return;
+        }
+        for (int g = 0; g < 2; g++) {
+            lists[g].reset(new DevBuf<int>(group[g].data(), group[g].size()));
+            launch((const int *)lists[g]->p, (int)group[g].size(), threads[g], (size_t)lds_doubles[g] * sizeof(double));
+        }
+    }
+    mutable std::unique_ptr<DevBuf<int>> lists[2];
 };
 
 float run_timed(hipStream_t st, const std::function<void()> &launch)
@@ -787,7 +812,10 @@ ELAG_HIP_API int elag_hip_coarsen_traces(const elag_hip_coarsen_traces_in *in, c
         a.pv = d_pv; a.T = d_T; a.ncoarse = d_nc; a.p_loc = d_p; a.cmass = d_cm; a.functional = d_f;
         a.ws_off = d_wsoff; a.gws = d_gws; a.singular = d_sing;
         const float ms = run_timed(st, [&] {
-            hipLaunchKernelGGL(coarsen_traces_kernel, dim3(ne), dim3(pl.threads), (size_t)pl.lds_doubles * sizeof(double), st, a);
+            pl.for_each_group([&](const int *list, int n, int threads, size_t lds) {
+                a.ent_list = list;
+                hipLaunchKernelGGL(coarsen_traces_kernel, dim3(n), dim3(threads), lds, st, a);
+            });
         });
         ELAG_LAUNCH_CHECK();
         if (kernel_ms) *kernel_ms = ms;
@@ -871,7 +899,10 @@ ELAG_HIP_API int elag_hip_coarsen_extension(const elag_hip_coarsen_extension_in 
         a.n_null = d_nnull; a.ext = d_ext; a.dc = d_dc; a.rt = d_rt; a.nul = d_nul; a.functional = d_fun; a.cmass = d_cm;
         a.ws_off = d_wsoff; a.gws = d_gws; a.singular = d_sing;
         const float ms = run_timed(st, [&] {
-            hipLaunchKernelGGL(coarsen_extension_kernel, dim3(ne), dim3(pl.threads), (size_t)pl.lds_doubles * sizeof(double), st, a);
+            pl.for_each_group([&](const int *list, int n, int threads, size_t lds) {
+                a.ent_list = list;
+                hipLaunchKernelGGL(coarsen_extension_kernel, dim3(n), dim3(threads), lds, st, a);
+            });
         });
         ELAG_LAUNCH_CHECK();
         if (kernel_ms) *kernel_ms = ms;
@@ -908,8 +939,11 @@ ELAG_HIP_API int elag_hip_batched_rank(int n_mat, const int *nrows, const int *n
         DevBuf<int> d_nr(nrows, n_mat), d_nc(ncols, n_mat), d_row(t_row, (size_t)nt), d_col(t_col, (size_t)nt), d_rank((size_t)n_mat);
         DevBuf<int64_t> d_ptr(t_ptr, (size_t)n_mat + 1), d_ws(pl.ws_off.data(), (size_t)n_mat);
         DevBuf<double> d_val(t_val, (size_t)nt), d_gws((size_t)pl.gws_total);
-        RankArgs a{n_mat, tol, d_nr, d_nc, d_ptr, d_row, d_col, d_val, d_rank, d_ws, d_gws};
-        hipLaunchKernelGGL(batched_rank_kernel, dim3(n_mat), dim3(pl.threads), (size_t)pl.lds_doubles * sizeof(double), st, a);
+        RankArgs a{nullptr, n_mat, tol, d_nr, d_nc, d_ptr, d_row, d_col, d_val, d_rank, d_ws, d_gws};
+        pl.for_each_group([&](const int *list, int n, int threads, size_t lds) {
+            a.ent_list = list;
+            hipLaunchKernelGGL(batched_rank_kernel, dim3(n), dim3(threads), lds, st, a);
+        });
         ELAG_LAUNCH_CHECK();
         ELAG_HIP_CHECK(hipMemcpyAsync(rank, d_rank.p, sizeof(int) * n_mat, hipMemcpyDeviceToHost, st));
         ELAG_HIP_CHECK(hipStreamSynchronize(st));

@@ -142,9 +142,11 @@ def test_count_exchange_over_gloo_world_size_2():
 def test_rank_pieces_reproduce_the_single_rank_coarsening_on_device(case):
     lv, part, nranks, owner = make(case)
     topo, pieces = in_process(lv, part, nranks, owner, derham.coarsen)
-    merged = dd.merge_pieces(lv, topo, pieces, atol=1e-11)
+    # bit for bit: workspace placement and workgroup size are properties of the entity, not of the launch it is part of
+    # (csrc/amge.hip, Placement), so an interface entity computed by two ranks, or in a smaller batch, comes out identical
+    merged = dd.merge_pieces(lv, topo, pieces, atol=1e-300)
     single = derham.coarsen(lv, part)
-    same_as_single_rank(lv, merged, single, tol=1e-10)
+    same_as_single_rank(lv, merged, single, tol=0.0)
     # the merged result is a valid coarsening on its own: the reference's invariants
     from tests.test_derham_oracle import invariants
     merged["Pi"] = {j: derham.projector(single, j) for j in range(4)}
