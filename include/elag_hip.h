@@ -528,6 +528,29 @@ ELAG_HIP_API int elag_hip_batched_rank(int n_mat, const int *nrows, const int *n
                                        const double *t_val, double tol, int *rank);
 
 /* --------------------------------------------------------------------------------------------------
+ * Host integer tables of the coarsening (csrc/host_tables.hip; no device work, callable before elag_hip_init).  Ragged tables
+ * are (ptr[n+1], idx[ptr[n]]) with int64 entries.
+ * ------------------------------------------------------------------------------------------------ */
+/* Row-by-row product of two ragged tables with the columns of a row in first-touch order: mfem::Mult on patterns as
+ * AgglomeratedTopology / DofAgglomeration use it; with a_sgn, b_sgn, out_sgn given it is MultOrientation
+ * (src/topology/TopologyTable.cpp:130-139): signed sums, cancelled entries dropped, values reduced to their sign.
+ * out_idx (and out_sgn) need room for sum over the left entries of the right rows' lengths; *out_nnz = entries written. */
+ELAG_HIP_API int elag_hip_host_table_product(int64_t nrow, const int64_t *a_ptr, const int64_t *a_idx, const double *a_sgn, int64_t nmid,
+                                         const int64_t *b_ptr, const int64_t *b_idx, const double *b_sgn, int64_t ncol, int64_t *out_ptr,
+                                         int64_t *out_idx, double *out_sgn, int64_t *out_nnz);
+/* pos[q] = position of q_id[q] within row q_row[q] of (ptr, idx) (ids in 0 .. nid), -1 when absent: the dof -> local index maps
+ * of DofAgglomeration (src/amge/DOFAgglomeration.cpp:533-655) for all agglomerated entities at once. */
+ELAG_HIP_API int elag_hip_host_lookup_find(int64_t nrow, const int64_t *ptr, const int64_t *idx, int64_t nid, int64_t nq, const int64_t *q_row,
+                                       const int64_t *q_id, int64_t *pos);
+/* mfem::SparseMatrix::GetSubMatrix for every entity of a codimension at once: block e = M[rows of e, columns of e], column-major
+ * nr_e x ncol[e] at out + out_ptr[e] (out zeroed by the caller; columns of M outside the entity's list are skipped). */
+ELAG_HIP_API int elag_hip_host_gather_dense(int64_t n_ent, const int64_t *row_ptr, const int64_t *rows, const int64_t *col_ptr, const int64_t *col_idx,
+                                        const int64_t *ncol, int64_t m_rows, int64_t m_cols, const int32_t *m_indptr, const int32_t *m_indices,
+                                        const double *m_data, const int64_t *out_ptr, double *out);
+/* idx = concatenation of the ranges [starts[i], starts[i] + counts[i]), owner[k] = i of entry k. */
+ELAG_HIP_API int elag_hip_host_expand_ranges(int64_t n, const int64_t *starts, const int64_t *counts, int64_t total, int64_t *idx, int64_t *owner);
+
+/* --------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): run `reps` launches of one fine-level kernel on the compute stream
  * bracketed by HIP events created on that stream and return the mean milliseconds per launch.
  * kernel: 0 = SpMV y=Ax, 1 = residual, 2 = l1-Jacobi sweep.

@@ -149,6 +149,11 @@ _SIGNATURES = {
     "elag_hip_krylov_get_stats": [_p, _ip, _ip, _dp],
     "elag_hip_krylov_destroy": [_p],
     "elag_hip_batched_rank": [_i, _p, _p, _p, _p, _p, _p, _d, _p],
+    # host integer tables of the coarsening (no device)
+    "elag_hip_host_table_product": [_i64, _p, _p, _p, _i64, _p, _p, _p, _i64, _p, _p, _p, _p],
+    "elag_hip_host_lookup_find": [_i64, _p, _p, _i64, _i64, _p, _p, _p],
+    "elag_hip_host_gather_dense": [_i64, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p],
+    "elag_hip_host_expand_ranges": [_i64, _p, _p, _i64, _p, _p],
     "elag_hip_coarsen_traces": [_p, _p, _dp],
     "elag_hip_coarsen_extension": [_p, _p, _dp],
     "elag_hip_time_kernel": [_p, _p, _i, _i, _p, _p, _dp],

@@ -25,12 +25,12 @@ EPS = float(np.finfo(np.float64).eps)
 
 def expand_ranges(starts, counts):
     """Concatenation of ``arange(starts[i], starts[i] + counts[i])``; also returns the owner index of every entry."""
-    counts = np.asarray(counts, dtype=np.int64)
-    starts = np.asarray(starts, dtype=np.int64)
+    counts = np.ascontiguousarray(counts, dtype=np.int64)
+    starts = np.ascontiguousarray(starts, dtype=np.int64)
     tot = int(counts.sum())
-    owner = np.repeat(np.arange(counts.size, dtype=np.int64), counts)
-    within = np.arange(tot, dtype=np.int64) - np.repeat(ptr_from_counts(counts)[:-1], counts)
-    return starts[owner] + within, owner
+    idx, owner = np.empty(tot, dtype=np.int64), np.empty(tot, dtype=np.int64)
+    _lib.check(_lib.load().elag_hip_host_expand_ranges(counts.size, _ptr(starts), _ptr(counts), tot, _ptr(idx), _ptr(owner)))
+    return idx, owner
 
 
 def _first_touch_groups(row, col, val):

@@ -1,0 +1,156 @@
+// Host-side integer tables of the AMGe coarsening (no device work): the ragged-table primitives every stage of
+// parelag_amd/derham.py is made of, in native code because they are 99 % of the coarsening's wall time.  They follow the
+// reference's own host loops:
+//   elag_hip_host_table_product   mfem::Mult pattern product with first-touch column order, and its signed form MultOrientation
+//                             (src/topology/TopologyTable.cpp:130-139; marker-array Gustavson rows)
+//   elag_hip_host_lookup_find     the position of a dof inside its agglomerate's dof list (DofAgglomeration's dofMapper /
+//                             mfem::SparseMatrix::GetSubMatrix column markers, src/amge/DOFAgglomeration.cpp:533-655)
+//   elag_hip_host_gather_dense    GetSubMatrix of a CSR matrix for every entity at once, packed column-major
+//   elag_hip_host_expand_ranges   concatenated index ranges with their owners
+// No GPU is touched; the functions are callable before elag_hip_init.
+#include "common.hpp"
+
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+using namespace elag;
+
+extern "C" {
+
+// out_ptr[nrow+1]; out_idx / out_sgn with room for sum_k |b row of a_idx[k]| entries.  a_sgn / b_sgn / out_sgn all null
+// (pattern product) or all given (signed product: sums with |s| <= 1e-10 are dropped, the others reduced to their sign).
+ELAG_HIP_API int elag_hip_host_table_product(int64_t nrow, const int64_t *a_ptr, const int64_t *a_idx, const double *a_sgn, int64_t nmid,
+                                         const int64_t *b_ptr, const int64_t *b_idx, const double *b_sgn, int64_t ncol, int64_t *out_ptr,
+                                         int64_t *out_idx, double *out_sgn, int64_t *out_nnz)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(nrow >= 0 && nmid >= 0 && ncol >= 0 && a_ptr && b_ptr && out_ptr && out_nnz, "table_product: null or negative argument");
+        const bool sgn = a_sgn != nullptr;
+        ELAG_REQUIRE(sgn == (b_sgn != nullptr) && sgn == (out_sgn != nullptr), "table_product: signs must be given for both tables and the output, or for none");
+        std::vector<int64_t> where((size_t)ncol, -1);          // position of a column in the current output row
+        int64_t n = 0;
+        out_ptr[0] = 0;
+        for (int64_t r = 0; r < nrow; r++) {
+            const int64_t row0 = n;
+            for (int64_t k = a_ptr[r]; k < a_ptr[r + 1]; k++) {
+                const int64_t m = a_idx[k];
+                ELAG_REQUIRE(m >= 0 && m < nmid, "table_product: entry %lld of the left table is outside the right table", (long long)m);
+                for (int64_t q = b_ptr[m]; q < b_ptr[m + 1]; q++) {
+                    const int64_t c = b_idx[q];
+                    ELAG_REQUIRE(c >= 0 && c < ncol, "table_product: column %lld outside 0..%lld", (long long)c, (long long)ncol);
+                    if (where[(size_t)c] < row0) {              // first touch in this row
+                        where[(size_t)c] = n;
+                        out_idx[n] = c;
+                        if (sgn) out_sgn[n] = 0.0;
+                        n++;
+                    }
+                    if (sgn) out_sgn[where[(size_t)c]] += a_sgn[k] * b_sgn[q];
+                }
+            }
+            if (sgn) {                                          // cancelled entries leave the row, the others keep their order
+                int64_t w = row0;
+                for (int64_t t = row0; t < n; t++) {
+                    const int64_t c = out_idx[t];
+                    const double v = out_sgn[t];
+                    where[(size_t)c] = -1;                      // positions move: no marker of this row survives it
+                    if (std::fabs(v) > 1e-10) {
+                        out_idx[w] = c;
+                        out_sgn[w] = v > 0.0 ? 1.0 : -1.0;
+                        w++;
+                    }
+                }
+                n = w;
+            }
+            out_ptr[r + 1] = n;
+        }
+        *out_nnz = n;
+    });
+}
+
+// pos[q] = position of q_id[q] inside row q_row[q] of the ragged table (ptr, idx), -1 when absent.
+ELAG_HIP_API int elag_hip_host_lookup_find(int64_t nrow, const int64_t *ptr, const int64_t *idx, int64_t nid, int64_t nq, const int64_t *q_row,
+                                       const int64_t *q_id, int64_t *pos)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(nrow >= 0 && nid >= 0 && nq >= 0 && ptr && (nq == 0 || (q_row && q_id && pos)), "lookup_find: null or negative argument");
+        if (nq == 0) return;
+        bool sorted = true;
+        for (int64_t q = 1; q < nq && sorted; q++) sorted = q_row[q - 1] <= q_row[q];
+        std::vector<int64_t> order;
+        if (!sorted) {                                          // counting sort of the queries by row
+            std::vector<int64_t> start((size_t)nrow + 1, 0);
+            for (int64_t q = 0; q < nq; q++) {
+                ELAG_REQUIRE(q_row[q] >= 0 && q_row[q] < nrow, "lookup_find: row %lld outside the table", (long long)q_row[q]);
+                start[(size_t)q_row[q] + 1]++;
+            }
+            for (int64_t r = 0; r < nrow; r++) start[(size_t)r + 1] += start[(size_t)r];
+            order.resize((size_t)nq);
+            for (int64_t q = 0; q < nq; q++) order[(size_t)start[(size_t)q_row[q]]++] = q;
+        }
+        std::vector<int64_t> mark((size_t)nid + 1, -1), stamp((size_t)nid + 1, -1);
+        int64_t cur = -1;
+        for (int64_t t = 0; t < nq; t++) {
+            const int64_t q = sorted ? t : order[(size_t)t];
+            const int64_t r = q_row[q];
+            ELAG_REQUIRE(r >= 0 && r < nrow, "lookup_find: row %lld outside the table", (long long)r);
+            if (r != cur) {
+                cur = r;
+                for (int64_t k = ptr[r]; k < ptr[r + 1]; k++) {
+                    const int64_t i = idx[k];
+                    ELAG_REQUIRE(i >= 0 && i <= nid, "lookup_find: id %lld outside 0..%lld", (long long)i, (long long)nid);
+                    if (stamp[(size_t)i] != r) { stamp[(size_t)i] = r; mark[(size_t)i] = k - ptr[r]; }   // first occurrence wins
+                }
+            }
+            const int64_t i = q_id[q];
+            pos[q] = (i >= 0 && i <= nid && stamp[(size_t)i] == r) ? mark[(size_t)i] : -1;
+        }
+    });
+}
+
+// For every entity e: the dense block M[rows of e, columns of e], packed column-major (nr_e x ncol_e) at out + out_ptr[e];
+// rows of e = rows[row_ptr[e] .. row_ptr[e+1]), columns of e = col_idx[col_ptr[e] .. col_ptr[e+1]) (entries of M outside them
+// are skipped, as mfem's GetSubMatrix does with unmarked columns).  `out` must be zero on entry.
+ELAG_HIP_API int elag_hip_host_gather_dense(int64_t n_ent, const int64_t *row_ptr, const int64_t *rows, const int64_t *col_ptr, const int64_t *col_idx,
+                                        const int64_t *ncol, int64_t m_rows, int64_t m_cols, const int32_t *m_indptr, const int32_t *m_indices,
+                                        const double *m_data, const int64_t *out_ptr, double *out)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(n_ent >= 0 && row_ptr && col_ptr && ncol && m_indptr && out_ptr, "gather_dense: null or negative argument");
+        std::vector<int64_t> mark((size_t)m_cols, -1), stamp((size_t)m_cols, -1);
+        for (int64_t e = 0; e < n_ent; e++) {
+            const int64_t nr = row_ptr[e + 1] - row_ptr[e];
+            ELAG_REQUIRE(col_ptr[e + 1] - col_ptr[e] <= ncol[e] && out_ptr[e + 1] - out_ptr[e] == nr * ncol[e], "gather_dense: block %lld has the wrong size", (long long)e);
+            for (int64_t k = col_ptr[e]; k < col_ptr[e + 1]; k++) {
+                const int64_t c = col_idx[k];
+                ELAG_REQUIRE(c >= 0 && c < m_cols, "gather_dense: column %lld outside the matrix", (long long)c);
+                if (stamp[(size_t)c] != e) { stamp[(size_t)c] = e; mark[(size_t)c] = k - col_ptr[e]; }
+            }
+            double *blk = out + out_ptr[e];
+            for (int64_t lr = 0; lr < nr; lr++) {
+                const int64_t g = rows[row_ptr[e] + lr];
+                ELAG_REQUIRE(g >= 0 && g < m_rows, "gather_dense: row %lld outside the matrix", (long long)g);
+                for (int32_t k = m_indptr[g]; k < m_indptr[g + 1]; k++) {
+                    const int32_t c = m_indices[k];
+                    if (stamp[(size_t)c] == e) blk[mark[(size_t)c] * nr + lr] = m_data[k];
+                }
+            }
+        }
+    });
+}
+
+// idx = concatenation of [starts[i], starts[i] + counts[i]); owner[k] = i.  `total` must equal the sum of the counts.
+ELAG_HIP_API int elag_hip_host_expand_ranges(int64_t n, const int64_t *starts, const int64_t *counts, int64_t total, int64_t *idx, int64_t *owner)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(n >= 0 && total >= 0 && (n == 0 || (starts && counts)) && (total == 0 || (idx && owner)), "expand_ranges: null or negative argument");
+        int64_t k = 0;
+        for (int64_t i = 0; i < n; i++) {
+            ELAG_REQUIRE(counts[i] >= 0 && k + counts[i] <= total, "expand_ranges: the counts do not add up to the given total");
+            for (int64_t j = 0; j < counts[i]; j++, k++) { idx[k] = starts[i] + j; owner[k] = i; }
+        }
+        ELAG_REQUIRE(k == total, "expand_ranges: the counts do not add up to the given total");
+    });
+}
+
+}  // extern "C"

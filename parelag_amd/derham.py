@@ -24,36 +24,34 @@ from .derham_level import SeqLevel, _Tables, _concat_rows, _product
 
 
 class _Lookup:
-    """position of (row, id) pairs inside ragged rows"""
+    """position of (row, id) pairs inside ragged rows (first occurrence); native host code (``csrc/host_tables.hip``)"""
 
     def __init__(self, ptr, idx, nid):
-        self.ptr, self.nid = ptr, int(nid) + 1
-        row = np.repeat(np.arange(len(ptr) - 1, dtype=np.int64), np.diff(ptr))
-        key = row * self.nid + idx
-        o = np.argsort(key, kind="stable")
-        self.key = key[o]
-        self.pos = (np.arange(idx.size, dtype=np.int64) - ptr[row])[o]
+        self.ptr = np.ascontiguousarray(ptr, dtype=np.int64)
+        self.idx = np.ascontiguousarray(idx, dtype=np.int64)
+        self.nid = int(nid)
 
     def find(self, row, ids):
-        k = row * self.nid + ids
-        if self.key.size == 0:
-            return np.full(k.size, -1, dtype=np.int64)
-        p = np.minimum(np.searchsorted(self.key, k), self.key.size - 1)
-        return np.where(self.key[p] == k, self.pos[p], -1)
+        row = np.ascontiguousarray(row, dtype=np.int64)
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        pos = np.empty(row.size, dtype=np.int64)
+        _lib.check(_lib.load().elag_hip_host_lookup_find(len(self.ptr) - 1, _ptr(self.ptr), _ptr(self.idx), self.nid, row.size, _ptr(row), _ptr(ids), _ptr(pos)))
+        return pos
 
 
 def _gather_dense(M: sp.csr_matrix, row_ptr, rows, col_lookup: _Lookup, ncol):
     """Per entity the dense sub-block M[rows of the entity, columns of the entity] packed col-major (nrows_e x ncol_e)."""
-    nr = np.diff(row_ptr)
-    out_ptr = ptr_from_counts(nr * ncol)
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    ncol = np.ascontiguousarray(np.broadcast_to(ncol, (len(row_ptr) - 1,)), dtype=np.int64)
+    out_ptr = ptr_from_counts(np.diff(row_ptr) * ncol)
     out = np.zeros(int(out_ptr[-1]))
-    ent = np.repeat(np.arange(nr.size, dtype=np.int64), nr)
-    lr = np.arange(rows.size, dtype=np.int64) - row_ptr[ent]
-    q, own = expand_ranges(M.indptr[rows], np.diff(M.indptr)[rows])
-    lc = col_lookup.find(ent[own], M.indices[q].astype(np.int64))
-    ok = lc >= 0
-    e = ent[own][ok]
-    out[out_ptr[e] + lc[ok] * nr[e] + lr[own][ok]] = M.data[q][ok]
+    if M.nnz > np.iinfo(np.int32).max:
+        raise ValueError("_gather_dense: matrix too large for 32-bit CSR indices")
+    indptr, indices = np.ascontiguousarray(M.indptr, dtype=np.int32), np.ascontiguousarray(M.indices, dtype=np.int32)
+    data = np.ascontiguousarray(M.data, dtype=np.float64)
+    _lib.check(_lib.load().elag_hip_host_gather_dense(len(row_ptr) - 1, _ptr(row_ptr), _ptr(rows), _ptr(col_lookup.ptr), _ptr(col_lookup.idx), _ptr(ncol),
+                                                  M.shape[0], M.shape[1], _ptr(indptr), _ptr(indices), _ptr(data), _ptr(out_ptr), _ptr(out)))
     return out
 
 

@@ -42,18 +42,26 @@ def _amge_helpers():
 
 def _product(a_ptr, a_idx, b_ptr, b_idx, a_sgn=None, b_sgn=None):
     """Row-by-row product of two ragged tables, columns in first-touch order (``mfem::Mult``).  With signs: the signed sum
-    per column, cancelled entries dropped, reduced to the sign (``MultOrientation``, ``TopologyTable.cpp:130-139``)."""
-    expand_ranges, _first_touch_groups = _amge_helpers()
-    nrow = len(a_ptr) - 1
-    cnt = np.diff(b_ptr)[a_idx]
-    q, own = expand_ranges(b_ptr[a_idx], cnt)
-    row = np.repeat(np.arange(nrow, dtype=np.int64), np.diff(a_ptr))[own]
-    val = np.ones(q.size) if a_sgn is None else a_sgn[own] * b_sgn[q]
-    r, c, s = _first_touch_groups(row, b_idx[q].astype(np.int64), val)
-    if a_sgn is not None:
-        keep = np.abs(s) > 1e-10
-        r, c, s = r[keep], c[keep], np.sign(s[keep])
-    return ptr_from_counts(np.bincount(r, minlength=nrow)), c, s
+    per column, cancelled entries dropped, reduced to the sign (``MultOrientation``, ``TopologyTable.cpp:130-139``).  Native
+    host code (``csrc/host_tables.hip``)."""
+    from . import _lib
+    from .amge import _ptr
+    c64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+    a_ptr, a_idx, b_ptr, b_idx = c64(a_ptr), c64(a_idx), c64(b_ptr), c64(b_idx)
+    nrow, nmid = len(a_ptr) - 1, len(b_ptr) - 1
+    cap = int(np.diff(b_ptr)[a_idx].sum()) if a_idx.size else 0
+    ncol = int(b_idx.max()) + 1 if b_idx.size else 1
+    out_ptr, out_idx = np.empty(nrow + 1, dtype=np.int64), np.empty(cap, dtype=np.int64)
+    signed = a_sgn is not None
+    if signed:
+        a_sgn, b_sgn = np.ascontiguousarray(a_sgn, dtype=np.float64), np.ascontiguousarray(b_sgn, dtype=np.float64)
+        out_sgn = np.empty(cap)
+    nnz = np.zeros(1, dtype=np.int64)
+    _lib.check(_lib.load().elag_hip_host_table_product(nrow, _ptr(a_ptr), _ptr(a_idx), _ptr(a_sgn) if signed else None, nmid, _ptr(b_ptr), _ptr(b_idx),
+                                                   _ptr(b_sgn) if signed else None, ncol, _ptr(out_ptr), _ptr(out_idx),
+                                                   _ptr(out_sgn) if signed else None, _ptr(nnz)))
+    n = int(nnz[0])
+    return out_ptr, out_idx[:n].copy(), (out_sgn[:n].copy() if signed else np.ones(n))
 
 
 def _concat_rows(tables, nrow):
