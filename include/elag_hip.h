@@ -547,6 +547,16 @@ ELAG_HIP_API int elag_hip_host_lookup_find(int64_t nrow, const int64_t *ptr, con
 ELAG_HIP_API int elag_hip_host_gather_dense(int64_t n_ent, const int64_t *row_ptr, const int64_t *rows, const int64_t *col_ptr, const int64_t *col_idx,
                                         const int64_t *ncol, int64_t m_rows, int64_t m_cols, const int32_t *m_indptr, const int32_t *m_indices,
                                         const double *m_data, const int64_t *out_ptr, double *out);
+/* Triplets (exact zeros dropped) of the sparse matrix whose entity blocks are the given dense local matrices: SetSubMatrix of every
+ * entity's block of P_j, the functionals or the coarse derivative (src/amge/DeRhamSequence.cpp:1971-2010, 2540-2570).  Slot e holds
+ * (slot_rows ? slot_rows[e] : nrows_e) * ld[e] doubles, column-major or row-major; out_* need sum_e nrows_e * ncols_e entries. */
+ELAG_HIP_API int elag_hip_host_blocks_to_coo(int64_t n_ent, const int64_t *rows_ptr, const int64_t *rows_idx, const int64_t *cols_ptr,
+                                             const int64_t *cols_idx, const double *vals, const int64_t *ld, const int64_t *slot_rows, int col_major,
+                                             int64_t *out_r, int64_t *out_c, double *out_v, int64_t *out_nnz);
+/* Per entity the rows dofs[ptr[e] .. ptr[e+1]) of the row-major ndof x nT array T, packed column-major (local target matrices). */
+ELAG_HIP_API int elag_hip_host_pack_cols(int64_t n_ent, const int64_t *ptr, const int64_t *dofs, int64_t ndof, int64_t nT, const double *T, double *out);
+/* From consecutive row-major ld[e] x ld[e] slots the leading k[e] x k[e] blocks, packed (coarse entity matrices). */
+ELAG_HIP_API int elag_hip_host_take_leading(int64_t n_ent, const int64_t *ld, const int64_t *k, const double *vals, double *out);
 /* idx = concatenation of the ranges [starts[i], starts[i] + counts[i]), owner[k] = i of entry k. */
 ELAG_HIP_API int elag_hip_host_expand_ranges(int64_t n, const int64_t *starts, const int64_t *counts, int64_t total, int64_t *idx, int64_t *owner);
 

@@ -174,24 +174,22 @@ def _blocks_to_csr(rows_ptr, rows_idx, cols_ptr, cols_idx, vals, ld_cols, shape,
     ``cols_idx[cols_ptr[e]:..]``; its values are stored in ``vals`` as consecutive slots of ``nrows_e * ld_cols[e]``
     entries (col-major: column c at ``c * nrows_e``; row-major: row r at ``r * ld``...).  Exact zeros are dropped like
     mfem's ``SetSubMatrix``."""
-    nr = np.diff(rows_ptr); nc = np.diff(cols_ptr)
-    ld = np.asarray(ld_cols, dtype=np.int64)
-    slot_ptr = ptr_from_counts((nr if slot_rows is None else np.asarray(slot_rows, dtype=np.int64)) * ld)
-    cnt = nr * nc
-    ent = np.repeat(np.arange(nr.size, dtype=np.int64), cnt)
-    k = np.arange(int(cnt.sum()), dtype=np.int64) - np.repeat(ptr_from_counts(cnt)[:-1], cnt)
-    nre = nr[ent]
-    if col_major:                       # slot = nrows x ld, column c contiguous
-        c = k // np.maximum(nre, 1); r = k % np.maximum(nre, 1)
-        src = slot_ptr[ent] + c * nre + r
-    else:                               # slot = ld x ncols-per-row layout: row-major (nrows x ld)
-        nce = nc[ent]
-        r = k // np.maximum(nce, 1); c = k % np.maximum(nce, 1)
-        src = slot_ptr[ent] + r * ld[ent] + c
-    v = vals[src]
-    R = rows_idx[rows_ptr[ent] + r]; Cc = cols_idx[cols_ptr[ent] + c]
-    m = v != 0.0
-    M = sp.csr_matrix((v[m], (R[m], Cc[m])), shape=shape)
+    c64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+    rows_ptr, rows_idx, cols_ptr, cols_idx = c64(rows_ptr), c64(rows_idx), c64(cols_ptr), c64(cols_idx)
+    ld = c64(np.broadcast_to(ld_cols, (len(rows_ptr) - 1,)))
+    sr = None if slot_rows is None else c64(np.broadcast_to(slot_rows, (len(rows_ptr) - 1,)))
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    nr, nc = np.diff(rows_ptr), np.diff(cols_ptr)
+    if vals.size < int(((nr if sr is None else sr) * ld).sum()):
+        raise ValueError("_blocks_to_csr: the value array is shorter than its slots")
+    cap = int((nr * nc).sum())
+    R, Cc, v = np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.int64), np.empty(cap)
+    nnz = np.zeros(1, dtype=np.int64)
+    _lib.check(_lib.load().elag_hip_host_blocks_to_coo(len(rows_ptr) - 1, _ptr(rows_ptr), _ptr(rows_idx), _ptr(cols_ptr), _ptr(cols_idx), _ptr(vals),
+                                                       _ptr(ld), None if sr is None else _ptr(sr), 1 if col_major else 0, _ptr(R), _ptr(Cc), _ptr(v),
+                                                       _ptr(nnz)))
+    n = int(nnz[0])
+    M = sp.csr_matrix((v[:n], (R[:n], Cc[:n])), shape=shape)
     M.sort_indices()
     return M
 
@@ -417,27 +415,24 @@ def coarsen_sequence(lv: AmgeLevel, parts: list, **kw) -> list:
 def _pack_cols(T, dofs, ptr):
     """Per entity the rows ``dofs[ptr[e]:ptr[e+1]]`` of ``T`` stored col-major, entities one after the other."""
     nT = T.shape[1]
-    n = np.diff(ptr)
     if nT == 0 or dofs.size == 0:
         return np.zeros(0)
-    ent = np.repeat(np.arange(n.size, dtype=np.int64), n)
-    within = np.arange(dofs.size, dtype=np.int64) - ptr[ent]
+    ptr, dofs = np.ascontiguousarray(ptr, dtype=np.int64), np.ascontiguousarray(dofs, dtype=np.int64)
+    T = np.ascontiguousarray(T, dtype=np.float64)
     out = np.empty(dofs.size * nT)
-    base = ptr[ent] * nT + within
-    for c in range(nT):
-        out[base + c * n[ent]] = T[dofs, c]
+    _lib.check(_lib.load().elag_hip_host_pack_cols(len(ptr) - 1, _ptr(ptr), _ptr(dofs), T.shape[0], nT, _ptr(T), _ptr(out)))
     return out
 
 
 def _take_leading(vals, ld, k):
     """From consecutive row-major ``ld[e] x ld[e]`` slots keep the leading ``k[e] x k[e]`` blocks, packed."""
-    ld = np.asarray(ld, dtype=np.int64); k = np.asarray(k, dtype=np.int64)
-    slot = ptr_from_counts(ld * ld)
-    cnt = k * k
-    ent = np.repeat(np.arange(k.size, dtype=np.int64), cnt)
-    q = np.arange(int(cnt.sum()), dtype=np.int64) - np.repeat(ptr_from_counts(cnt)[:-1], cnt)
-    ke = np.maximum(k[ent], 1)
-    return vals[slot[ent] + (q // ke) * ld[ent] + q % ke]
+    ld = np.ascontiguousarray(ld, dtype=np.int64); k = np.ascontiguousarray(k, dtype=np.int64)
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    if vals.size < int((ld * ld).sum()):
+        raise ValueError("_take_leading: the value array is shorter than its slots")
+    out = np.empty(int((k * k).sum()))
+    _lib.check(_lib.load().elag_hip_host_take_leading(k.size, _ptr(ld), _ptr(k), _ptr(vals), _ptr(out)))
+    return out
 
 
 def _take_leading_rows(vals, nrows_max, ncols, nrows):

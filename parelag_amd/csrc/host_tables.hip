@@ -153,4 +153,72 @@ ELAG_HIP_API int elag_hip_host_expand_ranges(int64_t n, const int64_t *starts, c
     });
 }
 
+// Triplets of a sparse matrix whose entity blocks are dense (mfem's SetSubMatrix / AddSubMatrix of every entity's local matrix,
+// exact zeros dropped): block e couples rows_idx[rows_ptr[e]..] with cols_idx[cols_ptr[e]..]; its values sit in consecutive slots
+// of (slot_rows ? slot_rows[e] : nrows_e) * ld[e] doubles -- column-major (column c at c * nrows_e) or row-major (row r at r * ld[e]).
+// out_* need room for sum_e nrows_e * ncols_e entries.
+ELAG_HIP_API int elag_hip_host_blocks_to_coo(int64_t n_ent, const int64_t *rows_ptr, const int64_t *rows_idx, const int64_t *cols_ptr,
+                                             const int64_t *cols_idx, const double *vals, const int64_t *ld, const int64_t *slot_rows, int col_major,
+                                             int64_t *out_r, int64_t *out_c, double *out_v, int64_t *out_nnz)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(n_ent >= 0 && rows_ptr && cols_ptr && ld && out_nnz, "blocks_to_coo: null or negative argument");
+        int64_t slot = 0, n = 0;
+        for (int64_t e = 0; e < n_ent; e++) {
+            const int64_t nr = rows_ptr[e + 1] - rows_ptr[e], nc = cols_ptr[e + 1] - cols_ptr[e];
+            ELAG_REQUIRE(nr >= 0 && nc >= 0 && ld[e] >= nc, "blocks_to_coo: block %lld does not fit its slot", (long long)e);
+            const double *v = vals + slot;
+            const int64_t *R = rows_idx + rows_ptr[e], *Cc = cols_idx + cols_ptr[e];
+            if (col_major) {
+                for (int64_t c = 0; c < nc; c++)
+                    for (int64_t r = 0; r < nr; r++) {
+                        const double x = v[c * nr + r];
+                        if (x != 0.0) { out_r[n] = R[r]; out_c[n] = Cc[c]; out_v[n] = x; n++; }
+                    }
+            } else {
+                for (int64_t r = 0; r < nr; r++)
+                    for (int64_t c = 0; c < nc; c++) {
+                        const double x = v[r * ld[e] + c];
+                        if (x != 0.0) { out_r[n] = R[r]; out_c[n] = Cc[c]; out_v[n] = x; n++; }
+                    }
+            }
+            slot += (slot_rows ? slot_rows[e] : nr) * ld[e];
+        }
+        *out_nnz = n;
+    });
+}
+
+// Per entity the rows dofs[ptr[e] .. ptr[e+1]) of the row-major (ndof x nT) array T, stored column-major, entities one after
+// the other (the local target matrices of ComputeCoarseTraces / the extensions).
+ELAG_HIP_API int elag_hip_host_pack_cols(int64_t n_ent, const int64_t *ptr, const int64_t *dofs, int64_t ndof, int64_t nT, const double *T, double *out)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(n_ent >= 0 && ptr && nT >= 0 && ndof >= 0, "pack_cols: null or negative argument");
+        for (int64_t e = 0; e < n_ent; e++) {
+            const int64_t n = ptr[e + 1] - ptr[e];
+            double *blk = out + ptr[e] * nT;
+            for (int64_t i = 0; i < n; i++) {
+                const int64_t d = dofs[ptr[e] + i];
+                ELAG_REQUIRE(d >= 0 && d < ndof, "pack_cols: dof %lld outside the vector", (long long)d);
+                for (int64_t c = 0; c < nT; c++) blk[c * n + i] = T[d * nT + c];
+            }
+        }
+    });
+}
+
+// From consecutive row-major ld[e] x ld[e] slots keep the leading k[e] x k[e] blocks, packed.
+ELAG_HIP_API int elag_hip_host_take_leading(int64_t n_ent, const int64_t *ld, const int64_t *k, const double *vals, double *out)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(n_ent >= 0 && (n_ent == 0 || (ld && k)), "take_leading: null or negative argument");
+        int64_t slot = 0, w = 0;
+        for (int64_t e = 0; e < n_ent; e++) {
+            ELAG_REQUIRE(k[e] >= 0 && k[e] <= ld[e], "take_leading: block %lld larger than its slot", (long long)e);
+            for (int64_t r = 0; r < k[e]; r++)
+                for (int64_t c = 0; c < k[e]; c++) out[w++] = vals[slot + r * ld[e] + c];
+            slot += ld[e] * ld[e];
+        }
+    });
+}
+
 }  // extern "C"

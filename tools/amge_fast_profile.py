@@ -1,0 +1,13 @@
+"""cProfile of the two-form fast path (parelag_amd/amge.py) on an SPE10-size hex grid:  python tools/amge_fast_profile.py 60 220 85"""
+import cProfile, os, pstats, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from parelag_amd import amge
+from parelag_amd.amge_level import box_partition, level_from_hex
+n = tuple(int(v) for v in sys.argv[1:4])
+lv = level_from_hex(n, h=(20.0, 10.0, 2.0), kinv=np.exp(2 * np.random.default_rng(0).standard_normal(n[0] * n[1] * n[2])))
+part = box_partition(n, (2, 2, 2))
+amge.coarsen(level_from_hex((2, 2, 2)), np.zeros(8, np.int32))
+pr = cProfile.Profile(); pr.enable(); t = time.time(); amge.coarsen(lv, part); w = time.time() - t; pr.disable()
+print("wall %.3f s" % w)
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
