@@ -60,12 +60,9 @@ def coarsen_topology(lv: AmgeLevel, part: np.ndarray) -> dict:
     nAE = int(part.max()) + 1
     order = np.argsort(part, kind="stable")
     ae_ptr = ptr_from_counts(np.bincount(part, minlength=nAE))
-    nfac = np.diff(lv.ef_ptr)
-    slots, owner = expand_ranges(lv.ef_ptr[order], nfac[order])        # facet slots in agglomerate traversal order
-    row = part[order][owner]
-    r, f, s = _first_touch_groups(row, lv.ef_idx[slots], lv.ef_sgn[slots])
-    keep = np.abs(s) > 1e-10
-    r, f, s = r[keep], f[keep], np.sign(s[keep])                       # AE_fc, first-touch order
+    from .derham_level import _product                                 # native first-touch products (csrc/host_tables.hip)
+    fc_ptr, f, s = _product(ae_ptr, order, lv.ef_ptr, lv.ef_idx, np.ones(order.size), lv.ef_sgn)       # AE_fc, first-touch order
+    r = np.repeat(np.arange(nAE, dtype=np.int64), np.diff(fc_ptr))
     # per facet: adjacent agglomerates (one or two) and the sign relative to the lowest one
     o = np.lexsort((r, f))
     fs, rs, ss = f[o], r[o], s[o]
@@ -102,12 +99,11 @@ def coarsen_topology(lv: AmgeLevel, part: np.ndarray) -> dict:
     af_ptr = ptr_from_counts(np.bincount(mis_of[fid], minlength=nAF))
     af_idx = fid[o2]
     # coarse element-facet table: MultOrientation(AE_fc, fc_AF)
-    br, bc, bs = _first_touch_groups(r, mis_of[f], s * ori[f])
-    keepb = np.abs(bs) > 1e-10
-    br, bc, bs = br[keepb], bc[keepb], np.sign(bs[keepb])
+    member = mis_of >= 0
+    B_ptr, bc, bs = _product(fc_ptr, f, ptr_from_counts(member.astype(np.int64)), mis_of[member], s, ori[member])
     return dict(nAE=nAE, nAF=nAF, ae_ptr=ae_ptr, ae_idx=order.astype(np.int64),
                 af_ptr=af_ptr, af_idx=af_idx, af_sgn=ori[af_idx],
-                B_ptr=ptr_from_counts(np.bincount(br, minlength=nAE)), B_idx=bc.astype(np.int64), B_sgn=bs,
+                B_ptr=B_ptr, B_idx=bc.astype(np.int64), B_sgn=bs,
                 facet_attr=lv.facet_attr[af_idx[af_ptr[:-1]]].astype(np.int32))
 
 

@@ -10,6 +10,7 @@
 // No GPU is touched; the functions are callable before elag_hip_init.
 #include "common.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -217,6 +218,21 @@ ELAG_HIP_API int elag_hip_host_take_leading(int64_t n_ent, const int64_t *ld, co
             for (int64_t r = 0; r < k[e]; r++)
                 for (int64_t c = 0; c < k[e]; c++) out[w++] = vals[slot + r * ld[e] + c];
             slot += ld[e] * ld[e];
+        }
+    });
+}
+
+// Every row of the ragged table sorted by (key[id], id): DofAgglomeration's reorderRow, which puts the dofs interior to an
+// agglomerated entity first and those shared with entities of higher codimension behind them, each group ascending
+// (src/amge/DOFAgglomeration.cpp:33-131).  In place.
+ELAG_HIP_API int elag_hip_host_sort_rows_by_key(int64_t nrow, const int64_t *ptr, int64_t *idx, int64_t nid, const int64_t *key)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(nrow >= 0 && ptr && (nid == 0 || key), "sort_rows_by_key: null or negative argument");
+        for (int64_t r = 0; r < nrow; r++) {
+            for (int64_t k = ptr[r]; k < ptr[r + 1]; k++)
+                ELAG_REQUIRE(idx[k] >= 0 && idx[k] < nid, "sort_rows_by_key: id %lld outside 0..%lld", (long long)idx[k], (long long)nid);
+            std::sort(idx + ptr[r], idx + ptr[r + 1], [key](int64_t a, int64_t b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
         }
     });
 }

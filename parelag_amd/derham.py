@@ -185,8 +185,9 @@ def agglomerate_dofs(lv: SeqLevel, tb: _Tables, topo: dict, j: int) -> dict:
         p, d = rows[c]
         a = np.repeat(np.arange(len(p) - 1, dtype=np.int64), np.diff(p))
         if cb > c:
-            o = np.lexsort((d, sep[d], a))
-            d = d[o]
+            d = np.ascontiguousarray(d, dtype=np.int64).copy()
+            pc = np.ascontiguousarray(p, dtype=np.int64)
+            _lib.check(_lib.load().elag_hip_host_sort_rows_by_key(len(pc) - 1, _ptr(pc), _ptr(d), nd, _ptr(sep)))      # reorderRow
             rows[c] = (p, d)
             nint[c] = np.bincount(a, weights=(sep[d] == c), minlength=len(p) - 1).astype(np.int64)
         else:
