@@ -323,4 +323,43 @@ inline std::unique_ptr<Hierarchy> BuildBlockedHierarchy(const std::shared_ptr<Mf
     return H;
 }
 
+// ---- the integer tables of the coarsening -------------------------------------------------------------------------------------
+// parelag::TopologyTable (src/topology/TopologyTable.hpp): a ragged +-1 table; products keep the columns of a row in
+// first-touch order like mfem::Mult.
+struct TopologyTable {
+    std::vector<int64_t> ptr{0}, idx;
+    std::vector<double> sgn;                 // empty: a pattern (boolean) table
+    int64_t Height() const { return (int64_t)ptr.size() - 1; }
+    int64_t Width = 0;
+};
+
+// MultOrientation (TopologyTable.cpp:130-139) when both tables carry signs, MultBoolean / mfem::Mult on patterns otherwise
+inline TopologyTable Mult(const TopologyTable &A, const TopologyTable &B)
+{
+    const bool sg = !A.sgn.empty() && !B.sgn.empty();
+    int64_t cap = 0;
+    for (int64_t k : A.idx) cap += B.ptr[(size_t)k + 1] - B.ptr[(size_t)k];
+    TopologyTable C;
+    C.Width = B.Width;
+    C.ptr.assign((size_t)A.Height() + 1, 0);
+    C.idx.resize((size_t)cap);
+    if (sg) C.sgn.resize((size_t)cap);
+    int64_t nnz = 0;
+    check(elag_hip_host_table_product(A.Height(), A.ptr.data(), A.idx.data(), sg ? A.sgn.data() : nullptr, B.Height(), B.ptr.data(), B.idx.data(),
+                                      sg ? B.sgn.data() : nullptr, B.Width, C.ptr.data(), C.idx.data(), sg ? C.sgn.data() : nullptr, &nnz));
+    C.idx.resize((size_t)nnz);
+    if (sg) C.sgn.resize((size_t)nnz);
+    return C;
+}
+
+// the DenseMatrix::Rank(tol) calls of AgglomeratedTopologyCheck::computeBettiNumbersAgglomeratedEntities
+// (src/topology/AgglomeratedTopologyCheck.cpp:241-318), all local boundary operators of a codimension in one launch
+inline std::vector<int> BatchedRank(const std::vector<int> &nrows, const std::vector<int> &ncols, const std::vector<int64_t> &t_ptr,
+                                    const std::vector<int> &t_row, const std::vector<int> &t_col, const std::vector<double> &t_val, double tol = 1e-9)
+{
+    std::vector<int> rank(nrows.size(), 0);
+    check(elag_hip_batched_rank((int)nrows.size(), nrows.data(), ncols.data(), t_ptr.data(), t_row.data(), t_col.data(), t_val.data(), tol, rank.data()));
+    return rank;
+}
+
 }  // namespace elag_hip

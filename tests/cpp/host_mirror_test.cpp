@@ -170,6 +170,30 @@ int main()
         try { op->SetBlock(1, 1, upload(M)); } catch (const std::runtime_error &) { threw = true; }   // size check of SetBlock
         REQUIRE(threw);
     }
+    {
+        // two triangles (0,1,2), (1,3,2) sharing the edge (1,2): element -> edge and edge -> vertex tables with orientations;
+        // MultOrientation gives B0 B1 = 0 (every entry cancels), the pattern product lists the vertices in first-touch order
+        TopologyTable B0, B1;
+        B0.ptr = {0, 3, 6}; B0.idx = {0, 1, 2, 1, 3, 4}; B0.sgn = {1, 1, -1, -1, 1, 1}; B0.Width = 5;      // edges: 01, 12, 02, 13, 32
+        B1.ptr = {0, 2, 4, 6, 8, 10}; B1.idx = {0, 1, 1, 2, 0, 2, 1, 3, 3, 2}; B1.sgn = {-1, 1, -1, 1, -1, 1, -1, 1, -1, 1}; B1.Width = 4;
+        TopologyTable BB = Mult(B0, B1);
+        REQUIRE(BB.idx.empty() && BB.ptr[2] == 0);
+        TopologyTable P0 = B0, P1 = B1;
+        P0.sgn.clear(); P1.sgn.clear();
+        TopologyTable EV = Mult(P0, P1);
+        REQUIRE(EV.ptr[1] == 3 && EV.ptr[2] == 6);
+        const int64_t want[6] = {0, 1, 2, 1, 2, 3};
+        for (int i = 0; i < 6; i++) REQUIRE(EV.idx[(size_t)i] == want[i]);
+        // ranks of the local boundary operators: edges -> vertices of one triangle (rank 2), of both (5 x 4: rank 3), a zero block
+        std::vector<int> nr = {3, 5, 2}, ncs = {3, 4, 2};
+        std::vector<int64_t> tp = {0, 6, 16, 16};
+        std::vector<int> tr = {0, 0, 1, 1, 2, 2}, tc = {0, 1, 1, 2, 0, 2};
+        std::vector<double> tv = {-1, 1, -1, 1, -1, 1};
+        for (int e = 0; e < 5; e++)
+            for (int k = 0; k < 2; k++) { tr.push_back(e); tc.push_back((int)B1.idx[(size_t)(2 * e + k)]); tv.push_back(B1.sgn[(size_t)(2 * e + k)]); }
+        std::vector<int> rk = BatchedRank(nr, ncs, tp, tr, tc, tv);
+        REQUIRE(rk[0] == 2 && rk[1] == 3 && rk[2] == 0);
+    }
     std::printf("HOST_MIRROR_OK\n");
     return 0;
 }
