@@ -49,6 +49,8 @@ def _product(a_ptr, a_idx, b_ptr, b_idx, a_sgn=None, b_sgn=None):
     c64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
     a_ptr, a_idx, b_ptr, b_idx = c64(a_ptr), c64(a_idx), c64(b_ptr), c64(b_idx)
     nrow, nmid = len(a_ptr) - 1, len(b_ptr) - 1
+    if a_idx.size and (a_idx.min() < 0 or a_idx.max() >= nmid):
+        raise ValueError("table product: an entry of the left table is outside the right table")
     cap = int(np.diff(b_ptr)[a_idx].sum()) if a_idx.size else 0
     ncol = int(b_idx.max()) + 1 if b_idx.size else 1
     out_ptr, out_idx = np.empty(nrow + 1, dtype=np.int64), np.empty(cap, dtype=np.int64)

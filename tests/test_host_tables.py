@@ -1,0 +1,129 @@
+"""The native host tables of the coarsening (``csrc/host_tables.hip``, ``elag_hip_host_*``; no device work) against plain
+restatements of the reference's loops: ``mfem::Mult`` with first-touch column order and ``MultOrientation``
+(``src/topology/TopologyTable.cpp:130-139``), ``GetSubMatrix`` / ``SetSubMatrix`` of all entities at once, ``reorderRow``
+(``src/amge/DOFAgglomeration.cpp:33-131``); empty and ragged inputs, unsorted queries, arguments that must be refused."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from parelag_amd import _lib, amge, derham
+from parelag_amd.amge_level import ptr_from_counts
+from parelag_amd.derham_level import _product, bool_mult
+
+
+def ragged(rng, nrow, ncol, maxlen, signed=False):
+    cnt = rng.integers(0, maxlen + 1, nrow)
+    idx = np.concatenate([rng.choice(ncol, c, replace=False) for c in cnt]) if cnt.sum() else np.zeros(0, dtype=np.int64)
+    out = (ptr_from_counts(cnt), idx.astype(np.int64))
+    return out + ((rng.choice([-1.0, 1.0], idx.size),) if signed else ())
+
+
+def mult_orientation(a, b):
+    """Row loop with a dict: insertion order = first touch; cancelled sums leave the row."""
+    (ap, ai, asg), (bp, bi, bsg) = a, b
+    ptr, idx, sgn = [0], [], []
+    for r in range(len(ap) - 1):
+        acc = {}
+        for k in range(ap[r], ap[r + 1]):
+            for q in range(bp[ai[k]], bp[ai[k] + 1]):
+                acc[int(bi[q])] = acc.get(int(bi[q]), 0.0) + asg[k] * bsg[q]
+        for c, v in acc.items():
+            if abs(v) > 1e-10:
+                idx.append(c); sgn.append(np.sign(v))
+        ptr.append(len(idx))
+    return np.array(ptr), np.array(idx, dtype=np.int64), np.array(sgn)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_table_products(seed):
+    rng = np.random.default_rng(seed)
+    a, b = ragged(rng, 40, 30, 6, signed=True), ragged(rng, 30, 25, 5, signed=True)
+    p, i, s = _product(a[0], a[1], b[0], b[1], a[2], b[2])
+    rp, ri, rs = mult_orientation(a, b)
+    assert np.array_equal(p, rp) and np.array_equal(i, ri) and np.array_equal(s, rs)
+    p, i, _ = _product(a[0], a[1], b[0], b[1])
+    rp, ri = bool_mult(a[0], a[1], b[0], b[1])
+    assert np.array_equal(p, rp) and np.array_equal(i, ri)
+
+
+def test_table_product_edge_cases():
+    empty = (np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int64))
+    p, i, s = _product(*empty, *empty)
+    assert p.tolist() == [0] and i.size == 0 and s.size == 0
+    a = (np.array([0, 0, 2]), np.array([0, 1]))                       # an empty row, then a row hitting an empty row of b
+    b = (np.array([0, 0, 3]), np.array([4, 2, 4]))                    # a repeated column inside one row of b
+    p, i, _ = _product(*a, *b)
+    assert p.tolist() == [0, 0, 2] and i.tolist() == [4, 2]
+    with pytest.raises(ValueError, match="outside the right table"):
+        _product(np.array([0, 1]), np.array([5]), *b)
+    lib = _lib.load()
+    assert lib.elag_hip_host_table_product(1, None, None, None, 0, None, None, None, 0, None, None, None, None) != 0
+
+
+def test_lookup_find_sorted_and_unsorted_queries():
+    rng = np.random.default_rng(3)
+    ptr, idx = ragged(rng, 50, 200, 12)
+    L = derham._Lookup(ptr, idx, 199)
+    row = rng.integers(0, 50, 500)
+    ids = rng.integers(0, 200, 500)
+    want = np.array([next((k - ptr[r] for k in range(ptr[r], ptr[r + 1]) if idx[k] == i), -1) for r, i in zip(row, ids)])
+    assert np.array_equal(L.find(row, ids), want)                                          # unsorted rows: counting sort inside
+    o = np.argsort(row, kind="stable")
+    assert np.array_equal(L.find(row[o], ids[o]), want[o])
+    assert L.find(np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)).size == 0
+    assert derham._Lookup(np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int64), 0).find(np.zeros(0, np.int64), np.zeros(0, np.int64)).size == 0
+    with pytest.raises(_lib.ElagHipError, match="outside the table"):
+        L.find(np.array([50]), np.array([0]))
+
+
+def test_gather_dense_blocks_to_csr_roundtrip():
+    rng = np.random.default_rng(7)
+    M = sp.random(60, 45, density=0.2, random_state=5, format="csr")
+    rows_ptr, rows = ragged(rng, 12, 60, 7)
+    cols_ptr, cols = ragged(rng, 12, 45, 6)
+    ncol = np.diff(cols_ptr)
+    blocks = derham._gather_dense(M, rows_ptr, rows, derham._Lookup(cols_ptr, cols, 44), ncol)
+    off = ptr_from_counts(np.diff(rows_ptr) * ncol)
+    Md = M.toarray()
+    for e in range(12):
+        r, c = rows[rows_ptr[e]:rows_ptr[e + 1]], cols[cols_ptr[e]:cols_ptr[e + 1]]
+        assert np.array_equal(blocks[off[e]:off[e + 1]].reshape(len(c), len(r)).T, Md[np.ix_(r, c)])          # column-major
+    # the blocks scattered back: entries covered by several blocks add up (AddSubMatrix), exact zeros are dropped
+    back = amge._blocks_to_csr(rows_ptr, rows, cols_ptr, cols, blocks, ncol, M.shape, col_major=True)
+    ref = np.zeros(M.shape)
+    for e in range(12):
+        r, c = rows[rows_ptr[e]:rows_ptr[e + 1]], cols[cols_ptr[e]:cols_ptr[e + 1]]
+        ref[np.ix_(r, c)] += Md[np.ix_(r, c)]
+    assert np.array_equal(back.toarray(), ref) and back.nnz == np.count_nonzero(ref)
+    # row-major slots with a leading dimension larger than the block and fewer rows used than stored
+    ld = ncol + 2
+    slot_rows = np.diff(rows_ptr) + 1
+    vals = np.zeros(int((slot_rows * ld).sum()))
+    so = ptr_from_counts(slot_rows * ld)
+    for e in range(12):
+        r, c = rows[rows_ptr[e]:rows_ptr[e + 1]], cols[cols_ptr[e]:cols_ptr[e + 1]]
+        blk = np.zeros((slot_rows[e], ld[e])); blk[:len(r), :len(c)] = Md[np.ix_(r, c)]
+        vals[so[e]:so[e + 1]] = blk.ravel()
+    back2 = amge._blocks_to_csr(rows_ptr, rows, cols_ptr, cols, vals, ld, M.shape, col_major=False, slot_rows=slot_rows)
+    assert np.array_equal(back2.toarray(), ref)
+    with pytest.raises(ValueError, match="shorter than its slots"):
+        amge._blocks_to_csr(rows_ptr, rows, cols_ptr, cols, vals[:-1], ld, M.shape, col_major=False, slot_rows=slot_rows)
+
+
+def test_small_helpers():
+    idx, own = amge.expand_ranges(np.array([5, 0, 9]), np.array([2, 0, 3]))
+    assert idx.tolist() == [5, 6, 9, 10, 11] and own.tolist() == [0, 0, 2, 2, 2]
+    idx, own = amge.expand_ranges(np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))
+    assert idx.size == 0 and own.size == 0
+    T = np.arange(12.0).reshape(6, 2)
+    out = amge._pack_cols(T, np.array([4, 1, 5, 0]), np.array([0, 3, 4]))
+    assert out.tolist() == [8, 2, 10, 9, 3, 11, 0, 1]                                    # entity 0: rows 4,1,5 column-major; entity 1: row 0
+    vals = np.arange(9.0 + 4.0)
+    assert amge._take_leading(vals, np.array([3, 2]), np.array([2, 1])).tolist() == [0, 1, 3, 4, 9]
+    with pytest.raises(_lib.ElagHipError, match="larger than its slot"):
+        amge._take_leading(vals, np.array([3, 2]), np.array([4, 1]))
+    # reorderRow: every row by (key, id)
+    ptr, idx = np.array([0, 4, 4, 7]), np.array([9, 2, 7, 4, 1, 8, 3])
+    key = np.array([0, 1, 0, 0, 1, 0, 0, 0, 0, 1])
+    _lib.check(_lib.load().elag_hip_host_sort_rows_by_key(3, amge._ptr(ptr), amge._ptr(idx), 10, amge._ptr(key)))
+    assert idx.tolist() == [2, 7, 4, 9, 3, 8, 1]
