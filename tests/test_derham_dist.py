@@ -57,7 +57,7 @@ def same_as_single_rank(lv, merged, single, tol):
 
 
 CASES = {"hex_blocks_2": ("hex", 2, None), "hex_blocks_3": ("hex", 3, None), "hex_checkerboard": ("hex", 2, "checker"),
-         "tets_hetero_3": ("tet", 3, None)}
+         "tets_hetero_3": ("tet", 3, None), "coarse_level_2": ("coarse", 2, None)}
 
 
 def make(case):
@@ -65,6 +65,12 @@ def make(case):
     if kind == "hex":
         n = (4, 4, 4)
         lv, part = seq_level_from_hex(n, h=(0.25, 0.5, 1.0), jstart=0), box_partition(n, (2, 2, 2)).astype(np.int64)
+    elif kind == "coarse":
+        # an algebraic level (null-space dofs, RangeT bubbles, several dofs per coarse entity) coarsened again: 27 agglomerates of
+        # 48 heterogeneous tets -> 2 x 1 x 1 slabs ... here 3 slabs of 9 agglomerates
+        lv0, part0 = kuhn_boxes(n=6)
+        lv = od.coarsen(lv0, part0)["coarse"]
+        part = (np.arange(27) // 9).astype(np.int64)
     else:
         lv, part = kuhn_boxes()
     owner = None if own is None else (np.arange(int(part.max()) + 1) * 7 // 3) % nranks

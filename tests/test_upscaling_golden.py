@@ -249,3 +249,23 @@ def test_three_level_hdiv_errors_through_the_device_solver_stack():
         de = D[0] @ e
         out.append(("%.4e" % np.sqrt(e @ (M[0] @ e)), "%.4e" % np.sqrt(de @ (W[0] @ de))))
     assert tuple(zip(*out)) == GOLDEN_2FORM
+
+
+@pytest.mark.gpu
+def test_geometric_variant_with_checked_topology_reproduces_the_form1_errors():
+    """``UpscalingGeneralForm --form 1 --nref_parallel 1 --geometric`` (``testsuite/CMakeLists.txt:176-183``): the partition comes from
+    ``GeometricBoxPartitioner`` (4 parts asked, 8 boxes made) and ``CoarsenLocalPartitioning`` runs with ``check_topology = true``
+    (``UpscalingGeneralForm.cpp:386-388``); the boxes are balls with disc facets, so nothing is de-agglomerated and the same two
+    numbers are printed."""
+    from parelag_amd.partitioning import GeometricBoxPartitioner
+    lv, _part = fine_level()
+    V, ev = grid_mesh(N)
+    part = GeometricBoxPartitioner().doPartition(V, ev, 4)
+    fine = derham.DeRhamSequence(lv)
+    fine.SetjformStart(0)
+    fine.SetTargets(lv.T)
+    fine.SetSVDTol(1e-9)
+    coarse = fine.Coarsen(part, check_topology=True)
+    assert fine.TopologyMessages == [] and coarse.level.n[0] == 8
+    l2, energy = upscaling_errors(1, fine, coarse, fine.GetP(1).tocsr())
+    assert ("%.4e" % l2, "%.4e" % energy) == GOLDEN[1]
