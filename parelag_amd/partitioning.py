@@ -37,3 +37,67 @@ class GeometricBoxPartitioner:
 
     def GetPartitionSizes(self) -> np.ndarray:
         return self.partition_sizes_
+
+
+# ---- logical (Cartesian / material) partitioning -------------------------------------------------------------------------------
+
+class CartesianIJK:
+    """``CartesianIJK`` (``src/partitioning/CartesianPartitioner.hpp:41-103``): logical (i, j, k) of the elements of a structured
+    grid; only the XYZ ordering exists there (element ``k N0 N1 + j N0 + i``).  ``order="generator"`` gives the same table for
+    the numbering of ``seq_level_from_hex`` (element ``(i N1 + j) N2 + k``)."""
+
+    @staticmethod
+    def SetupCartesianIJK(N, order: str = "XYZ") -> np.ndarray:
+        N = [int(v) for v in N]
+        e = np.arange(int(np.prod(N)), dtype=np.int64)
+        if order == "XYZ":
+            cols = [e % N[0]] + ([(e // N[0]) % N[1]] if len(N) > 1 else []) + ([e // (N[0] * N[1])] if len(N) > 2 else [])
+        elif order == "generator":
+            cols = [e // int(np.prod(N[1:]))] + ([(e // N[2]) % N[1], e % N[2]] if len(N) == 3 else [e % N[1]] if len(N) == 2 else [])
+        else:
+            raise ValueError("CartesianIJK only works for XYZ ordering")
+        return np.stack(cols, 1)
+
+    @staticmethod
+    def SetupCartesianIJKMaterialId(N, material_id, order: str = "XYZ") -> np.ndarray:
+        ijk = CartesianIJK.SetupCartesianIJK(N, order)
+        return np.concatenate([ijk, np.asarray(material_id, dtype=np.int64).reshape(-1, 1)], 1)
+
+
+class CoarsenLogicalCartesianOperator:
+    """``operator()`` of ``CoarsenLogicalCartesianOperator[MaterialId]`` (``CartesianPartitioner.hpp:117-152``): the logical
+    indices divided by the coarsening ratio, further columns (the material id) carried over."""
+
+    def __init__(self, coarseningratio):
+        self.ratio = np.asarray(coarseningratio, dtype=np.int64)
+
+    def __call__(self, fine: np.ndarray) -> np.ndarray:
+        fine = np.asarray(fine, dtype=np.int64)
+        out = fine.copy()
+        out[..., :self.ratio.size] //= self.ratio
+        return out
+
+
+CoarsenLogicalCartesianOperatorMaterialId = CoarsenLogicalCartesianOperator
+
+
+class LogicalPartitioner:
+    """``LogicalPartitioner`` (``src/partitioning/LogicalPartitioner.hpp:41-135``): a partition is a connected set of elements with
+    the same coarse logical value, partitions numbered in the order of their first element."""
+
+    def Partition(self, elem_elem, fine_logical: np.ndarray, coarsening_logical) -> np.ndarray:
+        from . import linalg
+        coarse = np.asarray(coarsening_logical(fine_logical))
+        _u, label = np.unique(coarse.reshape(coarse.shape[0], -1), axis=0, return_inverse=True)
+        _n, comp = linalg.connected_components(label.reshape(-1), elem_elem)            # connected pieces of equal labels
+        _u, first, inv = np.unique(comp, return_index=True, return_inverse=True)
+        rank = np.empty(first.size, dtype=np.int64)
+        rank[np.argsort(first, kind="stable")] = np.arange(first.size)                 # the stack search meets them in element order
+        return rank[inv.reshape(-1)]
+
+    def ComputeCoarseLogical(self, coarsen_map, AE_element, fine_logical: np.ndarray) -> np.ndarray:
+        """The coarse logical value of an agglomerate = that of its first element (``:108-129``)."""
+        ptr, idx = AE_element[0], AE_element[1]
+        if np.any(np.diff(ptr) == 0):
+            raise ValueError("ComputeCoarseLogical: empty agglomerate")
+        return np.asarray(coarsen_map(np.asarray(fine_logical)[idx[ptr[:-1]]]))
