@@ -1,7 +1,8 @@
 """CPU restatement of the whole ``DeRhamSequence::Coarsen`` (all forms ``jformStart_ .. 3`` of a 3-D sequence) -- TEST
 INFRASTRUCTURE ONLY (``tests/`` may import it; the product never does).  **Pinned by the reference's own known answers**: the
 upscaling errors ctest greps from ``testsuite/UpscalingGeneralForm.cpp --form 0|1|2 --nref_parallel 1``
-(``testsuite/CMakeLists.txt:97-178``; all three reproduced to the printed digits by ``tests/test_upscaling_golden.py``) and the
+(``testsuite/CMakeLists.txt:97-178``; all three reproduced to the printed digits by ``tests/test_upscaling_golden.py``), of
+``examples/Upscaling2FormAMGe`` and ``examples/LogicalPartitionerDemo`` (three and four levels; ``tests/test_logical_partitioner_golden.py``) and the
 diagnostics of ``testsuite/twentyseven.cpp`` (``:35-92``; ``tests/test_topology_check.py``); further by the reference's invariants
 (``DeRhamSequence::CheckInvariants``, ``src/amge/DeRhamSequence.cpp:694-970``) in ``tests/test_derham_oracle.py``.  The reference
 itself cannot be built here (MFEM, hypre, METIS, SuiteSparse absent), so there is no ``oracle/_ref``.

@@ -121,3 +121,78 @@ def test_device_coarsening_reproduces_the_reference_logical_partitioner_errors()
     levels, Ps, msgs = four_levels(coarsen_level)
     check_structure(levels, msgs)
     assert printed_errors(levels, Ps) == GOLDEN
+
+
+# ---- examples/EmbeddedMeshPartitionerDemo.cpp --mesh none --par_ref_levels 2 ----------------------------------------------------
+
+import re
+
+from parelag_amd.amge_level import box_partition
+
+EMBEDDED = ("u l2-like errors: 9.361[0-9]e-03 2.554[0-9]e-03 ", "u energy-like errors: 8.60[0-9]*e-02 4.292[0-9]e-02")   # examples/CMakeLists.txt:122-127
+
+
+def embedded_mesh_lines(coarsen_level):
+    """``EmbeddedMeshPartitionerDemo.cpp:148-160, 264-300, 385-400, 452-510``: 2 x 2 x 2 hexahedra refined twice, the lower half with its
+    own material id; agglomerates = connected cells with the same (derefinement partition, material) -- ``LogicalPartitioner`` with
+    ``CoarsenMFEMMaterialId``; ``check_topology = 1``; the 0-form problem with no load and the essential value 1 on the whole
+    boundary, carried to the coarse levels by the cochain projector (``GetPi(form)->GetProjectorMatrix().Mult(ess_data)``)."""
+    n = (8, 8, 8)
+    lv = seq_level_from_hex(n, h=(0.125,) * 3, jstart=0)
+    idx = np.arange(512)
+    mat = 1 + (idx % 8 < 4)                                        # the generator numbers (x 8 + y) 8 + z: lower half in z
+    identity = lambda logical: logical
+    partitioner = LogicalPartitioner()
+    levels, Ps, Pis, cur, m = [lv], [], [], lv, n
+    for _l in range(2):
+        logical = np.stack([box_partition(m, (2, 2, 2)).astype(np.int64), mat], 1)          # (MFEM_partition, materialId)
+        part = partitioner.Partition(element_element(cur), logical, identity)
+        assert part.max() + 1 == logical[:, 0].max() + 1          # the derefinement agglomerates do not straddle the interface
+        P, Pi, cur, topo = coarsen_level(cur, part)
+        assert topo["messages"] == []
+        mat = partitioner.ComputeCoarseLogical(identity, topo["A"][0], logical)[:, 1]
+        m = tuple(v // 2 for v in m)
+        Ps.append(P.tocsr()); Pis.append(Pi); levels.append(cur)
+    ess = [derham.DeRhamSequence(L)._marker(0, np.ones(6, dtype=np.int64)) for L in levels]
+    g = [ess[0].astype(np.float64)]                                # lift: ProjectBdrCoefficient(1) on every boundary attribute
+    for Pi in Pis:
+        g.append(Pi @ g[-1])
+    M = [L.mass(0).tocsr() for L in levels]
+    W = [L.mass(1).tocsr() for L in levels]
+    D = [L.D[0].tocsr() for L in levels]
+    sol = []
+    for k, L in enumerate(levels):
+        A = (M[k] + D[k].T @ W[k] @ D[k]).tocsr()
+        free, fix = np.nonzero(~ess[k])[0], np.nonzero(ess[k])[0]
+        u = np.zeros(L.ndof(0))
+        u[fix] = g[k][fix]                                         # EliminateRowCol(mm, ess_data(mm), rhs)
+        u[free] = spl.spsolve(A[free][:, free].tocsc(), -(A[free][:, fix] @ g[k][fix]))
+        sol.append(u)
+    l2, en = [], []
+    for k in (2, 1):
+        u = sol[k]
+        for j in range(k, 0, -1):
+            u = Ps[j - 1] @ u
+        e = u - sol[0]
+        de = D[0] @ e
+        l2.append("%.4e" % np.sqrt(e @ (M[0] @ e))); en.append("%.4e" % np.sqrt(de @ (W[0] @ de)))
+    return "u l2-like errors: " + " ".join(l2) + " ", "u energy-like errors: " + " ".join(en) + " "
+
+
+def test_oracle_reproduces_the_embedded_mesh_demo_errors():
+    def coarsen_level(lv, part):
+        topo = od.coarsen_topology(lv, part, check=True)
+        res = od.coarsen(lv, part, topo=topo)
+        return res["P"][0], res["Pi"][0], res["coarse"], topo
+    lines = embedded_mesh_lines(coarsen_level)
+    assert re.match(EMBEDDED[0], lines[0]) and re.match(EMBEDDED[1], lines[1]), lines
+
+
+@pytest.mark.gpu
+def test_device_coarsening_reproduces_the_embedded_mesh_demo_errors():
+    def coarsen_level(lv, part):
+        s = derham.DeRhamSequence(lv)
+        c = s.Coarsen(part, check_topology=True)
+        return s.GetP(0), s.GetPi(0), c.level, dict(A=s._res["topo"]["A"], messages=s.TopologyMessages)
+    lines = embedded_mesh_lines(coarsen_level)
+    assert re.match(EMBEDDED[0], lines[0]) and re.match(EMBEDDED[1], lines[1]), lines
