@@ -158,3 +158,26 @@ def test_rank_pieces_reproduce_the_single_rank_coarsening_on_device(case):
     merged["Pi"] = {j: derham.projector(single, j) for j in range(4)}
     inv = invariants(lv, merged, Pi=merged["Pi"])
     assert max(inv.values()) < 1e-9, inv
+
+
+def _two_rank_form1_errors(coarsen_fn):
+    """``par_form1_np2`` (``testsuite/CMakeLists.txt:127-133``): ``UpscalingGeneralForm --form 1 --nref_parallel 1`` on two ranks must
+    print the serial numbers."""
+    from tests import test_upscaling_golden as ug
+    lv, part = ug.fine_level()
+    topo, pieces = in_process(lv, part, 2, None, coarsen_fn)
+    merged = dd.merge_pieces(lv, topo, pieces)
+    fine, coarse = derham.DeRhamSequence(lv), derham.DeRhamSequence(merged["coarse"])
+    l2, energy = ug.upscaling_errors(1, fine, coarse, merged["P"][1].tocsr())
+    return ("%.4e" % l2, "%.4e" % energy), ug.GOLDEN[1]
+
+
+def test_two_ranks_print_the_serial_upscaling_errors_oracle_numerics():
+    got, want = _two_rank_form1_errors(od.coarsen)
+    assert got == want
+
+
+@pytest.mark.gpu
+def test_two_ranks_print_the_serial_upscaling_errors_on_device():
+    got, want = _two_rank_form1_errors(derham.coarsen)
+    assert got == want
