@@ -157,14 +157,26 @@ def coarsen_rank(lv: SeqLevel, part: np.ndarray, rank: int, nranks: int, owner: 
     topo = derham.coarsen_topology(lv, part) if topo is None else topo
     owner = agglomerate_owner(topo["n"][0], nranks) if owner is None else np.asarray(owner)
     mine = np.nonzero(owner == rank)[0]
-    R = restrict_level(lv, topo, mine)
-    res = coarsen_fn(R.level, None, topo=R.topo, **kw)
     js = lv.jstart
-    cl = res["coarse"]
-    # ---- global numbering of the coarse dofs: counts per coarse entity, exchanged ----
     keys = [(j, c) for j in range(js, 4) for c in range(lv.cb(j) + 1)]
     offs = np.concatenate([[0], np.cumsum([topo["n"][c] for _j, c in keys])])
     flat = np.zeros(int(offs[-1]), dtype=np.int64)
+    if mine.size == 0:
+        # a rank without agglomerates (more ranks than agglomerates on a coarse level) still takes part in the exchange
+        glob = exchange(flat)
+        counts = {key: glob[offs[k]:offs[k + 1]] for k, key in enumerate(keys)}
+        nco = {j: int(sum(counts[(j, c)].sum() for c in range(lv.cb(j) + 1))) for j in range(js, 4)}
+        e64 = np.zeros(0, dtype=np.int64)
+        return RankPiece(rank=rank, agglomerates=mine, fine_dofs=[None if j < js else e64 for j in range(4)],
+                         coarse_dofs=[None if j < js else e64 for j in range(4)],
+                         P=[None if j < js else sp.csr_matrix((0, nco[j])) for j in range(4)],
+                         D=[None if j < js else sp.csr_matrix((0, nco[j])) for j in range(3)],
+                         T=[None if j < js else np.zeros((0, lv.T[j].shape[1])) for j in range(4)], const3=np.zeros(0), csel=[e64] * 4,
+                         counts=counts, blocks={key: (np.zeros(1, dtype=np.int64), np.zeros(0)) for key in keys}, n_null={}, local={})
+    R = restrict_level(lv, topo, mine)
+    res = coarsen_fn(R.level, None, topo=R.topo, **kw)
+    cl = res["coarse"]
+    # ---- global numbering of the coarse dofs: counts per coarse entity, exchanged ----
     for k, (j, c) in enumerate(keys):
         flat[offs[k] + R.csel[c]] = np.diff(cl.idof[j][c])
     glob = exchange(flat)

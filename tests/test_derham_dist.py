@@ -88,6 +88,15 @@ def test_rank_pieces_reproduce_the_single_rank_coarsening_oracle_numerics(case):
     same_as_single_rank(lv, merged, od.coarsen(lv, part), tol=1e-14)
 
 
+def test_a_rank_without_agglomerates_takes_part_and_contributes_nothing():
+    lv, part, _n, _o = make("hex_blocks_2")
+    owner = np.zeros(8, dtype=np.int64)
+    owner[4:] = 2                                                    # rank 1 of 3 owns nothing
+    topo, pieces = in_process(lv, part, 3, owner, od.coarsen)
+    assert pieces[1].agglomerates.size == 0 and pieces[1].P[2].shape == (0, pieces[0].P[2].shape[1])
+    same_as_single_rank(lv, dd.merge_pieces(lv, topo, pieces, atol=1e-14), od.coarsen(lv, part), tol=1e-14)
+
+
 def test_restriction_keeps_the_sequence_exact():
     lv, part, _n, _o = make("tets_hetero_3")
     topo = derham.coarsen_topology(lv, part)
