@@ -33,19 +33,6 @@ def expand_ranges(starts, counts):
     return idx, owner
 
 
-def _first_touch_groups(row, col, val):
-    """Gustavson product rows: entries (row, col, val) listed in traversal order (rows ascending) are summed per
-    (row, col); within a row the columns keep the order of their first appearance (``mfem::Mult`` as used by
-    ``MultOrientation``, ``src/topology/TopologyTable.cpp:130-139``).  Returns (row, col, sum) in that order."""
-    ncol = int(col.max()) + 1 if col.size else 1
-    key = row * ncol + col
-    uk, first, inv = np.unique(key, return_index=True, return_inverse=True)
-    s = np.bincount(inv, weights=val, minlength=uk.size)
-    r = uk // ncol
-    order = np.lexsort((first, r))
-    return r[order], (uk % ncol)[order], s[order]
-
-
 # ---- integer tables --------------------------------------------------------------------------------------------------------
 
 def coarsen_topology(lv: AmgeLevel, part: np.ndarray) -> dict:

@@ -35,9 +35,9 @@ def bool_mult(a_ptr, a_idx, b_ptr, b_idx):
     return np.array(out_ptr, dtype=np.int64), np.array(out_idx, dtype=np.int64)
 
 
-def _amge_helpers():
+def _expand_ranges(starts, counts):
     from . import amge
-    return amge.expand_ranges, amge._first_touch_groups
+    return amge.expand_ranges(starts, counts)
 
 
 def _product(a_ptr, a_idx, b_ptr, b_idx, a_sgn=None, b_sgn=None):
@@ -68,7 +68,7 @@ def _product(a_ptr, a_idx, b_ptr, b_idx, a_sgn=None, b_sgn=None):
 
 def _concat_rows(tables, nrow):
     """Row-wise concatenation of ragged tables [(ptr, idx), ...] in the given order."""
-    expand_ranges, _ = _amge_helpers()
+    expand_ranges = _expand_ranges
     cnts = [np.diff(p) for p, _ in tables]
     ptr = ptr_from_counts(sum(cnts))
     out = np.empty(int(ptr[-1]), dtype=np.int64)
@@ -102,7 +102,7 @@ class _Tables:
     def edof(self, j, c):
         """(ptr, idx) of ``entity_dof[c]`` of form j: peaks', ridges', facets' dofs in connectivity order, then interior."""
         if (j, c) not in self._edof:
-            expand_ranges, _ = _amge_helpers()
+            expand_ranges = _expand_ranges
             lv = self.lv
             cb = lv.cb(j)
             tabs = []
