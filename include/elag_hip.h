@@ -557,6 +557,11 @@ ELAG_HIP_API int elag_hip_host_blocks_to_coo(int64_t n_ent, const int64_t *rows_
 ELAG_HIP_API int elag_hip_host_pack_cols(int64_t n_ent, const int64_t *ptr, const int64_t *dofs, int64_t ndof, int64_t nT, const double *T, double *out);
 /* From consecutive row-major ld[e] x ld[e] slots the leading k[e] x k[e] blocks, packed (coarse entity matrices). */
 ELAG_HIP_API int elag_hip_host_take_leading(int64_t n_ent, const int64_t *ld, const int64_t *k, const double *vals, double *out);
+/* findMinimalIntersectionSets (src/structures/minimalIntersectionSet.cpp:43-132) of Z = AE_fc^T AE_fc (+ the boundary-attribute term for
+ * facets, src/topology/Topology.cpp:757-765) from the adjacency signatures of the sub-entities, without forming Z: mis[e] = set of
+ * sub-entity e (-1: on no agglomerate boundary), sets numbered by their lowest member, ori[e] = orientation relative to it. */
+ELAG_HIP_API int elag_hip_host_minimal_intersection_sets(int64_t nrow, const int64_t *fp, const int64_t *fi, const double *fs, int64_t nsub,
+                                                         const int32_t *attr, int64_t *mis, double *ori, int64_t *n_sets);
 /* Every row of (ptr, idx) sorted in place by (key[id], id): DofAgglomeration's reorderRow (src/amge/DOFAgglomeration.cpp:33-131). */
 ELAG_HIP_API int elag_hip_host_sort_rows_by_key(int64_t nrow, const int64_t *ptr, int64_t *idx, int64_t nid, const int64_t *key);
 /* idx = concatenation of the ranges [starts[i], starts[i] + counts[i]), owner[k] = i of entry k. */

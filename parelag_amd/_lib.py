@@ -158,6 +158,7 @@ _SIGNATURES = {
     "elag_hip_host_pack_cols": [_i64, _p, _p, _i64, _i64, _p, _p],
     "elag_hip_host_take_leading": [_i64, _p, _p, _p, _p],
     "elag_hip_host_sort_rows_by_key": [_i64, _p, _p, _i64, _p],
+    "elag_hip_host_minimal_intersection_sets": [_i64, _p, _p, _p, _i64, _p, _p, _p, _p],
     "elag_hip_coarsen_traces": [_p, _p, _dp],
     "elag_hip_coarsen_extension": [_p, _p, _dp],
     "elag_hip_time_kernel": [_p, _p, _i, _i, _p, _p, _dp],

@@ -237,4 +237,71 @@ ELAG_HIP_API int elag_hip_host_sort_rows_by_key(int64_t nrow, const int64_t *ptr
     });
 }
 
+// findMinimalIntersectionSets (src/structures/minimalIntersectionSet.cpp:43-132) on Z = AE_fc^T AE_fc (+ the boundary-attribute
+// term for facets, Topology.cpp:757-765) without forming Z: two sub-entities on agglomerate boundaries belong to the same set iff
+// they have the same adjacency signature -- the same agglomerates with the same signs relative to the first one (absolute signs
+// and the same attribute for boundary facets with an attribute, whose term in Z cannot change sign).  Sets are numbered by their
+// lowest member and oriented like it.  (fp, fi, fs): AE_fc, rows ascending; mis[e] = set of sub-entity e or -1; ori[e] = +-1 or 0.
+ELAG_HIP_API int elag_hip_host_minimal_intersection_sets(int64_t nrow, const int64_t *fp, const int64_t *fi, const double *fs, int64_t nsub,
+                                                         const int32_t *attr, int64_t *mis, double *ori, int64_t *n_sets)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(nrow >= 0 && nsub >= 0 && fp && n_sets && (nsub == 0 || (mis && ori)), "minimal_intersection_sets: null or negative argument");
+        const int64_t nnz = fp[nrow];
+        std::vector<int64_t> tp((size_t)nsub + 1, 0);
+        for (int64_t q = 0; q < nnz; q++) {
+            ELAG_REQUIRE(fi[q] >= 0 && fi[q] < nsub, "minimal_intersection_sets: sub-entity %lld outside 0..%lld", (long long)fi[q], (long long)nsub);
+            tp[(size_t)fi[q] + 1]++;
+        }
+        for (int64_t e = 0; e < nsub; e++) tp[(size_t)e + 1] += tp[(size_t)e];
+        std::vector<int64_t> ta((size_t)nnz), fill(tp.begin(), tp.end() - 1);
+        std::vector<double> ts((size_t)nnz);
+        for (int64_t a = 0; a < nrow; a++)                       // rows ascending: every transposed row comes out ascending
+            for (int64_t q = fp[a]; q < fp[a + 1]; q++) {
+                const int64_t w = fill[(size_t)fi[q]]++;
+                ta[(size_t)w] = a;
+                ts[(size_t)w] = fs[q];
+            }
+        auto same = [&](int64_t e, int64_t r) {
+            const int64_t n = tp[(size_t)e + 1] - tp[(size_t)e];
+            if (n != tp[(size_t)r + 1] - tp[(size_t)r]) return false;
+            const int ae = attr ? attr[e] : 0, ar = attr ? attr[r] : 0;
+            if (ae != ar) return false;
+            const double se = ae > 0 ? 1.0 : ts[(size_t)tp[(size_t)e]], sr = ar > 0 ? 1.0 : ts[(size_t)tp[(size_t)r]];
+            for (int64_t k = 0; k < n; k++)
+                if (ta[(size_t)(tp[(size_t)e] + k)] != ta[(size_t)(tp[(size_t)r] + k)] ||
+                    ts[(size_t)(tp[(size_t)e] + k)] * se != ts[(size_t)(tp[(size_t)r] + k)] * sr)
+                    return false;
+            return true;
+        };
+        // open-addressing table of set representatives keyed by a hash of the signature
+        size_t cap = 16;
+        while (cap < (size_t)nsub * 2 + 16) cap <<= 1;
+        std::vector<int64_t> slot(cap, -1), rep;
+        int64_t nset = 0;
+        for (int64_t e = 0; e < nsub; e++) {
+            const int64_t n = tp[(size_t)e + 1] - tp[(size_t)e];
+            if (n == 0) { mis[e] = -1; ori[e] = 0.0; continue; }
+            const int ae = attr ? attr[e] : 0;
+            const double se = ae > 0 ? 1.0 : ts[(size_t)tp[(size_t)e]];
+            uint64_t h = 1469598103934665603ull ^ (uint64_t)ae;
+            for (int64_t k = 0; k < n; k++) {
+                const uint64_t v = (uint64_t)ta[(size_t)(tp[(size_t)e] + k)] * 2u + (ts[(size_t)(tp[(size_t)e] + k)] * se > 0 ? 1u : 0u);
+                h = (h ^ v) * 1099511628211ull;
+                h ^= h >> 29;
+            }
+            size_t p = (size_t)h & (cap - 1);
+            int64_t g = -1;
+            while (slot[p] >= 0) {
+                if (same(e, rep[(size_t)slot[p]])) { g = slot[p]; break; }
+                p = (p + 1) & (cap - 1);
+            }
+            if (g < 0) { g = nset++; slot[p] = g; rep.push_back(e); }            // e ascends: the representative is the lowest member
+            mis[e] = g;
+            ori[e] = ae > 0 ? 1.0 : se * ts[(size_t)tp[(size_t)rep[(size_t)g]]];
+        }
+        *n_sets = nset;
+    });
+}
+
 }  // extern "C"

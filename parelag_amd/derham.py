@@ -93,60 +93,19 @@ def coarsen_topology(lv: SeqLevel, part: np.ndarray, check: bool = False) -> dic
         ap, ai, asg = A[c]
         fp, fi, fs = _product(ap, ai, lv.B[c][0], lv.B[c][1], asg, lv.B[c][2])          # AE_fc
         nsub = lv.n[c + 1]
-        row = np.repeat(np.arange(len(fp) - 1, dtype=np.int64), np.diff(fp))
-        # adjacency signature of every sub-entity on an agglomerate boundary: its agglomerates (ascending) with the signs
-        # relative to the first one -- or the absolute signs and the attribute for boundary facets with an attribute, whose
-        # term in Z cannot change sign.  Equal signatures <=> Z_ii = Z_jj = |Z_ij|, without forming Z (which couples all the
-        # sub-entities of an agglomerate with each other: 10^8 entries on a 10^6-cell mesh).
-        o = np.lexsort((row, fi))
-        es, ea, eg = fi[o], row[o], fs[o]
-        firstm = np.r_[True, es[1:] != es[:-1]] if es.size else np.zeros(0, bool)
-        start = np.nonzero(firstm)[0]
-        mem = es[start]
-        kk = np.diff(np.r_[start, es.size])
-        ent = np.repeat(np.arange(mem.size, dtype=np.int64), kk)
-        pos_in = np.arange(es.size, dtype=np.int64) - start[ent]
-        attr_m = lv.facet_attr[mem].astype(np.int64) if c == 0 else np.zeros(mem.size, dtype=np.int64)
-        s_first = eg[start]
-        rsg = np.where(attr_m[ent] > 0, eg, eg * s_first[ent])
-        code = ((ea * 4 + (rsg + 1).astype(np.int64)) * 64 + np.minimum(pos_in, 63)).astype(np.uint64)
-        with np.errstate(over="ignore"):
-            def mix(v, m1, m2):
-                v = v * np.uint64(m1)
-                v ^= v >> np.uint64(29)
-                v = v * np.uint64(m2)
-                v ^= v >> np.uint64(32)
-                return v
-            h1 = np.add.reduceat(mix(code, 0x9E3779B97F4A7C15, 0xBF58476D1CE4E5B9), start) if es.size else np.zeros(0, np.uint64)
-            h2 = np.add.reduceat(mix(code + np.uint64(0x632BE59BD9B4E019), 0x94D049BB133111EB, 0xD6E8FEB86659FD93), start) if es.size else np.zeros(0, np.uint64)
-        key3 = (kk * 64 + attr_m).astype(np.uint64)
-        ko = np.lexsort((key3, h2, h1))
-        same = (h1[ko][1:] == h1[ko][:-1]) & (h2[ko][1:] == h2[ko][:-1]) & (key3[ko][1:] == key3[ko][:-1])
-        grp_sorted = np.r_[0, np.cumsum(~same)] if ko.size else np.zeros(0, np.int64)
-        grp = np.empty(mem.size, dtype=np.int64)
-        grp[ko] = grp_sorted
-        ngrp = int(grp_sorted[-1]) + 1 if ko.size else 0
-        lowest = np.full(ngrp, np.iinfo(np.int64).max)
-        np.minimum.at(lowest, grp, mem)                                         # mem ascends, but the groups are hash-ordered
-        rank = np.empty(ngrp, dtype=np.int64)
-        rank[np.argsort(lowest)] = np.arange(ngrp)
-        mis = np.full(nsub, -1, dtype=np.int64)
-        mis[mem] = rank[grp]
-        low_of_set = np.empty(ngrp, dtype=np.int64)
-        low_of_set[rank] = lowest
-        # the hashes only propose the classes: every member's signature is compared with its class representative's
-        idx_of_mem = np.full(nsub, -1, dtype=np.int64)
-        idx_of_mem[mem] = np.arange(mem.size)
-        rep = idx_of_mem[low_of_set[mis[mem]]]
-        rpos = start[rep[ent]] + pos_in
-        if not (np.array_equal(kk[rep], kk) and np.array_equal(ea[rpos], ea) and np.array_equal(rsg[rpos], rsg) and np.array_equal(attr_m[rep], attr_m)):
-            raise RuntimeError("coarsen_topology: adjacency-signature hash collision")
-        ori = np.zeros(nsub)
-        ori[mem] = np.where(attr_m > 0, 1.0, s_first * s_first[rep])           # Z(low, j) / Z(low, low)
-        member = np.zeros(nsub, dtype=bool)
-        member[mem] = True
-        ulab = lowest                                                           # (only its size is used below)
-        nmis = ulab.size
+        # minimal intersection sets from the adjacency signatures of the sub-entities on agglomerate boundaries: their
+        # agglomerates with the signs relative to the first one -- or the absolute signs and the attribute for boundary facets
+        # with an attribute, whose term in Z cannot change sign.  Equal signatures <=> Z_ii = Z_jj = |Z_ij|, without forming Z
+        # (which couples all the sub-entities of an agglomerate with each other: 10^8 entries on a 10^6-cell mesh).  Native host
+        # code (csrc/host_tables.hip).
+        fpc, fic, fsc = np.ascontiguousarray(fp, dtype=np.int64), np.ascontiguousarray(fi, dtype=np.int64), np.ascontiguousarray(fs, dtype=np.float64)
+        attr32 = np.ascontiguousarray(lv.facet_attr, dtype=np.int32) if c == 0 else None
+        mis, ori, nset = np.empty(nsub, dtype=np.int64), np.empty(nsub), np.zeros(1, dtype=np.int64)
+        _lib.check(_lib.load().elag_hip_host_minimal_intersection_sets(len(fpc) - 1, _ptr(fpc), _ptr(fic), _ptr(fsc), nsub,
+                                                                       None if attr32 is None else _ptr(attr32), _ptr(mis), _ptr(ori), _ptr(nset)))
+        nmis = int(nset[0])
+        member = mis >= 0
+        mem = np.nonzero(member)[0]
         o2 = np.argsort(mis[mem], kind="stable")
         Anew = (ptr_from_counts(np.bincount(mis[mem], minlength=nmis)), mem[o2].astype(np.int64), ori[mem[o2]])
         if check and c + 1 <= 2:
