@@ -49,39 +49,14 @@ def coarsen_topology(lv: AmgeLevel, part: np.ndarray) -> dict:
     ae_ptr = ptr_from_counts(np.bincount(part, minlength=nAE))
     from .derham_level import _product                                 # native first-touch products (csrc/host_tables.hip)
     fc_ptr, f, s = _product(ae_ptr, order, lv.ef_ptr, lv.ef_idx, np.ones(order.size), lv.ef_sgn)       # AE_fc, first-touch order
-    r = np.repeat(np.arange(nAE, dtype=np.int64), np.diff(fc_ptr))
-    # per facet: adjacent agglomerates (one or two) and the sign relative to the lowest one
-    o = np.lexsort((r, f))
-    fs, rs, ss = f[o], r[o], s[o]
-    firstf = np.r_[True, fs[1:] != fs[:-1]]
-    fid = fs[firstf]
-    a_lo = rs[firstf]
-    s_lo = ss[firstf]
-    cnt = np.diff(np.r_[np.nonzero(firstf)[0], fs.size])
-    a_hi = np.where(cnt == 2, rs[np.nonzero(firstf)[0] + cnt - 1], -1)
-    have_attr = bool(np.any(lv.facet_attr > 0))
-    attr = lv.facet_attr[fid].astype(np.int64)
-    is_bdr = cnt == 1
-    k3 = np.where(is_bdr, attr, 0)
-    k4 = np.where(is_bdr & (attr > 0) & have_attr, (s_lo > 0).astype(np.int64), 0)
-    k2 = np.where(is_bdr, -1, a_hi)
-    nattr = int(lv.facet_attr.max()) + 1
-    keys = ((a_lo * (nAE + 1) + (k2 + 1)) * nattr + k3) * 2 + k4          # one scalar per facet (< 2^63 for any realistic size)
-    uk, first, inv = np.unique(keys, return_index=True, return_inverse=True)
-    inv = inv.reshape(-1)
-    lowest = fid[first]                                                    # fid ascends, so the first occurrence is the lowest facet
-    rank = np.empty(uk.shape[0], dtype=np.int64)
-    rank[np.argsort(lowest)] = np.arange(uk.shape[0])
-    mis_of = np.full(lv.nF, -1, dtype=np.int64)
-    mis_of[fid] = rank[inv]
-    nAF = uk.shape[0]
-    # orientation relative to the lowest facet of the set: s_{a,j} s_{a,i0} with a the lowest adjacent agglomerate
-    s_lo_f = np.zeros(lv.nF)
-    s_lo_f[fid] = s_lo
-    low_facet = np.empty(nAF, dtype=np.int64)
-    low_facet[rank] = lowest
-    ori = np.zeros(lv.nF)
-    ori[fid] = s_lo * s_lo_f[low_facet[mis_of[fid]]]
+    # minimal intersection sets from the facets' adjacency signatures (native: csrc/host_tables.hip)
+    fcp, fc, sc = np.ascontiguousarray(fc_ptr, dtype=np.int64), np.ascontiguousarray(f, dtype=np.int64), np.ascontiguousarray(s, dtype=np.float64)
+    attr32 = np.ascontiguousarray(lv.facet_attr, dtype=np.int32)
+    mis_of, ori, nset = np.empty(lv.nF, dtype=np.int64), np.empty(lv.nF), np.zeros(1, dtype=np.int64)
+    _lib.check(_lib.load().elag_hip_host_minimal_intersection_sets(nAE, _ptr(fcp), _ptr(fc), _ptr(sc), lv.nF, _ptr(attr32), _ptr(mis_of), _ptr(ori),
+                                                                   _ptr(nset)))
+    nAF = int(nset[0])
+    fid = np.nonzero(mis_of >= 0)[0]
     o2 = np.argsort(mis_of[fid], kind="stable")
     af_ptr = ptr_from_counts(np.bincount(mis_of[fid], minlength=nAF))
     af_idx = fid[o2]
