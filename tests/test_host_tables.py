@@ -127,3 +127,29 @@ def test_small_helpers():
     key = np.array([0, 1, 0, 0, 1, 0, 0, 0, 0, 1])
     _lib.check(_lib.load().elag_hip_host_sort_rows_by_key(3, amge._ptr(ptr), amge._ptr(idx), 10, amge._ptr(key)))
     assert idx.tolist() == [2, 7, 4, 9, 3, 8, 1]
+
+
+def test_minimal_intersection_sets_against_the_matrix_form():
+    """The native signature grouping against the oracle's restatement of ``findMinimalIntersectionSets`` on the matrix
+    ``Z = AE_fc^T AE_fc`` (+ the boundary-attribute term), on random element -> facet tables of a partitioned grid."""
+    from oracle import derham as od
+    from parelag_amd.amge_level import box_partition
+    from parelag_amd.derham_level import seq_level_from_hex
+    rng = np.random.default_rng(11)
+    lv = seq_level_from_hex((4, 3, 5), jstart=2)
+    for trial in range(3):
+        part = box_partition((4, 3, 5), (2, 2, 2)).astype(np.int64) if trial == 0 else rng.integers(0, 7, lv.n[0])
+        _u, part = np.unique(part, return_inverse=True)
+        t_prod, t_orc = derham.coarsen_topology(lv, part), od.coarsen_topology(lv, part)
+        for c in range(4):
+            for k in range(3):
+                assert np.array_equal(t_prod["A"][c][k], t_orc["A"][c][k]), (trial, c, k)
+        for c in range(3):
+            for k in range(3):
+                assert np.array_equal(t_prod["B"][c][k], t_orc["B"][c][k]), (trial, c, k)
+    lib = _lib.load()
+    mis, ori, n = np.empty(3, dtype=np.int64), np.empty(3), np.zeros(1, dtype=np.int64)
+    fp, fi, fs = np.array([0, 2, 3]), np.array([0, 2, 2]), np.array([1.0, -1.0, 1.0])            # facet 1 on no boundary
+    _lib.check(lib.elag_hip_host_minimal_intersection_sets(2, amge._ptr(fp), amge._ptr(fi), amge._ptr(fs), 3, None, amge._ptr(mis), amge._ptr(ori), amge._ptr(n)))
+    assert mis.tolist() == [0, -1, 1] and ori.tolist() == [1.0, 0.0, 1.0] and n[0] == 2
+    assert lib.elag_hip_host_minimal_intersection_sets(2, amge._ptr(fp), amge._ptr(np.array([0, 2, 5])), amge._ptr(fs), 3, None, amge._ptr(mis), amge._ptr(ori), amge._ptr(n)) != 0
