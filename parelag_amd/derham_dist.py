@@ -83,10 +83,9 @@ def restrict_level(lv: SeqLevel, topo: dict, agglomerates: np.ndarray) -> Restri
         p, i, _s = topo["B"][c]
         q, _ = expand_ranges(p[csel[c]], np.diff(p)[csel[c]])
         csel.append(np.unique(i[q]))
-    g2l, cg2l = [], []
+    g2l = []
     for c in range(4):
         m = np.full(lv.n[c], -1, dtype=np.int64); m[sel[c]] = np.arange(sel[c].size); g2l.append(m)
-        m = np.full(topo["n"][c], -1, dtype=np.int64); m[csel[c]] = np.arange(csel[c].size); cg2l.append(m)
     # ---- the sub-level ----
     B = [_restrict_rows(*lv.B[c][:2], sel[c], g2l[c + 1], lv.B[c][2]) for c in range(3)]
     idof, M, dofs = [None] * 4, [None] * 4, [None] * 4
@@ -106,11 +105,26 @@ def restrict_level(lv: SeqLevel, topo: dict, agglomerates: np.ndarray) -> Restri
     sub = SeqLevel(n=[int(s.size) for s in sel], B=B, facet_attr=lv.facet_attr[sel[1]], jstart=js, idof=idof, M=M, D=D,
                    T=[None if j < js else lv.T[j][dofs[j]] for j in range(4)], pv=[None if j < js else lv.pv[j][dofs[j]] for j in range(4)],
                    const3=lv.const3[dofs[3]], meta=dict(lv.meta))
-    # ---- the agglomerated topology of the sub-level ----
+    return Restriction(level=sub, topo=_restrict_topology(topo, csel, g2l), sel=sel, csel=csel, dofs=dofs)
+
+
+def _coarse_closure(topo: dict, agglomerates: np.ndarray) -> list:
+    csel = [np.unique(np.asarray(agglomerates, dtype=np.int64))]
+    for c in range(3):
+        p, i, _s = topo["B"][c]
+        q, _ = expand_ranges(p[csel[c]], np.diff(p)[csel[c]])
+        csel.append(np.unique(i[q]))
+    return csel
+
+
+def _restrict_topology(topo: dict, csel: list, g2l: list) -> dict:
+    """The agglomerated topology restricted to the coarse entities ``csel`` with the fine entities renumbered by ``g2l``."""
+    cg2l = []
+    for c in range(4):
+        m = np.full(topo["n"][c], -1, dtype=np.int64); m[csel[c]] = np.arange(csel[c].size); cg2l.append(m)
     A = [_restrict_rows(*topo["A"][c][:2], csel[c], g2l[c], topo["A"][c][2]) for c in range(4)]
     Bc = [_restrict_rows(*topo["B"][c][:2], csel[c], cg2l[c + 1], topo["B"][c][2]) for c in range(3)]
-    sub_topo = dict(A=A, B=Bc, facet_attr=topo["facet_attr"][csel[1]], n=[int(s.size) for s in csel])
-    return Restriction(level=sub, topo=sub_topo, sel=sel, csel=csel, dofs=dofs)
+    return dict(A=A, B=Bc, facet_attr=topo["facet_attr"][csel[1]], n=[int(s.size) for s in csel])
 
 
 # ---- exchange of the coarse dof counts -----------------------------------------------------------------------------------------
@@ -148,10 +162,16 @@ class RankPiece:
 
 
 def coarsen_rank(lv: SeqLevel, part: np.ndarray, rank: int, nranks: int, owner: np.ndarray | None = None, topo: dict | None = None,
-                 exchange=exchange_counts, coarsen_fn=None, **kw) -> RankPiece:
+                 exchange=exchange_counts, coarsen_fn=None, held: "RankPiece | None" = None, **kw) -> RankPiece:
     """This rank's part of ``Coarsen``: global topology, restriction, the single-rank numeric path on the sub-level, the
     exchange of the coarse dof counts, the renumbering to global dofs.  ``coarsen_fn`` defaults to the device path
-    (``derham.coarsen``); ``exchange(local_counts) -> global_counts`` defaults to the ``torch.distributed`` all-reduce."""
+    (``derham.coarsen``); ``exchange(local_counts) -> global_counts`` defaults to the ``torch.distributed`` all-reduce.
+
+    ``held``: the piece this rank got from coarsening the level above.  ``lv`` then only needs the integer part of the level
+    (``n``, ``B``, ``facet_attr``, ``jstart``, ``idof`` sizes are not read): the numeric sub-level is the coarse level the rank
+    already holds (``held.local["coarse"]``, entities ``held.csel``, dofs ``held.coarse_dofs``), which is the closure of its
+    agglomerates when ownership is nested (an agglomerate of this level owns only agglomerates of the level above that the
+    same rank owns) -- the numeric data of a coarse level never exists in one place."""
     from . import derham
     coarsen_fn = derham.coarsen if coarsen_fn is None else coarsen_fn
     topo = derham.coarsen_topology(lv, part) if topo is None else topo
@@ -171,9 +191,22 @@ def coarsen_rank(lv: SeqLevel, part: np.ndarray, rank: int, nranks: int, owner: 
                          coarse_dofs=[None if j < js else e64 for j in range(4)],
                          P=[None if j < js else sp.csr_matrix((0, nco[j])) for j in range(4)],
                          D=[None if j < js else sp.csr_matrix((0, nco[j])) for j in range(3)],
-                         T=[None if j < js else np.zeros((0, lv.T[j].shape[1])) for j in range(4)], const3=np.zeros(0), csel=[e64] * 4,
+                         T=[None if j < js else np.zeros((0, (lv.T[j] if held is None else held.T[j]).shape[1])) for j in range(4)], const3=np.zeros(0),
+                         csel=[e64] * 4,
                          counts=counts, blocks={key: (np.zeros(1, dtype=np.int64), np.zeros(0)) for key in keys}, n_null={}, local={})
-    R = restrict_level(lv, topo, mine)
+    if held is None:
+        R = restrict_level(lv, topo, mine)
+    else:
+        csel = _coarse_closure(topo, mine)
+        g2l = []
+        for c in range(4):
+            m = np.full(lv.n[c], -1, dtype=np.int64); m[held.csel[c]] = np.arange(held.csel[c].size); g2l.append(m)
+        ap, ai, _ = topo["A"][0]
+        q, _ = expand_ranges(ap[mine], np.diff(ap)[mine])
+        if not np.array_equal(np.sort(ai[q]), held.csel[0]):
+            raise ValueError("coarsen_rank: ownership is not nested -- the elements of this rank's agglomerates are not the coarse "
+                             "elements it holds from the level above")
+        R = Restriction(level=held.local["coarse"], topo=_restrict_topology(topo, csel, g2l), sel=held.csel, csel=csel, dofs=held.coarse_dofs)
     res = coarsen_fn(R.level, None, topo=R.topo, **kw)
     cl = res["coarse"]
     # ---- global numbering of the coarse dofs: counts per coarse entity, exchanged ----
@@ -206,6 +239,13 @@ def coarsen_rank(lv: SeqLevel, part: np.ndarray, rank: int, nranks: int, owner: 
     blocks = {(j, c): cl.M[j][c] for j, c in keys}
     return RankPiece(rank=rank, agglomerates=mine, fine_dofs=R.dofs, coarse_dofs=cdofs, P=P, D=Dg, T=T, const3=cl.const3, csel=R.csel,
                      counts=counts, blocks=blocks, n_null=res["n_null"], local=res)
+
+
+def integer_level(topo: dict, jstart: int) -> SeqLevel:
+    """The integer part of the coarse level an agglomerated topology defines (entity counts, boundary tables, facet attributes):
+    all that ``coarsen_topology`` reads, and all of a coarse level that is replicated on every rank."""
+    return SeqLevel(n=list(topo["n"]), B=topo["B"], facet_attr=topo["facet_attr"], jstart=jstart, idof=[None] * 4, M=[None] * 4, D=[None] * 3,
+                    T=[None] * 4, pv=[None] * 4, const3=np.zeros(0), meta=dict(kind="integer"))
 
 
 def coarsen_allgather(lv: SeqLevel, part: np.ndarray, rank: int, nranks: int, owner: np.ndarray | None = None, group=None,

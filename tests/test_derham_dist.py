@@ -97,6 +97,42 @@ def test_a_rank_without_agglomerates_takes_part_and_contributes_nothing():
     same_as_single_rank(lv, dd.merge_pieces(lv, topo, pieces, atol=1e-14), od.coarsen(lv, part), tol=1e-14)
 
 
+def _two_level_chain(coarsen_fn, tol):
+    """Two coarsenings where the ranks never see the numeric data of the intermediate level as a whole: the second call gets
+    the piece of the first (``held``) and only the integer topology of the coarse level is global."""
+    n = (8, 8, 8)
+    lv = seq_level_from_hex(n, h=(0.125, 0.25, 0.5), jstart=0)
+    part0, part1 = box_partition(n, (2, 2, 2)).astype(np.int64), box_partition((4, 4, 4), (2, 2, 2)).astype(np.int64)
+    owner1 = np.array([0, 0, 0, 1, 1, 2, 2, 2])                     # three ranks; nested: a level-0 agglomerate follows its parent
+    owner0 = owner1[part1]
+    topo0, pieces0 = in_process(lv, part0, 3, owner0, coarsen_fn)
+    lv1_int = dd.integer_level(topo0, lv.jstart)
+    topo1 = derham.coarsen_topology(lv1_int, part1)
+    reported = []
+    for r in range(3):
+        dd.coarsen_rank(lv1_int, part1, r, 3, owner=owner1, topo=topo1, exchange=lambda a: (reported.append(a.copy()), a)[1],
+                        coarsen_fn=coarsen_fn, held=pieces0[r])
+    glob = np.max(np.stack(reported), axis=0)
+    pieces1 = [dd.coarsen_rank(lv1_int, part1, r, 3, owner=owner1, topo=topo1, exchange=lambda a: glob, coarsen_fn=coarsen_fn, held=pieces0[r])
+               for r in range(3)]
+    single0 = coarsen_fn(lv, part0)
+    single1 = coarsen_fn(single0["coarse"], part1)
+    same_as_single_rank(single0["coarse"], dd.merge_pieces(single0["coarse"], topo1, pieces1, atol=max(tol, 1e-300)), single1, tol)
+    # ownership that is not nested is refused
+    with pytest.raises(ValueError, match="not nested"):
+        dd.coarsen_rank(lv1_int, part1, 0, 3, owner=np.array([0, 1, 0, 1, 1, 2, 2, 2]), topo=topo1, exchange=lambda a: glob, coarsen_fn=coarsen_fn,
+                        held=pieces0[0])
+
+
+def test_two_level_chain_without_a_global_coarse_level_oracle_numerics():
+    _two_level_chain(od.coarsen, tol=1e-13)
+
+
+@pytest.mark.gpu
+def test_two_level_chain_without_a_global_coarse_level_on_device():
+    _two_level_chain(derham.coarsen, tol=0.0)
+
+
 def test_restriction_keeps_the_sequence_exact():
     lv, part, _n, _o = make("tets_hetero_3")
     topo = derham.coarsen_topology(lv, part)
