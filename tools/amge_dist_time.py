@@ -39,3 +39,32 @@ for N in (2, 4, 8):
     print("N=%d: per-rank wall (restriction + numeric + renumbering) max %.3f s mean %.3f s  -> %.2fx of single;  + replicated topology %.3f s;"
           "  facets held %.3fx;  |P_merged - P_single| %.2e;  (elements, restriction s) %s" %
           (N, max(walls), np.mean(walls), t_single / max(walls), t_topo, dup, err, sizes), flush=True)
+
+# ---- the whole hierarchy per rank: every further level goes on from the coarse level the rank already holds ----
+print("\nall %d coarsenings per rank (held coarse levels, integer topology replicated):" % k, flush=True)
+t = time.time(); cur = lv
+for l in range(k):
+    cur = derham.coarsen(cur, seq.partition(l))["coarse"]
+t_single_all = time.time() - t
+for N in (2, 4, 8):
+    eparts = partition.element_partitions(seq, N)
+    per_rank = np.zeros(N)
+    held = [None] * N
+    level_int, topo_time = lv, 0.0
+    for l in range(k):
+        part_l = seq.partition(l)
+        t = time.time(); topo_l = derham.coarsen_topology(level_int, part_l); topo_time += time.time() - t
+        owner = np.zeros(topo_l["n"][0], dtype=np.int64); owner[part_l] = eparts[l]
+        reported = []
+        for r in range(N):
+            dd.coarsen_rank(level_int, part_l, r, N, owner=owner, topo=topo_l, exchange=lambda a: (reported.append(a.copy()), a)[1], held=held[r])
+        glob = np.max(np.stack(reported), axis=0)
+        new = []
+        for r in range(N):
+            t = time.time()
+            new.append(dd.coarsen_rank(level_int, part_l, r, N, owner=owner, topo=topo_l, exchange=lambda a: glob, held=held[r]))
+            per_rank[r] += time.time() - t
+        held = new
+        level_int = dd.integer_level(topo_l, lv.jstart)
+    print("N=%d: numeric per rank max %.3f s mean %.3f s + replicated topologies %.3f s = %.3f s  (single rank, all levels: %.3f s -> %.2fx)" %
+          (N, per_rank.max(), per_rank.mean(), topo_time, per_rank.max() + topo_time, t_single_all, t_single_all / (per_rank.max() + topo_time)), flush=True)
