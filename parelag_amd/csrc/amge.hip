@@ -669,6 +669,63 @@ __global__ void batched_rank_kernel(RankArgs a)
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
 
+// Device scratch of one ABI call.  The calls of a coarsening stage need some dozens of buffers each; hipMalloc / hipFree per
+// buffer cost more than the kernels (about 10 ms a call against 1 ms of kernel at cube456 x3).  The arena is one grow-only
+// allocation per host thread, sized by the previous call's demand: buffers are bump-allocated from it, what does not fit is
+// allocated separately for this call, and the next call starts with an arena large enough for everything.  All buffers die
+// together when the call returns (every entry point synchronises its stream first).
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, off = 0, want = 0;
+    std::vector<void *> spill;
+    void begin()
+    {
+        end();
+        if (want > cap) {
+            if (base) (void)hipFree(base);
+            base = nullptr;
+            cap = want + want / 4;
+            ELAG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&base), cap));
+        }
+        off = 0;
+        want = 0;
+    }
+    void *take(size_t bytes)
+    {
+        bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+        want += bytes;
+        if (off + bytes <= cap) {
+            void *p = base + off;
+            off += bytes;
+            return p;
+        }
+        void *p = nullptr;
+        ELAG_HIP_CHECK(hipMalloc(&p, bytes));
+        spill.push_back(p);
+        return p;
+    }
+    void end()
+    {
+        for (void *p : spill) (void)hipFree(p);
+        spill.clear();
+    }
+    ~Arena() { end(); }                                      // the arena itself is left to process teardown
+};
+thread_local Arena g_arena;
+struct ArenaScope {
+    ArenaScope() { g_arena.begin(); }
+    ~ArenaScope() { g_arena.end(); }
+};
+template <class T>
+T *arena_alloc(size_t n) { return static_cast<T *>(g_arena.take(n * sizeof(T))); }
+template <class T>
+T *arena_from_host(const T *h, size_t n)
+{
+    T *p = arena_alloc<T>(n);
+    if (n) ELAG_HIP_CHECK(hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, ctx().stream));
+    return p;
+}
+
 struct AsmUpload {
     int64_t *asm_ptr = nullptr, *blk_off = nullptr, *loc_off = nullptr;
     int *blk_n = nullptr, *loc_idx = nullptr;
@@ -676,15 +733,14 @@ struct AsmUpload {
     AsmDev dev{};
     void upload(const elag_hip_dense_assembly &h, int n_ent)
     {
-        asm_ptr = dev_from_host(h.asm_ptr, (size_t)n_ent + 1);
-        blk_off = dev_from_host(h.blk_off, (size_t)h.n_items);
-        loc_off = dev_from_host(h.loc_off, (size_t)h.n_items);
-        blk_n = dev_from_host(h.blk_n, (size_t)h.n_items);
-        loc_idx = dev_from_host(h.loc_idx, (size_t)h.n_loc);
-        blocks = dev_from_host(h.blocks, (size_t)h.n_block_values);
+        asm_ptr = arena_from_host(h.asm_ptr, (size_t)n_ent + 1);
+        blk_off = arena_from_host(h.blk_off, (size_t)h.n_items);
+        loc_off = arena_from_host(h.loc_off, (size_t)h.n_items);
+        blk_n = arena_from_host(h.blk_n, (size_t)h.n_items);
+        loc_idx = arena_from_host(h.loc_idx, (size_t)h.n_loc);
+        blocks = arena_from_host(h.blocks, (size_t)h.n_block_values);
         dev = AsmDev{asm_ptr, blk_off, loc_off, blk_n, loc_idx, blocks};
     }
-    ~AsmUpload() { dev_free(asm_ptr); dev_free(blk_off); dev_free(loc_off); dev_free(blk_n); dev_free(loc_idx); dev_free(blocks); }
 };
 
 void check_assembly(const elag_hip_dense_assembly &h, int n_ent, const int *order, const char *what)
@@ -702,11 +758,10 @@ void check_assembly(const elag_hip_dense_assembly &h, int n_ent, const int *orde
 }
 
 template <class T>
-struct DevBuf {
+struct DevBuf {                                              // a buffer of the current call's arena
     T *p = nullptr;
-    explicit DevBuf(size_t n) : p(dev_alloc<T>(n)) {}
-    DevBuf(const T *h, size_t n) : p(dev_from_host(h, n)) {}
-    ~DevBuf() { dev_free(p); }
+    explicit DevBuf(size_t n) : p(arena_alloc<T>(n)) {}
+    DevBuf(const T *h, size_t n) : p(arena_from_host(h, n)) {}
     operator T *() const { return p; }
 };
 
@@ -782,6 +837,7 @@ ELAG_HIP_API int elag_hip_coarsen_traces(const elag_hip_coarsen_traces_in *in, c
 {
     return guarded([&] {
         require_init();
+        ArenaScope arena_scope;
         ELAG_REQUIRE(in && out, "null argument");
         const int ne = in->n_ent, nT = in->nT, kmax = 1 + nT;
         ELAG_REQUIRE(ne >= 0 && nT >= 0 && kmax <= kMaxCols, "at most %d target vectors are supported (got %d)", kMaxCols - 1, nT);
@@ -834,6 +890,7 @@ ELAG_HIP_API int elag_hip_coarsen_extension(const elag_hip_coarsen_extension_in 
 {
     return guarded([&] {
         require_init();
+        ArenaScope arena_scope;
         ELAG_REQUIRE(in && out, "null argument");
         const int ne = in->n_ent, nT = in->nT;
         ELAG_REQUIRE(ne >= 0 && nT >= 0 && nT < kMaxCols, "at most %d target vectors are supported (got %d)", kMaxCols - 1, nT);
@@ -923,6 +980,7 @@ ELAG_HIP_API int elag_hip_batched_rank(int n_mat, const int *nrows, const int *n
 {
     return guarded([&] {
         require_init();
+        ArenaScope arena_scope;
         ELAG_REQUIRE(n_mat >= 0 && (n_mat == 0 || (nrows && ncols && t_ptr && rank)), "null argument");
         if (n_mat == 0) return;
         hipStream_t st = ctx().stream;
