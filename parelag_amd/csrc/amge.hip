@@ -16,6 +16,7 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <memory>
@@ -685,6 +686,7 @@ struct Arena {
             if (base) (void)hipFree(base);
             base = nullptr;
             cap = want + want / 4;
+            if (std::getenv("ELAG_HIP_ARENA_TRACE")) std::fprintf(stderr, "[arena] grow to %zu MiB\n", cap >> 20);
             ELAG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&base), cap));
         }
         off = 0;
@@ -700,6 +702,7 @@ struct Arena {
             return p;
         }
         void *p = nullptr;
+        if (std::getenv("ELAG_HIP_ARENA_TRACE")) std::fprintf(stderr, "[arena] spill %zu KiB (cap %zu MiB, used %zu MiB)\n", bytes >> 10, cap >> 20, off >> 20);
         ELAG_HIP_CHECK(hipMalloc(&p, bytes));
         spill.push_back(p);
         return p;
