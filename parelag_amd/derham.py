@@ -786,6 +786,25 @@ def _check_codim(lv: SeqLevel, topo, codim: int):
     return b, bad, msg
 
 
+def show_me(topo: dict, weights: list | None = None) -> str:
+    """``AgglomeratedTopology::ShowMe`` (``src/topology/Topology.cpp:310-391``) for a coarsened topology on one rank: entity counts
+    (local and global columns coincide), the Euler characteristic, and -- when the fine entities' weights are given, one array
+    per codimension 0 .. 2 -- the MIN / MAX / AVERAGE weight of the agglomerated entities (``WedgeMult``: sums over members)."""
+    n = topo["n"]
+    lines = []
+    for name, c in (("N_elements", 0), ("N_facets  ", 1), ("N_ridges  ", 2), ("N_peaks   ", 3)):
+        lines.append("  %s = %10d%10d" % (name, n[c], n[c]))
+    euler = n[3] - n[2] + n[1] - n[0]
+    lines.append("Euler Characteristic = %10d%10d" % (euler, euler))
+    if weights is not None:
+        lines.append("Entity   MIN  MAX AVERAGE (weight)")
+        for name, c in (("Element", 0), ("Facet", 1), ("Ridge", 2)):
+            ptr, idx, _ = topo["A"][c]
+            w = np.add.reduceat(np.asarray(weights[c])[idx], ptr[:-1]) if idx.size else np.zeros(0)
+            lines.append("%s %g %g %g" % (name, w.min(), w.max(), w.mean()))
+    return "\n".join(lines) + "\n"
+
+
 def check_topology(lv: SeqLevel, topo: dict) -> dict:
     """``MarkBadAgglomeratedEntities`` / ``ShowBadAgglomeratedEntities`` (``:85-240``) for agglomerated elements, facets and
     ridges: Betti numbers, the extra boundary-connectivity test for codimensions 0 and 1, the reference's diagnostic lines.

@@ -172,7 +172,11 @@ def test_reference_diagnostics_cpu(name):
 
 def test_disconnected_partition_is_split_into_three():
     ncomp, topo, res = run("disconnected", product_ranks=False)
-    assert ncomp == 3 and topo["n"][0] == 3                       # "N_elements =          3"
+    assert ncomp == 3 and topo["n"][0] == 3
+    lv = mfem_hex_topology(3, 3, 3)
+    text = derham.show_me(topo, weights=[np.ones(lv.n[c]) for c in range(3)])
+    assert "N_elements =          3" in text                      # the line ctest greps (testsuite/CMakeLists.txt:35-40)
+    assert "Euler Characteristic =          1         1" in text and "Element 1 25 9" in text
     assert not res["isbad"][0].any()
 
 
