@@ -44,3 +44,16 @@ def test_product_path_fails_loudly_without_device():
     import numpy as np, scipy.sparse as sp
     with pytest.raises(_lib.ElagHipError):
         linalg.ParallelCSRMatrix.from_scipy(sp.eye(3, format="csr"))
+
+
+def test_header_is_plain_c_and_host_entry_points_run_without_a_device(tmp_path):
+    """``include/elag_hip.h`` compiles as C99 with ``-pedantic`` and a C program can call the device-free entry points."""
+    from parelag_amd import build
+    lib = build.build()
+    exe = str(tmp_path / "abi_header_test")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c", "abi_header_test.c"), "-o", exe, lib, f"-Wl,-rpath,{os.path.dirname(lib)}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "C_ABI_OK" in out.stdout, out.stdout + out.stderr
