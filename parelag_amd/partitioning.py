@@ -1,8 +1,12 @@
 """Element partitioners that feed ``DeRhamSequence.Coarsen`` (host integer work, like the reference's ``src/partitioning``).
 
-``GeometricBoxPartitioner`` follows ``src/partitioning/GeometricBoxPartitioner.cpp:20-80``; the Cartesian box partition of a
-structured grid is ``amge_level.box_partition``; the derefinement partition of a refined tet mesh is
-``meshgen.Sequence.partition``.  The graph partitioners (METIS / ParMETIS) are third-party and out of scope."""
+``GeometricBoxPartitioner`` follows ``src/partitioning/GeometricBoxPartitioner.cpp:20-80``; ``LogicalPartitioner`` with the Cartesian /
+material-id coarsening operators ``src/partitioning/LogicalPartitioner.hpp:41-135`` and ``CartesianPartitioner.hpp:25-152`` (any other
+"coarse logical value" works the same way: see the derefinement + material operator in ``tests/test_logical_partitioner_golden.py``);
+the plain Cartesian box partition of a structured grid is ``amge_level.box_partition``; the derefinement partition of a refined
+tet mesh is ``meshgen.Sequence.partition`` / ``linalg.partition_refined``.  The graph partitioners (METIS / ParMETIS) are
+third-party and out of scope.  Known answers of the reference reproduced with these: ``test_GeometricBoxPartitioner``,
+``UpscalingGeneralForm --geometric``, ``LogicalPartitionerDemo``, ``EmbeddedMeshPartitionerDemo``."""
 from __future__ import annotations
 
 import numpy as np
