@@ -96,6 +96,52 @@ def amge_darcy_problem(args, spe10, np):
     return dar
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """``python bench.py --gpus N`` without a launcher around it: start N fresh child ranks (one per GPU) under
+    torch.distributed.run and return the children's exit code.  Rank 0 of the children prints the JSON line on the
+    stdout this process hands down.  Called before the package is imported, so this process never initialises the GPU
+    (a process that has must not be replaced or forked into ranks on this pool)."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    note("launching %d ranks: %s" % (n, " ".join(cmd[1:])))
+    # stdout of the children is filtered: the JSON line(s) go to stdout, anything else a library wrote there to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:
+        if line.lstrip().startswith("{"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
+
+
+def launch_dry_run(rank: int, world: int):
+    """child side of --launch-dry-run: a gloo group over the launcher's rendezvous, every rank reports who it is"""
+    import torch.distributed as td
+    from parelag_amd.distributed import stdout_to_stderr
+    with stdout_to_stderr():
+        td.init_process_group("gloo", rank=rank, world_size=world)
+    mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", rank)), "world_size": world, "pid": os.getpid(),
+            "ppid": os.getppid()}
+    allr = [None] * world
+    td.all_gather_object(allr, mine)
+    td.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_dry_run": True, "n_gpus": world, "ranks": allr}), flush=True)
+    td.destroy_process_group()
+
+
 def note(msg):
     """progress line on stderr (stdout carries exactly one JSON line)"""
     print("[bench %7.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
@@ -137,15 +183,30 @@ def main():
                     "inverses are AMGe V-cycles on M and on B diag(M)^-1 Bt (the solver graph of spe10_example_parameters.xml:95-127)")
     ap.add_argument("--no-cpu-solve", action="store_true", help="--solve: skip the CPU port of the Krylov solve (minutes at SPE10 size)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even with one rank (testing)")
+    ap.add_argument("--launch-dry-run", action="store_true", help="start the ranks, report RANK / WORLD_SIZE of every child over a gloo "
+                    "group and exit: exercises the launcher without a GPU")
+    ap.add_argument("--large-refines", type=int, default=5, help="--gpus N > 1: refinements of the second, GPU-filling 0-form workload "
+                    "reported under \"large\" (0 disables it)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    # ---------------------------------------------------------------- launcher: nothing above or in here touches the GPU
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU (start bench.py without WORLD_SIZE and it "
+                         f"launches its own ranks, or give torch.distributed.run --nproc-per-node {args.gpus})")
+    if args.launch_dry_run:
+        return launch_dry_run(rank, world)
+
     spe10 = args.form == "spe10"
     darcy = args.form in ("darcy", "spe10")
     args.form = 3 if darcy else int(args.form)
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    mesh_label = ("Cartesian hex grid %dx%dx%d (cells 20x10x2, the mesh of MultigridTestSPE10.cpp:194-208), 2x2x2 box agglomerates" % tuple(args.hex)
+                  if args.hex else f"cube456 x{args.refines} uniform refines")
 
     import numpy as np
     import scipy.sparse as sp
@@ -512,13 +573,13 @@ def main():
                 mc = {"value": round(cm / (time.perf_counter() - t0), 2), "cores": ncores, "cycles": cm, "sweep": sweep,
                       "rel_diff_vs_serial": float(np.max(np.abs(xm - xs)) / np.max(np.abs(xs)))}
         cpu = {"value": round(cpu_rate, 2), "unit": "V-cycles/s", "cores": 1, "kind": "port",
-               "sample": f"{cnt} V-cycles of the same cube456 x{args.refines} hierarchy on one host core "
+               "sample": f"{cnt} V-cycles of the same {mesh_label} hierarchy on one host core "
                          + ("(oracle.OHierarchy over OBlockOperator: C kernels composed in numpy; hypre/MFEM unavailable, so this is a restatement)"
                             if darcy else
                             "(oracle/elag_oracle.c, -O3 -march=native; hypre/MFEM unavailable, so this is a restatement)")}
         if mc is not None and mc["value"] > cpu["value"]:
             cpu = {"value": mc["value"], "unit": "V-cycles/s", "cores": mc["cores"], "kind": "port",
-                   "sample": f"{mc['cycles']} V-cycles of the same cube456 x{args.refines} hierarchy with the row loops of oracle/elag_oracle.c split over "
+                   "sample": f"{mc['cycles']} V-cycles of the same {mesh_label} hierarchy with the row loops of oracle/elag_oracle.c split over "
                              f"{mc['cores']} host cores (-O3 -march=native -fopenmp; the work split of one MPI rank per core without its message "
                              f"passing; hypre/MFEM unavailable, so this is a restatement); single core: {cpu['value']} V-cycles/s",
                    "value_1core": cpu["value"], "multicore_rel_diff_vs_serial": mc["rel_diff_vs_serial"],
@@ -585,13 +646,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": (f"MultigridTest0Form cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
+            "config": {"workload": (f"MultigridTest0Form {mesh_label}, {len(Ps) + 1} levels, "
                                     f"{args.smoother} 1 sweep pre/post, dense coarse solve, b=2") if args.form == 0 else
                                    (("MultigridTestSPE10-like (synthetic log-normal k, sigma=%g, contrast %.1e) " % (args.perm_sigma, float(kinv.max() / kinv.min())) if spe10 else "") +
-                                    f"MultigridTestDarcy [[M,Bt],[B,0]] (forms 2,3) cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
+                                    f"MultigridTestDarcy [[M,Bt],[B,0]] (forms 2,3) {mesh_label}, {len(Ps) + 1} levels, "
                                     f"{args.block_smoother} (A00: {args.smoother}, A11: {args.smoother} on "
                                     f"{'S' if args.positive_s else '-S'} = -+B diag(M)^-1 Bt) pre/post, dense LU coarse solve, b=2") if darcy else
-                                   (f"MultigridTest{args.form}Form ({'H(div)' if args.form == 2 else 'H(curl)'}) cube456 x{args.refines} uniform refines, {len(Ps) + 1} levels, "
+                                   (f"MultigridTest{args.form}Form ({'H(div)' if args.form == 2 else 'H(curl)'}) {mesh_label}, {len(Ps) + 1} levels, "
                                     f"Hiptmair({args.smoother}, {args.smoother}) pre/post, dense coarse solve, b=2"),
                        "interpolators": (dar["amge"]["what"] if darcy and "amge" in dar else "nested geometric (generator)"),
                        "levels": [{"n": s[0], "nnz": s[1]} for s in level_shapes],

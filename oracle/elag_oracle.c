@@ -578,7 +578,9 @@ ORC_API int orc_connected_components(int n, int *partitioning, const int *I, con
         }
     }
     for (i = 0; i < num_part; i++) offset[i + 1] += offset[i];
-    for (i = 0; i < n; ++i) partitioning[i] = offset[partitioning[i]] + component[i];
+    /* nodes with a negative id were skipped by the sweep (:50-51, :62-63); the reference's last loop (:79-80) then reads
+     * offset_comp[-1] for them, which is undefined -- they keep their id here */
+    for (i = 0; i < n; ++i) if (partitioning[i] >= 0) partitioning[i] = offset[partitioning[i]] + component[i];
     int total = offset[num_part];
     free(component); free(offset); free(stack);
     return total;

@@ -712,9 +712,19 @@ struct Arena {
         for (void *p : spill) (void)hipFree(p);
         spill.clear();
     }
-    ~Arena() { end(); }                                      // the arena itself is left to process teardown
+    void release()                                           // elag_hip_finalize: give this thread's arena back
+    {
+        end();
+        if (base) (void)hipFree(base);
+        base = nullptr;
+        cap = off = want = 0;
+    }
+    ~Arena() { end(); }                                      // a thread that never finalises leaves the arena to process teardown
 };
 thread_local Arena g_arena;
+}  // namespace
+void amge_release_arena() { g_arena.release(); }
+namespace {
 struct ArenaScope {
     ArenaScope() { g_arena.begin(); }
     ~ArenaScope() { g_arena.end(); }

@@ -93,6 +93,7 @@ struct Context {
 };
 Context &ctx();
 void require_init();
+void amge_release_arena();            // amge.hip: frees the calling thread's coarsening arena (elag_hip_finalize)
 
 // ---- device memory helpers ---------------------------------------------------------------------
 bool debug_sync();     // ELAG_HIP_DEBUG_SYNC=1

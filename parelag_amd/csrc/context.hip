@@ -217,6 +217,7 @@ int elag_hip_finalize(void)
         (void)hipStreamSynchronize(c.comm_stream);
         comm_destroy();
         scratch_release_all();
+        amge_release_arena();
         (void)hipFree(c.d_scalar);
         if (c.reduce_part) (void)hipFree(c.reduce_part);
         (void)hipHostFree(c.h_scalar);

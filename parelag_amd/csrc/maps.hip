@@ -120,26 +120,26 @@ int elag_hip_connected_components(int n, int *part, const int *ci, const int *cj
         ELAG_REQUIRE(n >= 0 && (n == 0 || (part && ci && cj)), "bad argument");
         if (n == 0) { if (num_components) *num_components = 0; return; }
         int nparts = 0;
-        for (int i = 0; i < n; i++) {
-            ELAG_REQUIRE(part[i] >= 0, "negative part id at node %d", i);
-            nparts = std::max(nparts, part[i] + 1);
-        }
+        // nodes with a negative id belong to no part: the reference's sweep skips them (connectedComponents.cpp:50-51,
+        // 62-63, like transposePartitioning does); they keep their id
+        for (int i = 0; i < n; i++) nparts = std::max(nparts, part[i] + 1);
         // components = classes of "same part and adjacent"; representative = smallest node of the class
         DisjointSets ds(n);
         for (int i = 0; i < n; i++)
             for (int k = ci[i]; k < ci[i + 1]; k++) {
                 const int j = cj[k];
                 ELAG_REQUIRE(j >= 0 && j < n, "connectivity column %d out of range", j);
-                if (part[j] == part[i]) ds.unite(i, j);
+                if (part[i] >= 0 && part[j] == part[i]) ds.unite(i, j);
             }
         // The reference numbers the components of a part in the order in which a sweep over the nodes first meets them,
         // i.e. by their smallest node; ids of part q start after all components of parts < q.
         std::vector<int> ncomp((size_t)nparts + 1, 0), local((size_t)n, -1);
         for (int i = 0; i < n; i++)
-            if (ds.find(i) == i) local[(size_t)i] = ncomp[(size_t)part[i] + 1]++;
+            if (part[i] >= 0 && ds.find(i) == i) local[(size_t)i] = ncomp[(size_t)part[i] + 1]++;
         for (int q = 0; q < nparts; q++) ncomp[(size_t)q + 1] += ncomp[(size_t)q];
         const std::vector<int> old(part, part + n);   // representatives are rewritten before their members read them
         for (int i = 0; i < n; i++) {
+            if (old[(size_t)i] < 0) continue;
             const int r = ds.find(i);
             part[i] = ncomp[(size_t)old[(size_t)r]] + local[(size_t)r];
         }

@@ -224,10 +224,13 @@ int elag_hip_parcsr_create(elag_hip_parcsr_t *out, const elag_hip_parcsr_desc *d
             ELAG_REQUIRE(M->recv_starts[0] == 0 && M->recv_starts.back() == d->num_cols_offd,
                          "recv_vec_starts must cover exactly the %d ghost columns", d->num_cols_offd);
         } else {
-            ELAG_REQUIRE(d->num_cols_offd == 0 || ctx().nranks == 1 || true, "ghost columns without receive list");
+            ELAG_REQUIRE(d->num_cols_offd == 0, "%d ghost columns without a receive list", d->num_cols_offd);
         }
+        // neighbour ranks must exist in the communicator the exchange will run on (a descriptor built before
+        // elag_hip_comm_init is checked against the size it states itself: at least non-negative)
         const int nr = ctx().nranks;
-        for (int p : M->send_procs) ELAG_REQUIRE(p >= 0 && p < std::max(nr, 1 << 30), "bad send proc %d", p);
+        for (int p : M->send_procs) ELAG_REQUIRE(p >= 0 && (nr <= 1 || p < nr), "send proc %d outside the communicator of %d ranks", p, nr);
+        for (int p : M->recv_procs) ELAG_REQUIRE(p >= 0 && (nr <= 1 || p < nr), "recv proc %d outside the communicator of %d ranks", p, nr);
         M->finish_setup();
         *out = M.release();
     });

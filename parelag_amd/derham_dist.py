@@ -181,9 +181,22 @@ def coarsen_rank(lv: SeqLevel, part: np.ndarray, rank: int, nranks: int, owner: 
     keys = [(j, c) for j in range(js, 4) for c in range(lv.cb(j) + 1)]
     offs = np.concatenate([[0], np.cumsum([topo["n"][c] for _j, c in keys])])
     flat = np.zeros(int(offs[-1]), dtype=np.int64)
+    NOT_HELD = np.int64(-(1 << 40))
+
+    def exchange_checked(flat, heldmask):
+        """one MAX all-reduce that carries the counts and, negated, their minimum over the ranks that hold an entity: every
+        rank sees the same (max, min) pair per entity, so a disagreement raises on ALL ranks at once and nobody is left
+        waiting in the next collective"""
+        both = exchange(np.concatenate([flat, np.where(heldmask, -flat, NOT_HELD)]))
+        gmax, gmin = both[:flat.size], -both[flat.size:]
+        bad = np.nonzero((gmin < -NOT_HELD) & (gmax != gmin))[0]
+        if bad.size:
+            raise RuntimeError("coarsen_rank: ranks disagree on the number of coarse dofs of %d shared entit%s (first: flat index %d, "
+                               "counts between %d and %d)" % (bad.size, "y" if bad.size == 1 else "ies", int(bad[0]), int(gmin[bad[0]]), int(gmax[bad[0]])))
+        return gmax
     if mine.size == 0:
         # a rank without agglomerates (more ranks than agglomerates on a coarse level) still takes part in the exchange
-        glob = exchange(flat)
+        glob = exchange_checked(flat, np.zeros(flat.size, dtype=bool))
         counts = {key: glob[offs[k]:offs[k + 1]] for k, key in enumerate(keys)}
         nco = {j: int(sum(counts[(j, c)].sum() for c in range(lv.cb(j) + 1))) for j in range(js, 4)}
         e64 = np.zeros(0, dtype=np.int64)
@@ -210,11 +223,11 @@ def coarsen_rank(lv: SeqLevel, part: np.ndarray, rank: int, nranks: int, owner: 
     res = coarsen_fn(R.level, None, topo=R.topo, **kw)
     cl = res["coarse"]
     # ---- global numbering of the coarse dofs: counts per coarse entity, exchanged ----
+    heldmask = np.zeros(flat.size, dtype=bool)
     for k, (j, c) in enumerate(keys):
         flat[offs[k] + R.csel[c]] = np.diff(cl.idof[j][c])
-    glob = exchange(flat)
-    if np.any((flat > 0) & (glob != flat)):
-        raise RuntimeError("coarsen_rank: ranks disagree on the number of coarse dofs of a shared entity")
+        heldmask[offs[k] + R.csel[c]] = True
+    glob = exchange_checked(flat, heldmask)
     counts = {key: glob[offs[k]:offs[k + 1]] for k, key in enumerate(keys)}
     cidof = {j: [ptr_from_counts(counts[(j, c)]) for c in range(lv.cb(j) + 1)] for j in range(js, 4)}
     ncoarse = {j: int(sum(cidof[j][c][-1] for c in range(lv.cb(j) + 1))) for j in range(js, 4)}

@@ -6,8 +6,11 @@ it), and ``build_hierarchy`` hands every rank its rows of every level's operator
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
+import socket
+import sys
 import time
 
 import numpy as np
@@ -35,9 +38,35 @@ class Dist:
         return float(t[0])
 
 
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """fd-level redirect of stdout to stderr (gloo announces its connections on the C++ stdout; a benchmark's stdout carries
+    exactly one JSON line)"""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def init(rank: int, world: int) -> Dist:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29511")
+    if "MASTER_PORT" not in os.environ:
+        # a launcher (torch.distributed.run, bench.py --gpus N) always provides the port; only a lone rank gets here without
+        # one, and a lone rank may take any free port
+        if world > 1:
+            raise RuntimeError("distributed.init: MASTER_PORT is not set (start the ranks with torch.distributed.run or bench.py --gpus N)")
+        os.environ["MASTER_PORT"] = str(free_port())
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # Load the HIP library (and, across ranks, the system RCCL) BEFORE torch: the dynamic loader then binds
     # everything in this process to the one ROCm runtime the kernels were built with; torch is used on the CPU
@@ -53,7 +82,8 @@ def init(rank: int, world: int) -> Dist:
     import torch
     import torch.distributed as td
     if not td.is_initialized():
-        td.init_process_group("gloo", rank=rank, world_size=world)
+        with stdout_to_stderr():
+            td.init_process_group("gloo", rank=rank, world_size=world)
     uid = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
         buf = (C.c_ubyte * 128)()

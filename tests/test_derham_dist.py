@@ -33,7 +33,8 @@ def in_process(lv, part, nranks, owner, coarsen_fn):
         dd.coarsen_rank(lv, part, r, nranks, owner=owner, topo=topo, exchange=probe, coarsen_fn=coarsen_fn)
     glob = np.max(np.stack(reported), axis=0)
     for a in reported:
-        assert np.all((a == 0) | (a == glob))                      # ranks sharing an entity agree on its coarse dofs
+        h = a.size // 2                                            # [counts | -counts where held] (one MAX carries max and min)
+        assert np.all((a[:h] == 0) | (a[:h] == glob[:h]))           # ranks sharing an entity agree on its coarse dofs
     pieces = [dd.coarsen_rank(lv, part, r, nranks, owner=owner, topo=topo, exchange=lambda local: glob, coarsen_fn=coarsen_fn)
               for r in range(nranks)]
     return topo, pieces
@@ -226,3 +227,26 @@ def test_two_ranks_print_the_serial_upscaling_errors_oracle_numerics():
 def test_two_ranks_print_the_serial_upscaling_errors_on_device():
     got, want = _two_rank_form1_errors(derham.coarsen)
     assert got == want
+
+
+def test_disagreement_on_a_shared_entity_raises_on_every_rank():
+    """the count exchange carries max AND min over the holders of an entity, so the rank with the larger count notices too and
+    no rank walks on into the next collective alone"""
+    n = (4, 4, 2)
+    lv = seq_level_from_hex(n, jstart=1)
+    part = box_partition(n, (2, 2, 2)).astype(np.int64)
+    owner = np.array([0, 1, 0, 1])
+    topo = derham.coarsen_topology(lv, part)
+    reported = []
+    for r in range(2):
+        dd.coarsen_rank(lv, part, r, 2, owner=owner, topo=topo, exchange=lambda a: (reported.append(a.copy()), a)[1], coarsen_fn=od.coarsen)
+    h = reported[0].size // 2
+    shared = np.flatnonzero((reported[0][:h] > 0) & (reported[1][:h] > 0))
+    assert shared.size > 0
+    tampered = [a.copy() for a in reported]
+    tampered[1][shared[0]] += 1                                    # rank 1 believes the shared entity has one more coarse dof
+    tampered[1][h + shared[0]] -= 1
+    glob = np.max(np.stack(tampered), axis=0)
+    for r in range(2):
+        with pytest.raises(RuntimeError, match="ranks disagree"):
+            dd.coarsen_rank(lv, part, r, 2, owner=owner, topo=topo, exchange=lambda a: glob, coarsen_fn=od.coarsen)

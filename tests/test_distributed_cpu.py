@@ -9,6 +9,7 @@ import scipy.sparse as sp
 
 from oracle import oracle as orc
 from parelag_amd import meshgen, partition
+from parelag_amd.distributed import free_port
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -62,7 +63,7 @@ def test_rcb_is_balanced():
 def test_world_size_2_gloo():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29613", os.path.join(ROOT, "tests", "dist_worker.py")]
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "DIST_WORKER_OK 2" in r.stdout
@@ -93,3 +94,28 @@ def test_distributed_darcy_blocks_reassemble(nparts):
     mesh = dar["seq"].meshes[0]
     assert np.all(own2[mesh.tet_faces] <= ep[:, None])
     assert np.array_equal(partition.entity_owners(mesh, ep, 3), ep)
+
+
+def test_bench_launches_its_own_ranks():
+    """``python bench.py --gpus 2`` with no launcher around it (WORLD_SIZE unset) must start two child ranks itself -- before
+    anything touches a GPU -- and rank 0 must report n_gpus = 2 (the driver's N=1 invocation style applied to N > 1)"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-dry-run"], capture_output=True, text=True,
+                       env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                     # stdout carries exactly the JSON line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["launch_dry_run"] is True
+    assert sorted(c["rank"] for c in rec["ranks"]) == [0, 1]
+    assert all(c["world_size"] == 2 for c in rec["ranks"])
+    assert len({c["pid"] for c in rec["ranks"]}) == 2                  # two child processes, neither of them this launcher
+    assert len({c["ppid"] for c in rec["ranks"]}) == 1
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-dry-run"], capture_output=True, text=True,
+                       env=env, timeout=120, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

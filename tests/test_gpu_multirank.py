@@ -2,6 +2,7 @@
 context, and exchange through the in-process communicator (elag_hip_comm_init_inprocess) -- halo exchange with
 interior/boundary overlap, reverse halo of MatvecT, all-reduce / all-gather, distributed hierarchies.  Only the RCCL
 wrappers themselves are not covered here."""
+import gc
 import threading
 import traceback
 
@@ -42,6 +43,18 @@ def run_ranks(world, fn):
         except Exception:
             errors.append(f"rank {rank}:\n{traceback.format_exc()}")
             barrier.abort()
+        finally:
+            # a rank thread owns a library context (streams, scratch slabs, the coarsening arena): give it back once every
+            # rank is past its last exchange, or the suite accumulates one context per thread ever started
+            try:
+                barrier.wait(timeout=120)
+            except threading.BrokenBarrierError:
+                pass
+            gc.collect()
+            try:
+                _lib.load().elag_hip_finalize()
+            except Exception:
+                pass
     threads = [threading.Thread(target=target, args=(r,)) for r in range(world)]
     for t in threads: t.start()
     for t in threads: t.join(timeout=300)

@@ -73,4 +73,23 @@ def test_bad_arguments():
     with pytest.raises(ElagHipError):
         la.partition_refined(10, 3)
     with pytest.raises(ElagHipError):
-        la.connected_components(np.array([0, -1], np.int32), sp.eye(2, format="csr"))
+        la.connected_components(np.array([0, 0], np.int32), sp.csr_matrix(([1.0], ([0], [5])), shape=(2, 6)))
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_connected_components_skips_unassigned_nodes(seed):
+    """part id -1 = "in no part" (connectedComponents.cpp:50-51,62-63: the sweep passes over such nodes): they keep their id,
+    never join or bridge a component, and the other nodes are numbered as if they were absent"""
+    seq = meshgen.Sequence.cube456(1)
+    conn = tet_adjacency(seq.meshes[0])
+    rng = np.random.default_rng(seed)
+    part = rng.integers(-1, 12, conn.shape[0]).astype(np.int32)
+    n_ref, p_ref = orc.connected_components(part, conn)
+    n_dev, p_dev = la.connected_components(part, conn)
+    assert n_dev == n_ref and np.array_equal(p_dev, p_ref)
+    assert np.array_equal(p_dev < 0, part < 0)
+    # same as the components of the graph with the unassigned nodes removed
+    keep = np.flatnonzero(part >= 0)
+    sub = conn[keep][:, keep].tocsr()
+    n_sub, p_sub = la.connected_components(part[keep], sub)
+    assert n_sub == n_dev and np.array_equal(p_sub, p_dev[keep])
