@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--roofline-refines", type=int, default=5, help="refinements for the HBM-bound SpMV measurement")
     ap.add_argument("--roofline-reps", type=int, default=50)
     ap.add_argument("--roofline-only", action="store_true", help="only run the fine-level SpMV launches (for rocprofv3)")
+    ap.add_argument("--roofline-form", choices=["stream", "xc"], default=None, help="force the roofline operator onto one form of the "
+                    "stream SpMV (A/B profiles); default: the library's own choice")
     ap.add_argument("--smoother", default="L1 Jacobi")
     ap.add_argument("--form", default="0", choices=["0", "1", "2", "darcy", "spe10"],
                     help="0: MultigridTest0Form (H1, the BASELINE metric); 1: MultigridTest1Form (H(curl), Hiptmair through the gradient); "
@@ -238,14 +240,41 @@ def main():
         n, nnz = A0.Height(), A0.nnz
         x = la.DeviceVector.from_numpy(np.random.default_rng(12345).uniform(-1, 1, n))
         y = la.DeviceVector(n)
+        if args.roofline_form:
+            # A/B runs: the same operator forced onto one kernel (-2 plain stream kernel, -1 its windowed x-cache form)
+            A0.set_spmv_lanes({"stream": -2, "xc": -1}[args.roofline_form])
         ms = la.time_kernel(A0, "spmv", x, y, reps=args.roofline_reps)
+        kern = A0.spmv_kernel()          # what the launch was dispatched to (the library's measured choice unless forced)
         b = spmv_bytes(n, n, nnz)
+        # parity of exactly the object that was timed: the device's y against scipy's product of the exported operator
+        t0 = time.time()
+        A0s = A0.to_scipy()
+        xh, yh = x.to_numpy(), y.to_numpy()
+        yref = A0s @ xh
+        yscale = abs(A0s) @ np.abs(xh)
+        roof_err = float(np.max(np.abs(yh - yref) / yscale))
+        note("roofline operator: %s, %.2f us, parity vs scipy %.1e (check %.1f s)" % (kern, ms * 1e3, roof_err, time.time() - t0))
+        if not roof_err <= 1e-12:
+            raise SystemExit("roofline kernel %s: y differs from scipy's A x by %.3e of |A||x| (> 1e-12)" % (kern, roof_err))
         if args.roofline_only:
             # only the launches of the one kernel, so a rocprofv3 --stats / --pmc pass of this command sees nothing else
             # under that kernel's name
-            print(json.dumps({"roofline": {"kernel": "spmv_xc_kernel", "n": n, "nnz": nnz, "bytes_per_launch": b,
-                                           "ms_per_launch": round(ms, 5), "achieved_GBs": round(b / ms / 1e6, 1)}}))
+            print(json.dumps({"roofline": {"kernel": kern, "n": n, "nnz": nnz, "bytes_per_launch": b,
+                                           "ms_per_launch": round(ms, 5), "achieved_GBs": round(b / ms / 1e6, 1),
+                                           "parity_roofline_rel_err": roof_err}}))
             return
+        # both forms of the stream SpMV on a private copy of the same operator, in this session (the hierarchy's own
+        # operator keeps the form its captured graph was built with)
+        ab = {}
+        Aab = la.ParallelCSRMatrix.from_scipy(A0s)
+        yab = la.DeviceVector(n)
+        for name, code in (("spmv_stream_kernel", -2), ("spmv_xc_kernel", -1)):
+            Aab.set_spmv_lanes(code)
+            t_ab = la.time_kernel(Aab, "spmv", x, yab, reps=args.roofline_reps)
+            assert Aab.spmv_kernel() == name, (Aab.spmv_kernel(), name)
+            e_ab = float(np.max(np.abs(yab.to_numpy() - yref) / yscale))
+            ab[name] = {"ms_per_launch": round(t_ab, 5), "GBs": round(b / (t_ab * 1e-3) / 1e9, 1), "rel_err_vs_scipy": e_ab}
+        del Aab, yab
         # the fine-level Galerkin product of the same problem (SURVEY 8d "RAP": bytes(A) + 2 bytes(P) + bytes(AP) written and
         # read + bytes(A_c)), caller's numbering, wall time around a synchronised call
         csr_bytes = lambda rows, nz: 12 * nz + 4 * (rows + 1)
@@ -265,7 +294,25 @@ def main():
             op = Hr.GetOperator(l)
             shapes_r.append((op.Height(), op.nnz, Pr[l].shape[1] if l < len(Pr) else 0, Pr[l].nnz if l < len(Pr) else 0))
         vb = vcycle_bytes(shapes_r)
-        roof = {"bound": "hbm", "kernel": "spmv_xc_kernel (windowed x-cache form of the stream SpMV; fine-level y = A x, level-0 operator of the hierarchy)",
+        kdesc = {"spmv_xc_kernel": "windowed x-cache form of the stream SpMV", "spmv_stream_kernel": "LDS-staged stream SpMV"}.get(kern, "row-group SpMV")
+        # a k-refinement V-cycle against the CPU oracle on the same hierarchy (bounded: one oracle cycle)
+        roof_cycle_err = None
+        if not args.no_cpu_baseline:
+            from oracle import oracle as orc
+            from tests.helpers import oracle_h1_hierarchy
+            t0 = time.time()
+            hr = oracle_h1_hierarchy(Ar, Pr, smoother=la.HYPRE_SMOOTHER_TYPES[args.smoother])
+            bb = np.full(n, 2.0); xo = np.empty(n); xd = np.empty(n)
+            orc.CHierarchy(hr["As"], hr["Ps"], hr["sms"], hr["chol"]).apply(bb, xo)
+            Hr.Mult(bb, xd)
+            roof_cycle_err = float(np.max(np.abs(xd - xo)) / np.max(np.abs(xo)))
+            note("cube456 x%d V-cycle vs oracle: %.1e (%.1f s)" % (k, roof_cycle_err, time.time() - t0))
+            del hr
+            if not roof_cycle_err <= 1e-10:
+                raise SystemExit("cube456 x%d V-cycle differs from the oracle by %.3e (> 1e-10)" % (k, roof_cycle_err))
+        roof = {"bound": "hbm", "kernel": f"{kern} ({kdesc}; fine-level y = A x, level-0 operator of the hierarchy; chosen by the library's setup-time "
+                                          "measurement of both forms on this operator)",
+                "parity_roofline_rel_err": roof_err, "parity_vcycle_rel_err_vs_oracle": roof_cycle_err, "forms_same_session": ab,
                 "workload": f"cube456 x{k} refines, H1 A: n={n}, nnz={nnz}",
                 "achieved": round(b / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
@@ -274,7 +321,6 @@ def main():
                 "jacobi_sweep_GBs": round((b + 16 * n) / (ms_j * 1e-3) / 1e9, 1),
                 "callers_numbering_GBs": round(b / (ms_nat * 1e-3) / 1e9, 1),
                 "rap": rap,
-                "rap": rap,
                 "vcycle_ms": round(ms_v, 4), "vcycles_per_s": round(1e3 / ms_v, 1),
                 "vcycle_GBs": round(vb / (ms_v * 1e-3) / 1e9, 1), "vcycle_frac": round(vb / (ms_v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "hierarchy_setup_s": round(setup_r, 3), "generate_s": round(gen_s, 1)}
@@ -282,8 +328,11 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("n") == n and tj.get("nnz") == nnz:
+            if tj.get("n") == n and tj.get("nnz") == nnz and tj.get("kernel", "spmv_xc_kernel") == kern:
+                # counters cannot be read from inside this process: the figure is the one RECORDED by the committed rocprofv3
+                # --pmc passes of `bench.py --roofline-only` for this kernel on this operator, not a measurement of this run
                 roof["traffic"] = tj["traffic_bytes_per_launch"]
+                roof["traffic_measured_in"] = "recorded"
                 roof["traffic_source"] = tj["source"]
         del Hr, A0, dAr, dPr, x, y, rhs_r, sol_r
 

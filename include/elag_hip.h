@@ -189,6 +189,11 @@ ELAG_HIP_API int elag_hip_parcsr_compare(elag_hip_parcsr_t A, elag_hip_parcsr_t 
  * 0 restores the size heuristic; -2 forces the LDS-staged stream kernel, -1 its windowed x-cache form).
  * No reference counterpart. */
 ELAG_HIP_API int elag_hip_parcsr_set_spmv_lanes(elag_hip_parcsr_t A, int lanes);
+/* Which SpMV kernel the diag block of A is dispatched to as of now: *form = 0 row-group kernel (spmv_fused_kernel; *lanes =
+ * lanes per row), 1 LDS-staged stream kernel (spmv_stream_kernel), 2 its windowed x-cache form (spmv_xc_kernel).  The x-cache
+ * decision is taken on the first launch (or at hierarchy Finalize); before that a stream-kernel matrix reports 1.
+ * Diagnostic (bench.py names the kernel it timed from this, not from a constant).  No reference counterpart. */
+ELAG_HIP_API int elag_hip_parcsr_get_spmv_form(elag_hip_parcsr_t A, int *form, int *lanes);
 /* a_ii of every local row -> d (device or host vector of num_rows) */
 ELAG_HIP_API int elag_hip_parcsr_get_diagonal(elag_hip_parcsr_t A, double *d, int loc);
 

@@ -101,6 +101,7 @@ _SIGNATURES = {
     "elag_hip_parcsr_compare": [_p, _p, _d, _ip],
     "elag_hip_parcsr_get_diagonal": [_p, _p, _i],
     "elag_hip_parcsr_set_spmv_lanes": [_p, _i],
+    "elag_hip_parcsr_get_spmv_form": [_p, _ip, _ip],
     "elag_hip_parcsr_spmv_boolint": [_p, _i, _p, _i, _p, _i],
     "elag_hip_parcsr_keep_equal_entries": [_p, _p],
     "elag_hip_partition_refined": [_i, _i, _i, _i, _p],

@@ -142,9 +142,9 @@ typedef int int4v __attribute__((ext_vector_type(4)));
 typedef double double2v __attribute__((ext_vector_type(2)));
 
 template <bool HAS_CS, int VARIANT>
-__global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
+__device__ __forceinline__ void spmv_stream_body(
     int nrows, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
-    const int *__restrict__ block_row, const int *__restrict__ oI, SpmvArgs p)
+    const int *__restrict__ block_row, const int *__restrict__ oI, const SpmvArgs &p)
 {
     extern __shared__ double prod[];
     // one 16-byte scalar load: (first row, first entry) of this block and of the next one
@@ -215,6 +215,23 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
     }
 }
 
+template <bool HAS_CS, int VARIANT>
+__global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
+    int nrows, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
+    const int *__restrict__ block_row, const int *__restrict__ oI, SpmvArgs p)
+{
+    spmv_stream_body<HAS_CS, VARIANT>(nrows, I, J, a, block_row, oI, p);
+}
+
+// The same code under another name: the launches of the setup-time measurement (prepare_spmv) must not be counted under
+// the production kernel's name by rocprofv3 --stats / --pmc.
+__global__ __launch_bounds__(kBlock) void spmv_probe_stream_kernel(
+    int nrows, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
+    const int *__restrict__ block_row, const int *__restrict__ oI, SpmvArgs p)
+{
+    spmv_stream_body<false, 0>(nrows, I, J, a, block_row, oI, p);
+}
+
 // ---- x-cache variant -------------------------------------------------------------------------------------------------
 // Same window decomposition and storage-order row sums as spmv_stream_kernel, but the gather is done once per DISTINCT
 // column of the window: phase 1 loads x (times cs) for the window's sorted unique columns into LDS (ascending addresses,
@@ -223,10 +240,10 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
 typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
 
 template <bool HAS_CS>
-__global__ __launch_bounds__(kBlock) void spmv_xc_kernel(
+__device__ __forceinline__ void spmv_xc_body(
     int nrows, const int *__restrict__ I, const double *__restrict__ a, const unsigned short *__restrict__ lidx,
     const int *__restrict__ block_row, const int *__restrict__ uoff, const int *__restrict__ ucols, const int *__restrict__ oI,
-    int cap, SpmvArgs p)
+    int cap, const SpmvArgs &p)
 {
     extern __shared__ double sh[];
     double *prod = sh, *xs = sh + cap;
@@ -312,6 +329,23 @@ __global__ __launch_bounds__(kBlock) void spmv_xc_kernel(
         p.out[row] = t;
         if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
     }
+}
+
+template <bool HAS_CS>
+__global__ __launch_bounds__(kBlock) void spmv_xc_kernel(
+    int nrows, const int *__restrict__ I, const double *__restrict__ a, const unsigned short *__restrict__ lidx,
+    const int *__restrict__ block_row, const int *__restrict__ uoff, const int *__restrict__ ucols, const int *__restrict__ oI,
+    int cap, SpmvArgs p)
+{
+    spmv_xc_body<HAS_CS>(nrows, I, a, lidx, block_row, uoff, ucols, oI, cap, p);
+}
+
+__global__ __launch_bounds__(kBlock) void spmv_probe_xc_kernel(
+    int nrows, const int *__restrict__ I, const double *__restrict__ a, const unsigned short *__restrict__ lidx,
+    const int *__restrict__ block_row, const int *__restrict__ uoff, const int *__restrict__ ucols, const int *__restrict__ oI,
+    int cap, SpmvArgs p)
+{
+    spmv_xc_body<false>(nrows, I, a, lidx, block_row, uoff, ucols, oI, cap, p);
 }
 
 // One workgroup per window: sort the window's columns in LDS (bitonic), mark the first element of every run, scan.
@@ -512,6 +546,52 @@ void prepare_spmv(const DevCSR &A, bool force)
     ELAG_LAUNCH_CHECK();
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
     A.xc_state = 1;
+    if (force || xc_mode() >= 0) return;
+    // Heuristic mode: both forms exist now, so let the operator itself decide.  A few launches of each on a scratch
+    // vector pair (HIP events on this stream); the x-cache form is kept only when it is measurably faster on THIS
+    // operator and THIS device -- the two are within a few per cent of each other and which one wins depends on how well
+    // the numbering clusters the columns of a window (profiles/r02_spmv_ab_*.txt).
+    {
+        Temp<double> tx((size_t)std::max(A.ncols, A.nrows)), ty((size_t)A.nrows);
+        ELAG_HIP_CHECK(hipMemsetAsync(tx, 0, sizeof(double) * (size_t)std::max(A.ncols, A.nrows), st));
+        SpmvArgs p;
+        p.x = tx; p.out = ty;
+        hipEvent_t e0, e1;
+        ELAG_HIP_CHECK(hipEventCreate(&e0));
+        ELAG_HIP_CHECK(hipEventCreate(&e1));
+        const int cap = DevCSR::kStreamNnz + A.max_row_nnz + 8;
+        const size_t lds_s = sizeof(double) * (size_t)cap, lds_x = sizeof(double) * ((size_t)cap + (size_t)A.xc_max_unique);
+        auto probe = [&](bool xc) {
+            if (xc)
+                hipLaunchKernelGGL(spmv_probe_xc_kernel, dim3((unsigned)A.nblocks), dim3(kBlock), lds_x, st, A.nrows, A.I, A.a, A.lidx, A.block_row,
+                                   A.uoff, A.ucols, (const int *)nullptr, cap, p);
+            else
+                hipLaunchKernelGGL(spmv_probe_stream_kernel, dim3((unsigned)A.nblocks), dim3(kBlock), lds_s, st, A.nrows, A.I, A.J, A.a, A.block_row,
+                                   (const int *)nullptr, p);
+        };
+        auto run = [&](bool xc) {
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; rep++) {
+                for (int w = 0; w < 2; w++) probe(xc);
+                ELAG_HIP_CHECK(hipEventRecord(e0, st));
+                for (int w = 0; w < 8; w++) probe(xc);
+                ELAG_LAUNCH_CHECK();
+                ELAG_HIP_CHECK(hipEventRecord(e1, st));
+                ELAG_HIP_CHECK(hipEventSynchronize(e1));
+                float ms = 0.f;
+                ELAG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                best = std::min(best, ms / 8);
+            }
+            return best;
+        };
+        const float t_stream = run(false), t_xc = run(true);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (getenv("ELAG_HIP_XC_VERBOSE"))
+            fprintf(stderr, "[elag_hip] x-cache autotune: stream %.2f us, x-cache %.2f us -> %s\n", t_stream * 1e3, t_xc * 1e3,
+                    t_xc < 0.99f * t_stream ? "x-cache" : "stream");
+        if (!(t_xc < 0.99f * t_stream)) { A.release_xc(); A.xc_state = -1; }
+    }
 }
 
 void spmv_fused(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, hipStream_t st)

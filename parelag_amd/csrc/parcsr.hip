@@ -617,6 +617,17 @@ int elag_hip_parcsr_set_spmv_lanes(elag_hip_parcsr_t A, int lanes)
     });
 }
 
+int elag_hip_parcsr_get_spmv_form(elag_hip_parcsr_t A, int *form, int *lanes)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(A && form, "null argument");
+        const DevCSR &D = A->diag;
+        const bool stream = D.lanes_per_row == 0 && D.block_row;
+        *form = stream ? (D.xc_state == 1 ? 2 : 1) : 0;
+        if (lanes) *lanes = D.lanes_per_row;
+    });
+}
+
 int elag_hip_parcsr_get_diagonal(elag_hip_parcsr_t A, double *d, int loc)
 {
     return guarded([&] {

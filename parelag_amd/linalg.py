@@ -265,6 +265,14 @@ class ParallelCSRMatrix:
     def set_spmv_lanes(self, lanes: int):
         check(self._lib.elag_hip_parcsr_set_spmv_lanes(self.h, int(lanes)))
 
+    SPMV_FORMS = {0: "spmv_fused_kernel", 1: "spmv_stream_kernel", 2: "spmv_xc_kernel"}
+
+    def spmv_kernel(self) -> str:
+        """name of the kernel ``Mult`` is dispatched to as of now (the x-cache decision is taken on the first launch)"""
+        form, lanes = C.c_int(0), C.c_int(0)
+        check(self._lib.elag_hip_parcsr_get_spmv_form(self.h, C.byref(form), C.byref(lanes)))
+        return self.SPMV_FORMS[form.value] + ("<%d>" % lanes.value if form.value == 0 else "")
+
     def get_diagonal(self):
         d = np.empty(self.Height())
         check(self._lib.elag_hip_parcsr_get_diagonal(self.h, _np_ptr(d), HOST))

@@ -720,3 +720,52 @@ def test_hcurl_hiptmair_vcycle_and_pcg_match_the_oracle():
     ref = orc.mfem_cg(lambda v: A @ v, lambda r, z: Hc.apply(r, z), rhs, xo, rel_tol=1e-8, max_iter=100)
     assert K.GetConverged() and K.GetNumIterations() == ref.final_iter and ref.final_iter < 40
     assert np.max(np.abs(xs - xo)) <= 1e-8 * np.max(np.abs(xo))
+
+
+# ---- the object bench.py's roofline is quoted on: a >= 2^24-entry hierarchy with the library's own choices --------------------
+
+def test_roofline_size_hierarchy_with_default_heuristics(la):
+    """cube456 x5 (37.7 M entries): nothing is forced -- automatic renumbering, the setup-time choice between the stream kernel and
+    its x-cache form, fused levels, graph.  The level-0 operator exactly as the cycle runs it is checked against scipy's product
+    (<= 1e-12 of |A||x|), the caller's-numbering product likewise, both forced forms on the same operator, and the V-cycle
+    against the CPU oracle."""
+    from parelag_amd import meshgen
+    A, Ps, _ = meshgen.h1_problem(5)
+    assert A.nnz >= (1 << 24)
+    n = A.shape[0]
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi")
+    A0 = H.GetOperator(0)
+    rng = np.random.default_rng(12345)
+    xh = rng.uniform(-1, 1, n)
+    x, y = la.DeviceVector.from_numpy(xh), la.DeviceVector(n)
+    A0.Mult(x, y)
+    assert A0.spmv_kernel() in ("spmv_stream_kernel", "spmv_xc_kernel")          # an HBM-streaming form, chosen by measurement
+    A0s = A0.to_scipy()
+    assert A0s.nnz == A.nnz
+    ref, scale = A0s @ xh, abs(A0s) @ np.abs(xh)
+    assert np.max(np.abs(y.to_numpy() - ref) / scale) <= 1e-12
+    # the internal operator is a symmetric permutation of the caller's
+    order = H.GetOrdering(0)
+    assert np.array_equal(np.sort(order), np.arange(n))
+    Aperm = sp.csr_matrix(A)[order][:, order].tocsr()
+    Aperm.sort_indices(); A0s.sort_indices()
+    assert np.array_equal(Aperm.indptr, A0s.indptr) and np.array_equal(Aperm.indices, A0s.indices) and np.array_equal(Aperm.data, A0s.data)
+    yn = np.empty(n)
+    dA.Mult(xh, yn)
+    assert np.max(np.abs(yn - A @ xh) / (abs(A) @ np.abs(xh))) <= 1e-12
+    # both forms, forced, on a private copy of the internal operator
+    B = la.ParallelCSRMatrix.from_scipy(A0s)
+    for code, name in ((-2, "spmv_stream_kernel"), (-1, "spmv_xc_kernel")):
+        B.set_spmv_lanes(code)
+        B.Mult(x, y)
+        assert B.spmv_kernel() == name
+        assert np.max(np.abs(y.to_numpy() - ref) / scale) <= 1e-12
+    # V-cycle vs the oracle
+    h = oracle_h1_hierarchy(A, Ps)
+    b = rng.uniform(-1, 1, n)
+    xd, xo = np.full(n, 3.0), np.empty(n)
+    H.Mult(b, xd)
+    orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"]).apply(b, xo)
+    assert np.max(np.abs(xd - xo)) <= 1e-11 * np.max(np.abs(xo))

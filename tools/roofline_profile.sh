@@ -1,57 +1,66 @@
 #!/bin/bash
-# rocprofv3 evidence for bench.py's roofline object (run on the GPU box from the repo root):
-#   1. --kernel-trace --stats of bench.py --roofline-only    -> mean duration of spmv_xc_kernel
-#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE of the same command (separate passes)
-#   3. --pmc FETCH_SIZE of tools/calibrate_fetch.py              -> gfx950 FETCH_SIZE correction for this access pattern
-# usage: tools/roofline_profile.sh <tag>      (writes gpurun_out/<tag>/summary.txt and roofline_traffic.json)
-TAG=${1:-roofline_r01}
+# rocprofv3 evidence for bench.py's roofline object (run on the GPU box from the repo root), all in ONE session:
+#   for every form in $FORMS (auto = the library's own choice, stream / xc = that kernel forced on the same operator)
+#     1. --kernel-trace --stats of bench.py --roofline-only [--roofline-form F]   -> mean duration of the kernel
+#     2. --pmc FETCH_SIZE and --pmc WRITE_SIZE of the same command (separate passes, no trace domains beside them)
+#   3. --pmc FETCH_SIZE of tools/calibrate_fetch.py  -> gfx950 FETCH_SIZE correction for this access pattern
+# usage: tools/roofline_profile.sh <tag> [forms...]   (writes gpurun_out/<tag>/summary_<form>.txt, roofline_traffic.json for "auto")
+TAG=${1:-roofline_r02}; shift
+FORMS=${@:-auto stream xc}
 REPO=$PWD; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/bench.py --roofline-only > $OUT/kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $REPO/bench.py --roofline-only > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $REPO/bench.py --roofline-only > $OUT/write.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/calib -- python3 $REPO/tools/calibrate_fetch.py 5 > $OUT/calib.log 2>&1
+for F in $FORMS; do
+  ARG=""; [ "$F" != "auto" ] && ARG="--roofline-form $F"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$F -- python3 $REPO/bench.py --roofline-only $ARG > $OUT/kt_$F.log 2>&1 || { tail -5 $OUT/kt_$F.log; exit 1; }
+  echo "[roofline_profile] $F kernel trace done"
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$F -- python3 $REPO/bench.py --roofline-only $ARG > $OUT/fetch_$F.log 2>&1 || { tail -5 $OUT/fetch_$F.log; exit 1; }
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$F -- python3 $REPO/bench.py --roofline-only $ARG > $OUT/write_$F.log 2>&1 || { tail -5 $OUT/write_$F.log; exit 1; }
+  echo "[roofline_profile] $F counters done"
+done
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/calib -- python3 $REPO/tools/calibrate_fetch.py 5 > $OUT/calib.log 2>&1 || { tail -5 $OUT/calib.log; exit 1; }
 cd $REPO
-python3 - <<PY
-import csv, glob, json, collections
-out = "$OUT"
-L = []
-KERN = "spmv_xc_kernel"        # the kernel bench.py --roofline-only launches (windowed x-cache form of the stream SpMV)
-def stats():
-    for f in sorted(glob.glob(out + "/kt/**/*kernel_stats.csv", recursive=True)):
+python3 - "$OUT" $FORMS <<'PY'
+import csv, glob, json, sys
+out, forms = sys.argv[1], sys.argv[2:]
+def stats(d, kern):
+    for f in sorted(glob.glob(out + f"/{d}/**/*kernel_stats.csv", recursive=True)):
         for r in csv.DictReader(open(f)):
-            if KERN in r["Name"]:
-                return int(r["Calls"]), float(r["AverageNs"])
-    return 0, 0.0
-def pmc(d, counter, kern=None):
-    kern = kern or KERN
+            if kern in r["Name"]:
+                return int(r["Calls"]), float(r["AverageNs"]), r["Name"]
+    return 0, 0.0, ""
+def pmc(d, counter, kern):
     s = n = 0
     for f in glob.glob(out + f"/{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if kern in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 s += float(r["Counter_Value"]); n += 1
     return s / max(n, 1), n
-calls, avg_ns = stats()
-bench = json.loads([l for l in open(out + "/kt.log") if l.startswith("{")][-1])["roofline"]
-fetch_kb, nf = pmc("fetch", "FETCH_SIZE")
-write_kb, nw = pmc("write", "WRITE_SIZE")
-cal_kb, nc = pmc("calib", "FETCH_SIZE", "spmv_stream_kernel")
 cal = json.loads([l for l in open(out + "/calib.log") if l.startswith("{")][-1])
+cal_kb, nc = pmc("calib", "FETCH_SIZE", "spmv_stream_kernel")
 factor = cal["known_read_bytes"] / (cal_kb * 1024.0)
-traffic = factor * fetch_kb * 1024.0 + write_kb * 1024.0
-L.append("# rocprofv3 evidence for bench.py's roofline object -- command: python3 bench.py --roofline-only")
-L.append(f"kernel: {KERN}<false>  (level-0 operator of the cube456 x5 hierarchy, n={bench['n']}, nnz={bench['nnz']})")
-L.append(f"rocprofv3 --kernel-trace --stats: calls={calls}  AverageNs={avg_ns:.1f}  ({avg_ns/1e3:.2f} us)")
-L.append(f"bench.py HIP events (same run):  ms_per_launch={bench['ms_per_launch']}  ({bench['ms_per_launch']*1e3:.2f} us), algorithmic bytes/launch={bench['bytes_per_launch']}")
-L.append(f"achieved = {bench['bytes_per_launch']/avg_ns:.1f} GB/s by rocprof mean, {bench['achieved_GBs']} GB/s by HIP events; peak 8000 GB/s (HBM3E spec), 6290 GB/s measured copy")
-L.append(f"--pmc FETCH_SIZE (own pass): mean {fetch_kb:.1f} KB per launch over {nf} launches")
-L.append(f"--pmc WRITE_SIZE (own pass): mean {write_kb:.1f} KB per launch over {nw} launches")
-L.append(f"calibration (tools/calibrate_fetch.py: plain stream kernel on the same operator, all column indices 0 => HBM reads are exactly {cal['known_read_bytes']} B): FETCH_SIZE {cal_kb:.1f} KB over {nc} launches -> correction factor {factor:.4f}")
-L.append(f"traffic per launch = factor * FETCH_SIZE + WRITE_SIZE = {traffic:.0f} B = {traffic/bench['bytes_per_launch']:.3f} x algorithmic")
-open(out + "/summary.txt", "w").write("\n".join(L) + "\n")
-json.dump({"n": bench["n"], "nnz": bench["nnz"], "traffic_bytes_per_launch": int(traffic), "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
-           "fetch_correction_factor": factor, "rocprof_avg_ns": avg_ns,
-           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of bench.py --roofline-only, FETCH_SIZE calibrated per MI355X_MICROARCH.md (profiles/r01_roofline_spmv.txt)"},
-          open(out + "/roofline_traffic.json", "w"), indent=1)
-print("\n".join(L))
+for F in forms:
+    bench = json.loads([l for l in open(out + f"/kt_{F}.log") if l.startswith("{")][-1])["roofline"]
+    kern = bench["kernel"]
+    calls, avg_ns, full = stats(f"kt_{F}", kern)
+    fetch_kb, nf = pmc(f"fetch_{F}", "FETCH_SIZE", kern)
+    write_kb, nw = pmc(f"write_{F}", "WRITE_SIZE", kern)
+    traffic = factor * fetch_kb * 1024.0 + write_kb * 1024.0
+    L = [f"# rocprofv3 evidence for bench.py's roofline object -- command: python3 bench.py --roofline-only" + ("" if F == "auto" else f" --roofline-form {F}"),
+         f"kernel: {full or kern}  ({'the library chose it' if F == 'auto' else 'forced'}; level-0 operator of the cube456 x5 hierarchy, n={bench['n']}, nnz={bench['nnz']})",
+         f"parity of the timed launch vs scipy (same run): {bench['parity_roofline_rel_err']:.2e} of |A||x|",
+         f"rocprofv3 --kernel-trace --stats: calls={calls}  AverageNs={avg_ns:.1f}  ({avg_ns/1e3:.2f} us)",
+         f"bench.py HIP events (same run):  ms_per_launch={bench['ms_per_launch']}  ({bench['ms_per_launch']*1e3:.2f} us), algorithmic bytes/launch={bench['bytes_per_launch']}",
+         f"achieved = {bench['bytes_per_launch']/avg_ns:.1f} GB/s by rocprof mean ({bench['bytes_per_launch']/avg_ns/8000:.4f} of 8000 GB/s), {bench['achieved_GBs']} GB/s by HIP events; measured copy peak 6290 GB/s",
+         f"--pmc FETCH_SIZE (own pass): mean {fetch_kb:.1f} KB per launch over {nf} launches",
+         f"--pmc WRITE_SIZE (own pass): mean {write_kb:.1f} KB per launch over {nw} launches",
+         f"calibration (tools/calibrate_fetch.py: plain stream kernel on the same operator, all column indices 0 => HBM reads are exactly {cal['known_read_bytes']} B): FETCH_SIZE {cal_kb:.1f} KB over {nc} launches -> correction factor {factor:.4f}",
+         f"traffic per launch = factor * FETCH_SIZE + WRITE_SIZE = {traffic:.0f} B = {traffic/bench['bytes_per_launch']:.3f} x algorithmic"]
+    open(out + f"/summary_{F}.txt", "w").write("\n".join(L) + "\n")
+    print("\n".join(L)); print()
+    if F == "auto":
+        json.dump({"n": bench["n"], "nnz": bench["nnz"], "kernel": kern, "traffic_bytes_per_launch": int(traffic), "fetch_size_kb": fetch_kb,
+                   "write_size_kb": write_kb, "fetch_correction_factor": factor, "rocprof_avg_ns": avg_ns,
+                   "source": "RECORDED, not measured in the bench run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --roofline-only, FETCH_SIZE "
+                             "calibrated per MI355X_MICROARCH.md (tools/roofline_profile.sh; summary under profiles/)"},
+                  open(out + "/roofline_traffic.json", "w"), indent=1)
 PY
