@@ -178,6 +178,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-gs", action="store_true", help="skip the L1 Gauss-Seidel cycle reported beside the headline one")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--solve", action="store_true", help="also time the Krylov solve of the example (PCG / GMRES with the cycle as "
                                                         "preconditioner, device-resident) and report it under \"solve\"")
@@ -492,6 +493,36 @@ def main():
         fine = {"n": n0, "nnz": nnz0, "bytes_per_launch": b0, "us_per_launch": round(ms0 * 1e3, 2),
                 "achieved_GBs": round(b0 / (ms0 * 1e-3) / 1e9, 1), "note": "operator is cache resident (L2/Infinity Cache), not an HBM figure"}
 
+    # ---------------------------------------------------------------- the reference's shipped relaxation beside the headline one
+    gs = None
+    if single and args.form == 0 and not (args.amge or args.hex) and args.smoother != "L1 Gauss-Seidel" and not args.no_gs:
+        # "L1 Gauss-Seidel" (hypre relax type 2) is what every parameter list of the reference selects
+        # (Create0FormParameterList.hpp:103-116); on the device it runs as level-scheduled sweeps (csrc/sweep.hip)
+        t0 = time.time()
+        Hgs = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Gauss-Seidel", use_graph=not args.no_graph)
+        la.synchronize()
+        gs_setup = time.time() - t0
+        sol_gs = la.DeviceVector(n_local, 1.0)
+        ms_gs = Hgs.time_apply(rhs, sol_gs, max(50, min(args.steps, 500)))
+        gs = {"smoother": "L1 Gauss-Seidel (hypre relax type 2, 1 symmetric sweep pre/post)", "device_ms_per_step": round(ms_gs, 5),
+              "vcycles_per_s": round(1e3 / ms_gs, 1), "setup_s": round(gs_setup, 3)}
+        if not args.no_cpu_baseline:
+            from oracle import oracle as orc
+            from tests.helpers import oracle_h1_hierarchy
+            hg = oracle_h1_hierarchy(A, Ps, smoother=2)
+            Hcg = orc.CHierarchy(hg["As"], hg["Ps"], hg["sms"], hg["chol"], native=True)
+            bb = np.full(A.shape[0], 2.0); xg = np.empty_like(bb)
+            Hcg.apply(bb, xg)
+            cg, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < min(3.0, args.cpu_seconds):
+                for _ in range(5):
+                    Hcg.apply(bb, xg)
+                cg += 5
+            gs["cpu_port_vcycles_per_s_1core"] = round(cg / (time.perf_counter() - t0), 1)
+            gs["parity_rel_err_vs_oracle"] = float(np.max(np.abs(sol_gs.to_numpy() - xg)) / np.max(np.abs(xg)))
+        note("L1 Gauss-Seidel cycle: %.4f ms" % ms_gs)
+        del Hgs, sol_gs
+
     # ---------------------------------------------------------------- optional: the example's Krylov solve on the device
     solve = None
     if args.solve and single:
@@ -714,6 +745,8 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         })
+        if gs is not None:
+            out["l1_gauss_seidel_cycle"] = gs
         if solve is not None:
             out["solve"] = solve
         if not darcy and (args.amge or args.hex):

@@ -53,9 +53,15 @@ enum {
 };
 
 /* hypre relax types accepted by elag_hip_smoother_create -- the string->type table of
- * src/linalg/factories/ParELAG_HypreSmootherFactory.cpp:92-109.  Types that are sequential per rank
- * (l1-GS = 2, GS = 6, ...) are rejected with ELAG_HIP_ERR_ARG: GPU configurations select 1 or 16. */
-enum { ELAG_HIP_SMOOTHER_JACOBI = 0, ELAG_HIP_SMOOTHER_L1_JACOBI = 1, ELAG_HIP_SMOOTHER_CHEBYSHEV = 16 };
+ * src/linalg/factories/ParELAG_HypreSmootherFactory.cpp:92-109.  The Gauss-Seidel types (2 = the reference's shipped default
+ * "L1 Gauss-Seidel", 4 = "L1 Gauss-Seidel Truncated", 6 = "Gauss-Seidel") run as level-scheduled forward + backward sweeps with
+ * the sequential loop's results ("Damping Factor" = "Omega" = 1.0 only: hypre's SSOR branches are not built); 413 = "Hypre
+ * Jacobi" (mfem::HypreDiagScale, ParELAG_HypreSmootherFactory.cpp:28-31).  Kaczmarz (3), Lumped Jacobi (5), Taubin (1001) and
+ * FIR (1002) are rejected with ELAG_HIP_ERR_ARG. */
+enum {
+    ELAG_HIP_SMOOTHER_JACOBI = 0, ELAG_HIP_SMOOTHER_L1_JACOBI = 1, ELAG_HIP_SMOOTHER_L1_GS = 2, ELAG_HIP_SMOOTHER_L1_GS_TRUNCATED = 4,
+    ELAG_HIP_SMOOTHER_GS = 6, ELAG_HIP_SMOOTHER_CHEBYSHEV = 16, ELAG_HIP_SMOOTHER_HYPRE_JACOBI = 413
+};
 
 /* --------------------------------------------------------------------------------------------------
  * Library / device / communicator

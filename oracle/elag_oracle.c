@@ -194,6 +194,39 @@ ORC_API void orc_l1gs_sweep(int n, const int *dI, const int *dJ, const double *d
     }
 }
 
+/* hypre_BoomerAMGRelax relax_type 6 [3P parcsr_ls/par_relax.c], reached from hypre_ParCSRRelax's default branch for
+ * mfem::HypreSmoother::GS = 6 ("Gauss-Seidel", ParELAG_HypreSmootherFactory.cpp:99), relax_points = 0, relax_weight = omega = 1,
+ * one thread: hybrid symmetric Gauss-Seidel -- ghost values frozen for the sweep, forward then backward over the local rows,
+ * u_i = (f_i - sum_{j != i} a_ij u_j) / a_ii with a_ii the FIRST stored entry of the diag row (hypre's storage convention),
+ * rows with a zero diagonal left alone. */
+ORC_API void orc_gs_sweep(int n, const int *dI, const int *dJ, const double *da,
+                          const int *oI, const int *oJ, const double *oa,
+                          const double *f, const double *uext, double *u)
+{
+    int i, jj;
+    for (i = 0; i < n; i++) {
+        if (dI[i + 1] > dI[i] && da[dI[i]] != 0.0) {
+            double res = f[i];
+            for (jj = dI[i] + 1; jj < dI[i + 1]; jj++) res -= da[jj] * u[dJ[jj]];
+            if (oI) for (jj = oI[i]; jj < oI[i + 1]; jj++) res -= oa[jj] * uext[oJ[jj]];
+            u[i] = res / da[dI[i]];
+        }
+    }
+    for (i = n - 1; i > -1; i--) {
+        if (dI[i + 1] > dI[i] && da[dI[i]] != 0.0) {
+            double res = f[i];
+            for (jj = dI[i] + 1; jj < dI[i + 1]; jj++) res -= da[jj] * u[dJ[jj]];
+            if (oI) for (jj = oI[i]; jj < oI[i + 1]; jj++) res -= oa[jj] * uext[oJ[jj]];
+            u[i] = res / da[dI[i]];
+        }
+    }
+}
+
+/* HYPRE_ParCSRDiagScale(NULL, A, y, x) [3P parcsr_ls/HYPRE_parcsr_pcg.c]: x_i = y_i / a_ii (first stored entry), whatever x held --
+ * mfem::HypreDiagScale, the solver behind "Hypre Jacobi" = 413 (ParELAG_HypreSmootherFactory.cpp:28-31). */
+ORC_API void orc_diag_scale(int n, const int *dI, const double *da, const double *y, double *x)
+{ for (int i = 0; i < n; i++) x[i] = y[i] / da[dI[i]]; }
+
 /* ------------------------------------------------------------------------------------------------
  * Chebyshev coefficients of hypre_ParCSRRelax_Cheby(A,f,max,min,fraction,order,scale=1,variant=0,...)
  * [3P par_cheby.c], reached with "Cheby Poly Order"/"Cheby Poly Fraction"
@@ -615,10 +648,10 @@ typedef struct {
 } orc_csr;
 
 typedef struct {
-    int type;              /* 1, 2 or 16 */
+    int type;              /* 1, 2, 4, 6, 16 or 413 */
     int sweeps;
     double weight;         /* "Damping Factor" */
-    const double *l1;      /* types 1,2 */
+    const double *l1;      /* types 1, 2, 4 */
     int cheby_order;       /* = order-1 (type 16) */
     double coefs[5];
     const double *ds;      /* type 16 */
@@ -653,8 +686,12 @@ static void smoother_apply(const orc_csr *A, const orc_smoother *s, const double
             memcpy(v, f, sizeof(double) * (size_t)n);
             orc_csr_matvec(n, A->I, A->J, A->a, -s->weight, u, s->weight, v);
             orc_jacobi_update(n, v, s->l1, u);
-        } else if (s->type == 2) {
+        } else if (s->type == 2 || s->type == 4) {
             orc_l1gs_sweep(n, A->I, A->J, A->a, NULL, NULL, NULL, f, s->l1, NULL, u);
+        } else if (s->type == 6) {
+            orc_gs_sweep(n, A->I, A->J, A->a, NULL, NULL, NULL, f, NULL, u);
+        } else if (s->type == 413) {
+            orc_diag_scale(n, A->I, A->a, f, u);
         } else { /* 16 */
             int co = s->cheby_order;
             orc_csr_matvec(n, A->I, A->J, A->a, -1.0, u, 0.0, z);

@@ -373,7 +373,9 @@ def compare(A: OParCSR, B: OParCSR, tol: float) -> int:
 
 class OSmoother:
     """mfem::HypreSmoother as driven by HypreSmootherWrapper (ParELAG_HypreSmootherWrapper.cpp:28-34):
-    types 1 (l1-Jacobi), 2 (l1-GS), 16 (Chebyshev).  ``iterative_mode`` as in mfem::Solver."""
+    types 1 (l1-Jacobi), 2 / 4 (l1-GS, l1 norms option 2 / 4, relax_weight = omega = 1), 6 (hybrid symmetric GS),
+    16 (Chebyshev) and 413 ("Hypre Jacobi" = mfem::HypreDiagScale, HypreSmootherFactory.cpp:28-31).  ``iterative_mode`` as in
+    mfem::Solver.  Not restated: 0 (plain Jacobi through BoomerAMGRelax), 3 (Kaczmarz), 5 (lumped Jacobi), 1001 / 1002 (Taubin / FIR)."""
 
     def __init__(self, A: OParCSR, type=1, sweeps=1, weight=1.0, omega=1.0, order=2, fraction=0.3,
                  eig=None):
@@ -381,6 +383,8 @@ class OSmoother:
         self.order, self.fraction = order, fraction
         self.iterative_mode = True
         n = A.shape[0]
+        if type in (2, 4, 6) and (weight != 1.0 or omega != 1.0):
+            raise NotImplementedError("the SSOR branches of hypre's Gauss-Seidel relaxations (relax_weight or omega != 1) are not restated")
         if type in (1, 2, 3, 4):
             self.l1 = l1_norms(A.diag, A.offd, option=type)
         if type == 16:
@@ -400,7 +404,15 @@ class OSmoother:
                 v = f.copy()
                 A.matvec(-self.weight, u, self.weight, v)
                 L.orc_jacobi_update(C.c_int(n), _dp(v), _dp(self.l1), _dp(u))
-            elif self.type == 2:
+            elif self.type == 6:
+                ue = A.ghost(u)
+                has = A.offd.shape[1] > 0
+                L.orc_gs_sweep(C.c_int(n), _ip(A.diag.indptr), _ip(A.diag.indices), _dp(A.diag.data),
+                               _ip(A.offd.indptr) if has else None, _ip(A.offd.indices) if has else None,
+                               _dp(A.offd.data) if has else None, _dp(f), _dp(ue), _dp(u))
+            elif self.type == 413:
+                L.orc_diag_scale(C.c_int(n), _ip(A.diag.indptr), _dp(A.diag.data), _dp(f), _dp(u))
+            elif self.type in (2, 4):
                 ue = A.ghost(u)
                 has = A.offd.shape[1] > 0
                 L.orc_l1gs_sweep(C.c_int(n), _ip(A.diag.indptr), _ip(A.diag.indices), _dp(A.diag.data),

@@ -109,6 +109,25 @@ void par_spmv(ParCSR &A, k::SpmvArgs a)
     }
 }
 
+void par_halo_exchange(ParCSR &A, const double *x)
+{
+    Context &c = ctx();
+    if (!A.needs_exchange()) return;
+    const int st = A.send_total();
+    if (st) {
+        const unsigned g = (unsigned)std::min<long long>(((long long)st + 255) / 256, 1024);
+        hipLaunchKernelGGL(gather_scaled_kernel, dim3(g), dim3(256), 0, c.stream, st, (const int *)A.d_send_elmts, x, (const double *)nullptr,
+                           A.d_send_buf);
+        ELAG_LAUNCH_CHECK();
+    }
+    ELAG_HIP_CHECK(hipEventRecord(c.ev_pack, c.stream));
+    ELAG_HIP_CHECK(hipStreamWaitEvent(c.comm_stream, c.ev_pack, 0));
+    comm_neighbor_exchange(A.d_send_buf, (int)A.send_procs.size(), A.send_procs.data(), A.send_starts.data(), A.d_ghost,
+                           (int)A.recv_procs.size(), A.recv_procs.data(), A.recv_starts.data(), sizeof(double), c.comm_stream);
+    ELAG_HIP_CHECK(hipEventRecord(c.ev_halo, c.comm_stream));
+    ELAG_HIP_CHECK(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
+}
+
 // y += alpha * (reverse halo of A.d_rev_send): ghost-column contributions go back to their owners
 // (hypre_ParCSRMatrixMatvecT, comm job 2, hypre_ParCSRMatrixMatvecBoolInt.c:296-323).
 void reverse_halo_start(ParCSR &A)

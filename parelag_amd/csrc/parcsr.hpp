@@ -45,6 +45,8 @@ typedef elag_hip_parcsr_s ParCSR;
 // out_i = beta*yin_i + s_i*(gamma*f_i + alpha*s2_i*(A x)_i) with the halo exchange overlapped with the
 // interior rows.  `a.x` is the local vector (length ncols of diag); a.xg / a.csg are filled in here.
 void par_spmv(ParCSR &A, k::SpmvArgs a);
+// A.d_ghost <- the ghost values of the local vector x (pack, neighbour exchange on the comm stream, compute stream waits)
+void par_halo_exchange(ParCSR &A, const double *x);
 // y = alpha*A^T x + beta*y  (x: local rows, y: local columns of diag)
 // `row_scale` (optional, rank-local operators only): y_i = row_scale_i * (alpha*(A^T x)_i) + beta*y_i
 void par_spmvT(ParCSR &A, double alpha, const double *x, double beta, double *y, const double *row_scale = nullptr);

@@ -58,8 +58,9 @@ void RelaxSmoother::setup()
         compute_coefs();
     } else {
         fail(ELAG_HIP_ERR_ARG,
-             "relax type %d is not available on the device (sequential per rank); GPU configurations select "
-             "\"L1 Jacobi\" (1), \"Jacobi\" (0) or \"Chebyshev\" (16)", type);
+             "relax type %d is not available on the device: the table of ParELAG_HypreSmootherFactory.cpp:92-109 is served for "
+             "\"Jacobi\" (0), \"L1 Jacobi\" (1), \"L1 Gauss-Seidel\" (2), \"L1 Gauss-Seidel Truncated\" (4), \"Gauss-Seidel\" (6), "
+             "\"Chebyshev\" (16) and \"Hypre Jacobi\" (413)", type);
     }
     ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
 }
@@ -388,6 +389,19 @@ int elag_hip_smoother_create(elag_hip_smoother_t *out, elag_hip_parcsr_t A, int 
         ELAG_REQUIRE(out && A, "null argument");
         ELAG_REQUIRE(A->nrows() == A->ncols(), "smoother needs a square operator (%d x %d)", A->nrows(), A->ncols());
         ELAG_REQUIRE(sweeps >= 1, "Sweeps must be >= 1");
+        if (relax_type == ELAG_HIP_SMOOTHER_L1_GS || relax_type == ELAG_HIP_SMOOTHER_L1_GS_TRUNCATED || relax_type == ELAG_HIP_SMOOTHER_GS) {
+            std::unique_ptr<SweepSmoother> G(new SweepSmoother());
+            G->A = A; G->type = relax_type; G->sweeps = sweeps; G->weight = damping; G->omega = omega;
+            G->setup();
+            *out = G.release();
+            return;
+        }
+        if (relax_type == ELAG_HIP_SMOOTHER_HYPRE_JACOBI) {
+            std::unique_ptr<DiagScaleSmoother> G(new DiagScaleSmoother());
+            G->A = A;
+            *out = G.release();
+            return;
+        }
         std::unique_ptr<RelaxSmoother> S(new RelaxSmoother());
         S->A = A; S->type = relax_type; S->sweeps = sweeps; S->weight = damping; S->omega = omega;
         S->order = cheby_order; S->fraction = cheby_fraction;

@@ -46,6 +46,33 @@ struct RelaxSmoother : elag_hip_smoother_s {
     }
 };
 
+// hypre relax types 2 / 4 (l1 Gauss-Seidel, plain / truncated l1 norms) and 6 (hybrid symmetric Gauss-Seidel): level-scheduled
+// forward + backward sweeps in place (sweep.hip)
+struct SweepSmoother : elag_hip_smoother_s {
+    struct Segment { int first, count, max_rows; };   // levels [first, first + count), largest level in it
+    int type = 2, sweeps = 1, num_levels = 0;
+    double weight = 1.0, omega = 1.0;
+    int *d_rows = nullptr, *d_lev_ptr = nullptr;      // rows sorted by (level, row); level offsets into it
+    double *d_l1 = nullptr;                           // types 2 / 4
+    std::vector<Segment> segments;
+    ~SweepSmoother() override;
+    void setup();
+    void launch_segment(const Segment &s, int dir, const double *f, double *u);
+    void apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose) override;
+    int flips(bool) const override { return 0; }
+    bool same_scaling_as(const elag_hip_smoother_s *o) const override
+    {
+        const SweepSmoother *r = dynamic_cast<const SweepSmoother *>(o);
+        return r && r->A == A && r->type == type && r->sweeps == sweeps;
+    }
+};
+
+// "Hypre Jacobi" = 413 -> mfem::HypreDiagScale (ParELAG_HypreSmootherFactory.cpp:28-31): sol = rhs ./ diag(A), whatever sol held
+struct DiagScaleSmoother : elag_hip_smoother_s {
+    void apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose) override;
+    int flips(bool) const override { return 0; }
+};
+
 struct HiptmairSmoother : elag_hip_smoother_s {
     ParCSR *D = nullptr;
     elag_hip_smoother_s *primary = nullptr, *aux = nullptr;

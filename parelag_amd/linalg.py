@@ -343,7 +343,7 @@ def Compare(A: ParallelCSRMatrix, B: ParallelCSRMatrix, tol: float) -> int:
 # string -> hypre relax type, the table of src/linalg/factories/ParELAG_HypreSmootherFactory.cpp:92-109
 HYPRE_SMOOTHER_TYPES = {
     "Jacobi": 0, "L1 Jacobi": 1, "L1 Gauss-Seidel": 2, "Kaczmarz": 3, "L1 Gauss-Seidel Truncated": 4,
-    "Lumped Jacobi": 5, "Gauss-Seidel": 6, "Chebyshev": 16, "Taubin": 1001, "FIR": 1002,
+    "Lumped Jacobi": 5, "Gauss-Seidel": 6, "Chebyshev": 16, "Taubin": 1001, "FIR": 1002, "Hypre Jacobi": 413,
 }
 
 

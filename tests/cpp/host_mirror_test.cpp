@@ -134,8 +134,22 @@ int main()
     try { auto bad = RAP(*A, *P[1]); } catch (const std::runtime_error &) { threw = true; }
     REQUIRE(threw);
     threw = false;
-    try { HypreSmootherWrapper gs(A, 2); } catch (const std::runtime_error &) { threw = true; }  // l1-GS is CPU-only
+    try { HypreSmootherWrapper kz(A, 3); } catch (const std::runtime_error &) { threw = true; }  // Kaczmarz is not built
     REQUIRE(threw);
+    {
+        // the reference's shipped default, "L1 Gauss-Seidel" = 2 (Create0FormParameterList.hpp:103-116): one symmetric sweep from a zero
+        // guess on a symmetric matrix leaves b - A x orthogonal-ish small; at least it must reduce the residual and be repeatable
+        HypreSmootherWrapper gs(A, ELAG_HIP_SMOOTHER_L1_GS);
+        gs.iterative_mode = false;
+        std::vector<double> x1(n0, 7.0), x2(n0, -3.0), r(n0);
+        gs.Mult(b.data(), x1.data());
+        gs.Mult(b.data(), x2.data());
+        for (int i = 0; i < n0; i++) REQUIRE(x1[i] == x2[i]);
+        A->Mult(x1.data(), r.data());
+        double nb = 0, nr = 0;
+        for (int i = 0; i < n0; i++) { nb += b[i] * b[i]; nr += (b[i] - r[i]) * (b[i] - r[i]); }
+        REQUIRE(nr < nb);
+    }
 
     // ---- blocked layer on the explicit 6x6 system of src/linalg/unit_test/block2x2_test.cpp:14-34 ----------------------
     {

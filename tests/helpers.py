@@ -18,7 +18,7 @@ def oracle_h1_hierarchy(A, Ps, smoother=1, sweeps=1, weight=1.0, order=2, fracti
     sms = []
     for l, Al in enumerate(As):
         d = dict(type=smoother, sweeps=sweeps, weight=weight, order=order, fraction=fraction)
-        if smoother in (1, 2):
+        if smoother in (1, 2, 4):
             d["l1"] = orc.l1_norms(Al, None, option=smoother)
         if smoother == 16:
             M = orc.OParCSR(Al)

@@ -1,0 +1,223 @@
+"""The Gauss-Seidel relaxations of the reference's smoother table on the device (csrc/sweep.hip):
+"L1 Gauss-Seidel" = 2 -- the type EVERY shipped parameter list selects (examples/testing_helpers/Create0FormParameterList.hpp:
+103-116, Create2FormParameterList.hpp, example_parameterlists/*.xml) --, "L1 Gauss-Seidel Truncated" = 4, "Gauss-Seidel" = 6 and
+"Hypre Jacobi" = 413 (src/linalg/factories/ParELAG_HypreSmootherFactory.cpp:28-31, 92-109).
+
+The device runs a sweep as dependency levels; the rows of a level are independent and every row is summed by one lane in storage
+order, so on an operator uploaded in the oracle's storage order the result is the sequential loop's, bit for bit.  Operators the
+device builds itself (Galerkin products: columns ascending instead of hypre's diagonal-first order) agree to rounding."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import oracle as orc
+from tests.helpers import oracle_h1_hierarchy, oracle_hdiv_hierarchy
+
+pytestmark = pytest.mark.gpu
+
+# the "Gauss-Seidel" entry of the reference's preconditioner library, verbatim (Create0FormParameterList.hpp:103-116)
+REFERENCE_GS_BLOCK = {"Type": "L1 Gauss-Seidel", "Sweeps": 1, "Damping Factor": 1.0, "Omega": 1.0, "Cheby Poly Order": 2,
+                      "Cheby Poly Fraction": 0.3}
+
+
+@pytest.fixture(scope="module")
+def la():
+    from parelag_amd import linalg
+    return linalg
+
+
+@pytest.mark.parametrize("relax_type", [2, 4, 6])
+@pytest.mark.parametrize("sweeps", [1, 2])
+@pytest.mark.parametrize("iterative", [True, False])
+def test_sweep_is_the_sequential_loop_bit_for_bit(la, h1_k2, relax_type, sweeps, iterative):
+    A, _, _ = h1_k2
+    Ad = orc.diag_first(A)                                   # hypre's storage convention; uploaded as it is
+    ref_s = orc.OSmoother(orc.OParCSR(Ad), type=relax_type, sweeps=sweeps)
+    dev_s = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(Ad), relax_type, {"Sweeps": sweeps})
+    ref_s.iterative_mode = dev_s.iterative_mode = iterative
+    rng = np.random.default_rng(11)
+    f, u0 = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+    u, ur = u0.copy(), u0.copy()
+    dev_s.Mult(f, u); ref_s.Mult(f, ur)
+    assert np.array_equal(u, ur)
+    # the symmetric sweep is self-adjoint: MultTranspose is the same map (mfem::HypreSmoother::MultTranspose)
+    ut = u0.copy(); dev_s.MultTranspose(f, ut)
+    assert np.array_equal(ut, ur)
+
+
+@pytest.mark.parametrize("relax_type", [2, 6])
+def test_sweep_on_unsymmetric_patterns_and_awkward_rows(la, relax_type):
+    """anti-dependencies (a_ij != 0, a_ji == 0, j > i) must also hold row j back; for type 6 also rows without entries and a
+    stored zero diagonal (left alone, as in hypre_BoomerAMGRelax); a chain that makes every row its own level"""
+    rng = np.random.default_rng(5)
+    n = 700
+    B = sp.random(n, n, density=0.01, random_state=rng, format="lil")
+    B.setdiag(rng.uniform(2, 3, n))
+    A = orc.diag_first(B.tocsr())
+    if relax_type == 6:
+        A = A.tolil()
+        A[3, :] = 0                                                   # an empty row
+        A = orc.diag_first(A.tocsr())
+        A.eliminate_zeros()
+        A = orc.diag_first(A)
+        A.data[A.indptr[10]] = 0.0                                    # a stored zero on the diagonal (first entry of row 10)
+    cases = [A, orc.diag_first(sp.diags([np.full(n - 1, -1.0), np.full(n, 2.0), np.full(n - 1, -1.0)], [-1, 0, 1]).tocsr())]
+    for M in cases:
+        f, u0 = rng.standard_normal(n), rng.standard_normal(n)
+        ref_s = orc.OSmoother(orc.OParCSR(M), type=relax_type)
+        dev_s = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(M), relax_type)
+        u, ur = u0.copy(), u0.copy()
+        dev_s.Mult(f, u); ref_s.Mult(f, ur)
+        assert np.array_equal(u, ur)
+
+
+def test_the_reference_s_own_smoother_block_is_accepted_unchanged(la, h1_k2):
+    """Type / Sweeps / Damping Factor / Omega / Cheby keys exactly as the reference's lists spell them"""
+    A, Ps, _ = h1_k2
+    p = dict(REFERENCE_GS_BLOCK)
+    S = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(orc.diag_first(A)), la.HYPRE_SMOOTHER_TYPES[p.pop("Type")], p)
+    f = np.ones(A.shape[0]); u = np.zeros(A.shape[0]); ur = np.zeros(A.shape[0])
+    S.Mult(f, u)
+    orc.OSmoother(orc.OParCSR(orc.diag_first(A)), type=2).Mult(f, ur)
+    assert np.array_equal(u, ur)
+    # what is not built says so instead of computing something else
+    from parelag_amd._lib import ElagHipError
+    for name in ("Kaczmarz", "Lumped Jacobi", "Taubin", "FIR"):
+        with pytest.raises(ElagHipError, match="not available"):
+            la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), la.HYPRE_SMOOTHER_TYPES[name])
+    with pytest.raises(ElagHipError, match="Omega"):
+        la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), 2, {"Omega": 1.2})
+    # a zero l1 norm is an error in hypre_ParCSRComputeL1Norms, here too
+    Z = sp.csr_matrix(A).tolil(); Z[5, :] = 0; Z = Z.tocsr(); Z.eliminate_zeros()
+    with pytest.raises(ElagHipError, match="zero l1"):
+        la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(Z), 2)
+
+
+def test_hypre_jacobi_413_is_diag_scale(la, h1_k2):
+    A, _, _ = h1_k2
+    S = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), la.HYPRE_SMOOTHER_TYPES["Hypre Jacobi"])
+    rng = np.random.default_rng(3)
+    f, u = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+    ur = u.copy()
+    S.Mult(f, u)                                                # iterative_mode = true, yet the old x is ignored (HYPRE_ParCSRDiagScale)
+    orc.OSmoother(orc.OParCSR(orc.diag_first(A)), type=413).Mult(f, ur)
+    assert np.array_equal(u, ur) and np.array_equal(u, f / A.diagonal())
+
+
+@pytest.mark.parametrize("smoother", ["L1 Gauss-Seidel", "L1 Gauss-Seidel Truncated", "Gauss-Seidel"])
+def test_vcycle_with_gauss_seidel_smoothers_matches_oracle(la, h1_k2, smoother):
+    """buildHierarchyFromDeRhamSequence with the reference's default relaxation: device Galerkin operators (columns ascending)
+    against the oracle's (hypre's RAP order): equal to rounding; PCG iteration counts equal"""
+    A, Ps, _ = h1_k2
+    t = la.HYPRE_SMOOTHER_TYPES[smoother]
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    H = la.buildHierarchyFromDeRhamSequence(dA, dPs, smoother)
+    h = oracle_h1_hierarchy(A, Ps, smoother=t)
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"])
+    rng = np.random.default_rng(7)
+    n = A.shape[0]
+    for _ in range(2):
+        b = rng.uniform(-1, 1, n)
+        x, xr = np.full(n, 5.0), np.empty(n)
+        H.Mult(b, x)
+        Hc.apply(b, xr)
+        assert np.max(np.abs(x - xr)) <= 1e-12 * np.max(np.abs(xr))
+    # solver mode (iterative): sol <- sol + cycle(rhs - A sol)
+    H.iterative_mode = False
+    K = la.KrylovSolver(dA, H, {"Solver name": "PCG", "Relative tolerance": 1e-8, "Maximum iterations": 100})
+    rhs = rng.uniform(-1, 1, n)
+    xs, xo = np.zeros(n), np.zeros(n)
+    K.Mult(rhs, xs)
+    ref = orc.mfem_cg(lambda v: A @ v, lambda r, z: Hc.apply(r, z), rhs, xo, rel_tol=1e-8, max_iter=100)
+    assert K.GetConverged() and K.GetNumIterations() == ref.final_iter
+    assert np.max(np.abs(xs - xo)) <= 1e-9 * np.max(np.abs(xo))
+
+
+def test_gauss_seidel_cycle_converges_faster_than_l1_jacobi(la, h1_k2):
+    """the reason the reference ships it: fewer PCG iterations for the same hierarchy"""
+    A, Ps, _ = h1_k2
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    rhs = np.random.default_rng(1).uniform(-1, 1, A.shape[0])
+    its = {}
+    for sm in ("L1 Jacobi", "L1 Gauss-Seidel"):
+        H = la.buildHierarchyFromDeRhamSequence(dA, dPs, sm)
+        K = la.KrylovSolver(dA, H, {"Solver name": "PCG", "Relative tolerance": 1e-8, "Maximum iterations": 200})
+        x = np.zeros(A.shape[0]); K.Mult(rhs, x)
+        assert K.GetConverged()
+        its[sm] = K.GetNumIterations()
+    assert its["L1 Gauss-Seidel"] < its["L1 Jacobi"]
+
+
+def test_hiptmair_with_the_reference_s_gauss_seidel_smoothers(la):
+    """MultigridTest2Form's list wraps two "L1 Gauss-Seidel" smoothers in Hiptmair (Create2FormParameterList.hpp): primary on A,
+    auxiliary on D^T A D"""
+    from parelag_amd import meshgen
+    A, Ps, Ds, _ = meshgen.hdiv_problem(1)
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    dDs = [la.ParallelCSRMatrix.from_scipy(D) for D in Ds[:len(Ps)]]
+    H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Gauss-Seidel", Ds=dDs, aux_smoother="L1 Gauss-Seidel")
+    h = oracle_hdiv_hierarchy(A, Ps, Ds, primary=2, aux=2)
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], hipt=h["hipt"])
+    rng = np.random.default_rng(9)
+    n = A.shape[0]
+    b = rng.uniform(-1, 1, n)
+    x, xr = np.zeros(n), np.empty(n)
+    H.Mult(b, x)
+    Hc.apply(b, xr)
+    assert np.max(np.abs(x - xr)) <= 1e-11 * np.max(np.abs(xr))
+
+
+@pytest.mark.parametrize("relax_type", [2, 6])
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_sweep_freezes_the_ghost_values(h1_k2, relax_type, world):
+    """hybrid Gauss-Seidel across ranks (hypre_ParCSRRelax 2 / BoomerAMGRelax 6): every rank sweeps its own rows with the
+    neighbours' values as they were when the sweep began -- in-process device ranks against the oracle's loop fed with exactly
+    those ghost values, two sweeps (so the second one sees the neighbours' first)"""
+    from parelag_amd import linalg as la, partition
+    from tests.test_gpu_multirank import run_ranks
+    A, Ps, seq = h1_k2
+    d = partition.distributed_h1_hierarchy(A, Ps, seq, world)
+    parts, starts, Ag = d["levels"][0]["A_parts"], d["levels"][0]["starts"], d["A_global"][0]
+    n = Ag.shape[0]
+    rng = np.random.default_rng(13)
+    f, u0 = rng.standard_normal(n), rng.standard_normal(n)
+
+    def body(dist):
+        r = dist.rank
+        p = dict(parts[r]); p["diag"] = orc.diag_first(p["diag"])
+        M = la.ParallelCSRMatrix.from_parts(p)
+        S = la.HypreSmootherWrapper(M, relax_type, {"Sweeps": 2})
+        lo, hi = int(starts[r]), int(starts[r + 1])
+        u = u0[lo:hi].copy()
+        S.Mult(f[lo:hi], u)
+        return u
+    res = run_ranks(world, body)
+
+    class Frozen(orc.SerialExchange):
+        def __init__(self, p):
+            self.p, self.u = p, None
+
+        def forward(self, pkg, send_buf):
+            return self.u[self.p["col_map_offd"]]
+    ex = [Frozen(p) for p in parts]
+    sm = []
+    for r, p in enumerate(parts):
+        M = orc.oparcsr_from_part(dict(p, diag=orc.diag_first(p["diag"])), ex[r])
+        sm.append(orc.OSmoother(M, type=relax_type, sweeps=1))
+    ug = u0.copy()
+    for _ in range(2):
+        for e in ex:
+            e.u = ug.copy()
+        new = ug.copy()
+        for r in range(world):
+            lo, hi = int(starts[r]), int(starts[r + 1])
+            loc = ug[lo:hi].copy()
+            sm[r].Mult(f[lo:hi], loc)
+            new[lo:hi] = loc
+        ug = new
+    for r in range(world):
+        lo, hi = int(starts[r]), int(starts[r + 1])
+        assert np.array_equal(res[r], ug[lo:hi])
