@@ -186,6 +186,9 @@ def main():
                     "inverses are AMGe V-cycles on M and on B diag(M)^-1 Bt (the solver graph of spe10_example_parameters.xml:95-127)")
     ap.add_argument("--no-cpu-solve", action="store_true", help="--solve: skip the CPU port of the Krylov solve (minutes at SPE10 size)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even with one rank (testing)")
+    ap.add_argument("--force-large", action="store_true", help="with --force-dist: also run the GPU-filling workload of the multi-rank runs")
+    ap.add_argument("--parity-max-dofs", type=int, default=1500000, help="multi-rank darcy/spe10: largest system for which the serial CPU "
+                    "oracle's blocked cycle is run beside the distributed one")
     ap.add_argument("--launch-dry-run", action="store_true", help="start the ranks, report RANK / WORLD_SIZE of every child over a gloo "
                     "group and exit: exercises the launcher without a GPU")
     ap.add_argument("--large-refines", type=int, default=5, help="--gpus N > 1: refinements of the second, GPU-filling 0-form workload "
@@ -339,14 +342,24 @@ def main():
 
     # ---------------------------------------------------------------- V-cycle workload
     Ds = None
+    dd_hex = None
     if darcy:
         kinv = None
-        if args.amge or args.hex:
-            if not single and args.hex:
-                raise SystemExit("--hex: single-GPU only in this round (the row-block partitioner works on the cube456 meshes)")
-            # with several ranks every rank runs the (cheap) coarsening of the whole mesh on its own GPU and the distributed
-            # builder partitions the result like the generator's interpolators; a per-rank coarsening with shared
-            # agglomerated facets (AE_TrueAE.IsShared, DeRhamSequence.cpp:1820) is not built yet
+        if not single and args.hex:
+            # BASELINE configs[4] on N ranks: row blocks of whole coarsest boxes, the coarsening sharded by agglomerate ownership
+            from parelag_amd import distributed
+            from parelag_amd.amge_level import box_partition
+            nh = tuple(args.hex)
+            kinv = np.exp(args.perm_sigma * np.random.default_rng(2025).standard_normal(nh[0] * nh[1] * nh[2])) if spe10 else None
+            parts_h, mh = [], nh
+            while (args.amge_levels is None and mh[0] * mh[1] * mh[2] > 2000) or (args.amge_levels is not None and len(parts_h) < args.amge_levels):
+                parts_h.append(box_partition(mh, (2, 2, 2)))
+                mh = tuple(-(-v // 2) for v in mh)
+            dar, dd_hex = distributed.hex_darcy_problem(dist, nh, h=(20.0, 10.0, 2.0), kinv=kinv, parts=parts_h)
+            note("AMGe coarsening (sharded over %d ranks): %d levels in %.3f s" % (world, len(parts_h), dar["amge"]["coarsen_total_s"]))
+        elif args.amge or args.hex:
+            # tets with several ranks: every rank runs the (cheap) two-form coarsening of the whole mesh on its own GPU and the
+            # distributed builder partitions the result like the generator's interpolators
             dar = amge_darcy_problem(args, spe10, np)
             kinv = dar["kinv"]
         else:
@@ -399,7 +412,7 @@ def main():
     if darcy and not single:
         from parelag_amd import distributed
         H, n_local, level_shapes, setup_s = distributed.build_darcy_hierarchy(dist, dar, args.block_smoother, args.smoother,
-                                                                              use_negative_s=not args.positive_s)
+                                                                              use_negative_s=not args.positive_s, dd=dd_hex)
     elif darcy:
         n0, n1 = dar["M"].shape[0], dar["B"].shape[0]
         bop = la.MfemBlockOperator([0, n0, n0 + n1])
@@ -680,7 +693,12 @@ def main():
             solve["cpu_port_iterations"] = ref.final_iter
             solve["solution_rel_diff_vs_cpu_port"] = float(np.max(np.abs(xs_dev - xo)) / np.max(np.abs(xo)))
 
-    if not single and darcy:
+    if not single and darcy and A.shape[0] > args.parity_max_dofs:
+        # the serial oracle's blocked cycle is a numpy composition: minutes beyond ~1 M dofs.  The same code path is checked
+        # against it at smaller sizes (this branch with --hex 16 16 16, tests/test_gpu_hex_dist.py)
+        out["parity_rel_err_vs_oracle"] = None
+        out["parity_note"] = "skipped: %d dofs > --parity-max-dofs %d" % (A.shape[0], args.parity_max_dofs)
+    elif not single and darcy:
         from tests.helpers import oracle_blocked_hierarchy
         kind = {"Block GS": "Block GS Lower"}.get(args.block_smoother, args.block_smoother)
         spec = dict(type=la.HYPRE_SMOOTHER_TYPES[args.smoother])
@@ -711,7 +729,63 @@ def main():
         err = float(np.max(np.abs(sol.to_numpy() - ref)) / np.max(np.abs(xs)))
         out["parity_rel_err_vs_oracle"] = dist.allreduce_max(err)
 
+    # ---------------------------------------------------------------- several ranks: what the communicator says, and a GPU-filling size
+    if dist is not None:
+        import ctypes as C
+        cr, cn = C.c_int(-1), C.c_int(-1)
+        _lib.check(_lib.init().elag_hip_comm_rank(C.byref(cr), C.byref(cn)))
+        if (cr.value, cn.value) != (rank, world):
+            raise SystemExit(f"rank {rank}/{world}: the library's communicator reports rank {cr.value} of {cn.value}")
+        out["comm"] = {"data_plane": "RCCL (ncclSend/ncclRecv groups + ncclAllReduce inside libelag_hip.so)" if world > 1 else "none (one rank)",
+                       "control_plane": "torch.distributed gloo", "library_comm_rank": cr.value, "library_comm_nranks": cn.value,
+                       "ranks_agree": bool(dist.allreduce_max(float(cn.value)) == float(world) and dist.allreduce_sum(float(cr.value)) == world * (world - 1) / 2)}
+    large = None
+    if (dist is not None and args.form == 0 and not darcy and not (args.amge or args.hex) and args.large_refines > args.refines
+            and (world > 1 or args.force_large)):
+        # the headline size (42 k dofs at x3) is a latency problem across ranks by construction; this is the same example at a
+        # size that fills the GPUs.  Levels with more than 2^17 dofs are row-partitioned, the rest replicated behind one all-reduce.
+        kL = args.large_refines
+        t0 = time.time()
+        AL, PL, seqL = meshgen.h1_problem(kL)
+        genL = time.time() - t0
+        sizes = [AL.shape[0]] + [P.shape[1] for P in PL]
+        R = max(1, sum(1 for v in sizes[:-1] if v > (1 << 17)))
+        HL, nL, shapesL, setupL = distributed.build_hierarchy(dist, AL, PL, seqL, args.smoother, replicate_from=R)
+        rhsL, solL = la.DeviceVector(nL, 2.0), la.DeviceVector(nL, 1.0)
+        for _ in range(max(3, args.warmup // 5)):
+            HL.Mult(rhsL, solL)
+        barrier()
+        nstep = max(10, min(args.steps, 200))
+        t0 = time.perf_counter()
+        for _ in range(nstep):
+            HL.Mult(rhsL, solL)
+        barrier()
+        tL = dist.allreduce_max(time.perf_counter() - t0)
+        vbL = vcycle_bytes(shapesL)
+        large = {"workload": f"MultigridTest0Form cube456 x{kL} uniform refines, {len(PL) + 1} levels, {args.smoother}: levels 0..{R - 1} row-partitioned over "
+                             f"{world} rank(s), levels {R}.. replicated behind one all-reduce",
+                 "levels": [{"n": s_[0], "nnz": s_[1]} for s_ in shapesL], "steps": nstep, "ms_per_step": round(tL / nstep * 1e3, 4),
+                 "vcycles_per_s": round(nstep / tL, 2), "vcycle_algorithmic_bytes": vbL,
+                 "aggregate_GBs": round(vbL / (tL / nstep) / 1e9, 1), "frac_of_aggregate_hbm_peak": round(vbL / (tL / nstep) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                 "setup_s": round(setupL, 2), "generate_s": round(genL, 1)}
+        if not args.no_cpu_baseline:
+            from oracle import oracle as orc
+            from tests.helpers import oracle_h1_hierarchy
+            t0 = time.time()
+            hL = oracle_h1_hierarchy(AL, PL, smoother=la.HYPRE_SMOOTHER_TYPES[args.smoother])
+            xsL = np.empty(AL.shape[0])
+            orc.CHierarchy(hL["As"], hL["Ps"], hL["sms"], hL["chol"]).apply(np.full(AL.shape[0], 2.0), xsL)
+            infoL = HL._dist_info["levels"][0]
+            lo, hi = int(infoL["starts"][dist.rank]), int(infoL["starts"][dist.rank + 1])
+            errL = float(np.max(np.abs(solL.to_numpy() - xsL[infoL["order"]][lo:hi])) / np.max(np.abs(xsL)))
+            large["parity_rel_err_vs_oracle"] = dist.allreduce_max(errL)
+            del hL
+        note("large workload (x%d): %.3f ms per V-cycle" % (kL, tL / nstep * 1e3))
+        del HL, rhsL, solL
+
     if rank == 0:
+        if large is not None:
+            out["large"] = large
         out.update({
             "metric": ("V-cycles/sec (MultigridTestDarcy cube456, blocked Hierarchy::Mult in preconditioner mode)" if darcy else
                        f"V-cycles/sec (MultigridTest{args.form}Form cube456, Hierarchy::Mult in preconditioner mode)"),
@@ -754,11 +828,12 @@ def main():
             out["config"]["interpolators"] = amge_rec["what"]
         if darcy and "amge" in dar:
             rec = dar["amge"]
-            lv0, parts = rec.pop("level0"), rec.pop("parts")
+            lv0, parts = rec.pop("level0", None), rec.pop("parts", None)
             n_ae = sum(l["agglomerates"] for l in rec["levels"])
             rec["agglomerates_per_s"] = round(n_ae / rec["coarsen_total_s"], 1)
-            rec["kernel_ms_total"] = round(sum(sum(l["kernel_ms"].values()) for l in rec["levels"]), 3)
-            if not args.no_cpu_baseline:
+            if lv0 is not None:
+                rec["kernel_ms_total"] = round(sum(sum(l["kernel_ms"].values()) for l in rec["levels"]), 3)
+            if lv0 is not None and not args.no_cpu_baseline:
                 # CPU port of the same coarsening (oracle/amge.py: numpy, entity by entity) on a bounded sample: the levels
                 # with at most 4000 agglomerates, reached with the oracle's own coarse levels being skipped -- the device's
                 # levels are equal to 1e-10 (tests/test_gpu_amge.py), so the sample starts from them

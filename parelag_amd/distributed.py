@@ -104,9 +104,11 @@ def build_hierarchy(dist: Dist, A, Ps, seq, smoother="L1 Jacobi", params=None, r
     ``replicate_from = 1`` a V-cycle costs three RCCL rounds.  Returns (H, n_local, global level shapes, setup s)."""
     import scipy.sparse as sp
     t0 = time.time()
-    d = partition.distributed_h1_hierarchy(A, Ps, seq, dist.world)
-    nl = len(d["levels"])
+    nl = len(Ps) + 1
     R = max(1, min(int(replicate_from), nl - 1))
+    # host side: numbering and per-rank pieces of the fine operator and of the interpolators of the distributed head only;
+    # every Galerkin product is formed on the device
+    d = partition.distributed_h1_hierarchy(A, Ps, seq, dist.world, galerkin=False, split_levels=R)
     t = la.HYPRE_SMOOTHER_TYPES[smoother] if isinstance(smoother, str) else int(smoother)
     lib = _lib.init()
     # distributed head: levels 0..R-1; their Galerkin operators are formed on the device across the ranks
@@ -143,17 +145,63 @@ def build_hierarchy(dist: Dist, A, Ps, seq, smoother="L1 Jacobi", params=None, r
     H.Finalize(use_graph=False)
     H._keep += [Hsub, subA, *subP, *ops, *Pd]
     la.synchronize()
+    # global level shapes: distributed levels from the summed local entry counts, replicated levels from the complete copies
     shapes = []
     for l in range(nl):
-        Ag = d["A_global"][l]
         Pg = d["P_global"][l] if l < nl - 1 else None
-        shapes.append((Ag.shape[0], Ag.nnz, Pg.shape[1] if Pg is not None else 0, Pg.nnz if Pg is not None else 0))
+        if l < R:
+            v = C.c_double(float(ops[l].nnz))
+            _lib.check(lib.elag_hip_comm_allreduce(C.byref(v), 0))          # the library's communicator (RCCL / in-process), sum
+            rows, nnz = int(d["levels"][l]["starts"][-1]), int(round(v.value))
+        else:
+            op = Hsub.GetOperator(l - R)
+            rows, nnz = op.Height(), op.nnz
+        shapes.append((rows, nnz, Pg.shape[1] if Pg is not None else 0, Pg.nnz if Pg is not None else 0))
     n_local = ops[0].Height()
     H._dist_info = d
     return H, n_local, shapes, time.time() - t0
 
 
-def build_darcy_hierarchy(dist: Dist, dar, block_smoother="Block Jacobi", smoother="L1 Jacobi", params=None, use_negative_s=True):
+def hex_darcy_problem(dist: Dist, n, h=(20.0, 10.0, 2.0), kinv=None, parts=None):
+    """BASELINE configs[4] on several ranks: the mixed Darcy system on the Cartesian grid of ``examples/MultigridTestSPE10.cpp:194-208``
+    with ParElag's own coarse spaces, the coarsening SHARDED over the ranks.  The grid is cut into row blocks of whole coarsest
+    agglomerates (``partition.hex_element_owners``); on every level a rank runs ``DeRhamSequence::Coarsen`` (``jformStart = 2``,
+    device kernels) for the agglomerates it owns -- agglomerated facets on an interface are computed by both neighbours from the
+    same numbers, bit for bit -- and the pieces are all-gathered for the row-block builders (``derham_dist.coarsen_allgather``;
+    the reference's counterpart is the shared-entity ownership of ``src/amge/DeRhamSequence.cpp:1820,1971,2024``).
+    Returns (dar, dd): the ``dar`` dict of ``meshgen.darcy_problem`` (+ ``levels``, ``elem_owners``, ``amge`` record) and the
+    row-block decomposition ``partition.distributed_darcy_levels`` made of it."""
+    from . import derham_dist
+    from .derham_level import seq_level_from_hex
+    t0 = time.time()
+    lv = seq_level_from_hex(tuple(n), h=h, jstart=2, kinv=kinv)
+    eown = partition.hex_element_owners(n, parts, dist.world)
+    gen_s = time.time() - t0
+    levels, Ps, recs = [lv], [], []
+    t0 = time.time()
+    for l, part in enumerate(parts):
+        t1 = time.time()
+        # agglomerate a of level l is element a of level l + 1: its owner is that element's rank
+        res = derham_dist.coarsen_allgather(levels[-1], np.asarray(part, dtype=np.int64), dist.rank, dist.world, owner=eown[l + 1])
+        c = res["coarse"]
+        recs.append({"agglomerates": int(c.n[0]), "agglomerated_facets": int(c.n[1]), "dofs2": [levels[-1].ndof(2), c.ndof(2)],
+                     "dofs3": [levels[-1].ndof(3), c.ndof(3)], "mine": int(res["piece"].agglomerates.size), "wall_s": round(time.time() - t1, 4)})
+        Ps.append((res["P"][2].tocsr(), res["P"][3].tocsr()))
+        levels.append(c)
+    total_s = time.time() - t0
+    M = lv.mass(2)
+    W = lv.mass(3)
+    B = (W @ lv.D[2]).tocsr(); B.sort_indices()
+    Bt = B.T.tocsr(); Bt.sort_indices()
+    dar = dict(M=M, B=B, Bt=Bt, Ps=Ps, seq=None, rhs_p=W @ lv.const3, kinv=kinv, levels=levels, elem_owners=eown,
+               amge={"what": "DeRhamSequence::Coarsen (jformStart=2) on the device, sharded over %d rank(s) by agglomerate ownership: hex %dx%dx%d, "
+                             "2x2x2 box agglomerates" % ((dist.world,) + tuple(n)),
+                     "levels": recs, "coarsen_total_s": round(total_s, 3), "generate_s": round(gen_s, 2)})
+    dd = partition.distributed_darcy_levels(dar, levels, eown, dist.world)
+    return dar, dd
+
+
+def build_darcy_hierarchy(dist: Dist, dar, block_smoother="Block Jacobi", smoother="L1 Jacobi", params=None, use_negative_s=True, dd=None):
     """Distributed blocked (Darcy) hierarchy in the same layout as ``build_hierarchy``: the fine level is row-partitioned
     (faces and elements owned per rank, one merged operator = one halo exchange per product, block smoother on this
     rank's sub-vectors); the levels below are complete on every GPU as an ordinary single-GPU blocked hierarchy behind
@@ -163,7 +211,7 @@ def build_darcy_hierarchy(dist: Dist, dar, block_smoother="Block Jacobi", smooth
     t0 = time.time()
     lib = _lib.init()
     r = dist.rank
-    dd = partition.distributed_darcy(dar, dist.world)
+    dd = partition.distributed_darcy(dar, dist.world) if dd is None else dd
     (s2, s3) = dd["starts"][0]
     off = [0, int(s2[r + 1] - s2[r]), int(s2[r + 1] - s2[r] + s3[r + 1] - s3[r])]
     op = la.MfemBlockOperator(off)

@@ -121,14 +121,17 @@ def split_rows(A, row_starts, col_starts):
     return parts
 
 
-def distributed_h1_hierarchy(A, Ps, seq, nparts: int):
+def distributed_h1_hierarchy(A, Ps, seq, nparts: int, galerkin: bool = True, split_levels: int | None = None):
     """Block-number every level of the 0-form hierarchy for ``nparts`` ranks and split all operators.
 
-    Coarse operators are the Galerkin products in the new numbering (computed here with scipy: the distributed
-    device RAP is a later row of the scope table).  Returns dict(levels=[dict(A_parts, P_parts, starts, order)],
-    A_global=[...]) with P_parts[l] mapping level l+1 -> l."""
+    ``galerkin``: also form the coarse operators in the new numbering with scipy (tests compare the device's distributed RAP
+    with them); ``distributed.build_hierarchy`` only needs the fine operator and the interpolators and passes False.
+    ``split_levels``: number of leading levels whose operators / interpolators are split into per-rank pieces (default: all).
+    Returns dict(levels=[dict(A_parts, P_parts, starts, order)], A_global=[...], P_global=[...]) with P_parts[l] mapping
+    level l -> l-1."""
     eparts = element_partitions(seq, nparts)
     nl = len(Ps) + 1
+    ns = nl if split_levels is None else max(1, min(int(split_levels), nl))
     orders, news, starts = [], [], []
     for l in range(nl):
         own = vertex_owners(seq.meshes[l], eparts[l])
@@ -139,6 +142,8 @@ def distributed_h1_hierarchy(A, Ps, seq, nparts: int):
     for l, P in enumerate(Ps):
         Pp = canon(sp.csr_matrix(P)[orders[l]][:, orders[l + 1]])
         P_glob.append(Pp)
+        if not galerkin:
+            continue
         Ac = canon(Pp.T @ A_glob[-1] @ Pp)
         # hypre_ParCSRMatrixFixZeroRows: essential-BC rows of the Galerkin operator are empty -> unit diagonal
         zero = np.asarray(abs(Ac).sum(axis=1)).ravel() == 0
@@ -146,8 +151,10 @@ def distributed_h1_hierarchy(A, Ps, seq, nparts: int):
         A_glob.append(Ac)
     levels = []
     for l in range(nl):
-        lev = dict(A_parts=split_rows(A_glob[l], starts[l], starts[l]), starts=starts[l], order=orders[l])
-        if l > 0:
+        lev = dict(starts=starts[l], order=orders[l])
+        if l < len(A_glob) and l < ns:
+            lev["A_parts"] = split_rows(A_glob[l], starts[l], starts[l])
+        if 0 < l <= ns:
             lev["P_parts"] = split_rows(P_glob[l - 1], starts[l - 1], starts[l])
         levels.append(lev)
     return dict(levels=levels, A_global=A_glob, P_global=P_glob)
@@ -203,6 +210,92 @@ def entity_owners(mesh, elem_part: np.ndarray, form: int) -> np.ndarray:
     return owner
 
 
+def chain_element_owners(parts, coarsest_owner: np.ndarray):
+    """Element -> rank on every level of an agglomeration chain from the ownership of the coarsest level's elements: an element
+    belongs to the rank of its agglomerate (``parts[l]``: elements of level l -> elements of level l + 1), so every agglomerate
+    is rank-local on every level, as ParElag requires of a rank's partitioning (``src/topology/Topology.cpp:686-740``).
+    Returns one array per level, finest first (``len(parts) + 1`` of them)."""
+    out = [np.asarray(coarsest_owner, dtype=np.int32)]
+    for part in reversed(parts):
+        out.append(out[-1][np.asarray(part, dtype=np.int64)])
+    return out[::-1]
+
+
+def hex_element_owners(n, parts, nparts: int):
+    """Row-block decomposition of the Cartesian grid of ``examples/MultigridTestSPE10.cpp:194-208`` (``n[0] x n[1] x n[2]`` cells cut
+    into 2 x 2 x 2 boxes level after level, ``amge_level.box_partition``): the boxes of the COARSEST level are divided among the
+    ranks by recursive coordinate bisection of their (i, j, k) positions -- slabs across the longest direction first -- and every
+    finer cell follows the box it lies in.  Returns the element -> rank arrays of all levels, finest first."""
+    m = tuple(int(v) for v in n)
+    for _ in parts:
+        m = tuple(-(-v // 2) for v in m)
+    I, J, K = np.meshgrid(np.arange(m[0]), np.arange(m[1]), np.arange(m[2]), indexing="ij")
+    cent = np.stack([I.ravel(), J.ravel(), K.ravel()], axis=1).astype(np.float64) + 0.5
+    if cent.shape[0] < nparts:
+        raise ValueError("hex_element_owners: %d coarsest boxes cannot feed %d ranks (use fewer coarsenings or fewer ranks)" % (cent.shape[0], nparts))
+    return chain_element_owners(parts, rcb_partition(cent, nparts))
+
+
+def _darcy_tables(level):
+    """(element -> facet ptr, idx, dofs per facet of form 2, element-interior dofs of form 2 per element, dofs of form 3 per
+    element) of a ``SeqLevel`` (general sequence) or an ``AmgeLevel`` (two-form fast path): both number the facet dofs of form 2
+    first, facet by facet, then the element-interior ones (``DofHandlerALG::computeOffset``, ``src/amge/DofHandler.cpp:1058-1186``)."""
+    if hasattr(level, "ef_ptr"):
+        return level.ef_ptr, level.ef_idx, np.diff(level.f_dof2_ptr), np.diff(level.e_idof2_ptr), np.diff(level.e_dof3_ptr)
+    return level.B[0][0], level.B[0][1], np.diff(level.idof[2][1]), np.diff(level.idof[2][0]), np.diff(level.idof[3][0])
+
+
+def darcy_dof_owners(level, elem_owner: np.ndarray):
+    """Owner rank of every dof of forms 2 and 3 of a level (any element type, any number of dofs per entity): a dof living on
+    a facet belongs to the lowest rank among the facet's elements (the ``SharingMap`` master rule,
+    ``src/structures/SharingMap.cpp:975-1011``), a dof interior to an element to the element's rank."""
+    ef_ptr, ef_idx, nf2, ne2, ne3 = _darcy_tables(level)
+    elem_owner = np.asarray(elem_owner, dtype=np.int32)
+    nF = nf2.size
+    fown = np.full(nF, np.iinfo(np.int32).max, dtype=np.int32)
+    np.minimum.at(fown, ef_idx, np.repeat(elem_owner, np.diff(ef_ptr)))
+    if nF and fown.max() == np.iinfo(np.int32).max:
+        raise ValueError("darcy_dof_owners: a facet belongs to no element")
+    own2 = np.concatenate([np.repeat(fown, nf2), np.repeat(elem_owner, ne2)]).astype(np.int32)
+    own3 = np.repeat(elem_owner, ne3).astype(np.int32)
+    return own2, own3
+
+
+def distributed_darcy_from_owners(M, B, Bt, Ps, owners, nparts: int):
+    """The row-block pieces of the mixed system and its interpolators for given dof owners (``owners[l] = (own2, own3)`` per
+    level, ``len(Ps) + 1`` levels): block numbering per space and level, every block and interpolator block split into ParCSR
+    pieces with their comm packages.  Same return layout as ``distributed_darcy``."""
+    order, starts = [], []
+    for own2, own3 in owners:
+        o2, _n2, s2 = block_numbering(own2, nparts)
+        o3, _n3, s3 = block_numbering(own3, nparts)
+        order.append((o2, o3)); starts.append((s2, s3))
+    o2, o3 = order[0]
+    s2, s3 = starts[0]
+    glob = {(0, 0): canon(sp.csr_matrix(M)[o2][:, o2]), (0, 1): canon(sp.csr_matrix(Bt)[o2][:, o3]),
+            (1, 0): canon(sp.csr_matrix(B)[o3][:, o2])}
+    blocks = {(0, 0): split_rows(glob[(0, 0)], s2, s2), (0, 1): split_rows(glob[(0, 1)], s2, s3),
+              (1, 0): split_rows(glob[(1, 0)], s3, s2)}
+    P = []
+    for l, (P2, P3) in enumerate(Ps):
+        (f2, f3), (c2, c3) = order[l], order[l + 1]
+        P.append([split_rows(canon(sp.csr_matrix(P2)[f2][:, c2]), starts[l][0], starts[l + 1][0]),
+                  split_rows(canon(sp.csr_matrix(P3)[f3][:, c3]), starts[l][1], starts[l + 1][1])])
+    return dict(blocks=blocks, P=P, order=order, starts=starts, global_blocks=glob)
+
+
+def distributed_darcy_levels(dar, levels, elem_owners, nparts: int):
+    """``distributed_darcy`` for a hierarchy given by its levels' own tables (``SeqLevel`` / ``AmgeLevel``: Cartesian hex grids,
+    AMGe coarse spaces with several dofs per agglomerated entity) instead of the generator's tet meshes."""
+    owners = [darcy_dof_owners(L, eo) for L, eo in zip(levels, elem_owners)]
+    for l, (own2, own3) in enumerate(owners):
+        n2 = dar["M"].shape[0] if l == 0 else dar["Ps"][l - 1][0].shape[1]
+        n3 = dar["B"].shape[0] if l == 0 else dar["Ps"][l - 1][1].shape[1]
+        if own2.size != n2 or own3.size != n3:
+            raise ValueError("distributed_darcy_levels: level %d has %d / %d dofs but the operators have %d / %d" % (l, own2.size, own3.size, n2, n3))
+    return distributed_darcy_from_owners(dar["M"], dar["B"], dar["Bt"], dar["Ps"], owners, nparts)
+
+
 def distributed_darcy(dar, nparts: int):
     """Row-block decomposition of the mixed Darcy system of ``meshgen.darcy_problem`` for ``nparts`` ranks: faces (2-form)
     and elements (3-form) are block-numbered per level, every block and every interpolator block is split into ParCSR
@@ -210,23 +303,8 @@ def distributed_darcy(dar, nparts: int):
     starts=[(faces, tets) per level])."""
     seq = dar["seq"]
     eparts = element_partitions(seq, nparts)
-    order, starts = [], []
-    for l, mesh in enumerate(seq.meshes):
-        o2, _n2, s2 = block_numbering(entity_owners(mesh, eparts[l], 2), nparts)
-        o3, _n3, s3 = block_numbering(entity_owners(mesh, eparts[l], 3), nparts)
-        order.append((o2, o3)); starts.append((s2, s3))
-    o2, o3 = order[0]
-    s2, s3 = starts[0]
-    glob = {(0, 0): canon(sp.csr_matrix(dar["M"])[o2][:, o2]), (0, 1): canon(sp.csr_matrix(dar["Bt"])[o2][:, o3]),
-            (1, 0): canon(sp.csr_matrix(dar["B"])[o3][:, o2])}
-    blocks = {(0, 0): split_rows(glob[(0, 0)], s2, s2), (0, 1): split_rows(glob[(0, 1)], s2, s3),
-              (1, 0): split_rows(glob[(1, 0)], s3, s2)}
-    P = []
-    for l, (P2, P3) in enumerate(dar["Ps"]):
-        (f2, f3), (c2, c3) = order[l], order[l + 1]
-        P.append([split_rows(canon(sp.csr_matrix(P2)[f2][:, c2]), starts[l][0], starts[l + 1][0]),
-                  split_rows(canon(sp.csr_matrix(P3)[f3][:, c3]), starts[l][1], starts[l + 1][1])])
-    return dict(blocks=blocks, P=P, order=order, starts=starts, global_blocks=glob)
+    owners = [(entity_owners(mesh, eparts[l], 2), entity_owners(mesh, eparts[l], 3)) for l, mesh in enumerate(seq.meshes)]
+    return distributed_darcy_from_owners(dar["M"], dar["B"], dar["Bt"], dar["Ps"], owners[:len(dar["Ps"]) + 1], nparts)
 
 
 def distributed_hdiv(A, Ps, Ds, seq, nparts: int):

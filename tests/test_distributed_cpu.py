@@ -119,3 +119,59 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-dry-run"], capture_output=True, text=True,
                        env=env, timeout=120, cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+@pytest.mark.parametrize("nparts", [2, 3, 4])
+def test_hex_grid_row_blocks(nparts):
+    """BASELINE configs[4] on several ranks: the Cartesian grid of MultigridTestSPE10.cpp:194-208 cut into row blocks of whole
+    coarsest boxes; AMGe coarse spaces with several dofs per agglomerated entity (heterogeneous coefficient: null-space dofs,
+    element-interior dofs of form 2).  Ownership comes from the levels' own tables, every block / interpolator piece reproduces
+    the global product through the oracle's exchange, and no agglomerate of any level straddles two ranks."""
+    from oracle import derham as od
+    from parelag_amd.amge_level import box_partition
+    from parelag_amd.derham_level import seq_level_from_hex
+    n = (8, 8, 4)
+    kinv = np.exp(1.5 * np.random.default_rng(5).standard_normal(n[0] * n[1] * n[2]))
+    lv = seq_level_from_hex(n, h=(20.0, 10.0, 2.0), jstart=2, kinv=kinv)
+    parts = [box_partition(n, (2, 2, 2)).astype(np.int64), box_partition((4, 4, 2), (2, 2, 2)).astype(np.int64)]
+    levels, Ps = [lv], []
+    for part in parts:
+        res = od.coarsen(levels[-1], part)
+        Ps.append((res["P"][2].tocsr(), res["P"][3].tocsr()))
+        levels.append(res["coarse"])
+    assert levels[1].ndof(2) > levels[1].n[1]                       # more than one dof per coarse facet / interior dofs: not mesh-countable
+    M, W = lv.mass(2), lv.mass(3)
+    B = (W @ lv.D[2]).tocsr()
+    dar = dict(M=M, B=B, Bt=B.T.tocsr(), Ps=Ps)
+    eown = partition.hex_element_owners(n, parts, nparts)
+    assert [len(e) for e in eown] == [L.n[0] for L in levels]
+    for l, part in enumerate(parts):
+        assert np.array_equal(eown[l], eown[l + 1][part])            # agglomerates are rank-local, level after level
+    assert set(np.unique(eown[-1])) == set(range(nparts))
+    dd = partition.distributed_darcy_levels(dar, levels, eown, nparts)
+    rng = np.random.default_rng(1)
+    for k, pieces in dd["blocks"].items():
+        G = dd["global_blocks"][k]
+        W_ = orc.InProcessWorld(pieces)
+        x = rng.standard_normal(G.shape[1]); y = rng.standard_normal(G.shape[0])
+        assert np.allclose(W_.matvec(x), G @ x, rtol=1e-12, atol=1e-13)
+        assert np.allclose(W_.matvec(y, trans=True), G.T @ y, rtol=1e-12, atol=1e-13)
+    for l in range(len(Ps)):
+        (f2, f3), (c2, c3) = dd["order"][l], dd["order"][l + 1]
+        for pieces, P, fo, co in ((dd["P"][l][0], Ps[l][0], f2, c2), (dd["P"][l][1], Ps[l][1], f3, c3)):
+            Pg = sp.csr_matrix(P)[fo][:, co]
+            xc = rng.standard_normal(Pg.shape[1])
+            assert np.allclose(orc.InProcessWorld(pieces).matvec(xc), Pg @ xc, rtol=1e-12, atol=1e-13)
+    # ownership: an element's dofs follow the element, a facet's dofs the lowest rank among its elements
+    for L, eo in zip(levels, eown):
+        own2, own3 = partition.darcy_dof_owners(L, eo)
+        assert np.array_equal(own3, np.repeat(eo, np.diff(L.idof[3][0])))
+        ef_ptr, ef_idx = L.B[0][0], L.B[0][1]
+        e_of = np.repeat(np.arange(L.n[0]), np.diff(ef_ptr))
+        first_dof_of_facet = L.idof[2][1][:-1]
+        has = np.diff(L.idof[2][1]) > 0
+        fo = own2[first_dof_of_facet[has]]
+        lowest = np.full(L.n[1], 10 ** 6); np.minimum.at(lowest, ef_idx, eo[e_of])
+        assert np.array_equal(fo, lowest[has])
+    with pytest.raises(ValueError, match="coarsest boxes"):
+        partition.hex_element_owners((4, 4, 4), [box_partition((4, 4, 4), (2, 2, 2)), box_partition((2, 2, 2), (2, 2, 2))], 2)

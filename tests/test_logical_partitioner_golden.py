@@ -54,20 +54,30 @@ def four_levels(coarsen_level):
     return levels, Ps, msgs
 
 
-def printed_errors(levels, Ps):
+def direct_solves(As, ess, rhs, lift, Ps):
+    """every level's system solved directly: essential dofs carry ``lift``, the free ones solve A_ff u_f = b_f - A_fe lift_e"""
+    sol = []
+    for A, e, b, g in zip(As, ess, rhs, lift):
+        free, fix = np.nonzero(~e)[0], np.nonzero(e)[0]
+        u = np.zeros(A.shape[0])
+        u[fix] = g[fix]
+        u[free] = spl.spsolve(A[free][:, free].tocsc(), b[free] - A[free][:, fix] @ g[fix])
+        sol.append(u)
+    return sol
+
+
+def printed_errors(levels, Ps, solve_all=direct_solves):
+    """``solve_all(As, ess, rhs, lift, Ps) -> solutions``: how the level systems are solved (directly here; on the device through
+    Galerkin products, V-cycles and PCG in tests/test_gpu_known_answers.py)"""
     M = [L.mass(0).tocsr() for L in levels]
     W = [L.mass(1).tocsr() for L in levels]
     D = [L.D[0].tocsr() for L in levels]
     b = [M[0] @ np.ones(levels[0].ndof(0))]                        # DomainLFIntegrator(1): the constant is in the space
     for P in Ps:
         b.append(P.T @ b[-1])
-    sol = []
-    for k, L in enumerate(levels):
-        A = (M[k] + D[k].T @ W[k] @ D[k]).tocsr()
-        free = np.nonzero(~derham.DeRhamSequence(L)._marker(0, np.ones(6, dtype=np.int64)))[0]
-        u = np.zeros(L.ndof(0))
-        u[free] = spl.spsolve(A[free][:, free].tocsc(), b[k][free])
-        sol.append(u)
+    As = [(M[k] + D[k].T @ W[k] @ D[k]).tocsr() for k in range(len(levels))]
+    ess = [derham.DeRhamSequence(L)._marker(0, np.ones(6, dtype=np.int64)) for L in levels]
+    sol = solve_all(As, ess, b, [np.zeros(L.ndof(0)) for L in levels], Ps)
     l2, en = [], []
     for k in (3, 2, 1):                                            # coarsest first, as OutputUpscalingErrors prints them
         u = sol[k]
@@ -132,7 +142,7 @@ from parelag_amd.amge_level import box_partition
 EMBEDDED = ("u l2-like errors: 9.361[0-9]e-03 2.554[0-9]e-03 ", "u energy-like errors: 8.60[0-9]*e-02 4.292[0-9]e-02")   # examples/CMakeLists.txt:122-127
 
 
-def embedded_mesh_lines(coarsen_level):
+def embedded_mesh_lines(coarsen_level, solve_all=direct_solves):
     """``EmbeddedMeshPartitionerDemo.cpp:148-160, 264-300, 385-400, 452-510``: 2 x 2 x 2 hexahedra refined twice, the lower half with its
     own material id; agglomerates = connected cells with the same (derefinement partition, material) -- ``LogicalPartitioner`` with
     ``CoarsenMFEMMaterialId``; ``check_topology = 1``; the 0-form problem with no load and the essential value 1 on the whole
@@ -160,14 +170,8 @@ def embedded_mesh_lines(coarsen_level):
     M = [L.mass(0).tocsr() for L in levels]
     W = [L.mass(1).tocsr() for L in levels]
     D = [L.D[0].tocsr() for L in levels]
-    sol = []
-    for k, L in enumerate(levels):
-        A = (M[k] + D[k].T @ W[k] @ D[k]).tocsr()
-        free, fix = np.nonzero(~ess[k])[0], np.nonzero(ess[k])[0]
-        u = np.zeros(L.ndof(0))
-        u[fix] = g[k][fix]                                         # EliminateRowCol(mm, ess_data(mm), rhs)
-        u[free] = spl.spsolve(A[free][:, free].tocsc(), -(A[free][:, fix] @ g[k][fix]))
-        sol.append(u)
+    As = [(M[k] + D[k].T @ W[k] @ D[k]).tocsr() for k in range(len(levels))]
+    sol = solve_all(As, ess, [np.zeros(L.ndof(0)) for L in levels], g, Ps)      # EliminateRowCol(mm, ess_data(mm), rhs)
     l2, en = [], []
     for k in (2, 1):
         u = sol[k]
