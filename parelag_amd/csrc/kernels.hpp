@@ -36,6 +36,10 @@ void build_stream_plan(DevCSR &A);
 // spmv_fused does this lazily on the first uncaptured launch, hierarchies do it for their operators at Finalize
 void prepare_spmv(const DevCSR &A, bool force = false);
 
+// builds the 4-byte-per-entry sign form of a matrix whose stored values are all -1, 0 or +1 (returns false and leaves the
+// matrix alone otherwise); synchronous, setup time.  The caller vouches that the values stay as they are.
+bool prepare_sign_form(const DevCSR &A);
+
 // ---- vector kernels ----------------------------------------------------------------------------
 void vec_axpby(int n, double a, const double *x, double b, const double *y, double *out);  // out = a x + b y
 void vec_scale_mul(int n, double a, const double *x, const double *d, double *out);        // out = a x .* d

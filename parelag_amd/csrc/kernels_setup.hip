@@ -682,6 +682,7 @@ __global__ void scale_cols_kernel(long long nnz, const int *__restrict__ J, doub
 
 void csr_scale_cols(DevCSR &A, const double *d)
 {
+    A.release_sign();
     if (A.nnz == 0) return;
     long long g = (A.nnz + kBlock - 1) / kBlock; if (g > 4096) g = 4096;
     hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)g), dim3(kBlock), 0, ctx().stream, (long long)A.nnz, (const int *)A.J, A.a, d);
@@ -690,6 +691,7 @@ void csr_scale_cols(DevCSR &A, const double *d)
 
 void csr_scale_rows(DevCSR &A, const double *d)
 {
+    A.release_sign();
     if (A.nrows == 0) return;
     hipLaunchKernelGGL(scale_rows_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, ctx().stream, A.nrows, (const int *)A.I, A.a, d);
     ELAG_LAUNCH_CHECK();

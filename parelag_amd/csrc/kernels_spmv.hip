@@ -132,6 +132,76 @@ void launch_lpr(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hipStrea
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sign form (DevCSR::Js): rows of -1 / 0 / +1 entries, 4 bytes per entry.  LPR lanes per row, each lane takes up to four
+// entries per pass: the four words are requested together, then the four x values, and only then added -- in storage order
+// within a lane, so with LPR = 1 the row sum is the CPU loop's (a product by +-1 is exact).
+// ------------------------------------------------------------------------------------------------
+template <int LPR, bool HAS_CS>
+__global__ __launch_bounds__(kBlock) void spmv_sign_kernel(int nrows, const int *__restrict__ I, const int *__restrict__ Js, SpmvArgs p)
+{
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int row = gid / LPR;
+    const int lane = threadIdx.x & (LPR - 1);
+    if (row >= nrows) return;
+    const int s = I[row], e = I[row + 1];
+    double f0 = 0.0, y0 = 0.0, sc0 = 1.0, sc20 = 1.0;
+    if (lane == 0) {
+        if (p.s2) sc20 = p.s2[row];
+        if (p.f) f0 = p.f[row];
+        if (p.s) sc0 = p.s[row];
+        if (p.yin) y0 = p.yin[row];
+    }
+    const double *__restrict__ x = p.x;
+    const double *__restrict__ cs = p.cs;
+    double sum = 0.0;
+    for (int k = s + lane; k < e; k += 4 * LPR) {
+        int w[4];
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[q] = (k + q * LPR < e) ? Js[k + q * LPR] : 0x40000000;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int j = w[q] & 0x3fffffff;
+            v[q] = (w[q] & 0x40000000) ? 0.0 : (HAS_CS ? x[j] * cs[j] : x[j]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) sum += (w[q] < 0) ? -v[q] : v[q];
+    }
+    sum = group_reduce<LPR>(sum);
+    if (lane == 0) {
+        double t = p.alpha * sum;
+        t *= sc20;
+        t += p.gamma * f0;
+        t *= sc0;
+        t += p.beta * y0;
+        p.out[row] = t;
+        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
+    }
+}
+
+template <int LPR>
+void launch_sign(const DevCSR &A, const SpmvArgs &p, hipStream_t st)
+{
+    if (A.nrows == 0) return;
+    const unsigned grid = (unsigned)(((long long)A.nrows * LPR + kBlock - 1) / kBlock);
+    if (p.cs) hipLaunchKernelGGL((spmv_sign_kernel<LPR, true>), dim3(grid), dim3(kBlock), 0, st, A.nrows, (const int *)A.I, (const int *)A.Js, p);
+    else hipLaunchKernelGGL((spmv_sign_kernel<LPR, false>), dim3(grid), dim3(kBlock), 0, st, A.nrows, (const int *)A.I, (const int *)A.Js, p);
+    ELAG_LAUNCH_CHECK();
+}
+
+__global__ void sign_pack_kernel(long long nnz, const int *__restrict__ J, const double *__restrict__ a, int *__restrict__ Js, int *__restrict__ bad)
+{
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x) {
+        const double v = a[k];
+        int w = J[k];
+        if (v == -1.0) w |= (int)0x80000000;
+        else if (v == 0.0) w |= 0x40000000;
+        else if (v != 1.0) atomicAdd(bad, 1);
+        Js[k] = w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS-staged stream kernel (default).  A 256-thread workgroup owns the rows whose first entry lies in one
 // 2048-entry window of the CSR arrays.  Phase 1 streams that window with 16-byte loads (int4 of J, 2 x double2
 // of a per lane: up to 160 B in flight per lane), gathers x and parks the products in LDS; phase 2 gives each
@@ -594,11 +664,40 @@ void prepare_spmv(const DevCSR &A, bool force)
     }
 }
 
+bool prepare_sign_form(const DevCSR &A)
+{
+    if (A.sign_state != 0) return A.sign_state == 1;
+    A.sign_state = -1;
+    if (A.nnz == 0 || A.ncols >= (1 << 30)) return false;
+    hipStream_t st = ctx().stream;
+    int *Js = dev_alloc<int>((size_t)A.nnz);
+    Temp<int> bad(1);
+    ELAG_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), st));
+    const unsigned g = (unsigned)std::min<long long>((A.nnz + kBlock - 1) / kBlock, 4096);
+    hipLaunchKernelGGL(sign_pack_kernel, dim3(g), dim3(kBlock), 0, st, (long long)A.nnz, (const int *)A.J, (const double *)A.a, Js, bad.p);
+    ELAG_LAUNCH_CHECK();
+    int nbad = 0;
+    ELAG_HIP_CHECK(hipMemcpyAsync(&nbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    if (nbad) { dev_free(Js); return false; }
+    A.Js = Js;
+    A.sign_state = 1;
+    return true;
+}
+
 void spmv_fused(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, hipStream_t st)
 {
     if (!st) st = ctx().stream;
     const bool rowlist = args.rows != nullptr;
     const bool offd_terms = offd && offd->nnz > 0 && !args.skip_rows_with_offd;
+    if (A.sign_state == 1 && !rowlist && !offd_terms && !args.skip_rows_with_offd) {
+        const double avg = A.nrows ? (double)A.nnz / A.nrows : 0.0;
+        if (avg <= 6.0) launch_sign<1>(A, args, st);
+        else if (avg <= 12.0) launch_sign<2>(A, args, st);
+        else if (avg <= 24.0) launch_sign<4>(A, args, st);
+        else launch_sign<8>(A, args, st);
+        return;
+    }
     if (A.lanes_per_row == 0 && !rowlist && !offd_terms && A.block_row) {
         if (A.nrows) launch_stream(A, offd, args, st);
         return;
@@ -975,6 +1074,8 @@ void vec_reciprocal_scale(int n, double w, const double *d, double *out)
 int fix_zero_rows(DevCSR &diag, DevCSR *offd)
 {
     if (diag.nrows == 0) return 0;
+    diag.release_sign();
+    if (offd) offd->release_sign();
     Temp<int> cnt(1);
     ELAG_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int), ctx().stream));
     const bool ho = offd && offd->nnz > 0;

@@ -212,6 +212,7 @@ int elag_hip_parcsr_keep_equal_entries(elag_hip_parcsr_t A, elag_hip_parcsr_t B)
         ELAG_REQUIRE(A && B, "null matrix");
         ELAG_REQUIRE(same_pattern(A->diag, B->diag) && same_pattern(A->offd, B->offd), "KeepEqualEntries: A and B must have the same sparsity pattern");
         hipStream_t st = ctx().stream;
+        A->diag.release_sign(); A->offd.release_sign();
         if (A->diag.nnz) hipLaunchKernelGGL(keep_equal_kernel, dim3(1024), dim3(256), 0, st, (long long)A->diag.nnz, A->diag.a, (const double *)B->diag.a);
         if (A->offd.nnz) hipLaunchKernelGGL(keep_equal_kernel, dim3(1024), dim3(256), 0, st, (long long)A->offd.nnz, A->offd.a, (const double *)B->offd.a);
         ELAG_LAUNCH_CHECK();

@@ -520,6 +520,7 @@ int elag_hip_parcsr_sign_transform(elag_hip_parcsr_t A)
     return guarded([&] {
         require_init();
         ELAG_REQUIRE(A, "null matrix");
+        A->diag.release_sign(); A->offd.release_sign();
         k::values_sign(A->diag.nnz, A->diag.a);
         k::values_sign(A->offd.nnz, A->offd.a);
         A->diagT.reset(); A->offdT.reset();

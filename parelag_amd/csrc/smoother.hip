@@ -241,6 +241,12 @@ void HiptmairSmoother::setup()
     auxx = dev_alloc<double>((size_t)D->ncols());
     auxalt = dev_alloc<double>((size_t)D->ncols());
     D->ensure_transpose();
+    // the derivative of a lowest-order sequence is an incidence matrix (entries +-1, eliminated essential columns 0): both it
+    // and its stored transpose go to the 4-byte-per-entry sign form when that is what they hold (the smoother keeps D fixed)
+    if (!D->needs_exchange() && std::getenv("ELAG_HIP_NO_SIGN_FORM") == nullptr) {
+        k::prepare_sign_form(D->diag);
+        if (D->diagT) k::prepare_sign_form(*D->diagT);
+    }
     k::prepare_spmv(A->diag); k::prepare_spmv(D->diag);
     if (D->diagT) k::prepare_spmv(*D->diagT);
     if (aux->A) k::prepare_spmv(aux->A->diag);
