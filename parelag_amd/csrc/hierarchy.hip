@@ -23,6 +23,11 @@ struct Level {
     // which is algebraically the reference's  x = W f; r = f - A x; r_c = P^T r; x += P e; x += W (f - A x).
     std::shared_ptr<DevCSR> G, S;
     const double *fused_dinv = nullptr;
+    // launch-bound levels whose smoother is Hiptmair(l1-Jacobi, l1-Jacobi), one sweep each (see plan_fused): six launches
+    // instead of ten, with  Gaux = D Waux D^T  (the auxiliary-space correction as one operator),  RA = P^T A  and  PTneg = -P^T
+    // (restricted residual in one product pair),  S = A P - W^-1 P  (prolongation + primary post-sweep in one product pair)
+    std::shared_ptr<DevCSR> Gaux, RA, PTneg;
+    const double *hipt_w = nullptr;
 };
 
 struct GraphEntry {
@@ -113,6 +118,8 @@ struct elag_hip_hierarchy_s {
             if (L.P) { k::prepare_spmv(L.P->diag); if (L.P->diagT) k::prepare_spmv(*L.P->diagT); }
             if (L.G) k::prepare_spmv(*L.G);
             if (L.S) k::prepare_spmv(*L.S);
+            if (L.Gaux) k::prepare_spmv(*L.Gaux);
+            if (L.RA) k::prepare_spmv(*L.RA);
         }
         if (A_user) k::prepare_spmv(A_user->diag);
         plan_dense_tail();
@@ -165,6 +172,41 @@ struct elag_hip_hierarchy_s {
             Level &F = lev[(size_t)l];
             Level &C = lev[(size_t)l + 1];
             F.G.reset(); F.S.reset(); F.fused_dinv = nullptr;
+            F.Gaux.reset(); F.RA.reset(); F.PTneg.reset(); F.hipt_w = nullptr;
+            // ---- Hiptmair(l1-Jacobi, l1-Jacobi) on a launch-bound level ----
+            if (HiptmairSmoother *hs = (!disabled && all_local && F.pre && F.pre == F.post) ? dynamic_cast<HiptmairSmoother *>(F.pre) : nullptr) {
+                const double *w = (hs->primary && hs->primary->A == F.A) ? hs->primary->diag_scaling() : nullptr;
+                const double *wa = (hs->aux && hs->aux->A && hs->aux->n() == hs->D->ncols()) ? hs->aux->diag_scaling() : nullptr;
+                if (hs->A == F.A && w && wa && !hs->D->needs_exchange() && hs->D->offd.ncols == 0 && F.A->offd.ncols == 0 && C.P->offd.ncols == 0 &&
+                    F.A->diag.nnz < max_nnz) {
+                    const int n = F.A->nrows();
+                    hs->D->ensure_transpose();
+                    C.P->ensure_transpose();
+                    {   // Gaux = D (Waux D^T)
+                        DevCSR WDT;
+                        k::csr_copy(*hs->D->diagT, WDT);
+                        k::csr_scale_rows(WDT, wa);
+                        F.Gaux.reset(new DevCSR());
+                        k::csr_spgemm(hs->D->diag, WDT, *F.Gaux);
+                    }
+                    F.RA.reset(new DevCSR());
+                    k::csr_spgemm(*C.P->diagT, F.A->diag, *F.RA);
+                    F.PTneg.reset(new DevCSR());
+                    k::csr_add(-1.0, *C.P->diagT, 0.0, *C.P->diagT, *F.PTneg);
+                    {   // S = A P - W^-1 P
+                        DevCSR AP, WP;
+                        k::csr_spgemm(F.A->diag, C.P->diag, AP);
+                        k::csr_copy(C.P->diag, WP);
+                        Temp<double> winv((size_t)n);
+                        k::vec_reciprocal_scale(n, 1.0, w, winv);
+                        k::csr_scale_rows(WP, winv);
+                        F.S.reset(new DevCSR());
+                        k::csr_add(1.0, AP, -1.0, WP, *F.S);
+                    }
+                    F.hipt_w = w;
+                }
+                continue;
+            }
             const double *dinv = F.pre ? F.pre->diag_scaling() : nullptr;
             if (disabled || !all_local || !dinv || !F.post || !F.post->diag_scaling() || F.pre->A != F.A || F.post->A != F.A ||
                 !F.pre->same_scaling_as(F.post))
@@ -221,6 +263,32 @@ struct elag_hip_hierarchy_s {
             k::SpmvArgs u;  // coarse correction and post-smoothing in one product pair
             u.x = rhs; u.cs = F.fused_dinv; u.xg = C.sol; u.alpha = -1.0; u.f = rhs; u.gamma = 2.0; u.s = F.fused_dinv; u.out = sol;
             k::spmv_fused(F.A->diag, F.S.get(), u);
+            return;
+        }
+        if (F.Gaux) {
+            // Hiptmair(l1-Jacobi, l1-Jacobi) pre / post on a launch-bound level, algebraically the reference's sequence
+            //   x = W f; pv = f - A x; x += D Waux D^T pv | r_c = P^T (f - A x) | x += P e; x += W (f - A x); pv = f - A x; x += D Waux D^T pv
+            double *cur = alt, *oth = sol;
+            const double *w = F.hipt_w;
+            k::SpmvArgs a1;   // x = W f (the operand, written as out2) and pv = f - A x in one product
+            a1.x = rhs; a1.cs = w; a1.alpha = -1.0; a1.f = rhs; a1.gamma = 1.0; a1.out = F.tmp_resid; a1.out2 = cur;
+            k::spmv_fused(F.A->diag, nullptr, a1);
+            k::SpmvArgs a2;   // x += Gaux pv
+            a2.x = F.tmp_resid; a2.alpha = 1.0; a2.yin = cur; a2.beta = 1.0; a2.out = cur;
+            k::spmv_fused(*F.Gaux, nullptr, a2);
+            k::SpmvArgs a3;   // r_c = P^T f - (P^T A) x
+            a3.x = cur; a3.xg = rhs; a3.alpha = -1.0; a3.out = C.resid;
+            k::spmv_fused(*F.RA, F.PTneg.get(), a3);
+            iterate(l + 1, C.resid, C.sol, C.alt);
+            k::SpmvArgs a5;   // x' = x + W (f - A x - S e),  S = A P - W^-1 P
+            a5.x = cur; a5.xg = C.sol; a5.alpha = -1.0; a5.f = rhs; a5.gamma = 1.0; a5.s = w; a5.yin = cur; a5.beta = 1.0; a5.out = oth;
+            k::spmv_fused(F.A->diag, F.S.get(), a5);
+            k::SpmvArgs a6;   // pv = f - A x'
+            a6.x = oth; a6.alpha = -1.0; a6.f = rhs; a6.gamma = 1.0; a6.out = F.tmp_resid;
+            k::spmv_fused(F.A->diag, nullptr, a6);
+            k::SpmvArgs a7;   // x' += Gaux pv
+            a7.x = F.tmp_resid; a7.alpha = 1.0; a7.yin = oth; a7.beta = 1.0; a7.out = oth;
+            k::spmv_fused(*F.Gaux, nullptr, a7);
             return;
         }
         const int nf = (F.pre ? F.pre->flips(true) : 0) + (F.post ? F.post->flips(false) : 0);
