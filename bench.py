@@ -293,6 +293,23 @@ def main():
         ms_nat = la.time_kernel(dAr, "spmv", x, y, reps=args.roofline_reps)   # same matrix in the caller's numbering
         rhs_r, sol_r = la.DeviceVector(n, 2.0), la.DeviceVector(n, 1.0)
         ms_v = Hr.time_apply(rhs_r, sol_r, 20)
+        ms_vi = Hr.time_apply_internal(20)        # the cycle as a solver in the hierarchy's numbering runs it (no permutation in / out)
+        # PCG of the example at this size: the iteration lives in the hierarchy's numbering (vectors permuted once per solve)
+        Kr = la.KrylovSolver(dAr, Hr, {"Solver name": "PCG", "Relative tolerance": 1e-6, "Absolute tolerance": 1e-6, "Maximum iterations": 100})
+        br = la.DeviceVector.from_numpy(np.where(np.asarray(abs(Ar - sp.diags(Ar.diagonal())).sum(axis=1)).ravel() == 0.0, 0.0, 1.0))
+        xr = la.DeviceVector(n, 0.0)
+        for _ in range(4):                        # (the first solves of a process pay one-time graph / module costs)
+            Kr.Mult(br, xr)
+        la.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            Kr.Mult(br, xr)
+        la.synchronize()
+        pcg_ms = (time.perf_counter() - t0) / 5 * 1e3
+        pcg = {"iterations": Kr.GetNumIterations(), "converged": Kr.GetConverged(), "ms_per_solve": round(pcg_ms, 3),
+               "ms_per_iteration": round(pcg_ms / max(Kr.GetNumIterations(), 1), 4),
+               "true_rel_residual": float(np.linalg.norm(Ar @ xr.to_numpy() - br.to_numpy()) / np.linalg.norm(br.to_numpy()))}
+        del Kr, br, xr
         shapes_r = []
         for l in range(len(Pr) + 1):
             op = Hr.GetOperator(l)
@@ -327,6 +344,8 @@ def main():
                 "rap": rap,
                 "vcycle_ms": round(ms_v, 4), "vcycles_per_s": round(1e3 / ms_v, 1),
                 "vcycle_GBs": round(vb / (ms_v * 1e-3) / 1e9, 1), "vcycle_frac": round(vb / (ms_v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "vcycle_in_solve_ms": round(ms_vi, 4), "vcycle_in_solve_frac": round(vb / (ms_vi * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "pcg": pcg,
                 "hierarchy_setup_s": round(setup_r, 3), "generate_s": round(gen_s, 1)}
         # HBM traffic of the same launch from the committed PMC passes (tools/roofline_profile.sh), if present
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")

@@ -588,6 +588,9 @@ ELAG_HIP_API int elag_hip_time_kernel(elag_hip_parcsr_t A, elag_hip_smoother_t S
 /* Time `reps` applications of the hierarchy (preconditioner mode, device vectors) with HIP events. */
 ELAG_HIP_API int elag_hip_time_hierarchy(elag_hip_hierarchy_t H, const double *rhs_dev, double *sol_dev,
                                          int reps, double *ms_per_apply);
+/* The same for the cycle alone on vectors that already are in the hierarchy's internal numbering (no permutation around it):
+ * what one preconditioner application costs inside elag_hip_krylov_mult when the solver has adopted that numbering. */
+ELAG_HIP_API int elag_hip_time_hierarchy_internal(elag_hip_hierarchy_t H, int reps, double *ms_per_apply);
 
 #ifdef __cplusplus
 }

@@ -164,6 +164,7 @@ _SIGNATURES = {
     "elag_hip_coarsen_extension": [_p, _p, _dp],
     "elag_hip_time_kernel": [_p, _p, _i, _i, _p, _p, _dp],
     "elag_hip_time_hierarchy": [_p, _p, _p, _i, _dp],
+    "elag_hip_time_hierarchy_internal": [_p, _i, _dp],
 }
 _RESTYPES = {"elag_hip_last_error": C.c_char_p}
 

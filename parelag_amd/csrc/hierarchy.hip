@@ -390,6 +390,21 @@ void hierarchy_apply_raw(elag_hip_hierarchy_s *H, const double *rhs, double *sol
     H->run(rhs, sol, precond);
 }
 bool hierarchy_is_local(const elag_hip_hierarchy_s *H) { return H->all_local; }
+// A solver that iterates with a reordered hierarchy as its preconditioner can live in the hierarchy's numbering altogether:
+// the level-0 operator as the cycle runs it (same matrix as `A_user`, rows / columns permuted) and the new -> old map.
+bool hierarchy_internal_numbering(const elag_hip_hierarchy_s *H, const ParCSR *A_user, ParCSR **A_internal, const int **d_order0)
+{
+    if (!H->reordered || H->A_user != A_user || !H->d_order0) return false;
+    *A_internal = H->lev[0].A;
+    *d_order0 = H->d_order0;
+    return true;
+}
+// preconditioner-mode cycle on vectors that already are in the internal numbering (no gather / scatter around it)
+void hierarchy_apply_internal(elag_hip_hierarchy_s *H, const double *rhs_perm, double *sol_perm)
+{
+    ELAG_REQUIRE(H->finalized, "Hierarchy::Mult before Finalize()");
+    H->iterate(0, rhs_perm, sol_perm, H->lev[0].alt);
+}
 
 // A hierarchy standing where the reference puts any mfem::Solver: the "A00 Inverse" / "S Inverse" entries of the
 // Block2x2*SolverFactory lists name AMGe hierarchies (example_parameterlists/spe10_example_parameters.xml:114-127,
@@ -863,6 +878,50 @@ int elag_hip_time_hierarchy(elag_hip_hierarchy_t H, const double *rhs_dev, doubl
         }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
+        *ms_per_apply = total_ms / reps;
+    });
+}
+
+int elag_hip_time_hierarchy_internal(elag_hip_hierarchy_t H, int reps, double *ms_per_apply)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(H && ms_per_apply && reps > 0, "bad argument");
+        ELAG_REQUIRE(H->finalized, "hierarchy not finalised");
+        const int n = H->lev[0].A->nrows();
+        hipStream_t st = ctx().stream;
+        // the cycle as a solver living in the hierarchy's numbering runs it: no permutation on the way in or out
+        Temp<double> rhs((size_t)n), sol((size_t)n);
+        k::vec_fill(n, 2.0, rhs);
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        if (H->use_graph) {
+            ELAG_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            try { H->iterate(0, rhs, sol, H->lev[0].alt); } catch (...) { (void)hipStreamEndCapture(st, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+            ELAG_HIP_CHECK(hipStreamEndCapture(st, &graph));
+            ELAG_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+        }
+        auto once = [&] { if (exec) ELAG_HIP_CHECK(hipGraphLaunch(exec, st)); else H->iterate(0, rhs, sol, H->lev[0].alt); };
+        hipEvent_t e0, e1;
+        ELAG_HIP_CHECK(hipEventCreate(&e0));
+        ELAG_HIP_CHECK(hipEventCreate(&e1));
+        once();
+        double total_ms = 0.0;
+        for (int done = 0; done < reps;) {
+            const int chunk = std::min(64, reps - done);
+            ELAG_HIP_CHECK(hipEventRecord(e0, st));
+            for (int i = 0; i < chunk; i++) once();
+            ELAG_HIP_CHECK(hipEventRecord(e1, st));
+            ELAG_HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            ELAG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            total_ms += ms;
+            done += chunk;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (exec) (void)hipGraphExecDestroy(exec);
         *ms_per_apply = total_ms / reps;
     });
 }

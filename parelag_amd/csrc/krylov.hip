@@ -512,6 +512,13 @@ __global__ void sub_pred_kernel(int n, const KState *__restrict__ st, double *__
 
 struct elag_hip_krylov_s {
     ParCSR *A = nullptr;
+    // Preconditioned by a hierarchy that renumbered its levels (and built on this very operator), the whole iteration runs in
+    // the hierarchy's numbering: Aop is the hierarchy's level-0 operator, the right-hand side and the initial guess are
+    // permuted once on entry and the solution once on exit -- instead of a gather and a scatter around every V-cycle and an
+    // A p product on the less local numbering.  Dot products only change their order of summation.
+    ParCSR *Aop = nullptr;
+    const int *d_perm = nullptr;     // new -> old, device (owned by the hierarchy)
+    double *bperm = nullptr;
     int solver = ELAG_HIP_KRYLOV_CG;
     int max_iter = 10, restart = 50, check_every = 8;
     double rel_tol = 0.0, abs_tol = 0.0;
@@ -541,6 +548,7 @@ struct elag_hip_krylov_s {
     {
         if (cg_iter) (void)hipGraphExecDestroy(cg_iter);
         dev_free(x); dev_free(r); dev_free(z); dev_free(d); dev_free(w); dev_free(scr); dev_free(V); dev_free(Z); dev_free(hs); dev_free(part);
+        dev_free(bperm);
         for (auto &p : e) dev_free(p);
         if (st) (void)hipFree(st);
         if (h_flags) (void)hipHostFree(h_flags);
@@ -554,7 +562,13 @@ struct elag_hip_krylov_s {
         ELAG_HIP_CHECK(hipMemset(st, 0, sizeof(KState)));
         ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_flags), sizeof(int) * F_COUNT));
         ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_sc), sizeof(double) * S_COUNT));
-        k::prepare_spmv(A->diag);
+        Aop = A;
+        if (prec_kind == ELAG_HIP_PREC_HIERARCHY && !distributed() && std::getenv("ELAG_HIP_KRYLOV_NATURAL") == nullptr) {
+            ParCSR *Ai = nullptr;
+            if (hierarchy_internal_numbering(phier, A, &Ai, &d_perm)) { Aop = Ai; bperm = dev_alloc<double>(nn); }
+            else d_perm = nullptr;
+        }
+        k::prepare_spmv(Aop->diag);
         x = dev_alloc<double>(nn); r = dev_alloc<double>(nn); z = dev_alloc<double>(nn); scr = dev_alloc<double>(nn);
         if (solver == ELAG_HIP_KRYLOV_CG) { d = dev_alloc<double>(nn); part = dev_alloc<double>(2 * (size_t)kPart); }
         if (solver == ELAG_HIP_KRYLOV_STATIONARY) { d = dev_alloc<double>(nn); }
@@ -580,7 +594,8 @@ struct elag_hip_krylov_s {
             psm->apply(rin, c, a, true, false);
             if (c != zout) fail(ELAG_HIP_ERR_STATE, "internal: smoother result in scratch");
         } else if (prec_kind == ELAG_HIP_PREC_HIERARCHY) {
-            hierarchy_apply_raw(phier, rin, zout, true);
+            if (d_perm) hierarchy_apply_internal(phier, rin, zout);
+            else hierarchy_apply_raw(phier, rin, zout, true);
         } else if (prec_kind == ELAG_HIP_PREC_COARSE) {
             pcoarse->apply(rin, zout);
         } else {
@@ -592,13 +607,13 @@ struct elag_hip_krylov_s {
     {
         k::SpmvArgs a;
         a.x = in; a.alpha = 1.0; a.out = out;
-        par_spmv(*A, a);
+        par_spmv(*Aop, a);
     }
     void residual(const double *b, const double *xin, double *out)   // out = b - A x
     {
         k::SpmvArgs a;
         a.x = xin; a.alpha = -1.0; a.f = b; a.gamma = 1.0; a.out = out;
-        par_spmv(*A, a);
+        par_spmv(*Aop, a);
     }
 
     // (u, v) summed over the ranks, left in st->sc[S_TMP]
@@ -920,7 +935,14 @@ struct elag_hip_krylov_s {
     {
         hipStream_t s = ctx().stream;
         const size_t nn = (size_t)n();
-        if (iterative) ELAG_HIP_CHECK(hipMemcpyAsync(x, xio, sizeof(double) * nn, hipMemcpyDeviceToDevice, s));
+        if (d_perm) {
+            // into the hierarchy's numbering: v_perm[new] = v[order[new]]
+            k::vec_gather((int)nn, d_perm, b, bperm);
+            if (iterative) k::vec_gather((int)nn, d_perm, xio, x);
+            b = bperm;
+        } else if (iterative) {
+            ELAG_HIP_CHECK(hipMemcpyAsync(x, xio, sizeof(double) * nn, hipMemcpyDeviceToDevice, s));
+        }
         switch (solver) {
         case ELAG_HIP_KRYLOV_CG: run_cg(b, iterative); break;
         case ELAG_HIP_KRYLOV_GMRES: run_gmres(b, iterative, false); break;
@@ -930,7 +952,8 @@ struct elag_hip_krylov_s {
         default: run_stationary(b, iterative); break;
         }
         fetch_results();
-        ELAG_HIP_CHECK(hipMemcpyAsync(xio, x, sizeof(double) * nn, hipMemcpyDeviceToDevice, s));
+        if (d_perm) k::vec_scatter((int)nn, d_perm, x, xio, 0);
+        else ELAG_HIP_CHECK(hipMemcpyAsync(xio, x, sizeof(double) * nn, hipMemcpyDeviceToDevice, s));
     }
 };
 

@@ -506,6 +506,12 @@ class Hierarchy(_SolverBase):
         check(self._lib.elag_hip_hierarchy_get_ordering(self.h, level, _np_ptr(o)))
         return o
 
+    def time_apply_internal(self, reps) -> float:
+        """mean milliseconds per V-cycle on vectors in the hierarchy's own numbering (the cost inside a Krylov solve)"""
+        ms = C.c_double(0)
+        check(self._lib.elag_hip_time_hierarchy_internal(self.h, int(reps), C.byref(ms)))
+        return ms.value
+
     def time_apply(self, rhs, sol, reps) -> float:
         """mean milliseconds per V-cycle, measured with HIP events on the library's compute stream"""
         pr, lr, _k1 = _vec(rhs)

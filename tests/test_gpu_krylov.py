@@ -246,3 +246,47 @@ def test_krylov_solver_names(la, h1_k1):
         la.KrylovSolver(dA, None, {"Solver name": name})
     with pytest.raises(ValueError, match="Bad solver type"):
         la.KrylovSolver(dA, None, {"Solver name": "QMR"})
+
+
+@pytest.mark.parametrize("name", ["PCG", "GMRES", "BiCGSTAB"])
+def test_solver_adopts_the_numbering_of_a_reordered_hierarchy(la, h1_k2, name):
+    """A hierarchy that renumbered its levels (automatic above 2^18 rows, forced here) hands the Krylov shell its level-0 operator
+    and permutation: the iteration runs in that numbering -- right-hand side and initial guess permuted once on entry, the
+    solution once on exit, no gather / scatter around the V-cycles -- and the caller sees the same iteration as with the
+    natural numbering: same counts as the CPU port, same solution, in preconditioner and in iterative mode."""
+    A, Ps, _ = h1_k2
+    n = A.shape[0]
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi", reorder=1)
+    order = H.GetOrdering(0)
+    assert not np.array_equal(order, np.arange(n)) and np.array_equal(np.sort(order), np.arange(n))
+    h = oracle_h1_hierarchy(A, Ps)
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"])
+    oprec = lambda r, z: Hc.apply(r, z)
+    rng = np.random.default_rng(8)
+    b = rng.uniform(-1, 1, n)
+    params = {"Solver name": name, "Relative tolerance": 1e-9, "Absolute tolerance": 0.0, "Maximum iterations": 100, "Restart size": 30}
+    K = la.KrylovSolver(dA, H, params)
+    x = np.full(n, 3.0)
+    K.Mult(b, x)
+    xr = np.zeros(n)
+    if name == "PCG":
+        ref = orc.mfem_cg(lambda v: A @ v, oprec, b, xr, rel_tol=1e-9, max_iter=100)
+    elif name == "GMRES":
+        ref = orc.mfem_gmres(lambda v: A @ v, oprec, b, xr, rel_tol=1e-9, abs_tol=0.0, max_iter=100, m=30)
+    else:
+        ref = orc.mfem_bicgstab(lambda v: A @ v, oprec, b, xr, rel_tol=1e-9, abs_tol=0.0, max_iter=100)
+    assert K.GetConverged() and ref.converged and K.GetNumIterations() == ref.final_iter
+    assert close(x, xr, 1e-8) and np.linalg.norm(A @ x - b) <= 1e-8 * np.linalg.norm(b)
+    # iterative mode: the caller's initial guess goes through the permutation as well
+    x0 = rng.uniform(-1, 1, n)
+    xd = x0.copy()
+    K.iterative_mode = True
+    K.Mult(b, xd)
+    assert K.GetConverged() and np.linalg.norm(A @ xd - b) <= 1e-8 * np.linalg.norm(b - A @ x0)
+    # the standalone cycle (natural vectors in and out) is untouched
+    y, yr = np.empty(n), np.empty(n)
+    H.Mult(b, y); Hc.apply(b, yr)
+    assert close(y, yr, 1e-11)
+    assert H.time_apply_internal(3) > 0.0
