@@ -182,6 +182,8 @@ struct DevCSR {
     mutable int *uoff = nullptr, *ucols = nullptr;
     mutable int xc_state = 0;   // 0 = not examined, 1 = built, -1 = not worthwhile / not applicable
     mutable int xc_max_unique = 0;
+    mutable int *xc_block_row = nullptr;   // window plan of the x-cache form (== block_row for 2048-entry windows, own array otherwise)
+    mutable int xc_nblocks = 0, xc_window = 0;
     // "sign" form for incidence-type operators whose stored values are all -1, 0 or +1 (the derivatives D_j of the lowest-order
     // de Rham sequence, HiptmairSmoother's D): one 32-bit word per entry -- column in the low 30 bits, bit 31 = negative, bit 30 =
     // stored zero (an eliminated essential column) -- 4 bytes per entry instead of 12.  Built on request (k::prepare_sign_form)
@@ -203,16 +205,23 @@ struct DevCSR {
             nrows = o.nrows; ncols = o.ncols; nnz = o.nnz; I = o.I; J = o.J; a = o.a;
             lanes_per_row = o.lanes_per_row; block_row = o.block_row; nblocks = o.nblocks; max_row_nnz = o.max_row_nnz;
             lidx = o.lidx; uoff = o.uoff; ucols = o.ucols; xc_state = o.xc_state; xc_max_unique = o.xc_max_unique;
-            o.lidx = nullptr; o.uoff = nullptr; o.ucols = nullptr; o.xc_state = 0;
+            xc_block_row = o.xc_block_row; xc_nblocks = o.xc_nblocks; xc_window = o.xc_window;
+            o.lidx = nullptr; o.uoff = nullptr; o.ucols = nullptr; o.xc_state = 0; o.xc_block_row = nullptr; o.xc_nblocks = 0; o.xc_window = 0;
             Js = o.Js; sign_state = o.sign_state; o.Js = nullptr; o.sign_state = 0;
             o.I = o.J = nullptr; o.a = nullptr; o.block_row = nullptr; o.nnz = 0; o.nrows = o.ncols = 0; o.nblocks = 0;
         }
         return *this;
     }
     ~DevCSR() { release(); }
-    void release_xc() const { dev_free(lidx); dev_free(uoff); dev_free(ucols); xc_state = 0; }
+    void release_xc() const
+    {
+        dev_free(lidx); dev_free(uoff); dev_free(ucols);
+        if (xc_block_row && xc_block_row != block_row) dev_free(xc_block_row);
+        xc_block_row = nullptr; xc_nblocks = 0; xc_window = 0;
+        xc_state = 0;
+    }
     void release_sign() const { dev_free(Js); sign_state = 0; }
-    void release() { dev_free(I); dev_free(J); dev_free(a); dev_free(block_row); nblocks = 0; release_xc(); release_sign(); }
+    void release() { release_xc(); release_sign(); dev_free(I); dev_free(J); dev_free(a); dev_free(block_row); nblocks = 0; }
     void alloc(int nr, int nc, int64_t nz);
     void alloc_entries(int64_t nz);   // J / a (+pad) for a matrix whose I is already in place
     void upload(int nr, int nc, const int *hi, const int *hj, const double *ha);

@@ -160,10 +160,10 @@ void DevCSR::choose_spmv_shape()
         const char *e = getenv("ELAG_HIP_LPR");
         forced = e ? atoi(e) : 0;
     }
+    release_xc();          // (before the stream plan goes: the x-cache form may alias it)
+    release_sign();
     dev_free(block_row);
     nblocks = 0;
-    release_xc();
-    release_sign();
     k::build_stream_plan(*this);
     if (forced > 0) { lanes_per_row = forced; return; }
     // the stream kernel wins once the matrix outgrows the caches' latency regime; small (coarse-level) operators

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void spmv_probe_stream_kernel(
 // (10 bytes per entry from HBM instead of 12, and no global gather in the inner loop).
 typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
 
-template <bool HAS_CS>
+template <bool HAS_CS, int THREADS>
 __device__ __forceinline__ void spmv_xc_body(
     int nrows, const int *__restrict__ I, const double *__restrict__ a, const unsigned short *__restrict__ lidx,
     const int *__restrict__ block_row, const int *__restrict__ uoff, const int *__restrict__ ucols, const int *__restrict__ oI,
@@ -339,12 +339,12 @@ __device__ __forceinline__ void spmv_xc_body(
     }
     // the value / position stream of this lane's first two quads is requested before the gather phase, so both
     // memory streams are in flight together
-    const int k0 = kal + (int)threadIdx.x * 4, k1 = k0 + kBlock * 4;
+    const int k0 = kal + (int)threadIdx.x * 4, k1 = k0 + THREADS * 4;
     ushort4v l0 = {0, 0, 0, 0}, l1 = {0, 0, 0, 0};
     double2v a0a = {0, 0}, a0b = {0, 0}, a1a = {0, 0}, a1b = {0, 0};
     if (k0 < kend) { l0 = *reinterpret_cast<const ushort4v *>(lidx + k0); a0a = *reinterpret_cast<const double2v *>(a + k0); a0b = *reinterpret_cast<const double2v *>(a + k0 + 2); }
     if (k1 < kend) { l1 = *reinterpret_cast<const ushort4v *>(lidx + k1); a1a = *reinterpret_cast<const double2v *>(a + k1); a1b = *reinterpret_cast<const double2v *>(a + k1 + 2); }
-    for (int u = (int)threadIdx.x; u < nu; u += kBlock) {
+    for (int u = (int)threadIdx.x; u < nu; u += THREADS) {
         const int c = ucols[u0 + u];
         double v = x[c];
         if (HAS_CS) v *= cs[c];
@@ -363,7 +363,7 @@ __device__ __forceinline__ void spmv_xc_body(
         *reinterpret_cast<double2v *>(prod + (k1 - kal)) = p01;
         *reinterpret_cast<double2v *>(prod + (k1 - kal) + 2) = p23;
     }
-    for (int k = k1 + kBlock * 4; k < kend; k += kBlock * 4) {
+    for (int k = k1 + THREADS * 4; k < kend; k += THREADS * 4) {
         const ushort4v l4 = *reinterpret_cast<const ushort4v *>(lidx + k);
         const double2v a01 = *reinterpret_cast<const double2v *>(a + k);
         const double2v a23 = *reinterpret_cast<const double2v *>(a + k + 2);
@@ -386,7 +386,7 @@ __device__ __forceinline__ void spmv_xc_body(
         p.out[row0] = t;
         if (p.out2) p.out2[row0] = HAS_CS ? x[row0] * p.cs[row0] : x[row0];
     }
-    for (int row = row0 + kBlock; row < r1; row += kBlock) {
+    for (int row = row0 + THREADS; row < r1; row += THREADS) {
         if (p.skip_rows_with_offd && oI && oI[row + 1] > oI[row]) continue;
         const int s = I[row] - kal, e = I[row + 1] - kal;
         double sum = 0.0;
@@ -401,33 +401,35 @@ __device__ __forceinline__ void spmv_xc_body(
     }
 }
 
-template <bool HAS_CS>
-__global__ __launch_bounds__(kBlock) void spmv_xc_kernel(
+template <bool HAS_CS, int THREADS>
+__global__ __launch_bounds__(THREADS) void spmv_xc_kernel(
     int nrows, const int *__restrict__ I, const double *__restrict__ a, const unsigned short *__restrict__ lidx,
     const int *__restrict__ block_row, const int *__restrict__ uoff, const int *__restrict__ ucols, const int *__restrict__ oI,
     int cap, SpmvArgs p)
 {
-    spmv_xc_body<HAS_CS>(nrows, I, a, lidx, block_row, uoff, ucols, oI, cap, p);
+    spmv_xc_body<HAS_CS, THREADS>(nrows, I, a, lidx, block_row, uoff, ucols, oI, cap, p);
 }
 
-__global__ __launch_bounds__(kBlock) void spmv_probe_xc_kernel(
+// the same code under another name for the setup-time measurement (see spmv_probe_stream_kernel)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void spmv_probe_xc_kernel(
     int nrows, const int *__restrict__ I, const double *__restrict__ a, const unsigned short *__restrict__ lidx,
     const int *__restrict__ block_row, const int *__restrict__ uoff, const int *__restrict__ ucols, const int *__restrict__ oI,
     int cap, SpmvArgs p)
 {
-    spmv_xc_body<false>(nrows, I, a, lidx, block_row, uoff, ucols, oI, cap, p);
+    spmv_xc_body<false, THREADS>(nrows, I, a, lidx, block_row, uoff, ucols, oI, cap, p);
 }
 
 // One workgroup per window: sort the window's columns in LDS (bitonic), mark the first element of every run, scan.
 // fill == 0: ucount[c] = number of distinct columns.  fill == 1: ucols / lidx are written.
-constexpr int kXcCap = 4096;   // entries per window the builder handles (kStreamNnz + max_row <= kXcCap)
-
+// CAP: entries per window the builder handles (window + longest row + 8 <= CAP); 4096 for 2048-entry windows, 8192 for 4096
+template <int CAP>
 __global__ __launch_bounds__(kBlock) void xc_build_kernel(const int *__restrict__ block_row, const int *__restrict__ J, int *__restrict__ ucount,
                                                           const int *__restrict__ uoff, int *__restrict__ ucols,
                                                           unsigned short *__restrict__ lidx, int fill)
 {
-    __shared__ int keys[kXcCap];
-    __shared__ unsigned short pos[kXcCap];
+    __shared__ int keys[CAP];
+    __shared__ unsigned short pos[CAP];
     __shared__ int part[kBlock];
     const int c = blockIdx.x;
     const int kbeg = block_row[2 * c + 1], kend = block_row[2 * c + 3];
@@ -525,16 +527,26 @@ int xc_mode()
     return v;
 }
 
-void launch_xc(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hipStream_t st)
+template <int THREADS>
+void launch_xc_t(const DevCSR &A, const int *oI, const SpmvArgs &p, hipStream_t st, bool probe)
 {
-    const int cap = DevCSR::kStreamNnz + A.max_row_nnz + 8;
+    const int cap = A.xc_window + A.max_row_nnz + 8;
     const size_t lds = sizeof(double) * ((size_t)cap + (size_t)A.xc_max_unique);
-    const int *oI = (p.skip_rows_with_offd && offd) ? offd->I : nullptr;
-    if (p.cs)
-        hipLaunchKernelGGL((spmv_xc_kernel<true>), dim3((unsigned)A.nblocks), dim3(kBlock), lds, st, A.nrows, A.I, A.a, A.lidx, A.block_row, A.uoff, A.ucols, oI, cap, p);
+    const dim3 grid((unsigned)A.xc_nblocks), block(THREADS);
+    if (probe)
+        hipLaunchKernelGGL((spmv_probe_xc_kernel<THREADS>), grid, block, lds, st, A.nrows, A.I, A.a, A.lidx, A.xc_block_row, A.uoff, A.ucols, oI, cap, p);
+    else if (p.cs)
+        hipLaunchKernelGGL((spmv_xc_kernel<true, THREADS>), grid, block, lds, st, A.nrows, A.I, A.a, A.lidx, A.xc_block_row, A.uoff, A.ucols, oI, cap, p);
     else
-        hipLaunchKernelGGL((spmv_xc_kernel<false>), dim3((unsigned)A.nblocks), dim3(kBlock), lds, st, A.nrows, A.I, A.a, A.lidx, A.block_row, A.uoff, A.ucols, oI, cap, p);
+        hipLaunchKernelGGL((spmv_xc_kernel<false, THREADS>), grid, block, lds, st, A.nrows, A.I, A.a, A.lidx, A.xc_block_row, A.uoff, A.ucols, oI, cap, p);
     ELAG_LAUNCH_CHECK();
+}
+
+void launch_xc(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hipStream_t st, bool probe = false)
+{
+    const int *oI = (p.skip_rows_with_offd && offd) ? offd->I : nullptr;
+    if (A.xc_window > DevCSR::kStreamNnz) launch_xc_t<512>(A, oI, p, st, probe);   // 4096-entry windows: same entries per lane
+    else launch_xc_t<256>(A, oI, p, st, probe);
 }
 
 void launch_stream(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hipStream_t st)
@@ -572,96 +584,139 @@ void build_stream_plan(DevCSR &A)
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
 }
 
-void prepare_spmv(const DevCSR &A, bool force)
+namespace {
+
+// builds the x-cache tables of A for `window` entries per workgroup; false when it does not apply (or, unforced, does not pay)
+bool xc_build(const DevCSR &A, int window, bool force)
 {
-    if (A.xc_state != 0 || (xc_mode() == 0 && !force)) return;
-    A.xc_state = -1;
-    if (A.lanes_per_row != 0 || !A.block_row || A.nnz == 0 || A.nblocks == 0) return;
-    // Measured: the form pays only for operators streamed from HBM (cube456 x5, 37.7 M entries: +6 % SpMV, +12 % Jacobi
-    // sweep); operators that stay resident in the 256 MB Infinity Cache (x3 / x4 sizes) run 2-5 % faster with the plain
-    // stream kernel, whose single phase hides the cache latency better.
-    if (!force && xc_mode() < 0 && A.nnz < (int64_t(1) << 24)) return;
-    if (DevCSR::kStreamNnz + A.max_row_nnz + 8 > kXcCap) return;   // window must fit the builder and two LDS arrays (<= 64 KB)
+    const int cap = window + A.max_row_nnz + 8;
+    if (cap > 8192) return false;                       // builder capacity; two LDS arrays of the kernel stay <= 64 KB + xs
     hipStream_t st = ctx().stream;
-    const int nb = A.nblocks;
+    int *plan = nullptr;
+    int nb = A.nblocks;
+    if (window == DevCSR::kStreamNnz) {
+        plan = A.block_row;
+    } else {
+        nb = (int)((A.nnz + window - 1) / window);
+        plan = dev_alloc<int>(2 * ((size_t)nb + 1) + 2);
+        hipLaunchKernelGGL(stream_plan_kernel, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, st, A.nrows, (const int *)A.I, nb, window, plan);
+        ELAG_LAUNCH_CHECK();
+    }
+    auto build = [&](int *ucount, const int *uoff, int *ucols, unsigned short *lidx, int fill) {
+        if (cap <= 4096)
+            hipLaunchKernelGGL((xc_build_kernel<4096>), dim3((unsigned)nb), dim3(kBlock), 0, st, (const int *)plan, (const int *)A.J, ucount, uoff, ucols, lidx, fill);
+        else
+            hipLaunchKernelGGL((xc_build_kernel<8192>), dim3((unsigned)nb), dim3(kBlock), 0, st, (const int *)plan, (const int *)A.J, ucount, uoff, ucols, lidx, fill);
+        ELAG_LAUNCH_CHECK();
+    };
     int *uoff = dev_alloc<int>((size_t)nb + 1);
     int total = 0;
     {
         Temp<int> ucount((size_t)nb);
-        hipLaunchKernelGGL(xc_build_kernel, dim3((unsigned)nb), dim3(kBlock), 0, st, (const int *)A.block_row, (const int *)A.J, ucount.p,
-                           (const int *)nullptr, (int *)nullptr, (unsigned short *)nullptr, 0);
-        ELAG_LAUNCH_CHECK();
+        build(ucount.p, nullptr, nullptr, nullptr, 0);
         exclusive_scan(ucount, uoff, nb);
         ELAG_HIP_CHECK(hipMemcpyAsync(&total, uoff + nb, sizeof(int), hipMemcpyDeviceToHost, st));
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
     }
     // worthwhile when a column is used by >= 2 entries of its window on average (otherwise the plain gather is as good)
     const double reuse = total ? (double)A.nnz / total : 0.0;
-    {
-        std::vector<int> ho = host_from_dev((const int *)uoff, (size_t)nb + 1);
-        int mx = 0;
-        for (int c = 0; c < nb; c++) mx = std::max(mx, ho[(size_t)c + 1] - ho[(size_t)c]);
-        A.xc_max_unique = (mx + 7) & ~7;
-        if (getenv("ELAG_HIP_XC_VERBOSE"))
-            fprintf(stderr, "[elag_hip] x-cache: n=%d nnz=%lld windows=%d unique/window avg %.1f max %d reuse %.2f\n", A.nrows, (long long)A.nnz, nb,
-                    (double)total / nb, mx, reuse);
+    std::vector<int> ho = host_from_dev((const int *)uoff, (size_t)nb + 1);
+    int mx = 0;
+    for (int c = 0; c < nb; c++) mx = std::max(mx, ho[(size_t)c + 1] - ho[(size_t)c]);
+    if (getenv("ELAG_HIP_XC_VERBOSE"))
+        fprintf(stderr, "[elag_hip] x-cache: n=%d nnz=%lld window=%d windows=%d unique/window avg %.1f max %d reuse %.2f\n", A.nrows, (long long)A.nnz,
+                window, nb, (double)total / nb, mx, reuse);
+    if ((!force && reuse < 2.0) || mx > 65535) {
+        dev_free(uoff);
+        if (plan != A.block_row) dev_free(plan);
+        return false;
     }
-    if (!force && xc_mode() < 0 && reuse < 2.0) { dev_free(uoff); return; }
+    A.xc_max_unique = (mx + 7) & ~7;
     A.uoff = uoff;
     A.ucols = dev_alloc<int>((size_t)total);
     A.lidx = dev_alloc<unsigned short>((size_t)A.nnz + 8);
     ELAG_HIP_CHECK(hipMemsetAsync(A.lidx + A.nnz, 0, 8 * sizeof(unsigned short), st));
-    hipLaunchKernelGGL(xc_build_kernel, dim3((unsigned)nb), dim3(kBlock), 0, st, (const int *)A.block_row, (const int *)A.J, (int *)nullptr,
-                       (const int *)A.uoff, A.ucols, A.lidx, 1);
-    ELAG_LAUNCH_CHECK();
+    build(nullptr, A.uoff, A.ucols, A.lidx, 1);
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    A.xc_block_row = plan; A.xc_nblocks = nb; A.xc_window = window;
     A.xc_state = 1;
-    if (force || xc_mode() >= 0) return;
-    // Heuristic mode: both forms exist now, so let the operator itself decide.  A few launches of each on a scratch
-    // vector pair (HIP events on this stream); the x-cache form is kept only when it is measurably faster on THIS
-    // operator and THIS device -- the two are within a few per cent of each other and which one wins depends on how well
-    // the numbering clusters the columns of a window (profiles/r02_spmv_ab_*.txt).
-    {
-        Temp<double> tx((size_t)std::max(A.ncols, A.nrows)), ty((size_t)A.nrows);
-        ELAG_HIP_CHECK(hipMemsetAsync(tx, 0, sizeof(double) * (size_t)std::max(A.ncols, A.nrows), st));
-        SpmvArgs p;
-        p.x = tx; p.out = ty;
-        hipEvent_t e0, e1;
-        ELAG_HIP_CHECK(hipEventCreate(&e0));
-        ELAG_HIP_CHECK(hipEventCreate(&e1));
-        const int cap = DevCSR::kStreamNnz + A.max_row_nnz + 8;
-        const size_t lds_s = sizeof(double) * (size_t)cap, lds_x = sizeof(double) * ((size_t)cap + (size_t)A.xc_max_unique);
-        auto probe = [&](bool xc) {
-            if (xc)
-                hipLaunchKernelGGL(spmv_probe_xc_kernel, dim3((unsigned)A.nblocks), dim3(kBlock), lds_x, st, A.nrows, A.I, A.a, A.lidx, A.block_row,
-                                   A.uoff, A.ucols, (const int *)nullptr, cap, p);
-            else
-                hipLaunchKernelGGL(spmv_probe_stream_kernel, dim3((unsigned)A.nblocks), dim3(kBlock), lds_s, st, A.nrows, A.I, A.J, A.a, A.block_row,
-                                   (const int *)nullptr, p);
-        };
-        auto run = [&](bool xc) {
-            float best = 1e30f;
-            for (int rep = 0; rep < 3; rep++) {
-                for (int w = 0; w < 2; w++) probe(xc);
-                ELAG_HIP_CHECK(hipEventRecord(e0, st));
-                for (int w = 0; w < 8; w++) probe(xc);
-                ELAG_LAUNCH_CHECK();
-                ELAG_HIP_CHECK(hipEventRecord(e1, st));
-                ELAG_HIP_CHECK(hipEventSynchronize(e1));
-                float ms = 0.f;
-                ELAG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-                best = std::min(best, ms / 8);
-            }
-            return best;
-        };
-        const float t_stream = run(false), t_xc = run(true);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        if (getenv("ELAG_HIP_XC_VERBOSE"))
-            fprintf(stderr, "[elag_hip] x-cache autotune: stream %.2f us, x-cache %.2f us -> %s\n", t_stream * 1e3, t_xc * 1e3,
-                    t_xc < 0.99f * t_stream ? "x-cache" : "stream");
-        if (!(t_xc < 0.99f * t_stream)) { A.release_xc(); A.xc_state = -1; }
+    return true;
+}
+
+int xc_window_env()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ELAG_HIP_XC_WINDOW"); v = e ? atoi(e) : 0; }   // 0 = measure 2048 and 4096
+    return v;
+}
+
+}  // namespace
+
+void prepare_spmv(const DevCSR &A, bool force)
+{
+    if (A.xc_state != 0 || (xc_mode() == 0 && !force)) return;
+    A.xc_state = -1;
+    if (A.lanes_per_row != 0 || !A.block_row || A.nnz == 0 || A.nblocks == 0) return;
+    // Measured: the form pays only for operators streamed from HBM (cube456 x5, 37.7 M entries); operators that stay resident
+    // in the 256 MB Infinity Cache (x3 / x4 sizes) run 2-5 % faster with the plain stream kernel, whose single phase hides
+    // the cache latency better.
+    if (!force && xc_mode() < 0 && A.nnz < (int64_t(1) << 24)) return;
+    hipStream_t st = ctx().stream;
+    if (force || xc_mode() >= 0) {
+        const int w = xc_window_env() ? xc_window_env() : DevCSR::kStreamNnz;
+        if (!xc_build(A, w, force)) A.xc_state = -1;
+        return;
     }
+    // Heuristic mode: let the operator itself decide.  A few launches of each candidate on a scratch vector pair (HIP events
+    // on this stream, under kernel names of their own): the plain stream kernel and the x-cache form with 2048- and with
+    // 4096-entry windows (a larger window shares its gathered x among more rows: fewer distinct-column fetches in total; it
+    // also holds twice the LDS per workgroup).  The x-cache form is kept only when it is measurably faster on THIS operator
+    // and THIS device (profiles/r02_spmv_forms_*.txt).
+    Temp<double> tx((size_t)std::max(A.ncols, A.nrows)), ty((size_t)A.nrows);
+    ELAG_HIP_CHECK(hipMemsetAsync(tx, 0, sizeof(double) * (size_t)std::max(A.ncols, A.nrows), st));
+    SpmvArgs p;
+    p.x = tx; p.out = ty;
+    hipEvent_t e0, e1;
+    ELAG_HIP_CHECK(hipEventCreate(&e0));
+    ELAG_HIP_CHECK(hipEventCreate(&e1));
+    auto timed = [&](auto &&launch) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; rep++) {
+            for (int w = 0; w < 2; w++) launch();
+            ELAG_HIP_CHECK(hipEventRecord(e0, st));
+            for (int w = 0; w < 8; w++) launch();
+            ELAG_LAUNCH_CHECK();
+            ELAG_HIP_CHECK(hipEventRecord(e1, st));
+            ELAG_HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            ELAG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            best = std::min(best, ms / 8);
+        }
+        return best;
+    };
+    const size_t lds_s = sizeof(double) * (size_t)(DevCSR::kStreamNnz + A.max_row_nnz + 8);
+    const float t_stream = timed([&] {
+        hipLaunchKernelGGL(spmv_probe_stream_kernel, dim3((unsigned)A.nblocks), dim3(kBlock), lds_s, st, A.nrows, A.I, A.J, A.a, A.block_row,
+                           (const int *)nullptr, p);
+    });
+    float t_best = t_stream;
+    int w_best = 0;
+    const int candidates[2] = {DevCSR::kStreamNnz, 2 * DevCSR::kStreamNnz};
+    float t_w[2] = {0.f, 0.f};
+    for (int c = 0; c < 2; c++) {
+        if (xc_window_env() && xc_window_env() != candidates[c]) continue;
+        if (!xc_build(A, candidates[c], false)) { A.xc_state = -1; continue; }
+        t_w[c] = timed([&] { launch_xc(A, nullptr, p, st, true); });
+        if (t_w[c] < 0.99f * t_best) { t_best = t_w[c]; w_best = candidates[c]; }
+        A.release_xc();
+        A.xc_state = -1;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (getenv("ELAG_HIP_XC_VERBOSE"))
+        fprintf(stderr, "[elag_hip] SpMV forms on this operator: stream %.2f us, x-cache/2048 %.2f us, x-cache/4096 %.2f us -> %s\n", t_stream * 1e3,
+                t_w[0] * 1e3, t_w[1] * 1e3, w_best == 0 ? "stream" : (w_best == 2048 ? "x-cache/2048" : "x-cache/4096"));
+    if (w_best && !xc_build(A, w_best, false)) A.xc_state = -1;
 }
 
 bool prepare_sign_form(const DevCSR &A)
