@@ -68,7 +68,9 @@ double reduce_max(int64_t n, const double *a);
 void exclusive_scan(const int *in, int *out, int n);  // out has n+1 entries, out[n] = total
 void csr_transpose(const DevCSR &A, DevCSR &AT);
 void csr_sort_rows(DevCSR &A);
-void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C);  // C = A*B, columns ascending
+// C = A*B, columns ascending.  spmv_plan = false for an intermediate that is only ever an operand of another product (no SpMV
+// dispatch plan is built for it)
+void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C, bool spmv_plan = true);
 void csr_add(double a, const DevCSR &A, double b, const DevCSR &B, DevCSR &C);
 void csr_delete_zeros(const DevCSR &A, double tol, DevCSR &out);
 void csr_scale_rows(DevCSR &A, const double *d);

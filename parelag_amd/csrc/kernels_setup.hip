@@ -347,25 +347,34 @@ __global__ void split_big_kernel(int nrows, const int *__restrict__ ub, int *__r
 //   4. the lane owning an output entry walks the product list once more and adds the matching products in storage
 //      order -- deterministic, no atomics, and the same summation order as the reference's marker loop.
 // O(products) broadcast steps per row instead of O(products log^2) exchanges.
+// Single-pass use (NUMERIC with rownnz != nullptr): CI then holds the rows' offsets in an upper-bound layout (room for every
+// product of the row), the distinct entries are written there and their number recorded in rownnz; esc_compact_kernel moves
+// them to their final place once the scan of rownnz is known.  This replaces the symbolic launch of the two-pass scheme.
 template <int G, int R, bool NUMERIC, class Expander>
 __global__ __launch_bounds__(kBlock) void esc_wave_kernel(int nrows, const int *__restrict__ ub, int lo, int hi, Expander ex,
                                                           int *__restrict__ rownnz, const int *__restrict__ CI, int *__restrict__ CJ,
-                                                          double *__restrict__ Ca)
+                                                          double *__restrict__ Ca, const int *__restrict__ rowlist = nullptr, int nlist = 0)
 {
-    // a group of G lanes per row (G = 16 / 32: several rows per wavefront; G = 64: one row, R products per lane)
-    static_assert(G == 64 || R == 1, "several products per lane only with whole-wave groups");
+    // a group of G lanes per row (G = 16 / 32: several rows per wavefront; G = 64: one row), R products per lane.
+    // The groups of a wavefront walk their product lists in step (broadcast reads at the same offset of each group's slice):
+    // the slices are one entry longer than needed so that they start in different LDS banks (SQ_LDS_BANK_CONFLICT was 40 % of
+    // the LDS cycles with 256-byte slices, profiles/r02_rap_pmc.txt).
     constexpr int N = G * R;
+    constexpr int NP = (G < 64) ? N + 1 : N;
     constexpr int NG = kBlock / G;
-    __shared__ u64 key[NG * N];
-    __shared__ double val[NUMERIC ? NG * N : 1];
-    __shared__ int ucol[NG * N];
+    __shared__ u64 key[NG * NP];
+    __shared__ double val[NUMERIC ? NG * NP : 1];
+    __shared__ int ucol[NG * NP];
     const int g = threadIdx.x / G, lane = threadIdx.x & (G - 1);
-    const int row = blockIdx.x * NG + g;
+    // rowlist: the rows of this launch's class, gathered beforehand (a launch over all rows spends most of its waves on
+    // rows of other classes); without it every row is looked at and the (lo, hi] test decides
+    const int gi = blockIdx.x * NG + g;
+    const int row = rowlist ? (gi < nlist ? rowlist[gi] : nrows) : gi;
     const int u = row < nrows ? ub[row] : 0;
     const bool active = u > lo && u <= hi;          // (lo, hi]: this launch's class of rows
-    u64 *kw = key + g * N;
-    double *vw = NUMERIC ? val + g * N : val;
-    int *uc = ucol + g * N;
+    u64 *kw = key + g * NP;
+    double *vw = NUMERIC ? val + g * NP : val;
+    int *uc = ucol + g * NP;
     if (active) ex.template expand<NUMERIC, G>(row, 0u, 0, kw, vw);
     __syncthreads();
     int E = 0;
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(kBlock) void esc_wave_kernel(int nrows, const int *
             if (first[r]) uc[E + __popcll(m & ((1ull << lane) - 1ull))] = ck[r];
             E += __popcll(m);
         }
-        if (!NUMERIC && lane == 0) rownnz[row] = E;
+        if ((!NUMERIC || rownnz) && lane == 0) rownnz[row] = E;
     }
     if (!NUMERIC) return;
     __syncthreads();                                 // the distinct-column lists are complete
@@ -404,6 +413,76 @@ __global__ __launch_bounds__(kBlock) void esc_wave_kernel(int nrows, const int *
         CJ[base + rank] = c;
         Ca[base + rank] = sum;
     }
+}
+
+// ub of the rows the wave path handles (others 0): its scan gives the rows' offsets in the upper-bound layout
+__global__ void wave_ub_kernel(int nrows, const int *__restrict__ ub, int wave_cap, int *__restrict__ ubw, unsigned long long *__restrict__ total)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    int v = 0;
+    if (row < nrows) { const int u = ub[row]; v = (u > 0 && u <= wave_cap) ? u : 0; ubw[row] = v; }
+    // 64-bit total (the int scan of ubw is only used when this fits); only asked for when n * wave_cap could pass 2^31
+    if (total) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, (unsigned long long)v);
+    }
+}
+
+// rows written in the upper-bound layout -> their final place (16 lanes per row; rows of the chunked path have ubw == 0)
+__global__ __launch_bounds__(kBlock) void esc_compact_kernel(int nrows, const int *__restrict__ ubw, const int *__restrict__ UBI,
+                                                             const int *__restrict__ CI, const int *__restrict__ Ju, const double *__restrict__ au,
+                                                             int *__restrict__ CJ, double *__restrict__ Ca)
+{
+    const int row = (int)((blockIdx.x * (long long)kBlock + threadIdx.x) >> 4);
+    const int lane = threadIdx.x & 15;
+    if (row >= nrows || ubw[row] == 0) return;
+    const int src = UBI[row], dst = CI[row], cnt = CI[row + 1] - dst;
+    for (int e = lane; e < cnt; e += 16) { CJ[dst + e] = Ju[src + e]; Ca[dst + e] = au[src + e]; }
+}
+
+// rows of the wave path sorted into their classes by number of products: class c holds the rows with bounds[c] < ub <= bounds[c+1].
+// A workgroup reserves one range per class (one atomic each) and writes its rows there in ascending order.
+constexpr int kNumClasses = 5;
+struct ClassBounds { int b[kNumClasses + 1]; };
+
+__global__ __launch_bounds__(kBlock) void esc_classify_kernel(int nrows, const int *__restrict__ ub, ClassBounds cb, int *__restrict__ counters /*kNumClasses*/,
+                                                              int *__restrict__ lists /*kNumClasses x nrows*/, int fill)
+{
+    __shared__ int wcount[kNumClasses][kBlock / 64];
+    __shared__ int base[kNumClasses];
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    const int u = row < nrows ? ub[row] : 0;
+    int cls = -1;
+#pragma unroll
+    for (int c = 0; c < kNumClasses; c++)
+        if (u > cb.b[c] && u <= cb.b[c + 1]) cls = c;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int before = 0;
+#pragma unroll
+    for (int c = 0; c < kNumClasses; c++) {
+        const unsigned long long m = __ballot(cls == c);
+        if (cls == c) before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wcount[c][w] = __popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumClasses) {
+        int tot = 0;
+        for (int i = 0; i < kBlock / 64; i++) tot += wcount[threadIdx.x][i];
+        base[threadIdx.x] = tot ? atomicAdd(&counters[threadIdx.x], tot) : 0;
+    }
+    __syncthreads();
+    if (!fill || cls < 0) return;
+    int off = base[cls] + before;
+    for (int i = 0; i < w; i++) off += wcount[cls][i];
+    lists[(size_t)cls * nrows + off] = row;
+}
+
+inline bool single_pass_enabled()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ELAG_HIP_ESC_SINGLE_PASS"); v = e ? atoi(e) : 1; }   // 0 = two-pass (A/B runs)
+    return v != 0;
 }
 
 inline bool wave_path_enabled()
@@ -441,7 +520,7 @@ struct EscPlan {
 };
 
 template <class Expander>
-void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C)
+void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_plan = true)
 {
     hipStream_t st = ctx().stream;
     const int n = plan.nrows;
@@ -454,6 +533,83 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C)
     if (plan.nbig)
         hipLaunchKernelGGL((esc_kernel<kBigCap, true, false, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
                            plan.ub.p, plan.biglist.p, ex, rownnz.p, (const int *)nullptr, (int *)nullptr, (double *)nullptr);
+    // ---- single pass for the wave rows: numeric launch into an upper-bound layout, counts recorded on the way, then a
+    //      compaction (the symbolic launches of these rows -- a third of a Galerkin product's time -- are not needed) ----
+    if (plan.wave_cap > 0 && single_pass_enabled()) {
+        Temp<int> ubw((size_t)n), UBI((size_t)n + 1);
+        Temp<unsigned long long> tot64(1);
+        ELAG_HIP_CHECK(hipMemsetAsync(tot64, 0, sizeof(unsigned long long), st));
+        const bool may_overflow = (unsigned long long)n * (unsigned long long)plan.wave_cap >= (1ull << 31);
+        hipLaunchKernelGGL(wave_ub_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, (const int *)plan.ub.p, plan.wave_cap, ubw.p,
+                           may_overflow ? tot64.p : (unsigned long long *)nullptr);
+        ELAG_LAUNCH_CHECK();
+        unsigned long long total_ub = 0;
+        if (may_overflow) {
+            ELAG_HIP_CHECK(hipMemcpyAsync(&total_ub, tot64.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        // the upper-bound layout is indexed with ints and lives in the scratch arena: at most 2^31 - 1 products and 16 GiB
+        if (total_ub < (1ull << 31)) {
+            exclusive_scan(ubw, UBI, n);
+            int tot = 0;
+            ELAG_HIP_CHECK(hipMemcpyAsync(&tot, UBI.p + n, sizeof(int), hipMemcpyDeviceToHost, st));
+            ELAG_HIP_CHECK(hipStreamSynchronize(st));
+            total_ub = (unsigned long long)tot;
+        }
+        if (total_ub < (1ull << 31) && total_ub * 12ull <= (16ull << 30)) {
+            Temp<int> Ju((size_t)std::max<long long>(total_ub, 1));
+            Temp<double> au((size_t)std::max<long long>(total_ub, 1));
+            const int *ubp = plan.ub.p;
+            // row classes by number of products, each with the smallest lane group that still expands a row in one pass (the
+            // entries of the left factor's row are what the lanes of a group share out: 15 for A, 2-15 for P^T; the products
+            // only set how many slots a lane owns, R), each launched over the list of ITS rows
+            const ClassBounds cb{{0, 16, 32, 64, 128, kWaveCap}};
+            Temp<int> ccount(kNumClasses), lists((size_t)kNumClasses * (size_t)n);
+            ELAG_HIP_CHECK(hipMemsetAsync(ccount, 0, sizeof(int) * kNumClasses, st));
+            hipLaunchKernelGGL(esc_classify_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, ubp, cb, ccount.p, lists.p, 1);
+            ELAG_LAUNCH_CHECK();
+            int hc[kNumClasses];
+            ELAG_HIP_CHECK(hipMemcpyAsync(hc, ccount.p, sizeof(int) * kNumClasses, hipMemcpyDeviceToHost, st));
+            ELAG_HIP_CHECK(hipStreamSynchronize(st));
+            auto cls_list = [&](int c) { return (const int *)(lists.p + (size_t)c * n); };
+            if (hc[0])
+                hipLaunchKernelGGL((esc_wave_kernel<16, 1, true, Expander>), dim3(grid1((long long)hc[0] * 16)), dim3(kBlock), 0, st, n, ubp, 0, 16, ex,
+                                   rownnz.p, (const int *)UBI.p, Ju.p, au.p, cls_list(0), hc[0]);
+            if (hc[1])
+                hipLaunchKernelGGL((esc_wave_kernel<16, 2, true, Expander>), dim3(grid1((long long)hc[1] * 16)), dim3(kBlock), 0, st, n, ubp, 16, 32, ex,
+                                   rownnz.p, (const int *)UBI.p, Ju.p, au.p, cls_list(1), hc[1]);
+            if (hc[2])
+                hipLaunchKernelGGL((esc_wave_kernel<32, 2, true, Expander>), dim3(grid1((long long)hc[2] * 32)), dim3(kBlock), 0, st, n, ubp, 32, 64, ex,
+                                   rownnz.p, (const int *)UBI.p, Ju.p, au.p, cls_list(2), hc[2]);
+            if (hc[3])
+                hipLaunchKernelGGL((esc_wave_kernel<64, 2, true, Expander>), dim3(grid1((long long)hc[3] * 64)), dim3(kBlock), 0, st, n, ubp, 64, 128, ex,
+                                   rownnz.p, (const int *)UBI.p, Ju.p, au.p, cls_list(3), hc[3]);
+            if (hc[4])
+                hipLaunchKernelGGL((esc_wave_kernel<64, 4, true, Expander>), dim3(grid1((long long)hc[4] * 64)), dim3(kBlock), 0, st, n, ubp, 128, kWaveCap, ex,
+                                   rownnz.p, (const int *)UBI.p, Ju.p, au.p, cls_list(4), hc[4]);
+            ELAG_LAUNCH_CHECK();
+            int *CI = dev_alloc<int>((size_t)n + 1);
+            exclusive_scan(rownnz, CI, n);
+            int nnz = 0;
+            ELAG_HIP_CHECK(hipMemcpyAsync(&nnz, CI + n, sizeof(int), hipMemcpyDeviceToHost, st));
+            ELAG_HIP_CHECK(hipStreamSynchronize(st));
+            C.release();
+            C.nrows = n; C.ncols = ncols; C.I = CI;
+            C.alloc_entries(nnz);
+            if (nch)
+                hipLaunchKernelGGL((esc_kernel<2 * kCap, false, true, Expander>), dim3(nch), dim3(kBlock), 0, st, n, plan.ubscan.p,
+                                   plan.ub_small.p, (const int *)nullptr, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
+            if (plan.nbig)
+                hipLaunchKernelGGL((esc_kernel<kBigCap, true, true, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
+                                   plan.ub.p, plan.biglist.p, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
+            hipLaunchKernelGGL(esc_compact_kernel, dim3(grid1((long long)n * 16)), dim3(kBlock), 0, st, n, (const int *)ubw.p, (const int *)UBI.p,
+                               (const int *)C.I, (const int *)Ju.p, (const double *)au.p, C.J, C.a);
+            ELAG_LAUNCH_CHECK();
+            ELAG_HIP_CHECK(hipStreamSynchronize(st));      // Ju / au go back to the arena when this scope ends
+            if (spmv_plan) C.choose_spmv_shape();
+            return;
+        }
+    }
     // row classes by number of products: (0,16] 16 lanes per row, (16,32] 32, (32,64] a wavefront, (64,256] 4 per lane
     if (plan.wave_cap > 0) {
         const int *ubp = plan.ub.p;
@@ -493,12 +649,12 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C)
                            (const int *)C.I, C.J, C.a);
     }
     ELAG_LAUNCH_CHECK();
-    C.choose_spmv_shape();
+    if (spmv_plan) C.choose_spmv_shape();
 }
 
 }  // namespace
 
-void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C)
+void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C, bool spmv_plan)
 {
     ELAG_REQUIRE(A.ncols == B.nrows, "spgemm: inner dimensions differ (%d vs %d)", A.ncols, B.nrows);
     if (A.nrows == 0) { C.set_empty(0, B.ncols); return; }
@@ -508,7 +664,7 @@ void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C)
     plan.wave_cap = wave_path_enabled() ? kWaveCap : 0;
     plan.finish();
     MatmulExpander ex{a, b};
-    esc_run(plan, ex, B.ncols, C);
+    esc_run(plan, ex, B.ncols, C, spmv_plan);
 }
 
 void csr_add(double ca, const DevCSR &A, double cb, const DevCSR &B, DevCSR &C)

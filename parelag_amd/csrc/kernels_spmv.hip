@@ -494,11 +494,19 @@ __global__ void stream_plan_kernel(int nrows, const int *__restrict__ I, int nbl
 
 __global__ void max_row_kernel(int nrows, const int *__restrict__ I, int *__restrict__ result)
 {
+    __shared__ int sh[4];
     int m = 0;
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) m = max(m, I[r + 1] - I[r]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(result, m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // one atomic per workgroup, and only when it can change the result (thousands of waves hitting one address cost 50 us)
+    if (threadIdx.x == 0) {
+        const int w = (int)(blockDim.x >> 6);
+        for (int i = 1; i < w; i++) m = max(m, sh[i]);
+        if (m > 0) atomicMax(result, m);
+    }
 }
 
 int stream_variant()
@@ -576,7 +584,7 @@ void build_stream_plan(DevCSR &A)
     Temp<int> m(1);
     ELAG_HIP_CHECK(hipMemsetAsync(m, 0, sizeof(int), st));
     if (A.nrows) {
-        const unsigned g = (unsigned)std::min<long long>(((long long)A.nrows + 255) / 256, 1024);
+        const unsigned g = (unsigned)std::min<long long>(((long long)A.nrows + 255) / 256, 512);
         hipLaunchKernelGGL(max_row_kernel, dim3(g), dim3(256), 0, st, A.nrows, (const int *)A.I, m.p);
     }
     ELAG_LAUNCH_CHECK();
