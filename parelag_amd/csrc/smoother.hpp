@@ -49,10 +49,10 @@ struct RelaxSmoother : elag_hip_smoother_s {
 // hypre relax types 2 / 4 (l1 Gauss-Seidel, plain / truncated l1 norms) and 6 (hybrid symmetric Gauss-Seidel): level-scheduled
 // forward + backward sweeps in place (sweep.hip)
 struct SweepSmoother : elag_hip_smoother_s {
-    struct Segment { int first, count, max_rows; };   // levels [first, first + count), largest level in it
+    struct Segment { int first, count, max_rows; };   // steps [first, first + count); max_rows > 0: one big level (multi-workgroup launch)
     int type = 2, sweeps = 1, num_levels = 0;
     double weight = 1.0, omega = 1.0;
-    int *d_rows = nullptr, *d_lev_ptr = nullptr;      // rows sorted by (level, row); level offsets into it
+    int *d_rows = nullptr, *d_lev_ptr = nullptr;      // schedule slots (row, first entry, length, 0) by (level, row); step offsets into it
     double *d_l1 = nullptr;                           // types 2 / 4
     std::vector<Segment> segments;
     ~SweepSmoother() override;

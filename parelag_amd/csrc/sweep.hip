@@ -30,10 +30,12 @@ namespace {
 
 constexpr int kLPR = 16;           // lanes that fetch the entries of one row together (the row sum itself stays sequential)
 constexpr int kUnroll = 4;         // rows a lane group has in flight at once
-constexpr int kChainBlock = 1024;
-constexpr int kChainRows = (kChainBlock / kLPR) * kUnroll;   // levels up to this many rows are walked by one workgroup: 256
+constexpr int kChainBlock = 512;   // the chain workgroup: 32 lane groups (1024 threads would halve the steps but spill: 128 VGPRs per lane there)
+constexpr int kStepRows = (kChainBlock / kLPR) * kUnroll;    // rows of one chain step: 128 (a level is cut into steps of that many rows)
+constexpr int kChainRows = 4 * kStepRows;                    // levels up to this many rows are walked by the chain workgroup: 512
+constexpr int kEPL = 2;            // entries per lane the chain keeps in flight for a row (kLPR * kEPL = 32 entries without a further fetch)
 constexpr int kWideBlock = 256;
-constexpr int kMaxChain = 2048;    // levels per chain launch (their offsets sit in LDS)
+constexpr int kMaxChain = 4096;    // steps per chain launch (their offsets sit in LDS)
 
 typedef int int4s __attribute__((ext_vector_type(4)));
 
@@ -41,95 +43,205 @@ typedef int int4s __attribute__((ext_vector_type(4)));
 // (every lane does it, from shuffled products), so the value is the sequential loop's.
 // MODE 0 (types 2 / 4):  u_i += (f_i - sum_k a_ik u_k - sum_g o_ig ughost_g) / l1_i
 // MODE 1 (type 6):       u_i  = (f_i - sum_{k != i} a_ik u_k - sum_g o_ig ughost_g) / a_ii      rows with a_ii == 0 (or none) skipped
-template <int MODE>
-__device__ __forceinline__ void ordered_chunk(int lane, int cnt, int row, int j, double v, double x, double &res, double &aii, bool &have)
+// One chunk of up to kLPR entries of a row (lane q holds entry q: column j, value v, gathered x; lanes past the row's end hold
+// j = -1, v = x = 0): the subtraction runs over all kLPR slots in storage order, fully unrolled so that the kLPR lane
+// broadcasts are issued back to back instead of one per loop trip (a slot past the end subtracts +0.0, which leaves every
+// double as it is).
+// value of lane Q of the caller's 16-lane row in every lane of that row: a DPP move (row_newbcast), no LDS traffic.  (The
+// generic __shfl goes through ds_bpermute: 32 LDS operations per chunk of a row, and the chain workgroup's eight waves share one
+// LDS pipe -- measured 1.9 us per step, all of it there.)
+template <int Q>
+__device__ __forceinline__ double row_bcast(double v)
 {
-    const double p = v * x;
-    for (int q = 0; q < cnt; q++) {
-        const double pq = __shfl(p, q, kLPR);
+    static_assert(kLPR == 16, "a DPP row is 16 lanes");
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + Q, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + Q, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int Q>
+__device__ __forceinline__ int row_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + Q, 0xf, 0xf, false); }
+
+template <int MODE, int Q>
+struct OrderedSteps {
+    static __device__ __forceinline__ void run(int row, int j, double v, double p, double &res, double &aii, bool &have)
+    {
+        const double pq = row_bcast<Q>(p);
         if (MODE == 1) {
-            const int jq = __shfl(j, q, kLPR);
-            const double vq = __shfl(v, q, kLPR);
-            if (jq == row && !have) { aii = vq; have = true; continue; }
+            const int jq = row_bcast<Q>(j);
+            const double vq = row_bcast<Q>(v);
+            const bool diag = (jq == row) && !have;
+            if (diag) { aii = vq; have = true; }
+            res -= diag ? 0.0 : pq;
+        } else {
+            res -= pq;
         }
-        res -= pq;
+        OrderedSteps<MODE, Q + 1>::run(row, j, v, p, res, aii, have);
     }
-    (void)lane;
+};
+template <int MODE>
+struct OrderedSteps<MODE, kLPR> {
+    static __device__ __forceinline__ void run(int, int, double, double, double &, double &, bool &) {}
+};
+
+// One chunk of up to kLPR entries of a row (lane q holds entry q: column j, value v, gathered x; lanes past the row's end hold
+// j = -1, v = x = 0): the subtraction runs over all kLPR slots in storage order (a slot past the end subtracts +0.0, which
+// leaves every double as it is).
+template <int MODE>
+__device__ __forceinline__ void ordered_chunk(int row, int j, double v, double x, double &res, double &aii, bool &have)
+{
+    OrderedSteps<MODE, 0>::run(row, j, v, v * x, res, aii, have);
 }
 
+// the offd terms of a row (frozen ghost values), same order
+__device__ __forceinline__ void ordered_plain(double p, double &res)
+{
+    double aii = 0.0;
+    bool have = false;
+    OrderedSteps<0, 0>::run(0, 0, 0.0, p, res, aii, have);
+}
+
+// One big level as a multi-workgroup launch: rows [step_ptr[first], step_ptr[first + count]) of the schedule, a lane group each.
 template <int MODE>
-__global__ void sweep_levels_kernel(const int *__restrict__ lev_ptr, int l_first, int l_count, int dir, const int4s *__restrict__ sched,
-                                    const int *__restrict__ J, const double *__restrict__ a,
-                                    const int *__restrict__ oI, const int *__restrict__ oJ, const double *__restrict__ oa,
-                                    const double *__restrict__ f, const double *__restrict__ d, const double *__restrict__ ug, double *u)
+__global__ __launch_bounds__(kWideBlock) void sweep_levels_kernel(const int *__restrict__ step_ptr, int first, int count, const int4s *__restrict__ sched,
+                                                                  const int *__restrict__ J, const double *__restrict__ a,
+                                                                  const int *__restrict__ oI, const int *__restrict__ oJ, const double *__restrict__ oa,
+                                                                  const double *__restrict__ f, const double *__restrict__ d, const double *__restrict__ ug,
+                                                                  double *u)
+{
+    const int b = step_ptr[first], e = step_ptr[first + count];
+    const int lane = threadIdx.x & (kLPR - 1);
+    const int t = b + (int)(blockIdx.x * blockDim.x + threadIdx.x) / kLPR;
+    if (t >= e) return;
+    const int4s sl = sched[t];
+    const int row = sl.x, s = sl.y, len = sl.z;
+    double res = f[row], aii = 0.0;
+    const double dr = (MODE == 0) ? d[row] : 0.0, uo = (MODE == 0) ? u[row] : 0.0;
+    bool have = false;
+    for (int k0 = 0; k0 < len; k0 += kLPR) {
+        const bool has = k0 + lane < len;
+        const int j = has ? J[s + k0 + lane] : -1;
+        const double v = has ? a[s + k0 + lane] : 0.0;
+        const double x = has ? u[j] : 0.0;
+        ordered_chunk<MODE>(row, j, v, x, res, aii, have);
+    }
+    if (oI) {
+        const int os = oI[row], ol = oI[row + 1] - os;
+        for (int k0 = 0; k0 < ol; k0 += kLPR) {
+            const bool has = k0 + lane < ol;
+            const double v = has ? oa[os + k0 + lane] : 0.0;
+            const double x = has ? ug[oJ[os + k0 + lane]] : 0.0;
+            ordered_plain(v * x, res);
+        }
+    }
+    if (lane == 0) {
+        if (MODE == 0) { if (dr != 0.0) u[row] = uo + res / dr; }
+        else if (have && aii != 0.0) u[row] = res / aii;
+    }
+}
+
+// The chain: ONE workgroup walks a run of consecutive small levels (cut into steps of <= kStepRows rows).  What a step needs that
+// does not depend on u -- its schedule slots, then the column indices and values of its rows -- is requested one and two steps
+// ahead, so that the only memory round trip left on the critical path of a step is the gather of u itself (written by the
+// previous step of this very workgroup, hence close by), followed by the ordered subtraction, the store and the barrier.
+template <int MODE>
+__global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__restrict__ step_ptr, int s_first, int s_count, int dir,
+                                                                  const int4s *__restrict__ sched, const int *__restrict__ J, const double *__restrict__ a,
+                                                                  const int *__restrict__ oI, const int *__restrict__ oJ, const double *__restrict__ oa,
+                                                                  const double *__restrict__ f, const double *__restrict__ d, const double *__restrict__ ug,
+                                                                  double *u)
 {
     __shared__ int lp[kMaxChain + 1];
-    // offsets of this launch's levels, lowest level first
-    const int l_lo = dir > 0 ? l_first : l_first - (l_count - 1);
-    for (int c = threadIdx.x; c <= l_count; c += blockDim.x) lp[c] = lev_ptr[l_lo + c];
+    const int s_lo = dir > 0 ? s_first : s_first - (s_count - 1);
+    for (int c = threadIdx.x; c <= s_count; c += kChainBlock) lp[c] = step_ptr[s_lo + c];
     __syncthreads();
+    constexpr int NG = kChainBlock / kLPR;
     const int lane = threadIdx.x & (kLPR - 1);
-    const int grp = (int)(blockIdx.x * blockDim.x + threadIdx.x) / kLPR;
-    const int ngrp = (int)(gridDim.x * blockDim.x) / kLPR;
-    // l_count > 1 only with a grid of ONE workgroup (launch_segment): the barrier below orders the levels
-    for (int c = 0; c < l_count; c++) {
-        const int li = dir > 0 ? c : l_count - 1 - c;
+    const int grp = threadIdx.x / kLPR;
+    auto load_slots = [&](int c, int4s (&sl)[kUnroll]) {
+        const int li = dir > 0 ? c : s_count - 1 - c;
         const int b = lp[li], e = lp[li + 1];
-        for (int t0 = b + grp; t0 < e; t0 += kUnroll * ngrp) {
-            int4s sl[kUnroll];
-            int j0[kUnroll];
-            double v0[kUnroll], x0[kUnroll], fr[kUnroll], dr[kUnroll], uo[kUnroll];
 #pragma unroll
-            for (int q = 0; q < kUnroll; q++) {
-                const int t = t0 + q * ngrp;
-                sl[q] = t < e ? sched[t] : int4s{0, 0, 0, 0};
+        for (int q = 0; q < kUnroll; q++) {
+            const int t = b + grp + q * NG;
+            sl[q] = t < e ? sched[t] : int4s{0, 0, 0, -1};          // .w = -1: no row here
+        }
+    };
+    auto load_entries = [&](const int4s (&sl)[kUnroll], int (&jj)[kUnroll][kEPL], double (&vv)[kUnroll][kEPL]) {
+#pragma unroll
+        for (int q = 0; q < kUnroll; q++)
+#pragma unroll
+            for (int e = 0; e < kEPL; e++) {
+                const bool has = e * kLPR + lane < sl[q].z;
+                jj[q][e] = has ? J[sl[q].y + e * kLPR + lane] : -1;
+                vv[q][e] = has ? a[sl[q].y + e * kLPR + lane] : 0.0;
             }
+    };
+    int4s slA[kUnroll], slB[kUnroll], slC[kUnroll];
+    int jA[kUnroll][kEPL], jB[kUnroll][kEPL];
+    double vA[kUnroll][kEPL], vB[kUnroll][kEPL];
 #pragma unroll
-            for (int q = 0; q < kUnroll; q++) {
-                const bool has = lane < sl[q].z;
-                j0[q] = has ? J[sl[q].y + lane] : 0;
-                v0[q] = has ? a[sl[q].y + lane] : 0.0;
-                fr[q] = f[sl[q].x];
-                dr[q] = (MODE == 0) ? d[sl[q].x] : 0.0;
+    for (int q = 0; q < kUnroll; q++) {
+        slB[q] = int4s{0, 0, 0, -1}; slC[q] = int4s{0, 0, 0, -1};
+#pragma unroll
+        for (int e = 0; e < kEPL; e++) { jB[q][e] = 0; vB[q][e] = 0.0; }
+    }
+    load_slots(0, slA);
+    if (s_count > 1) load_slots(1, slB);
+    load_entries(slA, jA, vA);
+    for (int c = 0; c < s_count; c++) {
+        // ---- what depends on u: this step's gathers
+        double xA[kUnroll][kEPL], fr[kUnroll], dr[kUnroll], uo[kUnroll];
+#pragma unroll
+        for (int q = 0; q < kUnroll; q++) {
+#pragma unroll
+            for (int e = 0; e < kEPL; e++) xA[q][e] = (e * kLPR + lane < slA[q].z) ? u[jA[q][e]] : 0.0;
+            fr[q] = f[slA[q].x];
+            dr[q] = (MODE == 0) ? d[slA[q].x] : 0.0;
+            uo[q] = (MODE == 0) ? u[slA[q].x] : 0.0;
+        }
+        // ---- what does not: the next step's entries (its slots are here already) and the slots of the step after it
+        if (c + 1 < s_count) load_entries(slB, jB, vB);
+        if (c + 2 < s_count) load_slots(c + 2, slC);
+        // ---- the rows of this step
+#pragma unroll
+        for (int q = 0; q < kUnroll; q++) {
+            if (slA[q].w < 0) continue;
+            const int row = slA[q].x, s0 = slA[q].y, len = slA[q].z;
+            double res = fr[q], aii = 0.0;
+            bool have = false;
+#pragma unroll
+            for (int e = 0; e < kEPL; e++)
+                if (e * kLPR < len) ordered_chunk<MODE>(row, jA[q][e], vA[q][e], xA[q][e], res, aii, have);
+            for (int k0 = kEPL * kLPR; k0 < len; k0 += kLPR) {      // rows longer than kLPR * kEPL entries: further chunks, fetched now
+                const bool has = k0 + lane < len;
+                const int j = has ? J[s0 + k0 + lane] : -1;
+                const double v = has ? a[s0 + k0 + lane] : 0.0;
+                const double x = has ? u[j] : 0.0;
+                ordered_chunk<MODE>(row, j, v, x, res, aii, have);
             }
-#pragma unroll
-            for (int q = 0; q < kUnroll; q++) {
-                x0[q] = (lane < sl[q].z) ? u[j0[q]] : 0.0;
-                uo[q] = (MODE == 0) ? u[sl[q].x] : 0.0;
+            if (oI) {
+                const int os = oI[row], ol = oI[row + 1] - os;
+                for (int k0 = 0; k0 < ol; k0 += kLPR) {
+                    const bool has = k0 + lane < ol;
+                    const double v = has ? oa[os + k0 + lane] : 0.0;
+                    const double x = has ? ug[oJ[os + k0 + lane]] : 0.0;
+                    ordered_plain(v * x, res);
+                }
             }
-#pragma unroll
-            for (int q = 0; q < kUnroll; q++) {
-                const int t = t0 + q * ngrp;
-                if (t >= e) continue;
-                const int row = sl[q].x, s = sl[q].y, len = sl[q].z;
-                double res = fr[q], aii = 0.0;
-                bool have = false;
-                ordered_chunk<MODE>(lane, min(len, kLPR), row, j0[q], v0[q], x0[q], res, aii, have);
-                for (int k0 = kLPR; k0 < len; k0 += kLPR) {          // long rows: further chunks, one after the other
-                    const bool has = k0 + lane < len;
-                    const int j = has ? J[s + k0 + lane] : 0;
-                    const double v = has ? a[s + k0 + lane] : 0.0;
-                    const double x = has ? u[j] : 0.0;
-                    ordered_chunk<MODE>(lane, min(len - k0, kLPR), row, j, v, x, res, aii, have);
-                }
-                if (oI) {
-                    const int os = oI[row], ol = oI[row + 1] - os;
-                    for (int k0 = 0; k0 < ol; k0 += kLPR) {
-                        const bool has = k0 + lane < ol;
-                        const double v = has ? oa[os + k0 + lane] : 0.0;
-                        const double x = has ? ug[oJ[os + k0 + lane]] : 0.0;
-                        const double p = v * x;
-                        const int cnt = min(ol - k0, kLPR);
-                        for (int r = 0; r < cnt; r++) res -= __shfl(p, r, kLPR);
-                    }
-                }
-                if (lane == 0) {
-                    if (MODE == 0) { if (dr[q] != 0.0) u[row] = uo[q] + res / dr[q]; }
-                    else if (have && aii != 0.0) u[row] = res / aii;
-                }
+            if (lane == 0) {
+                if (MODE == 0) { if (dr[q] != 0.0) u[row] = uo[q] + res / dr[q]; }
+                else if (have && aii != 0.0) u[row] = res / aii;
             }
         }
-        if (l_count > 1) __syncthreads();
+        __syncthreads();
+        // ---- rotate the pipeline
+#pragma unroll
+        for (int q = 0; q < kUnroll; q++) {
+            slA[q] = slB[q]; slB[q] = slC[q];
+#pragma unroll
+            for (int e = 0; e < kEPL; e++) { jA[q][e] = jB[q][e]; vA[q][e] = vB[q][e]; }
+        }
     }
 }
 
@@ -229,16 +341,23 @@ void SweepSmoother::setup()
         for (int i = 0; i < n; i++) rows[(size_t)cur[(size_t)level[(size_t)i]]++] = i;   // ascending row inside a level
     }
     num_levels = nlev;
+    // steps: every level cut into pieces of at most kStepRows rows (the rows of a level are independent, so the pieces may run
+    // one after the other); a segment is either one big level -- all its steps as ONE multi-workgroup launch -- or a run of
+    // small levels whose steps the chain workgroup walks
+    std::vector<int> step_ptr(1, 0);
+    std::vector<int> first_step((size_t)nlev + 1, 0);
+    for (int l = 0; l < nlev; l++) {
+        first_step[(size_t)l] = (int)step_ptr.size() - 1;
+        for (int b = ptr[(size_t)l]; b < ptr[(size_t)l + 1]; b += kStepRows) step_ptr.push_back(std::min(b + kStepRows, ptr[(size_t)l + 1]));
+    }
+    first_step[(size_t)nlev] = (int)step_ptr.size() - 1;
     segments.clear();
     for (int l = 0; l < nlev;) {
         const int sz = ptr[(size_t)l + 1] - ptr[(size_t)l];
-        if (sz > kChainRows) { segments.push_back(Segment{l, 1, sz}); l++; continue; }
-        int m = l, mx = 0;
-        while (m < nlev && m - l < kMaxChain && ptr[(size_t)m + 1] - ptr[(size_t)m] <= kChainRows) {
-            mx = std::max(mx, ptr[(size_t)m + 1] - ptr[(size_t)m]);
-            m++;
-        }
-        segments.push_back(Segment{l, m - l, mx});
+        if (sz > kChainRows) { segments.push_back(Segment{first_step[(size_t)l], first_step[(size_t)l + 1] - first_step[(size_t)l], sz}); l++; continue; }
+        int m = l;
+        while (m < nlev && first_step[(size_t)m + 1] - first_step[(size_t)l] <= kMaxChain && ptr[(size_t)m + 1] - ptr[(size_t)m] <= kChainRows) m++;
+        segments.push_back(Segment{first_step[(size_t)l], first_step[(size_t)m] - first_step[(size_t)l], 0});
         l = m;
     }
     // schedule slots: (row, first entry, row length) in level order -- one 16-byte load per row instead of three dependent ones
@@ -248,11 +367,11 @@ void SweepSmoother::setup()
         slot[(size_t)t * 4] = i; slot[(size_t)t * 4 + 1] = I[(size_t)i]; slot[(size_t)t * 4 + 2] = I[(size_t)i + 1] - I[(size_t)i];
     }
     d_rows = dev_from_host(slot.data(), slot.size());
-    d_lev_ptr = dev_from_host(ptr.data(), ptr.size());
+    d_lev_ptr = dev_from_host(step_ptr.data(), step_ptr.size());
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
     if (getenv("ELAG_HIP_SWEEP_VERBOSE"))
-        fprintf(stderr, "[elag_hip] sweep smoother type %d: n=%d, %d dependency levels in %d launches per direction\n", type, n, nlev,
-                (int)segments.size());
+        fprintf(stderr, "[elag_hip] sweep smoother type %d: n=%d, %d dependency levels = %d steps in %d launches per direction\n", type, n, nlev,
+                (int)step_ptr.size() - 1, (int)segments.size());
 }
 
 void SweepSmoother::launch_segment(const Segment &s, int dir, const double *f, double *u)
@@ -261,26 +380,26 @@ void SweepSmoother::launch_segment(const Segment &s, int dir, const double *f, d
     const bool ho = A->offd.nnz > 0;
     const int *oI = ho ? A->offd.I : nullptr, *oJ = ho ? A->offd.J : nullptr;
     const double *oa = ho ? A->offd.a : nullptr;
-    const int l_first = dir > 0 ? s.first : s.first + s.count - 1;
-    unsigned grid = 1, block = kChainBlock;
-    if (s.count == 1 && s.max_rows > kChainRows) {
-        // one big level: enough workgroups for one row per lane group
-        block = kWideBlock;
-        grid = (unsigned)(((long long)s.max_rows * kLPR + kWideBlock - 1) / kWideBlock);
-    } else {
-        // chain: as many lane groups as the largest level needs with kUnroll rows each, in whole waves
-        const int groups = (s.max_rows + kUnroll - 1) / kUnroll;
-        block = (unsigned)std::min(kChainBlock, std::max(64, ((groups * kLPR + 63) / 64) * 64));
-    }
     const int4s *sched = reinterpret_cast<const int4s *>(d_rows);
-    if (type == ELAG_HIP_SMOOTHER_GS)
-        hipLaunchKernelGGL(sweep_levels_kernel<1>, dim3(grid), dim3(block), 0, st, (const int *)d_lev_ptr, l_first, s.count, dir, sched,
-                           (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, (const double *)nullptr,
-                           (const double *)A->d_ghost, u);
-    else
-        hipLaunchKernelGGL(sweep_levels_kernel<0>, dim3(grid), dim3(block), 0, st, (const int *)d_lev_ptr, l_first, s.count, dir, sched,
-                           (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, (const double *)d_l1,
-                           (const double *)A->d_ghost, u);
+    const double *dd = (type == ELAG_HIP_SMOOTHER_GS) ? nullptr : d_l1;
+    if (s.max_rows > 0) {
+        // one big level (all its steps as one range): enough workgroups for one row per lane group
+        const unsigned grid = (unsigned)(((long long)s.max_rows * kLPR + kWideBlock - 1) / kWideBlock);
+        if (type == ELAG_HIP_SMOOTHER_GS)
+            hipLaunchKernelGGL(sweep_levels_kernel<1>, dim3(grid), dim3(kWideBlock), 0, st, (const int *)d_lev_ptr, s.first, s.count, sched,
+                               (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, dd, (const double *)A->d_ghost, u);
+        else
+            hipLaunchKernelGGL(sweep_levels_kernel<0>, dim3(grid), dim3(kWideBlock), 0, st, (const int *)d_lev_ptr, s.first, s.count, sched,
+                               (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, dd, (const double *)A->d_ghost, u);
+    } else {
+        const int s_first = dir > 0 ? s.first : s.first + s.count - 1;
+        if (type == ELAG_HIP_SMOOTHER_GS)
+            hipLaunchKernelGGL(sweep_chain_kernel<1>, dim3(1), dim3(kChainBlock), 0, st, (const int *)d_lev_ptr, s_first, s.count, dir, sched,
+                               (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, dd, (const double *)A->d_ghost, u);
+        else
+            hipLaunchKernelGGL(sweep_chain_kernel<0>, dim3(1), dim3(kChainBlock), 0, st, (const int *)d_lev_ptr, s_first, s.count, dir, sched,
+                               (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, dd, (const double *)A->d_ghost, u);
+    }
     ELAG_LAUNCH_CHECK();
 }
 
