@@ -28,6 +28,7 @@ struct SpmvArgs {
     const int *rows = nullptr;
     int nrows_sel = 0;
     int skip_rows_with_offd = 0;  // interior pass: rows whose offd row is non-empty are left untouched
+    int xcd_chunks = 0;           // x-cache kernel: window = f(workgroup id) that keeps an XCD on one contiguous run of windows (set by the launcher)
 };
 void spmv_fused(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, hipStream_t st = nullptr);
 // row-block plan of the LDS-staged stream kernel (block_row, nblocks, max_row_nnz); synchronous, setup time

@@ -317,7 +317,15 @@ __device__ __forceinline__ void spmv_xc_body(
 {
     extern __shared__ double sh[];
     double *prod = sh, *xs = sh + cap;
-    const int win = blockIdx.x;
+    // Workgroups are handed to the 8 XCDs round-robin by their id, and every XCD has an L2 of its own: with window = id,
+    // neighbouring windows -- which share most of the x lines they gather -- run on different XCDs and each fetches those lines
+    // from the fabric itself.  With xcd_chunks the ids of one XCD walk ONE contiguous eighth of the windows instead, so a line
+    // fetched for a window is still in that XCD's L2 when the next window needs it.
+    int win = blockIdx.x;
+    if (p.xcd_chunks) {
+        const int nb = (int)gridDim.x, xcd = win & 7, idx = win >> 3, per = nb >> 3, rem = nb & 7;
+        win = xcd * per + min(xcd, rem) + idx;
+    }
     const int4v br = *reinterpret_cast<const int4v *>(block_row + 2 * win);
     const int r0 = br.x, kbeg = br.y, r1 = br.z, kend = br.w;
     if (r0 >= r1) return;
@@ -535,9 +543,21 @@ int xc_mode()
     return v;
 }
 
-template <int THREADS>
-void launch_xc_t(const DevCSR &A, const int *oI, const SpmvArgs &p, hipStream_t st, bool probe)
+int xc_xcd_mode()
 {
+    static int v = -1;
+    // default off: measured on cube456 x5 (profiles/r02_spmv_xcd_placement.txt) the chunked placement cuts the launch's HBM
+    // reads from 550 to 447 MB (total traffic 0.93 x algorithmic instead of 1.13 x) and costs 1-4 % of time -- the duplicate
+    // fetches of x by several XCDs are where the excess traffic comes from, but they are not what bounds the kernel
+    if (v < 0) { const char *e = getenv("ELAG_HIP_XC_XCD"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+template <int THREADS>
+void launch_xc_t(const DevCSR &A, const int *oI, const SpmvArgs &pin, hipStream_t st, bool probe)
+{
+    SpmvArgs p = pin;
+    p.xcd_chunks = (xc_xcd_mode() && A.xc_nblocks >= 64) ? 1 : 0;
     const int cap = A.xc_window + A.max_row_nnz + 8;
     const size_t lds = sizeof(double) * ((size_t)cap + (size_t)A.xc_max_unique);
     const dim3 grid((unsigned)A.xc_nblocks), block(THREADS);
