@@ -769,3 +769,63 @@ def test_roofline_size_hierarchy_with_default_heuristics(la):
     H.Mult(b, xd)
     orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"]).apply(b, xo)
     assert np.max(np.abs(xd - xo)) <= 1e-11 * np.max(np.abs(xo))
+
+
+# ---- forms that are only reached through a switch or a particular caller ----------------------------------------------------
+
+def test_sign_form_of_incidence_operators(la):
+    """HiptmairSmoother stores D and D^T in the 4-byte sign form (entries -1 / 0 / +1, the 0 being an eliminated essential column):
+    every product the smoother makes with them equals the plain CSR product, and a smoother application equals the oracle's"""
+    from parelag_amd import meshgen
+    from tests.helpers import oracle_hdiv_hierarchy
+    A, Ps, Ds, _ = meshgen.hdiv_problem(2)
+    D = Ds[0].tocsr()
+    assert set(np.unique(D.data)) <= {-1.0, 0.0, 1.0} and (D.data == 0.0).any()
+    dA, dD = la.ParallelCSRMatrix.from_scipy(A), la.ParallelCSRMatrix.from_scipy(D)
+    rng = np.random.default_rng(17)
+    x, yt = rng.standard_normal(D.shape[1]), rng.standard_normal(D.shape[0])
+    y0, z0 = np.empty(D.shape[0]), np.empty(D.shape[1])
+    dD.Mult(x, y0); dD.MultTranspose(yt, z0)                       # before: generic kernels
+    dX = la.RAP(dA, dD); dX.fix_zero_rows()
+    S = la.HiptmairSmoother(dA, dD, la.HypreSmootherWrapper(dA, 1), la.HypreSmootherWrapper(dX, 1))     # builds the sign forms
+    y1, z1 = np.empty(D.shape[0]), np.empty(D.shape[1])
+    dD.Mult(x, y1, 1.0, 0.0); dD.MultTranspose(yt, z1)
+    assert close(y1, D @ x) and close(z1, D.T @ yt) and close(y1, y0) and close(z1, z0)
+    y2 = y0.copy()
+    dD.Mult(x, y2, -0.5, 2.0)                                       # epilogue operands through the sign kernel
+    assert close(y2, -0.5 * (D @ x) + 2.0 * y0)
+    h = oracle_hdiv_hierarchy(A, Ps, Ds)
+    ref = orc.OHiptmair(orc.OParCSR(h["As"][0]), orc.OParCSR(h["hipt"][0]["D"]), orc.OSmoother(orc.OParCSR(h["As"][0]), 1),
+                        orc.OSmoother(orc.OParCSR(h["hipt"][0]["Aaux"]), 1))
+    f, u0 = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+    u, ur = u0.copy(), u0.copy()
+    S.Mult(f, u); ref.Mult(f, ur)
+    assert close(u, ur, tol=1e-11)
+    # a matrix that is not an incidence matrix keeps its generic kernels and its values
+    dP = la.ParallelCSRMatrix.from_scipy(Ps[0])
+    assert dP.spmv_kernel().startswith("spmv_")
+
+
+def test_two_pass_spgemm_fallback_equals_the_single_pass_product():
+    """the symbolic + numeric scheme is still what runs when the upper-bound layout of the single pass would not fit (> 2^31
+    products); forced here with ELAG_HIP_ESC_SINGLE_PASS=0 in a child process: same pattern bit for bit, same values"""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import numpy as np
+        from oracle import oracle as orc
+        from parelag_amd import linalg as la, meshgen
+        A, Ps, _ = meshgen.h1_problem(2)
+        C = la.RAP(la.ParallelCSRMatrix.from_scipy(A), la.ParallelCSRMatrix.from_scipy(Ps[0])).to_scipy()
+        R = orc.rap(orc.csr(Ps[0]), orc.diag_first(A), orc.csr(Ps[0])); R.sort_indices(); C.sort_indices()
+        assert np.array_equal(C.indptr, R.indptr) and np.array_equal(C.indices, R.indices)
+        assert np.max(np.abs(C.data - R.data)) <= 1e-12 * np.max(np.abs(R.data))
+        print("SPGEMM_OK", C.nnz)
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for single in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root,
+                           env=dict(os.environ, ELAG_HIP_ESC_SINGLE_PASS=single))
+        assert r.returncode == 0 and "SPGEMM_OK" in r.stdout, r.stdout + r.stderr
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
