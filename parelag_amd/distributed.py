@@ -68,6 +68,9 @@ def init(rank: int, world: int) -> Dist:
             raise RuntimeError("distributed.init: MASTER_PORT is not set (start the ranks with torch.distributed.run or bench.py --gpus N)")
         os.environ["MASTER_PORT"] = str(free_port())
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if int(os.environ.get("NNODES", os.environ.get("GROUP_WORLD_SIZE", "1")) or 1) <= 1:
+        # one node: RCCL's bootstrap sockets on the loopback interface (the container's hostname may not resolve)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     # Load the HIP library (and, across ranks, the system RCCL) BEFORE torch: the dynamic loader then binds
     # everything in this process to the one ROCm runtime the kernels were built with; torch is used on the CPU
     # only (gloo rendezvous / barriers), so its bundled copies of the same sonames are never needed.
