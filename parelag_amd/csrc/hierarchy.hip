@@ -348,9 +348,47 @@ struct elag_hip_hierarchy_s {
             par_spmv(*A_user, a);
             src = r0;
         }
+        if (iterate0_permuted(src, sol, !precond)) return;
         k::vec_gather(n, d_order0, src, p_rhs);
         iterate(0, p_rhs, p_sol, L0.alt);
         k::vec_scatter(n, d_order0, p_sol, sol, precond ? 0 : 1);
+    }
+
+    // Level 0 of a renumbered hierarchy with the permutations folded into its first and last kernel: the caller's right-hand side
+    // is gathered by the kernel that starts the zero-guess Jacobi sweep, and the kernel that finishes the post-smoothing writes
+    // (or adds to) the caller's numbering directly -- two passes over level-0 vectors less per cycle.  Only for the layout this is
+    // worth it on (HBM-bound level 0 with one l1-Jacobi / Jacobi sweep before and after); false = not applicable.
+    bool iterate0_permuted(const double *src_nat, double *sol_nat, bool add)
+    {
+        if (lev.size() < 2 || dense_level == 0) return false;
+        Level &F = lev[0];
+        Level &C = lev[1];
+        if (F.G || F.Gaux || !F.pre || !F.post || F.pre->A != F.A || F.post->A != F.A) return false;
+        const double *pre_dinv = F.pre->diag_scaling(), *post_dinv = F.post->diag_scaling();
+        if (!pre_dinv || !post_dinv || F.A->needs_exchange() || F.A->diag.nnz < (int64_t(1) << 20)) return false;
+        const int n = F.A->nrows();
+        double *cur = F.alt;           // (never F.sol / F.resid: host callers' vectors are staged there, i.e. they may BE sol_nat / src_nat)
+        // p_rhs = src[order], x = W p_rhs in one pass
+        k::vec_gather_scale(n, d_order0, src_nat, pre_dinv, p_rhs, cur);
+        {
+            k::SpmvArgs a;  // r = f - A x
+            a.x = cur; a.alpha = -1.0; a.f = p_rhs; a.gamma = 1.0; a.out = F.tmp_resid;
+            par_spmv(*F.A, a);
+        }
+        par_spmvT(*C.P, 1.0, F.tmp_resid, 0.0, C.resid);
+        iterate(1, C.resid, C.sol, C.alt);
+        {
+            k::SpmvArgs a;  // x += P e
+            a.x = C.sol; a.alpha = 1.0; a.yin = cur; a.beta = 1.0; a.out = cur;
+            par_spmv(*C.P, a);
+        }
+        {
+            k::SpmvArgs a;  // x' = x + W (f - A x), written to the caller's numbering: sol[order[i]] (+)= x'_i
+            a.x = cur; a.alpha = -1.0; a.f = p_rhs; a.gamma = 1.0; a.s = post_dinv; a.yin = cur; a.beta = 1.0;
+            a.out = sol_nat; a.out_perm = d_order0; a.out_add = add ? sol_nat : nullptr;
+            par_spmv(*F.A, a);
+        }
+        return true;
     }
 
     void apply_device(const double *rhs, double *sol, bool precond)

@@ -29,6 +29,10 @@ struct SpmvArgs {
     int nrows_sel = 0;
     int skip_rows_with_offd = 0;  // interior pass: rows whose offd row is non-empty are left untouched
     int xcd_chunks = 0;           // x-cache kernel: window = f(workgroup id) that keeps an XCD on one contiguous run of windows (set by the launcher)
+    // stream / x-cache kernels only: the result row i goes to out[out_perm[i]] (the hierarchy's last kernel writes the caller's
+    // numbering directly instead of a scatter pass after it); with out_add the value is added to out_add[out_perm[i]] on the way
+    const int *out_perm = nullptr;
+    const double *out_add = nullptr;
 };
 void spmv_fused(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, hipStream_t st = nullptr);
 // row-block plan of the LDS-staged stream kernel (block_row, nblocks, max_row_nnz); synchronous, setup time
@@ -49,6 +53,7 @@ void vec_add_scaled_mul(int n, const double *y, const double *d, const double *z
 void vec_fill(int n, double v, double *x);
 void vec_dot(int n, const double *x, const double *y, double *d_result);  // deterministic 2-stage
 void vec_gather(int n, const int *idx, const double *x, double *buf, hipStream_t st = nullptr);
+void vec_gather_scale(int n, const int *idx, const double *x, const double *d, double *buf, double *scaled);  // buf = x[idx], scaled = d .* buf
 void vec_scatter(int n, const int *idx, const double *src, double *dst, int add);  // dst[idx[i]] (+)= src[i], idx a permutation
 void vec_hypre_random(int n, int seed, double *out);  // Lehmer 16807 stream, 2 r - 1 (host generated)
 

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void spmv_fused_kernel(
         t += p.gamma * f0;
         t *= sc0;
         t += p.beta * y0;
-        p.out[row] = t;
+        p.out[p.out_perm ? p.out_perm[row] : row] = p.out_add ? p.out_add[p.out_perm[row]] + t : t;
         if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
     }
 }
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void spmv_sign_kernel(int nrows, const int 
         t += p.gamma * f0;
         t *= sc0;
         t += p.beta * y0;
-        p.out[row] = t;
+        p.out[p.out_perm ? p.out_perm[row] : row] = p.out_add ? p.out_add[p.out_perm[row]] + t : t;
         if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
     }
 }
@@ -266,7 +266,7 @@ __device__ __forceinline__ void spmv_stream_body(
         t += p.gamma * f0;
         t *= sc0;
         t += p.beta * y0;
-        p.out[row0] = t;
+        p.out[p.out_perm ? p.out_perm[row0] : row0] = p.out_add ? p.out_add[p.out_perm[row0]] + t : t;
         if (p.out2) p.out2[row0] = HAS_CS ? x[row0] * p.cs[row0] : x[row0];
     }
     // blocks of short rows hold more than 256 rows: remaining rows the plain way
@@ -280,7 +280,7 @@ __device__ __forceinline__ void spmv_stream_body(
         if (p.f) t += p.gamma * p.f[row];
         if (p.s) t *= p.s[row];
         if (p.yin) t += p.beta * p.yin[row];
-        p.out[row] = t;
+        p.out[p.out_perm ? p.out_perm[row] : row] = p.out_add ? p.out_add[p.out_perm[row]] + t : t;
         if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
     }
 }
@@ -391,7 +391,7 @@ __device__ __forceinline__ void spmv_xc_body(
         t += p.gamma * f0;
         t *= sc0;
         t += p.beta * y0;
-        p.out[row0] = t;
+        p.out[p.out_perm ? p.out_perm[row0] : row0] = p.out_add ? p.out_add[p.out_perm[row0]] + t : t;
         if (p.out2) p.out2[row0] = HAS_CS ? x[row0] * p.cs[row0] : x[row0];
     }
     for (int row = row0 + THREADS; row < r1; row += THREADS) {
@@ -404,7 +404,7 @@ __device__ __forceinline__ void spmv_xc_body(
         if (p.f) t += p.gamma * p.f[row];
         if (p.s) t *= p.s[row];
         if (p.yin) t += p.beta * p.yin[row];
-        p.out[row] = t;
+        p.out[p.out_perm ? p.out_perm[row] : row] = p.out_add ? p.out_add[p.out_perm[row]] + t : t;
         if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
     }
 }
@@ -853,6 +853,16 @@ __global__ void gather_kernel(int n, const int *__restrict__ idx, const double *
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) buf[i] = x[idx[i]];
 }
 
+__global__ void gather_scale_kernel(int n, const int *__restrict__ idx, const double *__restrict__ x, const double *__restrict__ d,
+                                    double *__restrict__ buf, double *__restrict__ scaled)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double v = x[idx[i]];
+        buf[i] = v;
+        scaled[i] = 1.0 * v * d[i];          // same expression as scale_mul_kernel with a = 1
+    }
+}
+
 __global__ void scatter_kernel(int n, const int *__restrict__ idx, const double *__restrict__ src, double *__restrict__ dst, int add)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -974,6 +984,12 @@ void vec_gather(int n, const int *idx, const double *x, double *buf, hipStream_t
 {
     if (n == 0) return;
     hipLaunchKernelGGL(gather_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, st ? st : ctx().stream, n, idx, x, buf);
+    ELAG_LAUNCH_CHECK();
+}
+void vec_gather_scale(int n, const int *idx, const double *x, const double *d, double *buf, double *scaled)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(gather_scale_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, ctx().stream, n, idx, x, d, buf, scaled);
     ELAG_LAUNCH_CHECK();
 }
 void vec_scatter(int n, const int *idx, const double *src, double *dst, int add)

@@ -767,8 +767,18 @@ def test_roofline_size_hierarchy_with_default_heuristics(la):
     b = rng.uniform(-1, 1, n)
     xd, xo = np.full(n, 3.0), np.empty(n)
     H.Mult(b, xd)
-    orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"]).apply(b, xo)
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"])
+    Hc.apply(b, xo)
     assert np.max(np.abs(xd - xo)) <= 1e-11 * np.max(np.abs(xo))
+    # solver mode (Hierarchy::Mult with iterative_mode: sol += cycle(rhs - A sol)): the level-0 kernels read and write the caller's
+    # numbering through the permutation (no gather / scatter passes), here with the "add to the caller's vector" epilogue
+    H.iterative_mode = True
+    x0 = rng.uniform(-1, 1, n)
+    xs = x0.copy()
+    H.Mult(b, xs)
+    corr = np.empty(n)
+    Hc.apply(b - A @ x0, corr)
+    assert np.max(np.abs(xs - (x0 + corr))) <= 1e-11 * np.max(np.abs(x0 + corr))
 
 
 # ---- forms that are only reached through a switch or a particular caller ----------------------------------------------------
