@@ -55,12 +55,12 @@ enum {
 /* hypre relax types accepted by elag_hip_smoother_create -- the string->type table of
  * src/linalg/factories/ParELAG_HypreSmootherFactory.cpp:92-109.  The Gauss-Seidel types (2 = the reference's shipped default
  * "L1 Gauss-Seidel", 4 = "L1 Gauss-Seidel Truncated", 6 = "Gauss-Seidel") run as level-scheduled forward + backward sweeps with
- * the sequential loop's results ("Damping Factor" = "Omega" = 1.0 only: hypre's SSOR branches are not built); 413 = "Hypre
- * Jacobi" (mfem::HypreDiagScale, ParELAG_HypreSmootherFactory.cpp:28-31).  Kaczmarz (3), Lumped Jacobi (5), Taubin (1001) and
- * FIR (1002) are rejected with ELAG_HIP_ERR_ARG. */
+ * the sequential loop's results ("Damping Factor" = 1.0; "Omega" free for 2 / 4 and 1.0 for 6: hypre's SSOR branches are not
+ * built); 5 = "Lumped Jacobi" (mfem::HypreSmoother: l1 = A 1, then type 1); 413 = "Hypre Jacobi" (mfem::HypreDiagScale,
+ * ParELAG_HypreSmootherFactory.cpp:28-31).  Kaczmarz (3), Taubin (1001) and FIR (1002) are rejected with ELAG_HIP_ERR_ARG. */
 enum {
     ELAG_HIP_SMOOTHER_JACOBI = 0, ELAG_HIP_SMOOTHER_L1_JACOBI = 1, ELAG_HIP_SMOOTHER_L1_GS = 2, ELAG_HIP_SMOOTHER_L1_GS_TRUNCATED = 4,
-    ELAG_HIP_SMOOTHER_GS = 6, ELAG_HIP_SMOOTHER_CHEBYSHEV = 16, ELAG_HIP_SMOOTHER_HYPRE_JACOBI = 413
+    ELAG_HIP_SMOOTHER_LUMPED_JACOBI = 5, ELAG_HIP_SMOOTHER_GS = 6, ELAG_HIP_SMOOTHER_CHEBYSHEV = 16, ELAG_HIP_SMOOTHER_HYPRE_JACOBI = 413
 };
 
 /* --------------------------------------------------------------------------------------------------

@@ -171,6 +171,30 @@ ORC_API void orc_jacobi_update(int n, const double *v, const double *l1, double 
 /* hypre_ParCSRRelax relax_type 2/4 (l1 Gauss-Seidel, the reference's shipped default smoother:
  * examples/testing_helpers/Create0FormParameterList.hpp:103-116), relax_weight = omega = 1 branch:
  * ghost values frozen for the sweep, forward then backward over local rows. */
+ORC_API void orc_l1gs_sweep_omega(int n, const int *dI, const int *dJ, const double *da,
+                                  const int *oI, const int *oJ, const double *oa,
+                                  const double *f, const double *l1, const double *uext, double omega, double *u)
+{
+    /* relax_weight = 1, omega != 1 branch of the same relaxation: u_i += omega * res / l1_i */
+    int i, jj;
+    for (i = 0; i < n; i++) {
+        if (l1[i] != 0.0) {
+            double res = f[i];
+            for (jj = dI[i]; jj < dI[i + 1]; jj++) res -= da[jj] * u[dJ[jj]];
+            if (oI) for (jj = oI[i]; jj < oI[i + 1]; jj++) res -= oa[jj] * uext[oJ[jj]];
+            u[i] += omega * res / l1[i];
+        }
+    }
+    for (i = n - 1; i > -1; i--) {
+        if (l1[i] != 0.0) {
+            double res = f[i];
+            for (jj = dI[i]; jj < dI[i + 1]; jj++) res -= da[jj] * u[dJ[jj]];
+            if (oI) for (jj = oI[i]; jj < oI[i + 1]; jj++) res -= oa[jj] * uext[oJ[jj]];
+            u[i] += omega * res / l1[i];
+        }
+    }
+}
+
 ORC_API void orc_l1gs_sweep(int n, const int *dI, const int *dJ, const double *da,
                             const int *oI, const int *oJ, const double *oa,
                             const double *f, const double *l1, const double *uext, double *u)
@@ -682,7 +706,7 @@ static void smoother_apply(const orc_csr *A, const orc_smoother *s, const double
     int n = A->n, i, sw;
     if (zero_guess) memset(u, 0, sizeof(double) * (size_t)n);
     for (sw = 0; sw < s->sweeps; sw++) {
-        if (s->type == 1) {
+        if (s->type == 1 || s->type == 5) {        /* 5 = lumped Jacobi: mfem::HypreSmoother turns it into type 1 with l1 = A 1 */
             memcpy(v, f, sizeof(double) * (size_t)n);
             orc_csr_matvec(n, A->I, A->J, A->a, -s->weight, u, s->weight, v);
             orc_jacobi_update(n, v, s->l1, u);

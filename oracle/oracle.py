@@ -383,10 +383,14 @@ class OSmoother:
         self.order, self.fraction = order, fraction
         self.iterative_mode = True
         n = A.shape[0]
-        if type in (2, 4, 6) and (weight != 1.0 or omega != 1.0):
-            raise NotImplementedError("the SSOR branches of hypre's Gauss-Seidel relaxations (relax_weight or omega != 1) are not restated")
+        if (type in (2, 4, 6) and weight != 1.0) or (type == 6 and omega != 1.0):
+            raise NotImplementedError("the SSOR branches of hypre's Gauss-Seidel relaxations (relax_weight != 1; omega != 1 for type 6) are not restated")
         if type in (1, 2, 3, 4):
             self.l1 = l1_norms(A.diag, A.offd, option=type)
+        if type == 5:
+            # mfem::HypreSmoother::SetOperator: l1_norms = A * 1 (row sums, ghost columns included), then the relaxation of type 1
+            self.l1 = np.zeros(n)
+            A.matvec(1.0, np.ones(A.shape[1]), 0.0, self.l1)
         if type == 16:
             self.max_eig, self.min_eig = eig if eig is not None else max_eig_estimate_cg(A, 1, 10)
             self.co, self.coefs = cheby_coefs(self.max_eig, self.min_eig, fraction, order)
@@ -400,7 +404,7 @@ class OSmoother:
             u[:] = 0.0
         L = lib()
         for _ in range(self.sweeps):
-            if self.type == 1:
+            if self.type in (1, 5):
                 v = f.copy()
                 A.matvec(-self.weight, u, self.weight, v)
                 L.orc_jacobi_update(C.c_int(n), _dp(v), _dp(self.l1), _dp(u))
@@ -415,9 +419,13 @@ class OSmoother:
             elif self.type in (2, 4):
                 ue = A.ghost(u)
                 has = A.offd.shape[1] > 0
-                L.orc_l1gs_sweep(C.c_int(n), _ip(A.diag.indptr), _ip(A.diag.indices), _dp(A.diag.data),
-                                 _ip(A.offd.indptr) if has else None, _ip(A.offd.indices) if has else None,
-                                 _dp(A.offd.data) if has else None, _dp(f), _dp(self.l1), _dp(ue), _dp(u))
+                args = (C.c_int(n), _ip(A.diag.indptr), _ip(A.diag.indices), _dp(A.diag.data),
+                        _ip(A.offd.indptr) if has else None, _ip(A.offd.indices) if has else None,
+                        _dp(A.offd.data) if has else None, _dp(f), _dp(self.l1), _dp(ue))
+                if self.omega == 1.0:
+                    L.orc_l1gs_sweep(*args, _dp(u))
+                else:
+                    L.orc_l1gs_sweep_omega(*args, C.c_double(self.omega), _dp(u))
             elif self.type == 16:
                 tmp = np.zeros(n); r = np.empty(n); orig = np.empty(n); v = np.zeros(n)
                 A.matvec(-1.0, u, 0.0, tmp)

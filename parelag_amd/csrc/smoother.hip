@@ -33,9 +33,16 @@ void RelaxSmoother::setup()
     const int nn = n();
     Temp<int> bad(1);
     ELAG_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), ctx().stream));
-    if (type == ELAG_HIP_SMOOTHER_L1_JACOBI || type == ELAG_HIP_SMOOTHER_JACOBI) {
+    if (type == ELAG_HIP_SMOOTHER_L1_JACOBI || type == ELAG_HIP_SMOOTHER_JACOBI || type == ELAG_HIP_SMOOTHER_LUMPED_JACOBI) {
         Temp<double> l1((size_t)nn);
-        if (type == ELAG_HIP_SMOOTHER_L1_JACOBI) {
+        if (type == ELAG_HIP_SMOOTHER_LUMPED_JACOBI) {
+            // mfem::HypreSmoother::SetOperator, type 5: l1_norms = A * 1 (row sums over diag and offd), relaxation of type 1 from there on
+            Temp<double> ones((size_t)std::max(A->ncols(), 1));
+            k::vec_fill(A->ncols(), 1.0, ones);
+            k::SpmvArgs a;
+            a.x = ones; a.alpha = 1.0; a.out = l1;
+            par_spmv(*A, a);
+        } else if (type == ELAG_HIP_SMOOTHER_L1_JACOBI) {
             // mfem::HypreSmoother::SetOperator: l1_norms = hypre_ParCSRComputeL1Norms(A, 1)
             k::l1_norms(A->diag, &A->offd, 1, l1, bad);
             if (read_int(bad)) fail(ELAG_HIP_ERR_NUMERIC, "l1-Jacobi: matrix has a zero l1 row norm");
@@ -59,7 +66,7 @@ void RelaxSmoother::setup()
     } else {
         fail(ELAG_HIP_ERR_ARG,
              "relax type %d is not available on the device: the table of ParELAG_HypreSmootherFactory.cpp:92-109 is served for "
-             "\"Jacobi\" (0), \"L1 Jacobi\" (1), \"L1 Gauss-Seidel\" (2), \"L1 Gauss-Seidel Truncated\" (4), \"Gauss-Seidel\" (6), "
+             "\"Jacobi\" (0), \"L1 Jacobi\" (1), \"L1 Gauss-Seidel\" (2), \"L1 Gauss-Seidel Truncated\" (4), \"Lumped Jacobi\" (5), \"Gauss-Seidel\" (6), "
              "\"Chebyshev\" (16) and \"Hypre Jacobi\" (413)", type);
     }
     ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));

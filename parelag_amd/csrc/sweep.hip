@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kWideBlock) void sweep_levels_kernel(const int *__r
                                                                   const int *__restrict__ J, const double *__restrict__ a,
                                                                   const int *__restrict__ oI, const int *__restrict__ oJ, const double *__restrict__ oa,
                                                                   const double *__restrict__ f, const double *__restrict__ d, const double *__restrict__ ug,
-                                                                  double *u)
+                                                                  double omega, double *u)
 {
     const int b = step_ptr[first], e = step_ptr[first + count];
     const int lane = threadIdx.x & (kLPR - 1);
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kWideBlock) void sweep_levels_kernel(const int *__r
         }
     }
     if (lane == 0) {
-        if (MODE == 0) { if (dr != 0.0) u[row] = uo + res / dr; }
+        if (MODE == 0) { if (dr != 0.0) u[row] = uo + omega * res / dr; }
         else if (have && aii != 0.0) u[row] = res / aii;
     }
 }
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__r
                                                                   const int4s *__restrict__ sched, const int *__restrict__ J, const double *__restrict__ a,
                                                                   const int *__restrict__ oI, const int *__restrict__ oJ, const double *__restrict__ oa,
                                                                   const double *__restrict__ f, const double *__restrict__ d, const double *__restrict__ ug,
-                                                                  double *u)
+                                                                  double omega, double *u)
 {
     __shared__ int lp[kMaxChain + 1];
     const int s_lo = dir > 0 ? s_first : s_first - (s_count - 1);
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__r
                 }
             }
             if (lane == 0) {
-                if (MODE == 0) { if (dr[q] != 0.0) u[row] = uo[q] + res / dr[q]; }
+                if (MODE == 0) { if (dr[q] != 0.0) u[row] = uo[q] + omega * res / dr[q]; }
                 else if (have && aii != 0.0) u[row] = res / aii;
             }
         }
@@ -292,9 +292,9 @@ void SweepSmoother::setup()
                  "internal: relax type %d is not a sweep", type);
     // hypre_ParCSRRelax 2/4 and hypre_BoomerAMGRelax 6 branch on (relax_weight, omega): (1, 1) is the symmetric Gauss-Seidel of
     // every shipped parameter list ("Damping Factor" 1.0, "Omega" 1.0); the SSOR branches are not built
-    if (weight != 1.0 || omega != 1.0)
-        fail(ELAG_HIP_ERR_ARG, "relax type %d: only \"Damping Factor\" = \"Omega\" = 1.0 (symmetric Gauss-Seidel) is available, got %g / %g",
-             type, weight, omega);
+    if (weight != 1.0 || (omega != 1.0 && type == ELAG_HIP_SMOOTHER_GS))
+        fail(ELAG_HIP_ERR_ARG, "relax type %d: \"Damping Factor\" must be 1.0 (and \"Omega\" 1.0 for \"Gauss-Seidel\"): hypre's SSOR branches are "
+             "not built; got %g / %g", type, weight, omega);
     const int n = A->nrows();
     hipStream_t st = ctx().stream;
     if (type != ELAG_HIP_SMOOTHER_GS) {
@@ -387,18 +387,18 @@ void SweepSmoother::launch_segment(const Segment &s, int dir, const double *f, d
         const unsigned grid = (unsigned)(((long long)s.max_rows * kLPR + kWideBlock - 1) / kWideBlock);
         if (type == ELAG_HIP_SMOOTHER_GS)
             hipLaunchKernelGGL(sweep_levels_kernel<1>, dim3(grid), dim3(kWideBlock), 0, st, (const int *)d_lev_ptr, s.first, s.count, sched,
-                               (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, dd, (const double *)A->d_ghost, u);
+                               (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, dd, (const double *)A->d_ghost, omega, u);
         else
             hipLaunchKernelGGL(sweep_levels_kernel<0>, dim3(grid), dim3(kWideBlock), 0, st, (const int *)d_lev_ptr, s.first, s.count, sched,
-                               (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, dd, (const double *)A->d_ghost, u);
+                               (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, dd, (const double *)A->d_ghost, omega, u);
     } else {
         const int s_first = dir > 0 ? s.first : s.first + s.count - 1;
         if (type == ELAG_HIP_SMOOTHER_GS)
             hipLaunchKernelGGL(sweep_chain_kernel<1>, dim3(1), dim3(kChainBlock), 0, st, (const int *)d_lev_ptr, s_first, s.count, dir, sched,
-                               (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, dd, (const double *)A->d_ghost, u);
+                               (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, dd, (const double *)A->d_ghost, omega, u);
         else
             hipLaunchKernelGGL(sweep_chain_kernel<0>, dim3(1), dim3(kChainBlock), 0, st, (const int *)d_lev_ptr, s_first, s.count, dir, sched,
-                               (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, dd, (const double *)A->d_ghost, u);
+                               (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, dd, (const double *)A->d_ghost, omega, u);
     }
     ELAG_LAUNCH_CHECK();
 }

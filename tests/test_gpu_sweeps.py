@@ -82,11 +82,13 @@ def test_the_reference_s_own_smoother_block_is_accepted_unchanged(la, h1_k2):
     assert np.array_equal(u, ur)
     # what is not built says so instead of computing something else
     from parelag_amd._lib import ElagHipError
-    for name in ("Kaczmarz", "Lumped Jacobi", "Taubin", "FIR"):
+    for name in ("Kaczmarz", "Taubin", "FIR"):
         with pytest.raises(ElagHipError, match="not available"):
             la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), la.HYPRE_SMOOTHER_TYPES[name])
     with pytest.raises(ElagHipError, match="Omega"):
-        la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), 2, {"Omega": 1.2})
+        la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), 6, {"Omega": 1.2})          # SSOR branch of BoomerAMGRelax: not built
+    with pytest.raises(ElagHipError, match="Damping"):
+        la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), 2, {"Damping Factor": 0.8})
     # a zero l1 norm is an error in hypre_ParCSRComputeL1Norms, here too
     Z = sp.csr_matrix(A).tolil(); Z[5, :] = 0; Z = Z.tocsr(); Z.eliminate_zeros()
     with pytest.raises(ElagHipError, match="zero l1"):
@@ -221,3 +223,33 @@ def test_distributed_sweep_freezes_the_ghost_values(h1_k2, relax_type, world):
     for r in range(world):
         lo, hi = int(starts[r]), int(starts[r + 1])
         assert np.array_equal(res[r], ug[lo:hi])
+
+
+@pytest.mark.parametrize("relax_type", [2, 4])
+def test_l1_gauss_seidel_with_omega(la, h1_k2, relax_type):
+    """relax_weight = 1, omega != 1: u_i += omega * res / l1_i in both directions (hypre_ParCSRRelax 2 / 4)"""
+    A, _, _ = h1_k2
+    Ad = orc.diag_first(A)
+    ref_s = orc.OSmoother(orc.OParCSR(Ad), type=relax_type, omega=1.3)
+    dev_s = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(Ad), relax_type, {"Omega": 1.3})
+    rng = np.random.default_rng(2)
+    f, u0 = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+    u, ur = u0.copy(), u0.copy()
+    dev_s.Mult(f, u); ref_s.Mult(f, ur)
+    assert np.array_equal(u, ur)
+
+
+def test_lumped_jacobi_is_l1_jacobi_with_row_sums(la, h1_k2):
+    """"Lumped Jacobi" = 5: mfem::HypreSmoother takes l1 = A 1 (row sums) and runs relaxation type 1 with it -- on a matrix whose
+    row sums are positive (a shifted stiffness matrix: the plain one has zero row sums, i.e. the reference divides by zero)"""
+    A, _, _ = h1_k2
+    B = orc.diag_first((A + 0.3 * sp.eye(A.shape[0])).tocsr())
+    ref_s = orc.OSmoother(orc.OParCSR(B), type=5, sweeps=2, weight=0.9)
+    dev_s = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(B), la.HYPRE_SMOOTHER_TYPES["Lumped Jacobi"], {"Sweeps": 2, "Damping Factor": 0.9})
+    rng = np.random.default_rng(4)
+    f, u0 = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+    u, ur = u0.copy(), u0.copy()
+    dev_s.Mult(f, u); ref_s.Mult(f, ur)
+    assert np.max(np.abs(u - ur)) <= 1e-12 * np.max(np.abs(ur))
+    rs = np.asarray(B.sum(axis=1)).ravel()
+    assert np.max(np.abs(ur - (lambda v: v + 0.9 * (f - B @ v) / rs)(u0 + 0.9 * (f - B @ u0) / rs))) <= 1e-12 * np.max(np.abs(ur))
