@@ -578,6 +578,25 @@ ELAG_HIP_API int elag_hip_host_sort_rows_by_key(int64_t nrow, const int64_t *ptr
 /* idx = concatenation of the ranges [starts[i], starts[i] + counts[i]), owner[k] = i of entry k. */
 ELAG_HIP_API int elag_hip_host_expand_ranges(int64_t n, const int64_t *starts, const int64_t *counts, int64_t total, int64_t *idx, int64_t *owner);
 
+/* Index tables between the facet stage and the extension stage of the two-form coarsening, one agglomerate at a time on host threads
+ * (csrc/host_amge_tables.hip).  Replaces the per-agglomerate loops of DofAgglomeration (src/amge/DOFAgglomeration.cpp:86-131, reorderRow),
+ * of hFacetExtension's boundary bookkeeping (src/amge/DeRhamSequence.cpp:2214-2290) and of DistributeAgglomerateMatrix.
+ *  - dof_agglomeration: agglomerate a = elements els[ae_ptr[a]..), element e = dofs e_idx[e_ptr[e]..); sep[d] != 0 for dofs on agglomerated
+ *    facets.  Writes ae_dof_ptr (nAE+1), n_int (nAE), ae_dofs (distinct dofs, interior first, each group ascending; room for all repeated
+ *    dofs) and loc (position of every repeated dof in its agglomerate's list).
+ *  - boundary_traces: coarse trace columns on every agglomerate's boundary (cb_ptr/cb) and the col-major (nb x next) blocks of trace values on
+ *    its boundary dofs (Rb_ptr/R_b) taken from the facet kernel's packed output p_loc; cb == NULL: sizes only.
+ *  - local_derivative: triplets of D (32-bit CSR) localised to (range dofs, agglomerate dofs) of every agglomerate; d_row == NULL: d_ptr only. */
+ELAG_HIP_API int elag_hip_host_amge_dof_agglomeration(int64_t nAE, const int64_t *ae_ptr, const int64_t *els, const int64_t *e_ptr, const int64_t *e_idx,
+                                                      int64_t ndof, const int64_t *sep, int64_t *ae_dof_ptr, int64_t *n_int, int64_t *ae_dofs, int64_t *loc);
+ELAG_HIP_API int elag_hip_host_amge_boundary_traces(int64_t nAE, const int64_t *B_ptr, const int64_t *B_idx, const int64_t *cf_ptr, const int64_t *af_of_dof,
+                                                    const int64_t *pos_in_af, const int64_t *af_d_ptr, int64_t k, const double *p_loc,
+                                                    const int64_t *ae_dof_ptr, const int64_t *ae_dofs, const int64_t *n_int, int64_t *cb_ptr, int64_t *Rb_ptr,
+                                                    int64_t *cb, double *R_b);
+ELAG_HIP_API int elag_hip_host_amge_local_derivative(int64_t nAE, const int64_t *row_ptr, const int64_t *row_dofs, const int32_t *D_indptr,
+                                                     const int32_t *D_indices, const double *D_data, const int64_t *ae_dof_ptr, const int64_t *ae_dofs,
+                                                     const int64_t *n_int, int64_t *d_ptr, int32_t *d_row, int32_t *d_col, double *d_val);
+
 /* --------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): run `reps` launches of one fine-level kernel on the compute stream
  * bracketed by HIP events created on that stream and return the mean milliseconds per launch.

@@ -155,6 +155,9 @@ _SIGNATURES = {
     "elag_hip_host_lookup_find": [_i64, _p, _p, _i64, _i64, _p, _p, _p],
     "elag_hip_host_gather_dense": [_i64, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p],
     "elag_hip_host_expand_ranges": [_i64, _p, _p, _i64, _p, _p],
+    "elag_hip_host_amge_dof_agglomeration": [_i64, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p],
+    "elag_hip_host_amge_boundary_traces": [_i64, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
+    "elag_hip_host_amge_local_derivative": [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "elag_hip_host_blocks_to_coo": [_i64, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "elag_hip_host_pack_cols": [_i64, _p, _p, _i64, _i64, _p, _p],
     "elag_hip_host_take_leading": [_i64, _p, _p, _p, _p],

@@ -13,6 +13,7 @@ calls raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import scipy.sparse as sp
@@ -152,6 +153,118 @@ def _blocks_to_csr(rows_ptr, rows_idx, cols_ptr, cols_idx, vals, ld_cols, shape,
     return M
 
 
+def _agglomerate_tables_numpy(ndof2, nAE, nAF, ae_ptr, els, e2_ptr, e2_idx, af_dofs, af_of_afdof, locf, af_d_ptr, B_ptr, AFs, cf_ptr, k2, o_pf,
+                              ae_d3_ptr, ae_dofs3, D) -> dict:
+    """Whole-array numpy statement of :func:`_agglomerate_tables` (the tests compare the two array by array)."""
+    ae_of_item = np.repeat(np.arange(nAE, dtype=np.int64), np.diff(ae_ptr))
+    ncf = np.diff(cf_ptr)
+    sep = np.zeros(ndof2, dtype=np.int64)
+    sep[af_dofs] = 1
+    n2e = np.diff(e2_ptr)
+    rd, ownr = expand_ranges(e2_ptr[els], n2e[els])              # rdofs (element-local copies) in agglomerate order
+    rd_dof = e2_idx[rd]
+    rd_ae = ae_of_item[ownr]
+    big = 2 * ndof2
+    key = rd_ae * big + sep[rd_dof] * ndof2 + rd_dof             # order of reorderRow: (agglomerate, separator type, dof)
+    ukey, loc_of_rd = np.unique(key, return_inverse=True)
+    ae_of_u = ukey // big
+    ae_dofs2 = ukey % ndof2
+    sep_u = (ukey % big) // ndof2
+    ae_d2_ptr = ptr_from_counts(np.bincount(ae_of_u, minlength=nAE))
+    ni = np.bincount(ae_of_u, weights=(sep_u == 0), minlength=nAE).astype(np.int64)
+    nu = np.diff(ae_d2_ptr)
+    loc2 = loc_of_rd.reshape(-1) - ae_d2_ptr[rd_ae]
+    # coarse trace dofs on the boundary of an agglomerate: facets of the coarse element-facet row, dofs facet by facet
+    ae_of_B = np.repeat(np.arange(nAE, dtype=np.int64), np.diff(B_ptr))
+    cbd, ownb = expand_ranges(cf_ptr[AFs], ncf[AFs])
+    cbd_ptr = ptr_from_counts(np.bincount(ae_of_B, weights=ncf[AFs], minlength=nAE).astype(np.int64))
+    nxt = np.diff(cbd_ptr)
+    # R_b: traces on the boundary dofs of the agglomerate, col-major (nb x next).  Trace values per (fine dof, local coarse
+    # column of its AF) come from p_loc of the facet kernel.
+    af_of_dof = np.full(ndof2, -1, dtype=np.int64); af_of_dof[af_dofs] = af_of_afdof
+    pos_in_af = np.zeros(ndof2, dtype=np.int64); pos_in_af[af_dofs] = locf
+    nb = nu - ni
+    Rb_ptr = ptr_from_counts(nb * nxt)
+    R_b = np.zeros(int(Rb_ptr[-1]))
+    # for every coarse boundary column (ae, j): its AF F, its index c within the AF; rows = boundary dofs of ae lying on F
+    col_ae = ae_of_B[ownb]; col_F = AFs[ownb]; col_c = cbd - cf_ptr[col_F]
+    col_j = np.arange(cbd.size, dtype=np.int64) - cbd_ptr[col_ae]
+    bsel = np.nonzero(sep_u == 1)[0]
+    b_ae = ae_of_u[bsel]; b_dof = ae_dofs2[bsel]; b_loc = bsel - ae_d2_ptr[b_ae] - ni[b_ae]; b_F = af_of_dof[b_dof]
+    # join (ae, F) of columns with (ae, F) of boundary dofs
+    ckey = col_ae * nAF + col_F
+    bkey = b_ae * nAF + b_F
+    so = np.argsort(bkey, kind="stable")
+    bkey_s = bkey[so]
+    lo = np.searchsorted(bkey_s, ckey, side="left"); hi = np.searchsorted(bkey_s, ckey, side="right")
+    pair_b, pair_col = expand_ranges(lo, hi - lo)
+    pb = so[pair_b]
+    src = af_d_ptr[b_F[pb]] * k2 + col_c[pair_col] * np.diff(af_d_ptr)[b_F[pb]] + pos_in_af[b_dof[pb]]
+    dst = Rb_ptr[col_ae[pair_col]] + col_j[pair_col] * nb[col_ae[pair_col]] + b_loc[pb]
+    R_b[dst] = o_pf[src]
+    # local derivative triplets: rows = p dofs of the agglomerate (position in ae_dofs3), cols = u dofs (position in ae_dofs2)
+    prow_ae = np.repeat(np.arange(nAE, dtype=np.int64), np.diff(ae_d3_ptr))
+    cnt_row = np.diff(D.indptr)[ae_dofs3]
+    dq, own_row = expand_ranges(D.indptr[ae_dofs3], cnt_row)
+    d_ae = prow_ae[own_row]
+    d_row = own_row - ae_d3_ptr[d_ae]
+    dcol_glob = D.indices[dq].astype(np.int64)
+    dkey = d_ae * big + sep[dcol_glob] * ndof2 + dcol_glob
+    pos = np.searchsorted(ukey, dkey)
+    if not np.array_equal(ukey[np.minimum(pos, ukey.size - 1)], dkey):
+        raise ValueError("DistributeAgglomerateMatrix: D_2 couples an agglomerate with a dof outside it")
+    d_col = pos - ae_d2_ptr[d_ae]
+    d_ptr = ptr_from_counts(np.bincount(d_ae, minlength=nAE))
+    return dict(ae_d2_ptr=ae_d2_ptr, ae_dofs2=ae_dofs2, ni=ni, loc2=loc2, cbd_ptr=cbd_ptr, cbd=cbd, R_b=R_b, d_ptr=d_ptr,
+                d_row=d_row.astype(np.int32), d_col=d_col.astype(np.int32), d_val=D.data[dq])
+
+
+def _agglomerate_tables(ndof2, nAE, nAF, ae_ptr, els, e2_ptr, e2_idx, af_dofs, af_of_afdof, locf, af_d_ptr, B_ptr, AFs, cf_ptr, k2, o_pf,
+                        ae_d3_ptr, ae_dofs3, D) -> dict:
+    """The index tables between the facet stage and the extension stage of ``Coarsen``, agglomerate by agglomerate in threaded
+    host code (``csrc/host_amge_tables.hip``): DofAgglomeration of form 2 (``DOFAgglomeration.cpp:86-131``: dofs of every
+    agglomerate, interior first, and the local index of every element dof), the coarse trace columns on its boundary with
+    the traces restricted to its boundary dofs (``DeRhamSequence.cpp:2214-2290``), and the local triplets of ``D_2``
+    (``DistributeAgglomerateMatrix``)."""
+    Lh = _lib.load()
+
+    def chk(status):                                            # same exception as the numpy statement
+        try:
+            _lib.check(status)
+        except _lib.ElagHipError as e:
+            raise ValueError(str(e)) from None
+
+    c64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+    ae_ptr, els, e2_ptr, e2_idx, af_d_ptr, B_ptr, AFs, cf_ptr, ae_d3_ptr, ae_dofs3 = map(c64, (ae_ptr, els, e2_ptr, e2_idx, af_d_ptr, B_ptr, AFs, cf_ptr,
+                                                                                                 ae_d3_ptr, ae_dofs3))
+    sep = np.zeros(ndof2, dtype=np.int64); sep[af_dofs] = 1
+    af_of_dof = np.full(ndof2, -1, dtype=np.int64); af_of_dof[af_dofs] = af_of_afdof
+    pos_in_af = np.zeros(ndof2, dtype=np.int64); pos_in_af[af_dofs] = locf
+    n_rd = int(np.diff(e2_ptr)[els].sum())
+    ae_d2_ptr = np.empty(nAE + 1, dtype=np.int64); ni = np.empty(nAE, dtype=np.int64)
+    dofs_buf = np.empty(n_rd, dtype=np.int64); loc2 = np.empty(n_rd, dtype=np.int64)
+    chk(Lh.elag_hip_host_amge_dof_agglomeration(nAE, _ptr(ae_ptr), _ptr(els), _ptr(e2_ptr), _ptr(e2_idx), ndof2, _ptr(sep), _ptr(ae_d2_ptr),
+                                                       _ptr(ni), _ptr(dofs_buf), _ptr(loc2)))
+    ae_dofs2 = dofs_buf[:int(ae_d2_ptr[-1])].copy()
+    cbd_ptr = np.empty(nAE + 1, dtype=np.int64); Rb_ptr = np.empty(nAE + 1, dtype=np.int64)
+    o_pf = np.ascontiguousarray(o_pf, dtype=np.float64)
+    args = (nAE, _ptr(B_ptr), _ptr(AFs), _ptr(cf_ptr), _ptr(af_of_dof), _ptr(pos_in_af), _ptr(af_d_ptr), int(k2), _ptr(o_pf), _ptr(ae_d2_ptr),
+            _ptr(ae_dofs2), _ptr(ni), _ptr(cbd_ptr), _ptr(Rb_ptr))
+    chk(Lh.elag_hip_host_amge_boundary_traces(*args, None, None))
+    cbd = np.empty(int(cbd_ptr[-1]), dtype=np.int64); R_b = np.empty(int(Rb_ptr[-1]))
+    chk(Lh.elag_hip_host_amge_boundary_traces(*args, _ptr(cbd), _ptr(R_b)))
+    indptr = np.ascontiguousarray(D.indptr, dtype=np.int32); indices = np.ascontiguousarray(D.indices, dtype=np.int32)
+    data = np.ascontiguousarray(D.data, dtype=np.float64)
+    d_ptr = np.empty(nAE + 1, dtype=np.int64)
+    dargs = (nAE, _ptr(ae_d3_ptr), _ptr(ae_dofs3), _ptr(indptr), _ptr(indices), _ptr(data), _ptr(ae_d2_ptr), _ptr(ae_dofs2), _ptr(ni), _ptr(d_ptr))
+    chk(Lh.elag_hip_host_amge_local_derivative(*dargs, None, None, None))
+    nd = int(d_ptr[-1])
+    d_row = np.empty(nd, dtype=np.int32); d_col = np.empty(nd, dtype=np.int32); d_val = np.empty(nd)
+    chk(Lh.elag_hip_host_amge_local_derivative(*dargs, _ptr(d_row), _ptr(d_col), _ptr(d_val)))
+    return dict(ae_d2_ptr=ae_d2_ptr, ae_dofs2=ae_dofs2, ni=ni, loc2=loc2, cbd_ptr=cbd_ptr, cbd=cbd, R_b=R_b, d_ptr=d_ptr, d_row=d_row, d_col=d_col,
+                d_val=d_val)
+
+
 # ---- Coarsen ----------------------------------------------------------------------------------------------------------------
 
 def coarsen(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entry: float = EPS, timings: dict | None = None) -> dict:
@@ -213,69 +326,18 @@ def coarsen(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_ent
     cf_idx = np.arange(ntrace, dtype=np.int64)
     M2fc_blocks = _take_leading(o_cmf, np.full(nAF, k2), ncf)
 
-    # ===== DofAgglomeration of form 2 on the agglomerated elements (DOFAgglomeration.cpp:86-131) =====
-    sep = np.zeros(lv.ndof2, dtype=np.int64)
-    sep[af_dofs] = 1
+    # ===== DofAgglomeration of form 2 on the agglomerated elements (DOFAgglomeration.cpp:86-131), boundary traces, local D =====
     e2_ptr, e2_idx = lv.elem_dof2_table()
     n2e = np.diff(e2_ptr)
-    rd, ownr = expand_ranges(e2_ptr[els], n2e[els])              # rdofs (element-local copies) in agglomerate order
-    rd_dof = e2_idx[rd]
-    rd_ae = ae_of_item[ownr]
-    big = 2 * lv.ndof2
-    key = rd_ae * big + sep[rd_dof] * lv.ndof2 + rd_dof          # order of reorderRow: (agglomerate, separator type, dof)
-    ukey, loc_of_rd = np.unique(key, return_inverse=True)
-    ae_of_u = ukey // big
-    ae_dofs2 = ukey % lv.ndof2
-    sep_u = (ukey % big) // lv.ndof2
-    ae_d2_ptr = ptr_from_counts(np.bincount(ae_of_u, minlength=nAE))
-    ni = np.bincount(ae_of_u, weights=(sep_u == 0), minlength=nAE).astype(np.int64)
-    nu = np.diff(ae_d2_ptr)
-    loc2 = loc_of_rd.reshape(-1) - ae_d2_ptr[rd_ae]
-    # position of every (agglomerate, dof) pair: used to localise D and the traces
-    # coarse trace dofs on the boundary of an agglomerate: facets of the coarse element-facet row, dofs facet by facet
-    AFs = topo["B_idx"]
-    ae_of_B = np.repeat(np.arange(nAE, dtype=np.int64), np.diff(topo["B_ptr"]))
-    cbd, ownb = expand_ranges(cf_ptr[AFs], ncf[AFs])
-    cbd_ptr = ptr_from_counts(np.bincount(ae_of_B, weights=ncf[AFs], minlength=nAE).astype(np.int64))
-    nxt = np.diff(cbd_ptr)
-    # R_b: traces on the boundary dofs of the agglomerate, col-major (nb x next).  Trace values per (fine dof, local coarse
-    # column of its AF) come from p_loc of the facet kernel.
-    af_of_dof = np.full(lv.ndof2, -1, dtype=np.int64); af_of_dof[af_dofs] = af_of_item[ownf]
-    pos_in_af = np.zeros(lv.ndof2, dtype=np.int64); pos_in_af[af_dofs] = locf
-    nb = nu - ni
-    Rb_ptr = ptr_from_counts(nb * nxt)
-    R_b = np.zeros(int(Rb_ptr[-1]))
-    # for every coarse boundary column (ae, j): its AF F, its index c within the AF; rows = boundary dofs of ae lying on F
-    col_ae = ae_of_B[ownb]; col_F = AFs[ownb]; col_c = cbd - cf_ptr[col_F]
-    col_j = np.arange(cbd.size, dtype=np.int64) - cbd_ptr[col_ae]
-    # boundary dofs of every agglomerate with their AF
-    bsel = np.nonzero(sep_u == 1)[0]
-    b_ae = ae_of_u[bsel]; b_dof = ae_dofs2[bsel]; b_loc = bsel - ae_d2_ptr[b_ae] - ni[b_ae]; b_F = af_of_dof[b_dof]
-    # join (ae, F) of columns with (ae, F) of boundary dofs
-    ckey = col_ae * nAF + col_F
-    bkey = b_ae * nAF + b_F
-    so = np.argsort(bkey, kind="stable")
-    bkey_s = bkey[so]
-    lo = np.searchsorted(bkey_s, ckey, side="left"); hi = np.searchsorted(bkey_s, ckey, side="right")
-    pair_b, pair_col = expand_ranges(lo, hi - lo)
-    pb = so[pair_b]
-    src = af_d_ptr[b_F[pb]] * k2 + col_c[pair_col] * np.diff(af_d_ptr)[b_F[pb]] + pos_in_af[b_dof[pb]]
-    dst = Rb_ptr[col_ae[pair_col]] + col_j[pair_col] * nb[col_ae[pair_col]] + b_loc[pb]
-    R_b[dst] = o_pf[src]
-    # local derivative triplets: rows = p dofs of the agglomerate (position in ae_dofs3), cols = u dofs (position in ae_dofs2)
     D = lv.D2.tocsr()
-    prow_ae = np.repeat(np.arange(nAE, dtype=np.int64), np.diff(ae_d3_ptr))
-    cnt_row = np.diff(D.indptr)[ae_dofs3]
-    dq, own_row = expand_ranges(D.indptr[ae_dofs3], cnt_row)
-    d_ae = prow_ae[own_row]
-    d_row = own_row - ae_d3_ptr[d_ae]
-    dcol_glob = D.indices[dq].astype(np.int64)
-    dkey = d_ae * big + sep[dcol_glob] * lv.ndof2 + dcol_glob
-    pos = np.searchsorted(ukey, dkey)
-    if not np.array_equal(ukey[np.minimum(pos, ukey.size - 1)], dkey):
-        raise ValueError("DistributeAgglomerateMatrix: D_2 couples an agglomerate with a dof outside it")
-    d_col = pos - ae_d2_ptr[d_ae]
-    d_ptr = ptr_from_counts(np.bincount(d_ae, minlength=nAE))
+    tables = _agglomerate_tables_numpy if os.environ.get("ELAG_HIP_AMGE_NUMPY_TABLES") else _agglomerate_tables
+    tb = tables(lv.ndof2, nAE, nAF, topo["ae_ptr"], els, e2_ptr, e2_idx, af_dofs, af_of_item[ownf], locf, af_d_ptr, topo["B_ptr"], topo["B_idx"],
+                cf_ptr, k2, o_pf, ae_d3_ptr, ae_dofs3, D)
+    ae_d2_ptr, ae_dofs2, ni, loc2 = tb["ae_d2_ptr"], tb["ae_dofs2"], tb["ni"], tb["loc2"]
+    cbd_ptr, cbd, R_b = tb["cbd_ptr"], tb["cbd"], tb["R_b"]
+    d_ptr, d_row, d_col, d_val = tb["d_ptr"], tb["d_row"], tb["d_col"], tb["d_val"]
+    nu = np.diff(ae_d2_ptr)
+    nxt = np.diff(cbd_ptr)
     # pv_p and cP from P_3 (packed p_loc of the element kernel: col-major np x k3 per agglomerate)
     np_ = np.diff(ae_d3_ptr)
     pv_p, _ = expand_ranges(ae_d3_ptr[:-1] * k3, np_)
@@ -288,7 +350,7 @@ def coarsen(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_ent
     ein = _ExtIn(nAE, nT2, 0, 1, svd_tol, smallest_entry, keep3.i32(nu), keep3.i32(ni), keep3.i32(np_), None, None, keep3.i32(nxt), keep3.i32(nrt),
                  _assembly(keep3, ae_of_item, nAE, lv.M2e_ptr[els], n2e[els], loc2, lv.M2e),
                  _assembly(keep3, ae_of_item, nAE, lv.M3e_ptr[els], n3e[els], loc3, lv.M3e), _Assembly(),
-                 keep3.i64(d_ptr), keep3.i32(d_row), keep3.i32(d_col), keep3.f64(D.data[dq]), None, None, None, None,
+                 keep3.i64(d_ptr), keep3.i32(d_row), keep3.i32(d_col), keep3.f64(d_val), None, None, None, None,
                  keep3.f64(pv_p), keep3.f64(R_b), keep3.f64(cP), keep3.f64(_pack_cols(lv.T2, ae_dofs2, ae_d2_ptr)), None)
     kf = nrt + nT2
     ncm = nxt + nrt + nT2

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libelag_hip.so")
 SOURCES = ["context.hip", "comm.hip", "kernels_spmv.hip", "kernels_setup.hip", "parcsr.hip", "dist_rap.hip", "maps.hip", "smoother.hip", "sweep.hip",
-           "hierarchy.hip", "dense.hip", "blocked.hip", "krylov.hip", "amge.hip", "host_tables.hip"]
+           "hierarchy.hip", "dense.hip", "blocked.hip", "krylov.hip", "amge.hip", "host_tables.hip", "host_amge_tables.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wextra",
          "-Wno-unused-parameter", "-ffp-contract=off", "-I/opt/rocm/include"]
 

@@ -1,0 +1,205 @@
+// Host-side tables of the two-form AMGe coarsening (parelag_amd/amge.py), one agglomerate at a time like the reference's own loops
+// (DofAgglomeration, src/amge/DOFAgglomeration.cpp:86-131, 533-655; hFacetExtension's local index work,
+// src/amge/DeRhamSequence.cpp:2214-2400), spread over host threads: an agglomerate only reads shared tables and writes its own
+// slices, so the loops split by agglomerate range with nothing to lock.  They replace whole-array numpy compositions
+// (unique / argsort / searchsorted joins on (agglomerate, dof) keys) and produce the same arrays bit for bit.
+// No device work; callable before elag_hip_init.
+#include "common.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace elag;
+
+namespace {
+
+int host_threads()
+{
+    static int n = 0;
+    if (n == 0) {
+        const char *e = getenv("ELAG_HIP_HOST_THREADS");
+        int hw = (int)std::thread::hardware_concurrency();
+        n = e ? atoi(e) : std::min(std::max(hw, 1), 16);
+        if (n < 1) n = 1;
+    }
+    return n;
+}
+
+// fn(begin, end) over [0, n) in contiguous chunks, one per thread; the first failure's message is rethrown on the caller's thread
+template <class F>
+void parallel_ranges(int64_t n, F &&fn)
+{
+    const int nt = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / 256));
+    if (nt <= 1) { fn((int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    std::vector<std::string> err((size_t)nt);
+    for (int t = 0; t < nt; t++) {
+        const int64_t b = n * t / nt, e = n * (t + 1) / nt;
+        th.emplace_back([&, b, e, t] {
+            try { fn(b, e); } catch (const std::exception &ex) { err[(size_t)t] = ex.what(); if (err[(size_t)t].empty()) err[(size_t)t] = "error"; }
+        });
+    }
+    for (auto &x : th) x.join();
+    for (auto &m : err)
+        if (!m.empty()) fail(ELAG_HIP_ERR_ARG, "%s", m.c_str());
+}
+
+struct Oops : std::exception {
+    std::string m;
+    explicit Oops(std::string s) : m(std::move(s)) {}
+    const char *what() const noexcept override { return m.c_str(); }
+};
+
+}  // namespace
+
+extern "C" {
+
+// DofAgglomeration of one form on the agglomerated elements.  Agglomerate a holds the elements els[ae_ptr[a] .. ae_ptr[a+1]); an
+// element e carries the dofs e_idx[e_ptr[e] .. e_ptr[e+1]) (its "repeated" dofs, in this order).  sep[d] != 0 marks the dofs that lie on
+// agglomerated facets.  Output: the dofs of every agglomerate without repetition, interior ones (sep == 0) first, each group
+// ascending (reorderRow) -- ae_dof_ptr (nAE+1), ae_dofs (room for the number of repeated dofs), n_int (nAE) -- and for every repeated dof,
+// in (agglomerate, element, local) order, its position in its agglomerate's list (loc, same length as the repeated dofs).
+ELAG_HIP_API int elag_hip_host_amge_dof_agglomeration(int64_t nAE, const int64_t *ae_ptr, const int64_t *els, const int64_t *e_ptr, const int64_t *e_idx,
+                                                      int64_t ndof, const int64_t *sep, int64_t *ae_dof_ptr, int64_t *n_int, int64_t *ae_dofs, int64_t *loc)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(nAE >= 0 && ae_ptr && els && e_ptr && e_idx && sep && ae_dof_ptr && n_int && ae_dofs && loc, "dof_agglomeration: null argument");
+        // repeated-dof offset of every agglomerate
+        std::vector<int64_t> rd_ptr((size_t)nAE + 1, 0);
+        for (int64_t a = 0; a < nAE; a++) {
+            int64_t s = 0;
+            for (int64_t q = ae_ptr[a]; q < ae_ptr[a + 1]; q++) s += e_ptr[els[q] + 1] - e_ptr[els[q]];
+            rd_ptr[(size_t)a + 1] = rd_ptr[(size_t)a] + s;
+        }
+        std::vector<int64_t> tmp((size_t)rd_ptr[(size_t)nAE]);          // sorted distinct keys of agglomerate a at tmp[rd_ptr[a] ..)
+        std::vector<int64_t> nu((size_t)nAE, 0);
+        const int64_t SEP = int64_t(1) << 62;
+        parallel_ranges(nAE, [&](int64_t b, int64_t e) {
+            std::vector<int64_t> keys;
+            for (int64_t a = b; a < e; a++) {
+                keys.clear();
+                for (int64_t q = ae_ptr[a]; q < ae_ptr[a + 1]; q++) {
+                    const int64_t el = els[q];
+                    for (int64_t t = e_ptr[el]; t < e_ptr[el + 1]; t++) {
+                        const int64_t d = e_idx[t];
+                        if (d < 0 || d >= ndof) throw Oops("dof_agglomeration: an element dof is outside the dof range");
+                        keys.push_back(sep[d] ? (d | SEP) : d);
+                    }
+                }
+                int64_t *u = tmp.data() + rd_ptr[(size_t)a];
+                std::copy(keys.begin(), keys.end(), u);
+                std::sort(u, u + keys.size());
+                const int64_t cnt = std::unique(u, u + keys.size()) - u;
+                nu[(size_t)a] = cnt;
+                int64_t ni = 0;
+                while (ni < cnt && u[ni] < SEP) ni++;
+                n_int[a] = ni;
+                int64_t *l = loc + rd_ptr[(size_t)a];
+                for (size_t t = 0; t < keys.size(); t++) l[t] = std::lower_bound(u, u + cnt, keys[t]) - u;
+            }
+        });
+        ae_dof_ptr[0] = 0;
+        for (int64_t a = 0; a < nAE; a++) ae_dof_ptr[a + 1] = ae_dof_ptr[a] + nu[(size_t)a];
+        parallel_ranges(nAE, [&](int64_t b, int64_t e) {
+            for (int64_t a = b; a < e; a++) {
+                const int64_t *u = tmp.data() + rd_ptr[(size_t)a];
+                int64_t *o = ae_dofs + ae_dof_ptr[a];
+                for (int64_t t = 0; t < nu[(size_t)a]; t++) o[t] = u[t] & ~SEP;
+            }
+        });
+    });
+}
+
+// Coarse trace columns on the boundary of every agglomerate and the traces restricted to its boundary dofs.  The coarse
+// element-facet table (B_ptr, B_idx) lists the agglomerated facets F of agglomerate a in column order; F carries the coarse dofs
+// cf_ptr[F] .. cf_ptr[F+1].  cb_ptr (nAE+1) / cb (their concatenation) are written; R_b gets, for every agglomerate, the column-major
+// (nb x next) block of trace values on its boundary dofs (positions n_int .. of its dof list): the value of coarse column c of
+// facet F at fine dof d sits in the facet kernel's packed output p_loc at  af_d_ptr[F] * k + c * (dofs of F) + pos_in_af[d].
+// Rb_ptr (nAE+1) is written too; cb must have room for cb_ptr[nAE] entries and R_b for Rb_ptr[nAE] (call with cb == NULL to get the sizes).
+ELAG_HIP_API int elag_hip_host_amge_boundary_traces(int64_t nAE, const int64_t *B_ptr, const int64_t *B_idx, const int64_t *cf_ptr, const int64_t *af_of_dof,
+                                                    const int64_t *pos_in_af, const int64_t *af_d_ptr, int64_t k, const double *p_loc,
+                                                    const int64_t *ae_dof_ptr, const int64_t *ae_dofs, const int64_t *n_int, int64_t *cb_ptr, int64_t *Rb_ptr,
+                                                    int64_t *cb, double *R_b)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(nAE >= 0 && B_ptr && B_idx && cf_ptr && ae_dof_ptr && n_int && cb_ptr && Rb_ptr, "boundary_traces: null argument");
+        cb_ptr[0] = 0; Rb_ptr[0] = 0;
+        for (int64_t a = 0; a < nAE; a++) {
+            int64_t nx = 0;
+            for (int64_t q = B_ptr[a]; q < B_ptr[a + 1]; q++) nx += cf_ptr[B_idx[q] + 1] - cf_ptr[B_idx[q]];
+            cb_ptr[a + 1] = cb_ptr[a] + nx;
+            const int64_t nb = (ae_dof_ptr[a + 1] - ae_dof_ptr[a]) - n_int[a];
+            Rb_ptr[a + 1] = Rb_ptr[a] + nb * nx;
+        }
+        if (!cb) return;
+        ELAG_REQUIRE(R_b && af_of_dof && pos_in_af && af_d_ptr && p_loc && ae_dofs, "boundary_traces: null argument");
+        parallel_ranges(nAE, [&](int64_t b, int64_t e) {
+            for (int64_t a = b; a < e; a++) {
+                const int64_t nb = (ae_dof_ptr[a + 1] - ae_dof_ptr[a]) - n_int[a];
+                const int64_t *bd = ae_dofs + ae_dof_ptr[a] + n_int[a];
+                double *R = R_b + Rb_ptr[a];
+                std::fill(R, R + (Rb_ptr[a + 1] - Rb_ptr[a]), 0.0);
+                int64_t j = 0;
+                for (int64_t q = B_ptr[a]; q < B_ptr[a + 1]; q++) {
+                    const int64_t F = B_idx[q], nF = af_d_ptr[F + 1] - af_d_ptr[F];
+                    for (int64_t c = 0; c < cf_ptr[F + 1] - cf_ptr[F]; c++, j++) {
+                        cb[cb_ptr[a] + j] = cf_ptr[F] + c;
+                        for (int64_t t = 0; t < nb; t++) {
+                            const int64_t d = bd[t];
+                            if (af_of_dof[d] == F) R[j * nb + t] = p_loc[af_d_ptr[F] * k + c * nF + pos_in_af[d]];
+                        }
+                    }
+                }
+            }
+        });
+    });
+}
+
+// Local triplets of a derivative on the agglomerates (DistributeAgglomerateMatrix): rows = the dofs of the range form of agglomerate a
+// (row_ptr / row_dofs, local row = position in that list), columns = positions in the agglomerate's dof list of the domain form
+// (ae_dof_ptr / ae_dofs / n_int as produced above: two ascending runs).  D is CSR with 32-bit arrays (scipy).  d_ptr (nAE+1) is always
+// written; with d_row != NULL also the triplets, rows in order, entries in D's storage order.  A column outside the agglomerate is an error.
+ELAG_HIP_API int elag_hip_host_amge_local_derivative(int64_t nAE, const int64_t *row_ptr, const int64_t *row_dofs, const int32_t *D_indptr,
+                                                     const int32_t *D_indices, const double *D_data, const int64_t *ae_dof_ptr, const int64_t *ae_dofs,
+                                                     const int64_t *n_int, int64_t *d_ptr, int32_t *d_row, int32_t *d_col, double *d_val)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(nAE >= 0 && row_ptr && row_dofs && D_indptr && D_indices && ae_dof_ptr && ae_dofs && n_int && d_ptr, "local_derivative: null argument");
+        d_ptr[0] = 0;
+        for (int64_t a = 0; a < nAE; a++) {
+            int64_t s = 0;
+            for (int64_t r = row_ptr[a]; r < row_ptr[a + 1]; r++) s += D_indptr[row_dofs[r] + 1] - D_indptr[row_dofs[r]];
+            d_ptr[a + 1] = d_ptr[a] + s;
+        }
+        if (!d_row) return;
+        ELAG_REQUIRE(d_col && d_val && D_data, "local_derivative: null argument");
+        parallel_ranges(nAE, [&](int64_t b, int64_t e) {
+            for (int64_t a = b; a < e; a++) {
+                const int64_t *u = ae_dofs + ae_dof_ptr[a];
+                const int64_t nu = ae_dof_ptr[a + 1] - ae_dof_ptr[a], ni = n_int[a];
+                int64_t w = d_ptr[a];
+                for (int64_t r = row_ptr[a]; r < row_ptr[a + 1]; r++) {
+                    const int64_t rd = row_dofs[r];
+                    for (int32_t q = D_indptr[rd]; q < D_indptr[rd + 1]; q++, w++) {
+                        const int64_t c = D_indices[q];
+                        const int64_t *p = std::lower_bound(u, u + ni, c);
+                        if (p == u + ni || *p != c) {
+                            p = std::lower_bound(u + ni, u + nu, c);
+                            if (p == u + nu || *p != c) throw Oops("DistributeAgglomerateMatrix: D_2 couples an agglomerate with a dof outside it");
+                        }
+                        d_row[w] = (int32_t)(r - row_ptr[a]);
+                        d_col[w] = (int32_t)(p - u);
+                        d_val[w] = D_data[q];
+                    }
+                }
+            }
+        });
+    });
+}
+
+}  // extern "C"

@@ -153,3 +153,63 @@ def test_minimal_intersection_sets_against_the_matrix_form():
     _lib.check(lib.elag_hip_host_minimal_intersection_sets(2, amge._ptr(fp), amge._ptr(fi), amge._ptr(fs), 3, None, amge._ptr(mis), amge._ptr(ori), amge._ptr(n)))
     assert mis.tolist() == [0, -1, 1] and ori.tolist() == [1.0, 0.0, 1.0] and n[0] == 2
     assert lib.elag_hip_host_minimal_intersection_sets(2, amge._ptr(fp), amge._ptr(np.array([0, 2, 5])), amge._ptr(fs), 3, None, amge._ptr(mis), amge._ptr(ori), amge._ptr(n)) != 0
+
+
+def _agglomerate_table_inputs(n, boxes, seed):
+    """The arguments ``amge.coarsen`` hands to its table stage on a hex grid, with made-up facet-stage outputs (a random number
+    of coarse traces per agglomerated facet, random trace values): no device work."""
+    from parelag_amd import amge_level
+    from parelag_amd.amge import expand_ranges
+    rng = np.random.default_rng(seed)
+    lv = amge_level.level_from_hex(n)
+    ijk = np.stack(np.unravel_index(np.arange(lv.nE), n[::-1]), axis=1)[:, ::-1]
+    cell = [np.minimum(ijk[:, d] * boxes[d] // n[d], boxes[d] - 1) for d in range(3)]
+    part = (cell[2] * boxes[1] + cell[1]) * boxes[0] + cell[0]
+    topo = amge.coarsen_topology(lv, part)
+    nAE, nAF = topo["nAE"], topo["nAF"]
+    els = topo["ae_idx"]
+    n3e = np.diff(lv.e_dof3_ptr)
+    ae_dofs3, _ = expand_ranges(lv.e_dof3_ptr[els], n3e[els])
+    ae_d3_ptr = ptr_from_counts(np.bincount(np.asarray(part)[els], weights=n3e[els], minlength=nAE).astype(np.int64))
+    n2f = np.diff(lv.f_dof2_ptr); fac = topo["af_idx"]
+    af_of_item = np.repeat(np.arange(nAF, dtype=np.int64), np.diff(topo["af_ptr"]))
+    af_dofs, ownf = expand_ranges(lv.f_dof2_ptr[fac], n2f[fac])
+    af_d_ptr = ptr_from_counts(np.bincount(af_of_item, weights=n2f[fac], minlength=nAF).astype(np.int64))
+    locf = np.arange(af_dofs.size, dtype=np.int64) - af_d_ptr[af_of_item[ownf]]
+    k2 = 3
+    cf_ptr = ptr_from_counts(rng.integers(1, k2 + 1, nAF))
+    o_pf = rng.standard_normal(af_dofs.size * k2)
+    e2_ptr, e2_idx = lv.elem_dof2_table()
+    return (lv.ndof2, nAE, nAF, topo["ae_ptr"], els, e2_ptr, e2_idx, af_dofs, af_of_item[ownf], locf, af_d_ptr, topo["B_ptr"], topo["B_idx"], cf_ptr, k2,
+            o_pf, ae_d3_ptr, ae_dofs3, lv.D2.tocsr())
+
+
+@pytest.mark.parametrize("n,boxes", [((6, 4, 4), (3, 2, 2)), ((5, 5, 3), (2, 2, 1)), ((4, 4, 4), (1, 1, 1)), ((4, 2, 2), (4, 2, 2))])
+def test_agglomerate_tables_match_the_whole_array_statement(n, boxes):
+    """Threaded per-agglomerate tables (``csrc/host_amge_tables.hip``) == the numpy composition, array by array and dtype by dtype:
+    dofs of the agglomerates (interior first), local indices, boundary columns, restricted traces, local ``D`` triplets.  The last two
+    cases are one agglomerate (no interior facets on its boundary but the domain's) and one element per agglomerate (no interior dofs)."""
+    args = _agglomerate_table_inputs(n, boxes, seed=sum(n))
+    got, ref = amge._agglomerate_tables(*args), amge._agglomerate_tables_numpy(*args)
+    assert got.keys() == ref.keys()
+    for k in ref:
+        assert got[k].dtype == ref[k].dtype and got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k]), k
+
+
+def test_agglomerate_tables_refuse_bad_input():
+    args = list(_agglomerate_table_inputs((4, 4, 2), (2, 2, 1), seed=1))
+    # D couples an agglomerate with a face outside it: an extra entry in the first row
+    D = args[-1].tolil(); ndof2 = args[0]
+    own = set(D.rows[0]); far = max(set(range(ndof2)) - own)
+    D[0, far] = 1.0
+    bad = args[:-1] + [D.tocsr()]
+    for tables in (amge._agglomerate_tables, amge._agglomerate_tables_numpy):
+        with pytest.raises(ValueError, match="outside it"):
+            tables(*bad)
+    bad = list(args); bad[6] = args[6].copy(); bad[6][0] = ndof2 + 5            # an element dof beyond the dof range
+    with pytest.raises(ValueError, match="outside the dof range"):
+        amge._agglomerate_tables(*bad)
+    lib = _lib.load()
+    assert lib.elag_hip_host_amge_dof_agglomeration(1, None, None, None, None, 0, None, None, None, None, None) != 0
+    assert lib.elag_hip_host_amge_boundary_traces(1, None, None, None, None, None, None, 1, None, None, None, None, None, None, None, None) != 0
+    assert lib.elag_hip_host_amge_local_derivative(1, None, None, None, None, None, None, None, None, None, None, None, None) != 0
