@@ -596,6 +596,15 @@ ELAG_HIP_API int elag_hip_host_amge_boundary_traces(int64_t nAE, const int64_t *
 ELAG_HIP_API int elag_hip_host_amge_local_derivative(int64_t nAE, const int64_t *row_ptr, const int64_t *row_dofs, const int32_t *D_indptr,
                                                      const int32_t *D_indices, const double *D_data, const int64_t *ae_dof_ptr, const int64_t *ae_dofs,
                                                      const int64_t *n_int, int64_t *d_ptr, int32_t *d_row, int32_t *d_col, double *d_val);
+/* Element-to-dof table of form 2 (facet dofs facet after facet, then the element's interior dofs; DofHandler::GetrDof order,
+ * src/amge/DofHandler.cpp:548-640).  ptr always written; idx == NULL: sizes only. */
+ELAG_HIP_API int elag_hip_host_amge_elem_dof_table(int64_t nE, const int64_t *ef_ptr, const int64_t *ef_idx, const int64_t *f_dof_ptr,
+                                                   const int64_t *e_idof_ptr, int64_t nfd, int64_t *ptr, int64_t *idx);
+/* elag_hip_host_blocks_to_coo straight to CSR with sorted 32-bit columns (exact zeros dropped, coinciding entries added in block order).
+ * indices == NULL: indptr (row counts before merging) only. */
+ELAG_HIP_API int elag_hip_host_blocks_to_csr(int64_t n_ent, const int64_t *rows_ptr, const int64_t *rows_idx, const int64_t *cols_ptr,
+                                             const int64_t *cols_idx, const double *vals, const int64_t *ld, const int64_t *slot_rows, int col_major,
+                                             int64_t nrow, int64_t ncol, int64_t *indptr, int32_t *indices, double *data, int64_t *out_nnz);
 
 /* --------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): run `reps` launches of one fine-level kernel on the compute stream

@@ -158,6 +158,8 @@ _SIGNATURES = {
     "elag_hip_host_amge_dof_agglomeration": [_i64, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p],
     "elag_hip_host_amge_boundary_traces": [_i64, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
     "elag_hip_host_amge_local_derivative": [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "elag_hip_host_amge_elem_dof_table": [_i64, _p, _p, _p, _p, _i64, _p, _p],
+    "elag_hip_host_blocks_to_csr": [_i64, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i64, _p, _p, _p, _p],
     "elag_hip_host_blocks_to_coo": [_i64, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "elag_hip_host_pack_cols": [_i64, _p, _p, _i64, _i64, _p, _p],
     "elag_hip_host_take_leading": [_i64, _p, _p, _p, _p],

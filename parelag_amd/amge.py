@@ -141,15 +141,20 @@ def _blocks_to_csr(rows_ptr, rows_idx, cols_ptr, cols_idx, vals, ld_cols, shape,
     nr, nc = np.diff(rows_ptr), np.diff(cols_ptr)
     if vals.size < int(((nr if sr is None else sr) * ld).sum()):
         raise ValueError("_blocks_to_csr: the value array is shorter than its slots")
-    cap = int((nr * nc).sum())
-    R, Cc, v = np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.int64), np.empty(cap)
+    Lh = _lib.load()
+    indptr = np.empty(shape[0] + 1, dtype=np.int64)
     nnz = np.zeros(1, dtype=np.int64)
-    _lib.check(_lib.load().elag_hip_host_blocks_to_coo(len(rows_ptr) - 1, _ptr(rows_ptr), _ptr(rows_idx), _ptr(cols_ptr), _ptr(cols_idx), _ptr(vals),
-                                                       _ptr(ld), None if sr is None else _ptr(sr), 1 if col_major else 0, _ptr(R), _ptr(Cc), _ptr(v),
-                                                       _ptr(nnz)))
+    args = (len(rows_ptr) - 1, _ptr(rows_ptr), _ptr(rows_idx), _ptr(cols_ptr), _ptr(cols_idx), _ptr(vals), _ptr(ld), None if sr is None else _ptr(sr),
+            1 if col_major else 0, int(shape[0]), int(shape[1]), _ptr(indptr))
+    _lib.check(Lh.elag_hip_host_blocks_to_csr(*args, None, None, None))
+    cap = int(indptr[-1])
+    if cap >= 2**31:
+        raise ValueError("_blocks_to_csr: more than 2^31 entries")
+    indices, data = np.empty(cap, dtype=np.int32), np.empty(cap)
+    _lib.check(Lh.elag_hip_host_blocks_to_csr(*args, _ptr(indices), _ptr(data), _ptr(nnz)))
     n = int(nnz[0])
-    M = sp.csr_matrix((v[:n], (R[:n], Cc[:n])), shape=shape)
-    M.sort_indices()
+    M = sp.csr_matrix((data[:n], indices[:n], indptr.astype(np.int32)), shape=shape)
+    M.has_sorted_indices = True
     return M
 
 
@@ -265,6 +270,25 @@ def _agglomerate_tables(ndof2, nAE, nAF, ae_ptr, els, e2_ptr, e2_idx, af_dofs, a
                 d_val=d_val)
 
 
+def _blocks_to_csr_sets(sets, shape):
+    """One matrix from several families of col-major dense blocks ``(rows_ptr, rows_idx, cols_ptr, cols_idx, vals, ld_cols)`` (see
+    :func:`_blocks_to_csr`): the families' entity lists are put one after the other, so entries that meet are added family by family."""
+    rp, ri, cp, ci, vv, ld = [], [], [], [], [], []
+    ro = co = 0
+    for rows_ptr, rows_idx, cols_ptr, cols_idx, vals, ld_cols in sets:
+        rows_ptr, cols_ptr = np.asarray(rows_ptr, dtype=np.int64), np.asarray(cols_ptr, dtype=np.int64)
+        n = len(rows_ptr) - 1
+        l = np.broadcast_to(np.asarray(ld_cols, dtype=np.int64), (n,))
+        need = int((np.diff(rows_ptr) * l).sum())
+        if np.asarray(vals).size < need:
+            raise ValueError("_blocks_to_csr: the value array is shorter than its slots")
+        rp.append(rows_ptr[(1 if rp else 0):] + ro); cp.append(cols_ptr[(1 if cp else 0):] + co)
+        ri.append(rows_idx); ci.append(cols_idx); vv.append(np.asarray(vals)[:need]); ld.append(l)
+        ro += int(rows_ptr[-1]); co += int(cols_ptr[-1])
+    cat = np.concatenate
+    return _blocks_to_csr(cat(rp), cat(ri), cat(cp), cat(ci), cat(vv), cat(ld), shape, col_major=True)
+
+
 # ---- Coarsen ----------------------------------------------------------------------------------------------------------------
 
 def coarsen(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entry: float = EPS, timings: dict | None = None) -> dict:
@@ -371,17 +395,17 @@ def coarsen(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_ent
     int_dofs, own_i = expand_ranges(ae_d2_ptr[:-1], ni)
     int_dofs = ae_dofs2[int_dofs]                                   # interior fine dofs, agglomerate by agglomerate
     ci_idx = ntrace + np.arange(int(ci_ptr[-1]), dtype=np.int64)
-    P_tr = _blocks_to_csr(af_d_ptr, af_dofs, cf_ptr, cf_idx, o_pf, np.full(nAF, k2), (lv.ndof2, ndof2c), col_major=True)
-    P_ext = _blocks_to_csr(int_ptr, int_dofs, cbd_ptr, cbd, o_ext, nxt, (lv.ndof2, ndof2c), col_major=True)
-    # bubbles: [RangeT | null] columns
-    bub = _join_cols(o_rt, ni, nrt, o_nul, nT2, n_null)
-    P_bub = _blocks_to_csr(int_ptr, int_dofs, ci_ptr, ci_idx, bub, nint_c, (lv.ndof2, ndof2c), col_major=True)
-    P2 = (P_tr + P_ext + P_bub).tocsr()
-    P2.sort_indices()
-    # coarse D_2: row of the PV dof of the agglomerate, unit entries for the RangeT bubbles (:2408, :2441)
-    dsel = o_dc != 0.0
+    # P_2 = [traces on the agglomerated facets | extensions into the interiors | bubbles: RangeT columns, null-space columns]: four families of
+    # dense blocks with disjoint (row, column) sets, assembled in one pass
     rt_rows, own_rt = expand_ranges(c3_ptr[:-1] + 1, nrt)
     rt_cols, _ = expand_ranges(ntrace + ci_ptr[:-1], nrt)
+    nul_cols, _ = expand_ranges(ntrace + ci_ptr[:-1] + nrt, n_null)
+    P2 = _blocks_to_csr_sets([(af_d_ptr, af_dofs, cf_ptr, cf_idx, o_pf, np.full(nAF, k2)),
+                              (int_ptr, int_dofs, cbd_ptr, cbd, o_ext, nxt),
+                              (int_ptr, int_dofs, ptr_from_counts(nrt), rt_cols, o_rt, nrt),
+                              (int_ptr, int_dofs, ptr_from_counts(n_null), nul_cols, o_nul, np.full(nAE, nT2))], (lv.ndof2, ndof2c))
+    # coarse D_2: row of the PV dof of the agglomerate, unit entries for the RangeT bubbles (:2408, :2441)
+    dsel = o_dc != 0.0
     rows = np.r_[np.repeat(c3_ptr[:-1], nxt)[dsel], rt_rows]
     cols = np.r_[cbd[dsel], rt_cols]
     D2c = sp.csr_matrix((np.r_[o_dc[dsel], np.ones(rt_rows.size)], (rows, cols)), shape=(ndof3c, ndof2c))

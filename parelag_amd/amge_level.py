@@ -82,7 +82,20 @@ class AmgeLevel:
         return np.concatenate(parts) if parts else np.zeros(0, np.int64)
 
     def elem_dof2_table(self):
-        """(ptr, idx) of ``elem_dof2`` for all elements (vectorised)."""
+        """(ptr, idx) of ``elem_dof2`` for all elements (threaded host code, ``csrc/host_amge_tables.hip``)."""
+        from . import _lib
+        L = _lib.load()
+        c64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+        ef_ptr, ef_idx, fp, ip = c64(self.ef_ptr), c64(self.ef_idx), c64(self.f_dof2_ptr), c64(self.e_idof2_ptr)
+        vp = lambda a: a.ctypes.data_as(_lib.C.c_void_p)
+        ptr = np.empty(self.nE + 1, dtype=np.int64)
+        _lib.check(L.elag_hip_host_amge_elem_dof_table(self.nE, vp(ef_ptr), vp(ef_idx), vp(fp), vp(ip), int(self.nfd2), vp(ptr), None))
+        idx = np.empty(int(ptr[-1]), dtype=np.int64)
+        _lib.check(L.elag_hip_host_amge_elem_dof_table(self.nE, vp(ef_ptr), vp(ef_idx), vp(fp), vp(ip), int(self.nfd2), vp(ptr), vp(idx)))
+        return ptr, idx
+
+    def elem_dof2_table_numpy(self):
+        """Whole-array statement of :meth:`elem_dof2_table` (the tests compare the two)."""
         nfac = np.diff(self.f_dof2_ptr)
         cnt_f = np.add.reduceat(nfac[self.ef_idx], self.ef_ptr[:-1]) if self.ef_idx.size else np.zeros(self.nE, np.int64)
         cnt_f = np.where(np.diff(self.ef_ptr) > 0, cnt_f, 0)

@@ -203,3 +203,142 @@ ELAG_HIP_API int elag_hip_host_amge_local_derivative(int64_t nAE, const int64_t 
 }
 
 }  // extern "C"
+
+extern "C" {
+
+// Element-to-dof table of form 2 on a level: element e carries the dofs of its facets (ef_ptr / ef_idx rows, facet f = dofs
+// f_dof_ptr[f] .. f_dof_ptr[f+1]), facet after facet, then its own interior dofs nfd + e_idof_ptr[e] .. (DofHandler::GetrDof order of
+// src/amge/DofHandler.cpp:548-640 for codimension 0).  ptr (nE+1) is always written; idx when it is not NULL (room for ptr[nE]).
+ELAG_HIP_API int elag_hip_host_amge_elem_dof_table(int64_t nE, const int64_t *ef_ptr, const int64_t *ef_idx, const int64_t *f_dof_ptr,
+                                                   const int64_t *e_idof_ptr, int64_t nfd, int64_t *ptr, int64_t *idx)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(nE >= 0 && ef_ptr && f_dof_ptr && e_idof_ptr && ptr && (ef_idx || ef_ptr[nE] == 0), "elem_dof_table: null argument");
+        if (!idx) {
+            ptr[0] = 0;
+            for (int64_t e = 0; e < nE; e++) {
+                int64_t s = e_idof_ptr[e + 1] - e_idof_ptr[e];
+                for (int64_t q = ef_ptr[e]; q < ef_ptr[e + 1]; q++) s += f_dof_ptr[ef_idx[q] + 1] - f_dof_ptr[ef_idx[q]];
+                ptr[e + 1] = ptr[e] + s;
+            }
+            return;
+        }
+        parallel_ranges(nE, [&](int64_t b, int64_t e_end) {
+            for (int64_t e = b; e < e_end; e++) {
+                int64_t w = ptr[e];
+                for (int64_t q = ef_ptr[e]; q < ef_ptr[e + 1]; q++)
+                    for (int64_t d = f_dof_ptr[ef_idx[q]]; d < f_dof_ptr[ef_idx[q] + 1]; d++) idx[w++] = d;
+                for (int64_t d = e_idof_ptr[e]; d < e_idof_ptr[e + 1]; d++) idx[w++] = nfd + d;
+            }
+        });
+    });
+}
+
+// Sparse matrix whose entity blocks are dense (mfem's SetSubMatrix over all entities, exact zeros dropped), straight to CSR with sorted
+// 32-bit columns: block e couples rows rows_idx[rows_ptr[e]..) with columns cols_idx[cols_ptr[e]..); its values are the next
+// (slot_rows ? slot_rows[e] : nrows_e) * ld[e] entries of vals (col_major: entry (r,c) at c*nrows_e + r; else at r*ld[e] + c).
+// Entries that meet in one (row, column) are added in block order.  indptr (nrow+1) is always written; indices / data when not NULL
+// (room for indptr[nrow] before duplicates merge; *out_nnz = entries kept, and indptr is rewritten if duplicates merged).
+ELAG_HIP_API int elag_hip_host_blocks_to_csr(int64_t n_ent, const int64_t *rows_ptr, const int64_t *rows_idx, const int64_t *cols_ptr,
+                                             const int64_t *cols_idx, const double *vals, const int64_t *ld, const int64_t *slot_rows, int col_major,
+                                             int64_t nrow, int64_t ncol, int64_t *indptr, int32_t *indices, double *data, int64_t *out_nnz)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(n_ent >= 0 && rows_ptr && cols_ptr && ld && indptr && nrow >= 0 && ncol >= 0 && ncol < (int64_t(1) << 31), "blocks_to_csr: bad argument");
+        // slot offset of every block
+        std::vector<int64_t> slot((size_t)n_ent + 1, 0);
+        for (int64_t e = 0; e < n_ent; e++) {
+            const int64_t nr = rows_ptr[e + 1] - rows_ptr[e], nc = cols_ptr[e + 1] - cols_ptr[e];
+            ELAG_REQUIRE(nr >= 0 && nc >= 0 && ld[e] >= nc, "blocks_to_csr: block %lld does not fit its slot", (long long)e);
+            slot[(size_t)e + 1] = slot[(size_t)e] + (slot_rows ? slot_rows[e] : nr) * ld[e];
+        }
+        auto at = [&](int64_t e, int64_t nr, int64_t r, int64_t c) { return vals[slot[(size_t)e] + (col_major ? c * nr + r : r * ld[e] + c)]; };
+        if (!indices) {
+            std::fill(indptr, indptr + nrow + 1, (int64_t)0);
+            parallel_ranges(n_ent, [&](int64_t b, int64_t e_end) {
+                for (int64_t e = b; e < e_end; e++) {
+                    const int64_t nr = rows_ptr[e + 1] - rows_ptr[e], nc = cols_ptr[e + 1] - cols_ptr[e];
+                    const int64_t *R = rows_idx + rows_ptr[e];
+                    for (int64_t r = 0; r < nr; r++) {
+                        if (R[r] < 0 || R[r] >= nrow) throw Oops("blocks_to_csr: a row index is outside the matrix");
+                        int64_t n = 0;
+                        for (int64_t c = 0; c < nc; c++) n += at(e, nr, r, c) != 0.0;
+                        if (n) __atomic_fetch_add(&indptr[R[r] + 1], n, __ATOMIC_RELAXED);
+                    }
+                }
+            });
+            for (int64_t i = 0; i < nrow; i++) indptr[i + 1] += indptr[i];
+            return;
+        }
+        ELAG_REQUIRE(data && out_nnz, "blocks_to_csr: null argument");
+        std::vector<int64_t> cur;
+        // a row's entries land in whatever order the threads reach it and are sorted by column afterwards; only when two blocks set the
+        // same (row, column) does the order matter (the sum), and then the fill is repeated on one thread, in block order
+        auto fill = [&](int64_t b, int64_t e_end, bool shared) {
+            for (int64_t e = b; e < e_end; e++) {
+                const int64_t nr = rows_ptr[e + 1] - rows_ptr[e], nc = cols_ptr[e + 1] - cols_ptr[e];
+                const int64_t *R = rows_idx + rows_ptr[e], *Cc = cols_idx + cols_ptr[e];
+                for (int64_t r = 0; r < nr; r++) {
+                    int64_t n = 0;
+                    for (int64_t c = 0; c < nc; c++) n += at(e, nr, r, c) != 0.0;
+                    if (!n) continue;
+                    int64_t w = shared ? __atomic_fetch_add(&cur[(size_t)R[r]], n, __ATOMIC_RELAXED) : cur[(size_t)R[r]];
+                    if (!shared) cur[(size_t)R[r]] += n;
+                    for (int64_t c = 0; c < nc; c++) {
+                        const double x = at(e, nr, r, c);
+                        if (x != 0.0) {
+                            if (Cc[c] < 0 || Cc[c] >= ncol) throw Oops("blocks_to_csr: a column index is outside the matrix");
+                            indices[w] = (int32_t)Cc[c]; data[w] = x; w++;
+                        }
+                    }
+                }
+            }
+        };
+        std::atomic<int> dup{0};
+        auto sort_rows = [&] {
+            parallel_ranges(nrow, [&](int64_t b, int64_t e_end) {
+                std::vector<std::pair<int32_t, double>> tmp;
+                for (int64_t i = b; i < e_end; i++) {
+                    const int64_t lo = indptr[i], n = indptr[i + 1] - lo;
+                    bool sorted = true;
+                    for (int64_t t = 1; t < n; t++)
+                        if (indices[lo + t] <= indices[lo + t - 1]) { sorted = false; break; }
+                    if (sorted) continue;
+                    tmp.resize((size_t)n);
+                    for (int64_t t = 0; t < n; t++) tmp[(size_t)t] = {indices[lo + t], data[lo + t]};
+                    std::stable_sort(tmp.begin(), tmp.end(),
+                                     [](const std::pair<int32_t, double> &x, const std::pair<int32_t, double> &y) { return x.first < y.first; });
+                    for (int64_t t = 0; t < n; t++) {
+                        indices[lo + t] = tmp[(size_t)t].first; data[lo + t] = tmp[(size_t)t].second;
+                        if (t && tmp[(size_t)t].first == tmp[(size_t)t - 1].first) dup.store(1, std::memory_order_relaxed);
+                    }
+                }
+            });
+        };
+        cur.assign(indptr, indptr + nrow);
+        parallel_ranges(n_ent, [&](int64_t b, int64_t e_end) { fill(b, e_end, true); });
+        sort_rows();
+        if (dup.load()) {
+            cur.assign(indptr, indptr + nrow);
+            fill(0, n_ent, false);
+            sort_rows();
+        }
+        int64_t nnz = indptr[nrow];
+        if (dup.load()) {
+            int64_t w = 0, lo = 0;
+            for (int64_t i = 0; i < nrow; i++) {
+                const int64_t hi = indptr[i + 1];
+                for (int64_t t = lo; t < hi; t++) {
+                    if (t > lo && indices[t] == indices[w - 1]) data[w - 1] += data[t];
+                    else { indices[w] = indices[t]; data[w] = data[t]; w++; }
+                }
+                lo = hi;
+                indptr[i + 1] = w;
+            }
+            nnz = w;
+        }
+        *out_nnz = nnz;
+    });
+}
+
+}  // extern "C"

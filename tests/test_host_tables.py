@@ -213,3 +213,63 @@ def test_agglomerate_tables_refuse_bad_input():
     assert lib.elag_hip_host_amge_dof_agglomeration(1, None, None, None, None, 0, None, None, None, None, None) != 0
     assert lib.elag_hip_host_amge_boundary_traces(1, None, None, None, None, None, None, 1, None, None, None, None, None, None, None, None) != 0
     assert lib.elag_hip_host_amge_local_derivative(1, None, None, None, None, None, None, None, None, None, None, None, None) != 0
+
+
+def test_elem_dof_table_and_direct_csr_assembly():
+    from parelag_amd import amge_level
+    lv = amge_level.level_from_hex((5, 4, 3))
+    lv.e_idof2_ptr = ptr_from_counts(np.arange(lv.nE) % 3)                         # pretend interior dofs, ragged
+    for got, ref in zip(lv.elem_dof2_table(), lv.elem_dof2_table_numpy()):
+        assert got.dtype == ref.dtype and np.array_equal(got, ref)
+    # blocks -> CSR: overlapping blocks (entries that meet are added), exact zeros dropped, both storage orders, padded slots
+    rng = np.random.default_rng(3)
+    for col_major in (True, False):
+        n_ent, nrow, ncol = 30, 40, 25
+        rp, ri = ragged(rng, n_ent, nrow, 5); cp, ci = ragged(rng, n_ent, ncol, 4)
+        nr, nc = np.diff(rp), np.diff(cp)
+        ld = nc + rng.integers(0, 3, n_ent)
+        sr = nr + rng.integers(0, 2, n_ent)
+        slots = ptr_from_counts(sr * ld)
+        vals = rng.integers(-2, 3, slots[-1]).astype(np.float64)                   # small integers: sums are exact whatever the order
+        M = amge._blocks_to_csr(rp, ri, cp, ci, vals, ld, (nrow, ncol), col_major=col_major, slot_rows=sr)
+        ref = np.zeros((nrow, ncol)); touched = np.zeros((nrow, ncol), dtype=bool)
+        for e in range(n_ent):
+            v = vals[slots[e]:slots[e + 1]]
+            for r in range(nr[e]):
+                for c in range(nc[e]):
+                    x = v[c * nr[e] + r] if col_major else v[r * ld[e] + c]
+                    if x != 0.0:
+                        ref[ri[rp[e] + r], ci[cp[e] + c]] += x; touched[ri[rp[e] + r], ci[cp[e] + c]] = True
+        assert M.has_sorted_indices and M.indices.dtype == np.int32
+        assert np.array_equal(M.toarray(), ref)
+        assert M.nnz == int(touched.sum())                                           # stored pattern = entries some block set (a sum may be 0)
+        chk = M.copy(); chk.has_sorted_indices = False; chk.sort_indices()
+        assert np.array_equal(chk.indices, M.indices)
+    empty = amge._blocks_to_csr(np.zeros(1, np.int64), np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros(0, np.int64), np.zeros(0), np.zeros(0, np.int64),
+                                (3, 2), col_major=True)
+    assert empty.nnz == 0 and empty.shape == (3, 2)
+    with pytest.raises(ValueError, match="shorter than its slots"):
+        amge._blocks_to_csr(np.array([0, 2]), np.array([0, 1]), np.array([0, 2]), np.array([0, 1]), np.zeros(3), np.array([2]), (2, 2), col_major=True)
+    with pytest.raises(_lib.ElagHipError, match="outside the matrix"):
+        amge._blocks_to_csr(np.array([0, 1]), np.array([7]), np.array([0, 1]), np.array([0]), np.ones(1), np.array([1]), (2, 2), col_major=True)
+
+
+def test_direct_csr_assembly_is_deterministic_across_threads():
+    """Many overlapping blocks with non-integer values: entries that meet are added in block order whatever the thread schedule."""
+    rng = np.random.default_rng(11)
+    n_ent, nrow, ncol = 3000, 400, 300
+    rp, ri = ragged(rng, n_ent, nrow, 4); cp, ci = ragged(rng, n_ent, ncol, 3)
+    nr, nc = np.diff(rp), np.diff(cp)
+    slots = ptr_from_counts(nr * nc)
+    vals = rng.standard_normal(slots[-1])
+    ref = {}
+    for e in range(n_ent):
+        v = vals[slots[e]:slots[e + 1]]
+        for r in range(nr[e]):
+            for c in range(nc[e]):
+                k = (int(ri[rp[e] + r]), int(ci[cp[e] + c]))
+                ref[k] = ref[k] + v[r * nc[e] + c] if k in ref else v[r * nc[e] + c]
+    for _ in range(3):
+        M = amge._blocks_to_csr(rp, ri, cp, ci, vals, nc, (nrow, ncol), col_major=False).tocoo()
+        assert M.nnz == len(ref)
+        assert all(ref[(int(r), int(c))] == v for r, c, v in zip(M.row, M.col, M.data))
