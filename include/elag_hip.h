@@ -587,6 +587,13 @@ ELAG_HIP_API int elag_hip_host_expand_ranges(int64_t n, const int64_t *starts, c
  *  - boundary_traces: coarse trace columns on every agglomerate's boundary (cb_ptr/cb) and the col-major (nb x next) blocks of trace values on
  *    its boundary dofs (Rb_ptr/R_b) taken from the facet kernel's packed output p_loc; cb == NULL: sizes only.
  *  - local_derivative: triplets of D (32-bit CSR) localised to (range dofs, agglomerate dofs) of every agglomerate; d_row == NULL: d_ptr only. */
+/* Allocator policy for the host table stage (glibc mallopt): on != 0 keeps the pages of freed large arrays with the process (no mmap for
+ * large blocks, trim threshold 2 GiB) so that the stages do not fault their work arrays in again; on == 0 restores glibc's defaults.
+ * Process-wide; the Python host layer turns it on at the first coarsening unless ELAG_HIP_HOST_KEEP_PAGES=0. */
+ELAG_HIP_API int elag_hip_host_keep_pages(int on);
+/* Host threads the elag_hip_host_* table functions may use (n <= 0: the default = hardware threads, at most 16, or ELAG_HIP_HOST_THREADS);
+ * returns the count in force.  The tables do not depend on it. */
+ELAG_HIP_API int elag_hip_host_set_threads(int n);
 ELAG_HIP_API int elag_hip_host_amge_dof_agglomeration(int64_t nAE, const int64_t *ae_ptr, const int64_t *els, const int64_t *e_ptr, const int64_t *e_idx,
                                                       int64_t ndof, const int64_t *sep, int64_t *ae_dof_ptr, int64_t *n_int, int64_t *ae_dofs, int64_t *loc);
 ELAG_HIP_API int elag_hip_host_amge_boundary_traces(int64_t nAE, const int64_t *B_ptr, const int64_t *B_idx, const int64_t *cf_ptr, const int64_t *af_of_dof,
@@ -600,7 +607,22 @@ ELAG_HIP_API int elag_hip_host_amge_local_derivative(int64_t nAE, const int64_t 
  * src/amge/DofHandler.cpp:548-640).  ptr always written; idx == NULL: sizes only. */
 ELAG_HIP_API int elag_hip_host_amge_elem_dof_table(int64_t nE, const int64_t *ef_ptr, const int64_t *ef_idx, const int64_t *f_dof_ptr,
                                                    const int64_t *e_idof_ptr, int64_t nfd, int64_t *ptr, int64_t *idx);
-/* elag_hip_host_blocks_to_coo straight to CSR with sorted 32-bit columns (exact zeros dropped, coinciding entries added in block order).
+/* A family of dense blocks of a sparse matrix (mfem SetSubMatrix over all entities of one kind): block e couples rows
+ * rows_idx[rows_ptr[e]..) with columns cols_idx[cols_ptr[e]..); its values are the next (slot_rows ? slot_rows[e] : nrows_e) * ld[e]
+ * entries of vals (n_vals = length of vals; col_major: entry (r,c) at c*nrows_e + r, else at r*ld[e] + c). */
+typedef struct elag_hip_block_family {
+    int64_t n_ent;
+    const int64_t *rows_ptr, *rows_idx, *cols_ptr, *cols_idx;
+    const double *vals;
+    int64_t n_vals;
+    const int64_t *ld, *slot_rows;        /* slot_rows may be NULL */
+    int col_major;
+} elag_hip_block_family;
+/* All families into one CSR matrix with sorted 32-bit columns (exact zeros dropped; entries that meet are added family by family, block by
+ * block, whatever the thread count).  indices == NULL: indptr (row counts before merging) only. */
+ELAG_HIP_API int elag_hip_host_block_families_to_csr(int n_fam, const elag_hip_block_family *fam, int64_t nrow, int64_t ncol, int64_t *indptr,
+                                                     int32_t *indices, double *data, int64_t *out_nnz);
+/* One family given by its arrays (elag_hip_host_blocks_to_coo's arguments) straight to CSR (exact zeros dropped, coinciding entries added in block order).
  * indices == NULL: indptr (row counts before merging) only. */
 ELAG_HIP_API int elag_hip_host_blocks_to_csr(int64_t n_ent, const int64_t *rows_ptr, const int64_t *rows_idx, const int64_t *cols_ptr,
                                              const int64_t *cols_idx, const double *vals, const int64_t *ld, const int64_t *slot_rows, int col_major,

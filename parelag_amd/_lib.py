@@ -155,10 +155,13 @@ _SIGNATURES = {
     "elag_hip_host_lookup_find": [_i64, _p, _p, _i64, _i64, _p, _p, _p],
     "elag_hip_host_gather_dense": [_i64, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p],
     "elag_hip_host_expand_ranges": [_i64, _p, _p, _i64, _p, _p],
+    "elag_hip_host_set_threads": [_i],
+    "elag_hip_host_keep_pages": [_i],
     "elag_hip_host_amge_dof_agglomeration": [_i64, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p],
     "elag_hip_host_amge_boundary_traces": [_i64, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
     "elag_hip_host_amge_local_derivative": [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "elag_hip_host_amge_elem_dof_table": [_i64, _p, _p, _p, _p, _i64, _p, _p],
+    "elag_hip_host_block_families_to_csr": [_i, _p, _i64, _i64, _p, _p, _p, _p],
     "elag_hip_host_blocks_to_csr": [_i64, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i64, _p, _p, _p, _p],
     "elag_hip_host_blocks_to_coo": [_i64, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "elag_hip_host_pack_cols": [_i64, _p, _p, _i64, _i64, _p, _p],
@@ -224,3 +227,17 @@ def device_name() -> str:
     buf = C.create_string_buffer(256)
     check(init().elag_hip_device_name(buf, 256))
     return buf.value.decode()
+
+
+_kept_pages = False
+
+
+def keep_host_pages():
+    """Once per process: keep the pages of freed large host arrays (``elag_hip_host_keep_pages``) -- the coarsening's table stage allocates
+    and frees arrays of hundreds of MB per level and otherwise faults them in again every time.  ``ELAG_HIP_HOST_KEEP_PAGES=0`` leaves
+    glibc's defaults alone."""
+    global _kept_pages
+    if not _kept_pages:
+        _kept_pages = True
+        if os.environ.get("ELAG_HIP_HOST_KEEP_PAGES", "1") != "0":
+            check(load().elag_hip_host_keep_pages(1))

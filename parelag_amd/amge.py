@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 
 import numpy as np
 import scipy.sparse as sp
@@ -132,30 +133,17 @@ def _blocks_to_csr(rows_ptr, rows_idx, cols_ptr, cols_idx, vals, ld_cols, shape,
     """Sparse matrix whose entity blocks are dense: block e couples rows ``rows_idx[rows_ptr[e]:..]`` with columns
     ``cols_idx[cols_ptr[e]:..]``; its values are stored in ``vals`` as consecutive slots of ``nrows_e * ld_cols[e]``
     entries (col-major: column c at ``c * nrows_e``; row-major: row r at ``r * ld``...).  Exact zeros are dropped like
-    mfem's ``SetSubMatrix``."""
-    c64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
-    rows_ptr, rows_idx, cols_ptr, cols_idx = c64(rows_ptr), c64(rows_idx), c64(cols_ptr), c64(cols_idx)
-    ld = c64(np.broadcast_to(ld_cols, (len(rows_ptr) - 1,)))
-    sr = None if slot_rows is None else c64(np.broadcast_to(slot_rows, (len(rows_ptr) - 1,)))
+    mfem's ``SetSubMatrix``; straight to CSR with sorted columns in threaded host code (``csrc/host_amge_tables.hip``)."""
+    keep = _Keep()
+    n = len(rows_ptr) - 1
     vals = np.ascontiguousarray(vals, dtype=np.float64)
-    nr, nc = np.diff(rows_ptr), np.diff(cols_ptr)
-    if vals.size < int(((nr if sr is None else sr) * ld).sum()):
-        raise ValueError("_blocks_to_csr: the value array is shorter than its slots")
-    Lh = _lib.load()
-    indptr = np.empty(shape[0] + 1, dtype=np.int64)
-    nnz = np.zeros(1, dtype=np.int64)
-    args = (len(rows_ptr) - 1, _ptr(rows_ptr), _ptr(rows_idx), _ptr(cols_ptr), _ptr(cols_idx), _ptr(vals), _ptr(ld), None if sr is None else _ptr(sr),
-            1 if col_major else 0, int(shape[0]), int(shape[1]), _ptr(indptr))
-    _lib.check(Lh.elag_hip_host_blocks_to_csr(*args, None, None, None))
-    cap = int(indptr[-1])
-    if cap >= 2**31:
-        raise ValueError("_blocks_to_csr: more than 2^31 entries")
-    indices, data = np.empty(cap, dtype=np.int32), np.empty(cap)
-    _lib.check(Lh.elag_hip_host_blocks_to_csr(*args, _ptr(indices), _ptr(data), _ptr(nnz)))
-    n = int(nnz[0])
-    M = sp.csr_matrix((data[:n], indices[:n], indptr.astype(np.int32)), shape=shape)
-    M.has_sorted_indices = True
-    return M
+    fam = (_BlockFamily * 1)()
+    f = fam[0]
+    f.n_ent, f.n_vals, f.col_major = n, vals.size, 1 if col_major else 0
+    f.rows_ptr, f.rows_idx, f.cols_ptr, f.cols_idx = keep.i64(rows_ptr), keep.i64(rows_idx), keep.i64(cols_ptr), keep.i64(cols_idx)
+    f.vals, f.ld = _ptr(vals), keep.i64(np.broadcast_to(ld_cols, (n,)))
+    f.slot_rows = None if slot_rows is None else keep.i64(np.broadcast_to(slot_rows, (n,)))
+    return _families_to_csr(fam, shape)
 
 
 def _agglomerate_tables_numpy(ndof2, nAE, nAF, ae_ptr, els, e2_ptr, e2_idx, af_dofs, af_of_afdof, locf, af_d_ptr, B_ptr, AFs, cf_ptr, k2, o_pf,
@@ -270,23 +258,47 @@ def _agglomerate_tables(ndof2, nAE, nAF, ae_ptr, els, e2_ptr, e2_idx, af_dofs, a
                 d_val=d_val)
 
 
+class _BlockFamily(C.Structure):
+    _fields_ = [("n_ent", C.c_int64), ("rows_ptr", C.c_void_p), ("rows_idx", C.c_void_p), ("cols_ptr", C.c_void_p), ("cols_idx", C.c_void_p),
+                ("vals", C.c_void_p), ("n_vals", C.c_int64), ("ld", C.c_void_p), ("slot_rows", C.c_void_p), ("col_major", C.c_int)]
+
+
 def _blocks_to_csr_sets(sets, shape):
     """One matrix from several families of col-major dense blocks ``(rows_ptr, rows_idx, cols_ptr, cols_idx, vals, ld_cols)`` (see
-    :func:`_blocks_to_csr`): the families' entity lists are put one after the other, so entries that meet are added family by family."""
-    rp, ri, cp, ci, vv, ld = [], [], [], [], [], []
-    ro = co = 0
-    for rows_ptr, rows_idx, cols_ptr, cols_idx, vals, ld_cols in sets:
-        rows_ptr, cols_ptr = np.asarray(rows_ptr, dtype=np.int64), np.asarray(cols_ptr, dtype=np.int64)
+    :func:`_blocks_to_csr`) in one pass (``elag_hip_host_block_families_to_csr``); entries that meet are added family by family."""
+    keep = _Keep()
+    fam = (_BlockFamily * len(sets))()
+    for f, (rows_ptr, rows_idx, cols_ptr, cols_idx, vals, ld_cols) in zip(fam, sets):
         n = len(rows_ptr) - 1
-        l = np.broadcast_to(np.asarray(ld_cols, dtype=np.int64), (n,))
-        need = int((np.diff(rows_ptr) * l).sum())
-        if np.asarray(vals).size < need:
-            raise ValueError("_blocks_to_csr: the value array is shorter than its slots")
-        rp.append(rows_ptr[(1 if rp else 0):] + ro); cp.append(cols_ptr[(1 if cp else 0):] + co)
-        ri.append(rows_idx); ci.append(cols_idx); vv.append(np.asarray(vals)[:need]); ld.append(l)
-        ro += int(rows_ptr[-1]); co += int(cols_ptr[-1])
-    cat = np.concatenate
-    return _blocks_to_csr(cat(rp), cat(ri), cat(cp), cat(ci), cat(vv), cat(ld), shape, col_major=True)
+        vals = np.ascontiguousarray(vals, dtype=np.float64); keep.refs.append(vals)
+        f.n_ent, f.n_vals, f.col_major, f.slot_rows = n, vals.size, 1, None
+        f.rows_ptr, f.rows_idx, f.cols_ptr, f.cols_idx = keep.i64(rows_ptr), keep.i64(rows_idx), keep.i64(cols_ptr), keep.i64(cols_idx)
+        f.vals, f.ld = _ptr(vals), keep.i64(np.broadcast_to(ld_cols, (n,)))
+    return _families_to_csr(fam, shape)
+
+
+def _families_to_csr(fam, shape):
+    Lh = _lib.load()
+
+    def chk(status):
+        try:
+            _lib.check(status)
+        except _lib.ElagHipError as e:
+            if "shorter than its slots" in str(e):
+                raise ValueError("_blocks_to_csr: the value array is shorter than its slots") from None
+            raise
+    indptr = np.empty(shape[0] + 1, dtype=np.int64)
+    nnz = np.zeros(1, dtype=np.int64)
+    chk(Lh.elag_hip_host_block_families_to_csr(len(fam), C.byref(fam), int(shape[0]), int(shape[1]), _ptr(indptr), None, None, None))
+    cap = int(indptr[-1])
+    if cap >= 2**31:
+        raise ValueError("_blocks_to_csr: more than 2^31 entries")
+    indices, data = np.empty(cap, dtype=np.int32), np.empty(cap)
+    chk(Lh.elag_hip_host_block_families_to_csr(len(fam), C.byref(fam), int(shape[0]), int(shape[1]), _ptr(indptr), _ptr(indices), _ptr(data), _ptr(nnz)))
+    n = int(nnz[0])
+    M = sp.csr_matrix((data[:n], indices[:n], indptr.astype(np.int32)), shape=shape)
+    M.has_sorted_indices = True
+    return M
 
 
 # ---- Coarsen ----------------------------------------------------------------------------------------------------------------
@@ -294,7 +306,15 @@ def _blocks_to_csr_sets(sets, shape):
 def coarsen(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entry: float = EPS, timings: dict | None = None) -> dict:
     """``DeRhamSequence::Coarsen`` for forms 2 and 3.  Returns dict(P2, P3, Pi2 parts, coarse (AmgeLevel), topo)."""
     L = _lib.init()
+    _lib.keep_host_pages()
+    t_mark = [time.perf_counter()]
+
+    def mark(name):                                             # host wall time of the stage that just ended (seconds)
+        if timings is not None:
+            now = time.perf_counter(); timings["host_" + name + "_s"] = now - t_mark[0]; t_mark[0] = now
+
     topo = coarsen_topology(lv, part)
+    mark("topology")
     nAE, nAF = topo["nAE"], topo["nAF"]
     nT2, nT3 = lv.T2.shape[1], lv.T3.shape[1]
     ae_of_elem = np.asarray(part, dtype=np.int64)
@@ -327,6 +347,7 @@ def coarsen(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_ent
                          slot_rows=np.full(nAE, k3))
     M3c_blocks = _take_leading(o_cm3, np.full(nAE, k3), n3c)
 
+    mark("form3")
     # ===== form 2 on the agglomerated facets =====
     n2f = np.diff(lv.f_dof2_ptr)
     fac = topo["af_idx"]
@@ -350,6 +371,7 @@ def coarsen(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_ent
     cf_idx = np.arange(ntrace, dtype=np.int64)
     M2fc_blocks = _take_leading(o_cmf, np.full(nAF, k2), ncf)
 
+    mark("facets2")
     # ===== DofAgglomeration of form 2 on the agglomerated elements (DOFAgglomeration.cpp:86-131), boundary traces, local D =====
     e2_ptr, e2_idx = lv.elem_dof2_table()
     n2e = np.diff(e2_ptr)
@@ -362,6 +384,7 @@ def coarsen(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_ent
     d_ptr, d_row, d_col, d_val = tb["d_ptr"], tb["d_row"], tb["d_col"], tb["d_val"]
     nu = np.diff(ae_d2_ptr)
     nxt = np.diff(cbd_ptr)
+    mark("tables2")
     # pv_p and cP from P_3 (packed p_loc of the element kernel: col-major np x k3 per agglomerate)
     np_ = np.diff(ae_d3_ptr)
     pv_p, _ = expand_ranges(ae_d3_ptr[:-1] * k3, np_)
@@ -390,6 +413,7 @@ def coarsen(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_ent
     ci_ptr = ptr_from_counts(nint_c)
     ndof2c = ntrace + int(ci_ptr[-1])
 
+    mark("extension2")
     # ===== assemble P_2, the coarse derivative and the projector pieces =====
     int_ptr = ptr_from_counts(ni)
     int_dofs, own_i = expand_ranges(ae_d2_ptr[:-1], ni)
@@ -414,11 +438,13 @@ def coarsen(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_ent
                           slot_rows=np.full(nAF, k2))
     hat0 = _blocks_to_csr(ci_ptr, ci_idx, int_ptr, int_dofs, _take_leading_rows(o_fun, kf, ni, nint_c), ni, (ndof2c, lv.ndof2), col_major=False)
 
+    mark("assemble2")
     # ===== project the targets: CochainProjector::Project (codim 1 then 0) with device products =====
     T2c = _project(hat1, hat0, P2, lv.T2)
-    T3c = _spmm_device(Pi3, lv.T3)
-    const3c = _spmm_device(Pi3, lv.const3[:, None])[:, 0]
+    T3c = _spmm_device(Pi3, np.c_[lv.T3, lv.const3])
+    T3c, const3c = np.ascontiguousarray(T3c[:, :-1]), np.ascontiguousarray(T3c[:, -1])
 
+    mark("project")
     M2ec_blocks = _take_leading(o_cm, ncm, nxt + nint_c)
     n2ec = nxt + nint_c
     coarse = AmgeLevel(
@@ -429,6 +455,7 @@ def coarsen(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_ent
         M2f_ptr=ptr_from_counts(ncf * ncf), M2f=M2fc_blocks,
         D2=D2c, T2=T2c, T3=T3c, const3=const3c,
         pv2=_first_dof_indicator(cf_ptr, ndof2c), pv3=_first_dof_indicator(c3_ptr, ndof3c), meta=dict(kind="alg"))
+    mark("coarse_level")
     return dict(P2=P2, P3=P3, Pi3=Pi3, hat1=hat1, hat0=hat0, coarse=coarse, topo=topo, n_rt=nrt, n_null=n_null,
                 agg=dict(ae_d2_ptr=ae_d2_ptr, ae_dofs2=ae_dofs2, ni=ni, ae_d3_ptr=ae_d3_ptr, ae_dofs3=ae_dofs3,
                          af_d_ptr=af_d_ptr, af_dofs=af_dofs))
@@ -519,7 +546,21 @@ def _spmm_device(A: sp.csr_matrix, X: np.ndarray) -> np.ndarray:
 
 
 def _project(hat1, hat0, P2, T):
-    """``CochainProjector::Project`` (``CochainProjector.cpp:158-216``): facet functionals, residual, element functionals."""
-    v1 = _spmm_device(hat1, T)
-    res = T - _spmm_device(P2, v1)
-    return v1 + _spmm_device(hat0, res)
+    """``CochainProjector::Project`` (``CochainProjector.cpp:158-216``): facet functionals, residual, element functionals; the three
+    products of a column run on device vectors (one upload of the column, one download of the result)."""
+    out = np.zeros((hat1.shape[0], T.shape[1]))
+    if T.shape[1] == 0:
+        return out
+    from . import linalg as la
+    d1, dP, d0 = (la.ParallelCSRMatrix.from_scipy(M) if M.nnz else None for M in (hat1, P2, hat0))
+    for c in range(T.shape[1]):
+        t = la.DeviceVector.from_numpy(np.ascontiguousarray(T[:, c]))
+        v1 = la.DeviceVector(hat1.shape[0], fill=0.0)
+        if d1 is not None:
+            d1.Mult(t, v1)                                        # v1 = hat1 T
+        if dP is not None:
+            dP.Mult(v1, t, alpha=-1.0, beta=1.0)                  # t = T - P v1
+        if d0 is not None:
+            d0.Mult(t, v1, alpha=1.0, beta=1.0)                   # v1 += hat0 (T - P v1)
+        out[:, c] = v1.to_numpy()
+    return out

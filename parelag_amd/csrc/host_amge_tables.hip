@@ -5,6 +5,9 @@
 // (unique / argsort / searchsorted joins on (agglomerate, dof) keys) and produce the same arrays bit for bit.
 // No device work; callable before elag_hip_init.
 #include "common.hpp"
+#include "host_parallel.hpp"
+
+#include <malloc.h>
 
 #include <algorithm>
 #include <atomic>
@@ -16,48 +19,28 @@
 
 using namespace elag;
 
-namespace {
-
-int host_threads()
-{
-    static int n = 0;
-    if (n == 0) {
-        const char *e = getenv("ELAG_HIP_HOST_THREADS");
-        int hw = (int)std::thread::hardware_concurrency();
-        n = e ? atoi(e) : std::min(std::max(hw, 1), 16);
-        if (n < 1) n = 1;
-    }
-    return n;
-}
-
-// fn(begin, end) over [0, n) in contiguous chunks, one per thread; the first failure's message is rethrown on the caller's thread
-template <class F>
-void parallel_ranges(int64_t n, F &&fn)
-{
-    const int nt = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / 256));
-    if (nt <= 1) { fn((int64_t)0, n); return; }
-    std::vector<std::thread> th;
-    std::vector<std::string> err((size_t)nt);
-    for (int t = 0; t < nt; t++) {
-        const int64_t b = n * t / nt, e = n * (t + 1) / nt;
-        th.emplace_back([&, b, e, t] {
-            try { fn(b, e); } catch (const std::exception &ex) { err[(size_t)t] = ex.what(); if (err[(size_t)t].empty()) err[(size_t)t] = "error"; }
-        });
-    }
-    for (auto &x : th) x.join();
-    for (auto &m : err)
-        if (!m.empty()) fail(ELAG_HIP_ERR_ARG, "%s", m.c_str());
-}
-
-struct Oops : std::exception {
-    std::string m;
-    explicit Oops(std::string s) : m(std::move(s)) {}
-    const char *what() const noexcept override { return m.c_str(); }
-};
-
-}  // namespace
 
 extern "C" {
+
+// Number of host threads the table functions may use (n <= 0: back to the default / ELAG_HIP_HOST_THREADS); returns the count in force.
+ELAG_HIP_API int elag_hip_host_set_threads(int n)
+{
+    host_threads_setting() = n > 0 ? std::min(n, 256) : 0;
+    return host_threads();
+}
+
+// Allocator policy for the table stage: its arrays are tens to hundreds of MB, allocated and freed once per stage; glibc hands such blocks
+// back to the kernel on free, so every stage pays the page faults again (and faults taken by many threads at once serialise on the
+// process's address-space lock: 0.76 s -> 0.46 s for the finest coarsening of the SPE10-size grid).  on != 0: large blocks come from the
+// heap and freed pages stay with the process (M_MMAP_MAX = 0, M_TRIM_THRESHOLD = 2 GiB - 1); on == 0: glibc's defaults again.
+ELAG_HIP_API int elag_hip_host_keep_pages(int on)
+{
+    return guarded([&] {
+        const int ok = on ? (mallopt(M_MMAP_MAX, 0) && mallopt(M_TRIM_THRESHOLD, 0x7fffffff))
+                          : (mallopt(M_MMAP_MAX, 65536) && mallopt(M_TRIM_THRESHOLD, 128 * 1024));
+        ELAG_REQUIRE(ok, "elag_hip_host_keep_pages: mallopt refused the setting");
+    });
+}
 
 // DofAgglomeration of one form on the agglomerated elements.  Agglomerate a holds the elements els[ae_ptr[a] .. ae_ptr[a+1]); an
 // element e carries the dofs e_idx[e_ptr[e] .. e_ptr[e+1]) (its "repeated" dofs, in this order).  sep[d] != 0 marks the dofs that lie on
@@ -235,34 +218,49 @@ ELAG_HIP_API int elag_hip_host_amge_elem_dof_table(int64_t nE, const int64_t *ef
 }
 
 // Sparse matrix whose entity blocks are dense (mfem's SetSubMatrix over all entities, exact zeros dropped), straight to CSR with sorted
-// 32-bit columns: block e couples rows rows_idx[rows_ptr[e]..) with columns cols_idx[cols_ptr[e]..); its values are the next
-// (slot_rows ? slot_rows[e] : nrows_e) * ld[e] entries of vals (col_major: entry (r,c) at c*nrows_e + r; else at r*ld[e] + c).
-// Entries that meet in one (row, column) are added in block order.  indptr (nrow+1) is always written; indices / data when not NULL
-// (room for indptr[nrow] before duplicates merge; *out_nnz = entries kept, and indptr is rewritten if duplicates merged).
-ELAG_HIP_API int elag_hip_host_blocks_to_csr(int64_t n_ent, const int64_t *rows_ptr, const int64_t *rows_idx, const int64_t *cols_ptr,
-                                             const int64_t *cols_idx, const double *vals, const int64_t *ld, const int64_t *slot_rows, int col_major,
-                                             int64_t nrow, int64_t ncol, int64_t *indptr, int32_t *indices, double *data, int64_t *out_nnz)
+// 32-bit columns.  The blocks come in families (elag_hip_block_family): block e of a family couples rows rows_idx[rows_ptr[e]..) with
+// columns cols_idx[cols_ptr[e]..); its values are the next (slot_rows ? slot_rows[e] : nrows_e) * ld[e] entries of vals (col_major: entry
+// (r,c) at c*nrows_e + r; else at r*ld[e] + c).  Entries that meet in one (row, column) are added family by family, block by block.
+// indptr (nrow+1) is always written; indices / data when not NULL (room for indptr[nrow] before duplicates merge; *out_nnz = entries
+// kept, and indptr is rewritten if duplicates merged).
+ELAG_HIP_API int elag_hip_host_block_families_to_csr(int n_fam, const elag_hip_block_family *fam, int64_t nrow, int64_t ncol, int64_t *indptr,
+                                                     int32_t *indices, double *data, int64_t *out_nnz)
 {
     return guarded([&] {
-        ELAG_REQUIRE(n_ent >= 0 && rows_ptr && cols_ptr && ld && indptr && nrow >= 0 && ncol >= 0 && ncol < (int64_t(1) << 31), "blocks_to_csr: bad argument");
-        // slot offset of every block
-        std::vector<int64_t> slot((size_t)n_ent + 1, 0);
-        for (int64_t e = 0; e < n_ent; e++) {
-            const int64_t nr = rows_ptr[e + 1] - rows_ptr[e], nc = cols_ptr[e + 1] - cols_ptr[e];
-            ELAG_REQUIRE(nr >= 0 && nc >= 0 && ld[e] >= nc, "blocks_to_csr: block %lld does not fit its slot", (long long)e);
-            slot[(size_t)e + 1] = slot[(size_t)e] + (slot_rows ? slot_rows[e] : nr) * ld[e];
+        ELAG_REQUIRE(n_fam >= 0 && (n_fam == 0 || fam) && indptr && nrow >= 0 && ncol >= 0 && ncol < (int64_t(1) << 31), "blocks_to_csr: bad argument");
+        struct Ent { const int64_t *R, *C; const double *v; int64_t nr, nc, ld; bool cm; };
+        int64_t n_ent = 0;
+        for (int f = 0; f < n_fam; f++) {
+            ELAG_REQUIRE(fam[f].n_ent >= 0 && fam[f].rows_ptr && fam[f].cols_ptr && fam[f].ld, "blocks_to_csr: null or negative argument in family %d", f);
+            n_ent += fam[f].n_ent;
         }
-        auto at = [&](int64_t e, int64_t nr, int64_t r, int64_t c) { return vals[slot[(size_t)e] + (col_major ? c * nr + r : r * ld[e] + c)]; };
+        std::vector<Ent> ent((size_t)n_ent);
+        {
+            int64_t w = 0;
+            for (int f = 0; f < n_fam; f++) {
+                const elag_hip_block_family &F = fam[f];
+                int64_t slot = 0;
+                for (int64_t e = 0; e < F.n_ent; e++, w++) {
+                    const int64_t nr = F.rows_ptr[e + 1] - F.rows_ptr[e], nc = F.cols_ptr[e + 1] - F.cols_ptr[e];
+                    ELAG_REQUIRE(nr >= 0 && nc >= 0 && F.ld[e] >= nc, "blocks_to_csr: block %lld of family %d does not fit its slot", (long long)e, f);
+                    ent[(size_t)w] = Ent{F.rows_idx + F.rows_ptr[e], F.cols_idx + F.cols_ptr[e], F.vals + slot, nr, nc, F.ld[e], F.col_major != 0};
+                    slot += (F.slot_rows ? F.slot_rows[e] : nr) * F.ld[e];
+                }
+                ELAG_REQUIRE(slot <= F.n_vals, "blocks_to_csr: the value array of family %d is shorter than its slots", f);
+            }
+        }
+        auto at = [](const Ent &E, int64_t r, int64_t c) { return E.v[E.cm ? c * E.nr + r : r * E.ld + c]; };
         if (!indices) {
             std::fill(indptr, indptr + nrow + 1, (int64_t)0);
             parallel_ranges(n_ent, [&](int64_t b, int64_t e_end) {
                 for (int64_t e = b; e < e_end; e++) {
-                    const int64_t nr = rows_ptr[e + 1] - rows_ptr[e], nc = cols_ptr[e + 1] - cols_ptr[e];
-                    const int64_t *R = rows_idx + rows_ptr[e];
+                    const Ent &E = ent[(size_t)e];
+                    const int64_t nr = E.nr, nc = E.nc;
+                    const int64_t *R = E.R;
                     for (int64_t r = 0; r < nr; r++) {
                         if (R[r] < 0 || R[r] >= nrow) throw Oops("blocks_to_csr: a row index is outside the matrix");
                         int64_t n = 0;
-                        for (int64_t c = 0; c < nc; c++) n += at(e, nr, r, c) != 0.0;
+                        for (int64_t c = 0; c < nc; c++) n += at(E, r, c) != 0.0;
                         if (n) __atomic_fetch_add(&indptr[R[r] + 1], n, __ATOMIC_RELAXED);
                     }
                 }
@@ -276,16 +274,17 @@ ELAG_HIP_API int elag_hip_host_blocks_to_csr(int64_t n_ent, const int64_t *rows_
         // same (row, column) does the order matter (the sum), and then the fill is repeated on one thread, in block order
         auto fill = [&](int64_t b, int64_t e_end, bool shared) {
             for (int64_t e = b; e < e_end; e++) {
-                const int64_t nr = rows_ptr[e + 1] - rows_ptr[e], nc = cols_ptr[e + 1] - cols_ptr[e];
-                const int64_t *R = rows_idx + rows_ptr[e], *Cc = cols_idx + cols_ptr[e];
+                const Ent &E = ent[(size_t)e];
+                const int64_t nr = E.nr, nc = E.nc;
+                const int64_t *R = E.R, *Cc = E.C;
                 for (int64_t r = 0; r < nr; r++) {
                     int64_t n = 0;
-                    for (int64_t c = 0; c < nc; c++) n += at(e, nr, r, c) != 0.0;
+                    for (int64_t c = 0; c < nc; c++) n += at(E, r, c) != 0.0;
                     if (!n) continue;
                     int64_t w = shared ? __atomic_fetch_add(&cur[(size_t)R[r]], n, __ATOMIC_RELAXED) : cur[(size_t)R[r]];
                     if (!shared) cur[(size_t)R[r]] += n;
                     for (int64_t c = 0; c < nc; c++) {
-                        const double x = at(e, nr, r, c);
+                        const double x = at(E, r, c);
                         if (x != 0.0) {
                             if (Cc[c] < 0 || Cc[c] >= ncol) throw Oops("blocks_to_csr: a column index is outside the matrix");
                             indices[w] = (int32_t)Cc[c]; data[w] = x; w++;
@@ -339,6 +338,15 @@ ELAG_HIP_API int elag_hip_host_blocks_to_csr(int64_t n_ent, const int64_t *rows_
         }
         *out_nnz = nnz;
     });
+}
+
+// One family (the layout of elag_hip_host_blocks_to_coo).
+ELAG_HIP_API int elag_hip_host_blocks_to_csr(int64_t n_ent, const int64_t *rows_ptr, const int64_t *rows_idx, const int64_t *cols_ptr,
+                                             const int64_t *cols_idx, const double *vals, const int64_t *ld, const int64_t *slot_rows, int col_major,
+                                             int64_t nrow, int64_t ncol, int64_t *indptr, int32_t *indices, double *data, int64_t *out_nnz)
+{
+    elag_hip_block_family F{n_ent, rows_ptr, rows_idx, cols_ptr, cols_idx, vals, INT64_MAX, ld, slot_rows, col_major};
+    return elag_hip_host_block_families_to_csr(1, &F, nrow, ncol, indptr, indices, data, out_nnz);
 }
 
 }  // extern "C"

@@ -9,10 +9,13 @@
 //   elag_hip_host_expand_ranges   concatenated index ranges with their owners
 // No GPU is touched; the functions are callable before elag_hip_init.
 #include "common.hpp"
+#include "host_parallel.hpp"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <string>
+#include <thread>
 #include <vector>
 
 using namespace elag;
@@ -248,20 +251,28 @@ ELAG_HIP_API int elag_hip_host_minimal_intersection_sets(int64_t nrow, const int
     return guarded([&] {
         ELAG_REQUIRE(nrow >= 0 && nsub >= 0 && fp && n_sets && (nsub == 0 || (mis && ori)), "minimal_intersection_sets: null or negative argument");
         const int64_t nnz = fp[nrow];
+        // transposed table (sub-entity -> rows, ascending): every thread owns a range of sub-entities and scans the whole table for them
         std::vector<int64_t> tp((size_t)nsub + 1, 0);
-        for (int64_t q = 0; q < nnz; q++) {
-            ELAG_REQUIRE(fi[q] >= 0 && fi[q] < nsub, "minimal_intersection_sets: sub-entity %lld outside 0..%lld", (long long)fi[q], (long long)nsub);
-            tp[(size_t)fi[q] + 1]++;
-        }
+        parallel_parts(nsub, [&](int, int64_t sb, int64_t se) {
+            for (int64_t q = 0; q < nnz; q++) {
+                const int64_t e = fi[q];
+                if (e < 0 || e >= nsub) throw Oops("minimal_intersection_sets: a sub-entity is outside the sub-entity range");
+                if (e >= sb && e < se) tp[(size_t)e + 1]++;
+            }
+        }, 4096);
         for (int64_t e = 0; e < nsub; e++) tp[(size_t)e + 1] += tp[(size_t)e];
         std::vector<int64_t> ta((size_t)nnz), fill(tp.begin(), tp.end() - 1);
         std::vector<double> ts((size_t)nnz);
-        for (int64_t a = 0; a < nrow; a++)                       // rows ascending: every transposed row comes out ascending
-            for (int64_t q = fp[a]; q < fp[a + 1]; q++) {
-                const int64_t w = fill[(size_t)fi[q]]++;
-                ta[(size_t)w] = a;
-                ts[(size_t)w] = fs[q];
-            }
+        parallel_parts(nsub, [&](int, int64_t sb, int64_t se) {
+            for (int64_t a = 0; a < nrow; a++)                   // rows ascending: every transposed row comes out ascending
+                for (int64_t q = fp[a]; q < fp[a + 1]; q++) {
+                    const int64_t e = fi[q];
+                    if (e < sb || e >= se) continue;
+                    const int64_t w = fill[(size_t)e]++;
+                    ta[(size_t)w] = a;
+                    ts[(size_t)w] = fs[q];
+                }
+        }, 4096);
         auto same = [&](int64_t e, int64_t r) {
             const int64_t n = tp[(size_t)e + 1] - tp[(size_t)e];
             if (n != tp[(size_t)r + 1] - tp[(size_t)r]) return false;
@@ -274,32 +285,74 @@ ELAG_HIP_API int elag_hip_host_minimal_intersection_sets(int64_t nrow, const int
                     return false;
             return true;
         };
-        // open-addressing table of set representatives keyed by a hash of the signature
-        size_t cap = 16;
-        while (cap < (size_t)nsub * 2 + 16) cap <<= 1;
-        std::vector<int64_t> slot(cap, -1), rep;
-        int64_t nset = 0;
-        for (int64_t e = 0; e < nsub; e++) {
-            const int64_t n = tp[(size_t)e + 1] - tp[(size_t)e];
-            if (n == 0) { mis[e] = -1; ori[e] = 0.0; continue; }
-            const int ae = attr ? attr[e] : 0;
-            const double se = ae > 0 ? 1.0 : ts[(size_t)tp[(size_t)e]];
-            uint64_t h = 1469598103934665603ull ^ (uint64_t)ae;
-            for (int64_t k = 0; k < n; k++) {
-                const uint64_t v = (uint64_t)ta[(size_t)(tp[(size_t)e] + k)] * 2u + (ts[(size_t)(tp[(size_t)e] + k)] * se > 0 ? 1u : 0u);
-                h = (h ^ v) * 1099511628211ull;
-                h ^= h >> 29;
+        // hash of every signature; the hash's top bits pick the thread that groups the sub-entity
+        const int nparts = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, nsub / 4096));
+        std::vector<uint64_t> hash((size_t)nsub);
+        std::vector<int64_t> part_count((size_t)nparts * (size_t)host_threads(), 0);
+        auto part_of = [&](uint64_t h) { return (int)(((h >> 33) * (uint64_t)nparts) >> 31); };
+        parallel_parts(nsub, [&](int t, int64_t sb, int64_t se) {
+            for (int64_t e = sb; e < se; e++) {
+                const int64_t n = tp[(size_t)e + 1] - tp[(size_t)e];
+                if (n == 0) { hash[(size_t)e] = 0; continue; }
+                const int ae = attr ? attr[e] : 0;
+                const double s0 = ae > 0 ? 1.0 : ts[(size_t)tp[(size_t)e]];
+                uint64_t h = 1469598103934665603ull ^ (uint64_t)ae;
+                for (int64_t k = 0; k < n; k++) {
+                    const uint64_t v = (uint64_t)ta[(size_t)(tp[(size_t)e] + k)] * 2u + (ts[(size_t)(tp[(size_t)e] + k)] * s0 > 0 ? 1u : 0u);
+                    h = (h ^ v) * 1099511628211ull;
+                    h ^= h >> 29;
+                }
+                hash[(size_t)e] = h;
+                part_count[(size_t)t * (size_t)nparts + (size_t)part_of(h)]++;
             }
-            size_t p = (size_t)h & (cap - 1);
-            int64_t g = -1;
-            while (slot[p] >= 0) {
-                if (same(e, rep[(size_t)slot[p]])) { g = slot[p]; break; }
-                p = (p + 1) & (cap - 1);
-            }
-            if (g < 0) { g = nset++; slot[p] = g; rep.push_back(e); }            // e ascends: the representative is the lowest member
-            mis[e] = g;
-            ori[e] = ae > 0 ? 1.0 : se * ts[(size_t)tp[(size_t)rep[(size_t)g]]];
+        }, 4096);
+        // representative (lowest member) of every sub-entity's set: each thread scans the sub-entities in ascending order and groups its share
+        std::vector<int64_t> rep_of((size_t)nsub, -1);
+        std::vector<std::thread> th;
+        std::vector<std::string> err((size_t)nparts);
+        for (int p = 0; p < nparts; p++) {
+            auto job = [&, p] {
+                try {
+                    int64_t mine = 0;
+                    for (int t = 0; t < host_threads(); t++) mine += part_count[(size_t)t * (size_t)nparts + (size_t)p];
+                    size_t cap = 16;
+                    while (cap < (size_t)mine * 2 + 16) cap <<= 1;
+                    std::vector<int64_t> slot(cap, -1);
+                    for (int64_t e = 0; e < nsub; e++) {
+                        if (tp[(size_t)e + 1] == tp[(size_t)e]) continue;
+                        const uint64_t h = hash[(size_t)e];
+                        if (part_of(h) != p) continue;
+                        size_t q = (size_t)h & (cap - 1);
+                        int64_t g = -1;
+                        while (slot[q] >= 0) {
+                            if (same(e, slot[q])) { g = slot[q]; break; }
+                            q = (q + 1) & (cap - 1);
+                        }
+                        if (g < 0) { g = e; slot[q] = e; }                                // e ascends: the representative is the lowest member
+                        rep_of[(size_t)e] = g;
+                    }
+                } catch (const std::exception &ex) { err[(size_t)p] = ex.what(); }
+            };
+            if (nparts == 1) job(); else th.emplace_back(job);
         }
+        for (auto &x : th) x.join();
+        for (auto &m : err)
+            if (!m.empty()) fail(ELAG_HIP_ERR_ARG, "%s", m.c_str());
+        // sets are numbered by their lowest member
+        std::vector<int64_t> set_of_rep((size_t)nsub, -1);
+        int64_t nset = 0;
+        for (int64_t e = 0; e < nsub; e++)
+            if (rep_of[(size_t)e] == e) set_of_rep[(size_t)e] = nset++;
+        parallel_ranges(nsub, [&](int64_t sb, int64_t se) {
+            for (int64_t e = sb; e < se; e++) {
+                const int64_t r = rep_of[(size_t)e];
+                if (r < 0) { mis[e] = -1; ori[e] = 0.0; continue; }
+                const int ae = attr ? attr[e] : 0;
+                const double s0 = ae > 0 ? 1.0 : ts[(size_t)tp[(size_t)e]];
+                mis[e] = set_of_rep[(size_t)r];
+                ori[e] = ae > 0 ? 1.0 : s0 * ts[(size_t)tp[(size_t)r]];
+            }
+        });
         *n_sets = nset;
     });
 }

@@ -204,6 +204,7 @@ def coarsen(lv: SeqLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entr
     build the agglomerated topology with the checks and repairs of ``CoarsenLocalPartitioning(..., check_topology = true)``.
     ``topo``: an agglomerated topology made elsewhere (``derham_dist``: the global one restricted to a rank's part)."""
     L = _lib.init()
+    _lib.keep_host_pages()
     tb = _Tables(lv)
     topo = coarsen_topology(lv, part, check=check_topology) if topo is None else topo
     js = lv.jstart

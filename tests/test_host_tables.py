@@ -273,3 +273,51 @@ def test_direct_csr_assembly_is_deterministic_across_threads():
         M = amge._blocks_to_csr(rp, ri, cp, ci, vals, nc, (nrow, ncol), col_major=False).tocoo()
         assert M.nnz == len(ref)
         assert all(ref[(int(r), int(c))] == v for r, c, v in zip(M.row, M.col, M.data))
+
+
+def test_tables_do_not_depend_on_the_thread_count():
+    """Sizes large enough that the table functions split their work: products (signed and pattern), minimal intersection sets, the
+    coarse topology and the agglomerate tables with 1 thread == with 7 threads, entry for entry."""
+    from parelag_amd import amge_level
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    a, b = ragged(rng, 3000, 800, 6, signed=True), ragged(rng, 800, 500, 5, signed=True)
+    args = _agglomerate_table_inputs((16, 16, 16), (4, 4, 4), seed=2)
+    lv = amge_level.level_from_hex((20, 20, 20))
+    ijk = np.stack(np.unravel_index(np.arange(lv.nE), (20, 20, 20)), axis=1)
+    part = (ijk[:, 0] // 4) * 25 + (ijk[:, 1] // 4) * 5 + ijk[:, 2] // 4
+
+    def everything():
+        out = list(_product(a[0], a[1], b[0], b[1], a[2], b[2])) + list(_product(a[0], a[1], b[0], b[1]))
+        topo = amge.coarsen_topology(lv, part)
+        out += [np.asarray(topo[k]) for k in sorted(topo)]
+        tb = amge._agglomerate_tables(*args)
+        return out + [tb[k] for k in sorted(tb)]
+    try:
+        assert lib.elag_hip_host_set_threads(1) == 1
+        one = everything()
+        assert lib.elag_hip_host_set_threads(7) == 7
+        many = everything()
+    finally:
+        lib.elag_hip_host_set_threads(0)
+    assert len(one) == len(many)
+    for x, y in zip(one, many):
+        assert x.dtype == y.dtype and np.array_equal(x, y)
+    rp, ri, rs = mult_orientation(a, b)                                   # and the row-loop statement of the product
+    assert np.array_equal(one[0], rp) and np.array_equal(one[1], ri) and np.array_equal(one[2], rs)
+
+
+def test_block_families_in_one_pass_equal_the_sum_of_the_families():
+    rng = np.random.default_rng(8)
+    nrow, ncol, sets, total = 60, 45, [], 0
+    for n_ent in (25, 0, 40):
+        rp, ri = ragged(rng, n_ent, nrow, 5); cp, ci = ragged(rng, n_ent, ncol, 4)
+        ld = np.diff(cp) + rng.integers(0, 3, n_ent)
+        vals = rng.integers(-2, 3, int((np.diff(rp) * ld).sum()) + 3).astype(np.float64)      # a longer value array is fine
+        sets.append((rp, ri, cp, ci, vals, ld))
+        total = total + amge._blocks_to_csr(rp, ri, cp, ci, vals, ld, (nrow, ncol), col_major=True).toarray()
+    M = amge._blocks_to_csr_sets(sets, (nrow, ncol))
+    assert M.has_sorted_indices and np.array_equal(M.toarray(), total)
+    short = list(sets); short[0] = sets[0][:4] + (sets[0][4][:2], sets[0][5])
+    with pytest.raises(ValueError, match="shorter than its slots"):
+        amge._blocks_to_csr_sets(short, (nrow, ncol))
