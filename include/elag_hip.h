@@ -594,6 +594,8 @@ ELAG_HIP_API int elag_hip_host_keep_pages(int on);
 /* Host threads the elag_hip_host_* table functions may use (n <= 0: the default = hardware threads, at most 16, or ELAG_HIP_HOST_THREADS);
  * returns the count in force.  The tables do not depend on it. */
 ELAG_HIP_API int elag_hip_host_set_threads(int n);
+/* Work (about a nanosecond per unit) a thread must get before a table loop is split over threads; <= 0: the default (131072). Returns the value in force. */
+ELAG_HIP_API int64_t elag_hip_host_set_min_work(int64_t min_work);
 ELAG_HIP_API int elag_hip_host_amge_dof_agglomeration(int64_t nAE, const int64_t *ae_ptr, const int64_t *els, const int64_t *e_ptr, const int64_t *e_idx,
                                                       int64_t ndof, const int64_t *sep, int64_t *ae_dof_ptr, int64_t *n_int, int64_t *ae_dofs, int64_t *loc);
 ELAG_HIP_API int elag_hip_host_amge_boundary_traces(int64_t nAE, const int64_t *B_ptr, const int64_t *B_idx, const int64_t *cf_ptr, const int64_t *af_of_dof,

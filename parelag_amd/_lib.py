@@ -156,6 +156,7 @@ _SIGNATURES = {
     "elag_hip_host_gather_dense": [_i64, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p],
     "elag_hip_host_expand_ranges": [_i64, _p, _p, _i64, _p, _p],
     "elag_hip_host_set_threads": [_i],
+    "elag_hip_host_set_min_work": [_i64],
     "elag_hip_host_keep_pages": [_i],
     "elag_hip_host_amge_dof_agglomeration": [_i64, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p],
     "elag_hip_host_amge_boundary_traces": [_i64, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
@@ -174,7 +175,7 @@ _SIGNATURES = {
     "elag_hip_time_hierarchy": [_p, _p, _p, _i, _dp],
     "elag_hip_time_hierarchy_internal": [_p, _i, _dp],
 }
-_RESTYPES = {"elag_hip_last_error": C.c_char_p}
+_RESTYPES = {"elag_hip_last_error": C.c_char_p, "elag_hip_host_set_min_work": C.c_int64}
 
 ABI_SYMBOLS = tuple(_SIGNATURES)
 

@@ -29,6 +29,13 @@ ELAG_HIP_API int elag_hip_host_set_threads(int n)
     return host_threads();
 }
 
+// Work (about a nanosecond per unit) a thread must get before a table loop is split; min_work <= 0: the default, 131072.  Returns the value in force.
+ELAG_HIP_API int64_t elag_hip_host_set_min_work(int64_t min_work)
+{
+    host_min_work() = min_work > 0 ? min_work : 131072;
+    return host_min_work();
+}
+
 // Allocator policy for the table stage: its arrays are tens to hundreds of MB, allocated and freed once per stage; glibc hands such blocks
 // back to the kernel on free, so every stage pays the page faults again (and faults taken by many threads at once serialise on the
 // process's address-space lock: 0.76 s -> 0.46 s for the finest coarsening of the SPE10-size grid).  on != 0: large blocks come from the

@@ -32,41 +32,96 @@ ELAG_HIP_API int elag_hip_host_table_product(int64_t nrow, const int64_t *a_ptr,
         ELAG_REQUIRE(nrow >= 0 && nmid >= 0 && ncol >= 0 && a_ptr && b_ptr && out_ptr && out_nnz, "table_product: null or negative argument");
         const bool sgn = a_sgn != nullptr;
         ELAG_REQUIRE(sgn == (b_sgn != nullptr) && sgn == (out_sgn != nullptr), "table_product: signs must be given for both tables and the output, or for none");
-        std::vector<int64_t> where((size_t)ncol, -1);          // position of a column in the current output row
+        const int64_t row_grain = grain_for(nrow, 4 * a_ptr[nrow]);
         int64_t n = 0;
-        out_ptr[0] = 0;
-        for (int64_t r = 0; r < nrow; r++) {
-            const int64_t row0 = n;
-            for (int64_t k = a_ptr[r]; k < a_ptr[r + 1]; k++) {
-                const int64_t m = a_idx[k];
-                ELAG_REQUIRE(m >= 0 && m < nmid, "table_product: entry %lld of the left table is outside the right table", (long long)m);
-                for (int64_t q = b_ptr[m]; q < b_ptr[m + 1]; q++) {
-                    const int64_t c = b_idx[q];
-                    ELAG_REQUIRE(c >= 0 && c < ncol, "table_product: column %lld outside 0..%lld", (long long)c, (long long)ncol);
-                    if (where[(size_t)c] < row0) {              // first touch in this row
-                        where[(size_t)c] = n;
-                        out_idx[n] = c;
-                        if (sgn) out_sgn[n] = 0.0;
-                        n++;
+        if (nrow / std::max<int64_t>(1, (int64_t)((double)row_grain * (double)host_min_work() / 131072.0)) <= 1 || host_threads() == 1) {
+            // small table: one pass with a marker array over the columns (Gustavson's row loop)
+            std::vector<int64_t> where((size_t)ncol, -1);          // position of a column in the current output row
+            out_ptr[0] = 0;
+            for (int64_t r = 0; r < nrow; r++) {
+                const int64_t row0 = n;
+                for (int64_t k = a_ptr[r]; k < a_ptr[r + 1]; k++) {
+                    const int64_t m = a_idx[k];
+                    ELAG_REQUIRE(m >= 0 && m < nmid, "table_product: entry %lld of the left table is outside the right table", (long long)m);
+                    for (int64_t q = b_ptr[m]; q < b_ptr[m + 1]; q++) {
+                        const int64_t c = b_idx[q];
+                        ELAG_REQUIRE(c >= 0 && c < ncol, "table_product: column %lld outside 0..%lld", (long long)c, (long long)ncol);
+                        if (where[(size_t)c] < row0) {              // first touch in this row
+                            where[(size_t)c] = n;
+                            out_idx[n] = c;
+                            if (sgn) out_sgn[n] = 0.0;
+                            n++;
+                        }
+                        if (sgn) out_sgn[where[(size_t)c]] += a_sgn[k] * b_sgn[q];
                     }
-                    if (sgn) out_sgn[where[(size_t)c]] += a_sgn[k] * b_sgn[q];
                 }
+                if (sgn) {                                          // cancelled entries leave the row, the others keep their order
+                    int64_t w = row0;
+                    for (int64_t t = row0; t < n; t++) {
+                        const int64_t c = out_idx[t];
+                        const double v = out_sgn[t];
+                        where[(size_t)c] = -1;                      // positions move: no marker of this row survives it
+                        if (std::fabs(v) > 1e-10) {
+                            out_idx[w] = c;
+                            out_sgn[w] = v > 0.0 ? 1.0 : -1.0;
+                            w++;
+                        }
+                    }
+                    n = w;
+                }
+                out_ptr[r + 1] = n;
             }
-            if (sgn) {                                          // cancelled entries leave the row, the others keep their order
-                int64_t w = row0;
-                for (int64_t t = row0; t < n; t++) {
-                    const int64_t c = out_idx[t];
-                    const double v = out_sgn[t];
-                    where[(size_t)c] = -1;                      // positions move: no marker of this row survives it
-                    if (std::fabs(v) > 1e-10) {
-                        out_idx[w] = c;
-                        out_sgn[w] = v > 0.0 ? 1.0 : -1.0;
+        } else {
+            // two passes over the rows, both on threads: count the columns every row keeps, then write them at their final place.  A thread
+            // holds the columns of its current row in a small open-addressing table (insertion order = first touch).
+            auto rows = [&](int64_t rb, int64_t re, bool write) {
+                std::vector<int64_t> hk, hp, cols;
+                std::vector<double> acc;
+                std::vector<size_t> used;
+                size_t cap = 0; int shift = 0;
+                for (int64_t r = rb; r < re; r++) {
+                    int64_t cand = 0;
+                    for (int64_t k = a_ptr[r]; k < a_ptr[r + 1]; k++) {
+                        const int64_t m = a_idx[k];
+                        if (m < 0 || m >= nmid) throw Oops("table_product: an entry of the left table is outside the right table");
+                        cand += b_ptr[m + 1] - b_ptr[m];
+                    }
+                    if ((size_t)(2 * cand + 2) > cap) {
+                        cap = 64; shift = 58;
+                        while (cap < (size_t)(2 * cand + 2)) { cap <<= 1; shift--; }
+                        hk.assign(cap, -1); hp.assign(cap, 0);
+                    }
+                    cols.clear(); acc.clear(); used.clear();
+                    for (int64_t k = a_ptr[r]; k < a_ptr[r + 1]; k++) {
+                        const int64_t m = a_idx[k];
+                        for (int64_t q = b_ptr[m]; q < b_ptr[m + 1]; q++) {
+                            const int64_t c = b_idx[q];
+                            if (c < 0 || c >= ncol) throw Oops("table_product: a column is outside the column range");
+                            size_t p = (size_t)(((uint64_t)c * 0x9E3779B97F4A7C15ull) >> shift);
+                            while (hk[p] != -1 && hk[p] != c) p = (p + 1) & (cap - 1);
+                            if (hk[p] == -1) {                      // first touch in this row
+                                hk[p] = c; hp[p] = (int64_t)cols.size(); used.push_back(p);
+                                cols.push_back(c);
+                                if (sgn) acc.push_back(0.0);
+                            }
+                            if (sgn) acc[(size_t)hp[p]] += a_sgn[k] * b_sgn[q];
+                        }
+                    }
+                    for (size_t p : used) hk[p] = -1;
+                    int64_t w = write ? out_ptr[r] : 0;
+                    for (size_t x = 0; x < cols.size(); x++) {
+                        if (sgn && !(std::fabs(acc[x]) > 1e-10)) continue;       // cancelled entries leave the row, the others keep their order
+                        if (write) { out_idx[w] = cols[x]; if (sgn) out_sgn[w] = acc[x] > 0.0 ? 1.0 : -1.0; }
                         w++;
                     }
+                    if (!write) out_ptr[r + 1] = w;
                 }
-                n = w;
-            }
-            out_ptr[r + 1] = n;
+            };
+            out_ptr[0] = 0;
+            parallel_parts(nrow, [&](int, int64_t rb, int64_t re) { rows(rb, re, false); }, row_grain);
+            for (int64_t r = 0; r < nrow; r++) out_ptr[r + 1] += out_ptr[r];
+            n = out_ptr[nrow];
+            parallel_parts(nrow, [&](int, int64_t rb, int64_t re) { rows(rb, re, true); }, row_grain);
         }
         *out_nnz = n;
     });
@@ -79,36 +134,16 @@ ELAG_HIP_API int elag_hip_host_lookup_find(int64_t nrow, const int64_t *ptr, con
     return guarded([&] {
         ELAG_REQUIRE(nrow >= 0 && nid >= 0 && nq >= 0 && ptr && (nq == 0 || (q_row && q_id && pos)), "lookup_find: null or negative argument");
         if (nq == 0) return;
-        bool sorted = true;
-        for (int64_t q = 1; q < nq && sorted; q++) sorted = q_row[q - 1] <= q_row[q];
-        std::vector<int64_t> order;
-        if (!sorted) {                                          // counting sort of the queries by row
-            std::vector<int64_t> start((size_t)nrow + 1, 0);
-            for (int64_t q = 0; q < nq; q++) {
-                ELAG_REQUIRE(q_row[q] >= 0 && q_row[q] < nrow, "lookup_find: row %lld outside the table", (long long)q_row[q]);
-                start[(size_t)q_row[q] + 1]++;
+        // queries are independent: a thread keeps the row of its last query at hand (queries usually come grouped by row)
+        parallel_parts(nq, [&](int, int64_t qb, int64_t qe) {
+            RowFinder f;
+            for (int64_t q = qb; q < qe; q++) {
+                const int64_t r = q_row[q];
+                if (r < 0 || r >= nrow) throw Oops("lookup_find: a query row is outside the table");
+                f.set(idx + ptr[r], ptr[r + 1] - ptr[r]);
+                pos[q] = f.find(q_id[q]);
             }
-            for (int64_t r = 0; r < nrow; r++) start[(size_t)r + 1] += start[(size_t)r];
-            order.resize((size_t)nq);
-            for (int64_t q = 0; q < nq; q++) order[(size_t)start[(size_t)q_row[q]]++] = q;
-        }
-        std::vector<int64_t> mark((size_t)nid + 1, -1), stamp((size_t)nid + 1, -1);
-        int64_t cur = -1;
-        for (int64_t t = 0; t < nq; t++) {
-            const int64_t q = sorted ? t : order[(size_t)t];
-            const int64_t r = q_row[q];
-            ELAG_REQUIRE(r >= 0 && r < nrow, "lookup_find: row %lld outside the table", (long long)r);
-            if (r != cur) {
-                cur = r;
-                for (int64_t k = ptr[r]; k < ptr[r + 1]; k++) {
-                    const int64_t i = idx[k];
-                    ELAG_REQUIRE(i >= 0 && i <= nid, "lookup_find: id %lld outside 0..%lld", (long long)i, (long long)nid);
-                    if (stamp[(size_t)i] != r) { stamp[(size_t)i] = r; mark[(size_t)i] = k - ptr[r]; }   // first occurrence wins
-                }
-            }
-            const int64_t i = q_id[q];
-            pos[q] = (i >= 0 && i <= nid && stamp[(size_t)i] == r) ? mark[(size_t)i] : -1;
-        }
+        }, 16384);
     });
 }
 
@@ -121,25 +156,25 @@ ELAG_HIP_API int elag_hip_host_gather_dense(int64_t n_ent, const int64_t *row_pt
 {
     return guarded([&] {
         ELAG_REQUIRE(n_ent >= 0 && row_ptr && col_ptr && ncol && m_indptr && out_ptr, "gather_dense: null or negative argument");
-        std::vector<int64_t> mark((size_t)m_cols, -1), stamp((size_t)m_cols, -1);
-        for (int64_t e = 0; e < n_ent; e++) {
-            const int64_t nr = row_ptr[e + 1] - row_ptr[e];
-            ELAG_REQUIRE(col_ptr[e + 1] - col_ptr[e] <= ncol[e] && out_ptr[e + 1] - out_ptr[e] == nr * ncol[e], "gather_dense: block %lld has the wrong size", (long long)e);
-            for (int64_t k = col_ptr[e]; k < col_ptr[e + 1]; k++) {
-                const int64_t c = col_idx[k];
-                ELAG_REQUIRE(c >= 0 && c < m_cols, "gather_dense: column %lld outside the matrix", (long long)c);
-                if (stamp[(size_t)c] != e) { stamp[(size_t)c] = e; mark[(size_t)c] = k - col_ptr[e]; }
-            }
-            double *blk = out + out_ptr[e];
-            for (int64_t lr = 0; lr < nr; lr++) {
-                const int64_t g = rows[row_ptr[e] + lr];
-                ELAG_REQUIRE(g >= 0 && g < m_rows, "gather_dense: row %lld outside the matrix", (long long)g);
-                for (int32_t k = m_indptr[g]; k < m_indptr[g + 1]; k++) {
-                    const int32_t c = m_indices[k];
-                    if (stamp[(size_t)c] == e) blk[mark[(size_t)c] * nr + lr] = m_data[k];
+        parallel_parts(n_ent, [&](int, int64_t eb, int64_t ee) {
+            RowFinder f;
+            for (int64_t e = eb; e < ee; e++) {
+                const int64_t nr = row_ptr[e + 1] - row_ptr[e];
+                if (col_ptr[e + 1] - col_ptr[e] > ncol[e] || out_ptr[e + 1] - out_ptr[e] != nr * ncol[e]) throw Oops("gather_dense: a block has the wrong size");
+                for (int64_t k = col_ptr[e]; k < col_ptr[e + 1]; k++)
+                    if (col_idx[k] < 0 || col_idx[k] >= m_cols) throw Oops("gather_dense: a column is outside the matrix");
+                f.set(col_idx + col_ptr[e], col_ptr[e + 1] - col_ptr[e]);
+                double *blk = out + out_ptr[e];
+                for (int64_t lr = 0; lr < nr; lr++) {
+                    const int64_t g = rows[row_ptr[e] + lr];
+                    if (g < 0 || g >= m_rows) throw Oops("gather_dense: a row is outside the matrix");
+                    for (int32_t k = m_indptr[g]; k < m_indptr[g + 1]; k++) {
+                        const int64_t at = f.find(m_indices[k]);
+                        if (at >= 0) blk[at * nr + lr] = m_data[k];
+                    }
                 }
             }
-        }
+        }, grain_for(n_ent, 8 * row_ptr[n_ent]));
     });
 }
 
@@ -148,12 +183,18 @@ ELAG_HIP_API int elag_hip_host_expand_ranges(int64_t n, const int64_t *starts, c
 {
     return guarded([&] {
         ELAG_REQUIRE(n >= 0 && total >= 0 && (n == 0 || (starts && counts)) && (total == 0 || (idx && owner)), "expand_ranges: null or negative argument");
-        int64_t k = 0;
+        std::vector<int64_t> off((size_t)n + 1, 0);
         for (int64_t i = 0; i < n; i++) {
-            ELAG_REQUIRE(counts[i] >= 0 && k + counts[i] <= total, "expand_ranges: the counts do not add up to the given total");
-            for (int64_t j = 0; j < counts[i]; j++, k++) { idx[k] = starts[i] + j; owner[k] = i; }
+            ELAG_REQUIRE(counts[i] >= 0 && off[(size_t)i] + counts[i] <= total, "expand_ranges: the counts do not add up to the given total");
+            off[(size_t)i + 1] = off[(size_t)i] + counts[i];
         }
-        ELAG_REQUIRE(k == total, "expand_ranges: the counts do not add up to the given total");
+        ELAG_REQUIRE(off[(size_t)n] == total, "expand_ranges: the counts do not add up to the given total");
+        parallel_parts(n, [&](int, int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; i++) {
+                int64_t k = off[(size_t)i];
+                for (int64_t j = 0; j < counts[i]; j++, k++) { idx[k] = starts[i] + j; owner[k] = i; }
+            }
+        }, grain_for(n, total, 262144));
     });
 }
 
@@ -198,15 +239,17 @@ ELAG_HIP_API int elag_hip_host_pack_cols(int64_t n_ent, const int64_t *ptr, cons
 {
     return guarded([&] {
         ELAG_REQUIRE(n_ent >= 0 && ptr && nT >= 0 && ndof >= 0, "pack_cols: null or negative argument");
-        for (int64_t e = 0; e < n_ent; e++) {
-            const int64_t n = ptr[e + 1] - ptr[e];
-            double *blk = out + ptr[e] * nT;
-            for (int64_t i = 0; i < n; i++) {
-                const int64_t d = dofs[ptr[e] + i];
-                ELAG_REQUIRE(d >= 0 && d < ndof, "pack_cols: dof %lld outside the vector", (long long)d);
-                for (int64_t c = 0; c < nT; c++) blk[c * n + i] = T[d * nT + c];
+        parallel_parts(n_ent, [&](int, int64_t eb, int64_t ee) {
+            for (int64_t e = eb; e < ee; e++) {
+                const int64_t n = ptr[e + 1] - ptr[e];
+                double *blk = out + ptr[e] * nT;
+                for (int64_t i = 0; i < n; i++) {
+                    const int64_t d = dofs[ptr[e] + i];
+                    if (d < 0 || d >= ndof) throw Oops("pack_cols: a dof is outside the vector");
+                    for (int64_t c = 0; c < nT; c++) blk[c * n + i] = T[d * nT + c];
+                }
             }
-        }
+        }, grain_for(n_ent, ptr[n_ent] * std::max<int64_t>(nT, 1)));
     });
 }
 
@@ -232,11 +275,13 @@ ELAG_HIP_API int elag_hip_host_sort_rows_by_key(int64_t nrow, const int64_t *ptr
 {
     return guarded([&] {
         ELAG_REQUIRE(nrow >= 0 && ptr && (nid == 0 || key), "sort_rows_by_key: null or negative argument");
-        for (int64_t r = 0; r < nrow; r++) {
-            for (int64_t k = ptr[r]; k < ptr[r + 1]; k++)
-                ELAG_REQUIRE(idx[k] >= 0 && idx[k] < nid, "sort_rows_by_key: id %lld outside 0..%lld", (long long)idx[k], (long long)nid);
-            std::sort(idx + ptr[r], idx + ptr[r + 1], [key](int64_t a, int64_t b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
-        }
+        parallel_parts(nrow, [&](int, int64_t rb, int64_t re) {
+            for (int64_t r = rb; r < re; r++) {
+                for (int64_t k = ptr[r]; k < ptr[r + 1]; k++)
+                    if (idx[k] < 0 || idx[k] >= nid) throw Oops("sort_rows_by_key: an id is outside the key range");
+                std::sort(idx + ptr[r], idx + ptr[r + 1], [key](int64_t a, int64_t b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
+            }
+        }, grain_for(nrow, 8 * ptr[nrow]));
     });
 }
 

@@ -296,10 +296,10 @@ def test_tables_do_not_depend_on_the_thread_count():
     try:
         assert lib.elag_hip_host_set_threads(1) == 1
         one = everything()
-        assert lib.elag_hip_host_set_threads(7) == 7
+        assert lib.elag_hip_host_set_threads(7) == 7 and lib.elag_hip_host_set_min_work(64) == 64         # split even these small tables
         many = everything()
     finally:
-        lib.elag_hip_host_set_threads(0)
+        lib.elag_hip_host_set_threads(0); lib.elag_hip_host_set_min_work(0)
     assert len(one) == len(many)
     for x, y in zip(one, many):
         assert x.dtype == y.dtype and np.array_equal(x, y)
