@@ -605,6 +605,10 @@ ELAG_HIP_API int elag_hip_host_amge_boundary_traces(int64_t nAE, const int64_t *
 ELAG_HIP_API int elag_hip_host_amge_local_derivative(int64_t nAE, const int64_t *row_ptr, const int64_t *row_dofs, const int32_t *D_indptr,
                                                      const int32_t *D_indices, const double *D_data, const int64_t *ae_dof_ptr, const int64_t *ae_dofs,
                                                      const int64_t *n_int, int64_t *d_ptr, int32_t *d_row, int32_t *d_col, double *d_val);
+/* local_derivative for any pair of forms: the entity's columns come as an unordered list (local column = first position). 64-bit triplets. */
+ELAG_HIP_API int elag_hip_host_local_triplets(int64_t n_ent, const int64_t *rows_ptr, const int64_t *rows, const int32_t *D_indptr, const int32_t *D_indices,
+                                              const double *D_data, const int64_t *col_ptr, const int64_t *col_idx, int64_t *d_ptr, int64_t *d_row,
+                                              int64_t *d_col, double *d_val);
 /* Element-to-dof table of form 2 (facet dofs facet after facet, then the element's interior dofs; DofHandler::GetrDof order,
  * src/amge/DofHandler.cpp:548-640).  ptr always written; idx == NULL: sizes only. */
 ELAG_HIP_API int elag_hip_host_amge_elem_dof_table(int64_t nE, const int64_t *ef_ptr, const int64_t *ef_idx, const int64_t *f_dof_ptr,

@@ -161,6 +161,7 @@ _SIGNATURES = {
     "elag_hip_host_amge_dof_agglomeration": [_i64, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p],
     "elag_hip_host_amge_boundary_traces": [_i64, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
     "elag_hip_host_amge_local_derivative": [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "elag_hip_host_local_triplets": [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "elag_hip_host_amge_elem_dof_table": [_i64, _p, _p, _p, _p, _i64, _p, _p],
     "elag_hip_host_block_families_to_csr": [_i, _p, _i64, _i64, _p, _p, _p, _p],
     "elag_hip_host_blocks_to_csr": [_i64, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i64, _p, _p, _p, _p],

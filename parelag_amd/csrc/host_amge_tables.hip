@@ -196,6 +196,40 @@ ELAG_HIP_API int elag_hip_host_amge_local_derivative(int64_t nAE, const int64_t 
 
 extern "C" {
 
+// Local triplets of a sparse matrix D (32-bit CSR) on entities (DistributeAgglomerateMatrix for any pair of forms): entity e has the rows
+// rows[rows_ptr[e]..) (local row = position) and the columns col_idx[col_ptr[e]..) in any order (local column = first position).  d_ptr
+// (n_ent+1) is always written; with d_row != NULL the triplets too, rows in order, entries in D's storage order.  An entry whose column
+// is not among the entity's columns is an error.
+ELAG_HIP_API int elag_hip_host_local_triplets(int64_t n_ent, const int64_t *rows_ptr, const int64_t *rows, const int32_t *D_indptr, const int32_t *D_indices,
+                                              const double *D_data, const int64_t *col_ptr, const int64_t *col_idx, int64_t *d_ptr, int64_t *d_row,
+                                              int64_t *d_col, double *d_val)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(n_ent >= 0 && rows_ptr && D_indptr && col_ptr && d_ptr, "local_triplets: null argument");
+        d_ptr[0] = 0;
+        for (int64_t e = 0; e < n_ent; e++) {
+            int64_t s = 0;
+            for (int64_t r = rows_ptr[e]; r < rows_ptr[e + 1]; r++) s += D_indptr[rows[r] + 1] - D_indptr[rows[r]];
+            d_ptr[e + 1] = d_ptr[e] + s;
+        }
+        if (!d_row) return;
+        ELAG_REQUIRE(d_col && d_val && (d_ptr[n_ent] == 0 || (D_indices && D_data && col_idx)), "local_triplets: null argument");
+        parallel_ranges(n_ent, [&](int64_t b, int64_t e_end) {
+            RowFinder f;
+            for (int64_t e = b; e < e_end; e++) {
+                f.set(col_idx + col_ptr[e], col_ptr[e + 1] - col_ptr[e]);
+                int64_t w = d_ptr[e];
+                for (int64_t r = rows_ptr[e]; r < rows_ptr[e + 1]; r++)
+                    for (int32_t q = D_indptr[rows[r]]; q < D_indptr[rows[r] + 1]; q++, w++) {
+                        const int64_t at = f.find(D_indices[q]);
+                        if (at < 0) throw Oops("DistributeAgglomerateMatrix: a derivative couples an agglomerate with a dof outside it");
+                        d_row[w] = r - rows_ptr[e]; d_col[w] = at; d_val[w] = D_data[q];
+                    }
+            }
+        }, grain_for(n_ent, 8 * d_ptr[n_ent]));
+    });
+}
+
 // Element-to-dof table of form 2 on a level: element e carries the dofs of its facets (ef_ptr / ef_idx rows, facet f = dofs
 // f_dof_ptr[f] .. f_dof_ptr[f+1]), facet after facet, then its own interior dofs nfd + e_idof_ptr[e] .. (DofHandler::GetrDof order of
 // src/amge/DofHandler.cpp:548-640 for codimension 0).  ptr (nE+1) is always written; idx when it is not NULL (room for ptr[nE]).

@@ -17,7 +17,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _lib
-from .amge import (EPS, _Assembly, _ExtIn, _ExtOut, _Keep, _TracesIn, _TracesOut, _assembly, _blocks_to_csr, _join_cols,
+from .amge import (EPS, _Assembly, _ExtIn, _ExtOut, _Keep, _TracesIn, _TracesOut, _assembly, _blocks_to_csr, _blocks_to_csr_sets, _join_cols,
                    _pack_cols, _ptr, _spmm_device, _take_leading, _take_leading_rows, expand_ranges)
 from .amge_level import ptr_from_counts
 from .derham_level import SeqLevel, _Tables, _concat_rows, _product
@@ -185,7 +185,29 @@ def _asm(keep, lv, tb, j, c, topo, look):
 
 
 def _triplets(D: sp.csr_matrix, rows_ptr, rows, look_cols: _Lookup):
-    """Local triplets of D restricted to (rows of the entity) x (its columns)."""
+    """Local triplets of D restricted to (rows of the entity) x (its columns): threaded host code (``elag_hip_host_local_triplets``)."""
+    if D.nnz > np.iinfo(np.int32).max:
+        raise ValueError("_triplets: matrix too large for 32-bit CSR indices")
+    c64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+    rows_ptr, rows = c64(rows_ptr), c64(rows)
+    indptr, indices = np.ascontiguousarray(D.indptr, dtype=np.int32), np.ascontiguousarray(D.indices, dtype=np.int32)
+    data = np.ascontiguousarray(D.data, dtype=np.float64)
+    n = len(rows_ptr) - 1
+    d_ptr = np.empty(n + 1, dtype=np.int64)
+    args = (n, _ptr(rows_ptr), _ptr(rows), _ptr(indptr), _ptr(indices), _ptr(data), _ptr(look_cols.ptr), _ptr(look_cols.idx), _ptr(d_ptr))
+    L = _lib.load()
+    _lib.check(L.elag_hip_host_local_triplets(*args, None, None, None))
+    nd = int(d_ptr[-1])
+    lr, lc, v = np.empty(nd, dtype=np.int64), np.empty(nd, dtype=np.int64), np.empty(nd)
+    try:
+        _lib.check(L.elag_hip_host_local_triplets(*args, _ptr(lr), _ptr(lc), _ptr(v)))
+    except _lib.ElagHipError as e:
+        raise ValueError(str(e)) from None
+    return d_ptr, lr, lc, v
+
+
+def _triplets_numpy(D: sp.csr_matrix, rows_ptr, rows, look_cols: _Lookup):
+    """Whole-array statement of :func:`_triplets` (the tests compare the two)."""
     ent = np.repeat(np.arange(len(rows_ptr) - 1, dtype=np.int64), np.diff(rows_ptr))
     lr = np.arange(rows.size, dtype=np.int64) - rows_ptr[ent]
     q, own = expand_ranges(D.indptr[rows], np.diff(D.indptr)[rows])
@@ -438,8 +460,9 @@ def _assemble_P(pieces, nrows, ncols, keep_zeros, cache=None):
     """Sum of the dense-block pieces of an interpolator as one CSR with ``ncols`` columns.  ``cache`` = [n pieces already
     summed, their sum]: only the new pieces are converted and added."""
     done, out = (cache[0], cache[1]) if cache else (0, None)
-    for _tag, rptr, ridx, cptr, cidx, vals, ld in pieces[done:]:
-        M = _blocks_to_csr(rptr, ridx, cptr, cidx, vals, ld, (nrows, ncols), col_major=True)
+    fresh = [piece[1:] for piece in pieces[done:]]
+    if fresh:                                               # the new pieces in one pass (their (row, column) sets are disjoint)
+        M = _blocks_to_csr_sets(fresh, (nrows, ncols))
         if out is None:
             out = M
         else:

@@ -321,3 +321,24 @@ def test_block_families_in_one_pass_equal_the_sum_of_the_families():
     short = list(sets); short[0] = sets[0][:4] + (sets[0][4][:2], sets[0][5])
     with pytest.raises(ValueError, match="shorter than its slots"):
         amge._blocks_to_csr_sets(short, (nrow, ncol))
+
+
+def test_local_triplets_match_the_whole_array_statement():
+    rng = np.random.default_rng(21)
+    n_ent, nrow, ncol = 300, 500, 400
+    D = sp.random(nrow, ncol, density=0.02, random_state=4, format="csr")
+    rp, rows = ragged(rng, n_ent, nrow, 6)
+    # the columns of an entity: everything its rows touch, shuffled, plus a few more (one list is long enough for the hashed finder)
+    cols = []
+    for e in range(n_ent):
+        c = np.unique(np.concatenate([D.indices[D.indptr[r]:D.indptr[r + 1]] for r in rows[rp[e]:rp[e + 1]]] + [rng.choice(ncol, 40 if e == 7 else 3)]))
+        cols.append(rng.permutation(c))
+    look = derham._Lookup(ptr_from_counts([len(c) for c in cols]), np.concatenate(cols), ncol)
+    got, ref = derham._triplets(D, rp, rows, look), derham._triplets_numpy(D, rp, rows, look)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r)
+    look.idx[look.ptr[5]:look.ptr[6]] = (look.idx[look.ptr[5]:look.ptr[6]] + 1) % ncol                 # entity 5 loses its columns
+    if rp[6] > rp[5] and np.diff(D.indptr)[rows[rp[5]:rp[6]]].sum():
+        for fn in (derham._triplets, derham._triplets_numpy):
+            with pytest.raises(ValueError, match="outside it"):
+                fn(D, rp, rows, look)
