@@ -39,6 +39,13 @@ def agglomerate_owner(n_agglomerates: int, nranks: int) -> np.ndarray:
     return (np.arange(n_agglomerates, dtype=np.int64) * nranks) // max(n_agglomerates, 1)
 
 
+def _distinct(ids, n):
+    """The distinct values of ``ids`` (all in 0 .. n-1), ascending: a marker array instead of a sort."""
+    mark = np.zeros(n, dtype=bool)
+    mark[ids] = True
+    return np.flatnonzero(mark).astype(np.int64)
+
+
 def _restrict_rows(ptr, idx, rows, col_map, sgn=None):
     q, _own = expand_ranges(ptr[rows], np.diff(ptr)[rows])
     cols = col_map[idx[q]]
@@ -71,18 +78,22 @@ def restrict_level(lv: SeqLevel, topo: dict, agglomerates: np.ndarray) -> Restri
     """The sub-level spanned by the given agglomerates of ``topo`` and the matching part of ``topo``."""
     agglomerates = np.unique(np.asarray(agglomerates, dtype=np.int64))
     js = lv.jstart
+    if agglomerates.size == topo["n"][0]:                       # every agglomerate (one rank): the level itself, numbering unchanged
+        ident = lambda n: np.arange(n, dtype=np.int64)
+        return Restriction(level=lv, topo=topo, sel=[ident(lv.n[c]) for c in range(4)], csel=[ident(topo["n"][c]) for c in range(4)],
+                           dofs=[None if j < js else ident(lv.ndof(j)) for j in range(4)])
     # ---- fine and coarse entities of the closure, ascending ----
     ap, ai, _ = topo["A"][0]
     q, _ = expand_ranges(ap[agglomerates], np.diff(ap)[agglomerates])
-    sel = [np.sort(ai[q])]
+    sel = [_distinct(ai[q], lv.n[0])]
     csel = [agglomerates]
     for c in range(3):
         p, i, _s = lv.B[c]
         q, _ = expand_ranges(p[sel[c]], np.diff(p)[sel[c]])
-        sel.append(np.unique(i[q]))
+        sel.append(_distinct(i[q], lv.n[c + 1]))
         p, i, _s = topo["B"][c]
         q, _ = expand_ranges(p[csel[c]], np.diff(p)[csel[c]])
-        csel.append(np.unique(i[q]))
+        csel.append(_distinct(i[q], topo["n"][c + 1]))
     g2l = []
     for c in range(4):
         m = np.full(lv.n[c], -1, dtype=np.int64); m[sel[c]] = np.arange(sel[c].size); g2l.append(m)
@@ -113,7 +124,7 @@ def _coarse_closure(topo: dict, agglomerates: np.ndarray) -> list:
     for c in range(3):
         p, i, _s = topo["B"][c]
         q, _ = expand_ranges(p[csel[c]], np.diff(p)[csel[c]])
-        csel.append(np.unique(i[q]))
+        csel.append(_distinct(i[q], topo["n"][c + 1]))
     return csel
 
 
@@ -241,13 +252,13 @@ def coarsen_rank(lv: SeqLevel, part: np.ndarray, rank: int, nranks: int, owner: 
     # ---- results in global numbers ----
     P, Dg, T = [None] * 4, [None] * 3, [None] * 4
     for j in range(js, 4):
-        Pl = res["P"][j].tocoo()
-        P[j] = sp.csr_matrix((Pl.data, (Pl.row, cdofs[j][Pl.col])), shape=(Pl.shape[0], ncoarse[j]))
+        Pl = res["P"][j].tocsr()
+        P[j] = sp.csr_matrix((Pl.data.copy(), cdofs[j][Pl.indices], Pl.indptr.copy()), shape=(Pl.shape[0], ncoarse[j]))   # (sorted in place below)
         P[j].sort_indices()
         T[j] = cl.T[j]
         if j < 3:
-            Dl = cl.D[j].tocoo()
-            Dg[j] = sp.csr_matrix((Dl.data, (Dl.row, cdofs[j][Dl.col])), shape=(Dl.shape[0], ncoarse[j]))
+            Dl = cl.D[j].tocsr()
+            Dg[j] = sp.csr_matrix((Dl.data.copy(), cdofs[j][Dl.indices], Dl.indptr.copy()), shape=(Dl.shape[0], ncoarse[j]))
             Dg[j].sort_indices()
     blocks = {(j, c): cl.M[j][c] for j, c in keys}
     return RankPiece(rank=rank, agglomerates=mine, fine_dofs=R.dofs, coarse_dofs=cdofs, P=P, D=Dg, T=T, const3=cl.const3, csel=R.csel,
@@ -292,23 +303,36 @@ def merge_pieces(lv: SeqLevel, topo: dict, pieces: list, atol: float = 0.0) -> d
     const3 = np.zeros(nco[3])
 
     def stack_rows(nrows, ncols, items):
-        """items: (global rows, csr) per rank; first writer wins."""
+        """items: (global rows, csr) per rank; first writer wins.  The rows are copied straight into the CSR arrays of the result."""
         taken = np.zeros(nrows, dtype=bool)
-        r_, c_, v_ = [], [], []
+        cnt = np.zeros(nrows, dtype=np.int64)
+        chosen = []
         for rows, mat in items:
+            mat = mat.tocsr()
             new = ~taken[rows]
-            if atol and np.any(~new) and r_:
-                cur = sp.csr_matrix((np.concatenate(v_), (np.concatenate(r_), np.concatenate(c_))), shape=(nrows, ncols))
+            if atol and np.any(~new) and chosen:
+                cur = assemble(nrows, ncols, cnt, chosen)
                 d = abs(cur[rows[~new]] - mat[np.nonzero(~new)[0]])
                 if d.nnz and d.max() > atol:
                     raise RuntimeError(f"merge_pieces: ranks disagree on shared rows by {d.max():.3e}")
-            sub = mat[np.nonzero(new)[0]].tocoo()
-            r_.append(rows[new][sub.row]); c_.append(sub.col); v_.append(sub.data)
+            loc = np.flatnonzero(new)
+            cnt[rows[loc]] = np.diff(mat.indptr)[loc]
+            chosen.append((rows[loc], mat, loc))
             taken[rows] = True
         if not np.all(taken):
             raise RuntimeError("merge_pieces: some rows are held by no rank")
-        out = sp.csr_matrix((np.concatenate(v_), (np.concatenate(r_), np.concatenate(c_))), shape=(nrows, ncols))
-        out.sort_indices()
+        return assemble(nrows, ncols, cnt, chosen)
+
+    def assemble(nrows, ncols, cnt, chosen):
+        indptr = ptr_from_counts(cnt)
+        indices, data = np.empty(int(indptr[-1]), dtype=np.int64), np.empty(int(indptr[-1]))
+        for grows, mat, loc in chosen:
+            n_r = np.diff(mat.indptr)[loc].astype(np.int64)
+            src, _ = expand_ranges(mat.indptr[loc].astype(np.int64), n_r)
+            dst, _ = expand_ranges(indptr[grows], n_r)
+            indices[dst] = mat.indices[src]; data[dst] = mat.data[src]
+        out = sp.csr_matrix((data, indices, indptr), shape=(nrows, ncols))
+        out.sort_indices()                                          # (a pass over the pattern; the pieces' rows come sorted)
         return out
     for j in range(js, 4):
         P[j] = stack_rows(lv.ndof(j), nco[j], [(p.fine_dofs[j], p.P[j]) for p in pieces])
