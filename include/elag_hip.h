@@ -57,10 +57,15 @@ enum {
  * "L1 Gauss-Seidel", 4 = "L1 Gauss-Seidel Truncated", 6 = "Gauss-Seidel") run as level-scheduled forward + backward sweeps with
  * the sequential loop's results ("Damping Factor" = 1.0; "Omega" free for 2 / 4 and 1.0 for 6: hypre's SSOR branches are not
  * built); 5 = "Lumped Jacobi" (mfem::HypreSmoother: l1 = A 1, then type 1); 413 = "Hypre Jacobi" (mfem::HypreDiagScale,
- * ParELAG_HypreSmootherFactory.cpp:28-31).  Kaczmarz (3), Taubin (1001) and FIR (1002) are rejected with ELAG_HIP_ERR_ARG. */
+ * ParELAG_HypreSmootherFactory.cpp:28-31); 3 = "Kaczmarz" (hypre_ParCSRRelax with the rows' squared 2-norms: level-scheduled on the
+ * rows' shared columns, the sequential loop's results; "Omega" free); 1001 = "Taubin" and 1002 = "FIR" (the polynomial smoothers of
+ * mfem::HypreSmoother with mfem's default options -- lambda 0.5, mu -0.5, 40 steps; Blackman window -- which the reference's factory
+ * cannot change, ParELAG_HypreSmootherFactory.cpp:38-40; "Cheby Poly Order" / "Cheby Poly Fraction" are FIR's order and pass band;
+ * max_eig = hypre_ParCSRMaxEigEstimateCG(A, scale 0, 10) / 2, readable and settable through the eig-estimate entry points). */
 enum {
-    ELAG_HIP_SMOOTHER_JACOBI = 0, ELAG_HIP_SMOOTHER_L1_JACOBI = 1, ELAG_HIP_SMOOTHER_L1_GS = 2, ELAG_HIP_SMOOTHER_L1_GS_TRUNCATED = 4,
-    ELAG_HIP_SMOOTHER_LUMPED_JACOBI = 5, ELAG_HIP_SMOOTHER_GS = 6, ELAG_HIP_SMOOTHER_CHEBYSHEV = 16, ELAG_HIP_SMOOTHER_HYPRE_JACOBI = 413
+    ELAG_HIP_SMOOTHER_JACOBI = 0, ELAG_HIP_SMOOTHER_L1_JACOBI = 1, ELAG_HIP_SMOOTHER_L1_GS = 2, ELAG_HIP_SMOOTHER_KACZMARZ = 3,
+    ELAG_HIP_SMOOTHER_L1_GS_TRUNCATED = 4, ELAG_HIP_SMOOTHER_LUMPED_JACOBI = 5, ELAG_HIP_SMOOTHER_GS = 6, ELAG_HIP_SMOOTHER_CHEBYSHEV = 16,
+    ELAG_HIP_SMOOTHER_HYPRE_JACOBI = 413, ELAG_HIP_SMOOTHER_TAUBIN = 1001, ELAG_HIP_SMOOTHER_FIR = 1002
 };
 
 /* --------------------------------------------------------------------------------------------------

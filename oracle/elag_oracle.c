@@ -195,6 +195,24 @@ ORC_API void orc_l1gs_sweep_omega(int n, const int *dI, const int *dJ, const dou
     }
 }
 
+/* hypre_ParCSRRelax relax_type 3 (Kaczmarz; "Kaczmarz" in src/linalg/factories/ParELAG_HypreSmootherFactory.cpp:95,113) [3P par_relax_more.c]:
+ * l1 = squared 2-norms of the rows (hypre_ParCSRComputeL1Norms option 3); per row, forward then backward over the local rows with the
+ * ghost values frozen: res = (f_i - a_i . u) / l1_i, then u_j += omega * res * a_ij for the local columns of the row. */
+ORC_API void orc_kaczmarz_sweep(int n, const int *dI, const int *dJ, const double *da,
+                                const int *oI, const int *oJ, const double *oa,
+                                const double *f, const double *l1, const double *uext, double omega, double *u)
+{
+    int i, jj, pass;
+    for (pass = 0; pass < 2; pass++)
+        for (i = pass ? n - 1 : 0; pass ? i > -1 : i < n; i += pass ? -1 : 1) {
+            double res = f[i];
+            for (jj = dI[i]; jj < dI[i + 1]; jj++) res -= da[jj] * u[dJ[jj]];
+            if (oI) for (jj = oI[i]; jj < oI[i + 1]; jj++) res -= oa[jj] * uext[oJ[jj]];
+            res /= l1[i];
+            for (jj = dI[i]; jj < dI[i + 1]; jj++) u[dJ[jj]] += omega * res * da[jj];
+        }
+}
+
 ORC_API void orc_l1gs_sweep(int n, const int *dI, const int *dJ, const double *da,
                             const int *oI, const int *oJ, const double *oa,
                             const double *f, const double *l1, const double *uext, double *u)

@@ -375,10 +375,14 @@ class OSmoother:
     """mfem::HypreSmoother as driven by HypreSmootherWrapper (ParELAG_HypreSmootherWrapper.cpp:28-34):
     types 1 (l1-Jacobi), 2 / 4 (l1-GS, l1 norms option 2 / 4, relax_weight = omega = 1), 6 (hybrid symmetric GS),
     16 (Chebyshev) and 413 ("Hypre Jacobi" = mfem::HypreDiagScale, HypreSmootherFactory.cpp:28-31).  ``iterative_mode`` as in
-    mfem::Solver.  Not restated: 0 (plain Jacobi through BoomerAMGRelax), 3 (Kaczmarz), 5 (lumped Jacobi), 1001 / 1002 (Taubin / FIR)."""
+    mfem::Solver.  Also 3 (Kaczmarz: hypre_ParCSRRelax with the rows' squared 2-norms), 5 (lumped Jacobi) and the two polynomial
+    smoothers of mfem::HypreSmoother, 1001 (Taubin: ``taubin_iter`` steps u += c r / max_eig, c alternating lambda, mu) and 1002 (FIR:
+    windowed Chebyshev low-pass of order ``order``, pass band ``fraction * max_eig``), with mfem's default options (lambda 0.5, mu -0.5,
+    40 steps, Blackman window 0.42 / 0.50 / 0.08; the reference's factory cannot set others: HypreSmootherFactory.cpp:38-40) and
+    max_eig = hypre_ParCSRMaxEigEstimateCG(A, scale 0, 10) / 2.  Not restated: 0 (plain Jacobi through BoomerAMGRelax)."""
 
     def __init__(self, A: OParCSR, type=1, sweeps=1, weight=1.0, omega=1.0, order=2, fraction=0.3,
-                 eig=None):
+                 eig=None, taubin=(0.5, -0.5, 40), window=(0.42, 0.50, 0.08)):
         self.A, self.type, self.sweeps, self.weight, self.omega = A, type, sweeps, weight, omega
         self.order, self.fraction = order, fraction
         self.iterative_mode = True
@@ -391,6 +395,20 @@ class OSmoother:
             # mfem::HypreSmoother::SetOperator: l1_norms = A * 1 (row sums, ghost columns included), then the relaxation of type 1
             self.l1 = np.zeros(n)
             A.matvec(1.0, np.ones(A.shape[1]), 0.0, self.l1)
+        if type in (1001, 1002):
+            # mfem::HypreSmoother::SetOperator: poly_scale = 0; the Taubin and FIR polynomials are defined on [0, 2]
+            self.max_eig, self.min_eig = eig if eig is not None else max_eig_estimate_cg(A, 0, 10)
+            self.max_eig /= 2.0
+            self.taubin = taubin
+            if type == 1002:                                     # SetFIRCoefficients(max_eig)
+                i = np.arange(order + 1)
+                t = i * np.pi / (order + 1)
+                win = window[0] + window[1] * np.cos(t) + window[2] * np.cos(2 * t)
+                theta = np.arccos(1.0 - 0.5 * fraction * self.max_eig)
+                ch = np.empty(order + 1)
+                ch[0] = theta / np.pi
+                ch[1:] = 2.0 * np.sin(i[1:] * theta) / (i[1:] * np.pi)
+                self.fir = win * ch
         if type == 16:
             self.max_eig, self.min_eig = eig if eig is not None else max_eig_estimate_cg(A, 1, 10)
             self.co, self.coefs = cheby_coefs(self.max_eig, self.min_eig, fraction, order)
@@ -414,6 +432,35 @@ class OSmoother:
                 L.orc_gs_sweep(C.c_int(n), _ip(A.diag.indptr), _ip(A.diag.indices), _dp(A.diag.data),
                                _ip(A.offd.indptr) if has else None, _ip(A.offd.indices) if has else None,
                                _dp(A.offd.data) if has else None, _dp(f), _dp(ue), _dp(u))
+            elif self.type == 3:
+                ue = A.ghost(u)
+                has = A.offd.shape[1] > 0
+                L.orc_kaczmarz_sweep(C.c_int(n), _ip(A.diag.indptr), _ip(A.diag.indices), _dp(A.diag.data),
+                                     _ip(A.offd.indptr) if has else None, _ip(A.offd.indices) if has else None,
+                                     _dp(A.offd.data) if has else None, _dp(f), _dp(self.l1), _dp(ue), C.c_double(self.omega), _dp(u))
+            elif self.type == 1001:                              # ParCSRRelax_Taubin
+                lam, mu, N = self.taubin
+                r = np.empty(n)
+                for i in range(N):
+                    r[:] = f
+                    A.matvec(-1.0, u, 1.0, r)
+                    coef = lam if i % 2 == 0 else mu
+                    u += coef * r / self.max_eig
+            elif self.type == 1002:                              # ParCSRRelax_FIR
+                x0 = u.copy()
+                x1 = f.copy()
+                A.matvec(-1.0, x0, 1.0, x1)
+                x1 /= -self.max_eig
+                x1 = x0 - x1
+                x3 = self.fir[0] * x0 + self.fir[1] * x1
+                for k in range(2, self.order + 1):
+                    x2 = f.copy()
+                    A.matvec(-1.0, x1, 1.0, x2)
+                    x2 /= -self.max_eig
+                    x2 = (x1 - x0) + (x1 - 2 * x2)
+                    x3 += self.fir[k] * x2
+                    x0, x1 = x1, x2
+                u[:] = x3
             elif self.type == 413:
                 L.orc_diag_scale(C.c_int(n), _ip(A.diag.indptr), _dp(A.diag.data), _dp(f), _dp(u))
             elif self.type in (2, 4):

@@ -702,7 +702,7 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
         // ---- optional internal renumbering for gather locality -------------------------------------
         // (a Gauss-Seidel sweep is defined by the caller's row order: those hierarchies keep it)
         const bool ordered_relax = opt.relax_type == ELAG_HIP_SMOOTHER_L1_GS || opt.relax_type == ELAG_HIP_SMOOTHER_L1_GS_TRUNCATED ||
-                                   opt.relax_type == ELAG_HIP_SMOOTHER_GS;
+                                   opt.relax_type == ELAG_HIP_SMOOTHER_GS || opt.relax_type == ELAG_HIP_SMOOTHER_KACZMARZ;
         ELAG_REQUIRE(!(ordered_relax && opt.reorder > 0), "reorder = 1 would change what a Gauss-Seidel sweep computes");
         const bool reorder = !A->needs_exchange() && A->global_rows == A->nrows() && D == nullptr && !ordered_relax &&
                              (opt.reorder > 0 || (opt.reorder < 0 && A->nrows() >= (1 << 18)));

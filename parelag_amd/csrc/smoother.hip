@@ -63,13 +63,36 @@ void RelaxSmoother::setup()
         zb = dev_alloc<double>((size_t)nn);
         estimate_eigs();
         compute_coefs();
+    } else if (type == ELAG_HIP_SMOOTHER_TAUBIN || type == ELAG_HIP_SMOOTHER_FIR) {
+        // mfem::HypreSmoother::SetOperator, types 1001 / 1002: poly_scale = 0, hypre_ParCSRMaxEigEstimateCG(A, 0, 10); "the Taubin and
+        // FIR polynomials are defined on [0, 2]": max_eig /= 2; FIR: window x Chebyshev coefficients
+        ELAG_REQUIRE(order >= 1, "FIR / Taubin: \"Cheby Poly Order\" must be >= 1");
+        r = dev_alloc<double>((size_t)nn);
+        za = dev_alloc<double>((size_t)nn);
+        zb = dev_alloc<double>((size_t)nn);
+        estimate_eigs();
+        max_eig /= 2.0;
+        if (!(max_eig > 0.0)) fail(ELAG_HIP_ERR_NUMERIC, "Taubin / FIR: the eigenvalue estimate is not positive (%g)", max_eig);
+        compute_fir();
     } else {
         fail(ELAG_HIP_ERR_ARG,
              "relax type %d is not available on the device: the table of ParELAG_HypreSmootherFactory.cpp:92-109 is served for "
-             "\"Jacobi\" (0), \"L1 Jacobi\" (1), \"L1 Gauss-Seidel\" (2), \"L1 Gauss-Seidel Truncated\" (4), \"Lumped Jacobi\" (5), \"Gauss-Seidel\" (6), "
-             "\"Chebyshev\" (16) and \"Hypre Jacobi\" (413)", type);
+             "\"Jacobi\" (0), \"L1 Jacobi\" (1), \"L1 Gauss-Seidel\" (2), \"Kaczmarz\" (3), \"L1 Gauss-Seidel Truncated\" (4), \"Lumped Jacobi\" (5), "
+             "\"Gauss-Seidel\" (6), \"Chebyshev\" (16), \"Hypre Jacobi\" (413), \"Taubin\" (1001) and \"FIR\" (1002)", type);
     }
     ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+}
+
+void RelaxSmoother::compute_fir()
+{
+    fir.assign((size_t)order + 1, 0.0);
+    const double theta = std::acos(1.0 - 0.5 * fraction * max_eig);          // pass band k_pb = poly_fraction * max_eig
+    for (int i = 0; i <= order; i++) {
+        const double t = (i * M_PI) / (order + 1);
+        const double win = window[0] + window[1] * std::cos(t) + window[2] * std::cos(2 * t);
+        const double ch = i == 0 ? theta / M_PI : 2.0 * std::sin(i * theta) / (i * M_PI);
+        fir[(size_t)i] = win * ch;
+    }
 }
 
 void RelaxSmoother::compute_coefs()
@@ -159,7 +182,7 @@ void RelaxSmoother::estimate_eigs()
             beta = gamma / gamma_old;
             k::vec_axpby(nn, 1.0, rv, beta, p, p);
         }
-        k::SpmvArgs a;  // s = ds .* A (ds .* p)
+        k::SpmvArgs a;  // s = ds .* A (ds .* p)        (ds == nullptr: scale = 0, s = A p)
         a.x = p; a.cs = ds; a.alpha = 1.0; a.s = ds; a.out = s;
         par_spmv(*A, a);
         k::vec_dot(nn, s, p, c.d_scalar);
@@ -182,13 +205,53 @@ void RelaxSmoother::estimate_eigs()
 
 int RelaxSmoother::flips(bool zero_guess) const
 {
-    if (type == ELAG_HIP_SMOOTHER_CHEBYSHEV) return 0;
+    if (type == ELAG_HIP_SMOOTHER_CHEBYSHEV || type == ELAG_HIP_SMOOTHER_TAUBIN || type == ELAG_HIP_SMOOTHER_FIR) return 0;
     return zero_guess ? sweeps - 1 : sweeps;
 }
 
 void RelaxSmoother::apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool /*transpose*/)
 {
     const int nn = n();
+    if (type == ELAG_HIP_SMOOTHER_TAUBIN) {
+        // mfem ParCSRRelax_Taubin: taubin_iter steps  r = f - A u;  u += c r / max_eig,  c = lambda, mu, lambda, ...
+        if (zero_guess) k::vec_fill(nn, 0.0, cur);
+        double *u = cur, *w = r;
+        for (int sw = 0; sw < sweeps; sw++)
+            for (int i = 0; i < taubin_iter; i++) {
+                const double c = ((i % 2) == 0 ? taubin_lambda : taubin_mu) / max_eig;
+                k::SpmvArgs a;
+                a.x = u; a.alpha = -c; a.f = f; a.gamma = c; a.yin = u; a.beta = 1.0; a.out = w;
+                par_spmv(*A, a);
+                std::swap(u, w);
+            }
+        if (u != cur) ELAG_HIP_CHECK(hipMemcpyAsync(cur, u, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, ctx().stream));
+        return;
+    }
+    if (type == ELAG_HIP_SMOOTHER_FIR) {
+        // mfem ParCSRRelax_FIR: x1 = x0 + (f - A x0) / m;  x3 = c0 x0 + c1 x1;  x2 = 2 x1 - x0 + 2 (f - A x1) / m;  x3 += c_k x2;  u = x3
+        if (zero_guess) k::vec_fill(nn, 0.0, cur);
+        const double m = max_eig;
+        for (int sw = 0; sw < sweeps; sw++) {
+            double *x0 = cur, *x1 = za, *x2 = zb, *x3 = r;
+            {
+                k::SpmvArgs a;
+                a.x = x0; a.alpha = -1.0 / m; a.f = f; a.gamma = 1.0 / m; a.yin = x0; a.beta = 1.0; a.out = x1;
+                par_spmv(*A, a);
+            }
+            k::vec_axpby(nn, fir[0], x0, fir[1], x1, x3);
+            for (int kk = 2; kk <= order; kk++) {
+                k::SpmvArgs a;                                    // x2 = 2 x1 + 2 (f - A x1) / m
+                a.x = x1; a.alpha = -2.0 / m; a.f = f; a.gamma = 2.0 / m; a.yin = x1; a.beta = 2.0; a.out = x2;
+                par_spmv(*A, a);
+                k::vec_axpby(nn, 1.0, x2, -1.0, x0, x2);          // x2 -= x0
+                k::vec_axpby(nn, fir[(size_t)kk], x2, 1.0, x3, x3);
+                double *old0 = x0;                                // (the old x0 -- `cur` itself the first time -- is free from here on)
+                x0 = x1; x1 = x2; x2 = old0;
+            }
+            ELAG_HIP_CHECK(hipMemcpyAsync(cur, x3, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, ctx().stream));
+        }
+        return;
+    }
     if (type != ELAG_HIP_SMOOTHER_CHEBYSHEV) {
         for (int sw = 0; sw < sweeps; sw++) {
             if (zero_guess && sw == 0) {
@@ -402,7 +465,8 @@ int elag_hip_smoother_create(elag_hip_smoother_t *out, elag_hip_parcsr_t A, int 
         ELAG_REQUIRE(out && A, "null argument");
         ELAG_REQUIRE(A->nrows() == A->ncols(), "smoother needs a square operator (%d x %d)", A->nrows(), A->ncols());
         ELAG_REQUIRE(sweeps >= 1, "Sweeps must be >= 1");
-        if (relax_type == ELAG_HIP_SMOOTHER_L1_GS || relax_type == ELAG_HIP_SMOOTHER_L1_GS_TRUNCATED || relax_type == ELAG_HIP_SMOOTHER_GS) {
+        if (relax_type == ELAG_HIP_SMOOTHER_L1_GS || relax_type == ELAG_HIP_SMOOTHER_L1_GS_TRUNCATED || relax_type == ELAG_HIP_SMOOTHER_GS ||
+            relax_type == ELAG_HIP_SMOOTHER_KACZMARZ) {
             std::unique_ptr<SweepSmoother> G(new SweepSmoother());
             G->A = A; G->type = relax_type; G->sweeps = sweeps; G->weight = damping; G->omega = omega;
             G->setup();
@@ -427,7 +491,8 @@ int elag_hip_smoother_get_eig_estimate(elag_hip_smoother_t S, double *max_eig, d
 {
     return guarded([&] {
         auto *R = dynamic_cast<RelaxSmoother *>(S);
-        ELAG_REQUIRE(R && R->type == ELAG_HIP_SMOOTHER_CHEBYSHEV, "not a Chebyshev smoother");
+        ELAG_REQUIRE(R && (R->type == ELAG_HIP_SMOOTHER_CHEBYSHEV || R->type == ELAG_HIP_SMOOTHER_TAUBIN || R->type == ELAG_HIP_SMOOTHER_FIR),
+                     "not a Chebyshev, Taubin or FIR smoother");
         if (max_eig) *max_eig = R->max_eig;
         if (min_eig) *min_eig = R->min_eig;
     });
@@ -437,9 +502,11 @@ int elag_hip_smoother_set_eig_estimate(elag_hip_smoother_t S, double max_eig, do
 {
     return guarded([&] {
         auto *R = dynamic_cast<RelaxSmoother *>(S);
-        ELAG_REQUIRE(R && R->type == ELAG_HIP_SMOOTHER_CHEBYSHEV, "not a Chebyshev smoother");
+        ELAG_REQUIRE(R && (R->type == ELAG_HIP_SMOOTHER_CHEBYSHEV || R->type == ELAG_HIP_SMOOTHER_TAUBIN || R->type == ELAG_HIP_SMOOTHER_FIR),
+                     "not a Chebyshev, Taubin or FIR smoother");
         R->max_eig = max_eig; R->min_eig = min_eig;
-        R->compute_coefs();
+        if (R->type == ELAG_HIP_SMOOTHER_CHEBYSHEV) R->compute_coefs();
+        else R->compute_fir();                                 // (max_eig is taken as given: the halved estimate)
     });
 }
 

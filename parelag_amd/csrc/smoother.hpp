@@ -3,6 +3,7 @@
 // Jacobi update never needs an extra copy pass.
 #pragma once
 #include <functional>
+#include <vector>
 
 #include "parcsr.hpp"
 
@@ -32,9 +33,15 @@ struct RelaxSmoother : elag_hip_smoother_s {
     double *dinv = nullptr;               // weight / l1   (types 0, 1)
     double *ds = nullptr;                 // 1/sqrt(a_ii)  (type 16)
     double *r = nullptr, *za = nullptr, *zb = nullptr;
+    // types 1001 / 1002 (mfem::HypreSmoother's Taubin and FIR polynomials; max_eig holds the halved estimate)
+    double taubin_lambda = 0.5, taubin_mu = -0.5;
+    int taubin_iter = 40;
+    double window[3] = {0.42, 0.50, 0.08};
+    std::vector<double> fir;
+    void compute_fir();                   // HypreSmoother::SetFIRCoefficients(max_eig)
     ~RelaxSmoother() override;
     void setup();
-    void estimate_eigs();                 // hypre_ParCSRMaxEigEstimateCG(A, scale=1, 10)
+    void estimate_eigs();                 // hypre_ParCSRMaxEigEstimateCG(A, scale = 1 (Chebyshev) or 0 (Taubin, FIR), 10)
     void compute_coefs();
     void apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose) override;
     int flips(bool zero_guess) const override;
@@ -46,8 +53,8 @@ struct RelaxSmoother : elag_hip_smoother_s {
     }
 };
 
-// hypre relax types 2 / 4 (l1 Gauss-Seidel, plain / truncated l1 norms) and 6 (hybrid symmetric Gauss-Seidel): level-scheduled
-// forward + backward sweeps in place (sweep.hip)
+// hypre relax types 2 / 4 (l1 Gauss-Seidel, plain / truncated l1 norms), 6 (hybrid symmetric Gauss-Seidel) and 3 (Kaczmarz):
+// level-scheduled forward + backward sweeps in place (sweep.hip)
 struct SweepSmoother : elag_hip_smoother_s {
     struct Segment { int first, count, max_rows; };   // steps [first, first + count); max_rows > 0: one big level (multi-workgroup launch)
     int type = 2, sweeps = 1, num_levels = 0;

@@ -43,6 +43,8 @@ typedef int int4s __attribute__((ext_vector_type(4)));
 // (every lane does it, from shuffled products), so the value is the sequential loop's.
 // MODE 0 (types 2 / 4):  u_i += (f_i - sum_k a_ik u_k - sum_g o_ig ughost_g) / l1_i
 // MODE 1 (type 6):       u_i  = (f_i - sum_{k != i} a_ik u_k - sum_g o_ig ughost_g) / a_ii      rows with a_ii == 0 (or none) skipped
+// MODE 2 (type 3):       res = (f_i - sum_k a_ik u_k - sum_g o_ig ughost_g) / |a_i|^2;  u_k += omega res a_ik for every local column k of row i
+//                        (Kaczmarz: the rows of a level share no column, so the lanes' updates never meet)
 // One chunk of up to kLPR entries of a row (lane q holds entry q: column j, value v, gathered x; lanes past the row's end hold
 // j = -1, v = x = 0): the subtraction runs over all kLPR slots in storage order, fully unrolled so that the kLPR lane
 // broadcasts are issued back to back instead of one per loop trip (a slot past the end subtracts +0.0, which leaves every
@@ -116,14 +118,14 @@ __global__ __launch_bounds__(kWideBlock) void sweep_levels_kernel(const int *__r
     const int4s sl = sched[t];
     const int row = sl.x, s = sl.y, len = sl.z;
     double res = f[row], aii = 0.0;
-    const double dr = (MODE == 0) ? d[row] : 0.0, uo = (MODE == 0) ? u[row] : 0.0;
+    const double dr = (MODE != 1) ? d[row] : 0.0, uo = (MODE == 0) ? u[row] : 0.0;
     bool have = false;
     for (int k0 = 0; k0 < len; k0 += kLPR) {
         const bool has = k0 + lane < len;
         const int j = has ? J[s + k0 + lane] : -1;
         const double v = has ? a[s + k0 + lane] : 0.0;
         const double x = has ? u[j] : 0.0;
-        ordered_chunk<MODE>(row, j, v, x, res, aii, have);
+        ordered_chunk<MODE == 1 ? 1 : 0>(row, j, v, x, res, aii, have);
     }
     if (oI) {
         const int os = oI[row], ol = oI[row + 1] - os;
@@ -133,6 +135,12 @@ __global__ __launch_bounds__(kWideBlock) void sweep_levels_kernel(const int *__r
             const double x = has ? ug[oJ[os + k0 + lane]] : 0.0;
             ordered_plain(v * x, res);
         }
+    }
+    if (MODE == 2) {
+        res /= dr;
+        for (int k0 = 0; k0 < len; k0 += kLPR)
+            if (k0 + lane < len) u[J[s + k0 + lane]] += omega * res * a[s + k0 + lane];
+        return;
     }
     if (lane == 0) {
         if (MODE == 0) { if (dr != 0.0) u[row] = uo + omega * res / dr; }
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__r
 #pragma unroll
             for (int e = 0; e < kEPL; e++) xA[q][e] = (e * kLPR + lane < slA[q].z) ? u[jA[q][e]] : 0.0;
             fr[q] = f[slA[q].x];
-            dr[q] = (MODE == 0) ? d[slA[q].x] : 0.0;
+            dr[q] = (MODE != 1) ? d[slA[q].x] : 0.0;
             uo[q] = (MODE == 0) ? u[slA[q].x] : 0.0;
         }
         // ---- what does not: the next step's entries (its slots are here already) and the slots of the step after it
@@ -212,13 +220,13 @@ __global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__r
             bool have = false;
 #pragma unroll
             for (int e = 0; e < kEPL; e++)
-                if (e * kLPR < len) ordered_chunk<MODE>(row, jA[q][e], vA[q][e], xA[q][e], res, aii, have);
+                if (e * kLPR < len) ordered_chunk<MODE == 1 ? 1 : 0>(row, jA[q][e], vA[q][e], xA[q][e], res, aii, have);
             for (int k0 = kEPL * kLPR; k0 < len; k0 += kLPR) {      // rows longer than kLPR * kEPL entries: further chunks, fetched now
                 const bool has = k0 + lane < len;
                 const int j = has ? J[s0 + k0 + lane] : -1;
                 const double v = has ? a[s0 + k0 + lane] : 0.0;
                 const double x = has ? u[j] : 0.0;
-                ordered_chunk<MODE>(row, j, v, x, res, aii, have);
+                ordered_chunk<MODE == 1 ? 1 : 0>(row, j, v, x, res, aii, have);
             }
             if (oI) {
                 const int os = oI[row], ol = oI[row + 1] - os;
@@ -229,7 +237,14 @@ __global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__r
                     ordered_plain(v * x, res);
                 }
             }
-            if (lane == 0) {
+            if (MODE == 2) {
+                res /= dr[q];
+#pragma unroll
+                for (int e = 0; e < kEPL; e++)
+                    if (e * kLPR + lane < len) u[jA[q][e]] += omega * res * vA[q][e];
+                for (int k0 = kEPL * kLPR; k0 < len; k0 += kLPR)
+                    if (k0 + lane < len) u[J[s0 + k0 + lane]] += omega * res * a[s0 + k0 + lane];
+            } else if (lane == 0) {
                 if (MODE == 0) { if (dr[q] != 0.0) u[row] = uo[q] + omega * res / dr[q]; }
                 else if (have && aii != 0.0) u[row] = res / aii;
             }
@@ -257,7 +272,12 @@ __global__ void l1_norms_ordered_kernel(int n, const int *__restrict__ I, const 
         bool neg = false, first = true;
         for (int k = I[i]; k < I[i + 1]; k++)
             if (J[k] == i) { d += fabs(a[k]); if (first) { neg = a[k] < 0.0; first = false; } }
-        if (option == 2) {
+        if (option == 3) {                                       // squared 2-norm of the row (Kaczmarz)
+            r = 0.0;
+            for (int k = I[i]; k < I[i + 1]; k++) r += a[k] * a[k];
+            if (oI) for (int k = oI[i]; k < oI[i + 1]; k++) r += oa[k] * oa[k];
+            // (the sign flip: hypre tests the first stored entry, which is the diagonal one there; here the diagonal entry found above)
+        } else if (option == 2) {
             r = d;
             if (oI) for (int k = oI[i]; k < oI[i + 1]; k++) r += fabs(oa[k]);
         } else {
@@ -288,17 +308,18 @@ SweepSmoother::~SweepSmoother() { dev_free(d_rows); dev_free(d_lev_ptr); dev_fre
 
 void SweepSmoother::setup()
 {
-    ELAG_REQUIRE(type == ELAG_HIP_SMOOTHER_L1_GS || type == ELAG_HIP_SMOOTHER_L1_GS_TRUNCATED || type == ELAG_HIP_SMOOTHER_GS,
-                 "internal: relax type %d is not a sweep", type);
+    ELAG_REQUIRE(type == ELAG_HIP_SMOOTHER_L1_GS || type == ELAG_HIP_SMOOTHER_L1_GS_TRUNCATED || type == ELAG_HIP_SMOOTHER_GS ||
+                 type == ELAG_HIP_SMOOTHER_KACZMARZ, "internal: relax type %d is not a sweep", type);
+    const bool kaczmarz = type == ELAG_HIP_SMOOTHER_KACZMARZ;
     // hypre_ParCSRRelax 2/4 and hypre_BoomerAMGRelax 6 branch on (relax_weight, omega): (1, 1) is the symmetric Gauss-Seidel of
     // every shipped parameter list ("Damping Factor" 1.0, "Omega" 1.0); the SSOR branches are not built
-    if (weight != 1.0 || (omega != 1.0 && type == ELAG_HIP_SMOOTHER_GS))
+    if (!kaczmarz && (weight != 1.0 || (omega != 1.0 && type == ELAG_HIP_SMOOTHER_GS)))
         fail(ELAG_HIP_ERR_ARG, "relax type %d: \"Damping Factor\" must be 1.0 (and \"Omega\" 1.0 for \"Gauss-Seidel\"): hypre's SSOR branches are "
              "not built; got %g / %g", type, weight, omega);
     const int n = A->nrows();
     hipStream_t st = ctx().stream;
     if (type != ELAG_HIP_SMOOTHER_GS) {
-        // mfem::HypreSmoother::SetOperator: l1_norms = hypre_ParCSRComputeL1Norms(A, type) for types 1..4
+        // mfem::HypreSmoother::SetOperator: l1_norms = hypre_ParCSRComputeL1Norms(A, type) for types 1..4 (3: the rows' squared 2-norms)
         Temp<int> bad(1);
         ELAG_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), st));
         d_l1 = dev_alloc<double>((size_t)std::max(n, 1));
@@ -307,20 +328,38 @@ void SweepSmoother::setup()
             const unsigned g = (unsigned)std::min<long long>(((long long)n + 255) / 256, 2048);
             hipLaunchKernelGGL(l1_norms_ordered_kernel, dim3(g), dim3(256), 0, st, n, (const int *)A->diag.I, (const int *)A->diag.J,
                                (const double *)A->diag.a, ho ? (const int *)A->offd.I : nullptr, ho ? (const double *)A->offd.a : nullptr, type,
-                               d_l1, bad.p);
+                               d_l1, bad.p);                     // (option = relax type: 2, 3 or 4)
             ELAG_LAUNCH_CHECK();
         }
         int nbad = 0;
         ELAG_HIP_CHECK(hipMemcpyAsync(&nbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
-        if (nbad) fail(ELAG_HIP_ERR_NUMERIC, "l1 Gauss-Seidel: matrix has %d zero l1 row norm(s)", nbad);
+        if (nbad) fail(ELAG_HIP_ERR_NUMERIC, "%s: matrix has %d zero l1 row norm(s)", kaczmarz ? "Kaczmarz" : "l1 Gauss-Seidel", nbad);
     }
     // ---- dependency levels of the symmetrised pattern, one pass over the rows ----
     std::vector<int> I = host_from_dev(A->diag.I, (size_t)n + 1);
     std::vector<int> J = host_from_dev(A->diag.J, (size_t)A->diag.nnz);
     std::vector<int> level((size_t)n, 0);     // doubles as "pending" for rows not reached yet
     int nlev = n ? 1 : 0;
-    for (int i = 0; i < n; i++) {
+    if (kaczmarz) {
+        // a Kaczmarz step reads AND writes u on the columns of its row: two rows are ordered iff they share a local column.
+        //     level(i) = 1 + max { level(k) : k < i, rows i and k share a column }
+        // through the highest level seen so far on every column; the rows of a level then share no column at all.
+        std::vector<int> col_level((size_t)std::max(A->diag.ncols, 1), -1), seen((size_t)std::max(A->diag.ncols, 1), -1);
+        for (int i = 0; i < n; i++) {
+            int lv = 0;
+            for (int k = I[(size_t)i]; k < I[(size_t)i + 1]; k++) {
+                const int j = J[(size_t)k];
+                if (seen[(size_t)j] == i) fail(ELAG_HIP_ERR_ARG, "Kaczmarz: row %d stores column %d twice", i, j);
+                seen[(size_t)j] = i;
+                lv = std::max(lv, col_level[(size_t)j] + 1);
+            }
+            level[(size_t)i] = lv;
+            nlev = std::max(nlev, lv + 1);
+            for (int k = I[(size_t)i]; k < I[(size_t)i + 1]; k++) col_level[(size_t)J[(size_t)k]] = lv;
+        }
+    }
+    for (int i = 0; i < n && !kaczmarz; i++) {
         int lv = level[(size_t)i];
         for (int k = I[(size_t)i]; k < I[(size_t)i + 1]; k++) {
             const int j = J[(size_t)k];
@@ -382,23 +421,25 @@ void SweepSmoother::launch_segment(const Segment &s, int dir, const double *f, d
     const double *oa = ho ? A->offd.a : nullptr;
     const int4s *sched = reinterpret_cast<const int4s *>(d_rows);
     const double *dd = (type == ELAG_HIP_SMOOTHER_GS) ? nullptr : d_l1;
+    const int *lev = d_lev_ptr, *Jd = A->diag.J;
+    const double *ad = A->diag.a, *ug = A->d_ghost;
     if (s.max_rows > 0) {
         // one big level (all its steps as one range): enough workgroups for one row per lane group
         const unsigned grid = (unsigned)(((long long)s.max_rows * kLPR + kWideBlock - 1) / kWideBlock);
-        if (type == ELAG_HIP_SMOOTHER_GS)
-            hipLaunchKernelGGL(sweep_levels_kernel<1>, dim3(grid), dim3(kWideBlock), 0, st, (const int *)d_lev_ptr, s.first, s.count, sched,
-                               (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, dd, (const double *)A->d_ghost, omega, u);
-        else
-            hipLaunchKernelGGL(sweep_levels_kernel<0>, dim3(grid), dim3(kWideBlock), 0, st, (const int *)d_lev_ptr, s.first, s.count, sched,
-                               (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, dd, (const double *)A->d_ghost, omega, u);
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kWideBlock), 0, st, lev, s.first, s.count, sched, Jd, ad, oI, oJ, oa, f, dd, ug, omega, u);
+        };
+        if (type == ELAG_HIP_SMOOTHER_GS) go(sweep_levels_kernel<1>);
+        else if (type == ELAG_HIP_SMOOTHER_KACZMARZ) go(sweep_levels_kernel<2>);
+        else go(sweep_levels_kernel<0>);
     } else {
         const int s_first = dir > 0 ? s.first : s.first + s.count - 1;
-        if (type == ELAG_HIP_SMOOTHER_GS)
-            hipLaunchKernelGGL(sweep_chain_kernel<1>, dim3(1), dim3(kChainBlock), 0, st, (const int *)d_lev_ptr, s_first, s.count, dir, sched,
-                               (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, dd, (const double *)A->d_ghost, omega, u);
-        else
-            hipLaunchKernelGGL(sweep_chain_kernel<0>, dim3(1), dim3(kChainBlock), 0, st, (const int *)d_lev_ptr, s_first, s.count, dir, sched,
-                               (const int *)A->diag.J, (const double *)A->diag.a, oI, oJ, oa, f, dd, (const double *)A->d_ghost, omega, u);
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(1), dim3(kChainBlock), 0, st, lev, s_first, s.count, dir, sched, Jd, ad, oI, oJ, oa, f, dd, ug, omega, u);
+        };
+        if (type == ELAG_HIP_SMOOTHER_GS) go(sweep_chain_kernel<1>);
+        else if (type == ELAG_HIP_SMOOTHER_KACZMARZ) go(sweep_chain_kernel<2>);
+        else go(sweep_chain_kernel<0>);
     }
     ELAG_LAUNCH_CHECK();
 }

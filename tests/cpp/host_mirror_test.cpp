@@ -134,7 +134,7 @@ int main()
     try { auto bad = RAP(*A, *P[1]); } catch (const std::runtime_error &) { threw = true; }
     REQUIRE(threw);
     threw = false;
-    try { HypreSmootherWrapper kz(A, 3); } catch (const std::runtime_error &) { threw = true; }  // Kaczmarz is not built
+    try { HypreSmootherWrapper kz(A, 7); } catch (const std::runtime_error &) { threw = true; }  // not in the reference's smoother table
     REQUIRE(threw);
     {
         // the reference's shipped default, "L1 Gauss-Seidel" = 2 (Create0FormParameterList.hpp:103-116): one symmetric sweep from a zero

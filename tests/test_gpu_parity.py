@@ -90,8 +90,8 @@ def test_bad_arguments_raise(la):
     bad = sp.csr_matrix((np.ones(2), np.array([0, 7]), np.array([0, 1, 2])), shape=(2, 3))
     with pytest.raises(ElagHipError):
         la.ParallelCSRMatrix.from_scipy(bad)
-    with pytest.raises(ElagHipError):   # not every entry of the reference's smoother table is built (tests/test_gpu_sweeps.py)
-        la.HypreSmootherWrapper(A, la.HYPRE_SMOOTHER_TYPES["Kaczmarz"])
+    with pytest.raises(ElagHipError):   # a relax type outside the reference's smoother table (ParELAG_HypreSmootherFactory.cpp:92-109)
+        la.HypreSmootherWrapper(A, 7)
     B = la.ParallelCSRMatrix.from_scipy(sp.eye(5, format="csr"))
     with pytest.raises(ElagHipError):
         A.matmul(B)

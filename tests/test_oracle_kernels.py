@@ -205,3 +205,65 @@ def test_index_maps():
     assert n == 3 and newp.tolist() == [0, 0, 2, 2, 1]
     I, J = orc.transpose_partitioning(np.array([1, 0, -1, 1, 0, 2]), 3)
     assert I.tolist() == [0, 2, 4, 5] and J.tolist() == [1, 4, 0, 3, 5]
+
+
+def test_kaczmarz_matches_dense_loop_and_projects():
+    """hypre_ParCSRRelax type 3 restated twice: the C loop against plain numpy on dense rows; one row step projects u onto the
+    hyperplane a_i . u = f_i (omega = 1), so a consistent system's error never grows"""
+    rng = np.random.default_rng(5)
+    n = 40
+    B = sp.random(n, n, density=0.2, random_state=rng, format="lil"); B.setdiag(rng.uniform(1, 2, n))
+    A = orc.diag_first(B.tocsr())
+    D = A.toarray()
+    for omega in (1.0, 0.7):
+        f, u = rng.standard_normal(n), rng.standard_normal(n)
+        ur = u.copy()
+        orc.OSmoother(orc.OParCSR(A), type=3, omega=omega).Mult(f, u)
+        for i in list(range(n)) + list(range(n - 1, -1, -1)):
+            res = f[i]
+            for k in range(A.indptr[i], A.indptr[i + 1]):
+                res -= A.data[k] * ur[A.indices[k]]
+            res /= np.sum(A.data[A.indptr[i]:A.indptr[i + 1]] ** 2)
+            for k in range(A.indptr[i], A.indptr[i + 1]):
+                ur[A.indices[k]] += omega * res * A.data[k]
+        assert np.allclose(u, ur, rtol=1e-13, atol=1e-13)
+    x = rng.standard_normal(n); b = D @ x
+    u = np.zeros(n); e = np.linalg.norm(x)
+    S = orc.OSmoother(orc.OParCSR(A), type=3)
+    for _ in range(4):
+        S.Mult(b, u)
+        assert np.linalg.norm(x - u) < e
+        e = np.linalg.norm(x - u)
+
+
+def test_taubin_and_fir_are_the_polynomials_they_claim(h1_k1):
+    """types 1001 / 1002 (mfem::HypreSmoother): with f = 0 a sweep is a polynomial in t = A / max_eig applied to u -- Taubin's
+    prod (1 - c_i t), FIR's sum_k c_k T_k(1 - t) with the windowed Chebyshev coefficients of the low-pass with pass band
+    acos(1 - fraction max_eig / 2)"""
+    A = h1_k1[0]
+    Ad = orc.diag_first(A)
+    lam, V = np.linalg.eigh(A.toarray())
+    rng = np.random.default_rng(8)
+    u0 = rng.standard_normal(A.shape[0])
+    S = orc.OSmoother(orc.OParCSR(Ad), type=1001)
+    assert 0.3 * lam[-1] <= 2 * S.max_eig <= 1.02 * lam[-1]
+    u = u0.copy(); S.Mult(np.zeros_like(u0), u)
+    t = lam / S.max_eig
+    p = np.ones_like(t)
+    for i in range(40):
+        p *= 1.0 - (0.5 if i % 2 == 0 else -0.5) * t
+    assert np.allclose(u, V @ (p * (V.T @ u0)), rtol=1e-9, atol=1e-9 * np.abs(u0).max())
+    for order in (1, 2, 5):
+        S = orc.OSmoother(orc.OParCSR(Ad), type=1002, order=order, fraction=0.3)
+        theta = np.arccos(1.0 - 0.5 * 0.3 * S.max_eig)
+        k = np.arange(order + 1)
+        win = 0.42 + 0.50 * np.cos(k * np.pi / (order + 1)) + 0.08 * np.cos(2 * k * np.pi / (order + 1))
+        cheb = np.r_[theta / np.pi, 2 * np.sin(k[1:] * theta) / (k[1:] * np.pi)]
+        assert np.allclose(S.fir, win * cheb, rtol=1e-14)
+        u = u0.copy(); S.Mult(np.zeros_like(u0), u)
+        t = lam / S.max_eig
+        Tk = [np.ones_like(t), 1.0 - t]                                  # x1 = x0 - A x0 / m; then x2 = 2 x1 - x0 - 2 A x1 / m = 2 (1 - t) x1 - x0
+        for _ in range(2, order + 1):
+            Tk.append(2 * (1.0 - t) * Tk[-1] - Tk[-2])
+        p = sum(S.fir[i] * Tk[i] for i in range(order + 1))
+        assert np.allclose(u, V @ (p * (V.T @ u0)), rtol=1e-9, atol=1e-9 * np.abs(u0).max())
