@@ -56,6 +56,10 @@ struct elag_hip_hierarchy_s {
     // is a linear map; B's columns are its images of the unit vectors, computed once in finalize), applied as a GEMV
     int dense_level = -1;
     double *Bdense = nullptr;
+    // resident tail: the levels from resident_top down, when every one of them is a fused launch-bound level (G / S or the Hiptmair
+    // composition) ending in a dense product, run as ONE kernel with grid-wide barriers between the products (kernels_spmv.hip)
+    int resident_top = -1;
+    k::ResidentSeq res_seq;
     // internal renumbering (elag_hip_amge_options::reorder): order[l][new] = old
     bool reordered = false;
     ParCSR *A_user = nullptr;             // level-0 operator in the caller's numbering (solver-mode residual)
@@ -68,6 +72,7 @@ struct elag_hip_hierarchy_s {
         for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);
         for (auto it = adopted.rbegin(); it != adopted.rend(); ++it) (*it)();
         for (auto &l : lev) { dev_free(l.resid); dev_free(l.sol); dev_free(l.alt); dev_free(l.tmp_resid); }
+        k::resident_free(res_seq);
         dev_free(r0); dev_free(e0); dev_free(d_order0); dev_free(p_rhs); dev_free(p_sol); dev_free(Bdense);
         for (auto *s : owned_smoothers) delete s;
         delete owned_coarse;
@@ -103,6 +108,8 @@ struct elag_hip_hierarchy_s {
         }
         for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);
         graphs.clear();
+        resident_top = -1;
+        k::resident_free(res_seq);
         bool local_only = true;   // every operator rank-local (no halo): graphs / fusion are safe even across ranks
         for (auto &L : lev) {
             if (L.A && L.A->needs_exchange()) local_only = false;
@@ -123,6 +130,7 @@ struct elag_hip_hierarchy_s {
         }
         if (A_user) k::prepare_spmv(A_user->diag);
         plan_dense_tail();
+        plan_resident();
         finalized = true;
         ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
     }
@@ -157,6 +165,80 @@ struct elag_hip_hierarchy_s {
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
         dev_free(Bt);
         dense_level = L;
+    }
+
+    // the products iterate(l, ...) would launch from level l down and up again, as a list; false when a level on the way is not one of
+    // the fused launch-bound forms (or a product would not take the row-group kernel)
+    bool record(int l, const double *rhs, double *sol, double *alt, std::vector<k::ResidentOp> &ops)
+    {
+        Level &F = lev[(size_t)l];
+        const int nl = (int)lev.size();
+        k::ResidentOp op;
+        if (l == dense_level) { k::resident_op_dense(F.A->nrows(), F.A->nrows(), Bdense, rhs, sol, op); ops.push_back(op); return true; }
+        if (l == nl - 1) {
+            if (!coarse || coarse->custom_apply || coarse->replicated || !coarse->Minv) return false;
+            k::resident_op_dense(coarse->n, coarse->n, coarse->Minv, rhs, sol, op); ops.push_back(op);
+            return true;
+        }
+        Level &C = lev[(size_t)l + 1];
+        auto add = [&](const DevCSR &A, const DevCSR *offd, const k::SpmvArgs &a) {
+            if (!k::resident_op_spmv(A, offd, a, op)) return false;
+            ops.push_back(op);
+            return true;
+        };
+        if (F.G) {                                   // (the argument lists are iterate()'s)
+            k::SpmvArgs d;
+            d.x = rhs; d.alpha = 1.0; d.out = C.resid;
+            if (!add(*F.G, nullptr, d)) return false;
+            if (!record(l + 1, C.resid, C.sol, C.alt, ops)) return false;
+            k::SpmvArgs u;
+            u.x = rhs; u.cs = F.fused_dinv; u.xg = C.sol; u.alpha = -1.0; u.f = rhs; u.gamma = 2.0; u.s = F.fused_dinv; u.out = sol;
+            return add(F.A->diag, F.S.get(), u);
+        }
+        if (F.Gaux) {
+            double *cur = alt, *oth = sol;
+            const double *w = F.hipt_w;
+            k::SpmvArgs a1;
+            a1.x = rhs; a1.cs = w; a1.alpha = -1.0; a1.f = rhs; a1.gamma = 1.0; a1.out = F.tmp_resid; a1.out2 = cur;
+            k::SpmvArgs a2;
+            a2.x = F.tmp_resid; a2.alpha = 1.0; a2.yin = cur; a2.beta = 1.0; a2.out = cur;
+            k::SpmvArgs a3;
+            a3.x = cur; a3.xg = rhs; a3.alpha = -1.0; a3.out = C.resid;
+            if (!add(F.A->diag, nullptr, a1) || !add(*F.Gaux, nullptr, a2) || !add(*F.RA, F.PTneg.get(), a3)) return false;
+            if (!record(l + 1, C.resid, C.sol, C.alt, ops)) return false;
+            k::SpmvArgs a5;
+            a5.x = cur; a5.xg = C.sol; a5.alpha = -1.0; a5.f = rhs; a5.gamma = 1.0; a5.s = w; a5.yin = cur; a5.beta = 1.0; a5.out = oth;
+            k::SpmvArgs a6;
+            a6.x = oth; a6.alpha = -1.0; a6.f = rhs; a6.gamma = 1.0; a6.out = F.tmp_resid;
+            k::SpmvArgs a7;
+            a7.x = F.tmp_resid; a7.alpha = 1.0; a7.yin = oth; a7.beta = 1.0; a7.out = oth;
+            return add(F.A->diag, F.S.get(), a5) && add(F.A->diag, nullptr, a6) && add(*F.Gaux, nullptr, a7);
+        }
+        return false;
+    }
+
+    void plan_resident()
+    {
+        // OFF unless ELAG_HIP_RESIDENT=1: measured on MI355X (cube456 x3, 5 products per cycle) the grid-wide barrier costs ~20 us -- an
+        // agent-scope release / acquire has to write back and invalidate the eight XCDs' L2s, and 128-512 arrivals on one address are
+        // serialised at the memory side -- against ~4.5 us for a kernel boundary inside a replayed graph: 0.107 ms per cycle at the best
+        // grid (128 workgroups) against 0.029 ms for the five separate launches.  Kept for the record and for
+        // hardware where the trade is different; results are bit-identical either way (tests/test_gpu_parity.py).
+        const char *en = getenv("ELAG_HIP_RESIDENT");          // (read at every Finalize: a test switches it)
+        if (!(en && atoi(en)) || !all_local) return;
+        const int nl = (int)lev.size();
+        // the highest level from which everything below is recordable; level 0 takes the caller's vectors (given at launch time)
+        for (int top = 0; top < nl - 1; top++) {
+            std::vector<k::ResidentOp> ops;
+            const double *rhs = top == 0 ? k::resident_rhs() : lev[(size_t)top].resid;
+            double *sol = top == 0 ? k::resident_sol() : lev[(size_t)top].sol;
+            if (!record(top, rhs, sol, lev[(size_t)top].alt, ops) || ops.size() < 3) continue;
+            k::resident_build(ops, res_seq);
+            resident_top = top;
+            if (getenv("ELAG_HIP_RESIDENT_VERBOSE"))
+                fprintf(stderr, "[elag_hip] resident tail from level %d: %d products in one launch of %u workgroups\n", top, (int)ops.size(), res_seq.grid);
+            return;
+        }
     }
 
     void plan_fused()
@@ -242,6 +324,7 @@ struct elag_hip_hierarchy_s {
     {
         Level &F = lev[(size_t)l];
         const int nl = (int)lev.size();
+        if (l == resident_top) { k::resident_launch(res_seq, rhs, sol); return; }
         if (l == dense_level) { k::dense_gemv(F.A->nrows(), F.A->nrows(), Bdense, rhs, sol); return; }
         if (l == nl - 1) {
             if (coarse) { coarse->apply(rhs, sol); return; }

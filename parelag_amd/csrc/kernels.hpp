@@ -1,6 +1,8 @@
 // Host-callable launchers of the hand-written gfx950 kernels (defined in kernels_*.hip).
 // Everything is enqueued on ctx().stream unless a stream is passed explicitly.
 #pragma once
+#include <cstdint>
+#include <vector>
 #include "common.hpp"
 
 namespace elag {
@@ -35,6 +37,35 @@ struct SpmvArgs {
     const double *out_add = nullptr;
 };
 void spmv_fused(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, hipStream_t st = nullptr);
+// A dependent chain of launch-bound products as ONE kernel with grid-wide barriers in between (kernels_spmv.hip, "Resident sequence").
+// Pointers equal to resident_rhs() / resident_sol() in an op's arguments stand for the vectors given at launch time.
+struct ResidentOp {
+    int kind = 0;                    // 0: CSR row-group product (spmv_fused on the row-group kernel), 1 / 2: dense product (workgroup / wavefront per row)
+    int lpr = 1, has_offd = 0, has_cs = 0;
+    int nrows = 0, ncols = 0;
+    const int *I = nullptr, *J = nullptr;
+    const double *a = nullptr;
+    const int *oI = nullptr, *oJ = nullptr;
+    const double *oa = nullptr;
+    const double *M = nullptr;       // dense, row-major nrows x ncols
+    SpmvArgs p;
+};
+struct ResidentSeq {
+    ResidentOp *d_ops = nullptr;
+    int nops = 0;
+    unsigned *d_bar = nullptr;       // arrivals, generation
+    int *d_err = nullptr;            // set when a barrier wait ran out
+    unsigned grid = 0;
+};
+constexpr uintptr_t kResidentRhs = 8, kResidentSol = 16;
+inline const double *resident_rhs() { return reinterpret_cast<const double *>(kResidentRhs); }
+inline double *resident_sol() { return reinterpret_cast<double *>(kResidentSol); }
+bool resident_op_spmv(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, ResidentOp &op);   // false: spmv_fused would not take the row-group kernel
+void resident_op_dense(int nrows, int ncols, const double *M, const double *x, double *y, ResidentOp &op);
+void resident_build(const std::vector<ResidentOp> &ops, ResidentSeq &seq);
+void resident_free(ResidentSeq &seq);
+void resident_launch(const ResidentSeq &seq, const double *rhs, double *sol, hipStream_t st = nullptr);
+int resident_error(const ResidentSeq &seq);     // synchronous read of the error flag
 // row-block plan of the LDS-staged stream kernel (block_row, nblocks, max_row_nnz); synchronous, setup time
 void build_stream_plan(DevCSR &A);
 // builds the x-cache form of a stream-kernel matrix if it pays (synchronous, allocates: never call while capturing);

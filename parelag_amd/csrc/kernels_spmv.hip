@@ -25,18 +25,11 @@ __device__ __forceinline__ double group_reduce(double v)
     return v;
 }
 
+// one row by a group of LPR lanes (all of them active): products in lane order, group reduction, fused epilogue by lane 0
 template <int LPR, bool HAS_OFFD, bool HAS_CS>
-__global__ __launch_bounds__(kBlock) void spmv_fused_kernel(
-    int nrows, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
-    const int *__restrict__ oI, const int *__restrict__ oJ, const double *__restrict__ oa, SpmvArgs p)
+__device__ __forceinline__ void spmv_fused_row(int row, int lane, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
+                                               const int *__restrict__ oI, const int *__restrict__ oJ, const double *__restrict__ oa, const SpmvArgs &p)
 {
-    const int gid = blockIdx.x * kBlock + threadIdx.x;
-    const int grp = gid / LPR;
-    const int lane = threadIdx.x & (LPR - 1);
-    const int nsel = p.rows ? p.nrows_sel : nrows;
-    if (grp >= nsel) return;
-    const int row = p.rows ? p.rows[grp] : grp;
-
     int os = 0, oe = 0;
     if (HAS_OFFD || p.skip_rows_with_offd) {
         if (oI) { os = oI[row]; oe = oI[row + 1]; }
@@ -103,6 +96,20 @@ __global__ __launch_bounds__(kBlock) void spmv_fused_kernel(
         p.out[p.out_perm ? p.out_perm[row] : row] = p.out_add ? p.out_add[p.out_perm[row]] + t : t;
         if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
     }
+}
+
+template <int LPR, bool HAS_OFFD, bool HAS_CS>
+__global__ __launch_bounds__(kBlock) void spmv_fused_kernel(
+    int nrows, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
+    const int *__restrict__ oI, const int *__restrict__ oJ, const double *__restrict__ oa, SpmvArgs p)
+{
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int grp = gid / LPR;
+    const int lane = threadIdx.x & (LPR - 1);
+    const int nsel = p.rows ? p.nrows_sel : nrows;
+    if (grp >= nsel) return;
+    const int row = p.rows ? p.rows[grp] : grp;
+    spmv_fused_row<LPR, HAS_OFFD, HAS_CS>(row, lane, I, J, a, oI, oJ, oa, p);
 }
 
 template <int LPR>
@@ -800,6 +807,201 @@ void spmv_fused(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, hipSt
     case 32: launch_lpr<32>(A, offd, args, st); break;
     default: launch_lpr<64>(A, offd, args, st); break;
     }
+}
+
+// ================================================================================================
+// Resident sequence: a dependent chain of launch-bound products (the fused level kernels of a small hierarchy and its dense
+// tail) as ONE kernel.  Every product alone takes 4-5 us as a graph node whatever its size; here the workgroups of one launch
+// (at most two per CU, so that all of them are resident together) walk the list of products, each taking rows grid-stride, with a
+// grid-wide barrier in between: release fence, one atomic arrival per workgroup, the last one opens the next generation,
+// acquire fence.  The row arithmetic is spmv_fused_row / the dense row kernels', lane for lane, so the results are those of the
+// separate launches bit for bit.  Every wait is bounded: a workgroup that does not see the barrier open within ~2^24 polls
+// sets the error flag and leaves (so does, then, everyone else).
+// ================================================================================================
+namespace {
+
+__device__ __forceinline__ bool grid_barrier(unsigned *bar, int *err)
+{
+    // every wave waits for its own stores; the cache maintenance of the release / acquire (L2 write-back, L1 / L2 invalidate: the
+    // caches belong to the CU and the XCD, not to the wave) is done once per workgroup, by the wave that arrives at the barrier
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        ok = 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            int polls = 0;
+            while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++polls > (1 << 24)) { ok = 0; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    return ok != 0;
+}
+
+__device__ __forceinline__ const double *resident_in(const double *p, const double *rhs, const double *sol)
+{
+    const uintptr_t v = reinterpret_cast<uintptr_t>(p);
+    return v == kResidentRhs ? rhs : (v == kResidentSol ? sol : p);
+}
+
+template <int LPR>
+__device__ __forceinline__ void resident_rows(const ResidentOp &o)
+{
+    constexpr int GPB = kBlock / LPR;
+    const int lane = threadIdx.x & (LPR - 1);
+    for (int row = blockIdx.x * GPB + threadIdx.x / LPR; row < o.nrows; row += gridDim.x * GPB) {
+        if (o.has_offd) {
+            if (o.has_cs) spmv_fused_row<LPR, true, true>(row, lane, o.I, o.J, o.a, o.oI, o.oJ, o.oa, o.p);
+            else spmv_fused_row<LPR, true, false>(row, lane, o.I, o.J, o.a, o.oI, o.oJ, o.oa, o.p);
+        } else {
+            if (o.has_cs) spmv_fused_row<LPR, false, true>(row, lane, o.I, o.J, o.a, o.oI, o.oJ, o.oa, o.p);
+            else spmv_fused_row<LPR, false, false>(row, lane, o.I, o.J, o.a, o.oI, o.oJ, o.oa, o.p);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void resident_kernel(const ResidentOp *__restrict__ ops, int nops, const double *rhs, double *sol, unsigned *bar,
+                                                          int *err)
+{
+    __shared__ double sh[kBlock / 64];
+    for (int i = 0; i < nops; i++) {
+        ResidentOp o = ops[i];
+        o.p.x = resident_in(o.p.x, rhs, sol); o.p.xg = resident_in(o.p.xg, rhs, sol);
+        o.p.f = resident_in(o.p.f, rhs, sol); o.p.yin = resident_in(o.p.yin, rhs, sol);
+        o.p.out = const_cast<double *>(resident_in(o.p.out, rhs, sol));
+        o.p.out2 = const_cast<double *>(resident_in(o.p.out2, rhs, sol));
+        if (o.kind == 0) {
+            switch (o.lpr) {
+            case 1: resident_rows<1>(o); break;
+            case 2: resident_rows<2>(o); break;
+            case 4: resident_rows<4>(o); break;
+            case 8: resident_rows<8>(o); break;
+            case 16: resident_rows<16>(o); break;
+            case 32: resident_rows<32>(o); break;
+            default: resident_rows<64>(o); break;
+            }
+        } else if (o.kind == 1) {
+            // dense_gemv_row_kernel: a workgroup per row
+            const int n = o.ncols;
+            const double *x = o.p.x;
+            for (int row = blockIdx.x; row < o.nrows; row += gridDim.x) {
+                const double *m = o.M + (size_t)row * n;
+                double s = 0.0;
+                for (int j0 = threadIdx.x; j0 < n; j0 += 4 * kBlock) {
+                    const int j1 = j0 + kBlock, j2 = j0 + 2 * kBlock, j3 = j0 + 3 * kBlock;
+                    const double a0 = m[j0], b0 = x[j0];
+                    const double a1 = j1 < n ? m[j1] : 0.0, b1 = j1 < n ? x[j1] : 0.0;
+                    const double a2 = j2 < n ? m[j2] : 0.0, b2 = j2 < n ? x[j2] : 0.0;
+                    const double a3 = j3 < n ? m[j3] : 0.0, b3 = j3 < n ? x[j3] : 0.0;
+                    s += a0 * b0; s += a1 * b1; s += a2 * b2; s += a3 * b3;
+                }
+                s = group_reduce<64>(s);
+                if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+                __syncthreads();
+                if (threadIdx.x == 0) o.p.out[row] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+                __syncthreads();
+            }
+        } else {
+            // dense_gemv_kernel: a wavefront per row
+            const int n = o.ncols, lane = threadIdx.x & 63;
+            const double *x = o.p.x;
+            for (int row = (blockIdx.x * kBlock + threadIdx.x) >> 6; row < o.nrows; row += (gridDim.x * kBlock) >> 6) {
+                const double *m = o.M + (size_t)row * n;
+                double s = 0.0;
+                for (int j = lane; j < n; j += 64) s += m[j] * x[j];
+                s = group_reduce<64>(s);
+                if (lane == 0) o.p.out[row] = s;
+            }
+        }
+        if (i + 1 < nops && !grid_barrier(bar, err)) return;
+    }
+}
+
+}  // namespace
+
+bool resident_op_spmv(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, ResidentOp &op)
+{
+    // the launch spmv_fused would make must be the row-group kernel
+    const bool offd_terms = offd && offd->nnz > 0 && !args.skip_rows_with_offd;
+    if (args.rows || args.out_perm || args.out_add || args.skip_rows_with_offd) return false;
+    if (A.sign_state == 1 && !offd_terms) return false;
+    if (A.lanes_per_row == 0 && !offd_terms && A.block_row) return false;
+    int lanes = A.lanes_per_row;
+    if (lanes == 0) {
+        const double avg = A.nrows ? (double)(A.nnz + (offd ? offd->nnz : 0)) / A.nrows : 0.0;
+        lanes = 1;
+        while (lanes < 64 && 2.0 * lanes < avg) lanes <<= 1;
+    }
+    op = ResidentOp();
+    op.kind = 0; op.lpr = lanes; op.has_offd = offd_terms ? 1 : 0; op.has_cs = args.cs ? 1 : 0;
+    op.nrows = A.nrows; op.ncols = A.ncols;
+    op.I = A.I; op.J = A.J; op.a = A.a;
+    op.oI = offd ? offd->I : nullptr; op.oJ = offd ? offd->J : nullptr; op.oa = offd ? offd->a : nullptr;
+    op.p = args;
+    return true;
+}
+
+void resident_op_dense(int nrows, int ncols, const double *M, const double *x, double *y, ResidentOp &op)
+{
+    op = ResidentOp();
+    op.kind = ncols >= 256 ? 1 : 2;           // the choice of dense_gemv
+    op.nrows = nrows; op.ncols = ncols; op.M = M;
+    op.p.x = x; op.p.out = y;
+}
+
+void resident_build(const std::vector<ResidentOp> &ops, ResidentSeq &seq)
+{
+    resident_free(seq);
+    if (ops.empty()) return;
+    seq.nops = (int)ops.size();
+    seq.d_ops = reinterpret_cast<ResidentOp *>(dev_alloc<char>(sizeof(ResidentOp) * ops.size()));
+    ELAG_HIP_CHECK(hipMemcpyAsync(seq.d_ops, ops.data(), sizeof(ResidentOp) * ops.size(), hipMemcpyHostToDevice, ctx().stream));
+    seq.d_bar = dev_alloc<unsigned>(2);
+    seq.d_err = dev_alloc<int>(1);
+    ELAG_HIP_CHECK(hipMemsetAsync(seq.d_bar, 0, 2 * sizeof(unsigned), ctx().stream));
+    ELAG_HIP_CHECK(hipMemsetAsync(seq.d_err, 0, sizeof(int), ctx().stream));
+    ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    // workgroups: what the widest product can use, at most two per CU (all resident together: 8 waves per CU)
+    long long want = 1;
+    for (const ResidentOp &o : ops) {
+        const long long w = o.kind == 0 ? ((long long)o.nrows * o.lpr + kBlock - 1) / kBlock : (o.kind == 1 ? o.nrows : ((long long)o.nrows * 64 + kBlock - 1) / kBlock);
+        want = std::max(want, w);
+    }
+    const int cus = ctx().num_cus > 0 ? ctx().num_cus : 64;
+    long long cap = cus / 2;                       // (measured best on MI355X: 128 of 256 CUs -- more arrivals cost more than they compute)
+    if (const char *e = getenv("ELAG_HIP_RESIDENT_WGS")) cap = std::max(1, std::min(atoi(e), 2 * cus));
+    seq.grid = (unsigned)std::min<long long>(want, cap);
+}
+
+void resident_free(ResidentSeq &seq)
+{
+    if (seq.d_ops) dev_free(reinterpret_cast<char *&>(seq.d_ops));
+    dev_free(seq.d_bar); dev_free(seq.d_err);
+    seq = ResidentSeq();
+}
+
+void resident_launch(const ResidentSeq &seq, const double *rhs, double *sol, hipStream_t st)
+{
+    if (!st) st = ctx().stream;
+    hipLaunchKernelGGL(resident_kernel, dim3(seq.grid), dim3(kBlock), 0, st, (const ResidentOp *)seq.d_ops, seq.nops, rhs, sol, seq.d_bar, seq.d_err);
+    ELAG_LAUNCH_CHECK();
+}
+
+int resident_error(const ResidentSeq &seq)
+{
+    if (!seq.d_err) return 0;
+    int e = 0;
+    ELAG_HIP_CHECK(hipMemcpy(&e, seq.d_err, sizeof(int), hipMemcpyDeviceToHost));
+    return e;
 }
 
 // ================================================================================================

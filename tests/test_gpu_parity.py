@@ -839,3 +839,41 @@ def test_two_pass_spgemm_fallback_equals_the_single_pass_product():
         assert r.returncode == 0 and "SPGEMM_OK" in r.stdout, r.stdout + r.stderr
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1]
+
+
+def test_resident_tail_kernel_gives_the_separate_launches_bits(la, h1_k2, hdiv_k2, capfd):
+    """ELAG_HIP_RESIDENT=1: the fused launch-bound levels and the dense tail as ONE kernel with grid-wide barriers between the products
+    (off by default: the barrier costs more than a kernel boundary on this GPU).  Same lane arithmetic, so the cycle
+    is the default path's bit for bit -- H1 (G / S levels) and H(div) with Hiptmair (the six-product composition)."""
+    import os
+    rng = np.random.default_rng(41)
+
+    def cycle(build, n):
+        b = rng.uniform(-1, 1, n)
+        out = []
+        for flag in ("0", "1"):
+            os.environ["ELAG_HIP_RESIDENT"] = flag
+            os.environ["ELAG_HIP_RESIDENT_VERBOSE"] = "1"
+            try:
+                H = build()
+                x = np.full(n, 2.0)
+                H.Mult(b, x)                                     # preconditioner mode
+                H.iterative_mode = False                         # what a stationary iteration calls: sol += cycle(rhs - A sol)
+                y = np.full(n, 2.0)
+                H.Mult(b, y)
+                out.append((x, y))
+            finally:
+                os.environ.pop("ELAG_HIP_RESIDENT", None); os.environ.pop("ELAG_HIP_RESIDENT_VERBOSE", None)
+        return out
+    A, Ps, _ = h1_k2
+    dA = la.ParallelCSRMatrix.from_scipy(A); dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    (x0, y0), (x1, y1) = cycle(lambda: la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi"), A.shape[0])
+    assert np.array_equal(x0, x1) and np.array_equal(y0, y1)
+    err = capfd.readouterr().err
+    assert err.count("resident tail from level 0") == 1, err
+    A2, Ps2, Ds2, _ = hdiv_k2
+    dA2 = la.ParallelCSRMatrix.from_scipy(A2); dPs2 = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps2]
+    dDs2 = [la.ParallelCSRMatrix.from_scipy(D) for D in Ds2[:len(Ps2)]]
+    (x0, y0), (x1, y1) = cycle(lambda: la.buildHierarchyFromDeRhamSequence(dA2, dPs2, "L1 Jacobi", Ds=dDs2, aux_smoother="L1 Jacobi"), A2.shape[0])
+    assert np.array_equal(x0, x1) and np.array_equal(y0, y1)
+    assert "resident tail from level" in capfd.readouterr().err
