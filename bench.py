@@ -585,6 +585,11 @@ def main():
 
     vbytes = vcycle_bytes(level_shapes)
     ms_per_step = elapsed / args.steps * 1e3
+    # replayed hipGraph or plain stream launches: the library times a short cycle both ways at Finalize and keeps the faster
+    try:
+        launch = H.launch_mode()
+    except Exception:                                   # blocked hierarchies keep their own record
+        launch = {"hipgraph": not args.no_graph and single}
 
     # fine-level kernel at the benchmark size (cache-resident at x3)
     fine = None
@@ -851,7 +856,8 @@ def main():
                                     f"Hiptmair({args.smoother}, {args.smoother}) pre/post, dense coarse solve, b=2"),
                        "interpolators": (dar["amge"]["what"] if darcy and "amge" in dar else "nested geometric (generator)"),
                        "levels": [{"n": s[0], "nnz": s[1]} for s in level_shapes],
-                       "hipgraph": not args.no_graph and single, "parallelism": f"row-block domain decomposition x{world}"},
+                       "hipgraph": launch.get("hipgraph", False), "launch_mode": launch,
+                       "parallelism": f"row-block domain decomposition x{world}"},
             "device_ms_per_step": round(ms_dev, 5), "device_timed_steps": max(200, min(args.steps, 500)),
             "device_vcycles_per_s": round(1e3 / ms_dev, 1),
             "vcycle_algorithmic_bytes": vbytes,

@@ -298,6 +298,11 @@ ELAG_HIP_API int elag_hip_hierarchy_set_coarse_solver(elag_hip_hierarchy_t H, el
 /* Hierarchy::Finalize (:255-267): size the per-level vectors; also builds explicit P^T and, when
  * use_graph != 0, arms hipGraph capture of the whole cycle (launch-bound small levels). */
 ELAG_HIP_API int elag_hip_hierarchy_finalize(elag_hip_hierarchy_t H, int use_graph);
+/* How Finalize decided to issue a cycle when use_graph was asked for: a replayed hipGraph costs a fixed few microseconds per launch on
+ * top of its nodes, so a cycle of a handful of kernels is timed both ways at Finalize (host clock, queue drained) and the plain stream
+ * launches are kept when they are at least 5 % faster (ELAG_HIP_GRAPH_MODE=graph | eager forces either).  uses_graph: the outcome;
+ * kernels: graph nodes of one cycle (0: not counted); graph_us / launches_us: the two timings (0 when the cycle was not timed). */
+ELAG_HIP_API int elag_hip_hierarchy_launch_mode(elag_hip_hierarchy_t H, int *uses_graph, int *kernels, double *graph_us, double *launches_us);
 /* Hierarchy::Mult (:109-136): is_preconditioner != 0 -> sol = cycle(rhs); else r = rhs - A sol,
  * sol += cycle(r).  mu = 0 (V-cycle) only, as in the reference. */
 ELAG_HIP_API int elag_hip_hierarchy_apply(elag_hip_hierarchy_t H, const double *rhs, double *sol,

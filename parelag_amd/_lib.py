@@ -124,6 +124,7 @@ _SIGNATURES = {
     "elag_hip_hierarchy_set_smoothers": [_p, _i, _p, _p],
     "elag_hip_hierarchy_set_coarse_solver": [_p, _p],
     "elag_hip_hierarchy_finalize": [_p, _i],
+    "elag_hip_hierarchy_launch_mode": [_p, _p, _p, _p, _p],
     "elag_hip_hierarchy_apply": [_p, _p, _p, _i, _i],
     "elag_hip_hierarchy_destroy": [_p],
     "elag_hip_amge_default_options": [C.POINTER(AMGeOptions)],

@@ -8,6 +8,9 @@
 #include "smoother.hpp"
 #include "staging.hpp"
 
+#include <chrono>
+#include <cstring>
+
 using namespace elag;
 
 namespace {
@@ -60,6 +63,10 @@ struct elag_hip_hierarchy_s {
     // composition) ending in a dense product, run as ONE kernel with grid-wide barriers between the products (kernels_spmv.hip)
     int resident_top = -1;
     k::ResidentSeq res_seq;
+    // graph replay or plain stream launches, by measurement at Finalize (tune_launch_mode): a replayed hipGraph costs a fixed 7-9 us per
+    // launch on top of its nodes, which a cycle of a handful of kernels does not earn back (cube456 x3: 29 us replayed, 21.5 us launched)
+    int tune_nodes = 0;
+    double tune_graph_us = 0.0, tune_eager_us = 0.0;
     // internal renumbering (elag_hip_amge_options::reorder): order[l][new] = old
     bool reordered = false;
     ParCSR *A_user = nullptr;             // level-0 operator in the caller's numbering (solver-mode residual)
@@ -133,6 +140,54 @@ struct elag_hip_hierarchy_s {
         plan_resident();
         finalized = true;
         ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+        tune_graph_us = tune_eager_us = 0.0; tune_nodes = 0;
+        if (use_graph) tune_launch_mode();
+    }
+
+    // One Mult in preconditioner mode as a replayed graph and as plain launches, host clock around a drained queue (what a caller that
+    // issues cycles back to back sees, whichever side -- host or device -- is the slower one); the graph stays unless the plain launches
+    // are at least 5 % faster.  Cycles of more than 64 kernels (the Gauss-Seidel chains) are not measured: they stay graphs.
+    // ELAG_HIP_GRAPH_MODE=graph | eager forces either.
+    void tune_launch_mode()
+    {
+        const char *mode = getenv("ELAG_HIP_GRAPH_MODE");
+        if (mode && !strcmp(mode, "graph")) return;
+        if (mode && !strcmp(mode, "eager")) { use_graph = false; return; }
+        const int n = lev[0].A->nrows();
+        if (n == 0) return;
+        hipStream_t st = ctx().stream;
+        Temp<double> rhs((size_t)n), sol((size_t)n);
+        k::vec_fill(n, 1.0, rhs);
+        hipGraph_t graph = nullptr;
+        ELAG_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        try { run(rhs, sol, true); } catch (...) { (void)hipStreamEndCapture(st, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+        ELAG_HIP_CHECK(hipStreamEndCapture(st, &graph));
+        size_t nodes = 0;
+        ELAG_HIP_CHECK(hipGraphGetNodes(graph, nullptr, &nodes));
+        tune_nodes = (int)nodes;
+        if (nodes > 64) { (void)hipGraphDestroy(graph); return; }
+        hipGraphExec_t exec = nullptr;
+        ELAG_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        auto clock_us = [&](auto once) {
+            double best = 1e30;
+            for (int rep = 0; rep < 3; rep++) {
+                for (int i = 0; i < 5; i++) once();
+                ELAG_HIP_CHECK(hipStreamSynchronize(st));
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int i = 0; i < 40; i++) once();
+                ELAG_HIP_CHECK(hipStreamSynchronize(st));
+                best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 40.0);
+            }
+            return best;
+        };
+        tune_graph_us = clock_us([&] { ELAG_HIP_CHECK(hipGraphLaunch(exec, st)); });
+        tune_eager_us = clock_us([&] { run(rhs, sol, true); });
+        (void)hipGraphExecDestroy(exec);
+        if (tune_eager_us < 0.95 * tune_graph_us) use_graph = false;
+        if (getenv("ELAG_HIP_GRAPH_VERBOSE"))
+            fprintf(stderr, "[elag_hip] cycle of %d kernels: %.1f us replayed as a graph, %.1f us as plain launches -> %s\n", tune_nodes, tune_graph_us,
+                    tune_eager_us, use_graph ? "graph" : "plain launches");
     }
 
     void plan_dense_tail()
@@ -1000,6 +1055,18 @@ int elag_hip_time_hierarchy(elag_hip_hierarchy_t H, const double *rhs_dev, doubl
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         *ms_per_apply = total_ms / reps;
+    });
+}
+
+int elag_hip_hierarchy_launch_mode(elag_hip_hierarchy_t H, int *uses_graph, int *kernels, double *graph_us, double *launches_us)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(H, "null hierarchy");
+        ELAG_REQUIRE(H->finalized, "hierarchy not finalised");
+        if (uses_graph) *uses_graph = H->use_graph ? 1 : 0;
+        if (kernels) *kernels = H->tune_nodes;
+        if (graph_us) *graph_us = H->tune_graph_us;
+        if (launches_us) *launches_us = H->tune_eager_us;
     });
 }
 

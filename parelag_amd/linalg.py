@@ -506,6 +506,13 @@ class Hierarchy(_SolverBase):
         check(self._lib.elag_hip_hierarchy_get_ordering(self.h, level, _np_ptr(o)))
         return o
 
+    def launch_mode(self) -> dict:
+        """how Finalize decided to issue a cycle: replayed hipGraph or plain launches, with the two timings when it measured them"""
+        g, k = C.c_int(), C.c_int()
+        tg, te = C.c_double(), C.c_double()
+        check(self._lib.elag_hip_hierarchy_launch_mode(self.h, C.byref(g), C.byref(k), C.byref(tg), C.byref(te)))
+        return {"hipgraph": bool(g.value), "kernels_per_cycle": k.value, "graph_us": round(tg.value, 2), "plain_launches_us": round(te.value, 2)}
+
     def time_apply_internal(self, reps) -> float:
         """mean milliseconds per V-cycle on vectors in the hierarchy's own numbering (the cost inside a Krylov solve)"""
         ms = C.c_double(0)
