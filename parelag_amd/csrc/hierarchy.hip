@@ -566,6 +566,7 @@ void hierarchy_apply_raw(elag_hip_hierarchy_s *H, const double *rhs, double *sol
     H->run(rhs, sol, precond);
 }
 bool hierarchy_is_local(const elag_hip_hierarchy_s *H) { return H->all_local; }
+bool hierarchy_prefers_plain_launches(const elag_hip_hierarchy_s *H) { return H->tune_eager_us > 0.0 && !H->use_graph; }
 // A solver that iterates with a reordered hierarchy as its preconditioner can live in the hierarchy's numbering altogether:
 // the level-0 operator as the cycle runs it (same matrix as `A_user`, rows / columns permuted) and the new -> old map.
 bool hierarchy_internal_numbering(const elag_hip_hierarchy_s *H, const ParCSR *A_user, ParCSR **A_internal, const int **d_order0)

@@ -651,7 +651,9 @@ struct elag_hip_krylov_s {
     bool capturable() const
     {
         if (!use_graph || distributed() || A->needs_exchange()) return false;
-        if (prec_kind == ELAG_HIP_PREC_HIERARCHY) return hierarchy_is_local(phier);
+        // an iteration is the preconditioner's cycle plus half a dozen small kernels and a graph launch costs the same fixed few
+        // microseconds: where the hierarchy measured its cycle faster as plain launches, the iteration is issued that way too
+        if (prec_kind == ELAG_HIP_PREC_HIERARCHY) return hierarchy_is_local(phier) && !hierarchy_prefers_plain_launches(phier);
         if (prec_kind == ELAG_HIP_PREC_SMOOTHER) return !psm->A->needs_exchange() && !is_distributed(*psm->A);
         if (prec_kind == ELAG_HIP_PREC_COARSE) return !pcoarse->replicated && !pcoarse->custom_apply;
         return true;

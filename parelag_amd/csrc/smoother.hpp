@@ -100,6 +100,7 @@ void hierarchy_adopt(elag_hip_hierarchy_s *H, std::function<void()> destroy);
 // Hierarchy::Mult on device vectors without the hierarchy's own graph replay (callers that capture their own graph)
 void hierarchy_apply_raw(elag_hip_hierarchy_s *H, const double *rhs, double *sol, bool precond);
 bool hierarchy_is_local(const elag_hip_hierarchy_s *H);   // no halo exchange / collective anywhere in the cycle
+bool hierarchy_prefers_plain_launches(const elag_hip_hierarchy_s *H);   // Finalize measured the cycle faster as plain launches than as a replayed graph
 bool hierarchy_internal_numbering(const elag_hip_hierarchy_s *H, const ParCSR *A_user, ParCSR **A_internal, const int **d_order0);
 void hierarchy_apply_internal(elag_hip_hierarchy_s *H, const double *rhs_perm, double *sol_perm);
 int hierarchy_height(const elag_hip_hierarchy_s *H);
