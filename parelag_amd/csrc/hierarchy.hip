@@ -169,6 +169,15 @@ struct elag_hip_hierarchy_s {
         hipGraphExec_t exec = nullptr;
         ELAG_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         (void)hipGraphDestroy(graph);
+        {   // the fixed cost of a graph launch is 5-7 us: a cycle of more than 120 us cannot gain 5 % -- no need to spend setup time on it
+            for (int i = 0; i < 2; i++) ELAG_HIP_CHECK(hipGraphLaunch(exec, st));
+            ELAG_HIP_CHECK(hipStreamSynchronize(st));
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < 4; i++) ELAG_HIP_CHECK(hipGraphLaunch(exec, st));
+            ELAG_HIP_CHECK(hipStreamSynchronize(st));
+            tune_graph_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 4.0;
+            if (tune_graph_us > 120.0) { (void)hipGraphExecDestroy(exec); return; }
+        }
         auto clock_us = [&](auto once) {
             double best = 1e30;
             for (int rep = 0; rep < 3; rep++) {
