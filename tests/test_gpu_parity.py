@@ -877,3 +877,32 @@ def test_resident_tail_kernel_gives_the_separate_launches_bits(la, h1_k2, hdiv_k
     (x0, y0), (x1, y1) = cycle(lambda: la.buildHierarchyFromDeRhamSequence(dA2, dPs2, "L1 Jacobi", Ds=dDs2, aux_smoother="L1 Jacobi"), A2.shape[0])
     assert np.array_equal(x0, x1) and np.array_equal(y0, y1)
     assert "resident tail from level" in capfd.readouterr().err
+
+
+def test_graph_replay_and_plain_launches_are_the_same_cycle(la, h1_k2):
+    """Finalize times a short cycle as a replayed hipGraph and as plain launches and keeps the faster (elag_hip_hierarchy_launch_mode);
+    ELAG_HIP_GRAPH_MODE forces either.  The kernels are the same, so is every bit of the result; the record says what was measured."""
+    import os
+    A, Ps, _ = h1_k2
+    dA = la.ParallelCSRMatrix.from_scipy(A); dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    b = np.random.default_rng(43).uniform(-1, 1, A.shape[0])
+    outs, modes = [], {}
+    for mode in ("graph", "eager", None):
+        if mode:
+            os.environ["ELAG_HIP_GRAPH_MODE"] = mode
+        try:
+            H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi")
+        finally:
+            os.environ.pop("ELAG_HIP_GRAPH_MODE", None)
+        modes[mode] = H.launch_mode()
+        x = np.zeros(A.shape[0])
+        for _ in range(3):                                       # (a graph is captured at the first call and replayed afterwards)
+            H.Mult(b, x)
+        outs.append(x)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert modes["graph"]["hipgraph"] is True and modes["eager"]["hipgraph"] is False
+    auto = modes[None]
+    assert 0 < auto["kernels_per_cycle"] <= 16 and auto["graph_us"] > 0 and auto["plain_launches_us"] > 0
+    assert auto["hipgraph"] == (not auto["plain_launches_us"] < 0.95 * auto["graph_us"])
+    H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi", use_graph=False)
+    assert H.launch_mode() == {"hipgraph": False, "kernels_per_cycle": 0, "graph_us": 0.0, "plain_launches_us": 0.0}
