@@ -321,6 +321,7 @@ def main():
             A0.set_spmv_lanes({"stream": -2, "xc": -1}[args.roofline_form])
         ms = la.time_kernel(A0, "spmv", x, y, reps=args.roofline_reps)
         kern = A0.spmv_kernel()          # what the launch was dispatched to (the library's measured choice unless forced)
+        kwin = A0.spmv_window()          # entries per workgroup window of that kernel
         b = spmv_bytes(n, n, nnz)
         # parity of exactly the object that was timed: the device's y against scipy's product of the exported operator
         t0 = time.time()
@@ -335,7 +336,7 @@ def main():
         if args.roofline_only:
             # only the launches of the one kernel, so a rocprofv3 --stats / --pmc pass of this command sees nothing else
             # under that kernel's name
-            print(json.dumps({"roofline": {"kernel": kern, "n": n, "nnz": nnz, "bytes_per_launch": b,
+            print(json.dumps({"roofline": {"kernel": kern, "window": kwin, "n": n, "nnz": nnz, "bytes_per_launch": b,
                                            "ms_per_launch": round(ms, 5), "achieved_GBs": round(b / ms / 1e6, 1),
                                            "parity_roofline_rel_err": roof_err}}))
             return
@@ -403,8 +404,9 @@ def main():
             del hr
             if not roof_cycle_err <= 1e-10:
                 raise SystemExit("cube456 x%d V-cycle differs from the oracle by %.3e (> 1e-10)" % (k, roof_cycle_err))
-        roof = {"bound": "hbm", "kernel": f"{kern} ({kdesc}; fine-level y = A x, level-0 operator of the hierarchy; chosen by the library's setup-time "
-                                          "measurement of both forms on this operator)",
+        roof = {"bound": "hbm", "kernel": f"{kern} ({kdesc}; {kwin} entries per workgroup window; fine-level y = A x, level-0 operator of the hierarchy; chosen by "
+                                          "the library's setup-time measurement of the stream form and three x-cache window sizes on this operator)",
+                "window": kwin,
                 "parity_roofline_rel_err": roof_err, "parity_vcycle_rel_err_vs_oracle": roof_cycle_err, "forms_same_session": ab,
                 "workload": f"cube456 x{k} refines, H1 A: n={n}, nnz={nnz}",
                 "achieved": round(b / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -423,7 +425,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("n") == n and tj.get("nnz") == nnz and tj.get("kernel", "spmv_xc_kernel") == kern:
+            if tj.get("n") == n and tj.get("nnz") == nnz and tj.get("kernel", "spmv_xc_kernel") == kern and tj.get("window") == kwin:
                 # counters cannot be read from inside this process: the figure is the one RECORDED by the committed rocprofv3
                 # --pmc passes of `bench.py --roofline-only` for this kernel on this operator, not a measurement of this run
                 roof["traffic"] = tj["traffic_bytes_per_launch"]

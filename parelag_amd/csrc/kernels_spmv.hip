@@ -703,10 +703,8 @@ void prepare_spmv(const DevCSR &A, bool force)
         return;
     }
     // Heuristic mode: let the operator itself decide.  A few launches of each candidate on a scratch vector pair (HIP events
-    // on this stream, under kernel names of their own): the plain stream kernel and the x-cache form with 2048- and with
-    // 4096-entry windows (a larger window shares its gathered x among more rows: fewer distinct-column fetches in total; it
-    // also holds twice the LDS per workgroup).  The x-cache form is kept only when it is measurably faster on THIS operator
-    // and THIS device (profiles/r02_spmv_forms_*.txt).
+    // on this stream, under kernel names of their own): the plain stream kernel and the x-cache form with three window sizes.
+    // The x-cache form is kept only when it is measurably faster on THIS operator and THIS device (profiles/r02_spmv_forms_*.txt).
     Temp<double> tx((size_t)std::max(A.ncols, A.nrows)), ty((size_t)A.nrows);
     ELAG_HIP_CHECK(hipMemsetAsync(tx, 0, sizeof(double) * (size_t)std::max(A.ncols, A.nrows), st));
     SpmvArgs p;
@@ -736,9 +734,13 @@ void prepare_spmv(const DevCSR &A, bool force)
     });
     float t_best = t_stream;
     int w_best = 0;
-    const int candidates[2] = {DevCSR::kStreamNnz, 2 * DevCSR::kStreamNnz};
-    float t_w[2] = {0.f, 0.f};
-    for (int c = 0; c < 2; c++) {
+    // Window sizes: 2048 (the stream kernel's) and two that are NOT powers of two.  Consecutive workgroups start their value / position
+    // streams one window apart, and with 2^k entries per window those starts are 2^k bytes apart too -- the same few HBM channels for
+    // every workgroup in flight: measured on cube456 x5, 94-95 us with 2048-entry windows, 101 us with 4096, 86-89 us with 1536 ... 2816
+    // that are not powers of two (profiles/r02_spmv_xc_window_scan.txt).
+    const int candidates[3] = {DevCSR::kStreamNnz, 2304, 1664};
+    float t_w[3] = {0.f, 0.f, 0.f};
+    for (int c = 0; c < 3; c++) {
         if (xc_window_env() && xc_window_env() != candidates[c]) continue;
         if (!xc_build(A, candidates[c], false)) { A.xc_state = -1; continue; }
         t_w[c] = timed([&] { launch_xc(A, nullptr, p, st, true); });
@@ -749,8 +751,9 @@ void prepare_spmv(const DevCSR &A, bool force)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (getenv("ELAG_HIP_XC_VERBOSE"))
-        fprintf(stderr, "[elag_hip] SpMV forms on this operator: stream %.2f us, x-cache/2048 %.2f us, x-cache/4096 %.2f us -> %s\n", t_stream * 1e3,
-                t_w[0] * 1e3, t_w[1] * 1e3, w_best == 0 ? "stream" : (w_best == 2048 ? "x-cache/2048" : "x-cache/4096"));
+        fprintf(stderr, "[elag_hip] SpMV forms on this operator: stream %.2f us, x-cache/%d %.2f us, x-cache/%d %.2f us, x-cache/%d %.2f us -> %s%d\n",
+                t_stream * 1e3, candidates[0], t_w[0] * 1e3, candidates[1], t_w[1] * 1e3, candidates[2], t_w[2] * 1e3, w_best == 0 ? "stream " : "x-cache/",
+                w_best);
     if (w_best && !xc_build(A, w_best, false)) A.xc_state = -1;
 }
 

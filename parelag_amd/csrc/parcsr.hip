@@ -644,7 +644,8 @@ int elag_hip_parcsr_get_spmv_form(elag_hip_parcsr_t A, int *form, int *lanes)
         const DevCSR &D = A->diag;
         const bool stream = D.lanes_per_row == 0 && D.block_row;
         *form = stream ? (D.xc_state == 1 ? 2 : 1) : 0;
-        if (lanes) *lanes = D.lanes_per_row;
+        // row-group kernel: lanes per row; stream / x-cache kernels: entries per window (workgroup)
+        if (lanes) *lanes = stream ? (D.xc_state == 1 ? D.xc_window : DevCSR::kStreamNnz) : D.lanes_per_row;
     });
 }
 

@@ -273,6 +273,12 @@ class ParallelCSRMatrix:
         check(self._lib.elag_hip_parcsr_get_spmv_form(self.h, C.byref(form), C.byref(lanes)))
         return self.SPMV_FORMS[form.value] + ("<%d>" % lanes.value if form.value == 0 else "")
 
+    def spmv_window(self) -> int:
+        """entries per workgroup window of the stream / x-cache kernel ``Mult`` is dispatched to (0 for the row-group kernel)"""
+        form, lanes = C.c_int(0), C.c_int(0)
+        check(self._lib.elag_hip_parcsr_get_spmv_form(self.h, C.byref(form), C.byref(lanes)))
+        return 0 if form.value == 0 else lanes.value
+
     def get_diagonal(self):
         d = np.empty(self.Height())
         check(self._lib.elag_hip_parcsr_get_diagonal(self.h, _np_ptr(d), HOST))

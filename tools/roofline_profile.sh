@@ -46,7 +46,7 @@ for F in forms:
     write_kb, nw = pmc(f"write_{F}", "WRITE_SIZE", kern)
     traffic = factor * fetch_kb * 1024.0 + write_kb * 1024.0
     L = [f"# rocprofv3 evidence for bench.py's roofline object -- command: python3 bench.py --roofline-only" + ("" if F == "auto" else f" --roofline-form {F}"),
-         f"kernel: {full or kern}  ({'the library chose it' if F == 'auto' else 'forced'}; level-0 operator of the cube456 x5 hierarchy, n={bench['n']}, nnz={bench['nnz']})",
+         f"kernel: {full or kern}  ({'the library chose it' if F == 'auto' else 'forced'}; {bench.get('window')} entries per workgroup window; level-0 operator of the cube456 x5 hierarchy, n={bench['n']}, nnz={bench['nnz']})",
          f"parity of the timed launch vs scipy (same run): {bench['parity_roofline_rel_err']:.2e} of |A||x|",
          f"rocprofv3 --kernel-trace --stats: calls={calls}  AverageNs={avg_ns:.1f}  ({avg_ns/1e3:.2f} us)",
          f"bench.py HIP events (same run):  ms_per_launch={bench['ms_per_launch']}  ({bench['ms_per_launch']*1e3:.2f} us), algorithmic bytes/launch={bench['bytes_per_launch']}",
@@ -58,7 +58,7 @@ for F in forms:
     open(out + f"/summary_{F}.txt", "w").write("\n".join(L) + "\n")
     print("\n".join(L)); print()
     if F == "auto":
-        json.dump({"n": bench["n"], "nnz": bench["nnz"], "kernel": kern, "traffic_bytes_per_launch": int(traffic), "fetch_size_kb": fetch_kb,
+        json.dump({"n": bench["n"], "nnz": bench["nnz"], "kernel": kern, "window": bench.get("window"), "traffic_bytes_per_launch": int(traffic), "fetch_size_kb": fetch_kb,
                    "write_size_kb": write_kb, "fetch_correction_factor": factor, "rocprof_avg_ns": avg_ns,
                    "source": "RECORDED, not measured in the bench run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --roofline-only, FETCH_SIZE "
                              "calibrated per MI355X_MICROARCH.md (tools/roofline_profile.sh; summary under profiles/)"},
