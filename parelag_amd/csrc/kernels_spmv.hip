@@ -678,6 +678,13 @@ bool xc_build(const DevCSR &A, int window, bool force)
     return true;
 }
 
+int64_t xc_min_nnz()
+{
+    static int64_t v = -1;
+    if (v < 0) { const char *e = getenv("ELAG_HIP_XC_MIN_NNZ"); v = e ? atoll(e) : (int64_t(1) << 22); }
+    return v;
+}
+
 int xc_window_env()
 {
     static int v = -1;
@@ -692,10 +699,11 @@ void prepare_spmv(const DevCSR &A, bool force)
     if (A.xc_state != 0 || (xc_mode() == 0 && !force)) return;
     A.xc_state = -1;
     if (A.lanes_per_row != 0 || !A.block_row || A.nnz == 0 || A.nblocks == 0) return;
-    // Measured: the form pays only for operators streamed from HBM (cube456 x5, 37.7 M entries); operators that stay resident
-    // in the 256 MB Infinity Cache (x3 / x4 sizes) run 2-5 % faster with the plain stream kernel, whose single phase hides
-    // the cache latency better.
-    if (!force && xc_mode() < 0 && A.nnz < (int64_t(1) << 24)) return;
+    // Operators of fewer than 2^22 entries are not measured (ELAG_HIP_XC_MIN_NNZ): they are launch / latency-bound, and a measurement
+    // costs three sorted window plans.  From there up the measurement decides: with windows that are not powers of two the form also
+    // wins on operators resident in the Infinity Cache (cube456 x5 level 1, 4.8 M entries: 13.5 against 15.0 us; round 1 found the
+    // opposite with 2048-entry windows).
+    if (!force && xc_mode() < 0 && A.nnz < xc_min_nnz()) return;
     hipStream_t st = ctx().stream;
     if (force || xc_mode() >= 0) {
         const int w = xc_window_env() ? xc_window_env() : 2304;      // forced without a measurement: the window that measures best on MI355X
