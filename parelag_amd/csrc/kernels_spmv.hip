@@ -681,7 +681,7 @@ bool xc_build(const DevCSR &A, int window, bool force)
 int64_t xc_min_nnz()
 {
     static int64_t v = -1;
-    if (v < 0) { const char *e = getenv("ELAG_HIP_XC_MIN_NNZ"); v = e ? atoll(e) : (int64_t(1) << 22); }
+    if (v < 0) { const char *e = getenv("ELAG_HIP_XC_MIN_NNZ"); v = e ? atoll(e) : (int64_t(1) << 21); }
     return v;
 }
 
@@ -699,7 +699,7 @@ void prepare_spmv(const DevCSR &A, bool force)
     if (A.xc_state != 0 || (xc_mode() == 0 && !force)) return;
     A.xc_state = -1;
     if (A.lanes_per_row != 0 || !A.block_row || A.nnz == 0 || A.nblocks == 0) return;
-    // Operators of fewer than 2^22 entries are not measured (ELAG_HIP_XC_MIN_NNZ): they are launch / latency-bound, and a measurement
+    // Operators of fewer than 2^21 entries are not measured (ELAG_HIP_XC_MIN_NNZ): they are launch / latency-bound, and a measurement
     // costs three sorted window plans.  From there up the measurement decides: with windows that are not powers of two the form also
     // wins on operators resident in the Infinity Cache (cube456 x5 level 1, 4.8 M entries: 13.5 against 15.0 us; round 1 found the
     // opposite with 2048-entry windows).
