@@ -300,9 +300,9 @@ ELAG_HIP_API int elag_hip_hierarchy_set_coarse_solver(elag_hip_hierarchy_t H, el
 ELAG_HIP_API int elag_hip_hierarchy_finalize(elag_hip_hierarchy_t H, int use_graph);
 /* How Finalize decided to issue a cycle when use_graph was asked for: a replayed hipGraph costs a fixed few microseconds per launch on
  * top of its nodes, so a cycle of a handful of kernels is timed both ways at Finalize (host clock, queue drained) and the plain stream
- * launches are kept when they are at least 5 % faster (ELAG_HIP_GRAPH_MODE=graph | eager forces either).  uses_graph: the outcome;
+ * launches are kept when they are at least 3 % faster (ELAG_HIP_GRAPH_MODE=graph | eager forces either).  uses_graph: the outcome;
  * kernels: graph nodes of one cycle (0: not counted); graph_us / launches_us: the two timings (launches_us 0 when only the graph was timed: cycles
- * of more than 64 kernels or longer than 120 us cannot gain 5 % from the few microseconds a graph launch costs). */
+ * of more than 64 kernels or longer than 170 us cannot gain 3 % from the few microseconds a graph launch costs). */
 ELAG_HIP_API int elag_hip_hierarchy_launch_mode(elag_hip_hierarchy_t H, int *uses_graph, int *kernels, double *graph_us, double *launches_us);
 /* Hierarchy::Mult (:109-136): is_preconditioner != 0 -> sol = cycle(rhs); else r = rhs - A sol,
  * sol += cycle(r).  mu = 0 (V-cycle) only, as in the reference. */

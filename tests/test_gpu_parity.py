@@ -903,6 +903,6 @@ def test_graph_replay_and_plain_launches_are_the_same_cycle(la, h1_k2):
     assert modes["graph"]["hipgraph"] is True and modes["eager"]["hipgraph"] is False
     auto = modes[None]
     assert 0 < auto["kernels_per_cycle"] <= 16 and auto["graph_us"] > 0 and auto["plain_launches_us"] > 0
-    assert auto["hipgraph"] == (not auto["plain_launches_us"] < 0.95 * auto["graph_us"])
+    assert auto["hipgraph"] == (not auto["plain_launches_us"] < 0.97 * auto["graph_us"])
     H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi", use_graph=False)
     assert H.launch_mode() == {"hipgraph": False, "kernels_per_cycle": 0, "graph_us": 0.0, "plain_launches_us": 0.0}
