@@ -434,6 +434,10 @@ def main():
         del Hr, A0, dAr, dPr, x, y, rhs_r, sol_r
 
     # ---------------------------------------------------------------- V-cycle workload
+    # forms 1 / 2: the relaxation inside Hiptmair, for the CPU restatement the device cycle is compared with and timed against
+    hipt_type = la.HYPRE_SMOOTHER_TYPES.get(args.smoother, 1)
+    if args.form in (1, 2) and hipt_type not in (1, 2, 4):
+        raise SystemExit("--form 1 / 2: the CPU restatement of the Hiptmair cycle exists for L1 Jacobi, L1 Gauss-Seidel and its truncated variant only")
     Ds = None
     dd_hex = None
     if darcy:
@@ -697,7 +701,7 @@ def main():
                     Ho.Mult(b, x)
             Hc = _Hc
         elif args.form in (1, 2):
-            h = oracle_hdiv_hierarchy(A, Ps, Ds)
+            h = oracle_hdiv_hierarchy(A, Ps, Ds, primary=hipt_type, aux=hipt_type)
             Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], native=True, hipt=h["hipt"])
             Hmc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], hipt=h["hipt"], omp=True)
         else:
@@ -798,7 +802,7 @@ def main():
         from tests.helpers import oracle_h1_hierarchy, oracle_hdiv_hierarchy
         xs = np.empty(A.shape[0])
         if args.form == 2:
-            h = oracle_hdiv_hierarchy(A, Ps, Ds)
+            h = oracle_hdiv_hierarchy(A, Ps, Ds, primary=hipt_type, aux=hipt_type)
             orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], hipt=h["hipt"]).apply(np.full(A.shape[0], 2.0), xs)
         else:
             h = oracle_h1_hierarchy(A, Ps, smoother=la.HYPRE_SMOOTHER_TYPES[args.smoother])
