@@ -342,3 +342,27 @@ def test_local_triplets_match_the_whole_array_statement():
         for fn in (derham._triplets, derham._triplets_numpy):
             with pytest.raises(ValueError, match="outside it"):
                 fn(D, rp, rows, look)
+
+
+def test_agglomerate_table_functions_on_empty_input():
+    """no agglomerates, no blocks, no elements: sizes come back zero and nothing is touched"""
+    import ctypes as C
+    lib = _lib.load()
+    z64 = np.zeros(1, dtype=np.int64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    e64, ed = np.zeros(0, dtype=np.int64), np.zeros(0)
+    out_ptr = np.full(1, -7, dtype=np.int64)
+    assert lib.elag_hip_host_amge_dof_agglomeration(0, p(z64), p(e64), p(z64), p(e64), 0, p(e64), p(out_ptr), p(e64), p(e64), p(e64)) == 0 and out_ptr[0] == 0
+    cb, rb = np.full(1, -7, dtype=np.int64), np.full(1, -7, dtype=np.int64)
+    assert lib.elag_hip_host_amge_boundary_traces(0, p(z64), p(e64), p(z64), p(e64), p(e64), p(z64), 1, p(ed), p(z64), p(e64), p(e64), p(cb), p(rb), None, None) == 0
+    assert cb[0] == 0 and rb[0] == 0
+    i32 = np.zeros(1, dtype=np.int32)
+    dp = np.full(1, -7, dtype=np.int64)
+    assert lib.elag_hip_host_amge_local_derivative(0, p(z64), p(e64), p(i32), p(i32), p(ed), p(z64), p(e64), p(e64), p(dp), None, None, None) == 0 and dp[0] == 0
+    assert lib.elag_hip_host_local_triplets(0, p(z64), p(e64), p(i32), p(i32), p(ed), p(z64), p(e64), p(dp), None, None, None) == 0 and dp[0] == 0
+    tp = np.full(1, -7, dtype=np.int64)
+    assert lib.elag_hip_host_amge_elem_dof_table(0, p(z64), p(e64), p(z64), p(z64), 0, p(tp), None) == 0 and tp[0] == 0
+    indptr = np.full(4, -7, dtype=np.int64)
+    assert lib.elag_hip_host_block_families_to_csr(0, None, 3, 2, p(indptr), None, None, None) == 0 and indptr.tolist() == [0, 0, 0, 0]
+    M = amge._blocks_to_csr_sets([], (3, 2))
+    assert M.shape == (3, 2) and M.nnz == 0
