@@ -57,7 +57,7 @@ struct RelaxSmoother : elag_hip_smoother_s {
 // level-scheduled forward + backward sweeps in place (sweep.hip)
 struct SweepSmoother : elag_hip_smoother_s {
     struct Segment { int first, count, max_rows; };   // steps [first, first + count); max_rows > 0: one big level (multi-workgroup launch)
-    int type = 2, sweeps = 1, num_levels = 0;
+    int type = 2, sweeps = 1, num_levels = 0, n_steps = 0;
     double weight = 1.0, omega = 1.0;
     int *d_rows = nullptr, *d_lev_ptr = nullptr;      // schedule slots (row, first entry, length, 0) by (level, row); step offsets into it
     double *d_l1 = nullptr;                           // types 2 / 4

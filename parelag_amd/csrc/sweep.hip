@@ -148,12 +148,12 @@ __global__ __launch_bounds__(kWideBlock) void sweep_levels_kernel(const int *__r
     }
 }
 
-// The chain: ONE workgroup walks a run of consecutive small levels (cut into steps of <= kStepRows rows).  What a step needs that
+// The chain: ONE workgroup walks a run of consecutive small levels (cut into steps of <= kStepRows rows; a barrier between levels only).  What a step needs that
 // does not depend on u -- its schedule slots, then the column indices and values of its rows -- is requested one and two steps
 // ahead, so that the only memory round trip left on the critical path of a step is the gather of u itself (written by the
 // previous step of this very workgroup, hence close by), followed by the ordered subtraction, the store and the barrier.
 template <int MODE>
-__global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__restrict__ step_ptr, int s_first, int s_count, int dir,
+__global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__restrict__ step_ptr, const int *__restrict__ step_first, int s_first, int s_count, int dir,
                                                                   const int4s *__restrict__ sched, const int *__restrict__ J, const double *__restrict__ a,
                                                                   const int *__restrict__ oI, const int *__restrict__ oJ, const double *__restrict__ oa,
                                                                   const double *__restrict__ f, const double *__restrict__ d, const double *__restrict__ ug,
@@ -161,14 +161,15 @@ __global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__r
 {
     __shared__ int lp[kMaxChain + 1];
     const int s_lo = dir > 0 ? s_first : s_first - (s_count - 1);
-    for (int c = threadIdx.x; c <= s_count; c += kChainBlock) lp[c] = step_ptr[s_lo + c];
+    // (top bit: this step is the first one of its dependency level)
+    for (int c = threadIdx.x; c <= s_count; c += kChainBlock) lp[c] = step_ptr[s_lo + c] | (step_first[s_lo + c] ? (int)0x80000000 : 0);
     __syncthreads();
     constexpr int NG = kChainBlock / kLPR;
     const int lane = threadIdx.x & (kLPR - 1);
     const int grp = threadIdx.x / kLPR;
     auto load_slots = [&](int c, int4s (&sl)[kUnroll]) {
         const int li = dir > 0 ? c : s_count - 1 - c;
-        const int b = lp[li], e = lp[li + 1];
+        const int b = lp[li] & 0x7fffffff, e = lp[li + 1] & 0x7fffffff;
 #pragma unroll
         for (int q = 0; q < kUnroll; q++) {
             const int t = b + grp + q * NG;
@@ -249,7 +250,12 @@ __global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__r
                 else if (have && aii != 0.0) u[row] = res / aii;
             }
         }
-        __syncthreads();
+        // the steps of ONE level are independent of each other (that is what a level is): the workgroup only has to meet where the
+        // next step belongs to another level -- within a level the waves run on, and the steps' memory round trips overlap
+        {
+            const int li = dir > 0 ? c : s_count - 1 - c;
+            if (dir > 0 ? (lp[li + 1] < 0) : (lp[li] < 0)) __syncthreads();
+        }
         // ---- rotate the pipeline
 #pragma unroll
         for (int q = 0; q < kUnroll; q++) {
@@ -383,12 +389,16 @@ void SweepSmoother::setup()
     // steps: every level cut into pieces of at most kStepRows rows (the rows of a level are independent, so the pieces may run
     // one after the other); a segment is either one big level -- all its steps as ONE multi-workgroup launch -- or a run of
     // small levels whose steps the chain workgroup walks
-    std::vector<int> step_ptr(1, 0);
+    std::vector<int> step_ptr(1, 0), step_first;
     std::vector<int> first_step((size_t)nlev + 1, 0);
     for (int l = 0; l < nlev; l++) {
         first_step[(size_t)l] = (int)step_ptr.size() - 1;
-        for (int b = ptr[(size_t)l]; b < ptr[(size_t)l + 1]; b += kStepRows) step_ptr.push_back(std::min(b + kStepRows, ptr[(size_t)l + 1]));
+        for (int b = ptr[(size_t)l]; b < ptr[(size_t)l + 1]; b += kStepRows) {
+            step_ptr.push_back(std::min(b + kStepRows, ptr[(size_t)l + 1]));
+            step_first.push_back(b == ptr[(size_t)l] ? 1 : 0);
+        }
     }
+    step_first.push_back(1);                                   // (the position after the last step)
     first_step[(size_t)nlev] = (int)step_ptr.size() - 1;
     segments.clear();
     for (int l = 0; l < nlev;) {
@@ -406,11 +416,13 @@ void SweepSmoother::setup()
         slot[(size_t)t * 4] = i; slot[(size_t)t * 4 + 1] = I[(size_t)i]; slot[(size_t)t * 4 + 2] = I[(size_t)i + 1] - I[(size_t)i];
     }
     d_rows = dev_from_host(slot.data(), slot.size());
+    n_steps = (int)step_ptr.size() - 1;
+    step_ptr.insert(step_ptr.end(), step_first.begin(), step_first.end());       // [offsets (n_steps + 1) | first-of-level flags (n_steps + 1)]
     d_lev_ptr = dev_from_host(step_ptr.data(), step_ptr.size());
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
     if (getenv("ELAG_HIP_SWEEP_VERBOSE"))
         fprintf(stderr, "[elag_hip] sweep smoother type %d: n=%d, %d dependency levels = %d steps in %d launches per direction\n", type, n, nlev,
-                (int)step_ptr.size() - 1, (int)segments.size());
+                n_steps, (int)segments.size());
 }
 
 void SweepSmoother::launch_segment(const Segment &s, int dir, const double *f, double *u)
@@ -435,7 +447,7 @@ void SweepSmoother::launch_segment(const Segment &s, int dir, const double *f, d
     } else {
         const int s_first = dir > 0 ? s.first : s.first + s.count - 1;
         auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(1), dim3(kChainBlock), 0, st, lev, s_first, s.count, dir, sched, Jd, ad, oI, oJ, oa, f, dd, ug, omega, u);
+            hipLaunchKernelGGL(kern, dim3(1), dim3(kChainBlock), 0, st, lev, lev + n_steps + 1, s_first, s.count, dir, sched, Jd, ad, oI, oJ, oa, f, dd, ug, omega, u);
         };
         if (type == ELAG_HIP_SMOOTHER_GS) go(sweep_chain_kernel<1>);
         else if (type == ELAG_HIP_SMOOTHER_KACZMARZ) go(sweep_chain_kernel<2>);
