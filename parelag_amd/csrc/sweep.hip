@@ -32,7 +32,7 @@ constexpr int kLPR = 16;           // lanes that fetch the entries of one row to
 constexpr int kUnroll = 4;         // rows a lane group has in flight at once
 constexpr int kChainBlock = 512;   // the chain workgroup: 32 lane groups (1024 threads would halve the steps but spill: 128 VGPRs per lane there)
 constexpr int kStepRows = (kChainBlock / kLPR) * kUnroll;    // rows of one chain step: 128 (a level is cut into steps of that many rows)
-constexpr int kChainRows = 4 * kStepRows;                    // levels up to this many rows are walked by the chain workgroup: 512
+constexpr int kChainRows = kStepRows;                        // levels up to this many rows (one step) are walked by the chain workgroup: measured, see setup()
 constexpr int kEPL = 2;            // entries per lane the chain keeps in flight for a row (kLPR * kEPL = 32 entries without a further fetch)
 constexpr int kWideBlock = 256;
 constexpr int kMaxChain = 4096;    // steps per chain launch (their offsets sit in LDS)
@@ -400,12 +400,18 @@ void SweepSmoother::setup()
     }
     step_first.push_back(1);                                   // (the position after the last step)
     first_step[(size_t)nlev] = (int)step_ptr.size() - 1;
+    // Levels up to chain_rows rows are walked by the chain workgroup, larger ones get a launch of their own.  Measured on MI355X
+    // (ELAG_HIP_SWEEP_CHAIN_ROWS; cube456 x3 H1 cycle / H(div) Hiptmair cycle, V-cycles per second): 8192: 179 / 19, 2048: 241 / 37,
+    // 512: 398 / 59, 256: 492 / 75, 128: 595 / 93, 64: 612 / 94, 16: 579 / 90, 1: 577 / 88 -- a chain step of 128 rows costs about
+    // what a launch costs, so a level is chained only when it fits ONE step.
+    static int chain_rows = 0;
+    if (chain_rows == 0) { const char *e = getenv("ELAG_HIP_SWEEP_CHAIN_ROWS"); chain_rows = e && atoi(e) > 0 ? atoi(e) : kChainRows; }
     segments.clear();
     for (int l = 0; l < nlev;) {
         const int sz = ptr[(size_t)l + 1] - ptr[(size_t)l];
-        if (sz > kChainRows) { segments.push_back(Segment{first_step[(size_t)l], first_step[(size_t)l + 1] - first_step[(size_t)l], sz}); l++; continue; }
+        if (sz > chain_rows) { segments.push_back(Segment{first_step[(size_t)l], first_step[(size_t)l + 1] - first_step[(size_t)l], sz}); l++; continue; }
         int m = l;
-        while (m < nlev && first_step[(size_t)m + 1] - first_step[(size_t)l] <= kMaxChain && ptr[(size_t)m + 1] - ptr[(size_t)m] <= kChainRows) m++;
+        while (m < nlev && first_step[(size_t)m + 1] - first_step[(size_t)l] <= kMaxChain && ptr[(size_t)m + 1] - ptr[(size_t)m] <= chain_rows) m++;
         segments.push_back(Segment{first_step[(size_t)l], first_step[(size_t)m] - first_step[(size_t)l], 0});
         l = m;
     }
