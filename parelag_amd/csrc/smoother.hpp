@@ -56,11 +56,13 @@ struct RelaxSmoother : elag_hip_smoother_s {
 // hypre relax types 2 / 4 (l1 Gauss-Seidel, plain / truncated l1 norms), 6 (hybrid symmetric Gauss-Seidel) and 3 (Kaczmarz):
 // level-scheduled forward + backward sweeps in place (sweep.hip)
 struct SweepSmoother : elag_hip_smoother_s {
-    struct Segment { int first, count, max_rows; };   // steps [first, first + count); max_rows > 0: one big level (multi-workgroup launch)
+    struct Segment { int first, count, max_rows, row_begin, row_end; };   // steps [first, first + count); max_rows > 0: one big level = schedule slots [row_begin, row_end) (multi-workgroup launch)
     int type = 2, sweeps = 1, num_levels = 0, n_steps = 0;
     double weight = 1.0, omega = 1.0;
     int *d_rows = nullptr, *d_lev_ptr = nullptr;      // schedule slots (row, first entry, length, 0) by (level, row); step offsets into it
     double *d_l1 = nullptr;                           // types 2 / 4
+    int *d_sJ = nullptr;                              // the first 16 entries of every row in schedule order (columns, -1 past the end; values)
+    double *d_sa = nullptr;
     std::vector<Segment> segments;
     ~SweepSmoother() override;
     void setup();

@@ -103,24 +103,30 @@ __device__ __forceinline__ void ordered_plain(double p, double &res)
     OrderedSteps<0, 0>::run(0, 0, 0.0, p, res, aii, have);
 }
 
-// One big level as a multi-workgroup launch: rows [step_ptr[first], step_ptr[first + count]) of the schedule, a lane group each.
+// One big level as a multi-workgroup launch: slots [b, e) of the schedule, a lane group each.  A launch is a chain of dependent memory
+// round trips, so what can be addressed from the slot number alone travels in the FIRST one: the slot itself and the first kLPR
+// entries of its row, kept in schedule order (sJ / sa, packed at setup; a row's further entries come from the CSR arrays).  The second
+// trip gathers u and the row's f, d, u; then the ordered subtraction and the store.
 template <int MODE>
-__global__ __launch_bounds__(kWideBlock) void sweep_levels_kernel(const int *__restrict__ step_ptr, int first, int count, const int4s *__restrict__ sched,
+__global__ __launch_bounds__(kWideBlock) void sweep_levels_kernel(int b, int e, const int4s *__restrict__ sched, const int *__restrict__ sJ,
+                                                                  const double *__restrict__ sa,
                                                                   const int *__restrict__ J, const double *__restrict__ a,
                                                                   const int *__restrict__ oI, const int *__restrict__ oJ, const double *__restrict__ oa,
                                                                   const double *__restrict__ f, const double *__restrict__ d, const double *__restrict__ ug,
                                                                   double omega, double *u)
 {
-    const int b = step_ptr[first], e = step_ptr[first + count];
     const int lane = threadIdx.x & (kLPR - 1);
     const int t = b + (int)(blockIdx.x * blockDim.x + threadIdx.x) / kLPR;
     if (t >= e) return;
     const int4s sl = sched[t];
+    const int j0 = sJ[(size_t)t * kLPR + lane];                 // -1 past the row's end
+    const double v0 = sa[(size_t)t * kLPR + lane];              // 0 there
     const int row = sl.x, s = sl.y, len = sl.z;
     double res = f[row], aii = 0.0;
     const double dr = (MODE != 1) ? d[row] : 0.0, uo = (MODE == 0) ? u[row] : 0.0;
     bool have = false;
-    for (int k0 = 0; k0 < len; k0 += kLPR) {
+    ordered_chunk<MODE == 1 ? 1 : 0>(row, j0, v0, j0 >= 0 ? u[j0] : 0.0, res, aii, have);
+    for (int k0 = kLPR; k0 < len; k0 += kLPR) {
         const bool has = k0 + lane < len;
         const int j = has ? J[s + k0 + lane] : -1;
         const double v = has ? a[s + k0 + lane] : 0.0;
@@ -138,7 +144,8 @@ __global__ __launch_bounds__(kWideBlock) void sweep_levels_kernel(const int *__r
     }
     if (MODE == 2) {
         res /= dr;
-        for (int k0 = 0; k0 < len; k0 += kLPR)
+        if (j0 >= 0) u[j0] += omega * res * v0;
+        for (int k0 = kLPR; k0 < len; k0 += kLPR)
             if (k0 + lane < len) u[J[s + k0 + lane]] += omega * res * a[s + k0 + lane];
         return;
     }
@@ -266,6 +273,19 @@ __global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__r
     }
 }
 
+// the first kLPR entries of every row in schedule order (sweep_levels_kernel's first memory round trip)
+__global__ void sched_pack_kernel(int n, const int4s *__restrict__ sched, const int *__restrict__ J, const double *__restrict__ a, int *__restrict__ sJ,
+                                  double *__restrict__ sa)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)n * kLPR; i += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(i / kLPR), q = (int)(i % kLPR);
+        const int4s sl = sched[t];
+        const bool has = q < sl.z;
+        sJ[i] = has ? J[sl.y + q] : -1;
+        sa[i] = has ? a[sl.y + q] : 0.0;
+    }
+}
+
 // hypre_ParCSRComputeL1Norms options 2 / 4 with the CPU loop's order of additions (one lane per row, storage order), so that
 // a sweep divides by the very same number: |a_ii| (+ |offd| terms; option 4: halved and dropped when small), negative where
 // the first diagonal entry is negative.
@@ -310,7 +330,7 @@ __global__ void diag_scale_kernel(int n, const int *__restrict__ I, const int *_
 
 }  // namespace
 
-SweepSmoother::~SweepSmoother() { dev_free(d_rows); dev_free(d_lev_ptr); dev_free(d_l1); }
+SweepSmoother::~SweepSmoother() { dev_free(d_rows); dev_free(d_lev_ptr); dev_free(d_l1); dev_free(d_sJ); dev_free(d_sa); }
 
 void SweepSmoother::setup()
 {
@@ -409,10 +429,10 @@ void SweepSmoother::setup()
     segments.clear();
     for (int l = 0; l < nlev;) {
         const int sz = ptr[(size_t)l + 1] - ptr[(size_t)l];
-        if (sz > chain_rows) { segments.push_back(Segment{first_step[(size_t)l], first_step[(size_t)l + 1] - first_step[(size_t)l], sz}); l++; continue; }
+        if (sz > chain_rows) { segments.push_back(Segment{first_step[(size_t)l], first_step[(size_t)l + 1] - first_step[(size_t)l], sz, ptr[(size_t)l], ptr[(size_t)l + 1]}); l++; continue; }
         int m = l;
         while (m < nlev && first_step[(size_t)m + 1] - first_step[(size_t)l] <= kMaxChain && ptr[(size_t)m + 1] - ptr[(size_t)m] <= chain_rows) m++;
-        segments.push_back(Segment{first_step[(size_t)l], first_step[(size_t)m] - first_step[(size_t)l], 0});
+        segments.push_back(Segment{first_step[(size_t)l], first_step[(size_t)m] - first_step[(size_t)l], 0, 0, 0});
         l = m;
     }
     // schedule slots: (row, first entry, row length) in level order -- one 16-byte load per row instead of three dependent ones
@@ -422,6 +442,15 @@ void SweepSmoother::setup()
         slot[(size_t)t * 4] = i; slot[(size_t)t * 4 + 1] = I[(size_t)i]; slot[(size_t)t * 4 + 2] = I[(size_t)i + 1] - I[(size_t)i];
     }
     d_rows = dev_from_host(slot.data(), slot.size());
+    dev_free(d_sJ); dev_free(d_sa);
+    d_sJ = dev_alloc<int>((size_t)std::max(n, 1) * kLPR);
+    d_sa = dev_alloc<double>((size_t)std::max(n, 1) * kLPR);
+    if (n) {
+        const unsigned g = (unsigned)std::min<long long>(((long long)n * kLPR + 255) / 256, 4096);
+        hipLaunchKernelGGL(sched_pack_kernel, dim3(g), dim3(256), 0, st, n, reinterpret_cast<const int4s *>(d_rows), (const int *)A->diag.J,
+                           (const double *)A->diag.a, d_sJ, d_sa);
+        ELAG_LAUNCH_CHECK();
+    }
     n_steps = (int)step_ptr.size() - 1;
     step_ptr.insert(step_ptr.end(), step_first.begin(), step_first.end());       // [offsets (n_steps + 1) | first-of-level flags (n_steps + 1)]
     d_lev_ptr = dev_from_host(step_ptr.data(), step_ptr.size());
@@ -445,7 +474,8 @@ void SweepSmoother::launch_segment(const Segment &s, int dir, const double *f, d
         // one big level (all its steps as one range): enough workgroups for one row per lane group
         const unsigned grid = (unsigned)(((long long)s.max_rows * kLPR + kWideBlock - 1) / kWideBlock);
         auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kWideBlock), 0, st, lev, s.first, s.count, sched, Jd, ad, oI, oJ, oa, f, dd, ug, omega, u);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kWideBlock), 0, st, s.row_begin, s.row_end, sched, (const int *)d_sJ, (const double *)d_sa, Jd, ad, oI, oJ, oa, f,
+                               dd, ug, omega, u);
         };
         if (type == ELAG_HIP_SMOOTHER_GS) go(sweep_levels_kernel<1>);
         else if (type == ELAG_HIP_SMOOTHER_KACZMARZ) go(sweep_levels_kernel<2>);
