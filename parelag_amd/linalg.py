@@ -491,6 +491,12 @@ class Hierarchy(_SolverBase):
         check(self._lib.elag_hip_hierarchy_finalize(self.h, int(use_graph)))
 
     def Mult(self, rhs, sol):
+        if type(rhs) is DeviceVector and type(sol) is DeviceVector:
+            # the launch-bound case (a cycle is a handful of 4 us kernels): no per-call work on the host beyond the call itself
+            st = self._lib.elag_hip_hierarchy_apply(self.h, rhs.ptr, sol.ptr, 0 if self.iterative_mode else 1, DEVICE)
+            if st:
+                check(st)
+            return
         pr, lr, _k1 = _vec(rhs)
         ps, ls, _k2 = _vec(sol, writable=True)
         check(self._lib.elag_hip_hierarchy_apply(self.h, pr, ps, int(self.IsPreconditioner()), _same_loc(lr, ls)))
