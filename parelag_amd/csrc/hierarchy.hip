@@ -31,6 +31,11 @@ struct Level {
     // (restricted residual in one product pair),  S = A P - W^-1 P  (prolongation + primary post-sweep in one product pair)
     std::shared_ptr<DevCSR> Gaux, RA, PTneg;
     const double *hipt_w = nullptr;
+    // launch-bound levels smoothed by one Chebyshev sweep of order <= 2 before and after (see plan_fused): the sweep is the linear map
+    // u += Sc (f - A u),  Sc = Ds (c0 I + c1 Ds A Ds) Ds  (A's pattern), so the level is two products like the diagonal case:
+    //   down:  r_c = G f,           G  = P^T - (P^T A) Sc
+    //   up:    x   = U1 f + U2 e,   U1 = Sc (2 I - A Sc),   U2 = P - Sc (A P)
+    std::shared_ptr<DevCSR> U1, U2;
 };
 
 struct GraphEntry {
@@ -132,6 +137,7 @@ struct elag_hip_hierarchy_s {
             if (L.P) { k::prepare_spmv(L.P->diag); if (L.P->diagT) k::prepare_spmv(*L.P->diagT); }
             if (L.G) k::prepare_spmv(*L.G);
             if (L.S) k::prepare_spmv(*L.S);
+            if (L.U1) k::prepare_spmv(*L.U1);
             if (L.Gaux) k::prepare_spmv(*L.Gaux);
             if (L.RA) k::prepare_spmv(*L.RA);
         }
@@ -250,6 +256,15 @@ struct elag_hip_hierarchy_s {
             ops.push_back(op);
             return true;
         };
+        if (F.U1) {
+            k::SpmvArgs d;
+            d.x = rhs; d.alpha = 1.0; d.out = C.resid;
+            if (!add(*F.G, nullptr, d)) return false;
+            if (!record(l + 1, C.resid, C.sol, C.alt, ops)) return false;
+            k::SpmvArgs u;
+            u.x = rhs; u.xg = C.sol; u.alpha = 1.0; u.out = sol;
+            return add(*F.U1, F.U2.get(), u);
+        }
         if (F.G) {                                   // (the argument lists are iterate()'s)
             k::SpmvArgs d;
             d.x = rhs; d.alpha = 1.0; d.out = C.resid;
@@ -319,6 +334,69 @@ struct elag_hip_hierarchy_s {
             Level &C = lev[(size_t)l + 1];
             F.G.reset(); F.S.reset(); F.fused_dinv = nullptr;
             F.Gaux.reset(); F.RA.reset(); F.PTneg.reset(); F.hipt_w = nullptr;
+            F.U1.reset(); F.U2.reset();
+            // ---- Chebyshev of order <= 2 on a launch-bound level below the finest ----
+            if (RelaxSmoother *cs = (!disabled && all_local && l >= 1 && F.pre && F.post) ? dynamic_cast<RelaxSmoother *>(F.pre) : nullptr) {
+                RelaxSmoother *cp = dynamic_cast<RelaxSmoother *>(F.post);
+                if (cs->type == ELAG_HIP_SMOOTHER_CHEBYSHEV && cp && cp->type == ELAG_HIP_SMOOTHER_CHEBYSHEV && cs->A == F.A && cp->A == F.A &&
+                    cs->sweeps == 1 && cp->sweeps == 1 && cs->cheby_order <= 1 && cp->cheby_order == cs->cheby_order &&
+                    cs->coefs[0] == cp->coefs[0] && cs->coefs[1] == cp->coefs[1] && F.A->offd.ncols == 0 && C.P->offd.ncols == 0 &&
+                    F.A->diag.nnz < max_nnz / 4) {
+                    const int n = F.A->nrows();
+                    C.P->ensure_transpose();
+                    try {
+                    // Sc = c0 Ds^2 + c1 Ds^2 A Ds^2
+                    std::vector<double> hds = host_from_dev((const double *)cs->ds, (size_t)n);
+                    std::vector<int> hi((size_t)n + 1), hj((size_t)n);
+                    std::vector<double> ha((size_t)n);
+                    for (int i = 0; i < n; i++) { hi[(size_t)i] = i; hj[(size_t)i] = i; ha[(size_t)i] = hds[(size_t)i] * hds[(size_t)i]; }
+                    hi[(size_t)n] = n;
+                    DevCSR Ds2, Sc;
+                    Ds2.upload(n, n, hi.data(), hj.data(), ha.data());
+                    Temp<double> ds2((size_t)n);
+                    ELAG_HIP_CHECK(hipMemcpyAsync(ds2.p, ha.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx().stream));
+                    if (cs->cheby_order == 1) {
+                        DevCSR T;
+                        k::csr_copy(F.A->diag, T);
+                        k::csr_scale_rows(T, ds2);
+                        k::csr_scale_cols(T, ds2);
+                        k::csr_add(cs->coefs[0], Ds2, cs->coefs[1], T, Sc);
+                    } else {
+                        k::csr_add(cs->coefs[0], Ds2, 0.0, Ds2, Sc);
+                    }
+                    for (int i = 0; i < n; i++) ha[(size_t)i] = 1.0;
+                    DevCSR Id;
+                    Id.upload(n, n, hi.data(), hj.data(), ha.data());
+                    // G = P^T - (P^T A) Sc
+                    {
+                        DevCSR RA, RAS;
+                        k::csr_spgemm(*C.P->diagT, F.A->diag, RA, false);
+                        k::csr_spgemm(RA, Sc, RAS, false);
+                        F.G.reset(new DevCSR());
+                        k::csr_add(1.0, *C.P->diagT, -1.0, RAS, *F.G);
+                    }
+                    // U1 = Sc (2 I - A Sc),  U2 = P - Sc (A P)
+                    {
+                        DevCSR AS, T2;
+                        k::csr_spgemm(F.A->diag, Sc, AS, false);
+                        k::csr_add(2.0, Id, -1.0, AS, T2);
+                        F.U1.reset(new DevCSR());
+                        k::csr_spgemm(Sc, T2, *F.U1);
+                        DevCSR AP, SAP;
+                        k::csr_spgemm(F.A->diag, C.P->diag, AP, false);
+                        k::csr_spgemm(Sc, AP, SAP, false);
+                        F.U2.reset(new DevCSR());
+                        k::csr_add(1.0, C.P->diag, -1.0, SAP, *F.U2);
+                    }
+                    ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+                    continue;
+                    } catch (const Error &) {
+                        // a row of one of the products expands beyond what the SpGEMM handles (operators with long rows: AMGe coarse
+                        // levels): this level keeps the separate sweeps
+                        F.G.reset(); F.U1.reset(); F.U2.reset();
+                    }
+                }
+            }
             // ---- Hiptmair(l1-Jacobi, l1-Jacobi) on a launch-bound level ----
             if (HiptmairSmoother *hs = (!disabled && all_local && F.pre && F.pre == F.post) ? dynamic_cast<HiptmairSmoother *>(F.pre) : nullptr) {
                 const double *w = (hs->primary && hs->primary->A == F.A) ? hs->primary->diag_scaling() : nullptr;
@@ -402,6 +480,16 @@ struct elag_hip_hierarchy_s {
         }
         Level &C = lev[(size_t)l + 1];
         const int n = F.A->nrows();
+        if (F.U1) {
+            k::SpmvArgs d;  // restricted residual of the zero-guess Chebyshev sweep in one product
+            d.x = rhs; d.alpha = 1.0; d.out = C.resid;
+            k::spmv_fused(*F.G, nullptr, d);
+            iterate(l + 1, C.resid, C.sol, C.alt);
+            k::SpmvArgs u;  // coarse correction and the post-sweep: x = U1 f + U2 e
+            u.x = rhs; u.xg = C.sol; u.alpha = 1.0; u.out = sol;
+            k::spmv_fused(*F.U1, F.U2.get(), u);
+            return;
+        }
         if (F.G) {
             k::SpmvArgs d;  // restricted residual of the zero-guess Jacobi sweep in one product
             d.x = rhs; d.alpha = 1.0; d.out = C.resid;

@@ -252,7 +252,7 @@ def device_hierarchy(la, A, Ps, smoother, params=None, use_graph=True):
 
 @pytest.mark.parametrize("use_graph", [False, True])
 @pytest.mark.parametrize("smoother,params", [("L1 Jacobi", {}), ("L1 Jacobi", {"Sweeps": 2, "Damping Factor": 0.9}),
-                                             ("Chebyshev", {"Cheby Poly Order": 3})])
+                                             ("Chebyshev", {"Cheby Poly Order": 3}), ("Chebyshev", {}), ("Chebyshev", {"Cheby Poly Order": 1})])
 def test_vcycle_matches_oracle(la, h1_k2, smoother, params, use_graph):
     A, Ps, _ = h1_k2
     H = device_hierarchy(la, A, Ps, smoother, params, use_graph)
