@@ -10,7 +10,7 @@
 
 namespace elag {
 
-RelaxSmoother::~RelaxSmoother() { dev_free(dinv); dev_free(ds); dev_free(r); dev_free(za); dev_free(zb); }
+RelaxSmoother::~RelaxSmoother() { dev_free(dinv); dev_free(ds); dev_free(r); dev_free(za); dev_free(zb); dev_free(ds2); dev_free(cds2); dev_free(cds); }
 
 static int read_int(int *d)
 {
@@ -111,6 +111,13 @@ void RelaxSmoother::compute_coefs()
     default: den = std::pow(de, 4) - 8 * de * de * th * th + 8 * std::pow(th, 4);
              coefs[0] = (32 * std::pow(th, 3) - 16 * de * de * th) / den;
              coefs[1] = (8 * de * de - 48 * th * th) / den; coefs[2] = 32 * th / den; coefs[3] = -8 / den; break;
+    }
+    if (type == ELAG_HIP_SMOOTHER_CHEBYSHEV && cheby_order == 1 && ds) {
+        const int nn = n();
+        if (!ds2) { ds2 = dev_alloc<double>((size_t)nn); cds2 = dev_alloc<double>((size_t)nn); cds = dev_alloc<double>((size_t)nn); }
+        k::vec_scale_mul(nn, 1.0, ds, ds, ds2);
+        k::vec_scale_mul(nn, coefs[1], ds, ds, cds2);
+        k::vec_axpby(nn, coefs[1], ds, 0.0, nullptr, cds);
     }
 }
 
@@ -271,6 +278,24 @@ void RelaxSmoother::apply(const double *f, double *&cur, double *&alt, bool zero
     const int co = cheby_order;
     for (int sw = 0; sw < sweeps; sw++) {
         const bool zero = zero_guess && sw == 0;
+        if (co == 1 && ds2) {
+            // order 2: the sweep's vector passes ride on its products.  From the zero guess
+            //   u = ds (c0 ds f + ds A (ds c1 ds f)) = ds^2 (c0 f + A (c1 ds^2 f))                                  -- one product;
+            // otherwise r = ds (f - A u), then u += ds (c0 r + ds A (c1 ds r))                                       -- two.
+            if (zero) {
+                k::SpmvArgs a;
+                a.x = f; a.cs = cds2; a.alpha = 1.0; a.f = f; a.gamma = coefs[0]; a.s = ds2; a.out = cur;
+                par_spmv(*A, a);
+            } else {
+                k::SpmvArgs a;  // r = ds .* (f - A u)
+                a.x = cur; a.alpha = -1.0; a.f = f; a.gamma = 1.0; a.s = ds; a.out = r;
+                par_spmv(*A, a);
+                k::SpmvArgs b;
+                b.x = r; b.cs = cds; b.alpha = 1.0; b.s2 = ds; b.f = r; b.gamma = coefs[0]; b.s = ds; b.yin = cur; b.beta = 1.0; b.out = cur;
+                par_spmv(*A, b);
+            }
+            continue;
+        }
         if (zero) {
             k::vec_scale_mul(nn, 1.0, f, ds, r);  // r = ds .* f
         } else {

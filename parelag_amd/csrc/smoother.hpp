@@ -33,6 +33,7 @@ struct RelaxSmoother : elag_hip_smoother_s {
     double *dinv = nullptr;               // weight / l1   (types 0, 1)
     double *ds = nullptr;                 // 1/sqrt(a_ii)  (type 16)
     double *r = nullptr, *za = nullptr, *zb = nullptr;
+    double *ds2 = nullptr, *cds2 = nullptr, *cds = nullptr;   // order 2: ds.^2, c1 ds.^2, c1 ds (the sweep's vector passes folded into its products)
     // types 1001 / 1002 (mfem::HypreSmoother's Taubin and FIR polynomials; max_eig holds the halved estimate)
     double taubin_lambda = 0.5, taubin_mu = -0.5;
     int taubin_iter = 40;
