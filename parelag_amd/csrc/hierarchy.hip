@@ -31,6 +31,9 @@ struct Level {
     // (restricted residual in one product pair),  S = A P - W^-1 P  (prolongation + primary post-sweep in one product pair)
     std::shared_ptr<DevCSR> Gaux, RA, PTneg;
     const double *hipt_w = nullptr;
+    // ... and on the smallest of them (where the denser composites still cost one launch each) four launches instead of six:
+    //   Kh = W + Gaux (I - A W)  (the whole pre-sweep from the zero guess, x = Kh f),   Mh = I - Gaux A  (x'' = Mh x' + Gaux f)
+    std::shared_ptr<DevCSR> Kh, Mh;
     // launch-bound levels smoothed by one Chebyshev sweep of order <= 2 before and after (see plan_fused): the sweep is the linear map
     // u += Sc (f - A u),  Sc = Ds (c0 I + c1 Ds A Ds) Ds  (A's pattern), so the level is two products like the diagonal case:
     //   down:  r_c = G f,           G  = P^T - (P^T A) Sc
@@ -138,6 +141,7 @@ struct elag_hip_hierarchy_s {
             if (L.G) k::prepare_spmv(*L.G);
             if (L.S) k::prepare_spmv(*L.S);
             if (L.U1) k::prepare_spmv(*L.U1);
+            if (L.Kh) { k::prepare_spmv(*L.Kh); k::prepare_spmv(*L.Mh); }
             if (L.Gaux) k::prepare_spmv(*L.Gaux);
             if (L.RA) k::prepare_spmv(*L.RA);
         }
@@ -274,6 +278,21 @@ struct elag_hip_hierarchy_s {
             u.x = rhs; u.cs = F.fused_dinv; u.xg = C.sol; u.alpha = -1.0; u.f = rhs; u.gamma = 2.0; u.s = F.fused_dinv; u.out = sol;
             return add(F.A->diag, F.S.get(), u);
         }
+        if (F.Gaux && F.Kh) {
+            double *cur = alt, *oth = sol;
+            const double *w = F.hipt_w;
+            k::SpmvArgs k1;
+            k1.x = rhs; k1.alpha = 1.0; k1.out = cur;
+            k::SpmvArgs a3;
+            a3.x = cur; a3.xg = rhs; a3.alpha = -1.0; a3.out = C.resid;
+            if (!add(*F.Kh, nullptr, k1) || !add(*F.RA, F.PTneg.get(), a3)) return false;
+            if (!record(l + 1, C.resid, C.sol, C.alt, ops)) return false;
+            k::SpmvArgs a5;
+            a5.x = cur; a5.xg = C.sol; a5.alpha = -1.0; a5.f = rhs; a5.gamma = 1.0; a5.s = w; a5.yin = cur; a5.beta = 1.0; a5.out = F.tmp_resid;
+            k::SpmvArgs m;
+            m.x = F.tmp_resid; m.xg = rhs; m.alpha = 1.0; m.out = oth;
+            return add(F.A->diag, F.S.get(), a5) && add(*F.Mh, F.Gaux.get(), m);
+        }
         if (F.Gaux) {
             double *cur = alt, *oth = sol;
             const double *w = F.hipt_w;
@@ -334,7 +353,7 @@ struct elag_hip_hierarchy_s {
             Level &C = lev[(size_t)l + 1];
             F.G.reset(); F.S.reset(); F.fused_dinv = nullptr;
             F.Gaux.reset(); F.RA.reset(); F.PTneg.reset(); F.hipt_w = nullptr;
-            F.U1.reset(); F.U2.reset();
+            F.U1.reset(); F.U2.reset(); F.Kh.reset(); F.Mh.reset();
             // ---- Chebyshev of order <= 2 on a launch-bound level below the finest ----
             if (RelaxSmoother *cs = (!disabled && all_local && l >= 1 && F.pre && F.post) ? dynamic_cast<RelaxSmoother *>(F.pre) : nullptr) {
                 RelaxSmoother *cp = dynamic_cast<RelaxSmoother *>(F.post);
@@ -428,6 +447,31 @@ struct elag_hip_hierarchy_s {
                         k::csr_add(1.0, AP, -1.0, WP, *F.S);
                     }
                     F.hipt_w = w;
+                    static long long compose_nnz = -1;
+                    if (compose_nnz < 0) { const char *e = getenv("ELAG_HIP_HIPTMAIR_COMPOSE_NNZ"); compose_nnz = e ? atoll(e) : (1ll << 17); }
+                    if (F.A->diag.nnz < compose_nnz) {
+                        try {
+                            std::vector<double> hw = host_from_dev(w, (size_t)n);
+                            std::vector<int> hi((size_t)n + 1), hj((size_t)n);
+                            std::vector<double> one((size_t)n, 1.0);
+                            for (int i = 0; i < n; i++) { hi[(size_t)i] = i; hj[(size_t)i] = i; }
+                            hi[(size_t)n] = n;
+                            DevCSR Wd, Id, GA, GAW, T;
+                            Wd.upload(n, n, hi.data(), hj.data(), hw.data());
+                            Id.upload(n, n, hi.data(), hj.data(), one.data());
+                            k::csr_spgemm(*F.Gaux, F.A->diag, GA, false);
+                            k::csr_copy(GA, GAW);
+                            k::csr_scale_cols(GAW, w);
+                            k::csr_add(1.0, Wd, 1.0, *F.Gaux, T);
+                            F.Kh.reset(new DevCSR());
+                            k::csr_add(1.0, T, -1.0, GAW, *F.Kh);
+                            F.Mh.reset(new DevCSR());
+                            k::csr_add(1.0, Id, -1.0, GA, *F.Mh);
+                            ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+                        } catch (const Error &) {
+                            F.Kh.reset(); F.Mh.reset();
+                        }
+                    }
                 }
                 continue;
             }
@@ -505,19 +549,32 @@ struct elag_hip_hierarchy_s {
             //   x = W f; pv = f - A x; x += D Waux D^T pv | r_c = P^T (f - A x) | x += P e; x += W (f - A x); pv = f - A x; x += D Waux D^T pv
             double *cur = alt, *oth = sol;
             const double *w = F.hipt_w;
-            k::SpmvArgs a1;   // x = W f (the operand, written as out2) and pv = f - A x in one product
-            a1.x = rhs; a1.cs = w; a1.alpha = -1.0; a1.f = rhs; a1.gamma = 1.0; a1.out = F.tmp_resid; a1.out2 = cur;
-            k::spmv_fused(F.A->diag, nullptr, a1);
-            k::SpmvArgs a2;   // x += Gaux pv
-            a2.x = F.tmp_resid; a2.alpha = 1.0; a2.yin = cur; a2.beta = 1.0; a2.out = cur;
-            k::spmv_fused(*F.Gaux, nullptr, a2);
+            if (F.Kh) {
+                k::SpmvArgs k1;   // x = Kh f: the primary sweep from the zero guess and the auxiliary-space correction in one product
+                k1.x = rhs; k1.alpha = 1.0; k1.out = cur;
+                k::spmv_fused(*F.Kh, nullptr, k1);
+            } else {
+                k::SpmvArgs a1;   // x = W f (the operand, written as out2) and pv = f - A x in one product
+                a1.x = rhs; a1.cs = w; a1.alpha = -1.0; a1.f = rhs; a1.gamma = 1.0; a1.out = F.tmp_resid; a1.out2 = cur;
+                k::spmv_fused(F.A->diag, nullptr, a1);
+                k::SpmvArgs a2;   // x += Gaux pv
+                a2.x = F.tmp_resid; a2.alpha = 1.0; a2.yin = cur; a2.beta = 1.0; a2.out = cur;
+                k::spmv_fused(*F.Gaux, nullptr, a2);
+            }
             k::SpmvArgs a3;   // r_c = P^T f - (P^T A) x
             a3.x = cur; a3.xg = rhs; a3.alpha = -1.0; a3.out = C.resid;
             k::spmv_fused(*F.RA, F.PTneg.get(), a3);
             iterate(l + 1, C.resid, C.sol, C.alt);
             k::SpmvArgs a5;   // x' = x + W (f - A x - S e),  S = A P - W^-1 P
-            a5.x = cur; a5.xg = C.sol; a5.alpha = -1.0; a5.f = rhs; a5.gamma = 1.0; a5.s = w; a5.yin = cur; a5.beta = 1.0; a5.out = oth;
+            a5.x = cur; a5.xg = C.sol; a5.alpha = -1.0; a5.f = rhs; a5.gamma = 1.0; a5.s = w; a5.yin = cur; a5.beta = 1.0;
+            a5.out = F.Mh ? F.tmp_resid : oth;
             k::spmv_fused(F.A->diag, F.S.get(), a5);
+            if (F.Mh) {
+                k::SpmvArgs m;    // x'' = x' + Gaux (f - A x') = Mh x' + Gaux f
+                m.x = F.tmp_resid; m.xg = rhs; m.alpha = 1.0; m.out = oth;
+                k::spmv_fused(*F.Mh, F.Gaux.get(), m);
+                return;
+            }
             k::SpmvArgs a6;   // pv = f - A x'
             a6.x = oth; a6.alpha = -1.0; a6.f = rhs; a6.gamma = 1.0; a6.out = F.tmp_resid;
             k::spmv_fused(F.A->diag, nullptr, a6);
