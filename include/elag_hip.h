@@ -245,7 +245,8 @@ ELAG_HIP_API int elag_hip_smoother_create(elag_hip_smoother_t *out, elag_hip_par
                                           int sweeps, double damping, double omega,
                                           int cheby_order, double cheby_fraction);
 /* Chebyshev: eigenvalue bounds of D^-1/2 A D^-1/2.  create() runs hypre_ParCSRMaxEigEstimateCG's
- * algorithm (10 CG-Lanczos steps, hypre RNG seed 1); set() injects bounds (parity of the sweep). */
+ * algorithm (10 CG-Lanczos steps, hypre RNG seed 1); set() injects bounds (parity of the sweep).  A hierarchy composes the
+ * order-2 sweep into its level operators at Finalize: after set() on a smoother that sits in a finalised hierarchy, finalise again. */
 ELAG_HIP_API int elag_hip_smoother_get_eig_estimate(elag_hip_smoother_t S, double *max_eig, double *min_eig);
 ELAG_HIP_API int elag_hip_smoother_set_eig_estimate(elag_hip_smoother_t S, double max_eig, double min_eig);
 /* HiptmairSmoother(A, D, primary, auxiliary) (ParELAG_HiptmairSmoother.cpp:22-46); A_aux = D^T A D is owned
