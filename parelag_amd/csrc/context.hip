@@ -176,6 +176,11 @@ void DevCSR::choose_spmv_shape()
     const double avg = nrows ? (double)nnz / nrows : 0.0;
     int l = 1;
     while (l < 64 && 2.0 * l < avg) l <<= 1;
+    // a small operator leaves most of the chip idle at that count (5 739 rows x 8 lanes are 180 workgroups for 256 CUs) and its launch is a
+    // latency chain: more lanes per row (up to the row length) shorten it.  Measured by timing half / same / twice the lanes on the composed
+    // level operators of the cube456 x3 hierarchies: the products with fewer than 2^16 lanes in all wanted twice as many (headline cycle
+    // 21.4 -> 20.4 us); the rule reproduces those choices without a timing at setup, so that results do not depend on one.
+    while (l < 64 && (int64_t)nrows * l < 65536 && l < avg) l <<= 1;
     lanes_per_row = l;
 }
 
