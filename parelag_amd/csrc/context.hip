@@ -180,7 +180,9 @@ void DevCSR::choose_spmv_shape()
     // latency chain: more lanes per row (up to the row length) shorten it.  Measured by timing half / same / twice the lanes on the composed
     // level operators of the cube456 x3 hierarchies: the products with fewer than 2^16 lanes in all wanted twice as many (headline cycle
     // 21.4 -> 20.4 us); the rule reproduces those choices without a timing at setup, so that results do not depend on one.
-    while (l < 64 && (int64_t)nrows * l < 65536 && l < avg) l <<= 1;
+    static int64_t min_lanes = 0;
+    if (min_lanes == 0) { const char *e = getenv("ELAG_HIP_MIN_LANES_TOTAL"); min_lanes = e && atoll(e) > 0 ? atoll(e) : 65536; }
+    while (l < 64 && (int64_t)nrows * l < min_lanes && l < avg) l <<= 1;
     lanes_per_row = l;
 }
 
