@@ -39,7 +39,8 @@ bool debug_sync();
 #define ELAG_LAUNCH_CHECK()                                             \
     do {                                                                \
         ELAG_HIP_CHECK(hipGetLastError());                              \
-        if (::elag::debug_sync() && !::elag::stream_is_capturing()) ELAG_HIP_CHECK(hipDeviceSynchronize()); \
+        /* (the caller's own stream: a device-wide wait is refused while another rank thread of the process captures a graph) */ \
+        if (::elag::debug_sync() && !::elag::stream_is_capturing()) ELAG_HIP_CHECK(hipStreamSynchronize(::elag::ctx().stream)); \
     } while (0)
 
 #define ELAG_REQUIRE(cond, ...)                                  \
