@@ -225,8 +225,8 @@ _T0 = time.time()
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20, help="timed V-cycles (the driver's command uses 20; README / DESIGN quote the numbers of that command)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--refines", type=int, default=3, help="uniform refinements of cube456 for the V-cycle workload")
     ap.add_argument("--roofline-refines", type=int, default=5, help="refinements for the HBM-bound SpMV measurement")
     ap.add_argument("--roofline-reps", type=int, default=50)
@@ -420,7 +420,8 @@ def main():
                 "vcycle_GBs": round(vb / (ms_v * 1e-3) / 1e9, 1), "vcycle_frac": round(vb / (ms_v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "vcycle_in_solve_ms": round(ms_vi, 4), "vcycle_in_solve_frac": round(vb / (ms_vi * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "pcg": pcg,
-                "hierarchy_setup_s": round(setup_r, 3), "generate_s": round(gen_s, 1)}
+                "hierarchy_setup_s": round(setup_r, 3), "hierarchy_setup_breakdown_ms": {k_: round(v_, 3) for k_, v_ in Hr.setup_breakdown().items()},
+                "generate_s": round(gen_s, 1)}
         # HBM traffic of the same launch from the committed PMC passes (tools/roofline_profile.sh), if present
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
@@ -575,17 +576,22 @@ def main():
 
     for _ in range(args.warmup):
         H.Mult(rhs, sol)
-    # a launch-bound cycle of ~20 us: W steps are over before the GPU has left its idle clocks (first-run readings were 20 % low on a cold
-    # device); keep cycling, untimed, until 0.3 s have passed
+    # A launch-bound cycle of ~16 us: W steps are over before the GPU has left its idle clocks (first-run readings were 20 % low on a cold
+    # device), so keep cycling, untimed, until 0.3 s have passed -- in bursts shaped like the timed region itself (drain, `steps` cycles,
+    # drain).  (Round 2 warmed up with bursts of 200 cycles; on some boxes the ~40 launches that follow the drain of such a burst cost the
+    # host twice their usual time -- tools/headline_probe.py -- and the 20 timed cycles of the driver's command were exactly those.)
     # (one rank only: with several, every rank must issue the same number of cycles -- they exchange halos)
+    burst = max(1, min(args.steps, 200))
     t_warm = time.perf_counter()
     while dist is None and time.perf_counter() - t_warm < 0.3:
-        for _ in range(200):
+        for _ in range(burst):
             H.Mult(rhs, sol)
         la.synchronize()
     if dist is not None:
-        for _ in range(1000):                                   # the same count on every rank
-            H.Mult(rhs, sol)
+        for _ in range(-(-1000 // burst)):                      # the same count on every rank
+            for _ in range(burst):
+                H.Mult(rhs, sol)
+            la.synchronize()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -594,6 +600,15 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         elapsed = dist.allreduce_max(elapsed)
+    # the same loop over 2000 cycles (what rounds 1-2 quoted): a caller that keeps the queue full
+    steady = None
+    if dist is None:
+        la.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2000):
+            H.Mult(rhs, sol)
+        la.synchronize()
+        steady = (time.perf_counter() - t1) / 2000
     # device-side time of the same loop by HIP events (no host launch overhead in between)
     # (at least 200 cycles here whatever --steps says: BASELINE.md quotes the rate over >= 200 cycles, and 20 cycles are 0.6 ms)
     ms_dev = H.time_apply(rhs, sol, max(200, min(args.steps, 500)))
@@ -602,6 +617,10 @@ def main():
 
     vbytes = vcycle_bytes(level_shapes)
     ms_per_step = elapsed / args.steps * 1e3
+    try:
+        setup_breakdown = {k: round(v, 3) for k, v in H.setup_breakdown().items()}
+    except Exception:                                   # hierarchies assembled level by level in Python have no build record
+        setup_breakdown = None
     # replayed hipGraph or plain stream launches: the library times a short cycle both ways at Finalize and keeps the faster
     try:
         launch = H.launch_mode()
@@ -875,11 +894,13 @@ def main():
                        "levels": [{"n": s[0], "nnz": s[1]} for s in level_shapes],
                        "hipgraph": launch.get("hipgraph", False), "launch_mode": launch,
                        "parallelism": f"row-block domain decomposition x{world}"},
+            "steady_state": (None if steady is None else {"steps": 2000, "ms_per_step": round(steady * 1e3, 5), "vcycles_per_s": round(1.0 / steady, 1)}),
             "device_ms_per_step": round(ms_dev, 5), "device_timed_steps": max(200, min(args.steps, 500)),
             "device_vcycles_per_s": round(1e3 / ms_dev, 1),
             "vcycle_algorithmic_bytes": vbytes,
             "vcycle_achieved_GBs": round(vbytes / (ms_dev * 1e-3) / 1e9, 1),
-            "setup_s": round(setup_s, 3),
+            "setup_s": round(setup_s, 4),
+            "setup_breakdown_ms": setup_breakdown,
             "fine_level_spmv": fine,
             "roofline": roof,
             "cpu_baseline": cpu,

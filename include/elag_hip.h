@@ -299,12 +299,17 @@ ELAG_HIP_API int elag_hip_hierarchy_set_coarse_solver(elag_hip_hierarchy_t H, el
 /* Hierarchy::Finalize (:255-267): size the per-level vectors; also builds explicit P^T and, when
  * use_graph != 0, arms hipGraph capture of the whole cycle (launch-bound small levels). */
 ELAG_HIP_API int elag_hip_hierarchy_finalize(elag_hip_hierarchy_t H, int use_graph);
-/* How Finalize decided to issue a cycle when use_graph was asked for: a replayed hipGraph costs a fixed few microseconds per launch on
- * top of its nodes, so a cycle of a handful of kernels is timed both ways at Finalize (host clock, queue drained) and the plain stream
- * launches are kept when they are at least 3 % faster (ELAG_HIP_GRAPH_MODE=graph | eager forces either).  uses_graph: the outcome;
- * kernels: graph nodes of one cycle (0: not counted); graph_us / launches_us: the two timings (launches_us 0 when only the graph was timed: cycles
- * of more than 64 kernels or longer than 170 us cannot gain 3 % from the few microseconds a graph launch costs). */
+/* How Finalize decided to issue a cycle when use_graph was asked for: a replayed hipGraph costs the device a fixed few microseconds per
+ * launch on top of its nodes and saves the host ~2.5 us per kernel, so the rule is the kernel count of one cycle -- plain stream launches
+ * up to 32 kernels, a replayed graph beyond (the Gauss-Seidel chains).  ELAG_HIP_GRAPH_MODE=graph | eager forces either, =measure times
+ * one cycle both ways at Finalize (host clock, queue drained) and keeps the plain launches when they are at least 3 % faster.
+ * uses_graph: the outcome; kernels: graph nodes of one cycle (0: not counted); graph_us / launches_us: the two timings (0 unless measured). */
 ELAG_HIP_API int elag_hip_hierarchy_launch_mode(elag_hip_hierarchy_t H, int *uses_graph, int *kernels, double *graph_us, double *launches_us);
+/* Wall time of the hierarchy's setup by phase, as "name=milliseconds;name=milliseconds;..." (what the reference prints under
+ * "Build Hierarchy", src/linalg/factories/ParELAG_AMGeSolverFactory.cpp:48-49,130-135, broken down): galerkin_products, renumbering,
+ * smoothers, coarse_solver (elag_hip_hierarchy_build), fused_level_operators, spmv_forms, dense_tail, flat_cycle_operators, launch_mode
+ * (Finalize).  Every phase ends with a drain of the compute stream. */
+ELAG_HIP_API int elag_hip_hierarchy_setup_breakdown(elag_hip_hierarchy_t H, char *buf, int len);
 /* Hierarchy::Mult (:109-136): is_preconditioner != 0 -> sol = cycle(rhs); else r = rhs - A sol,
  * sol += cycle(r).  mu = 0 (V-cycle) only, as in the reference. */
 ELAG_HIP_API int elag_hip_hierarchy_apply(elag_hip_hierarchy_t H, const double *rhs, double *sol,

@@ -125,6 +125,7 @@ _SIGNATURES = {
     "elag_hip_hierarchy_set_coarse_solver": [_p, _p],
     "elag_hip_hierarchy_finalize": [_p, _i],
     "elag_hip_hierarchy_launch_mode": [_p, _p, _p, _p, _p],
+    "elag_hip_hierarchy_setup_breakdown": [_p, C.c_char_p, _i],
     "elag_hip_hierarchy_apply": [_p, _p, _p, _i, _i],
     "elag_hip_hierarchy_destroy": [_p],
     "elag_hip_amge_default_options": [C.POINTER(AMGeOptions)],

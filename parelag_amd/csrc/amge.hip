@@ -824,7 +824,7 @@ float run_timed(hipStream_t st, const std::function<void()> &launch)
     ELAG_HIP_CHECK(hipEventRecord(e0, st));
     launch();
     ELAG_HIP_CHECK(hipEventRecord(e1, st));
-    ELAG_HIP_CHECK(hipEventSynchronize(e1));
+    event_wait(e1);
     float ms = 0.f;
     ELAG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0);

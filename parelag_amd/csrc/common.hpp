@@ -94,6 +94,14 @@ struct Context {
 };
 Context &ctx();
 void require_init();
+// Waiting for the device from a caller's thread.  hipStreamSynchronize / hipEventSynchronize put the thread to sleep on the
+// completion interrupt once the wait gets long, and on this stack the ~40 kernel launches that FOLLOW such a sleep cost the host
+// about twice their usual time (measured on MI355X / ROCm 7.2: 16 -> 29 us per 5-kernel cycle, tools/headline_probe.py) -- which
+// turns a launch-bound cycle host-bound exactly where a caller times it (drain, K cycles, drain).  These poll instead
+// (hipStreamQuery / hipEventQuery) for up to ELAG_HIP_SPIN_MS milliseconds (default 200) and only then fall back to the
+// blocking call; ELAG_HIP_SPIN_MS=0 always blocks.
+void stream_wait(hipStream_t st);
+void event_wait(hipEvent_t ev);
 void amge_release_arena();            // amge.hip: frees the calling thread's coarsening arena (elag_hip_finalize)
 
 // ---- device memory helpers ---------------------------------------------------------------------

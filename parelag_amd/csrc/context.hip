@@ -3,6 +3,7 @@
 #include "comm.hpp"
 
 #include <algorithm>
+#include <chrono>
 
 namespace elag {
 
@@ -172,10 +173,12 @@ void DevCSR::choose_spmv_shape()
     //  per row than with 2048-entry windows that hold 800 rows each -- tools/hdiv_kernels.py)
     const double avg_row = nrows ? (double)nnz / nrows : 0.0;
     if (max_row_nnz <= kStreamMaxRow && nnz >= (int64_t(1) << 20) && !(avg_row < 3.5 && nnz < (int64_t(1) << 22))) { lanes_per_row = 0; return; }
-    // lanes per row = smallest power of two >= (nnz/row)/2
+    // lanes per row = smallest power of two >= (nnz/row)/2 (measured against /4 and /8 with four entries in flight per lane: tools/lane_ab.sh)
     const double avg = nrows ? (double)nnz / nrows : 0.0;
+    static double lane_div = 0.0;
+    if (lane_div == 0.0) { const char *e = getenv("ELAG_HIP_LANE_DIV"); lane_div = e && atof(e) > 0 ? atof(e) : 2.0; }
     int l = 1;
-    while (l < 64 && 2.0 * l < avg) l <<= 1;
+    while (l < 64 && lane_div * l < avg) l <<= 1;
     // a small operator leaves most of the chip idle at that count (5 739 rows x 8 lanes are 180 workgroups for 256 CUs) and its launch is a
     // latency chain: more lanes per row (up to the row length) shorten it.  Measured by timing half / same / twice the lanes on the composed
     // level operators of the cube456 x3 hierarchies: the products with fewer than 2^16 lanes in all wanted twice as many (headline cycle
@@ -186,6 +189,34 @@ void DevCSR::choose_spmv_shape()
     lanes_per_row = l;
 }
 
+}  // namespace elag
+
+namespace elag {
+namespace {
+double spin_budget_ms()
+{
+    static double ms = -1.0;
+    if (ms < 0.0) { const char *e = getenv("ELAG_HIP_SPIN_MS"); ms = e ? std::max(0.0, atof(e)) : 200.0; }
+    return ms;
+}
+template <class Query, class Block>
+void poll_then_block(Query query, Block block)
+{
+    const double budget = spin_budget_ms();
+    if (budget > 0.0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int it = 0;; it++) {
+            const hipError_t e = query();
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) ELAG_HIP_CHECK(e);
+            if ((it & 63) == 63 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > budget) break;
+        }
+    }
+    ELAG_HIP_CHECK(block());
+}
+}  // namespace
+void stream_wait(hipStream_t st) { poll_then_block([&] { return hipStreamQuery(st); }, [&] { return hipStreamSynchronize(st); }); }
+void event_wait(hipEvent_t ev) { poll_then_block([&] { return hipEventQuery(ev); }, [&] { return hipEventSynchronize(ev); }); }
 }  // namespace elag
 
 using namespace elag;
@@ -244,7 +275,7 @@ int elag_hip_synchronize(void)
 {
     return guarded([&] {
         require_init();
-        ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+        stream_wait(ctx().stream);
     });
 }
 

@@ -132,5 +132,66 @@ void dense_inverse_general(const DevCSR &A, double *Minv)
     dev_free(M);
 }
 
+namespace {
+__global__ void dense_times_csr_t_kernel(int nc, int n, const double *__restrict__ Bc, const int *__restrict__ TI, const int *__restrict__ TJ,
+                                         const double *__restrict__ Ta, double *__restrict__ X)
+{
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long long)nc * n) return;
+    const int r = (int)(id / n), j = (int)(id % n);
+    double s = 0.0;
+    for (int q = TI[j]; q < TI[j + 1]; q++) s += Bc[(size_t)r * nc + TJ[q]] * Ta[q];
+    X[(size_t)r * n + j] = s;
+}
+__global__ void dense_level_vx_kernel(int n, const int *__restrict__ VI, const int *__restrict__ VJ, const double *__restrict__ Va,
+                                      const double *__restrict__ vw, const double *__restrict__ X, double *__restrict__ B)
+{
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long long)n * n) return;
+    const int i = (int)(id / n), j = (int)(id % n);
+    double s = 0.0;
+    for (int q = VI[i]; q < VI[i + 1]; q++) s += Va[q] * X[(size_t)VJ[q] * n + j];
+    B[(size_t)i * n + j] = vw ? -vw[i] * s : s;
+}
+// one thread per row: the row's entries are added one after the other (a row may store its diagonal or not)
+__global__ void dense_level_u_kernel(int n, const int *__restrict__ UI, const int *__restrict__ UJ, const double *__restrict__ Ua,
+                                     const double *__restrict__ w, double *__restrict__ B)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double *__restrict__ row = B + (size_t)i * n;
+    if (w) {
+        row[i] += 2.0 * w[i];
+        for (int q = UI[i]; q < UI[i + 1]; q++) row[UJ[q]] -= w[i] * Ua[q] * w[UJ[q]];
+    } else {
+        for (int q = UI[i]; q < UI[i + 1]; q++) row[UJ[q]] += Ua[q];
+    }
+}
+}  // namespace
+
+void dense_times_csr_t(int nc, int n, const double *Bc, const DevCSR &GT, double *X)
+{
+    ELAG_REQUIRE(GT.nrows == n && GT.ncols == nc, "internal: dense_times_csr_t shape");
+    const long long tot = (long long)nc * n;
+    if (tot == 0) return;
+    hipLaunchKernelGGL(dense_times_csr_t_kernel, dim3((unsigned)((tot + kB - 1) / kB)), dim3(kB), 0, ctx().stream, nc, n, Bc, (const int *)GT.I,
+                       (const int *)GT.J, (const double *)GT.a, X);
+    ELAG_LAUNCH_CHECK();
+}
+
+void dense_level_op(int n, int nc, const DevCSR &V, const double *vw, const double *X, const DevCSR *U, const DevCSR *A, const double *w, double *B)
+{
+    ELAG_REQUIRE(V.nrows == n && V.ncols == nc && ((U && U->nrows == n) || (A && w && A->nrows == n)), "internal: dense_level_op shape");
+    if (n == 0) return;
+    const long long tot = (long long)n * n;
+    hipLaunchKernelGGL(dense_level_vx_kernel, dim3((unsigned)((tot + kB - 1) / kB)), dim3(kB), 0, ctx().stream, n, (const int *)V.I, (const int *)V.J,
+                       (const double *)V.a, vw, X, B);
+    ELAG_LAUNCH_CHECK();
+    const DevCSR &M = U ? *U : *A;
+    hipLaunchKernelGGL(dense_level_u_kernel, dim3((unsigned)((n + kB - 1) / kB)), dim3(kB), 0, ctx().stream, n, (const int *)M.I, (const int *)M.J,
+                       (const double *)M.a, U ? nullptr : w, B);
+    ELAG_LAUNCH_CHECK();
+}
+
 }  // namespace k
 }  // namespace elag

@@ -71,6 +71,26 @@ struct elag_hip_hierarchy_s {
     // composition) ending in a dense product, run as ONE kernel with grid-wide barriers between the products (kernels_spmv.hip)
     int resident_top = -1;
     k::ResidentSeq res_seq;
+    // wall time of the setup phases (Finalize's, and elag_hip_hierarchy_build's before it), each closed by a drain of the compute stream:
+    // what the reference reports as "Build Hierarchy" (ParELAG_AMGeSolverFactory.cpp:48-49,130-135), by phase
+    std::vector<std::pair<const char *, double>> setup_ms;
+    template <class F>
+    void phase(const char *name, F &&f)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        f();
+        stream_wait(ctx().stream);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        for (auto &p : setup_ms)
+            if (!strcmp(p.first, name)) { p.second += ms; return; }
+        setup_ms.emplace_back(name, ms);
+    }
+    // flattened tail: the fused launch-bound levels flat_top .. flat_bottom-1 above a dense product on level flat_bottom run as THREE
+    // launches however many levels they are (plan_flat): everything that depends on the same inputs shares a launch
+    int flat_top = -1, flat_bottom = -1;
+    k::FlatSegs flat_s1, flat_s2;
+    k::FlatSum flat_s3;
+    std::vector<std::shared_ptr<DevCSR>> flat_ops;
     // graph replay or plain stream launches, by measurement at Finalize (tune_launch_mode): a replayed hipGraph costs a fixed 7-9 us per
     // launch on top of its nodes, which a cycle of a handful of kernels does not earn back (cube456 x3: 29 us replayed, 21.5 us launched)
     int tune_nodes = 0;
@@ -133,36 +153,43 @@ struct elag_hip_hierarchy_s {
         if (coarse && (coarse->replicated || coarse->custom_apply)) local_only = false;
         all_local = local_only;
         use_graph = graph && local_only;
-        plan_fused();
+        phase("fused_level_operators", [&] { plan_fused(); });
         // SpMV forms that are built on first use must exist before the cycle is captured into a graph
-        for (auto &L : lev) {
-            k::prepare_spmv(L.A->diag);
-            if (L.P) { k::prepare_spmv(L.P->diag); if (L.P->diagT) k::prepare_spmv(*L.P->diagT); }
-            if (L.G) k::prepare_spmv(*L.G);
-            if (L.S) k::prepare_spmv(*L.S);
-            if (L.U1) k::prepare_spmv(*L.U1);
-            if (L.Kh) { k::prepare_spmv(*L.Kh); k::prepare_spmv(*L.Mh); }
-            if (L.Gaux) k::prepare_spmv(*L.Gaux);
-            if (L.RA) k::prepare_spmv(*L.RA);
-        }
-        if (A_user) k::prepare_spmv(A_user->diag);
-        plan_dense_tail();
-        plan_resident();
+        phase("spmv_forms", [&] {
+            for (auto &L : lev) {
+                k::prepare_spmv(L.A->diag);
+                if (L.P) { k::prepare_spmv(L.P->diag); if (L.P->diagT) k::prepare_spmv(*L.P->diagT); }
+                if (L.G) k::prepare_spmv(*L.G);
+                if (L.S) k::prepare_spmv(*L.S);
+                if (L.U1) k::prepare_spmv(*L.U1);
+                if (L.Kh) { k::prepare_spmv(*L.Kh); k::prepare_spmv(*L.Mh); }
+                if (L.Gaux) k::prepare_spmv(*L.Gaux);
+                if (L.RA) k::prepare_spmv(*L.RA);
+            }
+            if (A_user) k::prepare_spmv(A_user->diag);
+        });
+        phase("dense_tail", [&] { plan_dense_tail(); });
+        phase("flat_cycle_operators", [&] { plan_flat(); plan_resident(); });
         finalized = true;
-        ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
         tune_graph_us = tune_eager_us = 0.0; tune_nodes = 0;
-        if (use_graph) tune_launch_mode();
+        if (use_graph) phase("launch_mode", [&] { tune_launch_mode(); });
     }
 
-    // One Mult in preconditioner mode as a replayed graph and as plain launches, host clock around a drained queue (what a caller that
-    // issues cycles back to back sees, whichever side -- host or device -- is the slower one); the graph stays unless the plain launches
-    // are at least 3 % faster.  Cycles of more than 64 kernels (the Gauss-Seidel chains) are not measured: they stay graphs.
-    // ELAG_HIP_GRAPH_MODE=graph | eager forces either.
+    // Replayed graph or plain stream launches?  A replayed hipGraph costs the DEVICE a fixed 5-9 us per launch on this stack (the gap in front of
+    // the first node of every replay, profiles/r02_cycle_trace_k3_graph_vs_plain.txt) and saves the HOST ~2.5 us per kernel.  Every cycle of
+    // up to 23 kernels that was timed both ways (round 2: H1 x3 / x4 / x5, Chebyshev, Darcy, H(div), H(curl), SPE10 size) ran faster as plain
+    // launches, by 1-25 %; the Gauss-Seidel cycles -- hundreds to thousands of 2-4 us kernels -- are host-bound without a graph.  The rule
+    // is therefore the kernel count: plain launches up to kPlainLaunchNodes kernels per cycle, a graph beyond.  It is deterministic (the
+    // round-2 choice by timing at every Finalize differed from run to run on a busy host, and so did everything downstream of it).
+    // ELAG_HIP_GRAPH_MODE=graph | eager forces either; =measure times one cycle both ways (host clock around a drained queue, best of
+    // 3 x 40) and keeps plain launches when they are >= 3 % faster.
+    static constexpr int kPlainLaunchNodes = 32;
     void tune_launch_mode()
     {
         const char *mode = getenv("ELAG_HIP_GRAPH_MODE");
         if (mode && !strcmp(mode, "graph")) return;
         if (mode && !strcmp(mode, "eager")) { use_graph = false; return; }
+        const bool measure = mode && !strcmp(mode, "measure");
         const int n = lev[0].A->nrows();
         if (n == 0) return;
         hipStream_t st = ctx().stream;
@@ -175,27 +202,23 @@ struct elag_hip_hierarchy_s {
         size_t nodes = 0;
         ELAG_HIP_CHECK(hipGraphGetNodes(graph, nullptr, &nodes));
         tune_nodes = (int)nodes;
+        if (!measure) {
+            (void)hipGraphDestroy(graph);
+            if (nodes <= (size_t)kPlainLaunchNodes) use_graph = false;
+            return;
+        }
         if (nodes > 64) { (void)hipGraphDestroy(graph); return; }
         hipGraphExec_t exec = nullptr;
         ELAG_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         (void)hipGraphDestroy(graph);
-        {   // the fixed cost of a graph launch is 5-7 us: a cycle of more than 170 us cannot gain 3 % -- no need to spend setup time on it
-            for (int i = 0; i < 2; i++) ELAG_HIP_CHECK(hipGraphLaunch(exec, st));
-            ELAG_HIP_CHECK(hipStreamSynchronize(st));
-            const auto t0 = std::chrono::steady_clock::now();
-            for (int i = 0; i < 4; i++) ELAG_HIP_CHECK(hipGraphLaunch(exec, st));
-            ELAG_HIP_CHECK(hipStreamSynchronize(st));
-            tune_graph_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 4.0;
-            if (tune_graph_us > 170.0) { (void)hipGraphExecDestroy(exec); return; }
-        }
         auto clock_us = [&](auto once) {
             double best = 1e30;
             for (int rep = 0; rep < 3; rep++) {
                 for (int i = 0; i < 5; i++) once();
-                ELAG_HIP_CHECK(hipStreamSynchronize(st));
+                stream_wait(st);
                 const auto t0 = std::chrono::steady_clock::now();
                 for (int i = 0; i < 40; i++) once();
-                ELAG_HIP_CHECK(hipStreamSynchronize(st));
+                stream_wait(st);
                 best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 40.0);
             }
             return best;
@@ -224,21 +247,55 @@ struct elag_hip_hierarchy_s {
         const int n = lev[(size_t)L].A->nrows();
         if (n == 0) return;
         hipStream_t st = ctx().stream;
-        // column j of B = sub-cycle applied to e_j; stored transposed first (one contiguous row per application)
+        if (dense_tail_by_recursion(L)) { dense_level = L; return; }
+        // general levels: column j of B = sub-cycle applied to e_j; stored transposed first (one contiguous row per application)
         double *Bt = dev_alloc<double>((size_t)n * n);
         Temp<double> ej((size_t)n);
         ELAG_HIP_CHECK(hipMemsetAsync(ej, 0, sizeof(double) * (size_t)n, st));
-        const double one = 1.0, zero = 0.0;
         for (int j = 0; j < n; j++) {
-            ELAG_HIP_CHECK(hipMemcpyAsync(ej.p + j, &one, sizeof(double), hipMemcpyHostToDevice, st));
+            k::vec_fill(1, 1.0, ej.p + j);           // (a kernel, not a copy from pageable host memory: that one is synchronous)
             iterate(L, ej, Bt + (size_t)j * n, lev[(size_t)L].alt);
-            ELAG_HIP_CHECK(hipMemcpyAsync(ej.p + j, &zero, sizeof(double), hipMemcpyHostToDevice, st));
+            k::vec_fill(1, 0.0, ej.p + j);
         }
         Bdense = dev_alloc<double>((size_t)n * n);
         k::dense_transpose(n, Bt, Bdense);
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
         dev_free(Bt);
         dense_level = L;
+    }
+
+    // The dense operator of the sub-cycle from level L down, level by level from the bottom, when every level on the way is one of the
+    // fused forms with linear level maps  f_c = G f,  x = U f + V x_c  (l1-Jacobi: U = W (2 I - A W), V = -W S; Chebyshev: U1, U2) above a
+    // dense inverse:   B_last = Minv,   B_l = U_l + V_l (B_{l+1} G_l)   -- one transpose and three small launches per level instead of n_L
+    // applications of the sub-cycle to unit vectors (cube456 x3, n_L = 840: ~20 ms of a 24 ms Finalize).
+    bool dense_tail_by_recursion(int L)
+    {
+        const char *en = getenv("ELAG_HIP_DENSE_TAIL_RECURSION");          // (read at every Finalize: a test switches it)
+        const int nl = (int)lev.size();
+        if ((en && !atoi(en)) || !coarse || coarse->custom_apply || coarse->replicated || !coarse->Minv || coarse->n != lev[(size_t)nl - 1].A->nrows()) return false;
+        for (int l = L; l < nl - 1; l++) {
+            const Level &F = lev[(size_t)l];
+            if (F.Gaux || !F.G || !(F.U1 || (F.S && F.fused_dinv))) return false;
+        }
+        const double *Bc = coarse->Minv;
+        double *own = nullptr;            // B of the level below (owned unless it is Minv)
+        int nc = coarse->n;
+        for (int l = nl - 2; l >= L; l--) {
+            Level &F = lev[(size_t)l];
+            const int n = F.A->nrows();
+            DevCSR GT;
+            k::csr_transpose(*F.G, GT);
+            Temp<double> X((size_t)nc * n);
+            k::dense_times_csr_t(nc, n, Bc, GT, X);
+            double *B = dev_alloc<double>((size_t)n * n);
+            if (F.U1) k::dense_level_op(n, nc, *F.U2, nullptr, X, F.U1.get(), nullptr, nullptr, B);
+            else k::dense_level_op(n, nc, *F.S, F.fused_dinv, X, nullptr, &F.A->diag, F.fused_dinv, B);
+            ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));      // (GT and X go out of scope)
+            dev_free(own);
+            own = B; Bc = B; nc = n;
+        }
+        Bdense = own;
+        return true;
     }
 
     // the products iterate(l, ...) would launch from level l down and up again, as a list; false when a level on the way is not one of
@@ -336,6 +393,98 @@ struct elag_hip_hierarchy_s {
             if (getenv("ELAG_HIP_RESIDENT_VERBOSE"))
                 fprintf(stderr, "[elag_hip] resident tail from level %d: %d products in one launch of %u workgroups\n", top, (int)ops.size(), res_seq.grid);
             return;
+        }
+    }
+
+    // The levels of a launch-bound cycle are a chain of dependent launches, each about 4 us on MI355X whatever its size (two per fused
+    // level, one for the dense tail).  With linear level maps
+    //     f_{l+1} = G_l f_l,     x_l = U_l f_l + V_l x_{l+1}        (l1-Jacobi levels: U = W (2 I - A W), V = -W S; Chebyshev levels: U1, U2)
+    // and a dense x_D = B f_D at the bottom, the same cycle is
+    //     stage 1:  h = U_top f,   f_l = (G_{l-1} ... G_top) f            for l = top+1 .. D      (all read f:      ONE launch)
+    //     stage 2:  t_l = U_l f_l  for l = top+1 .. D-1,   x_D = B f_D                                (all read stage 1: ONE launch)
+    //     stage 3:  x_top = h + sum_l (V_top ... V_{l-1}) t_l + (V_top ... V_{D-1}) x_D              (ONE launch)
+    // with the products of G and of V formed once here by the device SpGEMM: three dependent launches instead of 2 (D - top) + 1, for
+    // more bytes (cube456 x3: 5 launches -> 3, 1.9 M -> 2.7 M stored entries, all cache resident).  Same linear map, other rounding
+    // (parity with the oracle's level-by-level cycle stays ~1e-15).  ELAG_HIP_FLAT_CYCLE=0 keeps the level-by-level launches.
+    void plan_flat()
+    {
+        flat_top = flat_bottom = -1;
+        flat_ops.clear();
+        const char *en = getenv("ELAG_HIP_FLAT_CYCLE");          // (read at every Finalize: tests switch it)
+        const char *res = getenv("ELAG_HIP_RESIDENT");
+        if ((en && !atoi(en)) || (res && atoi(res)) || !all_local) return;
+        const int nl = (int)lev.size();
+        int D = -1, nd = 0;
+        const double *Md = nullptr;
+        if (dense_level >= 0) { D = dense_level; Md = Bdense; nd = lev[(size_t)D].A->nrows(); }
+        else if (coarse && !coarse->custom_apply && !coarse->replicated && coarse->Minv) { D = nl - 1; Md = coarse->Minv; nd = coarse->n; }
+        if (D < 2 || !Md || nd == 0) return;
+        auto fused = [&](int l) {
+            const Level &F = lev[(size_t)l];
+            if (F.Gaux || !F.G) return false;
+            return (bool)F.U1 || (F.S && F.fused_dinv);
+        };
+        int top_min = D;
+        while (top_min > 0 && D - (top_min - 1) <= 4 && fused(top_min - 1)) top_min--;
+        for (int top = top_min; D - top >= 2; top++) {
+            const int m = D - top;
+            try {
+                std::vector<std::shared_ptr<DevCSR>> U((size_t)m), V((size_t)m), Gc((size_t)m), Vc((size_t)m);
+                for (int i = 0; i < m; i++) {
+                    Level &F = lev[(size_t)(top + i)];
+                    if (F.U1) { U[(size_t)i] = F.U1; V[(size_t)i] = F.U2; continue; }
+                    const int n = F.A->nrows();
+                    const double *w = F.fused_dinv;
+                    DevCSR T, Wd, WS;
+                    k::csr_copy(F.A->diag, T);
+                    k::csr_scale_rows(T, w);
+                    k::csr_scale_cols(T, w);
+                    k::csr_diagonal(n, w, 1.0, Wd);
+                    U[(size_t)i].reset(new DevCSR());
+                    k::csr_add(2.0, Wd, -1.0, T, *U[(size_t)i]);
+                    Temp<double> negw((size_t)n);
+                    k::vec_scale_mul(n, -1.0, w, nullptr, negw);
+                    V[(size_t)i].reset(new DevCSR());
+                    k::csr_copy(*F.S, *V[(size_t)i]);
+                    k::csr_scale_rows(*V[(size_t)i], negw);
+                }
+                Gc[0] = lev[(size_t)top].G;
+                Vc[0] = V[0];
+                long long extra = 0;
+                const long long budget = std::max<long long>(1ll << 20, 4 * lev[(size_t)top].A->diag.nnz);
+                for (int i = 1; i < m; i++) {
+                    Gc[(size_t)i].reset(new DevCSR());
+                    k::csr_spgemm(*lev[(size_t)(top + i)].G, *Gc[(size_t)i - 1], *Gc[(size_t)i], false);
+                    Vc[(size_t)i].reset(new DevCSR());
+                    k::csr_spgemm(*Vc[(size_t)i - 1], *V[(size_t)i], *Vc[(size_t)i], false);
+                    extra += Gc[(size_t)i]->nnz + Vc[(size_t)i]->nnz;
+                    if (extra > budget) fail(ELAG_HIP_ERR_STATE, "flattened cycle: composites outgrow their budget");
+                }
+                const double *rhs = k::resident_rhs();
+                double *sol = k::resident_sol();
+                double *h = lev[(size_t)top].tmp_resid;
+                k::FlatSegs s1, s2;
+                k::FlatSum s3;
+                // (the segments with the longest rows first: their workgroups take longest and should not start last)
+                for (int i = m - 1; i >= 0; i--) k::flat_segs_add_csr(s1, *Gc[(size_t)i], rhs, lev[(size_t)(top + i + 1)].resid);
+                k::flat_segs_add_csr(s1, *U[0], rhs, h);
+                k::flat_segs_add_dense(s2, nd, nd, Md, lev[(size_t)D].resid, lev[(size_t)D].sol);
+                for (int i = m - 1; i >= 1; i--) k::flat_segs_add_csr(s2, *U[(size_t)i], lev[(size_t)(top + i)].resid, lev[(size_t)(top + i)].alt);
+                for (int i = 0; i < m; i++) k::flat_sum_add(s3, *Vc[(size_t)i], i + 1 < m ? lev[(size_t)(top + i + 1)].alt : lev[(size_t)D].sol);
+                k::flat_sum_finish(s3, h, sol);
+                flat_s1 = s1; flat_s2 = s2; flat_s3 = s3;
+                for (auto &v : {U, V, Gc, Vc})
+                    for (auto &q : v) flat_ops.push_back(q);
+                flat_top = top; flat_bottom = D;
+                ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+                if (getenv("ELAG_HIP_FLAT_VERBOSE"))
+                    fprintf(stderr, "[elag_hip] flattened cycle: levels %d..%d in three launches (%u + %u + %u workgroups, %lld composite entries)\n", top, D,
+                            s1.grid, s2.grid, s3.grid, extra);
+                return;
+            } catch (const Error &) {
+                // a product's rows outgrow what the SpGEMM handles, or the composites their budget: flatten fewer levels
+                flat_ops.clear();
+            }
         }
     }
 
@@ -510,6 +659,12 @@ struct elag_hip_hierarchy_s {
     {
         Level &F = lev[(size_t)l];
         const int nl = (int)lev.size();
+        if (l == flat_top) {
+            k::flat_segs_launch(flat_s1, rhs, sol);
+            k::flat_segs_launch(flat_s2, rhs, sol);
+            k::flat_sum_launch(flat_s3, rhs, sol);
+            return;
+        }
         if (l == resident_top) { k::resident_launch(res_seq, rhs, sol); return; }
         if (l == dense_level) { k::dense_gemv(F.A->nrows(), F.A->nrows(), Bdense, rhs, sol); return; }
         if (l == nl - 1) {
@@ -720,7 +875,7 @@ void hierarchy_apply_raw(elag_hip_hierarchy_s *H, const double *rhs, double *sol
     H->run(rhs, sol, precond);
 }
 bool hierarchy_is_local(const elag_hip_hierarchy_s *H) { return H->all_local; }
-bool hierarchy_prefers_plain_launches(const elag_hip_hierarchy_s *H) { return H->tune_eager_us > 0.0 && !H->use_graph; }
+bool hierarchy_prefers_plain_launches(const elag_hip_hierarchy_s *H) { return H->tune_nodes > 0 && !H->use_graph; }
 // A solver that iterates with a reordered hierarchy as its preconditioner can live in the hierarchy's numbering altogether:
 // the level-0 operator as the cycle runs it (same matrix as `A_user`, rows / columns permuted) and the new -> old map.
 bool hierarchy_internal_numbering(const elag_hip_hierarchy_s *H, const ParCSR *A_user, ParCSR **A_internal, const int **d_order0)
@@ -977,6 +1132,7 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
         std::unique_ptr<elag_hip_hierarchy_s> H(new elag_hip_hierarchy_s());
         H->lev.resize((size_t)num_P + 1);
         H->lev[0].A = A;
+        H->phase("galerkin_products", [&] {
         for (int l = 0; l < num_P; l++) {
             ParCSR *Af = H->lev[(size_t)l].A;
             ParCSR *Pl = P[l];
@@ -991,6 +1147,7 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
             H->lev[(size_t)l + 1].A = Ac;
             H->lev[(size_t)l + 1].P = Pl;
         }
+        });
 
         // ---- optional internal renumbering for gather locality -------------------------------------
         // (a Gauss-Seidel sweep is defined by the caller's row order: those hierarchies keep it)
@@ -999,7 +1156,7 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
         ELAG_REQUIRE(!(ordered_relax && opt.reorder > 0), "reorder = 1 would change what a Gauss-Seidel sweep computes");
         const bool reorder = !A->needs_exchange() && A->global_rows == A->nrows() && D == nullptr && !ordered_relax &&
                              (opt.reorder > 0 || (opt.reorder < 0 && A->nrows() >= (1 << 18)));
-        if (reorder) {
+        if (reorder) H->phase("renumbering", [&] {
             const int nl = num_P + 1;
             H->order.resize((size_t)nl);
             {
@@ -1042,8 +1199,9 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
             for (int l = 0; l < nl; l++) dev_free(d_rank[(size_t)l]);
             H->A_user = A;
             H->reordered = true;
-        }
+        });
 
+        H->phase("smoothers", [&] {
         for (int l = 0; l < num_P; l++) {
             elag_hip_smoother_t S = nullptr;
             int rc = elag_hip_smoother_create(&S, H->lev[(size_t)l].A, opt.relax_type, opt.sweeps, opt.damping, 1.0, opt.cheby_order,
@@ -1075,6 +1233,8 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
             H->lev[(size_t)l].pre = S;
             H->lev[(size_t)l].post = S;  // same parameters => same operator; scratch is not shared across calls
         }
+        });
+        H->phase("coarse_solver", [&] {
         elag_hip_coarse_t C = nullptr;
         int rc;
         if (is_distributed(*H->lev.back().A)) {
@@ -1089,6 +1249,7 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
         if (rc) fail(rc, "%s", elag_hip_last_error());
         H->owned_coarse = C;
         H->coarse = C;
+        });
         H->finalize(opt.use_graph != 0);
         *out = H.release();
     }
@@ -1174,7 +1335,7 @@ int elag_hip_time_kernel(elag_hip_parcsr_t A, elag_hip_smoother_t S, int kernel,
         ELAG_HIP_CHECK(hipEventRecord(e0, st));
         for (int i = 0; i < reps; i++) launch();
         ELAG_HIP_CHECK(hipEventRecord(e1, st));
-        ELAG_HIP_CHECK(hipEventSynchronize(e1));
+        event_wait(e1);
         float ms = 0.f;
         ELAG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
         (void)hipEventDestroy(e0);
@@ -1201,7 +1362,7 @@ int elag_hip_time_hierarchy(elag_hip_hierarchy_t H, const double *rhs_dev, doubl
             ELAG_HIP_CHECK(hipEventRecord(e0, st));
             for (int i = 0; i < chunk; i++) H->apply_device(rhs_dev, sol_dev, true);
             ELAG_HIP_CHECK(hipEventRecord(e1, st));
-            ELAG_HIP_CHECK(hipEventSynchronize(e1));
+            event_wait(e1);
             float ms = 0.f;
             ELAG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
             total_ms += ms;
@@ -1222,6 +1383,21 @@ int elag_hip_hierarchy_launch_mode(elag_hip_hierarchy_t H, int *uses_graph, int 
         if (kernels) *kernels = H->tune_nodes;
         if (graph_us) *graph_us = H->tune_graph_us;
         if (launches_us) *launches_us = H->tune_eager_us;
+    });
+}
+
+int elag_hip_hierarchy_setup_breakdown(elag_hip_hierarchy_t H, char *buf, int len)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(H && buf && len > 0, "bad argument");
+        std::string out;
+        char tmp[96];
+        for (auto &p : H->setup_ms) {
+            snprintf(tmp, sizeof tmp, "%s%s=%.4f", out.empty() ? "" : ";", p.first, p.second);
+            out += tmp;
+        }
+        ELAG_REQUIRE((int)out.size() < len, "buffer of %d bytes is too small for %d", len, (int)out.size() + 1);
+        memcpy(buf, out.c_str(), out.size() + 1);
     });
 }
 
@@ -1256,7 +1432,7 @@ int elag_hip_time_hierarchy_internal(elag_hip_hierarchy_t H, int reps, double *m
             ELAG_HIP_CHECK(hipEventRecord(e0, st));
             for (int i = 0; i < chunk; i++) once();
             ELAG_HIP_CHECK(hipEventRecord(e1, st));
-            ELAG_HIP_CHECK(hipEventSynchronize(e1));
+            event_wait(e1);
             float ms = 0.f;
             ELAG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
             total_ms += ms;

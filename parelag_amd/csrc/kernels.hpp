@@ -66,6 +66,46 @@ void resident_build(const std::vector<ResidentOp> &ops, ResidentSeq &seq);
 void resident_free(ResidentSeq &seq);
 void resident_launch(const ResidentSeq &seq, const double *rhs, double *sol, hipStream_t st = nullptr);
 int resident_error(const ResidentSeq &seq);     // synchronous read of the error flag
+// ---- "flat stage": several INDEPENDENT products in ONE launch (kernels_spmv.hip) --------------------------------------------
+// A launch-bound cycle costs what its chain of dependent launches costs (~4 us each on MI355X, whatever their size), so the flattened
+// form of a cycle (hierarchy.hip, plan_flat) puts everything that depends on the same inputs into one launch.  Two shapes:
+//   FlatSegs: up to five segments, each  out = A x  (CSR with its own lanes per row, or a dense row-major matrix), the workgroups of
+//             the launch dealt to the segments by ranges of blockIdx;
+//   FlatSum:  out = yin + sum_t A_t x_t  over up to four CSR terms with common rows.
+// Both are structs of arrays passed by value: a workgroup finds everything it needs in the kernel-argument preload (a descriptor
+// fetched through a pointer, or a dynamically indexed array of structs, costs every wave one more dependent round trip -- measured:
+// 7 us per stage instead of 4).
+constexpr int kFlatSegs = 5, kFlatTerms = 4;
+struct FlatSegs {
+    int nsegs = 0;
+    unsigned grid = 0;
+    unsigned block_begin[kFlatSegs] = {0, 0, 0, 0, 0};
+    int nrows[kFlatSegs] = {0, 0, 0, 0, 0};
+    int lpr[kFlatSegs] = {1, 1, 1, 1, 1};          // lanes per row: 1..64, 256 = a workgroup per row, 0 = dense (a = M row-major, ncols wide)
+    int ncols[kFlatSegs] = {0, 0, 0, 0, 0};
+    const int *I[kFlatSegs] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int *J[kFlatSegs] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const double *a[kFlatSegs] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const double *x[kFlatSegs] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *out[kFlatSegs] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+struct FlatSum {
+    int nrows = 0, nterms = 0, lpr = 1;
+    unsigned grid = 0;
+    const int *I[kFlatTerms] = {nullptr, nullptr, nullptr, nullptr};
+    const int *J[kFlatTerms] = {nullptr, nullptr, nullptr, nullptr};
+    const double *a[kFlatTerms] = {nullptr, nullptr, nullptr, nullptr};
+    const double *x[kFlatTerms] = {nullptr, nullptr, nullptr, nullptr};
+    const double *yin = nullptr;
+    double *out = nullptr;
+};
+void flat_segs_add_csr(FlatSegs &S, const DevCSR &A, const double *x, double *out);       // lanes from the rows' average length
+void flat_segs_add_dense(FlatSegs &S, int nrows, int ncols, const double *M, const double *x, double *out);
+void flat_sum_add(FlatSum &S, const DevCSR &A, const double *x);                          // call flat_sum_finish after the last term
+void flat_sum_finish(FlatSum &S, const double *yin, double *out);
+// pointers equal to resident_rhs() / resident_sol() stand for the vectors given here
+void flat_segs_launch(const FlatSegs &S, const double *rhs, double *sol, hipStream_t st = nullptr);
+void flat_sum_launch(const FlatSum &S, const double *rhs, double *sol, hipStream_t st = nullptr);
 // row-block plan of the LDS-staged stream kernel (block_row, nblocks, max_row_nnz); synchronous, setup time
 void build_stream_plan(DevCSR &A);
 // builds the x-cache form of a stream-kernel matrix if it pays (synchronous, allocates: never call while capturing);
@@ -113,12 +153,19 @@ void csr_delete_zeros(const DevCSR &A, double tol, DevCSR &out);
 void csr_scale_rows(DevCSR &A, const double *d);
 void csr_scale_cols(DevCSR &A, const double *d);  // a_ij *= d_j
 void csr_copy(const DevCSR &A, DevCSR &out);
+void csr_diagonal(int n, const double *d, double scale, DevCSR &out);   // out = scale * diag(d)  (d == nullptr: scale * I)
 // out = A(order_rows, :) with columns renumbered by rank_cols (old -> new); rows come back column-sorted
 void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_cols, int ncols_out, DevCSR &out);
 
 // ---- dense coarse solve ------------------------------------------------------------------------
 void dense_gemv(int nrows, int ncols, const double *M, const double *x, double *y);  // y = M x, M row-major
 void dense_transpose(int n, const double *in, double *out);                           // out = in^T (n x n)
+// One level of the dense coarse-cycle operator (hierarchy.hip, plan_dense_tail): with the level maps f_c = G f, x = U f + V x_c and the
+// dense operator Bc (nc x nc) of the levels below, the level's own operator is  B = U + V (Bc G)  (n x n, row-major):
+//   dense_times_csr_t : X (nc x n) = Bc GT^T, GT = G^T in CSR (n rows), one thread per entry of X;
+//   dense_level_op    : B = rs . (V X) + U-part, rs_i = vw ? -vw_i : 1;  U-part: U given -> B += U;  else (A, w) -> B += 2 diag(w) - diag(w) A diag(w)
+void dense_times_csr_t(int nc, int n, const double *Bc, const DevCSR &GT, double *X);
+void dense_level_op(int n, int nc, const DevCSR &V, const double *vw, const double *X, const DevCSR *U, const DevCSR *A, const double *w, double *B);
 // Minv (n x n row-major, device) = A^-1 for a general square CSR (Gauss-Jordan, partial pivoting); throws when singular
 void dense_inverse_general(const DevCSR &A, double *Minv);
 

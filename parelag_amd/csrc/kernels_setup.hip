@@ -894,6 +894,23 @@ void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_col
     else out.choose_spmv_shape();
 }
 
+namespace {
+__global__ void diagonal_fill_kernel(int n, const double *__restrict__ d, double scale, int *__restrict__ I, int *__restrict__ J, double *__restrict__ a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { I[i] = i; J[i] = i; a[i] = d ? scale * d[i] : scale; }
+    if (i == n) I[n] = n;
+}
+}  // namespace
+
+void csr_diagonal(int n, const double *d, double scale, DevCSR &out)
+{
+    out.alloc(n, n, n);
+    hipLaunchKernelGGL(diagonal_fill_kernel, dim3(grid1(n + 1)), dim3(kBlock), 0, ctx().stream, n, d, scale, out.I, out.J, out.a);
+    ELAG_LAUNCH_CHECK();
+    out.choose_spmv_shape();
+}
+
 void csr_copy(const DevCSR &A, DevCSR &out)
 {
     hipStream_t st = ctx().stream;

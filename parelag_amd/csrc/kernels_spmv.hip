@@ -25,6 +25,8 @@ __device__ __forceinline__ double group_reduce(double v)
     return v;
 }
 
+constexpr int kRowU = 4;      // entries per lane and pass of the row-group kernels (see spmv_fused_row)
+
 // one row by a group of LPR lanes (all of them active): products in lane order, group reduction, fused epilogue by lane 0
 template <int LPR, bool HAS_OFFD, bool HAS_CS>
 __device__ __forceinline__ void spmv_fused_row(int row, int lane, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
@@ -50,40 +52,41 @@ __device__ __forceinline__ void spmv_fused_row(int row, int lane, const int *__r
     const double *__restrict__ x = p.x;
     const double *__restrict__ cs = p.cs;
     const double *__restrict__ xg = p.xg;
-    int k = s + lane, ko = os + lane;
-    const bool hd = k < e, ho = HAS_OFFD && ko < oe;
-    int jd = 0, jo = 0;
-    double ad = 0.0, ao = 0.0;
-    if (hd) { jd = J[k]; ad = a[k]; }
-    if (ho) { jo = oJ[ko]; ao = oa[ko]; }
-    double xd = 0.0, xo = 0.0;
-    if (hd) { xd = x[jd]; if (HAS_CS) xd *= cs[jd]; }
-    if (ho) { xo = xg[jo]; if (HAS_CS && p.csg) xo *= p.csg[jo]; }
+    // kRowU entries per lane and pass, diag and offd together: all the column / value loads of a pass are requested before the first
+    // gather, all the gathers before the first product.  The operators these kernels serve sit in L2 / Infinity Cache, where a
+    // launch costs (entries) / (entries in flight per CU) round trips.  (What this buys depends on the size of the launch: the
+    // 0.2-0.9 M-entry products of the level-by-level cycles sit on the ~4 us floor of a dependent launch either way -- H(div) x3
+    // 0.139 -> 0.134 ms, Darcy 0.0886 -> 0.086 ms --, the 1.2 M-entry stages of the flattened cycle went from 6.5 to 5.3 us.)
+    constexpr int U = kRowU;
     double sum = 0.0;
-    if (hd) sum += ad * xd;
-    k += LPR;
-    if (HAS_CS) {
-        for (; k < e; k += LPR) {
-            const int j = J[k];
-            sum += a[k] * (x[j] * cs[j]);
+    const int nd_ = e - s, no_ = HAS_OFFD ? oe - os : 0;
+    for (int q0 = lane; q0 < nd_ || q0 < no_; q0 += U * LPR) {
+        int jd[U], jo[U];
+        double ad[U], ao[U], xd[U], xo[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int q = q0 + u * LPR;
+            jd[u] = 0; ad[u] = 0.0;
+            if (q < nd_) { jd[u] = J[s + q]; ad[u] = a[s + q]; }
+            if (HAS_OFFD) {
+                jo[u] = 0; ao[u] = 0.0;
+                if (q < no_) { jo[u] = oJ[os + q]; ao[u] = oa[os + q]; }
+            }
         }
-    } else {
-        // two independent loads in flight per lane
-        for (; k + LPR < e; k += 2 * LPR) {
-            const int j0 = J[k], j1 = J[k + LPR];
-            const double a0 = a[k], a1 = a[k + LPR];
-            sum += a0 * x[j0];
-            sum += a1 * x[j1];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int q = q0 + u * LPR;
+            xd[u] = 0.0;
+            if (q < nd_) { xd[u] = x[jd[u]]; if (HAS_CS) xd[u] *= cs[jd[u]]; }
+            if (HAS_OFFD) {
+                xo[u] = 0.0;
+                if (q < no_) { xo[u] = xg[jo[u]]; if (HAS_CS && p.csg) xo[u] *= p.csg[jo[u]]; }
+            }
         }
-        if (k < e) sum += a[k] * x[J[k]];
-    }
-    if (HAS_OFFD) {
-        if (ho) sum += ao * xo;
-        ko += LPR;
-        if (HAS_CS && p.csg) {
-            for (; ko < oe; ko += LPR) { const int j = oJ[ko]; sum += oa[ko] * (xg[j] * p.csg[j]); }
-        } else {
-            for (; ko < oe; ko += LPR) sum += oa[ko] * xg[oJ[ko]];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            sum += ad[u] * xd[u];
+            if (HAS_OFFD) sum += ao[u] * xo[u];
         }
     }
     sum = group_reduce<LPR>(sum);
@@ -728,7 +731,7 @@ void prepare_spmv(const DevCSR &A, bool force)
             for (int w = 0; w < 8; w++) launch();
             ELAG_LAUNCH_CHECK();
             ELAG_HIP_CHECK(hipEventRecord(e1, st));
-            ELAG_HIP_CHECK(hipEventSynchronize(e1));
+            event_wait(e1);
             float ms = 0.f;
             ELAG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
             best = std::min(best, ms / 8);
@@ -856,6 +859,12 @@ __device__ __forceinline__ bool grid_barrier(unsigned *bar, int *err)
     }
     __syncthreads();
     return ok != 0;
+}
+
+inline const double *resident_in_host(const double *p, const double *rhs, const double *sol)
+{
+    const uintptr_t v = reinterpret_cast<uintptr_t>(p);
+    return v == kResidentRhs ? rhs : (v == kResidentSol ? sol : p);
 }
 
 __device__ __forceinline__ const double *resident_in(const double *p, const double *rhs, const double *sol)
@@ -1013,6 +1022,244 @@ int resident_error(const ResidentSeq &seq)
     int e = 0;
     ELAG_HIP_CHECK(hipMemcpy(&e, seq.d_err, sizeof(int), hipMemcpyDeviceToHost));
     return e;
+}
+
+// ================================================================================================
+// Flat stages: the independent products of one dependency stage of a flattened cycle in ONE launch (see kernels.hpp).
+// ================================================================================================
+namespace {
+
+// one CSR row by LPR lanes, kFlatU entries per lane and pass: all the column / value loads of a pass are requested before the first
+// gather, all the gathers before the first product.  These operators sit in L2 / Infinity Cache and a row is a chain of round trips,
+// so the time of a launch is (entries) / (entries in flight per CU): four entries per lane instead of one let a wave cover 4 x 64
+// entries per trip (cube456 x3, stage 1 of the flattened cycle: 8.8 -> X us).
+constexpr int kFlatU = 4;
+template <int LPR, int U = kFlatU>
+__device__ __forceinline__ double flat_row_sum(int s, int e, int lane, const int *__restrict__ J, const double *__restrict__ a, const double *__restrict__ x)
+{
+    double sum = 0.0;
+    for (int k0 = s + lane; k0 < e; k0 += U * LPR) {
+        int j[U];
+        double av[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = k0 + u * LPR;
+            j[u] = 0; av[u] = 0.0;
+            if (k < e) { j[u] = J[k]; av[u] = a[k]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            xv[u] = 0.0;
+            if (k0 + u * LPR < e) xv[u] = x[j[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) sum += av[u] * xv[u];
+    }
+    return sum;
+}
+
+template <int LPR, int U>
+__device__ __forceinline__ void flat_seg_rows(unsigned blk, int nrows, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
+                                              const double *__restrict__ x, double *__restrict__ out)
+{
+    constexpr int GPB = kBlock / LPR;
+    const int row = (int)blk * GPB + (int)threadIdx.x / LPR;
+    const int lane = threadIdx.x & (LPR - 1);
+    if (row >= nrows) return;
+    const double sum = group_reduce<LPR>(flat_row_sum<LPR, U>(I[row], I[row + 1], lane, J, a, x));
+    if (lane == 0) out[row] = sum;
+}
+
+template <int U>
+__global__ __launch_bounds__(kBlock) void flat_segs_kernel(const FlatSegs S)
+{
+    __shared__ double sh[kBlock / 64];
+    // the segment of this workgroup: selects on values that all arrive with the kernel arguments, no dependent load
+    unsigned bb = 0;
+    int nrows = S.nrows[0], lpr = S.lpr[0], ncols = S.ncols[0];
+    const int *I = S.I[0], *J = S.J[0];
+    const double *a = S.a[0], *x = S.x[0];
+    double *out = S.out[0];
+#pragma unroll
+    for (int i = 1; i < kFlatSegs; i++)
+        if (i < S.nsegs && blockIdx.x >= S.block_begin[i]) {
+            bb = S.block_begin[i]; nrows = S.nrows[i]; lpr = S.lpr[i]; ncols = S.ncols[i];
+            I = S.I[i]; J = S.J[i]; a = S.a[i]; x = S.x[i]; out = S.out[i];
+        }
+    const unsigned blk = blockIdx.x - bb;
+    switch (lpr) {
+    case 0: {
+        // dense row: every lane requests its (up to 4) matrix and vector entries before the first use (dense_gemv_row_kernel)
+        const int n = ncols;
+        const double *__restrict__ m = a + (size_t)blk * n;
+        double s = 0.0;
+        for (int j0 = threadIdx.x; j0 < n; j0 += 4 * kBlock) {
+            const int j1 = j0 + kBlock, j2 = j0 + 2 * kBlock, j3 = j0 + 3 * kBlock;
+            const double a0 = m[j0], b0 = x[j0];
+            const double a1 = j1 < n ? m[j1] : 0.0, b1 = j1 < n ? x[j1] : 0.0;
+            const double a2 = j2 < n ? m[j2] : 0.0, b2 = j2 < n ? x[j2] : 0.0;
+            const double a3 = j3 < n ? m[j3] : 0.0, b3 = j3 < n ? x[j3] : 0.0;
+            s += a0 * b0; s += a1 * b1; s += a2 * b2; s += a3 * b3;
+        }
+        s = group_reduce<64>(s);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) out[blk] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        break;
+    }
+    case 1: flat_seg_rows<1, U>(blk, nrows, I, J, a, x, out); break;
+    case 2: flat_seg_rows<2, U>(blk, nrows, I, J, a, x, out); break;
+    case 4: flat_seg_rows<4, U>(blk, nrows, I, J, a, x, out); break;
+    case 8: flat_seg_rows<8, U>(blk, nrows, I, J, a, x, out); break;
+    case 16: flat_seg_rows<16, U>(blk, nrows, I, J, a, x, out); break;
+    case 32: flat_seg_rows<32, U>(blk, nrows, I, J, a, x, out); break;
+    case 64: flat_seg_rows<64, U>(blk, nrows, I, J, a, x, out); break;
+    default: {
+        // a workgroup per (long) row
+        double s = flat_row_sum<kBlock, U>(I[blk], I[blk + 1], (int)threadIdx.x, J, a, x);
+        s = group_reduce<64>(s);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) out[blk] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        break;
+    }
+    }
+}
+
+template <int LPR, int NT, int U>
+__global__ __launch_bounds__(kBlock) void flat_sum_kernel(const FlatSum S)
+{
+    constexpr int GPB = kBlock / LPR;
+    const int row = (int)blockIdx.x * GPB + (int)threadIdx.x / LPR;
+    const int lane = threadIdx.x & (LPR - 1);
+    if (row >= S.nrows) return;
+    // every term's row bounds are requested together; then term after term, kFlatU entries per lane in flight
+    int s[NT], e[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) { s[t] = S.I[t][row]; e[t] = S.I[t][row + 1]; }
+    double y0 = 0.0;
+    if (lane == 0 && S.yin) y0 = S.yin[row];
+    double sum = 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; t++) sum += flat_row_sum<LPR, U>(s[t], e[t], lane, S.J[t], S.a[t], S.x[t]);
+    sum = group_reduce<LPR>(sum);
+    if (lane == 0) S.out[row] = y0 + sum;
+}
+
+template <int NT, int U>
+void flat_sum_dispatch(const FlatSum &S, hipStream_t st)
+{
+    switch (S.lpr) {
+    case 1: hipLaunchKernelGGL((flat_sum_kernel<1, NT, U>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    case 2: hipLaunchKernelGGL((flat_sum_kernel<2, NT, U>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    case 4: hipLaunchKernelGGL((flat_sum_kernel<4, NT, U>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    case 8: hipLaunchKernelGGL((flat_sum_kernel<8, NT, U>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    case 16: hipLaunchKernelGGL((flat_sum_kernel<16, NT, U>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    case 32: hipLaunchKernelGGL((flat_sum_kernel<32, NT, U>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    default: hipLaunchKernelGGL((flat_sum_kernel<64, NT, U>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    }
+}
+
+// lanes for rows of the given average length: the smallest power of two >= avg / 2; short of 2^16 lanes in all, the chain of a row is
+// the price and rows get up to as many lanes as they have entries (the rule of DevCSR::choose_spmv_shape)
+int flat_u()
+{
+    static int u = 0;
+    if (u == 0) { const char *e = getenv("ELAG_HIP_FLAT_U"); u = e ? atoi(e) : kFlatU; if (u != 2 && u != 8) u = 4; }
+    return u;
+}
+
+int flat_lanes(int nrows, double avg)
+{
+    static double div = 0.0;
+    static long long min_lanes = 0;
+    if (div == 0.0) {
+        const char *e = getenv("ELAG_HIP_FLAT_LANE_DIV"); div = e && atof(e) > 0 ? atof(e) : (double)flat_u();
+        const char *m = getenv("ELAG_HIP_FLAT_MIN_LANES"); min_lanes = m && atoll(m) > 0 ? atoll(m) : 32768;
+    }
+    int l = 1;
+    while (l < 64 && div * l < avg) l <<= 1;
+    while (l < 64 && (long long)nrows * l < min_lanes && l < avg) l <<= 1;
+    return l;
+}
+
+}  // namespace
+
+void flat_segs_add_csr(FlatSegs &S, const DevCSR &A, const double *x, double *out)
+{
+    ELAG_REQUIRE(S.nsegs < kFlatSegs, "internal: too many segments in a flat stage");
+    const int i = S.nsegs++;
+    const double avg = A.nrows ? (double)A.nnz / A.nrows : 0.0;
+    const int l = avg > 64.0 * flat_u() ? kBlock : flat_lanes(A.nrows, avg);
+    S.block_begin[i] = S.grid;
+    S.nrows[i] = A.nrows; S.ncols[i] = A.ncols; S.lpr[i] = l;
+    S.I[i] = A.I; S.J[i] = A.J; S.a[i] = A.a; S.x[i] = x; S.out[i] = out;
+    S.grid += l == kBlock ? (unsigned)A.nrows : (unsigned)(((long long)A.nrows * l + kBlock - 1) / kBlock);
+}
+
+void flat_segs_add_dense(FlatSegs &S, int nrows, int ncols, const double *M, const double *x, double *out)
+{
+    ELAG_REQUIRE(S.nsegs < kFlatSegs, "internal: too many segments in a flat stage");
+    const int i = S.nsegs++;
+    S.block_begin[i] = S.grid;
+    S.nrows[i] = nrows; S.ncols[i] = ncols; S.lpr[i] = 0;
+    S.a[i] = M; S.x[i] = x; S.out[i] = out;
+    S.grid += (unsigned)nrows;
+}
+
+void flat_sum_add(FlatSum &S, const DevCSR &A, const double *x)
+{
+    ELAG_REQUIRE(S.nterms < kFlatTerms, "internal: too many terms in a flat sum");
+    ELAG_REQUIRE(S.nterms == 0 || S.nrows == A.nrows, "internal: flat sum over operators of different heights");
+    const int t = S.nterms++;
+    S.nrows = A.nrows;
+    S.I[t] = A.I; S.J[t] = A.J; S.a[t] = A.a; S.x[t] = x;
+    S.grid += (unsigned)A.nnz;          // (entry count until flat_sum_finish)
+}
+
+void flat_sum_finish(FlatSum &S, const double *yin, double *out)
+{
+    const double avg = S.nrows ? (double)S.grid / S.nrows : 0.0;
+    S.lpr = flat_lanes(S.nrows, avg);
+    S.grid = (unsigned)(((long long)S.nrows * S.lpr + kBlock - 1) / kBlock);
+    S.yin = yin; S.out = out;
+}
+
+void flat_segs_launch(const FlatSegs &S0, const double *rhs, double *sol, hipStream_t st)
+{
+    if (!st) st = ctx().stream;
+    if (S0.grid == 0) return;
+    FlatSegs S = S0;
+    for (int i = 0; i < S.nsegs; i++) {
+        S.x[i] = resident_in_host(S.x[i], rhs, sol);
+        S.out[i] = const_cast<double *>(resident_in_host(S.out[i], rhs, sol));
+    }
+    switch (flat_u()) {
+    case 2: hipLaunchKernelGGL(flat_segs_kernel<2>, dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    case 8: hipLaunchKernelGGL(flat_segs_kernel<8>, dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    default: hipLaunchKernelGGL(flat_segs_kernel<4>, dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    }
+    ELAG_LAUNCH_CHECK();
+}
+
+void flat_sum_launch(const FlatSum &S0, const double *rhs, double *sol, hipStream_t st)
+{
+    if (!st) st = ctx().stream;
+    if (S0.grid == 0) return;
+    FlatSum S = S0;
+    for (int t = 0; t < S.nterms; t++) S.x[t] = resident_in_host(S.x[t], rhs, sol);
+    S.yin = resident_in_host(S.yin, rhs, sol);
+    S.out = const_cast<double *>(resident_in_host(S.out, rhs, sol));
+    const int u = flat_u();
+#define ELAG_FLAT_SUM(NT) (u == 2 ? flat_sum_dispatch<NT, 2>(S, st) : u == 8 ? flat_sum_dispatch<NT, 8>(S, st) : flat_sum_dispatch<NT, 4>(S, st))
+    switch (S.nterms) {
+    case 1: ELAG_FLAT_SUM(1); break;
+    case 2: ELAG_FLAT_SUM(2); break;
+    case 3: ELAG_FLAT_SUM(3); break;
+    default: ELAG_FLAT_SUM(4); break;
+    }
+#undef ELAG_FLAT_SUM
+    ELAG_LAUNCH_CHECK();
 }
 
 // ================================================================================================

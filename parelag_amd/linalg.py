@@ -525,6 +525,18 @@ class Hierarchy(_SolverBase):
         check(self._lib.elag_hip_hierarchy_launch_mode(self.h, C.byref(g), C.byref(k), C.byref(tg), C.byref(te)))
         return {"hipgraph": bool(g.value), "kernels_per_cycle": k.value, "graph_us": round(tg.value, 2), "plain_launches_us": round(te.value, 2)}
 
+    def setup_breakdown(self) -> dict:
+        """milliseconds of wall time per setup phase (Galerkin products, renumbering, smoothers, coarse solver, fused level operators,
+        SpMV forms, dense tail, flattened-cycle operators, launch mode): the reference's "Build Hierarchy" timer by phase"""
+        buf = C.create_string_buffer(2048)
+        check(self._lib.elag_hip_hierarchy_setup_breakdown(self.h, buf, 2048))
+        out = {}
+        for item in buf.value.decode().split(";"):
+            if item:
+                k, v = item.split("=")
+                out[k] = float(v)
+        return out
+
     def time_apply_internal(self, reps) -> float:
         """mean milliseconds per V-cycle on vectors in the hierarchy's own numbering (the cost inside a Krylov solve)"""
         ms = C.c_double(0)

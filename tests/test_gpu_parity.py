@@ -879,15 +879,51 @@ def test_resident_tail_kernel_gives_the_separate_launches_bits(la, h1_k2, hdiv_k
     assert "resident tail from level" in capfd.readouterr().err
 
 
+@pytest.mark.parametrize("smoother", ["L1 Jacobi", "Chebyshev"])
+def test_flattened_cycle_is_the_level_by_level_cycle(la, h1_k3, smoother, capfd):
+    """The launch-bound levels above the dense tail run as three launches with composed operators (hierarchy.hip, plan_flat), and the dense
+    tail itself is built by the recursion B_l = U_l + V_l B_{l+1} G_l instead of n applications of the sub-cycle: the same linear map as
+    the level-by-level launches (ELAG_HIP_FLAT_CYCLE=0, ELAG_HIP_DENSE_TAIL_RECURSION=0) up to rounding, and the oracle's cycle."""
+    import os
+    from oracle import oracle as orc
+    from tests.helpers import oracle_h1_hierarchy
+    A, Ps, _ = h1_k3
+    dA = la.ParallelCSRMatrix.from_scipy(A); dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    b = np.random.default_rng(47).uniform(-1, 1, A.shape[0])
+    outs = {}
+    for name, env in (("flat", {"ELAG_HIP_FLAT_VERBOSE": "1"}), ("levels", {"ELAG_HIP_FLAT_CYCLE": "0"}),
+                      ("levels_unit_vectors", {"ELAG_HIP_FLAT_CYCLE": "0", "ELAG_HIP_DENSE_TAIL_RECURSION": "0"})):
+        os.environ.update(env)
+        try:
+            H = la.buildHierarchyFromDeRhamSequence(dA, dPs, smoother)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        if name == "flat" and smoother == "L1 Jacobi":     # (the Chebyshev hierarchy of this size has one composed level only: nothing to flatten)
+            assert "flattened cycle: levels 0..2" in capfd.readouterr().err
+        x = np.zeros(A.shape[0])
+        H.Mult(b, x)
+        outs[name] = x
+    scale = np.max(np.abs(outs["levels"]))
+    assert np.max(np.abs(outs["flat"] - outs["levels"])) <= 1e-13 * scale
+    assert np.max(np.abs(outs["levels_unit_vectors"] - outs["levels"])) <= 1e-13 * scale
+    if smoother == "L1 Jacobi":
+        h = oracle_h1_hierarchy(A, Ps)
+        xr = np.empty_like(b)
+        orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"]).apply(b, xr)
+        assert np.max(np.abs(outs["flat"] - xr)) <= 1e-12 * np.max(np.abs(xr))
+
+
 def test_graph_replay_and_plain_launches_are_the_same_cycle(la, h1_k2):
-    """Finalize times a short cycle as a replayed hipGraph and as plain launches and keeps the faster (elag_hip_hierarchy_launch_mode);
-    ELAG_HIP_GRAPH_MODE forces either.  The kernels are the same, so is every bit of the result; the record says what was measured."""
+    """Finalize issues a cycle of up to 32 kernels as plain launches and a longer one as a replayed hipGraph (elag_hip_hierarchy_launch_mode);
+    ELAG_HIP_GRAPH_MODE forces either, or asks for the round-2 timing of both.  The kernels are the same, so is every bit of the result; the
+    record says what was decided and, when asked, measured."""
     import os
     A, Ps, _ = h1_k2
     dA = la.ParallelCSRMatrix.from_scipy(A); dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
     b = np.random.default_rng(43).uniform(-1, 1, A.shape[0])
     outs, modes = [], {}
-    for mode in ("graph", "eager", None):
+    for mode in ("graph", "eager", "measure", None):
         if mode:
             os.environ["ELAG_HIP_GRAPH_MODE"] = mode
         try:
@@ -899,10 +935,14 @@ def test_graph_replay_and_plain_launches_are_the_same_cycle(la, h1_k2):
         for _ in range(3):                                       # (a graph is captured at the first call and replayed afterwards)
             H.Mult(b, x)
         outs.append(x)
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
     assert modes["graph"]["hipgraph"] is True and modes["eager"]["hipgraph"] is False
-    auto = modes[None]
-    assert 0 < auto["kernels_per_cycle"] <= 16 and auto["graph_us"] > 0 and auto["plain_launches_us"] > 0
-    assert auto["hipgraph"] == (not auto["plain_launches_us"] < 0.97 * auto["graph_us"])
+    meas = modes["measure"]
+    assert 0 < meas["kernels_per_cycle"] <= 16 and meas["graph_us"] > 0 and meas["plain_launches_us"] > 0
+    assert meas["hipgraph"] == (not meas["plain_launches_us"] < 0.97 * meas["graph_us"])
+    auto = modes[None]                                           # the rule: a short cycle runs as plain launches, nothing is timed
+    assert 0 < auto["kernels_per_cycle"] <= 16 and auto["hipgraph"] is False and auto["graph_us"] == 0.0 and auto["plain_launches_us"] == 0.0
+    sb = H.setup_breakdown()
+    assert {"galerkin_products", "smoothers", "coarse_solver", "fused_level_operators", "dense_tail"} <= set(sb) and all(v >= 0.0 for v in sb.values())
     H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi", use_graph=False)
     assert H.launch_mode() == {"hipgraph": False, "kernels_per_cycle": 0, "graph_us": 0.0, "plain_launches_us": 0.0}
