@@ -405,7 +405,7 @@ def main():
             if not roof_cycle_err <= 1e-10:
                 raise SystemExit("cube456 x%d V-cycle differs from the oracle by %.3e (> 1e-10)" % (k, roof_cycle_err))
         roof = {"bound": "hbm", "kernel": f"{kern} ({kdesc}; {kwin} entries per workgroup window; fine-level y = A x, level-0 operator of the hierarchy; chosen by "
-                                          "the library's setup-time measurement of the stream form and three x-cache window sizes on this operator)",
+                                          "the library's rule: x-cache / 2304 where a window's entries share their columns >= 4-fold, the stream kernel below)",
                 "window": kwin,
                 "parity_roofline_rel_err": roof_err, "parity_vcycle_rel_err_vs_oracle": roof_cycle_err, "forms_same_session": ab,
                 "workload": f"cube456 x{k} refines, H1 A: n={n}, nnz={nnz}",

@@ -4,6 +4,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 
 namespace elag {
 
@@ -164,15 +167,17 @@ void DevCSR::choose_spmv_shape()
     release_xc();          // (before the stream plan goes: the x-cache form may alias it)
     release_sign();
     dev_free(block_row);
-    nblocks = 0;
-    k::build_stream_plan(*this);
+    nblocks = 0; max_row_nnz = 0;
+    // the window plan (and the longest row) is what the stream kernels need: operators below their size gate get it when someone asks
+    // for it (csr_sort_rows, a forced form) -- an allocation, two launches and a drain less per small matrix at setup
+    if (nnz >= (int64_t(1) << 20)) k::build_stream_plan(*this);
     if (forced > 0) { lanes_per_row = forced; return; }
     // the stream kernel wins once the matrix outgrows the caches' latency regime; small (coarse-level) operators
     // are launch/latency-bound and do better with one dependent phase less
     // (measured on the H(div) hierarchy of cube456 x3: an interpolator with 2.5 entries per row runs 25 % faster with one lane
     //  per row than with 2048-entry windows that hold 800 rows each -- tools/hdiv_kernels.py)
     const double avg_row = nrows ? (double)nnz / nrows : 0.0;
-    if (max_row_nnz <= kStreamMaxRow && nnz >= (int64_t(1) << 20) && !(avg_row < 3.5 && nnz < (int64_t(1) << 22))) { lanes_per_row = 0; return; }
+    if (block_row && max_row_nnz <= kStreamMaxRow && nnz >= (int64_t(1) << 20) && !(avg_row < 3.5 && nnz < (int64_t(1) << 22))) { lanes_per_row = 0; return; }
     // lanes per row = smallest power of two >= (nnz/row)/2 (measured against /4 and /8 with four entries in flight per lane: tools/lane_ab.sh)
     const double avg = nrows ? (double)nnz / nrows : 0.0;
     static double lane_div = 0.0;
@@ -192,6 +197,84 @@ void DevCSR::choose_spmv_shape()
 }  // namespace elag
 
 namespace elag {
+namespace {
+// block sizes of live device allocations (any thread may free what another allocated)
+std::mutex g_alloc_mu;
+std::unordered_map<void *, size_t> g_alloc_size;
+struct AllocCache {
+    int depth = 0;
+    size_t held = 0;
+    std::multimap<size_t, void *> blocks;
+};
+thread_local AllocCache t_cache;
+constexpr size_t kCacheMaxHeld = size_t(2) << 30;
+
+size_t round_block(size_t bytes)
+{
+    if (bytes < 256) return 256;
+    // a sixteenth of the size's power of two: at most 6 % over the request
+    size_t g = 256;
+    while ((g << 4) <= bytes) g <<= 1;
+    return (bytes + g - 1) / g * g;
+}
+}  // namespace
+
+void *raw_alloc(size_t bytes)
+{
+    const size_t sz = round_block(bytes);
+    void *p = nullptr;
+    if (t_cache.depth > 0) {
+        auto it = t_cache.blocks.lower_bound(sz);
+        if (it != t_cache.blocks.end() && it->first <= sz + sz / 4) {
+            p = it->second;
+            t_cache.held -= it->first;
+            std::lock_guard<std::mutex> lk(g_alloc_mu);
+            g_alloc_size[p] = it->first;
+            t_cache.blocks.erase(it);
+            return p;
+        }
+    }
+    ELAG_HIP_CHECK(hipMalloc(&p, sz));
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    g_alloc_size[p] = sz;
+    return p;
+}
+
+void raw_free(void *p)
+{
+    if (!p) return;
+    size_t sz = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_alloc_mu);
+        auto it = g_alloc_size.find(p);
+        if (it != g_alloc_size.end()) { sz = it->second; g_alloc_size.erase(it); }
+    }
+    if (t_cache.depth > 0 && sz > 0 && t_cache.held + sz <= kCacheMaxHeld) {
+        t_cache.blocks.emplace(sz, p);
+        t_cache.held += sz;
+        return;
+    }
+    (void)hipFree(p);
+}
+
+AllocScope::AllocScope(bool enable)
+{
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("ELAG_HIP_NO_ALLOC_CACHE"); off = (e && atoi(e)) ? 1 : 0; }
+    active = enable && !off;
+    if (active) t_cache.depth++;
+}
+
+AllocScope::~AllocScope()
+{
+    if (!active) return;
+    if (--t_cache.depth > 0) return;
+    if (ctx().stream) (void)hipStreamSynchronize(ctx().stream);
+    for (auto &b : t_cache.blocks) (void)hipFree(b.second);
+    t_cache.blocks.clear();
+    t_cache.held = 0;
+}
+
 namespace {
 double spin_budget_ms()
 {

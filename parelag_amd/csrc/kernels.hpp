@@ -154,6 +154,11 @@ void csr_scale_rows(DevCSR &A, const double *d);
 void csr_scale_cols(DevCSR &A, const double *d);  // a_ij *= d_j
 void csr_copy(const DevCSR &A, DevCSR &out);
 void csr_diagonal(int n, const double *d, double scale, DevCSR &out);   // out = scale * diag(d)  (d == nullptr: scale * I)
+// Renumbering of a level under its coarse level's (hierarchy.hip, `reorder`): children contiguous under their strongest coarse parent.
+// d_order_out[new] = old for the nf rows of P: a stable counting sort of the rows by rank_c[argmax_k |P_ik|] (first maximum in
+// storage order; rows without entries last) -- the sort is a transpose of the (row -> key) incidence, whose rows come back ascending.
+void child_order(const DevCSR &P, const int *d_rank_c, int *d_order_out);
+void inverse_permutation(int n, const int *d_order, int *d_rank);     // rank[order[r]] = r
 // out = A(order_rows, :) with columns renumbered by rank_cols (old -> new); rows come back column-sorted
 void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_cols, int ncols_out, DevCSR &out);
 

@@ -497,9 +497,17 @@ inline unsigned grid1(long long n, int b = kBlock) { return (unsigned)((n + b - 
 struct EscPlan {
     int nrows;
     Temp<int> ub, ub_small, ubscan, biglist, counters;
+    // single-pass wave path: per-row upper bounds of the wave rows, their scan, and the class row lists -- launched in finish() with the
+    // rest of the plan, so that ONE drain returns every number the host needs (three drains per sparse product in round 2)
+    Temp<int> ubw, UBI, ccount, lists;
     int total_small = 0, nbig = 0;
     int wave_cap = 0;   // > 0: rows with at most this many products go to esc_wave_kernel
-    explicit EscPlan(int n) : nrows(n), ub((size_t)n), ub_small((size_t)n), ubscan((size_t)n + 1), biglist((size_t)n), counters(2) {}
+    bool wave_ready = false;          // ubw / UBI / class lists are in place and total_ub / hc are known
+    unsigned long long total_ub = 0;
+    int hc[kNumClasses] = {0, 0, 0, 0, 0};
+    explicit EscPlan(int n)
+        : nrows(n), ub((size_t)n), ub_small((size_t)n), ubscan((size_t)n + 1), biglist((size_t)n), counters(2 + kNumClasses + 1), ubw((size_t)n),
+          UBI((size_t)n + 1), ccount(kNumClasses), lists((size_t)kNumClasses * (size_t)n) {}
     void finish()
     {
         hipStream_t st = ctx().stream;
@@ -507,14 +515,29 @@ struct EscPlan {
         hipLaunchKernelGGL(split_big_kernel, dim3(grid1(nrows)), dim3(kBlock), 0, st, nrows, ub.p, ub_small.p, biglist.p,
                            counters.p, counters.p + 1, wave_cap);
         exclusive_scan(ub_small, ubscan, nrows);
-        int h[2], tot;
+        // an upper-bound layout indexed with ints: only when nrows * wave_cap cannot overflow them (the caller's fallback handles the rest)
+        const bool wave = wave_cap > 0 && single_pass_enabled() && (unsigned long long)nrows * (unsigned long long)wave_cap < (1ull << 31);
+        if (wave) {
+            hipLaunchKernelGGL(wave_ub_kernel, dim3(grid1(nrows)), dim3(kBlock), 0, st, nrows, (const int *)ub.p, wave_cap, ubw.p, (unsigned long long *)nullptr);
+            exclusive_scan(ubw, UBI, nrows);
+            const ClassBounds cb{{0, 16, 32, 64, 128, kWaveCap}};
+            ELAG_HIP_CHECK(hipMemsetAsync(ccount, 0, sizeof(int) * kNumClasses, st));
+            hipLaunchKernelGGL(esc_classify_kernel, dim3(grid1(nrows)), dim3(kBlock), 0, st, nrows, (const int *)ub.p, cb, ccount.p, lists.p, 1);
+            ELAG_LAUNCH_CHECK();
+        }
+        int h[2], tot, totw = 0;
         ELAG_HIP_CHECK(hipMemcpyAsync(h, counters.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
         ELAG_HIP_CHECK(hipMemcpyAsync(&tot, ubscan.p + nrows, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (wave) {
+            ELAG_HIP_CHECK(hipMemcpyAsync(&totw, UBI.p + nrows, sizeof(int), hipMemcpyDeviceToHost, st));
+            ELAG_HIP_CHECK(hipMemcpyAsync(hc, ccount.p, sizeof(int) * kNumClasses, hipMemcpyDeviceToHost, st));
+        }
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
         if (h[1] > 0)
             fail(ELAG_HIP_ERR_ARG, "sparse product: %d rows expand to more than %d intermediate products (unsupported)", h[1], kBigCap);
         nbig = h[0];
         total_small = tot;
+        if (wave) { wave_ready = true; total_ub = (unsigned long long)totw; }
     }
     int nchunks() const { return (total_small + kCap - 1) / kCap; }
 };
@@ -536,41 +559,37 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
     // ---- single pass for the wave rows: numeric launch into an upper-bound layout, counts recorded on the way, then a
     //      compaction (the symbolic launches of these rows -- a third of a Galerkin product's time -- are not needed) ----
     if (plan.wave_cap > 0 && single_pass_enabled()) {
-        Temp<int> ubw((size_t)n), UBI((size_t)n + 1);
-        Temp<unsigned long long> tot64(1);
-        ELAG_HIP_CHECK(hipMemsetAsync(tot64, 0, sizeof(unsigned long long), st));
-        const bool may_overflow = (unsigned long long)n * (unsigned long long)plan.wave_cap >= (1ull << 31);
-        hipLaunchKernelGGL(wave_ub_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, (const int *)plan.ub.p, plan.wave_cap, ubw.p,
-                           may_overflow ? tot64.p : (unsigned long long *)nullptr);
-        ELAG_LAUNCH_CHECK();
-        unsigned long long total_ub = 0;
-        if (may_overflow) {
+        Temp<int> &ubw = plan.ubw, &UBI = plan.UBI, &lists = plan.lists;
+        unsigned long long total_ub = plan.total_ub;
+        int hc[kNumClasses];
+        const int *ubp = plan.ub.p;
+        if (plan.wave_ready) {
+            for (int c = 0; c < kNumClasses; c++) hc[c] = plan.hc[c];
+        } else {
+            // (plans whose nrows * wave_cap could overflow the int layout: the total first, the layout only if it fits)
+            Temp<unsigned long long> tot64(1);
+            ELAG_HIP_CHECK(hipMemsetAsync(tot64, 0, sizeof(unsigned long long), st));
+            hipLaunchKernelGGL(wave_ub_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, (const int *)plan.ub.p, plan.wave_cap, ubw.p, tot64.p);
+            ELAG_LAUNCH_CHECK();
             ELAG_HIP_CHECK(hipMemcpyAsync(&total_ub, tot64.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             ELAG_HIP_CHECK(hipStreamSynchronize(st));
+            if (total_ub < (1ull << 31)) {
+                exclusive_scan(ubw, UBI, n);
+                const ClassBounds cb{{0, 16, 32, 64, 128, kWaveCap}};
+                ELAG_HIP_CHECK(hipMemsetAsync(plan.ccount, 0, sizeof(int) * kNumClasses, st));
+                hipLaunchKernelGGL(esc_classify_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, ubp, cb, plan.ccount.p, lists.p, 1);
+                ELAG_LAUNCH_CHECK();
+                ELAG_HIP_CHECK(hipMemcpyAsync(hc, plan.ccount.p, sizeof(int) * kNumClasses, hipMemcpyDeviceToHost, st));
+                ELAG_HIP_CHECK(hipStreamSynchronize(st));
+            }
         }
         // the upper-bound layout is indexed with ints and lives in the scratch arena: at most 2^31 - 1 products and 16 GiB
-        if (total_ub < (1ull << 31)) {
-            exclusive_scan(ubw, UBI, n);
-            int tot = 0;
-            ELAG_HIP_CHECK(hipMemcpyAsync(&tot, UBI.p + n, sizeof(int), hipMemcpyDeviceToHost, st));
-            ELAG_HIP_CHECK(hipStreamSynchronize(st));
-            total_ub = (unsigned long long)tot;
-        }
         if (total_ub < (1ull << 31) && total_ub * 12ull <= (16ull << 30)) {
             Temp<int> Ju((size_t)std::max<long long>(total_ub, 1));
             Temp<double> au((size_t)std::max<long long>(total_ub, 1));
-            const int *ubp = plan.ub.p;
             // row classes by number of products, each with the smallest lane group that still expands a row in one pass (the
             // entries of the left factor's row are what the lanes of a group share out: 15 for A, 2-15 for P^T; the products
             // only set how many slots a lane owns, R), each launched over the list of ITS rows
-            const ClassBounds cb{{0, 16, 32, 64, 128, kWaveCap}};
-            Temp<int> ccount(kNumClasses), lists((size_t)kNumClasses * (size_t)n);
-            ELAG_HIP_CHECK(hipMemsetAsync(ccount, 0, sizeof(int) * kNumClasses, st));
-            hipLaunchKernelGGL(esc_classify_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, ubp, cb, ccount.p, lists.p, 1);
-            ELAG_LAUNCH_CHECK();
-            int hc[kNumClasses];
-            ELAG_HIP_CHECK(hipMemcpyAsync(hc, ccount.p, sizeof(int) * kNumClasses, hipMemcpyDeviceToHost, st));
-            ELAG_HIP_CHECK(hipStreamSynchronize(st));
             auto cls_list = [&](int c) { return (const int *)(lists.p + (size_t)c * n); };
             if (hc[0])
                 hipLaunchKernelGGL((esc_wave_kernel<16, 1, true, Expander>), dim3(grid1((long long)hc[0] * 16)), dim3(kBlock), 0, st, n, ubp, 0, 16, ex,
@@ -605,7 +624,7 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
             hipLaunchKernelGGL(esc_compact_kernel, dim3(grid1((long long)n * 16)), dim3(kBlock), 0, st, n, (const int *)ubw.p, (const int *)UBI.p,
                                (const int *)C.I, (const int *)Ju.p, (const double *)au.p, C.J, C.a);
             ELAG_LAUNCH_CHECK();
-            ELAG_HIP_CHECK(hipStreamSynchronize(st));      // Ju / au go back to the arena when this scope ends
+            // (Ju / au go back to the arena when this scope ends: the arena recycles in stream order, no drain needed)
             if (spmv_plan) C.choose_spmv_shape();
             return;
         }
@@ -892,6 +911,52 @@ void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_col
     ELAG_LAUNCH_CHECK();
     if (A.nnz) csr_sort_rows(out);
     else out.choose_spmv_shape();
+}
+
+namespace {
+__global__ void parent_key_kernel(int nf, int nc, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
+                                  const int *__restrict__ rank_c, int *__restrict__ KI, int *__restrict__ KJ, double *__restrict__ Ka)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nf) return;
+    KI[i] = i;
+    if (i == nf) return;
+    int best = -1;
+    double bv = -1.0;
+    for (int k = I[i]; k < I[i + 1]; k++) {
+        const double v = fabs(a[k]);
+        if (v > bv) { bv = v; best = J[k]; }
+    }
+    KJ[i] = best < 0 ? nc : rank_c[best];
+    Ka[i] = 1.0;
+}
+__global__ void inverse_perm_kernel(int n, const int *__restrict__ order, int *__restrict__ rank)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) rank[order[r]] = r;
+}
+}  // namespace
+
+void child_order(const DevCSR &P, const int *d_rank_c, int *d_order_out)
+{
+    const int nf = P.nrows, nc = P.ncols;
+    if (nf == 0) return;
+    hipStream_t st = ctx().stream;
+    DevCSR K, KT;
+    K.alloc(nf, nc + 1, nf);
+    hipLaunchKernelGGL(parent_key_kernel, dim3(grid1(nf + 1)), dim3(kBlock), 0, st, nf, nc, (const int *)P.I, (const int *)P.J, (const double *)P.a, d_rank_c,
+                       K.I, K.J, K.a);
+    ELAG_LAUNCH_CHECK();
+    csr_transpose(K, KT);            // row p of KT: the children of the coarse dof of rank p, ascending
+    ELAG_HIP_CHECK(hipMemcpyAsync(d_order_out, KT.J, sizeof(int) * (size_t)nf, hipMemcpyDeviceToDevice, st));
+    ELAG_HIP_CHECK(hipStreamSynchronize(st));        // (K / KT go out of scope)
+}
+
+void inverse_permutation(int n, const int *d_order, int *d_rank)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(inverse_perm_kernel, dim3(grid1(n)), dim3(kBlock), 0, ctx().stream, n, d_order, d_rank);
+    ELAG_LAUNCH_CHECK();
 }
 
 namespace {

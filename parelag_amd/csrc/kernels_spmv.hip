@@ -625,7 +625,7 @@ void build_stream_plan(DevCSR &A)
 namespace {
 
 // builds the x-cache tables of A for `window` entries per workgroup; false when it does not apply (or, unforced, does not pay)
-bool xc_build(const DevCSR &A, int window, bool force)
+bool xc_build(const DevCSR &A, int window, bool force, double min_reuse = 2.0)
 {
     const int cap = window + A.max_row_nnz + 8;
     if (cap > 8192) return false;                       // builder capacity; two LDS arrays of the kernel stay <= 64 KB + xs
@@ -664,7 +664,7 @@ bool xc_build(const DevCSR &A, int window, bool force)
     if (getenv("ELAG_HIP_XC_VERBOSE"))
         fprintf(stderr, "[elag_hip] x-cache: n=%d nnz=%lld window=%d windows=%d unique/window avg %.1f max %d reuse %.2f\n", A.nrows, (long long)A.nnz,
                 window, nb, (double)total / nb, mx, reuse);
-    if ((!force && reuse < 2.0) || mx > 65535) {
+    if ((!force && reuse < min_reuse) || mx > 65535) {
         dev_free(uoff);
         if (plan != A.block_row) dev_free(plan);
         return false;
@@ -713,9 +713,23 @@ void prepare_spmv(const DevCSR &A, bool force)
         if (!xc_build(A, w, force)) A.xc_state = -1;
         return;
     }
-    // Heuristic mode: let the operator itself decide.  A few launches of each candidate on a scratch vector pair (HIP events
-    // on this stream, under kernel names of their own): the plain stream kernel and the x-cache form with three window sizes.
-    // The x-cache form is kept only when it is measurably faster on THIS operator and THIS device (profiles/r02_spmv_forms_*.txt).
+    // Heuristic mode.  Round 2 let a measurement decide at every Finalize -- the plain stream kernel against x-cache windows of 2048, 2304
+    // and 1664 entries, three sorted window plans and ~40 launches per operator, 29 ms of a 70 ms setup at cube456 x5 -- and every
+    // operator it ever measured came out the same way (tools/xc_reuse_probe.py): the 2304-entry window is the best of the three wherever
+    // the form wins, and the form wins exactly where a window's entries share their columns well -- entries per distinct column 4.6-6.9
+    // on the renumbered level operators and on P (x-cache faster by 7-15 %), 2.9-3.1 on the same operators in the caller's numbering
+    // (stream kernel faster by 3-7 %), 1.4 on P^T.  So the rule is the reuse itself, counted by the first pass of the one plan that
+    // would be built anyway: x-cache / 2304 from 4 entries per distinct column, the stream kernel below.  ELAG_HIP_XC_MEASURE=1 keeps
+    // the measurement (A/B runs).
+    static int measure = -1;
+    if (measure < 0) { const char *e = getenv("ELAG_HIP_XC_MEASURE"); measure = (e && atoi(e)) ? 1 : 0; }
+    if (!measure) {
+        const int w = xc_window_env() ? xc_window_env() : 2304;
+        if (!xc_build(A, w, false, 4.0)) A.xc_state = -1;
+        return;
+    }
+    // A few launches of each candidate on a scratch vector pair (HIP events on this stream, under kernel names of their own): the plain
+    // stream kernel and the x-cache form with three window sizes; the x-cache form is kept only when it is measurably faster.
     Temp<double> tx((size_t)std::max(A.ncols, A.nrows)), ty((size_t)A.nrows);
     ELAG_HIP_CHECK(hipMemsetAsync(tx, 0, sizeof(double) * (size_t)std::max(A.ncols, A.nrows), st));
     SpmvArgs p;

@@ -624,6 +624,7 @@ int elag_hip_parcsr_set_spmv_lanes(elag_hip_parcsr_t A, int lanes)
         ELAG_REQUIRE(A, "null matrix");
         if (lanes == -1 || lanes == -2) {
             // the LDS-staged stream kernel regardless of size; -1 additionally forces its windowed x-cache form
+            if (!A->diag.block_row) k::build_stream_plan(A->diag);         // (small operators get their window plan on request)
             ELAG_REQUIRE(A->diag.block_row && A->diag.max_row_nnz <= DevCSR::kStreamMaxRow, "rows too long for the stream kernel");
             A->diag.lanes_per_row = 0;
             A->diag.release_xc();
