@@ -127,7 +127,17 @@ struct CsrView {
 // Expanders: ub(row) = number of expanded entries, expand(row) writes them at lds offset `off`.
 struct MatmulExpander {
     CsrView A, B;
+    static constexpr bool kUnits = true;
     __device__ int ub_entry(int k) const { const int j = A.J[k]; return B.I[j + 1] - B.I[j]; }
+    // hash path: a row is a list of units (the entries of A's row), each a run of products scale * a[pbeg + q] in column J[pbeg + q]
+    __device__ void units(int row, int &ubeg, int &nu) const { ubeg = A.I[row]; nu = A.I[row + 1] - ubeg; }
+    __device__ void unit(int row, int ubeg, int u, int &pbeg, int &plen, double &scale, const int *&J, const double *&a) const
+    {
+        const int j = A.J[ubeg + u];
+        scale = A.a[ubeg + u];
+        pbeg = B.I[j]; plen = B.I[j + 1] - pbeg;
+        J = B.J; a = B.a;
+    }
     // cooperative expansion of one row by a group of G lanes (G = 64: a wavefront)
     template <bool NUMERIC, int G = 64>
     __device__ void expand(int row, unsigned rl, int off, u64 *key, double *val) const
@@ -155,6 +165,16 @@ struct MatmulExpander {
 struct AddExpander {
     CsrView A, B;
     double ca, cb;
+    static constexpr bool kUnits = true;
+    // two units: A's row scaled by ca, then B's row scaled by cb
+    __device__ void units(int row, int &ubeg, int &nu) const { ubeg = 0; nu = 2; }
+    __device__ void unit(int row, int, int u, int &pbeg, int &plen, double &scale, const int *&J, const double *&a) const
+    {
+        const CsrView &M = u == 0 ? A : B;
+        scale = u == 0 ? ca : cb;
+        pbeg = M.I[row]; plen = M.I[row + 1] - pbeg;
+        J = M.J; a = M.a;
+    }
     template <bool NUMERIC, int G = 64>
     __device__ void expand(int row, unsigned rl, int off, u64 *key, double *val) const
     {
@@ -174,6 +194,7 @@ struct AddExpander {
 
 struct SortExpander {  // identity: re-emit the row (used to sort columns inside rows)
     CsrView A;
+    static constexpr bool kUnits = false;
     template <bool NUMERIC, int G = 64>
     __device__ void expand(int row, unsigned rl, int off, u64 *key, double *val) const
     {
@@ -415,6 +436,107 @@ __global__ __launch_bounds__(kBlock) void esc_wave_kernel(int nrows, const int *
     }
 }
 
+// ---- hash path -------------------------------------------------------------------------------------------------------
+// The wave path above spends 587 VALU + 285 SALU + 99 LDS instructions per wavefront on 15 memory reads (profiles/r02_rap_pmc.txt): every lane
+// compares its products with every product of the row, twice.  Here a group of G lanes owns a row and a small open-addressing table
+// in LDS (S slots >= the row's products): the lanes fetch the row's units together (an entry of the left factor's row and the bounds of
+// the right factor's row it selects) and R products each, then insert them ONE LANE AFTER THE OTHER, in storage order -- first product
+// of a column stored, later ones added: the sums are the wave path's (and the reference's marker loop's) bit for bit, and no atomics
+// are involved.  The distinct columns are then compacted, ranked among themselves (E^2 / G comparisons instead of products^2 / G) and
+// written in ascending order into the upper-bound layout, like the wave path's single pass.
+template <int G, int R, int S, int NU, int BLOCK, class Expander>
+__global__ __launch_bounds__(BLOCK) void esc_hash_kernel(int nrows, Expander ex, int *__restrict__ rownnz, const int *__restrict__ CI,
+                                                         int *__restrict__ CJ, double *__restrict__ Ca, const int *__restrict__ rowlist, int nlist)
+{
+    constexpr int NG = BLOCK / G;
+    constexpr int LOG2S = S == 16 ? 4 : S == 32 ? 5 : S == 64 ? 6 : S == 128 ? 7 : 8;
+    static_assert((1 << LOG2S) == S, "table sizes are 16 ... 256");
+    __shared__ int key[NG * S];
+    __shared__ double val[NG * S];
+    const int g = threadIdx.x / G, lane = threadIdx.x & (G - 1);
+    const int gi = blockIdx.x * NG + g;
+    const bool active = gi < nlist;
+    const int row = active ? rowlist[gi] : 0;
+    int *kt = key + g * S;
+    double *vt = val + g * S;
+    for (int s = lane; s < S; s += G) kt[s] = -1;
+    int ubeg = 0, nu = 0;
+    if (active) ex.units(row, ubeg, nu);
+    const int gshift = (int)(threadIdx.x & 63) & ~(G - 1);          // first lane of this group inside its wavefront
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << gshift;
+    // NU units per lane and pass, R products per unit: everything a pass needs is requested before the first insert, so a row of up to
+    // G * NU units costs four memory round trips (row bounds, units, their product runs' bounds, the products) however long it is --
+    // with one unit per lane and pass the A P rows of cube456 x5 (15 units) paid sixteen: 327 us for the product, 2 x that per RAP
+    for (int u0 = 0; __ballot(u0 < nu) & gmask; u0 += G * NU) {
+        int pbeg[NU], plen[NU];
+        double scale[NU];
+        const int *J[NU];
+        const double *a[NU];
+#pragma unroll
+        for (int t = 0; t < NU; t++) {
+            const int u = u0 + t * G + lane;
+            pbeg[t] = 0; plen[t] = 0; scale[t] = 0.0; J[t] = nullptr; a[t] = nullptr;
+            if (u < nu) ex.unit(row, ubeg, u, pbeg[t], plen[t], scale[t], J[t], a[t]);
+        }
+        int pmax = 0;
+#pragma unroll
+        for (int t = 0; t < NU; t++) pmax = plen[t] > pmax ? plen[t] : pmax;
+        for (int q0 = 0; __ballot(q0 < pmax) & gmask; q0 += R) {
+            int c[NU][R];
+            double v[NU][R];
+#pragma unroll
+            for (int t = 0; t < NU; t++)
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    c[t][r] = -1; v[t][r] = 0.0;
+                    if (q0 + r < plen[t]) { c[t][r] = J[t][pbeg[t] + q0 + r]; v[t][r] = a[t][pbeg[t] + q0 + r]; }
+                }
+            // one lane after the other, unit after unit: the insertion order is the storage order of the products (exactly so when a
+            // unit's products fit one pass of R; a longer unit's later products follow the other units' first R -- still one fixed order)
+#pragma unroll
+            for (int t = 0; t < NU; t++) {
+                for (int p = 0; p < G; p++) {
+                    if (lane == p) {
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            if (c[t][r] >= 0) {
+                                const double pv = scale[t] * v[t][r];
+                                unsigned h = ((unsigned)c[t][r] * 2654435761u) >> (32 - LOG2S);
+                                while (true) {
+                                    const int kk = kt[h];
+                                    if (kk == c[t][r]) { vt[h] += pv; break; }
+                                    if (kk < 0) { kt[h] = c[t][r]; vt[h] = pv; break; }
+                                    h = (h + 1) & (S - 1);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // compact the occupied slots to the front of the table, chunk of G slots by chunk (every lane reads its slot before any writes)
+    int E = 0;
+    for (int s0 = 0; s0 < S; s0 += G) {
+        const int kk = kt[s0 + lane];
+        const double vv = vt[s0 + lane];
+        unsigned long long m = __ballot(kk >= 0) & gmask;
+        m >>= gshift;
+        if (kk >= 0) { const int e = E + __popcll(m & ((1ull << lane) - 1ull)); kt[e] = kk; vt[e] = vv; }
+        E += __popcll(m);
+    }
+    if (!active) return;
+    if (lane == 0) rownnz[row] = E;
+    const int base = CI[row];
+    for (int i = lane; i < E; i += G) {
+        const int ci = kt[i];
+        int rank = 0;
+        for (int t = 0; t < E; t++) rank += (kt[t] < ci) ? 1 : 0;
+        CJ[base + rank] = ci;
+        Ca[base + rank] = vt[i];
+    }
+}
+
 // ub of the rows the wave path handles (others 0): its scan gives the rows' offsets in the upper-bound layout
 __global__ void wave_ub_kernel(int nrows, const int *__restrict__ ub, int wave_cap, int *__restrict__ ubw, unsigned long long *__restrict__ total)
 {
@@ -429,16 +551,16 @@ __global__ void wave_ub_kernel(int nrows, const int *__restrict__ ub, int wave_c
     }
 }
 
-// rows written in the upper-bound layout -> their final place (16 lanes per row; rows of the chunked path have ubw == 0)
+// rows written in the upper-bound layout -> their final place (8 lanes per row; rows of the chunked path have ubw == 0)
 __global__ __launch_bounds__(kBlock) void esc_compact_kernel(int nrows, const int *__restrict__ ubw, const int *__restrict__ UBI,
                                                              const int *__restrict__ CI, const int *__restrict__ Ju, const double *__restrict__ au,
                                                              int *__restrict__ CJ, double *__restrict__ Ca)
 {
-    const int row = (int)((blockIdx.x * (long long)kBlock + threadIdx.x) >> 4);
-    const int lane = threadIdx.x & 15;
+    const int row = (int)((blockIdx.x * (long long)kBlock + threadIdx.x) >> 3);
+    const int lane = threadIdx.x & 7;
     if (row >= nrows || ubw[row] == 0) return;
     const int src = UBI[row], dst = CI[row], cnt = CI[row + 1] - dst;
-    for (int e = lane; e < cnt; e += 16) { CJ[dst + e] = Ju[src + e]; Ca[dst + e] = au[src + e]; }
+    for (int e = lane; e < cnt; e += 8) { CJ[dst + e] = Ju[src + e]; Ca[dst + e] = au[src + e]; }
 }
 
 // rows of the wave path sorted into their classes by number of products: class c holds the rows with bounds[c] < ub <= bounds[c+1].
@@ -449,33 +571,67 @@ struct ClassBounds { int b[kNumClasses + 1]; };
 __global__ __launch_bounds__(kBlock) void esc_classify_kernel(int nrows, const int *__restrict__ ub, ClassBounds cb, int *__restrict__ counters /*kNumClasses*/,
                                                               int *__restrict__ lists /*kNumClasses x nrows*/, int fill)
 {
+    // A workgroup owns a contiguous span of rows: it counts its rows per class, reserves one range per class (ONE atomic each for the whole
+    // span -- with a reservation per 256 rows the 50 000 atomics on five addresses were 100 of this kernel's 116 us at cube456 x5) and
+    // writes its rows there in ascending order.
     __shared__ int wcount[kNumClasses][kBlock / 64];
     __shared__ int base[kNumClasses];
-    const int row = blockIdx.x * kBlock + threadIdx.x;
-    const int u = row < nrows ? ub[row] : 0;
-    int cls = -1;
-#pragma unroll
-    for (int c = 0; c < kNumClasses; c++)
-        if (u > cb.b[c] && u <= cb.b[c + 1]) cls = c;
+    __shared__ int running[kNumClasses];
+    const int span = (int)((((long long)nrows + gridDim.x - 1) / gridDim.x + kBlock - 1) / kBlock) * kBlock;
+    const int r0 = (int)blockIdx.x * span, r1 = min(nrows, r0 + span);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int before = 0;
+    auto cls_of = [&](int row) {
+        const int u = row < r1 ? ub[row] : 0;
+        int cls = -1;
 #pragma unroll
-    for (int c = 0; c < kNumClasses; c++) {
-        const unsigned long long m = __ballot(cls == c);
-        if (cls == c) before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wcount[c][w] = __popcll(m);
+        for (int c = 0; c < kNumClasses; c++)
+            if (u > cb.b[c] && u <= cb.b[c + 1]) cls = c;
+        return cls;
+    };
+    int mine[kNumClasses] = {0, 0, 0, 0, 0};
+    for (int c0 = r0; c0 < r1; c0 += kBlock) {
+        const int cls = cls_of(c0 + (int)threadIdx.x);
+#pragma unroll
+        for (int c = 0; c < kNumClasses; c++) {
+            const unsigned long long m = __ballot(cls == c);
+            if (lane == 0) mine[c] += __popcll(m);
+        }
     }
+    if (lane == 0)
+        for (int c = 0; c < kNumClasses; c++) wcount[c][w] = mine[c];
     __syncthreads();
     if (threadIdx.x < kNumClasses) {
         int tot = 0;
         for (int i = 0; i < kBlock / 64; i++) tot += wcount[threadIdx.x][i];
         base[threadIdx.x] = tot ? atomicAdd(&counters[threadIdx.x], tot) : 0;
+        running[threadIdx.x] = 0;
     }
     __syncthreads();
-    if (!fill || cls < 0) return;
-    int off = base[cls] + before;
-    for (int i = 0; i < w; i++) off += wcount[cls][i];
-    lists[(size_t)cls * nrows + off] = row;
+    if (!fill) return;
+    for (int c0 = r0; c0 < r1; c0 += kBlock) {
+        const int row = c0 + (int)threadIdx.x;
+        const int cls = cls_of(row);
+        int before = 0;
+#pragma unroll
+        for (int c = 0; c < kNumClasses; c++) {
+            const unsigned long long m = __ballot(cls == c);
+            if (cls == c) before = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wcount[c][w] = __popcll(m);
+        }
+        __syncthreads();
+        if (cls >= 0) {
+            int off = base[cls] + running[cls] + before;
+            for (int i = 0; i < w; i++) off += wcount[cls][i];
+            lists[(size_t)cls * nrows + off] = row;
+        }
+        __syncthreads();
+        if (threadIdx.x < kNumClasses) {
+            int tot = 0;
+            for (int i = 0; i < kBlock / 64; i++) tot += wcount[threadIdx.x][i];
+            running[threadIdx.x] += tot;
+        }
+        __syncthreads();
+    }
 }
 
 inline bool single_pass_enabled()
@@ -483,6 +639,21 @@ inline bool single_pass_enabled()
     static int v = -1;
     if (v < 0) { const char *e = getenv("ELAG_HIP_ESC_SINGLE_PASS"); v = e ? atoi(e) : 1; }   // 0 = two-pass (A/B runs)
     return v != 0;
+}
+
+__global__ void esc_gather_kernel(int *__restrict__ counters, const int *__restrict__ tot_small, const int *__restrict__ tot_wave, const int *__restrict__ ccount)
+{
+    const int t = threadIdx.x;
+    if (t == 0) counters[2] = *tot_small;
+    if (t == 1) counters[3] = tot_wave ? *tot_wave : 0;
+    if (t >= 2 && t < 2 + kNumClasses) counters[2 + t] = ccount ? ccount[t - 2] : 0;
+}
+
+inline int hash_classes()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ELAG_HIP_ESC_HASH"); v = e ? atoi(e) : 31; }     // bit mask of wave-path classes (A/B runs); 0 = wave path only
+    return v;
 }
 
 inline bool wave_path_enabled()
@@ -506,7 +677,7 @@ struct EscPlan {
     unsigned long long total_ub = 0;
     int hc[kNumClasses] = {0, 0, 0, 0, 0};
     explicit EscPlan(int n)
-        : nrows(n), ub((size_t)n), ub_small((size_t)n), ubscan((size_t)n + 1), biglist((size_t)n), counters(2 + kNumClasses + 1), ubw((size_t)n),
+        : nrows(n), ub((size_t)n), ub_small((size_t)n), ubscan((size_t)n + 1), biglist((size_t)n), counters(4 + kNumClasses), ubw((size_t)n),
           UBI((size_t)n + 1), ccount(kNumClasses), lists((size_t)kNumClasses * (size_t)n) {}
     void finish()
     {
@@ -522,17 +693,18 @@ struct EscPlan {
             exclusive_scan(ubw, UBI, nrows);
             const ClassBounds cb{{0, 16, 32, 64, 128, kWaveCap}};
             ELAG_HIP_CHECK(hipMemsetAsync(ccount, 0, sizeof(int) * kNumClasses, st));
-            hipLaunchKernelGGL(esc_classify_kernel, dim3(grid1(nrows)), dim3(kBlock), 0, st, nrows, (const int *)ub.p, cb, ccount.p, lists.p, 1);
+            hipLaunchKernelGGL(esc_classify_kernel, dim3(std::min(grid1(nrows), 1024u)), dim3(kBlock), 0, st, nrows, (const int *)ub.p, cb, ccount.p, lists.p, 1);
             ELAG_LAUNCH_CHECK();
         }
-        int h[2], tot, totw = 0;
-        ELAG_HIP_CHECK(hipMemcpyAsync(h, counters.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-        ELAG_HIP_CHECK(hipMemcpyAsync(&tot, ubscan.p + nrows, sizeof(int), hipMemcpyDeviceToHost, st));
-        if (wave) {
-            ELAG_HIP_CHECK(hipMemcpyAsync(&totw, UBI.p + nrows, sizeof(int), hipMemcpyDeviceToHost, st));
-            ELAG_HIP_CHECK(hipMemcpyAsync(hc, ccount.p, sizeof(int) * kNumClasses, hipMemcpyDeviceToHost, st));
-        }
+        // every number the host needs, gathered into one block and read back by ONE copy into pinned memory (four small copies into
+        // pageable variables cost ~25 us of host time each: profiles/r03_rap_timeline.txt)
+        hipLaunchKernelGGL(esc_gather_kernel, dim3(1), dim3(64), 0, st, counters.p, (const int *)(ubscan.p + nrows), wave ? (const int *)(UBI.p + nrows) : (const int *)nullptr,
+                           wave ? (const int *)ccount.p : (const int *)nullptr);
+        int *hp = reinterpret_cast<int *>(ctx().h_scalar + 10);          // (doubles 0 and 8 of the pinned block belong to the reductions)
+        ELAG_HIP_CHECK(hipMemcpyAsync(hp, counters.p, (4 + kNumClasses) * sizeof(int), hipMemcpyDeviceToHost, st));
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        const int h[2] = {hp[0], hp[1]}, tot = hp[2], totw = hp[3];
+        for (int c = 0; c < kNumClasses; c++) hc[c] = hp[4 + c];
         if (h[1] > 0)
             fail(ELAG_HIP_ERR_ARG, "sparse product: %d rows expand to more than %d intermediate products (unsupported)", h[1], kBigCap);
         nbig = h[0];
@@ -577,7 +749,7 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
                 exclusive_scan(ubw, UBI, n);
                 const ClassBounds cb{{0, 16, 32, 64, 128, kWaveCap}};
                 ELAG_HIP_CHECK(hipMemsetAsync(plan.ccount, 0, sizeof(int) * kNumClasses, st));
-                hipLaunchKernelGGL(esc_classify_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, ubp, cb, plan.ccount.p, lists.p, 1);
+                hipLaunchKernelGGL(esc_classify_kernel, dim3(std::min(grid1(n), 1024u)), dim3(kBlock), 0, st, n, ubp, cb, plan.ccount.p, lists.p, 1);
                 ELAG_LAUNCH_CHECK();
                 ELAG_HIP_CHECK(hipMemcpyAsync(hc, plan.ccount.p, sizeof(int) * kNumClasses, hipMemcpyDeviceToHost, st));
                 ELAG_HIP_CHECK(hipStreamSynchronize(st));
@@ -591,27 +763,47 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
             // entries of the left factor's row are what the lanes of a group share out: 15 for A, 2-15 for P^T; the products
             // only set how many slots a lane owns, R), each launched over the list of ITS rows
             auto cls_list = [&](int c) { return (const int *)(lists.p + (size_t)c * n); };
-            if (hc[0])
+            const int hm = hash_classes();         // bit c: class c goes to the hash path (ELAG_HIP_ESC_HASH, default all)
+            bool done[kNumClasses] = {false, false, false, false, false};
+            if constexpr (Expander::kUnits) {
+#define ELAG_HASH_LAUNCH(c, G, R, S, NU, BLOCK)                                                                                                  \
+    do {                                                                                                                                        \
+        hipLaunchKernelGGL((esc_hash_kernel<G, R, S, NU, BLOCK, Expander>), dim3(grid1((long long)hc[c] * G, BLOCK)), dim3(BLOCK), 0, st, n, ex, \
+                           rownnz.p, (const int *)UBI.p, Ju.p, au.p, cls_list(c), hc[c]);                                                       \
+        done[c] = true;                                                                                                                         \
+    } while (0)
+                // (lanes per row, products per lane and pass, table slots, units per lane and pass, workgroup size) per class.  Fewer lanes
+                // per row -- (2,2,32,8), (4,8,128,4) -- were measured slower on cube456 x5 (A P 395 against 298 us): the loads of a row
+                // coalesce worse, and the kernel is bound by memory and LDS latency, not by the serialised inserts' instructions
+                if (hc[0] && (hm & 1)) ELAG_HASH_LAUNCH(0, 4, 2, 16, 2, 256);
+                if (hc[1] && (hm & 2)) ELAG_HASH_LAUNCH(1, 4, 2, 32, 4, 256);
+                if (hc[2] && (hm & 4)) ELAG_HASH_LAUNCH(2, 8, 4, 64, 2, 256);
+                if (hc[3] && (hm & 8)) ELAG_HASH_LAUNCH(3, 8, 8, 128, 2, 256);
+                if (hc[4] && (hm & 16)) ELAG_HASH_LAUNCH(4, 16, 8, 256, 1, 256);
+#undef ELAG_HASH_LAUNCH
+            }
+            if (hc[0] && !done[0])
                 hipLaunchKernelGGL((esc_wave_kernel<16, 1, true, Expander>), dim3(grid1((long long)hc[0] * 16)), dim3(kBlock), 0, st, n, ubp, 0, 16, ex,
                                    rownnz.p, (const int *)UBI.p, Ju.p, au.p, cls_list(0), hc[0]);
-            if (hc[1])
+            if (hc[1] && !done[1])
                 hipLaunchKernelGGL((esc_wave_kernel<16, 2, true, Expander>), dim3(grid1((long long)hc[1] * 16)), dim3(kBlock), 0, st, n, ubp, 16, 32, ex,
                                    rownnz.p, (const int *)UBI.p, Ju.p, au.p, cls_list(1), hc[1]);
-            if (hc[2])
+            if (hc[2] && !done[2])
                 hipLaunchKernelGGL((esc_wave_kernel<32, 2, true, Expander>), dim3(grid1((long long)hc[2] * 32)), dim3(kBlock), 0, st, n, ubp, 32, 64, ex,
                                    rownnz.p, (const int *)UBI.p, Ju.p, au.p, cls_list(2), hc[2]);
-            if (hc[3])
+            if (hc[3] && !done[3])
                 hipLaunchKernelGGL((esc_wave_kernel<64, 2, true, Expander>), dim3(grid1((long long)hc[3] * 64)), dim3(kBlock), 0, st, n, ubp, 64, 128, ex,
                                    rownnz.p, (const int *)UBI.p, Ju.p, au.p, cls_list(3), hc[3]);
-            if (hc[4])
+            if (hc[4] && !done[4])
                 hipLaunchKernelGGL((esc_wave_kernel<64, 4, true, Expander>), dim3(grid1((long long)hc[4] * 64)), dim3(kBlock), 0, st, n, ubp, 128, kWaveCap, ex,
                                    rownnz.p, (const int *)UBI.p, Ju.p, au.p, cls_list(4), hc[4]);
             ELAG_LAUNCH_CHECK();
             int *CI = dev_alloc<int>((size_t)n + 1);
             exclusive_scan(rownnz, CI, n);
-            int nnz = 0;
-            ELAG_HIP_CHECK(hipMemcpyAsync(&nnz, CI + n, sizeof(int), hipMemcpyDeviceToHost, st));
+            int *hnnz = reinterpret_cast<int *>(ctx().h_scalar + 10);
+            ELAG_HIP_CHECK(hipMemcpyAsync(hnnz, CI + n, sizeof(int), hipMemcpyDeviceToHost, st));
             ELAG_HIP_CHECK(hipStreamSynchronize(st));
+            const int nnz = *hnnz;
             C.release();
             C.nrows = n; C.ncols = ncols; C.I = CI;
             C.alloc_entries(nnz);
@@ -621,7 +813,7 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
             if (plan.nbig)
                 hipLaunchKernelGGL((esc_kernel<kBigCap, true, true, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
                                    plan.ub.p, plan.biglist.p, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
-            hipLaunchKernelGGL(esc_compact_kernel, dim3(grid1((long long)n * 16)), dim3(kBlock), 0, st, n, (const int *)ubw.p, (const int *)UBI.p,
+            hipLaunchKernelGGL(esc_compact_kernel, dim3(grid1((long long)n * 8)), dim3(kBlock), 0, st, n, (const int *)ubw.p, (const int *)UBI.p,
                                (const int *)C.I, (const int *)Ju.p, (const double *)au.p, C.J, C.a);
             ELAG_LAUNCH_CHECK();
             // (Ju / au go back to the arena when this scope ends: the arena recycles in stream order, no drain needed)
