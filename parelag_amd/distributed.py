@@ -277,3 +277,67 @@ def build_darcy_hierarchy(dist: Dist, dar, block_smoother="Block Jacobi", smooth
     H._dist_info = dd
     H._block_op = op
     return H, off[-1], shapes, time.time() - t0
+
+
+def _two_layer_hierarchy(A_d, P0_d, Ploc_sp, sub_Ps_sp, smoother, params=None):
+    """A scalar hierarchy in the layout of ``build_hierarchy`` on a distributed fine operator: level 0 row-partitioned with its own
+    relaxation; the Galerkin operator ``P0^T A P0`` formed across the ranks, gathered, and the levels below built complete on
+    every GPU (device RAP chain) behind one all-reduce of the restricted residual.  ``P0_d``: the interpolator's rows of this rank
+    with the distributed coarse numbering (for the Galerkin product); ``Ploc_sp``: the same rows with GLOBAL coarse columns (for
+    the cycle); ``sub_Ps_sp``: interpolators of the replicated levels.  Returns (H, keepalive)."""
+    lib = _lib.init()
+    t = la.HYPRE_SMOOTHER_TYPES[smoother] if isinstance(smoother, str) else int(smoother)
+    Ac = la.RAP(P0_d, A_d, P0_d)
+    Ac.fix_zero_rows()
+    subA, _st = Ac.Replicate()
+    del Ac
+    subP = [la.ParallelCSRMatrix.from_scipy(partition.canon(P)) for P in sub_Ps_sp]
+    Hsub = la.buildHierarchyFromDeRhamSequence(subA, subP, smoother, params or {}, reorder=0)       # (no level below: a dense solve)
+    hc = C.c_void_p()
+    _lib.check(lib.elag_hip_coarse_create_from_hierarchy(C.byref(hc), Hsub.h, 1))
+    cs = la.CoarseSolver.__new__(la.CoarseSolver)
+    cs._lib, cs.A, cs.h, cs.iterative_mode = lib, subA, hc, False
+    S0 = la.HypreSmootherWrapper(A_d, t, params or {})
+    Ploc = la.ParallelCSRMatrix.from_scipy(partition.canon(Ploc_sp))
+    H = la.Hierarchy(2)
+    H.SetOperator(0, A_d)
+    H.SetSmoothers(0, S0, S0)
+    H.SetOperator(1, subA)
+    H.SetProlongator(1, Ploc)
+    H.SetCoarseSolver(cs)
+    H.Finalize(use_graph=False)
+    H._keep += [Hsub, subA, subP, S0, Ploc, cs, A_d, P0_d]
+    return H
+
+
+def build_darcy_ldu_amge(dist: Dist, dar, H_blocked, smoother="L1 Jacobi", params=None):
+    """The reference's SPE10 solver graph (``examples/example_parameterlists/spe10_example_parameters.xml:95-127``) on N ranks: Block LDU
+    whose three ``A00`` inverses are AMGe V-cycles on the velocity mass matrix ``M`` (2-form interpolators) and whose ``S`` inverse is an
+    AMGe V-cycle on ``B diag(M)^-1 B^T`` (3-form interpolators), negated -- every one of them a distributed hierarchy in the layout of
+    ``build_hierarchy`` (fine level row-partitioned, the rest replicated behind one all-reduce).  ``H_blocked`` is the hierarchy of
+    ``build_darcy_hierarchy`` on the same decomposition (its fine-level block operator and numbering are reused).  Returns the
+    preconditioner (a ``Block2x2LDUInverseOperator`` with ``iterative_mode = False``)."""
+    import scipy.sparse as sp
+    dd, op, r = H_blocked._dist_info, H_blocked._block_op, dist.rank
+    (s2, s3) = dd["starts"][0]
+    (o2, o3) = dd["order"][0]
+    (o2c, o3c) = dd["order"][1]
+    P0 = [la.ParallelCSRMatrix.from_parts(p[r]) for p in dd["P"][0]]
+    Ps = dar["Ps"]
+    # form k (0: velocity / 2-form, 1: pressure / 3-form): rows of this rank with global level-1 columns, and the replicated levels'
+    # interpolators (level 1 rows in the level-1 block numbering, natural columns below)
+    def pieces(k, o, s, oc):
+        Pg = sp.csr_matrix(Ps[0][k])[o[int(s[r]):int(s[r + 1])]][:, oc]
+        sub = [sp.csr_matrix(P[k])[oc] if l == 1 else sp.csr_matrix(P[k]) for l, P in enumerate(Ps[1:], start=1)]
+        return Pg, sub
+    P2g, sub2 = pieces(0, o2, s2, o2c)
+    P3g, sub3 = pieces(1, o3, s3, o3c)
+    Md = op.GetBlock(0, 0)
+    Spos = la.SchurComplement(op, "DIAGONAL", 1.0, True)            # -(0 - B diag(M)^-1 B^T) = B diag(M)^-1 B^T, distributed
+    HM = _two_layer_hierarchy(Md, P0[0], P2g, sub2, smoother, params)
+    HS = _two_layer_hierarchy(Spos, P0[1], P3g, sub3, smoother, params)
+    iM, iS = la.HierarchySolver(HM), la.HierarchySolver(HS, scale=-1.0)
+    ldu = la.Block2x2LDUInverseOperator(op, iM, iM, iM, iS)
+    ldu.iterative_mode = False
+    ldu._keep_ldu = [HM, HS, iM, iS, Spos, Md, P0]
+    return ldu

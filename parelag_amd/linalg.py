@@ -709,6 +709,23 @@ def Block2x2LDUInverseOperator(op, invA00_1, invA00_2, invA00_3, invS, damping=1
     return BlockSolver(op, [invA00_1, invA00_2, invA00_3, invS], "Block LDU", damping)
 
 
+def darcy_ldu_amge_preconditioner(op: MfemBlockOperator, M, B, Ps, smoother="L1 Jacobi", params=None):
+    """The reference's SPE10 solver graph (``examples/example_parameterlists/spe10_example_parameters.xml:95-127``) for the mixed system
+    ``[[M, B^T], [B, 0]]`` on one rank: ``Block2x2LDUInverseOperator`` whose three ``A00`` inverses are AMGe V-cycles on ``M`` (2-form
+    interpolators ``Ps[l][0]``) and whose ``S`` inverse is an AMGe V-cycle on ``B diag(M)^-1 B^T`` (3-form interpolators ``Ps[l][1]``),
+    negated.  ``M``, ``B``, ``Ps`` are scipy matrices; the N-rank form is ``distributed.build_darcy_ldu_amge``."""
+    Mm, Bm = sp.csr_matrix(M), sp.csr_matrix(B)
+    Spos = (Bm @ sp.diags(1.0 / Mm.diagonal()) @ Bm.T).tocsr()
+    Spos.sort_indices()
+    HM = buildHierarchyFromDeRhamSequence(ParallelCSRMatrix.from_scipy(Mm), [ParallelCSRMatrix.from_scipy(sp.csr_matrix(P[0])) for P in Ps], smoother, params)
+    HS = buildHierarchyFromDeRhamSequence(ParallelCSRMatrix.from_scipy(Spos), [ParallelCSRMatrix.from_scipy(sp.csr_matrix(P[1])) for P in Ps], smoother, params)
+    iM, iS = HierarchySolver(HM), HierarchySolver(HS, scale=-1.0)
+    ldu = Block2x2LDUInverseOperator(op, iM, iM, iM, iS)
+    ldu.iterative_mode = False
+    ldu._keep_ldu = [HM, HS, iM, iS]
+    return ldu
+
+
 def buildBlockedHierarchyFromDeRhamSequence(A: MfemBlockOperator, Ps, block_smoother="Block Jacobi",
                                             a00_inverse="L1 Jacobi", a00_params=None, a11_inverse="L1 Jacobi", a11_params=None,
                                             s_type="DIAGONAL", alpha=1.0, use_negative_s=True, damping=1.0,

@@ -395,3 +395,28 @@ def test_block_ldu_with_inner_amge_hierarchies(la, darcy_small):
     with pytest.raises(la._lib.ElagHipError, match="preconditioner"):
         iS.iterative_mode = True
         iS.Mult(r[n0:], y)
+
+
+def test_default_darcy_solver_graph_converges_at_full_size(la):
+    """BASELINE configs[3] at cube456 x3 (473 536 + 233 472 dofs): GMRES(50) preconditioned by the reference's SPE10 solver graph -- Block LDU
+    with AMGe V-cycles on M and on B diag(M)^-1 B^T (la.darcy_ldu_amge_preconditioner) -- converges to the example's 1e-6 within its 300
+    iterations (the blocked cycle with Jacobi-class block smoothers does not: profiles/r02_bench_darcy.json), also with a heterogeneous
+    coefficient (the bench's log-normal field, contrast 2e5)."""
+    import scipy.sparse as sp
+    from parelag_amd import meshgen
+    for kinv_sigma in (None, 2.0):
+        kinv = meshgen.lognormal_inverse_permeability(meshgen.Sequence.cube456(3), kinv_sigma) if kinv_sigma else None
+        dar = meshgen.darcy_problem(3, kinv=kinv)
+        n0, n1 = dar["M"].shape[0], dar["B"].shape[0]
+        bop = la.MfemBlockOperator([0, n0, n0 + n1])
+        for (i, j), M in {(0, 0): dar["M"], (0, 1): dar["Bt"], (1, 0): dar["B"]}.items():
+            bop.SetBlock(i, j, la.ParallelCSRMatrix.from_scipy(M))
+        ldu = la.darcy_ldu_amge_preconditioner(bop, dar["M"], dar["B"], dar["Ps"])
+        K = la.KrylovSolver(bop, ldu, {"Solver name": "GMRES", "Relative tolerance": 1e-6, "Absolute tolerance": 1e-6, "Maximum iterations": 300,
+                                       "Restart size": 50})
+        b = np.concatenate([np.zeros(n0), dar["seq"].meshes[0].M3() @ np.ones(n1)])
+        x = np.zeros(n0 + n1)
+        K.Mult(b, x)
+        assert K.GetConverged() and K.GetNumIterations() <= 60, (kinv_sigma, K.GetNumIterations())
+        A = sp.bmat([[dar["M"], dar["Bt"]], [dar["B"], None]]).tocsr()
+        assert np.linalg.norm(A @ x - b) <= 1e-4 * np.linalg.norm(b)
