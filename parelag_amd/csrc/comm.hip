@@ -57,18 +57,44 @@ static Comm *load_rccl()
 // thread-local context and streams.  Messages are matched through a mailbox keyed by (source, destination, sequence)
 // and delivered by device-to-device copies.  It exists so that the whole multi-rank code path (halo exchange with
 // interior/boundary overlap, reverse halo, all-gather, all-reduce, distributed hierarchies) is exercised on a
-// single-GPU box; only the thin RCCL wrappers above differ on a real multi-GPU node.  Host-synchronous by design.
+// single-GPU box; only the thin RCCL wrappers above differ on a real multi-GPU node.
+// Like RCCL, an exchange is STREAM-ORDERED, not host-synchronous: the sender records an event behind the work that fills its
+// buffer and posts (pointer, event); the receiver makes its stream wait for that event, enqueues the copy, records an event of
+// its own behind it and posts it back; the sender's stream waits for that one before anything that follows may overwrite the
+// buffer.  The host threads only rendezvous on the mailbox (as ncclGroupEnd does on its proxies); no stream is ever drained, so
+// the interior-rows / halo overlap of par_spmv runs against a transport that is as asynchronous as the real one.
+// (Round 2's hub drained the stream twice per message; ELAG_HIP_HUB_SYNC=1 brings that back for A/B runs.)
 // ------------------------------------------------------------------------------------------------------------------
-struct HubMsg { const void *ptr; size_t bytes; };
+struct HubMsg { const void *ptr; size_t bytes; hipEvent_t ready; };
 struct Hub {
     std::mutex m;
     std::condition_variable cv;
     int nranks = 0, attached = 0;
     std::map<std::tuple<int, int, unsigned long long>, HubMsg> box;
+    std::map<std::tuple<int, int, unsigned long long>, hipEvent_t> acks;     // the receiver's copy of a message is enqueued; fires when it is done
 };
 struct HubEndpoint {                      // per rank (lives in the thread's context)
     std::shared_ptr<Hub> hub;
     std::map<int, unsigned long long> send_seq, recv_seq;
+    // events are taken round-robin from a pool that is far larger than the number of messages a rank can have in flight: a wait
+    // enqueued on an event refers to the record that preceded it, so re-recording a pool entry later is harmless
+    std::vector<hipEvent_t> events;
+    size_t next_event = 0;
+    double *red_buf = nullptr;            // all-reduce staging (nranks x n doubles), grown on demand
+    size_t red_cap = 0;
+    hipEvent_t event()
+    {
+        if (events.empty()) {
+            events.resize(512);
+            for (auto &e : events) ELAG_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        return events[next_event++ % events.size()];
+    }
+    ~HubEndpoint()
+    {
+        for (auto &e : events) (void)hipEventDestroy(e);
+        if (red_buf) (void)hipFree(red_buf);
+    }
 };
 
 static std::mutex g_hubs_m;
@@ -76,13 +102,23 @@ static std::map<int, std::shared_ptr<Hub>> g_hubs;
 
 static HubEndpoint *hub_ep() { return static_cast<HubEndpoint *>(ctx().hub); }
 
+static bool hub_sync_mode()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ELAG_HIP_HUB_SYNC"); v = (e && atoi(e)) ? 1 : 0; }
+    return v == 1;
+}
+
 static void hub_exchange(const void *sendbuf, int nsend, const int *send_procs, const int *send_starts, void *recvbuf, int nrecv,
                          const int *recv_procs, const int *recv_starts, size_t elem_bytes, hipStream_t st, int skip_s, int skip_r)
 {
     HubEndpoint *ep = hub_ep();
     Hub &H = *ep->hub;
     const int me = ctx().rank;
-    ELAG_HIP_CHECK(hipStreamSynchronize(st));   // the data to send is final
+    const bool sync = hub_sync_mode();
+    hipEvent_t ready = ep->event();
+    ELAG_HIP_CHECK(hipEventRecord(ready, st));     // the data to send is final when this fires
+    if (sync) ELAG_HIP_CHECK(hipStreamSynchronize(st));
     std::vector<std::tuple<int, int, unsigned long long>> mine;
     {
         std::unique_lock<std::mutex> lk(H.m);
@@ -91,7 +127,7 @@ static void hub_exchange(const void *sendbuf, int nsend, const int *send_procs, 
             const size_t n = (size_t)(send_starts[i + 1] - send_starts[i]) * elem_bytes;
             if (!n) continue;
             auto key = std::make_tuple(me, send_procs[i], ep->send_seq[send_procs[i]]++);
-            H.box[key] = HubMsg{static_cast<const char *>(sendbuf) + (size_t)send_starts[i] * elem_bytes, n};
+            H.box[key] = HubMsg{static_cast<const char *>(sendbuf) + (size_t)send_starts[i] * elem_bytes, n, ready};
             mine.push_back(key);
         }
     }
@@ -108,20 +144,29 @@ static void hub_exchange(const void *sendbuf, int nsend, const int *send_procs, 
             msg = H.box[key];
         }
         if (msg.bytes != n) fail(ELAG_HIP_ERR_COMM, "hub: rank %d expected %zu bytes from %d, got %zu", me, n, recv_procs[i], msg.bytes);
+        ELAG_HIP_CHECK(hipStreamWaitEvent(st, msg.ready, 0));
         ELAG_HIP_CHECK(hipMemcpyAsync(static_cast<char *>(recvbuf) + (size_t)recv_starts[i] * elem_bytes, msg.ptr, n, hipMemcpyDeviceToDevice, st));
-        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        hipEvent_t done = ep->event();
+        ELAG_HIP_CHECK(hipEventRecord(done, st));
+        if (sync) ELAG_HIP_CHECK(hipStreamSynchronize(st));
         {
             std::unique_lock<std::mutex> lk(H.m);
             H.box.erase(key);
+            H.acks[key] = done;
         }
         H.cv.notify_all();
     }
-    // my send buffers may be reused only after every receiver has copied them
-    std::unique_lock<std::mutex> lk(H.m);
-    H.cv.wait(lk, [&] {
-        for (auto &k : mine) if (H.box.count(k)) return false;
-        return true;
-    });
+    // my send buffers may be reused only after every receiver has copied them: this stream waits for the receivers' copies
+    for (auto &k : mine) {
+        hipEvent_t done;
+        {
+            std::unique_lock<std::mutex> lk(H.m);
+            H.cv.wait(lk, [&] { return H.acks.count(k) > 0; });
+            done = H.acks[k];
+            H.acks.erase(k);
+        }
+        ELAG_HIP_CHECK(hipStreamWaitEvent(st, done, 0));
+    }
 }
 
 static void hub_init(int rank, int nranks, int group)
@@ -260,28 +305,36 @@ void comm_allgatherv(const double *send, double *recv, const int *counts, const 
     ELAG_NCCL_CHECK(c, c->GroupEnd());
 }
 
+__global__ void hub_reduce_kernel(int n, int nr, int op, const double *__restrict__ all, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double acc = all[i];
+    for (int r = 1; r < nr; r++) acc = (op == 0) ? acc + all[(size_t)r * n + i] : fmax(acc, all[(size_t)r * n + i]);
+    out[i] = acc;
+}
+
 void comm_allreduce_device(double *d_values, int n, int op, hipStream_t st)
 {
     if (!comm_active() || n == 0) return;
     if (ctx().comm_kind == 2) {
-        // gather every rank's vector (rank order), reduce on the host in that order, write back: deterministic
-        const int nr = ctx().nranks, me = ctx().rank;
-        double *all = dev_alloc<double>((size_t)n * nr);
+        // gather every rank's vector (rank order) and reduce on the device in that order: deterministic, and stream-ordered like
+        // ncclAllReduce (round 2 reduced on the host between two drains of the stream)
+        const int nr = ctx().nranks;
+        HubEndpoint *ep = hub_ep();
+        if (ep->red_cap < (size_t)n * nr) {
+            ELAG_HIP_CHECK(hipStreamSynchronize(st));        // (a previous, smaller staging block may still be in use)
+            if (ep->red_buf) (void)hipFree(ep->red_buf);
+            ep->red_cap = std::max<size_t>((size_t)n * nr, 4096);
+            ELAG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&ep->red_buf), sizeof(double) * ep->red_cap));
+        }
         std::vector<int> counts((size_t)nr, n), displs((size_t)nr);
         for (int r = 0; r < nr; r++) displs[(size_t)r] = r * n;
-        comm_allgatherv(d_values, all, counts.data(), displs.data(), st);
-        std::vector<double> h((size_t)n * nr), out((size_t)n);
-        ELAG_HIP_CHECK(hipMemcpyAsync(h.data(), all, sizeof(double) * h.size(), hipMemcpyDeviceToHost, st));
-        ELAG_HIP_CHECK(hipStreamSynchronize(st));
-        for (int i = 0; i < n; i++) {
-            double acc = h[(size_t)i];
-            for (int r = 1; r < nr; r++) acc = (op == 0) ? acc + h[(size_t)r * n + i] : std::max(acc, h[(size_t)r * n + i]);
-            out[(size_t)i] = acc;
-        }
-        ELAG_HIP_CHECK(hipMemcpyAsync(d_values, out.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
-        ELAG_HIP_CHECK(hipStreamSynchronize(st));
-        (void)me;
-        dev_free(all);
+        comm_allgatherv(d_values, ep->red_buf, counts.data(), displs.data(), st);
+        hipLaunchKernelGGL(hub_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, nr, op, (const double *)ep->red_buf, d_values);
+        ELAG_HIP_CHECK(hipGetLastError());
+        // the next all-reduce of this rank overwrites the staging block: every rank's copy OUT of it is ordered by hub_exchange's
+        // own hand-shake (a sender's stream waits for its receivers), the reduction above by the stream itself
         return;
     }
     Comm *c = ctx().comm;
