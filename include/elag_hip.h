@@ -92,6 +92,10 @@ ELAG_HIP_API int elag_hip_comm_init_inprocess(int rank, int nranks, int group);
  * this rank, ncclCommDestroy).  Both outputs have 4 entries and must come back equal to the inputs. */
 ELAG_HIP_API int elag_hip_comm_selftest(double *allreduce_out, double *sendrecv_out);
 ELAG_HIP_API int elag_hip_comm_rank(int *rank, int *nranks);
+/* Data-plane rounds this rank has issued since it was initialised: neighbour exchanges with at least one remote peer (the halo /
+ * reverse-halo of hypre_ParCSRMatrixMatvec(T), src/hypreExtension/hypre_ParCSRMatrixMatvecBoolInt.c:178-196,296-323) and device
+ * all-reduces.  Differences around a call count the messages of that call (tests pin the rounds of a V-cycle with them). */
+ELAG_HIP_API int elag_hip_comm_rounds(long long *exchanges, long long *allreduces);
 /* 8-byte reductions that end the norm / dot routines (MPI_Allreduce in hypre_ParCSRMatrixNorms.c:60) */
 ELAG_HIP_API int elag_hip_comm_allreduce(double *value, int op /*0 sum, 1 max*/);
 

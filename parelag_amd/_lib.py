@@ -74,6 +74,7 @@ _SIGNATURES = {
     "elag_hip_comm_init_inprocess": [_i, _i, _i],
     "elag_hip_comm_selftest": [_dp, _dp],
     "elag_hip_comm_rank": [_ip, _ip],
+    "elag_hip_comm_rounds": [_p, _p],
     "elag_hip_comm_allreduce": [_dp, _i],
     "elag_hip_malloc": [C.POINTER(_p), C.c_size_t],
     "elag_hip_free": [_p],

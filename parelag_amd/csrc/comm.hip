@@ -258,6 +258,7 @@ void comm_neighbor_exchange(const void *sendbuf, int nsend, const int *send_proc
     }
     if (!remote) return;
     if (!comm_active()) fail(ELAG_HIP_ERR_COMM, "matrix has off-rank columns but no communicator was initialised");
+    ctx().n_exchanges++;
     if (ctx().comm_kind == 2) {
         hub_exchange(sendbuf, nsend, send_procs, send_starts, recvbuf, nrecv, recv_procs, recv_starts, elem_bytes, st, self_s, self_r);
         return;
@@ -317,6 +318,7 @@ __global__ void hub_reduce_kernel(int n, int nr, int op, const double *__restric
 void comm_allreduce_device(double *d_values, int n, int op, hipStream_t st)
 {
     if (!comm_active() || n == 0) return;
+    ctx().n_allreduces++;
     if (ctx().comm_kind == 2) {
         // gather every rank's vector (rank order) and reduce on the device in that order: deterministic, and stream-ordered like
         // ncclAllReduce (round 2 reduced on the host between two drains of the stream)
@@ -418,6 +420,14 @@ int elag_hip_comm_rank(int *rank, int *nranks)
     return guarded([&] {
         if (rank) *rank = ctx().rank;
         if (nranks) *nranks = ctx().nranks;
+    });
+}
+
+int elag_hip_comm_rounds(long long *exchanges, long long *allreduces)
+{
+    return guarded([&] {
+        if (exchanges) *exchanges = ctx().n_exchanges;
+        if (allreduces) *allreduces = ctx().n_allreduces;
     });
 }
 

@@ -26,6 +26,11 @@ struct Level {
     // which is algebraically the reference's  x = W f; r = f - A x; r_c = P^T r; x += P e; x += W (f - A x).
     std::shared_ptr<DevCSR> G, S;
     const double *fused_dinv = nullptr;
+    // the same l1-Jacobi level when its operators live on several ranks (see plan_fused): S = A P - W^-1 P as a distributed operator.  With
+    // r = f - A W f from the way down, the way up is  x = W (f + r - S e):  no product with A, no halo exchange for x -- a level costs
+    // one exchange for W f, the reverse exchange of P^T r and one for e (none where the coarse level is replicated) instead of four
+    std::shared_ptr<ParCSR> Sd;
+    const double *dist_w = nullptr;
     // launch-bound levels whose smoother is Hiptmair(l1-Jacobi, l1-Jacobi), one sweep each (see plan_fused): six launches
     // instead of ten, with  Gaux = D Waux D^T  (the auxiliary-space correction as one operator),  RA = P^T A  and  PTneg = -P^T
     // (restricted residual in one product pair),  S = A P - W^-1 P  (prolongation + primary post-sweep in one product pair)
@@ -504,6 +509,7 @@ struct elag_hip_hierarchy_s {
             Level &F = lev[(size_t)l];
             Level &C = lev[(size_t)l + 1];
             F.G.reset(); F.S.reset(); F.fused_dinv = nullptr;
+            F.Sd.reset(); F.dist_w = nullptr;
             F.Gaux.reset(); F.RA.reset(); F.PTneg.reset(); F.hipt_w = nullptr;
             F.U1.reset(); F.U2.reset(); F.Kh.reset(); F.Mh.reset();
             // ---- Chebyshev of order <= 2 on a launch-bound level below the finest ----
@@ -628,9 +634,27 @@ struct elag_hip_hierarchy_s {
                 continue;
             }
             const double *dinv = F.pre ? F.pre->diag_scaling() : nullptr;
-            if (disabled || !all_local || !dinv || !F.post || !F.post->diag_scaling() || F.pre->A != F.A || F.post->A != F.A ||
+            if (disabled || !dinv || !F.post || !F.post->diag_scaling() || F.pre->A != F.A || F.post->A != F.A ||
                 !F.pre->same_scaling_as(F.post))
                 continue;
+            if (!all_local) {
+                // ---- l1-Jacobi level of a hierarchy that lives on several ranks ----
+                const char *nf = getenv("ELAG_HIP_NO_DIST_LEVEL_FUSION");          // (read at every Finalize: a test switches it)
+                if ((nf && atoi(nf)) || !comm_active()) continue;
+                const int n = F.A->nrows();
+                std::unique_ptr<ParCSR> AP(distributed_matmul(*F.A, *C.P));
+                std::unique_ptr<ParCSR> WP(parcsr_clone(*C.P));
+                {
+                    Temp<double> winv((size_t)n);
+                    k::vec_reciprocal_scale(n, 1.0, dinv, winv);
+                    k::csr_scale_rows(WP->diag, winv);
+                    if (WP->offd.nnz) k::csr_scale_rows(WP->offd, winv);
+                    ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+                }
+                F.Sd.reset(distributed_add(1.0, *AP, -1.0, *WP));
+                F.dist_w = dinv;
+                continue;
+            }
             if (F.A->offd.ncols > 0 || C.P->offd.ncols > 0 || F.A->diag.nnz >= max_nnz) continue;
             const int n = F.A->nrows();
             C.P->ensure_transpose();
@@ -739,6 +763,26 @@ struct elag_hip_hierarchy_s {
             k::SpmvArgs a7;   // x' += Gaux pv
             a7.x = F.tmp_resid; a7.alpha = 1.0; a7.yin = oth; a7.beta = 1.0; a7.out = oth;
             k::spmv_fused(*F.Gaux, nullptr, a7);
+            return;
+        }
+        if (F.Sd) {
+            const double *w = F.dist_w;
+            if (F.A->diag.nnz < (int64_t(1) << 20)) {
+                k::SpmvArgs a;   // r = f - A (W f): the sweep from the zero guess gathered on the fly, ONE halo exchange (of W f)
+                a.x = rhs; a.cs = w; a.alpha = -1.0; a.f = rhs; a.gamma = 1.0; a.out = F.tmp_resid;
+                par_spmv(*F.A, a);
+            } else {
+                k::vec_scale_mul(n, 1.0, rhs, w, alt);
+                k::SpmvArgs a;
+                a.x = alt; a.alpha = -1.0; a.f = rhs; a.gamma = 1.0; a.out = F.tmp_resid;
+                par_spmv(*F.A, a);
+            }
+            par_spmvT(*C.P, 1.0, F.tmp_resid, 0.0, C.resid);
+            iterate(l + 1, C.resid, C.sol, C.alt);
+            k::vec_axpby(n, 1.0, rhs, 1.0, F.tmp_resid, F.tmp_resid);          // f + r
+            k::SpmvArgs u;       // x = W (f + r - S e)
+            u.x = C.sol; u.alpha = -1.0; u.f = F.tmp_resid; u.gamma = 1.0; u.s = w; u.out = sol;
+            par_spmv(*F.Sd, u);
             return;
         }
         const int nf = (F.pre ? F.pre->flips(true) : 0) + (F.post ? F.post->flips(false) : 0);

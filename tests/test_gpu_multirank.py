@@ -155,6 +155,54 @@ def test_distributed_vcycle_matches_serial_oracle(problem, world, replicate_from
         assert r1 < 0.6 * r0
 
 
+@pytest.mark.parametrize("world,replicate_from,rounds", [(2, 1, (1, 1)), (3, 2, (4, 1))])
+def test_distributed_l1_jacobi_level_costs_one_halo_exchange(problem, world, replicate_from, rounds):
+    """A distributed l1-Jacobi level runs as  r = f - A W f  (ONE halo exchange, of W f) -> P^T r -> coarse -> x = W (f + r - S e)  with the
+    distributed operator S = A P - W^-1 P formed at Finalize: no product with A on the way up and no halo exchange for x.  With the fine
+    level distributed and the rest replicated (bench.py's layout) a V-cycle is 1 neighbour exchange + 1 all-reduce (2 + 1 level by
+    level, ELAG_HIP_NO_DIST_LEVEL_FUSION=1); with two distributed levels above the replicated part 4 exchanges + 1 all-reduce (W f, the reverse halo
+    of P^T r and e on level 0; W f on level 1), 6 + 1 before.  Same cycle either way, to rounding."""
+    import ctypes as C
+    import os
+    from parelag_amd import _lib, distributed, linalg as la
+    A, Ps, seq = problem
+    b_nat = np.random.default_rng(5).uniform(-1, 1, A.shape[0])
+
+    def body(dist):
+        lib = _lib.init()
+        out = {}
+        for name, env in (("fused", {}), ("levels", {"ELAG_HIP_NO_DIST_LEVEL_FUSION": "1"})):
+            dist.barrier()
+            if dist.rank == 0:
+                os.environ.pop("ELAG_HIP_NO_DIST_LEVEL_FUSION", None)
+                os.environ.update(env)
+            dist.barrier()
+            H, n_local, _shapes, _ = distributed.build_hierarchy(dist, A, Ps, seq, "L1 Jacobi", replicate_from=replicate_from)
+            info = H._dist_info["levels"][0]
+            lo, hi = int(info["starts"][dist.rank]), int(info["starts"][dist.rank + 1])
+            rhs = la.DeviceVector.from_numpy(b_nat[info["order"]][lo:hi])
+            sol = la.DeviceVector(n_local, 7.0)
+            H.Mult(rhs, sol)
+            la.synchronize()
+            e0, a0, e1, a1 = C.c_longlong(), C.c_longlong(), C.c_longlong(), C.c_longlong()
+            _lib.check(lib.elag_hip_comm_rounds(C.byref(e0), C.byref(a0)))
+            H.Mult(rhs, sol)
+            la.synchronize()
+            _lib.check(lib.elag_hip_comm_rounds(C.byref(e1), C.byref(a1)))
+            out[name] = (sol.to_numpy(), e1.value - e0.value, a1.value - a0.value)
+            del H, rhs, sol
+        dist.barrier()
+        if dist.rank == 0:
+            os.environ.pop("ELAG_HIP_NO_DIST_LEVEL_FUSION", None)
+        return out
+    res = run_ranks(world, body)
+    for out in res:
+        xf, ef, af = out["fused"]
+        xl, el, al = out["levels"]
+        assert np.max(np.abs(xf - xl)) <= 1e-13 * np.max(np.abs(xl))
+        assert (ef, af) == rounds and el > ef, ((ef, af), (el, al))
+
+
 def _local_global_csr(M, shape):
     """device ParCSR (this rank's rows) -> scipy CSR with global column ids"""
     out = M.to_scipy()
