@@ -44,6 +44,69 @@ def vcycle_bytes(shapes):
     return total
 
 
+def vcycle_bytes_hiptmair(shapes):
+    """Algorithmic bytes of one V-cycle whose smoother is HiptmairSmoother(l1-Jacobi, l1-Jacobi), one sweep before and after
+    (ParELAG_HiptmairSmoother.cpp:48-76): per non-coarsest level four products with A (the sweeps' two residuals each way), two with D and
+    two with D^T (the auxiliary-space corrections), P^T and P, and the vector passes of the reference's sequence -- primary sweep 24 n,
+    auxiliary sweep 24 n_aux, x += D y 24 n, twice --; dense coarse solve 8 nc^2.  shapes: (n, nnzA, nc, nnzP, n_aux, nnzD) per level."""
+    total = 0
+    for (n, nnzA, nc, nnzP, na, nnzD) in shapes[:-1]:
+        total += 4 * (spmv_bytes(n, n, nnzA) + 8 * n) + 2 * spmv_bytes(na, n, nnzD) + 2 * spmv_bytes(n, na, nnzD) \
+            + spmv_bytes(nc, n, nnzP) + (spmv_bytes(n, nc, nnzP) + 8 * n) + 2 * (24 * n + 24 * na + 24 * n)
+    nc = shapes[-1][0]
+    total += 8 * nc * nc + 16 * nc
+    return total
+
+
+def hiptmair_hbm_leg(args, la, meshgen, np, hipt_type):
+    """--form 1 / 2: the same cycle one refinement up, where the fine level no longer fits the caches -- the cycle against the HBM
+    roofline, checked against the CPU oracle's cycle on the same hierarchy."""
+    k = args.refines + 1
+    t0 = time.time()
+    A, Ps, Ds, _seq = (meshgen.hdiv_problem if args.form == 2 else meshgen.hcurl_problem)(k)
+    gen_s = time.time() - t0
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    dDs = [la.ParallelCSRMatrix.from_scipy(D) for D in Ds[:len(Ps)]]
+    t0 = time.time()
+    H = la.buildHierarchyFromDeRhamSequence(dA, dPs, args.smoother, use_graph=not args.no_graph, Ds=dDs, aux_smoother=args.smoother)
+    la.synchronize()
+    setup_s = time.time() - t0
+    n = A.shape[0]
+    shapes = []
+    for l in range(len(Ps) + 1):
+        op = H.GetOperator(l)
+        shapes.append((op.Height(), op.nnz, Ps[l].shape[1] if l < len(Ps) else 0, Ps[l].nnz if l < len(Ps) else 0,
+                       Ds[l].shape[1] if l < len(Ps) else 0, Ds[l].nnz if l < len(Ps) else 0))
+    rhs, sol = la.DeviceVector(n, 2.0), la.DeviceVector(n, 1.0)
+    for _ in range(5):
+        H.Mult(rhs, sol)
+    ms = H.time_apply(rhs, sol, 50)
+    vb = vcycle_bytes_hiptmair(shapes)
+    rec = {"workload": f"MultigridTest{args.form}Form cube456 x{k} refines, {len(Ps) + 1} levels, Hiptmair({args.smoother}, {args.smoother}): A n={n}, nnz={A.nnz}",
+           "levels": [{"n": s_[0], "nnz": s_[1], "n_aux": s_[4], "nnz_D": s_[5]} for s_ in shapes],
+           "vcycle_ms": round(ms, 4), "vcycles_per_s": round(1e3 / ms, 1), "vcycle_algorithmic_bytes": vb,
+           "vcycle_GBs": round(vb / (ms * 1e-3) / 1e9, 1), "vcycle_frac": round(vb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "launch_mode": H.launch_mode(), "hierarchy_setup_s": round(setup_s, 3), "generate_s": round(gen_s, 1)}
+    if not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        from tests.helpers import oracle_hdiv_hierarchy
+        t0 = time.time()
+        h = oracle_hdiv_hierarchy(A, Ps, Ds, primary=hipt_type, aux=hipt_type)
+        Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], native=True, hipt=h["hipt"])
+        b = np.full(n, 2.0); xo = np.empty(n)
+        Hc.apply(b, xo)
+        t1 = time.perf_counter()
+        Hc.apply(b, xo)
+        rec["cpu_port_vcycles_per_s_1core"] = round(1.0 / (time.perf_counter() - t1), 3)
+        rec["parity_rel_err_vs_oracle"] = float(np.max(np.abs(sol.to_numpy() - xo)) / np.max(np.abs(xo)))
+        note("x%d Hiptmair cycle vs oracle: %.1e (%.1f s)" % (k, rec["parity_rel_err_vs_oracle"], time.time() - t0))
+        if not rec["parity_rel_err_vs_oracle"] <= 1e-10:
+            raise SystemExit("cube456 x%d Hiptmair V-cycle differs from the oracle by %.3e (> 1e-10)" % (k, rec["parity_rel_err_vs_oracle"]))
+    note("HBM-bound Hiptmair cycle (x%d): %.4f ms, %.1f %% of HBM" % (k, ms, 100 * rec["vcycle_frac"]))
+    return rec
+
+
 def seq_fine_M3_one(dar):
     """(1, q) for the piecewise-constant pressure space: element volumes (rhs_p of MultigridTestDarcy with f = 1)"""
     if "rhs_p" in dar:
@@ -616,7 +679,10 @@ def main():
     if dist is not None:
         ms_dev = dist.allreduce_max(ms_dev)
 
-    vbytes = vcycle_bytes(level_shapes)
+    if args.form in (1, 2) and Ds is not None and single:
+        vbytes = vcycle_bytes_hiptmair([sh + ((Ds[l].shape[1], Ds[l].nnz) if l < len(Ps) else (0, 0)) for l, sh in enumerate(level_shapes)])
+    else:
+        vbytes = vcycle_bytes(level_shapes)
     ms_per_step = elapsed / args.steps * 1e3
     try:
         setup_breakdown = {k: round(v, 3) for k, v in H.setup_breakdown().items()}
@@ -639,6 +705,17 @@ def main():
         b0 = spmv_bytes(n0, n0, nnz0)
         fine = {"n": n0, "nnz": nnz0, "bytes_per_launch": b0, "us_per_launch": round(ms0 * 1e3, 2),
                 "achieved_GBs": round(b0 / (ms0 * 1e-3) / 1e9, 1), "note": "operator is cache resident (L2/Infinity Cache), not an HBM figure"}
+
+    # ---------------------------------------------------------------- forms 1 / 2: the cycle at an HBM-bound size
+    hbm = None
+    if single and args.form in (1, 2) and not (args.amge or args.hex) and not args.no_roofline:
+        try:
+            hbm = hiptmair_hbm_leg(args, la, meshgen, np, hipt_type)
+        except SystemExit:
+            raise
+        except Exception as exc:                                   # an extra of the line: the headline must not depend on it
+            note("HBM-bound Hiptmair leg failed: %r" % (exc,))
+            hbm = {"error": repr(exc)[:400]}
 
     # ---------------------------------------------------------------- the reference's shipped relaxation beside the headline one
     gs = None
@@ -926,6 +1003,8 @@ def main():
         })
         if gs is not None:
             out["l1_gauss_seidel_cycle"] = gs
+        if hbm is not None:
+            out["hbm_bound_cycle"] = hbm
         if solve is not None:
             out["solve"] = solve
         if not darcy and (args.amge or args.hex):

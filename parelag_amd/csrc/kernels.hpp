@@ -173,6 +173,8 @@ void dense_times_csr_t(int nc, int n, const double *Bc, const DevCSR &GT, double
 void dense_level_op(int n, int nc, const DevCSR &V, const double *vw, const double *X, const DevCSR *U, const DevCSR *A, const double *w, double *B);
 // Minv (n x n row-major, device) = A^-1 for a general square CSR (Gauss-Jordan, partial pivoting); throws when singular
 void dense_inverse_general(const DevCSR &A, double *Minv);
+// Minv = A^-1 for a symmetric positive definite CSR (Gauss-Jordan without pivoting on the device, result symmetrised); throws when a pivot is not positive
+void dense_inverse_spd(const DevCSR &A, double *Minv);
 
 }  // namespace k
 }  // namespace elag

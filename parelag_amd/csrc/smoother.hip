@@ -414,6 +414,15 @@ void elag_hip_coarse_s::setup()
         k::dense_inverse_general(A->diag, Minv);
         return;
     }
+    // beyond a few hundred dofs the host's scalar Cholesky + n triangular solve pairs take longer than everything else of a setup (358 ms at
+    // n = 1 015): the device inverts those (two launches per pivot, ~10 ms); small operators keep the host path
+    static int dev_from = -1;
+    if (dev_from < 0) { const char *e = getenv("ELAG_HIP_COARSE_DEVICE_FROM"); dev_from = e ? atoi(e) : 256; }
+    if (n >= dev_from) {
+        Minv = dev_alloc<double>((size_t)n * n);
+        k::dense_inverse_spd(A->diag, Minv);
+        return;
+    }
     std::vector<int> I = host_from_dev(A->diag.I, (size_t)n + 1);
     std::vector<int> J = host_from_dev(A->diag.J, (size_t)A->diag.nnz);
     std::vector<double> a = host_from_dev(A->diag.a, (size_t)A->diag.nnz);
