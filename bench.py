@@ -277,6 +277,23 @@ def large_workload(args, dist, world, kL, la, meshgen, distributed, np, barrier)
     return large
 
 
+def spmd_cpu_baseline(refines, seconds, workers=None):
+    """The CPU baseline in the reference's own layout: oracle/spmd_baseline.py as a CHILD process (it forks one worker per
+    core; this process must not have touched the GPU yet, so it is started first thing).  Returns its JSON record or an {"error": ...}."""
+    import subprocess
+    cmd = [sys.executable, "-m", "oracle.spmd_baseline", "--refines", str(refines), "--seconds", str(seconds)]
+    if workers:
+        cmd += ["--workers", ",".join(str(w) for w in workers)]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        return json.loads(lines[-1])
+    except Exception as exc:
+        return {"error": repr(exc)[:400]}
+
+
 def note(msg):
     """progress line on stderr (stdout carries exactly one JSON line)"""
     print("[bench %7.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
@@ -349,6 +366,18 @@ def main():
     args.form = 3 if darcy else int(args.form)
     mesh_label = ("Cartesian hex grid %dx%dx%d (cells 20x10x2, the mesh of MultigridTestSPE10.cpp:194-208), 2x2x2 box agglomerates" % tuple(args.hex)
                   if args.hex else f"cube456 x{args.refines} uniform refines")
+
+    # CPU baseline of the headline workload in the reference's layout, measured before this process touches the GPU (the child forks)
+    spmd = {}
+    if world == 1 and not args.force_dist and not args.no_cpu_baseline and args.form == 0 and not darcy and not (args.amge or args.hex) \
+            and args.smoother == "L1 Jacobi":
+        note("CPU baseline (one process per core) ...")
+        spmd["headline"] = spmd_cpu_baseline(args.refines, max(1.0, args.cpu_seconds / 5))
+        if not args.no_roofline:
+            # the same layout at the size the roofline is quoted on: one core, and the worker counts around the headline's best
+            best = spmd["headline"].get("best_workers", 16) if "error" not in spmd["headline"] else 16
+            spmd["roofline_size"] = spmd_cpu_baseline(args.roofline_refines, max(2.0, args.cpu_seconds / 4), workers=sorted({1, max(2, best // 2), best, 2 * best}))
+        note("CPU baseline done: %s" % json.dumps({k_: (v_.get("best_vcycles_per_s"), v_.get("best_workers")) for k_, v_ in spmd.items()}))
 
     import numpy as np
     import scipy.sparse as sp
@@ -842,8 +871,8 @@ def main():
                 break
         cpu_rate = cnt / (time.perf_counter() - t0)
         mc = None
-        if not darcy:
-            # the same all-C cycle with its row loops split over the host cores (the work split of one MPI rank per core,
+        if not darcy and not (spmd.get("headline") and "error" not in spmd["headline"]):
+            # (forms without a process-per-core run:) the same all-C cycle with its row loops split over the host cores (the work split of one MPI rank per core,
             # without the message passing): the multi-core figure is the baseline, the single-core one is kept beside it
             avail = len(os.sched_getaffinity(0))
             xm = np.empty_like(b)
@@ -885,6 +914,25 @@ def main():
                    "threads_sweep_Vcycles_per_s": mc["sweep"]}
         elif mc is not None:
             cpu["threads_sweep_Vcycles_per_s"] = mc["sweep"]
+        hs = spmd.get("headline")
+        if hs and "error" not in hs:
+            # the baseline in the reference's own layout: one process per core, row blocks, shared vectors (oracle/spmd_baseline.py)
+            cpu = {"value": hs["best_vcycles_per_s"], "unit": "V-cycles/s", "cores": hs["best_workers"], "kind": "port",
+                   "layout": "one process per core, no OpenMP (the reference's: CMakeLists.txt:130-132): each process owns a row block of every "
+                             "level, vectors in shared memory, a barrier where MPI ranks would exchange halos",
+                   "sample": f"{hs['seconds_per_point']} s of V-cycles per worker count on the same {mesh_label} hierarchy (oracle/elag_oracle.c "
+                             f"orc_hier_spmd_bench, -O3 -march=native; hypre/MFEM unavailable, so this is a restatement); in-process single core: "
+                             f"{round(cpu_rate, 2)} V-cycles/s",
+                   "vcycles_per_s_by_processes": hs["vcycles_per_s_by_workers"], "value_1core": hs["vcycles_per_s_by_workers"].get("1", round(cpu_rate, 2)),
+                   "rel_diff_vs_serial_cycle": hs["rel_diff_vs_serial_cycle"], "setup_s_1core": hs["setup_s_1core"],
+                   "cores_available": hs["cores_available"], "cpu_model": hs["cpu_model"]}
+            hr = spmd.get("roofline_size")
+            if hr:
+                cpu["at_roofline_size"] = hr if "error" in hr else {
+                    "workload": f"cube456 x{hr['refines']} refines (n = {hr['n']})", "vcycles_per_s_by_processes": hr["vcycles_per_s_by_workers"],
+                    "value": hr["best_vcycles_per_s"], "cores": hr["best_workers"], "setup_s_1core": hr["setup_s_1core"]}
+        elif hs:
+            cpu["process_per_core_error"] = hs["error"]
         # parity spot check of the timed operator against the baseline operator
         xd = sol.to_numpy()
         out["parity_rel_err_vs_oracle"] = float(np.max(np.abs(xd - xs)) / np.max(np.abs(xs)))

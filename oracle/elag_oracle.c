@@ -932,3 +932,191 @@ ORC_API void orc_hier_destroy(orc_hier *H)
     }
     free(H->lev); free(H);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * CPU baseline in the reference's own layout: one process per core, no OpenMP
+ * (CMakeLists.txt:130-132 switches OpenMP off; the examples run one MPI rank per core).  W worker
+ * processes are forked; each owns a contiguous row block of every level, like hypre's row
+ * partitioning; vectors live in memory shared by the workers, so a rank's "halo exchange" is a read
+ * of its neighbours' entries once everyone has passed a barrier -- the cheapest message passing a
+ * node can offer (it flatters the CPU against an MPI run).  The arithmetic per row is the serial
+ * oracle's (l1-Jacobi levels, dense Cholesky on the coarsest level by rank 0); only P^T r is formed
+ * from the explicit transpose, as newer hypre does.  Test infrastructure: bench.py's cpu_baseline.
+ * ---------------------------------------------------------------------------------------------- */
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <time.h>
+#include <unistd.h>
+
+typedef struct { volatile int count; volatile int sense; char pad[56]; } spmd_barrier_t;
+typedef struct {
+    spmd_barrier_t bar;
+    volatile int stop;
+    volatile long cycles;
+    volatile double elapsed;
+} spmd_ctl;
+typedef struct { double *sol, *resid, *v, *tc, *tr; } spmd_vecs;
+
+static void *shared_alloc(size_t bytes)
+{
+    void *p = mmap(NULL, bytes ? bytes : 8, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    return p == MAP_FAILED ? NULL : p;
+}
+
+static inline void spmd_wait(spmd_barrier_t *b, int n, int *sense)
+{
+    *sense = !*sense;
+    if (__sync_add_and_fetch(&b->count, 1) == n) { b->count = 0; __sync_synchronize(); b->sense = *sense; }
+    else while (b->sense != *sense) __builtin_ia32_pause();
+    __sync_synchronize();
+}
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+#define SPMD_LO(n) ((int)((long)(n) * rank / W))
+#define SPMD_HI(n) ((int)((long)(n) * (rank + 1) / W))
+#define SPMD_BARRIER() spmd_wait(&ctl->bar, W, sense)
+
+/* one l1-Jacobi sweep of this rank's rows: v = w f - w A u; barrier; u += v / l1 (smoother_apply, type 1) */
+static void spmd_jacobi(const orc_level *L, const double *f, double *u, double *v, int rank, int W, spmd_ctl *ctl, int *sense)
+{
+    const int n = L->A.n, lo = SPMD_LO(n), hi = SPMD_HI(n);
+    const double w = L->sm.weight;
+    for (int i = lo; i < hi; i++) {
+        double t = 0.0;
+        for (int jj = L->A.I[i]; jj < L->A.I[i + 1]; jj++) t += L->A.a[jj] * u[L->A.J[jj]];
+        /* memcpy(v, f); matvec(-w, A, u, w, v): v = (w / -w) v; v += t; v *= -w */
+        double y = f[i] * (w / -w);
+        y += t;
+        v[i] = y * -w;
+    }
+    SPMD_BARRIER();
+    for (int i = lo; i < hi; i++) u[i] += v[i] / L->sm.l1[i];
+    SPMD_BARRIER();
+}
+
+static void spmd_iterate(orc_hier *H, spmd_vecs *V, const double *RHS, double *SOL, int l, int rank, int W, spmd_ctl *ctl, int *sense)
+{
+    orc_level *F = &H->lev[l];
+    if (l == H->nlevels - 1) {
+        if (rank == 0) orc_chol_solve(H->ncoarse, H->chol, RHS, SOL);
+        SPMD_BARRIER();
+        return;
+    }
+    const int n = F->A.n, nc = F->ncoarse, lo = SPMD_LO(n), hi = SPMD_HI(n), clo = SPMD_LO(nc), chi = SPMD_HI(nc);
+    spmd_jacobi(F, RHS, SOL, V[l].v, rank, W, ctl, sense);
+    for (int i = lo; i < hi; i++) {
+        double t = 0.0;
+        for (int jj = F->A.I[i]; jj < F->A.I[i + 1]; jj++) t += F->A.a[jj] * SOL[F->A.J[jj]];
+        V[l].tc[i] = t;
+        V[l].tr[i] = RHS[i] + (-1.0) * t;
+    }
+    SPMD_BARRIER();
+    double *cr = V[l + 1].resid, *cs = V[l + 1].sol;
+    for (int i = clo; i < chi; i++) {
+        double t = 0.0;
+        for (int jj = F->PTI[i]; jj < F->PTI[i + 1]; jj++) t += F->PTa[jj] * V[l].tr[F->PTJ[jj]];
+        cr[i] = t;
+        cs[i] = 0.0;
+    }
+    SPMD_BARRIER();
+    spmd_iterate(H, V, cr, cs, l + 1, rank, W, ctl, sense);
+    for (int i = lo; i < hi; i++) {
+        double t = 0.0;
+        for (int jj = F->P.I[i]; jj < F->P.I[i + 1]; jj++) t += F->P.a[jj] * cs[F->P.J[jj]];
+        SOL[i] += t;
+    }
+    SPMD_BARRIER();
+    spmd_jacobi(F, RHS, SOL, V[l].v, rank, W, ctl, sense);
+}
+
+/* Runs V-cycles (preconditioner mode, rhs fixed) on W forked worker processes for about `seconds`; returns the number of
+ * cycles and the elapsed time of the team, and the last solution (for the parity check against the serial cycle).
+ * Every level must be an l1-Jacobi level (type 1, one sweep) above a dense Cholesky coarse solve.  Returns 0 on success. */
+ORC_API int orc_hier_spmd_bench(orc_hier *H, int W, double seconds, const double *rhs, double *sol_out, long *cycles_out, double *elapsed_out)
+{
+    const int nl = H->nlevels;
+    if (W < 1 || !H->chol) return 1;
+    for (int l = 0; l < nl - 1; l++)
+        if (H->lev[l].sm.type != 1 || H->lev[l].sm.sweeps != 1 || H->lev[l].hiptmair) return 2;
+    /* explicit transposes of the interpolators (read-only after this point: shared with the children copy-on-write) */
+    for (int l = 0; l < nl - 1; l++) {
+        orc_level *L = &H->lev[l];
+        if (!L->PTI) {
+            const int nnz = L->P.I[L->A.n];
+            L->PTI = (int *)malloc(sizeof(int) * ((size_t)L->ncoarse + 1)); L->PTJ = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+            L->PTa = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+            orc_csr_transpose(L->A.n, L->ncoarse, L->P.I, L->P.J, L->P.a, L->PTI, L->PTJ, L->PTa);
+        }
+    }
+    spmd_ctl *ctl = (spmd_ctl *)shared_alloc(sizeof(spmd_ctl));
+    spmd_vecs *V = (spmd_vecs *)calloc((size_t)nl, sizeof(spmd_vecs));
+    if (!ctl || !V) return 3;
+    memset((void *)ctl, 0, sizeof(*ctl));
+    const int n0 = H->lev[0].A.n;
+    double *rhs_s = (double *)shared_alloc(sizeof(double) * (size_t)n0);
+    for (int l = 0; l < nl; l++) {
+        const size_t n = (size_t)H->lev[l].A.n;
+        V[l].sol = (double *)shared_alloc(sizeof(double) * n); V[l].resid = (double *)shared_alloc(sizeof(double) * n);
+        V[l].v = (double *)shared_alloc(sizeof(double) * n); V[l].tc = (double *)shared_alloc(sizeof(double) * n);
+        V[l].tr = (double *)shared_alloc(sizeof(double) * n);
+        if (!V[l].sol || !V[l].resid || !V[l].v || !V[l].tc || !V[l].tr) return 3;
+    }
+    memcpy(rhs_s, rhs, sizeof(double) * (size_t)n0);
+    const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    pid_t *kids = (pid_t *)calloc((size_t)W, sizeof(pid_t));
+    int rank = 0;
+    for (int r = 1; r < W; r++) {
+        pid_t p = fork();
+        if (p < 0) { W = r; break; }          /* (could not start all of them: run with what we have -- every worker reads W after this) */
+        if (p == 0) { rank = r; break; }
+        kids[r] = p;
+    }
+    /* NOTE: W as seen by the children forked before a failure would be stale; a failed fork is reported instead of used */
+    /* one process per core: the scheduler spreads W <= cores runnable processes over the cores by itself; explicit pinning
+     * (ORC_SPMD_PIN=1: the rank-th allowed core) made things worse in containers whose visible cores share physical ones */
+    if (getenv("ORC_SPMD_PIN")) {
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+            /* pin to the rank-th allowed core (one process per core) */
+            int seen = 0;
+            for (int c = 0; c < (int)ncpu && c < CPU_SETSIZE; c++)
+                if (CPU_ISSET(c, &set)) {
+                    if (seen == rank) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(c, &one); sched_setaffinity(0, sizeof(one), &one); break; }
+                    seen++;
+                }
+        }
+    }
+    int sense_v = 0, *sense = &sense_v;
+    long done = 0;
+    double t0 = 0.0;
+    /* two untimed cycles, then cycles until rank 0 says stop (checked by everyone at the same barrier) */
+    for (int it = 0;; it++) {
+        if (it == 2) { SPMD_BARRIER(); if (rank == 0) t0 = now_s(); }
+        {
+            const int lo = SPMD_LO(n0), hi = SPMD_HI(n0);
+            for (int i = lo; i < hi; i++) V[0].sol[i] = 0.0;
+            SPMD_BARRIER();
+        }
+        spmd_iterate(H, V, rhs_s, V[0].sol, 0, rank, W, ctl, sense);
+        if (it >= 2) done++;
+        if (rank == 0 && it >= 2 && (done % 8) == 0 && now_s() - t0 >= seconds) ctl->stop = 1;
+        SPMD_BARRIER();
+        if (ctl->stop) break;
+    }
+    if (rank != 0) _exit(0);
+    ctl->elapsed = now_s() - t0;
+    ctl->cycles = done;
+    for (int r = 1; r < W; r++) if (kids[r] > 0) { int st; waitpid(kids[r], &st, 0); }
+    memcpy(sol_out, V[0].sol, sizeof(double) * (size_t)n0);
+    *cycles_out = ctl->cycles; *elapsed_out = ctl->elapsed;
+    for (int l = 0; l < nl; l++) {
+        const size_t n = (size_t)H->lev[l].A.n;
+        munmap(V[l].sol, sizeof(double) * n); munmap(V[l].resid, sizeof(double) * n); munmap(V[l].v, sizeof(double) * n);
+        munmap(V[l].tc, sizeof(double) * n); munmap(V[l].tr, sizeof(double) * n);
+    }
+    munmap(rhs_s, sizeof(double) * (size_t)n0); munmap((void *)ctl, sizeof(*ctl));
+    free(V); free(kids);
+    return 0;
+}

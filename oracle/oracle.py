@@ -1138,6 +1138,18 @@ class CHierarchy:
     def apply(self, rhs, sol, symmetric_post=False):
         self.L.orc_hier_apply(self.h, _dp(_f64(rhs)), _dp(sol), C.c_int(int(symmetric_post)))
 
+    def spmd_bench(self, rhs, workers, seconds):
+        """The reference's CPU layout: ``workers`` forked processes, one per core, each owning a row block of every level,
+        vectors in shared memory (orc_hier_spmd_bench; l1-Jacobi levels above a dense coarse solve only).  Runs V-cycles for about
+        ``seconds``; returns (cycles per second, last solution).  Forks: call it from a process that holds no GPU context."""
+        sol = np.empty(self.n)
+        cycles, elapsed = C.c_long(0), C.c_double(0.0)
+        rc = self.L.orc_hier_spmd_bench(self.h, C.c_int(int(workers)), C.c_double(float(seconds)), _dp(_f64(rhs)), _dp(sol),
+                                        C.byref(cycles), C.byref(elapsed))
+        if rc:
+            raise RuntimeError(f"orc_hier_spmd_bench failed with code {rc} (1: bad arguments, 2: not an l1-Jacobi hierarchy, 3: no shared memory)")
+        return cycles.value / elapsed.value, sol
+
     def __del__(self):
         try:
             self.L.orc_hier_destroy(self.h)

@@ -84,3 +84,22 @@ def test_hiptmair_vcycle_is_a_good_hdiv_preconditioner():
     x1 = np.zeros_like(b); S.Mult(b, x1); S.Mult(b, x1)
     x2 = np.empty_like(b); Hc1.apply(b, x2)
     assert np.allclose(x1, x2, rtol=1e-12, atol=1e-14)
+
+
+def test_process_per_core_cycle_is_the_serial_cycle(h1_k2):
+    """bench.py's CPU baseline in the reference's layout (one process-rank per core): forked workers own row blocks of every
+    level and share their vectors (orc_hier_spmd_bench).  Whatever the number of processes, the cycle is the serial oracle's."""
+    from tests.helpers import oracle_h1_hierarchy
+    A, Ps, _ = h1_k2
+    h = oracle_h1_hierarchy(A, Ps, smoother=1)
+    H = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"])
+    b = np.random.default_rng(11).uniform(-1, 1, A.shape[0])
+    xs = np.empty_like(b)
+    H.apply(b, xs)
+    for workers in (1, 2, 3):
+        rate, x = H.spmd_bench(b, workers, 0.2)
+        assert rate > 0
+        assert np.max(np.abs(x - xs)) <= 1e-13 * np.max(np.abs(xs))
+    hg = oracle_h1_hierarchy(A, Ps, smoother=2)                    # Gauss-Seidel levels are refused (the team runs l1-Jacobi levels only)
+    with pytest.raises(RuntimeError):
+        orc.CHierarchy(hg["As"], hg["Ps"], hg["sms"], hg["chol"]).spmd_bench(b, 2, 0.1)
