@@ -294,6 +294,57 @@ def spmd_cpu_baseline(refines, seconds, workers=None):
         return {"error": repr(exc)[:400]}
 
 
+def measure_roofline_traffic(args):
+    """HBM bytes per launch of the roofline kernel from the PMC counters, measured in THIS run: `bench.py --roofline-only` (nothing but
+    the launches of that one kernel) as a child process under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no
+    trace domains beside them), plus the gfx950 FETCH_SIZE calibration pass of MI355X_MICROARCH.md on a known byte count in the same
+    access pattern (tools/calibrate_fetch.py).  Children of a process that has not touched the GPU yet.  Returns a dict or None."""
+    import csv, glob, shutil, subprocess, tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None
+    tmp = tempfile.mkdtemp(prefix="elag_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--roofline-only", "--roofline-refines", str(args.roofline_refines), "--smoother", args.smoother]
+    if args.roofline_form:
+        base += ["--roofline-form", args.roofline_form]
+
+    def run(counter, prog, tag):
+        d = os.path.join(tmp, tag)
+        r = subprocess.run([rp, "--pmc", counter, "--output-format", "csv", "-d", d, "--", *prog], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError((r.stderr or r.stdout)[-300:])
+        return d, json.loads(lines[-1])
+
+    def mean(d, counter, kern):
+        tot = cnt = 0
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            for row in csv.DictReader(open(f)):
+                if kern in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    tot += float(row["Counter_Value"]); cnt += 1
+        if not cnt:
+            raise RuntimeError("no %s samples of %s" % (counter, kern))
+        return tot / cnt, cnt
+    try:
+        df, rec = run("FETCH_SIZE", base, "fetch")
+        kern = rec["roofline"]["kernel"]
+        dw, _ = run("WRITE_SIZE", base, "write")
+        dc, cal = run("FETCH_SIZE", [sys.executable, os.path.join(ROOT, "tools", "calibrate_fetch.py"), str(args.roofline_refines)], "calib")
+        fetch_kb, nf = mean(df, "FETCH_SIZE", kern)
+        write_kb, _nw = mean(dw, "WRITE_SIZE", kern)
+        cal_kb, _nc = mean(dc, "FETCH_SIZE", "spmv_stream_kernel")
+        factor = cal["known_read_bytes"] / (cal_kb * 1024.0)
+        return {"kernel": kern, "n": rec["roofline"]["n"], "nnz": rec["roofline"]["nnz"], "window": rec["roofline"].get("window"),
+                "traffic_bytes_per_launch": int(factor * fetch_kb * 1024.0 + write_kb * 1024.0), "fetch_size_kb": round(fetch_kb, 1),
+                "write_size_kb": round(write_kb, 1), "fetch_correction_factor": round(factor, 4), "launches_sampled": nf}
+    except Exception as exc:
+        note("traffic measurement failed: %r" % (exc,))
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def note(msg):
     """progress line on stderr (stdout carries exactly one JSON line)"""
     print("[bench %7.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
@@ -330,6 +381,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic in this run (three rocprofv3 --pmc child passes, ~40 s): "
+                    "report the figure recorded under profiles/ instead")
     ap.add_argument("--no-gs", action="store_true", help="skip the L1 Gauss-Seidel cycle reported beside the headline one")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--solve", action="store_true", help="also time the Krylov solve of the example (PCG / GMRES with the cycle as "
@@ -369,8 +422,8 @@ def main():
 
     # CPU baseline of the headline workload in the reference's layout, measured before this process touches the GPU (the child forks)
     spmd = {}
-    if world == 1 and not args.force_dist and not args.no_cpu_baseline and args.form == 0 and not darcy and not (args.amge or args.hex) \
-            and args.smoother == "L1 Jacobi":
+    if world == 1 and not args.force_dist and not args.no_cpu_baseline and not args.roofline_only and args.form == 0 and not darcy \
+            and not (args.amge or args.hex) and args.smoother == "L1 Jacobi":
         note("CPU baseline (one process per core) ...")
         spmd["headline"] = spmd_cpu_baseline(args.refines, max(1.0, args.cpu_seconds / 5))
         if not args.no_roofline:
@@ -378,6 +431,13 @@ def main():
             best = spmd["headline"].get("best_workers", 16) if "error" not in spmd["headline"] else 16
             spmd["roofline_size"] = spmd_cpu_baseline(args.roofline_refines, max(2.0, args.cpu_seconds / 4), workers=sorted({1, max(2, best // 2), best, 2 * best}))
         note("CPU baseline done: %s" % json.dumps({k_: (v_.get("best_vcycles_per_s"), v_.get("best_workers")) for k_, v_ in spmd.items()}))
+
+    # HBM traffic of the roofline kernel from the PMC counters, in this run (children under rocprofv3, before this process touches the GPU)
+    live_traffic = None
+    if world == 1 and not args.force_dist and not args.no_roofline and not args.roofline_only and not args.no_traffic and args.form == 0 and not darcy:
+        note("roofline traffic: rocprofv3 --pmc passes ...")
+        live_traffic = measure_roofline_traffic(args)
+        note("roofline traffic: %s" % (live_traffic,))
 
     import numpy as np
     import scipy.sparse as sp
@@ -515,9 +575,15 @@ def main():
                 "pcg": pcg,
                 "hierarchy_setup_s": round(setup_r, 3), "hierarchy_setup_breakdown_ms": {k_: round(v_, 3) for k_, v_ in Hr.setup_breakdown().items()},
                 "generate_s": round(gen_s, 1)}
-        # HBM traffic of the same launch from the committed PMC passes (tools/roofline_profile.sh), if present
+        # HBM traffic of the same launch: measured in this run by the rocprofv3 --pmc child passes (measure_roofline_traffic) when they
+        # ran on this operator and kernel; else the figure recorded by the committed passes (tools/roofline_profile.sh), if present
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tpath):
+        if live_traffic and live_traffic["n"] == n and live_traffic["nnz"] == nnz and live_traffic["kernel"] == kern and live_traffic["window"] == kwin:
+            roof["traffic"] = live_traffic["traffic_bytes_per_launch"]
+            roof["traffic_measured_in"] = "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --roofline-only` as child processes, FETCH_SIZE calibrated per MI355X_MICROARCH.md"
+            roof["traffic_detail"] = {k_: live_traffic[k_] for k_ in ("fetch_size_kb", "write_size_kb", "fetch_correction_factor", "launches_sampled")}
+            roof["traffic_over_algorithmic"] = round(live_traffic["traffic_bytes_per_launch"] / b, 4)
+        elif os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("n") == n and tj.get("nnz") == nnz and tj.get("kernel", "spmv_xc_kernel") == kern and tj.get("window") == kwin:
                 # counters cannot be read from inside this process: the figure is the one RECORDED by the committed rocprofv3
