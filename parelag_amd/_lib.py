@@ -234,15 +234,31 @@ def device_name() -> str:
     return buf.value.decode()
 
 
-_kept_pages = False
+import contextlib
+
+
+@contextlib.contextmanager
+def host_pages_kept():
+    """For the duration of one coarsening: large host blocks come from the heap and freed pages stay with the process
+    (``elag_hip_host_keep_pages``: glibc's ``M_MMAP_MAX = 0``, ``M_TRIM_THRESHOLD = 2 GiB``) -- the table stage allocates and frees arrays of
+    hundreds of MB per level and otherwise faults them in again every time (0.76 -> 0.46 s for the finest coarsening of the SPE10-size
+    grid).  The embedding process's allocator policy is glibc's own again when the coarsening returns, and the heap is trimmed
+    (``malloc_trim``): a library call must not change the application's allocator for good.  ``ELAG_HIP_HOST_KEEP_PAGES=0`` never touches
+    it, ``=1`` (the round-2 behaviour) leaves the setting on for the life of the process."""
+    mode = os.environ.get("ELAG_HIP_HOST_KEEP_PAGES", "scoped")
+    if mode == "0":
+        yield
+        return
+    lib = load()
+    check(lib.elag_hip_host_keep_pages(1))
+    try:
+        yield
+    finally:
+        if mode != "1":
+            check(lib.elag_hip_host_keep_pages(0))
 
 
 def keep_host_pages():
-    """Once per process: keep the pages of freed large host arrays (``elag_hip_host_keep_pages``) -- the coarsening's table stage allocates
-    and frees arrays of hundreds of MB per level and otherwise faults them in again every time.  ``ELAG_HIP_HOST_KEEP_PAGES=0`` leaves
-    glibc's defaults alone."""
-    global _kept_pages
-    if not _kept_pages:
-        _kept_pages = True
-        if os.environ.get("ELAG_HIP_HOST_KEEP_PAGES", "1") != "0":
-            check(load().elag_hip_host_keep_pages(1))
+    """(kept for callers of round 2) the process-wide form of ``host_pages_kept``; only acts when ELAG_HIP_HOST_KEEP_PAGES=1"""
+    if os.environ.get("ELAG_HIP_HOST_KEEP_PAGES", "scoped") == "1":
+        check(load().elag_hip_host_keep_pages(1))

@@ -305,8 +305,13 @@ def _families_to_csr(fam, shape):
 
 def coarsen(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entry: float = EPS, timings: dict | None = None) -> dict:
     """``DeRhamSequence::Coarsen`` for forms 2 and 3.  Returns dict(P2, P3, Pi2 parts, coarse (AmgeLevel), topo)."""
+    with _lib.host_pages_kept():          # (the table stage's allocator policy, for the duration of this call only)
+        return _coarsen_impl(lv, part, svd_tol=svd_tol, smallest_entry=smallest_entry, timings=timings)
+
+
+def _coarsen_impl(lv: AmgeLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entry: float = EPS, timings: dict | None = None) -> dict:
+
     L = _lib.init()
-    _lib.keep_host_pages()
     t_mark = [time.perf_counter()]
 
     def mark(name):                                             # host wall time of the stage that just ended (seconds)

@@ -39,13 +39,15 @@ ELAG_HIP_API int64_t elag_hip_host_set_min_work(int64_t min_work)
 // Allocator policy for the table stage: its arrays are tens to hundreds of MB, allocated and freed once per stage; glibc hands such blocks
 // back to the kernel on free, so every stage pays the page faults again (and faults taken by many threads at once serialise on the
 // process's address-space lock: 0.76 s -> 0.46 s for the finest coarsening of the SPE10-size grid).  on != 0: large blocks come from the
-// heap and freed pages stay with the process (M_MMAP_MAX = 0, M_TRIM_THRESHOLD = 2 GiB - 1); on == 0: glibc's defaults again.
+// heap and freed pages stay with the process (M_MMAP_MAX = 0, M_TRIM_THRESHOLD = 2 GiB - 1); on == 0: glibc's defaults again and the
+// kept pages returned (malloc_trim).  The Python callers switch it on for the duration of one coarsening only (_lib.host_pages_kept).
 ELAG_HIP_API int elag_hip_host_keep_pages(int on)
 {
     return guarded([&] {
         const int ok = on ? (mallopt(M_MMAP_MAX, 0) && mallopt(M_TRIM_THRESHOLD, 0x7fffffff))
                           : (mallopt(M_MMAP_MAX, 65536) && mallopt(M_TRIM_THRESHOLD, 128 * 1024));
         ELAG_REQUIRE(ok, "elag_hip_host_keep_pages: mallopt refused the setting");
+        if (!on) (void)malloc_trim(0);         // the pages kept meanwhile go back to the system
     });
 }
 

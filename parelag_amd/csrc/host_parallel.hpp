@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -47,15 +48,29 @@ int parallel_parts(int64_t n, F &&fn, int64_t grain = 256)
     if (nt <= 1) { fn(0, (int64_t)0, n); return 1; }
     std::vector<std::thread> th;
     std::vector<std::string> err((size_t)nt);
+    std::vector<int> code((size_t)nt, 0);
+    auto body = [&](int t, int64_t b, int64_t e) {
+        try { fn(t, b, e); }
+        catch (const Error &ex) { err[(size_t)t] = ex.what(); code[(size_t)t] = ex.code; }
+        catch (const std::bad_alloc &) { err[(size_t)t] = "out of host memory"; code[(size_t)t] = ELAG_HIP_ERR_STATE; }
+        catch (const std::exception &ex) { err[(size_t)t] = ex.what(); code[(size_t)t] = ELAG_HIP_ERR_ARG; }
+        catch (...) { err[(size_t)t] = "unknown exception in a table worker"; code[(size_t)t] = ELAG_HIP_ERR_STATE; }
+        if (code[(size_t)t] && err[(size_t)t].empty()) err[(size_t)t] = "error";
+    };
+    int started = 0;
     for (int t = 0; t < nt; t++) {
         const int64_t b = n * t / nt, e = n * (t + 1) / nt;
-        th.emplace_back([&, b, e, t] {
-            try { fn(t, b, e); } catch (const std::exception &ex) { err[(size_t)t] = ex.what(); if (err[(size_t)t].empty()) err[(size_t)t] = "error"; }
-        });
+        try {
+            th.emplace_back([&body, b, e, t] { body(t, b, e); });
+            started++;
+        } catch (const std::system_error &) {
+            break;           // no more threads to be had (EAGAIN): the caller's thread takes the remaining ranges below
+        }
     }
+    for (int t = started; t < nt; t++) body(t, n * t / nt, n * (t + 1) / nt);
     for (auto &x : th) x.join();
-    for (auto &m : err)
-        if (!m.empty()) fail(ELAG_HIP_ERR_ARG, "%s", m.c_str());
+    for (int t = 0; t < nt; t++)
+        if (code[(size_t)t]) fail(code[(size_t)t], "%s", err[(size_t)t].c_str());
     return nt;
 }
 

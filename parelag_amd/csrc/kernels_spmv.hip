@@ -806,6 +806,7 @@ bool prepare_sign_form(const DevCSR &A)
 void spmv_fused(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, hipStream_t st)
 {
     if (!st) st = ctx().stream;
+    ELAG_REQUIRE(!args.out_add || args.out_perm, "internal: out_add needs out_perm (the epilogues index it with the permuted row)");
     const bool rowlist = args.rows != nullptr;
     const bool offd_terms = offd && offd->nnz > 0 && !args.skip_rows_with_offd;
     if (A.sign_state == 1 && !rowlist && !offd_terms && !args.skip_rows_with_offd) {

@@ -425,13 +425,22 @@ void SweepSmoother::setup()
     // 512: 398 / 59, 256: 492 / 75, 128: 595 / 93, 64: 612 / 94, 16: 579 / 90, 1: 577 / 88 -- a chain step of 128 rows costs about
     // what a launch costs, so a level is chained only when it fits ONE step.
     static int chain_rows = 0;
-    if (chain_rows == 0) { const char *e = getenv("ELAG_HIP_SWEEP_CHAIN_ROWS"); chain_rows = e && atoi(e) > 0 ? atoi(e) : kChainRows; }
+    if (chain_rows == 0) {
+        const char *e = getenv("ELAG_HIP_SWEEP_CHAIN_ROWS");
+        // (never more than a chain launch can hold: a level of more steps than kMaxChain would otherwise neither be chained nor advance the loop below)
+        chain_rows = e && atoi(e) > 0 ? std::min(atoi(e), kMaxChain * kStepRows) : kChainRows;
+    }
     segments.clear();
     for (int l = 0; l < nlev;) {
         const int sz = ptr[(size_t)l + 1] - ptr[(size_t)l];
         if (sz > chain_rows) { segments.push_back(Segment{first_step[(size_t)l], first_step[(size_t)l + 1] - first_step[(size_t)l], sz, ptr[(size_t)l], ptr[(size_t)l + 1]}); l++; continue; }
         int m = l;
         while (m < nlev && first_step[(size_t)m + 1] - first_step[(size_t)l] <= kMaxChain && ptr[(size_t)m + 1] - ptr[(size_t)m] <= chain_rows) m++;
+        if (m == l) {    // a single level with more steps than one chain launch holds: a launch of its own
+            segments.push_back(Segment{first_step[(size_t)l], first_step[(size_t)l + 1] - first_step[(size_t)l], sz, ptr[(size_t)l], ptr[(size_t)l + 1]});
+            l++;
+            continue;
+        }
         segments.push_back(Segment{first_step[(size_t)l], first_step[(size_t)m] - first_step[(size_t)l], 0, 0, 0});
         l = m;
     }

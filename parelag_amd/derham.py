@@ -225,8 +225,14 @@ def coarsen(lv: SeqLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entr
     """``DeRhamSequence::Coarsen`` for forms ``lv.jstart .. 3``.  Returns dict(P, hat, coarse, topo, n_null).  ``check_topology``:
     build the agglomerated topology with the checks and repairs of ``CoarsenLocalPartitioning(..., check_topology = true)``.
     ``topo``: an agglomerated topology made elsewhere (``derham_dist``: the global one restricted to a rank's part)."""
+    with _lib.host_pages_kept():          # (the table stage's allocator policy, for the duration of this call only)
+        return _coarsen_impl(lv, part, svd_tol=svd_tol, smallest_entry=smallest_entry, timings=timings, check_topology=check_topology, topo=topo)
+
+
+def _coarsen_impl(lv: SeqLevel, part: np.ndarray, svd_tol: float = 1e-9, smallest_entry: float = EPS, timings: dict | None = None,
+            check_topology: bool = False, topo: dict | None = None) -> dict:
+
     L = _lib.init()
-    _lib.keep_host_pages()
     tb = _Tables(lv)
     topo = coarsen_topology(lv, part, check=check_topology) if topo is None else topo
     js = lv.jstart
