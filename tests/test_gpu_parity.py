@@ -242,6 +242,36 @@ def test_chebyshev_eig_estimate_matches_oracle(la, h1_k2):
     assert mn == pytest.approx(mn_ref, rel=1e-8)
 
 
+def test_chebyshev_eig_estimate_on_galerkin_operators_and_at_full_size(la, h1_k3):
+    """The estimator on what the cycle actually smooths: every level of the cube456 x3 hierarchy (42 309 dofs on the finest), the coarse ones
+    being the DEVICE's Galerkin products (columns ascending, not the oracle's diagonal-first storage: the Lanczos recurrence sees the same
+    operator, so the estimates agree to rounding) -- and the V-cycle test no longer has to take its eigenvalues from the device on trust."""
+    A, Ps, _ = h1_k3
+    H = device_hierarchy(la, A, Ps, "Chebyshev")
+    h = oracle_h1_hierarchy(A, Ps, smoother=1)
+    for l in range(len(Ps)):
+        mx_ref, mn_ref = orc.max_eig_estimate_cg(orc.OParCSR(orc.diag_first(h["As"][l])), 1, 10)
+        mx, mn = H.GetSmoother(l).eig_estimate()
+        assert mx == pytest.approx(mx_ref, rel=1e-9), l
+        assert mn == pytest.approx(mn_ref, rel=1e-6), l
+
+
+def test_ssor_branches_of_the_gauss_seidel_relaxations_are_refused(la, h1_k2):
+    """hypre's relax types 2 / 4 / 6 switch to SSOR-style branches for relax_weight != 1 (and omega != 1 for type 6); neither the oracle nor
+    the device restates them (the shipped lists use 1 / 1, Create0FormParameterList.hpp:103-116): the ABI refuses them with ELAG_HIP_ERR_ARG
+    instead of silently running the weight-1 sweep, like oracle.OSmoother raises."""
+    from parelag_amd import _lib
+    A, _, _ = h1_k2
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    for stype, params in ((2, {"Damping Factor": 0.8}), (4, {"Damping Factor": 1.2}), (6, {"Damping Factor": 0.9}), (6, {"Omega": 1.3})):
+        with pytest.raises(_lib.ElagHipError) as ei:
+            la.HypreSmootherWrapper(dA, stype, params)
+        assert ei.value.code == 1, (stype, params, ei.value)                    # ELAG_HIP_ERR_ARG
+        with pytest.raises(NotImplementedError):
+            orc.OSmoother(orc.OParCSR(orc.diag_first(A)), type=stype, weight=params.get("Damping Factor", 1.0), omega=params.get("Omega", 1.0))
+    la.HypreSmootherWrapper(dA, 2, {"Damping Factor": 1.0, "Omega": 1.3})       # omega is free for types 2 / 4 with weight 1
+
+
 # ---- the V-cycle -----------------------------------------------------------------------------------------
 
 def device_hierarchy(la, A, Ps, smoother, params=None, use_graph=True):
