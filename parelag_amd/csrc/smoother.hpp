@@ -67,7 +67,8 @@ struct SweepSmoother : elag_hip_smoother_s {
     std::vector<Segment> segments;
     ~SweepSmoother() override;
     void setup();
-    void launch_segment(const Segment &s, int dir, const double *f, double *u);
+    bool lds_u = false;                               // the operator's u fits the chain workgroup's LDS: every level is chained (sweep.hip)
+    void launch_segment(const Segment &s, int dir, const double *f, double *u, bool sym = false);
     void apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose) override;
     int flips(bool) const override { return 0; }
     bool same_scaling_as(const elag_hip_smoother_s *o) const override

@@ -36,6 +36,7 @@ constexpr int kChainRows = kStepRows;                        // levels up to thi
 constexpr int kEPL = 2;            // entries per lane the chain keeps in flight for a row (kLPR * kEPL = 32 entries without a further fetch)
 constexpr int kWideBlock = 256;
 constexpr int kMaxChain = 4096;    // steps per chain launch (their offsets sit in LDS)
+constexpr int kLdsRows = 16384;    // operators up to this many rows keep u in the chain workgroup's LDS (128 KB of the CU's 160)
 
 typedef int int4s __attribute__((ext_vector_type(4)));
 
@@ -159,21 +160,32 @@ __global__ __launch_bounds__(kWideBlock) void sweep_levels_kernel(int b, int e, 
 // does not depend on u -- its schedule slots, then the column indices and values of its rows -- is requested one and two steps
 // ahead, so that the only memory round trip left on the critical path of a step is the gather of u itself (written by the
 // previous step of this very workgroup, hence close by), followed by the ordered subtraction, the store and the barrier.
-template <int MODE>
-__global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__restrict__ step_ptr, const int *__restrict__ step_first, int s_first, int s_count, int dir,
+// LDSU (round 3, an experiment kept off by default -- see setup()): operators of up to kLdsRows rows keep the WHOLE vector u in the
+// workgroup's LDS for the length of the launch, every level of the sweep joins the chain, and with `sym` the backward sweep follows the
+// forward one in the same launch.  Updates are written to LDS and to memory, so the result is where it always was; the arithmetic -- and
+// every bit of the result -- is the other path's (tests/test_gpu_sweeps.py runs one case with ELAG_HIP_SWEEP_LDS=1).
+template <int MODE, bool LDSU>
+__global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__restrict__ step_ptr, const int *__restrict__ step_first, int s_first, int s_count, int dir0,
                                                                   const int4s *__restrict__ sched, const int *__restrict__ J, const double *__restrict__ a,
                                                                   const int *__restrict__ oI, const int *__restrict__ oJ, const double *__restrict__ oa,
                                                                   const double *__restrict__ f, const double *__restrict__ d, const double *__restrict__ ug,
-                                                                  double omega, double *u)
+                                                                  double omega, double *u, int n, int sym)
 {
     __shared__ int lp[kMaxChain + 1];
-    const int s_lo = dir > 0 ? s_first : s_first - (s_count - 1);
+    extern __shared__ double ul[];          // LDSU: u[0 .. n)
+    const int s_lo = dir0 > 0 ? s_first : s_first - (s_count - 1);
     // (top bit: this step is the first one of its dependency level)
     for (int c = threadIdx.x; c <= s_count; c += kChainBlock) lp[c] = step_ptr[s_lo + c] | (step_first[s_lo + c] ? (int)0x80000000 : 0);
+    if (LDSU)
+        for (int i = threadIdx.x; i < n; i += kChainBlock) ul[i] = u[i];
     __syncthreads();
     constexpr int NG = kChainBlock / kLPR;
     const int lane = threadIdx.x & (kLPR - 1);
     const int grp = threadIdx.x / kLPR;
+    auto U = [&](int j) -> double { return LDSU ? ul[j] : u[j]; };
+    for (int pass = 0; pass < (sym ? 2 : 1); pass++) {
+    const int dir = pass == 0 ? dir0 : -dir0;
+    if (pass) __syncthreads();
     auto load_slots = [&](int c, int4s (&sl)[kUnroll]) {
         const int li = dir > 0 ? c : s_count - 1 - c;
         const int b = lp[li] & 0x7fffffff, e = lp[li + 1] & 0x7fffffff;
@@ -211,10 +223,10 @@ __global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__r
 #pragma unroll
         for (int q = 0; q < kUnroll; q++) {
 #pragma unroll
-            for (int e = 0; e < kEPL; e++) xA[q][e] = (e * kLPR + lane < slA[q].z) ? u[jA[q][e]] : 0.0;
+            for (int e = 0; e < kEPL; e++) xA[q][e] = (e * kLPR + lane < slA[q].z) ? U(jA[q][e]) : 0.0;
             fr[q] = f[slA[q].x];
             dr[q] = (MODE != 1) ? d[slA[q].x] : 0.0;
-            uo[q] = (MODE == 0) ? u[slA[q].x] : 0.0;
+            uo[q] = (MODE == 0) ? U(slA[q].x) : 0.0;
         }
         // ---- what does not: the next step's entries (its slots are here already) and the slots of the step after it
         if (c + 1 < s_count) load_entries(slB, jB, vB);
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__r
                 const bool has = k0 + lane < len;
                 const int j = has ? J[s0 + k0 + lane] : -1;
                 const double v = has ? a[s0 + k0 + lane] : 0.0;
-                const double x = has ? u[j] : 0.0;
+                const double x = has ? U(j) : 0.0;
                 ordered_chunk<MODE == 1 ? 1 : 0>(row, j, v, x, res, aii, have);
             }
             if (oI) {
@@ -245,16 +257,17 @@ __global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__r
                     ordered_plain(v * x, res);
                 }
             }
+            auto put = [&](int j, double val) { u[j] = val; if (LDSU) ul[j] = val; };
             if (MODE == 2) {
                 res /= dr[q];
 #pragma unroll
                 for (int e = 0; e < kEPL; e++)
-                    if (e * kLPR + lane < len) u[jA[q][e]] += omega * res * vA[q][e];
+                    if (e * kLPR + lane < len) put(jA[q][e], U(jA[q][e]) + omega * res * vA[q][e]);
                 for (int k0 = kEPL * kLPR; k0 < len; k0 += kLPR)
-                    if (k0 + lane < len) u[J[s0 + k0 + lane]] += omega * res * a[s0 + k0 + lane];
+                    if (k0 + lane < len) { const int j = J[s0 + k0 + lane]; put(j, U(j) + omega * res * a[s0 + k0 + lane]); }
             } else if (lane == 0) {
-                if (MODE == 0) { if (dr[q] != 0.0) u[row] = uo[q] + omega * res / dr[q]; }
-                else if (have && aii != 0.0) u[row] = res / aii;
+                if (MODE == 0) { if (dr[q] != 0.0) put(row, uo[q] + omega * res / dr[q]); }
+                else if (have && aii != 0.0) put(row, res / aii);
             }
         }
         // the steps of ONE level are independent of each other (that is what a level is): the workgroup only has to meet where the
@@ -271,6 +284,7 @@ __global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__r
             for (int e = 0; e < kEPL; e++) { jA[q][e] = jB[q][e]; vA[q][e] = vB[q][e]; }
         }
     }
+    }   // pass
 }
 
 // the first kLPR entries of every row in schedule order (sweep_levels_kernel's first memory round trip)
@@ -430,12 +444,22 @@ void SweepSmoother::setup()
         // (never more than a chain launch can hold: a level of more steps than kMaxChain would otherwise neither be chained nor advance the loop below)
         chain_rows = e && atoi(e) > 0 ? std::min(atoi(e), kMaxChain * kStepRows) : kChainRows;
     }
+    // operators whose u fits the chain workgroup's LDS: every level joins the chain.  OFF unless ELAG_HIP_SWEEP_LDS=1: measured on MI355X
+    // (cube456 x3, L1 Gauss-Seidel cycle) 572 V-cycles/s against 632 for the plan below although the cycle has 50 launches fewer -- with u in
+    // LDS a step no longer waits for u but for the NEXT step's matrix entries, which are requested only one step ahead (1-2 us of memory
+    // latency against ~0.3 us of work), and a 500-row level costs four such steps instead of one 4 us launch.  The lever is a deeper
+    // prefetch (or the level operators in LDS, which fit only below ~10^4 entries), not where u lives.  Results are the other path's bit for bit.
+    {
+        const char *e = getenv("ELAG_HIP_SWEEP_LDS");          // (read at every setup: a test switches it)
+        lds_u = n > 0 && n <= kLdsRows && e && atoi(e);
+    }
+    const int cr = lds_u ? kMaxChain * kStepRows : chain_rows;
     segments.clear();
     for (int l = 0; l < nlev;) {
         const int sz = ptr[(size_t)l + 1] - ptr[(size_t)l];
-        if (sz > chain_rows) { segments.push_back(Segment{first_step[(size_t)l], first_step[(size_t)l + 1] - first_step[(size_t)l], sz, ptr[(size_t)l], ptr[(size_t)l + 1]}); l++; continue; }
+        if (sz > cr) { segments.push_back(Segment{first_step[(size_t)l], first_step[(size_t)l + 1] - first_step[(size_t)l], sz, ptr[(size_t)l], ptr[(size_t)l + 1]}); l++; continue; }
         int m = l;
-        while (m < nlev && first_step[(size_t)m + 1] - first_step[(size_t)l] <= kMaxChain && ptr[(size_t)m + 1] - ptr[(size_t)m] <= chain_rows) m++;
+        while (m < nlev && first_step[(size_t)m + 1] - first_step[(size_t)l] <= kMaxChain && ptr[(size_t)m + 1] - ptr[(size_t)m] <= cr) m++;
         if (m == l) {    // a single level with more steps than one chain launch holds: a launch of its own
             segments.push_back(Segment{first_step[(size_t)l], first_step[(size_t)l + 1] - first_step[(size_t)l], sz, ptr[(size_t)l], ptr[(size_t)l + 1]});
             l++;
@@ -465,11 +489,11 @@ void SweepSmoother::setup()
     d_lev_ptr = dev_from_host(step_ptr.data(), step_ptr.size());
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
     if (getenv("ELAG_HIP_SWEEP_VERBOSE"))
-        fprintf(stderr, "[elag_hip] sweep smoother type %d: n=%d, %d dependency levels = %d steps in %d launches per direction\n", type, n, nlev,
-                n_steps, (int)segments.size());
+        fprintf(stderr, "[elag_hip] sweep smoother type %d: n=%d, %d dependency levels = %d steps in %d launches per direction%s\n", type, n, nlev,
+                n_steps, (int)segments.size(), lds_u ? " (u in LDS)" : "");
 }
 
-void SweepSmoother::launch_segment(const Segment &s, int dir, const double *f, double *u)
+void SweepSmoother::launch_segment(const Segment &s, int dir, const double *f, double *u, bool sym)
 {
     hipStream_t st = ctx().stream;
     const bool ho = A->offd.nnz > 0;
@@ -491,12 +515,30 @@ void SweepSmoother::launch_segment(const Segment &s, int dir, const double *f, d
         else go(sweep_levels_kernel<0>);
     } else {
         const int s_first = dir > 0 ? s.first : s.first + s.count - 1;
+        const int n = A->nrows();
+        const size_t lds = lds_u ? sizeof(double) * (size_t)n : 0;
         auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(1), dim3(kChainBlock), 0, st, lev, lev + n_steps + 1, s_first, s.count, dir, sched, Jd, ad, oI, oJ, oa, f, dd, ug, omega, u);
+            if (lds > (size_t)(48 << 10)) {
+                // (beyond the default dynamic LDS limit: raise it once per kernel)
+                static thread_local std::vector<const void *> raised;
+                const void *fn = reinterpret_cast<const void *>(kern);
+                if (std::find(raised.begin(), raised.end(), fn) == raised.end()) {
+                    ELAG_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kLdsRows)));
+                    raised.push_back(fn);
+                }
+            }
+            hipLaunchKernelGGL(kern, dim3(1), dim3(kChainBlock), lds, st, lev, lev + n_steps + 1, s_first, s.count, dir, sched, Jd, ad, oI, oJ, oa, f, dd, ug, omega, u,
+                               n, sym ? 1 : 0);
         };
-        if (type == ELAG_HIP_SMOOTHER_GS) go(sweep_chain_kernel<1>);
-        else if (type == ELAG_HIP_SMOOTHER_KACZMARZ) go(sweep_chain_kernel<2>);
-        else go(sweep_chain_kernel<0>);
+        if (lds_u) {
+            if (type == ELAG_HIP_SMOOTHER_GS) go(sweep_chain_kernel<1, true>);
+            else if (type == ELAG_HIP_SMOOTHER_KACZMARZ) go(sweep_chain_kernel<2, true>);
+            else go(sweep_chain_kernel<0, true>);
+        } else {
+            if (type == ELAG_HIP_SMOOTHER_GS) go(sweep_chain_kernel<1, false>);
+            else if (type == ELAG_HIP_SMOOTHER_KACZMARZ) go(sweep_chain_kernel<2, false>);
+            else go(sweep_chain_kernel<0, false>);
+        }
     }
     ELAG_LAUNCH_CHECK();
 }
@@ -508,6 +550,10 @@ void SweepSmoother::apply(const double *f, double *&cur, double *&, bool zero_gu
     for (int sw = 0; sw < sweeps; sw++) {
         // "Copy off-diag values of u to the current processor": once per symmetric sweep
         if (A->needs_exchange()) par_halo_exchange(*A, cur);
+        if (lds_u && segments.size() == 1 && segments[0].max_rows == 0) {
+            launch_segment(segments[0], +1, f, cur, true);        // forward then backward in one launch, u in LDS throughout
+            continue;
+        }
         for (size_t s = 0; s < segments.size(); s++) launch_segment(segments[s], +1, f, cur);
         for (size_t s = segments.size(); s-- > 0;) launch_segment(segments[s], -1, f, cur);
     }

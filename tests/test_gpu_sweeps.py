@@ -45,6 +45,32 @@ def test_sweep_is_the_sequential_loop_bit_for_bit(la, h1_k2, relax_type, sweeps,
     assert np.array_equal(ut, ur)
 
 
+@pytest.mark.parametrize("relax_type", [2, 3, 6])
+def test_sweep_with_u_in_lds_is_the_same_sweep(la, h1_k2, relax_type, capfd):
+    """ELAG_HIP_SWEEP_LDS=1 (off by default: measured slower, sweep.hip): the whole vector lives in the chain workgroup's LDS, every level
+    joins the chain and the backward sweep follows the forward one in the same launch -- every bit of the result is the default plan's."""
+    import os
+    A, _, _ = h1_k2
+    Ad = orc.diag_first(A)
+    dA = la.ParallelCSRMatrix.from_scipy(Ad)
+    rng = np.random.default_rng(13)
+    f, u0 = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+    outs = []
+    for lds in ("0", "1"):
+        os.environ["ELAG_HIP_SWEEP_LDS"] = lds
+        os.environ["ELAG_HIP_SWEEP_VERBOSE"] = "1"
+        try:
+            s = la.HypreSmootherWrapper(dA, relax_type, {"Sweeps": 2})
+        finally:
+            os.environ.pop("ELAG_HIP_SWEEP_LDS", None); os.environ.pop("ELAG_HIP_SWEEP_VERBOSE", None)
+        assert ("(u in LDS)" in capfd.readouterr().err) == (lds == "1")
+        s.iterative_mode = True
+        u = u0.copy()
+        s.Mult(f, u)
+        outs.append(u)
+    assert np.array_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("relax_type", [2, 6])
 def test_sweep_on_unsymmetric_patterns_and_awkward_rows(la, relax_type):
     """anti-dependencies (a_ij != 0, a_ji == 0, j > i) must also hold row j back; for type 6 also rows without entries and a
