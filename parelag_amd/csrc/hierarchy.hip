@@ -443,13 +443,19 @@ struct elag_hip_hierarchy_s {
                     if (F.U1) { U[(size_t)i] = F.U1; V[(size_t)i] = F.U2; continue; }
                     const int n = F.A->nrows();
                     const double *w = F.fused_dinv;
-                    DevCSR T, Wd, WS;
-                    k::csr_copy(F.A->diag, T);
-                    k::csr_scale_rows(T, w);
-                    k::csr_scale_cols(T, w);
-                    k::csr_diagonal(n, w, 1.0, Wd);
+                    // U = 2 W - W A W: on a copy of A in one launch where every row stores its diagonal (the general route otherwise)
                     U[(size_t)i].reset(new DevCSR());
-                    k::csr_add(2.0, Wd, -1.0, T, *U[(size_t)i]);
+                    k::csr_copy(F.A->diag, *U[(size_t)i]);
+                    k::CsrCombine uop;
+                    uop.c_scale = -1.0; uop.c_row = w; uop.c_col = w; uop.diag = w; uop.d_scale = 2.0;
+                    if (!k::csr_combine_inplace(*U[(size_t)i], uop)) {
+                        DevCSR T, Wd;
+                        k::csr_copy(F.A->diag, T);
+                        k::csr_scale_rows(T, w);
+                        k::csr_scale_cols(T, w);
+                        k::csr_diagonal(n, w, 1.0, Wd);
+                        k::csr_add(2.0, Wd, -1.0, T, *U[(size_t)i]);
+                    }
                     Temp<double> negw((size_t)n);
                     k::vec_scale_mul(n, -1.0, w, nullptr, negw);
                     V[(size_t)i].reset(new DevCSR());
@@ -460,6 +466,9 @@ struct elag_hip_hierarchy_s {
                 Vc[0] = V[0];
                 long long extra = 0;
                 const long long budget = std::max<long long>(1ll << 20, 4 * lev[(size_t)top].A->diag.nnz);
+                // (The rows of G_l ... G_top are long -- cube456 x3: 840 rows of ~512 entries from 1 300-6 000 products each, the SpGEMM's
+                // one-row-per-workgroup path, 1.4 ms for its two launches.  Forming the product transposed on the short-row path and transposing
+                // it back was tried: 0.2 ms SLOWER, the transpose's per-row column sort is the same long-row work.)
                 for (int i = 1; i < m; i++) {
                     Gc[(size_t)i].reset(new DevCSR());
                     k::csr_spgemm(*lev[(size_t)(top + i)].G, *Gc[(size_t)i - 1], *Gc[(size_t)i], false);
@@ -658,22 +667,43 @@ struct elag_hip_hierarchy_s {
             if (F.A->offd.ncols > 0 || C.P->offd.ncols > 0 || F.A->diag.nnz >= max_nnz) continue;
             const int n = F.A->nrows();
             C.P->ensure_transpose();
-            // G = R - (R A) W
-            DevCSR RA;
-            k::csr_spgemm(*C.P->diagT, F.A->diag, RA);
-            k::csr_scale_cols(RA, dinv);
-            F.G.reset(new DevCSR());
-            k::csr_add(1.0, *C.P->diagT, -1.0, RA, *F.G);
-            // S = A P - W^-1 P
-            DevCSR AP, WP;
-            k::csr_spgemm(F.A->diag, C.P->diag, AP);
-            k::csr_copy(C.P->diag, WP);
+            // G = R - (R A) W  and  S = A P - W^-1 P.  With a full diagonal in A the pattern of R A contains R's and the pattern of A P contains
+            // P's, so each is ONE in-place launch on the product (csr_combine_inplace); the general route -- scale, copy, sparse add through the
+            // ESC engine, ~0.35 ms more per operator on the small levels -- stays for operators where an entry has no place
             {
-                Temp<double> winv((size_t)n);
-                k::vec_reciprocal_scale(n, 1.0, dinv, winv);
-                k::csr_scale_rows(WP, winv);
-                F.S.reset(new DevCSR());
-                k::csr_add(1.0, AP, -1.0, WP, *F.S);
+                std::unique_ptr<DevCSR> RA(new DevCSR());
+                k::csr_spgemm(*C.P->diagT, F.A->diag, *RA);
+                k::CsrCombine g;
+                g.c_scale = -1.0; g.c_col = dinv; g.B = C.P->diagT.get(); g.b_scale = 1.0;
+                if (k::csr_combine_inplace(*RA, g)) {
+                    RA->choose_spmv_shape();
+                    F.G.reset(RA.release());
+                } else {
+                    DevCSR RA2;
+                    k::csr_spgemm(*C.P->diagT, F.A->diag, RA2);
+                    k::csr_scale_cols(RA2, dinv);
+                    F.G.reset(new DevCSR());
+                    k::csr_add(1.0, *C.P->diagT, -1.0, RA2, *F.G);
+                }
+            }
+            {
+                std::unique_ptr<DevCSR> AP(new DevCSR());
+                k::csr_spgemm(F.A->diag, C.P->diag, *AP);
+                k::CsrCombine sop;
+                sop.B = &C.P->diag; sop.b_scale = -1.0; sop.b_row = dinv; sop.b_row_divide = 1;
+                if (k::csr_combine_inplace(*AP, sop)) {
+                    AP->choose_spmv_shape();
+                    F.S.reset(AP.release());
+                } else {
+                    DevCSR AP2, WP;
+                    k::csr_spgemm(F.A->diag, C.P->diag, AP2);
+                    k::csr_copy(C.P->diag, WP);
+                    Temp<double> winv((size_t)n);
+                    k::vec_reciprocal_scale(n, 1.0, dinv, winv);
+                    k::csr_scale_rows(WP, winv);
+                    F.S.reset(new DevCSR());
+                    k::csr_add(1.0, AP2, -1.0, WP, *F.S);
+                }
             }
             F.fused_dinv = dinv;
         }

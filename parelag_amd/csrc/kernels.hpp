@@ -153,7 +153,18 @@ void csr_delete_zeros(const DevCSR &A, double tol, DevCSR &out);
 void csr_scale_rows(DevCSR &A, const double *d);
 void csr_scale_cols(DevCSR &A, const double *d);  // a_ij *= d_j
 void csr_copy(const DevCSR &A, DevCSR &out);
-void csr_diagonal(int n, const double *d, double scale, DevCSR &out);   // out = scale * diag(d)  (d == nullptr: scale * I)
+void csr_diagonal(int n, const double *d, double scale, DevCSR &out);
+// In place, for operators whose pattern contains the other operand's (both with ascending columns):
+//     C_ij <- c_scale * (c_row ? c_row[i] : 1) * C_ij * (c_col ? c_col[j] : 1)
+//             + (B ? b_scale * B_ij * (b_row ? (b_row_divide ? 1 / b_row[i] : b_row[i]) : 1) : 0)  +  (diag && i == j ? d_scale * diag[i] : 0)
+// One launch instead of copy / scale / scale / sparse add through the ESC engine (~0.1 against ~0.4 ms on the level operators of a small
+// hierarchy).  Returns false -- C is then in an unspecified state -- when an entry of B (or a requested diagonal entry) has no place in C.
+struct CsrCombine {
+    double c_scale = 1.0; const double *c_row = nullptr, *c_col = nullptr;
+    const DevCSR *B = nullptr; double b_scale = 1.0; const double *b_row = nullptr; int b_row_divide = 0;
+    const double *diag = nullptr; double d_scale = 0.0;
+};
+bool csr_combine_inplace(DevCSR &C, const CsrCombine &op);   // out = scale * diag(d)  (d == nullptr: scale * I)
 // Renumbering of a level under its coarse level's (hierarchy.hip, `reorder`): children contiguous under their strongest coarse parent.
 // d_order_out[new] = old for the nf rows of P: a stable counting sort of the rows by rank_c[argmax_k |P_ik|] (first maximum in
 // storage order; rows without entries last) -- the sort is a transpose of the (row -> key) incidence, whose rows come back ascending.

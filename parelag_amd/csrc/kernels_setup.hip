@@ -1168,6 +1168,56 @@ void csr_diagonal(int n, const double *d, double scale, DevCSR &out)
     out.choose_spmv_shape();
 }
 
+namespace {
+__global__ void combine_inplace_kernel(int nrows, const int *__restrict__ CI, const int *__restrict__ CJ, double *__restrict__ Ca, double c_scale,
+                                       const double *__restrict__ c_row, const double *__restrict__ c_col, const int *__restrict__ BI,
+                                       const int *__restrict__ BJ, const double *__restrict__ Ba, double b_scale, const double *__restrict__ b_row,
+                                       int b_row_divide, const double *__restrict__ diag, double d_scale, int *__restrict__ missing)
+{
+    // 8 lanes per row of C: every entry of C is written by exactly one lane (scaled, plus the other operand's entry of that column if
+    // there is one -- a binary search in B's ascending row --, plus the diagonal term); the entries found are counted against B's row
+    const int row = (int)((blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 3);
+    const int lane = threadIdx.x & 7;
+    if (row >= nrows) return;
+    const int cs = CI[row], ce = CI[row + 1];
+    const int bs = BI ? BI[row] : 0, be = BI ? BI[row + 1] : 0;
+    const double rs = c_scale * (c_row ? c_row[row] : 1.0);
+    double bs_row = b_scale;
+    if (b_row) bs_row = b_row_divide ? b_scale / b_row[row] : b_scale * b_row[row];
+    int found = 0, has_diag = 0;
+    for (int k = cs + lane; k < ce; k += 8) {
+        const int j = CJ[k];
+        double v = rs * Ca[k] * (c_col ? c_col[j] : 1.0);
+        int lo = bs, hi = be;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (BJ[mid] < j) lo = mid + 1; else hi = mid; }
+        if (lo < be && BJ[lo] == j) { v += bs_row * Ba[lo]; found++; }
+        if (diag && j == row) { v += d_scale * diag[row]; has_diag = 1; }
+        Ca[k] = v;
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { found += __shfl_xor(found, o, 8); has_diag += __shfl_xor(has_diag, o, 8); }
+    if (lane == 0 && (found != be - bs || (diag && !has_diag))) atomicAdd(missing, 1);
+}
+}  // namespace
+
+bool csr_combine_inplace(DevCSR &C, const CsrCombine &op)
+{
+    if (C.nrows == 0) return true;
+    if (op.B) ELAG_REQUIRE(op.B->nrows == C.nrows && op.B->ncols == C.ncols, "internal: csr_combine_inplace shapes");
+    hipStream_t st = ctx().stream;
+    C.release_sign();
+    Temp<int> missing(1);
+    ELAG_HIP_CHECK(hipMemsetAsync(missing, 0, sizeof(int), st));
+    hipLaunchKernelGGL(combine_inplace_kernel, dim3(grid1((long long)C.nrows * 8)), dim3(kBlock), 0, st, C.nrows, (const int *)C.I, (const int *)C.J, C.a, op.c_scale,
+                       op.c_row, op.c_col, op.B ? (const int *)op.B->I : nullptr, op.B ? (const int *)op.B->J : nullptr,
+                       op.B ? (const double *)op.B->a : nullptr, op.b_scale, op.b_row, op.b_row_divide, op.diag, op.d_scale, missing.p);
+    ELAG_LAUNCH_CHECK();
+    int *hm = reinterpret_cast<int *>(ctx().h_scalar + 10);
+    ELAG_HIP_CHECK(hipMemcpyAsync(hm, missing.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    return *hm == 0;
+}
+
 void csr_copy(const DevCSR &A, DevCSR &out)
 {
     hipStream_t st = ctx().stream;
