@@ -128,6 +128,7 @@ struct CsrView {
 struct MatmulExpander {
     CsrView A, B;
     static constexpr bool kUnits = true;
+    static constexpr bool kFlat = true;
     __device__ int ub_entry(int k) const { const int j = A.J[k]; return B.I[j + 1] - B.I[j]; }
     // hash path: a row is a list of units (the entries of A's row), each a run of products scale * a[pbeg + q] in column J[pbeg + q]
     __device__ void units(int row, int &ubeg, int &nu) const { ubeg = A.I[row]; nu = A.I[row + 1] - ubeg; }
@@ -162,10 +163,46 @@ struct MatmulExpander {
     }
 };
 
+// Expansion of ONE long row by a whole workgroup (the one-row-per-workgroup launches of esc_kernel): the products are dealt to the threads
+// by their position in the row's product list -- a scan of the right factor's row lengths over the entries of the left factor's row, then a
+// binary search per product -- so every thread fetches products all the time.  (A wavefront expanding the row entry by entry has 29 lanes
+// writing ~44 products each one after the other for a row of G1 G0: most of the 700 us of such a launch.)  Same product order as expand().
+constexpr int kFlatUnits = 1024;      // entries of the left factor's row the scan holds; longer rows take expand()
+template <bool NUMERIC>
+__device__ bool matmul_expand_flat(const CsrView &A, const CsrView &B, int row, u64 *key, double *val, int *pre /*kFlatUnits + 1*/)
+{
+    const int as = A.I[row], na = A.I[row + 1] - as;
+    if (na > kFlatUnits) return false;                                 // (uniform over the workgroup)
+    for (int t = threadIdx.x; t < na; t += blockDim.x) { const int j = A.J[as + t]; pre[t + 1] = B.I[j + 1] - B.I[j]; }
+    if (threadIdx.x == 0) pre[0] = 0;
+    __syncthreads();
+    if (threadIdx.x < 64) {                                            // inclusive scan by the first wavefront, 64 entries at a time
+        int carry = 0;
+        for (int b = 0; b < na; b += 64) {
+            const int t = b + (int)threadIdx.x;
+            int v = t < na ? pre[t + 1] : 0;
+            v = wave_incl_scan(v);
+            if (t < na) pre[t + 1] = v + carry;
+            carry += __shfl(v, 63, 64);
+        }
+    }
+    __syncthreads();
+    const int total = pre[na];
+    for (int p = threadIdx.x; p < total; p += blockDim.x) {
+        int lo = 0, hi = na;                                           // the entry whose run holds product p: pre[lo] <= p < pre[lo + 1]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= p) lo = mid; else hi = mid; }
+        const int j = A.J[as + lo], q = B.I[j] + (p - pre[lo]);
+        key[p] = (u64)(unsigned)B.J[q];
+        if (NUMERIC) val[p] = A.a[as + lo] * B.a[q];
+    }
+    return true;
+}
+
 struct AddExpander {
     CsrView A, B;
     double ca, cb;
     static constexpr bool kUnits = true;
+    static constexpr bool kFlat = false;
     // two units: A's row scaled by ca, then B's row scaled by cb
     __device__ void units(int row, int &ubeg, int &nu) const { ubeg = 0; nu = 2; }
     __device__ void unit(int row, int, int u, int &pbeg, int &plen, double &scale, const int *&J, const double *&a) const
@@ -195,6 +232,7 @@ struct AddExpander {
 struct SortExpander {  // identity: re-emit the row (used to sort columns inside rows)
     CsrView A;
     static constexpr bool kUnits = false;
+    static constexpr bool kFlat = false;
     template <bool NUMERIC, int G = 64>
     __device__ void expand(int row, unsigned rl, int off, u64 *key, double *val) const
     {
@@ -261,12 +299,18 @@ __global__ __launch_bounds__(kBlock) void esc_kernel(int nrows, const int *__res
     if (count == 0) return;
     int n2 = 64;
     while (n2 < count) n2 <<= 1;
-    // expand: one wavefront per row, round-robin
-    const int w = threadIdx.x >> 6;
-    for (int row = r0 + w; row < r1; row += kBlock / 64) {
-        const int off = BIG ? 0 : (ubscan[row] - base);
-        if (BIG || ub[row] > 0) ex.template expand<NUMERIC>(row, (unsigned)(row - r0), off, key, val);
+    // expand: one wavefront per row, round-robin; the single long row of a BIG workgroup by all of its threads where the expander can
+    bool flat_done = false;
+    if constexpr (BIG && Expander::kFlat) {
+        __shared__ int pre[kFlatUnits + 1];
+        flat_done = matmul_expand_flat<NUMERIC>(ex.A, ex.B, r0, key, val, pre);
     }
+    const int w = threadIdx.x >> 6;
+    if (!flat_done)
+        for (int row = r0 + w; row < r1; row += kBlock / 64) {
+            const int off = BIG ? 0 : (ubscan[row] - base);
+            if (BIG || ub[row] > 0) ex.template expand<NUMERIC>(row, (unsigned)(row - r0), off, key, val);
+        }
     for (int i = count + threadIdx.x; i < n2; i += kBlock) key[i] = ~0ull;
     __syncthreads();
     bitonic_sort_lds<NUMERIC>(key, val, n2);
@@ -290,6 +334,7 @@ __global__ __launch_bounds__(kBlock) void esc_kernel(int nrows, const int *__res
     }
     int tot;
     int hidx = block_excl_scan(nheads, sh, &tot);
+    if (BIG && rownnz && threadIdx.x == 0) rownnz[r0] = tot;
     // Output position of a head = CI[its row] + its rank among the heads of that row.  (The rows of a chunk need not be
     // adjacent in C: rows handled by the wave-per-row kernel may lie between them.)  rank = hidx - (heads before the
     // row's first sorted entry); the latter from the per-thread head offsets.
@@ -316,6 +361,8 @@ __global__ __launch_bounds__(kBlock) void esc_kernel(int nrows, const int *__res
                 CJ[pos] = (int)(kk & 0xffffffffu);
                 Ca[pos] = s;
                 hidx++;
+                // single pass (rownnz given with NUMERIC): CI holds upper-bound offsets, the rows' entry counts are recorded on the way
+                if (rownnz && !BIG) atomicAdd(&rownnz[r0 + (int)rl], 1);
             }
         }
 }
@@ -538,11 +585,11 @@ __global__ __launch_bounds__(BLOCK) void esc_hash_kernel(int nrows, Expander ex,
 }
 
 // ub of the rows the wave path handles (others 0): its scan gives the rows' offsets in the upper-bound layout
-__global__ void wave_ub_kernel(int nrows, const int *__restrict__ ub, int wave_cap, int *__restrict__ ubw, unsigned long long *__restrict__ total)
+__global__ void wave_ub_kernel(int nrows, const int *__restrict__ ub, int wave_cap, int *__restrict__ ubw, unsigned long long *__restrict__ total, int all_rows)
 {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     int v = 0;
-    if (row < nrows) { const int u = ub[row]; v = (u > 0 && u <= wave_cap) ? u : 0; ubw[row] = v; }
+    if (row < nrows) { const int u = ub[row]; v = (u > 0 && (u <= wave_cap || all_rows)) ? u : 0; ubw[row] = v; }
     // 64-bit total (the int scan of ubw is only used when this fits); only asked for when n * wave_cap could pass 2^31
     if (total) {
 #pragma unroll
@@ -674,6 +721,7 @@ struct EscPlan {
     int total_small = 0, nbig = 0;
     int wave_cap = 0;   // > 0: rows with at most this many products go to esc_wave_kernel
     bool wave_ready = false;          // ubw / UBI / class lists are in place and total_ub / hc are known
+    bool all_rows = false;            // ... and the upper-bound layout has room for EVERY row (chunked and one-row-per-workgroup rows too): no symbolic launches at all
     unsigned long long total_ub = 0;
     int hc[kNumClasses] = {0, 0, 0, 0, 0};
     explicit EscPlan(int n)
@@ -689,7 +737,8 @@ struct EscPlan {
         // an upper-bound layout indexed with ints: only when nrows * wave_cap cannot overflow them (the caller's fallback handles the rest)
         const bool wave = wave_cap > 0 && single_pass_enabled() && (unsigned long long)nrows * (unsigned long long)wave_cap < (1ull << 31);
         if (wave) {
-            hipLaunchKernelGGL(wave_ub_kernel, dim3(grid1(nrows)), dim3(kBlock), 0, st, nrows, (const int *)ub.p, wave_cap, ubw.p, (unsigned long long *)nullptr);
+            all_rows = (unsigned long long)nrows * (unsigned long long)kBigCap < (1ull << 31);        // (every row's products fit the int layout whatever their class)
+            hipLaunchKernelGGL(wave_ub_kernel, dim3(grid1(nrows)), dim3(kBlock), 0, st, nrows, (const int *)ub.p, wave_cap, ubw.p, (unsigned long long *)nullptr, all_rows ? 1 : 0);
             exclusive_scan(ubw, UBI, nrows);
             const ClassBounds cb{{0, 16, 32, 64, 128, kWaveCap}};
             ELAG_HIP_CHECK(hipMemsetAsync(ccount, 0, sizeof(int) * kNumClasses, st));
@@ -709,6 +758,9 @@ struct EscPlan {
             fail(ELAG_HIP_ERR_ARG, "sparse product: %d rows expand to more than %d intermediate products (unsupported)", h[1], kBigCap);
         nbig = h[0];
         total_small = tot;
+        if (getenv("ELAG_HIP_ESC_VERBOSE"))
+            fprintf(stderr, "[elag_hip] sparse product plan: %d rows, %d one-row workgroups (> %d products), %d products in %d chunks, wave path %llu\n", nrows, nbig, kCap,
+                    total_small, nchunks(), wave ? (unsigned long long)totw : 0ull);
         if (wave) { wave_ready = true; total_ub = (unsigned long long)totw; }
     }
     int nchunks() const { return (total_small + kCap - 1) / kCap; }
@@ -722,10 +774,13 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
     Temp<int> rownnz((size_t)n);
     ELAG_HIP_CHECK(hipMemsetAsync(rownnz, 0, sizeof(int) * (size_t)n, st));
     const int nch = plan.nchunks();
-    if (nch)
+    // the symbolic launches of the chunked / one-row-per-workgroup rows -- unless the single pass below has room for those rows too
+    const bool single_all = plan.wave_cap > 0 && single_pass_enabled() && plan.wave_ready && plan.all_rows &&
+                            plan.total_ub < (1ull << 31) && plan.total_ub * 12ull <= (16ull << 30);
+    if (nch && !single_all)
         hipLaunchKernelGGL((esc_kernel<2 * kCap, false, false, Expander>), dim3(nch), dim3(kBlock), 0, st, n, plan.ubscan.p,
                            plan.ub_small.p, (const int *)nullptr, ex, rownnz.p, (const int *)nullptr, (int *)nullptr, (double *)nullptr);
-    if (plan.nbig)
+    if (plan.nbig && !single_all)
         hipLaunchKernelGGL((esc_kernel<kBigCap, true, false, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
                            plan.ub.p, plan.biglist.p, ex, rownnz.p, (const int *)nullptr, (int *)nullptr, (double *)nullptr);
     // ---- single pass for the wave rows: numeric launch into an upper-bound layout, counts recorded on the way, then a
@@ -741,7 +796,7 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
             // (plans whose nrows * wave_cap could overflow the int layout: the total first, the layout only if it fits)
             Temp<unsigned long long> tot64(1);
             ELAG_HIP_CHECK(hipMemsetAsync(tot64, 0, sizeof(unsigned long long), st));
-            hipLaunchKernelGGL(wave_ub_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, (const int *)plan.ub.p, plan.wave_cap, ubw.p, tot64.p);
+            hipLaunchKernelGGL(wave_ub_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, (const int *)plan.ub.p, plan.wave_cap, ubw.p, tot64.p, 0);
             ELAG_LAUNCH_CHECK();
             ELAG_HIP_CHECK(hipMemcpyAsync(&total_ub, tot64.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             ELAG_HIP_CHECK(hipStreamSynchronize(st));
@@ -797,6 +852,16 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
             if (hc[4] && !done[4])
                 hipLaunchKernelGGL((esc_wave_kernel<64, 4, true, Expander>), dim3(grid1((long long)hc[4] * 64)), dim3(kBlock), 0, st, n, ubp, 128, kWaveCap, ex,
                                    rownnz.p, (const int *)UBI.p, Ju.p, au.p, cls_list(4), hc[4]);
+            if (single_all) {
+                // the chunked and the one-row-per-workgroup rows write into the upper-bound layout too and record their counts: one
+                // numeric launch each instead of a symbolic and a numeric one (cube456 x3, the flattened cycle's G1 G0: 0.67 + 0.38 ms)
+                if (nch)
+                    hipLaunchKernelGGL((esc_kernel<2 * kCap, false, true, Expander>), dim3(nch), dim3(kBlock), 0, st, n, plan.ubscan.p,
+                                       plan.ub_small.p, (const int *)nullptr, ex, rownnz.p, (const int *)UBI.p, Ju.p, au.p);
+                if (plan.nbig)
+                    hipLaunchKernelGGL((esc_kernel<kBigCap, true, true, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
+                                       plan.ub.p, plan.biglist.p, ex, rownnz.p, (const int *)UBI.p, Ju.p, au.p);
+            }
             ELAG_LAUNCH_CHECK();
             int *CI = dev_alloc<int>((size_t)n + 1);
             exclusive_scan(rownnz, CI, n);
@@ -807,10 +872,10 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
             C.release();
             C.nrows = n; C.ncols = ncols; C.I = CI;
             C.alloc_entries(nnz);
-            if (nch)
+            if (nch && !single_all)
                 hipLaunchKernelGGL((esc_kernel<2 * kCap, false, true, Expander>), dim3(nch), dim3(kBlock), 0, st, n, plan.ubscan.p,
                                    plan.ub_small.p, (const int *)nullptr, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
-            if (plan.nbig)
+            if (plan.nbig && !single_all)
                 hipLaunchKernelGGL((esc_kernel<kBigCap, true, true, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
                                    plan.ub.p, plan.biglist.p, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
             hipLaunchKernelGGL(esc_compact_kernel, dim3(grid1((long long)n * 8)), dim3(kBlock), 0, st, n, (const int *)ubw.p, (const int *)UBI.p,
