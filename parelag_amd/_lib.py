@@ -203,6 +203,12 @@ def load(path: str = LIB_PATH):
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: run `python -m parelag_amd.build` (hipcc, gfx950). "
                           "There is no CPU fallback for the product path.")
+    # Kernel arguments in device memory: the HIP runtime of this image places the kernarg segment in host memory on some boxes of the
+    # pool and in device memory on others; with host-resident kernargs every wave's first scalar loads cross PCIe, which costs a
+    # launch-bound cycle ~2 us per kernel (the 3-launch cube456 x3 cycle: 21.6 us against 15.8 us, tools/headline_probe.py run with
+    # HIP_FORCE_DEV_KERNARG=0 / 1 on such a box).  The runtime reads the variable when it is first loaded, so it is only a default
+    # for processes that have not loaded HIP yet; an application that sets it (either way) keeps its choice.
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI and the header drift apart
