@@ -238,14 +238,20 @@ def gauss_seidel_leg(args, la, np, dA, dPs, rhs, n_local, A, Ps):
 
 
 def large_workload(args, dist, world, kL, la, meshgen, distributed, np, barrier):
-    """The multi-rank runs' second workload: MultigridTest0Form at a size that fills the GPUs (cube456 x kL): levels with more than 2^17
-    dofs row-partitioned, the rest replicated behind one all-reduce; timed like the headline, checked against the serial oracle."""
+    """The multi-rank runs' second workload: MultigridTest0Form at a size that fills the GPUs (cube456 x kL).  No rank holds the
+    global problem: every rank generates its own sub-domain (parelag_amd/meshgen_sharded.py: the reference's ParMesh + SharingMap
+    shape), levels with more than 2^17 dofs are row-partitioned, the rest replicated behind one all-reduce; timed like the headline.
+    Checked by properties that need no global operator (symmetry of the distributed operator, a PCG + V-cycle solve to a known
+    solution) and, up to x5, against the serial oracle on the gathered shards."""
+    from parelag_amd import meshgen_sharded as msh
+    comm = msh.TorchComm(dist._td, dist.rank, world)
     t0 = time.time()
-    AL, PL, seqL = meshgen.h1_problem(kL)
-    genL = time.time() - t0
-    sizes = [AL.shape[0]] + [P.shape[1] for P in PL]
+    shards = msh.sharded_h1_problem(comm, kL)
+    genL = dist.allreduce_max(time.time() - t0)
+    starts = shards["starts"]
+    sizes = [int(st[-1]) for st in starts]
     R = max(1, sum(1 for v in sizes[:-1] if v > (1 << 17)))
-    HL, nL, shapesL, setupL = distributed.build_hierarchy(dist, AL, PL, seqL, args.smoother, replicate_from=R)
+    HL, nL, shapesL, setupL = distributed.build_hierarchy_sharded(dist, comm, shards, args.smoother, replicate_from=R)
     rhsL, solL = la.DeviceVector(nL, 2.0), la.DeviceVector(nL, 1.0)
     for _ in range(max(3, args.warmup // 5)):
         HL.Mult(rhsL, solL)
@@ -257,24 +263,55 @@ def large_workload(args, dist, world, kL, la, meshgen, distributed, np, barrier)
     barrier()
     tL = dist.allreduce_max(time.perf_counter() - t0)
     vbL = vcycle_bytes(shapesL)
-    large = {"workload": f"MultigridTest0Form cube456 x{kL} uniform refines, {len(PL) + 1} levels, {args.smoother}: levels 0..{R - 1} row-partitioned over "
+    large = {"workload": f"MultigridTest0Form cube456 x{kL} uniform refines, {len(sizes)} levels, {args.smoother}: levels 0..{R - 1} row-partitioned over "
                          f"{world} rank(s), levels {R}.. replicated behind one all-reduce",
-             "levels": [{"n": s_[0], "nnz": s_[1]} for s_ in shapesL], "steps": nstep, "ms_per_step": round(tL / nstep * 1e3, 4),
+             "generator": "sharded: every rank refines its own sub-domain of the 456 base tets, shared vertices matched across ranks, rows of shared "
+                          "vertices assembled on their owners; no rank holds a global operator",
+             "levels": [{"n": s_[0], "nnz": s_[1]} for s_ in shapesL], "rows_per_rank_min_max": [int(np.diff(starts[0]).min()), int(np.diff(starts[0]).max())],
+             "steps": nstep, "ms_per_step": round(tL / nstep * 1e3, 4),
              "vcycles_per_s": round(nstep / tL, 2), "vcycle_algorithmic_bytes": vbL,
              "aggregate_GBs": round(vbL / (tL / nstep) / 1e9, 1), "frac_of_aggregate_hbm_peak": round(vbL / (tL / nstep) / 1e9 / (HBM_PEAK_GBS * world), 4),
              "setup_s": round(setupL, 2), "generate_s": round(genL, 1)}
-    if not args.no_cpu_baseline:
-        from oracle import oracle as orc
-        from tests.helpers import oracle_h1_hierarchy
-        t0 = time.time()
-        hL = oracle_h1_hierarchy(AL, PL, smoother=la.HYPRE_SMOOTHER_TYPES[args.smoother])
-        xsL = np.empty(AL.shape[0])
-        orc.CHierarchy(hL["As"], hL["Ps"], hL["sms"], hL["chol"]).apply(np.full(AL.shape[0], 2.0), xsL)
-        infoL = HL._dist_info["levels"][0]
-        lo, hi = int(infoL["starts"][dist.rank]), int(infoL["starts"][dist.rank + 1])
-        errL = float(np.max(np.abs(solL.to_numpy() - xsL[infoL["order"]][lo:hi])) / np.max(np.abs(xsL)))
+    # properties that need no global operator: (u, A v) = (v, A u) on the distributed operator, and PCG + V-cycle to a known solution
+    rng = np.random.default_rng(100 + dist.rank)
+    A0 = HL.GetOperator(0)
+    u, v = rng.standard_normal(nL), rng.standard_normal(nL)
+    Au, Av = np.zeros(nL), np.zeros(nL)
+    A0.Mult(u, Au); A0.Mult(v, Av)
+    uAv, vAu, scale = dist.allreduce_sum(float(u @ Av)), dist.allreduce_sum(float(v @ Au)), dist.allreduce_sum(float(np.abs(u) @ np.abs(Av)))
+    large["symmetry_rel_defect"] = abs(uAv - vAu) / scale
+    xstar = rng.uniform(-1, 1, nL)
+    bL = np.zeros(nL)
+    A0.Mult(xstar, bL)
+    K = la.KrylovSolver(A0, HL, {"Solver name": "PCG", "Relative tolerance": 1e-8, "Maximum iterations": 100, "Check every": 4})
+    bdev, xdev = la.DeviceVector.from_numpy(bL), la.DeviceVector(nL, 0.0)
+    barrier()
+    t0 = time.perf_counter()
+    K.Mult(bdev, xdev)
+    la.synchronize()
+    tS = dist.allreduce_max(time.perf_counter() - t0)
+    xs = xdev.to_numpy()
+    err2, ref2 = dist.allreduce_sum(float((xs - xstar) @ (xs - xstar))), dist.allreduce_sum(float(xstar @ xstar))
+    large["solve"] = {"solver": "PCG + the V-cycle timed above, rhs = A x* for a random x*", "converged": bool(K.GetConverged()),
+                      "iterations": int(K.GetNumIterations()), "ms": round(tS * 1e3, 2), "rel_error_vs_known_solution": float((err2 / ref2) ** 0.5)}
+    del K, bdev, xdev
+    if not args.no_cpu_baseline and sizes[0] <= args.parity_max_dofs * 2:
+        # serial oracle on the gathered shards (block numbering: the l1-Jacobi cycle does not care how the dofs are numbered)
+        import scipy.sparse as sp
+        got = comm.gather0((shards["A_rows"], shards["P_rows"], solL.to_numpy()))
+        errL = 0.0
+        if dist.rank == 0:
+            from oracle import oracle as orc
+            from tests.helpers import oracle_h1_hierarchy
+            AL = sp.vstack([g[0] for g in got]).tocsr()
+            PL = [sp.vstack([g[1][l] for g in got]).tocsr() for l in range(len(sizes) - 1)]
+            hL = oracle_h1_hierarchy(AL, PL, smoother=la.HYPRE_SMOOTHER_TYPES[args.smoother])
+            xsL = np.empty(AL.shape[0])
+            orc.CHierarchy(hL["As"], hL["Ps"], hL["sms"], hL["chol"]).apply(np.full(AL.shape[0], 2.0), xsL)
+            errL = float(np.max(np.abs(np.concatenate([g[2] for g in got]) - xsL)) / np.max(np.abs(xsL)))
+            del hL, AL, PL
+        del got
         large["parity_rel_err_vs_oracle"] = dist.allreduce_max(errL)
-        del hL
     note("large workload (x%d): %.3f ms per V-cycle" % (kL, tL / nstep * 1e3))
     del HL, rhsL, solL
     return large
@@ -400,8 +437,8 @@ def main():
                     "oracle's blocked cycle is run beside the distributed one")
     ap.add_argument("--launch-dry-run", action="store_true", help="start the ranks, report RANK / WORLD_SIZE of every child over a gloo "
                     "group and exit: exercises the launcher without a GPU")
-    ap.add_argument("--large-refines", type=int, default=5, help="--gpus N > 1: refinements of the second, GPU-filling 0-form workload "
-                    "reported under \"large\" (0 disables it)")
+    ap.add_argument("--large-refines", type=int, default=-1, help="--gpus N > 1: refinements of the second, GPU-filling 0-form workload "
+                    "reported under \"large\" (0 disables it; default: 6 from 8 ranks on -- 20 M dofs, 2.5 M per GPU -- else 5)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -1080,6 +1117,8 @@ def main():
                        "control_plane": "torch.distributed gloo", "library_comm_rank": cr.value, "library_comm_nranks": cn.value,
                        "ranks_agree": bool(dist.allreduce_max(float(cn.value)) == float(world) and dist.allreduce_sum(float(cr.value)) == world * (world - 1) / 2)}
     large = None
+    if args.large_refines < 0:
+        args.large_refines = 6 if world >= 8 else 5
     if (dist is not None and args.form == 0 and not darcy and not (args.amge or args.hex) and args.large_refines > args.refines
             and (world > 1 or args.force_large)):
         # the headline size (42 k dofs at x3) is a latency problem across ranks by construction; this is the same example at a

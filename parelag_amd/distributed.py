@@ -98,27 +98,17 @@ def init(rank: int, world: int) -> Dist:
     return Dist(rank, world, td)
 
 
-def build_hierarchy(dist: Dist, A, Ps, seq, smoother="L1 Jacobi", params=None, replicate_from=1):
-    """Distributed 0-form hierarchy.  Levels < ``replicate_from`` are row-partitioned over the ranks (halo exchange per
-    operator apply, hypre's ParCSR model); the levels from ``replicate_from`` down are far too small to be worth a halo
-    exchange and live, complete, on every GPU as an ordinary single-GPU hierarchy (fused levels, dense tail, hipGraph).
-    The restriction into the first replicated level produces per-rank partial sums (its P is stored with global coarse
-    columns) that one RCCL all-reduce completes, and the prolongation back needs no exchange at all -- with
-    ``replicate_from = 1`` a V-cycle costs three RCCL rounds.  Returns (H, n_local, global level shapes, setup s)."""
-    import scipy.sparse as sp
-    t0 = time.time()
-    nl = len(Ps) + 1
-    R = max(1, min(int(replicate_from), nl - 1))
-    # host side: numbering and per-rank pieces of the fine operator and of the interpolators of the distributed head only;
-    # every Galerkin product is formed on the device
-    d = partition.distributed_h1_hierarchy(A, Ps, seq, dist.world, galerkin=False, split_levels=R)
+def _build_from_pieces(dist, A_part, P_parts, Ploc, P_tail, level_rows, P_shapes, smoother, params, R, nl):
+    """The device side of ``build_hierarchy``: this rank's ParCSR pieces of the fine operator and of the interpolators of the
+    distributed head (levels 0..R-1), its rows of the interpolator into the first replicated level (global coarse columns) and the
+    complete interpolators below.  Every Galerkin product is formed on the device."""
     t = la.HYPRE_SMOOTHER_TYPES[smoother] if isinstance(smoother, str) else int(smoother)
     lib = _lib.init()
     # distributed head: levels 0..R-1; their Galerkin operators are formed on the device across the ranks
     # (elag_hip_parcsr_rap with distributed operands + FixZeroRows), inputs are the fine operator and the true P's
     H = la.Hierarchy(R + 1)
-    ops = [la.ParallelCSRMatrix.from_parts(d["levels"][0]["A_parts"][dist.rank])]
-    Pd = [la.ParallelCSRMatrix.from_parts(d["levels"][l]["P_parts"][dist.rank]) for l in range(1, R + 1)]
+    ops = [la.ParallelCSRMatrix.from_parts(A_part)]
+    Pd = [la.ParallelCSRMatrix.from_parts(p) for p in P_parts]
     for l in range(1, R + 1):
         Ac = la.RAP(ops[-1], Pd[l - 1])
         Ac.fix_zero_rows()
@@ -133,7 +123,7 @@ def build_hierarchy(dist: Dist, A, Ps, seq, smoother="L1 Jacobi", params=None, r
         H._keep_smoothers.append(S)
     # replicated tail: level R gathered onto every GPU, the levels below built there redundantly (device RAP)
     subA, _starts = ops[R].Replicate()
-    subP = [la.ParallelCSRMatrix.from_scipy(P) for P in d["P_global"][R:]]
+    subP = [la.ParallelCSRMatrix.from_scipy(P) for P in P_tail]
     Hsub = la.buildHierarchyFromDeRhamSequence(subA, subP, smoother, params or {}, reorder=0)
     hc = C.c_void_p()
     _lib.check(lib.elag_hip_coarse_create_from_hierarchy(C.byref(hc), Hsub.h, 1))
@@ -141,8 +131,6 @@ def build_hierarchy(dist: Dist, A, Ps, seq, smoother="L1 Jacobi", params=None, r
     cs._lib, cs.A, cs.h, cs.iterative_mode = lib, subA, hc, False
     H.SetOperator(R, subA)
     # P from the first replicated level: this rank's rows, GLOBAL coarse columns, no comm package
-    s = d["levels"][R - 1]["starts"]
-    Ploc = sp.csr_matrix(d["P_global"][R - 1])[int(s[dist.rank]):int(s[dist.rank + 1])].tocsr()
     H.SetProlongator(R, la.ParallelCSRMatrix.from_scipy(Ploc))
     H.SetCoarseSolver(cs)
     H.Finalize(use_graph=False)
@@ -151,17 +139,61 @@ def build_hierarchy(dist: Dist, A, Ps, seq, smoother="L1 Jacobi", params=None, r
     # global level shapes: distributed levels from the summed local entry counts, replicated levels from the complete copies
     shapes = []
     for l in range(nl):
-        Pg = d["P_global"][l] if l < nl - 1 else None
+        pc, pn = P_shapes[l] if l < nl - 1 else (0, 0)
         if l < R:
             v = C.c_double(float(ops[l].nnz))
             _lib.check(lib.elag_hip_comm_allreduce(C.byref(v), 0))          # the library's communicator (RCCL / in-process), sum
-            rows, nnz = int(d["levels"][l]["starts"][-1]), int(round(v.value))
+            rows, nnz = int(level_rows[l]), int(round(v.value))
         else:
             op = Hsub.GetOperator(l - R)
             rows, nnz = op.Height(), op.nnz
-        shapes.append((rows, nnz, Pg.shape[1] if Pg is not None else 0, Pg.nnz if Pg is not None else 0))
-    n_local = ops[0].Height()
+        shapes.append((rows, nnz, int(pc), int(pn)))
+    return H, ops[0].Height(), shapes
+
+
+def build_hierarchy(dist: Dist, A, Ps, seq, smoother="L1 Jacobi", params=None, replicate_from=1):
+    """Distributed 0-form hierarchy.  Levels < ``replicate_from`` are row-partitioned over the ranks (halo exchange per
+    operator apply, hypre's ParCSR model); the levels from ``replicate_from`` down are far too small to be worth a halo
+    exchange and live, complete, on every GPU as an ordinary single-GPU hierarchy (fused levels, dense tail, hipGraph).
+    The restriction into the first replicated level produces per-rank partial sums (its P is stored with global coarse
+    columns) that one RCCL all-reduce completes, and the prolongation back needs no exchange at all -- with
+    ``replicate_from = 1`` a V-cycle costs three RCCL rounds.  Returns (H, n_local, global level shapes, setup s)."""
+    import scipy.sparse as sp
+    t0 = time.time()
+    nl = len(Ps) + 1
+    R = max(1, min(int(replicate_from), nl - 1))
+    # host side: numbering and per-rank pieces of the fine operator and of the interpolators of the distributed head only;
+    # every Galerkin product is formed on the device
+    d = partition.distributed_h1_hierarchy(A, Ps, seq, dist.world, galerkin=False, split_levels=R)
+    s = d["levels"][R - 1]["starts"]
+    Ploc = sp.csr_matrix(d["P_global"][R - 1])[int(s[dist.rank]):int(s[dist.rank + 1])].tocsr()
+    H, n_local, shapes = _build_from_pieces(
+        dist, d["levels"][0]["A_parts"][dist.rank], [d["levels"][l]["P_parts"][dist.rank] for l in range(1, R + 1)], Ploc, d["P_global"][R:],
+        [int(d["levels"][l]["starts"][-1]) for l in range(R)], [(P.shape[1], P.nnz) for P in d["P_global"]], smoother, params, R, nl)
     H._dist_info = d
+    return H, n_local, shapes, time.time() - t0
+
+
+def build_hierarchy_sharded(dist: Dist, comm, shards, smoother="L1 Jacobi", params=None, replicate_from=1):
+    """``build_hierarchy`` from the shards of ``meshgen_sharded.sharded_h1_problem``: no rank ever holds a global operator of a
+    distributed level -- the ParCSR pieces and their comm packages come from the rank's own rows and one all-gather of the ghost
+    lists per operator (the role of ``hypre_MatvecCommPkgCreate``, call sites in SURVEY 2.3); only the interpolators of the
+    replicated tail (levels with at most ~2^17 dofs) are gathered.  ``comm``: the control-plane communicator the shards were made
+    with.  Returns (H, n_local, global level shapes, setup s)."""
+    import scipy.sparse as sp
+    from . import meshgen_sharded as msh
+    t0 = time.time()
+    starts, P_rows = shards["starts"], shards["P_rows"]
+    nl = len(P_rows) + 1
+    R = max(1, min(int(replicate_from), nl - 1))
+    A_part = msh.parcsr_piece(comm, shards["A_rows"], starts[0], starts[0])
+    P_parts = [msh.parcsr_piece(comm, P_rows[l - 1], starts[l - 1], starts[l]) for l in range(1, R + 1)]
+    tail = msh.agree(comm, lambda: ([P_rows[l] for l in range(R, nl - 1)], [P.nnz for P in P_rows]))
+    P_tail = [sp.vstack([t[0][i] for t in tail]).tocsr() for i in range(nl - 1 - R)]
+    P_shapes = [(int(starts[l + 1][-1]), sum(t[1][l] for t in tail)) for l in range(nl - 1)]
+    H, n_local, shapes = _build_from_pieces(dist, A_part, P_parts, P_rows[R - 1], P_tail, [int(starts[l][-1]) for l in range(R)], P_shapes,
+                                            smoother, params, R, nl)
+    H._dist_info = dict(levels=[dict(starts=st) for st in starts])
     return H, n_local, shapes, time.time() - t0
 
 

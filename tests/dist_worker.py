@@ -107,6 +107,28 @@ def main():
     M0 = levels[0]["A"]
     mx, mn = orc.max_eig_estimate_cg(M0, 1, 10)
     assert 0.5 < mx < 2.5 and mn > 0
+
+    # --- the sharded generator over gloo: every rank makes only its rows, and they are the serial problem's row blocks with the
+    #     comm package split_rows computes from the global matrix; the oracle's ParCSR product on the shard is the global product
+    from parelag_amd import meshgen_sharded as msh
+    comm = msh.TorchComm(td, rank, world)
+    sh = msh.sharded_h1_problem(comm, 2)
+    for l in range(nl):
+        assert np.array_equal(sh["starts"][l], d["levels"][l]["starts"]), f"sharded starts level {l}"
+    mine = partition.canon(sh["A_rows"])
+    want = partition.canon(d["A_global"][0][s0[rank]:s0[rank + 1]])
+    assert np.array_equal(mine.indptr, want.indptr) and np.array_equal(mine.indices, want.indices)
+    assert np.max(np.abs(mine.data - want.data)) <= 1e-13 * np.max(np.abs(want.data))
+    for l in range(nl - 1):
+        sf = d["levels"][l]["starts"]
+        got, ref_p = partition.canon(sh["P_rows"][l]), partition.canon(d["P_global"][l][sf[rank]:sf[rank + 1]])
+        assert np.array_equal(got.indptr, ref_p.indptr) and np.array_equal(got.indices, ref_p.indices) and np.array_equal(got.data, ref_p.data)
+    piece = msh.parcsr_piece(comm, sh["A_rows"], sh["starts"][0], sh["starts"][0])
+    Msh = orc.oparcsr_from_part(piece, ex)
+    xg = rng.standard_normal(A.shape[0])
+    ysh = np.zeros(Msh.shape[0])
+    Msh.matvec(1.0, xg[s0[rank]:s0[rank + 1]], 0.0, ysh)
+    assert np.allclose(ysh, (d["A_global"][0] @ xg)[s0[rank]:s0[rank + 1]], rtol=1e-12, atol=1e-13), "sharded operator product"
     td.barrier()
     if rank == 0:
         print("DIST_WORKER_OK", world)
