@@ -507,12 +507,11 @@ struct elag_hip_hierarchy_s {
 
     void plan_fused()
     {
-        static int disabled = -1;
-        static long long max_nnz = 0;
-        if (disabled < 0) {
-            const char *e = getenv("ELAG_HIP_NO_LEVEL_FUSION"); disabled = (e && atoi(e)) ? 1 : 0;
-            const char *m = getenv("ELAG_HIP_FUSE_NNZ"); max_nnz = m ? atoll(m) : (1ll << 20);
-        }
+        // (read at every Finalize: tests switch them)
+        const char *e_dis = getenv("ELAG_HIP_NO_LEVEL_FUSION"), *e_nnz = getenv("ELAG_HIP_FUSE_NNZ"), *e_big = getenv("ELAG_HIP_BIG_LEVEL_S");
+        const int disabled = (e_dis && atoi(e_dis)) ? 1 : 0;
+        const long long max_nnz = e_nnz ? atoll(e_nnz) : (1ll << 20);
+        const int big_s = e_big ? atoi(e_big) : 1;
         const int nl = (int)lev.size();
         for (int l = 0; l + 1 < nl; l++) {
             Level &F = lev[(size_t)l];
@@ -664,7 +663,29 @@ struct elag_hip_hierarchy_s {
                 F.dist_w = dinv;
                 continue;
             }
-            if (F.A->offd.ncols > 0 || C.P->offd.ncols > 0 || F.A->diag.nnz >= max_nnz) continue;
+            if (F.A->offd.ncols > 0 || C.P->offd.ncols > 0) continue;
+            if (F.A->diag.nnz >= max_nnz) {
+                // ---- bandwidth-bound l1-Jacobi level: only the way up changes.  With r = f - A W f kept from the way down,
+                //   x + P e + W (f - A (x + P e)) = x + W (r - S e),  S = A P - W^-1 P:
+                // one pass over S instead of a pass over P (read and rewrite x) and a second pass over A -- whenever S is the smaller
+                // object (nested P1: 9 entries per row against 15 + 2); the way down stays the reference's sequence, G would not pay there
+                // (it replaces one pass over A by a pass over an operator with S's pattern transposed, and r would be gone)
+                if (!big_s) continue;
+                try {
+                    std::unique_ptr<DevCSR> AP(new DevCSR());
+                    k::csr_spgemm(F.A->diag, C.P->diag, *AP);
+                    if (AP->nnz > F.A->diag.nnz + C.P->diag.nnz) continue;
+                    k::CsrCombine sop;
+                    sop.B = &C.P->diag; sop.b_scale = -1.0; sop.b_row = dinv; sop.b_row_divide = 1;
+                    if (!k::csr_combine_inplace(*AP, sop)) continue;
+                    AP->choose_spmv_shape();
+                    F.S.reset(AP.release());
+                    F.fused_dinv = dinv;
+                } catch (const Error &) {
+                    F.S.reset(); F.fused_dinv = nullptr;
+                }
+                continue;
+            }
             const int n = F.A->nrows();
             C.P->ensure_transpose();
             // G = R - (R A) W  and  S = A P - W^-1 P.  With a full diagonal in A the pattern of R A contains R's and the pattern of A P contains
@@ -837,6 +858,13 @@ struct elag_hip_hierarchy_s {
         par_spmvT(*C.P, 1.0, F.tmp_resid, 0.0, C.resid);
         // coarse-grid correction (:212-227)
         iterate(l + 1, C.resid, C.sol, C.alt);
+        if (F.S && !F.G) {
+            // bandwidth-bound l1-Jacobi level (plan_fused): prolongation and post-sweep in one pass over S, x' = x + W (r - S e)
+            k::SpmvArgs u;
+            u.x = C.sol; u.alpha = -1.0; u.f = F.tmp_resid; u.gamma = 1.0; u.s = F.fused_dinv; u.yin = cur; u.beta = 1.0; u.out = sol;
+            k::spmv_fused(*F.S, nullptr, u);
+            return;
+        }
         // SOL += P * coarse_sol (:231-238), fused
         {
             k::SpmvArgs a;
@@ -901,6 +929,13 @@ struct elag_hip_hierarchy_s {
         }
         par_spmvT(*C.P, 1.0, F.tmp_resid, 0.0, C.resid);
         iterate(1, C.resid, C.sol, C.alt);
+        if (F.S) {
+            k::SpmvArgs a;  // x' = x + W (r - S e) (plan_fused: prolongation and post-sweep in one pass over S), written to the caller's numbering
+            a.x = C.sol; a.alpha = -1.0; a.f = F.tmp_resid; a.gamma = 1.0; a.s = F.fused_dinv; a.yin = cur; a.beta = 1.0;
+            a.out = sol_nat; a.out_perm = d_order0; a.out_add = add ? sol_nat : nullptr;
+            k::spmv_fused(*F.S, nullptr, a);
+            return true;
+        }
         {
             k::SpmvArgs a;  // x += P e
             a.x = C.sol; a.alpha = 1.0; a.yin = cur; a.beta = 1.0; a.out = cur;

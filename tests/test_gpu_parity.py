@@ -944,6 +944,45 @@ def test_flattened_cycle_is_the_level_by_level_cycle(la, h1_k3, smoother, capfd)
         assert np.max(np.abs(outs["flat"] - xr)) <= 1e-12 * np.max(np.abs(xr))
 
 
+@pytest.mark.parametrize("reorder", [0, -1])
+def test_bandwidth_bound_level_goes_up_through_S(la, h1_k2, reorder):
+    """A level too large to be launch-bound keeps the reference's way down and goes up in one pass over S = A P - W^-1 P:
+    x + P e + W (f - A (x + P e)) = x + W (r - S e) with r kept from the way down (hierarchy.hip, plan_fused).  ELAG_HIP_FUSE_NNZ=1 makes
+    every level of a small problem such a level; ELAG_HIP_BIG_LEVEL_S=0 is the separate prolongation + post-sweep.  Same map, and the
+    oracle's cycle, in preconditioner and in solver mode."""
+    import os
+    from oracle import oracle as orc
+    from tests.helpers import oracle_h1_hierarchy
+    A, Ps, _ = h1_k2
+    dA = la.ParallelCSRMatrix.from_scipy(A); dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    rng = np.random.default_rng(53)
+    b, x0 = rng.uniform(-1, 1, A.shape[0]), rng.uniform(-1, 1, A.shape[0])
+    outs = {}
+    for name, env in (("S", {"ELAG_HIP_FUSE_NNZ": "1"}), ("separate", {"ELAG_HIP_FUSE_NNZ": "1", "ELAG_HIP_BIG_LEVEL_S": "0"})):
+        os.environ.update(env)
+        try:
+            H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi", reorder=reorder)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        x = np.zeros(A.shape[0])
+        H.Mult(b, x)
+        H.iterative_mode = True
+        xs = x0.copy()
+        H.Mult(b, xs)
+        outs[name] = (x, xs)
+    h = oracle_h1_hierarchy(A, Ps)
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"])
+    xr = np.empty_like(b)
+    Hc.apply(b, xr)
+    er = np.empty_like(b)
+    Hc.apply(b - A @ x0, er)
+    for k in (0, 1):
+        assert np.max(np.abs(outs["S"][k] - outs["separate"][k])) <= 1e-13 * np.max(np.abs(outs["separate"][k]))
+    assert np.max(np.abs(outs["S"][0] - xr)) <= 1e-12 * np.max(np.abs(xr))
+    assert np.max(np.abs(outs["S"][1] - (x0 + er))) <= 1e-12 * np.max(np.abs(x0 + er))
+
+
 def test_graph_replay_and_plain_launches_are_the_same_cycle(la, h1_k2):
     """Finalize issues a cycle of up to 32 kernels as plain launches and a longer one as a replayed hipGraph (elag_hip_hierarchy_launch_mode);
     ELAG_HIP_GRAPH_MODE forces either, or asks for the round-2 timing of both.  The kernels are the same, so is every bit of the result; the
