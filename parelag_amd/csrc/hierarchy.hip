@@ -26,6 +26,9 @@ struct Level {
     // which is algebraically the reference's  x = W f; r = f - A x; r_c = P^T r; x += P e; x += W (f - A x).
     std::shared_ptr<DevCSR> G, S;
     const double *fused_dinv = nullptr;
+    // A P of this level when elag_hip_hierarchy_build formed it on the way to the Galerkin product and the level is a candidate for
+    // the bandwidth-bound form of plan_fused (S is made from it there, in place, and this pointer is gone afterwards)
+    std::shared_ptr<DevCSR> AP_kept;
     // the same l1-Jacobi level when its operators live on several ranks (see plan_fused): S = A P - W^-1 P as a distributed operator.  With
     // r = f - A W f from the way down, the way up is  x = W (f + r - S e):  no product with A, no halo exchange for x -- a level costs
     // one exchange for W f, the reverse exchange of P^T r and one for e (none where the coarse level is replicated) instead of four
@@ -164,9 +167,12 @@ struct elag_hip_hierarchy_s {
         phase("fused_level_operators", [&] { plan_fused(); });
         // SpMV forms that are built on first use must exist before the cycle is captured into a graph
         phase("spmv_forms", [&] {
-            for (auto &L : lev) {
+            for (size_t l = 0; l < lev.size(); l++) {
+                Level &L = lev[l];
                 k::prepare_spmv(L.A->diag);
-                if (L.P) { k::prepare_spmv(L.P->diag); if (L.P->diagT) k::prepare_spmv(*L.P->diagT); }
+                // (a bandwidth-bound level that goes up through S never multiplies by P itself)
+                const bool p_unused = l > 0 && lev[l - 1].S && !lev[l - 1].G && !lev[l - 1].Gaux;
+                if (L.P) { if (!p_unused) k::prepare_spmv(L.P->diag); if (L.P->diagT) k::prepare_spmv(*L.P->diagT); }
                 if (L.G) k::prepare_spmv(*L.G);
                 if (L.S) k::prepare_spmv(*L.S);
                 if (L.U1) k::prepare_spmv(*L.U1);
@@ -518,6 +524,8 @@ struct elag_hip_hierarchy_s {
             Level &C = lev[(size_t)l + 1];
             F.G.reset(); F.S.reset(); F.fused_dinv = nullptr;
             F.Sd.reset(); F.dist_w = nullptr;
+            std::shared_ptr<DevCSR> kept;                 // (used by the bandwidth-bound l1-Jacobi branch or dropped here)
+            kept.swap(F.AP_kept);
             F.Gaux.reset(); F.RA.reset(); F.PTneg.reset(); F.hipt_w = nullptr;
             F.U1.reset(); F.U2.reset(); F.Kh.reset(); F.Mh.reset();
             // ---- Chebyshev of order <= 2 on a launch-bound level below the finest ----
@@ -672,14 +680,17 @@ struct elag_hip_hierarchy_s {
                 // (it replaces one pass over A by a pass over an operator with S's pattern transposed, and r would be gone)
                 if (!big_s) continue;
                 try {
-                    std::unique_ptr<DevCSR> AP(new DevCSR());
-                    k::csr_spgemm(F.A->diag, C.P->diag, *AP);
+                    std::shared_ptr<DevCSR> AP = kept;
+                    if (!AP || AP->nrows != F.A->nrows() || AP->ncols != C.P->ncols()) {
+                        AP.reset(new DevCSR());
+                        k::csr_spgemm(F.A->diag, C.P->diag, *AP, false);
+                    }
                     if (AP->nnz > F.A->diag.nnz + C.P->diag.nnz) continue;
                     k::CsrCombine sop;
                     sop.B = &C.P->diag; sop.b_scale = -1.0; sop.b_row = dinv; sop.b_row_divide = 1;
                     if (!k::csr_combine_inplace(*AP, sop)) continue;
                     AP->choose_spmv_shape();
-                    F.S.reset(AP.release());
+                    F.S = AP;
                     F.fused_dinv = dinv;
                 } catch (const Error &) {
                     F.S.reset(); F.fused_dinv = nullptr;
@@ -1221,8 +1232,22 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
             // "Number of rows in P does not match A" check of Hierarchy.cpp:344-352
             ELAG_REQUIRE(Pl->nrows() == Af->nrows(), "buildHierarchy: P[%d] has %d rows but A has %d", l, Pl->nrows(), Af->nrows());
             elag_hip_parcsr_t Ac = nullptr;
-            int rc = elag_hip_parcsr_rap(Pl, Af, Pl, &Ac);
-            if (rc) fail(rc, "%s", elag_hip_last_error());
+            const bool diag_relax = opt.relax_type == ELAG_HIP_SMOOTHER_L1_JACOBI || opt.relax_type == ELAG_HIP_SMOOTHER_JACOBI ||
+                                    opt.relax_type == ELAG_HIP_SMOOTHER_LUMPED_JACOBI || opt.relax_type == ELAG_HIP_SMOOTHER_HYPRE_JACOBI;
+            if (!D && diag_relax && !is_distributed(*Af) && !is_distributed(*Pl) && Af->diag.nnz >= (int64_t(1) << 20)) {
+                // the product of elag_hip_parcsr_rap, with A P kept for plan_fused (a bandwidth-bound level goes up through S = A P - W^-1 P)
+                ELAG_REQUIRE(Af->ncols() == Pl->nrows(), "rap: shapes do not chain");
+                std::shared_ptr<DevCSR> AP(new DevCSR());
+                DevCSR prod;
+                k::csr_spgemm(Af->diag, Pl->diag, *AP, false);
+                Pl->ensure_transpose();
+                k::csr_spgemm(*Pl->diagT, *AP, prod);
+                Ac = parcsr_from_diag(std::move(prod), Pl->first_col, Pl->first_col, Pl->global_cols, Pl->global_cols);
+                H->lev[(size_t)l].AP_kept = AP;
+            } else {
+                int rc = elag_hip_parcsr_rap(Pl, Af, Pl, &Ac);
+                if (rc) fail(rc, "%s", elag_hip_last_error());
+            }
             H->owned_mats.push_back(Ac);
             if (opt.fix_zero_rows) k::fix_zero_rows(Ac->diag, &Ac->offd);
             H->lev[(size_t)l + 1].A = Ac;
@@ -1271,6 +1296,11 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
                     DevCSR Pp;
                     k::csr_permute(Pl->diag, d_order[(size_t)l - 1], d_rank[(size_t)l], Pl->ncols(), Pp);
                     newP[(size_t)l] = parcsr_from_diag(std::move(Pp), 0, 0, Pl->global_rows, Pl->global_cols);
+                    if (H->lev[(size_t)l - 1].AP_kept) {
+                        std::shared_ptr<DevCSR> APp(new DevCSR());
+                        k::csr_permute(*H->lev[(size_t)l - 1].AP_kept, d_order[(size_t)l - 1], d_rank[(size_t)l], Pl->ncols(), *APp, false);   // (only ever a SpMV operand)
+                        H->lev[(size_t)l - 1].AP_kept = APp;
+                    }
                 }
             }
             ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));

@@ -171,7 +171,7 @@ bool csr_combine_inplace(DevCSR &C, const CsrCombine &op);   // out = scale * di
 void child_order(const DevCSR &P, const int *d_rank_c, int *d_order_out);
 void inverse_permutation(int n, const int *d_order, int *d_rank);     // rank[order[r]] = r
 // out = A(order_rows, :) with columns renumbered by rank_cols (old -> new); rows come back column-sorted
-void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_cols, int ncols_out, DevCSR &out);
+void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_cols, int ncols_out, DevCSR &out, bool sort_rows = true);
 
 // ---- dense coarse solve ------------------------------------------------------------------------
 void dense_gemv(int nrows, int ncols, const double *M, const double *x, double *y);  // y = M x, M row-major

@@ -1149,7 +1149,7 @@ __global__ void perm_fill_kernel(int n, const int *__restrict__ I, const int *__
 }
 }  // namespace
 
-void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_cols, int ncols_out, DevCSR &out)
+void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_cols, int ncols_out, DevCSR &out, bool sort_rows)
 {
     hipStream_t st = ctx().stream;
     const int n = A.nrows;
@@ -1166,7 +1166,7 @@ void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_col
         hipLaunchKernelGGL(perm_fill_kernel, dim3(grid1((long long)n * 8)), dim3(kBlock), 0, st, n, (const int *)A.I, (const int *)A.J,
                            (const double *)A.a, d_order_rows, d_rank_cols, (const int *)out.I, out.J, out.a);
     ELAG_LAUNCH_CHECK();
-    if (A.nnz) csr_sort_rows(out);
+    if (A.nnz && sort_rows) csr_sort_rows(out);
     else out.choose_spmv_shape();
 }
 

@@ -439,17 +439,19 @@ __global__ __launch_bounds__(THREADS) void spmv_probe_xc_kernel(
 }
 
 // One workgroup per window: sort the window's columns in LDS (bitonic), mark the first element of every run, scan.
-// fill == 0: ucount[c] = number of distinct columns.  fill == 1: ucols / lidx are written.
+// fill == 0: a SAMPLE -- workgroup b looks at window b * step and writes ucount[2 b] = its number of distinct columns, ucount[2 b + 1] = its
+// entries.  fill == 1: ucols (at uoff[c]) / lidx are written.  fill == 2: the one full pass of xc_build -- ucount[c], lidx and the window's
+// columns at ucols + c * step (a slot per window; compacted once the counts are scanned).
 // CAP: entries per window the builder handles (window + longest row + 8 <= CAP); 4096 for 2048-entry windows, 8192 for 4096
 template <int CAP>
 __global__ __launch_bounds__(kBlock) void xc_build_kernel(const int *__restrict__ block_row, const int *__restrict__ J, int *__restrict__ ucount,
                                                           const int *__restrict__ uoff, int *__restrict__ ucols,
-                                                          unsigned short *__restrict__ lidx, int fill)
+                                                          unsigned short *__restrict__ lidx, int fill, int step)
 {
     __shared__ int keys[CAP];
     __shared__ unsigned short pos[CAP];
     __shared__ int part[kBlock];
-    const int c = blockIdx.x;
+    const int c = fill == 0 ? (int)blockIdx.x * step : (int)blockIdx.x;
     const int kbeg = block_row[2 * c + 1], kend = block_row[2 * c + 3];
     const int len = kend - kbeg;
     int npow = 256;
@@ -478,12 +480,13 @@ __global__ __launch_bounds__(kBlock) void xc_build_kernel(const int *__restrict_
     if (threadIdx.x == 0) {
         int acc = 0;
         for (int t = 0; t < kBlock; t++) { const int v = part[t]; part[t] = acc; acc += v; }
-        if (!fill) ucount[c] = acc;
+        if (fill == 0) { ucount[2 * blockIdx.x] = acc; ucount[2 * blockIdx.x + 1] = len; }
+        if (fill == 2) ucount[c] = acc;
     }
     __syncthreads();
     if (!fill) return;
     int run = part[threadIdx.x];   // distinct columns before this chunk
-    const int u0 = uoff[c];
+    const long long u0 = fill == 2 ? (long long)c * step : (long long)uoff[c];
     for (int i = b0; i < b0 + per; i++) {
         if (i >= len) break;
         if (i == 0 || keys[i] != keys[i - 1]) { ucols[u0 + run] = keys[i]; run++; }
@@ -495,6 +498,15 @@ __global__ __launch_bounds__(kBlock) void xc_build_kernel(const int *__restrict_
         int lo = 0, hi = len;   // first sorted position holding col
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < col) lo = mid + 1; else hi = mid; }
         lidx[kbeg + e] = pos[lo];
+    }
+}
+
+// the windows' column lists out of their slots into one array (uoff = scanned counts)
+__global__ void xc_compact_kernel(int nb, int slot, const int *__restrict__ slots, const int *__restrict__ uoff, int *__restrict__ ucols)
+{
+    for (int c = blockIdx.x; c < nb; c += gridDim.x) {
+        const int u0 = uoff[c], n = uoff[c + 1] - u0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) ucols[u0 + i] = slots[(size_t)c * slot + i];
     }
 }
 
@@ -640,42 +652,65 @@ bool xc_build(const DevCSR &A, int window, bool force, double min_reuse = 2.0)
         hipLaunchKernelGGL(stream_plan_kernel, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, st, A.nrows, (const int *)A.I, nb, window, plan);
         ELAG_LAUNCH_CHECK();
     }
-    auto build = [&](int *ucount, const int *uoff, int *ucols, unsigned short *lidx, int fill) {
+    auto build = [&](int grid, int *ucount, const int *uoff, int *ucols, unsigned short *lidx, int fill, int step) {
         if (cap <= 4096)
-            hipLaunchKernelGGL((xc_build_kernel<4096>), dim3((unsigned)nb), dim3(kBlock), 0, st, (const int *)plan, (const int *)A.J, ucount, uoff, ucols, lidx, fill);
+            hipLaunchKernelGGL((xc_build_kernel<4096>), dim3((unsigned)grid), dim3(kBlock), 0, st, (const int *)plan, (const int *)A.J, ucount, uoff, ucols, lidx, fill, step);
         else
-            hipLaunchKernelGGL((xc_build_kernel<8192>), dim3((unsigned)nb), dim3(kBlock), 0, st, (const int *)plan, (const int *)A.J, ucount, uoff, ucols, lidx, fill);
+            hipLaunchKernelGGL((xc_build_kernel<8192>), dim3((unsigned)grid), dim3(kBlock), 0, st, (const int *)plan, (const int *)A.J, ucount, uoff, ucols, lidx, fill, step);
         ELAG_LAUNCH_CHECK();
     };
-    int *uoff = dev_alloc<int>((size_t)nb + 1);
-    int total = 0;
-    {
-        Temp<int> ucount((size_t)nb);
-        build(ucount.p, nullptr, nullptr, nullptr, 0);
-        exclusive_scan(ucount, uoff, nb);
-        ELAG_HIP_CHECK(hipMemcpyAsync(&total, uoff + nb, sizeof(int), hipMemcpyDeviceToHost, st));
-        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    auto drop_plan = [&] { if (plan != A.block_row) dev_free(plan); };
+    // Does the form pay?  Entries per distinct column of a window, from a sample of up to 512 windows spread evenly over the operator (the
+    // full count was a sorting pass over every window of its own -- and all of it wasted on the operators that fail the rule: the
+    // caller's-numbering operator and P^T at every Finalize)
+    double reuse = 0.0;
+    if (!force) {
+        const int step = std::max(1, nb / 512), ns = (nb + step - 1) / step;
+        Temp<int> sample((size_t)2 * ns);
+        build(ns, sample.p, nullptr, nullptr, nullptr, 0, step);
+        std::vector<int> hs = host_from_dev((const int *)sample.p, (size_t)2 * ns);
+        long long distinct = 0, entries = 0;
+        for (int b = 0; b < ns; b++) { distinct += hs[(size_t)2 * b]; entries += hs[(size_t)2 * b + 1]; }
+        reuse = distinct ? (double)entries / (double)distinct : 0.0;
+        if (reuse < min_reuse) {
+            if (getenv("ELAG_HIP_XC_VERBOSE"))
+                fprintf(stderr, "[elag_hip] x-cache: n=%d nnz=%lld window=%d: reuse %.2f over %d sampled windows, stream kernel kept\n", A.nrows, (long long)A.nnz, window, reuse, ns);
+            drop_plan();
+            return false;
+        }
     }
-    // worthwhile when a column is used by >= 2 entries of its window on average (otherwise the plain gather is as good)
-    const double reuse = total ? (double)A.nnz / total : 0.0;
-    std::vector<int> ho = host_from_dev((const int *)uoff, (size_t)nb + 1);
-    int mx = 0;
-    for (int c = 0; c < nb; c++) mx = std::max(mx, ho[(size_t)c + 1] - ho[(size_t)c]);
+    // one sorting pass: positions (final) and every window's distinct columns into a slot of its own, then scan the counts and compact
+    int *uoff = dev_alloc<int>((size_t)nb + 1);
+    unsigned short *lidx = dev_alloc<unsigned short>((size_t)A.nnz + 8);
+    ELAG_HIP_CHECK(hipMemsetAsync(lidx + A.nnz, 0, 8 * sizeof(unsigned short), st));
+    int total = 0, mx = 0;
+    int *ucols = nullptr;
+    {
+        Temp<int> ucount((size_t)nb), slots((size_t)nb * (size_t)cap);
+        build(nb, ucount.p, nullptr, slots.p, lidx, 2, cap);
+        exclusive_scan(ucount, uoff, nb);
+        std::vector<int> ho = host_from_dev((const int *)uoff, (size_t)nb + 1);
+        total = ho[(size_t)nb];
+        for (int c = 0; c < nb; c++) mx = std::max(mx, ho[(size_t)c + 1] - ho[(size_t)c]);
+        if (mx <= 65535) {
+            ucols = dev_alloc<int>((size_t)std::max(total, 1));
+            hipLaunchKernelGGL(xc_compact_kernel, dim3((unsigned)std::min(nb, 4096)), dim3(kBlock), 0, st, nb, cap, (const int *)slots.p, (const int *)uoff, ucols);
+            ELAG_LAUNCH_CHECK();
+            ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        }
+    }
     if (getenv("ELAG_HIP_XC_VERBOSE"))
-        fprintf(stderr, "[elag_hip] x-cache: n=%d nnz=%lld window=%d windows=%d unique/window avg %.1f max %d reuse %.2f\n", A.nrows, (long long)A.nnz,
-                window, nb, (double)total / nb, mx, reuse);
-    if ((!force && reuse < min_reuse) || mx > 65535) {
-        dev_free(uoff);
-        if (plan != A.block_row) dev_free(plan);
+        fprintf(stderr, "[elag_hip] x-cache: n=%d nnz=%lld window=%d windows=%d unique/window avg %.1f max %d reuse %.2f (sampled %.2f)\n", A.nrows, (long long)A.nnz,
+                window, nb, (double)total / nb, mx, total ? (double)A.nnz / total : 0.0, reuse);
+    if (mx > 65535) {
+        dev_free(uoff); dev_free(lidx);
+        drop_plan();
         return false;
     }
     A.xc_max_unique = (mx + 7) & ~7;
     A.uoff = uoff;
-    A.ucols = dev_alloc<int>((size_t)total);
-    A.lidx = dev_alloc<unsigned short>((size_t)A.nnz + 8);
-    ELAG_HIP_CHECK(hipMemsetAsync(A.lidx + A.nnz, 0, 8 * sizeof(unsigned short), st));
-    build(nullptr, A.uoff, A.ucols, A.lidx, 1);
-    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    A.ucols = ucols;
+    A.lidx = lidx;
     A.xc_block_row = plan; A.xc_nblocks = nb; A.xc_window = window;
     A.xc_state = 1;
     return true;
