@@ -584,6 +584,102 @@ __global__ __launch_bounds__(BLOCK) void esc_hash_kernel(int nrows, Expander ex,
     }
 }
 
+// ---- hash path, unit after unit ---------------------------------------------------------------------------------------
+// The same tables, for rows whose units carry LONG product runs (P^T (A P): a unit is a row of A P, 8 products on average; a sum of two
+// matrices: a unit is a whole row).  The kernel above gives every lane a unit and lets the lanes insert one after the other -- 135
+// serialised inserts for a row of 15 units x 9 products, with 1 / G of the lanes active: 22-25 k cycles per wavefront
+// (profiles/r03_rap_pmc.txt).  Here the UNITS take turns and the lanes of the group insert a unit's products together: the columns of one
+// unit are distinct (a CSR row), so no two lanes meet in a slot during a turn -- keys are claimed with an LDS compare-and-swap, sums go
+// through the LDS f64 atomic so that even a non-canonical row with a repeated column stays a sum -- and a column's products still arrive
+// in storage order, unit by unit: the same bits as the serial insertion.  A wavefront executes its LDS operations in order, so the turns
+// need no barrier.  Every unit's first RP * G products are requested before the first turn (three memory round trips per G units);
+// longer units fetch the rest during their turn.
+template <int G, int S, int RP, int BLOCK, class Expander>
+__global__ __launch_bounds__(BLOCK) void esc_hashu_kernel(int nrows, Expander ex, int *__restrict__ rownnz, const int *__restrict__ CI,
+                                                          int *__restrict__ CJ, double *__restrict__ Ca, const int *__restrict__ rowlist, int nlist)
+{
+    constexpr int NG = BLOCK / G;
+    constexpr int LOG2S = S == 16 ? 4 : S == 32 ? 5 : S == 64 ? 6 : S == 128 ? 7 : 8;
+    static_assert((1 << LOG2S) == S, "table sizes are 16 ... 256");
+    __shared__ int key[NG * S];
+    __shared__ double val[NG * S];
+    const int g = threadIdx.x / G, lane = threadIdx.x & (G - 1);
+    const int gi = blockIdx.x * NG + g;
+    const bool active = gi < nlist;
+    const int row = active ? rowlist[gi] : 0;
+    int *kt = key + g * S;
+    double *vt = val + g * S;
+    for (int s = lane; s < S; s += G) { kt[s] = -1; vt[s] = 0.0; }
+    int ubeg = 0, nu = 0;
+    if (active) ex.units(row, ubeg, nu);
+    const int gshift = (int)(threadIdx.x & 63) & ~(G - 1);          // first lane of this group inside its wavefront
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << gshift;
+    auto insert = [&](int c, double pv) {
+        unsigned h = ((unsigned)c * 2654435761u) >> (32 - LOG2S);
+        while (true) {
+            const int prev = atomicCAS(&kt[h], -1, c);
+            if (prev == -1 || prev == c) break;
+            h = (h + 1) & (S - 1);
+        }
+        atomicAdd(&vt[h], pv);
+    };
+    for (int u0 = 0; __ballot(u0 < nu) & gmask; u0 += G) {
+        int pbeg = 0, plen = 0;
+        double scale = 0.0;
+        const int *J = nullptr;
+        const double *a = nullptr;
+        if (u0 + lane < nu) ex.unit(row, ubeg, u0 + lane, pbeg, plen, scale, J, a);
+        int c[G][RP];
+        double v[G][RP];
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            const int pb = __shfl(pbeg, t, G), pl = __shfl(plen, t, G);
+            const int *Jt = reinterpret_cast<const int *>(__shfl((unsigned long long)J, t, G));
+            const double *at = reinterpret_cast<const double *>(__shfl((unsigned long long)a, t, G));
+#pragma unroll
+            for (int r = 0; r < RP; r++) {
+                const int q = lane + r * G;
+                c[t][r] = -1; v[t][r] = 0.0;
+                if (q < pl) { c[t][r] = Jt[pb + q]; v[t][r] = at[pb + q]; }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            const double sc = __shfl(scale, t, G);
+            const int pl = __shfl(plen, t, G);
+#pragma unroll
+            for (int r = 0; r < RP; r++)
+                if (c[t][r] >= 0) insert(c[t][r], sc * v[t][r]);
+            if (pl > G * RP) {                                      // (uniform over the group)
+                const int pb = __shfl(pbeg, t, G);
+                const int *Jt = reinterpret_cast<const int *>(__shfl((unsigned long long)J, t, G));
+                const double *at = reinterpret_cast<const double *>(__shfl((unsigned long long)a, t, G));
+                for (int q = G * RP + lane; q < pl; q += G) insert(Jt[pb + q], sc * at[pb + q]);
+            }
+        }
+    }
+    // compact the occupied slots to the front of the table, chunk of G slots by chunk (every lane reads its slot before any writes)
+    int E = 0;
+    for (int s0 = 0; s0 < S; s0 += G) {
+        const int kk = kt[s0 + lane];
+        const double vv = vt[s0 + lane];
+        unsigned long long m = __ballot(kk >= 0) & gmask;
+        m >>= gshift;
+        if (kk >= 0) { const int e = E + __popcll(m & ((1ull << lane) - 1ull)); kt[e] = kk; vt[e] = vv; }
+        E += __popcll(m);
+    }
+    if (!active) return;
+    if (lane == 0) rownnz[row] = E;
+    const int base = CI[row];
+    for (int i = lane; i < E; i += G) {
+        const int ci = kt[i];
+        int rank = 0;
+        for (int t = 0; t < E; t++) rank += (kt[t] < ci) ? 1 : 0;
+        CJ[base + rank] = ci;
+        Ca[base + rank] = vt[i];
+    }
+}
+
 // ub of the rows the wave path handles (others 0): its scan gives the rows' offsets in the upper-bound layout
 __global__ void wave_ub_kernel(int nrows, const int *__restrict__ ub, int wave_cap, int *__restrict__ ubw, unsigned long long *__restrict__ total, int all_rows)
 {
@@ -703,6 +799,13 @@ inline int hash_classes()
     return v;
 }
 
+inline bool hashu_enabled()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ELAG_HIP_ESC_HASHU"); v = e ? atoi(e) : 1; }   // 0 = serial insertion only (A/B runs)
+    return v != 0;
+}
+
 inline bool wave_path_enabled()
 {
     static int v = -1;
@@ -724,6 +827,7 @@ struct EscPlan {
     bool all_rows = false;            // ... and the upper-bound layout has room for EVERY row (chunked and one-row-per-workgroup rows too): no symbolic launches at all
     unsigned long long total_ub = 0;
     int hc[kNumClasses] = {0, 0, 0, 0, 0};
+    double unit_run = 0.0;            // products per unit on average (a product: the right factor's entries per row): picks the insertion scheme of the hash path
     explicit EscPlan(int n)
         : nrows(n), ub((size_t)n), ub_small((size_t)n), ubscan((size_t)n + 1), biglist((size_t)n), counters(4 + kNumClasses), ubw((size_t)n),
           UBI((size_t)n + 1), ccount(kNumClasses), lists((size_t)kNumClasses * (size_t)n) {}
@@ -830,11 +934,34 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
                 // (lanes per row, products per lane and pass, table slots, units per lane and pass, workgroup size) per class.  Fewer lanes
                 // per row -- (2,2,32,8), (4,8,128,4) -- were measured slower on cube456 x5 (A P 395 against 298 us): the loads of a row
                 // coalesce worse, and the kernel is bound by memory and LDS latency, not by the serialised inserts' instructions
-                if (hc[0] && (hm & 1)) ELAG_HASH_LAUNCH(0, 4, 2, 16, 2, 256);
-                if (hc[1] && (hm & 2)) ELAG_HASH_LAUNCH(1, 4, 2, 32, 4, 256);
-                if (hc[2] && (hm & 4)) ELAG_HASH_LAUNCH(2, 8, 4, 64, 2, 256);
-                if (hc[3] && (hm & 8)) ELAG_HASH_LAUNCH(3, 8, 8, 128, 2, 256);
-                if (hc[4] && (hm & 16)) ELAG_HASH_LAUNCH(4, 16, 8, 256, 1, 256);
+#define ELAG_HASHU_LAUNCH(c, G, S, RP, BLOCK)                                                                                                    \
+    do {                                                                                                                                        \
+        hipLaunchKernelGGL((esc_hashu_kernel<G, S, RP, BLOCK, Expander>), dim3(grid1((long long)hc[c] * G, BLOCK)), dim3(BLOCK), 0, st, n, ex,   \
+                           rownnz.p, (const int *)UBI.p, Ju.p, au.p, cls_list(c), hc[c]);                                                       \
+        done[c] = true;                                                                                                                         \
+    } while (0)
+                // long product runs per unit (plan.unit_run: the right factor's entries per row): the units take turns and the lanes insert
+                // a unit's products together (esc_hashu_kernel); lanes per row = about the run length
+                const double run = hashu_enabled() ? plan.unit_run : 0.0;
+                if (run >= 12.0) {
+                    if (hc[0] && (hm & 1)) ELAG_HASHU_LAUNCH(0, 16, 16, 1, 256);
+                    if (hc[1] && (hm & 2)) ELAG_HASHU_LAUNCH(1, 16, 32, 2, 256);
+                    if (hc[2] && (hm & 4)) ELAG_HASHU_LAUNCH(2, 16, 64, 2, 256);
+                    if (hc[3] && (hm & 8)) ELAG_HASHU_LAUNCH(3, 16, 128, 2, 256);
+                    if (hc[4] && (hm & 16)) ELAG_HASHU_LAUNCH(4, 16, 256, 2, 256);
+                } else if (run >= 5.0) {
+                    if (hc[0] && (hm & 1)) ELAG_HASHU_LAUNCH(0, 8, 16, 2, 256);
+                    if (hc[1] && (hm & 2)) ELAG_HASHU_LAUNCH(1, 8, 32, 2, 256);
+                    if (hc[2] && (hm & 4)) ELAG_HASHU_LAUNCH(2, 8, 64, 2, 256);
+                    if (hc[3] && (hm & 8)) ELAG_HASHU_LAUNCH(3, 8, 128, 2, 256);
+                    if (hc[4] && (hm & 16)) ELAG_HASHU_LAUNCH(4, 16, 256, 2, 256);
+                }
+#undef ELAG_HASHU_LAUNCH
+                if (hc[0] && !done[0] && (hm & 1)) ELAG_HASH_LAUNCH(0, 4, 2, 16, 2, 256);
+                if (hc[1] && !done[1] && (hm & 2)) ELAG_HASH_LAUNCH(1, 4, 2, 32, 4, 256);
+                if (hc[2] && !done[2] && (hm & 4)) ELAG_HASH_LAUNCH(2, 8, 4, 64, 2, 256);
+                if (hc[3] && !done[3] && (hm & 8)) ELAG_HASH_LAUNCH(3, 8, 8, 128, 2, 256);
+                if (hc[4] && !done[4] && (hm & 16)) ELAG_HASH_LAUNCH(4, 16, 8, 256, 1, 256);
 #undef ELAG_HASH_LAUNCH
             }
             if (hc[0] && !done[0])
@@ -938,6 +1065,7 @@ void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C, bool spmv_plan)
     CsrView a{A.I, A.J, A.a}, b{B.I, B.J, B.a};
     hipLaunchKernelGGL(matmul_ub_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, ctx().stream, A.nrows, a, b, plan.ub.p);
     plan.wave_cap = wave_path_enabled() ? kWaveCap : 0;
+    plan.unit_run = B.nrows ? (double)B.nnz / (double)B.nrows : 0.0;
     plan.finish();
     MatmulExpander ex{a, b};
     esc_run(plan, ex, B.ncols, C, spmv_plan);
@@ -951,6 +1079,7 @@ void csr_add(double ca, const DevCSR &A, double cb, const DevCSR &B, DevCSR &C)
     CsrView a{A.I, A.J, A.a}, b{B.I, B.J, B.a};
     hipLaunchKernelGGL(add_ub_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, ctx().stream, A.nrows, a, b, plan.ub.p);
     plan.wave_cap = wave_path_enabled() ? kWaveCap : 0;
+    plan.unit_run = (double)(A.nnz + B.nnz) / (2.0 * (double)A.nrows);          // (a unit is a whole row of A or of B)
     plan.finish();
     AddExpander ex{a, b, ca, cb};
     esc_run(plan, ex, A.ncols, C);
