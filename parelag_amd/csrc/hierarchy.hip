@@ -594,6 +594,24 @@ struct elag_hip_hierarchy_s {
             if (HiptmairSmoother *hs = (!disabled && all_local && F.pre && F.pre == F.post) ? dynamic_cast<HiptmairSmoother *>(F.pre) : nullptr) {
                 const double *w = (hs->primary && hs->primary->A == F.A) ? hs->primary->diag_scaling() : nullptr;
                 const double *wa = (hs->aux && hs->aux->A && hs->aux->n() == hs->D->ncols()) ? hs->aux->diag_scaling() : nullptr;
+                if (hs->A == F.A && w && F.A->offd.ncols == 0 && C.P->offd.ncols == 0 && F.A->diag.nnz >= max_nnz && big_s) {
+                    // bandwidth-bound Hiptmair level: the primary post-sweep goes up through S like the l1-Jacobi level below (the residual of
+                    // the way down, f - A x after the whole pre-sweep, is what the restriction used); the auxiliary correction follows as it is
+                    try {
+                        std::shared_ptr<DevCSR> AP(new DevCSR());
+                        k::csr_spgemm(F.A->diag, C.P->diag, *AP, false);
+                        k::CsrCombine sop;
+                        sop.B = &C.P->diag; sop.b_scale = -1.0; sop.b_row = w; sop.b_row_divide = 1;
+                        if (AP->nnz <= F.A->diag.nnz + C.P->diag.nnz && k::csr_combine_inplace(*AP, sop)) {
+                            AP->choose_spmv_shape();
+                            F.S = AP;
+                            F.hipt_w = w;
+                        }
+                    } catch (const Error &) {
+                        F.S.reset(); F.hipt_w = nullptr;
+                    }
+                    continue;
+                }
                 if (hs->A == F.A && w && wa && !hs->D->needs_exchange() && hs->D->offd.ncols == 0 && F.A->offd.ncols == 0 && C.P->offd.ncols == 0 &&
                     F.A->diag.nnz < max_nnz) {
                     const int n = F.A->nrows();
@@ -869,11 +887,13 @@ struct elag_hip_hierarchy_s {
         par_spmvT(*C.P, 1.0, F.tmp_resid, 0.0, C.resid);
         // coarse-grid correction (:212-227)
         iterate(l + 1, C.resid, C.sol, C.alt);
-        if (F.S && !F.G) {
-            // bandwidth-bound l1-Jacobi level (plan_fused): prolongation and post-sweep in one pass over S, x' = x + W (r - S e)
+        if (F.S && !F.G && !F.Gaux) {
+            // bandwidth-bound l1-Jacobi level (plan_fused): prolongation and post-sweep in one pass over S, x' = x + W (r - S e);
+            // Hiptmair: that is the primary relaxation of the post-sweep, the residual and the auxiliary-space correction follow
             k::SpmvArgs u;
-            u.x = C.sol; u.alpha = -1.0; u.f = F.tmp_resid; u.gamma = 1.0; u.s = F.fused_dinv; u.yin = cur; u.beta = 1.0; u.out = sol;
+            u.x = C.sol; u.alpha = -1.0; u.f = F.tmp_resid; u.gamma = 1.0; u.s = F.hipt_w ? F.hipt_w : F.fused_dinv; u.yin = cur; u.beta = 1.0; u.out = sol;
             k::spmv_fused(*F.S, nullptr, u);
+            if (F.hipt_w) static_cast<HiptmairSmoother *>(F.post)->finish_after_primary(rhs, sol);
             return;
         }
         // SOL += P * coarse_sol (:231-238), fused

@@ -365,6 +365,14 @@ void HiptmairSmoother::aux_correct(const double *resid, double *x)
     par_spmv(*D, a);
 }
 
+void HiptmairSmoother::finish_after_primary(const double *f, double *x)
+{
+    k::SpmvArgs a;  // R = B - A X
+    a.x = x; a.alpha = -1.0; a.f = f; a.gamma = 1.0; a.out = pv;
+    par_spmv(*A, a);
+    aux_correct(pv, x);
+}
+
 void HiptmairSmoother::apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose)
 {
     if (!transpose) {

@@ -91,6 +91,8 @@ struct HiptmairSmoother : elag_hip_smoother_s {
     ~HiptmairSmoother() override;
     void setup();
     void aux_correct(const double *resid, double *x);
+    // the second half of a (non-transposed) sweep once the primary relaxation has been applied to x elsewhere: R = B - A X, X += D aux(D^T R)
+    void finish_after_primary(const double *f, double *x);
     void apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose) override;
     int flips(bool zero_guess) const override { return primary->flips(zero_guess); }
 };

@@ -514,6 +514,36 @@ def test_hdiv_hiptmair_vcycle_matches_oracle(la, hdiv_k2, use_graph):
     assert it_d == it_o and abs(hist_d[-1] - hist_o[-1]) <= 1e-10 * hist_o[0]
 
 
+def test_bandwidth_bound_hiptmair_level_goes_up_through_S(la, hdiv_k2):
+    """The primary relaxation of a bandwidth-bound Hiptmair level's post-sweep is one pass over S = A P - W^-1 P too (the residual the
+    restriction used is kept); the auxiliary-space correction follows as it is.  ELAG_HIP_FUSE_NNZ=1 makes every level of the small
+    problem such a level: the oracle's cycle, and the separate sequence (ELAG_HIP_BIG_LEVEL_S=0) to rounding."""
+    import os
+    A, Ps, Ds, _ = hdiv_k2
+    from tests.helpers import oracle_hdiv_hierarchy
+    h = oracle_hdiv_hierarchy(A, Ps, Ds)
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], hipt=h["hipt"])
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    dDs = [la.ParallelCSRMatrix.from_scipy(D) for D in Ds]
+    b = np.random.default_rng(34).uniform(-1, 1, A.shape[0])
+    outs = {}
+    for name, env in (("S", {"ELAG_HIP_FUSE_NNZ": "1"}), ("separate", {"ELAG_HIP_FUSE_NNZ": "1", "ELAG_HIP_BIG_LEVEL_S": "0"})):
+        os.environ.update(env)
+        try:
+            H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi", Ds=dDs, aux_smoother="L1 Jacobi")
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        x = np.empty_like(b)
+        H.Mult(b, x)
+        outs[name] = x
+    xr = np.empty_like(b)
+    Hc.apply(b, xr)
+    assert np.max(np.abs(outs["S"] - outs["separate"])) <= 1e-12 * np.max(np.abs(xr))
+    assert close(outs["S"], xr, tol=1e-10)
+
+
 # ---- operator hand-off from amge (SURVEY 8a-13) -----------------------------------------------------------------
 
 def test_operator_handoff_triple_products(la, h1_k1):
