@@ -47,7 +47,15 @@ ELAG_HIP_API int elag_hip_host_keep_pages(int on)
         const int ok = on ? (mallopt(M_MMAP_MAX, 0) && mallopt(M_TRIM_THRESHOLD, 0x7fffffff))
                           : (mallopt(M_MMAP_MAX, 65536) && mallopt(M_TRIM_THRESHOLD, 128 * 1024));
         ELAG_REQUIRE(ok, "elag_hip_host_keep_pages: mallopt refused the setting");
-        if (!on) (void)malloc_trim(0);         // the pages kept meanwhile go back to the system
+        if (!on) {
+            // the pages kept meanwhile go back to the system -- when there are enough of them to matter: malloc_trim walks every heap and
+            // costs ~50 ms after a cube456 x3 coarsening whose whole table stage takes 0.2 s; below 512 MiB at the top of the heap
+            // (ELAG_HIP_HOST_TRIM_FROM_MB) glibc's own trimming, back in force with the thresholds above, takes care of it at the next large free
+            static long long from_mb = -1;
+            if (from_mb < 0) { const char *e = getenv("ELAG_HIP_HOST_TRIM_FROM_MB"); from_mb = e ? atoll(e) : 512; }
+            const struct mallinfo2 mi = mallinfo2();
+            if ((long long)(mi.keepcost >> 20) >= from_mb) (void)malloc_trim(0);
+        }
     });
 }
 
