@@ -148,6 +148,11 @@ void csr_sort_rows(DevCSR &A);
 // C = A*B, columns ascending.  spmv_plan = false for an intermediate that is only ever an operand of another product (no SpMV
 // dispatch plan is built for it)
 void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C, bool spmv_plan = true);
+// C = R (A P) with A P never leaving the layout its kernels wrote it in (row r: its entries, ascending columns, from the scanned upper
+// bound of its products on): as the intermediate of a triple product it needs neither the scan of the rows' entry counts, nor the host
+// round trip for their total, nor the compaction into CSR -- a quarter of A P's time at cube456 x5.  Falls back to two plain products
+// where the first one's rows do not all fit that layout.
+void csr_rap(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, bool spmv_plan = true);
 void csr_add(double a, const DevCSR &A, double b, const DevCSR &B, DevCSR &C);
 void csr_delete_zeros(const DevCSR &A, double tol, DevCSR &out);
 void csr_scale_rows(DevCSR &A, const double *d);

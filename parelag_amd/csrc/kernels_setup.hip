@@ -122,6 +122,8 @@ constexpr int kBigCap = 8192; // single-row workgroups for rows with more produc
 struct CsrView {
     const int *I, *J;
     const double *a;
+    const int *len = nullptr;      // rows shorter than I[r + 1] - I[r] (a LooseCSR operand); null: plain CSR
+    __device__ int rowlen(int r) const { return len ? len[r] : I[r + 1] - I[r]; }
 };
 
 // Expanders: ub(row) = number of expanded entries, expand(row) writes them at lds offset `off`.
@@ -129,14 +131,14 @@ struct MatmulExpander {
     CsrView A, B;
     static constexpr bool kUnits = true;
     static constexpr bool kFlat = true;
-    __device__ int ub_entry(int k) const { const int j = A.J[k]; return B.I[j + 1] - B.I[j]; }
+    __device__ int ub_entry(int k) const { return B.rowlen(A.J[k]); }
     // hash path: a row is a list of units (the entries of A's row), each a run of products scale * a[pbeg + q] in column J[pbeg + q]
     __device__ void units(int row, int &ubeg, int &nu) const { ubeg = A.I[row]; nu = A.I[row + 1] - ubeg; }
     __device__ void unit(int row, int ubeg, int u, int &pbeg, int &plen, double &scale, const int *&J, const double *&a) const
     {
         const int j = A.J[ubeg + u];
         scale = A.a[ubeg + u];
-        pbeg = B.I[j]; plen = B.I[j + 1] - pbeg;
+        pbeg = B.I[j]; plen = B.rowlen(j);
         J = B.J; a = B.a;
     }
     // cooperative expansion of one row by a group of G lanes (G = 64: a wavefront)
@@ -147,7 +149,7 @@ struct MatmulExpander {
         for (int k0 = A.I[row]; k0 < A.I[row + 1]; k0 += G) {
             const int k = k0 + lane;
             int len = 0, j = 0;
-            if (k < A.I[row + 1]) { j = A.J[k]; len = B.I[j + 1] - B.I[j]; }
+            if (k < A.I[row + 1]) { j = A.J[k]; len = B.rowlen(j); }
             const int incl = group_incl_scan<G>(len);
             int pos = off + incl - len;
             if (len) {
@@ -173,7 +175,7 @@ __device__ bool matmul_expand_flat(const CsrView &A, const CsrView &B, int row, 
 {
     const int as = A.I[row], na = A.I[row + 1] - as;
     if (na > kFlatUnits) return false;                                 // (uniform over the workgroup)
-    for (int t = threadIdx.x; t < na; t += blockDim.x) { const int j = A.J[as + t]; pre[t + 1] = B.I[j + 1] - B.I[j]; }
+    for (int t = threadIdx.x; t < na; t += blockDim.x) { const int j = A.J[as + t]; pre[t + 1] = B.rowlen(j); }
     if (threadIdx.x == 0) pre[0] = 0;
     __syncthreads();
     if (threadIdx.x < 64) {                                            // inclusive scan by the first wavefront, 64 entries at a time
@@ -372,7 +374,7 @@ __global__ void matmul_ub_kernel(int nrows, CsrView A, CsrView B, int *__restric
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= nrows) return;
     int s = 0;
-    for (int k = A.I[row]; k < A.I[row + 1]; k++) { const int j = A.J[k]; s += B.I[j + 1] - B.I[j]; }
+    for (int k = A.I[row]; k < A.I[row + 1]; k++) s += B.rowlen(A.J[k]);
     ub[row] = s;
 }
 
@@ -784,12 +786,24 @@ inline bool single_pass_enabled()
     return v != 0;
 }
 
-__global__ void esc_gather_kernel(int *__restrict__ counters, const int *__restrict__ tot_small, const int *__restrict__ tot_wave, const int *__restrict__ ccount)
+__global__ void esc_gather_kernel(int *__restrict__ counters, const int *__restrict__ tot_small, const int *__restrict__ tot_wave, const int *__restrict__ ccount,
+                                  const int *__restrict__ extra)
 {
     const int t = threadIdx.x;
     if (t == 0) counters[2] = *tot_small;
     if (t == 1) counters[3] = tot_wave ? *tot_wave : 0;
     if (t >= 2 && t < 2 + kNumClasses) counters[2 + t] = ccount ? ccount[t - 2] : 0;
+    if (t == 2 + kNumClasses) counters[4 + kNumClasses] = extra ? *extra : 0;
+}
+
+// number of entries of a product left in the upper-bound layout (LooseCSR::d_nnz)
+__global__ void sum_int_kernel(int n, const int *__restrict__ v, int *__restrict__ out)
+{
+    int s = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += v[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
 }
 
 inline int hash_classes()
@@ -827,9 +841,11 @@ struct EscPlan {
     bool all_rows = false;            // ... and the upper-bound layout has room for EVERY row (chunked and one-row-per-workgroup rows too): no symbolic launches at all
     unsigned long long total_ub = 0;
     int hc[kNumClasses] = {0, 0, 0, 0, 0};
+    const int *extra = nullptr;       // a device scalar of the caller's, read back with the plan's own numbers (extra_value)
+    int extra_value = 0;
     double unit_run = 0.0;            // products per unit on average (a product: the right factor's entries per row): picks the insertion scheme of the hash path
     explicit EscPlan(int n)
-        : nrows(n), ub((size_t)n), ub_small((size_t)n), ubscan((size_t)n + 1), biglist((size_t)n), counters(4 + kNumClasses), ubw((size_t)n),
+        : nrows(n), ub((size_t)n), ub_small((size_t)n), ubscan((size_t)n + 1), biglist((size_t)n), counters(5 + kNumClasses), ubw((size_t)n),
           UBI((size_t)n + 1), ccount(kNumClasses), lists((size_t)kNumClasses * (size_t)n) {}
     void finish()
     {
@@ -852,12 +868,13 @@ struct EscPlan {
         // every number the host needs, gathered into one block and read back by ONE copy into pinned memory (four small copies into
         // pageable variables cost ~25 us of host time each: profiles/r03_rap_timeline.txt)
         hipLaunchKernelGGL(esc_gather_kernel, dim3(1), dim3(64), 0, st, counters.p, (const int *)(ubscan.p + nrows), wave ? (const int *)(UBI.p + nrows) : (const int *)nullptr,
-                           wave ? (const int *)ccount.p : (const int *)nullptr);
+                           wave ? (const int *)ccount.p : (const int *)nullptr, extra);
         int *hp = reinterpret_cast<int *>(ctx().h_scalar + 10);          // (doubles 0 and 8 of the pinned block belong to the reductions)
-        ELAG_HIP_CHECK(hipMemcpyAsync(hp, counters.p, (4 + kNumClasses) * sizeof(int), hipMemcpyDeviceToHost, st));
+        ELAG_HIP_CHECK(hipMemcpyAsync(hp, counters.p, (5 + kNumClasses) * sizeof(int), hipMemcpyDeviceToHost, st));
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
         const int h[2] = {hp[0], hp[1]}, tot = hp[2], totw = hp[3];
         for (int c = 0; c < kNumClasses; c++) hc[c] = hp[4 + c];
+        extra_value = hp[4 + kNumClasses];
         if (h[1] > 0)
             fail(ELAG_HIP_ERR_ARG, "sparse product: %d rows expand to more than %d intermediate products (unsupported)", h[1], kBigCap);
         nbig = h[0];
@@ -870,13 +887,29 @@ struct EscPlan {
     int nchunks() const { return (total_small + kCap - 1) / kCap; }
 };
 
+// `keep`: the caller's arrays for a product that stays in the upper-bound layout (esc_layout_fits said yes): entries, values and the rows'
+// entry counts are written there, nothing else happens (no scan of the counts, no host round trip, no compaction) and C is not touched.
+struct EscLayout {
+    int *J = nullptr;
+    double *a = nullptr;
+    int *rownnz = nullptr;
+};
+inline bool esc_layout_fits(const EscPlan &plan)
+{
+    const bool in_range = plan.total_ub < (1ull << 31) && plan.total_ub * 12ull <= (16ull << 30);
+    const bool single_all = plan.wave_cap > 0 && single_pass_enabled() && plan.wave_ready && plan.all_rows && in_range;
+    return plan.wave_cap > 0 && single_pass_enabled() && plan.wave_ready && in_range && (single_all || (plan.nchunks() == 0 && plan.nbig == 0));
+}
+
 template <class Expander>
-void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_plan = true)
+void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_plan = true, const EscLayout *keep = nullptr)
 {
     hipStream_t st = ctx().stream;
     const int n = plan.nrows;
-    Temp<int> rownnz((size_t)n);
+    Temp<int> rownnz_own(keep ? 1 : (size_t)n);
+    struct { int *p; operator int *() const { return p; } } rownnz{keep ? keep->rownnz : rownnz_own.p};
     ELAG_HIP_CHECK(hipMemsetAsync(rownnz, 0, sizeof(int) * (size_t)n, st));
+    if (keep) ELAG_REQUIRE(esc_layout_fits(plan), "internal: esc_run asked to keep a layout that does not hold every row");
     const int nch = plan.nchunks();
     // the symbolic launches of the chunked / one-row-per-workgroup rows -- unless the single pass below has room for those rows too
     const bool single_all = plan.wave_cap > 0 && single_pass_enabled() && plan.wave_ready && plan.all_rows &&
@@ -916,8 +949,10 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
         }
         // the upper-bound layout is indexed with ints and lives in the scratch arena: at most 2^31 - 1 products and 16 GiB
         if (total_ub < (1ull << 31) && total_ub * 12ull <= (16ull << 30)) {
-            Temp<int> Ju((size_t)std::max<long long>(total_ub, 1));
-            Temp<double> au((size_t)std::max<long long>(total_ub, 1));
+            Temp<int> Ju_own(keep ? 1 : (size_t)std::max<long long>(total_ub, 1));
+            Temp<double> au_own(keep ? 1 : (size_t)std::max<long long>(total_ub, 1));
+            struct { int *p; } Ju{keep ? keep->J : Ju_own.p};
+            struct { double *p; } au{keep ? keep->a : au_own.p};
             // row classes by number of products, each with the smallest lane group that still expands a row in one pass (the
             // entries of the left factor's row are what the lanes of a group share out: 15 for A, 2-15 for P^T; the products
             // only set how many slots a lane owns, R), each launched over the list of ITS rows
@@ -990,6 +1025,7 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
                                        plan.ub.p, plan.biglist.p, ex, rownnz.p, (const int *)UBI.p, Ju.p, au.p);
             }
             ELAG_LAUNCH_CHECK();
+            if (keep) return;                        // the product stays where its kernels wrote it
             int *CI = dev_alloc<int>((size_t)n + 1);
             exclusive_scan(rownnz, CI, n);
             int *hnnz = reinterpret_cast<int *>(ctx().h_scalar + 10);
@@ -1069,6 +1105,52 @@ void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C, bool spmv_plan)
     plan.finish();
     MatmulExpander ex{a, b};
     esc_run(plan, ex, B.ncols, C, spmv_plan);
+}
+
+void csr_rap(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, bool spmv_plan)
+{
+    ELAG_REQUIRE(A.ncols == P.nrows && R.ncols == A.nrows, "rap: shapes do not chain");
+    static int loose = -1;
+    if (loose < 0) { const char *e = getenv("ELAG_HIP_RAP_LOOSE"); loose = e ? atoi(e) : 1; }
+    hipStream_t st = ctx().stream;
+    if (loose && A.nrows > 0 && R.nrows > 0) {
+        EscPlan plan(A.nrows);
+        CsrView a{A.I, A.J, A.a}, p{P.I, P.J, P.a};
+        hipLaunchKernelGGL(matmul_ub_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, st, A.nrows, a, p, plan.ub.p);
+        plan.wave_cap = wave_path_enabled() ? kWaveCap : 0;
+        plan.unit_run = P.nrows ? (double)P.nnz / (double)P.nrows : 0.0;
+        plan.finish();
+        MatmulExpander ex{a, p};
+        if (esc_layout_fits(plan)) {
+            // A P in the upper-bound layout: rows at plan.UBI, their lengths in `len`; every array is a Temp of this frame, released (in
+            // reverse order) when the second product is done
+            Temp<int> Jap((size_t)std::max<unsigned long long>(plan.total_ub, 1)), len((size_t)A.nrows), nnz_ap(1);
+            Temp<double> aap((size_t)std::max<unsigned long long>(plan.total_ub, 1));
+            const EscLayout lay{Jap.p, aap.p, len.p};
+            DevCSR unused;
+            esc_run(plan, ex, P.ncols, unused, false, &lay);
+            ELAG_HIP_CHECK(hipMemsetAsync(nnz_ap, 0, sizeof(int), st));
+            hipLaunchKernelGGL(sum_int_kernel, dim3(std::min(grid1(A.nrows), 1024u)), dim3(kBlock), 0, st, A.nrows, (const int *)len.p, nnz_ap.p);
+            ELAG_LAUNCH_CHECK();
+            EscPlan plan2(R.nrows);
+            CsrView r{R.I, R.J, R.a}, ap{plan.UBI.p, Jap.p, aap.p, len.p};
+            hipLaunchKernelGGL(matmul_ub_kernel, dim3(grid1(R.nrows)), dim3(kBlock), 0, st, R.nrows, r, ap, plan2.ub.p);
+            plan2.wave_cap = wave_path_enabled() ? kWaveCap : 0;
+            plan2.extra = nnz_ap.p;                        // (the number of entries of A P comes back with the second plan's own numbers)
+            plan2.finish();
+            plan2.unit_run = (double)plan2.extra_value / (double)A.nrows;
+            MatmulExpander ex2{r, ap};
+            esc_run(plan2, ex2, P.ncols, C, spmv_plan);
+            return;
+        }
+        DevCSR AP;
+        esc_run(plan, ex, P.ncols, AP, false);
+        csr_spgemm(R, AP, C, spmv_plan);
+        return;
+    }
+    DevCSR AP;
+    csr_spgemm(A, P, AP, false);
+    csr_spgemm(R, AP, C, spmv_plan);
 }
 
 void csr_add(double ca, const DevCSR &A, double cb, const DevCSR &B, DevCSR &C)

@@ -391,10 +391,9 @@ int elag_hip_parcsr_rap(elag_hip_parcsr_t RT, elag_hip_parcsr_t A, elag_hip_parc
         ELAG_REQUIRE(RT->nrows() == A->nrows() && A->ncols() == P->nrows(),
                      "rap: shapes RT %dx%d, A %dx%d, P %dx%d do not chain", RT->nrows(), RT->ncols(), A->nrows(), A->ncols(),
                      P->nrows(), P->ncols());
-        DevCSR AP, out;
-        k::csr_spgemm(A->diag, P->diag, AP, false);
+        DevCSR out;
         RT->ensure_transpose();
-        k::csr_spgemm(*RT->diagT, AP, out);
+        k::csr_rap(*RT->diagT, A->diag, P->diag, out);
         *RAP = parcsr_from_diag(std::move(out), RT->first_col, P->first_col, RT->global_cols, P->global_cols);
     });
 }
