@@ -231,6 +231,31 @@ struct AddExpander {
     }
 };
 
+// A * B for a right factor whose rows hold at most W entries (W <= 4: nested low-order interpolators), stored a second time with W
+// slots per row (column -1 past the row's end): a unit's product run starts at j * W -- one dependent memory round trip less per row
+// than through B's row pointers (row bounds, A's entries, B's row bounds, B's entries: the hash kernel is bound by exactly these trips), and
+// the upper bound of a row's products is W times its length, no gather at all.  Hash path only (every class): the padded slots are
+// skipped there; expand() exists for the templates that are never launched with this expander.
+struct MatmulEllExpander {
+    CsrView A;
+    const int *EJ;
+    const double *Ea;
+    int W;
+    static constexpr bool kUnits = true;
+    static constexpr bool kFlat = false;
+    __device__ int ub_entry(int) const { return W; }
+    __device__ void units(int row, int &ubeg, int &nu) const { ubeg = A.I[row]; nu = A.I[row + 1] - ubeg; }
+    __device__ void unit(int, int ubeg, int u, int &pbeg, int &plen, double &scale, const int *&J, const double *&a) const
+    {
+        const int j = A.J[ubeg + u];
+        scale = A.a[ubeg + u];
+        pbeg = j * W; plen = W;
+        J = EJ; a = Ea;
+    }
+    template <bool NUMERIC, int G = 64>
+    __device__ void expand(int, unsigned, int, u64 *, double *) const {}
+};
+
 struct SortExpander {  // identity: re-emit the row (used to sort columns inside rows)
     CsrView A;
     static constexpr bool kUnits = false;
@@ -367,6 +392,23 @@ __global__ __launch_bounds__(kBlock) void esc_kernel(int nrows, const int *__res
                 if (rownnz && !BIG) atomicAdd(&rownnz[r0 + (int)rl], 1);
             }
         }
+}
+
+__global__ void ell_build_kernel(int nrows, int W, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a, int *__restrict__ EJ,
+                                 double *__restrict__ Ea)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nrows * W) return;
+    const int r = (int)(i / W), q = (int)(i % W);
+    const int s = I[r], len = I[r + 1] - s;
+    EJ[i] = q < len ? J[s + q] : -1;
+    Ea[i] = q < len ? a[s + q] : 0.0;
+}
+
+__global__ void ell_ub_kernel(int nrows, int W, const int *__restrict__ I, int *__restrict__ ub)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < nrows) ub[row] = W * (I[row + 1] - I[row]);
 }
 
 __global__ void matmul_ub_kernel(int nrows, CsrView A, CsrView B, int *__restrict__ ub)
@@ -787,23 +829,18 @@ inline bool single_pass_enabled()
 }
 
 __global__ void esc_gather_kernel(int *__restrict__ counters, const int *__restrict__ tot_small, const int *__restrict__ tot_wave, const int *__restrict__ ccount,
-                                  const int *__restrict__ extra)
+                                  const int *__restrict__ extra, int extra_n)
 {
     const int t = threadIdx.x;
     if (t == 0) counters[2] = *tot_small;
     if (t == 1) counters[3] = tot_wave ? *tot_wave : 0;
     if (t >= 2 && t < 2 + kNumClasses) counters[2 + t] = ccount ? ccount[t - 2] : 0;
-    if (t == 2 + kNumClasses) counters[4 + kNumClasses] = extra ? *extra : 0;
-}
-
-// number of entries of a product left in the upper-bound layout (LooseCSR::d_nnz)
-__global__ void sum_int_kernel(int n, const int *__restrict__ v, int *__restrict__ out)
-{
-    int s = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += v[i];
+    // a caller's array, sampled: the sum of 64 entries spread evenly over its extra_n (the mean row length of a product left in the
+    // upper-bound layout -- all the next product wants from it is which insertion scheme to take)
+    int v = (extra && extra_n > 0) ? extra[(long long)t * extra_n / 64] : 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (t == 0) counters[4 + kNumClasses] = v;
 }
 
 inline int hash_classes()
@@ -841,8 +878,8 @@ struct EscPlan {
     bool all_rows = false;            // ... and the upper-bound layout has room for EVERY row (chunked and one-row-per-workgroup rows too): no symbolic launches at all
     unsigned long long total_ub = 0;
     int hc[kNumClasses] = {0, 0, 0, 0, 0};
-    const int *extra = nullptr;       // a device scalar of the caller's, read back with the plan's own numbers (extra_value)
-    int extra_value = 0;
+    const int *extra = nullptr;       // an array of the caller's (extra_n entries), sampled at 64 places with the plan's own read-back (extra_value = their sum)
+    int extra_n = 0, extra_value = 0;
     double unit_run = 0.0;            // products per unit on average (a product: the right factor's entries per row): picks the insertion scheme of the hash path
     explicit EscPlan(int n)
         : nrows(n), ub((size_t)n), ub_small((size_t)n), ubscan((size_t)n + 1), biglist((size_t)n), counters(5 + kNumClasses), ubw((size_t)n),
@@ -868,7 +905,7 @@ struct EscPlan {
         // every number the host needs, gathered into one block and read back by ONE copy into pinned memory (four small copies into
         // pageable variables cost ~25 us of host time each: profiles/r03_rap_timeline.txt)
         hipLaunchKernelGGL(esc_gather_kernel, dim3(1), dim3(64), 0, st, counters.p, (const int *)(ubscan.p + nrows), wave ? (const int *)(UBI.p + nrows) : (const int *)nullptr,
-                           wave ? (const int *)ccount.p : (const int *)nullptr, extra);
+                           wave ? (const int *)ccount.p : (const int *)nullptr, extra, extra_n);
         int *hp = reinterpret_cast<int *>(ctx().h_scalar + 10);          // (doubles 0 and 8 of the pinned block belong to the reductions)
         ELAG_HIP_CHECK(hipMemcpyAsync(hp, counters.p, (5 + kNumClasses) * sizeof(int), hipMemcpyDeviceToHost, st));
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
@@ -1114,8 +1151,43 @@ void csr_rap(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, bool 
     if (loose < 0) { const char *e = getenv("ELAG_HIP_RAP_LOOSE"); loose = e ? atoi(e) : 1; }
     hipStream_t st = ctx().stream;
     if (loose && A.nrows > 0 && R.nrows > 0) {
-        EscPlan plan(A.nrows);
         CsrView a{A.I, A.J, A.a}, p{P.I, P.J, P.a};
+        static int use_ell = -1;
+        if (use_ell < 0) { const char *e = getenv("ELAG_HIP_RAP_ELL"); use_ell = e ? atoi(e) : 1; }
+        const int W = P.max_row_nnz;
+        if (use_ell && W >= 1 && W <= 4 && P.nnz > 0 && (long long)P.nrows * W < (1ll << 31) && hash_classes() == 31 && wave_path_enabled()) {
+            // the right factor with W slots per row (MatmulEllExpander): valid when every row of A P takes the hash path
+            Temp<int> EJ((size_t)P.nrows * W);
+            Temp<double> Ea((size_t)P.nrows * W);
+            hipLaunchKernelGGL(ell_build_kernel, dim3(grid1((long long)P.nrows * W)), dim3(kBlock), 0, st, P.nrows, W, (const int *)P.I, (const int *)P.J,
+                               (const double *)P.a, EJ.p, Ea.p);
+            EscPlan plan(A.nrows);
+            hipLaunchKernelGGL(ell_ub_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, st, A.nrows, W, (const int *)A.I, plan.ub.p);
+            ELAG_LAUNCH_CHECK();
+            plan.wave_cap = kWaveCap;
+            plan.unit_run = (double)W;
+            plan.finish();
+            if (esc_layout_fits(plan) && plan.nchunks() == 0 && plan.nbig == 0) {
+                MatmulEllExpander exl{a, EJ.p, Ea.p, W};
+                Temp<int> Jap((size_t)std::max<unsigned long long>(plan.total_ub, 1)), len((size_t)A.nrows);
+                Temp<double> aap((size_t)std::max<unsigned long long>(plan.total_ub, 1));
+                const EscLayout lay{Jap.p, aap.p, len.p};
+                DevCSR unused;
+                esc_run(plan, exl, P.ncols, unused, false, &lay);
+                EscPlan plan2(R.nrows);
+                CsrView r{R.I, R.J, R.a}, ap{plan.UBI.p, Jap.p, aap.p, len.p};
+                hipLaunchKernelGGL(matmul_ub_kernel, dim3(grid1(R.nrows)), dim3(kBlock), 0, st, R.nrows, r, ap, plan2.ub.p);
+                plan2.wave_cap = kWaveCap;
+                plan2.extra = len.p; plan2.extra_n = A.nrows;
+                plan2.finish();
+                plan2.unit_run = (double)plan2.extra_value / 64.0;
+                MatmulExpander ex2{r, ap};
+                esc_run(plan2, ex2, P.ncols, C, spmv_plan);
+                return;
+            }
+            // (a row of A with more than 256 / W entries: the general route below)
+        }
+        EscPlan plan(A.nrows);
         hipLaunchKernelGGL(matmul_ub_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, st, A.nrows, a, p, plan.ub.p);
         plan.wave_cap = wave_path_enabled() ? kWaveCap : 0;
         plan.unit_run = P.nrows ? (double)P.nnz / (double)P.nrows : 0.0;
@@ -1124,21 +1196,18 @@ void csr_rap(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, bool 
         if (esc_layout_fits(plan)) {
             // A P in the upper-bound layout: rows at plan.UBI, their lengths in `len`; every array is a Temp of this frame, released (in
             // reverse order) when the second product is done
-            Temp<int> Jap((size_t)std::max<unsigned long long>(plan.total_ub, 1)), len((size_t)A.nrows), nnz_ap(1);
+            Temp<int> Jap((size_t)std::max<unsigned long long>(plan.total_ub, 1)), len((size_t)A.nrows);
             Temp<double> aap((size_t)std::max<unsigned long long>(plan.total_ub, 1));
             const EscLayout lay{Jap.p, aap.p, len.p};
             DevCSR unused;
             esc_run(plan, ex, P.ncols, unused, false, &lay);
-            ELAG_HIP_CHECK(hipMemsetAsync(nnz_ap, 0, sizeof(int), st));
-            hipLaunchKernelGGL(sum_int_kernel, dim3(std::min(grid1(A.nrows), 1024u)), dim3(kBlock), 0, st, A.nrows, (const int *)len.p, nnz_ap.p);
-            ELAG_LAUNCH_CHECK();
             EscPlan plan2(R.nrows);
             CsrView r{R.I, R.J, R.a}, ap{plan.UBI.p, Jap.p, aap.p, len.p};
             hipLaunchKernelGGL(matmul_ub_kernel, dim3(grid1(R.nrows)), dim3(kBlock), 0, st, R.nrows, r, ap, plan2.ub.p);
             plan2.wave_cap = wave_path_enabled() ? kWaveCap : 0;
-            plan2.extra = nnz_ap.p;                        // (the number of entries of A P comes back with the second plan's own numbers)
+            plan2.extra = len.p; plan2.extra_n = A.nrows;   // (the mean row length of A P, sampled, comes back with the second plan's own numbers)
             plan2.finish();
-            plan2.unit_run = (double)plan2.extra_value / (double)A.nrows;
+            plan2.unit_run = (double)plan2.extra_value / 64.0;
             MatmulExpander ex2{r, ap};
             esc_run(plan2, ex2, P.ncols, C, spmv_plan);
             return;
