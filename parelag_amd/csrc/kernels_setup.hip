@@ -405,10 +405,14 @@ __global__ void ell_build_kernel(int nrows, int W, const int *__restrict__ I, co
     Ea[i] = q < len ? a[s + q] : 0.0;
 }
 
-__global__ void ell_ub_kernel(int nrows, int W, const int *__restrict__ I, int *__restrict__ ub)
+// the whole plan of A * B for a W-slot right factor: a row's products are bounded by W times its length, so the upper-bound layout is W
+// times A's row pointers -- no gather, no scan
+__global__ void ell_plan_kernel(int nrows, int W, const int *__restrict__ I, int *__restrict__ ub, int *__restrict__ ubw, int *__restrict__ UBI)
 {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row < nrows) ub[row] = W * (I[row + 1] - I[row]);
+    if (row > nrows) return;
+    UBI[row] = W * I[row];
+    if (row < nrows) { const int u = W * (I[row + 1] - I[row]); ub[row] = u; ubw[row] = u; }
 }
 
 __global__ void matmul_ub_kernel(int nrows, CsrView A, CsrView B, int *__restrict__ ub)
@@ -921,6 +925,24 @@ struct EscPlan {
                     total_small, nchunks(), wave ? (unsigned long long)totw : 0ull);
         if (wave) { wave_ready = true; total_ub = (unsigned long long)totw; }
     }
+    // The plan of A * B when B has W slots per row (MatmulEllExpander) and no row of A is longer than kWaveCap / W: every row is a
+    // hash-path row, the layout is W * A.I, and the only number the host waits for is how many rows each class has.
+    void finish_ell(const int *AI, int W, long long nnzA)
+    {
+        hipStream_t st = ctx().stream;
+        hipLaunchKernelGGL(ell_plan_kernel, dim3(grid1((long long)nrows + 1)), dim3(kBlock), 0, st, nrows, W, AI, ub.p, ubw.p, UBI.p);
+        const ClassBounds cb{{0, 16, 32, 64, 128, kWaveCap}};
+        ELAG_HIP_CHECK(hipMemsetAsync(ccount, 0, sizeof(int) * kNumClasses, st));
+        hipLaunchKernelGGL(esc_classify_kernel, dim3(std::min(grid1(nrows), 1024u)), dim3(kBlock), 0, st, nrows, (const int *)ub.p, cb, ccount.p, lists.p, 1);
+        ELAG_LAUNCH_CHECK();
+        int *hp = reinterpret_cast<int *>(ctx().h_scalar + 10);
+        ELAG_HIP_CHECK(hipMemcpyAsync(hp, ccount.p, kNumClasses * sizeof(int), hipMemcpyDeviceToHost, st));
+        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        for (int c = 0; c < kNumClasses; c++) hc[c] = hp[c];
+        nbig = 0; total_small = 0;
+        wave_ready = true; all_rows = false;
+        total_ub = (unsigned long long)W * (unsigned long long)nnzA;
+    }
     int nchunks() const { return (total_small + kCap - 1) / kCap; }
 };
 
@@ -1155,18 +1177,18 @@ void csr_rap(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, bool 
         static int use_ell = -1;
         if (use_ell < 0) { const char *e = getenv("ELAG_HIP_RAP_ELL"); use_ell = e ? atoi(e) : 1; }
         const int W = P.max_row_nnz;
-        if (use_ell && W >= 1 && W <= 4 && P.nnz > 0 && (long long)P.nrows * W < (1ll << 31) && hash_classes() == 31 && wave_path_enabled()) {
+        if (use_ell && W >= 1 && W <= 4 && P.nnz > 0 && (long long)P.nrows * W < (1ll << 31) && hash_classes() == 31 && wave_path_enabled() &&
+            single_pass_enabled() && A.max_row_nnz > 0 && (long long)A.max_row_nnz * W <= kWaveCap && (long long)A.nnz * W < (1ll << 31) &&
+            (unsigned long long)A.nnz * W * 12ull <= (16ull << 30)) {
             // the right factor with W slots per row (MatmulEllExpander): valid when every row of A P takes the hash path
             Temp<int> EJ((size_t)P.nrows * W);
             Temp<double> Ea((size_t)P.nrows * W);
             hipLaunchKernelGGL(ell_build_kernel, dim3(grid1((long long)P.nrows * W)), dim3(kBlock), 0, st, P.nrows, W, (const int *)P.I, (const int *)P.J,
                                (const double *)P.a, EJ.p, Ea.p);
             EscPlan plan(A.nrows);
-            hipLaunchKernelGGL(ell_ub_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, st, A.nrows, W, (const int *)A.I, plan.ub.p);
-            ELAG_LAUNCH_CHECK();
             plan.wave_cap = kWaveCap;
             plan.unit_run = (double)W;
-            plan.finish();
+            plan.finish_ell(A.I, W, (long long)A.nnz);
             if (esc_layout_fits(plan) && plan.nchunks() == 0 && plan.nbig == 0) {
                 MatmulEllExpander exl{a, EJ.p, Ea.p, W};
                 Temp<int> Jap((size_t)std::max<unsigned long long>(plan.total_ub, 1)), len((size_t)A.nrows);
