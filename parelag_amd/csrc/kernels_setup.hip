@@ -1152,10 +1152,39 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
 
 }  // namespace
 
+namespace {
+// A * B may go through the W-slot copy of B (MatmulEllExpander + EscPlan::finish_ell): B's rows hold at most 4 entries, every row of the
+// product stays within the hash path's 256 products, and the upper-bound layout fits its int indices and the scratch arena
+bool ell_applies(const DevCSR &A, const DevCSR &B)
+{
+    static int use_ell = -1;
+    if (use_ell < 0) { const char *e = getenv("ELAG_HIP_RAP_ELL"); use_ell = e ? atoi(e) : 1; }
+    const int W = B.max_row_nnz;
+    return use_ell && W >= 1 && W <= 4 && B.nnz > 0 && (long long)B.nrows * W < (1ll << 31) && hash_classes() == 31 && wave_path_enabled() &&
+           single_pass_enabled() && A.max_row_nnz > 0 && (long long)A.max_row_nnz * W <= kWaveCap && (long long)A.nnz * W < (1ll << 31) &&
+           (unsigned long long)A.nnz * W * 12ull <= (16ull << 30);
+}
+}  // namespace
+
 void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C, bool spmv_plan)
 {
     ELAG_REQUIRE(A.ncols == B.nrows, "spgemm: inner dimensions differ (%d vs %d)", A.ncols, B.nrows);
     if (A.nrows == 0) { C.set_empty(0, B.ncols); return; }
+    if (ell_applies(A, B)) {
+        hipStream_t st = ctx().stream;
+        const int W = B.max_row_nnz;
+        Temp<int> EJ((size_t)B.nrows * W);
+        Temp<double> Ea((size_t)B.nrows * W);
+        hipLaunchKernelGGL(ell_build_kernel, dim3(grid1((long long)B.nrows * W)), dim3(kBlock), 0, st, B.nrows, W, (const int *)B.I, (const int *)B.J,
+                           (const double *)B.a, EJ.p, Ea.p);
+        EscPlan plan(A.nrows);
+        plan.wave_cap = kWaveCap;
+        plan.unit_run = (double)W;
+        plan.finish_ell(A.I, W, (long long)A.nnz);
+        MatmulEllExpander ex{CsrView{A.I, A.J, A.a}, EJ.p, Ea.p, W};
+        esc_run(plan, ex, B.ncols, C, spmv_plan);
+        return;
+    }
     EscPlan plan(A.nrows);
     CsrView a{A.I, A.J, A.a}, b{B.I, B.J, B.a};
     hipLaunchKernelGGL(matmul_ub_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, ctx().stream, A.nrows, a, b, plan.ub.p);
@@ -1174,12 +1203,8 @@ void csr_rap(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, bool 
     hipStream_t st = ctx().stream;
     if (loose && A.nrows > 0 && R.nrows > 0) {
         CsrView a{A.I, A.J, A.a}, p{P.I, P.J, P.a};
-        static int use_ell = -1;
-        if (use_ell < 0) { const char *e = getenv("ELAG_HIP_RAP_ELL"); use_ell = e ? atoi(e) : 1; }
         const int W = P.max_row_nnz;
-        if (use_ell && W >= 1 && W <= 4 && P.nnz > 0 && (long long)P.nrows * W < (1ll << 31) && hash_classes() == 31 && wave_path_enabled() &&
-            single_pass_enabled() && A.max_row_nnz > 0 && (long long)A.max_row_nnz * W <= kWaveCap && (long long)A.nnz * W < (1ll << 31) &&
-            (unsigned long long)A.nnz * W * 12ull <= (16ull << 30)) {
+        if (ell_applies(A, P)) {
             // the right factor with W slots per row (MatmulEllExpander): valid when every row of A P takes the hash path
             Temp<int> EJ((size_t)P.nrows * W);
             Temp<double> Ea((size_t)P.nrows * W);
