@@ -233,6 +233,31 @@ def gauss_seidel_leg(args, la, np, dA, dPs, rhs, n_local, A, Ps):
             cg += 5
         gs["cpu_port_vcycles_per_s_1core"] = round(cg / (time.perf_counter() - t0), 1)
         gs["parity_rel_err_vs_oracle"] = float(np.max(np.abs(sol_gs.to_numpy() - xg)) / np.max(np.abs(xg)))
+    # hypre's Gauss-Seidel is Gauss-Seidel inside an MPI rank and Jacobi across ranks, so what the reference computes depends on the number of
+    # ranks it runs on; the figure above is ONE rank (the sequential loop, bit for bit).  The same cycle with the rows of every level cut
+    # into B contiguous blocks swept as B ranks would (elag_hip_set_gs_hybrid_blocks: tests/test_gpu_sweeps.py pins the sweep bit for bit
+    # against the oracle's loop on that partition), with what the example's PCG makes of each
+    def pcg_iterations(H):
+        K = la.KrylovSolver(dA, H, {"Solver name": "PCG", "Relative tolerance": 1e-6, "Absolute tolerance": 1e-6, "Maximum iterations": 200})
+        x = la.DeviceVector(n_local, 0.0)
+        K.Mult(rhs, x)
+        la.synchronize()
+        return int(K.GetNumIterations()), bool(K.GetConverged())
+    if A.shape[0] == n_local:
+        gs["pcg_iterations"] = pcg_iterations(Hgs)[0]
+        vr = {}
+        for B in args.gs_blocks:
+            la.set_gs_hybrid_blocks(B)
+            try:
+                Hb = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Gauss-Seidel", use_graph=not args.no_graph)
+            finally:
+                la.set_gs_hybrid_blocks(0)
+            sb = la.DeviceVector(n_local, 1.0)
+            ms_b = Hb.time_apply(rhs, sb, max(50, min(args.steps, 500)))
+            its, conv = pcg_iterations(Hb)
+            vr[str(B)] = {"device_ms_per_step": round(ms_b, 5), "vcycles_per_s": round(1e3 / ms_b, 1), "pcg_iterations": its, "pcg_converged": conv}
+            del Hb, sb
+        gs["virtual_ranks"] = vr
     note("L1 Gauss-Seidel cycle: %.4f ms" % ms_gs)
     return gs
 
@@ -435,6 +460,8 @@ def main():
     ap.add_argument("--force-large", action="store_true", help="with --force-dist: also run the GPU-filling workload of the multi-rank runs")
     ap.add_argument("--parity-max-dofs", type=int, default=1500000, help="multi-rank darcy/spe10: largest system for which the serial CPU "
                     "oracle's blocked cycle is run beside the distributed one")
+    ap.add_argument("--gs-blocks", type=int, nargs="*", default=[16, 256], help="the L1 Gauss-Seidel cycle is also timed with the sweeps on this many "
+                    "virtual ranks (hypre's hybrid Gauss-Seidel as the reference runs it on that many MPI ranks)")
     ap.add_argument("--launch-dry-run", action="store_true", help="start the ranks, report RANK / WORLD_SIZE of every child over a gloo "
                     "group and exit: exercises the launcher without a GPU")
     ap.add_argument("--large-refines", type=int, default=-1, help="--gpus N > 1: refinements of the second, GPU-filling 0-form workload "

@@ -251,6 +251,15 @@ ELAG_HIP_API int elag_hip_smoother_create(elag_hip_smoother_t *out, elag_hip_par
 /* Chebyshev: eigenvalue bounds of D^-1/2 A D^-1/2.  create() runs hypre_ParCSRMaxEigEstimateCG's
  * algorithm (10 CG-Lanczos steps, hypre RNG seed 1); set() injects bounds (parity of the sweep).  A hierarchy composes the
  * order-2 sweep into its level operators at Finalize: after set() on a smoother that sits in a finalised hierarchy, finalise again. */
+/* Hybrid Gauss-Seidel on "virtual ranks".  hypre's relax types 2 / 4 / 6 are Gauss-Seidel inside an MPI rank and Jacobi across ranks (the
+ * neighbours' values stay as they were when the symmetric sweep began: hypre_ParCSRRelax / hypre_BoomerAMGRelax; the reference picks them in
+ * src/linalg/factories/ParELAG_HypreSmootherFactory.cpp:92-109 and runs one rank per core), so what a sweep computes depends on how many ranks the
+ * reference runs on.  nblocks = 1 (the default; also ELAG_HIP_GS_BLOCKS) is one rank: the sequential loop, bit for bit.  nblocks > 1 makes the sweep
+ * smoothers created AFTER the call (elag_hip_smoother_create, elag_hip_hierarchy_build; rank-local operators) cut their rows into nblocks
+ * contiguous, even blocks -- rows [b*size + min(b, rest), ...), size = n / nblocks, rest = n % nblocks -- and sweep them as that many ranks would:
+ * the bits of the reference's loop on that row partition, with dependency chains nblocks times shorter.  Per host thread (like the library
+ * context); 0 restores the default. */
+ELAG_HIP_API int elag_hip_set_gs_hybrid_blocks(int nblocks);
 ELAG_HIP_API int elag_hip_smoother_get_eig_estimate(elag_hip_smoother_t S, double *max_eig, double *min_eig);
 ELAG_HIP_API int elag_hip_smoother_set_eig_estimate(elag_hip_smoother_t S, double max_eig, double min_eig);
 /* HiptmairSmoother(A, D, primary, auxiliary) (ParELAG_HiptmairSmoother.cpp:22-46); A_aux = D^T A D is owned

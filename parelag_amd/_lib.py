@@ -111,6 +111,7 @@ _SIGNATURES = {
     "elag_hip_smoother_create": [C.POINTER(_p), _p, _i, _i, _d, _d, _i, _d],
     "elag_hip_smoother_get_eig_estimate": [_p, _dp, _dp],
     "elag_hip_smoother_set_eig_estimate": [_p, _d, _d],
+    "elag_hip_set_gs_hybrid_blocks": [_i],
     "elag_hip_hiptmair_create": [C.POINTER(_p), _p, _p, _p, _p],
     "elag_hip_smoother_apply": [_p, _p, _p, _i, _i, _i],
     "elag_hip_smoother_destroy": [_p],

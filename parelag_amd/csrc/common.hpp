@@ -91,6 +91,7 @@ struct Context {
     double *reduce_part = nullptr;      // partial sums of the two-stage reductions
     double *d_scalar = nullptr;         // device scratch for reductions (16 doubles)
     double *h_scalar = nullptr;         // pinned mirror
+    int gs_blocks = 0;                  // elag_hip_set_gs_hybrid_blocks (0: ELAG_HIP_GS_BLOCKS, else 1)
     long long n_exchanges = 0, n_allreduces = 0;   // data-plane rounds issued by this rank (neighbour exchanges with a remote peer, device all-reduces)
 };
 Context &ctx();

@@ -540,6 +540,15 @@ int elag_hip_smoother_get_eig_estimate(elag_hip_smoother_t S, double *max_eig, d
     });
 }
 
+int elag_hip_set_gs_hybrid_blocks(int nblocks)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(nblocks >= 0, "elag_hip_set_gs_hybrid_blocks: nblocks must be >= 0 (got %d)", nblocks);
+        ctx().gs_blocks = nblocks;
+    });
+}
+
 int elag_hip_smoother_set_eig_estimate(elag_hip_smoother_t S, double max_eig, double min_eig)
 {
     return guarded([&] {

@@ -2,6 +2,7 @@
 // dense coarse solver.  Internally smoothers work on a ping-pong pair of device vectors so that the
 // Jacobi update never needs an extra copy pass.
 #pragma once
+#include <memory>
 #include <functional>
 #include <vector>
 
@@ -68,6 +69,14 @@ struct SweepSmoother : elag_hip_smoother_s {
     ~SweepSmoother() override;
     void setup();
     bool lds_u = false;                               // the operator's u fits the chain workgroup's LDS: every level is chained (sweep.hip)
+    // "virtual ranks" (elag_hip_set_gs_hybrid_blocks > 1, rank-local operators): the rows are cut into that many contiguous blocks and the
+    // sweep is hypre's hybrid Gauss-Seidel as the reference runs it on that many MPI ranks -- Gauss-Seidel inside a block, the other
+    // blocks' values frozen as they were when the symmetric sweep began.  As = the operator split like a ParCSR matrix on those ranks
+    // (diag: the block-diagonal part, offd: the rest, its columns numbered through d_self_ghost); M = what the sweep runs on
+    int blocks = 1;
+    std::unique_ptr<ParCSR> As;
+    int *d_self_ghost = nullptr;
+    ParCSR *M = nullptr;
     void launch_segment(const Segment &s, int dir, const double *f, double *u, bool sym = false);
     void apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose) override;
     int flips(bool) const override { return 0; }

@@ -342,9 +342,17 @@ __global__ void diag_scale_kernel(int n, const int *__restrict__ I, const int *_
     }
 }
 
+int gs_hybrid_blocks()
+{
+    // elag_hip_set_gs_hybrid_blocks, else ELAG_HIP_GS_BLOCKS, else 1 (one rank: the sequential loop)
+    if (ctx().gs_blocks > 0) return ctx().gs_blocks;
+    const char *e = getenv("ELAG_HIP_GS_BLOCKS");
+    return e && atoi(e) > 0 ? atoi(e) : 1;
+}
+
 }  // namespace
 
-SweepSmoother::~SweepSmoother() { dev_free(d_rows); dev_free(d_lev_ptr); dev_free(d_l1); dev_free(d_sJ); dev_free(d_sa); }
+SweepSmoother::~SweepSmoother() { dev_free(d_rows); dev_free(d_lev_ptr); dev_free(d_l1); dev_free(d_sJ); dev_free(d_sa); dev_free(d_self_ghost); }
 
 void SweepSmoother::setup()
 {
@@ -356,18 +364,62 @@ void SweepSmoother::setup()
     if (!kaczmarz && (weight != 1.0 || (omega != 1.0 && type == ELAG_HIP_SMOOTHER_GS)))
         fail(ELAG_HIP_ERR_ARG, "relax type %d: \"Damping Factor\" must be 1.0 (and \"Omega\" 1.0 for \"Gauss-Seidel\"): hypre's SSOR branches are "
              "not built; got %g / %g", type, weight, omega);
+    M = A;
     const int n = A->nrows();
     hipStream_t st = ctx().stream;
+    As.reset(); dev_free(d_self_ghost); d_self_ghost = nullptr;
+    blocks = gs_hybrid_blocks();
+    if (blocks > 1 && !kaczmarz && !is_distributed(*A) && A->nrows() == A->ncols() && n >= 2 * blocks) {
+        // ---- virtual ranks: A split like a ParCSR matrix on `blocks` ranks with contiguous, even row blocks ----
+        std::vector<int> I = host_from_dev(A->diag.I, (size_t)n + 1), J = host_from_dev(A->diag.J, (size_t)A->diag.nnz);
+        std::vector<double> a = host_from_dev(A->diag.a, (size_t)A->diag.nnz);
+        const int size = n / blocks, rest = n - size * blocks;
+        std::vector<int> block_of((size_t)n);
+        for (int b = 0, r = 0; b < blocks; b++) {
+            const int len = size + (b < rest ? 1 : 0);
+            for (int q = 0; q < len; q++) block_of[(size_t)r++] = b;
+        }
+        std::vector<int> dI((size_t)n + 1, 0), oI((size_t)n + 1, 0), dJ, oJ;
+        std::vector<double> da, oa;
+        std::vector<char> is_ghost((size_t)n, 0);
+        for (int i = 0; i < n; i++)
+            for (int k = I[(size_t)i]; k < I[(size_t)i + 1]; k++)
+                if (block_of[(size_t)J[(size_t)k]] != block_of[(size_t)i]) is_ghost[(size_t)J[(size_t)k]] = 1;
+        std::vector<int> ghost_id((size_t)n, -1), ghost_col;
+        for (int j = 0; j < n; j++)
+            if (is_ghost[(size_t)j]) { ghost_id[(size_t)j] = (int)ghost_col.size(); ghost_col.push_back(j); }
+        for (int i = 0; i < n; i++) {
+            for (int k = I[(size_t)i]; k < I[(size_t)i + 1]; k++) {
+                const int j = J[(size_t)k];
+                if (block_of[(size_t)j] == block_of[(size_t)i]) { dJ.push_back(j); da.push_back(a[(size_t)k]); }
+                else { oJ.push_back(ghost_id[(size_t)j]); oa.push_back(a[(size_t)k]); }
+            }
+            dI[(size_t)i + 1] = (int)dJ.size(); oI[(size_t)i + 1] = (int)oJ.size();
+        }
+        if (!ghost_col.empty()) {
+            As.reset(new ParCSR());
+            As->diag.upload(n, n, dI.data(), dJ.data(), da.data());
+            As->offd.upload(n, (int)ghost_col.size(), oI.data(), oJ.data(), oa.data());
+            As->d_ghost = dev_alloc<double>(ghost_col.size());
+            As->first_row = As->first_col = 0; As->global_rows = As->global_cols = n;
+            d_self_ghost = dev_from_host(ghost_col.data(), ghost_col.size());
+            M = As.get();
+        } else {
+            blocks = 1;
+        }
+    } else {
+        blocks = 1;
+    }
     if (type != ELAG_HIP_SMOOTHER_GS) {
         // mfem::HypreSmoother::SetOperator: l1_norms = hypre_ParCSRComputeL1Norms(A, type) for types 1..4 (3: the rows' squared 2-norms)
         Temp<int> bad(1);
         ELAG_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), st));
         d_l1 = dev_alloc<double>((size_t)std::max(n, 1));
         if (n) {
-            const bool ho = A->offd.nnz > 0;
+            const bool ho = M->offd.nnz > 0;
             const unsigned g = (unsigned)std::min<long long>(((long long)n + 255) / 256, 2048);
-            hipLaunchKernelGGL(l1_norms_ordered_kernel, dim3(g), dim3(256), 0, st, n, (const int *)A->diag.I, (const int *)A->diag.J,
-                               (const double *)A->diag.a, ho ? (const int *)A->offd.I : nullptr, ho ? (const double *)A->offd.a : nullptr, type,
+            hipLaunchKernelGGL(l1_norms_ordered_kernel, dim3(g), dim3(256), 0, st, n, (const int *)M->diag.I, (const int *)M->diag.J,
+                               (const double *)M->diag.a, ho ? (const int *)M->offd.I : nullptr, ho ? (const double *)M->offd.a : nullptr, type,
                                d_l1, bad.p);                     // (option = relax type: 2, 3 or 4)
             ELAG_LAUNCH_CHECK();
         }
@@ -377,15 +429,15 @@ void SweepSmoother::setup()
         if (nbad) fail(ELAG_HIP_ERR_NUMERIC, "%s: matrix has %d zero l1 row norm(s)", kaczmarz ? "Kaczmarz" : "l1 Gauss-Seidel", nbad);
     }
     // ---- dependency levels of the symmetrised pattern, one pass over the rows ----
-    std::vector<int> I = host_from_dev(A->diag.I, (size_t)n + 1);
-    std::vector<int> J = host_from_dev(A->diag.J, (size_t)A->diag.nnz);
+    std::vector<int> I = host_from_dev(M->diag.I, (size_t)n + 1);
+    std::vector<int> J = host_from_dev(M->diag.J, (size_t)M->diag.nnz);
     std::vector<int> level((size_t)n, 0);     // doubles as "pending" for rows not reached yet
     int nlev = n ? 1 : 0;
     if (kaczmarz) {
         // a Kaczmarz step reads AND writes u on the columns of its row: two rows are ordered iff they share a local column.
         //     level(i) = 1 + max { level(k) : k < i, rows i and k share a column }
         // through the highest level seen so far on every column; the rows of a level then share no column at all.
-        std::vector<int> col_level((size_t)std::max(A->diag.ncols, 1), -1), seen((size_t)std::max(A->diag.ncols, 1), -1);
+        std::vector<int> col_level((size_t)std::max(M->diag.ncols, 1), -1), seen((size_t)std::max(M->diag.ncols, 1), -1);
         for (int i = 0; i < n; i++) {
             int lv = 0;
             for (int k = I[(size_t)i]; k < I[(size_t)i + 1]; k++) {
@@ -480,8 +532,8 @@ void SweepSmoother::setup()
     d_sa = dev_alloc<double>((size_t)std::max(n, 1) * kLPR);
     if (n) {
         const unsigned g = (unsigned)std::min<long long>(((long long)n * kLPR + 255) / 256, 4096);
-        hipLaunchKernelGGL(sched_pack_kernel, dim3(g), dim3(256), 0, st, n, reinterpret_cast<const int4s *>(d_rows), (const int *)A->diag.J,
-                           (const double *)A->diag.a, d_sJ, d_sa);
+        hipLaunchKernelGGL(sched_pack_kernel, dim3(g), dim3(256), 0, st, n, reinterpret_cast<const int4s *>(d_rows), (const int *)M->diag.J,
+                           (const double *)M->diag.a, d_sJ, d_sa);
         ELAG_LAUNCH_CHECK();
     }
     n_steps = (int)step_ptr.size() - 1;
@@ -496,13 +548,13 @@ void SweepSmoother::setup()
 void SweepSmoother::launch_segment(const Segment &s, int dir, const double *f, double *u, bool sym)
 {
     hipStream_t st = ctx().stream;
-    const bool ho = A->offd.nnz > 0;
-    const int *oI = ho ? A->offd.I : nullptr, *oJ = ho ? A->offd.J : nullptr;
-    const double *oa = ho ? A->offd.a : nullptr;
+    const bool ho = M->offd.nnz > 0;
+    const int *oI = ho ? M->offd.I : nullptr, *oJ = ho ? M->offd.J : nullptr;
+    const double *oa = ho ? M->offd.a : nullptr;
     const int4s *sched = reinterpret_cast<const int4s *>(d_rows);
     const double *dd = (type == ELAG_HIP_SMOOTHER_GS) ? nullptr : d_l1;
-    const int *lev = d_lev_ptr, *Jd = A->diag.J;
-    const double *ad = A->diag.a, *ug = A->d_ghost;
+    const int *lev = d_lev_ptr, *Jd = M->diag.J;
+    const double *ad = M->diag.a, *ug = M->d_ghost;
     if (s.max_rows > 0) {
         // one big level (all its steps as one range): enough workgroups for one row per lane group
         const unsigned grid = (unsigned)(((long long)s.max_rows * kLPR + kWideBlock - 1) / kWideBlock);
@@ -515,7 +567,7 @@ void SweepSmoother::launch_segment(const Segment &s, int dir, const double *f, d
         else go(sweep_levels_kernel<0>);
     } else {
         const int s_first = dir > 0 ? s.first : s.first + s.count - 1;
-        const int n = A->nrows();
+        const int n = M->nrows();
         const size_t lds = lds_u ? sizeof(double) * (size_t)n : 0;
         auto go = [&](auto kern) {
             if (lds > (size_t)(48 << 10)) {
@@ -545,11 +597,12 @@ void SweepSmoother::launch_segment(const Segment &s, int dir, const double *f, d
 
 void SweepSmoother::apply(const double *f, double *&cur, double *&, bool zero_guess, bool /*transpose: the symmetric sweep is self-adjoint*/)
 {
-    const int n = A->nrows();
+    const int n = M->nrows();
     if (zero_guess) k::vec_fill(n, 0.0, cur);
     for (int sw = 0; sw < sweeps; sw++) {
         // "Copy off-diag values of u to the current processor": once per symmetric sweep
-        if (A->needs_exchange()) par_halo_exchange(*A, cur);
+        if (As) k::vec_gather(As->offd.ncols, d_self_ghost, cur, As->d_ghost);        // (virtual ranks: the other blocks' values, frozen here)
+        else if (M->needs_exchange()) par_halo_exchange(*M, cur);
         if (lds_u && segments.size() == 1 && segments[0].max_rows == 0) {
             launch_segment(segments[0], +1, f, cur, true);        // forward then backward in one launch, u in LDS throughout
             continue;

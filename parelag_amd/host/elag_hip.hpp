@@ -29,6 +29,8 @@ inline void check(int status)
 
 inline void Init(int device = 0) { check(elag_hip_init(device)); }
 inline void Synchronize() { check(elag_hip_synchronize()); }
+// hybrid Gauss-Seidel of the smoothers created from here on as the reference runs it on `nblocks` ranks (1: the sequential loop)
+inline void SetGaussSeidelHybridBlocks(int nblocks) { check(elag_hip_set_gs_hybrid_blocks(nblocks)); }
 
 // Minimal solver base with mfem::Solver's iterative_mode / parelag::Solver::IsPreconditioner
 // (src/linalg/solver_core/ParELAG_Solver.hpp:57-103).

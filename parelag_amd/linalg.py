@@ -93,6 +93,13 @@ def _same_loc(*locs):
     return locs[0]
 
 
+def set_gs_hybrid_blocks(nblocks: int):
+    """Sweep smoothers ("L1 Gauss-Seidel", "Gauss-Seidel", ...) created after this call treat ``nblocks`` contiguous row blocks as ranks:
+    hypre's hybrid Gauss-Seidel as the reference runs it on that many MPI ranks (``elag_hip_set_gs_hybrid_blocks``); 1 = the sequential
+    loop (default), 0 = back to the default / ``ELAG_HIP_GS_BLOCKS``."""
+    check(_lib.init().elag_hip_set_gs_hybrid_blocks(int(nblocks)))
+
+
 def synchronize():
     check(_lib.init().elag_hip_synchronize())
 

@@ -252,6 +252,74 @@ def test_distributed_sweep_freezes_the_ghost_values(h1_k2, relax_type, world):
         assert np.array_equal(res[r], ug[lo:hi])
 
 
+@pytest.mark.parametrize("relax_type", [2, 4, 6])
+@pytest.mark.parametrize("blocks", [2, 7, 64])
+def test_virtual_ranks_are_the_reference_s_sweep_on_that_many_ranks(la, h1_k2, relax_type, blocks):
+    """elag_hip_set_gs_hybrid_blocks(B): ONE device rank cuts its rows into B contiguous, even blocks and sweeps them as B MPI ranks would --
+    Gauss-Seidel inside a block, the other blocks' values frozen as they were when the symmetric sweep began.  Bit for bit the oracle's loop
+    run block by block on that partition with exactly those frozen values (two sweeps: the second sees the neighbours' first); B = 1 is the
+    sequential loop again."""
+    import scipy.sparse as sp
+    A = orc.diag_first(h1_k2[0])
+    n = A.shape[0]
+    size, rest = n // blocks, n % blocks
+    starts = np.array([b * size + min(b, rest) for b in range(blocks + 1)])
+    rng = np.random.default_rng(17)
+    f, u0 = rng.standard_normal(n), rng.standard_normal(n)
+    la.set_gs_hybrid_blocks(blocks)
+    try:
+        S = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), relax_type, {"Sweeps": 2})
+    finally:
+        la.set_gs_hybrid_blocks(0)
+    u = u0.copy()
+    S.Mult(f, u)
+    # the oracle, rank by rank: rows of block b, columns split into the block's own (diag) and the others' (offd, ascending)
+    Ac = sp.csr_matrix(A)
+    block_of = np.repeat(np.arange(blocks), np.diff(starts))
+
+    class Frozen(orc.SerialExchange):
+        def __init__(self, cols):
+            self.cols, self.u = cols, None
+
+        def forward(self, pkg, send_buf):
+            return self.u[self.cols]
+    sm, ex = [], []
+    for b in range(blocks):
+        lo, hi = int(starts[b]), int(starts[b + 1])
+        rows = Ac[lo:hi].tocsr()
+        own = (rows.indices >= lo) & (rows.indices < hi)
+        rr = np.repeat(np.arange(hi - lo), np.diff(rows.indptr))
+        cnt_d = np.bincount(rr[own], minlength=hi - lo); cnt_o = np.bincount(rr[~own], minlength=hi - lo)
+        diag = sp.csr_matrix((rows.data[own], rows.indices[own] - lo, np.concatenate([[0], np.cumsum(cnt_d)])), shape=(hi - lo, hi - lo))
+        col_map = np.unique(rows.indices[~own])
+        offd = sp.csr_matrix((rows.data[~own], np.searchsorted(col_map, rows.indices[~own]), np.concatenate([[0], np.cumsum(cnt_o)])),
+                             shape=(hi - lo, len(col_map)))
+        part = dict(diag=diag, offd=offd, col_map_offd=col_map.astype(np.int64), first_row=lo, first_col=lo, global_shape=A.shape,
+                    recv_procs=np.zeros(0, np.int32), recv_starts=np.zeros(1, np.int32), send_procs=np.zeros(0, np.int32),
+                    send_starts=np.zeros(1, np.int32), send_elmts=np.zeros(0, np.int32))
+        e = Frozen(col_map)
+        ex.append(e)
+        sm.append(orc.OSmoother(orc.oparcsr_from_part(part, e), type=relax_type, sweeps=1))
+    ug = u0.copy()
+    for _ in range(2):
+        for e in ex:
+            e.u = ug.copy()
+        new = ug.copy()
+        for b in range(blocks):
+            lo, hi = int(starts[b]), int(starts[b + 1])
+            loc = ug[lo:hi].copy()
+            sm[b].Mult(f[lo:hi], loc)
+            new[lo:hi] = loc
+        ug = new
+    assert np.array_equal(u, ug)
+    # one block: the sequential loop
+    S1 = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), relax_type, {"Sweeps": 2})
+    u1, us = u0.copy(), u0.copy()
+    S1.Mult(f, u1)
+    orc.OSmoother(orc.OParCSR(A), type=relax_type, sweeps=2).Mult(f, us)
+    assert np.array_equal(u1, us) and not np.array_equal(u1, u)
+
+
 @pytest.mark.parametrize("relax_type", [2, 4])
 def test_l1_gauss_seidel_with_omega(la, h1_k2, relax_type):
     """relax_weight = 1, omega != 1: u_i += omega * res / l1_i in both directions (hypre_ParCSRRelax 2 / 4)"""
