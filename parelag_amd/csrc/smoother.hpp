@@ -76,6 +76,7 @@ struct SweepSmoother : elag_hip_smoother_s {
     int blocks = 1;
     std::unique_ptr<ParCSR> As;
     int *d_self_ghost = nullptr;
+    int *d_blk_first = nullptr, *d_blk_count = nullptr;    // per block: its first step and its number of steps (a workgroup per block walks them)
     ParCSR *M = nullptr;
     void launch_segment(const Segment &s, int dir, const double *f, double *u, bool sym = false);
     void apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose) override;

@@ -169,10 +169,15 @@ __global__ __launch_bounds__(kChainBlock) void sweep_chain_kernel(const int *__r
                                                                   const int4s *__restrict__ sched, const int *__restrict__ J, const double *__restrict__ a,
                                                                   const int *__restrict__ oI, const int *__restrict__ oJ, const double *__restrict__ oa,
                                                                   const double *__restrict__ f, const double *__restrict__ d, const double *__restrict__ ug,
-                                                                  double omega, double *u, int n, int sym)
+                                                                  double omega, double *u, int n, int sym, const int *__restrict__ blk_first,
+                                                                  const int *__restrict__ blk_count)
 {
     __shared__ int lp[kMaxChain + 1];
     extern __shared__ double ul[];          // LDSU: u[0 .. n)
+    // virtual ranks (SweepSmoother::blocks > 1): a workgroup per block, each walking the steps of ITS rows -- the blocks share nothing during a
+    // sweep (the diagonal part of the split operator is block diagonal, the other blocks' values are the frozen ghosts)
+    if (blk_first) { s_first = blk_first[blockIdx.x]; s_count = blk_count[blockIdx.x]; }
+    if (s_count <= 0) return;
     const int s_lo = dir0 > 0 ? s_first : s_first - (s_count - 1);
     // (top bit: this step is the first one of its dependency level)
     for (int c = threadIdx.x; c <= s_count; c += kChainBlock) lp[c] = step_ptr[s_lo + c] | (step_first[s_lo + c] ? (int)0x80000000 : 0);
@@ -352,7 +357,7 @@ int gs_hybrid_blocks()
 
 }  // namespace
 
-SweepSmoother::~SweepSmoother() { dev_free(d_rows); dev_free(d_lev_ptr); dev_free(d_l1); dev_free(d_sJ); dev_free(d_sa); dev_free(d_self_ghost); }
+SweepSmoother::~SweepSmoother() { dev_free(d_rows); dev_free(d_lev_ptr); dev_free(d_l1); dev_free(d_sJ); dev_free(d_sa); dev_free(d_self_ghost); dev_free(d_blk_first); dev_free(d_blk_count); }
 
 void SweepSmoother::setup()
 {
@@ -368,13 +373,15 @@ void SweepSmoother::setup()
     const int n = A->nrows();
     hipStream_t st = ctx().stream;
     As.reset(); dev_free(d_self_ghost); d_self_ghost = nullptr;
+    dev_free(d_blk_first); dev_free(d_blk_count); d_blk_first = d_blk_count = nullptr;
+    std::vector<int> block_of;
     blocks = gs_hybrid_blocks();
     if (blocks > 1 && !kaczmarz && !is_distributed(*A) && A->nrows() == A->ncols() && n >= 2 * blocks) {
         // ---- virtual ranks: A split like a ParCSR matrix on `blocks` ranks with contiguous, even row blocks ----
         std::vector<int> I = host_from_dev(A->diag.I, (size_t)n + 1), J = host_from_dev(A->diag.J, (size_t)A->diag.nnz);
         std::vector<double> a = host_from_dev(A->diag.a, (size_t)A->diag.nnz);
         const int size = n / blocks, rest = n - size * blocks;
-        std::vector<int> block_of((size_t)n);
+        block_of.assign((size_t)n, 0);
         for (int b = 0, r = 0; b < blocks; b++) {
             const int len = size + (b < rest ? 1 : 0);
             for (int q = 0; q < len; q++) block_of[(size_t)r++] = b;
@@ -464,14 +471,30 @@ void SweepSmoother::setup()
             if (j > i && j < n) level[(size_t)j] = std::max(level[(size_t)j], lv + 1);
         }
     }
-    std::vector<int> ptr((size_t)nlev + 1, 0), rows((size_t)n);
-    for (int i = 0; i < n; i++) ptr[(size_t)level[(size_t)i] + 1]++;
+    num_levels = nlev;
+    // Virtual ranks: the blocks share nothing during a sweep, so each gets a chain of its own -- rows ordered by (block, level), a "level" below
+    // being one block's rows of one dependency level -- and ONE launch of a workgroup per block walks all of them, forward and backward
+    // (ELAG_HIP_SWEEP_BLOCK_CHAINS=0: the blocks' levels side by side in the common schedule, one launch or chain step per level)
+    // Measured on MI355X (cube456 x3 L1 Gauss-Seidel cycle, V-cycles/s, chains / common schedule): B = 8: 680 / 1 011, 16: 1 108 / 1 179,
+    // 32: 1 562 / 1 294, 128: 2 557 / 1 763, 256: 3 012 / 1 979, 512: 2 760 / 2 417, 2 048: 1 638 / 4 091 -- a chain per block pays while a block
+    // is not a long chain of its own (few blocks: few CUs at work) and the blocks are not thousands of workgroups for a handful of rows each:
+    // blocks of at most 2 048 rows, at most 512 of them (1 024: 2 127 / ~3 000).  ELAG_HIP_SWEEP_BLOCK_CHAINS = 0 / 1 forces either.
+    bool block_chains = false;
+    if (As && nlev > 0 && (long long)blocks * nlev < (1ll << 27)) {
+        const char *e = getenv("ELAG_HIP_SWEEP_BLOCK_CHAINS");
+        const int per_block = n / blocks;
+        block_chains = e ? atoi(e) != 0 : (per_block <= 2048 && blocks <= 512);
+    }
+    const int nkeys = block_chains ? blocks * nlev : nlev;
+    auto key_of = [&](int i) { return block_chains ? block_of[(size_t)i] * nlev + level[(size_t)i] : level[(size_t)i]; };
+    std::vector<int> ptr((size_t)nkeys + 1, 0), rows((size_t)n);
+    for (int i = 0; i < n; i++) ptr[(size_t)key_of(i) + 1]++;
     std::partial_sum(ptr.begin(), ptr.end(), ptr.begin());
     {
         std::vector<int> cur(ptr.begin(), ptr.end() - 1);
-        for (int i = 0; i < n; i++) rows[(size_t)cur[(size_t)level[(size_t)i]]++] = i;   // ascending row inside a level
+        for (int i = 0; i < n; i++) rows[(size_t)cur[(size_t)key_of(i)]++] = i;   // ascending row inside a level
     }
-    num_levels = nlev;
+    nlev = nkeys;                              // (from here on a "level" is a key)
     // steps: every level cut into pieces of at most kStepRows rows (the rows of a level are independent, so the pieces may run
     // one after the other); a segment is either one big level -- all its steps as ONE multi-workgroup launch -- or a run of
     // small levels whose steps the chain workgroup walks
@@ -507,7 +530,25 @@ void SweepSmoother::setup()
     }
     const int cr = lds_u ? kMaxChain * kStepRows : chain_rows;
     segments.clear();
-    for (int l = 0; l < nlev;) {
+    if (block_chains) {
+        std::vector<int> bf((size_t)blocks), bc((size_t)blocks);
+        int longest = 0;
+        for (int b = 0; b < blocks; b++) {
+            bf[(size_t)b] = first_step[(size_t)b * num_levels];
+            bc[(size_t)b] = first_step[(size_t)(b + 1) * num_levels] - bf[(size_t)b];
+            longest = std::max(longest, bc[(size_t)b]);
+        }
+        if (longest <= kMaxChain) {
+            d_blk_first = dev_from_host(bf.data(), bf.size());
+            d_blk_count = dev_from_host(bc.data(), bc.size());
+            lds_u = false;
+            segments.push_back(Segment{0, (int)step_ptr.size() - 1, -1, 0, 0});      // max_rows < 0: a workgroup per block
+        } else {
+            fail(ELAG_HIP_ERR_ARG, "Gauss-Seidel on %d virtual ranks: a block's chain has %d steps (at most %d): use more blocks or ELAG_HIP_SWEEP_BLOCK_CHAINS=0",
+                 blocks, longest, kMaxChain);          // (blocks of at most 2 048 rows cannot get here unless the chains were forced)
+        }
+    }
+    for (int l = 0; l < nlev && !block_chains;) {
         const int sz = ptr[(size_t)l + 1] - ptr[(size_t)l];
         if (sz > cr) { segments.push_back(Segment{first_step[(size_t)l], first_step[(size_t)l + 1] - first_step[(size_t)l], sz, ptr[(size_t)l], ptr[(size_t)l + 1]}); l++; continue; }
         int m = l;
@@ -555,6 +596,18 @@ void SweepSmoother::launch_segment(const Segment &s, int dir, const double *f, d
     const double *dd = (type == ELAG_HIP_SMOOTHER_GS) ? nullptr : d_l1;
     const int *lev = d_lev_ptr, *Jd = M->diag.J;
     const double *ad = M->diag.a, *ug = M->d_ghost;
+    if (s.max_rows < 0) {
+        // virtual ranks: a workgroup per block, the symmetric sweep in one launch
+        const int n = M->nrows();
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kChainBlock), 0, st, lev, lev + n_steps + 1, 0, 0, +1, sched, Jd, ad, oI, oJ, oa, f, dd, ug, omega, u,
+                               n, 1, (const int *)d_blk_first, (const int *)d_blk_count);
+        };
+        if (type == ELAG_HIP_SMOOTHER_GS) go(sweep_chain_kernel<1, false>);
+        else go(sweep_chain_kernel<0, false>);
+        ELAG_LAUNCH_CHECK();
+        return;
+    }
     if (s.max_rows > 0) {
         // one big level (all its steps as one range): enough workgroups for one row per lane group
         const unsigned grid = (unsigned)(((long long)s.max_rows * kLPR + kWideBlock - 1) / kWideBlock);
@@ -580,7 +633,7 @@ void SweepSmoother::launch_segment(const Segment &s, int dir, const double *f, d
                 }
             }
             hipLaunchKernelGGL(kern, dim3(1), dim3(kChainBlock), lds, st, lev, lev + n_steps + 1, s_first, s.count, dir, sched, Jd, ad, oI, oJ, oa, f, dd, ug, omega, u,
-                               n, sym ? 1 : 0);
+                               n, sym ? 1 : 0, (const int *)nullptr, (const int *)nullptr);
         };
         if (lds_u) {
             if (type == ELAG_HIP_SMOOTHER_GS) go(sweep_chain_kernel<1, true>);
@@ -603,6 +656,7 @@ void SweepSmoother::apply(const double *f, double *&cur, double *&, bool zero_gu
         // "Copy off-diag values of u to the current processor": once per symmetric sweep
         if (As) k::vec_gather(As->offd.ncols, d_self_ghost, cur, As->d_ghost);        // (virtual ranks: the other blocks' values, frozen here)
         else if (M->needs_exchange()) par_halo_exchange(*M, cur);
+        if (segments.size() == 1 && segments[0].max_rows < 0) { launch_segment(segments[0], +1, f, cur, true); continue; }
         if (lds_u && segments.size() == 1 && segments[0].max_rows == 0) {
             launch_segment(segments[0], +1, f, cur, true);        // forward then backward in one launch, u in LDS throughout
             continue;
