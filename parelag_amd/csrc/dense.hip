@@ -248,6 +248,49 @@ __global__ void dense_level_u_kernel(int n, const int *__restrict__ UI, const in
 }
 }  // namespace
 
+namespace {
+// out (nr x m, row-major) = (ident ? I : 0) + beta * out + alpha * (S X): one thread per entry, the row's terms in storage order
+__global__ void csr_times_dense_kernel(int nr, int m, const int *__restrict__ SI, const int *__restrict__ SJ, const double *__restrict__ Sa, double alpha,
+                                       const double *__restrict__ X, double beta, int ident, double *__restrict__ out)
+{
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long long)nr * m) return;
+    const int i = (int)(id / m), c = (int)(id % m);
+    double s = 0.0;
+    for (int q = SI[i]; q < SI[i + 1]; q++) s += Sa[q] * X[(size_t)SJ[q] * m + c];
+    double v = alpha * s + (ident && i == c ? 1.0 : 0.0);
+    if (beta != 0.0) v += beta * out[id];
+    out[id] = v;
+}
+// out (nr x m) = M (nr x nk, row-major) X (nk x m)
+__global__ void dense_mm_kernel(int nr, int nk, int m, const double *__restrict__ M, const double *__restrict__ X, double *__restrict__ out)
+{
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long long)nr * m) return;
+    const int i = (int)(id / m), c = (int)(id % m);
+    double s = 0.0;
+    for (int q = 0; q < nk; q++) s += M[(size_t)i * nk + q] * X[(size_t)q * m + c];
+    out[id] = s;
+}
+}  // namespace
+
+void csr_times_dense(const DevCSR &S, int m, double alpha, const double *X, double beta, bool add_identity, double *out)
+{
+    const long long tot = (long long)S.nrows * m;
+    if (tot == 0) return;
+    hipLaunchKernelGGL(csr_times_dense_kernel, dim3((unsigned)((tot + kB - 1) / kB)), dim3(kB), 0, ctx().stream, S.nrows, m, (const int *)S.I, (const int *)S.J,
+                       (const double *)S.a, alpha, X, beta, add_identity ? 1 : 0, out);
+    ELAG_LAUNCH_CHECK();
+}
+
+void dense_mm(int nr, int nk, int m, const double *M, const double *X, double *out)
+{
+    const long long tot = (long long)nr * m;
+    if (tot == 0) return;
+    hipLaunchKernelGGL(dense_mm_kernel, dim3((unsigned)((tot + kB - 1) / kB)), dim3(kB), 0, ctx().stream, nr, nk, m, M, X, out);
+    ELAG_LAUNCH_CHECK();
+}
+
 void dense_times_csr_t(int nc, int n, const double *Bc, const DevCSR &GT, double *X)
 {
     ELAG_REQUIRE(GT.nrows == n && GT.ncols == nc, "internal: dense_times_csr_t shape");

@@ -262,7 +262,22 @@ struct elag_hip_hierarchy_s {
         if (n == 0) return;
         hipStream_t st = ctx().stream;
         if (dense_tail_by_recursion(L)) { dense_level = L; return; }
-        // general levels: column j of B = sub-cycle applied to e_j; stored transposed first (one contiguous row per application)
+        if (dense_tail_by_sweeps(L)) { dense_level = L; return; }
+        // general levels: column j of B = sub-cycle applied to e_j -- n applications of the sub-cycle, which must not cost more than the tail
+        // will ever give back: with Gauss-Seidel sweeps (a dependency level per ~2 us step) 840 applications were 266 ms of a 284 ms
+        // Finalize at cube456 x3 for 0.25 ms per cycle, against 15 ms for the example's whole PCG solve.  Priced in dependent device steps
+        // (smoother.hpp, chain_cost); ELAG_HIP_DENSE_TAIL_STEPS (default 60 000, ~0.1 s) is the most the loop may take.
+        {
+            static long long budget = -1;
+            if (budget < 0) { const char *e = getenv("ELAG_HIP_DENSE_TAIL_STEPS"); budget = e ? atoll(e) : 60000; }
+            double steps = 2.0;                                  // (the coarse solve)
+            for (int l = L; l < nl - 1; l++) {
+                const Level &F = lev[(size_t)l];
+                steps += (F.pre ? F.pre->chain_cost() : 0.0) + (F.post ? F.post->chain_cost() : 0.0) + 4.0;
+            }
+            if ((double)n * steps > (double)budget) return;
+        }
+        // stored transposed first (one contiguous row per application)
         double *Bt = dev_alloc<double>((size_t)n * n);
         Temp<double> ej((size_t)n);
         ELAG_HIP_CHECK(hipMemsetAsync(ej, 0, sizeof(double) * (size_t)n, st));
@@ -276,6 +291,38 @@ struct elag_hip_hierarchy_s {
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
         dev_free(Bt);
         dense_level = L;
+    }
+
+    // Gauss-Seidel levels: the sweeps are linear too, and a sweep on n right-hand sides at once is n columns per dependency level instead of n
+    // sweeps -- with one level above a dense coarse inverse,
+    //   X1 = S(I; 0),   X2 = X1 + P Minv P^T (I - A X1),   B = S(I; X2)          (S(F; X0): the symmetric sweep on F from X0)
+    // a few hundred small launches where 840 applications of the sub-cycle were 266 ms of a 284 ms Finalize (cube456 x3).
+    bool dense_tail_by_sweeps(int L)
+    {
+        const int nl = (int)lev.size();
+        const char *en = getenv("ELAG_HIP_DENSE_TAIL_SWEEPS");            // (read at every Finalize)
+        if ((en && !atoi(en)) || L != nl - 2 || !coarse || coarse->custom_apply || coarse->replicated || !coarse->Minv) return false;
+        Level &F = lev[(size_t)L];
+        Level &C = lev[(size_t)L + 1];
+        SweepSmoother *pre = dynamic_cast<SweepSmoother *>(F.pre), *post = dynamic_cast<SweepSmoother *>(F.post);
+        if (!pre || !post || pre->A != F.A || post->A != F.A || F.A->needs_exchange() || C.P->needs_exchange()) return false;
+        const int n = F.A->nrows(), nc = coarse->n;
+        if (nc != C.A->nrows() || C.P->nrows() != n || C.P->ncols() != nc) return false;
+        double *B = dev_alloc<double>((size_t)n * n);
+        if (!pre->apply_dense(nullptr, B, n, true)) { dev_free(B); return false; }
+        {
+            Temp<double> R((size_t)n * n), T1((size_t)nc * n), T2((size_t)nc * n);
+            k::csr_times_dense(F.A->diag, n, -1.0, B, 0.0, true, R);               // R = I - A X1
+            C.P->ensure_transpose();
+            k::csr_times_dense(*C.P->diagT, n, 1.0, R, 0.0, false, T1);            // T1 = P^T R
+            k::dense_mm(nc, nc, n, coarse->Minv, T1, T2);                          // T2 = Minv T1
+            k::csr_times_dense(C.P->diag, n, 1.0, T2, 1.0, false, B);              // X2 = X1 + P T2
+            ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));                    // (the scratch goes out of scope)
+        }
+        if (!post->apply_dense(nullptr, B, n, false)) { dev_free(B); return false; }
+        ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+        Bdense = B;
+        return true;
     }
 
     // The dense operator of the sub-cycle from level L down, level by level from the bottom, when every level on the way is one of the

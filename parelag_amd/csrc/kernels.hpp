@@ -186,6 +186,9 @@ void dense_transpose(int n, const double *in, double *out);                     
 //   dense_times_csr_t : X (nc x n) = Bc GT^T, GT = G^T in CSR (n rows), one thread per entry of X;
 //   dense_level_op    : B = rs . (V X) + U-part, rs_i = vw ? -vw_i : 1;  U-part: U given -> B += U;  else (A, w) -> B += 2 diag(w) - diag(w) A diag(w)
 void dense_times_csr_t(int nc, int n, const double *Bc, const DevCSR &GT, double *X);
+// dense blocks of m columns, row-major: out = (add_identity ? I : 0) + beta out + alpha S X;  out = M X
+void csr_times_dense(const DevCSR &S, int m, double alpha, const double *X, double beta, bool add_identity, double *out);
+void dense_mm(int nr, int nk, int m, const double *M, const double *X, double *out);
 void dense_level_op(int n, int nc, const DevCSR &V, const double *vw, const double *X, const DevCSR *U, const DevCSR *A, const double *w, double *B);
 // Minv (n x n row-major, device) = A^-1 for a general square CSR (Gauss-Jordan, partial pivoting); throws when singular
 void dense_inverse_general(const DevCSR &A, double *Minv);

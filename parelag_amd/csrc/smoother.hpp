@@ -21,6 +21,9 @@ struct elag_hip_smoother_s {
     virtual const double *diag_scaling() const { return nullptr; }
     // identifies smoothers that are the same operator (same W): type/weight for the relaxations
     virtual bool same_scaling_as(const elag_hip_smoother_s *o) const { return o == this; }
+    // roughly how many dependent device steps (~2 us each) one apply() is: a launch for most smoothers, a dependency level for the
+    // sweeps -- what the hierarchy prices a sub-cycle with before it builds a dense tail out of n applications of it
+    virtual double chain_cost() const { return 2.0; }
     int n() const { return A->nrows(); }
 };
 
@@ -81,6 +84,13 @@ struct SweepSmoother : elag_hip_smoother_s {
     void launch_segment(const Segment &s, int dir, const double *f, double *u, bool sym = false);
     void apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose) override;
     int flips(bool) const override { return 0; }
+    int longest_chain = 0;                            // steps of the longest per-block chain (virtual ranks with a workgroup per block)
+    // the sweeps applied to m right-hand sides at once (X, F: n x m row-major; F == nullptr: the identity, m == n): what the hierarchy builds
+    // the dense operator of its smallest levels with -- m columns per dependency level instead of m sweeps.  false: not available (Kaczmarz)
+    bool apply_dense(const double *F, double *X, int m, bool zero_guess);
+    std::vector<int> h_lev_ptr;                       // rows by dependency level (whatever the launch plan does with them): offsets ...
+    int *d_lev_rows = nullptr;                        // ... into this list
+    double chain_cost() const override { return 2.0 * sweeps * (double)(longest_chain > 0 ? longest_chain : n_steps) + 2.0; }
     bool same_scaling_as(const elag_hip_smoother_s *o) const override
     {
         const SweepSmoother *r = dynamic_cast<const SweepSmoother *>(o);
@@ -105,6 +115,7 @@ struct HiptmairSmoother : elag_hip_smoother_s {
     void finish_after_primary(const double *f, double *x);
     void apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose) override;
     int flips(bool zero_guess) const override { return primary->flips(zero_guess); }
+    double chain_cost() const override { return primary->chain_cost() + aux->chain_cost() + 4.0; }
 };
 
 }  // namespace elag

@@ -357,7 +357,7 @@ int gs_hybrid_blocks()
 
 }  // namespace
 
-SweepSmoother::~SweepSmoother() { dev_free(d_rows); dev_free(d_lev_ptr); dev_free(d_l1); dev_free(d_sJ); dev_free(d_sa); dev_free(d_self_ghost); dev_free(d_blk_first); dev_free(d_blk_count); }
+SweepSmoother::~SweepSmoother() { dev_free(d_rows); dev_free(d_lev_ptr); dev_free(d_l1); dev_free(d_sJ); dev_free(d_sa); dev_free(d_self_ghost); dev_free(d_blk_first); dev_free(d_blk_count); dev_free(d_lev_rows); }
 
 void SweepSmoother::setup()
 {
@@ -472,6 +472,16 @@ void SweepSmoother::setup()
         }
     }
     num_levels = nlev;
+    {
+        // rows by dependency level, for apply_dense
+        h_lev_ptr.assign((size_t)nlev + 1, 0);
+        for (int i = 0; i < n; i++) h_lev_ptr[(size_t)level[(size_t)i] + 1]++;
+        std::partial_sum(h_lev_ptr.begin(), h_lev_ptr.end(), h_lev_ptr.begin());
+        std::vector<int> cur(h_lev_ptr.begin(), h_lev_ptr.end() - 1), lr((size_t)std::max(n, 1));
+        for (int i = 0; i < n; i++) lr[(size_t)cur[(size_t)level[(size_t)i]]++] = i;
+        dev_free(d_lev_rows);
+        d_lev_rows = dev_from_host(lr.data(), lr.size());
+    }
     // Virtual ranks: the blocks share nothing during a sweep, so each gets a chain of its own -- rows ordered by (block, level), a "level" below
     // being one block's rows of one dependency level -- and ONE launch of a workgroup per block walks all of them, forward and backward
     // (ELAG_HIP_SWEEP_BLOCK_CHAINS=0: the blocks' levels side by side in the common schedule, one launch or chain step per level)
@@ -530,6 +540,7 @@ void SweepSmoother::setup()
     }
     const int cr = lds_u ? kMaxChain * kStepRows : chain_rows;
     segments.clear();
+    longest_chain = 0;
     if (block_chains) {
         std::vector<int> bf((size_t)blocks), bc((size_t)blocks);
         int longest = 0;
@@ -539,6 +550,7 @@ void SweepSmoother::setup()
             longest = std::max(longest, bc[(size_t)b]);
         }
         if (longest <= kMaxChain) {
+            longest_chain = longest;
             d_blk_first = dev_from_host(bf.data(), bf.size());
             d_blk_count = dev_from_host(bc.data(), bc.size());
             lds_u = false;
@@ -584,6 +596,65 @@ void SweepSmoother::setup()
     if (getenv("ELAG_HIP_SWEEP_VERBOSE"))
         fprintf(stderr, "[elag_hip] sweep smoother type %d: n=%d, %d dependency levels = %d steps in %d launches per direction%s\n", type, n, nlev,
                 n_steps, (int)segments.size(), lds_u ? " (u in LDS)" : "");
+}
+
+namespace {
+// One dependency level of a sweep on m right-hand sides: a thread per (row of the level, column).  MODE as in the sweep kernels (0: types
+// 2 / 4, 1: type 6); F == nullptr: the identity; Xs: the frozen copy the off-block terms read (virtual ranks), ghost_col: their rows in it.
+template <int MODE>
+__global__ void sweep_dense_level_kernel(int r0, int r1, const int *__restrict__ rows, const int *__restrict__ I, const int *__restrict__ J,
+                                         const double *__restrict__ a, const int *__restrict__ oI, const int *__restrict__ oJ, const double *__restrict__ oa,
+                                         const int *__restrict__ ghost_col, const double *__restrict__ F, const double *__restrict__ d, double omega,
+                                         const double *__restrict__ Xs, double *X, int m)
+{
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ri = r0 + (int)(id / m), c = (int)(id % m);
+    if (ri >= r1) return;
+    const int row = rows[ri];
+    double res = F ? F[(size_t)row * m + c] : (row == c ? 1.0 : 0.0), aii = 0.0;
+    bool have = false;
+    for (int k = I[row]; k < I[row + 1]; k++) {
+        const int j = J[k];
+        if (MODE == 1 && j == row && !have) { aii = a[k]; have = true; continue; }
+        res -= a[k] * X[(size_t)j * m + c];
+    }
+    if (oI)
+        for (int k = oI[row]; k < oI[row + 1]; k++) res -= oa[k] * Xs[(size_t)ghost_col[oJ[k]] * m + c];
+    if (MODE == 0) { if (d[row] != 0.0) X[(size_t)row * m + c] += omega * res / d[row]; }
+    else if (have && aii != 0.0) X[(size_t)row * m + c] = res / aii;
+}
+}  // namespace
+
+bool SweepSmoother::apply_dense(const double *F, double *X, int m, bool zero_guess)
+{
+    if (type == ELAG_HIP_SMOOTHER_KACZMARZ || h_lev_ptr.empty()) return false;
+    const int n = M->nrows();
+    if (n == 0 || m == 0) return true;
+    hipStream_t st = ctx().stream;
+    if (zero_guess) ELAG_HIP_CHECK(hipMemsetAsync(X, 0, sizeof(double) * (size_t)n * m, st));
+    const bool ho = M->offd.nnz > 0;
+    ELAG_REQUIRE(!ho || As, "internal: apply_dense on an operator with real ghosts");
+    Temp<double> snap(ho ? (size_t)n * m : 1);
+    const int nlev = (int)h_lev_ptr.size() - 1;
+    auto level = [&](int l) {
+        const int r0 = h_lev_ptr[(size_t)l], r1 = h_lev_ptr[(size_t)l + 1];
+        if (r1 == r0) return;
+        const long long tot = (long long)(r1 - r0) * m;
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, r0, r1, (const int *)d_lev_rows, (const int *)M->diag.I,
+                               (const int *)M->diag.J, (const double *)M->diag.a, ho ? (const int *)M->offd.I : nullptr, ho ? (const int *)M->offd.J : nullptr,
+                               ho ? (const double *)M->offd.a : nullptr, (const int *)d_self_ghost, F, (const double *)d_l1, omega, (const double *)snap.p, X, m);
+        };
+        if (type == ELAG_HIP_SMOOTHER_GS) go(sweep_dense_level_kernel<1>);
+        else go(sweep_dense_level_kernel<0>);
+    };
+    for (int sw = 0; sw < sweeps; sw++) {
+        if (ho) ELAG_HIP_CHECK(hipMemcpyAsync(snap.p, X, sizeof(double) * (size_t)n * m, hipMemcpyDeviceToDevice, st));   // the other blocks' values, frozen
+        for (int l = 0; l < nlev; l++) level(l);
+        for (int l = nlev - 1; l >= 0; l--) level(l);
+    }
+    ELAG_LAUNCH_CHECK();
+    return true;
 }
 
 void SweepSmoother::launch_segment(const Segment &s, int dir, const double *f, double *u, bool sym)
