@@ -257,6 +257,26 @@ struct elag_hip_hierarchy_s {
         int L = -1;
         for (int l = 1; l < nl - 1; l++)   // the coarsest level alone is already a single dense product
             if (lev[(size_t)l].A->nrows() <= max_n && lev[(size_t)l].A->offd.ncols == 0) { L = l; break; }
+        // Gauss-Seidel levels are dependency chains (a level of the cube456 x3 hierarchy with 5 739 dofs: two sweeps of 2 x 51 steps, ~0.3 ms)
+        // where a dense product streams n^2 doubles (0.05 ms at that size): the tail may start higher up, wherever the product is the cheaper
+        // of the two and the operator fits ELAG_HIP_DENSE_TAIL_N_SWEEPS (8 192: 0.5 GB)
+        {
+            static int max_ns = -1;
+            if (max_ns < 0) { const char *e = getenv("ELAG_HIP_DENSE_TAIL_N_SWEEPS"); max_ns = e ? atoi(e) : 8192; }
+            double below = 2.0;                                   // dependent device steps of the sub-cycle from level l down (~1.5 us each)
+            int best = -1;
+            for (int l = nl - 2; l >= 1; l--) {
+                const Level &F = lev[(size_t)l];
+                if (!dynamic_cast<SweepSmoother *>(F.pre) || !dynamic_cast<SweepSmoother *>(F.post) || F.A->offd.ncols != 0) break;
+                below += F.pre->chain_cost() + F.post->chain_cost() + 4.0;
+                const double nn = (double)F.A->nrows();
+                if (nn > max_ns) break;
+                if (nn * nn * 8.0 / 5.0e6 < below * 1.5) best = l;      // (bytes / (5 TB/s) in us against steps x 1.5 us)
+            }
+            if (best >= 1 && (L < 0 || best < L)) {
+                if (dense_tail_by_sweeps(best)) { dense_level = best; return; }
+            }
+        }
         if (L < 0) return;
         const int n = lev[(size_t)L].A->nrows();
         if (n == 0) return;
@@ -295,33 +315,49 @@ struct elag_hip_hierarchy_s {
 
     // Gauss-Seidel levels: the sweeps are linear too, and a sweep on n right-hand sides at once is n columns per dependency level instead of n
     // sweeps -- with one level above a dense coarse inverse,
-    //   X1 = S(I; 0),   X2 = X1 + P Minv P^T (I - A X1),   B = S(I; X2)          (S(F; X0): the symmetric sweep on F from X0)
-    // a few hundred small launches where 840 applications of the sub-cycle were 266 ms of a 284 ms Finalize (cube456 x3).
+    //   X1 = S(I; 0),   X2 = X1 + P B_below P^T (I - A X1),   B = S(I; X2)       (S(F; X0): the symmetric sweep on F from X0)
+    // level by level from the dense coarse inverse up -- a few hundred small launches where 840 applications of the sub-cycle were 266 ms
+    // of a 284 ms Finalize (cube456 x3).
     bool dense_tail_by_sweeps(int L)
     {
         const int nl = (int)lev.size();
         const char *en = getenv("ELAG_HIP_DENSE_TAIL_SWEEPS");            // (read at every Finalize)
-        if ((en && !atoi(en)) || L != nl - 2 || !coarse || coarse->custom_apply || coarse->replicated || !coarse->Minv) return false;
-        Level &F = lev[(size_t)L];
-        Level &C = lev[(size_t)L + 1];
-        SweepSmoother *pre = dynamic_cast<SweepSmoother *>(F.pre), *post = dynamic_cast<SweepSmoother *>(F.post);
-        if (!pre || !post || pre->A != F.A || post->A != F.A || F.A->needs_exchange() || C.P->needs_exchange()) return false;
-        const int n = F.A->nrows(), nc = coarse->n;
-        if (nc != C.A->nrows() || C.P->nrows() != n || C.P->ncols() != nc) return false;
-        double *B = dev_alloc<double>((size_t)n * n);
-        if (!pre->apply_dense(nullptr, B, n, true)) { dev_free(B); return false; }
-        {
-            Temp<double> R((size_t)n * n), T1((size_t)nc * n), T2((size_t)nc * n);
-            k::csr_times_dense(F.A->diag, n, -1.0, B, 0.0, true, R);               // R = I - A X1
-            C.P->ensure_transpose();
-            k::csr_times_dense(*C.P->diagT, n, 1.0, R, 0.0, false, T1);            // T1 = P^T R
-            k::dense_mm(nc, nc, n, coarse->Minv, T1, T2);                          // T2 = Minv T1
-            k::csr_times_dense(C.P->diag, n, 1.0, T2, 1.0, false, B);              // X2 = X1 + P T2
-            ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));                    // (the scratch goes out of scope)
+        if ((en && !atoi(en)) || !coarse || coarse->custom_apply || coarse->replicated || !coarse->Minv) return false;
+        if (coarse->n != lev[(size_t)nl - 1].A->nrows()) return false;
+        for (int l = L; l < nl - 1; l++) {
+            Level &F = lev[(size_t)l];
+            Level &C = lev[(size_t)l + 1];
+            SweepSmoother *pre = dynamic_cast<SweepSmoother *>(F.pre), *post = dynamic_cast<SweepSmoother *>(F.post);
+            if (!pre || !post || pre->A != F.A || post->A != F.A || F.A->needs_exchange() || C.P->needs_exchange()) return false;
+            if (pre->type == ELAG_HIP_SMOOTHER_KACZMARZ || post->type == ELAG_HIP_SMOOTHER_KACZMARZ) return false;
+            if (C.P->nrows() != F.A->nrows() || C.P->ncols() != C.A->nrows()) return false;
         }
-        if (!post->apply_dense(nullptr, B, n, false)) { dev_free(B); return false; }
-        ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
-        Bdense = B;
+        const double *Bc = coarse->Minv;         // the dense operator of the sub-cycle below the level at hand
+        double *own = nullptr;
+        int nc = coarse->n;
+        for (int l = nl - 2; l >= L; l--) {
+            Level &F = lev[(size_t)l];
+            Level &C = lev[(size_t)l + 1];
+            SweepSmoother *pre = static_cast<SweepSmoother *>(F.pre), *post = static_cast<SweepSmoother *>(F.post);
+            const int n = F.A->nrows();
+            double *B = dev_alloc<double>((size_t)n * n);
+            bool ok = pre->apply_dense(nullptr, B, n, true);                           // X1 = S(I; 0)
+            if (ok) {
+                Temp<double> R((size_t)n * n), T1((size_t)nc * n), T2((size_t)nc * n);
+                k::csr_times_dense(F.A->diag, n, -1.0, B, 0.0, true, R);               // R = I - A X1
+                C.P->ensure_transpose();
+                k::csr_times_dense(*C.P->diagT, n, 1.0, R, 0.0, false, T1);            // T1 = P^T R
+                k::dense_mm(nc, nc, n, Bc, T1, T2);                                    // T2 = B_below T1
+                k::csr_times_dense(C.P->diag, n, 1.0, T2, 1.0, false, B);              // X2 = X1 + P T2
+                ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));                    // (the scratch goes out of scope)
+                ok = post->apply_dense(nullptr, B, n, false);                          // B = S(I; X2)
+            }
+            ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+            dev_free(own);
+            if (!ok) { dev_free(B); return false; }
+            own = B; Bc = B; nc = n;
+        }
+        Bdense = own;
         return true;
     }
 
