@@ -200,6 +200,7 @@ struct DevCSR {
     int lanes_per_row = 8;
     int *block_row = nullptr;  // nblocks+1 row offsets: block c owns rows whose first entry lies in [c*kStreamNnz, (c+1)*kStreamNnz)
     int nblocks = 0, max_row_nnz = 0;
+    int known_max_row = 0;     // set by a builder that has the longest row at hand already (the sparse products): build_stream_plan takes it once instead of a kernel and a drain
     // "x-cache" form of the stream kernel (built on first use for matrices whose windows reuse their columns): per
     // window the sorted unique columns (ucols[uoff[c] .. uoff[c+1])) and, per entry, the 16-bit position of its column
     // in that list.  The kernel gathers x once per unique column into LDS and streams 10 bytes per entry.

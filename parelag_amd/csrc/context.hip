@@ -171,6 +171,7 @@ void DevCSR::choose_spmv_shape()
     // the window plan (and the longest row) is what the stream kernels need: operators below their size gate get it when someone asks
     // for it (csr_sort_rows, a forced form) -- an allocation, two launches and a drain less per small matrix at setup
     if (nnz >= (int64_t(1) << 20)) k::build_stream_plan(*this);
+    known_max_row = 0;         // (a builder's hint holds for the call that follows it, no longer)
     if (forced > 0) { lanes_per_row = forced; return; }
     // the stream kernel wins once the matrix outgrows the caches' latency regime; small (coarse-level) operators
     // are launch/latency-bound and do better with one dependent phase less

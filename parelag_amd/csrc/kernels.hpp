@@ -111,6 +111,7 @@ void build_stream_plan(DevCSR &A);
 // builds the x-cache form of a stream-kernel matrix if it pays (synchronous, allocates: never call while capturing);
 // spmv_fused does this lazily on the first uncaptured launch, hierarchies do it for their operators at Finalize
 void prepare_spmv(const DevCSR &A, bool force = false);
+void longest_row(int nrows, const int *I, int *d_out);      // *d_out = max_r I[r + 1] - I[r] (device scalar, compute stream)
 
 // builds the 4-byte-per-entry sign form of a matrix whose stored values are all -1, 0 or +1 (returns false and leaves the
 // matrix alone otherwise); synchronous, setup time.  The caller vouches that the values stay as they are.

@@ -1088,12 +1088,16 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
             int *CI = dev_alloc<int>((size_t)n + 1);
             exclusive_scan(rownnz, CI, n);
             int *hnnz = reinterpret_cast<int *>(ctx().h_scalar + 10);
+            Temp<int> longest(1);
+            if (spmv_plan) longest_row(n, CI, longest.p);          // (the result's longest row rides along: no kernel + drain for it in choose_spmv_shape)
             ELAG_HIP_CHECK(hipMemcpyAsync(hnnz, CI + n, sizeof(int), hipMemcpyDeviceToHost, st));
+            if (spmv_plan) ELAG_HIP_CHECK(hipMemcpyAsync(hnnz + 1, longest.p, sizeof(int), hipMemcpyDeviceToHost, st));
             ELAG_HIP_CHECK(hipStreamSynchronize(st));
             const int nnz = *hnnz;
             C.release();
             C.nrows = n; C.ncols = ncols; C.I = CI;
             C.alloc_entries(nnz);
+            if (spmv_plan) C.known_max_row = hnnz[1];
             if (nch && !single_all)
                 hipLaunchKernelGGL((esc_kernel<2 * kCap, false, true, Expander>), dim3(nch), dim3(kBlock), 0, st, n, plan.ubscan.p,
                                    plan.ub_small.p, (const int *)nullptr, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);

@@ -623,6 +623,12 @@ void build_stream_plan(DevCSR &A)
     A.block_row = dev_alloc<int>(2 * ((size_t)A.nblocks + 1) + 2);
     hipLaunchKernelGGL(stream_plan_kernel, dim3((unsigned)((A.nblocks + 1 + 255) / 256)), dim3(256), 0, st, A.nrows, (const int *)A.I,
                        A.nblocks, DevCSR::kStreamNnz, A.block_row);
+    if (A.known_max_row > 0) {
+        A.max_row_nnz = A.known_max_row;
+        A.known_max_row = 0;
+        ELAG_LAUNCH_CHECK();
+        return;
+    }
     Temp<int> m(1);
     ELAG_HIP_CHECK(hipMemsetAsync(m, 0, sizeof(int), st));
     if (A.nrows) {
@@ -632,6 +638,17 @@ void build_stream_plan(DevCSR &A)
     ELAG_LAUNCH_CHECK();
     ELAG_HIP_CHECK(hipMemcpyAsync(&A.max_row_nnz, m.p, sizeof(int), hipMemcpyDeviceToHost, st));
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
+}
+
+void longest_row(int nrows, const int *I, int *d_out)
+{
+    hipStream_t st = ctx().stream;
+    ELAG_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(int), st));
+    if (nrows) {
+        const unsigned g = (unsigned)std::min<long long>(((long long)nrows + 255) / 256, 512);
+        hipLaunchKernelGGL(max_row_kernel, dim3(g), dim3(256), 0, st, nrows, I, d_out);
+    }
+    ELAG_LAUNCH_CHECK();
 }
 
 namespace {
