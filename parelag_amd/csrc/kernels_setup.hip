@@ -1161,8 +1161,8 @@ namespace {
 // product stays within the hash path's 256 products, and the upper-bound layout fits its int indices and the scratch arena
 bool ell_applies(const DevCSR &A, const DevCSR &B)
 {
-    static int use_ell = -1;
-    if (use_ell < 0) { const char *e = getenv("ELAG_HIP_RAP_ELL"); use_ell = e ? atoi(e) : 1; }
+    const char *e_ell = getenv("ELAG_HIP_RAP_ELL");                 // (read at every call: a test switches it)
+    const int use_ell = e_ell ? atoi(e_ell) : 1;
     const int W = B.max_row_nnz;
     return use_ell && W >= 1 && W <= 4 && B.nnz > 0 && (long long)B.nrows * W < (1ll << 31) && hash_classes() == 31 && wave_path_enabled() &&
            single_pass_enabled() && A.max_row_nnz > 0 && (long long)A.max_row_nnz * W <= kWaveCap && (long long)A.nnz * W < (1ll << 31) &&
@@ -1202,8 +1202,8 @@ void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C, bool spmv_plan)
 void csr_rap(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, bool spmv_plan)
 {
     ELAG_REQUIRE(A.ncols == P.nrows && R.ncols == A.nrows, "rap: shapes do not chain");
-    static int loose = -1;
-    if (loose < 0) { const char *e = getenv("ELAG_HIP_RAP_LOOSE"); loose = e ? atoi(e) : 1; }
+    const char *e_loose = getenv("ELAG_HIP_RAP_LOOSE");             // (read at every call: a test switches it)
+    const int loose = e_loose ? atoi(e_loose) : 1;
     hipStream_t st = ctx().stream;
     if (loose && A.nrows > 0 && R.nrows > 0) {
         CsrView a{A.I, A.J, A.a}, p{P.I, P.J, P.a};

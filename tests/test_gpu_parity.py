@@ -1013,6 +1013,31 @@ def test_bandwidth_bound_level_goes_up_through_S(la, h1_k2, reorder):
     assert np.max(np.abs(outs["S"][1] - (x0 + er))) <= 1e-12 * np.max(np.abs(x0 + er))
 
 
+def test_triple_product_routes_give_the_same_matrix(la, h1_k2, hdiv_k2):
+    """P^T A P takes the shortest route its operands allow (kernels_setup.hip, csr_rap): A P left in the upper-bound layout its kernels wrote
+    it in, a right factor of at most 4 entries per row through its W-slot copy with an analytic plan.  Every route inserts a row's products in
+    storage order, so switching them off one by one (ELAG_HIP_RAP_ELL=0, ELAG_HIP_RAP_LOOSE=0) must not change a bit -- for the nested P1
+    interpolator (2 entries per row), the face interpolator of the 2-form (up to 4) and a product whose right factor has long rows (A A)."""
+    import os
+    cases = [(h1_k2[0], h1_k2[1][0]), (hdiv_k2[0], hdiv_k2[1][0]), (h1_k2[0], sp.csr_matrix(h1_k2[0]))]
+    for A, P in cases:
+        dA, dP = la.ParallelCSRMatrix.from_scipy(A), la.ParallelCSRMatrix.from_scipy(P)
+        outs = []
+        for env in ({}, {"ELAG_HIP_RAP_ELL": "0"}, {"ELAG_HIP_RAP_ELL": "0", "ELAG_HIP_RAP_LOOSE": "0"}):
+            os.environ.update(env)
+            try:
+                outs.append(la.RAP(dA, dP).to_scipy())
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+        ref = (sp.csr_matrix(P).T @ sp.csr_matrix(A) @ sp.csr_matrix(P)).tocsr()
+        ref.sort_indices()
+        for M in outs:
+            M.sort_indices()
+            assert np.array_equal(M.indptr, outs[0].indptr) and np.array_equal(M.indices, outs[0].indices) and np.array_equal(M.data, outs[0].data)
+        assert abs(outs[0] - ref).max() <= 1e-12 * abs(ref).max()
+
+
 def test_graph_replay_and_plain_launches_are_the_same_cycle(la, h1_k2):
     """Finalize issues a cycle of up to 32 kernels as plain launches and a longer one as a replayed hipGraph (elag_hip_hierarchy_launch_mode);
     ELAG_HIP_GRAPH_MODE forces either, or asks for the round-2 timing of both.  The kernels are the same, so is every bit of the result; the
