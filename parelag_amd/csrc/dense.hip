@@ -176,12 +176,80 @@ __global__ void symmetrise_kernel(int n, const double *__restrict__ M, double *_
 }
 }  // namespace
 
+namespace {
+// The same elimination for operators that fit ONE workgroup's LDS (n <= 141: n^2 doubles in the CU's 160 KB): scatter, symmetrise, n pivots
+// with two barriers each, symmetrise, store -- one launch of ~0.25 ms where the host's Cholesky + 2 n triangular solves (and the copies
+// either way) took 1.0 ms of a 5.8 ms cube456 x3 setup and the multi-launch form above 2 n launches.
+constexpr int kLdsInvMax = 141;            // (n^2 doubles + the two pivot vectors within the 160 KB of a CU)
+constexpr int kLdsInvBlock = 1024;
+__global__ __launch_bounds__(kLdsInvBlock) void spd_inverse_lds_kernel(int n, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
+                                                                   double *__restrict__ Minv, int *__restrict__ bad)
+{
+    extern __shared__ double Ml[];          // n x n, row-major
+    __shared__ double colk[kLdsInvMax + 1], rowk[kLdsInvMax + 1];
+    // a thread owns column tx of the rows ty, ty + kRowsPerPass, ...: no index arithmetic inside the pivot loop
+    constexpr int kCols = 144, kRowsPerPass = kLdsInvBlock / kCols;          // 7 rows x 144 columns = 1008 of the 1024 threads
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int tx = t % kCols, ty = t / kCols;
+    const bool own = tx < n && ty < kRowsPerPass;
+    for (int e = t; e < n * n; e += nt) Ml[e] = 0.0;
+    __syncthreads();
+    for (int i = t; i < n; i += nt)
+        for (int q = I[i]; q < I[i + 1]; q++) Ml[i * n + J[q]] += a[q];       // (one thread per row: repeated columns add up in storage order)
+    __syncthreads();
+    // exactly symmetric first, like the host path: the upper triangle's owner writes both
+    if (own)
+        for (int i = ty; i < n; i += kRowsPerPass)
+            if (tx > i) { const double v = 0.5 * (Ml[i * n + tx] + Ml[tx * n + i]); Ml[i * n + tx] = v; Ml[tx * n + i] = v; }
+    __syncthreads();
+    for (int k = 0; k < n; k++) {
+        const double p = Ml[k * n + k];
+        if (t == 0 && !(p > 0.0)) atomicAdd(bad, 1);
+        if (t < n) {
+            colk[t] = (t == k) ? 0.0 : Ml[t * n + k];
+            rowk[t] = (t == k) ? 1.0 / p : Ml[k * n + t] / p;
+        }
+        __syncthreads();
+        if (own) {
+            const double rk = rowk[tx];
+            for (int i = ty; i < n; i += kRowsPerPass) {
+                double *m = Ml + i * n + tx;
+                if (i == k) *m = rk;
+                else if (tx == k) *m = -colk[i] * rk;          // rowk[k] = 1 / p
+                else *m -= colk[i] * rk;
+            }
+        }
+        __syncthreads();
+    }
+    if (own)
+        for (int i = ty; i < n; i += kRowsPerPass) Minv[(size_t)i * n + tx] = 0.5 * (Ml[i * n + tx] + Ml[tx * n + i]);
+}
+}  // namespace
+
 void dense_inverse_spd(const DevCSR &A, double *Minv)
 {
     hipStream_t st = ctx().stream;
     const int n = A.nrows;
     ELAG_REQUIRE(n == A.ncols, "dense inverse needs a square matrix");
     if (n == 0) return;
+    if (n <= kLdsInvMax) {
+        static thread_local bool raised = false;
+        const size_t lds = sizeof(double) * (size_t)n * n;
+        if (!raised && lds > (size_t)(48 << 10)) {
+            ELAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(spd_inverse_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)(sizeof(double) * kLdsInvMax * kLdsInvMax)));
+            raised = true;
+        }
+        Temp<int> bad(1);
+        ELAG_HIP_CHECK(hipMemsetAsync(bad.p, 0, sizeof(int), st));
+        hipLaunchKernelGGL(spd_inverse_lds_kernel, dim3(1), dim3(kLdsInvBlock), lds, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, Minv, bad.p);
+        ELAG_LAUNCH_CHECK();
+        int nbad = 0;
+        ELAG_HIP_CHECK(hipMemcpyAsync(&nbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        if (nbad) fail(ELAG_HIP_ERR_NUMERIC, "coarse operator is not positive definite (%d non-positive pivots)", nbad);
+        return;
+    }
     double *M = dev_alloc<double>((size_t)n * n);
     try {
         Temp<int> bad(1);

@@ -426,7 +426,10 @@ void elag_hip_coarse_s::setup()
     // n = 1 015): the device inverts those (two launches per pivot, ~10 ms); small operators keep the host path
     static int dev_from = -1;
     if (dev_from < 0) { const char *e = getenv("ELAG_HIP_COARSE_DEVICE_FROM"); dev_from = e ? atoi(e) : 256; }
-    if (n >= dev_from) {
+    // ... and up to 141 dofs the matrix fits one workgroup's LDS: one launch (dense.hip; ELAG_HIP_COARSE_LDS=0: the host path)
+    static int lds_inv = -1;
+    if (lds_inv < 0) { const char *e = getenv("ELAG_HIP_COARSE_LDS"); lds_inv = e ? atoi(e) : 1; }
+    if (n >= dev_from || (lds_inv && n >= 8 && n <= 141)) {
         Minv = dev_alloc<double>((size_t)n * n);
         k::dense_inverse_spd(A->diag, Minv);
         return;
