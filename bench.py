@@ -460,6 +460,8 @@ def main():
     ap.add_argument("--force-large", action="store_true", help="with --force-dist: also run the GPU-filling workload of the multi-rank runs")
     ap.add_argument("--parity-max-dofs", type=int, default=1500000, help="multi-rank darcy/spe10: largest system for which the serial CPU "
                     "oracle's blocked cycle is run beside the distributed one")
+    ap.add_argument("--large-timeout", type=int, default=420, help="seconds the extra GPU-filling workload of a multi-rank run may take before the headline "
+                    "is reported without it")
     ap.add_argument("--gs-blocks", type=int, nargs="*", default=[16, 256], help="the L1 Gauss-Seidel cycle is also timed with the sweeps on this many "
                     "virtual ranks (hypre's hybrid Gauss-Seidel as the reference runs it on that many MPI ranks)")
     ap.add_argument("--launch-dry-run", action="store_true", help="start the ranks, report RANK / WORLD_SIZE of every child over a gloo "
@@ -1143,6 +1145,94 @@ def main():
         out["comm"] = {"data_plane": "RCCL (ncclSend/ncclRecv groups + ncclAllReduce inside libelag_hip.so)" if world > 1 else "none (one rank)",
                        "control_plane": "torch.distributed gloo", "library_comm_rank": cr.value, "library_comm_nranks": cn.value,
                        "ranks_agree": bool(dist.allreduce_max(float(cn.value)) == float(world) and dist.allreduce_sum(float(cr.value)) == world * (world - 1) / 2)}
+    import threading
+    emitted = threading.Lock()
+
+    def emit(large):
+        """rank 0 prints the ONE line of the run (once: the watchdog of the extra workload below may get here first)"""
+        if not emitted.acquire(blocking=False):
+            return
+        if rank == 0:
+            if large is not None:
+                out["large"] = large
+            out.update({
+                "metric": ("V-cycles/sec (MultigridTestDarcy cube456, blocked Hierarchy::Mult in preconditioner mode)" if darcy else
+                           f"V-cycles/sec (MultigridTest{args.form}Form cube456, Hierarchy::Mult in preconditioner mode)"),
+                "value": round(args.steps / elapsed, 2),
+                "unit": "V-cycles/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 5),
+                "higher_is_better": True,
+                "scaling": "strong",
+                "vs_baseline": None,
+                "dtype": "f64",
+                "data": "synthetic",
+                "config": {"workload": (f"MultigridTest0Form {mesh_label}, {len(Ps) + 1} levels, "
+                                        f"{args.smoother} 1 sweep pre/post, dense coarse solve, b=2") if args.form == 0 else
+                                       (("MultigridTestSPE10-like (synthetic log-normal k, sigma=%g, contrast %.1e) " % (args.perm_sigma, float(kinv.max() / kinv.min())) if spe10 else "") +
+                                        f"MultigridTestDarcy [[M,Bt],[B,0]] (forms 2,3) {mesh_label}, {len(Ps) + 1} levels, "
+                                        f"{args.block_smoother} (A00: {args.smoother}, A11: {args.smoother} on "
+                                        f"{'S' if args.positive_s else '-S'} = -+B diag(M)^-1 Bt) pre/post, dense LU coarse solve, b=2") if darcy else
+                                       (f"MultigridTest{args.form}Form ({'H(div)' if args.form == 2 else 'H(curl)'}) {mesh_label}, {len(Ps) + 1} levels, "
+                                        f"Hiptmair({args.smoother}, {args.smoother}) pre/post, dense coarse solve, b=2"),
+                           "interpolators": (dar["amge"]["what"] if darcy and "amge" in dar else "nested geometric (generator)"),
+                           "levels": [{"n": s[0], "nnz": s[1]} for s in level_shapes],
+                           "hipgraph": launch.get("hipgraph", False), "launch_mode": launch,
+                           "env": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
+                           "parallelism": f"row-block domain decomposition x{world}"},
+                "steady_state": (None if steady is None else {"steps": 2000, "ms_per_step": round(steady * 1e3, 5), "vcycles_per_s": round(1.0 / steady, 1)}),
+                "device_ms_per_step": round(ms_dev, 5), "device_timed_steps": max(200, min(args.steps, 500)),
+                "device_vcycles_per_s": round(1e3 / ms_dev, 1),
+                "vcycle_algorithmic_bytes": vbytes,
+                "vcycle_achieved_GBs": round(vbytes / (ms_dev * 1e-3) / 1e9, 1),
+                "setup_s": round(setup_s, 4),
+                "setup_breakdown_ms": setup_breakdown,
+                "fine_level_spmv": fine,
+                "roofline": roof,
+                "cpu_baseline": cpu,
+            })
+            if gs is not None:
+                out["l1_gauss_seidel_cycle"] = gs
+            if hbm is not None:
+                out["hbm_bound_cycle"] = hbm
+            if solve is not None:
+                out["solve"] = solve
+            if not darcy and (args.amge or args.hex):
+                out["amge"] = amge_rec
+                out["config"]["interpolators"] = amge_rec["what"]
+            if darcy and "amge" in dar:
+                rec = dar["amge"]
+                lv0, parts = rec.pop("level0", None), rec.pop("parts", None)
+                n_ae = sum(l["agglomerates"] for l in rec["levels"])
+                rec["agglomerates_per_s"] = round(n_ae / rec["coarsen_total_s"], 1)
+                if lv0 is not None:
+                    rec["kernel_ms_total"] = round(sum(sum(l["kernel_ms"].values()) for l in rec["levels"]), 3)
+                if lv0 is not None and not args.no_cpu_baseline:
+                    # CPU port of the same coarsening (oracle/amge.py: numpy, entity by entity) on a bounded sample: the levels
+                    # with at most 4000 agglomerates, reached with the oracle's own coarse levels being skipped -- the device's
+                    # levels are equal to 1e-10 (tests/test_gpu_amge.py), so the sample starts from them
+                    from oracle import amge as oa
+                    from parelag_amd import amge as pa
+                    cur, done, t_cpu = lv0, 0, 0.0
+                    for part in parts:
+                        n_here = int(part.max()) + 1
+                        if n_here <= 4000 and t_cpu < 3 * args.cpu_seconds:
+                            t1 = time.perf_counter()
+                            res = oa.coarsen(cur, part)
+                            t_cpu += time.perf_counter() - t1
+                            done += n_here
+                        else:
+                            res = pa.coarsen(cur, part)
+                        cur = res["coarse"]
+                    if done:
+                        rec["cpu_port"] = {"agglomerates_per_s": round(done / t_cpu, 1), "cores": 1, "kind": "port",
+                                           "sample": f"{done} agglomerates (the levels with <= 4000 of them) in {t_cpu:.2f} s, oracle/amge.py"}
+                out["amge"] = rec
+            print(json.dumps(out))
+        sys.stdout.flush()
+
     large = None
     if args.large_refines < 0:
         args.large_refines = 6 if world >= 8 else 5
@@ -1151,91 +1241,24 @@ def main():
         # the headline size (42 k dofs at x3) is a latency problem across ranks by construction; this is the same example at a
         # size that fills the GPUs.  Levels with more than 2^17 dofs are row-partitioned, the rest replicated behind one all-reduce.
         kL = args.large_refines
+        # The headline is measured by now and must not depend on this workload: an exception is caught below, and a rank that never
+        # comes back from a collective (a peer died, an 8-rank path no single-GPU box could rehearse) is cut off by a watchdog that
+        # prints the line without `large` and ends the process (every rank has one: they all go)
+        def give_up():
+            note("large workload: no result after %d s, reporting the headline without it" % args.large_timeout)
+            emit({"error": "timed out after %d s" % args.large_timeout})
+            os._exit(0)
+        dog = threading.Timer(args.large_timeout, give_up)
+        dog.daemon = True
+        dog.start()
         try:
             large = large_workload(args, dist, world, kL, la, meshgen, distributed, np, barrier)
         except Exception as exc:                                   # the headline line must not depend on the extra workload
             import traceback
             note("large workload failed: " + "".join(traceback.format_exception_only(type(exc), exc)).strip())
             large = {"error": repr(exc)[:400]}
-    if rank == 0:
-        if large is not None:
-            out["large"] = large
-        out.update({
-            "metric": ("V-cycles/sec (MultigridTestDarcy cube456, blocked Hierarchy::Mult in preconditioner mode)" if darcy else
-                       f"V-cycles/sec (MultigridTest{args.form}Form cube456, Hierarchy::Mult in preconditioner mode)"),
-            "value": round(args.steps / elapsed, 2),
-            "unit": "V-cycles/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 5),
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": (f"MultigridTest0Form {mesh_label}, {len(Ps) + 1} levels, "
-                                    f"{args.smoother} 1 sweep pre/post, dense coarse solve, b=2") if args.form == 0 else
-                                   (("MultigridTestSPE10-like (synthetic log-normal k, sigma=%g, contrast %.1e) " % (args.perm_sigma, float(kinv.max() / kinv.min())) if spe10 else "") +
-                                    f"MultigridTestDarcy [[M,Bt],[B,0]] (forms 2,3) {mesh_label}, {len(Ps) + 1} levels, "
-                                    f"{args.block_smoother} (A00: {args.smoother}, A11: {args.smoother} on "
-                                    f"{'S' if args.positive_s else '-S'} = -+B diag(M)^-1 Bt) pre/post, dense LU coarse solve, b=2") if darcy else
-                                   (f"MultigridTest{args.form}Form ({'H(div)' if args.form == 2 else 'H(curl)'}) {mesh_label}, {len(Ps) + 1} levels, "
-                                    f"Hiptmair({args.smoother}, {args.smoother}) pre/post, dense coarse solve, b=2"),
-                       "interpolators": (dar["amge"]["what"] if darcy and "amge" in dar else "nested geometric (generator)"),
-                       "levels": [{"n": s[0], "nnz": s[1]} for s in level_shapes],
-                       "hipgraph": launch.get("hipgraph", False), "launch_mode": launch,
-                       "env": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
-                       "parallelism": f"row-block domain decomposition x{world}"},
-            "steady_state": (None if steady is None else {"steps": 2000, "ms_per_step": round(steady * 1e3, 5), "vcycles_per_s": round(1.0 / steady, 1)}),
-            "device_ms_per_step": round(ms_dev, 5), "device_timed_steps": max(200, min(args.steps, 500)),
-            "device_vcycles_per_s": round(1e3 / ms_dev, 1),
-            "vcycle_algorithmic_bytes": vbytes,
-            "vcycle_achieved_GBs": round(vbytes / (ms_dev * 1e-3) / 1e9, 1),
-            "setup_s": round(setup_s, 4),
-            "setup_breakdown_ms": setup_breakdown,
-            "fine_level_spmv": fine,
-            "roofline": roof,
-            "cpu_baseline": cpu,
-        })
-        if gs is not None:
-            out["l1_gauss_seidel_cycle"] = gs
-        if hbm is not None:
-            out["hbm_bound_cycle"] = hbm
-        if solve is not None:
-            out["solve"] = solve
-        if not darcy and (args.amge or args.hex):
-            out["amge"] = amge_rec
-            out["config"]["interpolators"] = amge_rec["what"]
-        if darcy and "amge" in dar:
-            rec = dar["amge"]
-            lv0, parts = rec.pop("level0", None), rec.pop("parts", None)
-            n_ae = sum(l["agglomerates"] for l in rec["levels"])
-            rec["agglomerates_per_s"] = round(n_ae / rec["coarsen_total_s"], 1)
-            if lv0 is not None:
-                rec["kernel_ms_total"] = round(sum(sum(l["kernel_ms"].values()) for l in rec["levels"]), 3)
-            if lv0 is not None and not args.no_cpu_baseline:
-                # CPU port of the same coarsening (oracle/amge.py: numpy, entity by entity) on a bounded sample: the levels
-                # with at most 4000 agglomerates, reached with the oracle's own coarse levels being skipped -- the device's
-                # levels are equal to 1e-10 (tests/test_gpu_amge.py), so the sample starts from them
-                from oracle import amge as oa
-                from parelag_amd import amge as pa
-                cur, done, t_cpu = lv0, 0, 0.0
-                for part in parts:
-                    n_here = int(part.max()) + 1
-                    if n_here <= 4000 and t_cpu < 3 * args.cpu_seconds:
-                        t1 = time.perf_counter()
-                        res = oa.coarsen(cur, part)
-                        t_cpu += time.perf_counter() - t1
-                        done += n_here
-                    else:
-                        res = pa.coarsen(cur, part)
-                    cur = res["coarse"]
-                if done:
-                    rec["cpu_port"] = {"agglomerates_per_s": round(done / t_cpu, 1), "cores": 1, "kind": "port",
-                                       "sample": f"{done} agglomerates (the levels with <= 4000 of them) in {t_cpu:.2f} s, oracle/amge.py"}
-            out["amge"] = rec
-        print(json.dumps(out))
+        dog.cancel()
+    emit(large)
 
 
 if __name__ == "__main__":
