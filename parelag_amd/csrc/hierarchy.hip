@@ -786,6 +786,8 @@ struct elag_hip_hierarchy_s {
                         AP.reset(new DevCSR());
                         k::csr_spgemm(F.A->diag, C.P->diag, *AP, false);
                     }
+                    if (getenv("ELAG_HIP_FLAT_VERBOSE"))
+                        fprintf(stderr, "[elag_hip] level %d: nnz(A) %lld + nnz(P) %lld against nnz(A P) %lld\n", l, (long long)F.A->diag.nnz, (long long)C.P->diag.nnz, (long long)AP->nnz);
                     if (AP->nnz > F.A->diag.nnz + C.P->diag.nnz) continue;
                     k::CsrCombine sop;
                     sop.B = &C.P->diag; sop.b_scale = -1.0; sop.b_row = dinv; sop.b_row_divide = 1;
