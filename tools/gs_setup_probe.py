@@ -1,5 +1,7 @@
+"""Hierarchy setup with the reference's shipped relaxation ("L1 Gauss-Seidel") on 1 / 256 / 2048 virtual ranks: build time by phase, first
+and second Mult (tuning aid)."""
 import sys, os, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from parelag_amd import linalg as la, meshgen
 A, Ps, _ = meshgen.h1_problem(3)

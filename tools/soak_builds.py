@@ -2,7 +2,7 @@
 with a V-cycle each -- device memory in use before and after (a leak shows as growth), every result equal to the first bit for bit.
 usage: soak_builds.py [k] [N] [smoother]"""
 import sys, time, ctypes as C, numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from parelag_amd import meshgen, linalg as la, _lib
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
