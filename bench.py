@@ -271,7 +271,7 @@ def large_workload(args, dist, world, kL, la, meshgen, distributed, np, barrier)
     from parelag_amd import meshgen_sharded as msh
     comm = msh.TorchComm(dist._td, dist.rank, world)
     t0 = time.time()
-    shards = msh.sharded_h1_problem(comm, kL)
+    shards = msh.sharded_h1_problem(comm, kL, order="tree")          # (a rank's dofs by the refinement tree: the numbering the SpMV's gathers want)
     genL = dist.allreduce_max(time.time() - t0)
     starts = shards["starts"]
     sizes = [int(st[-1]) for st in starts]

@@ -137,8 +137,9 @@ def _refine_surface(mesh: TetMesh, tri: np.ndarray) -> np.ndarray:
     return np.sort(ch, axis=1)
 
 
-def _number_level(comm, mesh: TetMesh, iface: np.ndarray):
-    """block numbering of one level: (gid: local vertex -> global dof, owned: bool per local vertex, starts)"""
+def _number_level(comm, mesh: TetMesh, iface: np.ndarray, numbering: str = "natural"):
+    """block numbering of one level: (gid: local vertex -> global dof, owned: bool per local vertex, owner, starts, row_order: the owned
+    local vertices in the order of their global numbers)"""
     def local():
         shared = np.unique(iface)
         return mesh.nv, shared, mesh.vertices[shared] + 0.0          # (+0.0: no negative zeros in the keys)
@@ -162,46 +163,54 @@ def _number_level(comm, mesh: TetMesh, iface: np.ndarray):
     off = np.concatenate([[0], np.cumsum(counts)])
     if np.any(gsize < 2):                                            # (every rank sees every list: all ranks raise together)
         raise RuntimeError("sharded generator: an interface vertex has no partner on another rank")
-    # every rank's numbering of its shared vertices, from the gathered lists alone
-    starts = np.zeros(W + 1, dtype=np.int64)
-    nonowned, bn = [], []
-    for q in range(W):
-        nv_q, shared_q = msgs[q][0], msgs[q][1]
-        no = own_rank[off[q]:off[q + 1]] != q
-        nonowned.append(shared_q[no])
-        starts[q + 1] = starts[q] + nv_q - int(no.sum())
-        bn.append(shared_q - (np.cumsum(no) - no))                  # local rank among q's owned vertices (garbage where not owned)
-    for q in range(W):
-        bn[q] = bn[q] + starts[q]
-    lv = np.arange(mesh.nv, dtype=np.int64)
-    gid = starts[r] + lv - np.searchsorted(nonowned[r], lv)
-    owned = np.ones(mesh.nv, dtype=bool)
+    # who owns what is now known everywhere; every rank orders its OWN vertices and publishes where its shared ones landed
     mine = slice(off[r], off[r + 1])
     shared, no = msgs[r][1], own_rank[mine] != r
+    owned = np.ones(mesh.nv, dtype=bool)
     owned[shared[no]] = False
+    if numbering == "tree":
+        # by the refinement tree: a vertex goes with the first tet that holds it (children of tet i are 8 i .. 8 i + 7, so the tet number IS
+        # a position in the tree) -- neighbours in the mesh end up close in memory at every scale, which is what the SpMV's gathers want
+        key = np.full(mesh.nv, mesh.nt, dtype=np.int64)
+        np.minimum.at(key, mesh.tets.reshape(-1), np.repeat(np.arange(mesh.nt, dtype=np.int64), 4))
+    elif numbering == "natural":
+        key = np.arange(mesh.nv, dtype=np.int64)                 # local order = the serial generator's order restricted to this rank
+    else:
+        raise ValueError("order must be 'natural' or 'tree'")
+    own_ids = np.nonzero(owned)[0]
+    row_order = own_ids[np.argsort(key[own_ids], kind="stable")]    # this rank's rows, in the order of their global numbers
+    local_rank = np.full(mesh.nv, -1, dtype=np.int64)
+    local_rank[row_order] = np.arange(len(row_order))
+    placed = agree(comm, lambda: (len(row_order), local_rank[shared]))
+    starts = np.concatenate([[0], np.cumsum([p[0] for p in placed])]).astype(np.int64)
+    gid = np.where(owned, starts[r] + local_rank, -1)
     orr, opp = own_rank[mine][no], own_pos[mine][no]
     g = np.empty(len(orr), dtype=np.int64)
     for q in np.unique(orr):
         sel = orr == q
-        g[sel] = bn[q][opp[sel]]
+        g[sel] = starts[q] + placed[q][1][opp[sel]]
+    if len(g) and g.min() < 0:
+        raise RuntimeError("sharded generator: an owner did not number one of its shared vertices")
     gid[shared[no]] = g
     owner = np.full(mesh.nv, r, dtype=np.int64)
     owner[shared[no]] = orr
-    return gid, owned, owner, starts
+    return gid, owned, owner, starts, row_order
 
 
-def _owned_rows(M: sp.csr_matrix, owned: np.ndarray, gid_cols: np.ndarray, ncols_global: int) -> sp.csr_matrix:
-    """rows of the owned local dofs (ascending local order = ascending global order), columns in global numbering"""
-    R = M[np.nonzero(owned)[0]].tocsr()
+def _owned_rows(M: sp.csr_matrix, row_order: np.ndarray, gid_cols: np.ndarray, ncols_global: int) -> sp.csr_matrix:
+    """rows of the owned local dofs in the order of their global numbers, columns in global numbering"""
+    R = M[row_order].tocsr()
     out = sp.csr_matrix((R.data, gid_cols[R.indices].astype(np.int32 if ncols_global < 2**31 else np.int64), R.indptr), shape=(R.shape[0], ncols_global))
     out.has_sorted_indices = False
     out.sort_indices()
     return out
 
 
-def sharded_h1_problem(comm, nref: int, nlevels: int | None = None, base=None):
-    """This rank's rows of ``meshgen.h1_problem(nref, nlevels)`` in the block numbering of
-    ``partition.distributed_h1_hierarchy(..., comm.world)``.
+def sharded_h1_problem(comm, nref: int, nlevels: int | None = None, base=None, order: str = "natural"):
+    """This rank's rows of ``meshgen.h1_problem(nref, nlevels)``.  ``order="natural"``: in the block numbering of
+    ``partition.distributed_h1_hierarchy(..., comm.world)`` (a rank's dofs in the serial generator's order); ``order="tree"``: a rank's dofs
+    ordered by the refinement tree instead (a symmetric permutation of the same problem inside every rank's block: same partition, same
+    owners) -- the numbering a bandwidth-bound SpMV wants, and the one ``bench.py`` uses for its GPU-filling workload.
 
     Returns dict(A_rows, P_rows=[...], starts=[...], n_local_vertices, generate_local_s): ``A_rows`` = owned rows of the
     fine operator (global columns), ``P_rows[l]`` = owned rows of the interpolator level l+1 -> l, ``starts[l]`` = the row
@@ -223,14 +232,14 @@ def sharded_h1_problem(comm, nref: int, nlevels: int | None = None, base=None):
         return len(meshes)
     nl = agree(comm, refine_all)[0]
     meshes, ifaces = state["meshes"], state["ifaces"]
-    num = [_number_level(comm, meshes[l], ifaces[l]) for l in range(nl)]
+    num = [_number_level(comm, meshes[l], ifaces[l], order) for l in range(nl)]
     starts = [n[3] for n in num]
 
     # fine operator: Neumann sub-assembly, essential rows / columns zeroed with the pattern kept (meshgen.eliminate_rowcol; the unit
     # diagonal of an essential row comes from its owner alone), rows of shared vertices travel to their owners
     def local_operator():
         fine = meshes[0]
-        gid, owned, owner, st = num[0]
+        gid, owned, owner, st, _rows = num[0]
         S = fine.M0_P1_stiffness()
         mk = fine.boundary_marker_unit_cube()
         rows = np.repeat(np.arange(fine.nv), np.diff(S.indptr))
@@ -268,11 +277,12 @@ def sharded_h1_problem(comm, nref: int, nlevels: int | None = None, base=None):
             f, c = meshes[l], meshes[l + 1]
             P = interp_P0(c, f)
             P.data[c.boundary_marker_unit_cube()[P.indices]] = 0.0           # meshgen.eliminate_cols
-            P_rows.append(_owned_rows(P, num[l][1], num[l + 1][0], int(starts[l + 1][-1])))
+            P_rows.append(_owned_rows(P, num[l][4], num[l + 1][0], int(starts[l + 1][-1])))
         state["A"], state["P"] = A, P_rows
         return True
     agree(comm, assemble)
-    return dict(A_rows=state["A"], P_rows=state["P"], starts=starts, n_local_vertices=[m.nv for m in meshes], rank=comm.rank, world=comm.world)
+    return dict(A_rows=state["A"], P_rows=state["P"], starts=starts, n_local_vertices=[m.nv for m in meshes], rank=comm.rank, world=comm.world,
+                gid=[n[0] for n in num], owned=[n[1] for n in num])
 
 
 def parcsr_piece(comm, rows: sp.csr_matrix, row_starts, col_starts):

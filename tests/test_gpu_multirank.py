@@ -155,8 +155,9 @@ def test_distributed_vcycle_matches_serial_oracle(problem, world, replicate_from
         assert r1 < 0.6 * r0
 
 
+@pytest.mark.parametrize("numbering", ["natural", "tree"])
 @pytest.mark.parametrize("world,replicate_from", [(2, 1), (3, 2), (4, 1)])
-def test_hierarchy_from_sharded_generator_is_the_serial_cycle(problem, world, replicate_from):
+def test_hierarchy_from_sharded_generator_is_the_serial_cycle(problem, world, replicate_from, numbering):
     """no rank holds a global operator: every rank generates its own sub-domain (meshgen_sharded), the ParCSR pieces and comm
     packages come from the rows alone, and the V-cycle and the PCG solve on them are the serial oracle's"""
     from parelag_amd import distributed, linalg as la, meshgen_sharded as msh, partition
@@ -169,21 +170,29 @@ def test_hierarchy_from_sharded_generator_is_the_serial_cycle(problem, world, re
 
     def body(dist):
         comm = msh.ThreadComm(group, dist.rank)
-        shards = msh.sharded_h1_problem(comm, 2)
+        shards = msh.sharded_h1_problem(comm, 2, order=numbering)
         H, n_local, shapes, _ = distributed.build_hierarchy_sharded(dist, comm, shards, "L1 Jacobi", replicate_from=replicate_from)
         st = H._dist_info["levels"][0]["starts"]
         assert np.array_equal(st, starts)
         lo, hi = int(st[dist.rank]), int(st[dist.rank + 1])
-        rhs = la.DeviceVector.from_numpy(b_nat[order][lo:hi])
+        # position of this rank's dofs in the serial problem's block numbering ("tree" permutes inside the rank's block)
+        pos = np.arange(lo, hi)
+        if numbering == "tree":
+            nat = msh.sharded_h1_problem(comm, 2, order="natural")
+            ow = shards["owned"][0]
+            pos = np.empty(hi - lo, dtype=np.int64)
+            pos[shards["gid"][0][ow] - lo] = nat["gid"][0][ow]
+        rhs = la.DeviceVector.from_numpy(b_nat[order][pos])
         sol = la.DeviceVector(n_local, 7.0)
         H.Mult(rhs, sol)
         la.synchronize()
-        x = sol.to_numpy()
+        x = np.empty(hi - lo); x[pos - lo] = sol.to_numpy()
         K = la.KrylovSolver(H.GetOperator(0), H, params)
         sol2 = la.DeviceVector(n_local, 0.0)
         K.Mult(rhs, sol2)
         la.synchronize()
-        out = (x, (lo, hi), shapes, K.GetConverged(), K.GetNumIterations(), sol2.to_numpy())
+        x2 = np.empty(hi - lo); x2[pos - lo] = sol2.to_numpy()
+        out = (x, (lo, hi), shapes, K.GetConverged(), K.GetNumIterations(), x2)
         del K, H, rhs, sol, sol2
         return out
     res = run_ranks(world, body)
