@@ -323,6 +323,13 @@ int elag_hip_init(int device)
         hipDeviceProp_t prop;
         ELAG_HIP_CHECK(hipGetDeviceProperties(&prop, device));
         c.num_cus = prop.multiProcessorCount;
+        {
+            static std::once_flag preloaded;           // (code objects are per process, contexts per host thread)
+            std::call_once(preloaded, [] {
+                const char *e = getenv("ELAG_HIP_NO_PRELOAD");
+                if (!(e && atoi(e))) { k::preload_setup_kernels(); k::preload_spmv_kernels(); k::preload_dense_kernels(); }
+            });
+        }
         ELAG_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
         ELAG_HIP_CHECK(hipStreamCreateWithFlags(&c.comm_stream, hipStreamNonBlocking));
         ELAG_HIP_CHECK(hipEventCreateWithFlags(&c.ev_pack, hipEventDisableTiming));

@@ -359,6 +359,12 @@ void dense_mm(int nr, int nk, int m, const double *M, const double *X, double *o
     ELAG_LAUNCH_CHECK();
 }
 
+void preload_dense_kernels()
+{
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(dense_mm_kernel));
+}
+
 void dense_times_csr_t(int nc, int n, const double *Bc, const DevCSR &GT, double *X)
 {
     ELAG_REQUIRE(GT.nrows == n && GT.ncols == nc, "internal: dense_times_csr_t shape");

@@ -110,6 +110,12 @@ void flat_sum_launch(const FlatSum &S, const double *rhs, double *sol, hipStream
 void build_stream_plan(DevCSR &A);
 // builds the x-cache form of a stream-kernel matrix if it pays (synchronous, allocates: never call while capturing);
 // spmv_fused does this lazily on the first uncaptured launch, hierarchies do it for their operators at Finalize
+// Kernels live in per-source code objects that the HIP runtime loads when the first kernel of a source is used: the first sparse product
+// of a process paid ~10 ms for it inside what a caller times as hierarchy setup (cube456 x3: 15.7 ms against 5.0 ms for every later
+// build).  elag_hip_init touches one kernel of each large source instead (once per process).
+void preload_setup_kernels();   // kernels_setup.hip
+void preload_spmv_kernels();    // kernels_spmv.hip
+void preload_dense_kernels();   // dense.hip
 void prepare_spmv(const DevCSR &A, bool force = false);
 void longest_row(int nrows, const int *I, int *d_out);      // *d_out = max_r I[r + 1] - I[r] (device scalar, compute stream)
 

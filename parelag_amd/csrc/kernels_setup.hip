@@ -1273,6 +1273,12 @@ void csr_rap(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, bool 
     csr_spgemm(R, AP, C, spmv_plan);
 }
 
+void preload_setup_kernels()
+{
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(matmul_ub_kernel));
+}
+
 void csr_add(double ca, const DevCSR &A, double cb, const DevCSR &B, DevCSR &C)
 {
     ELAG_REQUIRE(A.nrows == B.nrows && A.ncols == B.ncols, "add: incompatible matrix dimensions");

@@ -615,6 +615,12 @@ void launch_stream(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hipSt
 
 }  // namespace
 
+void preload_spmv_kernels()
+{
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(stream_plan_kernel));
+}
+
 void build_stream_plan(DevCSR &A)
 {
     hipStream_t st = ctx().stream;
