@@ -687,7 +687,7 @@ struct Arena {
             base = nullptr;
             cap = want + want / 4;
             if (std::getenv("ELAG_HIP_ARENA_TRACE")) std::fprintf(stderr, "[arena] grow to %zu MiB\n", cap >> 20);
-            ELAG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&base), cap));
+            base = static_cast<char *>(device_malloc(cap));
         }
         off = 0;
         want = 0;
@@ -703,7 +703,7 @@ struct Arena {
         }
         void *p = nullptr;
         if (std::getenv("ELAG_HIP_ARENA_TRACE")) std::fprintf(stderr, "[arena] spill %zu KiB (cap %zu MiB, used %zu MiB)\n", bytes >> 10, cap >> 20, off >> 20);
-        ELAG_HIP_CHECK(hipMalloc(&p, bytes));
+        p = device_malloc(bytes);
         spill.push_back(p);
         return p;
     }

@@ -118,6 +118,8 @@ int debug_poison();  // ELAG_HIP_DEBUG_POISON=<byte>: fill every fresh allocatio
 // returns what it kept.  (hipMallocAsync's pool is not used: see Temp.)
 void *raw_alloc(size_t bytes);
 void raw_free(void *p);
+void *device_malloc(size_t bytes);      // hipMalloc; on out-of-memory the calling thread's cached blocks and idle scratch slabs go back first, then one retry
+size_t alloc_cache_release();           // drains the compute stream and frees what this thread's AllocScope cache and idle scratch slabs hold; bytes given back
 struct AllocScope {
     bool active = false;
     explicit AllocScope(bool enable);
@@ -216,6 +218,13 @@ struct DevCSR {
     // by owners that keep the values fixed; the value-changing setup kernels drop it.
     mutable int *Js = nullptr;
     mutable int sign_state = 0; // 0 = not examined, 1 = built, -1 = values are not all in {-1, 0, 1}
+    // "W-slot" copy of a matrix whose rows hold at most 4 entries (the interpolators of the lowest-order sequence as RIGHT factors of a sparse
+    // product: kernels_setup.hip, csr_rap_ell): row r at [r * ellW, (r + 1) * ellW), column -1 past the row's end.  Built on first use, kept
+    // for the next product with the same right factor (a P serves the Galerkin product and the level's S = A P - W^-1 P), dropped with
+    // the sign form whenever values change.
+    mutable int *ellJ = nullptr;
+    mutable double *ella = nullptr;
+    mutable int ellW = 0;
 
     static constexpr int kStreamNnz = 2048;     // entries per 256-thread workgroup
     static constexpr int kStreamMaxRow = 4096;  // longer rows fall back to the row-group kernel
@@ -234,6 +243,7 @@ struct DevCSR {
             xc_block_row = o.xc_block_row; xc_nblocks = o.xc_nblocks; xc_window = o.xc_window;
             o.lidx = nullptr; o.uoff = nullptr; o.ucols = nullptr; o.xc_state = 0; o.xc_block_row = nullptr; o.xc_nblocks = 0; o.xc_window = 0;
             Js = o.Js; sign_state = o.sign_state; o.Js = nullptr; o.sign_state = 0;
+            ellJ = o.ellJ; ella = o.ella; ellW = o.ellW; o.ellJ = nullptr; o.ella = nullptr; o.ellW = 0;
             o.I = o.J = nullptr; o.a = nullptr; o.block_row = nullptr; o.nnz = 0; o.nrows = o.ncols = 0; o.nblocks = 0;
         }
         return *this;
@@ -246,7 +256,7 @@ struct DevCSR {
         xc_block_row = nullptr; xc_nblocks = 0; xc_window = 0;
         xc_state = 0;
     }
-    void release_sign() const { dev_free(Js); sign_state = 0; }
+    void release_sign() const { dev_free(Js); sign_state = 0; dev_free(ellJ); dev_free(ella); ellW = 0; }   // every form derived from the VALUES
     void release() { release_xc(); release_sign(); dev_free(I); dev_free(J); dev_free(a); dev_free(block_row); nblocks = 0; }
     void alloc(int nr, int nc, int64_t nz);
     void alloc_entries(int64_t nz);   // J / a (+pad) for a matrix whose I is already in place

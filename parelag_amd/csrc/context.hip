@@ -6,6 +6,7 @@
 #include <chrono>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 
 namespace elag {
@@ -22,6 +23,16 @@ void fail(int code, const char *fmt, ...)
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     throw Error(code, buf);
+}
+
+// Kernel arguments in device memory.  On hosts whose HIP runtime keeps kernel arguments in host memory every kernel of a launch-bound cycle
+// pays ~2 us more (cube456 x3: 43.7 k against 61.1 k V-cycles/s, profiles/r03_bench_default_kernarg_*.json).  The runtime reads
+// HIP_FORCE_DEV_KERNARG when it initialises (at the first HIP call of the process), so the library makes 1 the default when it is LOADED --
+// a C++ caller that links -lelag_hip gets it without touching its launcher; a value the user exported is left alone.  Priority 101: before
+// this library's own code-object registration (which is what may initialise the runtime).
+__attribute__((constructor(101))) static void elag_hip_default_environment()
+{
+    setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
 }
 
 Context &ctx()
@@ -63,7 +74,7 @@ void *scratch_push(size_t bytes, int *slab, size_t *prev_top)
         if (!slabs.empty()) cap = std::max(cap, 2 * slabs.back().cap);
         cap = std::max(cap, bytes);
         ScratchSlab s{nullptr, cap, 0};
-        ELAG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s.p), cap));
+        s.p = static_cast<char *>(device_malloc(cap));
         slabs.push_back(s);
         cur++;
     }
@@ -127,6 +138,11 @@ void DevCSR::upload(int nr, int nc, const int *hi, const int *hj, const double *
         ELAG_HIP_CHECK(hipMemcpyAsync(a, ha, sizeof(double) * (size_t)nz, hipMemcpyHostToDevice, st));
     }
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    // (the longest row is free here -- the row pointers are on the host -- and it is what decides whether a sparse product may take this
+    // matrix through its W-slot copy: kernels_setup.hip, ell_applies)
+    int longest = 0;
+    for (int i = 0; i < nr; i++) longest = std::max(longest, hi[i + 1] - hi[i]);
+    known_max_row = longest;
     choose_spmv_shape();
 }
 
@@ -171,6 +187,7 @@ void DevCSR::choose_spmv_shape()
     // the window plan (and the longest row) is what the stream kernels need: operators below their size gate get it when someone asks
     // for it (csr_sort_rows, a forced form) -- an allocation, two launches and a drain less per small matrix at setup
     if (nnz >= (int64_t(1) << 20)) k::build_stream_plan(*this);
+    if (max_row_nnz == 0 && known_max_row > 0) max_row_nnz = known_max_row;      // (kept for operators below the gate too: ell_applies asks for it)
     known_max_row = 0;         // (a builder's hint holds for the call that follows it, no longer)
     if (forced > 0) { lanes_per_row = forced; return; }
     // the stream kernel wins once the matrix outgrows the caches' latency regime; small (coarse-level) operators
@@ -226,7 +243,7 @@ void *raw_alloc(size_t bytes)
     void *p = nullptr;
     if (t_cache.depth > 0) {
         auto it = t_cache.blocks.lower_bound(sz);
-        if (it != t_cache.blocks.end() && it->first <= sz + sz / 4) {
+        if (it != t_cache.blocks.end() && it->first <= sz + sz / 8) {
             p = it->second;
             t_cache.held -= it->first;
             std::lock_guard<std::mutex> lk(g_alloc_mu);
@@ -235,10 +252,42 @@ void *raw_alloc(size_t bytes)
             return p;
         }
     }
-    ELAG_HIP_CHECK(hipMalloc(&p, sz));
+    p = device_malloc(sz);
     std::lock_guard<std::mutex> lk(g_alloc_mu);
     g_alloc_size[p] = sz;
     return p;
+}
+
+// Every growing allocation of the library (raw_alloc, the Temp arena's slabs, the coarsening arena) comes through here: when the driver is
+// out of memory the calling thread's cache of freed blocks (AllocScope: up to kCacheMaxHeld of them during a hierarchy build) and its idle
+// scratch slabs are what stands between the request and success -- drain the compute stream (cached blocks may still be read by queued
+// kernels), hand them back and try once more.
+void *device_malloc(size_t bytes)
+{
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        const size_t given = alloc_cache_release();
+        if (given > 0) e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) fail(ELAG_HIP_ERR_HIP, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    return p;
+}
+
+size_t alloc_cache_release()
+{
+    size_t given = 0;
+    Context &c = ctx();
+    if (t_cache.blocks.empty() && (c.slabs.empty() || c.cur_slab + 1 >= (int)c.slabs.size())) return 0;
+    if (c.stream) (void)hipStreamSynchronize(c.stream);
+    for (auto &b : t_cache.blocks) { (void)hipFree(b.second); given += b.first; }
+    t_cache.blocks.clear();
+    t_cache.held = 0;
+    // scratch slabs above the one in use hold nothing
+    for (size_t i = (size_t)(c.cur_slab + 1); i < c.slabs.size(); i++) { (void)hipFree(c.slabs[i].p); given += c.slabs[i].cap; }
+    c.slabs.resize((size_t)(c.cur_slab + 1));
+    return given;
 }
 
 void raw_free(void *p)
@@ -289,11 +338,20 @@ void poll_then_block(Query query, Block block)
     const double budget = spin_budget_ms();
     if (budget > 0.0) {
         const auto t0 = std::chrono::steady_clock::now();
+        // the first ~50 us in a tight loop (a launch-bound cycle is over by then), afterwards the core is offered to whoever else can run between
+        // two polls: the in-process rank threads of a multi-rank test, or the process-per-core CPU baseline sharing the host, are not starved
+        // by a waiting thread
+        bool polite = false;
         for (int it = 0;; it++) {
             const hipError_t e = query();
             if (e == hipSuccess) return;
             if (e != hipErrorNotReady) ELAG_HIP_CHECK(e);
-            if ((it & 63) == 63 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > budget) break;
+            if (polite) std::this_thread::yield(); else __builtin_ia32_pause();
+            if ((it & 15) == 15) {
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                if (ms > budget) break;
+                if (ms > 0.05) polite = true;
+            }
         }
     }
     ELAG_HIP_CHECK(block());
@@ -328,6 +386,16 @@ int elag_hip_init(int device)
             std::call_once(preloaded, [] {
                 const char *e = getenv("ELAG_HIP_NO_PRELOAD");
                 if (!(e && atoi(e))) { k::preload_setup_kernels(); k::preload_spmv_kernels(); k::preload_dense_kernels(); }
+            });
+        }
+        {
+            static std::once_flag warned;
+            std::call_once(warned, [] {
+                const char *e = getenv("HIP_FORCE_DEV_KERNARG");
+                if (!(e && atoi(e)) && !getenv("ELAG_HIP_QUIET"))
+                    fprintf(stderr, "[elag_hip] warning: HIP_FORCE_DEV_KERNARG=%s: kernel arguments may live in host memory and every kernel of a "
+                                    "launch-bound V-cycle then costs ~2 us more (about -30 %% V-cycles/s on small hierarchies); export HIP_FORCE_DEV_KERNARG=1 "
+                                    "before the process starts (INTEGRATION.md)\n", e ? e : "(unset)");
             });
         }
         ELAG_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));

@@ -64,6 +64,7 @@ struct elag_hip_hierarchy_s {
     bool finalized = false;
     bool use_graph = false;
     bool all_local = true;
+    bool dist_pieces = false;           // some operator is a rank's piece of a distributed one: Finalize's decisions are taken by all ranks together
     std::vector<GraphEntry> graphs;
     // objects created by elag_hip_hierarchy_build (owned)
     std::vector<ParCSR *> owned_mats;
@@ -162,6 +163,19 @@ struct elag_hip_hierarchy_s {
             if (L.P && L.P->needs_exchange()) local_only = false;
         }
         if (coarse && (coarse->replicated || coarse->custom_apply)) local_only = false;
+        // A hierarchy whose operators are pieces of distributed ones is finalised by all of its ranks together, and what follows (plan_fused's
+        // distributed products) is collective: the ranks must take the same branch even when one of them happens to have no off-rank coupling
+        // (a user-assembled partition with an isolated sub-domain) -- agree on the AND of the ranks' views.
+        dist_pieces = false;
+        for (auto &L : lev) {
+            if (L.A && is_distributed(*L.A)) dist_pieces = true;
+            if (L.P && is_distributed(*L.P)) dist_pieces = true;
+        }
+        if (dist_pieces && comm_active()) {
+            double not_local = local_only ? 0.0 : 1.0;
+            comm_allreduce_scalar(&not_local, 1);
+            local_only = not_local == 0.0;
+        }
         all_local = local_only;
         use_graph = graph && local_only;
         phase("fused_level_operators", [&] { plan_fused(); });
@@ -751,27 +765,50 @@ struct elag_hip_hierarchy_s {
                 continue;
             }
             const double *dinv = F.pre ? F.pre->diag_scaling() : nullptr;
-            if (disabled || !dinv || !F.post || !F.post->diag_scaling() || F.pre->A != F.A || F.post->A != F.A ||
-                !F.pre->same_scaling_as(F.post))
-                continue;
+            bool diag_level = !(disabled || !dinv || !F.post || !F.post->diag_scaling() || F.pre->A != F.A || F.post->A != F.A ||
+                                !F.pre->same_scaling_as(F.post));
             if (!all_local) {
                 // ---- l1-Jacobi level of a hierarchy that lives on several ranks ----
                 const char *nf = getenv("ELAG_HIP_NO_DIST_LEVEL_FUSION");          // (read at every Finalize: a test switches it)
                 if ((nf && atoi(nf)) || !comm_active()) continue;
-                const int n = F.A->nrows();
-                std::unique_ptr<ParCSR> AP(distributed_matmul(*F.A, *C.P));
-                std::unique_ptr<ParCSR> WP(parcsr_clone(*C.P));
-                {
-                    Temp<double> winv((size_t)n);
-                    k::vec_reciprocal_scale(n, 1.0, dinv, winv);
-                    k::csr_scale_rows(WP->diag, winv);
-                    if (WP->offd.nnz) k::csr_scale_rows(WP->offd, winv);
-                    ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+                // the products below are collective: every rank enters them or none does (a rank's own smoother may differ), and a rank that
+                // fails inside (memory, a row beyond the SpGEMM's limits) must not leave the others waiting in the next collective
+                if (dist_pieces) {
+                    double no = diag_level ? 0.0 : 1.0;
+                    comm_allreduce_scalar(&no, 1);
+                    diag_level = no == 0.0;
                 }
-                F.Sd.reset(distributed_add(1.0, *AP, -1.0, *WP));
+                if (!diag_level) continue;
+                const int n = F.A->nrows();
+                std::shared_ptr<ParCSR> Sd;
+                double failed = 0.0;
+                std::string why;
+                try {
+                    std::unique_ptr<ParCSR> AP(distributed_matmul(*F.A, *C.P));
+                    std::unique_ptr<ParCSR> WP(parcsr_clone(*C.P));
+                    {
+                        Temp<double> winv((size_t)n);
+                        k::vec_reciprocal_scale(n, 1.0, dinv, winv);
+                        k::csr_scale_rows(WP->diag, winv);
+                        if (WP->offd.nnz) k::csr_scale_rows(WP->offd, winv);
+                        ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+                    }
+                    Sd.reset(distributed_add(1.0, *AP, -1.0, *WP));
+                } catch (const Error &e) {
+                    // (an error between two collectives of the products desynchronises the ranks for good: only what fails before or after
+                    // them is recoverable, and that is what the agreement below covers)
+                    failed = 1.0; why = e.what();
+                }
+                if (dist_pieces) comm_allreduce_scalar(&failed, 1);
+                if (failed != 0.0) {
+                    if (getenv("ELAG_HIP_FLAT_VERBOSE")) fprintf(stderr, "[elag_hip] level %d keeps the separate sweeps on every rank (%s)\n", l, why.empty() ? "another rank failed" : why.c_str());
+                    continue;
+                }
+                F.Sd = Sd;
                 F.dist_w = dinv;
                 continue;
             }
+            if (!diag_level) continue;
             if (F.A->offd.ncols > 0 || C.P->offd.ncols > 0) continue;
             if (F.A->diag.nnz >= max_nnz) {
                 // ---- bandwidth-bound l1-Jacobi level: only the way up changes.  With r = f - A W f kept from the way down,
@@ -1339,7 +1376,10 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
             elag_hip_parcsr_t Ac = nullptr;
             const bool diag_relax = opt.relax_type == ELAG_HIP_SMOOTHER_L1_JACOBI || opt.relax_type == ELAG_HIP_SMOOTHER_JACOBI ||
                                     opt.relax_type == ELAG_HIP_SMOOTHER_LUMPED_JACOBI || opt.relax_type == ELAG_HIP_SMOOTHER_HYPRE_JACOBI;
-            if (!D && diag_relax && !is_distributed(*Af) && !is_distributed(*Pl) && Af->diag.nnz >= (int64_t(1) << 20)) {
+            // (the same size gate as plan_fused's bandwidth-bound branch, which is the one consumer of AP_kept: ELAG_HIP_FUSE_NNZ, read at every build)
+            const char *e_nnz = getenv("ELAG_HIP_FUSE_NNZ");
+            const long long keep_nnz = e_nnz ? atoll(e_nnz) : (1ll << 20);
+            if (!D && diag_relax && !is_distributed(*Af) && !is_distributed(*Pl) && Af->diag.nnz >= keep_nnz) {
                 // the product of elag_hip_parcsr_rap, with A P kept for plan_fused (a bandwidth-bound level goes up through S = A P - W^-1 P)
                 ELAG_REQUIRE(Af->ncols() == Pl->nrows(), "rap: shapes do not chain");
                 std::shared_ptr<DevCSR> AP(new DevCSR());

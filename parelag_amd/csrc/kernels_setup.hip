@@ -10,6 +10,10 @@
 // wave64 + LDS instead of a per-thread marker array.
 #include "kernels.hpp"
 
+#include <cmath>
+#include <mutex>
+#include <type_traits>
+
 namespace elag {
 namespace k {
 
@@ -111,6 +115,80 @@ void exclusive_scan(const int *in, int *out, int n)
     ELAG_LAUNCH_CHECK();
 }
 
+// 64-bit variant (two quantities scanned at once: a count in the high word, a sum below 2^31 in the low one)
+namespace {
+typedef long long i64;
+__device__ __forceinline__ i64 wave_incl_scan64(i64 v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const i64 t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ i64 block_excl_scan64(i64 v, i64 *sh /*>= 4*/, i64 *total)
+{
+    const i64 incl = wave_incl_scan64(v);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 63) sh[w] = incl;
+    __syncthreads();
+    i64 off = 0, tot = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) {
+        const i64 s = sh[i];
+        if (i < w) off += s;
+        tot += s;
+    }
+    *total = tot;
+    return off + incl - v;
+}
+__global__ __launch_bounds__(kBlock) void scan64_block_sums(const i64 *__restrict__ in, int n, i64 *__restrict__ bsum)
+{
+    __shared__ i64 sh[4];
+    const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+    i64 s = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (base + q < n) s += in[base + q];
+    i64 tot;
+    block_excl_scan64(s, sh, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(kBlock) void scan64_block_final(const i64 *__restrict__ in, int n, const i64 *__restrict__ boff, i64 *__restrict__ out)
+{
+    __shared__ i64 sh[4];
+    const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+    i64 v[4], s = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { v[q] = (base + q < n) ? in[base + q] : 0; s += v[q]; }
+    i64 tot;
+    i64 off = block_excl_scan64(s, sh, &tot) + (boff ? boff[blockIdx.x] : 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (base + q < n) out[base + q] = off;
+        off += v[q];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) out[n] = off;
+}
+void exclusive_scan64(const i64 *in, i64 *out, int n)
+{
+    hipStream_t st = ctx().stream;
+    if (n == 0) { ELAG_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(i64), st)); return; }
+    const int nb = (n + 1023) / 1024;
+    if (nb == 1) {
+        hipLaunchKernelGGL(scan64_block_final, dim3(1), dim3(kBlock), 0, st, in, n, (const i64 *)nullptr, out);
+    } else {
+        Temp<i64> bsum((size_t)nb), boff((size_t)nb + 1);
+        hipLaunchKernelGGL(scan64_block_sums, dim3(nb), dim3(kBlock), 0, st, in, n, bsum.p);
+        exclusive_scan64(bsum, boff, nb);
+        hipLaunchKernelGGL(scan64_block_final, dim3(nb), dim3(kBlock), 0, st, in, n, (const i64 *)boff.p, out);
+    }
+    ELAG_LAUNCH_CHECK();
+}
+}  // namespace
+
 // ================================================================================================
 // ESC engine
 // ================================================================================================
@@ -123,7 +201,9 @@ struct CsrView {
     const int *I, *J;
     const double *a;
     const int *len = nullptr;      // rows shorter than I[r + 1] - I[r] (a LooseCSR operand); null: plain CSR
+    int iscale = 1;                // a loose operand whose rows start at iscale * I[r] (A * ELL(B) left in its layout: W times A's row pointers)
     __device__ int rowlen(int r) const { return len ? len[r] : I[r + 1] - I[r]; }
+    __device__ int rowbeg(int r) const { return I[r] * iscale; }
 };
 
 // Expanders: ub(row) = number of expanded entries, expand(row) writes them at lds offset `off`.
@@ -138,7 +218,7 @@ struct MatmulExpander {
     {
         const int j = A.J[ubeg + u];
         scale = A.a[ubeg + u];
-        pbeg = B.I[j]; plen = B.rowlen(j);
+        pbeg = B.rowbeg(j); plen = B.rowlen(j);
         J = B.J; a = B.a;
     }
     // cooperative expansion of one row by a group of G lanes (G = 64: a wavefront)
@@ -154,7 +234,7 @@ struct MatmulExpander {
             int pos = off + incl - len;
             if (len) {
                 const double av = NUMERIC ? A.a[k] : 0.0;
-                const int bs = B.I[j];
+                const int bs = B.rowbeg(j);
                 for (int q = 0; q < len; q++) {
                     key[pos + q] = ((u64)rl << 32) | (unsigned)B.J[bs + q];
                     if (NUMERIC) val[pos + q] = av * B.a[bs + q];
@@ -193,7 +273,7 @@ __device__ bool matmul_expand_flat(const CsrView &A, const CsrView &B, int row, 
     for (int p = threadIdx.x; p < total; p += blockDim.x) {
         int lo = 0, hi = na;                                           // the entry whose run holds product p: pre[lo] <= p < pre[lo + 1]
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= p) lo = mid; else hi = mid; }
-        const int j = A.J[as + lo], q = B.I[j] + (p - pre[lo]);
+        const int j = A.J[as + lo], q = B.rowbeg(j) + (p - pre[lo]);
         key[p] = (u64)(unsigned)B.J[q];
         if (NUMERIC) val[p] = A.a[as + lo] * B.a[q];
     }
@@ -544,6 +624,7 @@ __global__ __launch_bounds__(BLOCK) void esc_hash_kernel(int nrows, Expander ex,
                                                          int *__restrict__ CJ, double *__restrict__ Ca, const int *__restrict__ rowlist, int nlist)
 {
     constexpr int NG = BLOCK / G;
+    constexpr int NGW = 64 / G;              // lane groups (rows) per wavefront
     constexpr int LOG2S = S == 16 ? 4 : S == 32 ? 5 : S == 64 ? 6 : S == 128 ? 7 : 8;
     static_assert((1 << LOG2S) == S, "table sizes are 16 ... 256");
     __shared__ int key[NG * S];
@@ -552,9 +633,14 @@ __global__ __launch_bounds__(BLOCK) void esc_hash_kernel(int nrows, Expander ex,
     const int gi = blockIdx.x * NG + g;
     const bool active = gi < nlist;
     const int row = active ? rowlist[gi] : 0;
-    int *kt = key + g * S;
-    double *vt = val + g * S;
-    for (int s = lane; s < S; s += G) kt[s] = -1;
+    // The tables of a wavefront's NGW rows are INTERLEAVED: slot s of row-group gw lives at s * NGW + gw.  During the serialised inserts one lane
+    // per group is active and each goes to a random slot of its own table: with a table per group stored contiguously (g * S + h) the bank is
+    // h mod 32 -- random, 58 % of this kernel's LDS cycles were bank conflicts (profiles/r03_rap_pmc_final.txt) and the LDS pipeline was busy 65 %
+    // of its time.  Interleaved, the bank of (gw, s) is gw + NGW * (s mod 32 / NGW) for the 4-byte keys and 2 gw + ... for the 8-byte sums:
+    // the groups of a half-wavefront never meet on a bank, whatever their slots.
+    int *kt = key + (g / NGW) * (NGW * S) + (g % NGW);
+    double *vt = val + (g / NGW) * (NGW * S) + (g % NGW);
+    for (int s = lane; s < S; s += G) kt[s * NGW] = -1;
     int ubeg = 0, nu = 0;
     if (active) ex.units(row, ubeg, nu);
     const int gshift = (int)(threadIdx.x & 63) & ~(G - 1);          // first lane of this group inside its wavefront
@@ -587,7 +673,9 @@ __global__ __launch_bounds__(BLOCK) void esc_hash_kernel(int nrows, Expander ex,
                     if (q0 + r < plen[t]) { c[t][r] = J[t][pbeg[t] + q0 + r]; v[t][r] = a[t][pbeg[t] + q0 + r]; }
                 }
             // one lane after the other, unit after unit: the insertion order is the storage order of the products (exactly so when a
-            // unit's products fit one pass of R; a longer unit's later products follow the other units' first R -- still one fixed order)
+            // unit's products fit one pass of R; a longer unit's later products follow the other units' first R -- still one fixed order).
+            // The turns are separated by wave barriers: the compiler must not merge or reorder the mutually exclusive bodies (the lanes of a
+            // group read and write the same table; a wavefront executes its LDS operations in order).
 #pragma unroll
             for (int t = 0; t < NU; t++) {
                 for (int p = 0; p < G; p++) {
@@ -598,14 +686,15 @@ __global__ __launch_bounds__(BLOCK) void esc_hash_kernel(int nrows, Expander ex,
                                 const double pv = scale[t] * v[t][r];
                                 unsigned h = ((unsigned)c[t][r] * 2654435761u) >> (32 - LOG2S);
                                 while (true) {
-                                    const int kk = kt[h];
-                                    if (kk == c[t][r]) { vt[h] += pv; break; }
-                                    if (kk < 0) { kt[h] = c[t][r]; vt[h] = pv; break; }
+                                    const int kk = kt[h * NGW];
+                                    if (kk == c[t][r]) { vt[h * NGW] += pv; break; }
+                                    if (kk < 0) { kt[h * NGW] = c[t][r]; vt[h * NGW] = pv; break; }
                                     h = (h + 1) & (S - 1);
                                 }
                             }
                         }
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
         }
@@ -613,23 +702,206 @@ __global__ __launch_bounds__(BLOCK) void esc_hash_kernel(int nrows, Expander ex,
     // compact the occupied slots to the front of the table, chunk of G slots by chunk (every lane reads its slot before any writes)
     int E = 0;
     for (int s0 = 0; s0 < S; s0 += G) {
-        const int kk = kt[s0 + lane];
-        const double vv = vt[s0 + lane];
+        const int kk = kt[(s0 + lane) * NGW];
+        const double vv = vt[(s0 + lane) * NGW];
         unsigned long long m = __ballot(kk >= 0) & gmask;
         m >>= gshift;
-        if (kk >= 0) { const int e = E + __popcll(m & ((1ull << lane) - 1ull)); kt[e] = kk; vt[e] = vv; }
+        __builtin_amdgcn_wave_barrier();
+        if (kk >= 0) { const int e = E + __popcll(m & ((1ull << lane) - 1ull)); kt[e * NGW] = kk; vt[e * NGW] = vv; }
         E += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
     }
     if (!active) return;
     if (lane == 0) rownnz[row] = E;
     const int base = CI[row];
     for (int i = lane; i < E; i += G) {
-        const int ci = kt[i];
+        const int ci = kt[i * NGW];
         int rank = 0;
-        for (int t = 0; t < E; t++) rank += (kt[t] < ci) ? 1 : 0;
+        for (int t = 0; t < E; t++) rank += (kt[t * NGW] < ci) ? 1 : 0;
         CJ[base + rank] = ci;
-        Ca[base + rank] = vt[i];
+        Ca[base + rank] = vt[i * NGW];
     }
+}
+
+// ---- hash path for a W-slot right factor: ordered parallel inserts, software-pipelined ------------------------------------------
+// Where esc_hash_kernel's time goes on A * ELL(B) (cube456 x5, profiles/r04_rap_pmc_*.txt): 840 VALU + 825 SALU + 220 LDS instructions per
+// wavefront of 16 rows -- the lanes of a group insert ONE AFTER THE OTHER, so every insert is a wave-wide instruction sequence for 16 useful
+// lanes, and a wave64 VALU instruction holds its SIMD for four cycles: the kernel is bound by instruction issue (a first software-pipelined
+// version with the same serialised inserts hid the memory latency and was SLOWER, 545 against 420 us: fewer waves, same instructions).
+// Here the lanes of a group insert TOGETHER.  Lane l of the group holds slot l % LPU of unit l / LPU of the step at hand, so ascending lanes are
+// ascending products in storage order; the key is claimed with an LDS compare-and-swap and the value added with the LDS f64 atomic.  Lanes
+// of ONE instruction that meet on an address are served in ascending lane order on gfx950 -- measured (tools/lds_atomic_order_probe.cpp: 504 000
+// groups of 2 ... 64 lanes, every one the left-to-right sum) and CHECKED once per process before this kernel is ever chosen
+// (lds_atomics_lane_ordered) -- and a wavefront's LDS instructions execute in order, so a column's products are added in storage order:
+// the bits of the serial insertion, at one instruction sequence per G products instead of one per product.
+// The loads are software-pipelined over the rows a group walks: while row m is inserted, the slots of row m+1, the entries of row m+2, the
+// bounds of row m+3 and the number of row m+4 are in flight.
+// LPU = min(W, R) lanes per unit: where esc_hash_kernel takes R < W products per unit and turn, a unit's later slots follow every unit's first
+// R (pass after pass) -- the same order here, so that every route of a product gives the same bits.
+template <int G, int NSP, int W, int R, int S, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void ell_hash_kernel(CsrView A, const int *__restrict__ EJ, const double *__restrict__ Ea, int *__restrict__ rownnz,
+                                                        int *__restrict__ CJ, double *__restrict__ Ca, const int *__restrict__ rowlist,
+                                                        const int *__restrict__ nlist_dev, int nlist_host, int nlists, int list_cap, int lo,
+                                                        int *__restrict__ ovf_list, int *__restrict__ ovf_count, int ovf_nlists, int ovf_cap)
+{
+    // Rows: the list `rowlist` (its length on the device, nlist_dev: the rows an earlier launch passed on) or, without a list, rows 0 .. nlist_host - 1.
+    // The launch takes the rows of more than `lo` and at most NSP * UPS entries; a longer row is appended to ovf_list for a wider launch, or only
+    // counted, or -- without ovf_count -- left alone like the short ones (another launch over the same rows takes it).
+    // Lists come in sets of `nlists` (list l at rowlist + l * list_cap, its length at nlist_dev[32 l]; workgroup b reads list b mod nlists):
+    // a sixth of the rows of A at cube456 x5 are too long for the first launch, and that many atomics on ONE counter cost 2.3 ms (5.9 ns each) --
+    // a wavefront reserves room for its rows with one atomic, on the counter of the list it is assigned (128 bytes apart: other channels).
+    constexpr int NG = BLOCK / G;
+    constexpr int LPU = W < R ? W : R;          // lanes per unit
+    constexpr int NPASS = W / LPU;              // passes over the units (slots [q * LPU, (q + 1) * LPU) in pass q)
+    constexpr int UPS = G / LPU;                // units per step
+    constexpr int NS = NSP * NPASS;             // steps per row
+    constexpr int MAXU = NSP * UPS;             // entries per row at most
+    constexpr int LOG2S = S == 16 ? 4 : S == 32 ? 5 : S == 64 ? 6 : S == 128 ? 7 : 8;
+    constexpr int LOG2MIN = G <= 16 ? 4 : 5;    // a row's table: the smallest power of two >= its products, at least 16 slots and a slot per lane
+    static_assert((1 << LOG2S) == S, "table sizes are 16 ... 256");
+    static_assert(W % LPU == 0 && G % LPU == 0 && W * MAXU <= S, "slots and lanes split evenly over the units; a full row fits the table");
+    // the tables of a half-wavefront's groups start G banks apart (a table of 32 k entries per group puts the lanes l of ALL its groups on bank l:
+    // every initialisation, compaction and ranking access was a 4-way conflict, 56 % of the LDS cycles -- profiles/r04_rap_pmc_ordered.txt)
+    constexpr int TS = S + (G < 32 ? G : 0);
+    __shared__ int key[NG * TS];
+    __shared__ double val[NG * TS];
+    const int g = threadIdx.x / G, lane = threadIdx.x & (G - 1);
+    int *kt = key + g * TS;
+    double *vt = val + g * TS;
+    const int gshift = (int)(threadIdx.x & 63) & ~(G - 1);
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << gshift;
+    const int lu = lane / LPU, ls = lane % LPU;
+    int nlist = nlist_dev ? *nlist_dev : nlist_host;
+    long long tg = (long long)gridDim.x * NG;                        // groups of the launch: trip m takes list entries [m * tg, (m + 1) * tg)
+    long long first = (long long)blockIdx.x * NG + g;
+    if (nlists > 1) {
+        const int l = (int)(blockIdx.x % (unsigned)nlists);
+        rowlist += (size_t)l * list_cap;
+        nlist = nlist_dev[32 * l];
+        tg = (long long)(gridDim.x / (unsigned)nlists) * NG;
+        first = (long long)(blockIdx.x / (unsigned)nlists) * NG + g;
+    }
+    const int trips = (int)((nlist + tg - 1) / tg);
+    // pipeline registers: stage 0 = row number, stage 1 = row bounds, stage 2 = A's entries, stage 3 = products (already scaled)
+    int row0 = -1;
+    int row1 = -1, ub1 = 0, nu1 = 0;
+    int row2 = -1, ub2 = 0, nu2 = 0, j2[NSP];
+    double s2[NSP];
+    int row3 = -1, ub3 = 0, nu3 = 0, c3[NS];
+    double v3[NS];
+#pragma unroll
+    for (int t = 0; t < NSP; t++) { j2[t] = -1; s2[t] = 0.0; }
+#pragma unroll
+    for (int t = 0; t < NS; t++) { c3[t] = -1; v3[t] = 0.0; }
+    for (int m = -4; m < trips; m++) {
+        // ---- issue this trip's loads (each uses what the previous trip's loads brought) ----
+        int row0n = -1;
+        {
+            const long long li = first + (long long)(m + 4) * tg;
+            if (m + 4 < trips && li < nlist) row0n = rowlist ? rowlist[li] : (int)li;
+        }
+        int ub1n = 0, nu1n = 0;
+        if (row0 >= 0) { ub1n = A.I[row0]; nu1n = A.I[row0 + 1] - ub1n; }
+        {                                                   // too long for this launch: pass the row on (one atomic per wavefront and trip)
+            const bool ovf = nu1 > MAXU;                       // (uniform over the group)
+            const unsigned long long om = __ballot(ovf && lane == 0);
+            if (om && ovf_count) {
+                const int wl = ovf_nlists > 1 ? (int)((blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) % (unsigned)ovf_nlists) : 0;
+                const int leader = __ffsll((long long)om) - 1;
+                int basek = 0;
+                if ((int)(threadIdx.x & 63) == leader) basek = atomicAdd(ovf_count + 32 * wl, __popcll(om));
+                basek = __shfl(basek, leader, 64);
+                if (ovf && lane == 0 && ovf_list) {
+                    const int k = basek + __popcll(om & ((1ull << (threadIdx.x & 63)) - 1ull));
+                    if (k < ovf_cap) ovf_list[(size_t)wl * ovf_cap + k] = row1;            // (k >= ovf_cap cannot happen: the caller sized the lists; the count would tell)
+                }
+            }
+            if (ovf) { row1 = -1; nu1 = 0; }
+        }
+        if (nu1 <= lo) { row1 = -1; nu1 = 0; }              // (another launch's row; an empty row: its count stays the memset's zero)
+        int j2n[NSP];
+        double s2n[NSP];
+#pragma unroll
+        for (int t = 0; t < NSP; t++) {
+            const int u = t * UPS + lu;
+            j2n[t] = -1; s2n[t] = 0.0;
+            if (u < nu1) { j2n[t] = A.J[ub1 + u]; s2n[t] = A.a[ub1 + u]; }
+        }
+        int c3n[NS];
+        double v3n[NS];
+#pragma unroll
+        for (int t = 0; t < NS; t++) {
+            const int tu = t % NSP, slot = (t / NSP) * LPU + ls;
+            c3n[t] = -1; v3n[t] = 0.0;
+            if (j2[tu] >= 0) { c3n[t] = EJ[(unsigned)(j2[tu] * W + slot)]; v3n[t] = Ea[(unsigned)(j2[tu] * W + slot)]; }
+        }
+        // ---- the row whose products arrived during the previous trip ----
+        if (row3 >= 0) {
+            int l2 = 32 - __clz(W * nu3 - 1);                // table of this row: 2^l2 >= its products
+            l2 = l2 < LOG2MIN ? LOG2MIN : l2;
+            const int Srow = 1 << l2;
+            for (int s = lane; s < Srow; s += G) { kt[s] = -1; vt[s] = 0.0; }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < NS; t++) {
+                if (c3[t] >= 0) {
+                    unsigned h = ((unsigned)c3[t] * 2654435761u) >> (32 - l2);
+                    while (true) {
+                        const int prev = atomicCAS(&kt[h], -1, c3[t]);
+                        if (prev == -1 || prev == c3[t]) break;
+                        h = (h + 1) & (Srow - 1);
+                    }
+                    atomicAdd(&vt[h], v3[t]);
+                }
+                __builtin_amdgcn_wave_barrier();            // (a step's LDS atomics stay in front of the next step's: compiler fence, no instruction)
+            }
+            int E = 0;
+            for (int s0 = 0; s0 < Srow; s0 += G) {
+                const int kk = kt[s0 + lane];
+                const double vv = vt[s0 + lane];
+                unsigned long long mk = __ballot(kk >= 0) & gmask;
+                mk >>= gshift;
+                __builtin_amdgcn_wave_barrier();
+                if (kk >= 0) { const int e = E + __popcll(mk & ((1ull << lane) - 1ull)); kt[e] = kk; vt[e] = vv; }
+                E += __popcll(mk);
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (lane == 0) rownnz[row3] = E;
+            const unsigned base = (unsigned)ub3 * W;                 // the upper-bound layout of A * ELL(B): W times A's row pointers
+            for (int i = lane; i < E; i += G) {
+                const int ci = kt[i];
+                int rank = 0;
+                for (int t = 0; t < E; t++) rank += (kt[t] < ci) ? 1 : 0;
+                CJ[base + rank] = ci;
+                Ca[base + rank] = vt[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- rotate ----
+        row3 = row2; ub3 = ub2; nu3 = nu2;
+#pragma unroll
+        for (int t = 0; t < NS; t++) { c3[t] = c3n[t]; v3[t] = s2[t % NSP] * v3n[t]; }
+        row2 = row1; ub2 = ub1; nu2 = nu1;
+#pragma unroll
+        for (int t = 0; t < NSP; t++) { j2[t] = j2n[t]; s2[t] = s2n[t]; }
+        row1 = row0; ub1 = ub1n; nu1 = nu1n;
+        row0 = row0n;
+    }
+}
+
+// one instruction's same-address LDS f64 atomic adds are applied in ascending lane order (and the lowest lane wins a same-slot compare-and-swap):
+// what ell_hash_kernel's bits rest on, checked on the device the first time it matters
+__global__ void lds_order_probe_kernel(const double *__restrict__ v, double *__restrict__ out, int *__restrict__ winner)
+{
+    __shared__ double acc[16];
+    __shared__ int key[16];
+    const int t = threadIdx.x, g = t >> 2;
+    if (t < 16) { acc[t] = 0.0; key[t] = -1; }
+    __syncthreads();
+    atomicAdd(&acc[g], v[blockIdx.x * 64 + t]);
+    (void)atomicCAS(&key[g], -1, t);
+    __syncthreads();
+    if ((t & 3) == 0) { out[blockIdx.x * 16 + g] = acc[g]; winner[blockIdx.x * 16 + g] = key[g]; }
 }
 
 // ---- hash path, unit after unit ---------------------------------------------------------------------------------------
@@ -649,14 +921,15 @@ __global__ __launch_bounds__(BLOCK) void esc_hashu_kernel(int nrows, Expander ex
     constexpr int NG = BLOCK / G;
     constexpr int LOG2S = S == 16 ? 4 : S == 32 ? 5 : S == 64 ? 6 : S == 128 ? 7 : 8;
     static_assert((1 << LOG2S) == S, "table sizes are 16 ... 256");
-    __shared__ int key[NG * S];
-    __shared__ double val[NG * S];
+    constexpr int TS = S + (G < 32 ? G : 0);                         // (tables G banks apart: see ell_hash_kernel)
+    __shared__ int key[NG * TS];
+    __shared__ double val[NG * TS];
     const int g = threadIdx.x / G, lane = threadIdx.x & (G - 1);
     const int gi = blockIdx.x * NG + g;
     const bool active = gi < nlist;
     const int row = active ? rowlist[gi] : 0;
-    int *kt = key + g * S;
-    double *vt = val + g * S;
+    int *kt = key + g * TS;
+    double *vt = val + g * TS;
     for (int s = lane; s < S; s += G) { kt[s] = -1; vt[s] = 0.0; }
     int ubeg = 0, nu = 0;
     if (active) ex.units(row, ubeg, nu);
@@ -704,6 +977,7 @@ __global__ __launch_bounds__(BLOCK) void esc_hashu_kernel(int nrows, Expander ex
                 const double *at = reinterpret_cast<const double *>(__shfl((unsigned long long)a, t, G));
                 for (int q = G * RP + lane; q < pl; q += G) insert(Jt[pb + q], sc * at[pb + q]);
             }
+            __builtin_amdgcn_wave_barrier();                        // (a turn's LDS atomics stay in front of the next turn's: compiler fence, no instruction)
         }
     }
     // compact the occupied slots to the front of the table, chunk of G slots by chunk (every lane reads its slot before any writes)
@@ -713,8 +987,10 @@ __global__ __launch_bounds__(BLOCK) void esc_hashu_kernel(int nrows, Expander ex
         const double vv = vt[s0 + lane];
         unsigned long long m = __ballot(kk >= 0) & gmask;
         m >>= gshift;
+        __builtin_amdgcn_wave_barrier();
         if (kk >= 0) { const int e = E + __popcll(m & ((1ull << lane) - 1ull)); kt[e] = kk; vt[e] = vv; }
         E += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
     }
     if (!active) return;
     if (lane == 0) rownnz[row] = E;
@@ -726,6 +1002,144 @@ __global__ __launch_bounds__(BLOCK) void esc_hashu_kernel(int nrows, Expander ex
         CJ[base + rank] = ci;
         Ca[base + rank] = vt[i];
     }
+}
+
+// ---- hash path, unit after unit, without a plan -------------------------------------------------------------------------------
+// esc_hashu_kernel for the second product of a triple product whose first stayed in its layout (csr_rap_ell): the rows are addressed directly
+// (or through the list an earlier launch passed on, its length on the device), a row's upper bound `ub` and offset `UBI` come from one
+// kernel and one scan -- no classes, no lists, no numbers the host would have to wait for.  A row of more than S products is appended to
+// ovf_list for the next, wider launch (or only counted); a row's table is the smallest power of two that holds its products.
+template <int G, int S, int RP, int BLOCK, class Expander>
+__global__ __launch_bounds__(BLOCK) void esc_hashd_kernel(Expander ex, const int *__restrict__ ub, const int *__restrict__ UBI, int *__restrict__ rownnz,
+                                                          int *__restrict__ CJ, double *__restrict__ Ca, const int *__restrict__ rowlist,
+                                                          const int *__restrict__ nlist_dev, int nlist_host, int *__restrict__ ovf_list, int *__restrict__ ovf_count)
+{
+    constexpr int NG = BLOCK / G;
+    constexpr int LOG2MIN = G <= 16 ? 4 : 5;
+    constexpr int TS = S + (G < 32 ? G : 0);                         // (tables G banks apart: see ell_hash_kernel)
+    __shared__ int key[NG * TS];
+    __shared__ double val[NG * TS];
+    const int g = threadIdx.x / G, lane = threadIdx.x & (G - 1);
+    int *kt = key + g * TS;
+    double *vt = val + g * TS;
+    const int gshift = (int)(threadIdx.x & 63) & ~(G - 1);          // first lane of this group inside its wavefront
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << gshift;
+    const int nlist = nlist_dev ? *nlist_dev : nlist_host;
+    for (long long li = (long long)blockIdx.x * NG + g; li < nlist; li += (long long)gridDim.x * NG) {
+        const int row = rowlist ? rowlist[li] : (int)li;
+        const int u = ub[row];
+        if (u == 0) continue;                                            // (its count stays the memset's zero)
+        if (u > S) {                                                     // (left to a wider launch -- the caller listed it -- or, there, counted)
+            if (ovf_count && lane == 0) { const int k = atomicAdd(ovf_count, 1); if (ovf_list) ovf_list[k] = row; }
+            continue;
+        }
+        int l2 = 32 - __clz(u - 1);
+        l2 = l2 < LOG2MIN ? LOG2MIN : l2;
+        const int Srow = 1 << l2;
+        for (int s = lane; s < Srow; s += G) { kt[s] = -1; vt[s] = 0.0; }
+        int ubeg = 0, nu = 0;
+        ex.units(row, ubeg, nu);
+        auto insert = [&](int c, double pv) {
+            unsigned h = ((unsigned)c * 2654435761u) >> (32 - l2);
+            while (true) {
+                const int prev = atomicCAS(&kt[h], -1, c);
+                if (prev == -1 || prev == c) break;
+                h = (h + 1) & (Srow - 1);
+            }
+            atomicAdd(&vt[h], pv);
+        };
+        for (int u0 = 0; u0 < nu; u0 += G) {
+            int pbeg = 0, plen = 0;
+            double scale = 0.0;
+            const int *J = nullptr;
+            const double *a = nullptr;
+            if (u0 + lane < nu) ex.unit(row, ubeg, u0 + lane, pbeg, plen, scale, J, a);
+            int c[G][RP];
+            double v[G][RP];
+#pragma unroll
+            for (int t = 0; t < G; t++) {
+                const int pb = __shfl(pbeg, t, G), pl = __shfl(plen, t, G);
+                const int *Jt = reinterpret_cast<const int *>(__shfl((unsigned long long)J, t, G));
+                const double *at = reinterpret_cast<const double *>(__shfl((unsigned long long)a, t, G));
+#pragma unroll
+                for (int r = 0; r < RP; r++) {
+                    const int q = lane + r * G;
+                    c[t][r] = -1; v[t][r] = 0.0;
+                    if (q < pl) { c[t][r] = Jt[pb + q]; v[t][r] = at[pb + q]; }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < G; t++) {
+                const double sc = __shfl(scale, t, G);
+                const int pl = __shfl(plen, t, G);
+#pragma unroll
+                for (int r = 0; r < RP; r++)
+                    if (c[t][r] >= 0) insert(c[t][r], sc * v[t][r]);
+                if (pl > G * RP) {                                      // (uniform over the group)
+                    const int pb = __shfl(pbeg, t, G);
+                    const int *Jt = reinterpret_cast<const int *>(__shfl((unsigned long long)J, t, G));
+                    const double *at = reinterpret_cast<const double *>(__shfl((unsigned long long)a, t, G));
+                    for (int q = G * RP + lane; q < pl; q += G) insert(Jt[pb + q], sc * at[pb + q]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        int E = 0;
+        for (int s0 = 0; s0 < Srow; s0 += G) {
+            const int kk = kt[s0 + lane];
+            const double vv = vt[s0 + lane];
+            unsigned long long m = __ballot(kk >= 0) & gmask;
+            m >>= gshift;
+            __builtin_amdgcn_wave_barrier();
+            if (kk >= 0) { const int e = E + __popcll(m & ((1ull << lane) - 1ull)); kt[e] = kk; vt[e] = vv; }
+            E += __popcll(m);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) rownnz[row] = E;
+        const int base = UBI[row];
+        for (int i = lane; i < E; i += G) {
+            const int ci = kt[i];
+            int rank = 0;
+            for (int t = 0; t < E; t++) rank += (kt[t] < ci) ? 1 : 0;
+            CJ[base + rank] = ci;
+            Ca[base + rank] = vt[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// upper bound of a row's products, 8 lanes per row (matmul_ub_kernel walks a row with one thread: 27 us for the 325 k rows of P^T at cube456 x5),
+// packed for ONE scan of two quantities: the bound in the low word, in the high word 1 for a row beyond `wide` products (the rows the first
+// launch of esc_hashd_kernel leaves to the second)
+__global__ __launch_bounds__(kBlock) void matmul_ub8_kernel(int nrows, CsrView A, CsrView B, int wide, int *__restrict__ ub, long long *__restrict__ packed)
+{
+    const int row = (int)((blockIdx.x * (long long)kBlock + threadIdx.x) >> 3);
+    const int lane = threadIdx.x & 7;
+    int s = 0;
+    if (row < nrows)
+        for (int k = A.I[row] + lane; k < A.I[row + 1]; k += 8) s += B.rowlen(A.J[k]);
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) s += __shfl_xor(s, o, 8);
+    if (row < nrows && lane == 0) { ub[row] = s; packed[row] = ((long long)(s > wide ? 1 : 0) << 32) | (long long)s; }
+}
+
+// the scanned pairs apart: UBI[r] = offset of row r in the upper-bound layout; the rows beyond `wide` products, in ascending order, and their number
+__global__ void rap_unpack_kernel(int nrows, const long long *__restrict__ scanned, const int *__restrict__ ub, int wide, int *__restrict__ UBI, int *__restrict__ wide_list,
+                                  int *__restrict__ wide_count)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row > nrows) return;
+    const long long v = scanned[row];
+    UBI[row] = (int)(v & 0xffffffffll);
+    if (row == nrows) { *wide_count = (int)(v >> 32); return; }
+    if (ub[row] > wide) wide_list[(int)(v >> 32)] = row;
+}
+
+// every number the host reads after a csr_rap_ell, in one block: [0..4] the launches' counters as they are, [5] nnz(C), [6] longest row of C,
+// [7] nnz(A P), [8] longest row of A P
+__global__ void rap_gather_kernel(int *__restrict__ ctl, const int *__restrict__ nnzC, const int *__restrict__ longC, const int *__restrict__ nnzAP, const int *__restrict__ longAP)
+{
+    if (threadIdx.x == 0) { ctl[5] = nnzC ? *nnzC : 0; ctl[6] = longC ? *longC : 0; ctl[7] = nnzAP ? *nnzAP : 0; ctl[8] = longAP ? *longAP : 0; }
 }
 
 // ub of the rows the wave path handles (others 0): its scan gives the rows' offsets in the upper-bound layout
@@ -745,12 +1159,12 @@ __global__ void wave_ub_kernel(int nrows, const int *__restrict__ ub, int wave_c
 // rows written in the upper-bound layout -> their final place (8 lanes per row; rows of the chunked path have ubw == 0)
 __global__ __launch_bounds__(kBlock) void esc_compact_kernel(int nrows, const int *__restrict__ ubw, const int *__restrict__ UBI,
                                                              const int *__restrict__ CI, const int *__restrict__ Ju, const double *__restrict__ au,
-                                                             int *__restrict__ CJ, double *__restrict__ Ca)
+                                                             int *__restrict__ CJ, double *__restrict__ Ca, int src_scale = 1)
 {
     const int row = (int)((blockIdx.x * (long long)kBlock + threadIdx.x) >> 3);
     const int lane = threadIdx.x & 7;
-    if (row >= nrows || ubw[row] == 0) return;
-    const int src = UBI[row], dst = CI[row], cnt = CI[row + 1] - dst;
+    if (row >= nrows || (ubw && ubw[row] == 0)) return;
+    const int src = UBI[row] * src_scale, dst = CI[row], cnt = CI[row + 1] - dst;
     for (int e = lane; e < cnt; e += 8) { CJ[dst + e] = Ju[src + e]; Ca[dst + e] = au[src + e]; }
 }
 
@@ -861,6 +1275,52 @@ inline bool hashu_enabled()
     return v != 0;
 }
 
+bool lds_atomics_lane_ordered()
+{
+    static int ordered = -1;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (ordered >= 0) return ordered == 1;
+    constexpr int NB = 64;
+    std::vector<double> v((size_t)NB * 64), out((size_t)NB * 16);
+    std::vector<int> win((size_t)NB * 16);
+    unsigned long long x = 88172645463325252ull;
+    for (auto &d : v) {                                // values of very different magnitude: any other order of the four shows in the last bits
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        d = std::ldexp((double)(x % 2000001ull) / 1e6 - 1.0, (int)((x >> 32) % 60) - 30);
+    }
+    double *dv = nullptr, *dout = nullptr;
+    int *dw = nullptr;
+    hipStream_t st = ctx().stream;
+    dv = dev_alloc<double>(v.size()); dout = dev_alloc<double>(out.size()); dw = dev_alloc<int>(win.size());
+    ELAG_HIP_CHECK(hipMemcpyAsync(dv, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(lds_order_probe_kernel, dim3(NB), dim3(64), 0, st, (const double *)dv, dout, dw);
+    ELAG_HIP_CHECK(hipMemcpyAsync(out.data(), dout, sizeof(double) * out.size(), hipMemcpyDeviceToHost, st));
+    ELAG_HIP_CHECK(hipMemcpyAsync(win.data(), dw, sizeof(int) * win.size(), hipMemcpyDeviceToHost, st));
+    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    dev_free(dv); dev_free(dout); dev_free(dw);
+    bool ok = true;
+    for (int b = 0; b < NB && ok; b++)
+        for (int g = 0; g < 16; g++) {
+            double sum = 0.0;
+            for (int l = 0; l < 4; l++) sum += v[(size_t)b * 64 + g * 4 + l];
+            if (memcmp(&sum, &out[(size_t)b * 16 + g], sizeof(double)) != 0 || win[(size_t)b * 16 + g] != g * 4) { ok = false; break; }
+        }
+    ordered = ok ? 1 : 0;
+    if (!ok && !getenv("ELAG_HIP_QUIET"))
+        fprintf(stderr, "[elag_hip] this device does not apply the LDS atomics of one instruction in lane order: sparse products keep the serialised inserts\n");
+    return ok;
+}
+
+inline bool ell_pipe_enabled()
+{
+    const char *e = getenv("ELAG_HIP_ELL_PIPE");       // (read at every product: A/B runs and a test switch it); 0 = esc_hash_kernel for the W-slot right factor too
+    return !(e && !atoi(e)) && lds_atomics_lane_ordered();
+}
+
+// slots per row of the W-slot copy of a right factor with rows of at most `max_row` entries: 2 or 4 (the widths ell_hash_kernel is built for)
+inline int ell_width(int max_row) { return max_row <= 2 ? 2 : 4; }
+
 inline bool wave_path_enabled()
 {
     static int v = -1;
@@ -885,6 +1345,7 @@ struct EscPlan {
     const int *extra = nullptr;       // an array of the caller's (extra_n entries), sampled at 64 places with the plan's own read-back (extra_value = their sum)
     int extra_n = 0, extra_value = 0;
     double unit_run = 0.0;            // products per unit on average (a product: the right factor's entries per row): picks the insertion scheme of the hash path
+    int max_unit = 0;                 // ... and at most, where the right factor knows its longest row (0: unknown)
     explicit EscPlan(int n)
         : nrows(n), ub((size_t)n), ub_small((size_t)n), ubscan((size_t)n + 1), biglist((size_t)n), counters(5 + kNumClasses), ubw((size_t)n),
           UBI((size_t)n + 1), ccount(kNumClasses), lists((size_t)kNumClasses * (size_t)n) {}
@@ -1051,8 +1512,11 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
                     if (hc[4] && (hm & 16)) ELAG_HASHU_LAUNCH(4, 16, 256, 2, 256);
                 }
 #undef ELAG_HASHU_LAUNCH
-                if (hc[0] && !done[0] && (hm & 1)) ELAG_HASH_LAUNCH(0, 4, 2, 16, 2, 256);
-                if (hc[1] && !done[1] && (hm & 2)) ELAG_HASH_LAUNCH(1, 4, 2, 32, 4, 256);
+                // (a right factor known to hold 3 or 4 entries per row: four products per unit and turn, so that a unit's products are inserted
+                // together -- storage order, the order of csr_rap_ell's kernels on the same product: every route gives the same bits)
+                const bool r4 = plan.max_unit > 2 && plan.max_unit <= 4;
+                if (hc[0] && !done[0] && (hm & 1)) { if (r4) ELAG_HASH_LAUNCH(0, 4, 4, 16, 2, 256); else ELAG_HASH_LAUNCH(0, 4, 2, 16, 2, 256); }
+                if (hc[1] && !done[1] && (hm & 2)) { if (r4) ELAG_HASH_LAUNCH(1, 4, 4, 32, 4, 256); else ELAG_HASH_LAUNCH(1, 4, 2, 32, 4, 256); }
                 if (hc[2] && !done[2] && (hm & 4)) ELAG_HASH_LAUNCH(2, 8, 4, 64, 2, 256);
                 if (hc[3] && !done[3] && (hm & 8)) ELAG_HASH_LAUNCH(3, 8, 8, 128, 2, 256);
                 if (hc[4] && !done[4] && (hm & 16)) ELAG_HASH_LAUNCH(4, 16, 8, 256, 1, 256);
@@ -1163,10 +1627,151 @@ bool ell_applies(const DevCSR &A, const DevCSR &B)
 {
     const char *e_ell = getenv("ELAG_HIP_RAP_ELL");                 // (read at every call: a test switches it)
     const int use_ell = e_ell ? atoi(e_ell) : 1;
-    const int W = B.max_row_nnz;
-    return use_ell && W >= 1 && W <= 4 && B.nnz > 0 && (long long)B.nrows * W < (1ll << 31) && hash_classes() == 31 && wave_path_enabled() &&
+    const int W = ell_width(B.max_row_nnz);
+    return use_ell && B.max_row_nnz >= 1 && B.max_row_nnz <= 4 && B.nnz > 0 && (long long)B.nrows * W < (1ll << 31) && hash_classes() == 31 && wave_path_enabled() &&
            single_pass_enabled() && A.max_row_nnz > 0 && (long long)A.max_row_nnz * W <= kWaveCap && (long long)A.nnz * W < (1ll << 31) &&
            (unsigned long long)A.nnz * W * 12ull <= (16ull << 30);
+}
+}  // namespace
+
+namespace {
+// the W-slot copy of a right factor, built once and kept with the matrix (DevCSR::ellJ / ella)
+void ensure_ell(const DevCSR &B, int W)
+{
+    if (B.ellW == W && B.ellJ && B.ella) return;
+    dev_free(B.ellJ); dev_free(B.ella);
+    B.ellJ = dev_alloc<int>((size_t)B.nrows * W);
+    B.ella = dev_alloc<double>((size_t)B.nrows * W);
+    B.ellW = W;
+    hipLaunchKernelGGL(ell_build_kernel, dim3(grid1((long long)B.nrows * W)), dim3(kBlock), 0, ctx().stream, B.nrows, W, (const int *)B.I, (const int *)B.J,
+                       (const double *)B.a, B.ellJ, B.ella);
+    ELAG_LAUNCH_CHECK();
+}
+
+unsigned stride_grid(long long groups_wanted, int groups_per_wg, long long max_wgs)
+{
+    long long wgs = (groups_wanted + groups_per_wg - 1) / groups_per_wg;
+    if (wgs > max_wgs) wgs = max_wgs;
+    return (unsigned)(wgs < 1 ? 1 : wgs);
+}
+
+// A P and, with R, C = R (A P) for a right factor P of at most 4 entries per row (the interpolators of the lowest-order sequence), without a plan:
+//   * A P: the W-slot copy of P makes the layout analytic (row i at W * A.I[i], room for every product) -- ell_hash_kernel over ALL rows, the
+//     few rows too long for it passed on to a wider launch through a list whose length stays on the device;
+//   * R (A P): the rows' upper bounds (one kernel), their scan (the layout), esc_hashd_kernel over all rows, its long rows passed on likewise;
+//   * the counts' scan, and ONE read-back after the last kernel: nnz(C), nnz(A P) when the caller wants A P as a matrix too, the longest rows
+//     (for the SpMV plans) and whether any row outgrew the widest launch -- in which case nothing has been touched and the caller takes the
+//     general route.
+// No class lists, no numbers the host waits for in the middle: ~25 dispatches and one drain where the planned route took ~55 and three
+// (profiles/r03_rap_timeline_final.txt against profiles/r04_rap_timeline.txt).  The scratch for C's upper-bound layout is sized by the host's
+// bound W x (entries of the layout of A P): the route is taken only where that fits kRapEllScratch.
+constexpr unsigned long long kRapEllScratch = 24ull << 30;
+bool rap_ell(const DevCSR *R, const DevCSR &A, const DevCSR &P, DevCSR *C, DevCSR *AP_out, bool spmv_plan)
+{
+    hipStream_t st = ctx().stream;
+    const int W = ell_width(P.max_row_nnz);
+    const int n = A.nrows, nr = R ? R->nrows : 0;
+    const unsigned long long total1 = (unsigned long long)W * (unsigned long long)A.nnz;           // entries of the layout of A P
+    const unsigned long long bound2 = R ? total1 * (unsigned long long)W : 0ull;                   // sum of the rows' upper bounds of R (A P), at most
+    if (total1 >= (1ull << 31) || bound2 >= (1ull << 31) || (total1 + bound2) * 12ull > kRapEllScratch) return false;
+    if (R && ((long long)R->nnz <= 0 || nr == 0)) return false;
+    ensure_ell(P, W);
+    Temp<int> Jap((size_t)std::max<unsigned long long>(total1, 1)), len((size_t)n), ovfA((size_t)n), ovfB((size_t)n), ctl(16);
+    Temp<double> aap((size_t)std::max<unsigned long long>(total1, 1));
+    ELAG_HIP_CHECK(hipMemsetAsync(ctl, 0, 16 * sizeof(int), st));
+    ELAG_HIP_CHECK(hipMemsetAsync(len, 0, sizeof(int) * (size_t)n, st));
+    const CsrView a{A.I, A.J, A.a};
+    // (lanes per row, steps per pass, slots, products per unit and turn as esc_hash_kernel's class table, table size): rows of at most
+    // steps x lanes / min(W, R) entries; the order of insertion is esc_hash_kernel's for the same row, so every route gives the same bits
+    // (lanes per row, steps per pass, slots, products per unit and turn, table size): rows of at most steps x lanes / W entries.
+    //   launch 1: every row, those of up to 16 (W = 2) / 8 (W = 4) entries are taken, the longer ones passed on through kLists lists;
+    //   launch 2: the lists, rows of up to 32 / 16 entries -- every row of the examples' operators is done here;
+    //   launches 3, 4: what is longer still (rare; one list), up to 64 | 128 / 32 | 64 entries; beyond that the caller takes the general route.
+    constexpr int kLists = 256;
+    const long long cus = ctx().num_cus;
+    const unsigned grid1a = stride_grid(((long long)n + 7) / 8, 32, 1ll << 30);
+    const int capA = (int)(((long long)grid1a * 4 + kLists - 1) / kLists) * (int)(((long long)n + (long long)grid1a * 32 - 1) / ((long long)grid1a * 32)) * 8;   // waves per list x trips x rows per wave and trip
+    Temp<int> listsA((size_t)kLists * (size_t)std::max(capA, 1)), cntA(32 * kLists);
+    ELAG_HIP_CHECK(hipMemsetAsync(cntA, 0, sizeof(int) * 32 * kLists, st));
+    const int *none = nullptr;
+    int *nolist = nullptr;
+#define ELAG_ELL_LAUNCH(G, NSP, WW, RR, S, GRID, LIST, NDEV, NHOST, NLISTS, CAP, LO, OVF, OVFC, ONL, OCAP)                                         \
+    hipLaunchKernelGGL((ell_hash_kernel<G, NSP, WW, RR, S, 256>), dim3(GRID), dim3(256), 0, st, a, (const int *)P.ellJ, (const double *)P.ella, len.p, Jap.p, aap.p, \
+                       LIST, NDEV, NHOST, NLISTS, CAP, LO, OVF, OVFC, ONL, OCAP)
+    const unsigned grid1b = (unsigned)(kLists * std::max<long long>(1, std::min<long long>(8, ((long long)n / 6 / 8 / 16 + kLists - 1) / kLists)));   // ~n / 6 rows, 8 trips, 16 groups
+    if (W == 2) {
+        ELAG_ELL_LAUNCH(8, 4, 2, 2, 32, grid1a, none, none, n, 0, 0, 0, listsA.p, cntA.p, kLists, capA);
+        ELAG_ELL_LAUNCH(16, 4, 2, 2, 64, grid1b, (const int *)listsA.p, (const int *)cntA.p, n, kLists, capA, 16, ovfA.p, ctl.p + 0, 1, n);
+        ELAG_ELL_LAUNCH(16, 8, 2, 2, 128, (unsigned)(2 * cus), (const int *)ovfA.p, (const int *)(ctl.p + 0), n, 0, 0, 32, ovfB.p, ctl.p + 1, 1, n);
+        ELAG_ELL_LAUNCH(32, 8, 2, 2, 256, (unsigned)(2 * cus), (const int *)ovfB.p, (const int *)(ctl.p + 1), n, 0, 0, 64, nolist, ctl.p + 2, 1, n);
+    } else {
+        ELAG_ELL_LAUNCH(8, 4, 4, 4, 32, grid1a, none, none, n, 0, 0, 0, listsA.p, cntA.p, kLists, capA);
+        ELAG_ELL_LAUNCH(16, 4, 4, 4, 64, grid1b, (const int *)listsA.p, (const int *)cntA.p, n, kLists, capA, 8, ovfA.p, ctl.p + 0, 1, n);
+        ELAG_ELL_LAUNCH(16, 8, 4, 4, 128, (unsigned)(2 * cus), (const int *)ovfA.p, (const int *)(ctl.p + 0), n, 0, 0, 16, ovfB.p, ctl.p + 1, 1, n);
+        ELAG_ELL_LAUNCH(32, 8, 4, 4, 256, (unsigned)(2 * cus), (const int *)ovfB.p, (const int *)(ctl.p + 1), n, 0, 0, 32, nolist, ctl.p + 2, 1, n);
+    }
+#undef ELAG_ELL_LAUNCH
+    ELAG_LAUNCH_CHECK();
+    int *h = reinterpret_cast<int *>(ctx().h_scalar + 10);              // (doubles 0 and 8 of the pinned block belong to the reductions)
+    // ---- A P as a matrix of its own: the scan of the rows' counts (its entries move once their total is known) ----
+    int *API = nullptr;
+    Temp<int> longAP(1);
+    if (AP_out) {
+        API = dev_alloc<int>((size_t)n + 1);
+        exclusive_scan(len, API, n);
+        longest_row(n, API, longAP.p);
+    }
+    if (!R) {
+        hipLaunchKernelGGL(rap_gather_kernel, dim3(1), dim3(64), 0, st, ctl.p, (const int *)nullptr, (const int *)nullptr, (const int *)(API + n), (const int *)longAP.p);
+        ELAG_HIP_CHECK(hipMemcpyAsync(h, ctl.p, 9 * sizeof(int), hipMemcpyDeviceToHost, st));
+        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        if (h[2] > 0) { dev_free(API); return false; }
+    } else {
+        // ---- C = R (A P) ----
+        CsrView r{R->I, R->J, R->a}, ap{A.I, Jap.p, aap.p, len.p, W};
+        Temp<int> ub2((size_t)nr), UBI2((size_t)nr + 1), rn2((size_t)nr), ovfC((size_t)nr), longC(1);
+        Temp<long long> pk((size_t)nr), pks((size_t)nr + 1);
+        Temp<int> Ju((size_t)std::max<unsigned long long>(bound2, 1));
+        Temp<double> au((size_t)std::max<unsigned long long>(bound2, 1));
+        // the rows' bounds, and in the same scan the list of the rows beyond 128 products (a sixth of them at cube456 x5: through one counter that
+        // many atomics cost more than the launch they feed)
+        hipLaunchKernelGGL(matmul_ub8_kernel, dim3(grid1((long long)nr * 8)), dim3(kBlock), 0, st, nr, r, ap, 128, ub2.p, pk.p);
+        exclusive_scan64(pk, pks, nr);
+        hipLaunchKernelGGL(rap_unpack_kernel, dim3(grid1((long long)nr + 1)), dim3(kBlock), 0, st, nr, (const long long *)pks.p, (const int *)ub2.p, 128, UBI2.p, ovfC.p, ctl.p + 3);
+        ELAG_HIP_CHECK(hipMemsetAsync(rn2, 0, sizeof(int) * (size_t)nr, st));
+        MatmulExpander ex2{r, ap};
+        hipLaunchKernelGGL((esc_hashd_kernel<8, 128, 2, 256, MatmulExpander>), dim3(stride_grid(nr, 32, 1ll << 30)), dim3(256), 0, st, ex2, (const int *)ub2.p,
+                           (const int *)UBI2.p, rn2.p, Ju.p, au.p, (const int *)nullptr, (const int *)nullptr, nr, (int *)nullptr, (int *)nullptr);
+        hipLaunchKernelGGL((esc_hashd_kernel<16, 256, 2, 256, MatmulExpander>), dim3(stride_grid(nr, 16, 4 * cus)), dim3(256), 0, st, ex2, (const int *)ub2.p,
+                           (const int *)UBI2.p, rn2.p, Ju.p, au.p, (const int *)ovfC.p, (const int *)(ctl.p + 3), nr, (int *)nullptr, ctl.p + 4);
+        ELAG_LAUNCH_CHECK();
+        int *CI = dev_alloc<int>((size_t)nr + 1);
+        exclusive_scan(rn2, CI, nr);
+        if (spmv_plan) longest_row(nr, CI, longC.p);
+        hipLaunchKernelGGL(rap_gather_kernel, dim3(1), dim3(64), 0, st, ctl.p, (const int *)(CI + nr), spmv_plan ? (const int *)longC.p : (const int *)nullptr,
+                           AP_out ? (const int *)(API + n) : (const int *)nullptr, AP_out ? (const int *)longAP.p : (const int *)nullptr);
+        ELAG_HIP_CHECK(hipMemcpyAsync(h, ctl.p, 9 * sizeof(int), hipMemcpyDeviceToHost, st));
+        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        if (h[2] > 0 || h[4] > 0) { dev_free(API); dev_free(CI); return false; }        // a row beyond the widest launch: the general route
+        C->release();
+        C->nrows = nr; C->ncols = P.ncols; C->I = CI;
+        C->alloc_entries(h[5]);
+        if (spmv_plan) C->known_max_row = h[6];
+        hipLaunchKernelGGL(esc_compact_kernel, dim3(grid1((long long)nr * 8)), dim3(kBlock), 0, st, nr, (const int *)ub2.p, (const int *)UBI2.p, (const int *)C->I,
+                           (const int *)Ju.p, (const double *)au.p, C->J, C->a, 1);
+        ELAG_LAUNCH_CHECK();
+        if (spmv_plan) C->choose_spmv_shape();
+    }
+    if (AP_out) {
+        AP_out->release();
+        AP_out->nrows = n; AP_out->ncols = P.ncols; AP_out->I = API;
+        AP_out->alloc_entries(h[7]);
+        AP_out->known_max_row = h[8];
+        hipLaunchKernelGGL(esc_compact_kernel, dim3(grid1((long long)n * 8)), dim3(kBlock), 0, st, n, (const int *)nullptr, (const int *)A.I, (const int *)AP_out->I,
+                           (const int *)Jap.p, (const double *)aap.p, AP_out->J, AP_out->a, W);
+        ELAG_LAUNCH_CHECK();
+    }
+    return true;
 }
 }  // namespace
 
@@ -1174,9 +1779,14 @@ void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C, bool spmv_plan)
 {
     ELAG_REQUIRE(A.ncols == B.nrows, "spgemm: inner dimensions differ (%d vs %d)", A.ncols, B.nrows);
     if (A.nrows == 0) { C.set_empty(0, B.ncols); return; }
+    if (ell_applies(A, B) && ell_pipe_enabled() && rap_ell(nullptr, A, B, nullptr, &C, spmv_plan)) {
+        if (spmv_plan) C.choose_spmv_shape();
+        else { C.max_row_nnz = C.known_max_row; C.known_max_row = 0; }
+        return;
+    }
     if (ell_applies(A, B)) {
         hipStream_t st = ctx().stream;
-        const int W = B.max_row_nnz;
+        const int W = ell_width(B.max_row_nnz);
         Temp<int> EJ((size_t)B.nrows * W);
         Temp<double> Ea((size_t)B.nrows * W);
         hipLaunchKernelGGL(ell_build_kernel, dim3(grid1((long long)B.nrows * W)), dim3(kBlock), 0, st, B.nrows, W, (const int *)B.I, (const int *)B.J,
@@ -1184,6 +1794,7 @@ void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C, bool spmv_plan)
         EscPlan plan(A.nrows);
         plan.wave_cap = kWaveCap;
         plan.unit_run = (double)W;
+        plan.max_unit = W;
         plan.finish_ell(A.I, W, (long long)A.nnz);
         MatmulEllExpander ex{CsrView{A.I, A.J, A.a}, EJ.p, Ea.p, W};
         esc_run(plan, ex, B.ncols, C, spmv_plan);
@@ -1194,6 +1805,7 @@ void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C, bool spmv_plan)
     hipLaunchKernelGGL(matmul_ub_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, ctx().stream, A.nrows, a, b, plan.ub.p);
     plan.wave_cap = wave_path_enabled() ? kWaveCap : 0;
     plan.unit_run = B.nrows ? (double)B.nnz / (double)B.nrows : 0.0;
+    plan.max_unit = B.max_row_nnz;
     plan.finish();
     MatmulExpander ex{a, b};
     esc_run(plan, ex, B.ncols, C, spmv_plan);
@@ -1207,7 +1819,8 @@ void csr_rap(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, bool 
     hipStream_t st = ctx().stream;
     if (loose && A.nrows > 0 && R.nrows > 0) {
         CsrView a{A.I, A.J, A.a}, p{P.I, P.J, P.a};
-        const int W = P.max_row_nnz;
+        const int W = ell_width(P.max_row_nnz);
+        if (ell_applies(A, P) && ell_pipe_enabled() && rap_ell(&R, A, P, &C, nullptr, spmv_plan)) return;
         if (ell_applies(A, P)) {
             // the right factor with W slots per row (MatmulEllExpander): valid when every row of A P takes the hash path
             Temp<int> EJ((size_t)P.nrows * W);
@@ -1217,6 +1830,7 @@ void csr_rap(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, bool 
             EscPlan plan(A.nrows);
             plan.wave_cap = kWaveCap;
             plan.unit_run = (double)W;
+            plan.max_unit = W;
             plan.finish_ell(A.I, W, (long long)A.nnz);
             if (esc_layout_fits(plan) && plan.nchunks() == 0 && plan.nbig == 0) {
                 MatmulEllExpander exl{a, EJ.p, Ea.p, W};
@@ -1242,6 +1856,7 @@ void csr_rap(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, bool 
         hipLaunchKernelGGL(matmul_ub_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, st, A.nrows, a, p, plan.ub.p);
         plan.wave_cap = wave_path_enabled() ? kWaveCap : 0;
         plan.unit_run = P.nrows ? (double)P.nnz / (double)P.nrows : 0.0;
+        plan.max_unit = P.max_row_nnz;
         plan.finish();
         MatmulExpander ex{a, p};
         if (esc_layout_fits(plan)) {
@@ -1335,6 +1950,7 @@ void csr_sort_rows(DevCSR &A)
         else if (A.max_row_nnz <= 32) hipLaunchKernelGGL((sort_rows_group_kernel<32>), dim3(grid1((long long)A.nrows * 32)), dim3(kBlock), 0, st, A.nrows, I, A.J, A.a);
         else hipLaunchKernelGGL((sort_rows_group_kernel<64>), dim3(grid1((long long)A.nrows * 64)), dim3(kBlock), 0, st, A.nrows, I, A.J, A.a);
         ELAG_LAUNCH_CHECK();
+        A.known_max_row = A.max_row_nnz;               // (sorting a row does not change its length: no second look for the longest one)
         A.choose_spmv_shape();
         return;
     }
@@ -1503,6 +2119,7 @@ void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_col
         hipLaunchKernelGGL(perm_fill_kernel, dim3(grid1((long long)n * 8)), dim3(kBlock), 0, st, n, (const int *)A.I, (const int *)A.J,
                            (const double *)A.a, d_order_rows, d_rank_cols, (const int *)out.I, out.J, out.a);
     ELAG_LAUNCH_CHECK();
+    out.known_max_row = A.max_row_nnz;                 // (a permutation of the rows keeps the longest one)
     if (A.nnz && sort_rows) csr_sort_rows(out);
     else out.choose_spmv_shape();
 }

@@ -27,7 +27,7 @@ import numpy as np
 import scipy.sparse as sp
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_FIXTURE = os.path.join(os.path.dirname(_HERE), "tests", "golden", "cube456.npz")
+_FIXTURE = os.path.join(_HERE, "data", "cube456.npz")     # the reference's benchmark mesh as arrays (an input of the workload generator, not a test fixture)
 
 # local edges / faces of a tet in terms of local vertex numbers
 _LE = np.array([[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]])

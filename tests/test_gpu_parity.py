@@ -287,11 +287,10 @@ def test_vcycle_matches_oracle(la, h1_k2, smoother, params, use_graph):
     A, Ps, _ = h1_k2
     H = device_hierarchy(la, A, Ps, smoother, params, use_graph)
     stype = la.HYPRE_SMOOTHER_TYPES[smoother]
-    eigs = None
-    if stype == 16:
-        eigs = [H.GetSmoother(l).eig_estimate() for l in range(len(Ps))] + [(1.0, 0.1)]
+    # (Chebyshev: each side runs on ITS OWN eigenvalue estimates -- the oracle's hypre_ParCSRMaxEigEstimateCG restatement on the oracle's
+    # Galerkin operators, the device's estimator on the device's; nothing is handed across)
     h = oracle_h1_hierarchy(A, Ps, smoother=stype, sweeps=params.get("Sweeps", 1), weight=params.get("Damping Factor", 1.0),
-                            order=params.get("Cheby Poly Order", 2), eigs=eigs)
+                            order=params.get("Cheby Poly Order", 2), eigs=None)
     Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"])
     rng = np.random.default_rng(21)
     for trial in range(3):      # repeated applies exercise graph replay
@@ -299,7 +298,9 @@ def test_vcycle_matches_oracle(la, h1_k2, smoother, params, use_graph):
         x, xr = np.full_like(b, 7.0), np.empty_like(b)
         H.Mult(b, x)
         Hc.apply(b, xr)
-        assert close(x, xr, tol=1e-11)
+        # (two independent 10-step Lanczos estimates agree to ~1e-10 relative -- test_chebyshev_eig_estimate_* -- and the polynomial's
+        # coefficients carry that difference into the cycle)
+        assert close(x, xr, tol=1e-11 if stype != 16 else 1e-9)
 
 
 def test_vcycle_device_vectors_solver_mode_and_symmetry(la, h1_k2):
@@ -974,12 +975,14 @@ def test_flattened_cycle_is_the_level_by_level_cycle(la, h1_k3, smoother, capfd)
         assert np.max(np.abs(outs["flat"] - xr)) <= 1e-12 * np.max(np.abs(xr))
 
 
-@pytest.mark.parametrize("reorder", [0, -1])
+@pytest.mark.parametrize("reorder", [0, -1, 1])
 def test_bandwidth_bound_level_goes_up_through_S(la, h1_k2, reorder):
     """A level too large to be launch-bound keeps the reference's way down and goes up in one pass over S = A P - W^-1 P:
     x + P e + W (f - A (x + P e)) = x + W (r - S e) with r kept from the way down (hierarchy.hip, plan_fused).  ELAG_HIP_FUSE_NNZ=1 makes
     every level of a small problem such a level; ELAG_HIP_BIG_LEVEL_S=0 is the separate prolongation + post-sweep.  Same map, and the
-    oracle's cycle, in preconditioner and in solver mode."""
+    oracle's cycle, in preconditioner and in solver mode.  The same gate makes elag_hip_hierarchy_build keep A P from the Galerkin product;
+    with reorder = 1 that kept product is permuted (rows left unsorted) before S is made from it in place -- the route only cube456 x5 and
+    larger took before."""
     import os
     from oracle import oracle as orc
     from tests.helpers import oracle_h1_hierarchy
@@ -1023,7 +1026,9 @@ def test_triple_product_routes_give_the_same_matrix(la, h1_k2, hdiv_k2):
     for A, P in cases:
         dA, dP = la.ParallelCSRMatrix.from_scipy(A), la.ParallelCSRMatrix.from_scipy(P)
         outs = []
-        for env in ({}, {"ELAG_HIP_RAP_ELL": "0"}, {"ELAG_HIP_RAP_ELL": "0", "ELAG_HIP_RAP_LOOSE": "0"}):
+        # (an uploaded matrix knows its longest row, so the W-slot route -- and its software-pipelined kernel, ELAG_HIP_ELL_PIPE -- is what the
+        # first two interpolators take by default even at this size)
+        for env in ({}, {"ELAG_HIP_ELL_PIPE": "0"}, {"ELAG_HIP_RAP_ELL": "0"}, {"ELAG_HIP_RAP_ELL": "0", "ELAG_HIP_RAP_LOOSE": "0"}):
             os.environ.update(env)
             try:
                 outs.append(la.RAP(dA, dP).to_scipy())

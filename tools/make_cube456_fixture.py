@@ -21,7 +21,7 @@ t = np.array(tok[p:p + 5 * nt], dtype=np.int64).reshape(nt, 5); p += 5 * nt
 nb = int(tok[p]); p += 1
 b = np.array(tok[p:p + 4 * nb], dtype=np.int64).reshape(nb, 4); p += 4 * nb
 assert p == len(tok)
-np.savez_compressed("tests/golden/cube456.npz",
+np.savez_compressed("parelag_amd/data/cube456.npz",
                     vertices=verts,
                     tets=(t[:, 1:] - 1).astype(np.int32), tet_attr=t[:, 0].astype(np.int32),
                     bdr_tris=(b[:, 1:] - 1).astype(np.int32), bdr_attr=b[:, 0].astype(np.int32))

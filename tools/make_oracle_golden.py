@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Golden vectors of the V-cycle path on cube456 refined once (840 -> 141 dofs), generated with the CPU oracle
 (nothing can be captured from the reference itself -- hypre/MFEM are absent -- so these pin the ORACLE against
-accidental change and give the device tests a fixed target).  Inputs are reproducible from tests/golden/cube456.npz and
+accidental change and give the device tests a fixed target).  Inputs are reproducible from parelag_amd/data/cube456.npz and
 the seeds below; outputs are stored.
 
     python tools/make_oracle_golden.py          # writes tests/golden/oracle_h1_k1.npz

@@ -16,7 +16,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for d in ("pmc", "pmc2"):
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % d, recursive=True):
         for r in csv.DictReader(open(f)):
-            m = re.search(r"(esc_wave_kernel<\d+, \d+, (?:true|false))|(esc_hash_kernel<\d+, \d+, \d+, \d+, \d+)|(esc_hashu_kernel<\d+, \d+, \d+, \d+)|esc_compact_kernel|esc_classify_kernel|esc_kernel", r["Kernel_Name"])
+            m = re.search(r"(esc_wave_kernel<\d+, \d+, (?:true|false))|(esc_hash_kernel<\d+, \d+, \d+, \d+, \d+)|(ell_hash_kernel<\d+, \d+, \d+, \d+, \d+, \d+)|(esc_hashu_kernel<\d+, \d+, \d+, \d+)|esc_compact_kernel|esc_classify_kernel|esc_kernel", r["Kernel_Name"])
             if m:
                 a = acc[m.group(0)][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 for k in sorted(acc):
