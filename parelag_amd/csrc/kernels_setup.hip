@@ -1108,6 +1108,217 @@ __global__ __launch_bounds__(BLOCK) void esc_hashd_kernel(Expander ex, const int
     }
 }
 
+// ---- the fused triple product ---------------------------------------------------------------------------------------------------
+// C = R A P in ONE pass, no stored A P: hypre's own formulation of the Galerkin product (hypre_BoomerAMGBuildCoarseOperator, the reference's call
+// at src/linalg/solver_ops/ParELAG_Hierarchy.cpp:365: for each coarse row ic, each entry i of R's row, each entry j of A's row i, each entry jc of
+// P's row j, accumulate (r * a) * p into C(ic, jc)) for a right factor with at most 4 entries per row (its W-slot copy).  The two-step route
+// pays the per-row work of a sparse product -- table, compaction, ranking, output -- once for every FINE row of A P (2.5 M of them at cube456 x5)
+// and once more for every coarse row, writes A P in a layout with room for every product and reads it back; this one pays it for the coarse
+// rows only (0.33 M) and reads A once per parent of a row.  Where A P is wanted anyway (S = A P - W^-1 P of a bandwidth-bound level) the
+// two-step route stays (rap_ell with AP_out).
+// One wavefront per coarse row.  The products of the row are numbered through: the entries of A's rows i, child after child in the storage
+// order of R's row, W slots each; a step of the wavefront takes 64 / W consecutive entries (lane l: entry l / W, slot l % W), whatever child
+// they belong to -- every lane works whatever the children's row lengths.  The child of an entry comes from the children's offsets (held
+// one child per lane, exclusive scan of their row lengths): the first entry's by one ballot, the few boundaries inside a step by
+// v_readlane.  Inserts are the ordered parallel inserts of ell_hash_kernel (ascending lanes = ascending products: the sums are those of
+// the sequential triple loop, bit for bit -- tests/test_gpu_parity.py compares them with the oracle's restatement of hypre's loop).
+// Everything is software-pipelined: steps go through  [A's entries] -> [P's slots] -> [insert]  B at a time and one trip apart, across row
+// boundaries; rows go through  [R's row bounds] -> [R's entries] -> [A's row bounds]  one row apart.  Two sets of stage registers alternate,
+// so that nothing is copied from trip to trip, and which lanes of a step hold a product is a wave-uniform mask (scalar registers).
+// A row of more than 64 children, or with more than 64 distinct columns, counts as failed: the caller takes the two-step route then.
+template <int B>
+struct FusedStageA {       // a batch of B steps whose entries of A are in flight / have arrived
+    int row = -1;
+    bool first = false, last = false;
+    unsigned long long valid[B];    // lanes of the step that hold a product (wave-uniform: scalar registers)
+    int j[B];
+    double av[B], rv[B];
+};
+template <int B>
+struct FusedStageB {       // ... whose slots of P are in flight / have arrived
+    int row = -1;
+    bool first = false, last = false;
+    unsigned long long valid[B];
+    int c[B];
+    double pv[B], sc[B];
+};
+
+template <int W, int B, int S, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void rap_fused_kernel(CsrView R, CsrView A, const int *__restrict__ EJ, const double *__restrict__ Ea, int nrows,
+                                                         int *__restrict__ rownnz, int *__restrict__ CJ, double *__restrict__ Ca, int out_stride,
+                                                         int *__restrict__ fail_count)
+{
+    constexpr int EPS = 64 / W;                  // entries of A per step
+    constexpr int NW = BLOCK / 64;
+    constexpr int LOG2S = S == 64 ? 6 : S == 128 ? 7 : 8;
+    static_assert((1 << LOG2S) == S, "table sizes are 64 ... 256");
+    __shared__ int key[NW * S];
+    __shared__ double val[NW * S];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;     // (the wavefront's number is uniform: rows, bounds and flags stay scalar)
+    int *kt = key + wave * S;
+    double *vt = val + wave * S;
+    const int le = lane / W, ls = lane % W;
+    const int tw = (int)gridDim.x * NW, wid = (int)blockIdx.x * NW + wave;
+    // ---- row pipeline: q0 = row bounds in flight, q1 = children in flight, q2 = children's bounds in A in flight, g = the row being generated ----
+    int m_next = 0;
+    int q0_row = -1, q0_kb = 0, q0_ke = 0;
+    int q1_row = -1, q1_nc = 0, q1_ci = 0;
+    double q1_rv = 0.0;
+    int q2_row = -1, q2_nc = 0, q2_ab = 0, q2_ae = 0;
+    double q2_rv = 0.0;
+    int g_row = -1, g_nc = 0, g_T = 0, g_ns = 0, g_s = 0, g_pre = 0, g_d = 0;      // g_d: a child's first entry in A minus its offset in the row's numbering
+    double g_rv = 0.0;
+    int claimed = 0;
+    bool failed = false;
+    bool more_rows = true;
+    // One trip: generate a batch (entries of A requested) into `na`, request the slots of P for the batch in `sa` into `nb`, insert the batch in `sb`.
+    auto trip = [&](FusedStageA<B> &sa, FusedStageB<B> &sb, FusedStageA<B> &na, FusedStageB<B> &nb) -> bool {
+        // ================= generator: the next B steps of the row at hand, or the next row =================
+        if (g_s >= g_ns) {
+            // ---- the row whose children's bounds arrived becomes the row at hand ----
+            g_row = q2_row; g_nc = q2_nc;
+            const int al = (lane < g_nc) ? q2_ae - q2_ab : 0;
+            g_rv = q2_rv;
+            int incl = al;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            g_pre = incl - al;
+            g_d = q2_ab - g_pre;
+            g_T = __builtin_amdgcn_readlane(incl, 63);
+            g_ns = (g_T + EPS - 1) / EPS;
+            g_s = 0;
+            // ---- the children's bounds in A of the row whose children arrived ----
+            q2_row = q1_row; q2_nc = q1_nc; q2_rv = q1_rv; q2_ab = 0; q2_ae = 0;
+            if (lane < q1_nc) { q2_ab = A.I[q1_ci]; q2_ae = A.I[q1_ci + 1]; }
+            // ---- the children of the row whose bounds arrived ----
+            q1_row = q0_row; q1_ci = 0; q1_rv = 0.0;
+            {
+                const int kb = __builtin_amdgcn_readfirstlane(q0_kb), ke = __builtin_amdgcn_readfirstlane(q0_ke);
+                int nc = ke - kb;
+                if (nc > 64) {                                  // more children than lanes: not this kernel's row
+                    if (lane == 0) atomicAdd(fail_count, 1);
+                    nc = 0;
+                }
+                q1_nc = nc;
+                if (lane < nc) { q1_ci = R.J[kb + lane]; q1_rv = R.a[kb + lane]; }
+            }
+            // ---- the bounds of the next row of this wavefront ----
+            {
+                const int row = wid + m_next * tw;
+                m_next++;
+                q0_row = -1; q0_kb = 0; q0_ke = 0;
+                if (more_rows && row < nrows) { q0_row = row; q0_kb = R.I[row]; q0_ke = R.I[row + 1]; }
+                else more_rows = false;
+            }
+        }
+        na.row = -1; na.first = false; na.last = false;
+        if (g_s < g_ns) {
+            na.row = g_row; na.first = g_s == 0; na.last = g_s + B >= g_ns;
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                const int st = g_s + b;
+                na.valid[b] = 0ull;
+                if (st < g_ns) {                                // (uniform)
+                    const int e_first = st * EPS, e_last = min(e_first + EPS, g_T) - 1, e = e_first + le;
+                    // the child of the step's first entry: the last one whose offset is <= it; the boundaries inside the step one by one
+                    const int c_lo = __popcll(__ballot(lane < g_nc && g_pre <= e_first)) - 1;
+                    int c = c_lo;
+                    for (int cn = c_lo + 1; cn < g_nc; cn++) {
+                        const int pn = __builtin_amdgcn_readlane(g_pre, cn);
+                        if (pn > e_last) break;
+                        c += (e >= pn) ? 1 : 0;
+                    }
+                    const bool ok = e <= e_last;
+                    na.valid[b] = __ballot(ok);
+                    // (every lane loads: the lanes past the row's end read the step's first entry again and are masked out of the inserts)
+                    const int cc = ok ? c : c_lo;
+                    const int q = __shfl(g_d, cc, 64) + (ok ? e : e_first);
+                    na.rv[b] = __shfl(g_rv, cc, 64);
+                    na.j[b] = A.J[q]; na.av[b] = A.a[q];
+                }
+            }
+            g_s += B;
+        }
+        // ================= P's slots of the steps whose entries of A arrived =================
+        nb.row = sa.row; nb.first = sa.first; nb.last = sa.last;
+        if (sa.row >= 0) {
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                nb.valid[b] = sa.valid[b];
+                if (sa.valid[b]) {                              // (uniform)
+                    nb.sc[b] = sa.rv[b] * sa.av[b];             // (r * a first, then * p: hypre's order)
+                    nb.c[b] = EJ[(unsigned)(sa.j[b] * W + ls)]; nb.pv[b] = Ea[(unsigned)(sa.j[b] * W + ls)];
+                }
+            }
+        }
+        // ================= inserts of the steps whose slots arrived =================
+        if (sb.row >= 0) {
+            if (sb.first) {
+                for (int s = lane; s < S; s += 64) { kt[s] = -1; vt[s] = 0.0; }
+                claimed = 0; failed = false;
+                __builtin_amdgcn_wave_barrier();
+            }
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                if (sb.valid[b]) {                              // (uniform)
+                    if (!failed && claimed > S - 64) failed = true;    // (the table could fill up during this step: more distinct columns than this kernel takes)
+                    if (!failed) {
+                        bool fresh = false;
+                        if (((sb.valid[b] >> lane) & 1ull) && sb.c[b] >= 0) {
+                            unsigned h = ((unsigned)sb.c[b] * 2654435761u) >> (32 - LOG2S);
+                            while (true) {
+                                const int prev = atomicCAS(&kt[h], -1, sb.c[b]);
+                                if (prev == -1) { fresh = true; break; }
+                                if (prev == sb.c[b]) break;
+                                h = (h + 1) & (S - 1);
+                            }
+                            atomicAdd(&vt[h], sb.sc[b] * sb.pv[b]);
+                        }
+                        claimed += __popcll(__ballot(fresh));
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (sb.last) {
+                int E = 0;
+                if (!failed) {
+                    for (int s0 = 0; s0 < S; s0 += 64) {
+                        const int kk = kt[s0 + lane];
+                        const double vv = vt[s0 + lane];
+                        const unsigned long long mk = __ballot(kk >= 0);
+                        __builtin_amdgcn_wave_barrier();
+                        if (kk >= 0) { const int e = E + __popcll(mk & ((1ull << lane) - 1ull)); kt[e] = kk; vt[e] = vv; }
+                        E += __popcll(mk);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if (E > out_stride) failed = true;
+                }
+                if (failed) {
+                    if (lane == 0) atomicAdd(fail_count, 1);
+                } else {
+                    if (lane == 0) rownnz[sb.row] = E;
+                    const long long base = (long long)sb.row * out_stride;
+                    for (int i = lane; i < E; i += 64) {
+                        const int ci = kt[i];
+                        int rank = 0;
+                        for (int t = 0; t < E; t++) rank += (kt[t] < ci) ? 1 : 0;
+                        CJ[base + rank] = ci;
+                        Ca[base + rank] = vt[i];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return !more_rows && g_s >= g_ns && q0_row < 0 && q1_row < 0 && q2_row < 0 && na.row < 0 && nb.row < 0;
+    };
+    FusedStageA<B> a0, a1;
+    FusedStageB<B> b0, b1;
+    while (true) {
+        if (trip(a0, b0, a1, b1)) break;
+        if (trip(a1, b1, a0, b0)) break;
+    }
+}
+
 // upper bound of a row's products, 8 lanes per row (matmul_ub_kernel walks a row with one thread: 27 us for the 325 k rows of P^T at cube456 x5),
 // packed for ONE scan of two quantities: the bound in the low word, in the high word 1 for a row beyond `wide` products (the rows the first
 // launch of esc_hashd_kernel leaves to the second)
@@ -1164,7 +1375,7 @@ __global__ __launch_bounds__(kBlock) void esc_compact_kernel(int nrows, const in
     const int row = (int)((blockIdx.x * (long long)kBlock + threadIdx.x) >> 3);
     const int lane = threadIdx.x & 7;
     if (row >= nrows || (ubw && ubw[row] == 0)) return;
-    const int src = UBI[row] * src_scale, dst = CI[row], cnt = CI[row + 1] - dst;
+    const int src = (UBI ? UBI[row] : row) * src_scale, dst = CI[row], cnt = CI[row + 1] - dst;
     for (int e = lane; e < cnt; e += 8) { CJ[dst + e] = Ju[src + e]; Ca[dst + e] = au[src + e]; }
 }
 
@@ -1773,6 +1984,51 @@ bool rap_ell(const DevCSR *R, const DevCSR &A, const DevCSR &P, DevCSR *C, DevCS
     }
     return true;
 }
+
+// C = R A P by rap_fused_kernel; false (nothing touched) where the route does not apply or a row outgrew it
+bool rap_fused(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, bool spmv_plan)
+{
+    const char *e = getenv("ELAG_HIP_RAP_FUSED");                     // (read at every call: A/B runs and a test switch it)
+    if (e && !atoi(e)) return false;
+    constexpr int kStride = 64;
+    hipStream_t st = ctx().stream;
+    const int W = ell_width(P.max_row_nnz);
+    const int nr = R.nrows;
+    if (nr == 0 || R.nnz == 0 || A.nnz == 0) return false;
+    if ((unsigned long long)nr * kStride >= (1ull << 31) || (unsigned long long)nr * kStride * 12ull > kRapEllScratch) return false;
+    if (R.max_row_nnz > 64) return false;                               // (known to hold a row of more than 64 children)
+    ensure_ell(P, W);
+    Temp<int> rn((size_t)nr), ctl(16), longC(1), Ju((size_t)nr * kStride);
+    Temp<double> au((size_t)nr * kStride);
+    ELAG_HIP_CHECK(hipMemsetAsync(ctl, 0, 16 * sizeof(int), st));
+    ELAG_HIP_CHECK(hipMemsetAsync(rn, 0, sizeof(int) * (size_t)nr, st));
+    const CsrView r{R.I, R.J, R.a}, a{A.I, A.J, A.a};
+    // a wavefront walks ~8 rows (the pipeline takes four rows to fill), four wavefronts per workgroup
+    const unsigned grid = stride_grid(((long long)nr + 7) / 8, 4, 1ll << 30);
+    if (W == 2)
+        hipLaunchKernelGGL((rap_fused_kernel<2, 4, 128, 256>), dim3(grid), dim3(256), 0, st, r, a, (const int *)P.ellJ, (const double *)P.ella, nr, rn.p, Ju.p, au.p, kStride, ctl.p + 2);
+    else
+        hipLaunchKernelGGL((rap_fused_kernel<4, 4, 128, 256>), dim3(grid), dim3(256), 0, st, r, a, (const int *)P.ellJ, (const double *)P.ella, nr, rn.p, Ju.p, au.p, kStride, ctl.p + 2);
+    ELAG_LAUNCH_CHECK();
+    int *CI = dev_alloc<int>((size_t)nr + 1);
+    exclusive_scan(rn, CI, nr);
+    if (spmv_plan) longest_row(nr, CI, longC.p);
+    hipLaunchKernelGGL(rap_gather_kernel, dim3(1), dim3(64), 0, st, ctl.p, (const int *)(CI + nr), spmv_plan ? (const int *)longC.p : (const int *)nullptr, (const int *)nullptr,
+                       (const int *)nullptr);
+    int *h = reinterpret_cast<int *>(ctx().h_scalar + 10);
+    ELAG_HIP_CHECK(hipMemcpyAsync(h, ctl.p, 9 * sizeof(int), hipMemcpyDeviceToHost, st));
+    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    if (h[2] > 0) { dev_free(CI); return false; }
+    C.release();
+    C.nrows = nr; C.ncols = P.ncols; C.I = CI;
+    C.alloc_entries(h[5]);
+    if (spmv_plan) C.known_max_row = h[6];
+    hipLaunchKernelGGL(esc_compact_kernel, dim3(grid1((long long)nr * 8)), dim3(kBlock), 0, st, nr, (const int *)nullptr, (const int *)nullptr, (const int *)C.I,
+                       (const int *)Ju.p, (const double *)au.p, C.J, C.a, kStride);
+    ELAG_LAUNCH_CHECK();
+    if (spmv_plan) C.choose_spmv_shape();
+    return true;
+}
 }  // namespace
 
 void csr_spgemm(const DevCSR &A, const DevCSR &B, DevCSR &C, bool spmv_plan)
@@ -1820,7 +2076,7 @@ void csr_rap(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, bool 
     if (loose && A.nrows > 0 && R.nrows > 0) {
         CsrView a{A.I, A.J, A.a}, p{P.I, P.J, P.a};
         const int W = ell_width(P.max_row_nnz);
-        if (ell_applies(A, P) && ell_pipe_enabled() && rap_ell(&R, A, P, &C, nullptr, spmv_plan)) return;
+        if (ell_applies(A, P) && ell_pipe_enabled() && (rap_fused(R, A, P, C, spmv_plan) || rap_ell(&R, A, P, &C, nullptr, spmv_plan))) return;
         if (ell_applies(A, P)) {
             // the right factor with W slots per row (MatmulEllExpander): valid when every row of A P takes the hash path
             Temp<int> EJ((size_t)P.nrows * W);

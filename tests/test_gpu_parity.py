@@ -1026,9 +1026,11 @@ def test_triple_product_routes_give_the_same_matrix(la, h1_k2, hdiv_k2):
     for A, P in cases:
         dA, dP = la.ParallelCSRMatrix.from_scipy(A), la.ParallelCSRMatrix.from_scipy(P)
         outs = []
-        # (an uploaded matrix knows its longest row, so the W-slot route -- and its software-pipelined kernel, ELAG_HIP_ELL_PIPE -- is what the
-        # first two interpolators take by default even at this size)
-        for env in ({}, {"ELAG_HIP_ELL_PIPE": "0"}, {"ELAG_HIP_RAP_ELL": "0"}, {"ELAG_HIP_RAP_ELL": "0", "ELAG_HIP_RAP_LOOSE": "0"}):
+        # (an uploaded matrix knows its longest row, so the W-slot routes are what the first two interpolators take by default even at this
+        # size: two-step with the ordered parallel inserts, two-step with the serialised ones -- ELAG_HIP_ELL_PIPE=0 --, then the planned routes)
+        two_step = ({"ELAG_HIP_RAP_FUSED": "0"}, {"ELAG_HIP_RAP_FUSED": "0", "ELAG_HIP_ELL_PIPE": "0"}, {"ELAG_HIP_RAP_ELL": "0"},
+                    {"ELAG_HIP_RAP_ELL": "0", "ELAG_HIP_RAP_LOOSE": "0"})
+        for env in two_step + ({},):
             os.environ.update(env)
             try:
                 outs.append(la.RAP(dA, dP).to_scipy())
@@ -1039,8 +1041,30 @@ def test_triple_product_routes_give_the_same_matrix(la, h1_k2, hdiv_k2):
         ref.sort_indices()
         for M in outs:
             M.sort_indices()
+        for M in outs[:len(two_step)]:
             assert np.array_equal(M.indptr, outs[0].indptr) and np.array_equal(M.indices, outs[0].indices) and np.array_equal(M.data, outs[0].data)
         assert abs(outs[0] - ref).max() <= 1e-12 * abs(ref).max()
+        # the default where the right factor is narrow is the FUSED product (no A P): hypre's association (r a) p summed in the triple loop's order --
+        # the same entries, other rounding than (sum a p) r
+        F = outs[-1]
+        assert np.array_equal(F.indptr, outs[0].indptr) and np.array_equal(F.indices, outs[0].indices)
+        assert np.max(np.abs(F.data - outs[0].data)) <= 1e-13 * np.max(np.abs(outs[0].data))
+
+
+def test_fused_triple_product_is_the_reference_s_loop_bit_for_bit(la, h1_k2, hdiv_k2):
+    """C = R A P without a stored A P (kernels_setup.hip, rap_fused_kernel) is hypre_BoomerAMGBuildCoarseOperator's own loop -- for each coarse
+    row, each entry of R's row, each entry of A's row, each entry of P's row: C += (r a) p (the reference's call: ParELAG_Hierarchy.cpp:365) --
+    with the lanes of a wavefront taking consecutive products and the LDS atomics of one instruction applied in lane order.  So the device's
+    coarse operator is the oracle's restatement of that loop BIT FOR BIT (same storage order of the operands on both sides; the oracle emits the
+    diagonal first and the other columns in first-touch order, hence the sort), for the nested P1 interpolator (2 entries per row) and the
+    face interpolator of the 2-form (up to 4)."""
+    for A, P in ((h1_k2[0], h1_k2[1][0]), (hdiv_k2[0], hdiv_k2[1][0])):
+        A, P = sp.csr_matrix(A), sp.csr_matrix(P)
+        dev = la.RAP(la.ParallelCSRMatrix.from_scipy(A), la.ParallelCSRMatrix.from_scipy(P)).to_scipy()
+        ref = orc.rap(P, A, P)
+        dev.sort_indices(); ref.sort_indices()
+        assert np.array_equal(dev.indptr, ref.indptr) and np.array_equal(dev.indices, ref.indices)
+        assert np.array_equal(dev.data, ref.data)
 
 
 def test_graph_replay_and_plain_launches_are_the_same_cycle(la, h1_k2):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # RAP-focused GPU call: parity tests that touch the sparse products, kernel stats + timeline (+ SQ counters with $2 = pmc)
 TAG=${1:-r04b}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_known_answers.py -m gpu -x -q > $OUT/pytest.txt 2>&1; echo "pytest rc $?" | tee -a $OUT/pytest.txt
+timeout -k 10 400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_known_answers.py -m gpu -x -q > $OUT/pytest.txt 2>&1; echo "pytest rc $?" | tee -a $OUT/pytest.txt
 tail -3 $OUT/pytest.txt
 grep -q "rc 0" $OUT/pytest.txt || exit 1
 bash tools/rap_profile.sh $TAG/rap 5 > $OUT/rap_stats.txt 2>&1
