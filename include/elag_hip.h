@@ -74,6 +74,11 @@ enum {
 ELAG_HIP_API int elag_hip_init(int device);                 /* hipSetDevice + private streams          */
 ELAG_HIP_API int elag_hip_finalize(void);
 ELAG_HIP_API int elag_hip_synchronize(void);                /* wait for the compute stream             */
+/* Device memory the library holds without using it goes back to the driver: the pool of freed blocks it keeps between calls (as hypre's
+ * caching allocator does for its work arrays: the products, transposes and level operators a ParElag setup makes one by one reuse each other's
+ * memory; ELAG_HIP_POOL_MB, default 1024, 0 = no pool) and the idle slabs of the setup scratch arena (elag_hip_init reserves the first one:
+ * ELAG_HIP_ARENA_MB, default 2048).  The library does this by itself when the driver runs out of memory.  bytes_released may be NULL. */
+ELAG_HIP_API int elag_hip_trim_memory(size_t *bytes_released);
 ELAG_HIP_API const char *elag_hip_last_error(void);
 ELAG_HIP_API int elag_hip_device_name(char *buf, int len);
 

@@ -67,6 +67,7 @@ _SIGNATURES = {
     "elag_hip_init": [_i],
     "elag_hip_finalize": [],
     "elag_hip_synchronize": [],
+    "elag_hip_trim_memory": [C.POINTER(C.c_size_t)],
     "elag_hip_last_error": [],
     "elag_hip_device_name": [C.c_char_p, _i],
     "elag_hip_comm_unique_id": [_p],
@@ -230,9 +231,23 @@ def init(device: int | None = None):
     if not getattr(_tls, "initialised", False):   # the library context is per host thread (one thread per rank)
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
+        import time
+        t0 = time.perf_counter()
         check(lib.elag_hip_init(device))
+        global init_seconds
+        init_seconds = time.perf_counter() - t0      # HIP runtime start-up, the library's code objects, the scratch arena's first slab (bench.py reports it as init_s)
         _tls.initialised = True
     return lib
+
+
+init_seconds = 0.0
+
+
+def trim_memory() -> int:
+    """elag_hip_trim_memory: the pool of freed device blocks and the idle scratch slabs go back to the driver; returns the bytes released."""
+    n = C.c_size_t(0)
+    check(init().elag_hip_trim_memory(C.byref(n)))
+    return int(n.value)
 
 
 def device_name() -> str:

@@ -227,6 +227,19 @@ struct AllocCache {
 thread_local AllocCache t_cache;
 constexpr size_t kCacheMaxHeld = size_t(2) << 30;
 
+// The pool: freed blocks kept BETWEEN scopes too (up to ELAG_HIP_POOL_MB, default 1024; 0 = off), so that the products, transposes and level
+// operators a caller makes one by one -- and the second hierarchy of a process -- do not pay the driver for memory the library gave back a
+// moment ago: hipMalloc + hipFree of the two arrays of a coarse operator are ~0.1 ms of a 1 ms triple product at cube456 x5.  Only while the
+// calling thread is the process's single rank (every use of a block is ordered on the one compute stream then); given back by
+// elag_hip_trim_memory, elag_hip_finalize, or when the driver runs out of memory.
+size_t pool_cap()
+{
+    static long long mb = -1;
+    if (mb < 0) { const char *e = getenv("ELAG_HIP_POOL_MB"); mb = e ? std::max(0ll, atoll(e)) : 1024; }
+    return (size_t)mb << 20;
+}
+bool pool_active() { return pool_cap() > 0 && !comm_active() && ctx().initialised; }
+
 size_t round_block(size_t bytes)
 {
     if (bytes < 256) return 256;
@@ -241,7 +254,7 @@ void *raw_alloc(size_t bytes)
 {
     const size_t sz = round_block(bytes);
     void *p = nullptr;
-    if (t_cache.depth > 0) {
+    if (t_cache.depth > 0 || (!t_cache.blocks.empty() && pool_active())) {
         auto it = t_cache.blocks.lower_bound(sz);
         if (it != t_cache.blocks.end() && it->first <= sz + sz / 8) {
             p = it->second;
@@ -299,7 +312,7 @@ void raw_free(void *p)
         auto it = g_alloc_size.find(p);
         if (it != g_alloc_size.end()) { sz = it->second; g_alloc_size.erase(it); }
     }
-    if (t_cache.depth > 0 && sz > 0 && t_cache.held + sz <= kCacheMaxHeld) {
+    if (sz > 0 && ((t_cache.depth > 0 && t_cache.held + sz <= kCacheMaxHeld) || (t_cache.depth == 0 && pool_active() && t_cache.held + sz <= pool_cap()))) {
         t_cache.blocks.emplace(sz, p);
         t_cache.held += sz;
         return;
@@ -319,10 +332,16 @@ AllocScope::~AllocScope()
 {
     if (!active) return;
     if (--t_cache.depth > 0) return;
+    // what the scope kept beyond the pool's size goes back (largest blocks first); the rest stays for the next request
+    const size_t keep = pool_active() ? pool_cap() : 0;
+    if (t_cache.held <= keep) return;
     if (ctx().stream) (void)hipStreamSynchronize(ctx().stream);
-    for (auto &b : t_cache.blocks) (void)hipFree(b.second);
-    t_cache.blocks.clear();
-    t_cache.held = 0;
+    while (t_cache.held > keep && !t_cache.blocks.empty()) {
+        auto it = std::prev(t_cache.blocks.end());
+        (void)hipFree(it->second);
+        t_cache.held -= it->first;
+        t_cache.blocks.erase(it);
+    }
 }
 
 namespace {
@@ -406,6 +425,20 @@ int elag_hip_init(int device)
         ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c.h_scalar), 16 * sizeof(double), hipHostMallocDefault));
         c.device = device;
         c.initialised = true;
+        // The first slab of the setup scratch arena, here instead of inside the first sparse product: the arena grows by doubling from 64 MiB, and
+        // on some boxes of the pool each of those hipMallocs costs 5-20 ms -- 20 of the 36 ms of a process's first cube456 x5 hierarchy
+        // (profiles/r03_setup_probe_k5_after_S.txt).  ELAG_HIP_ARENA_MB (default: 2048, at most an eighth of the free memory; 0 = grow on demand).
+        {
+            const char *e = getenv("ELAG_HIP_ARENA_MB");
+            size_t want = (size_t)(e ? std::max(0ll, atoll(e)) : 2048) << 20;
+            size_t free_b = 0, total_b = 0;
+            if (want && hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, free_b / 8);
+            if (want >= (size_t(64) << 20) && c.slabs.empty()) {
+                void *p = nullptr;
+                if (hipMalloc(&p, want) == hipSuccess) { c.slabs.push_back(ScratchSlab{static_cast<char *>(p), want, 0}); c.cur_slab = 0; }
+                else (void)hipGetLastError();
+            }
+        }
     });
 }
 
@@ -417,6 +450,9 @@ int elag_hip_finalize(void)
         (void)hipStreamSynchronize(c.stream);
         (void)hipStreamSynchronize(c.comm_stream);
         comm_destroy();
+        for (auto &b : t_cache.blocks) (void)hipFree(b.second);
+        t_cache.blocks.clear();
+        t_cache.held = 0;
         scratch_release_all();
         amge_release_arena();
         (void)hipFree(c.d_scalar);
@@ -427,6 +463,15 @@ int elag_hip_finalize(void)
         (void)hipStreamDestroy(c.stream);
         (void)hipStreamDestroy(c.comm_stream);
         c = Context();
+    });
+}
+
+int elag_hip_trim_memory(size_t *bytes_released)
+{
+    return guarded([&] {
+        require_init();
+        const size_t n = alloc_cache_release();
+        if (bytes_released) *bytes_released = n;
     });
 }
 

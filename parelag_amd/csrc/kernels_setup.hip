@@ -2005,10 +2005,16 @@ bool rap_fused(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, boo
     const CsrView r{R.I, R.J, R.a}, a{A.I, A.J, A.a};
     // a wavefront walks ~8 rows (the pipeline takes four rows to fill), four wavefronts per workgroup
     const unsigned grid = stride_grid(((long long)nr + 7) / 8, 4, 1ll << 30);
-    if (W == 2)
+    // (steps per trip: 2 -- 0.92-0.96 ms per product at cube456 x5 -- against 1.0-1.07 with 3 or 4 and 1.5 with 8: the registers of a deeper batch cost more
+    // wavefronts than its loads in flight buy; ELAG_HIP_FUSED_B=4 for A/B runs)
+    static int fb = -1;
+    if (fb < 0) { const char *eb = getenv("ELAG_HIP_FUSED_B"); fb = eb ? atoi(eb) : 2; }
+    if (W == 2 && fb == 4)
         hipLaunchKernelGGL((rap_fused_kernel<2, 4, 128, 256>), dim3(grid), dim3(256), 0, st, r, a, (const int *)P.ellJ, (const double *)P.ella, nr, rn.p, Ju.p, au.p, kStride, ctl.p + 2);
+    else if (W == 2)
+        hipLaunchKernelGGL((rap_fused_kernel<2, 2, 128, 256>), dim3(grid), dim3(256), 0, st, r, a, (const int *)P.ellJ, (const double *)P.ella, nr, rn.p, Ju.p, au.p, kStride, ctl.p + 2);
     else
-        hipLaunchKernelGGL((rap_fused_kernel<4, 4, 128, 256>), dim3(grid), dim3(256), 0, st, r, a, (const int *)P.ellJ, (const double *)P.ella, nr, rn.p, Ju.p, au.p, kStride, ctl.p + 2);
+        hipLaunchKernelGGL((rap_fused_kernel<4, 2, 128, 256>), dim3(grid), dim3(256), 0, st, r, a, (const int *)P.ellJ, (const double *)P.ella, nr, rn.p, Ju.p, au.p, kStride, ctl.p + 2);
     ELAG_LAUNCH_CHECK();
     int *CI = dev_alloc<int>((size_t)nr + 1);
     exclusive_scan(rn, CI, nr);

@@ -29,6 +29,7 @@ inline void check(int status)
 
 inline void Init(int device = 0) { check(elag_hip_init(device)); }
 inline void Synchronize() { check(elag_hip_synchronize()); }
+inline size_t TrimMemory() { size_t n = 0; check(elag_hip_trim_memory(&n)); return n; }
 // hybrid Gauss-Seidel of the smoothers created from here on as the reference runs it on `nblocks` ranks (1: the sequential loop)
 inline void SetGaussSeidelHybridBlocks(int nblocks) { check(elag_hip_set_gs_hybrid_blocks(nblocks)); }
 
