@@ -226,6 +226,89 @@ __global__ __launch_bounds__(kLdsInvBlock) void spd_inverse_lds_kernel(int n, co
 }
 }  // namespace
 
+namespace {
+// ---- the same elimination in blocks of kNB pivots (operators beyond one workgroup's LDS) -------------------------------------------------
+// 2 n launches -- 2 030 for the 1 015-dof coarsest operator of the cube456 x3 H(div) hierarchy, 7.8 of its 13 ms of setup -- become 2 n / kNB:
+// with K the block of pivots, D = A_KK,
+//     A_KK <- D^-1,   A_Kj <- D^-1 A_Kj,   A_iK <- -A_iK D^-1,   A_ij <- A_ij - A_iK (D^-1 A_Kj)        (i, j outside K)
+// which is kNB steps of the scalar sweep at once.  Launch 1 (panel): every workgroup inverts D in LDS by the scalar sweep (32 x 32: cheaper than a
+// launch of its own), writes its columns of the row panel R = D^-1 A_K: and its rows of a copy of the column panel A_:K.  Launch 2 (update): 32 x 32
+// tiles, the two panels' tiles staged in LDS.
+constexpr int kNB = 32;
+__global__ __launch_bounds__(1024) void spd_block_panel_kernel(int n, int K, const double *__restrict__ M, double *__restrict__ Dinv, double *__restrict__ R,
+                                                               double *__restrict__ Cc, int *__restrict__ bad)
+{
+    __shared__ double D[kNB][kNB + 1];
+    __shared__ double ck[kNB], rk[kNB];
+    const int t = threadIdx.x, r = t >> 5, c = t & 31;
+    const int nb = min(kNB, n - K);
+    // D = A_KK, padded with the identity
+    D[r][c] = (r < nb && c < nb) ? M[(size_t)(K + r) * n + K + c] : (r == c ? 1.0 : 0.0);
+    __syncthreads();
+    for (int k = 0; k < nb; k++) {
+        const double p = D[k][k];
+        if (t == 0 && blockIdx.x == 0 && !(p > 0.0)) atomicAdd(bad, 1);
+        if (t < kNB) {
+            ck[t] = (t == k) ? 0.0 : D[t][k];
+            rk[t] = (t == k) ? 1.0 / p : D[k][t] / p;
+        }
+        __syncthreads();
+        {
+            double m = D[r][c];
+            if (r == k) m = rk[c];
+            else if (c == k) m = -ck[r] * rk[c];            // rk[k] = 1 / p
+            else m -= ck[r] * rk[c];
+            D[r][c] = m;
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) Dinv[r * kNB + c] = D[r][c];
+    // this workgroup's 256 columns of R = D^-1 A_K:  (row r of the panel, 32 columns at a time)
+    const int j0 = blockIdx.x * 256;
+    for (int jj = 0; jj < 256; jj += 32) {
+        const int j = j0 + jj + c;
+        if (j < n && r < nb) {
+            double sum = 0.0;
+            for (int q = 0; q < nb; q++) sum += D[r][q] * M[(size_t)(K + q) * n + j];
+            R[(size_t)r * n + j] = sum;
+        }
+    }
+    // ... and its 256 rows of the column panel (the update overwrites it)
+    for (int ii = 0; ii < 256; ii += 32) {
+        const int i = j0 + ii + r;
+        if (i < n) Cc[(size_t)i * kNB + c] = c < nb ? M[(size_t)i * n + K + c] : 0.0;
+    }
+}
+__global__ __launch_bounds__(256) void spd_block_update_kernel(int n, int K, double *__restrict__ M, const double *__restrict__ Dinv, const double *__restrict__ R,
+                                                               const double *__restrict__ Cc)
+{
+    __shared__ double Ct[kNB][kNB + 1], Rt[kNB][kNB + 1];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8 threads, four rows each
+    const int i0 = blockIdx.y * kNB, j0 = blockIdx.x * kNB;
+    const int nb = min(kNB, n - K);
+    const bool irow = i0 == K, jcol = j0 == K;                        // (K is a multiple of the tile size)
+    for (int q = ty; q < kNB; q += 8) {
+        const int i = i0 + q;
+        Ct[q][tx] = (i < n && tx < nb) ? Cc[(size_t)i * kNB + tx] : 0.0;                        // Ct[row][pivot]
+        const int j = j0 + tx;
+        Rt[q][tx] = (q < nb && j < n) ? (jcol ? (tx < nb ? Dinv[q * kNB + tx] : 0.0) : R[(size_t)q * n + j]) : 0.0;   // Rt[pivot][column]
+    }
+    __syncthreads();
+    const int j = j0 + tx;
+    if (j >= n) return;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int il = ty + 8 * s, i = i0 + il;
+        if (i >= n) break;
+        double *m = M + (size_t)i * n + j;
+        if (irow) { *m = Rt[il][tx]; continue; }                      // rows of the pivot block: D^-1 (on the block) or D^-1 A_Kj
+        double acc = 0.0;
+        for (int q = 0; q < nb; q++) acc += Ct[il][q] * Rt[q][tx];
+        *m = jcol ? -acc : *m - acc;
+    }
+}
+}  // namespace
+
 void dense_inverse_spd(const DevCSR &A, double *Minv)
 {
     hipStream_t st = ctx().stream;
@@ -260,10 +343,22 @@ void dense_inverse_spd(const DevCSR &A, double *Minv)
         // the (numerically symmetric) input made exactly symmetric first, like the host path
         hipLaunchKernelGGL(symmetrise_kernel, dim3((n + kB - 1) / kB, n), dim3(kB), 0, st, n, (const double *)M, Minv);
         ELAG_HIP_CHECK(hipMemcpyAsync(M, Minv, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, st));
+        const char *e_blk = getenv("ELAG_HIP_SPD_BLOCKED");                 // (0 = the pivot-by-pivot sweeps: A/B runs and a test)
+        if (!(e_blk && !atoi(e_blk))) {
+            Temp<double> Dinv((size_t)kNB * kNB), Rp((size_t)kNB * n), Cc((size_t)n * kNB);
+            const dim3 gp((n + 255) / 256), gu((n + kNB - 1) / kNB, (n + kNB - 1) / kNB);
+            for (int K = 0; K < n; K += kNB) {
+                hipLaunchKernelGGL(spd_block_panel_kernel, gp, dim3(1024), 0, st, n, K, (const double *)M, Dinv.p, Rp.p, Cc.p, bad.p);
+                hipLaunchKernelGGL(spd_block_update_kernel, gu, dim3(256), 0, st, n, K, M, (const double *)Dinv.p, (const double *)Rp.p, (const double *)Cc.p);
+            }
+            ELAG_LAUNCH_CHECK();
+            ELAG_HIP_CHECK(hipStreamSynchronize(st));                     // (the panels go out of scope)
+        } else {
         const dim3 g1((n + kB - 1) / kB), g2((n + kB - 1) / kB, (n + 7) / 8);
         for (int k = 0; k < n; k++) {
             hipLaunchKernelGGL(spd_prep_kernel, g1, dim3(kB), 0, st, n, k, (const double *)M, colk.p, rowk.p, bad.p);
             hipLaunchKernelGGL(spd_sweep_kernel, g2, dim3(kB), 0, st, n, k, M, (const double *)colk.p, (const double *)rowk.p);
+        }
         }
         // exact symmetry of the stored inverse keeps the cycle symmetric to rounding
         hipLaunchKernelGGL(symmetrise_kernel, dim3((n + kB - 1) / kB, n), dim3(kB), 0, st, n, (const double *)M, Minv);

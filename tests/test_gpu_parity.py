@@ -1099,3 +1099,32 @@ def test_graph_replay_and_plain_launches_are_the_same_cycle(la, h1_k2):
     assert {"galerkin_products", "smoothers", "coarse_solver", "fused_level_operators", "dense_tail"} <= set(sb) and all(v >= 0.0 for v in sb.values())
     H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi", use_graph=False)
     assert H.launch_mode() == {"hipgraph": False, "kernels_per_cycle": 0, "graph_us": 0.0, "plain_launches_us": 0.0}
+
+
+@pytest.mark.parametrize("n", [150, 257, 1015])
+def test_blocked_spd_inverse_is_the_pivot_by_pivot_one(la, n):
+    """The coarsest SPD operator beyond one workgroup's LDS (n > 141) is inverted in blocks of 32 pivots (dense.hip, spd_block_*_kernel): 2 n / 32
+    launches instead of 2 n.  Same elimination, other rounding: the solves agree with the pivot-by-pivot sweeps (ELAG_HIP_SPD_BLOCKED=0) and with
+    a host solve to 1e-10 of the solution on a graph Laplacian + mass matrix -- sizes with a partial last block and the 1 015 dofs of the
+    cube456 x3 H(div) hierarchy."""
+    import os
+    rng = np.random.default_rng(n)
+    G = sp.random(n, n, density=min(1.0, 8.0 / n), random_state=int(n), format="csr")
+    G = abs(G) + abs(G).T
+    A = (sp.diags(np.asarray(G.sum(axis=1)).ravel() + rng.uniform(0.5, 1.5, n)) - G).tocsr()      # strictly diagonally dominant, symmetric: SPD
+    b = rng.uniform(-1, 1, n)
+    xs = []
+    for env in ({}, {"ELAG_HIP_SPD_BLOCKED": "0"}):
+        os.environ.update(env)
+        try:
+            C = la.CoarseSolver(la.ParallelCSRMatrix.from_scipy(A), kind=0)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        x = np.zeros(n)
+        C.Mult(b, x)
+        xs.append(x)
+    ref = np.linalg.solve(A.toarray(), b)
+    for x in xs:
+        assert np.max(np.abs(x - ref)) <= 1e-10 * np.max(np.abs(ref))
+    assert np.max(np.abs(xs[0] - xs[1])) <= 1e-11 * np.max(np.abs(ref))
