@@ -205,7 +205,7 @@ def other_configs_leg(args, la, meshgen, np, sp, budget_s=60.0):
         kparams = {"Solver name": "GMRES", "Relative tolerance": 1e-6, "Absolute tolerance": 1e-6, "Maximum iterations": 300, "Restart size": 50}
         b_solve = np.concatenate([np.zeros(n0), seq_fine_M3_one(dar)])
         t0 = time.time()
-        ldu = la.darcy_ldu_amge_preconditioner(bop, dar["M"], dar["B"], Ps, "L1 Jacobi")
+        ldu = la.darcy_ldu_amge_preconditioner(bop, dar["M"], dar["B"], Ps, "L1 Jacobi", dPs=dPs)
         la.synchronize()
         ldu_setup = time.time() - t0
         K = la.KrylovSolver(bop, ldu, kparams)
@@ -1096,7 +1096,7 @@ def main():
             Kop = bop if single else H._block_op
             t0 = time.time()
             if single:
-                ldu = la.darcy_ldu_amge_preconditioner(bop, dar["M"], dar["B"], Ps, args.smoother)
+                ldu = la.darcy_ldu_amge_preconditioner(bop, dar["M"], dar["B"], Ps, args.smoother, dPs=dPs)
             else:
                 ldu = distributed.build_darcy_ldu_amge(dist, dar, H, args.smoother)
             la.synchronize()

@@ -134,6 +134,13 @@ typedef struct {
 } elag_hip_parcsr_desc;
 
 ELAG_HIP_API int elag_hip_parcsr_create(elag_hip_parcsr_t *out, const elag_hip_parcsr_desc *desc);
+/* The same matrix from this rank's rows in GLOBAL column numbering -- what mfem::HypreParMatrix(comm, nrows, glob_nrows, glob_ncols, I, J, data,
+ * rows, cols) takes ([3P] mfem linalg/hypre.cpp; hypre_ParCSRMatrixGenerateFromCSR / hypre_MatvecCommPkgCreate behind it): the library splits
+ * the rows into the diag / offd blocks on the device, builds col_map_offd and negotiates the comm package over ITS communicator (collective:
+ * every rank of elag_hip_comm_init calls it).  Column ids ascending within a row are not required; global sizes below 2^31. */
+ELAG_HIP_API int elag_hip_parcsr_create_from_global_csr(elag_hip_parcsr_t *out, int num_rows, const int *row_ptr, const int *global_col,
+                                                        const double *values, int64_t first_row, int64_t global_num_rows, int64_t first_col,
+                                                        int num_cols_local, int64_t global_num_cols);
 ELAG_HIP_API int elag_hip_parcsr_destroy(elag_hip_parcsr_t A);
 
 typedef struct {

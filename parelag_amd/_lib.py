@@ -82,6 +82,7 @@ _SIGNATURES = {
     "elag_hip_memcpy": [_p, _p, C.c_size_t, _i],
     "elag_hip_memset": [_p, _i, C.c_size_t],
     "elag_hip_parcsr_create": [C.POINTER(_p), C.POINTER(ParCSRDesc)],
+    "elag_hip_parcsr_create_from_global_csr": [C.POINTER(_p), _i, _p, _p, _p, C.c_int64, C.c_int64, C.c_int64, _i, C.c_int64],
     "elag_hip_parcsr_destroy": [_p],
     "elag_hip_parcsr_get_info": [_p, C.POINTER(ParCSRInfo)],
     "elag_hip_parcsr_export": [_p, _i, _p, _p, _p, _p, _p, _p, _p],

@@ -202,11 +202,25 @@ __global__ void split_fill_kernel(int n, const int *__restrict__ I, const int *_
         const int j = J[k];
         if (j >= c0 && j < c1) { DJ[d] = j - c0; Da[d] = a[k]; d++; }
         else {
-            int lo = 0, hi = ncm;  // position of j in the ascending col_map
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (cmap[mid] < j) lo = mid + 1; else hi = mid; }
+            int lo = j;                                  // (without a map: the global id stays; split_remap_kernel follows)
+            if (cmap) {
+                int hi = ncm;  // position of j in the ascending col_map
+                lo = 0;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (cmap[mid] < j) lo = mid + 1; else hi = mid; }
+            }
             OJ[o] = lo; Oa[o] = a[k]; o++;
         }
     }
+}
+
+__global__ void split_remap_kernel(int nnz, int *__restrict__ OJ, const int *__restrict__ cmap, int ncm)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const int j = OJ[k];
+    int lo = 0, hi = ncm;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cmap[mid] < j) lo = mid + 1; else hi = mid; }
+    OJ[k] = lo;
 }
 
 std::vector<double> allgather_scalar(double v)
@@ -237,21 +251,18 @@ ParCSR *parcsr_from_global_columns(const DevCSR &Cg, int64_t first_row, int64_t 
     hipStream_t st = c.stream;
     const int n = Cg.nrows, nr = c.nranks, me = c.rank;
     const int c0 = (int)first_col, c1 = (int)first_col + ncols_local;
-    // col_map_offd: ascending unique non-local columns (host, like hypre)
-    std::vector<int> J = host_from_dev((const int *)Cg.J, (size_t)Cg.nnz);
-    std::vector<int> cmap;
-    for (int j : J) if (j < c0 || j >= c1) cmap.push_back(j);
-    std::sort(cmap.begin(), cmap.end());
-    cmap.erase(std::unique(cmap.begin(), cmap.end()), cmap.end());
-    const int ncm = (int)cmap.size();
+    // The split first, with the off-rank entries keeping their GLOBAL column ids; then col_map_offd = their ascending unique values (on the
+    // host, like hypre -- but only the off-rank ids travel: round 3 pulled every column id of the operator to the host for this, 150 MB at
+    // cube456 x5), and the off-rank block's ids become positions in that map.
     std::unique_ptr<ParCSR> M(new ParCSR());
+    std::vector<int> cmap;
+    int ncm = 0;
     {
-        Temp<int> nd((size_t)n), no((size_t)n), dcm((size_t)ncm);
-        if (ncm) ELAG_HIP_CHECK(hipMemcpyAsync(dcm.p, cmap.data(), sizeof(int) * (size_t)ncm, hipMemcpyHostToDevice, st));
+        Temp<int> nd((size_t)n), no((size_t)n);
         if (n) hipLaunchKernelGGL(split_count_kernel, dim3(g1(n)), dim3(kB), 0, st, n, (const int *)Cg.I, (const int *)Cg.J, c0, c1, nd.p, no.p);
         ELAG_LAUNCH_CHECK();
         M->diag.nrows = n; M->diag.ncols = ncols_local; M->diag.I = dev_alloc<int>((size_t)n + 1);
-        M->offd.nrows = n; M->offd.ncols = ncm; M->offd.I = dev_alloc<int>((size_t)n + 1);
+        M->offd.nrows = n; M->offd.I = dev_alloc<int>((size_t)n + 1);
         k::exclusive_scan(nd, M->diag.I, n);
         k::exclusive_scan(no, M->offd.I, n);
         int tot[2] = {0, 0};
@@ -261,8 +272,19 @@ ParCSR *parcsr_from_global_columns(const DevCSR &Cg, int64_t first_row, int64_t 
         M->diag.alloc_entries(tot[0]);
         M->offd.alloc_entries(tot[1]);
         if (n) hipLaunchKernelGGL(split_fill_kernel, dim3(g1(n)), dim3(kB), 0, st, n, (const int *)Cg.I, (const int *)Cg.J, (const double *)Cg.a, c0,
-                                  c1, (const int *)dcm.p, ncm, (const int *)M->diag.I, M->diag.J, M->diag.a, (const int *)M->offd.I, M->offd.J, M->offd.a);
+                                  c1, (const int *)nullptr, 0, (const int *)M->diag.I, M->diag.J, M->diag.a, (const int *)M->offd.I, M->offd.J, M->offd.a);
         ELAG_LAUNCH_CHECK();
+        if (tot[1]) {
+            cmap = host_from_dev((const int *)M->offd.J, (size_t)tot[1]);
+            std::sort(cmap.begin(), cmap.end());
+            cmap.erase(std::unique(cmap.begin(), cmap.end()), cmap.end());
+            ncm = (int)cmap.size();
+            Temp<int> dcm((size_t)ncm);
+            ELAG_HIP_CHECK(hipMemcpyAsync(dcm.p, cmap.data(), sizeof(int) * (size_t)ncm, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(split_remap_kernel, dim3(g1(tot[1])), dim3(kB), 0, st, tot[1], M->offd.J, (const int *)dcm.p, ncm);
+            ELAG_LAUNCH_CHECK();
+        }
+        M->offd.ncols = ncm;
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
     }
     M->diag.choose_spmv_shape();

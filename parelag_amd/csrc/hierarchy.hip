@@ -970,8 +970,8 @@ struct elag_hip_hierarchy_s {
         if (F.Sd) {
             const double *w = F.dist_w;
             if (F.A->diag.nnz < (int64_t(1) << 20)) {
-                k::SpmvArgs a;   // r = f - A (W f): the sweep from the zero guess gathered on the fly, ONE halo exchange (of W f)
-                a.x = rhs; a.cs = w; a.alpha = -1.0; a.f = rhs; a.gamma = 1.0; a.out = F.tmp_resid;
+                k::SpmvArgs a;   // r = f - A (W f): the sweep from the zero guess gathered on the fly, ONE halo exchange (of W f); W f kept for the way up
+                a.x = rhs; a.cs = w; a.alpha = -1.0; a.f = rhs; a.gamma = 1.0; a.out = F.tmp_resid; a.out2 = alt;
                 par_spmv(*F.A, a);
             } else {
                 k::vec_scale_mul(n, 1.0, rhs, w, alt);
@@ -981,9 +981,8 @@ struct elag_hip_hierarchy_s {
             }
             par_spmvT(*C.P, 1.0, F.tmp_resid, 0.0, C.resid);
             iterate(l + 1, C.resid, C.sol, C.alt);
-            k::vec_axpby(n, 1.0, rhs, 1.0, F.tmp_resid, F.tmp_resid);          // f + r
-            k::SpmvArgs u;       // x = W (f + r - S e)
-            u.x = C.sol; u.alpha = -1.0; u.f = F.tmp_resid; u.gamma = 1.0; u.s = w; u.out = sol;
+            k::SpmvArgs u;       // x = W f + W (r - S e)  (= W (f + r - S e): the vector pass that formed f + r is gone, W f comes from the way down)
+            u.x = C.sol; u.alpha = -1.0; u.f = F.tmp_resid; u.gamma = 1.0; u.s = w; u.yin = alt; u.beta = 1.0; u.out = sol;
             par_spmv(*F.Sd, u);
             return;
         }

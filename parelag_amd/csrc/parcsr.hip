@@ -202,6 +202,21 @@ static void require_single_rank(const ParCSR *A, const char *what)
 
 extern "C" {
 
+int elag_hip_parcsr_create_from_global_csr(elag_hip_parcsr_t *out, int num_rows, const int *row_ptr, const int *global_col, const double *values,
+                                           int64_t first_row, int64_t global_num_rows, int64_t first_col, int num_cols_local, int64_t global_num_cols)
+{
+    return guarded([&] {
+        require_init();
+        ELAG_REQUIRE(out && num_rows >= 0 && num_cols_local >= 0 && (num_rows == 0 || row_ptr), "bad argument");
+        ELAG_REQUIRE(global_num_cols < (int64_t(1) << 31) && global_num_rows < (int64_t(1) << 31), "global sizes beyond 2^31 are not supported");
+        ELAG_REQUIRE(first_col >= 0 && first_col + num_cols_local <= global_num_cols && first_row >= 0 && first_row + num_rows <= global_num_rows,
+                     "this rank's rows / columns lie outside the global matrix");
+        DevCSR Cg;
+        Cg.upload(num_rows, (int)global_num_cols, row_ptr, global_col, values);
+        *out = parcsr_from_global_columns(Cg, first_row, global_num_rows, first_col, num_cols_local, global_num_cols);
+    });
+}
+
 int elag_hip_parcsr_create(elag_hip_parcsr_t *out, const elag_hip_parcsr_desc *d)
 {
     return guarded([&] {

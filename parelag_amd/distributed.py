@@ -107,8 +107,9 @@ def _build_from_pieces(dist, A_part, P_parts, Ploc, P_tail, level_rows, P_shapes
     # distributed head: levels 0..R-1; their Galerkin operators are formed on the device across the ranks
     # (elag_hip_parcsr_rap with distributed operands + FixZeroRows), inputs are the fine operator and the true P's
     H = la.Hierarchy(R + 1)
-    ops = [la.ParallelCSRMatrix.from_parts(A_part)]
-    Pd = [la.ParallelCSRMatrix.from_parts(p) for p in P_parts]
+    as_dev = lambda p: p if isinstance(p, la.ParallelCSRMatrix) else la.ParallelCSRMatrix.from_parts(p)      # (pieces as dicts, or made on the device already)
+    ops = [as_dev(A_part)]
+    Pd = [as_dev(p) for p in P_parts]
     for l in range(1, R + 1):
         Ac = la.RAP(ops[-1], Pd[l - 1])
         Ac.fix_zero_rows()
@@ -186,8 +187,15 @@ def build_hierarchy_sharded(dist: Dist, comm, shards, smoother="L1 Jacobi", para
     starts, P_rows = shards["starts"], shards["P_rows"]
     nl = len(P_rows) + 1
     R = max(1, min(int(replicate_from), nl - 1))
-    A_part = msh.parcsr_piece(comm, shards["A_rows"], starts[0], starts[0])
-    P_parts = [msh.parcsr_piece(comm, P_rows[l - 1], starts[l - 1], starts[l]) for l in range(1, R + 1)]
+    # the ParCSR pieces: the rank's rows go to the device as they are (global columns); the split into diag / offd blocks and the comm package
+    # are the library's (elag_hip_parcsr_create_from_global_csr) -- round 3 split them with scipy on the host: 0.45 of the 0.50 s of this
+    # setup at cube456 x5 (profiles/r04_dist_setup_probe.txt)
+    r = dist.rank
+
+    def piece(rows, rs, cs):
+        return la.ParallelCSRMatrix.from_global_rows(rows, int(rs[r]), int(rs[-1]), int(cs[r]), int(cs[r + 1] - cs[r]), int(cs[-1]))
+    A_part = piece(shards["A_rows"], starts[0], starts[0])
+    P_parts = [piece(P_rows[l - 1], starts[l - 1], starts[l]) for l in range(1, R + 1)]
     tail = msh.agree(comm, lambda: ([P_rows[l] for l in range(R, nl - 1)], [P.nnz for P in P_rows]))
     P_tail = [sp.vstack([t[0][i] for t in tail]).tocsr() for i in range(nl - 1 - R)]
     P_shapes = [(int(starts[l + 1][-1]), sum(t[1][l] for t in tail)) for l in range(nl - 1)]

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# every rank thread of the in-process multi-rank tests owns a library context: a small first scratch slab each (the default reserves 2 GiB at init)
+os.environ.setdefault("ELAG_HIP_ARENA_MB", "128")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

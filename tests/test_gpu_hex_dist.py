@@ -32,7 +32,7 @@ def _hex_problem(n, sigma, levels):
     return dict(M=M, B=B, Bt=Bt, Ps=Ps, seq=None), lvls, parts
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])                       # (8: the rank count of BASELINE configs 4 / 5 and of the driver's scaling run)
 @pytest.mark.parametrize("kind", ["Block Jacobi", "Block GS"])
 def test_hex_darcy_cycle_on_row_blocks_matches_serial_oracle(world, kind):
     """--form spe10 --hex 16 16 16 --gpus N, in process: partition, distributed per-block Galerkin products, replicated blocked
@@ -70,7 +70,7 @@ def test_hex_darcy_cycle_on_row_blocks_matches_serial_oracle(world, kind):
         assert np.max(np.abs(x - local(0, r, xr[:n0], xr[n0:]))) <= 1e-10 * np.max(np.abs(xr))
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_hex_darcy_default_solver_graph_converges_on_row_blocks(world):
     """configs[4] with the reference's SPE10 solver graph (spe10_example_parameters.xml:95-127) on N ranks: GMRES preconditioned by
     Block LDU whose inverses are distributed AMGe V-cycles on M and on B diag(M)^-1 B^T (distributed.build_darcy_ldu_amge).  The solve

@@ -107,7 +107,7 @@ def test_distributed_operator_products(problem, world):
     run_ranks(world, body)
 
 
-@pytest.mark.parametrize("world,replicate_from", [(2, 1), (4, 1), (2, 2), (3, 2)])
+@pytest.mark.parametrize("world,replicate_from", [(2, 1), (4, 1), (2, 2), (3, 2), (8, 1)])       # (8: the only rank count the driver's scaling run ever uses)
 @pytest.mark.parametrize("smoother", ["L1 Jacobi", "Chebyshev"])
 def test_distributed_vcycle_matches_serial_oracle(problem, world, replicate_from, smoother):
     """replicate_from=1: the layout bench.py uses (fine level distributed, rest replicated behind one all-reduce);
@@ -156,7 +156,7 @@ def test_distributed_vcycle_matches_serial_oracle(problem, world, replicate_from
 
 
 @pytest.mark.parametrize("numbering", ["natural", "tree"])
-@pytest.mark.parametrize("world,replicate_from", [(2, 1), (3, 2), (4, 1)])
+@pytest.mark.parametrize("world,replicate_from", [(2, 1), (3, 2), (4, 1), (8, 1)])
 def test_hierarchy_from_sharded_generator_is_the_serial_cycle(problem, world, replicate_from, numbering):
     """no rank holds a global operator: every rank generates its own sub-domain (meshgen_sharded), the ParCSR pieces and comm
     packages come from the rows alone, and the V-cycle and the PCG solve on them are the serial oracle's"""
@@ -478,7 +478,7 @@ def test_distributed_block_operator_and_schur(darcy, world):
     run_ranks(world, body)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("kind", ["Block Jacobi", "Block GS", "Block LDU"])
 def test_distributed_blocked_vcycle_matches_serial_oracle(darcy, world, kind):
     """per-block distributed RAP, merged operators with one halo exchange per product, block smoothers on sub-vectors,
@@ -516,7 +516,7 @@ def test_distributed_blocked_vcycle_matches_serial_oracle(darcy, world, kind):
         assert np.max(np.abs(xs[r] - ref)) <= 1e-10 * np.max(np.abs(xr))
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("name", ["PCG", "GMRES"])
 def test_distributed_krylov_matches_serial_oracle(problem, world, name):
     """dots are all-reduced on the device scalars; iteration counts and iterates equal the serial algorithm's"""
