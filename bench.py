@@ -332,7 +332,7 @@ def launch_dry_run(rank: int, world: int):
     td.destroy_process_group()
 
 
-def gauss_seidel_leg(args, la, np, dA, dPs, rhs, n_local, A, Ps):
+def gauss_seidel_leg(args, la, np, dA, dPs, rhs, n_local, A, Ps, cpu_gs=None):
     """The same hierarchy with the reference's shipped relaxation, "L1 Gauss-Seidel" (hypre relax type 2,
     Create0FormParameterList.hpp:103-116): on the device it runs as level-scheduled sweeps (csrc/sweep.hip)."""
     t0 = time.time()
@@ -379,9 +379,26 @@ def gauss_seidel_leg(args, la, np, dA, dPs, rhs, n_local, A, Ps):
             sb = la.DeviceVector(n_local, 1.0)
             ms_b = Hb.time_apply(rhs, sb, max(50, min(args.steps, 500)))
             its, conv = pcg_iterations(Hb)
-            vr[str(B)] = {"device_ms_per_step": round(ms_b, 5), "vcycles_per_s": round(1e3 / ms_b, 1), "pcg_iterations": its, "pcg_converged": conv}
+            vr[str(B)] = {"device_ms_per_step": round(ms_b, 5), "vcycles_per_s": round(1e3 / ms_b, 1), "pcg_iterations": its, "pcg_converged": conv,
+                          "pcg_time_to_solution_ms_cycles_only": round(its * ms_b, 3)}
+            # the CPU port running the SAME arithmetic: hybrid Gauss-Seidel on B process-ranks (oracle/elag_oracle.c, orc_hier_spmd_bench with type-2 levels)
+            cw = (cpu_gs or {}).get("vcycles_per_s_by_workers", {}).get(str(B))
+            if cw:
+                vr[str(B)]["cpu_port_vcycles_per_s_same_ranks"] = cw
+                vr[str(B)]["cpu_pcg_time_to_solution_ms_cycles_only"] = round(its * 1e3 / cw, 2)
             del Hb, sb
         gs["virtual_ranks"] = vr
+        if cpu_gs and "error" not in cpu_gs:
+            gs["cpu_port_process_per_core"] = {"layout": "one process per core, each sweeps its own rows, the others' values frozen for the sweep (hybrid Gauss-Seidel on W ranks: "
+                                               "what hypre's relax type 2 IS on W MPI ranks), l1 norms of that partition",
+                                               "vcycles_per_s_by_processes": cpu_gs["vcycles_per_s_by_workers"], "rel_diff_vs_serial_cycle_1_process": cpu_gs["rel_diff_vs_serial_cycle"],
+                                               "cores_available": cpu_gs["cores_available"]}
+            one = cpu_gs["vcycles_per_s_by_workers"].get("1")
+            if one:
+                gs["cpu_pcg_time_to_solution_ms_cycles_only_1_rank"] = round(gs["pcg_iterations"] * 1e3 / one, 2)
+                gs["pcg_time_to_solution_ms_cycles_only"] = round(gs["pcg_iterations"] * ms_gs, 3)
+        elif cpu_gs:
+            gs["cpu_port_process_per_core"] = cpu_gs
     note("L1 Gauss-Seidel cycle: %.4f ms" % ms_gs)
     return gs
 
@@ -466,13 +483,15 @@ def large_workload(args, dist, world, kL, la, meshgen, distributed, np, barrier)
     return large
 
 
-def spmd_cpu_baseline(refines, seconds, workers=None):
+def spmd_cpu_baseline(refines, seconds, workers=None, smoother=1):
     """The CPU baseline in the reference's own layout: oracle/spmd_baseline.py as a CHILD process (it forks one worker per
     core; this process must not have touched the GPU yet, so it is started first thing).  Returns its JSON record or an {"error": ...}."""
     import subprocess
     cmd = [sys.executable, "-m", "oracle.spmd_baseline", "--refines", str(refines), "--seconds", str(seconds)]
     if workers:
         cmd += ["--workers", ",".join(str(w) for w in workers)]
+    if smoother != 1:
+        cmd += ["--smoother", str(smoother)]
     try:
         r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -624,6 +643,9 @@ def main():
             # the same layout at the size the roofline is quoted on: one core, and the worker counts around the headline's best
             best = spmd["headline"].get("best_workers", 16) if "error" not in spmd["headline"] else 16
             spmd["roofline_size"] = spmd_cpu_baseline(args.roofline_refines, max(2.0, args.cpu_seconds / 4), workers=sorted({1, max(2, best // 2), best, 2 * best}))
+        if not args.no_gs:
+            # the reference's shipped smoother in the same layout: hybrid Gauss-Seidel on W process-ranks (what the device's virtual ranks compute)
+            spmd["gauss_seidel"] = spmd_cpu_baseline(args.refines, max(1.0, args.cpu_seconds / 5), workers=sorted({1, *[b_ for b_ in args.gs_blocks if b_ <= 64]}), smoother=2)
         note("CPU baseline done: %s" % json.dumps({k_: (v_.get("best_vcycles_per_s"), v_.get("best_workers")) for k_, v_ in spmd.items()}))
 
     # HBM traffic of the roofline kernel from the PMC counters, in this run (children under rocprofv3, before this process touches the GPU)
@@ -1025,7 +1047,7 @@ def main():
         # "L1 Gauss-Seidel" (hypre relax type 2) is what every parameter list of the reference selects
         # (Create0FormParameterList.hpp:103-116); on the device it runs as level-scheduled sweeps (csrc/sweep.hip)
         try:
-            gs = gauss_seidel_leg(args, la, np, dA, dPs, rhs, n_local, A, Ps)
+            gs = gauss_seidel_leg(args, la, np, dA, dPs, rhs, n_local, A, Ps, cpu_gs=spmd.get("gauss_seidel"))
         except Exception as exc:                                   # an extra of the line: the headline must not depend on it
             note("L1 Gauss-Seidel leg failed: %r" % (exc,))
             gs = {"error": repr(exc)[:400]}

@@ -716,6 +716,7 @@ typedef struct {
     int nlevels;
     orc_level *lev;
     int ncoarse; const double *chol;   /* dense lower Cholesky factor, row-major ncoarse x ncoarse */
+    const double *spmd_l1[64];         /* orc_hier_spmd_bench with type-2 levels: the l1 norms of the partition it runs on */
 } orc_hier;
 
 static void smoother_apply(const orc_csr *A, const orc_smoother *s, const double *f, double *u,
@@ -996,6 +997,32 @@ static void spmd_jacobi(const orc_level *L, const double *f, double *u, double *
     SPMD_BARRIER();
 }
 
+/* hypre's relax type 2 ("L1 Gauss-Seidel", the reference's shipped smoother: Create0FormParameterList.hpp:103-116) on W ranks is HYBRID
+ * Gauss-Seidel: each rank sweeps its own rows forward then backward (orc_l1gs_sweep), the other ranks' values frozen at what they were
+ * when the sweep started -- Gauss-Seidel inside a rank, Jacobi across ranks --, and the l1 norms count the off-rank entries of a row
+ * (hypre_ParCSRComputeL1Norms option 2): WHAT the reference computes depends on how many ranks it runs on.  The rows are cut like the
+ * device's virtual ranks (sweep.hip: n / W rows each, the first n mod W blocks one more), so that a W-process run here and
+ * elag_hip_set_gs_hybrid_blocks(W) there are the same arithmetic.  l1W: the l1 norms of that partition.  uold: the frozen copy. */
+#define SPMD_GS_LO(n, r) ((r) * ((n) / W) + ((r) < (n) % W ? (r) : (n) % W))
+static void spmd_l1gs(const orc_level *L, const double *l1W, const double *f, double *u, double *uold, int rank, int W, spmd_ctl *ctl, int *sense)
+{
+    const int n = L->A.n, lo = SPMD_GS_LO(n, rank), hi = SPMD_GS_LO(n, rank + 1);
+    const int *I = L->A.I, *J = L->A.J;
+    const double *a = L->A.a;
+    for (int i = lo; i < hi; i++) uold[i] = u[i];
+    SPMD_BARRIER();
+    for (int pass = 0; pass < 2; pass++)
+        for (int i = pass ? hi - 1 : lo; pass ? i >= lo : i < hi; i += pass ? -1 : 1) {
+            if (l1W[i] != 0.0) {
+                double res = f[i];
+                for (int jj = I[i]; jj < I[i + 1]; jj++) { const int j = J[jj]; if (j >= lo && j < hi) res -= a[jj] * u[j]; }       /* the rank's own block first ... */
+                for (int jj = I[i]; jj < I[i + 1]; jj++) { const int j = J[jj]; if (j < lo || j >= hi) res -= a[jj] * uold[j]; }   /* ... then its ghosts (diag, offd) */
+                u[i] += res / l1W[i];
+            }
+        }
+    SPMD_BARRIER();
+}
+
 static void spmd_iterate(orc_hier *H, spmd_vecs *V, const double *RHS, double *SOL, int l, int rank, int W, spmd_ctl *ctl, int *sense)
 {
     orc_level *F = &H->lev[l];
@@ -1004,8 +1031,10 @@ static void spmd_iterate(orc_hier *H, spmd_vecs *V, const double *RHS, double *S
         SPMD_BARRIER();
         return;
     }
-    const int n = F->A.n, nc = F->ncoarse, lo = SPMD_LO(n), hi = SPMD_HI(n), clo = SPMD_LO(nc), chi = SPMD_HI(nc);
-    spmd_jacobi(F, RHS, SOL, V[l].v, rank, W, ctl, sense);
+    const int gs = F->sm.type == 2;
+    const int n = F->A.n, nc = F->ncoarse, lo = gs ? SPMD_GS_LO(n, rank) : SPMD_LO(n), hi = gs ? SPMD_GS_LO(n, rank + 1) : SPMD_HI(n), clo = SPMD_LO(nc), chi = SPMD_HI(nc);
+    if (gs) spmd_l1gs(F, H->spmd_l1[l], RHS, SOL, V[l].v, rank, W, ctl, sense);
+    else spmd_jacobi(F, RHS, SOL, V[l].v, rank, W, ctl, sense);
     for (int i = lo; i < hi; i++) {
         double t = 0.0;
         for (int jj = F->A.I[i]; jj < F->A.I[i + 1]; jj++) t += F->A.a[jj] * SOL[F->A.J[jj]];
@@ -1028,7 +1057,14 @@ static void spmd_iterate(orc_hier *H, spmd_vecs *V, const double *RHS, double *S
         SOL[i] += t;
     }
     SPMD_BARRIER();
-    spmd_jacobi(F, RHS, SOL, V[l].v, rank, W, ctl, sense);
+    if (gs) spmd_l1gs(F, H->spmd_l1[l], RHS, SOL, V[l].v, rank, W, ctl, sense);
+    else spmd_jacobi(F, RHS, SOL, V[l].v, rank, W, ctl, sense);
+}
+
+/* the l1 norms of level l for the partition the next orc_hier_spmd_bench runs on (type-2 levels; the caller keeps the array alive) */
+ORC_API void orc_hier_set_spmd_l1(orc_hier *H, int l, const double *l1W)
+{
+    if (l >= 0 && l < 64) H->spmd_l1[l] = l1W;
 }
 
 /* Runs V-cycles (preconditioner mode, rhs fixed) on W forked worker processes for about `seconds`; returns the number of
@@ -1038,8 +1074,11 @@ ORC_API int orc_hier_spmd_bench(orc_hier *H, int W, double seconds, const double
 {
     const int nl = H->nlevels;
     if (W < 1 || !H->chol) return 1;
-    for (int l = 0; l < nl - 1; l++)
-        if (H->lev[l].sm.type != 1 || H->lev[l].sm.sweeps != 1 || H->lev[l].hiptmair) return 2;
+    for (int l = 0; l < nl - 1; l++) {
+        const int t = H->lev[l].sm.type;
+        if ((t != 1 && t != 2) || H->lev[l].sm.sweeps != 1 || H->lev[l].hiptmair || nl > 64) return 2;
+        if (t == 2 && !H->spmd_l1[l]) return 2;          /* (hybrid Gauss-Seidel needs the l1 norms of THIS partition: orc_hier_set_spmd_l1) */
+    }
     /* explicit transposes of the interpolators (read-only after this point: shared with the children copy-on-write) */
     for (int l = 0; l < nl - 1; l++) {
         orc_level *L = &H->lev[l];

@@ -206,6 +206,28 @@ def l1_norms(diag, offd=None, option=1) -> np.ndarray:
     return l1
 
 
+def block_starts(n, nblocks):
+    """row blocks of the device's virtual ranks (sweep.hip) and of orc_hier_spmd_bench's type-2 levels: n // nblocks rows each, the first
+    n % nblocks blocks one more"""
+    size, rest = divmod(int(n), int(nblocks))
+    return np.concatenate([[0], np.cumsum([size + (1 if b < rest else 0) for b in range(int(nblocks))])]).astype(np.int64)
+
+
+def l1_norms_blocks(A, nblocks, option=2) -> np.ndarray:
+    """hypre_ParCSRComputeL1Norms (options 1, 2, 4) of a square operator split like a ParCSR matrix on ``nblocks`` ranks with the contiguous row
+    blocks of ``block_starts``: the entries of a row outside its own block are its offd part."""
+    A = csr(A)
+    n = A.shape[0]
+    if int(nblocks) <= 1:
+        return l1_norms(A, None, option)
+    st = block_starts(n, nblocks)
+    blk = np.searchsorted(st, np.arange(n), side="right") - 1
+    rows = np.repeat(np.arange(n), np.diff(A.indptr))
+    inside = blk[A.indices] == blk[rows]
+    keep = lambda m: sp.csr_matrix((A.data[m], A.indices[m], np.concatenate([[0], np.cumsum(np.bincount(rows[m], minlength=n))]).astype(np.int32)), shape=A.shape)
+    return l1_norms(keep(inside), keep(~inside), option)
+
+
 def cheby_coefs(max_eig, min_eig, fraction, order):
     c = np.zeros(5)
     co = lib().orc_cheby_coefs(C.c_double(max_eig), C.c_double(min_eig), C.c_double(fraction), C.c_int(order), _dp(c))
@@ -1140,8 +1162,17 @@ class CHierarchy:
 
     def spmd_bench(self, rhs, workers, seconds):
         """The reference's CPU layout: ``workers`` forked processes, one per core, each owning a row block of every level,
-        vectors in shared memory (orc_hier_spmd_bench; l1-Jacobi levels above a dense coarse solve only).  Runs V-cycles for about
-        ``seconds``; returns (cycles per second, last solution).  Forks: call it from a process that holds no GPU context."""
+        vectors in shared memory (orc_hier_spmd_bench; l1-Jacobi or "L1 Gauss-Seidel" levels above a dense coarse solve).  Type-2 levels run
+        hypre's HYBRID Gauss-Seidel on that many ranks -- each process sweeps its own rows, the others' values frozen, l1 norms of that
+        partition (``l1_norms_blocks``) -- i.e. what ``elag_hip_set_gs_hybrid_blocks(workers)`` computes on the device.  Runs V-cycles for
+        about ``seconds``; returns (cycles per second, last solution).  Forks: call it from a process that holds no GPU context."""
+        As, _Ps, smoothers = self.keep[0], self.keep[1], self.keep[2]
+        self._spmd_l1 = []
+        for l, sm in enumerate(smoothers[:len(As) - 1]):
+            if sm["type"] == 2:
+                l1 = l1_norms_blocks(As[l], int(workers), option=2)
+                self._spmd_l1.append(l1)
+                self.L.orc_hier_set_spmd_l1(self.h, C.c_int(l), _dp(l1))
         sol = np.empty(self.n)
         cycles, elapsed = C.c_long(0), C.c_double(0.0)
         rc = self.L.orc_hier_spmd_bench(self.h, C.c_int(int(workers)), C.c_double(float(seconds)), _dp(_f64(rhs)), _dp(sol),

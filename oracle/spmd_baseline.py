@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--refines", type=int, default=3)
     ap.add_argument("--seconds", type=float, default=3.0, help="per worker count")
     ap.add_argument("--workers", default=None, help="comma list; default: powers of two up to the cores this process may use")
+    ap.add_argument("--smoother", type=int, default=1, choices=[1, 2], help="hypre relax type of every level: 1 = l1-Jacobi; 2 = \"L1 Gauss-Seidel\", the "
+                    "reference's shipped smoother -- on W processes hybrid Gauss-Seidel on W ranks (each sweeps its own rows, the others frozen)")
     args = ap.parse_args()
     import numpy as np
     from parelag_amd import meshgen
@@ -63,7 +65,7 @@ def main():
     gen_s = time.perf_counter() - t0
     orc.build(native=True)
     t0 = time.perf_counter()
-    h = oracle_h1_hierarchy(A, Ps, smoother=1)
+    h = oracle_h1_hierarchy(A, Ps, smoother=args.smoother)
     setup_s = time.perf_counter() - t0                      # RAP chain + FixZeroRows + l1 norms + dense Cholesky, one core
     H = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"], native=True)
     b = np.full(A.shape[0], 2.0)
@@ -73,9 +75,10 @@ def main():
     for w in workers:
         rate, x = H.spmd_bench(b, w, args.seconds)
         sweep[w] = round(rate, 3)
-        diff = max(diff, float(np.max(np.abs(x - xs)) / np.max(np.abs(xs))))
+        if args.smoother == 1 or w == 1:                     # (hybrid Gauss-Seidel on W > 1 ranks is another cycle than the one-rank one, by definition)
+            diff = max(diff, float(np.max(np.abs(x - xs)) / np.max(np.abs(xs))))
     best = max(sweep, key=sweep.get)
-    print(json.dumps({"refines": args.refines, "n": int(A.shape[0]), "nnz": int(A.nnz), "levels": len(Ps) + 1,
+    print(json.dumps({"refines": args.refines, "n": int(A.shape[0]), "nnz": int(A.nnz), "levels": len(Ps) + 1, "relax_type": args.smoother,
                       "vcycles_per_s_by_workers": sweep, "best_workers": best, "best_vcycles_per_s": sweep[best],
                       "rel_diff_vs_serial_cycle": diff, "setup_s_1core": round(setup_s, 4), "generate_s": round(gen_s, 2),
                       "cores_available": avail, "cpu_model": cpu_model(), "seconds_per_point": args.seconds}), flush=True)

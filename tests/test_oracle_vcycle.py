@@ -100,6 +100,60 @@ def test_process_per_core_cycle_is_the_serial_cycle(h1_k2):
         rate, x = H.spmd_bench(b, workers, 0.2)
         assert rate > 0
         assert np.max(np.abs(x - xs)) <= 1e-13 * np.max(np.abs(xs))
-    hg = oracle_h1_hierarchy(A, Ps, smoother=2)                    # Gauss-Seidel levels are refused (the team runs l1-Jacobi levels only)
+    hc = oracle_h1_hierarchy(A, Ps, smoother=16)                   # Chebyshev levels are refused (the team runs l1-Jacobi and l1-Gauss-Seidel levels)
     with pytest.raises(RuntimeError):
-        orc.CHierarchy(hg["As"], hg["Ps"], hg["sms"], hg["chol"]).spmd_bench(b, 2, 0.1)
+        orc.CHierarchy(hc["As"], hc["Ps"], hc["sms"], hc["chol"]).spmd_bench(b, 2, 0.1)
+
+
+def test_process_per_core_gauss_seidel_cycle_is_hybrid_gauss_seidel_on_that_many_ranks(h1_k2):
+    """The reference's shipped smoother ("L1 Gauss-Seidel", hypre relax type 2) in the same layout: on W processes it is HYBRID Gauss-Seidel --
+    each process sweeps its own rows forward then backward, the other processes' values frozen at the start of the sweep, l1 norms of that
+    partition (hypre_ParCSRComputeL1Norms option 2 counts the off-rank entries) -- so the cycle DEPENDS on W.  One process is the serial
+    oracle's cycle; three are a plain restatement of the hybrid sweep, block by block, on the blocks of the device's virtual ranks
+    (what elag_hip_set_gs_hybrid_blocks(3) runs: tests/test_gpu_sweeps.py)."""
+    from tests.helpers import oracle_h1_hierarchy
+    A, Ps, _ = h1_k2
+    h = oracle_h1_hierarchy(A, Ps, smoother=2)
+    H = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"])
+    b = np.random.default_rng(12).uniform(-1, 1, A.shape[0])
+    xs = np.empty_like(b)
+    H.apply(b, xs)
+    _rate, x1 = H.spmd_bench(b, 1, 0.2)
+    assert np.array_equal(x1, xs)
+
+    def hybrid_sweep(Al, l1, f, u, W):
+        st = orc.block_starts(Al.shape[0], W)
+        old = u.copy()
+        I, J, a = Al.indptr, Al.indices, Al.data
+        for r in range(W):
+            lo, hi = int(st[r]), int(st[r + 1])
+            for rows in (range(lo, hi), range(hi - 1, lo - 1, -1)):
+                for i in rows:
+                    if l1[i] != 0.0:
+                        res = f[i]
+                        cols, vals = J[I[i]:I[i + 1]], a[I[i]:I[i + 1]]
+                        own = (cols >= lo) & (cols < hi)
+                        for j, v in zip(cols[own], vals[own]):
+                            res -= v * u[j]
+                        for j, v in zip(cols[~own], vals[~own]):
+                            res -= v * old[j]
+                        u[i] += res / l1[i]
+
+    def cycle(l, f, W):
+        Al = h["As"][l]
+        if l == len(h["As"]) - 1:
+            x = np.zeros_like(f)
+            orc.chol_solve(h["chol"], f, x)
+            return x
+        l1 = orc.l1_norms_blocks(Al, W, option=2)
+        u = np.zeros_like(f)
+        hybrid_sweep(Al, l1, f, u, W)
+        P = h["Ps"][l]
+        u += P @ cycle(l + 1, P.T @ (f - Al @ u), W)
+        hybrid_sweep(Al, l1, f, u, W)
+        return u
+    W = 3
+    _rate, x3 = H.spmd_bench(b, W, 0.2)
+    ref = cycle(0, b, W)
+    assert np.max(np.abs(x3 - ref)) <= 1e-12 * np.max(np.abs(ref))
+    assert np.max(np.abs(x3 - xs)) > 1e-6 * np.max(np.abs(xs))          # (and it is NOT the one-rank cycle)
