@@ -240,6 +240,23 @@ size_t pool_cap()
 }
 bool pool_active() { return pool_cap() > 0 && !comm_active() && ctx().initialised; }
 
+// The pool's slab: one allocation made by elag_hip_init (ELAG_HIP_POOL_SLAB_MB, default 1024, at most a sixteenth of the free memory; 0 = none) from
+// which the library's persistent blocks are carved by a bump pointer until it is full -- the level operators, SpMV forms and vectors of the
+// FIRST hierarchy of a process then cost no hipMalloc either (the x-cache tables of the cube456 x5 operators alone were 7 of the 23 ms of a
+// first build, against 14 ms for every later one).  A carved block that is freed always goes to the calling thread's cache (it cannot go back
+// to the driver on its own); the slab is returned whole by elag_hip_finalize, or by elag_hip_trim_memory / an out-of-memory drain once no
+// carved block is in use.
+struct PoolSlab { char *base = nullptr; size_t cap = 0, top = 0, live = 0; };
+thread_local PoolSlab t_slab;
+std::vector<std::pair<char *, size_t>> g_slabs;          // every thread's slab (g_alloc_mu): a block freed by another thread than its slab's is left alone
+bool in_my_slab(const void *p) { return t_slab.base && (const char *)p >= t_slab.base && (const char *)p < t_slab.base + t_slab.cap; }
+bool in_any_slab(const void *p)
+{
+    for (auto &sl : g_slabs)
+        if ((const char *)p >= sl.first && (const char *)p < sl.first + sl.second) return true;
+    return false;
+}
+
 size_t round_block(size_t bytes)
 {
     if (bytes < 256) return 256;
@@ -258,14 +275,20 @@ void *raw_alloc(size_t bytes)
         auto it = t_cache.blocks.lower_bound(sz);
         if (it != t_cache.blocks.end() && it->first <= sz + sz / 8) {
             p = it->second;
-            t_cache.held -= it->first;
+            if (in_my_slab(p)) t_slab.live++; else t_cache.held -= it->first;
             std::lock_guard<std::mutex> lk(g_alloc_mu);
             g_alloc_size[p] = it->first;
             t_cache.blocks.erase(it);
             return p;
         }
     }
-    p = device_malloc(sz);
+    if (t_slab.base && t_slab.top + sz <= t_slab.cap && pool_active()) {
+        p = t_slab.base + t_slab.top;
+        t_slab.top += sz;
+        t_slab.live++;
+    } else {
+        p = device_malloc(sz);
+    }
     std::lock_guard<std::mutex> lk(g_alloc_mu);
     g_alloc_size[p] = sz;
     return p;
@@ -292,11 +315,26 @@ size_t alloc_cache_release()
 {
     size_t given = 0;
     Context &c = ctx();
-    if (t_cache.blocks.empty() && (c.slabs.empty() || c.cur_slab + 1 >= (int)c.slabs.size())) return 0;
+    if (t_cache.blocks.empty() && !(t_slab.base && t_slab.live == 0) && (c.slabs.empty() || c.cur_slab + 1 >= (int)c.slabs.size())) return 0;
     if (c.stream) (void)hipStreamSynchronize(c.stream);
-    for (auto &b : t_cache.blocks) { (void)hipFree(b.second); given += b.first; }
-    t_cache.blocks.clear();
+    for (auto it = t_cache.blocks.begin(); it != t_cache.blocks.end();) {
+        if (in_my_slab(it->second)) {
+            if (t_slab.live == 0) it = t_cache.blocks.erase(it); else ++it;          // (the slab goes as a whole, below, or stays)
+        } else {
+            (void)hipFree(it->second); given += it->first;
+            it = t_cache.blocks.erase(it);
+        }
+    }
     t_cache.held = 0;
+    if (t_slab.base && t_slab.live == 0) {
+        {
+            std::lock_guard<std::mutex> lk(g_alloc_mu);
+            g_slabs.erase(std::remove_if(g_slabs.begin(), g_slabs.end(), [&](const std::pair<char *, size_t> &sl) { return sl.first == t_slab.base; }), g_slabs.end());
+        }
+        (void)hipFree(t_slab.base);
+        given += t_slab.cap;
+        t_slab = PoolSlab();
+    }
     // scratch slabs above the one in use hold nothing
     for (size_t i = (size_t)(c.cur_slab + 1); i < c.slabs.size(); i++) { (void)hipFree(c.slabs[i].p); given += c.slabs[i].cap; }
     c.slabs.resize((size_t)(c.cur_slab + 1));
@@ -311,6 +349,15 @@ void raw_free(void *p)
         std::lock_guard<std::mutex> lk(g_alloc_mu);
         auto it = g_alloc_size.find(p);
         if (it != g_alloc_size.end()) { sz = it->second; g_alloc_size.erase(it); }
+    }
+    if (sz > 0 && in_my_slab(p)) {                           // carved from the slab: kept for the next request whatever the pool's limit
+        t_cache.blocks.emplace(sz, p);
+        t_slab.live--;
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_alloc_mu);
+        if (in_any_slab(p)) return;                           // another thread's slab (or one already returned): not the driver's to free
     }
     if (sz > 0 && ((t_cache.depth > 0 && t_cache.held + sz <= kCacheMaxHeld) || (t_cache.depth == 0 && pool_active() && t_cache.held + sz <= pool_cap()))) {
         t_cache.blocks.emplace(sz, p);
@@ -336,11 +383,12 @@ AllocScope::~AllocScope()
     const size_t keep = pool_active() ? pool_cap() : 0;
     if (t_cache.held <= keep) return;
     if (ctx().stream) (void)hipStreamSynchronize(ctx().stream);
-    while (t_cache.held > keep && !t_cache.blocks.empty()) {
-        auto it = std::prev(t_cache.blocks.end());
+    for (auto it = t_cache.blocks.end(); t_cache.held > keep && it != t_cache.blocks.begin();) {
+        --it;
+        if (in_my_slab(it->second)) continue;
         (void)hipFree(it->second);
         t_cache.held -= it->first;
-        t_cache.blocks.erase(it);
+        it = t_cache.blocks.erase(it);
     }
 }
 
@@ -438,6 +486,18 @@ int elag_hip_init(int device)
                 if (hipMalloc(&p, want) == hipSuccess) { c.slabs.push_back(ScratchSlab{static_cast<char *>(p), want, 0}); c.cur_slab = 0; }
                 else (void)hipGetLastError();
             }
+            // ... and the pool's slab (see PoolSlab)
+            const char *es = getenv("ELAG_HIP_POOL_SLAB_MB");
+            size_t slab = (size_t)(es ? std::max(0ll, atoll(es)) : 1024) << 20;
+            if (slab && hipMemGetInfo(&free_b, &total_b) == hipSuccess) slab = std::min(slab, free_b / 16);
+            if (slab >= (size_t(64) << 20) && pool_cap() > 0 && !t_slab.base) {
+                void *p = nullptr;
+                if (hipMalloc(&p, slab) == hipSuccess) {
+                    t_slab.base = static_cast<char *>(p); t_slab.cap = slab; t_slab.top = 0; t_slab.live = 0;
+                    std::lock_guard<std::mutex> lk(g_alloc_mu);
+                    g_slabs.emplace_back(t_slab.base, slab);
+                } else (void)hipGetLastError();
+            }
         }
     });
 }
@@ -450,9 +510,18 @@ int elag_hip_finalize(void)
         (void)hipStreamSynchronize(c.stream);
         (void)hipStreamSynchronize(c.comm_stream);
         comm_destroy();
-        for (auto &b : t_cache.blocks) (void)hipFree(b.second);
+        for (auto &b : t_cache.blocks)
+            if (!in_my_slab(b.second)) (void)hipFree(b.second);
         t_cache.blocks.clear();
         t_cache.held = 0;
+        if (t_slab.base) {
+            // (objects the caller still holds point into memory that is gone with the library's context: releasing one later is a hipFree of an
+            // address the driver does not know, which it refuses and the library ignores)
+            (void)hipFree(t_slab.base);
+            std::lock_guard<std::mutex> lk(g_alloc_mu);
+            g_slabs.erase(std::remove_if(g_slabs.begin(), g_slabs.end(), [&](const std::pair<char *, size_t> &sl) { return sl.first == t_slab.base; }), g_slabs.end());
+            t_slab = PoolSlab();
+        }
         scratch_release_all();
         amge_release_arena();
         (void)hipFree(c.d_scalar);

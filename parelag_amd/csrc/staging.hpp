@@ -16,7 +16,7 @@ struct VecIn {
         if (n) ELAG_HIP_CHECK(hipMemcpyAsync(tmp, p, n * sizeof(double), hipMemcpyHostToDevice, ctx().stream));
         d = tmp;
     }
-    ~VecIn() { if (tmp) { (void)hipStreamSynchronize(ctx().stream); (void)hipFree(tmp); } }
+    ~VecIn() { if (tmp) { (void)hipStreamSynchronize(ctx().stream); dev_free(tmp); } }      // (dev_alloc's blocks go back through dev_free: they may be pooled)
 };
 struct VecInOut {
     double *d = nullptr, *host = nullptr, *tmp = nullptr;
@@ -35,7 +35,7 @@ struct VecInOut {
         if (n) ELAG_HIP_CHECK(hipMemcpyAsync(host, tmp, n * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
         ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
     }
-    ~VecInOut() { if (tmp) { (void)hipStreamSynchronize(ctx().stream); (void)hipFree(tmp); } }
+    ~VecInOut() { if (tmp) { (void)hipStreamSynchronize(ctx().stream); dev_free(tmp); } }
 };
 
 
