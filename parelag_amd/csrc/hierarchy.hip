@@ -488,7 +488,7 @@ struct elag_hip_hierarchy_s {
         // OFF unless ELAG_HIP_RESIDENT=1: measured on MI355X (cube456 x3, 5 products per cycle) the grid-wide barrier costs ~20 us -- an
         // agent-scope release / acquire has to write back and invalidate the eight XCDs' L2s, and 128-512 arrivals on one address are
         // serialised at the memory side -- against ~4.5 us for a kernel boundary inside a replayed graph: 0.107 ms per cycle at the best
-        // grid (128 workgroups) against 0.029 ms for the five separate launches.  Kept for the record and for
+        // grid (128 workgroups) against 0.029 ms for the five separate launches (CHANGELOG.md, round 2).  Kept for the record and for
         // hardware where the trade is different; results are bit-identical either way (tests/test_gpu_parity.py).
         const char *en = getenv("ELAG_HIP_RESIDENT");          // (read at every Finalize: a test switches it)
         if (!(en && atoi(en)) || !all_local) return;

@@ -608,7 +608,7 @@ void launch_stream(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hipSt
     }
     if (A.xc_state == 1 && stream_variant() != 4) { launch_xc(A, offd, p, st); return; }
     // ELAG_HIP_STREAM_VARIANT=4 selects a DIAGNOSTIC build of the kernel (coalesced x reads, wrong results) that
-    // prices the gather: 7.2 TB/s against 5.1-5.4 TB/s for the real kernel
+    // prices the gather: 7.2 TB/s against 5.1-5.4 TB/s for the real kernel (CHANGELOG.md, round 2)
     if (stream_variant() == 4) launch_stream_v<4>(A, offd, p, st);
     else launch_stream_v<0>(A, offd, p, st);
 }
