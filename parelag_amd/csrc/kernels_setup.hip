@@ -2005,16 +2005,16 @@ bool rap_fused(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, boo
     const CsrView r{R.I, R.J, R.a}, a{A.I, A.J, A.a};
     // a wavefront walks ~8 rows (the pipeline takes four rows to fill), four wavefronts per workgroup
     const unsigned grid = stride_grid(((long long)nr + 7) / 8, 4, 1ll << 30);
-    // (steps per trip: 2 -- 0.92-0.96 ms per product at cube456 x5 -- against 1.0-1.07 with 3 or 4 and 1.5 with 8: the registers of a deeper batch cost more
-    // wavefronts than its loads in flight buy; ELAG_HIP_FUSED_B=4 for A/B runs)
+    // (steps per trip: 2 -- 0.78-0.96 ms per product at cube456 x5 -- against 1.0-1.07 with 3 or 4 and 1.5 with 8: the registers of a deeper batch cost more
+    // wavefronts than its loads in flight buy, ELAG_HIP_FUSED_B=4 for A/B runs; and holding the compiler to 6 / 7 / 8 wavefronts per SIMD
+    // -- amdgpu_waves_per_eu: 80 / 72 / 64 registers with 6 / 8 / 16 of them spilled -- costs 0.85 / 0.92 / 1.37 ms against 0.78 at its own 5)
     static int fb = -1;
     if (fb < 0) { const char *eb = getenv("ELAG_HIP_FUSED_B"); fb = eb ? atoi(eb) : 2; }
-    if (W == 2 && fb == 4)
-        hipLaunchKernelGGL((rap_fused_kernel<2, 4, 128, 256>), dim3(grid), dim3(256), 0, st, r, a, (const int *)P.ellJ, (const double *)P.ella, nr, rn.p, Ju.p, au.p, kStride, ctl.p + 2);
-    else if (W == 2)
-        hipLaunchKernelGGL((rap_fused_kernel<2, 2, 128, 256>), dim3(grid), dim3(256), 0, st, r, a, (const int *)P.ellJ, (const double *)P.ella, nr, rn.p, Ju.p, au.p, kStride, ctl.p + 2);
-    else
-        hipLaunchKernelGGL((rap_fused_kernel<4, 2, 128, 256>), dim3(grid), dim3(256), 0, st, r, a, (const int *)P.ellJ, (const double *)P.ella, nr, rn.p, Ju.p, au.p, kStride, ctl.p + 2);
+#define ELAG_FUSED_LAUNCH(WW, BB) hipLaunchKernelGGL((rap_fused_kernel<WW, BB, 128, 256>), dim3(grid), dim3(256), 0, st, r, a, (const int *)P.ellJ, (const double *)P.ella, nr, rn.p, Ju.p, au.p, kStride, ctl.p + 2)
+    if (W == 2 && fb == 4) ELAG_FUSED_LAUNCH(2, 4);
+    else if (W == 2) ELAG_FUSED_LAUNCH(2, 2);
+    else ELAG_FUSED_LAUNCH(4, 2);
+#undef ELAG_FUSED_LAUNCH
     ELAG_LAUNCH_CHECK();
     int *CI = dev_alloc<int>((size_t)nr + 1);
     exclusive_scan(rn, CI, nr);
