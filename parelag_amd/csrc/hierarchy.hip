@@ -100,6 +100,14 @@ struct elag_hip_hierarchy_s {
     k::FlatSegs flat_s1, flat_s2;
     k::FlatSum flat_s3;
     std::vector<std::shared_ptr<DevCSR>> flat_ops;
+    // distributed flattened cycle (plan_flat_dist): a row-partitioned l1-Jacobi level above a replicated sub-hierarchy as
+    //   [pack + exchange of f] -> stage 1 -> [ONE all-reduce of the stacked coarse right-hand sides] -> stage 2 -> stage 3
+    bool fd_active = false;
+    k::FlatSegs fd_s1, fd_s2;
+    k::FlatSum fd_s3;
+    std::vector<std::shared_ptr<DevCSR>> fd_ops;
+    double *fd_stack = nullptr, *fd_fext = nullptr;
+    int fd_stack_n = 0;
     // graph replay or plain stream launches, by measurement at Finalize (tune_launch_mode): a replayed hipGraph costs a fixed 7-9 us per
     // launch on top of its nodes, which a cycle of a handful of kernels does not earn back (cube456 x3: 29 us replayed, 21.5 us launched)
     int tune_nodes = 0;
@@ -120,6 +128,7 @@ struct elag_hip_hierarchy_s {
         k::resident_free(res_seq);
         for (size_t l = 1; l < d_order.size(); l++) dev_free(d_order[l]);
         dev_free(r0); dev_free(e0); dev_free(d_order0); dev_free(p_rhs); dev_free(p_sol); dev_free(Bdense);
+        dev_free(fd_stack); dev_free(fd_fext);
         for (auto *s : owned_smoothers) delete s;
         delete owned_coarse;
         for (auto *m : owned_mats) delete m;
@@ -197,7 +206,7 @@ struct elag_hip_hierarchy_s {
             if (A_user) k::prepare_spmv(A_user->diag);
         });
         phase("dense_tail", [&] { plan_dense_tail(); });
-        phase("flat_cycle_operators", [&] { plan_flat(); plan_resident(); });
+        phase("flat_cycle_operators", [&] { plan_flat(); plan_resident(); plan_flat_dist(); });
         finalized = true;
         tune_graph_us = tune_eager_us = 0.0; tune_nodes = 0;
         if (use_graph) phase("launch_mode", [&] { tune_launch_mode(); });
@@ -608,6 +617,175 @@ struct elag_hip_hierarchy_s {
         }
     }
 
+    // the linear maps of a fused level,  x_l = U f_l + V x_{l+1}:  l1-Jacobi  U = 2 W - W A W, V = -W S;  Chebyshev  U1, U2  (see plan_flat)
+    static bool level_maps(Level &F, std::shared_ptr<DevCSR> &U, std::shared_ptr<DevCSR> &V)
+    {
+        if (F.U1) { U = F.U1; V = F.U2; return true; }
+        if (!(F.S && F.fused_dinv && F.G) || F.Gaux) return false;
+        const int n = F.A->nrows();
+        const double *w = F.fused_dinv;
+        U.reset(new DevCSR());
+        k::csr_copy(F.A->diag, *U);
+        k::CsrCombine uop;
+        uop.c_scale = -1.0; uop.c_row = w; uop.c_col = w; uop.diag = w; uop.d_scale = 2.0;
+        if (!k::csr_combine_inplace(*U, uop)) {
+            DevCSR T, Wd;
+            k::csr_copy(F.A->diag, T);
+            k::csr_scale_rows(T, w);
+            k::csr_scale_cols(T, w);
+            k::csr_diagonal(n, w, 1.0, Wd);
+            k::csr_add(2.0, Wd, -1.0, T, *U);
+        }
+        Temp<double> negw((size_t)n);
+        k::vec_scale_mul(n, -1.0, w, nullptr, negw);
+        V.reset(new DevCSR());
+        k::csr_copy(*F.S, *V);
+        k::csr_scale_rows(*V, negw);
+        ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));       // (negw goes out of scope)
+        return true;
+    }
+
+    // The flattened cycle for the layout of the multi-rank runs: level 0 row-partitioned (l1-Jacobi, one sweep before and after), the levels below
+    // complete on every rank as a hierarchy of their own behind one all-reduce (distributed.py, elag_hip_coarse_create_from_hierarchy).
+    // Level by level that is 7 launches -- A, P^T | G, dense, up | S -- before any communication (one rank through it: 31.5 k V-cycles/s against
+    // 60 k for the one-rank path).  With the level maps  f_{l+1} = G_l f_l,  x_l = U_l f_l + V_l x_{l+1}  it becomes
+    //     pack + exchange of f                                                      (ONE neighbour exchange, as before)
+    //     stage 1:  h = U_0 f,   partial f_l = (G_{l-1} ... G_0)|my columns f     for l = 1 .. D, stacked          (one launch)
+    //     all-reduce of the stack                                                   (ONE all-reduce, as before: of every f_l instead of f_1)
+    //     stage 2:  t_l = U_l f_l,   x_D = B f_D                                   on every rank                    (one launch)
+    //     stage 3:  x = h + sum_l (V_0 ... V_{l-1})|my rows t_l                                                     (one launch)
+    // G_0 = P^T (I - A W) and U_0 = 2 W - W A W act on [own | ghost] entries of f (A's diag and offd blocks side by side, W's ghost entries
+    // fetched once here); V_0 = -W S is the rows this rank owns of the distributed S = A P - W^-1 P that plan_fused formed (global coarse
+    // columns, no ghosts: the coarse level is replicated).  Same linear map as the level-by-level cycle, other rounding.  Taken only when every
+    // rank can (agreed by an all-reduce); ELAG_HIP_FLAT_DIST=0 keeps the level-by-level launches.
+    void plan_flat_dist()
+    {
+        fd_active = false;
+        fd_ops.clear();
+        dev_free(fd_stack); dev_free(fd_fext);
+        fd_stack_n = 0;
+        const char *en = getenv("ELAG_HIP_FLAT_DIST");            // (read at every Finalize: tests switch it)
+        if (lev.size() != 2 || !coarse || !coarse->sub || !coarse->sub_allreduce) return;
+        Level &F = lev[0];
+        Level &C = lev[1];
+        elag_hip_hierarchy_s *S = coarse->sub;
+        const int nlS = (int)S->lev.size();
+        int D = -1, nd = 0;
+        const double *Md = nullptr;
+        if (S->dense_level >= 0) { D = S->dense_level; Md = S->Bdense; nd = S->lev[(size_t)D].A->nrows(); }
+        else if (S->coarse && !S->coarse->custom_apply && !S->coarse->replicated && S->coarse->Minv) { D = nlS - 1; Md = S->coarse->Minv; nd = S->coarse->n; }
+        bool can = !(en && !atoi(en)) && F.Sd && F.dist_w && F.Sd->offd.ncols == 0 && S->finalized && S->all_local && !S->reordered && D >= 0 && Md && nd > 0 &&
+                   D + 1 <= k::kFlatTerms && D + 2 <= k::kFlatSegs && !C.P->needs_exchange() && C.P->ncols() == S->lev[0].A->nrows() &&
+                   F.A->diag.nnz + F.A->offd.nnz < (int64_t(1) << 20);
+        for (int i = 0; can && i < D; i++) {
+            const Level &L = S->lev[(size_t)i];
+            can = L.G && !L.Gaux && (L.U1 || (L.S && L.fused_dinv));
+        }
+        // every rank or none (the stacked all-reduce has another length than the level-by-level one)
+        if (dist_pieces && comm_active()) {
+            double no = can ? 0.0 : 1.0;
+            comm_allreduce_scalar(&no, 1);
+            can = no == 0.0;
+        }
+        if (!can) {
+            if (getenv("ELAG_HIP_FLAT_VERBOSE"))
+                fprintf(stderr, "[elag_hip] distributed flattened cycle not applicable (Sd %d, sub finalised %d local %d reordered %d, dense level %d of %d, local entries %lld)\n", F.Sd ? 1 : 0,
+                        (int)S->finalized, (int)S->all_local, (int)S->reordered, D, nlS, (long long)(F.A->diag.nnz + F.A->offd.nnz));
+            return;
+        }
+        double failed = 0.0;
+        try {
+            const int n = F.A->nrows(), ng = F.A->offd.ncols, next = n + ng, m = D + 1;
+            const double *w = F.dist_w;
+            // W on [own | ghost] entries
+            Temp<double> wext((size_t)std::max(next, 1));
+            ELAG_HIP_CHECK(hipMemcpyAsync(wext.p, w, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx().stream));
+            par_halo_exchange(*F.A, w);                                                          // (collective: every rank is here)
+            if (ng) ELAG_HIP_CHECK(hipMemcpyAsync(wext.p + n, F.A->d_ghost, sizeof(double) * (size_t)ng, hipMemcpyDeviceToDevice, ctx().stream));
+            std::vector<std::shared_ptr<DevCSR>> U((size_t)m), V((size_t)m), Gc((size_t)m), Vc((size_t)m);
+            DevCSR Aloc;                                                                         // [diag | offd], n x (n + ng)
+            csr_hstack(F.A->diag, nullptr, 0, ng ? &F.A->offd : nullptr, nullptr, n, next, false, Aloc);
+            C.P->ensure_transpose();
+            {   // G_0 = [P^T | 0] - (P^T [diag | offd]) W
+                DevCSR PText;
+                k::csr_copy(*C.P->diagT, PText);
+                PText.ncols = next;
+                std::shared_ptr<DevCSR> RA(new DevCSR());
+                k::csr_spgemm(*C.P->diagT, Aloc, *RA);
+                k::CsrCombine g;
+                g.c_scale = -1.0; g.c_col = wext; g.B = &PText; g.b_scale = 1.0;
+                if (k::csr_combine_inplace(*RA, g)) {
+                    RA->choose_spmv_shape();
+                    Gc[0] = RA;
+                } else {
+                    DevCSR RA2;
+                    k::csr_spgemm(*C.P->diagT, Aloc, RA2);
+                    k::csr_scale_cols(RA2, wext);
+                    Gc[0].reset(new DevCSR());
+                    k::csr_add(1.0, PText, -1.0, RA2, *Gc[0]);
+                }
+            }
+            {   // U_0 = 2 W - W [diag | offd] W
+                U[0].reset(new DevCSR());
+                k::csr_copy(Aloc, *U[0]);
+                k::CsrCombine uop;
+                uop.c_scale = -1.0; uop.c_row = w; uop.c_col = wext; uop.diag = w; uop.d_scale = 2.0;
+                if (!k::csr_combine_inplace(*U[0], uop)) fail(ELAG_HIP_ERR_STATE, "distributed flattened cycle: a row of the fine operator stores no diagonal entry");
+            }
+            {   // V_0 = -W S (this rank's rows, global coarse columns)
+                Temp<double> negw((size_t)n);
+                k::vec_scale_mul(n, -1.0, w, nullptr, negw);
+                V[0].reset(new DevCSR());
+                k::csr_copy(F.Sd->diag, *V[0]);
+                k::csr_scale_rows(*V[0], negw);
+                ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+            }
+            for (int i = 1; i < m; i++)
+                if (!level_maps(S->lev[(size_t)i - 1], U[(size_t)i], V[(size_t)i])) fail(ELAG_HIP_ERR_STATE, "distributed flattened cycle: level without linear maps");
+            Vc[0] = V[0];
+            long long extra = 0;
+            const long long budget = std::max<long long>(1ll << 21, 8 * (F.A->diag.nnz + F.A->offd.nnz));
+            for (int i = 1; i < m; i++) {
+                Gc[(size_t)i].reset(new DevCSR());
+                k::csr_spgemm(*S->lev[(size_t)i - 1].G, *Gc[(size_t)i - 1], *Gc[(size_t)i], false);
+                Vc[(size_t)i].reset(new DevCSR());
+                k::csr_spgemm(*Vc[(size_t)i - 1], *V[(size_t)i], *Vc[(size_t)i], false);
+                extra += Gc[(size_t)i]->nnz + Vc[(size_t)i]->nnz;
+                if (extra > budget) fail(ELAG_HIP_ERR_STATE, "distributed flattened cycle: composites outgrow their budget");
+            }
+            // the stacked coarse right-hand sides f_1 .. f_D (one all-reduce) -- f_l has the height of sub level l - 1
+            std::vector<int> off((size_t)m + 1, 0);
+            for (int i = 1; i <= m; i++) off[(size_t)i] = off[(size_t)i - 1] + S->lev[(size_t)i - 1].A->nrows();
+            fd_stack_n = off[(size_t)m];
+            fd_stack = dev_alloc<double>((size_t)fd_stack_n);
+            if (F.A->needs_exchange()) fd_fext = dev_alloc<double>((size_t)next);
+            const double *rhs = k::resident_rhs();
+            double *sol = k::resident_sol();
+            double *h = F.tmp_resid;
+            k::FlatSegs s1, s2;
+            k::FlatSum s3;
+            for (int i = m - 1; i >= 0; i--) k::flat_segs_add_csr(s1, *Gc[(size_t)i], rhs, fd_stack + off[(size_t)i]);
+            k::flat_segs_add_csr(s1, *U[0], rhs, h);
+            k::flat_segs_add_dense(s2, nd, nd, Md, fd_stack + off[(size_t)m - 1], S->lev[(size_t)D].sol);
+            for (int i = m - 1; i >= 1; i--) k::flat_segs_add_csr(s2, *U[(size_t)i], fd_stack + off[(size_t)i - 1], S->lev[(size_t)i - 1].alt);
+            for (int i = 0; i < m; i++) k::flat_sum_add(s3, *Vc[(size_t)i], i + 1 < m ? S->lev[(size_t)i].alt : S->lev[(size_t)D].sol);
+            k::flat_sum_finish(s3, h, sol);
+            fd_s1 = s1; fd_s2 = s2; fd_s3 = s3;
+            for (auto &v : {U, V, Gc, Vc})
+                for (auto &q : v) fd_ops.push_back(q);
+            ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+            if (getenv("ELAG_HIP_FLAT_VERBOSE"))
+                fprintf(stderr, "[elag_hip] distributed flattened cycle: level 0 (%d rows + %d ghosts) over %d replicated levels in three launches (%u + %u + %u workgroups)\n", n, ng,
+                        m, s1.grid, s2.grid, s3.grid);
+        } catch (const Error &e) {
+            failed = 1.0;
+            if (getenv("ELAG_HIP_FLAT_VERBOSE")) fprintf(stderr, "[elag_hip] distributed flattened cycle not built: %s\n", e.what());
+        }
+        if (dist_pieces && comm_active()) comm_allreduce_scalar(&failed, 1);
+        if (failed != 0.0) { fd_ops.clear(); dev_free(fd_stack); dev_free(fd_fext); fd_stack_n = 0; return; }
+        fd_active = true;
+    }
+
     void plan_fused()
     {
         // (read at every Finalize: tests switch them)
@@ -770,7 +948,7 @@ struct elag_hip_hierarchy_s {
             if (!all_local) {
                 // ---- l1-Jacobi level of a hierarchy that lives on several ranks ----
                 const char *nf = getenv("ELAG_HIP_NO_DIST_LEVEL_FUSION");          // (read at every Finalize: a test switches it)
-                if ((nf && atoi(nf)) || !comm_active()) continue;
+                if (nf && atoi(nf)) continue;                 // (one rank through this layout -- bench.py --force-dist -- takes the same branch: the products below need no peer)
                 // the products below are collective: every rank enters them or none does (a rank's own smoother may differ), and a rank that
                 // fails inside (memory, a row beyond the SpGEMM's limits) must not leave the others waiting in the next collective
                 if (dist_pieces) {
@@ -894,6 +1072,7 @@ struct elag_hip_hierarchy_s {
             k::flat_sum_launch(flat_s3, rhs, sol);
             return;
         }
+        if (l == 0 && fd_active) { iterate_flat_dist(rhs, sol); return; }
         if (l == resident_top) { k::resident_launch(res_seq, rhs, sol); return; }
         if (l == dense_level) { k::dense_gemv(F.A->nrows(), F.A->nrows(), Bdense, rhs, sol); return; }
         if (l == nl - 1) {
@@ -1026,6 +1205,35 @@ struct elag_hip_hierarchy_s {
         // post-smoothing (:244-249)
         if (F.post) F.post->apply(rhs, cur, oth, false, false);
         if (cur != sol) fail(ELAG_HIP_ERR_STATE, "internal: ping-pong parity mismatch on level %d", l);
+    }
+
+    void iterate_flat_dist(const double *rhs, double *sol)
+    {
+        Context &c = ctx();
+        ParCSR &A = *lev[0].A;
+        const double *x1 = rhs;
+        if (A.needs_exchange()) {
+            // f on [own | ghost] entries: the pack kernel also copies the own part, the exchange delivers the ghosts behind it
+            const int n = A.nrows(), st = A.send_total();
+            k::vec_pack_copy(n, st, A.d_send_elmts, rhs, A.d_send_buf, fd_fext);
+            ELAG_HIP_CHECK(hipEventRecord(c.ev_pack, c.stream));
+            ELAG_HIP_CHECK(hipStreamWaitEvent(c.comm_stream, c.ev_pack, 0));
+            comm_neighbor_exchange(A.d_send_buf, (int)A.send_procs.size(), A.send_procs.data(), A.send_starts.data(), fd_fext + n,
+                                   (int)A.recv_procs.size(), A.recv_procs.data(), A.recv_starts.data(), sizeof(double), c.comm_stream);
+            ELAG_HIP_CHECK(hipEventRecord(c.ev_halo, c.comm_stream));
+            ELAG_HIP_CHECK(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
+            x1 = fd_fext;
+        }
+        k::flat_segs_launch(fd_s1, x1, sol);
+        if (comm_active()) {
+            ELAG_HIP_CHECK(hipEventRecord(c.ev_pack, c.stream));
+            ELAG_HIP_CHECK(hipStreamWaitEvent(c.comm_stream, c.ev_pack, 0));
+            comm_allreduce_device(fd_stack, fd_stack_n, 0, c.comm_stream);
+            ELAG_HIP_CHECK(hipEventRecord(c.ev_halo, c.comm_stream));
+            ELAG_HIP_CHECK(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
+        }
+        k::flat_segs_launch(fd_s2, x1, sol);
+        k::flat_sum_launch(fd_s3, x1, sol);
     }
 
     void run(const double *rhs, double *sol, bool precond)
@@ -1279,6 +1487,7 @@ int elag_hip_coarse_create_from_hierarchy(elag_hip_coarse_t *out, elag_hip_hiera
         const int n = C->n;
         double *buf = dev_alloc<double>((size_t)n);   // owned through full_rhs
         C->full_rhs = buf;
+        C->sub = sub; C->sub_allreduce = allreduce_rhs;
         C->custom_apply = [sub, buf, n, allreduce_rhs](const double *rhs, double *sol) {
             Context &c = ctx();
             const double *src = rhs;

@@ -131,6 +131,7 @@ void vec_add_scaled_mul(int n, const double *y, const double *d, const double *z
 void vec_fill(int n, double v, double *x);
 void vec_dot(int n, const double *x, const double *y, double *d_result);  // deterministic 2-stage
 void vec_gather(int n, const int *idx, const double *x, double *buf, hipStream_t st = nullptr);
+void vec_pack_copy(int n, int nsend, const int *idx, const double *x, double *send_buf, double *copy);   // send_buf = x[idx] (nsend entries) and copy = x (n entries) in one launch
 void vec_gather_scale(int n, const int *idx, const double *x, const double *d, double *buf, double *scaled);  // buf = x[idx], scaled = d .* buf
 void vec_scatter(int n, const int *idx, const double *src, double *dst, int add);  // dst[idx[i]] (+)= src[i], idx a permutation
 void vec_hypre_random(int n, int seed, double *out);  // Lehmer 16807 stream, 2 r - 1 (host generated)

@@ -1519,6 +1519,21 @@ void vec_gather(int n, const int *idx, const double *x, double *buf, hipStream_t
     hipLaunchKernelGGL(gather_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, st ? st : ctx().stream, n, idx, x, buf);
     ELAG_LAUNCH_CHECK();
 }
+namespace {
+__global__ void pack_copy_kernel(int n, int nsend, const int *__restrict__ idx, const double *__restrict__ x, double *__restrict__ send_buf, double *__restrict__ copy)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + nsend; i += gridDim.x * blockDim.x) {
+        if (i < nsend) send_buf[i] = x[idx[i]];
+        else copy[i - nsend] = x[i - nsend];
+    }
+}
+}  // namespace
+void vec_pack_copy(int n, int nsend, const int *idx, const double *x, double *send_buf, double *copy)
+{
+    if (n + nsend == 0) return;
+    hipLaunchKernelGGL(pack_copy_kernel, dim3(vec_grid(n + nsend)), dim3(kBlock), 0, ctx().stream, n, nsend, idx, x, send_buf, copy);
+    ELAG_LAUNCH_CHECK();
+}
 void vec_gather_scale(int n, const int *idx, const double *x, const double *d, double *buf, double *scaled)
 {
     if (n == 0) return;

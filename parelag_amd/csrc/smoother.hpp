@@ -144,6 +144,8 @@ struct elag_hip_coarse_s {
     double *full_rhs = nullptr;
     // sub-hierarchy mode (elag_hip_coarse_create_from_hierarchy): apply() = [all-reduce rhs] + replicated cycle
     std::function<void(const double *, double *)> custom_apply;
+    elag_hip_hierarchy_s *sub = nullptr;          // ... that hierarchy (the owning hierarchy's distributed flattened cycle reads its level maps)
+    int sub_allreduce = 0;
     ~elag_hip_coarse_s() { elag::dev_free(Minv); elag::dev_free(full_rhs); }
     void setup();
     void apply(const double *rhs, double *sol);

@@ -258,6 +258,57 @@ def test_distributed_l1_jacobi_level_costs_one_halo_exchange(problem, world, rep
         assert (ef, af) == rounds and el > ef, ((ef, af), (el, al))
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_distributed_flattened_cycle_is_the_level_by_level_cycle(problem, world):
+    """bench.py's multi-rank layout (fine level row-partitioned, the rest replicated behind one all-reduce) runs as pack + ONE exchange ->
+    stage 1 -> ONE all-reduce of the stacked coarse right-hand sides -> stage 2 -> stage 3 (hierarchy.hip, plan_flat_dist): four launches where
+    the level-by-level cycle has eight, the same two communication rounds, the same linear map (ELAG_HIP_FLAT_DIST=0 keeps the levels), and the
+    serial oracle's cycle."""
+    import ctypes as C
+    import os
+    from parelag_amd import _lib, distributed, linalg as la
+    A, Ps, seq = problem
+    b_nat = np.random.default_rng(6).uniform(-1, 1, A.shape[0])
+
+    def body(dist):
+        lib = _lib.init()
+        out = {}
+        for name, env in (("flat", {}), ("levels", {"ELAG_HIP_FLAT_DIST": "0"})):
+            dist.barrier()
+            if dist.rank == 0:
+                os.environ.pop("ELAG_HIP_FLAT_DIST", None)
+                os.environ.update(env)
+            dist.barrier()
+            H, n_local, _shapes, _ = distributed.build_hierarchy(dist, A, Ps, seq, "L1 Jacobi", replicate_from=1)
+            info = H._dist_info["levels"][0]
+            lo, hi = int(info["starts"][dist.rank]), int(info["starts"][dist.rank + 1])
+            rhs = la.DeviceVector.from_numpy(b_nat[info["order"]][lo:hi])
+            sol = la.DeviceVector(n_local, 7.0)
+            H.Mult(rhs, sol)
+            la.synchronize()
+            e0, a0, e1, a1 = C.c_longlong(), C.c_longlong(), C.c_longlong(), C.c_longlong()
+            _lib.check(lib.elag_hip_comm_rounds(C.byref(e0), C.byref(a0)))
+            H.Mult(rhs, sol)
+            la.synchronize()
+            _lib.check(lib.elag_hip_comm_rounds(C.byref(e1), C.byref(a1)))
+            out[name] = (sol.to_numpy(), e1.value - e0.value, a1.value - a0.value, info["order"], (lo, hi))
+            del H, rhs, sol
+        dist.barrier()
+        if dist.rank == 0:
+            os.environ.pop("ELAG_HIP_FLAT_DIST", None)
+        return out
+    res = run_ranks(world, body)
+    h = oracle_h1_hierarchy(A, Ps, smoother=1)
+    xs = np.empty_like(b_nat)
+    orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"]).apply(b_nat, xs)
+    for out in res:
+        xf, ef, af, order, (lo, hi) = out["flat"]
+        xl, el, al, _o, _r = out["levels"]
+        assert np.max(np.abs(xf - xl)) <= 1e-13 * np.max(np.abs(xl))
+        assert (ef, af) == (1, 1) and (el, al) == (1, 1), ((ef, af), (el, al))
+        assert np.max(np.abs(xf - xs[order][lo:hi])) <= 1e-11 * np.max(np.abs(xs))
+
+
 def _local_global_csr(M, shape):
     """device ParCSR (this rank's rows) -> scipy CSR with global column ids"""
     out = M.to_scipy()
