@@ -122,6 +122,8 @@ void longest_row(int nrows, const int *I, int *d_out);      // *d_out = max_r I[
 // builds the 4-byte-per-entry sign form of a matrix whose stored values are all -1, 0 or +1 (returns false and leaves the
 // matrix alone otherwise); synchronous, setup time.  The caller vouches that the values stay as they are.
 bool prepare_sign_form(const DevCSR &A);
+// x_out = x_in + D (wa .* (D^T pv)) in one launch for a sign-form D and its sign-form transpose DT (false: a form is missing, nothing launched)
+bool sign_twohop(const DevCSR &D, const DevCSR &DT, const double *wa, const double *pv, const double *xin, double *xout);
 
 // ---- vector kernels ----------------------------------------------------------------------------
 void vec_axpby(int n, double a, const double *x, double b, const double *y, double *out);  // out = a x + b y

@@ -199,6 +199,48 @@ void launch_sign(const DevCSR &A, const SpmvArgs &p, hipStream_t st)
     ELAG_LAUNCH_CHECK();
 }
 
+// x_out = x_in + D (wa .* (D^T pv)) for a sign-form D and its stored transpose, in ONE launch and without the intermediate vector: the
+// auxiliary-space correction of a Hiptmair sweep whose auxiliary smoother is one diagonal sweep from the zero guess (HiptmairSmoother.cpp:61-75:
+// cB = D^T defect; relax; X += D correction).  A group of LPR lanes per row of D; a lane walks the transposed row of its entry four words
+// at a time.  (Two launches -- D^T with the scaling in its epilogue, then D -- were 2 x 5.8 us of the 130 us H(div) cycle at cube456 x3,
+// four times per cycle.)
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void sign_twohop_kernel(int nrows, const int *__restrict__ DI, const int *__restrict__ DJs, const int *__restrict__ TI,
+                                                            const int *__restrict__ TJs, const double *__restrict__ wa, const double *__restrict__ pv,
+                                                            const double *__restrict__ xin, double *__restrict__ xout)
+{
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int row = gid / LPR;
+    const int lane = threadIdx.x & (LPR - 1);
+    if (row >= nrows) return;
+    const int s = DI[row], e = DI[row + 1];
+    double x0 = 0.0;
+    if (lane == 0) x0 = xin[row];
+    double sum = 0.0;
+    for (int k = s + lane; k < e; k += LPR) {
+        const int w = DJs[k];
+        if (w & 0x40000000) continue;                       // a stored zero (eliminated essential column)
+        const int j = w & 0x3fffffff;
+        const int ts = TI[j], te = TI[j + 1];
+        const double wj = wa[j];
+        double t = 0.0;
+        for (int q0 = ts; q0 < te; q0 += 4) {
+            int u[4];
+            double v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) u[q] = (q0 + q < te) ? TJs[q0 + q] : 0x40000000;
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = (u[q] & 0x40000000) ? 0.0 : pv[u[q] & 0x3fffffff];
+#pragma unroll
+            for (int q = 0; q < 4; q++) t += (u[q] < 0) ? -v[q] : v[q];
+        }
+        t *= wj;
+        sum += (w < 0) ? -t : t;
+    }
+    sum = group_reduce<LPR>(sum);
+    if (lane == 0) xout[row] = x0 + sum;
+}
+
 __global__ void sign_pack_kernel(long long nnz, const int *__restrict__ J, const double *__restrict__ a, int *__restrict__ Js, int *__restrict__ bad)
 {
     for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x) {
@@ -858,6 +900,22 @@ bool prepare_sign_form(const DevCSR &A)
     if (nbad) { dev_free(Js); return false; }
     A.Js = Js;
     A.sign_state = 1;
+    return true;
+}
+
+bool sign_twohop(const DevCSR &D, const DevCSR &DT, const double *wa, const double *pv, const double *xin, double *xout)
+{
+    // OFF unless ELAG_HIP_TWOHOP=1: measured on the cube456 x3 H(div) hierarchy the one launch is SLOWER than the two it replaces (cycle 0.146 against
+    // 0.128 ms, 18 against 20 launches): five dependent round trips per row (row bounds, D's words, the transposed rows' bounds, their words, pv)
+    // where each of the two launches has three, and the transposed rows are walked by one lane each.  Kept for A/B runs.
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("ELAG_HIP_TWOHOP"); on = (e && atoi(e)) ? 1 : 0; }
+    if (!on || D.sign_state != 1 || DT.sign_state != 1 || !D.Js || !DT.Js || DT.nrows != D.ncols || DT.ncols != D.nrows) return false;
+    if (D.nrows == 0) return true;
+    const unsigned grid = (unsigned)(((long long)D.nrows * 4 + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((sign_twohop_kernel<4>), dim3(grid), dim3(kBlock), 0, ctx().stream, D.nrows, (const int *)D.I, (const int *)D.Js, (const int *)DT.I, (const int *)DT.Js, wa, pv,
+                       xin, xout);
+    ELAG_LAUNCH_CHECK();
     return true;
 }
 

@@ -352,6 +352,7 @@ void HiptmairSmoother::aux_correct(const double *resid, double *x)
     // cB = D^T defect ; relax on A_aux (iterative_mode == false) ; X += D * correction   (HiptmairSmoother.cpp:61-75)
     double *cx = auxx, *ca = auxalt;
     const double *aux_w = (aux->A && aux->n() == D->ncols()) ? aux->diag_scaling() : nullptr;
+    if (aux_w && !D->needs_exchange() && D->diagT && k::sign_twohop(D->diag, *D->diagT, aux_w, resid, x, x)) return;      // D^T, the scaling and D in one launch
     if (aux_w && !D->needs_exchange()) {
         // one diagonal sweep from the zero guess is a row scaling: folded into the epilogue of the D^T product
         par_spmvT(*D, 1.0, resid, 0.0, cx, aux_w);
