@@ -437,7 +437,7 @@ def large_workload(args, dist, world, kL, la, meshgen, distributed, np, barrier)
              "steps": nstep, "ms_per_step": round(tL / nstep * 1e3, 4),
              "vcycles_per_s": round(nstep / tL, 2), "vcycle_algorithmic_bytes": vbL,
              "aggregate_GBs": round(vbL / (tL / nstep) / 1e9, 1), "frac_of_aggregate_hbm_peak": round(vbL / (tL / nstep) / 1e9 / (HBM_PEAK_GBS * world), 4),
-             "setup_s": round(setupL, 2), "generate_s": round(genL, 1)}
+             "setup_s": round(setupL, 3), "generate_s": round(genL, 1)}
     # properties that need no global operator: (u, A v) = (v, A u) on the distributed operator, and PCG + V-cycle to a known solution
     rng = np.random.default_rng(100 + dist.rank)
     A0 = HL.GetOperator(0)
@@ -1345,6 +1345,7 @@ def main():
                 "vcycle_algorithmic_bytes": vbytes,
                 "vcycle_achieved_GBs": round(vbytes / (ms_dev * 1e-3) / 1e9, 1),
                 "setup_s": round(setup_s, 4),
+                "partition_s": (round(H._partition_s, 4) if getattr(H, "_partition_s", None) is not None else None),
                 "setup_breakdown_ms": setup_breakdown,
                 "fine_level_spmv": fine,
                 "roofline": roof,

@@ -165,14 +165,28 @@ def build_hierarchy(dist: Dist, A, Ps, seq, smoother="L1 Jacobi", params=None, r
     R = max(1, min(int(replicate_from), nl - 1))
     # host side: numbering and per-rank pieces of the fine operator and of the interpolators of the distributed head only;
     # every Galerkin product is formed on the device
-    d = partition.distributed_h1_hierarchy(A, Ps, seq, dist.world, galerkin=False, split_levels=R)
-    s = d["levels"][R - 1]["starts"]
-    Ploc = sp.csr_matrix(d["P_global"][R - 1])[int(s[dist.rank]):int(s[dist.rank + 1])].tocsr()
+    # (the numbering and the operators in it: what a ParElag rank is handed by its mesh partition.  No per-rank pieces are cut on the host --
+    # split_levels = 0 -- : this rank's rows go to the device with global columns and the library makes the ParCSR pieces)
+    d = partition.distributed_h1_hierarchy(A, Ps, seq, dist.world, galerkin=False, split_levels=0)
+    r = dist.rank
+    st = [d["levels"][l]["starts"] for l in range(nl)]
+    rows = lambda M, l: sp.csr_matrix(M)[int(st[l][r]):int(st[l][r + 1])].tocsr()
+    A_rows = rows(d["A_global"][0], 0)
+    P_rows = [rows(d["P_global"][l - 1], l - 1) for l in range(1, R + 1)]
+    Ploc = rows(d["P_global"][R - 1], R - 1)
+    partition_s = time.time() - t0
+    t1 = time.time()
+
+    def piece(M, rs, cs):
+        return la.ParallelCSRMatrix.from_global_rows(M, int(rs[r]), int(rs[-1]), int(cs[r]), int(cs[r + 1] - cs[r]), int(cs[-1]))
+    A_part = piece(A_rows, st[0], st[0])
+    P_parts = [piece(P_rows[l - 1], st[l - 1], st[l]) for l in range(1, R + 1)]
     H, n_local, shapes = _build_from_pieces(
-        dist, d["levels"][0]["A_parts"][dist.rank], [d["levels"][l]["P_parts"][dist.rank] for l in range(1, R + 1)], Ploc, d["P_global"][R:],
-        [int(d["levels"][l]["starts"][-1]) for l in range(R)], [(P.shape[1], P.nnz) for P in d["P_global"]], smoother, params, R, nl)
+        dist, A_part, P_parts, Ploc, d["P_global"][R:],
+        [int(st[l][-1]) for l in range(R)], [(P.shape[1], P.nnz) for P in d["P_global"]], smoother, params, R, nl)
     H._dist_info = d
-    return H, n_local, shapes, time.time() - t0
+    H._partition_s = partition_s                       # host: block numbering of every level, the operators permuted into it (the generator's side)
+    return H, n_local, shapes, time.time() - t1
 
 
 def build_hierarchy_sharded(dist: Dist, comm, shards, smoother="L1 Jacobi", params=None, replicate_from=1):

@@ -131,7 +131,7 @@ def distributed_h1_hierarchy(A, Ps, seq, nparts: int, galerkin: bool = True, spl
     level l -> l-1."""
     eparts = element_partitions(seq, nparts)
     nl = len(Ps) + 1
-    ns = nl if split_levels is None else max(1, min(int(split_levels), nl))
+    ns = nl if split_levels is None else max(0, min(int(split_levels), nl))          # (0: numbering and permuted operators only, no per-rank pieces)
     orders, news, starts = [], [], []
     for l in range(nl):
         own = vertex_owners(seq.meshes[l], eparts[l])
