@@ -240,7 +240,7 @@ size_t pool_cap()
 }
 bool pool_active() { return pool_cap() > 0 && !comm_active() && ctx().initialised; }
 
-// The pool's slab: one allocation made by elag_hip_init (ELAG_HIP_POOL_SLAB_MB, default 1024, at most a sixteenth of the free memory; 0 = none) from
+// The pool's slab: one allocation made by elag_hip_init (ELAG_HIP_POOL_SLAB_MB, default 0 = none; at most a sixteenth of the free memory) from
 // which the library's persistent blocks are carved by a bump pointer until it is full -- the level operators, SpMV forms and vectors of the
 // FIRST hierarchy of a process then cost no hipMalloc either (the x-cache tables of the cube456 x5 operators alone were 7 of the 23 ms of a
 // first build, against 14 ms for every later one).  A carved block that is freed always goes to the calling thread's cache (it cannot go back
@@ -488,7 +488,7 @@ int elag_hip_init(int device)
             }
             // ... and the pool's slab (see PoolSlab)
             const char *es = getenv("ELAG_HIP_POOL_SLAB_MB");
-            size_t slab = (size_t)(es ? std::max(0ll, atoll(es)) : 1024) << 20;
+            size_t slab = (size_t)(es ? std::max(0ll, atoll(es)) : 0) << 20;          // (off by default: reserving 1 GiB costs elag_hip_init ~0.2 s on this stack and saves a first build 0.4 ms)
             if (slab && hipMemGetInfo(&free_b, &total_b) == hipSuccess) slab = std::min(slab, free_b / 16);
             if (slab >= (size_t(64) << 20) && pool_cap() > 0 && !t_slab.base) {
                 void *p = nullptr;
