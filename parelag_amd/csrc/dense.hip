@@ -59,6 +59,52 @@ __global__ void __launch_bounds__(1024) gj_pivot_kernel(int n, int k, const doub
     }
 }
 
+// pivot search, row swap + scaling and the saved column in ONE single-workgroup launch (three launches before: 1 471 columns of the Darcy
+// hierarchy's coarsest saddle-point operator were 5 900 launches, 27 of the 34 ms of that hierarchy's setup); the elimination keeps the grid
+__global__ void __launch_bounds__(1024) gj_column_kernel(int n, int k, double *__restrict__ M, int ld, double *__restrict__ colk, int *__restrict__ singular)
+{
+    __shared__ double sv[1024];
+    __shared__ int si[1024];
+    __shared__ int s_p;
+    __shared__ double s_pv;
+    double best = -1.0;
+    int bi = n;
+    for (int i = k + (int)threadIdx.x; i < n; i += 1024) {
+        const double v = fabs(M[(size_t)i * ld + k]);
+        if (v > best) { best = v; bi = i; }
+    }
+    sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            const double ov = sv[threadIdx.x + s];
+            const int oi = si[threadIdx.x + s];
+            if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int p = si[0] < n ? si[0] : k;
+        s_p = p;
+        s_pv = M[(size_t)p * ld + k];
+    }
+    __syncthreads();
+    const int p = s_p;
+    const double pv = s_pv;
+    if (pv == 0.0 || pv != pv) {
+        if (threadIdx.x == 0) atomicAdd(singular, 1);
+        for (int i = threadIdx.x; i < n; i += 1024) colk[i] = 0.0;          // (the elimination that follows is a no-op)
+        return;
+    }
+    for (int c = threadIdx.x; c < ld; c += 1024) {
+        const double tk = M[(size_t)k * ld + c], tp = M[(size_t)p * ld + c];
+        if (p != k) M[(size_t)p * ld + c] = tk;
+        M[(size_t)k * ld + c] = tp / pv;
+    }
+    __syncthreads();                                                           // (the workgroup's own global writes are visible to it after the barrier)
+    for (int i = threadIdx.x; i < n; i += 1024) colk[i] = (i == k) ? 0.0 : M[(size_t)i * ld + k];
+}
+
 __global__ void gj_swap_scale_kernel(int k, double *__restrict__ M, int ld, const int *__restrict__ piv, const double *__restrict__ pivval,
                                      int *__restrict__ singular)
 {
@@ -120,10 +166,16 @@ void dense_inverse_general(const DevCSR &A, double *Minv)
         hipLaunchKernelGGL(dense_scatter_kernel, dim3((n + kB - 1) / kB), dim3(kB), 0, st, n, (const int *)A.I, (const int *)A.J,
                            (const double *)A.a, M, ld);
         const dim3 gcol((ld + kB - 1) / kB), grow((n + kB - 1) / kB), gel((ld + kB - 1) / kB, (n + 7) / 8);
+        const char *e_fuse = getenv("ELAG_HIP_LU_FUSED_COLUMN");          // (0 = the four launches per column: A/B runs and a test)
+        const bool fuse = !(e_fuse && !atoi(e_fuse));
         for (int k = 0; k < n; k++) {
-            hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(1024), 0, st, n, k, (const double *)M, ld, piv.p, pivval.p);
-            hipLaunchKernelGGL(gj_swap_scale_kernel, gcol, dim3(kB), 0, st, k, M, ld, (const int *)piv.p, (const double *)pivval.p, singular.p);
-            hipLaunchKernelGGL(gj_savecol_kernel, grow, dim3(kB), 0, st, n, k, (const double *)M, ld, colk.p);
+            if (fuse) {
+                hipLaunchKernelGGL(gj_column_kernel, dim3(1), dim3(1024), 0, st, n, k, M, ld, colk.p, singular.p);
+            } else {
+                hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(1024), 0, st, n, k, (const double *)M, ld, piv.p, pivval.p);
+                hipLaunchKernelGGL(gj_swap_scale_kernel, gcol, dim3(kB), 0, st, k, M, ld, (const int *)piv.p, (const double *)pivval.p, singular.p);
+                hipLaunchKernelGGL(gj_savecol_kernel, grow, dim3(kB), 0, st, n, k, (const double *)M, ld, colk.p);
+            }
             hipLaunchKernelGGL(gj_eliminate_kernel, gel, dim3(kB), 0, st, n, k, M, ld, (const double *)colk.p);
         }
         hipLaunchKernelGGL(gj_extract_kernel, dim3((n + kB - 1) / kB, n), dim3(kB), 0, st, n, (const double *)M, ld, Minv);

@@ -193,12 +193,6 @@ ParCSR *parcsr_from_diag(DevCSR &&d, int64_t first_row, int64_t first_col, int64
 }  // namespace elag
 
 
-static void require_single_rank(const ParCSR *A, const char *what)
-{
-    // rank-local operands only (a matrix replicated on every rank of a multi-GPU run qualifies)
-    if (A->needs_exchange() || A->global_rows != A->nrows())
-        fail(ELAG_HIP_ERR_ARG, "%s: distributed (offd) operands are not supported by this entry point yet", what);
-}
 
 extern "C" {
 

@@ -1128,3 +1128,27 @@ def test_blocked_spd_inverse_is_the_pivot_by_pivot_one(la, n):
     for x in xs:
         assert np.max(np.abs(x - ref)) <= 1e-10 * np.max(np.abs(ref))
     assert np.max(np.abs(xs[0] - xs[1])) <= 1e-11 * np.max(np.abs(ref))
+
+
+def test_memory_pool_and_trim(la, h1_k2):
+    """Freed device blocks are pooled between calls (single-rank processes) and elag_hip_trim_memory gives the pool and the idle scratch slabs
+    back to the driver; the library keeps working across a trim (the next product allocates afresh) and its results do not change."""
+    from parelag_amd import _lib
+    A, Ps, _ = h1_k2
+    dA, dP = la.ParallelCSRMatrix.from_scipy(A), la.ParallelCSRMatrix.from_scipy(Ps[0])
+    C1 = la.RAP(dA, dP).to_scipy()
+    tmp = la.RAP(dA, dP)
+    del tmp                                             # its blocks go to the pool
+    la.synchronize()
+    released = _lib.trim_memory()
+    assert released > 0
+    assert _lib.trim_memory() >= 0                      # (idempotent: nothing left, or only what the calls in between freed)
+    C2 = la.RAP(dA, dP).to_scipy()
+    assert np.array_equal(C1.indptr, C2.indptr) and np.array_equal(C1.indices, C2.indices) and np.array_equal(C1.data, C2.data)
+    H = la.buildHierarchyFromDeRhamSequence(dA, [la.ParallelCSRMatrix.from_scipy(P) for P in Ps], "L1 Jacobi")
+    b = np.full(A.shape[0], 2.0)
+    x1, x2 = np.zeros_like(b), np.zeros_like(b)
+    H.Mult(b, x1)
+    _lib.trim_memory()
+    H.Mult(b, x2)
+    assert np.array_equal(x1, x2)
