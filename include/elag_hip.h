@@ -55,8 +55,8 @@ enum {
 /* hypre relax types accepted by elag_hip_smoother_create -- the string->type table of
  * src/linalg/factories/ParELAG_HypreSmootherFactory.cpp:92-109.  The Gauss-Seidel types (2 = the reference's shipped default
  * "L1 Gauss-Seidel", 4 = "L1 Gauss-Seidel Truncated", 6 = "Gauss-Seidel") run as level-scheduled forward + backward sweeps with
- * the sequential loop's results ("Damping Factor" = 1.0; "Omega" free for 2 / 4 and 1.0 for 6: hypre's SSOR branches are not
- * built); 5 = "Lumped Jacobi" (mfem::HypreSmoother: l1 = A 1, then type 1); 413 = "Hypre Jacobi" (mfem::HypreDiagScale,
+ * the sequential loop's results; "Damping Factor" != 1 (2 / 4: hypre_ParCSRRelax's scaled SSOR) and, for 6, "Omega" != 1
+ * (hypre_BoomerAMGRelax's weighted branch) take hypre's own branches, one launch per dependency level; 5 = "Lumped Jacobi" (mfem::HypreSmoother: l1 = A 1, then type 1); 413 = "Hypre Jacobi" (mfem::HypreDiagScale,
  * ParELAG_HypreSmootherFactory.cpp:28-31); 3 = "Kaczmarz" (hypre_ParCSRRelax with the rows' squared 2-norms: level-scheduled on the
  * rows' shared columns, the sequential loop's results; "Omega" free); 1001 = "Taubin" and 1002 = "FIR" (the polynomial smoothers of
  * mfem::HypreSmoother with mfem's default options -- lambda 0.5, mu -0.5, 40 steps; Blackman window -- which the reference's factory

@@ -264,6 +264,67 @@ ORC_API void orc_gs_sweep(int n, const int *dI, const int *dJ, const double *da,
     }
 }
 
+/* hypre_ParCSRRelax relax_type 2/4, relax_weight != 1: the "scaled SSOR" branch [3P parcsr_ls/ams.c] (c1 = omega w,
+ * c2 = omega (1 - w) and the saved pre-sweep vector; the reference forwards "Damping Factor" / "Omega" unconditionally,
+ * src/linalg/solver_ops/ParELAG_HypreSmootherWrapper.cpp:28-33).  v receives the vector the forward pass started from (hypre saves
+ * v_i = u_i when row i's turn comes, i.e. before that row is written), and BOTH passes read it:
+ *   forward   dif = sum_{j < i} a_ij (v_j - u_j)      backward   dif = sum_{j > i} a_ij (v_j - u_j)
+ *   u_i += (c1 res + c2 dif) / l1_i,   res = f_i - sum_diag a_ij u_j - sum_offd a_ij ughost_j   (ghost values frozen for the sweep) */
+ORC_API void orc_l1gs_sweep_scaled(int n, const int *dI, const int *dJ, const double *da,
+                                   const int *oI, const int *oJ, const double *oa,
+                                   const double *f, const double *l1, const double *uext, double weight, double omega, double *u, double *v)
+{
+    const double c1 = omega * weight, c2 = omega * (1.0 - weight);
+    int i, jj;
+    for (i = 0; i < n; i++) {
+        double dif = 0.0, res = f[i];
+        v[i] = u[i];
+        if (l1[i] == 0.0) continue;
+        for (jj = dI[i]; jj < dI[i + 1]; jj++) {
+            res -= da[jj] * u[dJ[jj]];
+            if (dJ[jj] < i) dif += da[jj] * (v[dJ[jj]] - u[dJ[jj]]);
+        }
+        if (oI) for (jj = oI[i]; jj < oI[i + 1]; jj++) res -= oa[jj] * uext[oJ[jj]];
+        u[i] += (c1 * res + c2 * dif) / l1[i];
+    }
+    for (i = n - 1; i > -1; i--) {
+        double dif = 0.0, res = f[i];
+        if (l1[i] == 0.0) continue;
+        for (jj = dI[i]; jj < dI[i + 1]; jj++) {
+            res -= da[jj] * u[dJ[jj]];
+            if (dJ[jj] > i) dif += da[jj] * (v[dJ[jj]] - u[dJ[jj]]);
+        }
+        if (oI) for (jj = oI[i]; jj < oI[i + 1]; jj++) res -= oa[jj] * uext[oJ[jj]];
+        u[i] += (c1 * res + c2 * dif) / l1[i];
+    }
+}
+
+/* hypre_BoomerAMGRelax relax_type 6, relax_weight != 1 or omega != 1 [3P parcsr_ls/par_relax.c], relax_points = 0, one thread:
+ * Vtemp = u once before the forward pass, prod = 1 - w omega, then forward and backward over the local rows with a nonzero diagonal
+ *   res0 = - sum_{j != i} a_ij u_j,  res2 = + sum_{j != i} a_ij Vtemp_j,  res = f_i - sum_offd a_ij ughost_j
+ *   u_i = prod u_i + w (omega res + res0 + (1 - omega) res2) / a_ii          (a_ii = the first stored entry of the diag row) */
+ORC_API void orc_gs_sweep_sor(int n, const int *dI, const int *dJ, const double *da,
+                              const int *oI, const int *oJ, const double *oa,
+                              const double *f, const double *uext, double weight, double omega, double *u, double *vtemp)
+{
+    const double prod = 1.0 - weight * omega, one_minus_omega = 1.0 - omega;
+    int i, jj, pass;
+    for (i = 0; i < n; i++) vtemp[i] = u[i];
+    for (pass = 0; pass < 2; pass++)
+        for (i = pass ? n - 1 : 0; pass ? i > -1 : i < n; i += pass ? -1 : 1) {
+            if (dI[i + 1] > dI[i] && da[dI[i]] != 0.0) {
+                double res0 = 0.0, res2 = 0.0, res = f[i];
+                for (jj = dI[i] + 1; jj < dI[i + 1]; jj++) {
+                    res0 -= da[jj] * u[dJ[jj]];
+                    res2 += da[jj] * vtemp[dJ[jj]];
+                }
+                if (oI) for (jj = oI[i]; jj < oI[i + 1]; jj++) res -= oa[jj] * uext[oJ[jj]];
+                u[i] *= prod;
+                u[i] += weight * (omega * res + res0 + one_minus_omega * res2) / da[dI[i]];
+            }
+        }
+}
+
 /* HYPRE_ParCSRDiagScale(NULL, A, y, x) [3P parcsr_ls/HYPRE_parcsr_pcg.c]: x_i = y_i / a_ii (first stored entry), whatever x held --
  * mfem::HypreDiagScale, the solver behind "Hypre Jacobi" = 413 (ParELAG_HypreSmootherFactory.cpp:28-31). */
 ORC_API void orc_diag_scale(int n, const int *dI, const double *da, const double *y, double *x)

@@ -395,7 +395,8 @@ def compare(A: OParCSR, B: OParCSR, tol: float) -> int:
 
 class OSmoother:
     """mfem::HypreSmoother as driven by HypreSmootherWrapper (ParELAG_HypreSmootherWrapper.cpp:28-34):
-    types 1 (l1-Jacobi), 2 / 4 (l1-GS, l1 norms option 2 / 4, relax_weight = omega = 1), 6 (hybrid symmetric GS),
+    types 1 (l1-Jacobi), 2 / 4 (l1-GS, l1 norms option 2 / 4; hypre's three branches: relax_weight = omega = 1, relax_weight = 1 "SSOR",
+    relax_weight != 1 "scaled SSOR"), 6 (hybrid symmetric GS; (1, 1) and the weighted / over-relaxed branch),
     16 (Chebyshev) and 413 ("Hypre Jacobi" = mfem::HypreDiagScale, HypreSmootherFactory.cpp:28-31).  ``iterative_mode`` as in
     mfem::Solver.  Also 3 (Kaczmarz: hypre_ParCSRRelax with the rows' squared 2-norms), 5 (lumped Jacobi) and the two polynomial
     smoothers of mfem::HypreSmoother, 1001 (Taubin: ``taubin_iter`` steps u += c r / max_eig, c alternating lambda, mu) and 1002 (FIR:
@@ -409,8 +410,6 @@ class OSmoother:
         self.order, self.fraction = order, fraction
         self.iterative_mode = True
         n = A.shape[0]
-        if (type in (2, 4, 6) and weight != 1.0) or (type == 6 and omega != 1.0):
-            raise NotImplementedError("the SSOR branches of hypre's Gauss-Seidel relaxations (relax_weight != 1; omega != 1 for type 6) are not restated")
         if type in (1, 2, 3, 4):
             self.l1 = l1_norms(A.diag, A.offd, option=type)
         if type == 5:
@@ -451,9 +450,14 @@ class OSmoother:
             elif self.type == 6:
                 ue = A.ghost(u)
                 has = A.offd.shape[1] > 0
-                L.orc_gs_sweep(C.c_int(n), _ip(A.diag.indptr), _ip(A.diag.indices), _dp(A.diag.data),
-                               _ip(A.offd.indptr) if has else None, _ip(A.offd.indices) if has else None,
-                               _dp(A.offd.data) if has else None, _dp(f), _dp(ue), _dp(u))
+                args = (C.c_int(n), _ip(A.diag.indptr), _ip(A.diag.indices), _dp(A.diag.data),
+                        _ip(A.offd.indptr) if has else None, _ip(A.offd.indices) if has else None,
+                        _dp(A.offd.data) if has else None, _dp(f), _dp(ue))
+                if self.weight == 1.0 and self.omega == 1.0:
+                    L.orc_gs_sweep(*args, _dp(u))
+                else:
+                    vt = np.empty(n)
+                    L.orc_gs_sweep_sor(*args, C.c_double(self.weight), C.c_double(self.omega), _dp(u), _dp(vt))
             elif self.type == 3:
                 ue = A.ghost(u)
                 has = A.offd.shape[1] > 0
@@ -491,7 +495,10 @@ class OSmoother:
                 args = (C.c_int(n), _ip(A.diag.indptr), _ip(A.diag.indices), _dp(A.diag.data),
                         _ip(A.offd.indptr) if has else None, _ip(A.offd.indices) if has else None,
                         _dp(A.offd.data) if has else None, _dp(f), _dp(self.l1), _dp(ue))
-                if self.omega == 1.0:
+                if self.weight != 1.0:
+                    vt = np.empty(n)
+                    L.orc_l1gs_sweep_scaled(*args, C.c_double(self.weight), C.c_double(self.omega), _dp(u), _dp(vt))
+                elif self.omega == 1.0:
                     L.orc_l1gs_sweep(*args, _dp(u))
                 else:
                     L.orc_l1gs_sweep_omega(*args, C.c_double(self.omega), _dp(u))

@@ -149,6 +149,160 @@ __global__ void gj_extract_kernel(int n, const double *__restrict__ M, int ld, d
     if (c < n) out[(size_t)r * n + c] = M[(size_t)r * ld + n + c];
 }
 
+
+// ---- blocked form: B = 8 pivots per step, in place (n x n, no augmented half) -----------------------------------------------------------------
+// One step = two launches.  The panel kernel (one workgroup, the panel's rows k0.. in LDS) finds the B pivots by an unblocked elimination of the
+// panel's own columns, swaps those rows of M, and leaves what the update needs:  Dinv = (M_KK)^-1,  Rp = Dinv M_K: (the new pivot rows) and
+// Cc = M_:K (the column panel before the update overwrites it).  The update kernel then is one pass over M:
+//     rows of K:  Dinv (columns of K) | Rp          other rows:  -Cc Dinv (columns of K) | M - Cc Rp
+// -- Gauss-Jordan with the identity's columns stored where the eliminated ones were.  With P the row swaps, the result is (P A)^-1 = A^-1 P^T: the
+// columns are put back by one gather at the end (column j of the inverse = column colsrc[j], the swaps applied to 0..n-1 in reverse order).
+// 1 471 dofs: 2 x 184 launches and ~6 GB of traffic where the column-by-column form had 2 942 launches and 150 GB.
+constexpr int kGB = 8;
+__global__ void __launch_bounds__(1024) gj_block_panel_kernel(int n, int k0, double *__restrict__ M, int *__restrict__ piv_all, double *__restrict__ Dinv,
+                                                              double *__restrict__ Rp, double *__restrict__ Cc, int *__restrict__ singular)
+{
+    extern __shared__ double Pn[];                   // (n - k0) x kGB, row-major: the panel's columns of the rows from k0 on
+    __shared__ double sv[1024];
+    __shared__ int si[1024];
+    __shared__ int s_piv[kGB];
+    __shared__ double D[kGB][kGB + 1], ck[kGB], rk[kGB];
+    const int t = threadIdx.x, m = n - k0, nb = min(kGB, m);
+    for (int e = t; e < m * kGB; e += 1024) {
+        const int r = e / kGB, c = e % kGB;
+        Pn[e] = c < nb ? M[(size_t)(k0 + r) * n + k0 + c] : 0.0;
+    }
+    __syncthreads();
+    for (int q = 0; q < nb; q++) {
+        double best = -1.0;
+        int bi = m;
+        for (int r = q + t; r < m; r += 1024) {
+            const double v = fabs(Pn[r * kGB + q]);
+            if (v > best) { best = v; bi = r; }
+        }
+        sv[t] = best; si[t] = bi;
+        __syncthreads();
+        for (int s = 512; s > 0; s >>= 1) {
+            if (t < s) {
+                const double ov = sv[t + s];
+                const int oi = si[t + s];
+                if (ov > sv[t] || (ov == sv[t] && oi < si[t])) { sv[t] = ov; si[t] = oi; }
+            }
+            __syncthreads();
+        }
+        const int p = si[0] < m ? si[0] : q;                                  // argmax |column q| over the rows from q on, lowest index on ties
+        __syncthreads();                                                       // (si[0] read by everybody before the next search overwrites it)
+        if (t < kGB) {
+            const double a = Pn[q * kGB + t], b = Pn[p * kGB + t];
+            Pn[q * kGB + t] = b; Pn[p * kGB + t] = a;
+        }
+        if (t == 0) s_piv[q] = k0 + p;
+        __syncthreads();
+        const double pv = Pn[q * kGB + q];
+        if (pv == 0.0 || pv != pv) { if (t == 0) atomicAdd(singular, 1); continue; }     // (uniform: every thread reads the same pv)
+        for (int r = q + 1 + t; r < m; r += 1024) {
+            const double f = Pn[r * kGB + q] / pv;
+            for (int c = q + 1; c < nb; c++) Pn[r * kGB + c] -= f * Pn[q * kGB + c];
+        }
+        __syncthreads();
+    }
+    // the swaps on the rows of M, one column per thread (the swaps of a column in their order)
+    for (int c = t; c < n; c += 1024)
+        for (int q = 0; q < nb; q++) {
+            const int k = k0 + q, p = s_piv[q];
+            if (p != k) {
+                const double a = M[(size_t)k * n + c], b = M[(size_t)p * n + c];
+                M[(size_t)k * n + c] = b; M[(size_t)p * n + c] = a;
+            }
+        }
+    if (t < nb) piv_all[k0 + t] = s_piv[t];
+    __threadfence_block();
+    __syncthreads();                                                           // (the workgroup's own global writes are visible to it after the barrier)
+    // D = M_KK (padded with the identity), inverted without further pivoting: the swaps made its leading pivots the ones found above
+    const int r = t / kGB, c = t % kGB;
+    if (t < kGB * kGB) D[r][c] = (r < nb && c < nb) ? M[(size_t)(k0 + r) * n + k0 + c] : (r == c ? 1.0 : 0.0);
+    __syncthreads();
+    for (int k = 0; k < nb; k++) {
+        const double p = D[k][k];
+        if (t < kGB) {
+            ck[t] = (t == k) ? 0.0 : D[t][k];
+            rk[t] = (t == k) ? 1.0 / p : D[k][t] / p;
+        }
+        __syncthreads();
+        if (t < kGB * kGB) {
+            double v = D[r][c];
+            if (r == k) v = rk[c];
+            else if (c == k) v = -ck[r] * rk[c];                               // rk[k] = 1 / p
+            else v -= ck[r] * rk[c];
+            D[r][c] = v;
+        }
+        __syncthreads();
+    }
+    if (t < kGB * kGB) Dinv[t] = D[r][c];
+    for (int e = t; e < n * kGB; e += 1024) {
+        const int i = e / kGB, q = e % kGB;
+        Cc[e] = q < nb ? M[(size_t)i * n + k0 + q] : 0.0;
+    }
+    for (int j = t; j < n; j += 1024) {
+        double col[kGB];
+#pragma unroll
+        for (int q = 0; q < kGB; q++) col[q] = q < nb ? M[(size_t)(k0 + q) * n + j] : 0.0;
+#pragma unroll
+        for (int q = 0; q < kGB; q++) {
+            double sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < kGB; w++) sum += D[q][w] * col[w];
+            Rp[(size_t)q * n + j] = sum;
+        }
+    }
+}
+
+constexpr int kGRows = 16;                           // rows per workgroup of the update (a thread per column)
+__global__ void __launch_bounds__(256) gj_block_update_kernel(int n, int k0, double *__restrict__ M, const double *__restrict__ Dinv, const double *__restrict__ Rp,
+                                                              const double *__restrict__ Cc)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = blockIdx.y * kGRows;
+    if (j >= n) return;
+    const int nb = min(kGB, n - k0);
+    const bool jcol = j >= k0 && j < k0 + nb;
+    double rp[kGB];
+#pragma unroll
+    for (int q = 0; q < kGB; q++) rp[q] = q < nb ? (jcol ? Dinv[q * kGB + (j - k0)] : Rp[(size_t)q * n + j]) : 0.0;
+    for (int s = 0; s < kGRows; s++) {
+        const int i = i0 + s;
+        if (i >= n) break;
+        double *mp = M + (size_t)i * n + j;
+        if (i >= k0 && i < k0 + nb) { *mp = rp[i - k0]; continue; }           // rows of the pivot block: Dinv | Dinv M_K:
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < kGB; q++) acc += Cc[(size_t)i * kGB + q] * rp[q];
+        *mp = jcol ? -acc : *mp - acc;
+    }
+}
+
+// colsrc = the row swaps applied to 0 .. n-1 in reverse order (one workgroup, the list in LDS, one thread walks the swaps)
+__global__ void __launch_bounds__(1024) gj_colsrc_kernel(int n, const int *__restrict__ piv_all, int *__restrict__ colsrc)
+{
+    extern __shared__ int sh[];                      // idx[n] | piv[n]
+    int *idx = sh, *pv = sh + n;
+    for (int i = threadIdx.x; i < n; i += 1024) { idx[i] = i; pv[i] = piv_all[i]; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = n - 1; k >= 0; k--) {
+            const int p = pv[k];
+            if (p != k) { const int a = idx[k]; idx[k] = idx[p]; idx[p] = a; }
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) colsrc[i] = idx[i];
+}
+
+__global__ void gj_gather_cols_kernel(int n, const double *__restrict__ M, const int *__restrict__ colsrc, double *__restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c < n) out[(size_t)r * n + c] = M[(size_t)r * n + colsrc[c]];
+}
 }  // namespace
 
 void dense_inverse_general(const DevCSR &A, double *Minv)
@@ -157,6 +311,42 @@ void dense_inverse_general(const DevCSR &A, double *Minv)
     const int n = A.nrows, ld = 2 * n;
     ELAG_REQUIRE(n == A.ncols, "dense inverse needs a square matrix");
     if (n == 0) return;
+    const char *e_blk = getenv("ELAG_HIP_LU_BLOCKED");                    // (0 = the column-by-column form on [A | I]: A/B runs and a test)
+    const size_t panel_lds = sizeof(double) * (size_t)n * kGB;
+    if (!(e_blk && !atoi(e_blk)) && panel_lds <= (size_t)(144 << 10)) {
+        // blocked, in place: the panel of the first step (all n rows x 8 columns) must fit one workgroup's LDS
+        static thread_local bool raised = false;
+        if (!raised && panel_lds > (size_t)(32 << 10)) {
+            ELAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gj_block_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 << 10));
+            raised = true;
+        }
+        double *Mb = dev_alloc<double>((size_t)n * n);
+        try {
+            Temp<int> piv_all((size_t)n), colsrc((size_t)n), singular(1);
+            Temp<double> Dinv((size_t)kGB * kGB), Rp((size_t)kGB * n), Cc((size_t)n * kGB);
+            ELAG_HIP_CHECK(hipMemsetAsync(Mb, 0, sizeof(double) * (size_t)n * n, st));
+            ELAG_HIP_CHECK(hipMemsetAsync(singular.p, 0, sizeof(int), st));
+            hipLaunchKernelGGL(dense_scatter_plain_kernel, dim3((n + kB - 1) / kB), dim3(kB), 0, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, Mb);
+            const dim3 gu((n + 255) / 256, (n + kGRows - 1) / kGRows);
+            for (int k0 = 0; k0 < n; k0 += kGB) {
+                hipLaunchKernelGGL(gj_block_panel_kernel, dim3(1), dim3(1024), sizeof(double) * (size_t)(n - k0) * kGB, st, n, k0, Mb, piv_all.p, Dinv.p, Rp.p, Cc.p,
+                                   singular.p);
+                hipLaunchKernelGGL(gj_block_update_kernel, gu, dim3(256), 0, st, n, k0, Mb, (const double *)Dinv.p, (const double *)Rp.p, (const double *)Cc.p);
+            }
+            hipLaunchKernelGGL(gj_colsrc_kernel, dim3(1), dim3(1024), sizeof(int) * 2 * (size_t)n, st, n, (const int *)piv_all.p, colsrc.p);
+            hipLaunchKernelGGL(gj_gather_cols_kernel, dim3((n + kB - 1) / kB, n), dim3(kB), 0, st, n, (const double *)Mb, (const int *)colsrc.p, Minv);
+            ELAG_LAUNCH_CHECK();
+            int bad = 0;
+            ELAG_HIP_CHECK(hipMemcpyAsync(&bad, singular.p, sizeof(int), hipMemcpyDeviceToHost, st));
+            ELAG_HIP_CHECK(hipStreamSynchronize(st));
+            if (bad) fail(ELAG_HIP_ERR_NUMERIC, "coarse operator is singular (%d zero pivots in the dense LU)", bad);
+        } catch (...) {
+            dev_free(Mb);
+            throw;
+        }
+        dev_free(Mb);
+        return;
+    }
     double *M = dev_alloc<double>((size_t)n * ld);
     try {
         Temp<int> piv(1), singular(1);

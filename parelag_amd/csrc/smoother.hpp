@@ -82,6 +82,9 @@ struct SweepSmoother : elag_hip_smoother_s {
     int *d_blk_first = nullptr, *d_blk_count = nullptr;    // per block: its first step and its number of steps (a workgroup per block walks them)
     ParCSR *M = nullptr;
     void launch_segment(const Segment &s, int dir, const double *f, double *u, bool sym = false);
+    bool sor = false;                                 // hypre's weighted branches (relax_weight != 1; omega != 1 for type 6): a launch per dependency level
+    double *d_v = nullptr;                            // ... and the vector the forward pass started from
+    void sweep_sor(const double *f, double *u);
     void apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose) override;
     int flips(bool) const override { return 0; }
     int longest_chain = 0;                            // steps of the longest per-block chain (virtual ranks with a workgroup per block)
@@ -90,11 +93,11 @@ struct SweepSmoother : elag_hip_smoother_s {
     bool apply_dense(const double *F, double *X, int m, bool zero_guess);
     std::vector<int> h_lev_ptr;                       // rows by dependency level (whatever the launch plan does with them): offsets ...
     int *d_lev_rows = nullptr;                        // ... into this list
-    double chain_cost() const override { return 2.0 * sweeps * (double)(longest_chain > 0 ? longest_chain : n_steps) + 2.0; }
+    double chain_cost() const override { return 2.0 * sweeps * (double)(sor ? num_levels : longest_chain > 0 ? longest_chain : n_steps) + 2.0; }
     bool same_scaling_as(const elag_hip_smoother_s *o) const override
     {
         const SweepSmoother *r = dynamic_cast<const SweepSmoother *>(o);
-        return r && r->A == A && r->type == type && r->sweeps == sweeps;
+        return r && r->A == A && r->type == type && r->sweeps == sweeps && r->weight == weight && r->omega == omega;
     }
 };
 

@@ -347,6 +347,54 @@ __global__ void diag_scale_kernel(int n, const int *__restrict__ I, const int *_
     }
 }
 
+// hypre's weighted / over-relaxed branches of the same relaxations (the reference forwards "Damping Factor" and "Omega" unconditionally,
+// src/linalg/solver_ops/ParELAG_HypreSmootherWrapper.cpp:28-33; no shipped list selects them), one dependency level per launch, a thread per
+// row, the sums in storage order (the CPU loop's bits).  v = the vector as it was before the forward pass (both passes read it).
+//   MODE 0, types 2 / 4 with relax_weight != 1 ("scaled SSOR", hypre_ParCSRRelax):  c1 = omega w, c2 = omega (1 - w),
+//           dif = sum over the diag entries with j < i (forward; j > i backward) of a_ij (v_j - u_j),  u_i += (c1 res + c2 dif) / l1_i
+//   MODE 1, type 6 with relax_weight != 1 or omega != 1 (hypre_BoomerAMGRelax):  res0 = -sum_{j != i} a_ij u_j,  res2 = sum_{j != i} a_ij v_j,
+//           res = f_i - offd terms,  u_i = (1 - w omega) u_i + w (omega res + res0 + (1 - omega) res2) / a_ii
+template <int MODE>
+__global__ void sweep_sor_level_kernel(int r0, int r1, int dir, const int *__restrict__ rows, const int *__restrict__ I, const int *__restrict__ J,
+                                       const double *__restrict__ a, const int *__restrict__ oI, const int *__restrict__ oJ, const double *__restrict__ oa,
+                                       const double *__restrict__ f, const double *__restrict__ d, const double *__restrict__ ug, double weight, double omega,
+                                       const double *__restrict__ v, double *u)
+{
+    const int ri = r0 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (ri >= r1) return;
+    const int row = rows[ri];
+    double res = f[row];
+    if (MODE == 0) {
+        const double dr = d[row];
+        if (dr == 0.0) return;
+        double dif = 0.0;
+        for (int k = I[row]; k < I[row + 1]; k++) {
+            const int j = J[k];
+            const double uj = u[j];
+            res -= a[k] * uj;
+            if (dir > 0 ? j < row : j > row) dif += a[k] * (v[j] - uj);
+        }
+        if (oI)
+            for (int k = oI[row]; k < oI[row + 1]; k++) res -= oa[k] * ug[oJ[k]];
+        u[row] += (omega * weight * res + omega * (1.0 - weight) * dif) / dr;
+    } else {
+        double res0 = 0.0, res2 = 0.0, aii = 0.0;
+        bool have = false;
+        for (int k = I[row]; k < I[row + 1]; k++) {
+            const int j = J[k];
+            if (j == row && !have) { aii = a[k]; have = true; continue; }
+            res0 -= a[k] * u[j];
+            res2 += a[k] * v[j];
+        }
+        if (!have || aii == 0.0) return;
+        if (oI)
+            for (int k = oI[row]; k < oI[row + 1]; k++) res -= oa[k] * ug[oJ[k]];
+        double ui = u[row] * (1.0 - weight * omega);
+        ui += weight * (omega * res + res0 + (1.0 - omega) * res2) / aii;
+        u[row] = ui;
+    }
+}
+
 int gs_hybrid_blocks()
 {
     // elag_hip_set_gs_hybrid_blocks, else ELAG_HIP_GS_BLOCKS, else 1 (one rank: the sequential loop)
@@ -357,18 +405,17 @@ int gs_hybrid_blocks()
 
 }  // namespace
 
-SweepSmoother::~SweepSmoother() { dev_free(d_rows); dev_free(d_lev_ptr); dev_free(d_l1); dev_free(d_sJ); dev_free(d_sa); dev_free(d_self_ghost); dev_free(d_blk_first); dev_free(d_blk_count); dev_free(d_lev_rows); }
+SweepSmoother::~SweepSmoother() { dev_free(d_rows); dev_free(d_lev_ptr); dev_free(d_l1); dev_free(d_sJ); dev_free(d_sa); dev_free(d_self_ghost); dev_free(d_blk_first); dev_free(d_blk_count); dev_free(d_lev_rows); dev_free(d_v); }
 
 void SweepSmoother::setup()
 {
     ELAG_REQUIRE(type == ELAG_HIP_SMOOTHER_L1_GS || type == ELAG_HIP_SMOOTHER_L1_GS_TRUNCATED || type == ELAG_HIP_SMOOTHER_GS ||
                  type == ELAG_HIP_SMOOTHER_KACZMARZ, "internal: relax type %d is not a sweep", type);
     const bool kaczmarz = type == ELAG_HIP_SMOOTHER_KACZMARZ;
-    // hypre_ParCSRRelax 2/4 and hypre_BoomerAMGRelax 6 branch on (relax_weight, omega): (1, 1) is the symmetric Gauss-Seidel of
-    // every shipped parameter list ("Damping Factor" 1.0, "Omega" 1.0); the SSOR branches are not built
-    if (!kaczmarz && (weight != 1.0 || (omega != 1.0 && type == ELAG_HIP_SMOOTHER_GS)))
-        fail(ELAG_HIP_ERR_ARG, "relax type %d: \"Damping Factor\" must be 1.0 (and \"Omega\" 1.0 for \"Gauss-Seidel\"): hypre's SSOR branches are "
-             "not built; got %g / %g", type, weight, omega);
+    // hypre_ParCSRRelax 2/4 and hypre_BoomerAMGRelax 6 branch on (relax_weight, omega): (1, 1) is the symmetric Gauss-Seidel of every shipped
+    // parameter list ("Damping Factor" 1.0, "Omega" 1.0) and the tuned launch plan below; types 2 / 4 with omega != 1 run on it too (a factor
+    // in the update); the weighted branches take one plain launch per dependency level (sweep_sor_level_kernel)
+    sor = !kaczmarz && (weight != 1.0 || (omega != 1.0 && type == ELAG_HIP_SMOOTHER_GS));
     M = A;
     const int n = A->nrows();
     hipStream_t st = ctx().stream;
@@ -627,7 +674,7 @@ __global__ void sweep_dense_level_kernel(int r0, int r1, const int *__restrict__
 
 bool SweepSmoother::apply_dense(const double *F, double *X, int m, bool zero_guess)
 {
-    if (type == ELAG_HIP_SMOOTHER_KACZMARZ || h_lev_ptr.empty()) return false;
+    if (type == ELAG_HIP_SMOOTHER_KACZMARZ || sor || h_lev_ptr.empty()) return false;
     const int n = M->nrows();
     if (n == 0 || m == 0) return true;
     hipStream_t st = ctx().stream;
@@ -727,6 +774,7 @@ void SweepSmoother::apply(const double *f, double *&cur, double *&, bool zero_gu
         // "Copy off-diag values of u to the current processor": once per symmetric sweep
         if (As) k::vec_gather(As->offd.ncols, d_self_ghost, cur, As->d_ghost);        // (virtual ranks: the other blocks' values, frozen here)
         else if (M->needs_exchange()) par_halo_exchange(*M, cur);
+        if (sor) { sweep_sor(f, cur); continue; }
         if (segments.size() == 1 && segments[0].max_rows < 0) { launch_segment(segments[0], +1, f, cur, true); continue; }
         if (lds_u && segments.size() == 1 && segments[0].max_rows == 0) {
             launch_segment(segments[0], +1, f, cur, true);        // forward then backward in one launch, u in LDS throughout
@@ -735,6 +783,30 @@ void SweepSmoother::apply(const double *f, double *&cur, double *&, bool zero_gu
         for (size_t s = 0; s < segments.size(); s++) launch_segment(segments[s], +1, f, cur);
         for (size_t s = segments.size(); s-- > 0;) launch_segment(segments[s], -1, f, cur);
     }
+}
+
+void SweepSmoother::sweep_sor(const double *f, double *u)
+{
+    const int n = M->nrows(), nlev = (int)h_lev_ptr.size() - 1;
+    if (n == 0) return;
+    hipStream_t st = ctx().stream;
+    const bool ho = M->offd.nnz > 0;
+    if (!d_v) d_v = dev_alloc<double>((size_t)n);
+    ELAG_HIP_CHECK(hipMemcpyAsync(d_v, u, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    auto level = [&](int l, int dir) {
+        const int r0 = h_lev_ptr[(size_t)l], r1 = h_lev_ptr[(size_t)l + 1];
+        if (r1 == r0) return;
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, st, r0, r1, dir, (const int *)d_lev_rows, (const int *)M->diag.I,
+                               (const int *)M->diag.J, (const double *)M->diag.a, ho ? (const int *)M->offd.I : nullptr, ho ? (const int *)M->offd.J : nullptr,
+                               ho ? (const double *)M->offd.a : nullptr, f, (const double *)d_l1, (const double *)M->d_ghost, weight, omega, (const double *)d_v, u);
+        };
+        if (type == ELAG_HIP_SMOOTHER_GS) go(sweep_sor_level_kernel<1>);
+        else go(sweep_sor_level_kernel<0>);
+    };
+    for (int l = 0; l < nlev; l++) level(l, +1);
+    for (int l = nlev - 1; l >= 0; l--) level(l, -1);
+    ELAG_LAUNCH_CHECK();
 }
 
 // mfem::HypreDiagScale ("Hypre Jacobi" = 413, ParELAG_HypreSmootherFactory.cpp:28-31): HYPRE_ParCSRDiagScale, x = b ./ diag(A)

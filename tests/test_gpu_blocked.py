@@ -420,3 +420,44 @@ def test_default_darcy_solver_graph_converges_at_full_size(la):
         assert K.GetConverged() and K.GetNumIterations() <= 60, (kinv_sigma, K.GetNumIterations())
         A = sp.bmat([[dar["M"], dar["Bt"]], [dar["B"], None]]).tocsr()
         assert np.linalg.norm(A @ x - b) <= 1e-4 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("n", [3, 8, 9, 150, 1471])
+def test_blocked_dense_lu_is_the_column_by_column_one(la, n):
+    """The coarsest saddle-point operator is inverted in place in blocks of 8 pivots (dense.hip, gj_block_*_kernel: two launches per block, the
+    columns put back by one gather) where the column-by-column Gauss-Jordan on [A | I] (ELAG_HIP_LU_BLOCKED=0) takes two launches per pivot.
+    Same partial pivoting (the pivots are found by eliminating the panel's own columns), other rounding: both agree with a host solve on an
+    indefinite saddle-point matrix [[M, B^T], [B, 0]] -- zero diagonal block, so rows must be swapped -- at sizes with a partial last block and
+    the 1 471 dofs of the cube456 x3 Darcy hierarchy."""
+    import os
+    rng = np.random.default_rng(n)
+    n1 = max(1, (2 * n) // 3)
+    n0 = n - n1
+    Mb = sp.diags(rng.uniform(1.0, 2.0, n1)) + 0.1 * sp.random(n1, n1, density=min(1.0, 4.0 / n1), random_state=n)
+    Mb = (Mb + Mb.T).tocsr()
+    if n0:
+        Bb = sp.random(n0, n1, density=min(1.0, 6.0 / n1), random_state=n + 1, format="lil")
+        for i in range(n0):
+            Bb[i, (2 * i) % n1] = 1.0 + 0.1 * i / n0               # full row rank
+            Bb[i, (2 * i + 1) % n1] = -1.0
+        A = sp.bmat([[None, Bb.tocsr()], [Bb.T.tocsr(), Mb]]).tocsr()       # the ZERO block first: the leading pivots must come from below
+    else:
+        A = Mb
+    A = orc.csr(A)
+    b = rng.uniform(-1, 1, n)
+    xs = []
+    for env in ({}, {"ELAG_HIP_LU_BLOCKED": "0"}):
+        os.environ.update(env)
+        try:
+            C = la.CoarseSolver(la.ParallelCSRMatrix.from_scipy(A), kind=1)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        x = np.zeros(n)
+        C.Mult(b, x)
+        xs.append(x)
+    ref = np.linalg.solve(A.toarray(), b)
+    scale = np.max(np.abs(ref)) * max(1.0, np.linalg.cond(A.toarray()) * 1e-4)
+    for x in xs:
+        assert np.max(np.abs(x - ref)) <= 1e-10 * scale
+    assert np.max(np.abs(xs[0] - xs[1])) <= 1e-10 * scale

@@ -112,10 +112,6 @@ def test_the_reference_s_own_smoother_block_is_accepted_unchanged(la, h1_k2):
         la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(orc.diag_first((A + 0.3 * sp.eye(A.shape[0])).tocsr())), la.HYPRE_SMOOTHER_TYPES[name])
     with pytest.raises(ElagHipError, match="not available"):
         la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), 7)
-    with pytest.raises(ElagHipError, match="Omega"):
-        la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), 6, {"Omega": 1.2})          # SSOR branch of BoomerAMGRelax: not built
-    with pytest.raises(ElagHipError, match="Damping"):
-        la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), 2, {"Damping Factor": 0.8})
     # a zero l1 norm is an error in hypre_ParCSRComputeL1Norms, here too
     Z = sp.csr_matrix(A).tolil(); Z[5, :] = 0; Z = Z.tocsr(); Z.eliminate_zeros()
     with pytest.raises(ElagHipError, match="zero l1"):
@@ -252,30 +248,14 @@ def test_distributed_sweep_freezes_the_ghost_values(h1_k2, relax_type, world):
         assert np.array_equal(res[r], ug[lo:hi])
 
 
-@pytest.mark.parametrize("relax_type", [2, 4, 6])
-@pytest.mark.parametrize("blocks", [2, 7, 64])
-def test_virtual_ranks_are_the_reference_s_sweep_on_that_many_ranks(la, h1_k2, relax_type, blocks):
-    """elag_hip_set_gs_hybrid_blocks(B): ONE device rank cuts its rows into B contiguous, even blocks and sweeps them as B MPI ranks would --
-    Gauss-Seidel inside a block, the other blocks' values frozen as they were when the symmetric sweep began.  Bit for bit the oracle's loop
-    run block by block on that partition with exactly those frozen values (two sweeps: the second sees the neighbours' first); B = 1 is the
-    sequential loop again."""
-    import scipy.sparse as sp
-    A = orc.diag_first(h1_k2[0])
+def _hybrid_reference(A, blocks, relax_type, sweeps, f, u, weight=1.0, omega=1.0):
+    """the oracle's relaxation as hybrid Gauss-Seidel on `blocks` ranks with contiguous, even row blocks (u updated in place): rank by
+    rank, rows of block b, columns split into the block's own (diag) and the others' (offd, ascending), the others' values frozen as
+    they were when the symmetric sweep began"""
     n = A.shape[0]
     size, rest = n // blocks, n % blocks
     starts = np.array([b * size + min(b, rest) for b in range(blocks + 1)])
-    rng = np.random.default_rng(17)
-    f, u0 = rng.standard_normal(n), rng.standard_normal(n)
-    la.set_gs_hybrid_blocks(blocks)
-    try:
-        S = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), relax_type, {"Sweeps": 2})
-    finally:
-        la.set_gs_hybrid_blocks(0)
-    u = u0.copy()
-    S.Mult(f, u)
-    # the oracle, rank by rank: rows of block b, columns split into the block's own (diag) and the others' (offd, ascending)
     Ac = sp.csr_matrix(A)
-    block_of = np.repeat(np.arange(blocks), np.diff(starts))
 
     class Frozen(orc.SerialExchange):
         def __init__(self, cols):
@@ -299,9 +279,9 @@ def test_virtual_ranks_are_the_reference_s_sweep_on_that_many_ranks(la, h1_k2, r
                     send_starts=np.zeros(1, np.int32), send_elmts=np.zeros(0, np.int32))
         e = Frozen(col_map)
         ex.append(e)
-        sm.append(orc.OSmoother(orc.oparcsr_from_part(part, e), type=relax_type, sweeps=1))
-    ug = u0.copy()
-    for _ in range(2):
+        sm.append(orc.OSmoother(orc.oparcsr_from_part(part, e), type=relax_type, sweeps=1, weight=weight, omega=omega))
+    ug = u.copy()
+    for _ in range(sweeps):
         for e in ex:
             e.u = ug.copy()
         new = ug.copy()
@@ -311,6 +291,29 @@ def test_virtual_ranks_are_the_reference_s_sweep_on_that_many_ranks(la, h1_k2, r
             sm[b].Mult(f[lo:hi], loc)
             new[lo:hi] = loc
         ug = new
+    u[:] = ug
+
+
+@pytest.mark.parametrize("relax_type", [2, 4, 6])
+@pytest.mark.parametrize("blocks", [2, 7, 64])
+def test_virtual_ranks_are_the_reference_s_sweep_on_that_many_ranks(la, h1_k2, relax_type, blocks):
+    """elag_hip_set_gs_hybrid_blocks(B): ONE device rank cuts its rows into B contiguous, even blocks and sweeps them as B MPI ranks would --
+    Gauss-Seidel inside a block, the other blocks' values frozen as they were when the symmetric sweep began.  Bit for bit the oracle's loop
+    run block by block on that partition with exactly those frozen values (two sweeps: the second sees the neighbours' first); B = 1 is the
+    sequential loop again."""
+    A = orc.diag_first(h1_k2[0])
+    n = A.shape[0]
+    rng = np.random.default_rng(17)
+    f, u0 = rng.standard_normal(n), rng.standard_normal(n)
+    la.set_gs_hybrid_blocks(blocks)
+    try:
+        S = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), relax_type, {"Sweeps": 2})
+    finally:
+        la.set_gs_hybrid_blocks(0)
+    u = u0.copy()
+    S.Mult(f, u)
+    ug = u0.copy()
+    _hybrid_reference(A, blocks, relax_type, 2, f, ug)
     assert np.array_equal(u, ug)
     # one block: the sequential loop
     S1 = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(A), relax_type, {"Sweeps": 2})
@@ -332,6 +335,33 @@ def test_l1_gauss_seidel_with_omega(la, h1_k2, relax_type):
     u, ur = u0.copy(), u0.copy()
     dev_s.Mult(f, u); ref_s.Mult(f, ur)
     assert np.array_equal(u, ur)
+
+
+@pytest.mark.parametrize("relax_type,weight,omega", [(2, 0.8, 1.0), (4, 0.7, 1.3), (2, 1.25, 0.9), (6, 1.0, 1.2), (6, 0.8, 1.0), (6, 0.9, 1.4)])
+@pytest.mark.parametrize("blocks", [1, 7])
+def test_weighted_branches_of_the_gauss_seidel_relaxations(la, h1_k2, relax_type, weight, omega, blocks):
+    """hypre's branches for "Damping Factor" != 1 (types 2 / 4: scaled SSOR with the saved pre-sweep vector) and for type 6 with either
+    parameter off 1 (the reference forwards both keys unconditionally, ParELAG_HypreSmootherWrapper.cpp:28-33): bit for bit the oracle's
+    loops, two sweeps, from a non-zero guess and from zero; also as hybrid Gauss-Seidel on 7 virtual ranks against the oracle on that partition"""
+    A, _, _ = h1_k2
+    Ad = orc.diag_first(A)
+    n = A.shape[0]
+    rng = np.random.default_rng(21)
+    f, u0 = rng.standard_normal(n), rng.standard_normal(n)
+    la.set_gs_hybrid_blocks(blocks)
+    try:
+        dev_s = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(Ad), relax_type, {"Sweeps": 2, "Damping Factor": weight, "Omega": omega})
+    finally:
+        la.set_gs_hybrid_blocks(0)
+    if blocks == 1:
+        ref = lambda f_, u_: orc.OSmoother(orc.OParCSR(Ad), type=relax_type, sweeps=2, weight=weight, omega=omega).Mult(f_, u_)
+    else:
+        ref = lambda f_, u_: _hybrid_reference(Ad, blocks, relax_type, 2, f_, u_, weight=weight, omega=omega)
+    for iterative in (True, False):
+        dev_s.iterative_mode = iterative
+        u, ur = u0.copy(), (u0.copy() if iterative else np.zeros(n))
+        dev_s.Mult(f, u); ref(f, ur)
+        assert np.array_equal(u, ur)
 
 
 def test_lumped_jacobi_is_l1_jacobi_with_row_sums(la, h1_k2):

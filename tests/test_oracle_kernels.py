@@ -138,6 +138,66 @@ def test_l1gs_matches_dense_loop():
     assert np.allclose(u, ref, rtol=1e-12)
 
 
+def test_l1gs_scaled_ssor_branch_matches_dense_loop_and_reduces_to_the_others():
+    """hypre_ParCSRRelax 2 / 4 with relax_weight != 1: c1 = omega w, c2 = omega (1 - w), dif over the rows already visited
+    in this direction against the vector the forward pass started from; w = 1 is the omega branch bit for bit"""
+    rng = np.random.default_rng(6)
+    n = 40
+    B = rng.standard_normal((n, n)); B[abs(B) < 1.1] = 0
+    Ad = B + B.T + 10 * np.eye(n)
+    A = orc.diag_first(sp.csr_matrix(Ad))
+    l1 = abs(np.diag(Ad))
+    f, u0 = rng.standard_normal(n), rng.standard_normal(n)
+    for w, om in ((0.8, 1.0), (0.7, 1.3), (1.25, 0.9)):
+        ref, v = u0.copy(), u0.copy()
+        c1, c2 = om * w, om * (1 - w)
+        for i in range(n):
+            res = f[i] - Ad[i] @ ref
+            dif = Ad[i, :i] @ (v[:i] - ref[:i])
+            ref[i] += (c1 * res + c2 * dif) / l1[i]
+        for i in range(n - 1, -1, -1):
+            res = f[i] - Ad[i] @ ref
+            dif = Ad[i, i + 1:] @ (v[i + 1:] - ref[i + 1:])
+            ref[i] += (c1 * res + c2 * dif) / l1[i]
+        u = u0.copy()
+        orc.OSmoother(orc.OParCSR(A), type=2, weight=w, omega=om).Mult(f, u)
+        assert np.allclose(u, ref, rtol=1e-12, atol=1e-13)
+    vt = np.empty(n)
+    ua, ub = u0.copy(), u0.copy()
+    L = orc.lib()
+    args = (orc.C.c_int(n), orc._ip(A.indptr), orc._ip(A.indices), orc._dp(A.data), None, None, None, orc._dp(f), orc._dp(l1), None)
+    L.orc_l1gs_sweep_scaled(*args, orc.C.c_double(1.0), orc.C.c_double(1.3), orc._dp(ua), orc._dp(vt))
+    L.orc_l1gs_sweep_omega(*args, orc.C.c_double(1.3), orc._dp(ub))
+    assert np.array_equal(ua, ub) and np.array_equal(vt, u0)
+
+
+def test_gs_weighted_branch_matches_dense_loop():
+    """hypre_BoomerAMGRelax 6 with relax_weight != 1 or omega != 1: u_i = (1 - w omega) u_i + w (omega res + res0 + (1 - omega) res2) / a_ii with
+    res0 over the current vector, res2 over the copy taken before the forward pass; (1, 1) falls back to plain symmetric Gauss-Seidel"""
+    rng = np.random.default_rng(7)
+    n = 40
+    B = rng.standard_normal((n, n)); B[abs(B) < 1.1] = 0
+    Ad = B + B.T + 10 * np.eye(n)
+    A = orc.diag_first(sp.csr_matrix(Ad))
+    off = Ad - np.diag(np.diag(Ad))
+    f, u0 = rng.standard_normal(n), rng.standard_normal(n)
+    for w, om in ((1.0, 1.2), (0.8, 1.0), (0.9, 1.4)):
+        ref, v = u0.copy(), u0.copy()
+        for i in list(range(n)) + list(range(n - 1, -1, -1)):
+            res0, res2 = -(off[i] @ ref), off[i] @ v
+            ref[i] = (1 - w * om) * ref[i] + w * (om * f[i] + res0 + (1 - om) * res2) / Ad[i, i]
+        u = u0.copy()
+        orc.OSmoother(orc.OParCSR(A), type=6, weight=w, omega=om).Mult(f, u)
+        assert np.allclose(u, ref, rtol=1e-12, atol=1e-13)
+    # the formula at (1, 1) is the plain sweep (hypre takes the other branch there; the two agree to rounding)
+    ua, ub, vt = u0.copy(), u0.copy(), np.empty(n)
+    L = orc.lib()
+    args = (orc.C.c_int(n), orc._ip(A.indptr), orc._ip(A.indices), orc._dp(A.data), None, None, None, orc._dp(f), None)
+    L.orc_gs_sweep_sor(*args, orc.C.c_double(1.0), orc.C.c_double(1.0), orc._dp(ua), orc._dp(vt))
+    L.orc_gs_sweep(*args, orc._dp(ub))
+    assert np.allclose(ua, ub, rtol=1e-12, atol=1e-13)
+
+
 @pytest.mark.parametrize("order", [1, 2, 3, 4])
 def test_cheby_coefs_identity(order):
     """1 - t s(t) = T_k((theta-t)/delta) / T_k(theta/delta)  (SURVEY A.3)."""
