@@ -150,134 +150,262 @@ __global__ void gj_extract_kernel(int n, const double *__restrict__ M, int ld, d
 }
 
 
-// ---- blocked form: B = 8 pivots per step, in place (n x n, no augmented half) -----------------------------------------------------------------
-// One step = two launches.  The panel kernel (one workgroup, the panel's rows k0.. in LDS) finds the B pivots by an unblocked elimination of the
-// panel's own columns, swaps those rows of M, and leaves what the update needs:  Dinv = (M_KK)^-1,  Rp = Dinv M_K: (the new pivot rows) and
-// Cc = M_:K (the column panel before the update overwrites it).  The update kernel then is one pass over M:
-//     rows of K:  Dinv (columns of K) | Rp          other rows:  -Cc Dinv (columns of K) | M - Cc Rp
+// ---- blocked form: B = 8 pivots per step, n x n (no augmented half), two launches per step ---------------------------------------------------
+// The panel kernel (ONE workgroup, the panel's rows from k0 on in LDS) finds the B pivots by an unblocked elimination of the panel's own columns
+// and leaves a small record: the rows that move (at most 2 B of them) with the row each receives, and Dinv = (M_KK)^-1 of the swapped matrix.
+// The update kernel is then one pass from the old matrix to the new one (two buffers, swapped every step: a row that moves is simply read from
+// where it was -- no row is swapped in memory, nothing is read that the same launch writes):
+//     rows of K:  Dinv (columns of K) | Dinv M_K:          other rows:  -M_:K Dinv (columns of K) | M - M_:K (Dinv M_K:)
 // -- Gauss-Jordan with the identity's columns stored where the eliminated ones were.  With P the row swaps, the result is (P A)^-1 = A^-1 P^T: the
 // columns are put back by one gather at the end (column j of the inverse = column colsrc[j], the swaps applied to 0..n-1 in reverse order).
-// 1 471 dofs: 2 x 184 launches and ~6 GB of traffic where the column-by-column form had 2 942 launches and 150 GB.
+// 1 471 dofs: 2 x 184 launches and ~6 GB of traffic where the column-by-column form had 2 942 launches and 150 GB.  (A first version did the row
+// swaps and the products Dinv M_K:, M_:K in the panel kernel: ~300 KB through ONE compute unit in five dependent phases, 48 us per step.)
 constexpr int kGB = 8;
-__global__ void __launch_bounds__(1024) gj_block_panel_kernel(int n, int k0, double *__restrict__ M, int *__restrict__ piv_all, double *__restrict__ Dinv,
-                                                              double *__restrict__ Rp, double *__restrict__ Cc, int *__restrict__ singular)
+constexpr int kGPanelRows = 3072;                  // largest n: a thread of the panel kernel keeps three rows of the panel
+struct GjStep {                                    // what the panel kernel leaves for the update
+    int nr, pad[3];
+    int row[2 * kGB], src[2 * kGB];                // row[z] receives the old row src[z]  (rows not listed stay)
+    double Dinv[kGB * kGB];
+};
+// argmax (|value|, lowest index on ties) across lanes without LDS: DPP moves inside a row of 16 lanes, lane reads across the four rows
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
 {
-    extern __shared__ double Pn[];                   // (n - k0) x kGB, row-major: the panel's columns of the rows from k0 on
-    __shared__ double sv[1024];
-    __shared__ int si[1024];
-    __shared__ int s_piv[kGB];
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void argmax_take(double &best, int &bi, double &bsv, double ov, int oi, double os)
+{
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; bsv = os; }
+}
+template <int CTRL>
+__device__ __forceinline__ void argmax_dpp(double &best, int &bi, double &bsv)
+{
+    const double ov = dpp_f64<CTRL>(best), os = dpp_f64<CTRL>(bsv);
+    const int oi = __builtin_amdgcn_update_dpp(bi, bi, CTRL, 0xf, 0xf, false);
+    argmax_take(best, bi, bsv, ov, oi, os);
+}
+__device__ __forceinline__ void argmax_row16(double &best, int &bi, double &bsv)      // afterwards every lane of a row of 16 holds the row's winner
+{
+    argmax_dpp<0xB1>(best, bi, bsv);             // quad_perm [1, 0, 3, 2]
+    argmax_dpp<0x4E>(best, bi, bsv);             // quad_perm [2, 3, 0, 1]
+    argmax_dpp<0x141>(best, bi, bsv);            // row_half_mirror
+    argmax_dpp<0x140>(best, bi, bsv);            // row_mirror
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+// (Measured on MI355X with the wall clock at the phase boundaries, ELAG_HIP_LU_TIMING=1, n = 1 471: with the panel in LDS the eight pivots were
+//  22-26 us of the kernel -- 16 waves' shuffles, candidate reads and row updates all through the one LDS pipe of the CU.  Now a thread keeps
+//  its rows of the panel in registers, the reductions are DPP moves and lane reads, and LDS carries two rows and 16 candidates per pivot.)
+//  The kernel is bound by vector-instruction issue (a wave64 instruction holds its SIMD for 4+ cycles, and every wave pays the reductions): 512
+//  threads -- two waves per SIMD -- with up to six rows each, empty row slots skipped, one reciprocal of the pivot instead of a division per row.
+constexpr int kGThreads = 512;
+constexpr int kGRowsPer = 6;                       // rows of the panel per thread: n <= 3 072
+__global__ void __launch_bounds__(kGThreads) gj_block_panel_kernel(int n, int k0, const double *__restrict__ M, int *__restrict__ piv_all, GjStep *__restrict__ step,
+                                                              int *__restrict__ singular, long long *__restrict__ dbg)
+{
+    // dbg (ELAG_HIP_LU_TIMING=1): the 100 MHz wall clock at the kernel's phase boundaries, six per step
+    auto stamp = [&](int w) { if (dbg && threadIdx.x == 0) dbg[(size_t)(k0 / kGB) * 6 + w] = (long long)wall_clock64(); };
+    stamp(0);
+    constexpr int kWaves = kGThreads / 64;
+    __shared__ double sv[kWaves], ss[kWaves];        // a candidate per wave: |value|, value
+    __shared__ int si[kWaves];
+    __shared__ double prow[kGB], qrow[kGB];          // the pivot row and the row it changes places with
+    __shared__ int s_piv[kGB], s_src[2 * kGB];
     __shared__ double D[kGB][kGB + 1], ck[kGB], rk[kGB];
     const int t = threadIdx.x, m = n - k0, nb = min(kGB, m);
-    for (int e = t; e < m * kGB; e += 1024) {
-        const int r = e / kGB, c = e % kGB;
-        Pn[e] = c < nb ? M[(size_t)(k0 + r) * n + k0 + c] : 0.0;
+    // this thread's rows of the panel (positions t, t + 512, ... from k0 on), 64 contiguous bytes each
+    double rv[kGRowsPer][kGB];
+#pragma unroll
+    for (int u = 0; u < kGRowsPer; u++) {
+        const int r = t + u * kGThreads;
+#pragma unroll
+        for (int c = 0; c < kGB; c++) rv[u][c] = (r < m && c < nb) ? M[(size_t)(k0 + r) * n + k0 + c] : 0.0;
     }
-    __syncthreads();
-    for (int q = 0; q < nb; q++) {
-        double best = -1.0;
+    stamp(1);
+#pragma unroll
+    for (int q = 0; q < kGB; q++) {
+        if (q >= nb) break;                                                    // (uniform)
+        // argmax |column q| over the rows from q on, lowest index on ties
+        double best = -1.0, bsv = 0.0;
         int bi = m;
-        for (int r = q + t; r < m; r += 1024) {
-            const double v = fabs(Pn[r * kGB + q]);
-            if (v > best) { best = v; bi = r; }
+#pragma unroll
+        for (int u = 0; u < kGRowsPer; u++) {
+            if (u * kGThreads >= m) break;                                     // (uniform: an empty slot)
+            const int r = t + u * kGThreads;
+            const double v = fabs(rv[u][q]);
+            if (r >= q && r < m && v > best) { best = v; bi = r; bsv = rv[u][q]; }
         }
-        sv[t] = best; si[t] = bi;
+        argmax_row16(best, bi, bsv);
+        {
+            double b = readlane_f64(best, 0), sg = readlane_f64(bsv, 0);
+            int ix = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+            for (int l = 16; l < 64; l += 16) argmax_take(b, ix, sg, readlane_f64(best, l), __builtin_amdgcn_readlane(bi, l), readlane_f64(bsv, l));
+            if ((t & 63) == 0) { sv[t >> 6] = b; si[t >> 6] = ix; ss[t >> 6] = sg; }
+        }
         __syncthreads();
-        for (int s = 512; s > 0; s >>= 1) {
-            if (t < s) {
-                const double ov = sv[t + s];
-                const int oi = si[t + s];
-                if (ov > sv[t] || (ov == sv[t] && oi < si[t])) { sv[t] = ov; si[t] = oi; }
-            }
-            __syncthreads();
-        }
-        const int p = si[0] < m ? si[0] : q;                                  // argmax |column q| over the rows from q on, lowest index on ties
-        __syncthreads();                                                       // (si[0] read by everybody before the next search overwrites it)
-        if (t < kGB) {
-            const double a = Pn[q * kGB + t], b = Pn[p * kGB + t];
-            Pn[q * kGB + t] = b; Pn[p * kGB + t] = a;
-        }
+        best = sv[0]; bi = si[0]; bsv = ss[0];                                 // (the waves' candidates, by every thread)
+#pragma unroll
+        for (int w = 1; w < kWaves; w++) argmax_take(best, bi, bsv, sv[w], si[w], ss[w]);
+        const int p = __builtin_amdgcn_readfirstlane(bi < m ? bi : q);
+        const double pv = readlane_f64(bi < m ? bsv : 0.0, 0);
+        const bool bad = pv == 0.0 || pv != pv;
+        if (bad && t == 0) atomicAdd(singular, 1);
         if (t == 0) s_piv[q] = k0 + p;
-        __syncthreads();
-        const double pv = Pn[q * kGB + q];
-        if (pv == 0.0 || pv != pv) { if (t == 0) atomicAdd(singular, 1); continue; }     // (uniform: every thread reads the same pv)
-        for (int r = q + 1 + t; r < m; r += 1024) {
-            const double f = Pn[r * kGB + q] / pv;
-            for (int c = q + 1; c < nb; c++) Pn[r * kGB + c] -= f * Pn[q * kGB + c];
+        // the two rows through LDS: position q takes the pivot row, position p the row that was at q
+        const int pt = p % kGThreads, pu = p / kGThreads;
+        if (t == pt) {
+#pragma unroll
+            for (int u = 0; u < kGRowsPer; u++)
+                if (u == pu) {
+#pragma unroll
+                    for (int c = 0; c < kGB; c++) prow[c] = rv[u][c];
+                }
+        }
+        if (t == q) {
+#pragma unroll
+            for (int c = 0; c < kGB; c++) qrow[c] = rv[0][c];
         }
         __syncthreads();
-    }
-    // the swaps on the rows of M, one column per thread (the swaps of a column in their order)
-    for (int c = t; c < n; c += 1024)
-        for (int q = 0; q < nb; q++) {
-            const int k = k0 + q, p = s_piv[q];
-            if (p != k) {
-                const double a = M[(size_t)k * n + c], b = M[(size_t)p * n + c];
-                M[(size_t)k * n + c] = b; M[(size_t)p * n + c] = a;
+        double pr[kGB];
+#pragma unroll
+        for (int c = 0; c < kGB; c++) pr[c] = prow[c];
+        if (p != q) {
+            if (t == pt) {
+#pragma unroll
+                for (int u = 0; u < kGRowsPer; u++)
+                    if (u == pu) {
+#pragma unroll
+                        for (int c = 0; c < kGB; c++) rv[u][c] = qrow[c];
+                    }
+            }
+            if (t == q) {
+#pragma unroll
+                for (int c = 0; c < kGB; c++) rv[0][c] = pr[c];
             }
         }
+        // eliminate the rows below
+        const double ipv = bad ? 0.0 : 1.0 / pv;
+#pragma unroll
+        for (int u = 0; u < kGRowsPer; u++) {
+            if (u * kGThreads >= m) break;                                     // (uniform)
+            const int r = t + u * kGThreads;
+            if (r > q && r < m) {
+                const double f = rv[u][q] * ipv;
+#pragma unroll
+                for (int c = q + 1; c < kGB; c++) rv[u][c] -= f * pr[c];
+            }
+        }
+        // (prow / qrow / sv are written again only behind the next pivot's first barrier, and read here in front of it)
+    }
+    stamp(2);
+    if (t >= 64) return;                                                       // the rest is one wavefront's work (no workgroup barrier below)
+    __builtin_amdgcn_wave_barrier();
+    // The rows that move and, for each, the row it receives: position x ends up with the old row found by walking the swaps backwards from x
+    // (8 compare-and-select steps), independently for each of the 2 kGB positions a swap touches -- a lane each, no serial walk over lists.
+    if (t < 2 * kGB) {
+        const int q0 = t >> 1;
+        int y = (q0 < nb) ? ((t & 1) ? s_piv[q0] : k0 + q0) : -1;
+        const int x = y;
+        for (int q = nb - 1; q >= 0; q--) {
+            const int k = k0 + q, p = s_piv[q];
+            if (y == k) y = p;
+            else if (y == p) y = k;
+        }
+        s_src[t] = y;
+        step->row[t] = x; step->src[t] = y;
+    }
+    if (t == 0) step->nr = 2 * kGB;
     if (t < nb) piv_all[k0 + t] = s_piv[t];
-    __threadfence_block();
-    __syncthreads();                                                           // (the workgroup's own global writes are visible to it after the barrier)
-    // D = M_KK (padded with the identity), inverted without further pivoting: the swaps made its leading pivots the ones found above
+    __builtin_amdgcn_wave_barrier();
+    stamp(3);
+    // D = the swapped M_KK (padded with the identity), inverted without further pivoting: the swaps made its leading pivots the ones found above
     const int r = t / kGB, c = t % kGB;
-    if (t < kGB * kGB) D[r][c] = (r < nb && c < nb) ? M[(size_t)(k0 + r) * n + k0 + c] : (r == c ? 1.0 : 0.0);
-    __syncthreads();
+    D[r][c] = (r < nb && c < nb) ? M[(size_t)s_src[2 * r] * n + k0 + c] : (r == c ? 1.0 : 0.0);                         // (position k0 + r is entry 2 r of the list)
+    __builtin_amdgcn_wave_barrier();
+    stamp(4);
     for (int k = 0; k < nb; k++) {
         const double p = D[k][k];
         if (t < kGB) {
             ck[t] = (t == k) ? 0.0 : D[t][k];
             rk[t] = (t == k) ? 1.0 / p : D[k][t] / p;
         }
-        __syncthreads();
-        if (t < kGB * kGB) {
-            double v = D[r][c];
-            if (r == k) v = rk[c];
-            else if (c == k) v = -ck[r] * rk[c];                               // rk[k] = 1 / p
-            else v -= ck[r] * rk[c];
-            D[r][c] = v;
-        }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        double v = D[r][c];
+        if (r == k) v = rk[c];
+        else if (c == k) v = -ck[r] * rk[c];                                   // rk[k] = 1 / p
+        else v -= ck[r] * rk[c];
+        __builtin_amdgcn_wave_barrier();
+        D[r][c] = v;
+        __builtin_amdgcn_wave_barrier();
     }
-    if (t < kGB * kGB) Dinv[t] = D[r][c];
-    for (int e = t; e < n * kGB; e += 1024) {
-        const int i = e / kGB, q = e % kGB;
-        Cc[e] = q < nb ? M[(size_t)i * n + k0 + q] : 0.0;
+    step->Dinv[t] = D[r][c];
+    stamp(5);
+}
+
+constexpr int kGRows = 16;                           // rows per workgroup of the update (a thread per column)
+__global__ void __launch_bounds__(256) gj_block_update_kernel(int n, int k0, const double *__restrict__ Mo, double *__restrict__ Mn, const GjStep *__restrict__ step)
+{
+    __shared__ GjStep st;
+    __shared__ int s_old[kGRows + kGB];              // the old row each of this workgroup's rows -- and each row of K -- receives
+    __shared__ double cc[kGRows][kGB];               // ... and its entries in the panel's columns
+    for (int e = threadIdx.x; e < (int)(sizeof(GjStep) / sizeof(int)); e += 256) reinterpret_cast<int *>(&st)[e] = reinterpret_cast<const int *>(step)[e];
+    __syncthreads();
+    const int i0 = blockIdx.y * kGRows;
+    const int nb = min(kGB, n - k0);
+    if (threadIdx.x < kGRows + kGB) {
+        const int i = threadIdx.x < kGRows ? i0 + (int)threadIdx.x : k0 + (int)threadIdx.x - kGRows;
+        int o = i;
+        for (int z = 0; z < st.nr; z++)
+            if (st.row[z] == i) o = st.src[z];
+        s_old[threadIdx.x] = min(o, n - 1);
     }
-    for (int j = t; j < n; j += 1024) {
+    __syncthreads();
+    if (threadIdx.x < kGRows * kGB) {
+        const int sr = threadIdx.x / kGB, q = threadIdx.x % kGB;
+        cc[sr][q] = (i0 + sr < n && q < nb) ? Mo[(size_t)s_old[sr] * n + k0 + q] : 0.0;
+    }
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const bool jcol = j >= k0 && j < k0 + nb;
+    // rp = column j of the new pivot rows: Dinv itself on the columns of K, Dinv M_K: elsewhere
+    double rp[kGB];
+    if (jcol) {
+#pragma unroll
+        for (int q = 0; q < kGB; q++) rp[q] = q < nb ? st.Dinv[q * kGB + (j - k0)] : 0.0;
+    } else {
         double col[kGB];
 #pragma unroll
-        for (int q = 0; q < kGB; q++) col[q] = q < nb ? M[(size_t)(k0 + q) * n + j] : 0.0;
+        for (int w = 0; w < kGB; w++) col[w] = w < nb ? Mo[(size_t)s_old[kGRows + w] * n + j] : 0.0;
 #pragma unroll
         for (int q = 0; q < kGB; q++) {
             double sum = 0.0;
 #pragma unroll
-            for (int w = 0; w < kGB; w++) sum += D[q][w] * col[w];
-            Rp[(size_t)q * n + j] = sum;
+            for (int w = 0; w < kGB; w++) sum += st.Dinv[q * kGB + w] * col[w];
+            rp[q] = q < nb ? sum : 0.0;
         }
     }
-}
-
-constexpr int kGRows = 16;                           // rows per workgroup of the update (a thread per column)
-__global__ void __launch_bounds__(256) gj_block_update_kernel(int n, int k0, double *__restrict__ M, const double *__restrict__ Dinv, const double *__restrict__ Rp,
-                                                              const double *__restrict__ Cc)
-{
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int i0 = blockIdx.y * kGRows;
-    if (j >= n) return;
-    const int nb = min(kGB, n - k0);
-    const bool jcol = j >= k0 && j < k0 + nb;
-    double rp[kGB];
+    // (this thread's column of the workgroup's rows, all requested before the first is used)
+    double mo[kGRows];
 #pragma unroll
-    for (int q = 0; q < kGB; q++) rp[q] = q < nb ? (jcol ? Dinv[q * kGB + (j - k0)] : Rp[(size_t)q * n + j]) : 0.0;
+    for (int s = 0; s < kGRows; s++) mo[s] = (i0 + s < n && !jcol) ? Mo[(size_t)s_old[s] * n + j] : 0.0;
+#pragma unroll
     for (int s = 0; s < kGRows; s++) {
         const int i = i0 + s;
         if (i >= n) break;
-        double *mp = M + (size_t)i * n + j;
-        if (i >= k0 && i < k0 + nb) { *mp = rp[i - k0]; continue; }           // rows of the pivot block: Dinv | Dinv M_K:
+        double *mp = Mn + (size_t)i * n + j;
+        if (i >= k0 && i < k0 + nb) { *mp = rp[i - k0]; continue; }           // rows of the pivot block
         double acc = 0.0;
 #pragma unroll
-        for (int q = 0; q < kGB; q++) acc += Cc[(size_t)i * kGB + q] * rp[q];
-        *mp = jcol ? -acc : *mp - acc;
+        for (int q = 0; q < kGB; q++) acc += cc[s][q] * rp[q];
+        *mp = jcol ? -acc : mo[s] - acc;
     }
 }
 
@@ -312,33 +440,40 @@ void dense_inverse_general(const DevCSR &A, double *Minv)
     ELAG_REQUIRE(n == A.ncols, "dense inverse needs a square matrix");
     if (n == 0) return;
     const char *e_blk = getenv("ELAG_HIP_LU_BLOCKED");                    // (0 = the column-by-column form on [A | I]: A/B runs and a test)
-    const size_t panel_lds = sizeof(double) * (size_t)n * kGB;
-    if (!(e_blk && !atoi(e_blk)) && panel_lds <= (size_t)(144 << 10)) {
-        // blocked, in place: the panel of the first step (all n rows x 8 columns) must fit one workgroup's LDS
-        static thread_local bool raised = false;
-        if (!raised && panel_lds > (size_t)(32 << 10)) {
-            ELAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gj_block_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 << 10));
-            raised = true;
-        }
-        double *Mb = dev_alloc<double>((size_t)n * n);
+    if (!(e_blk && !atoi(e_blk)) && n <= kGPanelRows) {
+        double *Mb = dev_alloc<double>((size_t)n * n * 2);                   // two buffers: every step reads one and writes the other
         try {
             Temp<int> piv_all((size_t)n), colsrc((size_t)n), singular(1);
-            Temp<double> Dinv((size_t)kGB * kGB), Rp((size_t)kGB * n), Cc((size_t)n * kGB);
-            ELAG_HIP_CHECK(hipMemsetAsync(Mb, 0, sizeof(double) * (size_t)n * n, st));
+            Temp<GjStep> step(1);
+            const char *e_tim = getenv("ELAG_HIP_LU_TIMING");
+            const size_t nsteps = (size_t)(n + kGB - 1) / kGB;
+            Temp<long long> dbg(e_tim && atoi(e_tim) ? nsteps * 6 : 1);
+            long long *dbgp = e_tim && atoi(e_tim) ? dbg.p : nullptr;
+            double *Mo = Mb, *Mn = Mb + (size_t)n * n;
+            ELAG_HIP_CHECK(hipMemsetAsync(Mo, 0, sizeof(double) * (size_t)n * n, st));
             ELAG_HIP_CHECK(hipMemsetAsync(singular.p, 0, sizeof(int), st));
-            hipLaunchKernelGGL(dense_scatter_plain_kernel, dim3((n + kB - 1) / kB), dim3(kB), 0, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, Mb);
+            hipLaunchKernelGGL(dense_scatter_plain_kernel, dim3((n + kB - 1) / kB), dim3(kB), 0, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, Mo);
             const dim3 gu((n + 255) / 256, (n + kGRows - 1) / kGRows);
             for (int k0 = 0; k0 < n; k0 += kGB) {
-                hipLaunchKernelGGL(gj_block_panel_kernel, dim3(1), dim3(1024), sizeof(double) * (size_t)(n - k0) * kGB, st, n, k0, Mb, piv_all.p, Dinv.p, Rp.p, Cc.p,
-                                   singular.p);
-                hipLaunchKernelGGL(gj_block_update_kernel, gu, dim3(256), 0, st, n, k0, Mb, (const double *)Dinv.p, (const double *)Rp.p, (const double *)Cc.p);
+                hipLaunchKernelGGL(gj_block_panel_kernel, dim3(1), dim3(kGThreads), 0, st, n, k0, (const double *)Mo, piv_all.p, step.p,
+                                   singular.p, dbgp);
+                hipLaunchKernelGGL(gj_block_update_kernel, gu, dim3(256), 0, st, n, k0, (const double *)Mo, Mn, (const GjStep *)step.p);
+                std::swap(Mo, Mn);
             }
             hipLaunchKernelGGL(gj_colsrc_kernel, dim3(1), dim3(1024), sizeof(int) * 2 * (size_t)n, st, n, (const int *)piv_all.p, colsrc.p);
-            hipLaunchKernelGGL(gj_gather_cols_kernel, dim3((n + kB - 1) / kB, n), dim3(kB), 0, st, n, (const double *)Mb, (const int *)colsrc.p, Minv);
+            hipLaunchKernelGGL(gj_gather_cols_kernel, dim3((n + kB - 1) / kB, n), dim3(kB), 0, st, n, (const double *)Mo, (const int *)colsrc.p, Minv);
             ELAG_LAUNCH_CHECK();
             int bad = 0;
             ELAG_HIP_CHECK(hipMemcpyAsync(&bad, singular.p, sizeof(int), hipMemcpyDeviceToHost, st));
             ELAG_HIP_CHECK(hipStreamSynchronize(st));
+            if (dbgp) {
+                std::vector<long long> h = host_from_dev(dbgp, nsteps * 6);
+                double acc[5] = {0, 0, 0, 0, 0};
+                for (size_t q = 0; q < nsteps; q++)
+                    for (int w = 0; w < 5; w++) acc[w] += (double)(h[q * 6 + w + 1] - h[q * 6 + w]) * 0.01;     // 100 MHz ticks -> us
+                fprintf(stderr, "[elag_hip] blocked LU panel kernel, n = %d, mean us per step: load %.2f, pivots %.2f, swap lists %.2f, D load %.2f, D inverse %.2f\n", n,
+                        acc[0] / nsteps, acc[1] / nsteps, acc[2] / nsteps, acc[3] / nsteps, acc[4] / nsteps);
+            }
             if (bad) fail(ELAG_HIP_ERR_NUMERIC, "coarse operator is singular (%d zero pivots in the dense LU)", bad);
         } catch (...) {
             dev_free(Mb);
