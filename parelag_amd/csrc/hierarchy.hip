@@ -1169,8 +1169,10 @@ struct elag_hip_hierarchy_s {
         double *cur = (nf & 1) ? alt : sol, *oth = (nf & 1) ? sol : alt;
         // pre-smoothing (:180-184) and residual (:191-194)
         const double *pre_dinv = (F.pre && F.pre->A == F.A) ? F.pre->diag_scaling() : nullptr;
-        // (worth it only while the level is launch-bound: the fused form gathers two vectors per entry)
-        if (pre_dinv && F.A->diag.nnz < (int64_t(1) << 20)) {
+        // (worth it while the level is launch-bound -- the stream kernel's fused form gathers two vectors per entry -- and wherever the
+        //  operator runs in its x-cache form, which gathers once per DISTINCT column of a window: there the separate pass that formed W f,
+        //  13.8 us of a 386 us PCG iteration at cube456 x5, is one more gather per cached column)
+        if (pre_dinv && (F.A->diag.nnz < (int64_t(1) << 20) || (F.A->diag.xc_state == 1 && !F.A->needs_exchange()))) {
             // one kernel: SOL = dinv .* RHS (Jacobi sweep from the zero guess) gathered on the fly as the SpMV
             // operand, tmp_resid = RHS - A SOL
             k::SpmvArgs a;

@@ -825,7 +825,9 @@ void prepare_spmv(const DevCSR &A, bool force)
     if (measure < 0) { const char *e = getenv("ELAG_HIP_XC_MEASURE"); measure = (e && atoi(e)) ? 1 : 0; }
     if (!measure) {
         const int w = xc_window_env() ? xc_window_env() : 2304;
-        if (!xc_build(A, w, false, 4.0)) A.xc_state = -1;
+        static double min_reuse = -1.0;
+        if (min_reuse < 0.0) { const char *e = getenv("ELAG_HIP_XC_MIN_REUSE"); min_reuse = e ? atof(e) : 4.0; }
+        if (!xc_build(A, w, false, min_reuse)) A.xc_state = -1;
         return;
     }
     // A few launches of each candidate on a scratch vector pair (HIP events on this stream, under kernel names of their own): the plain

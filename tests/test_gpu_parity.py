@@ -256,20 +256,34 @@ def test_chebyshev_eig_estimate_on_galerkin_operators_and_at_full_size(la, h1_k3
         assert mn == pytest.approx(mn_ref, rel=1e-6), l
 
 
-def test_ssor_branches_of_the_gauss_seidel_relaxations_are_refused(la, h1_k2):
-    """hypre's relax types 2 / 4 / 6 switch to SSOR-style branches for relax_weight != 1 (and omega != 1 for type 6); neither the oracle nor
-    the device restates them (the shipped lists use 1 / 1, Create0FormParameterList.hpp:103-116): the ABI refuses them with ELAG_HIP_ERR_ARG
-    instead of silently running the weight-1 sweep, like oracle.OSmoother raises."""
-    from parelag_amd import _lib
+def test_weighted_gauss_seidel_smoothers_build_and_match_the_oracle(la, h1_k2):
+    """hypre's relax types 2 / 4 / 6 switch branches for relax_weight != 1 (and omega != 1 for type 6); the reference forwards both keys
+    unconditionally (ParELAG_HypreSmootherWrapper.cpp:28-33).  Refused until round 4; now the oracle restates the branches and the device runs
+    them (bit for bit: tests/test_gpu_sweeps.py); here one sweep of each against the oracle on the level operator."""
     A, _, _ = h1_k2
-    dA = la.ParallelCSRMatrix.from_scipy(A)
-    for stype, params in ((2, {"Damping Factor": 0.8}), (4, {"Damping Factor": 1.2}), (6, {"Damping Factor": 0.9}), (6, {"Omega": 1.3})):
-        with pytest.raises(_lib.ElagHipError) as ei:
-            la.HypreSmootherWrapper(dA, stype, params)
-        assert ei.value.code == 1, (stype, params, ei.value)                    # ELAG_HIP_ERR_ARG
-        with pytest.raises(NotImplementedError):
-            orc.OSmoother(orc.OParCSR(orc.diag_first(A)), type=stype, weight=params.get("Damping Factor", 1.0), omega=params.get("Omega", 1.0))
-    la.HypreSmootherWrapper(dA, 2, {"Damping Factor": 1.0, "Omega": 1.3})       # omega is free for types 2 / 4 with weight 1
+    Ad = orc.diag_first(A)
+    dA = la.ParallelCSRMatrix.from_scipy(Ad)
+    rng = np.random.default_rng(8)
+    f, u0 = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+    for stype, params in ((2, {"Damping Factor": 0.8}), (4, {"Damping Factor": 1.2}), (6, {"Damping Factor": 0.9}), (6, {"Omega": 1.3}),
+                          (2, {"Damping Factor": 1.0, "Omega": 1.3})):
+        S = la.HypreSmootherWrapper(dA, stype, params)
+        ref = orc.OSmoother(orc.OParCSR(Ad), type=stype, weight=params.get("Damping Factor", 1.0), omega=params.get("Omega", 1.0))
+        u, ur = u0.copy(), u0.copy()
+        S.Mult(f, u); ref.Mult(f, ur)
+        assert np.array_equal(u, ur), (stype, params)
+
+
+def test_vcycle_with_a_weighted_gauss_seidel_smoother(la, h1_k2):
+    """the whole cycle with "L1 Gauss-Seidel", "Damping Factor" 0.8 (hypre's scaled SSOR branch) against the oracle's cycle"""
+    A, Ps, _ = h1_k2
+    H = device_hierarchy(la, A, Ps, "L1 Gauss-Seidel", {"Damping Factor": 0.8})
+    ref = oracle_py_hierarchy(oracle_h1_hierarchy(A, Ps, smoother=2, weight=0.8))
+    b = np.random.default_rng(9).standard_normal(A.shape[0])
+    x, xr = np.zeros_like(b), np.zeros_like(b)
+    H.Mult(b, x)
+    ref.Mult(b, xr)
+    assert np.max(np.abs(x - xr)) <= 1e-11 * np.max(np.abs(xr))
 
 
 # ---- the V-cycle -----------------------------------------------------------------------------------------
