@@ -154,6 +154,14 @@ void DevCSR::alloc(int nr, int nc, int64_t nz)
     alloc_entries(nz);
 }
 
+namespace {
+// the zero pads of a CSR's column and value arrays in ONE launch (two fill kernels before: a setup is made of hundreds of these)
+__global__ void csr_pad_kernel(int *__restrict__ Jpad, double *__restrict__ apad)
+{
+    if (threadIdx.x < 4) { Jpad[threadIdx.x] = 0; apad[threadIdx.x] = 0.0; }
+}
+}  // namespace
+
 void DevCSR::alloc_entries(int64_t nz)
 {
     dev_free(J); dev_free(a);
@@ -161,8 +169,8 @@ void DevCSR::alloc_entries(int64_t nz)
     J = dev_alloc<int>((size_t)nz + 4);
     a = dev_alloc<double>((size_t)nz + 4);
     // zero pad: the stream kernel's 16-byte loads may run up to 3 entries past nnz
-    ELAG_HIP_CHECK(hipMemsetAsync(J + nz, 0, 4 * sizeof(int), ctx().stream));
-    ELAG_HIP_CHECK(hipMemsetAsync(a + nz, 0, 4 * sizeof(double), ctx().stream));
+    hipLaunchKernelGGL(csr_pad_kernel, dim3(1), dim3(64), 0, ctx().stream, J + nz, a + nz);
+    ELAG_LAUNCH_CHECK();
 }
 
 void DevCSR::set_empty(int nr, int nc)

@@ -152,7 +152,7 @@ double reduce_sum_sq(int64_t n, const double *a);
 double reduce_max(int64_t n, const double *a);
 
 // ---- sparse setup (two-pass, wave-level) -------------------------------------------------------
-void exclusive_scan(const int *in, int *out, int n);  // out has n+1 entries, out[n] = total
+void exclusive_scan(const int *in, int *out, int n, int *d_max = nullptr, int *d_total = nullptr);  // out has n+1 entries, out[n] = total; d_max (zeroed by the caller): the largest element, d_total: a copy of the total
 void csr_transpose(const DevCSR &A, DevCSR &AT);
 void csr_sort_rows(DevCSR &A);
 // C = A*B, columns ascending.  spmv_plan = false for an intermediate that is only ever an operand of another product (no SpMV

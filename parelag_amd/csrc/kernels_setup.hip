@@ -66,51 +66,95 @@ __device__ __forceinline__ int block_excl_scan(int v, int *sh /*>= 5 ints*/, int
     return off + incl - v;
 }
 
-__global__ __launch_bounds__(kBlock) void scan_block_sums(const int *__restrict__ in, int n, int *__restrict__ bsum)
+constexpr int kScanDirectBlocks = 8192;            // up to this many blocks (8 M elements) the final pass adds up the block sums itself
+
+// bmax (optional): the block's largest element, for callers that scan row lengths and want the longest row with it (the final pass's last
+// block folds the blocks' maxima: one atomic per wavefront on one word was 1 272 serialised atomics, 12 us, at 324 k rows)
+__global__ __launch_bounds__(kBlock) void scan_block_sums(const int *__restrict__ in, int n, int *__restrict__ bsum, int *__restrict__ bmax)
 {
+    __shared__ int shm[kBlock / 64];
     __shared__ int sh[8];
     const int base = blockIdx.x * 1024 + threadIdx.x * 4;
-    int s = 0;
+    int s = 0, mx = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++)
-        if (base + q < n) s += in[base + q];
+        if (base + q < n) { const int v = in[base + q]; s += v; mx = max(mx, v); }
     int tot;
     block_excl_scan(s, sh, &tot);
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+    if (bmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+        if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kBlock / 64; w++) mx = max(mx, shm[w]);
+            bmax[blockIdx.x] = mx;
+        }
+    }
 }
 
-__global__ __launch_bounds__(kBlock) void scan_block_final(const int *__restrict__ in, int n, const int *__restrict__ boff,
-                                                           int *__restrict__ out, int write_total)
+// boff: the blocks' offsets (scanned block sums); or bsum: the block sums themselves -- a block then adds up the sums in front of it (a few
+// thousand words out of L2: one launch and one scan level less; every setup phase is made of these scans)
+__global__ __launch_bounds__(kBlock) void scan_block_final(const int *__restrict__ in, int n, const int *__restrict__ boff, const int *__restrict__ bsum,
+                                                           int *__restrict__ out, int write_total, int *__restrict__ maxout = nullptr,
+                                                           int *__restrict__ total_copy = nullptr, const int *__restrict__ bmax = nullptr)
 {
     __shared__ int sh[8];
     const int base = blockIdx.x * 1024 + threadIdx.x * 4;
     int v[4], s = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) { v[q] = (base + q < n) ? in[base + q] : 0; s += v[q]; }
+    if (maxout && (!bmax || blockIdx.x == gridDim.x - 1)) {
+        // the one-block scan (no sums kernel in front): its own elements; otherwise the last block folds the blocks' maxima
+        int mx = 0;
+        if (!bmax) mx = max(max(v[0], v[1]), max(v[2], v[3]));
+        else for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock) mx = max(mx, bmax[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+        if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(maxout, mx);
+    }
+    int front = boff ? boff[blockIdx.x] : 0;
+    if (bsum) {
+        int part = 0;
+        for (int i = threadIdx.x; i < (int)blockIdx.x; i += kBlock) part += bsum[i];
+        block_excl_scan(part, sh, &front);
+    }
     int tot;
-    int off = block_excl_scan(s, sh, &tot) + (boff ? boff[blockIdx.x] : 0);
+    int off = block_excl_scan(s, sh, &tot) + front;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         if (base + q < n) out[base + q] = off;
         off += v[q];
     }
-    if (write_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) out[n] = off;
+    if (write_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) { out[n] = off; if (total_copy) *total_copy = off; }
 }
 
 }  // namespace
 
-void exclusive_scan(const int *in, int *out, int n)
+// d_max (optional, a device word the caller has zeroed): receives the largest element; d_total (optional): a copy of out[n]
+void exclusive_scan(const int *in, int *out, int n, int *d_max, int *d_total)
 {
     hipStream_t st = ctx().stream;
-    if (n == 0) { ELAG_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(int), st)); return; }
+    if (n == 0) {
+        ELAG_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(int), st));
+        if (d_total) ELAG_HIP_CHECK(hipMemsetAsync(d_total, 0, sizeof(int), st));
+        return;
+    }
     const int nb = (n + 1023) / 1024;
     if (nb == 1) {
-        hipLaunchKernelGGL(scan_block_final, dim3(1), dim3(kBlock), 0, st, in, n, (const int *)nullptr, out, 1);
+        hipLaunchKernelGGL(scan_block_final, dim3(1), dim3(kBlock), 0, st, in, n, (const int *)nullptr, (const int *)nullptr, out, 1, d_max, d_total);
+    } else if (nb <= kScanDirectBlocks) {
+        Temp<int> bsum((size_t)nb), bmax(d_max ? (size_t)nb : 1);
+        hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(kBlock), 0, st, in, n, bsum.p, d_max ? bmax.p : (int *)nullptr);
+        hipLaunchKernelGGL(scan_block_final, dim3(nb), dim3(kBlock), 0, st, in, n, (const int *)nullptr, (const int *)bsum.p, out, 1, d_max, d_total,
+                           d_max ? (const int *)bmax.p : (const int *)nullptr);
     } else {
-        Temp<int> bsum((size_t)nb), boff((size_t)nb + 1);
-        hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(kBlock), 0, st, in, n, bsum.p);
+        Temp<int> bsum((size_t)nb), boff((size_t)nb + 1), bmax(d_max ? (size_t)nb : 1);
+        hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(kBlock), 0, st, in, n, bsum.p, d_max ? bmax.p : (int *)nullptr);
         exclusive_scan(bsum, boff, nb);
-        hipLaunchKernelGGL(scan_block_final, dim3(nb), dim3(kBlock), 0, st, in, n, (const int *)boff.p, out, 1);
+        hipLaunchKernelGGL(scan_block_final, dim3(nb), dim3(kBlock), 0, st, in, n, (const int *)boff.p, (const int *)nullptr, out, 1, d_max, d_total,
+                           d_max ? (const int *)bmax.p : (const int *)nullptr);
     }
     ELAG_LAUNCH_CHECK();
 }
@@ -156,15 +200,22 @@ __global__ __launch_bounds__(kBlock) void scan64_block_sums(const i64 *__restric
     block_excl_scan64(s, sh, &tot);
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(kBlock) void scan64_block_final(const i64 *__restrict__ in, int n, const i64 *__restrict__ boff, i64 *__restrict__ out)
+__global__ __launch_bounds__(kBlock) void scan64_block_final(const i64 *__restrict__ in, int n, const i64 *__restrict__ boff, const i64 *__restrict__ bsum,
+                                                             i64 *__restrict__ out)
 {
     __shared__ i64 sh[4];
     const int base = blockIdx.x * 1024 + threadIdx.x * 4;
     i64 v[4], s = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) { v[q] = (base + q < n) ? in[base + q] : 0; s += v[q]; }
+    i64 front = boff ? boff[blockIdx.x] : 0;
+    if (bsum) {
+        i64 part = 0;
+        for (int i = threadIdx.x; i < (int)blockIdx.x; i += kBlock) part += bsum[i];
+        block_excl_scan64(part, sh, &front);
+    }
     i64 tot;
-    i64 off = block_excl_scan64(s, sh, &tot) + (boff ? boff[blockIdx.x] : 0);
+    i64 off = block_excl_scan64(s, sh, &tot) + front;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         if (base + q < n) out[base + q] = off;
@@ -178,12 +229,16 @@ void exclusive_scan64(const i64 *in, i64 *out, int n)
     if (n == 0) { ELAG_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(i64), st)); return; }
     const int nb = (n + 1023) / 1024;
     if (nb == 1) {
-        hipLaunchKernelGGL(scan64_block_final, dim3(1), dim3(kBlock), 0, st, in, n, (const i64 *)nullptr, out);
+        hipLaunchKernelGGL(scan64_block_final, dim3(1), dim3(kBlock), 0, st, in, n, (const i64 *)nullptr, (const i64 *)nullptr, out);
+    } else if (nb <= kScanDirectBlocks) {
+        Temp<i64> bsum((size_t)nb);
+        hipLaunchKernelGGL(scan64_block_sums, dim3(nb), dim3(kBlock), 0, st, in, n, bsum.p);
+        hipLaunchKernelGGL(scan64_block_final, dim3(nb), dim3(kBlock), 0, st, in, n, (const i64 *)nullptr, (const i64 *)bsum.p, out);
     } else {
         Temp<i64> bsum((size_t)nb), boff((size_t)nb + 1);
         hipLaunchKernelGGL(scan64_block_sums, dim3(nb), dim3(kBlock), 0, st, in, n, bsum.p);
         exclusive_scan64(bsum, boff, nb);
-        hipLaunchKernelGGL(scan64_block_final, dim3(nb), dim3(kBlock), 0, st, in, n, (const i64 *)boff.p, out);
+        hipLaunchKernelGGL(scan64_block_final, dim3(nb), dim3(kBlock), 0, st, in, n, (const i64 *)boff.p, (const i64 *)nullptr, out);
     }
     ELAG_LAUNCH_CHECK();
 }
@@ -1761,10 +1816,10 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
             ELAG_LAUNCH_CHECK();
             if (keep) return;                        // the product stays where its kernels wrote it
             int *CI = dev_alloc<int>((size_t)n + 1);
-            exclusive_scan(rownnz, CI, n);
             int *hnnz = reinterpret_cast<int *>(ctx().h_scalar + 10);
             Temp<int> longest(1);
-            if (spmv_plan) longest_row(n, CI, longest.p);          // (the result's longest row rides along: no kernel + drain for it in choose_spmv_shape)
+            if (spmv_plan) ELAG_HIP_CHECK(hipMemsetAsync(longest.p, 0, sizeof(int), st));
+            exclusive_scan(rownnz, CI, n, spmv_plan ? longest.p : nullptr);          // (the result's longest row rides along with the scan: no kernel + drain for it in choose_spmv_shape)
             ELAG_HIP_CHECK(hipMemcpyAsync(hnnz, CI + n, sizeof(int), hipMemcpyDeviceToHost, st));
             if (spmv_plan) ELAG_HIP_CHECK(hipMemcpyAsync(hnnz + 1, longest.p, sizeof(int), hipMemcpyDeviceToHost, st));
             ELAG_HIP_CHECK(hipStreamSynchronize(st));
@@ -1998,7 +2053,7 @@ bool rap_fused(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, boo
     if ((unsigned long long)nr * kStride >= (1ull << 31) || (unsigned long long)nr * kStride * 12ull > kRapEllScratch) return false;
     if (R.max_row_nnz > 64) return false;                               // (known to hold a row of more than 64 children)
     ensure_ell(P, W);
-    Temp<int> rn((size_t)nr), ctl(16), longC(1), Ju((size_t)nr * kStride);
+    Temp<int> rn((size_t)nr), ctl(16), Ju((size_t)nr * kStride);
     Temp<double> au((size_t)nr * kStride);
     ELAG_HIP_CHECK(hipMemsetAsync(ctl, 0, 16 * sizeof(int), st));
     ELAG_HIP_CHECK(hipMemsetAsync(rn, 0, sizeof(int) * (size_t)nr, st));
@@ -2017,10 +2072,9 @@ bool rap_fused(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, boo
 #undef ELAG_FUSED_LAUNCH
     ELAG_LAUNCH_CHECK();
     int *CI = dev_alloc<int>((size_t)nr + 1);
-    exclusive_scan(rn, CI, nr);
-    if (spmv_plan) longest_row(nr, CI, longC.p);
-    hipLaunchKernelGGL(rap_gather_kernel, dim3(1), dim3(64), 0, st, ctl.p, (const int *)(CI + nr), spmv_plan ? (const int *)longC.p : (const int *)nullptr, (const int *)nullptr,
-                       (const int *)nullptr);
+    // the rows' offsets, with nnz(C) -> ctl[5] and the longest row -> ctl[6] by the scan's own kernels (ctl was zeroed above; three scan kernels,
+    // a fill, a row-length maximum and a gather kernel before: 35 of the ~125 us between the product kernel and the result)
+    exclusive_scan(rn, CI, nr, spmv_plan ? ctl.p + 6 : nullptr, ctl.p + 5);
     int *h = reinterpret_cast<int *>(ctx().h_scalar + 10);
     ELAG_HIP_CHECK(hipMemcpyAsync(h, ctl.p, 9 * sizeof(int), hipMemcpyDeviceToHost, st));
     ELAG_HIP_CHECK(hipStreamSynchronize(st));

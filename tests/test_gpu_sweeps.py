@@ -195,12 +195,12 @@ def test_hiptmair_with_the_reference_s_gauss_seidel_smoothers(la):
     assert np.max(np.abs(x - xr)) <= 1e-11 * np.max(np.abs(xr))
 
 
-@pytest.mark.parametrize("relax_type", [2, 6])
+@pytest.mark.parametrize("relax_type,weight,omega", [(2, 1.0, 1.0), (6, 1.0, 1.0), (2, 0.8, 1.2), (6, 0.9, 1.3)])
 @pytest.mark.parametrize("world", [2, 3])
-def test_distributed_sweep_freezes_the_ghost_values(h1_k2, relax_type, world):
+def test_distributed_sweep_freezes_the_ghost_values(h1_k2, relax_type, weight, omega, world):
     """hybrid Gauss-Seidel across ranks (hypre_ParCSRRelax 2 / BoomerAMGRelax 6): every rank sweeps its own rows with the
     neighbours' values as they were when the sweep began -- in-process device ranks against the oracle's loop fed with exactly
-    those ghost values, two sweeps (so the second one sees the neighbours' first)"""
+    those ghost values, two sweeps (so the second one sees the neighbours' first); also hypre's weighted branches"""
     from parelag_amd import linalg as la, partition
     from tests.test_gpu_multirank import run_ranks
     A, Ps, seq = h1_k2
@@ -214,7 +214,7 @@ def test_distributed_sweep_freezes_the_ghost_values(h1_k2, relax_type, world):
         r = dist.rank
         p = dict(parts[r]); p["diag"] = orc.diag_first(p["diag"])
         M = la.ParallelCSRMatrix.from_parts(p)
-        S = la.HypreSmootherWrapper(M, relax_type, {"Sweeps": 2})
+        S = la.HypreSmootherWrapper(M, relax_type, {"Sweeps": 2, "Damping Factor": weight, "Omega": omega})
         lo, hi = int(starts[r]), int(starts[r + 1])
         u = u0[lo:hi].copy()
         S.Mult(f[lo:hi], u)
@@ -231,7 +231,7 @@ def test_distributed_sweep_freezes_the_ghost_values(h1_k2, relax_type, world):
     sm = []
     for r, p in enumerate(parts):
         M = orc.oparcsr_from_part(dict(p, diag=orc.diag_first(p["diag"])), ex[r])
-        sm.append(orc.OSmoother(M, type=relax_type, sweeps=1))
+        sm.append(orc.OSmoother(M, type=relax_type, sweeps=1, weight=weight, omega=omega))
     ug = u0.copy()
     for _ in range(2):
         for e in ex:
