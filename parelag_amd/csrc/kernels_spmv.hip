@@ -480,25 +480,69 @@ __global__ __launch_bounds__(THREADS) void spmv_probe_xc_kernel(
     spmv_xc_body<false, THREADS>(nrows, I, a, lidx, block_row, uoff, ucols, oI, cap, p);
 }
 
-// One workgroup per window: sort the window's columns in LDS (bitonic), mark the first element of every run, scan.
+// One workgroup per window: the window's DISTINCT columns through a hash table in LDS, sorted (bitonic, over the few hundred distinct columns
+// only), every entry's position in that list looked up through the table.  (Until round 4 the kernel sorted all the window's ENTRIES, padded to
+// the next power of two -- 4 096 keys, 78 barrier-separated stages of 8 compare-exchanges per thread for a 2 304-entry window -- and was 2.9 ms
+// of a 16.4 ms hierarchy build at cube456 x5.)  The result -- sorted distinct columns, 16-bit positions -- does not depend on the insertion order.
 // fill == 0: a SAMPLE -- workgroup b looks at window b * step and writes ucount[2 b] = its number of distinct columns, ucount[2 b + 1] = its
 // entries.  fill == 1: ucols (at uoff[c]) / lidx are written.  fill == 2: the one full pass of xc_build -- ucount[c], lidx and the window's
 // columns at ucols + c * step (a slot per window; compacted once the counts are scanned).
-// CAP: entries per window the builder handles (window + longest row + 8 <= CAP); 4096 for 2048-entry windows, 8192 for 4096
+// CAP: entries per window the builder handles (window + longest row + 8 <= CAP) = slots of the table; 4096 for 2048-entry windows, 8192 for 4096
 template <int CAP>
 __global__ __launch_bounds__(kBlock) void xc_build_kernel(const int *__restrict__ block_row, const int *__restrict__ J, int *__restrict__ ucount,
                                                           const int *__restrict__ uoff, int *__restrict__ ucols,
                                                           unsigned short *__restrict__ lidx, int fill, int step)
 {
-    __shared__ int keys[CAP];
-    __shared__ unsigned short pos[CAP];
-    __shared__ int part[kBlock];
+    constexpr int LOG2CAP = CAP == 4096 ? 12 : 13;
+    static_assert((1 << LOG2CAP) == CAP, "table sizes are 4096 and 8192");
+    __shared__ int hkey[CAP];                    // the table's keys (-1: empty)
+    __shared__ unsigned short hval[CAP];         // ... and each key's position in the sorted list
+    __shared__ int ukeys[CAP];                   // the distinct columns, sorted in place
+    __shared__ int wsum[kBlock / 64];
     const int c = fill == 0 ? (int)blockIdx.x * step : (int)blockIdx.x;
     const int kbeg = block_row[2 * c + 1], kend = block_row[2 * c + 3];
     const int len = kend - kbeg;
-    int npow = 256;
-    while (npow < len) npow <<= 1;
-    for (int i = threadIdx.x; i < npow; i += kBlock) keys[i] = i < len ? J[kbeg + i] : 0x7fffffff;
+    auto slot_of = [](int col) { return (int)(((unsigned)col * 2654435761u) >> (32 - LOG2CAP)); };
+    for (int i = threadIdx.x; i < CAP; i += kBlock) hkey[i] = -1;
+    __syncthreads();
+    for (int e = threadIdx.x; e < len; e += kBlock) {
+        const int col = J[kbeg + e];
+        int h = slot_of(col);
+        for (;;) {
+            const int prev = atomicCAS(&hkey[h], -1, col);
+            if (prev == -1 || prev == col) break;
+            h = (h + 1) & (CAP - 1);
+        }
+    }
+    __syncthreads();
+    // the occupied slots, compacted: a thread owns CAP / kBlock consecutive slots
+    constexpr int PER = CAP / kBlock;
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < PER; q++) cnt += hkey[threadIdx.x * PER + q] >= 0 ? 1 : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if ((int)(threadIdx.x & 63) >= o) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int off = incl - cnt, nu = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) {
+        const int v = wsum[w];
+        if (w < (int)(threadIdx.x >> 6)) off += v;
+        nu += v;
+    }
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const int k = hkey[threadIdx.x * PER + q];
+        if (k >= 0) ukeys[off++] = k;
+    }
+    int npow = 64;
+    while (npow < nu) npow <<= 1;
+    for (int i = nu + (int)threadIdx.x; i < npow; i += kBlock) ukeys[i] = 0x7fffffff;
     __syncthreads();
     for (int size = 2; size <= npow; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -506,40 +550,30 @@ __global__ __launch_bounds__(kBlock) void xc_build_kernel(const int *__restrict_
                 const int lo = 2 * t - (t & (stride - 1));
                 const int hi = lo + stride;
                 const bool up = ((lo & size) == 0);
-                const int a = keys[lo], b = keys[hi];
-                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+                const int a = ukeys[lo], b = ukeys[hi];
+                if ((a > b) == up) { ukeys[lo] = b; ukeys[hi] = a; }
             }
             __syncthreads();
         }
-    // run starts among the first `len` sorted keys; each thread owns a contiguous chunk
-    const int per = npow / kBlock;
-    const int b0 = threadIdx.x * per;
-    int cnt = 0;
-    for (int i = b0; i < b0 + per; i++)
-        if (i < len && (i == 0 || keys[i] != keys[i - 1])) cnt++;
-    part[threadIdx.x] = cnt;
-    __syncthreads();
     if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int t = 0; t < kBlock; t++) { const int v = part[t]; part[t] = acc; acc += v; }
-        if (fill == 0) { ucount[2 * blockIdx.x] = acc; ucount[2 * blockIdx.x + 1] = len; }
-        if (fill == 2) ucount[c] = acc;
+        if (fill == 0) { ucount[2 * blockIdx.x] = nu; ucount[2 * blockIdx.x + 1] = len; }
+        if (fill == 2) ucount[c] = nu;
     }
-    __syncthreads();
     if (!fill) return;
-    int run = part[threadIdx.x];   // distinct columns before this chunk
     const long long u0 = fill == 2 ? (long long)c * step : (long long)uoff[c];
-    for (int i = b0; i < b0 + per; i++) {
-        if (i >= len) break;
-        if (i == 0 || keys[i] != keys[i - 1]) { ucols[u0 + run] = keys[i]; run++; }
-        pos[i] = (unsigned short)(run - 1);
+    for (int i = threadIdx.x; i < nu; i += kBlock) {
+        const int col = ukeys[i];
+        ucols[u0 + i] = col;
+        int h = slot_of(col);
+        while (hkey[h] != col) h = (h + 1) & (CAP - 1);
+        hval[h] = (unsigned short)i;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < len; e += kBlock) {
         const int col = J[kbeg + e];
-        int lo = 0, hi = len;   // first sorted position holding col
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < col) lo = mid + 1; else hi = mid; }
-        lidx[kbeg + e] = pos[lo];
+        int h = slot_of(col);
+        while (hkey[h] != col) h = (h + 1) & (CAP - 1);
+        lidx[kbeg + e] = hval[h];
     }
 }
 
