@@ -91,6 +91,8 @@ struct Context {
     double *reduce_part = nullptr;      // partial sums of the two-stage reductions
     double *d_scalar = nullptr;         // device scratch for reductions (16 doubles)
     double *h_scalar = nullptr;         // pinned mirror
+    char *h_stage = nullptr;            // pinned staging buffer of host_from_dev (kHostStage bytes): read-backs beyond a few tens of KB into pageable
+                                        // memory take the runtime's pin-the-user-buffer path, 2-8 ms the first time a buffer is seen
     int gs_blocks = 0;                  // elag_hip_set_gs_hybrid_blocks (0: ELAG_HIP_GS_BLOCKS, else 1)
     long long n_exchanges = 0, n_allreduces = 0;   // data-plane rounds issued by this rank (neighbour exchanges with a remote peer, device all-reduces)
 };
@@ -148,21 +150,26 @@ void dev_free(T *&p)
     if (p) raw_free(const_cast<void *>(static_cast<const void *>(p)));
     p = nullptr;
 }
+void stage_h2d(void *dev_dst, const void *host_src, size_t bytes);
 template <class T>
 T *dev_from_host(const T *h, size_t n)
 {
     T *p = dev_alloc<T>(n);
-    if (n) ELAG_HIP_CHECK(hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, ctx().stream));
+    if (n) stage_h2d(p, h, n * sizeof(T));
     return p;
 }
+constexpr size_t kHostStage = size_t(4) << 20;
+// Copies between host and device by KERNELS through the context's pinned, device-visible staging buffer (a chunk at a time; synchronous): the
+// setup path's read-backs and small uploads.  The copy API's own paths (DMA queues, staging pools) grow lazily and each growth is a 6-7 ms
+// stall of one hipMemcpyAsync somewhere in a process's first few thousand copies -- measured as idle gaps in the kernel traces of first
+// hierarchy builds, at call sites that moved with the number of copies issued before them.  ELAG_HIP_KERNEL_COPIES=0: the copy API.
+void stage_d2h(void *host_dst, const void *dev_src, size_t bytes);
+void stage_h2d(void *dev_dst, const void *host_src, size_t bytes);
 template <class T>
 std::vector<T> host_from_dev(const T *d, size_t n)
 {
     std::vector<T> v(n);
-    if (n) {
-        ELAG_HIP_CHECK(hipMemcpyAsync(v.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, ctx().stream));
-        ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
-    }
+    if (n) stage_d2h(v.data(), d, n * sizeof(T));
     return v;
 }
 

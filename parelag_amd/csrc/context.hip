@@ -155,6 +155,77 @@ void DevCSR::alloc(int nr, int nc, int64_t nz)
 }
 
 namespace {
+__global__ void stage_copy_kernel(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, size_t bytes)
+{
+    // 16-byte words where both ends allow it (the staging buffer and hipMalloc blocks are aligned; sub-ranges need not be), bytes otherwise
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const size_t nw = bytes / 16;
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+        for (size_t i = tid; i < nw; i += nth) d4[i] = s4[i];
+        for (size_t i = nw * 16 + tid; i < bytes; i += nth) dst[i] = src[i];
+    } else if ((((uintptr_t)src | (uintptr_t)dst) & 3) == 0) {
+        const size_t nw = bytes / 4;
+        const unsigned *s1 = reinterpret_cast<const unsigned *>(src);
+        unsigned *d1 = reinterpret_cast<unsigned *>(dst);
+        for (size_t i = tid; i < nw; i += nth) d1[i] = s1[i];
+        for (size_t i = nw * 4 + tid; i < bytes; i += nth) dst[i] = src[i];
+    } else {
+        for (size_t i = tid; i < bytes; i += nth) dst[i] = src[i];
+    }
+}
+bool kernel_copies()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ELAG_HIP_KERNEL_COPIES"); v = e ? (atoi(e) != 0) : 1; }
+    return v != 0;
+}
+}  // namespace
+
+void stage_d2h(void *host_dst, const void *dev_src, size_t bytes)
+{
+    Context &c = ctx();
+    if (bytes == 0) return;
+    if (!c.h_stage || !kernel_copies()) {
+        ELAG_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c.stream));
+        ELAG_HIP_CHECK(hipStreamSynchronize(c.stream));
+        return;
+    }
+    const unsigned char *src = static_cast<const unsigned char *>(dev_src);
+    unsigned char *dst = static_cast<unsigned char *>(host_dst);
+    for (size_t off = 0; off < bytes; off += kHostStage) {
+        const size_t len = std::min(kHostStage, bytes - off);
+        const unsigned g = (unsigned)std::min<size_t>((len / 16 + 255) / 256 + 1, 1024);
+        hipLaunchKernelGGL(stage_copy_kernel, dim3(g), dim3(256), 0, c.stream, src + off, reinterpret_cast<unsigned char *>(c.h_stage), len);
+        ELAG_LAUNCH_CHECK();
+        ELAG_HIP_CHECK(hipStreamSynchronize(c.stream));
+        memcpy(dst + off, c.h_stage, len);
+    }
+}
+
+void stage_h2d(void *dev_dst, const void *host_src, size_t bytes)
+{
+    Context &c = ctx();
+    if (bytes == 0) return;
+    if (!c.h_stage || !kernel_copies() || bytes > 8 * kHostStage) {           // (large uploads: the copy API's pipelined path)
+        ELAG_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c.stream));
+        return;
+    }
+    const unsigned char *src = static_cast<const unsigned char *>(host_src);
+    unsigned char *dst = static_cast<unsigned char *>(dev_dst);
+    for (size_t off = 0; off < bytes; off += kHostStage) {
+        const size_t len = std::min(kHostStage, bytes - off);
+        ELAG_HIP_CHECK(hipStreamSynchronize(c.stream));                        // (the staging buffer's previous use)
+        memcpy(c.h_stage, src + off, len);
+        const unsigned g = (unsigned)std::min<size_t>((len / 16 + 255) / 256 + 1, 1024);
+        hipLaunchKernelGGL(stage_copy_kernel, dim3(g), dim3(256), 0, c.stream, reinterpret_cast<const unsigned char *>(c.h_stage), dst + off, len);
+        ELAG_LAUNCH_CHECK();
+    }
+    ELAG_HIP_CHECK(hipStreamSynchronize(c.stream));                            // (the caller may reuse host_src; the staging buffer is free again)
+}
+
+namespace {
 // the zero pads of a CSR's column and value arrays in ONE launch (two fill kernels before: a setup is made of hundreds of these)
 __global__ void csr_pad_kernel(int *__restrict__ Jpad, double *__restrict__ apad)
 {
@@ -479,8 +550,12 @@ int elag_hip_init(int device)
         ELAG_HIP_CHECK(hipEventCreateWithFlags(&c.ev_halo, hipEventDisableTiming));
         ELAG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&c.d_scalar), 16 * sizeof(double)));
         ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c.h_scalar), 16 * sizeof(double), hipHostMallocDefault));
+        ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c.h_stage), kHostStage, hipHostMallocDefault));
         c.device = device;
         c.initialised = true;
+        // (Warming the copy API's paths here -- a few host <-> device copies of 16 B ... 1 MiB -- was tried and made things worse: the lazy growth it
+        //  triggers completes later and stalls some LATER copy for 6-7 ms, inside the first build of small hierarchies.  The setup path's read-backs
+        //  and small uploads go through kernels instead: stage_d2h / stage_h2d.)
         // The first slab of the setup scratch arena, here instead of inside the first sparse product: the arena grows by doubling from 64 MiB, and
         // on some boxes of the pool each of those hipMallocs costs 5-20 ms -- 20 of the 36 ms of a process's first cube456 x5 hierarchy
         // (profiles/r03_setup_probe_k5_after_S.txt).  ELAG_HIP_ARENA_MB (default: 2048, at most an eighth of the free memory; 0 = grow on demand).
@@ -535,6 +610,8 @@ int elag_hip_finalize(void)
         (void)hipFree(c.d_scalar);
         if (c.reduce_part) (void)hipFree(c.reduce_part);
         (void)hipHostFree(c.h_scalar);
+        if (c.h_stage) (void)hipHostFree(c.h_stage);
+        c.h_stage = nullptr;
         (void)hipEventDestroy(c.ev_pack);
         (void)hipEventDestroy(c.ev_halo);
         (void)hipStreamDestroy(c.stream);
