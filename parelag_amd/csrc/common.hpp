@@ -232,6 +232,13 @@ struct DevCSR {
     mutable int *ellJ = nullptr;
     mutable double *ella = nullptr;
     mutable int ellW = 0;
+    // "flat pack" of an operator of the flattened cycle (kernels_spmv.hip, flat_*_kernel): the first fpU * fpL entries of every row in the order
+    // the kernel's lanes read them -- entry u * fpL + lane of row r at ((r * fpU + u) * fpL + lane), column 0 / value 0.0 past the row's end --
+    // so that a row's first pass needs no row pointer: one dependent round trip less per stage.  Built by flat_segs_add_csr, dropped with the
+    // value-derived forms.
+    mutable int *fpJ = nullptr;
+    mutable double *fpa = nullptr;
+    mutable int fpL = 0, fpU = 0;
 
     static constexpr int kStreamNnz = 2048;     // entries per 256-thread workgroup
     static constexpr int kStreamMaxRow = 4096;  // longer rows fall back to the row-group kernel
@@ -251,6 +258,7 @@ struct DevCSR {
             o.lidx = nullptr; o.uoff = nullptr; o.ucols = nullptr; o.xc_state = 0; o.xc_block_row = nullptr; o.xc_nblocks = 0; o.xc_window = 0;
             Js = o.Js; sign_state = o.sign_state; o.Js = nullptr; o.sign_state = 0;
             ellJ = o.ellJ; ella = o.ella; ellW = o.ellW; o.ellJ = nullptr; o.ella = nullptr; o.ellW = 0;
+            fpJ = o.fpJ; fpa = o.fpa; fpL = o.fpL; fpU = o.fpU; o.fpJ = nullptr; o.fpa = nullptr; o.fpL = o.fpU = 0;
             o.I = o.J = nullptr; o.a = nullptr; o.block_row = nullptr; o.nnz = 0; o.nrows = o.ncols = 0; o.nblocks = 0;
         }
         return *this;
@@ -263,7 +271,7 @@ struct DevCSR {
         xc_block_row = nullptr; xc_nblocks = 0; xc_window = 0;
         xc_state = 0;
     }
-    void release_sign() const { dev_free(Js); sign_state = 0; dev_free(ellJ); dev_free(ella); ellW = 0; }   // every form derived from the VALUES
+    void release_sign() const { dev_free(Js); sign_state = 0; dev_free(ellJ); dev_free(ella); ellW = 0; dev_free(fpJ); dev_free(fpa); fpL = fpU = 0; }   // every form derived from the VALUES
     void release() { release_xc(); release_sign(); dev_free(I); dev_free(J); dev_free(a); dev_free(block_row); nblocks = 0; }
     void alloc(int nr, int nc, int64_t nz);
     void alloc_entries(int64_t nz);   // J / a (+pad) for a matrix whose I is already in place

@@ -88,6 +88,8 @@ struct FlatSegs {
     const double *a[kFlatSegs] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     const double *x[kFlatSegs] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double *out[kFlatSegs] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int *pJ[kFlatSegs] = {nullptr, nullptr, nullptr, nullptr, nullptr};        // the segment's flat pack (DevCSR::fpJ / fpa) or null
+    const double *pa[kFlatSegs] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 struct FlatSum {
     int nrows = 0, nterms = 0, lpr = 1;

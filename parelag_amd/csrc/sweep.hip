@@ -416,6 +416,8 @@ void SweepSmoother::setup()
     // parameter list ("Damping Factor" 1.0, "Omega" 1.0) and the tuned launch plan below; types 2 / 4 with omega != 1 run on it too (a factor
     // in the update); the weighted branches take one plain launch per dependency level (sweep_sor_level_kernel)
     sor = !kaczmarz && (weight != 1.0 || (omega != 1.0 && type == ELAG_HIP_SMOOTHER_GS));
+    dev_free(d_v);
+    if (sor) d_v = dev_alloc<double>((size_t)std::max(A->nrows(), 1));
     M = A;
     const int n = A->nrows();
     hipStream_t st = ctx().stream;
@@ -791,8 +793,7 @@ void SweepSmoother::sweep_sor(const double *f, double *u)
     if (n == 0) return;
     hipStream_t st = ctx().stream;
     const bool ho = M->offd.nnz > 0;
-    if (!d_v) d_v = dev_alloc<double>((size_t)n);
-    ELAG_HIP_CHECK(hipMemcpyAsync(d_v, u, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    ELAG_HIP_CHECK(hipMemcpyAsync(d_v, u, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));          // (d_v: allocated by setup -- a cycle may be under capture here)
     auto level = [&](int l, int dir) {
         const int r0 = h_lev_ptr[(size_t)l], r1 = h_lev_ptr[(size_t)l + 1];
         if (r1 == r0) return;
