@@ -239,6 +239,9 @@ struct DevCSR {
     mutable int *fpJ = nullptr;
     mutable double *fpa = nullptr;
     mutable int fpL = 0, fpU = 0;
+    // the column indices as 16-bit words (operators of the flattened cycle with at most 65 536 columns: 10 bytes per entry instead of 12 in
+    // kernels that are bound by the bytes they pull out of the caches); a pattern-derived form like the x-cache tables
+    mutable unsigned short *J16 = nullptr;
 
     static constexpr int kStreamNnz = 2048;     // entries per 256-thread workgroup
     static constexpr int kStreamMaxRow = 4096;  // longer rows fall back to the row-group kernel
@@ -259,6 +262,7 @@ struct DevCSR {
             Js = o.Js; sign_state = o.sign_state; o.Js = nullptr; o.sign_state = 0;
             ellJ = o.ellJ; ella = o.ella; ellW = o.ellW; o.ellJ = nullptr; o.ella = nullptr; o.ellW = 0;
             fpJ = o.fpJ; fpa = o.fpa; fpL = o.fpL; fpU = o.fpU; o.fpJ = nullptr; o.fpa = nullptr; o.fpL = o.fpU = 0;
+            J16 = o.J16; o.J16 = nullptr;
             o.I = o.J = nullptr; o.a = nullptr; o.block_row = nullptr; o.nnz = 0; o.nrows = o.ncols = 0; o.nblocks = 0;
         }
         return *this;
@@ -266,7 +270,7 @@ struct DevCSR {
     ~DevCSR() { release(); }
     void release_xc() const
     {
-        dev_free(lidx); dev_free(uoff); dev_free(ucols);
+        dev_free(lidx); dev_free(uoff); dev_free(ucols); dev_free(J16);
         if (xc_block_row && xc_block_row != block_row) dev_free(xc_block_row);
         xc_block_row = nullptr; xc_nblocks = 0; xc_window = 0;
         xc_state = 0;

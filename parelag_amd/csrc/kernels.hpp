@@ -90,6 +90,7 @@ struct FlatSegs {
     double *out[kFlatSegs] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     const int *pJ[kFlatSegs] = {nullptr, nullptr, nullptr, nullptr, nullptr};        // the segment's flat pack (DevCSR::fpJ / fpa) or null
     const double *pa[kFlatSegs] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const unsigned short *j16p[kFlatSegs] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // DevCSR::J16 of the segment's operator (null: none)
 };
 struct FlatSum {
     int nrows = 0, nterms = 0, lpr = 1;
@@ -100,6 +101,7 @@ struct FlatSum {
     const double *x[kFlatTerms] = {nullptr, nullptr, nullptr, nullptr};
     const double *yin = nullptr;
     double *out = nullptr;
+    const unsigned short *j16p[kFlatTerms] = {nullptr, nullptr, nullptr, nullptr};            // DevCSR::J16 of the term's operator (null: none)
 };
 void flat_segs_add_csr(FlatSegs &S, const DevCSR &A, const double *x, double *out);       // lanes from the rows' average length
 void flat_segs_add_dense(FlatSegs &S, int nrows, int ncols, const double *M, const double *x, double *out);

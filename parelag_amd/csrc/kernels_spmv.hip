@@ -1201,8 +1201,8 @@ namespace {
 // so the time of a launch is (entries) / (entries in flight per CU): four entries per lane instead of one let a wave cover 4 x 64
 // entries per trip (cube456 x3, stage 1 of the flattened cycle: 8.8 -> X us).
 constexpr int kFlatU = 4;
-template <int LPR, int U = kFlatU>
-__device__ __forceinline__ double flat_row_sum(int s, int e, int lane, const int *__restrict__ J, const double *__restrict__ a, const double *__restrict__ x)
+template <int LPR, int U = kFlatU, typename JT = int>
+__device__ __forceinline__ double flat_row_sum(int s, int e, int lane, const JT *__restrict__ J, const double *__restrict__ a, const double *__restrict__ x)
 {
     double sum = 0.0;
     for (int k0 = s + lane; k0 < e; k0 += U * LPR) {
@@ -1212,7 +1212,7 @@ __device__ __forceinline__ double flat_row_sum(int s, int e, int lane, const int
         for (int u = 0; u < U; u++) {
             const int k = k0 + u * LPR;
             j[u] = 0; av[u] = 0.0;
-            if (k < e) { j[u] = J[k]; av[u] = a[k]; }
+            if (k < e) { j[u] = (int)J[k]; av[u] = a[k]; }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -1247,7 +1247,7 @@ __device__ __forceinline__ double flat_row_sum_packed(int row, int lane, const i
     return sum;
 }
 
-template <int LPR, int U>
+template <int LPR, int U, bool J16>
 __device__ __forceinline__ void flat_seg_rows(unsigned blk, int nrows, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
                                               const int *__restrict__ pJ, const double *__restrict__ pa, const double *__restrict__ x, double *__restrict__ out)
 {
@@ -1255,12 +1255,14 @@ __device__ __forceinline__ void flat_seg_rows(unsigned blk, int nrows, const int
     const int row = (int)blk * GPB + (int)threadIdx.x / LPR;
     const int lane = threadIdx.x & (LPR - 1);
     if (row >= nrows) return;
-    const double part = pJ ? flat_row_sum_packed<LPR, U>(row, lane, I, J, a, pJ, pa, x) : flat_row_sum<LPR, U>(I[row], I[row + 1], lane, J, a, x);
+    const double part = J16 ? flat_row_sum<LPR, U, unsigned short>(I[row], I[row + 1], lane, reinterpret_cast<const unsigned short *>(J), a, x)
+                        : pJ ? flat_row_sum_packed<LPR, U>(row, lane, I, J, a, pJ, pa, x) : flat_row_sum<LPR, U>(I[row], I[row + 1], lane, J, a, x);
     const double sum = group_reduce<LPR>(part);
     if (lane == 0) out[row] = sum;
 }
 
-template <int U>
+// J16: the CSR segments' J arrays hold 16-bit words (every operator of the stage has at most 65 536 columns): 10 bytes per entry instead of 12
+template <int U, bool J16 = false>
 __global__ __launch_bounds__(kBlock) void flat_segs_kernel(const FlatSegs S)
 {
     __shared__ double sh[kBlock / 64];
@@ -1297,16 +1299,17 @@ __global__ __launch_bounds__(kBlock) void flat_segs_kernel(const FlatSegs S)
         if (threadIdx.x == 0) out[blk] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
         break;
     }
-    case 1: flat_seg_rows<1, U>(blk, nrows, I, J, a, pJ, pa, x, out); break;
-    case 2: flat_seg_rows<2, U>(blk, nrows, I, J, a, pJ, pa, x, out); break;
-    case 4: flat_seg_rows<4, U>(blk, nrows, I, J, a, pJ, pa, x, out); break;
-    case 8: flat_seg_rows<8, U>(blk, nrows, I, J, a, pJ, pa, x, out); break;
-    case 16: flat_seg_rows<16, U>(blk, nrows, I, J, a, pJ, pa, x, out); break;
-    case 32: flat_seg_rows<32, U>(blk, nrows, I, J, a, pJ, pa, x, out); break;
-    case 64: flat_seg_rows<64, U>(blk, nrows, I, J, a, pJ, pa, x, out); break;
+    case 1: flat_seg_rows<1, U, J16>(blk, nrows, I, J, a, pJ, pa, x, out); break;
+    case 2: flat_seg_rows<2, U, J16>(blk, nrows, I, J, a, pJ, pa, x, out); break;
+    case 4: flat_seg_rows<4, U, J16>(blk, nrows, I, J, a, pJ, pa, x, out); break;
+    case 8: flat_seg_rows<8, U, J16>(blk, nrows, I, J, a, pJ, pa, x, out); break;
+    case 16: flat_seg_rows<16, U, J16>(blk, nrows, I, J, a, pJ, pa, x, out); break;
+    case 32: flat_seg_rows<32, U, J16>(blk, nrows, I, J, a, pJ, pa, x, out); break;
+    case 64: flat_seg_rows<64, U, J16>(blk, nrows, I, J, a, pJ, pa, x, out); break;
     default: {
         // a workgroup per (long) row
-        double s = flat_row_sum<kBlock, U>(I[blk], I[blk + 1], (int)threadIdx.x, J, a, x);
+        double s = J16 ? flat_row_sum<kBlock, U, unsigned short>(I[blk], I[blk + 1], (int)threadIdx.x, reinterpret_cast<const unsigned short *>(J), a, x)
+                       : flat_row_sum<kBlock, U>(I[blk], I[blk + 1], (int)threadIdx.x, J, a, x);
         s = group_reduce<64>(s);
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
         __syncthreads();
@@ -1316,7 +1319,7 @@ __global__ __launch_bounds__(kBlock) void flat_segs_kernel(const FlatSegs S)
     }
 }
 
-template <int LPR, int NT, int U>
+template <int LPR, int NT, int U, bool J16 = false>
 __global__ __launch_bounds__(kBlock) void flat_sum_kernel(const FlatSum S)
 {
     constexpr int GPB = kBlock / LPR;
@@ -1331,22 +1334,24 @@ __global__ __launch_bounds__(kBlock) void flat_sum_kernel(const FlatSum S)
     if (lane == 0 && S.yin) y0 = S.yin[row];
     double sum = 0.0;
 #pragma unroll
-    for (int t = 0; t < NT; t++) sum += flat_row_sum<LPR, U>(s[t], e[t], lane, S.J[t], S.a[t], S.x[t]);
+    for (int t = 0; t < NT; t++)
+        sum += J16 ? flat_row_sum<LPR, U, unsigned short>(s[t], e[t], lane, reinterpret_cast<const unsigned short *>(S.J[t]), S.a[t], S.x[t])
+                   : flat_row_sum<LPR, U>(s[t], e[t], lane, S.J[t], S.a[t], S.x[t]);
     sum = group_reduce<LPR>(sum);
     if (lane == 0) S.out[row] = y0 + sum;
 }
 
-template <int NT, int U>
+template <int NT, int U, bool J16 = false>
 void flat_sum_dispatch(const FlatSum &S, hipStream_t st)
 {
     switch (S.lpr) {
-    case 1: hipLaunchKernelGGL((flat_sum_kernel<1, NT, U>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
-    case 2: hipLaunchKernelGGL((flat_sum_kernel<2, NT, U>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
-    case 4: hipLaunchKernelGGL((flat_sum_kernel<4, NT, U>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
-    case 8: hipLaunchKernelGGL((flat_sum_kernel<8, NT, U>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
-    case 16: hipLaunchKernelGGL((flat_sum_kernel<16, NT, U>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
-    case 32: hipLaunchKernelGGL((flat_sum_kernel<32, NT, U>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
-    default: hipLaunchKernelGGL((flat_sum_kernel<64, NT, U>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    case 1: hipLaunchKernelGGL((flat_sum_kernel<1, NT, U, J16>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    case 2: hipLaunchKernelGGL((flat_sum_kernel<2, NT, U, J16>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    case 4: hipLaunchKernelGGL((flat_sum_kernel<4, NT, U, J16>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    case 8: hipLaunchKernelGGL((flat_sum_kernel<8, NT, U, J16>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    case 16: hipLaunchKernelGGL((flat_sum_kernel<16, NT, U, J16>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    case 32: hipLaunchKernelGGL((flat_sum_kernel<32, NT, U, J16>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
+    default: hipLaunchKernelGGL((flat_sum_kernel<64, NT, U, J16>), dim3(S.grid), dim3(kBlock), 0, st, S); break;
     }
 }
 
@@ -1388,6 +1393,23 @@ __global__ void flat_pack_kernel(int nrows, int L, int U, const int *__restrict_
         pa[i] = has ? a[k] : 0.0;
     }
 }
+__global__ void j16_kernel(long long nnz, const int *__restrict__ J, unsigned short *__restrict__ J16)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) J16[i] = (unsigned short)J[i];
+}
+// the 16-bit copy of an operator's column indices (null where it has more than 65 536 columns, or with ELAG_HIP_FLAT_J16=0)
+const unsigned short *flat_j16(const DevCSR &A)
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("ELAG_HIP_FLAT_J16"); on = e ? (atoi(e) != 0) : 1; }
+    if (!on || A.ncols > 65536 || A.nnz == 0) return nullptr;
+    if (!A.J16) {
+        A.J16 = dev_alloc<unsigned short>((size_t)A.nnz + 8);
+        hipLaunchKernelGGL(j16_kernel, dim3((unsigned)std::min<long long>((A.nnz + 255) / 256, 4096)), dim3(256), 0, ctx().stream, (long long)A.nnz, (const int *)A.J, A.J16);
+        ELAG_LAUNCH_CHECK();
+    }
+    return A.J16;
+}
 bool flat_pack_enabled()
 {
     static int v = -1;
@@ -1408,6 +1430,7 @@ void flat_segs_add_csr(FlatSegs &S, const DevCSR &A, const double *x, double *ou
     S.nrows[i] = A.nrows; S.ncols[i] = A.ncols; S.lpr[i] = l;
     S.I[i] = A.I; S.J[i] = A.J; S.a[i] = A.a; S.x[i] = x; S.out[i] = out;
     S.pJ[i] = nullptr; S.pa[i] = nullptr;
+    S.j16p[i] = flat_j16(A);
     if (flat_pack_enabled() && l >= 1 && l <= 64 && A.nrows > 0 && A.nnz > 0 && A.ncols > 0) {
         // the rows' first passes in lane order (DevCSR::fpJ): once per operator and lane count
         const int U = flat_u();
@@ -1443,6 +1466,7 @@ void flat_sum_add(FlatSum &S, const DevCSR &A, const double *x)
     const int t = S.nterms++;
     S.nrows = A.nrows;
     S.I[t] = A.I; S.J[t] = A.J; S.a[t] = A.a; S.x[t] = x;
+    S.j16p[t] = flat_j16(A);
     S.grid += (unsigned)A.nnz;          // (entry count until flat_sum_finish)
 }
 
@@ -1463,6 +1487,17 @@ void flat_segs_launch(const FlatSegs &S0, const double *rhs, double *sol, hipStr
         S.x[i] = resident_in_host(S.x[i], rhs, sol);
         S.out[i] = const_cast<double *>(resident_in_host(S.out[i], rhs, sol));
     }
+    // 16-bit columns where every CSR segment of the stage has them (and no flat pack is in use: that form keeps 32-bit columns)
+    bool j16 = flat_u() == 4;
+    for (int i = 0; i < S.nsegs; i++)
+        if (S.lpr[i] != 0 && (!S.j16p[i] || S.pJ[i])) j16 = false;
+    if (j16) {
+        for (int i = 0; i < S.nsegs; i++)
+            if (S.lpr[i] != 0) S.J[i] = reinterpret_cast<const int *>(S.j16p[i]);
+        hipLaunchKernelGGL((flat_segs_kernel<4, true>), dim3(S.grid), dim3(kBlock), 0, st, S);
+        ELAG_LAUNCH_CHECK();
+        return;
+    }
     switch (flat_u()) {
     case 2: hipLaunchKernelGGL(flat_segs_kernel<2>, dim3(S.grid), dim3(kBlock), 0, st, S); break;
     case 8: hipLaunchKernelGGL(flat_segs_kernel<8>, dim3(S.grid), dim3(kBlock), 0, st, S); break;
@@ -1480,6 +1515,20 @@ void flat_sum_launch(const FlatSum &S0, const double *rhs, double *sol, hipStrea
     S.yin = resident_in_host(S.yin, rhs, sol);
     S.out = const_cast<double *>(resident_in_host(S.out, rhs, sol));
     const int u = flat_u();
+    bool j16 = u == 4;
+    for (int t = 0; t < S.nterms; t++)
+        if (!S.j16p[t]) j16 = false;
+    if (j16) {
+        for (int t = 0; t < S.nterms; t++) S.J[t] = reinterpret_cast<const int *>(S.j16p[t]);
+        switch (S.nterms) {
+        case 1: flat_sum_dispatch<1, 4, true>(S, st); break;
+        case 2: flat_sum_dispatch<2, 4, true>(S, st); break;
+        case 3: flat_sum_dispatch<3, 4, true>(S, st); break;
+        default: flat_sum_dispatch<4, 4, true>(S, st); break;
+        }
+        ELAG_LAUNCH_CHECK();
+        return;
+    }
 #define ELAG_FLAT_SUM(NT) (u == 2 ? flat_sum_dispatch<NT, 2>(S, st) : u == 8 ? flat_sum_dispatch<NT, 8>(S, st) : flat_sum_dispatch<NT, 4>(S, st))
     switch (S.nterms) {
     case 1: ELAG_FLAT_SUM(1); break;
