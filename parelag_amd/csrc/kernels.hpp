@@ -26,6 +26,7 @@ struct SpmvArgs {
     const double *s = nullptr, *s2 = nullptr;
     double alpha = 1.0;
     double *out = nullptr, *out2 = nullptr;
+    const double *o2s = nullptr;  // out2[i] = x[i] * o2s[i] (without cs; with cs out2 is the scaled operand x[i] * cs[i]): the operand of a product whose matrix carries the column scaling
     // row subset (multi-GPU overlap): rows == nullptr -> all rows [0,nrows)
     const int *rows = nullptr;
     int nrows_sel = 0;

@@ -97,7 +97,7 @@ __device__ __forceinline__ void spmv_fused_row(int row, int lane, const int *__r
         t *= sc0;
         t += p.beta * y0;
         p.out[p.out_perm ? p.out_perm[row] : row] = p.out_add ? p.out_add[p.out_perm[row]] + t : t;
-        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
+        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : (p.o2s ? x[row] * p.o2s[row] : x[row]);
     }
 }
 
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kBlock) void spmv_sign_kernel(int nrows, const int 
         t *= sc0;
         t += p.beta * y0;
         p.out[p.out_perm ? p.out_perm[row] : row] = p.out_add ? p.out_add[p.out_perm[row]] + t : t;
-        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
+        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : (p.o2s ? x[row] * p.o2s[row] : x[row]);
     }
 }
 
@@ -319,7 +319,7 @@ __device__ __forceinline__ void spmv_stream_body(
         t *= sc0;
         t += p.beta * y0;
         p.out[p.out_perm ? p.out_perm[row0] : row0] = p.out_add ? p.out_add[p.out_perm[row0]] + t : t;
-        if (p.out2) p.out2[row0] = HAS_CS ? x[row0] * p.cs[row0] : x[row0];
+        if (p.out2) p.out2[row0] = HAS_CS ? x[row0] * p.cs[row0] : (p.o2s ? x[row0] * p.o2s[row0] : x[row0]);
     }
     // blocks of short rows hold more than 256 rows: remaining rows the plain way
     for (int row = row0 + kBlock; row < r1; row += kBlock) {
@@ -333,7 +333,7 @@ __device__ __forceinline__ void spmv_stream_body(
         if (p.s) t *= p.s[row];
         if (p.yin) t += p.beta * p.yin[row];
         p.out[p.out_perm ? p.out_perm[row] : row] = p.out_add ? p.out_add[p.out_perm[row]] + t : t;
-        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
+        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : (p.o2s ? x[row] * p.o2s[row] : x[row]);
     }
 }
 
@@ -444,7 +444,7 @@ __device__ __forceinline__ void spmv_xc_body(
         t *= sc0;
         t += p.beta * y0;
         p.out[p.out_perm ? p.out_perm[row0] : row0] = p.out_add ? p.out_add[p.out_perm[row0]] + t : t;
-        if (p.out2) p.out2[row0] = HAS_CS ? x[row0] * p.cs[row0] : x[row0];
+        if (p.out2) p.out2[row0] = HAS_CS ? x[row0] * p.cs[row0] : (p.o2s ? x[row0] * p.o2s[row0] : x[row0]);
     }
     for (int row = row0 + THREADS; row < r1; row += THREADS) {
         if (p.skip_rows_with_offd && oI && oI[row + 1] > oI[row]) continue;
@@ -457,7 +457,7 @@ __device__ __forceinline__ void spmv_xc_body(
         if (p.s) t *= p.s[row];
         if (p.yin) t += p.beta * p.yin[row];
         p.out[p.out_perm ? p.out_perm[row] : row] = p.out_add ? p.out_add[p.out_perm[row]] + t : t;
-        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
+        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : (p.o2s ? x[row] * p.o2s[row] : x[row]);
     }
 }
 

@@ -345,6 +345,16 @@ void HiptmairSmoother::setup()
     k::prepare_spmv(A->diag); k::prepare_spmv(D->diag);
     if (D->diagT) k::prepare_spmv(*D->diagT);
     if (aux->A) k::prepare_spmv(aux->A->diag);
+    // A W for the sweep from the zero guess on a bandwidth-bound level (smoother.hpp)
+    AW.reset();
+    const double *w = (primary && primary->A == A) ? primary->diag_scaling() : nullptr;
+    const char *e_aw = std::getenv("ELAG_HIP_HIPTMAIR_AW");                  // (0: the product that gathers f and W per entry; A/B runs)
+    if (w && !(e_aw && !atoi(e_aw)) && !A->needs_exchange() && A->offd.ncols == 0 && A->diag.nnz >= (int64_t(1) << 20)) {
+        AW.reset(new DevCSR());
+        k::csr_copy(A->diag, *AW);
+        k::csr_scale_cols(*AW, w);
+        k::prepare_spmv(*AW);
+    }
 }
 
 void HiptmairSmoother::aux_correct(const double *resid, double *x)
@@ -378,7 +388,11 @@ void HiptmairSmoother::apply(const double *f, double *&cur, double *&alt, bool z
 {
     if (!transpose) {
         const double *w = (primary->A == A) ? primary->diag_scaling() : nullptr;
-        if (zero_guess && w) {
+        if (zero_guess && w && AW) {
+            k::SpmvArgs a;   // R = B - (A W) B, X = W B written beside it
+            a.x = f; a.alpha = -1.0; a.f = f; a.gamma = 1.0; a.out = pv; a.out2 = cur; a.o2s = w;
+            k::spmv_fused(*AW, nullptr, a);
+        } else if (zero_guess && w) {
             // X = W B and R = B - A X in one product: the sweep's result is the (column-scaled) operand of the SpMV
             k::SpmvArgs a;
             a.x = f; a.cs = w; a.alpha = -1.0; a.f = f; a.gamma = 1.0; a.out = pv; a.out2 = cur;
