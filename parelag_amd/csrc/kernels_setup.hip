@@ -2255,6 +2255,52 @@ __global__ __launch_bounds__(kBlock) void sort_rows_group_kernel(int nrows, cons
 }
 }  // namespace
 
+namespace {
+// The same for rows of at most 16 / 32 entries by RANKING: a lane counts the keys of its row that come before its own (ties by lane) and
+// stores its pair at that position -- the other keys pass by through DPP row rotations (vector-ALU moves; the second half of a 32-lane group
+// through one shuffle), where the bitonic network above exchanges 3 words through the LDS crossbar 15 times per lane: that kernel was
+// bound by the LDS pipe, 628 us for the 37.7 M entries of the renumbered cube456 x5 operator.
+template <int N>
+struct RankSteps {
+    static __device__ __forceinline__ void run(int key, int other, int lane16, bool other_is_mine, bool other_before, int &rank)
+    {
+        constexpr int n = 16 - N;                                             // rotation 0 (only for the other half) ... 15
+        if (n > 0 || !other_is_mine) {
+            const int k = n == 0 ? other : __builtin_amdgcn_update_dpp(0, other, 0x120 + (n == 0 ? 1 : n), 0xf, 0xf, false);   // row_ror:n -- lane i reads lane (i - n) & 15
+            const int src = (lane16 - n) & 15;
+            const bool before = other_is_mine ? (k < key || (k == key && src < lane16)) : (k < key || (k == key && other_before));
+            rank += before ? 1 : 0;
+        }
+        RankSteps<N - 1>::run(key, other, lane16, other_is_mine, other_before, rank);
+    }
+};
+template <>
+struct RankSteps<0> {
+    static __device__ __forceinline__ void run(int, int, int, bool, bool, int &) {}
+};
+
+template <int G>
+__global__ __launch_bounds__(kBlock) void sort_rows_rank_kernel(int nrows, const int *__restrict__ I, int *__restrict__ J, double *__restrict__ a)
+{
+    static_assert(G == 16 || G == 32, "rank sort: groups of 16 or 32 lanes");
+    const int row = (blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1), lane16 = threadIdx.x & 15;
+    // (no early exit: DPP and shuffles read the lanes of rows past the end and of short rows too)
+    int s = 0, len = 0;
+    if (row < nrows) { s = I[row]; len = I[row + 1] - s; }
+    int key = 0x7fffffff;
+    double v = 0.0;
+    if (lane < len) { key = J[s + lane]; v = a[s + lane]; }
+    int rank = 0;
+    RankSteps<16>::run(key, key, lane16, true, false, rank);                   // the 15 other lanes of this lane's DPP row
+    if (G == 32) {
+        const int other = __shfl_xor(key, 16, 64);                             // the key of the same position in the other half
+        RankSteps<16>::run(key, other, lane16, false, (lane & 16) != 0, rank);    // all 16 of them (ties: the lower half comes first)
+    }
+    if (len >= 2 && lane < len) { J[s + rank] = key; a[s + rank] = v; }
+}
+}  // namespace
+
 void csr_sort_rows(DevCSR &A)
 {
     if (A.nrows == 0 || A.nnz == 0) return;
@@ -2262,7 +2308,11 @@ void csr_sort_rows(DevCSR &A)
     if (A.max_row_nnz <= 64) {
         hipStream_t st = ctx().stream;
         const int *I = A.I;
-        if (A.max_row_nnz <= 16) hipLaunchKernelGGL((sort_rows_group_kernel<16>), dim3(grid1((long long)A.nrows * 16)), dim3(kBlock), 0, st, A.nrows, I, A.J, A.a);
+        static int rank_sort = -1;
+        if (rank_sort < 0) { const char *e = getenv("ELAG_HIP_RANK_SORT"); rank_sort = e ? atoi(e) : 1; }
+        if (rank_sort && A.max_row_nnz <= 16) hipLaunchKernelGGL((sort_rows_rank_kernel<16>), dim3(grid1((long long)A.nrows * 16)), dim3(kBlock), 0, st, A.nrows, I, A.J, A.a);
+        else if (rank_sort && A.max_row_nnz <= 32) hipLaunchKernelGGL((sort_rows_rank_kernel<32>), dim3(grid1((long long)A.nrows * 32)), dim3(kBlock), 0, st, A.nrows, I, A.J, A.a);
+        else if (A.max_row_nnz <= 16) hipLaunchKernelGGL((sort_rows_group_kernel<16>), dim3(grid1((long long)A.nrows * 16)), dim3(kBlock), 0, st, A.nrows, I, A.J, A.a);
         else if (A.max_row_nnz <= 32) hipLaunchKernelGGL((sort_rows_group_kernel<32>), dim3(grid1((long long)A.nrows * 32)), dim3(kBlock), 0, st, A.nrows, I, A.J, A.a);
         else hipLaunchKernelGGL((sort_rows_group_kernel<64>), dim3(grid1((long long)A.nrows * 64)), dim3(kBlock), 0, st, A.nrows, I, A.J, A.a);
         ELAG_LAUNCH_CHECK();
