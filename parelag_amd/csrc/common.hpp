@@ -240,7 +240,7 @@ struct DevCSR {
     mutable double *fpa = nullptr;
     mutable int fpL = 0, fpU = 0;
     // the column indices as 16-bit words (operators of the flattened cycle with at most 65 536 columns: 10 bytes per entry instead of 12 in
-    // kernels that are bound by the bytes they pull out of the caches); a pattern-derived form like the x-cache tables
+    // kernels that are bound by the bytes they pull out of the caches); lives as long as J itself (alloc_entries / release drop it)
     mutable unsigned short *J16 = nullptr;
 
     static constexpr int kStreamNnz = 2048;     // entries per 256-thread workgroup
@@ -270,13 +270,13 @@ struct DevCSR {
     ~DevCSR() { release(); }
     void release_xc() const
     {
-        dev_free(lidx); dev_free(uoff); dev_free(ucols); dev_free(J16);
+        dev_free(lidx); dev_free(uoff); dev_free(ucols);
         if (xc_block_row && xc_block_row != block_row) dev_free(xc_block_row);
         xc_block_row = nullptr; xc_nblocks = 0; xc_window = 0;
         xc_state = 0;
     }
     void release_sign() const { dev_free(Js); sign_state = 0; dev_free(ellJ); dev_free(ella); ellW = 0; dev_free(fpJ); dev_free(fpa); fpL = fpU = 0; }   // every form derived from the VALUES
-    void release() { release_xc(); release_sign(); dev_free(I); dev_free(J); dev_free(a); dev_free(block_row); nblocks = 0; }
+    void release() { release_xc(); release_sign(); dev_free(I); dev_free(J); dev_free(J16); dev_free(a); dev_free(block_row); nblocks = 0; }
     void alloc(int nr, int nc, int64_t nz);
     void alloc_entries(int64_t nz);   // J / a (+pad) for a matrix whose I is already in place
     void upload(int nr, int nc, const int *hi, const int *hj, const double *ha);

@@ -235,7 +235,7 @@ __global__ void csr_pad_kernel(int *__restrict__ Jpad, double *__restrict__ apad
 
 void DevCSR::alloc_entries(int64_t nz)
 {
-    dev_free(J); dev_free(a);
+    dev_free(J); dev_free(a); dev_free(J16);
     nnz = nz;
     J = dev_alloc<int>((size_t)nz + 4);
     a = dev_alloc<double>((size_t)nz + 4);

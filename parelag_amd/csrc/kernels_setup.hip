@@ -2304,6 +2304,7 @@ __global__ __launch_bounds__(kBlock) void sort_rows_rank_kernel(int nrows, const
 void csr_sort_rows(DevCSR &A)
 {
     if (A.nrows == 0 || A.nnz == 0) return;
+    dev_free(A.J16);                                                           // (a copy of J in its old order)
     if (A.block_row == nullptr || A.max_row_nnz <= 0) build_stream_plan(A);   // max_row_nnz
     if (A.max_row_nnz <= 64) {
         hipStream_t st = ctx().stream;
