@@ -116,8 +116,9 @@ def other_configs_leg(args, la, meshgen, np, sp, budget_s=60.0):
       config 3: MultigridTest2Form (H(div)) cube456 x3, Hiptmair(L1 Jacobi, L1 Jacobi): cycle rate (HIP events over 200 cycles), the cycle
                 against the CPU oracle's restatement of the same Hiptmair cycle at full size, setup, the one-core CPU port;
       config 4: MultigridTestDarcy cube456 x3 on one GPU: the blocked cycle's rate, and the example's GMRES(50) solve preconditioned by the
-                solver graph of the reference's own list (Block LDU with AMGe inverses): iterations, ms per solve, converged, true residual.
-    (The 8-rank forms of configs 4 / 5 are the driver's --gpus 8 runs of `--form darcy | spe10`.)"""
+                solver graph of the reference's own list (Block LDU with AMGe inverses): iterations, ms per solve, converged, true residual;
+      config 5: the same system with the synthetic log-normal permeability of `--form spe10` (MultigridTestSPE10; the SPE10 data file is not shipped).
+    (Configs 4 / 5 on ONE GPU here; their 8-rank forms are the driver's --gpus 8 runs of `--form darcy | spe10`.)"""
     t_leg = time.time()
     rec = {}
     # ---- config 3 ----
@@ -176,60 +177,65 @@ def other_configs_leg(args, la, meshgen, np, sp, budget_s=60.0):
         raise
     except Exception as exc:
         rec["config3_hdiv_hiptmair"] = {"error": repr(exc)[:400]}
-    # ---- config 4 ----
-    if time.time() - t_leg > budget_s:
-        rec["config4_darcy"] = {"skipped": "time budget of this leg (%.0f s) spent" % budget_s}
-        return rec
-    try:
-        t0 = time.time()
-        dar = meshgen.darcy_problem(3)
-        gen_s = time.time() - t0
-        Ps = dar["Ps"]
-        n0, n1 = dar["M"].shape[0], dar["B"].shape[0]
-        bop = la.MfemBlockOperator([0, n0, n0 + n1])
-        for (i, j), M in {(0, 0): dar["M"], (0, 1): dar["Bt"], (1, 0): dar["B"]}.items():
-            bop.SetBlock(i, j, la.ParallelCSRMatrix.from_scipy(M))
-        dPs = [[la.ParallelCSRMatrix.from_scipy(P) for P in Pl] for Pl in Ps]
-        t0 = time.time()
-        H = la.buildBlockedHierarchyFromDeRhamSequence(bop, dPs, block_smoother="Block Jacobi", a00_inverse="L1 Jacobi", a11_inverse="L1 Jacobi",
-                                                       use_negative_s=True, use_graph=not args.no_graph)
-        la.synchronize()
-        setup_s = time.time() - t0
-        n = n0 + n1
-        rhs, sol = la.DeviceVector(n, 2.0), la.DeviceVector(n, 1.0)
-        for _ in range(20):
-            H.Mult(rhs, sol)
-        ms = H.time_apply(rhs, sol, 200)
-        c4 = {"workload": "MultigridTestDarcy cube456 x3 refines on one GPU: %d + %d dofs, %d levels, Block Jacobi(L1 Jacobi, L1 Jacobi)" % (n0, n1, len(Ps) + 1),
-              "vcycle_ms": round(ms, 4), "vcycles_per_s": round(1e3 / ms, 1), "hierarchy_setup_s": round(setup_s, 4), "generate_s": round(gen_s, 1)}
-        kparams = {"Solver name": "GMRES", "Relative tolerance": 1e-6, "Absolute tolerance": 1e-6, "Maximum iterations": 300, "Restart size": 50}
-        b_solve = np.concatenate([np.zeros(n0), seq_fine_M3_one(dar)])
-        t0 = time.time()
-        ldu = la.darcy_ldu_amge_preconditioner(bop, dar["M"], dar["B"], Ps, "L1 Jacobi", dPs=dPs)
-        la.synchronize()
-        ldu_setup = time.time() - t0
-        K = la.KrylovSolver(bop, ldu, kparams)
-        db, dx = la.DeviceVector.from_numpy(b_solve), la.DeviceVector(n, 0.0)
-        K.Mult(db, dx)
-        la.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
+    # ---- configs 4 and 5: the Darcy system on one GPU, homogeneous and with the synthetic log-normal permeability of --form spe10 ----
+    for key, spe10 in (("config4_darcy", False), ("config5_spe10", True)):
+        if time.time() - t_leg > budget_s:
+            rec[key] = {"skipped": "time budget of this leg (%.0f s) spent" % budget_s}
+            continue
+        try:
+            t0 = time.time()
+            seq = meshgen.Sequence.cube456(3)
+            kinv = meshgen.lognormal_inverse_permeability(seq, args.perm_sigma) if spe10 else None
+            dar = meshgen.darcy_problem(3, seq=seq, kinv=kinv)
+            gen_s = time.time() - t0
+            Ps = dar["Ps"]
+            n0, n1 = dar["M"].shape[0], dar["B"].shape[0]
+            bop = la.MfemBlockOperator([0, n0, n0 + n1])
+            for (i, j), M in {(0, 0): dar["M"], (0, 1): dar["Bt"], (1, 0): dar["B"]}.items():
+                bop.SetBlock(i, j, la.ParallelCSRMatrix.from_scipy(M))
+            dPs = [[la.ParallelCSRMatrix.from_scipy(P) for P in Pl] for Pl in Ps]
+            t0 = time.time()
+            H = la.buildBlockedHierarchyFromDeRhamSequence(bop, dPs, block_smoother="Block Jacobi", a00_inverse="L1 Jacobi", a11_inverse="L1 Jacobi",
+                                                           use_negative_s=True, use_graph=not args.no_graph)
+            la.synchronize()
+            setup_s = time.time() - t0
+            n = n0 + n1
+            rhs, sol = la.DeviceVector(n, 2.0), la.DeviceVector(n, 1.0)
+            for _ in range(20):
+                H.Mult(rhs, sol)
+            ms = H.time_apply(rhs, sol, 200)
+            what = ("MultigridTestSPE10-like (synthetic log-normal permeability, sigma %g, contrast %.1e; the SPE10 data file is not shipped)" %
+                    (args.perm_sigma, float(kinv.max() / kinv.min()))) if spe10 else "MultigridTestDarcy"
+            c4 = {"workload": "%s cube456 x3 refines on one GPU: %d + %d dofs, %d levels, Block Jacobi(L1 Jacobi, L1 Jacobi)" % (what, n0, n1, len(Ps) + 1),
+                  "vcycle_ms": round(ms, 4), "vcycles_per_s": round(1e3 / ms, 1), "hierarchy_setup_s": round(setup_s, 4), "generate_s": round(gen_s, 1)}
+            kparams = {"Solver name": "GMRES", "Relative tolerance": 1e-6, "Absolute tolerance": 1e-6, "Maximum iterations": 300, "Restart size": 50}
+            b_solve = np.concatenate([np.zeros(n0), seq_fine_M3_one(dar)])
+            t0 = time.time()
+            ldu = la.darcy_ldu_amge_preconditioner(bop, dar["M"], dar["B"], Ps, "L1 Jacobi", dPs=dPs)
+            la.synchronize()
+            ldu_setup = time.time() - t0
+            K = la.KrylovSolver(bop, ldu, kparams)
+            db, dx = la.DeviceVector.from_numpy(b_solve), la.DeviceVector(n, 0.0)
             K.Mult(db, dx)
-        la.synchronize()
-        ms_solve = (time.perf_counter() - t0) / 5 * 1e3
-        dr = la.DeviceVector(n, 0.0)
-        bop.Monolithic().residual(db, dx, dr)
-        c4["solve"] = {"solver": "GMRES(50)", "preconditioner": "Block LDU, inverses = AMGe V-cycles (L1 Jacobi) on M (x3) and on B diag(M)^-1 Bt (negated): "
-                       "the solver graph of spe10_example_parameters.xml:95-127", "rel_tol": 1e-6, "iterations": K.GetNumIterations(),
-                       "converged": bool(K.GetConverged()), "ms_per_solve": round(ms_solve, 3), "preconditioner_setup_s": round(ldu_setup, 4),
-                       "true_rel_residual": float(np.linalg.norm(dr.to_numpy()) / np.linalg.norm(b_solve))}
-        rec["config4_darcy"] = c4
-        note("config 4 (Darcy x3): %.1f cycles/s; GMRES %d iterations, %.2f ms, converged %s" % (c4["vcycles_per_s"], c4["solve"]["iterations"], ms_solve, c4["solve"]["converged"]))
-        del K, ldu, H, bop, dPs
-    except SystemExit:
-        raise
-    except Exception as exc:
-        rec["config4_darcy"] = {"error": repr(exc)[:400]}
+            la.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                K.Mult(db, dx)
+            la.synchronize()
+            ms_solve = (time.perf_counter() - t0) / 5 * 1e3
+            dr = la.DeviceVector(n, 0.0)
+            bop.Monolithic().residual(db, dx, dr)
+            c4["solve"] = {"solver": "GMRES(50)", "preconditioner": "Block LDU, inverses = AMGe V-cycles (L1 Jacobi) on M (x3) and on B diag(M)^-1 Bt (negated): "
+                           "the solver graph of spe10_example_parameters.xml:95-127", "rel_tol": 1e-6, "iterations": K.GetNumIterations(),
+                           "converged": bool(K.GetConverged()), "ms_per_solve": round(ms_solve, 3), "preconditioner_setup_s": round(ldu_setup, 4),
+                           "true_rel_residual": float(np.linalg.norm(dr.to_numpy()) / np.linalg.norm(b_solve))}
+            rec[key] = c4
+            note("%s (x3): %.1f cycles/s; GMRES %d iterations, %.2f ms, converged %s" % (key, c4["vcycles_per_s"], c4["solve"]["iterations"], ms_solve, c4["solve"]["converged"]))
+            del K, ldu, H, bop, dPs
+        except SystemExit:
+            raise
+        except Exception as exc:
+            rec[key] = {"error": repr(exc)[:400]}
     rec["leg_s"] = round(time.time() - t_leg, 1)
     return rec
 
