@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU tests, then the default bench line without the PMC passes and the CPU baseline (other_configs: Darcy hierarchy setup with the fused column kernel)
-TAG=${1:-r04s2a}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
+TAG=${1:-r04tb}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/pytest.txt 2>&1; echo "pytest rc $?" | tee -a $OUT/pytest.txt
 tail -3 $OUT/pytest.txt
 grep -q "rc 0" $OUT/pytest.txt || exit 1
