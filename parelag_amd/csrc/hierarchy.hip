@@ -1305,19 +1305,9 @@ struct elag_hip_hierarchy_s {
         if (!pre_dinv || !post_dinv || F.A->needs_exchange() || F.A->diag.nnz < (int64_t(1) << 20)) return false;
         const int n = F.A->nrows();
         double *cur = F.alt;           // (never F.sol / F.resid: host callers' vectors are staged there, i.e. they may BE sol_nat / src_nat)
-        // (OFF unless ELAG_HIP_FOLD_INPUT_PERM=1: measured at cube456 x5 the cycle with the folded input is 0.267 ms against 0.254 -- the cached columns'
-        //  operands come from scattered places of the caller's vector, which costs the product more than the gather pass it replaces)
-        static int fold_in = -1;
-        if (fold_in < 0) { const char *e = getenv("ELAG_HIP_FOLD_INPUT_PERM"); fold_in = e ? atoi(e) : 0; }
-        if (fold_in && F.S && F.A->diag.xc_state == 1 && F.A->diag.lanes_per_row == 0 && F.A->offd.ncols == 0) {
-            // r = f - A (W f) and x = W f with f read from the caller's numbering by the product itself (the x-cache kernel gathers once per
-            // cached column: one more index per gather instead of a pass over four vectors in front of the cycle)
-            k::SpmvArgs a;
-            a.x = src_nat; a.cs = pre_dinv; a.in_perm = d_order0; a.alpha = -1.0; a.f = src_nat; a.gamma = 1.0; a.out = F.tmp_resid; a.out2 = cur;
-            k::spmv_fused(F.A->diag, nullptr, a);
-        } else {
-            // p_rhs = src[order], x = W p_rhs in one pass
-            k::vec_gather_scale(n, d_order0, src_nat, pre_dinv, p_rhs, cur);
+        // p_rhs = src[order], x = W p_rhs in one pass
+        k::vec_gather_scale(n, d_order0, src_nat, pre_dinv, p_rhs, cur);
+        {
             k::SpmvArgs a;  // r = f - A x
             a.x = cur; a.alpha = -1.0; a.f = p_rhs; a.gamma = 1.0; a.out = F.tmp_resid;
             par_spmv(*F.A, a);

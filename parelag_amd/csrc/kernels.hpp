@@ -36,9 +36,6 @@ struct SpmvArgs {
     // numbering directly instead of a scatter pass after it); with out_add the value is added to out_add[out_perm[i]] on the way
     const int *out_perm = nullptr;
     const double *out_add = nullptr;
-    // x-cache kernel only: x and f are given in ANOTHER numbering -- entry i of this operator's numbering is x[in_perm[i]], f[in_perm[i]]
-    // (the hierarchy's first kernel reads the caller's right-hand side directly instead of a gather pass in front of it)
-    const int *in_perm = nullptr;
 };
 void spmv_fused(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, hipStream_t st = nullptr);
 // A dependent chain of launch-bound products as ONE kernel with grid-wide barriers in between (kernels_spmv.hip, "Resident sequence").

@@ -390,10 +390,9 @@ __device__ __forceinline__ void spmv_xc_body(
     const bool has0 = row0 < r1;
     int s0 = 0, e0 = 0;
     double f0 = 0.0, y0 = 0.0, sc0 = 1.0, sc20 = 1.0;
-    const int *__restrict__ in_perm = p.in_perm;
     if (has0) {
         s0 = I[row0]; e0 = I[row0 + 1];
-        if (p.f) f0 = p.f[in_perm ? in_perm[row0] : row0];
+        if (p.f) f0 = p.f[row0];
         if (p.yin) y0 = p.yin[row0];
         if (p.s) sc0 = p.s[row0];
         if (p.s2) sc20 = p.s2[row0];
@@ -407,7 +406,7 @@ __device__ __forceinline__ void spmv_xc_body(
     if (k1 < kend) { l1 = *reinterpret_cast<const ushort4v *>(lidx + k1); a1a = *reinterpret_cast<const double2v *>(a + k1); a1b = *reinterpret_cast<const double2v *>(a + k1 + 2); }
     for (int u = (int)threadIdx.x; u < nu; u += THREADS) {
         const int c = ucols[u0 + u];
-        double v = x[in_perm ? in_perm[c] : c];
+        double v = x[c];
         if (HAS_CS) v *= cs[c];
         xs[u] = v;
     }
@@ -445,10 +444,7 @@ __device__ __forceinline__ void spmv_xc_body(
         t *= sc0;
         t += p.beta * y0;
         p.out[p.out_perm ? p.out_perm[row0] : row0] = p.out_add ? p.out_add[p.out_perm[row0]] + t : t;
-        if (p.out2) {
-            const double xr = x[in_perm ? in_perm[row0] : row0];
-            p.out2[row0] = HAS_CS ? xr * p.cs[row0] : (p.o2s ? xr * p.o2s[row0] : xr);
-        }
+        if (p.out2) p.out2[row0] = HAS_CS ? x[row0] * p.cs[row0] : (p.o2s ? x[row0] * p.o2s[row0] : x[row0]);
     }
     for (int row = row0 + THREADS; row < r1; row += THREADS) {
         if (p.skip_rows_with_offd && oI && oI[row + 1] > oI[row]) continue;
@@ -457,14 +453,11 @@ __device__ __forceinline__ void spmv_xc_body(
         for (int k = s; k < e; k++) sum += prod[k];
         double t = p.alpha * sum;
         if (p.s2) t *= p.s2[row];
-        if (p.f) t += p.gamma * p.f[in_perm ? in_perm[row] : row];
+        if (p.f) t += p.gamma * p.f[row];
         if (p.s) t *= p.s[row];
         if (p.yin) t += p.beta * p.yin[row];
         p.out[p.out_perm ? p.out_perm[row] : row] = p.out_add ? p.out_add[p.out_perm[row]] + t : t;
-        if (p.out2) {
-            const double xr = x[in_perm ? in_perm[row] : row];
-            p.out2[row] = HAS_CS ? xr * p.cs[row] : (p.o2s ? xr * p.o2s[row] : xr);
-        }
+        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : (p.o2s ? x[row] * p.o2s[row] : x[row]);
     }
 }
 
@@ -968,8 +961,6 @@ void spmv_fused(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, hipSt
     ELAG_REQUIRE(!args.out_add || args.out_perm, "internal: out_add needs out_perm (the epilogues index it with the permuted row)");
     const bool rowlist = args.rows != nullptr;
     const bool offd_terms = offd && offd->nnz > 0 && !args.skip_rows_with_offd;
-    ELAG_REQUIRE(!args.in_perm || (A.xc_state == 1 && A.lanes_per_row == 0 && !rowlist && !offd_terms && A.sign_state != 1 && stream_variant() != 4),
-                 "internal: in_perm is an option of the x-cache kernel");
     if (A.sign_state == 1 && !rowlist && !offd_terms && !args.skip_rows_with_offd) {
         const double avg = A.nrows ? (double)A.nnz / A.nrows : 0.0;
         if (avg <= 6.0) launch_sign<1>(A, args, st);
