@@ -222,6 +222,7 @@ struct elag_hip_hierarchy_s {
                 k::csr_copy(L.A->diag, *L.AW);
                 k::csr_scale_cols(*L.AW, w);
                 k::prepare_spmv(*L.AW);
+                if (L.AW->xc_state == 1 || L.AW->lanes_per_row != 0) L.AW.reset();
             }
         });
         phase("dense_tail", [&] { plan_dense_tail(); });

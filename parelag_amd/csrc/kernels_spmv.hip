@@ -97,7 +97,7 @@ __device__ __forceinline__ void spmv_fused_row(int row, int lane, const int *__r
         t *= sc0;
         t += p.beta * y0;
         p.out[p.out_perm ? p.out_perm[row] : row] = p.out_add ? p.out_add[p.out_perm[row]] + t : t;
-        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : (p.o2s ? x[row] * p.o2s[row] : x[row]);
+        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
     }
 }
 
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kBlock) void spmv_sign_kernel(int nrows, const int 
         t *= sc0;
         t += p.beta * y0;
         p.out[p.out_perm ? p.out_perm[row] : row] = p.out_add ? p.out_add[p.out_perm[row]] + t : t;
-        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : (p.o2s ? x[row] * p.o2s[row] : x[row]);
+        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
     }
 }
 
@@ -319,7 +319,7 @@ __device__ __forceinline__ void spmv_stream_body(
         t *= sc0;
         t += p.beta * y0;
         p.out[p.out_perm ? p.out_perm[row0] : row0] = p.out_add ? p.out_add[p.out_perm[row0]] + t : t;
-        if (p.out2) p.out2[row0] = HAS_CS ? x[row0] * p.cs[row0] : (p.o2s ? x[row0] * p.o2s[row0] : x[row0]);
+        if (p.out2) p.out2[row0] = HAS_CS ? x[row0] * p.cs[row0] : ((VARIANT & 1) ? x[row0] * p.o2s[row0] : x[row0]);   // (variant 1: out2 scaled by o2s)
     }
     // blocks of short rows hold more than 256 rows: remaining rows the plain way
     for (int row = row0 + kBlock; row < r1; row += kBlock) {
@@ -333,7 +333,7 @@ __device__ __forceinline__ void spmv_stream_body(
         if (p.s) t *= p.s[row];
         if (p.yin) t += p.beta * p.yin[row];
         p.out[p.out_perm ? p.out_perm[row] : row] = p.out_add ? p.out_add[p.out_perm[row]] + t : t;
-        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : (p.o2s ? x[row] * p.o2s[row] : x[row]);
+        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : ((VARIANT & 1) ? x[row] * p.o2s[row] : x[row]);
     }
 }
 
@@ -444,7 +444,7 @@ __device__ __forceinline__ void spmv_xc_body(
         t *= sc0;
         t += p.beta * y0;
         p.out[p.out_perm ? p.out_perm[row0] : row0] = p.out_add ? p.out_add[p.out_perm[row0]] + t : t;
-        if (p.out2) p.out2[row0] = HAS_CS ? x[row0] * p.cs[row0] : (p.o2s ? x[row0] * p.o2s[row0] : x[row0]);
+        if (p.out2) p.out2[row0] = HAS_CS ? x[row0] * p.cs[row0] : x[row0];          // (o2s: not in this kernel)
     }
     for (int row = row0 + THREADS; row < r1; row += THREADS) {
         if (p.skip_rows_with_offd && oI && oI[row + 1] > oI[row]) continue;
@@ -457,7 +457,7 @@ __device__ __forceinline__ void spmv_xc_body(
         if (p.s) t *= p.s[row];
         if (p.yin) t += p.beta * p.yin[row];
         p.out[p.out_perm ? p.out_perm[row] : row] = p.out_add ? p.out_add[p.out_perm[row]] + t : t;
-        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : (p.o2s ? x[row] * p.o2s[row] : x[row]);
+        if (p.out2) p.out2[row] = HAS_CS ? x[row] * p.cs[row] : x[row];
     }
 }
 
@@ -686,6 +686,7 @@ void launch_stream(const DevCSR &A, const DevCSR *offd, const SpmvArgs &p, hipSt
     // ELAG_HIP_STREAM_VARIANT=4 selects a DIAGNOSTIC build of the kernel (coalesced x reads, wrong results) that
     // prices the gather: 7.2 TB/s against 5.1-5.4 TB/s for the real kernel (CHANGELOG.md, round 2)
     if (stream_variant() == 4) launch_stream_v<4>(A, offd, p, st);
+    else if (p.o2s && !p.cs) launch_stream_v<1>(A, offd, p, st);             // (a build of its own: the option's select in the common epilogue cost the x-cache kernel 7 %)
     else launch_stream_v<0>(A, offd, p, st);
 }
 
@@ -959,6 +960,9 @@ void spmv_fused(const DevCSR &A, const DevCSR *offd, const SpmvArgs &args, hipSt
 {
     if (!st) st = ctx().stream;
     ELAG_REQUIRE(!args.out_add || args.out_perm, "internal: out_add needs out_perm (the epilogues index it with the permuted row)");
+    ELAG_REQUIRE(!args.o2s || (A.xc_state != 1 && A.lanes_per_row == 0 && A.block_row && args.rows == nullptr && !(offd && offd->nnz > 0 && !args.skip_rows_with_offd) &&
+                               A.sign_state != 1 && xc_mode() != 1),
+                 "internal: o2s is an option of the plain stream kernel");
     const bool rowlist = args.rows != nullptr;
     const bool offd_terms = offd && offd->nnz > 0 && !args.skip_rows_with_offd;
     if (A.sign_state == 1 && !rowlist && !offd_terms && !args.skip_rows_with_offd) {

@@ -354,6 +354,7 @@ void HiptmairSmoother::setup()
         k::csr_copy(A->diag, *AW);
         k::csr_scale_cols(*AW, w);
         k::prepare_spmv(*AW);
+        if (AW->xc_state == 1 || AW->lanes_per_row != 0) AW.reset();           // (the option is the plain stream kernel's; with an x-cache form the fused gather is cheap anyway)
     }
 }
 
