@@ -361,7 +361,9 @@ __global__ __launch_bounds__(kBlock) void spmv_probe_stream_kernel(
 // (10 bytes per entry from HBM instead of 12, and no global gather in the inner loop).
 typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
 
-template <bool HAS_CS, int THREADS>
+// LEAN: the plain product out = A x (no epilogue operand, no permuted output, no second output, alpha = 1): a build of its own -- this kernel's
+// time moves by several per cent with what its epilogue has to keep alive (an unused select there cost 7 %)
+template <bool HAS_CS, int THREADS, bool LEAN = false>
 __device__ __forceinline__ void spmv_xc_body(
     int nrows, const int *__restrict__ I, const double *__restrict__ a, const unsigned short *__restrict__ lidx,
     const int *__restrict__ block_row, const int *__restrict__ uoff, const int *__restrict__ ucols, const int *__restrict__ oI,
@@ -392,10 +394,12 @@ __device__ __forceinline__ void spmv_xc_body(
     double f0 = 0.0, y0 = 0.0, sc0 = 1.0, sc20 = 1.0;
     if (has0) {
         s0 = I[row0]; e0 = I[row0 + 1];
-        if (p.f) f0 = p.f[row0];
-        if (p.yin) y0 = p.yin[row0];
-        if (p.s) sc0 = p.s[row0];
-        if (p.s2) sc20 = p.s2[row0];
+        if (!LEAN) {
+            if (p.f) f0 = p.f[row0];
+            if (p.yin) y0 = p.yin[row0];
+            if (p.s) sc0 = p.s[row0];
+            if (p.s2) sc20 = p.s2[row0];
+        }
     }
     // the value / position stream of this lane's first two quads is requested before the gather phase, so both
     // memory streams are in flight together
@@ -435,6 +439,20 @@ __device__ __forceinline__ void spmv_xc_body(
         *reinterpret_cast<double2v *>(prod + (k - kal) + 2) = p23;
     }
     __syncthreads();
+    if (LEAN) {
+        if (has0) {
+            double sum = 0.0;
+            for (int k = s0 - kal; k < e0 - kal; k++) sum += prod[k];
+            p.out[row0] = sum;
+        }
+        for (int row = row0 + THREADS; row < r1; row += THREADS) {
+            const int s = I[row] - kal, e = I[row + 1] - kal;
+            double sum = 0.0;
+            for (int k = s; k < e; k++) sum += prod[k];
+            p.out[row] = sum;
+        }
+        return;
+    }
     if (has0 && !(p.skip_rows_with_offd && oI && oI[row0 + 1] > oI[row0])) {
         double sum = 0.0;
         for (int k = s0 - kal; k < e0 - kal; k++) sum += prod[k];
@@ -461,13 +479,13 @@ __device__ __forceinline__ void spmv_xc_body(
     }
 }
 
-template <bool HAS_CS, int THREADS>
+template <bool HAS_CS, int THREADS, bool LEAN = false>
 __global__ __launch_bounds__(THREADS) void spmv_xc_kernel(
     int nrows, const int *__restrict__ I, const double *__restrict__ a, const unsigned short *__restrict__ lidx,
     const int *__restrict__ block_row, const int *__restrict__ uoff, const int *__restrict__ ucols, const int *__restrict__ oI,
     int cap, SpmvArgs p)
 {
-    spmv_xc_body<HAS_CS, THREADS>(nrows, I, a, lidx, block_row, uoff, ucols, oI, cap, p);
+    spmv_xc_body<HAS_CS, THREADS, LEAN>(nrows, I, a, lidx, block_row, uoff, ucols, oI, cap, p);
 }
 
 // the same code under another name for the setup-time measurement (see spmv_probe_stream_kernel)
@@ -651,6 +669,13 @@ int xc_xcd_mode()
     return v;
 }
 
+bool xc_lean_enabled()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ELAG_HIP_XC_LEAN"); v = e ? (atoi(e) != 0) : 1; }
+    return v != 0;
+}
+
 template <int THREADS>
 void launch_xc_t(const DevCSR &A, const int *oI, const SpmvArgs &pin, hipStream_t st, bool probe)
 {
@@ -661,6 +686,8 @@ void launch_xc_t(const DevCSR &A, const int *oI, const SpmvArgs &pin, hipStream_
     const dim3 grid((unsigned)A.xc_nblocks), block(THREADS);
     if (probe)
         hipLaunchKernelGGL((spmv_probe_xc_kernel<THREADS>), grid, block, lds, st, A.nrows, A.I, A.a, A.lidx, A.xc_block_row, A.uoff, A.ucols, oI, cap, p);
+    else if (xc_lean_enabled() && !p.cs && !p.f && !p.yin && !p.s && !p.s2 && !p.out2 && !p.out_perm && !p.out_add && !oI && p.alpha == 1.0)
+        hipLaunchKernelGGL((spmv_xc_kernel<false, THREADS, true>), grid, block, lds, st, A.nrows, A.I, A.a, A.lidx, A.xc_block_row, A.uoff, A.ucols, oI, cap, p);
     else if (p.cs)
         hipLaunchKernelGGL((spmv_xc_kernel<true, THREADS>), grid, block, lds, st, A.nrows, A.I, A.a, A.lidx, A.xc_block_row, A.uoff, A.ucols, oI, cap, p);
     else
