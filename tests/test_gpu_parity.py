@@ -1166,3 +1166,25 @@ def test_memory_pool_and_trim(la, h1_k2):
     _lib.trim_memory()
     H.Mult(b, x2)
     assert np.array_equal(x1, x2)
+
+
+def test_staged_copies_in_several_chunks_and_odd_sizes(la):
+    """The setup path's read-backs and small uploads go through kernels and a 4 MiB pinned staging buffer (context.hip, stage_d2h / stage_h2d):
+    arrays of several chunks whose byte counts are not multiples of 16 come back / arrive intact -- a CSR of 1 300 003 rows read back
+    (10.4 and 20.8 MB arrays), a 5.2 MB integer vector uploaded for hypre_ParCSRMatrixMatvecBoolInt."""
+    n = 1300003
+    rng = np.random.default_rng(31)
+    cols = np.stack([np.arange(n), rng.integers(0, n, n)], axis=1)
+    cols.sort(axis=1)
+    keep = np.ones((n, 2), dtype=bool)
+    keep[:, 1] = cols[:, 1] != cols[:, 0]
+    indptr = np.concatenate([[0], np.cumsum(keep.sum(axis=1))]).astype(np.int32)
+    A = sp.csr_matrix((rng.standard_normal(int(indptr[-1])), cols[keep].astype(np.int32), indptr), shape=(n, n))
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    B = dA.to_scipy()
+    assert np.array_equal(B.indptr, A.indptr) and np.array_equal(B.indices, A.indices) and np.array_equal(B.data, A.data)
+    x = rng.integers(0, 5, n).astype(np.int32)
+    y = np.zeros(n, dtype=np.int32)
+    dA.MultBoolInt(x, y)
+    pat = sp.csr_matrix((np.ones(A.nnz, dtype=np.int64), A.indices, A.indptr), shape=A.shape)
+    assert np.array_equal(y, (pat @ x.astype(np.int64)).astype(np.int32))
