@@ -1,10 +1,11 @@
-// Dense inverse of a small general (indefinite) operator on the device: Gauss-Jordan with partial pivoting on the
-// augmented matrix [A | I].  Used for the coarsest saddle-point operator of the blocked (Darcy) hierarchy, where the
-// reference's XML names a "Direct" solver (SuperLU; src/linalg/factories/ParELAG_DirectSolverFactory.cpp) or a short
-// GMRES; the SPD single-form hierarchies keep the Cholesky path of smoother.hip.
+// Dense inverse of a small general (indefinite) operator on the device: Gauss-Jordan with partial pivoting.  Used for the
+// coarsest saddle-point operator of the blocked (Darcy) hierarchy, where the reference's XML names a "Direct" solver (SuperLU;
+// src/linalg/factories/ParELAG_DirectSolverFactory.cpp) or a short GMRES; the SPD single-form hierarchies keep the Cholesky /
+// unpivoted Gauss-Jordan paths further down.
 //
-// One elimination step = 4 small launches (pivot search, row swap + scale, column save, rank-1 update); n steps.  The
-// work is n * (n x 2n) updates, i.e. ~13 GFLOP at n = 1500: tens of milliseconds, once per hierarchy.
+// Default: the blocked in-place form (gj_block_*_kernel, 8 pivots per step, two launches per step; up to 3 072 dofs).  Fallback and
+// A/B reference (ELAG_HIP_LU_BLOCKED=0): one column at a time on the augmented matrix [A | I], two launches per pivot
+// (gj_column_kernel + gj_eliminate_kernel) or four (ELAG_HIP_LU_FUSED_COLUMN=0).
 #include "kernels.hpp"
 
 namespace elag {
@@ -161,7 +162,7 @@ __global__ void gj_extract_kernel(int n, const double *__restrict__ M, int ld, d
 // 1 471 dofs: 2 x 184 launches and ~6 GB of traffic where the column-by-column form had 2 942 launches and 150 GB.  (A first version did the row
 // swaps and the products Dinv M_K:, M_:K in the panel kernel: ~300 KB through ONE compute unit in five dependent phases, 48 us per step.)
 constexpr int kGB = 8;
-constexpr int kGPanelRows = 3072;                  // largest n: a thread of the panel kernel keeps three rows of the panel
+constexpr int kGPanelRows = 3072;                  // largest n: a thread of the panel kernel keeps up to six rows of the panel (kGThreads x kGRowsPer)
 struct GjStep {                                    // what the panel kernel leaves for the update
     int nr, pad[3];
     int row[2 * kGB], src[2 * kGB];                // row[z] receives the old row src[z]  (rows not listed stay)
