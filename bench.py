@@ -15,8 +15,11 @@ Besides the V-cycle rate the line carries
 from __future__ import annotations
 
 import argparse
+import contextlib
+import gc
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,6 +31,32 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy peak 6290 GB/s
 
+
+
+@contextlib.contextmanager
+def no_gc():
+    """Timed regions run with Python's cyclic collector off: a generation-2 collection of this process's heap (meshes, scipy operators) is a
+    pause of tens of milliseconds that landed inside a 60 ms timed loop now and then -- the Darcy solve read 27 ms instead of 12 in one run out
+    of four while the library's own clock around every solve (ELAG_HIP_KRYLOV_TIMING=1) said 11.9 ms each."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
+def median_ms(call, n):
+    """median wall time (ms) of n calls, each timed on its own (the call returns when its work is done)"""
+    ts = []
+    with no_gc():
+        for _ in range(n):
+            t0 = time.perf_counter()
+            call()
+            ts.append((time.perf_counter() - t0) * 1e3)
+    return statistics.median(ts)
 
 def spmv_bytes(n_rows, n_cols, nnz):
     """12 nnz + 4 (n+1) + 8 n_cols (x once) + 8 n (y write)."""
@@ -218,11 +247,7 @@ def other_configs_leg(args, la, meshgen, np, sp, budget_s=60.0):
             db, dx = la.DeviceVector.from_numpy(b_solve), la.DeviceVector(n, 0.0)
             K.Mult(db, dx)
             la.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                K.Mult(db, dx)
-            la.synchronize()
-            ms_solve = (time.perf_counter() - t0) / 5 * 1e3
+            ms_solve = median_ms(lambda: K.Mult(db, dx), 5)
             dr = la.DeviceVector(n, 0.0)
             bop.Monolithic().residual(db, dx, dr)
             c4["solve"] = {"solver": "GMRES(50)", "preconditioner": "Block LDU, inverses = AMGe V-cycles (L1 Jacobi) on M (x3) and on B diag(M)^-1 Bt (negated): "
@@ -760,11 +785,7 @@ def main():
         for _ in range(4):                        # (the first solves of a process pay one-time graph / module costs)
             Kr.Mult(br, xr)
         la.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            Kr.Mult(br, xr)
-        la.synchronize()
-        pcg_ms = (time.perf_counter() - t0) / 5 * 1e3
+        pcg_ms = median_ms(lambda: Kr.Mult(br, xr), 5)
         pcg = {"iterations": Kr.GetNumIterations(), "converged": Kr.GetConverged(), "ms_per_solve": round(pcg_ms, 3),
                "ms_per_iteration": round(pcg_ms / max(Kr.GetNumIterations(), 1), 4),
                "true_rel_residual": float(np.linalg.norm(Ar @ xr.to_numpy() - br.to_numpy()) / np.linalg.norm(br.to_numpy()))}
@@ -987,22 +1008,24 @@ def main():
                 H.Mult(rhs, sol)
             la.synchronize()
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        H.Mult(rhs, sol)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    with no_gc():
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            H.Mult(rhs, sol)
+        barrier()
+        elapsed = time.perf_counter() - t0
     if dist is not None:
         elapsed = dist.allreduce_max(elapsed)
     # the same loop over 2000 cycles (what rounds 1-2 quoted): a caller that keeps the queue full
     steady = None
     if dist is None:
         la.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(2000):
-            H.Mult(rhs, sol)
-        la.synchronize()
-        steady = (time.perf_counter() - t1) / 2000
+        with no_gc():
+            t1 = time.perf_counter()
+            for _ in range(2000):
+                H.Mult(rhs, sol)
+            la.synchronize()
+            steady = (time.perf_counter() - t1) / 2000
     # device-side time of the same loop by HIP events (no host launch overhead in between)
     # (at least 200 cycles here whatever --steps says: BASELINE.md quotes the rate over >= 200 cycles, and 20 cycles are 0.6 ms)
     ms_dev = H.time_apply(rhs, sol, max(200, min(args.steps, 500)))
@@ -1101,11 +1124,12 @@ def main():
             db, dx = la.DeviceVector.from_numpy(local_part(b_solve)), la.DeviceVector(n_local, 0.0)
             K.Mult(db, dx)
             barrier()
-            t0 = time.perf_counter()
-            for _ in range(nsolve):
-                K.Mult(db, dx)
-            barrier()
-            ms = (time.perf_counter() - t0) / nsolve * 1e3
+            with no_gc():
+                t0 = time.perf_counter()
+                for _ in range(nsolve):
+                    K.Mult(db, dx)
+                barrier()
+                ms = (time.perf_counter() - t0) / nsolve * 1e3
             if dist is not None:
                 ms = dist.allreduce_max(ms)
             # true residual || b - A x || / || b || of the returned iterate, on the device (rows of this rank, summed over the ranks)

@@ -16,6 +16,7 @@
 // the iterate and the iteration count are exactly those of the reference's sequential loop.
 #include <cmath>
 
+#include <chrono>
 #include "comm.hpp"
 #include "smoother.hpp"
 #include "staging.hpp"
@@ -31,7 +32,7 @@ enum { S_NOM, S_DEN, S_BETANOM, S_R0, S_ALPHA, S_BETA, S_TMP, S_FINAL_NORM, S_GB
        // BiCGSTAB / MINRES recurrences
        S_RHO1, S_RHO2, S_OMEGA, S_RESID, S_GOAL, S_TS, S_ETA, S_GAMMA0, S_GAMMA1, S_SIGMA0, S_SIGMA1, S_DELTA, S_MRHO1, S_MRHO2, S_MRHO3,
        S_C0, S_C1, S_C2, S_COUNT = 40 };
-enum { F_DONE, F_CONVERGED, F_FINAL_ITER, F_ITER, F_PENDING, F_ITER2, F_COUNT = 8 };
+enum { F_DONE, F_CONVERGED, F_FINAL_ITER, F_ITER, F_PENDING, F_ITER2, F_STEP, F_JBASE, F_COUNT = 8 };   // F_STEP / F_JBASE: GMRES -- the step counter and the iteration number of a cycle's first step, kept on the device so that a step's launches take no per-step argument (they replay as a graph)
 
 struct KState {
     double sc[S_COUNT];
@@ -114,16 +115,17 @@ __global__ void gmres_init_kernel(KState *st, double rel_tol, double abs_tol, in
 {
     const double beta = sqrt(st->sc[S_TMP]);
     st->sc[S_GBETA] = beta;
-    st->fl[F_DONE] = 0; st->fl[F_CONVERGED] = 0; st->fl[F_FINAL_ITER] = max_iter; st->fl[F_PENDING] = -1;
+    st->fl[F_DONE] = 0; st->fl[F_CONVERGED] = 0; st->fl[F_FINAL_ITER] = max_iter; st->fl[F_PENDING] = -1; st->fl[F_STEP] = 0; st->fl[F_JBASE] = 1;
     const double thr = fmax(rel_tol * beta, abs_tol);
     st->sc[S_THRESH] = thr;
     st->sc[S_FINAL_NORM] = beta;
     if (beta <= thr) { st->fl[F_DONE] = 1; st->fl[F_CONVERGED] = 1; st->fl[F_FINAL_ITER] = 0; }
 }
 
-__global__ void gmres_start_cycle_kernel(KState *st, double *hs, int m)
+__global__ void gmres_start_cycle_kernel(KState *st, double *hs, int m, int jbase)
 {
     if (st->fl[F_DONE]) return;
+    st->fl[F_JBASE] = jbase;
     double *s = hs + (size_t)m * (m + 1);
     for (int k = 0; k <= m; k++) s[k] = 0.0;
     s[0] = st->sc[S_GBETA];
@@ -193,11 +195,34 @@ __global__ void __launch_bounds__(kB) gmres_orth_fused_kernel(int n, const KStat
                                                               double *__restrict__ part_out)
 {
     __shared__ double sh[4];
+    // A Gram-Schmidt step is a chain of these kernels, each a chain of dependent round trips (flag, partial sums, operands): the operands of
+    // the thread's first kPre elements -- all of them up to ~790 k unknowns -- and the partial sums are requested together with the flag, before
+    // anything is waited for (same arithmetic, same order).
+    constexpr int kPre = 6;
+    const int t0 = blockIdx.x * kB + threadIdx.x, stride = kPart * kB;
+    double pw[kPre], pv[kPre], pn[kPre];
+#pragma unroll
+    for (int u = 0; u < kPre; u++) {
+        const int t = t0 + u * stride;
+        pw[u] = 0.0; pv[u] = 0.0; pn[u] = 0.0;
+        if (t < n) { pw[u] = w[t]; pv[u] = vk[t]; if (vnext) pn[u] = vnext[t]; }
+    }
+    double pp = 0.0;
+    for (int q = threadIdx.x; q < kPart; q += kB) pp += part_in[q];
     if (st->fl[F_DONE]) return;
-    const double h = sum_partials(part_in, sh);
+    const double h = block_sum_256(pp, sh);
     if (blockIdx.x == 0 && threadIdx.x == 0) Hm(hs, m, k, i) = h;
     double acc = 0.0;
-    for (int t = blockIdx.x * kB + threadIdx.x; t < n; t += kPart * kB) {
+#pragma unroll
+    for (int u = 0; u < kPre; u++) {
+        const int t = t0 + u * stride;
+        if (t < n) {
+            const double wn = pw[u] + (-h) * pv[u];
+            w[t] = wn;
+            acc += wn * (vnext ? pn[u] : wn);
+        }
+    }
+    for (int t = t0 + kPre * stride; t < n; t += stride) {
         const double wn = w[t] + (-h) * vk[t];
         w[t] = wn;
         acc += wn * (vnext ? vnext[t] : wn);
@@ -288,9 +313,11 @@ __device__ inline void backsolve(double *hs, int m, int k)   // Update(): y = s;
     }
 }
 
-__global__ void gmres_givens_kernel(KState *st, double *hs, int m, int i, int j, int step_id)
+__global__ void gmres_givens_kernel(KState *st, double *hs, int m, int i)
 {
+    const int step_id = ++st->fl[F_STEP];        // (counted whether or not the solve is over: a step's update kernel runs for ITS step only)
     if (st->fl[F_DONE]) return;
+    const int j = st->fl[F_JBASE] + i;
     double *s = hs + (size_t)m * (m + 1), *cs = s + (m + 1), *sn = cs + (m + 1);
     for (int k = 0; k < i; k++) app_rot(Hm(hs, m, k, i), Hm(hs, m, k + 1, i), cs[k], sn[k]);
     gen_rot(Hm(hs, m, i, i), Hm(hs, m, i + 1, i), cs[i], sn[i]);
@@ -304,18 +331,19 @@ __global__ void gmres_givens_kernel(KState *st, double *hs, int m, int i, int j,
     }
 }
 
-__global__ void gmres_restart_backsolve_kernel(KState *st, double *hs, int m, int k, int step_id)
+__global__ void gmres_restart_backsolve_kernel(KState *st, double *hs, int m, int k)
 {
+    const int step_id = ++st->fl[F_STEP];
     if (st->fl[F_DONE]) return;
     backsolve(hs, m, k);
     st->fl[F_PENDING] = step_id;
 }
 
 // x += sum_{q < count} y_q V_q    (runs only for the step that set F_PENDING; `done` may already be set by that step)
-__global__ void gmres_update_kernel(int n, const KState *__restrict__ st, int step_id, const double *__restrict__ hs, int m, int count,
+__global__ void gmres_update_kernel(int n, const KState *__restrict__ st, const double *__restrict__ hs, int m, int count,
                                     const double *__restrict__ V, double *__restrict__ x)
 {
-    if (st->fl[F_PENDING] != step_id) return;
+    if (st->fl[F_PENDING] != st->fl[F_STEP]) return;
     const double *y = hs + (size_t)m * (m + 1) + 3 * (m + 1);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -536,6 +564,8 @@ struct elag_hip_krylov_s {
     double *V = nullptr, *Z = nullptr, *hs = nullptr, *part = nullptr;
     double *e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // BiCGSTAB / MINRES work vectors
     hipGraphExec_t cg_iter = nullptr;
+    std::vector<hipGraphExec_t> gm_step;          // GMRES: one replayable step per position of the restart cycle
+    bool gm_graph_ok = true, gm_flex = false;
     // results of the last Mult
     int converged = 0, final_iter = 0;
     double final_norm = 0.0;
@@ -547,6 +577,7 @@ struct elag_hip_krylov_s {
     ~elag_hip_krylov_s()
     {
         if (cg_iter) (void)hipGraphExecDestroy(cg_iter);
+        for (auto g : gm_step) if (g) (void)hipGraphExecDestroy(g);
         dev_free(x); dev_free(r); dev_free(z); dev_free(d); dev_free(w); dev_free(scr); dev_free(V); dev_free(Z); dev_free(hs); dev_free(part);
         dev_free(bperm);
         for (auto &p : e) dev_free(p);
@@ -630,12 +661,18 @@ struct elag_hip_krylov_s {
         }
     }
 
+    // ELAG_HIP_KRYLOV_TIMING=1: host time of a solve split into enqueueing and waiting in poll() (printed by solve())
+    double t_poll = 0.0;
+    int n_poll = 0;
     bool poll()
     {
         hipStream_t s = ctx().stream;
+        const auto t0 = std::chrono::steady_clock::now();
         ELAG_HIP_CHECK(hipMemcpyAsync(h_flags, st->fl, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, s));
         ELAG_HIP_CHECK(hipMemcpyAsync(h_sc, st->sc, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, s));
         ELAG_HIP_CHECK(hipStreamSynchronize(s));
+        t_poll += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        n_poll++;
         return h_flags[F_DONE] != 0;
     }
 
@@ -760,55 +797,77 @@ struct elag_hip_krylov_s {
         hipLaunchKernelGGL(gmres_init_kernel, dim3(1), dim3(1), 0, s, st, rel_tol, abs_tol, max_iter);
         ELAG_LAUNCH_CHECK();
         if (poll()) return;
-        int step_id = 0, since_poll = 0;
+        int since_poll = 0;
         bool finished = false;
+        // One inner step (product, preconditioner, modified Gram-Schmidt against i + 1 vectors, rotation, conditional update) is 40 + i
+        // launches that depend on nothing the host knows: replayed as ONE graph per position i of the cycle (built on first use, kept for
+        // the solver's life).  Enqueueing them one by one is half of a solve's wall time on a fast host (cube456 x3 Darcy: 6-8 of 12 ms)
+        // and all of it on a slow one (22-29 ms seen on some boxes of the pool).  ELAG_HIP_GMRES_GRAPH=0: plain launches.
+        auto step = [&](int i) {
+            double *target = flexible ? r : w;   // the vector that is orthogonalised
+            if (flexible) {
+                if (has_prec()) prec(Vq(i), Zq(i));
+                else ELAG_HIP_CHECK(hipMemcpyAsync(Zq(i), Vq(i), sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s));
+                amul(Zq(i), r);
+            } else if (has_prec()) {
+                amul(Vq(i), r);
+                prec(r, w);
+            } else {
+                amul(Vq(i), w);
+            }
+            if (!distributed()) {
+                // fused modified Gram-Schmidt: see gmres_orth_fused_kernel
+                double *pin = part, *pout = part + kPart;
+                hipLaunchKernelGGL(gmres_dot0_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, (const double *)target, (const double *)Vq(0), pin);
+                for (int k = 0; k <= i; k++) {
+                    hipLaunchKernelGGL(gmres_orth_fused_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, hs, m, k, i, target,
+                                       (const double *)Vq(k), (const double *)(k < i ? Vq(k + 1) : nullptr), (const double *)pin, pout);
+                    std::swap(pin, pout);
+                }
+                hipLaunchKernelGGL(gmres_norm_fused_kernel, dim3(1), dim3(kB), 0, s, st, hs, m, i, (const double *)pin);
+            } else {
+                for (int k = 0; k <= i; k++) {
+                    dot(target, Vq(k));
+                    hipLaunchKernelGGL(gmres_orth_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, hs, m, k, i, target, (const double *)Vq(k));
+                }
+                dot(target, target);
+                hipLaunchKernelGGL(gmres_norm_kernel, dim3(1), dim3(1), 0, s, st, hs, m, i);
+            }
+            hipLaunchKernelGGL(scale_inv_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, (int)S_BETA, (const double *)target, Vq(i + 1));
+            hipLaunchKernelGGL(gmres_givens_kernel, dim3(1), dim3(1), 0, s, st, hs, m, i);
+            hipLaunchKernelGGL(gmres_update_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, (const double *)hs, m, i + 1,
+                               (const double *)(flexible ? Z : V), x);
+            ELAG_LAUNCH_CHECK();
+        };
+        static const bool graph_env = !(std::getenv("ELAG_HIP_GMRES_GRAPH") && !atoi(std::getenv("ELAG_HIP_GMRES_GRAPH")));
+        bool graphs = graph_env && gm_graph_ok && capturable();
+        if (graphs && (int)gm_step.size() != m) { for (auto g : gm_step) if (g) (void)hipGraphExecDestroy(g); gm_step.assign((size_t)m, nullptr); gm_flex = flexible; }
+        if (graphs && gm_flex != flexible) graphs = false;
         for (int j = 1; j <= max_iter && !finished;) {
             hipLaunchKernelGGL(scale_inv_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, (int)S_GBETA, (const double *)r, Vq(0));
-            hipLaunchKernelGGL(gmres_start_cycle_kernel, dim3(1), dim3(1), 0, s, st, hs, m);
+            hipLaunchKernelGGL(gmres_start_cycle_kernel, dim3(1), dim3(1), 0, s, st, hs, m, j);
             int i = 0;
             for (; i < m && j <= max_iter; i++, j++) {
-                double *target = flexible ? r : w;   // the vector that is orthogonalised
-                if (flexible) {
-                    if (has_prec()) prec(Vq(i), Zq(i));
-                    else ELAG_HIP_CHECK(hipMemcpyAsync(Zq(i), Vq(i), sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s));
-                    amul(Zq(i), r);
-                } else if (has_prec()) {
-                    amul(Vq(i), r);
-                    prec(r, w);
-                } else {
-                    amul(Vq(i), w);
-                }
-                if (!distributed()) {
-                    // fused modified Gram-Schmidt: see gmres_orth_fused_kernel
-                    double *pin = part, *pout = part + kPart;
-                    hipLaunchKernelGGL(gmres_dot0_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, (const double *)target, (const double *)Vq(0), pin);
-                    for (int k = 0; k <= i; k++) {
-                        hipLaunchKernelGGL(gmres_orth_fused_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, hs, m, k, i, target,
-                                           (const double *)Vq(k), (const double *)(k < i ? Vq(k + 1) : nullptr), (const double *)pin, pout);
-                        std::swap(pin, pout);
+                if (graphs && !gm_step[(size_t)i]) {
+                    hipGraph_t g = nullptr;
+                    bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                    if (ok) {
+                        try { step(i); } catch (...) { ok = false; }
+                        if (hipStreamEndCapture(s, &g) != hipSuccess) ok = false;
                     }
-                    hipLaunchKernelGGL(gmres_norm_fused_kernel, dim3(1), dim3(kB), 0, s, st, hs, m, i, (const double *)pin);
-                } else {
-                    for (int k = 0; k <= i; k++) {
-                        dot(target, Vq(k));
-                        hipLaunchKernelGGL(gmres_orth_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, hs, m, k, i, target, (const double *)Vq(k));
-                    }
-                    dot(target, target);
-                    hipLaunchKernelGGL(gmres_norm_kernel, dim3(1), dim3(1), 0, s, st, hs, m, i);
+                    hipGraphExec_t ge = nullptr;
+                    if (ok && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) gm_step[(size_t)i] = ge;
+                    else { (void)hipGetLastError(); graphs = false; gm_graph_ok = false; }       // (this solver keeps to plain launches)
+                    if (g) (void)hipGraphDestroy(g);
                 }
-                hipLaunchKernelGGL(scale_inv_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, (int)S_BETA, (const double *)target, Vq(i + 1));
-                ++step_id;
-                hipLaunchKernelGGL(gmres_givens_kernel, dim3(1), dim3(1), 0, s, st, hs, m, i, j, step_id);
-                hipLaunchKernelGGL(gmres_update_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, step_id, (const double *)hs, m, i + 1,
-                                   (const double *)(flexible ? Z : V), x);
-                ELAG_LAUNCH_CHECK();
+                if (graphs) ELAG_HIP_CHECK(hipGraphLaunch(gm_step[(size_t)i], s));
+                else step(i);
                 if (++since_poll >= check_every) { since_poll = 0; if (poll()) { finished = true; i++; j++; break; } }
             }
             if (finished) break;
             // restart: Update(x, i-1, ...), true residual, convergence test on its norm
-            ++step_id;
-            hipLaunchKernelGGL(gmres_restart_backsolve_kernel, dim3(1), dim3(1), 0, s, st, hs, m, i - 1, step_id);
-            hipLaunchKernelGGL(gmres_update_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, step_id, (const double *)hs, m, i,
+            hipLaunchKernelGGL(gmres_restart_backsolve_kernel, dim3(1), dim3(1), 0, s, st, hs, m, i - 1);
+            hipLaunchKernelGGL(gmres_update_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, (const double *)hs, m, i,
                                (const double *)(flexible ? Z : V), x);
             if (!flexible && has_prec()) { residual(b, x, w); prec(w, r); }
             else residual(b, x, r);
@@ -945,6 +1004,9 @@ struct elag_hip_krylov_s {
         } else if (iterative) {
             ELAG_HIP_CHECK(hipMemcpyAsync(x, xio, sizeof(double) * nn, hipMemcpyDeviceToDevice, s));
         }
+        static const bool timing = std::getenv("ELAG_HIP_KRYLOV_TIMING") != nullptr;
+        const auto t_begin = std::chrono::steady_clock::now();
+        t_poll = 0.0; n_poll = 0;
         switch (solver) {
         case ELAG_HIP_KRYLOV_CG: run_cg(b, iterative); break;
         case ELAG_HIP_KRYLOV_GMRES: run_gmres(b, iterative, false); break;
@@ -953,9 +1015,17 @@ struct elag_hip_krylov_s {
         case ELAG_HIP_KRYLOV_MINRES: run_minres(b, iterative); break;
         default: run_stationary(b, iterative); break;
         }
+        const double t_run = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
         fetch_results();
+        if (timing)
+            fprintf(stderr, "[elag_hip] krylov solve: %d iterations, host %.3f ms up to the last poll: %.3f ms enqueueing, %.3f ms waiting in %d polls\n", final_iter,
+                    t_run * 1e3, (t_run - t_poll) * 1e3, t_poll * 1e3, n_poll);
         if (d_perm) k::vec_scatter((int)nn, d_perm, x, xio, 0);
         else ELAG_HIP_CHECK(hipMemcpyAsync(xio, x, sizeof(double) * nn, hipMemcpyDeviceToDevice, s));
+        if (timing) {
+            ELAG_HIP_CHECK(hipStreamSynchronize(s));
+            fprintf(stderr, "[elag_hip] krylov mult: %.3f ms in all\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3);
+        }
     }
 };
 
