@@ -439,7 +439,7 @@ template <int NMAX, bool BIG, bool NUMERIC, class Expander>
 __global__ __launch_bounds__(kBlock) void esc_kernel(int nrows, const int *__restrict__ ubscan /*nrows+1*/,
                                                      const int *__restrict__ ub, const int *__restrict__ biglist,
                                                      Expander ex, int *__restrict__ rownnz,
-                                                     const int *__restrict__ CI, int *__restrict__ CJ, double *__restrict__ Ca)
+                                                     const int *__restrict__ CI, int *__restrict__ CJ, double *__restrict__ Ca, int big_hash = 0)
 {
     __shared__ u64 key[NMAX];
     __shared__ double val[NUMERIC ? NMAX : 1];
@@ -459,6 +459,109 @@ __global__ __launch_bounds__(kBlock) void esc_kernel(int nrows, const int *__res
         base = ubscan[r0]; count = ubscan[r1] - base;
     }
     if (count == 0) return;
+    if constexpr (BIG && NUMERIC && Expander::kFlat && NMAX == 8192) {
+        // One long row, without sorting its products (up to 8 192 of them: 91 barrier-separated stages over (key, value) pairs -- 0.56-0.74 ms
+        // of every hierarchy build for a few hundred such rows): the products are staged 2 048 at a time in their order, ONE wavefront adds them
+        // to a hash table of column sums in LDS -- 64 at a time, in ascending lane order (lds_atomics_lane_ordered: the adds of one instruction
+        // that meet on a column are applied lowest lane first, the lowest lane wins an empty slot), so a column's sum is the sum of its
+        // products in product order whatever the schedule --, then only the distinct columns are sorted.
+        const CsrView &A = ex.A, &B = ex.B;
+        const int as = A.I[r0], na = A.I[r0 + 1] - as;
+        if (big_hash && na <= kFlatUnits) {                                    // (uniform over the workgroup)
+            __shared__ int pre[kFlatUnits + 1];
+            constexpr int HT = 8192, CH = 2048;
+            int *hk = reinterpret_cast<int *>(key);                            // HT slots: column (-1: empty)
+            int *pk = hk + HT;                                                 // CH staged columns
+            double *pv = reinterpret_cast<double *>(pk + CH);                  // CH staged values
+            double *hv = val;                                                  // HT sums
+            int *uk = hk + HT;                                                 // afterwards: the distinct columns (over pk / pv and the rest of `key`)
+            auto slot_of = [](int col) { return (int)(((unsigned)col * 2654435761u) >> 19); };
+            for (int i = threadIdx.x; i < HT; i += kBlock) { hk[i] = -1; hv[i] = 0.0; }
+            for (int t = threadIdx.x; t < na; t += kBlock) pre[t + 1] = B.rowlen(A.J[as + t]);
+            if (threadIdx.x == 0) pre[0] = 0;
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                int carry = 0;
+                for (int b = 0; b < na; b += 64) {
+                    const int t = b + (int)threadIdx.x;
+                    int v = t < na ? pre[t + 1] : 0;
+                    v = wave_incl_scan(v);
+                    if (t < na) pre[t + 1] = v + carry;
+                    carry += __shfl(v, 63, 64);
+                }
+            }
+            __syncthreads();
+            const int total = pre[na];
+            for (int c0 = 0; c0 < total; c0 += CH) {
+                const int nch = min(CH, total - c0);
+                for (int p = threadIdx.x; p < nch; p += kBlock) {
+                    const int pp = c0 + p;
+                    int lo = 0, hi = na;                                       // the entry whose run holds product pp: pre[lo] <= pp < pre[lo + 1]
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= pp) lo = mid; else hi = mid; }
+                    const int j = A.J[as + lo], q = B.rowbeg(j) + (pp - pre[lo]);
+                    pk[p] = B.J[q];
+                    pv[p] = A.a[as + lo] * B.a[q];
+                }
+                __syncthreads();
+                if (threadIdx.x < 64) {
+                    for (int p0 = 0; p0 < nch; p0 += 64) {
+                        const int p = p0 + (int)threadIdx.x;
+                        const bool on = p < nch;
+                        const int col = on ? pk[p] : 0;
+                        const double v = on ? pv[p] : 0.0;
+                        int h = slot_of(col);
+                        if (on)
+                            for (;;) {
+                                const int prev = atomicCAS(&hk[h], -1, col);
+                                if (prev == -1 || prev == col) break;
+                                h = (h + 1) & (HT - 1);
+                            }
+                        __builtin_amdgcn_wave_barrier();
+                        if (on) atomicAdd(&hv[h], v);                           // ONE instruction for the 64 products: lanes ascending
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                __syncthreads();
+            }
+            // the distinct columns, compacted (a thread owns HT / kBlock consecutive slots) and sorted
+            constexpr int PER = HT / kBlock;
+            int cnt = 0;
+#pragma unroll 4
+            for (int q = 0; q < PER; q++) cnt += hk[threadIdx.x * PER + q] >= 0 ? 1 : 0;
+            int nu;
+            int off = block_excl_scan(cnt, sh, &nu);
+            for (int q = 0; q < PER; q++) {
+                const int k = hk[threadIdx.x * PER + q];
+                if (k >= 0) uk[off++] = k;
+            }
+            int npow = 64;
+            while (npow < nu) npow <<= 1;
+            __syncthreads();
+            for (int i = nu + (int)threadIdx.x; i < npow; i += kBlock) uk[i] = 0x7fffffff;
+            __syncthreads();
+            for (int size = 2; size <= npow; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int t = threadIdx.x; t < (npow >> 1); t += kBlock) {
+                        const int lo = 2 * t - (t & (stride - 1));
+                        const int hi = lo + stride;
+                        const bool up = ((lo & size) == 0);
+                        const int a0 = uk[lo], b0 = uk[hi];
+                        if ((a0 > b0) == up) { uk[lo] = b0; uk[hi] = a0; }
+                    }
+                    __syncthreads();
+                }
+            const int cbeg = CI[r0];
+            for (int i = threadIdx.x; i < nu; i += kBlock) {
+                const int col = uk[i];
+                int h = slot_of(col);
+                while (hk[h] != col) h = (h + 1) & (HT - 1);
+                CJ[cbeg + i] = col;
+                Ca[cbeg + i] = hv[h];
+            }
+            if (rownnz && threadIdx.x == 0) rownnz[r0] = nu;
+            return;
+        }
+    }
     int n2 = 64;
     while (n2 < count) n2 <<= 1;
     // expand: one wavefront per row, round-robin; the single long row of a BIG workgroup by all of its threads where the expander can
@@ -1578,6 +1681,13 @@ bool lds_atomics_lane_ordered()
     return ok;
 }
 
+// long single rows of a product through the hash table of column sums (esc_kernel, BIG): needs the lane order of the LDS atomics
+inline int esc_big_hash()
+{
+    const char *e = getenv("ELAG_HIP_BIG_HASH");       // (read at every product: A/B runs and a test switch it)
+    return (!(e && !atoi(e)) && lds_atomics_lane_ordered()) ? 1 : 0;
+}
+
 inline bool ell_pipe_enabled()
 {
     const char *e = getenv("ELAG_HIP_ELL_PIPE");       // (read at every product: A/B runs and a test switch it); 0 = esc_hash_kernel for the W-slot right factor too
@@ -1811,7 +1921,7 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
                                        plan.ub_small.p, (const int *)nullptr, ex, rownnz.p, (const int *)UBI.p, Ju.p, au.p);
                 if (plan.nbig)
                     hipLaunchKernelGGL((esc_kernel<kBigCap, true, true, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
-                                       plan.ub.p, plan.biglist.p, ex, rownnz.p, (const int *)UBI.p, Ju.p, au.p);
+                                       plan.ub.p, plan.biglist.p, ex, rownnz.p, (const int *)UBI.p, Ju.p, au.p, esc_big_hash());
             }
             ELAG_LAUNCH_CHECK();
             if (keep) return;                        // the product stays where its kernels wrote it
@@ -1833,7 +1943,7 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
                                    plan.ub_small.p, (const int *)nullptr, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
             if (plan.nbig && !single_all)
                 hipLaunchKernelGGL((esc_kernel<kBigCap, true, true, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
-                                   plan.ub.p, plan.biglist.p, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
+                                   plan.ub.p, plan.biglist.p, ex, (int *)nullptr, (const int *)C.I, C.J, C.a, esc_big_hash());
             hipLaunchKernelGGL(esc_compact_kernel, dim3(grid1((long long)n * 8)), dim3(kBlock), 0, st, n, (const int *)ubw.p, (const int *)UBI.p,
                                (const int *)C.I, (const int *)Ju.p, (const double *)au.p, C.J, C.a);
             ELAG_LAUNCH_CHECK();
@@ -1868,7 +1978,7 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
                            plan.ub_small.p, (const int *)nullptr, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
     if (plan.nbig)
         hipLaunchKernelGGL((esc_kernel<kBigCap, true, true, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
-                           plan.ub.p, plan.biglist.p, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
+                           plan.ub.p, plan.biglist.p, ex, (int *)nullptr, (const int *)C.I, C.J, C.a, esc_big_hash());
     if (plan.wave_cap > 0) {
         const int *ubp = plan.ub.p;
         hipLaunchKernelGGL((esc_wave_kernel<16, 1, true, Expander>), dim3(grid1((long long)n * 16)), dim3(kBlock), 0, st, n, ubp, 0, 16, ex, (int *)nullptr,
