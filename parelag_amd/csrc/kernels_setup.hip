@@ -576,6 +576,78 @@ __global__ __launch_bounds__(kBlock) void esc_kernel(int nrows, const int *__res
             const int off = BIG ? 0 : (ubscan[row] - base);
             if (BIG || ub[row] > 0) ex.template expand<NUMERIC>(row, (unsigned)(row - r0), off, key, val);
         }
+    if constexpr (!BIG && NUMERIC && NMAX == 2 * kCap) {
+        // A chunk of rows the same way (see the BIG branch above): the chunk's products sit in key / val in product order row after row; one
+        // wavefront adds them to a table of (row, column) sums, the distinct (row, column) pairs are sorted, a pair's place in C is its row's
+        // offset plus its rank among the row's pairs.
+        if (big_hash) {
+            constexpr int HT = NMAX;                                            // at most NMAX products, hence at most NMAX distinct pairs
+            __shared__ u64 hk[HT];
+            __shared__ double hv[HT];
+            static_assert(HT == 4096, "the slot is the top 12 bits of the mixed key");
+            auto slot_of = [](u64 k) { return (int)((((unsigned)k + (unsigned)(k >> 32) * 0x9E3779B1u) * 2654435761u) >> 20); };
+            for (int i = threadIdx.x; i < HT; i += kBlock) { hk[i] = ~0ull; hv[i] = 0.0; }
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                for (int p0 = 0; p0 < count; p0 += 64) {
+                    const int p = p0 + (int)threadIdx.x;
+                    const u64 kk = p < count ? key[p] : ~0ull;
+                    const bool on = kk != ~0ull;                                // (an expander may leave unused places of its upper bound)
+                    const double v = on ? val[p] : 0.0;
+                    int h = slot_of(kk);
+                    if (on)
+                        for (;;) {
+                            const u64 prev = atomicCAS(reinterpret_cast<unsigned long long *>(&hk[h]), ~0ull, (unsigned long long)kk);
+                            if (prev == ~0ull || prev == kk) break;
+                            h = (h + 1) & (HT - 1);
+                        }
+                    __builtin_amdgcn_wave_barrier();
+                    if (on) atomicAdd(&hv[h], v);                               // ONE instruction for the 64 products: lanes ascending
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            __syncthreads();
+            constexpr int PER = HT / kBlock;
+            int cnt = 0;
+            for (int q = 0; q < PER; q++) cnt += hk[threadIdx.x * PER + q] != ~0ull ? 1 : 0;
+            int nu;
+            int off = block_excl_scan(cnt, sh, &nu);
+            for (int q = 0; q < PER; q++) {
+                const u64 k = hk[threadIdx.x * PER + q];
+                if (k != ~0ull) key[off++] = k;                                 // (the products are in the table: `key` holds the distinct pairs now)
+            }
+            int npow = 64;
+            while (npow < nu) npow <<= 1;
+            __syncthreads();
+            for (int i = nu + (int)threadIdx.x; i < npow; i += kBlock) key[i] = ~0ull;
+            __syncthreads();
+            for (int size = 2; size <= npow; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int t = threadIdx.x; t < (npow >> 1); t += kBlock) {
+                        const int lo = 2 * t - (t & (stride - 1));
+                        const int hi = lo + stride;
+                        const bool up = ((lo & size) == 0);
+                        const u64 a0 = key[lo], b0 = key[hi];
+                        if ((a0 > b0) == up) { key[lo] = b0; key[hi] = a0; }
+                    }
+                    __syncthreads();
+                }
+            for (int i = threadIdx.x; i < nu; i += kBlock) {
+                const u64 kk = key[i];
+                const unsigned rl = (unsigned)(kk >> 32);
+                const u64 rowkey = (u64)rl << 32;
+                int lo = 0, hi = i;                                             // first sorted pair of row rl (<= i)
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (key[mid] < rowkey) lo = mid + 1; else hi = mid; }
+                int h = slot_of(kk);
+                while (hk[h] != kk) h = (h + 1) & (HT - 1);
+                const int pos = CI[r0 + (int)rl] + (i - lo);
+                CJ[pos] = (int)(kk & 0xffffffffu);
+                Ca[pos] = hv[h];
+                if (rownnz) atomicAdd(&rownnz[r0 + (int)rl], 1);               // (single pass: CI holds upper-bound offsets, the rows' entry counts are recorded on the way)
+            }
+            return;
+        }
+    }
     for (int i = count + threadIdx.x; i < n2; i += kBlock) key[i] = ~0ull;
     __syncthreads();
     bitonic_sort_lds<NUMERIC>(key, val, n2);
@@ -1918,7 +1990,7 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
                 // numeric launch each instead of a symbolic and a numeric one (cube456 x3, the flattened cycle's G1 G0: 0.67 + 0.38 ms)
                 if (nch)
                     hipLaunchKernelGGL((esc_kernel<2 * kCap, false, true, Expander>), dim3(nch), dim3(kBlock), 0, st, n, plan.ubscan.p,
-                                       plan.ub_small.p, (const int *)nullptr, ex, rownnz.p, (const int *)UBI.p, Ju.p, au.p);
+                                       plan.ub_small.p, (const int *)nullptr, ex, rownnz.p, (const int *)UBI.p, Ju.p, au.p, esc_big_hash());
                 if (plan.nbig)
                     hipLaunchKernelGGL((esc_kernel<kBigCap, true, true, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
                                        plan.ub.p, plan.biglist.p, ex, rownnz.p, (const int *)UBI.p, Ju.p, au.p, esc_big_hash());
@@ -1940,7 +2012,7 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
             if (spmv_plan) C.known_max_row = hnnz[1];
             if (nch && !single_all)
                 hipLaunchKernelGGL((esc_kernel<2 * kCap, false, true, Expander>), dim3(nch), dim3(kBlock), 0, st, n, plan.ubscan.p,
-                                   plan.ub_small.p, (const int *)nullptr, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
+                                   plan.ub_small.p, (const int *)nullptr, ex, (int *)nullptr, (const int *)C.I, C.J, C.a, esc_big_hash());
             if (plan.nbig && !single_all)
                 hipLaunchKernelGGL((esc_kernel<kBigCap, true, true, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
                                    plan.ub.p, plan.biglist.p, ex, (int *)nullptr, (const int *)C.I, C.J, C.a, esc_big_hash());
@@ -1975,7 +2047,7 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
     C.alloc_entries(nnz);
     if (nch)
         hipLaunchKernelGGL((esc_kernel<2 * kCap, false, true, Expander>), dim3(nch), dim3(kBlock), 0, st, n, plan.ubscan.p,
-                           plan.ub_small.p, (const int *)nullptr, ex, (int *)nullptr, (const int *)C.I, C.J, C.a);
+                           plan.ub_small.p, (const int *)nullptr, ex, (int *)nullptr, (const int *)C.I, C.J, C.a, esc_big_hash());
     if (plan.nbig)
         hipLaunchKernelGGL((esc_kernel<kBigCap, true, true, Expander>), dim3(plan.nbig), dim3(kBlock), 0, st, n, plan.ubscan.p,
                            plan.ub.p, plan.biglist.p, ex, (int *)nullptr, (const int *)C.I, C.J, C.a, esc_big_hash());
