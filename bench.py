@@ -139,6 +139,31 @@ def hiptmair_hbm_leg(args, la, meshgen, np, hipt_type):
     return rec
 
 
+def other_configs_in_child(args, timeout_s=300):
+    """The `other_configs` leg in a process of its own: three more hierarchies, two GMRES solves and their step graphs are extras of the line,
+    and a fault in one of them (seen once: a SIGSEGV inside hipGraphLaunch under rocprofv3's kernel trace) must not take the headline with
+    it.  The child is this script with --other-configs-only; it starts after the parent's own device legs have finished and released their
+    operators, and prints one JSON line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--other-configs-only", "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if args.no_graph: cmd.append("--no-graph")
+    if args.no_cpu_baseline: cmd.append("--no-cpu-baseline")
+    cmd += ["--perm-sigma", str(args.perm_sigma)]
+    t0 = time.time()
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "the other_configs child did not finish within %d s" % timeout_s}
+    if r.returncode != 0:
+        return {"error": "the other_configs child ended with return code %d" % r.returncode}
+    try:
+        rec = json.loads(r.stdout.strip().splitlines()[-1])["other_configs"]
+    except Exception as exc:
+        return {"error": "unreadable output of the other_configs child: %r" % (exc,)}
+    rec["process"] = "child of the bench process (%.1f s with its start-up)" % (time.time() - t0)
+    return rec
+
+
 def other_configs_leg(args, la, meshgen, np, sp, budget_s=60.0):
     """BASELINE configs[2] and configs[3] in the default line, compact and bounded: the driver times only this command, so without this
     object every number of four of the five BASELINE configurations is the builder's own.
@@ -623,6 +648,7 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic in this run (three rocprofv3 --pmc child passes, ~40 s): "
                     "report the figure recorded under profiles/ instead")
     ap.add_argument("--no-gs", action="store_true", help="skip the L1 Gauss-Seidel cycle reported beside the headline one")
+    ap.add_argument("--other-configs-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact BASELINE configs 3 / 4 legs of the default line (other_configs)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--solve", action="store_true", help="also time the Krylov solve of the example (PCG / GMRES with the cycle as "
@@ -666,8 +692,8 @@ def main():
 
     # CPU baseline of the headline workload in the reference's layout, measured before this process touches the GPU (the child forks)
     spmd = {}
-    if world == 1 and not args.force_dist and not args.no_cpu_baseline and not args.roofline_only and args.form == 0 and not darcy \
-            and not (args.amge or args.hex) and args.smoother == "L1 Jacobi":
+    if world == 1 and not args.force_dist and not args.no_cpu_baseline and not args.roofline_only and not args.other_configs_only and args.form == 0 \
+            and not darcy and not (args.amge or args.hex) and args.smoother == "L1 Jacobi":
         note("CPU baseline (one process per core) ...")
         spmd["headline"] = spmd_cpu_baseline(args.refines, max(1.0, args.cpu_seconds / 5))
         if not args.no_roofline:
@@ -681,7 +707,8 @@ def main():
 
     # HBM traffic of the roofline kernel from the PMC counters, in this run (children under rocprofv3, before this process touches the GPU)
     live_traffic = None
-    if world == 1 and not args.force_dist and not args.no_roofline and not args.roofline_only and not args.no_traffic and args.form == 0 and not darcy:
+    if world == 1 and not args.force_dist and not args.no_roofline and not args.roofline_only and not args.other_configs_only and not args.no_traffic \
+            and args.form == 0 and not darcy:
         note("roofline traffic: rocprofv3 --pmc passes ...")
         live_traffic = measure_roofline_traffic(args)
         note("roofline traffic: %s" % (live_traffic,))
@@ -696,6 +723,14 @@ def main():
         dist = distributed.init(rank, world)
     else:
         _lib.init()
+
+    if args.other_configs_only:
+        # the child process of the default line's `other_configs` leg (see other_configs_in_child): one JSON line, nothing else on stdout
+        from parelag_amd.distributed import stdout_to_stderr
+        with stdout_to_stderr():
+            rec = other_configs_leg(args, la, meshgen, np, sp)
+        print(json.dumps({"other_configs": rec}), flush=True)
+        return 0
 
     out = {}
     # ---------------------------------------------------------------- roofline leg (rank 0 of N=1 runs only)
@@ -1085,7 +1120,7 @@ def main():
     other = None
     if single and args.form == 0 and not darcy and not (args.amge or args.hex) and args.smoother == "L1 Jacobi" and args.refines == 3 and not args.no_other_configs:
         note("other configs (H(div) + Hiptmair x3, Darcy x3) ...")
-        other = other_configs_leg(args, la, meshgen, np, sp)
+        other = other_configs_in_child(args)
 
     # ---------------------------------------------------------------- optional: the example's Krylov solve on the device
     # forms 0 / 1 / 2: PCG preconditioned by the cycle (Create0FormParameterList.hpp:78-83).  Darcy / SPE10: GMRES preconditioned by the

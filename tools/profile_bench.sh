@@ -4,7 +4,8 @@
 OUT=$PWD/gpurun_out/$1; shift
 REPO=$PWD; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/bench.py "$@" > $OUT/bench.log 2>&1
+# (ELAG_HIP_GMRES_GRAPH=0: the kernel trace faults inside hipGraphLaunch on the GMRES step graphs of the other_configs child -- seen in this round)
+ELAG_HIP_GMRES_GRAPH=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/bench.py "$@" > $OUT/bench.log 2>&1
 cd $REPO
 tail -1 $OUT/bench.log | cut -c1-600
 python3 - <<PY
