@@ -602,6 +602,75 @@ __global__ __launch_bounds__(kLdsInvBlock) void spd_inverse_lds_kernel(int n, co
     if (own)
         for (int i = ty; i < n; i += kRowsPerPass) Minv[(size_t)i * n + tx] = 0.5 * (Ml[i * n + tx] + Ml[tx * n + i]);
 }
+
+// The same launch with the matrix in REGISTERS during the elimination: the sweep above reads and writes every entry in LDS at every pivot (three LDS
+// accesses per entry and pivot: 2.6 us per pivot at n = 141, LDS-throughput bound), here a thread keeps its column's entries of the rows ty, ty + 7,
+// ... (21 registers) and a pivot costs it the broadcast reads of column k (two entries per read), one read of row k, one barrier (the two pivot
+// vectors are double-buffered).  The loop over the pivots is unrolled over the register that holds row k, so no register is indexed dynamically.
+// Same arithmetic, entry by entry, as the LDS sweep (ELAG_HIP_SPD_REG=0 selects that one).
+constexpr int kRegCols = 144, kRegGroups = kLdsInvBlock / kRegCols, kRegRows = (kLdsInvMax + kRegGroups - 1) / kRegGroups;   // 7 groups x 21 rows
+__global__ __launch_bounds__(kLdsInvBlock) void spd_inverse_reg_kernel(int n, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
+                                                                   double *__restrict__ Minv, int *__restrict__ bad)
+{
+    extern __shared__ double Ml[];          // n x n, row-major: the scatter, the first symmetrisation and the last one
+    __shared__ double colk[2][kRegGroups][kRegRows + 1];   // colk[.][ty][s] = M[ty + 7 s][k]
+    __shared__ double rowk[2][kRegCols];                    // M[k][.]
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int tx = t % kRegCols, ty = t / kRegCols;
+    const bool own = tx < n && ty < kRegGroups;
+    for (int e = t; e < n * n; e += nt) Ml[e] = 0.0;
+    __syncthreads();
+    for (int i = t; i < n; i += nt)
+        for (int q = I[i]; q < I[i + 1]; q++) Ml[i * n + J[q]] += a[q];       // (one thread per row: repeated columns add up in storage order)
+    __syncthreads();
+    if (own)
+        for (int i = ty; i < n; i += kRegGroups)
+            if (tx > i) { const double v = 0.5 * (Ml[i * n + tx] + Ml[tx * n + i]); Ml[i * n + tx] = v; Ml[tx * n + i] = v; }
+    __syncthreads();
+    double m[kRegRows];
+#pragma unroll
+    for (int s = 0; s < kRegRows; s++) {
+        const int i = ty + kRegGroups * s;
+        m[s] = (own && i < n) ? Ml[i * n + tx] : 0.0;
+    }
+    int nbad = 0;
+#pragma unroll
+    for (int s0 = 0; s0 < kRegRows; s0++) {
+        if (kRegGroups * s0 >= n) break;
+        for (int ty0 = 0; ty0 < kRegGroups; ty0++) {
+            const int k = kRegGroups * s0 + ty0;
+            if (k >= n) break;
+            const int b = k & 1;
+            if (ty == ty0 && ty < kRegGroups) rowk[b][tx] = m[s0];
+            if (tx == k && ty < kRegGroups) {
+#pragma unroll
+                for (int s = 0; s < kRegRows; s++) colk[b][ty][s] = m[s];
+            }
+            __syncthreads();
+            const double p = rowk[b][k];
+            if (!(p > 0.0)) nbad++;
+            const double rk = (tx == k) ? 1.0 / p : rowk[b][tx] / p;
+            if (ty < kRegGroups) {
+#pragma unroll
+                for (int s = 0; s < kRegRows; s++) {
+                    const double c = colk[b][ty][s];
+                    const double upd = (tx == k) ? -c * rk : m[s] - c * rk;          // rk = 1 / p on column k
+                    m[s] = (s == s0 && ty == ty0) ? rk : upd;
+                }
+            }
+        }
+    }
+    if (t == 0 && nbad) atomicAdd(bad, nbad);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kRegRows; s++) {
+        const int i = ty + kRegGroups * s;
+        if (own && i < n) Ml[i * n + tx] = m[s];
+    }
+    __syncthreads();
+    if (own)
+        for (int i = ty; i < n; i += kRegGroups) Minv[(size_t)i * n + tx] = 0.5 * (Ml[i * n + tx] + Ml[tx * n + i]);
+}
 }  // namespace
 
 namespace {
@@ -699,11 +768,18 @@ void dense_inverse_spd(const DevCSR &A, double *Minv)
         if (!raised && lds > (size_t)(48 << 10)) {
             ELAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(spd_inverse_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)(sizeof(double) * kLdsInvMax * kLdsInvMax)));
+            ELAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(spd_inverse_reg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)(sizeof(double) * kLdsInvMax * kLdsInvMax)));
             raised = true;
         }
         Temp<int> bad(1);
         ELAG_HIP_CHECK(hipMemsetAsync(bad.p, 0, sizeof(int), st));
-        hipLaunchKernelGGL(spd_inverse_lds_kernel, dim3(1), dim3(kLdsInvBlock), lds, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, Minv, bad.p);
+        const char *e_reg = getenv("ELAG_HIP_SPD_REG");                 // (read at every call: a test switches it)
+        const bool in_regs = !(e_reg && !atoi(e_reg));
+        if (in_regs)
+            hipLaunchKernelGGL(spd_inverse_reg_kernel, dim3(1), dim3(kLdsInvBlock), lds, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, Minv, bad.p);
+        else
+            hipLaunchKernelGGL(spd_inverse_lds_kernel, dim3(1), dim3(kLdsInvBlock), lds, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, Minv, bad.p);
         ELAG_LAUNCH_CHECK();
         int nbad = 0;
         ELAG_HIP_CHECK(hipMemcpyAsync(&nbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -461,3 +461,31 @@ def test_blocked_dense_lu_is_the_column_by_column_one(la, n):
     for x in xs:
         assert np.max(np.abs(x - ref)) <= 1e-10 * scale
     assert np.max(np.abs(xs[0] - xs[1])) <= 1e-10 * scale
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 50, 97, 140, 141])
+def test_spd_inverse_in_registers_is_the_lds_sweep_bit_for_bit(la, n):
+    """The coarsest SPD operator of the single-form hierarchies (141 dofs at cube456 x3) is inverted by one workgroup: spd_inverse_reg_kernel keeps the
+    matrix in registers during the elimination, spd_inverse_lds_kernel (ELAG_HIP_SPD_REG=0) sweeps it in LDS.  Entry by entry the same
+    operations in the same order: the two inverses applied to a vector agree to the last bit, and with a host solve; repeated columns of a row
+    add up in storage order either way."""
+    import os
+    rng = np.random.default_rng(100 + n)
+    R = sp.random(n, n, density=min(1.0, 6.0 / n), random_state=n, format="csr")
+    A = (R @ R.T + sp.diags(rng.uniform(1.0, 2.0, n))).tocsr()
+    A = orc.csr(A)
+    b = rng.uniform(-1, 1, n)
+    xs = []
+    for env in ({}, {"ELAG_HIP_SPD_REG": "0"}):
+        os.environ.update(env)
+        try:
+            C = la.CoarseSolver(la.ParallelCSRMatrix.from_scipy(A), kind=0)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        x = np.zeros(n)
+        C.Mult(b, x)
+        xs.append(x)
+    ref = np.linalg.solve(A.toarray(), b)
+    assert np.max(np.abs(xs[0] - ref)) <= 1e-12 * np.max(np.abs(ref)) * np.linalg.cond(A.toarray())
+    assert np.array_equal(xs[0], xs[1])
