@@ -93,6 +93,8 @@ struct Context {
     double *h_scalar = nullptr;         // pinned mirror
     char *h_stage = nullptr;            // pinned staging buffer of host_from_dev (kHostStage bytes): read-backs beyond a few tens of KB into pageable
                                         // memory take the runtime's pin-the-user-buffer path, 2-8 ms the first time a buffer is seen
+    int *h_fetch = nullptr;             // pinned, device-visible: the words of fetch_ints, [31] = the sequence number of the last fetch that arrived
+    int fetch_seq = 0;
     int gs_blocks = 0;                  // elag_hip_set_gs_hybrid_blocks (0: ELAG_HIP_GS_BLOCKS, else 1)
     long long n_exchanges = 0, n_allreduces = 0;   // data-plane rounds issued by this rank (neighbour exchanges with a remote peer, device all-reduces)
 };
@@ -106,6 +108,13 @@ void require_init();
 // blocking call; ELAG_HIP_SPIN_MS=0 always blocks.
 void stream_wait(hipStream_t st);
 void event_wait(hipEvent_t ev);
+// A few words of device memory on the host, ordered after everything queued on the compute stream: the counts and flags the setup path
+// sizes its next step by (45 of them in one cube456 x3 hierarchy build).  A one-wavefront kernel writes them into pinned host memory, then a
+// sequence number; the host polls that number -- 9.5 us per round trip against 15 for hipMemcpyAsync + hipStreamSynchronize and more when
+// the destination is pageable (tools/sync_probe.cpp).  ELAG_HIP_FETCH_KERNEL=0: the copy API.  count <= 30 ints / 15 doubles.
+void fetch_ints(const int *dev, int count, int *out);
+inline void fetch_doubles(const double *dev, int count, double *out) { fetch_ints(reinterpret_cast<const int *>(dev), 2 * count, reinterpret_cast<int *>(out)); }
+inline int fetch_int(const int *dev) { int v = 0; fetch_ints(dev, 1, &v); return v; }
 void amge_release_arena();            // amge.hip: frees the calling thread's coarsening arena (elag_hip_finalize)
 
 // ---- device memory helpers ---------------------------------------------------------------------

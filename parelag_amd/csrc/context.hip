@@ -3,6 +3,7 @@
 #include "comm.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -190,6 +191,10 @@ void stage_d2h(void *host_dst, const void *dev_src, size_t bytes)
     if (!c.h_stage || !kernel_copies()) {
         ELAG_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c.stream));
         ELAG_HIP_CHECK(hipStreamSynchronize(c.stream));
+        return;
+    }
+    if (bytes <= 120 && bytes % 4 == 0 && ((uintptr_t)dev_src & 3) == 0 && ((uintptr_t)host_dst & 3) == 0) {      // a few words: see fetch_ints
+        fetch_ints(static_cast<const int *>(dev_src), (int)(bytes / 4), static_cast<int *>(host_dst));
         return;
     }
     const unsigned char *src = static_cast<const unsigned char *>(dev_src);
@@ -503,6 +508,36 @@ void poll_then_block(Query query, Block block)
     ELAG_HIP_CHECK(block());
 }
 }  // namespace
+namespace {
+__global__ void fetch_publish_kernel(const int *__restrict__ src, int count, volatile int *host, int seq)
+{
+    const int l = threadIdx.x;                       // one wavefront
+    if (l < count) host[l] = src[l];
+    __threadfence_system();
+    if (l == 0) host[31] = seq;
+}
+}  // namespace
+void fetch_ints(const int *dev, int count, int *out)
+{
+    Context &c = ctx();
+    ELAG_REQUIRE(count >= 0 && count <= 30, "fetch_ints: %d words", count);
+    if (count == 0) return;
+    static const bool by_kernel = !(getenv("ELAG_HIP_FETCH_KERNEL") && !atoi(getenv("ELAG_HIP_FETCH_KERNEL")));
+    if (!by_kernel || !c.h_fetch) {
+        ELAG_HIP_CHECK(hipMemcpyAsync(c.h_fetch ? (void *)c.h_fetch : (void *)out, dev, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost, c.stream));
+        ELAG_HIP_CHECK(hipStreamSynchronize(c.stream));
+        if (c.h_fetch) for (int i = 0; i < count; i++) out[i] = c.h_fetch[i];
+        return;
+    }
+    const int seq = ++c.fetch_seq;
+    volatile int *h = c.h_fetch;
+    hipLaunchKernelGGL(fetch_publish_kernel, dim3(1), dim3(64), 0, c.stream, dev, count, h, seq);
+    ELAG_LAUNCH_CHECK();
+    poll_then_block([&] { return h[31] == seq ? hipSuccess : hipErrorNotReady; }, [&] { return hipStreamSynchronize(c.stream); });
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (h[31] != seq) fail(ELAG_HIP_ERR_HIP, "fetch_ints: the stream drained without the words arriving");
+    for (int i = 0; i < count; i++) out[i] = h[i];
+}
 void stream_wait(hipStream_t st) { poll_then_block([&] { return hipStreamQuery(st); }, [&] { return hipStreamSynchronize(st); }); }
 void event_wait(hipEvent_t ev) { poll_then_block([&] { return hipEventQuery(ev); }, [&] { return hipEventSynchronize(ev); }); }
 }  // namespace elag
@@ -551,6 +586,9 @@ int elag_hip_init(int device)
         ELAG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&c.d_scalar), 16 * sizeof(double)));
         ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c.h_scalar), 16 * sizeof(double), hipHostMallocDefault));
         ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c.h_stage), kHostStage, hipHostMallocDefault));
+        ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c.h_fetch), 32 * sizeof(int), hipHostMallocCoherent));
+        for (int i = 0; i < 32; i++) c.h_fetch[i] = 0;
+        c.fetch_seq = 0;
         c.device = device;
         c.initialised = true;
         // (Warming the copy API's paths here -- a few host <-> device copies of 16 B ... 1 MiB -- was tried and made things worse: the lazy growth it
@@ -612,6 +650,8 @@ int elag_hip_finalize(void)
         (void)hipHostFree(c.h_scalar);
         if (c.h_stage) (void)hipHostFree(c.h_stage);
         c.h_stage = nullptr;
+        if (c.h_fetch) (void)hipHostFree(c.h_fetch);
+        c.h_fetch = nullptr;
         (void)hipEventDestroy(c.ev_pack);
         (void)hipEventDestroy(c.ev_halo);
         (void)hipStreamDestroy(c.stream);

@@ -464,9 +464,7 @@ void dense_inverse_general(const DevCSR &A, double *Minv)
             hipLaunchKernelGGL(gj_colsrc_kernel, dim3(1), dim3(1024), sizeof(int) * 2 * (size_t)n, st, n, (const int *)piv_all.p, colsrc.p);
             hipLaunchKernelGGL(gj_gather_cols_kernel, dim3((n + kB - 1) / kB, n), dim3(kB), 0, st, n, (const double *)Mo, (const int *)colsrc.p, Minv);
             ELAG_LAUNCH_CHECK();
-            int bad = 0;
-            ELAG_HIP_CHECK(hipMemcpyAsync(&bad, singular.p, sizeof(int), hipMemcpyDeviceToHost, st));
-            ELAG_HIP_CHECK(hipStreamSynchronize(st));
+            const int bad = fetch_int(singular.p);
             if (dbgp) {
                 std::vector<long long> h = host_from_dev(dbgp, nsteps * 6);
                 double acc[5] = {0, 0, 0, 0, 0};
@@ -506,9 +504,7 @@ void dense_inverse_general(const DevCSR &A, double *Minv)
         }
         hipLaunchKernelGGL(gj_extract_kernel, dim3((n + kB - 1) / kB, n), dim3(kB), 0, st, n, (const double *)M, ld, Minv);
         ELAG_LAUNCH_CHECK();
-        int bad = 0;
-        ELAG_HIP_CHECK(hipMemcpyAsync(&bad, singular.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        const int bad = fetch_int(singular.p);
         if (bad) fail(ELAG_HIP_ERR_NUMERIC, "coarse operator is singular (%d zero pivots in the dense LU)", bad);
     } catch (...) {
         dev_free(M);
@@ -781,9 +777,7 @@ void dense_inverse_spd(const DevCSR &A, double *Minv)
         else
             hipLaunchKernelGGL(spd_inverse_lds_kernel, dim3(1), dim3(kLdsInvBlock), lds, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, Minv, bad.p);
         ELAG_LAUNCH_CHECK();
-        int nbad = 0;
-        ELAG_HIP_CHECK(hipMemcpyAsync(&nbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        const int nbad = fetch_int(bad.p);
         if (nbad) fail(ELAG_HIP_ERR_NUMERIC, "coarse operator is not positive definite (%d non-positive pivots)", nbad);
         return;
     }
@@ -817,9 +811,7 @@ void dense_inverse_spd(const DevCSR &A, double *Minv)
         // exact symmetry of the stored inverse keeps the cycle symmetric to rounding
         hipLaunchKernelGGL(symmetrise_kernel, dim3((n + kB - 1) / kB, n), dim3(kB), 0, st, n, (const double *)M, Minv);
         ELAG_LAUNCH_CHECK();
-        int nbad = 0;
-        ELAG_HIP_CHECK(hipMemcpyAsync(&nbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        const int nbad = fetch_int(bad.p);
         if (nbad) fail(ELAG_HIP_ERR_NUMERIC, "coarse operator is not positive definite (%d non-positive pivots)", nbad);
     } catch (...) {
         dev_free(M);

@@ -1820,8 +1820,7 @@ struct EscPlan {
         hipLaunchKernelGGL(esc_gather_kernel, dim3(1), dim3(64), 0, st, counters.p, (const int *)(ubscan.p + nrows), wave ? (const int *)(UBI.p + nrows) : (const int *)nullptr,
                            wave ? (const int *)ccount.p : (const int *)nullptr, extra, extra_n);
         int *hp = reinterpret_cast<int *>(ctx().h_scalar + 10);          // (doubles 0 and 8 of the pinned block belong to the reductions)
-        ELAG_HIP_CHECK(hipMemcpyAsync(hp, counters.p, (5 + kNumClasses) * sizeof(int), hipMemcpyDeviceToHost, st));
-        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        fetch_ints(counters.p, 5 + kNumClasses, hp);
         const int h[2] = {hp[0], hp[1]}, tot = hp[2], totw = hp[3];
         for (int c = 0; c < kNumClasses; c++) hc[c] = hp[4 + c];
         extra_value = hp[4 + kNumClasses];
@@ -1845,8 +1844,7 @@ struct EscPlan {
         hipLaunchKernelGGL(esc_classify_kernel, dim3(std::min(grid1(nrows), 1024u)), dim3(kBlock), 0, st, nrows, (const int *)ub.p, cb, ccount.p, lists.p, 1);
         ELAG_LAUNCH_CHECK();
         int *hp = reinterpret_cast<int *>(ctx().h_scalar + 10);
-        ELAG_HIP_CHECK(hipMemcpyAsync(hp, ccount.p, kNumClasses * sizeof(int), hipMemcpyDeviceToHost, st));
-        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        fetch_ints(ccount.p, kNumClasses, hp);
         for (int c = 0; c < kNumClasses; c++) hc[c] = hp[c];
         nbig = 0; total_small = 0;
         wave_ready = true; all_rows = false;
@@ -1903,16 +1901,14 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
             ELAG_HIP_CHECK(hipMemsetAsync(tot64, 0, sizeof(unsigned long long), st));
             hipLaunchKernelGGL(wave_ub_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, (const int *)plan.ub.p, plan.wave_cap, ubw.p, tot64.p, 0);
             ELAG_LAUNCH_CHECK();
-            ELAG_HIP_CHECK(hipMemcpyAsync(&total_ub, tot64.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-            ELAG_HIP_CHECK(hipStreamSynchronize(st));
+            fetch_ints(reinterpret_cast<const int *>(tot64.p), 2, reinterpret_cast<int *>(&total_ub));
             if (total_ub < (1ull << 31)) {
                 exclusive_scan(ubw, UBI, n);
                 const ClassBounds cb{{0, 16, 32, 64, 128, kWaveCap}};
                 ELAG_HIP_CHECK(hipMemsetAsync(plan.ccount, 0, sizeof(int) * kNumClasses, st));
                 hipLaunchKernelGGL(esc_classify_kernel, dim3(std::min(grid1(n), 1024u)), dim3(kBlock), 0, st, n, ubp, cb, plan.ccount.p, lists.p, 1);
                 ELAG_LAUNCH_CHECK();
-                ELAG_HIP_CHECK(hipMemcpyAsync(hc, plan.ccount.p, sizeof(int) * kNumClasses, hipMemcpyDeviceToHost, st));
-                ELAG_HIP_CHECK(hipStreamSynchronize(st));
+                fetch_ints(plan.ccount.p, kNumClasses, hc);
             }
         }
         // the upper-bound layout is indexed with ints and lives in the scratch arena: at most 2^31 - 1 products and 16 GiB
@@ -1999,17 +1995,15 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
             if (keep) return;                        // the product stays where its kernels wrote it
             int *CI = dev_alloc<int>((size_t)n + 1);
             int *hnnz = reinterpret_cast<int *>(ctx().h_scalar + 10);
-            Temp<int> longest(1);
-            if (spmv_plan) ELAG_HIP_CHECK(hipMemsetAsync(longest.p, 0, sizeof(int), st));
-            exclusive_scan(rownnz, CI, n, spmv_plan ? longest.p : nullptr);          // (the result's longest row rides along with the scan: no kernel + drain for it in choose_spmv_shape)
-            ELAG_HIP_CHECK(hipMemcpyAsync(hnnz, CI + n, sizeof(int), hipMemcpyDeviceToHost, st));
-            if (spmv_plan) ELAG_HIP_CHECK(hipMemcpyAsync(hnnz + 1, longest.p, sizeof(int), hipMemcpyDeviceToHost, st));
-            ELAG_HIP_CHECK(hipStreamSynchronize(st));
-            const int nnz = *hnnz;
+            Temp<int> longest(2);                    // [0] the longest row, [1] the number of entries
+            ELAG_HIP_CHECK(hipMemsetAsync(longest.p, 0, 2 * sizeof(int), st));
+            exclusive_scan(rownnz, CI, n, spmv_plan ? longest.p : nullptr, longest.p + 1);          // (both ride along with the scan: no kernel + drain for them afterwards)
+            fetch_ints(longest.p, 2, hnnz);
+            const int nnz = hnnz[1];
             C.release();
             C.nrows = n; C.ncols = ncols; C.I = CI;
             C.alloc_entries(nnz);
-            if (spmv_plan) C.known_max_row = hnnz[1];
+            if (spmv_plan) C.known_max_row = hnnz[0];
             if (nch && !single_all)
                 hipLaunchKernelGGL((esc_kernel<2 * kCap, false, true, Expander>), dim3(nch), dim3(kBlock), 0, st, n, plan.ubscan.p,
                                    plan.ub_small.p, (const int *)nullptr, ex, (int *)nullptr, (const int *)C.I, C.J, C.a, esc_big_hash());
@@ -2039,9 +2033,7 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
     ELAG_LAUNCH_CHECK();
     int *CI = dev_alloc<int>((size_t)n + 1);
     exclusive_scan(rownnz, CI, n);
-    int nnz = 0;
-    ELAG_HIP_CHECK(hipMemcpyAsync(&nnz, CI + n, sizeof(int), hipMemcpyDeviceToHost, st));
-    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    const int nnz = fetch_int(CI + n);
     C.release();
     C.nrows = n; C.ncols = ncols; C.I = CI;
     C.alloc_entries(nnz);
@@ -2171,8 +2163,7 @@ bool rap_ell(const DevCSR *R, const DevCSR &A, const DevCSR &P, DevCSR *C, DevCS
     }
     if (!R) {
         hipLaunchKernelGGL(rap_gather_kernel, dim3(1), dim3(64), 0, st, ctl.p, (const int *)nullptr, (const int *)nullptr, (const int *)(API + n), (const int *)longAP.p);
-        ELAG_HIP_CHECK(hipMemcpyAsync(h, ctl.p, 9 * sizeof(int), hipMemcpyDeviceToHost, st));
-        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        fetch_ints(ctl.p, 9, h);
         if (h[2] > 0) { dev_free(API); return false; }
     } else {
         // ---- C = R (A P) ----
@@ -2198,8 +2189,7 @@ bool rap_ell(const DevCSR *R, const DevCSR &A, const DevCSR &P, DevCSR *C, DevCS
         if (spmv_plan) longest_row(nr, CI, longC.p);
         hipLaunchKernelGGL(rap_gather_kernel, dim3(1), dim3(64), 0, st, ctl.p, (const int *)(CI + nr), spmv_plan ? (const int *)longC.p : (const int *)nullptr,
                            AP_out ? (const int *)(API + n) : (const int *)nullptr, AP_out ? (const int *)longAP.p : (const int *)nullptr);
-        ELAG_HIP_CHECK(hipMemcpyAsync(h, ctl.p, 9 * sizeof(int), hipMemcpyDeviceToHost, st));
-        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        fetch_ints(ctl.p, 9, h);
         if (h[2] > 0 || h[4] > 0) { dev_free(API); dev_free(CI); return false; }        // a row beyond the widest launch: the general route
         C->release();
         C->nrows = nr; C->ncols = P.ncols; C->I = CI;
@@ -2258,8 +2248,7 @@ bool rap_fused(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, boo
     // a fill, a row-length maximum and a gather kernel before: 35 of the ~125 us between the product kernel and the result)
     exclusive_scan(rn, CI, nr, spmv_plan ? ctl.p + 6 : nullptr, ctl.p + 5);
     int *h = reinterpret_cast<int *>(ctx().h_scalar + 10);
-    ELAG_HIP_CHECK(hipMemcpyAsync(h, ctl.p, 9 * sizeof(int), hipMemcpyDeviceToHost, st));
-    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    fetch_ints(ctl.p, 9, h);
     if (h[2] > 0) { dev_free(CI); return false; }
     C.release();
     C.nrows = nr; C.ncols = P.ncols; C.I = CI;
@@ -2595,9 +2584,7 @@ void csr_delete_zeros(const DevCSR &A, double tol, DevCSR &out)
     int *OI = dev_alloc<int>((size_t)n + 1);
     if (n) hipLaunchKernelGGL(count_keep_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, (const int *)A.I, (const double *)A.a, tol, cnt.p);
     exclusive_scan(cnt, OI, n);
-    int nnz = 0;
-    ELAG_HIP_CHECK(hipMemcpyAsync(&nnz, OI + n, sizeof(int), hipMemcpyDeviceToHost, st));
-    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    const int nnz = fetch_int(OI + n);
     out.release();
     out.nrows = n; out.ncols = A.ncols; out.I = OI;
     out.alloc_entries(nnz);
@@ -2781,8 +2768,7 @@ bool csr_combine_inplace(DevCSR &C, const CsrCombine &op)
                        op.B ? (const double *)op.B->a : nullptr, op.b_scale, op.b_row, op.b_row_divide, op.diag, op.d_scale, missing.p);
     ELAG_LAUNCH_CHECK();
     int *hm = reinterpret_cast<int *>(ctx().h_scalar + 10);
-    ELAG_HIP_CHECK(hipMemcpyAsync(hm, missing.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    fetch_ints(missing.p, 1, hm);
     return *hm == 0;
 }
 

@@ -746,8 +746,7 @@ void build_stream_plan(DevCSR &A)
         hipLaunchKernelGGL(max_row_kernel, dim3(g), dim3(256), 0, st, A.nrows, (const int *)A.I, m.p);
     }
     ELAG_LAUNCH_CHECK();
-    ELAG_HIP_CHECK(hipMemcpyAsync(&A.max_row_nnz, m.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    A.max_row_nnz = fetch_int(m.p);
 }
 
 void longest_row(int nrows, const int *I, int *d_out)
@@ -958,9 +957,7 @@ bool prepare_sign_form(const DevCSR &A)
     const unsigned g = (unsigned)std::min<long long>((A.nnz + kBlock - 1) / kBlock, 4096);
     hipLaunchKernelGGL(sign_pack_kernel, dim3(g), dim3(kBlock), 0, st, (long long)A.nnz, (const int *)A.J, (const double *)A.a, Js, bad.p);
     ELAG_LAUNCH_CHECK();
-    int nbad = 0;
-    ELAG_HIP_CHECK(hipMemcpyAsync(&nbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    const int nbad = fetch_int(bad.p);
     if (nbad) { dev_free(Js); return false; }
     A.Js = Js;
     A.sign_state = 1;
@@ -1718,9 +1715,9 @@ double reduce_to_host(long long n, const double *x, int mode)
     if (n == 0) return 0.0;
     Context &c = ctx();
     reduce_launch(n, x, nullptr, mode, c.d_scalar);
-    ELAG_HIP_CHECK(hipMemcpyAsync(c.h_scalar, c.d_scalar, sizeof(double), hipMemcpyDeviceToHost, c.stream));
-    ELAG_HIP_CHECK(hipStreamSynchronize(c.stream));
-    return c.h_scalar[0];
+    double v = 0.0;
+    fetch_doubles(c.d_scalar, 1, &v);
+    return v;
 }
 
 }  // namespace
@@ -1915,10 +1912,7 @@ inline unsigned row_grid(int n, int lpr) { return (unsigned)(((long long)n * lpr
 
 int read_counter(int *d_cnt)
 {
-    int h = 0;
-    ELAG_HIP_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
-    ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
-    return h;
+    return fetch_int(d_cnt);
 }
 
 }  // namespace
