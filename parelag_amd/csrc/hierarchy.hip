@@ -392,7 +392,7 @@ struct elag_hip_hierarchy_s {
                 k::csr_times_dense(*C.P->diagT, n, 1.0, R, 0.0, false, T1);            // T1 = P^T R
                 k::dense_mm(nc, nc, n, Bc, T1, T2);                                    // T2 = B_below T1
                 k::csr_times_dense(C.P->diag, n, 1.0, T2, 1.0, false, B);              // X2 = X1 + P T2
-                ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));                    // (the scratch goes out of scope)
+                // (no drain: the scratch is reused in stream order)
                 ok = post->apply_dense(nullptr, B, n, false);                          // B = S(I; X2)
             }
             ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
@@ -661,7 +661,7 @@ struct elag_hip_hierarchy_s {
         V.reset(new DevCSR());
         k::csr_copy(*F.S, *V);
         k::csr_scale_rows(*V, negw);
-        ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));       // (negw goes out of scope)
+        // (no drain: the scratch is reused in stream order)
         return true;
     }
 
@@ -758,7 +758,7 @@ struct elag_hip_hierarchy_s {
                 V[0].reset(new DevCSR());
                 k::csr_copy(F.Sd->diag, *V[0]);
                 k::csr_scale_rows(*V[0], negw);
-                ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+                // (no drain: the scratch is reused in stream order)
             }
             for (int i = 1; i < m; i++)
                 if (!level_maps(S->lev[(size_t)i - 1], U[(size_t)i], V[(size_t)i])) fail(ELAG_HIP_ERR_STATE, "distributed flattened cycle: level without linear maps");
@@ -876,7 +876,7 @@ struct elag_hip_hierarchy_s {
                         F.U2.reset(new DevCSR());
                         k::csr_add(1.0, C.P->diag, -1.0, SAP, *F.U2);
                     }
-                    ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+                    // (no drain: the scratch is reused in stream order)
                     continue;
                     } catch (const Error &) {
                         // a row of one of the products expands beyond what the SpGEMM handles (operators with long rows: AMGe coarse
@@ -954,7 +954,7 @@ struct elag_hip_hierarchy_s {
                             k::csr_add(1.0, T, -1.0, GAW, *F.Kh);
                             F.Mh.reset(new DevCSR());
                             k::csr_add(1.0, Id, -1.0, GA, *F.Mh);
-                            ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+                            // (no drain: the scratch is reused in stream order)
                         } catch (const Error &) {
                             F.Kh.reset(); F.Mh.reset();
                         }
@@ -989,7 +989,7 @@ struct elag_hip_hierarchy_s {
                         k::vec_reciprocal_scale(n, 1.0, dinv, winv);
                         k::csr_scale_rows(WP->diag, winv);
                         if (WP->offd.nnz) k::csr_scale_rows(WP->offd, winv);
-                        ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+                        // (no drain: the scratch is reused in stream order)
                     }
                     Sd.reset(distributed_add(1.0, *AP, -1.0, *WP));
                 } catch (const Error &e) {

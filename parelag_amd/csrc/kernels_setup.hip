@@ -2696,7 +2696,7 @@ void child_order(const DevCSR &P, const int *d_rank_c, int *d_order_out)
     ELAG_LAUNCH_CHECK();
     csr_transpose(K, KT);            // row p of KT: the children of the coarse dof of rank p, ascending
     ELAG_HIP_CHECK(hipMemcpyAsync(d_order_out, KT.J, sizeof(int) * (size_t)nf, hipMemcpyDeviceToDevice, st));
-    ELAG_HIP_CHECK(hipStreamSynchronize(st));        // (K / KT go out of scope)
+    // (no drain: K / KT go back to the pool, which hands them out again in stream order)
 }
 
 void inverse_permutation(int n, const int *d_order, int *d_rank)

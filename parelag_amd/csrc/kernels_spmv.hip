@@ -821,8 +821,7 @@ bool xc_build(const DevCSR &A, int window, bool force, double min_reuse = 2.0)
         if (mx <= 65535) {
             ucols = dev_alloc<int>((size_t)std::max(total, 1));
             hipLaunchKernelGGL(xc_compact_kernel, dim3((unsigned)std::min(nb, 4096)), dim3(kBlock), 0, st, nb, cap, (const int *)slots.p, (const int *)uoff, ucols);
-            ELAG_LAUNCH_CHECK();
-            ELAG_HIP_CHECK(hipStreamSynchronize(st));
+            ELAG_LAUNCH_CHECK();                     // (no drain: the scratch is reused in stream order)
         }
     }
     if (getenv("ELAG_HIP_XC_VERBOSE"))
