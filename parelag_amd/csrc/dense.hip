@@ -678,37 +678,38 @@ namespace {
 // launch of its own), writes its columns of the row panel R = D^-1 A_K: and its rows of a copy of the column panel A_:K.  Launch 2 (update): 32 x 32
 // tiles, the two panels' tiles staged in LDS.
 constexpr int kNB = 32;
+constexpr int kPanelCols = 32;
 __global__ __launch_bounds__(1024) void spd_block_panel_kernel(int n, int K, const double *__restrict__ M, double *__restrict__ Dinv, double *__restrict__ R,
                                                                double *__restrict__ Cc, int *__restrict__ bad)
 {
     __shared__ double D[kNB][kNB + 1];
-    __shared__ double ck[kNB], rk[kNB];
+    __shared__ double ck[2][kNB], rk[2][kNB];
     const int t = threadIdx.x, r = t >> 5, c = t & 31;
     const int nb = min(kNB, n - K);
-    // D = A_KK, padded with the identity
-    D[r][c] = (r < nb && c < nb) ? M[(size_t)(K + r) * n + K + c] : (r == c ? 1.0 : 0.0);
-    __syncthreads();
+    // D = A_KK, padded with the identity: a thread keeps its entry in a register during the elimination, the pivot's row and column go through
+    // LDS (double-buffered: one barrier per pivot); the same operations, entry by entry, as the sweep over a matrix in LDS
+    double m = (r < nb && c < nb) ? M[(size_t)(K + r) * n + K + c] : (r == c ? 1.0 : 0.0);
+    int nbad = 0;
     for (int k = 0; k < nb; k++) {
-        const double p = D[k][k];
-        if (t == 0 && blockIdx.x == 0 && !(p > 0.0)) atomicAdd(bad, 1);
-        if (t < kNB) {
-            ck[t] = (t == k) ? 0.0 : D[t][k];
-            rk[t] = (t == k) ? 1.0 / p : D[k][t] / p;
-        }
+        const int b = k & 1;
+        if (c == k) ck[b][r] = m;
+        if (r == k) rk[b][c] = m;
         __syncthreads();
-        {
-            double m = D[r][c];
-            if (r == k) m = rk[c];
-            else if (c == k) m = -ck[r] * rk[c];            // rk[k] = 1 / p
-            else m -= ck[r] * rk[c];
-            D[r][c] = m;
-        }
-        __syncthreads();
+        const double p = rk[b][k];
+        if (!(p > 0.0)) nbad++;
+        const double rkc = (c == k) ? 1.0 / p : rk[b][c] / p;
+        if (r == k) m = rkc;
+        else if (c == k) m = -ck[b][r] * rkc;               // rkc = 1 / p
+        else m -= ck[b][r] * rkc;
     }
+    if (t == 0 && blockIdx.x == 0 && nbad) atomicAdd(bad, nbad);
+    D[r][c] = m;
+    __syncthreads();
     if (blockIdx.x == 0) Dinv[r * kNB + c] = D[r][c];
-    // this workgroup's 256 columns of R = D^-1 A_K:  (row r of the panel, 32 columns at a time)
-    const int j0 = blockIdx.x * 256;
-    for (int jj = 0; jj < 256; jj += 32) {
+    // this workgroup's kPanelCols columns of R = D^-1 A_K:  (row r of the panel; 32 columns per workgroup: at 256 the 1 015-dof
+    // coarsest H(div) operator kept four workgroups busy for 45 us per panel, 2.0 ms of coarse-solver setup against 1.1)
+    const int j0 = blockIdx.x * kPanelCols;
+    for (int jj = 0; jj < kPanelCols; jj += 32) {
         const int j = j0 + jj + c;
         if (j < n && r < nb) {
             double sum = 0.0;
@@ -716,8 +717,8 @@ __global__ __launch_bounds__(1024) void spd_block_panel_kernel(int n, int K, con
             R[(size_t)r * n + j] = sum;
         }
     }
-    // ... and its 256 rows of the column panel (the update overwrites it)
-    for (int ii = 0; ii < 256; ii += 32) {
+    // ... and as many rows of the column panel (the update overwrites it)
+    for (int ii = 0; ii < kPanelCols; ii += 32) {
         const int i = j0 + ii + r;
         if (i < n) Cc[(size_t)i * kNB + c] = c < nb ? M[(size_t)i * n + K + c] : 0.0;
     }
@@ -794,7 +795,7 @@ void dense_inverse_spd(const DevCSR &A, double *Minv)
         const char *e_blk = getenv("ELAG_HIP_SPD_BLOCKED");                 // (0 = the pivot-by-pivot sweeps: A/B runs and a test)
         if (!(e_blk && !atoi(e_blk))) {
             Temp<double> Dinv((size_t)kNB * kNB), Rp((size_t)kNB * n), Cc((size_t)n * kNB);
-            const dim3 gp((n + 255) / 256), gu((n + kNB - 1) / kNB, (n + kNB - 1) / kNB);
+            const dim3 gp((n + kPanelCols - 1) / kPanelCols), gu((n + kNB - 1) / kNB, (n + kNB - 1) / kNB);
             for (int K = 0; K < n; K += kNB) {
                 hipLaunchKernelGGL(spd_block_panel_kernel, gp, dim3(1024), 0, st, n, K, (const double *)M, Dinv.p, Rp.p, Cc.p, bad.p);
                 hipLaunchKernelGGL(spd_block_update_kernel, gu, dim3(256), 0, st, n, K, M, (const double *)Dinv.p, (const double *)Rp.p, (const double *)Cc.p);
