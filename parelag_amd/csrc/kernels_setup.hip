@@ -407,6 +407,21 @@ struct SortExpander {  // identity: re-emit the row (used to sort columns inside
     }
 };
 
+// The barrier after the compare-exchange stage (size k, stride j) of a bitonic network run by kBlock threads, thread t on the pairs t, t + kBlock,
+// ...: a stage of stride <= 64 stays inside the 128 keys that a wavefront's 64 pairs span, so between two such stages a wavefront only waits
+// for itself (49 of the 55 stages of a 1 024-key network; 18 us of every 50-100 us chunk of a sparse product went to workgroup barriers here).
+__device__ __forceinline__ void bitonic_stage_sync(int k, int j, int n2)
+{
+    const int next = j > 1 ? (j >> 1) : (k < n2 ? k : 0);        // the next stage's stride (0: the network ends)
+    if (j > 64 || next > 64 || next == 0) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 template <bool HAS_VAL>
 __device__ void bitonic_sort_lds(u64 *key, double *val, int n2)
 {
@@ -422,7 +437,7 @@ __device__ void bitonic_sort_lds(u64 *key, double *val, int n2)
                     if (HAS_VAL) { const double t2 = val[i]; val[i] = val[p]; val[p] = t2; }
                 }
             }
-            __syncthreads();
+            bitonic_stage_sync(k, j, n2);
         }
     }
 }
@@ -548,7 +563,7 @@ __global__ __launch_bounds__(kBlock) void esc_kernel(int nrows, const int *__res
                         const int a0 = uk[lo], b0 = uk[hi];
                         if ((a0 > b0) == up) { uk[lo] = b0; uk[hi] = a0; }
                     }
-                    __syncthreads();
+                    bitonic_stage_sync(size, stride, npow);
                 }
             const int cbeg = CI[r0];
             for (int i = threadIdx.x; i < nu; i += kBlock) {
@@ -571,7 +586,13 @@ __global__ __launch_bounds__(kBlock) void esc_kernel(int nrows, const int *__res
         flat_done = matmul_expand_flat<NUMERIC>(ex.A, ex.B, r0, key, val, pre);
     }
     const int w = threadIdx.x >> 6;
-    if (!flat_done)
+    if (!BIG && r1 - r0 >= 32) {
+        // many short rows: sixteen lanes per row, four rows per wavefront at a time (a row costs its group four dependent loads whatever its length)
+        for (int row = r0 + ((int)threadIdx.x >> 4); row < r1; row += kBlock / 16) {
+            const int off = ubscan[row] - base;
+            if (ub[row] > 0) ex.template expand<NUMERIC, 16>(row, (unsigned)(row - r0), off, key, val);
+        }
+    } else if (!flat_done)
         for (int row = r0 + w; row < r1; row += kBlock / 64) {
             const int off = BIG ? 0 : (ubscan[row] - base);
             if (BIG || ub[row] > 0) ex.template expand<NUMERIC>(row, (unsigned)(row - r0), off, key, val);
@@ -630,7 +651,7 @@ __global__ __launch_bounds__(kBlock) void esc_kernel(int nrows, const int *__res
                         const u64 a0 = key[lo], b0 = key[hi];
                         if ((a0 > b0) == up) { key[lo] = b0; key[hi] = a0; }
                     }
-                    __syncthreads();
+                    bitonic_stage_sync(size, stride, npow);
                 }
             for (int i = threadIdx.x; i < nu; i += kBlock) {
                 const u64 kk = key[i];
@@ -643,7 +664,9 @@ __global__ __launch_bounds__(kBlock) void esc_kernel(int nrows, const int *__res
                 const int pos = CI[r0 + (int)rl] + (i - lo);
                 CJ[pos] = (int)(kk & 0xffffffffu);
                 Ca[pos] = hv[h];
-                if (rownnz) atomicAdd(&rownnz[r0 + (int)rl], 1);               // (single pass: CI holds upper-bound offsets, the rows' entry counts are recorded on the way)
+                // (single pass: CI holds upper-bound offsets, the rows' entry counts are recorded on the way -- by the row's last pair: a row lies
+                //  in one chunk, and hundreds of atomics on the three counters of a three-row chunk took 40 us)
+                if (rownnz && (i + 1 == nu || (unsigned)(key[i + 1] >> 32) != rl)) rownnz[r0 + (int)rl] = i - lo + 1;
             }
             return;
         }
