@@ -17,6 +17,7 @@
 #include <cmath>
 
 #include <chrono>
+#include <cstring>
 #include "comm.hpp"
 #include "smoother.hpp"
 #include "staging.hpp"
@@ -35,9 +36,11 @@ enum { S_NOM, S_DEN, S_BETANOM, S_R0, S_ALPHA, S_BETA, S_TMP, S_FINAL_NORM, S_GB
 enum { F_DONE, F_CONVERGED, F_FINAL_ITER, F_ITER, F_PENDING, F_ITER2, F_STEP, F_JBASE, F_COUNT = 8 };   // F_STEP / F_JBASE: GMRES -- the step counter and the iteration number of a cycle's first step, kept on the device so that a step's launches take no per-step argument (they replay as a graph)
 
 struct KState {
+    int fl[F_COUNT];          // (first: the flags and the scalars the host reads -- S_NOM ... S_FINAL_NORM -- are 24 consecutive words, one fetch_ints)
     double sc[S_COUNT];
-    int fl[F_COUNT];
 };
+constexpr int kPollWords = F_COUNT + 2 * (S_FINAL_NORM + 1);
+static_assert(F_COUNT % 2 == 0 && kPollWords <= 30, "the polled words: the flags, then the leading scalars");
 
 // ---- CG scalar kernels (mfem::CGSolver::Mult) --------------------------------------------------------------------------
 __global__ void cg_init1_kernel(KState *st, double rel_tol, double abs_tol, int max_iter)
@@ -664,13 +667,18 @@ struct elag_hip_krylov_s {
     // ELAG_HIP_KRYLOV_TIMING=1: host time of a solve split into enqueueing and waiting in poll() (printed by solve())
     double t_poll = 0.0;
     int n_poll = 0;
+    // the flags and the scalars the host looks at (h_sc beyond S_FINAL_NORM is not refreshed), in one round trip
+    void fetch_state()
+    {
+        int w[kPollWords];
+        fetch_ints(st->fl, kPollWords, w);
+        std::memcpy(h_flags, w, sizeof(int) * F_COUNT);
+        std::memcpy(h_sc, w + F_COUNT, sizeof(double) * (S_FINAL_NORM + 1));
+    }
     bool poll()
     {
-        hipStream_t s = ctx().stream;
         const auto t0 = std::chrono::steady_clock::now();
-        ELAG_HIP_CHECK(hipMemcpyAsync(h_flags, st->fl, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, s));
-        ELAG_HIP_CHECK(hipMemcpyAsync(h_sc, st->sc, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, s));
-        ELAG_HIP_CHECK(hipStreamSynchronize(s));
+        fetch_state();
         t_poll += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         n_poll++;
         return h_flags[F_DONE] != 0;
@@ -678,10 +686,7 @@ struct elag_hip_krylov_s {
 
     void fetch_results()
     {
-        hipStream_t s = ctx().stream;
-        ELAG_HIP_CHECK(hipMemcpyAsync(h_flags, st->fl, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, s));
-        ELAG_HIP_CHECK(hipMemcpyAsync(h_sc, st->sc, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, s));
-        ELAG_HIP_CHECK(hipStreamSynchronize(s));
+        fetch_state();
         converged = h_flags[F_CONVERGED]; final_iter = h_flags[F_FINAL_ITER]; final_norm = h_sc[S_FINAL_NORM];
     }
 
