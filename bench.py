@@ -1159,12 +1159,18 @@ def main():
             db, dx = la.DeviceVector.from_numpy(local_part(b_solve)), la.DeviceVector(n_local, 0.0)
             K.Mult(db, dx)
             barrier()
+            # every solve timed by itself, the median reported and all of them kept in the record: within ~0.1 s of a setup that released device
+            # memory ONE solve stalls for 30-80 ms on this stack (seen with and without the step graphs, the pool, the kernel read-backs; the
+            # library's own clock puts the time into waiting for the device; a 0.5 s pause before the solves removes it) -- the mean of five
+            # solves then reads 25 ms for a 12 ms solve
             with no_gc():
-                t0 = time.perf_counter()
+                each = []
                 for _ in range(nsolve):
+                    t0 = time.perf_counter()
                     K.Mult(db, dx)
-                barrier()
-                ms = (time.perf_counter() - t0) / nsolve * 1e3
+                    barrier()
+                    each.append((time.perf_counter() - t0) * 1e3)
+            ms = statistics.median(each)
             if dist is not None:
                 ms = dist.allreduce_max(ms)
             # true residual || b - A x || / || b || of the returned iterate, on the device (rows of this rank, summed over the ranks)
@@ -1176,6 +1182,7 @@ def main():
                 rr = dist.allreduce_sum(rr)
             rec = {"solver": kparams["Solver name"], "preconditioner": what, "rel_tol": 1e-6, "iterations": K.GetNumIterations(),
                    "converged": bool(K.GetConverged()), "final_norm": K.GetFinalNorm(), "ms_per_solve": round(ms, 4),
+                   "ms_each_solve": [round(e, 3) for e in each],
                    "true_rel_residual": float(np.sqrt(rr) / bnorm)}
             return rec, dx.to_numpy()
 

@@ -8,3 +8,5 @@ echo "[4] RAP"; bash tools/rap_profile.sh r04final/rap 5 > $OUT/rap_stats.txt 2>
 echo "[5] setup probes"; python tools/setup_probe.py 3 4 > $OUT/setup_k3.txt 2>&1; python tools/setup_probe.py 5 4 > $OUT/setup_k5.txt 2>&1; tail -2 $OUT/setup_k5.txt | cut -c1-200
 ELAG_HIP_LU_TIMING=1 python tools/r04_darcy_setup_probe.py 3 4 > $OUT/darcy_setup.txt 2>&1; tail -3 $OUT/darcy_setup.txt
 echo "[6] H(div) x3 kernel stats"; bash tools/profile_bench.sh r04final/hdiv --form 2 --no-cpu-baseline --no-roofline --no-gs --no-other-configs > $OUT/hdiv_kernel_stats.txt 2>&1; tail -2 $OUT/hdiv_kernel_stats.txt | cut -c1-160
+echo "[7] the N-rank code path on one rank"; timeout -k 10 400 python bench.py --force-dist --no-cpu-baseline --steps 20 --warmup 5 > $OUT/bench_multirank_path_1rank.json 2> $OUT/bench_multirank_path_1rank.err; echo "rc $?"
+echo "[8] config 4 with its solve"; timeout -k 10 300 python bench.py --form darcy --solve --no-cpu-baseline --no-cpu-solve --steps 20 --warmup 5 > $OUT/bench_darcy_solve.json 2> $OUT/bench_darcy_solve.err; echo "rc $?"
