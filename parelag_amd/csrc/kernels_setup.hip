@@ -2495,6 +2495,38 @@ __global__ __launch_bounds__(kBlock) void sort_rows_rank_kernel(int nrows, const
 }
 }  // namespace
 
+namespace {
+// Row permutation, column renumbering and the sort of the renumbered rows in ONE pass (rows of at most G entries): the permuted operator was
+// written unsorted and read again by the rank sort -- at cube456 x5 253 + 469 us for the level-0 operator alone, 0.6 ms of perm_fill_kernel per build.
+template <int G>
+__global__ __launch_bounds__(kBlock) void perm_sort_rank_kernel(int n, const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
+                                                                const int *__restrict__ order, const int *__restrict__ colrank, const int *__restrict__ OI,
+                                                                int *__restrict__ OJ, double *__restrict__ Oa)
+{
+    static_assert(G == 16 || G == 32, "rank sort: groups of 16 or 32 lanes");
+    const int row = (blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1), lane16 = threadIdx.x & 15;
+    int s = 0, len = 0, d = 0;
+    if (row < n) { const int o = order[row]; s = I[o]; len = I[o + 1] - s; d = OI[row]; }
+    int key = 0x7fffffff;
+    double v = 0.0;
+    if (lane < len) { const int c = J[s + lane]; key = colrank ? colrank[c] : c; v = a[s + lane]; }
+    int rank = 0;
+    RankSteps<16>::run(key, key, lane16, true, false, rank);
+    if (G == 32) {
+        const int other = __shfl_xor(key, 16, 64);
+        RankSteps<16>::run(key, other, lane16, false, (lane & 16) != 0, rank);
+    }
+    if (lane < len) { OJ[d + rank] = key; Oa[d + rank] = v; }
+}
+bool rank_sort_enabled()
+{
+    static int rank_sort = -1;
+    if (rank_sort < 0) { const char *e = getenv("ELAG_HIP_RANK_SORT"); rank_sort = e ? atoi(e) : 1; }
+    return rank_sort != 0;
+}
+}  // namespace
+
 void csr_sort_rows(DevCSR &A)
 {
     if (A.nrows == 0 || A.nnz == 0) return;
@@ -2503,8 +2535,7 @@ void csr_sort_rows(DevCSR &A)
     if (A.max_row_nnz <= 64) {
         hipStream_t st = ctx().stream;
         const int *I = A.I;
-        static int rank_sort = -1;
-        if (rank_sort < 0) { const char *e = getenv("ELAG_HIP_RANK_SORT"); rank_sort = e ? atoi(e) : 1; }
+        const bool rank_sort = rank_sort_enabled();
         if (rank_sort && A.max_row_nnz <= 16) hipLaunchKernelGGL((sort_rows_rank_kernel<16>), dim3(grid1((long long)A.nrows * 16)), dim3(kBlock), 0, st, A.nrows, I, A.J, A.a);
         else if (rank_sort && A.max_row_nnz <= 32) hipLaunchKernelGGL((sort_rows_rank_kernel<32>), dim3(grid1((long long)A.nrows * 32)), dim3(kBlock), 0, st, A.nrows, I, A.J, A.a);
         else if (A.max_row_nnz <= 16) hipLaunchKernelGGL((sort_rows_group_kernel<16>), dim3(grid1((long long)A.nrows * 16)), dim3(kBlock), 0, st, A.nrows, I, A.J, A.a);
@@ -2674,6 +2705,20 @@ void csr_permute(const DevCSR &A, const int *d_order_rows, const int *d_rank_col
         exclusive_scan(len, out.I, n);
     }
     out.alloc_entries(A.nnz);
+    static const bool fused_sort = !(getenv("ELAG_HIP_PERM_SORT") && !atoi(getenv("ELAG_HIP_PERM_SORT")));
+    if (n && A.nnz && sort_rows && fused_sort && rank_sort_enabled() && A.max_row_nnz > 0 && A.max_row_nnz <= 32) {
+        if (A.max_row_nnz <= 16)
+            hipLaunchKernelGGL((perm_sort_rank_kernel<16>), dim3(grid1((long long)n * 16)), dim3(kBlock), 0, st, n, (const int *)A.I, (const int *)A.J,
+                               (const double *)A.a, d_order_rows, d_rank_cols, (const int *)out.I, out.J, out.a);
+        else
+            hipLaunchKernelGGL((perm_sort_rank_kernel<32>), dim3(grid1((long long)n * 32)), dim3(kBlock), 0, st, n, (const int *)A.I, (const int *)A.J,
+                               (const double *)A.a, d_order_rows, d_rank_cols, (const int *)out.I, out.J, out.a);
+        ELAG_LAUNCH_CHECK();
+        out.known_max_row = A.max_row_nnz;
+        out.max_row_nnz = A.max_row_nnz;
+        out.choose_spmv_shape();
+        return;
+    }
     if (n && A.nnz)
         hipLaunchKernelGGL(perm_fill_kernel, dim3(grid1((long long)n * 8)), dim3(kBlock), 0, st, n, (const int *)A.I, (const int *)A.J,
                            (const double *)A.a, d_order_rows, d_rank_cols, (const int *)out.I, out.J, out.a);
