@@ -467,7 +467,7 @@ int elag_hip_hierarchy_build_blocked(elag_hip_hierarchy_t *out, elag_hip_blockop
                     elag_hip_parcsr_t C = nullptr;
                     check_rc(elag_hip_parcsr_rap(Pl[i], Aij, Pl[j], &C));
                     Ac->set_block(i, j, C, true);
-                    if (i == j && fix_zero_rows && fix_zero_rows[i]) k::fix_zero_rows(C->diag, &C->offd);   // :515-519
+                    if (i == j && fix_zero_rows && fix_zero_rows[i]) k::fix_zero_rows(C->diag, &C->offd, false);   // :515-519
                 }
                 Pb->set_block(i, i, Pl[i], false);
             }

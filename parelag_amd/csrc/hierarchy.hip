@@ -1628,7 +1628,7 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
                 if (rc) fail(rc, "%s", elag_hip_last_error());
             }
             H->owned_mats.push_back(Ac);
-            if (opt.fix_zero_rows) k::fix_zero_rows(Ac->diag, &Ac->offd);
+            if (opt.fix_zero_rows) k::fix_zero_rows(Ac->diag, &Ac->offd, false);
             H->lev[(size_t)l + 1].A = Ac;
             H->lev[(size_t)l + 1].P = Pl;
         }
@@ -1716,7 +1716,7 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
                 rc = elag_hip_parcsr_rap(Dl, H->lev[(size_t)l].A, Dl, &Aaux);
                 if (rc) fail(rc, "%s", elag_hip_last_error());
                 H->owned_mats.push_back(Aaux);
-                k::fix_zero_rows(Aaux->diag, &Aaux->offd);
+                k::fix_zero_rows(Aaux->diag, &Aaux->offd, false);
                 elag_hip_smoother_t Sa = nullptr, Sh = nullptr;
                 rc = elag_hip_smoother_create(&Sa, Aaux, aux.relax_type, aux.sweeps, aux.damping, 1.0, aux.cheby_order, aux.cheby_fraction);
                 if (rc) fail(rc, "%s", elag_hip_last_error());

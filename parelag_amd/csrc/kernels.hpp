@@ -149,7 +149,7 @@ void l1_norms(const DevCSR &diag, const DevCSR *offd, int option, double *l1, in
 void extract_diagonal(const DevCSR &diag, double *d);  // 0 where the row stores no diagonal entry
 void vec_rsqrt(int n, const double *d, double *out, int *d_bad);            // 1/sqrt(d), counts d <= 0
 void vec_reciprocal_scale(int n, double w, const double *d, double *out);   // w / d
-int fix_zero_rows(DevCSR &diag, DevCSR *offd);
+int fix_zero_rows(DevCSR &diag, DevCSR *offd, bool count = true);   // the number of rows fixed (0 when count is false: no read-back)
 void values_abs(int64_t n, const double *a, double *out);
 void values_sign(int64_t n, double *a);
 double reduce_max_abs(int64_t n, const double *a);

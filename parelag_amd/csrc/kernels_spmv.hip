@@ -1947,7 +1947,7 @@ void vec_reciprocal_scale(int n, double w, const double *d, double *out)
     ELAG_LAUNCH_CHECK();
 }
 
-int fix_zero_rows(DevCSR &diag, DevCSR *offd)
+int fix_zero_rows(DevCSR &diag, DevCSR *offd, bool count)
 {
     if (diag.nrows == 0) return 0;
     diag.release_sign();
@@ -1958,7 +1958,7 @@ int fix_zero_rows(DevCSR &diag, DevCSR *offd)
     hipLaunchKernelGGL(fix_zero_rows_kernel, dim3(row_grid(diag.nrows, 8)), dim3(kBlock), 0, ctx().stream, diag.nrows,
                        diag.I, diag.J, diag.a, ho ? offd->I : nullptr, ho ? offd->a : nullptr, cnt.p);
     ELAG_LAUNCH_CHECK();
-    return read_counter(cnt);
+    return count ? read_counter(cnt) : 0;            // (a hierarchy build does not ask: one round trip less per level)
 }
 
 void values_abs(int64_t n, const double *a, double *out)
