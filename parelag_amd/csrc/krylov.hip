@@ -234,6 +234,79 @@ __global__ void __launch_bounds__(kB) gmres_orth_fused_kernel(int n, const KStat
     if (threadIdx.x == 0) part_out[blockIdx.x] = acc;
 }
 
+// ---- the same chain two basis vectors per link --------------------------------------------------------------------------------------
+// An inner step of GMRES(50) on the Darcy system spends 30 % of its time in the chain above: i + 1 links of ~6 us, each one pass over w and two
+// basis vectors.  Two vectors per link: with d_a = <w, v_a>, d_b = <w, v_b>, g = <v_a, v_b> taken in the PREVIOUS link's pass,
+//     H(a,i) = d_a,   H(b,i) = <w - H(a,i) v_a, v_b> = d_b - H(a,i) g,   w <- (w - H(a,i) v_a) - H(b,i) v_b
+// -- modified Gram-Schmidt's coefficients exactly (g is the computed inner product of the two vectors, not assumed zero), evaluated in another
+// order: rounding-level differences from the one-vector chain (ELAG_HIP_GMRES_PAIR=0 keeps that one, which is MFEM's loop operation by
+// operation).  Half the links, 6 vector passes per two columns instead of 8.  part_*: three runs of kPart partial sums (d_a, d_b, g).
+__global__ void __launch_bounds__(kB) gmres_dot0_pair_kernel(int n, const KState *__restrict__ st, const double *__restrict__ w,
+                                                             const double *__restrict__ va, const double *__restrict__ vb, double *__restrict__ part_out)
+{
+    __shared__ double sh[4];
+    if (st->fl[F_DONE]) return;
+    double da = 0.0, db = 0.0, g = 0.0;
+    for (int t = blockIdx.x * kB + threadIdx.x; t < n; t += kPart * kB) {
+        const double wt = w[t], a = va[t];
+        da += wt * a;
+        if (vb) { const double b = vb[t]; db += wt * b; g += a * b; }
+    }
+    da = block_sum_256(da, sh);
+    if (vb) { db = block_sum_256(db, sh); g = block_sum_256(g, sh); }
+    if (threadIdx.x == 0) { part_out[blockIdx.x] = da; if (vb) { part_out[kPart + blockIdx.x] = db; part_out[2 * kPart + blockIdx.x] = g; } }
+}
+
+// columns ka (and ka + 1 when vb != nullptr) of step i; the next link's columns na / nb (nullptr: none; both nullptr: <w, w> for the norm)
+__global__ void __launch_bounds__(kB) gmres_orth_pair_kernel(int n, const KState *__restrict__ st, double *__restrict__ hs, int m, int ka, int i,
+                                                             double *__restrict__ w, const double *__restrict__ va, const double *__restrict__ vb,
+                                                             const double *__restrict__ na, const double *__restrict__ nb,
+                                                             const double *__restrict__ part_in, double *__restrict__ part_out)
+{
+    __shared__ double sh[4];
+    constexpr int kPre = 4;
+    const int t0 = blockIdx.x * kB + threadIdx.x, stride = kPart * kB;
+    double pw[kPre], pa[kPre], pb[kPre], p1[kPre], p2[kPre];
+#pragma unroll
+    for (int u = 0; u < kPre; u++) {
+        const int t = t0 + u * stride;
+        pw[u] = pa[u] = pb[u] = p1[u] = p2[u] = 0.0;
+        if (t < n) {
+            pw[u] = w[t]; pa[u] = va[t];
+            if (vb) pb[u] = vb[t];
+            if (na) p1[u] = na[t];
+            if (nb) p2[u] = nb[t];
+        }
+    }
+    double sa = 0.0, sb = 0.0, sg = 0.0;
+    for (int q = threadIdx.x; q < kPart; q += kB) {
+        sa += part_in[q];
+        if (vb) { sb += part_in[kPart + q]; sg += part_in[2 * kPart + q]; }
+    }
+    if (st->fl[F_DONE]) return;
+    const double ha = block_sum_256(sa, sh);
+    double hb = 0.0;
+    if (vb) { const double db = block_sum_256(sb, sh), g = block_sum_256(sg, sh); hb = db - ha * g; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { Hm(hs, m, ka, i) = ha; if (vb) Hm(hs, m, ka + 1, i) = hb; }
+    double d1 = 0.0, d2 = 0.0, gg = 0.0;
+    auto one = [&](double wt, double a, double b, double x1, double x2, int t) {
+        double wn = wt + (-ha) * a;
+        if (vb) wn = wn + (-hb) * b;
+        w[t] = wn;
+        if (na) { d1 += wn * x1; if (nb) { d2 += wn * x2; gg += x1 * x2; } }
+        else d1 += wn * wn;
+    };
+#pragma unroll
+    for (int u = 0; u < kPre; u++) {
+        const int t = t0 + u * stride;
+        if (t < n) one(pw[u], pa[u], pb[u], p1[u], p2[u], t);
+    }
+    for (int t = t0 + kPre * stride; t < n; t += stride) one(w[t], va[t], vb ? vb[t] : 0.0, na ? na[t] : 0.0, nb ? nb[t] : 0.0, t);
+    d1 = block_sum_256(d1, sh);
+    if (nb) { d2 = block_sum_256(d2, sh); gg = block_sum_256(gg, sh); }
+    if (threadIdx.x == 0) { part_out[blockIdx.x] = d1; if (nb) { part_out[kPart + blockIdx.x] = d2; part_out[2 * kPart + blockIdx.x] = gg; } }
+}
+
 // H(i+1,i) = sqrt(sum(part_in))
 __global__ void __launch_bounds__(kB) gmres_norm_fused_kernel(KState *st, double *hs, int m, int i, const double *__restrict__ part_in)
 {
@@ -569,6 +642,7 @@ struct elag_hip_krylov_s {
     hipGraphExec_t cg_iter = nullptr;
     std::vector<hipGraphExec_t> gm_step;          // GMRES: one replayable step per position of the restart cycle
     bool gm_graph_ok = true, gm_flex = false;
+    bool gm_pairs = !(std::getenv("ELAG_HIP_GMRES_PAIR") && !atoi(std::getenv("ELAG_HIP_GMRES_PAIR")));   // (read when the solver is made: a test compares the two chains)
     // results of the last Mult
     int converged = 0, final_iter = 0;
     double final_norm = 0.0;
@@ -615,7 +689,7 @@ struct elag_hip_krylov_s {
             V = dev_alloc<double>((m + 1) * nn);
             if (solver == ELAG_HIP_KRYLOV_FGMRES) Z = dev_alloc<double>(m * nn);
             hs = dev_alloc<double>(m * (m + 1) + 4 * (m + 1));
-            part = dev_alloc<double>(2 * (size_t)kPart);
+            part = dev_alloc<double>(6 * (size_t)kPart);          // (two buffers of three runs: the two-vector Gram-Schmidt links)
         }
     }
 
@@ -822,6 +896,21 @@ struct elag_hip_krylov_s {
             }
             if (!distributed()) {
                 // fused modified Gram-Schmidt: see gmres_orth_fused_kernel
+                if (gm_pairs && i >= 1) {
+                    // two basis vectors per link (gmres_orth_pair_kernel): columns (0, 1), (2, 3), ..., a last single one when i is even
+                    double *pin = part, *pout = part + 3 * kPart;
+                    hipLaunchKernelGGL(gmres_dot0_pair_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, (const double *)target, (const double *)Vq(0),
+                                       (const double *)Vq(1), pin);
+                    for (int k = 0; k <= i; k += 2) {
+                        const double *vb = k + 1 <= i ? Vq(k + 1) : nullptr;
+                        const double *na = k + 2 <= i ? Vq(k + 2) : nullptr;
+                        const double *nb = k + 3 <= i ? Vq(k + 3) : nullptr;
+                        hipLaunchKernelGGL(gmres_orth_pair_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, hs, m, k, i, target, (const double *)Vq(k), vb,
+                                           na, nb, (const double *)pin, pout);
+                        std::swap(pin, pout);
+                    }
+                    hipLaunchKernelGGL(gmres_norm_fused_kernel, dim3(1), dim3(kB), 0, s, st, hs, m, i, (const double *)pin);
+                } else {
                 double *pin = part, *pout = part + kPart;
                 hipLaunchKernelGGL(gmres_dot0_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, (const double *)target, (const double *)Vq(0), pin);
                 for (int k = 0; k <= i; k++) {
@@ -830,6 +919,7 @@ struct elag_hip_krylov_s {
                     std::swap(pin, pout);
                 }
                 hipLaunchKernelGGL(gmres_norm_fused_kernel, dim3(1), dim3(kB), 0, s, st, hs, m, i, (const double *)pin);
+                }
             } else {
                 for (int k = 0; k <= i; k++) {
                     dot(target, Vq(k));

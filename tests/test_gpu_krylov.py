@@ -290,3 +290,33 @@ def test_solver_adopts_the_numbering_of_a_reordered_hierarchy(la, h1_k2, name):
     H.Mult(b, y); Hc.apply(b, yr)
     assert close(y, yr, 1e-11)
     assert H.time_apply_internal(3) > 0.0
+
+
+def test_gmres_two_vector_gram_schmidt_links_are_the_one_vector_chain(la):
+    """The fused modified Gram-Schmidt of GMRES takes two basis vectors per link by default (krylov.hip, gmres_orth_pair_kernel):
+    H(b,i) = <w, v_b> - H(a,i) <v_a, v_b> instead of a dot with the updated vector -- the same coefficients in exact arithmetic, rounding-level
+    differences from MFEM's loop, which ELAG_HIP_GMRES_PAIR=0 runs operation by operation.  Both against the oracle's restatement of
+    mfem::GMRESSolver and against each other, on steps with an even and an odd number of columns and across a restart."""
+    import os
+    rng = np.random.default_rng(11)
+    n = 400
+    A = orc.csr(sp.random(n, n, density=0.02, random_state=rng) + sp.diags(np.full(n, 2.5)))
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    b = rng.uniform(-1, 1, n)
+    out = []
+    for env in ({}, {"ELAG_HIP_GMRES_PAIR": "0"}):
+        os.environ.update(env)
+        try:
+            K = la.KrylovSolver(dA, None, {"Solver name": "GMRES", "Relative tolerance": 1e-10, "Maximum iterations": 200, "Restart size": 9})
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        x = np.zeros(n)
+        K.Mult(b, x)
+        out.append((K.GetConverged(), K.GetNumIterations(), x, K.GetFinalNorm()))
+    xr = np.zeros(n)
+    ref = orc.mfem_gmres(lambda v: A @ v, None, b, xr, rel_tol=1e-10, max_iter=200, m=9)
+    assert ref.final_iter > 12                                   # (more than one cycle)
+    for conv, it, x, fn in out:
+        assert conv and it == ref.final_iter and close(x, xr, 1e-9) and np.isclose(fn, ref.final_norm, rtol=1e-6)
+    assert close(out[0][2], out[1][2], 1e-10)
