@@ -266,9 +266,18 @@ void BlockSmoother::block_solve(const double *r, double *t, bool transpose)
         { k::SpmvArgs a; a.x = t0; a.alpha = -1.0; a.yin = r1; a.beta = 1.0; a.out = r1; par_spmv(*B->block(1, 0), a); }   // r_g -= A10 du~
         inner(inv[3], r1, c1, s1, false);                              // dp = S^-1 (...)
         { k::SpmvArgs a; a.x = c1; a.alpha = 1.0; a.out = c0; par_spmv(*B->block(0, 1), a); }                              // A01 dp
-        inner(inv[2], c0, t0, s0, false);                              // A_3^-1 A01 dp
-        inner(inv[0], r0, c0, s0, false);                              // du^ = A_1^-1 r_f
-        k::vec_axpby(n0, 1.0, c0, -1.0, t0, c0);                       // du = du^ - A_3^-1 A01 dp
+        static const bool reuse = !(getenv("ELAG_HIP_LDU_REUSE") && !atoi(getenv("ELAG_HIP_LDU_REUSE")));
+        if (reuse && inv[0] == inv[1]) {
+            // A_1^-1 and A_2^-1 are ONE object (the reference's own lists give one A00 inverse to all three places) applied to the same r_f from
+            // the zero guess: du^ is du~, bit for bit -- kept in t0, and the third application writes into r_f's place, which nobody reads again.
+            // One of the four inner cycles of every application less.
+            inner(inv[2], c0, r0, s0, false);                          // A_3^-1 A01 dp
+            k::vec_axpby(n0, 1.0, t0, -1.0, r0, c0);                   // du = du^ - A_3^-1 A01 dp
+        } else {
+            inner(inv[2], c0, t0, s0, false);                          // A_3^-1 A01 dp
+            inner(inv[0], r0, c0, s0, false);                          // du^ = A_1^-1 r_f
+            k::vec_axpby(n0, 1.0, c0, -1.0, t0, c0);                   // du = du^ - A_3^-1 A01 dp
+        }
         if (damping != 1.0) k::vec_axpby(n0 + n1, damping, t, 0.0, t, t);
         return;
     }
