@@ -258,12 +258,14 @@ void BlockSmoother::block_solve(const double *r, double *t, bool transpose)
     if (kind == ELAG_HIP_BLOCK_LDU) {
         ELAG_REQUIRE(!transpose, "Block2x2LDUInverseOperator::MultTranspose is not implemented");   // as the reference (:140-146)
         const int n0 = off[1], n1 = off[2] - off[1];
-        double *r0 = resid, *r1 = resid + n0;   // r aliases resid here (see apply)
+        // r is the caller's right-hand side (zero guess) or the residual in resid; r_g' = r_g - A10 du~ goes to resid either way, and
+        // resid's first block is free for the third application's result (no copy of the right-hand side first)
+        const double *rf = r, *rg = r + n0;
+        double *r0 = resid, *r1 = resid + n0;
         double *c0 = t, *c1 = t + n0;
         double *t0 = tmp, *s0 = spare, *s1 = spare + n0;
-        (void)r;
-        inner(inv[1], r0, t0, s0, false);                              // du~ = A_2^-1 r_f
-        { k::SpmvArgs a; a.x = t0; a.alpha = -1.0; a.yin = r1; a.beta = 1.0; a.out = r1; par_spmv(*B->block(1, 0), a); }   // r_g -= A10 du~
+        inner(inv[1], rf, t0, s0, false);                              // du~ = A_2^-1 r_f
+        { k::SpmvArgs a; a.x = t0; a.alpha = -1.0; a.f = rg; a.gamma = 1.0; a.out = r1; par_spmv(*B->block(1, 0), a); }   // r_g' = r_g - A10 du~
         inner(inv[3], r1, c1, s1, false);                              // dp = S^-1 (...)
         { k::SpmvArgs a; a.x = c1; a.alpha = 1.0; a.out = c0; par_spmv(*B->block(0, 1), a); }                              // A01 dp
         static const bool reuse = !(getenv("ELAG_HIP_LDU_REUSE") && !atoi(getenv("ELAG_HIP_LDU_REUSE")));
@@ -275,7 +277,7 @@ void BlockSmoother::block_solve(const double *r, double *t, bool transpose)
             k::vec_axpby(n0, 1.0, t0, -1.0, r0, c0);                   // du = du^ - A_3^-1 A01 dp
         } else {
             inner(inv[2], c0, t0, s0, false);                          // A_3^-1 A01 dp
-            inner(inv[0], r0, c0, s0, false);                          // du^ = A_1^-1 r_f
+            inner(inv[0], rf, c0, s0, false);                          // du^ = A_1^-1 r_f
             k::vec_axpby(n0, 1.0, c0, -1.0, t0, c0);                   // du = du^ - A_3^-1 A01 dp
         }
         if (damping != 1.0) k::vec_axpby(n0 + n1, damping, t, 0.0, t, t);
@@ -326,9 +328,6 @@ void BlockSmoother::apply(const double *f, double *&cur, double *&alt, bool zero
         k::SpmvArgs a;   // Resid = rhs - A sol (BlockDiagonalSolver.cpp:84-91)
         a.x = cur; a.alpha = -1.0; a.f = f; a.gamma = 1.0; a.out = resid;
         par_spmv(*A, a);
-        r = resid;
-    } else if (kind == ELAG_HIP_BLOCK_LDU) {
-        ELAG_HIP_CHECK(hipMemcpyAsync(resid, f, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, ctx().stream));   // the LDU sweep updates r_g in place
         r = resid;
     }
     double *t = zero_guess ? cur : corr;
