@@ -720,7 +720,9 @@ def main():
     dist = None
     if world > 1 or args.force_dist:
         from parelag_amd import distributed
+        note("rank %d of %d: device, process group, communicator ..." % (rank, world))
         dist = distributed.init(rank, world)
+        note("rank %d: communicator ready" % rank)
     else:
         _lib.init()
 

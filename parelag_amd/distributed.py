@@ -71,6 +71,8 @@ def init(rank: int, world: int) -> Dist:
     if int(os.environ.get("NNODES", os.environ.get("GROUP_WORLD_SIZE", "1")) or 1) <= 1:
         # one node: RCCL's bootstrap sockets on the loopback interface (the container's hostname may not resolve)
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        # ... and gloo's: without it gloo looks its interface up through the host name, which may not resolve (or may take minutes not to)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     # Load the HIP library (and, across ranks, the system RCCL) BEFORE torch: the dynamic loader then binds
     # everything in this process to the one ROCm runtime the kernels were built with; torch is used on the CPU
     # only (gloo rendezvous / barriers), so its bundled copies of the same sonames are never needed.
