@@ -88,7 +88,12 @@ def init(rank: int, world: int) -> Dist:
     import torch.distributed as td
     if not td.is_initialized():
         with stdout_to_stderr():
-            td.init_process_group("gloo", rank=rank, world_size=world)
+            if world == 1:
+                # a lone rank needs no rendezvous: an in-process store (the TCP store looks host names up, which on a box whose name does
+                # not resolve costs a warning at best and minutes at worst)
+                td.init_process_group("gloo", store=td.HashStore(), rank=0, world_size=1)
+            else:
+                td.init_process_group("gloo", rank=rank, world_size=world)
     uid = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
         buf = (C.c_ubyte * 128)()
