@@ -549,7 +549,7 @@ def spmd_cpu_baseline(refines, seconds, workers=None, smoother=1):
     if smoother != 1:
         cmd += ["--smoother", str(smoother)]
     try:
-        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=180)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not lines:
             return {"error": (r.stderr or r.stdout)[-400:]}
@@ -575,7 +575,7 @@ def measure_roofline_traffic(args):
 
     def run(counter, prog, tag):
         d = os.path.join(tmp, tag)
-        r = subprocess.run([rp, "--pmc", counter, "--output-format", "csv", "-d", d, "--", *prog], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+        r = subprocess.run([rp, "--pmc", counter, "--output-format", "csv", "-d", d, "--", *prog], cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not lines:
             raise RuntimeError((r.stderr or r.stdout)[-300:])
