@@ -884,6 +884,60 @@ __global__ void dense_mm_kernel(int nr, int nk, int m, const double *__restrict_
 }
 }  // namespace
 
+namespace {
+// The same product on the matrix cores: the one dense GEMM of the path (the dense operator of a Gauss-Seidel hierarchy's coarse tail: 840 x 840 x 5 739
+// at cube456 x3, 8.1 GFLOP -- 1.9 ms at one thread per entry of the result).  v_mfma_f64_16x16x4_f64: lane l holds A[l & 15][k = l >> 4] and
+// B[k = l >> 4][l & 15], result register r of lane l is C[(l >> 4) + 4 r][l & 15].  A workgroup computes a 64 x 64 tile, its four wavefronts
+// 32 x 32 corners (2 x 2 instruction tiles), the operands' 64 x 16 and 16 x 64 panels staged in LDS.  fp64 FMAs in ascending k per entry (fused,
+// where the scalar kernel rounds the product and the sum separately).
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void dense_mm_mfma_kernel(int nr, int nk, int m, const double *__restrict__ M, const double *__restrict__ X, double *__restrict__ out)
+{
+    __shared__ double As[64][17];      // [row][k]
+    __shared__ double Bs[16][66];      // [k][column]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
+    mfma_d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+    const int ar = tid >> 2, ak = (tid & 3) * 4;       // this thread's four consecutive k of one row of the A panel
+    const int bk = tid >> 4, bc = (tid & 15) * 4;      // ... and four consecutive columns of one k of the B panel
+    for (int k0 = 0; k0 < nk; k0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = i0 + ar, k = k0 + ak + q;
+            As[ar][ak + q] = (i < nr && k < nk) ? M[(size_t)i * nk + k] : 0.0;
+            const int kk = k0 + bk, j = j0 + bc + q;
+            Bs[bk][bc + q] = (kk < nk && j < m) ? X[(size_t)kk * m + j] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 4) {
+            const int kl = ks + (lane >> 4), l15 = lane & 15;
+            const double a0 = As[wr + l15][kl], a1 = As[wr + 16 + l15][kl];
+            const double b0 = Bs[kl][wc + l15], b1 = Bs[kl][wc + 16 + l15];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = i0 + wr + a * 16 + (lane >> 4) + 4 * r, j = j0 + wc + b * 16 + (lane & 15);
+                if (i < nr && j < m) out[(size_t)i * m + j] = acc[a][b][r];
+            }
+}
+}  // namespace
+
 void csr_times_dense(const DevCSR &S, int m, double alpha, const double *X, double beta, bool add_identity, double *out)
 {
     const long long tot = (long long)S.nrows * m;
@@ -897,6 +951,12 @@ void dense_mm(int nr, int nk, int m, const double *M, const double *X, double *o
 {
     const long long tot = (long long)nr * m;
     if (tot == 0) return;
+    const char *e = getenv("ELAG_HIP_DENSE_MFMA");                     // (read at every call: a test compares the two kernels)
+    if (!(e && !atoi(e)) && nk > 0 && (long long)nr * nk * m >= (1ll << 18)) {
+        hipLaunchKernelGGL(dense_mm_mfma_kernel, dim3((unsigned)((m + 63) / 64), (unsigned)((nr + 63) / 64)), dim3(256), 0, ctx().stream, nr, nk, m, M, X, out);
+        ELAG_LAUNCH_CHECK();
+        return;
+    }
     hipLaunchKernelGGL(dense_mm_kernel, dim3((unsigned)((tot + kB - 1) / kB)), dim3(kB), 0, ctx().stream, nr, nk, m, M, X, out);
     ELAG_LAUNCH_CHECK();
 }
@@ -905,6 +965,7 @@ void preload_dense_kernels()
 {
     hipFuncAttributes attr;
     (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(dense_mm_kernel));
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(dense_mm_mfma_kernel));
 }
 
 void dense_times_csr_t(int nc, int n, const double *Bc, const DevCSR &GT, double *X)

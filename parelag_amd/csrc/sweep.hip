@@ -672,6 +672,56 @@ __global__ void sweep_dense_level_kernel(int r0, int r1, const int *__restrict__
     if (MODE == 0) { if (d[row] != 0.0) X[(size_t)row * m + c] += omega * res / d[row]; }
     else if (have && aii != 0.0) X[(size_t)row * m + c] = res / aii;
 }
+
+// The same sweeps with the COLUMNS of X dealt to the workgroups: the columns are independent systems, so a workgroup that owns a strip of 16 of
+// them walks all dependency levels of all sweeps by itself with a workgroup barrier between levels -- one launch where the level kernel above takes
+// two per level and sweep (368 launches of ~16 us for the 5 739 x 5 739 block of cube456 x3's level 1: 5.9 of a 13 ms Gauss-Seidel hierarchy
+// build).  Same operations per entry, same order inside a row (operators without ghosts; 64 rows of a level at a time).
+constexpr int kStripCols = 16, kStripThreads = 1024;
+template <int MODE>
+__global__ __launch_bounds__(kStripThreads) void sweep_dense_strip_kernel(int nlev, const int *__restrict__ lev_ptr, const int *__restrict__ rows,
+                                                                          const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
+                                                                          const double *__restrict__ F, const double *__restrict__ d, double omega, double *X, int m,
+                                                                          int sweeps)
+{
+    constexpr int kSlots = kStripThreads / kStripCols;
+    const int c = blockIdx.x * kStripCols + (int)(threadIdx.x % kStripCols), rs = (int)(threadIdx.x / kStripCols);
+    const bool on = c < m;
+    for (int sw = 0; sw < sweeps; sw++)
+        for (int pass = 0; pass < 2; pass++)
+            for (int q = 0; q < nlev; q++) {
+                const int l = pass == 0 ? q : nlev - 1 - q;
+                const int r0 = lev_ptr[l], r1 = lev_ptr[l + 1];
+                for (int ri = r0 + rs; ri < r1; ri += kSlots) {
+                    if (!on) continue;
+                    const int row = rows[ri];
+                    double res = F ? F[(size_t)row * m + c] : (row == c ? 1.0 : 0.0), aii = 0.0;
+                    bool have = false;
+                    // eight entries of the row at a time: their columns and values, then their X entries, requested together (entry by entry a row
+                    // is a chain of two dependent loads per entry); the sum is taken in the row's order as before.  (What is left is bandwidth: a sweep reads
+                    // nnz(A) x m entries of X -- 3.6 GB per direction for the 5 739 x 5 739 block, whose 263 MB fit no cache -- at ~3 TB/s in 128 B
+                    // pieces.  Requesting the next level's row ahead and keeping the schedule in LDS were tried: slower / no change.)
+                    const int ke = I[row + 1];
+                    for (int k = I[row]; k < ke; k += 8) {
+                        int jj[8];
+                        double aa[8], xx[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) { const bool in = k + u < ke; jj[u] = in ? J[k + u] : row; aa[u] = in ? a[k + u] : 0.0; }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) xx[u] = X[(size_t)jj[u] * m + c];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            if (k + u >= ke) continue;
+                            if (MODE == 1 && jj[u] == row && !have) { aii = aa[u]; have = true; continue; }
+                            res -= aa[u] * xx[u];
+                        }
+                    }
+                    if (MODE == 0) { if (d[row] != 0.0) X[(size_t)row * m + c] += omega * res / d[row]; }
+                    else if (have && aii != 0.0) X[(size_t)row * m + c] = res / aii;
+                }
+                __syncthreads();          // (the level's rows of this strip are written before the next level reads them: columns never cross strips)
+            }
+}
 }  // namespace
 
 bool SweepSmoother::apply_dense(const double *F, double *X, int m, bool zero_guess)
@@ -685,6 +735,22 @@ bool SweepSmoother::apply_dense(const double *F, double *X, int m, bool zero_gue
     ELAG_REQUIRE(!ho || As, "internal: apply_dense on an operator with real ghosts");
     Temp<double> snap(ho ? (size_t)n * m : 1);
     const int nlev = (int)h_lev_ptr.size() - 1;
+    {
+        const char *e = getenv("ELAG_HIP_DENSE_STRIPS");              // (read at every call: a test compares the two routes)
+        if (!ho && !(e && !atoi(e)) && m >= 64) {
+            Temp<int> dlp((size_t)nlev + 1);
+            stage_h2d(dlp.p, h_lev_ptr.data(), sizeof(int) * ((size_t)nlev + 1));
+            const unsigned g = (unsigned)((m + kStripCols - 1) / kStripCols);
+            auto go = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(g), dim3(kStripThreads), 0, st, nlev, (const int *)dlp.p, (const int *)d_lev_rows, (const int *)M->diag.I,
+                                   (const int *)M->diag.J, (const double *)M->diag.a, F, (const double *)d_l1, omega, X, m, sweeps);
+            };
+            if (type == ELAG_HIP_SMOOTHER_GS) go(sweep_dense_strip_kernel<1>);
+            else go(sweep_dense_strip_kernel<0>);
+            ELAG_LAUNCH_CHECK();
+            return true;
+        }
+    }
     auto level = [&](int l) {
         const int r0 = h_lev_ptr[(size_t)l], r1 = h_lev_ptr[(size_t)l + 1];
         if (r1 == r0) return;

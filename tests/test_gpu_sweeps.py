@@ -515,3 +515,36 @@ def test_vcycle_with_the_remaining_entries_of_the_smoother_table(la, h1_k2, smoo
     H.Mult(b, x)
     Ho.Mult(b, xr)
     assert np.max(np.abs(x - xr)) <= 1e-10 * np.max(np.abs(xr))
+
+
+def test_dense_tail_product_on_the_matrix_cores_is_the_scalar_product(la, h1_k2):
+    """The dense operator of a Gauss-Seidel hierarchy's coarse tail is a chain of dense products; the one true GEMM of it (B_below times P^T R) runs on
+    the matrix cores (dense.hip, dense_mm_mfma_kernel: v_mfma_f64_16x16x4_f64, 64 x 64 tiles) where ELAG_HIP_DENSE_MFMA=0 keeps one thread per
+    entry.  Fused multiply-adds in ascending k against separately rounded products and sums: the two cycles agree to rounding, and each with the oracle."""
+    import os
+    A, Ps, _ = h1_k2
+    t = la.HYPRE_SMOOTHER_TYPES["L1 Gauss-Seidel"]
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    h = oracle_h1_hierarchy(A, Ps, smoother=t)
+    Hc = orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"])
+    n = A.shape[0]
+    b = np.random.default_rng(17).uniform(-1, 1, n)
+    xr = np.empty(n)
+    Hc.apply(b, xr)
+    xs = []
+    for env in ({}, {"ELAG_HIP_DENSE_MFMA": "0"}, {"ELAG_HIP_DENSE_STRIPS": "0"}):
+        os.environ.update(env)
+        try:
+            H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Gauss-Seidel")
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        x = np.full(n, 3.0)
+        H.Mult(b, x)
+        xs.append(x)
+        assert np.max(np.abs(x - xr)) <= 1e-12 * np.max(np.abs(xr))
+    assert np.max(np.abs(xs[0] - xs[1])) <= 1e-13 * np.max(np.abs(xr))
+    # the sweeps over the dense block: a workgroup per strip of 16 columns walking all levels (default) against a launch per level -- the same
+    # operations entry by entry
+    assert np.array_equal(xs[0], xs[2])
