@@ -3,7 +3,7 @@
 OUT=$PWD/gpurun_out/$1; shift
 REPO=$PWD; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python3 $REPO/tools/setup_probe.py "$@" > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python3 $REPO/tools/${PROBE:-setup_probe.py} "$@" > $OUT/run.log 2>&1
 cd $REPO
 tail -n 1 $OUT/run.log | cut -c1-250
 python3 - <<PY
