@@ -447,12 +447,16 @@ def test_blocked_dense_lu_is_the_column_by_column_one(la, n):
     b = rng.uniform(-1, 1, n)
     xs = []
     for env in ({}, {"ELAG_HIP_LU_BLOCKED": "0"}):
+        saved_env = {k: os.environ.get(k) for k in env}      # (a variable the run itself was started with is put back, not dropped)
         os.environ.update(env)
         try:
             C = la.CoarseSolver(la.ParallelCSRMatrix.from_scipy(A), kind=1)
         finally:
-            for k in env:
-                os.environ.pop(k, None)
+            for k, v in saved_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         x = np.zeros(n)
         C.Mult(b, x)
         xs.append(x)
@@ -477,12 +481,16 @@ def test_spd_inverse_in_registers_is_the_lds_sweep_bit_for_bit(la, n):
     b = rng.uniform(-1, 1, n)
     xs = []
     for env in ({}, {"ELAG_HIP_SPD_REG": "0"}):
+        saved_env = {k: os.environ.get(k) for k in env}      # (a variable the run itself was started with is put back, not dropped)
         os.environ.update(env)
         try:
             C = la.CoarseSolver(la.ParallelCSRMatrix.from_scipy(A), kind=0)
         finally:
-            for k in env:
-                os.environ.pop(k, None)
+            for k, v in saved_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         x = np.zeros(n)
         C.Mult(b, x)
         xs.append(x)

@@ -305,12 +305,16 @@ def test_gmres_two_vector_gram_schmidt_links_are_the_one_vector_chain(la):
     b = rng.uniform(-1, 1, n)
     out = []
     for env in ({}, {"ELAG_HIP_GMRES_PAIR": "0"}):
+        saved_env = {k: os.environ.get(k) for k in env}      # (a variable the run itself was started with is put back, not dropped)
         os.environ.update(env)
         try:
             K = la.KrylovSolver(dA, None, {"Solver name": "GMRES", "Relative tolerance": 1e-10, "Maximum iterations": 200, "Restart size": 9})
         finally:
-            for k in env:
-                os.environ.pop(k, None)
+            for k, v in saved_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         x = np.zeros(n)
         K.Mult(b, x)
         out.append((K.GetConverged(), K.GetNumIterations(), x, K.GetFinalNorm()))

@@ -544,12 +544,16 @@ def test_bandwidth_bound_hiptmair_level_goes_up_through_S(la, hdiv_k2):
     b = np.random.default_rng(34).uniform(-1, 1, A.shape[0])
     outs = {}
     for name, env in (("S", {"ELAG_HIP_FUSE_NNZ": "1"}), ("separate", {"ELAG_HIP_FUSE_NNZ": "1", "ELAG_HIP_BIG_LEVEL_S": "0"})):
+        saved_env = {k: os.environ.get(k) for k in env}      # (a variable the run itself was started with is put back, not dropped)
         os.environ.update(env)
         try:
             H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi", Ds=dDs, aux_smoother="L1 Jacobi")
         finally:
-            for k in env:
-                os.environ.pop(k, None)
+            for k, v in saved_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         x = np.empty_like(b)
         H.Mult(b, x)
         outs[name] = x
@@ -968,12 +972,16 @@ def test_flattened_cycle_is_the_level_by_level_cycle(la, h1_k3, smoother, capfd)
     outs = {}
     for name, env in (("flat", {"ELAG_HIP_FLAT_VERBOSE": "1"}), ("levels", {"ELAG_HIP_FLAT_CYCLE": "0"}),
                       ("levels_unit_vectors", {"ELAG_HIP_FLAT_CYCLE": "0", "ELAG_HIP_DENSE_TAIL_RECURSION": "0"})):
+        saved_env = {k: os.environ.get(k) for k in env}      # (a variable the run itself was started with is put back, not dropped)
         os.environ.update(env)
         try:
             H = la.buildHierarchyFromDeRhamSequence(dA, dPs, smoother)
         finally:
-            for k in env:
-                os.environ.pop(k, None)
+            for k, v in saved_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         if name == "flat" and smoother == "L1 Jacobi":     # (the Chebyshev hierarchy of this size has one composed level only: nothing to flatten)
             assert "flattened cycle: levels 0..2" in capfd.readouterr().err
         x = np.zeros(A.shape[0])
@@ -1006,12 +1014,16 @@ def test_bandwidth_bound_level_goes_up_through_S(la, h1_k2, reorder):
     b, x0 = rng.uniform(-1, 1, A.shape[0]), rng.uniform(-1, 1, A.shape[0])
     outs = {}
     for name, env in (("S", {"ELAG_HIP_FUSE_NNZ": "1"}), ("separate", {"ELAG_HIP_FUSE_NNZ": "1", "ELAG_HIP_BIG_LEVEL_S": "0"})):
+        saved_env = {k: os.environ.get(k) for k in env}      # (a variable the run itself was started with is put back, not dropped)
         os.environ.update(env)
         try:
             H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi", reorder=reorder)
         finally:
-            for k in env:
-                os.environ.pop(k, None)
+            for k, v in saved_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         x = np.zeros(A.shape[0])
         H.Mult(b, x)
         H.iterative_mode = True
@@ -1045,12 +1057,16 @@ def test_triple_product_routes_give_the_same_matrix(la, h1_k2, hdiv_k2):
         two_step = ({"ELAG_HIP_RAP_FUSED": "0"}, {"ELAG_HIP_RAP_FUSED": "0", "ELAG_HIP_ELL_PIPE": "0"}, {"ELAG_HIP_RAP_ELL": "0"},
                     {"ELAG_HIP_RAP_ELL": "0", "ELAG_HIP_RAP_LOOSE": "0"})
         for env in two_step + ({},):
+            saved_env = {k: os.environ.get(k) for k in env}      # (a variable the run itself was started with is put back, not dropped)
             os.environ.update(env)
             try:
                 outs.append(la.RAP(dA, dP).to_scipy())
             finally:
-                for k in env:
-                    os.environ.pop(k, None)
+                for k, v in saved_env.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
         ref = (sp.csr_matrix(P).T @ sp.csr_matrix(A) @ sp.csr_matrix(P)).tocsr()
         ref.sort_indices()
         for M in outs:
@@ -1129,12 +1145,16 @@ def test_blocked_spd_inverse_is_the_pivot_by_pivot_one(la, n):
     b = rng.uniform(-1, 1, n)
     xs = []
     for env in ({}, {"ELAG_HIP_SPD_BLOCKED": "0"}):
+        saved_env = {k: os.environ.get(k) for k in env}      # (a variable the run itself was started with is put back, not dropped)
         os.environ.update(env)
         try:
             C = la.CoarseSolver(la.ParallelCSRMatrix.from_scipy(A), kind=0)
         finally:
-            for k in env:
-                os.environ.pop(k, None)
+            for k, v in saved_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         x = np.zeros(n)
         C.Mult(b, x)
         xs.append(x)

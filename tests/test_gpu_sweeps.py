@@ -534,12 +534,16 @@ def test_dense_tail_product_on_the_matrix_cores_is_the_scalar_product(la, h1_k2)
     Hc.apply(b, xr)
     xs = []
     for env in ({}, {"ELAG_HIP_DENSE_MFMA": "0"}, {"ELAG_HIP_DENSE_STRIPS": "0"}):
+        saved_env = {k: os.environ.get(k) for k in env}      # (a variable the run itself was started with is put back, not dropped)
         os.environ.update(env)
         try:
             H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Gauss-Seidel")
         finally:
-            for k in env:
-                os.environ.pop(k, None)
+            for k, v in saved_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         x = np.full(n, 3.0)
         H.Mult(b, x)
         xs.append(x)
