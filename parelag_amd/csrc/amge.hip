@@ -875,7 +875,7 @@ ELAG_HIP_API int elag_hip_coarsen_traces(const elag_hip_coarsen_traces_in *in, c
         DevBuf<int64_t> d_doff(doff.data(), (size_t)ne + 1), d_wsoff(pl.ws_off.data(), (size_t)ne);
         DevBuf<double> d_pv(in->pv, (size_t)nd), d_T(in->T, (size_t)nd * nT), d_p((size_t)nd * kmax), d_cm((size_t)ne * kmax * kmax),
             d_f((size_t)nd * kmax), d_gws((size_t)pl.gws_total);
-        ELAG_HIP_CHECK(hipMemsetAsync(d_sing.p, 0, sizeof(int), st));
+        zero_async(d_sing.p, sizeof(int));
         TracesArgs a{};
         a.n_ent = ne; a.nT = nT; a.svd_tol = in->svd_tol; a.ndof = d_ndof; a.dof_off = d_doff; a.mass = mass.dev;
         a.pv = d_pv; a.T = d_T; a.ncoarse = d_nc; a.p_loc = d_p; a.cmass = d_cm; a.functional = d_f;
@@ -957,7 +957,7 @@ ELAG_HIP_API int elag_hip_coarsen_extension(const elag_hip_coarsen_extension_in 
             d_T(in->T, (size_t)o_T[ne]);
         DevBuf<double> d_ext((size_t)o_ext[ne]), d_dc((size_t)o_dc[ne]), d_rt((size_t)o_rt[ne]), d_nul((size_t)o_nul[ne]), d_fun((size_t)o_fun[ne]),
             d_cm((size_t)o_cm[ne]), d_gws((size_t)pl.gws_total);
-        ELAG_HIP_CHECK(hipMemsetAsync(d_sing.p, 0, sizeof(int), st));
+        zero_async(d_sing.p, sizeof(int));
         ExtArgs a{};
         a.n_ent = ne; a.nT = nT; a.mode = mode; a.null_dofs = in->null_dofs; a.debug_stop = getenv("ELAG_HIP_AMGE_STOP") ? atoi(getenv("ELAG_HIP_AMGE_STOP")) : 0; a.svd_tol = in->svd_tol; a.smallest_entry = in->smallest_entry;
         a.nu = d_nu; a.ni = d_ni; a.np = d_np; a.npi = d_npi; a.nq = d_nq; a.next = d_nx; a.nrt = d_nrt; a.mass_u = mu.dev; a.mass_p = mp.dev; a.mass_q = mq.dev;

@@ -169,7 +169,7 @@ static ParCSR *schur_complement(elag_hip_blockop_s &B, int type, double alpha, b
         k::extract_diagonal(A00->diag, d);
     } else {
         Temp<int> bad(1);
-        ELAG_HIP_CHECK(hipMemsetAsync(bad.p, 0, sizeof(int), ctx().stream));
+        zero_async(bad.p, sizeof(int));
         k::l1_norms(A00->diag, &A00->offd, 1, d, bad);   // +-(sum |diag row| + sum |offd row|)
         k::values_abs(n0, d, d);
     }

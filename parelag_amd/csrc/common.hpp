@@ -113,6 +113,9 @@ void event_wait(hipEvent_t ev);
 // sequence number; the host polls that number -- 9.5 us per round trip against 15 for hipMemcpyAsync + hipStreamSynchronize and more when
 // the destination is pageable (tools/sync_probe.cpp).  ELAG_HIP_FETCH_KERNEL=0: the copy API.  count <= 30 ints / 15 doubles.
 void fetch_ints(const int *dev, int count, int *out);
+// Zeroes device memory on the compute stream by a kernel launch: a hipMemsetAsync call costs the host 8-10 us on this stack (a launch ~4), and a
+// hierarchy build issues 60-160 of them in front of kernels that wait for nothing else.  (Other values, unaligned ends: hipMemsetAsync.)
+void zero_async(void *dev, size_t bytes);
 inline void fetch_doubles(const double *dev, int count, double *out) { fetch_ints(reinterpret_cast<const int *>(dev), 2 * count, reinterpret_cast<int *>(out)); }
 inline int fetch_int(const int *dev) { int v = 0; fetch_ints(dev, 1, &v); return v; }
 void amge_release_arena();            // amge.hip: frees the calling thread's coarsening arena (elag_hip_finalize)

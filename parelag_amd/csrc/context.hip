@@ -133,7 +133,7 @@ void DevCSR::upload(int nr, int nc, const int *hi, const int *hj, const double *
     alloc(nr, nc, nz);
     hipStream_t st = ctx().stream;
     if (nr) ELAG_HIP_CHECK(hipMemcpyAsync(I, hi, sizeof(int) * ((size_t)nr + 1), hipMemcpyHostToDevice, st));
-    else ELAG_HIP_CHECK(hipMemsetAsync(I, 0, sizeof(int), st));
+    else zero_async(I, sizeof(int));
     if (nz) {
         ELAG_HIP_CHECK(hipMemcpyAsync(J, hj, sizeof(int) * (size_t)nz, hipMemcpyHostToDevice, st));
         ELAG_HIP_CHECK(hipMemcpyAsync(a, ha, sizeof(double) * (size_t)nz, hipMemcpyHostToDevice, st));
@@ -252,7 +252,7 @@ void DevCSR::alloc_entries(int64_t nz)
 void DevCSR::set_empty(int nr, int nc)
 {
     alloc(nr, nc, 0);
-    ELAG_HIP_CHECK(hipMemsetAsync(I, 0, sizeof(int) * ((size_t)nr + 1), ctx().stream));
+    zero_async(I, sizeof(int) * ((size_t)nr + 1));
     choose_spmv_shape();
 }
 
@@ -517,6 +517,34 @@ __global__ void fetch_publish_kernel(const int *__restrict__ src, int count, vol
     if (l == 0) host[31] = seq;
 }
 }  // namespace
+namespace {
+__global__ void zero_words_kernel(size_t nwords, unsigned *__restrict__ p)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    if (((uintptr_t)p & 15) == 0) {
+        uint4 *p4 = reinterpret_cast<uint4 *>(p);
+        const size_t n4 = nwords / 4;
+        for (size_t i = tid; i < n4; i += nth) p4[i] = uint4{0u, 0u, 0u, 0u};
+        for (size_t i = n4 * 4 + tid; i < nwords; i += nth) p[i] = 0u;
+    } else {
+        for (size_t i = tid; i < nwords; i += nth) p[i] = 0u;
+    }
+}
+}  // namespace
+void zero_async(void *dev, size_t bytes)
+{
+    if (bytes == 0) return;
+    Context &c = ctx();
+    static const bool by_kernel = !(getenv("ELAG_HIP_ZERO_KERNEL") && !atoi(getenv("ELAG_HIP_ZERO_KERNEL")));
+    if (!by_kernel || (bytes & 3) || ((uintptr_t)dev & 3)) {
+        ELAG_HIP_CHECK(hipMemsetAsync(dev, 0, bytes, c.stream));
+        return;
+    }
+    const size_t nwords = bytes / 4;
+    const unsigned g = (unsigned)std::min<size_t>((nwords / 4 + 255) / 256 + 1, (size_t)8 * (size_t)std::max(c.num_cus, 1));
+    hipLaunchKernelGGL(zero_words_kernel, dim3(g), dim3(256), 0, c.stream, nwords, static_cast<unsigned *>(dev));
+    ELAG_LAUNCH_CHECK();
+}
 void fetch_ints(const int *dev, int count, int *out)
 {
     Context &c = ctx();

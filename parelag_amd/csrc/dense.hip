@@ -451,8 +451,8 @@ void dense_inverse_general(const DevCSR &A, double *Minv)
             Temp<long long> dbg(e_tim && atoi(e_tim) ? nsteps * 6 : 1);
             long long *dbgp = e_tim && atoi(e_tim) ? dbg.p : nullptr;
             double *Mo = Mb, *Mn = Mb + (size_t)n * n;
-            ELAG_HIP_CHECK(hipMemsetAsync(Mo, 0, sizeof(double) * (size_t)n * n, st));
-            ELAG_HIP_CHECK(hipMemsetAsync(singular.p, 0, sizeof(int), st));
+            zero_async(Mo, sizeof(double) * (size_t)n * n);
+            zero_async(singular.p, sizeof(int));
             hipLaunchKernelGGL(dense_scatter_plain_kernel, dim3((n + kB - 1) / kB), dim3(kB), 0, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, Mo);
             const dim3 gu((n + 255) / 256, (n + kGRows - 1) / kGRows);
             for (int k0 = 0; k0 < n; k0 += kGB) {
@@ -485,8 +485,8 @@ void dense_inverse_general(const DevCSR &A, double *Minv)
     try {
         Temp<int> piv(1), singular(1);
         Temp<double> pivval(1), colk((size_t)n);
-        ELAG_HIP_CHECK(hipMemsetAsync(M, 0, sizeof(double) * (size_t)n * ld, st));
-        ELAG_HIP_CHECK(hipMemsetAsync(singular.p, 0, sizeof(int), st));
+        zero_async(M, sizeof(double) * (size_t)n * ld);
+        zero_async(singular.p, sizeof(int));
         hipLaunchKernelGGL(dense_scatter_kernel, dim3((n + kB - 1) / kB), dim3(kB), 0, st, n, (const int *)A.I, (const int *)A.J,
                            (const double *)A.a, M, ld);
         const dim3 gcol((ld + kB - 1) / kB), grow((n + kB - 1) / kB), gel((ld + kB - 1) / kB, (n + 7) / 8);
@@ -770,7 +770,7 @@ void dense_inverse_spd(const DevCSR &A, double *Minv)
             raised = true;
         }
         Temp<int> bad(1);
-        ELAG_HIP_CHECK(hipMemsetAsync(bad.p, 0, sizeof(int), st));
+        zero_async(bad.p, sizeof(int));
         const char *e_reg = getenv("ELAG_HIP_SPD_REG");                 // (read at every call: a test switches it)
         const bool in_regs = !(e_reg && !atoi(e_reg));
         if (in_regs)
@@ -786,8 +786,8 @@ void dense_inverse_spd(const DevCSR &A, double *Minv)
     try {
         Temp<int> bad(1);
         Temp<double> colk((size_t)n), rowk((size_t)n);
-        ELAG_HIP_CHECK(hipMemsetAsync(M, 0, sizeof(double) * (size_t)n * n, st));
-        ELAG_HIP_CHECK(hipMemsetAsync(bad.p, 0, sizeof(int), st));
+        zero_async(M, sizeof(double) * (size_t)n * n);
+        zero_async(bad.p, sizeof(int));
         hipLaunchKernelGGL(dense_scatter_plain_kernel, dim3((n + kB - 1) / kB), dim3(kB), 0, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, M);
         // the (numerically symmetric) input made exactly symmetric first, like the host path
         hipLaunchKernelGGL(symmetrise_kernel, dim3((n + kB - 1) / kB, n), dim3(kB), 0, st, n, (const double *)M, Minv);

@@ -343,7 +343,7 @@ struct elag_hip_hierarchy_s {
         // stored transposed first (one contiguous row per application)
         double *Bt = dev_alloc<double>((size_t)n * n);
         Temp<double> ej((size_t)n);
-        ELAG_HIP_CHECK(hipMemsetAsync(ej, 0, sizeof(double) * (size_t)n, st));
+        zero_async(ej, sizeof(double) * (size_t)n);
         for (int j = 0; j < n; j++) {
             k::vec_fill(1, 1.0, ej.p + j);           // (a kernel, not a copy from pageable host memory: that one is synchronous)
             iterate(L, ej, Bt + (size_t)j * n, lev[(size_t)L].alt);

@@ -137,8 +137,8 @@ void exclusive_scan(const int *in, int *out, int n, int *d_max, int *d_total)
 {
     hipStream_t st = ctx().stream;
     if (n == 0) {
-        ELAG_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(int), st));
-        if (d_total) ELAG_HIP_CHECK(hipMemsetAsync(d_total, 0, sizeof(int), st));
+        zero_async(out, sizeof(int));
+        if (d_total) zero_async(d_total, sizeof(int));
         return;
     }
     const int nb = (n + 1023) / 1024;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void scan64_block_final(const i64 *__restri
 void exclusive_scan64(const i64 *in, i64 *out, int n)
 {
     hipStream_t st = ctx().stream;
-    if (n == 0) { ELAG_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(i64), st)); return; }
+    if (n == 0) { zero_async(out, sizeof(i64)); return; }
     const int nb = (n + 1023) / 1024;
     if (nb == 1) {
         hipLaunchKernelGGL(scan64_block_final, dim3(1), dim3(kBlock), 0, st, in, n, (const i64 *)nullptr, (const i64 *)nullptr, out);
@@ -1823,7 +1823,7 @@ struct EscPlan {
     void finish()
     {
         hipStream_t st = ctx().stream;
-        ELAG_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * sizeof(int), st));
+        zero_async(counters, 2 * sizeof(int));
         hipLaunchKernelGGL(split_big_kernel, dim3(grid1(nrows)), dim3(kBlock), 0, st, nrows, ub.p, ub_small.p, biglist.p,
                            counters.p, counters.p + 1, wave_cap);
         exclusive_scan(ub_small, ubscan, nrows);
@@ -1834,7 +1834,7 @@ struct EscPlan {
             hipLaunchKernelGGL(wave_ub_kernel, dim3(grid1(nrows)), dim3(kBlock), 0, st, nrows, (const int *)ub.p, wave_cap, ubw.p, (unsigned long long *)nullptr, all_rows ? 1 : 0);
             exclusive_scan(ubw, UBI, nrows);
             const ClassBounds cb{{0, 16, 32, 64, 128, kWaveCap}};
-            ELAG_HIP_CHECK(hipMemsetAsync(ccount, 0, sizeof(int) * kNumClasses, st));
+            zero_async(ccount, sizeof(int) * kNumClasses);
             hipLaunchKernelGGL(esc_classify_kernel, dim3(std::min(grid1(nrows), 1024u)), dim3(kBlock), 0, st, nrows, (const int *)ub.p, cb, ccount.p, lists.p, 1);
             ELAG_LAUNCH_CHECK();
         }
@@ -1863,7 +1863,7 @@ struct EscPlan {
         hipStream_t st = ctx().stream;
         hipLaunchKernelGGL(ell_plan_kernel, dim3(grid1((long long)nrows + 1)), dim3(kBlock), 0, st, nrows, W, AI, ub.p, ubw.p, UBI.p);
         const ClassBounds cb{{0, 16, 32, 64, 128, kWaveCap}};
-        ELAG_HIP_CHECK(hipMemsetAsync(ccount, 0, sizeof(int) * kNumClasses, st));
+        zero_async(ccount, sizeof(int) * kNumClasses);
         hipLaunchKernelGGL(esc_classify_kernel, dim3(std::min(grid1(nrows), 1024u)), dim3(kBlock), 0, st, nrows, (const int *)ub.p, cb, ccount.p, lists.p, 1);
         ELAG_LAUNCH_CHECK();
         int *hp = reinterpret_cast<int *>(ctx().h_scalar + 10);
@@ -1897,7 +1897,7 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
     const int n = plan.nrows;
     Temp<int> rownnz_own(keep ? 1 : (size_t)n);
     struct { int *p; operator int *() const { return p; } } rownnz{keep ? keep->rownnz : rownnz_own.p};
-    ELAG_HIP_CHECK(hipMemsetAsync(rownnz, 0, sizeof(int) * (size_t)n, st));
+    zero_async(rownnz, sizeof(int) * (size_t)n);
     if (keep) ELAG_REQUIRE(esc_layout_fits(plan), "internal: esc_run asked to keep a layout that does not hold every row");
     const int nch = plan.nchunks();
     // the symbolic launches of the chunked / one-row-per-workgroup rows -- unless the single pass below has room for those rows too
@@ -1921,14 +1921,14 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
         } else {
             // (plans whose nrows * wave_cap could overflow the int layout: the total first, the layout only if it fits)
             Temp<unsigned long long> tot64(1);
-            ELAG_HIP_CHECK(hipMemsetAsync(tot64, 0, sizeof(unsigned long long), st));
+            zero_async(tot64, sizeof(unsigned long long));
             hipLaunchKernelGGL(wave_ub_kernel, dim3(grid1(n)), dim3(kBlock), 0, st, n, (const int *)plan.ub.p, plan.wave_cap, ubw.p, tot64.p, 0);
             ELAG_LAUNCH_CHECK();
             fetch_ints(reinterpret_cast<const int *>(tot64.p), 2, reinterpret_cast<int *>(&total_ub));
             if (total_ub < (1ull << 31)) {
                 exclusive_scan(ubw, UBI, n);
                 const ClassBounds cb{{0, 16, 32, 64, 128, kWaveCap}};
-                ELAG_HIP_CHECK(hipMemsetAsync(plan.ccount, 0, sizeof(int) * kNumClasses, st));
+                zero_async(plan.ccount, sizeof(int) * kNumClasses);
                 hipLaunchKernelGGL(esc_classify_kernel, dim3(std::min(grid1(n), 1024u)), dim3(kBlock), 0, st, n, ubp, cb, plan.ccount.p, lists.p, 1);
                 ELAG_LAUNCH_CHECK();
                 fetch_ints(plan.ccount.p, kNumClasses, hc);
@@ -2019,7 +2019,7 @@ void esc_run(EscPlan &plan, const Expander &ex, int ncols, DevCSR &C, bool spmv_
             int *CI = dev_alloc<int>((size_t)n + 1);
             int *hnnz = reinterpret_cast<int *>(ctx().h_scalar + 10);
             Temp<int> longest(2);                    // [0] the longest row, [1] the number of entries
-            ELAG_HIP_CHECK(hipMemsetAsync(longest.p, 0, 2 * sizeof(int), st));
+            zero_async(longest.p, 2 * sizeof(int));
             exclusive_scan(rownnz, CI, n, spmv_plan ? longest.p : nullptr, longest.p + 1);          // (both ride along with the scan: no kernel + drain for them afterwards)
             fetch_ints(longest.p, 2, hnnz);
             const int nnz = hnnz[1];
@@ -2141,8 +2141,8 @@ bool rap_ell(const DevCSR *R, const DevCSR &A, const DevCSR &P, DevCSR *C, DevCS
     ensure_ell(P, W);
     Temp<int> Jap((size_t)std::max<unsigned long long>(total1, 1)), len((size_t)n), ovfA((size_t)n), ovfB((size_t)n), ctl(16);
     Temp<double> aap((size_t)std::max<unsigned long long>(total1, 1));
-    ELAG_HIP_CHECK(hipMemsetAsync(ctl, 0, 16 * sizeof(int), st));
-    ELAG_HIP_CHECK(hipMemsetAsync(len, 0, sizeof(int) * (size_t)n, st));
+    zero_async(ctl, 16 * sizeof(int));
+    zero_async(len, sizeof(int) * (size_t)n);
     const CsrView a{A.I, A.J, A.a};
     // (lanes per row, steps per pass, slots, products per unit and turn as esc_hash_kernel's class table, table size): rows of at most
     // steps x lanes / min(W, R) entries; the order of insertion is esc_hash_kernel's for the same row, so every route gives the same bits
@@ -2155,7 +2155,7 @@ bool rap_ell(const DevCSR *R, const DevCSR &A, const DevCSR &P, DevCSR *C, DevCS
     const unsigned grid1a = stride_grid(((long long)n + 7) / 8, 32, 1ll << 30);
     const int capA = (int)(((long long)grid1a * 4 + kLists - 1) / kLists) * (int)(((long long)n + (long long)grid1a * 32 - 1) / ((long long)grid1a * 32)) * 8;   // waves per list x trips x rows per wave and trip
     Temp<int> listsA((size_t)kLists * (size_t)std::max(capA, 1)), cntA(32 * kLists);
-    ELAG_HIP_CHECK(hipMemsetAsync(cntA, 0, sizeof(int) * 32 * kLists, st));
+    zero_async(cntA, sizeof(int) * 32 * kLists);
     const int *none = nullptr;
     int *nolist = nullptr;
 #define ELAG_ELL_LAUNCH(G, NSP, WW, RR, S, GRID, LIST, NDEV, NHOST, NLISTS, CAP, LO, OVF, OVFC, ONL, OCAP)                                         \
@@ -2200,7 +2200,7 @@ bool rap_ell(const DevCSR *R, const DevCSR &A, const DevCSR &P, DevCSR *C, DevCS
         hipLaunchKernelGGL(matmul_ub8_kernel, dim3(grid1((long long)nr * 8)), dim3(kBlock), 0, st, nr, r, ap, 128, ub2.p, pk.p);
         exclusive_scan64(pk, pks, nr);
         hipLaunchKernelGGL(rap_unpack_kernel, dim3(grid1((long long)nr + 1)), dim3(kBlock), 0, st, nr, (const long long *)pks.p, (const int *)ub2.p, 128, UBI2.p, ovfC.p, ctl.p + 3);
-        ELAG_HIP_CHECK(hipMemsetAsync(rn2, 0, sizeof(int) * (size_t)nr, st));
+        zero_async(rn2, sizeof(int) * (size_t)nr);
         MatmulExpander ex2{r, ap};
         hipLaunchKernelGGL((esc_hashd_kernel<8, 128, 2, 256, MatmulExpander>), dim3(stride_grid(nr, 32, 1ll << 30)), dim3(256), 0, st, ex2, (const int *)ub2.p,
                            (const int *)UBI2.p, rn2.p, Ju.p, au.p, (const int *)nullptr, (const int *)nullptr, nr, (int *)nullptr, (int *)nullptr);
@@ -2235,6 +2235,11 @@ bool rap_ell(const DevCSR *R, const DevCSR &A, const DevCSR &P, DevCSR *C, DevCS
     return true;
 }
 
+__global__ void zero_ints_kernel(long long n, int *__restrict__ p)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0;
+}
+
 // C = R A P by rap_fused_kernel; false (nothing touched) where the route does not apply or a row outgrew it
 bool rap_fused(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, bool spmv_plan)
 {
@@ -2248,10 +2253,12 @@ bool rap_fused(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, boo
     if ((unsigned long long)nr * kStride >= (1ull << 31) || (unsigned long long)nr * kStride * 12ull > kRapEllScratch) return false;
     if (R.max_row_nnz > 64) return false;                               // (known to hold a row of more than 64 children)
     ensure_ell(P, W);
-    Temp<int> rn((size_t)nr), ctl(16), Ju((size_t)nr * kStride);
+    // the rows' counters and the 16 control words behind them in one block, zeroed by ONE kernel launch (two hipMemsetAsync calls cost the host
+    // 8-10 us each before the product kernel could be enqueued: it started 22 us after the second fill had ended)
+    Temp<int> rnctl((size_t)nr + 16), Ju((size_t)nr * kStride);
     Temp<double> au((size_t)nr * kStride);
-    ELAG_HIP_CHECK(hipMemsetAsync(ctl, 0, 16 * sizeof(int), st));
-    ELAG_HIP_CHECK(hipMemsetAsync(rn, 0, sizeof(int) * (size_t)nr, st));
+    struct { int *p; } rn{rnctl.p}, ctl{rnctl.p + nr};
+    hipLaunchKernelGGL(zero_ints_kernel, dim3(std::min(grid1((long long)nr + 16), 2048u)), dim3(kBlock), 0, st, (long long)nr + 16, rnctl.p);
     const CsrView r{R.I, R.J, R.a}, a{A.I, A.J, A.a};
     // a wavefront walks ~8 rows (the pipeline takes four rows to fill), four wavefronts per workgroup
     const unsigned grid = stride_grid(((long long)nr + 7) / 8, 4, 1ll << 30);
@@ -2269,7 +2276,7 @@ bool rap_fused(const DevCSR &R, const DevCSR &A, const DevCSR &P, DevCSR &C, boo
     int *CI = dev_alloc<int>((size_t)nr + 1);
     // the rows' offsets, with nnz(C) -> ctl[5] and the longest row -> ctl[6] by the scan's own kernels (ctl was zeroed above; three scan kernels,
     // a fill, a row-length maximum and a gather kernel before: 35 of the ~125 us between the product kernel and the result)
-    exclusive_scan(rn, CI, nr, spmv_plan ? ctl.p + 6 : nullptr, ctl.p + 5);
+    exclusive_scan(rn.p, CI, nr, spmv_plan ? ctl.p + 6 : nullptr, ctl.p + 5);
     int *h = reinterpret_cast<int *>(ctx().h_scalar + 10);
     fetch_ints(ctl.p, 9, h);
     if (h[2] > 0) { dev_free(CI); return false; }
@@ -2582,7 +2589,7 @@ void csr_transpose(const DevCSR &A, DevCSR &AT)
     hipStream_t st = ctx().stream;
     AT.alloc(A.ncols, A.nrows, A.nnz);
     Temp<int> cnt((size_t)A.ncols);
-    ELAG_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(A.ncols > 0 ? A.ncols : 1), st));
+    zero_async(cnt, sizeof(int) * (size_t)(A.ncols > 0 ? A.ncols : 1));
     if (A.nnz) {
         long long g = (A.nnz + kBlock - 1) / kBlock; if (g > 4096) g = 4096;
         hipLaunchKernelGGL(col_hist_kernel, dim3((unsigned)g), dim3(kBlock), 0, st, (long long)A.nnz, (const int *)A.J, cnt.p);
@@ -2830,7 +2837,7 @@ bool csr_combine_inplace(DevCSR &C, const CsrCombine &op)
     hipStream_t st = ctx().stream;
     C.release_sign();
     Temp<int> missing(1);
-    ELAG_HIP_CHECK(hipMemsetAsync(missing, 0, sizeof(int), st));
+    zero_async(missing, sizeof(int));
     hipLaunchKernelGGL(combine_inplace_kernel, dim3(grid1((long long)C.nrows * 8)), dim3(kBlock), 0, st, C.nrows, (const int *)C.I, (const int *)C.J, C.a, op.c_scale,
                        op.c_row, op.c_col, op.B ? (const int *)op.B->I : nullptr, op.B ? (const int *)op.B->J : nullptr,
                        op.B ? (const double *)op.B->a : nullptr, op.b_scale, op.b_row, op.b_row_divide, op.diag, op.d_scale, missing.p);

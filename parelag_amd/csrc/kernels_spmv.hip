@@ -740,7 +740,7 @@ void build_stream_plan(DevCSR &A)
         return;
     }
     Temp<int> m(1);
-    ELAG_HIP_CHECK(hipMemsetAsync(m, 0, sizeof(int), st));
+    zero_async(m, sizeof(int));
     if (A.nrows) {
         const unsigned g = (unsigned)std::min<long long>(((long long)A.nrows + 255) / 256, 512);
         hipLaunchKernelGGL(max_row_kernel, dim3(g), dim3(256), 0, st, A.nrows, (const int *)A.I, m.p);
@@ -752,7 +752,7 @@ void build_stream_plan(DevCSR &A)
 void longest_row(int nrows, const int *I, int *d_out)
 {
     hipStream_t st = ctx().stream;
-    ELAG_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(int), st));
+    zero_async(d_out, sizeof(int));
     if (nrows) {
         const unsigned g = (unsigned)std::min<long long>(((long long)nrows + 255) / 256, 512);
         hipLaunchKernelGGL(max_row_kernel, dim3(g), dim3(256), 0, st, nrows, I, d_out);
@@ -808,7 +808,7 @@ bool xc_build(const DevCSR &A, int window, bool force, double min_reuse = 2.0)
     // one sorting pass: positions (final) and every window's distinct columns into a slot of its own, then scan the counts and compact
     int *uoff = dev_alloc<int>((size_t)nb + 1);
     unsigned short *lidx = dev_alloc<unsigned short>((size_t)A.nnz + 8);
-    ELAG_HIP_CHECK(hipMemsetAsync(lidx + A.nnz, 0, 8 * sizeof(unsigned short), st));
+    zero_async(lidx + A.nnz, 8 * sizeof(unsigned short));
     int total = 0, mx = 0;
     int *ucols = nullptr;
     {
@@ -893,7 +893,7 @@ void prepare_spmv(const DevCSR &A, bool force)
     // A few launches of each candidate on a scratch vector pair (HIP events on this stream, under kernel names of their own): the plain
     // stream kernel and the x-cache form with three window sizes; the x-cache form is kept only when it is measurably faster.
     Temp<double> tx((size_t)std::max(A.ncols, A.nrows)), ty((size_t)A.nrows);
-    ELAG_HIP_CHECK(hipMemsetAsync(tx, 0, sizeof(double) * (size_t)std::max(A.ncols, A.nrows), st));
+    zero_async(tx, sizeof(double) * (size_t)std::max(A.ncols, A.nrows));
     SpmvArgs p;
     p.x = tx; p.out = ty;
     hipEvent_t e0, e1;
@@ -952,7 +952,7 @@ bool prepare_sign_form(const DevCSR &A)
     hipStream_t st = ctx().stream;
     int *Js = dev_alloc<int>((size_t)A.nnz);
     Temp<int> bad(1);
-    ELAG_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), st));
+    zero_async(bad, sizeof(int));
     const unsigned g = (unsigned)std::min<long long>((A.nnz + kBlock - 1) / kBlock, 4096);
     hipLaunchKernelGGL(sign_pack_kernel, dim3(g), dim3(kBlock), 0, st, (long long)A.nnz, (const int *)A.J, (const double *)A.a, Js, bad.p);
     ELAG_LAUNCH_CHECK();
@@ -1181,8 +1181,8 @@ void resident_build(const std::vector<ResidentOp> &ops, ResidentSeq &seq)
     ELAG_HIP_CHECK(hipMemcpyAsync(seq.d_ops, ops.data(), sizeof(ResidentOp) * ops.size(), hipMemcpyHostToDevice, ctx().stream));
     seq.d_bar = dev_alloc<unsigned>(2);
     seq.d_err = dev_alloc<int>(1);
-    ELAG_HIP_CHECK(hipMemsetAsync(seq.d_bar, 0, 2 * sizeof(unsigned), ctx().stream));
-    ELAG_HIP_CHECK(hipMemsetAsync(seq.d_err, 0, sizeof(int), ctx().stream));
+    zero_async(seq.d_bar, 2 * sizeof(unsigned));
+    zero_async(seq.d_err, sizeof(int));
     ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
     // workgroups: what the widest product can use, at most two per CU (all resident together: 8 waves per CU)
     long long want = 1;
@@ -1780,7 +1780,7 @@ void vec_scatter(int n, const int *idx, const double *src, double *dst, int add)
 }
 void vec_dot(int n, const double *x, const double *y, double *d_result)
 {
-    if (n == 0) { ELAG_HIP_CHECK(hipMemsetAsync(d_result, 0, sizeof(double), ctx().stream)); return; }
+    if (n == 0) { zero_async(d_result, sizeof(double)); return; }
     reduce_launch(n, x, y, 0, d_result);
 }
 
@@ -1953,7 +1953,7 @@ int fix_zero_rows(DevCSR &diag, DevCSR *offd, bool count)
     diag.release_sign();
     if (offd) offd->release_sign();
     Temp<int> cnt(1);
-    ELAG_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int), ctx().stream));
+    zero_async(cnt, sizeof(int));
     const bool ho = offd && offd->nnz > 0;
     hipLaunchKernelGGL(fix_zero_rows_kernel, dim3(row_grid(diag.nrows, 8)), dim3(kBlock), 0, ctx().stream, diag.nrows,
                        diag.I, diag.J, diag.a, ho ? offd->I : nullptr, ho ? offd->a : nullptr, cnt.p);

@@ -76,7 +76,7 @@ bool same_pattern(const DevCSR &A, const DevCSR &B)
     if (A.nrows != B.nrows || A.ncols != B.ncols || A.nnz != B.nnz) return false;
     Temp<int> flag(1);
     hipStream_t st = ctx().stream;
-    ELAG_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), st));
+    zero_async(flag, sizeof(int));
     hipLaunchKernelGGL(pattern_differs_kernel, dim3(256), dim3(256), 0, st, (long long)A.nrows + 1, (const int *)A.I, (const int *)B.I, flag.p);
     if (A.nnz) hipLaunchKernelGGL(pattern_differs_kernel, dim3(1024), dim3(256), 0, st, (long long)A.nnz, (const int *)A.J, (const int *)B.J, flag.p);
     ELAG_LAUNCH_CHECK();

@@ -569,7 +569,7 @@ int elag_hip_parcsr_norm(elag_hip_parcsr_t A, int kind, double *value)
             const int n = A->nrows();
             Temp<double> rs((size_t)n);
             Temp<int> bad(1);
-            ELAG_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), ctx().stream));
+            zero_async(bad, sizeof(int));
             k::l1_norms(A->diag, &A->offd, 1, rs, bad);
             v = k::reduce_max_abs(n, rs);
             comm_allreduce_scalar(&v, 1);
@@ -579,7 +579,7 @@ int elag_hip_parcsr_norm(elag_hip_parcsr_t A, int kind, double *value)
             const int nc = A->ncols();
             Temp<double> cs((size_t)nc);
             Temp<int> bad(1);
-            ELAG_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), ctx().stream));
+            zero_async(bad, sizeof(int));
             k::l1_norms(*A->diagT, nullptr, 1, cs, bad);
             k::values_abs(nc, cs, cs);
             if (A->offd.ncols > 0) {

@@ -29,7 +29,7 @@ void RelaxSmoother::setup()
     const int nn = n();
     Temp<int> bad(1);
     bool check_l1 = false;
-    ELAG_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), ctx().stream));
+    zero_async(bad, sizeof(int));
     if (type == ELAG_HIP_SMOOTHER_L1_JACOBI || type == ELAG_HIP_SMOOTHER_JACOBI || type == ELAG_HIP_SMOOTHER_LUMPED_JACOBI) {
         Temp<double> l1((size_t)nn);
         if (type == ELAG_HIP_SMOOTHER_LUMPED_JACOBI) {

@@ -469,7 +469,7 @@ void SweepSmoother::setup()
     if (type != ELAG_HIP_SMOOTHER_GS) {
         // mfem::HypreSmoother::SetOperator: l1_norms = hypre_ParCSRComputeL1Norms(A, type) for types 1..4 (3: the rows' squared 2-norms)
         Temp<int> bad(1);
-        ELAG_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), st));
+        zero_async(bad, sizeof(int));
         d_l1 = dev_alloc<double>((size_t)std::max(n, 1));
         if (n) {
             const bool ho = M->offd.nnz > 0;
@@ -730,7 +730,7 @@ bool SweepSmoother::apply_dense(const double *F, double *X, int m, bool zero_gue
     const int n = M->nrows();
     if (n == 0 || m == 0) return true;
     hipStream_t st = ctx().stream;
-    if (zero_guess) ELAG_HIP_CHECK(hipMemsetAsync(X, 0, sizeof(double) * (size_t)n * m, st));
+    if (zero_guess) zero_async(X, sizeof(double) * (size_t)n * m);
     const bool ho = M->offd.nnz > 0;
     ELAG_REQUIRE(!ho || As, "internal: apply_dense on an operator with real ghosts");
     Temp<double> snap(ho ? (size_t)n * m : 1);
