@@ -485,6 +485,11 @@ ELAG_HIP_API int elag_hip_krylov_create(elag_hip_krylov_t *out, elag_hip_parcsr_
 ELAG_HIP_API int elag_hip_krylov_mult(elag_hip_krylov_t K, const double *b, double *x, int iterative_mode, int loc);
 /* GetConverged / GetNumIterations / GetFinalNorm of the last Mult */
 ELAG_HIP_API int elag_hip_krylov_get_stats(elag_hip_krylov_t K, int *converged, int *final_iter, double *final_norm);
+/* How the last Mult issued its iterations: "graph" (a CG iteration / a GMRES inner step replays as one hipGraph), "plain" (kernel by
+ * kernel: distributed operators, solvers whose apply is not pure stream work, ELAG_HIP_GMRES_GRAPH=0, use_graph == 0) or
+ * "plain: <why a capture was given up>".  Diagnostic only -- no reference counterpart (mfem::IterativeSolver has no launch mode); the
+ * iterates are the same either way.  The string lives as long as the solver. */
+ELAG_HIP_API const char *elag_hip_krylov_launch_mode(elag_hip_krylov_t K);
 ELAG_HIP_API int elag_hip_krylov_destroy(elag_hip_krylov_t K);
 
 /* --------------------------------------------------------------------------------------------------

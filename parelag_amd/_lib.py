@@ -154,6 +154,7 @@ _SIGNATURES = {
     "elag_hip_krylov_create": [C.POINTER(_p), _p, _i, _p, C.POINTER(KrylovOptions)],
     "elag_hip_krylov_mult": [_p, _p, _p, _i, _i],
     "elag_hip_krylov_get_stats": [_p, _ip, _ip, _dp],
+    "elag_hip_krylov_launch_mode": [_p],
     "elag_hip_krylov_destroy": [_p],
     "elag_hip_batched_rank": [_i, _p, _p, _p, _p, _p, _p, _d, _p],
     # host integer tables of the coarsening (no device)
@@ -182,7 +183,7 @@ _SIGNATURES = {
     "elag_hip_time_hierarchy": [_p, _p, _p, _i, _dp],
     "elag_hip_time_hierarchy_internal": [_p, _i, _dp],
 }
-_RESTYPES = {"elag_hip_last_error": C.c_char_p, "elag_hip_host_set_min_work": C.c_int64}
+_RESTYPES = {"elag_hip_last_error": C.c_char_p, "elag_hip_krylov_launch_mode": C.c_char_p, "elag_hip_host_set_min_work": C.c_int64}
 
 ABI_SYMBOLS = tuple(_SIGNATURES)
 

@@ -200,6 +200,17 @@ BlockSmoother::~BlockSmoother() { dev_free(resid); dev_free(corr); dev_free(tmp)
 
 bool BlockSmoother::same_scaling_as(const elag_hip_smoother_s *o) const { return o == this; }
 
+// a block solver replays inside a graph when every product with its blocks is rank-local and every one of its inverses says it may
+bool BlockSmoother::graph_capturable() const
+{
+    if (!A || is_distributed(*A)) return false;
+    for (ParCSR *blk : B->blk)
+        if (blk && is_distributed(*blk)) return false;
+    for (auto *s : inv)
+        if (!s || !s->graph_capturable()) return false;
+    return true;
+}
+
 void BlockSmoother::setup()
 {
     ELAG_REQUIRE(B->nbr == B->nbc, "block smoothers need a block-square operator");

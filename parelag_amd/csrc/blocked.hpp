@@ -36,6 +36,7 @@ struct BlockSmoother : elag_hip_smoother_s {
     int flips(bool zero_guess) const override { return (dscale && !zero_guess) ? 1 : 0; }
     const double *diag_scaling() const override { return dscale; }
     bool same_scaling_as(const elag_hip_smoother_s *o) const override;
+    bool graph_capturable() const override;
 private:
     void inner(elag_hip_smoother_s *S, const double *rhs, double *out, double *scratch, bool transpose);
     void block_solve(const double *r, double *t, bool transpose);

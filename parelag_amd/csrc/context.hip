@@ -513,8 +513,12 @@ __global__ void fetch_publish_kernel(const int *__restrict__ src, int count, vol
 {
     const int l = threadIdx.x;                       // one wavefront
     if (l < count) host[l] = src[l];
+    // every lane's payload store is made visible system-wide (its own fence), the workgroup barrier orders all of those fences before
+    // lane 0 goes on, and the sequence word is a system-scope release store: the host's acquire of `seq` sees the payload by the memory
+    // model, not by the lanes of one wavefront happening to issue their stores as one instruction
     __threadfence_system();
-    if (l == 0) host[31] = seq;
+    __syncthreads();
+    if (l == 0) __hip_atomic_store(const_cast<int *>(host) + 31, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 }  // namespace
 namespace {

@@ -1406,6 +1406,7 @@ struct HierarchySolver : elag_hip_smoother_s {
         if (scale != 1.0) k::vec_axpby(n(), scale, cur, 0.0, cur, cur);
     }
     int flips(bool) const override { return 0; }
+    bool graph_capturable() const override { return hierarchy_is_local(H); }
 };
 int hierarchy_height(const elag_hip_hierarchy_s *H) { return (H->reordered ? H->A_user : H->lev[0].A)->nrows(); }
 }  // namespace elag

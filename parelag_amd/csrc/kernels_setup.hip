@@ -1144,17 +1144,20 @@ __global__ __launch_bounds__(BLOCK) void ell_hash_kernel(CsrView A, const int *_
 
 // one instruction's same-address LDS f64 atomic adds are applied in ascending lane order (and the lowest lane wins a same-slot compare-and-swap):
 // what ell_hash_kernel's bits rest on, checked on the device the first time it matters
-__global__ void lds_order_probe_kernel(const double *__restrict__ v, double *__restrict__ out, int *__restrict__ winner)
+__global__ void lds_order_probe_kernel(const double *__restrict__ v, const int *__restrict__ slot, double *__restrict__ out, int *__restrict__ winner)
 {
-    __shared__ double acc[16];
-    __shared__ int key[16];
-    const int t = threadIdx.x, g = t >> 2;
-    if (t < 16) { acc[t] = 0.0; key[t] = -1; }
+    // 256 slots: lane t of the one wavefront adds v[t] to slot[t] and bids for it -- the host chooses the collision patterns (groups of four, all
+    // 64 lanes on one slot, random multiplicities, the W-slot interleaving of ell_hash_kernel, slots a whole number of banks apart)
+    __shared__ double acc[256];
+    __shared__ int key[256];
+    const int t = threadIdx.x;
+    for (int q = t; q < 256; q += 64) { acc[q] = 0.0; key[q] = -1; }
     __syncthreads();
-    atomicAdd(&acc[g], v[blockIdx.x * 64 + t]);
-    (void)atomicCAS(&key[g], -1, t);
+    const int sl = slot[blockIdx.x * 64 + t];
+    atomicAdd(&acc[sl], v[blockIdx.x * 64 + t]);
+    (void)atomicCAS(&key[sl], -1, t);
     __syncthreads();
-    if ((t & 3) == 0) { out[blockIdx.x * 16 + g] = acc[g]; winner[blockIdx.x * 16 + g] = key[g]; }
+    for (int q = t; q < 256; q += 64) { out[blockIdx.x * 256 + q] = acc[q]; winner[blockIdx.x * 256 + q] = key[q]; }
 }
 
 // ---- hash path, unit after unit ---------------------------------------------------------------------------------------
@@ -1745,31 +1748,50 @@ bool lds_atomics_lane_ordered()
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
     if (ordered >= 0) return ordered == 1;
-    constexpr int NB = 64;
-    std::vector<double> v((size_t)NB * 64), out((size_t)NB * 16);
-    std::vector<int> win((size_t)NB * 16);
+    // The patterns the product kernels produce, not only the easy one: groups of 4 lanes on 16 slots; all 64 lanes on ONE slot;
+    // 2 ... 33 slots with random multiplicities; lane l on slot l mod W (the W-slot interleaving, W = 2 ... 32: every slot met by 64 / W lanes
+    // that are W apart); colliding slots 32 / 64 words apart (all of them in the same banks); runs of random length.  Values of very
+    // different magnitude, so that any other order of a slot's additions shows in the last bits.
+    constexpr int NB = 384;
+    std::vector<double> v((size_t)NB * 64), out((size_t)NB * 256);
+    std::vector<int> slot((size_t)NB * 64), win((size_t)NB * 256);
     unsigned long long x = 88172645463325252ull;
-    for (auto &d : v) {                                // values of very different magnitude: any other order of the four shows in the last bits
-        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
-        d = std::ldexp((double)(x % 2000001ull) / 1e6 - 1.0, (int)((x >> 32) % 60) - 30);
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (auto &d : v) { const unsigned long long r = rnd(); d = std::ldexp((double)(r % 2000001ull) / 1e6 - 1.0, (int)((r >> 32) % 60) - 30); }
+    for (int b = 0; b < NB; b++) {
+        int *sl = &slot[(size_t)b * 64];
+        const int kind = b % 6;
+        if (kind == 0) for (int t = 0; t < 64; t++) sl[t] = t >> 2;
+        else if (kind == 1) { const int one = (int)(rnd() % 256); for (int t = 0; t < 64; t++) sl[t] = one; }
+        else if (kind == 2) { static const int ks[] = {2, 3, 5, 8, 16, 33}; const int K = ks[(b / 6) % 6]; for (int t = 0; t < 64; t++) sl[t] = (int)(rnd() % (unsigned)K) * 7 % 256; }
+        else if (kind == 3) { const int W = 2 << ((b / 6) % 5); for (int t = 0; t < 64; t++) sl[t] = t % W; }
+        else if (kind == 4) { const int K = 2 + (b / 6) % 7, step = (b / 6) % 2 ? 64 : 32; for (int t = 0; t < 64; t++) sl[t] = ((int)(rnd() % (unsigned)K) * step) % 256; }
+        else { int t = 0, cur = (int)(rnd() % 256); while (t < 64) { int len = 1 + (int)(rnd() % 9); while (len-- && t < 64) sl[t++] = cur; cur = (int)(rnd() % 256); } }
     }
     double *dv = nullptr, *dout = nullptr;
-    int *dw = nullptr;
+    int *dw = nullptr, *ds = nullptr;
     hipStream_t st = ctx().stream;
-    dv = dev_alloc<double>(v.size()); dout = dev_alloc<double>(out.size()); dw = dev_alloc<int>(win.size());
+    dv = dev_alloc<double>(v.size()); dout = dev_alloc<double>(out.size()); dw = dev_alloc<int>(win.size()); ds = dev_alloc<int>(slot.size());
     ELAG_HIP_CHECK(hipMemcpyAsync(dv, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(lds_order_probe_kernel, dim3(NB), dim3(64), 0, st, (const double *)dv, dout, dw);
+    ELAG_HIP_CHECK(hipMemcpyAsync(ds, slot.data(), sizeof(int) * slot.size(), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(lds_order_probe_kernel, dim3(NB), dim3(64), 0, st, (const double *)dv, (const int *)ds, dout, dw);
     ELAG_HIP_CHECK(hipMemcpyAsync(out.data(), dout, sizeof(double) * out.size(), hipMemcpyDeviceToHost, st));
     ELAG_HIP_CHECK(hipMemcpyAsync(win.data(), dw, sizeof(int) * win.size(), hipMemcpyDeviceToHost, st));
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
-    dev_free(dv); dev_free(dout); dev_free(dw);
+    dev_free(dv); dev_free(dout); dev_free(dw); dev_free(ds);
     bool ok = true;
-    for (int b = 0; b < NB && ok; b++)
-        for (int g = 0; g < 16; g++) {
-            double sum = 0.0;
-            for (int l = 0; l < 4; l++) sum += v[(size_t)b * 64 + g * 4 + l];
-            if (memcmp(&sum, &out[(size_t)b * 16 + g], sizeof(double)) != 0 || win[(size_t)b * 16 + g] != g * 4) { ok = false; break; }
+    for (int b = 0; b < NB && ok; b++) {
+        double sum[256];
+        int first[256];
+        for (int q = 0; q < 256; q++) { sum[q] = 0.0; first[q] = -1; }
+        for (int t = 0; t < 64; t++) {                       // ascending lanes: the sequential loop
+            const int q = slot[(size_t)b * 64 + t];
+            sum[q] += v[(size_t)b * 64 + t];
+            if (first[q] < 0) first[q] = t;
         }
+        for (int q = 0; q < 256; q++)
+            if (memcmp(&sum[q], &out[(size_t)b * 256 + q], sizeof(double)) != 0 || win[(size_t)b * 256 + q] != first[q]) { ok = false; break; }
+    }
     ordered = ok ? 1 : 0;
     if (!ok && !getenv("ELAG_HIP_QUIET"))
         fprintf(stderr, "[elag_hip] this device does not apply the LDS atomics of one instruction in lane order: sparse products keep the serialised inserts\n");

@@ -24,6 +24,10 @@ struct elag_hip_smoother_s {
     // roughly how many dependent device steps (~2 us each) one apply() is: a launch for most smoothers, a dependency level for the
     // sweeps -- what the hierarchy prices a sub-cycle with before it builds a dense tail out of n applications of it
     virtual double chain_cost() const { return 2.0; }
+    // true iff apply() does nothing but enqueue kernels on the compute stream -- no read-back of a count or a flag, no allocation, no halo
+    // exchange or collective: the only solvers a Krylov step that replays as a graph may contain.  A whitelist: a solver that does not
+    // say so is issued as plain launches (krylov.hip: capturable()).
+    virtual bool graph_capturable() const { return false; }
     int n() const { return A->nrows(); }
 };
 
@@ -51,6 +55,7 @@ struct RelaxSmoother : elag_hip_smoother_s {
     void apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose) override;
     int flips(bool zero_guess) const override;
     const double *diag_scaling() const override { return (dinv && sweeps == 1) ? dinv : nullptr; }
+    bool graph_capturable() const override { return !is_distributed(*A); }
     bool same_scaling_as(const elag_hip_smoother_s *o) const override
     {
         const RelaxSmoother *r = dynamic_cast<const RelaxSmoother *>(o);
@@ -87,6 +92,7 @@ struct SweepSmoother : elag_hip_smoother_s {
     void sweep_sor(const double *f, double *u);
     void apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose) override;
     int flips(bool) const override { return 0; }
+    bool graph_capturable() const override { return !is_distributed(*A); }   // (all scratch is allocated by setup())
     int longest_chain = 0;                            // steps of the longest per-block chain (virtual ranks with a workgroup per block)
     // the sweeps applied to m right-hand sides at once (X, F: n x m row-major; F == nullptr: the identity, m == n): what the hierarchy builds
     // the dense operator of its smallest levels with -- m columns per dependency level instead of m sweeps.  false: not available (Kaczmarz)
@@ -105,6 +111,7 @@ struct SweepSmoother : elag_hip_smoother_s {
 struct DiagScaleSmoother : elag_hip_smoother_s {
     void apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose) override;
     int flips(bool) const override { return 0; }
+    bool graph_capturable() const override { return true; }
 };
 
 struct HiptmairSmoother : elag_hip_smoother_s {
@@ -122,6 +129,7 @@ struct HiptmairSmoother : elag_hip_smoother_s {
     void apply(const double *f, double *&cur, double *&alt, bool zero_guess, bool transpose) override;
     int flips(bool zero_guess) const override { return primary->flips(zero_guess); }
     double chain_cost() const override { return primary->chain_cost() + aux->chain_cost() + 4.0; }
+    bool graph_capturable() const override { return !is_distributed(*A) && !is_distributed(*D) && primary->graph_capturable() && aux->graph_capturable(); }
 };
 
 }  // namespace elag

@@ -248,6 +248,7 @@ public:
     int GetNumIterations() const { int c, it; double nrm; check(elag_hip_krylov_get_stats(h_, &c, &it, &nrm)); return it; }
     bool GetConverged() const { int c, it; double nrm; check(elag_hip_krylov_get_stats(h_, &c, &it, &nrm)); return c != 0; }
     double GetFinalNorm() const { int c, it; double nrm; check(elag_hip_krylov_get_stats(h_, &c, &it, &nrm)); return nrm; }
+    std::string LaunchMode() const { return elag_hip_krylov_launch_mode(h_); }   // "graph" / "plain" / "plain: <why>" (diagnostic)
 
 private:
     std::shared_ptr<ParallelCSRMatrix> A_;

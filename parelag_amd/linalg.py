@@ -849,6 +849,10 @@ class KrylovSolver(_SolverBase):
     def GetFinalNorm(self):
         return self._stats()[2]
 
+    def launch_mode(self) -> str:
+        """How the last Mult issued its iterations: "graph", "plain" or "plain: <why a capture was given up>" (diagnostic)."""
+        return (self._lib.elag_hip_krylov_launch_mode(self.h) or b"").decode()
+
     def __del__(self):
         try:
             if self.h:

@@ -324,3 +324,47 @@ def test_gmres_two_vector_gram_schmidt_links_are_the_one_vector_chain(la):
     for conv, it, x, fn in out:
         assert conv and it == ref.final_iter and close(x, xr, 1e-9) and np.isclose(fn, ref.final_norm, rtol=1e-6)
     assert close(out[0][2], out[1][2], 1e-10)
+
+
+def test_gmres_two_vector_links_on_a_nearly_dependent_krylov_basis(la):
+    """inside a pair the second coefficient is <w, v_b> - H(a,i) <v_a, v_b>, a difference that cancels when w is nearly parallel to
+    v_a -- in working precision that is classical Gram-Schmidt's error (eps |w|), so the pair chain takes its inner products and the difference
+    in double-double.  An operator that is an involution up to 1e-8 makes exactly that case: A v_1 = A^2 v_0 ~ v_0, so at step 1 the pair
+    (v_0, v_1) sees w = v_0 + O(1e-8).  The pair chain, the one-vector chain (MFEM's loop) and the oracle's mfem::GMRESSolver must agree on the
+    iteration count, reach the same true residual and the same iterate; the solver also says how it issued its steps."""
+    import os
+    rng = np.random.default_rng(5)
+    n = 600
+    perm = np.arange(n).reshape(-1, 2)[:, ::-1].reshape(-1)            # swaps 2k <-> 2k+1: P^2 = I
+    P = sp.csr_matrix((np.ones(n), (np.arange(n), perm)), shape=(n, n))
+    S = sp.random(n, n, density=0.02, random_state=rng)
+    for eps_op, tol in ((1e-8, 1e-12), (1e-5, 1e-12), (1e-2, 1e-10)):
+        A = orc.csr(P + eps_op * S)
+        dA = la.ParallelCSRMatrix.from_scipy(A)
+        b = rng.uniform(-1, 1, n)
+        out = []
+        for env in ({}, {"ELAG_HIP_GMRES_PAIR": "0"}):
+            saved_env = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                K = la.KrylovSolver(dA, None, {"Solver name": "GMRES", "Relative tolerance": tol, "Maximum iterations": 300, "Restart size": 30})
+            finally:
+                for k, v in saved_env.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            x = np.zeros(n)
+            K.Mult(b, x)
+            assert K.launch_mode().startswith(("graph", "plain"))
+            out.append((K.GetConverged(), K.GetNumIterations(), x, K.GetFinalNorm()))
+        xr = np.zeros(n)
+        ref = orc.mfem_gmres(lambda v: A @ v, None, b, xr, rel_tol=tol, max_iter=300, m=30)
+        assert ref.converged and ref.final_iter >= 2
+        bn = np.linalg.norm(b)
+        true_res = [np.linalg.norm(b - A @ o[2]) / bn for o in out] + [np.linalg.norm(b - A @ xr) / bn]
+        for (conv, it, x, fn), tr in zip(out, true_res):
+            assert conv and it == ref.final_iter, (eps_op, it, ref.final_iter)
+            assert tr <= 20 * tol + 1e-13, (eps_op, true_res)
+            assert close(x, xr, 1e-7)
+        assert max(true_res[:2]) <= 10 * true_res[2] + 1e-13, (eps_op, true_res)     # neither chain loses accuracy against MFEM's loop

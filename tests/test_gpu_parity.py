@@ -920,6 +920,40 @@ def test_two_pass_spgemm_fallback_equals_the_single_pass_product():
     assert outs[0] == outs[1]
 
 
+def test_default_arena_and_pool_in_a_fresh_process():
+    """tests/conftest.py gives every test process a 128 MiB first scratch slab (one library context per rank thread); what ships is a 2 GiB
+    slab and a 1 GiB pool.  One process without the test suite's memory settings: build a x3 hierarchy twice (the second build
+    runs out of the pool), a triple product, a cycle against the oracle, and give the memory back."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import numpy as np
+        from oracle import oracle as orc
+        from parelag_amd import linalg as la, meshgen, _lib
+        from tests.helpers import oracle_h1_hierarchy
+        A, Ps, _ = meshgen.h1_problem(3)
+        b = np.full(A.shape[0], 2.0)
+        xs = []
+        for rep in range(2):
+            dA = la.ParallelCSRMatrix.from_scipy(A)
+            dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+            H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi")
+            x = np.empty_like(b); H.Mult(b, x); xs.append(x)
+            del H, dA, dPs
+        assert np.array_equal(xs[0], xs[1])
+        h = oracle_h1_hierarchy(A, Ps)
+        xr = np.empty_like(b)
+        orc.CHierarchy(h["As"], h["Ps"], h["sms"], h["chol"]).apply(b, xr)
+        err = np.max(np.abs(xs[0] - xr)) / np.max(np.abs(xr))
+        assert err < 1e-11, err
+        released = _lib.trim_memory()
+        print("DEFAULT_MEMORY_OK", err, released)
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("ELAG_HIP_ARENA_MB", "ELAG_HIP_POOL_MB", "ELAG_HIP_POOL_SLAB_MB")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0 and "DEFAULT_MEMORY_OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_resident_tail_kernel_gives_the_separate_launches_bits(la, h1_k2, hdiv_k2, capfd):
     """ELAG_HIP_RESIDENT=1: the fused launch-bound levels and the dense tail as ONE kernel with grid-wide barriers between the products
     (off by default: the barrier costs more than a kernel boundary on this GPU).  Same lane arithmetic, so the cycle
