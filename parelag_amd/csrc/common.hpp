@@ -49,11 +49,13 @@ bool debug_sync();
     } while (0)
 
 // Wrap an ABI body: translate exceptions to status codes.
+void check_device_error();   // throws when a kernel has reported a failure through Context::h_dev_err (context.hip)
 template <class F>
 int guarded(F &&f) noexcept
 {
     try {
         f();
+        check_device_error();
         return ELAG_HIP_OK;
     } catch (const Error &e) {
         set_last_error(e.what());
@@ -95,6 +97,8 @@ struct Context {
                                         // memory take the runtime's pin-the-user-buffer path, 2-8 ms the first time a buffer is seen
     int *h_fetch = nullptr;             // pinned, device-visible: the words of fetch_ints, [31] = the sequence number of the last fetch that arrived
     int fetch_seq = 0;
+    int *h_dev_err = nullptr;           // pinned, device-visible (h_fetch + 32): a kernel that has to give up (the bounded spins of the Gauss-Seidel dataflow sweep) stores a
+                                        // code here with a system-scope store; every ABI call checks it on its way out (check_device_error)
     int gs_blocks = 0;                  // elag_hip_set_gs_hybrid_blocks (0: ELAG_HIP_GS_BLOCKS, else 1)
     long long n_exchanges = 0, n_allreduces = 0;   // data-plane rounds issued by this rank (neighbour exchanges with a remote peer, device all-reduces)
 };

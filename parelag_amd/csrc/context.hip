@@ -570,6 +570,18 @@ void fetch_ints(const int *dev, int count, int *out)
     if (h[31] != seq) fail(ELAG_HIP_ERR_HIP, "fetch_ints: the stream drained without the words arriving");
     for (int i = 0; i < count; i++) out[i] = h[i];
 }
+void check_device_error()
+{
+    Context &c = ctx();
+    if (!c.initialised || !c.h_dev_err) return;
+    const int code = *reinterpret_cast<volatile int *>(c.h_dev_err);
+    if (code == 0) return;
+    *reinterpret_cast<volatile int *>(c.h_dev_err) = 0;
+    if (code == 1)
+        fail(ELAG_HIP_ERR_STATE, "a Gauss-Seidel dataflow sweep gave up waiting for a row it depends on (its workgroups were not all resident, or another such "
+                                 "kernel held the device): results since the last successful call are not valid; ELAG_HIP_SWEEP_DATAFLOW=0 keeps the launch-per-level sweeps");
+    fail(ELAG_HIP_ERR_STATE, "a kernel reported failure code %d", code);
+}
 void stream_wait(hipStream_t st) { poll_then_block([&] { return hipStreamQuery(st); }, [&] { return hipStreamSynchronize(st); }); }
 void event_wait(hipEvent_t ev) { poll_then_block([&] { return hipEventQuery(ev); }, [&] { return hipEventSynchronize(ev); }); }
 }  // namespace elag
@@ -618,8 +630,9 @@ int elag_hip_init(int device)
         ELAG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&c.d_scalar), 16 * sizeof(double)));
         ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c.h_scalar), 16 * sizeof(double), hipHostMallocDefault));
         ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c.h_stage), kHostStage, hipHostMallocDefault));
-        ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c.h_fetch), 32 * sizeof(int), hipHostMallocCoherent));
-        for (int i = 0; i < 32; i++) c.h_fetch[i] = 0;
+        ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c.h_fetch), 64 * sizeof(int), hipHostMallocCoherent));
+        for (int i = 0; i < 64; i++) c.h_fetch[i] = 0;
+        c.h_dev_err = c.h_fetch + 32;
         c.fetch_seq = 0;
         c.device = device;
         c.initialised = true;
@@ -683,7 +696,7 @@ int elag_hip_finalize(void)
         if (c.h_stage) (void)hipHostFree(c.h_stage);
         c.h_stage = nullptr;
         if (c.h_fetch) (void)hipHostFree(c.h_fetch);
-        c.h_fetch = nullptr;
+        c.h_fetch = nullptr; c.h_dev_err = nullptr;
         (void)hipEventDestroy(c.ev_pack);
         (void)hipEventDestroy(c.ev_halo);
         (void)hipStreamDestroy(c.stream);

@@ -14,9 +14,9 @@
 // predicated on its `done` flag.  The host enqueues iterations blindly (CG: one captured hipGraph per iteration) and
 // only polls the flag every `check_every` iterations; once `done` is set the remaining enqueued kernels are no-ops, so
 // the iterate and the iteration count are those of the reference's sequential loop -- operation by operation for CG, BiCGSTAB, MINRES,
-// the stationary iteration and the one-vector Gram-Schmidt chain of GMRES / FGMRES (ELAG_HIP_GMRES_PAIR=0, and every distributed
-// operator); the default two-vector chain of a rank-local GMRES computes modified Gram-Schmidt's coefficients in another order of
-// evaluation with double-double inner products (see gmres_orth_pair_kernel): same iteration, rounding-level differences in H.
+// the stationary iteration and GMRES / FGMRES with their one-vector modified Gram-Schmidt chain (the default; the only chain of a distributed
+// operator).  ELAG_HIP_GMRES_PAIR=1 switches a rank-local GMRES to a two-vector Gram-Schmidt chain that evaluates MGS's coefficients in
+// another order (see gmres_orth_pair_kernel): faster, the same iteration in exact arithmetic, not MFEM's rounding.
 #include <cmath>
 
 #include <chrono>
@@ -241,61 +241,30 @@ __global__ void __launch_bounds__(kB) gmres_orth_fused_kernel(int n, const KStat
 // An inner step of GMRES(50) on the Darcy system spends 30 % of its time in the chain above: i + 1 links of ~6 us, each one pass over w and two
 // basis vectors.  Two vectors per link: with d_a = <w, v_a>, d_b = <w, v_b>, g = <v_a, v_b> taken in the PREVIOUS link's pass,
 //     H(a,i) = d_a,   H(b,i) = <w - H(a,i) v_a, v_b> = d_b - H(a,i) g,   w <- (w - H(a,i) v_a) - H(b,i) v_b
-// -- modified Gram-Schmidt's coefficients (g is the computed inner product of the two vectors, not assumed zero), evaluated in another
-// order.  Half the links, 6 vector passes per two columns instead of 8.
+// -- modified Gram-Schmidt's coefficients in exact arithmetic (g is the computed inner product of the two vectors, not assumed zero), evaluated
+// in another order.  Half the links, 6 vector passes per two columns instead of 8: cube456 x3 Darcy, GMRES(50), 32 iterations: 9.55 against
+// 10.2 ms.  part_*: three runs of kPart partial sums (d_a, d_b, g).
 //
-// Stability.  d_b is a dot with the vector BEFORE v_a's component left it: evaluated in working precision, d_b - H(a,i) g cancels
-// down from |w| to |w - H(a,i) v_a| and its error is eps |w|, not MGS's eps |w - H(a,i) v_a| -- classical Gram-Schmidt inside the pair, worse the
-// closer w is to v_a.  So the three inner products of a link are accumulated in double-double (an error-free product by fma and a two-sum
-// per term, per-block partial sums kept as (hi, lo), the block sums added the same way) and the difference d_b - H(a,i) g is taken in
-// double-double with the H(a,i) that is actually applied (the rounded one): its error is eps^2 |w| + eps |H(b,i)|, i.e. the coefficient is the
-// correctly rounded MGS one up to eps -- at least as accurate as the one-vector chain's plain dot.  The arithmetic is hidden behind the
-// loads (the links run at ~3.7 TB/s out of the caches).  Differences from MFEM's loop are of rounding size either way;
-// ELAG_HIP_GMRES_PAIR=0 keeps the one-vector chain, which is MFEM's loop operation by operation (and what a distributed operator runs:
-// its dots end in an all-reduce, which has no double-double form).
-// part_*: six runs of kPart partial sums -- d_a, d_b, g (hi), then their low words.
-__device__ inline void dd_add_prod(double &hi, double &lo, double a, double b)       // (hi, lo) += a b
-{
-    const double p = a * b, pe = fma(a, b, -p);
-    const double s = hi + p, bb = s - hi;
-    lo += ((hi - (s - bb)) + (p - bb)) + pe;
-    hi = s;
-}
-__device__ inline void dd_add(double &hi, double &lo, double h2, double l2)          // (hi, lo) += (h2, l2)
-{
-    const double s = hi + h2, bb = s - hi;
-    lo += ((hi - (s - bb)) + (h2 - bb)) + l2;
-    hi = s;
-}
-__device__ inline void dd_block_sum_256(double &hi, double &lo, double *sh)           // same (hi, lo) on every thread; sh: 8 doubles
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const double h2 = __shfl_xor(hi, o, 64), l2 = __shfl_xor(lo, o, 64); dd_add(hi, lo, h2, l2); }
-    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = hi; sh[4 + (threadIdx.x >> 6)] = lo; }
-    __syncthreads();
-    double H = sh[0], L = sh[4];
-    dd_add(H, L, sh[1], sh[5]); dd_add(H, L, sh[2], sh[6]); dd_add(H, L, sh[3], sh[7]);
-    __syncthreads();
-    hi = H + L; lo = L - (hi - H);       // renormalised
-}
-
+// OPT-IN (ELAG_HIP_GMRES_PAIR=1).  d_b is a dot with the vector BEFORE v_a's component left it, so d_b - H(a,i) g cancels down from
+// |w| to |w - H(a,i) v_a| and carries an error of eps |w| where MGS's own dot has eps |w - H(a,i) v_a|: classical Gram-Schmidt inside the pair,
+// worse the closer w is to v_a.  Taking the three inner products and the difference in double-double repairs that (measured in round 5:
+// the coefficient is then MGS's to the last bit or two) but costs more than the halved chain saves -- 10.3 ms, slower than the one-vector
+// chain -- so the default is MFEM's loop operation by operation, on one rank as on many, and this chain is a switch for well-conditioned
+// bases (tests/test_gpu_krylov.py runs both on an operator that is an involution up to 1e-8, where w ~ v_a at step 1).
 __global__ void __launch_bounds__(kB) gmres_dot0_pair_kernel(int n, const KState *__restrict__ st, const double *__restrict__ w,
                                                              const double *__restrict__ va, const double *__restrict__ vb, double *__restrict__ part_out)
 {
-    __shared__ double sh[8];
+    __shared__ double sh[4];
     if (st->fl[F_DONE]) return;
-    double da = 0.0, db = 0.0, g = 0.0, dal = 0.0, dbl = 0.0, gl = 0.0;
+    double da = 0.0, db = 0.0, g = 0.0;
     for (int t = blockIdx.x * kB + threadIdx.x; t < n; t += kPart * kB) {
         const double wt = w[t], a = va[t];
-        dd_add_prod(da, dal, wt, a);
-        if (vb) { const double b = vb[t]; dd_add_prod(db, dbl, wt, b); dd_add_prod(g, gl, a, b); }
+        da += wt * a;
+        if (vb) { const double b = vb[t]; db += wt * b; g += a * b; }
     }
-    dd_block_sum_256(da, dal, sh);
-    if (vb) { dd_block_sum_256(db, dbl, sh); dd_block_sum_256(g, gl, sh); }
-    if (threadIdx.x == 0) {
-        part_out[blockIdx.x] = da; part_out[3 * kPart + blockIdx.x] = dal;
-        if (vb) { part_out[kPart + blockIdx.x] = db; part_out[2 * kPart + blockIdx.x] = g; part_out[4 * kPart + blockIdx.x] = dbl; part_out[5 * kPart + blockIdx.x] = gl; }
-    }
+    da = block_sum_256(da, sh);
+    if (vb) { db = block_sum_256(db, sh); g = block_sum_256(g, sh); }
+    if (threadIdx.x == 0) { part_out[blockIdx.x] = da; if (vb) { part_out[kPart + blockIdx.x] = db; part_out[2 * kPart + blockIdx.x] = g; } }
 }
 
 // columns ka (and ka + 1 when vb != nullptr) of step i; the next link's columns na / nb (nullptr: none; both nullptr: <w, w> for the norm)
@@ -304,7 +273,7 @@ __global__ void __launch_bounds__(kB) gmres_orth_pair_kernel(int n, const KState
                                                              const double *__restrict__ na, const double *__restrict__ nb,
                                                              const double *__restrict__ part_in, double *__restrict__ part_out)
 {
-    __shared__ double sh[8];
+    __shared__ double sh[4];
     constexpr int kPre = 4;
     const int t0 = blockIdx.x * kB + threadIdx.x, stride = kPart * kB;
     double pw[kPre], pa[kPre], pb[kPre], p1[kPre], p2[kPre];
@@ -319,32 +288,23 @@ __global__ void __launch_bounds__(kB) gmres_orth_pair_kernel(int n, const KState
             if (nb) p2[u] = nb[t];
         }
     }
-    double sa = 0.0, sb = 0.0, sg = 0.0, sal = 0.0, sbl = 0.0, sgl = 0.0;
+    double sa = 0.0, sb = 0.0, sg = 0.0;
     for (int q = threadIdx.x; q < kPart; q += kB) {
-        dd_add(sa, sal, part_in[q], part_in[3 * kPart + q]);
-        if (vb) { dd_add(sb, sbl, part_in[kPart + q], part_in[4 * kPart + q]); dd_add(sg, sgl, part_in[2 * kPart + q], part_in[5 * kPart + q]); }
+        sa += part_in[q];
+        if (vb) { sb += part_in[kPart + q]; sg += part_in[2 * kPart + q]; }
     }
     if (st->fl[F_DONE]) return;
-    dd_block_sum_256(sa, sal, sh);
-    const double ha = sa;                                       // H(a,i), rounded once: the coefficient that is applied
+    const double ha = block_sum_256(sa, sh);
     double hb = 0.0;
-    if (vb) {
-        dd_block_sum_256(sb, sbl, sh);
-        dd_block_sum_256(sg, sgl, sh);
-        // d_b - ha g in double-double: (sb, sbl) - ha (sg, sgl)
-        const double p = ha * sg, pe = fma(ha, sg, -p) + ha * sgl;
-        const double d = sb - p, bb = d - sb;
-        const double de = ((sb - (d - bb)) + (-p - bb)) + (sbl - pe);
-        hb = d + de;
-    }
+    if (vb) { const double db = block_sum_256(sb, sh), g = block_sum_256(sg, sh); hb = db - ha * g; }
     if (blockIdx.x == 0 && threadIdx.x == 0) { Hm(hs, m, ka, i) = ha; if (vb) Hm(hs, m, ka + 1, i) = hb; }
-    double d1 = 0.0, d2 = 0.0, gg = 0.0, d1l = 0.0, d2l = 0.0, ggl = 0.0;
+    double d1 = 0.0, d2 = 0.0, gg = 0.0;
     auto one = [&](double wt, double a, double b, double x1, double x2, int t) {
         double wn = wt + (-ha) * a;
         if (vb) wn = wn + (-hb) * b;
         w[t] = wn;
-        if (na) { dd_add_prod(d1, d1l, wn, x1); if (nb) { dd_add_prod(d2, d2l, wn, x2); dd_add_prod(gg, ggl, x1, x2); } }
-        else d1 += wn * wn;                                     // (the norm: a sum of squares, nothing cancels)
+        if (na) { d1 += wn * x1; if (nb) { d2 += wn * x2; gg += x1 * x2; } }
+        else d1 += wn * wn;
     };
 #pragma unroll
     for (int u = 0; u < kPre; u++) {
@@ -352,16 +312,9 @@ __global__ void __launch_bounds__(kB) gmres_orth_pair_kernel(int n, const KState
         if (t < n) one(pw[u], pa[u], pb[u], p1[u], p2[u], t);
     }
     for (int t = t0 + kPre * stride; t < n; t += stride) one(w[t], va[t], vb ? vb[t] : 0.0, na ? na[t] : 0.0, nb ? nb[t] : 0.0, t);
-    if (na) {
-        dd_block_sum_256(d1, d1l, sh);
-        if (nb) { dd_block_sum_256(d2, d2l, sh); dd_block_sum_256(gg, ggl, sh); }
-    } else {
-        d1 = block_sum_256(d1, sh);
-    }
-    if (threadIdx.x == 0) {
-        part_out[blockIdx.x] = d1; part_out[3 * kPart + blockIdx.x] = d1l;
-        if (nb) { part_out[kPart + blockIdx.x] = d2; part_out[2 * kPart + blockIdx.x] = gg; part_out[4 * kPart + blockIdx.x] = d2l; part_out[5 * kPart + blockIdx.x] = ggl; }
-    }
+    d1 = block_sum_256(d1, sh);
+    if (nb) { d2 = block_sum_256(d2, sh); gg = block_sum_256(gg, sh); }
+    if (threadIdx.x == 0) { part_out[blockIdx.x] = d1; if (nb) { part_out[kPart + blockIdx.x] = d2; part_out[2 * kPart + blockIdx.x] = gg; } }
 }
 
 // H(i+1,i) = sqrt(sum(part_in))
@@ -701,7 +654,7 @@ struct elag_hip_krylov_s {
     bool gm_graph_ok = true, gm_flex = false;
     std::string launch_mode = "plain";          // what elag_hip_krylov_launch_mode reports (set by the last Mult)
     std::string gm_graph_note;                    // why the step graphs are off for this solver (empty: they are on, or were never asked for)
-    bool gm_pairs = !(std::getenv("ELAG_HIP_GMRES_PAIR") && !atoi(std::getenv("ELAG_HIP_GMRES_PAIR")));   // (read when the solver is made: a test compares the two chains)
+    bool gm_pairs = std::getenv("ELAG_HIP_GMRES_PAIR") && atoi(std::getenv("ELAG_HIP_GMRES_PAIR"));   // opt-in (read when the solver is made: a test compares the two chains)
     // results of the last Mult
     int converged = 0, final_iter = 0;
     double final_norm = 0.0;
@@ -748,7 +701,7 @@ struct elag_hip_krylov_s {
             V = dev_alloc<double>((m + 1) * nn);
             if (solver == ELAG_HIP_KRYLOV_FGMRES) Z = dev_alloc<double>(m * nn);
             hs = dev_alloc<double>(m * (m + 1) + 4 * (m + 1));
-            part = dev_alloc<double>(12 * (size_t)kPart);         // (two buffers of six runs: the two-vector Gram-Schmidt links' (hi, lo) partial sums)
+            part = dev_alloc<double>(6 * (size_t)kPart);          // (two buffers of three runs: the two-vector Gram-Schmidt links)
         }
     }
 
@@ -960,7 +913,7 @@ struct elag_hip_krylov_s {
                 // fused modified Gram-Schmidt: see gmres_orth_fused_kernel
                 if (gm_pairs && i >= 1) {
                     // two basis vectors per link (gmres_orth_pair_kernel): columns (0, 1), (2, 3), ..., a last single one when i is even
-                    double *pin = part, *pout = part + 6 * kPart;
+                    double *pin = part, *pout = part + 3 * kPart;
                     hipLaunchKernelGGL(gmres_dot0_pair_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, (const double *)target, (const double *)Vq(0),
                                        (const double *)Vq(1), pin);
                     for (int k = 0; k <= i; k += 2) {

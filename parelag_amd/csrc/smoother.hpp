@@ -76,6 +76,19 @@ struct SweepSmoother : elag_hip_smoother_s {
     std::vector<Segment> segments;
     ~SweepSmoother() override;
     void setup();
+    // The dataflow sweep (sweep.hip, sweep_dataflow_kernel): ONE launch per symmetric sweep in which every row waits for the rows it depends on
+    // and for nothing else -- no launch and no barrier per dependency level.  df_slots: (row | -1, first entry in df_J / df_a, 16-entry chunks, 0)
+    // per schedule position, the levels padded to whole wave tiles of 4; df_J: column | flags per entry (rows padded to 16); df_gran: two arrays
+    // of 2 n tagged 8-byte words (the row's value as two {epoch, half} granules), used in turn; df_state: done counter, array in use, abort word.
+    bool dataflow = false;
+    int *d_df_slots = nullptr;
+    unsigned *d_df_J = nullptr;
+    double *d_df_a = nullptr;
+    unsigned long long *d_df_gran = nullptr;
+    int *d_df_state = nullptr;
+    int df_npos = 0, df_grid = 0;
+    void setup_dataflow(const std::vector<int> &I, const std::vector<int> &J, const std::vector<int> &level, const std::vector<int> &ptr, const std::vector<int> &rows);
+    void launch_dataflow(const double *f, double *u);
     bool lds_u = false;                               // the operator's u fits the chain workgroup's LDS: every level is chained (sweep.hip)
     // "virtual ranks" (elag_hip_set_gs_hybrid_blocks > 1, rank-local operators): the rows are cut into that many contiguous blocks and the
     // sweep is hypre's hybrid Gauss-Seidel as the reference runs it on that many MPI ranks -- Gauss-Seidel inside a block, the other
@@ -99,7 +112,12 @@ struct SweepSmoother : elag_hip_smoother_s {
     bool apply_dense(const double *F, double *X, int m, bool zero_guess);
     std::vector<int> h_lev_ptr;                       // rows by dependency level (whatever the launch plan does with them): offsets ...
     int *d_lev_rows = nullptr;                        // ... into this list
-    double chain_cost() const override { return 2.0 * sweeps * (double)(sor ? num_levels : longest_chain > 0 ? longest_chain : n_steps) + 2.0; }
+    // (the dataflow sweep: a dependency level is one hand-off between workgroups, ~1 us against the ~2-3 us of a launch or a chain step)
+    double chain_cost() const override
+    {
+        if (dataflow) return 2.0 * sweeps * 0.45 * (double)num_levels + 4.0;
+        return 2.0 * sweeps * (double)(sor ? num_levels : longest_chain > 0 ? longest_chain : n_steps) + 2.0;
+    }
     bool same_scaling_as(const elag_hip_smoother_s *o) const override
     {
         const SweepSmoother *r = dynamic_cast<const SweepSmoother *>(o);

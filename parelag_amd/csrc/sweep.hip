@@ -19,6 +19,7 @@
 // slot per row (row, first entry, length), kLPR lanes fetching a row's entries and their u values together, kUnroll rows in
 // flight per lane group; only the subtraction itself is sequential, done from shuffled products in storage order.
 #include <algorithm>
+#include <atomic>
 #include <numeric>
 
 #include "comm.hpp"
@@ -395,6 +396,288 @@ __global__ void sweep_sor_level_kernel(int r0, int r1, int dir, const int *__res
     }
 }
 
+// ---- the dataflow sweep -------------------------------------------------------------------------------------------------------------------
+// A launch per dependency level costs ~3 us and a level of the cube456 x3 operator is ~500 independent rows: 89 levels x 4 half-sweeps are
+// 1.0 of the 1.08 ms of the reference's shipped cycle, nearly all of it launch boundaries.  Here ONE launch runs a whole symmetric sweep
+// (forward, then backward) and a row waits for exactly the rows it reads -- the hand-off between workgroups that
+// MI355X_MICROARCH.md prices at 0.8-1.0 us (its "handoff-1to1" row) instead of a kernel boundary plus the first round trips of the next kernel.
+//
+// * Work: the schedule (rows by dependency level) cut into TILES of 4 rows that never straddle a level (levels are padded); tile T of a
+//   half-sweep belongs to wavefront T mod W (W = all wavefronts of the grid), 16 lanes per row as in the level kernels, the subtraction in
+//   storage order by the same ordered_chunk: the sequential loop's bits.  The backward half walks the tiles in reverse.
+// * Hand-off (cdna_hip_programming.md, Guideline 16, form R2: the data is the flag): a row's value is published as two 8-byte granules
+//   {epoch, low half} {epoch, high half}, each ONE agent-scope (sc1, write-through) store; a reader polls the two words with agent-scope
+//   loads until both carry the epoch it needs -- epoch 1 = after the forward half, 2 = after the backward half; a neighbour that comes LATER in
+//   the half-sweep is read at the previous epoch (its value after the previous half; in the forward half the plain input vector).  Nothing
+//   else is shared: no flag, no fence, no counter on the critical path.  Two granule arrays take turns: the kernel zeroes the one it does
+//   NOT use (epochs restart at 1 in every launch, so the launch works unchanged under graph replay), the last workgroup out flips
+//   the selector (a word in device memory).
+// * No deadlock by construction: order the tasks (half-sweep, tile); a task waits only for smaller tasks (earlier tiles of its half, any tile
+//   of the half before), every wavefront takes its own tasks in increasing order, and every workgroup of the grid is resident (at most one
+//   256-thread workgroup per CU) -- so the smallest unfinished task can always run.  Results do not depend on placement or dispatch order.
+//   Even so every wait is bounded (ELAG_HIP_SWEEP_DATAFLOW_MS of the 100 MHz clock, default 250): a wavefront that runs out sets the abort
+//   word, every poller sees it and leaves, the code lands in pinned host memory and the next ABI call fails (check_device_error) -- another
+//   kernel of this kind holding the device, say.  In-place safe: a row's input value is read only by its neighbours' forward tasks, all done
+//   before the row's backward task can start.
+typedef unsigned long long u64t;
+struct DfArgs {
+    const int4s *slots;
+    const unsigned *J;
+    const double *a;
+    const int *oI, *oJ;
+    const double *oa, *ug;
+    const double *f, *d;
+    double omega;
+    double *u;
+    u64t *gran;            // [2][2 n]
+    int *state;            // [0] workgroups done, [1] array in use, [2] abort
+    int *host_err;
+    int n, npos;
+    long long ticks;
+    int stall_row;         // -1; a test sets the row whose value is never handed on (ELAG_HIP_SWEEP_DATAFLOW_STALL_ROW): its readers run out of time
+};
+// kDfWait: an entry that is only waited for (value 0, contributes +0.0): row j gets one for every row i that reads u_j without being read by
+// row j (a_ij != 0, a_ji == 0) -- in the level launches the anti-dependency is kept by the levels alone, here row j has to see that row i is done
+constexpr unsigned kDfLower = 1u << 30, kDfSelf = 1u << 29, kDfWait = 1u << 28, kDfNone = 1u << 31, kDfCol = (1u << 28) - 1;
+
+// One chunk of a row in the dataflow kernel.  Type 6 leaves the row's first stored diagonal entry out of the sum and divides by it: instead of
+// the level kernels' per-step test (three broadcasts and a select per entry: 0.6 us per dependency level here) the lane that holds that entry is
+// found once per chunk, hands its value to the row and contributes +0.0 -- subtracting +0.0 leaves every double as it is, so the sum is the same.
+template <int MODE>
+__device__ __forceinline__ void df_chunk(int row, bool real, int j, double v, double x, double &res, double &aii, bool &have)
+{
+    if (MODE == 1) {
+        const int sh = (int)(threadIdx.x & 48u);
+        const unsigned m = (unsigned)((__ballot(real && j == row) >> sh) & 0xffffull);
+        if (m != 0u && !have) {
+            const int first = __ffs((int)m) - 1;
+            aii = __shfl(v, first, kLPR);
+            have = true;
+            if ((int)(threadIdx.x & (kLPR - 1)) == first) { v = 0.0; x = 0.0; }
+        }
+    }
+    if (!real) { v = 0.0; x = 0.0; }
+    double a0 = 0.0;
+    bool h0 = false;
+    ordered_chunk<0>(row, real ? j : -1, v, x, res, a0, h0);
+}
+
+constexpr int kDfC = 2;            // chunks of 16 entries a row keeps in registers (32 entries: longer rows fetch the rest when their turn comes)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void sweep_dataflow_kernel(const DfArgs A)
+{
+    const int tid = (int)(blockIdx.x * 256 + threadIdx.x), nthreads = (int)gridDim.x * 256;
+    const int wave = tid >> 6, nwaves = nthreads >> 6;
+    const int grp = (threadIdx.x & 63) >> 4, lane = threadIdx.x & (kLPR - 1);
+    const int cur = A.state[1] & 1;
+    u64t *g = A.gran + (size_t)cur * 2 * A.n;
+    {   // the other array, for the next launch
+        u64t *gz = A.gran + (size_t)(cur ^ 1) * 2 * A.n;
+        for (size_t i = (size_t)tid; i < (size_t)2 * A.n; i += (size_t)nthreads) gz[i] = 0ull;
+    }
+    const long long t0 = (long long)wall_clock64();
+    const int ntiles = A.npos >> 2;
+    const int cnt = wave < ntiles ? (ntiles - wave + nwaves - 1) / nwaves : 0;       // this wavefront's tiles per half-sweep
+    bool dead = false;
+    // one poll of row j's two words; true once both carry `need`
+    auto poll = [&](int j, unsigned need, double &x) -> bool {
+        const u64t w0 = __hip_atomic_load(g + 2 * (size_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64t w1 = __hip_atomic_load(g + 2 * (size_t)j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(w0 >> 32) != need || (unsigned)(w1 >> 32) != need) return false;
+        x = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
+        return true;
+    };
+    // the wavefront leaves a wait together; false: it (or somebody else) has run out of time
+    auto give_up = [&](unsigned &spins) -> bool {
+        if ((++spins & 63u) != 0) { __builtin_amdgcn_s_sleep(1); return false; }
+        const bool late = (long long)wall_clock64() - t0 > A.ticks;
+        const bool stop = __hip_atomic_load(A.state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (!__any(late || stop)) return false;
+        if (__any(late) && (threadIdx.x & 63) == 0) {
+            __hip_atomic_store(A.state + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.host_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return true;
+    };
+    // What a task needs that no other row writes -- its slot, then its first kDfC chunks of entries and its f, d -- is requested two and
+    // one tasks ahead: the only memory round trips left on a task's own path are the polls.
+    auto tile_of = [&](int q) { const int half = q / cnt, T = wave + (q - half * cnt) * nwaves; return half == 0 ? T : ntiles - 1 - T; };
+    auto load_slot = [&](int q) -> int4s { return q < 2 * cnt ? A.slots[(size_t)tile_of(q) * 4 + grp] : int4s{-1, 0, 0, 0}; };
+    auto load_entries = [&](const int4s &sl, unsigned (&w)[kDfC], double (&v)[kDfC], double &fr, double &dr) {
+#pragma unroll
+        for (int c = 0; c < kDfC; c++) {
+            w[c] = kDfNone; v[c] = 0.0;
+            if (c < sl.z) { w[c] = A.J[(size_t)sl.y + c * kLPR + lane]; v[c] = A.a[(size_t)sl.y + c * kLPR + lane]; }
+        }
+        fr = 0.0; dr = 0.0;
+        if (sl.x >= 0) { fr = A.f[sl.x]; if (MODE == 0) dr = A.d[sl.x]; }
+    };
+    int4s slA = load_slot(0), slB = load_slot(1), slC = int4s{-1, 0, 0, 0};
+    unsigned wA[kDfC], wB[kDfC];
+    double vA[kDfC], vB[kDfC], fA, dA, fB = 0.0, dB = 0.0;
+    load_entries(slA, wA, vA, fA, dA);
+#pragma unroll
+    for (int c = 0; c < kDfC; c++) { wB[c] = kDfNone; vB[c] = 0.0; }
+    for (int q = 0; q < 2 * cnt && !dead; q++) {
+        const int half = q / cnt;
+        const unsigned e_new = (unsigned)half + 1u;
+        load_entries(slB, wB, vB, fB, dB);
+        slC = load_slot(q + 2);
+        const int row = slA.x, off = slA.y, nch = slA.z;
+        double res = fA, uo = 0.0, aii = 0.0;
+        bool have = false;
+        // ---- decode; values nobody writes in this launch (the input vector) are plain loads
+        int j[kDfC];
+        unsigned need[kDfC];
+        double x[kDfC];
+        bool ok[kDfC];
+#pragma unroll
+        for (int c = 0; c < kDfC; c++) {
+            const unsigned w = wA[c];
+            const bool valid = !(w & kDfNone);
+            j[c] = (int)(w & kDfCol);
+            const bool earlier = valid && !(w & kDfSelf) && (half == 0 ? (w & kDfLower) != 0 : (w & kDfLower) == 0);
+            need[c] = earlier ? e_new : e_new - 1u;
+            x[c] = 0.0;
+            ok[c] = !valid || need[c] == 0u;
+            if (valid && need[c] == 0u && !(w & kDfWait)) x[c] = A.u[j[c]];
+        }
+        const bool self_lane = lane == 0 && row >= 0;           // the row's own value before this half
+        bool ok_s = !(self_lane && e_new != 1u);
+        if (self_lane && e_new == 1u) uo = A.u[row];
+        // ---- the wait
+        {
+            unsigned spins = 0;
+            for (;;) {
+#pragma unroll
+                for (int c = 0; c < kDfC; c++)
+                    if (!ok[c]) ok[c] = poll(j[c], need[c], x[c]);
+                if (!ok_s) ok_s = poll(row, e_new - 1u, uo);
+                bool all = ok_s;
+#pragma unroll
+                for (int c = 0; c < kDfC; c++) all = all && ok[c];
+                if (__all(all)) break;
+                if (give_up(spins)) { dead = true; break; }
+            }
+            if (dead) break;
+        }
+#pragma unroll
+        for (int c = 0; c < kDfC; c++)
+            if (c < nch) {
+                df_chunk<MODE>(row, !(wA[c] & (kDfNone | kDfWait)), j[c], vA[c], x[c], res, aii, have);
+            }
+        // ---- rows of more than kDfC chunks: the rest, chunk by chunk (the wavefront walks its longest row)
+        int maxch = nch;
+        maxch = max(maxch, __shfl_xor(maxch, 16, 64));
+        maxch = max(maxch, __shfl_xor(maxch, 32, 64));
+        for (int c = kDfC; c < maxch && !dead; c++) {
+            unsigned w = kDfNone;
+            double v = 0.0, xx = 0.0;
+            if (c < nch) { w = A.J[(size_t)off + c * kLPR + lane]; v = A.a[(size_t)off + c * kLPR + lane]; }
+            const bool valid = !(w & kDfNone);
+            const int jj = (int)(w & kDfCol);
+            const bool earlier = valid && !(w & kDfSelf) && (half == 0 ? (w & kDfLower) != 0 : (w & kDfLower) == 0);
+            const unsigned nd = earlier ? e_new : e_new - 1u;
+            bool okx = !valid || nd == 0u;
+            if (valid && nd == 0u && !(w & kDfWait)) xx = A.u[jj];
+            unsigned spins = 0;
+            for (;;) {
+                if (!okx) okx = poll(jj, nd, xx);
+                if (__all(okx)) break;
+                if (give_up(spins)) { dead = true; break; }
+            }
+            if (dead) break;
+            if (c < nch) df_chunk<MODE>(row, valid && !(w & kDfWait), jj, v, xx, res, aii, have);
+        }
+        if (dead) break;
+        if (row >= 0 && A.oI) {
+            const int os = A.oI[row], ol = A.oI[row + 1] - os;
+            for (int k0 = 0; k0 < ol; k0 += kLPR) {
+                const bool has = k0 + lane < ol;
+                const double v = has ? A.oa[os + k0 + lane] : 0.0;
+                const double xg = has ? A.ug[A.oJ[os + k0 + lane]] : 0.0;
+                ordered_plain(v * xg, res);
+            }
+        }
+        if (row >= 0 && lane == 0 && row != A.stall_row) {
+            double un = uo;
+            if (MODE == 0) { if (dA != 0.0) un = uo + A.omega * res / dA; }
+            else if (have && aii != 0.0) un = res / aii;
+            const u64t tag = (u64t)e_new << 32;
+            __hip_atomic_store(g + 2 * (size_t)row, tag | (unsigned)__double2loint(un), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 2 * (size_t)row + 1, tag | (unsigned)__double2hiint(un), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (half == 1) A.u[row] = un;
+        }
+        // ---- rotate the pipeline
+        slA = slB; slB = slC; fA = fB; dA = dB;
+#pragma unroll
+        for (int c = 0; c < kDfC; c++) { wA[c] = wB[c]; vA[c] = vB[c]; }
+    }
+    // the last workgroup out hands the arrays over for the next launch (nobody reads state[1] any more: everybody has started)
+    __syncthreads();
+    if (threadIdx.x == 0 && !dead) {
+        const int before = __hip_atomic_fetch_add(A.state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == (int)gridDim.x - 1) {
+            __hip_atomic_store(A.state, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.state + 1, cur ^ 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// The dataflow arrays of a structurally symmetric operator, on the device: a lane group per schedule position writes its row's entries (column |
+// flags from the two rows' levels, value) chunk by chunk; every entry (i, j) also looks for (j, i) -- a row that is read without reading back
+// needs a wait-only entry, which only the host path below builds (*nanti > 0: it takes over).
+__global__ __launch_bounds__(256) void df_build_kernel(int npos, const int4s *__restrict__ slots, const int *__restrict__ I, const int *__restrict__ J,
+                                                       const double *__restrict__ a, const int *__restrict__ level, unsigned *__restrict__ dj,
+                                                       double *__restrict__ da, int *__restrict__ nanti)
+{
+    const int pos = (int)((blockIdx.x * 256 + threadIdx.x) / kLPR), lane = threadIdx.x & (kLPR - 1);
+    if (pos >= npos) return;
+    const int4s sl = slots[pos];
+    const int i = sl.x;
+    if (i < 0) return;
+    const int s0 = I[i], len = I[i + 1] - s0, li = level[i];
+    for (int q = lane; q < sl.z * kLPR; q += kLPR) {
+        unsigned w = kDfNone;
+        double v = 0.0;
+        if (q < len) {
+            const int j = J[s0 + q];
+            v = a[s0 + q];
+            w = (unsigned)j;
+            if (j == i) w |= kDfSelf;
+            else {
+                const int lj = level[j];
+                if (lj < li) w |= kDfLower;
+                bool back = false;
+                for (int k = I[j]; k < I[j + 1] && !back; k++) back = J[k] == i;
+                if (!back || lj == li) atomicAdd(nanti, 1);
+            }
+        }
+        dj[(size_t)sl.y + q] = w;
+        da[(size_t)sl.y + q] = v;
+    }
+}
+
+__global__ void df_gather_values_kernel(long long m, const int *__restrict__ src, const double *__restrict__ a, double *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) out[i] = src[i] >= 0 ? a[src[i]] : 0.0;
+}
+// test vectors of the self-check (any reproducible values of mixed sign and magnitude)
+__global__ void df_fill_kernel(int n, unsigned salt, double *__restrict__ out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        unsigned h = ((unsigned)i + salt) * 2654435761u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        out[i] = ((double)(h & 0xfffffu) / 524288.0 - 1.0) * (1.0 + (double)((h >> 20) & 7u));
+    }
+}
+__global__ void df_count_diff_kernel(int n, const double *__restrict__ x, const double *__restrict__ y, int *__restrict__ ndiff)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (__double_as_longlong(x[i]) != __double_as_longlong(y[i])) atomicAdd(ndiff, 1);
+}
+
 int gs_hybrid_blocks()
 {
     // elag_hip_set_gs_hybrid_blocks, else ELAG_HIP_GS_BLOCKS, else 1 (one rank: the sequential loop)
@@ -405,7 +688,8 @@ int gs_hybrid_blocks()
 
 }  // namespace
 
-SweepSmoother::~SweepSmoother() { dev_free(d_rows); dev_free(d_lev_ptr); dev_free(d_l1); dev_free(d_sJ); dev_free(d_sa); dev_free(d_self_ghost); dev_free(d_blk_first); dev_free(d_blk_count); dev_free(d_lev_rows); dev_free(d_v); }
+SweepSmoother::~SweepSmoother() { dev_free(d_rows); dev_free(d_lev_ptr); dev_free(d_l1); dev_free(d_sJ); dev_free(d_sa); dev_free(d_self_ghost); dev_free(d_blk_first); dev_free(d_blk_count); dev_free(d_lev_rows); dev_free(d_v);
+    dev_free(d_df_slots); dev_free(d_df_J); dev_free(d_df_a); dev_free(d_df_gran); dev_free(d_df_state); }
 
 void SweepSmoother::setup()
 {
@@ -642,9 +926,191 @@ void SweepSmoother::setup()
     step_ptr.insert(step_ptr.end(), step_first.begin(), step_first.end());       // [offsets (n_steps + 1) | first-of-level flags (n_steps + 1)]
     d_lev_ptr = dev_from_host(step_ptr.data(), step_ptr.size());
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
+    dataflow = false;
+    if (!kaczmarz && !sor && blocks == 1 && !block_chains) setup_dataflow(I, J, level, ptr, rows);
     if (getenv("ELAG_HIP_SWEEP_VERBOSE"))
-        fprintf(stderr, "[elag_hip] sweep smoother type %d: n=%d, %d dependency levels = %d steps in %d launches per direction%s\n", type, n, nlev,
-                n_steps, (int)segments.size(), lds_u ? " (u in LDS)" : "");
+        fprintf(stderr, "[elag_hip] sweep smoother type %d: n=%d, %d dependency levels = %d steps in %d launches per direction%s%s\n", type, n, nlev,
+                n_steps, (int)segments.size(), lds_u ? " (u in LDS)" : "", dataflow ? "; dataflow sweep: one launch per symmetric sweep" : "");
+}
+
+namespace {
+// ELAG_HIP_SWEEP_DATAFLOW: 0 = never; unset / 1 = where it pays (below); 2 = wherever it is possible (tests)
+int dataflow_mode()
+{
+    const char *e = getenv("ELAG_HIP_SWEEP_DATAFLOW");       // (read at every setup: tests switch it)
+    return e ? atoi(e) : 1;
+}
+std::atomic<int> g_dataflow_checked{0};    // 0: not yet, 1: this device runs the dataflow sweep bit for bit like the level launches, -1: it does not (off for the process)
+}  // namespace
+
+void SweepSmoother::setup_dataflow(const std::vector<int> &I, const std::vector<int> &J, const std::vector<int> &level, const std::vector<int> &ptr,
+                                   const std::vector<int> &rows)
+{
+    dev_free(d_df_slots); dev_free(d_df_J); dev_free(d_df_a); dev_free(d_df_gran); dev_free(d_df_state);
+    d_df_slots = nullptr; d_df_J = nullptr; d_df_a = nullptr; d_df_gran = nullptr; d_df_state = nullptr;
+    const int mode = dataflow_mode();
+    const int n = M->nrows(), nlev = (int)ptr.size() - 1;
+    Context &c = ctx();
+    // one rank thread per process only (several contexts of one process would run such kernels side by side: each waits for workgroups the
+    // other ones' spinning workgroups keep off the CUs); local square diagonal block; and enough dependency levels for a launch per level to hurt
+    if (mode <= 0 || g_dataflow_checked.load() < 0 || c.comm_kind == 2 || n <= 0 || M->diag.ncols != n || n >= (1 << 28) || !c.h_dev_err) return;
+    if (mode == 1 && (nlev < 4 || n < 256)) return;
+    hipStream_t st = c.stream;
+    // ---- the device path: slots from the row lengths alone, entries and flags by a kernel; taken unless some row is read without reading back ----
+    {
+        long long npos0 = 0, nent0 = 0;
+        for (int l = 0; l < nlev; l++) npos0 += ((long long)(ptr[(size_t)l + 1] - ptr[(size_t)l]) + 3) / 4 * 4;
+        for (int i = 0; i < n; i++) nent0 += (long long)std::max(1, (I[(size_t)i + 1] - I[(size_t)i] + kLPR - 1) / kLPR) * kLPR;
+        if (npos0 >= (1ll << 30) || nent0 >= (1ll << 31)) return;
+        std::vector<int> slots0((size_t)npos0 * 4, 0);
+        long long pos0 = 0, off0 = 0;
+        for (int l = 0; l < nlev; l++) {
+            for (int t = ptr[(size_t)l]; t < ptr[(size_t)l + 1]; t++, pos0++) {
+                const int i = rows[(size_t)t], nch = std::max(1, (I[(size_t)i + 1] - I[(size_t)i] + kLPR - 1) / kLPR);
+                slots0[(size_t)pos0 * 4] = i; slots0[(size_t)pos0 * 4 + 1] = (int)off0; slots0[(size_t)pos0 * 4 + 2] = nch;
+                off0 += (long long)nch * kLPR;
+            }
+            for (; pos0 % 4 != 0; pos0++) slots0[(size_t)pos0 * 4] = -1;
+        }
+        d_df_slots = dev_from_host(slots0.data(), slots0.size());
+        int *d_level = dev_from_host(level.data(), (size_t)n);
+        d_df_J = dev_alloc<unsigned>((size_t)nent0);
+        d_df_a = dev_alloc<double>((size_t)nent0);
+        Temp<int> nanti(1);
+        zero_async(nanti, sizeof(int));
+        hipLaunchKernelGGL(df_build_kernel, dim3((unsigned)((npos0 * kLPR + 255) / 256)), dim3(256), 0, st, (int)npos0, reinterpret_cast<const int4s *>(d_df_slots),
+                           (const int *)M->diag.I, (const int *)M->diag.J, (const double *)M->diag.a, (const int *)d_level, d_df_J, d_df_a, nanti.p);
+        ELAG_LAUNCH_CHECK();
+        const int na = fetch_int(nanti);
+        dev_free(d_level);
+        if (na == 0) df_npos = (int)npos0;
+        else { dev_free(d_df_slots); dev_free(d_df_J); dev_free(d_df_a); d_df_slots = nullptr; d_df_J = nullptr; d_df_a = nullptr; }
+    }
+    if (!d_df_slots) {
+    // ---- the host path: anti-dependencies -- rows i that store column j while row j does not store column i ----
+    std::vector<int> tptr((size_t)n + 1, 0), tidx((size_t)J.size()), xptr((size_t)n + 1, 0), xidx;
+    for (int i = 0; i < n; i++)
+        for (int k = I[(size_t)i]; k < I[(size_t)i + 1]; k++) tptr[(size_t)J[(size_t)k] + 1]++;
+    std::partial_sum(tptr.begin(), tptr.end(), tptr.begin());
+    {
+        std::vector<int> fill(tptr.begin(), tptr.end() - 1);
+        for (int i = 0; i < n; i++)
+            for (int k = I[(size_t)i]; k < I[(size_t)i + 1]; k++) tidx[(size_t)fill[(size_t)J[(size_t)k]]++] = i;
+        std::vector<int> mark((size_t)n, -1);
+        for (int j = 0; j < n; j++) {
+            for (int k = I[(size_t)j]; k < I[(size_t)j + 1]; k++) mark[(size_t)J[(size_t)k]] = j;
+            for (int q = tptr[(size_t)j]; q < tptr[(size_t)j + 1]; q++) {
+                const int i = tidx[(size_t)q];
+                if (i != j && mark[(size_t)i] != j) { mark[(size_t)i] = j; xidx.push_back(i); }
+            }
+            xptr[(size_t)j + 1] = (int)xidx.size();
+        }
+    }
+    // ---- tiles: the levels padded to whole wave tiles of 4 positions; rows padded to whole chunks of 16 entries (at least one) ----
+    auto chunks_of = [&](int i) { return std::max(1, (I[(size_t)i + 1] - I[(size_t)i] + xptr[(size_t)i + 1] - xptr[(size_t)i] + kLPR - 1) / kLPR); };
+    long long npos = 0, nent = 0;
+    for (int l = 0; l < nlev; l++) npos += ((long long)(ptr[(size_t)l + 1] - ptr[(size_t)l]) + 3) / 4 * 4;
+    for (int i = 0; i < n; i++) nent += (long long)chunks_of(i) * kLPR;
+    if (npos >= (1ll << 30) || nent >= (1ll << 31)) return;
+    std::vector<int> slots((size_t)npos * 4, 0), src((size_t)std::max<long long>(nent, 1), -1);
+    std::vector<unsigned> dj((size_t)std::max<long long>(nent, 1), kDfNone);
+    long long pos = 0, off = 0;
+    for (int l = 0; l < nlev; l++) {
+        for (int t = ptr[(size_t)l]; t < ptr[(size_t)l + 1]; t++, pos++) {
+            const int i = rows[(size_t)t], len = I[(size_t)i + 1] - I[(size_t)i], nch = chunks_of(i);
+            slots[(size_t)pos * 4] = i; slots[(size_t)pos * 4 + 1] = (int)off; slots[(size_t)pos * 4 + 2] = nch;
+            auto flags = [&](int j) -> unsigned {
+                if (j == i) return kDfSelf;
+                return level[(size_t)j] < level[(size_t)i] ? kDfLower : 0u;
+            };
+            for (int q = 0; q < len; q++) {
+                const int k = I[(size_t)i] + q, j = J[(size_t)k];
+                if (j != i && level[(size_t)j] == level[(size_t)i]) return;      // (cannot be: two rows of one level share no entry)
+                dj[(size_t)off + q] = (unsigned)j | flags(j);
+                src[(size_t)off + q] = k;
+            }
+            for (int q = xptr[(size_t)i]; q < xptr[(size_t)i + 1]; q++) {
+                const int j = xidx[(size_t)q];
+                if (level[(size_t)j] == level[(size_t)i]) return;
+                dj[(size_t)off + len + (q - xptr[(size_t)i])] = (unsigned)j | flags(j) | kDfWait;
+            }
+            off += (long long)nch * kLPR;
+        }
+        for (; pos % 4 != 0; pos++) { slots[(size_t)pos * 4] = -1; slots[(size_t)pos * 4 + 2] = 0; }
+    }
+    df_npos = (int)npos;
+    d_df_slots = dev_from_host(slots.data(), slots.size());
+    d_df_J = dev_from_host(dj.data(), dj.size());
+    d_df_a = dev_alloc<double>(dj.size());
+    {
+        int *d_src = dev_from_host(src.data(), src.size());
+        const unsigned gsz = (unsigned)std::min<long long>(((long long)dj.size() + 255) / 256, 4096);
+        hipLaunchKernelGGL(df_gather_values_kernel, dim3(gsz), dim3(256), 0, st, (long long)dj.size(), (const int *)d_src, (const double *)M->diag.a, d_df_a);
+        ELAG_LAUNCH_CHECK();
+        ELAG_HIP_CHECK(hipStreamSynchronize(st));
+        dev_free(d_src);
+    }
+    }   // host path
+    d_df_gran = dev_alloc<unsigned long long>((size_t)4 * n);
+    d_df_state = dev_alloc<int>(4);
+    zero_async(d_df_gran, sizeof(unsigned long long) * (size_t)4 * n);
+    zero_async(d_df_state, sizeof(int) * 4);
+    // every workgroup resident whatever else the kernel needs: at most one 256-thread workgroup per CU; two tiles per wavefront and half-sweep at least
+    const int ntiles = df_npos / 4, cus = c.num_cus > 0 ? c.num_cus : 64;
+    df_grid = std::max(1, std::min(cus, (ntiles + 7) / 8));
+    if (const char *e = getenv("ELAG_HIP_SWEEP_DATAFLOW_WGS")) df_grid = std::max(1, std::min(atoi(e), cus));
+    dataflow = true;
+    // ---- once per process: the same symmetric sweep by the level launches and by the dataflow kernel, bit for bit ----
+    const char *always = getenv("ELAG_HIP_SWEEP_DATAFLOW_CHECK");
+    if (g_dataflow_checked.load() == 0 || (always && atoi(always))) {
+        Temp<double> tf((size_t)n), ua((size_t)n), ub((size_t)n);
+        Temp<int> nd(1);
+        const unsigned gsz = (unsigned)std::min<long long>(((long long)n + 255) / 256, 2048);
+        hipLaunchKernelGGL(df_fill_kernel, dim3(gsz), dim3(256), 0, st, n, 17u, tf.p);
+        hipLaunchKernelGGL(df_fill_kernel, dim3(gsz), dim3(256), 0, st, n, 90001u, ua.p);
+        hipLaunchKernelGGL(df_fill_kernel, dim3(gsz), dim3(256), 0, st, n, 90001u, ub.p);
+        zero_async(nd, sizeof(int));
+        const bool ghosts = M->offd.nnz > 0;
+        if (ghosts) zero_async(M->d_ghost, sizeof(double) * (size_t)M->offd.ncols);      // (any frozen ghost values, the same for both)
+        for (size_t q = 0; q < segments.size(); q++) launch_segment(segments[q], +1, tf, ua);
+        for (size_t q = segments.size(); q-- > 0;) launch_segment(segments[q], -1, tf, ua);
+        launch_dataflow(tf, ub);
+        launch_dataflow(tf, ub);                                                          // (twice: the second launch runs on the other granule array)
+        for (size_t q = 0; q < segments.size(); q++) launch_segment(segments[q], +1, tf, ua);
+        for (size_t q = segments.size(); q-- > 0;) launch_segment(segments[q], -1, tf, ua);
+        hipLaunchKernelGGL(df_count_diff_kernel, dim3(gsz), dim3(256), 0, st, n, (const double *)ua.p, (const double *)ub.p, nd.p);
+        ELAG_LAUNCH_CHECK();
+        const int ndiff = fetch_int(nd);
+        const int gave_up = *reinterpret_cast<volatile int *>(c.h_dev_err);
+        if (ndiff != 0 || gave_up != 0) {
+            *reinterpret_cast<volatile int *>(c.h_dev_err) = 0;
+            g_dataflow_checked.store(-1);
+            dataflow = false;
+            if (!getenv("ELAG_HIP_QUIET"))
+                fprintf(stderr, "[elag_hip] the Gauss-Seidel dataflow sweep %s on this device: the launch-per-level sweeps stay (n = %d, %d levels, %d workgroups)\n",
+                        gave_up ? "gave up waiting" : "did not reproduce the level launches bit for bit", n, nlev, df_grid);
+        } else {
+            g_dataflow_checked.store(1);
+        }
+    }
+}
+
+void SweepSmoother::launch_dataflow(const double *f, double *u)
+{
+    static long long ticks = 0;
+    if (ticks == 0) { const char *e = getenv("ELAG_HIP_SWEEP_DATAFLOW_MS"); ticks = std::max(1ll, (long long)((e && atof(e) > 0 ? atof(e) : 250.0) * 1.0e5)); }   // (100 MHz)
+    const bool ho = M->offd.nnz > 0;
+    DfArgs A;
+    A.slots = reinterpret_cast<const int4s *>(d_df_slots);
+    A.J = d_df_J; A.a = d_df_a;
+    A.oI = ho ? M->offd.I : nullptr; A.oJ = ho ? M->offd.J : nullptr; A.oa = ho ? M->offd.a : nullptr; A.ug = M->d_ghost;
+    A.f = f; A.d = (type == ELAG_HIP_SMOOTHER_GS) ? nullptr : d_l1; A.omega = omega;
+    A.u = u; A.gran = d_df_gran; A.state = d_df_state; A.host_err = ctx().h_dev_err;
+    A.n = M->nrows(); A.npos = df_npos; A.ticks = ticks;
+    { const char *e = getenv("ELAG_HIP_SWEEP_DATAFLOW_STALL_ROW"); A.stall_row = e ? atoi(e) : -1; }
+    if (type == ELAG_HIP_SMOOTHER_GS) hipLaunchKernelGGL(sweep_dataflow_kernel<1>, dim3((unsigned)df_grid), dim3(256), 0, ctx().stream, A);
+    else hipLaunchKernelGGL(sweep_dataflow_kernel<0>, dim3((unsigned)df_grid), dim3(256), 0, ctx().stream, A);
+    ELAG_LAUNCH_CHECK();
 }
 
 namespace {
@@ -843,6 +1309,7 @@ void SweepSmoother::apply(const double *f, double *&cur, double *&, bool zero_gu
         if (As) k::vec_gather(As->offd.ncols, d_self_ghost, cur, As->d_ghost);        // (virtual ranks: the other blocks' values, frozen here)
         else if (M->needs_exchange()) par_halo_exchange(*M, cur);
         if (sor) { sweep_sor(f, cur); continue; }
+        if (dataflow) { launch_dataflow(f, cur); continue; }
         if (segments.size() == 1 && segments[0].max_rows < 0) { launch_segment(segments[0], +1, f, cur, true); continue; }
         if (lds_u && segments.size() == 1 && segments[0].max_rows == 0) {
             launch_segment(segments[0], +1, f, cur, true);        // forward then backward in one launch, u in LDS throughout

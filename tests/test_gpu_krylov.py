@@ -293,9 +293,9 @@ def test_solver_adopts_the_numbering_of_a_reordered_hierarchy(la, h1_k2, name):
 
 
 def test_gmres_two_vector_gram_schmidt_links_are_the_one_vector_chain(la):
-    """The fused modified Gram-Schmidt of GMRES takes two basis vectors per link by default (krylov.hip, gmres_orth_pair_kernel):
+    """ELAG_HIP_GMRES_PAIR=1: the fused modified Gram-Schmidt of GMRES takes two basis vectors per link (krylov.hip, gmres_orth_pair_kernel):
     H(b,i) = <w, v_b> - H(a,i) <v_a, v_b> instead of a dot with the updated vector -- the same coefficients in exact arithmetic, rounding-level
-    differences from MFEM's loop, which ELAG_HIP_GMRES_PAIR=0 runs operation by operation.  Both against the oracle's restatement of
+    differences from MFEM's loop, which the default chain runs operation by operation.  Both against the oracle's restatement of
     mfem::GMRESSolver and against each other, on steps with an even and an odd number of columns and across a restart."""
     import os
     rng = np.random.default_rng(11)
@@ -304,7 +304,7 @@ def test_gmres_two_vector_gram_schmidt_links_are_the_one_vector_chain(la):
     dA = la.ParallelCSRMatrix.from_scipy(A)
     b = rng.uniform(-1, 1, n)
     out = []
-    for env in ({}, {"ELAG_HIP_GMRES_PAIR": "0"}):
+    for env in ({"ELAG_HIP_GMRES_PAIR": "1"}, {"ELAG_HIP_GMRES_PAIR": "0"}):
         saved_env = {k: os.environ.get(k) for k in env}      # (a variable the run itself was started with is put back, not dropped)
         os.environ.update(env)
         try:
@@ -326,12 +326,13 @@ def test_gmres_two_vector_gram_schmidt_links_are_the_one_vector_chain(la):
     assert close(out[0][2], out[1][2], 1e-10)
 
 
-def test_gmres_two_vector_links_on_a_nearly_dependent_krylov_basis(la):
-    """inside a pair the second coefficient is <w, v_b> - H(a,i) <v_a, v_b>, a difference that cancels when w is nearly parallel to
-    v_a -- in working precision that is classical Gram-Schmidt's error (eps |w|), so the pair chain takes its inner products and the difference
-    in double-double.  An operator that is an involution up to 1e-8 makes exactly that case: A v_1 = A^2 v_0 ~ v_0, so at step 1 the pair
-    (v_0, v_1) sees w = v_0 + O(1e-8).  The pair chain, the one-vector chain (MFEM's loop) and the oracle's mfem::GMRESSolver must agree on the
-    iteration count, reach the same true residual and the same iterate; the solver also says how it issued its steps."""
+def test_gmres_chains_on_a_nearly_dependent_krylov_basis(la):
+    """inside a pair of the two-vector chain the second coefficient is <w, v_b> - H(a,i) <v_a, v_b>, a difference that cancels when
+    w is nearly parallel to v_a -- classical Gram-Schmidt's error (eps |w|) where MGS has eps |w - H(a,i) v_a|; that is why the chain is opt-in and
+    the default is MFEM's loop.  An operator that is an involution up to 1e-8 makes exactly that case: A v_1 = A^2 v_0 ~ v_0, so at step 1 the
+    pair (v_0, v_1) sees w = v_0 + O(1e-8).  The default chain must agree with the oracle's mfem::GMRESSolver on the iteration count, the
+    iterate and the true residual; the pair chain must still converge to the same solution (its count may differ by the rounding it adds);
+    the solver says how it issued its steps."""
     import os
     rng = np.random.default_rng(5)
     n = 600
@@ -343,7 +344,7 @@ def test_gmres_two_vector_links_on_a_nearly_dependent_krylov_basis(la):
         dA = la.ParallelCSRMatrix.from_scipy(A)
         b = rng.uniform(-1, 1, n)
         out = []
-        for env in ({}, {"ELAG_HIP_GMRES_PAIR": "0"}):
+        for env in ({"ELAG_HIP_GMRES_PAIR": "0"}, {"ELAG_HIP_GMRES_PAIR": "1"}):
             saved_env = {k: os.environ.get(k) for k in env}
             os.environ.update(env)
             try:
@@ -363,8 +364,9 @@ def test_gmres_two_vector_links_on_a_nearly_dependent_krylov_basis(la):
         assert ref.converged and ref.final_iter >= 2
         bn = np.linalg.norm(b)
         true_res = [np.linalg.norm(b - A @ o[2]) / bn for o in out] + [np.linalg.norm(b - A @ xr) / bn]
-        for (conv, it, x, fn), tr in zip(out, true_res):
-            assert conv and it == ref.final_iter, (eps_op, it, ref.final_iter)
-            assert tr <= 20 * tol + 1e-13, (eps_op, true_res)
-            assert close(x, xr, 1e-7)
-        assert max(true_res[:2]) <= 10 * true_res[2] + 1e-13, (eps_op, true_res)     # neither chain loses accuracy against MFEM's loop
+        print("eps", eps_op, "iterations", [o[1] for o in out], ref.final_iter, "true residuals", true_res)
+        conv, it, x, fn = out[0]                                        # the default chain: MFEM's loop
+        assert conv and it == ref.final_iter, (eps_op, it, ref.final_iter)
+        assert true_res[0] <= 10 * true_res[2] + 1e-13 and close(x, xr, 1e-9), (eps_op, true_res)
+        conv, it, x, fn = out[1]                                        # the opt-in pair chain
+        assert conv and abs(it - ref.final_iter) <= 2 and close(x, xr, 1e-7), (eps_op, it, ref.final_iter, true_res)

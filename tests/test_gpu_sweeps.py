@@ -552,3 +552,128 @@ def test_dense_tail_product_on_the_matrix_cores_is_the_scalar_product(la, h1_k2)
     # the sweeps over the dense block: a workgroup per strip of 16 columns walking all levels (default) against a launch per level -- the same
     # operations entry by entry
     assert np.array_equal(xs[0], xs[2])
+
+
+# ---- the dataflow sweep (sweep.hip, sweep_dataflow_kernel): one launch per symmetric sweep, rows waiting for the rows they read ---------------
+
+def _with_env(env, fn):
+    import os
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("relax_type", [2, 4, 6])
+@pytest.mark.parametrize("sweeps", [1, 3])
+def test_dataflow_sweep_is_the_sequential_loop_bit_for_bit(la, h1_k2, relax_type, sweeps, capfd):
+    """forced on (ELAG_HIP_SWEEP_DATAFLOW=2) and off (0): the oracle's sequential loop both ways, from a guess and from zero, and applied
+    repeatedly (the two granule arrays take turns: every launch runs on the array the launch before it zeroed)"""
+    A, _, _ = h1_k2
+    Ad = orc.diag_first(A)
+    dA = la.ParallelCSRMatrix.from_scipy(Ad)
+    rng = np.random.default_rng(21)
+    n = A.shape[0]
+    f, u0 = rng.standard_normal(n), rng.standard_normal(n)
+    for mode in ("2", "0"):
+        S = _with_env({"ELAG_HIP_SWEEP_DATAFLOW": mode, "ELAG_HIP_SWEEP_VERBOSE": "1"}, lambda: la.HypreSmootherWrapper(dA, relax_type, {"Sweeps": sweeps}))
+        assert ("dataflow sweep" in capfd.readouterr().err) == (mode == "2")
+        ref = orc.OSmoother(orc.OParCSR(Ad), type=relax_type, sweeps=sweeps)
+        for iterative in (True, False):
+            S.iterative_mode = ref.iterative_mode = iterative
+            u, ur = u0.copy(), u0.copy()
+            for _ in range(3):
+                S.Mult(f, u); ref.Mult(f, ur)
+                assert np.array_equal(u, ur)
+
+
+@pytest.mark.parametrize("relax_type", [2, 6])
+def test_dataflow_sweep_on_unsymmetric_patterns_long_and_empty_rows(la, relax_type, capfd):
+    """a row that is read without reading back gets a wait-only entry (the host-built schedule); rows of more than 32 entries fetch their later
+    chunks when their turn comes; type 6: rows without entries and a stored zero diagonal are left alone but still hand their value on"""
+    rng = np.random.default_rng(5)
+    n = 900
+    B = sp.random(n, n, density=0.01, random_state=rng, format="lil")
+    B.setdiag(rng.uniform(2, 3, n))
+    for r in (7, 300, 640):                                           # long rows: 70 / 40 / 33 entries
+        cols = rng.choice(n, size={7: 70, 300: 40, 640: 33}[r], replace=False)
+        B[r, cols] = rng.uniform(-0.01, 0.01, cols.size)
+        B[r, r] = 2.5
+    A = orc.diag_first(B.tocsr())
+    sym = orc.diag_first((A + A.T).tocsr())                            # structurally symmetric: the schedule is built on the device
+    if relax_type == 6:
+        A = A.tolil()
+        A[3, :] = 0
+        A = orc.diag_first(A.tocsr())
+        A.eliminate_zeros()
+        A = orc.diag_first(A)
+        A.data[A.indptr[10]] = 0.0
+    for M in (A, sym):
+        S = _with_env({"ELAG_HIP_SWEEP_DATAFLOW": "2", "ELAG_HIP_SWEEP_VERBOSE": "1"},
+                      lambda: la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(M), relax_type, {"Sweeps": 2}))
+        assert "dataflow sweep" in capfd.readouterr().err
+        ref = orc.OSmoother(orc.OParCSR(M), type=relax_type, sweeps=2)
+        f, u0 = rng.standard_normal(n), rng.standard_normal(n)
+        u, ur = u0.copy(), u0.copy()
+        S.Mult(f, u); ref.Mult(f, ur)
+        assert np.array_equal(u, ur)
+
+
+def test_gauss_seidel_cycle_with_and_without_the_dataflow_sweep(la, h1_k2):
+    """the cycle the reference ships, with the dataflow sweeps on the levels above the dense tail and with the level launches: the same
+    arithmetic row by row, so the same vector bit for bit; also replayed inside PCG (a graph where the hierarchy prefers one)"""
+    A, Ps, _ = h1_k2
+    dA = la.ParallelCSRMatrix.from_scipy(A)
+    dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    n = A.shape[0]
+    rng = np.random.default_rng(33)
+    b = rng.uniform(-1, 1, n)
+    xs, its = [], []
+    for mode in ("2", "0"):
+        H = _with_env({"ELAG_HIP_SWEEP_DATAFLOW": mode}, lambda: la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Gauss-Seidel"))
+        x = np.empty(n)
+        for _ in range(3):
+            H.Mult(b, x)
+        xs.append(x)
+        H.iterative_mode = False
+        K = la.KrylovSolver(dA, H, {"Solver name": "PCG", "Relative tolerance": 1e-8, "Maximum iterations": 100})
+        y = np.zeros(n); K.Mult(b, y)
+        assert K.GetConverged()
+        its.append(K.GetNumIterations()); xs.append(y)
+    assert np.array_equal(xs[0], xs[2]) and np.array_equal(xs[1], xs[3]) and its[0] == its[1]
+
+
+def test_dataflow_sweep_that_gives_up_leaves_the_level_launches_in_charge():
+    """every wait of the dataflow kernel is bounded; a kernel that runs out of time says so through pinned host memory and the library keeps
+    the launch-per-level sweeps for the rest of the process.  Forced in a child process: the self-check at
+    setup sees the give-up, warns once, and the sweep is still the sequential loop.  (The stall: a test switch keeps row 0's value from ever being
+    handed on, so its readers wait until the 2 ms limit.)"""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import numpy as np
+        from oracle import oracle as orc
+        from parelag_amd import linalg as la, meshgen
+        A, _, _ = meshgen.h1_problem(2)
+        Ad = orc.diag_first(A)
+        S = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(Ad), 2, {"Sweeps": 1})
+        rng = np.random.default_rng(1)
+        f, u = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+        ur = u.copy()
+        S.Mult(f, u)
+        orc.OSmoother(orc.OParCSR(Ad), type=2).Mult(f, ur)
+        assert np.array_equal(u, ur)
+        S2 = la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(Ad), 6, {"Sweeps": 1})      # (off for the process: no second warning)
+        print("GAVE_UP_OK")
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ELAG_HIP_SWEEP_DATAFLOW="2", ELAG_HIP_SWEEP_DATAFLOW_MS="2", ELAG_HIP_SWEEP_DATAFLOW_STALL_ROW="0")
+    env.pop("ELAG_HIP_QUIET", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0 and "GAVE_UP_OK" in r.stdout, r.stdout + r.stderr
+    assert r.stderr.count("gave up waiting") == 1, r.stderr
