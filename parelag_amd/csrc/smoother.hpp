@@ -87,6 +87,7 @@ struct SweepSmoother : elag_hip_smoother_s {
     unsigned long long *d_df_gran = nullptr;
     int *d_df_state = nullptr;
     int df_npos = 0, df_grid = 0;
+    bool df_xcd = false;                              // the launch confines itself to one XCD (plain stores through that XCD's L2)
     void setup_dataflow(const std::vector<int> &I, const std::vector<int> &J, const std::vector<int> &level, const std::vector<int> &ptr, const std::vector<int> &rows);
     void launch_dataflow(const double *f, double *u);
     bool lds_u = false;                               // the operator's u fits the chain workgroup's LDS: every level is chained (sweep.hip)

@@ -430,7 +430,7 @@ struct DfArgs {
     double omega;
     double *u;
     u64t *gran;            // [2][2 n]
-    int *state;            // [0] workgroups done, [1] array in use, [2] abort
+    int *state;            // [0] workgroups done, [1] array in use, [2] abort, [3] the XCD of the launch (-1 between launches), [4] next tile
     int *host_err;
     int n, npos;
     long long ticks;
@@ -462,9 +462,27 @@ __device__ __forceinline__ void df_chunk(int row, bool real, int j, double v, do
     ordered_chunk<0>(row, real ? j : -1, v, x, res, a0, h0);
 }
 
+// the XCD this wavefront runs on: bits 3:0 of hardware register 20 (XCC_ID) on gfx942 / gfx950
+__device__ __forceinline__ int df_xcc_id()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+#else
+    return 0;
+#endif
+}
+
 constexpr int kDfC = 2;            // chunks of 16 entries a row keeps in registers (32 entries: longer rows fetch the rest when their turn comes)
 
-template <int MODE>
+// XCD = true: the same sweep confined to ONE of the chip's eight XCDs.  A hand-off through agent-scope (write-through) stores costs a trip to
+// memory and back, ~1.1 us of the ~1.5 us a dependency level takes above; workgroups of one XCD share its L2, where a PLAIN store of one CU is
+// what an L1-bypassing (sc1) load of another CU reads ~0.3 us later.  Placement is not assumed: every workgroup reads the XCD it runs on from
+// the hardware (HW_REG_XCC_ID); the first one to arrive names the XCD of the launch (a compare-and-swap on a word in device memory) and the
+// workgroups that find themselves elsewhere zero their share of the idle granule array and leave -- a seventh of the grid stays under the
+// observed round-robin placement, whatever stays does the work under any other.  Tiles are not dealt in advance but taken from a counter
+// (the smallest tile not yet taken; a wavefront holds up to three and works them in order), which also lifts the residency condition:
+// a workgroup that has not started holds no tile, so the smallest unfinished tile is always in the hands of a running wavefront.
+template <int MODE, bool XCD>
 __global__ __launch_bounds__(256) void sweep_dataflow_kernel(const DfArgs A)
 {
     const int tid = (int)(blockIdx.x * 256 + threadIdx.x), nthreads = (int)gridDim.x * 256;
@@ -478,8 +496,20 @@ __global__ __launch_bounds__(256) void sweep_dataflow_kernel(const DfArgs A)
     }
     const long long t0 = (long long)wall_clock64();
     const int ntiles = A.npos >> 2;
-    const int cnt = wave < ntiles ? (ntiles - wave + nwaves - 1) / nwaves : 0;       // this wavefront's tiles per half-sweep
+    int cnt = wave < ntiles ? (ntiles - wave + nwaves - 1) / nwaves : 0;             // this wavefront's tiles per half-sweep
     bool dead = false;
+    if (XCD) {
+        // which XCD this launch runs on: the first workgroup's; the others stay only if they are there too
+        __shared__ int stay;
+        if (threadIdx.x == 0) {
+            const int mine = df_xcc_id();
+            int seen = -1;
+            const bool first = __hip_atomic_compare_exchange_strong(A.state + 3, &seen, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stay = (first || seen == mine) ? 1 : 0;
+        }
+        __syncthreads();
+        cnt = stay ? ntiles : 0;                                                    // (tickets: cnt only says "in" or "out" here)
+    }
     // one poll of row j's two words; true once both carry `need`
     auto poll = [&](int j, unsigned need, double &x) -> bool {
         const u64t w0 = __hip_atomic_load(g + 2 * (size_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -502,8 +532,20 @@ __global__ __launch_bounds__(256) void sweep_dataflow_kernel(const DfArgs A)
     };
     // What a task needs that no other row writes -- its slot, then its first kDfC chunks of entries and its f, d -- is requested two and
     // one tasks ahead: the only memory round trips left on a task's own path are the polls.
-    auto tile_of = [&](int q) { const int half = q / cnt, T = wave + (q - half * cnt) * nwaves; return half == 0 ? T : ntiles - 1 - T; };
-    auto load_slot = [&](int q) -> int4s { return q < 2 * cnt ? A.slots[(size_t)tile_of(q) * 4 + grp] : int4s{-1, 0, 0, 0}; };
+    // task number -> (half-sweep, tile); static deal: this wavefront's q-th task; tickets: the number drawn from the counter
+    auto take = [&](int q) -> int {
+        if (!XCD) return q < 2 * cnt ? (q / cnt) * ntiles + wave + (q % cnt) * nwaves : 2 * ntiles;
+        if (cnt == 0) return 2 * ntiles;
+        int t = 0;
+        if ((threadIdx.x & 63) == 0) t = __hip_atomic_fetch_add(A.state + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = __builtin_amdgcn_readfirstlane(t);
+        return t < 2 * ntiles ? t : 2 * ntiles;
+    };
+    auto load_slot = [&](int task) -> int4s {
+        if (task >= 2 * ntiles) return int4s{-1, 0, 0, 0};
+        const int half = task / ntiles, T = task - half * ntiles;
+        return A.slots[(size_t)(half == 0 ? T : ntiles - 1 - T) * 4 + grp];
+    };
     auto load_entries = [&](const int4s &sl, unsigned (&w)[kDfC], double (&v)[kDfC], double &fr, double &dr) {
 #pragma unroll
         for (int c = 0; c < kDfC; c++) {
@@ -513,17 +555,19 @@ __global__ __launch_bounds__(256) void sweep_dataflow_kernel(const DfArgs A)
         fr = 0.0; dr = 0.0;
         if (sl.x >= 0) { fr = A.f[sl.x]; if (MODE == 0) dr = A.d[sl.x]; }
     };
-    int4s slA = load_slot(0), slB = load_slot(1), slC = int4s{-1, 0, 0, 0};
+    int tkA = take(0), tkB = take(1), tkC = 2 * ntiles;
+    int4s slA = load_slot(tkA), slB = load_slot(tkB), slC = int4s{-1, 0, 0, 0};
     unsigned wA[kDfC], wB[kDfC];
     double vA[kDfC], vB[kDfC], fA, dA, fB = 0.0, dB = 0.0;
     load_entries(slA, wA, vA, fA, dA);
 #pragma unroll
     for (int c = 0; c < kDfC; c++) { wB[c] = kDfNone; vB[c] = 0.0; }
-    for (int q = 0; q < 2 * cnt && !dead; q++) {
-        const int half = q / cnt;
+    for (int q = 0; tkA < 2 * ntiles && !dead; q++) {
+        const int half = tkA / ntiles;
         const unsigned e_new = (unsigned)half + 1u;
         load_entries(slB, wB, vB, fB, dB);
-        slC = load_slot(q + 2);
+        tkC = take(q + 2);
+        slC = load_slot(tkC);
         const int row = slA.x, off = slA.y, nch = slA.z;
         double res = fA, uo = 0.0, aii = 0.0;
         bool have = false;
@@ -605,12 +649,18 @@ __global__ __launch_bounds__(256) void sweep_dataflow_kernel(const DfArgs A)
             if (MODE == 0) { if (dA != 0.0) un = uo + A.omega * res / dA; }
             else if (have && aii != 0.0) un = res / aii;
             const u64t tag = (u64t)e_new << 32;
-            __hip_atomic_store(g + 2 * (size_t)row, tag | (unsigned)__double2loint(un), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g + 2 * (size_t)row + 1, tag | (unsigned)__double2hiint(un), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (XCD: plain stores -- they stay in the XCD's L2, where every reader of this launch looks; otherwise write-through to memory)
+            if (XCD) {
+                __hip_atomic_store(g + 2 * (size_t)row, tag | (unsigned)__double2loint(un), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(g + 2 * (size_t)row + 1, tag | (unsigned)__double2hiint(un), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                __hip_atomic_store(g + 2 * (size_t)row, tag | (unsigned)__double2loint(un), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g + 2 * (size_t)row + 1, tag | (unsigned)__double2hiint(un), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (half == 1) A.u[row] = un;
         }
         // ---- rotate the pipeline
-        slA = slB; slB = slC; fA = fB; dA = dB;
+        slA = slB; slB = slC; fA = fB; dA = dB; tkA = tkB; tkB = tkC;
 #pragma unroll
         for (int c = 0; c < kDfC; c++) { wA[c] = wB[c]; vA[c] = vB[c]; }
     }
@@ -621,6 +671,8 @@ __global__ __launch_bounds__(256) void sweep_dataflow_kernel(const DfArgs A)
         if (before == (int)gridDim.x - 1) {
             __hip_atomic_store(A.state, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(A.state + 1, cur ^ 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.state + 3, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.state + 4, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -1052,13 +1104,24 @@ void SweepSmoother::setup_dataflow(const std::vector<int> &I, const std::vector<
     }
     }   // host path
     d_df_gran = dev_alloc<unsigned long long>((size_t)4 * n);
-    d_df_state = dev_alloc<int>(4);
+    {
+        const int st0[8] = {0, 0, 0, -1, 0, 0, 0, 0};
+        d_df_state = dev_from_host(st0, 8);
+    }
     zero_async(d_df_gran, sizeof(unsigned long long) * (size_t)4 * n);
-    zero_async(d_df_state, sizeof(int) * 4);
     // every workgroup resident whatever else the kernel needs: at most one 256-thread workgroup per CU; two tiles per wavefront and half-sweep at least
     const int ntiles = df_npos / 4, cus = c.num_cus > 0 ? c.num_cus : 64;
     df_grid = std::max(1, std::min(cus, (ntiles + 7) / 8));
-    if (const char *e = getenv("ELAG_HIP_SWEEP_DATAFLOW_WGS")) df_grid = std::max(1, std::min(atoi(e), cus));
+    {
+        // One XCD or the whole chip (ELAG_HIP_SWEEP_DATAFLOW_XCD = 1 / 0 forces either).  Measured on MI355X, a symmetric sweep of the cube456 x3
+        // level operators, whole chip / one XCD (a workgroup per CU launched, 32 of them stay): 42 309 rows in 89 levels (119 tiles per level)
+        // 262 / 405 us; 5 739 rows in 51 levels (28 tiles per level) 148 / 121 us; 840 rows in 41 levels 118 / 93 us; a tridiagonal chain 1.08 /
+        // 0.85 us per hop -- an XCD's L2 makes the hand-off shorter, its 32 CUs make a wide level longer.
+        const char *e = getenv("ELAG_HIP_SWEEP_DATAFLOW_XCD");
+        df_xcd = e ? atoi(e) != 0 : (ntiles <= 48 * nlev);
+        if (df_xcd) df_grid = cus;
+    }
+    if (const char *e = getenv("ELAG_HIP_SWEEP_DATAFLOW_WGS")) df_grid = std::max(1, std::min(atoi(e), df_xcd ? 8 * cus : cus));
     dataflow = true;
     // ---- once per process: the same symmetric sweep by the level launches and by the dataflow kernel, bit for bit ----
     const char *always = getenv("ELAG_HIP_SWEEP_DATAFLOW_CHECK");
@@ -1108,8 +1171,13 @@ void SweepSmoother::launch_dataflow(const double *f, double *u)
     A.u = u; A.gran = d_df_gran; A.state = d_df_state; A.host_err = ctx().h_dev_err;
     A.n = M->nrows(); A.npos = df_npos; A.ticks = ticks;
     { const char *e = getenv("ELAG_HIP_SWEEP_DATAFLOW_STALL_ROW"); A.stall_row = e ? atoi(e) : -1; }
-    if (type == ELAG_HIP_SMOOTHER_GS) hipLaunchKernelGGL(sweep_dataflow_kernel<1>, dim3((unsigned)df_grid), dim3(256), 0, ctx().stream, A);
-    else hipLaunchKernelGGL(sweep_dataflow_kernel<0>, dim3((unsigned)df_grid), dim3(256), 0, ctx().stream, A);
+    if (df_xcd) {
+        if (type == ELAG_HIP_SMOOTHER_GS) hipLaunchKernelGGL((sweep_dataflow_kernel<1, true>), dim3((unsigned)df_grid), dim3(256), 0, ctx().stream, A);
+        else hipLaunchKernelGGL((sweep_dataflow_kernel<0, true>), dim3((unsigned)df_grid), dim3(256), 0, ctx().stream, A);
+    } else {
+        if (type == ELAG_HIP_SMOOTHER_GS) hipLaunchKernelGGL((sweep_dataflow_kernel<1, false>), dim3((unsigned)df_grid), dim3(256), 0, ctx().stream, A);
+        else hipLaunchKernelGGL((sweep_dataflow_kernel<0, false>), dim3((unsigned)df_grid), dim3(256), 0, ctx().stream, A);
+    }
     ELAG_LAUNCH_CHECK();
 }
 

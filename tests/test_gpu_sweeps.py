@@ -581,8 +581,9 @@ def test_dataflow_sweep_is_the_sequential_loop_bit_for_bit(la, h1_k2, relax_type
     rng = np.random.default_rng(21)
     n = A.shape[0]
     f, u0 = rng.standard_normal(n), rng.standard_normal(n)
-    for mode in ("2", "0"):
-        S = _with_env({"ELAG_HIP_SWEEP_DATAFLOW": mode, "ELAG_HIP_SWEEP_VERBOSE": "1"}, lambda: la.HypreSmootherWrapper(dA, relax_type, {"Sweeps": sweeps}))
+    for mode, xcd in (("2", "0"), ("2", "1"), ("0", "0")):            # whole chip / confined to one XCD (plain stores through its L2) / level launches
+        S = _with_env({"ELAG_HIP_SWEEP_DATAFLOW": mode, "ELAG_HIP_SWEEP_DATAFLOW_XCD": xcd, "ELAG_HIP_SWEEP_VERBOSE": "1"},
+                      lambda: la.HypreSmootherWrapper(dA, relax_type, {"Sweeps": sweeps}))
         assert ("dataflow sweep" in capfd.readouterr().err) == (mode == "2")
         ref = orc.OSmoother(orc.OParCSR(Ad), type=relax_type, sweeps=sweeps)
         for iterative in (True, False):
@@ -614,8 +615,8 @@ def test_dataflow_sweep_on_unsymmetric_patterns_long_and_empty_rows(la, relax_ty
         A.eliminate_zeros()
         A = orc.diag_first(A)
         A.data[A.indptr[10]] = 0.0
-    for M in (A, sym):
-        S = _with_env({"ELAG_HIP_SWEEP_DATAFLOW": "2", "ELAG_HIP_SWEEP_VERBOSE": "1"},
+    for M, xcd in ((A, "0"), (A, "1"), (sym, "0"), (sym, "1")):
+        S = _with_env({"ELAG_HIP_SWEEP_DATAFLOW": "2", "ELAG_HIP_SWEEP_DATAFLOW_XCD": xcd, "ELAG_HIP_SWEEP_VERBOSE": "1"},
                       lambda: la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(M), relax_type, {"Sweeps": 2}))
         assert "dataflow sweep" in capfd.readouterr().err
         ref = orc.OSmoother(orc.OParCSR(M), type=relax_type, sweeps=2)
