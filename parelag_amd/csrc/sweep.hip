@@ -979,7 +979,8 @@ void SweepSmoother::setup()
     d_lev_ptr = dev_from_host(step_ptr.data(), step_ptr.size());
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
     dataflow = false;
-    if (!kaczmarz && !sor && blocks == 1 && !block_chains) setup_dataflow(I, J, level, ptr, rows);
+    // (virtual ranks too where their blocks share the common schedule: the diagonal part of the split operator is what the levels were computed on)
+    if (!kaczmarz && !sor && !block_chains) setup_dataflow(I, J, level, ptr, rows);
     if (getenv("ELAG_HIP_SWEEP_VERBOSE"))
         fprintf(stderr, "[elag_hip] sweep smoother type %d: n=%d, %d dependency levels = %d steps in %d launches per direction%s%s\n", type, n, nlev,
                 n_steps, (int)segments.size(), lds_u ? " (u in LDS)" : "", dataflow ? "; dataflow sweep: one launch per symmetric sweep" : "");
