@@ -482,7 +482,7 @@ constexpr int kDfC = 2;            // chunks of 16 entries a row keeps in regist
 // observed round-robin placement, whatever stays does the work under any other.  Tiles are not dealt in advance but taken from a counter
 // (the smallest tile not yet taken; a wavefront holds up to three and works them in order), which also lifts the residency condition:
 // a workgroup that has not started holds no tile, so the smallest unfinished tile is always in the hands of a running wavefront.
-template <int MODE, bool XCD>
+template <int MODE, bool XCD, bool TICKETS = XCD>
 __global__ __launch_bounds__(256) void sweep_dataflow_kernel(const DfArgs A)
 {
     const int tid = (int)(blockIdx.x * 256 + threadIdx.x), nthreads = (int)gridDim.x * 256;
@@ -509,6 +509,8 @@ __global__ __launch_bounds__(256) void sweep_dataflow_kernel(const DfArgs A)
         }
         __syncthreads();
         cnt = stay ? ntiles : 0;                                                    // (tickets: cnt only says "in" or "out" here)
+    } else if (TICKETS) {
+        cnt = ntiles;
     }
     // one poll of row j's two words; true once both carry `need`
     auto poll = [&](int j, unsigned need, double &x) -> bool {
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(256) void sweep_dataflow_kernel(const DfArgs A)
     // one tasks ahead: the only memory round trips left on a task's own path are the polls.
     // task number -> (half-sweep, tile); static deal: this wavefront's q-th task; tickets: the number drawn from the counter
     auto take = [&](int q) -> int {
-        if (!XCD) return q < 2 * cnt ? (q / cnt) * ntiles + wave + (q % cnt) * nwaves : 2 * ntiles;
+        if (!TICKETS) return q < 2 * cnt ? (q / cnt) * ntiles + wave + (q % cnt) * nwaves : 2 * ntiles;
         if (cnt == 0) return 2 * ntiles;
         int t = 0;
         if ((threadIdx.x & 63) == 0) t = __hip_atomic_fetch_add(A.state + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1176,6 +1178,8 @@ void SweepSmoother::launch_dataflow(const double *f, double *u)
         if (type == ELAG_HIP_SMOOTHER_GS) hipLaunchKernelGGL((sweep_dataflow_kernel<1, true>), dim3((unsigned)df_grid), dim3(256), 0, ctx().stream, A);
         else hipLaunchKernelGGL((sweep_dataflow_kernel<0, true>), dim3((unsigned)df_grid), dim3(256), 0, ctx().stream, A);
     } else {
+        // (the whole chip keeps the static deal: one tile counter for 1 024 wavefronts on eight XCDs was measured at 532 us against 262 for the
+        // cube456 x3 level-0 sweep -- the counter is the chip's slowest word)
         if (type == ELAG_HIP_SMOOTHER_GS) hipLaunchKernelGGL((sweep_dataflow_kernel<1, false>), dim3((unsigned)df_grid), dim3(256), 0, ctx().stream, A);
         else hipLaunchKernelGGL((sweep_dataflow_kernel<0, false>), dim3((unsigned)df_grid), dim3(256), 0, ctx().stream, A);
     }
