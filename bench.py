@@ -409,7 +409,9 @@ def launch_dry_run(rank: int, world: int):
 
 def gauss_seidel_leg(args, la, np, dA, dPs, rhs, n_local, A, Ps, cpu_gs=None):
     """The same hierarchy with the reference's shipped relaxation, "L1 Gauss-Seidel" (hypre relax type 2,
-    Create0FormParameterList.hpp:103-116): on the device it runs as level-scheduled sweeps (csrc/sweep.hip)."""
+    Create0FormParameterList.hpp:103-116): on the device a symmetric sweep is ONE launch in which every row waits for exactly the rows it
+    reads (the dataflow sweep of csrc/sweep.hip, round 5; the sequential loop's bits) -- a launch per dependency level until round 4
+    (ELAG_HIP_SWEEP_DATAFLOW=0), which is also timed here for the record."""
     t0 = time.time()
     Hgs = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Gauss-Seidel", use_graph=not args.no_graph)
     la.synchronize()
@@ -417,7 +419,25 @@ def gauss_seidel_leg(args, la, np, dA, dPs, rhs, n_local, A, Ps, cpu_gs=None):
     sol_gs = la.DeviceVector(n_local, 1.0)
     ms_gs = Hgs.time_apply(rhs, sol_gs, max(50, min(args.steps, 500)))
     gs = {"smoother": "L1 Gauss-Seidel (hypre relax type 2, 1 symmetric sweep pre/post)", "device_ms_per_step": round(ms_gs, 5),
-          "vcycles_per_s": round(1e3 / ms_gs, 1), "setup_s": round(gs_setup, 3)}
+          "vcycles_per_s": round(1e3 / ms_gs, 1), "setup_s": round(gs_setup, 3), "launch_mode": Hgs.launch_mode(),
+          "sweeps": "dataflow: one launch per symmetric sweep, rows wait for the rows they read (sweep_dataflow_kernel)"
+                    if os.environ.get("ELAG_HIP_SWEEP_DATAFLOW", "1") != "0" else "a launch per dependency level (ELAG_HIP_SWEEP_DATAFLOW=0)"}
+    if os.environ.get("ELAG_HIP_SWEEP_DATAFLOW", "1") != "0":
+        # the same cycle with the launch-per-level sweeps of rounds 1-4 (same arithmetic, same bits)
+        saved = os.environ.get("ELAG_HIP_SWEEP_DATAFLOW")
+        os.environ["ELAG_HIP_SWEEP_DATAFLOW"] = "0"
+        try:
+            Hlv = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Gauss-Seidel", use_graph=not args.no_graph)
+        finally:
+            if saved is None:
+                os.environ.pop("ELAG_HIP_SWEEP_DATAFLOW", None)
+            else:
+                os.environ["ELAG_HIP_SWEEP_DATAFLOW"] = saved
+        sol_lv = la.DeviceVector(n_local, 1.0)
+        ms_lv = Hlv.time_apply(rhs, sol_lv, max(50, min(args.steps, 500)))
+        gs["level_launches"] = {"device_ms_per_step": round(ms_lv, 5), "vcycles_per_s": round(1e3 / ms_lv, 1), "kernels_per_cycle": Hlv.launch_mode().get("kernels_per_cycle"),
+                                "same_bits_as_the_dataflow_cycle": bool(np.array_equal(sol_lv.to_numpy(), sol_gs.to_numpy()))}
+        del Hlv, sol_lv
     if not args.no_cpu_baseline:
         from oracle import oracle as orc
         from tests.helpers import oracle_h1_hierarchy

@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 5: the evidence behind DESIGN.md's numbers, from one tree, in one GPU call (profiles/r05_* are copies of what this writes)
+OUT=$PWD/gpurun_out/r05final; mkdir -p $OUT
+echo "[1] default bench (the driver's command)"; timeout -k 10 500 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "rc $?"
+echo "[2] kernel stats of the same"; bash tools/profile_bench.sh r05final/prof --no-traffic --no-cpu-baseline > $OUT/bench_default_kernel_stats.txt 2>&1; tail -3 $OUT/bench_default_kernel_stats.txt | cut -c1-160
+echo "[3] roofline kernel: rocprof mean + PMC traffic"; bash tools/roofline_profile.sh r05final/roof auto > $OUT/roofline.txt 2>&1; tail -6 $OUT/roofline.txt | cut -c1-200
+echo "[4] RAP"; bash tools/rap_profile.sh r05final/rap 5 > $OUT/rap_stats.txt 2>&1; grep "RAP ms" $OUT/rap_stats.txt
+echo "[5] the Gauss-Seidel dataflow sweep: level operators of cube456 x3, the pure chain, the cycle's kernel stats"
+python tools/r05_dataflow_probe.py 3 2 2>&1 | grep -v "^\[elag" > $OUT/dataflow_probe.txt; python tools/r05_dataflow_probe.py 3 6 2>&1 | grep -v "^\[elag" >> $OUT/dataflow_probe.txt
+python tools/r05_dataflow_chain.py 2000 >> $OUT/dataflow_probe.txt 2>&1; cat $OUT/dataflow_probe.txt | cut -c1-200
+python tools/gs_setup_probe.py > $OUT/gs_setup.txt 2>&1; tail -4 $OUT/gs_setup.txt | cut -c1-300
+echo "[6] H(div) x3 kernel stats"; bash tools/profile_bench.sh r05final/hdiv --form 2 --no-cpu-baseline --no-roofline --no-gs --no-other-configs > $OUT/hdiv_kernel_stats.txt 2>&1; tail -2 $OUT/hdiv_kernel_stats.txt | cut -c1-160
+echo "[7] the reference's own 2-form list: Hiptmair(L1 Gauss-Seidel, L1 Gauss-Seidel), dataflow on / off"
+for m in 1 0; do ELAG_HIP_SWEEP_DATAFLOW=$m timeout -k 10 400 python bench.py --form 2 --smoother "L1 Gauss-Seidel" --no-roofline --no-cpu-baseline --no-other-configs --no-gs > $OUT/hdiv_gs_dataflow_$m.json 2> $OUT/hdiv_gs_dataflow_$m.err; echo "rc $?"; done
+echo "[8] the N-rank code path on one rank"; timeout -k 10 400 python bench.py --force-dist --no-cpu-baseline --steps 20 --warmup 5 > $OUT/bench_multirank_path_1rank.json 2> $OUT/bench_multirank_path_1rank.err; echo "rc $?"
+echo "[9] config 4 with its solve"; timeout -k 10 300 python bench.py --form darcy --solve --no-cpu-baseline --no-cpu-solve --steps 20 --warmup 5 > $OUT/bench_darcy_solve.json 2> $OUT/bench_darcy_solve.err; echo "rc $?"
