@@ -2,7 +2,9 @@
 # round 5: the evidence behind DESIGN.md's numbers, from one tree, in one GPU call (profiles/r05_* are copies of what this writes)
 OUT=$PWD/gpurun_out/r05final; mkdir -p $OUT
 echo "[1] default bench (the driver's command)"; timeout -k 10 500 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "rc $?"
-echo "[2] kernel stats of the same"; bash tools/profile_bench.sh r05final/prof --no-traffic --no-cpu-baseline > $OUT/bench_default_kernel_stats.txt 2>&1; tail -3 $OUT/bench_default_kernel_stats.txt | cut -c1-160
+echo "[2] kernel stats of the same"; bash tools/profile_bench.sh r05final/prof --no-traffic --no-cpu-baseline --no-gs > $OUT/bench_default_kernel_stats.txt 2>&1; tail -3 $OUT/bench_default_kernel_stats.txt | cut -c1-160
+# (the Gauss-Seidel leg apart and as plain launches: rocprofv3 --kernel-trace faults inside hipGraphLaunch on this stack, as it did on the GMRES step graphs in round 4)
+echo "[2b] kernel stats of the Gauss-Seidel cycles"; bash tools/profile_bench.sh r05final/gs --no-roofline --no-cpu-baseline --no-other-configs --no-graph > $OUT/gs_kernel_stats.txt 2>&1; grep -a "dataflow\|sweep_levels\|sweep_chain" $OUT/gs_kernel_stats.txt | cut -c1-200
 echo "[3] roofline kernel: rocprof mean + PMC traffic"; bash tools/roofline_profile.sh r05final/roof auto > $OUT/roofline.txt 2>&1; tail -6 $OUT/roofline.txt | cut -c1-200
 echo "[4] RAP"; bash tools/rap_profile.sh r05final/rap 5 > $OUT/rap_stats.txt 2>&1; grep "RAP ms" $OUT/rap_stats.txt
 echo "[5] the Gauss-Seidel dataflow sweep: level operators of cube456 x3, the pure chain, the cycle's kernel stats"
