@@ -21,6 +21,7 @@ struct Error : std::runtime_error {
     Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
 };
 void set_last_error(const std::string &m) { fprintf(stderr, "elag_hip error: %s\n", m.c_str()); }
+void check_device_error() {}                       // (no device in this build)
 [[noreturn]] void fail(int code, const char *fmt, ...)
 {
     char buf[1024];
