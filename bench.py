@@ -1093,14 +1093,35 @@ def main():
                 H.Mult(rhs, sol)
             la.synchronize()
     barrier()
+    # The opening barrier of an N-rank run ends in gloo's blocking wait: the rank's core has idled, and on this stack the first ~40 launches after a
+    # sleep cost the host two to three times their usual time ("Waiting") -- with K = 20 steps of three launches the whole timed region.
+    # Half a millisecond of spinning between the barrier and the clock brings the core back up; no GPU work, outside the timed region, the same on every rank.
+    if dist is not None:
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 5e-4:
+            pass
     with no_gc():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             H.Mult(rhs, sol)
-        barrier()
+        enqueue_s = time.perf_counter() - t0                  # the host's share: K cycles enqueued (the device may lag behind)
+        # the clock stops when this rank's device has drained; the closing barrier follows it and the MAX over ranks is taken below.  (Until round 4 the
+        # control plane's barrier -- a gloo round over TCP, 0.04 ms on one rank and milliseconds on eight -- sat inside the clock: with K = 20 steps of
+        # ~15 us it was most of what an N-rank run reported.  The ranks of a cycle with a halo exchange and an all-reduce finish together anyway.)
+        la.synchronize()
         elapsed = time.perf_counter() - t0
+        barrier()
+        elapsed_with_barrier = time.perf_counter() - t0
+    # what the closing barrier of the timed region costs by itself (drain + gloo barrier + drain on an idle device): with K = 20 steps of ~15 us it is
+    # a large share of the N-rank figure -- 0.3 ms of the 0.64 ms that 20 cycles take through the N-rank path on one rank (round 5)
+    closing_barrier_ms = None
+    if dist is not None:
+        tb = time.perf_counter()
+        barrier()
+        closing_barrier_ms = dist.allreduce_max(time.perf_counter() - tb) * 1e3
     if dist is not None:
         elapsed = dist.allreduce_max(elapsed)
+        elapsed_with_barrier = dist.allreduce_max(elapsed_with_barrier)
     # the same loop over 2000 cycles (what rounds 1-2 quoted): a caller that keeps the queue full
     steady = None
     if dist is None:
@@ -1462,6 +1483,9 @@ def main():
                            "env": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
                            "parallelism": f"row-block domain decomposition x{world}"},
                 "steady_state": (None if steady is None else {"steps": 2000, "ms_per_step": round(steady * 1e3, 5), "vcycles_per_s": round(1.0 / steady, 1)}),
+                "closing_barrier_ms": (None if closing_barrier_ms is None else round(closing_barrier_ms, 4)),
+                "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 5),
+                "ms_per_step_with_closing_barrier_in_the_clock": round(elapsed_with_barrier / args.steps * 1e3, 5),
                 "device_ms_per_step": round(ms_dev, 5), "device_timed_steps": max(200, min(args.steps, 500)),
                 "device_vcycles_per_s": round(1e3 / ms_dev, 1),
                 "vcycle_algorithmic_bytes": vbytes,

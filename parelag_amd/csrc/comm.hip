@@ -236,6 +236,11 @@ void comm_init(int rank, int nranks, const void *id128)
     x.nranks = nranks;
 }
 
+__global__ void self_copy_kernel(size_t nwords, const unsigned long long *__restrict__ src, unsigned long long *__restrict__ dst)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 void comm_neighbor_exchange(const void *sendbuf, int nsend, const int *send_procs, const int *send_starts,
                             void *recvbuf, int nrecv, const int *recv_procs, const int *recv_starts,
                             size_t elem_bytes, hipStream_t st)
@@ -251,10 +256,20 @@ void comm_neighbor_exchange(const void *sendbuf, int nsend, const int *send_proc
     if (self_s >= 0) {
         const size_t ns = (size_t)(send_starts[self_s + 1] - send_starts[self_s]), nr = (size_t)(recv_starts[self_r + 1] - recv_starts[self_r]);
         if (ns != nr) fail(ELAG_HIP_ERR_COMM, "self neighbour: send and receive lengths differ (%zu vs %zu)", ns, nr);
-        if (ns)
-            ELAG_HIP_CHECK(hipMemcpyAsync(static_cast<char *>(recvbuf) + (size_t)recv_starts[self_r] * elem_bytes,
-                                          static_cast<const char *>(sendbuf) + (size_t)send_starts[self_s] * elem_bytes, ns * elem_bytes,
-                                          hipMemcpyDeviceToDevice, st));
+        if (ns) {
+            // (a kernel, not hipMemcpyAsync: the copy API costs the host 8-10 us a call on this stack, a launch ~4)
+            const char *src = static_cast<const char *>(sendbuf) + (size_t)send_starts[self_s] * elem_bytes;
+            char *dst = static_cast<char *>(recvbuf) + (size_t)recv_starts[self_r] * elem_bytes;
+            const size_t nb = ns * elem_bytes;
+            if (nb <= ((size_t)4 << 20) && (nb % 8) == 0 && ((uintptr_t)src % 8) == 0 && ((uintptr_t)dst % 8) == 0) {
+                const size_t nw = nb / 8;
+                hipLaunchKernelGGL(self_copy_kernel, dim3((unsigned)std::min<size_t>((nw + 255) / 256, 1024)), dim3(256), 0, st, nw,
+                                   reinterpret_cast<const unsigned long long *>(src), reinterpret_cast<unsigned long long *>(dst));
+                ELAG_HIP_CHECK(hipGetLastError());
+            } else {
+                ELAG_HIP_CHECK(hipMemcpyAsync(dst, src, nb, hipMemcpyDeviceToDevice, st));
+            }
+        }
     }
     if (!remote) return;
     if (!comm_active()) fail(ELAG_HIP_ERR_COMM, "matrix has off-rank columns but no communicator was initialised");
