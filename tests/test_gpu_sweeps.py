@@ -678,3 +678,46 @@ def test_dataflow_sweep_that_gives_up_leaves_the_level_launches_in_charge():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert r.returncode == 0 and "GAVE_UP_OK" in r.stdout, r.stdout + r.stderr
     assert r.stderr.count("gave up waiting") == 1, r.stderr
+
+
+def test_dataflow_sweep_that_gives_up_later_is_reported_by_the_next_call():
+    """a give-up after the self-check -- in production: the device held by something that keeps the kernel's workgroups from running -- cannot be
+    repaired (the sweep works in place), so it must not pass silently: the kernel stores a code in pinned host memory and the ABI call that
+    follows fails with ELAG_HIP_ERR_STATE and says why; the library stays usable (the level launches, a new smoother)."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os
+        import numpy as np
+        from oracle import oracle as orc
+        from parelag_amd import linalg as la, meshgen, _lib
+        A, _, _ = meshgen.h1_problem(2)
+        Ad = orc.diag_first(A)
+        dA = la.ParallelCSRMatrix.from_scipy(Ad)
+        S = la.HypreSmootherWrapper(dA, 2, {"Sweeps": 1})                # (self-check passes: nothing stalls yet)
+        rng = np.random.default_rng(1)
+        f, u0 = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+        ur = u0.copy(); orc.OSmoother(orc.OParCSR(Ad), type=2).Mult(f, ur)
+        u = u0.copy(); S.Mult(f, u)
+        assert np.array_equal(u, ur)
+        os.environ["ELAG_HIP_SWEEP_DATAFLOW_STALL_ROW"] = "0"             # from here on row 0 never hands its value on
+        df, du = la.DeviceVector.from_numpy(f), la.DeviceVector.from_numpy(u0)
+        failed = False
+        try:
+            S.Mult(df, du)                                               # the launch itself returns; the code arrives with the kernel
+            la.synchronize()
+            S.Mult(df, du)
+        except _lib.ElagHipError as e:
+            failed = "gave up" in str(e)
+        assert failed
+        os.environ.pop("ELAG_HIP_SWEEP_DATAFLOW_STALL_ROW")
+        os.environ["ELAG_HIP_SWEEP_DATAFLOW"] = "0"
+        S2 = la.HypreSmootherWrapper(dA, 2, {"Sweeps": 1})               # the library goes on: the launch-per-level sweeps
+        u = u0.copy(); S2.Mult(f, u)
+        assert np.array_equal(u, ur)
+        print("REPORTED_OK")
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ELAG_HIP_SWEEP_DATAFLOW="2", ELAG_HIP_SWEEP_DATAFLOW_MS="2")
+    env.pop("ELAG_HIP_SWEEP_DATAFLOW_STALL_ROW", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0 and "REPORTED_OK" in r.stdout, r.stdout + r.stderr
