@@ -415,7 +415,7 @@ __global__ void sweep_sor_level_kernel(int r0, int r1, int dir, const int *__res
 // * No deadlock by construction: order the tasks (half-sweep, tile); a task waits only for smaller tasks (earlier tiles of its half, any tile
 //   of the half before), every wavefront takes its own tasks in increasing order, and every workgroup of the grid is resident (at most one
 //   256-thread workgroup per CU) -- so the smallest unfinished task can always run.  Results do not depend on placement or dispatch order.
-//   Even so every wait is bounded (ELAG_HIP_SWEEP_DATAFLOW_MS of the 100 MHz clock, default 250): a wavefront that runs out sets the abort
+//   Even so every wait is bounded (ELAG_HIP_SWEEP_DATAFLOW_MS of the 100 MHz clock per wait, default 250): a wavefront that runs out sets the abort
 //   word, every poller sees it and leaves, the code lands in pinned host memory and the next ABI call fails (check_device_error) -- another
 //   kernel of this kind holding the device, say.  In-place safe: a row's input value is read only by its neighbours' forward tasks, all done
 //   before the row's backward task can start.
@@ -494,7 +494,6 @@ __global__ __launch_bounds__(256) void sweep_dataflow_kernel(const DfArgs A)
         u64t *gz = A.gran + (size_t)(cur ^ 1) * 2 * A.n;
         for (size_t i = (size_t)tid; i < (size_t)2 * A.n; i += (size_t)nthreads) gz[i] = 0ull;
     }
-    const long long t0 = (long long)wall_clock64();
     const int ntiles = A.npos >> 2;
     int cnt = wave < ntiles ? (ntiles - wave + nwaves - 1) / nwaves : 0;             // this wavefront's tiles per half-sweep
     bool dead = false;
@@ -521,9 +520,12 @@ __global__ __launch_bounds__(256) void sweep_dataflow_kernel(const DfArgs A)
         return true;
     };
     // the wavefront leaves a wait together; false: it (or somebody else) has run out of time
-    auto give_up = [&](unsigned &spins) -> bool {
+    // (the limit is per WAIT, counted from its 64th poll: a sweep over a very large operator may take long, a single hand-off may not)
+    auto give_up = [&](unsigned &spins, long long &tw) -> bool {
         if ((++spins & 63u) != 0) { __builtin_amdgcn_s_sleep(1); return false; }
-        const bool late = (long long)wall_clock64() - t0 > A.ticks;
+        const long long now = (long long)wall_clock64();
+        if (spins == 64u) tw = now;
+        const bool late = now - tw > A.ticks;
         const bool stop = __hip_atomic_load(A.state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
         if (!__any(late || stop)) return false;
         if (__any(late) && (threadIdx.x & 63) == 0) {
@@ -595,6 +597,7 @@ __global__ __launch_bounds__(256) void sweep_dataflow_kernel(const DfArgs A)
         // ---- the wait
         {
             unsigned spins = 0;
+            long long tw = 0;
             for (;;) {
 #pragma unroll
                 for (int c = 0; c < kDfC; c++)
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(256) void sweep_dataflow_kernel(const DfArgs A)
 #pragma unroll
                 for (int c = 0; c < kDfC; c++) all = all && ok[c];
                 if (__all(all)) break;
-                if (give_up(spins)) { dead = true; break; }
+                if (give_up(spins, tw)) { dead = true; break; }
             }
             if (dead) break;
         }
@@ -628,10 +631,11 @@ __global__ __launch_bounds__(256) void sweep_dataflow_kernel(const DfArgs A)
             bool okx = !valid || nd == 0u;
             if (valid && nd == 0u && !(w & kDfWait)) xx = A.u[jj];
             unsigned spins = 0;
+            long long tw = 0;
             for (;;) {
                 if (!okx) okx = poll(jj, nd, xx);
                 if (__all(okx)) break;
-                if (give_up(spins)) { dead = true; break; }
+                if (give_up(spins, tw)) { dead = true; break; }
             }
             if (dead) break;
             if (c < nch) df_chunk<MODE>(row, valid && !(w & kDfWait), jj, v, xx, res, aii, have);
