@@ -1120,6 +1120,17 @@ void SweepSmoother::setup_dataflow(const std::vector<int> &I, const std::vector<
     const int ntiles = df_npos / 4, cus = c.num_cus > 0 ? c.num_cus : 64;
     df_grid = std::max(1, std::min(cus, (ntiles + 7) / 8));
     {
+        // wide levels want more wavefronts than one workgroup per CU gives (a wavefront works one tile at a time, ~2 us each): about one workgroup
+        // per tile of an average level, four per CU at most (all resident).  Measured, us per symmetric sweep with 256 / 512 / 1 024 workgroups:
+        // cube456 x3 (119 tiles per level) 265 / 277 / 317; x4 (480 tiles per level) 693 / 600 / 614.
+        const int tpl = ntiles / std::max(nlev, 1);
+        if (tpl > cus) {
+            int g2 = cus;
+            while (g2 < tpl && g2 < 4 * cus) g2 *= 2;
+            df_grid = std::min(g2, 4 * cus);
+        }
+    }
+    {
         // One XCD or the whole chip (ELAG_HIP_SWEEP_DATAFLOW_XCD = 1 / 0 forces either).  Measured on MI355X, a symmetric sweep of the cube456 x3
         // level operators, whole chip / one XCD (a workgroup per CU launched, 32 of them stay): 42 309 rows in 89 levels (119 tiles per level)
         // 262 / 405 us; 5 739 rows in 51 levels (28 tiles per level) 148 / 121 us; 840 rows in 41 levels 118 / 93 us; a tridiagonal chain 1.08 /
@@ -1128,7 +1139,7 @@ void SweepSmoother::setup_dataflow(const std::vector<int> &I, const std::vector<
         df_xcd = e ? atoi(e) != 0 : (ntiles <= 48 * nlev);
         if (df_xcd) df_grid = cus;
     }
-    if (const char *e = getenv("ELAG_HIP_SWEEP_DATAFLOW_WGS")) df_grid = std::max(1, std::min(atoi(e), df_xcd ? 8 * cus : cus));
+    if (const char *e = getenv("ELAG_HIP_SWEEP_DATAFLOW_WGS")) df_grid = std::max(1, std::min(atoi(e), df_xcd ? 8 * cus : 4 * cus));   // (whole chip: every workgroup must be resident -- 4 per CU at most)
     dataflow = true;
     // ---- once per process: the same symmetric sweep by the level launches and by the dataflow kernel, bit for bit ----
     const char *always = getenv("ELAG_HIP_SWEEP_DATAFLOW_CHECK");
