@@ -90,6 +90,15 @@ struct SweepSmoother : elag_hip_smoother_s {
     bool df_xcd = false;                              // the launch confines itself to one XCD (plain stores through that XCD's L2)
     void setup_dataflow(const std::vector<int> &I, const std::vector<int> &J, const std::vector<int> &level, const std::vector<int> &ptr, const std::vector<int> &rows);
     void launch_dataflow(const double *f, double *u);
+    // setup() = the common part (virtual ranks, l1 norms), then the schedule: for large operators by kernels (setup_device: dependency levels by a
+    // dataflow kernel in natural row order, rows dealt to their levels, entries and flags -- nothing but a few counts crosses to the host), otherwise, or
+    // when a kernel path does not apply, the host's pass over the rows (setup_host), which also builds the launch-per-level plan.  host_ready: that plan
+    // exists (built on demand for what needs it: apply_dense, a sweep with the dataflow form switched off).
+    bool host_ready = false;
+    std::vector<int> h_block_of;
+    bool setup_device();
+    void setup_host(bool allow_dataflow);
+    void finish_dataflow(int nlev);
     bool lds_u = false;                               // the operator's u fits the chain workgroup's LDS: every level is chained (sweep.hip)
     // "virtual ranks" (elag_hip_set_gs_hybrid_blocks > 1, rank-local operators): the rows are cut into that many contiguous blocks and the
     // sweep is hypre's hybrid Gauss-Seidel as the reference runs it on that many MPI ranks -- Gauss-Seidel inside a block, the other

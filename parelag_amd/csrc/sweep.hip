@@ -20,6 +20,7 @@
 // flight per lane group; only the subtraction itself is sequential, done from shuffled products in storage order.
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <numeric>
 
 #include "comm.hpp"
@@ -717,6 +718,102 @@ __global__ __launch_bounds__(256) void df_build_kernel(int npos, const int4s *__
     }
 }
 
+// ---- the schedule of a large operator by kernels (SweepSmoother::setup_device) -------------------------------------------------------------
+// Dependency levels:  level(i) = 1 + max { level(j) : j < i, a_ij != 0 }  (structurally symmetric pattern: checked afterwards by df_build_kernel) is the
+// same kind of chain as the sweep itself, so it is computed the same way: rows in NATURAL order, 64 per wavefront task, a row's lane reads the levels of
+// its lower neighbours four at a time and waits for the ones that are not there yet.  lev[] holds level + 1 (0 = not yet), one agent-scope word per row.
+// The lanes of a task may depend on each other (rows i and i + 1 are often neighbours), so nobody spins alone: every lane of the wavefront makes one
+// attempt per trip of the loop and publishes inside it.  ctl: [0] abort, [1] the largest level + 1.
+__global__ __launch_bounds__(256) void df_levels_kernel(int n, const int *__restrict__ I, const int *__restrict__ J, int *lev, int *ctl, long long ticks)
+{
+    const int wave = (int)((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (int)(gridDim.x * 4), lane = threadIdx.x & 63;
+    int wmax = 0;
+    bool dead = false;
+    for (int task = wave; (long long)task * 64 < n && !dead; task += nwaves) {
+        const int row = task * 64 + lane;
+        const bool valid = row < n;
+        int k = valid ? I[row] : 0;
+        const int e = valid ? I[row + 1] : 0;
+        int m = 0;
+        bool done = !valid;
+        unsigned spins = 0;
+        long long tw = 0;
+        int jj[4] = {-1, -1, -1, -1};
+        bool have = false;                                 // jj holds the columns of entries k .. k + 3
+        for (;;) {
+            if (!done) {
+                if (!have) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) jj[u] = (k + u < e) ? J[k + u] : -1;
+                    have = true;
+                }
+                int v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = (jj[u] >= 0 && jj[u] < row) ? __hip_atomic_load(lev + jj[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+                bool all = true;
+#pragma unroll
+                for (int u = 0; u < 4; u++) all = all && v[u] != 0;
+                if (all) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) m = max(m, v[u]);
+                    k += 4; have = false;
+                    if (k >= e) {
+                        __hip_atomic_store(lev + row, m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        wmax = max(wmax, m + 1);
+                        done = true;
+                    }
+                }
+            }
+            if (__all(done)) break;
+            if ((++spins & 63u) == 0) {
+                const long long now = (long long)wall_clock64();
+                if (spins == 64u) tw = now;
+                const bool stop = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                if (__any(now - tw > ticks || stop)) {
+                    if (lane == 0) __hip_atomic_store(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dead = true;
+                    break;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+    if (lane == 0 && wmax > 0) atomicMax(ctl + 1, wmax);
+}
+
+// rows per level (lev[] = level + 1), through a histogram in LDS; chunks of 16 entries per row (at least one)
+__global__ __launch_bounds__(256) void df_level_count_kernel(int n, int nlev, const int *__restrict__ lev, const int *__restrict__ I, int *__restrict__ count,
+                                                             int *__restrict__ nch16)
+{
+    extern __shared__ int hist[];
+    for (int q = threadIdx.x; q < nlev; q += 256) hist[q] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        atomicAdd(&hist[lev[i] - 1], 1);
+        nch16[i] = max(1, (I[i + 1] - I[i] + kLPR - 1) / kLPR) * kLPR;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < nlev; q += 256)
+        if (hist[q]) atomicAdd(&count[q], hist[q]);
+}
+
+// every row takes the next free position of its level (any order inside a level is a schedule: its rows are independent)
+__global__ __launch_bounds__(256) void df_deal_rows_kernel(int n, const int *__restrict__ lev, const int *__restrict__ base, int *__restrict__ cursor,
+                                                           const int *__restrict__ off, const int *__restrict__ nch16, int4s *__restrict__ slots)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int l = lev[i] - 1;
+    const int pos = base[l] + atomicAdd(&cursor[l], 1);
+    slots[pos] = int4s{i, off[i], nch16[i] / kLPR, 0};
+}
+
+__global__ void df_fill_slots_kernel(int npos, int4s *__restrict__ slots)
+{
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npos; p += gridDim.x * blockDim.x) slots[p] = int4s{-1, 0, 0, 0};
+}
+
 __global__ void df_gather_values_kernel(long long m, const int *__restrict__ src, const double *__restrict__ a, double *__restrict__ out)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) out[i] = src[i] >= 0 ? a[src[i]] : 0.0;
@@ -736,8 +833,10 @@ __global__ void df_count_diff_kernel(int n, const double *__restrict__ x, const 
         if (__double_as_longlong(x[i]) != __double_as_longlong(y[i])) atomicAdd(ndiff, 1);
 }
 
+thread_local bool t_one_block = false;        // (the dataflow self-check's operator is swept as one rank whatever the caller has set)
 int gs_hybrid_blocks()
 {
+    if (t_one_block) return 1;
     // elag_hip_set_gs_hybrid_blocks, else ELAG_HIP_GS_BLOCKS, else 1 (one rank: the sequential loop)
     if (ctx().gs_blocks > 0) return ctx().gs_blocks;
     const char *e = getenv("ELAG_HIP_GS_BLOCKS");
@@ -765,7 +864,8 @@ void SweepSmoother::setup()
     hipStream_t st = ctx().stream;
     As.reset(); dev_free(d_self_ghost); d_self_ghost = nullptr;
     dev_free(d_blk_first); dev_free(d_blk_count); d_blk_first = d_blk_count = nullptr;
-    std::vector<int> block_of;
+    std::vector<int> &block_of = h_block_of;
+    block_of.clear();
     blocks = gs_hybrid_blocks();
     if (blocks > 1 && !kaczmarz && !is_distributed(*A) && A->nrows() == A->ncols() && n >= 2 * blocks) {
         // ---- virtual ranks: A split like a ParCSR matrix on `blocks` ranks with contiguous, even row blocks ----
@@ -826,6 +926,20 @@ void SweepSmoother::setup()
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
         if (nbad) fail(ELAG_HIP_ERR_NUMERIC, "%s: matrix has %d zero l1 row norm(s)", kaczmarz ? "Kaczmarz" : "l1 Gauss-Seidel", nbad);
     }
+    host_ready = false;
+    dataflow = false;
+    h_lev_ptr.clear();
+    // large operators: dependency levels, schedule and entries by kernels (below); everything else: the host's pass over the rows
+    if (setup_device()) return;
+    setup_host(true);
+}
+
+void SweepSmoother::setup_host(bool allow_dataflow)
+{
+    const bool kaczmarz = type == ELAG_HIP_SMOOTHER_KACZMARZ;
+    const int n = M->nrows();
+    hipStream_t st = ctx().stream;
+    const std::vector<int> &block_of = h_block_of;
     // ---- dependency levels of the symmetrised pattern, one pass over the rows ----
     std::vector<int> I = host_from_dev(M->diag.I, (size_t)n + 1);
     std::vector<int> J = host_from_dev(M->diag.J, (size_t)M->diag.nnz);
@@ -984,9 +1098,9 @@ void SweepSmoother::setup()
     step_ptr.insert(step_ptr.end(), step_first.begin(), step_first.end());       // [offsets (n_steps + 1) | first-of-level flags (n_steps + 1)]
     d_lev_ptr = dev_from_host(step_ptr.data(), step_ptr.size());
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
-    dataflow = false;
+    host_ready = true;
     // (virtual ranks too where their blocks share the common schedule: the diagonal part of the split operator is what the levels were computed on)
-    if (!kaczmarz && !sor && !block_chains) setup_dataflow(I, J, level, ptr, rows);
+    if (allow_dataflow && !dataflow && !kaczmarz && !sor && !block_chains) setup_dataflow(I, J, level, ptr, rows);
     if (getenv("ELAG_HIP_SWEEP_VERBOSE"))
         fprintf(stderr, "[elag_hip] sweep smoother type %d: n=%d, %d dependency levels = %d steps in %d launches per direction%s%s\n", type, n, nlev,
                 n_steps, (int)segments.size(), lds_u ? " (u in LDS)" : "", dataflow ? "; dataflow sweep: one launch per symmetric sweep" : "");
@@ -1000,7 +1114,89 @@ int dataflow_mode()
     return e ? atoi(e) : 1;
 }
 std::atomic<int> g_dataflow_checked{0};    // 0: not yet, 1: this device runs the dataflow sweep bit for bit like the level launches, -1: it does not (off for the process)
+thread_local bool g_self_check_running = false;     // (this thread is inside dataflow_self_check: its own smoother must not start another)
+
+// Once per process, before the first operator takes the dataflow sweep: a 12 x 12 x 12 seven-point operator (1 728 rows, 34 dependency levels) swept by
+// the level launches and by the dataflow kernel (both granule arrays), bit for bit -- does THIS device run the hand-off protocol?  On the library's
+// own operator rather than the caller's first one: the check costs the same ~1 ms whatever the caller builds, and needs no launch-per-level plan of a
+// large operator (setup_device builds none).
+void dataflow_self_check()
+{
+    if (g_dataflow_checked.load() != 0 || g_self_check_running) return;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (g_dataflow_checked.load() != 0) return;
+    g_self_check_running = true;
+    try {
+        const int m = 12, n = m * m * m;
+        std::vector<int> I(1, 0), J;
+        std::vector<double> a;
+        for (int z = 0; z < m; z++)
+            for (int y = 0; y < m; y++)
+                for (int x = 0; x < m; x++) {
+                    const int i = (z * m + y) * m + x;
+                    J.push_back(i); a.push_back(6.5 + 0.01 * (i % 7));           // the diagonal entry first (hypre's convention)
+                    auto off = [&](int j, double v) { J.push_back(j); a.push_back(v); };
+                    if (x > 0) off(i - 1, -1.0);
+                    if (x < m - 1) off(i + 1, -1.0);
+                    if (y > 0) off(i - m, -0.9);
+                    if (y < m - 1) off(i + m, -0.9);
+                    if (z > 0) off(i - m * m, -1.1);
+                    if (z < m - 1) off(i + m * m, -1.1);
+                    I.push_back((int)J.size());
+                }
+        DevCSR d;
+        d.upload(n, n, I.data(), J.data(), a.data());
+        std::unique_ptr<ParCSR> P(parcsr_from_diag(std::move(d), 0, 0, n, n));
+        SweepSmoother T;
+        T.A = P.get();
+        T.type = ELAG_HIP_SMOOTHER_L1_GS;
+        t_one_block = true;
+        try { T.setup(); } catch (...) { t_one_block = false; throw; }
+        t_one_block = false;                       // (small: the host path, whose setup_dataflow runs the comparison while g_dataflow_checked is 0)
+        if (g_dataflow_checked.load() == 0) g_dataflow_checked.store(-1);          // (the operator did not take the dataflow form at all: leave it off)
+    } catch (...) {
+        g_dataflow_checked.store(-1);
+    }
+    g_self_check_running = false;
+}
 }  // namespace
+
+void SweepSmoother::finish_dataflow(int nlev)
+{
+    Context &c = ctx();
+    const int n = M->nrows();
+    d_df_gran = dev_alloc<unsigned long long>((size_t)4 * n);
+    {
+        const int st0[8] = {0, 0, 0, -1, 0, 0, 0, 0};
+        d_df_state = dev_from_host(st0, 8);
+    }
+    zero_async(d_df_gran, sizeof(unsigned long long) * (size_t)4 * n);
+    // every workgroup resident whatever else the kernel needs: at most one 256-thread workgroup per CU; two tiles per wavefront and half-sweep at least
+    const int ntiles = df_npos / 4, cus = c.num_cus > 0 ? c.num_cus : 64;
+    df_grid = std::max(1, std::min(cus, (ntiles + 7) / 8));
+    {
+        // wide levels want more wavefronts than one workgroup per CU gives (a wavefront works one tile at a time, ~2 us each): about one workgroup
+        // per tile of an average level, four per CU at most (all resident).  Measured, us per symmetric sweep with 256 / 512 / 1 024 workgroups:
+        // cube456 x3 (119 tiles per level) 265 / 277 / 317; x4 (480 tiles per level) 693 / 600 / 614.
+        const int tpl = ntiles / std::max(nlev, 1);
+        if (tpl > cus) {
+            int g2 = cus;
+            while (g2 < tpl && g2 < 4 * cus) g2 *= 2;
+            df_grid = std::min(g2, 4 * cus);
+        }
+    }
+    {
+        // One XCD or the whole chip (ELAG_HIP_SWEEP_DATAFLOW_XCD = 1 / 0 forces either).  Measured on MI355X, a symmetric sweep of the cube456 x3
+        // level operators, whole chip / one XCD (a workgroup per CU launched, 32 of them stay): 42 309 rows in 89 levels (119 tiles per level)
+        // 262 / 405 us; 5 739 rows in 51 levels (28 tiles per level) 148 / 121 us; 840 rows in 41 levels 118 / 93 us; a tridiagonal chain 1.08 /
+        // 0.85 us per hop -- an XCD's L2 makes the hand-off shorter, its 32 CUs make a wide level longer.
+        const char *e = getenv("ELAG_HIP_SWEEP_DATAFLOW_XCD");
+        df_xcd = e ? atoi(e) != 0 : (ntiles <= 48 * nlev);
+        if (df_xcd) df_grid = cus;
+    }
+    if (const char *e = getenv("ELAG_HIP_SWEEP_DATAFLOW_WGS")) df_grid = std::max(1, std::min(atoi(e), df_xcd ? 8 * cus : 4 * cus));   // (whole chip: every workgroup must be resident -- 4 per CU at most)
+}
 
 void SweepSmoother::setup_dataflow(const std::vector<int> &I, const std::vector<int> &J, const std::vector<int> &level, const std::vector<int> &ptr,
                                    const std::vector<int> &rows)
@@ -1010,9 +1206,11 @@ void SweepSmoother::setup_dataflow(const std::vector<int> &I, const std::vector<
     const int mode = dataflow_mode();
     const int n = M->nrows(), nlev = (int)ptr.size() - 1;
     Context &c = ctx();
+    if (mode > 0 && c.comm_kind != 2 && c.h_dev_err) dataflow_self_check();
     // one rank thread per process only (several contexts of one process would run such kernels side by side: each waits for workgroups the
     // other ones' spinning workgroups keep off the CUs); local square diagonal block; and enough dependency levels for a launch per level to hurt
     if (mode <= 0 || g_dataflow_checked.load() < 0 || c.comm_kind == 2 || n <= 0 || M->diag.ncols != n || n >= (1 << 28) || !c.h_dev_err) return;
+    if (g_dataflow_checked.load() == 0 && !g_self_check_running) return;      // (the self-check could not run)
     if (mode == 1 && (nlev < 4 || n < 256)) return;
     hipStream_t st = c.stream;
     // ---- the device path: slots from the row lengths alone, entries and flags by a kernel; taken unless some row is read without reading back ----
@@ -1110,38 +1308,10 @@ void SweepSmoother::setup_dataflow(const std::vector<int> &I, const std::vector<
         dev_free(d_src);
     }
     }   // host path
-    d_df_gran = dev_alloc<unsigned long long>((size_t)4 * n);
-    {
-        const int st0[8] = {0, 0, 0, -1, 0, 0, 0, 0};
-        d_df_state = dev_from_host(st0, 8);
-    }
-    zero_async(d_df_gran, sizeof(unsigned long long) * (size_t)4 * n);
-    // every workgroup resident whatever else the kernel needs: at most one 256-thread workgroup per CU; two tiles per wavefront and half-sweep at least
-    const int ntiles = df_npos / 4, cus = c.num_cus > 0 ? c.num_cus : 64;
-    df_grid = std::max(1, std::min(cus, (ntiles + 7) / 8));
-    {
-        // wide levels want more wavefronts than one workgroup per CU gives (a wavefront works one tile at a time, ~2 us each): about one workgroup
-        // per tile of an average level, four per CU at most (all resident).  Measured, us per symmetric sweep with 256 / 512 / 1 024 workgroups:
-        // cube456 x3 (119 tiles per level) 265 / 277 / 317; x4 (480 tiles per level) 693 / 600 / 614.
-        const int tpl = ntiles / std::max(nlev, 1);
-        if (tpl > cus) {
-            int g2 = cus;
-            while (g2 < tpl && g2 < 4 * cus) g2 *= 2;
-            df_grid = std::min(g2, 4 * cus);
-        }
-    }
-    {
-        // One XCD or the whole chip (ELAG_HIP_SWEEP_DATAFLOW_XCD = 1 / 0 forces either).  Measured on MI355X, a symmetric sweep of the cube456 x3
-        // level operators, whole chip / one XCD (a workgroup per CU launched, 32 of them stay): 42 309 rows in 89 levels (119 tiles per level)
-        // 262 / 405 us; 5 739 rows in 51 levels (28 tiles per level) 148 / 121 us; 840 rows in 41 levels 118 / 93 us; a tridiagonal chain 1.08 /
-        // 0.85 us per hop -- an XCD's L2 makes the hand-off shorter, its 32 CUs make a wide level longer.
-        const char *e = getenv("ELAG_HIP_SWEEP_DATAFLOW_XCD");
-        df_xcd = e ? atoi(e) != 0 : (ntiles <= 48 * nlev);
-        if (df_xcd) df_grid = cus;
-    }
-    if (const char *e = getenv("ELAG_HIP_SWEEP_DATAFLOW_WGS")) df_grid = std::max(1, std::min(atoi(e), df_xcd ? 8 * cus : 4 * cus));   // (whole chip: every workgroup must be resident -- 4 per CU at most)
+    finish_dataflow(nlev);
     dataflow = true;
-    // ---- once per process: the same symmetric sweep by the level launches and by the dataflow kernel, bit for bit ----
+    // ---- the same symmetric sweep by the level launches and by the dataflow kernel, bit for bit: on the process's self-check operator
+    //      (dataflow_self_check below), or on every operator that comes this way with ELAG_HIP_SWEEP_DATAFLOW_CHECK=1 ----
     const char *always = getenv("ELAG_HIP_SWEEP_DATAFLOW_CHECK");
     if (g_dataflow_checked.load() == 0 || (always && atoi(always))) {
         Temp<double> tf((size_t)n), ua((size_t)n), ub((size_t)n);
@@ -1174,6 +1344,85 @@ void SweepSmoother::setup_dataflow(const std::vector<int> &I, const std::vector<
             g_dataflow_checked.store(1);
         }
     }
+}
+
+bool SweepSmoother::setup_device()
+{
+    int min_rows = 100000;                             // (read at every setup: a test forces the kernels on a small operator)
+    if (const char *e = getenv("ELAG_HIP_SWEEP_DEVICE_SETUP_ROWS")) min_rows = atoi(e);
+    const int mode = dataflow_mode();
+    Context &c = ctx();
+    const int n = M->nrows();
+    const char *always = getenv("ELAG_HIP_SWEEP_DATAFLOW_CHECK");
+    if (type == ELAG_HIP_SMOOTHER_KACZMARZ || sor || blocks != 1 || mode <= 0 || c.comm_kind == 2 || !c.h_dev_err || n < min_rows || M->diag.ncols != n ||
+        n >= (1 << 28) || (always && atoi(always)))
+        return false;
+    dataflow_self_check();
+    if (g_dataflow_checked.load() <= 0) return false;
+    static long long ticks = 0;
+    if (ticks == 0) { const char *e = getenv("ELAG_HIP_SWEEP_DATAFLOW_MS"); ticks = std::max(1ll, (long long)((e && atof(e) > 0 ? atof(e) : 250.0) * 1.0e5)); }
+    hipStream_t st = c.stream;
+    const int cus = c.num_cus > 0 ? c.num_cus : 64;
+    // ---- 1. dependency levels ----
+    int *d_level = dev_alloc<int>((size_t)n);
+    Temp<int> ctl(2);
+    zero_async(d_level, sizeof(int) * (size_t)n);
+    zero_async(ctl, sizeof(int) * 2);
+    {
+        const int tasks = (n + 63) / 64;
+        const unsigned g = (unsigned)std::max(1, std::min(4 * cus, (tasks + 3) / 4));      // (every workgroup resident: 4 per CU at most)
+        hipLaunchKernelGGL(df_levels_kernel, dim3(g), dim3(256), 0, st, n, (const int *)M->diag.I, (const int *)M->diag.J, d_level, ctl.p, ticks);
+        ELAG_LAUNCH_CHECK();
+    }
+    int hc[2] = {0, 0};
+    fetch_ints(ctl, 2, hc);
+    const int nlev = hc[1];
+    auto give_up = [&]() { dev_free(d_level); dev_free(d_df_slots); dev_free(d_df_J); dev_free(d_df_a); d_df_slots = nullptr; d_df_J = nullptr; d_df_a = nullptr; return false; };
+    if (hc[0] != 0 || nlev <= 0 || nlev > 12000) return give_up();                  // (ran out of time; or more levels than the LDS histogram holds)
+    if (mode == 1 && nlev < 4) return give_up();
+    // ---- 2. rows per level, chunks per row ----
+    Temp<int> count((size_t)nlev), nch16((size_t)n), off((size_t)n + 1), tot(1);
+    zero_async(count, sizeof(int) * (size_t)nlev);
+    hipLaunchKernelGGL(df_level_count_kernel, dim3((unsigned)std::min(2 * cus, (n + 255) / 256)), dim3(256), sizeof(int) * (size_t)nlev, st, n, nlev,
+                       (const int *)d_level, (const int *)M->diag.I, count.p, nch16.p);
+    ELAG_LAUNCH_CHECK();
+    k::exclusive_scan(nch16, off, n, nullptr, tot);
+    std::vector<int> hcount((size_t)nlev);
+    stage_d2h(hcount.data(), count.p, sizeof(int) * (size_t)nlev);
+    const int nent = fetch_int(tot);
+    if (nent <= 0) return give_up();                                                 // (the scan's total does not fit an int)
+    std::vector<int> base((size_t)nlev + 1, 0);
+    long long npos = 0;
+    for (int l = 0; l < nlev; l++) { base[(size_t)l] = (int)npos; npos += ((long long)hcount[(size_t)l] + 3) / 4 * 4; }
+    if (npos >= (1ll << 30)) return give_up();
+    base[(size_t)nlev] = (int)npos;
+    // ---- 3. the slots: every row to a position of its level ----
+    Temp<int> dbase((size_t)nlev + 1), cursor((size_t)nlev);
+    stage_h2d(dbase.p, base.data(), sizeof(int) * ((size_t)nlev + 1));
+    zero_async(cursor, sizeof(int) * (size_t)nlev);
+    d_df_slots = dev_alloc<int>((size_t)npos * 4);
+    hipLaunchKernelGGL(df_fill_slots_kernel, dim3((unsigned)std::min<long long>((npos + 255) / 256, 2048)), dim3(256), 0, st, (int)npos, reinterpret_cast<int4s *>(d_df_slots));
+    hipLaunchKernelGGL(df_deal_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (const int *)d_level, (const int *)dbase.p, cursor.p,
+                       (const int *)off.p, (const int *)nch16.p, reinterpret_cast<int4s *>(d_df_slots));
+    ELAG_LAUNCH_CHECK();
+    // ---- 4. entries and flags; a row that is read without reading back sends the operator to the host path ----
+    d_df_J = dev_alloc<unsigned>((size_t)nent);
+    d_df_a = dev_alloc<double>((size_t)nent);
+    Temp<int> nanti(1);
+    zero_async(nanti, sizeof(int));
+    hipLaunchKernelGGL(df_build_kernel, dim3((unsigned)((npos * kLPR + 255) / 256)), dim3(256), 0, st, (int)npos, reinterpret_cast<const int4s *>(d_df_slots),
+                       (const int *)M->diag.I, (const int *)M->diag.J, (const double *)M->diag.a, (const int *)d_level, d_df_J, d_df_a, nanti.p);
+    ELAG_LAUNCH_CHECK();
+    const int na = fetch_int(nanti);
+    if (na != 0) return give_up();
+    dev_free(d_level);
+    df_npos = (int)npos;
+    num_levels = nlev;
+    finish_dataflow(nlev);
+    dataflow = true;
+    if (getenv("ELAG_HIP_SWEEP_VERBOSE"))
+        fprintf(stderr, "[elag_hip] sweep smoother type %d: n=%d, %d dependency levels; dataflow sweep: one launch per symmetric sweep (schedule built on the device)\n", type, n, nlev);
+    return true;
 }
 
 void SweepSmoother::launch_dataflow(const double *f, double *u)
@@ -1280,6 +1529,7 @@ __global__ __launch_bounds__(kStripThreads) void sweep_dense_strip_kernel(int nl
 
 bool SweepSmoother::apply_dense(const double *F, double *X, int m, bool zero_guess)
 {
+    if (!host_ready) setup_host(false);          // (the rows by dependency level: a schedule built on the device does not keep them on the host)
     if (type == ELAG_HIP_SMOOTHER_KACZMARZ || sor || h_lev_ptr.empty()) return false;
     const int n = M->nrows();
     if (n == 0 || m == 0) return true;
@@ -1398,6 +1648,10 @@ void SweepSmoother::apply(const double *f, double *&cur, double *&, bool zero_gu
         else if (M->needs_exchange()) par_halo_exchange(*M, cur);
         if (sor) { sweep_sor(f, cur); continue; }
         if (dataflow) { launch_dataflow(f, cur); continue; }
+        if (!host_ready) {
+            if (stream_is_capturing()) fail(ELAG_HIP_ERR_STATE, "internal: the launch-per-level plan of a Gauss-Seidel smoother is missing inside a graph capture");
+            setup_host(false);
+        }
         if (segments.size() == 1 && segments[0].max_rows < 0) { launch_segment(segments[0], +1, f, cur, true); continue; }
         if (lds_u && segments.size() == 1 && segments[0].max_rows == 0) {
             launch_segment(segments[0], +1, f, cur, true);        // forward then backward in one launch, u in LDS throughout

@@ -721,3 +721,40 @@ def test_dataflow_sweep_that_gives_up_later_is_reported_by_the_next_call():
     env.pop("ELAG_HIP_SWEEP_DATAFLOW_STALL_ROW", None)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert r.returncode == 0 and "REPORTED_OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("relax_type", [2, 6])
+def test_dataflow_schedule_built_on_the_device_gives_the_same_sweep(la, h1_k2, relax_type, capfd):
+    """large operators get their dependency levels, their schedule and their entries from kernels (SweepSmoother::setup_device: the levels by a
+    dataflow kernel in natural row order, the rows dealt to their levels in whatever order the atomics fall); forced here on a small one
+    (ELAG_HIP_SWEEP_DEVICE_SETUP_ROWS): the sweep is the oracle's sequential loop bit for bit, like the host-built schedule's -- and an operator
+    with an unsymmetric pattern goes back to the host path."""
+    A, _, _ = h1_k2
+    Ad = orc.diag_first(A)
+    dA = la.ParallelCSRMatrix.from_scipy(Ad)
+    rng = np.random.default_rng(44)
+    n = A.shape[0]
+    f, u0 = rng.standard_normal(n), rng.standard_normal(n)
+    ref = orc.OSmoother(orc.OParCSR(Ad), type=relax_type, sweeps=2)
+    ref.iterative_mode = True
+    ur = u0.copy(); ref.Mult(f, ur)
+    for xcd in ("0", "1"):
+        S = _with_env({"ELAG_HIP_SWEEP_DEVICE_SETUP_ROWS": "1000", "ELAG_HIP_SWEEP_DATAFLOW_XCD": xcd, "ELAG_HIP_SWEEP_VERBOSE": "1"},
+                      lambda: la.HypreSmootherWrapper(dA, relax_type, {"Sweeps": 2}))
+        assert "schedule built on the device" in capfd.readouterr().err
+        S.iterative_mode = True
+        for _ in range(2):
+            u = u0.copy(); S.Mult(f, u)
+            assert np.array_equal(u, ur)
+    # a pattern with one-way entries: the device path notices and leaves the operator to the host path (wait-only entries)
+    B = sp.random(1500, 1500, density=0.01, random_state=rng, format="lil")
+    B.setdiag(rng.uniform(2, 3, 1500))
+    Bd = orc.diag_first(B.tocsr())
+    S = _with_env({"ELAG_HIP_SWEEP_DEVICE_SETUP_ROWS": "1000", "ELAG_HIP_SWEEP_DATAFLOW": "2", "ELAG_HIP_SWEEP_VERBOSE": "1"},
+                  lambda: la.HypreSmootherWrapper(la.ParallelCSRMatrix.from_scipy(Bd), relax_type, {"Sweeps": 1}))
+    err = capfd.readouterr().err
+    assert "schedule built on the device" not in err and "dataflow sweep" in err
+    g, v0 = rng.standard_normal(1500), rng.standard_normal(1500)
+    v, vr = v0.copy(), v0.copy()
+    S.Mult(g, v); orc.OSmoother(orc.OParCSR(Bd), type=relax_type).Mult(g, vr)
+    assert np.array_equal(v, vr)
