@@ -11,6 +11,11 @@
 // storage order, so the results carry the CPU loop's bits.  Ghost values are exchanged once per symmetric sweep and stay frozen,
 // as in hypre.
 //
+// Two ways to run the levels.  (1) The dataflow sweep (round 5, sweep_dataflow_kernel below; the default where it applies): ONE launch per symmetric
+// sweep in which every row waits for exactly the rows it reads -- a hand-off between workgroups (~1.1-1.5 us) per dependency level instead of a launch;
+// for large operators the levels and the schedule themselves are computed by kernels of the same kind (setup_device).  (2) The launch plan of rounds
+// 1-4, kept for Kaczmarz, hypre's weighted branches, virtual ranks with a chain per block, several rank threads on one device, as the reference the
+// dataflow sweep is checked against, and behind ELAG_HIP_SWEEP_DATAFLOW=0:
 // Launch plan ("segments"): a level with more than kChainRows rows is one multi-workgroup launch; a run of consecutive smaller
 // levels is ONE launch of a single workgroup that walks the levels with a workgroup barrier in between (the waves of a
 // workgroup share their CU's L1, so values written before the barrier are read after it without leaving the CU).  All
