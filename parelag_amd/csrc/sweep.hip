@@ -488,8 +488,9 @@ constexpr int kDfC = 2;            // chunks of 16 entries a row keeps in regist
 // observed round-robin placement, whatever stays does the work under any other.  Tiles are not dealt in advance but taken from a counter
 // (the smallest tile not yet taken; a wavefront holds up to three and works them in order), which also lifts the residency condition:
 // a workgroup that has not started holds no tile, so the smallest unfinished tile is always in the hands of a running wavefront.
+// (launch bounds: four 256-thread workgroups per CU must fit -- the whole-chip form launches up to that many and needs every one of them resident)
 template <int MODE, bool XCD, bool TICKETS = XCD>
-__global__ __launch_bounds__(256) void sweep_dataflow_kernel(const DfArgs A)
+__global__ __launch_bounds__(256, 4) void sweep_dataflow_kernel(const DfArgs A)
 {
     const int tid = (int)(blockIdx.x * 256 + threadIdx.x), nthreads = (int)gridDim.x * 256;
     const int wave = tid >> 6, nwaves = nthreads >> 6;
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(256) void df_build_kernel(int npos, const int4s *__
 // its lower neighbours four at a time and waits for the ones that are not there yet.  lev[] holds level + 1 (0 = not yet), one agent-scope word per row.
 // The lanes of a task may depend on each other (rows i and i + 1 are often neighbours), so nobody spins alone: every lane of the wavefront makes one
 // attempt per trip of the loop and publishes inside it.  ctl: [0] abort, [1] the largest level + 1.
-__global__ __launch_bounds__(256) void df_levels_kernel(int n, const int *__restrict__ I, const int *__restrict__ J, int *lev, int *ctl, long long ticks)
+__global__ __launch_bounds__(256, 4) void df_levels_kernel(int n, const int *__restrict__ I, const int *__restrict__ J, int *lev, int *ctl, long long ticks)
 {
     const int wave = (int)((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (int)(gridDim.x * 4), lane = threadIdx.x & 63;
     int wmax = 0;
