@@ -314,7 +314,16 @@ struct elag_hip_hierarchy_s {
                 below += F.pre->chain_cost() + F.post->chain_cost() + 4.0;
                 const double nn = (double)F.A->nrows();
                 if (nn > max_ns) break;
-                if (nn * nn * 8.0 / 5.0e6 < below * 1.5) best = l;      // (bytes / (5 TB/s) in us against steps x 1.5 us)
+                const double dense_us = nn * nn * 8.0 / 5.0e6, chains_us = below * 1.5;      // (bytes / (5 TB/s) against steps x 1.5 us)
+                if (!(dense_us < chains_us)) continue;
+                // ... and the product has to be BUILT: four half-sweeps over the n x n block, nnz(A) x n entries of 8 bytes each at ~3 TB/s (6.5 ms for
+                // the 5 739-dof level of cube456 x3, against 0.2-0.5 ms a cycle saved).  ELAG_HIP_DENSE_TAIL_CYCLES = the number of cycles the caller
+                // expects to run on this hierarchy (default: many -- a tail wherever it is the cheaper cycle); with a small number the tail starts
+                // only where building it pays within that many cycles -- one PCG solve of the example is 6-16 cycles.
+                double horizon = 1.0e9;                                  // (read at every Finalize)
+                if (const char *e = getenv("ELAG_HIP_DENSE_TAIL_CYCLES")) horizon = atof(e) > 0 ? atof(e) : horizon;
+                const double build_us = 4.0 * (double)F.A->diag.nnz * nn * 8.0 / 3.0e6;
+                if (build_us <= horizon * (chains_us - dense_us)) best = l;
             }
             if (best >= 1 && (L < 0 || best < L)) {
                 if (dense_tail_by_sweeps(best)) { dense_level = best; return; }
