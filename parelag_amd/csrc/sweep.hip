@@ -788,33 +788,19 @@ __global__ __launch_bounds__(256, 4) void df_levels_kernel(int n, const int *__r
     if (lane == 0 && wmax > 0) atomicMax(ctl + 1, wmax);
 }
 
-// rows per level (lev[] = level + 1), through a histogram in LDS; chunks of 16 entries per row (at least one)
-__global__ __launch_bounds__(256) void df_level_count_kernel(int n, int nlev, const int *__restrict__ lev, const int *__restrict__ I, int *__restrict__ count,
-                                                             int *__restrict__ nch16)
-{
-    extern __shared__ int hist[];
-    for (int q = threadIdx.x; q < nlev; q += 256) hist[q] = 0;
-    __syncthreads();
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        atomicAdd(&hist[lev[i] - 1], 1);
-        nch16[i] = max(1, (I[i + 1] - I[i] + kLPR - 1) / kLPR) * kLPR;
-    }
-    __syncthreads();
-    for (int q = threadIdx.x; q < nlev; q += 256)
-        if (hist[q]) atomicAdd(&count[q], hist[q]);
-}
-
-// Every row takes a position of its level.  Any order inside a level is a schedule (its rows are independent), but not every order is a good one: a tile's
-// four rows should be neighbours in memory (with one atomic per row the positions fall in the order the atomics are served, and the x5 cycle was 14 %
-// slower than with the host's ascending rows).  So a workgroup sorts its 256 consecutive rows by level (a bitonic network in LDS on level << 8 | thread),
-// the first row of every run of equal levels reserves the run's positions with ONE atomic, and the rows of a run keep their order: runs of neighbours.
-__global__ __launch_bounds__(256) void df_deal_rows_kernel(int n, const int *__restrict__ lev, const int *__restrict__ base, int *__restrict__ cursor,
-                                                           const int *__restrict__ off, const int *__restrict__ nch16, int4s *__restrict__ slots)
+// Rows by (level, row) -- the host path's schedule, as a counting sort in three steps.  (1) df_runs_kernel: a workgroup sorts its 256 consecutive rows by
+// level (a bitonic network in LDS on level << 8 | thread), keeps the sorted keys, and the first row of every run of equal levels writes the run's length to
+// H[level * nwg + workgroup]; also the chunks of 16 entries per row (at least one).  (2) One exclusive scan over H: S[level * nwg + workgroup] = the rows of
+// lower levels plus the rows of this level in workgroups before this one.  (3) df_place_rows_kernel: position = the level's padded base + (S of the run -
+// S of the level's first workgroup) + place in the run.  No atomics: the same slots every time, ascending rows inside a level (with one atomic per row the x5
+// cycle was 14 % slower -- a tile's rows scattered over memory; with one per run 2 %).
+__global__ __launch_bounds__(256) void df_runs_kernel(int n, int nwg, const int *__restrict__ lev, const int *__restrict__ I, unsigned *__restrict__ skey,
+                                                      int *__restrict__ H, int *__restrict__ nch16)
 {
     __shared__ unsigned key[256];
-    __shared__ int start[256];
     const int t = threadIdx.x, i = blockIdx.x * 256 + t;
     key[t] = i < n ? ((unsigned)(lev[i] - 1) << 8) | (unsigned)t : 0xffffffffu;
+    if (i < n) nch16[i] = max(1, (I[i + 1] - I[i] + kLPR - 1) / kLPR) * kLPR;
     __syncthreads();
     for (int k = 2; k <= 256; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -827,25 +813,39 @@ __global__ __launch_bounds__(256) void df_deal_rows_kernel(int n, const int *__r
             __syncthreads();
         }
     const unsigned mine = key[t];
-    const bool real = mine != 0xffffffffu;
+    skey[(size_t)blockIdx.x * 256 + t] = mine;
+    if (mine == 0xffffffffu) return;
     const int l = (int)(mine >> 8);
-    const bool head = real && (t == 0 || (int)(key[t - 1] >> 8) != l);
-    start[t] = head ? t : -1;
-    __syncthreads();
-    // the head of my run: the nearest head at or below t (runs are short: a few steps)
-    int h = t;
-    while (real && start[h] < 0) h--;
-    __syncthreads();
-    if (head) {
+    if (t == 0 || (int)(key[t - 1] >> 8) != l) {
         int len = 1;
         while (t + len < 256 && key[t + len] != 0xffffffffu && (int)(key[t + len] >> 8) == l) len++;
-        start[t] = base[l] + atomicAdd(&cursor[l], len);
+        H[(size_t)l * nwg + blockIdx.x] = len;
     }
+}
+
+// the first entry of every level's row of S (nlev + 1 values: the rows of the levels before it)
+__global__ void df_level_starts_kernel(int nlev, int nwg, const int *__restrict__ S, int *__restrict__ start)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l <= nlev) start[l] = S[(size_t)l * nwg];
+}
+
+__global__ __launch_bounds__(256) void df_place_rows_kernel(int n, int nwg, const unsigned *__restrict__ skey, const int *__restrict__ S,
+                                                            const int *__restrict__ start, const int *__restrict__ base, const int *__restrict__ off,
+                                                            const int *__restrict__ nch16, int4s *__restrict__ slots)
+{
+    __shared__ unsigned key[256];
+    const int t = threadIdx.x;
+    const unsigned mine = skey[(size_t)blockIdx.x * 256 + t];
+    key[t] = mine;
     __syncthreads();
-    if (real) {
-        const int row = blockIdx.x * 256 + (int)(mine & 255u);
-        slots[start[h] + (t - h)] = int4s{row, off[row], nch16[row] / kLPR, 0};
-    }
+    if (mine == 0xffffffffu) return;
+    const int l = (int)(mine >> 8);
+    int h = t;                                                         // the head of my run (runs are short: a few steps)
+    while (h > 0 && (int)(key[h - 1] >> 8) == l) h--;
+    const int row = blockIdx.x * 256 + (int)(mine & 255u);
+    const int pos = base[l] + (S[(size_t)l * nwg + blockIdx.x] - start[l]) + (t - h);
+    slots[pos] = int4s{row, off[row], nch16[row] / kLPR, 0};
 }
 
 __global__ void df_fill_slots_kernel(int npos, int4s *__restrict__ slots)
@@ -1387,8 +1387,8 @@ void SweepSmoother::setup_dataflow(const std::vector<int> &I, const std::vector<
 
 bool SweepSmoother::setup_device()
 {
-    // from 20 000 rows: measured on the 42 309-row level of cube456 x3 the kernels take 1.4-1.8 ms against the host's 2.5 (the sweep itself 268 against 262 us: the
-    // rows of a level are no longer ascending), on 5 739 rows 0.42 against 0.46; below, the host path also leaves the launch-per-level plan a dense tail is built with
+    // from 20 000 rows: measured on the 42 309-row level of cube456 x3 the kernels take 1.8 ms against the host's 2.5 (same schedule, same sweep), on 5 739 rows 0.42
+    // against 0.46; below, the host path also leaves the launch-per-level plan a dense tail is built with
     int min_rows = 20000;                              // (read at every setup: a test forces the kernels on a small operator)
     if (const char *e = getenv("ELAG_HIP_SWEEP_DEVICE_SETUP_ROWS")) min_rows = atoi(e);
     const int mode = dataflow_mode();
@@ -1419,32 +1419,37 @@ bool SweepSmoother::setup_device()
     fetch_ints(ctl, 2, hc);
     const int nlev = hc[1];
     auto give_up = [&]() { dev_free(d_level); dev_free(d_df_slots); dev_free(d_df_J); dev_free(d_df_a); d_df_slots = nullptr; d_df_J = nullptr; d_df_a = nullptr; return false; };
-    if (hc[0] != 0 || nlev <= 0 || nlev > 12000) return give_up();                  // (ran out of time; or more levels than the LDS histogram holds)
+    if (hc[0] != 0 || nlev <= 0) return give_up();                                  // (ran out of time)
     if (mode == 1 && nlev < 4) return give_up();
-    // ---- 2. rows per level, chunks per row ----
-    Temp<int> count((size_t)nlev), nch16((size_t)n), off((size_t)n + 1), tot(1);
-    zero_async(count, sizeof(int) * (size_t)nlev);
-    hipLaunchKernelGGL(df_level_count_kernel, dim3((unsigned)std::min(2 * cus, (n + 255) / 256)), dim3(256), sizeof(int) * (size_t)nlev, st, n, nlev,
-                       (const int *)d_level, (const int *)M->diag.I, count.p, nch16.p);
+    // ---- 2. rows by (level, row): runs per workgroup, one scan, placement (df_runs_kernel) ----
+    const int nwg = (n + 255) / 256;
+    const long long hsize = (long long)nlev * nwg;
+    if (hsize + 1 >= (1ll << 30)) return give_up();
+    Temp<unsigned> skey((size_t)nwg * 256);
+    Temp<int> H((size_t)hsize + 1), S((size_t)hsize + 2), nch16((size_t)n), off((size_t)n + 1), tot(1), dstart((size_t)nlev + 1);
+    zero_async(H, sizeof(int) * ((size_t)hsize + 1));
+    hipLaunchKernelGGL(df_runs_kernel, dim3((unsigned)nwg), dim3(256), 0, st, n, nwg, (const int *)d_level, (const int *)M->diag.I, skey.p, H.p, nch16.p);
     ELAG_LAUNCH_CHECK();
+    k::exclusive_scan(H, S, (int)hsize + 1);                                          // (S[nlev * nwg] = n)
     k::exclusive_scan(nch16, off, n, nullptr, tot);
-    std::vector<int> hcount((size_t)nlev);
-    stage_d2h(hcount.data(), count.p, sizeof(int) * (size_t)nlev);
+    hipLaunchKernelGGL(df_level_starts_kernel, dim3((unsigned)((nlev + 256) / 256)), dim3(256), 0, st, nlev, nwg, (const int *)S.p, dstart.p);
+    ELAG_LAUNCH_CHECK();
+    std::vector<int> hstart((size_t)nlev + 1);
+    stage_d2h(hstart.data(), dstart.p, sizeof(int) * ((size_t)nlev + 1));
     const int nent = fetch_int(tot);
-    if (nent <= 0) return give_up();                                                 // (the scan's total does not fit an int)
+    if (nent <= 0 || hstart[(size_t)nlev] != n) return give_up();                    // (the scan's total does not fit an int; or the runs do not add up)
     std::vector<int> base((size_t)nlev + 1, 0);
     long long npos = 0;
-    for (int l = 0; l < nlev; l++) { base[(size_t)l] = (int)npos; npos += ((long long)hcount[(size_t)l] + 3) / 4 * 4; }
+    for (int l = 0; l < nlev; l++) { base[(size_t)l] = (int)npos; npos += ((long long)(hstart[(size_t)l + 1] - hstart[(size_t)l]) + 3) / 4 * 4; }
     if (npos >= (1ll << 30)) return give_up();
     base[(size_t)nlev] = (int)npos;
-    // ---- 3. the slots: every row to a position of its level ----
-    Temp<int> dbase((size_t)nlev + 1), cursor((size_t)nlev);
+    // ---- 3. the slots ----
+    Temp<int> dbase((size_t)nlev + 1);
     stage_h2d(dbase.p, base.data(), sizeof(int) * ((size_t)nlev + 1));
-    zero_async(cursor, sizeof(int) * (size_t)nlev);
     d_df_slots = dev_alloc<int>((size_t)npos * 4);
     hipLaunchKernelGGL(df_fill_slots_kernel, dim3((unsigned)std::min<long long>((npos + 255) / 256, 2048)), dim3(256), 0, st, (int)npos, reinterpret_cast<int4s *>(d_df_slots));
-    hipLaunchKernelGGL(df_deal_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (const int *)d_level, (const int *)dbase.p, cursor.p,
-                       (const int *)off.p, (const int *)nch16.p, reinterpret_cast<int4s *>(d_df_slots));
+    hipLaunchKernelGGL(df_place_rows_kernel, dim3((unsigned)nwg), dim3(256), 0, st, n, nwg, (const unsigned *)skey.p, (const int *)S.p, (const int *)dstart.p,
+                       (const int *)dbase.p, (const int *)off.p, (const int *)nch16.p, reinterpret_cast<int4s *>(d_df_slots));
     ELAG_LAUNCH_CHECK();
     // ---- 4. entries and flags; a row that is read without reading back sends the operator to the host path ----
     d_df_J = dev_alloc<unsigned>((size_t)nent);
