@@ -622,6 +622,13 @@ ELAG_HIP_API int elag_hip_host_minimal_intersection_sets(int64_t nrow, const int
                                                          const int32_t *attr, int64_t *mis, double *ori, int64_t *n_sets);
 /* Every row of (ptr, idx) sorted in place by (key[id], id): DofAgglomeration's reorderRow (src/amge/DOFAgglomeration.cpp:33-131). */
 ELAG_HIP_API int elag_hip_host_sort_rows_by_key(int64_t nrow, const int64_t *ptr, int64_t *idx, int64_t nid, const int64_t *key);
+/* entity_dof[c] of one form (DofHandler's entity -> dof table, src/amge/DofHandler.cpp:105-137 / DOFAgglomeration.cpp: rows = the entities of codimension c):
+ * for every layer q = the codimensions 3 ... c + 1 that carry dofs of the form, the interior dofs of the sub-entities conn_q(r, :) in connectivity order
+ * (base[q] + dof_off[q][e] ... dof_off[q][e + 1]), then the entity's own interior dofs (own_base + own_off[r] ...).  Call once with out_idx == NULL for
+ * the row pointers (out_ptr[nrow] = the size of out_idx), then again to fill. */
+ELAG_HIP_API int elag_hip_host_entity_dof_table(int64_t nrow, int nlayers, const int64_t *const *conn_ptr, const int64_t *const *conn_idx,
+                                                const int64_t *const *dof_off, const int64_t *base, const int64_t *own_off, int64_t own_base,
+                                                int64_t *out_ptr, int64_t *out_idx);
 /* idx = concatenation of the ranges [starts[i], starts[i] + counts[i]), owner[k] = i of entry k. */
 ELAG_HIP_API int elag_hip_host_expand_ranges(int64_t n, const int64_t *starts, const int64_t *counts, int64_t total, int64_t *idx, int64_t *owner);
 

@@ -162,6 +162,7 @@ _SIGNATURES = {
     "elag_hip_host_lookup_find": [_i64, _p, _p, _i64, _i64, _p, _p, _p],
     "elag_hip_host_gather_dense": [_i64, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p],
     "elag_hip_host_expand_ranges": [_i64, _p, _p, _i64, _p, _p],
+    "elag_hip_host_entity_dof_table": [_i64, _i, _p, _p, _p, _p, _p, _i64, _p, _p],
     "elag_hip_host_set_threads": [_i],
     "elag_hip_host_set_min_work": [_i64],
     "elag_hip_host_keep_pages": [_i],

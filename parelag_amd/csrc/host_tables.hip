@@ -198,6 +198,47 @@ ELAG_HIP_API int elag_hip_host_expand_ranges(int64_t n, const int64_t *starts, c
     });
 }
 
+// entity_dof of one form and one codimension: row r = for every layer q (the codimensions 3 ... c + 1 that carry dofs of the form, in that order) the
+// interior dofs of the entities conn_q(r, :) in connectivity order -- base[q] + dof_off[q][e] ... dof_off[q][e + 1] -- then the entity's own interior dofs
+// own_base + own_off[r] ... own_off[r + 1].  out_idx == NULL: only the row pointers (out_ptr[nrow]: the size to allocate).
+ELAG_HIP_API int elag_hip_host_entity_dof_table(int64_t nrow, int nlayers, const int64_t *const *conn_ptr, const int64_t *const *conn_idx,
+                                                const int64_t *const *dof_off, const int64_t *base, const int64_t *own_off, int64_t own_base,
+                                                int64_t *out_ptr, int64_t *out_idx)
+{
+    return guarded([&] {
+        ELAG_REQUIRE(nrow >= 0 && nlayers >= 0 && out_ptr && own_off && (nlayers == 0 || (conn_ptr && conn_idx && dof_off && base)), "entity_dof_table: null or negative argument");
+        for (int q = 0; q < nlayers; q++) ELAG_REQUIRE(conn_ptr[q] && dof_off[q] && (conn_ptr[q][nrow] == 0 || conn_idx[q]), "entity_dof_table: null layer %d", q);
+        int64_t work = own_off[nrow] - own_off[0];
+        for (int q = 0; q < nlayers; q++) work += 2 * conn_ptr[q][nrow];
+        const int64_t grain = grain_for(nrow, 2 * work + nrow);
+        if (!out_idx) {
+            parallel_ranges(nrow, [&](int64_t b, int64_t e) {
+                for (int64_t r = b; r < e; r++) {
+                    int64_t cnt = own_off[r + 1] - own_off[r];
+                    for (int q = 0; q < nlayers; q++)
+                        for (int64_t k = conn_ptr[q][r]; k < conn_ptr[q][r + 1]; k++) { const int64_t en = conn_idx[q][k]; cnt += dof_off[q][en + 1] - dof_off[q][en]; }
+                    out_ptr[r + 1] = cnt;
+                }
+            }, grain);
+            out_ptr[0] = 0;
+            for (int64_t r = 0; r < nrow; r++) out_ptr[r + 1] += out_ptr[r];
+            return;
+        }
+        parallel_ranges(nrow, [&](int64_t b, int64_t e) {
+            for (int64_t r = b; r < e; r++) {
+                int64_t w = out_ptr[r];
+                for (int q = 0; q < nlayers; q++)
+                    for (int64_t k = conn_ptr[q][r]; k < conn_ptr[q][r + 1]; k++) {
+                        const int64_t en = conn_idx[q][k];
+                        for (int64_t d = dof_off[q][en]; d < dof_off[q][en + 1]; d++) out_idx[w++] = base[q] + d;
+                    }
+                for (int64_t d = own_off[r]; d < own_off[r + 1]; d++) out_idx[w++] = own_base + d;
+                if (w != out_ptr[r + 1]) throw Error(ELAG_HIP_ERR_ARG, "entity_dof_table: the row pointers do not belong to these tables");
+            }
+        }, grain);
+    });
+}
+
 // Triplets of a sparse matrix whose entity blocks are dense (mfem's SetSubMatrix / AddSubMatrix of every entity's local matrix,
 // exact zeros dropped): block e couples rows_idx[rows_ptr[e]..] with cols_idx[cols_ptr[e]..]; its values sit in consecutive slots
 // of (slot_rows ? slot_rows[e] : nrows_e) * ld[e] doubles -- column-major (column c at c * nrows_e) or row-major (row r at r * ld[e]).

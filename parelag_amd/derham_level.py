@@ -66,6 +66,33 @@ def _product(a_ptr, a_idx, b_ptr, b_idx, a_sgn=None, b_sgn=None):
     return out_ptr, out_idx[:n].copy(), (out_sgn[:n].copy() if signed else np.ones(n))
 
 
+def entity_dof_table(nrow, layers, own_off, own_base):
+    """``entity_dof`` rows: for every layer ((ptr, idx) of the rows' sub-entities, the sub-entities' interior dof offsets, their base) the dofs in
+    connectivity order, then the rows' own interior dofs.  Native host code (``csrc/host_tables.hip``, ``elag_hip_host_entity_dof_table``); round 5 -- the
+    whole-array numpy form of it (ranges expanded, counted with bincount over repeat, rows concatenated) was the largest single piece of a coarsening."""
+    import ctypes as C
+    from . import _lib
+    from .amge import _ptr
+    c64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+    keep = [(c64(p), c64(i), c64(off)) for (p, i), off, _ in layers]
+    nl = len(keep)
+    arr = lambda k: (C.c_void_p * max(nl, 1))(*[t[k].ctypes.data for t in keep]) if nl else None
+    cp, ci, do = arr(0), arr(1), arr(2)
+    base = c64([b for _, _, b in layers]) if nl else np.zeros(1, dtype=np.int64)
+    own = c64(own_off)
+    if len(own) != nrow + 1 or any(len(t[0]) != nrow + 1 for t in keep):
+        raise ValueError("entity_dof_table: a table does not have one row per entity")
+    for p_, i_, off_ in keep:
+        if i_.size and (i_.min() < 0 or i_.max() + 1 >= len(off_)):
+            raise ValueError("entity_dof_table: a connectivity entry is outside its layer's dof offsets")
+    ptr = np.empty(nrow + 1, dtype=np.int64)
+    lib = _lib.load()
+    _lib.check(lib.elag_hip_host_entity_dof_table(nrow, nl, cp, ci, do, _ptr(base), _ptr(own), int(own_base), _ptr(ptr), None))
+    idx = np.empty(int(ptr[-1]), dtype=np.int64)
+    _lib.check(lib.elag_hip_host_entity_dof_table(nrow, nl, cp, ci, do, _ptr(base), _ptr(own), int(own_base), _ptr(ptr), _ptr(idx)))
+    return ptr, idx
+
+
 def _concat_rows(tables, nrow):
     """Row-wise concatenation of ragged tables [(ptr, idx), ...] in the given order."""
     expand_ranges = _expand_ranges
@@ -102,22 +129,10 @@ class _Tables:
     def edof(self, j, c):
         """(ptr, idx) of ``entity_dof[c]`` of form j: peaks', ridges', facets' dofs in connectivity order, then interior."""
         if (j, c) not in self._edof:
-            expand_ranges = _expand_ranges
             lv = self.lv
             cb = lv.cb(j)
-            tabs = []
-            for c2 in range(3, c, -1):
-                if c2 > cb:
-                    continue
-                p, i = self.conn(c, c2)
-                ip = lv.idof[j][c2]
-                d, own = expand_ranges(lv.base(j, c2) + ip[i], np.diff(ip)[i])
-                cnt = np.bincount(np.repeat(np.arange(len(p) - 1, dtype=np.int64), np.diff(p))[own], minlength=len(p) - 1)
-                tabs.append((ptr_from_counts(cnt), d))
-            ip = lv.idof[j][c]
-            d, _ = expand_ranges(lv.base(j, c) + ip[:-1], np.diff(ip))
-            tabs.append((ip.astype(np.int64), d))
-            self._edof[(j, c)] = _concat_rows(tabs, lv.n[c])
+            layers = [(self.conn(c, c2), lv.idof[j][c2], lv.base(j, c2)) for c2 in range(3, c, -1) if c2 <= cb]
+            self._edof[(j, c)] = entity_dof_table(lv.n[c], layers, lv.idof[j][c], lv.base(j, c))
         return self._edof[(j, c)]
 
 

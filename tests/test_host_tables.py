@@ -366,3 +366,45 @@ def test_agglomerate_table_functions_on_empty_input():
     assert lib.elag_hip_host_block_families_to_csr(0, None, 3, 2, p(indptr), None, None, None) == 0 and indptr.tolist() == [0, 0, 0, 0]
     M = amge._blocks_to_csr_sets([], (3, 2))
     assert M.shape == (3, 2) and M.nnz == 0
+
+
+def test_entity_dof_table_equals_the_whole_array_statement():
+    """elag_hip_host_entity_dof_table (round 5: the entity -> dof rows of DofHandler, layer by layer in connectivity order, then the entity's own interior
+    dofs) against the numpy form it replaced -- ranges expanded, counted with bincount over repeat, rows concatenated -- on random tables: empty
+    rows, empty layers, no layer at all, entities without dofs; and with one thread and several."""
+    import numpy as np
+    from parelag_amd import derham_level as dl, _lib
+
+    def reference(nrow, layers, own_off, own_base):
+        tabs = []
+        for (p, i), ip, base in layers:
+            d, own = dl._expand_ranges(base + np.asarray(ip)[i], np.diff(ip)[i])
+            cnt = np.bincount(np.repeat(np.arange(len(p) - 1, dtype=np.int64), np.diff(p))[own], minlength=len(p) - 1)
+            tabs.append((dl.ptr_from_counts(cnt), d))
+        ip = np.asarray(own_off)
+        d, _ = dl._expand_ranges(own_base + ip[:-1], np.diff(ip))
+        tabs.append((ip.astype(np.int64), d))
+        return dl._concat_rows(tabs, nrow)
+
+    rng = np.random.default_rng(3)
+    lib = _lib.load()
+    for threads in (1, 6):
+        lib.elag_hip_host_set_threads(threads)
+        old = lib.elag_hip_host_set_min_work(64)
+        try:
+            for nrow in (0, 1, 7, 300, 20000):
+                layers = []
+                for _q in range(int(rng.integers(0, 4))):
+                    n2 = int(rng.integers(1, 60))
+                    p = np.concatenate([[0], np.cumsum(rng.integers(0, 4, nrow))]).astype(np.int64)
+                    i = rng.integers(0, n2, int(p[-1])).astype(np.int64)
+                    off = np.concatenate([[0], np.cumsum(rng.integers(0, 3, n2))]).astype(np.int64)
+                    layers.append(((p, i), off, int(rng.integers(0, 1000))))
+                own = np.concatenate([[0], np.cumsum(rng.integers(0, 3, nrow))]).astype(np.int64)
+                got, ref = dl.entity_dof_table(nrow, layers, own, 17), reference(nrow, layers, own, 17)
+                assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+        finally:
+            lib.elag_hip_host_set_min_work(old)
+            lib.elag_hip_host_set_threads(0)
+    with pytest.raises(ValueError):
+        dl.entity_dof_table(3, [((np.array([0, 1, 2, 3]), np.array([0, 5, 1])), np.array([0, 1, 2]), 0)], np.zeros(4, dtype=np.int64), 0)
