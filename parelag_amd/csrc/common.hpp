@@ -50,6 +50,7 @@ bool debug_sync();
 
 // Wrap an ABI body: translate exceptions to status codes.
 void check_device_error();   // throws when a kernel has reported a failure through Context::h_dev_err (context.hip)
+int device_error_codes_seen();   // bit c set: a kernel of this process has reported code c at some point (the callers that launched it take their fallback from then on)
 template <class F>
 int guarded(F &&f) noexcept
 {

@@ -570,6 +570,8 @@ void fetch_ints(const int *dev, int count, int *out)
     if (h[31] != seq) fail(ELAG_HIP_ERR_HIP, "fetch_ints: the stream drained without the words arriving");
     for (int i = 0; i < count; i++) out[i] = h[i];
 }
+static std::atomic<int> g_dev_err_codes{0};
+int device_error_codes_seen() { return g_dev_err_codes.load(); }
 void check_device_error()
 {
     Context &c = ctx();
@@ -577,6 +579,11 @@ void check_device_error()
     const int code = *reinterpret_cast<volatile int *>(c.h_dev_err);
     if (code == 0) return;
     *reinterpret_cast<volatile int *>(c.h_dev_err) = 0;
+    if (code > 0 && code < 31) g_dev_err_codes.fetch_or(1 << code);
+    if (code == 2)
+        fail(ELAG_HIP_ERR_STATE, "the Gram-Schmidt chain of a GMRES step gave up waiting for a partial sum (its workgroups were not all resident: another process "
+                                 "held the device): the solve that was running is not valid; the solvers of this process use a launch per link from here on "
+                                 "(ELAG_HIP_GMRES_CHAIN=0 does from the start)");
     if (code == 1)
         fail(ELAG_HIP_ERR_STATE, "a Gauss-Seidel dataflow sweep gave up waiting for a row it depends on (its workgroups were not all resident, or another such "
                                  "kernel held the device): results since the last successful call are not valid; ELAG_HIP_SWEEP_DATAFLOW=0 keeps the launch-per-level sweeps");

@@ -14,9 +14,11 @@
 // predicated on its `done` flag.  The host enqueues iterations blindly (CG: one captured hipGraph per iteration) and
 // only polls the flag every `check_every` iterations; once `done` is set the remaining enqueued kernels are no-ops, so
 // the iterate and the iteration count are those of the reference's sequential loop -- operation by operation for CG, BiCGSTAB, MINRES,
-// the stationary iteration and GMRES / FGMRES with their one-vector modified Gram-Schmidt chain (the default; the only chain of a distributed
-// operator).  ELAG_HIP_GMRES_PAIR=1 switches a rank-local GMRES to a two-vector Gram-Schmidt chain that evaluates MGS's coefficients in
-// another order (see gmres_orth_pair_kernel): faster, the same iteration in exact arithmetic, not MFEM's rounding.
+// the stationary iteration and GMRES / FGMRES with MFEM's modified Gram-Schmidt loop, one basis vector at a time.  On one rank a GMRES step's
+// whole chain, its norm and the new basis vector are ONE launch (gmres_chain_kernel: w stays in registers, the inner products' partial sums
+// go from workgroup to workgroup as tagged granules); ELAG_HIP_GMRES_CHAIN=0, a distributed operator or more than 1.5 M unknowns: a launch per
+// link, the same bits.  (A two-vector chain that evaluated MGS's coefficients in another order -- rounds 4 and 5, opt-in in round 5 -- is gone:
+// slower than the chain in one launch and not MFEM's rounding.)
 #include <cmath>
 
 #include <chrono>
@@ -41,6 +43,7 @@ enum { F_DONE, F_CONVERGED, F_FINAL_ITER, F_ITER, F_PENDING, F_ITER2, F_STEP, F_
 struct KState {
     int fl[F_COUNT];          // (first: the flags and the scalars the host reads -- S_NOM ... S_FINAL_NORM -- are 24 consecutive words, one fetch_ints)
     double sc[S_COUNT];
+    int chain[4];             // gmres_chain_kernel: [0] launches completed (the tag of the next launch's partial sums is this + 1), [1] workgroups out, [2] somebody gave up
 };
 constexpr int kPollWords = F_COUNT + 2 * (S_FINAL_NORM + 1);
 static_assert(F_COUNT % 2 == 0 && kPollWords <= 30, "the polled words: the flags, then the leading scalars");
@@ -164,10 +167,31 @@ __global__ void gmres_orth_kernel(int n, const KState *__restrict__ st, double *
 // (<w, v_{k+1}>, or <w, w> after the last vector).  i+2 launches and 4 vector passes per link instead of 3(i+1) and 5.
 constexpr int kPart = 512;   // partial sums per dot (= blocks of the fused kernels)
 
+// The sum of a wavefront's 64 values, the same on every lane: an inclusive scan along each row of 16 lanes (row_shr 1, 2, 4, 8), the rows'
+// totals carried over by row_bcast 15 and 31 -- six DPP steps of ~20 cycles where six ds_bpermute exchanges took ~0.5 us (measured in
+// gmres_chain_kernel, whose every link waits for two such sums).  A fixed tree: ((a15 + a14) + (a13 + a12)) + ... per row, (row3 + row2) +
+// (row1 + row0) at lane 63.  Every inner product of this file is summed through it, so the kernels that must agree bit for bit do.
+template <int CTRL, int ROWS>
+__device__ inline double dpp_take(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double wave_sum(double v)
+{
+    v += dpp_take<0x111, 0xf>(v);     // row_shr:1
+    v += dpp_take<0x112, 0xf>(v);     // row_shr:2
+    v += dpp_take<0x114, 0xf>(v);     // row_shr:4
+    v += dpp_take<0x118, 0xf>(v);     // row_shr:8   (lane 15 of every row: the row's sum)
+    v += dpp_take<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+    v += dpp_take<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3   (lane 63: the wavefront's sum)
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 __device__ inline double block_sum_256(double v, double *sh)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
     const double r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
@@ -175,12 +199,11 @@ __device__ inline double block_sum_256(double v, double *sh)
     return r;   // same value on every thread
 }
 
-__device__ inline double sum_partials(const double *__restrict__ part, double *sh)
-{
-    double v = 0.0;
-    for (int q = threadIdx.x; q < kPart; q += kB) v += part[q];
-    return block_sum_256(v, sh);
-}
+// the kPart partial sums of an inner product, added up: thread q takes the pair (2q, 2q + 1) -- the two virtual blocks of one workgroup of
+// gmres_chain_kernel, which hands their sum over as one value --, then the block's tree
+__device__ inline double pair_of(const double *__restrict__ part) { return part[2 * threadIdx.x] + part[2 * threadIdx.x + 1]; }
+static_assert(kPart == 2 * kB, "pair_of(): one pair of partial sums per thread");
+__device__ inline double sum_partials(const double *__restrict__ part, double *sh) { return block_sum_256(pair_of(part), sh); }
 
 // part_out[b] = partial sums of <w, v> (no update): first link of a step
 __global__ void __launch_bounds__(kB) gmres_dot0_kernel(int n, const KState *__restrict__ st, const double *__restrict__ w,
@@ -213,8 +236,7 @@ __global__ void __launch_bounds__(kB) gmres_orth_fused_kernel(int n, const KStat
         pw[u] = 0.0; pv[u] = 0.0; pn[u] = 0.0;
         if (t < n) { pw[u] = w[t]; pv[u] = vk[t]; if (vnext) pn[u] = vnext[t]; }
     }
-    double pp = 0.0;
-    for (int q = threadIdx.x; q < kPart; q += kB) pp += part_in[q];
+    const double pp = pair_of(part_in);
     if (st->fl[F_DONE]) return;
     const double h = block_sum_256(pp, sh);
     if (blockIdx.x == 0 && threadIdx.x == 0) Hm(hs, m, k, i) = h;
@@ -237,86 +259,6 @@ __global__ void __launch_bounds__(kB) gmres_orth_fused_kernel(int n, const KStat
     if (threadIdx.x == 0) part_out[blockIdx.x] = acc;
 }
 
-// ---- the same chain two basis vectors per link --------------------------------------------------------------------------------------
-// An inner step of GMRES(50) on the Darcy system spends 30 % of its time in the chain above: i + 1 links of ~6 us, each one pass over w and two
-// basis vectors.  Two vectors per link: with d_a = <w, v_a>, d_b = <w, v_b>, g = <v_a, v_b> taken in the PREVIOUS link's pass,
-//     H(a,i) = d_a,   H(b,i) = <w - H(a,i) v_a, v_b> = d_b - H(a,i) g,   w <- (w - H(a,i) v_a) - H(b,i) v_b
-// -- modified Gram-Schmidt's coefficients in exact arithmetic (g is the computed inner product of the two vectors, not assumed zero), evaluated
-// in another order.  Half the links, 6 vector passes per two columns instead of 8: cube456 x3 Darcy, GMRES(50), 32 iterations: 9.55 against
-// 10.2 ms.  part_*: three runs of kPart partial sums (d_a, d_b, g).
-//
-// OPT-IN (ELAG_HIP_GMRES_PAIR=1).  d_b is a dot with the vector BEFORE v_a's component left it, so d_b - H(a,i) g cancels down from
-// |w| to |w - H(a,i) v_a| and carries an error of eps |w| where MGS's own dot has eps |w - H(a,i) v_a|: classical Gram-Schmidt inside the pair,
-// worse the closer w is to v_a.  Taking the three inner products and the difference in double-double repairs that (measured in round 5:
-// the coefficient is then MGS's to the last bit or two) but costs more than the halved chain saves -- 10.3 ms, slower than the one-vector
-// chain -- so the default is MFEM's loop operation by operation, on one rank as on many, and this chain is a switch for well-conditioned
-// bases (tests/test_gpu_krylov.py runs both on an operator that is an involution up to 1e-8, where w ~ v_a at step 1).
-__global__ void __launch_bounds__(kB) gmres_dot0_pair_kernel(int n, const KState *__restrict__ st, const double *__restrict__ w,
-                                                             const double *__restrict__ va, const double *__restrict__ vb, double *__restrict__ part_out)
-{
-    __shared__ double sh[4];
-    if (st->fl[F_DONE]) return;
-    double da = 0.0, db = 0.0, g = 0.0;
-    for (int t = blockIdx.x * kB + threadIdx.x; t < n; t += kPart * kB) {
-        const double wt = w[t], a = va[t];
-        da += wt * a;
-        if (vb) { const double b = vb[t]; db += wt * b; g += a * b; }
-    }
-    da = block_sum_256(da, sh);
-    if (vb) { db = block_sum_256(db, sh); g = block_sum_256(g, sh); }
-    if (threadIdx.x == 0) { part_out[blockIdx.x] = da; if (vb) { part_out[kPart + blockIdx.x] = db; part_out[2 * kPart + blockIdx.x] = g; } }
-}
-
-// columns ka (and ka + 1 when vb != nullptr) of step i; the next link's columns na / nb (nullptr: none; both nullptr: <w, w> for the norm)
-__global__ void __launch_bounds__(kB) gmres_orth_pair_kernel(int n, const KState *__restrict__ st, double *__restrict__ hs, int m, int ka, int i,
-                                                             double *__restrict__ w, const double *__restrict__ va, const double *__restrict__ vb,
-                                                             const double *__restrict__ na, const double *__restrict__ nb,
-                                                             const double *__restrict__ part_in, double *__restrict__ part_out)
-{
-    __shared__ double sh[4];
-    constexpr int kPre = 4;
-    const int t0 = blockIdx.x * kB + threadIdx.x, stride = kPart * kB;
-    double pw[kPre], pa[kPre], pb[kPre], p1[kPre], p2[kPre];
-#pragma unroll
-    for (int u = 0; u < kPre; u++) {
-        const int t = t0 + u * stride;
-        pw[u] = pa[u] = pb[u] = p1[u] = p2[u] = 0.0;
-        if (t < n) {
-            pw[u] = w[t]; pa[u] = va[t];
-            if (vb) pb[u] = vb[t];
-            if (na) p1[u] = na[t];
-            if (nb) p2[u] = nb[t];
-        }
-    }
-    double sa = 0.0, sb = 0.0, sg = 0.0;
-    for (int q = threadIdx.x; q < kPart; q += kB) {
-        sa += part_in[q];
-        if (vb) { sb += part_in[kPart + q]; sg += part_in[2 * kPart + q]; }
-    }
-    if (st->fl[F_DONE]) return;
-    const double ha = block_sum_256(sa, sh);
-    double hb = 0.0;
-    if (vb) { const double db = block_sum_256(sb, sh), g = block_sum_256(sg, sh); hb = db - ha * g; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { Hm(hs, m, ka, i) = ha; if (vb) Hm(hs, m, ka + 1, i) = hb; }
-    double d1 = 0.0, d2 = 0.0, gg = 0.0;
-    auto one = [&](double wt, double a, double b, double x1, double x2, int t) {
-        double wn = wt + (-ha) * a;
-        if (vb) wn = wn + (-hb) * b;
-        w[t] = wn;
-        if (na) { d1 += wn * x1; if (nb) { d2 += wn * x2; gg += x1 * x2; } }
-        else d1 += wn * wn;
-    };
-#pragma unroll
-    for (int u = 0; u < kPre; u++) {
-        const int t = t0 + u * stride;
-        if (t < n) one(pw[u], pa[u], pb[u], p1[u], p2[u], t);
-    }
-    for (int t = t0 + kPre * stride; t < n; t += stride) one(w[t], va[t], vb ? vb[t] : 0.0, na ? na[t] : 0.0, nb ? nb[t] : 0.0, t);
-    d1 = block_sum_256(d1, sh);
-    if (nb) { d2 = block_sum_256(d2, sh); gg = block_sum_256(gg, sh); }
-    if (threadIdx.x == 0) { part_out[blockIdx.x] = d1; if (nb) { part_out[kPart + blockIdx.x] = d2; part_out[2 * kPart + blockIdx.x] = gg; } }
-}
-
 // H(i+1,i) = sqrt(sum(part_in))
 __global__ void __launch_bounds__(kB) gmres_norm_fused_kernel(KState *st, double *hs, int m, int i, const double *__restrict__ part_in)
 {
@@ -324,6 +266,197 @@ __global__ void __launch_bounds__(kB) gmres_norm_fused_kernel(KState *st, double
     if (st->fl[F_DONE]) return;
     const double nw = sqrt(sum_partials(part_in, sh));
     if (threadIdx.x == 0) { Hm(hs, m, i + 1, i) = nw; st->sc[S_BETA] = nw; }
+}
+
+// ---- the whole chain of a step in ONE launch ------------------------------------------------------------------------------------------
+// The chain above is i + 3 launches per step and each link re-reads w and two basis vectors (6 us a link at 700 k unknowns, 528 links in a
+// 32-iteration GMRES(50): a third of the Darcy solve).  Here kChainG workgroups keep their elements of w in registers for the whole step (a
+// workgroup = two virtual blocks of kB threads, the blocks of the kernels above: same elements, same order of summation); a link costs one
+// read of v_k and one hand-off: the workgroup publishes the sum of its two blocks as two tagged 8-byte granules {launch number, half of the
+// double} with agent-scope stores, a wavefront of each workgroup that holds no vector data polls all kChainG values with agent-scope loads
+// (cdna_hip_programming.md, Guideline 16, form R2: the data is the flag; MI355X_MICROARCH.md prices the hand-off at 0.8-1.1 us against
+// 1.5-1.9 us for a kernel boundary plus the next kernel's first round trips), adds them up in the order of sum_partials() and hands the
+// coefficient to the others through LDS.  While it waits, the data wavefronts' loads of the next basis vector are in flight (loads return in
+// order per wavefront: the polls must not queue behind them, hence the wavefront of its own).  The norm of the step and v_{i+1} = w / |w|
+// come out of the same launch.  Bit for bit the per-link chain: the arithmetic is MFEM's modified Gram-Schmidt loop, one vector at a time.
+//   Every workgroup must be resident (one per CU: they are, unless another process fills the device): every wait is bounded
+// (ELAG_HIP_GMRES_CHAIN_MS, 250 ms); a launch that gives up stores code 2 in the context's error word, the next ABI call fails and the solvers
+// of the process go back to a launch per link.
+typedef unsigned long long u64k;
+typedef unsigned int u32x4k __attribute__((ext_vector_type(4)));
+constexpr int kChainG = kPart / 2;          // workgroups of gmres_chain_kernel = values handed over per inner product
+struct ChainArgs {
+    int n, m, i;
+    KState *st;
+    double *hs, *w;
+    const double *V;          // the basis, column q at V + q n
+    double *vout;             // v_{i+1}
+    u64k *gran;               // [m + 2][kChainG][2]
+    int *host_err;
+    long long ticks;
+    int stall;                // test hook: workgroup stall - 1 publishes its first partial sums ten time limits late (ELAG_HIP_GMRES_CHAIN_STALL)
+};
+
+// PF: the next basis vector is requested a link ahead (a third register array); without it the load follows the coefficient.  Two forms are
+// built: 6 elements per thread with the look-ahead (up to 786 432 unknowns), 12 without (up to 1 572 864); 24 elements in half-size
+// workgroups, two per CU, spilled 230 registers and are not built -- larger systems keep the launch per link.
+template <int PRE, bool PF>
+__global__ void __launch_bounds__(2 * kB + 64) gmres_chain_kernel(const ChainArgs A)
+{
+    constexpr int kData = 2 * kB, kWaves = kData / 64;
+    __shared__ double sh_a[2][kWaves];
+    __shared__ double sh_h[2];
+    __shared__ int sh_dead;
+    if (A.st->fl[F_DONE]) return;
+    const bool poller = threadIdx.x >= kData;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned tag = (unsigned)A.st->chain[0] + 1u;
+    if (threadIdx.x == 0) sh_dead = 0;
+    const int vb = blockIdx.x * 2 + (threadIdx.x >> 8);               // the virtual block of a data thread
+    const int t0 = vb * kB + (threadIdx.x & (kB - 1)), stride = kPart * kB;
+    const int n = A.n, i = A.i;
+    double pw[PRE], pv[PRE], pn[PF ? PRE : 1];
+    auto load_vec = [&](const double *__restrict__ v, double *dst) {
+#pragma unroll
+        for (int u = 0; u < PRE; u++) { const int t = t0 + u * stride; dst[u] = t < n ? v[t] : 0.0; }
+    };
+    if (!poller) { load_vec(A.w, pw); load_vec(A.V, pv); }
+    __syncthreads();
+    // data wavefronts: each one's sum to LDS, then the barrier; the workgroup's first thread adds them up as block_sum_256() and pair_of() do and
+    // publishes the one value (a data wavefront's store: loads and stores of a wavefront share a counter, the polling wavefront's polls would
+    // wait for the write-through of its own store)
+    auto publish = [&](double acc, int slot) {
+        if (!poller) {
+            acc = wave_sum(acc);
+            if (lane == 0) sh_a[slot & 1][wv] = acc;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (slot == 0 && A.stall == (int)blockIdx.x + 1) {
+                const long long t_in = (long long)wall_clock64();
+                while ((long long)wall_clock64() - t_in < 10 * A.ticks) __builtin_amdgcn_s_sleep(8);
+            }
+            const double *q = sh_a[slot & 1];
+            const double r = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+            const u64k bits = (u64k)__double_as_longlong(r);
+            u64k *g = A.gran + ((size_t)slot * kChainG + blockIdx.x) * 2;
+            __hip_atomic_store(g, ((u64k)tag << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 1, ((u64k)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    // the polling wavefront: the kChainG sums of `slot`, four per lane, each granule pair one 16-byte load; all four requested before any is
+    // looked at (tested one by one as they come, the compiler puts a wait between the requests: a round trip each); added up as
+    // sum_partials() does: lane l's j-th value is thread 64 j + l's pair.  The sum to everybody through LDS
+    auto collect = [&](int slot, bool root) -> double {
+        if (poller) {
+            const u64k *g = A.gran + ((size_t)slot * kChainG + lane) * 2;
+            double p[4];
+            unsigned spins = 0;
+            long long tw = 0;
+            bool dead = false;
+            while (true) {
+                u32x4k w[4];
+                asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                             "global_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+                             "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\t"
+                             "global_load_dwordx4 %3, %4, off offset:3072 sc1\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(g) : "memory");
+                bool have = true;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    have = have && w[j].y == tag && w[j].w == tag;
+                    p[j] = __hiloint2double((int)w[j].z, (int)w[j].x);
+                }
+                if (__all(have)) break;
+                if ((++spins & 63u) != 0) continue;
+                const long long now = (long long)wall_clock64();
+                if (spins == 64u) tw = now;
+                const bool late = now - tw > A.ticks;
+                const bool stop = __hip_atomic_load(A.st->chain + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                if (__any(late || stop)) {
+                    if (__any(late) && lane == 0) {
+                        __hip_atomic_store(A.st->chain + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(A.host_err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    dead = true;
+                    break;
+                }
+            }
+            double r = 0.0;
+            if (!dead) {
+                const double s0 = wave_sum(p[0]), s1 = wave_sum(p[1]), s2 = wave_sum(p[2]), s3 = wave_sum(p[3]);
+                r = (s0 + s1) + (s2 + s3);
+                if (root) r = sqrt(r);
+            }
+            if (lane == 0) { sh_h[slot & 1] = r; if (dead) sh_dead = 1; }
+        }
+        __syncthreads();
+        return sh_h[slot & 1];
+    };
+    double acc = 0.0;
+    if (!poller) {
+#pragma unroll
+        for (int u = 0; u < PRE; u++) if (t0 + u * stride < n) acc += pw[u] * pv[u];
+    }
+    publish(acc, 0);
+    if (PF && !poller && i >= 1) load_vec(A.V + (size_t)n, pn);
+    bool dead = false;
+    for (int k = 0; k <= i; k++) {
+        const double h = collect(k, false);
+        if (sh_dead) { dead = true; break; }
+        if (poller && blockIdx.x == 0 && lane == 0) Hm(A.hs, A.m, k, i) = h;
+        acc = 0.0;
+        if (!poller) {
+            const bool last = k == i;
+            if (PF) {
+#pragma unroll
+                for (int u = 0; u < PRE; u++) {
+                    if (t0 + u * stride < n) {
+                        const double wn = pw[u] + (-h) * pv[u];
+                        pw[u] = wn;
+                        acc += wn * (last ? wn : pn[u]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < PRE; u++) pw[u] = pw[u] + (-h) * pv[u];           // (elements beyond n: 0 + (-h) 0, never stored, never summed)
+                if (!last) load_vec(A.V + (size_t)(k + 1) * n, pv);
+#pragma unroll
+                for (int u = 0; u < PRE; u++) if (t0 + u * stride < n) acc += pw[u] * (last ? pw[u] : pv[u]);
+            }
+        }
+        publish(acc, k + 1);
+        if (PF && !poller) {
+#pragma unroll
+            for (int u = 0; u < PRE; u++) pv[u] = pn[u];
+            if (k + 2 <= i) load_vec(A.V + (size_t)(k + 2) * n, pn);
+        }
+    }
+    if (!dead) {
+        const double nw = collect(i + 1, true);
+        dead = sh_dead != 0;
+        if (!dead) {
+            if (poller && blockIdx.x == 0 && lane == 0) { Hm(A.hs, A.m, i + 1, i) = nw; A.st->sc[S_BETA] = nw; }
+            if (!poller) {
+                const double f = 1.0 / nw;
+#pragma unroll
+                for (int u = 0; u < PRE; u++) {
+                    const int t = t0 + u * stride;
+                    if (t < n) { A.w[t] = pw[u]; A.vout[t] = f * pw[u]; }
+                }
+            }
+        }
+    }
+    // the last workgroup out closes the launch: the next one's tag, the counters back to zero
+    if (poller && lane == 0) {
+        const int out = __hip_atomic_fetch_add(A.st->chain + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (out == (int)gridDim.x - 1) {
+            __hip_atomic_store(A.st->chain + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.st->chain + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.st->chain, (int)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ---- CG with the reductions finished inside their consumers (single rank) ------------------------------------------------
@@ -648,13 +781,14 @@ struct elag_hip_krylov_s {
     double *h_sc = nullptr;       // pinned mirror of st->sc
     double *x = nullptr, *r = nullptr, *z = nullptr, *d = nullptr, *w = nullptr, *scr = nullptr;
     double *V = nullptr, *Z = nullptr, *hs = nullptr, *part = nullptr;
+    u64k *gm_gran = nullptr;                      // gmres_chain_kernel's tagged sums, [restart + 2][kChainG][2]
+    int gm_chain = std::getenv("ELAG_HIP_GMRES_CHAIN") ? atoi(std::getenv("ELAG_HIP_GMRES_CHAIN")) : 1;   // (read when the solver is made: a test compares the chains)
     double *e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // BiCGSTAB / MINRES work vectors
     hipGraphExec_t cg_iter = nullptr;
     std::vector<hipGraphExec_t> gm_step;          // GMRES: one replayable step per position of the restart cycle
     bool gm_graph_ok = true, gm_flex = false;
     std::string launch_mode = "plain";          // what elag_hip_krylov_launch_mode reports (set by the last Mult)
     std::string gm_graph_note;                    // why the step graphs are off for this solver (empty: they are on, or were never asked for)
-    bool gm_pairs = std::getenv("ELAG_HIP_GMRES_PAIR") && atoi(std::getenv("ELAG_HIP_GMRES_PAIR"));   // opt-in (read when the solver is made: a test compares the two chains)
     // results of the last Mult
     int converged = 0, final_iter = 0;
     double final_norm = 0.0;
@@ -668,7 +802,7 @@ struct elag_hip_krylov_s {
         if (cg_iter) (void)hipGraphExecDestroy(cg_iter);
         for (auto g : gm_step) if (g) (void)hipGraphExecDestroy(g);
         dev_free(x); dev_free(r); dev_free(z); dev_free(d); dev_free(w); dev_free(scr); dev_free(V); dev_free(Z); dev_free(hs); dev_free(part);
-        dev_free(bperm);
+        dev_free(bperm); dev_free(gm_gran);
         for (auto &p : e) dev_free(p);
         if (st) (void)hipFree(st);
         if (h_flags) (void)hipHostFree(h_flags);
@@ -701,7 +835,11 @@ struct elag_hip_krylov_s {
             V = dev_alloc<double>((m + 1) * nn);
             if (solver == ELAG_HIP_KRYLOV_FGMRES) Z = dev_alloc<double>(m * nn);
             hs = dev_alloc<double>(m * (m + 1) + 4 * (m + 1));
-            part = dev_alloc<double>(6 * (size_t)kPart);          // (two buffers of three runs: the two-vector Gram-Schmidt links)
+            part = dev_alloc<double>(2 * (size_t)kPart);
+            if (!distributed() && gm_chain) {
+                gm_gran = dev_alloc<u64k>((m + 2) * (size_t)kChainG * 2);
+                zero_async(gm_gran, sizeof(u64k) * (m + 2) * (size_t)kChainG * 2);
+            }
         }
     }
 
@@ -870,6 +1008,18 @@ struct elag_hip_krylov_s {
         }
     }
 
+    // which gmres_chain_kernel a step uses: 0 none (a launch per link), 1 / 2 = 6 / 12 elements per thread.  None: the switch is off,
+    // the operator is distributed or belongs to a rank thread of a process that runs several (their chains would wait for CUs the others'
+    // spinning workgroups hold), a chain of this process has given up before, or the vectors do not fit the registers
+    int chain_form(int nn) const
+    {
+        if (!gm_gran || ctx().comm_kind == 2 || !ctx().h_dev_err || (device_error_codes_seen() & (1 << 2))) return 0;
+        const long long per = (long long)kPart * kB;
+        for (int form = std::min(std::max(gm_chain, 1), 2); form <= 2; form++)                              // (ELAG_HIP_GMRES_CHAIN = 2: the wider form on a small system too)
+            if (nn <= per * (6 << (form - 1))) return form;
+        return 0;
+    }
+
     void run_gmres(const double *b, bool iterative, bool flexible)
     {
         hipStream_t s = ctx().stream;
@@ -909,22 +1059,23 @@ struct elag_hip_krylov_s {
             } else {
                 amul(Vq(i), w);
             }
+            bool basis_vector_written = false;
             if (!distributed()) {
                 // fused modified Gram-Schmidt: see gmres_orth_fused_kernel
-                if (gm_pairs && i >= 1) {
-                    // two basis vectors per link (gmres_orth_pair_kernel): columns (0, 1), (2, 3), ..., a last single one when i is even
-                    double *pin = part, *pout = part + 3 * kPart;
-                    hipLaunchKernelGGL(gmres_dot0_pair_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, (const double *)target, (const double *)Vq(0),
-                                       (const double *)Vq(1), pin);
-                    for (int k = 0; k <= i; k += 2) {
-                        const double *vb = k + 1 <= i ? Vq(k + 1) : nullptr;
-                        const double *na = k + 2 <= i ? Vq(k + 2) : nullptr;
-                        const double *nb = k + 3 <= i ? Vq(k + 3) : nullptr;
-                        hipLaunchKernelGGL(gmres_orth_pair_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, hs, m, k, i, target, (const double *)Vq(k), vb,
-                                           na, nb, (const double *)pin, pout);
-                        std::swap(pin, pout);
+                if (chain_form(nn) != 0) {
+                    // the whole chain, the norm and v_{i+1} in one launch (gmres_chain_kernel)
+                    ChainArgs a;
+                    a.n = nn; a.m = m; a.i = i; a.st = st; a.hs = hs; a.w = target; a.V = V; a.vout = Vq(i + 1); a.gran = gm_gran;
+                    a.host_err = ctx().h_dev_err;
+                    double ms = 250.0;
+                    if (const char *e = std::getenv("ELAG_HIP_GMRES_CHAIN_MS")) ms = atof(e);
+                    a.ticks = std::max(1ll, (long long)(ms * 1e5));
+                    a.stall = std::getenv("ELAG_HIP_GMRES_CHAIN_STALL") ? atoi(std::getenv("ELAG_HIP_GMRES_CHAIN_STALL")) : 0;
+                    switch (chain_form(nn)) {
+                    case 1: hipLaunchKernelGGL((gmres_chain_kernel<6, true>), dim3(kChainG), dim3(2 * kB + 64), 0, s, a); break;
+                    default: hipLaunchKernelGGL((gmres_chain_kernel<12, false>), dim3(kChainG), dim3(2 * kB + 64), 0, s, a); break;
                     }
-                    hipLaunchKernelGGL(gmres_norm_fused_kernel, dim3(1), dim3(kB), 0, s, st, hs, m, i, (const double *)pin);
+                    basis_vector_written = true;
                 } else {
                 double *pin = part, *pout = part + kPart;
                 hipLaunchKernelGGL(gmres_dot0_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, (const double *)target, (const double *)Vq(0), pin);
@@ -943,7 +1094,8 @@ struct elag_hip_krylov_s {
                 dot(target, target);
                 hipLaunchKernelGGL(gmres_norm_kernel, dim3(1), dim3(1), 0, s, st, hs, m, i);
             }
-            hipLaunchKernelGGL(scale_inv_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, (int)S_BETA, (const double *)target, Vq(i + 1));
+            if (!basis_vector_written)
+                hipLaunchKernelGGL(scale_inv_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, (int)S_BETA, (const double *)target, Vq(i + 1));
             hipLaunchKernelGGL(gmres_givens_kernel, dim3(1), dim3(1), 0, s, st, hs, m, i);
             hipLaunchKernelGGL(gmres_update_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, (const double *)hs, m, i + 1,
                                (const double *)(flexible ? Z : V), x);
