@@ -479,21 +479,25 @@ int elag_hip_hierarchy_build_blocked(elag_hip_hierarchy_t *out, elag_hip_blockop
             adopt_op(Ac);
             check_rc(elag_hip_blockop_create(&Pb, nb, nb, Af->row_off.data(), coff.data()));
             adopt_op(Pb);
-            for (int i = 0; i < nb; i++) {
-                for (int j = 0; j < nb; j++) {
-                    ParCSR *Aij = Af->block(i, j);
-                    if (!Aij) continue;                          // zero blocks stay zero (Hierarchy.cpp:503)
-                    elag_hip_parcsr_t C = nullptr;
-                    check_rc(elag_hip_parcsr_rap(Pl[i], Aij, Pl[j], &C));
-                    Ac->set_block(i, j, C, true);
-                    if (i == j && fix_zero_rows && fix_zero_rows[i]) k::fix_zero_rows(C->diag, &C->offd, false);   // :515-519
+            hierarchy_phase(H, "galerkin_products", [&] {
+                for (int i = 0; i < nb; i++) {
+                    for (int j = 0; j < nb; j++) {
+                        ParCSR *Aij = Af->block(i, j);
+                        if (!Aij) continue;                          // zero blocks stay zero (Hierarchy.cpp:503)
+                        elag_hip_parcsr_t C = nullptr;
+                        check_rc(elag_hip_parcsr_rap(Pl[i], Aij, Pl[j], &C));
+                        Ac->set_block(i, j, C, true);
+                        if (i == j && fix_zero_rows && fix_zero_rows[i]) k::fix_zero_rows(C->diag, &C->offd, false);   // :515-519
+                    }
+                    Pb->set_block(i, i, Pl[i], false);
                 }
-                Pb->set_block(i, i, Pl[i], false);
-            }
+            });
             ops[(size_t)l + 1] = Ac;
-            check_rc(elag_hip_hierarchy_set_prolongator(H, l + 1, Pb->monolithic()));
+            hierarchy_phase(H, "merged_operators", [&] { check_rc(elag_hip_hierarchy_set_prolongator(H, l + 1, Pb->monolithic())); });
         }
-        for (int l = 0; l <= num_P; l++) check_rc(elag_hip_hierarchy_set_operator(H, l, ops[(size_t)l]->monolithic()));
+        hierarchy_phase(H, "merged_operators", [&] {
+            for (int l = 0; l <= num_P; l++) check_rc(elag_hip_hierarchy_set_operator(H, l, ops[(size_t)l]->monolithic()));
+        });
 
         auto relax = [&](ParCSR *M, const elag_hip_amge_options &o) {
             elag_hip_smoother_t S = nullptr;
@@ -507,9 +511,13 @@ int elag_hip_hierarchy_build_blocked(elag_hip_hierarchy_t *out, elag_hip_blockop
             if (nb == 2 && (needs_s || opt.block_smoother == ELAG_HIP_BLOCK_LDU)) {
                 ELAG_REQUIRE(Bl->block(0, 0), "block smoother: A00 is a zero block on level %d", l);
                 ParCSR *A11 = Bl->block(1, 1);
-                if (needs_s) { A11 = schur_complement(*Bl, opt.s_type, opt.alpha, opt.use_negative_s != 0); adopt_mat(A11); }
+                if (needs_s) {
+                    hierarchy_phase(H, "schur_complements", [&] { A11 = schur_complement(*Bl, opt.s_type, opt.alpha, opt.use_negative_s != 0); });
+                    adopt_mat(A11);
+                }
                 ELAG_REQUIRE(A11, "block smoother: A11 is a zero block and no Schur complement was requested (level %d)", l);
-                elag_hip_smoother_t s00 = relax(Bl->block(0, 0), opt.inv_a00), s11 = relax(A11, opt.inv_a11);
+                elag_hip_smoother_t s00 = nullptr, s11 = nullptr;
+                hierarchy_phase(H, "smoothers", [&] { s00 = relax(Bl->block(0, 0), opt.inv_a00); s11 = relax(A11, opt.inv_a11); });
                 if (opt.block_smoother == ELAG_HIP_BLOCK_LDU) inv = {s00, s00, s00, s11};
                 else inv = {s00, s11};
             } else {
@@ -519,7 +527,7 @@ int elag_hip_hierarchy_build_blocked(elag_hip_hierarchy_t *out, elag_hip_blockop
                 }
             }
             elag_hip_smoother_t S = nullptr;
-            check_rc(elag_hip_block_smoother_create(&S, Bl, opt.block_smoother, (int)inv.size(), inv.data(), opt.damping));
+            hierarchy_phase(H, "smoothers", [&] { check_rc(elag_hip_block_smoother_create(&S, Bl, opt.block_smoother, (int)inv.size(), inv.data(), opt.damping)); });
             adopt_sm(S);
             check_rc(elag_hip_hierarchy_set_smoothers(H, l, S, S));
         }
@@ -532,7 +540,7 @@ int elag_hip_hierarchy_build_blocked(elag_hip_hierarchy_t *out, elag_hip_blockop
             adopt_mat(Arep);
             check_rc(elag_hip_coarse_create_replicated(&C, Arep, starts.data(), opt.coarse_kind));
         } else {
-            check_rc(elag_hip_coarse_create(&C, Ac, opt.coarse_kind, 0));
+            hierarchy_phase(H, "coarse_solver", [&] { check_rc(elag_hip_coarse_create(&C, Ac, opt.coarse_kind, 0)); });
         }
         hierarchy_adopt(H, [C] { delete C; });
         check_rc(elag_hip_hierarchy_set_coarse_solver(H, C));

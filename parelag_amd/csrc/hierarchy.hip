@@ -1386,6 +1386,7 @@ struct elag_hip_hierarchy_s {
 
 namespace elag {
 void hierarchy_adopt(elag_hip_hierarchy_s *H, std::function<void()> destroy) { H->adopted.push_back(std::move(destroy)); }
+void hierarchy_phase(elag_hip_hierarchy_s *H, const char *name, const std::function<void()> &f) { H->phase(name, f); }
 void hierarchy_apply_raw(elag_hip_hierarchy_s *H, const double *rhs, double *sol, bool precond)
 {
     ELAG_REQUIRE(H->finalized, "Hierarchy::Mult before Finalize()");

@@ -166,6 +166,8 @@ struct elag_hip_hierarchy_s;
 namespace elag {
 // hands an object's destructor to the hierarchy (run, in reverse order, when the hierarchy is destroyed)
 void hierarchy_adopt(elag_hip_hierarchy_s *H, std::function<void()> destroy);
+// runs f as a named phase of the hierarchy's set-up (wall time up to a drain of the compute stream, added to the phase of that name: elag_hip_hierarchy_setup_breakdown)
+void hierarchy_phase(elag_hip_hierarchy_s *H, const char *name, const std::function<void()> &f);
 // Hierarchy::Mult on device vectors without the hierarchy's own graph replay (callers that capture their own graph)
 void hierarchy_apply_raw(elag_hip_hierarchy_s *H, const double *rhs, double *sol, bool precond);
 bool hierarchy_is_local(const elag_hip_hierarchy_s *H);   // no halo exchange / collective anywhere in the cycle
