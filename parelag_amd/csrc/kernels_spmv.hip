@@ -17,11 +17,34 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// the sum of a group's LPR values on every lane of the group (a butterfly of ds_bpermute exchanges)
 template <int LPR>
-__device__ __forceinline__ double group_reduce(double v)
+__device__ __forceinline__ double group_reduce_all(double v)
 {
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// ... and on lane 0 of the group only (the others end with partial sums): the butterfly's value there bit for bit -- at stride o lane L adds
+// lane L + o, which is its butterfly partner wherever the result still matters -- with the strides inside a row of 16 lanes taken by DPP
+// row shifts (~20 cycles a step where a ds_bpermute exchange of a double is ~140; these reductions end the dependent chain of every
+// launch-bound product)
+template <int CTRL>
+__device__ __forceinline__ double dpp_shifted(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int LPR>
+__device__ __forceinline__ double group_reduce(double v)
+{
+    if (LPR >= 64) v += __shfl_xor(v, 32, 64);
+    if (LPR >= 32) v += __shfl_xor(v, 16, 64);
+    if (LPR >= 16) v += dpp_shifted<0x108>(v);     // row_shl:8
+    if (LPR >= 8) v += dpp_shifted<0x104>(v);      // row_shl:4
+    if (LPR >= 4) v += dpp_shifted<0x102>(v);      // row_shl:2
+    if (LPR >= 2) v += dpp_shifted<0x101>(v);      // row_shl:1
     return v;
 }
 
@@ -1884,7 +1907,7 @@ __global__ __launch_bounds__(kBlock) void fix_zero_rows_kernel(int n, const int 
     for (int k = I[row] + lane; k < I[row + 1]; k += LPR) l1 += fabs(a[k]);
     if (oI)
         for (int k = oI[row] + lane; k < oI[row + 1]; k += LPR) l1 += fabs(oa[k]);
-    l1 = group_reduce<LPR>(l1);
+    l1 = group_reduce_all<LPR>(l1);
     if (l1 <= 0.0) {
         for (int k = I[row] + lane; k < I[row + 1]; k += LPR) a[k] = (J[k] == row) ? 1.0 : 0.0;
         if (oI)
