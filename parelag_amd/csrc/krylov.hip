@@ -346,7 +346,9 @@ __global__ void __launch_bounds__(2 * kB + 64) gmres_chain_kernel(const ChainArg
     };
     // the polling wavefront: the kChainG sums of `slot`, four per lane, each granule pair one 16-byte load; all four requested before any is
     // looked at (tested one by one as they come, the compiler puts a wait between the requests: a round trip each); added up as
-    // sum_partials() does: lane l's j-th value is thread 64 j + l's pair.  The sum to everybody through LDS
+    // sum_partials() does: lane l's j-th value is thread 64 j + l's pair.  The sum to everybody through LDS.  (Nothing is assumed about the
+    // 16 bytes as a whole: each aligned 8-byte half is one granule with its own tag, and a pair counts only when both halves carry this
+    // launch's tag -- a load that catches one new and one old half is a round that is repeated.)
     auto collect = [&](int slot, bool root) -> double {
         if (poller) {
             const u64k *g = A.gran + ((size_t)slot * kChainG + lane) * 2;
