@@ -16,3 +16,6 @@ echo "[7] the reference's own 2-form list: Hiptmair(L1 Gauss-Seidel, L1 Gauss-Se
 for m in 1 0; do ELAG_HIP_SWEEP_DATAFLOW=$m timeout -k 10 400 python bench.py --form 2 --smoother "L1 Gauss-Seidel" --no-roofline --no-cpu-baseline --no-other-configs --no-gs > $OUT/hdiv_gs_dataflow_$m.json 2> $OUT/hdiv_gs_dataflow_$m.err; echo "rc $?"; done
 echo "[8] the N-rank code path on one rank"; timeout -k 10 400 python bench.py --force-dist --no-cpu-baseline --steps 20 --warmup 5 > $OUT/bench_multirank_path_1rank.json 2> $OUT/bench_multirank_path_1rank.err; echo "rc $?"
 echo "[9] config 4 with its solve"; timeout -k 10 300 python bench.py --form darcy --solve --no-cpu-baseline --no-cpu-solve --steps 20 --warmup 5 > $OUT/bench_darcy_solve.json 2> $OUT/bench_darcy_solve.err; echo "rc $?"
+echo "[10] GMRES: a step's Gram-Schmidt chain in one launch -- per link, per step, soak"
+(python tools/r05_gmres_chain_probe.py 706000 50; python tools/r05_gmres_chain_probe.py 1400000 40; python tools/r05_gmres_chain_probe.py 30000 50; bash tools/r05_gmres_chain_profile.sh r05final/chain 2>&1 | grep -v "rocprofv3\]\|Opened result") > $OUT/gmres_chain.txt 2>&1; tail -4 $OUT/gmres_chain.txt | cut -c1-220
+python tools/r05_gmres_chain_soak.py 1000 > $OUT/gmres_chain_soak.txt 2>&1; tail -3 $OUT/gmres_chain_soak.txt | cut -c1-200
