@@ -817,7 +817,7 @@ struct elag_hip_krylov_s {
     double *e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // BiCGSTAB / MINRES work vectors
     hipGraphExec_t cg_iter = nullptr;
     std::vector<hipGraphExec_t> gm_step;          // GMRES: one replayable step per position of the restart cycle
-    bool gm_graph_ok = true, gm_flex = false;
+    bool gm_graph_ok = true, gm_flex = false, gm_graphs_chain = false;   // gm_graphs_chain: some captured step holds a gmres_chain_kernel
     std::string launch_mode = "plain";          // what elag_hip_krylov_launch_mode reports (set by the last Mult)
     std::string gm_graph_note;                    // why the step graphs are off for this solver (empty: they are on, or were never asked for)
     // results of the last Mult
@@ -1135,6 +1135,12 @@ struct elag_hip_krylov_s {
         };
         static const bool graph_env = !(std::getenv("ELAG_HIP_GMRES_GRAPH") && !atoi(std::getenv("ELAG_HIP_GMRES_GRAPH")));
         bool graphs = graph_env && gm_graph_ok && capturable();
+        // step graphs captured with the one-launch chain are thrown away once a chain of this process has given up: a replay would launch it again
+        if (gm_graphs_chain && chain_form(nn) == 0) {
+            for (auto g : gm_step) if (g) (void)hipGraphExecDestroy(g);
+            gm_step.clear();
+            gm_graphs_chain = false;
+        }
         if (graphs && (int)gm_step.size() != m) { for (auto g : gm_step) if (g) (void)hipGraphExecDestroy(g); gm_step.assign((size_t)m, nullptr); gm_flex = flexible; }
         if (graphs && gm_flex != flexible) graphs = false;
         for (int j = 1; j <= max_iter && !finished;) {
@@ -1158,7 +1164,7 @@ struct elag_hip_krylov_s {
                         const hipError_t ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
                         if (ie != hipSuccess) { ok = false; why = std::string("hipGraphInstantiate: ") + hipGetErrorString(ie); }
                     }
-                    if (ok && ge) gm_step[(size_t)i] = ge;
+                    if (ok && ge) { gm_step[(size_t)i] = ge; if (chain_form(nn) != 0) gm_graphs_chain = true; }
                     else {
                         // this solver keeps to plain launches; the reason stays with it (elag_hip_krylov_graph_note) and is printed once
                         // under ELAG_HIP_VERBOSE -- a failed capture must not leave a latched runtime error or an error text behind

@@ -406,9 +406,12 @@ del os.environ["ELAG_HIP_GMRES_CHAIN_STALL"]
 K2 = la.KrylovSolver(dA, None, params)
 x2 = np.zeros(n); K2.Mult(b, x2)
 print("SAME:", bool(np.array_equal(x2, x0)), K2.GetNumIterations() == K0.GetNumIterations(), K2.GetConverged())
+x3 = np.zeros(n); K.Mult(b, x3)             # the solver whose chain gave up: its captured steps are dropped, a launch per link from here on
+print("AGAIN:", bool(np.array_equal(x3, x0)), K.GetNumIterations() == K0.GetNumIterations(), K.GetConverged())
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = {ln.split(":", 1)[0]: ln.split(":", 1)[1].strip() for ln in r.stdout.splitlines() if ":" in ln}
     assert "Gram-Schmidt chain" in lines["FAILED"], r.stdout + r.stderr
     assert lines["SAME"] == "True True True", r.stdout + r.stderr
+    assert lines["AGAIN"] == "True True True", r.stdout + r.stderr
