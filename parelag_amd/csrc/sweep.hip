@@ -64,10 +64,11 @@ template <int Q>
 __device__ __forceinline__ double row_bcast(double v)
 {
     static_assert(kLPR == 16, "a DPP row is 16 lanes");
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + Q, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + Q, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
+    // (the 64-bit form: row_newbcast is the one DPP control the double-precision ALU takes -- one v_mov_b64_dpp where the halves took two moves:
+    //  cube456 x3 level 0 260 -> 251 us per symmetric dataflow sweep, 589 -> 530 as a launch per level.  Stopping the subtraction behind the last
+    //  slot any row of the wavefront uses -- a second chunk holds 1-5 entries -- was measured too: tested per slot 267 us, as 4- / 8- / 16-slot
+    //  forms behind one branch 260: the tridiagonal chain gains 5 %, the operators lose what the extra code costs)
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + Q, 0xf, 0xf, false);
 }
 template <int Q>
 __device__ __forceinline__ int row_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + Q, 0xf, 0xf, false); }
