@@ -739,7 +739,7 @@ def test_dataflow_schedule_built_on_the_device_gives_the_same_sweep(la, h1_k2, r
     ref.iterative_mode = True
     ur = u0.copy(); ref.Mult(f, ur)
     for xcd in ("0", "1"):
-        S = _with_env({"ELAG_HIP_SWEEP_DEVICE_SETUP_ROWS": "1000", "ELAG_HIP_SWEEP_DATAFLOW_XCD": xcd, "ELAG_HIP_SWEEP_VERBOSE": "1"},
+        S = _with_env({"ELAG_HIP_SWEEP_DEVICE_SETUP_ROWS": "1000", "ELAG_HIP_SWEEP_DATAFLOW": "1", "ELAG_HIP_SWEEP_DATAFLOW_XCD": xcd, "ELAG_HIP_SWEEP_VERBOSE": "1"},
                       lambda: la.HypreSmootherWrapper(dA, relax_type, {"Sweeps": 2}))
         assert "schedule built on the device" in capfd.readouterr().err
         S.iterative_mode = True
