@@ -504,6 +504,29 @@ __global__ void __launch_bounds__(kB) cg_fused_step2_kernel(KState *st, const do
     }
 }
 
+// cg_step2 and the update of x and r that mfem::CGSolver makes at the top of the NEXT pass, in one launch: every block adds the partial sums of
+// (d, A d) up itself (the same fixed order everywhere), block 0 takes cg_step2's branch and writes the state, and the update follows at once
+// -- only den == 0 ends the loop between the two statements, and then nothing is applied.  One launch of a pass less (4.4 us of the 40 a pass
+// takes at the 42 309 unknowns of cube456 x3); alpha = nom / den is the same division, the iterates the same bits.
+__global__ void __launch_bounds__(kB) cg_fused_step2_update_kernel(int n, KState *__restrict__ st, const double *__restrict__ part, double *__restrict__ x,
+                                                                   const double *__restrict__ d, double *__restrict__ r, const double *__restrict__ z)
+{
+    __shared__ double sh[4];
+    if (st->fl[F_DONE]) return;
+    const double betanom = st->sc[S_BETANOM];
+    const int iter2 = st->fl[F_ITER2];
+    const double den = sum_partials(part, sh);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->fl[F_ITER] = iter2;
+        st->sc[S_DEN] = den;
+        if (den == 0.0) { st->fl[F_FINAL_ITER] = iter2; st->fl[F_DONE] = 1; }
+        else { st->sc[S_NOM] = betanom; st->sc[S_ALPHA] = betanom / den; }
+    }
+    if (den == 0.0) return;
+    const double alpha = betanom / den;
+    for (int t = blockIdx.x * kB + threadIdx.x; t < n; t += kPart * kB) { x[t] = x[t] + alpha * d[t]; r[t] = r[t] + (-alpha) * z[t]; }
+}
+
 __global__ void gmres_norm_kernel(KState *st, double *hs, int m, int i)
 {
     if (st->fl[F_DONE]) return;
@@ -814,6 +837,7 @@ struct elag_hip_krylov_s {
     double *V = nullptr, *Z = nullptr, *hs = nullptr, *part = nullptr;
     u64k *gm_gran = nullptr;                      // gmres_chain_kernel's tagged sums, [restart + 2][kChainG][2]
     int gm_chain = std::getenv("ELAG_HIP_GMRES_CHAIN") ? atoi(std::getenv("ELAG_HIP_GMRES_CHAIN")) : 1;   // (read when the solver is made: a test compares the chains)
+    bool cg_tail = !(std::getenv("ELAG_HIP_CG_TAIL_UPDATE") && !atoi(std::getenv("ELAG_HIP_CG_TAIL_UPDATE")));   // CG: the update of x, r in the launch that computes alpha (0: a launch of its own)
     double *e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // BiCGSTAB / MINRES work vectors
     hipGraphExec_t cg_iter = nullptr;
     std::vector<hipGraphExec_t> gm_step;          // GMRES: one replayable step per position of the restart cycle
@@ -959,11 +983,13 @@ struct elag_hip_krylov_s {
         return prec_kind == ELAG_HIP_PREC_NONE;
     }
 
+    // single rank: the update of x and r rides on the launch that computes its alpha (cg_fused_step2_update_kernel); run_cg applies the first pass's itself
+    bool cg_tail_update() const { return !distributed() && cg_tail; }
     void cg_iteration()
     {
         hipStream_t s = ctx().stream;
         const int nn = n();
-        hipLaunchKernelGGL(cg_update_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, x, (const double *)d, r, (const double *)z);
+        if (!cg_tail_update()) hipLaunchKernelGGL(cg_update_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, x, (const double *)d, r, (const double *)z);
         if (!distributed()) {
             // single rank: each dot is one partial-sum kernel, finished inside the kernel that consumes it
             const double *src = has_prec() ? z : r;
@@ -972,7 +998,9 @@ struct elag_hip_krylov_s {
             hipLaunchKernelGGL(cg_fused_dir_kernel, dim3(kPart), dim3(kB), 0, s, nn, st, max_iter, (const double *)part, src, d);
             amul(d, z);
             hipLaunchKernelGGL(gmres_dot0_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, (const double *)d, (const double *)z, part + kPart);
-            hipLaunchKernelGGL(cg_fused_step2_kernel, dim3(1), dim3(kB), 0, s, st, (const double *)(part + kPart));
+            if (cg_tail_update())
+                hipLaunchKernelGGL(cg_fused_step2_update_kernel, dim3(kPart), dim3(kB), 0, s, nn, st, (const double *)(part + kPart), x, (const double *)d, r, (const double *)z);
+            else hipLaunchKernelGGL(cg_fused_step2_kernel, dim3(1), dim3(kB), 0, s, st, (const double *)(part + kPart));
             ELAG_LAUNCH_CHECK();
             return;
         }
@@ -1005,6 +1033,8 @@ struct elag_hip_krylov_s {
         if (poll()) return;
         const bool graph = capturable();
         launch_mode = graph ? "graph" : "plain";
+        if (cg_tail_update())   // mfem's first statement of the first pass; every later pass's is applied by the launch that computes its alpha
+            hipLaunchKernelGGL(cg_update_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, x, (const double *)d, r, (const double *)z);
         if (graph && !cg_iter) {
             hipGraph_t g = nullptr;
             ELAG_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));

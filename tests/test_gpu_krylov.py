@@ -415,3 +415,36 @@ print("AGAIN:", bool(np.array_equal(x3, x0)), K.GetNumIterations() == K0.GetNumI
     assert "Gram-Schmidt chain" in lines["FAILED"], r.stdout + r.stderr
     assert lines["SAME"] == "True True True", r.stdout + r.stderr
     assert lines["AGAIN"] == "True True True", r.stdout + r.stderr
+
+
+def test_cg_with_the_update_in_the_launch_that_computes_alpha_is_the_same_iteration_bit_for_bit(la):
+    """cg_fused_step2_update_kernel (krylov.hip): the update of x and r that mfem::CGSolver makes at the top of a pass is applied by the launch
+    that computes its alpha at the end of the pass before (only den == 0 ends the loop between the two, and then nothing is applied): a launch
+    a pass less, the same operations in the same order.  Iterate, iteration count, final norm and flags are those of the form with a launch of
+    its own (ELAG_HIP_CG_TAIL_UPDATE=0) to the last bit: with and without a preconditioner, converging, running into the iteration limit,
+    from an initial guess, on a zero right-hand side, around the block boundaries; and the oracle's mfem::CGSolver agrees as before."""
+    rng = np.random.default_rng(31)
+    for n, with_prec, max_iter, tol in ((1, False, 10, 1e-10), (255, True, 50, 1e-10), (1025, False, 7, 1e-14), (40000, True, 60, 1e-9), (140001, False, 30, 1e-8)):
+        S0 = sp.random(n, n, density=min(1.0, 5.0 / n), random_state=rng)
+        A = orc.csr(S0 + S0.T + sp.diags(np.full(n, 12.0)))
+        dA = la.ParallelCSRMatrix.from_scipy(A)
+        params = {"Solver name": "PCG", "Relative tolerance": tol, "Maximum iterations": max_iter}
+        for b, x_init, iterative in ((rng.uniform(-1, 1, n), None, False), (rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), True), (np.zeros(n), None, False)):
+            out = []
+            for env in ({"ELAG_HIP_CG_TAIL_UPDATE": "0"}, {"ELAG_HIP_CG_TAIL_UPDATE": "1"}):
+                P = la.HypreSmootherWrapper(dA, 1, {"Sweeps": 1}) if with_prec else None      # l1-Jacobi
+                K = _krylov_with_env(la, env, dA, P, params)
+                K.iterative_mode = iterative
+                for trial in range(2):                                                          # (the second solve replays the captured iteration)
+                    x = np.zeros(n) if x_init is None else x_init.copy()
+                    K.Mult(b, x)
+                out.append((K.GetConverged(), K.GetNumIterations(), x, K.GetFinalNorm()))
+            assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and out[0][3] == out[1][3], (n, with_prec, [(q[0], q[1], q[3]) for q in out])
+            assert np.array_equal(out[0][2], out[1][2]), (n, with_prec, np.abs(out[0][2] - out[1][2]).max())
+        if not with_prec:
+            b = rng.uniform(-1, 1, n)
+            K = la.KrylovSolver(dA, None, params)
+            x = np.zeros(n); K.Mult(b, x)
+            xr = np.zeros(n)
+            ref = orc.mfem_cg(lambda v: A @ v, None, b, xr, rel_tol=tol, max_iter=max_iter)
+            assert K.GetNumIterations() == ref.final_iter and bool(K.GetConverged()) == bool(ref.converged) and close(x, xr, 1e-9)
