@@ -1047,7 +1047,9 @@ struct elag_hip_krylov_s {
         // Iterations enqueued past convergence are no-ops for the iterate but still run the (unpredicated) preconditioner,
         // so the batch between two reads of the state is sized from the observed convergence rate: the host reads
         // (B r, r) with the flag and enqueues about as many iterations as the rate predicts are still needed.
-        double prev = 0.0;
+        // (the first rate comes from the initial (B r, r), which the poll above has fetched: without it the second batch repeated the first one's
+        //  size -- 4 + 4 passes for the 6 the reference's default example needs with its L1 Gauss-Seidel cycle, two 0.56 ms cycles for nothing)
+        double prev = h_sc[S_BETANOM];
         int batch = std::min(check_every, std::max(1, std::min(total, 4)));
         for (int it = 0; it < total;) {
             batch = std::min(batch, total - it);
