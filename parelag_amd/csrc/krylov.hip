@@ -128,6 +128,7 @@ __global__ void gmres_init_kernel(KState *st, double rel_tol, double abs_tol, in
     const double thr = fmax(rel_tol * beta, abs_tol);
     st->sc[S_THRESH] = thr;
     st->sc[S_FINAL_NORM] = beta;
+    st->sc[S_BETANOM] = beta; st->sc[S_R0] = thr;      // (among the words the host polls: the residual estimate of the last step and what it has to reach -- the host sizes its batches from them)
     if (beta <= thr) { st->fl[F_DONE] = 1; st->fl[F_CONVERGED] = 1; st->fl[F_FINAL_ITER] = 0; }
 }
 
@@ -593,6 +594,7 @@ __global__ void __launch_bounds__(64) gmres_givens_kernel(KState *st, double *hs
         cs[i] = ci; sn[i] = sni; s[i] = si; s[i + 1] = si1;
         resid = fabs(si1);
         converged = resid <= thresh;
+        st->sc[S_BETANOM] = resid;
     }
     __syncthreads();
     for (int k = threadIdx.x; k <= i + 1; k += 64) Hm(hs, m, k, i) = hout[k];
@@ -631,6 +633,7 @@ __global__ void gmres_restart_norm_kernel(KState *st, int j)
     const double beta = sqrt(st->sc[S_TMP]);
     st->sc[S_GBETA] = beta;
     st->sc[S_FINAL_NORM] = beta;
+    st->sc[S_BETANOM] = beta;
     if (beta <= st->sc[S_THRESH]) { st->fl[F_FINAL_ITER] = j; st->fl[F_CONVERGED] = 1; st->fl[F_DONE] = 1; }
 }
 
@@ -1105,7 +1108,11 @@ struct elag_hip_krylov_s {
         hipLaunchKernelGGL(gmres_init_kernel, dim3(1), dim3(1), 0, s, st, rel_tol, abs_tol, max_iter);
         ELAG_LAUNCH_CHECK();
         if (poll()) return;
-        int since_poll = 0;
+        // Steps enqueued past convergence change nothing but still run the (unpredicated) preconditioner -- three V-cycles of the Block-LDU graph --,
+        // so the host looks at the state as often as the residual estimate's rate says it should: after a batch, the steps still needed are
+        // log(estimate / threshold) / (its decrease per step), at most check_every (the SPE10-like system needs 36 steps: polled every 8, four of 40 were for nothing)
+        int since_poll = 0, poll_after = std::min(check_every, 4);
+        double est_prev = h_sc[S_BETANOM];
         bool finished = false;
         // One inner step (product, preconditioner, modified Gram-Schmidt against i + 1 vectors, rotation, conditional update) is 40 + i
         // launches that depend on nothing the host knows: replayed as ONE graph per position i of the cycle (built on first use, kept for
@@ -1209,7 +1216,18 @@ struct elag_hip_krylov_s {
                 }
                 if (graphs) ELAG_HIP_CHECK(hipGraphLaunch(gm_step[(size_t)i], s));
                 else step(i);
-                if (++since_poll >= check_every) { since_poll = 0; if (poll()) { finished = true; i++; j++; break; } }
+                if (++since_poll >= poll_after) {
+                    const int steps = since_poll;
+                    since_poll = 0;
+                    if (poll()) { finished = true; i++; j++; break; }
+                    const double est = h_sc[S_BETANOM], thr = h_sc[S_R0];
+                    poll_after = check_every;
+                    if (est_prev > 0.0 && est > 0.0 && est < est_prev && thr > 0.0 && est > thr) {
+                        const double rate = std::log(est_prev / est) / steps;
+                        poll_after = std::max(1, std::min(check_every, (int)std::ceil(std::log(est / thr) / rate)));
+                    }
+                    est_prev = est;
+                }
             }
             launch_mode = graphs ? "graph" : gm_graph_note.empty() ? "plain" : "plain: " + gm_graph_note;
             if (finished) break;
