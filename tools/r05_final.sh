@@ -19,3 +19,5 @@ echo "[9] config 4 with its solve"; timeout -k 10 300 python bench.py --form dar
 echo "[10] GMRES: a step's Gram-Schmidt chain in one launch -- per link, per step, soak"
 (python tools/r05_gmres_chain_probe.py 706000 50; python tools/r05_gmres_chain_probe.py 1400000 40; python tools/r05_gmres_chain_probe.py 30000 50; bash tools/r05_gmres_chain_profile.sh r05final/chain 2>&1 | grep -v "rocprofv3\]\|Opened result") > $OUT/gmres_chain.txt 2>&1; tail -4 $OUT/gmres_chain.txt | cut -c1-220
 python tools/r05_gmres_chain_soak.py 1000 > $OUT/gmres_chain_soak.txt 2>&1; tail -3 $OUT/gmres_chain_soak.txt | cut -c1-200
+echo "[11] the reference's default example end to end (L1 Gauss-Seidel hierarchy set-up + one PCG solve); the smoother's set-up at scale"
+(python tools/r05_gs_time_to_solution.py 2>&1 | grep -v "^\[elag"; python tools/r05_gs_setup_scale.py 4 2>&1 | grep -v "^\[elag" | tail -2; python tools/r05_gs_setup_scale.py 5 2>&1 | grep -v "^\[elag" | tail -2) > $OUT/gs_time_to_solution.txt 2>&1; tail -4 $OUT/gs_time_to_solution.txt | cut -c1-200
