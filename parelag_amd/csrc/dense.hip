@@ -207,8 +207,20 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 //  threads -- two waves per SIMD -- with up to six rows each, empty row slots skipped, one reciprocal of the pivot instead of a division per row.
 constexpr int kGThreads = 512;
 constexpr int kGRowsPer = 6;                       // rows of the panel per thread: n <= 3 072
-__global__ void __launch_bounds__(kGThreads) gj_block_panel_kernel(int n, int k0, const double *__restrict__ M, int *__restrict__ piv_all, GjStep *__restrict__ step,
-                                                              int *__restrict__ singular, long long *__restrict__ dbg)
+// LOAD::row(i, out): the kGB entries of row i in the panel's columns -- read from the matrix (GjPlainRows), or worked out from the matrix of
+// the step before (GjLookAheadRows: gj_block_step_kernel)
+struct GjPlainRows {
+    const double *M;
+    int n, k0;
+    __device__ __forceinline__ void row(int i, double (&out)[kGB]) const
+    {
+#pragma unroll
+        for (int c = 0; c < kGB; c++) out[c] = k0 + c < n ? M[(size_t)i * n + k0 + c] : 0.0;
+    }
+};
+template <class LOAD>
+__device__ __forceinline__ void gj_panel_body(int n, int k0, const LOAD &load, int *__restrict__ piv_all, GjStep *__restrict__ step,
+                                              int *__restrict__ singular, long long *__restrict__ dbg)
 {
     // dbg (ELAG_HIP_LU_TIMING=1): the 100 MHz wall clock at the kernel's phase boundaries, six per step
     auto stamp = [&](int w) { if (dbg && threadIdx.x == 0) dbg[(size_t)(k0 / kGB) * 6 + w] = (long long)wall_clock64(); };
@@ -225,8 +237,12 @@ __global__ void __launch_bounds__(kGThreads) gj_block_panel_kernel(int n, int k0
 #pragma unroll
     for (int u = 0; u < kGRowsPer; u++) {
         const int r = t + u * kGThreads;
+        double rowv[kGB];
 #pragma unroll
-        for (int c = 0; c < kGB; c++) rv[u][c] = (r < m && c < nb) ? M[(size_t)(k0 + r) * n + k0 + c] : 0.0;
+        for (int c = 0; c < kGB; c++) rowv[c] = 0.0;
+        if (r < m) load.row(k0 + r, rowv);
+#pragma unroll
+        for (int c = 0; c < kGB; c++) rv[u][c] = (r < m && c < nb) ? rowv[c] : 0.0;
     }
     stamp(1);
 #pragma unroll
@@ -328,7 +344,16 @@ __global__ void __launch_bounds__(kGThreads) gj_block_panel_kernel(int n, int k0
     stamp(3);
     // D = the swapped M_KK (padded with the identity), inverted without further pivoting: the swaps made its leading pivots the ones found above
     const int r = t / kGB, c = t % kGB;
-    D[r][c] = (r < nb && c < nb) ? M[(size_t)s_src[2 * r] * n + k0 + c] : (r == c ? 1.0 : 0.0);                         // (position k0 + r is entry 2 r of the list)
+    {
+        double rowv[kGB];
+#pragma unroll
+        for (int q = 0; q < kGB; q++) rowv[q] = 0.0;
+        if (r < nb && c < nb) load.row(s_src[2 * r], rowv);                                                            // (position k0 + r is entry 2 r of the list)
+        double mine = 0.0;
+#pragma unroll
+        for (int q = 0; q < kGB; q++) mine = q == c ? rowv[q] : mine;
+        D[r][c] = (r < nb && c < nb) ? mine : (r == c ? 1.0 : 0.0);
+    }
     __builtin_amdgcn_wave_barrier();
     stamp(4);
     for (int k = 0; k < nb; k++) {
@@ -348,6 +373,12 @@ __global__ void __launch_bounds__(kGThreads) gj_block_panel_kernel(int n, int k0
     }
     step->Dinv[t] = D[r][c];
     stamp(5);
+}
+
+__global__ void __launch_bounds__(kGThreads) gj_block_panel_kernel(int n, int k0, const double *__restrict__ M, int *__restrict__ piv_all, GjStep *__restrict__ step,
+                                                              int *__restrict__ singular, long long *__restrict__ dbg)
+{
+    gj_panel_body(n, k0, GjPlainRows{M, n, k0}, piv_all, step, singular, dbg);
 }
 
 constexpr int kGRows = 16;                           // rows per workgroup of the update (a thread per column)
@@ -410,6 +441,125 @@ __global__ void __launch_bounds__(256) gj_block_update_kernel(int n, int k0, con
     }
 }
 
+// Look-ahead: the next panel needs nothing of the updated matrix but its own kGB columns.  A step is two launches as before, cut differently:
+//   gj_lookahead_cols_kernel   the update of columns k0 + kGB .. k0 + 2 kGB - 1 alone (n x kGB entries: a few microseconds), then
+//   gj_block_step_kernel       workgroup 0 factorises the next panel out of those columns WHILE the other workgroups update the rest of the matrix
+// -- a step costs a small launch plus the longer of panel (22 us) and update (13 us) instead of their sum.  Entry for entry the update's
+// operations in the update's order: the inverse is the same to the last bit.
+__global__ void __launch_bounds__(256) gj_lookahead_cols_kernel(int n, int k0, const double *__restrict__ Mo, double *__restrict__ Mn, const GjStep *__restrict__ step)
+{
+    constexpr int kRows = 256 / kGB;                 // 32 rows x kGB columns per workgroup
+    __shared__ GjStep st;
+    __shared__ int s_old[kRows + kGB];
+    __shared__ double cc[kRows][kGB], rpn[kGB][kGB];
+    for (int e = threadIdx.x; e < (int)(sizeof(GjStep) / sizeof(int)); e += 256) reinterpret_cast<int *>(&st)[e] = reinterpret_cast<const int *>(step)[e];
+    __syncthreads();
+    const int i0 = blockIdx.x * kRows, nb = min(kGB, n - k0);
+    if (threadIdx.x < kRows + kGB) {
+        const int i = threadIdx.x < kRows ? i0 + (int)threadIdx.x : k0 + (int)threadIdx.x - kRows;
+        int o = i;
+        for (int z = 0; z < st.nr; z++)
+            if (st.row[z] == i) o = st.src[z];
+        s_old[threadIdx.x] = min(o, n - 1);
+    }
+    __syncthreads();
+    {
+        const int sr = threadIdx.x / kGB, q = threadIdx.x % kGB;
+        cc[sr][q] = (i0 + sr < n && q < nb) ? Mo[(size_t)s_old[sr] * n + k0 + q] : 0.0;
+    }
+    if (threadIdx.x < kGB * kGB) {
+        // rpn[q][c]: row q of the new pivot rows in column k0 + kGB + c  (the update's rp[q] of that column)
+        const int q = threadIdx.x / kGB, c = threadIdx.x % kGB, j = k0 + kGB + c;
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < kGB; w++) {
+            const double col = (w < nb && j < n) ? Mo[(size_t)s_old[kRows + w] * n + j] : 0.0;
+            sum += st.Dinv[q * kGB + w] * col;
+        }
+        rpn[q][c] = q < nb ? sum : 0.0;
+    }
+    __syncthreads();
+    const int sr = threadIdx.x / kGB, c = threadIdx.x % kGB, i = i0 + sr, j = k0 + kGB + c;
+    if (i >= n || j >= n) return;
+    double *mp = Mn + (size_t)i * n + j;
+    if (i >= k0 && i < k0 + nb) { *mp = rpn[i - k0][c]; return; }               // rows of the pivot block
+    const double mo = Mo[(size_t)s_old[sr] * n + j];
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < kGB; q++) acc += cc[sr][q] * rpn[q][c];
+    *mp = mo - acc;
+}
+
+__global__ void __launch_bounds__(kGThreads) gj_block_step_kernel(int n, int k0, const double *__restrict__ Mo, double *__restrict__ Mn, const GjStep *__restrict__ step,
+                                                             GjStep *__restrict__ step_next, int *__restrict__ piv_all, int *__restrict__ singular)
+{
+    static_assert(kGThreads == 512, "two 256-thread halves");
+    if (blockIdx.x == 0) {
+        // ---- the next panel, out of the columns gj_lookahead_cols_kernel has just written
+        if (k0 + kGB < n) gj_panel_body(n, k0 + kGB, GjPlainRows{Mn, n, k0 + kGB}, piv_all, step_next, singular, nullptr);
+        return;
+    }
+    // ---- the update (gj_block_update_kernel's, two row blocks per workgroup) of every column but those
+    __shared__ GjStep st;
+    __shared__ int s_old[2][kGRows + kGB];
+    __shared__ double cc[2][kGRows][kGB];
+    for (int e = threadIdx.x; e < (int)(sizeof(GjStep) / sizeof(int)); e += kGThreads) reinterpret_cast<int *>(&st)[e] = reinterpret_cast<const int *>(step)[e];
+    __syncthreads();
+    const int nb = min(kGB, n - k0);
+    const int ntile = (n + 255) / 256, nrow = (n + 2 * kGRows - 1) / (2 * kGRows);
+    const int half = (int)(threadIdx.x >> 8), tx = (int)(threadIdx.x & 255);
+    const int wid = (int)blockIdx.x - 1;
+    const int bx = wid % ntile, by = wid / ntile;
+    const int i0 = (by * 2 + half) * kGRows;
+    if (tx < kGRows + kGB) {
+        const int i = tx < kGRows ? i0 + tx : k0 + tx - kGRows;
+        int o = i;
+        for (int z = 0; z < st.nr; z++)
+            if (st.row[z] == i) o = st.src[z];
+        s_old[half][tx] = min(o, n - 1);
+    }
+    __syncthreads();
+    if (tx < kGRows * kGB) {
+        const int sr = tx / kGB, q = tx % kGB;
+        cc[half][sr][q] = (i0 + sr < n && q < nb) ? Mo[(size_t)s_old[half][sr] * n + k0 + q] : 0.0;
+    }
+    __syncthreads();
+    const int j = bx * 256 + tx;
+    if (j >= n || by >= nrow) return;
+    if (j >= k0 + kGB && j < k0 + 2 * kGB) return;                            // (the look-ahead columns are done)
+    const bool jcol = j >= k0 && j < k0 + nb;
+    double rp[kGB];
+    if (jcol) {
+#pragma unroll
+        for (int q = 0; q < kGB; q++) rp[q] = q < nb ? st.Dinv[q * kGB + (j - k0)] : 0.0;
+    } else {
+        double col[kGB];
+#pragma unroll
+        for (int w = 0; w < kGB; w++) col[w] = w < nb ? Mo[(size_t)s_old[half][kGRows + w] * n + j] : 0.0;
+#pragma unroll
+        for (int q = 0; q < kGB; q++) {
+            double sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < kGB; w++) sum += st.Dinv[q * kGB + w] * col[w];
+            rp[q] = q < nb ? sum : 0.0;
+        }
+    }
+    double mo[kGRows];
+#pragma unroll
+    for (int sI = 0; sI < kGRows; sI++) mo[sI] = (i0 + sI < n && !jcol) ? Mo[(size_t)s_old[half][sI] * n + j] : 0.0;
+#pragma unroll
+    for (int sI = 0; sI < kGRows; sI++) {
+        const int i = i0 + sI;
+        if (i >= n) break;
+        double *mp = Mn + (size_t)i * n + j;
+        if (i >= k0 && i < k0 + nb) { *mp = rp[i - k0]; continue; }           // rows of the pivot block
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < kGB; q++) acc += cc[half][sI][q] * rp[q];
+        *mp = jcol ? -acc : mo[sI] - acc;
+    }
+}
+
 // colsrc = the row swaps applied to 0 .. n-1 in reverse order (one workgroup, the list in LDS, one thread walks the swaps)
 __global__ void __launch_bounds__(1024) gj_colsrc_kernel(int n, const int *__restrict__ piv_all, int *__restrict__ colsrc)
 {
@@ -455,6 +605,21 @@ void dense_inverse_general(const DevCSR &A, double *Minv)
             zero_async(singular.p, sizeof(int));
             hipLaunchKernelGGL(dense_scatter_plain_kernel, dim3((n + kB - 1) / kB), dim3(kB), 0, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, Mo);
             const dim3 gu((n + 255) / 256, (n + kGRows - 1) / kGRows);
+            const char *e_ovl = getenv("ELAG_HIP_LU_LOOKAHEAD");            // (0 = a panel launch and an update launch per step: A/B runs and a test)
+            if (!(e_ovl && !atoi(e_ovl)) && !dbgp) {
+                // the update of a step and the panel of the next one in one launch (gj_block_step_kernel); the first panel by itself
+                Temp<GjStep> step2(1);
+                GjStep *sa = step.p, *sb = step2.p;
+                hipLaunchKernelGGL(gj_block_panel_kernel, dim3(1), dim3(kGThreads), 0, st, n, 0, (const double *)Mo, piv_all.p, sa, singular.p, (long long *)nullptr);
+                const dim3 gs(1 + ((n + 255) / 256) * ((n + 2 * kGRows - 1) / (2 * kGRows)));
+                for (int k0 = 0; k0 < n; k0 += kGB) {
+                    if (k0 + kGB < n)
+                        hipLaunchKernelGGL(gj_lookahead_cols_kernel, dim3((n + 31) / 32), dim3(256), 0, st, n, k0, (const double *)Mo, Mn, (const GjStep *)sa);
+                    hipLaunchKernelGGL(gj_block_step_kernel, gs, dim3(kGThreads), 0, st, n, k0, (const double *)Mo, Mn, (const GjStep *)sa, sb, piv_all.p, singular.p);
+                    std::swap(Mo, Mn);
+                    std::swap(sa, sb);
+                }
+            } else
             for (int k0 = 0; k0 < n; k0 += kGB) {
                 hipLaunchKernelGGL(gj_block_panel_kernel, dim3(1), dim3(kGThreads), 0, st, n, k0, (const double *)Mo, piv_all.p, step.p,
                                    singular.p, dbgp);

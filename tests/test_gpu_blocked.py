@@ -446,7 +446,7 @@ def test_blocked_dense_lu_is_the_column_by_column_one(la, n):
     A = orc.csr(A)
     b = rng.uniform(-1, 1, n)
     xs = []
-    for env in ({}, {"ELAG_HIP_LU_BLOCKED": "0"}):
+    for env in ({}, {"ELAG_HIP_LU_BLOCKED": "0"}, {"ELAG_HIP_LU_LOOKAHEAD": "0"}):
         saved_env = {k: os.environ.get(k) for k in env}      # (a variable the run itself was started with is put back, not dropped)
         os.environ.update(env)
         try:
@@ -465,6 +465,9 @@ def test_blocked_dense_lu_is_the_column_by_column_one(la, n):
     for x in xs:
         assert np.max(np.abs(x - ref)) <= 1e-10 * scale
     assert np.max(np.abs(xs[0] - xs[1])) <= 1e-10 * scale
+    # the blocked form with a step's update and the next step's panel in one launch (gj_block_step_kernel, the default) and with a launch each
+    # (ELAG_HIP_LU_LOOKAHEAD=0): the same operations, the same inverse to the last bit
+    assert np.array_equal(xs[0], xs[2])
 
 
 @pytest.mark.parametrize("n", [1, 2, 7, 8, 50, 97, 140, 141])

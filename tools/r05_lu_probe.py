@@ -2,7 +2,7 @@
 """Round 5: the dense inverse of the Darcy hierarchy's coarsest (saddle-point) operator by phase (ELAG_HIP_LU_TIMING=1 prints the panel kernel's clocks)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["ELAG_HIP_LU_TIMING"] = "1"
+os.environ.setdefault("ELAG_HIP_LU_TIMING", "1")
 import numpy as np, scipy.sparse as sp
 from parelag_amd import linalg as la
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1471
