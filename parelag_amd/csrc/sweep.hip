@@ -888,6 +888,12 @@ int gs_hybrid_blocks()
 
 }  // namespace
 
+void preload_sweep_kernels()
+{
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(sched_pack_kernel));
+}
+
 SweepSmoother::~SweepSmoother() { dev_free(d_rows); dev_free(d_lev_ptr); dev_free(d_l1); dev_free(d_sJ); dev_free(d_sa); dev_free(d_self_ghost); dev_free(d_blk_first); dev_free(d_blk_count); dev_free(d_lev_rows); dev_free(d_v);
     dev_free(d_df_slots); dev_free(d_df_J); dev_free(d_df_a); dev_free(d_df_gran); dev_free(d_df_state); }
 
