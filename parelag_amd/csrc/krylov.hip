@@ -844,8 +844,10 @@ struct elag_hip_krylov_s {
     elag_hip_coarse_s *pcoarse = nullptr;
     // device state
     KState *st = nullptr;
-    int *h_flags = nullptr;       // pinned mirror of st->fl
-    double *h_sc = nullptr;       // pinned mirror of st->sc
+    // host mirrors of st->fl and of the leading scalars of st->sc (filled from the fetched words: plain memory -- a solver's construction used
+    // to pin two blocks of its own and hipMalloc its state block, ~0.4 ms each time and ~9 ms the first time in a process)
+    int h_flags[F_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double h_sc[S_COUNT] = {};
     double *x = nullptr, *r = nullptr, *z = nullptr, *d = nullptr, *w = nullptr, *scr = nullptr;
     double *V = nullptr, *Z = nullptr, *hs = nullptr, *part = nullptr;
     u64k *gm_gran = nullptr;                      // gmres_chain_kernel's tagged sums, [restart + 2][kChainG][2]
@@ -872,18 +874,14 @@ struct elag_hip_krylov_s {
         dev_free(x); dev_free(r); dev_free(z); dev_free(d); dev_free(w); dev_free(scr); dev_free(V); dev_free(Z); dev_free(hs); dev_free(part);
         dev_free(bperm); dev_free(gm_gran);
         for (auto &p : e) dev_free(p);
-        if (st) (void)hipFree(st);
-        if (h_flags) (void)hipHostFree(h_flags);
-        if (h_sc) (void)hipHostFree(h_sc);
+        dev_free(st);
     }
 
     void setup()
     {
         const size_t nn = (size_t)n();
-        ELAG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&st), sizeof(KState)));
-        ELAG_HIP_CHECK(hipMemset(st, 0, sizeof(KState)));
-        ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_flags), sizeof(int) * F_COUNT));
-        ELAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_sc), sizeof(double) * S_COUNT));
+        st = reinterpret_cast<KState *>(dev_alloc<double>((sizeof(KState) + sizeof(double) - 1) / sizeof(double)));
+        zero_async(st, sizeof(KState));
         Aop = A;
         if (prec_kind == ELAG_HIP_PREC_HIERARCHY && !distributed() && std::getenv("ELAG_HIP_KRYLOV_NATURAL") == nullptr) {
             ParCSR *Ai = nullptr;
