@@ -735,7 +735,7 @@ template <class T>
 T *arena_from_host(const T *h, size_t n)
 {
     T *p = arena_alloc<T>(n);
-    if (n) ELAG_HIP_CHECK(hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, ctx().stream));
+    if (n) stage_h2d(p, h, n * sizeof(T));
     return p;
 }
 
@@ -889,11 +889,11 @@ ELAG_HIP_API int elag_hip_coarsen_traces(const elag_hip_coarsen_traces_in *in, c
         ELAG_LAUNCH_CHECK();
         if (kernel_ms) *kernel_ms = ms;
         int bad = 0;
-        ELAG_HIP_CHECK(hipMemcpyAsync(&bad, d_sing.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        ELAG_HIP_CHECK(hipMemcpyAsync(out->ncoarse, d_nc.p, sizeof(int) * ne, hipMemcpyDeviceToHost, st));
-        ELAG_HIP_CHECK(hipMemcpyAsync(out->p_loc, d_p.p, sizeof(double) * nd * kmax, hipMemcpyDeviceToHost, st));
-        ELAG_HIP_CHECK(hipMemcpyAsync(out->cmass, d_cm.p, sizeof(double) * (size_t)ne * kmax * kmax, hipMemcpyDeviceToHost, st));
-        ELAG_HIP_CHECK(hipMemcpyAsync(out->functional, d_f.p, sizeof(double) * nd * kmax, hipMemcpyDeviceToHost, st));
+        stage_d2h(&bad, d_sing.p, sizeof(int));
+        stage_d2h(out->ncoarse, d_nc.p, sizeof(int) * ne);
+        stage_d2h(out->p_loc, d_p.p, sizeof(double) * nd * kmax);
+        stage_d2h(out->cmass, d_cm.p, sizeof(double) * (size_t)ne * kmax * kmax);
+        stage_d2h(out->functional, d_f.p, sizeof(double) * nd * kmax);
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
         if (bad) fail(ELAG_HIP_ERR_NUMERIC, "coarsen_traces: %d entities with a singular coarse mass matrix", bad);
     });
@@ -977,9 +977,9 @@ ELAG_HIP_API int elag_hip_coarsen_extension(const elag_hip_coarsen_extension_in 
         ELAG_LAUNCH_CHECK();
         if (kernel_ms) *kernel_ms = ms;
         int bad = 0;
-        ELAG_HIP_CHECK(hipMemcpyAsync(&bad, d_sing.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        ELAG_HIP_CHECK(hipMemcpyAsync(out->n_null, d_nnull.p, sizeof(int) * ne, hipMemcpyDeviceToHost, st));
-        auto down = [&](double *h, const double *d, int64_t n) { if (n) ELAG_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(double) * n, hipMemcpyDeviceToHost, st)); };
+        stage_d2h(&bad, d_sing.p, sizeof(int));
+        stage_d2h(out->n_null, d_nnull.p, sizeof(int) * ne);
+        auto down = [&](double *h, const double *d, int64_t n) { if (n) stage_d2h(h, d, sizeof(double) * n); };
         down(out->ext, d_ext, o_ext[ne]); down(out->dc, d_dc, o_dc[ne]); down(out->rt, d_rt, o_rt[ne]); down(out->nul, d_nul, o_nul[ne]);
         down(out->functional, d_fun, o_fun[ne]); down(out->cmass, d_cm, o_cm[ne]);
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
@@ -1016,7 +1016,7 @@ ELAG_HIP_API int elag_hip_batched_rank(int n_mat, const int *nrows, const int *n
             hipLaunchKernelGGL(batched_rank_kernel, dim3(n), dim3(threads), lds, st, a);
         });
         ELAG_LAUNCH_CHECK();
-        ELAG_HIP_CHECK(hipMemcpyAsync(rank, d_rank.p, sizeof(int) * n_mat, hipMemcpyDeviceToHost, st));
+        stage_d2h(rank, d_rank.p, sizeof(int) * n_mat);
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
     });
 }

@@ -241,8 +241,7 @@ void BlockSmoother::setup()
             for (int i = 0; i < nb; i++) {
                 const size_t ni = (size_t)(B->row_off[(size_t)i + 1] - B->row_off[(size_t)i]);
                 if (ni)
-                    ELAG_HIP_CHECK(hipMemcpyAsync(dscale + B->row_off[(size_t)i], inv[(size_t)i]->diag_scaling(), sizeof(double) * ni,
-                                                  hipMemcpyDeviceToDevice, ctx().stream));
+                    dev_copy(dscale + B->row_off[(size_t)i], inv[(size_t)i]->diag_scaling(), sizeof(double) * ni, ctx().stream);
             }
         }
     }
@@ -314,7 +313,7 @@ void BlockSmoother::block_solve(const double *r, double *t, bool transpose)
             } else {
                 ParCSR *Aji = B->block(j, i);
                 if (!Aji) continue;
-                if (first && ni) ELAG_HIP_CHECK(hipMemcpyAsync(ti, ri, sizeof(double) * (size_t)ni, hipMemcpyDeviceToDevice, ctx().stream));
+                if (first && ni) dev_copy(ti, ri, sizeof(double) * (size_t)ni, ctx().stream);
                 par_spmvT(*Aji, -1.0, t + off[(size_t)j], 1.0, ti);
             }
             first = false;

@@ -145,7 +145,7 @@ static void hub_exchange(const void *sendbuf, int nsend, const int *send_procs, 
         }
         if (msg.bytes != n) fail(ELAG_HIP_ERR_COMM, "hub: rank %d expected %zu bytes from %d, got %zu", me, n, recv_procs[i], msg.bytes);
         ELAG_HIP_CHECK(hipStreamWaitEvent(st, msg.ready, 0));
-        ELAG_HIP_CHECK(hipMemcpyAsync(static_cast<char *>(recvbuf) + (size_t)recv_starts[i] * elem_bytes, msg.ptr, n, hipMemcpyDeviceToDevice, st));
+        dev_copy(static_cast<char *>(recvbuf) + (size_t)recv_starts[i] * elem_bytes, msg.ptr, n, st);
         hipEvent_t done = ep->event();
         ELAG_HIP_CHECK(hipEventRecord(done, st));
         if (sync) ELAG_HIP_CHECK(hipStreamSynchronize(st));
@@ -267,7 +267,7 @@ void comm_neighbor_exchange(const void *sendbuf, int nsend, const int *send_proc
                                    reinterpret_cast<const unsigned long long *>(src), reinterpret_cast<unsigned long long *>(dst));
                 ELAG_HIP_CHECK(hipGetLastError());
             } else {
-                ELAG_HIP_CHECK(hipMemcpyAsync(dst, src, nb, hipMemcpyDeviceToDevice, st));
+                dev_copy(dst, src, nb, st);
             }
         }
     }
@@ -298,7 +298,7 @@ void comm_allgatherv(const double *send, double *recv, const int *counts, const 
     Context &x = ctx();
     const int me = x.rank, n = x.nranks;
     if (counts[me])
-        ELAG_HIP_CHECK(hipMemcpyAsync(recv + displs[me], send, sizeof(double) * (size_t)counts[me], hipMemcpyDeviceToDevice, st));
+        dev_copy(recv + displs[me], send, sizeof(double) * (size_t)counts[me], st);
     if (n == 1) return;
     if (!comm_active()) fail(ELAG_HIP_ERR_COMM, "all-gather without a communicator");
     if (x.comm_kind == 2) {

@@ -182,6 +182,9 @@ constexpr size_t kHostStage = size_t(4) << 20;
 // setup path's read-backs and small uploads.  The copy API's own paths (DMA queues, staging pools) grow lazily and each growth is a 6-7 ms
 // stall of one hipMemcpyAsync somewhere in a process's first few thousand copies -- measured as idle gaps in the kernel traces of first
 // hierarchy builds, at call sites that moved with the number of copies issued before them.  ELAG_HIP_KERNEL_COPIES=0: the copy API.
+// device-to-device copy by a kernel on stream st (the compute stream if null): the copy API costs the host 8-10 us a call where a launch costs ~4,
+// and its first call of a process -- in any direction -- 8 ms
+void dev_copy(void *dst, const void *src, size_t bytes, hipStream_t st = nullptr);
 void stage_d2h(void *host_dst, const void *dev_src, size_t bytes);
 void stage_h2d(void *dev_dst, const void *host_src, size_t bytes);
 template <class T>

@@ -132,11 +132,11 @@ void DevCSR::upload(int nr, int nc, const int *hi, const int *hj, const double *
         ELAG_REQUIRE(hj[k] >= 0 && hj[k] < nc, "column index %d out of range [0,%d) at entry %lld", hj[k], nc, (long long)k);
     alloc(nr, nc, nz);
     hipStream_t st = ctx().stream;
-    if (nr) ELAG_HIP_CHECK(hipMemcpyAsync(I, hi, sizeof(int) * ((size_t)nr + 1), hipMemcpyHostToDevice, st));
+    if (nr) stage_h2d(I, hi, sizeof(int) * ((size_t)nr + 1));
     else zero_async(I, sizeof(int));
     if (nz) {
-        ELAG_HIP_CHECK(hipMemcpyAsync(J, hj, sizeof(int) * (size_t)nz, hipMemcpyHostToDevice, st));
-        ELAG_HIP_CHECK(hipMemcpyAsync(a, ha, sizeof(double) * (size_t)nz, hipMemcpyHostToDevice, st));
+        stage_h2d(J, hj, sizeof(int) * (size_t)nz);
+        stage_h2d(a, ha, sizeof(double) * (size_t)nz);
     }
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
     // (the longest row is free here -- the row pointers are on the host -- and it is what decides whether a sparse product may take this
@@ -184,11 +184,31 @@ bool kernel_copies()
 }
 }  // namespace
 
+// The copy API's first transfer from or to pageable memory costs a process 7-9 ms in either direction (its staging is built on first use); a
+// transfer through the library's own pinned buffer and a copy kernel costs ~0.15 ms per MB and nothing the first time.  So: transfers of up to
+// 8 staging buffers go through the kernel -- until a larger one has taken the copy API in that direction, which is the faster way from then
+// on (cube456 x3: the first upload of a process 8.7 -> 1.4 ms, its first read-back 7.3 -> 0.1 ms; every later one as before)
+std::atomic<bool> g_api_h2d{false}, g_api_d2h{false};
+// ... or until the process has moved so much through the staging buffer (64 MB in a direction) that the copy API's start-up would have paid by now
+std::atomic<size_t> g_staged_h2d{0}, g_staged_d2h{0};
+constexpr size_t kStagedSwitch = size_t(64) << 20;
+
+void dev_copy(void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0 || dst == src) return;
+    if (!st) st = ctx().stream;
+    const unsigned g = (unsigned)std::min<size_t>((bytes / 16 + 255) / 256 + 1, 4096);
+    hipLaunchKernelGGL(stage_copy_kernel, dim3(g), dim3(256), 0, st, static_cast<const unsigned char *>(src), static_cast<unsigned char *>(dst), bytes);
+    ELAG_LAUNCH_CHECK();
+}
+
 void stage_d2h(void *host_dst, const void *dev_src, size_t bytes)
 {
     Context &c = ctx();
     if (bytes == 0) return;
-    if (!c.h_stage || !kernel_copies()) {
+    if (bytes > 120 && g_staged_d2h.fetch_add(bytes) > kStagedSwitch) g_api_d2h.store(true);
+    if (!c.h_stage || !kernel_copies() || bytes > 8 * kHostStage || g_api_d2h.load()) {
+        if (bytes > 120) g_api_d2h.store(true);
         ELAG_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c.stream));
         ELAG_HIP_CHECK(hipStreamSynchronize(c.stream));
         return;
@@ -213,7 +233,9 @@ void stage_h2d(void *dev_dst, const void *host_src, size_t bytes)
 {
     Context &c = ctx();
     if (bytes == 0) return;
-    if (!c.h_stage || !kernel_copies() || bytes > 8 * kHostStage) {           // (large uploads: the copy API's pipelined path)
+    if (g_staged_h2d.fetch_add(bytes) > kStagedSwitch) g_api_h2d.store(true);
+    if (!c.h_stage || !kernel_copies() || bytes > 8 * kHostStage || g_api_h2d.load()) {           // (large uploads: the copy API's pipelined path)
+        g_api_h2d.store(true);
         ELAG_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c.stream));
         return;
     }
@@ -762,11 +784,9 @@ int elag_hip_memcpy(void *dst, const void *src, size_t bytes, int kind)
     return guarded([&] {
         require_init();
         ELAG_REQUIRE(kind >= 0 && kind <= 2, "bad memcpy kind %d", kind);
-        const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : (kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
-        if (bytes) {
-            ELAG_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, k, ctx().stream));
-            if (kind != 2) ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
-        }
+        if (bytes && kind == 0) { stage_h2d(dst, src, bytes); ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream)); }
+        else if (bytes && kind == 1) stage_d2h(dst, src, bytes);
+        else if (bytes) dev_copy(dst, src, bytes);
     });
 }
 

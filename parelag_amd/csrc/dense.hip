@@ -956,7 +956,7 @@ void dense_inverse_spd(const DevCSR &A, double *Minv)
         hipLaunchKernelGGL(dense_scatter_plain_kernel, dim3((n + kB - 1) / kB), dim3(kB), 0, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, M);
         // the (numerically symmetric) input made exactly symmetric first, like the host path
         hipLaunchKernelGGL(symmetrise_kernel, dim3((n + kB - 1) / kB, n), dim3(kB), 0, st, n, (const double *)M, Minv);
-        ELAG_HIP_CHECK(hipMemcpyAsync(M, Minv, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, st));
+        dev_copy(M, Minv, sizeof(double) * (size_t)n * n, st);
         const char *e_blk = getenv("ELAG_HIP_SPD_BLOCKED");                 // (0 = the pivot-by-pivot sweeps: A/B runs and a test)
         if (!(e_blk && !atoi(e_blk))) {
             Temp<double> Dinv((size_t)kNB * kNB), Rp((size_t)kNB * n), Cc((size_t)n * kNB);

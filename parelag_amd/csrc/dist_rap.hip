@@ -83,16 +83,16 @@ void vstack(const DevCSR &X, const DevCSR &Y, DevCSR &out)
 {
     hipStream_t st = ctx().stream;
     out.alloc(X.nrows + Y.nrows, X.ncols, X.nnz + Y.nnz);
-    ELAG_HIP_CHECK(hipMemcpyAsync(out.I, X.I, sizeof(int) * ((size_t)X.nrows + 1), hipMemcpyDeviceToDevice, st));
+    dev_copy(out.I, X.I, sizeof(int) * ((size_t)X.nrows + 1), st);
     if (Y.nrows)
         hipLaunchKernelGGL(add_offset_kernel, dim3(g1(Y.nrows)), dim3(kB), 0, st, Y.nrows, (const int *)(Y.I + 1), (int)X.nnz, out.I + X.nrows + 1);
     if (X.nnz) {
-        ELAG_HIP_CHECK(hipMemcpyAsync(out.J, X.J, sizeof(int) * (size_t)X.nnz, hipMemcpyDeviceToDevice, st));
-        ELAG_HIP_CHECK(hipMemcpyAsync(out.a, X.a, sizeof(double) * (size_t)X.nnz, hipMemcpyDeviceToDevice, st));
+        dev_copy(out.J, X.J, sizeof(int) * (size_t)X.nnz, st);
+        dev_copy(out.a, X.a, sizeof(double) * (size_t)X.nnz, st);
     }
     if (Y.nnz) {
-        ELAG_HIP_CHECK(hipMemcpyAsync(out.J + X.nnz, Y.J, sizeof(int) * (size_t)Y.nnz, hipMemcpyDeviceToDevice, st));
-        ELAG_HIP_CHECK(hipMemcpyAsync(out.a + X.nnz, Y.a, sizeof(double) * (size_t)Y.nnz, hipMemcpyDeviceToDevice, st));
+        dev_copy(out.J + X.nnz, Y.J, sizeof(int) * (size_t)Y.nnz, st);
+        dev_copy(out.a + X.nnz, Y.a, sizeof(double) * (size_t)Y.nnz, st);
     }
     ELAG_LAUNCH_CHECK();
     out.choose_spmv_shape();
@@ -103,15 +103,15 @@ void slice_rows(const DevCSR &X, int r0, int r1, DevCSR &out)
 {
     hipStream_t st = ctx().stream;
     int b[2] = {0, 0};
-    ELAG_HIP_CHECK(hipMemcpyAsync(&b[0], X.I + r0, sizeof(int), hipMemcpyDeviceToHost, st));
-    ELAG_HIP_CHECK(hipMemcpyAsync(&b[1], X.I + r1, sizeof(int), hipMemcpyDeviceToHost, st));
+    stage_d2h(&b[0], X.I + r0, sizeof(int));
+    stage_d2h(&b[1], X.I + r1, sizeof(int));
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
     const int n = r1 - r0, nnz = b[1] - b[0];
     out.alloc(n, X.ncols, nnz);
     hipLaunchKernelGGL(add_offset_kernel, dim3(g1(n + 1)), dim3(kB), 0, st, n + 1, (const int *)(X.I + r0), -b[0], out.I);
     if (nnz) {
-        ELAG_HIP_CHECK(hipMemcpyAsync(out.J, X.J + b[0], sizeof(int) * (size_t)nnz, hipMemcpyDeviceToDevice, st));
-        ELAG_HIP_CHECK(hipMemcpyAsync(out.a, X.a + b[0], sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, st));
+        dev_copy(out.J, X.J + b[0], sizeof(int) * (size_t)nnz, st);
+        dev_copy(out.a, X.a + b[0], sizeof(double) * (size_t)nnz, st);
     }
     ELAG_LAUNCH_CHECK();
     out.choose_spmv_shape();
@@ -230,7 +230,7 @@ std::vector<double> allgather_scalar(double v)
     std::vector<double> out((size_t)nr, v);
     if (nr == 1) return out;
     Temp<double> dv(1), dall((size_t)nr);
-    ELAG_HIP_CHECK(hipMemcpyAsync(dv.p, &v, sizeof(double), hipMemcpyHostToDevice, c.stream));
+    stage_h2d(dv.p, &v, sizeof(double));
     ELAG_HIP_CHECK(hipStreamSynchronize(c.stream));
     std::vector<int> counts((size_t)nr, 1), displs((size_t)nr);
     std::iota(displs.begin(), displs.end(), 0);
@@ -266,8 +266,8 @@ ParCSR *parcsr_from_global_columns(const DevCSR &Cg, int64_t first_row, int64_t 
         k::exclusive_scan(nd, M->diag.I, n);
         k::exclusive_scan(no, M->offd.I, n);
         int tot[2] = {0, 0};
-        ELAG_HIP_CHECK(hipMemcpyAsync(&tot[0], M->diag.I + n, sizeof(int), hipMemcpyDeviceToHost, st));
-        ELAG_HIP_CHECK(hipMemcpyAsync(&tot[1], M->offd.I + n, sizeof(int), hipMemcpyDeviceToHost, st));
+        stage_d2h(&tot[0], M->diag.I + n, sizeof(int));
+        stage_d2h(&tot[1], M->offd.I + n, sizeof(int));
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
         M->diag.alloc_entries(tot[0]);
         M->offd.alloc_entries(tot[1]);
@@ -280,7 +280,7 @@ ParCSR *parcsr_from_global_columns(const DevCSR &Cg, int64_t first_row, int64_t 
             cmap.erase(std::unique(cmap.begin(), cmap.end()), cmap.end());
             ncm = (int)cmap.size();
             Temp<int> dcm((size_t)ncm);
-            ELAG_HIP_CHECK(hipMemcpyAsync(dcm.p, cmap.data(), sizeof(int) * (size_t)ncm, hipMemcpyHostToDevice, st));
+            stage_h2d(dcm.p, cmap.data(), sizeof(int) * (size_t)ncm);
             hipLaunchKernelGGL(split_remap_kernel, dim3(g1(tot[1])), dim3(kB), 0, st, tot[1], M->offd.J, (const int *)dcm.p, ncm);
             ELAG_LAUNCH_CHECK();
         }
@@ -307,7 +307,7 @@ ParCSR *parcsr_from_global_columns(const DevCSR &Cg, int64_t first_row, int64_t 
         // all-gather the need matrix (nr x nr): need_all[r * nr + q] = number of columns rank r wants from rank q
         Temp<double> dn((size_t)nr), dall((size_t)nr * nr);
         std::vector<double> needd(need.begin(), need.end());
-        ELAG_HIP_CHECK(hipMemcpyAsync(dn.p, needd.data(), sizeof(double) * (size_t)nr, hipMemcpyHostToDevice, st));
+        stage_h2d(dn.p, needd.data(), sizeof(double) * (size_t)nr);
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
         std::vector<int> counts((size_t)nr, nr), displs((size_t)nr);
         for (int r = 0; r < nr; r++) displs[(size_t)r] = r * nr;
@@ -321,7 +321,7 @@ ParCSR *parcsr_from_global_columns(const DevCSR &Cg, int64_t first_row, int64_t 
         // requests: I send the global ids I need to their owners and receive the ids others need from me
         const int st_total = M->send_starts.back();
         Temp<int> dreq((size_t)ncm), dgot((size_t)st_total);
-        if (ncm) ELAG_HIP_CHECK(hipMemcpyAsync(dreq.p, cmap.data(), sizeof(int) * (size_t)ncm, hipMemcpyHostToDevice, st));
+        if (ncm) stage_h2d(dreq.p, cmap.data(), sizeof(int) * (size_t)ncm);
         exchange_sync(dreq, (int)M->recv_procs.size(), M->recv_procs.data(), M->recv_starts.data(), dgot, (int)M->send_procs.size(),
                       M->send_procs.data(), M->send_starts.data(), sizeof(int));
         std::vector<int> got = host_from_dev((const int *)dgot.p, (size_t)st_total);
@@ -345,7 +345,7 @@ static void to_global(ParCSR &M, DevCSR &out)
     ELAG_REQUIRE(M.global_cols < (int64_t(1) << 31), "global sizes beyond 2^31 are not supported");
     std::vector<int> cm(M.col_map_offd.begin(), M.col_map_offd.end());
     Temp<int> dcm(cm.size());
-    if (!cm.empty()) ELAG_HIP_CHECK(hipMemcpyAsync(dcm.p, cm.data(), sizeof(int) * cm.size(), hipMemcpyHostToDevice, st));
+    if (!cm.empty()) stage_h2d(dcm.p, cm.data(), sizeof(int) * cm.size());
     concat_rows(M.diag, nullptr, (int)M.first_col, M.offd.ncols ? &M.offd : nullptr, dcm.p, 0, (int)M.global_cols, true, out);
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
 }
@@ -454,7 +454,7 @@ ParCSR *replicate_matrix(ParCSR &A, std::vector<int64_t> *row_starts_out)
     {
         std::vector<int> cm(A.col_map_offd.begin(), A.col_map_offd.end());
         Temp<int> dcm(cm.size());
-        if (!cm.empty()) ELAG_HIP_CHECK(hipMemcpyAsync(dcm.p, cm.data(), sizeof(int) * cm.size(), hipMemcpyHostToDevice, st));
+        if (!cm.empty()) stage_h2d(dcm.p, cm.data(), sizeof(int) * cm.size());
         concat_rows(A.diag, nullptr, (int)A.first_col, A.offd.ncols ? &A.offd : nullptr, dcm.p, 0, (int)A.global_cols, true, Ag);
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
     }
@@ -476,7 +476,7 @@ ParCSR *replicate_matrix(ParCSR &A, std::vector<int64_t> *row_starts_out)
             for (int i = 0; i < n; i++) idx.push_back(i);
         }
         Temp<int> didx(idx.size());
-        if (!idx.empty()) ELAG_HIP_CHECK(hipMemcpyAsync(didx.p, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice, st));
+        if (!idx.empty()) stage_h2d(didx.p, idx.data(), sizeof(int) * idx.size());
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
         DevCSR others;
         exchange_rows(Ag, didx.p, procs, sst, procs, rst, others);
@@ -512,7 +512,7 @@ ParCSR *distributed_rap(ParCSR &RT, ParCSR &A, ParCSR &P, bool ignore_nonlocal_r
     {
         std::vector<int> cm(P.col_map_offd.begin(), P.col_map_offd.end());
         Temp<int> dcm(cm.size());
-        if (!cm.empty()) ELAG_HIP_CHECK(hipMemcpyAsync(dcm.p, cm.data(), sizeof(int) * cm.size(), hipMemcpyHostToDevice, st));
+        if (!cm.empty()) stage_h2d(dcm.p, cm.data(), sizeof(int) * cm.size());
         concat_rows(P.diag, nullptr, (int)P.first_col, P.offd.ncols ? &P.offd : nullptr, dcm.p, 0, (int)P.global_cols, true, Pg);
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
     }

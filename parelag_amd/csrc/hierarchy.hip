@@ -728,9 +728,9 @@ struct elag_hip_hierarchy_s {
             const double *w = F.dist_w;
             // W on [own | ghost] entries
             Temp<double> wext((size_t)std::max(next, 1));
-            ELAG_HIP_CHECK(hipMemcpyAsync(wext.p, w, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx().stream));
+            dev_copy(wext.p, w, sizeof(double) * (size_t)n, ctx().stream);
             par_halo_exchange(*F.A, w);                                                          // (collective: every rank is here)
-            if (ng) ELAG_HIP_CHECK(hipMemcpyAsync(wext.p + n, F.A->d_ghost, sizeof(double) * (size_t)ng, hipMemcpyDeviceToDevice, ctx().stream));
+            if (ng) dev_copy(wext.p + n, F.A->d_ghost, sizeof(double) * (size_t)ng, ctx().stream);
             std::vector<std::shared_ptr<DevCSR>> U((size_t)m), V((size_t)m), Gc((size_t)m), Vc((size_t)m);
             DevCSR Aloc;                                                                         // [diag | offd], n x (n + ng)
             csr_hstack(F.A->diag, nullptr, 0, ng ? &F.A->offd : nullptr, nullptr, n, next, false, Aloc);
@@ -851,7 +851,7 @@ struct elag_hip_hierarchy_s {
                     DevCSR Ds2, Sc;
                     Ds2.upload(n, n, hi.data(), hj.data(), ha.data());
                     Temp<double> ds2((size_t)n);
-                    ELAG_HIP_CHECK(hipMemcpyAsync(ds2.p, ha.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx().stream));
+                    stage_h2d(ds2.p, ha.data(), sizeof(double) * (size_t)n);
                     if (cs->cheby_order == 1) {
                         DevCSR T;
                         k::csr_copy(F.A->diag, T);
@@ -1512,10 +1512,10 @@ int elag_hip_hierarchy_apply(elag_hip_hierarchy_t H, const double *rhs, double *
             // host vectors are staged through the level-0 scratch (stable addresses keep the graph cache warm)
             hipStream_t st = ctx().stream;
             double *drhs = H->lev[0].resid, *dsol = H->lev[0].sol;
-            ELAG_HIP_CHECK(hipMemcpyAsync(drhs, rhs, n * sizeof(double), hipMemcpyHostToDevice, st));
-            if (!is_preconditioner) ELAG_HIP_CHECK(hipMemcpyAsync(dsol, sol, n * sizeof(double), hipMemcpyHostToDevice, st));
+            stage_h2d(drhs, rhs, n * sizeof(double));
+            if (!is_preconditioner) stage_h2d(dsol, sol, n * sizeof(double));
             H->apply_device(drhs, dsol, is_preconditioner != 0);
-            ELAG_HIP_CHECK(hipMemcpyAsync(sol, dsol, n * sizeof(double), hipMemcpyDeviceToHost, st));
+            stage_d2h(sol, dsol, n * sizeof(double));
             ELAG_HIP_CHECK(hipStreamSynchronize(st));
         }
     });
@@ -1540,7 +1540,7 @@ int elag_hip_coarse_create_from_hierarchy(elag_hip_coarse_t *out, elag_hip_hiera
             const double *src = rhs;
             if (allreduce_rhs && comm_active()) {
                 // sum the ranks' partial restricted residuals: one collective on the comm stream, fork/join by events
-                ELAG_HIP_CHECK(hipMemcpyAsync(buf, rhs, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, c.stream));
+                dev_copy(buf, rhs, sizeof(double) * (size_t)n, c.stream);
                 ELAG_HIP_CHECK(hipEventRecord(c.ev_pack, c.stream));
                 ELAG_HIP_CHECK(hipStreamWaitEvent(c.comm_stream, c.ev_pack, 0));
                 comm_allreduce_device(buf, n, 0, c.comm_stream);

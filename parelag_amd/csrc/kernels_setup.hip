@@ -1772,11 +1772,11 @@ bool lds_atomics_lane_ordered()
     int *dw = nullptr, *ds = nullptr;
     hipStream_t st = ctx().stream;
     dv = dev_alloc<double>(v.size()); dout = dev_alloc<double>(out.size()); dw = dev_alloc<int>(win.size()); ds = dev_alloc<int>(slot.size());
-    ELAG_HIP_CHECK(hipMemcpyAsync(dv, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice, st));
-    ELAG_HIP_CHECK(hipMemcpyAsync(ds, slot.data(), sizeof(int) * slot.size(), hipMemcpyHostToDevice, st));
+    stage_h2d(dv, v.data(), sizeof(double) * v.size());
+    stage_h2d(ds, slot.data(), sizeof(int) * slot.size());
     hipLaunchKernelGGL(lds_order_probe_kernel, dim3(NB), dim3(64), 0, st, (const double *)dv, (const int *)ds, dout, dw);
-    ELAG_HIP_CHECK(hipMemcpyAsync(out.data(), dout, sizeof(double) * out.size(), hipMemcpyDeviceToHost, st));
-    ELAG_HIP_CHECK(hipMemcpyAsync(win.data(), dw, sizeof(int) * win.size(), hipMemcpyDeviceToHost, st));
+    stage_d2h(out.data(), dout, sizeof(double) * out.size());
+    stage_d2h(win.data(), dw, sizeof(int) * win.size());
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
     dev_free(dv); dev_free(dout); dev_free(dw); dev_free(ds);
     bool ok = true;
@@ -2619,7 +2619,7 @@ void csr_transpose(const DevCSR &A, DevCSR &AT)
     exclusive_scan(cnt, AT.I, A.ncols);
     if (A.nnz) {
         Temp<int> cursor((size_t)A.ncols);
-        ELAG_HIP_CHECK(hipMemcpyAsync(cursor, AT.I, sizeof(int) * (size_t)A.ncols, hipMemcpyDeviceToDevice, st));
+        dev_copy(cursor, AT.I, sizeof(int) * (size_t)A.ncols, st);
         hipLaunchKernelGGL(transpose_fill_kernel, dim3(grid1(A.nrows)), dim3(kBlock), 0, st, A.nrows, (const int *)A.I,
                            (const int *)A.J, (const double *)A.a, cursor.p, AT.J, AT.a);
         ELAG_LAUNCH_CHECK();
@@ -2792,7 +2792,7 @@ void child_order(const DevCSR &P, const int *d_rank_c, int *d_order_out)
                        K.I, K.J, K.a);
     ELAG_LAUNCH_CHECK();
     csr_transpose(K, KT);            // row p of KT: the children of the coarse dof of rank p, ascending
-    ELAG_HIP_CHECK(hipMemcpyAsync(d_order_out, KT.J, sizeof(int) * (size_t)nf, hipMemcpyDeviceToDevice, st));
+    dev_copy(d_order_out, KT.J, sizeof(int) * (size_t)nf, st);
     // (no drain: K / KT go back to the pool, which hands them out again in stream order)
 }
 
@@ -2873,10 +2873,10 @@ void csr_copy(const DevCSR &A, DevCSR &out)
 {
     hipStream_t st = ctx().stream;
     out.alloc(A.nrows, A.ncols, A.nnz);
-    ELAG_HIP_CHECK(hipMemcpyAsync(out.I, A.I, sizeof(int) * ((size_t)A.nrows + 1), hipMemcpyDeviceToDevice, st));
+    dev_copy(out.I, A.I, sizeof(int) * ((size_t)A.nrows + 1), st);
     if (A.nnz) {
-        ELAG_HIP_CHECK(hipMemcpyAsync(out.J, A.J, sizeof(int) * (size_t)A.nnz, hipMemcpyDeviceToDevice, st));
-        ELAG_HIP_CHECK(hipMemcpyAsync(out.a, A.a, sizeof(double) * (size_t)A.nnz, hipMemcpyDeviceToDevice, st));
+        dev_copy(out.J, A.J, sizeof(int) * (size_t)A.nnz, st);
+        dev_copy(out.a, A.a, sizeof(double) * (size_t)A.nnz, st);
     }
     out.choose_spmv_shape();
 }

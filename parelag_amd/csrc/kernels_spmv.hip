@@ -1213,7 +1213,7 @@ void resident_build(const std::vector<ResidentOp> &ops, ResidentSeq &seq)
     if (ops.empty()) return;
     seq.nops = (int)ops.size();
     seq.d_ops = reinterpret_cast<ResidentOp *>(dev_alloc<char>(sizeof(ResidentOp) * ops.size()));
-    ELAG_HIP_CHECK(hipMemcpyAsync(seq.d_ops, ops.data(), sizeof(ResidentOp) * ops.size(), hipMemcpyHostToDevice, ctx().stream));
+    stage_h2d(seq.d_ops, ops.data(), sizeof(ResidentOp) * ops.size());
     seq.d_bar = dev_alloc<unsigned>(2);
     seq.d_err = dev_alloc<int>(1);
     zero_async(seq.d_bar, 2 * sizeof(unsigned));
@@ -1828,7 +1828,7 @@ void vec_hypre_random(int n, int seed, double *out)
     long long s = seed;
     for (int i = 0; i < n; i++) { s = (a * s) % m; h[(size_t)i] = 2.0 * ((double)s / (double)m) - 1.0; }
     if (n) {
-        ELAG_HIP_CHECK(hipMemcpyAsync(out, h.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx().stream));
+        stage_h2d(out, h.data(), sizeof(double) * (size_t)n);
         ELAG_HIP_CHECK(hipStreamSynchronize(ctx().stream));
     }
 }

@@ -924,7 +924,7 @@ struct elag_hip_krylov_s {
         } else if (prec_kind == ELAG_HIP_PREC_COARSE) {
             pcoarse->apply(rin, zout);
         } else {
-            ELAG_HIP_CHECK(hipMemcpyAsync(zout, rin, sizeof(double) * (size_t)n(), hipMemcpyDeviceToDevice, ctx().stream));
+            dev_copy(zout, rin, sizeof(double) * (size_t)n(), ctx().stream);
         }
     }
 
@@ -1030,11 +1030,11 @@ struct elag_hip_krylov_s {
         const int nn = n();
         if (iterative) residual(b, x, r);
         else {
-            ELAG_HIP_CHECK(hipMemcpyAsync(r, b, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s));
+            dev_copy(r, b, sizeof(double) * (size_t)nn, s);
             k::vec_fill(nn, 0.0, x);
         }
-        if (has_prec()) { prec(r, z); ELAG_HIP_CHECK(hipMemcpyAsync(d, z, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s)); }
-        else ELAG_HIP_CHECK(hipMemcpyAsync(d, r, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s));
+        if (has_prec()) { prec(r, z); dev_copy(d, z, sizeof(double) * (size_t)nn, s); }
+        else dev_copy(d, r, sizeof(double) * (size_t)nn, s);
         dot(d, r);
         hipLaunchKernelGGL(cg_init1_kernel, dim3(1), dim3(1), 0, s, st, rel_tol, abs_tol, max_iter);
         amul(d, z);
@@ -1104,13 +1104,13 @@ struct elag_hip_krylov_s {
         // initial (preconditioned) residual
         if (flexible) {
             if (iterative) residual(b, x, r);
-            else { k::vec_fill(nn, 0.0, x); ELAG_HIP_CHECK(hipMemcpyAsync(r, b, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s)); }
+            else { k::vec_fill(nn, 0.0, x); dev_copy(r, b, sizeof(double) * (size_t)nn, s); }
         } else if (has_prec()) {
             if (iterative) { residual(b, x, w); prec(w, r); }
             else { k::vec_fill(nn, 0.0, x); prec(b, r); }
         } else {
             if (iterative) residual(b, x, r);
-            else { k::vec_fill(nn, 0.0, x); ELAG_HIP_CHECK(hipMemcpyAsync(r, b, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s)); }
+            else { k::vec_fill(nn, 0.0, x); dev_copy(r, b, sizeof(double) * (size_t)nn, s); }
         }
         dot(r, r);
         hipLaunchKernelGGL(gmres_init_kernel, dim3(1), dim3(1), 0, s, st, rel_tol, abs_tol, max_iter);
@@ -1130,7 +1130,7 @@ struct elag_hip_krylov_s {
             double *target = flexible ? r : w;   // the vector that is orthogonalised
             if (flexible) {
                 if (has_prec()) prec(Vq(i), Zq(i));
-                else ELAG_HIP_CHECK(hipMemcpyAsync(Zq(i), Vq(i), sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s));
+                else dev_copy(Zq(i), Vq(i), sizeof(double) * (size_t)nn, s);
                 amul(Zq(i), r);
             } else if (has_prec()) {
                 amul(Vq(i), r);
@@ -1260,8 +1260,8 @@ struct elag_hip_krylov_s {
         const dim3 g(g1(nn)), blk(kB);
         double *rt = z, *p = e[0], *phat = e[1], *v = e[2], *sv = e[3], *shat = e[4], *t = e[5];
         if (iterative) residual(b, x, r);
-        else { k::vec_fill(nn, 0.0, x); ELAG_HIP_CHECK(hipMemcpyAsync(r, b, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s)); }
-        ELAG_HIP_CHECK(hipMemcpyAsync(rt, r, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s));
+        else { k::vec_fill(nn, 0.0, x); dev_copy(r, b, sizeof(double) * (size_t)nn, s); }
+        dev_copy(rt, r, sizeof(double) * (size_t)nn, s);
         dot(r, r);
         hipLaunchKernelGGL(bicg_init_kernel, dim3(1), dim3(1), 0, s, st, rel_tol, abs_tol, max_iter);
         ELAG_LAUNCH_CHECK();
@@ -1305,7 +1305,7 @@ struct elag_hip_krylov_s {
         const dim3 g(g1(nn)), blk(kB);
         double *v0 = e[0], *v1 = e[1], *w0 = e[2], *w1 = e[3], *q = e[4], *u1 = e[5];
         if (iterative) residual(b, x, v1);
-        else { ELAG_HIP_CHECK(hipMemcpyAsync(v1, b, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s)); k::vec_fill(nn, 0.0, x); }
+        else { dev_copy(v1, b, sizeof(double) * (size_t)nn, s); k::vec_fill(nn, 0.0, x); }
         if (has_prec()) prec(v1, u1);
         dot(has_prec() ? u1 : v1, v1);
         hipLaunchKernelGGL(minres_init_kernel, dim3(1), dim3(1), 0, s, st, rel_tol, abs_tol, max_iter);
@@ -1347,7 +1347,7 @@ struct elag_hip_krylov_s {
         hipStream_t s = ctx().stream;
         const int nn = n();
         if (iterative) residual(b, x, r);
-        else { ELAG_HIP_CHECK(hipMemcpyAsync(r, b, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, s)); k::vec_fill(nn, 0.0, x); }
+        else { dev_copy(r, b, sizeof(double) * (size_t)nn, s); k::vec_fill(nn, 0.0, x); }
         dot(r, r);
         hipLaunchKernelGGL(stat_init_kernel, dim3(1), dim3(1), 0, s, st, max_iter);
         for (int it = 0; it < max_iter;) {
@@ -1376,7 +1376,7 @@ struct elag_hip_krylov_s {
             if (iterative) k::vec_gather((int)nn, d_perm, xio, x);
             b = bperm;
         } else if (iterative) {
-            ELAG_HIP_CHECK(hipMemcpyAsync(x, xio, sizeof(double) * nn, hipMemcpyDeviceToDevice, s));
+            dev_copy(x, xio, sizeof(double) * nn, s);
         }
         static const bool timing = std::getenv("ELAG_HIP_KRYLOV_TIMING") != nullptr;
         const auto t_begin = std::chrono::steady_clock::now();
@@ -1395,7 +1395,7 @@ struct elag_hip_krylov_s {
             fprintf(stderr, "[elag_hip] krylov solve: %d iterations, host %.3f ms up to the last poll: %.3f ms enqueueing, %.3f ms waiting in %d polls\n", final_iter,
                     t_run * 1e3, (t_run - t_poll) * 1e3, t_poll * 1e3, n_poll);
         if (d_perm) k::vec_scatter((int)nn, d_perm, x, xio, 0);
-        else ELAG_HIP_CHECK(hipMemcpyAsync(xio, x, sizeof(double) * nn, hipMemcpyDeviceToDevice, s));
+        else dev_copy(xio, x, sizeof(double) * nn, s);
         if (timing) {
             ELAG_HIP_CHECK(hipStreamSynchronize(s));
             fprintf(stderr, "[elag_hip] krylov mult: %.3f ms in all\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3);

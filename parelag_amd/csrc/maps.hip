@@ -81,7 +81,7 @@ bool same_pattern(const DevCSR &A, const DevCSR &B)
     if (A.nnz) hipLaunchKernelGGL(pattern_differs_kernel, dim3(1024), dim3(256), 0, st, (long long)A.nnz, (const int *)A.J, (const int *)B.J, flag.p);
     ELAG_LAUNCH_CHECK();
     int h = 0;
-    ELAG_HIP_CHECK(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    stage_d2h(&h, flag.p, sizeof(int));
     ELAG_HIP_CHECK(hipStreamSynchronize(st));
     return h == 0;
 }
@@ -199,7 +199,7 @@ int elag_hip_parcsr_spmv_boolint(elag_hip_parcsr_t A, int alpha, const int *x, i
                                (const int *)A->diag.J, A->offd.ncols > 0 ? (const int *)A->offd.I : nullptr, A->offd.ncols > 0 ? (const int *)A->offd.J : nullptr, dx,
                                (const int *)ghost, alpha, beta, dy);
         ELAG_LAUNCH_CHECK();
-        if (loc == ELAG_HIP_HOST && n) ELAG_HIP_CHECK(hipMemcpyAsync(y, ty, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+        if (loc == ELAG_HIP_HOST && n) stage_d2h(y, ty, sizeof(int) * (size_t)n);
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
         dev_free(tx); dev_free(ty); dev_free(ghost); dev_free(sbuf);
     });

@@ -185,7 +185,7 @@ void RelaxSmoother::estimate_eigs()
         if (distributed) comm_allreduce_scalar(&gamma, 0);
         if (i == 0) {
             beta = 1.0;
-            ELAG_HIP_CHECK(hipMemcpyAsync(p, rv, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, c.stream));
+            dev_copy(p, rv, sizeof(double) * (size_t)nn, c.stream);
         } else {
             beta = gamma / gamma_old;
             k::vec_axpby(nn, 1.0, rv, beta, p, p);
@@ -232,7 +232,7 @@ void RelaxSmoother::apply(const double *f, double *&cur, double *&alt, bool zero
                 par_spmv(*A, a);
                 std::swap(u, w);
             }
-        if (u != cur) ELAG_HIP_CHECK(hipMemcpyAsync(cur, u, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, ctx().stream));
+        if (u != cur) dev_copy(cur, u, sizeof(double) * (size_t)nn, ctx().stream);
         return;
     }
     if (type == ELAG_HIP_SMOOTHER_FIR) {
@@ -256,7 +256,7 @@ void RelaxSmoother::apply(const double *f, double *&cur, double *&alt, bool zero
                 double *old0 = x0;                                // (the old x0 -- `cur` itself the first time -- is free from here on)
                 x0 = x1; x1 = x2; x2 = old0;
             }
-            ELAG_HIP_CHECK(hipMemcpyAsync(cur, x3, sizeof(double) * (size_t)nn, hipMemcpyDeviceToDevice, ctx().stream));
+            dev_copy(cur, x3, sizeof(double) * (size_t)nn, ctx().stream);
         }
         return;
     }
@@ -607,7 +607,7 @@ int elag_hip_smoother_apply(elag_hip_smoother_t S, const double *rhs, double *so
         double *cur = u.d, *alt = altbuf;
         S->apply(f.d, cur, alt, zero_initial_guess != 0, transpose != 0);
         if (cur != u.d)
-            ELAG_HIP_CHECK(hipMemcpyAsync(u.d, cur, n * sizeof(double), hipMemcpyDeviceToDevice, ctx().stream));
+            dev_copy(u.d, cur, n * sizeof(double), ctx().stream);
         u.finish();
     });
 }

@@ -971,7 +971,7 @@ void SweepSmoother::setup()
             ELAG_LAUNCH_CHECK();
         }
         int nbad = 0;
-        ELAG_HIP_CHECK(hipMemcpyAsync(&nbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        stage_d2h(&nbad, bad.p, sizeof(int));
         ELAG_HIP_CHECK(hipStreamSynchronize(st));
         if (nbad) fail(ELAG_HIP_ERR_NUMERIC, "%s: matrix has %d zero l1 row norm(s)", kaczmarz ? "Kaczmarz" : "l1 Gauss-Seidel", nbad);
     }
@@ -1624,7 +1624,7 @@ bool SweepSmoother::apply_dense(const double *F, double *X, int m, bool zero_gue
         else go(sweep_dense_level_kernel<0>);
     };
     for (int sw = 0; sw < sweeps; sw++) {
-        if (ho) ELAG_HIP_CHECK(hipMemcpyAsync(snap.p, X, sizeof(double) * (size_t)n * m, hipMemcpyDeviceToDevice, st));   // the other blocks' values, frozen
+        if (ho) dev_copy(snap.p, X, sizeof(double) * (size_t)n * m, st);   // the other blocks' values, frozen
         for (int l = 0; l < nlev; l++) level(l);
         for (int l = nlev - 1; l >= 0; l--) level(l);
     }
@@ -1724,7 +1724,7 @@ void SweepSmoother::sweep_sor(const double *f, double *u)
     if (n == 0) return;
     hipStream_t st = ctx().stream;
     const bool ho = M->offd.nnz > 0;
-    ELAG_HIP_CHECK(hipMemcpyAsync(d_v, u, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));          // (d_v: allocated by setup -- a cycle may be under capture here)
+    dev_copy(d_v, u, sizeof(double) * (size_t)n, st);          // (d_v: allocated by setup -- a cycle may be under capture here)
     auto level = [&](int l, int dir) {
         const int r0 = h_lev_ptr[(size_t)l], r1 = h_lev_ptr[(size_t)l + 1];
         if (r1 == r0) return;
