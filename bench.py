@@ -29,6 +29,33 @@ sys.path.insert(0, ROOT)
 # set here, before anything can load it; children inherit it)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
+
+def _granted_cores() -> int:
+    """CPU cores this process may use: the cgroup's quota where there is one (a GPU box of the pool shows 256 CPUs and grants 16 cores' worth)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if q > 0:
+                n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+# The host libraries of the checker (numpy / scipy's BLAS, the oracle's OpenMP build) size their thread pools by the CPUs they SEE and keep the
+# workers spinning after a parallel region.  On a box that shows 256 CPUs and grants 16 that is 256 spinning threads against a 16-core quota:
+# the scheduler throttles the whole process for the rest of its 100 ms period -- the "one-off 30-80 ms stall" of the first solves after a
+# parity check, chased through rounds 4 and 5 (the library's clock put it into waiting for the device: its polling thread was frozen).
+# Pools of the granted size and passive waits; set before numpy is imported, inherited by the children.
+for _var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_var, str(_granted_cores()))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy peak 6290 GB/s
 
 
@@ -1252,10 +1279,9 @@ def main():
             db, dx = la.DeviceVector.from_numpy(local_part(b_solve)), la.DeviceVector(n_local, 0.0)
             K.Mult(db, dx)
             barrier()
-            # every solve timed by itself, the median reported and all of them kept in the record: within ~0.1 s of a setup that released device
-            # memory ONE solve stalls for 30-80 ms on this stack (seen with and without the step graphs, the pool, the kernel read-backs; the
-            # library's own clock puts the time into waiting for the device; a 0.5 s pause before the solves removes it) -- the mean of five
-            # solves then reads 25 ms for a 12 ms solve
+            # every solve timed by itself, the median reported and all of them kept in the record (rounds 4-5 saw ONE solve of a process stall for
+            # 30-80 ms: the scheduler throttling the process after the checker's oversubscribed thread pools had burnt the CPU quota -- see the top
+            # of this file; the mean of five solves then read 25 ms for a 12 ms solve)
             with no_gc():
                 each = []
                 for _ in range(nsolve):

@@ -5,6 +5,20 @@ import pytest
 
 # every rank thread of the in-process multi-rank tests owns a library context: a small first scratch slab each (the default reserves 2 GiB at init)
 os.environ.setdefault("ELAG_HIP_ARENA_MB", "128")
+# thread pools of the checker's host libraries (numpy's BLAS, the oracle's OpenMP build) at the size of the CPU quota, passive waits: a GPU box of
+# the pool shows 256 CPUs and grants 16 cores' worth, and 256 spinning workers get the whole process throttled (bench.py tells the story)
+def _granted_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+for _var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_var, str(_granted_cores()))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
