@@ -221,6 +221,7 @@ void BlockSmoother::setup()
         ELAG_REQUIRE(B->block(0, 1) && B->block(1, 0), "Block LDU needs the off-diagonal blocks");
         for (int q = 0; q < 3; q++) ELAG_REQUIRE(inv[(size_t)q]->n() == B->row_off[1], "A00 inverse %d has the wrong size", q + 1);
         ELAG_REQUIRE(inv[3]->n() == B->row_off[2] - B->row_off[1], "S inverse has the wrong size");
+        fold = !(getenv("ELAG_HIP_LDU_FOLD") && !atoi(getenv("ELAG_HIP_LDU_FOLD")));
     } else {
         ELAG_REQUIRE(kind == ELAG_HIP_BLOCK_JACOBI || kind == ELAG_HIP_BLOCK_GS_LOWER || kind == ELAG_HIP_BLOCK_GS_UPPER, "unknown block smoother kind %d", kind);
         ELAG_REQUIRE((int)inv.size() == nb, "block smoother needs one inverse per block (%d given, %d blocks)", (int)inv.size(), nb);
@@ -274,11 +275,26 @@ void BlockSmoother::block_solve(const double *r, double *t, bool transpose)
         double *r0 = resid, *r1 = resid + n0;
         double *c0 = t, *c1 = t + n0;
         double *t0 = tmp, *s0 = spare, *s1 = spare + n0;
-        inner(inv[1], rf, t0, s0, false);                              // du~ = A_2^-1 r_f
-        { k::SpmvArgs a; a.x = t0; a.alpha = -1.0; a.f = rg; a.gamma = 1.0; a.out = r1; par_spmv(*B->block(1, 0), a); }   // r_g' = r_g - A10 du~
-        inner(inv[3], r1, c1, s1, false);                              // dp = S^-1 (...)
-        { k::SpmvArgs a; a.x = c1; a.alpha = 1.0; a.out = c0; par_spmv(*B->block(0, 1), a); }                              // A01 dp
         static const bool reuse = !(getenv("ELAG_HIP_LDU_REUSE") && !atoi(getenv("ELAG_HIP_LDU_REUSE")));
+        // An inverse that multiplies its result with -1 (the AMGe cycle on the positive B D^-1 B^T standing for the negative Schur complement)
+        // is given the negated right-hand side instead -- the sign of the product that forms it -- and applied without its factor: the
+        // same bits (smoother.hpp: result_scale()), one pass over the pressure vector less per application.
+        const bool neg_s = fold && inv[3]->result_scale() == -1.0 && (inv[3]->plain_forms() & 1);
+        if (fold && reuse && inv[0] == inv[1] && inv[2]->result_scale() == 1.0 && (inv[2]->plain_forms() & 2)) {
+            // ... and where the third inverse can add its result in place, du~ is computed where du belongs, the product A01 dp is formed
+            // with the other sign and  du = du~ + A_3^-1 (-A01 dp)  needs no subtraction of its own: the same bits again.
+            inner(inv[1], rf, c0, s0, false);                          // du~ = A_2^-1 r_f, in du's place
+            { k::SpmvArgs a; a.x = c0; a.alpha = neg_s ? 1.0 : -1.0; a.f = rg; a.gamma = neg_s ? -1.0 : 1.0; a.out = r1; par_spmv(*B->block(1, 0), a); }
+            if (neg_s) inv[3]->apply_plain(r1, c1, false); else inner(inv[3], r1, c1, s1, false);
+            { k::SpmvArgs a; a.x = c1; a.alpha = -1.0; a.out = t0; par_spmv(*B->block(0, 1), a); }                         // -A01 dp
+            inv[2]->apply_plain(t0, c0, true);                          // du = du~ + A_3^-1 (-A01 dp)
+            if (damping != 1.0) k::vec_axpby(n0 + n1, damping, t, 0.0, t, t);
+            return;
+        }
+        inner(inv[1], rf, t0, s0, false);                              // du~ = A_2^-1 r_f
+        { k::SpmvArgs a; a.x = t0; a.alpha = neg_s ? 1.0 : -1.0; a.f = rg; a.gamma = neg_s ? -1.0 : 1.0; a.out = r1; par_spmv(*B->block(1, 0), a); }   // r_g' = r_g - A10 du~ (or its negative)
+        if (neg_s) inv[3]->apply_plain(r1, c1, false); else inner(inv[3], r1, c1, s1, false);                              // dp = S^-1 (...)
+        { k::SpmvArgs a; a.x = c1; a.alpha = 1.0; a.out = c0; par_spmv(*B->block(0, 1), a); }                              // A01 dp
         if (reuse && inv[0] == inv[1]) {
             // A_1^-1 and A_2^-1 are ONE object (the reference's own lists give one A00 inverse to all three places) applied to the same r_f from
             // the zero guess: du^ is du~, bit for bit -- kept in t0, and the third application writes into r_f's place, which nobody reads again.

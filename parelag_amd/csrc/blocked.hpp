@@ -29,6 +29,7 @@ struct BlockSmoother : elag_hip_smoother_s {
     int kind = 0;
     std::vector<elag_hip_smoother_s *> inv;   // kinds 0-2: one per block; kind 3: {A00_1, A00_2, A00_3, S}
     double damping = 1.0;
+    bool fold = true;                         // kind 3: signs and the last subtraction ride on the products' epilogues (ELAG_HIP_LDU_FOLD=0: a vector pass each)
     double *resid = nullptr, *corr = nullptr, *tmp = nullptr, *spare = nullptr, *dscale = nullptr;
     ~BlockSmoother() override;
     void setup();

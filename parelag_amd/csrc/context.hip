@@ -206,9 +206,8 @@ void stage_d2h(void *host_dst, const void *dev_src, size_t bytes)
 {
     Context &c = ctx();
     if (bytes == 0) return;
-    static const bool stage_all = getenv("ELAG_HIP_STAGE_ALL") && atoi(getenv("ELAG_HIP_STAGE_ALL"));
-    if (!stage_all && bytes > 120 && g_staged_d2h.fetch_add(bytes) > kStagedSwitch) g_api_d2h.store(true);
-    if (!c.h_stage || !kernel_copies() || (!stage_all && (bytes > 8 * kHostStage || g_api_d2h.load()))) {
+    if (bytes > 120 && g_staged_d2h.fetch_add(bytes) > kStagedSwitch) g_api_d2h.store(true);
+    if (!c.h_stage || !kernel_copies() || bytes > 8 * kHostStage || g_api_d2h.load()) {
         if (bytes > 120) g_api_d2h.store(true);
         ELAG_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c.stream));
         ELAG_HIP_CHECK(hipStreamSynchronize(c.stream));
@@ -234,9 +233,8 @@ void stage_h2d(void *dev_dst, const void *host_src, size_t bytes)
 {
     Context &c = ctx();
     if (bytes == 0) return;
-    static const bool stage_all = getenv("ELAG_HIP_STAGE_ALL") && atoi(getenv("ELAG_HIP_STAGE_ALL"));
-    if (!stage_all && g_staged_h2d.fetch_add(bytes) > kStagedSwitch) g_api_h2d.store(true);
-    if (!c.h_stage || !kernel_copies() || (!stage_all && (bytes > 8 * kHostStage || g_api_h2d.load()))) {           // (large uploads: the copy API's pipelined path)
+    if (g_staged_h2d.fetch_add(bytes) > kStagedSwitch) g_api_h2d.store(true);
+    if (!c.h_stage || !kernel_copies() || bytes > 8 * kHostStage || g_api_h2d.load()) {           // (large uploads: the copy API's pipelined path)
         g_api_h2d.store(true);
         ELAG_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c.stream));
         return;

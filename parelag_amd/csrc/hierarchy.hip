@@ -1311,6 +1311,19 @@ struct elag_hip_hierarchy_s {
         k::vec_scatter(n, d_order0, p_sol, sol, precond ? 0 : 1);
     }
 
+    // sol += cycle(rhs) from the zero guess, where that costs no pass of its own: a renumbered hierarchy leaves its numbering by a kernel
+    // that can add as well as store
+    bool adds_in_place() const { return reordered; }
+    void run_add(const double *rhs, double *sol)
+    {
+        ELAG_REQUIRE(reordered, "internal: run_add() on a hierarchy in the caller's numbering");
+        if (iterate0_permuted(rhs, sol, true)) return;
+        const int n = lev[0].A->nrows();
+        k::vec_gather(n, d_order0, rhs, p_rhs);
+        iterate(0, p_rhs, p_sol, lev[0].alt);
+        k::vec_scatter(n, d_order0, p_sol, sol, 1);
+    }
+
     // Level 0 of a renumbered hierarchy with the permutations folded into its first and last kernel: the caller's right-hand side
     // is gathered by the kernel that starts the zero-guess Jacobi sweep, and the kernel that finishes the post-smoothing writes
     // (or adds to) the caller's numbering directly -- two passes over level-0 vectors less per cycle.  Only for the layout this is
@@ -1427,6 +1440,14 @@ struct HierarchySolver : elag_hip_smoother_s {
     }
     int flips(bool) const override { return 0; }
     bool graph_capturable() const override { return hierarchy_is_local(H); }
+    double result_scale() const override { return scale; }
+    int plain_forms() const override { return 1 | (H->adds_in_place() ? 2 : 0); }
+    void apply_plain(const double *f, double *out, bool add) override
+    {
+        ELAG_REQUIRE(H->finalized, "Hierarchy::Mult before Finalize()");
+        if (add) H->run_add(f, out);
+        else H->run(f, out, true);
+    }
 };
 int hierarchy_height(const elag_hip_hierarchy_s *H) { return (H->reordered ? H->A_user : H->lev[0].A)->nrows(); }
 }  // namespace elag

@@ -38,10 +38,10 @@ enum { S_NOM, S_DEN, S_BETANOM, S_R0, S_ALPHA, S_BETA, S_TMP, S_FINAL_NORM, S_GB
        // BiCGSTAB / MINRES recurrences
        S_RHO1, S_RHO2, S_OMEGA, S_RESID, S_GOAL, S_TS, S_ETA, S_GAMMA0, S_GAMMA1, S_SIGMA0, S_SIGMA1, S_DELTA, S_MRHO1, S_MRHO2, S_MRHO3,
        S_C0, S_C1, S_C2, S_COUNT = 40 };
-enum { F_DONE, F_CONVERGED, F_FINAL_ITER, F_ITER, F_PENDING, F_ITER2, F_STEP, F_JBASE, F_COUNT = 8 };   // F_STEP / F_JBASE: GMRES -- the step counter and the iteration number of a cycle's first step, kept on the device so that a step's launches take no per-step argument (they replay as a graph)
+enum { F_DONE, F_CONVERGED, F_FINAL_ITER, F_ITER, F_PENDING, F_ITER2, F_STEP, F_JBASE, F_FINAL_COUNT, F_COUNT = 10 };   // F_STEP / F_JBASE: GMRES -- the step counter and the iteration number of a cycle's first step, kept on the device so that a step's launches take no per-step argument (they replay as a graph)
 
 struct KState {
-    int fl[F_COUNT];          // (first: the flags and the scalars the host reads -- S_NOM ... S_FINAL_NORM -- are 24 consecutive words, one fetch_ints)
+    int fl[F_COUNT];          // (first: the flags and the scalars the host reads -- S_NOM ... S_FINAL_NORM -- are 26 consecutive words, one fetch_ints)
     double sc[S_COUNT];
     int chain[4];             // gmres_chain_kernel: [0] launches completed (the tag of the next launch's partial sums is this + 1), [1] workgroups out, [2] somebody gave up
 };
@@ -125,6 +125,7 @@ __global__ void gmres_init_kernel(KState *st, double rel_tol, double abs_tol, in
     const double beta = sqrt(st->sc[S_TMP]);
     st->sc[S_GBETA] = beta;
     st->fl[F_DONE] = 0; st->fl[F_CONVERGED] = 0; st->fl[F_FINAL_ITER] = max_iter; st->fl[F_PENDING] = -1; st->fl[F_STEP] = 0; st->fl[F_JBASE] = 1;
+    st->fl[F_FINAL_COUNT] = 0;
     const double thr = fmax(rel_tol * beta, abs_tol);
     st->sc[S_THRESH] = thr;
     st->sc[S_FINAL_NORM] = beta;
@@ -269,6 +270,28 @@ __global__ void __launch_bounds__(kB) gmres_norm_fused_kernel(KState *st, double
     if (threadIdx.x == 0) { Hm(hs, m, i + 1, i) = nw; st->sc[S_BETA] = nw; }
 }
 
+__device__ inline void gen_rot(double dx, double dy, double &cs, double &sn)
+{
+    if (dy == 0.0) { cs = 1.0; sn = 0.0; }
+    else if (fabs(dy) > fabs(dx)) { const double t = dx / dy; sn = 1.0 / sqrt(1.0 + t * t); cs = t * sn; }
+    else { const double t = dy / dx; cs = 1.0 / sqrt(1.0 + t * t); sn = t * cs; }
+}
+__device__ inline void app_rot(double &dx, double &dy, double cs, double sn)
+{
+    const double t = cs * dx + sn * dy;
+    dy = -sn * dx + cs * dy;
+    dx = t;
+}
+__device__ inline void backsolve(double *hs, int m, int k)   // Update(): y = s; back substitution with H(0..k, 0..k)
+{
+    double *s = hs + (size_t)m * (m + 1), *y = s + 3 * (m + 1);
+    for (int q = 0; q <= m; q++) y[q] = s[q];
+    for (int i = k; i >= 0; i--) {
+        y[i] /= Hm(hs, m, i, i);
+        for (int j = i - 1; j >= 0; j--) y[j] -= Hm(hs, m, j, i) * y[i];
+    }
+}
+
 // ---- the whole chain of a step in ONE launch ------------------------------------------------------------------------------------------
 // The chain above is i + 3 launches per step and each link re-reads w and two basis vectors (6 us a link at 700 k unknowns, 528 links in a
 // 32-iteration GMRES(50): a third of the Darcy solve).  Here kChainG workgroups keep their elements of w in registers for the whole step (a
@@ -296,6 +319,7 @@ struct ChainArgs {
     int *host_err;
     long long ticks;
     int stall;                // test hook: workgroup stall - 1 publishes its first partial sums ten time limits late (ELAG_HIP_GMRES_CHAIN_STALL)
+    int givens;               // the step's rotations (gmres_givens_kernel's work) by workgroup 0's polling wavefront, as the coefficients arrive
 };
 
 // PF: the next basis vector is requested a link ahead (a third register array); without it the load follows the coefficient.  Two forms are
@@ -322,6 +346,18 @@ __global__ void __launch_bounds__(2 * kB + 64) gmres_chain_kernel(const ChainArg
         for (int u = 0; u < PRE; u++) { const int t = t0 + u * stride; dst[u] = t < n ? v[t] : 0.0; }
     };
     if (!poller) { load_vec(A.w, pw); load_vec(A.V, pv); }
+    // The step's rotations ride along (A.givens): workgroup 0's polling wavefront is handed every coefficient of column i anyway, so its first
+    // lane applies rotation k - 1 when H(k, i) arrives -- while the data wavefronts are busy with the link -- and generates the step's own
+    // rotation from the norm: gmres_givens_kernel's operations in its order, one launch of a step less.  The rotations so far wait in LDS.
+    extern __shared__ double sh_rot[];                                // c at [0, m), s at [m, 2 m)
+    __shared__ double sh_g[4];                                        // the entry of column i being rotated, s_i, s_{i+1}, the threshold (LDS, not registers: the 12-element form has none to spare)
+    __shared__ int sh_jbase;
+    const bool giv = A.givens != 0 && poller && blockIdx.x == 0;
+    if (giv) {
+        const double *rs = A.hs + (size_t)A.m * (A.m + 1), *rc = rs + (A.m + 1), *rn = rc + (A.m + 1);
+        for (int k = lane; k < i; k += 64) { sh_rot[k] = rc[k]; sh_rot[A.m + k] = rn[k]; }
+        if (lane == 0) { sh_g[1] = rs[i]; sh_g[2] = rs[i + 1]; sh_g[3] = A.st->sc[S_THRESH]; sh_jbase = A.st->fl[F_JBASE]; }
+    }
     __syncthreads();
     // data wavefronts: each one's sum to LDS, then the barrier; the workgroup's first thread adds them up as block_sum_256() and pair_of() do and
     // publishes the one value (a data wavefront's store: loads and stores of a wavefront share a counter, the polling wavefront's polls would
@@ -408,7 +444,16 @@ __global__ void __launch_bounds__(2 * kB + 64) gmres_chain_kernel(const ChainArg
     for (int k = 0; k <= i; k++) {
         const double h = collect(k, false);
         if (sh_dead) { dead = true; break; }
-        if (poller && blockIdx.x == 0 && lane == 0) Hm(A.hs, A.m, k, i) = h;
+        if (poller && blockIdx.x == 0 && lane == 0) {
+            if (!giv) Hm(A.hs, A.m, k, i) = h;
+            else if (k == 0) sh_g[0] = h;
+            else {                                                    // app_rot(H(k-1,i), H(k,i), cs[k-1], sn[k-1])
+                double cur = sh_g[0], nxt = h;
+                app_rot(cur, nxt, sh_rot[k - 1], sh_rot[A.m + k - 1]);
+                Hm(A.hs, A.m, k - 1, i) = cur;
+                sh_g[0] = nxt;
+            }
+        }
         acc = 0.0;
         if (!poller) {
             const bool last = k == i;
@@ -440,7 +485,26 @@ __global__ void __launch_bounds__(2 * kB + 64) gmres_chain_kernel(const ChainArg
         const double nw = collect(i + 1, true);
         dead = sh_dead != 0;
         if (!dead) {
-            if (poller && blockIdx.x == 0 && lane == 0) { Hm(A.hs, A.m, i + 1, i) = nw; A.st->sc[S_BETA] = nw; }
+            if (poller && blockIdx.x == 0 && lane == 0) {
+                A.st->sc[S_BETA] = nw;
+                if (!giv) Hm(A.hs, A.m, i + 1, i) = nw;
+                else {
+                    double *rs = A.hs + (size_t)A.m * (A.m + 1), *rc = rs + (A.m + 1), *rn = rc + (A.m + 1);
+                    double cur = sh_g[0], last = nw, ci, sni, si = sh_g[1], si1 = sh_g[2];
+                    gen_rot(cur, last, ci, sni);
+                    app_rot(cur, last, ci, sni);
+                    Hm(A.hs, A.m, i, i) = cur; Hm(A.hs, A.m, i + 1, i) = last;
+                    app_rot(si, si1, ci, sni);
+                    rc[i] = ci; rn[i] = sni; rs[i] = si; rs[i + 1] = si1;
+                    const double resid = fabs(si1);
+                    A.st->sc[S_BETANOM] = resid;
+                    if (resid <= sh_g[3]) {
+                        backsolve(A.hs, A.m, i);
+                        A.st->fl[F_FINAL_COUNT] = i + 1;
+                        A.st->sc[S_FINAL_NORM] = resid; A.st->fl[F_FINAL_ITER] = sh_jbase + i; A.st->fl[F_CONVERGED] = 1; A.st->fl[F_DONE] = 1;
+                    }
+                }
+            }
             if (!poller) {
                 const double f = 1.0 / nw;
 #pragma unroll
@@ -536,28 +600,6 @@ __global__ void gmres_norm_kernel(KState *st, double *hs, int m, int i)
     st->sc[S_BETA] = nw;   // divisor of the next basis vector
 }
 
-__device__ inline void gen_rot(double dx, double dy, double &cs, double &sn)
-{
-    if (dy == 0.0) { cs = 1.0; sn = 0.0; }
-    else if (fabs(dy) > fabs(dx)) { const double t = dx / dy; sn = 1.0 / sqrt(1.0 + t * t); cs = t * sn; }
-    else { const double t = dy / dx; cs = 1.0 / sqrt(1.0 + t * t); sn = t * cs; }
-}
-__device__ inline void app_rot(double &dx, double &dy, double cs, double sn)
-{
-    const double t = cs * dx + sn * dy;
-    dy = -sn * dx + cs * dy;
-    dx = t;
-}
-__device__ inline void backsolve(double *hs, int m, int k)   // Update(): y = s; back substitution with H(0..k, 0..k)
-{
-    double *s = hs + (size_t)m * (m + 1), *y = s + 3 * (m + 1);
-    for (int q = 0; q <= m; q++) y[q] = s[q];
-    for (int i = k; i >= 0; i--) {
-        y[i] /= Hm(hs, m, i, i);
-        for (int j = i - 1; j >= 0; j--) y[j] -= Hm(hs, m, j, i) * y[i];
-    }
-}
-
 // One wavefront: column i of H and the rotations so far are fetched side by side into LDS, thread 0 applies them from there (the same
 // operations in the same order), the column goes back side by side.  (One thread working in global memory paid a memory round trip per
 // rotation: 9.2 us a step at i ~ 16, measured, against the launch floor.)  Dynamic LDS: 4 m + 6 doubles.
@@ -601,7 +643,8 @@ __global__ void __launch_bounds__(64) gmres_givens_kernel(KState *st, double *hs
     __syncthreads();
     if (converged) {
         backsolve(hs, m, i);
-        st->fl[F_PENDING] = step_id;   // the update kernel of this step applies x += sum_{q<=i} y_q v_q
+        st->fl[F_PENDING] = step_id;   // the update kernel of this step applies x += sum_{q<=i} y_q v_q ...
+        st->fl[F_FINAL_COUNT] = i + 1; // ... or the one the host launches when it reads `done` (gmres_final_update_kernel)
         st->sc[S_FINAL_NORM] = resid; st->fl[F_FINAL_ITER] = jbase + i; st->fl[F_CONVERGED] = 1; st->fl[F_DONE] = 1;
     }
 }
@@ -621,6 +664,22 @@ __global__ void gmres_update_kernel(int n, const KState *__restrict__ st, const 
     if (st->fl[F_PENDING] != st->fl[F_STEP]) return;
     const double *y = hs + (size_t)m * (m + 1) + 3 * (m + 1);
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {      // (a small grid: all but one of a solve's launches return at once)
+        double acc = x[t];
+        for (int q = 0; q < count; q++) acc = acc + y[q] * V[(size_t)q * n + t];
+        x[t] = acc;
+    }
+}
+
+// The update of the step that converged, launched ONCE by the host when it has read `done` (a launch of every step that returned at once in
+// all but one of them was 4.8 us of the ~260 a step of the Darcy x3 solve takes): x += sum_{q < F_FINAL_COUNT} y_q V_q, nothing where the solve
+// ended otherwise (the restart's update has been applied by the restart).
+__global__ void gmres_final_update_kernel(int n, const KState *__restrict__ st, const double *__restrict__ hs, int m, const double *__restrict__ V,
+                                          double *__restrict__ x)
+{
+    const int count = st->fl[F_FINAL_COUNT];
+    if (count <= 0) return;
+    const double *y = hs + (size_t)m * (m + 1) + 3 * (m + 1);
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
         double acc = x[t];
         for (int q = 0; q < count; q++) acc = acc + y[q] * V[(size_t)q * n + t];
         x[t] = acc;
@@ -846,12 +905,16 @@ struct elag_hip_krylov_s {
     KState *st = nullptr;
     // host mirrors of st->fl and of the leading scalars of st->sc (filled from the fetched words: plain memory -- a solver's construction used
     // to pin two blocks of its own and hipMalloc its state block, ~0.4 ms each time and ~9 ms the first time in a process)
-    int h_flags[F_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int h_flags[F_COUNT] = {};
     double h_sc[S_COUNT] = {};
     double *x = nullptr, *r = nullptr, *z = nullptr, *d = nullptr, *w = nullptr, *scr = nullptr;
     double *V = nullptr, *Z = nullptr, *hs = nullptr, *part = nullptr;
     u64k *gm_gran = nullptr;                      // gmres_chain_kernel's tagged sums, [restart + 2][kChainG][2]
     int gm_chain = std::getenv("ELAG_HIP_GMRES_CHAIN") ? atoi(std::getenv("ELAG_HIP_GMRES_CHAIN")) : 1;   // (read when the solver is made: a test compares the chains)
+    // the update of the converged step: one launch when the host has read `done` (default) or a launch in every step that returns at once in all but one
+    bool gm_update_each = std::getenv("ELAG_HIP_GMRES_UPDATE_EACH_STEP") && atoi(std::getenv("ELAG_HIP_GMRES_UPDATE_EACH_STEP"));
+    // the step's rotations inside gmres_chain_kernel (0: gmres_givens_kernel, a launch of its own; needed by the update in every step, which counts the steps there)
+    bool gm_chain_givens = !(std::getenv("ELAG_HIP_GMRES_CHAIN_GIVENS") && !atoi(std::getenv("ELAG_HIP_GMRES_CHAIN_GIVENS")));
     bool cg_tail = !(std::getenv("ELAG_HIP_CG_TAIL_UPDATE") && !atoi(std::getenv("ELAG_HIP_CG_TAIL_UPDATE")));   // CG: the update of x, r in the launch that computes alpha (0: a launch of its own)
     double *e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // BiCGSTAB / MINRES work vectors
     hipGraphExec_t cg_iter = nullptr;
@@ -1122,7 +1185,7 @@ struct elag_hip_krylov_s {
         int since_poll = 0, poll_after = std::min(check_every, 4);
         double est_prev = h_sc[S_BETANOM];
         bool finished = false;
-        // One inner step (product, preconditioner, modified Gram-Schmidt against i + 1 vectors, rotation, conditional update) is 40 + i
+        // One inner step (product, preconditioner, modified Gram-Schmidt against i + 1 vectors, rotation) is some 30 (a launch per link: 40 + i)
         // launches that depend on nothing the host knows: replayed as ONE graph per position i of the cycle (built on first use, kept for
         // the solver's life).  Enqueueing them one by one is half of a solve's wall time on a fast host (cube456 x3 Darcy: 6-8 of 12 ms)
         // and all of it on a slow one (22-29 ms seen on some boxes of the pool).  ELAG_HIP_GMRES_GRAPH=0: plain launches.
@@ -1138,7 +1201,7 @@ struct elag_hip_krylov_s {
             } else {
                 amul(Vq(i), w);
             }
-            bool basis_vector_written = false;
+            bool basis_vector_written = false, rotated = false;
             if (!distributed()) {
                 // fused modified Gram-Schmidt: see gmres_orth_fused_kernel
                 if (chain_form(nn) != 0) {
@@ -1146,13 +1209,15 @@ struct elag_hip_krylov_s {
                     ChainArgs a;
                     a.n = nn; a.m = m; a.i = i; a.st = st; a.hs = hs; a.w = target; a.V = V; a.vout = Vq(i + 1); a.gran = gm_gran;
                     a.host_err = ctx().h_dev_err;
+                    a.givens = (gm_chain_givens && !gm_update_each) ? 1 : 0;
+                    rotated = a.givens != 0;
                     double ms = 250.0;
                     if (const char *e = std::getenv("ELAG_HIP_GMRES_CHAIN_MS")) ms = atof(e);
                     a.ticks = std::max(1ll, (long long)(ms * 1e5));
                     a.stall = std::getenv("ELAG_HIP_GMRES_CHAIN_STALL") ? atoi(std::getenv("ELAG_HIP_GMRES_CHAIN_STALL")) : 0;
                     switch (chain_form(nn)) {
-                    case 1: hipLaunchKernelGGL((gmres_chain_kernel<6, true>), dim3(kChainG), dim3(2 * kB + 64), 0, s, a); break;
-                    default: hipLaunchKernelGGL((gmres_chain_kernel<12, false>), dim3(kChainG), dim3(2 * kB + 64), 0, s, a); break;
+                    case 1: hipLaunchKernelGGL((gmres_chain_kernel<6, true>), dim3(kChainG), dim3(2 * kB + 64), sizeof(double) * 2 * (size_t)m, s, a); break;
+                    default: hipLaunchKernelGGL((gmres_chain_kernel<12, false>), dim3(kChainG), dim3(2 * kB + 64), sizeof(double) * 2 * (size_t)m, s, a); break;
                     }
                     basis_vector_written = true;
                 } else {
@@ -1175,8 +1240,16 @@ struct elag_hip_krylov_s {
             }
             if (!basis_vector_written)
                 hipLaunchKernelGGL(scale_inv_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, (int)S_BETA, (const double *)target, Vq(i + 1));
-            hipLaunchKernelGGL(gmres_givens_kernel, dim3(1), dim3(64), sizeof(double) * (size_t)(4 * m + 6), s, st, hs, m, i);
-            hipLaunchKernelGGL(gmres_update_kernel, dim3(std::min(g1(nn), 512u)), dim3(kB), 0, s, nn, (const KState *)st, (const double *)hs, m, i + 1,
+            if (!rotated) hipLaunchKernelGGL(gmres_givens_kernel, dim3(1), dim3(64), sizeof(double) * (size_t)(4 * m + 6), s, st, hs, m, i);
+            if (gm_update_each)
+                hipLaunchKernelGGL(gmres_update_kernel, dim3(std::min(g1(nn), 512u)), dim3(kB), 0, s, nn, (const KState *)st, (const double *)hs, m, i + 1,
+                                   (const double *)(flexible ? Z : V), x);
+            ELAG_LAUNCH_CHECK();
+        };
+        // the converged step's update, once the host has read `done` (nothing where the solve ended at a restart: gmres_final_update_kernel)
+        auto final_update = [&]() {
+            if (gm_update_each) return;
+            hipLaunchKernelGGL(gmres_final_update_kernel, dim3(std::min(g1(nn), 2048u)), dim3(kB), 0, s, nn, (const KState *)st, (const double *)hs, m,
                                (const double *)(flexible ? Z : V), x);
             ELAG_LAUNCH_CHECK();
         };
@@ -1227,7 +1300,7 @@ struct elag_hip_krylov_s {
                 if (++since_poll >= poll_after) {
                     const int steps = since_poll;
                     since_poll = 0;
-                    if (poll()) { finished = true; i++; j++; break; }
+                    if (poll()) { final_update(); finished = true; i++; j++; break; }
                     const double est = h_sc[S_BETANOM], thr = h_sc[S_R0];
                     poll_after = check_every;
                     if (est_prev > 0.0 && est > 0.0 && est < est_prev && thr > 0.0 && est > thr) {
@@ -1248,7 +1321,7 @@ struct elag_hip_krylov_s {
             dot(r, r);
             hipLaunchKernelGGL(gmres_restart_norm_kernel, dim3(1), dim3(1), 0, s, st, j);
             ELAG_LAUNCH_CHECK();
-            if (poll()) break;
+            if (poll()) { final_update(); break; }      // (a step of this cycle may have converged since the last look)
         }
     }
 

@@ -28,6 +28,15 @@ struct elag_hip_smoother_s {
     // exchange or collective: the only solvers a Krylov step that replays as a graph may contain.  A whitelist: a solver that does not
     // say so is issued as plain launches (krylov.hip: capturable()).
     virtual bool graph_capturable() const { return false; }
+    // A solver applied from the zero guess is linear in its right-hand side, and S(-f) = -S(f) to the last bit (round to nearest is symmetric): a
+    // caller that can hand over -f, or take the result with a sign, for nothing -- the sign of a product's epilogue -- asks for the solver
+    // WITHOUT its own factor and, where offered, for the result added in place, instead of paying a vector pass for either (blocked.hip: LDU).
+    //   result_scale(): the factor apply() multiplies its result with (1: none)
+    //   plain_forms(): bit 0 = apply_plain(f, out, false) is offered, bit 1 = apply_plain(f, out, true)
+    //   apply_plain(f, out, add): out (+)= S(f) from the zero guess, the factor left out
+    virtual double result_scale() const { return 1.0; }
+    virtual int plain_forms() const { return 0; }
+    virtual void apply_plain(const double *, double *, bool) { elag::fail(ELAG_HIP_ERR_STATE, "internal: apply_plain() of a solver that does not offer it"); }
     int n() const { return A->nrows(); }
 };
 

@@ -353,9 +353,17 @@ def test_gmres_chain_in_one_launch_is_the_launch_per_link_bit_for_bit(la, name):
         A = orc.csr(sp.random(n, n, density=min(1.0, 6.0 / n), random_state=rng) + sp.diags(np.full(n, 2.5)))
         dA = la.ParallelCSRMatrix.from_scipy(A)
         b = rng.uniform(-1, 1, n)
-        params = {"Solver name": name, "Relative tolerance": 1e-10, "Maximum iterations": 60, "Restart size": restart}
+        params0 = {"Solver name": name, "Relative tolerance": 1e-10, "Maximum iterations": 60, "Restart size": restart}
         out = []
-        for env in ({"ELAG_HIP_GMRES_CHAIN": "0"}, {"ELAG_HIP_GMRES_CHAIN": "1"}, {"ELAG_HIP_GMRES_CHAIN": "2"}):
+        # ... and the step's rotations done inside that launch as the coefficients arrive (the default) or by gmres_givens_kernel
+        # (ELAG_HIP_GMRES_CHAIN_GIVENS=0), the converged step's update launched once when the host has read `done` (the default) or by a
+        # launch in every step (ELAG_HIP_GMRES_UPDATE_EACH_STEP=1): the same bits, whatever the batch the host polls in (check every 1 / 3 steps)
+        for env in ({"ELAG_HIP_GMRES_CHAIN": "0"}, {"ELAG_HIP_GMRES_CHAIN": "1"}, {"ELAG_HIP_GMRES_CHAIN": "2"},
+                    {"ELAG_HIP_GMRES_CHAIN": "1", "ELAG_HIP_GMRES_CHAIN_GIVENS": "0"}, {"ELAG_HIP_GMRES_CHAIN": "1", "ELAG_HIP_GMRES_UPDATE_EACH_STEP": "1"},
+                    {"ELAG_HIP_GMRES_CHAIN": "0", "ELAG_HIP_GMRES_UPDATE_EACH_STEP": "1"}, {"ELAG_HIP_GMRES_CHAIN": "1", "check": 1},
+                    {"ELAG_HIP_GMRES_CHAIN": "1", "check": 3}):
+            env = dict(env)
+            params = dict(params0, **({"Check every": env.pop("check")} if "check" in env else {}))
             S = la.HypreSmootherWrapper(dA, 1, {"Sweeps": 1}) if with_prec else None      # l1-Jacobi
             K = _krylov_with_env(la, env, dA, S, params)
             for trial in range(2):                                                          # (the second solve: a solver's launches are replayed)
