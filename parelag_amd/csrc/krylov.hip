@@ -26,6 +26,7 @@
 #include "comm.hpp"
 #include "smoother.hpp"
 #include "staging.hpp"
+#include "row_group.hpp"
 
 using namespace elag;
 
@@ -554,6 +555,98 @@ __global__ void __launch_bounds__(kB) cg_fused_dir_kernel(int n, KState *__restr
     for (int t = blockIdx.x * kB + threadIdx.x; t < n; t += kPart * kB) d[t] = src[t] + beta * d[t];
 }
 
+// The direction update, the product A d and the partial sums of (d, A d) in ONE launch, for the systems whose product is launch-bound (a
+// row-group product: a group of LPR lanes per row, at most kPart kB rows): three launches of a pass -- cg_fused_dir_kernel, the product,
+// gmres_dot0_kernel -- were ~13 of the 40 us a pass takes at the 42 309 unknowns of cube456 x3.  Every workgroup finishes (r, z) itself as
+// cg_fused_dir_kernel does; the new direction is not gathered from memory but formed where it is needed, d'_c = z_c + beta d_c with the
+// expression of the update (the old direction stays untouched in its buffer: the directions alternate between two), by the lanes that
+// spmv_fused_row would give the entry to, summed in its order; lane 0 of a row stores (A d')_row and d'_row.  Workgroup b owns rows
+// [256 b, 256 b + 256) -- the elements of block b of gmres_dot0_kernel -- in passes of blockDim / LPR rows, leaves d'_row (A d')_row in LDS
+// and adds the 256 up through the tree of block_sum_256(): the partial sums, hence alpha, are those of the three launches bit for bit.
+template <int LPR>
+__global__ void __launch_bounds__(1024) cg_dir_amul_dot_kernel(int n, KState *__restrict__ st, int max_iter, const double *__restrict__ part_in,
+                                                               const double *__restrict__ src, const double *__restrict__ d_old,
+                                                               double *__restrict__ d_new, const int *__restrict__ I, const int *__restrict__ J,
+                                                               const double *__restrict__ a, double *__restrict__ ad, double *__restrict__ part_out)
+{
+    __shared__ double sh[4];
+    __shared__ double sprod[kB];
+    if (st->fl[F_DONE]) return;
+    // (r, z) as sum_partials() adds it up, by the first kB threads
+    double pp = 0.0;
+    if (threadIdx.x < kB) { pp = pair_of(part_in); pp = wave_sum(pp); if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pp; }
+    __syncthreads();
+    const double betanom = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    const int it = st->fl[F_ITER];
+    const double r0 = st->sc[S_R0], nom = st->sc[S_NOM];
+    const bool stop = (betanom < 0.0) || (betanom <= r0) || (it + 1 > max_iter);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                        // cg_fused_dir_kernel's branches
+        st->sc[S_BETANOM] = betanom;
+        st->sc[S_FINAL_NORM] = sqrt(betanom);
+        st->fl[F_ITER2] = it;
+        if (betanom < 0.0) { st->fl[F_FINAL_ITER] = it; st->fl[F_DONE] = 1; }
+        else if (betanom <= r0) { st->fl[F_CONVERGED] = 1; st->fl[F_FINAL_ITER] = it; st->fl[F_DONE] = 1; }
+        else if (it + 1 > max_iter) { st->fl[F_ITER2] = it + 1; st->fl[F_DONE] = 1; }
+        else { st->fl[F_ITER2] = it + 1; st->sc[S_BETA] = betanom / nom; }
+    }
+    if (stop) return;
+    const double beta = betanom / nom;
+    const int row0 = (int)blockIdx.x * kB;
+    if (row0 >= n) { if (threadIdx.x == 0) part_out[blockIdx.x] = 0.0; return; }
+    const int lane = threadIdx.x & (LPR - 1), grp = (int)threadIdx.x / LPR, rpp = (int)blockDim.x / LPR;
+    constexpr int U = k::rowgroup::kRowU;
+    for (int p0 = 0; p0 < kB; p0 += rpp) {
+        const int lr = p0 + grp, row = row0 + lr;
+        if (lr < kB && row < n) {
+            const int s = I[row], e = I[row + 1], nd_ = e - s;
+            double own_s = 0.0, own_d = 0.0;
+            if (lane == 0) { own_s = src[row]; own_d = d_old[row]; }
+            double sum = 0.0;
+            for (int q0 = lane; q0 < nd_; q0 += U * LPR) {             // spmv_fused_row's passes: U entries per lane in flight
+                int jd[U];
+                double av[U], xs[U], xd[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int q = q0 + u * LPR;
+                    jd[u] = 0; av[u] = 0.0;
+                    if (q < nd_) { jd[u] = J[s + q]; av[u] = a[s + q]; }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int q = q0 + u * LPR;
+                    xs[u] = 0.0; xd[u] = 0.0;
+                    if (q < nd_) { xs[u] = src[jd[u]]; xd[u] = d_old[jd[u]]; }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int q = q0 + u * LPR;
+                    const double xv = q < nd_ ? xs[u] + beta * xd[u] : 0.0;     // the entry of the new direction, as the update would have stored it
+                    sum += av[u] * xv;
+                }
+            }
+            sum = k::rowgroup::group_reduce<LPR>(sum);
+            if (lane == 0) {
+                double t = 1.0 * sum;                                  // the product's epilogue with its defaults: alpha = 1, no other operand
+                t *= 1.0; t += 0.0 * 0.0; t *= 1.0; t += 0.0 * 0.0;
+                const double dn = own_s + beta * own_d;
+                ad[row] = t;
+                d_new[row] = dn;
+                sprod[lr] = dn * t;
+            }
+        }
+    }
+    __syncthreads();
+    double acc = 0.0;
+    if (threadIdx.x < kB) {
+        if (row0 + (int)threadIdx.x < n) acc += sprod[threadIdx.x];
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) part_out[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
 // cg_step2 with the dot finished in-kernel (one block)
 __global__ void __launch_bounds__(kB) cg_fused_step2_kernel(KState *st, const double *__restrict__ part)
 {
@@ -918,6 +1011,13 @@ struct elag_hip_krylov_s {
     bool cg_tail = !(std::getenv("ELAG_HIP_CG_TAIL_UPDATE") && !atoi(std::getenv("ELAG_HIP_CG_TAIL_UPDATE")));   // CG: the update of x, r in the launch that computes alpha (0: a launch of its own)
     double *e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // BiCGSTAB / MINRES work vectors
     hipGraphExec_t cg_iter = nullptr;
+    // CG on a launch-bound system: direction update, product and (d, A d) in one launch (cg_dir_amul_dot_kernel); the directions alternate
+    // between d and d2, the product goes to ad; a replayed pass is one graph per parity.  ELAG_HIP_CG_LEAN=0: the three launches
+    bool cg_lean_env = !(std::getenv("ELAG_HIP_CG_LEAN") && !atoi(std::getenv("ELAG_HIP_CG_LEAN")));
+    bool cg_lean = false;
+    double *d2 = nullptr, *ad = nullptr;
+    int cg_par = 0;
+    hipGraphExec_t cg_iter_par[2] = {nullptr, nullptr};
     std::vector<hipGraphExec_t> gm_step;          // GMRES: one replayable step per position of the restart cycle
     bool gm_graph_ok = true, gm_flex = false, gm_graphs_chain = false;   // gm_graphs_chain: some captured step holds a gmres_chain_kernel
     std::string launch_mode = "plain";          // what elag_hip_krylov_launch_mode reports (set by the last Mult)
@@ -933,6 +1033,8 @@ struct elag_hip_krylov_s {
     ~elag_hip_krylov_s()
     {
         if (cg_iter) (void)hipGraphExecDestroy(cg_iter);
+        for (auto g : cg_iter_par) if (g) (void)hipGraphExecDestroy(g);
+        dev_free(d2); dev_free(ad);
         for (auto g : gm_step) if (g) (void)hipGraphExecDestroy(g);
         dev_free(x); dev_free(r); dev_free(z); dev_free(d); dev_free(w); dev_free(scr); dev_free(V); dev_free(Z); dev_free(hs); dev_free(part);
         dev_free(bperm); dev_free(gm_gran);
@@ -953,7 +1055,14 @@ struct elag_hip_krylov_s {
         }
         k::prepare_spmv(Aop->diag);
         x = dev_alloc<double>(nn); r = dev_alloc<double>(nn); z = dev_alloc<double>(nn); scr = dev_alloc<double>(nn);
-        if (solver == ELAG_HIP_KRYLOV_CG) { d = dev_alloc<double>(nn); part = dev_alloc<double>(2 * (size_t)kPart); }
+        if (solver == ELAG_HIP_KRYLOV_CG) {
+            d = dev_alloc<double>(nn); part = dev_alloc<double>(2 * (size_t)kPart);
+            // (the product as spmv_fused would run it: the row-group kernel on a rank-local matrix, not the stream / x-cache / sign forms)
+            const DevCSR &D = Aop->diag;
+            cg_lean = cg_lean_env && cg_tail && !distributed() && !Aop->needs_exchange() && nn >= 1 && nn <= (size_t)kPart * kB && D.lanes_per_row >= 1 &&
+                      D.lanes_per_row <= 16 && D.sign_state != 1 && D.xc_state != 1;
+            if (cg_lean) { d2 = dev_alloc<double>(nn); ad = dev_alloc<double>(nn); }
+        }
         if (solver == ELAG_HIP_KRYLOV_STATIONARY) { d = dev_alloc<double>(nn); }
         if (solver == ELAG_HIP_KRYLOV_BICGSTAB || solver == ELAG_HIP_KRYLOV_MINRES)
             for (auto &p : e) p = dev_alloc<double>(nn);
@@ -1069,6 +1178,26 @@ struct elag_hip_krylov_s {
             const double *src = has_prec() ? z : r;
             if (has_prec()) prec(r, z);
             hipLaunchKernelGGL(gmres_dot0_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, (const double *)r, src, part);
+            if (cg_lean) {
+                const double *dold = cg_par ? d2 : d;
+                double *dnew = cg_par ? d : d2;
+                const DevCSR &D = Aop->diag;
+                const dim3 g(kPart), b((unsigned)std::min(1024, kB * D.lanes_per_row));
+#define ELAG_CG_LEAN(L) hipLaunchKernelGGL((cg_dir_amul_dot_kernel<L>), g, b, 0, s, nn, st, max_iter, (const double *)part, src, dold, dnew, (const int *)D.I, \
+                                           (const int *)D.J, (const double *)D.a, ad, part + kPart)
+                switch (D.lanes_per_row) {
+                case 1: ELAG_CG_LEAN(1); break;
+                case 2: ELAG_CG_LEAN(2); break;
+                case 4: ELAG_CG_LEAN(4); break;
+                case 8: ELAG_CG_LEAN(8); break;
+                default: ELAG_CG_LEAN(16); break;
+                }
+#undef ELAG_CG_LEAN
+                hipLaunchKernelGGL(cg_fused_step2_update_kernel, dim3(kPart), dim3(kB), 0, s, nn, st, (const double *)(part + kPart), x, (const double *)dnew, r, (const double *)ad);
+                ELAG_LAUNCH_CHECK();
+                cg_par ^= 1;
+                return;
+            }
             hipLaunchKernelGGL(cg_fused_dir_kernel, dim3(kPart), dim3(kB), 0, s, nn, st, max_iter, (const double *)part, src, d);
             amul(d, z);
             hipLaunchKernelGGL(gmres_dot0_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, (const double *)d, (const double *)z, part + kPart);
@@ -1109,13 +1238,20 @@ struct elag_hip_krylov_s {
         launch_mode = graph ? "graph" : "plain";
         if (cg_tail_update())   // mfem's first statement of the first pass; every later pass's is applied by the launch that computes its alpha
             hipLaunchKernelGGL(cg_update_kernel, dim3(g1(nn)), dim3(kB), 0, s, nn, (const KState *)st, x, (const double *)d, r, (const double *)z);
-        if (graph && !cg_iter) {
+        cg_par = 0;                                   // (the first direction is in d)
+        auto capture_pass = [&](hipGraphExec_t *exec) {
             hipGraph_t g = nullptr;
             ELAG_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             try { cg_iteration(); } catch (...) { (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); throw; }
             ELAG_HIP_CHECK(hipStreamEndCapture(s, &g));
-            ELAG_HIP_CHECK(hipGraphInstantiate(&cg_iter, g, nullptr, nullptr, 0));
+            ELAG_HIP_CHECK(hipGraphInstantiate(exec, g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
+        };
+        if (graph && !cg_lean && !cg_iter) capture_pass(&cg_iter);
+        if (graph && cg_lean && !cg_iter_par[0]) {    // one graph per parity of the direction buffers (a capture enqueues nothing: the parity is put back)
+            capture_pass(&cg_iter_par[0]);
+            capture_pass(&cg_iter_par[1]);
+            cg_par = 0;
         }
         const int total = std::max(1, max_iter);   // mfem's loop body runs once even with max_iter == 0
         // Iterations enqueued past convergence are no-ops for the iterate but still run the (unpredicated) preconditioner,
@@ -1128,7 +1264,8 @@ struct elag_hip_krylov_s {
         for (int it = 0; it < total;) {
             batch = std::min(batch, total - it);
             for (int q = 0; q < batch; q++) {
-                if (graph) ELAG_HIP_CHECK(hipGraphLaunch(cg_iter, s));
+                if (graph && cg_lean) { ELAG_HIP_CHECK(hipGraphLaunch(cg_iter_par[cg_par], s)); cg_par ^= 1; }
+                else if (graph) ELAG_HIP_CHECK(hipGraphLaunch(cg_iter, s));
                 else cg_iteration();
             }
             it += batch;

@@ -439,7 +439,7 @@ def test_cg_with_the_update_in_the_launch_that_computes_alpha_is_the_same_iterat
         params = {"Solver name": "PCG", "Relative tolerance": tol, "Maximum iterations": max_iter}
         for b, x_init, iterative in ((rng.uniform(-1, 1, n), None, False), (rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), True), (np.zeros(n), None, False)):
             out = []
-            for env in ({"ELAG_HIP_CG_TAIL_UPDATE": "0"}, {"ELAG_HIP_CG_TAIL_UPDATE": "1"}):
+            for env in ({"ELAG_HIP_CG_TAIL_UPDATE": "0"}, {"ELAG_HIP_CG_TAIL_UPDATE": "1", "ELAG_HIP_CG_LEAN": "0"}):
                 P = la.HypreSmootherWrapper(dA, 1, {"Sweeps": 1}) if with_prec else None      # l1-Jacobi
                 K = _krylov_with_env(la, env, dA, P, params)
                 K.iterative_mode = iterative
@@ -456,3 +456,58 @@ def test_cg_with_the_update_in_the_launch_that_computes_alpha_is_the_same_iterat
             xr = np.zeros(n)
             ref = orc.mfem_cg(lambda v: A @ v, None, b, xr, rel_tol=tol, max_iter=max_iter)
             assert K.GetNumIterations() == ref.final_iter and bool(K.GetConverged()) == bool(ref.converged) and close(x, xr, 1e-9)
+
+
+def test_cg_pass_with_direction_product_and_inner_product_in_one_launch_is_the_same_iteration_bit_for_bit(la):
+    """cg_dir_amul_dot_kernel (krylov.hip): on a launch-bound system (a row-group product, at most 131 072 unknowns) the direction update
+    d' = z + beta d, the product A d' and the partial sums of (d', A d') are ONE launch -- the entries of d' are formed where the product needs
+    them, by the lanes and in the order of spmv_fused_row, the partial sums come out of the blocks and the tree of gmres_dot0_kernel.  Iterate,
+    iteration count, final norm and flags are those of the three launches (ELAG_HIP_CG_LEAN=0) to the last bit: rows of 1 to 40 entries (1 to
+    16 lanes per row), sizes around the block boundaries and at the limit (beyond it the three launches run either way), with and without a
+    preconditioner, from an initial guess, into the iteration limit, replayed as a graph and as plain launches."""
+    rng = np.random.default_rng(77)
+    cases = ((1, 1.0, False, 5, 1e-10), (255, 1.0, True, 40, 1e-10), (257, 3.0, False, 40, 1e-12), (1024, 9.0, True, 9, 1e-14), (5000, 20.0, False, 60, 1e-10),
+             (42309, 7.0, True, 60, 1e-9), (131072, 2.0, False, 25, 1e-8), (131073, 2.0, False, 25, 1e-8))
+    for n, half_row, with_prec, max_iter, tol in cases:
+        S0 = sp.random(n, n, density=min(1.0, half_row / n), random_state=rng)
+        A = orc.csr(S0 + S0.T + sp.diags(np.full(n, 4.0 * half_row + 2.0)))
+        dA = la.ParallelCSRMatrix.from_scipy(A)
+        params = {"Solver name": "PCG", "Relative tolerance": tol, "Maximum iterations": max_iter}
+        for b, x_init, iterative in ((rng.uniform(-1, 1, n), None, False), (rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), True)):
+            out = []
+            for env in ({"ELAG_HIP_CG_LEAN": "0"}, {"ELAG_HIP_CG_LEAN": "1"}, {"ELAG_HIP_CG_LEAN": "1", "ELAG_HIP_KRYLOV_GRAPH": "0"}):
+                env = dict(env)
+                pr = dict(params, **({"Use graph": False} if env.pop("ELAG_HIP_KRYLOV_GRAPH", None) == "0" else {}))
+                P = la.HypreSmootherWrapper(dA, 1, {"Sweeps": 1}) if with_prec else None      # l1-Jacobi
+                K = _krylov_with_env(la, env, dA, P, pr)
+                K.iterative_mode = iterative
+                for trial in range(2):
+                    x = np.zeros(n) if x_init is None else x_init.copy()
+                    K.Mult(b, x)
+                out.append((K.GetConverged(), K.GetNumIterations(), x, K.GetFinalNorm()))
+            for o in out[1:]:
+                assert o[0] == out[0][0] and o[1] == out[0][1] and o[3] == out[0][3], (n, half_row, with_prec, [(q[0], q[1], q[3]) for q in out])
+                assert np.array_equal(o[2], out[0][2]), (n, half_row, with_prec, np.abs(o[2] - out[0][2]).max())
+            if not iterative and not with_prec:
+                xr = np.zeros(n)
+                ref = orc.mfem_cg(lambda v: A @ v, None, b, xr, rel_tol=tol, max_iter=max_iter)
+                assert out[1][1] == ref.final_iter and bool(out[1][0]) == bool(ref.converged) and close(out[1][2], xr, 1e-9)
+
+
+def test_pcg_with_vcycle_in_the_lean_pass_is_the_three_launch_pass_bit_for_bit(la, h1_k2):
+    """MultigridTest0Form's solve (PCG + the AMGe cycle) through cg_dir_amul_dot_kernel and through the three launches it replaces: the same
+    iterate to the last bit, the same count, the same final norm."""
+    A = h1_k2[0]
+    dA, H, oprec = h1_setup(la, h1_k2)
+    b = np.random.default_rng(4).uniform(-1, 1, A.shape[0])
+    params = {"Solver name": "PCG", "Relative tolerance": 1e-10, "Absolute tolerance": 1e-14, "Maximum iterations": 100}
+    out = []
+    for env in ({"ELAG_HIP_CG_LEAN": "0"}, {"ELAG_HIP_CG_LEAN": "1"}):
+        K = _krylov_with_env(la, env, dA, H, params)
+        x = np.zeros(A.shape[0])
+        K.Mult(b, x)
+        out.append((K.GetConverged(), K.GetNumIterations(), x, K.GetFinalNorm()))
+    assert out[0][0] and out[0][:2] == out[1][:2] and out[0][3] == out[1][3] and np.array_equal(out[0][2], out[1][2])
+    xr = np.zeros_like(b)
+    ref = orc.mfem_cg(lambda v: A @ v, oprec, b, xr, rel_tol=1e-10, abs_tol=1e-14, max_iter=100)
+    assert out[1][1] == ref.final_iter and close(out[1][2], xr, 1e-9)
