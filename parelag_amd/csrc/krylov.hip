@@ -1016,7 +1016,7 @@ struct elag_hip_krylov_s {
     bool cg_lean_env = !(std::getenv("ELAG_HIP_CG_LEAN") && !atoi(std::getenv("ELAG_HIP_CG_LEAN")));
     bool cg_lean = false;
     double *d2 = nullptr, *ad = nullptr;
-    int cg_par = 0;
+    int cg_par = 0, cg_lpr = 1;                   // cg_lpr: the lanes per row the product had when the solver was made (the kernel reads I, J, a itself: any count is a correct product)
     hipGraphExec_t cg_iter_par[2] = {nullptr, nullptr};
     std::vector<hipGraphExec_t> gm_step;          // GMRES: one replayable step per position of the restart cycle
     bool gm_graph_ok = true, gm_flex = false, gm_graphs_chain = false;   // gm_graphs_chain: some captured step holds a gmres_chain_kernel
@@ -1061,7 +1061,7 @@ struct elag_hip_krylov_s {
             const DevCSR &D = Aop->diag;
             cg_lean = cg_lean_env && cg_tail && !distributed() && !Aop->needs_exchange() && nn >= 1 && nn <= (size_t)kPart * kB && D.lanes_per_row >= 1 &&
                       D.lanes_per_row <= 16 && D.sign_state != 1 && D.xc_state != 1;
-            if (cg_lean) { d2 = dev_alloc<double>(nn); ad = dev_alloc<double>(nn); }
+            if (cg_lean) { d2 = dev_alloc<double>(nn); ad = dev_alloc<double>(nn); cg_lpr = D.lanes_per_row; }
         }
         if (solver == ELAG_HIP_KRYLOV_STATIONARY) { d = dev_alloc<double>(nn); }
         if (solver == ELAG_HIP_KRYLOV_BICGSTAB || solver == ELAG_HIP_KRYLOV_MINRES)
@@ -1182,10 +1182,10 @@ struct elag_hip_krylov_s {
                 const double *dold = cg_par ? d2 : d;
                 double *dnew = cg_par ? d : d2;
                 const DevCSR &D = Aop->diag;
-                const dim3 g(kPart), b((unsigned)std::min(1024, kB * D.lanes_per_row));
+                const dim3 g(kPart), b((unsigned)std::min(1024, kB * cg_lpr));
 #define ELAG_CG_LEAN(L) hipLaunchKernelGGL((cg_dir_amul_dot_kernel<L>), g, b, 0, s, nn, st, max_iter, (const double *)part, src, dold, dnew, (const int *)D.I, \
                                            (const int *)D.J, (const double *)D.a, ad, part + kPart)
-                switch (D.lanes_per_row) {
+                switch (cg_lpr) {
                 case 1: ELAG_CG_LEAN(1); break;
                 case 2: ELAG_CG_LEAN(2); break;
                 case 4: ELAG_CG_LEAN(4); break;
