@@ -213,9 +213,14 @@ __global__ void __launch_bounds__(kB) gmres_dot0_kernel(int n, const KState *__r
                                                         const double *__restrict__ v, double *__restrict__ part_out)
 {
     __shared__ double sh[4];
-    if (st->fl[F_DONE]) return;
+    const int done = st->fl[F_DONE];                                  // (the flag and the thread's first element travel together)
+    const int t0 = blockIdx.x * kB + threadIdx.x;
+    double w0 = 0.0, v0 = 0.0;
+    if (t0 < n) { w0 = w[t0]; v0 = v[t0]; }
+    if (done) return;
     double acc = 0.0;
-    for (int t = blockIdx.x * kB + threadIdx.x; t < n; t += kPart * kB) acc += w[t] * v[t];
+    if (t0 < n) acc += w0 * v0;
+    for (int t = t0 + kPart * kB; t < n; t += kPart * kB) acc += w[t] * v[t];
     acc = block_sum_256(acc, sh);
     if (threadIdx.x == 0) part_out[blockIdx.x] = acc;
 }
@@ -571,15 +576,61 @@ __global__ void __launch_bounds__(1024) cg_dir_amul_dot_kernel(int n, KState *__
 {
     __shared__ double sh[4];
     __shared__ double sprod[kB];
-    if (st->fl[F_DONE]) return;
-    // (r, z) as sum_partials() adds it up, by the first kB threads
+    // (the flag, the scalars, the partial sums and the first rows' bounds are requested together, before anything is waited for: one round trip, not four)
+    const int done = st->fl[F_DONE], it = st->fl[F_ITER];
+    const double r0 = st->sc[S_R0], nom = st->sc[S_NOM];
     double pp = 0.0;
-    if (threadIdx.x < kB) { pp = pair_of(part_in); pp = wave_sum(pp); if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pp; }
+    if (threadIdx.x < kB) pp = pair_of(part_in);
+    const int row0 = (int)blockIdx.x * kB;
+    const int lane = threadIdx.x & (LPR - 1), grp = (int)threadIdx.x / LPR, rpp = (int)blockDim.x / LPR;
+    constexpr int U = k::rowgroup::kRowU;
+    // A workgroup of 1024 threads covers its 256 rows in LPR / 4 passes; two passes travel together -- row bounds, then the entries, then the
+    // gathers of both are requested before anything is waited for (a pass is a chain of four round trips: one after the other was 8.5 us at
+    // 42 309 rows where the product alone takes 4.8) -- and the first two are requested before (r, z) is added up: only the products need beta.
+    // A lane's sum is formed in spmv_fused_row's order either way: its entries in storage order.
+    constexpr int NP = LPR >= 8 ? 2 : 1;
+    int row[NP], s[NP], nd[NP];
+    double own_s[NP], own_d[NP], sum[NP];
+    int jd[NP][U];
+    double av[NP][U], xs[NP][U], xd[NP][U];
+    auto request_bounds = [&](int p0) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const int lr = p0 + p * rpp + grp;
+            row[p] = (lr < kB && row0 + lr < n) ? row0 + lr : -1;
+            s[p] = 0; nd[p] = 0; own_s[p] = 0.0; own_d[p] = 0.0; sum[p] = 0.0;
+            if (row[p] >= 0) {
+                s[p] = I[row[p]]; nd[p] = I[row[p] + 1] - s[p];
+                if (lane == 0) { own_s[p] = src[row[p]]; own_d[p] = d_old[row[p]]; }
+            }
+        }
+    };
+    auto request_entries = [&]() {
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int q = lane + u * LPR;
+                jd[p][u] = 0; av[p][u] = 0.0;
+                if (q < nd[p]) { jd[p][u] = J[s[p] + q]; av[p][u] = a[s[p] + q]; }
+            }
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int q = lane + u * LPR;
+                xs[p][u] = 0.0; xd[p][u] = 0.0;
+                if (q < nd[p]) { xs[p][u] = src[jd[p][u]]; xd[p][u] = d_old[jd[p][u]]; }
+            }
+    };
+    request_bounds(0);
+    if (done) return;
+    request_entries();
+    // (r, z) as sum_partials() adds it up, by the first kB threads
+    if (threadIdx.x < kB) { pp = wave_sum(pp); if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pp; }
     __syncthreads();
     const double betanom = (sh[0] + sh[1]) + (sh[2] + sh[3]);
     __syncthreads();
-    const int it = st->fl[F_ITER];
-    const double r0 = st->sc[S_R0], nom = st->sc[S_NOM];
     const bool stop = (betanom < 0.0) || (betanom <= r0) || (it + 1 > max_iter);
     if (blockIdx.x == 0 && threadIdx.x == 0) {                        // cg_fused_dir_kernel's branches
         st->sc[S_BETANOM] = betanom;
@@ -592,47 +643,51 @@ __global__ void __launch_bounds__(1024) cg_dir_amul_dot_kernel(int n, KState *__
     }
     if (stop) return;
     const double beta = betanom / nom;
-    const int row0 = (int)blockIdx.x * kB;
-    if (row0 >= n) { if (threadIdx.x == 0) part_out[blockIdx.x] = 0.0; return; }
-    const int lane = threadIdx.x & (LPR - 1), grp = (int)threadIdx.x / LPR, rpp = (int)blockDim.x / LPR;
-    constexpr int U = k::rowgroup::kRowU;
-    for (int p0 = 0; p0 < kB; p0 += rpp) {
-        const int lr = p0 + grp, row = row0 + lr;
-        if (lr < kB && row < n) {
-            const int s = I[row], e = I[row + 1], nd_ = e - s;
-            double own_s = 0.0, own_d = 0.0;
-            if (lane == 0) { own_s = src[row]; own_d = d_old[row]; }
-            double sum = 0.0;
-            for (int q0 = lane; q0 < nd_; q0 += U * LPR) {             // spmv_fused_row's passes: U entries per lane in flight
-                int jd[U];
-                double av[U], xs[U], xd[U];
+    for (int p0 = 0; p0 < kB; p0 += NP * rpp) {
+        if (p0 > 0) { request_bounds(p0); request_entries(); }
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            if (lane < nd[p]) {                                       // (spmv_fused_row's loop does not run for a lane without an entry)
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    const int q = q0 + u * LPR;
-                    jd[u] = 0; av[u] = 0.0;
-                    if (q < nd_) { jd[u] = J[s + q]; av[u] = a[s + q]; }
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int q = q0 + u * LPR;
-                    xs[u] = 0.0; xd[u] = 0.0;
-                    if (q < nd_) { xs[u] = src[jd[u]]; xd[u] = d_old[jd[u]]; }
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int q = q0 + u * LPR;
-                    const double xv = q < nd_ ? xs[u] + beta * xd[u] : 0.0;     // the entry of the new direction, as the update would have stored it
-                    sum += av[u] * xv;
+                    const int q = lane + u * LPR;
+                    const double xv = q < nd[p] ? xs[p][u] + beta * xd[p][u] : 0.0;   // the entry of the new direction, as the update would have stored it
+                    sum[p] += av[p][u] * xv;
                 }
             }
-            sum = k::rowgroup::group_reduce<LPR>(sum);
-            if (lane == 0) {
-                double t = 1.0 * sum;                                  // the product's epilogue with its defaults: alpha = 1, no other operand
+            for (int q0 = lane + U * LPR; q0 < nd[p]; q0 += U * LPR) {    // rows beyond U entries per lane: the later passes of spmv_fused_row's loop
+                int j2[U];
+                double a2[U], s2[U], d2[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int q = q0 + u * LPR;
+                    j2[u] = 0; a2[u] = 0.0;
+                    if (q < nd[p]) { j2[u] = J[s[p] + q]; a2[u] = a[s[p] + q]; }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int q = q0 + u * LPR;
+                    s2[u] = 0.0; d2[u] = 0.0;
+                    if (q < nd[p]) { s2[u] = src[j2[u]]; d2[u] = d_old[j2[u]]; }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int q = q0 + u * LPR;
+                    const double xv = q < nd[p] ? s2[u] + beta * d2[u] : 0.0;
+                    sum[p] += a2[u] * xv;
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const double tot = k::rowgroup::group_reduce<LPR>(sum[p]);
+            if (lane == 0 && row[p] >= 0) {
+                double t = 1.0 * tot;                                  // the product's epilogue with its defaults: alpha = 1, no other operand
                 t *= 1.0; t += 0.0 * 0.0; t *= 1.0; t += 0.0 * 0.0;
-                const double dn = own_s + beta * own_d;
-                ad[row] = t;
-                d_new[row] = dn;
-                sprod[lr] = dn * t;
+                const double dn = own_s[p] + beta * own_d[p];
+                ad[row[p]] = t;
+                d_new[row[p]] = dn;
+                sprod[row[p] - row0] = dn * t;
             }
         }
     }
@@ -670,10 +725,16 @@ __global__ void __launch_bounds__(kB) cg_fused_step2_update_kernel(int n, KState
                                                                    const double *__restrict__ d, double *__restrict__ r, const double *__restrict__ z)
 {
     __shared__ double sh[4];
-    if (st->fl[F_DONE]) return;
+    // (the flag, the scalars, the partial sums and the thread's first elements are requested together: one round trip)
+    const int done = st->fl[F_DONE];
     const double betanom = st->sc[S_BETANOM];
     const int iter2 = st->fl[F_ITER2];
-    const double den = sum_partials(part, sh);
+    const double pp = pair_of(part);
+    const int t0 = blockIdx.x * kB + threadIdx.x;
+    double x0 = 0.0, d0 = 0.0, rr0 = 0.0, z0 = 0.0;
+    if (t0 < n) { x0 = x[t0]; d0 = d[t0]; rr0 = r[t0]; z0 = z[t0]; }
+    if (done) return;
+    const double den = block_sum_256(pp, sh);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->fl[F_ITER] = iter2;
         st->sc[S_DEN] = den;
@@ -682,7 +743,8 @@ __global__ void __launch_bounds__(kB) cg_fused_step2_update_kernel(int n, KState
     }
     if (den == 0.0) return;
     const double alpha = betanom / den;
-    for (int t = blockIdx.x * kB + threadIdx.x; t < n; t += kPart * kB) { x[t] = x[t] + alpha * d[t]; r[t] = r[t] + (-alpha) * z[t]; }
+    if (t0 < n) { x[t0] = x0 + alpha * d0; r[t0] = rr0 + (-alpha) * z0; }
+    for (int t = t0 + kPart * kB; t < n; t += kPart * kB) { x[t] = x[t] + alpha * d[t]; r[t] = r[t] + (-alpha) * z[t]; }
 }
 
 __global__ void gmres_norm_kernel(KState *st, double *hs, int m, int i)
@@ -1061,7 +1123,10 @@ struct elag_hip_krylov_s {
             const DevCSR &D = Aop->diag;
             cg_lean = cg_lean_env && cg_tail && !distributed() && !Aop->needs_exchange() && nn >= 1 && nn <= (size_t)kPart * kB && D.lanes_per_row >= 1 &&
                       D.lanes_per_row <= 16 && D.sign_state != 1 && D.xc_state != 1;
-            if (cg_lean) { d2 = dev_alloc<double>(nn); ad = dev_alloc<double>(nn); cg_lpr = D.lanes_per_row; }
+            if (cg_lean) {
+                d2 = dev_alloc<double>(nn); ad = dev_alloc<double>(nn); cg_lpr = D.lanes_per_row;
+                zero_async(part, sizeof(double) * 2 * (size_t)kPart);   // (the blocks beyond the last row: written by nobody, read as zeros)
+            }
         }
         if (solver == ELAG_HIP_KRYLOV_STATIONARY) { d = dev_alloc<double>(nn); }
         if (solver == ELAG_HIP_KRYLOV_BICGSTAB || solver == ELAG_HIP_KRYLOV_MINRES)
@@ -1182,7 +1247,7 @@ struct elag_hip_krylov_s {
                 const double *dold = cg_par ? d2 : d;
                 double *dnew = cg_par ? d : d2;
                 const DevCSR &D = Aop->diag;
-                const dim3 g(kPart), b((unsigned)std::min(1024, kB * cg_lpr));
+                const dim3 g((unsigned)((nn + kB - 1) / kB)), b((unsigned)std::min(1024, kB * cg_lpr));   // (a workgroup per block of gmres_dot0_kernel that holds a row)
 #define ELAG_CG_LEAN(L) hipLaunchKernelGGL((cg_dir_amul_dot_kernel<L>), g, b, 0, s, nn, st, max_iter, (const double *)part, src, dold, dnew, (const int *)D.I, \
                                            (const int *)D.J, (const double *)D.a, ad, part + kPart)
                 switch (cg_lpr) {

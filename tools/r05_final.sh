@@ -25,3 +25,5 @@ echo "[12] one run of the default example, phase by phase (first run of a proces
 (python tools/r05_single_run.py "L1 Jacobi" 2>&1 | grep -v "^\[elag"; python tools/r05_single_run.py "L1 Gauss-Seidel" 2>&1 | grep -v "^\[elag") > $OUT/single_run.txt 2>&1; tail -3 $OUT/single_run.txt | cut -c1-220
 (for L in 0 1; do echo "ELAG_HIP_CG_LEAN=$L"; ELAG_HIP_CG_LEAN=$L python tools/pcg_iter_cost.py 3 2>&1 | grep -v "^\[elag"; done) > $OUT/pcg_pass.txt 2>&1; grep -a "LEAN\|marginal" $OUT/pcg_pass.txt
 bash tools/r05_darcy_iteration_timeline.sh r05final/dtl > $OUT/darcy_step_timeline.txt 2>&1; tail -26 $OUT/darcy_step_timeline.txt | cut -c1-140
+# the raw traces stay on the box: what is merged back is capped at 64 MiB, the summaries above are what profiles/ keeps
+find $OUT -type d \( -name kt -o -name tr \) -prune -exec rm -rf {} + ; du -sh $OUT | cut -f1
