@@ -568,7 +568,10 @@ __global__ void __launch_bounds__(kB) cg_fused_dir_kernel(int n, KState *__restr
 // spmv_fused_row would give the entry to, summed in its order; lane 0 of a row stores (A d')_row and d'_row.  Workgroup b owns rows
 // [256 b, 256 b + 256) -- the elements of block b of gmres_dot0_kernel -- in passes of blockDim / LPR rows, leaves d'_row (A d')_row in LDS
 // and adds the 256 up through the tree of block_sum_256(): the partial sums, hence alpha, are those of the three launches bit for bit.
-template <int LPR>
+//   ROWS = 64 (4 to 16 lanes per row): a workgroup owns the 64 rows of ONE wavefront of such a block and stores that wavefront's sum -- a
+// quarter of a partial sum, which the launch that computes alpha puts together as block_sum_256() would have -- so that the product spreads
+// over the chip as spmv_fused's does (662 workgroups at 42 309 rows; with 256 rows each 166 of the 256 CUs did all of it: 8.4 us a launch).
+template <int LPR, int ROWS>
 __global__ void __launch_bounds__(1024) cg_dir_amul_dot_kernel(int n, KState *__restrict__ st, int max_iter, const double *__restrict__ part_in,
                                                                const double *__restrict__ src, const double *__restrict__ d_old,
                                                                double *__restrict__ d_new, const int *__restrict__ I, const int *__restrict__ J,
@@ -581,14 +584,14 @@ __global__ void __launch_bounds__(1024) cg_dir_amul_dot_kernel(int n, KState *__
     const double r0 = st->sc[S_R0], nom = st->sc[S_NOM];
     double pp = 0.0;
     if (threadIdx.x < kB) pp = pair_of(part_in);
-    const int row0 = (int)blockIdx.x * kB;
+    const int row0 = (int)blockIdx.x * ROWS;
     const int lane = threadIdx.x & (LPR - 1), grp = (int)threadIdx.x / LPR, rpp = (int)blockDim.x / LPR;
     constexpr int U = k::rowgroup::kRowU;
     // A workgroup of 1024 threads covers its 256 rows in LPR / 4 passes; two passes travel together -- row bounds, then the entries, then the
     // gathers of both are requested before anything is waited for (a pass is a chain of four round trips: one after the other was 8.5 us at
     // 42 309 rows where the product alone takes 4.8) -- and the first two are requested before (r, z) is added up: only the products need beta.
     // A lane's sum is formed in spmv_fused_row's order either way: its entries in storage order.
-    constexpr int NP = LPR >= 8 ? 2 : 1;
+    constexpr int NP = (ROWS == kB && LPR >= 8) ? 2 : 1;
     int row[NP], s[NP], nd[NP];
     double own_s[NP], own_d[NP], sum[NP];
     int jd[NP][U];
@@ -597,7 +600,7 @@ __global__ void __launch_bounds__(1024) cg_dir_amul_dot_kernel(int n, KState *__
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             const int lr = p0 + p * rpp + grp;
-            row[p] = (lr < kB && row0 + lr < n) ? row0 + lr : -1;
+            row[p] = (lr < ROWS && row0 + lr < n) ? row0 + lr : -1;
             s[p] = 0; nd[p] = 0; own_s[p] = 0.0; own_d[p] = 0.0; sum[p] = 0.0;
             if (row[p] >= 0) {
                 s[p] = I[row[p]]; nd[p] = I[row[p] + 1] - s[p];
@@ -643,7 +646,7 @@ __global__ void __launch_bounds__(1024) cg_dir_amul_dot_kernel(int n, KState *__
     }
     if (stop) return;
     const double beta = betanom / nom;
-    for (int p0 = 0; p0 < kB; p0 += NP * rpp) {
+    for (int p0 = 0; p0 < ROWS; p0 += NP * rpp) {
         if (p0 > 0) { request_bounds(p0); request_entries(); }
 #pragma unroll
         for (int p = 0; p < NP; p++) {
@@ -693,6 +696,14 @@ __global__ void __launch_bounds__(1024) cg_dir_amul_dot_kernel(int n, KState *__
     }
     __syncthreads();
     double acc = 0.0;
+    if (ROWS == 64) {                                                  // one wavefront's sum: part_out holds quarters (cg_fused_step2_update_kernel adds them up)
+        if (threadIdx.x < 64) {
+            if (row0 + (int)threadIdx.x < n) acc += sprod[threadIdx.x];
+            acc = wave_sum(acc);
+            if (threadIdx.x == 0) part_out[blockIdx.x] = acc;
+        }
+        return;
+    }
     if (threadIdx.x < kB) {
         if (row0 + (int)threadIdx.x < n) acc += sprod[threadIdx.x];
         acc = wave_sum(acc);
@@ -721,6 +732,8 @@ __global__ void __launch_bounds__(kB) cg_fused_step2_kernel(KState *st, const do
 // (d, A d) up itself (the same fixed order everywhere), block 0 takes cg_step2's branch and writes the state, and the update follows at once
 // -- only den == 0 ends the loop between the two statements, and then nothing is applied.  One launch of a pass less (4.4 us of the 40 a pass
 // takes at the 42 309 unknowns of cube456 x3); alpha = nom / den is the same division, the iterates the same bits.
+// QUARTERS: part holds the four wavefront sums of every block (cg_dir_amul_dot_kernel<LPR, 64>): a partial sum is (q0 + q1) + (q2 + q3), block_sum_256()'s last line
+template <bool QUARTERS>
 __global__ void __launch_bounds__(kB) cg_fused_step2_update_kernel(int n, KState *__restrict__ st, const double *__restrict__ part, double *__restrict__ x,
                                                                    const double *__restrict__ d, double *__restrict__ r, const double *__restrict__ z)
 {
@@ -729,7 +742,13 @@ __global__ void __launch_bounds__(kB) cg_fused_step2_update_kernel(int n, KState
     const int done = st->fl[F_DONE];
     const double betanom = st->sc[S_BETANOM];
     const int iter2 = st->fl[F_ITER2];
-    const double pp = pair_of(part);
+    double pp;
+    if (QUARTERS) {
+        typedef double d2k __attribute__((ext_vector_type(2)));
+        const d2k *q = reinterpret_cast<const d2k *>(part + 8 * threadIdx.x);   // (64 aligned bytes a thread: four 16-byte loads)
+        const d2k q01 = q[0], q23 = q[1], q45 = q[2], q67 = q[3];
+        pp = ((q01.x + q01.y) + (q23.x + q23.y)) + ((q45.x + q45.y) + (q67.x + q67.y));
+    } else pp = pair_of(part);
     const int t0 = blockIdx.x * kB + threadIdx.x;
     double x0 = 0.0, d0 = 0.0, rr0 = 0.0, z0 = 0.0;
     if (t0 < n) { x0 = x[t0]; d0 = d[t0]; rr0 = r[t0]; z0 = z[t0]; }
@@ -1077,7 +1096,7 @@ struct elag_hip_krylov_s {
     // between d and d2, the product goes to ad; a replayed pass is one graph per parity.  ELAG_HIP_CG_LEAN=0: the three launches
     bool cg_lean_env = !(std::getenv("ELAG_HIP_CG_LEAN") && !atoi(std::getenv("ELAG_HIP_CG_LEAN")));
     bool cg_lean = false;
-    double *d2 = nullptr, *ad = nullptr;
+    double *d2 = nullptr, *ad = nullptr, *qpart = nullptr;   // qpart: the wavefront sums of (d, A d), four per block of gmres_dot0_kernel
     int cg_par = 0, cg_lpr = 1;                   // cg_lpr: the lanes per row the product had when the solver was made (the kernel reads I, J, a itself: any count is a correct product)
     hipGraphExec_t cg_iter_par[2] = {nullptr, nullptr};
     std::vector<hipGraphExec_t> gm_step;          // GMRES: one replayable step per position of the restart cycle
@@ -1096,7 +1115,7 @@ struct elag_hip_krylov_s {
     {
         if (cg_iter) (void)hipGraphExecDestroy(cg_iter);
         for (auto g : cg_iter_par) if (g) (void)hipGraphExecDestroy(g);
-        dev_free(d2); dev_free(ad);
+        dev_free(d2); dev_free(ad); dev_free(qpart);
         for (auto g : gm_step) if (g) (void)hipGraphExecDestroy(g);
         dev_free(x); dev_free(r); dev_free(z); dev_free(d); dev_free(w); dev_free(scr); dev_free(V); dev_free(Z); dev_free(hs); dev_free(part);
         dev_free(bperm); dev_free(gm_gran);
@@ -1126,6 +1145,8 @@ struct elag_hip_krylov_s {
             if (cg_lean) {
                 d2 = dev_alloc<double>(nn); ad = dev_alloc<double>(nn); cg_lpr = D.lanes_per_row;
                 zero_async(part, sizeof(double) * 2 * (size_t)kPart);   // (the blocks beyond the last row: written by nobody, read as zeros)
+                qpart = dev_alloc<double>(4 * (size_t)kPart);
+                zero_async(qpart, sizeof(double) * 4 * (size_t)kPart);
             }
         }
         if (solver == ELAG_HIP_KRYLOV_STATIONARY) { d = dev_alloc<double>(nn); }
@@ -1247,18 +1268,23 @@ struct elag_hip_krylov_s {
                 const double *dold = cg_par ? d2 : d;
                 double *dnew = cg_par ? d : d2;
                 const DevCSR &D = Aop->diag;
-                const dim3 g((unsigned)((nn + kB - 1) / kB)), b((unsigned)std::min(1024, kB * cg_lpr));   // (a workgroup per block of gmres_dot0_kernel that holds a row)
-#define ELAG_CG_LEAN(L) hipLaunchKernelGGL((cg_dir_amul_dot_kernel<L>), g, b, 0, s, nn, st, max_iter, (const double *)part, src, dold, dnew, (const int *)D.I, \
-                                           (const int *)D.J, (const double *)D.a, ad, part + kPart)
+                // 4 to 16 lanes per row: a workgroup per wavefront of a block of gmres_dot0_kernel (64 rows), quarters of the partial sums; 1 or 2: a workgroup per block
+                const bool quarters = cg_lpr >= 4;
+                const int rows = quarters ? 64 : kB;
+                const dim3 g((unsigned)((nn + rows - 1) / rows)), b((unsigned)std::min(1024, rows * cg_lpr));
+                double *pout = quarters ? qpart : part + kPart;
+#define ELAG_CG_LEAN(L, R) hipLaunchKernelGGL((cg_dir_amul_dot_kernel<L, R>), g, b, 0, s, nn, st, max_iter, (const double *)part, src, dold, dnew, (const int *)D.I, \
+                                              (const int *)D.J, (const double *)D.a, ad, pout)
                 switch (cg_lpr) {
-                case 1: ELAG_CG_LEAN(1); break;
-                case 2: ELAG_CG_LEAN(2); break;
-                case 4: ELAG_CG_LEAN(4); break;
-                case 8: ELAG_CG_LEAN(8); break;
-                default: ELAG_CG_LEAN(16); break;
+                case 1: ELAG_CG_LEAN(1, kB); break;
+                case 2: ELAG_CG_LEAN(2, kB); break;
+                case 4: ELAG_CG_LEAN(4, 64); break;
+                case 8: ELAG_CG_LEAN(8, 64); break;
+                default: ELAG_CG_LEAN(16, 64); break;
                 }
 #undef ELAG_CG_LEAN
-                hipLaunchKernelGGL(cg_fused_step2_update_kernel, dim3(kPart), dim3(kB), 0, s, nn, st, (const double *)(part + kPart), x, (const double *)dnew, r, (const double *)ad);
+                if (quarters) hipLaunchKernelGGL(cg_fused_step2_update_kernel<true>, dim3(kPart), dim3(kB), 0, s, nn, st, (const double *)qpart, x, (const double *)dnew, r, (const double *)ad);
+                else hipLaunchKernelGGL(cg_fused_step2_update_kernel<false>, dim3(kPart), dim3(kB), 0, s, nn, st, (const double *)(part + kPart), x, (const double *)dnew, r, (const double *)ad);
                 ELAG_LAUNCH_CHECK();
                 cg_par ^= 1;
                 return;
@@ -1267,7 +1293,7 @@ struct elag_hip_krylov_s {
             amul(d, z);
             hipLaunchKernelGGL(gmres_dot0_kernel, dim3(kPart), dim3(kB), 0, s, nn, (const KState *)st, (const double *)d, (const double *)z, part + kPart);
             if (cg_tail_update())
-                hipLaunchKernelGGL(cg_fused_step2_update_kernel, dim3(kPart), dim3(kB), 0, s, nn, st, (const double *)(part + kPart), x, (const double *)d, r, (const double *)z);
+                hipLaunchKernelGGL(cg_fused_step2_update_kernel<false>, dim3(kPart), dim3(kB), 0, s, nn, st, (const double *)(part + kPart), x, (const double *)d, r, (const double *)z);
             else hipLaunchKernelGGL(cg_fused_step2_kernel, dim3(1), dim3(kB), 0, s, st, (const double *)(part + kPart));
             ELAG_LAUNCH_CHECK();
             return;
