@@ -63,6 +63,16 @@ struct GraphEntry {
 
 }  // namespace
 
+// What a Finalize may invest in a faster cycle is priced against the cycles the caller expects to run on the hierarchy: ELAG_HIP_EXPECTED_CYCLES
+// (or ELAG_HIP_DENSE_TAIL_CYCLES, the name the first such decision gave it), read at every Finalize; default: many.
+static double expected_cycles()
+{
+    for (const char *name : {"ELAG_HIP_EXPECTED_CYCLES", "ELAG_HIP_DENSE_TAIL_CYCLES"})
+        if (const char *e = getenv(name))
+            if (atof(e) > 0) return atof(e);
+    return 1.0e9;
+}
+
 struct elag_hip_hierarchy_s {
     std::vector<Level> lev;
     elag_hip_coarse_s *coarse = nullptr;
@@ -317,11 +327,10 @@ struct elag_hip_hierarchy_s {
                 const double dense_us = nn * nn * 8.0 / 5.0e6, chains_us = below * 1.5;      // (bytes / (5 TB/s) against steps x 1.5 us)
                 if (!(dense_us < chains_us)) continue;
                 // ... and the product has to be BUILT: four half-sweeps over the n x n block, nnz(A) x n entries of 8 bytes each at ~3 TB/s (6.5 ms for
-                // the 5 739-dof level of cube456 x3, against 0.2-0.5 ms a cycle saved).  ELAG_HIP_DENSE_TAIL_CYCLES = the number of cycles the caller
-                // expects to run on this hierarchy (default: many -- a tail wherever it is the cheaper cycle); with a small number the tail starts
-                // only where building it pays within that many cycles -- one PCG solve of the example is 6-16 cycles.
-                double horizon = 1.0e9;                                  // (read at every Finalize)
-                if (const char *e = getenv("ELAG_HIP_DENSE_TAIL_CYCLES")) horizon = atof(e) > 0 ? atof(e) : horizon;
+                // the 5 739-dof level of cube456 x3, against 0.2-0.5 ms a cycle saved).  ELAG_HIP_EXPECTED_CYCLES (ELAG_HIP_DENSE_TAIL_CYCLES, its first
+                // name) = the number of cycles the caller expects to run on this hierarchy (default: many -- a tail wherever it is the cheaper cycle);
+                // with a small number the tail starts only where building it pays within that many cycles -- one PCG solve of the example is 6-16 cycles.
+                const double horizon = expected_cycles();                // (read at every Finalize)
                 const double build_us = 4.0 * (double)F.A->diag.nnz * nn * 8.0 / 3.0e6;
                 if (build_us <= horizon * (chains_us - dense_us)) best = l;
             }
@@ -575,6 +584,10 @@ struct elag_hip_hierarchy_s {
         };
         int top_min = D;
         while (top_min > 0 && D - (top_min - 1) <= 4 && fused(top_min - 1)) top_min--;
+        // The composites have to be BUILT (0.7-0.9 ms of products at cube456 x3, where they save two launches = ~5 us a cycle: 140 cycles, ten
+        // solves of the example, before they have paid): with the number of cycles the caller expects to run on this hierarchy
+        // (expected_cycles(): ELAG_HIP_EXPECTED_CYCLES, default many) below that, the level-by-level launches stay.
+        if (D - top_min >= 2 && expected_cycles() * 2.5 * (2.0 * (D - top_min) + 1.0 - 3.0) < 800.0) return;
         for (int top = top_min; D - top >= 2; top++) {
             const int m = D - top;
             try {

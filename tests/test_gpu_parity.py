@@ -1005,7 +1005,8 @@ def test_flattened_cycle_is_the_level_by_level_cycle(la, h1_k3, smoother, capfd)
     b = np.random.default_rng(47).uniform(-1, 1, A.shape[0])
     outs = {}
     for name, env in (("flat", {"ELAG_HIP_FLAT_VERBOSE": "1"}), ("levels", {"ELAG_HIP_FLAT_CYCLE": "0"}),
-                      ("levels_unit_vectors", {"ELAG_HIP_FLAT_CYCLE": "0", "ELAG_HIP_DENSE_TAIL_RECURSION": "0"})):
+                      ("levels_unit_vectors", {"ELAG_HIP_FLAT_CYCLE": "0", "ELAG_HIP_DENSE_TAIL_RECURSION": "0"}),
+                      ("few_cycles_expected", {"ELAG_HIP_EXPECTED_CYCLES": "16"}), ("many_cycles_expected", {"ELAG_HIP_EXPECTED_CYCLES": "100000"})):
         saved_env = {k: os.environ.get(k) for k in env}      # (a variable the run itself was started with is put back, not dropped)
         os.environ.update(env)
         try:
@@ -1022,6 +1023,11 @@ def test_flattened_cycle_is_the_level_by_level_cycle(la, h1_k3, smoother, capfd)
         H.Mult(b, x)
         outs[name] = x
     scale = np.max(np.abs(outs["levels"]))
+    # the composites are priced against the cycles the caller expects (ELAG_HIP_EXPECTED_CYCLES): one solve's worth keeps the level-by-level
+    # launches (what the composites cost to build is ~140 cycles' gain), many build them
+    assert np.array_equal(outs["few_cycles_expected"], outs["levels"]) and np.array_equal(outs["many_cycles_expected"], outs["flat"])
+    if smoother == "L1 Jacobi":
+        assert not np.array_equal(outs["flat"], outs["levels"])           # (other rounding: the two forms are told apart)
     assert np.max(np.abs(outs["flat"] - outs["levels"])) <= 1e-13 * scale
     assert np.max(np.abs(outs["levels_unit_vectors"] - outs["levels"])) <= 1e-13 * scale
     if smoother == "L1 Jacobi":

@@ -22,7 +22,7 @@ python tools/r05_gmres_chain_soak.py 1000 > $OUT/gmres_chain_soak.txt 2>&1; tail
 echo "[11] the reference's default example end to end (L1 Gauss-Seidel hierarchy set-up + one PCG solve); the smoother's set-up at scale"
 (python tools/r05_gs_time_to_solution.py 2>&1 | grep -v "^\[elag"; python tools/r05_gs_setup_scale.py 4 2>&1 | grep -v "^\[elag" | tail -2; python tools/r05_gs_setup_scale.py 5 2>&1 | grep -v "^\[elag" | tail -2) > $OUT/gs_time_to_solution.txt 2>&1; tail -4 $OUT/gs_time_to_solution.txt | cut -c1-200
 echo "[12] one run of the default example, phase by phase (first run of a process and later ones); a PCG pass with and without cg_dir_amul_dot_kernel; a GMRES step of the Darcy solve kernel by kernel"
-(python tools/r05_single_run.py "L1 Jacobi" 2>&1 | grep -v "^\[elag"; python tools/r05_single_run.py "L1 Gauss-Seidel" 2>&1 | grep -v "^\[elag") > $OUT/single_run.txt 2>&1; tail -3 $OUT/single_run.txt | cut -c1-220
+(python tools/r05_single_run.py "L1 Jacobi"; ELAG_HIP_EXPECTED_CYCLES=16 python tools/r05_single_run.py "L1 Jacobi"; python tools/r05_single_run.py "L1 Gauss-Seidel"; ELAG_HIP_EXPECTED_CYCLES=16 python tools/r05_single_run.py "L1 Gauss-Seidel") 2>&1 | grep -v "^\[elag" > $OUT/single_run.txt; tail -3 $OUT/single_run.txt | cut -c1-220
 (python tools/r05_pcg_pass_probe.py 3 256; python tools/r05_pcg_pass_probe.py 3 256; python tools/r05_pcg_pass_probe.py 2 256; bash tools/r05_pcg_pass_profile.sh r05final/pcgprof 3 256 | grep -a "cg_\|spmv_fused\|dot0\|flat_") 2>&1 | grep -v "^\[elag" > $OUT/pcg_pass.txt; cat $OUT/pcg_pass.txt | cut -c1-200
 bash tools/r05_darcy_iteration_timeline.sh r05final/dtl > $OUT/darcy_step_timeline.txt 2>&1; tail -26 $OUT/darcy_step_timeline.txt | cut -c1-140
 # the raw traces stay on the box: what is merged back is capped at 64 MiB, the summaries above are what profiles/ keeps

@@ -27,7 +27,7 @@ def once(tag):
     d = np.diff(t) * 1e3
     print("%s (%s): upload %.2f ms, hierarchy %.2f, solver %.2f, vectors %.2f, solve %.2f (%d iterations), download %.2f; total %.2f ms" %
           (tag, sm, d[0], d[1], d[2], d[3], d[4], K.GetNumIterations(), d[5], d.sum()), flush=True)
-print("import + library start %.1f ms" % (t_init * 1e3))
+print("import + library start %.1f ms%s" % (t_init * 1e3, "".join("; %s=%s" % (q, os.environ[q]) for q in ("ELAG_HIP_EXPECTED_CYCLES", "ELAG_HIP_DENSE_TAIL_CYCLES") if q in os.environ)))
 once("first run of the process")
 once("second")
 once("third")
