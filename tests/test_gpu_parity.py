@@ -1007,6 +1007,7 @@ def test_flattened_cycle_is_the_level_by_level_cycle(la, h1_k3, smoother, capfd)
     for name, env in (("flat", {"ELAG_HIP_FLAT_VERBOSE": "1"}), ("levels", {"ELAG_HIP_FLAT_CYCLE": "0"}),
                       ("levels_unit_vectors", {"ELAG_HIP_FLAT_CYCLE": "0", "ELAG_HIP_DENSE_TAIL_RECURSION": "0"}),
                       ("few_cycles_expected", {"ELAG_HIP_EXPECTED_CYCLES": "16"}), ("many_cycles_expected", {"ELAG_HIP_EXPECTED_CYCLES": "100000"})):
+        env = dict({"ELAG_HIP_EXPECTED_CYCLES": "1000000000", "ELAG_HIP_DENSE_TAIL_CYCLES": "1000000000"}, **env)   # (the test's own horizon, whatever the run was started with)
         saved_env = {k: os.environ.get(k) for k in env}      # (a variable the run itself was started with is put back, not dropped)
         os.environ.update(env)
         try:
