@@ -87,6 +87,7 @@ struct Context {
     hipStream_t comm_stream = nullptr;  // halo exchange stream
     hipEvent_t ev_pack = nullptr;       // send buffer packed   (compute -> comm)
     hipEvent_t ev_halo = nullptr;       // ghost values arrived (comm -> compute)
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};   // stage_h2d: the copy kernel has read this half of the staging buffer
     int rank = 0, nranks = 1;
     int comm_kind = 0;                  // 0 none, 1 RCCL, 2 in-process hub
     Comm *comm = nullptr;               // RCCL
