@@ -18,7 +18,10 @@
 // whole chain, its norm and the new basis vector are ONE launch (gmres_chain_kernel: w stays in registers, the inner products' partial sums
 // go from workgroup to workgroup as tagged granules); ELAG_HIP_GMRES_CHAIN=0, a distributed operator or more than 1.5 M unknowns: a launch per
 // link, the same bits.  (A two-vector chain that evaluated MGS's coefficients in another order -- rounds 4 and 5, opt-in in round 5 -- is gone:
-// slower than the chain in one launch and not MFEM's rounding.)
+// slower than the chain in one launch and not MFEM's rounding.)  The step's Givens rotations ride in that launch too; the ONE update x += V y
+// of a solve that converges inside a cycle is launched by the host when it has read `done` (gmres_final_update_kernel).  CG on a
+// launch-bound system: direction update, product and (d, A d) in one launch (cg_dir_amul_dot_kernel), the update of x and r in the launch
+// that computes alpha: six launches a pass with a three-launch cycle.
 #include <cmath>
 
 #include <chrono>
