@@ -510,6 +510,13 @@ int elag_hip_hierarchy_build_blocked(elag_hip_hierarchy_t *out, elag_hip_blockop
             ops[(size_t)l + 1] = Ac;
             hierarchy_phase(H, "merged_operators", [&] { check_rc(elag_hip_hierarchy_set_prolongator(H, l + 1, Pb->monolithic())); });
         }
+        // the coarsest level's direct solve of the (indefinite) merged operator: its dense LU inverse -- 5.9 ms of launches for the 1 471 dofs of
+        // cube456 x3 -- starts as soon as that operator is merged and runs on the second stream beside the other levels' merges, the Schur
+        // complements, the smoothers and the fused level operators of Finalize, which waits for it where the dense tail is planned
+        elag_hip_coarse_t C = nullptr;
+        ParCSR *Ac_merged = nullptr;
+        hierarchy_phase(H, "merged_operators", [&] { Ac_merged = ops[(size_t)num_P]->monolithic(); });
+        if (!is_distributed(*Ac_merged)) hierarchy_phase(H, "coarse_solver", [&] { C = coarse_create_beside(Ac_merged, opt.coarse_kind); });
         hierarchy_phase(H, "merged_operators", [&] {
             for (int l = 0; l <= num_P; l++) check_rc(elag_hip_hierarchy_set_operator(H, l, ops[(size_t)l]->monolithic()));
         });
@@ -548,14 +555,11 @@ int elag_hip_hierarchy_build_blocked(elag_hip_hierarchy_t *out, elag_hip_blockop
         }
         // coarsest level: direct solve of the (indefinite) merged operator
         ParCSR *Ac = ops[(size_t)num_P]->monolithic();
-        elag_hip_coarse_t C = nullptr;
         if (is_distributed(*Ac)) {
             std::vector<int64_t> starts;
             ParCSR *Arep = replicate_matrix(*Ac, &starts);
             adopt_mat(Arep);
             check_rc(elag_hip_coarse_create_replicated(&C, Arep, starts.data(), opt.coarse_kind));
-        } else {
-            hierarchy_phase(H, "coarse_solver", [&] { check_rc(elag_hip_coarse_create(&C, Ac, opt.coarse_kind, 0)); });
         }
         hierarchy_adopt(H, [C] { delete C; });
         check_rc(elag_hip_hierarchy_set_coarse_solver(H, C));

@@ -584,13 +584,85 @@ __global__ void gj_gather_cols_kernel(int n, const double *__restrict__ M, const
 }
 }  // namespace
 
-void dense_inverse_general(const DevCSR &A, double *Minv)
+namespace {
+// the launches of a job go to its stream: the library's helpers launch on ctx().stream, which is swapped for as long as this lives; the job's
+// stream first waits for what the compute stream has been given so far (the operator to invert)
+struct JobStream {
+    Context &c;
+    hipStream_t saved;
+    explicit JobStream(hipStream_t side) : c(ctx()), saved(c.stream)
+    {
+        if (!side || side == saved) return;
+        hipEvent_t ev = nullptr;
+        ELAG_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ELAG_HIP_CHECK(hipEventRecord(ev, saved));
+        ELAG_HIP_CHECK(hipStreamWaitEvent(side, ev, 0));
+        ELAG_HIP_CHECK(hipEventDestroy(ev));                              // (released by the runtime once the wait has gone through)
+        c.stream = side;
+    }
+    ~JobStream() { c.stream = saved; }
+};
+// scratch of the blocked LU that outlives the call (a job gives it back in finish(); Temp's stack would have to be unwound in order)
+struct GjScratch {
+    double *Mb = nullptr;
+    int *piv_all = nullptr, *colsrc = nullptr, *singular = nullptr;
+    GjStep *step = nullptr, *step2 = nullptr;
+    void release()
+    {
+        dev_free(Mb); dev_free(piv_all); dev_free(colsrc); dev_free(singular); dev_free(step); dev_free(step2);
+    }
+    ~GjScratch() { release(); }
+};
+}  // namespace
+
+void dense_inverse_general(const DevCSR &A, double *Minv, DenseJob *job)
 {
-    hipStream_t st = ctx().stream;
     const int n = A.nrows, ld = 2 * n;
     ELAG_REQUIRE(n == A.ncols, "dense inverse needs a square matrix");
     if (n == 0) return;
     const char *e_blk = getenv("ELAG_HIP_LU_BLOCKED");                    // (0 = the column-by-column form on [A | I]: A/B runs and a test)
+    {
+        // the default form -- blocked, with look-ahead -- on scratch of its own, beside the rest of a build when the caller brings a job
+        const char *e_tim = getenv("ELAG_HIP_LU_TIMING"), *e_ovl = getenv("ELAG_HIP_LU_LOOKAHEAD");
+        if (!(e_blk && !atoi(e_blk)) && n <= kGPanelRows && !(e_tim && atoi(e_tim)) && !(e_ovl && !atoi(e_ovl))) {
+            auto B = std::make_shared<GjScratch>();
+            const hipStream_t side = job ? job->stream : nullptr;
+            {
+                JobStream js(side);
+                hipStream_t st = ctx().stream;
+                B->Mb = dev_alloc<double>((size_t)n * n * 2);                // two buffers: every step reads one and writes the other
+                B->piv_all = dev_alloc<int>((size_t)n); B->colsrc = dev_alloc<int>((size_t)n); B->singular = dev_alloc<int>(1);
+                B->step = dev_alloc<GjStep>(1); B->step2 = dev_alloc<GjStep>(1);
+                double *Mo = B->Mb, *Mn = B->Mb + (size_t)n * n;
+                zero_async(Mo, sizeof(double) * (size_t)n * n);
+                zero_async(B->singular, sizeof(int));
+                hipLaunchKernelGGL(dense_scatter_plain_kernel, dim3((n + kB - 1) / kB), dim3(kB), 0, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, Mo);
+                // the update of a step and the panel of the next one in one launch (gj_block_step_kernel); the first panel by itself
+                GjStep *sa = B->step, *sb = B->step2;
+                hipLaunchKernelGGL(gj_block_panel_kernel, dim3(1), dim3(kGThreads), 0, st, n, 0, (const double *)Mo, B->piv_all, sa, B->singular, (long long *)nullptr);
+                const dim3 gs(1 + ((n + 255) / 256) * ((n + 2 * kGRows - 1) / (2 * kGRows)));
+                for (int k0 = 0; k0 < n; k0 += kGB) {
+                    if (k0 + kGB < n)
+                        hipLaunchKernelGGL(gj_lookahead_cols_kernel, dim3((n + 31) / 32), dim3(256), 0, st, n, k0, (const double *)Mo, Mn, (const GjStep *)sa);
+                    hipLaunchKernelGGL(gj_block_step_kernel, gs, dim3(kGThreads), 0, st, n, k0, (const double *)Mo, Mn, (const GjStep *)sa, sb, B->piv_all, B->singular);
+                    std::swap(Mo, Mn);
+                    std::swap(sa, sb);
+                }
+                hipLaunchKernelGGL(gj_colsrc_kernel, dim3(1), dim3(1024), sizeof(int) * 2 * (size_t)n, st, n, (const int *)B->piv_all, B->colsrc);
+                hipLaunchKernelGGL(gj_gather_cols_kernel, dim3((n + kB - 1) / kB, n), dim3(kB), 0, st, n, (const double *)Mo, (const int *)B->colsrc, Minv);
+                ELAG_LAUNCH_CHECK();
+            }
+            auto tail = [B]() {
+                const int bad = fetch_int(B->singular);
+                B->release();
+                if (bad) fail(ELAG_HIP_ERR_NUMERIC, "coarse operator is singular (%d zero pivots in the dense LU)", bad);
+            };
+            if (side && side != ctx().stream) job->finish = [tail, side]() { ELAG_HIP_CHECK(hipStreamSynchronize(side)); tail(); };
+            else tail();
+            return;
+        }
+    }
+    hipStream_t st = ctx().stream;
     if (!(e_blk && !atoi(e_blk)) && n <= kGPanelRows) {
         double *Mb = dev_alloc<double>((size_t)n * n * 2);                   // two buffers: every step reads one and writes the other
         try {
@@ -918,13 +990,16 @@ __global__ __launch_bounds__(256) void spd_block_update_kernel(int n, int K, dou
 }
 }  // namespace
 
-void dense_inverse_spd(const DevCSR &A, double *Minv)
+void dense_inverse_spd(const DevCSR &A, double *Minv, DenseJob *job)
 {
-    hipStream_t st = ctx().stream;
     const int n = A.nrows;
     ELAG_REQUIRE(n == A.ncols, "dense inverse needs a square matrix");
     if (n == 0) return;
     if (n <= kLdsInvMax) {
+        // one launch of one workgroup (0.22 ms at 141 dofs: a latency chain) -- beside the rest of a build when the caller brings a job
+        const hipStream_t side = job ? job->stream : nullptr;
+        int *bad_flag = dev_alloc<int>(1);
+        std::shared_ptr<int> bad(bad_flag, [](int *q) { dev_free(q); });
         static thread_local bool raised = false;
         const size_t lds = sizeof(double) * (size_t)n * n;
         if (!raised && lds > (size_t)(48 << 10)) {
@@ -934,19 +1009,27 @@ void dense_inverse_spd(const DevCSR &A, double *Minv)
                                                (int)(sizeof(double) * kLdsInvMax * kLdsInvMax)));
             raised = true;
         }
-        Temp<int> bad(1);
-        zero_async(bad.p, sizeof(int));
-        const char *e_reg = getenv("ELAG_HIP_SPD_REG");                 // (read at every call: a test switches it)
-        const bool in_regs = !(e_reg && !atoi(e_reg));
-        if (in_regs)
-            hipLaunchKernelGGL(spd_inverse_reg_kernel, dim3(1), dim3(kLdsInvBlock), lds, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, Minv, bad.p);
-        else
-            hipLaunchKernelGGL(spd_inverse_lds_kernel, dim3(1), dim3(kLdsInvBlock), lds, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, Minv, bad.p);
-        ELAG_LAUNCH_CHECK();
-        const int nbad = fetch_int(bad.p);
-        if (nbad) fail(ELAG_HIP_ERR_NUMERIC, "coarse operator is not positive definite (%d non-positive pivots)", nbad);
+        {
+            JobStream js(side);
+            hipStream_t st = ctx().stream;
+            zero_async(bad.get(), sizeof(int));
+            const char *e_reg = getenv("ELAG_HIP_SPD_REG");                 // (read at every call: a test switches it)
+            const bool in_regs = !(e_reg && !atoi(e_reg));
+            if (in_regs)
+                hipLaunchKernelGGL(spd_inverse_reg_kernel, dim3(1), dim3(kLdsInvBlock), lds, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, Minv, bad.get());
+            else
+                hipLaunchKernelGGL(spd_inverse_lds_kernel, dim3(1), dim3(kLdsInvBlock), lds, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, Minv, bad.get());
+            ELAG_LAUNCH_CHECK();
+        }
+        auto tail = [bad]() {
+            const int nbad = fetch_int(bad.get());
+            if (nbad) fail(ELAG_HIP_ERR_NUMERIC, "coarse operator is not positive definite (%d non-positive pivots)", nbad);
+        };
+        if (side && side != ctx().stream) job->finish = [tail, side]() { ELAG_HIP_CHECK(hipStreamSynchronize(side)); tail(); };
+        else tail();
         return;
     }
+    hipStream_t st = ctx().stream;
     double *M = dev_alloc<double>((size_t)n * n);
     try {
         Temp<int> bad(1);

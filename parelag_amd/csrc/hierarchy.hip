@@ -235,6 +235,8 @@ struct elag_hip_hierarchy_s {
                 if (L.AW->xc_state == 1 || L.AW->lanes_per_row != 0) L.AW.reset();
             }
         });
+        // (the coarsest operator's inverse may still be running on the second stream: the tail is the first to read it)
+        if (coarse && coarse->job.finish) phase("coarse_solver_wait", [&] { coarse->finish(); });
         phase("dense_tail", [&] { plan_dense_tail(); });
         phase("flat_cycle_operators", [&] { plan_flat(); plan_resident(); plan_flat_dist(); });
         finalized = true;
@@ -1795,7 +1797,8 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
             H->owned_mats.push_back(Arep);
             rc = elag_hip_coarse_create_replicated(&C, Arep, starts.data(), opt.coarse_kind);
         } else {
-            rc = elag_hip_coarse_create(&C, H->lev.back().A, opt.coarse_kind, opt.coarse_iters);
+            C = coarse_create_beside(H->lev.back().A, opt.coarse_kind);
+            rc = 0;
         }
         if (rc) fail(rc, "%s", elag_hip_last_error());
         H->owned_coarse = C;

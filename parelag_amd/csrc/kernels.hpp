@@ -1,6 +1,7 @@
 // Host-callable launchers of the hand-written gfx950 kernels (defined in kernels_*.hip).
 // Everything is enqueued on ctx().stream unless a stream is passed explicitly.
 #pragma once
+#include <functional>
 #include <cstdint>
 #include <vector>
 #include "common.hpp"
@@ -206,9 +207,16 @@ void csr_times_dense(const DevCSR &S, int m, double alpha, const double *X, doub
 void dense_mm(int nr, int nk, int m, const double *M, const double *X, double *out);
 void dense_level_op(int n, int nc, const DevCSR &V, const double *vw, const double *X, const DevCSR *U, const DevCSR *A, const double *w, double *B);
 // Minv (n x n row-major, device) = A^-1 for a general square CSR (Gauss-Jordan, partial pivoting); throws when singular
-void dense_inverse_general(const DevCSR &A, double *Minv);
+// An inverse that runs beside the rest of a build: with a job whose `stream` is set, the launches go to that stream (ordered behind what the
+// compute stream has been given so far), nothing is read back, and `finish` -- to be called before anybody reads Minv -- waits for the
+// stream, looks at the flag and gives the scratch back.  Forms that do not offer it run as without a job and leave `finish` empty.
+struct DenseJob {
+    hipStream_t stream = nullptr;
+    std::function<void()> finish;
+};
+void dense_inverse_general(const DevCSR &A, double *Minv, DenseJob *job = nullptr);
 // Minv = A^-1 for a symmetric positive definite CSR (Gauss-Jordan without pivoting on the device, result symmetrised); throws when a pivot is not positive
-void dense_inverse_spd(const DevCSR &A, double *Minv);
+void dense_inverse_spd(const DevCSR &A, double *Minv, DenseJob *job = nullptr);
 
 }  // namespace k
 }  // namespace elag

@@ -436,7 +436,8 @@ void elag_hip_coarse_s::setup()
     if (kind == 1) {
         // general (indefinite) operator: Gauss-Jordan with partial pivoting on the device (dense.hip)
         Minv = dev_alloc<double>((size_t)n * n);
-        k::dense_inverse_general(A->diag, Minv);
+        job.stream = async_stream;
+        k::dense_inverse_general(A->diag, Minv, async_stream ? &job : nullptr);
         return;
     }
     // beyond a few hundred dofs the host's scalar Cholesky + n triangular solve pairs take longer than everything else of a setup (358 ms at
@@ -448,7 +449,8 @@ void elag_hip_coarse_s::setup()
     if (lds_inv < 0) { const char *e = getenv("ELAG_HIP_COARSE_LDS"); lds_inv = e ? atoi(e) : 1; }
     if (n >= dev_from || (lds_inv && n >= 8 && n <= 141)) {
         Minv = dev_alloc<double>((size_t)n * n);
-        k::dense_inverse_spd(A->diag, Minv);
+        job.stream = async_stream;
+        k::dense_inverse_spd(A->diag, Minv, async_stream ? &job : nullptr);
         return;
     }
     std::vector<int> I = host_from_dev(A->diag.I, (size_t)n + 1);
@@ -504,6 +506,7 @@ void elag_hip_coarse_s::apply(const double *rhs, double *sol)
 {
     using namespace elag;
     if (custom_apply) { custom_apply(rhs, sol); return; }
+    finish();                                                            // (an inverse still running beside a build: nobody reads Minv before it is there)
     if (!replicated) { k::dense_gemv(n, n, Minv, rhs, sol); return; }
     // RCCL traffic always goes through the comm stream (one communicator, one stream): fork/join with events
     Context &c = ctx();
@@ -618,6 +621,23 @@ int elag_hip_smoother_destroy(elag_hip_smoother_t S)
         if (S) { (void)hipStreamSynchronize(ctx().stream); delete S; }
     });
 }
+
+}  // extern "C"
+
+namespace elag {
+elag_hip_coarse_s *coarse_create_beside(ParCSR *A, int kind)
+{
+    std::unique_ptr<elag_hip_coarse_s> C(new elag_hip_coarse_s());
+    C->A = A; C->kind = kind;
+    const char *e = getenv("ELAG_HIP_COARSE_ASYNC");                     // (read at every build: a test compares the two)
+    Context &c = ctx();
+    if (!(e && !atoi(e)) && c.nranks == 1 && c.comm_kind != 2 && c.comm_stream && !comm_active()) C->async_stream = c.comm_stream;
+    C->setup();
+    return C.release();
+}
+}  // namespace elag
+
+extern "C" {
 
 int elag_hip_coarse_create(elag_hip_coarse_t *out, elag_hip_parcsr_t A, int kind, int iters)
 {

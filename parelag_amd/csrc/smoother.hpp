@@ -42,6 +42,10 @@ struct elag_hip_smoother_s {
 
 namespace elag {
 
+// The coarsest operator's dense solver with its inverse computed beside the rest of the build (elag_hip_coarse_s::async_stream: the second
+// stream, idle on one rank; ELAG_HIP_COARSE_ASYNC=0, several ranks: as elag_hip_coarse_create).  The caller calls finish() before Minv is read.
+elag_hip_coarse_s *coarse_create_beside(ParCSR *A, int kind);
+
 struct RelaxSmoother : elag_hip_smoother_s {
     int type = 1, sweeps = 1, order = 2, cheby_order = 1;
     double weight = 1.0, omega = 1.0, fraction = 0.3;
@@ -199,7 +203,23 @@ struct elag_hip_coarse_s {
     std::function<void(const double *, double *)> custom_apply;
     elag_hip_hierarchy_s *sub = nullptr;          // ... that hierarchy (the owning hierarchy's distributed flattened cycle reads its level maps)
     int sub_allreduce = 0;
-    ~elag_hip_coarse_s() { elag::dev_free(Minv); elag::dev_free(full_rhs); }
+    // The dense inverse is a latency chain (one workgroup's 141 pivots: 0.22 ms; the blocked LU of a 1 471-dof saddle point: 5.9 ms) that the rest
+    // of a hierarchy's build does not wait for until its dense tail is planned: with `async_stream` set before setup() it runs there, beside the
+    // build's products on the compute stream, and finish() -- before anybody reads Minv -- waits for it and looks at its flag (kernels.hpp: DenseJob).
+    hipStream_t async_stream = nullptr;
+    elag::k::DenseJob job;
+    void finish()
+    {
+        if (!job.finish) return;
+        std::function<void()> f;
+        f.swap(job.finish);
+        f();
+    }
+    ~elag_hip_coarse_s()
+    {
+        try { finish(); } catch (...) {}
+        elag::dev_free(Minv); elag::dev_free(full_rhs);
+    }
     void setup();
     void apply(const double *rhs, double *sol);
 };

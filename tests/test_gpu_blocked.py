@@ -544,3 +544,34 @@ def test_spd_inverse_in_registers_is_the_lds_sweep_bit_for_bit(la, n):
     ref = np.linalg.solve(A.toarray(), b)
     assert np.max(np.abs(xs[0] - ref)) <= 1e-12 * np.max(np.abs(ref)) * np.linalg.cond(A.toarray())
     assert np.array_equal(xs[0], xs[1])
+
+
+def test_coarsest_inverse_beside_the_build_is_the_same_hierarchy(la, darcy_small):
+    """The coarsest operator's dense inverse -- the blocked LU of the saddle-point operator, the one-workgroup inverse of an SPD operator -- runs on
+    the second stream beside the rest of a build (elag_hip_coarse_s::async_stream, DenseJob in kernels.hpp) and Finalize waits for it where the
+    dense tail is planned; with ELAG_HIP_COARSE_ASYNC=0 it runs where it is created.  The same launches either way: the cycle of the blocked
+    Darcy hierarchy and of an H1 hierarchy are the same bits, build after build (the job's scratch and the build's are disjoint)."""
+    from parelag_amd import meshgen
+    d = darcy_small
+    rng = np.random.default_rng(3)
+    n = d["off"][-1]
+    b = rng.uniform(-1, 1, n)
+    A1, Ps1, _ = meshgen.h1_problem(2)
+    dA1 = la.ParallelCSRMatrix.from_scipy(A1); dPs1 = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps1]
+    b1 = rng.uniform(-1, 1, A1.shape[0])
+    outs = {}
+    for mode in ("1", "0", "1", "1"):
+        with _env(ELAG_HIP_COARSE_ASYNC=mode):
+            H, _op = device_blocked_hierarchy(la, d, True, block_smoother="Block Jacobi")
+            H1 = la.buildHierarchyFromDeRhamSequence(dA1, dPs1, "L1 Jacobi")
+        x, x1 = np.zeros(n), np.zeros(A1.shape[0])
+        H.Mult(b, x); H1.Mult(b1, x1)
+        outs.setdefault(mode, []).append((x, x1))
+    ref = outs["0"][0]
+    assert np.linalg.norm(ref[0]) > 0 and np.linalg.norm(ref[1]) > 0
+    for x, x1 in outs["1"]:
+        assert np.array_equal(x, ref[0]) and np.array_equal(x1, ref[1])
+    # a singular coarsest operator is still reported (by Finalize, which waits for the inverse)
+    Z = sp.csr_matrix(np.array([[1., 2], [2, 4]]))
+    with pytest.raises(la._lib.ElagHipError, match="singular"):
+        la.CoarseSolver(la.ParallelCSRMatrix.from_scipy(orc.csr(Z)), kind=1)
