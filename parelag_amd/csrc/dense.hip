@@ -1029,6 +1029,49 @@ void dense_inverse_spd(const DevCSR &A, double *Minv, DenseJob *job)
         else tail();
         return;
     }
+    {
+        // the blocked form (the default) on scratch of its own, beside the rest of a build when the caller brings a job
+        const char *e_blk0 = getenv("ELAG_HIP_SPD_BLOCKED");
+        if (!(e_blk0 && !atoi(e_blk0))) {
+            struct Scratch {
+                double *M = nullptr, *Dinv = nullptr, *Rp = nullptr, *Cc = nullptr;
+                int *bad = nullptr;
+                void release() { dev_free(M); dev_free(Dinv); dev_free(Rp); dev_free(Cc); dev_free(bad); }
+                ~Scratch() { release(); }
+            };
+            auto B = std::make_shared<Scratch>();
+            const hipStream_t side = job ? job->stream : nullptr;
+            {
+                JobStream js(side);
+                hipStream_t st = ctx().stream;
+                B->M = dev_alloc<double>((size_t)n * n); B->bad = dev_alloc<int>(1);
+                B->Dinv = dev_alloc<double>((size_t)kNB * kNB); B->Rp = dev_alloc<double>((size_t)kNB * n); B->Cc = dev_alloc<double>((size_t)n * kNB);
+                double *M = B->M;
+                zero_async(M, sizeof(double) * (size_t)n * n);
+                zero_async(B->bad, sizeof(int));
+                hipLaunchKernelGGL(dense_scatter_plain_kernel, dim3((n + kB - 1) / kB), dim3(kB), 0, st, n, (const int *)A.I, (const int *)A.J, (const double *)A.a, M);
+                // the (numerically symmetric) input made exactly symmetric first, like the host path
+                hipLaunchKernelGGL(symmetrise_kernel, dim3((n + kB - 1) / kB, n), dim3(kB), 0, st, n, (const double *)M, Minv);
+                dev_copy(M, Minv, sizeof(double) * (size_t)n * n, st);
+                const dim3 gp((n + kPanelCols - 1) / kPanelCols), gu((n + kNB - 1) / kNB, (n + kNB - 1) / kNB);
+                for (int K = 0; K < n; K += kNB) {
+                    hipLaunchKernelGGL(spd_block_panel_kernel, gp, dim3(1024), 0, st, n, K, (const double *)M, B->Dinv, B->Rp, B->Cc, B->bad);
+                    hipLaunchKernelGGL(spd_block_update_kernel, gu, dim3(256), 0, st, n, K, M, (const double *)B->Dinv, (const double *)B->Rp, (const double *)B->Cc);
+                }
+                // exact symmetry of the stored inverse keeps the cycle symmetric to rounding
+                hipLaunchKernelGGL(symmetrise_kernel, dim3((n + kB - 1) / kB, n), dim3(kB), 0, st, n, (const double *)M, Minv);
+                ELAG_LAUNCH_CHECK();
+            }
+            auto tail = [B]() {
+                const int nbad = fetch_int(B->bad);
+                B->release();
+                if (nbad) fail(ELAG_HIP_ERR_NUMERIC, "coarse operator is not positive definite (%d non-positive pivots)", nbad);
+            };
+            if (side && side != ctx().stream) job->finish = [tail, side]() { ELAG_HIP_CHECK(hipStreamSynchronize(side)); tail(); };
+            else tail();
+            return;
+        }
+    }
     hipStream_t st = ctx().stream;
     double *M = dev_alloc<double>((size_t)n * n);
     try {
