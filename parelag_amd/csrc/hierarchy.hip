@@ -1754,6 +1754,24 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
             H->reordered = true;
         });
 
+        // (the coarsest operator's inverse first: it runs on the second stream beside the smoothers' set-up and the fused level operators)
+        H->phase("coarse_solver", [&] {
+        elag_hip_coarse_t C = nullptr;
+        int rc;
+        if (is_distributed(*H->lev.back().A)) {
+            // coarsest operator gathered onto every rank, right-hand side all-gathered at apply time
+            std::vector<int64_t> starts;
+            ParCSR *Arep = replicate_matrix(*H->lev.back().A, &starts);
+            H->owned_mats.push_back(Arep);
+            rc = elag_hip_coarse_create_replicated(&C, Arep, starts.data(), opt.coarse_kind);
+        } else {
+            C = coarse_create_beside(H->lev.back().A, opt.coarse_kind);
+            rc = 0;
+        }
+        if (rc) fail(rc, "%s", elag_hip_last_error());
+        H->owned_coarse = C;
+        H->coarse = C;
+        });
         H->phase("smoothers", [&] {
         for (int l = 0; l < num_P; l++) {
             elag_hip_smoother_t S = nullptr;
@@ -1786,23 +1804,6 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
             H->lev[(size_t)l].pre = S;
             H->lev[(size_t)l].post = S;  // same parameters => same operator; scratch is not shared across calls
         }
-        });
-        H->phase("coarse_solver", [&] {
-        elag_hip_coarse_t C = nullptr;
-        int rc;
-        if (is_distributed(*H->lev.back().A)) {
-            // coarsest operator gathered onto every rank, right-hand side all-gathered at apply time
-            std::vector<int64_t> starts;
-            ParCSR *Arep = replicate_matrix(*H->lev.back().A, &starts);
-            H->owned_mats.push_back(Arep);
-            rc = elag_hip_coarse_create_replicated(&C, Arep, starts.data(), opt.coarse_kind);
-        } else {
-            C = coarse_create_beside(H->lev.back().A, opt.coarse_kind);
-            rc = 0;
-        }
-        if (rc) fail(rc, "%s", elag_hip_last_error());
-        H->owned_coarse = C;
-        H->coarse = C;
         });
         H->finalize(opt.use_graph != 0);
         *out = H.release();

@@ -1532,11 +1532,11 @@ __global__ void sweep_dense_level_kernel(int r0, int r1, const int *__restrict__
     else if (have && aii != 0.0) X[(size_t)row * m + c] = res / aii;
 }
 
-// The same sweeps with the COLUMNS of X dealt to the workgroups: the columns are independent systems, so a workgroup that owns a strip of 16 of
+// The same sweeps with the COLUMNS of X dealt to the workgroups: the columns are independent systems, so a workgroup that owns a strip of 32 of
 // them walks all dependency levels of all sweeps by itself with a workgroup barrier between levels -- one launch where the level kernel above takes
 // two per level and sweep (368 launches of ~16 us for the 5 739 x 5 739 block of cube456 x3's level 1: 5.9 of a 13 ms Gauss-Seidel hierarchy
 // build).  Same operations per entry, same order inside a row (operators without ghosts; 64 rows of a level at a time).
-constexpr int kStripCols = 16, kStripThreads = 1024;
+constexpr int kStripCols = 32, kStripThreads = 1024;     // (32 columns: 256-byte pieces of a row of X; 16 read the 263 MB block 6 % slower, 64 leave too few workgroups: 9.5 against 6.1 ms)
 template <int MODE>
 __global__ __launch_bounds__(kStripThreads) void sweep_dense_strip_kernel(int nlev, const int *__restrict__ lev_ptr, const int *__restrict__ rows,
                                                                           const int *__restrict__ I, const int *__restrict__ J, const double *__restrict__ a,
