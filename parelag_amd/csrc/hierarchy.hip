@@ -1697,7 +1697,8 @@ static void build_impl(elag_hip_hierarchy_t *out, elag_hip_parcsr_t A, int num_P
                                    opt.relax_type == ELAG_HIP_SMOOTHER_GS || opt.relax_type == ELAG_HIP_SMOOTHER_KACZMARZ;
         ELAG_REQUIRE(!(ordered_relax && opt.reorder > 0), "reorder = 1 would change what a Gauss-Seidel sweep computes");
         const bool reorder = !A->needs_exchange() && A->global_rows == A->nrows() && D == nullptr && !ordered_relax &&
-                             (opt.reorder > 0 || (opt.reorder < 0 && A->nrows() >= (1 << 18)));
+                             (opt.reorder > 0 || (opt.reorder < 0 && A->nrows() >= (1 << 18) && expected_cycles() >= 64.0));
+        // (the renumbering is an investment too -- 2.6 ms at cube456 x5 for ~50 us a cycle: left out in the automatic mode when the caller expects fewer than 64 cycles)
         if (reorder) H->phase("renumbering", [&] {
             const int nl = num_P + 1;
             H->order.resize((size_t)nl);

@@ -1249,3 +1249,35 @@ def test_staged_copies_in_several_chunks_and_odd_sizes(la):
     dA.MultBoolInt(x, y)
     pat = sp.csr_matrix((np.ones(A.nnz, dtype=np.int64), A.indices, A.indptr), shape=A.shape)
     assert np.array_equal(y, (pat @ x.astype(np.int64)).astype(np.int32))
+
+
+def test_set_up_is_priced_against_the_cycles_the_caller_expects(la):
+    """ELAG_HIP_EXPECTED_CYCLES (hierarchy.hip, expected_cycles()): what a Finalize may invest in a faster cycle -- the automatic renumbering of a large
+    hierarchy (2.6 ms at cube456 x5 for ~50 us a cycle), the flattened cycle's composite operators, a Gauss-Seidel hierarchy's dense tail -- is left out
+    where it cannot pay within the cycles the caller expects to run; the default expects many.  At cube456 x4 (324 681 dofs: above the renumbering's
+    size gate): with 16 expected cycles no renumbering and no composites, the same cycle to rounding, a faster set-up; an explicit reorder = 1 is an
+    instruction, not an investment decision."""
+    import os
+    from parelag_amd import meshgen
+    A, Ps, _ = meshgen.h1_problem(4)
+    dA = la.ParallelCSRMatrix.from_scipy(A); dPs = [la.ParallelCSRMatrix.from_scipy(P) for P in Ps]
+    b = np.random.default_rng(12).uniform(-1, 1, A.shape[0])
+    outs, phases = {}, {}
+    for name, env, kw in (("many", {"ELAG_HIP_EXPECTED_CYCLES": "1000000"}, {}), ("few", {"ELAG_HIP_EXPECTED_CYCLES": "16"}, {}),
+                          ("few_but_told_to_reorder", {"ELAG_HIP_EXPECTED_CYCLES": "16"}, {"reorder": 1})):
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            H = la.buildHierarchyFromDeRhamSequence(dA, dPs, "L1 Jacobi", **kw)
+        finally:
+            for k, v in saved.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        x = np.zeros(A.shape[0])
+        H.Mult(b, x)
+        outs[name], phases[name] = x, H.setup_breakdown()
+    assert "renumbering" in phases["many"] and phases["many"]["flat_cycle_operators"] > 0.1
+    assert "renumbering" not in phases["few"] and phases["few"]["flat_cycle_operators"] < 0.05
+    assert "renumbering" in phases["few_but_told_to_reorder"]
+    scale = np.max(np.abs(outs["many"]))
+    for name in ("few", "few_but_told_to_reorder"):
+        assert np.max(np.abs(outs[name] - outs["many"])) <= 1e-13 * scale
