@@ -238,7 +238,7 @@ struct DevCSR {
     // in that list.  The kernel gathers x once per unique column into LDS and streams 10 bytes per entry.
     mutable unsigned short *lidx = nullptr;
     mutable int *uoff = nullptr, *ucols = nullptr;
-    mutable int xc_state = 0;   // 0 = not examined, 1 = built, -1 = not worthwhile / not applicable
+    mutable int xc_state = 0;   // 0 = not examined, 1 = built, -1 = not worthwhile / not applicable, -2 = declined unexamined (kernels.hpp: decline_spmv_forms)
     mutable int xc_max_unique = 0;
     mutable int *xc_block_row = nullptr;   // window plan of the x-cache form (== block_row for 2048-entry windows, own array otherwise)
     mutable int xc_nblocks = 0, xc_window = 0;

@@ -205,25 +205,29 @@ struct elag_hip_hierarchy_s {
         phase("fused_level_operators", [&] { plan_fused(); });
         // SpMV forms that are built on first use must exist before the cycle is captured into a graph
         phase("spmv_forms", [&] {
+            // (the x-cache window plans -- sampled for every large operator, built where the columns are reused -- and the stored A W are investments
+            //  too: 1.5 ms of a 5.3 ms set-up at cube456 x5 for ~45 us a cycle; with fewer than 64 cycles expected the operators keep the stream kernel)
+            const bool invest = expected_cycles() >= 64.0;
+            auto prepare = [&](const DevCSR &M) { if (invest) k::prepare_spmv(M); else k::decline_spmv_forms(M); };
             for (size_t l = 0; l < lev.size(); l++) {
                 Level &L = lev[l];
-                k::prepare_spmv(L.A->diag);
+                prepare(L.A->diag);
                 // (a bandwidth-bound level that goes up through S never multiplies by P itself)
                 const bool p_unused = l > 0 && lev[l - 1].S && !lev[l - 1].G && !lev[l - 1].Gaux;
-                if (L.P) { if (!p_unused) k::prepare_spmv(L.P->diag); if (L.P->diagT) k::prepare_spmv(*L.P->diagT); }
-                if (L.G) k::prepare_spmv(*L.G);
-                if (L.S) k::prepare_spmv(*L.S);
-                if (L.U1) k::prepare_spmv(*L.U1);
-                if (L.Kh) { k::prepare_spmv(*L.Kh); k::prepare_spmv(*L.Mh); }
-                if (L.Gaux) k::prepare_spmv(*L.Gaux);
-                if (L.RA) k::prepare_spmv(*L.RA);
+                if (L.P) { if (!p_unused) prepare(L.P->diag); if (L.P->diagT) prepare(*L.P->diagT); }
+                if (L.G) prepare(*L.G);
+                if (L.S) prepare(*L.S);
+                if (L.U1) prepare(*L.U1);
+                if (L.Kh) { prepare(*L.Kh); prepare(*L.Mh); }
+                if (L.Gaux) prepare(*L.Gaux);
+                if (L.RA) prepare(*L.RA);
             }
-            if (A_user) k::prepare_spmv(A_user->diag);
+            if (A_user) prepare(A_user->diag);
             const char *e_aw = getenv("ELAG_HIP_LEVEL_AW");                  // (0: off; read at every Finalize)
             for (size_t l = 0; l + 1 < lev.size(); l++) {
                 Level &L = lev[l];
                 L.AW.reset();
-                if (e_aw && !atoi(e_aw)) continue;
+                if ((e_aw && !atoi(e_aw)) || !invest) continue;
                 const double *w = (L.pre && L.pre->A == L.A) ? L.pre->diag_scaling() : nullptr;
                 if (!w || L.G || L.Gaux || L.U1 || L.Sd || L.A->needs_exchange() || L.A->offd.ncols != 0) continue;
                 if (L.A->diag.nnz < (int64_t(1) << 20) || L.A->diag.xc_state == 1 || L.A->diag.lanes_per_row != 0) continue;

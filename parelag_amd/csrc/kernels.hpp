@@ -123,6 +123,9 @@ void preload_setup_kernels();   // kernels_setup.hip
 void preload_spmv_kernels();    // kernels_spmv.hip
 void preload_dense_kernels();   // dense.hip
 void prepare_spmv(const DevCSR &A, bool force = false);
+// the stream / row-group kernels as they are: no window plan is sampled or built at the first launch (state -2: a later prepare_spmv(), i.e. a
+// Finalize that does invest, examines the operator as if nobody had looked at it)
+inline void decline_spmv_forms(const DevCSR &A) { if (A.xc_state == 0) A.xc_state = -2; }
 void longest_row(int nrows, const int *I, int *d_out);      // *d_out = max_r I[r + 1] - I[r] (device scalar, compute stream)
 
 // builds the 4-byte-per-entry sign form of a matrix whose stored values are all -1, 0 or +1 (returns false and leaves the

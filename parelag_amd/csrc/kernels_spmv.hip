@@ -860,6 +860,7 @@ int xc_window_env()
 
 void prepare_spmv(const DevCSR &A, bool force)
 {
+    if (A.xc_state == -2) A.xc_state = 0;                   // (declined by a Finalize that expected few cycles: this caller asks)
     if (A.xc_state != 0 || (xc_mode() == 0 && !force)) return;
     A.xc_state = -1;
     if (A.lanes_per_row != 0 || !A.block_row || A.nnz == 0 || A.nblocks == 0) return;
